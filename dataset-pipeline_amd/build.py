@@ -1,0 +1,60 @@
+"""Build libe3dhip.so (HIP kernels + C-ABI) for gfx950 with hipcc, in-tree.
+
+    python dataset-pipeline_amd/build.py [--force]
+
+hipcc cross-compiles without a GPU.  -ffp-contract=off is REQUIRED: the reference is built without FMA
+contraction (CMakeLists.txt:82) and correspondence counts are only identical if the f32 arithmetic is.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+SOURCES = ["e3d_icp.hip", "e3d_icp_kernels.hip", "e3d_sort.hip", "e3d_normals.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+         "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+
+
+def lib_path():
+    return os.path.join(LIBDIR, "libe3dhip.so")
+
+
+def _newer(src, dst):
+    return (not os.path.exists(dst)) or os.path.getmtime(src) > os.path.getmtime(dst)
+
+
+def build(force=False, verbose=False):
+    os.makedirs(LIBDIR, exist_ok=True)
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".h"))]
+    hdrs.append(os.path.join(HERE, "..", "include", "e3d_hip.h"))
+    objs = []
+    procs = []
+    for s in SOURCES:
+        src = os.path.join(CSRC, s)
+        if not os.path.exists(src):
+            continue
+        obj = os.path.join(objdir, s.replace(".hip", ".o"))
+        objs.append(obj)
+        if force or _newer(src, obj) or any(_newer(hd, obj) for hd in hdrs):
+            cmd = ["hipcc"] + FLAGS + ["-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            procs.append((s, subprocess.Popen(cmd)))
+    for s, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError("hipcc failed on " + s)
+    so = lib_path()
+    if force or procs or not os.path.exists(so):
+        cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so] + objs
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return so
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

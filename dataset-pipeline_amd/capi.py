@@ -1,0 +1,259 @@
+"""ctypes binding of libe3dhip.so -- one Python method per C-ABI entry point of include/e3d_hip.h.
+
+Array arguments may be numpy arrays (host) or torch CUDA tensors (device pointers are passed through;
+the library detects them).  There is deliberately NO fallback path: if the shared library is missing the
+import of any entry point fails loudly.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class E3DError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return os.path.join(_HERE, "lib", "libe3dhip.so")
+
+
+class PairRecord(C.Structure):
+    _fields_ = [("iteration", C.c_int32), ("src", C.c_int32), ("tgt", C.c_int32),
+                ("count", C.c_int64), ("distance_sum", C.c_double)]
+
+
+class IterRecord(C.Structure):
+    _fields_ = [("iteration", C.c_int32), ("inner_iterations", C.c_int32), ("full_passes", C.c_int32),
+                ("cost_passes", C.c_int32), ("correspondences", C.c_int64), ("queries", C.c_int64),
+                ("initial_cost", C.c_double), ("final_cost", C.c_double),
+                ("t_transform_ms", C.c_double), ("t_nn_ms", C.c_double), ("t_lm_ms", C.c_double),
+                ("t_lm_kernel_ms", C.c_double)]
+
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_size_t, C.c_void_p)
+
+# name -> (restype, argtypes); also the list of symbols include/e3d_hip.h declares
+SIGNATURES = {
+    "e3d_abi_version": (C.c_int, []),
+    "e3d_init": (C.c_int, [C.c_int]),
+    "e3d_last_error": (C.c_char_p, []),
+    "e3d_icp_create": (C.c_void_p, []),
+    "e3d_icp_destroy": (None, [C.c_void_p]),
+    "e3d_icp_add_cloud": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]),
+    "e3d_icp_run": (C.c_int, [C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_float, C.c_int]),
+    "e3d_icp_get_pose": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "e3d_icp_set_max_inner_iterations": (C.c_int, [C.c_void_p, C.c_int]),
+    "e3d_icp_num_pair_records": (C.c_size_t, [C.c_void_p]),
+    "e3d_icp_pair_records": (C.POINTER(PairRecord), [C.c_void_p]),
+    "e3d_icp_num_iter_records": (C.c_size_t, [C.c_void_p]),
+    "e3d_icp_iter_records": (C.POINTER(IterRecord), [C.c_void_p]),
+    "e3d_icp_clear_records": (None, [C.c_void_p]),
+    "e3d_icp_set_shard": (C.c_int, [C.c_void_p, C.c_int, C.c_int, ALLREDUCE_FN, C.c_void_p]),
+    "e3d_find_correspondences": (C.c_int64, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_float,
+                                             C.c_void_p, C.c_void_p]),
+    "e3d_transform_cloud": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_void_p]),
+    "e3d_icp_pair_system": (C.c_int, [C.c_void_p] * 6 + [C.c_int64] + [C.c_void_p] * 7),
+    "e3d_normals_knn": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+}
+
+
+def lib():
+    """Load libe3dhip.so (raises E3DError if it has not been built -- no fallback)."""
+    global _LIB
+    if _LIB is None:
+        p = lib_path()
+        if not os.path.exists(p):
+            raise E3DError("HIP extension missing: %s (run `python dataset-pipeline_amd/build.py`)" % p)
+        L = C.CDLL(p)
+        for name, (res, args) in SIGNATURES.items():
+            f = getattr(L, name)
+            f.restype = res
+            f.argtypes = args
+        _LIB = L
+    return _LIB
+
+
+def _err(prefix, code=None):
+    msg = lib().e3d_last_error()
+    raise E3DError("%s: %s%s" % (prefix, msg.decode() if msg else "unknown error",
+                                 "" if code is None else " (code %d)" % code))
+
+
+def _is_torch(a):
+    return type(a).__module__.startswith("torch")
+
+
+def _ptr(a, dtype, keep):
+    """Pointer of a numpy array / torch tensor with the given numpy dtype (contiguous); None passes through."""
+    if a is None:
+        return None
+    if _is_torch(a):
+        import torch
+        want = {np.float32: torch.float32, np.int32: torch.int32, np.float64: torch.float64}[dtype]
+        t = a.contiguous()
+        if t.dtype != want:
+            t = t.to(want)
+        keep.append(t)
+        return C.c_void_p(t.data_ptr())
+    arr = np.ascontiguousarray(a, dtype=dtype)
+    keep.append(arr)
+    return C.c_void_p(arr.ctypes.data)
+
+
+def _pose12(T):
+    T = np.asarray(T, dtype=np.float32)
+    return np.ascontiguousarray(T[:3, :4])
+
+
+class PointToPlaneICP:
+    """Host-side mirror of icp::PointToPlaneICP (src/icp/icp_point_to_plane.h:39-80) on the HIP library."""
+
+    def __init__(self, device=None):
+        L = lib()
+        if device is not None and L.e3d_init(int(device)) < 0:
+            _err("e3d_init")
+        self._h = L.e3d_icp_create()
+        if not self._h:
+            _err("e3d_icp_create")
+        self._cb = None
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            lib().e3d_icp_destroy(h)
+            self._h = None
+
+    # int AddPointCloud(cloud, global_T_cloud, fixed)
+    def add_point_cloud(self, xyz, normals, global_T_cloud, fixed):
+        keep = []
+        n = int(xyz.shape[0])
+        T = _pose12(global_T_cloud)
+        r = lib().e3d_icp_add_cloud(self._h, _ptr(xyz, np.float32, keep), _ptr(normals, np.float32, keep), n,
+                                    C.c_void_p(T.ctypes.data), int(bool(fixed)))
+        if r < -1:
+            _err("e3d_icp_add_cloud", r)
+        return r
+
+    # bool Run(max_correspondence_distance, initial_iteration, max_num_iterations, thr, print_progress)
+    def run(self, max_correspondence_distance, initial_iteration, max_num_iterations,
+            convergence_threshold_max_movement, print_progress=False):
+        r = lib().e3d_icp_run(self._h, float(np.float32(max_correspondence_distance)), int(initial_iteration),
+                              int(max_num_iterations), float(np.float32(convergence_threshold_max_movement)),
+                              int(bool(print_progress)))
+        if r < 0:
+            _err("e3d_icp_run", r)
+        return bool(r)
+
+    # Eigen::Affine3f GetResultGlobalTCloud(int)
+    def get_result_global_T_cloud(self, cloud_index):
+        T = np.zeros((3, 4), np.float32)
+        r = lib().e3d_icp_get_pose(self._h, int(cloud_index), C.c_void_p(T.ctypes.data))
+        if r < 0:
+            if r == -5:
+                raise IndexError(cloud_index)
+            _err("e3d_icp_get_pose", r)
+        out = np.eye(4, dtype=np.float32)
+        out[:3] = T
+        return out
+
+    def set_max_inner_iterations(self, n):
+        if lib().e3d_icp_set_max_inner_iterations(self._h, int(n)) < 0:
+            _err("e3d_icp_set_max_inner_iterations")
+
+    def set_shard(self, rank, world_size, allreduce=None):
+        """allreduce(np.ndarray float64, in place) -> None; called from inside run()."""
+        if allreduce is not None:
+            def _cb(buf, count, _user):
+                try:
+                    arr = np.ctypeslib.as_array(buf, shape=(count,))
+                    allreduce(arr)
+                    return 0
+                except Exception:  # noqa: BLE001 -- must not propagate through C
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+            self._cb = ALLREDUCE_FN(_cb)
+        else:
+            self._cb = ALLREDUCE_FN()
+        if lib().e3d_icp_set_shard(self._h, int(rank), int(world_size), self._cb, None) < 0:
+            _err("e3d_icp_set_shard")
+
+    def pair_records(self):
+        n = lib().e3d_icp_num_pair_records(self._h)
+        p = lib().e3d_icp_pair_records(self._h)
+        return [(p[i].iteration, p[i].src, p[i].tgt, p[i].count, p[i].distance_sum) for i in range(n)]
+
+    def iter_records(self):
+        n = lib().e3d_icp_num_iter_records(self._h)
+        p = lib().e3d_icp_iter_records(self._h)
+        names = [f[0] for f in IterRecord._fields_]
+        return [{k: getattr(p[i], k) for k in names} for i in range(n)]
+
+    def clear_records(self):
+        lib().e3d_icp_clear_records(self._h)
+
+
+def find_correspondences(source_xyz, target_xyz, max_correspondence_distance):
+    """FindCorrespondencesFast: returns (match_index[n_src] int32 (-1 = none), sq_distance[n_src], count)."""
+    keep = []
+    ns, nt = int(source_xyz.shape[0]), int(target_xyz.shape[0])
+    idx = np.full(max(ns, 1), -1, np.int32)
+    d2 = np.zeros(max(ns, 1), np.float32)
+    c = lib().e3d_find_correspondences(_ptr(source_xyz, np.float32, keep), ns, _ptr(target_xyz, np.float32, keep), nt,
+                                       float(np.float32(max_correspondence_distance)),
+                                       C.c_void_p(idx.ctypes.data), C.c_void_p(d2.ctypes.data))
+    if c < 0:
+        _err("e3d_find_correspondences", c)
+    return idx[:ns], d2[:ns], int(c)
+
+
+def transform_cloud(xyz, normals, T):
+    keep = []
+    n = int(xyz.shape[0])
+    T = _pose12(T)
+    oxyz = np.zeros((n, 3), np.float32)
+    onrm = np.zeros((n, 3), np.float32)
+    bmin = np.zeros(3, np.float32)
+    bmax = np.zeros(3, np.float32)
+    r = lib().e3d_transform_cloud(_ptr(xyz, np.float32, keep), _ptr(normals, np.float32, keep), n,
+                                  C.c_void_p(T.ctypes.data), C.c_void_p(oxyz.ctypes.data),
+                                  C.c_void_p(onrm.ctypes.data), C.c_void_p(bmin.ctypes.data),
+                                  C.c_void_p(bmax.ctypes.data))
+    if r < 0:
+        _err("e3d_transform_cloud", r)
+    return oxyz, onrm, bmin, bmax
+
+
+def icp_pair_system(sxyz, snrm, txyz, tnrm, iq, im, sq, st, tq, tt):
+    keep = []
+    H = np.zeros((12, 12)); b = np.zeros(12); cost = np.zeros(1)
+    r = lib().e3d_icp_pair_system(
+        _ptr(sxyz, np.float32, keep), _ptr(snrm, np.float32, keep), _ptr(txyz, np.float32, keep),
+        _ptr(tnrm, np.float32, keep), _ptr(iq, np.int32, keep), _ptr(im, np.int32, keep), int(len(iq)),
+        _ptr(sq, np.float32, keep), _ptr(st, np.float32, keep), _ptr(tq, np.float32, keep),
+        _ptr(tt, np.float32, keep), C.c_void_p(H.ctypes.data), C.c_void_p(b.ctypes.data),
+        C.c_void_p(cost.ctypes.data))
+    if r < 0:
+        _err("e3d_icp_pair_system", r)
+    return H, b, float(cost[0])
+
+
+def normals_knn(xyz, k, viewpoint=(0.0, 0.0, 0.0), return_knn=False):
+    """NormalEstimationTwoPassOMP with setKSearch(k): returns (normals[n,3], curvature[n][, knn_idx[n,k]])."""
+    keep = []
+    n = int(xyz.shape[0])
+    vp = np.ascontiguousarray(viewpoint, np.float32)
+    on = np.zeros((n, 3), np.float32)
+    oc = np.zeros(n, np.float32)
+    knn = np.zeros((n, k), np.int32) if return_knn else None
+    r = lib().e3d_normals_knn(_ptr(xyz, np.float32, keep), n, int(k), C.c_void_p(vp.ctypes.data),
+                              C.c_void_p(on.ctypes.data), C.c_void_p(oc.ctypes.data),
+                              C.c_void_p(knn.ctypes.data) if knn is not None else None)
+    if r < 0:
+        _err("e3d_normals_knn", r)
+    return (on, oc, knn) if return_knn else (on, oc)

@@ -1,0 +1,106 @@
+// e3d_common.hpp -- shared host-side plumbing of libe3dhip.so (error state, device buffers,
+// HIP call checking).  gfx950 only; no CUDA compatibility paths.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace e3d {
+
+struct Error : std::runtime_error {
+  int code;
+  Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+void set_last_error(const std::string& msg);
+
+inline std::string fmt(const char* f, ...) {
+  char buf[512];
+  va_list ap; va_start(ap, f); vsnprintf(buf, sizeof buf, f, ap); va_end(ap);
+  return std::string(buf);
+}
+
+#define E3D_HIP(expr)                                                                     \
+  do {                                                                                    \
+    hipError_t e3d_err__ = (expr);                                                        \
+    if (e3d_err__ != hipSuccess)                                                          \
+      throw ::e3d::Error(-3, ::e3d::fmt("%s failed: %s (%s:%d)", #expr,                   \
+                                        hipGetErrorString(e3d_err__), __FILE__, __LINE__)); \
+  } while (0)
+
+// Owning device buffer (hipMalloc), grow-only reserve.
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t cap = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  DevBuf(DevBuf&& o) noexcept : p(o.p), cap(o.cap) { o.p = nullptr; o.cap = 0; }
+  DevBuf& operator=(DevBuf&& o) noexcept {
+    if (this != &o) { release(); p = o.p; cap = o.cap; o.p = nullptr; o.cap = 0; }
+    return *this;
+  }
+  ~DevBuf() { release(); }
+  void release() { if (p) { (void)hipFree(p); p = nullptr; cap = 0; } }
+  void reserve(size_t n) {
+    if (n <= cap) return;
+    release();
+    E3D_HIP(hipMalloc((void**)&p, sizeof(T) * (n ? n : 1)));
+    cap = n;
+  }
+  // grow keeping contents
+  void grow_keep(size_t n, size_t used, hipStream_t s) {
+    if (n <= cap) return;
+    T* q = nullptr;
+    E3D_HIP(hipMalloc((void**)&q, sizeof(T) * n));
+    if (p && used) E3D_HIP(hipMemcpyAsync(q, p, sizeof(T) * used, hipMemcpyDeviceToDevice, s));
+    E3D_HIP(hipStreamSynchronize(s));
+    if (p) (void)hipFree(p);
+    p = q; cap = n;
+  }
+};
+
+// Pinned host buffer.
+template <typename T>
+struct PinBuf {
+  T* p = nullptr;
+  size_t cap = 0;
+  ~PinBuf() { if (p) (void)hipHostFree(p); }
+  void reserve(size_t n) {
+    if (n <= cap) return;
+    if (p) (void)hipHostFree(p);
+    E3D_HIP(hipHostMalloc((void**)&p, sizeof(T) * (n ? n : 1)));
+    cap = n;
+  }
+};
+
+// Copy n elements from a host-or-device pointer into device memory.
+inline void copy_in(void* dst_dev, const void* src, size_t bytes, hipStream_t s) {
+  if (bytes == 0) return;
+  E3D_HIP(hipMemcpyAsync(dst_dev, src, bytes, hipMemcpyDefault, s));
+}
+inline void copy_out(void* dst, const void* src_dev, size_t bytes, hipStream_t s) {
+  if (bytes == 0) return;
+  E3D_HIP(hipMemcpyAsync(dst, src_dev, bytes, hipMemcpyDefault, s));
+}
+
+struct EventTimer {
+  hipEvent_t a = nullptr, b = nullptr;
+  EventTimer() { E3D_HIP(hipEventCreate(&a)); E3D_HIP(hipEventCreate(&b)); }
+  ~EventTimer() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+  void start(hipStream_t s) { E3D_HIP(hipEventRecord(a, s)); }
+  void stop(hipStream_t s) { E3D_HIP(hipEventRecord(b, s)); }
+  float ms() { E3D_HIP(hipEventSynchronize(b)); float t = 0; E3D_HIP(hipEventElapsedTime(&t, a, b)); return t; }
+};
+
+inline size_t div_up(size_t a, size_t b) { return (a + b - 1) / b; }
+
+}  // namespace e3d

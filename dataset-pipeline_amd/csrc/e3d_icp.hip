@@ -1,0 +1,817 @@
+// e3d_icp.hip -- host driver of the point-to-plane ICP path and its C-ABI (include/e3d_hip.h).
+//
+// Mirrors icp::PointToPlaneICP (src/icp/icp_point_to_plane.{h,cc}) and PointToPlaneICPImpl
+// (src/icp/icp_point_to_plane_impl.h) of the reference; see DESIGN.md for the MI355X-side design:
+//   * every cloud gets a STATIC hash grid in its own local frame (cell >= search radius), built once
+//     per search radius; queries are mapped into the target's local frame to pick the 27 candidate
+//     cells, distances are evaluated on the global-frame f32 coordinates exactly like the reference
+//     (so no index is rebuilt per outer iteration, unlike the reference's per-pair kd-trees);
+//   * correspondences are materialised once per outer iteration as three float4 planes; every LM
+//     pass streams them (48 B/correspondence) and reduces cost + Gramian blocks in f64;
+//   * the accumulate pass and the cost pass of consecutive LM steps are fused (same numbers, half the
+//     passes); the tiny LDL^T solve and the SE3 update run on the host in the reference's precisions.
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <memory>
+
+#include "../../include/e3d_hip.h"
+#include "e3d_icp_kernels.hpp"
+#include "e3d_math.hpp"
+
+#pragma clang fp contract(off)
+
+namespace e3d {
+
+static thread_local std::string g_last_error;
+void set_last_error(const std::string& msg) { g_last_error = msg; }
+const char* last_error_cstr() { return g_last_error.c_str(); }
+
+static int g_device = 0;
+
+// -------------------------------------------------------------------------------------------------
+struct Cloud {
+  size_t n = 0;
+  bool fixed = false;
+  DevBuf<float> raw_xyz, raw_nrm;   // as given (fixed: already in the global frame), AoS
+  float T[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};   // global_T_cloud
+  // static grid (valid for grid_radius)
+  bool grid_valid = false;
+  float grid_radius = -1.f;
+  float grid_T[12];                 // pose the grid's slack was sized for (only its linear part matters)
+  DevBuf<float4> L4, LN, G4;
+  DevBuf<HashEntry> table;
+  GridDesc grid{};
+  float lmin[3], lmax[3];           // local bbox
+  float bmin[3], bmax[3];           // global bbox of the current outer iteration
+  int cloud_index = -1;             // impl index in the current AlignMeshes
+};
+
+struct PairJob {
+  int src, tgt;            // indices into the handle's cloud table (fixed = clouds.size())
+  int impl_src, impl_tgt;
+  long long count = 0;
+  double dsum = 0.0;
+  size_t corr_off = 0;
+  bool mine = true;
+};
+
+}  // namespace e3d
+
+using namespace e3d;
+
+struct e3d_icp {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::vector<std::unique_ptr<Cloud>> clouds;   // movable clouds
+  std::unique_ptr<Cloud> fixed;                 // merged fixed cloud (global frame)
+  int max_inner = 150;
+  int rank = 0, world = 1;
+  e3d_allreduce_fn allreduce = nullptr;
+  void* allreduce_user = nullptr;
+
+  // scratch
+  DevBuf<float> bbox_partial, bbox_out;
+  PinBuf<float> h_bbox;
+  DevBuf<unsigned long long> keys_a, keys_b;
+  DevBuf<unsigned> vals_a, vals_b, counter;
+  DevBuf<char> sort_temp;
+  DevBuf<int> match_pos;
+  DevBuf<float> match_d2;
+  DevBuf<unsigned> block_counts, block_offsets;
+  DevBuf<double> block_d2;
+  DevBuf<unsigned long long> d_total;
+  DevBuf<double> d_total_d2;
+  PinBuf<unsigned long long> h_total;
+  PinBuf<double> h_total_d2;
+  DevBuf<float4> cA, cB, cC;
+  size_t corr_used = 0;
+  DevBuf<LmSet> d_sets;
+  PinBuf<LmSet> h_sets;
+  DevBuf<int> d_block_set;
+  DevBuf<double> d_partial, d_setsum;
+  PinBuf<double> h_setsum;
+  std::unique_ptr<EventTimer> lm_timer;
+
+  std::vector<e3d_icp_pair_record> pair_records;
+  std::vector<e3d_icp_iter_record> iter_records;
+
+  ~e3d_icp() {
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+};
+
+namespace e3d {
+
+static Affine to_affine(const float* T) {
+  Affine a;
+  for (int i = 0; i < 12; ++i) a.m[i] = T[i];
+  return a;
+}
+
+static void sync(e3d_icp* h) { E3D_HIP(hipStreamSynchronize(h->stream)); }
+
+static void upload_cloud(e3d_icp* h, Cloud& c, const float* xyz, const float* nrm, size_t n) {
+  c.n = n;
+  c.raw_xyz.reserve(3 * n);
+  c.raw_nrm.reserve(3 * n);
+  copy_in(c.raw_xyz.p, xyz, sizeof(float) * 3 * n, h->stream);
+  copy_in(c.raw_nrm.p, nrm, sizeof(float) * 3 * n, h->stream);
+  sync(h);
+}
+
+static void ensure_bbox_scratch(e3d_icp* h) {
+  h->bbox_partial.reserve(6 * (size_t)kMaxBboxBlocks);
+  h->bbox_out.reserve(6);
+  h->h_bbox.reserve(6);
+}
+
+// Build the static local-frame grid of a cloud for search radius d (global frame).
+static void build_grid(e3d_icp* h, Cloud& c, float d) {
+  hipStream_t s = h->stream;
+  ensure_bbox_scratch(h);
+  const size_t n = c.n;
+  // local bbox
+  if (n > 0) {
+    launch_bbox_aos(c.raw_xyz.p, n, h->bbox_partial.p, h->bbox_out.p, s);
+    copy_out(h->h_bbox.p, h->bbox_out.p, sizeof(float) * 6, s);
+    sync(h);
+    for (int k = 0; k < 3; ++k) { c.lmin[k] = h->h_bbox.p[k]; c.lmax[k] = h->h_bbox.p[3 + k]; }
+  } else {
+    for (int k = 0; k < 3; ++k) { c.lmin[k] = 0.f; c.lmax[k] = 0.f; }
+  }
+  // cell size: local search radius (r / sigma_min) plus slack for the f32 global->local mapping and the
+  // f32 cell-index computation (derivation in DESIGN.md "NN search: exactness of the candidate set").
+  const double r = (double)d;
+  double smin = min_singular_value_3x3(c.T);
+  if (!(smin > 1e-12)) smin = 1e-12;
+  double Linv[9];
+  double ninv = 1.0;
+  if (invert_3x3(c.T, Linv)) {
+    ninv = 0;
+    for (int i = 0; i < 3; ++i) ninv = std::max(ninv, std::fabs(Linv[3 * i]) + std::fabs(Linv[3 * i + 1]) + std::fabs(Linv[3 * i + 2]));
+  }
+  double m_local = 0, nL = 0, m_t = 0;
+  for (int k = 0; k < 3; ++k) {
+    m_local = std::max(m_local, std::max(std::fabs((double)c.lmin[k]), std::fabs((double)c.lmax[k])));
+    nL = std::max(nL, std::fabs((double)c.T[4 * k]) + std::fabs((double)c.T[4 * k + 1]) + std::fabs((double)c.T[4 * k + 2]));
+    m_t = std::max(m_t, std::fabs((double)c.T[4 * k + 3]));
+  }
+  const double m_global = nL * m_local + m_t + r;
+  const double r_local = r / smin;
+  const double slack = 16.0 * FLT_EPSILON * (m_global * ninv + m_local + r_local);
+  double extent = 0;
+  for (int k = 0; k < 3; ++k) extent = std::max(extent, (double)c.lmax[k] - (double)c.lmin[k]);
+  double cell = (r_local + slack) * (1.0 + 1e-3 + 8.0 * FLT_EPSILON * (extent / std::max(r_local, 1e-30) + 4.0));
+  // 21 bits per axis: enlarge the cell if the extent would not fit (keeps exactness, costs candidates)
+  const double max_cells = (double)((1 << 21) - 8);
+  if (extent / cell > max_cells) cell = extent / max_cells;
+  if (!(cell > 0) || !std::isfinite(cell)) cell = 1.0;
+  c.grid.inv_cell = (float)(1.0 / cell);
+  // make sure the f32 inverse does not shrink the effective cell below the bound
+  while (1.0 / (double)c.grid.inv_cell < (r_local + slack) * (1.0 + 5e-4)) c.grid.inv_cell = std::nextafter(c.grid.inv_cell, 0.f);
+  for (int k = 0; k < 3; ++k) c.grid.origin[k] = (float)((double)c.lmin[k] - 2.0 * cell);
+
+  c.L4.reserve(n); c.LN.reserve(n); c.G4.reserve(n);
+  unsigned n_cells = 0;
+  if (n > 0) {
+    h->keys_a.reserve(n); h->keys_b.reserve(n); h->vals_a.reserve(n); h->vals_b.reserve(n);
+    h->counter.reserve(1);
+    launch_cell_keys(c.raw_xyz.p, n, c.grid, h->keys_a.p, h->vals_a.p, s);
+    sort_pairs_u64_u32(h->keys_a.p, h->keys_b.p, h->vals_a.p, h->vals_b.p, n, 63, h->sort_temp, s);
+    launch_permute(c.raw_xyz.p, c.raw_nrm.p, h->vals_b.p, n, c.L4.p, c.LN.p, s);
+    E3D_HIP(hipMemsetAsync(h->counter.p, 0, sizeof(unsigned), s));
+    launch_count_cells(h->keys_b.p, n, h->counter.p, s);
+    E3D_HIP(hipMemcpyAsync(&n_cells, h->counter.p, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+    sync(h);
+  }
+  size_t tsize = 64;
+  while (tsize < 2 * (size_t)n_cells) tsize <<= 1;
+  c.table.reserve(tsize);
+  c.grid.mask = (unsigned)(tsize - 1);
+  E3D_HIP(hipMemsetAsync(c.table.p, 0xFF, sizeof(HashEntry) * tsize, s));
+  if (n > 0) launch_build_table(h->keys_b.p, n, c.table.p, c.grid.mask, s);
+  sync(h);
+  c.grid_valid = true;
+  c.grid_radius = d;
+  std::memcpy(c.grid_T, c.T, sizeof c.grid_T);
+}
+
+// The grid stays valid while the search radius is unchanged and the pose's linear part has not drifted
+// in scale (ICP only left-multiplies rotations, so sigma_min is constant up to rounding).
+static bool grid_usable(const Cloud& c, float d) {
+  if (!c.grid_valid || c.grid_radius != d) return false;
+  const double s0 = min_singular_value_3x3(c.grid_T), s1 = min_singular_value_3x3(c.T);
+  return std::fabs(s0 - s1) <= 1e-4 * std::max(s0, 1e-30);
+}
+
+static InvMap make_invmap(const Cloud& c) {
+  InvMap im;
+  double Linv[9];
+  if (!invert_3x3(c.T, Linv)) { for (int i = 0; i < 9; ++i) Linv[i] = (i % 4 == 0) ? 1.0 : 0.0; }
+  for (int i = 0; i < 9; ++i) im.Linv[i] = (float)Linv[i];
+  for (int k = 0; k < 3; ++k) im.t[k] = c.T[4 * k + 3];
+  return im;
+}
+
+static void transform_cloud(e3d_icp* h, Cloud& c) {
+  ensure_bbox_scratch(h);
+  if (c.n == 0) {
+    for (int k = 0; k < 3; ++k) { c.bmin[k] = FLT_MAX; c.bmax[k] = -FLT_MAX; }
+    return;
+  }
+  launch_transform_bbox(c.L4.p, c.n, to_affine(c.T), c.G4.p, h->bbox_partial.p, h->bbox_out.p, h->stream);
+  copy_out(h->h_bbox.p, h->bbox_out.p, sizeof(float) * 6, h->stream);
+  sync(h);
+  for (int k = 0; k < 3; ++k) { c.bmin[k] = h->h_bbox.p[k]; c.bmax[k] = h->h_bbox.p[3 + k]; }
+}
+
+static bool bbox_intersects(const Cloud& a, const Cloud& b) {
+  // !a.bbox.intersection(b.bbox).isEmpty()   (icp_point_to_plane.cc:214-215)
+  for (int k = 0; k < 3; ++k) {
+    const float lo = std::max(a.bmin[k], b.bmin[k]);
+    const float hi = std::min(a.bmax[k], b.bmax[k]);
+    if (lo > hi) return false;
+  }
+  return true;
+}
+
+static inline float radius_sq(float d) {
+  const double r = (double)d;   // pcl::KdTreeFLANN::radiusSearch: static_cast<float>(radius * radius)
+  return (float)(r * r);
+}
+
+// NN search + compaction for one directed pair; appends to the correspondence planes.
+static void find_pair(e3d_icp* h, Cloud& src, Cloud& tgt, float d, PairJob& job) {
+  hipStream_t s = h->stream;
+  const size_t n = src.n;
+  job.count = 0; job.dsum = 0.0; job.corr_off = h->corr_used;
+  if (n == 0 || tgt.n == 0) return;
+  h->match_pos.reserve(n); h->match_d2.reserve(n);
+  const size_t nb = div_up(n, kBlock);
+  h->block_counts.reserve(nb); h->block_offsets.reserve(nb); h->block_d2.reserve(nb);
+  h->d_total.reserve(1); h->d_total_d2.reserve(1); h->h_total.reserve(1); h->h_total_d2.reserve(1);
+  launch_nn_query(src.G4.p, n, tgt.G4.p, tgt.table.p, tgt.grid, make_invmap(tgt), radius_sq(d), h->match_pos.p,
+                  h->match_d2.p, s);
+  launch_match_scan(h->match_pos.p, h->match_d2.p, n, h->block_counts.p, h->block_offsets.p, h->block_d2.p,
+                    h->d_total.p, h->d_total_d2.p, s);
+  copy_out(h->h_total.p, h->d_total.p, sizeof(unsigned long long), s);
+  copy_out(h->h_total_d2.p, h->d_total_d2.p, sizeof(double), s);
+  sync(h);
+  job.count = (long long)h->h_total.p[0];
+  job.dsum = h->h_total_d2.p[0];
+  if (job.count == 0) return;
+  const size_t need = h->corr_used + (size_t)job.count;
+  if (need > h->cA.cap) {
+    const size_t ncap = std::max(need, h->cA.cap + h->cA.cap / 2);
+    h->cA.grow_keep(ncap, h->corr_used, s);
+    h->cB.grow_keep(ncap, h->corr_used, s);
+    h->cC.grow_keep(ncap, h->corr_used, s);
+  }
+  launch_compact_corr(h->match_pos.p, n, h->block_offsets.p, src.G4.p, src.LN.p,
+                      to_affine(src.T), tgt.G4.p, tgt.LN.p, to_affine(tgt.T), h->cA.p, h->cB.p, h->cC.p,
+                      h->corr_used, s);   // the merged fixed cloud keeps T = identity (exact)
+  h->corr_used = need;
+}
+
+// number of LM blocks for a set of n correspondences (deterministic function of n only)
+static int lm_blocks_for(long long n) {
+  long long b = (n + (long long)kBlock * 8 - 1) / ((long long)kBlock * 8);
+  if (b < 1) b = 1;
+  if (b > 2048) b = 2048;
+  return (int)b;
+}
+
+struct LmSystem {
+  int n_impl = 0, nv = 0;
+  std::vector<PairJob*> sets;        // this rank's non-empty pairs, grouped by mode
+  std::vector<int> mode_begin, mode_blocks, mode_block_base;   // per mode 1..3
+  int total_blocks = 0;
+  std::vector<double> H, b;
+  double cost = 0;
+};
+
+// Evaluate cost (+ H, b when full) at the given inner poses.
+static void lm_evaluate(e3d_icp* h, LmSystem& L, const std::vector<SE3f>& poses, bool full, std::vector<double>& H,
+                        std::vector<double>& b, double& cost, e3d_icp_iter_record& rec) {
+  hipStream_t s = h->stream;
+  const int ns = (int)L.sets.size();
+  const int nv = L.nv;
+  H.assign((size_t)nv * nv, 0.0);
+  b.assign((size_t)nv, 0.0);
+  cost = 0.0;
+  if (ns > 0) {
+    for (int i = 0; i < ns; ++i) {
+      LmSet& S = h->h_sets.p[i];
+      const SE3f& ps = poses[L.sets[i]->impl_src];
+      const SE3f& pt = poses[L.sets[i]->impl_tgt];
+      quat_to_matrix<float>(ps.q.w, ps.q.x, ps.q.y, ps.q.z, S.Rs);
+      quat_to_matrix<float>(pt.q.w, pt.q.x, pt.q.y, pt.q.z, S.Rt);
+      for (int k = 0; k < 3; ++k) { S.ts[k] = ps.t[k]; S.tt[k] = pt.t[k]; }
+    }
+    E3D_HIP(hipMemcpyAsync(h->d_sets.p, h->h_sets.p, sizeof(LmSet) * ns, hipMemcpyHostToDevice, s));
+    if (!h->lm_timer) h->lm_timer.reset(new EventTimer());
+    EventTimer& tm = *h->lm_timer;
+    tm.start(s);
+    if (full) {
+      for (int m = 1; m <= 3; ++m)
+        launch_lm_pass(m, h->cA.p, h->cB.p, h->cC.p, h->d_sets.p, h->d_block_set.p, L.mode_block_base[m],
+                       L.mode_blocks[m], h->d_partial.p, s);
+    } else {
+      launch_lm_pass(kModeCost, h->cA.p, h->cB.p, h->cC.p, h->d_sets.p, h->d_block_set.p, 0, L.total_blocks,
+                     h->d_partial.p, s);
+    }
+    tm.stop(s);
+    launch_lm_reduce(h->d_partial.p, h->d_sets.p, ns, kLmSlot, h->d_setsum.p, s);
+    copy_out(h->h_setsum.p, h->d_setsum.p, sizeof(double) * kLmSlot * ns, s);
+    sync(h);
+    rec.t_lm_kernel_ms += tm.ms();
+    if (full) rec.full_passes++; else rec.cost_passes++;
+    // scatter the per-set systems into H, b  (Accumulate, icp_point_to_plane_impl.h:82-113)
+    for (int i = 0; i < ns; ++i) {
+      const double* r = h->h_setsum.p + (size_t)kLmSlot * i;
+      cost += r[0];
+      if (!full) continue;
+      const PairJob& pj = *L.sets[i];
+      const int si = 6 * (pj.impl_src - 1), ti = 6 * (pj.impl_tgt - 1);
+      const LmSet& S = h->h_sets.p[i];
+      if (S.mode == kModeOne) {
+        const int vi = (S.side == 0) ? si : ti;
+        int k = 1;
+        for (int a = 0; a < 6; ++a) for (int c = a; c < 6; ++c) H[(size_t)(vi + a) * nv + vi + c] += r[k++];
+        for (int a = 0; a < 6; ++a) b[vi + a] += r[22 + a];
+      } else {
+        int k = 1;
+        for (int a = 0; a < 6; ++a) for (int c = a; c < 6; ++c) H[(size_t)(si + a) * nv + si + c] += r[k++];
+        for (int a = 0; a < 6; ++a) b[si + a] += r[22 + a];
+        k = 28;
+        for (int a = 0; a < 6; ++a) for (int c = a; c < 6; ++c) H[(size_t)(ti + a) * nv + ti + c] += r[k++];
+        for (int a = 0; a < 6; ++a) b[ti + a] += r[49 + a];
+        if (S.mode == kModeTwoCross)
+          for (int a = 0; a < 6; ++a) for (int c = 0; c < 6; ++c) H[(size_t)(si + a) * nv + ti + c] += r[55 + 6 * a + c];
+        // kModeTwo: the (src,tgt) block lies in the lower triangle, which the solver never reads [QUIRK]
+      }
+    }
+  } else {
+    if (full) rec.full_passes++; else rec.cost_passes++;
+  }
+  if (h->world > 1) {
+    // one fused buffer [upper(H) as dense nv*nv, b, cost] summed over ranks
+    std::vector<double> buf((size_t)nv * nv + nv + 1);
+    std::copy(H.begin(), H.end(), buf.begin());
+    std::copy(b.begin(), b.end(), buf.begin() + (size_t)nv * nv);
+    buf.back() = cost;
+    const size_t cnt = full ? buf.size() : 1;
+    double* ptr = full ? buf.data() : &buf.back();
+    if (h->allreduce(ptr, cnt, h->allreduce_user) != 0) throw Error(E3D_ERR_INVALID, "allreduce callback failed");
+    if (full) {
+      std::copy(buf.begin(), buf.begin() + (size_t)nv * nv, H.begin());
+      std::copy(buf.begin() + (size_t)nv * nv, buf.begin() + (size_t)nv * nv + nv, b.begin());
+    }
+    cost = buf.back();
+  }
+}
+
+static void lm_prepare(e3d_icp* h, LmSystem& L, std::vector<PairJob>& jobs) {
+  // group this rank's non-empty sets by full-pass mode; assign LM blocks
+  L.sets.clear();
+  L.mode_begin.assign(5, 0); L.mode_blocks.assign(5, 0); L.mode_block_base.assign(5, 0);
+  std::vector<std::vector<PairJob*>> by_mode(4);
+  for (PairJob& j : jobs) {
+    if (!j.mine || j.count == 0) continue;
+    const int si = j.impl_src - 1, ti = j.impl_tgt - 1;
+    int mode;
+    if (si < 0 || ti < 0) mode = kModeOne;
+    else mode = (si < ti) ? kModeTwoCross : kModeTwo;
+    by_mode[mode].push_back(&j);
+  }
+  int block = 0;
+  const int ns_total = (int)(by_mode[1].size() + by_mode[2].size() + by_mode[3].size());
+  h->h_sets.reserve(std::max(ns_total, 1));
+  h->d_sets.reserve(std::max(ns_total, 1));
+  std::vector<int> block_set;
+  for (int m = 1; m <= 3; ++m) {
+    L.mode_begin[m] = (int)L.sets.size();
+    L.mode_block_base[m] = block;
+    for (PairJob* j : by_mode[m]) {
+      const int i = (int)L.sets.size();
+      LmSet& S = h->h_sets.p[i];
+      S.off = (long long)j->corr_off; S.n = j->count;
+      S.block_begin = block; S.nblocks = lm_blocks_for(j->count);
+      S.mode = m;
+      S.side = (j->impl_src - 1 >= 0) ? 0 : 1;
+      for (int b = 0; b < S.nblocks; ++b) block_set.push_back(i);
+      block += S.nblocks;
+      L.sets.push_back(j);
+    }
+    L.mode_blocks[m] = block - L.mode_block_base[m];
+  }
+  L.total_blocks = block;
+  h->d_block_set.reserve(std::max(block, 1));
+  h->d_partial.reserve((size_t)std::max(block, 1) * kLmSlot);
+  h->d_setsum.reserve((size_t)std::max(ns_total, 1) * kLmSlot);
+  h->h_setsum.reserve((size_t)std::max(ns_total, 1) * kLmSlot);
+  if (block > 0) {
+    E3D_HIP(hipMemcpyAsync(h->d_block_set.p, block_set.data(), sizeof(int) * block, hipMemcpyHostToDevice, h->stream));
+    sync(h);
+  }
+}
+
+// PointToPlaneICPImpl::compute  (icp_point_to_plane_impl.h:115-293)
+static void lm_compute(e3d_icp* h, LmSystem& L, std::vector<SE3f>& poses, e3d_icp_iter_record& rec) {
+  const int nv = L.nv;
+  std::vector<double> H, b, Hn, bn, Hl((size_t)nv * nv), x(nv), W;
+  std::vector<int> perm;
+  double cost = 0, new_cost = 0;
+  double lambda = 0.1;
+  lm_evaluate(h, L, poses, true, H, b, cost, rec);
+  rec.initial_cost = cost;
+  rec.final_cost = cost;
+  std::vector<SE3f> upd(poses.size());
+  for (int it = 0; it < h->max_inner; ++it) {
+    rec.inner_iterations++;
+    bool applied = false;
+    for (int lm = 0; lm < 10; ++lm) {
+      Hl = H;
+      for (int i = 0; i < nv; ++i) Hl[(size_t)i * nv + i] += lambda;       // additive damping (impl.h:223)
+      if (nv > 0) ldlt_solve_upper(Hl.data(), nv, b.data(), x.data(), W, perm);
+      upd[0] = poses[0];
+      for (size_t ci = 1; ci < poses.size(); ++ci) upd[ci] = se3_apply_update(&x[6 * (ci - 1)], poses[ci]);   // impl.h:235
+      // The first try of an iteration is usually accepted: evaluate cost AND the next iteration's H, b in
+      // one pass.  Later tries are usually rejected: cost only, and one extra full pass if accepted.
+      const bool full = (lm == 0);
+      lm_evaluate(h, L, upd, full, Hn, bn, new_cost, rec);
+      if (new_cost < cost) {
+        if (!full) {
+          double c2;
+          lm_evaluate(h, L, upd, true, Hn, bn, c2, rec);
+          new_cost = c2;   // identical by construction (same kernels' cost path and reduction tree)
+        }
+        poses = upd; H.swap(Hn); b.swap(bn); cost = new_cost;
+        lambda = 0.5f * lambda;
+        applied = true;
+        break;
+      } else {
+        lambda = 2.f * lambda;
+      }
+    }
+    rec.final_cost = cost;
+    if (!applied) break;
+  }
+}
+
+// PointToPlaneICP::AlignMeshes  (icp_point_to_plane.cc:169-342)
+static bool align_meshes(e3d_icp* h, float max_d, float thr, bool print, int iteration) {
+  e3d_icp_iter_record rec{};
+  rec.iteration = iteration;
+  hipStream_t s = h->stream;
+  EventTimer t_tr, t_nn, t_lm;
+  const int M = (int)h->clouds.size();
+  const bool has_fixed = (bool)h->fixed;
+  int n_impl = 0, fixed_vertex = -1;
+
+  t_tr.start(s);
+  if (has_fixed) {
+    Cloud& f = *h->fixed;
+    fixed_vertex = n_impl++;
+    f.cloud_index = fixed_vertex;
+    if (!grid_usable(f, max_d)) build_grid(h, f, max_d);
+    // fixed cloud lives in the global frame: G4 = L4 (identity transform is exact), bbox recomputed
+    transform_cloud(h, f);
+  }
+  for (int i = 0; i < M; ++i) {
+    Cloud& c = *h->clouds[i];
+    if (!grid_usable(c, max_d)) build_grid(h, c, max_d);
+    transform_cloud(h, c);
+    c.cloud_index = n_impl++;
+  }
+  t_tr.stop(s);
+
+  // pair list in the sequential order of the reference's ik loop (cc:208-309)
+  std::vector<PairJob> jobs;
+  for (int ik = 0; ik < M * M; ++ik) {
+    const int i = ik / M, k = ik % M;
+    if (i != k && bbox_intersects(*h->clouds[i], *h->clouds[k]))
+      jobs.push_back({i, k, h->clouds[i]->cloud_index, h->clouds[k]->cloud_index});
+    if (i == k && has_fixed && bbox_intersects(*h->fixed, *h->clouds[i])) {
+      jobs.push_back({i, M, h->clouds[i]->cloud_index, fixed_vertex});
+      jobs.push_back({M, i, fixed_vertex, h->clouds[i]->cloud_index});
+    }
+  }
+  t_nn.start(s);
+  h->corr_used = 0;
+  for (size_t p = 0; p < jobs.size(); ++p) {
+    PairJob& j = jobs[p];
+    j.mine = ((int)(p % (size_t)h->world) == h->rank);
+    if (!j.mine) continue;
+    Cloud& src = (j.src == M) ? *h->fixed : *h->clouds[j.src];
+    Cloud& tgt = (j.tgt == M) ? *h->fixed : *h->clouds[j.tgt];
+    find_pair(h, src, tgt, max_d, j);
+    rec.queries += (long long)src.n;
+  }
+  t_nn.stop(s);
+  if (h->world > 1 && !jobs.empty()) {
+    std::vector<double> buf(2 * jobs.size(), 0.0);
+    for (size_t p = 0; p < jobs.size(); ++p)
+      if (jobs[p].mine) { buf[2 * p] = (double)jobs[p].count; buf[2 * p + 1] = jobs[p].dsum; }
+    if (h->allreduce(buf.data(), buf.size(), h->allreduce_user) != 0) throw Error(E3D_ERR_INVALID, "allreduce callback failed");
+    for (size_t p = 0; p < jobs.size(); ++p)
+      if (!jobs[p].mine) { jobs[p].count = (long long)buf[2 * p]; jobs[p].dsum = buf[2 * p + 1]; }
+  }
+  for (const PairJob& j : jobs) {
+    const int psrc = (j.impl_src == fixed_vertex) ? -1 : j.impl_src;
+    const int ptgt = (j.impl_tgt == fixed_vertex) ? -1 : j.impl_tgt;
+    h->pair_records.push_back({iteration, psrc, ptgt, (int64_t)j.count, j.dsum});
+    if (j.mine) rec.correspondences += j.count;
+    if (print) {
+      char avg[64] = "";
+      if (j.count > 0) snprintf(avg, sizeof avg, " (avg. distance: %g)", (double)(float)(j.dsum / (double)j.count));
+      if (psrc >= 0 && ptgt >= 0) printf("  found correspondences from %d to %d: %lld%s\n", j.impl_src, j.impl_tgt, j.count, avg);
+      else if (ptgt < 0) printf("  found correspondences from %d to fixed clouds: %lld%s\n", j.impl_src, j.count, avg);
+      else printf("  found correspondences from fixed clouds to %d: %lld%s\n", j.impl_tgt, j.count, avg);
+    }
+  }
+
+  // impl.setMaxIterations(150); impl.compute()  (cc:312-316)
+  t_lm.start(s);
+  std::vector<SE3f> poses((size_t)n_impl);
+  LmSystem L;
+  L.n_impl = n_impl;
+  L.nv = 6 * (n_impl - 1);
+  lm_prepare(h, L, jobs);
+  if (n_impl >= 1) lm_compute(h, L, poses, rec);
+  t_lm.stop(s);
+
+  // pose write-back (cc:318-341): new = Affine3f(pose.matrix()) * global_T_cloud
+  bool converged = true;
+  for (int i = 0; i < M; ++i) {
+    Cloud& c = *h->clouds[i];
+    const SE3f& p = poses[c.cloud_index];
+    float R[9];
+    quat_to_matrix<float>(p.q.w, p.q.x, p.q.y, p.q.z, R);
+    float Tn[12];
+    for (int r = 0; r < 3; ++r) {
+      for (int col = 0; col < 3; ++col)
+        Tn[4 * r + col] = dot3(R[3 * r], R[3 * r + 1], R[3 * r + 2], c.T[col], c.T[4 + col], c.T[8 + col]);
+      Tn[4 * r + 3] = dot3(R[3 * r], R[3 * r + 1], R[3 * r + 2], c.T[3], c.T[7], c.T[11]) + p.t[r];
+    }
+    const float dx = c.T[3] - Tn[3], dy = c.T[7] - Tn[7], dz = c.T[11] - Tn[11];
+    const float movement = std::sqrt(dx * dx + (dy * dy + dz * dz));
+    if (movement > thr) converged = false;
+    if (print) printf("  %d moved by %g\n", c.cloud_index, (double)movement);
+    std::memcpy(c.T, Tn, sizeof Tn);
+  }
+  rec.t_transform_ms = t_tr.ms();
+  rec.t_nn_ms = t_nn.ms();
+  rec.t_lm_ms = t_lm.ms();
+  h->iter_records.push_back(rec);
+  return converged;
+}
+
+}  // namespace e3d
+
+// =================================================================================================
+// C-ABI
+// =================================================================================================
+#define E3D_TRY try {
+#define E3D_CATCH()                                                                         \
+  } catch (const e3d::Error& e) { e3d::set_last_error(e.what()); return e.code; }           \
+  catch (const std::exception& e) { e3d::set_last_error(e.what()); return E3D_ERR_INVALID; }
+
+extern "C" {
+
+int e3d_abi_version(void) { return E3D_ABI_VERSION; }
+
+const char* e3d_last_error(void) { return e3d::last_error_cstr(); }
+
+int e3d_init(int device) {
+  E3D_TRY
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) throw Error(E3D_ERR_NO_DEVICE, "no HIP device visible (libe3dhip needs an MI355X / gfx950 GPU)");
+  if (device < 0 || device >= n) throw Error(E3D_ERR_INVALID, fmt("device %d out of range (%d devices)", device, n));
+  E3D_HIP(hipSetDevice(device));
+  g_device = device;
+  return n;
+  E3D_CATCH()
+}
+
+e3d_icp_t* e3d_icp_create(void) {
+  try {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) throw Error(E3D_ERR_NO_DEVICE, "no HIP device visible (libe3dhip needs an MI355X / gfx950 GPU)");
+    E3D_HIP(hipSetDevice(g_device));
+    std::unique_ptr<e3d_icp> h(new e3d_icp());
+    h->device = g_device;
+    E3D_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    return h.release();
+  } catch (const std::exception& e) {
+    e3d::set_last_error(e.what());
+    return nullptr;
+  }
+}
+
+void e3d_icp_destroy(e3d_icp_t* icp) { delete icp; }
+
+int e3d_icp_add_cloud(e3d_icp_t* h, const float* xyz, const float* normals, size_t n, const float T[12], int fixed) {
+  E3D_TRY
+  if (!h || (!xyz && n) || (!normals && n) || !T) throw Error(E3D_ERR_INVALID, "e3d_icp_add_cloud: null argument");
+  if (n >= (size_t)1 << 31) throw Error(E3D_ERR_INVALID, "e3d_icp_add_cloud: more than 2^31-1 points (reference uses int indices)");
+  E3D_HIP(hipSetDevice(h->device));
+  if (fixed) {
+    // transform to the global frame once and concatenate (icp_point_to_plane.cc:112-127)
+    if (!h->fixed) { h->fixed.reset(new Cloud()); h->fixed->fixed = true; }
+    Cloud& f = *h->fixed;
+    const size_t n0 = f.n;
+    f.raw_xyz.grow_keep(3 * (n0 + n), 3 * n0, h->stream);
+    f.raw_nrm.grow_keep(3 * (n0 + n), 3 * n0, h->stream);
+    if (n > 0) {
+      DevBuf<float> tx, tn;
+      tx.reserve(3 * n); tn.reserve(3 * n);
+      copy_in(tx.p, xyz, sizeof(float) * 3 * n, h->stream);
+      copy_in(tn.p, normals, sizeof(float) * 3 * n, h->stream);
+      ensure_bbox_scratch(h);
+      launch_transform_aos(tx.p, tn.p, n, to_affine(T), f.raw_xyz.p + 3 * n0, f.raw_nrm.p + 3 * n0, h->bbox_partial.p,
+                           h->bbox_out.p, h->stream);
+      sync(h);
+    }
+    f.n = n0 + n;
+    f.grid_valid = false;
+    return -1;
+  }
+  std::unique_ptr<Cloud> c(new Cloud());
+  std::memcpy(c->T, T, sizeof(float) * 12);
+  upload_cloud(h, *c, xyz, normals, n);
+  h->clouds.push_back(std::move(c));
+  return (int)h->clouds.size() - 1;
+  E3D_CATCH()
+}
+
+int e3d_icp_run(e3d_icp_t* h, float max_d, int initial_iteration, int max_num_iterations, float thr, int print) {
+  E3D_TRY
+  if (!h) throw Error(E3D_ERR_INVALID, "e3d_icp_run: null handle");
+  if (h->clouds.empty()) throw Error(E3D_ERR_INVALID, "e3d_icp_run: no clouds to optimize (reference: CHECK(!clouds_.empty()))");
+  E3D_HIP(hipSetDevice(h->device));
+  for (int i = initial_iteration; i < initial_iteration + max_num_iterations; ++i) {
+    if (print) printf("-- Alignment iteration %d --\n", i);
+    const bool converged = align_meshes(h, max_d, thr, print != 0, i);
+    if (converged) {
+      if (print) { printf("Convergence is assumed as the maximum movement is less than the threshold.\n"); fflush(stdout); }
+      return 1;
+    }
+  }
+  if (print) fflush(stdout);
+  return 0;
+  E3D_CATCH()
+}
+
+int e3d_icp_get_pose(e3d_icp_t* h, int idx, float T[12]) {
+  E3D_TRY
+  if (!h || !T) throw Error(E3D_ERR_INVALID, "e3d_icp_get_pose: null argument");
+  if (idx < 0 || idx >= (int)h->clouds.size()) throw Error(E3D_ERR_INDEX, fmt("cloud index %d out of range", idx));
+  std::memcpy(T, h->clouds[idx]->T, sizeof(float) * 12);
+  return 0;
+  E3D_CATCH()
+}
+
+int e3d_icp_set_max_inner_iterations(e3d_icp_t* h, int n) {
+  if (!h || n < 0) { e3d::set_last_error("e3d_icp_set_max_inner_iterations: bad argument"); return E3D_ERR_INVALID; }
+  h->max_inner = n;
+  return 0;
+}
+
+size_t e3d_icp_num_pair_records(const e3d_icp_t* h) { return h ? h->pair_records.size() : 0; }
+const e3d_icp_pair_record* e3d_icp_pair_records(const e3d_icp_t* h) { return h ? h->pair_records.data() : nullptr; }
+size_t e3d_icp_num_iter_records(const e3d_icp_t* h) { return h ? h->iter_records.size() : 0; }
+const e3d_icp_iter_record* e3d_icp_iter_records(const e3d_icp_t* h) { return h ? h->iter_records.data() : nullptr; }
+void e3d_icp_clear_records(e3d_icp_t* h) { if (h) { h->pair_records.clear(); h->iter_records.clear(); } }
+
+int e3d_icp_set_shard(e3d_icp_t* h, int rank, int world, e3d_allreduce_fn fn, void* user) {
+  if (!h || world < 1 || rank < 0 || rank >= world || (world > 1 && !fn)) {
+    e3d::set_last_error("e3d_icp_set_shard: bad argument");
+    return E3D_ERR_INVALID;
+  }
+  h->rank = rank; h->world = world; h->allreduce = fn; h->allreduce_user = user;
+  return 0;
+}
+
+// ---- stand-alone entry points ------------------------------------------------------------------
+int64_t e3d_find_correspondences(const float* sxyz, size_t ns, const float* txyz, size_t nt, float d,
+                                 int32_t* match_index, float* sq_distance) {
+  E3D_TRY
+  if ((!sxyz && ns) || (!txyz && nt) || !match_index || !sq_distance) throw Error(E3D_ERR_INVALID, "e3d_find_correspondences: null argument");
+  std::unique_ptr<e3d_icp> h(e3d_icp_create());
+  if (!h) throw Error(E3D_ERR_NO_DEVICE, e3d::last_error_cstr());
+  Cloud src, tgt;
+  upload_cloud(h.get(), src, sxyz, sxyz, ns);   // normals unused here
+  upload_cloud(h.get(), tgt, txyz, txyz, nt);
+  build_grid(h.get(), src, d);
+  build_grid(h.get(), tgt, d);
+  transform_cloud(h.get(), src);
+  transform_cloud(h.get(), tgt);
+  hipStream_t s = h->stream;
+  DevBuf<int> out_idx; DevBuf<float> out_d2;
+  out_idx.reserve(ns); out_d2.reserve(ns);
+  int64_t count = 0;
+  if (ns > 0) {
+    if (nt > 0) {
+      h->match_pos.reserve(ns); h->match_d2.reserve(ns);
+      launch_nn_query(src.G4.p, ns, tgt.G4.p, tgt.table.p, tgt.grid, make_invmap(tgt), radius_sq(d), h->match_pos.p, h->match_d2.p, s);
+      launch_unpermute_matches(h->match_pos.p, h->match_d2.p, ns, src.G4.p, tgt.G4.p, out_idx.p, out_d2.p, s);
+      copy_out(match_index, out_idx.p, sizeof(int) * ns, s);
+      copy_out(sq_distance, out_d2.p, sizeof(float) * ns, s);
+      const size_t nb = div_up(ns, kBlock);
+      h->block_counts.reserve(nb); h->block_offsets.reserve(nb); h->block_d2.reserve(nb);
+      h->d_total.reserve(1); h->d_total_d2.reserve(1); h->h_total.reserve(1);
+      launch_match_scan(h->match_pos.p, h->match_d2.p, ns, h->block_counts.p, h->block_offsets.p, h->block_d2.p, h->d_total.p, h->d_total_d2.p, s);
+      copy_out(h->h_total.p, h->d_total.p, sizeof(unsigned long long), s);
+      sync(h.get());
+      count = (int64_t)h->h_total.p[0];
+    } else {
+      E3D_HIP(hipMemsetAsync(out_idx.p, 0xFF, sizeof(int) * ns, s));
+      E3D_HIP(hipMemsetAsync(out_d2.p, 0, sizeof(float) * ns, s));
+      copy_out(match_index, out_idx.p, sizeof(int) * ns, s);
+      copy_out(sq_distance, out_d2.p, sizeof(float) * ns, s);
+      sync(h.get());
+    }
+  }
+  return count;
+  E3D_CATCH()
+}
+
+int e3d_transform_cloud(const float* xyz, const float* normals, size_t n, const float T[12], float* oxyz,
+                        float* onrm, float bmin[3], float bmax[3]) {
+  E3D_TRY
+  if ((!xyz && n) || !T || (!oxyz && n) || !bmin || !bmax) throw Error(E3D_ERR_INVALID, "e3d_transform_cloud: null argument");
+  std::unique_ptr<e3d_icp> h(e3d_icp_create());
+  if (!h) throw Error(E3D_ERR_NO_DEVICE, e3d::last_error_cstr());
+  hipStream_t s = h->stream;
+  DevBuf<float> ix, in, ox, on;
+  ix.reserve(3 * n); ox.reserve(3 * n);
+  copy_in(ix.p, xyz, sizeof(float) * 3 * n, s);
+  if (normals) { in.reserve(3 * n); on.reserve(3 * n); copy_in(in.p, normals, sizeof(float) * 3 * n, s); }
+  ensure_bbox_scratch(h.get());
+  launch_transform_aos(ix.p, normals ? in.p : nullptr, n, to_affine(T), ox.p, normals ? on.p : nullptr,
+                       h->bbox_partial.p, h->bbox_out.p, s);
+  copy_out(oxyz, ox.p, sizeof(float) * 3 * n, s);
+  if (normals && onrm) copy_out(onrm, on.p, sizeof(float) * 3 * n, s);
+  copy_out(h->h_bbox.p, h->bbox_out.p, sizeof(float) * 6, s);
+  sync(h.get());
+  for (int k = 0; k < 3; ++k) { bmin[k] = h->h_bbox.p[k]; bmax[k] = h->h_bbox.p[3 + k]; }
+  return 0;
+  E3D_CATCH()
+}
+
+int e3d_icp_pair_system(const float* sxyz, const float* snrm, const float* txyz, const float* tnrm,
+                        const int32_t* iq, const int32_t* im, int64_t n, const float sq[4], const float st[3],
+                        const float tq[4], const float tt[3], double H[144], double b[12], double* cost) {
+  E3D_TRY
+  if (!sxyz || !snrm || !txyz || !tnrm || (!iq && n) || (!im && n) || !sq || !st || !tq || !tt || !H || !b || !cost)
+    throw Error(E3D_ERR_INVALID, "e3d_icp_pair_system: null argument");
+  std::unique_ptr<e3d_icp> h(e3d_icp_create());
+  if (!h) throw Error(E3D_ERR_NO_DEVICE, e3d::last_error_cstr());
+  hipStream_t s = h->stream;
+  // the caller's clouds may be host or device memory of unknown size: gather on the host side of the ABI is not
+  // possible without sizes, so sizes are derived from the index lists
+  int32_t ms = -1, mt = -1;
+  std::vector<int32_t> hq((size_t)n), hm((size_t)n);
+  E3D_HIP(hipMemcpy(hq.data(), iq, sizeof(int32_t) * (size_t)n, hipMemcpyDefault));
+  E3D_HIP(hipMemcpy(hm.data(), im, sizeof(int32_t) * (size_t)n, hipMemcpyDefault));
+  for (int64_t c = 0; c < n; ++c) { ms = std::max(ms, hq[c]); mt = std::max(mt, hm[c]); }
+  const size_t ns = (size_t)(ms + 1), nt = (size_t)(mt + 1);
+  DevBuf<float> dsx, dsn, dtx, dtn; DevBuf<int> dq, dm;
+  dsx.reserve(3 * ns); dsn.reserve(3 * ns); dtx.reserve(3 * nt); dtn.reserve(3 * nt); dq.reserve(n); dm.reserve(n);
+  copy_in(dsx.p, sxyz, sizeof(float) * 3 * ns, s); copy_in(dsn.p, snrm, sizeof(float) * 3 * ns, s);
+  copy_in(dtx.p, txyz, sizeof(float) * 3 * nt, s); copy_in(dtn.p, tnrm, sizeof(float) * 3 * nt, s);
+  copy_in(dq.p, hq.data(), sizeof(int) * (size_t)n, s); copy_in(dm.p, hm.data(), sizeof(int) * (size_t)n, s);
+  h->cA.reserve(n); h->cB.reserve(n); h->cC.reserve(n);
+  launch_gather_corr(dsx.p, dsn.p, dtx.p, dtn.p, dq.p, dm.p, (size_t)n, h->cA.p, h->cB.p, h->cC.p, s);
+  LmSet S{};
+  S.off = 0; S.n = n; S.block_begin = 0; S.nblocks = lm_blocks_for(n); S.mode = kModeTwoCross; S.side = 0;
+  quat_to_matrix<float>(sq[0], sq[1], sq[2], sq[3], S.Rs);
+  quat_to_matrix<float>(tq[0], tq[1], tq[2], tq[3], S.Rt);
+  for (int k = 0; k < 3; ++k) { S.ts[k] = st[k]; S.tt[k] = tt[k]; }
+  DevBuf<LmSet> dset; dset.reserve(1);
+  DevBuf<int> dbs; dbs.reserve(S.nblocks);
+  std::vector<int> bs(S.nblocks, 0);
+  DevBuf<double> part, out; part.reserve((size_t)S.nblocks * kLmSlot); out.reserve(kLmSlot);
+  copy_in(dset.p, &S, sizeof S, s); copy_in(dbs.p, bs.data(), sizeof(int) * S.nblocks, s);
+  launch_lm_pass(kModeTwoCross, h->cA.p, h->cB.p, h->cC.p, dset.p, dbs.p, 0, S.nblocks, part.p, s);
+  launch_lm_reduce(part.p, dset.p, 1, kLmSlot, out.p, s);
+  double r[kLmSlot];
+  copy_out(r, out.p, sizeof r, s);
+  sync(h.get());
+  std::memset(H, 0, sizeof(double) * 144); std::memset(b, 0, sizeof(double) * 12);
+  *cost = r[0];
+  int k = 1;
+  for (int a = 0; a < 6; ++a) for (int c = a; c < 6; ++c) { H[12 * a + c] = r[k]; H[12 * c + a] = r[k]; ++k; }
+  for (int a = 0; a < 6; ++a) b[a] = r[22 + a];
+  k = 28;
+  for (int a = 0; a < 6; ++a) for (int c = a; c < 6; ++c) { H[12 * (6 + a) + 6 + c] = r[k]; H[12 * (6 + c) + 6 + a] = r[k]; ++k; }
+  for (int a = 0; a < 6; ++a) b[6 + a] = r[49 + a];
+  for (int a = 0; a < 6; ++a) for (int c = 0; c < 6; ++c) { H[12 * a + 6 + c] = r[55 + 6 * a + c]; H[12 * (6 + c) + a] = r[55 + 6 * a + c]; }
+  return 0;
+  E3D_CATCH()
+}
+
+}  // extern "C"

@@ -1,0 +1,60 @@
+// e3d_icp_kernels.hpp -- launch interface of the ICP kernels (see e3d_icp_kernels.hip).
+#pragma once
+
+#include "e3d_common.hpp"
+#include "e3d_kernels.hpp"
+
+namespace e3d {
+
+// LM pass modes: which Gramian blocks a directed pair (src -> tgt) contributes
+// (icp_point_to_plane_impl.h:82-113).  Variables exist for every impl cloud except cloud 0.
+enum { kModeCost = 0,      // cost only
+       kModeOne = 1,       // exactly one side has variables: 21 + 6 (+ cost)
+       kModeTwo = 2,       // both sides, off-diagonal block would land in the lower triangle => dropped [QUIRK]
+       kModeTwoCross = 3   // both sides, src block before tgt block: SS, TT, ST
+};
+constexpr int kLmSlot = 91;          // doubles per block partial / per set result
+constexpr int kMaxBboxBlocks = 2048;
+
+// One directed pair's slice of the concatenated correspondence planes, with the inner poses
+// (R = so3().matrix() in f32, row-major) of its two impl clouds.
+struct LmSet {
+  long long off, n;        // slice [off, off+n)
+  int block_begin, nblocks;
+  int mode;                // full-pass mode of this set
+  int side;                // kModeOne: 0 = source has the variables, 1 = target
+  float Rs[9], ts[3], Rt[9], tt[3];
+};
+
+int launch_transform_aos(const float* xyz, const float* nrm, size_t n, const Affine& T, float* oxyz, float* onrm,
+                         float* bbox_partial, float* bbox_out, hipStream_t s);
+int launch_transform_bbox(const float4* L4, size_t n, const Affine& T, float4* G4, float* bbox_partial,
+                          float* bbox_out, hipStream_t s);
+void launch_bbox_aos(const float* xyz, size_t n, float* bbox_partial, float* bbox_out, hipStream_t s);
+void launch_cell_keys(const float* xyz, size_t n, const GridDesc& g, unsigned long long* keys, unsigned* vals,
+                      hipStream_t s);
+void launch_permute(const float* xyz, const float* nrm, const unsigned* order, size_t n, float4* L4, float4* LN,
+                    hipStream_t s);
+void launch_count_cells(const unsigned long long* keys, size_t n, unsigned* counter, hipStream_t s);
+void launch_build_table(const unsigned long long* keys, size_t n, HashEntry* table, unsigned mask, hipStream_t s);
+void launch_nn_query(const float4* Gsrc, size_t n_src, const float4* Gtgt, const HashEntry* table, const GridDesc& g,
+                     const InvMap& im, float r2, int* match_pos, float* match_d2, hipStream_t s);
+void launch_match_scan(const int* match_pos, const float* match_d2, size_t n, unsigned* block_counts,
+                       unsigned* block_offsets, double* block_d2, unsigned long long* total, double* total_d2,
+                       hipStream_t s);
+void launch_compact_corr(const int* match_pos, size_t n, const unsigned* block_offsets, const float4* Gsrc,
+                         const float4* LNsrc, const Affine& Tsrc, const float4* Gtgt, const float4* LNtgt,
+                         const Affine& Ttgt, float4* A, float4* B, float4* C, size_t out_base, hipStream_t s);
+void launch_gather_corr(const float* sxyz, const float* snrm, const float* txyz, const float* tnrm, const int* iq,
+                        const int* im, size_t n, float4* A, float4* B, float4* C, hipStream_t s);
+void launch_unpermute_matches(const int* match_pos, const float* match_d2, size_t n, const float4* Gsrc,
+                              const float4* Gtgt, int* out_idx, float* out_d2, hipStream_t s);
+void launch_lm_pass(int mode, const float4* A, const float4* B, const float4* C, const LmSet* sets,
+                    const int* block_set, int block_base, int nblocks, double* partial, hipStream_t s);
+void launch_lm_reduce(const double* partial, const LmSet* sets, int n_sets, int nacc, double* out, hipStream_t s);
+
+// radix sort of (cell key, point index) pairs -- rocPRIM device primitive (e3d_sort.hip)
+void sort_pairs_u64_u32(unsigned long long* keys_in, unsigned long long* keys_out, unsigned* vals_in,
+                        unsigned* vals_out, size_t n, int end_bit, DevBuf<char>& temp, hipStream_t s);
+
+}  // namespace e3d

@@ -1,0 +1,22 @@
+// e3d_sort.hip -- device radix sort of (cell key, point index) pairs.  The sort itself is the
+// rocPRIM library primitive (one-off per cloud: the grid is static); everything
+// on the per-iteration hot path is hand-written.
+#include <cstring>
+#include <string.h>
+
+#include <rocprim/rocprim.hpp>
+
+#include "e3d_icp_kernels.hpp"
+
+namespace e3d {
+
+void sort_pairs_u64_u32(unsigned long long* keys_in, unsigned long long* keys_out, unsigned* vals_in,
+                        unsigned* vals_out, size_t n, int end_bit, DevBuf<char>& temp, hipStream_t s) {
+  if (n == 0) return;
+  size_t bytes = 0;
+  E3D_HIP(rocprim::radix_sort_pairs(nullptr, bytes, keys_in, keys_out, vals_in, vals_out, n, 0u, (unsigned)end_bit, s));
+  temp.reserve(bytes);
+  E3D_HIP(rocprim::radix_sort_pairs(temp.p, bytes, keys_in, keys_out, vals_in, vals_out, n, 0u, (unsigned)end_bit, s));
+}
+
+}  // namespace e3d

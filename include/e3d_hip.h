@@ -1,0 +1,150 @@
+/*
+ * include/e3d_hip.h -- C-ABI of libe3dhip.so (MI355X / gfx950 HIP implementation of the
+ * ETH3D dataset-pipeline scan-alignment hot path).
+ *
+ * The reference has no FFI: its drop-in boundary is the C++ class surface that the tool
+ * mains and gtest binaries call.  Every entry point below names the
+ * reference interface it replaces (file:line relative to the reference tree).  A thin C++
+ * shim with the reference's class and method names sits on top of this ABI
+ * (dataset-pipeline_amd/csrc/host/icp_point_to_plane.h); INTEGRATION.md shows the binding a
+ * maintainer would add to the reference.
+ *
+ * Conventions
+ *   - all functions return int status: >= 0 success (value documented per function),
+ *     E3D_ERR_* (< -1) on failure; e3d_last_error() returns a thread-local message.  Nothing
+ *     aborts the process (the reference CHECK()s / throws instead).
+ *   - point data is n x 3 float32, row-major ("xyz xyz ...").  Pointers may be host pointers
+ *     or HIP device pointers (detected with hipPointerGetAttributes); the library copies what
+ *     it needs into its own device buffers (SoA, sorted by grid cell), so callers keep
+ *     ownership and may free their buffers after the call returns.
+ *   - poses are row-major 3x4 float32 affine matrices (Eigen::Affine3f rows 0..2).
+ *   - one host thread per handle; each handle owns one HIP stream on the device that was
+ *     current when it was created.
+ */
+#ifndef E3D_HIP_H
+#define E3D_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define E3D_ABI_VERSION 1
+
+#define E3D_ERR_INVALID   (-2)   /* bad argument / bad handle state          */
+#define E3D_ERR_HIP       (-3)   /* a HIP runtime call failed                */
+#define E3D_ERR_NO_DEVICE (-4)   /* no gfx950 device visible                 */
+#define E3D_ERR_INDEX     (-5)   /* cloud index out of range (reference: .at() throws) */
+
+/* ---- library ------------------------------------------------------------------------- */
+int e3d_abi_version(void);
+/* Select the HIP device for subsequently created handles; returns the device count. */
+int e3d_init(int device);
+const char* e3d_last_error(void);
+
+/* ---- (A) icp::PointToPlaneICP  (src/icp/icp_point_to_plane.h:39-80) --------------------- */
+typedef struct e3d_icp e3d_icp_t;
+
+/* PointToPlaneICP::PointToPlaneICP()  (icp_point_to_plane.cc:107) */
+e3d_icp_t* e3d_icp_create(void);
+void e3d_icp_destroy(e3d_icp_t* icp);
+
+/* int PointToPlaneICP::AddPointCloud(cloud, global_T_cloud, fixed)
+ * (icp_point_to_plane.h:46-48, .cc:109-135).  Returns the cloud index (>= 0) for movable
+ * clouds and -1 for fixed clouds (which are transformed once and merged into one fixed
+ * cloud), exactly like the reference. */
+int e3d_icp_add_cloud(e3d_icp_t* icp, const float* xyz, const float* normals, size_t n,
+                      const float global_T_cloud[12], int fixed);
+
+/* bool PointToPlaneICP::Run(max_correspondence_distance, initial_iteration,
+ *   max_num_iterations, convergence_threshold_max_movement, print_progress)
+ * (icp_point_to_plane.h:50-54, .cc:137-163).  Returns 1 if converged, 0 if not.  With
+ * print_progress the reference's stdout lines are printed (same text; "avg. distance" is
+ * accumulated in f64 on the device instead of a sequential f32 sum). */
+int e3d_icp_run(e3d_icp_t* icp, float max_correspondence_distance, int initial_iteration,
+                int max_num_iterations, float convergence_threshold_max_movement,
+                int print_progress);
+
+/* Eigen::Affine3f PointToPlaneICP::GetResultGlobalTCloud(int)  (icp_point_to_plane.h:56,
+ * .cc:165-167). */
+int e3d_icp_get_pose(e3d_icp_t* icp, int cloud_index, float global_T_cloud[12]);
+
+/* Inner LM iteration cap of PointToPlaneICPImpl (reference constant 150,
+ * icp_point_to_plane.cc:312); exposed for bounded benchmarks, default 150. */
+int e3d_icp_set_max_inner_iterations(e3d_icp_t* icp, int n);
+
+/* Per-pair correspondence report of every AlignMeshes call since creation -- the numbers the
+ * reference only prints (icp_point_to_plane.cc:226-237).  src/tgt are the impl cloud indices
+ * the reference prints; -1 stands for "fixed clouds". */
+typedef struct {
+  int32_t iteration;
+  int32_t src, tgt;
+  int64_t count;
+  double  distance_sum;      /* sum of squared NN distances (f64 accumulation) */
+} e3d_icp_pair_record;
+
+typedef struct {
+  int32_t iteration;
+  int32_t inner_iterations;  /* LM iterations executed (<= 150)                            */
+  int32_t full_passes;       /* fused H/b/cost passes over all correspondences             */
+  int32_t cost_passes;       /* cost-only passes                                           */
+  int64_t correspondences;   /* total over all directed pairs of this rank                 */
+  int64_t queries;           /* NN queries issued by this rank                             */
+  double  initial_cost, final_cost;
+  double  t_transform_ms, t_nn_ms, t_lm_ms;   /* HIP-event times on the handle's stream   */
+  double  t_lm_kernel_ms;    /* sum of LM pass kernel durations (HIP events)               */
+} e3d_icp_iter_record;
+
+size_t e3d_icp_num_pair_records(const e3d_icp_t* icp);
+const e3d_icp_pair_record* e3d_icp_pair_records(const e3d_icp_t* icp);
+size_t e3d_icp_num_iter_records(const e3d_icp_t* icp);
+const e3d_icp_iter_record* e3d_icp_iter_records(const e3d_icp_t* icp);
+void e3d_icp_clear_records(e3d_icp_t* icp);
+
+/* Multi-GPU (one process per GPU): directed cloud pairs are dealt round-robin to
+ * `world_size` ranks; every rank holds all clouds.  `allreduce` must sum `count` doubles in
+ * place across ranks (RCCL/gloo through the host language; buffer is HOST memory) and leave
+ * the identical result on every rank.  The reference has no equivalent (single process). */
+typedef int (*e3d_allreduce_fn)(double* buffer, size_t count, void* user);
+int e3d_icp_set_shard(e3d_icp_t* icp, int rank, int world_size,
+                      e3d_allreduce_fn allreduce, void* user);
+
+/* ---- stand-alone kernels behind the same arithmetic (parity tests, other callers) ------ */
+
+/* FindCorrespondencesFast(source, target, max_correspondence_distance)
+ * (icp_point_to_plane.cc:42-105): for every source point the exact nearest target point with
+ * squared distance < (float)(d*d), lowest target index on ties.  match_index[i] = target index
+ * or -1; sq_distance[i] valid where matched.  Returns the number of correspondences. */
+int64_t e3d_find_correspondences(const float* source_xyz, size_t n_source,
+                                 const float* target_xyz, size_t n_target,
+                                 float max_correspondence_distance,
+                                 int32_t* match_index, float* sq_distance);
+
+/* pcl::transformPointCloudWithNormals + AlignedBox extend (icp_point_to_plane.cc:189-205). */
+int e3d_transform_cloud(const float* xyz, const float* normals, size_t n, const float T[12],
+                        float* out_xyz, float* out_normals, float bbox_min[3], float bbox_max[3]);
+
+/* One accumulate pass of PointToPlaneICPImpl::compute (icp_point_to_plane_impl.h:119-211) for
+ * one directed pair at inner poses {q = w,x,y,z ; t}.  Outputs the 12x12 pair system over
+ * [source(6), target(6)] (row-major, upper triangle filled, lower mirrored), b(12), cost. */
+int e3d_icp_pair_system(const float* src_xyz, const float* src_normals,
+                        const float* tgt_xyz, const float* tgt_normals,
+                        const int32_t* index_query, const int32_t* index_match, int64_t n_corr,
+                        const float src_q[4], const float src_t[3],
+                        const float tgt_q[4], const float tgt_t[3],
+                        double H[144], double b[12], double* cost);
+
+/* ---- (A') pcl::NormalEstimationTwoPassOMP (src/geometry/two_pass_normal_3d_omp.h:53-99) - */
+/* setInputCloud + setKSearch(k) + setViewPoint + compute  (call sites
+ * src/exe/icp_scan_aligner.cc:323-330, src/exe/normal_estimator.cc:177-194).
+ * out_normals n x 3, out_curvature n.  knn_indices (optional, n*k int32) receives each point's
+ * neighbour list sorted by (squared distance, index). */
+int e3d_normals_knn(const float* xyz, size_t n, int k, const float viewpoint[3],
+                    float* out_normals, float* out_curvature, int32_t* knn_indices);
+
+#ifdef __cplusplus
+}
+#endif
+#endif  /* E3D_HIP_H */

@@ -1,0 +1,200 @@
+"""GPU parity tests of the ICP path: HIP library (through the C-ABI) vs the CPU oracle on identical inputs.
+
+Bars (BASELINE.json north_star): identical correspondence counts / indices (bit-exact integer work, bit-exact f32
+squared distances), final poses within 1e-5 rad / 1e-4 m.
+"""
+import numpy as np
+import pytest
+
+from conftest import identical_cloud_case, plane_case, pose_error
+
+pytestmark = pytest.mark.gpu
+
+ROT_TOL = 1e-5   # rad   (north_star)
+TRANS_TOL = 1e-4  # m    (north_star)
+
+
+def _rand_T(rng, scale=1.0):
+    ax = rng.normal(size=3); ax /= np.linalg.norm(ax)
+    ang = rng.uniform(-0.5, 0.5)
+    K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+    R = np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * (K @ K)
+    T = np.eye(4, dtype=np.float32)
+    T[:3, :3] = (scale * R).astype(np.float32)
+    T[:3, 3] = rng.uniform(-3, 3, 3).astype(np.float32)
+    return T
+
+
+# ---- a3: transform + bbox ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [0, 1, 63, 64, 1000, 100003])
+def test_transform_bit_exact(e3d, ob, n):
+    rng = np.random.RandomState(n + 1)
+    xyz = rng.uniform(-20, 20, (n, 3)).astype(np.float32)
+    nrm = rng.normal(size=(n, 3)).astype(np.float32)
+    T = _rand_T(rng)
+    gx, gn, gmin, gmax = e3d.transform_cloud(xyz, nrm, T)
+    ox, on, omin, omax = ob.transform_cloud(xyz, nrm, T)
+    assert np.array_equal(gx.view(np.uint32), ox.view(np.uint32))
+    assert np.array_equal(gn.view(np.uint32), on.view(np.uint32))
+    assert np.array_equal(gmin, omin) and np.array_equal(gmax, omax)
+
+
+# ---- a5: FindCorrespondencesFast --------------------------------------------------------------------------------
+def _check_nn(e3d, ob, src, tgt, d):
+    idx, d2, count = e3d.find_correspondences(src, tgt, d)
+    iq, im, sd = ob.find_correspondences(src, tgt, d)
+    ref = np.full(src.shape[0], -1, np.int32)
+    ref[iq] = im
+    refd = np.zeros(src.shape[0], np.float32)
+    refd[iq] = sd
+    assert count == len(iq)
+    assert np.array_equal(idx, ref)
+    assert np.array_equal(d2.view(np.uint32)[ref >= 0], refd.view(np.uint32)[ref >= 0])
+    return count
+
+
+@pytest.mark.parametrize("ns,nt,d", [(1000, 1000, 0.1), (5000, 300, 0.3), (300, 5000, 0.05), (1, 1, 10.0),
+                                     (20000, 20000, 0.02), (777, 1234, 1e-3)])
+def test_nn_random(e3d, ob, ns, nt, d):
+    rng = np.random.RandomState(ns * 7 + nt)
+    src = rng.uniform(-1, 1, (ns, 3)).astype(np.float32)
+    tgt = rng.uniform(-1, 1, (nt, 3)).astype(np.float32)
+    _check_nn(e3d, ob, src, tgt, d)
+
+
+def test_nn_empty_and_ragged(e3d, ob):
+    rng = np.random.RandomState(5)
+    a = rng.uniform(-1, 1, (100, 3)).astype(np.float32)
+    e = np.zeros((0, 3), np.float32)
+    idx, d2, c = e3d.find_correspondences(a, e, 0.5)
+    assert c == 0 and np.all(idx == -1)
+    idx, d2, c = e3d.find_correspondences(e, a, 0.5)
+    assert c == 0 and idx.shape[0] == 0
+
+
+def test_nn_lattice_ties_lowest_index(e3d, ob):
+    """Equidistant neighbours on an integer lattice (PlaneCase geometry): lowest target index wins, radius strict."""
+    xs, ys = np.meshgrid(np.arange(40), np.arange(40), indexing="ij")
+    tgt = np.stack([xs.ravel(), ys.ravel(), np.zeros(1600)], 1).astype(np.float32)
+    src = tgt + np.array([0.5, 0.5, 0.0], np.float32)     # 4 equidistant neighbours each
+    _check_nn(e3d, ob, src, tgt, 1.5)
+    # radius exactly equal to the neighbour distance: strict '<' => no correspondences at all
+    src2 = tgt + np.array([1.0, 0.0, 0.0], np.float32)
+    idx, d2, c = e3d.find_correspondences(src2[:1], tgt[:1], 1.0)
+    assert c == 0
+    _check_nn(e3d, ob, src2, tgt, 1.0)
+    # duplicates in the target
+    tgt3 = np.vstack([tgt, tgt[::3]])
+    _check_nn(e3d, ob, src, tgt3, 1.5)
+
+
+def test_nn_far_offset_and_duplicates(e3d, ob):
+    """Large coordinates (f32 ulp ~ 1e-5) with a radius of a few ulps; boundary decisions must match exactly."""
+    rng = np.random.RandomState(11)
+    base = np.array([131.0, -77.0, 45.0], np.float32)
+    tgt = (base + rng.uniform(-0.05, 0.05, (30000, 3))).astype(np.float32)
+    src = (tgt[rng.randint(0, 30000, 20000)] + rng.uniform(-2e-4, 2e-4, (20000, 3))).astype(np.float32)
+    for d in (1e-4, 2.5e-4, 1e-3):
+        _check_nn(e3d, ob, src, tgt, d)
+
+
+def test_nn_self_match_property(e3d):
+    """Size-independent property at a larger size: a cloud matched against itself finds every point at distance 0."""
+    rng = np.random.RandomState(3)
+    a = rng.uniform(-5, 5, (2_000_000, 3)).astype(np.float32)
+    idx, d2, c = e3d.find_correspondences(a, a, 0.01)
+    assert c == a.shape[0]
+    assert np.all(d2 == 0)
+    # ties at distance 0 only for exact duplicates -> lowest index
+    assert np.all(idx <= np.arange(a.shape[0]))
+    assert np.array_equal(a[idx], a)
+
+
+# ---- a7: accumulate pass ----------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [1, 100, 70001])
+def test_pair_system(e3d, ob, n):
+    rng = np.random.RandomState(n)
+    S = rng.uniform(-2, 2, (500, 3)).astype(np.float32); Sn = rng.normal(size=(500, 3)).astype(np.float32)
+    Tt = rng.uniform(-2, 2, (400, 3)).astype(np.float32); Tn = rng.normal(size=(400, 3)).astype(np.float32)
+    iq = rng.randint(0, 500, n).astype(np.int32); im = rng.randint(0, 400, n).astype(np.int32)
+    iq[0] = 499; im[0] = 399
+    q = rng.normal(size=4).astype(np.float32); q /= np.linalg.norm(q)
+    q2 = rng.normal(size=4).astype(np.float32); q2 /= np.linalg.norm(q2)
+    st = rng.normal(size=3).astype(np.float32); tt = rng.normal(size=3).astype(np.float32)
+    Hg, bg, cg = e3d.icp_pair_system(S, Sn, Tt, Tn, iq, im, q, st, q2, tt)
+    Ho, bo, co = ob.pair_system(S, Sn, Tt, Tn, iq, im, q, st, q2, tt)
+    scale = np.abs(Ho).max()
+    assert np.abs(Hg - Ho).max() <= 1e-12 * scale
+    assert np.abs(bg - bo).max() <= 1e-12 * np.abs(bo).max()
+    assert abs(cg - co) <= 1e-12 * co
+
+
+# ---- end to end -------------------------------------------------------------------------------------------------
+def _run_both(e3d, ob, clouds, d, iters, thr=1e-7):
+    g = e3d.PointToPlaneICP(); o = ob.OracleICP()
+    gi, oi = [], []
+    for (xyz, nrm, T, fixed) in clouds:
+        gi.append(g.add_point_cloud(xyz, nrm, T, fixed)); oi.append(o.add_point_cloud(xyz, nrm, T, fixed))
+    assert gi == oi
+    cg = g.run(d, 0, iters, thr, False); co = o.run(d, 0, iters, thr, False)
+    return g, o, gi, cg, co
+
+
+def _compare(g, o, ids, cg, co, exact_iters=None):
+    assert cg == co
+    pg = [(r[0], r[1], r[2], r[3]) for r in g.pair_records()]
+    po = [(r[0], r[1], r[2], r[3]) for r in o.pair_records()]
+    assert pg == po, "per-pair correspondence counts differ"
+    for i in ids:
+        if i < 0:
+            continue
+        ang, tr = pose_error(g.get_result_global_T_cloud(i), o.get_result_global_T_cloud(i))
+        assert ang <= ROT_TOL and tr <= TRANS_TOL, (i, ang, tr)
+
+
+def test_icp_plane_case(e3d, ob):
+    xyz, nrm, T0, T1 = plane_case()
+    g, o, ids, cg, co = _run_both(e3d, ob, [(xyz, nrm, T0, False), (xyz, nrm, T1, False)], 1.5, 100)
+    _compare(g, o, ids, cg, co)
+    A, B = g.get_result_global_T_cloud(0), g.get_result_global_T_cloud(1)
+    assert np.abs(A - B).max() <= 1e-5          # the reference test's own assertion (test_icp.cc:159-171)
+
+
+def test_icp_identical_clouds(e3d, ob):
+    P, N, Ts = identical_cloud_case()
+    clouds = [(P, N, T, False) for T in Ts]
+    g, o, ids, cg, co = _run_both(e3d, ob, clouds, np.float32(0.15) * np.sqrt(3), 100)
+    _compare(g, o, ids, cg, co)
+    T0 = g.get_result_global_T_cloud(0)
+    for i in ids[1:]:
+        assert np.abs(g.get_result_global_T_cloud(i) - T0).max() <= 1e-5   # test_icp.cc:98-108
+
+
+def test_icp_with_fixed_clouds(e3d, ob, synth):
+    scans = synth.make_scene(4, 20000, seed=7)
+    clouds = []
+    for i, s in enumerate(scans):
+        clouds.append((s["xyz"].numpy(), s["normals"].numpy(), s["T_init"], i in (0, 2)))
+    g, o, ids, cg, co = _run_both(e3d, ob, clouds, 0.15, 6, thr=1e-9)
+    assert ids == [-1, 0, -1, 1]
+    _compare(g, o, ids, cg, co)
+
+
+def test_icp_c1_config(e3d, ob, synth):
+    """BASELINE.json configs[0]: 2 scans x 100k points, d = 0.05."""
+    scans = synth.make_scene(2, 100_000, seed=1234)
+    clouds = [(s["xyz"].numpy(), s["normals"].numpy(), s["T_init"], False) for s in scans]
+    g, o, ids, cg, co = _run_both(e3d, ob, clouds, 0.05, 8, thr=1e-9)
+    _compare(g, o, ids, cg, co)
+    # the alignment actually improves: scan 1 ends close to its true pose relative to scan 0
+    ang0, tr0 = pose_error(scans[1]["T_init"], scans[1]["T_true"])
+    ang1, tr1 = pose_error(g.get_result_global_T_cloud(1), scans[1]["T_true"])
+    assert tr1 < 0.3 * tr0 and ang1 < 0.3 * ang0
+
+
+def test_icp_errors(e3d):
+    g = e3d.PointToPlaneICP()
+    with pytest.raises(e3d.E3DError):
+        g.run(0.1, 0, 1, 1e-6)          # reference: CHECK(!clouds_.empty())
+    with pytest.raises(IndexError):
+        g.get_result_global_T_cloud(0)  # reference: clouds_.at() throws

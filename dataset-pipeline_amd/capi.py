@@ -31,7 +31,7 @@ class IterRecord(C.Structure):
                 ("cost_passes", C.c_int32), ("correspondences", C.c_int64), ("queries", C.c_int64),
                 ("initial_cost", C.c_double), ("final_cost", C.c_double),
                 ("t_transform_ms", C.c_double), ("t_nn_ms", C.c_double), ("t_lm_ms", C.c_double),
-                ("t_lm_kernel_ms", C.c_double)]
+                ("t_lm_kernel_ms", C.c_double), ("t_nn_query_ms", C.c_double)]
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_size_t, C.c_void_p)
@@ -41,6 +41,7 @@ SIGNATURES = {
     "e3d_abi_version": (C.c_int, []),
     "e3d_init": (C.c_int, [C.c_int]),
     "e3d_last_error": (C.c_char_p, []),
+    "e3d_set_nn_mode": (C.c_int, [C.c_int]),
     "e3d_icp_create": (C.c_void_p, []),
     "e3d_icp_destroy": (None, [C.c_void_p]),
     "e3d_icp_add_cloud": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]),

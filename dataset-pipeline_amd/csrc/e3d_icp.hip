@@ -29,6 +29,7 @@ void set_last_error(const std::string& msg) { g_last_error = msg; }
 const char* last_error_cstr() { return g_last_error.c_str(); }
 
 static int g_device = 0;
+static int g_nn_mode = 0;   // E3D_NN_MODE / e3d_set_nn_mode: 0 auto, 1 per-query kernel, 2 LDS-bucket kernel
 
 // -------------------------------------------------------------------------------------------------
 struct Cloud {
@@ -42,7 +43,12 @@ struct Cloud {
   float grid_T[12];                 // pose the grid's slack was sized for (only its linear part matters)
   DevBuf<float4> L4, LN, G4;
   DevBuf<HashEntry> table;
+  DevBuf<unsigned> dense_start;     // dense cell-start directory over qrange (empty if the grid is too large)
+  bool has_dense = false;
   GridDesc grid{};
+  QueryRange qrange{};              // target-cell range a query needs to hit to have candidates
+  unsigned n_cells = 0;             // occupied cells
+  int key_bits = 0;                 // bits of the dense query keys
   float lmin[3], lmax[3];           // local bbox
   float bmin[3], bmax[3];           // global bbox of the current outer iteration
   int cloud_index = -1;             // impl index in the current AlignMeshes
@@ -67,6 +73,8 @@ struct e3d_icp {
   std::vector<std::unique_ptr<Cloud>> clouds;   // movable clouds
   std::unique_ptr<Cloud> fixed;                 // merged fixed cloud (global frame)
   int max_inner = 150;
+  int nn_mode = 0;                              // 0 auto, 1 force per-query kernel, 2 force LDS-bucket kernel
+  size_t dense_cell_budget = (size_t)1 << 31;   // max cells of a dense directory (8 GB); hash table beyond
   int rank = 0, world = 1;
   e3d_allreduce_fn allreduce = nullptr;
   void* allreduce_user = nullptr;
@@ -80,8 +88,8 @@ struct e3d_icp {
   DevBuf<int> match_pos;
   DevBuf<float> match_d2;
   DevBuf<unsigned> block_counts, block_offsets;
-  DevBuf<double> block_d2;
-  DevBuf<unsigned long long> d_total;
+  DevBuf<double> block_d2, chunk_d2;
+  DevBuf<unsigned long long> d_total, chunk_sum;
   DevBuf<double> d_total_d2;
   PinBuf<unsigned long long> h_total;
   PinBuf<double> h_total_d2;
@@ -92,7 +100,7 @@ struct e3d_icp {
   DevBuf<int> d_block_set;
   DevBuf<double> d_partial, d_setsum;
   PinBuf<double> h_setsum;
-  std::unique_ptr<EventTimer> lm_timer;
+  std::unique_ptr<EventTimer> lm_timer, nn_timer;
 
   std::vector<e3d_icp_pair_record> pair_records;
   std::vector<e3d_icp_iter_record> iter_records;
@@ -193,6 +201,32 @@ static void build_grid(e3d_icp* h, Cloud& c, float d) {
   E3D_HIP(hipMemsetAsync(c.table.p, 0xFF, sizeof(HashEntry) * tsize, s));
   if (n > 0) launch_build_table(h->keys_b.p, n, c.table.p, c.grid.mask, s);
   sync(h);
+  // dense query-key range: cells of the stored points +- 2 (one for the 27-neighbourhood, one for host/device
+  // rounding of the bbox corners)
+  double prod = 1.0;
+  for (int k = 0; k < 3; ++k) {
+    const int cmin = (int)std::floor(((float)c.lmin[k] - c.grid.origin[k]) * c.grid.inv_cell);
+    const int cmax = (int)std::floor(((float)c.lmax[k] - c.grid.origin[k]) * c.grid.inv_cell);
+    c.qrange.lo[k] = cmin - 2;
+    c.qrange.D[k] = (unsigned)(cmax - cmin + 5);
+    prod *= (double)c.qrange.D[k];
+  }
+  c.key_bits = 1;
+  while (c.key_bits < 63 && std::ldexp(1.0, c.key_bits) <= prod + 1.0) ++c.key_bits;
+  c.n_cells = n_cells;
+  // dense cell-start directory (4 B per cell of the bounding grid) when it fits the budget: replaces 27 random
+  // hash probes per cell group by one coalesced lookup.  288 GB of HBM make this the default; huge sparse grids
+  // keep the hash table.
+  c.has_dense = false;
+  if (n > 0 && prod + 2.0 <= (double)h->dense_cell_budget) {
+    const size_t ncell = (size_t)prod;
+    c.dense_start.reserve(ncell + 2);
+    E3D_HIP(hipMemsetAsync(c.dense_start.p, 0, sizeof(unsigned) * (ncell + 2), s));
+    launch_dense_counts(h->keys_b.p, n, c.qrange, c.dense_start.p, s);
+    exclusive_max_scan_u32(c.dense_start.p, ncell + 2, h->sort_temp, s);
+    sync(h);
+    c.has_dense = true;
+  }
   c.grid_valid = true;
   c.grid_radius = d;
   std::memcpy(c.grid_T, c.T, sizeof c.grid_T);
@@ -243,22 +277,45 @@ static inline float radius_sq(float d) {
 }
 
 // NN search + compaction for one directed pair; appends to the correspondence planes.
-static void find_pair(e3d_icp* h, Cloud& src, Cloud& tgt, float d, PairJob& job) {
+// Multi-GPU: every rank holds all clouds and handles the slice [j0, j1) of the source cloud (cell order).
+static void find_pair(e3d_icp* h, Cloud& src, Cloud& tgt, float d, PairJob& job, size_t j0, size_t j1,
+                      e3d_icp_iter_record& rec) {
   hipStream_t s = h->stream;
-  const size_t n = src.n;
+  const size_t n = j1 - j0;
   job.count = 0; job.dsum = 0.0; job.corr_off = h->corr_used;
   if (n == 0 || tgt.n == 0) return;
+  const float4* srcG = src.G4.p + j0;
+  const float4* srcLN = src.LN.p + j0;
   h->match_pos.reserve(n); h->match_d2.reserve(n);
   const size_t nb = div_up(n, kBlock);
   h->block_counts.reserve(nb); h->block_offsets.reserve(nb); h->block_d2.reserve(nb);
   h->d_total.reserve(1); h->d_total_d2.reserve(1); h->h_total.reserve(1); h->h_total_d2.reserve(1);
-  launch_nn_query(src.G4.p, n, tgt.G4.p, tgt.table.p, tgt.grid, make_invmap(tgt), radius_sq(d), h->match_pos.p,
-                  h->match_d2.p, s);
+  if (!h->nn_timer) h->nn_timer.reset(new EventTimer());
+  // dense data (many points per cell): sort the queries by target cell and use the LDS-bucket kernel;
+  // sparse data: one thread per query.  Both are exact and return identical results.
+  const bool dense = h->nn_mode == 2 || (h->nn_mode == 0 && (double)tgt.n >= 4.0 * (double)std::max(tgt.n_cells, 1u));
+  const unsigned* order = nullptr;
+  h->nn_timer->start(s);
+  if (dense) {
+    h->keys_a.reserve(n); h->keys_b.reserve(n); h->vals_a.reserve(n); h->vals_b.reserve(n);
+    const InvMap im = make_invmap(tgt);
+    launch_query_keys(srcG, n, tgt.grid, im, tgt.qrange, h->keys_a.p, h->vals_a.p, s);
+    sort_pairs_u64_u32(h->keys_a.p, h->keys_b.p, h->vals_a.p, h->vals_b.p, n, tgt.key_bits, h->sort_temp, s);
+    launch_nn_cells(srcG, h->vals_b.p, n, tgt.G4.p, tgt.table.p, tgt.has_dense ? tgt.dense_start.p : nullptr, tgt.grid, im,
+                    tgt.qrange, radius_sq(d), h->match_pos.p, h->match_d2.p, s);
+    order = h->vals_b.p;
+  } else {
+    launch_nn_query(srcG, n, tgt.G4.p, tgt.table.p, tgt.grid, make_invmap(tgt), radius_sq(d), h->match_pos.p,
+                    h->match_d2.p, s);
+  }
+  h->nn_timer->stop(s);
+  h->chunk_sum.reserve(div_up(nb, 256) + 1); h->chunk_d2.reserve(div_up(nb, 256) + 1);
   launch_match_scan(h->match_pos.p, h->match_d2.p, n, h->block_counts.p, h->block_offsets.p, h->block_d2.p,
-                    h->d_total.p, h->d_total_d2.p, s);
+                    h->chunk_sum.p, h->chunk_d2.p, h->d_total.p, h->d_total_d2.p, s);
   copy_out(h->h_total.p, h->d_total.p, sizeof(unsigned long long), s);
   copy_out(h->h_total_d2.p, h->d_total_d2.p, sizeof(double), s);
   sync(h);
+  rec.t_nn_query_ms += h->nn_timer->ms();
   job.count = (long long)h->h_total.p[0];
   job.dsum = h->h_total_d2.p[0];
   if (job.count == 0) return;
@@ -269,7 +326,7 @@ static void find_pair(e3d_icp* h, Cloud& src, Cloud& tgt, float d, PairJob& job)
     h->cB.grow_keep(ncap, h->corr_used, s);
     h->cC.grow_keep(ncap, h->corr_used, s);
   }
-  launch_compact_corr(h->match_pos.p, n, h->block_offsets.p, src.G4.p, src.LN.p,
+  launch_compact_corr(h->match_pos.p, order, n, h->block_offsets.p, srcG, srcLN,
                       to_affine(src.T), tgt.G4.p, tgt.LN.p, to_affine(tgt.T), h->cA.p, h->cB.p, h->cC.p,
                       h->corr_used, s);   // the merged fixed cloud keeps T = identity (exact)
   h->corr_used = need;
@@ -279,7 +336,7 @@ static void find_pair(e3d_icp* h, Cloud& src, Cloud& tgt, float d, PairJob& job)
 static int lm_blocks_for(long long n) {
   long long b = (n + (long long)kBlock * 8 - 1) / ((long long)kBlock * 8);
   if (b < 1) b = 1;
-  if (b > 2048) b = 2048;
+  if (b > 1024) b = 1024;   // 4 blocks per CU; the rest is grid-stride
   return (int)b;
 }
 
@@ -379,7 +436,7 @@ static void lm_prepare(e3d_icp* h, LmSystem& L, std::vector<PairJob>& jobs) {
   L.mode_begin.assign(5, 0); L.mode_blocks.assign(5, 0); L.mode_block_base.assign(5, 0);
   std::vector<std::vector<PairJob*>> by_mode(4);
   for (PairJob& j : jobs) {
-    if (!j.mine || j.count == 0) continue;
+    if (j.count == 0) continue;
     const int si = j.impl_src - 1, ti = j.impl_tgt - 1;
     int mode;
     if (si < 0 || ti < 0) mode = kModeOne;
@@ -501,35 +558,49 @@ static bool align_meshes(e3d_icp* h, float max_d, float thr, bool print, int ite
   }
   t_nn.start(s);
   h->corr_used = 0;
+  {
+    // correspondences <= queries: size the planes once (no hipMalloc/hipFree inside the iteration loop)
+    size_t qtot = 0;
+    for (const PairJob& j : jobs) {
+      const Cloud& src = (j.src == M) ? *h->fixed : *h->clouds[j.src];
+      qtot += (size_t)((unsigned __int128)src.n * (unsigned)(h->rank + 1) / (unsigned)h->world) -
+              (size_t)((unsigned __int128)src.n * (unsigned)h->rank / (unsigned)h->world);
+    }
+    if (qtot > h->cA.cap) { h->cA.reserve(qtot); h->cB.reserve(qtot); h->cC.reserve(qtot); }
+  }
   for (size_t p = 0; p < jobs.size(); ++p) {
     PairJob& j = jobs[p];
-    j.mine = ((int)(p % (size_t)h->world) == h->rank);
-    if (!j.mine) continue;
     Cloud& src = (j.src == M) ? *h->fixed : *h->clouds[j.src];
     Cloud& tgt = (j.tgt == M) ? *h->fixed : *h->clouds[j.tgt];
-    find_pair(h, src, tgt, max_d, j);
-    rec.queries += (long long)src.n;
+    // this rank's slice of the source cloud (cell order); world == 1 => the whole cloud
+    const size_t j0 = (size_t)((unsigned __int128)src.n * (unsigned)h->rank / (unsigned)h->world);
+    const size_t j1 = (size_t)((unsigned __int128)src.n * (unsigned)(h->rank + 1) / (unsigned)h->world);
+    find_pair(h, src, tgt, max_d, j, j0, j1, rec);
+    rec.queries += (long long)(j1 - j0);
+    rec.correspondences += j.count;
   }
   t_nn.stop(s);
+  // global per-pair counts (what the reference prints); local counts stay in j.count for the LM sets
+  std::vector<long long> gcount(jobs.size());
+  std::vector<double> gdsum(jobs.size());
+  for (size_t p = 0; p < jobs.size(); ++p) { gcount[p] = jobs[p].count; gdsum[p] = jobs[p].dsum; }
   if (h->world > 1 && !jobs.empty()) {
     std::vector<double> buf(2 * jobs.size(), 0.0);
-    for (size_t p = 0; p < jobs.size(); ++p)
-      if (jobs[p].mine) { buf[2 * p] = (double)jobs[p].count; buf[2 * p + 1] = jobs[p].dsum; }
+    for (size_t p = 0; p < jobs.size(); ++p) { buf[2 * p] = (double)jobs[p].count; buf[2 * p + 1] = jobs[p].dsum; }
     if (h->allreduce(buf.data(), buf.size(), h->allreduce_user) != 0) throw Error(E3D_ERR_INVALID, "allreduce callback failed");
-    for (size_t p = 0; p < jobs.size(); ++p)
-      if (!jobs[p].mine) { jobs[p].count = (long long)buf[2 * p]; jobs[p].dsum = buf[2 * p + 1]; }
+    for (size_t p = 0; p < jobs.size(); ++p) { gcount[p] = (long long)buf[2 * p]; gdsum[p] = buf[2 * p + 1]; }
   }
-  for (const PairJob& j : jobs) {
+  for (size_t p = 0; p < jobs.size(); ++p) {
+    const PairJob& j = jobs[p];
     const int psrc = (j.impl_src == fixed_vertex) ? -1 : j.impl_src;
     const int ptgt = (j.impl_tgt == fixed_vertex) ? -1 : j.impl_tgt;
-    h->pair_records.push_back({iteration, psrc, ptgt, (int64_t)j.count, j.dsum});
-    if (j.mine) rec.correspondences += j.count;
-    if (print) {
+    h->pair_records.push_back({iteration, psrc, ptgt, (int64_t)gcount[p], gdsum[p]});
+    if (print && h->rank == 0) {
       char avg[64] = "";
-      if (j.count > 0) snprintf(avg, sizeof avg, " (avg. distance: %g)", (double)(float)(j.dsum / (double)j.count));
-      if (psrc >= 0 && ptgt >= 0) printf("  found correspondences from %d to %d: %lld%s\n", j.impl_src, j.impl_tgt, j.count, avg);
-      else if (ptgt < 0) printf("  found correspondences from %d to fixed clouds: %lld%s\n", j.impl_src, j.count, avg);
-      else printf("  found correspondences from fixed clouds to %d: %lld%s\n", j.impl_tgt, j.count, avg);
+      if (gcount[p] > 0) snprintf(avg, sizeof avg, " (avg. distance: %g)", (double)(float)(gdsum[p] / (double)gcount[p]));
+      if (psrc >= 0 && ptgt >= 0) printf("  found correspondences from %d to %d: %lld%s\n", j.impl_src, j.impl_tgt, gcount[p], avg);
+      else if (ptgt < 0) printf("  found correspondences from %d to fixed clouds: %lld%s\n", j.impl_src, gcount[p], avg);
+      else printf("  found correspondences from fixed clouds to %d: %lld%s\n", j.impl_tgt, gcount[p], avg);
     }
   }
 
@@ -559,7 +630,7 @@ static bool align_meshes(e3d_icp* h, float max_d, float thr, bool print, int ite
     const float dx = c.T[3] - Tn[3], dy = c.T[7] - Tn[7], dz = c.T[11] - Tn[11];
     const float movement = std::sqrt(dx * dx + (dy * dy + dz * dz));
     if (movement > thr) converged = false;
-    if (print) printf("  %d moved by %g\n", c.cloud_index, (double)movement);
+    if (print && h->rank == 0) printf("  %d moved by %g\n", c.cloud_index, (double)movement);
     std::memcpy(c.T, Tn, sizeof Tn);
   }
   rec.t_transform_ms = t_tr.ms();
@@ -596,6 +667,12 @@ int e3d_init(int device) {
   E3D_CATCH()
 }
 
+int e3d_set_nn_mode(int mode) {
+  if (mode < 0 || mode > 2) { e3d::set_last_error("e3d_set_nn_mode: mode must be 0, 1 or 2"); return E3D_ERR_INVALID; }
+  g_nn_mode = mode;
+  return 0;
+}
+
 e3d_icp_t* e3d_icp_create(void) {
   try {
     int n = 0;
@@ -603,6 +680,7 @@ e3d_icp_t* e3d_icp_create(void) {
     E3D_HIP(hipSetDevice(g_device));
     std::unique_ptr<e3d_icp> h(new e3d_icp());
     h->device = g_device;
+    h->nn_mode = g_nn_mode;
     E3D_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     return h.release();
   } catch (const std::exception& e) {
@@ -653,10 +731,10 @@ int e3d_icp_run(e3d_icp_t* h, float max_d, int initial_iteration, int max_num_it
   if (h->clouds.empty()) throw Error(E3D_ERR_INVALID, "e3d_icp_run: no clouds to optimize (reference: CHECK(!clouds_.empty()))");
   E3D_HIP(hipSetDevice(h->device));
   for (int i = initial_iteration; i < initial_iteration + max_num_iterations; ++i) {
-    if (print) printf("-- Alignment iteration %d --\n", i);
+    if (print && h->rank == 0) printf("-- Alignment iteration %d --\n", i);
     const bool converged = align_meshes(h, max_d, thr, print != 0, i);
     if (converged) {
-      if (print) { printf("Convergence is assumed as the maximum movement is less than the threshold.\n"); fflush(stdout); }
+      if (print && h->rank == 0) { printf("Convergence is assumed as the maximum movement is less than the threshold.\n"); fflush(stdout); }
       return 1;
     }
   }
@@ -716,14 +794,27 @@ int64_t e3d_find_correspondences(const float* sxyz, size_t ns, const float* txyz
   if (ns > 0) {
     if (nt > 0) {
       h->match_pos.reserve(ns); h->match_d2.reserve(ns);
-      launch_nn_query(src.G4.p, ns, tgt.G4.p, tgt.table.p, tgt.grid, make_invmap(tgt), radius_sq(d), h->match_pos.p, h->match_d2.p, s);
-      launch_unpermute_matches(h->match_pos.p, h->match_d2.p, ns, src.G4.p, tgt.G4.p, out_idx.p, out_d2.p, s);
+      const int mode = g_nn_mode;
+      const bool dense = mode == 2 || (mode == 0 && (double)tgt.n >= 4.0 * (double)std::max(tgt.n_cells, 1u));
+      const unsigned* order = nullptr;
+      if (dense) {
+        h->keys_a.reserve(ns); h->keys_b.reserve(ns); h->vals_a.reserve(ns); h->vals_b.reserve(ns);
+        const InvMap im = make_invmap(tgt);
+        launch_query_keys(src.G4.p, ns, tgt.grid, im, tgt.qrange, h->keys_a.p, h->vals_a.p, s);
+        sort_pairs_u64_u32(h->keys_a.p, h->keys_b.p, h->vals_a.p, h->vals_b.p, ns, tgt.key_bits, h->sort_temp, s);
+        launch_nn_cells(src.G4.p, h->vals_b.p, ns, tgt.G4.p, tgt.table.p, tgt.has_dense ? tgt.dense_start.p : nullptr, tgt.grid, im, tgt.qrange, radius_sq(d), h->match_pos.p, h->match_d2.p, s);
+        order = h->vals_b.p;
+      } else {
+        launch_nn_query(src.G4.p, ns, tgt.G4.p, tgt.table.p, tgt.grid, make_invmap(tgt), radius_sq(d), h->match_pos.p, h->match_d2.p, s);
+      }
+      launch_unpermute_matches(h->match_pos.p, h->match_d2.p, order, ns, src.G4.p, tgt.G4.p, out_idx.p, out_d2.p, s);
       copy_out(match_index, out_idx.p, sizeof(int) * ns, s);
       copy_out(sq_distance, out_d2.p, sizeof(float) * ns, s);
       const size_t nb = div_up(ns, kBlock);
       h->block_counts.reserve(nb); h->block_offsets.reserve(nb); h->block_d2.reserve(nb);
       h->d_total.reserve(1); h->d_total_d2.reserve(1); h->h_total.reserve(1);
-      launch_match_scan(h->match_pos.p, h->match_d2.p, ns, h->block_counts.p, h->block_offsets.p, h->block_d2.p, h->d_total.p, h->d_total_d2.p, s);
+      h->chunk_sum.reserve(div_up(nb, 256) + 1); h->chunk_d2.reserve(div_up(nb, 256) + 1);
+      launch_match_scan(h->match_pos.p, h->match_d2.p, ns, h->block_counts.p, h->block_offsets.p, h->block_d2.p, h->chunk_sum.p, h->chunk_d2.p, h->d_total.p, h->d_total_d2.p, s);
       copy_out(h->h_total.p, h->d_total.p, sizeof(unsigned long long), s);
       sync(h.get());
       count = (int64_t)h->h_total.p[0];

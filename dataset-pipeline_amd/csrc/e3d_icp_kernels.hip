@@ -144,10 +144,15 @@ __global__ __launch_bounds__(kBlock) void k_permute(const float* __restrict__ xy
 
 __global__ __launch_bounds__(kBlock) void k_count_cells(const unsigned long long* __restrict__ keys, size_t n,
                                                         unsigned* __restrict__ counter) {
-  const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const bool start = (j < n) && (j == 0 || keys[j] != keys[j - 1]);
-  const unsigned long long b = __ballot(start);
-  if ((threadIdx.x & 63) == 0 && b) atomicAdd(counter, (unsigned)__popcll(b));
+  unsigned c = 0;
+  for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (size_t)gridDim.x * blockDim.x)
+    c += (j == 0 || keys[j] != keys[j - 1]) ? 1u : 0u;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+  __shared__ unsigned sc[kBlock / kWave];
+  if ((threadIdx.x & 63) == 0) sc[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(counter, sc[0] + sc[1] + sc[2] + sc[3]);
 }
 
 __device__ __forceinline__ unsigned table_find_or_insert(HashEntry* table, unsigned mask, unsigned long long key) {
@@ -171,6 +176,21 @@ __global__ __launch_bounds__(kBlock) void k_build_table(const unsigned long long
     if (is_start) table[h].start = (unsigned)j;
     if (is_end) table[h].end = (unsigned)(j + 1);
   }
+}
+
+// dense cell-start directory: ends[lin(cell)] = end index of the cell's run in the sorted arrays (written by the
+// last point of each run, 0 elsewhere); an exclusive MAX scan turns it into starts, with
+// starts[lin + 1] = max(starts[lin], ends[lin]) = end of the cell's run (or its start if the cell is empty).
+__global__ __launch_bounds__(kBlock) void k_dense_counts(const unsigned long long* __restrict__ keys, size_t n,
+                                                         QueryRange qr, unsigned* __restrict__ ends) {
+  const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const unsigned long long k = keys[j];
+  if (j + 1 < n && keys[j + 1] == k) return;          // only the last point of a run writes
+  const int cx = (int)(k & 0x1FFFFFull), cy = (int)((k >> 21) & 0x1FFFFFull), cz = (int)((k >> 42) & 0x1FFFFFull);
+  const size_t lin = ((size_t)(unsigned)(cz - qr.lo[2]) * qr.D[1] + (unsigned)(cy - qr.lo[1])) * qr.D[0] +
+                     (unsigned)(cx - qr.lo[0]);
+  ends[lin] = (unsigned)(j + 1);
 }
 
 // =================================================================================================
@@ -236,6 +256,179 @@ __global__ __launch_bounds__(kBlock) void k_nn_query(const float4* __restrict__ 
   match_d2[j] = best_d2;
 }
 
+// -------------------------------------------------------------------------------------------------
+// Dense-data path of a5: queries are radix-sorted by the TARGET grid cell they fall into, then one
+// wave handles 64 consecutive sorted queries.  For every distinct cell in its chunk the wave stages the
+// cell's 27-neighbourhood (contiguous runs of the target's cell-ordered G4 array, found with 27 parallel
+// hash lookups) in LDS with coalesced loads, and the lanes -- arranged as (queries of that cell) x
+// (candidate slices) -- scan the bucket with broadcast LDS reads.  Same arithmetic, same (d2, index)
+// ordering and strict radius test as k_nn_query, so both kernels return identical results.
+// -------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long query_cell_key(const float4 q, const InvMap& im, const GridDesc& g,
+                                                             const QueryRange& qr, int& cx, int& cy, int& cz) {
+  const float dx = q.x - im.t[0], dy = q.y - im.t[1], dz = q.z - im.t[2];
+  const float lx = im.Linv[0] * dx + im.Linv[1] * dy + im.Linv[2] * dz;
+  const float ly = im.Linv[3] * dx + im.Linv[4] * dy + im.Linv[5] * dz;
+  const float lz = im.Linv[6] * dx + im.Linv[7] * dy + im.Linv[8] * dz;
+  cx = cell_coord(lx, g.origin[0], g.inv_cell);
+  cy = cell_coord(ly, g.origin[1], g.inv_cell);
+  cz = cell_coord(lz, g.origin[2], g.inv_cell);
+  const unsigned kx = (unsigned)(cx - qr.lo[0]), ky = (unsigned)(cy - qr.lo[1]), kz = (unsigned)(cz - qr.lo[2]);
+  if (kx >= qr.D[0] || ky >= qr.D[1] || kz >= qr.D[2]) return kEmptyKey;   // no target cell within reach
+  return ((unsigned long long)kz * qr.D[1] + ky) * qr.D[0] + kx;
+}
+
+__global__ __launch_bounds__(kBlock) void k_query_keys(const float4* __restrict__ Gsrc, size_t n, GridDesc g, InvMap im,
+                                                       QueryRange qr, unsigned long long* __restrict__ keys,
+                                                       unsigned* __restrict__ vals) {
+  const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  int cx, cy, cz;
+  keys[j] = query_cell_key(Gsrc[j], im, g, qr, cx, cy, cz);
+  vals[j] = (unsigned)j;
+}
+
+__device__ __forceinline__ int rdlane_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ unsigned rdlane_u(unsigned v, int l) { return (unsigned)__builtin_amdgcn_readlane((int)v, l); }
+
+__global__ __launch_bounds__(kBlock, 6) void k_nn_cells(const float4* __restrict__ Gsrc, const unsigned* __restrict__ order,
+                                                     size_t n, const float4* __restrict__ Gtgt,
+                                                     const HashEntry* __restrict__ table,
+                                                     const unsigned* __restrict__ dense_start, GridDesc g, InvMap im,
+                                                     QueryRange qr, float r2, int* __restrict__ match_pos,
+                                                     float* __restrict__ match_d2) {
+  __shared__ float4 s_c[kBlock / kWave][kNNCap];
+  __shared__ int s_p[kBlock / kWave][kNNCap];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const size_t pos = ((size_t)blockIdx.x * (kBlock / kWave) + w) * kWave + lane;
+  const bool valid = pos < n;
+  const unsigned j = valid ? order[pos] : 0u;
+  const float4 q = valid ? Gsrc[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+  int cx = 0, cy = 0, cz = 0;
+  const unsigned long long key = valid ? query_cell_key(q, im, g, qr, cx, cy, cz) : kEmptyKey;
+
+  float best_d2 = r2;      // strict radius: with best_oi == 0 a candidate at exactly r2 can never win
+  unsigned best_oi = 0u;
+  int best_pos = -1;
+  constexpr int kMaxC = (1 << 21) - 1;
+
+  unsigned long long remaining = __ballot(key != kEmptyKey);
+  while (remaining) {
+    const int f = __ffsll((long long)remaining) - 1;                      // first lane of the next cell group
+    const unsigned klo = rdlane_u((unsigned)key, f), khi = rdlane_u((unsigned)(key >> 32), f);
+    const unsigned long long cur = ((unsigned long long)khi << 32) | klo;
+    const unsigned long long group = __ballot(key == cur);                // contiguous lanes (sorted input)
+    const int a = __popcll(group);
+    const int ccx = rdlane_i(cx, f), ccy = rdlane_i(cy, f), ccz = rdlane_i(cz, f);
+
+    // 27 parallel cell lookups: dense cell-start directory (one coalesced round trip, runs of x-neighbours
+    // are adjacent words) or, for grids too large for it, the hash table
+    unsigned st = 0u, cnt = 0u;
+    if (lane < 27) {
+      const int x = ccx + (lane % 3) - 1, y = ccy + ((lane / 3) % 3) - 1, z = ccz + (lane / 9) - 1;
+      if (dense_start) {
+        const unsigned kx = (unsigned)(x - qr.lo[0]), ky = (unsigned)(y - qr.lo[1]), kz = (unsigned)(z - qr.lo[2]);
+        if (kx < qr.D[0] && ky < qr.D[1] && kz < qr.D[2]) {
+          const size_t lin = ((size_t)kz * qr.D[1] + ky) * qr.D[0] + kx;
+          st = dense_start[lin];
+          cnt = dense_start[lin + 1] - st;
+        }
+      } else if (x >= 0 && y >= 0 && z >= 0 && x <= kMaxC && y <= kMaxC && z <= kMaxC) {
+        const unsigned long long ck = cell_key(x, y, z);
+        unsigned h = hash_key(ck) & g.mask;
+        for (;;) {
+          const HashEntry en = table[h];
+          if (en.key == ck) { st = en.start; cnt = en.end - en.start; break; }
+          if (en.key == kEmptyKey) break;
+          h = (h + 1) & g.mask;
+        }
+      }
+    }
+    unsigned inc = cnt;
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) {
+      const unsigned t = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += t;
+    }
+    const unsigned off = inc - cnt;
+    const unsigned total = rdlane_u(inc, 26);
+
+    // lanes = (query slot) x (candidate slice)
+    int lg = 0;
+    while ((1 << lg) < a) ++lg;
+    const int A2 = 1 << lg, slices = kWave >> lg;
+    const int qi = lane & (A2 - 1), sl = lane >> lg;
+    const bool act = qi < a;
+    const int owner = (f + qi) & 63;
+    const float qx = __shfl(q.x, owner, 64), qy = __shfl(q.y, owner, 64), qz = __shfl(q.z, owner, 64);
+    float lb_d2 = r2;
+    unsigned lb_oi = 0u;
+    int lb_pos = -1;
+
+    for (unsigned base = 0; base < total; base += kNNCap) {
+      const unsigned nb = min((unsigned)kNNCap, total - base);
+      // stage the bucket: every lane first resolves the source positions of its kNNCap/64 slots (flat
+      // candidate index -> (cell run, offset) via the 27 prefix sums), then all loads are issued
+      // back-to-back, then the LDS stores -- one memory round trip per batch instead of one per run.
+      static_assert(kNNCap == 4 * kWave, "staging below is written for 4 slots per lane");
+      const unsigned t0 = base + (unsigned)lane, t1 = t0 + kWave, t2 = t1 + kWave, t3 = t2 + kWave;
+      unsigned m0 = 0xFFFFFFFFu, m1 = 0xFFFFFFFFu, m2 = 0xFFFFFFFFu, m3 = 0xFFFFFFFFu;
+      for (int r = 0; r < 27; ++r) {
+        const unsigned c_r = rdlane_u(cnt, r);
+        if (c_r == 0u) continue;
+        const unsigned o_r = rdlane_u(off, r), s_r = rdlane_u(st, r);
+        if (t0 - o_r < c_r) m0 = s_r + (t0 - o_r);     // unsigned wrap makes this "o_r <= t < o_r + c_r"
+        if (t1 - o_r < c_r) m1 = s_r + (t1 - o_r);
+        if (t2 - o_r < c_r) m2 = s_r + (t2 - o_r);
+        if (t3 - o_r < c_r) m3 = s_r + (t3 - o_r);
+      }
+      float4 c0, c1, c2, c3;
+      if (m0 != 0xFFFFFFFFu) c0 = Gtgt[m0];
+      if (m1 != 0xFFFFFFFFu) c1 = Gtgt[m1];
+      if (m2 != 0xFFFFFFFFu) c2 = Gtgt[m2];
+      if (m3 != 0xFFFFFFFFu) c3 = Gtgt[m3];
+      if (m0 != 0xFFFFFFFFu) { s_c[w][lane] = c0; s_p[w][lane] = (int)m0; }
+      if (m1 != 0xFFFFFFFFu) { s_c[w][kWave + lane] = c1; s_p[w][kWave + lane] = (int)m1; }
+      if (m2 != 0xFFFFFFFFu) { s_c[w][2 * kWave + lane] = c2; s_p[w][2 * kWave + lane] = (int)m2; }
+      if (m3 != 0xFFFFFFFFu) { s_c[w][3 * kWave + lane] = c3; s_p[w][3 * kWave + lane] = (int)m3; }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      int lb_t = -1;
+      if (act) {
+#pragma unroll 4
+        for (unsigned t = sl; t < nb; t += slices) {
+          const float4 c = s_c[w][t];
+          const float d2 = sqdist_l2(qx, qy, qz, c.x, c.y, c.z);
+          const unsigned oi = __float_as_uint(c.w);
+          if (d2 < lb_d2 || (d2 == lb_d2 && oi < lb_oi)) { lb_d2 = d2; lb_oi = oi; lb_t = (int)t; }
+        }
+        if (lb_t >= 0) lb_pos = s_p[w][lb_t];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    // min over the candidate slices of each query slot
+    for (int stx = A2; stx < kWave; stx <<= 1) {
+      const float od2 = __shfl_xor(lb_d2, stx, 64);
+      const unsigned ooi = (unsigned)__shfl_xor((int)lb_oi, stx, 64);
+      const int opos = __shfl_xor(lb_pos, stx, 64);
+      if (od2 < lb_d2 || (od2 == lb_d2 && ooi < lb_oi)) { lb_d2 = od2; lb_oi = ooi; lb_pos = opos; }
+    }
+    // hand the result to the lane that owns the query
+    const int srcl = (lane - f) & 63;
+    const float rd2 = __shfl(lb_d2, srcl, 64);
+    const unsigned roi = (unsigned)__shfl((int)lb_oi, srcl, 64);
+    const int rpos = __shfl(lb_pos, srcl, 64);
+    if ((group >> lane) & 1ull) {
+      if (rd2 < best_d2 || (rd2 == best_d2 && roi < best_oi)) { best_d2 = rd2; best_oi = roi; best_pos = rpos; }
+    }
+    remaining &= ~group;
+  }
+  if (valid) { match_pos[pos] = best_pos; match_d2[pos] = best_d2; }
+}
+
 // flags -> per-block counts (first stage of the order-preserving compaction)
 __global__ __launch_bounds__(kBlock) void k_match_block_counts(const int* __restrict__ match_pos, size_t n,
                                                                unsigned* __restrict__ block_counts,
@@ -257,17 +450,38 @@ __global__ __launch_bounds__(kBlock) void k_match_block_counts(const int* __rest
   }
 }
 
-// single-block exclusive scan of the per-block counts (nblocks <= a few hundred thousand)
-__global__ void k_scan_block_counts(const unsigned* __restrict__ counts, int nblocks,
-                                    unsigned* __restrict__ offsets, unsigned long long* __restrict__ total,
-                                    const double* __restrict__ block_d2, double* __restrict__ total_d2) {
+// exclusive scan of the per-block counts in three small steps: chunk sums (kScanChunk entries per chunk),
+// single-block scan of the chunk sums, per-chunk scan with its base.
+constexpr int kScanChunk = 256;
+__global__ __launch_bounds__(kScanChunk) void k_scan_chunk_sums(const unsigned* __restrict__ counts, int nblocks,
+                                                                const double* __restrict__ block_d2,
+                                                                unsigned long long* __restrict__ chunk_sum,
+                                                                double* __restrict__ chunk_d2) {
+  const int b = blockIdx.x * kScanChunk + threadIdx.x;
+  unsigned long long c = (b < nblocks) ? counts[b] : 0ull;
+  double d = (b < nblocks) ? block_d2[b] : 0.0;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { c += __shfl_xor(c, o, 64); d += __shfl_xor(d, o, 64); }
+  __shared__ unsigned long long sc[kScanChunk / kWave];
+  __shared__ double sd[kScanChunk / kWave];
+  if ((threadIdx.x & 63) == 0) { sc[threadIdx.x >> 6] = c; sd[threadIdx.x >> 6] = d; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long t = 0; double td = 0;
+    for (int k = 0; k < kScanChunk / kWave; ++k) { t += sc[k]; td += sd[k]; }
+    chunk_sum[blockIdx.x] = t; chunk_d2[blockIdx.x] = td;
+  }
+}
+
+__global__ void k_scan_chunks(unsigned long long* __restrict__ chunk_sum, int nchunks, const double* __restrict__ chunk_d2,
+                              unsigned long long* __restrict__ total, double* __restrict__ total_d2) {
   __shared__ unsigned long long s[1024];
   __shared__ double sd[1024];
   const int t = threadIdx.x, T = blockDim.x;
-  const int per = (nblocks + T - 1) / T;
-  const int b0 = t * per, b1 = min(nblocks, b0 + per);
+  const int per = (nchunks + T - 1) / T;
+  const int b0 = min(nchunks, t * per), b1 = min(nchunks, b0 + per);
   unsigned long long sum = 0; double d = 0;
-  for (int b = b0; b < b1; ++b) { sum += counts[b]; d += block_d2[b]; }
+  for (int b = b0; b < b1; ++b) { sum += chunk_sum[b]; d += chunk_d2[b]; }
   s[t] = sum; sd[t] = d;
   __syncthreads();
   if (t == 0) {
@@ -277,11 +491,32 @@ __global__ void k_scan_block_counts(const unsigned* __restrict__ counts, int nbl
   }
   __syncthreads();
   unsigned long long run = s[t];
-  for (int b = b0; b < b1; ++b) { offsets[b] = (unsigned)run; run += counts[b]; }
+  for (int b = b0; b < b1; ++b) { const unsigned long long v = chunk_sum[b]; chunk_sum[b] = run; run += v; }
+}
+
+__global__ __launch_bounds__(kScanChunk) void k_scan_within_chunks(const unsigned* __restrict__ counts, int nblocks,
+                                                                   const unsigned long long* __restrict__ chunk_base,
+                                                                   unsigned* __restrict__ offsets) {
+  const int b = blockIdx.x * kScanChunk + threadIdx.x;
+  const unsigned c = (b < nblocks) ? counts[b] : 0u;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  unsigned inc = c;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned t = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += t;
+  }
+  __shared__ unsigned ws[kScanChunk / kWave];
+  if (lane == 63) ws[w] = inc;
+  __syncthreads();
+  unsigned wbase = 0;
+  for (int k = 0; k < w; ++k) wbase += ws[k];
+  if (b < nblocks) offsets[b] = (unsigned)chunk_base[blockIdx.x] + wbase + (inc - c);
 }
 
 // second stage: write the correspondence planes in source (cell) order
-__global__ __launch_bounds__(kBlock) void k_compact_corr(const int* __restrict__ match_pos, size_t n,
+__global__ __launch_bounds__(kBlock) void k_compact_corr(const int* __restrict__ match_pos,
+                                                         const unsigned* __restrict__ order, size_t n,
                                                          const unsigned* __restrict__ block_offsets,
                                                          const float4* __restrict__ Gsrc, const float4* __restrict__ LNsrc,
                                                          Affine Tsrc, const float4* __restrict__ Gtgt,
@@ -301,8 +536,9 @@ __global__ __launch_bounds__(kBlock) void k_compact_corr(const int* __restrict__
   if (!f) return;
   const unsigned rank = (unsigned)__popcll(b & ((1ull << lane) - 1ull));
   const size_t o = out_base + base + rank;
-  const float4 sp = Gsrc[j];
-  const float4 ln = LNsrc[j];
+  const size_t js = order ? (size_t)order[j] : j;     // query j of the (sorted) search order -> source position
+  const float4 sp = Gsrc[js];
+  const float4 ln = LNsrc[js];
   const float3 sn = pcl_so3(Tsrc, ln.x, ln.y, ln.z);
   const float4 tp = Gtgt[m];
   const float4 tl = LNtgt[m];
@@ -329,13 +565,15 @@ __global__ __launch_bounds__(kBlock) void k_gather_corr(const float* __restrict_
 
 // un-permute NN results to original source order / original target indices
 __global__ __launch_bounds__(kBlock) void k_unpermute_matches(const int* __restrict__ match_pos,
-                                                              const float* __restrict__ match_d2, size_t n,
+                                                              const float* __restrict__ match_d2,
+                                                              const unsigned* __restrict__ order, size_t n,
                                                               const float4* __restrict__ Gsrc,
                                                               const float4* __restrict__ Gtgt,
                                                               int* __restrict__ out_idx, float* __restrict__ out_d2) {
   const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
-  const unsigned oi = __float_as_uint(Gsrc[j].w);
+  const size_t js = order ? (size_t)order[j] : j;
+  const unsigned oi = __float_as_uint(Gsrc[js].w);
   const int m = match_pos[j];
   out_idx[oi] = (m >= 0) ? (int)__float_as_uint(Gtgt[m].w) : -1;
   out_d2[oi] = (m >= 0) ? match_d2[j] : 0.f;
@@ -491,14 +729,33 @@ __global__ __launch_bounds__(kBlock) void k_lm_pass(const float4* __restrict__ A
   }
 }
 
-// one block per set: sum the set's block partials in block order
-__global__ void k_lm_reduce(const double* __restrict__ partial, const LmSet* __restrict__ sets, int nacc,
-                            double* __restrict__ out) {
+// one block per set: sum the set's block partials in a fixed order.  kRedParts threads share each of the
+// kLmSlot accumulators (interleaved block ranges, 4 independent loads in flight), then a fixed-order
+// LDS sum -- deterministic, and no 2048-long chain of dependent HBM loads.
+constexpr int kRedParts = 8;
+__global__ __launch_bounds__(kLmSlot * kRedParts) void k_lm_reduce(const double* __restrict__ partial,
+                                                                   const LmSet* __restrict__ sets, int nacc,
+                                                                   double* __restrict__ out) {
   const LmSet S = sets[blockIdx.x];
-  if ((int)threadIdx.x >= nacc) return;
-  double v = 0.0;
-  for (int b = 0; b < S.nblocks; ++b) v += partial[(size_t)(S.block_begin + b) * kLmSlot + threadIdx.x];
-  out[(size_t)blockIdx.x * kLmSlot + threadIdx.x] = v;
+  const int slot = threadIdx.x % kLmSlot, part = threadIdx.x / kLmSlot;
+  __shared__ double sh[kRedParts][kLmSlot];
+  double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
+  const double* base = partial + (size_t)S.block_begin * kLmSlot + slot;
+  int b = part;
+  for (; b + 3 * kRedParts < S.nblocks; b += 4 * kRedParts) {
+    const double a0 = base[(size_t)b * kLmSlot], a1 = base[(size_t)(b + kRedParts) * kLmSlot];
+    const double a2 = base[(size_t)(b + 2 * kRedParts) * kLmSlot], a3 = base[(size_t)(b + 3 * kRedParts) * kLmSlot];
+    v0 += a0; v1 += a1; v2 += a2; v3 += a3;
+  }
+  for (; b < S.nblocks; b += kRedParts) v0 += base[(size_t)b * kLmSlot];
+  sh[part][slot] = (v0 + v1) + (v2 + v3);
+  __syncthreads();
+  if (part == 0 && slot < nacc) {
+    double v = sh[0][slot];
+#pragma unroll
+    for (int k = 1; k < kRedParts; ++k) v += sh[k][slot];
+    out[(size_t)blockIdx.x * kLmSlot + slot] = v;
+  }
 }
 
 // =================================================================================================
@@ -547,7 +804,7 @@ void launch_permute(const float* xyz, const float* nrm, const unsigned* order, s
 
 void launch_count_cells(const unsigned long long* keys, size_t n, unsigned* counter, hipStream_t s) {
   if (!n) return;
-  hipLaunchKernelGGL(k_count_cells, dim3((unsigned)div_up(n, kBlock)), dim3(kBlock), 0, s, keys, n, counter);
+  hipLaunchKernelGGL(k_count_cells, dim3(grid_for(n, 2048)), dim3(kBlock), 0, s, keys, n, counter);
 }
 
 void launch_build_table(const unsigned long long* keys, size_t n, HashEntry* table, unsigned mask, hipStream_t s) {
@@ -563,20 +820,41 @@ void launch_nn_query(const float4* Gsrc, size_t n_src, const float4* Gtgt, const
 }
 
 void launch_match_scan(const int* match_pos, const float* match_d2, size_t n, unsigned* block_counts,
-                       unsigned* block_offsets, double* block_d2, unsigned long long* total, double* total_d2,
-                       hipStream_t s) {
+                       unsigned* block_offsets, double* block_d2, unsigned long long* chunk_sum, double* chunk_d2,
+                       unsigned long long* total, double* total_d2, hipStream_t s) {
   const int nb = (int)div_up(n ? n : 1, kBlock);
   hipLaunchKernelGGL(k_match_block_counts, dim3(nb), dim3(kBlock), 0, s, match_pos, n, block_counts, block_d2,
                      match_d2);
-  hipLaunchKernelGGL(k_scan_block_counts, dim3(1), dim3(1024), 0, s, block_counts, nb, block_offsets, total,
-                     block_d2, total_d2);
+  const int nch = (nb + kScanChunk - 1) / kScanChunk;
+  hipLaunchKernelGGL(k_scan_chunk_sums, dim3(nch), dim3(kScanChunk), 0, s, block_counts, nb, block_d2, chunk_sum, chunk_d2);
+  hipLaunchKernelGGL(k_scan_chunks, dim3(1), dim3(1024), 0, s, chunk_sum, nch, chunk_d2, total, total_d2);
+  hipLaunchKernelGGL(k_scan_within_chunks, dim3(nch), dim3(kScanChunk), 0, s, block_counts, nb, chunk_sum, block_offsets);
 }
 
-void launch_compact_corr(const int* match_pos, size_t n, const unsigned* block_offsets, const float4* Gsrc,
+void launch_query_keys(const float4* Gsrc, size_t n, const GridDesc& g, const InvMap& im, const QueryRange& qr,
+                       unsigned long long* keys, unsigned* vals, hipStream_t s) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_query_keys, dim3((unsigned)div_up(n, kBlock)), dim3(kBlock), 0, s, Gsrc, n, g, im, qr, keys, vals);
+}
+
+void launch_nn_cells(const float4* Gsrc, const unsigned* order, size_t n, const float4* Gtgt, const HashEntry* table,
+                     const unsigned* dense_start, const GridDesc& g, const InvMap& im, const QueryRange& qr, float r2,
+                     int* match_pos, float* match_d2, hipStream_t s) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_nn_cells, dim3((unsigned)div_up(n, kBlock)), dim3(kBlock), 0, s, Gsrc, order, n, Gtgt, table,
+                     dense_start, g, im, qr, r2, match_pos, match_d2);
+}
+
+void launch_dense_counts(const unsigned long long* keys, size_t n, const QueryRange& qr, unsigned* counts, hipStream_t s) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_dense_counts, dim3((unsigned)div_up(n, kBlock)), dim3(kBlock), 0, s, keys, n, qr, counts);
+}
+
+void launch_compact_corr(const int* match_pos, const unsigned* order, size_t n, const unsigned* block_offsets, const float4* Gsrc,
                          const float4* LNsrc, const Affine& Tsrc, const float4* Gtgt, const float4* LNtgt,
                          const Affine& Ttgt, float4* A, float4* B, float4* C, size_t out_base, hipStream_t s) {
   if (!n) return;
-  hipLaunchKernelGGL(k_compact_corr, dim3((unsigned)div_up(n, kBlock)), dim3(kBlock), 0, s, match_pos, n,
+  hipLaunchKernelGGL(k_compact_corr, dim3((unsigned)div_up(n, kBlock)), dim3(kBlock), 0, s, match_pos, order, n,
                      block_offsets, Gsrc, LNsrc, Tsrc, Gtgt, LNtgt, Ttgt, A, B, C, out_base);
 }
 
@@ -587,11 +865,11 @@ void launch_gather_corr(const float* sxyz, const float* snrm, const float* txyz,
                      im, n, A, B, C);
 }
 
-void launch_unpermute_matches(const int* match_pos, const float* match_d2, size_t n, const float4* Gsrc,
+void launch_unpermute_matches(const int* match_pos, const float* match_d2, const unsigned* order, size_t n, const float4* Gsrc,
                               const float4* Gtgt, int* out_idx, float* out_d2, hipStream_t s) {
   if (!n) return;
   hipLaunchKernelGGL(k_unpermute_matches, dim3((unsigned)div_up(n, kBlock)), dim3(kBlock), 0, s, match_pos, match_d2,
-                     n, Gsrc, Gtgt, out_idx, out_d2);
+                     order, n, Gsrc, Gtgt, out_idx, out_d2);
 }
 
 void launch_lm_pass(int mode, const float4* A, const float4* B, const float4* C, const LmSet* sets,
@@ -615,7 +893,7 @@ void launch_lm_pass(int mode, const float4* A, const float4* B, const float4* C,
 
 void launch_lm_reduce(const double* partial, const LmSet* sets, int n_sets, int nacc, double* out, hipStream_t s) {
   if (n_sets <= 0) return;
-  hipLaunchKernelGGL(k_lm_reduce, dim3(n_sets), dim3(128), 0, s, partial, sets, nacc, out);
+  hipLaunchKernelGGL(k_lm_reduce, dim3(n_sets), dim3(kLmSlot * kRedParts), 0, s, partial, sets, nacc, out);
 }
 
 }  // namespace e3d

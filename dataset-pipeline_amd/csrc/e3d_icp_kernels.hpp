@@ -15,6 +15,11 @@ enum { kModeCost = 0,      // cost only
 };
 constexpr int kLmSlot = 91;          // doubles per block partial / per set result
 constexpr int kMaxBboxBlocks = 2048;
+constexpr int kNNCap = 256;          // candidates staged in LDS per wave and batch (k_nn_cells)
+
+// Target-grid cell range a query must fall into to have any candidate (cells of the target's points +- 2),
+// used to build dense sort keys for the queries.
+struct QueryRange { int lo[3]; unsigned D[3]; };
 
 // One directed pair's slice of the concatenated correspondence planes, with the inner poses
 // (R = so3().matrix() in f32, row-major) of its two impl clouds.
@@ -40,14 +45,22 @@ void launch_build_table(const unsigned long long* keys, size_t n, HashEntry* tab
 void launch_nn_query(const float4* Gsrc, size_t n_src, const float4* Gtgt, const HashEntry* table, const GridDesc& g,
                      const InvMap& im, float r2, int* match_pos, float* match_d2, hipStream_t s);
 void launch_match_scan(const int* match_pos, const float* match_d2, size_t n, unsigned* block_counts,
-                       unsigned* block_offsets, double* block_d2, unsigned long long* total, double* total_d2,
-                       hipStream_t s);
-void launch_compact_corr(const int* match_pos, size_t n, const unsigned* block_offsets, const float4* Gsrc,
+                       unsigned* block_offsets, double* block_d2, unsigned long long* chunk_sum, double* chunk_d2,
+                       unsigned long long* total, double* total_d2, hipStream_t s);
+void launch_query_keys(const float4* Gsrc, size_t n, const GridDesc& g, const InvMap& im, const QueryRange& qr,
+                       unsigned long long* keys, unsigned* vals, hipStream_t s);
+void launch_nn_cells(const float4* Gsrc, const unsigned* order, size_t n, const float4* Gtgt, const HashEntry* table,
+                     const unsigned* dense_start, const GridDesc& g, const InvMap& im, const QueryRange& qr, float r2,
+                     int* match_pos, float* match_d2, hipStream_t s);
+void launch_dense_counts(const unsigned long long* keys, size_t n, const QueryRange& qr, unsigned* counts, hipStream_t s);
+// in-place exclusive MAX scan of n unsigned values (rocPRIM, e3d_sort.hip); one-off per grid build
+void exclusive_max_scan_u32(unsigned* data, size_t n, DevBuf<char>& temp, hipStream_t s);
+void launch_compact_corr(const int* match_pos, const unsigned* order, size_t n, const unsigned* block_offsets, const float4* Gsrc,
                          const float4* LNsrc, const Affine& Tsrc, const float4* Gtgt, const float4* LNtgt,
                          const Affine& Ttgt, float4* A, float4* B, float4* C, size_t out_base, hipStream_t s);
 void launch_gather_corr(const float* sxyz, const float* snrm, const float* txyz, const float* tnrm, const int* iq,
                         const int* im, size_t n, float4* A, float4* B, float4* C, hipStream_t s);
-void launch_unpermute_matches(const int* match_pos, const float* match_d2, size_t n, const float4* Gsrc,
+void launch_unpermute_matches(const int* match_pos, const float* match_d2, const unsigned* order, size_t n, const float4* Gsrc,
                               const float4* Gtgt, int* out_idx, float* out_d2, hipStream_t s);
 void launch_lm_pass(int mode, const float4* A, const float4* B, const float4* C, const LmSet* sets,
                     const int* block_set, int block_base, int nblocks, double* partial, hipStream_t s);

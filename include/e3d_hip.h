@@ -43,6 +43,10 @@ int e3d_abi_version(void);
 /* Select the HIP device for subsequently created handles; returns the device count. */
 int e3d_init(int device);
 const char* e3d_last_error(void);
+/* Nearest-neighbour kernel selection for handles created afterwards: 0 = automatic (by points per grid
+ * cell), 1 = one thread per query, 2 = queries sorted by target cell + LDS-staged candidate buckets.
+ * Both kernels are exact and return identical results; this only exists for tests and profiling. */
+int e3d_set_nn_mode(int mode);
 
 /* ---- (A) icp::PointToPlaneICP  (src/icp/icp_point_to_plane.h:39-80) --------------------- */
 typedef struct e3d_icp e3d_icp_t;
@@ -95,6 +99,7 @@ typedef struct {
   double  initial_cost, final_cost;
   double  t_transform_ms, t_nn_ms, t_lm_ms;   /* HIP-event times on the handle's stream   */
   double  t_lm_kernel_ms;    /* sum of LM pass kernel durations (HIP events)               */
+  double  t_nn_query_ms;     /* sum of NN query kernel durations (HIP events)              */
 } e3d_icp_iter_record;
 
 size_t e3d_icp_num_pair_records(const e3d_icp_t* icp);
@@ -103,8 +108,9 @@ size_t e3d_icp_num_iter_records(const e3d_icp_t* icp);
 const e3d_icp_iter_record* e3d_icp_iter_records(const e3d_icp_t* icp);
 void e3d_icp_clear_records(e3d_icp_t* icp);
 
-/* Multi-GPU (one process per GPU): directed cloud pairs are dealt round-robin to
- * `world_size` ranks; every rank holds all clouds.  `allreduce` must sum `count` doubles in
+/* Multi-GPU (one process per GPU): every rank holds all clouds and handles the slice
+ * [n*rank/world, n*(rank+1)/world) of every directed pair's source cloud (in grid-cell order), so
+ * any number of pairs -- including the 2 pairs of a 2-scan job -- shards evenly.  `allreduce` must sum `count` doubles in
  * place across ranks (RCCL/gloo through the host language; buffer is HOST memory) and leave
  * the identical result on every rank.  The reference has no equivalent (single process). */
 typedef int (*e3d_allreduce_fn)(double* buffer, size_t count, void* user);

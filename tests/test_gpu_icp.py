@@ -40,6 +40,14 @@ def test_transform_bit_exact(e3d, ob, n):
 
 
 # ---- a5: FindCorrespondencesFast --------------------------------------------------------------------------------
+@pytest.fixture(params=[1, 2], ids=["per-query-kernel", "lds-bucket-kernel"])
+def nn_mode(request, e3d):
+    """Both exact NN kernels must agree with the oracle bit for bit."""
+    assert e3d.lib().e3d_set_nn_mode(request.param) == 0
+    yield request.param
+    e3d.lib().e3d_set_nn_mode(0)
+
+
 def _check_nn(e3d, ob, src, tgt, d):
     idx, d2, count = e3d.find_correspondences(src, tgt, d)
     iq, im, sd = ob.find_correspondences(src, tgt, d)
@@ -55,14 +63,14 @@ def _check_nn(e3d, ob, src, tgt, d):
 
 @pytest.mark.parametrize("ns,nt,d", [(1000, 1000, 0.1), (5000, 300, 0.3), (300, 5000, 0.05), (1, 1, 10.0),
                                      (20000, 20000, 0.02), (777, 1234, 1e-3)])
-def test_nn_random(e3d, ob, ns, nt, d):
+def test_nn_random(e3d, ob, ns, nt, d, nn_mode):
     rng = np.random.RandomState(ns * 7 + nt)
     src = rng.uniform(-1, 1, (ns, 3)).astype(np.float32)
     tgt = rng.uniform(-1, 1, (nt, 3)).astype(np.float32)
     _check_nn(e3d, ob, src, tgt, d)
 
 
-def test_nn_empty_and_ragged(e3d, ob):
+def test_nn_empty_and_ragged(e3d, ob, nn_mode):
     rng = np.random.RandomState(5)
     a = rng.uniform(-1, 1, (100, 3)).astype(np.float32)
     e = np.zeros((0, 3), np.float32)
@@ -72,7 +80,7 @@ def test_nn_empty_and_ragged(e3d, ob):
     assert c == 0 and idx.shape[0] == 0
 
 
-def test_nn_lattice_ties_lowest_index(e3d, ob):
+def test_nn_lattice_ties_lowest_index(e3d, ob, nn_mode):
     """Equidistant neighbours on an integer lattice (PlaneCase geometry): lowest target index wins, radius strict."""
     xs, ys = np.meshgrid(np.arange(40), np.arange(40), indexing="ij")
     tgt = np.stack([xs.ravel(), ys.ravel(), np.zeros(1600)], 1).astype(np.float32)
@@ -88,7 +96,7 @@ def test_nn_lattice_ties_lowest_index(e3d, ob):
     _check_nn(e3d, ob, src, tgt3, 1.5)
 
 
-def test_nn_far_offset_and_duplicates(e3d, ob):
+def test_nn_far_offset_and_duplicates(e3d, ob, nn_mode):
     """Large coordinates (f32 ulp ~ 1e-5) with a radius of a few ulps; boundary decisions must match exactly."""
     rng = np.random.RandomState(11)
     base = np.array([131.0, -77.0, 45.0], np.float32)
@@ -98,7 +106,7 @@ def test_nn_far_offset_and_duplicates(e3d, ob):
         _check_nn(e3d, ob, src, tgt, d)
 
 
-def test_nn_self_match_property(e3d):
+def test_nn_self_match_property(e3d, nn_mode):
     """Size-independent property at a larger size: a cloud matched against itself finds every point at distance 0."""
     rng = np.random.RandomState(3)
     a = rng.uniform(-5, 5, (2_000_000, 3)).astype(np.float32)
@@ -152,7 +160,7 @@ def _compare(g, o, ids, cg, co, exact_iters=None):
         assert ang <= ROT_TOL and tr <= TRANS_TOL, (i, ang, tr)
 
 
-def test_icp_plane_case(e3d, ob):
+def test_icp_plane_case(e3d, ob, nn_mode):
     xyz, nrm, T0, T1 = plane_case()
     g, o, ids, cg, co = _run_both(e3d, ob, [(xyz, nrm, T0, False), (xyz, nrm, T1, False)], 1.5, 100)
     _compare(g, o, ids, cg, co)
@@ -160,7 +168,7 @@ def test_icp_plane_case(e3d, ob):
     assert np.abs(A - B).max() <= 1e-5          # the reference test's own assertion (test_icp.cc:159-171)
 
 
-def test_icp_identical_clouds(e3d, ob):
+def test_icp_identical_clouds(e3d, ob, nn_mode):
     P, N, Ts = identical_cloud_case()
     clouds = [(P, N, T, False) for T in Ts]
     g, o, ids, cg, co = _run_both(e3d, ob, clouds, np.float32(0.15) * np.sqrt(3), 100)
@@ -170,7 +178,7 @@ def test_icp_identical_clouds(e3d, ob):
         assert np.abs(g.get_result_global_T_cloud(i) - T0).max() <= 1e-5   # test_icp.cc:98-108
 
 
-def test_icp_with_fixed_clouds(e3d, ob, synth):
+def test_icp_with_fixed_clouds(e3d, ob, synth, nn_mode):
     scans = synth.make_scene(4, 20000, seed=7)
     clouds = []
     for i, s in enumerate(scans):
@@ -180,7 +188,7 @@ def test_icp_with_fixed_clouds(e3d, ob, synth):
     _compare(g, o, ids, cg, co)
 
 
-def test_icp_c1_config(e3d, ob, synth):
+def test_icp_c1_config(e3d, ob, synth, nn_mode):
     """BASELINE.json configs[0]: 2 scans x 100k points, d = 0.05."""
     scans = synth.make_scene(2, 100_000, seed=1234)
     clouds = [(s["xyz"].numpy(), s["normals"].numpy(), s["T_init"], False) for s in scans]
@@ -190,6 +198,25 @@ def test_icp_c1_config(e3d, ob, synth):
     ang0, tr0 = pose_error(scans[1]["T_init"], scans[1]["T_true"])
     ang1, tr1 = pose_error(g.get_result_global_T_cloud(1), scans[1]["T_true"])
     assert tr1 < 0.3 * tr0 and ang1 < 0.3 * ang0
+
+
+def test_nn_dense_buckets_overflow(e3d, ob, nn_mode):
+    """More candidates per 27-cell neighbourhood than one LDS batch holds (kNNCap = 256): batches must chain."""
+    rng = np.random.RandomState(21)
+    tgt = rng.uniform(0, 0.2, (40000, 3)).astype(np.float32)        # ~40000/8 * 27*0.1^3... dense: ~1350 per bucket
+    src = rng.uniform(0, 0.2, (3000, 3)).astype(np.float32)
+    _check_nn(e3d, ob, src, tgt, 0.02)
+    _check_nn(e3d, ob, src, tgt, 0.1)                               # every bucket holds the whole cloud
+
+
+def test_nn_rotated_scaled_target_frame(e3d, ob, synth, nn_mode):
+    """Non-trivial poses (incl. a non-rigid linear part): counts identical to the oracle inside the full ICP loop."""
+    scans = synth.make_scene(2, 30000, seed=99)
+    T0 = scans[0]["T_init"].copy(); T1 = scans[1]["T_init"].copy()
+    clouds = [(scans[0]["xyz"].numpy() / 1.3, scans[0]["normals"].numpy(), T0 @ np.diag([1.3, 1.3, 1.3, 1]).astype(np.float32), False),
+              (scans[1]["xyz"].numpy(), scans[1]["normals"].numpy(), T1, False)]
+    g, o, ids, cg, co = _run_both(e3d, ob, clouds, 0.12, 3, thr=1e-9)
+    _compare(g, o, ids, cg, co)
 
 
 def test_icp_errors(e3d):

@@ -73,7 +73,7 @@ struct e3d_icp {
   std::vector<std::unique_ptr<Cloud>> clouds;   // movable clouds
   std::unique_ptr<Cloud> fixed;                 // merged fixed cloud (global frame)
   int max_inner = 150;
-  int nn_mode = 0;                              // 0 auto, 1 force per-query kernel, 2 force LDS-bucket kernel
+  int nn_mode = 0;                              // 0 auto, 1 per-query kernel, 2 hash-table bucket kernel, 3 dense-directory row kernel
   size_t dense_cell_budget = (size_t)1 << 31;   // max cells of a dense directory (8 GB); hash table beyond
   int rank = 0, world = 1;
   e3d_allreduce_fn allreduce = nullptr;
@@ -293,7 +293,7 @@ static void find_pair(e3d_icp* h, Cloud& src, Cloud& tgt, float d, PairJob& job,
   if (!h->nn_timer) h->nn_timer.reset(new EventTimer());
   // dense data (many points per cell): sort the queries by target cell and use the LDS-bucket kernel;
   // sparse data: one thread per query.  Both are exact and return identical results.
-  const bool dense = h->nn_mode == 2 || (h->nn_mode == 0 && (double)tgt.n >= 4.0 * (double)std::max(tgt.n_cells, 1u));
+  const bool dense = h->nn_mode >= 2 || (h->nn_mode == 0 && (double)tgt.n >= 4.0 * (double)std::max(tgt.n_cells, 1u));
   const unsigned* order = nullptr;
   h->nn_timer->start(s);
   if (dense) {
@@ -301,8 +301,12 @@ static void find_pair(e3d_icp* h, Cloud& src, Cloud& tgt, float d, PairJob& job,
     const InvMap im = make_invmap(tgt);
     launch_query_keys(srcG, n, tgt.grid, im, tgt.qrange, h->keys_a.p, h->vals_a.p, s);
     sort_pairs_u64_u32(h->keys_a.p, h->keys_b.p, h->vals_a.p, h->vals_b.p, n, tgt.key_bits, h->sort_temp, s);
-    launch_nn_cells(srcG, h->vals_b.p, n, tgt.G4.p, tgt.table.p, tgt.has_dense ? tgt.dense_start.p : nullptr, tgt.grid, im,
-                    tgt.qrange, radius_sq(d), h->match_pos.p, h->match_d2.p, s);
+    if (tgt.has_dense && h->nn_mode != 2)
+      launch_nn_rows(srcG, h->vals_b.p, n, tgt.G4.p, tgt.dense_start.p, tgt.grid, im, tgt.qrange, radius_sq(d),
+                     h->match_pos.p, h->match_d2.p, s);
+    else
+      launch_nn_cells(srcG, h->vals_b.p, n, tgt.G4.p, tgt.table.p, nullptr, tgt.grid, im, tgt.qrange, radius_sq(d),
+                      h->match_pos.p, h->match_d2.p, s);
     order = h->vals_b.p;
   } else {
     launch_nn_query(srcG, n, tgt.G4.p, tgt.table.p, tgt.grid, make_invmap(tgt), radius_sq(d), h->match_pos.p,
@@ -668,7 +672,7 @@ int e3d_init(int device) {
 }
 
 int e3d_set_nn_mode(int mode) {
-  if (mode < 0 || mode > 2) { e3d::set_last_error("e3d_set_nn_mode: mode must be 0, 1 or 2"); return E3D_ERR_INVALID; }
+  if (mode < 0 || mode > 3) { e3d::set_last_error("e3d_set_nn_mode: mode must be 0..3"); return E3D_ERR_INVALID; }
   g_nn_mode = mode;
   return 0;
 }
@@ -795,14 +799,17 @@ int64_t e3d_find_correspondences(const float* sxyz, size_t ns, const float* txyz
     if (nt > 0) {
       h->match_pos.reserve(ns); h->match_d2.reserve(ns);
       const int mode = g_nn_mode;
-      const bool dense = mode == 2 || (mode == 0 && (double)tgt.n >= 4.0 * (double)std::max(tgt.n_cells, 1u));
+      const bool dense = mode >= 2 || (mode == 0 && (double)tgt.n >= 4.0 * (double)std::max(tgt.n_cells, 1u));
       const unsigned* order = nullptr;
       if (dense) {
         h->keys_a.reserve(ns); h->keys_b.reserve(ns); h->vals_a.reserve(ns); h->vals_b.reserve(ns);
         const InvMap im = make_invmap(tgt);
         launch_query_keys(src.G4.p, ns, tgt.grid, im, tgt.qrange, h->keys_a.p, h->vals_a.p, s);
         sort_pairs_u64_u32(h->keys_a.p, h->keys_b.p, h->vals_a.p, h->vals_b.p, ns, tgt.key_bits, h->sort_temp, s);
-        launch_nn_cells(src.G4.p, h->vals_b.p, ns, tgt.G4.p, tgt.table.p, tgt.has_dense ? tgt.dense_start.p : nullptr, tgt.grid, im, tgt.qrange, radius_sq(d), h->match_pos.p, h->match_d2.p, s);
+        if (tgt.has_dense && mode != 2)
+          launch_nn_rows(src.G4.p, h->vals_b.p, ns, tgt.G4.p, tgt.dense_start.p, tgt.grid, im, tgt.qrange, radius_sq(d), h->match_pos.p, h->match_d2.p, s);
+        else
+          launch_nn_cells(src.G4.p, h->vals_b.p, ns, tgt.G4.p, tgt.table.p, nullptr, tgt.grid, im, tgt.qrange, radius_sq(d), h->match_pos.p, h->match_d2.p, s);
         order = h->vals_b.p;
       } else {
         launch_nn_query(src.G4.p, ns, tgt.G4.p, tgt.table.p, tgt.grid, make_invmap(tgt), radius_sq(d), h->match_pos.p, h->match_d2.p, s);

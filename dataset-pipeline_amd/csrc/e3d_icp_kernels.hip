@@ -11,6 +11,8 @@
 //
 // Reference loops covered: a3 (transform+bbox), a5 (1-NN within radius),
 // a6 (count / distance sum), a7 (accumulate), a8 (cost).
+#include <cstdlib>
+
 #include "e3d_icp_kernels.hpp"
 
 #pragma clang fp contract(off)
@@ -429,6 +431,235 @@ __global__ __launch_bounds__(kBlock, 6) void k_nn_cells(const float4* __restrict
   if (valid) { match_pos[pos] = best_pos; match_d2[pos] = best_d2; }
 }
 
+// -------------------------------------------------------------------------------------------------
+// Dense-directory path of a5 (the default on MI355X: 4 B per grid cell is cheap in 288 GB of HBM).
+// Queries are sorted by target cell in (z, y, x) order -- the same order the target's points are stored
+// in -- so the candidates of a run of cells [xa, xb] inside one neighbour ROW (y+dy, z+dz) are ONE contiguous
+// run [S[lin(xa)], S[lin(xb)+1]) of the target array.  A wave handles a whole ROW SEGMENT of its 64 sorted
+// queries at once (consecutive lanes in the same row, x-extent <= kRowSpan cells): 18 directory words
+// (one round trip), the 9 union runs staged in LDS with all loads in flight together (second round trip),
+// then lanes arranged as (query slot) x (candidate slice) scan the staged superset.  Candidates outside a
+// query's own 27 cells are farther than the radius, so they can never win: results are identical to the
+// other two kernels.
+//
+// The scan is VALU-issue bound (rocprofv3 PMC: SQ_ACTIVE_INST_VALU ~ 75 % of the kernel), so the inner loop is
+// written for instruction count: candidates are staged as SoA PAIRS {x0,x1,y0,y1} {z0,z1} so that the three
+// subtractions, three squares and two sums run as packed f32 ops (v_pk_add_f32 / v_pk_mul_f32, each still an
+// individually rounded IEEE op in the (dx*dx + dy*dy) + dz*dz order); the bucket is padded with +inf sentinels
+// so the loop is uniform and branch free with four pairs prefetched; and the (d2, index) tie rule is applied
+// lazily: the fast loop tracks only (d2, slot) with a strict '<' and records whether ANY equality was seen, in
+// which case (rare: lattices, duplicates) the batch is re-scanned with the full comparator.
+// -------------------------------------------------------------------------------------------------
+typedef float f2_t __attribute__((ext_vector_type(2)));
+
+struct RowLds {
+  float4 xy[kRowCap / 2 + kWave];   // {x0, x1, y0, y1} per candidate pair
+  float2 z[kRowCap / 2 + kWave];    // {z0, z1}
+  unsigned oi[kRowCap];             // original target index (tie rule, result)
+};
+
+__device__ __forceinline__ void row_scan_fast(const RowLds& L, int sl, int slices, int trips, unsigned base, float qx,
+                                              float qy, float qz, float& bd, unsigned& bt, bool& tie) {
+  const f2_t QX = {qx, qx}, QY = {qy, qy}, QZ = {qz, qz};
+  int p = sl;
+  int i = 0;
+#define E3D_ROW_STEP(A, Zv, P)                                                            \
+  {                                                                                        \
+    const f2_t cx = {A.x, A.y}, cy = {A.z, A.w}, cz = {Zv.x, Zv.y};                         \
+    const f2_t dx = QX - cx, dy = QY - cy, dz = QZ - cz;                                    \
+    f2_t d = dx * dx;                                                                      \
+    d = d + dy * dy;                                                                       \
+    d = d + dz * dz;                                                                       \
+    tie = tie || (d.x == bd);                                                              \
+    const bool l0 = d.x < bd;                                                              \
+    bd = l0 ? d.x : bd;                                                                    \
+    bt = l0 ? base + 2u * (unsigned)(P) : bt;                                              \
+    tie = tie || (d.y == bd);                                                              \
+    const bool l1 = d.y < bd;                                                              \
+    bd = l1 ? d.y : bd;                                                                    \
+    bt = l1 ? base + 2u * (unsigned)(P) + 1u : bt;                                         \
+  }
+  for (; i + 4 <= trips; i += 4) {
+    const float4 a0 = L.xy[p], a1 = L.xy[p + slices], a2 = L.xy[p + 2 * slices], a3 = L.xy[p + 3 * slices];
+    const float2 z0 = L.z[p], z1 = L.z[p + slices], z2 = L.z[p + 2 * slices], z3 = L.z[p + 3 * slices];
+    E3D_ROW_STEP(a0, z0, p)
+    E3D_ROW_STEP(a1, z1, p + slices)
+    E3D_ROW_STEP(a2, z2, p + 2 * slices)
+    E3D_ROW_STEP(a3, z3, p + 3 * slices)
+    p += 4 * slices;
+  }
+  for (; i < trips; ++i) {
+    const float4 a0 = L.xy[p];
+    const float2 z0 = L.z[p];
+    E3D_ROW_STEP(a0, z0, p)
+    p += slices;
+  }
+#undef E3D_ROW_STEP
+}
+
+// exact re-scan with the full (d2, original index) comparator
+__device__ __forceinline__ void row_scan_exact(const RowLds& L, int sl, int slices, int trips, unsigned base, unsigned nb,
+                                               float qx, float qy, float qz, float& bd, unsigned& boi, unsigned& bt) {
+  int p = sl;
+  for (int i = 0; i < trips; ++i, p += slices) {
+    const float4 A = L.xy[p];
+    const float2 Zv = L.z[p];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const unsigned t = 2u * (unsigned)p + (unsigned)hh;
+      if (t >= nb) continue;
+      const float d2 = sqdist_l2(qx, qy, qz, hh ? A.y : A.x, hh ? A.w : A.z, hh ? Zv.y : Zv.x);
+      const unsigned oi = L.oi[t];
+      if (d2 < bd || (d2 == bd && oi < boi)) { bd = d2; boi = oi; bt = base + t; }
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock, 3) void k_nn_rows(const float4* __restrict__ Gsrc, const unsigned* __restrict__ order,
+                                                       size_t n, const float4* __restrict__ Gtgt,
+                                                       const unsigned* __restrict__ S, GridDesc g, InvMap im,
+                                                       QueryRange qr, float r2, int row_span,
+                                                       int* __restrict__ match_pos, float* __restrict__ match_d2) {
+  __shared__ RowLds lds[kBlock / kWave];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  RowLds& L = lds[w];
+  float* const xyf = reinterpret_cast<float*>(L.xy);
+  float* const zf = reinterpret_cast<float*>(L.z);
+  const size_t pos = ((size_t)blockIdx.x * (kBlock / kWave) + w) * kWave + lane;
+  const bool valid = pos < n;
+  const unsigned j = valid ? order[pos] : 0u;
+  const float4 q = valid ? Gsrc[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+  int cx = 0, cy = 0, cz = 0;
+  const unsigned long long key = valid ? query_cell_key(q, im, g, qr, cx, cy, cz) : kEmptyKey;
+  const int kx = cx - qr.lo[0], ky = cy - qr.lo[1], kz = cz - qr.lo[2];   // in [0, D) for valid keys
+
+  float best_d2 = r2;      // strict radius (see k_nn_query)
+  unsigned best_oi = 0u;
+  int best_pos = -1;
+  const float kInf = __uint_as_float(0x7f800000u);
+
+  unsigned long long remaining = __ballot(key != kEmptyKey);
+  while (remaining) {
+    const int f = __ffsll((long long)remaining) - 1;
+    const int fky = rdlane_i(ky, f), fkz = rdlane_i(kz, f), fkx = rdlane_i(kx, f);
+    // segment: lanes of the same row whose cells lie within kRowSpan cells of the first (contiguous: sorted input)
+    const unsigned long long seg =
+        __ballot(key != kEmptyKey && ky == fky && kz == fkz && (unsigned)(kx - fkx) <= (unsigned)row_span) & remaining;
+    const int a = __popcll(seg);
+    const int last = 63 - __clzll((long long)seg);
+    const int lkx = rdlane_i(kx, last);
+    const int xa = max(fkx - 1, 0), xb = min(lkx + 1, (int)qr.D[0] - 1);
+
+    // directory words of the 9 neighbour rows (lanes 0..8)
+    unsigned dst = 0u, dcnt = 0u;
+    if (lane < 9) {
+      const int y = fky + (lane % 3) - 1, z = fkz + (lane / 3) - 1;
+      if (y >= 0 && z >= 0 && y < (int)qr.D[1] && z < (int)qr.D[2]) {
+        const size_t row = ((size_t)z * qr.D[1] + (size_t)y) * qr.D[0];
+        dst = S[row + xa];
+        dcnt = S[row + xb + 1] - dst;
+      }
+    }
+    unsigned rs[9], rl[9];
+    unsigned total = 0;
+#pragma unroll
+    for (int r = 0; r < 9; ++r) { rs[r] = rdlane_u(dst, r); rl[r] = rdlane_u(dcnt, r); total += rl[r]; }
+
+    // lanes = (query slot) x (candidate slice)
+    int lg = 0;
+    while ((1 << lg) < a) ++lg;
+    const int A2 = 1 << lg, slices = kWave >> lg;
+    const int qi = lane & (A2 - 1), sl = lane >> lg;
+    const int owner = (f + qi) & 63;
+    const float qx = __shfl(q.x, owner, 64), qy = __shfl(q.y, owner, 64), qz = __shfl(q.z, owner, 64);
+    float lb_d2 = r2;
+    unsigned lb_oi = 0u;
+    unsigned lb_t = 0xFFFFFFFFu;      // flat index into the concatenated 9 runs
+
+    for (unsigned base = 0; base < total; base += kRowCap) {
+      const unsigned nb = min((unsigned)kRowCap, total - base);
+      const int np = (int)((nb + 1u) >> 1);
+      const int trips = (np + slices - 1) / slices;
+      // ---- stage [base, base + nb) of the concatenated runs: resolve, issue all loads, then store ----
+      unsigned m[kRowCap / kWave];
+#pragma unroll
+      for (int k = 0; k < kRowCap / kWave; ++k) m[k] = 0xFFFFFFFFu;
+      {
+        unsigned p = 0;
+#pragma unroll
+        for (int r = 0; r < 9; ++r) {
+#pragma unroll
+          for (int k = 0; k < kRowCap / kWave; ++k) {
+            const unsigned t = base + (unsigned)(k * kWave + lane) - p;     // offset inside run r (wraps if before it)
+            if (t < rl[r]) m[k] = rs[r] + t;
+          }
+          p += rl[r];
+        }
+      }
+      float4 cv[kRowCap / kWave];
+#pragma unroll
+      for (int k = 0; k < kRowCap / kWave; ++k) cv[k] = (m[k] != 0xFFFFFFFFu) ? Gtgt[m[k]] : make_float4(kInf, 0.f, 0.f, 0.f);
+      const unsigned padded = 2u * (unsigned)(trips * slices);            // candidates incl. sentinels (<= nb + 2*64)
+#pragma unroll
+      for (int k = 0; k < kRowCap / kWave + 2; ++k) {
+        const unsigned t = (unsigned)(k * kWave + lane);
+        if (t < padded) {
+          const float4 c = (k < kRowCap / kWave) ? cv[k < kRowCap / kWave ? k : 0] : make_float4(kInf, 0.f, 0.f, 0.f);
+          const unsigned pp = t >> 1, hh = t & 1u;
+          xyf[4u * pp + hh] = c.x;          // x = +inf for slots past nb: d2 = +inf never wins and never ties
+          xyf[4u * pp + 2u + hh] = c.y;
+          zf[2u * pp + hh] = c.z;
+          if (t < nb) L.oi[t] = __float_as_uint(c.w);
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+      const float in_d2 = lb_d2;
+      const unsigned in_oi = lb_oi, in_t = lb_t;
+      bool tie = false;
+      row_scan_fast(L, sl, slices, trips, base, qx, qy, qz, lb_d2, lb_t, tie);
+      if (__ballot(tie)) {                    // rare: some exact f32 distance tie -> full comparator for this batch
+        lb_d2 = in_d2; lb_oi = in_oi; lb_t = in_t;
+        row_scan_exact(L, sl, slices, trips, base, nb, qx, qy, qz, lb_d2, lb_oi, lb_t);
+      } else if (lb_t != in_t) {
+        lb_oi = L.oi[lb_t - base];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    // flat index of the slice winner -> position in the target array
+    int lb_pos = -1;
+    {
+      unsigned p = 0;
+#pragma unroll
+      for (int r = 0; r < 9; ++r) {
+        if (lb_t - p < rl[r]) lb_pos = (int)(rs[r] + (lb_t - p));
+        p += rl[r];
+      }
+    }
+    // min over the candidate slices of each query slot
+    for (int stx = A2; stx < kWave; stx <<= 1) {
+      const float od2 = __shfl_xor(lb_d2, stx, 64);
+      const unsigned ooi = (unsigned)__shfl_xor((int)lb_oi, stx, 64);
+      const int opos = __shfl_xor(lb_pos, stx, 64);
+      if (od2 < lb_d2 || (od2 == lb_d2 && ooi < lb_oi)) { lb_d2 = od2; lb_oi = ooi; lb_pos = opos; }
+    }
+    // hand the result to the lane that owns the query
+    const int srcl = (lane - f) & 63;
+    const float rd2 = __shfl(lb_d2, srcl, 64);
+    const unsigned roi = (unsigned)__shfl((int)lb_oi, srcl, 64);
+    const int rpos = __shfl(lb_pos, srcl, 64);
+    if ((seg >> lane) & 1ull) {
+      if (rd2 < best_d2 || (rd2 == best_d2 && roi < best_oi)) { best_d2 = rd2; best_oi = roi; best_pos = rpos; }
+    }
+    remaining &= ~seg;
+  }
+  if (valid) { match_pos[pos] = best_pos; match_d2[pos] = best_d2; }
+}
+
 // flags -> per-block counts (first stage of the order-preserving compaction)
 __global__ __launch_bounds__(kBlock) void k_match_block_counts(const int* __restrict__ match_pos, size_t n,
                                                                unsigned* __restrict__ block_counts,
@@ -843,6 +1074,25 @@ void launch_nn_cells(const float4* Gsrc, const unsigned* order, size_t n, const 
   if (!n) return;
   hipLaunchKernelGGL(k_nn_cells, dim3((unsigned)div_up(n, kBlock)), dim3(kBlock), 0, s, Gsrc, order, n, Gtgt, table,
                      dense_start, g, im, qr, r2, match_pos, match_d2);
+}
+
+static int row_span_setting() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("E3D_ROW_SPAN");      // tuning knob: x-extent (cells) of a row segment
+    v = e ? atoi(e) : kRowSpan;
+    if (v < 0) v = 0;
+    if (v > 62) v = 62;
+  }
+  return v;
+}
+
+void launch_nn_rows(const float4* Gsrc, const unsigned* order, size_t n, const float4* Gtgt, const unsigned* dense_start,
+                    const GridDesc& g, const InvMap& im, const QueryRange& qr, float r2, int* match_pos, float* match_d2,
+                    hipStream_t s) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_nn_rows, dim3((unsigned)div_up(n, kBlock)), dim3(kBlock), 0, s, Gsrc, order, n, Gtgt, dense_start,
+                     g, im, qr, r2, row_span_setting(), match_pos, match_d2);
 }
 
 void launch_dense_counts(const unsigned long long* keys, size_t n, const QueryRange& qr, unsigned* counts, hipStream_t s) {

@@ -15,6 +15,8 @@ enum { kModeCost = 0,      // cost only
 };
 constexpr int kLmSlot = 91;          // doubles per block partial / per set result
 constexpr int kMaxBboxBlocks = 2048;
+constexpr int kRowCap = 512;         // candidates staged in LDS per wave and batch (k_nn_rows): ~10 KB
+constexpr int kRowSpan = 4;          // max x-extent (cells) of a row segment handled at once (k_nn_rows)
 constexpr int kNNCap = 256;          // candidates staged in LDS per wave and batch (k_nn_cells)
 
 // Target-grid cell range a query must fall into to have any candidate (cells of the target's points +- 2),
@@ -52,6 +54,9 @@ void launch_query_keys(const float4* Gsrc, size_t n, const GridDesc& g, const In
 void launch_nn_cells(const float4* Gsrc, const unsigned* order, size_t n, const float4* Gtgt, const HashEntry* table,
                      const unsigned* dense_start, const GridDesc& g, const InvMap& im, const QueryRange& qr, float r2,
                      int* match_pos, float* match_d2, hipStream_t s);
+void launch_nn_rows(const float4* Gsrc, const unsigned* order, size_t n, const float4* Gtgt, const unsigned* dense_start,
+                    const GridDesc& g, const InvMap& im, const QueryRange& qr, float r2, int* match_pos, float* match_d2,
+                    hipStream_t s);
 void launch_dense_counts(const unsigned long long* keys, size_t n, const QueryRange& qr, unsigned* counts, hipStream_t s);
 // in-place exclusive MAX scan of n unsigned values (rocPRIM, e3d_sort.hip); one-off per grid build
 void exclusive_max_scan_u32(unsigned* data, size_t n, DevBuf<char>& temp, hipStream_t s);

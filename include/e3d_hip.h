@@ -44,8 +44,10 @@ int e3d_abi_version(void);
 int e3d_init(int device);
 const char* e3d_last_error(void);
 /* Nearest-neighbour kernel selection for handles created afterwards: 0 = automatic (by points per grid
- * cell), 1 = one thread per query, 2 = queries sorted by target cell + LDS-staged candidate buckets.
- * Both kernels are exact and return identical results; this only exists for tests and profiling. */
+ * cell and grid size), 1 = one thread per query (sparse data), 2 = queries sorted by target cell + LDS-staged
+ * candidate buckets found through the hash table (huge sparse grids), 3 = the same with the dense cell-start
+ * directory and whole row segments per wave (default for dense scans).  All three are exact and return
+ * identical results; the switch only exists for tests and profiling. */
 int e3d_set_nn_mode(int mode);
 
 /* ---- (A) icp::PointToPlaneICP  (src/icp/icp_point_to_plane.h:39-80) --------------------- */

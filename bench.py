@@ -145,7 +145,7 @@ def main():
         dt,
         sum(r["correspondences"] for r in recs), sum(r["queries"] for r in recs),
         sum(r["t_lm_kernel_ms"] for r in recs), sum(r["t_nn_query_ms"] for r in recs),
-        sum(r["full_passes"] + r["cost_passes"] for r in recs),
+        sum(r["full_passes"] + r["cost_passes"] + r["multi_cost_passes"] for r in recs),
         sum(r["t_transform_ms"] for r in recs), sum(r["t_nn_ms"] for r in recs), sum(r["t_lm_ms"] for r in recs),
     ], dtype=np.float64)
     if world > 1:

@@ -28,7 +28,8 @@ class PairRecord(C.Structure):
 
 class IterRecord(C.Structure):
     _fields_ = [("iteration", C.c_int32), ("inner_iterations", C.c_int32), ("full_passes", C.c_int32),
-                ("cost_passes", C.c_int32), ("correspondences", C.c_int64), ("queries", C.c_int64),
+                ("cost_passes", C.c_int32), ("multi_cost_passes", C.c_int32), ("reserved_", C.c_int32),
+                ("correspondences", C.c_int64), ("queries", C.c_int64),
                 ("initial_cost", C.c_double), ("final_cost", C.c_double),
                 ("t_transform_ms", C.c_double), ("t_nn_ms", C.c_double), ("t_lm_ms", C.c_double),
                 ("t_lm_kernel_ms", C.c_double), ("t_nn_query_ms", C.c_double)]

@@ -97,6 +97,8 @@ struct e3d_icp {
   size_t corr_used = 0;
   DevBuf<LmSet> d_sets;
   PinBuf<LmSet> h_sets;
+  DevBuf<LmPose> d_poses;
+  PinBuf<LmPose> h_poses;
   DevBuf<int> d_block_set;
   DevBuf<double> d_partial, d_setsum;
   PinBuf<double> h_setsum;
@@ -299,8 +301,15 @@ static void find_pair(e3d_icp* h, Cloud& src, Cloud& tgt, float d, PairJob& job,
   if (dense) {
     h->keys_a.reserve(n); h->keys_b.reserve(n); h->vals_a.reserve(n); h->vals_b.reserve(n);
     const InvMap im = make_invmap(tgt);
-    launch_query_keys(srcG, n, tgt.grid, im, tgt.qrange, h->keys_a.p, h->vals_a.p, s);
-    sort_pairs_u64_u32(h->keys_a.p, h->keys_b.p, h->vals_a.p, h->vals_b.p, n, tgt.key_bits, h->sort_temp, s);
+    if (tgt.key_bits <= 31) {   // 8-byte (key, index) pairs through the radix passes
+      unsigned* ka = reinterpret_cast<unsigned*>(h->keys_a.p);
+      unsigned* kb = reinterpret_cast<unsigned*>(h->keys_b.p);
+      launch_query_keys32(srcG, n, tgt.grid, im, tgt.qrange, ka, h->vals_a.p, s);
+      sort_pairs_u32_u32(ka, kb, h->vals_a.p, h->vals_b.p, n, tgt.key_bits, h->sort_temp, s);
+    } else {
+      launch_query_keys(srcG, n, tgt.grid, im, tgt.qrange, h->keys_a.p, h->vals_a.p, s);
+      sort_pairs_u64_u32(h->keys_a.p, h->keys_b.p, h->vals_a.p, h->vals_b.p, n, tgt.key_bits, h->sort_temp, s);
+    }
     if (tgt.has_dense && h->nn_mode != 2)
       launch_nn_rows(srcG, h->vals_b.p, n, tgt.G4.p, tgt.dense_start.p, tgt.grid, im, tgt.qrange, radius_sq(d),
                      h->match_pos.p, h->match_d2.p, s);
@@ -434,6 +443,45 @@ static void lm_evaluate(e3d_icp* h, LmSystem& L, const std::vector<SE3f>& poses,
   }
 }
 
+// Costs of up to kLmMaxPoses candidate pose sets in one pass (k_lm_cost_multi); costs[k] for cand[k].
+static void lm_evaluate_costs(e3d_icp* h, LmSystem& L, const std::vector<std::vector<SE3f>>& cand, std::vector<double>& costs,
+                              e3d_icp_iter_record& rec) {
+  hipStream_t s = h->stream;
+  const int ns = (int)L.sets.size();
+  const int np = (int)cand.size();
+  costs.assign(np, 0.0);
+  if (ns > 0) {
+    h->h_poses.reserve((size_t)np * ns);
+    h->d_poses.reserve((size_t)kLmMaxPoses * ns);
+    for (int k = 0; k < np; ++k)
+      for (int i = 0; i < ns; ++i) {
+        LmPose& P = h->h_poses.p[(size_t)k * ns + i];
+        const SE3f& ps = cand[k][L.sets[i]->impl_src];
+        const SE3f& pt = cand[k][L.sets[i]->impl_tgt];
+        quat_to_matrix<float>(ps.q.w, ps.q.x, ps.q.y, ps.q.z, P.Rs);
+        quat_to_matrix<float>(pt.q.w, pt.q.x, pt.q.y, pt.q.z, P.Rt);
+        for (int c = 0; c < 3; ++c) { P.ts[c] = ps.t[c]; P.tt[c] = pt.t[c]; }
+      }
+    E3D_HIP(hipMemcpyAsync(h->d_poses.p, h->h_poses.p, sizeof(LmPose) * (size_t)np * ns, hipMemcpyHostToDevice, s));
+    if (!h->lm_timer) h->lm_timer.reset(new EventTimer());
+    EventTimer& tm = *h->lm_timer;
+    tm.start(s);
+    launch_lm_cost_multi(h->cA.p, h->cB.p, h->cC.p, h->d_sets.p, h->d_poses.p, ns, np, h->d_block_set.p, L.total_blocks,
+                         h->d_partial.p, s);
+    tm.stop(s);
+    launch_lm_reduce(h->d_partial.p, h->d_sets.p, ns, kLmSlot, h->d_setsum.p, s);
+    copy_out(h->h_setsum.p, h->d_setsum.p, sizeof(double) * kLmSlot * ns, s);
+    sync(h);
+    rec.t_lm_kernel_ms += tm.ms();
+    for (int i = 0; i < ns; ++i)
+      for (int k = 0; k < np; ++k) costs[k] += h->h_setsum.p[(size_t)kLmSlot * i + k];
+  }
+  rec.multi_cost_passes++;
+  if (h->world > 1) {
+    if (h->allreduce(costs.data(), costs.size(), h->allreduce_user) != 0) throw Error(E3D_ERR_INVALID, "allreduce callback failed");
+  }
+}
+
 static void lm_prepare(e3d_icp* h, LmSystem& L, std::vector<PairJob>& jobs) {
   // group this rank's non-empty sets by full-pass mode; assign LM blocks
   L.sets.clear();
@@ -490,31 +538,43 @@ static void lm_compute(e3d_icp* h, LmSystem& L, std::vector<SE3f>& poses, e3d_ic
   rec.initial_cost = cost;
   rec.final_cost = cost;
   std::vector<SE3f> upd(poses.size());
+  auto candidate = [&](double lam, std::vector<SE3f>& out) {
+    Hl = H;
+    for (int i = 0; i < nv; ++i) Hl[(size_t)i * nv + i] += lam;            // additive damping (impl.h:223)
+    if (nv > 0) ldlt_solve_upper(Hl.data(), nv, b.data(), x.data(), W, perm);
+    out.resize(poses.size());
+    out[0] = poses[0];
+    for (size_t ci = 1; ci < poses.size(); ++ci) out[ci] = se3_apply_update(&x[6 * (ci - 1)], poses[ci]);   // impl.h:235
+  };
   for (int it = 0; it < h->max_inner; ++it) {
     rec.inner_iterations++;
     bool applied = false;
-    for (int lm = 0; lm < 10; ++lm) {
-      Hl = H;
-      for (int i = 0; i < nv; ++i) Hl[(size_t)i * nv + i] += lambda;       // additive damping (impl.h:223)
-      if (nv > 0) ldlt_solve_upper(Hl.data(), nv, b.data(), x.data(), W, perm);
-      upd[0] = poses[0];
-      for (size_t ci = 1; ci < poses.size(); ++ci) upd[ci] = se3_apply_update(&x[6 * (ci - 1)], poses[ci]);   // impl.h:235
-      // The first try of an iteration is usually accepted: evaluate cost AND the next iteration's H, b in
-      // one pass.  Later tries are usually rejected: cost only, and one extra full pass if accepted.
-      const bool full = (lm == 0);
-      lm_evaluate(h, L, upd, full, Hn, bn, new_cost, rec);
-      if (new_cost < cost) {
-        if (!full) {
-          double c2;
-          lm_evaluate(h, L, upd, true, Hn, bn, c2, rec);
-          new_cost = c2;   // identical by construction (same kernels' cost path and reduction tree)
-        }
-        poses = upd; H.swap(Hn); b.swap(bn); cost = new_cost;
-        lambda = 0.5f * lambda;
+    // try 0 is usually accepted: evaluate its cost together with the next iteration's H and b (one fused pass)
+    candidate(lambda, upd);
+    lm_evaluate(h, L, upd, true, Hn, bn, new_cost, rec);
+    if (new_cost < cost) {
+      poses = upd; H.swap(Hn); b.swap(bn); cost = new_cost;
+      lambda = 0.5f * lambda;
+      applied = true;
+    } else {
+      lambda = 2.f * lambda;
+      // tries 1..9 (lambda doubled after every rejection) only differ in their poses: one multi-pose cost pass,
+      // then the first try that lowers the cost is taken -- the reference's sequential decision
+      std::vector<std::vector<SE3f>> cand(9);
+      std::vector<double> lam(9), costs;
+      double l = lambda;
+      for (int k = 0; k < 9; ++k) { lam[k] = l; candidate(l, cand[k]); l = 2.f * l; }
+      lm_evaluate_costs(h, L, cand, costs, rec);
+      int hit = -1;
+      for (int k = 0; k < 9; ++k) if (costs[k] < cost) { hit = k; break; }
+      if (hit >= 0) {
+        double c2;
+        lm_evaluate(h, L, cand[hit], true, Hn, bn, c2, rec);   // H, b at the accepted pose; c2 == costs[hit] bit for bit
+        poses = cand[hit]; H.swap(Hn); b.swap(bn); cost = c2;
+        lambda = 0.5f * lam[hit];
         applied = true;
-        break;
       } else {
-        lambda = 2.f * lambda;
+        lambda = l;       // ten rejections: lambda doubled ten times
       }
     }
     rec.final_cost = cost;

@@ -290,6 +290,19 @@ __global__ __launch_bounds__(kBlock) void k_query_keys(const float4* __restrict_
   vals[j] = (unsigned)j;
 }
 
+// 32-bit variant of the sort keys (grids with fewer than 2^32 - 1 cells in the query range): 8 instead of 12
+// bytes per (key, index) pair through every radix pass.
+__global__ __launch_bounds__(kBlock) void k_query_keys32(const float4* __restrict__ Gsrc, size_t n, GridDesc g, InvMap im,
+                                                         QueryRange qr, unsigned* __restrict__ keys,
+                                                         unsigned* __restrict__ vals) {
+  const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  int cx, cy, cz;
+  const unsigned long long k = query_cell_key(Gsrc[j], im, g, qr, cx, cy, cz);
+  keys[j] = (k == kEmptyKey) ? 0xFFFFFFFFu : (unsigned)k;
+  vals[j] = (unsigned)j;
+}
+
 __device__ __forceinline__ int rdlane_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
 __device__ __forceinline__ unsigned rdlane_u(unsigned v, int l) { return (unsigned)__builtin_amdgcn_readlane((int)v, l); }
 
@@ -453,48 +466,74 @@ __global__ __launch_bounds__(kBlock, 6) void k_nn_cells(const float4* __restrict
 typedef float f2_t __attribute__((ext_vector_type(2)));
 
 struct RowLds {
-  float4 xy[kRowCap / 2 + kWave];   // {x0, x1, y0, y1} per candidate pair
-  float2 z[kRowCap / 2 + kWave];    // {z0, z1}
+  float4 xy[kRowCap / 2 + 2 * kWave];   // {x0, x1, y0, y1} per candidate pair (+ sentinel padding)
+  float2 z[kRowCap / 2 + 2 * kWave];    // {z0, z1}
   unsigned oi[kRowCap];             // original target index (tie rule, result)
 };
 
-__device__ __forceinline__ void row_scan_fast(const RowLds& L, int sl, int slices, int trips, unsigned base, float qx,
-                                              float qy, float qz, float& bd, unsigned& bt, bool& tie) {
+// Fast scan: per QUAD of candidates (two staged pairs) only the minimum distance is compared with the running
+// best -- 2 v_min + 2 v_cmp + 2 v_cndmask per four candidates instead of a compare/select chain per candidate.
+// The winning quad is re-evaluated exactly afterwards (row_scan_resolve); `tie` records whether a quad minimum
+// ever EQUALLED the running best (cross-quad tie), in which case the caller re-scans the batch with the full
+// comparator.  trips2 = number of quads per lane; quad i of a lane covers pairs sl + 2*i*slices and
+// sl + (2*i+1)*slices (sentinel padded).
+__device__ __forceinline__ f2_t row_pair_d2(const float4 A, const float2 Zv, const f2_t QX, const f2_t QY, const f2_t QZ) {
+  const f2_t cx = {A.x, A.y}, cy = {A.z, A.w}, cz = {Zv.x, Zv.y};
+  const f2_t dx = QX - cx, dy = QY - cy, dz = QZ - cz;
+  f2_t d = dx * dx;
+  d = d + dy * dy;
+  d = d + dz * dz;
+  return d;
+}
+
+__device__ __forceinline__ void row_scan_fast(const RowLds& L, int sl, int slices, int trips2, float qx, float qy,
+                                              float qz, float& bd, int& bq, bool& tie) {
   const f2_t QX = {qx, qx}, QY = {qy, qy}, QZ = {qz, qz};
   int p = sl;
   int i = 0;
-#define E3D_ROW_STEP(A, Zv, P)                                                            \
-  {                                                                                        \
-    const f2_t cx = {A.x, A.y}, cy = {A.z, A.w}, cz = {Zv.x, Zv.y};                         \
-    const f2_t dx = QX - cx, dy = QY - cy, dz = QZ - cz;                                    \
-    f2_t d = dx * dx;                                                                      \
-    d = d + dy * dy;                                                                       \
-    d = d + dz * dz;                                                                       \
-    tie = tie || (d.x == bd);                                                              \
-    const bool l0 = d.x < bd;                                                              \
-    bd = l0 ? d.x : bd;                                                                    \
-    bt = l0 ? base + 2u * (unsigned)(P) : bt;                                              \
-    tie = tie || (d.y == bd);                                                              \
-    const bool l1 = d.y < bd;                                                              \
-    bd = l1 ? d.y : bd;                                                                    \
-    bt = l1 ? base + 2u * (unsigned)(P) + 1u : bt;                                         \
+#define E3D_QUAD_STEP(A0, Z0, A1, Z1, I)                                      \
+  {                                                                          \
+    const f2_t d0 = row_pair_d2(A0, Z0, QX, QY, QZ);                          \
+    const f2_t d1 = row_pair_d2(A1, Z1, QX, QY, QZ);                          \
+    const float mq = fminf(fminf(d0.x, d0.y), fminf(d1.x, d1.y));            \
+    const bool lt = mq < bd, le = mq <= bd;                                  \
+    tie = tie || (le && !lt);                                                \
+    bd = lt ? mq : bd;                                                       \
+    bq = lt ? (I) : bq;                                                      \
   }
-  for (; i + 4 <= trips; i += 4) {
+  for (; i + 2 <= trips2; i += 2) {
     const float4 a0 = L.xy[p], a1 = L.xy[p + slices], a2 = L.xy[p + 2 * slices], a3 = L.xy[p + 3 * slices];
     const float2 z0 = L.z[p], z1 = L.z[p + slices], z2 = L.z[p + 2 * slices], z3 = L.z[p + 3 * slices];
-    E3D_ROW_STEP(a0, z0, p)
-    E3D_ROW_STEP(a1, z1, p + slices)
-    E3D_ROW_STEP(a2, z2, p + 2 * slices)
-    E3D_ROW_STEP(a3, z3, p + 3 * slices)
+    E3D_QUAD_STEP(a0, z0, a1, z1, i)
+    E3D_QUAD_STEP(a2, z2, a3, z3, i + 1)
     p += 4 * slices;
   }
-  for (; i < trips; ++i) {
-    const float4 a0 = L.xy[p];
-    const float2 z0 = L.z[p];
-    E3D_ROW_STEP(a0, z0, p)
-    p += slices;
+  for (; i < trips2; ++i) {
+    const float4 a0 = L.xy[p], a1 = L.xy[p + slices];
+    const float2 z0 = L.z[p], z1 = L.z[p + slices];
+    E3D_QUAD_STEP(a0, z0, a1, z1, i)
+    p += 2 * slices;
   }
-#undef E3D_ROW_STEP
+#undef E3D_QUAD_STEP
+}
+
+// exact (d2, original index) comparator over the four candidates of quad `bq` of this lane
+__device__ __forceinline__ void row_scan_resolve(const RowLds& L, int sl, int slices, int bq, unsigned base, unsigned nb,
+                                                 float qx, float qy, float qz, float& bd, unsigned& boi, unsigned& bt) {
+#pragma unroll
+  for (int h2 = 0; h2 < 2; ++h2) {
+    const int p = sl + (2 * bq + h2) * slices;
+    const float4 A = L.xy[p];
+    const float2 Zv = L.z[p];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const unsigned t = 2u * (unsigned)p + (unsigned)hh;
+      if (t >= nb) continue;
+      const float d2 = sqdist_l2(qx, qy, qz, hh ? A.y : A.x, hh ? A.w : A.z, hh ? Zv.y : Zv.x);
+      const unsigned oi = L.oi[t];
+      if (d2 < bd || (d2 == bd && oi < boi)) { bd = d2; boi = oi; bt = base + t; }
+    }
+  }
 }
 
 // exact re-scan with the full (d2, original index) comparator
@@ -579,7 +618,8 @@ __global__ __launch_bounds__(kBlock, 3) void k_nn_rows(const float4* __restrict_
     for (unsigned base = 0; base < total; base += kRowCap) {
       const unsigned nb = min((unsigned)kRowCap, total - base);
       const int np = (int)((nb + 1u) >> 1);
-      const int trips = (np + slices - 1) / slices;
+      const int trips2 = (np + 2 * slices - 1) / (2 * slices);   // quads (2 pairs) per lane
+      const int trips = 2 * trips2;
       // ---- stage [base, base + nb) of the concatenated runs: resolve, issue all loads, then store ----
       unsigned m[kRowCap / kWave];
 #pragma unroll
@@ -599,9 +639,9 @@ __global__ __launch_bounds__(kBlock, 3) void k_nn_rows(const float4* __restrict_
       float4 cv[kRowCap / kWave];
 #pragma unroll
       for (int k = 0; k < kRowCap / kWave; ++k) cv[k] = (m[k] != 0xFFFFFFFFu) ? Gtgt[m[k]] : make_float4(kInf, 0.f, 0.f, 0.f);
-      const unsigned padded = 2u * (unsigned)(trips * slices);            // candidates incl. sentinels (<= nb + 2*64)
+      const unsigned padded = 2u * (unsigned)(trips * slices);            // candidates incl. sentinels (<= nb + 4*64)
 #pragma unroll
-      for (int k = 0; k < kRowCap / kWave + 2; ++k) {
+      for (int k = 0; k < kRowCap / kWave + 4; ++k) {
         const unsigned t = (unsigned)(k * kWave + lane);
         if (t < padded) {
           const float4 c = (k < kRowCap / kWave) ? cv[k < kRowCap / kWave ? k : 0] : make_float4(kInf, 0.f, 0.f, 0.f);
@@ -619,12 +659,14 @@ __global__ __launch_bounds__(kBlock, 3) void k_nn_rows(const float4* __restrict_
       const float in_d2 = lb_d2;
       const unsigned in_oi = lb_oi, in_t = lb_t;
       bool tie = false;
-      row_scan_fast(L, sl, slices, trips, base, qx, qy, qz, lb_d2, lb_t, tie);
-      if (__ballot(tie)) {                    // rare: some exact f32 distance tie -> full comparator for this batch
+      int bq = -1;
+      float fd = lb_d2;
+      row_scan_fast(L, sl, slices, trips2, qx, qy, qz, fd, bq, tie);
+      if (__ballot(tie)) {                    // rare: cross-quad exact f32 distance tie -> full comparator for this batch
         lb_d2 = in_d2; lb_oi = in_oi; lb_t = in_t;
         row_scan_exact(L, sl, slices, trips, base, nb, qx, qy, qz, lb_d2, lb_oi, lb_t);
-      } else if (lb_t != in_t) {
-        lb_oi = L.oi[lb_t - base];
+      } else if (bq >= 0) {                   // winner quad: exact (d2, index) order among its four candidates
+        row_scan_resolve(L, sl, slices, bq, base, nb, qx, qy, qz, lb_d2, lb_oi, lb_t);
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -960,6 +1002,58 @@ __global__ __launch_bounds__(kBlock) void k_lm_pass(const float4* __restrict__ A
   }
 }
 
+// a8, batched: the LM tries 1..9 of one inner iteration (lambda doubled each time, icp_point_to_plane_impl.h:216-283)
+// only differ in the candidate poses, so their costs are evaluated in ONE pass over the correspondence planes: each
+// correspondence is loaded once and pushed through up to kLmMaxPoses pose sets.  Per pose the arithmetic, the
+// grid-stride order and the reduction tree are exactly those of k_lm_pass<kModeCost>, so every cost is bit-identical
+// to the one a separate pass would return; the host then takes the first try that lowers the cost, as the
+// reference's sequential loop does.
+__global__ __launch_bounds__(kBlock) void k_lm_cost_multi(const float4* __restrict__ A, const float4* __restrict__ B,
+                                                          const float4* __restrict__ C, const LmSet* __restrict__ sets,
+                                                          const LmPose* __restrict__ poses, int n_sets, int n_poses,
+                                                          const int* __restrict__ block_set, double* __restrict__ partial) {
+  const int gb = blockIdx.x;
+  const int si = block_set[gb];
+  LmSet S = sets[si];
+  double acc[kLmMaxPoses];
+#pragma unroll
+  for (int k = 0; k < kLmMaxPoses; ++k) acc[k] = 0.0;
+  const long long stride = (long long)S.nblocks * kBlock;
+  for (long long c = (long long)(gb - S.block_begin) * kBlock + threadIdx.x; c < S.n; c += stride) {
+    const float4 a = A[S.off + c], b = B[S.off + c], cc = C[S.off + c];
+#pragma unroll
+    for (int k = 0; k < kLmMaxPoses; ++k) {
+      if (k < n_poses) {
+        const LmPose P = poses[(size_t)k * n_sets + si];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) { S.Rs[i] = P.Rs[i]; S.Rt[i] = P.Rt[i]; }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { S.ts[i] = P.ts[i]; S.tt[i] = P.tt[i]; }
+        CorrRows R;
+        corr_rows<false, false>(S, a, b, cc, R);
+        acc[k] += (double)(R.r1 * R.r1);
+        acc[k] += (double)(R.r2 * R.r2);
+      }
+    }
+  }
+  __shared__ double s[kBlock / kWave][kLmMaxPoses];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < kLmMaxPoses; ++i) {
+    const double v = wave_sum(acc[i]);
+    if (lane == 0) s[w][i] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < kLmSlot) {
+    double v = 0.0;
+    if (threadIdx.x < kLmMaxPoses) {
+      v = s[0][threadIdx.x];
+      for (int k = 1; k < kBlock / kWave; ++k) v += s[k][threadIdx.x];
+    }
+    partial[(size_t)gb * kLmSlot + threadIdx.x] = v;
+  }
+}
+
 // one block per set: sum the set's block partials in a fixed order.  kRedParts threads share each of the
 // kLmSlot accumulators (interleaved block ranges, 4 independent loads in flight), then a fixed-order
 // LDS sum -- deterministic, and no 2048-long chain of dependent HBM loads.
@@ -1068,6 +1162,12 @@ void launch_query_keys(const float4* Gsrc, size_t n, const GridDesc& g, const In
   hipLaunchKernelGGL(k_query_keys, dim3((unsigned)div_up(n, kBlock)), dim3(kBlock), 0, s, Gsrc, n, g, im, qr, keys, vals);
 }
 
+void launch_query_keys32(const float4* Gsrc, size_t n, const GridDesc& g, const InvMap& im, const QueryRange& qr,
+                         unsigned* keys, unsigned* vals, hipStream_t s) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_query_keys32, dim3((unsigned)div_up(n, kBlock)), dim3(kBlock), 0, s, Gsrc, n, g, im, qr, keys, vals);
+}
+
 void launch_nn_cells(const float4* Gsrc, const unsigned* order, size_t n, const float4* Gtgt, const HashEntry* table,
                      const unsigned* dense_start, const GridDesc& g, const InvMap& im, const QueryRange& qr, float r2,
                      int* match_pos, float* match_d2, hipStream_t s) {
@@ -1139,6 +1239,13 @@ void launch_lm_pass(int mode, const float4* A, const float4* B, const float4* C,
       hipLaunchKernelGGL(k_lm_pass<kModeTwoCross>, dim3(nblocks), dim3(kBlock), 0, s, A, B, C, sets, block_set, block_base, partial);
       break;
   }
+}
+
+void launch_lm_cost_multi(const float4* A, const float4* B, const float4* C, const LmSet* sets, const LmPose* poses,
+                          int n_sets, int n_poses, const int* block_set, int nblocks, double* partial, hipStream_t s) {
+  if (nblocks <= 0) return;
+  hipLaunchKernelGGL(k_lm_cost_multi, dim3(nblocks), dim3(kBlock), 0, s, A, B, C, sets, poses, n_sets, n_poses, block_set,
+                     partial);
 }
 
 void launch_lm_reduce(const double* partial, const LmSet* sets, int n_sets, int nacc, double* out, hipStream_t s) {

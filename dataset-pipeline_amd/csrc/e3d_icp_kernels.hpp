@@ -13,6 +13,7 @@ enum { kModeCost = 0,      // cost only
        kModeTwo = 2,       // both sides, off-diagonal block would land in the lower triangle => dropped [QUIRK]
        kModeTwoCross = 3   // both sides, src block before tgt block: SS, TT, ST
 };
+constexpr int kLmMaxPoses = 9;       // LM tries 1..9 evaluated by one k_lm_cost_multi pass
 constexpr int kLmSlot = 91;          // doubles per block partial / per set result
 constexpr int kMaxBboxBlocks = 2048;
 constexpr int kRowCap = 512;         // candidates staged in LDS per wave and batch (k_nn_rows): ~10 KB
@@ -33,6 +34,9 @@ struct LmSet {
   float Rs[9], ts[3], Rt[9], tt[3];
 };
 
+// inner poses of one set for one candidate LM try
+struct LmPose { float Rs[9], ts[3], Rt[9], tt[3]; };
+
 int launch_transform_aos(const float* xyz, const float* nrm, size_t n, const Affine& T, float* oxyz, float* onrm,
                          float* bbox_partial, float* bbox_out, hipStream_t s);
 int launch_transform_bbox(const float4* L4, size_t n, const Affine& T, float4* G4, float* bbox_partial,
@@ -51,6 +55,8 @@ void launch_match_scan(const int* match_pos, const float* match_d2, size_t n, un
                        unsigned long long* total, double* total_d2, hipStream_t s);
 void launch_query_keys(const float4* Gsrc, size_t n, const GridDesc& g, const InvMap& im, const QueryRange& qr,
                        unsigned long long* keys, unsigned* vals, hipStream_t s);
+void launch_query_keys32(const float4* Gsrc, size_t n, const GridDesc& g, const InvMap& im, const QueryRange& qr,
+                         unsigned* keys, unsigned* vals, hipStream_t s);
 void launch_nn_cells(const float4* Gsrc, const unsigned* order, size_t n, const float4* Gtgt, const HashEntry* table,
                      const unsigned* dense_start, const GridDesc& g, const InvMap& im, const QueryRange& qr, float r2,
                      int* match_pos, float* match_d2, hipStream_t s);
@@ -58,6 +64,8 @@ void launch_nn_rows(const float4* Gsrc, const unsigned* order, size_t n, const f
                     const GridDesc& g, const InvMap& im, const QueryRange& qr, float r2, int* match_pos, float* match_d2,
                     hipStream_t s);
 void launch_dense_counts(const unsigned long long* keys, size_t n, const QueryRange& qr, unsigned* counts, hipStream_t s);
+void sort_pairs_u32_u32(unsigned* keys_in, unsigned* keys_out, unsigned* vals_in, unsigned* vals_out, size_t n,
+                        int end_bit, DevBuf<char>& temp, hipStream_t s);
 // in-place exclusive MAX scan of n unsigned values (rocPRIM, e3d_sort.hip); one-off per grid build
 void exclusive_max_scan_u32(unsigned* data, size_t n, DevBuf<char>& temp, hipStream_t s);
 void launch_compact_corr(const int* match_pos, const unsigned* order, size_t n, const unsigned* block_offsets, const float4* Gsrc,
@@ -69,6 +77,8 @@ void launch_unpermute_matches(const int* match_pos, const float* match_d2, const
                               const float4* Gtgt, int* out_idx, float* out_d2, hipStream_t s);
 void launch_lm_pass(int mode, const float4* A, const float4* B, const float4* C, const LmSet* sets,
                     const int* block_set, int block_base, int nblocks, double* partial, hipStream_t s);
+void launch_lm_cost_multi(const float4* A, const float4* B, const float4* C, const LmSet* sets, const LmPose* poses,
+                          int n_sets, int n_poses, const int* block_set, int nblocks, double* partial, hipStream_t s);
 void launch_lm_reduce(const double* partial, const LmSet* sets, int n_sets, int nacc, double* out, hipStream_t s);
 
 // radix sort of (cell key, point index) pairs -- rocPRIM device primitive (e3d_sort.hip)

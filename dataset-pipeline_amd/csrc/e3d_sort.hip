@@ -19,6 +19,15 @@ void sort_pairs_u64_u32(unsigned long long* keys_in, unsigned long long* keys_ou
   E3D_HIP(rocprim::radix_sort_pairs(temp.p, bytes, keys_in, keys_out, vals_in, vals_out, n, 0u, (unsigned)end_bit, s));
 }
 
+void sort_pairs_u32_u32(unsigned* keys_in, unsigned* keys_out, unsigned* vals_in, unsigned* vals_out, size_t n,
+                        int end_bit, DevBuf<char>& temp, hipStream_t s) {
+  if (n == 0) return;
+  size_t bytes = 0;
+  E3D_HIP(rocprim::radix_sort_pairs(nullptr, bytes, keys_in, keys_out, vals_in, vals_out, n, 0u, (unsigned)end_bit, s));
+  temp.reserve(bytes);
+  E3D_HIP(rocprim::radix_sort_pairs(temp.p, bytes, keys_in, keys_out, vals_in, vals_out, n, 0u, (unsigned)end_bit, s));
+}
+
 void exclusive_max_scan_u32(unsigned* data, size_t n, DevBuf<char>& temp, hipStream_t s) {
   if (n == 0) return;
   size_t bytes = 0;

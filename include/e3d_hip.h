@@ -95,7 +95,9 @@ typedef struct {
   int32_t iteration;
   int32_t inner_iterations;  /* LM iterations executed (<= 150)                            */
   int32_t full_passes;       /* fused H/b/cost passes over all correspondences             */
-  int32_t cost_passes;       /* cost-only passes                                           */
+  int32_t cost_passes;       /* cost-only passes (one pose set)                            */
+  int32_t multi_cost_passes; /* cost-only passes evaluating LM tries 1..9 at once          */
+  int32_t reserved_;
   int64_t correspondences;   /* total over all directed pairs of this rank                 */
   int64_t queries;           /* NN queries issued by this rank                             */
   double  initial_cost, final_cost;

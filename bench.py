@@ -119,11 +119,7 @@ def main():
     torch.cuda.empty_cache()
 
     if world > 1:
-        def allreduce(arr):
-            t = torch.from_numpy(arr).to(dev)
-            dist.all_reduce(t)
-            arr[:] = t.cpu().numpy()
-        icp.set_shard(rank, world, allreduce)
+        importlib.import_module("dataset-pipeline_amd.dist").attach(icp, device=dev)
 
     def barrier():
         torch.cuda.synchronize()

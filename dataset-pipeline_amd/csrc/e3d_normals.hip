@@ -1,8 +1,376 @@
-// e3d_normals.hip -- kNN normal estimation (pcl::NormalEstimationTwoPassOMP replacement).
-#include "../../include/e3d_hip.h"
-#include "e3d_common.hpp"
+// e3d_normals.hip -- k-nearest-neighbour normal estimation on gfx950 (path A' of SURVEY.md section 8):
+//   pcl::NormalEstimationTwoPassOMP::computeFeature      src/geometry/two_pass_normal_3d_omp.hpp:48-119
+//   pcl::computePointNormalTwoPass (indices)             src/geometry/two_pass_normal_3d.h:92-109
+//   pcl::computeMeanAndCovarianceMatrixTwoPass           src/geometry/two_pass_centroid.hpp:155-259
+//   pcl::solvePlaneParameters / pcl::eigen33 / flipNormalTowardsViewpoint   (PCL 1.10, recalled)
+//
+// Exact kNN without a tree: points are bucketed in a uniform grid (hash table); a query scans its 27-cell block
+// into a per-thread max-heap kept in LDS (column layout, bank-conflict free) and is RESOLVED when its k-th
+// neighbour is provably closer than the nearest face of the block (nothing outside can beat or tie it).
+// Unresolved queries (sparse regions, outliers) are retried on a 4x coarser grid, and so on until the block
+// covers the whole cloud -- so every neighbour list is exact, ordered by (f32 squared distance, original index),
+// and includes the query point itself, as FLANN's nearestKSearch returns it.
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <memory>
 
-extern "C" int e3d_normals_knn(const float*, size_t, int, const float*, float*, float*, int32_t*) {
-  e3d::set_last_error("e3d_normals_knn: not implemented yet");
-  return E3D_ERR_INVALID;
+#include "../../include/e3d_hip.h"
+#include "e3d_icp_kernels.hpp"
+
+#pragma clang fp contract(off)
+
+namespace e3d {
+
+constexpr int kKnnBlock = 128;   // threads per block; LDS = 128 * k * 8 bytes
+constexpr int kKnnMaxK = 128;
+
+struct KnnGrid {
+  GridDesc g;
+  float cell;
+  float dmin[3], dmax[3];   // data bbox
+  float slack;
+};
+
+__device__ __forceinline__ bool knn_less(float d1, unsigned p1, float d2, unsigned p2, const float4* __restrict__ P4) {
+  if (d1 != d2) return d1 < d2;
+  return __float_as_uint(P4[p1].w) < __float_as_uint(P4[p2].w);     // tie: lower ORIGINAL index first (rare path)
+}
+
+// pcl::computeRoots2 / computeRoots / eigen33 (PCL 1.10 common/eigen.hpp, recalled)
+__device__ __forceinline__ void compute_roots2(float b, float c, float* roots) {
+  roots[0] = 0.f;
+  float d = (float)((double)(b * b) - 4.0 * (double)c);
+  if (d < 0.0f) d = 0.0f;
+  const float sd = sqrtf(d);
+  roots[2] = 0.5f * (b + sd);
+  roots[1] = 0.5f * (b - sd);
+}
+
+__device__ __forceinline__ void compute_roots(const float* m, float* roots) {
+#define M(i, j) m[3 * (i) + (j)]
+  const float c0 = M(0, 0) * M(1, 1) * M(2, 2) + 2.f * M(0, 1) * M(0, 2) * M(1, 2) - M(0, 0) * M(1, 2) * M(1, 2) -
+                   M(1, 1) * M(0, 2) * M(0, 2) - M(2, 2) * M(0, 1) * M(0, 1);
+  const float c1 = M(0, 0) * M(1, 1) - M(0, 1) * M(0, 1) + M(0, 0) * M(2, 2) - M(0, 2) * M(0, 2) + M(1, 1) * M(2, 2) -
+                   M(1, 2) * M(1, 2);
+  const float c2 = M(0, 0) + M(1, 1) + M(2, 2);
+#undef M
+  if (fabsf(c0) < FLT_EPSILON) { compute_roots2(c2, c1, roots); return; }
+  const float s_inv3 = (float)(1.0 / 3.0);
+  const float s_sqrt3 = sqrtf(3.0f);
+  const float c2_over_3 = c2 * s_inv3;
+  float a_over_3 = (c1 - c2 * c2_over_3) * s_inv3;
+  if (a_over_3 > 0.f) a_over_3 = 0.f;
+  const float half_b = 0.5f * (c0 + c2_over_3 * (2.f * c2_over_3 * c2_over_3 - c1));
+  float q = half_b * half_b + a_over_3 * a_over_3 * a_over_3;
+  if (q > 0.f) q = 0.f;
+  const float rho = sqrtf(-a_over_3);
+  const float theta = atan2f(sqrtf(-q), half_b) * s_inv3;
+  const float cos_theta = cosf(theta);
+  const float sin_theta = sinf(theta);
+  roots[0] = c2_over_3 + 2.f * rho * cos_theta;
+  roots[1] = c2_over_3 - rho * (cos_theta + s_sqrt3 * sin_theta);
+  roots[2] = c2_over_3 - rho * (cos_theta - s_sqrt3 * sin_theta);
+  float t;
+  if (roots[0] >= roots[1]) { t = roots[0]; roots[0] = roots[1]; roots[1] = t; }
+  if (roots[1] >= roots[2]) {
+    t = roots[1]; roots[1] = roots[2]; roots[2] = t;
+    if (roots[0] >= roots[1]) { t = roots[0]; roots[0] = roots[1]; roots[1] = t; }
+  }
+  if (roots[0] <= 0.f) compute_roots2(c2, c1, roots);
+}
+
+__device__ __forceinline__ void eigen33_smallest(const float* cov, float& eigenvalue, float* v) {
+  float scale = 0.f;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) scale = fmaxf(scale, fabsf(cov[i]));
+  if (scale <= FLT_MIN) scale = 1.0f;
+  float s[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) s[i] = cov[i] / scale;
+  float roots[3];
+  compute_roots(s, roots);
+  eigenvalue = roots[0] * scale;
+  s[0] -= roots[0]; s[4] -= roots[0]; s[8] -= roots[0];
+  float v1[3], v2[3], v3[3];
+  v1[0] = s[1] * s[5] - s[2] * s[4]; v1[1] = s[2] * s[3] - s[0] * s[5]; v1[2] = s[0] * s[4] - s[1] * s[3];
+  v2[0] = s[1] * s[8] - s[2] * s[7]; v2[1] = s[2] * s[6] - s[0] * s[8]; v2[2] = s[0] * s[7] - s[1] * s[6];
+  v3[0] = s[4] * s[8] - s[5] * s[7]; v3[1] = s[5] * s[6] - s[3] * s[8]; v3[2] = s[3] * s[7] - s[4] * s[6];
+  const float l1 = v1[0] * v1[0] + (v1[1] * v1[1] + v1[2] * v1[2]);
+  const float l2 = v2[0] * v2[0] + (v2[1] * v2[1] + v2[2] * v2[2]);
+  const float l3 = v3[0] * v3[0] + (v3[1] * v3[1] + v3[2] * v3[2]);
+  const float* best; float len;
+  if (l1 >= l2 && l1 >= l3) { best = v1; len = l1; }
+  else if (l2 >= l1 && l2 >= l3) { best = v2; len = l2; }
+  else { best = v3; len = l3; }
+  const float sl = sqrtf(len);
+  v[0] = best[0] / sl; v[1] = best[1] / sl; v[2] = best[2] / sl;
+}
+
+// One pass over the queries listed in `todo` (or all points when todo == nullptr) on one grid level.
+__global__ __launch_bounds__(kKnnBlock) void k_knn_normals(const float4* __restrict__ P4, size_t n,
+                                                           const unsigned* __restrict__ todo, size_t n_todo,
+                                                           const HashEntry* __restrict__ table, KnnGrid G, int k,
+                                                           float vpx, float vpy, float vpz,
+                                                           const float4* __restrict__ Q4 /* queries by sorted pos of level 0 */,
+                                                           float* __restrict__ out_n, float* __restrict__ out_c,
+                                                           int* __restrict__ out_knn, unsigned* __restrict__ next_todo,
+                                                           unsigned* __restrict__ next_count) {
+  extern __shared__ unsigned char smem[];
+  float* hd = reinterpret_cast<float*>(smem);                         // [k][kKnnBlock]
+  unsigned* hp = reinterpret_cast<unsigned*>(smem) + (size_t)k * kKnnBlock;
+  const int tid = threadIdx.x;
+  const size_t gi = (size_t)blockIdx.x * blockDim.x + tid;
+  if (gi >= n_todo) return;
+  const unsigned qid = todo ? todo[gi] : (unsigned)gi;              // index into Q4
+  const float4 q = Q4[qid];
+  const unsigned q_oi = __float_as_uint(q.w);
+#define HD(i) hd[(size_t)(i) * kKnnBlock + tid]
+#define HP(i) hp[(size_t)(i) * kKnnBlock + tid]
+  int cnt = 0;
+  const int cx = cell_coord(q.x, G.g.origin[0], G.g.inv_cell);
+  const int cy = cell_coord(q.y, G.g.origin[1], G.g.inv_cell);
+  const int cz = cell_coord(q.z, G.g.origin[2], G.g.inv_cell);
+  constexpr int kMaxC = (1 << 21) - 1;
+  for (int oz = -1; oz <= 1; ++oz)
+    for (int oy = -1; oy <= 1; ++oy)
+      for (int ox = -1; ox <= 1; ++ox) {
+        const int x = cx + ox, y = cy + oy, z = cz + oz;
+        if (x < 0 || y < 0 || z < 0 || x > kMaxC || y > kMaxC || z > kMaxC) continue;
+        const unsigned long long key = cell_key(x, y, z);
+        unsigned h = hash_key(key) & G.g.mask;
+        unsigned s = 0, e = 0;
+        for (;;) {
+          const HashEntry en = table[h];
+          if (en.key == key) { s = en.start; e = en.end; break; }
+          if (en.key == kEmptyKey) break;
+          h = (h + 1) & G.g.mask;
+        }
+        for (unsigned m = s; m < e; ++m) {
+          const float4 c = P4[m];
+          const float d2 = sqdist_l2(q.x, q.y, q.z, c.x, c.y, c.z);
+          if (cnt < k) {
+            // sift up
+            int i = cnt++;
+            HD(i) = d2; HP(i) = m;
+            while (i > 0) {
+              const int p = (i - 1) >> 1;
+              const float pd = HD(p); const unsigned pp = HP(p);
+              if (knn_less(pd, pp, d2, m, P4)) { HD(i) = pd; HP(i) = pp; HD(p) = d2; HP(p) = m; i = p; } else break;
+            }
+          } else {
+            const float td = HD(0); const unsigned tp = HP(0);
+            if (d2 > td) continue;                                    // common case: one compare
+            if (!knn_less(d2, m, td, tp, P4)) continue;
+            // replace the root, sift down
+            int i = 0;
+            for (;;) {
+              const int l = 2 * i + 1, r = l + 1;
+              int big = -1; float bd = d2; unsigned bp = m;
+              if (l < k) { const float ld = HD(l); const unsigned lp = HP(l); if (knn_less(bd, bp, ld, lp, P4)) { big = l; bd = ld; bp = lp; } }
+              if (r < k) { const float rd = HD(r); const unsigned rp = HP(r); if (knn_less(bd, bp, rd, rp, P4)) { big = r; bd = rd; bp = rp; } }
+              if (big < 0) break;
+              HD(i) = bd; HP(i) = bp; i = big;
+            }
+            HD(i) = d2; HP(i) = m;
+          }
+        }
+      }
+  // resolved?  the k-th neighbour must be strictly closer than the nearest face of the 27-cell block that still
+  // has data behind it
+  bool resolved;
+  {
+    float safe = 3.402823466e+38f;
+    const int c[3] = {cx, cy, cz};
+    const float qq[3] = {q.x, q.y, q.z};
+    bool covers_all = true;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float lo = G.g.origin[a] + (float)(c[a] - 1) * G.cell;
+      const float hi = G.g.origin[a] + (float)(c[a] + 2) * G.cell;
+      if (lo > G.dmin[a]) { safe = fminf(safe, qq[a] - lo); covers_all = false; }
+      if (hi <= G.dmax[a]) { safe = fminf(safe, hi - qq[a]); covers_all = false; }
+    }
+    if (covers_all) resolved = true;
+    else {
+      safe -= G.slack;
+      resolved = (cnt == k) && safe > 0.f && HD(0) < safe * safe * 0.99999f;
+    }
+  }
+  if (!resolved) {
+    const unsigned slot = atomicAdd(next_count, 1u);
+    next_todo[slot] = qid;
+    return;
+  }
+  // heap sort in place -> ascending (d2, original index)
+  for (int end = cnt - 1; end > 0; --end) {
+    const float ld = HD(end); const unsigned lp = HP(end);
+    HD(end) = HD(0); HP(end) = HP(0);
+    int i = 0;
+    for (;;) {
+      const int l = 2 * i + 1, r = l + 1;
+      int big = -1; float bd = ld; unsigned bp = lp;
+      if (l < end) { const float xd = HD(l); const unsigned xp = HP(l); if (knn_less(bd, bp, xd, xp, P4)) { big = l; bd = xd; bp = xp; } }
+      if (r < end) { const float xd = HD(r); const unsigned xp = HP(r); if (knn_less(bd, bp, xd, xp, P4)) { big = r; bd = xd; bp = xp; } }
+      if (big < 0) break;
+      HD(i) = bd; HP(i) = bp; i = big;
+    }
+    HD(i) = ld; HP(i) = lp;
+  }
+  if (out_knn) {
+    for (int i = 0; i < k; ++i) out_knn[(size_t)q_oi * k + i] = (i < cnt) ? (int)__float_as_uint(P4[HP(i)].w) : -1;
+  }
+  float nx, ny, nz, curv;
+  const float qnan = __uint_as_float(0x7fc00000u);
+  if (cnt < 3) {                                                      // two_pass_normal_3d.h:97-103
+    nx = ny = nz = curv = qnan;
+  } else {
+    // two_pass_centroid.hpp:176-192 (dense branch), f32, neighbour order
+    float a6 = 0.f, a7 = 0.f, a8 = 0.f;
+    for (int i = 0; i < cnt; ++i) { const float4 p = P4[HP(i)]; a6 += p.x; a7 += p.y; a8 += p.z; }
+    const float fc = (float)cnt;
+    a6 = a6 / fc; a7 = a7 / fc; a8 = a8 / fc;
+    float a0 = 0.f / fc, a1 = 0.f / fc, a2 = 0.f / fc, a3 = 0.f / fc, a4 = 0.f / fc, a5 = 0.f / fc;
+    for (int i = 0; i < cnt; ++i) {
+      const float4 p = P4[HP(i)];
+      a0 += (p.x - a6) * (p.x - a6);
+      a1 += (p.x - a6) * (p.y - a7);
+      a2 += (p.x - a6) * (p.z - a8);
+      a3 += (p.y - a7) * (p.y - a7);
+      a4 += (p.y - a7) * (p.z - a8);
+      a5 += (p.z - a8) * (p.z - a8);
+    }
+    float cov[9];
+    cov[0] = a0 / fc; cov[1] = a1 / fc; cov[2] = a2 / fc; cov[4] = a3 / fc; cov[5] = a4 / fc; cov[8] = a5 / fc;
+    cov[3] = cov[1]; cov[6] = cov[2]; cov[7] = cov[5];
+    float ev, v[3];
+    eigen33_smallest(cov, ev, v);
+    nx = v[0]; ny = v[1]; nz = v[2];
+    const float eig_sum = cov[0] + cov[4] + cov[8];
+    curv = (eig_sum != 0.f) ? fabsf(ev / eig_sum) : 0.f;
+    // flipNormalTowardsViewpoint
+    const float vx = vpx - q.x, vy = vpy - q.y, vz = vpz - q.z;
+    const float cos_theta = (vx * nx + vy * ny + vz * nz);
+    if (cos_theta < 0) { nx *= -1; ny *= -1; nz *= -1; }
+  }
+  out_n[3 * (size_t)q_oi] = nx; out_n[3 * (size_t)q_oi + 1] = ny; out_n[3 * (size_t)q_oi + 2] = nz;
+  out_c[q_oi] = curv;
+#undef HD
+#undef HP
+}
+
+// grid keys for an arbitrary cell size (points taken from AoS xyz)
+struct LevelBuffers {
+  DevBuf<unsigned long long> ka, kb;
+  DevBuf<unsigned> va, vb, counter;
+  DevBuf<char> temp;
+  DevBuf<float4> P4, LN;
+  DevBuf<HashEntry> table;
+};
+
+}  // namespace e3d
+
+using namespace e3d;
+
+extern "C" int e3d_normals_knn(const float* xyz, size_t n, int k, const float* viewpoint, float* out_normals,
+                               float* out_curvature, int32_t* knn_indices) {
+  try {
+    if ((!xyz && n) || !viewpoint || (!out_normals && n) || (!out_curvature && n))
+      throw Error(E3D_ERR_INVALID, "e3d_normals_knn: null argument");
+    if (k < 1 || k > kKnnMaxK) throw Error(E3D_ERR_INVALID, fmt("e3d_normals_knn: k = %d outside [1, %d]", k, kKnnMaxK));
+    if (n >= (size_t)1 << 31) throw Error(E3D_ERR_INVALID, "e3d_normals_knn: more than 2^31-1 points");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+      throw Error(E3D_ERR_NO_DEVICE, "no HIP device visible (libe3dhip needs an MI355X / gfx950 GPU)");
+    if (n == 0) return 0;
+    hipStream_t s = nullptr;
+    E3D_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamDestroy(s); } } guard{s};
+
+    DevBuf<float> raw, d_on, d_oc, bbox_partial, bbox_out;
+    DevBuf<int> d_knn;
+    raw.reserve(3 * n); d_on.reserve(3 * n); d_oc.reserve(n);
+    if (knn_indices) d_knn.reserve(n * (size_t)k);
+    copy_in(raw.p, xyz, sizeof(float) * 3 * n, s);
+    bbox_partial.reserve(6 * (size_t)kMaxBboxBlocks); bbox_out.reserve(6);
+    launch_bbox_aos(raw.p, n, bbox_partial.p, bbox_out.p, s);
+    float bb[6];
+    copy_out(bb, bbox_out.p, sizeof bb, s);
+    E3D_HIP(hipStreamSynchronize(s));
+    double ext[3], extent = 0, vol = 1;
+    for (int a = 0; a < 3; ++a) { ext[a] = (double)bb[3 + a] - (double)bb[a]; extent = std::max(extent, ext[a]); }
+    if (!(extent > 0) || !std::isfinite(extent)) extent = 1.0;
+    // starting cell size: k points inside ~1.5 cells^2 of a surface-like cloud whose area is estimated from the
+    // bounding box faces; the multi-level retry makes any choice exact, this only sets the speed
+    double area = 2.0 * (ext[0] * ext[1] + ext[1] * ext[2] + ext[0] * ext[2]);
+    if (!(area > 0)) area = extent * extent;
+    (void)vol;
+    double cell = std::sqrt((double)k * area / (1.5 * M_PI * (double)n));
+    cell = std::max(cell, extent / 1.0e6);
+    double magnitude = 0;
+    for (int a = 0; a < 6; ++a) magnitude = std::max(magnitude, std::fabs((double)bb[a]));
+
+    LevelBuffers L;
+    L.ka.reserve(n); L.kb.reserve(n); L.va.reserve(n); L.vb.reserve(n); L.counter.reserve(2);
+    L.P4.reserve(n);
+    DevBuf<float4> Q4;             // queries in level-0 cell order (spatially coherent for every level)
+    DevBuf<unsigned> todo_a, todo_b;
+    todo_a.reserve(n); todo_b.reserve(n);
+    unsigned* todo = nullptr;
+    size_t n_todo = n;
+    const size_t lds = (size_t)k * kKnnBlock * 8;
+    E3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_knn_normals), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    for (int level = 0; level < 64 && n_todo > 0; ++level) {
+      KnnGrid G{};
+      G.cell = (float)cell;
+      G.g.inv_cell = (float)(1.0 / (double)G.cell);
+      for (int a = 0; a < 3; ++a) { G.g.origin[a] = (float)((double)bb[a] - 2.0 * cell); G.dmin[a] = bb[a]; G.dmax[a] = bb[3 + a]; }
+      G.slack = (float)(16.0 * FLT_EPSILON * (magnitude + 4.0 * cell) + 1e-4 * cell);
+      // too many cells for 21-bit coordinates: coarsen
+      if (extent / cell > (double)((1 << 21) - 8)) { cell *= 4.0; --level; continue; }
+      launch_cell_keys(raw.p, n, G.g, L.ka.p, L.va.p, s);
+      sort_pairs_u64_u32(L.ka.p, L.kb.p, L.va.p, L.vb.p, n, 63, L.temp, s);
+      launch_permute(raw.p, nullptr, L.vb.p, n, L.P4.p, nullptr, s);
+      E3D_HIP(hipMemsetAsync(L.counter.p, 0, 2 * sizeof(unsigned), s));
+      launch_count_cells(L.kb.p, n, L.counter.p, s);
+      unsigned n_cells = 0;
+      E3D_HIP(hipMemcpyAsync(&n_cells, L.counter.p, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+      E3D_HIP(hipStreamSynchronize(s));
+      size_t tsize = 64;
+      while (tsize < 2 * (size_t)n_cells) tsize <<= 1;
+      L.table.reserve(tsize);
+      G.g.mask = (unsigned)(tsize - 1);
+      E3D_HIP(hipMemsetAsync(L.table.p, 0xFF, sizeof(HashEntry) * tsize, s));
+      launch_build_table(L.kb.p, n, L.table.p, G.g.mask, s);
+      if (level == 0) {
+        Q4.reserve(n);
+        E3D_HIP(hipMemcpyAsync(Q4.p, L.P4.p, sizeof(float4) * n, hipMemcpyDeviceToDevice, s));
+      }
+      unsigned* next = (todo == todo_a.p) ? todo_b.p : todo_a.p;
+      E3D_HIP(hipMemsetAsync(L.counter.p + 1, 0, sizeof(unsigned), s));
+      const unsigned nblk = (unsigned)div_up(n_todo, kKnnBlock);
+      hipLaunchKernelGGL(k_knn_normals, dim3(nblk), dim3(kKnnBlock), lds, s, L.P4.p, n, todo, n_todo, L.table.p, G, k,
+                         viewpoint[0], viewpoint[1], viewpoint[2], Q4.p, d_on.p, d_oc.p,
+                         knn_indices ? d_knn.p : nullptr, next, L.counter.p + 1);
+      unsigned n_next = 0;
+      E3D_HIP(hipMemcpyAsync(&n_next, L.counter.p + 1, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+      E3D_HIP(hipStreamSynchronize(s));
+      E3D_HIP(hipGetLastError());
+      todo = next;
+      n_todo = n_next;
+      cell *= 4.0;
+    }
+    if (n_todo != 0) throw Error(E3D_ERR_INVALID, "e3d_normals_knn: internal error, unresolved queries remain");
+    copy_out(out_normals, d_on.p, sizeof(float) * 3 * n, s);
+    copy_out(out_curvature, d_oc.p, sizeof(float) * n, s);
+    if (knn_indices) copy_out(knn_indices, d_knn.p, sizeof(int) * n * (size_t)k, s);
+    E3D_HIP(hipStreamSynchronize(s));
+    return 0;
+  } catch (const e3d::Error& e) {
+    e3d::set_last_error(e.what());
+    return e.code;
+  } catch (const std::exception& e) {
+    e3d::set_last_error(e.what());
+    return E3D_ERR_INVALID;
+  }
 }

@@ -1,0 +1,80 @@
+"""GPU parity tests of the normal-estimation path (A'): exact neighbour lists (integer work: bit-exact) and normals /
+curvature within f32 tolerance of the CPU oracle (device atan2f/cosf/sinf differ from glibc in the last ulp)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+NORMAL_TOL = 2e-4     # |n_gpu - n_oracle| per component; closed-form eigenvector amplifies 1-ulp trig differences
+CURV_TOL = 2e-5
+
+
+def _compare(e3d, ob, P, k, vp=(0, 0, 0)):
+    gn, gc, gk = e3d.normals_knn(P, k, vp, return_knn=True)
+    on, oc, ok = ob.normals(P, k=k, viewpoint=vp, return_knn=True)
+    assert np.array_equal(gk, ok), "kNN index lists differ"
+    nan_o = np.isnan(on[:, 0])
+    assert np.array_equal(np.isnan(gn[:, 0]), nan_o)
+    v = ~nan_o
+    # well-conditioned neighbourhoods: direction must agree tightly
+    err = np.abs(gn[v] - on[v]).max(axis=1)
+    bad = err > NORMAL_TOL
+    assert bad.mean() < 2e-3, ("fraction of normals off", bad.mean(), err.max())
+    assert np.all(np.abs(np.einsum("ij,ij->i", gn[v][~bad], on[v][~bad])) > 1 - 1e-6)
+    # sign convention identical wherever (viewpoint - p).n is not ~0
+    dots = np.einsum("ij,ij->i", np.asarray(vp, np.float32) - P[v], on[v])
+    clear = np.abs(dots) > 1e-3 * np.linalg.norm(np.asarray(vp, np.float32) - P[v], axis=1)
+    assert np.all(np.einsum("ij,ij->i", gn[v][clear & ~bad], on[v][clear & ~bad]) > 0)
+    assert np.abs(gc[v][~bad] - oc[v][~bad]).max() <= CURV_TOL
+    return gk
+
+
+@pytest.mark.parametrize("k", [8, 32])
+def test_normals_room(e3d, ob, synth, k):
+    s = synth.make_scene(1, 60000, seed=21)[0]
+    _compare(e3d, ob, s["xyz"].numpy(), k)
+
+
+def test_normals_outliers_and_clusters(e3d, ob):
+    """Isolated outliers and very uneven density force several grid levels; lists stay exact."""
+    rng = np.random.RandomState(5)
+    dense = rng.normal(size=(20000, 3)).astype(np.float32) * np.array([1, 1, 0.01], np.float32)
+    tight = (rng.normal(size=(3000, 3)) * 1e-3 + np.array([5, 5, 5])).astype(np.float32)
+    far = np.array([[100, 0, 0], [0, -250, 3], [40, 40, 40], [-1000, 1000, 0.5]], np.float32)
+    P = np.vstack([dense, tight, far]).astype(np.float32)
+    _compare(e3d, ob, P, 16, vp=(0, 0, 10))
+
+
+def test_normals_small_and_degenerate(e3d, ob):
+    P = np.array([[0, 0, 0], [1, 0, 0]], np.float32)
+    n, c = e3d.normals_knn(P, 8)
+    assert np.all(np.isnan(n)) and np.all(np.isnan(c))             # fewer than 3 neighbours -> NaN
+    P = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [1, 1, 0], [0.5, 0.5, 0]], np.float32)
+    n, c, knn = e3d.normals_knn(P, 5, (0, 0, 5), return_knn=True)
+    assert np.allclose(n[:, 2], 1, atol=1e-6) and np.allclose(c, 0, atol=1e-7)
+    assert sorted(knn[0]) == [0, 1, 2, 3, 4] and knn[0][0] == 0     # the query itself comes first
+    n, c, knn = e3d.normals_knn(P, 8, (0, 0, 5), return_knn=True)  # k > n: all points, padded with -1
+    assert np.all(knn[:, 5:] == -1) and np.allclose(n[:, 2], 1, atol=1e-6)
+    with pytest.raises(e3d.E3DError):
+        e3d.normals_knn(P, 0)
+
+
+def test_normals_lattice_ties(e3d, ob):
+    """Integer lattice: many exactly equidistant neighbours -> the (distance, index) order decides the k-set."""
+    xs, ys = np.meshgrid(np.arange(30), np.arange(30), indexing="ij")
+    P = np.stack([xs.ravel(), ys.ravel(), np.zeros(900)], 1).astype(np.float32)
+    gk = _compare(e3d, ob, P, 8, vp=(0, 0, 1))
+    assert np.all(gk[:, 0] == np.arange(900))
+
+
+def test_normals_feed_icp(e3d, ob, synth):
+    """End to end like ICPScanAligner: normals from the GPU estimator (k = 32, viewpoint = scan origin) drive the ICP."""
+    scans = synth.make_scene(2, 40000, seed=31)
+    g = e3d.PointToPlaneICP(); o = ob.OracleICP()
+    for s in scans:
+        P = s["xyz"].numpy()
+        n, _ = e3d.normals_knn(P, 32, (0, 0, 0))
+        assert not np.isnan(n).any()
+        g.add_point_cloud(P, n, s["T_init"], False); o.add_point_cloud(P, n, s["T_init"], False)
+    g.run(0.1, 0, 5, 1e-9, False); o.run(0.1, 0, 5, 1e-9, False)
+    assert [(r[0], r[1], r[2], r[3]) for r in g.pair_records()] == [(r[0], r[1], r[2], r[3]) for r in o.pair_records()]

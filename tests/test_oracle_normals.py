@@ -1,0 +1,64 @@
+"""CPU tests of the normal-estimation oracle (path A').  The reference has no test for src/geometry, so these pin the
+restatement against independent numpy linear algebra and the committed goldens ("parity unpinned" vs PCL itself)."""
+import os
+
+import numpy as np
+import pytest
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_normals_golden(ob):
+    g = np.load(os.path.join(GOLD, "nn_and_normals.npz"))
+    n, c, knn = ob.normals(g["cloud"], k=16, viewpoint=(0, 0, 0), return_knn=True)
+    assert np.array_equal(knn, g["knn"])
+    assert np.abs(n - g["normals"]).max() <= 1e-6 and np.abs(c - g["curvature"]).max() <= 1e-6
+
+
+def test_knn_matches_bruteforce(ob):
+    rng = np.random.RandomState(0)
+    P = rng.uniform(-1, 1, (800, 3)).astype(np.float32)
+    idx, dist = ob.knn(P, P, 9)
+    D = ((P[:, None, :].astype(np.float32) - P[None, :, :]) ** 2)
+    D = (D[..., 0] + D[..., 1]) + D[..., 2]                     # L2_Simple order in f32
+    order = np.lexsort((np.broadcast_to(np.arange(800), D.shape), D), axis=1)[:, :9]
+    assert np.array_equal(idx, order.astype(np.int32))
+    assert np.all(idx[:, 0] == np.arange(800))                 # the query itself is its own first neighbour
+    assert np.array_equal(dist, np.take_along_axis(D, order, 1))
+
+
+def test_normals_against_numpy_eigh(ob, synth):
+    s = synth.make_scene(1, 5000, seed=9)[0]
+    P = s["xyz"].numpy()
+    n, c, knn = ob.normals(P, k=24, viewpoint=(0, 0, 0), return_knn=True)
+    for i in range(0, 5000, 97):
+        nb = P[knn[i]].astype(np.float64)
+        C = np.cov(nb.T, bias=True)
+        w, v = np.linalg.eigh(C)
+        ref = v[:, 0]
+        if np.dot(-P[i], ref) < 0:
+            ref = -ref
+        if w[1] - w[0] > 1e-3 * w[2]:                           # skip (near-)degenerate neighbourhoods
+            assert abs(np.dot(ref, n[i])) > 1 - 1e-4
+            assert np.dot(-P[i].astype(np.float64), n[i]) >= -1e-6     # flipped towards the viewpoint (origin)
+            assert abs(c[i] - w[0] / w.sum()) < 1e-3
+
+
+def test_normals_degenerate(ob):
+    P = np.array([[0, 0, 0], [1, 0, 0]], np.float32)
+    n, c = ob.normals(P, k=8)
+    assert np.all(np.isnan(n)) and np.all(np.isnan(c))           # < 3 neighbours -> NaN (two_pass_normal_3d.h:97-103)
+    P = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [1, 1, 0], [0.5, 0.5, 0]], np.float32)
+    n, c = ob.normals(P, k=5, viewpoint=(0, 0, 5))
+    assert np.allclose(np.abs(n[:, 2]), 1, atol=1e-6) and np.all(n[:, 2] > 0)
+    assert np.allclose(c, 0, atol=1e-7)
+    with pytest.raises(ValueError):
+        ob.normals(P, k=0, radius=-1)
+
+
+def test_normals_radius_search(ob):
+    rng = np.random.RandomState(4)
+    P = np.c_[rng.uniform(0, 1, (2000, 2)), 0.001 * rng.normal(size=2000)].astype(np.float32)
+    n, c = ob.normals(P, radius=0.1, viewpoint=(0, 0, 1))
+    ok = ~np.isnan(n[:, 0])
+    assert ok.sum() > 1900 and np.all(n[ok, 2] > 0.99)

@@ -1,0 +1,71 @@
+// e3d_loader.h -- thin run-time loader of the C-ABI (include/e3d_hip.h) for the C++ host tools: dlopen()s
+// libe3dhip.so and resolves the entry points.  There is no fallback: if the library or a symbol is missing the
+// tools stop with an error message.
+#pragma once
+
+#include <dlfcn.h>
+#include <libgen.h>
+#include <unistd.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+
+#include "../../../include/e3d_hip.h"
+
+namespace e3d_host {
+
+struct Api {
+  void* handle = nullptr;
+#define E3D_FN(name) decltype(&::name) name = nullptr;
+  E3D_FN(e3d_abi_version) E3D_FN(e3d_init) E3D_FN(e3d_last_error) E3D_FN(e3d_icp_create) E3D_FN(e3d_icp_destroy)
+  E3D_FN(e3d_icp_add_cloud) E3D_FN(e3d_icp_run) E3D_FN(e3d_icp_get_pose) E3D_FN(e3d_transform_cloud)
+  E3D_FN(e3d_normals_knn) E3D_FN(e3d_find_correspondences)
+#undef E3D_FN
+};
+
+inline std::string exe_dir() {
+  char buf[4096];
+  const ssize_t n = readlink("/proc/self/exe", buf, sizeof buf - 1);
+  if (n <= 0) return ".";
+  buf[n] = 0;
+  return std::string(dirname(buf));
+}
+
+inline Api& api() {
+  static Api a;
+  if (a.handle) return a;
+  std::string tried;
+  const char* env = getenv("E3D_HIP_LIBRARY");
+  const std::string candidates[] = {env ? std::string(env) : std::string(), exe_dir() + "/../lib/libe3dhip.so",
+                                    exe_dir() + "/libe3dhip.so", "libe3dhip.so"};
+  for (const std::string& c : candidates) {
+    if (c.empty()) continue;
+    a.handle = dlopen(c.c_str(), RTLD_NOW | RTLD_LOCAL);
+    if (a.handle) break;
+    tried += "\n  " + c + ": " + dlerror();
+  }
+  if (!a.handle) {
+    fprintf(stderr, "FATAL: cannot load the HIP library libe3dhip.so (set E3D_HIP_LIBRARY); tried:%s\n", tried.c_str());
+    exit(EXIT_FAILURE);
+  }
+#define E3D_LOAD(name)                                                             \
+  a.name = reinterpret_cast<decltype(a.name)>(dlsym(a.handle, #name));             \
+  if (!a.name) { fprintf(stderr, "FATAL: libe3dhip.so lacks symbol %s\n", #name); exit(EXIT_FAILURE); }
+  E3D_LOAD(e3d_abi_version) E3D_LOAD(e3d_init) E3D_LOAD(e3d_last_error) E3D_LOAD(e3d_icp_create)
+  E3D_LOAD(e3d_icp_destroy) E3D_LOAD(e3d_icp_add_cloud) E3D_LOAD(e3d_icp_run) E3D_LOAD(e3d_icp_get_pose)
+  E3D_LOAD(e3d_transform_cloud) E3D_LOAD(e3d_normals_knn) E3D_LOAD(e3d_find_correspondences)
+#undef E3D_LOAD
+  if (a.e3d_abi_version() != E3D_ABI_VERSION) {
+    fprintf(stderr, "FATAL: libe3dhip.so ABI version %d, expected %d\n", a.e3d_abi_version(), E3D_ABI_VERSION);
+    exit(EXIT_FAILURE);
+  }
+  const char* dev = getenv("E3D_DEVICE");
+  if (a.e3d_init(dev ? atoi(dev) : 0) < 1) {
+    fprintf(stderr, "FATAL: %s\n", a.e3d_last_error());
+    exit(EXIT_FAILURE);
+  }
+  return a;
+}
+
+}  // namespace e3d_host

@@ -1,0 +1,197 @@
+// io_ply.h -- PLY reader / writer for the tools (stand-in for pcl::io::loadPLYFile / savePLYFile, which the
+// reference uses at src/exe/icp_scan_aligner.cc:144 and src/exe/normal_estimator.cc:86,225).
+// Reader: ascii and binary_little_endian / binary_big_endian, any element order, vertex properties x y z
+// [red green blue | r g b] [nx ny nz] of any scalar type (converted to f32 / u8), list properties skipped.
+// Writer: the binary layout NormalEstimator emits (x y z nx ny nz f32 + red green blue u8 = 27 B/vertex) with the
+// "element camera" block PCL's PLYWriter appends.
+#pragma once
+
+#include <cstdint>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "host_types.h"
+
+namespace e3d_host {
+
+namespace ply_detail {
+struct Prop { std::string name, type, count_type; bool is_list = false; };
+struct Elem { std::string name; size_t count = 0; std::vector<Prop> props; };
+
+inline int type_size(const std::string& t) {
+  if (t == "char" || t == "uchar" || t == "int8" || t == "uint8") return 1;
+  if (t == "short" || t == "ushort" || t == "int16" || t == "uint16") return 2;
+  if (t == "int" || t == "uint" || t == "float" || t == "int32" || t == "uint32" || t == "float32") return 4;
+  if (t == "double" || t == "float64" || t == "int64" || t == "uint64") return 8;
+  return 0;
+}
+
+inline double read_scalar(const unsigned char* p, const std::string& t, bool swap) {
+  unsigned char b[8];
+  const int n = type_size(t);
+  for (int i = 0; i < n; ++i) b[i] = swap ? p[n - 1 - i] : p[i];
+  if (t == "char" || t == "int8") { int8_t v; memcpy(&v, b, 1); return v; }
+  if (t == "uchar" || t == "uint8") { uint8_t v; memcpy(&v, b, 1); return v; }
+  if (t == "short" || t == "int16") { int16_t v; memcpy(&v, b, 2); return v; }
+  if (t == "ushort" || t == "uint16") { uint16_t v; memcpy(&v, b, 2); return v; }
+  if (t == "int" || t == "int32") { int32_t v; memcpy(&v, b, 4); return v; }
+  if (t == "uint" || t == "uint32") { uint32_t v; memcpy(&v, b, 4); return v; }
+  if (t == "float" || t == "float32") { float v; memcpy(&v, b, 4); return v; }
+  if (t == "double" || t == "float64") { double v; memcpy(&v, b, 8); return v; }
+  if (t == "int64") { int64_t v; memcpy(&v, b, 8); return (double)v; }
+  if (t == "uint64") { uint64_t v; memcpy(&v, b, 8); return (double)v; }
+  return 0;
+}
+}  // namespace ply_detail
+
+// Returns 0 on success, < 0 on failure (like pcl::io::loadPLYFile).
+inline int loadPLYFile(const std::string& path, PointCloud& cloud, bool want_rgb = false) {
+  using namespace ply_detail;
+  std::ifstream f(path, std::ios::binary);
+  if (!f) { std::cerr << "[loadPLYFile] cannot open " << path << std::endl; return -1; }
+  std::string line;
+  if (!std::getline(f, line) || line.substr(0, 3) != "ply") { std::cerr << "[loadPLYFile] not a PLY file: " << path << std::endl; return -1; }
+  std::string format;
+  std::vector<Elem> elems;
+  while (std::getline(f, line)) {
+    if (!line.empty() && line.back() == '\r') line.pop_back();
+    std::istringstream ls(line);
+    std::string tok;
+    ls >> tok;
+    if (tok == "format") ls >> format;
+    else if (tok == "element") { Elem e; ls >> e.name >> e.count; elems.push_back(e); }
+    else if (tok == "property" && !elems.empty()) {
+      Prop p; std::string t; ls >> t;
+      if (t == "list") { p.is_list = true; ls >> p.count_type >> p.type >> p.name; }
+      else { p.type = t; ls >> p.name; }
+      elems.back().props.push_back(p);
+    } else if (tok == "end_header") break;
+  }
+  const bool ascii = (format == "ascii");
+  const bool swap = (format == "binary_big_endian");
+  if (!ascii && format != "binary_little_endian" && !swap) { std::cerr << "[loadPLYFile] unsupported format '" << format << "'" << std::endl; return -1; }
+  for (const Elem& e : elems) {
+    const bool is_vertex = (e.name == "vertex");
+    int ix = -1, iy = -1, iz = -1, ir = -1, ig = -1, ib = -1, inx = -1, iny = -1, inz = -1;
+    bool has_list = false;
+    for (size_t i = 0; i < e.props.size(); ++i) {
+      const std::string& nm = e.props[i].name;
+      if (e.props[i].is_list) has_list = true;
+      if (nm == "x") ix = (int)i; else if (nm == "y") iy = (int)i; else if (nm == "z") iz = (int)i;
+      else if (nm == "red" || nm == "r" || nm == "diffuse_red") ir = (int)i;
+      else if (nm == "green" || nm == "g" || nm == "diffuse_green") ig = (int)i;
+      else if (nm == "blue" || nm == "b" || nm == "diffuse_blue") ib = (int)i;
+      else if (nm == "nx" || nm == "normal_x") inx = (int)i; else if (nm == "ny" || nm == "normal_y") iny = (int)i;
+      else if (nm == "nz" || nm == "normal_z") inz = (int)i;
+    }
+    if (is_vertex) {
+      if (ix < 0 || iy < 0 || iz < 0) { std::cerr << "[loadPLYFile] vertex element without x/y/z in " << path << std::endl; return -1; }
+      cloud.xyz.resize(3 * e.count);
+      if (want_rgb) cloud.rgb.assign(3 * e.count, 0);
+      const bool nrm = inx >= 0 && iny >= 0 && inz >= 0;
+      if (nrm) cloud.normals.resize(3 * e.count);
+    }
+    std::vector<double> vals(e.props.size());
+    if (ascii) {
+      for (size_t i = 0; i < e.count; ++i) {
+        if (!std::getline(f, line)) { std::cerr << "[loadPLYFile] truncated file " << path << std::endl; return -1; }
+        if (!is_vertex) continue;
+        std::istringstream ls(line);
+        for (size_t p = 0; p < e.props.size(); ++p) {
+          if (e.props[p].is_list) { size_t c; ls >> c; double d; for (size_t k = 0; k < c; ++k) ls >> d; vals[p] = 0; }
+          else ls >> vals[p];
+        }
+        cloud.xyz[3 * i] = (float)vals[ix]; cloud.xyz[3 * i + 1] = (float)vals[iy]; cloud.xyz[3 * i + 2] = (float)vals[iz];
+        if (!cloud.rgb.empty() && ir >= 0 && ig >= 0 && ib >= 0) { cloud.rgb[3 * i] = (uint8_t)vals[ir]; cloud.rgb[3 * i + 1] = (uint8_t)vals[ig]; cloud.rgb[3 * i + 2] = (uint8_t)vals[ib]; }
+        if (!cloud.normals.empty()) { cloud.normals[3 * i] = (float)vals[inx]; cloud.normals[3 * i + 1] = (float)vals[iny]; cloud.normals[3 * i + 2] = (float)vals[inz]; }
+      }
+    } else if (!has_list) {
+      size_t stride = 0;
+      std::vector<size_t> off(e.props.size());
+      for (size_t p = 0; p < e.props.size(); ++p) { off[p] = stride; const int ts = type_size(e.props[p].type); if (!ts) { std::cerr << "[loadPLYFile] unknown type " << e.props[p].type << std::endl; return -1; } stride += ts; }
+      if (!is_vertex) { f.seekg((std::streamoff)(stride * e.count), std::ios::cur); continue; }
+      const size_t chunk = 1 << 20;
+      std::vector<unsigned char> buf(stride * std::min(chunk, e.count ? e.count : 1));
+      for (size_t i0 = 0; i0 < e.count; i0 += chunk) {
+        const size_t m = std::min(chunk, e.count - i0);
+        f.read(reinterpret_cast<char*>(buf.data()), (std::streamsize)(stride * m));
+        if ((size_t)f.gcount() != stride * m) { std::cerr << "[loadPLYFile] truncated file " << path << std::endl; return -1; }
+        for (size_t j = 0; j < m; ++j) {
+          const unsigned char* r = buf.data() + stride * j;
+          const size_t i = i0 + j;
+          cloud.xyz[3 * i] = (float)read_scalar(r + off[ix], e.props[ix].type, swap);
+          cloud.xyz[3 * i + 1] = (float)read_scalar(r + off[iy], e.props[iy].type, swap);
+          cloud.xyz[3 * i + 2] = (float)read_scalar(r + off[iz], e.props[iz].type, swap);
+          if (!cloud.rgb.empty() && ir >= 0 && ig >= 0 && ib >= 0) {
+            cloud.rgb[3 * i] = (uint8_t)read_scalar(r + off[ir], e.props[ir].type, swap);
+            cloud.rgb[3 * i + 1] = (uint8_t)read_scalar(r + off[ig], e.props[ig].type, swap);
+            cloud.rgb[3 * i + 2] = (uint8_t)read_scalar(r + off[ib], e.props[ib].type, swap);
+          }
+          if (!cloud.normals.empty()) {
+            cloud.normals[3 * i] = (float)read_scalar(r + off[inx], e.props[inx].type, swap);
+            cloud.normals[3 * i + 1] = (float)read_scalar(r + off[iny], e.props[iny].type, swap);
+            cloud.normals[3 * i + 2] = (float)read_scalar(r + off[inz], e.props[inz].type, swap);
+          }
+        }
+      }
+    } else {
+      // binary element with list properties (faces): walk it record by record
+      for (size_t i = 0; i < e.count; ++i)
+        for (size_t p = 0; p < e.props.size(); ++p) {
+          unsigned char b[8];
+          if (e.props[p].is_list) {
+            const int cs = type_size(e.props[p].count_type), ts = type_size(e.props[p].type);
+            f.read(reinterpret_cast<char*>(b), cs);
+            const size_t c = (size_t)read_scalar(b, e.props[p].count_type, swap);
+            f.seekg((std::streamoff)(c * ts), std::ios::cur);
+          } else {
+            f.seekg(type_size(e.props[p].type), std::ios::cur);
+          }
+        }
+      if (is_vertex) { std::cerr << "[loadPLYFile] list properties in the vertex element are not supported" << std::endl; return -1; }
+    }
+    if (is_vertex) return 0;   // everything after the vertices (faces, camera) is irrelevant for the tools
+  }
+  std::cerr << "[loadPLYFile] no vertex element in " << path << std::endl;
+  return -1;
+}
+
+// x y z nx ny nz (f32) + red green blue (u8), binary little endian, PCL-style header incl. the camera element.
+inline int savePLYFileBinaryXYZNormalRGB(const std::string& path, const std::vector<unsigned char>& data, size_t n) {
+  std::ofstream f(path, std::ios::binary);
+  if (!f) { std::cerr << "[savePLYFile] cannot open " << path << std::endl; return -1; }
+  f << "ply\nformat binary_little_endian 1.0\ncomment PCL generated\nelement vertex " << n << "\n"
+    << "property float x\nproperty float y\nproperty float z\nproperty float nx\nproperty float ny\nproperty float nz\n"
+    << "property uchar red\nproperty uchar green\nproperty uchar blue\n"
+    << "element camera 1\nproperty float view_px\nproperty float view_py\nproperty float view_pz\n"
+    << "property float x_axisx\nproperty float x_axisy\nproperty float x_axisz\n"
+    << "property float y_axisx\nproperty float y_axisy\nproperty float y_axisz\n"
+    << "property float z_axisx\nproperty float z_axisy\nproperty float z_axisz\n"
+    << "property float focal\nproperty float scalex\nproperty float scaley\nproperty float centerx\nproperty float centery\n"
+    << "property int viewportx\nproperty int viewporty\nproperty float k1\nproperty float k2\nend_header\n";
+  f.write(reinterpret_cast<const char*>(data.data()), (std::streamsize)data.size());
+  const float cam_f[12] = {0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0, 1};   // origin, identity orientation
+  f.write(reinterpret_cast<const char*>(cam_f), sizeof cam_f);
+  const float zeros5[5] = {0, 0, 0, 0, 0};
+  f.write(reinterpret_cast<const char*>(zeros5), sizeof zeros5);
+  const int32_t vp[2] = {(int32_t)n, 1};
+  f.write(reinterpret_cast<const char*>(vp), sizeof vp);
+  const float zeros2[2] = {0, 0};
+  f.write(reinterpret_cast<const char*>(zeros2), sizeof zeros2);
+  return f ? 0 : -1;
+}
+
+// minimal writer used by tests / examples: x y z as binary f32
+inline int savePLYFileBinaryXYZ(const std::string& path, const std::vector<float>& xyz) {
+  std::ofstream f(path, std::ios::binary);
+  if (!f) return -1;
+  f << "ply\nformat binary_little_endian 1.0\nelement vertex " << xyz.size() / 3 << "\nproperty float x\nproperty float y\nproperty float z\nend_header\n";
+  f.write(reinterpret_cast<const char*>(xyz.data()), (std::streamsize)(xyz.size() * sizeof(float)));
+  return f ? 0 : -1;
+}
+
+}  // namespace e3d_host

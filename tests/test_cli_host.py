@@ -1,0 +1,48 @@
+"""Host-side (no GPU) behaviour of the drop-in tools: flag handling, .mlp / PLY I/O, early-out paths."""
+import os
+import subprocess
+
+import numpy as np
+
+from cli_util import BIN, read_mlp, write_mlp, write_ply_xyz
+
+
+def _build():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(os.path.dirname(BIN), "csrc", "host")])
+
+
+def test_usage_and_exit_codes(tmp_path):
+    _build()
+    r = subprocess.run([os.path.join(BIN, "ICPScanAligner")], capture_output=True, text=True)
+    assert r.returncode != 0 and "Please provide input and output MeshLab project paths with -i and -o." in r.stdout
+    r = subprocess.run([os.path.join(BIN, "NormalEstimator"), "-i", "x.mlp"], capture_output=True, text=True)
+    assert r.returncode != 0 and "Please provide input paths." in r.stdout
+    r = subprocess.run([os.path.join(BIN, "ICPScanAligner"), "-i", str(tmp_path / "missing.mlp"), "-o", str(tmp_path / "o.mlp")],
+                       capture_output=True, text=True)
+    assert r.returncode != 0 and "Cannot load MeshLab project" in r.stdout
+
+
+def test_single_object_early_out_roundtrips_the_project(tmp_path):
+    """0 or 1 movable object and nothing fixed: the tool only rewrites the project (icp_scan_aligner.cc:262-272).
+    Exercises the .mlp reader/writer (entities, label/filename, 6-significant-digit matrix text with trailing
+    spaces) without touching the GPU."""
+    _build()
+    T = np.eye(4); T[:3, 3] = [1.5, -2.25, 0.333333333]; T[0, 0] = 0.999999999
+    write_ply_xyz(str(tmp_path / "a.ply"), np.zeros((3, 3), np.float32))
+    write_mlp(str(tmp_path / "in.mlp"), [("scan &amp; one", "a.ply", T), ("two", "b.ply", np.eye(4))])
+    out = tmp_path / "out.mlp"
+    r = subprocess.run([os.path.join(BIN, "ICPScanAligner"), "-i", str(tmp_path / "in.mlp"), "-o", str(out),
+                        "--objects_to_optimize", "a.ply", "--objects_to_ignore", "b.ply", "--unknown_flag", "7"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "Starting alignment with the following parameters:" in r.stdout
+    assert "  max_num_iterations: 50" in r.stdout and "  max_correspondence_distance: 0.1" in r.stdout
+    assert "  optimizing a.ply" in r.stdout and "  ignoring b.ply" in r.stdout
+    assert "Warning: Not enough active objects" in r.stdout
+    m = read_mlp(str(out))
+    assert [(x[0], x[1]) for x in m] == [("scan &amp; one", "a.ply"), ("two", "b.ply")]
+    assert np.allclose(m[0][2], T, atol=1e-5) and np.allclose(m[1][2], np.eye(4))
+    # text contract: four rows, every row ends with a space before the newline (MeshLab needs it)
+    rows = m[0][3].strip("\n").split("\n")
+    assert len(rows) == 4 and all(row.endswith(" ") for row in rows) and rows[3] == "0 0 0 1 "
+    assert rows[0].split()[3] == "1.5" and rows[1].split()[3] == "-2.25" and rows[2].split()[3] == "0.333333"

@@ -1,0 +1,101 @@
+"""End-to-end runs of the drop-in binaries on the GPU box: same inputs through ICPScanAligner / NormalEstimator and
+through the CPU oracle; stdout contract (correspondence counts), output poses and output PLY are compared."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from cli_util import BIN, read_mlp, read_ply_normals, write_mlp, write_ply_xyz
+from conftest import pose_error
+
+pytestmark = pytest.mark.gpu
+
+
+def _project(tmp_path, synth, n_scans, n_points, seed, binary=True, rgb=False):
+    scans = synth.make_scene(n_scans, n_points, seed=seed)
+    entries = []
+    for i, s in enumerate(scans):
+        fn = "scan%d.ply" % i
+        colors = (np.random.RandomState(i).randint(0, 256, (n_points, 3)).astype(np.uint8)) if rgb else None
+        write_ply_xyz(str(tmp_path / fn), s["xyz"].numpy(), colors, binary=binary)
+        s["rgb"] = colors
+        entries.append(("scan%d" % i, fn, s["T_init"].astype(np.float64)))
+    write_mlp(str(tmp_path / "in.mlp"), entries)
+    return scans
+
+
+def test_icp_scan_aligner_cli_matches_oracle(tmp_path, synth, ob, e3d):
+    scans = _project(tmp_path, synth, 3, 20000, seed=77, binary=True)
+    out = tmp_path / "out.mlp"
+    iters = 4
+    r = subprocess.run([os.path.join(BIN, "ICPScanAligner"), "-i", str(tmp_path / "in.mlp"), "-o", str(out), "-d", "0.15",
+                        "--max_iterations", str(iters), "--convergence_threshold", "1e-10",
+                        "--objects_to_optimize", "scan1.ply;scan2.ply", "--normal_estimation_neighbor_count", "16"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    # the oracle with the same steps as the tool: normals (k = 16, viewpoint origin) then ICP, scan0 fixed
+    o = ob.OracleICP()
+    ids = []
+    for i, s in enumerate(scans):
+        P = s["xyz"].numpy()
+        n, _ = ob.normals(P, k=16, viewpoint=(0, 0, 0))
+        # the .mlp text carries 9 significant digits -> poses as the tool parses them
+        ids.append(o.add_point_cloud(P, n, np.array(["%.9g" % v for v in s["T_init"].ravel()], np.float64).reshape(4, 4).astype(np.float32), i == 0))
+    for it in range(iters):
+        o.run(0.15, it, 1, 1e-10, False)
+    # stdout contract: iteration headers + one "found correspondences" line per directed pair with the exact counts
+    assert r.stdout.count("-- Alignment iteration") == iters and "Starting ICP ..." in r.stdout and r.stdout.rstrip().endswith("Finished!")
+    got = re.findall(r"found correspondences from (fixed clouds|\d+) to (fixed clouds|\d+): (\d+)", r.stdout)
+    exp = [(("fixed clouds" if a < 0 else str(a)), ("fixed clouds" if b < 0 else str(b)), str(c)) for (_, a, b, c, _) in o.pair_records()]
+    # GPU normals differ from the oracle's in the last ulp (device trig), so later iterations may differ by a few
+    # correspondences; the first iteration depends on positions only and must match exactly
+    n_first = len(exp) // iters
+    assert got[:n_first] == exp[:n_first]
+    for g, e in zip(got, exp):
+        assert g[:2] == e[:2] and abs(int(g[2]) - int(e[2])) <= max(3, int(e[2]) // 2000)
+    m = read_mlp(str(out))
+    assert [x[1] for x in m] == ["scan0.ply", "scan1.ply", "scan2.ply"]
+    assert np.allclose(m[0][2], scans[0]["T_init"], atol=1e-5)          # fixed scan untouched
+    for i in (1, 2):
+        ang, tr = pose_error(m[i][2], o.get_result_global_T_cloud(ids[i]))
+        assert ang <= 2e-5 and tr <= 1e-4 + 1e-5 * np.abs(m[i][2][:3, 3]).max()   # .mlp text keeps 6 significant digits
+
+
+def test_icp_scan_aligner_multiscale_runs(tmp_path, synth):
+    _project(tmp_path, synth, 2, 30000, seed=78, binary=False)            # ascii PLY input
+    out = tmp_path / "out.mlp"
+    r = subprocess.run([os.path.join(BIN, "ICPScanAligner"), "-i", str(tmp_path / "in.mlp"), "-o", str(out), "-d", "0.05",
+                        "--max_iterations", "3", "--number_of_scales", "2", "--downscale_step", "4"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "Optimizing at scale 0" in r.stdout and "Optimizing at scale 1" in r.stdout
+    assert r.stdout.count("Loaded mesh: scan0.ply") == 2                 # re-read from disk at every scale
+    # scale 0 uses every 4th point and twice the search distance
+    first = re.findall(r"found correspondences from 0 to 1: (\d+)", r.stdout)
+    assert len(first) >= 2 and int(first[0]) <= 7500
+    assert os.path.exists(out)
+
+
+def test_normal_estimator_cli(tmp_path, synth, ob):
+    scans = _project(tmp_path, synth, 2, 15000, seed=79, binary=True, rgb=True)
+    out = tmp_path / "normals.ply"
+    r = subprocess.run([os.path.join(BIN, "NormalEstimator"), "-i", str(tmp_path / "in.mlp"), "-o", str(out), "--neighbor_count", "8"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "Finished!" in r.stdout, r.stdout + r.stderr
+    header, rec, tail = read_ply_normals(str(out))
+    assert "property float nx" in header and "property uchar blue" in header and "element camera 1" in header
+    assert rec.shape[0] == 30000 and tail == 4 * 12 + 4 * 5 + 4 * 2 + 4 * 2      # PCL's camera block follows the vertices
+    off = 0
+    for s in scans:
+        T = np.array(["%.9g" % v for v in s["T_init"].ravel()], np.float64).reshape(4, 4).astype(np.float32)
+        gx, _, _, _ = ob.transform_cloud(s["xyz"].numpy(), s["xyz"].numpy(), T)
+        n = s["xyz"].shape[0]
+        # unit-scale project: scale_factor = 1/scale(first matrix) ~ 1 -> positions equal the transformed cloud to f32 rounding
+        assert np.abs(rec["p"][off:off + n] - gx).max() <= 2e-5
+        assert np.array_equal(rec["c"][off:off + n], s["rgb"])
+        on, _ = ob.normals(rec["p"][off:off + n].copy(), k=8, viewpoint=tuple(T[:3, 3]))
+        good = np.abs(np.einsum("ij,ij->i", rec["n"][off:off + n], on)) > 1 - 1e-3
+        assert good.mean() > 0.995
+        off += n

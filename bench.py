@@ -163,11 +163,21 @@ def main():
             per_launch_bytes = ALG_BYTES_PER_CORR_PASS * (corr / world / K)     # local correspondences of one iteration
             avg_ms = lm_ms / max(passes, 1)
             kernel = "k_lm_pass (fused cost + Gramian pass, a7/a8)"
+            kernel_key = "k_lm_pass<1>"
         else:
             per_launch_bytes = ALG_BYTES_PER_QUERY * (queries / world / n_nn_launch)
             avg_ms = nn_ms / n_nn_launch
-            kernel = "k_nn_query (exact 1-NN within radius, a5)"
+            kernel = "k_nn_rows (exact 1-NN within radius over LDS-staged cell rows, a5)"
+            kernel_key = "k_nn_rows"
         achieved = per_launch_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        # HBM traffic per launch of that kernel: rocprofv3 PMC (FETCH_SIZE / WRITE_SIZE, separate passes, gfx950
+        # corrections applied) of this same workload, committed under profiles/ (bench.py cannot run the profiler itself)
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", "round1_traffic.json")
+        if world == 1 and n_points == 50_000_000 and os.path.exists(tpath):
+            tk = json.load(open(tpath))["kernels"].get(kernel_key)
+            if tk:
+                traffic, traffic_src = tk["hbm_bytes_per_launch"], "profiles/round1_traffic.json"
         out = {
             "metric": "ICP correspondences/sec", "value": corr / dt, "unit": "correspondences/s",
             "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": dt / K * 1e3,
@@ -183,7 +193,10 @@ def main():
             "breakdown_ms_per_iter": {"transform_bbox": tot[6] / world / K, "nn_search_and_compaction": tot[7] / world / K,
                                       "lm_total": tot[8] / world / K, "lm_pass_kernels": lm_ms / K, "nn_query_kernels": nn_ms / K},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": kernel,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "kernel": kernel,
+                         "note": "the NN kernel is VALU-issue bound, not HBM bound (rocprofv3 PMC: SQ_ACTIVE_INST_VALU ~ 78 % of its "
+                                 "wave cycles, profiles/round1_nn_rows_pmc_sq_*.txt); the LM pass kernel streams at the HBM roofline "
+                                 "(see other.k_lm_pass_GBs)",
                          "algorithmic_bytes_per_launch": per_launch_bytes, "avg_launch_ms": avg_ms,
                          "other": {"k_lm_pass_GBs": (ALG_BYTES_PER_CORR_PASS * corr / world / K) / (lm_ms / max(passes, 1) * 1e-3) / 1e9 if lm_ms > 0 else None,
                                    "k_nn_query_GBs": (ALG_BYTES_PER_QUERY * queries / world / n_nn_launch) / (nn_ms / n_nn_launch * 1e-3) / 1e9 if nn_ms > 0 else None}},

@@ -88,11 +88,19 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no HIP device visible)")
+    # E3D_BENCH_SHARE_GPU=1: all ranks on GPU 0 with the gloo backend -- only for smoke-testing the multi-rank code
+    # path on a 1-GPU box; real runs use one GPU per rank and RCCL ("nccl").
+    share_gpu = os.environ.get("E3D_BENCH_SHARE_GPU", "0") == "1"
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        if share_gpu:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
 
     e3d = importlib.import_module("dataset-pipeline_amd")
     synth = importlib.import_module("dataset-pipeline_amd.synth")
@@ -145,9 +153,10 @@ def main():
         sum(r["t_transform_ms"] for r in recs), sum(r["t_nn_ms"] for r in recs), sum(r["t_lm_ms"] for r in recs),
     ], dtype=np.float64)
     if world > 1:
-        tmax = torch.tensor([local[0]], device=dev, dtype=torch.float64)
+        cdev = torch.device("cpu") if share_gpu else dev
+        tmax = torch.tensor([local[0]], device=cdev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        tsum = torch.from_numpy(local).to(dev)
+        tsum = torch.from_numpy(local).to(cdev)
         dist.all_reduce(tsum)
         tot = tsum.cpu().numpy()
         dt = float(tmax.item())

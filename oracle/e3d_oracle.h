@@ -116,6 +116,52 @@ void oracle_point_normal(const float* xyz, const int32_t* indices, int count,
 void oracle_knn(const float* xyz, size_t n, const float* queries, size_t n_q, int k,
                 int32_t* idx, float* dist);
 
+/* ---- (B) dense photometric image registration: per-observation arithmetic of ImageRegistrator (oracle_reg.c).
+ * PINHOLE cameras (type 0), non-rig images, colour residuals (fixed + variable descriptors). -------------------------- */
+typedef struct { int type; int width, height; float p[12]; float cutoff2; } oreg_camera;
+
+void oracle_reg_camera_init(oreg_camera* c, int type, int w, int h, const float* params);
+void oracle_reg_camera_scaled(const oreg_camera* in, float factor, oreg_camera* out);
+void oracle_interp_trilinear_u8(const uint8_t* img0, int w0, const uint8_t* img1, int w1, float x0, float y0, float z, float* value);
+void oracle_interp_trilinear_d_u8(const uint8_t* img0, int w0, const uint8_t* img1, int w1, float x0, float y0, float z,
+                                  float* value, float* dx, float* dy, float* dz);
+void oracle_interp_trilinear_f32(const float* img0, int w0, const float* img1, int w1, float x0, float y0, float z, float* value);
+void oracle_interp_trilinear_d_f32(const float* img0, int w0, const float* img1, int w1, float x0, float y0, float z,
+                                   float* value, float* dx, float* dy, float* dz);
+float oracle_reg_robust_residual(int type, float param, float r);
+float oracle_reg_robust_weight(int type, float param, float r);
+void oracle_reg_splat_depth(const float* pts, size_t n, const float R[9], const float t[3], const oreg_camera* cam,
+                            float point_radius, float* depth);
+size_t oracle_reg_observe(const float* pts, size_t n_pts, float point_radius, const uint32_t* indices, size_t n_idx,
+                          const float R[9], const float t[3], const oreg_camera* levels, int min_image_scale,
+                          int n_levels, const uint8_t* const* images, const uint8_t* const* masks,
+                          const float* occlusion, int image_scale, int border, int current_image_scale,
+                          int image_scale_count, float occlusion_threshold, float max_valid_intensity,
+                          uint32_t* out_idx, float* out_x, float* out_y, float* out_scale);
+void oracle_reg_neighbors_observed(size_t n_pts, const uint32_t* obs_idx, size_t n_obs, const uint32_t* nbr, int K,
+                                   uint8_t* flags);
+void oracle_reg_pass1(const float* pts, float point_radius, const oreg_camera* cam_min, int min_image_scale,
+                      const uint8_t* const* images, const int* widths, const float R[9], const float t[3],
+                      const uint32_t* obs_idx, const float* obs_x, const float* obs_y, const float* obs_scale, size_t n_obs,
+                      float* intensities, float* j_intr, float* j_pose);
+void oracle_reg_accumulate(const float* pts, size_t n_pts, float point_radius, const uint32_t* nbr, int K,
+                           const float* fixed_desc, const float* var_desc, const int32_t* obs_counts,
+                           const oreg_camera* cam_min, int min_image_scale, const uint8_t* const* images, const int* widths,
+                           const float R[9], const float t[3], const uint32_t* obs_idx, const float* obs_x,
+                           const float* obs_y, const float* obs_scale, const uint8_t* flags, size_t n_obs, int robust_type,
+                           float robust_param, float fixed_weight, float var_weight, double* H, double* b,
+                           double sums[2], int64_t counts[2]);
+void oracle_reg_cost(size_t n_pts, const uint32_t* nbr, int K, const float* fixed_desc, const float* var_desc,
+                     const int32_t* obs_counts, int min_image_scale, const uint8_t* const* images, const int* widths,
+                     const uint32_t* obs_idx, const float* obs_x, const float* obs_y, const float* obs_scale,
+                     const uint8_t* flags, size_t n_obs, int robust_type, float robust_param, float fixed_weight,
+                     float var_weight, double sums[2], int64_t counts[2]);
+void oracle_reg_color_accumulate(size_t n_pts, const uint32_t* nbr, int K, int min_image_scale, const uint8_t* const* images,
+                                 const int* widths, const uint32_t* obs_idx, const float* obs_x, const float* obs_y,
+                                 const float* obs_scale, const uint8_t* flags, size_t n_obs, float* descriptors,
+                                 int32_t* obs_counts);
+void oracle_reg_color_finish(size_t n_pts, int K, float* descriptors, const int32_t* obs_counts);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,429 @@
+/*
+ * oracle/oracle_reg.c -- TEST INFRASTRUCTURE ONLY (CPU oracle, path (B): dense photometric image registration).
+ *
+ * Restates the per-observation arithmetic of the reference's ImageRegistrator hot path:
+ *   InterpolateBilinear/Trilinear(WithDerivatives)NoCheck   src/opt/interpolate_bilinear.h:36-74, interpolate_trilinear.h:44-87
+ *   RobustWeighting                                        src/opt/robust_weighting.h:61-107
+ *   camera device functions (PINHOLE)                      src/camera/camera_base_impl.h:155-164,333-408,410-463, camera_pinhole.h:50-85
+ *   OcclusionGeometry::_RenderDepthMapWithSplatsCPU         src/opt/occlusion_geometry.cc:404-464
+ *   VisibilityEstimator::_AppendObservationsForImage /
+ *     _AppendObservationsForIndexedPointsVisibleInImage /
+ *     CreateObservationIfScaleFits /
+ *     DetermineIfAllNeighborsAreObserved                    src/opt/visibility_estimator.cc:258-295,366-403,405-532,199-256
+ *   IntrinsicsAndPoseOptimizer::AccumulateHAndBAndResidualsForObservations,
+ *     ComputePointIntensityAndJacobians, AccumulateHAndBAndResidualForColorObservation, AccumulateOnHAndB
+ *                                                          src/opt/intrinsics_and_pose_optimizer.cc:624-837,932-1217,839-930,1219-1296
+ *   CostCalculator::AccumulateResidualsForObservations / ComputePointColorResidual   src/opt/cost_calculator.cc:102-271
+ *   ColorOptimizer::Apply                                   src/opt/color_optimizer.cc:40-123
+ * Not covered yet: rig images (J_rig), depth residuals (weight 0 by default), the other 12 camera models.
+ * float -> int conversions follow x86 cvttss2si (out-of-range / NaN -> INT_MIN), which is what the reference's
+ * `int ix = v + 0.5f;` compiles to.
+ */
+#include <float.h>
+#include <limits.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "e3d_oracle.h"
+
+static inline int f2i(float v) { return (v >= -2147483648.0f && v < 2147483648.0f) ? (int)v : INT_MIN; }
+static inline int d2i(double v) { return (v > -2147483649.0 && v < 2147483648.0) ? (int)v : INT_MIN; }
+
+/* ---- cameras ---------------------------------------------------------------------------------------------- */
+void oracle_reg_camera_init(oreg_camera* c, int type, int w, int h, const float* params) {
+  memset(c, 0, sizeof *c);
+  c->type = type; c->width = w; c->height = h;
+  for (int i = 0; i < 4; ++i) c->p[i] = params[i];
+  /* CameraBase caches f_inv = 1/f, c_inv = -c/f (camera_base.h, recalled from its accessor use) */
+  const float fx = c->p[0], fy = c->p[1], cx = c->p[2], cy = c->p[3];
+  const float fxi = 1.0f / fx, fyi = 1.0f / fy, cxi = -cx / fx, cyi = -cy / fy;
+  /* InitCutoff (camera_base_impl.h:410-463) for an undistorted model: every border pixel un-distorts to itself, no
+   * second candidate exists => cutoff = 1.01 * max border r^2 */
+  float min_candidate = 0.f;
+  for (int pass = 0; pass < 2; ++pass) {
+    const int cnt = pass == 0 ? w : h;
+    for (int i = 0; i < cnt; ++i)
+      for (int e = 0; e < 2; ++e) {
+        const float px = pass == 0 ? (float)i : (e == 0 ? 0.f : (float)(w - 1));
+        const float py = pass == 0 ? (e == 0 ? 0.f : (float)(h - 1)) : (float)i;
+        const float nx = fxi * px + cxi, ny = fyi * py + cyi;
+        const float r2 = nx * nx + ny * ny;
+        if (r2 > min_candidate) min_candidate = r2;
+      }
+  }
+  c->cutoff2 = min_candidate * 1.01f;
+}
+
+/* CameraBaseImpl::ScaledBy (camera_base_impl.h:70-89) */
+void oracle_reg_camera_scaled(const oreg_camera* in, float factor, oreg_camera* out) {
+  float p[4];
+  p[0] = in->p[0] * factor; p[1] = in->p[1] * factor;
+  p[2] = factor * (in->p[2] + 0.5f) - 0.5f; p[3] = factor * (in->p[3] + 0.5f) - 0.5f;
+  oracle_reg_camera_init(out, in->type, (int)(factor * in->width + 0.5f), (int)(factor * in->height + 0.5f), p);
+}
+
+static inline void cam_normalized_to_image(const oreg_camera* c, float nx, float ny, float* ox, float* oy) {
+  const float r2 = nx * nx + ny * ny;
+  if (isinf(r2) || r2 > c->cutoff2) { *ox = nx * INFINITY; *oy = ny * INFINITY; return; }
+  *ox = c->p[0] * nx + c->p[2];
+  *oy = c->p[1] * ny + c->p[3];
+}
+/* 2x3 row-major */
+static inline void cam_image_deriv_by_world(const oreg_camera* c, const float* P, float* d) {
+  const float nx = P[0] / P[2], ny = P[1] / P[2];
+  if (nx * nx + ny * ny < c->cutoff2) {
+    const float zi = 1.f / P[2];
+    d[0] = zi; d[1] = 0.f; d[2] = (-1.f * nx) * zi;
+    d[3] = 0.f; d[4] = zi; d[5] = (-1.f * ny) * zi;
+  } else {
+    for (int i = 0; i < 6; ++i) d[i] = 0.f;
+  }
+  for (int i = 0; i < 3; ++i) { d[i] = c->p[0] * d[i]; d[3 + i] = c->p[1] * d[3 + i]; }
+}
+/* 2xI row-major, I = 4 */
+static inline void cam_image_deriv_by_intrinsics(const oreg_camera* c, const float* P, float* d) {
+  const float nx = P[0] / P[2], ny = P[1] / P[2];
+  if (nx * nx + ny * ny > c->cutoff2) { for (int i = 0; i < 8; ++i) d[i] = 0.f; return; }
+  d[0] = nx; d[1] = 0.f; d[2] = 1.f; d[3] = 0.f;
+  d[4] = 0.f; d[5] = ny; d[6] = 0.f; d[7] = 1.f;
+}
+
+/* ---- interpolation ------------------------------------------------------------------------------------------ */
+#define DEF_INTERP(SUFFIX, T)                                                                                   \
+  static inline float bilinear_##SUFFIX(const T* img, int w, float x, float y, int ix, int iy) {                 \
+    const float fx = x - ix, fxi = 1.f - fx, fy = y - iy, fyi = 1.f - fy;                                        \
+    const T* r0 = img + (size_t)iy * w; const T* r1 = img + (size_t)(iy + 1) * w;                                \
+    return fyi * (fxi * r0[ix] + fx * r0[ix + 1]) + fy * (fxi * r1[ix] + fx * r1[ix + 1]);                       \
+  }                                                                                                              \
+  static inline void bilinear_d_##SUFFIX(const T* img, int w, float x, float y, int ix, int iy, float* v,        \
+                                         float* dx, float* dy) {                                                 \
+    const T* r0 = img + (size_t)iy * w; const T* r1 = img + (size_t)(iy + 1) * w;                                \
+    const T tl = r0[ix], tr = r0[ix + 1], bl = r1[ix], br = r1[ix + 1];                                          \
+    const float fx = x - ix, fxi = 1.f - fx, fy = y - iy, fyi = 1.f - fy;                                        \
+    const float top = fxi * tl + fx * tr, bottom = fxi * bl + fx * br;                                           \
+    *v = fyi * top + fy * bottom;                                                                                \
+    *dx = fy * (br - bl) + fyi * (tr - tl);                                                                      \
+    *dy = bottom - top;                                                                                          \
+  }                                                                                                              \
+  void oracle_interp_trilinear_##SUFFIX(const T* img0, int w0, const T* img1, int w1, float x0, float y0,        \
+                                        float z, float* value) {                                                 \
+    const int ix0 = (int)x0, iy0 = (int)y0;                                                                      \
+    const float v0 = bilinear_##SUFFIX(img0, w0, x0, y0, ix0, iy0);                                              \
+    const float x1 = 2 * (x0 + 0.5f) - 0.5f, y1 = 2 * (y0 + 0.5f) - 0.5f;                                        \
+    const float v1 = bilinear_##SUFFIX(img1, w1, x1, y1, (int)x1, (int)y1);                                      \
+    *value = (1 - z) * v0 + z * v1;                                                                              \
+  }                                                                                                              \
+  void oracle_interp_trilinear_d_##SUFFIX(const T* img0, int w0, const T* img1, int w1, float x0, float y0,      \
+                                          float z, float* value, float* dx, float* dy, float* dz) {              \
+    float v0, dx0, dy0, v1, dx1, dy1;                                                                            \
+    bilinear_d_##SUFFIX(img0, w0, x0, y0, (int)x0, (int)y0, &v0, &dx0, &dy0);                                    \
+    const float x1 = 2 * (x0 + 0.5f) - 0.5f, y1 = 2 * (y0 + 0.5f) - 0.5f;                                        \
+    bilinear_d_##SUFFIX(img1, w1, x1, y1, (int)x1, (int)y1, &v1, &dx1, &dy1);                                    \
+    *value = (1 - z) * v0 + z * v1;                                                                              \
+    *dx = (1 - z) * dx0 + z * 2 * dx1;                                                                           \
+    *dy = (1 - z) * dy0 + z * 2 * dy1;                                                                           \
+    *dz = v1 - v0;                                                                                               \
+  }
+DEF_INTERP(u8, uint8_t)
+DEF_INTERP(f32, float)
+
+/* ---- robust weighting ----------------------------------------------------------------------------------------- */
+static inline float robust_residual(int type, float param, float r) {
+  if (type == 1) { const float a = fabsf(r); return (a < param) ? 0.5f * r * r : param * (a - 0.5f * param); }
+  if (type == 2) {
+    const float a = fabsf(r);
+    if (a < param) { const float q = r / param; const float t = 1.f - q * q; return (1 / 6.f) * param * param * (1 - t * t * t); }
+    return (1 / 6.f) * param * param;
+  }
+  return 0.5f * r * r;
+}
+static inline float robust_weight(int type, float param, float r) {
+  if (type == 1) { const float a = fabsf(r); return (a < param) ? 1.f : (param / a); }
+  if (type == 2) { const float a = fabsf(r); if (a < param) { const float q = r / param; const float t = 1.f - q * q; return t * t; } return 0.f; }
+  return 1.f;
+}
+float oracle_reg_robust_residual(int type, float param, float r) { return robust_residual(type, param, r); }
+float oracle_reg_robust_weight(int type, float param, float r) { return robust_weight(type, param, r); }
+
+static inline float dot3e(const float* a, const float* b) { return a[0] * b[0] + (a[1] * b[1] + a[2] * b[2]); }
+static inline void rt(const float* R, const float* t, const float* p, float* o) {
+  for (int i = 0; i < 3; ++i) o[i] = dot3e(R + 3 * i, p) + t[i];
+}
+
+/* ---- a24: splat depth map ---------------------------------------------------------------------------------------- */
+void oracle_reg_splat_depth(const float* pts, size_t n, const float R[9], const float t[3], const oreg_camera* cam,
+                            float point_radius, float* depth) {
+  const int W = cam->width, H = cam->height;
+  for (size_t i = 0; i < (size_t)W * H; ++i) depth[i] = INFINITY;
+  const float max_splat_radius = 10;
+  for (size_t i = 0; i < n; ++i) {
+    float pp[3];
+    rt(R, t, pts + 3 * i, pp);
+    if (!(pp[2] > 0.f)) continue;
+    float px, py, d[6];
+    cam_normalized_to_image(cam, pp[0] / pp[2], pp[1] / pp[2], &px, &py);
+    cam_image_deriv_by_world(cam, pp, d);
+    float rx = sqrtf(d[0] * d[0] + (d[1] * d[1] + d[2] * d[2])) * point_radius;
+    float ry = sqrtf(d[3] * d[3] + (d[4] * d[4] + d[5] * d[5])) * point_radius;
+    if (max_splat_radius < rx) rx = max_splat_radius;
+    if (max_splat_radius < ry) ry = max_splat_radius;
+    const int ix = f2i(px + 0.5f), iy = f2i(py + 0.5f);
+    int min_x = d2i((double)((float)ix - rx) + 0.5), min_y = d2i((double)((float)iy - ry) + 0.5);
+    int end_x = d2i((double)((float)ix + rx) + 1.5), end_y = d2i((double)((float)iy + ry) + 1.5);
+    if (min_x < 0) min_x = 0;
+    if (min_y < 0) min_y = 0;
+    if (end_x > W) end_x = W;
+    if (end_y > H) end_y = H;
+    if (min_y < end_y && min_x < end_x)
+      for (int y = min_y; y < end_y; ++y)
+        for (int x = min_x; x < end_x; ++x)
+          if (depth[(size_t)y * W + x] > pp[2]) depth[(size_t)y * W + x] = pp[2];
+  }
+}
+
+/* ---- a20 / a21: observations -------------------------------------------------------------------------------------- */
+size_t oracle_reg_observe(const float* pts, size_t n_pts, float point_radius, const uint32_t* indices, size_t n_idx,
+                          const float R[9], const float t[3], const oreg_camera* levels, int min_image_scale,
+                          int n_levels, const uint8_t* const* images, const uint8_t* const* masks,
+                          const float* occlusion, int image_scale, int border, int current_image_scale,
+                          int image_scale_count, float occlusion_threshold, float max_valid_intensity,
+                          uint32_t* out_idx, float* out_x, float* out_y, float* out_scale) {
+  const int lvl = image_scale - min_image_scale < 0 ? 0 : image_scale - min_image_scale;
+  const oreg_camera* cam = &levels[lvl];
+  const int check_masks = (indices == NULL);
+  const size_t count = indices ? n_idx : n_pts;
+  size_t n_out = 0;
+  for (size_t k = 0; k < count; ++k) {
+    const size_t pi = indices ? indices[k] : k;
+    float pp[3];
+    rt(R, t, pts + 3 * pi, pp);
+    if (!(pp[2] > 0.f)) continue;
+    float ixf, iyf;
+    cam_normalized_to_image(cam, pp[0] / pp[2], pp[1] / pp[2], &ixf, &iyf);
+    int ix = f2i(ixf + 0.5f), iy = f2i(iyf + 0.5f);
+    if (!(ix >= 0 && iy >= 0 && ix < cam->width && iy < cam->height)) continue;
+    if (!indices && !(occlusion[(size_t)iy * cam->width + ix] + occlusion_threshold >= pp[2])) continue;
+    /* CreateObservationIfScaleFits */
+    const float pr[3] = {pp[0] + point_radius, pp[1] + 0.f, pp[2] + 0.f};
+    float rxf, ryf;
+    cam_normalized_to_image(cam, pr[0] / pr[2], pr[1] / pr[2], &rxf, &ryf);
+    const float dx = rxf - ixf, dy = ryf - iyf;
+    const float radius_pixels = sqrtf(dx * dx + dy * dy);
+    const float observation_scale = image_scale + log2f(2 * radius_pixels);
+    const int lo = min_image_scale > current_image_scale ? min_image_scale : current_image_scale;
+    if (!(observation_scale >= lo && f2i(observation_scale) < image_scale_count - 1)) continue;
+    const int small_scale = f2i(observation_scale) + 1;
+    int li = small_scale - min_image_scale; if (li < 0) li = 0;
+    if (li >= n_levels) continue;   /* cannot happen for consistent inputs (image_scale_count bounds it) */
+    const oreg_camera* ic = &levels[li];
+    const float fxi = 1.0f / cam->p[0], fyi = 1.0f / cam->p[1], cxi = -cam->p[2] / cam->p[0], cyi = -cam->p[3] / cam->p[1];
+    const float nx = fxi * ixf + cxi, ny = fyi * iyf + cyi;
+    const float jx = ic->p[0] * nx + ic->p[2], jy = ic->p[1] * ny + ic->p[3];
+    ix = f2i(jx + 0.5f); iy = f2i(jy + 0.5f);
+    if (!(jx + 0.5f >= border && jy + 0.5f >= border && ix >= border && iy >= border && ix < ic->width - border &&
+          iy < ic->height - border))
+      continue;
+    if (check_masks) {
+      const int pl = small_scale - min_image_scale;
+      if (masks && masks[pl] && masks[pl][(size_t)iy * ic->width + ix] != 0) continue;
+      if (images[pl][(size_t)iy * ic->width + ix] > max_valid_intensity) continue;
+    }
+    out_idx[n_out] = (uint32_t)pi; out_x[n_out] = jx; out_y[n_out] = jy; out_scale[n_out] = observation_scale;
+    ++n_out;
+  }
+  return n_out;
+}
+
+/* ---- a22 ---------------------------------------------------------------------------------------------------------- */
+void oracle_reg_neighbors_observed(size_t n_pts, const uint32_t* obs_idx, size_t n_obs, const uint32_t* nbr, int K,
+                                   uint8_t* flags) {
+  uint8_t* seen = (uint8_t*)calloc(n_pts ? n_pts : 1, 1);
+  for (size_t i = 0; i < n_obs; ++i) seen[obs_idx[i]] = 1;
+  for (size_t i = 0; i < n_obs; ++i) {
+    uint8_t all = 1;
+    for (int k = 0; k < K; ++k) if (!seen[nbr[(size_t)obs_idx[i] * K + k]]) { all = 0; break; }
+    flags[i] = all;
+  }
+  free(seen);
+}
+
+/* ---- a16: intensity + Jacobian rows of one observation (PINHOLE, I = 4, non-rig) ---------------------------------------- */
+static void point_intensity_and_jacobians(const float* point, float point_radius, const oreg_camera* cam_min,
+                                          int min_image_scale, const uint8_t* const* images, const int* widths,
+                                          const float R[9], const float t[3], float ox, float oy, float oscale,
+                                          float* intensity, float* j_intr /*4*/, float* j_pose /*6*/) {
+  float T[3];
+  rt(R, t, point, T);
+  const int small_scale = f2i(oscale) + 1, large_scale = f2i(oscale);
+  float ji[3];
+  oracle_interp_trilinear_d_u8(images[small_scale - min_image_scale], widths[small_scale - min_image_scale],
+                               images[large_scale - min_image_scale], widths[large_scale - min_image_scale], ox, oy,
+                               1 - (oscale - (float)f2i(oscale)), intensity, &ji[0], &ji[1], &ji[2]);
+  ji[2] = -1 * ji[2];
+  const float scale_factor = (float)pow(2, min_image_scale - small_scale);
+  const float inv_scale_factor = 1.f / scale_factor;
+  ji[0] *= scale_factor; ji[1] *= scale_factor;
+  const float mx = inv_scale_factor * (ox + 0.5f) - 0.5f, my = inv_scale_factor * (oy + 0.5f) - 0.5f;
+  const float To[3] = {T[0] + point_radius, T[1], T[2]};
+  float offx, offy;
+  cam_normalized_to_image(cam_min, To[0] / To[2], To[1] / To[2], &offx, &offy);
+  const float rdx = offx - mx, rdy = offy - my;
+  float denom = 0.693147180559945f * (rdx * rdx + rdy * rdy);
+  if (denom < 1e-6f) denom = 1e-6f;
+  float P[12], Po[8];       /* 3 x 4 and 2 x 4 */
+  cam_image_deriv_by_intrinsics(cam_min, T, P);
+  cam_image_deriv_by_intrinsics(cam_min, To, Po);
+  for (int i = 0; i < 4; ++i) P[8 + i] = ((Po[i] - P[i]) * rdx + (Po[4 + i] - P[4 + i]) * rdy) / denom;
+  for (int i = 0; i < 4; ++i) j_intr[i] = ji[0] * P[i] + (ji[1] * P[4 + i] + ji[2] * P[8 + i]);
+  float W[9], Wo[6];        /* 3 x 3 and 2 x 3 */
+  cam_image_deriv_by_world(cam_min, T, W);
+  cam_image_deriv_by_world(cam_min, To, Wo);
+  for (int i = 0; i < 3; ++i) W[6 + i] = ((Wo[i] - W[i]) * rdx + (Wo[3 + i] - W[3 + i]) * rdy) / denom;
+  float a[3];
+  for (int i = 0; i < 3; ++i) a[i] = ji[0] * W[i] + (ji[1] * W[3 + i] + ji[2] * W[6 + i]);
+  /* [I3 | 0 z -y ; -z 0 x ; y -x 0] */
+  const float C[18] = {1, 0, 0, 0, T[2], -1 * T[1], 0, 1, 0, -1 * T[2], 0, T[0], 0, 0, 1, T[1], -1 * T[0], 0};
+  for (int j = 0; j < 6; ++j) j_pose[j] = a[0] * C[j] + (a[1] * C[6 + j] + a[2] * C[12 + j]);
+}
+
+void oracle_reg_pass1(const float* pts, float point_radius, const oreg_camera* cam_min, int min_image_scale,
+                      const uint8_t* const* images, const int* widths, const float R[9], const float t[3],
+                      const uint32_t* obs_idx, const float* obs_x, const float* obs_y, const float* obs_scale, size_t n_obs,
+                      float* intensities, float* j_intr, float* j_pose) {
+  for (size_t i = 0; i < n_obs; ++i)
+    point_intensity_and_jacobians(pts + 3 * (size_t)obs_idx[i], point_radius, cam_min, min_image_scale, images, widths, R,
+                                  t, obs_x[i], obs_y[i], obs_scale[i], &intensities[i], j_intr + 4 * i, j_pose + 6 * i);
+}
+
+/* a18: AccumulateOnHAndB on the local (I+6) x (I+6) block: products in f32, cast, add in f64 */
+static void accumulate_on_h_and_b(float weight, float residual, const float* ji, const float* jp, double* H, double* b) {
+  if (weight == 0) return;
+  const int V = 10;
+  float J[10];
+  for (int i = 0; i < 4; ++i) J[i] = ji[i];
+  for (int i = 0; i < 6; ++i) J[4 + i] = jp[i];
+  for (int i = 0; i < V; ++i)
+    for (int j = i; j < V; ++j) {
+      /* (weight * j^T) * j  in f32 (block-wise expressions of the reference evaluate to exactly this per entry) */
+      const float wj = weight * J[i];
+      H[i * V + j] += (double)(wj * J[j]);
+    }
+  const float wr = weight * residual;
+  for (int i = 0; i < V; ++i) b[i] += (double)(wr * J[i]);
+}
+
+/* ---- a15 + a17 + a18 --------------------------------------------------------------------------------------------------- */
+void oracle_reg_accumulate(const float* pts, size_t n_pts, float point_radius, const uint32_t* nbr, int K,
+                           const float* fixed_desc, const float* var_desc, const int32_t* obs_counts,
+                           const oreg_camera* cam_min, int min_image_scale, const uint8_t* const* images, const int* widths,
+                           const float R[9], const float t[3], const uint32_t* obs_idx, const float* obs_x,
+                           const float* obs_y, const float* obs_scale, const uint8_t* flags, size_t n_obs, int robust_type,
+                           float robust_param, float fixed_weight, float var_weight, double* H /*10x10*/, double* b /*10*/,
+                           double sums[2], int64_t counts[2]) {
+  float* I = (float*)malloc(sizeof(float) * (n_obs + 1));
+  float* JI = (float*)malloc(sizeof(float) * 4 * (n_obs + 1));
+  float* JP = (float*)malloc(sizeof(float) * 6 * (n_obs + 1));
+  int64_t* row = (int64_t*)malloc(sizeof(int64_t) * (n_pts + 1));
+  for (size_t i = 0; i < n_pts; ++i) row[i] = -1;
+  oracle_reg_pass1(pts, point_radius, cam_min, min_image_scale, images, widths, R, t, obs_idx, obs_x, obs_y, obs_scale, n_obs,
+                   I, JI, JP);
+  for (size_t i = 0; i < n_obs; ++i) row[obs_idx[i]] = (int64_t)i;
+  memset(H, 0, sizeof(double) * 100); memset(b, 0, sizeof(double) * 10);
+  sums[0] = sums[1] = 0; counts[0] = counts[1] = 0;
+  float comp[64];
+  for (size_t i = 0; i < n_obs; ++i) {
+    if (!flags[i]) continue;
+    const size_t p = obs_idx[i];
+    for (int kind = 0; kind < 2; ++kind) {
+      const float sw = kind == 0 ? fixed_weight : var_weight;
+      if (!(sw > 0)) continue;
+      if (kind == 1 && !(obs_counts[p] >= 2)) continue;
+      const float* desc = kind == 0 ? fixed_desc : var_desc;
+      float pr = 0.f;
+      for (int k = 0; k < K; ++k) {
+        const int64_t nr = row[nbr[p * K + k]];
+        const float image_descriptor = I[nr] - I[i];
+        const float c = image_descriptor - desc[p * K + k];
+        comp[k] = c;
+        pr += c * c;
+      }
+      pr = sqrtf(pr);
+      counts[kind]++;
+      sums[kind] += robust_residual(robust_type, robust_param, pr);
+      const float w = sw * robust_weight(robust_type, robust_param, pr);
+      if (w != 0) {
+        for (int k = 0; k < K; ++k) {
+          const int64_t nr = row[nbr[p * K + k]];
+          float ji[4], jp[6];
+          for (int q = 0; q < 4; ++q) ji[q] = JI[4 * nr + q] - JI[4 * i + q];
+          for (int q = 0; q < 6; ++q) jp[q] = JP[6 * nr + q] - JP[6 * i + q];
+          accumulate_on_h_and_b(w, comp[k], ji, jp, H, b);
+        }
+      }
+    }
+  }
+  free(I); free(JI); free(JP); free(row);
+}
+
+/* ---- a19 --------------------------------------------------------------------------------------------------------------- */
+void oracle_reg_cost(size_t n_pts, const uint32_t* nbr, int K, const float* fixed_desc, const float* var_desc,
+                     const int32_t* obs_counts, int min_image_scale, const uint8_t* const* images, const int* widths,
+                     const uint32_t* obs_idx, const float* obs_x, const float* obs_y, const float* obs_scale,
+                     const uint8_t* flags, size_t n_obs, int robust_type, float robust_param, float fixed_weight,
+                     float var_weight, double sums[2], int64_t counts[2]) {
+  float* I = (float*)malloc(sizeof(float) * (n_pts + 1));
+  for (size_t i = 0; i < n_pts; ++i) I[i] = -1.f;
+  for (size_t i = 0; i < n_obs; ++i) {
+    const int s = f2i(obs_scale[i]);
+    oracle_interp_trilinear_u8(images[s + 1 - min_image_scale], widths[s + 1 - min_image_scale], images[s - min_image_scale],
+                               widths[s - min_image_scale], obs_x[i], obs_y[i], 1 - (obs_scale[i] - (float)s), &I[obs_idx[i]]);
+  }
+  sums[0] = sums[1] = 0; counts[0] = counts[1] = 0;
+  for (size_t i = 0; i < n_obs; ++i) {
+    if (!flags[i]) continue;
+    const size_t p = obs_idx[i];
+    for (int kind = 0; kind < 2; ++kind) {
+      const float sw = kind == 0 ? fixed_weight : var_weight;
+      if (!(sw > 0)) continue;
+      if (kind == 1 && !(obs_counts[p] >= 2)) continue;
+      const float* desc = kind == 0 ? fixed_desc : var_desc;
+      float pr = 0.f;
+      for (int k = 0; k < K; ++k) {
+        const float c = (I[nbr[p * K + k]] - I[p]) - desc[p * K + k];
+        pr += c * c;
+      }
+      pr = sqrtf(pr);
+      sums[kind] += robust_residual(robust_type, robust_param, pr);
+      counts[kind]++;
+    }
+  }
+  free(I);
+}
+
+/* ---- a23: one image's contribution, and the final division ---------------------------------------------------------------- */
+void oracle_reg_color_accumulate(size_t n_pts, const uint32_t* nbr, int K, int min_image_scale, const uint8_t* const* images,
+                                 const int* widths, const uint32_t* obs_idx, const float* obs_x, const float* obs_y,
+                                 const float* obs_scale, const uint8_t* flags, size_t n_obs, float* descriptors,
+                                 int32_t* obs_counts) {
+  float* I = (float*)malloc(sizeof(float) * (n_pts + 1));
+  for (size_t i = 0; i < n_pts; ++i) I[i] = -1.f;
+  for (size_t i = 0; i < n_obs; ++i) {
+    const int s = f2i(obs_scale[i]);
+    oracle_interp_trilinear_u8(images[s + 1 - min_image_scale], widths[s + 1 - min_image_scale], images[s - min_image_scale],
+                               widths[s - min_image_scale], obs_x[i], obs_y[i], 1 - (obs_scale[i] - (float)s), &I[obs_idx[i]]);
+  }
+  for (size_t i = 0; i < n_obs; ++i) {
+    if (!flags[i]) continue;
+    const size_t p = obs_idx[i];
+    obs_counts[p] += 1;
+    for (int k = 0; k < K; ++k) descriptors[p * K + k] += I[nbr[p * K + k]] - I[p];
+  }
+  free(I);
+}
+void oracle_reg_color_finish(size_t n_pts, int K, float* descriptors, const int32_t* obs_counts) {
+  for (size_t i = 0; i < n_pts; ++i)
+    if (obs_counts[i] > 1)
+      for (int k = 0; k < K; ++k) descriptors[i * K + k] /= obs_counts[i];
+}

@@ -1,0 +1,177 @@
+"""ctypes binding of the path-(B) oracle (oracle/oracle_reg.c).  TEST INFRASTRUCTURE ONLY."""
+import ctypes as C
+
+import numpy as np
+
+from . import binding as _b
+
+
+class Camera(C.Structure):
+    _fields_ = [("type", C.c_int), ("width", C.c_int), ("height", C.c_int), ("p", C.c_float * 12), ("cutoff2", C.c_float)]
+
+    def params(self):
+        return np.array(self.p[:4], np.float32)
+
+
+_READY = False
+
+
+def lib():
+    global _READY
+    L = _b.lib()
+    if not _READY:
+        fp, u8p, u32p, dp = C.POINTER(C.c_float), C.POINTER(C.c_uint8), C.POINTER(C.c_uint32), C.POINTER(C.c_double)
+        i32p, i64p, ip = C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int)
+        u8pp = C.POINTER(u8p)
+        cp = C.POINTER(Camera)
+        L.oracle_reg_camera_init.argtypes = [cp, C.c_int, C.c_int, C.c_int, fp]
+        L.oracle_reg_camera_scaled.argtypes = [cp, C.c_float, cp]
+        for suffix, tp in (("u8", u8p), ("f32", fp)):
+            getattr(L, "oracle_interp_trilinear_" + suffix).argtypes = [tp, C.c_int, tp, C.c_int, C.c_float, C.c_float, C.c_float, fp]
+            getattr(L, "oracle_interp_trilinear_d_" + suffix).argtypes = [tp, C.c_int, tp, C.c_int, C.c_float, C.c_float, C.c_float, fp, fp, fp, fp]
+        L.oracle_reg_robust_residual.argtypes = [C.c_int, C.c_float, C.c_float]; L.oracle_reg_robust_residual.restype = C.c_float
+        L.oracle_reg_robust_weight.argtypes = [C.c_int, C.c_float, C.c_float]; L.oracle_reg_robust_weight.restype = C.c_float
+        L.oracle_reg_splat_depth.argtypes = [fp, C.c_size_t, fp, fp, cp, C.c_float, fp]
+        L.oracle_reg_observe.argtypes = [fp, C.c_size_t, C.c_float, u32p, C.c_size_t, fp, fp, cp, C.c_int, C.c_int, u8pp, u8pp, fp,
+                                         C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, u32p, fp, fp, fp]
+        L.oracle_reg_observe.restype = C.c_size_t
+        L.oracle_reg_neighbors_observed.argtypes = [C.c_size_t, u32p, C.c_size_t, u32p, C.c_int, u8p]
+        L.oracle_reg_pass1.argtypes = [fp, C.c_float, cp, C.c_int, u8pp, ip, fp, fp, u32p, fp, fp, fp, C.c_size_t, fp, fp, fp]
+        L.oracle_reg_accumulate.argtypes = [fp, C.c_size_t, C.c_float, u32p, C.c_int, fp, fp, i32p, cp, C.c_int, u8pp, ip, fp, fp,
+                                            u32p, fp, fp, fp, u8p, C.c_size_t, C.c_int, C.c_float, C.c_float, C.c_float, dp, dp, dp, i64p]
+        L.oracle_reg_cost.argtypes = [C.c_size_t, u32p, C.c_int, fp, fp, i32p, C.c_int, u8pp, ip, u32p, fp, fp, fp, u8p, C.c_size_t,
+                                      C.c_int, C.c_float, C.c_float, C.c_float, dp, i64p]
+        L.oracle_reg_color_accumulate.argtypes = [C.c_size_t, u32p, C.c_int, C.c_int, u8pp, ip, u32p, fp, fp, fp, u8p, C.c_size_t, fp, i32p]
+        L.oracle_reg_color_finish.argtypes = [C.c_size_t, C.c_int, fp, i32p]
+        _READY = True
+    return L
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def make_camera(w, h, params, ctype=0):
+    c = Camera()
+    pr = np.ascontiguousarray(params, np.float32)
+    lib().oracle_reg_camera_init(C.byref(c), ctype, w, h, _p(pr, C.c_float))
+    return c
+
+
+def camera_pyramid(cam, n_levels):
+    """Intrinsics::BuildModelPyramid: successive ScaledBy(0.5)."""
+    arr = (Camera * n_levels)()
+    arr[0] = cam
+    for i in range(1, n_levels):
+        lib().oracle_reg_camera_scaled(C.byref(arr[i - 1]), 0.5, C.byref(arr[i]))
+    return arr
+
+
+def _img_ptrs(images):
+    keep = [np.ascontiguousarray(im, np.uint8) if im is not None else None for im in images]
+    arr = (C.POINTER(C.c_uint8) * len(keep))()
+    for i, im in enumerate(keep):
+        arr[i] = _p(im, C.c_uint8) if im is not None else None
+    widths = np.array([im.shape[1] if im is not None else 0 for im in keep], np.int32)
+    return arr, widths, keep
+
+
+def trilinear(img0, img1, x0, y0, z, derivs=False):
+    f32 = img0.dtype != np.uint8
+    a0 = np.ascontiguousarray(img0, np.float32 if f32 else np.uint8)
+    a1 = np.ascontiguousarray(img1, np.float32 if f32 else np.uint8)
+    t = C.c_float if f32 else C.c_uint8
+    suffix = "f32" if f32 else "u8"
+    v, dx, dy, dz = C.c_float(), C.c_float(), C.c_float(), C.c_float()
+    if derivs:
+        getattr(lib(), "oracle_interp_trilinear_d_" + suffix)(_p(a0, t), a0.shape[1], _p(a1, t), a1.shape[1], x0, y0, z,
+                                                              C.byref(v), C.byref(dx), C.byref(dy), C.byref(dz))
+        return v.value, dx.value, dy.value, dz.value
+    getattr(lib(), "oracle_interp_trilinear_" + suffix)(_p(a0, t), a0.shape[1], _p(a1, t), a1.shape[1], x0, y0, z, C.byref(v))
+    return v.value
+
+
+def splat_depth(pts, R, t, cam, point_radius):
+    pts = np.ascontiguousarray(pts, np.float32); R = np.ascontiguousarray(R, np.float32); t = np.ascontiguousarray(t, np.float32)
+    d = np.zeros((cam.height, cam.width), np.float32)
+    lib().oracle_reg_splat_depth(_p(pts, C.c_float), pts.shape[0], _p(R, C.c_float), _p(t, C.c_float), C.byref(cam), point_radius, _p(d, C.c_float))
+    return d
+
+
+def observe(pts, point_radius, R, t, levels, min_image_scale, images, masks, occlusion, image_scale, border,
+            current_image_scale, image_scale_count, occlusion_threshold=0.01, max_valid_intensity=252.0, indices=None):
+    pts = np.ascontiguousarray(pts, np.float32); R = np.ascontiguousarray(R, np.float32); t = np.ascontiguousarray(t, np.float32)
+    n = pts.shape[0]
+    ip, widths, keep = _img_ptrs(images)
+    mp, _, keepm = _img_ptrs(masks if masks is not None else [None] * len(images))
+    idx = np.ascontiguousarray(indices, np.uint32) if indices is not None else None
+    cap = len(idx) if idx is not None else n
+    oi = np.zeros(cap + 1, np.uint32); ox = np.zeros(cap + 1, np.float32); oy = np.zeros(cap + 1, np.float32); os_ = np.zeros(cap + 1, np.float32)
+    occ = np.ascontiguousarray(occlusion, np.float32) if occlusion is not None else np.zeros((1, 1), np.float32)
+    c = lib().oracle_reg_observe(_p(pts, C.c_float), n, point_radius, _p(idx, C.c_uint32) if idx is not None else None, cap if idx is not None else 0,
+                                 _p(R, C.c_float), _p(t, C.c_float), levels, min_image_scale, len(levels), ip, mp if masks is not None else None,
+                                 _p(occ, C.c_float), image_scale, border, current_image_scale, image_scale_count,
+                                 occlusion_threshold, max_valid_intensity, _p(oi, C.c_uint32), _p(ox, C.c_float), _p(oy, C.c_float), _p(os_, C.c_float))
+    return oi[:c].copy(), ox[:c].copy(), oy[:c].copy(), os_[:c].copy()
+
+
+def neighbors_observed(n_pts, obs_idx, nbr, K):
+    obs_idx = np.ascontiguousarray(obs_idx, np.uint32); nbr = np.ascontiguousarray(nbr, np.uint32)
+    f = np.zeros(len(obs_idx) + 1, np.uint8)
+    lib().oracle_reg_neighbors_observed(n_pts, _p(obs_idx, C.c_uint32), len(obs_idx), _p(nbr, C.c_uint32), K, _p(f, C.c_uint8))
+    return f[:len(obs_idx)].copy()
+
+
+def pass1(pts, point_radius, cam_min, min_image_scale, images, R, t, obs):
+    pts = np.ascontiguousarray(pts, np.float32); R = np.ascontiguousarray(R, np.float32); t = np.ascontiguousarray(t, np.float32)
+    ip, widths, keep = _img_ptrs(images)
+    oi, ox, oy, os_ = [np.ascontiguousarray(a) for a in obs]
+    n = len(oi)
+    I = np.zeros(n + 1, np.float32); JI = np.zeros((n + 1, 4), np.float32); JP = np.zeros((n + 1, 6), np.float32)
+    lib().oracle_reg_pass1(_p(pts, C.c_float), point_radius, C.byref(cam_min), min_image_scale, ip, _p(widths, C.c_int), _p(R, C.c_float),
+                           _p(t, C.c_float), _p(oi, C.c_uint32), _p(ox, C.c_float), _p(oy, C.c_float), _p(os_, C.c_float), n,
+                           _p(I, C.c_float), _p(JI, C.c_float), _p(JP, C.c_float))
+    return I[:n].copy(), JI[:n].copy(), JP[:n].copy()
+
+
+def accumulate(pts, point_radius, nbr, K, fixed_desc, var_desc, obs_counts, cam_min, min_image_scale, images, R, t, obs, flags,
+               robust_type, robust_param, fixed_weight, var_weight):
+    pts = np.ascontiguousarray(pts, np.float32); R = np.ascontiguousarray(R, np.float32); t = np.ascontiguousarray(t, np.float32)
+    nbr = np.ascontiguousarray(nbr, np.uint32); fd = np.ascontiguousarray(fixed_desc, np.float32); vd = np.ascontiguousarray(var_desc, np.float32)
+    oc = np.ascontiguousarray(obs_counts, np.int32); fl = np.ascontiguousarray(flags, np.uint8)
+    ip, widths, keep = _img_ptrs(images)
+    oi, ox, oy, os_ = [np.ascontiguousarray(a) for a in obs]
+    H = np.zeros((10, 10)); b = np.zeros(10); sums = np.zeros(2); counts = np.zeros(2, np.int64)
+    lib().oracle_reg_accumulate(_p(pts, C.c_float), pts.shape[0], point_radius, _p(nbr, C.c_uint32), K, _p(fd, C.c_float), _p(vd, C.c_float),
+                                _p(oc, C.c_int32), C.byref(cam_min), min_image_scale, ip, _p(widths, C.c_int), _p(R, C.c_float), _p(t, C.c_float),
+                                _p(oi, C.c_uint32), _p(ox, C.c_float), _p(oy, C.c_float), _p(os_, C.c_float), _p(fl, C.c_uint8), len(oi),
+                                robust_type, robust_param, fixed_weight, var_weight, _p(H, C.c_double), _p(b, C.c_double),
+                                _p(sums, C.c_double), _p(counts, C.c_int64))
+    return H, b, sums, counts
+
+
+def cost(n_pts, nbr, K, fixed_desc, var_desc, obs_counts, min_image_scale, images, obs, flags, robust_type, robust_param,
+         fixed_weight, var_weight):
+    nbr = np.ascontiguousarray(nbr, np.uint32); fd = np.ascontiguousarray(fixed_desc, np.float32); vd = np.ascontiguousarray(var_desc, np.float32)
+    oc = np.ascontiguousarray(obs_counts, np.int32); fl = np.ascontiguousarray(flags, np.uint8)
+    ip, widths, keep = _img_ptrs(images)
+    oi, ox, oy, os_ = [np.ascontiguousarray(a) for a in obs]
+    sums = np.zeros(2); counts = np.zeros(2, np.int64)
+    lib().oracle_reg_cost(n_pts, _p(nbr, C.c_uint32), K, _p(fd, C.c_float), _p(vd, C.c_float), _p(oc, C.c_int32), min_image_scale, ip,
+                          _p(widths, C.c_int), _p(oi, C.c_uint32), _p(ox, C.c_float), _p(oy, C.c_float), _p(os_, C.c_float), _p(fl, C.c_uint8),
+                          len(oi), robust_type, robust_param, fixed_weight, var_weight, _p(sums, C.c_double), _p(counts, C.c_int64))
+    return sums, counts
+
+
+def color_accumulate(n_pts, nbr, K, min_image_scale, images, obs, flags, descriptors, obs_counts):
+    nbr = np.ascontiguousarray(nbr, np.uint32); fl = np.ascontiguousarray(flags, np.uint8)
+    ip, widths, keep = _img_ptrs(images)
+    oi, ox, oy, os_ = [np.ascontiguousarray(a) for a in obs]
+    assert descriptors.dtype == np.float32 and obs_counts.dtype == np.int32 and descriptors.flags.c_contiguous
+    lib().oracle_reg_color_accumulate(n_pts, _p(nbr, C.c_uint32), K, min_image_scale, ip, _p(widths, C.c_int), _p(oi, C.c_uint32),
+                                      _p(ox, C.c_float), _p(oy, C.c_float), _p(os_, C.c_float), _p(fl, C.c_uint8), len(oi),
+                                      _p(descriptors, C.c_float), _p(obs_counts, C.c_int32))
+
+
+def color_finish(K, descriptors, obs_counts):
+    lib().oracle_reg_color_finish(len(obs_counts), K, _p(descriptors, C.c_float), _p(obs_counts, C.c_int32))

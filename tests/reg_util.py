@@ -1,0 +1,49 @@
+"""Shared helpers for the path-(B) tests: image pyramids and a small synthetic registration scene."""
+import numpy as np
+
+
+def pyramid_u8(img, n_levels):
+    """Image::BuildImagePyramid (src/opt/image.cc:106-131): cv::resize(..., INTER_AREA) by 1/2 on CV_8U = exact 2x2 box
+    mean with round-half-up for even sizes (recalled); odd trailing rows/cols are dropped."""
+    out = [np.ascontiguousarray(img, np.uint8)]
+    for _ in range(1, n_levels):
+        a = out[-1]
+        h, w = (a.shape[0] // 2) * 2, (a.shape[1] // 2) * 2
+        a = a[:h, :w].astype(np.uint16)
+        s = a[0::2, 0::2] + a[0::2, 1::2] + a[1::2, 0::2] + a[1::2, 1::2]
+        out.append(((s + 2) >> 2).astype(np.uint8))
+    return out
+
+
+def look_at_pose(eye, target, up=(0, 0, 1)):
+    """image_T_global (R, t) of a camera at `eye` looking at `target` (camera z forward, y down)."""
+    eye = np.asarray(eye, np.float64); target = np.asarray(target, np.float64)
+    z = target - eye; z /= np.linalg.norm(z)
+    x = np.cross(z, np.asarray(up, np.float64)); x /= np.linalg.norm(x)
+    y = np.cross(z, x)
+    R = np.stack([x, y, z]).astype(np.float32)
+    t = (-R.astype(np.float64) @ eye).astype(np.float32)
+    return R, t
+
+
+def make_reg_scene(n_points=6000, width=320, height=240, n_levels=4, K=5, seed=0):
+    """A textured, slightly wavy wall seen by a pinhole camera: points + neighbour graph + descriptors + image pyramid."""
+    rng = np.random.RandomState(seed)
+    u = rng.uniform(-1.2, 1.2, n_points); v = rng.uniform(-0.9, 0.9, n_points)
+    pts = np.stack([u, 0.05 * np.sin(3 * u) * np.cos(2 * v) + 3.0, v], 1).astype(np.float32)      # wall near y = 3
+    # K nearest neighbours in 3D (any fixed neighbour graph works for the kernels)
+    from scipy.spatial import cKDTree
+    _, nn = cKDTree(pts).query(pts, k=K + 1)
+    nbr = nn[:, 1:].astype(np.uint32)
+    yy, xx = np.mgrid[0:height, 0:width]
+    img = (110 + 60 * np.sin(xx / 9.0) * np.cos(yy / 7.0) + 40 * np.sin((xx + 2 * yy) / 23.0)).clip(0, 250)
+    img = img.astype(np.uint8)
+    img[:12, :20] = 255                                     # an oversaturated corner
+    pyr = pyramid_u8(img, n_levels)
+    R, t = look_at_pose((0.1, -0.4, 0.05), (0, 3, 0))
+    params = np.array([260.0, 255.0, width / 2 - 0.3, height / 2 + 0.2], np.float32)
+    fixed_desc = rng.normal(0, 8, (n_points, K)).astype(np.float32)
+    var_desc = rng.normal(0, 8, (n_points, K)).astype(np.float32)
+    obs_counts = rng.randint(0, 4, n_points).astype(np.int32)
+    return dict(pts=pts, nbr=nbr, K=K, pyr=pyr, R=R, t=t, params=params, width=width, height=height, n_levels=n_levels,
+                fixed_desc=fixed_desc, var_desc=var_desc, obs_counts=obs_counts, point_radius=0.012)

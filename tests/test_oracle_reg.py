@@ -1,0 +1,151 @@
+"""CPU tests of the path-(B) oracle: the reference's interpolation known answers (src/opt/test/test_interpolation.cc:39-186)
+and its analytic-vs-finite-difference Jacobian test (src/opt/test/test_intrinsics_and_pose_optimizer.cc:101-336) restated,
+plus consistency checks of accumulate / cost / colour update."""
+import numpy as np
+import pytest
+
+from reg_util import make_reg_scene, pyramid_u8
+
+EPS_C = 1e-6
+EPS_E = 1e-5
+
+
+@pytest.fixture(scope="module")
+def rb():
+    from oracle import reg_binding
+    reg_binding.lib()
+    return reg_binding
+
+
+def test_interpolation_trilinear_known_answers(rb):
+    i0 = np.array([[1, 2], [3, 4]], np.float32)
+    i1 = np.arange(16, dtype=np.float32).reshape(4, 4)
+    T = lambda x, y, z: rb.trilinear(i0, i1, x, y, z)
+    assert abs(T(0, 0, 0) - 1) < EPS_E and abs(T(1 - EPS_C, 0, 0) - 2) < EPS_E
+    assert abs(T(0, 1 - EPS_C, 0) - 3) < EPS_E and abs(T(1 - EPS_C, 1 - EPS_C, 0) - 4) < EPS_E
+    assert abs(T(0.25, 0.25, 1) - i1[1, 1]) < EPS_E and abs(T(0.75, 0.25, 1) - i1[1, 2]) < EPS_E
+    assert abs(T(0.25, 0.75, 1) - i1[2, 1]) < EPS_E and abs(T(0.75, 0.75, 1) - i1[2, 2]) < EPS_E
+    assert abs(T(0.5, 0, 0) - 1.5) < EPS_E and abs(T(0, 0.5, 0) - 2.0) < EPS_E
+    assert abs(T(0.5, 0.25, 1) - 0.5 * (i1[1, 1] + i1[1, 2])) < EPS_E
+    assert abs(T(0.25, 0.5, 1) - 0.5 * (i1[1, 1] + i1[2, 1])) < EPS_E
+    assert abs(T(0, 0, 0.5) - (0.5 * 1 + 0.5 * 0.25 * (i1[0, 0] + i1[0, 1] + i1[1, 0] + i1[1, 1]))) < EPS_E
+    v, dx, dy, dz = rb.trilinear(i0, i1, 0, 0, 0, derivs=True)
+    assert abs(v - 1) < EPS_E and abs(dx - 1) < EPS_E and abs(dy - 2) < EPS_E
+    assert abs(dz - (0.25 * (i1[0, 0] + i1[0, 1] + i1[1, 0] + i1[1, 1]) - 1)) < EPS_E
+    v, dx, dy, dz = rb.trilinear(i0, i1, 1 - EPS_C, 0, 0, derivs=True)
+    assert abs(v - 2) < EPS_E and abs(dx - 1) < EPS_E and abs(dy - 2) < EPS_E
+    assert abs(dz - (0.25 * (i1[0, 2] + i1[0, 3] + i1[1, 2] + i1[1, 3]) - 2)) < EPS_E
+
+
+def _se3_exp_apply(delta, R, t):
+    """Image::Update: image_T_global' = exp(delta) * image_T_global (f64 here, cast to f32)."""
+    from scipy.linalg import expm
+    M = np.zeros((4, 4)); w = delta[3:]
+    M[:3, :3] = [[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]]; M[:3, 3] = delta[:3]
+    E = expm(M)
+    T = np.eye(4); T[:3, :3] = R; T[:3, 3] = t
+    Tn = E @ T
+    return Tn[:3, :3].astype(np.float32), Tn[:3, 3].astype(np.float32)
+
+
+def test_point_intensity_jacobians_vs_finite_differences(rb):
+    """ComputePointIntensityAndJacobians: PINHOLE 40x30 (f = 40,30 c = 20,15), image (x + 3y) % 256, 2 scales,
+    3 points, radius 0.036, tolerance 1e-3 -- the reference test's own set-up and bar."""
+    from scipy.spatial.transform import Rotation
+    a = np.array([0.1, 0.3, 0.785]); b = np.array([0.4375, 0.2458, 0.2724])
+    a /= np.linalg.norm(a); b /= np.linalg.norm(b)
+    axis = np.cross(a, b); ang = np.arccos(np.clip(a @ b, -1, 1))
+    Rg = Rotation.from_rotvec(axis / np.linalg.norm(axis) * ang).as_matrix()      # Quaternionf::FromTwoVectors
+    tg = np.array([0.89763, 0.789346, 0.21398])
+    R = Rg.T.astype(np.float32); t = (-Rg.T @ tg).astype(np.float32)              # image_T_global = global_T_image^-1
+    img = np.fromfunction(lambda y, x: (x + 3 * y) % 256, (30, 40)).astype(np.uint8)
+    pyr = pyramid_u8(img, 2)
+    params = np.array([40, 30, 20, 15], np.float32)
+    radius = 0.036
+    tol = 1e-3
+
+    def observe_and_eval(point, R, t, params):
+        cam = rb.make_camera(40, 30, params)
+        levels = rb.camera_pyramid(cam, 2)
+        depth = rb.splat_depth(point[None], R, t, levels[0], 0.03)
+        obs = rb.observe(point[None], radius, R, t, levels, 0, pyr, None, depth, 0, 0, 0, 2)
+        assert len(obs[0]) == 1
+        I, JI, JP = rb.pass1(point[None], radius, levels[0], 0, pyr, R, t, obs)
+        return I[0], JI[0], JP[0]
+
+    for local in ([0.1, 0.23, 2.0], [0.4, 0.67, 2.1], [0.0, 0.0, 1.9]):
+        point = (Rg @ np.array(local) + tg).astype(np.float32)
+        I0, JI, JP = observe_and_eval(point, R, t, params)
+        for c in range(4):
+            p2 = params.copy(); p2[c] += 1.0
+            I1, _, _ = observe_and_eval(point, R, t, p2)
+            assert abs(1.0 * JI[c] - (I1 - I0)) < tol, ("intrinsics", c, JI[c], I1 - I0)
+        for c in range(6):
+            delta = np.zeros(6); delta[c] = 2 * radius if c < 2 else 0.002
+            R2, t2 = _se3_exp_apply(delta, R.astype(np.float64), t.astype(np.float64))
+            I1, _, _ = observe_and_eval(point, R2, t2, params)
+            assert abs(delta[c] * JP[c] - (I1 - I0)) < tol, ("pose", c, delta[c] * JP[c], I1 - I0)
+
+
+def _scene_obs(rb, S, border=1, current_scale=0):
+    cam = rb.make_camera(S["width"], S["height"], S["params"])
+    levels = rb.camera_pyramid(cam, S["n_levels"])
+    depth = rb.splat_depth(S["pts"], S["R"], S["t"], levels[0], 0.03)
+    obs = rb.observe(S["pts"], S["point_radius"], S["R"], S["t"], levels, 0, S["pyr"], None, depth, 0, border, current_scale, S["n_levels"])
+    flags = rb.neighbors_observed(len(S["pts"]), obs[0], S["nbr"], S["K"])
+    return levels, depth, obs, flags
+
+
+def test_observations_and_flags(rb):
+    S = make_reg_scene()
+    levels, depth, obs, flags = _scene_obs(rb, S)
+    oi, ox, oy, os_ = obs
+    assert 2000 < len(oi) <= len(S["pts"]) and np.all(np.diff(oi.astype(np.int64)) > 0)        # point-index order, no duplicates
+    assert np.all(os_ >= 0) and np.all(os_.astype(int) < S["n_levels"] - 1)
+    lvl = os_.astype(int) + 1
+    for i in range(0, len(oi), 37):
+        w, h = levels[lvl[i]].width, levels[lvl[i]].height
+        assert 1 <= int(ox[i] + 0.5) < w - 1 and 1 <= int(oy[i] + 0.5) < h - 1                  # border of 1 px
+    seen = np.zeros(len(S["pts"]), bool); seen[oi] = True
+    assert np.array_equal(flags.astype(bool), seen[S["nbr"][oi]].all(axis=1))
+    # indexed re-observation (fixed visibility list) keeps occluded / masked points -> superset behaviour on the same list
+    obs2 = rb.observe(S["pts"], S["point_radius"], S["R"], S["t"], levels, 0, S["pyr"], None, None, 0, 1, 0, S["n_levels"], indices=oi)
+    assert np.array_equal(obs2[0], oi) and np.array_equal(obs2[1], ox) and np.array_equal(obs2[3], os_)
+
+
+def test_accumulate_matches_cost_and_is_consistent(rb):
+    S = make_reg_scene(seed=3)
+    levels, depth, obs, flags = _scene_obs(rb, S)
+    for rtype, rparam in ((1, 47.43), (2, 30.0), (0, 0.0)):
+        H, b, sums, counts = rb.accumulate(S["pts"], S["point_radius"], S["nbr"], S["K"], S["fixed_desc"], S["var_desc"], S["obs_counts"],
+                                           levels[0], 0, S["pyr"], S["R"], S["t"], obs, flags, rtype, rparam, 1.0, 1.0)
+        s2, c2 = rb.cost(len(S["pts"]), S["nbr"], S["K"], S["fixed_desc"], S["var_desc"], S["obs_counts"], 0, S["pyr"], obs, flags,
+                         rtype, rparam, 1.0, 1.0)
+        assert np.array_equal(counts, c2) and counts[0] == flags.sum() and 0 < counts[1] < counts[0]
+        assert np.allclose(sums, s2, rtol=1e-12)
+        U = np.triu(H)
+        assert np.allclose(np.tril(H, -1), 0) and np.linalg.eigvalsh(U + U.T - np.diag(np.diag(U))).min() > -1e-6 * np.abs(H).max()
+    # weights switch the residual kinds off
+    H, b, sums, counts = rb.accumulate(S["pts"], S["point_radius"], S["nbr"], S["K"], S["fixed_desc"], S["var_desc"], S["obs_counts"],
+                                       levels[0], 0, S["pyr"], S["R"], S["t"], obs, flags, 1, 47.43, 1.0, 0.0)
+    assert counts[1] == 0 and sums[1] == 0
+
+
+def test_color_update(rb):
+    S = make_reg_scene(seed=4)
+    levels, depth, obs, flags = _scene_obs(rb, S)
+    n, K = len(S["pts"]), S["K"]
+    desc = np.zeros((n, K), np.float32); cnt = np.zeros(n, np.int32)
+    for _ in range(3):                                       # the same image three times: mean equals one contribution
+        rb.color_accumulate(n, S["nbr"], K, 0, S["pyr"], obs, flags, desc, cnt)
+    once = np.zeros((n, K), np.float32); c1 = np.zeros(n, np.int32)
+    rb.color_accumulate(n, S["nbr"], K, 0, S["pyr"], obs, flags, once, c1)
+    rb.color_finish(K, desc, cnt)
+    full = obs[0][flags.astype(bool)]
+    assert np.all(cnt[full] == 3) and cnt.sum() == 3 * len(full)
+    assert np.allclose(desc[full], once[full], atol=1e-4)
+    rb.color_finish(K, once, c1)                              # count == 1: NOT divided (color_optimizer.cc:114-120)
+    I, _, _ = rb.pass1(S["pts"], S["point_radius"], levels[0], 0, S["pyr"], S["R"], S["t"], obs)
+    row = -np.ones(n, np.int64); row[obs[0]] = np.arange(len(obs[0]))
+    p = full[5]
+    assert np.allclose(once[p], I[row[S["nbr"][p]]] - I[row[p]], atol=1e-5)

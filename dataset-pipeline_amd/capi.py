@@ -61,6 +61,28 @@ SIGNATURES = {
                                       C.c_void_p, C.c_void_p]),
     "e3d_icp_pair_system": (C.c_int, [C.c_void_p] * 6 + [C.c_int64] + [C.c_void_p] * 7),
     "e3d_normals_knn": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    # (B) image registration kernels
+    "e3d_reg_create": (C.c_void_p, [C.c_void_p]),
+    "e3d_reg_destroy": (None, [C.c_void_p]),
+    "e3d_reg_set_params": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "e3d_reg_set_point_scale": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_float, C.c_void_p, C.c_void_p]),
+    "e3d_reg_set_variable_descriptors": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "e3d_reg_get_variable_descriptors": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "e3d_reg_set_intrinsics": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "e3d_reg_get_intrinsics_level": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "e3d_reg_set_image": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "e3d_reg_set_image_pose": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "e3d_reg_set_splat_points": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "e3d_reg_render_depth": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "e3d_reg_observe": (C.c_int64, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t]),
+    "e3d_reg_get_observations": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "e3d_reg_set_observations": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "e3d_reg_pass1": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "e3d_reg_accumulate": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "e3d_reg_cost": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "e3d_reg_color_begin": (C.c_int, [C.c_void_p, C.c_int]),
+    "e3d_reg_color_accumulate": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "e3d_reg_color_finish": (C.c_int, [C.c_void_p, C.c_int]),
 }
 
 
@@ -259,3 +281,139 @@ def normals_knn(xyz, k, viewpoint=(0.0, 0.0, 0.0), return_knn=False):
     if r < 0:
         _err("e3d_normals_knn", r)
     return (on, oc, knn) if return_knn else (on, oc)
+
+
+# ---- (B) image registration kernels ------------------------------------------------------------------------------------
+class RegParams(C.Structure):
+    """e3d_reg_params -- the opt::Parameters fields the device code reads (src/opt/parameters.h:40-68)."""
+    _fields_ = [("point_neighbor_count", C.c_int32), ("robust_weighting_type", C.c_int32),
+                ("robust_weighting_parameter", C.c_float), ("fixed_residuals_weight", C.c_float),
+                ("variable_residuals_weight", C.c_float), ("maximum_valid_intensity", C.c_float),
+                ("occlusion_depth_threshold", C.c_float), ("splat_radius", C.c_float),
+                ("current_image_scale", C.c_int32), ("image_scale_count", C.c_int32)]
+
+
+def default_reg_params(**kw):
+    p = RegParams(5, 1, float(np.float32(30 * np.sqrt(5) / np.sqrt(2))), 1.0, 1.0, 252.0, 0.01, 0.03, 0, 2)
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+class RegProblem:
+    """Device-resident mirror of the parts of opt::Problem the ImageRegistrator hot loops read, plus the kernel-level
+    operators (render depth / observe / accumulate / cost / colour update).  One method per C-ABI entry point."""
+
+    def __init__(self, params=None):
+        self.params = params if params is not None else default_reg_params()
+        self._h = lib().e3d_reg_create(C.byref(self.params))
+        if not self._h:
+            _err("e3d_reg_create")
+        self._levels = {}
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            lib().e3d_reg_destroy(h)
+            self._h = None
+
+    def _chk(self, r, what):
+        if r < 0:
+            _err(what, r)
+        return r
+
+    def set_params(self, params):
+        self.params = params
+        self._chk(lib().e3d_reg_set_params(self._h, C.byref(params)), "e3d_reg_set_params")
+
+    def set_point_scale(self, scale, xyz, radius, neighbor_indices, fixed_descriptors=None):
+        keep = []
+        xyz = np.ascontiguousarray(xyz, np.float32)
+        nbr = np.ascontiguousarray(neighbor_indices, np.uint32)
+        fd = np.ascontiguousarray(fixed_descriptors, np.float32) if fixed_descriptors is not None else None
+        self._chk(lib().e3d_reg_set_point_scale(self._h, scale, C.c_void_p(xyz.ctypes.data), xyz.shape[0], float(radius),
+                                                C.c_void_p(nbr.ctypes.data), C.c_void_p(fd.ctypes.data) if fd is not None else None),
+                  "e3d_reg_set_point_scale")
+
+    def set_variable_descriptors(self, scale, descriptors, counts):
+        d = np.ascontiguousarray(descriptors, np.float32); c = np.ascontiguousarray(counts, np.int32)
+        self._chk(lib().e3d_reg_set_variable_descriptors(self._h, scale, C.c_void_p(d.ctypes.data), C.c_void_p(c.ctypes.data)), "set_variable_descriptors")
+
+    def get_variable_descriptors(self, scale, n):
+        d = np.zeros((n, self.params.point_neighbor_count), np.float32); c = np.zeros(n, np.int32)
+        self._chk(lib().e3d_reg_get_variable_descriptors(self._h, scale, C.c_void_p(d.ctypes.data), C.c_void_p(c.ctypes.data)), "get_variable_descriptors")
+        return d, c
+
+    def set_intrinsics(self, intrinsics_id, width, height, parameters, min_image_scale, n_levels, camera_type=0):
+        p = np.ascontiguousarray(parameters, np.float32)
+        self._chk(lib().e3d_reg_set_intrinsics(self._h, intrinsics_id, camera_type, width, height, C.c_void_p(p.ctypes.data), len(p),
+                                               min_image_scale, n_levels), "e3d_reg_set_intrinsics")
+        self._levels[intrinsics_id] = n_levels
+
+    def intrinsics_level(self, intrinsics_id, level):
+        w = C.c_int(); h = C.c_int(); p = np.zeros(4, np.float32); c = C.c_float()
+        self._chk(lib().e3d_reg_get_intrinsics_level(self._h, intrinsics_id, level, C.byref(w), C.byref(h), C.c_void_p(p.ctypes.data), C.byref(c)), "get_intrinsics_level")
+        return w.value, h.value, p, c.value
+
+    def set_image(self, image_id, intrinsics_id, levels, masks=None):
+        keep = [np.ascontiguousarray(l, np.uint8) for l in levels]
+        arr = (C.c_void_p * len(keep))(*[l.ctypes.data for l in keep])
+        marr = None
+        if masks is not None:
+            keepm = [np.ascontiguousarray(m, np.uint8) if m is not None else None for m in masks]
+            marr = (C.c_void_p * len(keepm))(*[(m.ctypes.data if m is not None else None) for m in keepm])
+        self._chk(lib().e3d_reg_set_image(self._h, image_id, intrinsics_id, arr, marr), "e3d_reg_set_image")
+
+    def set_image_pose(self, image_id, R, t):
+        R = np.ascontiguousarray(R, np.float32); t = np.ascontiguousarray(t, np.float32)
+        self._chk(lib().e3d_reg_set_image_pose(self._h, image_id, C.c_void_p(R.ctypes.data), C.c_void_p(t.ctypes.data)), "e3d_reg_set_image_pose")
+
+    def set_splat_points(self, xyz):
+        xyz = np.ascontiguousarray(xyz, np.float32)
+        self._chk(lib().e3d_reg_set_splat_points(self._h, C.c_void_p(xyz.ctypes.data), xyz.shape[0]), "e3d_reg_set_splat_points")
+
+    def render_depth(self, image_id, image_scale, shape=None):
+        out = np.zeros(shape, np.float32) if shape is not None else None
+        self._chk(lib().e3d_reg_render_depth(self._h, image_id, image_scale, C.c_void_p(out.ctypes.data) if out is not None else None), "e3d_reg_render_depth")
+        return out
+
+    def observe(self, image_id, point_scale, image_scale, border_size, indices=None):
+        if indices is None:
+            n = lib().e3d_reg_observe(self._h, image_id, point_scale, image_scale, border_size, None, 0)
+        else:
+            idx = np.ascontiguousarray(indices, np.uint32)
+            n = lib().e3d_reg_observe(self._h, image_id, point_scale, image_scale, border_size, C.c_void_p(idx.ctypes.data), len(idx))
+        return int(self._chk(n, "e3d_reg_observe"))
+
+    def get_observations(self, image_id, point_scale, n):
+        idx = np.zeros(n, np.uint32); x = np.zeros(n, np.float32); y = np.zeros(n, np.float32); s = np.zeros(n, np.float32); f = np.zeros(n, np.uint8)
+        self._chk(lib().e3d_reg_get_observations(self._h, image_id, point_scale, *[C.c_void_p(a.ctypes.data) for a in (idx, x, y, s, f)]), "get_observations")
+        return idx, x, y, s, f
+
+    def set_observations(self, image_id, point_scale, idx, x, y, s):
+        idx = np.ascontiguousarray(idx, np.uint32); x, y, s = [np.ascontiguousarray(a, np.float32) for a in (x, y, s)]
+        self._chk(lib().e3d_reg_set_observations(self._h, image_id, point_scale, len(idx), *[C.c_void_p(a.ctypes.data) for a in (idx, x, y, s)]), "set_observations")
+
+    def pass1(self, image_id, point_scale, n):
+        I = np.zeros(n, np.float32); ji = np.zeros((n, 4), np.float32); jp = np.zeros((n, 6), np.float32)
+        self._chk(lib().e3d_reg_pass1(self._h, image_id, point_scale, *[C.c_void_p(a.ctypes.data) for a in (I, ji, jp)]), "e3d_reg_pass1")
+        return I, ji, jp
+
+    def accumulate(self, image_id, point_scale):
+        H = np.zeros((10, 10)); b = np.zeros(10); sums = np.zeros(2); counts = np.zeros(2, np.int64)
+        self._chk(lib().e3d_reg_accumulate(self._h, image_id, point_scale, *[C.c_void_p(a.ctypes.data) for a in (H, b, sums, counts)]), "e3d_reg_accumulate")
+        return H, b, sums, counts
+
+    def cost(self, image_id, point_scale):
+        sums = np.zeros(2); counts = np.zeros(2, np.int64)
+        self._chk(lib().e3d_reg_cost(self._h, image_id, point_scale, C.c_void_p(sums.ctypes.data), C.c_void_p(counts.ctypes.data)), "e3d_reg_cost")
+        return sums, counts
+
+    def color_begin(self, point_scale):
+        self._chk(lib().e3d_reg_color_begin(self._h, point_scale), "e3d_reg_color_begin")
+
+    def color_accumulate(self, image_id, point_scale):
+        self._chk(lib().e3d_reg_color_accumulate(self._h, image_id, point_scale), "e3d_reg_color_accumulate")
+
+    def color_finish(self, point_scale):
+        self._chk(lib().e3d_reg_color_finish(self._h, point_scale), "e3d_reg_color_finish")

@@ -1,0 +1,1027 @@
+// e3d_reg.hip -- path (B): dense photometric image-registration kernels on gfx950 and their C-ABI
+// (include/e3d_hip.h, section "(B) ImageRegistrator").
+//
+// Reference loops covered: a16 ComputePointIntensityAndJacobians, a17/a18 colour residual
+// accumulation, a19 cost, a20/a21 observation creation, a22 neighbour flags, a23 colour update, a24 splat depth,
+// a25 trilinear sampling, a27 camera device functions (PINHOLE).  One (image, point scale) per call; the LM driver
+// that assembles the per-image blocks is host code above this ABI.
+//
+// Data layout in HBM: point scale = float4 {x,y,z,0} + u32 neighbour table (n*K) + f32 descriptors (n*K) + i32 counts;
+// image = u8 pyramid levels (row-major, tightly packed) + optional u8 masks; observations = SoA {u32 point, f32 x, y,
+// scale, u8 flag}; pass 1 writes 48-byte rows {I, Ji[4], Jp[6], pad} (three float4) so that pass 2's K+1 row gathers
+// are 16 B/lane loads; `row_of_point` (i32 per point) replaces the reference's unordered_map.
+// Reductions are block partials + a fixed-order second stage (f64), no atomics on values.
+#include <algorithm>
+#include <cfloat>
+#include <climits>
+#include <cmath>
+#include <map>
+#include <memory>
+
+#include "../../include/e3d_hip.h"
+#include "e3d_icp_kernels.hpp"
+
+#pragma clang fp contract(off)
+
+namespace e3d {
+
+struct CamLevel {
+  int width, height;
+  float fx, fy, cx, cy;
+  float fx_inv, fy_inv, cx_inv, cy_inv;
+  float cutoff2;
+};
+
+struct Pose { float R[9]; float t[3]; };
+
+constexpr int kRegMaxLevels = 16;
+struct Pyramid {               // passed by value to kernels
+  const unsigned char* img[kRegMaxLevels];
+  const unsigned char* mask[kRegMaxLevels];
+  CamLevel cam[kRegMaxLevels];
+  int n_levels;
+  int min_image_scale;
+};
+
+// x86 cvttss2si / cvttsd2si semantics of the reference's `int ix = v + 0.5f;`
+__device__ __forceinline__ int f2i(float v) { return (v >= -2147483648.0f && v < 2147483648.0f) ? (int)v : INT_MIN; }
+__device__ __forceinline__ int d2i(double v) { return (v > -2147483649.0 && v < 2147483648.0) ? (int)v : INT_MIN; }
+
+// ---- camera device functions (PINHOLE): camera_base_impl.h:155-164, 333-408; camera_pinhole.h:50-85 -----------------
+__device__ __forceinline__ void cam_normalized_to_image(const CamLevel& c, float nx, float ny, float& ox, float& oy) {
+  const float r2 = nx * nx + ny * ny;
+  const float inf = __uint_as_float(0x7f800000u);
+  if (isinf(r2) || r2 > c.cutoff2) { ox = nx * inf; oy = ny * inf; return; }
+  ox = c.fx * nx + c.cx;
+  oy = c.fy * ny + c.cy;
+}
+__device__ __forceinline__ void cam_image_deriv_by_world(const CamLevel& c, float X, float Y, float Z, float* d) {
+  const float nx = X / Z, ny = Y / Z;
+  if (nx * nx + ny * ny < c.cutoff2) {
+    const float zi = 1.f / Z;
+    d[0] = zi; d[1] = 0.f; d[2] = (-1.f * nx) * zi;
+    d[3] = 0.f; d[4] = zi; d[5] = (-1.f * ny) * zi;
+  } else {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) d[i] = 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { d[i] = c.fx * d[i]; d[3 + i] = c.fy * d[3 + i]; }
+}
+__device__ __forceinline__ void cam_image_deriv_by_intrinsics(const CamLevel& c, float X, float Y, float Z, float* d) {
+  const float nx = X / Z, ny = Y / Z;
+  if (nx * nx + ny * ny > c.cutoff2) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) d[i] = 0.f;
+    return;
+  }
+  d[0] = nx; d[1] = 0.f; d[2] = 1.f; d[3] = 0.f;
+  d[4] = 0.f; d[5] = ny; d[6] = 0.f; d[7] = 1.f;
+}
+
+__device__ __forceinline__ void rt(const Pose& P, float x, float y, float z, float& ox, float& oy, float& oz) {
+  ox = dot3e(P.R[0], P.R[1], P.R[2], x, y, z) + P.t[0];
+  oy = dot3e(P.R[3], P.R[4], P.R[5], x, y, z) + P.t[1];
+  oz = dot3e(P.R[6], P.R[7], P.R[8], x, y, z) + P.t[2];
+}
+
+// ---- interpolation (interpolate_bilinear.h:36-74, interpolate_trilinear.h:44-87) ------------------------------------------
+__device__ __forceinline__ float bilinear(const unsigned char* img, int w, float x, float y, int ix, int iy) {
+  const float fx = x - ix, fxi = 1.f - fx, fy = y - iy, fyi = 1.f - fy;
+  const unsigned char* r0 = img + (size_t)iy * w;
+  const unsigned char* r1 = img + (size_t)(iy + 1) * w;
+  return fyi * (fxi * r0[ix] + fx * r0[ix + 1]) + fy * (fxi * r1[ix] + fx * r1[ix + 1]);
+}
+__device__ __forceinline__ void bilinear_d(const unsigned char* img, int w, float x, float y, int ix, int iy, float& v,
+                                           float& dx, float& dy) {
+  const unsigned char* r0 = img + (size_t)iy * w;
+  const unsigned char* r1 = img + (size_t)(iy + 1) * w;
+  const float tl = r0[ix], tr = r0[ix + 1], bl = r1[ix], br = r1[ix + 1];
+  const float fx = x - ix, fxi = 1.f - fx, fy = y - iy, fyi = 1.f - fy;
+  const float top = fxi * tl + fx * tr, bottom = fxi * bl + fx * br;
+  v = fyi * top + fy * bottom;
+  dx = fy * (br - bl) + fyi * (tr - tl);
+  dy = bottom - top;
+}
+__device__ __forceinline__ float trilinear(const unsigned char* i0, int w0, const unsigned char* i1, int w1, float x0,
+                                           float y0, float z) {
+  const float v0 = bilinear(i0, w0, x0, y0, (int)x0, (int)y0);
+  const float x1 = 2 * (x0 + 0.5f) - 0.5f, y1 = 2 * (y0 + 0.5f) - 0.5f;
+  const float v1 = bilinear(i1, w1, x1, y1, (int)x1, (int)y1);
+  return (1 - z) * v0 + z * v1;
+}
+__device__ __forceinline__ void trilinear_d(const unsigned char* i0, int w0, const unsigned char* i1, int w1, float x0,
+                                            float y0, float z, float& v, float& dx, float& dy, float& dz) {
+  float v0, dx0, dy0, v1, dx1, dy1;
+  bilinear_d(i0, w0, x0, y0, (int)x0, (int)y0, v0, dx0, dy0);
+  const float x1 = 2 * (x0 + 0.5f) - 0.5f, y1 = 2 * (y0 + 0.5f) - 0.5f;
+  bilinear_d(i1, w1, x1, y1, (int)x1, (int)y1, v1, dx1, dy1);
+  v = (1 - z) * v0 + z * v1;
+  dx = (1 - z) * dx0 + z * 2 * dx1;
+  dy = (1 - z) * dy0 + z * 2 * dy1;
+  dz = v1 - v0;
+}
+__device__ __forceinline__ float obs_intensity(const Pyramid& Y, float ox, float oy, float os) {
+  const int s = f2i(os);
+  const int l1 = s - Y.min_image_scale, l0 = l1 + 1;
+  return trilinear(Y.img[l0], Y.cam[l0].width, Y.img[l1], Y.cam[l1].width, ox, oy, 1 - (os - (float)s));
+}
+
+// ---- robust weighting (robust_weighting.h:61-107) ------------------------------------------------------------------------------
+__device__ __forceinline__ float robust_residual(int type, float param, float r) {
+  if (type == 1) { const float a = fabsf(r); return (a < param) ? 0.5f * r * r : param * (a - 0.5f * param); }
+  if (type == 2) {
+    const float a = fabsf(r);
+    if (a < param) { const float q = r / param; const float t = 1.f - q * q; return (1 / 6.f) * param * param * (1 - t * t * t); }
+    return (1 / 6.f) * param * param;
+  }
+  return 0.5f * r * r;
+}
+__device__ __forceinline__ float robust_weight(int type, float param, float r) {
+  if (type == 1) { const float a = fabsf(r); return (a < param) ? 1.f : (param / a); }
+  if (type == 2) { const float a = fabsf(r); if (a < param) { const float q = r / param; const float t = 1.f - q * q; return t * t; } return 0.f; }
+  return 1.f;
+}
+
+// ==== a24: OcclusionGeometry::_RenderDepthMapWithSplatsCPU ========================================================================
+__global__ __launch_bounds__(kBlock) void k_splat_depth(const float4* __restrict__ pts, size_t n, Pose P, CamLevel cam,
+                                                        float point_radius, unsigned* __restrict__ depth_bits) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float4 p = pts[i];
+  float X, Y, Z;
+  rt(P, p.x, p.y, p.z, X, Y, Z);
+  if (!(Z > 0.f)) return;
+  float px, py, d[6];
+  cam_normalized_to_image(cam, X / Z, Y / Z, px, py);
+  cam_image_deriv_by_world(cam, X, Y, Z, d);
+  float rx = sqrtf(d[0] * d[0] + (d[1] * d[1] + d[2] * d[2])) * point_radius;
+  float ry = sqrtf(d[3] * d[3] + (d[4] * d[4] + d[5] * d[5])) * point_radius;
+  rx = (10.f < rx) ? 10.f : rx;     // std::min(splat_radius, max_splat_radius)
+  ry = (10.f < ry) ? 10.f : ry;
+  const int ix = f2i(px + 0.5f), iy = f2i(py + 0.5f);
+  int min_x = d2i((double)((float)ix - rx) + 0.5), min_y = d2i((double)((float)iy - ry) + 0.5);
+  int end_x = d2i((double)((float)ix + rx) + 1.5), end_y = d2i((double)((float)iy + ry) + 1.5);
+  min_x = max(min_x, 0); min_y = max(min_y, 0);
+  end_x = min(end_x, cam.width); end_y = min(end_y, cam.height);
+  const unsigned zb = __float_as_uint(Z);      // Z > 0: the bit pattern is order preserving
+  for (int y = min_y; y < end_y; ++y)
+    for (int x = min_x; x < end_x; ++x) atomicMin(&depth_bits[(size_t)y * cam.width + x], zb);
+}
+
+// ==== a20 / a21: observation candidates =============================================================================================
+struct ObsParams {
+  float point_radius;
+  int image_scale, border, current_image_scale, image_scale_count;
+  float occlusion_threshold, max_valid_intensity;
+  int check;     // 1: occlusion + masks + over-saturation (all points); 0: indexed list
+};
+
+__global__ __launch_bounds__(kBlock) void k_obs_eval(const float4* __restrict__ pts, const unsigned* __restrict__ indices,
+                                                     size_t count, Pose P, Pyramid Y, const float* __restrict__ occlusion,
+                                                     ObsParams q, int* __restrict__ valid, float* __restrict__ ox,
+                                                     float* __restrict__ oy, float* __restrict__ os) {
+  const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= count) return;
+  const size_t pi = indices ? indices[k] : k;
+  valid[k] = -1;
+  const float4 p = pts[pi];
+  float X, Yc, Z;
+  rt(P, p.x, p.y, p.z, X, Yc, Z);
+  if (!(Z > 0.f)) return;
+  int lvl = q.image_scale - Y.min_image_scale;
+  if (lvl < 0) lvl = 0;
+  const CamLevel cam = Y.cam[lvl];
+  float ixf, iyf;
+  cam_normalized_to_image(cam, X / Z, Yc / Z, ixf, iyf);
+  int ix = f2i(ixf + 0.5f), iy = f2i(iyf + 0.5f);
+  if (!(ix >= 0 && iy >= 0 && ix < cam.width && iy < cam.height)) return;
+  if (q.check && !(occlusion[(size_t)iy * cam.width + ix] + q.occlusion_threshold >= Z)) return;
+  // CreateObservationIfScaleFits (visibility_estimator.cc:405-532)
+  const float prx = X + q.point_radius, pry = Yc + 0.f, prz = Z + 0.f;
+  float rxf, ryf;
+  cam_normalized_to_image(cam, prx / prz, pry / prz, rxf, ryf);
+  const float dx = rxf - ixf, dy = ryf - iyf;
+  const float radius_pixels = sqrtf(dx * dx + dy * dy);
+  const float observation_scale = q.image_scale + log2f(2 * radius_pixels);
+  const int lo = max(Y.min_image_scale, q.current_image_scale);
+  if (!(observation_scale >= lo && f2i(observation_scale) < q.image_scale_count - 1)) return;
+  const int small_scale = f2i(observation_scale) + 1;
+  int li = small_scale - Y.min_image_scale;
+  if (li < 0) li = 0;
+  if (li >= Y.n_levels) return;
+  const CamLevel ic = Y.cam[li];
+  const float nx = cam.fx_inv * ixf + cam.cx_inv, ny = cam.fy_inv * iyf + cam.cy_inv;
+  const float jx = ic.fx * nx + ic.cx, jy = ic.fy * ny + ic.cy;
+  ix = f2i(jx + 0.5f); iy = f2i(jy + 0.5f);
+  if (!(jx + 0.5f >= q.border && jy + 0.5f >= q.border && ix >= q.border && iy >= q.border && ix < ic.width - q.border &&
+        iy < ic.height - q.border))
+    return;
+  if (q.check) {
+    const int pl = small_scale - Y.min_image_scale;
+    if (Y.mask[pl] && Y.mask[pl][(size_t)iy * ic.width + ix] != 0) return;
+    if (Y.img[pl][(size_t)iy * ic.width + ix] > q.max_valid_intensity) return;
+  }
+  valid[k] = (int)pi;
+  ox[k] = jx; oy[k] = jy; os[k] = observation_scale;
+}
+
+__global__ __launch_bounds__(kBlock) void k_obs_compact(const int* __restrict__ valid, const float* __restrict__ ox,
+                                                        const float* __restrict__ oy, const float* __restrict__ os,
+                                                        size_t count, const unsigned* __restrict__ block_offsets,
+                                                        unsigned* __restrict__ o_idx, float* __restrict__ o_x,
+                                                        float* __restrict__ o_y, float* __restrict__ o_s) {
+  const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int v = (k < count) ? valid[k] : -1;
+  const bool f = v >= 0;
+  const unsigned long long b = __ballot(f);
+  __shared__ unsigned wbase[kBlock / kWave];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) wbase[w] = (unsigned)__popcll(b);
+  __syncthreads();
+  unsigned base = block_offsets[blockIdx.x];
+  for (int j = 0; j < w; ++j) base += wbase[j];
+  if (!f) return;
+  const size_t o = base + (unsigned)__popcll(b & ((1ull << lane) - 1ull));
+  o_idx[o] = (unsigned)v; o_x[o] = ox[k]; o_y[o] = oy[k]; o_s[o] = os[k];
+}
+
+// ==== a22 ===============================================================================================================================
+__global__ __launch_bounds__(kBlock) void k_obs_mark(const unsigned* __restrict__ o_idx, size_t n_obs, int* __restrict__ row_of_point) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_obs) row_of_point[o_idx[i]] = (int)i;
+}
+__global__ __launch_bounds__(kBlock) void k_obs_flags(const unsigned* __restrict__ o_idx, size_t n_obs,
+                                                      const unsigned* __restrict__ nbr, int K,
+                                                      const int* __restrict__ row_of_point, unsigned char* __restrict__ flags) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_obs) return;
+  const size_t p = o_idx[i];
+  bool all = true;
+  for (int k = 0; k < K; ++k) all = all && (row_of_point[nbr[p * K + k]] >= 0);
+  flags[i] = all ? 1 : 0;
+}
+
+// ==== a16: pass 1 =========================================================================================================================
+__global__ __launch_bounds__(kBlock) void k_reg_pass1(const float4* __restrict__ pts, float point_radius, Pose P, Pyramid Y,
+                                                      const unsigned* __restrict__ o_idx, const float* __restrict__ o_x,
+                                                      const float* __restrict__ o_y, const float* __restrict__ o_s,
+                                                      size_t n_obs, float4* __restrict__ rows) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_obs) return;
+  const float4 p = pts[o_idx[i]];
+  float T0, T1, T2;
+  rt(P, p.x, p.y, p.z, T0, T1, T2);
+  const float os = o_s[i], ox = o_x[i], oy = o_y[i];
+  const int si = f2i(os);
+  const int small_scale = si + 1;
+  const int l1 = si - Y.min_image_scale, l0 = l1 + 1;
+  float I, j0, j1, j2;
+  trilinear_d(Y.img[l0], Y.cam[l0].width, Y.img[l1], Y.cam[l1].width, ox, oy, 1 - (os - (float)si), I, j0, j1, j2);
+  j2 = -1 * j2;
+  const float scale_factor = exp2f((float)(Y.min_image_scale - small_scale));     // exact power of two
+  const float inv_scale_factor = 1.f / scale_factor;
+  j0 *= scale_factor; j1 *= scale_factor;
+  const float mx = inv_scale_factor * (ox + 0.5f) - 0.5f, my = inv_scale_factor * (oy + 0.5f) - 0.5f;
+  const CamLevel cam = Y.cam[0];                                                   // min_image_scale camera
+  const float To0 = T0 + point_radius;
+  float offx, offy;
+  cam_normalized_to_image(cam, To0 / T2, T1 / T2, offx, offy);
+  const float rdx = offx - mx, rdy = offy - my;
+  const float denom = fmaxf(1e-6f, 0.693147180559945f * (rdx * rdx + rdy * rdy));
+  float Pi[12], Po[8];
+  cam_image_deriv_by_intrinsics(cam, T0, T1, T2, Pi);
+  cam_image_deriv_by_intrinsics(cam, To0, T1, T2, Po);
+  float ji[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    Pi[8 + c] = ((Po[c] - Pi[c]) * rdx + (Po[4 + c] - Pi[4 + c]) * rdy) / denom;
+    ji[c] = j0 * Pi[c] + (j1 * Pi[4 + c] + j2 * Pi[8 + c]);
+  }
+  float W[9], Wo[6], a[3];
+  cam_image_deriv_by_world(cam, T0, T1, T2, W);
+  cam_image_deriv_by_world(cam, To0, T1, T2, Wo);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    W[6 + c] = ((Wo[c] - W[c]) * rdx + (Wo[3 + c] - W[3 + c]) * rdy) / denom;
+    a[c] = j0 * W[c] + (j1 * W[3 + c] + j2 * W[6 + c]);
+  }
+  // [I3 | 0 z -y ; -z 0 x ; y -x 0]
+  const float C0[6] = {1, 0, 0, 0, T2, -1 * T1};
+  const float C1[6] = {0, 1, 0, -1 * T2, 0, T0};
+  const float C2[6] = {0, 0, 1, T1, -1 * T0, 0};
+  float jp[6];
+#pragma unroll
+  for (int c = 0; c < 6; ++c) jp[c] = a[0] * C0[c] + (a[1] * C1[c] + a[2] * C2[c]);
+  rows[3 * i] = make_float4(I, ji[0], ji[1], ji[2]);
+  rows[3 * i + 1] = make_float4(ji[3], jp[0], jp[1], jp[2]);
+  rows[3 * i + 2] = make_float4(jp[3], jp[4], jp[5], 0.f);
+}
+
+// ==== a17 + a18: pass 2 =====================================================================================================================
+constexpr int kRegV = 10;                         // I + 6 for PINHOLE
+constexpr int kRegH = kRegV * (kRegV + 1) / 2;    // 55 upper-triangle entries
+constexpr int kRegSlot = kRegH + kRegV + 4;       // + b + {sum_f, sum_v, cnt_f, cnt_v}
+
+struct RegWeights { int robust_type; float robust_param; float fixed_weight, var_weight; };
+
+__device__ __forceinline__ void load_row(const float4* __restrict__ rows, size_t r, float& I, float* J) {
+  const float4 a = rows[3 * r], b = rows[3 * r + 1], c = rows[3 * r + 2];
+  I = a.x; J[0] = a.y; J[1] = a.z; J[2] = a.w; J[3] = b.x; J[4] = b.y; J[5] = b.z; J[6] = b.w; J[7] = c.x; J[8] = c.y; J[9] = c.z;
+}
+
+template <int K_MAX>
+__global__ __launch_bounds__(kBlock) void k_reg_pass2(const float4* __restrict__ rows, const unsigned* __restrict__ o_idx,
+                                                      const unsigned char* __restrict__ flags, size_t n_obs,
+                                                      const unsigned* __restrict__ nbr, int K,
+                                                      const int* __restrict__ row_of_point,
+                                                      const float* __restrict__ fixed_desc, const float* __restrict__ var_desc,
+                                                      const int* __restrict__ obs_counts, RegWeights wts,
+                                                      double* __restrict__ partial) {
+  double acc[kRegSlot];
+#pragma unroll
+  for (int i = 0; i < kRegSlot; ++i) acc[i] = 0.0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_obs; i += (size_t)gridDim.x * blockDim.x) {
+    if (!flags[i]) continue;
+    const size_t p = o_idx[i];
+    float Ic, Jc[kRegV];
+    load_row(rows, i, Ic, Jc);
+    int nrow[K_MAX];
+    float In[K_MAX];
+#pragma unroll
+    for (int k = 0; k < K_MAX; ++k)
+      if (k < K) { nrow[k] = row_of_point[nbr[p * K + k]]; In[k] = rows[3 * (size_t)nrow[k]].x; }
+#pragma unroll
+    for (int kind = 0; kind < 2; ++kind) {
+      const float sw = kind == 0 ? wts.fixed_weight : wts.var_weight;
+      if (!(sw > 0)) continue;
+      if (kind == 1 && !(obs_counts[p] >= 2)) continue;
+      const float* desc = kind == 0 ? fixed_desc : var_desc;
+      float comp[K_MAX];
+      float pr = 0.f;
+#pragma unroll
+      for (int k = 0; k < K_MAX; ++k)
+        if (k < K) {
+          const float image_descriptor = In[k] - Ic;
+          const float c = image_descriptor - desc[p * K + k];
+          comp[k] = c;
+          pr += c * c;
+        }
+      pr = sqrtf(pr);
+      acc[kRegH + kRegV + 2 + kind] += 1.0;
+      acc[kRegH + kRegV + kind] += (double)robust_residual(wts.robust_type, wts.robust_param, pr);
+      const float w = sw * robust_weight(wts.robust_type, wts.robust_param, pr);
+      if (w != 0) {
+#pragma unroll
+        for (int k = 0; k < K_MAX; ++k)
+          if (k < K) {
+            float In2, Jn[kRegV], J[kRegV];
+            load_row(rows, (size_t)nrow[k], In2, Jn);
+#pragma unroll
+            for (int c = 0; c < kRegV; ++c) J[c] = Jn[c] - Jc[c];
+            // AccumulateOnHAndB: products in f32, cast, add in f64 (intrinsics_and_pose_optimizer.cc:1246-1247)
+            int e = 0;
+#pragma unroll
+            for (int r = 0; r < kRegV; ++r) {
+              const float wj = w * J[r];
+#pragma unroll
+              for (int c = r; c < kRegV; ++c) { acc[e] += (double)(wj * J[c]); ++e; }
+            }
+            const float wr = w * comp[k];
+#pragma unroll
+            for (int c = 0; c < kRegV; ++c) acc[kRegH + c] += (double)(wr * J[c]);
+          }
+      }
+    }
+  }
+  __shared__ double s[kBlock / kWave][kRegSlot];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < kRegSlot; ++i) {
+    const double v = wave_sum(acc[i]);
+    if (lane == 0) s[wv][i] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < kRegSlot) {
+    double v = s[0][threadIdx.x];
+    for (int k = 1; k < kBlock / kWave; ++k) v += s[k][threadIdx.x];
+    partial[(size_t)blockIdx.x * kRegSlot + threadIdx.x] = v;
+  }
+}
+
+__global__ void k_reg_reduce(const double* __restrict__ partial, int nblocks, int slot, double* __restrict__ out) {
+  const int t = threadIdx.x;
+  if (t >= slot) return;
+  double v = 0.0;
+  for (int b = 0; b < nblocks; ++b) v += partial[(size_t)b * slot + t];
+  out[t] = v;
+}
+
+// ==== a19: cost ================================================================================================================================
+__global__ __launch_bounds__(kBlock) void k_reg_intensity(Pyramid Y, const unsigned* __restrict__ o_idx, const float* __restrict__ o_x,
+                                                          const float* __restrict__ o_y, const float* __restrict__ o_s,
+                                                          size_t n_obs, float* __restrict__ point_intensity) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_obs) return;
+  point_intensity[o_idx[i]] = obs_intensity(Y, o_x[i], o_y[i], o_s[i]);
+}
+
+__global__ __launch_bounds__(kBlock) void k_reg_cost(const float* __restrict__ point_intensity, const unsigned* __restrict__ o_idx,
+                                                     const unsigned char* __restrict__ flags, size_t n_obs,
+                                                     const unsigned* __restrict__ nbr, int K, const float* __restrict__ fixed_desc,
+                                                     const float* __restrict__ var_desc, const int* __restrict__ obs_counts,
+                                                     RegWeights wts, double* __restrict__ partial) {
+  double acc[4] = {0, 0, 0, 0};
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_obs; i += (size_t)gridDim.x * blockDim.x) {
+    if (!flags[i]) continue;
+    const size_t p = o_idx[i];
+    const float Ic = point_intensity[p];
+#pragma unroll
+    for (int kind = 0; kind < 2; ++kind) {
+      const float sw = kind == 0 ? wts.fixed_weight : wts.var_weight;
+      if (!(sw > 0)) continue;
+      if (kind == 1 && !(obs_counts[p] >= 2)) continue;
+      const float* desc = kind == 0 ? fixed_desc : var_desc;
+      float pr = 0.f;
+      for (int k = 0; k < K; ++k) {
+        const float c = (point_intensity[nbr[p * K + k]] - Ic) - desc[p * K + k];
+        pr += c * c;
+      }
+      pr = sqrtf(pr);
+      acc[kind] += (double)robust_residual(wts.robust_type, wts.robust_param, pr);
+      acc[2 + kind] += 1.0;
+    }
+  }
+  __shared__ double s[kBlock / kWave][4];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const double v = wave_sum(acc[i]);
+    if (lane == 0) s[wv][i] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    double v = s[0][threadIdx.x];
+    for (int k = 1; k < kBlock / kWave; ++k) v += s[k][threadIdx.x];
+    partial[(size_t)blockIdx.x * 4 + threadIdx.x] = v;
+  }
+}
+
+// ==== a23: colour update ========================================================================================================================
+// Within one image every point is observed at most once, so the per-image accumulation needs no atomics; images are
+// processed one after the other (same f32 summation order as a sequential loop over images).
+__global__ __launch_bounds__(kBlock) void k_color_accumulate(const float* __restrict__ point_intensity, const unsigned* __restrict__ o_idx,
+                                                             const unsigned char* __restrict__ flags, size_t n_obs,
+                                                             const unsigned* __restrict__ nbr, int K, float* __restrict__ desc,
+                                                             int* __restrict__ counts) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_obs || !flags[i]) return;
+  const size_t p = o_idx[i];
+  const float Ic = point_intensity[p];
+  counts[p] += 1;
+  for (int k = 0; k < K; ++k) desc[p * K + k] += point_intensity[nbr[p * K + k]] - Ic;
+}
+__global__ __launch_bounds__(kBlock) void k_color_finish(size_t n, int K, float* __restrict__ desc, const int* __restrict__ counts) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int c = counts[i];
+  if (c > 1)
+    for (int k = 0; k < K; ++k) desc[i * K + k] /= c;
+}
+
+__global__ __launch_bounds__(kBlock) void k_fill_f32(float* p, size_t n, float v) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+__global__ __launch_bounds__(kBlock) void k_fill_i32(int* p, size_t n, int v) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+__global__ __launch_bounds__(kBlock) void k_xyz_to_float4(const float* __restrict__ xyz, size_t n, float4* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = make_float4(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], 0.f);
+}
+
+// =====================================================================================================================================================
+// host side
+// =====================================================================================================================================================
+struct PointScale {
+  size_t n = 0;
+  float radius = 0;
+  DevBuf<float4> pts;
+  DevBuf<unsigned> nbr;
+  DevBuf<float> fixed_desc, var_desc, intensity;
+  DevBuf<int> obs_counts, row_of_point;
+  bool has_fixed = false;
+};
+struct Intrin {
+  int type = 0, min_image_scale = 0, n_params = 4;
+  std::vector<CamLevel> levels;
+};
+struct Obs {
+  size_t n = 0;
+  DevBuf<unsigned> idx;
+  DevBuf<float> x, y, s;
+  DevBuf<unsigned char> flags;
+  DevBuf<float4> rows;
+  bool rows_valid = false;
+};
+struct ImageDev {
+  int intrinsics_id = -1;
+  std::vector<DevBuf<unsigned char>> pix, mask;
+  std::vector<bool> has_mask;
+  Pose pose{};
+  DevBuf<float> depth;            // last rendered occlusion depth (as float bits)
+  int depth_scale = -1;
+  std::map<int, Obs> obs;         // per point scale
+};
+
+static CamLevel make_level(int w, int h, const float* p) {
+  CamLevel c{};
+  c.width = w; c.height = h; c.fx = p[0]; c.fy = p[1]; c.cx = p[2]; c.cy = p[3];
+  c.fx_inv = 1.0f / c.fx; c.fy_inv = 1.0f / c.fy; c.cx_inv = -c.cx / c.fx; c.cy_inv = -c.cy / c.fy;
+  // InitCutoff (camera_base_impl.h:410-463): undistorted model => 1.01 * max border r^2
+  float mc = 0.f;
+  auto upd = [&](float px, float py) {
+    const float nx = c.fx_inv * px + c.cx_inv, ny = c.fy_inv * py + c.cy_inv;
+    const float r2 = nx * nx + ny * ny;
+    if (r2 > mc) mc = r2;
+  };
+  for (int x = 0; x < w; ++x) { upd((float)x, 0.f); upd((float)x, (float)(h - 1)); }
+  for (int y = 0; y < h; ++y) { upd(0.f, (float)y); upd((float)(w - 1), (float)y); }
+  c.cutoff2 = mc * 1.01f;
+  return c;
+}
+
+}  // namespace e3d
+
+using namespace e3d;
+
+struct e3d_reg {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  e3d_reg_params prm{};
+  std::map<int, PointScale> scales;
+  std::map<int, Intrin> intr;
+  std::map<int, ImageDev> images;
+  DevBuf<float4> splat;
+  size_t n_splat = 0;
+  // scratch
+  DevBuf<int> valid;
+  DevBuf<float> tx, ty, ts;
+  DevBuf<unsigned> cand, block_counts, block_offsets;
+  DevBuf<double> block_d2, chunk_d2, d_total_d2, partial, red;
+  DevBuf<unsigned long long> chunk_sum, d_total;
+  DevBuf<float> dummy_d2;
+  ~e3d_reg() { if (stream) (void)hipStreamDestroy(stream); }
+};
+
+namespace e3d {
+
+static void rsync(e3d_reg* h) { E3D_HIP(hipStreamSynchronize(h->stream)); }
+static unsigned nblk(size_t n) { return (unsigned)div_up(n ? n : 1, kBlock); }
+
+static Pyramid make_pyramid(e3d_reg* h, const ImageDev& im) {
+  const Intrin& in = h->intr.at(im.intrinsics_id);
+  Pyramid Y{};
+  Y.n_levels = (int)in.levels.size();
+  Y.min_image_scale = in.min_image_scale;
+  for (int l = 0; l < Y.n_levels; ++l) {
+    Y.img[l] = im.pix[l].p;
+    Y.mask[l] = im.has_mask[l] ? im.mask[l].p : nullptr;
+    Y.cam[l] = in.levels[l];
+  }
+  return Y;
+}
+
+static PointScale& get_scale(e3d_reg* h, int s) {
+  auto it = h->scales.find(s);
+  if (it == h->scales.end()) throw Error(E3D_ERR_INDEX, fmt("point scale %d not set", s));
+  return it->second;
+}
+static ImageDev& get_image(e3d_reg* h, int id) {
+  auto it = h->images.find(id);
+  if (it == h->images.end()) throw Error(E3D_ERR_INDEX, fmt("image %d not set", id));
+  return it->second;
+}
+static Obs& get_obs(ImageDev& im, int s) {
+  auto it = im.obs.find(s);
+  if (it == im.obs.end()) throw Error(E3D_ERR_INVALID, fmt("no observations for point scale %d (call e3d_reg_observe first)", s));
+  return it->second;
+}
+
+static void check_params(const e3d_reg_params* p) {
+  if (!p) throw Error(E3D_ERR_INVALID, "null params");
+  if (p->point_neighbor_count < 1 || p->point_neighbor_count > 8) throw Error(E3D_ERR_INVALID, "point_neighbor_count must be in [1, 8]");
+  if (p->robust_weighting_type < 0 || p->robust_weighting_type > 2) throw Error(E3D_ERR_INVALID, "robust_weighting_type must be 0, 1 or 2");
+}
+
+// flags + row_of_point for the current observation list
+static void finish_observations(e3d_reg* h, PointScale& S, Obs& O) {
+  hipStream_t s = h->stream;
+  hipLaunchKernelGGL(k_fill_i32, dim3(nblk(S.n)), dim3(kBlock), 0, s, S.row_of_point.p, S.n, -1);
+  O.flags.reserve(O.n);
+  if (O.n) {
+    hipLaunchKernelGGL(k_obs_mark, dim3(nblk(O.n)), dim3(kBlock), 0, s, O.idx.p, O.n, S.row_of_point.p);
+    hipLaunchKernelGGL(k_obs_flags, dim3(nblk(O.n)), dim3(kBlock), 0, s, O.idx.p, O.n, S.nbr.p, h->prm.point_neighbor_count,
+                       S.row_of_point.p, O.flags.p);
+  }
+  O.rows_valid = false;
+}
+
+// row_of_point belongs to (image, scale) of the LAST observe/prepare call on that scale: re-mark before use
+static void prepare_rows(e3d_reg* h, ImageDev& im, PointScale& S, Obs& O) {
+  hipStream_t s = h->stream;
+  hipLaunchKernelGGL(k_fill_i32, dim3(nblk(S.n)), dim3(kBlock), 0, s, S.row_of_point.p, S.n, -1);
+  if (O.n) hipLaunchKernelGGL(k_obs_mark, dim3(nblk(O.n)), dim3(kBlock), 0, s, O.idx.p, O.n, S.row_of_point.p);
+  O.rows.reserve(3 * O.n);
+  if (O.n)
+    hipLaunchKernelGGL(k_reg_pass1, dim3(nblk(O.n)), dim3(kBlock), 0, s, S.pts.p, S.radius, im.pose, make_pyramid(h, im), O.idx.p,
+                       O.x.p, O.y.p, O.s.p, O.n, O.rows.p);
+  O.rows_valid = true;
+}
+
+static void dense_intensities(e3d_reg* h, ImageDev& im, PointScale& S, Obs& O) {
+  hipStream_t s = h->stream;
+  hipLaunchKernelGGL(k_fill_f32, dim3(nblk(S.n)), dim3(kBlock), 0, s, S.intensity.p, S.n, -1.f);
+  if (O.n)
+    hipLaunchKernelGGL(k_reg_intensity, dim3(nblk(O.n)), dim3(kBlock), 0, s, make_pyramid(h, im), O.idx.p, O.x.p, O.y.p, O.s.p, O.n,
+                       S.intensity.p);
+}
+
+}  // namespace e3d
+
+#define R_TRY try {
+#define R_CATCH()                                                                            \
+  } catch (const e3d::Error& e) { e3d::set_last_error(e.what()); return e.code; }            \
+  catch (const std::exception& e) { e3d::set_last_error(e.what()); return E3D_ERR_INVALID; }
+
+extern "C" {
+
+e3d_reg_t* e3d_reg_create(const e3d_reg_params* params) {
+  try {
+    check_params(params);
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) throw Error(E3D_ERR_NO_DEVICE, "no HIP device visible (libe3dhip needs an MI355X / gfx950 GPU)");
+    std::unique_ptr<e3d_reg> h(new e3d_reg());
+    E3D_HIP(hipGetDevice(&h->device));
+    E3D_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    h->prm = *params;
+    return h.release();
+  } catch (const std::exception& e) {
+    e3d::set_last_error(e.what());
+    return nullptr;
+  }
+}
+void e3d_reg_destroy(e3d_reg_t* reg) { delete reg; }
+
+int e3d_reg_set_params(e3d_reg_t* h, const e3d_reg_params* params) {
+  R_TRY
+  if (!h) throw Error(E3D_ERR_INVALID, "null handle");
+  check_params(params);
+  if (params->point_neighbor_count != h->prm.point_neighbor_count && !h->scales.empty())
+    throw Error(E3D_ERR_INVALID, "point_neighbor_count cannot change after point scales were set");
+  h->prm = *params;
+  return 0;
+  R_CATCH()
+}
+
+int e3d_reg_set_point_scale(e3d_reg_t* h, int point_scale, const float* xyz, size_t n, float point_radius,
+                            const uint32_t* neighbor_indices, const float* fixed_descriptors) {
+  R_TRY
+  if (!h || (!xyz && n) || (!neighbor_indices && n)) throw Error(E3D_ERR_INVALID, "e3d_reg_set_point_scale: null argument");
+  hipStream_t s = h->stream;
+  const int K = h->prm.point_neighbor_count;
+  PointScale& S = h->scales[point_scale];
+  S.n = n; S.radius = point_radius;
+  S.pts.reserve(n); S.nbr.reserve(n * K); S.fixed_desc.reserve(n * K); S.var_desc.reserve(n * K); S.intensity.reserve(n);
+  S.obs_counts.reserve(n); S.row_of_point.reserve(n);
+  DevBuf<float> tmp; tmp.reserve(3 * n);
+  copy_in(tmp.p, xyz, sizeof(float) * 3 * n, s);
+  hipLaunchKernelGGL(k_xyz_to_float4, dim3(nblk(n)), dim3(kBlock), 0, s, tmp.p, n, S.pts.p);
+  copy_in(S.nbr.p, neighbor_indices, sizeof(unsigned) * n * K, s);
+  S.has_fixed = fixed_descriptors != nullptr;
+  if (fixed_descriptors) copy_in(S.fixed_desc.p, fixed_descriptors, sizeof(float) * n * K, s);
+  else E3D_HIP(hipMemsetAsync(S.fixed_desc.p, 0, sizeof(float) * n * K, s));
+  E3D_HIP(hipMemsetAsync(S.var_desc.p, 0, sizeof(float) * n * K, s));
+  hipLaunchKernelGGL(k_fill_i32, dim3(nblk(n)), dim3(kBlock), 0, s, S.obs_counts.p, n, fixed_descriptors ? 99999 : 0);   // problem.cc:568-570
+  rsync(h);
+  for (auto& kv : h->images) kv.second.obs.erase(point_scale);
+  return 0;
+  R_CATCH()
+}
+
+int e3d_reg_set_variable_descriptors(e3d_reg_t* h, int point_scale, const float* descriptors, const int32_t* counts) {
+  R_TRY
+  if (!h || !descriptors || !counts) throw Error(E3D_ERR_INVALID, "null argument");
+  PointScale& S = get_scale(h, point_scale);
+  copy_in(S.var_desc.p, descriptors, sizeof(float) * S.n * h->prm.point_neighbor_count, h->stream);
+  copy_in(S.obs_counts.p, counts, sizeof(int) * S.n, h->stream);
+  rsync(h);
+  return 0;
+  R_CATCH()
+}
+int e3d_reg_get_variable_descriptors(e3d_reg_t* h, int point_scale, float* descriptors, int32_t* counts) {
+  R_TRY
+  if (!h) throw Error(E3D_ERR_INVALID, "null handle");
+  PointScale& S = get_scale(h, point_scale);
+  if (descriptors) copy_out(descriptors, S.var_desc.p, sizeof(float) * S.n * h->prm.point_neighbor_count, h->stream);
+  if (counts) copy_out(counts, S.obs_counts.p, sizeof(int) * S.n, h->stream);
+  rsync(h);
+  return 0;
+  R_CATCH()
+}
+
+int e3d_reg_set_intrinsics(e3d_reg_t* h, int intrinsics_id, int camera_type, int width, int height, const float* parameters,
+                           int n_parameters, int min_image_scale, int n_levels) {
+  R_TRY
+  if (!h || !parameters) throw Error(E3D_ERR_INVALID, "null argument");
+  if (camera_type != E3D_CAMERA_PINHOLE || n_parameters != 4) throw Error(E3D_ERR_INVALID, "only PINHOLE (4 parameters) is implemented on the HIP path yet");
+  if (n_levels < 1 || n_levels > kRegMaxLevels || width < 2 || height < 2 || min_image_scale < 0) throw Error(E3D_ERR_INVALID, "bad pyramid description");
+  Intrin in;
+  in.type = camera_type; in.min_image_scale = min_image_scale; in.n_params = n_parameters;
+  in.levels.push_back(make_level(width, height, parameters));
+  for (int l = 1; l < n_levels; ++l) {     // Intrinsics::BuildModelPyramid: ScaledBy(0.5) of the previous level
+    const CamLevel& p = in.levels.back();
+    const float f = 0.5f;
+    const float q[4] = {p.fx * f, p.fy * f, f * (p.cx + 0.5f) - 0.5f, f * (p.cy + 0.5f) - 0.5f};
+    in.levels.push_back(make_level((int)(f * p.width + 0.5f), (int)(f * p.height + 0.5f), q));
+  }
+  h->intr[intrinsics_id] = in;
+  return 0;
+  R_CATCH()
+}
+
+int e3d_reg_get_intrinsics_level(e3d_reg_t* h, int intrinsics_id, int level, int* width, int* height, float* parameters,
+                                 float* cutoff2) {
+  R_TRY
+  if (!h) throw Error(E3D_ERR_INVALID, "null handle");
+  auto it = h->intr.find(intrinsics_id);
+  if (it == h->intr.end() || level < 0 || level >= (int)it->second.levels.size()) throw Error(E3D_ERR_INDEX, "no such intrinsics level");
+  const CamLevel& c = it->second.levels[level];
+  if (width) *width = c.width;
+  if (height) *height = c.height;
+  if (parameters) { parameters[0] = c.fx; parameters[1] = c.fy; parameters[2] = c.cx; parameters[3] = c.cy; }
+  if (cutoff2) *cutoff2 = c.cutoff2;
+  return 0;
+  R_CATCH()
+}
+
+int e3d_reg_set_image(e3d_reg_t* h, int image_id, int intrinsics_id, const uint8_t* const* level_pixels,
+                      const uint8_t* const* level_masks) {
+  R_TRY
+  if (!h || !level_pixels) throw Error(E3D_ERR_INVALID, "null argument");
+  auto it = h->intr.find(intrinsics_id);
+  if (it == h->intr.end()) throw Error(E3D_ERR_INDEX, "intrinsics not set");
+  const Intrin& in = it->second;
+  ImageDev& im = h->images[image_id];
+  im.intrinsics_id = intrinsics_id;
+  const int L = (int)in.levels.size();
+  im.pix.resize(L); im.mask.resize(L); im.has_mask.assign(L, false);
+  for (int l = 0; l < L; ++l) {
+    const size_t bytes = (size_t)in.levels[l].width * in.levels[l].height;
+    if (!level_pixels[l]) throw Error(E3D_ERR_INVALID, "missing pyramid level");
+    im.pix[l].reserve(bytes);
+    copy_in(im.pix[l].p, level_pixels[l], bytes, h->stream);
+    if (level_masks && level_masks[l]) {
+      im.mask[l].reserve(bytes);
+      copy_in(im.mask[l].p, level_masks[l], bytes, h->stream);
+      im.has_mask[l] = true;
+    }
+  }
+  rsync(h);
+  im.obs.clear();
+  im.depth_scale = -1;
+  return 0;
+  R_CATCH()
+}
+
+int e3d_reg_set_image_pose(e3d_reg_t* h, int image_id, const float R[9], const float t[3]) {
+  R_TRY
+  if (!h || !R || !t) throw Error(E3D_ERR_INVALID, "null argument");
+  ImageDev& im = get_image(h, image_id);
+  for (int i = 0; i < 9; ++i) im.pose.R[i] = R[i];
+  for (int i = 0; i < 3; ++i) im.pose.t[i] = t[i];
+  for (auto& kv : im.obs) kv.second.rows_valid = false;
+  return 0;
+  R_CATCH()
+}
+
+int e3d_reg_set_splat_points(e3d_reg_t* h, const float* xyz, size_t n) {
+  R_TRY
+  if (!h || (!xyz && n)) throw Error(E3D_ERR_INVALID, "null argument");
+  DevBuf<float> tmp; tmp.reserve(3 * n);
+  copy_in(tmp.p, xyz, sizeof(float) * 3 * n, h->stream);
+  h->splat.reserve(n);
+  hipLaunchKernelGGL(k_xyz_to_float4, dim3(nblk(n)), dim3(kBlock), 0, h->stream, tmp.p, n, h->splat.p);
+  rsync(h);
+  h->n_splat = n;
+  return 0;
+  R_CATCH()
+}
+
+int e3d_reg_render_depth(e3d_reg_t* h, int image_id, int image_scale, float* depth_out) {
+  R_TRY
+  if (!h) throw Error(E3D_ERR_INVALID, "null handle");
+  ImageDev& im = get_image(h, image_id);
+  const Intrin& in = h->intr.at(im.intrinsics_id);
+  const int lvl = std::max(0, image_scale - in.min_image_scale);
+  if (lvl >= (int)in.levels.size()) throw Error(E3D_ERR_INDEX, "image scale beyond the pyramid");
+  const CamLevel& cam = in.levels[lvl];
+  const size_t px = (size_t)cam.width * cam.height;
+  im.depth.reserve(px);
+  hipLaunchKernelGGL(k_fill_f32, dim3(nblk(px)), dim3(kBlock), 0, h->stream, im.depth.p, px, INFINITY);
+  if (h->n_splat)
+    hipLaunchKernelGGL(k_splat_depth, dim3(nblk(h->n_splat)), dim3(kBlock), 0, h->stream, h->splat.p, h->n_splat, im.pose, cam,
+                       h->prm.splat_radius, reinterpret_cast<unsigned*>(im.depth.p));
+  if (depth_out) copy_out(depth_out, im.depth.p, sizeof(float) * px, h->stream);
+  rsync(h);
+  im.depth_scale = image_scale;
+  return 0;
+  R_CATCH()
+}
+
+int64_t e3d_reg_observe(e3d_reg_t* h, int image_id, int point_scale, int image_scale, int border_size, const uint32_t* indices,
+                        size_t n_indices) {
+  R_TRY
+  if (!h) throw Error(E3D_ERR_INVALID, "null handle");
+  hipStream_t s = h->stream;
+  ImageDev& im = get_image(h, image_id);
+  PointScale& S = get_scale(h, point_scale);
+  const bool all = (indices == nullptr);
+  if (all && im.depth_scale != image_scale) throw Error(E3D_ERR_INVALID, "render the occlusion depth map of this image and scale first (e3d_reg_render_depth)");
+  const size_t count = all ? S.n : n_indices;
+  Obs& O = im.obs[point_scale];
+  h->valid.reserve(count); h->tx.reserve(count); h->ty.reserve(count); h->ts.reserve(count); h->dummy_d2.reserve(count);
+  const unsigned* d_idx = nullptr;
+  if (!all) { h->cand.reserve(count); copy_in(h->cand.p, indices, sizeof(unsigned) * count, s); d_idx = h->cand.p; }
+  ObsParams q{};
+  q.point_radius = S.radius; q.image_scale = image_scale; q.border = border_size;
+  q.current_image_scale = h->prm.current_image_scale; q.image_scale_count = h->prm.image_scale_count;
+  q.occlusion_threshold = h->prm.occlusion_depth_threshold; q.max_valid_intensity = h->prm.maximum_valid_intensity;
+  q.check = all ? 1 : 0;
+  O.n = 0;
+  if (count) {
+    hipLaunchKernelGGL(k_obs_eval, dim3(nblk(count)), dim3(kBlock), 0, s, S.pts.p, d_idx, count, im.pose, make_pyramid(h, im),
+                       all ? im.depth.p : nullptr, q, h->valid.p, h->tx.p, h->ty.p, h->ts.p);
+    const size_t nb = div_up(count, kBlock);
+    h->block_counts.reserve(nb); h->block_offsets.reserve(nb); h->block_d2.reserve(nb);
+    h->chunk_sum.reserve(div_up(nb, 256) + 1); h->chunk_d2.reserve(div_up(nb, 256) + 1);
+    h->d_total.reserve(1); h->d_total_d2.reserve(1);
+    E3D_HIP(hipMemsetAsync(h->dummy_d2.p, 0, sizeof(float) * count, s));
+    launch_match_scan(h->valid.p, h->dummy_d2.p, count, h->block_counts.p, h->block_offsets.p, h->block_d2.p, h->chunk_sum.p,
+                      h->chunk_d2.p, h->d_total.p, h->d_total_d2.p, s);
+    unsigned long long total = 0;
+    copy_out(&total, h->d_total.p, sizeof total, s);
+    rsync(h);
+    O.n = (size_t)total;
+    O.idx.reserve(O.n); O.x.reserve(O.n); O.y.reserve(O.n); O.s.reserve(O.n);
+    if (O.n)
+      hipLaunchKernelGGL(k_obs_compact, dim3(nblk(count)), dim3(kBlock), 0, s, h->valid.p, h->tx.p, h->ty.p, h->ts.p, count,
+                         h->block_offsets.p, O.idx.p, O.x.p, O.y.p, O.s.p);
+  }
+  finish_observations(h, S, O);
+  rsync(h);
+  return (int64_t)O.n;
+  R_CATCH()
+}
+
+int e3d_reg_get_observations(e3d_reg_t* h, int image_id, int point_scale, uint32_t* idx, float* x, float* y, float* scale,
+                             uint8_t* flags) {
+  R_TRY
+  if (!h) throw Error(E3D_ERR_INVALID, "null handle");
+  Obs& O = get_obs(get_image(h, image_id), point_scale);
+  if (idx) copy_out(idx, O.idx.p, sizeof(unsigned) * O.n, h->stream);
+  if (x) copy_out(x, O.x.p, sizeof(float) * O.n, h->stream);
+  if (y) copy_out(y, O.y.p, sizeof(float) * O.n, h->stream);
+  if (scale) copy_out(scale, O.s.p, sizeof(float) * O.n, h->stream);
+  if (flags) copy_out(flags, O.flags.p, O.n, h->stream);
+  rsync(h);
+  return 0;
+  R_CATCH()
+}
+
+int e3d_reg_set_observations(e3d_reg_t* h, int image_id, int point_scale, size_t n, const uint32_t* idx, const float* x,
+                             const float* y, const float* scale) {
+  R_TRY
+  if (!h || (n && (!idx || !x || !y || !scale))) throw Error(E3D_ERR_INVALID, "null argument");
+  ImageDev& im = get_image(h, image_id);
+  PointScale& S = get_scale(h, point_scale);
+  Obs& O = im.obs[point_scale];
+  O.n = n;
+  O.idx.reserve(n); O.x.reserve(n); O.y.reserve(n); O.s.reserve(n);
+  copy_in(O.idx.p, idx, sizeof(unsigned) * n, h->stream); copy_in(O.x.p, x, sizeof(float) * n, h->stream);
+  copy_in(O.y.p, y, sizeof(float) * n, h->stream); copy_in(O.s.p, scale, sizeof(float) * n, h->stream);
+  finish_observations(h, S, O);
+  rsync(h);
+  return 0;
+  R_CATCH()
+}
+
+int e3d_reg_pass1(e3d_reg_t* h, int image_id, int point_scale, float* intensities, float* j_intrinsics, float* j_pose) {
+  R_TRY
+  if (!h) throw Error(E3D_ERR_INVALID, "null handle");
+  ImageDev& im = get_image(h, image_id);
+  PointScale& S = get_scale(h, point_scale);
+  Obs& O = get_obs(im, point_scale);
+  prepare_rows(h, im, S, O);
+  std::vector<float> rows(12 * O.n);
+  copy_out(rows.data(), O.rows.p, sizeof(float) * 12 * O.n, h->stream);
+  rsync(h);
+  for (size_t i = 0; i < O.n; ++i) {
+    const float* r = rows.data() + 12 * i;
+    if (intensities) intensities[i] = r[0];
+    if (j_intrinsics) for (int c = 0; c < 4; ++c) j_intrinsics[4 * i + c] = r[1 + c];
+    if (j_pose) for (int c = 0; c < 6; ++c) j_pose[6 * i + c] = r[5 + c];
+  }
+  return 0;
+  R_CATCH()
+}
+
+int e3d_reg_accumulate(e3d_reg_t* h, int image_id, int point_scale, double* H, double* b, double sums[2], int64_t counts[2]) {
+  R_TRY
+  if (!h || !H || !b || !sums || !counts) throw Error(E3D_ERR_INVALID, "null argument");
+  hipStream_t s = h->stream;
+  ImageDev& im = get_image(h, image_id);
+  PointScale& S = get_scale(h, point_scale);
+  Obs& O = get_obs(im, point_scale);
+  prepare_rows(h, im, S, O);
+  const int nb = (int)std::min<size_t>(std::max<size_t>(div_up(O.n, kBlock * 4), 1), 1024);
+  h->partial.reserve((size_t)nb * kRegSlot); h->red.reserve(kRegSlot);
+  const RegWeights w{h->prm.robust_weighting_type, h->prm.robust_weighting_parameter, h->prm.fixed_residuals_weight,
+                     h->prm.variable_residuals_weight};
+  hipLaunchKernelGGL(k_reg_pass2<8>, dim3(nb), dim3(kBlock), 0, s, O.rows.p, O.idx.p, O.flags.p, O.n, S.nbr.p,
+                     h->prm.point_neighbor_count, S.row_of_point.p, S.fixed_desc.p, S.var_desc.p, S.obs_counts.p, w, h->partial.p);
+  hipLaunchKernelGGL(k_reg_reduce, dim3(1), dim3(128), 0, s, h->partial.p, nb, kRegSlot, h->red.p);
+  double r[kRegSlot];
+  copy_out(r, h->red.p, sizeof r, s);
+  rsync(h);
+  std::fill(H, H + kRegV * kRegV, 0.0);
+  int e = 0;
+  for (int i = 0; i < kRegV; ++i) for (int j = i; j < kRegV; ++j) H[i * kRegV + j] = r[e++];
+  for (int i = 0; i < kRegV; ++i) b[i] = r[kRegH + i];
+  sums[0] = r[kRegH + kRegV]; sums[1] = r[kRegH + kRegV + 1];
+  counts[0] = (int64_t)r[kRegH + kRegV + 2]; counts[1] = (int64_t)r[kRegH + kRegV + 3];
+  return 0;
+  R_CATCH()
+}
+
+int e3d_reg_cost(e3d_reg_t* h, int image_id, int point_scale, double sums[2], int64_t counts[2]) {
+  R_TRY
+  if (!h || !sums || !counts) throw Error(E3D_ERR_INVALID, "null argument");
+  hipStream_t s = h->stream;
+  ImageDev& im = get_image(h, image_id);
+  PointScale& S = get_scale(h, point_scale);
+  Obs& O = get_obs(im, point_scale);
+  dense_intensities(h, im, S, O);
+  const int nb = (int)std::min<size_t>(std::max<size_t>(div_up(O.n, kBlock * 4), 1), 1024);
+  h->partial.reserve((size_t)nb * kRegSlot); h->red.reserve(kRegSlot);
+  const RegWeights w{h->prm.robust_weighting_type, h->prm.robust_weighting_parameter, h->prm.fixed_residuals_weight,
+                     h->prm.variable_residuals_weight};
+  hipLaunchKernelGGL(k_reg_cost, dim3(nb), dim3(kBlock), 0, s, S.intensity.p, O.idx.p, O.flags.p, O.n, S.nbr.p,
+                     h->prm.point_neighbor_count, S.fixed_desc.p, S.var_desc.p, S.obs_counts.p, w, h->partial.p);
+  hipLaunchKernelGGL(k_reg_reduce, dim3(1), dim3(64), 0, s, h->partial.p, nb, 4, h->red.p);
+  double r[4];
+  copy_out(r, h->red.p, sizeof r, s);
+  rsync(h);
+  sums[0] = r[0]; sums[1] = r[1]; counts[0] = (int64_t)r[2]; counts[1] = (int64_t)r[3];
+  return 0;
+  R_CATCH()
+}
+
+int e3d_reg_color_begin(e3d_reg_t* h, int point_scale) {
+  R_TRY
+  if (!h) throw Error(E3D_ERR_INVALID, "null handle");
+  PointScale& S = get_scale(h, point_scale);
+  E3D_HIP(hipMemsetAsync(S.var_desc.p, 0, sizeof(float) * S.n * h->prm.point_neighbor_count, h->stream));
+  E3D_HIP(hipMemsetAsync(S.obs_counts.p, 0, sizeof(int) * S.n, h->stream));
+  rsync(h);
+  return 0;
+  R_CATCH()
+}
+int e3d_reg_color_accumulate(e3d_reg_t* h, int image_id, int point_scale) {
+  R_TRY
+  if (!h) throw Error(E3D_ERR_INVALID, "null handle");
+  ImageDev& im = get_image(h, image_id);
+  PointScale& S = get_scale(h, point_scale);
+  Obs& O = get_obs(im, point_scale);
+  dense_intensities(h, im, S, O);
+  if (O.n)
+    hipLaunchKernelGGL(k_color_accumulate, dim3(nblk(O.n)), dim3(kBlock), 0, h->stream, S.intensity.p, O.idx.p, O.flags.p, O.n,
+                       S.nbr.p, h->prm.point_neighbor_count, S.var_desc.p, S.obs_counts.p);
+  rsync(h);
+  return 0;
+  R_CATCH()
+}
+int e3d_reg_color_finish(e3d_reg_t* h, int point_scale) {
+  R_TRY
+  if (!h) throw Error(E3D_ERR_INVALID, "null handle");
+  PointScale& S = get_scale(h, point_scale);
+  hipLaunchKernelGGL(k_color_finish, dim3(nblk(S.n)), dim3(kBlock), 0, h->stream, S.n, h->prm.point_neighbor_count, S.var_desc.p,
+                     S.obs_counts.p);
+  rsync(h);
+  return 0;
+  R_CATCH()
+}
+
+}  // extern "C"

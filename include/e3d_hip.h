@@ -154,6 +154,86 @@ int e3d_icp_pair_system(const float* src_xyz, const float* src_normals,
 int e3d_normals_knn(const float* xyz, size_t n, int k, const float viewpoint[3],
                     float* out_normals, float* out_curvature, int32_t* knn_indices);
 
+/* ---- (B) ImageRegistrator: dense photometric residual / Jacobian kernels -------------------------------------
+ * Device-resident mirror of the parts of opt::Problem the hot loops read (src/opt/problem.h:300-388) and the inner
+ * operator surfaces of the optimizer:
+ *   OcclusionGeometry::RenderDepthMap (CPU-splat path)      src/opt/occlusion_geometry.cc:404-464      -> e3d_reg_render_depth
+ *   VisibilityEstimator::AppendObservationsFor...           src/opt/visibility_estimator.cc:258-295,366-532 -> e3d_reg_observe
+ *   VisibilityEstimator::DetermineIfAllNeighborsAreObserved src/opt/visibility_estimator.cc:199-256    -> (inside e3d_reg_observe)
+ *   IntrinsicsAndPoseOptimizer::AccumulateHAndBAndResidualsForObservations
+ *                                                           src/opt/intrinsics_and_pose_optimizer.cc:624-1296 -> e3d_reg_accumulate
+ *   CostCalculator::AccumulateResidualsForObservations      src/opt/cost_calculator.cc:102-271         -> e3d_reg_cost
+ *   ColorOptimizer::Apply                                   src/opt/color_optimizer.cc:40-123          -> e3d_reg_color_*
+ * Round-1 coverage: PINHOLE cameras (camera type 0), non-rig images, colour residuals (fixed + variable descriptors);
+ * depth residuals (off by default in the reference) and rig images are not implemented and are rejected. */
+typedef struct e3d_reg e3d_reg_t;
+
+typedef struct {
+  int32_t point_neighbor_count;        /* K, opt::Parameters::point_neighbor_count (parameters.h:42)   */
+  int32_t robust_weighting_type;       /* 0 none, 1 Huber, 2 Tukey (robust_weighting.h:40-44)           */
+  float   robust_weighting_parameter;
+  float   fixed_residuals_weight;
+  float   variable_residuals_weight;
+  float   maximum_valid_intensity;     /* 252                                                           */
+  float   occlusion_depth_threshold;   /* 0.01                                                          */
+  float   splat_radius;                /* 0.03                                                          */
+  int32_t current_image_scale;         /* Problem::current_image_scale()                                */
+  int32_t image_scale_count;           /* Problem::image_scale_count()                                  */
+} e3d_reg_params;
+
+#define E3D_CAMERA_PINHOLE 0
+
+e3d_reg_t* e3d_reg_create(const e3d_reg_params* params);
+void e3d_reg_destroy(e3d_reg_t* reg);
+int e3d_reg_set_params(e3d_reg_t* reg, const e3d_reg_params* params);
+
+/* One point scale of the multi-resolution cloud: points()[s], point radius, neighbor_point_indices_[s] (n*K, u32),
+ * fixed_descriptors()[s] (n*K or NULL).  Variable descriptors start at 0 and observation counts at 99999 when fixed
+ * descriptors are given (problem.cc:549-572), else 0. */
+int e3d_reg_set_point_scale(e3d_reg_t* reg, int point_scale, const float* xyz, size_t n, float point_radius,
+                            const uint32_t* neighbor_indices, const float* fixed_descriptors);
+int e3d_reg_set_variable_descriptors(e3d_reg_t* reg, int point_scale, const float* descriptors,
+                                     const int32_t* observation_counts);
+int e3d_reg_get_variable_descriptors(e3d_reg_t* reg, int point_scale, float* descriptors, int32_t* observation_counts);
+
+/* opt::Intrinsics: the model of the best available scale + its ScaledBy(0.5) pyramid of n_levels models
+ * (intrinsics.cc:46-51, camera_base_impl.h:70-89) and radius cut-offs (camera_base_impl.h:410-463). */
+int e3d_reg_set_intrinsics(e3d_reg_t* reg, int intrinsics_id, int camera_type, int width, int height,
+                           const float* parameters, int n_parameters, int min_image_scale, int n_levels);
+/* queries the pyramid the library built: widths/heights (n_levels), parameters (n_levels x n_parameters), cut-offs */
+int e3d_reg_get_intrinsics_level(e3d_reg_t* reg, int intrinsics_id, int level, int* width, int* height,
+                                 float* parameters, float* radius_cutoff_squared);
+/* opt::Image: u8 pyramid (level l has the size of intrinsics level l) and optional masks; pose image_T_global as
+ * so3().matrix() (row-major) + translation. */
+int e3d_reg_set_image(e3d_reg_t* reg, int image_id, int intrinsics_id, const uint8_t* const* level_pixels,
+                      const uint8_t* const* level_masks);
+int e3d_reg_set_image_pose(e3d_reg_t* reg, int image_id, const float R[9], const float t[3]);
+/* OcclusionGeometry::SetSplatPoints */
+int e3d_reg_set_splat_points(e3d_reg_t* reg, const float* xyz, size_t n);
+
+/* Renders the occlusion depth map of an image at an image scale (kept on the device for e3d_reg_observe);
+ * depth_out (optional) receives height x width floats. */
+int e3d_reg_render_depth(e3d_reg_t* reg, int image_id, int image_scale, float* depth_out);
+/* Creates the observations of a point scale in an image (indices == NULL: every point, with occlusion, mask and
+ * over-saturation tests against the last rendered depth map of this image and scale; indices != NULL: the given
+ * visibility list without those tests) in point order, and their all-neighbours-observed flags.  Returns the count. */
+int64_t e3d_reg_observe(e3d_reg_t* reg, int image_id, int point_scale, int image_scale, int border_size,
+                        const uint32_t* indices, size_t n_indices);
+int e3d_reg_get_observations(e3d_reg_t* reg, int image_id, int point_scale, uint32_t* point_index, float* x, float* y,
+                             float* image_scale, uint8_t* all_neighbors_observed);
+int e3d_reg_set_observations(e3d_reg_t* reg, int image_id, int point_scale, size_t n, const uint32_t* point_index,
+                             const float* x, const float* y, const float* image_scale);
+/* ComputePointIntensityAndJacobians for every observation (n x 1, n x I, n x 6); mainly for tests. */
+int e3d_reg_pass1(e3d_reg_t* reg, int image_id, int point_scale, float* intensities, float* j_intrinsics, float* j_pose);
+/* H: (I+6) x (I+6) row-major, upper triangle filled (variables: [intrinsics(I), pose(6)]); b: I+6;
+ * sums / counts: [fixed, variable] robust residual sums and residual counts. */
+int e3d_reg_accumulate(e3d_reg_t* reg, int image_id, int point_scale, double* H, double* b, double sums[2],
+                       int64_t counts[2]);
+int e3d_reg_cost(e3d_reg_t* reg, int image_id, int point_scale, double sums[2], int64_t counts[2]);
+int e3d_reg_color_begin(e3d_reg_t* reg, int point_scale);
+int e3d_reg_color_accumulate(e3d_reg_t* reg, int image_id, int point_scale);
+int e3d_reg_color_finish(e3d_reg_t* reg, int point_scale);
+
 #ifdef __cplusplus
 }
 #endif

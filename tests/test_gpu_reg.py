@@ -1,0 +1,140 @@
+"""GPU parity tests of the path-(B) kernels against the CPU oracle: splat depth maps and observation lists bit-exact
+(integer / index work), intensities bit-exact and Jacobian rows to f32 round-off, normal-equation blocks and costs to
+1e-7 / 1e-9 relative (f64 sums of f32 products in a different order; device division/log2f differ in the last ulp)."""
+import numpy as np
+import pytest
+
+from reg_util import make_reg_scene
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def rb():
+    from oracle import reg_binding
+    reg_binding.lib()
+    return reg_binding
+
+
+def _setup(e3d, rb, S, **pk):
+    prm = e3d.default_reg_params(image_scale_count=S["n_levels"], point_neighbor_count=S["K"], **pk)
+    P = e3d.RegProblem(prm)
+    P.set_intrinsics(0, S["width"], S["height"], S["params"], 0, S["n_levels"])
+    P.set_image(0, 0, S["pyr"], S.get("masks"))
+    P.set_image_pose(0, S["R"], S["t"])
+    P.set_point_scale(0, S["pts"], S["point_radius"], S["nbr"], S["fixed_desc"])
+    P.set_variable_descriptors(0, S["var_desc"], S["obs_counts"])
+    P.set_splat_points(S["pts"])
+    cam = rb.make_camera(S["width"], S["height"], S["params"])
+    levels = rb.camera_pyramid(cam, S["n_levels"])
+    return P, levels
+
+
+def test_camera_pyramid_matches(e3d, rb):
+    S = make_reg_scene()
+    P, levels = _setup(e3d, rb, S)
+    for l in range(S["n_levels"]):
+        w, h, p, c = P.intrinsics_level(0, l)
+        assert (w, h) == (levels[l].width, levels[l].height)
+        assert np.array_equal(p, levels[l].params()) and c == levels[l].cutoff2
+
+
+@pytest.mark.parametrize("scale", [0, 1])
+def test_splat_depth_bit_exact(e3d, rb, scale):
+    S = make_reg_scene(n_points=20000)
+    P, levels = _setup(e3d, rb, S)
+    g = P.render_depth(0, scale, (levels[scale].height, levels[scale].width))
+    o = rb.splat_depth(S["pts"], S["R"], S["t"], levels[scale], 0.03)
+    assert np.array_equal(g.view(np.uint32), o.view(np.uint32))
+    assert np.isfinite(g).sum() > 1000
+
+
+def _observe_both(e3d, rb, S, P, levels, border=1, image_scale=0, masks=None):
+    depth_o = rb.splat_depth(S["pts"], S["R"], S["t"], levels[image_scale], 0.03)
+    P.render_depth(0, image_scale)
+    n = P.observe(0, 0, image_scale, border)
+    g = P.get_observations(0, 0, n)
+    o = rb.observe(S["pts"], S["point_radius"], S["R"], S["t"], levels, 0, S["pyr"], masks, depth_o, image_scale, border,
+                   P.params.current_image_scale, S["n_levels"])
+    of = rb.neighbors_observed(len(S["pts"]), o[0], S["nbr"], S["K"])
+    return g, o, of
+
+
+def test_observations_match_oracle(e3d, rb):
+    S = make_reg_scene(n_points=30000, seed=1)
+    mask = np.zeros_like(S["pyr"][0]); mask[100:140, 50:120] = 1
+    masks = [mask]
+    for _ in range(1, S["n_levels"]):
+        m = masks[-1]; h, w = (m.shape[0] // 2) * 2, (m.shape[1] // 2) * 2
+        masks.append(m[0:h:2, 0:w:2] | m[0:h:2, 1:w:2] | m[1:h:2, 0:w:2] | m[1:h:2, 1:w:2])   # Image::BuildMaskPyramid
+    S["masks"] = masks
+    P, levels = _setup(e3d, rb, S)
+    g, o, of = _observe_both(e3d, rb, S, P, levels, masks=masks)
+    assert len(g[0]) == len(o[0]) > 5000
+    assert np.array_equal(g[0], o[0])                                        # same points, same (point) order
+    assert np.array_equal(g[1].view(np.uint32), o[1].view(np.uint32)) and np.array_equal(g[2].view(np.uint32), o[2].view(np.uint32))
+    assert np.abs(g[3] - o[3]).max() <= 4e-7 * np.abs(o[3]).max() + 1e-7      # log2f: device vs glibc, last ulp
+    assert np.array_equal(g[4], of)
+    # indexed variant (fixed visibility list, no occlusion / mask tests)
+    n2 = P.observe(0, 0, 0, 1, indices=o[0][::3])
+    g2 = P.get_observations(0, 0, n2)
+    o2 = rb.observe(S["pts"], S["point_radius"], S["R"], S["t"], levels, 0, S["pyr"], None, None, 0, 1, 0, S["n_levels"], indices=o[0][::3])
+    assert np.array_equal(g2[0], o2[0]) and np.array_equal(g2[1].view(np.uint32), o2[1].view(np.uint32))
+    assert np.array_equal(g2[4], rb.neighbors_observed(len(S["pts"]), o2[0], S["nbr"], S["K"]))
+
+
+def test_pass1_rows(e3d, rb):
+    S = make_reg_scene(n_points=20000, seed=2)
+    P, levels = _setup(e3d, rb, S)
+    g, o, of = _observe_both(e3d, rb, S, P, levels)
+    P.set_observations(0, 0, *o)                       # identical inputs (incl. scale) for both sides
+    I, ji, jp = P.pass1(0, 0, len(o[0]))
+    Io, jio, jpo = rb.pass1(S["pts"], S["point_radius"], levels[0], 0, S["pyr"], S["R"], S["t"], o)
+    assert np.array_equal(I.view(np.uint32), Io.view(np.uint32))
+    assert np.abs(ji - jio).max() <= 1e-5 * np.abs(jio).max()
+    assert np.abs(jp - jpo).max() <= 1e-5 * np.abs(jpo).max()
+
+
+@pytest.mark.parametrize("rtype,rparam", [(1, 47.434166), (2, 30.0), (0, 0.0)])
+def test_accumulate_and_cost(e3d, rb, rtype, rparam):
+    S = make_reg_scene(n_points=40000, seed=3)
+    P, levels = _setup(e3d, rb, S, robust_weighting_type=rtype, robust_weighting_parameter=rparam)
+    g, o, of = _observe_both(e3d, rb, S, P, levels)
+    P.set_observations(0, 0, *o)
+    H, b, sums, counts = P.accumulate(0, 0)
+    Ho, bo, so, co = rb.accumulate(S["pts"], S["point_radius"], S["nbr"], S["K"], S["fixed_desc"], S["var_desc"], S["obs_counts"], levels[0], 0,
+                                   S["pyr"], S["R"], S["t"], o, of, rtype, rparam, 1.0, 1.0)
+    assert np.array_equal(counts, co) and counts[0] > 1000 and counts[1] > 100
+    assert np.abs(sums - so).max() <= 1e-9 * np.abs(so).max()
+    assert np.abs(H - Ho).max() <= 1e-6 * np.abs(Ho).max()
+    assert np.abs(b - bo).max() <= 1e-5 * np.abs(bo).max()
+    s2, c2 = P.cost(0, 0)
+    so2, co2 = rb.cost(len(S["pts"]), S["nbr"], S["K"], S["fixed_desc"], S["var_desc"], S["obs_counts"], 0, S["pyr"], o, of, rtype, rparam, 1.0, 1.0)
+    assert np.array_equal(c2, co2) and np.abs(s2 - so2).max() <= 1e-12 * np.abs(so2).max()
+    assert np.abs(s2 - sums).max() <= 1e-9 * np.abs(sums).max()   # cost pass == residual sums of the accumulate pass
+
+
+def test_color_update(e3d, rb):
+    S = make_reg_scene(n_points=20000, seed=4)
+    P, levels = _setup(e3d, rb, S)
+    g, o, of = _observe_both(e3d, rb, S, P, levels)
+    P.set_observations(0, 0, *o)
+    n, K = len(S["pts"]), S["K"]
+    P.color_begin(0)
+    for _ in range(2):
+        P.color_accumulate(0, 0)
+    P.color_finish(0)
+    d, c = P.get_variable_descriptors(0, n)
+    do = np.zeros((n, K), np.float32); co = np.zeros(n, np.int32)
+    for _ in range(2):
+        rb.color_accumulate(n, S["nbr"], K, 0, S["pyr"], o, of, do, co)
+    rb.color_finish(K, do, co)
+    assert np.array_equal(c, co) and np.array_equal(d.view(np.uint32), do.view(np.uint32))
+
+
+def test_reg_errors(e3d):
+    P = e3d.RegProblem()
+    with pytest.raises(e3d.E3DError):
+        P.observe(0, 0, 0, 1)
+    with pytest.raises(e3d.E3DError):
+        P.set_intrinsics(0, 64, 48, [50, 50, 32, 24, 0.1, 0, 0, 0], 0, 2, camera_type=2)   # only PINHOLE so far

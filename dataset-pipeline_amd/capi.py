@@ -83,6 +83,12 @@ SIGNATURES = {
     "e3d_reg_color_begin": (C.c_int, [C.c_void_p, C.c_int]),
     "e3d_reg_color_accumulate": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "e3d_reg_color_finish": (C.c_int, [C.c_void_p, C.c_int]),
+    "e3d_reg_get_image_pose": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "e3d_reg_update_observations": (C.c_int, [C.c_void_p, C.c_int]),
+    "e3d_reg_color_update": (C.c_int, [C.c_void_p]),
+    "e3d_reg_compute_cost": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "e3d_reg_apply": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "e3d_reg_run_on_current_scale": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
 }
 
 
@@ -364,9 +370,42 @@ class RegProblem:
             marr = (C.c_void_p * len(keepm))(*[(m.ctypes.data if m is not None else None) for m in keepm])
         self._chk(lib().e3d_reg_set_image(self._h, image_id, intrinsics_id, arr, marr), "e3d_reg_set_image")
 
-    def set_image_pose(self, image_id, R, t):
-        R = np.ascontiguousarray(R, np.float32); t = np.ascontiguousarray(t, np.float32)
-        self._chk(lib().e3d_reg_set_image_pose(self._h, image_id, C.c_void_p(R.ctypes.data), C.c_void_p(t.ctypes.data)), "e3d_reg_set_image_pose")
+    def set_image_pose(self, image_id, q, t):
+        """image_T_global as unit quaternion (w, x, y, z) + translation."""
+        q = np.ascontiguousarray(q, np.float32); t = np.ascontiguousarray(t, np.float32)
+        assert q.shape == (4,) and t.shape == (3,)
+        self._chk(lib().e3d_reg_set_image_pose(self._h, image_id, C.c_void_p(q.ctypes.data), C.c_void_p(t.ctypes.data)), "e3d_reg_set_image_pose")
+
+    def get_image_pose(self, image_id):
+        q = np.zeros(4, np.float32); t = np.zeros(3, np.float32)
+        self._chk(lib().e3d_reg_get_image_pose(self._h, image_id, C.c_void_p(q.ctypes.data), C.c_void_p(t.ctypes.data)), "e3d_reg_get_image_pose")
+        return q, t
+
+    def update_observations(self, border_size=1):
+        self._chk(lib().e3d_reg_update_observations(self._h, border_size), "e3d_reg_update_observations")
+
+    def color_update(self):
+        self._chk(lib().e3d_reg_color_update(self._h), "e3d_reg_color_update")
+
+    def compute_cost(self):
+        c = C.c_double()
+        self._chk(lib().e3d_reg_compute_cost(self._h, C.byref(c)), "e3d_reg_compute_cost")
+        return c.value
+
+    def apply(self, lam, print_progress=False):
+        """IntrinsicsAndPoseOptimizer::Apply -> (applied_update, lambda, max_change)."""
+        a = C.c_int(); l = C.c_float(lam); m = C.c_float()
+        self._chk(lib().e3d_reg_apply(self._h, int(print_progress), C.byref(a), C.byref(l), C.byref(m)), "e3d_reg_apply")
+        return bool(a.value), l.value, m.value
+
+    def run_on_current_scale(self, max_num_iterations, max_change_convergence_threshold=0.0,
+                             iterations_without_new_optimum_threshold=15, print_progress=False):
+        """Optimizer::RunOnCurrentScale -> (converged, optimum_cost, iterations)."""
+        c = C.c_double(); it = C.c_int()
+        r = self._chk(lib().e3d_reg_run_on_current_scale(self._h, max_num_iterations, max_change_convergence_threshold,
+                                                         iterations_without_new_optimum_threshold, int(print_progress),
+                                                         C.byref(c), C.byref(it)), "e3d_reg_run_on_current_scale")
+        return bool(r), c.value, it.value
 
     def set_splat_points(self, xyz):
         xyz = np.ascontiguousarray(xyz, np.float32)

@@ -20,6 +20,7 @@
 
 #include "../../include/e3d_hip.h"
 #include "e3d_icp_kernels.hpp"
+#include "e3d_math.hpp"
 
 #pragma clang fp contract(off)
 
@@ -516,6 +517,8 @@ struct PointScale {
 };
 struct Intrin {
   int type = 0, min_image_scale = 0, n_params = 4;
+  int width = 0, height = 0;
+  float params[12] = {0};
   std::vector<CamLevel> levels;
 };
 struct Obs {
@@ -530,7 +533,8 @@ struct ImageDev {
   int intrinsics_id = -1;
   std::vector<DevBuf<unsigned char>> pix, mask;
   std::vector<bool> has_mask;
-  Pose pose{};
+  Pose pose{};                    // so3().matrix() + translation of image_T_global, as the kernels read it
+  SE3f pose_q;                    // image_T_global (Sophus::SE3f state)
   DevBuf<float> depth;            // last rendered occlusion depth (as float bits)
   int depth_scale = -1;
   std::map<int, Obs> obs;         // per point scale
@@ -551,6 +555,24 @@ static CamLevel make_level(int w, int h, const float* p) {
   for (int y = 0; y < h; ++y) { upd(0.f, (float)y); upd((float)(w - 1), (float)y); }
   c.cutoff2 = mc * 1.01f;
   return c;
+}
+
+// Intrinsics::BuildModelPyramid (intrinsics.cc:46-51): level l = ScaledBy(0.5) of level l-1
+static void build_model_pyramid(Intrin& in, int n_levels) {
+  in.levels.clear();
+  in.levels.push_back(make_level(in.width, in.height, in.params));
+  for (int l = 1; l < n_levels; ++l) {
+    const CamLevel& p = in.levels.back();
+    const float f = 0.5f;
+    const float q[4] = {p.fx * f, p.fy * f, f * (p.cx + 0.5f) - 0.5f, f * (p.cy + 0.5f) - 0.5f};
+    in.levels.push_back(make_level((int)(f * p.width + 0.5f), (int)(f * p.height + 0.5f), q));
+  }
+}
+
+static void set_pose(ImageDev& im, const SE3f& T) {
+  im.pose_q = T;
+  quat_to_matrix<float>(T.q.w, T.q.x, T.q.y, T.q.z, im.pose.R);
+  for (int i = 0; i < 3; ++i) im.pose.t[i] = T.t[i];
 }
 
 }  // namespace e3d
@@ -740,13 +762,9 @@ int e3d_reg_set_intrinsics(e3d_reg_t* h, int intrinsics_id, int camera_type, int
   if (n_levels < 1 || n_levels > kRegMaxLevels || width < 2 || height < 2 || min_image_scale < 0) throw Error(E3D_ERR_INVALID, "bad pyramid description");
   Intrin in;
   in.type = camera_type; in.min_image_scale = min_image_scale; in.n_params = n_parameters;
-  in.levels.push_back(make_level(width, height, parameters));
-  for (int l = 1; l < n_levels; ++l) {     // Intrinsics::BuildModelPyramid: ScaledBy(0.5) of the previous level
-    const CamLevel& p = in.levels.back();
-    const float f = 0.5f;
-    const float q[4] = {p.fx * f, p.fy * f, f * (p.cx + 0.5f) - 0.5f, f * (p.cy + 0.5f) - 0.5f};
-    in.levels.push_back(make_level((int)(f * p.width + 0.5f), (int)(f * p.height + 0.5f), q));
-  }
+  in.width = width; in.height = height;
+  for (int i = 0; i < n_parameters; ++i) in.params[i] = parameters[i];
+  build_model_pyramid(in, n_levels);
   h->intr[intrinsics_id] = in;
   return 0;
   R_CATCH()
@@ -796,13 +814,25 @@ int e3d_reg_set_image(e3d_reg_t* h, int image_id, int intrinsics_id, const uint8
   R_CATCH()
 }
 
-int e3d_reg_set_image_pose(e3d_reg_t* h, int image_id, const float R[9], const float t[3]) {
+int e3d_reg_set_image_pose(e3d_reg_t* h, int image_id, const float q[4], const float t[3]) {
   R_TRY
-  if (!h || !R || !t) throw Error(E3D_ERR_INVALID, "null argument");
+  if (!h || !q || !t) throw Error(E3D_ERR_INVALID, "null argument");
   ImageDev& im = get_image(h, image_id);
-  for (int i = 0; i < 9; ++i) im.pose.R[i] = R[i];
-  for (int i = 0; i < 3; ++i) im.pose.t[i] = t[i];
+  SE3f T;
+  T.q.w = q[0]; T.q.x = q[1]; T.q.y = q[2]; T.q.z = q[3];
+  for (int i = 0; i < 3; ++i) T.t[i] = t[i];
+  set_pose(im, T);
   for (auto& kv : im.obs) kv.second.rows_valid = false;
+  return 0;
+  R_CATCH()
+}
+
+int e3d_reg_get_image_pose(e3d_reg_t* h, int image_id, float q[4], float t[3]) {
+  R_TRY
+  if (!h || !q || !t) throw Error(E3D_ERR_INVALID, "null argument");
+  const ImageDev& im = get_image(h, image_id);
+  q[0] = im.pose_q.q.w; q[1] = im.pose_q.q.x; q[2] = im.pose_q.q.y; q[3] = im.pose_q.q.z;
+  for (int i = 0; i < 3; ++i) t[i] = im.pose_q.t[i];
   return 0;
   R_CATCH()
 }
@@ -1024,4 +1054,286 @@ int e3d_reg_color_finish(e3d_reg_t* h, int point_scale) {
   R_CATCH()
 }
 
+
+// =====================================================================================================================================
+// Optimizer driver (host): the alternation of opt::Optimizer::RunOnCurrentScale (src/opt/optimizer.cc:49-182) and
+// IntrinsicsAndPoseOptimizer::Apply (src/opt/intrinsics_and_pose_optimizer.cc:48-259) over the kernel-level operators above.
+// Images are visited in ascending image id (the reference iterates an unordered_map, whose order is unspecified).
+// Non-rig images, PINHOLE, colour residuals.
+// =====================================================================================================================================
+}  // extern "C"
+
+namespace e3d {
+
+struct RegState {
+  std::map<int, Intrin> intr;
+  std::map<int, SE3f> poses;
+};
+
+static RegState get_state(e3d_reg* h) {
+  RegState st;
+  st.intr = h->intr;
+  for (auto& kv : h->images) st.poses[kv.first] = kv.second.pose_q;
+  return st;
+}
+static void set_state(e3d_reg* h, const RegState& st) {
+  h->intr = st.intr;
+  for (auto& kv : h->images) {
+    set_pose(kv.second, st.poses.at(kv.first));
+    for (auto& o : kv.second.obs) o.second.rows_valid = false;
+  }
+}
+
+static int best_available_scale(const e3d_reg* h, const Intrin& in) {
+  // Intrinsics::best_available_image_scale(max(min_occlusion_check_image_scale (0), current_image_scale))
+  const int want = std::max(0, (int)h->prm.current_image_scale);
+  return std::min<int>(in.min_image_scale + (int)in.levels.size() - 1, std::max<int>(in.min_image_scale, want));
+}
+
+// Problem::ComputeCost (problem.cc:602-631), colour terms
+static double compute_cost_value(const e3d_reg* h, const double sums[2], const int64_t counts[2]) {
+  const bool use_f = h->prm.fixed_residuals_weight > 0, use_v = h->prm.variable_residuals_weight > 0;
+  double r = 0;
+  if (use_f && counts[0] > 0) r += h->prm.fixed_residuals_weight * sums[0] / (double)counts[0];
+  if (use_v && counts[1] > 0) r += h->prm.variable_residuals_weight * sums[1] / (double)counts[1];
+  if ((!use_f && !use_v) || (counts[0] == 0 && counts[1] == 0)) r = std::numeric_limits<float>::infinity();
+  return r;
+}
+
+// VisibilityEstimator::CreateObservationsForAllImages + DetermineIfAllNeighborsAreObserved
+static void update_observations(e3d_reg* h, int border) {
+  constexpr size_t kManyObservationsCount = 100;
+  for (auto& kv : h->images) {
+    ImageDev& im = kv.second;
+    const int scale = best_available_scale(h, h->intr.at(im.intrinsics_id));
+    if (e3d_reg_render_depth(h, kv.first, scale, nullptr) < 0) throw Error(E3D_ERR_INVALID, e3d_last_error());
+    im.obs.clear();
+    bool had_many = false;
+    for (auto it = h->scales.rbegin(); it != h->scales.rend(); ++it) {
+      const int64_t n = e3d_reg_observe(h, kv.first, it->first, scale, border, nullptr, 0);
+      if (n < 0) throw Error(E3D_ERR_INVALID, e3d_last_error());
+      if ((size_t)n > kManyObservationsCount) had_many = true;
+      else if (n == 0 && had_many) break;
+    }
+  }
+}
+
+static void color_update(e3d_reg* h) {
+  for (auto& sc : h->scales) {
+    if (e3d_reg_color_begin(h, sc.first) < 0) throw Error(E3D_ERR_INVALID, e3d_last_error());
+    for (auto& kv : h->images)
+      if (kv.second.obs.count(sc.first) && e3d_reg_color_accumulate(h, kv.first, sc.first) < 0) throw Error(E3D_ERR_INVALID, e3d_last_error());
+    if (e3d_reg_color_finish(h, sc.first) < 0) throw Error(E3D_ERR_INVALID, e3d_last_error());
+  }
+}
+
+// CostCalculator::ComputeCost over the stored observations
+static double total_cost(e3d_reg* h) {
+  double sums[2] = {0, 0};
+  int64_t counts[2] = {0, 0};
+  for (auto& kv : h->images)
+    for (auto& sc : h->scales) {
+      if (!kv.second.obs.count(sc.first)) continue;
+      double s2[2]; int64_t c2[2];
+      if (e3d_reg_cost(h, kv.first, sc.first, s2, c2) < 0) throw Error(E3D_ERR_INVALID, e3d_last_error());
+      sums[0] += s2[0]; sums[1] += s2[1]; counts[0] += c2[0]; counts[1] += c2[1];
+    }
+  if (counts[0] == 0 && counts[1] == 0) return std::numeric_limits<double>::infinity();
+  return compute_cost_value(h, sums, counts);
+}
+
+// IntrinsicsAndPoseOptimizer::Apply
+static void apply_update(e3d_reg* h, bool print, bool* applied_update, float* lambda, float* max_change) {
+  hipStream_t s = h->stream;
+  // CountAndIndexVariables: [intrinsics blocks][6 per image]
+  std::map<int, int> intr_index, image_index;
+  int V = 0;
+  for (auto& kv : h->intr) { intr_index[kv.first] = V; V += kv.second.n_params; }
+  for (auto& kv : h->images) { image_index[kv.first] = V; V += 6; }
+  std::vector<double> H((size_t)V * V, 0.0), b((size_t)V, 0.0);
+  double sums[2] = {0, 0};
+  int64_t counts[2] = {0, 0};
+  // visibility lists = observed point indices of the current observations (device copies)
+  std::map<int, std::map<int, std::pair<std::shared_ptr<DevBuf<unsigned>>, size_t>>> vis;
+  for (auto& kv : h->images) {
+    ImageDev& im = kv.second;
+    const int I = h->intr.at(im.intrinsics_id).n_params;
+    const int ii = intr_index.at(im.intrinsics_id), pi = image_index.at(kv.first);
+    for (auto& sc : h->scales) {
+      if (!im.obs.count(sc.first)) continue;
+      Obs& O = im.obs.at(sc.first);
+      auto buf = std::make_shared<DevBuf<unsigned>>();
+      buf->reserve(O.n);
+      if (O.n) E3D_HIP(hipMemcpyAsync(buf->p, O.idx.p, sizeof(unsigned) * O.n, hipMemcpyDeviceToDevice, s));
+      vis[kv.first][sc.first] = {buf, O.n};
+      double Hl[kRegV * kRegV], bl[kRegV], s2[2]; int64_t c2[2];
+      if (e3d_reg_accumulate(h, kv.first, sc.first, Hl, bl, s2, c2) < 0) throw Error(E3D_ERR_INVALID, e3d_last_error());
+      sums[0] += s2[0]; sums[1] += s2[1]; counts[0] += c2[0]; counts[1] += c2[1];
+      // scatter the local [intrinsics(I), pose(6)] block (AccumulateOnHAndB's three block updates)
+      auto gidx = [&](int l) { return l < I ? ii + l : pi + (l - I); };
+      for (int r = 0; r < I + 6; ++r) {
+        for (int c = r; c < I + 6; ++c) H[(size_t)gidx(r) * V + gidx(c)] += Hl[r * kRegV + c];
+        b[gidx(r)] += bl[r];
+      }
+    }
+  }
+  E3D_HIP(hipStreamSynchronize(s));
+  const double initial_residual = compute_cost_value(h, sums, counts);
+  if (print)
+    printf("    Initial residual: %g (#fixed residuals: %lld, #variable residuals: %lld)\n", initial_residual, (long long)counts[0], (long long)counts[1]);
+
+  const RegState old_state = get_state(h);
+  *applied_update = false;
+  std::vector<double> Hlm, x(V), W;
+  std::vector<int> perm;
+  constexpr int kNumLMTries = 10;
+  for (int lm = 0; lm < kNumLMTries; ++lm) {
+    Hlm = H;
+    for (int i = 0; i < V; ++i) Hlm[(size_t)i * V + i] *= (1 + (*lambda));       // multiplicative damping (:206)
+    ldlt_solve_upper(Hlm.data(), V, b.data(), x.data(), W, perm);
+    // CreateDeltaState(-x)
+    RegState trial = old_state;
+    for (auto& kv : trial.intr) {
+      Intrin& in = kv.second;
+      const int base = intr_index.at(kv.first);
+      for (int i = 0; i < in.n_params; ++i) in.params[i] += -1 * x[base + i];      // float += double (intrinsics.cc:71-73)
+      build_model_pyramid(in, (int)in.levels.size());
+    }
+    for (auto& kv : trial.poses) kv.second = se3_apply_update(&x[image_index.at(kv.first)], old_state.poses.at(kv.first));   // exp(-x) * T
+    // ComputeResidualForState with the visibility lists fixed
+    set_state(h, trial);
+    double ts[2] = {0, 0}; int64_t tc[2] = {0, 0};
+    constexpr size_t kManyObservationsCount = 100;
+    for (auto& kv : h->images) {
+      const int scale = best_available_scale(h, h->intr.at(kv.second.intrinsics_id));
+      bool had_many = false;
+      std::vector<int> done;
+      for (auto it = h->scales.rbegin(); it != h->scales.rend(); ++it) {
+        auto vi = vis[kv.first].find(it->first);
+        const size_t nv = (vi == vis[kv.first].end()) ? 0 : vi->second.second;
+        const unsigned* ptr = nv ? vi->second.first->p : nullptr;
+        static const unsigned dummy = 0;
+        const int64_t n = e3d_reg_observe(h, kv.first, it->first, scale, 1, ptr ? ptr : &dummy, nv);
+        if (n < 0) throw Error(E3D_ERR_INVALID, e3d_last_error());
+        done.push_back(it->first);
+        if ((size_t)n > kManyObservationsCount) had_many = true;
+        else if (n == 0 && had_many) break;
+      }
+      for (auto& sc : h->scales) {
+        // scales skipped by the early-out have empty observation vectors in the reference
+        if (std::find(done.begin(), done.end(), sc.first) == done.end()) continue;
+        double s2[2]; int64_t c2[2];
+        if (e3d_reg_cost(h, kv.first, sc.first, s2, c2) < 0) throw Error(E3D_ERR_INVALID, e3d_last_error());
+        ts[0] += s2[0]; ts[1] += s2[1]; tc[0] += c2[0]; tc[1] += c2[1];
+      }
+    }
+    const double new_residual = compute_cost_value(h, ts, tc);
+    if (new_residual < initial_residual || lm == kNumLMTries - 1) {      // kAlwaysApplyLastUpdate
+      if (print) printf("    LM update accepted, new residual: %g\n", new_residual);
+      double mx = -std::numeric_limits<double>::infinity();
+      for (int i = 0; i < V; ++i) mx = std::max(mx, x[i]);               // x.maxCoeff(): signed max [QUIRK]
+      *max_change = (float)mx;
+      *lambda = 0.5f * (*lambda);
+      *applied_update = true;
+      break;                                                             // state stays at `trial`
+    } else {
+      *lambda = 2.f * (*lambda);
+      if (print) printf("    [%d of %d] LM update rejected (bad residual: %g), lambda increased to %g\n", lm + 1, kNumLMTries, new_residual, (double)*lambda);
+      set_state(h, old_state);
+    }
+  }
+}
+
+}  // namespace e3d
+
+extern "C" {
+
+int e3d_reg_update_observations(e3d_reg_t* h, int border_size) {
+  R_TRY
+  if (!h) throw Error(E3D_ERR_INVALID, "null handle");
+  update_observations(h, border_size);
+  return 0;
+  R_CATCH()
+}
+int e3d_reg_color_update(e3d_reg_t* h) {
+  R_TRY
+  if (!h) throw Error(E3D_ERR_INVALID, "null handle");
+  color_update(h);
+  return 0;
+  R_CATCH()
+}
+int e3d_reg_compute_cost(e3d_reg_t* h, double* cost) {
+  R_TRY
+  if (!h || !cost) throw Error(E3D_ERR_INVALID, "null argument");
+  *cost = total_cost(h);
+  return 0;
+  R_CATCH()
+}
+int e3d_reg_apply(e3d_reg_t* h, int print_progress, int* applied_update, float* lambda, float* max_change) {
+  R_TRY
+  if (!h || !applied_update || !lambda || !max_change) throw Error(E3D_ERR_INVALID, "null argument");
+  bool applied = false;
+  apply_update(h, print_progress != 0, &applied, lambda, max_change);
+  *applied_update = applied ? 1 : 0;
+  return 0;
+  R_CATCH()
+}
+
+// bool Optimizer::RunOnCurrentScale(...)  (src/opt/optimizer.cc:49-182), cache_observations == false
+int e3d_reg_run_on_current_scale(e3d_reg_t* h, int max_num_iterations, float max_change_convergence_threshold,
+                                 int iterations_without_new_optimum_threshold, int print_progress, double* optimum_cost,
+                                 int* iterations_done) {
+  R_TRY
+  if (!h || !optimum_cost) throw Error(E3D_ERR_INVALID, "null argument");
+  const bool print = print_progress != 0;
+  // never use the highest image scale (optimizer.cc:60-61)
+  h->prm.current_image_scale = std::min<int>(h->prm.current_image_scale, h->prm.image_scale_count - 1 - 1);
+  if (print) printf("--- Optimizing at scaling factor %g ---\n", std::pow(2.0, -1.0 * h->prm.current_image_scale));
+  bool converged = false;
+  float lambda = 64.0f;
+  int without = 0;
+  *optimum_cost = std::numeric_limits<double>::infinity();
+  RegState optimum = get_state(h);
+  int it = 0;
+  for (; it < max_num_iterations; ++it) {
+    if (print) printf("Iteration %d\n", it + 1);
+    bool applied = true;
+    float max_change = std::numeric_limits<float>::infinity();
+    if (it > 0) {
+      if (print) printf("  Intrinsics and poses update ...\n");
+      applied = false;
+      max_change = 0;
+      apply_update(h, print, &applied, &lambda, &max_change);
+    }
+    if (print) printf("  Observations update ...\n");
+    update_observations(h, /*kBorderSize*/ 1);
+    if (h->prm.variable_residuals_weight > 0) {
+      if (print) printf("  Color update ...\n");
+      color_update(h);
+    }
+    if (print) printf("  Determining cost ...\n");
+    const double current_cost = total_cost(h);
+    if (print) printf("  Cost (considering occlusions) is: %g\n", current_cost);
+    if (current_cost < *optimum_cost) {
+      *optimum_cost = current_cost;
+      without = 0;
+      optimum = get_state(h);
+    } else {
+      ++without;
+    }
+    if (!applied || max_change < max_change_convergence_threshold || without >= iterations_without_new_optimum_threshold) {
+      if (print) printf("Assuming convergence (applied_update: %d, max_change: %g, iterations_without_new_optimum: %d)\n", (int)applied, (double)max_change, without);
+      converged = true;
+      ++it;
+      break;
+    } else if (print) {
+      printf("max_change in this iteration: %g\n", (double)max_change);
+    }
+  }
+  set_state(h, optimum);
+  if (iterations_done) *iterations_done = it;
+  if (print) fflush(stdout);
+  return converged ? 1 : 0;
+  R_CATCH()
+}
 }  // extern "C"

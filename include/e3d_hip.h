@@ -203,11 +203,12 @@ int e3d_reg_set_intrinsics(e3d_reg_t* reg, int intrinsics_id, int camera_type, i
 /* queries the pyramid the library built: widths/heights (n_levels), parameters (n_levels x n_parameters), cut-offs */
 int e3d_reg_get_intrinsics_level(e3d_reg_t* reg, int intrinsics_id, int level, int* width, int* height,
                                  float* parameters, float* radius_cutoff_squared);
-/* opt::Image: u8 pyramid (level l has the size of intrinsics level l) and optional masks; pose image_T_global as
- * so3().matrix() (row-major) + translation. */
+/* opt::Image: u8 pyramid (level l has the size of intrinsics level l) and optional masks; pose image_T_global as the
+ * Sophus::SE3f state: unit quaternion {w, x, y, z} + translation (what COLMAP images.txt stores). */
 int e3d_reg_set_image(e3d_reg_t* reg, int image_id, int intrinsics_id, const uint8_t* const* level_pixels,
                       const uint8_t* const* level_masks);
-int e3d_reg_set_image_pose(e3d_reg_t* reg, int image_id, const float R[9], const float t[3]);
+int e3d_reg_set_image_pose(e3d_reg_t* reg, int image_id, const float q[4], const float t[3]);
+int e3d_reg_get_image_pose(e3d_reg_t* reg, int image_id, float q[4], float t[3]);
 /* OcclusionGeometry::SetSplatPoints */
 int e3d_reg_set_splat_points(e3d_reg_t* reg, const float* xyz, size_t n);
 
@@ -233,6 +234,23 @@ int e3d_reg_cost(e3d_reg_t* reg, int image_id, int point_scale, double sums[2], 
 int e3d_reg_color_begin(e3d_reg_t* reg, int point_scale);
 int e3d_reg_color_accumulate(e3d_reg_t* reg, int image_id, int point_scale);
 int e3d_reg_color_finish(e3d_reg_t* reg, int point_scale);
+
+/* Whole-problem steps of opt::Optimizer::RunOnCurrentScale (src/opt/optimizer.cc:49-182) on the device-resident state.
+ * Images are visited in ascending image id. */
+/* VisibilityEstimator::CreateObservationsForAllImages + DetermineIfAllNeighborsAreObserved (optimizer.cc:119-128) */
+int e3d_reg_update_observations(e3d_reg_t* reg, int border_size);
+/* ColorOptimizer::Apply (color_optimizer.cc:40-123) */
+int e3d_reg_color_update(e3d_reg_t* reg);
+/* CostCalculator::ComputeCost (cost_calculator.cc:44-100) */
+int e3d_reg_compute_cost(e3d_reg_t* reg, double* cost);
+/* IntrinsicsAndPoseOptimizer::Apply (intrinsics_and_pose_optimizer.cc:48-259): one LM step with <= 10 tries */
+int e3d_reg_apply(e3d_reg_t* reg, int print_progress, int* applied_update, float* lambda, float* max_change);
+/* bool Optimizer::RunOnCurrentScale(max_num_iterations, max_change_convergence_threshold,
+ *   iterations_without_new_optimum_threshold, <no observation cache>, print_progress, &optimum_cost); returns 1 if
+ * converged, 0 if not.  The state (intrinsics, poses) is left at the optimum, like the reference. */
+int e3d_reg_run_on_current_scale(e3d_reg_t* reg, int max_num_iterations, float max_change_convergence_threshold,
+                                 int iterations_without_new_optimum_threshold, int print_progress, double* optimum_cost,
+                                 int* iterations_done);
 
 #ifdef __cplusplus
 }

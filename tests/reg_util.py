@@ -26,6 +26,57 @@ def look_at_pose(eye, target, up=(0, 0, 1)):
     return R, t
 
 
+def quat_from_R(R):
+    """(w, x, y, z) float32 unit quaternion of a rotation matrix."""
+    from scipy.spatial.transform import Rotation
+    x, y, z, w = Rotation.from_matrix(np.asarray(R, np.float64)).as_quat()
+    q = np.array([w, x, y, z], np.float64)
+    return (q / np.linalg.norm(q)).astype(np.float32)
+
+
+def quat_to_R(q):
+    from oracle import binding as ob
+    return ob.quat_to_R(np.asarray(q, np.float32))
+
+
+def texture(u, v):
+    return 120 + 55 * np.sin(7.0 * u) * np.cos(5.0 * v) + 35 * np.sin(3.0 * u + 4.0 * v) + 20 * np.cos(11.0 * v - 2.0 * u)
+
+
+def make_multi_image_scene(n_points=5000, n_images=3, width=240, height=180, n_levels=3, K=5, seed=0, perturb=0.01):
+    """Planar textured wall (y = 3) seen by several pinhole cameras whose images are ray-traced from the texture, so that
+    the true poses minimise the photometric cost; returns true and perturbed poses."""
+    from scipy.spatial import cKDTree
+    rng = np.random.RandomState(seed)
+    u = rng.uniform(-1.0, 1.0, n_points); v = rng.uniform(-0.75, 0.75, n_points)
+    pts = np.stack([u, np.full(n_points, 3.0), v], 1).astype(np.float32)
+    _, nn = cKDTree(pts).query(pts, k=K + 1)
+    nbr = nn[:, 1:].astype(np.uint32)
+    tex = texture(pts[:, 0].astype(np.float64), pts[:, 2].astype(np.float64))
+    fixed_desc = (tex[nbr] - tex[:, None]).astype(np.float32)
+    params = np.array([210.0, 208.0, width / 2 - 0.4, height / 2 + 0.3], np.float32)
+    eyes = [(-0.35, -0.3, 0.1), (0.3, -0.2, -0.08), (0.02, -0.45, 0.2), (0.2, -0.5, -0.15)][:n_images]
+    images = []
+    for i, eye in enumerate(eyes):
+        R0, t0 = look_at_pose(eye, (0.05 * i, 3, 0.02 * i))
+        q = quat_from_R(R0); R = quat_to_R(q).astype(np.float64); t = t0.astype(np.float64)
+        yy, xx = np.mgrid[0:height, 0:width].astype(np.float64)
+        d = np.stack([(xx - params[2]) / params[0], (yy - params[3]) / params[1], np.ones_like(xx)], -1) @ R     # R^T * dir
+        o = -R.T @ t
+        lam = (3.0 - o[1]) / d[..., 1]
+        hit = o + lam[..., None] * d
+        img = texture(hit[..., 0], hit[..., 2]).clip(0, 250)
+        pyr = pyramid_u8(np.rint(img).astype(np.uint8), n_levels)
+        # perturbed start pose
+        dq = rng.normal(size=3) * perturb
+        dt = rng.normal(size=3) * perturb
+        from scipy.spatial.transform import Rotation
+        Rp = Rotation.from_rotvec(dq).as_matrix() @ R
+        images.append(dict(q_true=q, t_true=t0.astype(np.float32), q_init=quat_from_R(Rp), t_init=(t + dt).astype(np.float32), pyr=pyr))
+    return dict(pts=pts, nbr=nbr, K=K, fixed_desc=fixed_desc, params=params, width=width, height=height, n_levels=n_levels,
+                images=images, point_radius=0.01)
+
+
 def make_reg_scene(n_points=6000, width=320, height=240, n_levels=4, K=5, seed=0):
     """A textured, slightly wavy wall seen by a pinhole camera: points + neighbour graph + descriptors + image pyramid."""
     rng = np.random.RandomState(seed)
@@ -40,10 +91,12 @@ def make_reg_scene(n_points=6000, width=320, height=240, n_levels=4, K=5, seed=0
     img = img.astype(np.uint8)
     img[:12, :20] = 255                                     # an oversaturated corner
     pyr = pyramid_u8(img, n_levels)
-    R, t = look_at_pose((0.1, -0.4, 0.05), (0, 3, 0))
+    R0, t = look_at_pose((0.1, -0.4, 0.05), (0, 3, 0))
+    q = quat_from_R(R0)
+    R = quat_to_R(q)          # so3().matrix() of the stored quaternion: what both implementations actually use
     params = np.array([260.0, 255.0, width / 2 - 0.3, height / 2 + 0.2], np.float32)
     fixed_desc = rng.normal(0, 8, (n_points, K)).astype(np.float32)
     var_desc = rng.normal(0, 8, (n_points, K)).astype(np.float32)
     obs_counts = rng.randint(0, 4, n_points).astype(np.int32)
-    return dict(pts=pts, nbr=nbr, K=K, pyr=pyr, R=R, t=t, params=params, width=width, height=height, n_levels=n_levels,
+    return dict(pts=pts, nbr=nbr, K=K, pyr=pyr, R=R, q=q, t=t, params=params, width=width, height=height, n_levels=n_levels,
                 fixed_desc=fixed_desc, var_desc=var_desc, obs_counts=obs_counts, point_radius=0.012)

@@ -21,7 +21,7 @@ def _setup(e3d, rb, S, **pk):
     P = e3d.RegProblem(prm)
     P.set_intrinsics(0, S["width"], S["height"], S["params"], 0, S["n_levels"])
     P.set_image(0, 0, S["pyr"], S.get("masks"))
-    P.set_image_pose(0, S["R"], S["t"])
+    P.set_image_pose(0, S["q"], S["t"])
     P.set_point_scale(0, S["pts"], S["point_radius"], S["nbr"], S["fixed_desc"])
     P.set_variable_descriptors(0, S["var_desc"], S["obs_counts"])
     P.set_splat_points(S["pts"])
@@ -138,3 +138,71 @@ def test_reg_errors(e3d):
         P.observe(0, 0, 0, 1)
     with pytest.raises(e3d.E3DError):
         P.set_intrinsics(0, 64, 48, [50, 50, 32, 24, 0.1, 0, 0, 0], 0, 2, camera_type=2)   # only PINHOLE so far
+
+
+# ---- optimizer driver (Optimizer::RunOnCurrentScale / IntrinsicsAndPoseOptimizer::Apply) ---------------------------------------
+def _build_both(e3d, M, var_weight=1.0):
+    from oracle.reg_driver import OracleRegProblem
+    prm = e3d.default_reg_params(image_scale_count=M["n_levels"], point_neighbor_count=M["K"], variable_residuals_weight=var_weight)
+    G = e3d.RegProblem(prm)
+    O = OracleRegProblem(K=M["K"], image_scale_count=M["n_levels"], var_weight=var_weight)
+    for P in (G, O):
+        P.set_intrinsics(0, M["width"], M["height"], M["params"], 0, M["n_levels"])
+        P.set_point_scale(0, M["pts"], M["point_radius"], M["nbr"], M["fixed_desc"])
+        P.set_splat_points(M["pts"])
+        for i, im in enumerate(M["images"]):
+            P.set_image(i, 0, im["pyr"])
+            P.set_image_pose(i, im["q_init"], im["t_init"])
+    return G, O
+
+
+def _pose_delta(qa, ta, qb, tb):
+    from reg_util import quat_to_R
+    Ra, Rb = quat_to_R(qa).astype(np.float64), quat_to_R(qb).astype(np.float64)
+    S = Ra.T @ Rb
+    ang = 0.5 * np.linalg.norm([S[2, 1] - S[1, 2], S[0, 2] - S[2, 0], S[1, 0] - S[0, 1]])
+    return ang, np.linalg.norm(ta.astype(np.float64) - tb.astype(np.float64))
+
+
+def test_whole_problem_steps_match_oracle(e3d):
+    from reg_util import make_multi_image_scene
+    M = make_multi_image_scene(n_points=6000, n_images=3, seed=5)
+    G, O = _build_both(e3d, M)
+    G.update_observations(1); O.update_observations(1)
+    for i in range(3):
+        n = len(O.obs[(i, 0)][0])
+        g = G.get_observations(i, 0, n)
+        assert np.array_equal(g[0], O.obs[(i, 0)][0]) and np.array_equal(g[4], O.obs[(i, 0)][4])
+    G.color_update(); O.color_update()
+    d, c = G.get_variable_descriptors(0, len(M["pts"]))
+    assert np.array_equal(c, O.scales[0]["counts"]) and np.abs(d - O.scales[0]["var"]).max() <= 2e-4
+    cg, co = G.compute_cost(), O.compute_cost()
+    assert abs(cg - co) <= 1e-6 * co
+    ag, lg, mg = G.apply(64.0); ao, lo, mo = O.apply(64.0)
+    assert ag == ao and lg == lo and abs(mg - mo) <= 1e-3 * abs(mo) + 1e-6
+    for i in range(3):
+        ang, tr = _pose_delta(*G.get_image_pose(i), *O.get_image_pose(i))
+        assert ang <= 1e-5 and tr <= 1e-5
+    w, h, pg, _ = G.intrinsics_level(0, 0)
+    assert np.abs(pg - O.intr[0]["params"]).max() <= 1e-3
+
+
+@pytest.mark.parametrize("var_weight", [1.0, 0.0])
+def test_run_on_current_scale_matches_oracle_and_improves(e3d, var_weight):
+    from reg_util import make_multi_image_scene
+    M = make_multi_image_scene(n_points=6000, n_images=3, seed=6, perturb=0.006)
+    G, O = _build_both(e3d, M, var_weight)
+    cg, costg, itg = G.run_on_current_scale(8, 0.0, 15, False)
+    co, costo, ito = O.run_on_current_scale(8, 0.0, 15, False)
+    assert (cg, itg) == (co, ito)
+    assert abs(costg - costo) <= 1e-4 * costo
+    err0 = err1 = 0.0
+    for i, im in enumerate(M["images"]):
+        qg, tg = G.get_image_pose(i); qo, to = O.get_image_pose(i)
+        ang, tr = _pose_delta(qg, tg, qo, to)
+        assert ang <= 1e-4 and tr <= 1e-4, (i, ang, tr)
+        a0, t0 = _pose_delta(im["q_init"], im["t_init"], im["q_true"], im["t_true"])
+        a1, t1 = _pose_delta(qg, tg, im["q_true"], im["t_true"])
+        err0 += a0 + t0; err1 += a1 + t1
+    assert O.history[-1] < O.history[0]            # the photometric cost went down
+    assert costg <= O.history[0]

@@ -167,7 +167,11 @@ __global__ __launch_bounds__(kBlock) void k_splat_depth(const float4* __restrict
   end_x = min(end_x, cam.width); end_y = min(end_y, cam.height);
   const unsigned zb = __float_as_uint(Z);      // Z > 0: the bit pattern is order preserving
   for (int y = min_y; y < end_y; ++y)
-    for (int x = min_x; x < end_x; ++x) atomicMin(&depth_bits[(size_t)y * cam.width + x], zb);
+    for (int x = min_x; x < end_x; ++x) {
+      unsigned* a = &depth_bits[(size_t)y * cam.width + x];
+      // the depth only ever decreases, so a (possibly stale) larger-or-equal read is a safe reason to try; a smaller one to skip
+      if (zb < __hip_atomic_load(a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(a, zb);
+    }
 }
 
 // ==== a20 / a21: observation candidates =============================================================================================
@@ -410,12 +414,13 @@ __global__ __launch_bounds__(kBlock) void k_reg_pass2(const float4* __restrict__
   }
 }
 
-__global__ void k_reg_reduce(const double* __restrict__ partial, int nblocks, int slot, double* __restrict__ out) {
-  const int t = threadIdx.x;
-  if (t >= slot) return;
+// one wave per slot: lane l sums blocks l, l+64, ... in order, then a fixed-shape butterfly -> deterministic, no serial chain
+__global__ __launch_bounds__(kWave) void k_reg_reduce(const double* __restrict__ partial, int nblocks, int slot, double* __restrict__ out) {
+  const int t = blockIdx.x;
   double v = 0.0;
-  for (int b = 0; b < nblocks; ++b) v += partial[(size_t)b * slot + t];
-  out[t] = v;
+  for (int b = threadIdx.x; b < nblocks; b += kWave) v += partial[(size_t)b * slot + t];
+  v = wave_sum(v);
+  if (threadIdx.x == 0) out[t] = v;
 }
 
 // ==== a19: cost ================================================================================================================================
@@ -982,7 +987,7 @@ int e3d_reg_accumulate(e3d_reg_t* h, int image_id, int point_scale, double* H, d
                      h->prm.variable_residuals_weight};
   hipLaunchKernelGGL(k_reg_pass2<8>, dim3(nb), dim3(kBlock), 0, s, O.rows.p, O.idx.p, O.flags.p, O.n, S.nbr.p,
                      h->prm.point_neighbor_count, S.row_of_point.p, S.fixed_desc.p, S.var_desc.p, S.obs_counts.p, w, h->partial.p);
-  hipLaunchKernelGGL(k_reg_reduce, dim3(1), dim3(128), 0, s, h->partial.p, nb, kRegSlot, h->red.p);
+  hipLaunchKernelGGL(k_reg_reduce, dim3(kRegSlot), dim3(kWave), 0, s, h->partial.p, nb, kRegSlot, h->red.p);
   double r[kRegSlot];
   copy_out(r, h->red.p, sizeof r, s);
   rsync(h);
@@ -1010,7 +1015,7 @@ int e3d_reg_cost(e3d_reg_t* h, int image_id, int point_scale, double sums[2], in
                      h->prm.variable_residuals_weight};
   hipLaunchKernelGGL(k_reg_cost, dim3(nb), dim3(kBlock), 0, s, S.intensity.p, O.idx.p, O.flags.p, O.n, S.nbr.p,
                      h->prm.point_neighbor_count, S.fixed_desc.p, S.var_desc.p, S.obs_counts.p, w, h->partial.p);
-  hipLaunchKernelGGL(k_reg_reduce, dim3(1), dim3(64), 0, s, h->partial.p, nb, 4, h->red.p);
+  hipLaunchKernelGGL(k_reg_reduce, dim3(4), dim3(kWave), 0, s, h->partial.p, nb, 4, h->red.p);
   double r[4];
   copy_out(r, h->red.p, sizeof r, s);
   rsync(h);

@@ -117,11 +117,25 @@ void oracle_knn(const float* xyz, size_t n, const float* queries, size_t n_q, in
                 int32_t* idx, float* dist);
 
 /* ---- (B) dense photometric image registration: per-observation arithmetic of ImageRegistrator (oracle_reg.c).
- * PINHOLE cameras (type 0), non-rig images, colour residuals (fixed + variable descriptors). -------------------------- */
-typedef struct { int type; int width, height; float p[12]; float cutoff2; } oreg_camera;
+ * PINHOLE / OPENCV / THIN_PRISM_FISHEYE cameras, non-rig images, colour residuals (fixed + variable descriptors).
+ * Jacobian / system sizes follow the camera: I = n_params, V = I + 6; j_intr is n_obs x I, H is V x V row-major. ------- */
+/* type: 0 PINHOLE (4 parameters), 1 OPENCV (8), 2 THIN_PRISM_FISHEYE (12); see oracle_camera.h */
+typedef struct {
+  int type; int width, height; int n_params;
+  float p[12];
+  float cutoff2;          /* CameraBaseImpl::radius_cutoff_squared_ of the outermost model */
+  float inner_cutoff2;    /* that of the inner non-fisheye model (type 2) */
+  float fx_inv, fy_inv, cx_inv, cy_inv;
+} oreg_camera;
 
 void oracle_reg_camera_init(oreg_camera* c, int type, int w, int h, const float* params);
 void oracle_reg_camera_scaled(const oreg_camera* in, float factor, oreg_camera* out);
+/* single-point entry points of the camera functions (unit tests restating src/camera/test/test_camera.cc) */
+void oracle_reg_camera_distort(const oreg_camera* c, float nx, float ny, float out[2]);
+void oracle_reg_camera_undistort(const oreg_camera* c, float dx, float dy, float out[2], int* converged);
+void oracle_reg_camera_project(const oreg_camera* c, const float P[3], float out[2]);
+void oracle_reg_camera_deriv_by_world(const oreg_camera* c, const float P[3], float d[6]);
+void oracle_reg_camera_deriv_by_intrinsics(const oreg_camera* c, const float P[3], float* d /* 2 x n_params */);
 void oracle_interp_trilinear_u8(const uint8_t* img0, int w0, const uint8_t* img1, int w1, float x0, float y0, float z, float* value);
 void oracle_interp_trilinear_d_u8(const uint8_t* img0, int w0, const uint8_t* img1, int w1, float x0, float y0, float z,
                                   float* value, float* dx, float* dy, float* dz);

@@ -1,0 +1,293 @@
+/*
+ * oracle/oracle_camera.h -- TEST INFRASTRUCTURE ONLY.
+ *
+ * CPU restatement of the reference's camera models that ImageRegistrator is run with:
+ *   type 0  PINHOLE             camera::PinholeCamera               src/camera/camera_pinhole.h:40-86      I = 4
+ *   type 1  OPENCV              camera::PolynomialTangentialCamera  src/camera/camera_polynomial_tangential.h:41-159   I = 8
+ *   type 2  THIN_PRISM_FISHEYE  camera::BenchmarkCamera = FisheyeBase<ThinPrismCamera>
+ *                               src/camera/camera_benchmark.h:44-52, camera_base_impl_fisheye.h:43-162,
+ *                               camera_thin_prism.h:43-162                                                  I = 12
+ * and of the shared CRTP base (src/camera/camera_base_impl.h): NormalizedToImage :155-164, IterativeUndistort :216-250,
+ * UndistortFromInside :278-328, DistortedDerivativeByWorld / ImageDerivativeByWorld :333-360, ImageDerivativeByIntrinsics
+ * :369-408, InitCutoff :410-463, ScaledBy :70-89; CameraBase pixel mapping src/camera/camera_base.cc:81-86.
+ *
+ * All arithmetic is f32 in the reference's expression order (compile with -ffp-contract=off).  Eigen fixed-size products
+ * of 2-vectors / 2x2 matrices evaluate each coefficient as a0*b0 + a1*b1.
+ *
+ * Cut-offs: PinholeCamera never calls InitCutoff (camera_pinhole.cc:35-43) => +inf.  PolynomialTangentialCamera calls it
+ * in its constructor (camera_polynomial_tangential.cc:35-50).  BenchmarkCamera: the outer fisheye object never calls it
+ * (+inf, camera_benchmark.cc:35-46); its inner ThinPrismCamera does (camera_thin_prism.cc:34-51) and the fisheye wrapper
+ * tests atan(r)^2 against that inner value (camera_base_impl_fisheye.h:69-72).
+ *
+ * `atan2(r, 1.f)` (camera_base_impl_fisheye.h:68,109,140) is restated as atan2f: inside the opt/ translation units the float
+ * overload is assumed visible (same assumption as log2 in visibility_estimator.cc:437).  Unpinned by any reference test
+ * at the ulp level; the GPU parity tests for this model carry a tolerance for it.
+ */
+#ifndef E3D_ORACLE_CAMERA_H
+#define E3D_ORACLE_CAMERA_H
+
+#include <math.h>
+#include <string.h>
+
+#include "e3d_oracle.h"
+
+static inline int ocam_param_count(int type) { return type == 0 ? 4 : (type == 1 ? 8 : 12); }
+
+/* ---- the polynomial models' Distort on a point already past the (optional) fisheye pre-warp --------------------------- */
+static inline void ocam_distort_plain(const oreg_camera* c, float nx, float ny, float* ox, float* oy) {
+  if (c->type == 0) { *ox = nx; *oy = ny; return; }
+  const float* q = c->p + 4;
+  const float x2 = nx * nx, xy = nx * ny, y2 = ny * ny;
+  const float r2 = x2 + y2;
+  if (c->type == 1) {
+    const float k1 = q[0], k2 = q[1], p1 = q[2], p2 = q[3];
+    const float radial = 1 + r2 * (k1 + r2 * k2);
+    const float dx = 2.f * p1 * xy + p2 * (r2 + 2.f * x2);
+    const float dy = 2.f * p2 * xy + p1 * (r2 + 2.f * y2);
+    *ox = nx * radial + dx; *oy = ny * radial + dy;
+    return;
+  }
+  const float k1 = q[0], k2 = q[1], p1 = q[2], p2 = q[3], k3 = q[4], k4 = q[5], sx1 = q[6], sy1 = q[7];
+  const float radial = 1 + r2 * (k1 + r2 * (k2 + r2 * (k3 + r2 * k4)));
+  const float dx = 2.f * p1 * xy + p2 * (r2 + 2.f * x2) + sx1 * r2;
+  const float dy = 2.f * p2 * xy + p1 * (r2 + 2.f * y2) + sy1 * r2;
+  *ox = nx * radial + dx; *oy = ny * radial + dy;
+}
+
+/* DistortedDerivativeByNormalized of the polynomial part: J = [j0 j1; j2 j3] */
+static inline void ocam_ddn_plain(const oreg_camera* c, float nx, float ny, float* J) {
+  if (c->type == 0) { J[0] = 1.f; J[1] = 0.f; J[2] = 0.f; J[3] = 1.f; return; }
+  const float* q = c->p + 4;
+  const float nx2 = nx * nx, ny2 = ny * ny;
+  const float r2 = nx2 + ny2;
+  if (c->type == 1) {
+    const float k1 = q[0], k2 = q[1], p1 = q[2], p2 = q[3];
+    const float term1 = 2 * k1 + r2 * 4 * k2;
+    const float term2 = 1 + r2 * (k1 + r2 * k2);
+    J[0] = nx2 * term1 + term2 + 6 * p2 * nx + 2 * p1 * ny;
+    J[1] = nx * ny * term1 + 2 * p1 * nx + 2 * p2 * ny;
+    J[2] = J[1];
+    J[3] = ny2 * term1 + term2 + 2 * p2 * nx + 6 * p1 * ny;
+    return;
+  }
+  const float k1 = q[0], k2 = q[1], p1 = q[2], p2 = q[3], k3 = q[4], k4 = q[5], sx1 = q[6], sy1 = q[7];
+  const float nx_ny = nx * ny;
+  const float term1 = 2 * k1 + r2 * (4 * k2 + r2 * (6 * k3 + r2 * 8 * k4));
+  const float term2 = 1 + r2 * (k1 + r2 * (k2 + r2 * (k3 + r2 * k4)));
+  const float term3 = nx_ny * term1 + 2 * (p1 * nx + p2 * ny);
+  J[0] = nx2 * term1 + term2 + 6 * p2 * nx + 2 * p1 * ny + 2 * sx1 * nx;
+  J[1] = term3 + 2 * sx1 * ny;
+  J[2] = term3 + 2 * sy1 * nx;
+  J[3] = ny2 * term1 + term2 + 6 * p1 * ny + 2 * p2 * nx + 2 * sy1 * ny;
+}
+
+/* DistortedDerivativeByDistortionParameters of the polynomial part: 2 x (I-4), row-major with row stride `ld` */
+static inline void ocam_ddp_plain(const oreg_camera* c, float nx, float ny, float* d0, float* d1) {
+  if (c->type == 0) return;
+  const float nx2 = nx * nx, ny2 = ny * ny;
+  const float two_nx_ny = 2.f * nx * ny;
+  const float r2 = nx2 + ny2;
+  d0[0] = nx * r2; d0[1] = d0[0] * r2; d0[2] = two_nx_ny; d0[3] = (r2 + 2.f * nx2);
+  d1[0] = ny * r2; d1[1] = d1[0] * r2; d1[2] = (r2 + 2.f * ny2); d1[3] = two_nx_ny;
+  if (c->type == 2) {
+    d0[4] = d0[1] * r2; d0[5] = d0[4] * r2; d0[6] = r2; d0[7] = 0;
+    d1[4] = d1[1] * r2; d1[5] = d1[4] * r2; d1[6] = 0; d1[7] = r2;
+  }
+}
+
+#define OCAM_FISHEYE_EPS 1e-6f
+
+/* Child::Distort */
+static inline void ocam_distort(const oreg_camera* c, float nx, float ny, float* ox, float* oy) {
+  if (c->type != 2) { ocam_distort_plain(c, nx, ny, ox, oy); return; }
+  const float r = sqrtf(nx * nx + ny * ny);
+  if (r > OCAM_FISHEYE_EPS) {
+    const float atan_r = atan2f(r, 1.f);
+    if (atan_r * atan_r > c->inner_cutoff2) { *ox = nx * INFINITY; *oy = ny * INFINITY; return; }
+    const float theta_by_r = atan_r / r;
+    ocam_distort_plain(c, nx * theta_by_r, ny * theta_by_r, ox, oy);
+  } else {
+    ocam_distort_plain(c, nx, ny, ox, oy);
+  }
+}
+
+/* Child::DistortedDerivativeByNormalized */
+static inline void ocam_ddn(const oreg_camera* c, float nx, float ny, float* J) {
+  if (c->type != 2) { ocam_ddn_plain(c, nx, ny, J); return; }
+  const float nx_ny = nx * ny, nx2 = nx * nx, ny2 = ny * ny;
+  const float r2 = nx2 + ny2;
+  const float r = sqrtf(r2);
+  if (r > OCAM_FISHEYE_EPS) {
+    const float atan_r = atan2f(r, 1.f);
+    if (atan_r * atan_r > c->inner_cutoff2) { J[0] = J[1] = J[2] = J[3] = 0.f; return; }
+    const float theta_by_r = atan_r / r;
+    const float term1 = r2 * (r2 + 1);
+    const float term2 = theta_by_r / r2;
+    const float f00 = ny2 * term2 + nx2 / term1;
+    const float f01 = nx_ny / term1 - nx_ny * term2;
+    const float f10 = f01;
+    const float f11 = nx2 * term2 + ny2 / term1;
+    float D[4];
+    ocam_ddn_plain(c, theta_by_r * nx, theta_by_r * ny, D);
+    J[0] = D[0] * f00 + D[1] * f10; J[1] = D[0] * f01 + D[1] * f11;
+    J[2] = D[2] * f00 + D[3] * f10; J[3] = D[2] * f01 + D[3] * f11;
+  } else {
+    ocam_ddn_plain(c, nx, ny, J);
+  }
+}
+
+/* Child::DistortedDerivativeByDistortionParameters */
+static inline void ocam_ddp(const oreg_camera* c, float nx, float ny, float* d0, float* d1) {
+  if (c->type != 2) { ocam_ddp_plain(c, nx, ny, d0, d1); return; }
+  const float r = sqrtf(nx * nx + ny * ny);
+  if (r > OCAM_FISHEYE_EPS) {
+    const float atan_r = atan2f(r, 1.f);
+    if (atan_r * atan_r > c->inner_cutoff2) { for (int i = 0; i < 8; ++i) d0[i] = d1[i] = 0.f; return; }
+    const float theta_by_r = atan_r / r;
+    ocam_ddp_plain(c, theta_by_r * nx, theta_by_r * ny, d0, d1);
+  } else {
+    ocam_ddp_plain(c, nx, ny, d0, d1);
+  }
+}
+
+/* CameraBaseImpl::NormalizedToImage */
+static inline void cam_normalized_to_image(const oreg_camera* c, float nx, float ny, float* ox, float* oy) {
+  const float r2 = nx * nx + ny * ny;
+  if (isinf(r2) || r2 > c->cutoff2) { *ox = nx * INFINITY; *oy = ny * INFINITY; return; }
+  float dx, dy;
+  ocam_distort(c, nx, ny, &dx, &dy);
+  *ox = c->p[0] * dx + c->p[2];
+  *oy = c->p[1] * dy + c->p[3];
+}
+
+/* ImageDerivativeByWorld: 2x3 row-major */
+static inline void cam_image_deriv_by_world(const oreg_camera* c, const float* P, float* d) {
+  const float nx = P[0] / P[2], ny = P[1] / P[2];
+  if (nx * nx + ny * ny < c->cutoff2) {
+    const float zi = 1.f / P[2];
+    float J[4];
+    ocam_ddn(c, nx, ny, J);
+    /* normalize_deriv = [zi 0 -nx*zi ; 0 zi -ny*zi] */
+    const float n02 = (-1.f * nx) * zi, n12 = (-1.f * ny) * zi;
+    d[0] = J[0] * zi + J[1] * 0.f; d[1] = J[0] * 0.f + J[1] * zi; d[2] = J[0] * n02 + J[1] * n12;
+    d[3] = J[2] * zi + J[3] * 0.f; d[4] = J[2] * 0.f + J[3] * zi; d[5] = J[2] * n02 + J[3] * n12;
+  } else {
+    for (int i = 0; i < 6; ++i) d[i] = 0.f;
+  }
+  for (int i = 0; i < 3; ++i) { d[i] = c->p[0] * d[i]; d[3 + i] = c->p[1] * d[3 + i]; }
+}
+
+/* ImageDerivativeByIntrinsics: 2 x I row-major (row stride I) */
+static inline void cam_image_deriv_by_intrinsics(const oreg_camera* c, const float* P, float* d) {
+  const int I = c->n_params;
+  const float nx = P[0] / P[2], ny = P[1] / P[2];
+  if (nx * nx + ny * ny > c->cutoff2) { for (int i = 0; i < 2 * I; ++i) d[i] = 0.f; return; }
+  float dx, dy;
+  ocam_distort(c, nx, ny, &dx, &dy);
+  d[0] = dx; d[1] = 0.f; d[2] = 1.f; d[3] = 0.f;
+  d[I + 0] = 0.f; d[I + 1] = dy; d[I + 2] = 0.f; d[I + 3] = 1.f;
+  if (I > 4) {
+    ocam_ddp(c, nx, ny, d + 4, d + I + 4);
+    for (int i = 4; i < I; ++i) { d[i] = c->p[0] * d[i]; d[I + i] = c->p[1] * d[I + i]; }
+  }
+}
+
+/* IterativeUndistort of a non-fisheye model (camera_base_impl.h:216-250) */
+static inline void ocam_iterative_undistort(const oreg_camera* c, float dx, float dy, float sx, float sy, float* ux, float* uy,
+                                            int* converged) {
+  *converged = 0;
+  float x = sx, y = sy;
+  for (int i = 0; i < 100; ++i) {
+    float cx, cy;
+    ocam_distort_plain(c, x, y, &cx, &cy);
+    const float ex = cx - dx, ey = cy - dy;
+    if (ex * ex + ey * ey < 1e-10f) { *converged = 1; break; }
+    float J[4];
+    ocam_ddn_plain(c, x, y, J);
+    /* Jd2 = Jd^T Jd */
+    const float a = J[0] * J[0] + J[2] * J[2], b = J[0] * J[1] + J[2] * J[3];
+    const float cc = J[1] * J[0] + J[3] * J[2], d = J[1] * J[1] + J[3] * J[3];
+    /* Eigen 2x2 inverse: invdet = 1 / det; [d -b; -c a] * invdet */
+    const float invdet = 1.f / (a * d - cc * b);
+    const float i00 = d * invdet, i01 = -b * invdet, i10 = -cc * invdet, i11 = a * invdet;
+    /* M = inverse * Jd */
+    const float m00 = i00 * J[0] + i01 * J[2], m01 = i00 * J[1] + i01 * J[3];
+    const float m10 = i10 * J[0] + i11 * J[2], m11 = i10 * J[1] + i11 * J[3];
+    x -= m00 * ex + m01 * ey;
+    y -= m10 * ex + m11 * ey;
+  }
+  *ux = x; *uy = y;
+}
+
+/* UndistortFromInside (camera_base_impl.h:278-328): squared radius of the innermost solution and of the second best one
+ * (the latter only meaningful when *second_available) */
+static inline void ocam_undistort_from_inside(const oreg_camera* c, float dx, float dy, int* converged, float* best_r2,
+                                              int* second_available, float* second_r2) {
+  *converged = 0; *second_available = 0;
+  float best_radius = INFINITY, second_best_radius = INFINITY;
+  float bx = 0.f, by = 0.f, sbx = 0.f, sby = 0.f;
+  for (int yi = 0; yi < 10; ++yi) {
+    const float iy = dy + 1.5f * (yi - 0.5f * 10) / (0.5f * 10);
+    for (int xi = 0; xi < 10; ++xi) {
+      const float ix = dx + 1.5f * (xi - 0.5f * 10) / (0.5f * 10);
+      float rx, ry; int conv;
+      ocam_iterative_undistort(c, dx, dy, ix, iy, &rx, &ry, &conv);
+      if (!conv) continue;
+      const float radius = sqrtf(rx * rx + ry * ry);
+      if (radius < 0.99f * best_radius) {
+        second_best_radius = best_radius;
+        sbx = bx; sby = by;
+        *second_available = *converged;
+        best_radius = radius; bx = rx; by = ry;
+        *converged = 1;
+      } else if (radius > 1 / 0.99f * best_radius && radius < 0.99f * second_best_radius) {
+        second_best_radius = radius;
+        sbx = rx; sby = ry;
+        *second_available = 1;
+      }
+    }
+  }
+  *best_r2 = bx * bx + by * by;
+  *second_r2 = sbx * sbx + sby * sby;
+}
+
+/* InitCutoff of a non-fisheye distorted model (camera_base_impl.h:410-463) */
+static inline float ocam_init_cutoff(const oreg_camera* c) {
+  float min_candidate = 0.f, max_candidate = INFINITY;
+  for (int pass = 0; pass < 2; ++pass) {
+    const int cnt = pass == 0 ? c->width : c->height;
+    for (int i = 0; i < cnt; ++i)
+      for (int e = 0; e < 2; ++e) {
+        const float px = pass == 0 ? (float)i : (e == 0 ? 0.f : (float)(c->width - 1));
+        const float py = pass == 0 ? (e == 0 ? 0.f : (float)(c->height - 1)) : (float)i;
+        const float ddx = c->fx_inv * px + c->cx_inv, ddy = c->fy_inv * py + c->cy_inv;
+        int conv, second; float r2, s2 = 0.f;
+        ocam_undistort_from_inside(c, ddx, ddy, &conv, &r2, &second, &s2);
+        if (conv) {
+          if (r2 > min_candidate) min_candidate = r2;          /* std::max(r2, min_candidate) */
+          if (second && s2 < max_candidate) max_candidate = s2;
+        }
+      }
+  }
+  const float a = min_candidate * 1.01f;
+  return (max_candidate < a) ? max_candidate : a;              /* std::min(a, max_candidate) */
+}
+
+static inline void ocam_init(oreg_camera* c, int type, int w, int h, const float* params) {
+  memset(c, 0, sizeof *c);
+  c->type = type; c->width = w; c->height = h; c->n_params = ocam_param_count(type);
+  for (int i = 0; i < c->n_params; ++i) c->p[i] = params[i];
+  /* CameraBase (camera_base.cc:81-86): k_inv_ = (1.0/fx, 1.0/fy, -1.0*cx/fx, -1.0*cy/fy), double expressions -> float */
+  c->fx_inv = (float)(1.0 / (double)c->p[0]); c->fy_inv = (float)(1.0 / (double)c->p[1]);
+  c->cx_inv = (float)(-1.0 * (double)c->p[2] / (double)c->p[0]); c->cy_inv = (float)(-1.0 * (double)c->p[3] / (double)c->p[1]);
+  c->cutoff2 = INFINITY; c->inner_cutoff2 = INFINITY;
+  if (type == 1) c->cutoff2 = ocam_init_cutoff(c);
+  else if (type == 2) {
+    /* the inner ThinPrismCamera: a non-fisheye camera with the same parameters */
+    oreg_camera inner = *c;
+    inner.cutoff2 = INFINITY;
+    c->inner_cutoff2 = ocam_init_cutoff(&inner);
+  }
+}
+
+#endif

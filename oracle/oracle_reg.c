@@ -31,64 +31,38 @@
 static inline int f2i(float v) { return (v >= -2147483648.0f && v < 2147483648.0f) ? (int)v : INT_MIN; }
 static inline int d2i(double v) { return (v > -2147483649.0 && v < 2147483648.0) ? (int)v : INT_MIN; }
 
-/* ---- cameras ---------------------------------------------------------------------------------------------- */
-void oracle_reg_camera_init(oreg_camera* c, int type, int w, int h, const float* params) {
-  memset(c, 0, sizeof *c);
-  c->type = type; c->width = w; c->height = h;
-  for (int i = 0; i < 4; ++i) c->p[i] = params[i];
-  /* CameraBase caches f_inv = 1/f, c_inv = -c/f (camera_base.h, recalled from its accessor use) */
-  const float fx = c->p[0], fy = c->p[1], cx = c->p[2], cy = c->p[3];
-  const float fxi = 1.0f / fx, fyi = 1.0f / fy, cxi = -cx / fx, cyi = -cy / fy;
-  /* InitCutoff (camera_base_impl.h:410-463) for an undistorted model: every border pixel un-distorts to itself, no
-   * second candidate exists => cutoff = 1.01 * max border r^2 */
-  float min_candidate = 0.f;
-  for (int pass = 0; pass < 2; ++pass) {
-    const int cnt = pass == 0 ? w : h;
-    for (int i = 0; i < cnt; ++i)
-      for (int e = 0; e < 2; ++e) {
-        const float px = pass == 0 ? (float)i : (e == 0 ? 0.f : (float)(w - 1));
-        const float py = pass == 0 ? (e == 0 ? 0.f : (float)(h - 1)) : (float)i;
-        const float nx = fxi * px + cxi, ny = fyi * py + cyi;
-        const float r2 = nx * nx + ny * ny;
-        if (r2 > min_candidate) min_candidate = r2;
-      }
-  }
-  c->cutoff2 = min_candidate * 1.01f;
-}
+/* ---- cameras (oracle_camera.h) ------------------------------------------------------------------------------- */
+#include "oracle_camera.h"
 
-/* CameraBaseImpl::ScaledBy (camera_base_impl.h:70-89) */
+void oracle_reg_camera_init(oreg_camera* c, int type, int w, int h, const float* params) { ocam_init(c, type, w, h, params); }
+
+/* CameraBaseImpl::ScaledBy (camera_base_impl.h:70-89): constructs a new camera => re-runs InitCutoff */
 void oracle_reg_camera_scaled(const oreg_camera* in, float factor, oreg_camera* out) {
-  float p[4];
+  float p[12];
+  for (int i = 0; i < in->n_params; ++i) p[i] = in->p[i];
   p[0] = in->p[0] * factor; p[1] = in->p[1] * factor;
   p[2] = factor * (in->p[2] + 0.5f) - 0.5f; p[3] = factor * (in->p[3] + 0.5f) - 0.5f;
-  oracle_reg_camera_init(out, in->type, (int)(factor * in->width + 0.5f), (int)(factor * in->height + 0.5f), p);
+  ocam_init(out, in->type, (int)(factor * in->width + 0.5f), (int)(factor * in->height + 0.5f), p);
 }
-
-static inline void cam_normalized_to_image(const oreg_camera* c, float nx, float ny, float* ox, float* oy) {
-  const float r2 = nx * nx + ny * ny;
-  if (isinf(r2) || r2 > c->cutoff2) { *ox = nx * INFINITY; *oy = ny * INFINITY; return; }
-  *ox = c->p[0] * nx + c->p[2];
-  *oy = c->p[1] * ny + c->p[3];
-}
-/* 2x3 row-major */
-static inline void cam_image_deriv_by_world(const oreg_camera* c, const float* P, float* d) {
-  const float nx = P[0] / P[2], ny = P[1] / P[2];
-  if (nx * nx + ny * ny < c->cutoff2) {
-    const float zi = 1.f / P[2];
-    d[0] = zi; d[1] = 0.f; d[2] = (-1.f * nx) * zi;
-    d[3] = 0.f; d[4] = zi; d[5] = (-1.f * ny) * zi;
-  } else {
-    for (int i = 0; i < 6; ++i) d[i] = 0.f;
+void oracle_reg_camera_distort(const oreg_camera* c, float nx, float ny, float out[2]) { ocam_distort(c, nx, ny, &out[0], &out[1]); }
+/* Child::Undistort: IterativeUndistort from the distorted point itself; the fisheye wrapper un-warps the inner model's
+ * solution with tanf(r)/r (camera_base_impl_fisheye.h:81-92) */
+void oracle_reg_camera_undistort(const oreg_camera* c, float dx, float dy, float out[2], int* converged) {
+  float ux, uy; int conv;
+  ocam_iterative_undistort(c, dx, dy, dx, dy, &ux, &uy, &conv);
+  if (c->type == 2) {
+    const float r = sqrtf(ux * ux + uy * uy);
+    const float factor = (r < OCAM_FISHEYE_EPS) ? 1.f : ((r > (float)(M_PI / 2.f)) ? INFINITY : tanf(r) / r);
+    ux = factor * ux; uy = factor * uy;
   }
-  for (int i = 0; i < 3; ++i) { d[i] = c->p[0] * d[i]; d[3 + i] = c->p[1] * d[3 + i]; }
+  out[0] = ux; out[1] = uy;
+  if (converged) *converged = conv;
 }
-/* 2xI row-major, I = 4 */
-static inline void cam_image_deriv_by_intrinsics(const oreg_camera* c, const float* P, float* d) {
-  const float nx = P[0] / P[2], ny = P[1] / P[2];
-  if (nx * nx + ny * ny > c->cutoff2) { for (int i = 0; i < 8; ++i) d[i] = 0.f; return; }
-  d[0] = nx; d[1] = 0.f; d[2] = 1.f; d[3] = 0.f;
-  d[4] = 0.f; d[5] = ny; d[6] = 0.f; d[7] = 1.f;
+void oracle_reg_camera_project(const oreg_camera* c, const float P[3], float out[2]) {
+  cam_normalized_to_image(c, P[0] / P[2], P[1] / P[2], &out[0], &out[1]);
 }
+void oracle_reg_camera_deriv_by_world(const oreg_camera* c, const float P[3], float d[6]) { cam_image_deriv_by_world(c, P, d); }
+void oracle_reg_camera_deriv_by_intrinsics(const oreg_camera* c, const float P[3], float* d) { cam_image_deriv_by_intrinsics(c, P, d); }
 
 /* ---- interpolation ------------------------------------------------------------------------------------------ */
 #define DEF_INTERP(SUFFIX, T)                                                                                   \
@@ -218,8 +192,7 @@ size_t oracle_reg_observe(const float* pts, size_t n_pts, float point_radius, co
     int li = small_scale - min_image_scale; if (li < 0) li = 0;
     if (li >= n_levels) continue;   /* cannot happen for consistent inputs (image_scale_count bounds it) */
     const oreg_camera* ic = &levels[li];
-    const float fxi = 1.0f / cam->p[0], fyi = 1.0f / cam->p[1], cxi = -cam->p[2] / cam->p[0], cyi = -cam->p[3] / cam->p[1];
-    const float nx = fxi * ixf + cxi, ny = fyi * iyf + cyi;
+    const float nx = cam->fx_inv * ixf + cam->cx_inv, ny = cam->fy_inv * iyf + cam->cy_inv;
     const float jx = ic->p[0] * nx + ic->p[2], jy = ic->p[1] * ny + ic->p[3];
     ix = f2i(jx + 0.5f); iy = f2i(jy + 0.5f);
     if (!(jx + 0.5f >= border && jy + 0.5f >= border && ix >= border && iy >= border && ix < ic->width - border &&
@@ -249,11 +222,12 @@ void oracle_reg_neighbors_observed(size_t n_pts, const uint32_t* obs_idx, size_t
   free(seen);
 }
 
-/* ---- a16: intensity + Jacobian rows of one observation (PINHOLE, I = 4, non-rig) ---------------------------------------- */
+/* ---- a16: intensity + Jacobian rows of one observation (I = cam_min->n_params, non-rig) --------------------------------- */
 static void point_intensity_and_jacobians(const float* point, float point_radius, const oreg_camera* cam_min,
                                           int min_image_scale, const uint8_t* const* images, const int* widths,
                                           const float R[9], const float t[3], float ox, float oy, float oscale,
-                                          float* intensity, float* j_intr /*4*/, float* j_pose /*6*/) {
+                                          float* intensity, float* j_intr /*I*/, float* j_pose /*6*/) {
+  const int I = cam_min->n_params;
   float T[3];
   rt(R, t, point, T);
   const int small_scale = f2i(oscale) + 1, large_scale = f2i(oscale);
@@ -272,11 +246,11 @@ static void point_intensity_and_jacobians(const float* point, float point_radius
   const float rdx = offx - mx, rdy = offy - my;
   float denom = 0.693147180559945f * (rdx * rdx + rdy * rdy);
   if (denom < 1e-6f) denom = 1e-6f;
-  float P[12], Po[8];       /* 3 x 4 and 2 x 4 */
+  float P[36], Po[24];      /* 3 x I and 2 x I */
   cam_image_deriv_by_intrinsics(cam_min, T, P);
   cam_image_deriv_by_intrinsics(cam_min, To, Po);
-  for (int i = 0; i < 4; ++i) P[8 + i] = ((Po[i] - P[i]) * rdx + (Po[4 + i] - P[4 + i]) * rdy) / denom;
-  for (int i = 0; i < 4; ++i) j_intr[i] = ji[0] * P[i] + (ji[1] * P[4 + i] + ji[2] * P[8 + i]);
+  for (int i = 0; i < I; ++i) P[2 * I + i] = ((Po[i] - P[i]) * rdx + (Po[I + i] - P[I + i]) * rdy) / denom;
+  for (int i = 0; i < I; ++i) j_intr[i] = ji[0] * P[i] + (ji[1] * P[I + i] + ji[2] * P[2 * I + i]);
   float W[9], Wo[6];        /* 3 x 3 and 2 x 3 */
   cam_image_deriv_by_world(cam_min, T, W);
   cam_image_deriv_by_world(cam_min, To, Wo);
@@ -294,16 +268,17 @@ void oracle_reg_pass1(const float* pts, float point_radius, const oreg_camera* c
                       float* intensities, float* j_intr, float* j_pose) {
   for (size_t i = 0; i < n_obs; ++i)
     point_intensity_and_jacobians(pts + 3 * (size_t)obs_idx[i], point_radius, cam_min, min_image_scale, images, widths, R,
-                                  t, obs_x[i], obs_y[i], obs_scale[i], &intensities[i], j_intr + 4 * i, j_pose + 6 * i);
+                                  t, obs_x[i], obs_y[i], obs_scale[i], &intensities[i], j_intr + (size_t)cam_min->n_params * i,
+                                  j_pose + 6 * i);
 }
 
 /* a18: AccumulateOnHAndB on the local (I+6) x (I+6) block: products in f32, cast, add in f64 */
-static void accumulate_on_h_and_b(float weight, float residual, const float* ji, const float* jp, double* H, double* b) {
+static void accumulate_on_h_and_b(int I, float weight, float residual, const float* ji, const float* jp, double* H, double* b) {
   if (weight == 0) return;
-  const int V = 10;
-  float J[10];
-  for (int i = 0; i < 4; ++i) J[i] = ji[i];
-  for (int i = 0; i < 6; ++i) J[4 + i] = jp[i];
+  const int V = I + 6;
+  float J[18];
+  for (int i = 0; i < I; ++i) J[i] = ji[i];
+  for (int i = 0; i < 6; ++i) J[I + i] = jp[i];
   for (int i = 0; i < V; ++i)
     for (int j = i; j < V; ++j) {
       /* (weight * j^T) * j  in f32 (block-wise expressions of the reference evaluate to exactly this per entry) */
@@ -320,17 +295,18 @@ void oracle_reg_accumulate(const float* pts, size_t n_pts, float point_radius, c
                            const oreg_camera* cam_min, int min_image_scale, const uint8_t* const* images, const int* widths,
                            const float R[9], const float t[3], const uint32_t* obs_idx, const float* obs_x,
                            const float* obs_y, const float* obs_scale, const uint8_t* flags, size_t n_obs, int robust_type,
-                           float robust_param, float fixed_weight, float var_weight, double* H /*10x10*/, double* b /*10*/,
+                           float robust_param, float fixed_weight, float var_weight, double* H /*VxV*/, double* b /*V*/,
                            double sums[2], int64_t counts[2]) {
+  const int NI = cam_min->n_params, V = NI + 6;
   float* I = (float*)malloc(sizeof(float) * (n_obs + 1));
-  float* JI = (float*)malloc(sizeof(float) * 4 * (n_obs + 1));
+  float* JI = (float*)malloc(sizeof(float) * NI * (n_obs + 1));
   float* JP = (float*)malloc(sizeof(float) * 6 * (n_obs + 1));
   int64_t* row = (int64_t*)malloc(sizeof(int64_t) * (n_pts + 1));
   for (size_t i = 0; i < n_pts; ++i) row[i] = -1;
   oracle_reg_pass1(pts, point_radius, cam_min, min_image_scale, images, widths, R, t, obs_idx, obs_x, obs_y, obs_scale, n_obs,
                    I, JI, JP);
   for (size_t i = 0; i < n_obs; ++i) row[obs_idx[i]] = (int64_t)i;
-  memset(H, 0, sizeof(double) * 100); memset(b, 0, sizeof(double) * 10);
+  memset(H, 0, sizeof(double) * V * V); memset(b, 0, sizeof(double) * V);
   sums[0] = sums[1] = 0; counts[0] = counts[1] = 0;
   float comp[64];
   for (size_t i = 0; i < n_obs; ++i) {
@@ -356,10 +332,10 @@ void oracle_reg_accumulate(const float* pts, size_t n_pts, float point_radius, c
       if (w != 0) {
         for (int k = 0; k < K; ++k) {
           const int64_t nr = row[nbr[p * K + k]];
-          float ji[4], jp[6];
-          for (int q = 0; q < 4; ++q) ji[q] = JI[4 * nr + q] - JI[4 * i + q];
+          float ji[12], jp[6];
+          for (int q = 0; q < NI; ++q) ji[q] = JI[(size_t)NI * nr + q] - JI[(size_t)NI * i + q];
           for (int q = 0; q < 6; ++q) jp[q] = JP[6 * nr + q] - JP[6 * i + q];
-          accumulate_on_h_and_b(w, comp[k], ji, jp, H, b);
+          accumulate_on_h_and_b(NI, w, comp[k], ji, jp, H, b);
         }
       }
     }

@@ -7,10 +7,16 @@ from . import binding as _b
 
 
 class Camera(C.Structure):
-    _fields_ = [("type", C.c_int), ("width", C.c_int), ("height", C.c_int), ("p", C.c_float * 12), ("cutoff2", C.c_float)]
+    _fields_ = [("type", C.c_int), ("width", C.c_int), ("height", C.c_int), ("n_params", C.c_int), ("p", C.c_float * 12),
+                ("cutoff2", C.c_float), ("inner_cutoff2", C.c_float), ("fx_inv", C.c_float), ("fy_inv", C.c_float),
+                ("cx_inv", C.c_float), ("cy_inv", C.c_float)]
 
     def params(self):
-        return np.array(self.p[:4], np.float32)
+        return np.array(self.p[:self.n_params], np.float32)
+
+
+PINHOLE, OPENCV, THIN_PRISM_FISHEYE = 0, 1, 2
+PARAM_COUNT = {0: 4, 1: 8, 2: 12}
 
 
 _READY = False
@@ -26,6 +32,11 @@ def lib():
         cp = C.POINTER(Camera)
         L.oracle_reg_camera_init.argtypes = [cp, C.c_int, C.c_int, C.c_int, fp]
         L.oracle_reg_camera_scaled.argtypes = [cp, C.c_float, cp]
+        L.oracle_reg_camera_distort.argtypes = [cp, C.c_float, C.c_float, fp]
+        L.oracle_reg_camera_undistort.argtypes = [cp, C.c_float, C.c_float, fp, ip]
+        L.oracle_reg_camera_project.argtypes = [cp, fp, fp]
+        L.oracle_reg_camera_deriv_by_world.argtypes = [cp, fp, fp]
+        L.oracle_reg_camera_deriv_by_intrinsics.argtypes = [cp, fp, fp]
         for suffix, tp in (("u8", u8p), ("f32", fp)):
             getattr(L, "oracle_interp_trilinear_" + suffix).argtypes = [tp, C.c_int, tp, C.c_int, C.c_float, C.c_float, C.c_float, fp]
             getattr(L, "oracle_interp_trilinear_d_" + suffix).argtypes = [tp, C.c_int, tp, C.c_int, C.c_float, C.c_float, C.c_float, fp, fp, fp, fp]
@@ -56,6 +67,30 @@ def make_camera(w, h, params, ctype=0):
     pr = np.ascontiguousarray(params, np.float32)
     lib().oracle_reg_camera_init(C.byref(c), ctype, w, h, _p(pr, C.c_float))
     return c
+
+
+def cam_distort(cam, nx, ny):
+    o = np.zeros(2, np.float32); lib().oracle_reg_camera_distort(C.byref(cam), nx, ny, _p(o, C.c_float)); return o
+
+
+def cam_undistort(cam, dx, dy):
+    o = np.zeros(2, np.float32); conv = C.c_int()
+    lib().oracle_reg_camera_undistort(C.byref(cam), dx, dy, _p(o, C.c_float), C.byref(conv)); return o, bool(conv.value)
+
+
+def cam_project(cam, P):
+    P = np.ascontiguousarray(P, np.float32); o = np.zeros(2, np.float32)
+    lib().oracle_reg_camera_project(C.byref(cam), _p(P, C.c_float), _p(o, C.c_float)); return o
+
+
+def cam_deriv_by_world(cam, P):
+    P = np.ascontiguousarray(P, np.float32); o = np.zeros((2, 3), np.float32)
+    lib().oracle_reg_camera_deriv_by_world(C.byref(cam), _p(P, C.c_float), _p(o, C.c_float)); return o
+
+
+def cam_deriv_by_intrinsics(cam, P):
+    P = np.ascontiguousarray(P, np.float32); o = np.zeros((2, cam.n_params), np.float32)
+    lib().oracle_reg_camera_deriv_by_intrinsics(C.byref(cam), _p(P, C.c_float), _p(o, C.c_float)); return o
 
 
 def camera_pyramid(cam, n_levels):
@@ -127,7 +162,7 @@ def pass1(pts, point_radius, cam_min, min_image_scale, images, R, t, obs):
     ip, widths, keep = _img_ptrs(images)
     oi, ox, oy, os_ = [np.ascontiguousarray(a) for a in obs]
     n = len(oi)
-    I = np.zeros(n + 1, np.float32); JI = np.zeros((n + 1, 4), np.float32); JP = np.zeros((n + 1, 6), np.float32)
+    I = np.zeros(n + 1, np.float32); JI = np.zeros((n + 1, cam_min.n_params), np.float32); JP = np.zeros((n + 1, 6), np.float32)
     lib().oracle_reg_pass1(_p(pts, C.c_float), point_radius, C.byref(cam_min), min_image_scale, ip, _p(widths, C.c_int), _p(R, C.c_float),
                            _p(t, C.c_float), _p(oi, C.c_uint32), _p(ox, C.c_float), _p(oy, C.c_float), _p(os_, C.c_float), n,
                            _p(I, C.c_float), _p(JI, C.c_float), _p(JP, C.c_float))
@@ -141,7 +176,8 @@ def accumulate(pts, point_radius, nbr, K, fixed_desc, var_desc, obs_counts, cam_
     oc = np.ascontiguousarray(obs_counts, np.int32); fl = np.ascontiguousarray(flags, np.uint8)
     ip, widths, keep = _img_ptrs(images)
     oi, ox, oy, os_ = [np.ascontiguousarray(a) for a in obs]
-    H = np.zeros((10, 10)); b = np.zeros(10); sums = np.zeros(2); counts = np.zeros(2, np.int64)
+    V = cam_min.n_params + 6
+    H = np.zeros((V, V)); b = np.zeros(V); sums = np.zeros(2); counts = np.zeros(2, np.int64)
     lib().oracle_reg_accumulate(_p(pts, C.c_float), pts.shape[0], point_radius, _p(nbr, C.c_uint32), K, _p(fd, C.c_float), _p(vd, C.c_float),
                                 _p(oc, C.c_int32), C.byref(cam_min), min_image_scale, ip, _p(widths, C.c_int), _p(R, C.c_float), _p(t, C.c_float),
                                 _p(oi, C.c_uint32), _p(ox, C.c_float), _p(oy, C.c_float), _p(os_, C.c_float), _p(fl, C.c_uint8), len(oi),

@@ -7,7 +7,7 @@ Orchestrates the C per-observation oracle (oracle_reg.c) exactly as the referenc
   VisibilityEstimator::CreateObservationsForAllImages   src/opt/visibility_estimator.cc:49-91
   ColorOptimizer::Apply                                 src/opt/color_optimizer.cc:40-123
   CostCalculator::ComputeCost, Problem::ComputeCost     src/opt/cost_calculator.cc:44-100, src/opt/problem.cc:602-631
-Only numpy-array plumbing happens in Python; every per-point / per-observation loop is in C.  Non-rig images, PINHOLE.
+Only numpy-array plumbing happens in Python; every per-point / per-observation loop is in C.  Non-rig images; PINHOLE / OPENCV / THIN_PRISM_FISHEYE.
 Images are visited in ascending id (the reference's unordered_map order is unspecified).
 """
 import numpy as np
@@ -41,13 +41,14 @@ class OracleRegProblem:
         self.scales[s]["var"] = np.ascontiguousarray(desc, np.float32).copy()
         self.scales[s]["counts"] = np.ascontiguousarray(counts, np.int32).copy()
 
-    def set_intrinsics(self, iid, w, h, params, min_image_scale, n_levels):
-        self.intr[iid] = dict(w=w, h=h, params=np.ascontiguousarray(params, np.float32).copy(), min=min_image_scale, n=n_levels)
+    def set_intrinsics(self, iid, w, h, params, min_image_scale, n_levels, model=0):
+        self.intr[iid] = dict(w=w, h=h, params=np.ascontiguousarray(params, np.float32).copy(), min=min_image_scale, n=n_levels,
+                              model=model)
         self._rebuild(iid)
 
     def _rebuild(self, iid):
         I = self.intr[iid]
-        I["levels"] = rb.camera_pyramid(rb.make_camera(I["w"], I["h"], I["params"]), I["n"])
+        I["levels"] = rb.camera_pyramid(rb.make_camera(I["w"], I["h"], I["params"], I["model"]), I["n"])
 
     def set_image(self, image_id, iid, pyr, masks=None):
         self.images[image_id] = dict(intr=iid, pyr=pyr, masks=masks, q=np.array([1, 0, 0, 0], np.float32), t=np.zeros(3, np.float32))
@@ -146,7 +147,7 @@ class OracleRegProblem:
         intr_index, image_index = {}, {}
         V = 0
         for k in sorted(self.intr):
-            intr_index[k] = V; V += 4
+            intr_index[k] = V; V += len(self.intr[k]["params"])
         for k in sorted(self.images):
             image_index[k] = V; V += 6
         H = np.zeros((V, V)); b = np.zeros(V)
@@ -155,7 +156,8 @@ class OracleRegProblem:
         for image_id in sorted(self.images):
             im = self.images[image_id]; I = self.intr[im["intr"]]
             ii, pi = intr_index[im["intr"]], image_index[image_id]
-            g = list(range(ii, ii + 4)) + list(range(pi, pi + 6))
+            NI = len(I["params"])
+            g = list(range(ii, ii + NI)) + list(range(pi, pi + 6))
             for s in sorted(self.scales):
                 if (image_id, s) not in self.obs:
                     continue
@@ -165,8 +167,8 @@ class OracleRegProblem:
                                                I["min"], im["pyr"], self._R(im), im["t"], o[:4], o[4], self.robust_type, self.robust_param,
                                                self.fixed_weight, self.var_weight)
                 sums += s2; counts += c2
-                for r in range(10):
-                    for c in range(r, 10):
+                for r in range(NI + 6):
+                    for c in range(r, NI + 6):
                         H[g[r], g[c]] += Hl[r, c]
                     b[g[r]] += bl[r]
         initial = self._cost_value(sums, counts)
@@ -178,7 +180,7 @@ class OracleRegProblem:
             Hl = H.copy()
             Hl[np.diag_indices(V)] *= (1 + lam)
             x = ob.ldlt_solve_upper(Hl, b)
-            params = {k: (p + (-1 * x[intr_index[k]:intr_index[k] + 4])).astype(np.float32) for k, p in old[0].items()}
+            params = {k: (p + (-1 * x[intr_index[k]:intr_index[k] + len(p)])).astype(np.float32) for k, p in old[0].items()}
             poses = {k: ob.se3_update(x[image_index[k]:image_index[k] + 6], q, t) for k, (q, t) in old[1].items()}
             self.set_state((params, poses))
             trial_obs = {}

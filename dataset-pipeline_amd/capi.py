@@ -290,6 +290,9 @@ def normals_knn(xyz, k, viewpoint=(0.0, 0.0, 0.0), return_knn=False):
 
 
 # ---- (B) image registration kernels ------------------------------------------------------------------------------------
+CAMERA_PINHOLE, CAMERA_OPENCV, CAMERA_THIN_PRISM_FISHEYE = 0, 1, 2
+
+
 class RegParams(C.Structure):
     """e3d_reg_params -- the opt::Parameters fields the device code reads (src/opt/parameters.h:40-68)."""
     _fields_ = [("point_neighbor_count", C.c_int32), ("robust_weighting_type", C.c_int32),
@@ -316,6 +319,8 @@ class RegProblem:
         if not self._h:
             _err("e3d_reg_create")
         self._levels = {}
+        self._nparams = {}
+        self._image_intr = {}
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -355,9 +360,10 @@ class RegProblem:
         self._chk(lib().e3d_reg_set_intrinsics(self._h, intrinsics_id, camera_type, width, height, C.c_void_p(p.ctypes.data), len(p),
                                                min_image_scale, n_levels), "e3d_reg_set_intrinsics")
         self._levels[intrinsics_id] = n_levels
+        self._nparams[intrinsics_id] = len(p)
 
     def intrinsics_level(self, intrinsics_id, level):
-        w = C.c_int(); h = C.c_int(); p = np.zeros(4, np.float32); c = C.c_float()
+        w = C.c_int(); h = C.c_int(); p = np.zeros(self._nparams[intrinsics_id], np.float32); c = C.c_float()
         self._chk(lib().e3d_reg_get_intrinsics_level(self._h, intrinsics_id, level, C.byref(w), C.byref(h), C.c_void_p(p.ctypes.data), C.byref(c)), "get_intrinsics_level")
         return w.value, h.value, p, c.value
 
@@ -369,6 +375,7 @@ class RegProblem:
             keepm = [np.ascontiguousarray(m, np.uint8) if m is not None else None for m in masks]
             marr = (C.c_void_p * len(keepm))(*[(m.ctypes.data if m is not None else None) for m in keepm])
         self._chk(lib().e3d_reg_set_image(self._h, image_id, intrinsics_id, arr, marr), "e3d_reg_set_image")
+        self._image_intr[image_id] = intrinsics_id
 
     def set_image_pose(self, image_id, q, t):
         """image_T_global as unit quaternion (w, x, y, z) + translation."""
@@ -433,13 +440,17 @@ class RegProblem:
         idx = np.ascontiguousarray(idx, np.uint32); x, y, s = [np.ascontiguousarray(a, np.float32) for a in (x, y, s)]
         self._chk(lib().e3d_reg_set_observations(self._h, image_id, point_scale, len(idx), *[C.c_void_p(a.ctypes.data) for a in (idx, x, y, s)]), "set_observations")
 
+    def param_count(self, image_id):
+        return self._nparams[self._image_intr[image_id]]
+
     def pass1(self, image_id, point_scale, n):
-        I = np.zeros(n, np.float32); ji = np.zeros((n, 4), np.float32); jp = np.zeros((n, 6), np.float32)
+        I = np.zeros(n, np.float32); ji = np.zeros((n, self.param_count(image_id)), np.float32); jp = np.zeros((n, 6), np.float32)
         self._chk(lib().e3d_reg_pass1(self._h, image_id, point_scale, *[C.c_void_p(a.ctypes.data) for a in (I, ji, jp)]), "e3d_reg_pass1")
         return I, ji, jp
 
     def accumulate(self, image_id, point_scale):
-        H = np.zeros((10, 10)); b = np.zeros(10); sums = np.zeros(2); counts = np.zeros(2, np.int64)
+        V = self.param_count(image_id) + 6
+        H = np.zeros((V, V)); b = np.zeros(V); sums = np.zeros(2); counts = np.zeros(2, np.int64)
         self._chk(lib().e3d_reg_accumulate(self._h, image_id, point_scale, *[C.c_void_p(a.ctypes.data) for a in (H, b, sums, counts)]), "e3d_reg_accumulate")
         return H, b, sums, counts
 

@@ -1,0 +1,250 @@
+// Camera models of path (B) as device functions.  f32 throughout, reference expression order, no contraction.
+//
+//   kPinhole          camera::PinholeCamera               src/camera/camera_pinhole.h:40-86                     I = 4
+//   kOpenCV           camera::PolynomialTangentialCamera  src/camera/camera_polynomial_tangential.h:41-159      I = 8
+//   kThinPrismFisheye camera::BenchmarkCamera             src/camera/camera_benchmark.h:44-52 =
+//                     FisheyeBase (camera_base_impl_fisheye.h:43-162) over ThinPrismCamera (camera_thin_prism.h:43-162)   I = 12
+//
+// Shared CRTP base, src/camera/camera_base_impl.h: NormalizedToImage :155-164, IterativeUndistort :216-250,
+// UndistortFromInside :278-328, ImageDerivativeByWorld :333-360, ImageDerivativeByIntrinsics :369-408, InitCutoff :410-463.
+//
+// The model is a template parameter of every function (and of the kernels that call them): the Jacobian widths are
+// compile-time constants, so rows stay in registers, and a launch costs no per-thread model dispatch.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+namespace e3d {
+
+enum : int { kPinhole = 0, kOpenCV = 1, kThinPrismFisheye = 2 };
+
+__host__ __device__ constexpr int cam_param_count(int model) { return model == kPinhole ? 4 : (model == kOpenCV ? 8 : 12); }
+
+struct CamLevel {
+  int model;
+  int width, height;
+  float fx, fy, cx, cy;
+  float q[8];                                   // distortion parameters in the reference's GetParameters order
+  float fx_inv, fy_inv, cx_inv, cy_inv;         // CameraBase::k_inv_ (camera_base.cc:84)
+  float cutoff2;                                // radius_cutoff_squared_ of the outermost model
+  float inner_cutoff2;                          // ... of the non-fisheye model inside a FisheyeBase
+};
+
+#define E3D_CAM_INF __uint_as_float(0x7f800000u)
+
+// ---- polynomial part --------------------------------------------------------------------------------------------------------
+template <int M>
+__device__ __forceinline__ void cam_distort_plain(const CamLevel& c, float nx, float ny, float& ox, float& oy) {
+  if constexpr (M == kPinhole) {
+    ox = nx; oy = ny;
+  } else {
+    const float x2 = nx * nx, xy = nx * ny, y2 = ny * ny;
+    const float r2 = x2 + y2;
+    const float k1 = c.q[0], k2 = c.q[1], p1 = c.q[2], p2 = c.q[3];
+    if constexpr (M == kOpenCV) {
+      const float radial = 1 + r2 * (k1 + r2 * k2);
+      const float dx = 2.f * p1 * xy + p2 * (r2 + 2.f * x2);
+      const float dy = 2.f * p2 * xy + p1 * (r2 + 2.f * y2);
+      ox = nx * radial + dx; oy = ny * radial + dy;
+    } else {
+      const float k3 = c.q[4], k4 = c.q[5], sx1 = c.q[6], sy1 = c.q[7];
+      const float radial = 1 + r2 * (k1 + r2 * (k2 + r2 * (k3 + r2 * k4)));
+      const float dx = 2.f * p1 * xy + p2 * (r2 + 2.f * x2) + sx1 * r2;
+      const float dy = 2.f * p2 * xy + p1 * (r2 + 2.f * y2) + sy1 * r2;
+      ox = nx * radial + dx; oy = ny * radial + dy;
+    }
+  }
+}
+
+// DistortedDerivativeByNormalized, J = [J0 J1; J2 J3]
+template <int M>
+__device__ __forceinline__ void cam_ddn_plain(const CamLevel& c, float nx, float ny, float* J) {
+  if constexpr (M == kPinhole) {
+    J[0] = 1.f; J[1] = 0.f; J[2] = 0.f; J[3] = 1.f;
+  } else {
+    const float nx2 = nx * nx, ny2 = ny * ny;
+    const float r2 = nx2 + ny2;
+    const float k1 = c.q[0], k2 = c.q[1], p1 = c.q[2], p2 = c.q[3];
+    if constexpr (M == kOpenCV) {
+      const float term1 = 2 * k1 + r2 * 4 * k2;
+      const float term2 = 1 + r2 * (k1 + r2 * k2);
+      J[0] = nx2 * term1 + term2 + 6 * p2 * nx + 2 * p1 * ny;
+      J[1] = nx * ny * term1 + 2 * p1 * nx + 2 * p2 * ny;
+      J[2] = J[1];
+      J[3] = ny2 * term1 + term2 + 2 * p2 * nx + 6 * p1 * ny;
+    } else {
+      const float k3 = c.q[4], k4 = c.q[5], sx1 = c.q[6], sy1 = c.q[7];
+      const float nx_ny = nx * ny;
+      const float term1 = 2 * k1 + r2 * (4 * k2 + r2 * (6 * k3 + r2 * 8 * k4));
+      const float term2 = 1 + r2 * (k1 + r2 * (k2 + r2 * (k3 + r2 * k4)));
+      const float term3 = nx_ny * term1 + 2 * (p1 * nx + p2 * ny);
+      J[0] = nx2 * term1 + term2 + 6 * p2 * nx + 2 * p1 * ny + 2 * sx1 * nx;
+      J[1] = term3 + 2 * sx1 * ny;
+      J[2] = term3 + 2 * sy1 * nx;
+      J[3] = ny2 * term1 + term2 + 6 * p1 * ny + 2 * p2 * nx + 2 * sy1 * ny;
+    }
+  }
+}
+
+// DistortedDerivativeByDistortionParameters: rows d0, d1 of I - 4 entries
+template <int M>
+__device__ __forceinline__ void cam_ddp_plain(float nx, float ny, float* d0, float* d1) {
+  if constexpr (M != kPinhole) {
+    const float nx2 = nx * nx, ny2 = ny * ny;
+    const float two_nx_ny = 2.f * nx * ny;
+    const float r2 = nx2 + ny2;
+    d0[0] = nx * r2; d0[1] = d0[0] * r2; d0[2] = two_nx_ny; d0[3] = (r2 + 2.f * nx2);
+    d1[0] = ny * r2; d1[1] = d1[0] * r2; d1[2] = (r2 + 2.f * ny2); d1[3] = two_nx_ny;
+    if constexpr (M == kThinPrismFisheye) {
+      d0[4] = d0[1] * r2; d0[5] = d0[4] * r2; d0[6] = r2; d0[7] = 0;
+      d1[4] = d1[1] * r2; d1[5] = d1[4] * r2; d1[6] = 0; d1[7] = r2;
+    }
+  }
+}
+
+constexpr float kFisheyeEpsilon = 1e-6f;
+
+// ---- Child::Distort / DistortedDerivativeByNormalized / ...ByDistortionParameters ---------------------------------------------
+template <int M>
+__device__ __forceinline__ void cam_distort(const CamLevel& c, float nx, float ny, float& ox, float& oy) {
+  if constexpr (M != kThinPrismFisheye) {
+    cam_distort_plain<M>(c, nx, ny, ox, oy);
+  } else {
+    const float r = sqrtf(nx * nx + ny * ny);
+    if (r > kFisheyeEpsilon) {
+      const float atan_r = atan2f(r, 1.f);
+      if (atan_r * atan_r > c.inner_cutoff2) { ox = nx * E3D_CAM_INF; oy = ny * E3D_CAM_INF; return; }
+      const float theta_by_r = atan_r / r;
+      cam_distort_plain<M>(c, nx * theta_by_r, ny * theta_by_r, ox, oy);
+    } else {
+      cam_distort_plain<M>(c, nx, ny, ox, oy);
+    }
+  }
+}
+
+template <int M>
+__device__ __forceinline__ void cam_ddn(const CamLevel& c, float nx, float ny, float* J) {
+  if constexpr (M != kThinPrismFisheye) {
+    cam_ddn_plain<M>(c, nx, ny, J);
+  } else {
+    const float nx_ny = nx * ny, nx2 = nx * nx, ny2 = ny * ny;
+    const float r2 = nx2 + ny2;
+    const float r = sqrtf(r2);
+    if (r > kFisheyeEpsilon) {
+      const float atan_r = atan2f(r, 1.f);
+      if (atan_r * atan_r > c.inner_cutoff2) { J[0] = J[1] = J[2] = J[3] = 0.f; return; }
+      const float theta_by_r = atan_r / r;
+      const float term1 = r2 * (r2 + 1);
+      const float term2 = theta_by_r / r2;
+      const float f00 = ny2 * term2 + nx2 / term1;
+      const float f01 = nx_ny / term1 - nx_ny * term2;
+      const float f10 = f01;
+      const float f11 = nx2 * term2 + ny2 / term1;
+      float D[4];
+      cam_ddn_plain<M>(c, theta_by_r * nx, theta_by_r * ny, D);
+      J[0] = D[0] * f00 + D[1] * f10; J[1] = D[0] * f01 + D[1] * f11;
+      J[2] = D[2] * f00 + D[3] * f10; J[3] = D[2] * f01 + D[3] * f11;
+    } else {
+      cam_ddn_plain<M>(c, nx, ny, J);
+    }
+  }
+}
+
+template <int M>
+__device__ __forceinline__ void cam_ddp(const CamLevel& c, float nx, float ny, float* d0, float* d1) {
+  if constexpr (M != kThinPrismFisheye) {
+    cam_ddp_plain<M>(nx, ny, d0, d1);
+  } else {
+    const float r = sqrtf(nx * nx + ny * ny);
+    if (r > kFisheyeEpsilon) {
+      const float atan_r = atan2f(r, 1.f);
+      if (atan_r * atan_r > c.inner_cutoff2) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { d0[i] = 0.f; d1[i] = 0.f; }
+        return;
+      }
+      const float theta_by_r = atan_r / r;
+      cam_ddp_plain<M>(theta_by_r * nx, theta_by_r * ny, d0, d1);
+    } else {
+      cam_ddp_plain<M>(nx, ny, d0, d1);
+    }
+  }
+}
+
+// ---- CameraBaseImpl ---------------------------------------------------------------------------------------------------------------
+template <int M>
+__device__ __forceinline__ void cam_normalized_to_image(const CamLevel& c, float nx, float ny, float& ox, float& oy) {
+  const float r2 = nx * nx + ny * ny;
+  if (isinf(r2) || r2 > c.cutoff2) { ox = nx * E3D_CAM_INF; oy = ny * E3D_CAM_INF; return; }
+  float dx, dy;
+  cam_distort<M>(c, nx, ny, dx, dy);
+  ox = c.fx * dx + c.cx;
+  oy = c.fy * dy + c.cy;
+}
+
+// 2 x 3 row-major
+template <int M>
+__device__ __forceinline__ void cam_image_deriv_by_world(const CamLevel& c, float X, float Y, float Z, float* d) {
+  const float nx = X / Z, ny = Y / Z;
+  if (nx * nx + ny * ny < c.cutoff2) {
+    const float zi = 1.f / Z;
+    float J[4];
+    cam_ddn<M>(c, nx, ny, J);
+    const float n02 = (-1.f * nx) * zi, n12 = (-1.f * ny) * zi;      // normalize_deriv = [zi 0 n02; 0 zi n12]
+    d[0] = J[0] * zi + J[1] * 0.f; d[1] = J[0] * 0.f + J[1] * zi; d[2] = J[0] * n02 + J[1] * n12;
+    d[3] = J[2] * zi + J[3] * 0.f; d[4] = J[2] * 0.f + J[3] * zi; d[5] = J[2] * n02 + J[3] * n12;
+  } else {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) d[i] = 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { d[i] = c.fx * d[i]; d[3 + i] = c.fy * d[3 + i]; }
+}
+
+// 2 x I row-major (row stride I)
+template <int M>
+__device__ __forceinline__ void cam_image_deriv_by_intrinsics(const CamLevel& c, float X, float Y, float Z, float* d) {
+  constexpr int I = cam_param_count(M);
+  const float nx = X / Z, ny = Y / Z;
+  if (nx * nx + ny * ny > c.cutoff2) {
+#pragma unroll
+    for (int i = 0; i < 2 * I; ++i) d[i] = 0.f;
+    return;
+  }
+  float dx, dy;
+  cam_distort<M>(c, nx, ny, dx, dy);
+  d[0] = dx; d[1] = 0.f; d[2] = 1.f; d[3] = 0.f;
+  d[I + 0] = 0.f; d[I + 1] = dy; d[I + 2] = 0.f; d[I + 3] = 1.f;
+  if constexpr (I > 4) {
+    cam_ddp<M>(c, nx, ny, d + 4, d + I + 4);
+#pragma unroll
+    for (int i = 4; i < I; ++i) { d[i] = c.fx * d[i]; d[I + i] = c.fy * d[I + i]; }
+  }
+}
+
+// IterativeUndistort of the non-fisheye model M (Gauss-Newton, <= 100 iterations, |delta|^2 < 1e-10)
+template <int M>
+__device__ __forceinline__ bool cam_iterative_undistort(const CamLevel& c, float dx, float dy, float sx, float sy, float& ux, float& uy) {
+  bool converged = false;
+  float x = sx, y = sy;
+  for (int i = 0; i < 100; ++i) {
+    float cx, cy;
+    cam_distort_plain<M>(c, x, y, cx, cy);
+    const float ex = cx - dx, ey = cy - dy;
+    if (ex * ex + ey * ey < 1e-10f) { converged = true; break; }
+    float J[4];
+    cam_ddn_plain<M>(c, x, y, J);
+    const float a = J[0] * J[0] + J[2] * J[2], b = J[0] * J[1] + J[2] * J[3];        // Jd^T Jd
+    const float cc = J[1] * J[0] + J[3] * J[2], d = J[1] * J[1] + J[3] * J[3];
+    const float invdet = 1.f / (a * d - cc * b);                                      // Eigen's 2x2 inverse
+    const float i00 = d * invdet, i01 = -b * invdet, i10 = -cc * invdet, i11 = a * invdet;
+    const float m00 = i00 * J[0] + i01 * J[2], m01 = i00 * J[1] + i01 * J[3];
+    const float m10 = i10 * J[0] + i11 * J[2], m11 = i10 * J[1] + i11 * J[3];
+    x -= m00 * ex + m01 * ey;
+    y -= m10 * ex + m11 * ey;
+  }
+  ux = x; uy = y;
+  return converged;
+}
+
+}  // namespace e3d

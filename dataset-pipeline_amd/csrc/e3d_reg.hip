@@ -19,19 +19,13 @@
 #include <memory>
 
 #include "../../include/e3d_hip.h"
+#include "e3d_camera.hpp"
 #include "e3d_icp_kernels.hpp"
 #include "e3d_math.hpp"
 
 #pragma clang fp contract(off)
 
 namespace e3d {
-
-struct CamLevel {
-  int width, height;
-  float fx, fy, cx, cy;
-  float fx_inv, fy_inv, cx_inv, cy_inv;
-  float cutoff2;
-};
 
 struct Pose { float R[9]; float t[3]; };
 
@@ -47,38 +41,6 @@ struct Pyramid {               // passed by value to kernels
 // x86 cvttss2si / cvttsd2si semantics of the reference's `int ix = v + 0.5f;`
 __device__ __forceinline__ int f2i(float v) { return (v >= -2147483648.0f && v < 2147483648.0f) ? (int)v : INT_MIN; }
 __device__ __forceinline__ int d2i(double v) { return (v > -2147483649.0 && v < 2147483648.0) ? (int)v : INT_MIN; }
-
-// ---- camera device functions (PINHOLE): camera_base_impl.h:155-164, 333-408; camera_pinhole.h:50-85 -----------------
-__device__ __forceinline__ void cam_normalized_to_image(const CamLevel& c, float nx, float ny, float& ox, float& oy) {
-  const float r2 = nx * nx + ny * ny;
-  const float inf = __uint_as_float(0x7f800000u);
-  if (isinf(r2) || r2 > c.cutoff2) { ox = nx * inf; oy = ny * inf; return; }
-  ox = c.fx * nx + c.cx;
-  oy = c.fy * ny + c.cy;
-}
-__device__ __forceinline__ void cam_image_deriv_by_world(const CamLevel& c, float X, float Y, float Z, float* d) {
-  const float nx = X / Z, ny = Y / Z;
-  if (nx * nx + ny * ny < c.cutoff2) {
-    const float zi = 1.f / Z;
-    d[0] = zi; d[1] = 0.f; d[2] = (-1.f * nx) * zi;
-    d[3] = 0.f; d[4] = zi; d[5] = (-1.f * ny) * zi;
-  } else {
-#pragma unroll
-    for (int i = 0; i < 6; ++i) d[i] = 0.f;
-  }
-#pragma unroll
-  for (int i = 0; i < 3; ++i) { d[i] = c.fx * d[i]; d[3 + i] = c.fy * d[3 + i]; }
-}
-__device__ __forceinline__ void cam_image_deriv_by_intrinsics(const CamLevel& c, float X, float Y, float Z, float* d) {
-  const float nx = X / Z, ny = Y / Z;
-  if (nx * nx + ny * ny > c.cutoff2) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) d[i] = 0.f;
-    return;
-  }
-  d[0] = nx; d[1] = 0.f; d[2] = 1.f; d[3] = 0.f;
-  d[4] = 0.f; d[5] = ny; d[6] = 0.f; d[7] = 1.f;
-}
 
 __device__ __forceinline__ void rt(const Pose& P, float x, float y, float z, float& ox, float& oy, float& oz) {
   ox = dot3e(P.R[0], P.R[1], P.R[2], x, y, z) + P.t[0];
@@ -145,6 +107,7 @@ __device__ __forceinline__ float robust_weight(int type, float param, float r) {
 }
 
 // ==== a24: OcclusionGeometry::_RenderDepthMapWithSplatsCPU ========================================================================
+template <int M>
 __global__ __launch_bounds__(kBlock) void k_splat_depth(const float4* __restrict__ pts, size_t n, Pose P, CamLevel cam,
                                                         float point_radius, unsigned* __restrict__ depth_bits) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -154,8 +117,8 @@ __global__ __launch_bounds__(kBlock) void k_splat_depth(const float4* __restrict
   rt(P, p.x, p.y, p.z, X, Y, Z);
   if (!(Z > 0.f)) return;
   float px, py, d[6];
-  cam_normalized_to_image(cam, X / Z, Y / Z, px, py);
-  cam_image_deriv_by_world(cam, X, Y, Z, d);
+  cam_normalized_to_image<M>(cam, X / Z, Y / Z, px, py);
+  cam_image_deriv_by_world<M>(cam, X, Y, Z, d);
   float rx = sqrtf(d[0] * d[0] + (d[1] * d[1] + d[2] * d[2])) * point_radius;
   float ry = sqrtf(d[3] * d[3] + (d[4] * d[4] + d[5] * d[5])) * point_radius;
   rx = (10.f < rx) ? 10.f : rx;     // std::min(splat_radius, max_splat_radius)
@@ -182,6 +145,7 @@ struct ObsParams {
   int check;     // 1: occlusion + masks + over-saturation (all points); 0: indexed list
 };
 
+template <int M>
 __global__ __launch_bounds__(kBlock) void k_obs_eval(const float4* __restrict__ pts, const unsigned* __restrict__ indices,
                                                      size_t count, Pose P, Pyramid Y, const float* __restrict__ occlusion,
                                                      ObsParams q, int* __restrict__ valid, float* __restrict__ ox,
@@ -198,14 +162,14 @@ __global__ __launch_bounds__(kBlock) void k_obs_eval(const float4* __restrict__ 
   if (lvl < 0) lvl = 0;
   const CamLevel cam = Y.cam[lvl];
   float ixf, iyf;
-  cam_normalized_to_image(cam, X / Z, Yc / Z, ixf, iyf);
+  cam_normalized_to_image<M>(cam, X / Z, Yc / Z, ixf, iyf);
   int ix = f2i(ixf + 0.5f), iy = f2i(iyf + 0.5f);
   if (!(ix >= 0 && iy >= 0 && ix < cam.width && iy < cam.height)) return;
   if (q.check && !(occlusion[(size_t)iy * cam.width + ix] + q.occlusion_threshold >= Z)) return;
   // CreateObservationIfScaleFits (visibility_estimator.cc:405-532)
   const float prx = X + q.point_radius, pry = Yc + 0.f, prz = Z + 0.f;
   float rxf, ryf;
-  cam_normalized_to_image(cam, prx / prz, pry / prz, rxf, ryf);
+  cam_normalized_to_image<M>(cam, prx / prz, pry / prz, rxf, ryf);
   const float dx = rxf - ixf, dy = ryf - iyf;
   const float radius_pixels = sqrtf(dx * dx + dy * dy);
   const float observation_scale = q.image_scale + log2f(2 * radius_pixels);
@@ -268,10 +232,16 @@ __global__ __launch_bounds__(kBlock) void k_obs_flags(const unsigned* __restrict
 }
 
 // ==== a16: pass 1 =========================================================================================================================
+// Row of one observation: [intensity, J_intrinsics(I), J_pose(6), 0-padding] as rows4(I) float4.
+__host__ __device__ constexpr int rows4(int I) { return (I + 10) / 4; }     // 3, 4, 5 float4 for I = 4, 8, 12
+
+template <int M>
 __global__ __launch_bounds__(kBlock) void k_reg_pass1(const float4* __restrict__ pts, float point_radius, Pose P, Pyramid Y,
                                                       const unsigned* __restrict__ o_idx, const float* __restrict__ o_x,
                                                       const float* __restrict__ o_y, const float* __restrict__ o_s,
                                                       size_t n_obs, float4* __restrict__ rows) {
+  constexpr int I = cam_param_count(M);
+  constexpr int R4 = rows4(I);
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_obs) return;
   const float4 p = pts[o_idx[i]];
@@ -281,8 +251,11 @@ __global__ __launch_bounds__(kBlock) void k_reg_pass1(const float4* __restrict__
   const int si = f2i(os);
   const int small_scale = si + 1;
   const int l1 = si - Y.min_image_scale, l0 = l1 + 1;
-  float I, j0, j1, j2;
-  trilinear_d(Y.img[l0], Y.cam[l0].width, Y.img[l1], Y.cam[l1].width, ox, oy, 1 - (os - (float)si), I, j0, j1, j2);
+  float row[4 * R4];
+#pragma unroll
+  for (int c = 0; c < 4 * R4; ++c) row[c] = 0.f;
+  float j0, j1, j2;
+  trilinear_d(Y.img[l0], Y.cam[l0].width, Y.img[l1], Y.cam[l1].width, ox, oy, 1 - (os - (float)si), row[0], j0, j1, j2);
   j2 = -1 * j2;
   const float scale_factor = exp2f((float)(Y.min_image_scale - small_scale));     // exact power of two
   const float inv_scale_factor = 1.f / scale_factor;
@@ -291,21 +264,22 @@ __global__ __launch_bounds__(kBlock) void k_reg_pass1(const float4* __restrict__
   const CamLevel cam = Y.cam[0];                                                   // min_image_scale camera
   const float To0 = T0 + point_radius;
   float offx, offy;
-  cam_normalized_to_image(cam, To0 / T2, T1 / T2, offx, offy);
+  cam_normalized_to_image<M>(cam, To0 / T2, T1 / T2, offx, offy);
   const float rdx = offx - mx, rdy = offy - my;
   const float denom = fmaxf(1e-6f, 0.693147180559945f * (rdx * rdx + rdy * rdy));
-  float Pi[12], Po[8];
-  cam_image_deriv_by_intrinsics(cam, T0, T1, T2, Pi);
-  cam_image_deriv_by_intrinsics(cam, To0, T1, T2, Po);
-  float ji[4];
+  {
+    float Pi[2 * I], Po[2 * I];
+    cam_image_deriv_by_intrinsics<M>(cam, T0, T1, T2, Pi);
+    cam_image_deriv_by_intrinsics<M>(cam, To0, T1, T2, Po);
 #pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    Pi[8 + c] = ((Po[c] - Pi[c]) * rdx + (Po[4 + c] - Pi[4 + c]) * rdy) / denom;
-    ji[c] = j0 * Pi[c] + (j1 * Pi[4 + c] + j2 * Pi[8 + c]);
+    for (int c = 0; c < I; ++c) {
+      const float scale_row = ((Po[c] - Pi[c]) * rdx + (Po[I + c] - Pi[I + c]) * rdy) / denom;
+      row[1 + c] = j0 * Pi[c] + (j1 * Pi[I + c] + j2 * scale_row);
+    }
   }
   float W[9], Wo[6], a[3];
-  cam_image_deriv_by_world(cam, T0, T1, T2, W);
-  cam_image_deriv_by_world(cam, To0, T1, T2, Wo);
+  cam_image_deriv_by_world<M>(cam, T0, T1, T2, W);
+  cam_image_deriv_by_world<M>(cam, To0, T1, T2, Wo);
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     W[6 + c] = ((Wo[c] - W[c]) * rdx + (Wo[3 + c] - W[3 + c]) * rdy) / denom;
@@ -315,27 +289,36 @@ __global__ __launch_bounds__(kBlock) void k_reg_pass1(const float4* __restrict__
   const float C0[6] = {1, 0, 0, 0, T2, -1 * T1};
   const float C1[6] = {0, 1, 0, -1 * T2, 0, T0};
   const float C2[6] = {0, 0, 1, T1, -1 * T0, 0};
-  float jp[6];
 #pragma unroll
-  for (int c = 0; c < 6; ++c) jp[c] = a[0] * C0[c] + (a[1] * C1[c] + a[2] * C2[c]);
-  rows[3 * i] = make_float4(I, ji[0], ji[1], ji[2]);
-  rows[3 * i + 1] = make_float4(ji[3], jp[0], jp[1], jp[2]);
-  rows[3 * i + 2] = make_float4(jp[3], jp[4], jp[5], 0.f);
+  for (int c = 0; c < 6; ++c) row[1 + I + c] = a[0] * C0[c] + (a[1] * C1[c] + a[2] * C2[c]);
+#pragma unroll
+  for (int r = 0; r < R4; ++r) rows[R4 * i + r] = make_float4(row[4 * r], row[4 * r + 1], row[4 * r + 2], row[4 * r + 3]);
 }
 
 // ==== a17 + a18: pass 2 =====================================================================================================================
-constexpr int kRegV = 10;                         // I + 6 for PINHOLE
-constexpr int kRegH = kRegV * (kRegV + 1) / 2;    // 55 upper-triangle entries
-constexpr int kRegSlot = kRegH + kRegV + 4;       // + b + {sum_f, sum_v, cnt_f, cnt_v}
+// Local system of one (image, point scale): V = I + 6 unknowns [intrinsics(I), pose(6)].  Slot layout of the reduction:
+// [upper triangle of H row-major (V(V+1)/2)] [b (V)] [sum_fixed, sum_variable, count_fixed, count_variable].
+__host__ __device__ constexpr int reg_v(int I) { return I + 6; }
+__host__ __device__ constexpr int reg_h(int I) { return reg_v(I) * (reg_v(I) + 1) / 2; }
+__host__ __device__ constexpr int reg_slot(int I) { return reg_h(I) + reg_v(I) + 4; }
+__host__ __device__ constexpr int reg_row_start(int V, int r) { return r * V - r * (r - 1) / 2; }   // index of H(r, r)
 
 struct RegWeights { int robust_type; float robust_param; float fixed_weight, var_weight; };
 
-__device__ __forceinline__ void load_row(const float4* __restrict__ rows, size_t r, float& I, float* J) {
-  const float4 a = rows[3 * r], b = rows[3 * r + 1], c = rows[3 * r + 2];
-  I = a.x; J[0] = a.y; J[1] = a.z; J[2] = a.w; J[3] = b.x; J[4] = b.y; J[5] = b.z; J[6] = b.w; J[7] = c.x; J[8] = c.y; J[9] = c.z;
+template <int I>
+__device__ __forceinline__ void load_row(const float4* __restrict__ rows, size_t r, float* f) {
+  constexpr int R4 = rows4(I);
+#pragma unroll
+  for (int q = 0; q < R4; ++q) {
+    const float4 v = rows[R4 * r + q];
+    f[4 * q] = v.x; f[4 * q + 1] = v.y; f[4 * q + 2] = v.z; f[4 * q + 3] = v.w;
+  }
 }
 
-template <int K_MAX>
+// One launch accumulates the H rows [R0, R1) (and, if WITH_B, b and the residual sums): 69 f64 accumulators per thread for
+// PINHOLE in a single launch; the 14- and 18-unknown systems are split into 2 / 3 launches of <= 73 accumulators each so that
+// the accumulators stay in registers (the rows are re-read from L2, the arithmetic per launch is proportional to its rows).
+template <int K_MAX, int I, int R0, int R1, bool WITH_B>
 __global__ __launch_bounds__(kBlock) void k_reg_pass2(const float4* __restrict__ rows, const unsigned* __restrict__ o_idx,
                                                       const unsigned char* __restrict__ flags, size_t n_obs,
                                                       const unsigned* __restrict__ nbr, int K,
@@ -343,19 +326,22 @@ __global__ __launch_bounds__(kBlock) void k_reg_pass2(const float4* __restrict__
                                                       const float* __restrict__ fixed_desc, const float* __restrict__ var_desc,
                                                       const int* __restrict__ obs_counts, RegWeights wts,
                                                       double* __restrict__ partial) {
-  double acc[kRegSlot];
+  constexpr int V = reg_v(I), R4 = rows4(I);
+  constexpr int NH = reg_row_start(V, R1) - reg_row_start(V, R0);
+  constexpr int NL = NH + (WITH_B ? V + 4 : 0);
+  double acc[NL];
 #pragma unroll
-  for (int i = 0; i < kRegSlot; ++i) acc[i] = 0.0;
+  for (int i = 0; i < NL; ++i) acc[i] = 0.0;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_obs; i += (size_t)gridDim.x * blockDim.x) {
     if (!flags[i]) continue;
     const size_t p = o_idx[i];
-    float Ic, Jc[kRegV];
-    load_row(rows, i, Ic, Jc);
+    float fc[4 * R4];
+    load_row<I>(rows, i, fc);
     int nrow[K_MAX];
     float In[K_MAX];
 #pragma unroll
     for (int k = 0; k < K_MAX; ++k)
-      if (k < K) { nrow[k] = row_of_point[nbr[p * K + k]]; In[k] = rows[3 * (size_t)nrow[k]].x; }
+      if (k < K) { nrow[k] = row_of_point[nbr[p * K + k]]; In[k] = rows[R4 * (size_t)nrow[k]].x; }
 #pragma unroll
     for (int kind = 0; kind < 2; ++kind) {
       const float sw = kind == 0 ? wts.fixed_weight : wts.var_weight;
@@ -367,50 +353,97 @@ __global__ __launch_bounds__(kBlock) void k_reg_pass2(const float4* __restrict__
 #pragma unroll
       for (int k = 0; k < K_MAX; ++k)
         if (k < K) {
-          const float image_descriptor = In[k] - Ic;
+          const float image_descriptor = In[k] - fc[0];
           const float c = image_descriptor - desc[p * K + k];
           comp[k] = c;
           pr += c * c;
         }
       pr = sqrtf(pr);
-      acc[kRegH + kRegV + 2 + kind] += 1.0;
-      acc[kRegH + kRegV + kind] += (double)robust_residual(wts.robust_type, wts.robust_param, pr);
+      if constexpr (WITH_B) {
+        acc[NH + V + 2 + kind] += 1.0;
+        acc[NH + V + kind] += (double)robust_residual(wts.robust_type, wts.robust_param, pr);
+      }
       const float w = sw * robust_weight(wts.robust_type, wts.robust_param, pr);
       if (w != 0) {
 #pragma unroll
         for (int k = 0; k < K_MAX; ++k)
           if (k < K) {
-            float In2, Jn[kRegV], J[kRegV];
-            load_row(rows, (size_t)nrow[k], In2, Jn);
+            float fn[4 * R4], J[V];
+            load_row<I>(rows, (size_t)nrow[k], fn);
 #pragma unroll
-            for (int c = 0; c < kRegV; ++c) J[c] = Jn[c] - Jc[c];
+            for (int c = 0; c < V; ++c) J[c] = fn[1 + c] - fc[1 + c];
             // AccumulateOnHAndB: products in f32, cast, add in f64 (intrinsics_and_pose_optimizer.cc:1246-1247)
             int e = 0;
 #pragma unroll
-            for (int r = 0; r < kRegV; ++r) {
+            for (int r = R0; r < R1; ++r) {
               const float wj = w * J[r];
 #pragma unroll
-              for (int c = r; c < kRegV; ++c) { acc[e] += (double)(wj * J[c]); ++e; }
+              for (int c = r; c < V; ++c) { acc[e] += (double)(wj * J[c]); ++e; }
             }
-            const float wr = w * comp[k];
+            if constexpr (WITH_B) {
+              const float wr = w * comp[k];
 #pragma unroll
-            for (int c = 0; c < kRegV; ++c) acc[kRegH + c] += (double)(wr * J[c]);
+              for (int c = 0; c < V; ++c) acc[NH + c] += (double)(wr * J[c]);
+            }
           }
       }
     }
   }
-  __shared__ double s[kBlock / kWave][kRegSlot];
+  __shared__ double s[kBlock / kWave][NL];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
-  for (int i = 0; i < kRegSlot; ++i) {
+  for (int i = 0; i < NL; ++i) {
     const double v = wave_sum(acc[i]);
     if (lane == 0) s[wv][i] = v;
   }
   __syncthreads();
-  if (threadIdx.x < kRegSlot) {
+  if (threadIdx.x < NL) {
     double v = s[0][threadIdx.x];
     for (int k = 1; k < kBlock / kWave; ++k) v += s[k][threadIdx.x];
-    partial[(size_t)blockIdx.x * kRegSlot + threadIdx.x] = v;
+    const int t = threadIdx.x;
+    const int dst = t < NH ? reg_row_start(V, R0) + t : reg_h(I) + (t - NH);
+    partial[(size_t)blockIdx.x * reg_slot(I) + dst] = v;
+  }
+}
+
+// InitCutoff (camera_base_impl.h:410-463) of the non-fisheye model M: one thread per border test point runs
+// UndistortFromInside (:278-328) over the 10 x 10 seed grid in the reference's order; min_candidate / max_candidate are
+// order-free max / min reductions (non-negative floats: their bit patterns are ordered).
+template <int M>
+__global__ __launch_bounds__(kBlock) void k_cam_cutoff(CamLevel c, unsigned* __restrict__ out /* [max r2 bits, min second r2 bits] */) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int total = 2 * c.width + 2 * c.height;
+  if (t >= total) return;
+  float px, py;
+  if (t < 2 * c.width) { px = (float)(t >> 1); py = (t & 1) ? (float)(c.height - 1) : 0.f; }
+  else { const int u = t - 2 * c.width; py = (float)(u >> 1); px = (u & 1) ? (float)(c.width - 1) : 0.f; }
+  const float dx = c.fx_inv * px + c.cx_inv, dy = c.fy_inv * py + c.cy_inv;
+  bool converged = false, second_available = false;
+  float best_radius = E3D_CAM_INF, second_best_radius = E3D_CAM_INF;
+  float bx = 0.f, by = 0.f, sbx = 0.f, sby = 0.f;
+  for (int yi = 0; yi < 10; ++yi) {
+    const float iy = dy + 1.5f * (yi - 0.5f * 10) / (0.5f * 10);
+    for (int xi = 0; xi < 10; ++xi) {
+      const float ix = dx + 1.5f * (xi - 0.5f * 10) / (0.5f * 10);
+      float rx, ry;
+      if (!cam_iterative_undistort<M>(c, dx, dy, ix, iy, rx, ry)) continue;
+      const float radius = sqrtf(rx * rx + ry * ry);
+      if (radius < 0.99f * best_radius) {
+        second_best_radius = best_radius;
+        sbx = bx; sby = by;
+        second_available = converged;
+        best_radius = radius; bx = rx; by = ry;
+        converged = true;
+      } else if (radius > 1 / 0.99f * best_radius && radius < 0.99f * second_best_radius) {
+        second_best_radius = radius;
+        sbx = rx; sby = ry;
+        second_available = true;
+      }
+    }
+  }
+  if (converged) {
+    atomicMax(&out[0], __float_as_uint(bx * bx + by * by));
+    if (second_available) atomicMin(&out[1], __float_as_uint(sbx * sbx + sby * sby));
   }
 }
 
@@ -545,35 +578,6 @@ struct ImageDev {
   std::map<int, Obs> obs;         // per point scale
 };
 
-static CamLevel make_level(int w, int h, const float* p) {
-  CamLevel c{};
-  c.width = w; c.height = h; c.fx = p[0]; c.fy = p[1]; c.cx = p[2]; c.cy = p[3];
-  c.fx_inv = 1.0f / c.fx; c.fy_inv = 1.0f / c.fy; c.cx_inv = -c.cx / c.fx; c.cy_inv = -c.cy / c.fy;
-  // InitCutoff (camera_base_impl.h:410-463): undistorted model => 1.01 * max border r^2
-  float mc = 0.f;
-  auto upd = [&](float px, float py) {
-    const float nx = c.fx_inv * px + c.cx_inv, ny = c.fy_inv * py + c.cy_inv;
-    const float r2 = nx * nx + ny * ny;
-    if (r2 > mc) mc = r2;
-  };
-  for (int x = 0; x < w; ++x) { upd((float)x, 0.f); upd((float)x, (float)(h - 1)); }
-  for (int y = 0; y < h; ++y) { upd(0.f, (float)y); upd((float)(w - 1), (float)y); }
-  c.cutoff2 = mc * 1.01f;
-  return c;
-}
-
-// Intrinsics::BuildModelPyramid (intrinsics.cc:46-51): level l = ScaledBy(0.5) of level l-1
-static void build_model_pyramid(Intrin& in, int n_levels) {
-  in.levels.clear();
-  in.levels.push_back(make_level(in.width, in.height, in.params));
-  for (int l = 1; l < n_levels; ++l) {
-    const CamLevel& p = in.levels.back();
-    const float f = 0.5f;
-    const float q[4] = {p.fx * f, p.fy * f, f * (p.cx + 0.5f) - 0.5f, f * (p.cy + 0.5f) - 0.5f};
-    in.levels.push_back(make_level((int)(f * p.width + 0.5f), (int)(f * p.height + 0.5f), q));
-  }
-}
-
 static void set_pose(ImageDev& im, const SE3f& T) {
   im.pose_q = T;
   quat_to_matrix<float>(T.q.w, T.q.x, T.q.y, T.q.z, im.pose.R);
@@ -600,6 +604,7 @@ struct e3d_reg {
   DevBuf<double> block_d2, chunk_d2, d_total_d2, partial, red;
   DevBuf<unsigned long long> chunk_sum, d_total;
   DevBuf<float> dummy_d2;
+  DevBuf<unsigned> cut;
   ~e3d_reg() { if (stream) (void)hipStreamDestroy(stream); }
 };
 
@@ -607,6 +612,58 @@ namespace e3d {
 
 static void rsync(e3d_reg* h) { E3D_HIP(hipStreamSynchronize(h->stream)); }
 static unsigned nblk(size_t n) { return (unsigned)div_up(n ? n : 1, kBlock); }
+
+// run `stmt` with the camera model as the compile-time constant M
+#define E3D_CAM_SWITCH(model, stmt)                                                        \
+  switch (model) {                                                                         \
+    case kPinhole: { constexpr int M = kPinhole; stmt; } break;                            \
+    case kOpenCV: { constexpr int M = kOpenCV; stmt; } break;                              \
+    case kThinPrismFisheye: { constexpr int M = kThinPrismFisheye; stmt; } break;          \
+    default: throw Error(E3D_ERR_INVALID, "unknown camera model");                         \
+  }
+
+// One camera of the pyramid = one constructor call of the reference's camera class: pixel mapping (camera_base.cc:81-86) and,
+// for the distorted models, InitCutoff -- run on the device (k_cam_cutoff), 2(W+H) border points in parallel.
+static CamLevel make_level(e3d_reg* h, int model, int w, int h_px, const float* p) {
+  CamLevel c{};
+  c.model = model; c.width = w; c.height = h_px; c.fx = p[0]; c.fy = p[1]; c.cx = p[2]; c.cy = p[3];
+  for (int i = 0; i < cam_param_count(model) - 4; ++i) c.q[i] = p[4 + i];
+  c.fx_inv = (float)(1.0 / (double)c.fx); c.fy_inv = (float)(1.0 / (double)c.fy);
+  c.cx_inv = (float)(-1.0 * (double)c.cx / (double)c.fx); c.cy_inv = (float)(-1.0 * (double)c.cy / (double)c.fy);
+  c.cutoff2 = INFINITY; c.inner_cutoff2 = INFINITY;
+  if (model == kPinhole) return c;                  // PinholeCamera never calls InitCutoff (camera_pinhole.cc:35-43)
+  h->cut.reserve(2);
+  const unsigned init[2] = {0u, 0x7f800000u};       // min_candidate = 0, max_candidate = +inf
+  copy_in(h->cut.p, init, sizeof init, h->stream);
+  const int total = 2 * w + 2 * h_px;
+  if (model == kOpenCV) hipLaunchKernelGGL(k_cam_cutoff<kOpenCV>, dim3(nblk(total)), dim3(kBlock), 0, h->stream, c, h->cut.p);
+  else hipLaunchKernelGGL(k_cam_cutoff<kThinPrismFisheye>, dim3(nblk(total)), dim3(kBlock), 0, h->stream, c, h->cut.p);   // inner ThinPrismCamera
+  unsigned out[2];
+  copy_out(out, h->cut.p, sizeof out, h->stream);
+  rsync(h);
+  float mn, mx;
+  std::memcpy(&mn, &out[0], 4); std::memcpy(&mx, &out[1], 4);
+  const float a = mn * 1.01f;
+  const float cutoff = (mx < a) ? mx : a;           // std::min(min_candidate * kIncreaseFactor, max_candidate)
+  if (model == kOpenCV) c.cutoff2 = cutoff; else c.inner_cutoff2 = cutoff;
+  return c;
+}
+
+// Intrinsics::BuildModelPyramid (intrinsics.cc:46-51): level l = ScaledBy(0.5) of level l-1 (camera_base_impl.h:70-89)
+static void build_model_pyramid(e3d_reg* h, Intrin& in, int n_levels) {
+  in.levels.clear();
+  in.levels.push_back(make_level(h, in.type, in.width, in.height, in.params));
+  for (int l = 1; l < n_levels; ++l) {
+    const CamLevel& p = in.levels.back();
+    const float f = 0.5f;
+    float q[12];
+    for (int i = 4; i < in.n_params; ++i) q[i] = in.params[i];
+    q[0] = p.fx * f; q[1] = p.fy * f; q[2] = f * (p.cx + 0.5f) - 0.5f; q[3] = f * (p.cy + 0.5f) - 0.5f;
+    in.levels.push_back(make_level(h, in.type, (int)(f * p.width + 0.5f), (int)(f * p.height + 0.5f), q));
+  }
+}
+
+static int image_model(e3d_reg* h, const ImageDev& im) { return h->intr.at(im.intrinsics_id).type; }
 
 static Pyramid make_pyramid(e3d_reg* h, const ImageDev& im) {
   const Intrin& in = h->intr.at(im.intrinsics_id);
@@ -661,10 +718,11 @@ static void prepare_rows(e3d_reg* h, ImageDev& im, PointScale& S, Obs& O) {
   hipStream_t s = h->stream;
   hipLaunchKernelGGL(k_fill_i32, dim3(nblk(S.n)), dim3(kBlock), 0, s, S.row_of_point.p, S.n, -1);
   if (O.n) hipLaunchKernelGGL(k_obs_mark, dim3(nblk(O.n)), dim3(kBlock), 0, s, O.idx.p, O.n, S.row_of_point.p);
-  O.rows.reserve(3 * O.n);
+  const int model = image_model(h, im);
+  O.rows.reserve((size_t)rows4(cam_param_count(model)) * O.n);
   if (O.n)
-    hipLaunchKernelGGL(k_reg_pass1, dim3(nblk(O.n)), dim3(kBlock), 0, s, S.pts.p, S.radius, im.pose, make_pyramid(h, im), O.idx.p,
-                       O.x.p, O.y.p, O.s.p, O.n, O.rows.p);
+    E3D_CAM_SWITCH(model, hipLaunchKernelGGL(k_reg_pass1<M>, dim3(nblk(O.n)), dim3(kBlock), 0, s, S.pts.p, S.radius, im.pose,
+                                             make_pyramid(h, im), O.idx.p, O.x.p, O.y.p, O.s.p, O.n, O.rows.p));
   O.rows_valid = true;
 }
 
@@ -763,13 +821,15 @@ int e3d_reg_set_intrinsics(e3d_reg_t* h, int intrinsics_id, int camera_type, int
                            int n_parameters, int min_image_scale, int n_levels) {
   R_TRY
   if (!h || !parameters) throw Error(E3D_ERR_INVALID, "null argument");
-  if (camera_type != E3D_CAMERA_PINHOLE || n_parameters != 4) throw Error(E3D_ERR_INVALID, "only PINHOLE (4 parameters) is implemented on the HIP path yet");
+  if (camera_type != E3D_CAMERA_PINHOLE && camera_type != E3D_CAMERA_OPENCV && camera_type != E3D_CAMERA_THIN_PRISM_FISHEYE)
+    throw Error(E3D_ERR_INVALID, "camera model must be PINHOLE, OPENCV or THIN_PRISM_FISHEYE");
+  if (n_parameters != cam_param_count(camera_type)) throw Error(E3D_ERR_INVALID, fmt("camera model %d takes %d parameters, got %d", camera_type, cam_param_count(camera_type), n_parameters));
   if (n_levels < 1 || n_levels > kRegMaxLevels || width < 2 || height < 2 || min_image_scale < 0) throw Error(E3D_ERR_INVALID, "bad pyramid description");
   Intrin in;
   in.type = camera_type; in.min_image_scale = min_image_scale; in.n_params = n_parameters;
   in.width = width; in.height = height;
   for (int i = 0; i < n_parameters; ++i) in.params[i] = parameters[i];
-  build_model_pyramid(in, n_levels);
+  build_model_pyramid(h, in, n_levels);
   h->intr[intrinsics_id] = in;
   return 0;
   R_CATCH()
@@ -784,8 +844,11 @@ int e3d_reg_get_intrinsics_level(e3d_reg_t* h, int intrinsics_id, int level, int
   const CamLevel& c = it->second.levels[level];
   if (width) *width = c.width;
   if (height) *height = c.height;
-  if (parameters) { parameters[0] = c.fx; parameters[1] = c.fy; parameters[2] = c.cx; parameters[3] = c.cy; }
-  if (cutoff2) *cutoff2 = c.cutoff2;
+  if (parameters) {
+    parameters[0] = c.fx; parameters[1] = c.fy; parameters[2] = c.cx; parameters[3] = c.cy;
+    for (int i = 4; i < it->second.n_params; ++i) parameters[i] = c.q[i - 4];
+  }
+  if (cutoff2) *cutoff2 = (c.model == kThinPrismFisheye) ? c.inner_cutoff2 : c.cutoff2;
   return 0;
   R_CATCH()
 }
@@ -867,8 +930,8 @@ int e3d_reg_render_depth(e3d_reg_t* h, int image_id, int image_scale, float* dep
   im.depth.reserve(px);
   hipLaunchKernelGGL(k_fill_f32, dim3(nblk(px)), dim3(kBlock), 0, h->stream, im.depth.p, px, INFINITY);
   if (h->n_splat)
-    hipLaunchKernelGGL(k_splat_depth, dim3(nblk(h->n_splat)), dim3(kBlock), 0, h->stream, h->splat.p, h->n_splat, im.pose, cam,
-                       h->prm.splat_radius, reinterpret_cast<unsigned*>(im.depth.p));
+    E3D_CAM_SWITCH(in.type, hipLaunchKernelGGL(k_splat_depth<M>, dim3(nblk(h->n_splat)), dim3(kBlock), 0, h->stream, h->splat.p,
+                                               h->n_splat, im.pose, cam, h->prm.splat_radius, reinterpret_cast<unsigned*>(im.depth.p)));
   if (depth_out) copy_out(depth_out, im.depth.p, sizeof(float) * px, h->stream);
   rsync(h);
   im.depth_scale = image_scale;
@@ -897,8 +960,9 @@ int64_t e3d_reg_observe(e3d_reg_t* h, int image_id, int point_scale, int image_s
   q.check = all ? 1 : 0;
   O.n = 0;
   if (count) {
-    hipLaunchKernelGGL(k_obs_eval, dim3(nblk(count)), dim3(kBlock), 0, s, S.pts.p, d_idx, count, im.pose, make_pyramid(h, im),
-                       all ? im.depth.p : nullptr, q, h->valid.p, h->tx.p, h->ty.p, h->ts.p);
+    E3D_CAM_SWITCH(image_model(h, im), hipLaunchKernelGGL(k_obs_eval<M>, dim3(nblk(count)), dim3(kBlock), 0, s, S.pts.p, d_idx, count,
+                                                          im.pose, make_pyramid(h, im), all ? im.depth.p : nullptr, q, h->valid.p,
+                                                          h->tx.p, h->ty.p, h->ts.p));
     const size_t nb = div_up(count, kBlock);
     h->block_counts.reserve(nb); h->block_offsets.reserve(nb); h->block_d2.reserve(nb);
     h->chunk_sum.reserve(div_up(nb, 256) + 1); h->chunk_d2.reserve(div_up(nb, 256) + 1);
@@ -960,14 +1024,16 @@ int e3d_reg_pass1(e3d_reg_t* h, int image_id, int point_scale, float* intensitie
   PointScale& S = get_scale(h, point_scale);
   Obs& O = get_obs(im, point_scale);
   prepare_rows(h, im, S, O);
-  std::vector<float> rows(12 * O.n);
-  copy_out(rows.data(), O.rows.p, sizeof(float) * 12 * O.n, h->stream);
+  const int I = cam_param_count(image_model(h, im));
+  const size_t stride = 4 * (size_t)rows4(I);
+  std::vector<float> rows(stride * O.n);
+  copy_out(rows.data(), O.rows.p, sizeof(float) * stride * O.n, h->stream);
   rsync(h);
   for (size_t i = 0; i < O.n; ++i) {
-    const float* r = rows.data() + 12 * i;
+    const float* r = rows.data() + stride * i;
     if (intensities) intensities[i] = r[0];
-    if (j_intrinsics) for (int c = 0; c < 4; ++c) j_intrinsics[4 * i + c] = r[1 + c];
-    if (j_pose) for (int c = 0; c < 6; ++c) j_pose[6 * i + c] = r[5 + c];
+    if (j_intrinsics) for (int c = 0; c < I; ++c) j_intrinsics[(size_t)I * i + c] = r[1 + c];
+    if (j_pose) for (int c = 0; c < 6; ++c) j_pose[6 * i + c] = r[1 + I + c];
   }
   return 0;
   R_CATCH()
@@ -982,21 +1048,28 @@ int e3d_reg_accumulate(e3d_reg_t* h, int image_id, int point_scale, double* H, d
   Obs& O = get_obs(im, point_scale);
   prepare_rows(h, im, S, O);
   const int nb = (int)std::min<size_t>(std::max<size_t>(div_up(O.n, kBlock * 4), 1), 1024);
-  h->partial.reserve((size_t)nb * kRegSlot); h->red.reserve(kRegSlot);
+  const int I = cam_param_count(image_model(h, im));
+  const int V = reg_v(I), NH = reg_h(I), slot = reg_slot(I);
+  h->partial.reserve((size_t)nb * slot); h->red.reserve(slot);
   const RegWeights w{h->prm.robust_weighting_type, h->prm.robust_weighting_parameter, h->prm.fixed_residuals_weight,
                      h->prm.variable_residuals_weight};
-  hipLaunchKernelGGL(k_reg_pass2<8>, dim3(nb), dim3(kBlock), 0, s, O.rows.p, O.idx.p, O.flags.p, O.n, S.nbr.p,
-                     h->prm.point_neighbor_count, S.row_of_point.p, S.fixed_desc.p, S.var_desc.p, S.obs_counts.p, w, h->partial.p);
-  hipLaunchKernelGGL(k_reg_reduce, dim3(kRegSlot), dim3(kWave), 0, s, h->partial.p, nb, kRegSlot, h->red.p);
-  double r[kRegSlot];
-  copy_out(r, h->red.p, sizeof r, s);
+#define E3D_PASS2(I_, R0_, R1_, B_)                                                                                              \
+  hipLaunchKernelGGL((k_reg_pass2<8, I_, R0_, R1_, B_>), dim3(nb), dim3(kBlock), 0, s, O.rows.p, O.idx.p, O.flags.p, O.n, S.nbr.p, \
+                     h->prm.point_neighbor_count, S.row_of_point.p, S.fixed_desc.p, S.var_desc.p, S.obs_counts.p, w, h->partial.p)
+  if (I == 4) { E3D_PASS2(4, 0, 10, true); }
+  else if (I == 8) { E3D_PASS2(8, 0, 4, true); E3D_PASS2(8, 4, 14, false); }
+  else { E3D_PASS2(12, 0, 3, true); E3D_PASS2(12, 3, 7, false); E3D_PASS2(12, 7, 18, false); }
+#undef E3D_PASS2
+  hipLaunchKernelGGL(k_reg_reduce, dim3(slot), dim3(kWave), 0, s, h->partial.p, nb, slot, h->red.p);
+  std::vector<double> r(slot);
+  copy_out(r.data(), h->red.p, sizeof(double) * slot, s);
   rsync(h);
-  std::fill(H, H + kRegV * kRegV, 0.0);
+  std::fill(H, H + V * V, 0.0);
   int e = 0;
-  for (int i = 0; i < kRegV; ++i) for (int j = i; j < kRegV; ++j) H[i * kRegV + j] = r[e++];
-  for (int i = 0; i < kRegV; ++i) b[i] = r[kRegH + i];
-  sums[0] = r[kRegH + kRegV]; sums[1] = r[kRegH + kRegV + 1];
-  counts[0] = (int64_t)r[kRegH + kRegV + 2]; counts[1] = (int64_t)r[kRegH + kRegV + 3];
+  for (int i = 0; i < V; ++i) for (int j = i; j < V; ++j) H[i * V + j] = r[e++];
+  for (int i = 0; i < V; ++i) b[i] = r[NH + i];
+  sums[0] = r[NH + V]; sums[1] = r[NH + V + 1];
+  counts[0] = (int64_t)r[NH + V + 2]; counts[1] = (int64_t)r[NH + V + 3];
   return 0;
   R_CATCH()
 }
@@ -1010,7 +1083,7 @@ int e3d_reg_cost(e3d_reg_t* h, int image_id, int point_scale, double sums[2], in
   Obs& O = get_obs(im, point_scale);
   dense_intensities(h, im, S, O);
   const int nb = (int)std::min<size_t>(std::max<size_t>(div_up(O.n, kBlock * 4), 1), 1024);
-  h->partial.reserve((size_t)nb * kRegSlot); h->red.reserve(kRegSlot);
+  h->partial.reserve((size_t)nb * 4); h->red.reserve(4);
   const RegWeights w{h->prm.robust_weighting_type, h->prm.robust_weighting_parameter, h->prm.fixed_residuals_weight,
                      h->prm.variable_residuals_weight};
   hipLaunchKernelGGL(k_reg_cost, dim3(nb), dim3(kBlock), 0, s, S.intensity.p, O.idx.p, O.flags.p, O.n, S.nbr.p,
@@ -1064,7 +1137,7 @@ int e3d_reg_color_finish(e3d_reg_t* h, int point_scale) {
 // Optimizer driver (host): the alternation of opt::Optimizer::RunOnCurrentScale (src/opt/optimizer.cc:49-182) and
 // IntrinsicsAndPoseOptimizer::Apply (src/opt/intrinsics_and_pose_optimizer.cc:48-259) over the kernel-level operators above.
 // Images are visited in ascending image id (the reference iterates an unordered_map, whose order is unspecified).
-// Non-rig images, PINHOLE, colour residuals.
+// Non-rig images, colour residuals.
 // =====================================================================================================================================
 }  // extern "C"
 
@@ -1171,13 +1244,15 @@ static void apply_update(e3d_reg* h, bool print, bool* applied_update, float* la
       buf->reserve(O.n);
       if (O.n) E3D_HIP(hipMemcpyAsync(buf->p, O.idx.p, sizeof(unsigned) * O.n, hipMemcpyDeviceToDevice, s));
       vis[kv.first][sc.first] = {buf, O.n};
-      double Hl[kRegV * kRegV], bl[kRegV], s2[2]; int64_t c2[2];
-      if (e3d_reg_accumulate(h, kv.first, sc.first, Hl, bl, s2, c2) < 0) throw Error(E3D_ERR_INVALID, e3d_last_error());
+      const int Vl = I + 6;
+      std::vector<double> Hl((size_t)Vl * Vl), bl(Vl);
+      double s2[2]; int64_t c2[2];
+      if (e3d_reg_accumulate(h, kv.first, sc.first, Hl.data(), bl.data(), s2, c2) < 0) throw Error(E3D_ERR_INVALID, e3d_last_error());
       sums[0] += s2[0]; sums[1] += s2[1]; counts[0] += c2[0]; counts[1] += c2[1];
       // scatter the local [intrinsics(I), pose(6)] block (AccumulateOnHAndB's three block updates)
       auto gidx = [&](int l) { return l < I ? ii + l : pi + (l - I); };
       for (int r = 0; r < I + 6; ++r) {
-        for (int c = r; c < I + 6; ++c) H[(size_t)gidx(r) * V + gidx(c)] += Hl[r * kRegV + c];
+        for (int c = r; c < I + 6; ++c) H[(size_t)gidx(r) * V + gidx(c)] += Hl[(size_t)r * Vl + c];
         b[gidx(r)] += bl[r];
       }
     }
@@ -1202,7 +1277,7 @@ static void apply_update(e3d_reg* h, bool print, bool* applied_update, float* la
       Intrin& in = kv.second;
       const int base = intr_index.at(kv.first);
       for (int i = 0; i < in.n_params; ++i) in.params[i] += -1 * x[base + i];      // float += double (intrinsics.cc:71-73)
-      build_model_pyramid(in, (int)in.levels.size());
+      build_model_pyramid(h, in, (int)in.levels.size());
     }
     for (auto& kv : trial.poses) kv.second = se3_apply_update(&x[image_index.at(kv.first)], old_state.poses.at(kv.first));   // exp(-x) * T
     // ComputeResidualForState with the visibility lists fixed

@@ -181,7 +181,12 @@ typedef struct {
   int32_t image_scale_count;           /* Problem::image_scale_count()                                  */
 } e3d_reg_params;
 
-#define E3D_CAMERA_PINHOLE 0
+/* camera models (COLMAP names, src/camera/camera_base.cc:66-77) and their parameter counts:
+ * PINHOLE fx fy cx cy (camera_pinhole.h:40-86); OPENCV + k1 k2 p1 p2 (camera_polynomial_tangential.h:41-159);
+ * THIN_PRISM_FISHEYE + k1 k2 p1 p2 k3 k4 sx1 sy1 (camera_benchmark.h:44-52) */
+#define E3D_CAMERA_PINHOLE 0             /* I = 4  */
+#define E3D_CAMERA_OPENCV 1              /* I = 8  */
+#define E3D_CAMERA_THIN_PRISM_FISHEYE 2  /* I = 12 */
 
 e3d_reg_t* e3d_reg_create(const e3d_reg_params* params);
 void e3d_reg_destroy(e3d_reg_t* reg);
@@ -200,7 +205,8 @@ int e3d_reg_get_variable_descriptors(e3d_reg_t* reg, int point_scale, float* des
  * (intrinsics.cc:46-51, camera_base_impl.h:70-89) and radius cut-offs (camera_base_impl.h:410-463). */
 int e3d_reg_set_intrinsics(e3d_reg_t* reg, int intrinsics_id, int camera_type, int width, int height,
                            const float* parameters, int n_parameters, int min_image_scale, int n_levels);
-/* queries the pyramid the library built: widths/heights (n_levels), parameters (n_levels x n_parameters), cut-offs */
+/* queries one level of the pyramid the library built: size, parameters (n_parameters floats) and the radius cut-off
+ * (+inf for PINHOLE; for THIN_PRISM_FISHEYE the cut-off of the inner thin-prism model, which is the one projection tests) */
 int e3d_reg_get_intrinsics_level(e3d_reg_t* reg, int intrinsics_id, int level, int* width, int* height,
                                  float* parameters, float* radius_cutoff_squared);
 /* opt::Image: u8 pyramid (level l has the size of intrinsics level l) and optional masks; pose image_T_global as the

@@ -43,7 +43,43 @@ def texture(u, v):
     return 120 + 55 * np.sin(7.0 * u) * np.cos(5.0 * v) + 35 * np.sin(3.0 * u + 4.0 * v) + 20 * np.cos(11.0 * v - 2.0 * u)
 
 
-def make_multi_image_scene(n_points=5000, n_images=3, width=240, height=180, n_levels=3, K=5, seed=0, perturb=0.01):
+# distortion parameter sets of the test scenes, keyed by camera model (0 PINHOLE, 1 OPENCV, 2 THIN_PRISM_FISHEYE)
+DISTORTION = {
+    0: [],
+    1: [-0.101082, 0.0703954, 0.000438661, -0.000680887],
+    2: [0.0221184, 0.0128597, 0.000531602, -0.000388873, 0.00623079, 0.0020419, -0.000805024, 4.07704e-05],
+}
+
+
+def distort_np(model, q, nx, ny):
+    """float64 numpy version of the models' Distort (only for synthesising consistent test images)."""
+    if model == 0:
+        return nx, ny
+    if model == 2:
+        r = np.sqrt(nx * nx + ny * ny)
+        f = np.where(r > 1e-6, np.arctan(r) / np.maximum(r, 1e-12), 1.0)
+        nx, ny = nx * f, ny * f
+    x2, xy, y2 = nx * nx, nx * ny, ny * ny
+    r2 = x2 + y2
+    k1, k2, p1, p2 = q[:4]
+    if model == 1:
+        radial = 1 + r2 * (k1 + r2 * k2)
+        return nx * radial + 2 * p1 * xy + p2 * (r2 + 2 * x2), ny * radial + 2 * p2 * xy + p1 * (r2 + 2 * y2)
+    k3, k4, sx1, sy1 = q[4:8]
+    radial = 1 + r2 * (k1 + r2 * (k2 + r2 * (k3 + r2 * k4)))
+    return (nx * radial + 2 * p1 * xy + p2 * (r2 + 2 * x2) + sx1 * r2, ny * radial + 2 * p2 * xy + p1 * (r2 + 2 * y2) + sy1 * r2)
+
+
+def undistort_np(model, q, dx, dy, iters=30):
+    """Inverse of distort_np by fixed-point iteration on the normalized coordinates (mild distortions only)."""
+    nx, ny = dx.copy(), dy.copy()
+    for _ in range(iters):
+        ex, ey = distort_np(model, q, nx, ny)
+        nx, ny = nx - (ex - dx), ny - (ey - dy)
+    return nx, ny
+
+
+def make_multi_image_scene(n_points=5000, n_images=3, width=240, height=180, n_levels=3, K=5, seed=0, perturb=0.01, model=0):
     """Planar textured wall (y = 3) seen by several pinhole cameras whose images are ray-traced from the texture, so that
     the true poses minimise the photometric cost; returns true and perturbed poses."""
     from scipy.spatial import cKDTree
@@ -54,14 +90,15 @@ def make_multi_image_scene(n_points=5000, n_images=3, width=240, height=180, n_l
     nbr = nn[:, 1:].astype(np.uint32)
     tex = texture(pts[:, 0].astype(np.float64), pts[:, 2].astype(np.float64))
     fixed_desc = (tex[nbr] - tex[:, None]).astype(np.float32)
-    params = np.array([210.0, 208.0, width / 2 - 0.4, height / 2 + 0.3], np.float32)
+    params = np.array([210.0, 208.0, width / 2 - 0.4, height / 2 + 0.3] + DISTORTION[model], np.float32)
     eyes = [(-0.35, -0.3, 0.1), (0.3, -0.2, -0.08), (0.02, -0.45, 0.2), (0.2, -0.5, -0.15)][:n_images]
     images = []
     for i, eye in enumerate(eyes):
         R0, t0 = look_at_pose(eye, (0.05 * i, 3, 0.02 * i))
         q = quat_from_R(R0); R = quat_to_R(q).astype(np.float64); t = t0.astype(np.float64)
         yy, xx = np.mgrid[0:height, 0:width].astype(np.float64)
-        d = np.stack([(xx - params[2]) / params[0], (yy - params[3]) / params[1], np.ones_like(xx)], -1) @ R     # R^T * dir
+        unx, uny = undistort_np(model, [float(v) for v in params[4:]], (xx - params[2]) / params[0], (yy - params[3]) / params[1])
+        d = np.stack([unx, uny, np.ones_like(xx)], -1) @ R     # R^T * dir
         o = -R.T @ t
         lam = (3.0 - o[1]) / d[..., 1]
         hit = o + lam[..., None] * d
@@ -74,10 +111,10 @@ def make_multi_image_scene(n_points=5000, n_images=3, width=240, height=180, n_l
         Rp = Rotation.from_rotvec(dq).as_matrix() @ R
         images.append(dict(q_true=q, t_true=t0.astype(np.float32), q_init=quat_from_R(Rp), t_init=(t + dt).astype(np.float32), pyr=pyr))
     return dict(pts=pts, nbr=nbr, K=K, fixed_desc=fixed_desc, params=params, width=width, height=height, n_levels=n_levels,
-                images=images, point_radius=0.01)
+                images=images, point_radius=0.01, model=model)
 
 
-def make_reg_scene(n_points=6000, width=320, height=240, n_levels=4, K=5, seed=0):
+def make_reg_scene(n_points=6000, width=320, height=240, n_levels=4, K=5, seed=0, model=0):
     """A textured, slightly wavy wall seen by a pinhole camera: points + neighbour graph + descriptors + image pyramid."""
     rng = np.random.RandomState(seed)
     u = rng.uniform(-1.2, 1.2, n_points); v = rng.uniform(-0.9, 0.9, n_points)
@@ -94,9 +131,9 @@ def make_reg_scene(n_points=6000, width=320, height=240, n_levels=4, K=5, seed=0
     R0, t = look_at_pose((0.1, -0.4, 0.05), (0, 3, 0))
     q = quat_from_R(R0)
     R = quat_to_R(q)          # so3().matrix() of the stored quaternion: what both implementations actually use
-    params = np.array([260.0, 255.0, width / 2 - 0.3, height / 2 + 0.2], np.float32)
+    params = np.array([260.0, 255.0, width / 2 - 0.3, height / 2 + 0.2] + DISTORTION[model], np.float32)
     fixed_desc = rng.normal(0, 8, (n_points, K)).astype(np.float32)
     var_desc = rng.normal(0, 8, (n_points, K)).astype(np.float32)
     obs_counts = rng.randint(0, 4, n_points).astype(np.int32)
     return dict(pts=pts, nbr=nbr, K=K, pyr=pyr, R=R, q=q, t=t, params=params, width=width, height=height, n_levels=n_levels,
-                fixed_desc=fixed_desc, var_desc=var_desc, obs_counts=obs_counts, point_radius=0.012)
+                fixed_desc=fixed_desc, var_desc=var_desc, obs_counts=obs_counts, point_radius=0.012, model=model)

@@ -19,34 +19,46 @@ def rb():
 def _setup(e3d, rb, S, **pk):
     prm = e3d.default_reg_params(image_scale_count=S["n_levels"], point_neighbor_count=S["K"], **pk)
     P = e3d.RegProblem(prm)
-    P.set_intrinsics(0, S["width"], S["height"], S["params"], 0, S["n_levels"])
+    P.set_intrinsics(0, S["width"], S["height"], S["params"], 0, S["n_levels"], camera_type=S["model"])
     P.set_image(0, 0, S["pyr"], S.get("masks"))
     P.set_image_pose(0, S["q"], S["t"])
     P.set_point_scale(0, S["pts"], S["point_radius"], S["nbr"], S["fixed_desc"])
     P.set_variable_descriptors(0, S["var_desc"], S["obs_counts"])
     P.set_splat_points(S["pts"])
-    cam = rb.make_camera(S["width"], S["height"], S["params"])
+    cam = rb.make_camera(S["width"], S["height"], S["params"], S["model"])
     levels = rb.camera_pyramid(cam, S["n_levels"])
     return P, levels
 
 
-def test_camera_pyramid_matches(e3d, rb):
-    S = make_reg_scene()
+MODELS = [0, 1, 2]          # PINHOLE, OPENCV, THIN_PRISM_FISHEYE
+EXACT = [0, 1]              # models without transcendental functions: device == host bit for bit
+
+
+@pytest.mark.parametrize("model", MODELS)
+def test_camera_pyramid_matches(e3d, rb, model):
+    """ScaledBy pyramid and the InitCutoff radius (device kernel vs the oracle's host loop): bit-exact."""
+    S = make_reg_scene(model=model)
     P, levels = _setup(e3d, rb, S)
     for l in range(S["n_levels"]):
         w, h, p, c = P.intrinsics_level(0, l)
         assert (w, h) == (levels[l].width, levels[l].height)
-        assert np.array_equal(p, levels[l].params()) and c == levels[l].cutoff2
+        assert np.array_equal(p, levels[l].params())
+        co = levels[l].inner_cutoff2 if model == 2 else levels[l].cutoff2
+        assert c == co and (np.isinf(c) if model == 0 else np.isfinite(c))
 
 
+@pytest.mark.parametrize("model", MODELS)
 @pytest.mark.parametrize("scale", [0, 1])
-def test_splat_depth_bit_exact(e3d, rb, scale):
-    S = make_reg_scene(n_points=20000)
+def test_splat_depth_bit_exact(e3d, rb, scale, model):
+    S = make_reg_scene(n_points=20000, model=model)
     P, levels = _setup(e3d, rb, S)
     g = P.render_depth(0, scale, (levels[scale].height, levels[scale].width))
     o = rb.splat_depth(S["pts"], S["R"], S["t"], levels[scale], 0.03)
-    assert np.array_equal(g.view(np.uint32), o.view(np.uint32))
     assert np.isfinite(g).sum() > 1000
+    if model in EXACT:
+        assert np.array_equal(g.view(np.uint32), o.view(np.uint32))
+    else:   # atan2f: device vs glibc may differ in the last ulp -> a splat rectangle may move by one pixel in rare cases
+        assert (g.view(np.uint32) != o.view(np.uint32)).mean() < 1e-3
 
 
 def _observe_both(e3d, rb, S, P, levels, border=1, image_scale=0, masks=None):
@@ -60,8 +72,9 @@ def _observe_both(e3d, rb, S, P, levels, border=1, image_scale=0, masks=None):
     return g, o, of
 
 
-def test_observations_match_oracle(e3d, rb):
-    S = make_reg_scene(n_points=30000, seed=1)
+@pytest.mark.parametrize("model", MODELS)
+def test_observations_match_oracle(e3d, rb, model):
+    S = make_reg_scene(n_points=30000, seed=1, model=model)
     mask = np.zeros_like(S["pyr"][0]); mask[100:140, 50:120] = 1
     masks = [mask]
     for _ in range(1, S["n_levels"]):
@@ -72,32 +85,42 @@ def test_observations_match_oracle(e3d, rb):
     g, o, of = _observe_both(e3d, rb, S, P, levels, masks=masks)
     assert len(g[0]) == len(o[0]) > 5000
     assert np.array_equal(g[0], o[0])                                        # same points, same (point) order
-    assert np.array_equal(g[1].view(np.uint32), o[1].view(np.uint32)) and np.array_equal(g[2].view(np.uint32), o[2].view(np.uint32))
-    assert np.abs(g[3] - o[3]).max() <= 4e-7 * np.abs(o[3]).max() + 1e-7      # log2f: device vs glibc, last ulp
+    if model in EXACT:
+        assert np.array_equal(g[1].view(np.uint32), o[1].view(np.uint32)) and np.array_equal(g[2].view(np.uint32), o[2].view(np.uint32))
+        assert np.abs(g[3] - o[3]).max() <= 4e-7 * np.abs(o[3]).max() + 1e-7      # log2f: device vs glibc, last ulp
+    else:
+        assert np.abs(g[1] - o[1]).max() <= 1e-4 and np.abs(g[2] - o[2]).max() <= 1e-4     # atan2f last-ulp differences
+        assert np.abs(g[3] - o[3]).max() <= 1e-3
     assert np.array_equal(g[4], of)
     # indexed variant (fixed visibility list, no occlusion / mask tests)
     n2 = P.observe(0, 0, 0, 1, indices=o[0][::3])
     g2 = P.get_observations(0, 0, n2)
     o2 = rb.observe(S["pts"], S["point_radius"], S["R"], S["t"], levels, 0, S["pyr"], None, None, 0, 1, 0, S["n_levels"], indices=o[0][::3])
-    assert np.array_equal(g2[0], o2[0]) and np.array_equal(g2[1].view(np.uint32), o2[1].view(np.uint32))
+    assert np.array_equal(g2[0], o2[0])
+    assert np.array_equal(g2[1].view(np.uint32), o2[1].view(np.uint32)) if model in EXACT else np.abs(g2[1] - o2[1]).max() <= 1e-4
     assert np.array_equal(g2[4], rb.neighbors_observed(len(S["pts"]), o2[0], S["nbr"], S["K"]))
 
 
-def test_pass1_rows(e3d, rb):
-    S = make_reg_scene(n_points=20000, seed=2)
+@pytest.mark.parametrize("model", MODELS)
+def test_pass1_rows(e3d, rb, model):
+    S = make_reg_scene(n_points=20000, seed=2, model=model)
     P, levels = _setup(e3d, rb, S)
     g, o, of = _observe_both(e3d, rb, S, P, levels)
     P.set_observations(0, 0, *o)                       # identical inputs (incl. scale) for both sides
     I, ji, jp = P.pass1(0, 0, len(o[0]))
     Io, jio, jpo = rb.pass1(S["pts"], S["point_radius"], levels[0], 0, S["pyr"], S["R"], S["t"], o)
     assert np.array_equal(I.view(np.uint32), Io.view(np.uint32))
-    assert np.abs(ji - jio).max() <= 1e-5 * np.abs(jio).max()
-    assert np.abs(jp - jpo).max() <= 1e-5 * np.abs(jpo).max()
+    assert ji.shape == jio.shape == (len(o[0]), rb.PARAM_COUNT[model])
+    tol = 1e-5 if model in EXACT else 2e-4
+    for c in range(ji.shape[1]):                       # per parameter column (their magnitudes differ by orders)
+        assert np.abs(ji[:, c] - jio[:, c]).max() <= tol * np.abs(jio[:, c]).max() + 1e-30, c
+    assert np.abs(jp - jpo).max() <= tol * np.abs(jpo).max()
 
 
-@pytest.mark.parametrize("rtype,rparam", [(1, 47.434166), (2, 30.0), (0, 0.0)])
-def test_accumulate_and_cost(e3d, rb, rtype, rparam):
-    S = make_reg_scene(n_points=40000, seed=3)
+@pytest.mark.parametrize("model,rtype,rparam", [(0, 1, 47.434166), (0, 2, 30.0), (0, 0, 0.0), (1, 1, 47.434166), (2, 1, 47.434166),
+                                                (2, 2, 30.0)])
+def test_accumulate_and_cost(e3d, rb, model, rtype, rparam):
+    S = make_reg_scene(n_points=40000, seed=3, model=model)
     P, levels = _setup(e3d, rb, S, robust_weighting_type=rtype, robust_weighting_parameter=rparam)
     g, o, of = _observe_both(e3d, rb, S, P, levels)
     P.set_observations(0, 0, *o)
@@ -106,8 +129,13 @@ def test_accumulate_and_cost(e3d, rb, rtype, rparam):
                                    S["pyr"], S["R"], S["t"], o, of, rtype, rparam, 1.0, 1.0)
     assert np.array_equal(counts, co) and counts[0] > 1000 and counts[1] > 100
     assert np.abs(sums - so).max() <= 1e-9 * np.abs(so).max()
-    assert np.abs(H - Ho).max() <= 1e-6 * np.abs(Ho).max()
-    assert np.abs(b - bo).max() <= 1e-5 * np.abs(bo).max()
+    V = rb.PARAM_COUNT[model] + 6
+    assert H.shape == Ho.shape == (V, V)
+    assert np.array_equal(np.tril(H, -1), np.zeros_like(H))                 # upper triangle only, like the reference's H
+    scale = np.sqrt(np.outer(np.diag(Ho), np.diag(Ho)))                     # entries span many orders of magnitude
+    tol = 1e-6 if model in EXACT else 1e-4
+    assert (np.abs(H - Ho) / scale).max() <= tol
+    assert (np.abs(b - bo) / np.sqrt(np.diag(Ho))).max() <= tol * np.abs(bo / np.sqrt(np.diag(Ho))).max() * 10
     s2, c2 = P.cost(0, 0)
     so2, co2 = rb.cost(len(S["pts"]), S["nbr"], S["K"], S["fixed_desc"], S["var_desc"], S["obs_counts"], 0, S["pyr"], o, of, rtype, rparam, 1.0, 1.0)
     assert np.array_equal(c2, co2) and np.abs(s2 - so2).max() <= 1e-12 * np.abs(so2).max()
@@ -137,7 +165,9 @@ def test_reg_errors(e3d):
     with pytest.raises(e3d.E3DError):
         P.observe(0, 0, 0, 1)
     with pytest.raises(e3d.E3DError):
-        P.set_intrinsics(0, 64, 48, [50, 50, 32, 24, 0.1, 0, 0, 0], 0, 2, camera_type=2)   # only PINHOLE so far
+        P.set_intrinsics(0, 64, 48, [50, 50, 32, 24, 0.1, 0, 0, 0], 0, 2, camera_type=2)   # THIN_PRISM_FISHEYE takes 12 parameters
+    with pytest.raises(e3d.E3DError):
+        P.set_intrinsics(0, 64, 48, [50, 50, 32, 24], 0, 2, camera_type=7)
 
 
 # ---- optimizer driver (Optimizer::RunOnCurrentScale / IntrinsicsAndPoseOptimizer::Apply) ---------------------------------------
@@ -147,7 +177,10 @@ def _build_both(e3d, M, var_weight=1.0):
     G = e3d.RegProblem(prm)
     O = OracleRegProblem(K=M["K"], image_scale_count=M["n_levels"], var_weight=var_weight)
     for P in (G, O):
-        P.set_intrinsics(0, M["width"], M["height"], M["params"], 0, M["n_levels"])
+        if P is G:
+            P.set_intrinsics(0, M["width"], M["height"], M["params"], 0, M["n_levels"], camera_type=M["model"])
+        else:
+            P.set_intrinsics(0, M["width"], M["height"], M["params"], 0, M["n_levels"], model=M["model"])
         P.set_point_scale(0, M["pts"], M["point_radius"], M["nbr"], M["fixed_desc"])
         P.set_splat_points(M["pts"])
         for i, im in enumerate(M["images"]):
@@ -164,9 +197,10 @@ def _pose_delta(qa, ta, qb, tb):
     return ang, np.linalg.norm(ta.astype(np.float64) - tb.astype(np.float64))
 
 
-def test_whole_problem_steps_match_oracle(e3d):
+@pytest.mark.parametrize("model", MODELS)
+def test_whole_problem_steps_match_oracle(e3d, model):
     from reg_util import make_multi_image_scene
-    M = make_multi_image_scene(n_points=6000, n_images=3, seed=5)
+    M = make_multi_image_scene(n_points=6000, n_images=3, seed=5, model=model)
     G, O = _build_both(e3d, M)
     G.update_observations(1); O.update_observations(1)
     for i in range(3):
@@ -184,13 +218,14 @@ def test_whole_problem_steps_match_oracle(e3d):
         ang, tr = _pose_delta(*G.get_image_pose(i), *O.get_image_pose(i))
         assert ang <= 1e-5 and tr <= 1e-5
     w, h, pg, _ = G.intrinsics_level(0, 0)
-    assert np.abs(pg - O.intr[0]["params"]).max() <= 1e-3
+    po = O.intr[0]["params"]
+    assert np.abs(pg[:4] - po[:4]).max() <= 1e-3 and np.abs(pg[4:] - po[4:]).max() <= 1e-5 if len(pg) > 4 else True
 
 
-@pytest.mark.parametrize("var_weight", [1.0, 0.0])
-def test_run_on_current_scale_matches_oracle_and_improves(e3d, var_weight):
+@pytest.mark.parametrize("model,var_weight", [(0, 1.0), (0, 0.0), (1, 1.0), (2, 1.0)])
+def test_run_on_current_scale_matches_oracle_and_improves(e3d, model, var_weight):
     from reg_util import make_multi_image_scene
-    M = make_multi_image_scene(n_points=6000, n_images=3, seed=6, perturb=0.006)
+    M = make_multi_image_scene(n_points=6000, n_images=3, seed=6, perturb=0.006, model=model)
     G, O = _build_both(e3d, M, var_weight)
     cg, costg, itg = G.run_on_current_scale(8, 0.0, 15, False)
     co, costo, ito = O.run_on_current_scale(8, 0.0, 15, False)

@@ -68,6 +68,70 @@ def cpu_baseline(scans, d, thr, slab):
     }
 
 
+def image_registrator_leg(e3d, synth, cpu=True):
+    """Second BASELINE.json metric: ImageRegistrator residuals/s = (#fixed + #variable colour residuals) / wall time of the
+    accumulate pass of IntrinsicsAndPoseOptimizer::Apply (src/opt/intrinsics_and_pose_optimizer.cc:87-92,624-837) over all
+    images of one GPU; also ms per full RunOnCurrentScale iteration.  4 synthetic 3840x2160 images (6 pyramid levels,
+    configs[4] shape), 4 M points, K = 5, for the 4-parameter PINHOLE and the 12-parameter THIN_PRISM_FISHEYE model."""
+    out = {}
+    for model, name in ((0, "PINHOLE"), (2, "THIN_PRISM_FISHEYE")):
+        Wl = synth.make_reg_workload(n_points=4_000_000, n_images=4, model=model)
+        P = e3d.RegProblem(e3d.default_reg_params(image_scale_count=Wl["n_levels"], point_neighbor_count=Wl["K"]))
+        P.set_intrinsics(0, Wl["width"], Wl["height"], Wl["params"], 0, Wl["n_levels"], camera_type=model)
+        P.set_point_scale(0, Wl["pts"], Wl["point_radius"], Wl["nbr"], Wl["fixed_desc"])
+        P.set_splat_points(Wl["pts"])
+        ids = list(range(len(Wl["images"])))
+        for i, im in enumerate(Wl["images"]):
+            P.set_image(i, 0, im["pyr"]); P.set_image_pose(i, im["q"], im["t"])
+        t0 = time.perf_counter(); P.update_observations(1); t_obs = time.perf_counter() - t0
+        t0 = time.perf_counter(); P.color_update(); t_col = time.perf_counter() - t0
+        for i in ids:
+            P.accumulate(i, 0)
+        reps = 3
+        t0 = time.perf_counter()
+        res = 0
+        for _ in range(reps):
+            for i in ids:
+                _, _, _, c = P.accumulate(i, 0)
+                res += int(c[0] + c[1])
+        t_acc = (time.perf_counter() - t0) / reps
+        res //= reps
+        t0 = time.perf_counter(); P.compute_cost(); t_cost = time.perf_counter() - t0
+        t0 = time.perf_counter(); _, _, its = P.run_on_current_scale(2, 0.0, 15, False); t_run = time.perf_counter() - t0
+        I = len(Wl["params"]); r4 = (I + 10) // 4; K = Wl["K"]
+        obs = res // 2
+        alg = obs * (16 * r4 + K * (8 + 16 * r4) + 8 * K + 9)          # own row + K x (index, row slot, neighbour row) + descriptors + idx/flag/count
+        out[name] = {"residuals_per_s": res / t_acc, "accumulate_ms": t_acc * 1e3, "images": len(ids), "points": len(Wl["pts"]),
+                     "residuals": res, "unknowns_per_image_block": I + 6,
+                     "observation_refresh_ms": t_obs * 1e3, "colour_update_ms": t_col * 1e3, "cost_ms": t_cost * 1e3,
+                     "ms_per_run_iteration": t_run / max(its, 1) * 1e3,
+                     "roofline": {"bound": "hbm", "achieved": alg / t_acc / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": alg / t_acc / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                                  "kernel": "k_reg_pass1 + k_reg_pass2 (+ reduce, read-back) of e3d_reg_accumulate",
+                                  "algorithmic_bytes": alg}}
+        del P
+    if cpu:
+        from oracle import reg_binding as rb
+        from oracle.reg_driver import OracleRegProblem
+        Wl = synth.make_reg_workload(n_points=4_000_000, n_images=1, model=0)
+        O = OracleRegProblem(K=Wl["K"], image_scale_count=Wl["n_levels"])
+        O.set_intrinsics(0, Wl["width"], Wl["height"], Wl["params"], 0, Wl["n_levels"])
+        O.set_point_scale(0, Wl["pts"], Wl["point_radius"], Wl["nbr"], Wl["fixed_desc"])
+        O.set_splat_points(Wl["pts"])
+        O.set_image(0, 0, Wl["images"][0]["pyr"]); O.set_image_pose(0, Wl["images"][0]["q"], Wl["images"][0]["t"])
+        O.update_observations(1); O.color_update()
+        S = O.scales[0]; im = O.images[0]; I0 = O.intr[0]; o = O.obs[(0, 0)]
+        t0 = time.perf_counter()
+        _, _, _, c = rb.accumulate(S["pts"], float(S["radius"]), S["nbr"], O.K, S["fixed"], S["var"], S["counts"], I0["levels"][0], I0["min"],
+                                   im["pyr"], O._R(im), im["t"], o[:4], o[4], O.robust_type, O.robust_param, O.fixed_weight, O.var_weight)
+        tc = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": float(c[0] + c[1]) / tc, "unit": "residuals/s", "cores": 1, "kind": "port",
+                               "sample": "accumulate pass (oracle_reg_accumulate, single thread like the reference) of one 3840x2160 "
+                                         "PINHOLE image, 4 M points, K = 5: %d residuals in %.2f s" % (int(c[0] + c[1]), tc)}
+        out["speedup_vs_cpu"] = out["PINHOLE"]["residuals_per_s"] / out["cpu_baseline"]["value"]
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -76,6 +140,7 @@ def main():
     ap.add_argument("--points", type=int, default=0, help="points per scan (default 50 M x gpus)")
     ap.add_argument("--distance", type=float, default=0.01)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-reg", action="store_true", help="skip the ImageRegistrator leg (N=1 only)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -163,6 +228,11 @@ def main():
     else:
         tot = local
     if rank == 0:
+        reg_leg = None
+        if world == 1 and not args.no_reg:
+            del icp
+            torch.cuda.empty_cache()
+            reg_leg = image_registrator_leg(e3d, synth, cpu=not args.no_cpu_baseline)
         K = args.steps
         corr, queries = tot[1], tot[2]
         lm_ms, nn_ms, passes = tot[3] / world, tot[4] / world, tot[5] / world
@@ -210,6 +280,8 @@ def main():
                          "other": {"k_lm_pass_GBs": (ALG_BYTES_PER_CORR_PASS * corr / world / K) / (lm_ms / max(passes, 1) * 1e-3) / 1e9 if lm_ms > 0 else None,
                                    "k_nn_query_GBs": (ALG_BYTES_PER_QUERY * queries / world / n_nn_launch) / (nn_ms / n_nn_launch * 1e-3) / 1e9 if nn_ms > 0 else None}},
         }
+        if world == 1 and not args.no_reg:
+            out["image_registrator"] = reg_leg
         if base is not None:
             out["cpu_baseline"] = base
             out["speedup_vs_cpu_iteration_rate"] = (base["ms_per_iter"] / base["correspondences"]) / ((dt / K * 1e3) / (corr / K))

@@ -107,15 +107,19 @@ __device__ __forceinline__ float robust_weight(int type, float param, float r) {
 }
 
 // ==== a24: OcclusionGeometry::_RenderDepthMapWithSplatsCPU ========================================================================
+// depth(x, y) = min z over all points whose splat rectangle covers (x, y): an order-free reduction, so the result is exact
+// whatever the schedule.  Splats overlap heavily (a 3 cm splat at 3 m is the 21 x 21 pixel maximum; scan points are
+// millimetres apart), so instead of one global atomic per covered pixel the points are binned into 32 x 32 pixel tiles,
+// radix-sorted by tile, and each tile is reduced in LDS by one workgroup and written once.
+constexpr int kTile = 32;
+
+// the reference's rectangle of one point (occlusion_geometry.cc:423-452), clipped to the image; false if empty
 template <int M>
-__global__ __launch_bounds__(kBlock) void k_splat_depth(const float4* __restrict__ pts, size_t n, Pose P, CamLevel cam,
-                                                        float point_radius, unsigned* __restrict__ depth_bits) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const float4 p = pts[i];
+__device__ __forceinline__ bool splat_rect(const float4 p, const Pose& P, const CamLevel& cam, float point_radius, int& min_x, int& min_y,
+                                           int& end_x, int& end_y, unsigned& zb) {
   float X, Y, Z;
   rt(P, p.x, p.y, p.z, X, Y, Z);
-  if (!(Z > 0.f)) return;
+  if (!(Z > 0.f)) return false;
   float px, py, d[6];
   cam_normalized_to_image<M>(cam, X / Z, Y / Z, px, py);
   cam_image_deriv_by_world<M>(cam, X, Y, Z, d);
@@ -124,17 +128,95 @@ __global__ __launch_bounds__(kBlock) void k_splat_depth(const float4* __restrict
   rx = (10.f < rx) ? 10.f : rx;     // std::min(splat_radius, max_splat_radius)
   ry = (10.f < ry) ? 10.f : ry;
   const int ix = f2i(px + 0.5f), iy = f2i(py + 0.5f);
-  int min_x = d2i((double)((float)ix - rx) + 0.5), min_y = d2i((double)((float)iy - ry) + 0.5);
-  int end_x = d2i((double)((float)ix + rx) + 1.5), end_y = d2i((double)((float)iy + ry) + 1.5);
+  min_x = d2i((double)((float)ix - rx) + 0.5); min_y = d2i((double)((float)iy - ry) + 0.5);
+  end_x = d2i((double)((float)ix + rx) + 1.5); end_y = d2i((double)((float)iy + ry) + 1.5);
   min_x = max(min_x, 0); min_y = max(min_y, 0);
   end_x = min(end_x, cam.width); end_y = min(end_y, cam.height);
-  const unsigned zb = __float_as_uint(Z);      // Z > 0: the bit pattern is order preserving
-  for (int y = min_y; y < end_y; ++y)
-    for (int x = min_x; x < end_x; ++x) {
-      unsigned* a = &depth_bits[(size_t)y * cam.width + x];
-      // the depth only ever decreases, so a (possibly stale) larger-or-equal read is a safe reason to try; a smaller one to skip
-      if (zb < __hip_atomic_load(a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(a, zb);
-    }
+  zb = __float_as_uint(Z);          // Z > 0: the bit pattern is order preserving
+  return min_x < end_x && min_y < end_y;
+}
+
+// one (tile, point) pair per tile a rectangle touches (<= 2 x 2: rectangles are at most 22 pixels wide); wave-aggregated append
+template <int M>
+__global__ __launch_bounds__(kBlock) void k_splat_bin(const float4* __restrict__ pts, size_t n, Pose P, CamLevel cam,
+                                                      float point_radius, int tiles_x, uint4* __restrict__ rects,
+                                                      unsigned* __restrict__ keys, unsigned* __restrict__ vals,
+                                                      unsigned* __restrict__ counter) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int min_x = 0, min_y = 0, end_x = 0, end_y = 0;
+  unsigned zb = 0;
+  bool ok = false;
+  if (i < n) ok = splat_rect<M>(pts[i], P, cam, point_radius, min_x, min_y, end_x, end_y, zb);
+  int tx0 = 0, tx1 = -1, ty0 = 0, ty1 = -1;
+  if (ok) {
+    tx0 = min_x / kTile; tx1 = (end_x - 1) / kTile; ty0 = min_y / kTile; ty1 = (end_y - 1) / kTile;
+    rects[i] = make_uint4((unsigned)min_x | ((unsigned)min_y << 16), (unsigned)end_x | ((unsigned)end_y << 16), zb, 0u);
+  }
+  const unsigned count = ok ? (unsigned)((tx1 - tx0 + 1) * (ty1 - ty0 + 1)) : 0u;
+  const int lane = threadIdx.x & 63;
+  unsigned incl = count;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned v = __shfl_up(incl, o);
+    if (lane >= o) incl += v;
+  }
+  // one append per workgroup (a single hot address serialises: one atomic per wave costs more than the whole projection)
+  __shared__ unsigned wave_total[kBlock / kWave];
+  __shared__ unsigned block_base;
+  const int wv = threadIdx.x >> 6;
+  if (lane == 63) wave_total[wv] = incl;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned tot = 0;
+#pragma unroll
+    for (int k = 0; k < kBlock / kWave; ++k) tot += wave_total[k];
+    block_base = tot ? atomicAdd(counter, tot) : 0u;
+  }
+  __syncthreads();
+  unsigned base = block_base;
+  for (int k = 0; k < wv; ++k) base += wave_total[k];
+  unsigned o = base + incl - count;
+  for (int ty = ty0; ty <= ty1; ++ty)
+    for (int tx = tx0; tx <= tx1; ++tx) { keys[o] = (unsigned)(ty * tiles_x + tx); vals[o] = (unsigned)i; ++o; }
+}
+
+__global__ __launch_bounds__(kBlock) void k_tile_ranges(const unsigned* __restrict__ keys, size_t n, unsigned* __restrict__ start,
+                                                        unsigned* __restrict__ end) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const unsigned k = keys[i];
+  if (i == 0 || keys[i - 1] != k) start[k] = (unsigned)i;
+  if (i + 1 == n || keys[i + 1] != k) end[k] = (unsigned)(i + 1);
+}
+
+// one workgroup per tile: z-min of the tile's rectangles in LDS (ds_min_u32), every pixel of the tile written exactly once
+__global__ __launch_bounds__(kBlock) void k_splat_tiles(const uint4* __restrict__ rects, const unsigned* __restrict__ vals,
+                                                        const unsigned* __restrict__ start, const unsigned* __restrict__ end,
+                                                        int tiles_x, int width, int height, unsigned* __restrict__ depth_bits) {
+  __shared__ unsigned tile[kTile * kTile];
+  const int t = blockIdx.x;
+  const int x0 = (t % tiles_x) * kTile, y0 = (t / tiles_x) * kTile;
+  for (int i = threadIdx.x; i < kTile * kTile; i += kBlock) tile[i] = 0x7f800000u;
+  __syncthreads();
+  const unsigned s = start[t], e = end[t];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int lx = lane & 31, ly = lane >> 5;
+  constexpr unsigned kStep = kBlock / kWave;
+  uint4 nxt = (s + wv < e) ? rects[vals[s + wv]] : make_uint4(0, 0, 0, 0);
+  for (unsigned j = s + wv; j < e; j += kStep) {
+    const uint4 r = nxt;
+    if (j + kStep < e) nxt = rects[vals[j + kStep]];       // fetch the next rectangle while this one is applied
+    const int mx = max((int)(r.x & 0xffffu), x0) - x0, my = max((int)(r.x >> 16), y0) - y0;
+    const int ex = min((int)(r.y & 0xffffu), x0 + kTile) - x0, ey = min((int)(r.y >> 16), y0 + kTile) - y0;
+    const int x = mx + lx;
+    if (x < ex)
+      for (int y = my + ly; y < ey; y += 2) atomicMin(&tile[y * kTile + x], r.z);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < kTile * kTile; i += kBlock) {
+    const int x = x0 + (i & (kTile - 1)), y = y0 + (i / kTile);
+    if (x < width && y < height) depth_bits[(size_t)y * width + x] = tile[i];
+  }
 }
 
 // ==== a20 / a21: observation candidates =============================================================================================
@@ -560,6 +642,7 @@ struct Intrin {
   std::vector<CamLevel> levels;
 };
 struct Obs {
+  bool active = false;            // false: the reference would hold no vector for this (image, scale); buffers are kept for reuse
   size_t n = 0;
   DevBuf<unsigned> idx;
   DevBuf<float> x, y, s;
@@ -576,6 +659,7 @@ struct ImageDev {
   DevBuf<float> depth;            // last rendered occlusion depth (as float bits)
   int depth_scale = -1;
   std::map<int, Obs> obs;         // per point scale
+  std::map<int, DevBuf<unsigned>> vis;   // per point scale: visibility list of the running Apply (grow-only scratch)
 };
 
 static void set_pose(ImageDev& im, const SE3f& T) {
@@ -605,6 +689,10 @@ struct e3d_reg {
   DevBuf<unsigned long long> chunk_sum, d_total;
   DevBuf<float> dummy_d2;
   DevBuf<unsigned> cut;
+  // splat depth: per-point rectangles, (tile, point) pairs (double-buffered for the sort), tile ranges
+  DevBuf<uint4> rects;
+  DevBuf<unsigned> sp_keys[2], sp_vals[2], sp_counter, tile_start, tile_end;
+  DevBuf<char> sort_temp;
   ~e3d_reg() { if (stream) (void)hipStreamDestroy(stream); }
 };
 
@@ -688,9 +776,13 @@ static ImageDev& get_image(e3d_reg* h, int id) {
   if (it == h->images.end()) throw Error(E3D_ERR_INDEX, fmt("image %d not set", id));
   return it->second;
 }
+static bool has_obs(const ImageDev& im, int s) {
+  auto it = im.obs.find(s);
+  return it != im.obs.end() && it->second.active;
+}
 static Obs& get_obs(ImageDev& im, int s) {
   auto it = im.obs.find(s);
-  if (it == im.obs.end()) throw Error(E3D_ERR_INVALID, fmt("no observations for point scale %d (call e3d_reg_observe first)", s));
+  if (it == im.obs.end() || !it->second.active) throw Error(E3D_ERR_INVALID, fmt("no observations for point scale %d (call e3d_reg_observe first)", s));
   return it->second;
 }
 
@@ -928,10 +1020,36 @@ int e3d_reg_render_depth(e3d_reg_t* h, int image_id, int image_scale, float* dep
   const CamLevel& cam = in.levels[lvl];
   const size_t px = (size_t)cam.width * cam.height;
   im.depth.reserve(px);
-  hipLaunchKernelGGL(k_fill_f32, dim3(nblk(px)), dim3(kBlock), 0, h->stream, im.depth.p, px, INFINITY);
-  if (h->n_splat)
-    E3D_CAM_SWITCH(in.type, hipLaunchKernelGGL(k_splat_depth<M>, dim3(nblk(h->n_splat)), dim3(kBlock), 0, h->stream, h->splat.p,
-                                               h->n_splat, im.pose, cam, h->prm.splat_radius, reinterpret_cast<unsigned*>(im.depth.p)));
+  {
+    hipStream_t s = h->stream;
+    const size_t n = h->n_splat;
+    const int tiles_x = (int)div_up(cam.width, kTile), tiles_y = (int)div_up(cam.height, kTile);
+    const size_t n_tiles = (size_t)tiles_x * tiles_y;
+    if (cam.width > 65535 || cam.height > 65535) throw Error(E3D_ERR_INVALID, "image too large");
+    h->rects.reserve(n);
+    for (int k = 0; k < 2; ++k) { h->sp_keys[k].reserve(4 * n); h->sp_vals[k].reserve(4 * n); }
+    h->sp_counter.reserve(1); h->tile_start.reserve(n_tiles); h->tile_end.reserve(n_tiles);
+    E3D_HIP(hipMemsetAsync(h->sp_counter.p, 0, sizeof(unsigned), s));
+    E3D_HIP(hipMemsetAsync(h->tile_start.p, 0, sizeof(unsigned) * n_tiles, s));
+    E3D_HIP(hipMemsetAsync(h->tile_end.p, 0, sizeof(unsigned) * n_tiles, s));
+    unsigned n_pairs = 0;
+    if (n) {
+      E3D_CAM_SWITCH(in.type, hipLaunchKernelGGL(k_splat_bin<M>, dim3(nblk(n)), dim3(kBlock), 0, s, h->splat.p, n, im.pose, cam,
+                                                 h->prm.splat_radius, tiles_x, h->rects.p, h->sp_keys[0].p, h->sp_vals[0].p,
+                                                 h->sp_counter.p));
+      copy_out(&n_pairs, h->sp_counter.p, sizeof n_pairs, s);
+      rsync(h);
+    }
+    if (n_pairs) {
+      int bits = 1;
+      while (((size_t)1 << bits) < n_tiles) ++bits;
+      sort_pairs_u32_u32(h->sp_keys[0].p, h->sp_keys[1].p, h->sp_vals[0].p, h->sp_vals[1].p, n_pairs, bits, h->sort_temp, s);
+      hipLaunchKernelGGL(k_tile_ranges, dim3(nblk(n_pairs)), dim3(kBlock), 0, s, h->sp_keys[1].p, (size_t)n_pairs, h->tile_start.p,
+                         h->tile_end.p);
+    }
+    hipLaunchKernelGGL(k_splat_tiles, dim3((unsigned)n_tiles), dim3(kBlock), 0, s, h->rects.p, h->sp_vals[1].p, h->tile_start.p,
+                       h->tile_end.p, tiles_x, cam.width, cam.height, reinterpret_cast<unsigned*>(im.depth.p));
+  }
   if (depth_out) copy_out(depth_out, im.depth.p, sizeof(float) * px, h->stream);
   rsync(h);
   im.depth_scale = image_scale;
@@ -950,6 +1068,7 @@ int64_t e3d_reg_observe(e3d_reg_t* h, int image_id, int point_scale, int image_s
   if (all && im.depth_scale != image_scale) throw Error(E3D_ERR_INVALID, "render the occlusion depth map of this image and scale first (e3d_reg_render_depth)");
   const size_t count = all ? S.n : n_indices;
   Obs& O = im.obs[point_scale];
+  O.active = true;
   h->valid.reserve(count); h->tx.reserve(count); h->ty.reserve(count); h->ts.reserve(count); h->dummy_d2.reserve(count);
   const unsigned* d_idx = nullptr;
   if (!all) { h->cand.reserve(count); copy_in(h->cand.p, indices, sizeof(unsigned) * count, s); d_idx = h->cand.p; }
@@ -1007,6 +1126,7 @@ int e3d_reg_set_observations(e3d_reg_t* h, int image_id, int point_scale, size_t
   ImageDev& im = get_image(h, image_id);
   PointScale& S = get_scale(h, point_scale);
   Obs& O = im.obs[point_scale];
+  O.active = true;
   O.n = n;
   O.idx.reserve(n); O.x.reserve(n); O.y.reserve(n); O.s.reserve(n);
   copy_in(O.idx.p, idx, sizeof(unsigned) * n, h->stream); copy_in(O.x.p, x, sizeof(float) * n, h->stream);
@@ -1185,7 +1305,7 @@ static void update_observations(e3d_reg* h, int border) {
     ImageDev& im = kv.second;
     const int scale = best_available_scale(h, h->intr.at(im.intrinsics_id));
     if (e3d_reg_render_depth(h, kv.first, scale, nullptr) < 0) throw Error(E3D_ERR_INVALID, e3d_last_error());
-    im.obs.clear();
+    for (auto& o : im.obs) { o.second.active = false; o.second.n = 0; }      // keep the device buffers
     bool had_many = false;
     for (auto it = h->scales.rbegin(); it != h->scales.rend(); ++it) {
       const int64_t n = e3d_reg_observe(h, kv.first, it->first, scale, border, nullptr, 0);
@@ -1200,7 +1320,7 @@ static void color_update(e3d_reg* h) {
   for (auto& sc : h->scales) {
     if (e3d_reg_color_begin(h, sc.first) < 0) throw Error(E3D_ERR_INVALID, e3d_last_error());
     for (auto& kv : h->images)
-      if (kv.second.obs.count(sc.first) && e3d_reg_color_accumulate(h, kv.first, sc.first) < 0) throw Error(E3D_ERR_INVALID, e3d_last_error());
+      if (has_obs(kv.second, sc.first) && e3d_reg_color_accumulate(h, kv.first, sc.first) < 0) throw Error(E3D_ERR_INVALID, e3d_last_error());
     if (e3d_reg_color_finish(h, sc.first) < 0) throw Error(E3D_ERR_INVALID, e3d_last_error());
   }
 }
@@ -1211,7 +1331,7 @@ static double total_cost(e3d_reg* h) {
   int64_t counts[2] = {0, 0};
   for (auto& kv : h->images)
     for (auto& sc : h->scales) {
-      if (!kv.second.obs.count(sc.first)) continue;
+      if (!has_obs(kv.second, sc.first)) continue;
       double s2[2]; int64_t c2[2];
       if (e3d_reg_cost(h, kv.first, sc.first, s2, c2) < 0) throw Error(E3D_ERR_INVALID, e3d_last_error());
       sums[0] += s2[0]; sums[1] += s2[1]; counts[0] += c2[0]; counts[1] += c2[1];
@@ -1232,15 +1352,15 @@ static void apply_update(e3d_reg* h, bool print, bool* applied_update, float* la
   double sums[2] = {0, 0};
   int64_t counts[2] = {0, 0};
   // visibility lists = observed point indices of the current observations (device copies)
-  std::map<int, std::map<int, std::pair<std::shared_ptr<DevBuf<unsigned>>, size_t>>> vis;
+  std::map<int, std::map<int, std::pair<DevBuf<unsigned>*, size_t>>> vis;
   for (auto& kv : h->images) {
     ImageDev& im = kv.second;
     const int I = h->intr.at(im.intrinsics_id).n_params;
     const int ii = intr_index.at(im.intrinsics_id), pi = image_index.at(kv.first);
     for (auto& sc : h->scales) {
-      if (!im.obs.count(sc.first)) continue;
+      if (!has_obs(im, sc.first)) continue;
       Obs& O = im.obs.at(sc.first);
-      auto buf = std::make_shared<DevBuf<unsigned>>();
+      DevBuf<unsigned>* buf = &im.vis[sc.first];
       buf->reserve(O.n);
       if (O.n) E3D_HIP(hipMemcpyAsync(buf->p, O.idx.p, sizeof(unsigned) * O.n, hipMemcpyDeviceToDevice, s));
       vis[kv.first][sc.first] = {buf, O.n};

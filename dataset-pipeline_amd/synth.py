@@ -111,3 +111,55 @@ def make_scene(n_scans, n_points, seed=1234, sigma=0.002, device="cpu"):
         Ti[:3, 3] = Ti[:3, 3] + P[:3, 3]
         scans.append({"xyz": xyz, "normals": nrm, "T_true": T, "T_init": Ti.astype(np.float32)})
     return scans
+
+
+# ---- path (B): synthetic ImageRegistrator workload -------------------------------------------------------------------------
+def image_pyramid_u8(img, n_levels):
+    """Image::BuildImagePyramid (src/opt/image.cc:106-131): successive half-size INTER_AREA reductions of a u8 image =
+    2x2 box mean, round half up; odd trailing rows / columns are dropped."""
+    out = [np.ascontiguousarray(img, np.uint8)]
+    for _ in range(1, n_levels):
+        a = out[-1]
+        h, w = (a.shape[0] // 2) * 2, (a.shape[1] // 2) * 2
+        a = a[:h, :w].astype(np.uint16)
+        out.append(((a[0::2, 0::2] + a[0::2, 1::2] + a[1::2, 0::2] + a[1::2, 1::2] + 2) >> 2).astype(np.uint8))
+    return out
+
+
+REG_DISTORTION = {0: [], 1: [-0.101082, 0.0703954, 0.000438661, -0.000680887],
+                  2: [0.0221184, 0.0128597, 0.000531602, -0.000388873, 0.00623079, 0.0020419, -0.000805024, 4.07704e-05]}
+
+
+def make_reg_workload(n_points=4_000_000, width=3840, height=2160, n_levels=6, K=5, n_images=4, model=0, seed=0):
+    """A textured wall (y = 3) sampled on a jittered lattice with lattice neighbours, seen by `n_images` cameras placed on an arc;
+    one point scale whose radius makes every observation land between pyramid levels 0 and 1.  Shapes follow BASELINE.json
+    configs[4] (4K images, 6 levels); everything else (texture, poses) is synthetic."""
+    rng = np.random.RandomState(seed)
+    side = int(np.sqrt(n_points)); n = side * side
+    uu, vv = np.meshgrid(np.linspace(-1.6, 1.6, side), np.linspace(-0.9, 0.9, side), indexing="ij")
+    uu = uu + rng.uniform(-0.2, 0.2, uu.shape) * (3.2 / side); vv = vv + rng.uniform(-0.2, 0.2, vv.shape) * (1.8 / side)
+    pts = np.stack([uu.ravel(), np.full(n, 3.0), vv.ravel()], 1).astype(np.float32)
+    idx = np.arange(n).reshape(side, side)
+
+    def sh(dx, dy):
+        return np.roll(np.roll(idx, dx, 0), dy, 1).ravel()
+    nbr = np.stack([sh(1, 0), sh(-1, 0), sh(0, 1), sh(0, -1), sh(1, 1), sh(-1, -1), sh(1, -1), sh(-1, 1)][:K], 1).astype(np.uint32)
+    tex = 120 + 55 * np.sin(7.0 * pts[:, 0]) * np.cos(5.0 * pts[:, 2]) + 35 * np.sin(3.0 * pts[:, 0] + 4.0 * pts[:, 2])
+    fixed = (tex[nbr] - tex[:, None]).astype(np.float32)
+    params = np.array([0.55 * width, 0.55 * width, width / 2 - 0.5, height / 2 - 0.5] + REG_DISTORTION[model], np.float32)
+    yy, xx = np.mgrid[0:height, 0:width]
+    images = []
+    for i in range(n_images):
+        img = (120 + 60 * np.sin((xx + 37 * i) / 11.0) * np.cos(yy / 9.0) + 40 * np.sin((xx + 2 * yy) / 31.0)).clip(0, 250).astype(np.uint8)
+        a = 0.04 * (i - 0.5 * (n_images - 1))
+        eye = np.array([3.0 * np.sin(a), 3.0 - 3.0 * np.cos(a), 0.01 * i])
+        z = np.array([0.0, 3.0, 0.0]) - eye; z /= np.linalg.norm(z)
+        x = np.cross(z, [0.0, 0.0, 1.0]); x /= np.linalg.norm(x)
+        y = np.cross(z, x)
+        R = np.stack([x, y, z])
+        t = -R @ eye
+        w = np.sqrt(max(0.0, 1 + R[0, 0] + R[1, 1] + R[2, 2])) / 2
+        q = np.array([w, (R[2, 1] - R[1, 2]) / (4 * w), (R[0, 2] - R[2, 0]) / (4 * w), (R[1, 0] - R[0, 1]) / (4 * w)])
+        images.append(dict(pyr=image_pyramid_u8(img, n_levels), q=(q / np.linalg.norm(q)).astype(np.float32), t=t.astype(np.float32)))
+    return dict(pts=pts, nbr=nbr, K=K, fixed_desc=fixed, params=params, width=width, height=height, n_levels=n_levels,
+                images=images, point_radius=float(3.2 / side * 0.7), model=model)

@@ -36,6 +36,7 @@ class IterRecord(C.Structure):
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_size_t, C.c_void_p)
+ALLREDUCE_DEVICE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)
 
 # name -> (restype, argtypes); also the list of symbols include/e3d_hip.h declares
 SIGNATURES = {
@@ -89,6 +90,8 @@ SIGNATURES = {
     "e3d_reg_compute_cost": (C.c_int, [C.c_void_p, C.c_void_p]),
     "e3d_reg_apply": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "e3d_reg_run_on_current_scale": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "e3d_reg_set_shard": (C.c_int, [C.c_void_p, C.c_int, C.c_int, ALLREDUCE_FN, ALLREDUCE_DEVICE_FN, C.c_void_p]),
+    "e3d_reg_image_owner": (C.c_int, [C.c_void_p, C.c_int]),
 }
 
 
@@ -99,6 +102,14 @@ def lib():
         p = lib_path()
         if not os.path.exists(p):
             raise E3DError("HIP extension missing: %s (run `python dataset-pipeline_amd/build.py`)" % p)
+        # One HIP runtime per process: the ROCm torch wheel carries its own libamdhip64.  If torch is imported AFTER this
+        # library has pulled in the system runtime, torch.cuda sees no device; imported first, both bind to the same copy
+        # (measured on the MI355X box, tools/probe_hip_runtime.py).  torch is optional -- only tests / bench.py / dist.py use it.
+        if os.environ.get("E3D_NO_TORCH_PRELOAD", "0") != "1":
+            try:
+                import torch  # noqa: F401
+            except Exception:  # noqa: BLE001
+                pass
         L = C.CDLL(p)
         for name, (res, args) in SIGNATURES.items():
             f = getattr(L, name)
@@ -368,6 +379,10 @@ class RegProblem:
         return w.value, h.value, p, c.value
 
     def set_image(self, image_id, intrinsics_id, levels, masks=None):
+        if levels is None:                       # an image owned by another rank: id, intrinsics and pose only
+            self._chk(lib().e3d_reg_set_image(self._h, image_id, intrinsics_id, None, None), "e3d_reg_set_image")
+            self._image_intr[image_id] = intrinsics_id
+            return
         keep = [np.ascontiguousarray(l, np.uint8) for l in levels]
         arr = (C.c_void_p * len(keep))(*[l.ctypes.data for l in keep])
         marr = None
@@ -404,6 +419,35 @@ class RegProblem:
         a = C.c_int(); l = C.c_float(lam); m = C.c_float()
         self._chk(lib().e3d_reg_apply(self._h, int(print_progress), C.byref(a), C.byref(l), C.byref(m)), "e3d_reg_apply")
         return bool(a.value), l.value, m.value
+
+    def set_shard(self, rank, world_size, allreduce=None, allreduce_device=None):
+        """Image sharding over ranks (image id mod world_size).  allreduce(np.ndarray float64, in place);
+        allreduce_device(ptr, count, dtype) sums a DEVICE buffer in place (dtype 0 = f32, 1 = i32) -- see dist.py.
+        Must be called before the images are set."""
+        def _wrap_host(buf, count, _user):
+            try:
+                allreduce(np.ctypeslib.as_array(buf, shape=(count,)))
+                return 0
+            except Exception:  # noqa: BLE001 -- must not propagate through C
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        def _wrap_dev(ptr, count, dtype, _user):
+            try:
+                allreduce_device(ptr, count, dtype)
+                return 0
+            except Exception:  # noqa: BLE001
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._cb_host = ALLREDUCE_FN(_wrap_host) if allreduce is not None else ALLREDUCE_FN()
+        self._cb_dev = ALLREDUCE_DEVICE_FN(_wrap_dev) if allreduce_device is not None else ALLREDUCE_DEVICE_FN()
+        self._chk(lib().e3d_reg_set_shard(self._h, int(rank), int(world_size), self._cb_host, self._cb_dev, None), "e3d_reg_set_shard")
+        self._rank, self._world = int(rank), int(world_size)
+
+    def image_owner(self, image_id):
+        return self._chk(lib().e3d_reg_image_owner(self._h, int(image_id)), "e3d_reg_image_owner")
 
     def run_on_current_scale(self, max_num_iterations, max_change_convergence_threshold=0.0,
                              iterations_without_new_optimum_threshold=15, print_progress=False):

@@ -689,6 +689,12 @@ struct e3d_reg {
   DevBuf<unsigned long long> chunk_sum, d_total;
   DevBuf<float> dummy_d2;
   DevBuf<unsigned> cut;
+  // multi-GPU: image id mod world == rank -> owned
+  int rank = 0, world = 1;
+  e3d_allreduce_fn allreduce = nullptr;
+  e3d_allreduce_device_fn allreduce_dev = nullptr;
+  void* ar_user = nullptr;
+  bool owns(int image_id) const { return world <= 1 || ((image_id % world) + world) % world == rank; }
   // splat depth: per-point rectangles, (tile, point) pairs (double-buffered for the sort), tile ranges
   DevBuf<uint4> rects;
   DevBuf<unsigned> sp_keys[2], sp_vals[2], sp_counter, tile_start, tile_end;
@@ -700,6 +706,16 @@ namespace e3d {
 
 static void rsync(e3d_reg* h) { E3D_HIP(hipStreamSynchronize(h->stream)); }
 static unsigned nblk(size_t n) { return (unsigned)div_up(n ? n : 1, kBlock); }
+
+static void allreduce_host(e3d_reg* h, double* buf, size_t n) {
+  if (h->world <= 1) return;
+  if (!h->allreduce || h->allreduce(buf, n, h->ar_user) != 0) throw Error(E3D_ERR_INVALID, "all-reduce callback failed");
+}
+static void allreduce_device(e3d_reg* h, void* dev, size_t n, int dtype) {
+  if (h->world <= 1) return;
+  rsync(h);
+  if (!h->allreduce_dev || h->allreduce_dev(dev, n, dtype, h->ar_user) != 0) throw Error(E3D_ERR_INVALID, "device all-reduce callback failed");
+}
 
 // run `stmt` with the camera model as the compile-time constant M
 #define E3D_CAM_SWITCH(model, stmt)                                                        \
@@ -755,6 +771,7 @@ static int image_model(e3d_reg* h, const ImageDev& im) { return h->intr.at(im.in
 
 static Pyramid make_pyramid(e3d_reg* h, const ImageDev& im) {
   const Intrin& in = h->intr.at(im.intrinsics_id);
+  if (im.pix.size() != in.levels.size()) throw Error(E3D_ERR_INVALID, "the pyramid of this image is not resident on this rank");
   Pyramid Y{};
   Y.n_levels = (int)in.levels.size();
   Y.min_image_scale = in.min_image_scale;
@@ -948,10 +965,18 @@ int e3d_reg_get_intrinsics_level(e3d_reg_t* h, int intrinsics_id, int level, int
 int e3d_reg_set_image(e3d_reg_t* h, int image_id, int intrinsics_id, const uint8_t* const* level_pixels,
                       const uint8_t* const* level_masks) {
   R_TRY
-  if (!h || !level_pixels) throw Error(E3D_ERR_INVALID, "null argument");
+  if (!h) throw Error(E3D_ERR_INVALID, "null argument");
   auto it = h->intr.find(intrinsics_id);
   if (it == h->intr.end()) throw Error(E3D_ERR_INDEX, "intrinsics not set");
   const Intrin& in = it->second;
+  if (!h->owns(image_id)) {                     // another rank's image: only its id, intrinsics and pose are kept here
+    ImageDev& im = h->images[image_id];
+    im.intrinsics_id = intrinsics_id;
+    im.pix.clear(); im.mask.clear(); im.has_mask.clear(); im.obs.clear();
+    im.depth_scale = -1;
+    return 0;
+  }
+  if (!level_pixels) throw Error(E3D_ERR_INVALID, "null argument");
   ImageDev& im = h->images[image_id];
   im.intrinsics_id = intrinsics_id;
   const int L = (int)in.levels.size();
@@ -1014,6 +1039,7 @@ int e3d_reg_render_depth(e3d_reg_t* h, int image_id, int image_scale, float* dep
   R_TRY
   if (!h) throw Error(E3D_ERR_INVALID, "null handle");
   ImageDev& im = get_image(h, image_id);
+  if (!h->owns(image_id)) throw Error(E3D_ERR_INVALID, fmt("image %d belongs to rank %d", image_id, e3d_reg_image_owner(h, image_id)));
   const Intrin& in = h->intr.at(im.intrinsics_id);
   const int lvl = std::max(0, image_scale - in.min_image_scale);
   if (lvl >= (int)in.levels.size()) throw Error(E3D_ERR_INDEX, "image scale beyond the pyramid");
@@ -1302,6 +1328,7 @@ static double compute_cost_value(const e3d_reg* h, const double sums[2], const i
 static void update_observations(e3d_reg* h, int border) {
   constexpr size_t kManyObservationsCount = 100;
   for (auto& kv : h->images) {
+    if (!h->owns(kv.first)) continue;
     ImageDev& im = kv.second;
     const int scale = best_available_scale(h, h->intr.at(im.intrinsics_id));
     if (e3d_reg_render_depth(h, kv.first, scale, nullptr) < 0) throw Error(E3D_ERR_INVALID, e3d_last_error());
@@ -1320,9 +1347,20 @@ static void color_update(e3d_reg* h) {
   for (auto& sc : h->scales) {
     if (e3d_reg_color_begin(h, sc.first) < 0) throw Error(E3D_ERR_INVALID, e3d_last_error());
     for (auto& kv : h->images)
-      if (has_obs(kv.second, sc.first) && e3d_reg_color_accumulate(h, kv.first, sc.first) < 0) throw Error(E3D_ERR_INVALID, e3d_last_error());
+      if (h->owns(kv.first) && has_obs(kv.second, sc.first) && e3d_reg_color_accumulate(h, kv.first, sc.first) < 0)
+        throw Error(E3D_ERR_INVALID, e3d_last_error());
+    // the exchange step of (B): descriptor sums and observation counts over all images = over all ranks
+    allreduce_device(h, sc.second.var_desc.p, sc.second.n * (size_t)h->prm.point_neighbor_count, 0);
+    allreduce_device(h, sc.second.obs_counts.p, sc.second.n, 1);
     if (e3d_reg_color_finish(h, sc.first) < 0) throw Error(E3D_ERR_INVALID, e3d_last_error());
   }
+}
+
+static void reduce_sums(e3d_reg* h, double sums[2], int64_t counts[2]) {
+  if (h->world <= 1) return;
+  double buf[4] = {sums[0], sums[1], (double)counts[0], (double)counts[1]};      // counts < 2^53: exact in f64
+  allreduce_host(h, buf, 4);
+  sums[0] = buf[0]; sums[1] = buf[1]; counts[0] = (int64_t)buf[2]; counts[1] = (int64_t)buf[3];
 }
 
 // CostCalculator::ComputeCost over the stored observations
@@ -1331,11 +1369,12 @@ static double total_cost(e3d_reg* h) {
   int64_t counts[2] = {0, 0};
   for (auto& kv : h->images)
     for (auto& sc : h->scales) {
-      if (!has_obs(kv.second, sc.first)) continue;
+      if (!h->owns(kv.first) || !has_obs(kv.second, sc.first)) continue;
       double s2[2]; int64_t c2[2];
       if (e3d_reg_cost(h, kv.first, sc.first, s2, c2) < 0) throw Error(E3D_ERR_INVALID, e3d_last_error());
       sums[0] += s2[0]; sums[1] += s2[1]; counts[0] += c2[0]; counts[1] += c2[1];
     }
+  reduce_sums(h, sums, counts);
   if (counts[0] == 0 && counts[1] == 0) return std::numeric_limits<double>::infinity();
   return compute_cost_value(h, sums, counts);
 }
@@ -1354,6 +1393,7 @@ static void apply_update(e3d_reg* h, bool print, bool* applied_update, float* la
   // visibility lists = observed point indices of the current observations (device copies)
   std::map<int, std::map<int, std::pair<DevBuf<unsigned>*, size_t>>> vis;
   for (auto& kv : h->images) {
+    if (!h->owns(kv.first)) continue;
     ImageDev& im = kv.second;
     const int I = h->intr.at(im.intrinsics_id).n_params;
     const int ii = intr_index.at(im.intrinsics_id), pi = image_index.at(kv.first);
@@ -1378,6 +1418,17 @@ static void apply_update(e3d_reg* h, bool print, bool* applied_update, float* la
     }
   }
   E3D_HIP(hipStreamSynchronize(s));
+  if (h->world > 1) {                       // one exchange per Apply: [upper(H) as dense V x V, b, sums, counts]
+    std::vector<double> buf((size_t)V * V + V + 4);
+    std::copy(H.begin(), H.end(), buf.begin());
+    std::copy(b.begin(), b.end(), buf.begin() + (size_t)V * V);
+    double* tail = buf.data() + (size_t)V * V + V;
+    tail[0] = sums[0]; tail[1] = sums[1]; tail[2] = (double)counts[0]; tail[3] = (double)counts[1];
+    allreduce_host(h, buf.data(), buf.size());
+    std::copy(buf.begin(), buf.begin() + (size_t)V * V, H.begin());
+    std::copy(buf.begin() + (size_t)V * V, buf.begin() + (size_t)V * V + V, b.begin());
+    sums[0] = tail[0]; sums[1] = tail[1]; counts[0] = (int64_t)tail[2]; counts[1] = (int64_t)tail[3];
+  }
   const double initial_residual = compute_cost_value(h, sums, counts);
   if (print)
     printf("    Initial residual: %g (#fixed residuals: %lld, #variable residuals: %lld)\n", initial_residual, (long long)counts[0], (long long)counts[1]);
@@ -1405,6 +1456,7 @@ static void apply_update(e3d_reg* h, bool print, bool* applied_update, float* la
     double ts[2] = {0, 0}; int64_t tc[2] = {0, 0};
     constexpr size_t kManyObservationsCount = 100;
     for (auto& kv : h->images) {
+      if (!h->owns(kv.first)) continue;
       const int scale = best_available_scale(h, h->intr.at(kv.second.intrinsics_id));
       bool had_many = false;
       std::vector<int> done;
@@ -1427,6 +1479,7 @@ static void apply_update(e3d_reg* h, bool print, bool* applied_update, float* la
         ts[0] += s2[0]; ts[1] += s2[1]; tc[0] += c2[0]; tc[1] += c2[1];
       }
     }
+    reduce_sums(h, ts, tc);
     const double new_residual = compute_cost_value(h, ts, tc);
     if (new_residual < initial_residual || lm == kNumLMTries - 1) {      // kAlwaysApplyLastUpdate
       if (print) printf("    LM update accepted, new residual: %g\n", new_residual);
@@ -1447,6 +1500,24 @@ static void apply_update(e3d_reg* h, bool print, bool* applied_update, float* la
 }  // namespace e3d
 
 extern "C" {
+
+int e3d_reg_set_shard(e3d_reg_t* h, int rank, int world_size, e3d_allreduce_fn allreduce, e3d_allreduce_device_fn allreduce_device,
+                      void* user) {
+  R_TRY
+  if (!h) throw Error(E3D_ERR_INVALID, "null handle");
+  if (world_size < 1 || rank < 0 || rank >= world_size) throw Error(E3D_ERR_INVALID, "bad rank / world size");
+  if (world_size > 1 && (!allreduce || !allreduce_device)) throw Error(E3D_ERR_INVALID, "world_size > 1 needs both all-reduce callbacks");
+  if (!h->images.empty()) throw Error(E3D_ERR_INVALID, "e3d_reg_set_shard must be called before images are set");
+  h->rank = rank; h->world = world_size; h->allreduce = allreduce; h->allreduce_dev = allreduce_device; h->ar_user = user;
+  return 0;
+  R_CATCH()
+}
+int e3d_reg_image_owner(e3d_reg_t* h, int image_id) {
+  R_TRY
+  if (!h) throw Error(E3D_ERR_INVALID, "null handle");
+  return h->world <= 1 ? 0 : ((image_id % h->world) + h->world) % h->world;
+  R_CATCH()
+}
 
 int e3d_reg_update_observations(e3d_reg_t* h, int border_size) {
   R_TRY

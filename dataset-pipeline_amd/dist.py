@@ -35,3 +35,52 @@ def attach(icp, group=None, device=None):
     import torch.distributed as dist
     icp.set_shard(dist.get_rank(group), dist.get_world_size(group), make_allreduce(group, device))
     return icp
+
+
+# ---- path (B): image sharding ---------------------------------------------------------------------------------------------
+class _DeviceView:
+    """Zero-copy view of a device buffer of the C library for torch (`torch.as_tensor` reads __cuda_array_interface__)."""
+
+    def __init__(self, ptr, count, dtype):
+        self.__cuda_array_interface__ = {"shape": (int(count),), "typestr": "<f4" if dtype == 0 else "<i4",
+                                         "data": (int(ptr), False), "version": 2}
+
+
+def device_tensor(ptr, count, dtype, device=None):
+    import torch
+    return torch.as_tensor(_DeviceView(ptr, count, dtype), device=device if device is not None else "cuda")
+
+
+def make_allreduce_device(group=None, device=None):
+    """Returns f(ptr, count, dtype) that sums a device buffer of the library in place across the process group: RCCL straight
+    from HBM with the "nccl" backend (the descriptor exchange of the colour update is the one bandwidth-relevant collective
+    of path (B): K*N f32 + N i32 per point scale over xGMI); staged through the host for "gloo"."""
+    import torch
+    import torch.distributed as dist
+
+    backend = dist.get_backend(group)
+
+    def allreduce(ptr, count, dtype):
+        if count == 0:
+            return
+        t = device_tensor(ptr, count, dtype, device)
+        if backend == "nccl":
+            dist.all_reduce(t, group=group)
+        else:
+            c = t.cpu()
+            dist.all_reduce(c, group=group)
+            t.copy_(c)
+        torch.cuda.synchronize()
+    return allreduce
+
+
+def image_owner(image_id, world):
+    """Rank that owns an image -- same rule as the C library (e3d_reg_image_owner)."""
+    return image_id % world
+
+
+def attach_reg(problem, group=None, device=None):
+    """Configure a RegProblem for the current process group (call before set_image)."""
+    import torch.distributed as dist
+    problem.set_shard(dist.get_rank(group), dist.get_world_size(group), make_allreduce(group, device), make_allreduce_device(group, device))
+    return problem

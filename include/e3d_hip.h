@@ -258,6 +258,20 @@ int e3d_reg_run_on_current_scale(e3d_reg_t* reg, int max_num_iterations, float m
                                  int iterations_without_new_optimum_threshold, int print_progress, double* optimum_cost,
                                  int* iterations_done);
 
+/* Multi-GPU (one process per GPU): images are sharded, image `id` belongs to rank `id mod world_size`
+ * (e3d_reg_image_owner).  Every rank declares every intrinsics block, point scale and image (ids and poses) so that the
+ * variable layout is global, but only the owner of an image uploads its pyramid -- e3d_reg_set_image accepts
+ * level_pixels == NULL for images of other ranks -- and only the owner creates observations and residuals for it.
+ * Exchange steps: the dense H, b and the residual sums / counts once per Apply and 4 doubles per LM try and
+ * per cost evaluation (`allreduce`, HOST f64 buffer); the variable descriptors (K*N f32) and observation counts (N i32)
+ * of every point scale once per colour update (`allreduce_device`: DEVICE buffer, dtype 0 = f32, 1 = i32, in-place sum;
+ * the library has synchronised its stream before the call and the callback must return with the result complete).
+ * Both callbacks must leave the identical result on every rank; all ranks then take the same LM decisions. */
+typedef int (*e3d_allreduce_device_fn)(void* device_buffer, size_t count, int dtype, void* user);
+int e3d_reg_set_shard(e3d_reg_t* reg, int rank, int world_size, e3d_allreduce_fn allreduce,
+                      e3d_allreduce_device_fn allreduce_device, void* user);
+int e3d_reg_image_owner(e3d_reg_t* reg, int image_id);
+
 #ifdef __cplusplus
 }
 #endif

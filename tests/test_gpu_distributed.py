@@ -85,3 +85,90 @@ def test_sharded_equals_single_rank(e3d, ob, synth, world):
         o.add_point_cloud(*c)
     o.run(d, 0, iters, thr, False)
     assert [(r[0], r[1], r[2], r[3]) for r in o.pair_records()] == ref_counts
+
+
+# ---- path (B): image sharding ------------------------------------------------------------------------------------------------
+class _ThreadDeviceAllReduce:
+    """In-process stand-in for RCCL: sums the ranks' device buffers (fixed rank order) and writes the total back to each."""
+
+    def __init__(self, world):
+        self.world = world
+        self.barrier = threading.Barrier(world)
+        self.slots = [None] * world
+        self.calls = 0
+
+    def make(self, rank, dist_mod):
+        import torch
+
+        def allreduce(ptr, count, dtype):
+            t = dist_mod.device_tensor(ptr, count, dtype)          # the same zero-copy view the RCCL path reduces in place
+            self.slots[rank] = t.clone()
+            torch.cuda.synchronize()
+            self.barrier.wait(timeout=60)
+            total = self.slots[0].clone()
+            for r in range(1, self.world):
+                total += self.slots[r]
+            torch.cuda.synchronize()
+            self.barrier.wait(timeout=60)
+            t.copy_(total)
+            torch.cuda.synchronize()
+            if rank == 0:
+                self.calls += 1
+        return allreduce
+
+
+@pytest.mark.parametrize("world,model", [(2, 0), (3, 0), (2, 2)])
+def test_reg_image_sharding_equals_single_rank(e3d, world, model):
+    import importlib
+    from reg_util import make_multi_image_scene
+    from test_gpu_reg import _pose_delta
+    dist_mod = importlib.import_module("dataset-pipeline_amd.dist")
+    M = make_multi_image_scene(n_points=6000, n_images=4, seed=8, perturb=0.006, model=model)
+
+    def build(rank=None, ar=None, ard=None):
+        P = e3d.RegProblem(e3d.default_reg_params(image_scale_count=M["n_levels"], point_neighbor_count=M["K"]))
+        if rank is not None:
+            P.set_shard(rank, world, ar.make(rank), ard.make(rank, dist_mod))
+        P.set_intrinsics(0, M["width"], M["height"], M["params"], 0, M["n_levels"], camera_type=model)
+        P.set_point_scale(0, M["pts"], M["point_radius"], M["nbr"], M["fixed_desc"])
+        P.set_splat_points(M["pts"])
+        for i, im in enumerate(M["images"]):
+            owned = rank is None or dist_mod.image_owner(i, world) == rank
+            assert rank is None or P.image_owner(i) == dist_mod.image_owner(i, world)
+            P.set_image(i, 0, im["pyr"] if owned else None)          # other ranks' pixels never reach this rank
+            P.set_image_pose(i, im["q_init"], im["t_init"])
+        return P
+
+    ref = build()
+    r_ref = ref.run_on_current_scale(5, 0.0, 15, False)
+
+    ar, ard = _ThreadAllReduce(world), _ThreadDeviceAllReduce(world)
+    probs = [build(r, ar, ard) for r in range(world)]
+    results, errors = [None] * world, []
+
+    def work(r):
+        try:
+            results[r] = probs[r].run_on_current_scale(5, 0.0, 15, False)
+        except Exception as ex:  # noqa: BLE001
+            errors.append(ex)
+            ar.barrier.abort(); ard.barrier.abort()
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(180)
+    assert not errors, errors
+    assert ar.calls >= 5 and ard.calls >= 5          # H/b + cost exchanges, descriptor exchanges
+    for r in range(world):
+        assert results[r][0] == r_ref[0] and results[r][2] == r_ref[2]            # same convergence flag and iteration count
+        assert abs(results[r][1] - r_ref[1]) <= 1e-6 * r_ref[1]
+        for i in range(len(M["images"])):
+            ang, tr = _pose_delta(*probs[r].get_image_pose(i), *ref.get_image_pose(i))
+            assert ang <= 1e-5 and tr <= 1e-5
+            q0, t0 = probs[0].get_image_pose(i); q1, t1 = probs[r].get_image_pose(i)
+            assert np.array_equal(q0, q1) and np.array_equal(t0, t1)              # bit-identical state on every rank
+        assert np.array_equal(probs[r].intrinsics_level(0, 0)[2], probs[0].intrinsics_level(0, 0)[2])
+    # a rank cannot touch an image it does not own
+    with pytest.raises(e3d.E3DError):
+        probs[0].render_depth(1, 0)

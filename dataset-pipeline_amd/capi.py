@@ -90,6 +90,9 @@ SIGNATURES = {
     "e3d_reg_compute_cost": (C.c_int, [C.c_void_p, C.c_void_p]),
     "e3d_reg_apply": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "e3d_reg_run_on_current_scale": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "e3d_reg_set_rig": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "e3d_reg_get_rig": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "e3d_reg_add_rig_images": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
     "e3d_reg_set_shard": (C.c_int, [C.c_void_p, C.c_int, C.c_int, ALLREDUCE_FN, ALLREDUCE_DEVICE_FN, C.c_void_p]),
     "e3d_reg_image_owner": (C.c_int, [C.c_void_p, C.c_int]),
 }
@@ -331,6 +334,7 @@ class RegProblem:
             _err("e3d_reg_create")
         self._levels = {}
         self._nparams = {}
+        self._dependent = set()
         self._image_intr = {}
 
     def __del__(self):
@@ -484,8 +488,27 @@ class RegProblem:
         idx = np.ascontiguousarray(idx, np.uint32); x, y, s = [np.ascontiguousarray(a, np.float32) for a in (x, y, s)]
         self._chk(lib().e3d_reg_set_observations(self._h, image_id, point_scale, len(idx), *[C.c_void_p(a.ctypes.data) for a in (idx, x, y, s)]), "set_observations")
 
+    def set_rig(self, rig_id, image_T_rig):
+        """image_T_rig: list of (q wxyz, t) per camera, camera 0 = reference."""
+        q = np.ascontiguousarray([p[0] for p in image_T_rig], np.float32); t = np.ascontiguousarray([p[1] for p in image_T_rig], np.float32)
+        self._chk(lib().e3d_reg_set_rig(self._h, rig_id, len(image_T_rig), C.c_void_p(q.ctypes.data), C.c_void_p(t.ctypes.data)), "e3d_reg_set_rig")
+
+    def get_rig(self, rig_id, camera):
+        q = np.zeros(4, np.float32); t = np.zeros(3, np.float32)
+        self._chk(lib().e3d_reg_get_rig(self._h, rig_id, camera, C.c_void_p(q.ctypes.data), C.c_void_p(t.ctypes.data)), "e3d_reg_get_rig")
+        return q, t
+
+    def add_rig_images(self, rig_id, image_ids):
+        ids = np.ascontiguousarray(image_ids, np.int32)
+        self._chk(lib().e3d_reg_add_rig_images(self._h, rig_id, C.c_void_p(ids.ctypes.data), len(ids)), "e3d_reg_add_rig_images")
+        for i in image_ids[1:]:
+            self._dependent.add(int(i))
+
     def param_count(self, image_id):
         return self._nparams[self._image_intr[image_id]]
+
+    def local_unknowns(self, image_id):
+        return self.param_count(image_id) + (12 if image_id in self._dependent else 6)
 
     def pass1(self, image_id, point_scale, n):
         I = np.zeros(n, np.float32); ji = np.zeros((n, self.param_count(image_id)), np.float32); jp = np.zeros((n, 6), np.float32)
@@ -493,7 +516,7 @@ class RegProblem:
         return I, ji, jp
 
     def accumulate(self, image_id, point_scale):
-        V = self.param_count(image_id) + 6
+        V = self.local_unknowns(image_id)
         H = np.zeros((V, V)); b = np.zeros(V); sums = np.zeros(2); counts = np.zeros(2, np.int64)
         self._chk(lib().e3d_reg_accumulate(self._h, image_id, point_scale, *[C.c_void_p(a.ctypes.data) for a in (H, b, sums, counts)]), "e3d_reg_accumulate")
         return H, b, sums, counts

@@ -315,15 +315,20 @@ __global__ __launch_bounds__(kBlock) void k_obs_flags(const unsigned* __restrict
 
 // ==== a16: pass 1 =========================================================================================================================
 // Row of one observation: [intensity, J_intrinsics(I), J_pose(6), 0-padding] as rows4(I) float4.
-__host__ __device__ constexpr int rows4(int I) { return (I + 10) / 4; }     // 3, 4, 5 float4 for I = 4, 8, 12
+// NV = number of local unknowns: I + 6, or I + 12 for a non-reference rig image ([intrinsics, rig extrinsics, rig pose]).
+__host__ __device__ constexpr int rows4(int NV) { return (NV + 4) / 4; }     // float4 per row: 1 + NV floats, padded
 
-template <int M>
+// A non-reference image of a rig frame (intrinsics_and_pose_optimizer.cc:653-670): image_T_rig.rotationMatrix() of its
+// camera and the pose of the frame's reference image (Sophus::SE3f: unit quaternion w,x,y,z + translation).
+struct RigLink { float R_image_rig[9]; float q_rig_global[4]; float t_rig_global[3]; };
+
+template <int M, bool RIG>
 __global__ __launch_bounds__(kBlock) void k_reg_pass1(const float4* __restrict__ pts, float point_radius, Pose P, Pyramid Y,
                                                       const unsigned* __restrict__ o_idx, const float* __restrict__ o_x,
                                                       const float* __restrict__ o_y, const float* __restrict__ o_s,
-                                                      size_t n_obs, float4* __restrict__ rows) {
+                                                      size_t n_obs, RigLink L, float4* __restrict__ rows) {
   constexpr int I = cam_param_count(M);
-  constexpr int R4 = rows4(I);
+  constexpr int R4 = rows4(I + (RIG ? 12 : 6));
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_obs) return;
   const float4 p = pts[o_idx[i]];
@@ -371,8 +376,31 @@ __global__ __launch_bounds__(kBlock) void k_reg_pass1(const float4* __restrict__
   const float C0[6] = {1, 0, 0, 0, T2, -1 * T1};
   const float C1[6] = {0, 1, 0, -1 * T2, 0, T0};
   const float C2[6] = {0, 0, 1, T1, -1 * T0, 0};
+  if constexpr (!RIG) {
 #pragma unroll
-  for (int c = 0; c < 6; ++c) row[1 + I + c] = a[0] * C0[c] + (a[1] * C1[c] + a[2] * C2[c]);
+    for (int c = 0; c < 6; ++c) row[1 + I + c] = a[0] * C0[c] + (a[1] * C1[c] + a[2] * C2[c]);
+  } else {
+    // extrinsics block: the ordinary pose formula at the transformed point; pose block: through image_T_rig's rotation at
+    // rig_T_global * point (intrinsics_and_pose_optimizer.cc:1107-1150)
+#pragma unroll
+    for (int c = 0; c < 6; ++c) row[1 + I + c] = a[0] * C0[c] + (a[1] * C1[c] + a[2] * C2[c]);
+    float ar[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) ar[c] = a[0] * L.R_image_rig[c] + (a[1] * L.R_image_rig[3 + c] + a[2] * L.R_image_rig[6 + c]);
+    // Sophus SO3 action: p + w * uv + v x uv, uv = 2 (v x p); then + translation
+    const float vx = L.q_rig_global[1], vy = L.q_rig_global[2], vz = L.q_rig_global[3], w = L.q_rig_global[0];
+    float ux = vy * p.z - vz * p.y, uy = vz * p.x - vx * p.z, uz = vx * p.y - vy * p.x;
+    ux = ux + ux; uy = uy + uy; uz = uz + uz;
+    const float cx = vy * uz - vz * uy, cy = vz * ux - vx * uz, cz = vx * uy - vy * ux;
+    const float G0 = ((p.x + w * ux) + cx) + L.t_rig_global[0];
+    const float G1 = ((p.y + w * uy) + cy) + L.t_rig_global[1];
+    const float G2 = ((p.z + w * uz) + cz) + L.t_rig_global[2];
+    const float D0[6] = {1, 0, 0, 0, G2, -1 * G1};
+    const float D1[6] = {0, 1, 0, -1 * G2, 0, G0};
+    const float D2[6] = {0, 0, 1, G1, -1 * G0, 0};
+#pragma unroll
+    for (int c = 0; c < 6; ++c) row[1 + I + 6 + c] = ar[0] * D0[c] + (ar[1] * D1[c] + ar[2] * D2[c]);
+  }
 #pragma unroll
   for (int r = 0; r < R4; ++r) rows[R4 * i + r] = make_float4(row[4 * r], row[4 * r + 1], row[4 * r + 2], row[4 * r + 3]);
 }
@@ -380,16 +408,15 @@ __global__ __launch_bounds__(kBlock) void k_reg_pass1(const float4* __restrict__
 // ==== a17 + a18: pass 2 =====================================================================================================================
 // Local system of one (image, point scale): V = I + 6 unknowns [intrinsics(I), pose(6)].  Slot layout of the reduction:
 // [upper triangle of H row-major (V(V+1)/2)] [b (V)] [sum_fixed, sum_variable, count_fixed, count_variable].
-__host__ __device__ constexpr int reg_v(int I) { return I + 6; }
-__host__ __device__ constexpr int reg_h(int I) { return reg_v(I) * (reg_v(I) + 1) / 2; }
-__host__ __device__ constexpr int reg_slot(int I) { return reg_h(I) + reg_v(I) + 4; }
+__host__ __device__ constexpr int reg_h(int V) { return V * (V + 1) / 2; }
+__host__ __device__ constexpr int reg_slot(int V) { return reg_h(V) + V + 4; }
 __host__ __device__ constexpr int reg_row_start(int V, int r) { return r * V - r * (r - 1) / 2; }   // index of H(r, r)
 
 struct RegWeights { int robust_type; float robust_param; float fixed_weight, var_weight; };
 
-template <int I>
+template <int V>
 __device__ __forceinline__ void load_row(const float4* __restrict__ rows, size_t r, float* f) {
-  constexpr int R4 = rows4(I);
+  constexpr int R4 = rows4(V);
 #pragma unroll
   for (int q = 0; q < R4; ++q) {
     const float4 v = rows[R4 * r + q];
@@ -398,9 +425,9 @@ __device__ __forceinline__ void load_row(const float4* __restrict__ rows, size_t
 }
 
 // One launch accumulates the H rows [R0, R1) (and, if WITH_B, b and the residual sums): 69 f64 accumulators per thread for
-// PINHOLE in a single launch; the 14- and 18-unknown systems are split into 2 / 3 launches of <= 73 accumulators each so that
-// the accumulators stay in registers (the rows are re-read from L2, the arithmetic per launch is proportional to its rows).
-template <int K_MAX, int I, int R0, int R1, bool WITH_B>
+// PINHOLE in a single launch; the larger systems (14 ... 24 unknowns) are split into 2 ... 5 launches of <= 75 accumulators
+// each so that they stay in registers (the rows are re-read from L2, the arithmetic per launch is proportional to its rows).
+template <int K_MAX, int V, int R0, int R1, bool WITH_B>
 __global__ __launch_bounds__(kBlock) void k_reg_pass2(const float4* __restrict__ rows, const unsigned* __restrict__ o_idx,
                                                       const unsigned char* __restrict__ flags, size_t n_obs,
                                                       const unsigned* __restrict__ nbr, int K,
@@ -408,7 +435,7 @@ __global__ __launch_bounds__(kBlock) void k_reg_pass2(const float4* __restrict__
                                                       const float* __restrict__ fixed_desc, const float* __restrict__ var_desc,
                                                       const int* __restrict__ obs_counts, RegWeights wts,
                                                       double* __restrict__ partial) {
-  constexpr int V = reg_v(I), R4 = rows4(I);
+  constexpr int R4 = rows4(V);
   constexpr int NH = reg_row_start(V, R1) - reg_row_start(V, R0);
   constexpr int NL = NH + (WITH_B ? V + 4 : 0);
   double acc[NL];
@@ -418,7 +445,7 @@ __global__ __launch_bounds__(kBlock) void k_reg_pass2(const float4* __restrict__
     if (!flags[i]) continue;
     const size_t p = o_idx[i];
     float fc[4 * R4];
-    load_row<I>(rows, i, fc);
+    load_row<V>(rows, i, fc);
     int nrow[K_MAX];
     float In[K_MAX];
 #pragma unroll
@@ -451,7 +478,7 @@ __global__ __launch_bounds__(kBlock) void k_reg_pass2(const float4* __restrict__
         for (int k = 0; k < K_MAX; ++k)
           if (k < K) {
             float fn[4 * R4], J[V];
-            load_row<I>(rows, (size_t)nrow[k], fn);
+            load_row<V>(rows, (size_t)nrow[k], fn);
 #pragma unroll
             for (int c = 0; c < V; ++c) J[c] = fn[1 + c] - fc[1 + c];
             // AccumulateOnHAndB: products in f32, cast, add in f64 (intrinsics_and_pose_optimizer.cc:1246-1247)
@@ -483,8 +510,8 @@ __global__ __launch_bounds__(kBlock) void k_reg_pass2(const float4* __restrict__
     double v = s[0][threadIdx.x];
     for (int k = 1; k < kBlock / kWave; ++k) v += s[k][threadIdx.x];
     const int t = threadIdx.x;
-    const int dst = t < NH ? reg_row_start(V, R0) + t : reg_h(I) + (t - NH);
-    partial[(size_t)blockIdx.x * reg_slot(I) + dst] = v;
+    const int dst = t < NH ? reg_row_start(V, R0) + t : reg_h(V) + (t - NH);
+    partial[(size_t)blockIdx.x * reg_slot(V) + dst] = v;
   }
 }
 
@@ -660,7 +687,12 @@ struct ImageDev {
   int depth_scale = -1;
   std::map<int, Obs> obs;         // per point scale
   std::map<int, DevBuf<unsigned>> vis;   // per point scale: visibility list of the running Apply (grow-only scratch)
+  // rig membership (opt::RigImages): camera_index 0 = the frame's reference image, whose pose is the rig pose
+  int rig_id = -1, camera_index = 0, ref_image_id = -1;
+  bool dependent() const { return rig_id >= 0 && camera_index > 0; }
 };
+struct RigState { std::vector<SE3f> image_T_rig; };                 // opt::Rig (rig.h:41-76)
+struct RigFrame { int rig_id; std::vector<int> image_ids; };        // opt::RigImages
 
 static void set_pose(ImageDev& im, const SE3f& T) {
   im.pose_q = T;
@@ -679,6 +711,8 @@ struct e3d_reg {
   std::map<int, PointScale> scales;
   std::map<int, Intrin> intr;
   std::map<int, ImageDev> images;
+  std::map<int, RigState> rigs;
+  std::vector<RigFrame> frames;
   DevBuf<float4> splat;
   size_t n_splat = 0;
   // scratch
@@ -768,6 +802,31 @@ static void build_model_pyramid(e3d_reg* h, Intrin& in, int n_levels) {
 }
 
 static int image_model(e3d_reg* h, const ImageDev& im) { return h->intr.at(im.intrinsics_id).type; }
+static int local_unknowns(e3d_reg* h, const ImageDev& im) { return h->intr.at(im.intrinsics_id).n_params + (im.dependent() ? 12 : 6); }
+
+// image_T_global of the non-reference images of every rig frame = image_T_rig[camera] * reference image_T_global
+// (CreateDeltaState, intrinsics_and_pose_optimizer.cc:539-548)
+static void compose_rig_poses(e3d_reg* h) {
+  for (const RigFrame& f : h->frames) {
+    const RigState& rig = h->rigs.at(f.rig_id);
+    const SE3f ref = h->images.at(f.image_ids[0]).pose_q;
+    for (size_t c = 1; c < f.image_ids.size(); ++c) {
+      ImageDev& im = h->images.at(f.image_ids[c]);
+      set_pose(im, se3_mul(rig.image_T_rig[c], ref));
+      for (auto& o : im.obs) o.second.rows_valid = false;
+    }
+  }
+}
+static RigLink rig_link(e3d_reg* h, const ImageDev& im) {
+  RigLink L{};
+  if (!im.dependent()) return L;
+  const SE3f& ir = h->rigs.at(im.rig_id).image_T_rig[im.camera_index];
+  quat_to_matrix<float>(ir.q.w, ir.q.x, ir.q.y, ir.q.z, L.R_image_rig);
+  const SE3f& rg = h->images.at(im.ref_image_id).pose_q;
+  L.q_rig_global[0] = rg.q.w; L.q_rig_global[1] = rg.q.x; L.q_rig_global[2] = rg.q.y; L.q_rig_global[3] = rg.q.z;
+  for (int i = 0; i < 3; ++i) L.t_rig_global[i] = rg.t[i];
+  return L;
+}
 
 static Pyramid make_pyramid(e3d_reg* h, const ImageDev& im) {
   const Intrin& in = h->intr.at(im.intrinsics_id);
@@ -828,10 +887,17 @@ static void prepare_rows(e3d_reg* h, ImageDev& im, PointScale& S, Obs& O) {
   hipLaunchKernelGGL(k_fill_i32, dim3(nblk(S.n)), dim3(kBlock), 0, s, S.row_of_point.p, S.n, -1);
   if (O.n) hipLaunchKernelGGL(k_obs_mark, dim3(nblk(O.n)), dim3(kBlock), 0, s, O.idx.p, O.n, S.row_of_point.p);
   const int model = image_model(h, im);
-  O.rows.reserve((size_t)rows4(cam_param_count(model)) * O.n);
-  if (O.n)
-    E3D_CAM_SWITCH(model, hipLaunchKernelGGL(k_reg_pass1<M>, dim3(nblk(O.n)), dim3(kBlock), 0, s, S.pts.p, S.radius, im.pose,
-                                             make_pyramid(h, im), O.idx.p, O.x.p, O.y.p, O.s.p, O.n, O.rows.p));
+  O.rows.reserve((size_t)rows4(local_unknowns(h, im)) * O.n);
+  if (O.n) {
+    const RigLink L = rig_link(h, im);
+    if (im.dependent()) {
+      E3D_CAM_SWITCH(model, hipLaunchKernelGGL((k_reg_pass1<M, true>), dim3(nblk(O.n)), dim3(kBlock), 0, s, S.pts.p, S.radius, im.pose,
+                                               make_pyramid(h, im), O.idx.p, O.x.p, O.y.p, O.s.p, O.n, L, O.rows.p));
+    } else {
+      E3D_CAM_SWITCH(model, hipLaunchKernelGGL((k_reg_pass1<M, false>), dim3(nblk(O.n)), dim3(kBlock), 0, s, S.pts.p, S.radius, im.pose,
+                                               make_pyramid(h, im), O.idx.p, O.x.p, O.y.p, O.s.p, O.n, L, O.rows.p));
+    }
+  }
   O.rows_valid = true;
 }
 
@@ -1008,6 +1074,58 @@ int e3d_reg_set_image_pose(e3d_reg_t* h, int image_id, const float q[4], const f
   for (int i = 0; i < 3; ++i) T.t[i] = t[i];
   set_pose(im, T);
   for (auto& kv : im.obs) kv.second.rows_valid = false;
+  if (!h->frames.empty()) compose_rig_poses(h);
+  return 0;
+  R_CATCH()
+}
+
+/* opt::Rig: image_T_rig of every camera of a rig (camera 0 = reference, normally identity) */
+int e3d_reg_set_rig(e3d_reg_t* h, int rig_id, int n_cameras, const float* q, const float* t) {
+  R_TRY
+  if (!h || !q || !t || n_cameras < 1) throw Error(E3D_ERR_INVALID, "bad rig");
+  RigState r;
+  r.image_T_rig.resize(n_cameras);
+  for (int c = 0; c < n_cameras; ++c) {
+    SE3f T;
+    T.q.w = q[4 * c]; T.q.x = q[4 * c + 1]; T.q.y = q[4 * c + 2]; T.q.z = q[4 * c + 3];
+    for (int i = 0; i < 3; ++i) T.t[i] = t[3 * c + i];
+    r.image_T_rig[c] = T;
+  }
+  h->rigs[rig_id] = r;
+  if (!h->frames.empty()) compose_rig_poses(h);
+  return 0;
+  R_CATCH()
+}
+int e3d_reg_get_rig(e3d_reg_t* h, int rig_id, int camera_index, float q[4], float t[3]) {
+  R_TRY
+  if (!h || !q || !t) throw Error(E3D_ERR_INVALID, "null argument");
+  auto it = h->rigs.find(rig_id);
+  if (it == h->rigs.end() || camera_index < 0 || camera_index >= (int)it->second.image_T_rig.size()) throw Error(E3D_ERR_INDEX, "no such rig camera");
+  const SE3f& T = it->second.image_T_rig[camera_index];
+  q[0] = T.q.w; q[1] = T.q.x; q[2] = T.q.y; q[3] = T.q.z;
+  for (int i = 0; i < 3; ++i) t[i] = T.t[i];
+  return 0;
+  R_CATCH()
+}
+/* opt::RigImages: one frame of a rig = one image per camera, image_ids[0] is the reference image.  The poses of the other
+ * images become image_T_rig[camera] * image_T_global(reference). */
+int e3d_reg_add_rig_images(e3d_reg_t* h, int rig_id, const int* image_ids, int n_cameras) {
+  R_TRY
+  if (!h || !image_ids) throw Error(E3D_ERR_INVALID, "null argument");
+  auto it = h->rigs.find(rig_id);
+  if (it == h->rigs.end() || (int)it->second.image_T_rig.size() != n_cameras) throw Error(E3D_ERR_INVALID, "rig not set or camera count mismatch");
+  RigFrame f; f.rig_id = rig_id;
+  for (int c = 0; c < n_cameras; ++c) {
+    ImageDev& im = get_image(h, image_ids[c]);
+    if (im.rig_id >= 0) throw Error(E3D_ERR_INVALID, fmt("image %d already belongs to a rig frame", image_ids[c]));
+    f.image_ids.push_back(image_ids[c]);
+  }
+  for (int c = 0; c < n_cameras; ++c) {
+    ImageDev& im = h->images.at(image_ids[c]);
+    im.rig_id = rig_id; im.camera_index = c; im.ref_image_id = image_ids[0];
+  }
+  h->frames.push_back(f);
+  compose_rig_poses(h);
   return 0;
   R_CATCH()
 }
@@ -1171,7 +1289,8 @@ int e3d_reg_pass1(e3d_reg_t* h, int image_id, int point_scale, float* intensitie
   Obs& O = get_obs(im, point_scale);
   prepare_rows(h, im, S, O);
   const int I = cam_param_count(image_model(h, im));
-  const size_t stride = 4 * (size_t)rows4(I);
+  const int off_pose = 1 + I + (im.dependent() ? 6 : 0);
+  const size_t stride = 4 * (size_t)rows4(local_unknowns(h, im));
   std::vector<float> rows(stride * O.n);
   copy_out(rows.data(), O.rows.p, sizeof(float) * stride * O.n, h->stream);
   rsync(h);
@@ -1179,7 +1298,7 @@ int e3d_reg_pass1(e3d_reg_t* h, int image_id, int point_scale, float* intensitie
     const float* r = rows.data() + stride * i;
     if (intensities) intensities[i] = r[0];
     if (j_intrinsics) for (int c = 0; c < I; ++c) j_intrinsics[(size_t)I * i + c] = r[1 + c];
-    if (j_pose) for (int c = 0; c < 6; ++c) j_pose[6 * i + c] = r[1 + I + c];
+    if (j_pose) for (int c = 0; c < 6; ++c) j_pose[6 * i + c] = r[off_pose + c];
   }
   return 0;
   R_CATCH()
@@ -1194,17 +1313,23 @@ int e3d_reg_accumulate(e3d_reg_t* h, int image_id, int point_scale, double* H, d
   Obs& O = get_obs(im, point_scale);
   prepare_rows(h, im, S, O);
   const int nb = (int)std::min<size_t>(std::max<size_t>(div_up(O.n, kBlock * 4), 1), 1024);
-  const int I = cam_param_count(image_model(h, im));
-  const int V = reg_v(I), NH = reg_h(I), slot = reg_slot(I);
+  const int V = local_unknowns(h, im), NH = reg_h(V), slot = reg_slot(V);
   h->partial.reserve((size_t)nb * slot); h->red.reserve(slot);
   const RegWeights w{h->prm.robust_weighting_type, h->prm.robust_weighting_parameter, h->prm.fixed_residuals_weight,
                      h->prm.variable_residuals_weight};
-#define E3D_PASS2(I_, R0_, R1_, B_)                                                                                              \
-  hipLaunchKernelGGL((k_reg_pass2<8, I_, R0_, R1_, B_>), dim3(nb), dim3(kBlock), 0, s, O.rows.p, O.idx.p, O.flags.p, O.n, S.nbr.p, \
+#define E3D_PASS2(V_, R0_, R1_, B_)                                                                                              \
+  hipLaunchKernelGGL((k_reg_pass2<8, V_, R0_, R1_, B_>), dim3(nb), dim3(kBlock), 0, s, O.rows.p, O.idx.p, O.flags.p, O.n, S.nbr.p, \
                      h->prm.point_neighbor_count, S.row_of_point.p, S.fixed_desc.p, S.var_desc.p, S.obs_counts.p, w, h->partial.p)
-  if (I == 4) { E3D_PASS2(4, 0, 10, true); }
-  else if (I == 8) { E3D_PASS2(8, 0, 4, true); E3D_PASS2(8, 4, 14, false); }
-  else { E3D_PASS2(12, 0, 3, true); E3D_PASS2(12, 3, 7, false); E3D_PASS2(12, 7, 18, false); }
+  switch (V) {     // row ranges chosen so that every launch keeps <= 75 f64 accumulators
+    case 10: E3D_PASS2(10, 0, 10, true); break;
+    case 14: E3D_PASS2(14, 0, 4, true); E3D_PASS2(14, 4, 14, false); break;
+    case 16: E3D_PASS2(16, 0, 3, true); E3D_PASS2(16, 3, 8, false); E3D_PASS2(16, 8, 16, false); break;
+    case 18: E3D_PASS2(18, 0, 3, true); E3D_PASS2(18, 3, 7, false); E3D_PASS2(18, 7, 18, false); break;
+    case 20: E3D_PASS2(20, 0, 2, true); E3D_PASS2(20, 2, 6, false); E3D_PASS2(20, 6, 11, false); E3D_PASS2(20, 11, 20, false); break;
+    case 24: E3D_PASS2(24, 0, 2, true); E3D_PASS2(24, 2, 5, false); E3D_PASS2(24, 5, 9, false); E3D_PASS2(24, 9, 14, false);
+             E3D_PASS2(24, 14, 24, false); break;
+    default: throw Error(E3D_ERR_INVALID, "unsupported local system size");
+  }
 #undef E3D_PASS2
   hipLaunchKernelGGL(k_reg_reduce, dim3(slot), dim3(kWave), 0, s, h->partial.p, nb, slot, h->red.p);
   std::vector<double> r(slot);
@@ -1292,16 +1417,19 @@ namespace e3d {
 struct RegState {
   std::map<int, Intrin> intr;
   std::map<int, SE3f> poses;
+  std::map<int, RigState> rigs;
 };
 
 static RegState get_state(e3d_reg* h) {
   RegState st;
   st.intr = h->intr;
+  st.rigs = h->rigs;
   for (auto& kv : h->images) st.poses[kv.first] = kv.second.pose_q;
   return st;
 }
 static void set_state(e3d_reg* h, const RegState& st) {
   h->intr = st.intr;
+  h->rigs = st.rigs;
   for (auto& kv : h->images) {
     set_pose(kv.second, st.poses.at(kv.first));
     for (auto& o : kv.second.obs) o.second.rows_valid = false;
@@ -1385,8 +1513,13 @@ static void apply_update(e3d_reg* h, bool print, bool* applied_update, float* la
   // CountAndIndexVariables: [intrinsics blocks][6 per image]
   std::map<int, int> intr_index, image_index;
   int V = 0;
+  std::map<int, int> rig_index;
   for (auto& kv : h->intr) { intr_index[kv.first] = V; V += kv.second.n_params; }
-  for (auto& kv : h->images) { image_index[kv.first] = V; V += 6; }
+  for (auto& kv : h->rigs) { rig_index[kv.first] = V; V += 6 * ((int)kv.second.image_T_rig.size() - 1); }   // reference camera excluded (:455-460)
+  for (auto& kv : h->images) {                                                                             // dependent rig images share the
+    if (kv.second.dependent()) continue;                                                                   // reference image's pose (:461-472)
+    image_index[kv.first] = V; V += 6;
+  }
   std::vector<double> H((size_t)V * V, 0.0), b((size_t)V, 0.0);
   double sums[2] = {0, 0};
   int64_t counts[2] = {0, 0};
@@ -1396,7 +1529,10 @@ static void apply_update(e3d_reg* h, bool print, bool* applied_update, float* la
     if (!h->owns(kv.first)) continue;
     ImageDev& im = kv.second;
     const int I = h->intr.at(im.intrinsics_id).n_params;
-    const int ii = intr_index.at(im.intrinsics_id), pi = image_index.at(kv.first);
+    const bool dep = im.dependent();
+    const int ii = intr_index.at(im.intrinsics_id);
+    const int pi = image_index.at(dep ? im.ref_image_id : kv.first);
+    const int ri = dep ? rig_index.at(im.rig_id) + 6 * (im.camera_index - 1) : -1;
     for (auto& sc : h->scales) {
       if (!has_obs(im, sc.first)) continue;
       Obs& O = im.obs.at(sc.first);
@@ -1404,15 +1540,15 @@ static void apply_update(e3d_reg* h, bool print, bool* applied_update, float* la
       buf->reserve(O.n);
       if (O.n) E3D_HIP(hipMemcpyAsync(buf->p, O.idx.p, sizeof(unsigned) * O.n, hipMemcpyDeviceToDevice, s));
       vis[kv.first][sc.first] = {buf, O.n};
-      const int Vl = I + 6;
+      const int Vl = I + (dep ? 12 : 6);
       std::vector<double> Hl((size_t)Vl * Vl), bl(Vl);
       double s2[2]; int64_t c2[2];
       if (e3d_reg_accumulate(h, kv.first, sc.first, Hl.data(), bl.data(), s2, c2) < 0) throw Error(E3D_ERR_INVALID, e3d_last_error());
       sums[0] += s2[0]; sums[1] += s2[1]; counts[0] += c2[0]; counts[1] += c2[1];
-      // scatter the local [intrinsics(I), pose(6)] block (AccumulateOnHAndB's three block updates)
-      auto gidx = [&](int l) { return l < I ? ii + l : pi + (l - I); };
-      for (int r = 0; r < I + 6; ++r) {
-        for (int c = r; c < I + 6; ++c) H[(size_t)gidx(r) * V + gidx(c)] += Hl[(size_t)r * Vl + c];
+      // scatter the local [intrinsics(I), (rig extrinsics(6),) pose(6)] block (AccumulateOnHAndB's block updates)
+      auto gidx = [&](int l) { return l < I ? ii + l : ((dep && l < I + 6) ? ri + (l - I) : pi + (l - (Vl - 6))); };
+      for (int r = 0; r < Vl; ++r) {
+        for (int c = r; c < Vl; ++c) H[(size_t)gidx(r) * V + gidx(c)] += Hl[(size_t)r * Vl + c];
         b[gidx(r)] += bl[r];
       }
     }
@@ -1450,9 +1586,14 @@ static void apply_update(e3d_reg* h, bool print, bool* applied_update, float* la
       for (int i = 0; i < in.n_params; ++i) in.params[i] += -1 * x[base + i];      // float += double (intrinsics.cc:71-73)
       build_model_pyramid(h, in, (int)in.levels.size());
     }
-    for (auto& kv : trial.poses) kv.second = se3_apply_update(&x[image_index.at(kv.first)], old_state.poses.at(kv.first));   // exp(-x) * T
+    for (auto& kv : trial.rigs)                                                                    // Rig::Update (rig.cc:9-23)
+      for (size_t c = 1; c < kv.second.image_T_rig.size(); ++c)
+        kv.second.image_T_rig[c] = se3_apply_update(&x[rig_index.at(kv.first) + 6 * ((int)c - 1)], old_state.rigs.at(kv.first).image_T_rig[c]);
+    for (auto& kv : trial.poses)
+      if (image_index.count(kv.first)) kv.second = se3_apply_update(&x[image_index.at(kv.first)], old_state.poses.at(kv.first));   // exp(-x) * T
     // ComputeResidualForState with the visibility lists fixed
     set_state(h, trial);
+    compose_rig_poses(h);
     double ts[2] = {0, 0}; int64_t tc[2] = {0, 0};
     constexpr size_t kManyObservationsCount = 100;
     for (auto& kv : h->images) {

@@ -215,6 +215,14 @@ int e3d_reg_set_image(e3d_reg_t* reg, int image_id, int intrinsics_id, const uin
                       const uint8_t* const* level_masks);
 int e3d_reg_set_image_pose(e3d_reg_t* reg, int image_id, const float q[4], const float t[3]);
 int e3d_reg_get_image_pose(e3d_reg_t* reg, int image_id, float q[4], float t[3]);
+/* Camera rigs (src/opt/rig.h:41-76, RigImages in src/opt/problem.h): image_T_rig of every camera (n_cameras x {w,x,y,z},
+ * n_cameras x 3; camera 0 is the reference), and frames = one image id per camera, image_ids[0] being the reference
+ * image whose pose is the rig pose.  The other images' poses are derived: image_T_rig[c] * image_T_global(reference)
+ * (intrinsics_and_pose_optimizer.cc:539-548); they contribute the 6 extrinsics unknowns of their camera and the 6 pose
+ * unknowns of the reference image (:140-153, Rig::Update rig.cc:9-23). */
+int e3d_reg_set_rig(e3d_reg_t* reg, int rig_id, int n_cameras, const float* q, const float* t);
+int e3d_reg_get_rig(e3d_reg_t* reg, int rig_id, int camera_index, float q[4], float t[3]);
+int e3d_reg_add_rig_images(e3d_reg_t* reg, int rig_id, const int* image_ids, int n_cameras);
 /* OcclusionGeometry::SetSplatPoints */
 int e3d_reg_set_splat_points(e3d_reg_t* reg, const float* xyz, size_t n);
 
@@ -232,7 +240,8 @@ int e3d_reg_set_observations(e3d_reg_t* reg, int image_id, int point_scale, size
                              const float* x, const float* y, const float* image_scale);
 /* ComputePointIntensityAndJacobians for every observation (n x 1, n x I, n x 6); mainly for tests. */
 int e3d_reg_pass1(e3d_reg_t* reg, int image_id, int point_scale, float* intensities, float* j_intrinsics, float* j_pose);
-/* H: (I+6) x (I+6) row-major, upper triangle filled (variables: [intrinsics(I), pose(6)]); b: I+6;
+/* H: V x V row-major, upper triangle filled; b: V.  V = I + 6 with variables [intrinsics(I), pose(6)], or V = I + 12 with
+ * [intrinsics(I), rig extrinsics(6), pose of the rig frame's reference image(6)] for a non-reference rig image;
  * sums / counts: [fixed, variable] robust residual sums and residual counts. */
 int e3d_reg_accumulate(e3d_reg_t* reg, int image_id, int point_scale, double* H, double* b, double sums[2],
                        int64_t counts[2]);

@@ -128,6 +128,9 @@ typedef struct {
   float fx_inv, fy_inv, cx_inv, cy_inv;
 } oreg_camera;
 
+/* a non-reference image of a rig frame: image_T_rig of its camera and the pose of the frame's reference image */
+typedef struct { float q_image_T_rig[4]; float q_rig_T_global[4]; float t_rig_T_global[3]; } oreg_rig_link;
+
 void oracle_reg_camera_init(oreg_camera* c, int type, int w, int h, const float* params);
 void oracle_reg_camera_scaled(const oreg_camera* in, float factor, oreg_camera* out);
 /* single-point entry points of the camera functions (unit tests restating src/camera/test/test_camera.cc) */
@@ -165,6 +168,20 @@ void oracle_reg_accumulate(const float* pts, size_t n_pts, float point_radius, c
                            const float* obs_y, const float* obs_scale, const uint8_t* flags, size_t n_obs, int robust_type,
                            float robust_param, float fixed_weight, float var_weight, double* H, double* b,
                            double sums[2], int64_t counts[2]);
+/* rig variants: rig == NULL is the plain image; else j_rig is n_obs x 6 and the local system has V = I + 12 unknowns
+ * [intrinsics, rig extrinsics, pose of the rig frame's reference image] */
+void oracle_reg_pass1_rig(const float* pts, float point_radius, const oreg_camera* cam_min, int min_image_scale,
+                          const uint8_t* const* images, const int* widths, const float R[9], const float t[3],
+                          const uint32_t* obs_idx, const float* obs_x, const float* obs_y, const float* obs_scale, size_t n_obs,
+                          const oreg_rig_link* rig, float* intensities, float* j_intr, float* j_pose, float* j_rig);
+void oracle_reg_accumulate_rig(const float* pts, size_t n_pts, float point_radius, const uint32_t* nbr, int K,
+                               const float* fixed_desc, const float* var_desc, const int32_t* obs_counts,
+                               const oreg_camera* cam_min, int min_image_scale, const uint8_t* const* images, const int* widths,
+                               const float R[9], const float t[3], const uint32_t* obs_idx, const float* obs_x,
+                               const float* obs_y, const float* obs_scale, const uint8_t* flags, size_t n_obs, int robust_type,
+                               float robust_param, float fixed_weight, float var_weight, const oreg_rig_link* rig,
+                               double* H, double* b, double sums[2], int64_t counts[2]);
+void oracle_se3_mul(const float qa[4], const float ta[3], const float qb[4], const float tb[3], float q[4], float t[3]);
 void oracle_reg_cost(size_t n_pts, const uint32_t* nbr, int K, const float* fixed_desc, const float* var_desc,
                      const int32_t* obs_counts, int min_image_scale, const uint8_t* const* images, const int* widths,
                      const uint32_t* obs_idx, const float* obs_x, const float* obs_y, const float* obs_scale,

@@ -27,6 +27,7 @@
 #include <string.h>
 
 #include "e3d_oracle.h"
+#include "oracle_math.h"
 
 static inline int f2i(float v) { return (v >= -2147483648.0f && v < 2147483648.0f) ? (int)v : INT_MIN; }
 static inline int d2i(double v) { return (v > -2147483649.0 && v < 2147483648.0) ? (int)v : INT_MIN; }
@@ -226,7 +227,8 @@ void oracle_reg_neighbors_observed(size_t n_pts, const uint32_t* obs_idx, size_t
 static void point_intensity_and_jacobians(const float* point, float point_radius, const oreg_camera* cam_min,
                                           int min_image_scale, const uint8_t* const* images, const int* widths,
                                           const float R[9], const float t[3], float ox, float oy, float oscale,
-                                          float* intensity, float* j_intr /*I*/, float* j_pose /*6*/) {
+                                          float* intensity, float* j_intr /*I*/, float* j_pose /*6*/,
+                                          const oreg_rig_link* rig /* NULL unless a non-reference rig image */, float* j_rig /*6*/) {
   const int I = cam_min->n_params;
   float T[3];
   rt(R, t, point, T);
@@ -259,26 +261,60 @@ static void point_intensity_and_jacobians(const float* point, float point_radius
   for (int i = 0; i < 3; ++i) a[i] = ji[0] * W[i] + (ji[1] * W[3 + i] + ji[2] * W[6 + i]);
   /* [I3 | 0 z -y ; -z 0 x ; y -x 0] */
   const float C[18] = {1, 0, 0, 0, T[2], -1 * T[1], 0, 1, 0, -1 * T[2], 0, T[0], 0, 0, 1, T[1], -1 * T[0], 0};
-  for (int j = 0; j < 6; ++j) j_pose[j] = a[0] * C[j] + (a[1] * C[6 + j] + a[2] * C[12 + j]);
+  if (!rig) {
+    for (int j = 0; j < 6; ++j) j_pose[j] = a[0] * C[j] + (a[1] * C[6 + j] + a[2] * C[12 + j]);
+    return;
+  }
+  /* non-reference rig image (intrinsics_and_pose_optimizer.cc:1107-1150): the pose block differentiates the rig pose,
+   * j_pose = ((j * P) * image_T_rig.rotationMatrix()) * [I3 | -[rig_T_global * point]x], and the extrinsics block is the
+   * ordinary pose formula at the transformed point. */
+  for (int j = 0; j < 6; ++j) j_rig[j] = a[0] * C[j] + (a[1] * C[6 + j] + a[2] * C[12 + j]);
+  float Rir[9];
+  om_quat_to_R_f(rig->q_image_T_rig, Rir);
+  float ar[3];
+  for (int i = 0; i < 3; ++i) ar[i] = a[0] * Rir[i] + (a[1] * Rir[3 + i] + a[2] * Rir[6 + i]);
+  /* rig_point = rig_T_global * point: Sophus SO3 action p + w*uv + v x uv with uv = 2 (v x p), then + translation */
+  const float* v = rig->q_rig_T_global + 1; const float w = rig->q_rig_T_global[0];
+  float uv[3], cr[3], G[3];
+  om_cross_f(v, point, uv);
+  for (int i = 0; i < 3; ++i) uv[i] = uv[i] + uv[i];
+  om_cross_f(v, uv, cr);
+  for (int i = 0; i < 3; ++i) G[i] = ((point[i] + w * uv[i]) + cr[i]) + rig->t_rig_T_global[i];
+  const float D[18] = {1, 0, 0, 0, G[2], -1 * G[1], 0, 1, 0, -1 * G[2], 0, G[0], 0, 0, 1, G[1], -1 * G[0], 0};
+  for (int j = 0; j < 6; ++j) j_pose[j] = ar[0] * D[j] + (ar[1] * D[6 + j] + ar[2] * D[12 + j]);
 }
 
+void oracle_reg_pass1_rig(const float* pts, float point_radius, const oreg_camera* cam_min, int min_image_scale,
+                          const uint8_t* const* images, const int* widths, const float R[9], const float t[3],
+                          const uint32_t* obs_idx, const float* obs_x, const float* obs_y, const float* obs_scale, size_t n_obs,
+                          const oreg_rig_link* rig, float* intensities, float* j_intr, float* j_pose, float* j_rig) {
+  float dummy[6];
+  for (size_t i = 0; i < n_obs; ++i)
+    point_intensity_and_jacobians(pts + 3 * (size_t)obs_idx[i], point_radius, cam_min, min_image_scale, images, widths, R,
+                                  t, obs_x[i], obs_y[i], obs_scale[i], &intensities[i], j_intr + (size_t)cam_min->n_params * i,
+                                  j_pose + 6 * i, rig, (rig && j_rig) ? j_rig + 6 * i : dummy);
+}
 void oracle_reg_pass1(const float* pts, float point_radius, const oreg_camera* cam_min, int min_image_scale,
                       const uint8_t* const* images, const int* widths, const float R[9], const float t[3],
                       const uint32_t* obs_idx, const float* obs_x, const float* obs_y, const float* obs_scale, size_t n_obs,
                       float* intensities, float* j_intr, float* j_pose) {
-  for (size_t i = 0; i < n_obs; ++i)
-    point_intensity_and_jacobians(pts + 3 * (size_t)obs_idx[i], point_radius, cam_min, min_image_scale, images, widths, R,
-                                  t, obs_x[i], obs_y[i], obs_scale[i], &intensities[i], j_intr + (size_t)cam_min->n_params * i,
-                                  j_pose + 6 * i);
+  oracle_reg_pass1_rig(pts, point_radius, cam_min, min_image_scale, images, widths, R, t, obs_idx, obs_x, obs_y, obs_scale, n_obs,
+                       NULL, intensities, j_intr, j_pose, NULL);
 }
 
 /* a18: AccumulateOnHAndB on the local (I+6) x (I+6) block: products in f32, cast, add in f64 */
-static void accumulate_on_h_and_b(int I, float weight, float residual, const float* ji, const float* jp, double* H, double* b) {
+/* local variable order [intrinsics(I), rig extrinsics(6, dependent rig images only), pose(6)]: the global layout is
+ * intrinsics < rigs < poses (CountAndIndexVariables :442-473), so the local upper triangle is what the reference's block
+ * updates (:1246-1283) touch */
+static void accumulate_on_h_and_b(int I, float weight, float residual, const float* ji, const float* jr, const float* jp, double* H,
+                                  double* b) {
   if (weight == 0) return;
-  const int V = I + 6;
-  float J[18];
-  for (int i = 0; i < I; ++i) J[i] = ji[i];
-  for (int i = 0; i < 6; ++i) J[I + i] = jp[i];
+  const int V = I + (jr ? 12 : 6);
+  float J[24];
+  int n = 0;
+  for (int i = 0; i < I; ++i) J[n++] = ji[i];
+  if (jr) for (int i = 0; i < 6; ++i) J[n++] = jr[i];
+  for (int i = 0; i < 6; ++i) J[n++] = jp[i];
   for (int i = 0; i < V; ++i)
     for (int j = i; j < V; ++j) {
       /* (weight * j^T) * j  in f32 (block-wise expressions of the reference evaluate to exactly this per entry) */
@@ -297,14 +333,27 @@ void oracle_reg_accumulate(const float* pts, size_t n_pts, float point_radius, c
                            const float* obs_y, const float* obs_scale, const uint8_t* flags, size_t n_obs, int robust_type,
                            float robust_param, float fixed_weight, float var_weight, double* H /*VxV*/, double* b /*V*/,
                            double sums[2], int64_t counts[2]) {
-  const int NI = cam_min->n_params, V = NI + 6;
+  oracle_reg_accumulate_rig(pts, n_pts, point_radius, nbr, K, fixed_desc, var_desc, obs_counts, cam_min, min_image_scale, images,
+                            widths, R, t, obs_idx, obs_x, obs_y, obs_scale, flags, n_obs, robust_type, robust_param, fixed_weight,
+                            var_weight, NULL, H, b, sums, counts);
+}
+
+void oracle_reg_accumulate_rig(const float* pts, size_t n_pts, float point_radius, const uint32_t* nbr, int K,
+                               const float* fixed_desc, const float* var_desc, const int32_t* obs_counts,
+                               const oreg_camera* cam_min, int min_image_scale, const uint8_t* const* images, const int* widths,
+                               const float R[9], const float t[3], const uint32_t* obs_idx, const float* obs_x,
+                               const float* obs_y, const float* obs_scale, const uint8_t* flags, size_t n_obs, int robust_type,
+                               float robust_param, float fixed_weight, float var_weight, const oreg_rig_link* rig,
+                               double* H /*VxV*/, double* b /*V*/, double sums[2], int64_t counts[2]) {
+  const int NI = cam_min->n_params, V = NI + (rig ? 12 : 6);
+  float* JR = (float*)malloc(sizeof(float) * 6 * (n_obs + 1));
   float* I = (float*)malloc(sizeof(float) * (n_obs + 1));
   float* JI = (float*)malloc(sizeof(float) * NI * (n_obs + 1));
   float* JP = (float*)malloc(sizeof(float) * 6 * (n_obs + 1));
   int64_t* row = (int64_t*)malloc(sizeof(int64_t) * (n_pts + 1));
   for (size_t i = 0; i < n_pts; ++i) row[i] = -1;
-  oracle_reg_pass1(pts, point_radius, cam_min, min_image_scale, images, widths, R, t, obs_idx, obs_x, obs_y, obs_scale, n_obs,
-                   I, JI, JP);
+  oracle_reg_pass1_rig(pts, point_radius, cam_min, min_image_scale, images, widths, R, t, obs_idx, obs_x, obs_y, obs_scale, n_obs,
+                       rig, I, JI, JP, JR);
   for (size_t i = 0; i < n_obs; ++i) row[obs_idx[i]] = (int64_t)i;
   memset(H, 0, sizeof(double) * V * V); memset(b, 0, sizeof(double) * V);
   sums[0] = sums[1] = 0; counts[0] = counts[1] = 0;
@@ -332,15 +381,24 @@ void oracle_reg_accumulate(const float* pts, size_t n_pts, float point_radius, c
       if (w != 0) {
         for (int k = 0; k < K; ++k) {
           const int64_t nr = row[nbr[p * K + k]];
-          float ji[12], jp[6];
+          float ji[12], jp[6], jr[6];
           for (int q = 0; q < NI; ++q) ji[q] = JI[(size_t)NI * nr + q] - JI[(size_t)NI * i + q];
           for (int q = 0; q < 6; ++q) jp[q] = JP[6 * nr + q] - JP[6 * i + q];
-          accumulate_on_h_and_b(NI, w, comp[k], ji, jp, H, b);
+          if (rig) for (int q = 0; q < 6; ++q) jr[q] = JR[6 * nr + q] - JR[6 * i + q];
+          accumulate_on_h_and_b(NI, w, comp[k], ji, rig ? jr : NULL, jp, H, b);
         }
       }
     }
   }
-  free(I); free(JI); free(JP); free(row);
+  free(I); free(JI); free(JP); free(JR); free(row);
+}
+
+/* Sophus::SE3f product a * b (rig.image_T_rig[c] * first_image.image_T_global, intrinsics_and_pose_optimizer.cc:545-546) */
+void oracle_se3_mul(const float qa[4], const float ta[3], const float qb[4], const float tb[3], float q[4], float t[3]) {
+  om_se3f a, b, c;
+  memcpy(a.q, qa, sizeof a.q); memcpy(a.t, ta, sizeof a.t); memcpy(b.q, qb, sizeof b.q); memcpy(b.t, tb, sizeof b.t);
+  om_se3f_mul(&a, &b, &c);
+  memcpy(q, c.q, sizeof c.q); memcpy(t, c.t, sizeof c.t);
 }
 
 /* ---- a19 --------------------------------------------------------------------------------------------------------------- */

@@ -15,6 +15,19 @@ class Camera(C.Structure):
         return np.array(self.p[:self.n_params], np.float32)
 
 
+class RigLink(C.Structure):
+    """A non-reference image of a rig frame: image_T_rig quaternion of its camera + pose of the frame's reference image."""
+    _fields_ = [("q_image_T_rig", C.c_float * 4), ("q_rig_T_global", C.c_float * 4), ("t_rig_T_global", C.c_float * 3)]
+
+
+def rig_link(q_image_T_rig, q_rig_T_global, t_rig_T_global):
+    r = RigLink()
+    r.q_image_T_rig[:] = [float(v) for v in q_image_T_rig]
+    r.q_rig_T_global[:] = [float(v) for v in q_rig_T_global]
+    r.t_rig_T_global[:] = [float(v) for v in t_rig_T_global]
+    return r
+
+
 PINHOLE, OPENCV, THIN_PRISM_FISHEYE = 0, 1, 2
 PARAM_COUNT = {0: 4, 1: 8, 2: 12}
 
@@ -48,6 +61,11 @@ def lib():
         L.oracle_reg_observe.restype = C.c_size_t
         L.oracle_reg_neighbors_observed.argtypes = [C.c_size_t, u32p, C.c_size_t, u32p, C.c_int, u8p]
         L.oracle_reg_pass1.argtypes = [fp, C.c_float, cp, C.c_int, u8pp, ip, fp, fp, u32p, fp, fp, fp, C.c_size_t, fp, fp, fp]
+        rp = C.POINTER(RigLink)
+        L.oracle_reg_pass1_rig.argtypes = [fp, C.c_float, cp, C.c_int, u8pp, ip, fp, fp, u32p, fp, fp, fp, C.c_size_t, rp, fp, fp, fp, fp]
+        L.oracle_reg_accumulate_rig.argtypes = [fp, C.c_size_t, C.c_float, u32p, C.c_int, fp, fp, i32p, cp, C.c_int, u8pp, ip, fp, fp,
+                                                u32p, fp, fp, fp, u8p, C.c_size_t, C.c_int, C.c_float, C.c_float, C.c_float, rp, dp, dp, dp, i64p]
+        L.oracle_se3_mul.argtypes = [fp, fp, fp, fp, fp, fp]
         L.oracle_reg_accumulate.argtypes = [fp, C.c_size_t, C.c_float, u32p, C.c_int, fp, fp, i32p, cp, C.c_int, u8pp, ip, fp, fp,
                                             u32p, fp, fp, fp, u8p, C.c_size_t, C.c_int, C.c_float, C.c_float, C.c_float, dp, dp, dp, i64p]
         L.oracle_reg_cost.argtypes = [C.c_size_t, u32p, C.c_int, fp, fp, i32p, C.c_int, u8pp, ip, u32p, fp, fp, fp, u8p, C.c_size_t,
@@ -157,32 +175,43 @@ def neighbors_observed(n_pts, obs_idx, nbr, K):
     return f[:len(obs_idx)].copy()
 
 
-def pass1(pts, point_radius, cam_min, min_image_scale, images, R, t, obs):
+def se3_mul(qa, ta, qb, tb):
+    a = [np.ascontiguousarray(v, np.float32) for v in (qa, ta, qb, tb)]
+    q = np.zeros(4, np.float32); t = np.zeros(3, np.float32)
+    lib().oracle_se3_mul(*[_p(v, C.c_float) for v in a], _p(q, C.c_float), _p(t, C.c_float))
+    return q, t
+
+
+def pass1(pts, point_radius, cam_min, min_image_scale, images, R, t, obs, rig=None):
     pts = np.ascontiguousarray(pts, np.float32); R = np.ascontiguousarray(R, np.float32); t = np.ascontiguousarray(t, np.float32)
     ip, widths, keep = _img_ptrs(images)
     oi, ox, oy, os_ = [np.ascontiguousarray(a) for a in obs]
     n = len(oi)
     I = np.zeros(n + 1, np.float32); JI = np.zeros((n + 1, cam_min.n_params), np.float32); JP = np.zeros((n + 1, 6), np.float32)
-    lib().oracle_reg_pass1(_p(pts, C.c_float), point_radius, C.byref(cam_min), min_image_scale, ip, _p(widths, C.c_int), _p(R, C.c_float),
-                           _p(t, C.c_float), _p(oi, C.c_uint32), _p(ox, C.c_float), _p(oy, C.c_float), _p(os_, C.c_float), n,
-                           _p(I, C.c_float), _p(JI, C.c_float), _p(JP, C.c_float))
+    JR = np.zeros((n + 1, 6), np.float32)
+    lib().oracle_reg_pass1_rig(_p(pts, C.c_float), point_radius, C.byref(cam_min), min_image_scale, ip, _p(widths, C.c_int), _p(R, C.c_float),
+                               _p(t, C.c_float), _p(oi, C.c_uint32), _p(ox, C.c_float), _p(oy, C.c_float), _p(os_, C.c_float), n,
+                               C.byref(rig) if rig is not None else None, _p(I, C.c_float), _p(JI, C.c_float), _p(JP, C.c_float),
+                               _p(JR, C.c_float))
+    if rig is not None:
+        return I[:n].copy(), JI[:n].copy(), JP[:n].copy(), JR[:n].copy()
     return I[:n].copy(), JI[:n].copy(), JP[:n].copy()
 
 
 def accumulate(pts, point_radius, nbr, K, fixed_desc, var_desc, obs_counts, cam_min, min_image_scale, images, R, t, obs, flags,
-               robust_type, robust_param, fixed_weight, var_weight):
+               robust_type, robust_param, fixed_weight, var_weight, rig=None):
     pts = np.ascontiguousarray(pts, np.float32); R = np.ascontiguousarray(R, np.float32); t = np.ascontiguousarray(t, np.float32)
     nbr = np.ascontiguousarray(nbr, np.uint32); fd = np.ascontiguousarray(fixed_desc, np.float32); vd = np.ascontiguousarray(var_desc, np.float32)
     oc = np.ascontiguousarray(obs_counts, np.int32); fl = np.ascontiguousarray(flags, np.uint8)
     ip, widths, keep = _img_ptrs(images)
     oi, ox, oy, os_ = [np.ascontiguousarray(a) for a in obs]
-    V = cam_min.n_params + 6
+    V = cam_min.n_params + (12 if rig is not None else 6)
     H = np.zeros((V, V)); b = np.zeros(V); sums = np.zeros(2); counts = np.zeros(2, np.int64)
-    lib().oracle_reg_accumulate(_p(pts, C.c_float), pts.shape[0], point_radius, _p(nbr, C.c_uint32), K, _p(fd, C.c_float), _p(vd, C.c_float),
-                                _p(oc, C.c_int32), C.byref(cam_min), min_image_scale, ip, _p(widths, C.c_int), _p(R, C.c_float), _p(t, C.c_float),
-                                _p(oi, C.c_uint32), _p(ox, C.c_float), _p(oy, C.c_float), _p(os_, C.c_float), _p(fl, C.c_uint8), len(oi),
-                                robust_type, robust_param, fixed_weight, var_weight, _p(H, C.c_double), _p(b, C.c_double),
-                                _p(sums, C.c_double), _p(counts, C.c_int64))
+    lib().oracle_reg_accumulate_rig(_p(pts, C.c_float), pts.shape[0], point_radius, _p(nbr, C.c_uint32), K, _p(fd, C.c_float), _p(vd, C.c_float),
+                                    _p(oc, C.c_int32), C.byref(cam_min), min_image_scale, ip, _p(widths, C.c_int), _p(R, C.c_float), _p(t, C.c_float),
+                                    _p(oi, C.c_uint32), _p(ox, C.c_float), _p(oy, C.c_float), _p(os_, C.c_float), _p(fl, C.c_uint8), len(oi),
+                                    robust_type, robust_param, fixed_weight, var_weight, C.byref(rig) if rig is not None else None,
+                                    _p(H, C.c_double), _p(b, C.c_double), _p(sums, C.c_double), _p(counts, C.c_int64))
     return H, b, sums, counts
 
 

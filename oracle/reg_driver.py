@@ -7,7 +7,7 @@ Orchestrates the C per-observation oracle (oracle_reg.c) exactly as the referenc
   VisibilityEstimator::CreateObservationsForAllImages   src/opt/visibility_estimator.cc:49-91
   ColorOptimizer::Apply                                 src/opt/color_optimizer.cc:40-123
   CostCalculator::ComputeCost, Problem::ComputeCost     src/opt/cost_calculator.cc:44-100, src/opt/problem.cc:602-631
-Only numpy-array plumbing happens in Python; every per-point / per-observation loop is in C.  Non-rig images; PINHOLE / OPENCV / THIN_PRISM_FISHEYE.
+Only numpy-array plumbing happens in Python; every per-point / per-observation loop is in C.  Non-rig and rig images; PINHOLE / OPENCV / THIN_PRISM_FISHEYE.
 Images are visited in ascending id (the reference's unordered_map order is unspecified).
 """
 import numpy as np
@@ -28,6 +28,8 @@ class OracleRegProblem:
         self.splat_radius = splat_radius
         self.current_image_scale = current_image_scale; self.image_scale_count = image_scale_count
         self.scales = {}; self.intr = {}; self.images = {}; self.splat = None
+        self.rigs = {}         # rig_id -> list of (q, t) image_T_rig per camera (camera 0 = reference)
+        self.frames = []       # RigImages: (rig_id, [image id per camera])
         self.obs = {}     # (image, scale) -> (idx, x, y, s, flags)
 
     # ---- state ------------------------------------------------------------------------------------------------------------
@@ -56,9 +58,42 @@ class OracleRegProblem:
     def set_image_pose(self, image_id, q, t):
         self.images[image_id]["q"] = np.ascontiguousarray(q, np.float32).copy()
         self.images[image_id]["t"] = np.ascontiguousarray(t, np.float32).copy()
+        if self.frames:
+            self._compose_rig_poses()
 
     def get_image_pose(self, image_id):
         return self.images[image_id]["q"].copy(), self.images[image_id]["t"].copy()
+
+    # ---- rigs (src/opt/rig.h:41-76, problem.h RigImages) --------------------------------------------------------------------
+    def set_rig(self, rig_id, image_T_rig):
+        self.rigs[rig_id] = [(np.ascontiguousarray(q, np.float32).copy(), np.ascontiguousarray(t, np.float32).copy()) for q, t in image_T_rig]
+
+    def add_rig_images(self, rig_id, image_ids):
+        self.frames.append((rig_id, list(image_ids)))
+        for c, iid in enumerate(image_ids):
+            self.images[iid]["rig"] = (rig_id, c, image_ids[0])
+        self._compose_rig_poses()
+
+    def get_rig(self, rig_id, camera):
+        q, t = self.rigs[rig_id][camera]
+        return q.copy(), t.copy()
+
+    def _compose_rig_poses(self):
+        """image_T_global of non-reference rig images = image_T_rig[c] * reference image_T_global (CreateDeltaState :539-548)."""
+        for rig_id, ids in self.frames:
+            ref = self.images[ids[0]]
+            for c, iid in enumerate(ids):
+                if c == 0:
+                    continue
+                q, t = rb.se3_mul(*self.rigs[rig_id][c], ref["q"], ref["t"])
+                self.images[iid]["q"], self.images[iid]["t"] = q, t
+
+    def _rig_link(self, image_id):
+        r = self.images[image_id].get("rig")
+        if r is None or r[1] == 0:
+            return None
+        ref = self.images[r[2]]
+        return rb.rig_link(self.rigs[r[0]][r[1]][0], ref["q"], ref["t"])
 
     def set_splat_points(self, xyz):
         self.splat = np.ascontiguousarray(xyz, np.float32)
@@ -67,13 +102,16 @@ class OracleRegProblem:
         return ob.quat_to_R(im["q"])
 
     def get_state(self):
-        return ({k: v["params"].copy() for k, v in self.intr.items()}, {k: (v["q"].copy(), v["t"].copy()) for k, v in self.images.items()})
+        return ({k: v["params"].copy() for k, v in self.intr.items()}, {k: (v["q"].copy(), v["t"].copy()) for k, v in self.images.items()},
+                {k: [(q.copy(), t.copy()) for q, t in v] for k, v in self.rigs.items()})
 
     def set_state(self, st):
         for k, p in st[0].items():
             self.intr[k]["params"] = p.copy(); self._rebuild(k)
         for k, (q, t) in st[1].items():
             self.images[k]["q"] = q.copy(); self.images[k]["t"] = t.copy()
+        if len(st) > 2:
+            self.rigs = {k: [(q.copy(), t.copy()) for q, t in v] for k, v in st[2].items()}
 
     # ---- steps -------------------------------------------------------------------------------------------------------------
     def _best_scale(self, I):
@@ -148,16 +186,29 @@ class OracleRegProblem:
         V = 0
         for k in sorted(self.intr):
             intr_index[k] = V; V += len(self.intr[k]["params"])
-        for k in sorted(self.images):
+        rig_index = {}
+        for k in sorted(self.rigs):                       # rig extrinsics, reference camera excluded (:455-460)
+            rig_index[k] = V; V += 6 * (len(self.rigs[k]) - 1)
+        for k in sorted(self.images):                     # poses: non-rig images and rig reference images (:461-472)
+            r = self.images[k].get("rig")
+            if r is not None and r[1] > 0:
+                continue
             image_index[k] = V; V += 6
         H = np.zeros((V, V)); b = np.zeros(V)
         sums = np.zeros(2); counts = np.zeros(2, np.int64)
         vis = {}
         for image_id in sorted(self.images):
             im = self.images[image_id]; I = self.intr[im["intr"]]
-            ii, pi = intr_index[im["intr"]], image_index[image_id]
             NI = len(I["params"])
-            g = list(range(ii, ii + NI)) + list(range(pi, pi + 6))
+            ii = intr_index[im["intr"]]
+            link = self._rig_link(image_id)
+            if link is None:
+                pi = image_index[image_id]
+                g = list(range(ii, ii + NI)) + list(range(pi, pi + 6))
+            else:
+                rid, cam_i, ref_id = im["rig"]
+                ri = rig_index[rid] + 6 * (cam_i - 1); pi = image_index[ref_id]
+                g = list(range(ii, ii + NI)) + list(range(ri, ri + 6)) + list(range(pi, pi + 6))
             for s in sorted(self.scales):
                 if (image_id, s) not in self.obs:
                     continue
@@ -165,10 +216,10 @@ class OracleRegProblem:
                 vis[(image_id, s)] = o[0].copy()
                 Hl, bl, s2, c2 = rb.accumulate(S["pts"], float(S["radius"]), S["nbr"], self.K, S["fixed"], S["var"], S["counts"], I["levels"][0],
                                                I["min"], im["pyr"], self._R(im), im["t"], o[:4], o[4], self.robust_type, self.robust_param,
-                                               self.fixed_weight, self.var_weight)
+                                               self.fixed_weight, self.var_weight, rig=link)
                 sums += s2; counts += c2
-                for r in range(NI + 6):
-                    for c in range(r, NI + 6):
+                for r in range(len(g)):
+                    for c in range(r, len(g)):
                         H[g[r], g[c]] += Hl[r, c]
                     b[g[r]] += bl[r]
         initial = self._cost_value(sums, counts)
@@ -181,8 +232,12 @@ class OracleRegProblem:
             Hl[np.diag_indices(V)] *= (1 + lam)
             x = ob.ldlt_solve_upper(Hl, b)
             params = {k: (p + (-1 * x[intr_index[k]:intr_index[k] + len(p)])).astype(np.float32) for k, p in old[0].items()}
-            poses = {k: ob.se3_update(x[image_index[k]:image_index[k] + 6], q, t) for k, (q, t) in old[1].items()}
-            self.set_state((params, poses))
+            poses = {k: (ob.se3_update(x[image_index[k]:image_index[k] + 6], q, t) if k in image_index else (q, t))
+                     for k, (q, t) in old[1].items()}
+            rigs = {k: [v[0]] + [ob.se3_update(x[rig_index[k] + 6 * (c - 1):rig_index[k] + 6 * c], *v[c]) for c in range(1, len(v))]
+                    for k, v in old[2].items()}                                              # Rig::Update (rig.cc:9-23)
+            self.set_state((params, poses, rigs))
+            self._compose_rig_poses()
             trial_obs = {}
             for image_id in sorted(self.images):
                 I = self.intr[self.images[image_id]["intr"]]

@@ -137,3 +137,47 @@ def make_reg_scene(n_points=6000, width=320, height=240, n_levels=4, K=5, seed=0
     obs_counts = rng.randint(0, 4, n_points).astype(np.int32)
     return dict(pts=pts, nbr=nbr, K=K, pyr=pyr, R=R, q=q, t=t, params=params, width=width, height=height, n_levels=n_levels,
                 fixed_desc=fixed_desc, var_desc=var_desc, obs_counts=obs_counts, point_radius=0.012, model=model)
+
+
+def make_rig_scene(n_points=6000, n_frames=2, width=240, height=180, n_levels=3, K=5, seed=0, perturb=0.004, model=0):
+    """Two-camera rig observed in `n_frames` frames (image ids 2f = reference camera, 2f + 1 = second camera): images are
+    ray-traced from the true rig geometry; start values perturb the frame poses and the rig extrinsics."""
+    from scipy.spatial import cKDTree
+    from scipy.spatial.transform import Rotation
+    from oracle import reg_binding as rb
+    rng = np.random.RandomState(seed)
+    u = rng.uniform(-1.0, 1.0, n_points); v = rng.uniform(-0.75, 0.75, n_points)
+    pts = np.stack([u, np.full(n_points, 3.0), v], 1).astype(np.float32)
+    _, nn = cKDTree(pts).query(pts, k=K + 1)
+    nbr = nn[:, 1:].astype(np.uint32)
+    tex = texture(pts[:, 0].astype(np.float64), pts[:, 2].astype(np.float64))
+    fixed_desc = (tex[nbr] - tex[:, None]).astype(np.float32)
+    params = np.array([210.0, 208.0, width / 2 - 0.4, height / 2 + 0.3] + DISTORTION[model], np.float32)
+    # true extrinsics of camera 1: 12 cm baseline, a few degrees of rotation
+    R1 = Rotation.from_rotvec([0.01, -0.04, 0.02]).as_matrix()
+    q1_true = quat_from_R(R1); t1_true = np.array([-0.12, 0.01, 0.005], np.float32)
+    ident = (np.array([1, 0, 0, 0], np.float32), np.zeros(3, np.float32))
+    eyes = [(-0.3, -0.3, 0.1), (0.25, -0.25, -0.08), (0.0, -0.45, 0.2)][:n_frames]
+    images = []
+    for f, eye in enumerate(eyes):
+        R0, t0 = look_at_pose(eye, (0.05 * f, 3, 0.02 * f))
+        q_ref = quat_from_R(R0)
+        q_dep, t_dep = rb.se3_mul(q1_true, t1_true, q_ref, t0)
+        dq = rng.normal(size=3) * perturb; dt = rng.normal(size=3) * perturb
+        q_init = quat_from_R(Rotation.from_rotvec(dq).as_matrix() @ quat_to_R(q_ref).astype(np.float64))
+        for q, t in ((q_ref, t0), (q_dep, t_dep)):
+            R = quat_to_R(q).astype(np.float64); tt = t.astype(np.float64)
+            yy, xx = np.mgrid[0:height, 0:width].astype(np.float64)
+            unx, uny = undistort_np(model, [float(v) for v in params[4:]], (xx - params[2]) / params[0], (yy - params[3]) / params[1])
+            d = np.stack([unx, uny, np.ones_like(xx)], -1) @ R
+            o = -R.T @ tt
+            lam = (3.0 - o[1]) / d[..., 1]
+            hit = o + lam[..., None] * d
+            img = texture(hit[..., 0], hit[..., 2]).clip(0, 250)
+            images.append(dict(pyr=pyramid_u8(np.rint(img).astype(np.uint8), n_levels), q_true=q, t_true=t.astype(np.float32)))
+        images[-2]["q_init"] = q_init; images[-2]["t_init"] = (t0.astype(np.float64) + dt).astype(np.float32)
+    dq = rng.normal(size=3) * perturb
+    rig_init = [ident, (quat_from_R(Rotation.from_rotvec(dq).as_matrix() @ R1), (t1_true + rng.normal(size=3).astype(np.float32) * perturb).astype(np.float32))]
+    return dict(pts=pts, nbr=nbr, K=K, fixed_desc=fixed_desc, params=params, width=width, height=height, n_levels=n_levels,
+                images=images, point_radius=0.01, model=model, rig_true=[ident, (q1_true, t1_true)], rig_init=rig_init,
+                frames=[[2 * f, 2 * f + 1] for f in range(n_frames)])

@@ -241,3 +241,73 @@ def test_run_on_current_scale_matches_oracle_and_improves(e3d, model, var_weight
         err0 += a0 + t0; err1 += a1 + t1
     assert O.history[-1] < O.history[0]            # the photometric cost went down
     assert costg <= O.history[0]
+
+
+# ---- camera rigs (Rig::Update, dependent rig images) ----------------------------------------------------------------------------
+def _build_rig_both(e3d, M):
+    from oracle.reg_driver import OracleRegProblem
+    prm = e3d.default_reg_params(image_scale_count=M["n_levels"], point_neighbor_count=M["K"])
+    G = e3d.RegProblem(prm)
+    O = OracleRegProblem(K=M["K"], image_scale_count=M["n_levels"])
+    for P in (G, O):
+        if P is G:
+            P.set_intrinsics(0, M["width"], M["height"], M["params"], 0, M["n_levels"], camera_type=M["model"])
+        else:
+            P.set_intrinsics(0, M["width"], M["height"], M["params"], 0, M["n_levels"], model=M["model"])
+        P.set_point_scale(0, M["pts"], M["point_radius"], M["nbr"], M["fixed_desc"])
+        P.set_splat_points(M["pts"])
+        for i, im in enumerate(M["images"]):
+            P.set_image(i, 0, im["pyr"])
+            if "q_init" in im:
+                P.set_image_pose(i, im["q_init"], im["t_init"])
+        P.set_rig(0, M["rig_init"])
+        for ids in M["frames"]:
+            P.add_rig_images(0, ids)
+    return G, O
+
+
+@pytest.mark.parametrize("model", MODELS)
+def test_rig_image_blocks_match_oracle(e3d, rb, model):
+    """Non-reference rig image: derived pose, and the (I + 12)-unknown system [intrinsics, extrinsics, rig pose]."""
+    from reg_util import make_rig_scene
+    M = make_rig_scene(n_points=6000, seed=9, model=model)
+    G, O = _build_rig_both(e3d, M)
+    for i in (1, 3):                                          # derived poses: image_T_rig[1] * reference pose
+        qg, tg = G.get_image_pose(i); qo, to = O.get_image_pose(i)
+        assert np.array_equal(qg, qo) and np.array_equal(tg, to)
+    G.update_observations(1); O.update_observations(1)
+    NI = rb.PARAM_COUNT[model]
+    for i in range(4):
+        S = O.scales[0]; im = O.images[i]; I0 = O.intr[0]; o = O.obs[(i, 0)]
+        link = O._rig_link(i)
+        G.set_observations(i, 0, *o[:4])
+        H, b, sums, counts = G.accumulate(i, 0)
+        Ho, bo, so, co = rb.accumulate(S["pts"], float(S["radius"]), S["nbr"], O.K, S["fixed"], S["var"], S["counts"], I0["levels"][0], 0,
+                                       im["pyr"], O._R(im), im["t"], o[:4], o[4], O.robust_type, O.robust_param, 1.0, 1.0, rig=link)
+        V = NI + (12 if i % 2 else 6)
+        assert H.shape == Ho.shape == (V, V) and np.array_equal(counts, co) and counts[0] > 500
+        scale = np.sqrt(np.outer(np.diag(Ho), np.diag(Ho)))
+        tol = 1e-6 if model in EXACT else 1e-4
+        assert (np.abs(H - Ho) / scale).max() <= tol
+        assert (np.abs(b - bo) / np.sqrt(np.diag(Ho))).max() <= 10 * tol * np.abs(bo / np.sqrt(np.diag(Ho))).max()
+
+
+@pytest.mark.parametrize("model", [0, 2])
+def test_rig_optimization_matches_oracle(e3d, model):
+    from reg_util import make_rig_scene
+    M = make_rig_scene(n_points=6000, seed=10, model=model)
+    G, O = _build_rig_both(e3d, M)
+    cg, costg, itg = G.run_on_current_scale(6, 0.0, 15, False)
+    co, costo, ito = O.run_on_current_scale(6, 0.0, 15, False)
+    assert (cg, itg) == (co, ito) and abs(costg - costo) <= 1e-4 * costo
+    for i in range(4):
+        ang, tr = _pose_delta(*G.get_image_pose(i), *O.get_image_pose(i))
+        assert ang <= 1e-4 and tr <= 1e-4, (i, ang, tr)
+    ang, tr = _pose_delta(*G.get_rig(0, 1), *O.get_rig(0, 1))
+    assert ang <= 1e-4 and tr <= 1e-4
+    qg, tg = G.get_rig(0, 0)
+    assert np.array_equal(qg, M["rig_init"][0][0]) and np.array_equal(tg, M["rig_init"][0][1])      # the reference camera never moves
+    assert O.history[-1] < O.history[0]
+    # the extrinsics moved towards the truth
+    a0, t0 = _pose_delta(*M["rig_init"][1], *M["rig_true"][1]); a1, t1 = _pose_delta(*G.get_rig(0, 1), *M["rig_true"][1])
+    assert a1 + t1 < a0 + t0

@@ -93,6 +93,7 @@ SIGNATURES = {
     "e3d_reg_set_rig": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "e3d_reg_get_rig": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "e3d_reg_add_rig_images": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
+    "e3d_determine_point_neighbors": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "e3d_reg_set_shard": (C.c_int, [C.c_void_p, C.c_int, C.c_int, ALLREDUCE_FN, ALLREDUCE_DEVICE_FN, C.c_void_p]),
     "e3d_reg_image_owner": (C.c_int, [C.c_void_p, C.c_int]),
 }
@@ -305,6 +306,18 @@ def normals_knn(xyz, k, viewpoint=(0.0, 0.0, 0.0), return_knn=False):
 
 # ---- (B) image registration kernels ------------------------------------------------------------------------------------
 CAMERA_PINHOLE, CAMERA_OPENCV, CAMERA_THIN_PRISM_FISHEYE = 0, 1, 2
+
+
+def determine_point_neighbors(xyz, neighbor_count, candidate_count, scan_indices=None, scan_count=1):
+    """Problem::DeterminePointNeighbors -> (n, neighbor_count) uint32."""
+    xyz = np.ascontiguousarray(xyz, np.float32)
+    out = np.zeros((xyz.shape[0], neighbor_count), np.uint32)
+    si = np.ascontiguousarray(scan_indices, np.uint8) if scan_indices is not None else None
+    r = lib().e3d_determine_point_neighbors(C.c_void_p(xyz.ctypes.data), xyz.shape[0], C.c_void_p(si.ctypes.data) if si is not None else None,
+                                            scan_count, 1 if si is not None else 0, neighbor_count, candidate_count, C.c_void_p(out.ctypes.data))
+    if r < 0:
+        _err("e3d_determine_point_neighbors", r)
+    return out
 
 
 class RegParams(C.Structure):

@@ -18,6 +18,8 @@
 #include <map>
 #include <memory>
 
+#include <random>
+
 #include "../../include/e3d_hip.h"
 #include "e3d_camera.hpp"
 #include "e3d_icp_kernels.hpp"
@@ -1657,6 +1659,53 @@ int e3d_reg_image_owner(e3d_reg_t* h, int image_id) {
   R_TRY
   if (!h) throw Error(E3D_ERR_INVALID, "null handle");
   return h->world <= 1 ? 0 : ((image_id % h->world) + h->world) % h->world;
+  R_CATCH()
+}
+
+/* Problem::DeterminePointNeighbors (src/opt/problem.cc:706-786): the (candidates + 1) nearest neighbours of every point --
+ * within its own scan if limit_to_same_scan -- from the GPU k-NN of path (A'), then libstdc++'s
+ * std::shuffle(indices + 1, end, std::mt19937(0)) with ONE generator consumed in the reference's point order (scan by scan,
+ * point by point), keeping the first neighbor_count. */
+int e3d_determine_point_neighbors(const float* xyz, size_t n, const uint8_t* scan_indices, int scan_count, int limit_to_same_scan,
+                                  int neighbor_count, int candidate_count, uint32_t* neighbor_indices) {
+  R_TRY
+  if ((!xyz && n) || !neighbor_indices || neighbor_count < 1 || candidate_count < neighbor_count) throw Error(E3D_ERR_INVALID, "bad argument");
+  if (limit_to_same_scan && (!scan_indices || scan_count < 1)) throw Error(E3D_ERR_INVALID, "scan indices required");
+  const int k = candidate_count + 1;
+  std::mt19937 generator(/*seed*/ 0);
+  std::vector<int> indices(k);
+  const float vp[3] = {0.f, 0.f, 0.f};
+  auto run = [&](const std::vector<float>& pts, const std::vector<size_t>* original, bool check_self) {
+    const size_t m = pts.size() / 3;
+    if (m < (size_t)k) throw Error(E3D_ERR_INVALID, fmt("a cloud of %zu points cannot provide %d neighbour candidates", m, candidate_count));
+    std::vector<float> nrm(3 * m), curv(m);
+    std::vector<int32_t> knn(m * (size_t)k);
+    if (e3d_normals_knn(pts.data(), m, k, vp, nrm.data(), curv.data(), knn.data()) < 0) throw Error(E3D_ERR_INVALID, e3d_last_error());
+    for (size_t i = 0; i < m; ++i) {
+      for (int j = 0; j < k; ++j) indices[j] = knn[i * k + j];
+      if (check_self && indices[0] != (int)i) throw Error(E3D_ERR_INVALID, fmt("point %zu is not its own nearest neighbour (duplicate points)", i));
+      std::shuffle(indices.begin() + 1, indices.end(), generator);
+      const size_t o = original ? (*original)[i] : i;
+      for (int j = 0; j < neighbor_count; ++j)
+        neighbor_indices[o * neighbor_count + j] = (uint32_t)(original ? (*original)[indices[j + 1]] : (size_t)indices[j + 1]);
+    }
+  };
+  if (limit_to_same_scan) {
+    std::vector<std::vector<float>> clouds(scan_count);
+    std::vector<std::vector<size_t>> orig(scan_count);
+    for (size_t i = 0; i < n; ++i) {
+      const int sidx = scan_indices[i];
+      if (sidx >= scan_count) throw Error(E3D_ERR_INDEX, "scan index out of range");
+      clouds[sidx].insert(clouds[sidx].end(), xyz + 3 * i, xyz + 3 * i + 3);
+      orig[sidx].push_back(i);
+    }
+    for (int sidx = 0; sidx < scan_count; ++sidx)
+      if (clouds[sidx].size() / 3 < (size_t)k) throw Error(E3D_ERR_INVALID, fmt("scan %d has fewer than %d points at this scale", sidx, k));
+    for (int sidx = 0; sidx < scan_count; ++sidx) run(clouds[sidx], &orig[sidx], false);
+  } else {
+    run(std::vector<float>(xyz, xyz + 3 * n), nullptr, true);
+  }
+  return 0;
   R_CATCH()
 }
 

@@ -67,6 +67,7 @@ struct PointCloud {
   std::vector<float> normals;   // n x 3 (optional)
   std::vector<float> curvature; // n (optional)
   std::vector<uint8_t> rgb;     // n x 3 (optional)
+  std::vector<float> intensity; // n (optional; pcl::PointXYZI files of the multi-resolution cloud cache)
   size_t size() const { return xyz.size() / 3; }
   typedef std::shared_ptr<PointCloud> Ptr;
 };

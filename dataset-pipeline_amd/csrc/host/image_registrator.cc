@@ -1,0 +1,147 @@
+// ImageRegistrator -- drop-in replacement of the reference tool (src/exe/image_registrator.cc:58-332): refines camera
+// intrinsics, image poses and rig extrinsics against the laser scan geometry by dense photometric alignment, coarse to
+// fine over the image pyramid.  Same flags, same output layout (scale_<factor>_state/{cameras,images,points3D}.txt,
+// rigs.json, metadata.txt); the optimisation itself runs on the MI355X behind the C-ABI (e3d_reg_*).
+//
+// Not built yet (the tool says so instead of silently doing something else): --occlusion_mesh_path /
+// --occlusion_splats_path (OpenGL mesh renderer), computing the multi-resolution point cloud from the scans
+// (an existing cache directory is required), the observations cache, --write_debug_point_clouds, JPEG input.
+#include <cmath>
+#include <cstdlib>
+#include <iostream>
+#include <sstream>
+#include <string>
+#include <unordered_set>
+#include <vector>
+
+#include "opt_problem.h"
+
+using namespace e3d_host;
+
+int main(int argc, char** argv) {
+  std::string scan_alignment_path, occlusion_mesh_path, occlusion_splats_path, multi_res_point_cloud_directory_path, image_base_path,
+      state_path, output_folder_path, observations_cache_path, camera_ids_to_ignore_string;
+  parse_argument(argc, argv, "--scan_alignment_path", scan_alignment_path);
+  parse_argument(argc, argv, "--occlusion_mesh_path", occlusion_mesh_path);
+  parse_argument(argc, argv, "--occlusion_splats_path", occlusion_splats_path);
+  parse_argument(argc, argv, "--multi_res_point_cloud_directory_path", multi_res_point_cloud_directory_path);
+  parse_argument(argc, argv, "--image_base_path", image_base_path);
+  parse_argument(argc, argv, "--state_path", state_path);
+  parse_argument(argc, argv, "--output_folder_path", output_folder_path);
+  parse_argument(argc, argv, "--observations_cache_path", observations_cache_path);
+  int max_iterations = 400;
+  parse_argument(argc, argv, "--max_iterations", max_iterations);
+  float initial_scaling_factor = 0;     // 0 starts from the lowest-resolution scale
+  parse_argument(argc, argv, "--initial_scaling_factor", initial_scaling_factor);
+  float target_scaling_factor = 2;      // anything larger than 1 runs all scaling factors
+  parse_argument(argc, argv, "--target_scaling_factor", target_scaling_factor);
+  parse_argument(argc, argv, "--camera_ids_to_ignore", camera_ids_to_ignore_string);
+  std::unordered_set<int> camera_ids_to_ignore;
+  for (const std::string& id : SplitStringIntoSet(',', camera_ids_to_ignore_string)) camera_ids_to_ignore.insert(atoi(id.c_str()));
+
+  Problem problem;
+  if (!problem.prm.SetFromArguments(argc, argv)) return EXIT_FAILURE;
+
+  if (scan_alignment_path.empty() || multi_res_point_cloud_directory_path.empty() || image_base_path.empty() || state_path.empty() ||
+      output_folder_path.empty() || observations_cache_path.empty()) {
+    std::cerr << "Please specify all the required paths." << std::endl;
+    return EXIT_FAILURE;
+  }
+  if (!occlusion_mesh_path.empty() || !occlusion_splats_path.empty()) {
+    std::cerr << "--occlusion_mesh_path / --occlusion_splats_path need the mesh renderer, which is not part of this build; "
+                 "run without them to use 2D splats of the scan points." << std::endl;
+    return EXIT_FAILURE;
+  }
+  if (problem.prm.depth_residuals_weight > 0) {
+    std::cerr << "--depth_residuals_weight > 0 (depth-map residuals, not used in the ETH3D pipeline) is not part of this build." << std::endl;
+    return EXIT_FAILURE;
+  }
+  std::cout << "No occlusion meshes given, using 2D splats." << std::endl;
+  create_directories(output_folder_path);
+
+  // scans -> global frame (pcl::transformPointCloud on the GPU); their points are the occlusion splats
+  std::vector<MeshInfo> scan_infos;
+  if (!ReadMeshLabProject(scan_alignment_path, &scan_infos)) {
+    std::cerr << "Cannot read scan poses from " << scan_alignment_path << std::endl;
+    std::cerr << "Cannot load scan point clouds." << std::endl;
+    return EXIT_FAILURE;
+  }
+  std::cout << "Loading point clouds ..." << std::endl;
+  std::vector<float> occlusion_points;
+  const std::string project_dir = parent_path(scan_alignment_path);
+  for (const MeshInfo& info : scan_infos) {
+    PointCloud local;
+    const std::string filename = (!info.filename.empty() && info.filename[0] == '/') ? info.filename : join_path(project_dir, info.filename);
+    if (loadPLYFile(filename, local) < 0) { std::cerr << "Cannot load scan point clouds." << std::endl; return EXIT_FAILURE; }
+    float T[12], bmin[3], bmax[3];
+    info.global_T_mesh.matrix3x4(T);
+    const size_t base = occlusion_points.size();
+    occlusion_points.resize(base + local.xyz.size());
+    if (local.size() > 0 && api().e3d_transform_cloud(local.xyz.data(), nullptr, local.size(), T, occlusion_points.data() + base, nullptr, bmin, bmax) < 0) {
+      std::cerr << "transform failed: " << api().e3d_last_error() << std::endl;
+      return EXIT_FAILURE;
+    }
+  }
+  if (occlusion_points.empty()) { std::cerr << "Point cloud is empty." << std::endl; return EXIT_FAILURE; }
+  std::cout << "Done." << std::endl;
+
+  if (!problem.InitializeStateFromColmapModel(state_path, image_base_path, camera_ids_to_ignore)) return EXIT_FAILURE;
+  std::vector<ColmapRig> rig_vector;
+  if (ReadColmapRigs(state_path + "/rigs.json", &rig_vector) && !problem.AssignRigs(rig_vector)) return EXIT_FAILURE;
+  if (!problem.SetScanGeometryAndInitialize(occlusion_points, multi_res_point_cloud_directory_path)) return EXIT_FAILURE;
+
+  constexpr float kMaxChangeConvergenceThreshold = 0;
+  constexpr int kIterationsWithoutNewOptimumThreshold = 15;
+  const int max_image_scale_minus_one = problem.max_image_scale() - 1;
+  int current_image_scale = (initial_scaling_factor == 0)
+                                ? max_image_scale_minus_one
+                                : std::max(0, std::min<int>(max_image_scale_minus_one, (int)(-1 * std::log(initial_scaling_factor) / std::log(2))));
+  while (true) {
+    // Optimizer::RunOnCurrentScale (never the highest image scale, optimizer.cc:60-61)
+    current_image_scale = std::min(current_image_scale, problem.max_image_scale() - 1);
+    problem.reg_params.current_image_scale = current_image_scale;
+    if (api().e3d_reg_set_params(problem.reg, &problem.reg_params) < 0) { std::cerr << api().e3d_last_error() << std::endl; return EXIT_FAILURE; }
+    double optimum_cost = 0;
+    int iterations = 0;
+    if (api().e3d_reg_run_on_current_scale(problem.reg, max_iterations, kMaxChangeConvergenceThreshold, kIterationsWithoutNewOptimumThreshold,
+                                           /*print_progress*/ 1, &optimum_cost, &iterations) < 0) {
+      std::cerr << "optimisation failed: " << api().e3d_last_error() << std::endl;
+      return EXIT_FAILURE;
+    }
+    const double current_scaling_factor = std::pow(2, -1 * current_image_scale);
+
+    if (!problem.ReadBackState()) return EXIT_FAILURE;
+    std::ostringstream state_directory_name;
+    state_directory_name << "scale_" << current_scaling_factor << "_state";
+    const std::string out_state_path = join_path(output_folder_path, state_directory_name.str());
+    if (!problem.ExportToColmap(image_base_path, out_state_path)) { std::cerr << "Cannot write " << out_state_path << std::endl; return EXIT_FAILURE; }
+    if (!problem.rigs.empty() && !problem.ExportRigs(out_state_path)) return EXIT_FAILURE;
+    std::cout << "Wrote state to " << out_state_path << std::endl;
+
+    std::ofstream metadata_stream(out_state_path + "/metadata.txt");
+    metadata_stream << "scan_alignment_path " << scan_alignment_path << std::endl;
+    metadata_stream << "occlusion_mesh_path " << occlusion_mesh_path << std::endl;
+    metadata_stream << "occlusion_splats_path " << occlusion_splats_path << std::endl;
+    metadata_stream << "multi_res_point_cloud_directory_path " << multi_res_point_cloud_directory_path << std::endl;
+    metadata_stream << "image_base_path " << image_base_path << std::endl;
+    metadata_stream << "state_path " << out_state_path << std::endl;
+    metadata_stream << "output_folder_path " << output_folder_path << std::endl;
+    metadata_stream << "max_iterations " << max_iterations << std::endl;
+    metadata_stream << "initial_scaling_factor " << initial_scaling_factor << std::endl;
+    metadata_stream << "target_scaling_factor " << target_scaling_factor << std::endl;
+    metadata_stream << "camera_ids_to_ignore " << camera_ids_to_ignore_string << std::endl;
+    problem.prm.OutputValues(metadata_stream);
+    metadata_stream << std::endl;
+    metadata_stream << "optimum_cost " << optimum_cost << std::endl;
+    metadata_stream.close();
+
+    if (std::fabs(current_scaling_factor - target_scaling_factor) < 1e-8 || current_scaling_factor > target_scaling_factor) {
+      std::cout << "Target scaling factor reached, stopping." << std::endl;
+      break;
+    }
+    if (current_image_scale == 0) break;      // Optimizer::NextScale
+    current_image_scale -= 1;
+  }
+  std::cout << "Finished!" << std::endl;
+  return EXIT_SUCCESS;
+}

@@ -76,7 +76,7 @@ inline int loadPLYFile(const std::string& path, PointCloud& cloud, bool want_rgb
   if (!ascii && format != "binary_little_endian" && !swap) { std::cerr << "[loadPLYFile] unsupported format '" << format << "'" << std::endl; return -1; }
   for (const Elem& e : elems) {
     const bool is_vertex = (e.name == "vertex");
-    int ix = -1, iy = -1, iz = -1, ir = -1, ig = -1, ib = -1, inx = -1, iny = -1, inz = -1;
+    int ix = -1, iy = -1, iz = -1, ir = -1, ig = -1, ib = -1, inx = -1, iny = -1, inz = -1, iint = -1;
     bool has_list = false;
     for (size_t i = 0; i < e.props.size(); ++i) {
       const std::string& nm = e.props[i].name;
@@ -87,6 +87,7 @@ inline int loadPLYFile(const std::string& path, PointCloud& cloud, bool want_rgb
       else if (nm == "blue" || nm == "b" || nm == "diffuse_blue") ib = (int)i;
       else if (nm == "nx" || nm == "normal_x") inx = (int)i; else if (nm == "ny" || nm == "normal_y") iny = (int)i;
       else if (nm == "nz" || nm == "normal_z") inz = (int)i;
+      else if (nm == "intensity") iint = (int)i;
     }
     if (is_vertex) {
       if (ix < 0 || iy < 0 || iz < 0) { std::cerr << "[loadPLYFile] vertex element without x/y/z in " << path << std::endl; return -1; }
@@ -94,6 +95,7 @@ inline int loadPLYFile(const std::string& path, PointCloud& cloud, bool want_rgb
       if (want_rgb) cloud.rgb.assign(3 * e.count, 0);
       const bool nrm = inx >= 0 && iny >= 0 && inz >= 0;
       if (nrm) cloud.normals.resize(3 * e.count);
+      if (iint >= 0) cloud.intensity.resize(e.count);
     }
     std::vector<double> vals(e.props.size());
     if (ascii) {
@@ -108,6 +110,7 @@ inline int loadPLYFile(const std::string& path, PointCloud& cloud, bool want_rgb
         cloud.xyz[3 * i] = (float)vals[ix]; cloud.xyz[3 * i + 1] = (float)vals[iy]; cloud.xyz[3 * i + 2] = (float)vals[iz];
         if (!cloud.rgb.empty() && ir >= 0 && ig >= 0 && ib >= 0) { cloud.rgb[3 * i] = (uint8_t)vals[ir]; cloud.rgb[3 * i + 1] = (uint8_t)vals[ig]; cloud.rgb[3 * i + 2] = (uint8_t)vals[ib]; }
         if (!cloud.normals.empty()) { cloud.normals[3 * i] = (float)vals[inx]; cloud.normals[3 * i + 1] = (float)vals[iny]; cloud.normals[3 * i + 2] = (float)vals[inz]; }
+        if (iint >= 0) cloud.intensity[i] = (float)vals[iint];
       }
     } else if (!has_list) {
       size_t stride = 0;
@@ -136,6 +139,7 @@ inline int loadPLYFile(const std::string& path, PointCloud& cloud, bool want_rgb
             cloud.normals[3 * i + 1] = (float)read_scalar(r + off[iny], e.props[iny].type, swap);
             cloud.normals[3 * i + 2] = (float)read_scalar(r + off[inz], e.props[inz].type, swap);
           }
+          if (iint >= 0) cloud.intensity[i] = (float)read_scalar(r + off[iint], e.props[iint].type, swap);
         }
       }
     } else {
@@ -182,6 +186,20 @@ inline int savePLYFileBinaryXYZNormalRGB(const std::string& path, const std::vec
   f.write(reinterpret_cast<const char*>(vp), sizeof vp);
   const float zeros2[2] = {0, 0};
   f.write(reinterpret_cast<const char*>(zeros2), sizeof zeros2);
+  return f ? 0 : -1;
+}
+
+// x y z intensity (f32) binary little endian: the pcl::PointXYZI files of the multi-resolution cloud cache (problem.cc:364-411)
+inline int savePLYFileBinaryXYZI(const std::string& path, const std::vector<float>& xyz, const std::vector<float>& intensity) {
+  std::ofstream f(path, std::ios::binary);
+  if (!f) return -1;
+  const size_t n = xyz.size() / 3;
+  f << "ply\nformat binary_little_endian 1.0\ncomment PCL generated\nelement vertex " << n
+    << "\nproperty float x\nproperty float y\nproperty float z\nproperty float intensity\nend_header\n";
+  for (size_t i = 0; i < n; ++i) {
+    const float v[4] = {xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], intensity[i]};
+    f.write(reinterpret_cast<const char*>(v), sizeof v);
+  }
   return f ? 0 : -1;
 }
 

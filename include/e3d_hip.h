@@ -267,6 +267,14 @@ int e3d_reg_run_on_current_scale(e3d_reg_t* reg, int max_num_iterations, float m
                                  int iterations_without_new_optimum_threshold, int print_progress, double* optimum_cost,
                                  int* iterations_done);
 
+/* Problem::DeterminePointNeighbors (src/opt/problem.cc:706-786): neighbor_indices[p * neighbor_count + j] = the j-th of the
+ * shuffled (candidate_count + 1)-nearest-neighbour candidates of point p (the point itself excluded), searched within p's
+ * own scan when limit_to_same_scan != 0 (fixed scan colours).  Same libstdc++ std::shuffle / std::mt19937(0) stream as the
+ * reference. */
+int e3d_determine_point_neighbors(const float* xyz, size_t n, const uint8_t* scan_indices, int scan_count,
+                                  int limit_to_same_scan, int neighbor_count, int candidate_count,
+                                  uint32_t* neighbor_indices);
+
 /* Multi-GPU (one process per GPU): images are sharded, image `id` belongs to rank `id mod world_size`
  * (e3d_reg_image_owner).  Every rank declares every intrinsics block, point scale and image (ids and poses) so that the
  * variable layout is global, but only the owner of an image uploads its pyramid -- e3d_reg_set_image accepts

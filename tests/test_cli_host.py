@@ -46,3 +46,14 @@ def test_single_object_early_out_roundtrips_the_project(tmp_path):
     rows = m[0][3].strip("\n").split("\n")
     assert len(rows) == 4 and all(row.endswith(" ") for row in rows) and rows[3] == "0 0 0 1 "
     assert rows[0].split()[3] == "1.5" and rows[1].split()[3] == "-2.25" and rows[2].split()[3] == "0.333333"
+
+
+def test_image_registrator_usage(tmp_path):
+    """Argument validation happens before the HIP library is loaded (no GPU needed): same message and exit code as the
+    reference (src/exe/image_registrator.cc:118-128)."""
+    import subprocess
+    from cli_util import BIN
+    r = subprocess.run([os.path.join(BIN, "ImageRegistrator"), "--state_path", str(tmp_path)], capture_output=True, text=True)
+    assert r.returncode == 1 and "Please specify all the required paths." in r.stderr
+    r = subprocess.run([os.path.join(BIN, "ImageRegistrator"), "--robust_weighting_type", "bogus"], capture_output=True, text=True)
+    assert r.returncode == 1 and "--robust_weighting_type parameter not recognized" in r.stderr

@@ -1,0 +1,149 @@
+"""ImageRegistrator CLI end to end on a synthetic dataset written in the pipeline's own file formats (MeshLab project + PLY
+scans, COLMAP cameras.txt / images.txt, rigs.json, PNG images, multi-resolution point cloud cache): the tool's exported
+state must equal what the same optimisation gives when driven through the Python binding of the same C-ABI, level by
+level, and the photometric cost must go down."""
+import importlib
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from cli_util import BIN, ROOT, write_mlp, write_ply_xyz
+from reg_util import make_multi_image_scene, make_rig_scene
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, ROOT)
+
+
+def _write_png(path, img):
+    from PIL import Image
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    Image.fromarray(np.ascontiguousarray(img, np.uint8), mode="L").save(path)
+
+
+def _write_dataset(tmp, M, names, rigs=None, model_name="PINHOLE"):
+    from tools.make_multires_cache import write_cache
+    d = str(tmp)
+    write_ply_xyz(os.path.join(d, "scan.ply"), M["pts"], rgb=np.full((len(M["pts"]), 3), 128, np.uint8))
+    write_mlp(os.path.join(d, "scans.mlp"), [("scan", "scan.ply", np.eye(4))])
+    os.makedirs(os.path.join(d, "state"), exist_ok=True)
+    p = M["params"].astype(np.float64).copy(); p[2] += 0.5; p[3] += 0.5         # COLMAP's pixel-corner convention
+    with open(os.path.join(d, "state", "cameras.txt"), "w") as f:
+        f.write("# cameras\n7 %s %d %d %s\n" % (model_name, M["width"], M["height"], " ".join("%.9g" % v for v in p)))
+    with open(os.path.join(d, "state", "images.txt"), "w") as f:
+        f.write("# images\n")
+        for i, (im, name) in enumerate(zip(M["images"], names)):
+            q, t = im.get("q_init", im.get("q_true")), im.get("t_init", im.get("t_true"))
+            f.write("%d %s %s 7 %s\n\n" % (10 + i, " ".join("%.9g" % v for v in q), " ".join("%.9g" % v for v in t), name))
+            _write_png(os.path.join(d, "images", name), im["pyr"][0])
+    if rigs is not None:
+        import json
+        json.dump(rigs, open(os.path.join(d, "state", "rigs.json"), "w"), indent=4)
+    write_cache(os.path.join(d, "cache"), [(sc["radius"], sc["pts"], sc["tex"], sc["nbr"]) for sc in _point_scales(M)],
+                neighbor_count=M["K"], candidate_count=25)
+    return d
+
+
+def _point_scales(M):
+    """Two point scales like a real multi-resolution cloud: all points at the fine radius, every third point at twice the
+    radius (observed one image scale coarser).  The stored intensity is the scene texture, from which the tool derives the
+    fixed descriptors (problem.cc:549-572)."""
+    from scipy.spatial import cKDTree
+    from reg_util import texture
+    out = []
+    for radius, pts in ((M["point_radius"], M["pts"]), (2 * M["point_radius"], M["pts"][::3])):
+        pts = np.ascontiguousarray(pts, np.float32)
+        _, nn = cKDTree(pts).query(pts, k=M["K"] + 1)
+        nbr = nn[:, 1:].astype(np.uint32)
+        tex = texture(pts[:, 0].astype(np.float64), pts[:, 2].astype(np.float64)).astype(np.float32)
+        out.append(dict(radius=radius, pts=pts, nbr=nbr, tex=tex, fixed=(tex[nbr] - tex[:, None]).astype(np.float32)))
+    return out
+
+
+def _run_tool(d, extra=()):
+    cmd = [os.path.join(BIN, "ImageRegistrator"), "--scan_alignment_path", os.path.join(d, "scans.mlp"), "--multi_res_point_cloud_directory_path",
+           os.path.join(d, "cache"), "--image_base_path", os.path.join(d, "images"), "--state_path", os.path.join(d, "state"),
+           "--output_folder_path", os.path.join(d, "out"), "--observations_cache_path", os.path.join(d, "obs_cache"),
+           "--max_iterations", "4", "--max_initial_image_area_in_pixels", "3000"] + list(extra)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    return r.stdout
+
+
+def _read_images_txt(path):
+    out = {}
+    for line in open(path):
+        v = line.split()
+        if len(v) == 10 and not line.startswith("#"):
+            out[int(v[0])] = (np.array(v[1:5], np.float64), np.array(v[5:8], np.float64), int(v[8]), v[9])
+    return out
+
+
+def test_image_registrator_cli_matches_binding(tmp_path, e3d):
+    M = make_multi_image_scene(n_points=6000, n_images=3, seed=12, perturb=0.006)
+    names = ["dslr/img_%d.png" % i for i in range(3)]
+    d = _write_dataset(tmp_path, M, names)
+    out = _run_tool(d)
+    assert "--- Optimizing at scaling factor 0.5 ---" in out and "--- Optimizing at scaling factor 1 ---" in out and "Finished!" in out
+    # the same run through the Python binding: 3 image scales (area 43200 / 3000 -> 1 + ceil(log4(14.4)) = 3), scales 1 then 0
+    G = e3d.RegProblem(e3d.default_reg_params(image_scale_count=3, point_neighbor_count=M["K"]))
+    G.set_intrinsics(0, M["width"], M["height"], M["params"], 0, 3)
+    for s_i, sc in enumerate(_point_scales(M)):
+        G.set_point_scale(s_i, sc["pts"], sc["radius"], sc["nbr"], sc["fixed"])
+    G.set_splat_points(M["pts"])
+    from reg_util import pyramid_u8
+    for i, im in enumerate(M["images"]):
+        G.set_image(i, 0, pyramid_u8(im["pyr"][0], 3)); G.set_image_pose(i, im["q_init"], im["t_init"])
+    costs = []
+    for scale in (1, 0):
+        prm = G.params; prm.current_image_scale = scale; G.set_params(prm)
+        costs.append(G.run_on_current_scale(4, 0.0, 15, False)[1])
+        st = _read_images_txt(os.path.join(d, "out", "scale_%s_state" % ("0.5" if scale == 1 else "1"), "images.txt"))
+        assert sorted(st) == [0, 1, 2]
+        for i in range(3):
+            q, t = G.get_image_pose(i)
+            assert np.abs(st[i][0] - q).max() <= 2e-5 and np.abs(st[i][1] - t).max() <= 2e-5 and st[i][2] == 0 and st[i][3] == names[i]
+        cam = open(os.path.join(d, "out", "scale_%s_state" % ("0.5" if scale == 1 else "1"), "cameras.txt")).read().split("\n")[3].split()
+        p = G.intrinsics_level(0, 0)[2].astype(np.float64); p[2] += 0.5; p[3] += 0.5
+        assert cam[:4] == ["0", "PINHOLE", str(M["width"]), str(M["height"])]
+        assert np.abs(np.array(cam[4:], np.float64) - p).max() <= 2e-3
+        meta = open(os.path.join(d, "out", "scale_%s_state" % ("0.5" if scale == 1 else "1"), "metadata.txt")).read()
+        assert "optimum_cost " in meta and "point_neighbor_count 5" in meta
+        assert np.isfinite(costs[-1]) and abs(float(meta.strip().split("optimum_cost ")[1]) - costs[-1]) <= 1e-4 * costs[-1]
+
+
+def test_image_registrator_cli_with_rig(tmp_path, e3d):
+    M = make_rig_scene(n_points=6000, seed=13)
+    # image ids 2f / 2f+1 = cameras "cam0" / "cam1" of frame f; frames share the file name across the two folders
+    names = ["cam%d/frame_%d.png" % (i % 2, i // 2) for i in range(4)]
+    # COLMAP input carries full poses for every image (no rig knowledge): use the true dependent poses perturbed via the frame
+    from oracle import reg_binding as rb
+    for f in range(2):
+        ref, dep = M["images"][2 * f], M["images"][2 * f + 1]
+        dep["q_init"], dep["t_init"] = rb.se3_mul(*M["rig_init"][1], ref["q_init"], ref["t_init"])
+    rigs = [{"ref_camera_id": 7, "cameras": [{"camera_id": 7, "image_prefix": "cam0"}, {"camera_id": 7, "image_prefix": "cam1"}]}]
+    d = _write_dataset(tmp_path, M, names, rigs=rigs)
+    out = _run_tool(d, ["--max_initial_image_area_in_pixels", "32000"])
+    assert "AssignRigs(): assigned 4 out of 4 images to rig(s)" in out and "Finished!" in out
+    st = _read_images_txt(os.path.join(d, "out", "scale_1_state", "images.txt"))
+    assert len(st) == 4
+    rj = open(os.path.join(d, "out", "scale_1_state", "rigs.json")).read()
+    import json
+    assert json.loads(rj) == [{"ref_camera_id": 0, "cameras": [{"camera_id": 0, "image_prefix": "cam0"}, {"camera_id": 0, "image_prefix": "cam1"}]}]
+    # rig consistency of the exported poses: image_T_global(cam1) * global_T_image(cam0) is the same in both frames
+    from scipy.spatial.transform import Rotation
+
+    def T(q, t):
+        m = np.eye(4); m[:3, :3] = Rotation.from_quat([q[1], q[2], q[3], q[0]]).as_matrix(); m[:3, 3] = t; return m
+    rel = [T(*st[2 * f + 1][:2]) @ np.linalg.inv(T(*st[2 * f][:2])) for f in range(2)]
+    assert np.abs(rel[0] - rel[1]).max() <= 1e-4
+    # and the costs printed by the tool decreased
+    costs = [float(l.split(":")[-1]) for l in out.splitlines() if "Cost (considering occlusions) is" in l]
+    assert len(costs) >= 3 and min(costs) < costs[0]
+
+
+def test_image_registrator_cli_errors(tmp_path):
+    r = subprocess.run([os.path.join(BIN, "ImageRegistrator")], capture_output=True, text=True)
+    assert r.returncode != 0 and "Please specify all the required paths." in r.stderr

@@ -311,3 +311,28 @@ def test_rig_optimization_matches_oracle(e3d, model):
     # the extrinsics moved towards the truth
     a0, t0 = _pose_delta(*M["rig_init"][1], *M["rig_true"][1]); a1, t1 = _pose_delta(*G.get_rig(0, 1), *M["rig_true"][1])
     assert a1 + t1 < a0 + t0
+
+
+def test_determine_point_neighbors_reference_kat(e3d):
+    """The reference's own known-answer test, src/opt/test/test_problem.cc:35-110: six collinear points, 2 candidates, 2 neighbours."""
+    pts = np.array([[i, 0, 0] for i in range(6)], np.float32)
+    scan = np.array([0, 1, 0, 1, 0, 1], np.uint8)
+    nb = np.sort(e3d.determine_point_neighbors(pts, 2, 2, scan_indices=scan, scan_count=2), axis=1)
+    assert nb.tolist() == [[2, 4], [3, 5], [0, 4], [1, 5], [0, 2], [1, 3]]
+    nb = np.sort(e3d.determine_point_neighbors(pts, 2, 2), axis=1)
+    assert nb.tolist() == [[1, 2], [0, 2], [1, 3], [2, 4], [3, 5], [3, 4]]
+
+
+def test_determine_point_neighbors_shuffle_stream(e3d):
+    """25 candidates -> 5 neighbours: every neighbour is among the 25 nearest, never the point itself, no repeats, and the
+    result is deterministic (one std::mt19937(0) per call).  The exact draw sequence is libstdc++'s std::shuffle, which the
+    library calls directly; it is not re-derived here."""
+    from scipy.spatial import cKDTree
+    rng = np.random.RandomState(3)
+    pts = rng.uniform(-1, 1, (4000, 3)).astype(np.float32)
+    nb = e3d.determine_point_neighbors(pts, 5, 25)
+    _, nn = cKDTree(pts.astype(np.float64)).query(pts.astype(np.float64), k=26)
+    for i in range(0, 4000, 7):
+        assert i not in nb[i] and set(nb[i].tolist()) <= set(nn[i, 1:].tolist()) and len(set(nb[i].tolist())) == 5
+    # deterministic: same call, same result
+    assert np.array_equal(nb, e3d.determine_point_neighbors(pts, 5, 25))

@@ -453,20 +453,25 @@ __global__ __launch_bounds__(kBlock) void k_reg_pass2(const float4* __restrict__
 #pragma unroll
     for (int k = 0; k < K_MAX; ++k)
       if (k < K) { nrow[k] = row_of_point[nbr[p * K + k]]; In[k] = rows[R4 * (size_t)nrow[k]].x; }
+    // both residual kinds first (they only need the intensities), then every neighbour row is read ONCE and used for the
+    // fixed and the variable residual -- the same f32 products as the reference's two calls of
+    // AccumulateHAndBAndResidualForColorObservation; only the order of the f64 additions differs (as it already does
+    // between threads)
+    float comp[2][K_MAX];
+    float w[2] = {0.f, 0.f};
 #pragma unroll
     for (int kind = 0; kind < 2; ++kind) {
       const float sw = kind == 0 ? wts.fixed_weight : wts.var_weight;
       if (!(sw > 0)) continue;
       if (kind == 1 && !(obs_counts[p] >= 2)) continue;
       const float* desc = kind == 0 ? fixed_desc : var_desc;
-      float comp[K_MAX];
       float pr = 0.f;
 #pragma unroll
       for (int k = 0; k < K_MAX; ++k)
         if (k < K) {
           const float image_descriptor = In[k] - fc[0];
           const float c = image_descriptor - desc[p * K + k];
-          comp[k] = c;
+          comp[kind][k] = c;
           pr += c * c;
         }
       pr = sqrtf(pr);
@@ -474,30 +479,34 @@ __global__ __launch_bounds__(kBlock) void k_reg_pass2(const float4* __restrict__
         acc[NH + V + 2 + kind] += 1.0;
         acc[NH + V + kind] += (double)robust_residual(wts.robust_type, wts.robust_param, pr);
       }
-      const float w = sw * robust_weight(wts.robust_type, wts.robust_param, pr);
-      if (w != 0) {
+      w[kind] = sw * robust_weight(wts.robust_type, wts.robust_param, pr);
+    }
+    if (w[0] != 0 || w[1] != 0) {
 #pragma unroll
-        for (int k = 0; k < K_MAX; ++k)
-          if (k < K) {
-            float fn[4 * R4], J[V];
-            load_row<V>(rows, (size_t)nrow[k], fn);
+      for (int k = 0; k < K_MAX; ++k)
+        if (k < K) {
+          float fn[4 * R4], J[V];
+          load_row<V>(rows, (size_t)nrow[k], fn);
 #pragma unroll
-            for (int c = 0; c < V; ++c) J[c] = fn[1 + c] - fc[1 + c];
+          for (int c = 0; c < V; ++c) J[c] = fn[1 + c] - fc[1 + c];
+#pragma unroll
+          for (int kind = 0; kind < 2; ++kind) {
+            if (w[kind] == 0) continue;
             // AccumulateOnHAndB: products in f32, cast, add in f64 (intrinsics_and_pose_optimizer.cc:1246-1247)
             int e = 0;
 #pragma unroll
             for (int r = R0; r < R1; ++r) {
-              const float wj = w * J[r];
+              const float wj = w[kind] * J[r];
 #pragma unroll
               for (int c = r; c < V; ++c) { acc[e] += (double)(wj * J[c]); ++e; }
             }
             if constexpr (WITH_B) {
-              const float wr = w * comp[k];
+              const float wr = w[kind] * comp[kind][k];
 #pragma unroll
               for (int c = 0; c < V; ++c) acc[NH + c] += (double)(wr * J[c]);
             }
           }
-      }
+        }
     }
   }
   __shared__ double s[kBlock / kWave][NL];

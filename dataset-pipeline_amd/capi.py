@@ -62,6 +62,7 @@ SIGNATURES = {
                                       C.c_void_p, C.c_void_p]),
     "e3d_icp_pair_system": (C.c_int, [C.c_void_p] * 6 + [C.c_int64] + [C.c_void_p] * 7),
     "e3d_normals_knn": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "e3d_normals_radius": (C.c_int, [C.c_void_p, C.c_size_t, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     # (B) image registration kernels
     "e3d_reg_create": (C.c_void_p, [C.c_void_p]),
     "e3d_reg_destroy": (None, [C.c_void_p]),
@@ -302,6 +303,21 @@ def normals_knn(xyz, k, viewpoint=(0.0, 0.0, 0.0), return_knn=False):
     if r < 0:
         _err("e3d_normals_knn", r)
     return (on, oc, knn) if return_knn else (on, oc)
+
+
+def normals_radius(xyz, radius, viewpoint=(0.0, 0.0, 0.0), return_counts=False):
+    """NormalEstimationTwoPassOMP with setRadiusSearch(radius): (normals[n,3], curvature[n][, neighbour counts[n]])."""
+    keep = []
+    n = int(xyz.shape[0])
+    vp = np.ascontiguousarray(viewpoint, np.float32)
+    on = np.zeros((n, 3), np.float32)
+    oc = np.zeros(n, np.float32)
+    cnt = np.zeros(n, np.int32) if return_counts else None
+    r = lib().e3d_normals_radius(_ptr(xyz, np.float32, keep), n, float(radius), C.c_void_p(vp.ctypes.data), C.c_void_p(on.ctypes.data),
+                                 C.c_void_p(oc.ctypes.data), C.c_void_p(cnt.ctypes.data) if cnt is not None else None)
+    if r < 0:
+        _err("e3d_normals_radius", r)
+    return (on, oc, cnt) if return_counts else (on, oc)
 
 
 # ---- (B) image registration kernels ------------------------------------------------------------------------------------

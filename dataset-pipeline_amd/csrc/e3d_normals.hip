@@ -259,6 +259,85 @@ __global__ __launch_bounds__(kKnnBlock) void k_knn_normals(const float4* __restr
 #undef HP
 }
 
+// Radius-search variant (pcl::Feature::searchForNeighbors with setRadiusSearch, two_pass_normal_3d_omp.hpp:66): every
+// point within the radius (FLANN: squared distance strictly below (float)((double)r * r)) takes part; one thread per
+// point walks its 27 grid cells twice -- centroid, then centred products -- so nothing is stored per neighbour and the
+// neighbour count is unbounded.  The f32 sums run in grid order, not in the distance order PCL's sorted radius search
+// returns, so results agree with the reference to summation round-off, not bit for bit.
+__global__ __launch_bounds__(kKnnBlock) void k_radius_normals(const float4* __restrict__ P4, size_t n,
+                                                              const HashEntry* __restrict__ table, KnnGrid G, float r2,
+                                                              float vpx, float vpy, float vpz, float* __restrict__ out_n,
+                                                              float* __restrict__ out_c, int* __restrict__ out_count) {
+  const size_t gi = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gi >= n) return;
+  const float4 q = P4[gi];
+  const unsigned q_oi = __float_as_uint(q.w);
+  const int cx = cell_coord(q.x, G.g.origin[0], G.g.inv_cell);
+  const int cy = cell_coord(q.y, G.g.origin[1], G.g.inv_cell);
+  const int cz = cell_coord(q.z, G.g.origin[2], G.g.inv_cell);
+  constexpr int kMaxC = (1 << 21) - 1;
+  unsigned rs[27], re[27];
+  {
+    int r = 0;
+    for (int oz = -1; oz <= 1; ++oz)
+      for (int oy = -1; oy <= 1; ++oy)
+        for (int ox = -1; ox <= 1; ++ox, ++r) {
+          rs[r] = 0; re[r] = 0;
+          const int x = cx + ox, y = cy + oy, z = cz + oz;
+          if (x < 0 || y < 0 || z < 0 || x > kMaxC || y > kMaxC || z > kMaxC) continue;
+          const unsigned long long key = cell_key(x, y, z);
+          unsigned h = hash_key(key) & G.g.mask;
+          for (;;) {
+            const HashEntry en = table[h];
+            if (en.key == key) { rs[r] = en.start; re[r] = en.end; break; }
+            if (en.key == kEmptyKey) break;
+            h = (h + 1) & G.g.mask;
+          }
+        }
+  }
+  int cnt = 0;
+  float a6 = 0.f, a7 = 0.f, a8 = 0.f;
+  for (int r = 0; r < 27; ++r)
+    for (unsigned m = rs[r]; m < re[r]; ++m) {
+      const float4 c = P4[m];
+      if (sqdist_l2(q.x, q.y, q.z, c.x, c.y, c.z) < r2) { ++cnt; a6 += c.x; a7 += c.y; a8 += c.z; }
+    }
+  float nx, ny, nz, curv;
+  const float qnan = __uint_as_float(0x7fc00000u);
+  if (cnt < 3) {                                                      // two_pass_normal_3d.h:97-103 (0 neighbours: NaN as well, :68-71)
+    nx = ny = nz = curv = qnan;
+  } else {
+    const float fc = (float)cnt;
+    a6 = a6 / fc; a7 = a7 / fc; a8 = a8 / fc;
+    float a0 = 0.f / fc, a1 = 0.f / fc, a2 = 0.f / fc, a3 = 0.f / fc, a4 = 0.f / fc, a5 = 0.f / fc;
+    for (int r = 0; r < 27; ++r)
+      for (unsigned m = rs[r]; m < re[r]; ++m) {
+        const float4 p = P4[m];
+        if (!(sqdist_l2(q.x, q.y, q.z, p.x, p.y, p.z) < r2)) continue;
+        a0 += (p.x - a6) * (p.x - a6);
+        a1 += (p.x - a6) * (p.y - a7);
+        a2 += (p.x - a6) * (p.z - a8);
+        a3 += (p.y - a7) * (p.y - a7);
+        a4 += (p.y - a7) * (p.z - a8);
+        a5 += (p.z - a8) * (p.z - a8);
+      }
+    float cov[9];
+    cov[0] = a0 / fc; cov[1] = a1 / fc; cov[2] = a2 / fc; cov[4] = a3 / fc; cov[5] = a4 / fc; cov[8] = a5 / fc;
+    cov[3] = cov[1]; cov[6] = cov[2]; cov[7] = cov[5];
+    float ev, v[3];
+    eigen33_smallest(cov, ev, v);
+    nx = v[0]; ny = v[1]; nz = v[2];
+    const float eig_sum = cov[0] + cov[4] + cov[8];
+    curv = (eig_sum != 0.f) ? fabsf(ev / eig_sum) : 0.f;
+    const float vx = vpx - q.x, vy = vpy - q.y, vz = vpz - q.z;      // flipNormalTowardsViewpoint
+    const float cos_theta = (vx * nx + vy * ny + vz * nz);
+    if (cos_theta < 0) { nx *= -1; ny *= -1; nz *= -1; }
+  }
+  out_n[3 * (size_t)q_oi] = nx; out_n[3 * (size_t)q_oi + 1] = ny; out_n[3 * (size_t)q_oi + 2] = nz;
+  out_c[q_oi] = curv;
+  if (out_count) out_count[q_oi] = cnt;
+}
+
 // grid keys for an arbitrary cell size (points taken from AoS xyz)
 struct LevelBuffers {
   DevBuf<unsigned long long> ka, kb;
@@ -365,6 +444,75 @@ extern "C" int e3d_normals_knn(const float* xyz, size_t n, int k, const float* v
     copy_out(out_curvature, d_oc.p, sizeof(float) * n, s);
     if (knn_indices) copy_out(knn_indices, d_knn.p, sizeof(int) * n * (size_t)k, s);
     E3D_HIP(hipStreamSynchronize(s));
+    return 0;
+  } catch (const e3d::Error& e) {
+    e3d::set_last_error(e.what());
+    return e.code;
+  } catch (const std::exception& e) {
+    e3d::set_last_error(e.what());
+    return E3D_ERR_INVALID;
+  }
+}
+
+extern "C" int e3d_normals_radius(const float* xyz, size_t n, float radius, const float* viewpoint, float* out_normals,
+                                  float* out_curvature, int32_t* neighbor_counts) {
+  try {
+    if ((!xyz && n) || !viewpoint || (!out_normals && n) || (!out_curvature && n))
+      throw Error(E3D_ERR_INVALID, "e3d_normals_radius: null argument");
+    if (!(radius > 0.f) || !std::isfinite(radius)) throw Error(E3D_ERR_INVALID, "e3d_normals_radius: radius must be positive");
+    if (n >= (size_t)1 << 31) throw Error(E3D_ERR_INVALID, "e3d_normals_radius: more than 2^31-1 points");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+      throw Error(E3D_ERR_NO_DEVICE, "no HIP device visible (libe3dhip needs an MI355X / gfx950 GPU)");
+    if (n == 0) return 0;
+    hipStream_t s = nullptr;
+    E3D_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamDestroy(s); } } guard{s};
+    DevBuf<float> raw, d_on, d_oc, bbox_partial, bbox_out;
+    DevBuf<int> d_cnt;
+    raw.reserve(3 * n); d_on.reserve(3 * n); d_oc.reserve(n);
+    if (neighbor_counts) d_cnt.reserve(n);
+    copy_in(raw.p, xyz, sizeof(float) * 3 * n, s);
+    bbox_partial.reserve(6 * (size_t)kMaxBboxBlocks); bbox_out.reserve(6);
+    launch_bbox_aos(raw.p, n, bbox_partial.p, bbox_out.p, s);
+    float bb[6];
+    copy_out(bb, bbox_out.p, sizeof bb, s);
+    E3D_HIP(hipStreamSynchronize(s));
+    double extent = 0, magnitude = 0;
+    for (int a = 0; a < 3; ++a) extent = std::max(extent, (double)bb[3 + a] - (double)bb[a]);
+    for (int a = 0; a < 6; ++a) magnitude = std::max(magnitude, std::fabs((double)bb[a]));
+    // cell = radius plus slack for the f32 cell-index computation: every point within the radius lies in the 27 cells
+    double cell = (double)radius * (1.0 + 1e-4) + 16.0 * FLT_EPSILON * (magnitude + 4.0 * (double)radius);
+    if (extent / cell > (double)((1 << 21) - 8)) throw Error(E3D_ERR_INVALID, "e3d_normals_radius: radius too small for the extent of the cloud");
+    KnnGrid G{};
+    G.cell = (float)cell;
+    G.g.inv_cell = (float)(1.0 / (double)G.cell);
+    for (int a = 0; a < 3; ++a) { G.g.origin[a] = (float)((double)bb[a] - 2.0 * cell); G.dmin[a] = bb[a]; G.dmax[a] = bb[3 + a]; }
+    LevelBuffers L;
+    L.ka.reserve(n); L.kb.reserve(n); L.va.reserve(n); L.vb.reserve(n); L.counter.reserve(2); L.P4.reserve(n);
+    launch_cell_keys(raw.p, n, G.g, L.ka.p, L.va.p, s);
+    sort_pairs_u64_u32(L.ka.p, L.kb.p, L.va.p, L.vb.p, n, 63, L.temp, s);
+    launch_permute(raw.p, nullptr, L.vb.p, n, L.P4.p, nullptr, s);
+    E3D_HIP(hipMemsetAsync(L.counter.p, 0, 2 * sizeof(unsigned), s));
+    launch_count_cells(L.kb.p, n, L.counter.p, s);
+    unsigned n_cells = 0;
+    E3D_HIP(hipMemcpyAsync(&n_cells, L.counter.p, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+    E3D_HIP(hipStreamSynchronize(s));
+    size_t tsize = 64;
+    while (tsize < 2 * (size_t)n_cells) tsize <<= 1;
+    L.table.reserve(tsize);
+    G.g.mask = (unsigned)(tsize - 1);
+    E3D_HIP(hipMemsetAsync(L.table.p, 0xFF, sizeof(HashEntry) * tsize, s));
+    launch_build_table(L.kb.p, n, L.table.p, G.g.mask, s);
+    const double rr = (double)radius;
+    const float r2 = (float)(rr * rr);      // pcl::KdTreeFLANN::radiusSearch: static_cast<float>(radius * radius)
+    hipLaunchKernelGGL(k_radius_normals, dim3((unsigned)div_up(n, kKnnBlock)), dim3(kKnnBlock), 0, s, L.P4.p, n, L.table.p, G, r2,
+                       viewpoint[0], viewpoint[1], viewpoint[2], d_on.p, d_oc.p, neighbor_counts ? d_cnt.p : nullptr);
+    copy_out(out_normals, d_on.p, sizeof(float) * 3 * n, s);
+    copy_out(out_curvature, d_oc.p, sizeof(float) * n, s);
+    if (neighbor_counts) copy_out(neighbor_counts, d_cnt.p, sizeof(int) * n, s);
+    E3D_HIP(hipStreamSynchronize(s));
+    E3D_HIP(hipGetLastError());
     return 0;
   } catch (const e3d::Error& e) {
     e3d::set_last_error(e.what());

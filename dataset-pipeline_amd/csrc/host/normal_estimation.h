@@ -20,11 +20,15 @@ class NormalEstimationTwoPass {
   // fills normals + curvature of `output` (resized to the input size; xyz is NOT copied, like pcl::Normal output)
   void compute(PointCloud& output) {
     if (!input_) throw std::runtime_error("NormalEstimationTwoPass: no input cloud");
-    if (radius_ > 0) throw std::runtime_error("NormalEstimationTwoPass: radius search is not available on the HIP path yet (use k search)");
     const size_t n = input_->size();
     output.normals.assign(3 * n, 0.f);
     output.curvature.assign(n, 0.f);
     if (n == 0) return;
+    if (radius_ > 0) {
+      if (api().e3d_normals_radius(input_->xyz.data(), n, (float)radius_, vp_, output.normals.data(), output.curvature.data(), nullptr) < 0)
+        throw std::runtime_error(std::string("NormalEstimationTwoPass: ") + api().e3d_last_error());
+      return;
+    }
     if (api().e3d_normals_knn(input_->xyz.data(), n, k_, vp_, output.normals.data(), output.curvature.data(), nullptr) < 0)
       throw std::runtime_error(std::string("NormalEstimationTwoPass: ") + api().e3d_last_error());
   }

@@ -154,6 +154,12 @@ int e3d_icp_pair_system(const float* src_xyz, const float* src_normals,
 int e3d_normals_knn(const float* xyz, size_t n, int k, const float viewpoint[3],
                     float* out_normals, float* out_curvature, int32_t* knn_indices);
 
+/* The same estimator with setRadiusSearch(radius) instead of setKSearch: every point strictly within the radius
+ * (squared distance < (float)((double)radius * radius)) takes part; fewer than 3 -> NaN.  neighbor_counts (optional, n)
+ * receives the number of points found, the query itself included. */
+int e3d_normals_radius(const float* xyz, size_t n, float radius, const float viewpoint[3],
+                       float* out_normals, float* out_curvature, int32_t* neighbor_counts);
+
 /* ---- (B) ImageRegistrator: dense photometric residual / Jacobian kernels -------------------------------------
  * Device-resident mirror of the parts of opt::Problem the hot loops read (src/opt/problem.h:300-388) and the inner
  * operator surfaces of the optimizer:

@@ -78,3 +78,40 @@ def test_normals_feed_icp(e3d, ob, synth):
         g.add_point_cloud(P, n, s["T_init"], False); o.add_point_cloud(P, n, s["T_init"], False)
     g.run(0.1, 0, 5, 1e-9, False); o.run(0.1, 0, 5, 1e-9, False)
     assert [(r[0], r[1], r[2], r[3]) for r in g.pair_records()] == [(r[0], r[1], r[2], r[3]) for r in o.pair_records()]
+
+
+# ---- radius search (setRadiusSearch) ----------------------------------------------------------------------------------------
+@pytest.mark.parametrize("radius", [0.03, 0.08])
+def test_normals_radius_room(e3d, ob, synth, radius):
+    """Same neighbour SETS as the oracle (counts checked against scipy's ball query with the strict f32 radius test); the
+    f32 sums run in grid order instead of distance order, so normals agree to summation round-off."""
+    from scipy.spatial import cKDTree
+    P = synth.make_scene(1, 40000, seed=22)[0]["xyz"].numpy()
+    gn, gc, cnt = e3d.normals_radius(P, radius, (0, 0, 0), return_counts=True)
+    on, oc = ob.normals(P, radius=radius, viewpoint=(0, 0, 0))
+    # neighbour counts: exact strict test d2 < (float)((double)r * r) on f32 distances
+    r2 = np.float32(np.float64(np.float32(radius)) ** 2)
+    tree = cKDTree(P.astype(np.float64))
+    for i in range(0, len(P), 397):
+        idx = tree.query_ball_point(P[i].astype(np.float64), float(radius) * 1.001)
+        d = P[idx] - P[i]
+        d2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+        assert cnt[i] == int((d2 < r2).sum())
+    nan_o = np.isnan(on[:, 0])
+    assert np.array_equal(np.isnan(gn[:, 0]), nan_o) and np.array_equal(nan_o, cnt < 3)
+    v = ~nan_o
+    err = np.abs(gn[v] - on[v]).max(axis=1)
+    assert (err > 1e-3).mean() < 2e-3, (err.max(), (err > 1e-3).mean())
+    ok = err <= 1e-3
+    assert np.abs(gc[v][ok] - oc[v][ok]).max() <= 1e-4
+
+
+def test_normals_radius_degenerate(e3d):
+    P = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [1, 1, 0], [0.5, 0.5, 0], [50, 50, 50]], np.float32)
+    n, c, cnt = e3d.normals_radius(P, 2.0, (0, 0, 5), return_counts=True)
+    assert cnt.tolist() == [5, 5, 5, 5, 5, 1]
+    assert np.allclose(n[:5, 2], 1, atol=1e-6) and np.all(np.isnan(n[5])) and np.isnan(c[5])
+    n, c, cnt = e3d.normals_radius(P, 1.0, (0, 0, 5), return_counts=True)      # strict radius: points at exactly 1.0 are out
+    assert cnt.tolist() == [2, 2, 2, 2, 5, 1] and np.all(np.isnan(n[:4]))
+    with pytest.raises(e3d.E3DError):
+        e3d.normals_radius(P, 0.0)

@@ -95,6 +95,8 @@ SIGNATURES = {
     "e3d_reg_get_rig": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "e3d_reg_add_rig_images": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
     "e3d_determine_point_neighbors": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "e3d_merge_close_points": (C.c_int64, [C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
+                                             C.c_void_p, C.c_void_p]),
     "e3d_reg_set_shard": (C.c_int, [C.c_void_p, C.c_int, C.c_int, ALLREDUCE_FN, ALLREDUCE_DEVICE_FN, C.c_void_p]),
     "e3d_reg_image_owner": (C.c_int, [C.c_void_p, C.c_int]),
 }
@@ -334,6 +336,19 @@ def determine_point_neighbors(xyz, neighbor_count, candidate_count, scan_indices
     if r < 0:
         _err("e3d_determine_point_neighbors", r)
     return out
+
+
+def merge_close_points(merge_distance, num_scans, xyz, colors, scan_indices, max_radius):
+    """MergeClosePoints -> (xyz, colours, scan indices, max_radius) of the merged points, in centre order."""
+    xyz = np.ascontiguousarray(xyz, np.float32); colors = np.ascontiguousarray(colors, np.float32)
+    scan_indices = np.ascontiguousarray(scan_indices, np.uint8); max_radius = np.ascontiguousarray(max_radius, np.float32)
+    n = xyz.shape[0]
+    ox = np.zeros((max(n, 1), 3), np.float32); oc = np.zeros(max(n, 1), np.float32); osc = np.zeros(max(n, 1), np.uint8); om = np.zeros(max(n, 1), np.float32)
+    m = lib().e3d_merge_close_points(float(merge_distance), int(num_scans), *[C.c_void_p(a.ctypes.data) for a in (xyz, colors, scan_indices, max_radius)], n,
+                                     *[C.c_void_p(a.ctypes.data) for a in (ox, oc, osc, om)])
+    if m < 0:
+        _err("e3d_merge_close_points", m)
+    return ox[:m].copy(), oc[:m].copy(), osc[:m].copy(), om[:m].copy()
 
 
 class RegParams(C.Structure):

@@ -281,6 +281,14 @@ int e3d_determine_point_neighbors(const float* xyz, size_t n, const uint8_t* sca
                                   int limit_to_same_scan, int neighbor_count, int candidate_count,
                                   uint32_t* neighbor_indices);
 
+/* MergeClosePoints (src/opt/multi_scale_point_cloud.cc:44-124): greedy merge in point order -- every point not yet absorbed
+ * becomes a centre and absorbs all points strictly within merge_distance -- computed in parallel (the centres are the
+ * lexicographically first maximal independent set).  Outputs (capacity n each) in centre order: mean position, mean colour of
+ * the scan with most merged points, that scan's index, maximum of max_radius.  Returns the number of output points. */
+int64_t e3d_merge_close_points(float merge_distance, int num_scans, const float* xyz, const float* colors,
+                               const uint8_t* scan_indices, const float* max_radius, size_t n, float* out_xyz,
+                               float* out_colors, uint8_t* out_scan_indices, float* out_max_radius);
+
 /* Multi-GPU (one process per GPU): images are sharded, image `id` belongs to rank `id mod world_size`
  * (e3d_reg_image_owner).  Every rank declares every intrinsics block, point scale and image (ids and poses) so that the
  * variable layout is global, but only the owner of an image uploads its pyramid -- e3d_reg_set_image accepts

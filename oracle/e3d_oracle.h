@@ -193,6 +193,20 @@ void oracle_reg_color_accumulate(size_t n_pts, const uint32_t* nbr, int K, int m
                                  int32_t* obs_counts);
 void oracle_reg_color_finish(size_t n_pts, int K, float* descriptors, const int32_t* obs_counts);
 
+/* ---- (f1) multi-resolution point cloud construction (oracle_multires.c, oracle_shuffle.cc) ------------------------------- */
+void oracle_undistortion_lookup(const oreg_camera* c, float* out /* height x width x 2 */);
+void oracle_image_to_normalized(const oreg_camera* c, const float* lookup, float px, float py, float out[2]);
+void oracle_point_radius_minmax(const float* pts, size_t n, const float q[4], const float t[3], const oreg_camera* cam,
+                                int image_scale, int min_image_scale, const oreg_camera* cam_min, const float* lookup_min,
+                                const uint8_t* image_level, const uint8_t* mask_level, const float* occlusion,
+                                float occlusion_threshold, float max_valid_intensity, double min_scaling_factor,
+                                float* min_radius, float* max_radius);
+size_t oracle_merge_close_points(float merge_distance, int num_scans, const float* pts, const float* colors,
+                                 const uint8_t* scan_idx, const float* max_radius, size_t n, float* out_pts,
+                                 float* out_colors, uint8_t* out_scan, float* out_max_radius);
+int oracle_determine_point_neighbors(const float* xyz, size_t n, const uint8_t* scan_indices, int scan_count, int limit_to_same_scan,
+                                     int neighbor_count, int candidate_count, uint32_t* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,54 @@
+"""GPU parity tests of the multi-resolution point cloud construction against the CPU oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mr():
+    from oracle import multires
+    multires.lib()
+    return multires
+
+
+def _scan_like(n, seed, spacing=0.004):
+    """points on two walls in scan-line order (structured input: long greedy dependency chains) + noise"""
+    rng = np.random.RandomState(seed)
+    side = int(np.sqrt(n / 2))
+    u, v = np.meshgrid(np.arange(side) * spacing, np.arange(side) * spacing, indexing="ij")
+    a = np.stack([u.ravel(), v.ravel(), np.zeros(side * side)], 1)
+    b = np.stack([np.zeros(side * side), u.ravel(), v.ravel() + 0.3], 1)
+    P = np.concatenate([a, b]) + rng.normal(0, spacing * 0.15, (2 * side * side, 3))
+    return P.astype(np.float32)
+
+
+@pytest.mark.parametrize("n,dist,scans", [(20000, 0.009, 1), (60000, 0.013, 3), (3000, 0.5, 2)])
+def test_merge_close_points_matches_oracle(e3d, mr, n, dist, scans):
+    rng = np.random.RandomState(n)
+    P = _scan_like(n, n)
+    col = rng.uniform(0, 255, len(P)).astype(np.float32)
+    sidx = rng.randint(0, scans, len(P)).astype(np.uint8)
+    mxr = rng.uniform(0.001, 0.1, len(P)).astype(np.float32)
+    g = e3d.merge_close_points(dist, scans, P, col, sidx, mxr)
+    o = mr.merge_close_points(dist, scans, P, col, sidx, mxr)
+    assert len(g[0]) == len(o[0]) and len(g[0]) < len(P)                       # the same centres, in the same order
+    assert np.array_equal(g[2], o[2])                                          # majority scan incl. the tie rule
+    assert np.array_equal(g[3].view(np.uint32), o[3].view(np.uint32))          # max of max_radius: exact
+    assert np.abs(g[0] - o[0]).max() <= 1e-5 * max(1.0, np.abs(P).max())       # f32 means, different summation order
+    assert np.abs(g[1] - o[1]).max() <= 1e-3
+
+
+def test_merge_close_points_edge_cases(e3d, mr):
+    P = np.array([[0, 0, 0]], np.float32)
+    g = e3d.merge_close_points(0.1, 1, P, np.array([7], np.float32), np.array([0], np.uint8), np.array([0.5], np.float32))
+    assert len(g[0]) == 1 and np.array_equal(g[0][0], P[0]) and g[1][0] == 7 and g[3][0] == 0.5
+    # duplicates and a strict radius: points exactly merge_distance apart are NOT merged
+    P = np.array([[0, 0, 0], [0, 0, 0], [0.5, 0, 0], [1.0, 0, 0]], np.float32)
+    args = (np.arange(4, dtype=np.float32), np.zeros(4, np.uint8), np.ones(4, np.float32))
+    g = e3d.merge_close_points(0.5, 1, P, *args); o = mr.merge_close_points(0.5, 1, P, *args)
+    assert len(g[0]) == len(o[0]) == 3 and np.allclose(g[0], o[0])
+    with pytest.raises(e3d.E3DError):
+        e3d.merge_close_points(0.0, 1, P, *args)
+    with pytest.raises(e3d.E3DError):
+        e3d.merge_close_points(0.1, 99, P, *args)

@@ -95,6 +95,7 @@ SIGNATURES = {
     "e3d_reg_get_rig": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "e3d_reg_add_rig_images": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
     "e3d_determine_point_neighbors": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "e3d_reg_point_radius_minmax": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "e3d_merge_close_points": (C.c_int64, [C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
                                              C.c_void_p, C.c_void_p]),
     "e3d_reg_set_shard": (C.c_int, [C.c_void_p, C.c_int, C.c_int, ALLREDUCE_FN, ALLREDUCE_DEVICE_FN, C.c_void_p]),
@@ -531,6 +532,14 @@ class RegProblem:
     def set_observations(self, image_id, point_scale, idx, x, y, s):
         idx = np.ascontiguousarray(idx, np.uint32); x, y, s = [np.ascontiguousarray(a, np.float32) for a in (x, y, s)]
         self._chk(lib().e3d_reg_set_observations(self._h, image_id, point_scale, len(idx), *[C.c_void_p(a.ctypes.data) for a in (idx, x, y, s)]), "set_observations")
+
+    def point_radius_minmax(self, xyz):
+        """ComputeMinMaxPointRadius over the images of this problem -> (min_radius, max_radius)."""
+        xyz = np.ascontiguousarray(xyz, np.float32)
+        mn = np.zeros(xyz.shape[0], np.float32); mx = np.zeros(xyz.shape[0], np.float32)
+        self._chk(lib().e3d_reg_point_radius_minmax(self._h, C.c_void_p(xyz.ctypes.data), xyz.shape[0], C.c_void_p(mn.ctypes.data),
+                                                    C.c_void_p(mx.ctypes.data)), "e3d_reg_point_radius_minmax")
+        return mn, mx
 
     def set_rig(self, rig_id, image_T_rig):
         """image_T_rig: list of (q wxyz, t) per camera, camera 0 = reference."""

@@ -221,6 +221,93 @@ __global__ __launch_bounds__(kBlock) void k_splat_tiles(const uint4* __restrict_
   }
 }
 
+// ==== f1: per-point radius range (ComputeMinMaxPointRadius, multi_scale_point_cloud.cc:126-180) ==================================
+// CameraBaseImpl::InitializeUndistortionLookup (camera_base_impl.h:252-268): one Undistort per pixel
+template <int M>
+__global__ __launch_bounds__(kBlock) void k_undistort_lookup(CamLevel c, float2* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)c.width * c.height) return;
+  const int x = (int)(i % c.width), y = (int)(i / c.width);
+  const float dx = c.fx_inv * x + c.cx_inv, dy = c.fy_inv * y + c.cy_inv;
+  float ux, uy;
+  if constexpr (M == kPinhole) { ux = dx; uy = dy; }
+  else {
+    cam_iterative_undistort<M>(c, dx, dy, dx, dy, ux, uy);
+    if constexpr (M == kThinPrismFisheye) {      // FisheyeBase::Undistort (camera_base_impl_fisheye.h:81-92)
+      const float r = sqrtf(ux * ux + uy * uy);
+      const float factor = (r < kFisheyeEpsilon) ? 1.f : ((r > (float)(M_PI / 2.f)) ? E3D_CAM_INF : tanf(r) / r);
+      ux = factor * ux; uy = factor * uy;
+    }
+  }
+  out[i] = make_float2(ux, uy);
+}
+
+// ImageToNormalized(Vector2f) through the lookup table (camera_base_impl.h:188-211); the row index y + 1 is clamped where the
+// reference reads one row past the table with weight 0
+__device__ __forceinline__ float2 image_to_normalized(const CamLevel& c, const float2* __restrict__ lookup, float px, float py) {
+  float cx = px < c.width - 1.001f ? px : c.width - 1.001f;
+  float cy = py < c.height - 1.00f ? py : c.height - 1.00f;
+  if (!(cx > 0.f)) cx = 0.f;
+  if (!(cy > 0.f)) cy = 0.f;
+  const int ix = (int)cx, iy = (int)cy;
+  const float fx = cx - (float)ix, fy = cy - (float)iy;
+  const int iy1 = iy + 1 < c.height ? iy + 1 : c.height - 1;
+  const float2 tl = lookup[(size_t)iy * c.width + ix], tr = lookup[(size_t)iy * c.width + ix + 1];
+  const float2 bl = lookup[(size_t)iy1 * c.width + ix], br = lookup[(size_t)iy1 * c.width + ix + 1];
+  return make_float2((1 - fy) * ((1 - fx) * tl.x + fx * tr.x) + fy * ((1 - fx) * bl.x + fx * br.x),
+                     (1 - fy) * ((1 - fx) * tl.y + fx * tr.y) + fy * ((1 - fx) * bl.y + fx * br.y));
+}
+
+struct RadiusParams { int image_scale, min_image_scale; float occlusion_threshold, max_valid_intensity; double min_scaling_factor; };
+
+// one image: observations without scale test (visibility_estimator.cc:297-364), then the radius that projects to half a pixel
+// at the best image scale; each point is touched by one thread per image and the images are processed one after the other, so
+// the running min / max need no atomics
+template <int M>
+__global__ __launch_bounds__(kBlock) void k_point_radius(const float4* __restrict__ pts, size_t n, Pose P, float4 quat /*w x y z*/,
+                                                         CamLevel cam, CamLevel cam_min, const float2* __restrict__ lookup_min,
+                                                         const unsigned char* __restrict__ img, const unsigned char* __restrict__ mask,
+                                                         const float* __restrict__ occlusion, RadiusParams rp,
+                                                         float* __restrict__ min_radius, float* __restrict__ max_radius) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float4 p = pts[i];
+  float X, Y, Z;
+  rt(P, p.x, p.y, p.z, X, Y, Z);
+  if (!(Z > 0.f)) return;
+  float ixf, iyf;
+  cam_normalized_to_image<M>(cam, X / Z, Y / Z, ixf, iyf);
+  const int ix = f2i(ixf + 0.5f), iy = f2i(iyf + 0.5f);
+  if (!(ixf + 0.5f >= 0 && iyf + 0.5f >= 0 && ix >= 0 && iy >= 0 && ix < cam.width && iy < cam.height)) return;
+  if (!(occlusion[(size_t)iy * cam.width + ix] + rp.occlusion_threshold >= Z)) return;
+  if (mask && mask[(size_t)iy * cam.width + ix] != 0) return;
+  if (img[(size_t)iy * cam.width + ix] > rp.max_valid_intensity) return;
+  float returned_scale = rp.image_scale - 1e-6f;
+  float ox = ixf, oy = iyf;
+  if (returned_scale < 0.f) {
+    returned_scale = 0.f;
+    ox = 0.5f * (ox + 0.5f) - 0.5f;
+    oy = 0.5f * (oy + 0.5f) - 0.5f;
+  }
+  const int smaller_scale = (int)returned_scale + 1;
+  const float up = exp2f((float)(smaller_scale - rp.min_image_scale));     // exact power of two
+  const float mx = up * (ox + 0.5f) - 0.5f, my = up * (oy + 0.5f) - 0.5f;
+  // image.image_T_global * point as Sophus::SE3f (multi_scale_point_cloud.cc:149)
+  const float vx = quat.y, vy = quat.z, vz = quat.w, w = quat.x;
+  float ux = vy * p.z - vz * p.y, uy = vz * p.x - vx * p.z, uz = vx * p.y - vy * p.x;
+  ux = ux + ux; uy = uy + uy; uz = uz + uz;
+  const float cx = vy * uz - vz * uy, cy = vz * ux - vx * uz, cz = vx * uy - vy * ux;
+  const float G0 = ((p.x + w * ux) + cx) + P.t[0], G1 = ((p.y + w * uy) + cy) + P.t[1], G2 = ((p.z + w * uz) + cz) + P.t[2];
+  if (!(G2 > 0.f)) return;
+  const float offx = (mx - 0.5f < 0) ? (mx + 0.5f) : (mx - 0.5f);
+  const float2 nxy = image_to_normalized(cam_min, lookup_min, offx, my);
+  const float d0 = G0 - G2 * nxy.x, d1 = G1 - G2 * nxy.y, d2 = G2 - G2 * 1.f;
+  const float point_radius = sqrtf(d0 * d0 + (d1 * d1 + d2 * d2));
+  if (point_radius < min_radius[i]) min_radius[i] = point_radius;
+  const float mr = (float)((double)point_radius / rp.min_scaling_factor);
+  if (mr > max_radius[i]) max_radius[i] = mr;
+}
+
 // ==== a20 / a21: observation candidates =============================================================================================
 struct ObsParams {
   float point_radius;
@@ -1668,6 +1755,56 @@ int e3d_reg_image_owner(e3d_reg_t* h, int image_id) {
   R_TRY
   if (!h) throw Error(E3D_ERR_INVALID, "null handle");
   return h->world <= 1 ? 0 : ((image_id % h->world) + h->world) % h->world;
+  R_CATCH()
+}
+
+/* CreateMultiScalePointCloud, first part (multi_scale_point_cloud.cc:236-262): the radius range of every point over all
+ * images of this rank -- observations at the best available scale of max(min_occlusion_check_image_scale (0),
+ * current_image_scale) with occlusion, mask and saturation tests but no scale test, then the point radius that projects to
+ * half a pixel.  min_radius starts at +inf, max_radius at -inf (points seen by no image keep those values). */
+int e3d_reg_point_radius_minmax(e3d_reg_t* h, const float* xyz, size_t n, float* min_radius, float* max_radius) {
+  R_TRY
+  if (!h || (n && (!xyz || !min_radius || !max_radius))) throw Error(E3D_ERR_INVALID, "null argument");
+  hipStream_t s = h->stream;
+  DevBuf<float> tmp, d_min, d_max;
+  DevBuf<float4> pts;
+  tmp.reserve(3 * n); pts.reserve(n); d_min.reserve(n); d_max.reserve(n);
+  copy_in(tmp.p, xyz, sizeof(float) * 3 * n, s);
+  hipLaunchKernelGGL(k_xyz_to_float4, dim3(nblk(n)), dim3(kBlock), 0, s, tmp.p, n, pts.p);
+  hipLaunchKernelGGL(k_fill_f32, dim3(nblk(n)), dim3(kBlock), 0, s, d_min.p, n, INFINITY);
+  hipLaunchKernelGGL(k_fill_f32, dim3(nblk(n)), dim3(kBlock), 0, s, d_max.p, n, -INFINITY);
+  std::map<int, std::shared_ptr<DevBuf<float2>>> lookups;       // per intrinsics block: model(0)'s undistortion table
+  for (auto& kv : h->images) {
+    if (!h->owns(kv.first)) continue;
+    ImageDev& im = kv.second;
+    const Intrin& in = h->intr.at(im.intrinsics_id);
+    const int scale = best_available_scale(h, in);
+    if (e3d_reg_render_depth(h, kv.first, scale, nullptr) < 0) throw Error(E3D_ERR_INVALID, e3d_last_error());
+    const int lvl = std::max(0, scale - in.min_image_scale);
+    const CamLevel& cam = in.levels[lvl];
+    const CamLevel& cam_min = in.levels[0];
+    auto& lk = lookups[im.intrinsics_id];
+    if (!lk) {
+      lk = std::make_shared<DevBuf<float2>>();
+      const size_t px = (size_t)cam_min.width * cam_min.height;
+      lk->reserve(px);
+      E3D_CAM_SWITCH(in.type, hipLaunchKernelGGL(k_undistort_lookup<M>, dim3(nblk(px)), dim3(kBlock), 0, s, cam_min, lk->p));
+    }
+    RadiusParams rp{};
+    rp.image_scale = scale; rp.min_image_scale = in.min_image_scale;
+    rp.occlusion_threshold = h->prm.occlusion_depth_threshold; rp.max_valid_intensity = h->prm.maximum_valid_intensity;
+    rp.min_scaling_factor = std::pow(2.0, -1.0 * (h->prm.image_scale_count - 1));
+    const float4 quat = make_float4(im.pose_q.q.w, im.pose_q.q.x, im.pose_q.q.y, im.pose_q.q.z);
+    if (n)
+      E3D_CAM_SWITCH(in.type, hipLaunchKernelGGL(k_point_radius<M>, dim3(nblk(n)), dim3(kBlock), 0, s, pts.p, n, im.pose, quat, cam, cam_min,
+                                                 lk->p, im.pix[lvl].p, im.has_mask[lvl] ? im.mask[lvl].p : nullptr, im.depth.p, rp,
+                                                 d_min.p, d_max.p));
+  }
+  copy_out(min_radius, d_min.p, sizeof(float) * n, s);
+  copy_out(max_radius, d_max.p, sizeof(float) * n, s);
+  rsync(h);
+  E3D_HIP(hipGetLastError());
+  return 0;
   R_CATCH()
 }
 

@@ -4,8 +4,7 @@
 // rigs.json, metadata.txt); the optimisation itself runs on the MI355X behind the C-ABI (e3d_reg_*).
 //
 // Not built yet (the tool says so instead of silently doing something else): --occlusion_mesh_path /
-// --occlusion_splats_path (OpenGL mesh renderer), computing the multi-resolution point cloud from the scans
-// (an existing cache directory is required), the observations cache, --write_debug_point_clouds, JPEG input.
+// --occlusion_splats_path (OpenGL mesh renderer), the observations cache, --write_debug_point_clouds, JPEG input.
 #include <cmath>
 #include <cstdlib>
 #include <iostream>
@@ -68,19 +67,23 @@ int main(int argc, char** argv) {
   }
   std::cout << "Loading point clouds ..." << std::endl;
   std::vector<float> occlusion_points;
+  std::vector<PointCloud::Ptr> colored_scans;
   const std::string project_dir = parent_path(scan_alignment_path);
   for (const MeshInfo& info : scan_infos) {
     PointCloud local;
     const std::string filename = (!info.filename.empty() && info.filename[0] == '/') ? info.filename : join_path(project_dir, info.filename);
-    if (loadPLYFile(filename, local) < 0) { std::cerr << "Cannot load scan point clouds." << std::endl; return EXIT_FAILURE; }
+    if (loadPLYFile(filename, local, /*want_rgb=*/true) < 0) { std::cerr << "Cannot load scan point clouds." << std::endl; return EXIT_FAILURE; }
     float T[12], bmin[3], bmax[3];
     info.global_T_mesh.matrix3x4(T);
-    const size_t base = occlusion_points.size();
-    occlusion_points.resize(base + local.xyz.size());
-    if (local.size() > 0 && api().e3d_transform_cloud(local.xyz.data(), nullptr, local.size(), T, occlusion_points.data() + base, nullptr, bmin, bmax) < 0) {
+    PointCloud::Ptr global(new PointCloud());
+    global->xyz.resize(local.xyz.size());
+    global->rgb.swap(local.rgb);
+    if (local.size() > 0 && api().e3d_transform_cloud(local.xyz.data(), nullptr, local.size(), T, global->xyz.data(), nullptr, bmin, bmax) < 0) {
       std::cerr << "transform failed: " << api().e3d_last_error() << std::endl;
       return EXIT_FAILURE;
     }
+    occlusion_points.insert(occlusion_points.end(), global->xyz.begin(), global->xyz.end());
+    colored_scans.push_back(global);
   }
   if (occlusion_points.empty()) { std::cerr << "Point cloud is empty." << std::endl; return EXIT_FAILURE; }
   std::cout << "Done." << std::endl;
@@ -88,7 +91,7 @@ int main(int argc, char** argv) {
   if (!problem.InitializeStateFromColmapModel(state_path, image_base_path, camera_ids_to_ignore)) return EXIT_FAILURE;
   std::vector<ColmapRig> rig_vector;
   if (ReadColmapRigs(state_path + "/rigs.json", &rig_vector) && !problem.AssignRigs(rig_vector)) return EXIT_FAILURE;
-  if (!problem.SetScanGeometryAndInitialize(occlusion_points, multi_res_point_cloud_directory_path)) return EXIT_FAILURE;
+  if (!problem.SetScanGeometryAndInitialize(colored_scans, occlusion_points, multi_res_point_cloud_directory_path)) return EXIT_FAILURE;
 
   constexpr float kMaxChangeConvergenceThreshold = 0;
   constexpr int kIterationsWithoutNewOptimumThreshold = 15;

@@ -6,7 +6,9 @@
 //   io::InitializeStateFromColmapModel      src/io/colmap_model.cc:788-868
 //   opt::AssignRigs                         src/opt/rig.cc:25-271
 //   Problem::InitializeImages / LoadImages  src/opt/problem.cc:476-505, Image::LoadImageData src/opt/image.cc:40-72
-//   Problem::LoadMultiResPointCloud         src/opt/problem.cc:62-159   (ComputeMultiResPointCloud: SURVEY f1, not built)
+//   Problem::Load/SaveMultiResPointCloud    src/opt/problem.cc:62-159,364-411
+//   Problem::ComputeMultiResPointCloud      src/opt/problem.cc:160-362, CreateMultiScalePointCloud
+//                                           src/opt/multi_scale_point_cloud.cc:182-369 (radius ranges and merging on the GPU)
 //   fixed descriptors                       src/opt/problem.cc:549-572
 //   io::ExportProblemToColmap / ExportRigs  src/io/colmap_model.cc:286-516
 #pragma once
@@ -435,8 +437,159 @@ class Problem {
     return true;
   }
 
+  // Problem::SaveMultiResPointCloud (modify_colors_for_display = false)
+  bool SaveMultiResPointCloud(const std::string& dir) const {
+    create_directories(dir);
+    std::ofstream f(dir + "/metadata.txt");
+    f << "version 1" << std::endl;
+    f << "neighbor_candidate_count " << prm.point_neighbor_candidate_count << std::endl;
+    f << "neighbor_count " << prm.point_neighbor_count << std::endl;
+    f << "point_scale_count " << point_radii.size() << std::endl;
+    for (float r : point_radii) f << "point_radius " << r << std::endl;
+    f.close();
+    for (size_t s = 0; s < points.size(); ++s)
+      if (savePLYFileBinaryXYZI(dir + "/points_of_scale_" + std::to_string(s) + ".ply", points[s], colors[s]) < 0) return fail("Cannot write the multi-res point cloud to " + dir);
+    FILE* nf = fopen((dir + "/neighbor_point_indices").c_str(), "wb");
+    if (!nf) return fail("Cannot open " + dir + "/neighbor_point_indices for writing");
+    for (size_t s = 0; s < neighbors.size(); ++s) {
+      std::vector<uint64_t> raw(neighbors[s].begin(), neighbors[s].end());
+      fwrite(raw.data(), sizeof(uint64_t), raw.size(), nf);
+    }
+    fclose(nf);
+    return true;
+  }
+
+  struct ScaleCloud { double radius; std::vector<float> pts, col, max_radius; std::vector<uint8_t> scan; };
+
+  // Problem::ComputeMultiResPointCloud.  scans: global-frame points + RGB per scan (PreprocessScans :182-211).
+  bool ComputeMultiResPointCloud(const std::vector<PointCloud::Ptr>& scans) {
+    const bool use_fixed = prm.fixed_residuals_weight > 0;
+    const int num_scans = (int)scans.size();
+    std::cout << "ComputeMultiResPointCloud(): Pre-processing scans ..." << std::endl;
+    std::vector<float> pts, col;
+    std::vector<uint8_t> scan_idx;
+    for (int si = 0; si < num_scans; ++si) {
+      const PointCloud& c = *scans[si];
+      if (c.rgb.size() != c.xyz.size()) return fail("ComputeMultiResPointCloud(): the scans need colours (red green blue)");
+      pts.insert(pts.end(), c.xyz.begin(), c.xyz.end());
+      for (size_t i = 0; i < c.size(); ++i) {
+        col.push_back((float)(0.299 * c.rgb[3 * i] + 0.587 * c.rgb[3 * i + 1] + 0.114 * c.rgb[3 * i + 2]));
+        scan_idx.push_back((uint8_t)si);
+      }
+    }
+    const size_t n = pts.size() / 3;
+    std::cout << "ComputeMultiResPointCloud(): Creating multi-res point cloud ..." << std::endl;
+    std::vector<float> min_radius(n), max_radius(n);
+    if (api().e3d_reg_point_radius_minmax(reg, pts.data(), n, min_radius.data(), max_radius.data()) < 0) return lib_fail("e3d_reg_point_radius_minmax");
+    float min_radius_value = INFINITY, max_radius_value = -INFINITY;
+    for (size_t i = 0; i < n; ++i) { min_radius_value = std::min(min_radius_value, min_radius[i]); max_radius_value = std::max(max_radius_value, max_radius[i]); }
+    if (!std::isfinite(min_radius_value)) return fail("ComputeMultiResPointCloud(): no scan point is visible in any image");
+    // CreateMultiScalePointCloud :264-369
+    const float min_point_radius = min_radius_value * prm.min_radius_bias;
+    double radius = min_point_radius;
+    ScaleCloud last;
+    for (size_t i = 0; i < n; ++i)
+      if (radius >= min_radius[i]) {
+        last.pts.insert(last.pts.end(), pts.begin() + 3 * i, pts.begin() + 3 * i + 3);
+        last.col.push_back(col[i]); last.scan.push_back(scan_idx[i]); last.max_radius.push_back(max_radius[i]);
+      }
+    std::vector<ScaleCloud> out;
+    float last_radius = -1;
+    while (true) {
+      if (last_radius > 0) {
+        ScaleCloud next;
+        for (size_t i = 0; i < last.col.size(); ++i)
+          if (radius <= last.max_radius[i]) {
+            next.pts.insert(next.pts.end(), last.pts.begin() + 3 * i, last.pts.begin() + 3 * i + 3);
+            next.col.push_back(last.col[i]); next.scan.push_back(last.scan[i]); next.max_radius.push_back(last.max_radius[i]);
+          }
+        for (size_t i = 0; i < n; ++i)
+          if (last_radius < min_radius[i] && radius >= min_radius[i]) {
+            next.pts.insert(next.pts.end(), pts.begin() + 3 * i, pts.begin() + 3 * i + 3);
+            next.col.push_back(col[i]); next.scan.push_back(scan_idx[i]); next.max_radius.push_back(max_radius[i]);
+          }
+        last = std::move(next);
+      }
+      ScaleCloud merged;
+      merged.radius = radius;
+      const size_t m = last.col.size();
+      merged.pts.resize(3 * std::max<size_t>(m, 1)); merged.col.resize(std::max<size_t>(m, 1)); merged.scan.resize(std::max<size_t>(m, 1)); merged.max_radius.resize(std::max<size_t>(m, 1));
+      const int64_t k = m ? api().e3d_merge_close_points((float)(prm.merge_distance_factor * radius), num_scans, last.pts.data(), last.col.data(),
+                                                       last.scan.data(), last.max_radius.data(), m, merged.pts.data(), merged.col.data(),
+                                                       merged.scan.data(), merged.max_radius.data())
+                            : 0;
+      if (k < 0) return lib_fail("e3d_merge_close_points");
+      merged.pts.resize(3 * (size_t)k); merged.col.resize(k); merged.scan.resize(k); merged.max_radius.resize(k);
+      out.push_back(merged);
+      last_radius = (float)radius;
+      radius *= 2;
+      if (radius >= max_radius_value * 0.99f) break;
+      last = merged;
+    }
+    std::cout << "ComputeMultiResPointCloud(): #Initial point scales: " << out.size() << std::endl;
+    const int need = prm.point_neighbor_candidate_count + 1;
+    auto sufficient = [&](const ScaleCloud& c) {
+      if (!use_fixed) return (int)c.col.size() >= need;
+      std::vector<int> per(num_scans, 0);
+      for (uint8_t s2 : c.scan) per[s2]++;
+      for (int v : per) if (v < need) return false;
+      return true;
+    };
+    auto filter_scales = [&](const char* kept, std::vector<ScaleCloud>& v) {
+      std::vector<ScaleCloud> r;
+      for (size_t i = 0; i < v.size(); ++i) {
+        std::cout << (sufficient(v[i]) ? kept : "Deleting") << " point_scale " << i << ": " << v[i].col.size() << " points" << std::endl;
+        if (sufficient(v[i])) r.push_back(std::move(v[i]));
+      }
+      v.swap(r);
+    };
+    std::cout << "ComputeMultiResPointCloud(): Filtering out scales with insufficient point count ..." << std::endl;
+    filter_scales("Remaining", out);
+    const int K = prm.point_neighbor_count;
+    auto neighbors_of = [&](const ScaleCloud& c, std::vector<uint32_t>* nb) {
+      nb->resize(c.col.size() * (size_t)K);
+      return api().e3d_determine_point_neighbors(c.pts.data(), c.col.size(), c.scan.data(), num_scans, use_fixed ? 1 : 0, K,
+                                                 prm.point_neighbor_candidate_count, nb->data()) >= 0;
+    };
+    std::cout << "ComputeMultiResPointCloud(): Determining neighbors ..." << std::endl;
+    std::cout << "ComputeMultiResPointCloud(): Filtering out points with small intensity differences ..." << std::endl;
+    for (ScaleCloud& c : out) {
+      std::vector<uint32_t> nb;
+      if (!neighbors_of(c, &nb)) return lib_fail("e3d_determine_point_neighbors");
+      const size_t m = c.col.size();
+      std::vector<char> del(m), del2(m, 1);
+      for (size_t p = 0; p < m; ++p) {
+        float sum = 0;
+        for (int k = 0; k < K; ++k) sum += std::fabs(c.col[nb[p * K + k]] - c.col[p]);
+        del[p] = (sum / K) < prm.min_mean_intensity_difference_for_points;
+      }
+      for (size_t p = 0; p < m; ++p)
+        if (!del[p]) { del2[p] = 0; for (int k = 0; k < K; ++k) del2[nb[p * K + k]] = 0; }     // keep the neighbours of kept points too
+      size_t o = 0;
+      for (size_t p = 0; p < m; ++p) {
+        if (del2[p]) continue;
+        for (int a = 0; a < 3; ++a) c.pts[3 * o + a] = c.pts[3 * p + a];
+        c.col[o] = c.col[p]; c.scan[o] = c.scan[p];
+        ++o;
+      }
+      c.pts.resize(3 * o); c.col.resize(o); c.scan.resize(o);
+    }
+    std::cout << "ComputeMultiResPointCloud(): Filtering out scales with insufficient point count ..." << std::endl;
+    filter_scales("Final", out);
+    std::cout << "ComputeMultiResPointCloud(): Determining neighbors ..." << std::endl;
+    point_radii.clear(); points.clear(); colors.clear(); neighbors.clear();
+    for (ScaleCloud& c : out) {
+      std::vector<uint32_t> nb;
+      if (!neighbors_of(c, &nb)) return lib_fail("e3d_determine_point_neighbors");
+      point_radii.push_back((float)c.radius); points.push_back(std::move(c.pts)); colors.push_back(std::move(c.col)); neighbors.push_back(std::move(nb));
+    }
+    if (point_radii.empty()) return fail("ComputeMultiResPointCloud(): no point scale has enough points");
+    return true;
+  }
+
   // Problem::SetScanGeometryAndInitialize: image scales, pyramids, point scales, fixed descriptors -> device
-  bool SetScanGeometryAndInitialize(const std::vector<float>& occlusion_points, const std::string& multi_res_dir) {
+  bool SetScanGeometryAndInitialize(const std::vector<PointCloud::Ptr>& scans, const std::vector<float>& occlusion_points,
+                                    const std::string& multi_res_dir) {
     image_scale_count = 1;
     for (const HostIntrinsics& in : intrinsics_list) image_scale_count = std::max(image_scale_count, ComputeImageScaleCount(in));
     std::cout << "#Image scales: " << image_scale_count << std::endl;
@@ -522,11 +675,16 @@ class Problem {
     for (const HostRigImages& f : rig_images)
       if (api().e3d_reg_add_rig_images(reg, f.rig_id, f.image_ids.data(), (int)f.image_ids.size()) < 0) return lib_fail("e3d_reg_add_rig_images");
 
+    // the occlusion geometry (splats of all scan points) is needed by the radius-range pass already
+    if (api().e3d_reg_set_splat_points(reg, occlusion_points.data(), occlusion_points.size() / 3) < 0) return lib_fail("e3d_reg_set_splat_points");
     if (multi_res_dir.empty()) return fail("Please specify --multi_res_point_cloud_directory_path.");
-    if (!LoadMultiResPointCloud(multi_res_dir))
-      return fail("No multi-resolution point cloud found in " + multi_res_dir + ".\nComputing it from the scans (Problem::ComputeMultiResPointCloud, "
-                  "src/opt/problem.cc:160-362) is not part of this build yet; create the cache with the reference's tools or tools/make_multires_cache.py.");
-    std::cout << "SetScanGeometryAndInitialize(): Loaded existing multi-res point cloud." << std::endl;
+    if (LoadMultiResPointCloud(multi_res_dir)) {
+      std::cout << "SetScanGeometryAndInitialize(): Loaded existing multi-res point cloud." << std::endl;
+    } else {
+      if (!ComputeMultiResPointCloud(scans)) return false;
+      // saved for faster loading next time (and to keep it constant while camera poses change)
+      if (!SaveMultiResPointCloud(multi_res_dir)) return false;
+    }
     const int K = prm.point_neighbor_count;
     const bool use_fixed = prm.fixed_residuals_weight > 0;
     if (use_fixed) std::cout << "SetScanGeometryAndInitialize(): Compute fixed point descriptors from colors ..." << std::endl;
@@ -541,7 +699,6 @@ class Problem {
       if (api().e3d_reg_set_point_scale(reg, (int)s, points[s].data(), n, point_radii[s], neighbors[s].data(), use_fixed ? desc.data() : nullptr) < 0)
         return lib_fail("e3d_reg_set_point_scale");
     }
-    if (api().e3d_reg_set_splat_points(reg, occlusion_points.data(), occlusion_points.size() / 3) < 0) return lib_fail("e3d_reg_set_splat_points");
     return true;
   }
 

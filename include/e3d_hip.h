@@ -281,6 +281,12 @@ int e3d_determine_point_neighbors(const float* xyz, size_t n, const uint8_t* sca
                                   int limit_to_same_scan, int neighbor_count, int candidate_count,
                                   uint32_t* neighbor_indices);
 
+/* ComputeMinMaxPointRadius over all images (src/opt/multi_scale_point_cloud.cc:126-180,236-262): for every point the smallest
+ * radius that projects to half a pixel in some image (min_radius, +inf if never observed) and the largest such radius
+ * divided by the minimum scaling factor 2^-(image_scale_count - 1) (max_radius, -inf if never observed).  Uses the images,
+ * intrinsics, splat points and parameters already set on the handle (current_image_scale = 0 at set-up time). */
+int e3d_reg_point_radius_minmax(e3d_reg_t* reg, const float* xyz, size_t n, float* min_radius, float* max_radius);
+
 /* MergeClosePoints (src/opt/multi_scale_point_cloud.cc:44-124): greedy merge in point order -- every point not yet absorbed
  * becomes a centre and absorbs all points strictly within merge_distance -- computed in parallel (the centres are the
  * lexicographically first maximal independent set).  Outputs (capacity n each) in centre order: mean position, mean colour of

@@ -147,3 +147,65 @@ def test_image_registrator_cli_with_rig(tmp_path, e3d):
 def test_image_registrator_cli_errors(tmp_path):
     r = subprocess.run([os.path.join(BIN, "ImageRegistrator")], capture_output=True, text=True)
     assert r.returncode != 0 and "Please specify all the required paths." in r.stderr
+
+
+def _read_cache(d):
+    meta = open(os.path.join(d, "metadata.txt")).read().split()
+    assert meta[:2] == ["version", "1"]
+    nscales = int(meta[meta.index("point_scale_count") + 1])
+    radii = [float(meta[i + 1]) for i, v in enumerate(meta) if v == "point_radius"]
+    K = int(meta[meta.index("neighbor_count") + 1])
+    scales = []
+    nb_raw = np.fromfile(os.path.join(d, "neighbor_point_indices"), np.uint64)
+    off = 0
+    for s in range(nscales):
+        data = open(os.path.join(d, "points_of_scale_%d.ply" % s), "rb").read()
+        end = data.index(b"end_header\n") + len(b"end_header\n")
+        n = int(data[:end].decode().split("element vertex ")[1].split()[0])
+        rec = np.frombuffer(data, dtype=[("p", "<f4", 3), ("i", "<f4")], count=n, offset=end)
+        scales.append(dict(radius=radii[s], pts=rec["p"].copy(), colors=rec["i"].copy(), nbr=nb_raw[off:off + n * K].reshape(n, K).astype(np.int64)))
+        off += n * K
+    assert off == len(nb_raw)
+    return scales
+
+
+def test_image_registrator_computes_multires_cloud(tmp_path, e3d):
+    """No cache directory: the tool builds the multi-resolution point cloud from the coloured scans (radius ranges and
+    merging on the GPU), saves it in the reference's cache format and optimises on it.  Compared with the oracle pipeline."""
+    from oracle import multires as mr
+    from reg_util import texture
+    from tools.make_multires_cache import write_cache  # noqa: F401  (format documented there)
+    M = make_multi_image_scene(n_points=9000, n_images=3, seed=14, perturb=0.004)
+    names = ["dslr/img_%d.png" % i for i in range(3)]
+    d = _write_dataset(tmp_path, M, names)
+    import shutil
+    shutil.rmtree(os.path.join(d, "cache"))
+    # two coloured scans (grey = the scene texture), identity scan poses
+    tex = texture(M["pts"][:, 0].astype(np.float64), M["pts"][:, 2].astype(np.float64)).clip(0, 255)
+    rgb = np.repeat(np.rint(tex).astype(np.uint8)[:, None], 3, 1)
+    half = len(M["pts"]) // 2
+    write_ply_xyz(os.path.join(d, "scan_a.ply"), M["pts"][:half], rgb=rgb[:half])
+    write_ply_xyz(os.path.join(d, "scan_b.ply"), M["pts"][half:], rgb=rgb[half:])
+    write_mlp(os.path.join(d, "scans.mlp"), [("a", "scan_a.ply", np.eye(4)), ("b", "scan_b.ply", np.eye(4))])
+    out = _run_tool(d)          # --max_initial_image_area_in_pixels 3000 -> 3 image scales
+    assert "ComputeMultiResPointCloud(): Creating multi-res point cloud ..." in out and "Finished!" in out and "#Image scales: 3" in out
+    got = _read_cache(os.path.join(d, "cache"))
+    # oracle pipeline on the same inputs (initial poses, as the tool sees them)
+    images = {i: dict(intr=0, pyr=im["pyr"], masks=None, q=im["q_init"], t=im["t_init"]) for i, im in enumerate(M["images"])}
+    intr = {0: dict(w=M["width"], h=M["height"], params=M["params"], min=0, n=3, model=0)}
+    scans = [(M["pts"][:half], rgb[:half]), (M["pts"][half:], rgb[half:])]
+    exp = mr.compute_multi_res_point_cloud(scans, images, intr, image_scale_count=3)
+    assert len(got) == len(exp) >= 1
+    for g, o in zip(got, exp):
+        assert abs(g["radius"] - float(o["radius"])) <= 1e-6 * float(o["radius"])
+        assert abs(len(g["pts"]) - len(o["pts"])) <= max(2, len(o["pts"]) // 200)      # merged means differ in the last bits
+        assert g["nbr"].max() < len(g["pts"]) and np.all(g["nbr"] != np.arange(len(g["pts"]))[:, None])
+        if len(g["pts"]) == len(o["pts"]):
+            assert np.abs(g["pts"] - o["pts"]).max() <= 1e-4 and np.abs(g["colors"] - o["colors"]).max() <= 1e-2
+            assert (g["nbr"] == o["nbr"].astype(np.int64)).mean() > 0.98
+    costs = [float(l.split(":")[-1]) for l in out.splitlines() if "Cost (considering occlusions) is" in l]
+    assert len(costs) >= 2 and np.isfinite(costs).all() and min(costs) < costs[0]
+    # second run: the saved cache is picked up
+    shutil.rmtree(os.path.join(d, "out"))
+    out2 = _run_tool(d)
+    assert "Loaded existing multi-res point cloud." in out2 and "Creating multi-res point cloud" not in out2

@@ -52,3 +52,29 @@ def test_merge_close_points_edge_cases(e3d, mr):
         e3d.merge_close_points(0.0, 1, P, *args)
     with pytest.raises(e3d.E3DError):
         e3d.merge_close_points(0.1, 99, P, *args)
+
+
+@pytest.mark.parametrize("model", [0, 1, 2])
+def test_point_radius_minmax_matches_oracle(e3d, mr, model):
+    from reg_util import make_multi_image_scene
+    M = make_multi_image_scene(n_points=8000, n_images=3, seed=21, model=model)
+    G = e3d.RegProblem(e3d.default_reg_params(image_scale_count=M["n_levels"], point_neighbor_count=M["K"]))
+    G.set_intrinsics(0, M["width"], M["height"], M["params"], 0, M["n_levels"], camera_type=model)
+    G.set_splat_points(M["pts"])
+    images = {}
+    for i, im in enumerate(M["images"]):
+        G.set_image(i, 0, im["pyr"]); G.set_image_pose(i, im["q_true"], im["t_true"])
+        images[i] = dict(intr=0, pyr=im["pyr"], masks=None, q=im["q_true"], t=im["t_true"])
+    intr = {0: dict(w=M["width"], h=M["height"], params=M["params"], min=0, n=M["n_levels"], model=model)}
+    # some points far outside every frustum stay unobserved
+    pts = np.concatenate([M["pts"], np.array([[50, 3, 0], [0, -5, 0]], np.float32)])
+    gmn, gmx = G.point_radius_minmax(pts)
+    omn, omx = mr.point_radius_minmax(pts, images, intr, M["pts"], M["n_levels"])
+    seen_o = np.isfinite(omn)
+    assert np.array_equal(np.isfinite(gmn), seen_o) and seen_o[:-2].sum() > 4000 and not seen_o[-2:].any()
+    assert np.array_equal(np.isfinite(gmx), np.isfinite(omx))
+    tol = 1e-6 if model != 2 else 1e-4
+    assert np.abs(gmn[seen_o] - omn[seen_o]).max() <= tol * omn[seen_o].max()
+    assert np.abs(gmx[seen_o] - omx[seen_o]).max() <= tol * omx[seen_o].max()
+    # sanity of the magnitude: half a pixel at depth z and focal length f is about z / (2 f)
+    assert 0.5 * 2.5 / 210 / 2 < np.median(gmn[seen_o]) < 2 * 3.5 / 210 / 2

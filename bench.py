@@ -71,6 +71,15 @@ def cpu_baseline(scans, d, thr, slab):
     }
 
 
+def reg_traffic(model, n_images):
+    """Measured HBM bytes of pass 1 + pass 2 for the leg's n_images launches (PINHOLE only; profiles/round1_reg_traffic.json)."""
+    path = os.path.join(ROOT, "profiles", "round1_reg_traffic.json")
+    if model != 0 or not os.path.exists(path):
+        return None
+    k = json.load(open(path))["kernels"]
+    return n_images * sum(v["hbm_bytes_per_launch"] for v in k.values())
+
+
 def image_registrator_leg(e3d, synth, cpu=True):
     """Second BASELINE.json metric: ImageRegistrator residuals/s = (#fixed + #variable colour residuals) / wall time of the
     accumulate pass of IntrinsicsAndPoseOptimizer::Apply (src/opt/intrinsics_and_pose_optimizer.cc:87-92,624-837) over all
@@ -109,7 +118,7 @@ def image_registrator_leg(e3d, synth, cpu=True):
                      "observation_refresh_ms": t_obs * 1e3, "colour_update_ms": t_col * 1e3, "cost_ms": t_cost * 1e3,
                      "ms_per_run_iteration": t_run / max(its, 1) * 1e3,
                      "roofline": {"bound": "hbm", "achieved": alg / t_acc / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                  "frac": alg / t_acc / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                                  "frac": alg / t_acc / 1e9 / HBM_PEAK_GBS, "traffic": reg_traffic(model, len(ids)),
                                   "kernel": "k_reg_pass1 + k_reg_pass2 (+ reduce, read-back) of e3d_reg_accumulate",
                                   "algorithmic_bytes": alg}}
         del P

@@ -116,9 +116,12 @@ __device__ __forceinline__ float robust_weight(int type, float param, float r) {
 constexpr int kTile = 32;
 
 // the reference's rectangle of one point (occlusion_geometry.cc:423-452), clipped to the image; false if empty
+constexpr int kSplatMax = 10;        // max_splat_radius (occlusion_geometry.cc:417)
+
 template <int M>
 __device__ __forceinline__ bool splat_rect(const float4 p, const Pose& P, const CamLevel& cam, float point_radius, int& min_x, int& min_y,
-                                           int& end_x, int& end_y, unsigned& zb) {
+                                           int& end_x, int& end_y, unsigned& zb, bool& full_size, int& cxi, int& cyi) {
+  full_size = false;
   float X, Y, Z;
   rt(P, p.x, p.y, p.z, X, Y, Z);
   if (!(Z > 0.f)) return false;
@@ -127,9 +130,11 @@ __device__ __forceinline__ bool splat_rect(const float4 p, const Pose& P, const 
   cam_image_deriv_by_world<M>(cam, X, Y, Z, d);
   float rx = sqrtf(d[0] * d[0] + (d[1] * d[1] + d[2] * d[2])) * point_radius;
   float ry = sqrtf(d[3] * d[3] + (d[4] * d[4] + d[5] * d[5])) * point_radius;
+  full_size = rx >= 10.f && ry >= 10.f;     // both half-extents clamped: the rectangle is exactly [ix-10, ix+10] x [iy-10, iy+10]
   rx = (10.f < rx) ? 10.f : rx;     // std::min(splat_radius, max_splat_radius)
   ry = (10.f < ry) ? 10.f : ry;
   const int ix = f2i(px + 0.5f), iy = f2i(py + 0.5f);
+  cxi = ix; cyi = iy;
   min_x = d2i((double)((float)ix - rx) + 0.5); min_y = d2i((double)((float)iy - ry) + 0.5);
   end_x = d2i((double)((float)ix + rx) + 1.5); end_y = d2i((double)((float)iy + ry) + 1.5);
   min_x = max(min_x, 0); min_y = max(min_y, 0);
@@ -143,12 +148,21 @@ template <int M>
 __global__ __launch_bounds__(kBlock) void k_splat_bin(const float4* __restrict__ pts, size_t n, Pose P, CamLevel cam,
                                                       float point_radius, int tiles_x, uint4* __restrict__ rects,
                                                       unsigned* __restrict__ keys, unsigned* __restrict__ vals,
-                                                      unsigned* __restrict__ counter) {
+                                                      unsigned* __restrict__ counter, unsigned* __restrict__ zbuf) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  int min_x = 0, min_y = 0, end_x = 0, end_y = 0;
+  int min_x = 0, min_y = 0, end_x = 0, end_y = 0, cxi = 0, cyi = 0;
   unsigned zb = 0;
-  bool ok = false;
-  if (i < n) ok = splat_rect<M>(pts[i], P, cam, point_radius, min_x, min_y, end_x, end_y, zb);
+  bool ok = false, full_size = false;
+  if (i < n) ok = splat_rect<M>(pts[i], P, cam, point_radius, min_x, min_y, end_x, end_y, zb, full_size, cxi, cyi);
+  if (ok && full_size) {
+    // Full-size splats (the near, heavily overlapping ones) are not rasterised one by one: their union is the 21 x 21
+    // MIN FILTER of the one-pixel-per-point z-buffer, computed separably afterwards (k_min_filter_h / _v).  The buffer
+    // carries a 10-pixel apron because a splat centred outside the image can still reach into it.
+    const int wp = cam.width + 2 * kSplatMax;
+    if (cxi >= -kSplatMax && cyi >= -kSplatMax && cxi < cam.width + kSplatMax && cyi < cam.height + kSplatMax)
+      atomicMin(&zbuf[(size_t)(cyi + kSplatMax) * wp + (cxi + kSplatMax)], zb);
+    ok = false;
+  }
   int tx0 = 0, tx1 = -1, ty0 = 0, ty1 = -1;
   if (ok) {
     tx0 = min_x / kTile; tx1 = (end_x - 1) / kTile; ty0 = min_y / kTile; ty1 = (end_y - 1) / kTile;
@@ -219,6 +233,36 @@ __global__ __launch_bounds__(kBlock) void k_splat_tiles(const uint4* __restrict_
     const int x = x0 + (i & (kTile - 1)), y = y0 + (i / kTile);
     if (x < width && y < height) depth_bits[(size_t)y * width + x] = tile[i];
   }
+}
+
+// separable 21 x 21 min filter of the apron-padded point z-buffer (positive float bits compare like unsigned integers)
+__global__ __launch_bounds__(kBlock) void k_min_filter_h(const unsigned* __restrict__ zbuf, int width, int height,
+                                                         unsigned* __restrict__ tmp /* (height + 20) x width */) {
+  __shared__ unsigned row[kBlock + 2 * kSplatMax];
+  const int wp = width + 2 * kSplatMax;
+  const int y = blockIdx.y;                                   // padded row
+  const int x0 = blockIdx.x * kBlock;
+  for (int i = threadIdx.x; i < kBlock + 2 * kSplatMax; i += kBlock) {
+    const int xp = x0 + i;                                    // padded column of output column x0 + i - 10
+    row[i] = (xp < wp) ? zbuf[(size_t)y * wp + xp] : 0x7f800000u;
+  }
+  __syncthreads();
+  const int x = x0 + threadIdx.x;
+  if (x >= width) return;
+  unsigned m = 0x7f800000u;
+#pragma unroll
+  for (int d = 0; d <= 2 * kSplatMax; ++d) m = min(m, row[threadIdx.x + d]);
+  tmp[(size_t)y * width + x] = m;
+}
+__global__ __launch_bounds__(kBlock) void k_min_filter_v(const unsigned* __restrict__ tmp, int width, int height,
+                                                         unsigned* __restrict__ depth_bits) {
+  const int x = blockIdx.x * kBlock + threadIdx.x;
+  const int y = blockIdx.y;
+  if (x >= width) return;
+  unsigned m = depth_bits[(size_t)y * width + x];             // what the rectangle path (smaller splats) produced
+#pragma unroll
+  for (int d = 0; d <= 2 * kSplatMax; ++d) m = min(m, tmp[(size_t)(y + d) * width + x]);
+  depth_bits[(size_t)y * width + x] = m;
 }
 
 // ==== f1: per-point radius range (ComputeMinMaxPointRadius, multi_scale_point_cloud.cc:126-180) ==================================
@@ -829,7 +873,7 @@ struct e3d_reg {
   bool owns(int image_id) const { return world <= 1 || ((image_id % world) + world) % world == rank; }
   // splat depth: per-point rectangles, (tile, point) pairs (double-buffered for the sort), tile ranges
   DevBuf<uint4> rects;
-  DevBuf<unsigned> sp_keys[2], sp_vals[2], sp_counter, tile_start, tile_end;
+  DevBuf<unsigned> sp_keys[2], sp_vals[2], sp_counter, tile_start, tile_end, zbuf, ztmp;
   DevBuf<char> sort_temp;
   ~e3d_reg() { if (stream) (void)hipStreamDestroy(stream); }
 };
@@ -1275,10 +1319,13 @@ int e3d_reg_render_depth(e3d_reg_t* h, int image_id, int image_scale, float* dep
     E3D_HIP(hipMemsetAsync(h->tile_start.p, 0, sizeof(unsigned) * n_tiles, s));
     E3D_HIP(hipMemsetAsync(h->tile_end.p, 0, sizeof(unsigned) * n_tiles, s));
     unsigned n_pairs = 0;
+    const size_t zpx = (size_t)(cam.width + 2 * kSplatMax) * (cam.height + 2 * kSplatMax);
+    h->zbuf.reserve(zpx); h->ztmp.reserve((size_t)cam.width * (cam.height + 2 * kSplatMax));
+    hipLaunchKernelGGL(k_fill_f32, dim3(nblk(zpx)), dim3(kBlock), 0, s, reinterpret_cast<float*>(h->zbuf.p), zpx, INFINITY);
     if (n) {
       E3D_CAM_SWITCH(in.type, hipLaunchKernelGGL(k_splat_bin<M>, dim3(nblk(n)), dim3(kBlock), 0, s, h->splat.p, n, im.pose, cam,
                                                  h->prm.splat_radius, tiles_x, h->rects.p, h->sp_keys[0].p, h->sp_vals[0].p,
-                                                 h->sp_counter.p));
+                                                 h->sp_counter.p, h->zbuf.p));
       copy_out(&n_pairs, h->sp_counter.p, sizeof n_pairs, s);
       rsync(h);
     }
@@ -1291,6 +1338,10 @@ int e3d_reg_render_depth(e3d_reg_t* h, int image_id, int image_scale, float* dep
     }
     hipLaunchKernelGGL(k_splat_tiles, dim3((unsigned)n_tiles), dim3(kBlock), 0, s, h->rects.p, h->sp_vals[1].p, h->tile_start.p,
                        h->tile_end.p, tiles_x, cam.width, cam.height, reinterpret_cast<unsigned*>(im.depth.p));
+    hipLaunchKernelGGL(k_min_filter_h, dim3((unsigned)div_up(cam.width, kBlock), (unsigned)(cam.height + 2 * kSplatMax)), dim3(kBlock), 0, s,
+                       h->zbuf.p, cam.width, cam.height, h->ztmp.p);
+    hipLaunchKernelGGL(k_min_filter_v, dim3((unsigned)div_up(cam.width, kBlock), (unsigned)cam.height), dim3(kBlock), 0, s, h->ztmp.p,
+                       cam.width, cam.height, reinterpret_cast<unsigned*>(im.depth.p));
   }
   if (depth_out) copy_out(depth_out, im.depth.p, sizeof(float) * px, h->stream);
   rsync(h);

@@ -336,3 +336,35 @@ def test_determine_point_neighbors_shuffle_stream(e3d):
         assert i not in nb[i] and set(nb[i].tolist()) <= set(nn[i, 1:].tolist()) and len(set(nb[i].tolist())) == 5
     # deterministic: same call, same result
     assert np.array_equal(nb, e3d.determine_point_neighbors(pts, 5, 25))
+
+
+@pytest.mark.parametrize("model", MODELS)
+def test_splat_depth_full_size_and_small_splats(e3d, rb, model):
+    """High resolution: part of the splats hit the 10-pixel clamp (rendered as a separable min filter of the point z-buffer),
+    part do not (tile path); points just outside the image still reach into it.  The union must equal the reference's
+    per-splat rectangles bit for bit."""
+    from reg_util import DISTORTION, look_at_pose, quat_from_R, quat_to_R
+    rng = np.random.RandomState(11)
+    W, H = 1280, 960
+    n = 30000
+    u = rng.uniform(-2.2, 2.2, n); v = rng.uniform(-1.7, 1.7, n)
+    depth = 2.2 + 1.6 * rng.uniform(0, 1, n) ** 2 + 0.4 * np.sin(2 * u)          # 2.2 .. 4.2 m: radii 7 .. 14 px at f = 1040
+    pts = np.stack([u, depth, v], 1).astype(np.float32)
+    params = np.array([1040.0, 1020.0, W / 2 - 0.3, H / 2 + 0.2] + DISTORTION[model], np.float32)
+    R0, t = look_at_pose((0.05, -0.1, 0.02), (0, 3, 0))
+    q = quat_from_R(R0); R = quat_to_R(q)
+    P = e3d.RegProblem(e3d.default_reg_params(image_scale_count=3, point_neighbor_count=5))
+    P.set_intrinsics(0, W, H, params, 0, 3, camera_type=model)
+    img = np.zeros((H, W), np.uint8)
+    from reg_util import pyramid_u8
+    P.set_image(0, 0, pyramid_u8(img, 3)); P.set_image_pose(0, q, t)
+    P.set_splat_points(pts)
+    levels = rb.camera_pyramid(rb.make_camera(W, H, params, model), 3)
+    for scale in (0, 1):
+        g = P.render_depth(0, scale, (levels[scale].height, levels[scale].width))
+        o = rb.splat_depth(pts, R, t, levels[scale], 0.03)
+        assert np.isfinite(g).mean() > 0.5
+        if model in EXACT:
+            assert np.array_equal(g.view(np.uint32), o.view(np.uint32)), scale
+        else:
+            assert (g.view(np.uint32) != o.view(np.uint32)).mean() < 2e-3

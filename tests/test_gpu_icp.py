@@ -225,3 +225,16 @@ def test_icp_errors(e3d):
         g.run(0.1, 0, 1, 1e-6)          # reference: CHECK(!clouds_.empty())
     with pytest.raises(IndexError):
         g.get_result_global_T_cloud(0)  # reference: clouds_.at() throws
+
+
+def test_icp_c3_shape_all_pairs(e3d, ob, synth):
+    """BASELINE.json configs[2] in miniature: 6 scans, all movable, all 30 directed pairs, a 30-unknown LM system
+    (impl cloud 0 never moves) incl. the lower-triangle quirk for pairs (i, k) with i > k."""
+    scans = synth.make_scene(6, 15000, seed=31)
+    clouds = [(s["xyz"].numpy(), s["normals"].numpy(), s["T_init"], False) for s in scans]
+    g, o, ids, cg, co = _run_both(e3d, ob, clouds, 0.12, 4, thr=1e-9)
+    assert ids == list(range(6))
+    recs = g.pair_records()
+    assert len(recs) == 4 * 30 and len({(r[1], r[2]) for r in recs}) == 30
+    _compare(g, o, ids, cg, co)
+    assert np.array_equal(g.get_result_global_T_cloud(0), scans[0]["T_init"].astype(np.float32))

@@ -75,6 +75,10 @@ SIGNATURES = {
     "e3d_reg_set_image": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "e3d_reg_set_image_pose": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "e3d_reg_set_splat_points": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "e3d_reg_add_occlusion_mesh": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int]),
+    "e3d_reg_clear_occlusion_meshes": (C.c_int, [C.c_void_p]),
+    "e3d_reg_set_occlusion_options": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_int]),
+    "e3d_reg_occlusion_edge_count": (C.c_int64, [C.c_void_p, C.c_int]),
     "e3d_reg_render_depth": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "e3d_reg_observe": (C.c_int64, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t]),
     "e3d_reg_get_observations": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -506,6 +510,20 @@ class RegProblem:
                                                          iterations_without_new_optimum_threshold, int(print_progress),
                                                          C.byref(c), C.byref(it)), "e3d_reg_run_on_current_scale")
         return bool(r), c.value, it.value
+
+    def add_occlusion_mesh(self, vertices, triangles, compute_edges=True):
+        v = np.ascontiguousarray(vertices, np.float32); t = np.ascontiguousarray(triangles, np.uint32)
+        return self._chk(lib().e3d_reg_add_occlusion_mesh(self._h, C.c_void_p(v.ctypes.data), v.shape[0], C.c_void_p(t.ctypes.data), t.shape[0],
+                                                           1 if compute_edges else 0), "e3d_reg_add_occlusion_mesh")
+
+    def clear_occlusion_meshes(self):
+        self._chk(lib().e3d_reg_clear_occlusion_meshes(self._h), "e3d_reg_clear_occlusion_meshes")
+
+    def set_occlusion_options(self, min_depth=0.05, max_depth=100.0, mask_occlusion_boundaries=True):
+        self._chk(lib().e3d_reg_set_occlusion_options(self._h, min_depth, max_depth, 1 if mask_occlusion_boundaries else 0), "e3d_reg_set_occlusion_options")
+
+    def occlusion_edge_count(self, mesh_index):
+        return self._chk(lib().e3d_reg_occlusion_edge_count(self._h, mesh_index), "e3d_reg_occlusion_edge_count")
 
     def set_splat_points(self, xyz):
         xyz = np.ascontiguousarray(xyz, np.float32)

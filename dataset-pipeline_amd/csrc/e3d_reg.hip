@@ -265,6 +265,294 @@ __global__ __launch_bounds__(kBlock) void k_min_filter_v(const unsigned* __restr
   depth_bits[(size_t)y * width + x] = m;
 }
 
+// ==== f2: occlusion meshes (OcclusionGeometry::RenderDepthMap mesh branch, occlusion_geometry.cc:211-271; the reference
+// renders with OpenGL, src/opengl/renderer.cc) ================================================================================
+// Software rasteriser with the renderer's conventions: the vertex shader's distortion code per camera model
+// (renderer.cc:226-262,470-495,630-653: no cut-off branch for PINHOLE, `* 99` outside the cut-off), projection
+// p = f * x'/z + c (SetupProjection :919-974 maps pixel centres to integer coordinates of this code base), depth =
+// perspective-correct interpolation of the camera-space z (the fragment shader writes var_depth), nearest fragment wins,
+// pixels without geometry are 0 (glClearColor).  Triangles with a vertex in front of the near plane are dropped instead of
+// clipped.  OpenGL's own rasterisation is implementation-defined at pixel-boundary ties; here: samples at integer pixel
+// coordinates, edge functions in f64 (exact for f32 inputs), top-left rule.
+template <int M>
+__global__ __launch_bounds__(kBlock) void k_mesh_vertices(const float4* __restrict__ v, size_t n, Pose P, CamLevel cam,
+                                                          float4* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float4 p = v[i];
+  float X, Y, Z;
+  rt(P, p.x, p.y, p.z, X, Y, Z);
+  float lx = X, ly = Y;
+  if constexpr (M != kPinhole) {
+    float nx = X / Z, ny = Y / Z;
+    float r2 = nx * nx + ny * ny;
+    if (r2 <= cam.cutoff2) {
+      if constexpr (M == kThinPrismFisheye) {
+        const float r = sqrtf(r2);
+        if (r > 1e-6f) { const float theta_by_r = atan2f(r, 1.0f) / r; nx = theta_by_r * nx; ny = theta_by_r * ny; }
+      }
+      const float x2 = nx * nx, xy = nx * ny, y2 = ny * ny;
+      r2 = x2 + y2;
+      const float k1 = cam.q[0], k2 = cam.q[1], p1 = cam.q[2], p2 = cam.q[3];
+      if constexpr (M == kOpenCV) {
+        const float radial = 1.0f + r2 * (k1 + r2 * k2);
+        lx = Z * (radial * nx + 2.0f * p1 * xy + p2 * (r2 + 2.0f * x2));
+        ly = Z * (radial * ny + 2.0f * p2 * xy + p1 * (r2 + 2.0f * y2));
+      } else {
+        const float k3 = cam.q[4], k4 = cam.q[5], sx1 = cam.q[6], sy1 = cam.q[7];
+        const float radial = 1.0f + r2 * (k1 + r2 * (k2 + r2 * (k3 + r2 * k4)));
+        lx = Z * (radial * nx + 2.0f * p1 * xy + p2 * (r2 + 2.0f * x2) + sx1 * r2);
+        ly = Z * (radial * ny + 2.0f * p2 * xy + p1 * (r2 + 2.0f * y2) + sy1 * r2);
+      }
+    } else {
+      lx = X * 99.0f; ly = Y * 99.0f;
+    }
+  }
+  out[i] = make_float4(cam.fx * (lx / Z) + cam.cx, cam.fy * (ly / Z) + cam.cy, Z, 0.f);
+}
+
+struct TriSetup { double ax, ay, bx, by, cx, cy; float za, zb, zc; int x0, y0, x1, y1; bool ok; };
+
+// bounding box (inclusive pixel range) and validity of one projected triangle
+__device__ __forceinline__ TriSetup tri_setup(const float4 a, const float4 b, const float4 c, int width, int height, float min_depth,
+                                              float max_depth) {
+  TriSetup t{};
+  t.ok = false;
+  if (!(a.z > min_depth && b.z > min_depth && c.z > min_depth)) return t;      // near plane: dropped, not clipped
+  if (a.z > max_depth && b.z > max_depth && c.z > max_depth) return t;
+  if (!(isfinite(a.x) && isfinite(a.y) && isfinite(b.x) && isfinite(b.y) && isfinite(c.x) && isfinite(c.y))) return t;
+  const float fx0 = fminf(a.x, fminf(b.x, c.x)), fx1 = fmaxf(a.x, fmaxf(b.x, c.x));
+  const float fy0 = fminf(a.y, fminf(b.y, c.y)), fy1 = fmaxf(a.y, fmaxf(b.y, c.y));
+  if (fx1 < 0.f || fy1 < 0.f || fx0 > (float)(width - 1) || fy0 > (float)(height - 1)) return t;
+  t.x0 = max(0, (int)ceilf(fx0)); t.y0 = max(0, (int)ceilf(fy0));
+  t.x1 = min(width - 1, (int)floorf(fx1)); t.y1 = min(height - 1, (int)floorf(fy1));
+  if (t.x0 > t.x1 || t.y0 > t.y1) return t;
+  t.ax = a.x; t.ay = a.y; t.bx = b.x; t.by = b.y; t.cx = c.x; t.cy = c.y;
+  t.za = a.z; t.zb = b.z; t.zc = c.z;
+  const double area = (t.bx - t.ax) * (t.cy - t.ay) - (t.by - t.ay) * (t.cx - t.ax);
+  if (area == 0.0) return t;
+  if (area < 0.0) {     // orient so that interior points have positive edge functions (culling is disabled)
+    double d; float f;
+    d = t.bx; t.bx = t.cx; t.cx = d; d = t.by; t.by = t.cy; t.cy = d; f = t.zb; t.zb = t.zc; t.zc = f;
+  }
+  t.ok = true;
+  return t;
+}
+__device__ __forceinline__ bool edge_inside(double ax, double ay, double bx, double by, double px, double py, double& e) {
+  const double dx = bx - ax, dy = by - ay;
+  e = dx * (py - ay) - dy * (px - ax);
+  if (e > 0.0) return true;
+  if (e < 0.0) return false;
+  return dy < 0.0 || (dy == 0.0 && dx > 0.0);        // top-left rule for samples exactly on an edge
+}
+// depth of the triangle at an integer pixel, or 0 if the pixel is outside / beyond the depth range
+__device__ __forceinline__ float tri_depth(const TriSetup& t, int x, int y, float min_depth, float max_depth) {
+  double e0, e1, e2;
+  const bool in0 = edge_inside(t.bx, t.by, t.cx, t.cy, x, y, e0);
+  const bool in1 = edge_inside(t.cx, t.cy, t.ax, t.ay, x, y, e1);
+  const bool in2 = edge_inside(t.ax, t.ay, t.bx, t.by, x, y, e2);
+  if (!(in0 && in1 && in2)) return 0.f;
+  const double area = e0 + e1 + e2;
+  if (!(area > 0.0)) return 0.f;
+  const double inv = (e0 / (double)t.za + e1 / (double)t.zb + e2 / (double)t.zc) / area;      // interpolated 1/z
+  const float z = (float)(1.0 / inv);
+  if (!(z >= min_depth && z <= max_depth)) return 0.f;
+  return z;
+}
+
+__global__ __launch_bounds__(kBlock) void k_mesh_bin(const float4* __restrict__ pv, const unsigned* __restrict__ tris, size_t n_tris,
+                                                     int width, int height, float min_depth, float max_depth, int tiles_x,
+                                                     unsigned tri_offset, unsigned* __restrict__ keys, unsigned* __restrict__ vals,
+                                                     unsigned* __restrict__ counter, unsigned capacity) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  TriSetup t{};
+  if (i < n_tris) t = tri_setup(pv[tris[3 * i]], pv[tris[3 * i + 1]], pv[tris[3 * i + 2]], width, height, min_depth, max_depth);
+  int tx0 = 0, tx1 = -1, ty0 = 0, ty1 = -1;
+  if (t.ok) { tx0 = t.x0 / kTile; tx1 = t.x1 / kTile; ty0 = t.y0 / kTile; ty1 = t.y1 / kTile; }
+  const unsigned count = t.ok ? (unsigned)((tx1 - tx0 + 1) * (ty1 - ty0 + 1)) : 0u;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  unsigned incl = count;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const unsigned v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+  __shared__ unsigned wave_total[kBlock / kWave];
+  __shared__ unsigned block_base;
+  if (lane == 63) wave_total[wv] = incl;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned tot = 0;
+#pragma unroll
+    for (int k = 0; k < kBlock / kWave; ++k) tot += wave_total[k];
+    block_base = tot ? atomicAdd(counter, tot) : 0u;
+  }
+  __syncthreads();
+  unsigned o = block_base + incl - count;
+  for (int k = 0; k < wv; ++k) o += wave_total[k];
+  for (int ty = ty0; ty <= ty1; ++ty)
+    for (int tx = tx0; tx <= tx1; ++tx) {
+      if (o < capacity) { keys[o] = (unsigned)(ty * tiles_x + tx); vals[o] = tri_offset + (unsigned)i; }
+      ++o;
+    }
+}
+
+// one workgroup per tile, one LANE per triangle (occlusion meshes are fine: a triangle covers a few pixels)
+__global__ __launch_bounds__(kBlock) void k_mesh_tiles(const float4* __restrict__ pv, const unsigned* __restrict__ tris,
+                                                       const unsigned* __restrict__ vals, const unsigned* __restrict__ start,
+                                                       const unsigned* __restrict__ end, int tiles_x, int width, int height,
+                                                       float min_depth, float max_depth, unsigned* __restrict__ depth_bits) {
+  __shared__ unsigned tile[kTile * kTile];
+  const int t = blockIdx.x;
+  const int x0 = (t % tiles_x) * kTile, y0 = (t / tiles_x) * kTile;
+  for (int i = threadIdx.x; i < kTile * kTile; i += kBlock) tile[i] = 0x7f800000u;
+  __syncthreads();
+  const unsigned s = start[t], e = end[t];
+  for (unsigned j = s + threadIdx.x; j < e; j += kBlock) {
+    const unsigned f = vals[j];
+    const TriSetup ts = tri_setup(pv[tris[3 * (size_t)f]], pv[tris[3 * (size_t)f + 1]], pv[tris[3 * (size_t)f + 2]], width, height,
+                                  min_depth, max_depth);
+    if (!ts.ok) continue;
+    const int bx0 = max(ts.x0, x0), by0 = max(ts.y0, y0), bx1 = min(ts.x1, x0 + kTile - 1), by1 = min(ts.y1, y0 + kTile - 1);
+    for (int y = by0; y <= by1; ++y)
+      for (int x = bx0; x <= bx1; ++x) {
+        const float z = tri_depth(ts, x, y, min_depth, max_depth);
+        if (z > 0.f) atomicMin(&tile[(y - y0) * kTile + (x - x0)], __float_as_uint(z));
+      }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < kTile * kTile; i += kBlock) {
+    const int x = x0 + (i & (kTile - 1)), y = y0 + (i / kTile);
+    if (x < width && y < height) depth_bits[(size_t)y * width + x] = (tile[i] == 0x7f800000u) ? 0u : tile[i];     // no geometry: 0
+  }
+}
+
+// ---- occlusion boundaries (ComputeEdgeNormalsList / FilterEdgeList :488-645, MaskOutOcclusionBoundaries :284-402) -------------
+struct MeshEdge { unsigned v1, v2, f1, f2; int opposite; };       // f2 == 0xFFFFFFFF: boundary edge (one face)
+
+__global__ __launch_bounds__(kBlock) void k_face_normals(const float4* __restrict__ v, const unsigned* __restrict__ tris, size_t n_tris,
+                                                         float4* __restrict__ normals, unsigned long long* __restrict__ keys,
+                                                         unsigned* __restrict__ vals) {
+  const size_t f = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= n_tris) return;
+  const unsigned i0 = tris[3 * f], i1 = tris[3 * f + 1], i2 = tris[3 * f + 2];
+  const float4 p0 = v[i0], p1 = v[i1], p2 = v[i2];
+  const float ax = p1.x - p0.x, ay = p1.y - p0.y, az = p1.z - p0.z, bx = p2.x - p0.x, by = p2.y - p0.y, bz = p2.z - p0.z;
+  const float nx = ay * bz - az * by, ny = az * bx - ax * bz, nz = ax * by - ay * bx;
+  const float len = sqrtf(nx * nx + (ny * ny + nz * nz));
+  normals[f] = (len > 0.f) ? make_float4(nx / len, ny / len, nz / len, 0.f) : make_float4(nx, ny, nz, 0.f);     // Eigen normalized()
+  const unsigned e[3][2] = {{i0, i1}, {i1, i2}, {i2, i0}};
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {       // AddHalfEdge :466-487: key (smaller, larger) vertex, value (face, swapped)
+    const bool swap = e[k][0] > e[k][1];
+    const unsigned lo = swap ? e[k][1] : e[k][0], hi = swap ? e[k][0] : e[k][1];
+    keys[3 * f + k] = ((unsigned long long)lo << 32) | hi;
+    vals[3 * f + k] = ((unsigned)f << 1) | (swap ? 1u : 0u);
+  }
+}
+
+// one thread per group of equal keys (sorted; stable: faces in increasing index like the reference's insertion order)
+__global__ __launch_bounds__(kBlock) void k_filter_edges(const unsigned long long* __restrict__ keys, const unsigned* __restrict__ vals,
+                                                         size_t n, const float4* __restrict__ v, const float4* __restrict__ normals,
+                                                         MeshEdge* __restrict__ edges, unsigned* __restrict__ n_edges) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const unsigned long long key = keys[i];
+  if (i > 0 && keys[i - 1] == key) return;                       // not the head of its group
+  size_t j = i + 1;
+  while (j < n && keys[j] == key) ++j;
+  const size_t cnt = j - i;
+  MeshEdge E;
+  E.v1 = (unsigned)(key >> 32); E.v2 = (unsigned)key;
+  E.f1 = vals[i] >> 1; E.f2 = 0xFFFFFFFFu; E.opposite = 0;
+  bool keep = true;
+  if (cnt >= 2) {
+    const float kEpsilon = 1e-4f;
+    float factor1 = (vals[i] & 1u) ? -1.f : 1.f, factor2 = (vals[i + 1] & 1u) ? -1.f : 1.f;
+    const float4 s0 = v[E.v1], s1 = v[E.v2];
+    const float ex = s1.x - s0.x, ey = s1.y - s0.y, ez = s1.z - s0.z;
+    const float4 nA = normals[E.f1];
+    const float n1x = nA.x * factor1, n1y = nA.y * factor1, n1z = nA.z * factor1;
+    E.f2 = vals[i + 1] >> 1;
+    const float4 nB = normals[E.f2];
+    const float n2x = nB.x * factor2, n2y = nB.y * factor2, n2z = nB.z * factor2;
+    E.opposite = (factor1 * factor2 > 0) ? 1 : 0;
+    const float l1 = sqrtf(n1x * n1x + (n1y * n1y + n1z * n1z));
+    const float bxx = n1x / l1, bxy = n1y / l1, bxz = n1z / l1;                                   // base_x = first_normal.normalized()
+    float cyx = bxy * ez - bxz * ey, cyy = bxz * ex - bxx * ez, cyz = bxx * ey - bxy * ex;        // base_x x edge
+    const float l2 = sqrtf(cyx * cyx + (cyy * cyy + cyz * cyz));
+    cyx /= l2; cyy /= l2; cyz /= l2;
+    float n1_2x = 1.f, n1_2y = 0.f;
+    float n2_2x = bxx * n2x + (bxy * n2y + bxz * n2z), n2_2y = cyx * n2x + (cyy * n2y + cyz * n2z);
+    if (n2_2x < 0 && fabsf(n2_2y) < kEpsilon) keep = false;                                        // coplanar faces: no edge
+    else if (cnt > 2) {
+      const float cross_n1n2 = n2_2y;
+      for (size_t k = i + 2; k < j && keep; ++k) {
+        const unsigned f3 = vals[k] >> 1;
+        const float factor3 = (vals[k] & 1u) ? -1.f : 1.f;
+        const float4 nC = normals[f3];
+        const float cx = nC.x * factor3, cy = nC.y * factor3, cz = nC.z * factor3;
+        const float n3x = bxx * cx + (bxy * cy + bxz * cz), n3y = cyx * cx + (cyy * cy + cyz * cz);
+        const float cross_n1n3 = n1_2x * n3y - n1_2y * n3x;
+        const float cross_n2n3 = n2_2x * n3y - n2_2y * n3x;
+        const bool sign1 = cross_n1n3 * cross_n1n2 > 0;
+        const bool sign2 = cross_n2n3 * cross_n1n2 < 0;
+        if (sign1 && !sign2) { n2_2x = n3x; n2_2y = n3y; E.f2 = f3; factor2 = factor3; E.opposite = (factor1 * factor3 != 1) ? 1 : 0; }
+        else if (sign2 && !sign1) { n1_2x = n3x; n1_2y = n3y; E.f1 = f3; factor1 = factor3; E.opposite = (factor3 * factor2 != 1) ? 1 : 0; }
+        else if (!sign2 && !sign2) keep = false;              // [sic] the reference tests !sign2 twice (:631)
+      }
+    }
+  }
+  if (keep) edges[atomicAdd(n_edges, 1u)] = E;
+}
+
+// MaskOutOcclusionBoundaries: every silhouette (or boundary) edge that is visible splats -1 over the pixels it is not clearly
+// behind.  The reference runs its edge loop under `omp parallel for` while reading the map it writes (:305-334), so its result
+// depends on thread timing; here visibility and the per-pixel test read the UNMASKED depth map, which makes the result
+// deterministic (a superset of any reference run's mask).
+template <int M>
+__global__ __launch_bounds__(kBlock) void k_mask_boundaries(const MeshEdge* __restrict__ edges, size_t n_edges, const float4* __restrict__ v,
+                                                            const float4* __restrict__ normals, Pose P, float3 image_position,
+                                                            CamLevel cam, float splat_radius, const float* __restrict__ depth_in,
+                                                            float* __restrict__ depth_out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_edges) return;
+  const MeshEdge E = edges[i];
+  const float4 p1 = v[E.v1], p2 = v[E.v2];
+  if (E.f2 != 0xFFFFFFFFu) {
+    const float tx = image_position.x - p1.x, ty = image_position.y - p1.y, tz = image_position.z - p1.z;
+    const float4 na = normals[E.f1], nb = normals[E.f2];
+    const bool face1 = (na.x * tx + (na.y * ty + na.z * tz)) > 0, face2 = (nb.x * tx + (nb.y * ty + nb.z * tz)) > 0;
+    if (!((E.opposite && (face1 == face2)) || (face1 != face2 && !E.opposite))) return;
+  }
+  float a0, a1, a2, b0, b1, b2;
+  rt(P, p1.x, p1.y, p1.z, a0, a1, a2);
+  if (a2 <= 0) return;
+  rt(P, p2.x, p2.y, p2.z, b0, b1, b2);
+  if (b2 <= 0) return;
+  const float d0 = b0 - a0, d1 = b1 - a1, d2 = b2 - a2;
+  const int splat_point_count = 1 + min((int)(sqrtf(d0 * d0 + (d1 * d1 + d2 * d2)) / splat_radius + 0.5f), 150);
+  const float kOcclusionDepthThreshold = 0.05f;
+  for (int k = 0; k < splat_point_count; ++k) {
+    const float factor = k / (splat_point_count - 1.0f);        // 0/0 = NaN for a single point, like the reference
+    const float X = a0 + factor * d0, Y = a1 + factor * d1, Z = a2 + factor * d2;
+    if (!(Z > 0)) continue;
+    float px, py;
+    cam_normalized_to_image<M>(cam, X / Z, Y / Z, px, py);
+    const int ix = f2i(px + 0.5f), iy = f2i(py + 0.5f);
+    if (!(px + 0.5f >= 0 && py + 0.5f >= 0 && ix >= 0 && iy >= 0 && ix < cam.width && iy < cam.height)) continue;
+    if (!(depth_in[(size_t)iy * cam.width + ix] + kOcclusionDepthThreshold >= Z)) continue;
+    float d[6];
+    cam_image_deriv_by_world<M>(cam, X, Y, Z, d);
+    const float rx = sqrtf(d[0] * d[0] + (d[1] * d[1] + d[2] * d[2])) * splat_radius;
+    const float ry = sqrtf(d[3] * d[3] + (d[4] * d[4] + d[5] * d[5])) * splat_radius;
+    const int min_x = max(0, d2i((double)((float)ix - rx) + 0.5)), min_y = max(0, d2i((double)((float)iy - ry) + 0.5));
+    const int end_x = min(cam.width, d2i((double)((float)ix + rx) + 1.5)), end_y = min(cam.height, d2i((double)((float)iy + ry) + 1.5));
+    for (int y = min_y; y < end_y; ++y)
+      for (int x = min_x; x < end_x; ++x) {
+        const float old_depth = depth_in[(size_t)y * cam.width + x];
+        if (old_depth == 0 || old_depth + kOcclusionDepthThreshold > Z) depth_out[(size_t)y * cam.width + x] = -1.f;
+      }
+  }
+}
+
 // ==== f1: per-point radius range (ComputeMinMaxPointRadius, multi_scale_point_cloud.cc:126-180) ==================================
 // CameraBaseImpl::InitializeUndistortionLookup (camera_base_impl.h:252-268): one Undistort per pixel
 template <int M>
@@ -783,6 +1071,13 @@ __global__ __launch_bounds__(kBlock) void k_fill_f32(float* p, size_t n, float v
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = v;
 }
+// nearest of two mesh depth maps; 0 = no geometry
+__global__ __launch_bounds__(kBlock) void k_depth_merge(float* __restrict__ a, const float* __restrict__ b, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float x = a[i], y = b[i];
+  a[i] = (x == 0.f) ? y : ((y == 0.f) ? x : fminf(x, y));
+}
 __global__ __launch_bounds__(kBlock) void k_fill_i32(int* p, size_t n, int v) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = v;
@@ -833,6 +1128,14 @@ struct ImageDev {
   int rig_id = -1, camera_index = 0, ref_image_id = -1;
   bool dependent() const { return rig_id >= 0 && camera_index > 0; }
 };
+// one occlusion mesh (OcclusionGeometry::AddMesh): vertices in the global frame, triangles, and -- if requested -- the
+// silhouette-candidate edges with the normals of their two outermost faces
+struct MeshDev {
+  size_t n_vertices = 0, n_triangles = 0, n_edges = 0;
+  DevBuf<float4> vertices, normals;
+  DevBuf<unsigned> triangles;
+  DevBuf<MeshEdge> edges;
+};
 struct RigState { std::vector<SE3f> image_T_rig; };                 // opt::Rig (rig.h:41-76)
 struct RigFrame { int rig_id; std::vector<int> image_ids; };        // opt::RigImages
 
@@ -857,6 +1160,11 @@ struct e3d_reg {
   std::vector<RigFrame> frames;
   DevBuf<float4> splat;
   size_t n_splat = 0;
+  std::vector<std::unique_ptr<MeshDev>> meshes;
+  DevBuf<float4> mesh_projected;
+  DevBuf<float> depth_unmasked, ztmp_f;
+  float min_occlusion_depth = 0.05f, max_occlusion_depth = 100.f;     // opt::Parameters defaults (parameters.h:60-61)
+  bool mask_occlusion_boundaries = true;
   // scratch
   DevBuf<int> valid;
   DevBuf<float> tx, ty, ts;
@@ -1282,6 +1590,138 @@ int e3d_reg_get_image_pose(e3d_reg_t* h, int image_id, float q[4], float t[3]) {
   R_CATCH()
 }
 
+}  // extern "C"
+
+namespace e3d {
+// OcclusionGeometry::RenderDepthMap, mesh branch (:211-271): rasterise all meshes, then mask the occlusion boundaries
+static void render_depth_meshes(e3d_reg* h, ImageDev& im, const Intrin& in, const CamLevel& cam) {
+  hipStream_t s = h->stream;
+  const size_t px = (size_t)cam.width * cam.height;
+  const int tiles_x = (int)div_up(cam.width, kTile), tiles_y = (int)div_up(cam.height, kTile);
+  const size_t n_tiles = (size_t)tiles_x * tiles_y;
+  size_t total_tris = 0, max_vertices = 0;
+  for (auto& m : h->meshes) { total_tris += m->n_triangles; max_vertices = std::max(max_vertices, m->n_vertices); }
+  if (total_tris >= ((size_t)1 << 31)) throw Error(E3D_ERR_INVALID, "more than 2^31 occlusion triangles");
+  h->sp_counter.reserve(1); h->tile_start.reserve(n_tiles); h->tile_end.reserve(n_tiles);
+  // depth of all meshes = min over meshes; each mesh is binned, sorted and reduced on its own into im.depth
+  DevBuf<float>& D = (h->mask_occlusion_boundaries ? h->depth_unmasked : im.depth);
+  D.reserve(px);
+  bool first = true;
+  for (auto& m : h->meshes) {
+    h->mesh_projected.reserve(m->n_vertices);
+    E3D_CAM_SWITCH(in.type, hipLaunchKernelGGL(k_mesh_vertices<M>, dim3(nblk(m->n_vertices)), dim3(kBlock), 0, s, m->vertices.p,
+                                               m->n_vertices, im.pose, cam, h->mesh_projected.p));
+    // capacity: most triangles touch one tile; retried with the exact count if the first guess was too small
+    size_t capacity = m->n_triangles + m->n_triangles / 2 + 1024;
+    unsigned n_pairs = 0;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+      for (int k = 0; k < 2; ++k) { h->sp_keys[k].reserve(capacity); h->sp_vals[k].reserve(capacity); }
+      E3D_HIP(hipMemsetAsync(h->sp_counter.p, 0, sizeof(unsigned), s));
+      hipLaunchKernelGGL(k_mesh_bin, dim3(nblk(m->n_triangles)), dim3(kBlock), 0, s, h->mesh_projected.p, m->triangles.p, m->n_triangles,
+                         cam.width, cam.height, h->min_occlusion_depth, h->max_occlusion_depth, tiles_x, 0u, h->sp_keys[0].p,
+                         h->sp_vals[0].p, h->sp_counter.p, (unsigned)std::min<size_t>(capacity, 0xFFFFFFFFu));
+      copy_out(&n_pairs, h->sp_counter.p, sizeof n_pairs, s);
+      rsync(h);
+      if ((size_t)n_pairs <= capacity) break;
+      capacity = n_pairs;
+    }
+    E3D_HIP(hipMemsetAsync(h->tile_start.p, 0, sizeof(unsigned) * n_tiles, s));
+    E3D_HIP(hipMemsetAsync(h->tile_end.p, 0, sizeof(unsigned) * n_tiles, s));
+    if (n_pairs) {
+      int bits = 1;
+      while (((size_t)1 << bits) < n_tiles) ++bits;
+      sort_pairs_u32_u32(h->sp_keys[0].p, h->sp_keys[1].p, h->sp_vals[0].p, h->sp_vals[1].p, n_pairs, bits, h->sort_temp, s);
+      hipLaunchKernelGGL(k_tile_ranges, dim3(nblk(n_pairs)), dim3(kBlock), 0, s, h->sp_keys[1].p, (size_t)n_pairs, h->tile_start.p, h->tile_end.p);
+    }
+    DevBuf<float>& target = first ? D : h->ztmp_f;
+    target.reserve(px);
+    hipLaunchKernelGGL(k_mesh_tiles, dim3((unsigned)n_tiles), dim3(kBlock), 0, s, h->mesh_projected.p, m->triangles.p, h->sp_vals[1].p,
+                       h->tile_start.p, h->tile_end.p, tiles_x, cam.width, cam.height, h->min_occlusion_depth, h->max_occlusion_depth,
+                       reinterpret_cast<unsigned*>(target.p));
+    if (!first) hipLaunchKernelGGL(k_depth_merge, dim3(nblk(px)), dim3(kBlock), 0, s, D.p, h->ztmp_f.p, px);
+    first = false;
+  }
+  if (h->mask_occlusion_boundaries) {
+    E3D_HIP(hipMemcpyAsync(im.depth.p, D.p, sizeof(float) * px, hipMemcpyDeviceToDevice, s));
+    // image position = global_T_image.translation() = -R^T t
+    const float* R = im.pose.R; const float* t = im.pose.t;
+    float3 pos;
+    pos.x = -(R[0] * t[0] + R[3] * t[1] + R[6] * t[2]); pos.y = -(R[1] * t[0] + R[4] * t[1] + R[7] * t[2]); pos.z = -(R[2] * t[0] + R[5] * t[1] + R[8] * t[2]);
+    for (auto& m : h->meshes)
+      if (m->n_edges)
+        E3D_CAM_SWITCH(in.type, hipLaunchKernelGGL(k_mask_boundaries<M>, dim3(nblk(m->n_edges)), dim3(kBlock), 0, s, m->edges.p, m->n_edges,
+                                                   m->vertices.p, m->normals.p, im.pose, pos, cam, h->prm.splat_radius, D.p, im.depth.p));
+  }
+}
+}  // namespace e3d
+
+extern "C" {
+
+/* OcclusionGeometry::AddMesh / AddSplats (occlusion_geometry.cc:64-182): one more triangle mesh (vertices already in the
+ * global frame).  compute_edges != 0 also extracts the edges used for masking occlusion boundaries (meshes: yes, splat
+ * geometry: no). */
+int e3d_reg_add_occlusion_mesh(e3d_reg_t* h, const float* vertices, size_t n_vertices, const uint32_t* triangles, size_t n_triangles,
+                               int compute_edges) {
+  R_TRY
+  if (!h || !vertices || !triangles || !n_vertices || !n_triangles) throw Error(E3D_ERR_INVALID, "empty mesh");
+  if (n_triangles >= ((size_t)1 << 31) || n_vertices >= ((size_t)1 << 32)) throw Error(E3D_ERR_INVALID, "mesh too large");
+  hipStream_t s = h->stream;
+  std::unique_ptr<MeshDev> m(new MeshDev());
+  m->n_vertices = n_vertices; m->n_triangles = n_triangles;
+  DevBuf<float> tmp; tmp.reserve(3 * n_vertices);
+  copy_in(tmp.p, vertices, sizeof(float) * 3 * n_vertices, s);
+  m->vertices.reserve(n_vertices);
+  hipLaunchKernelGGL(k_xyz_to_float4, dim3(nblk(n_vertices)), dim3(kBlock), 0, s, tmp.p, n_vertices, m->vertices.p);
+  m->triangles.reserve(3 * n_triangles);
+  copy_in(m->triangles.p, triangles, sizeof(unsigned) * 3 * n_triangles, s);
+  rsync(h);
+  for (size_t i = 0; i < 3 * n_triangles; ++i) if (triangles[i] >= n_vertices) throw Error(E3D_ERR_INDEX, "triangle refers to a missing vertex");
+  if (compute_edges) {
+    const size_t ne = 3 * n_triangles;
+    DevBuf<unsigned long long> ka, kb;
+    DevBuf<unsigned> va, vb, cnt;
+    ka.reserve(ne); kb.reserve(ne); va.reserve(ne); vb.reserve(ne); cnt.reserve(1);
+    m->normals.reserve(n_triangles);
+    hipLaunchKernelGGL(k_face_normals, dim3(nblk(n_triangles)), dim3(kBlock), 0, s, m->vertices.p, m->triangles.p, n_triangles, m->normals.p,
+                       ka.p, va.p);
+    sort_pairs_u64_u32(ka.p, kb.p, va.p, vb.p, ne, 64, h->sort_temp, s);
+    m->edges.reserve(ne);
+    E3D_HIP(hipMemsetAsync(cnt.p, 0, sizeof(unsigned), s));
+    hipLaunchKernelGGL(k_filter_edges, dim3(nblk(ne)), dim3(kBlock), 0, s, kb.p, vb.p, ne, m->vertices.p, m->normals.p, m->edges.p, cnt.p);
+    unsigned n_edges = 0;
+    copy_out(&n_edges, cnt.p, sizeof n_edges, s);
+    rsync(h);
+    m->n_edges = n_edges;
+  }
+  h->meshes.push_back(std::move(m));
+  for (auto& kv : h->images) kv.second.depth_scale = -1;
+  return (int)h->meshes.size();
+  R_CATCH()
+}
+int e3d_reg_clear_occlusion_meshes(e3d_reg_t* h) {
+  R_TRY
+  if (!h) throw Error(E3D_ERR_INVALID, "null handle");
+  h->meshes.clear();
+  for (auto& kv : h->images) kv.second.depth_scale = -1;
+  return 0;
+  R_CATCH()
+}
+/* min_occlusion_depth / max_occlusion_depth (near / far plane of the mesh renderer) and mask_occlusion_boundaries of
+ * OcclusionGeometry::RenderDepthMap (occlusion_geometry.h:80-86); defaults 0.05, 100, true */
+int e3d_reg_set_occlusion_options(e3d_reg_t* h, float min_depth, float max_depth, int mask_occlusion_boundaries) {
+  R_TRY
+  if (!h || !(min_depth > 0) || !(max_depth > min_depth)) throw Error(E3D_ERR_INVALID, "bad occlusion depth range");
+  h->min_occlusion_depth = min_depth; h->max_occlusion_depth = max_depth; h->mask_occlusion_boundaries = mask_occlusion_boundaries != 0;
+  return 0;
+  R_CATCH()
+}
+int64_t e3d_reg_occlusion_edge_count(e3d_reg_t* h, int mesh_index) {
+  R_TRY
+  if (!h || mesh_index < 0 || mesh_index >= (int)h->meshes.size()) throw Error(E3D_ERR_INDEX, "no such mesh");
+  return (int64_t)h->meshes[mesh_index]->n_edges;
+  R_CATCH()
+}
+
 int e3d_reg_set_splat_points(e3d_reg_t* h, const float* xyz, size_t n) {
   R_TRY
   if (!h || (!xyz && n)) throw Error(E3D_ERR_INVALID, "null argument");
@@ -1306,7 +1746,12 @@ int e3d_reg_render_depth(e3d_reg_t* h, int image_id, int image_scale, float* dep
   const CamLevel& cam = in.levels[lvl];
   const size_t px = (size_t)cam.width * cam.height;
   im.depth.reserve(px);
-  {
+  if (h->n_splat == 0 && !h->meshes.empty()) {
+    render_depth_meshes(h, im, in, cam);
+  } else if (h->n_splat == 0) {
+    // no occlusion geometry: everything is visible (occlusion_geometry.cc:272-281)
+    hipLaunchKernelGGL(k_fill_f32, dim3(nblk(px)), dim3(kBlock), 0, h->stream, im.depth.p, px, INFINITY);
+  } else {
     hipStream_t s = h->stream;
     const size_t n = h->n_splat;
     const int tiles_x = (int)div_up(cam.width, kTile), tiles_y = (int)div_up(cam.height, kTile);

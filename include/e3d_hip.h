@@ -232,6 +232,19 @@ int e3d_reg_add_rig_images(e3d_reg_t* reg, int rig_id, const int* image_ids, int
 /* OcclusionGeometry::SetSplatPoints */
 int e3d_reg_set_splat_points(e3d_reg_t* reg, const float* xyz, size_t n);
 
+/* OcclusionGeometry::AddMesh / AddSplats (src/opt/occlusion_geometry.cc:64-182): occlusion geometry as triangle meshes,
+ * used when no splat points are set (OcclusionGeometry::RenderDepthMap :211-271).  The reference renders them with OpenGL
+ * (src/opengl/renderer.cc); here a software rasteriser with the same conventions (vertex-shader distortion per camera
+ * model, depth = camera-space z, nearest fragment, 0 where there is no geometry, near / far planes min / max occlusion
+ * depth) followed by MaskOutOcclusionBoundaries (:284-402) over the edges extracted when compute_edges != 0
+ * (ComputeEdgeNormalsList / FilterEdgeList :488-645).  Vertices are global-frame xyz, triangles 3 x u32.  Returns the
+ * number of meshes held. */
+int e3d_reg_add_occlusion_mesh(e3d_reg_t* reg, const float* vertices, size_t n_vertices, const uint32_t* triangles,
+                               size_t n_triangles, int compute_edges);
+int e3d_reg_clear_occlusion_meshes(e3d_reg_t* reg);
+int e3d_reg_set_occlusion_options(e3d_reg_t* reg, float min_depth, float max_depth, int mask_occlusion_boundaries);
+int64_t e3d_reg_occlusion_edge_count(e3d_reg_t* reg, int mesh_index);
+
 /* Renders the occlusion depth map of an image at an image scale (kept on the device for e3d_reg_observe);
  * depth_out (optional) receives height x width floats. */
 int e3d_reg_render_depth(e3d_reg_t* reg, int image_id, int image_scale, float* depth_out);

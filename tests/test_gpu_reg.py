@@ -368,3 +368,89 @@ def test_splat_depth_full_size_and_small_splats(e3d, rb, model):
             assert np.array_equal(g.view(np.uint32), o.view(np.uint32)), scale
         else:
             assert (g.view(np.uint32) != o.view(np.uint32)).mean() < 2e-3
+
+
+# ---- occlusion meshes (software rasteriser + boundary masking) ----------------------------------------------------------------
+def _mesh_scene():
+    """A wavy wall (grid mesh) with a box in front of it: occlusion, silhouettes, boundary edges."""
+    gx, gz = np.meshgrid(np.linspace(-1.3, 1.3, 41), np.linspace(-1.0, 1.0, 31), indexing="ij")
+    wall = np.stack([gx.ravel(), 3.0 + 0.08 * np.sin(3 * gx.ravel()) * np.cos(2 * gz.ravel()), gz.ravel()], 1)
+    tris = []
+    for i in range(40):
+        for j in range(30):
+            a, b, c, d = i * 31 + j, (i + 1) * 31 + j, (i + 1) * 31 + j + 1, i * 31 + j + 1
+            tris += [(a, b, c), (a, c, d)]
+    box = np.array([[x, y, z] for x in (-0.3, 0.25) for y in (2.0, 2.4) for z in (-0.2, 0.3)], np.float64)
+    bt = [(0, 1, 3), (0, 3, 2), (4, 6, 7), (4, 7, 5), (0, 4, 5), (0, 5, 1), (2, 3, 7), (2, 7, 6), (0, 2, 6), (0, 6, 4), (1, 5, 7), (1, 7, 3)]
+    verts = np.concatenate([wall, box]).astype(np.float32)
+    tris = np.array(tris + [(a + len(wall), b + len(wall), c + len(wall)) for a, b, c in bt], np.uint32)
+    return verts, tris
+
+
+@pytest.mark.parametrize("model", MODELS)
+def test_mesh_depth_matches_oracle(e3d, rb, model):
+    from oracle import mesh_occlusion as mo
+    from reg_util import DISTORTION, look_at_pose, pyramid_u8, quat_from_R, quat_to_R
+    verts, tris = _mesh_scene()
+    W, H = 320, 240
+    params = np.array([260.0, 255.0, W / 2 - 0.3, H / 2 + 0.2] + DISTORTION[model], np.float32)
+    R0, t = look_at_pose((0.3, -0.3, 0.1), (0, 3, 0))
+    q = quat_from_R(R0); R = quat_to_R(q)
+    P = e3d.RegProblem(e3d.default_reg_params(image_scale_count=3, point_neighbor_count=5))
+    P.set_intrinsics(0, W, H, params, 0, 3, camera_type=model)
+    P.set_image(0, 0, pyramid_u8(np.zeros((H, W), np.uint8), 3)); P.set_image_pose(0, q, t)
+    assert P.add_occlusion_mesh(verts, tris, compute_edges=True) == 1
+    levels = rb.camera_pyramid(rb.make_camera(W, H, params, model), 3)
+    edges, normals = mo.edge_list(verts, tris)
+    assert P.occlusion_edge_count(0) == len(edges)
+    for scale in (0, 1):
+        cam = levels[scale]
+        px, py, z = mo.project_vertices(model, cam, R, t, verts)
+        o_plain = mo.rasterise(px, py, z, tris, cam.width, cam.height)
+        P.set_occlusion_options(0.05, 100.0, False)
+        g_plain = P.render_depth(0, scale, (cam.height, cam.width))
+        diff = g_plain.view(np.uint32) != o_plain.view(np.uint32)
+        assert (o_plain > 0).mean() > 0.3
+        if model in EXACT:
+            assert not diff.any(), (scale, int(diff.sum()))
+        else:
+            cover = (g_plain == 0) ^ (o_plain == 0)                 # atan2f last-ulp differences move a vertex by ~1e-5 px
+            assert cover.mean() < 5e-3 and np.abs(g_plain - o_plain)[~cover].max() < 1e-3
+        # the box occludes the wall: nearest surface wins
+        assert g_plain[cam.height // 2, cam.width // 2] < 2.6
+        P.set_occlusion_options(0.05, 100.0, True)
+        g_mask = P.render_depth(0, scale, (cam.height, cam.width))
+        o_mask = mo.mask_boundaries(g_plain, edges, normals, verts, R, t, cam)
+        assert (g_mask == -1).sum() > 50 and (o_mask == -1).sum() > 50
+        mism = (g_mask == -1) != (o_mask == -1)
+        assert mism.mean() < (1e-4 if model in EXACT else 5e-3), float(mism.mean())
+        same = ~mism
+        assert np.array_equal(g_mask[same].view(np.uint32), o_mask[same].view(np.uint32))
+
+
+def test_mesh_occlusion_drives_visibility(e3d, rb):
+    """With meshes instead of splats, points behind the box are not observed, points with no geometry behind them are not
+    observed either (depth 0 where nothing was drawn), and near silhouettes nothing is observed (-1)."""
+    from reg_util import look_at_pose, pyramid_u8, quat_from_R
+    verts, tris = _mesh_scene()
+    W, H = 320, 240
+    params = np.array([260.0, 255.0, W / 2 - 0.3, H / 2 + 0.2], np.float32)
+    R0, t = look_at_pose((0.0, -0.3, 0.0), (0, 3, 0))
+    q = quat_from_R(R0)
+    rng = np.random.RandomState(2)
+    u, v = rng.uniform(-1.2, 1.2, 4000), rng.uniform(-0.9, 0.9, 4000)
+    pts = np.stack([u, 3.0 + 0.08 * np.sin(3 * u) * np.cos(2 * v), v], 1).astype(np.float32)        # on the wall
+    from scipy.spatial import cKDTree
+    nbr = cKDTree(pts).query(pts, k=6)[1][:, 1:].astype(np.uint32)
+    P = e3d.RegProblem(e3d.default_reg_params(image_scale_count=3, point_neighbor_count=5))
+    P.set_intrinsics(0, W, H, params, 0, 3)
+    yy, xx = np.mgrid[0:H, 0:W]
+    P.set_image(0, 0, pyramid_u8((100 + 50 * np.sin(xx / 7.0)).astype(np.uint8), 3)); P.set_image_pose(0, q, t)
+    P.set_point_scale(0, pts, 0.012, nbr, np.zeros((4000, 5), np.float32))
+    P.add_occlusion_mesh(verts, tris, True)
+    P.render_depth(0, 0)
+    n = P.observe(0, 0, 0, 1)
+    idx = P.get_observations(0, 0, n)[0]
+    seen = np.zeros(4000, bool); seen[idx] = True
+    behind_box = (np.abs(pts[:, 0] + 0.02) < 0.2) & (np.abs(pts[:, 2] - 0.05) < 0.18)
+    assert n > 1500 and not seen[behind_box].any() and seen[~behind_box].mean() > 0.6

@@ -3,8 +3,9 @@
 // fine over the image pyramid.  Same flags, same output layout (scale_<factor>_state/{cameras,images,points3D}.txt,
 // rigs.json, metadata.txt); the optimisation itself runs on the MI355X behind the C-ABI (e3d_reg_*).
 //
-// Not built yet (the tool says so instead of silently doing something else): --occlusion_mesh_path /
-// --occlusion_splats_path (OpenGL mesh renderer), the observations cache, --write_debug_point_clouds, JPEG input.
+// Occlusion meshes (--occlusion_mesh_path / --occlusion_splats_path) are rasterised on the GPU by the library instead of OpenGL.
+// Not built yet (the tool says so instead of silently doing something else): the observations cache,
+// --write_debug_point_clouds, JPEG input.
 #include <cmath>
 #include <cstdlib>
 #include <iostream>
@@ -46,16 +47,13 @@ int main(int argc, char** argv) {
     std::cerr << "Please specify all the required paths." << std::endl;
     return EXIT_FAILURE;
   }
-  if (!occlusion_mesh_path.empty() || !occlusion_splats_path.empty()) {
-    std::cerr << "--occlusion_mesh_path / --occlusion_splats_path need the mesh renderer, which is not part of this build; "
-                 "run without them to use 2D splats of the scan points." << std::endl;
-    return EXIT_FAILURE;
-  }
+  problem.occlusion_mesh_path = occlusion_mesh_path;
+  problem.occlusion_splats_path = occlusion_splats_path;
   if (problem.prm.depth_residuals_weight > 0) {
     std::cerr << "--depth_residuals_weight > 0 (depth-map residuals, not used in the ETH3D pipeline) is not part of this build." << std::endl;
     return EXIT_FAILURE;
   }
-  std::cout << "No occlusion meshes given, using 2D splats." << std::endl;
+  if (occlusion_mesh_path.empty() && occlusion_splats_path.empty()) std::cout << "No occlusion meshes given, using 2D splats." << std::endl;
   create_directories(output_folder_path);
 
   // scans -> global frame (pcl::transformPointCloud on the GPU); their points are the occlusion splats

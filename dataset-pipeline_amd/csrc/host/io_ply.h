@@ -164,6 +164,78 @@ inline int loadPLYFile(const std::string& path, PointCloud& cloud, bool want_rgb
   return -1;
 }
 
+// Triangle mesh: vertices (x y z) + faces (list property, 3 indices each) -- pcl::io::loadPLYFile(path, pcl::PolygonMesh&) as
+// OcclusionGeometry::AddMeshPLY uses it (src/opt/occlusion_geometry.cc:118-139); non-triangular faces are an error like the
+// reference's CHECK_EQ(face_vertices.size(), 3) (:508).
+inline int loadPLYMesh(const std::string& path, std::vector<float>& xyz, std::vector<uint32_t>& triangles) {
+  using namespace ply_detail;
+  std::ifstream f(path, std::ios::binary);
+  if (!f) { std::cerr << "[loadPLYMesh] cannot open " << path << std::endl; return -1; }
+  std::string line;
+  if (!std::getline(f, line) || line.substr(0, 3) != "ply") { std::cerr << "[loadPLYMesh] not a PLY file: " << path << std::endl; return -1; }
+  std::string format;
+  std::vector<Elem> elems;
+  while (std::getline(f, line)) {
+    if (!line.empty() && line.back() == '\r') line.pop_back();
+    std::istringstream ls(line);
+    std::string tok;
+    ls >> tok;
+    if (tok == "format") ls >> format;
+    else if (tok == "element") { Elem e; ls >> e.name >> e.count; elems.push_back(e); }
+    else if (tok == "property" && !elems.empty()) {
+      Prop p; std::string t; ls >> t;
+      if (t == "list") { p.is_list = true; ls >> p.count_type >> p.type >> p.name; }
+      else { p.type = t; ls >> p.name; }
+      elems.back().props.push_back(p);
+    } else if (tok == "end_header") break;
+  }
+  const bool ascii = (format == "ascii"), swap = (format == "binary_big_endian");
+  if (!ascii && format != "binary_little_endian" && !swap) { std::cerr << "[loadPLYMesh] unsupported format '" << format << "'" << std::endl; return -1; }
+  xyz.clear(); triangles.clear();
+  for (const Elem& e : elems) {
+    const bool is_vertex = (e.name == "vertex"), is_face = (e.name == "face");
+    int ix = -1, iy = -1, iz = -1, il = -1;
+    for (size_t i = 0; i < e.props.size(); ++i) {
+      const std::string& nm = e.props[i].name;
+      if (nm == "x") ix = (int)i; else if (nm == "y") iy = (int)i; else if (nm == "z") iz = (int)i;
+      if (e.props[i].is_list && (nm == "vertex_indices" || nm == "vertex_index")) il = (int)i;
+    }
+    if (is_vertex) { if (ix < 0 || iy < 0 || iz < 0) return -1; xyz.resize(3 * e.count); }
+    if (is_face) triangles.reserve(3 * e.count);
+    for (size_t i = 0; i < e.count; ++i) {
+      std::istringstream ls;
+      if (ascii) { if (!std::getline(f, line)) return -1; ls.str(line); }
+      for (size_t p = 0; p < e.props.size(); ++p) {
+        const Prop& pr = e.props[p];
+        if (pr.is_list) {
+          size_t c = 0;
+          std::vector<double> idx;
+          if (ascii) { ls >> c; idx.resize(c); for (size_t k = 0; k < c; ++k) ls >> idx[k]; }
+          else {
+            unsigned char b[8];
+            f.read(reinterpret_cast<char*>(b), type_size(pr.count_type));
+            c = (size_t)read_scalar(b, pr.count_type, swap);
+            idx.resize(c);
+            for (size_t k = 0; k < c; ++k) { f.read(reinterpret_cast<char*>(b), type_size(pr.type)); idx[k] = read_scalar(b, pr.type, swap); }
+          }
+          if (is_face && (int)p == il) {
+            if (c != 3) { std::cerr << "[loadPLYMesh] only triangle meshes are supported: " << path << std::endl; return -1; }
+            for (size_t k = 0; k < 3; ++k) triangles.push_back((uint32_t)idx[k]);
+          }
+        } else {
+          double v = 0;
+          if (ascii) ls >> v;
+          else { unsigned char b[8]; f.read(reinterpret_cast<char*>(b), type_size(pr.type)); v = read_scalar(b, pr.type, swap); }
+          if (is_vertex) { if ((int)p == ix) xyz[3 * i] = (float)v; else if ((int)p == iy) xyz[3 * i + 1] = (float)v; else if ((int)p == iz) xyz[3 * i + 2] = (float)v; }
+        }
+      }
+      if (!f && !ascii) { std::cerr << "[loadPLYMesh] truncated file " << path << std::endl; return -1; }
+    }
+  }
+  if (xyz.empty() || triangles.empty()) { std::cerr << "[loadPLYMesh] no vertices or faces in " << path << std::endl; return -1; }
+  return 0;
+}
+
 // x y z nx ny nz (f32) + red green blue (u8), binary little endian, PCL-style header incl. the camera element.
 inline int savePLYFileBinaryXYZNormalRGB(const std::string& path, const std::vector<unsigned char>& data, size_t n) {
   std::ofstream f(path, std::ios::binary);

@@ -259,6 +259,7 @@ class Problem {
   std::vector<std::vector<float>> colors;       // multi_res_colors
   std::vector<std::vector<uint32_t>> neighbors; // neighbor_point_indices_ (n * K)
   e3d_reg_t* reg = nullptr;
+  std::string occlusion_mesh_path, occlusion_splats_path;       // empty: splats of the scan points
 
   ~Problem() { if (reg) api().e3d_reg_destroy(reg); }
 
@@ -435,6 +436,43 @@ class Problem {
     }
     fclose(nf);
     return true;
+  }
+
+  // OcclusionGeometry::AddMesh / AddSplats (occlusion_geometry.cc:64-139): a .ply mesh (scaled by the global scale_factor) or a
+  // MeshLab project of meshes (each with its own Sim3 pose)
+  bool AddOcclusionMesh(const std::string& path, bool compute_edges) {
+    auto add = [&](const std::string& ply, const float* T) {
+      std::cout << "adding mesh " << ply << std::endl;
+      std::vector<float> xyz, global;
+      std::vector<uint32_t> tris;
+      if (loadPLYMesh(ply, xyz, tris) < 0) { std::cerr << "Cannot read file: " << ply << std::endl; return false; }
+      global.resize(xyz.size());
+      float bmin[3], bmax[3];
+      if (api().e3d_transform_cloud(xyz.data(), nullptr, xyz.size() / 3, T, global.data(), nullptr, bmin, bmax) < 0) return lib_fail("e3d_transform_cloud");
+      if (compute_edges) std::cout << "computing edges" << std::endl;
+      if (api().e3d_reg_add_occlusion_mesh(reg, global.data(), global.size() / 3, tris.data(), tris.size() / 3, compute_edges ? 1 : 0) < 0)
+        return lib_fail("e3d_reg_add_occlusion_mesh");
+      return true;
+    };
+    const std::string ext = path.size() >= 4 ? path.substr(path.size() - 4) : std::string();
+    if (ext == ".mlp") {
+      std::vector<MeshInfo> infos;
+      if (!ReadMeshLabProject(path, &infos)) return fail("Cannot read mesh poses from " + path);
+      for (const MeshInfo& info : infos) {
+        float T[12];
+        info.global_T_mesh.matrix3x4(T);
+        const std::string file = (!info.filename.empty() && info.filename[0] == '/') ? info.filename : join_path(parent_path(path), info.filename);
+        if (!add(file, T)) return false;
+      }
+      std::cout << "Done." << std::endl;
+      return true;
+    }
+    if (ext == ".ply") {
+      const float sc = global_scale_factor();                 // Sim3f(Identity * scale): uniform scaling
+      const float T[12] = {sc, 0, 0, 0, 0, sc, 0, 0, 0, 0, sc, 0};
+      return add(path, T);
+    }
+    return fail("Mesh file format must be either .mlp or .ply, got " + path);
   }
 
   // Problem::SaveMultiResPointCloud (modify_colors_for_display = false)
@@ -675,8 +713,14 @@ class Problem {
     for (const HostRigImages& f : rig_images)
       if (api().e3d_reg_add_rig_images(reg, f.rig_id, f.image_ids.data(), (int)f.image_ids.size()) < 0) return lib_fail("e3d_reg_add_rig_images");
 
-    // the occlusion geometry (splats of all scan points) is needed by the radius-range pass already
-    if (api().e3d_reg_set_splat_points(reg, occlusion_points.data(), occlusion_points.size() / 3) < 0) return lib_fail("e3d_reg_set_splat_points");
+    // the occlusion geometry is needed by the radius-range pass already: meshes if given, else 2D splats of all scan points
+    if (api().e3d_reg_set_occlusion_options(reg, prm.min_occlusion_depth, prm.max_occlusion_depth, 1) < 0) return lib_fail("e3d_reg_set_occlusion_options");
+    if (occlusion_mesh_path.empty() && occlusion_splats_path.empty()) {
+      if (api().e3d_reg_set_splat_points(reg, occlusion_points.data(), occlusion_points.size() / 3) < 0) return lib_fail("e3d_reg_set_splat_points");
+    } else {
+      if (!occlusion_mesh_path.empty() && !AddOcclusionMesh(occlusion_mesh_path, true)) return false;
+      if (!occlusion_splats_path.empty() && !AddOcclusionMesh(occlusion_splats_path, false)) return false;
+    }
     if (multi_res_dir.empty()) return fail("Please specify --multi_res_point_cloud_directory_path.");
     if (LoadMultiResPointCloud(multi_res_dir)) {
       std::cout << "SetScanGeometryAndInitialize(): Loaded existing multi-res point cloud." << std::endl;

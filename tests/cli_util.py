@@ -64,3 +64,20 @@ def read_ply_normals(path):
     rec = np.frombuffer(data, dtype=[("p", "<f4", 3), ("n", "<f4", 3), ("c", "u1", 3)], count=n, offset=end)
     tail = len(data) - end - 27 * n
     return header, rec, tail
+
+
+def write_ply_mesh(path, vertices, triangles, binary=True):
+    vertices = np.asarray(vertices, np.float32); triangles = np.asarray(triangles, np.int32)
+    with open(path, "wb") as f:
+        f.write(("ply\nformat %s 1.0\nelement vertex %d\nproperty float x\nproperty float y\nproperty float z\nelement face %d\n"
+                 "property list uchar int vertex_indices\nend_header\n" % ("binary_little_endian" if binary else "ascii", len(vertices), len(triangles))).encode())
+        if binary:
+            f.write(vertices.tobytes())
+            rec = np.zeros(len(triangles), dtype=[("c", "u1"), ("i", "<i4", 3)])
+            rec["c"] = 3; rec["i"] = triangles
+            f.write(rec.tobytes())
+        else:
+            for v in vertices:
+                f.write(("%.9g %.9g %.9g\n" % tuple(v)).encode())
+            for t in triangles:
+                f.write(("3 %d %d %d\n" % tuple(t)).encode())

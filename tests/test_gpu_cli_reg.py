@@ -209,3 +209,26 @@ def test_image_registrator_computes_multires_cloud(tmp_path, e3d):
     shutil.rmtree(os.path.join(d, "out"))
     out2 = _run_tool(d)
     assert "Loaded existing multi-res point cloud." in out2 and "Creating multi-res point cloud" not in out2
+
+
+@pytest.mark.parametrize("binary", [True, False])
+def test_image_registrator_cli_with_occlusion_mesh(tmp_path, e3d, binary):
+    """--occlusion_mesh_path: the wall as a triangle mesh (PLY, binary or ASCII) replaces the scan-point splats as
+    occlusion geometry; the tool must run through both image scales and lower the photometric cost."""
+    from cli_util import write_ply_mesh
+    M = make_multi_image_scene(n_points=6000, n_images=3, seed=15, perturb=0.005)
+    names = ["dslr/img_%d.png" % i for i in range(3)]
+    d = _write_dataset(tmp_path, M, names)
+    gx, gz = np.meshgrid(np.linspace(-1.6, 1.6, 33), np.linspace(-1.3, 1.3, 27), indexing="ij")
+    verts = np.stack([gx.ravel(), np.full(gx.size, 3.0), gz.ravel()], 1)
+    tris = []
+    for i in range(32):
+        for j in range(26):
+            a, b, c, dd = i * 27 + j, (i + 1) * 27 + j, (i + 1) * 27 + j + 1, i * 27 + j + 1
+            tris += [(a, b, c), (a, c, dd)]
+    write_ply_mesh(os.path.join(d, "occlusion.ply"), verts, tris, binary=binary)
+    out = _run_tool(d, ["--occlusion_mesh_path", os.path.join(d, "occlusion.ply")])
+    assert "adding mesh" in out and "computing edges" in out and "No occlusion meshes given" not in out and "Finished!" in out
+    costs = [float(l.split(":")[-1]) for l in out.splitlines() if "Cost (considering occlusions) is" in l]
+    assert len(costs) >= 4 and np.isfinite(costs).all() and min(costs) < costs[0]
+    assert os.path.exists(os.path.join(d, "out", "scale_1_state", "images.txt"))

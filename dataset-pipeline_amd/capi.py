@@ -91,6 +91,10 @@ SIGNATURES = {
     "e3d_reg_color_finish": (C.c_int, [C.c_void_p, C.c_int]),
     "e3d_reg_get_image_pose": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "e3d_reg_update_observations": (C.c_int, [C.c_void_p, C.c_int]),
+    "e3d_reg_set_cache_observations": (C.c_int, [C.c_void_p, C.c_int]),
+    "e3d_reg_determine_observed_indices": (C.c_int, [C.c_void_p]),
+    "e3d_reg_get_observed_indices": (C.c_int64, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "e3d_reg_set_observed_indices": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t]),
     "e3d_reg_color_update": (C.c_int, [C.c_void_p]),
     "e3d_reg_compute_cost": (C.c_int, [C.c_void_p, C.c_void_p]),
     "e3d_reg_apply": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -458,6 +462,29 @@ class RegProblem:
 
     def update_observations(self, border_size=1):
         self._chk(lib().e3d_reg_update_observations(self._h, border_size), "e3d_reg_update_observations")
+
+    def set_cache_observations(self, enabled):
+        """Optimizer::set_cache_observations: update_observations re-projects the cached point index lists."""
+        self._chk(lib().e3d_reg_set_cache_observations(self._h, int(bool(enabled))), "e3d_reg_set_cache_observations")
+
+    def determine_observed_indices(self):
+        """ObservationsCache::DetermineAndSaveObservedPointIndices without the files (full visibility pass at image scale 0)."""
+        self._chk(lib().e3d_reg_determine_observed_indices(self._h), "e3d_reg_determine_observed_indices")
+
+    def get_observed_indices(self, image_id, point_scale):
+        n = lib().e3d_reg_get_observed_indices(self._h, image_id, point_scale, None)
+        if n < 0:
+            self._chk(-1, "e3d_reg_get_observed_indices")
+        out = np.zeros(n, np.uint64)
+        if n:
+            self._chk(int(min(0, lib().e3d_reg_get_observed_indices(self._h, image_id, point_scale, C.c_void_p(out.ctypes.data)))),
+                      "e3d_reg_get_observed_indices")
+        return out
+
+    def set_observed_indices(self, image_id, point_scale, indices):
+        indices = np.ascontiguousarray(indices, np.uint64)
+        self._chk(lib().e3d_reg_set_observed_indices(self._h, image_id, point_scale, C.c_void_p(indices.ctypes.data), indices.size),
+                  "e3d_reg_set_observed_indices")
 
     def color_update(self):
         self._chk(lib().e3d_reg_color_update(self._h), "e3d_reg_color_update")

@@ -1124,6 +1124,9 @@ struct ImageDev {
   int depth_scale = -1;
   std::map<int, Obs> obs;         // per point scale
   std::map<int, DevBuf<unsigned>> vis;   // per point scale: visibility list of the running Apply (grow-only scratch)
+  // ObservationsCache::image_id_to_visibility_lists_ (observations_cache.h): per point scale, the observed point indices
+  std::map<int, std::pair<DevBuf<unsigned>, size_t>> observed;
+  bool has_observed = false;
   // rig membership (opt::RigImages): camera_index 0 = the frame's reference image, whose pose is the rig pose
   int rig_id = -1, camera_index = 0, ref_image_id = -1;
   bool dependent() const { return rig_id >= 0 && camera_index > 0; }
@@ -1165,6 +1168,7 @@ struct e3d_reg {
   DevBuf<float> depth_unmasked, ztmp_f;
   float min_occlusion_depth = 0.05f, max_occlusion_depth = 100.f;     // opt::Parameters defaults (parameters.h:60-61)
   bool mask_occlusion_boundaries = true;
+  bool cache_observations = false;        // Optimizer::cache_observations_ (optimizer.h)
   // scratch
   DevBuf<int> valid;
   DevBuf<float> tx, ty, ts;
@@ -2046,18 +2050,31 @@ static double compute_cost_value(const e3d_reg* h, const double sums[2], const i
   return r;
 }
 
-// VisibilityEstimator::CreateObservationsForAllImages + DetermineIfAllNeighborsAreObserved
+// VisibilityEstimator::CreateObservationsForAllImages + DetermineIfAllNeighborsAreObserved; with cache_observations the
+// ObservationsCache::GetObservations path (observations_cache.cc:52-68): the cached point indices of each image are
+// re-projected with the current state, without occlusion / mask / saturation tests (visibility_estimator.cc:140-168).
 static void update_observations(e3d_reg* h, int border) {
   constexpr size_t kManyObservationsCount = 100;
   for (auto& kv : h->images) {
     if (!h->owns(kv.first)) continue;
     ImageDev& im = kv.second;
     const int scale = best_available_scale(h, h->intr.at(im.intrinsics_id));
-    if (e3d_reg_render_depth(h, kv.first, scale, nullptr) < 0) throw Error(E3D_ERR_INVALID, e3d_last_error());
+    const bool cached = h->cache_observations;
+    if (cached && !im.has_observed)
+      throw Error(E3D_ERR_INVALID, fmt("no observed point indices for image %d (e3d_reg_determine_observed_indices / e3d_reg_set_observed_indices)", kv.first));
+    if (!cached && e3d_reg_render_depth(h, kv.first, scale, nullptr) < 0) throw Error(E3D_ERR_INVALID, e3d_last_error());
     for (auto& o : im.obs) { o.second.active = false; o.second.n = 0; }      // keep the device buffers
     bool had_many = false;
     for (auto it = h->scales.rbegin(); it != h->scales.rend(); ++it) {
-      const int64_t n = e3d_reg_observe(h, kv.first, it->first, scale, border, nullptr, 0);
+      int64_t n;
+      if (cached) {
+        auto ci = im.observed.find(it->first);
+        const size_t nv = (ci == im.observed.end()) ? 0 : ci->second.second;
+        static const unsigned dummy = 0;
+        n = e3d_reg_observe(h, kv.first, it->first, scale, border, nv ? ci->second.first.p : &dummy, nv);
+      } else {
+        n = e3d_reg_observe(h, kv.first, it->first, scale, border, nullptr, 0);
+      }
       if (n < 0) throw Error(E3D_ERR_INVALID, e3d_last_error());
       if ((size_t)n > kManyObservationsCount) had_many = true;
       else if (n == 0 && had_many) break;
@@ -2358,6 +2375,80 @@ int e3d_reg_update_observations(e3d_reg_t* h, int border_size) {
   return 0;
   R_CATCH()
 }
+// Optimizer::set_cache_observations (optimizer.h)
+int e3d_reg_set_cache_observations(e3d_reg_t* h, int enabled) {
+  R_TRY
+  if (!h) throw Error(E3D_ERR_INVALID, "null handle");
+  h->cache_observations = enabled != 0;
+  return 0;
+  R_CATCH()
+}
+// ObservationsCache::DetermineAndSaveObservedPointIndices (observations_cache.cc:104-158) without the files: the full
+// visibility test at image scale 0, whose observed point indices become the cached lists.
+int e3d_reg_determine_observed_indices(e3d_reg_t* h) {
+  R_TRY
+  if (!h) throw Error(E3D_ERR_INVALID, "null handle");
+  const int old_scale = h->prm.current_image_scale;
+  const bool old_cache = h->cache_observations;
+  h->prm.current_image_scale = 0;
+  h->cache_observations = false;
+  try { update_observations(h, 1); } catch (...) { h->prm.current_image_scale = old_scale; h->cache_observations = old_cache; throw; }
+  h->prm.current_image_scale = old_scale;
+  h->cache_observations = old_cache;
+  for (auto& kv : h->images) {
+    if (!h->owns(kv.first)) continue;
+    ImageDev& im = kv.second;
+    for (auto& sc : h->scales) {
+      auto& slot = im.observed[sc.first];
+      slot.second = 0;
+      if (!has_obs(im, sc.first)) continue;
+      Obs& O = im.obs.at(sc.first);
+      slot.first.reserve(O.n);
+      if (O.n) E3D_HIP(hipMemcpyAsync(slot.first.p, O.idx.p, sizeof(unsigned) * O.n, hipMemcpyDeviceToDevice, h->stream));
+      slot.second = O.n;
+    }
+    im.has_observed = true;
+  }
+  rsync(h);
+  return 0;
+  R_CATCH()
+}
+int64_t e3d_reg_get_observed_indices(e3d_reg_t* h, int image_id, int point_scale, uint64_t* indices) {
+  R_TRY
+  if (!h) throw Error(E3D_ERR_INVALID, "null handle");
+  ImageDev& im = get_image(h, image_id);
+  get_scale(h, point_scale);
+  if (!im.has_observed) throw Error(E3D_ERR_INVALID, fmt("image %d has no observed point indices", image_id));
+  auto ci = im.observed.find(point_scale);
+  const size_t n = (ci == im.observed.end()) ? 0 : ci->second.second;
+  if (indices && n) {
+    std::vector<unsigned> tmp(n);
+    copy_out(tmp.data(), ci->second.first.p, sizeof(unsigned) * n, h->stream);
+    rsync(h);
+    for (size_t i = 0; i < n; ++i) indices[i] = tmp[i];
+  }
+  return (int64_t)n;
+  R_CATCH()
+}
+int e3d_reg_set_observed_indices(e3d_reg_t* h, int image_id, int point_scale, const uint64_t* indices, size_t count) {
+  R_TRY
+  if (!h || (count && !indices)) throw Error(E3D_ERR_INVALID, "null argument");
+  ImageDev& im = get_image(h, image_id);
+  PointScale& S = get_scale(h, point_scale);
+  std::vector<unsigned> tmp(count);
+  for (size_t i = 0; i < count; ++i) {
+    if (indices[i] >= S.n) throw Error(E3D_ERR_INDEX, fmt("observed point index %llu out of range (scale %d has %zu points)", (unsigned long long)indices[i], point_scale, S.n));
+    tmp[i] = (unsigned)indices[i];
+  }
+  auto& slot = im.observed[point_scale];
+  slot.first.reserve(count);
+  if (count) copy_in(slot.first.p, tmp.data(), sizeof(unsigned) * count, h->stream);
+  rsync(h);
+  slot.second = count;
+  im.has_observed = true;
+  return 0;
+  R_CATCH()
+}
 int e3d_reg_color_update(e3d_reg_t* h) {
   R_TRY
   if (!h) throw Error(E3D_ERR_INVALID, "null handle");
@@ -2382,7 +2473,8 @@ int e3d_reg_apply(e3d_reg_t* h, int print_progress, int* applied_update, float* 
   R_CATCH()
 }
 
-// bool Optimizer::RunOnCurrentScale(...)  (src/opt/optimizer.cc:49-182), cache_observations == false
+// bool Optimizer::RunOnCurrentScale(...)  (src/opt/optimizer.cc:49-182); the observation source follows
+// e3d_reg_set_cache_observations (the files of the cache are the host side's business)
 int e3d_reg_run_on_current_scale(e3d_reg_t* h, int max_num_iterations, float max_change_convergence_threshold,
                                  int iterations_without_new_optimum_threshold, int print_progress, double* optimum_cost,
                                  int* iterations_done) {
@@ -2392,6 +2484,11 @@ int e3d_reg_run_on_current_scale(e3d_reg_t* h, int max_num_iterations, float max
   // never use the highest image scale (optimizer.cc:60-61)
   h->prm.current_image_scale = std::min<int>(h->prm.current_image_scale, h->prm.image_scale_count - 1 - 1);
   if (print) printf("--- Optimizing at scaling factor %g ---\n", std::pow(2.0, -1.0 * h->prm.current_image_scale));
+  if (h->cache_observations) {       // ObservationsCache constructor (observations_cache.cc:39-50), "path does not exist" branch
+    bool missing = false;
+    for (auto& kv : h->images) missing = missing || (h->owns(kv.first) && !kv.second.has_observed);
+    if (missing && e3d_reg_determine_observed_indices(h) < 0) throw Error(E3D_ERR_INVALID, e3d_last_error());
+  }
   bool converged = false;
   float lambda = 64.0f;
   int without = 0;

@@ -4,8 +4,9 @@
 // rigs.json, metadata.txt); the optimisation itself runs on the MI355X behind the C-ABI (e3d_reg_*).
 //
 // Occlusion meshes (--occlusion_mesh_path / --occlusion_splats_path) are rasterised on the GPU by the library instead of OpenGL.
-// Not built yet (the tool says so instead of silently doing something else): the observations cache,
-// --write_debug_point_clouds, JPEG input.
+// Observations are cached like in the reference: from the second image scale on (or from the first with
+// --cache_observations 1) the visible point lists are fixed and kept in --observations_cache_path.
+// Not built yet (the tool says so instead of silently doing something else): --write_debug_point_clouds, JPEG input.
 #include <cmath>
 #include <cstdlib>
 #include <iostream>
@@ -36,6 +37,8 @@ int main(int argc, char** argv) {
   float target_scaling_factor = 2;      // anything larger than 1 runs all scaling factors
   parse_argument(argc, argv, "--target_scaling_factor", target_scaling_factor);
   parse_argument(argc, argv, "--camera_ids_to_ignore", camera_ids_to_ignore_string);
+  bool cache_observations = false;
+  parse_argument(argc, argv, "--cache_observations", cache_observations);
   std::unordered_set<int> camera_ids_to_ignore;
   for (const std::string& id : SplitStringIntoSet(',', camera_ids_to_ignore_string)) camera_ids_to_ignore.insert(atoi(id.c_str()));
 
@@ -97,11 +100,17 @@ int main(int argc, char** argv) {
   int current_image_scale = (initial_scaling_factor == 0)
                                 ? max_image_scale_minus_one
                                 : std::max(0, std::min<int>(max_image_scale_minus_one, (int)(-1 * std::log(initial_scaling_factor) / std::log(2))));
+  bool is_first_scale = true;
   while (true) {
+    // caching observations is enabled after finishing on the first scale (image_registrator.cc:230-235)
+    if (is_first_scale) is_first_scale = false;
+    else cache_observations = true;
     // Optimizer::RunOnCurrentScale (never the highest image scale, optimizer.cc:60-61)
     current_image_scale = std::min(current_image_scale, problem.max_image_scale() - 1);
     problem.reg_params.current_image_scale = current_image_scale;
     if (api().e3d_reg_set_params(problem.reg, &problem.reg_params) < 0) { std::cerr << api().e3d_last_error() << std::endl; return EXIT_FAILURE; }
+    if (cache_observations && !problem.PrepareObservationsCache(observations_cache_path)) return EXIT_FAILURE;   // optimizer.cc:74-78
+    if (api().e3d_reg_set_cache_observations(problem.reg, cache_observations ? 1 : 0) < 0) { std::cerr << api().e3d_last_error() << std::endl; return EXIT_FAILURE; }
     double optimum_cost = 0;
     int iterations = 0;
     if (api().e3d_reg_run_on_current_scale(problem.reg, max_iterations, kMaxChangeConvergenceThreshold, kIterationsWithoutNewOptimumThreshold,

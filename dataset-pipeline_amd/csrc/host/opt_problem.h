@@ -749,6 +749,59 @@ class Problem {
   int max_image_scale() const { return image_scale_count - 1; }
   e3d_reg_params reg_params{};
 
+  // ObservationsCache::ObservationsCache (src/opt/observations_cache.cc:39-50): if the folder exists the per-image
+  // `<folder>/<image dir name>/<image file name>.observed_indices` files are loaded (:70-102; a missing file or a different
+  // point scale count is fatal), otherwise the lists are determined on the device at image scale 0 and written (:104-158).
+  // File layout: int point_scale_count, then per point scale std::size_t n + std::size_t[n].
+  bool PrepareObservationsCache(const std::string& path) {
+    auto file_of = [&](const HostImage& im) {
+      return join_path(join_path(path, path_filename(path_parent(im.file_path))), path_filename(im.file_path) + ".observed_indices");
+    };
+    const int scale_count = (int)point_radii.size();
+    if (file_exists(path)) {
+      for (auto& kv : images) {
+        const std::string fn = file_of(kv.second);
+        FILE* f = fopen(fn.c_str(), "rb");
+        if (!f) return fail("Missing file for observed point indices: " + fn + ". Delete the observed point indices directory to re-generate the files.");
+        int file_scale_count = 0;
+        bool ok = fread(&file_scale_count, sizeof(int), 1, f) == 1;
+        if (ok && file_scale_count != scale_count) {
+          fclose(f);
+          return fail("Point scale count differs between observed points file and current setting. Delete observed_point_indices directory to re-generate the files with the new setting.");
+        }
+        for (int ps = 0; ok && ps < scale_count; ++ps) {
+          uint64_t n = 0;
+          ok = fread(&n, sizeof(uint64_t), 1, f) == 1;
+          std::vector<uint64_t> list(ok ? n : 0);
+          ok = ok && fread(list.data(), sizeof(uint64_t), n, f) == n;
+          if (ok && api().e3d_reg_set_observed_indices(reg, kv.first, ps, list.data(), list.size()) < 0) { fclose(f); return lib_fail("e3d_reg_set_observed_indices"); }
+        }
+        fclose(f);
+        if (!ok) return fail("Cannot read observed point indices: " + fn + " (file corrupted?)");
+      }
+      return true;
+    }
+    if (api().e3d_reg_determine_observed_indices(reg) < 0) return lib_fail("e3d_reg_determine_observed_indices");
+    for (auto& kv : images) {
+      const std::string fn = file_of(kv.second);
+      create_directories(path_parent(fn));
+      FILE* f = fopen(fn.c_str(), "wb");
+      if (!f) return fail("Cannot write " + fn);
+      fwrite(&scale_count, sizeof(int), 1, f);
+      for (int ps = 0; ps < scale_count; ++ps) {
+        const int64_t n = api().e3d_reg_get_observed_indices(reg, kv.first, ps, nullptr);
+        if (n < 0) { fclose(f); return lib_fail("e3d_reg_get_observed_indices"); }
+        std::vector<uint64_t> list((size_t)n);
+        if (n && api().e3d_reg_get_observed_indices(reg, kv.first, ps, list.data()) < 0) { fclose(f); return lib_fail("e3d_reg_get_observed_indices"); }
+        const uint64_t count = (uint64_t)n;
+        fwrite(&count, sizeof(uint64_t), 1, f);
+        fwrite(list.data(), sizeof(uint64_t), list.size(), f);
+      }
+      fclose(f);
+    }
+    return true;
+  }
+
   // pulls the optimised intrinsics, poses and rig extrinsics back from the device
   bool ReadBackState() {
     for (HostIntrinsics& in : intrinsics_list)

@@ -25,6 +25,12 @@ inline int parse_argument(int argc, char** argv, const char* name, int& val) {
   if (i > 0 && i < argc) val = atoi(argv[i]);
   return i - 1;
 }
+// pcl::console::parse_argument(bool&): true iff atoi(value) == 1
+inline int parse_argument(int argc, char** argv, const char* name, bool& val) {
+  const int i = find_argument(argc, argv, name) + 1;
+  if (i > 0 && i < argc) val = atoi(argv[i]) == 1;
+  return i - 1;
+}
 inline int parse_argument(int argc, char** argv, const char* name, float& val) {
   const int i = find_argument(argc, argv, name) + 1;
   if (i > 0 && i < argc) val = static_cast<float>(atof(argv[i]));

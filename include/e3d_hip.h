@@ -271,8 +271,23 @@ int e3d_reg_color_finish(e3d_reg_t* reg, int point_scale);
 
 /* Whole-problem steps of opt::Optimizer::RunOnCurrentScale (src/opt/optimizer.cc:49-182) on the device-resident state.
  * Images are visited in ascending image id. */
-/* VisibilityEstimator::CreateObservationsForAllImages + DetermineIfAllNeighborsAreObserved (optimizer.cc:119-128) */
+/* VisibilityEstimator::CreateObservationsForAllImages + DetermineIfAllNeighborsAreObserved (optimizer.cc:119-128); with
+ * e3d_reg_set_cache_observations(1) it is ObservationsCache::GetObservations (observations_cache.cc:52-68) instead. */
 int e3d_reg_update_observations(e3d_reg_t* reg, int border_size);
+/* Observations cache (src/opt/observations_cache.{h,cc}; Optimizer::set_cache_observations, optimizer.h).  When enabled, the
+ * observation update re-projects a fixed per-image list of point indices with the current state and applies only the
+ * scale-fit and border tests (VisibilityEstimator::AppendObservationsForIndexedPointsVisibleInImage,
+ * visibility_estimator.cc:140-168, :367-403) -- no occlusion rendering, masks or over-saturation test.
+ *   e3d_reg_determine_observed_indices: ObservationsCache::DetermineAndSaveObservedPointIndices (observations_cache.cc:
+ *     104-125) minus the files -- a full visibility pass at image scale 0 with the current state fills the lists (of the
+ *     images this rank owns).  e3d_reg_run_on_current_scale calls it by itself when caching is on and lists are missing.
+ *   e3d_reg_get_observed_indices: returns the length of the list of (image, point scale) and, if `indices` is not NULL,
+ *     copies it out as the std::size_t values the `.observed_indices` files hold (observations_cache.cc:146-156).
+ *   e3d_reg_set_observed_indices: installs a list read from such a file (observations_cache.cc:70-102). */
+int e3d_reg_set_cache_observations(e3d_reg_t* reg, int enabled);
+int e3d_reg_determine_observed_indices(e3d_reg_t* reg);
+int64_t e3d_reg_get_observed_indices(e3d_reg_t* reg, int image_id, int point_scale, uint64_t* indices);
+int e3d_reg_set_observed_indices(e3d_reg_t* reg, int image_id, int point_scale, const uint64_t* indices, size_t count);
 /* ColorOptimizer::Apply (color_optimizer.cc:40-123) */
 int e3d_reg_color_update(e3d_reg_t* reg);
 /* CostCalculator::ComputeCost (cost_calculator.cc:44-100) */
@@ -280,7 +295,7 @@ int e3d_reg_compute_cost(e3d_reg_t* reg, double* cost);
 /* IntrinsicsAndPoseOptimizer::Apply (intrinsics_and_pose_optimizer.cc:48-259): one LM step with <= 10 tries */
 int e3d_reg_apply(e3d_reg_t* reg, int print_progress, int* applied_update, float* lambda, float* max_change);
 /* bool Optimizer::RunOnCurrentScale(max_num_iterations, max_change_convergence_threshold,
- *   iterations_without_new_optimum_threshold, <no observation cache>, print_progress, &optimum_cost); returns 1 if
+ *   iterations_without_new_optimum_threshold, <observations_cache_path: host side>, print_progress, &optimum_cost); returns 1 if
  * converged, 0 if not.  The state (intrinsics, poses) is left at the optimum, like the reference. */
 int e3d_reg_run_on_current_scale(e3d_reg_t* reg, int max_num_iterations, float max_change_convergence_threshold,
                                  int iterations_without_new_optimum_threshold, int print_progress, double* optimum_cost,

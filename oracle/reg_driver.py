@@ -125,15 +125,31 @@ class OracleRegProblem:
         f = rb.neighbors_observed(len(S["pts"]), o[0], S["nbr"], self.K)
         return o + (f,)
 
+    # ---- ObservationsCache (src/opt/observations_cache.cc) -----------------------------------------------------------------
+    def determine_observed_indices(self):
+        """DetermineAndSaveObservedPointIndices (:104-125): full visibility at image scale 0 -> per image, per point scale lists."""
+        old, old_cache = self.current_image_scale, getattr(self, "cache_observations", False)
+        self.current_image_scale = 0; self.cache_observations = False
+        self.update_observations(1)
+        self.current_image_scale = old; self.cache_observations = old_cache
+        self.observed = {}
+        for image_id in sorted(self.images):
+            self.observed[image_id] = {s: (np.asarray(self.obs[(image_id, s)][0], np.uint64) if (image_id, s) in self.obs
+                                           else np.zeros(0, np.uint64)) for s in sorted(self.scales)}
+
     def update_observations(self, border=1):
         self.obs = {}
+        cached = getattr(self, "cache_observations", False)
         for image_id in sorted(self.images):
             im = self.images[image_id]; I = self.intr[im["intr"]]
             scale = self._best_scale(I)
-            depth = rb.splat_depth(self.splat, self._R(im), im["t"], I["levels"][max(0, scale - I["min"])], self.splat_radius)
+            depth = None if cached else rb.splat_depth(self.splat, self._R(im), im["t"], I["levels"][max(0, scale - I["min"])], self.splat_radius)
             had_many = False
             for s in sorted(self.scales, reverse=True):
-                o = self._observe(image_id, s, scale, border, depth=depth)
+                if cached:     # GetObservations (:52-68) -> AppendObservationsForIndexedPointsVisibleInImage
+                    o = self._observe(image_id, s, scale, border, indices=np.asarray(self.observed[image_id][s], np.uint32))
+                else:
+                    o = self._observe(image_id, s, scale, border, depth=depth)
                 self.obs[(image_id, s)] = o
                 if len(o[0]) > K_MANY:
                     had_many = True
@@ -266,6 +282,8 @@ class OracleRegProblem:
     def run_on_current_scale(self, max_num_iterations, max_change_convergence_threshold=0.0,
                              iterations_without_new_optimum_threshold=15, print_progress=False):
         self.current_image_scale = min(self.current_image_scale, self.image_scale_count - 2)
+        if getattr(self, "cache_observations", False) and not hasattr(self, "observed"):
+            self.determine_observed_indices()
         converged = False
         lam = np.float32(64.0)
         without = 0
@@ -295,3 +313,30 @@ class OracleRegProblem:
         self.set_state(optimum)
         self.history = history
         return converged, optimum_cost, it
+
+
+# ---- `.observed_indices` files (observations_cache.cc:70-102 load, :127-158 save) -------------------------------------------------
+def observed_indices_path(cache_dir, image_file_path):
+    import os
+    return os.path.join(cache_dir, os.path.basename(os.path.dirname(image_file_path)), os.path.basename(image_file_path) + ".observed_indices")
+
+
+def write_observed_indices(path, lists):
+    """lists: per point scale (ascending), arrays of point indices.  int32 count, then per scale u64 n + u64[n]."""
+    import os
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    with open(path, "wb") as f:
+        f.write(np.int32(len(lists)).tobytes())
+        for l in lists:
+            l = np.asarray(l, np.uint64)
+            f.write(np.uint64(l.size).tobytes()); f.write(l.tobytes())
+
+
+def read_observed_indices(path):
+    raw = open(path, "rb").read()
+    n = int(np.frombuffer(raw, np.int32, 1, 0)[0]); pos = 4
+    out = []
+    for _ in range(n):
+        c = int(np.frombuffer(raw, np.uint64, 1, pos)[0]); pos += 8
+        out.append(np.frombuffer(raw, np.uint64, c, pos).copy()); pos += 8 * c
+    return out

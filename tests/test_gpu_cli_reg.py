@@ -99,6 +99,7 @@ def test_image_registrator_cli_matches_binding(tmp_path, e3d):
     costs = []
     for scale in (1, 0):
         prm = G.params; prm.current_image_scale = scale; G.set_params(prm)
+        G.set_cache_observations(scale != 1)           # enabled after the first scale (image_registrator.cc:230-235)
         costs.append(G.run_on_current_scale(4, 0.0, 15, False)[1])
         st = _read_images_txt(os.path.join(d, "out", "scale_%s_state" % ("0.5" if scale == 1 else "1"), "images.txt"))
         assert sorted(st) == [0, 1, 2]
@@ -112,6 +113,45 @@ def test_image_registrator_cli_matches_binding(tmp_path, e3d):
         meta = open(os.path.join(d, "out", "scale_%s_state" % ("0.5" if scale == 1 else "1"), "metadata.txt")).read()
         assert "optimum_cost " in meta and "point_neighbor_count 5" in meta
         assert np.isfinite(costs[-1]) and abs(float(meta.strip().split("optimum_cost ")[1]) - costs[-1]) <= 1e-4 * costs[-1]
+    # the `.observed_indices` files written before the second scale (observations_cache.cc:127-158) hold the lists of the binding
+    from oracle.reg_driver import observed_indices_path, read_observed_indices
+    lists = {}
+    for i in range(3):
+        fn = observed_indices_path(os.path.join(d, "obs_cache"), os.path.join(d, "images", names[i]))
+        assert fn.endswith("obs_cache/dslr/img_%d.png.observed_indices" % i) and os.path.isfile(fn)
+        lists[i] = read_observed_indices(fn)
+        assert len(lists[i]) == 2 and len(lists[i][0]) > 1000
+        for ps in range(2):
+            assert np.array_equal(lists[i][ps], G.get_observed_indices(i, ps))
+    # second run on the existing cache folder with --cache_observations 1: the lists are loaded (observations_cache.cc:70-102)
+    # and drive every scale
+    out2 = _run_tool(d, ["--cache_observations", "1"])
+    assert "Finished!" in out2
+    G2 = e3d.RegProblem(e3d.default_reg_params(image_scale_count=3, point_neighbor_count=M["K"]))
+    G2.set_intrinsics(0, M["width"], M["height"], M["params"], 0, 3)
+    for s_i, sc in enumerate(_point_scales(M)):
+        G2.set_point_scale(s_i, sc["pts"], sc["radius"], sc["nbr"], sc["fixed"])
+    G2.set_splat_points(M["pts"])
+    for i, im in enumerate(M["images"]):
+        G2.set_image(i, 0, pyramid_u8(im["pyr"][0], 3)); G2.set_image_pose(i, im["q_init"], im["t_init"])
+        for ps in range(2):
+            G2.set_observed_indices(i, ps, lists[i][ps])
+    G2.set_cache_observations(True)
+    for scale in (1, 0):
+        prm = G2.params; prm.current_image_scale = scale; G2.set_params(prm)
+        G2.run_on_current_scale(4, 0.0, 15, False)
+    st = _read_images_txt(os.path.join(d, "out", "scale_1_state", "images.txt"))
+    for i in range(3):
+        q, t = G2.get_image_pose(i)
+        assert np.abs(st[i][0] - q).max() <= 2e-5 and np.abs(st[i][1] - t).max() <= 2e-5
+    # a cache folder that lacks a file is fatal, like in the reference
+    os.remove(observed_indices_path(os.path.join(d, "obs_cache"), os.path.join(d, "images", names[1])))
+    cmd_fail = subprocess.run([os.path.join(BIN, "ImageRegistrator"), "--scan_alignment_path", os.path.join(d, "scans.mlp"),
+                               "--multi_res_point_cloud_directory_path", os.path.join(d, "cache"), "--image_base_path", os.path.join(d, "images"),
+                               "--state_path", os.path.join(d, "state"), "--output_folder_path", os.path.join(d, "out"), "--observations_cache_path",
+                               os.path.join(d, "obs_cache"), "--max_iterations", "2", "--max_initial_image_area_in_pixels", "3000",
+                               "--cache_observations", "1"], capture_output=True, text=True, timeout=600)
+    assert cmd_fail.returncode != 0 and "Missing file for observed point indices" in cmd_fail.stderr
 
 
 def test_image_registrator_cli_with_rig(tmp_path, e3d):

@@ -243,6 +243,68 @@ def test_run_on_current_scale_matches_oracle_and_improves(e3d, model, var_weight
     assert costg <= O.history[0]
 
 
+# ---- observations cache (src/opt/observations_cache.cc) ------------------------------------------------------------------------
+@pytest.mark.parametrize("model", [0, 2])
+def test_observation_cache_matches_oracle(e3d, model):
+    """ObservationsCache: lists from a full visibility pass at image scale 0, then GetObservations (indexed re-projection,
+    no occlusion / mask tests) drives RunOnCurrentScale at a coarser image scale."""
+    from reg_util import make_multi_image_scene
+    M = make_multi_image_scene(n_points=6000, n_images=3, seed=8, perturb=0.006, model=model)
+    G, O = _build_both(e3d, M)
+    with pytest.raises(e3d.E3DError):
+        G.get_observed_indices(0, 0)                                  # nothing determined yet
+    G.set_cache_observations(True)
+    with pytest.raises(e3d.E3DError):
+        G.update_observations(1)                                      # cache on, no lists
+    G.set_cache_observations(False)
+    # an occluder between the cameras and the wall, so that the lists are a strict subset of the points
+    bx, bz = np.meshgrid(np.arange(0.2, 0.5, 0.01), np.arange(-0.2, 0.2, 0.01))
+    blocker = np.stack([bx.ravel(), np.full(bx.size, 1.5), bz.ravel()], 1).astype(np.float32)
+    for P in (G, O):
+        P.set_splat_points(np.concatenate([M["pts"], blocker]))
+    G.determine_observed_indices(); O.determine_observed_indices()
+    for i in range(3):
+        lg = G.get_observed_indices(i, 0)
+        assert lg.dtype == np.uint64 and np.array_equal(lg, O.observed[i][0]) and 500 < len(lg) < len(M["pts"]) - 100
+    # a list installed from outside behaves like a determined one (the file-loading path)
+    G.set_observed_indices(1, 0, O.observed[1][0])
+    with pytest.raises(e3d.E3DError):
+        G.set_observed_indices(1, 0, np.array([len(M["pts"])], np.uint64))
+    G.set_cache_observations(True); O.cache_observations = True
+    G.update_observations(1); O.update_observations(1)
+    for i in range(3):
+        n = len(O.obs[(i, 0)][0])
+        g = G.get_observations(i, 0, n)
+        assert n > 300 and np.array_equal(g[0], O.obs[(i, 0)][0]) and np.array_equal(g[4], O.obs[(i, 0)][4])
+        tol = 0.0 if model in EXACT else 1e-4
+        assert np.abs(g[1] - O.obs[(i, 0)][1]).max() <= tol and np.abs(g[3] - O.obs[(i, 0)][3]).max() <= 1e-3 * (model not in EXACT) + 5e-7
+    cg, costg, itg = G.run_on_current_scale(6, 0.0, 15, False)
+    co, costo, ito = O.run_on_current_scale(6, 0.0, 15, False)
+    assert (cg, itg) == (co, ito) and abs(costg - costo) <= 1e-4 * costo
+    for i in range(3):
+        ang, tr = _pose_delta(*G.get_image_pose(i), *O.get_image_pose(i))
+        assert ang <= 1e-4 and tr <= 1e-4
+    # the cached path differs from the uncached one (no occlusion test): same lists, different observation sets are allowed,
+    # but a run with caching off must still work afterwards
+    G.set_cache_observations(False); O.cache_observations = False
+    G.update_observations(1); O.update_observations(1)
+    for i in range(3):
+        n = len(O.obs[(i, 0)][0])
+        assert np.array_equal(G.get_observations(i, 0, n)[0], O.obs[(i, 0)][0])
+
+
+def test_run_on_current_scale_determines_cache_itself(e3d):
+    from reg_util import make_multi_image_scene
+    M = make_multi_image_scene(n_points=5000, n_images=2, seed=9, perturb=0.004)
+    G, O = _build_both(e3d, M)
+    G.set_cache_observations(True); O.cache_observations = True
+    cg, costg, itg = G.run_on_current_scale(4, 0.0, 15, False)
+    co, costo, ito = O.run_on_current_scale(4, 0.0, 15, False)
+    assert (cg, itg) == (co, ito) and abs(costg - costo) <= 1e-4 * costo
+    for i in range(2):
+        assert np.array_equal(G.get_observed_indices(i, 0), O.observed[i][0])
+
+
 # ---- camera rigs (Rig::Update, dependent rig images) ----------------------------------------------------------------------------
 def _build_rig_both(e3d, M):
     from oracle.reg_driver import OracleRegProblem

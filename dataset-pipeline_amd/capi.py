@@ -63,6 +63,7 @@ SIGNATURES = {
     "e3d_icp_pair_system": (C.c_int, [C.c_void_p] * 6 + [C.c_int64] + [C.c_void_p] * 7),
     "e3d_normals_knn": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "e3d_normals_radius": (C.c_int, [C.c_void_p, C.c_size_t, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "e3d_local_outlier_removal": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_double, C.c_int, C.c_void_p, C.c_void_p]),
     # (B) image registration kernels
     "e3d_reg_create": (C.c_void_p, [C.c_void_p]),
     "e3d_reg_destroy": (None, [C.c_void_p]),
@@ -329,6 +330,19 @@ def normals_radius(xyz, radius, viewpoint=(0.0, 0.0, 0.0), return_counts=False):
     if r < 0:
         _err("e3d_normals_radius", r)
     return (on, oc, cnt) if return_counts else (on, oc)
+
+
+def local_outlier_removal(xyz, mean_k, distance_factor_threshold, negative=False, return_distances=False):
+    """pcl::LocalStatisticalOutlierRemoval: bool mask of the points the filter keeps [, first-pass mean neighbour distances]."""
+    keep = []
+    n = int(xyz.shape[0])
+    inl = np.zeros(n, np.uint8)
+    md = np.zeros(n, np.float32) if return_distances else None
+    r = lib().e3d_local_outlier_removal(_ptr(xyz, np.float32, keep), n, int(mean_k), float(distance_factor_threshold), int(bool(negative)),
+                                        C.c_void_p(inl.ctypes.data), C.c_void_p(md.ctypes.data) if md is not None else None)
+    if r < 0:
+        _err("e3d_local_outlier_removal", r)
+    return (inl.astype(bool), md) if return_distances else inl.astype(bool)
 
 
 # ---- (B) image registration kernels ------------------------------------------------------------------------------------

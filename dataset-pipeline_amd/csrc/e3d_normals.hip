@@ -114,7 +114,8 @@ __global__ __launch_bounds__(kKnnBlock) void k_knn_normals(const float4* __restr
                                                            float vpx, float vpy, float vpz,
                                                            const float4* __restrict__ Q4 /* queries by sorted pos of level 0 */,
                                                            float* __restrict__ out_n, float* __restrict__ out_c,
-                                                           int* __restrict__ out_knn, unsigned* __restrict__ next_todo,
+                                                           int* __restrict__ out_knn, float* __restrict__ out_mean,
+                                                           unsigned* __restrict__ next_todo,
                                                            unsigned* __restrict__ next_count) {
   extern __shared__ unsigned char smem[];
   float* hd = reinterpret_cast<float*>(smem);                         // [k][kKnnBlock]
@@ -220,6 +221,14 @@ __global__ __launch_bounds__(kKnnBlock) void k_knn_normals(const float4* __restr
   if (out_knn) {
     for (int i = 0; i < k; ++i) out_knn[(size_t)q_oi * k + i] = (i < cnt) ? (int)__float_as_uint(P4[HP(i)].w) : -1;
   }
+  if (out_mean) {
+    // LocalStatisticalOutlierRemoval, first pass (local_statistical_outlier_removal.hpp:104-109): mean distance to the
+    // k - 1 nearest neighbours (entry 0 is the query point), f64 sum of the f32 roots in neighbour order
+    double dist_sum = 0.0;
+    for (int i = 1; i < cnt; ++i) dist_sum += (double)sqrtf(HD(i));
+    out_mean[q_oi] = (float)(dist_sum / (double)(k - 1));
+  }
+  if (!out_n) return;
   float nx, ny, nz, curv;
   const float qnan = __uint_as_float(0x7fc00000u);
   if (cnt < 3) {                                                      // two_pass_normal_3d.h:97-103
@@ -351,25 +360,19 @@ struct LevelBuffers {
 
 using namespace e3d;
 
-extern "C" int e3d_normals_knn(const float* xyz, size_t n, int k, const float* viewpoint, float* out_normals,
-                               float* out_curvature, int32_t* knn_indices) {
-  try {
-    if ((!xyz && n) || !viewpoint || (!out_normals && n) || (!out_curvature && n))
-      throw Error(E3D_ERR_INVALID, "e3d_normals_knn: null argument");
-    if (k < 1 || k > kKnnMaxK) throw Error(E3D_ERR_INVALID, fmt("e3d_normals_knn: k = %d outside [1, %d]", k, kKnnMaxK));
-    if (n >= (size_t)1 << 31) throw Error(E3D_ERR_INVALID, "e3d_normals_knn: more than 2^31-1 points");
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
-      throw Error(E3D_ERR_NO_DEVICE, "no HIP device visible (libe3dhip needs an MI355X / gfx950 GPU)");
-    if (n == 0) return 0;
-    hipStream_t s = nullptr;
-    E3D_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-    struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamDestroy(s); } } guard{s};
-
-    DevBuf<float> raw, d_on, d_oc, bbox_partial, bbox_out;
-    DevBuf<int> d_knn;
-    raw.reserve(3 * n); d_on.reserve(3 * n); d_oc.reserve(n);
-    if (knn_indices) d_knn.reserve(n * (size_t)k);
+namespace e3d {
+// The exact kNN pass over a host cloud.  Results stay on the device: normals + curvature (if want_normals), the neighbour
+// index lists (if d_knn) and the mean neighbour distance (if d_mean), all in input order.
+static void knn_pass(const float* xyz, size_t n, int k, const float* viewpoint, bool want_normals, DevBuf<float>& d_on,
+                     DevBuf<float>& d_oc, DevBuf<int>* d_knn_out, DevBuf<float>* d_mean_out, hipStream_t s) {
+    DevBuf<float> raw, bbox_partial, bbox_out;
+    raw.reserve(3 * n);
+    if (want_normals) { d_on.reserve(3 * n); d_oc.reserve(n); }
+    if (d_knn_out) d_knn_out->reserve(n * (size_t)k);
+    if (d_mean_out) d_mean_out->reserve(n);
+    const bool knn_indices = d_knn_out != nullptr;
+    DevBuf<int> no_knn;
+    DevBuf<int>& d_knn = d_knn_out ? *d_knn_out : no_knn;
     copy_in(raw.p, xyz, sizeof(float) * 3 * n, s);
     bbox_partial.reserve(6 * (size_t)kMaxBboxBlocks); bbox_out.reserve(6);
     launch_bbox_aos(raw.p, n, bbox_partial.p, bbox_out.p, s);
@@ -429,8 +432,8 @@ extern "C" int e3d_normals_knn(const float* xyz, size_t n, int k, const float* v
       E3D_HIP(hipMemsetAsync(L.counter.p + 1, 0, sizeof(unsigned), s));
       const unsigned nblk = (unsigned)div_up(n_todo, kKnnBlock);
       hipLaunchKernelGGL(k_knn_normals, dim3(nblk), dim3(kKnnBlock), lds, s, L.P4.p, n, todo, n_todo, L.table.p, G, k,
-                         viewpoint[0], viewpoint[1], viewpoint[2], Q4.p, d_on.p, d_oc.p,
-                         knn_indices ? d_knn.p : nullptr, next, L.counter.p + 1);
+                         viewpoint[0], viewpoint[1], viewpoint[2], Q4.p, want_normals ? d_on.p : nullptr, want_normals ? d_oc.p : nullptr,
+                         knn_indices ? d_knn.p : nullptr, d_mean_out ? d_mean_out->p : nullptr, next, L.counter.p + 1);
       unsigned n_next = 0;
       E3D_HIP(hipMemcpyAsync(&n_next, L.counter.p + 1, sizeof(unsigned), hipMemcpyDeviceToHost, s));
       E3D_HIP(hipStreamSynchronize(s));
@@ -440,10 +443,115 @@ extern "C" int e3d_normals_knn(const float* xyz, size_t n, int k, const float* v
       cell *= 4.0;
     }
     if (n_todo != 0) throw Error(E3D_ERR_INVALID, "e3d_normals_knn: internal error, unresolved queries remain");
+}
+
+static void require_device() {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    throw Error(E3D_ERR_NO_DEVICE, "no HIP device visible (libe3dhip needs an MI355X / gfx950 GPU)");
+}
+
+// LocalStatisticalOutlierRemoval, second pass (local_statistical_outlier_removal.hpp:113-160)
+__global__ __launch_bounds__(256) void k_outlier_classify(const int* __restrict__ knn, const float* __restrict__ mean_dist, size_t n,
+                                                          int k, double factor, int negative, unsigned char* __restrict__ inlier) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int valid = 0;
+  double sum = 0;
+  for (int j = 1; j < k; ++j) {
+    const double d = (double)mean_dist[knn[i * k + j]];
+    if (d > 0) { ++valid; sum += d; }
+  }
+  const double mean = sum / (double)valid;              // 0 / 0 = NaN: every comparison below is false, as in the reference
+  const double threshold = mean * factor;
+  const double own = (double)mean_dist[i];
+  const bool removed = (!negative && own > threshold) || (negative && own <= threshold);
+  inlier[i] = removed ? 0 : 1;
+}
+}  // namespace e3d
+
+extern "C" int e3d_normals_knn(const float* xyz, size_t n, int k, const float* viewpoint, float* out_normals,
+                               float* out_curvature, int32_t* knn_indices) {
+  try {
+    if ((!xyz && n) || !viewpoint || (!out_normals && n) || (!out_curvature && n))
+      throw Error(E3D_ERR_INVALID, "e3d_normals_knn: null argument");
+    if (k < 1 || k > kKnnMaxK) throw Error(E3D_ERR_INVALID, fmt("e3d_normals_knn: k = %d outside [1, %d]", k, kKnnMaxK));
+    if (n >= (size_t)1 << 31) throw Error(E3D_ERR_INVALID, "e3d_normals_knn: more than 2^31-1 points");
+    require_device();
+    if (n == 0) return 0;
+    hipStream_t s = nullptr;
+    E3D_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamDestroy(s); } } guard{s};
+    DevBuf<float> d_on, d_oc;
+    DevBuf<int> d_knn;
+    knn_pass(xyz, n, k, viewpoint, true, d_on, d_oc, knn_indices ? &d_knn : nullptr, nullptr, s);
     copy_out(out_normals, d_on.p, sizeof(float) * 3 * n, s);
     copy_out(out_curvature, d_oc.p, sizeof(float) * n, s);
     if (knn_indices) copy_out(knn_indices, d_knn.p, sizeof(int) * n * (size_t)k, s);
     E3D_HIP(hipStreamSynchronize(s));
+    return 0;
+  } catch (const e3d::Error& e) {
+    e3d::set_last_error(e.what());
+    return e.code;
+  } catch (const std::exception& e) {
+    e3d::set_last_error(e.what());
+    return E3D_ERR_INVALID;
+  }
+}
+
+// pcl::LocalStatisticalOutlierRemoval<PointT>::applyFilterIndices (src/geometry/local_statistical_outlier_removal.hpp:71-172)
+extern "C" int e3d_local_outlier_removal(const float* xyz, size_t n, int mean_k, double distance_factor_threshold, int negative,
+                                         uint8_t* inlier, float* mean_distances) {
+  try {
+    if ((!xyz && n) || (!inlier && n)) throw Error(E3D_ERR_INVALID, "e3d_local_outlier_removal: null argument");
+    if (mean_k < 1 || mean_k + 1 > kKnnMaxK) throw Error(E3D_ERR_INVALID, fmt("e3d_local_outlier_removal: mean_k = %d outside [1, %d]", mean_k, kKnnMaxK - 1));
+    if (n >= (size_t)1 << 31) throw Error(E3D_ERR_INVALID, "e3d_local_outlier_removal: more than 2^31-1 points");
+    require_device();
+    if (n == 0) return 0;
+    // non-finite points: distance 0 in the first pass, "problematic" (removed unless negative) in the second (:88-95, :115-125)
+    std::vector<float> finite;
+    std::vector<size_t> origin;
+    bool all_finite = true;
+    for (size_t i = 0; i < n && all_finite; ++i)
+      all_finite = std::isfinite(xyz[3 * i]) && std::isfinite(xyz[3 * i + 1]) && std::isfinite(xyz[3 * i + 2]);
+    const float* pts = xyz;
+    size_t m = n;
+    if (!all_finite) {
+      for (size_t i = 0; i < n; ++i)
+        if (std::isfinite(xyz[3 * i]) && std::isfinite(xyz[3 * i + 1]) && std::isfinite(xyz[3 * i + 2])) {
+          finite.insert(finite.end(), xyz + 3 * i, xyz + 3 * i + 3);
+          origin.push_back(i);
+        }
+      pts = finite.data(); m = origin.size();
+    }
+    if (m <= (size_t)mean_k) throw Error(E3D_ERR_INVALID, fmt("e3d_local_outlier_removal: %zu finite points cannot provide %d neighbours", m, mean_k));
+    hipStream_t s = nullptr;
+    E3D_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamDestroy(s); } } guard{s};
+    DevBuf<float> d_on, d_oc, d_mean;
+    DevBuf<int> d_knn;
+    DevBuf<unsigned char> d_in;
+    const float vp[3] = {0.f, 0.f, 0.f};
+    const int k = mean_k + 1;
+    knn_pass(pts, m, k, vp, false, d_on, d_oc, &d_knn, &d_mean, s);
+    d_in.reserve(m);
+    hipLaunchKernelGGL(k_outlier_classify, dim3((unsigned)div_up(m, 256)), dim3(256), 0, s, d_knn.p, d_mean.p, m, k,
+                       distance_factor_threshold, negative, d_in.p);
+    if (all_finite) {
+      copy_out(inlier, d_in.p, m, s);
+      if (mean_distances) copy_out(mean_distances, d_mean.p, sizeof(float) * m, s);
+      E3D_HIP(hipStreamSynchronize(s));
+    } else {
+      std::vector<unsigned char> in(m);
+      std::vector<float> md(m);
+      copy_out(in.data(), d_in.p, m, s);
+      copy_out(md.data(), d_mean.p, sizeof(float) * m, s);
+      E3D_HIP(hipStreamSynchronize(s));
+      // a non-finite point is never an inlier: removed when !negative (:120-125); with negative it reaches the comparison
+      // with distance 0 <= threshold -> removed as well unless the threshold is NaN
+      for (size_t i = 0; i < n; ++i) { inlier[i] = 0; if (mean_distances) mean_distances[i] = 0.f; }
+      for (size_t j = 0; j < m; ++j) { inlier[origin[j]] = in[j]; if (mean_distances) mean_distances[origin[j]] = md[j]; }
+    }
     return 0;
   } catch (const e3d::Error& e) {
     e3d::set_last_error(e.what());

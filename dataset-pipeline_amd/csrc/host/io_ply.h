@@ -261,6 +261,40 @@ inline int savePLYFileBinaryXYZNormalRGB(const std::string& path, const std::vec
   return f ? 0 : -1;
 }
 
+// pcl::io::savePLYFileBinary of a pcl::PointXYZRGB cloud (point_cloud_cleaner.cc:132-133): x y z f32 + red green blue u8
+// (15 B/vertex) and PCL's camera element.  Clouds without colours get 0 0 0 (the packed rgb field of points loaded from a
+// colourless file).
+inline int savePLYFileBinaryXYZRGB(const std::string& path, const std::vector<float>& xyz, const std::vector<uint8_t>& rgb) {
+  std::ofstream f(path, std::ios::binary);
+  if (!f) { std::cerr << "[savePLYFile] cannot open " << path << std::endl; return -1; }
+  const size_t n = xyz.size() / 3;
+  f << "ply\nformat binary_little_endian 1.0\ncomment PCL generated\nelement vertex " << n << "\n"
+    << "property float x\nproperty float y\nproperty float z\n"
+    << "property uchar red\nproperty uchar green\nproperty uchar blue\n"
+    << "element camera 1\nproperty float view_px\nproperty float view_py\nproperty float view_pz\n"
+    << "property float x_axisx\nproperty float x_axisy\nproperty float x_axisz\n"
+    << "property float y_axisx\nproperty float y_axisy\nproperty float y_axisz\n"
+    << "property float z_axisx\nproperty float z_axisy\nproperty float z_axisz\n"
+    << "property float focal\nproperty float scalex\nproperty float scaley\nproperty float centerx\nproperty float centery\n"
+    << "property int viewportx\nproperty int viewporty\nproperty float k1\nproperty float k2\nend_header\n";
+  std::vector<unsigned char> row(15 * n);
+  const bool colours = rgb.size() == 3 * n;
+  for (size_t i = 0; i < n; ++i) {
+    memcpy(&row[15 * i], &xyz[3 * i], 12);
+    for (int c = 0; c < 3; ++c) row[15 * i + 12 + c] = colours ? rgb[3 * i + c] : 0;
+  }
+  f.write(reinterpret_cast<const char*>(row.data()), (std::streamsize)row.size());
+  const float cam_f[12] = {0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0, 1};
+  f.write(reinterpret_cast<const char*>(cam_f), sizeof cam_f);
+  const float zeros5[5] = {0, 0, 0, 0, 0};
+  f.write(reinterpret_cast<const char*>(zeros5), sizeof zeros5);
+  const int32_t vp[2] = {(int32_t)n, 1};
+  f.write(reinterpret_cast<const char*>(vp), sizeof vp);
+  const float zeros2[2] = {0, 0};
+  f.write(reinterpret_cast<const char*>(zeros2), sizeof zeros2);
+  return f ? 0 : -1;
+}
+
 // x y z intensity (f32) binary little endian: the pcl::PointXYZI files of the multi-resolution cloud cache (problem.cc:364-411)
 inline int savePLYFileBinaryXYZI(const std::string& path, const std::vector<float>& xyz, const std::vector<float>& intensity) {
   std::ofstream f(path, std::ios::binary);

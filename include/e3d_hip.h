@@ -160,6 +160,17 @@ int e3d_normals_knn(const float* xyz, size_t n, int k, const float viewpoint[3],
 int e3d_normals_radius(const float* xyz, size_t n, float radius, const float viewpoint[3],
                        float* out_normals, float* out_curvature, int32_t* neighbor_counts);
 
+/* pcl::LocalStatisticalOutlierRemoval<PointT>::applyFilterIndices (src/geometry/local_statistical_outlier_removal.hpp:71-172),
+ * the filter of PointCloudCleaner (src/exe/point_cloud_cleaner.cc:80-107) and of the multi-resolution pipeline's callers.
+ * First pass: per point the mean distance to its mean_k nearest neighbours (exact kNN with k = mean_k + 1, entry 0 being
+ * the point itself; f64 sum of the f32 roots of FLANN's squared f32 distances, stored as f32).  Second pass: a point is
+ * removed if its own value exceeds distance_factor_threshold x the f64 mean of its neighbours' (positive) values
+ * (`negative` inverts the test like setNegative).  inlier[i] = 1 for points the filter keeps; non-finite points are never
+ * kept.  mean_distances (optional, n floats) receives the first-pass values.  Neighbours at exactly equal distance are
+ * ordered by index (FLANN's order there is unpinned). */
+int e3d_local_outlier_removal(const float* xyz, size_t n, int mean_k, double distance_factor_threshold, int negative,
+                              uint8_t* inlier, float* mean_distances);
+
 /* ---- (B) ImageRegistrator: dense photometric residual / Jacobian kernels -------------------------------------
  * Device-resident mirror of the parts of opt::Problem the hot loops read (src/opt/problem.h:300-388) and the inner
  * operator surfaces of the optimizer:

@@ -222,3 +222,16 @@ def knn(xyz, queries, k):
     idx = np.zeros((queries.shape[0], k), np.int32); dist = np.zeros((queries.shape[0], k), np.float32)
     lib().oracle_knn(_f(xyz), xyz.shape[0], _f(queries), queries.shape[0], k, _i(idx), _f(dist))
     return idx, dist
+
+
+def local_outlier_removal(xyz, mean_k, factor, negative=False):
+    """LocalStatisticalOutlierRemoval on finite points -> (inlier mask, first-pass mean distances)."""
+    xyz = _c32(xyz)
+    n = xyz.shape[0]
+    inl = np.zeros(n, np.uint8); md = np.zeros(n, np.float32)
+    f = lib().oracle_local_outlier_removal
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_double, C.c_int, C.c_void_p, C.c_void_p]
+    if f(xyz.ctypes.data, n, int(mean_k), float(factor), int(bool(negative)), inl.ctypes.data, md.ctypes.data) != 0:
+        raise ValueError("oracle_local_outlier_removal: too few points")
+    return inl.astype(bool), md

@@ -198,3 +198,43 @@ void oracle_knn(const float* xyz, size_t n, const float* queries, size_t n_q, in
   }
   okd_free(tree);
 }
+
+/* pcl::LocalStatisticalOutlierRemoval<PointT>::applyFilterIndices (src/geometry/local_statistical_outlier_removal.hpp:71-172)
+ * for a cloud of finite points with indices_ = the whole cloud.  `sqrt (nn_dists[k])` on a float resolves to the float
+ * overload when <math.h> is visible (recalled; unpinned -- the reference has no test of this filter). */
+int oracle_local_outlier_removal(const float* xyz, size_t n, int mean_k, double factor, int negative, uint8_t* inlier,
+                                 float* distances) {
+  if (n <= (size_t)mean_k) return -1;
+  const int k = mean_k + 1;
+  okd_tree* tree = okd_build(xyz, n);
+  int32_t* nn = (int32_t*)malloc(sizeof(int32_t) * n * (size_t)k);
+  /* first pass (:85-110) */
+#pragma omp parallel
+  {
+    float* nd = (float*)malloc(sizeof(float) * (size_t)k);
+#pragma omp for schedule(dynamic, 1024)
+    for (long long i = 0; i < (long long)n; ++i) {
+      okd_knn(tree, xyz + 3 * (size_t)i, k, nn + (size_t)i * k, nd);
+      double dist_sum = 0.0;
+      for (int j = 1; j < mean_k + 1; ++j) dist_sum += sqrtf(nd[j]);
+      distances[i] = (float)(dist_sum / mean_k);
+    }
+    free(nd);
+  }
+  /* second pass (:113-160) */
+  for (size_t i = 0; i < n; ++i) {
+    int valid = 0;
+    double sum = 0;
+    for (int j = 1; j < k; ++j) {
+      const double d = distances[nn[i * k + j]];
+      if (d > 0) { ++valid; sum += d; }
+    }
+    const double mean = sum / (double)valid;
+    const double threshold = mean * factor;
+    const int removed = (!negative && distances[i] > threshold) || (negative && distances[i] <= threshold);
+    inlier[i] = removed ? 0 : 1;
+  }
+  free(nn);
+  okd_free(tree);
+  return 0;
+}

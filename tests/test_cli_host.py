@@ -57,3 +57,14 @@ def test_image_registrator_usage(tmp_path):
     assert r.returncode == 1 and "Please specify all the required paths." in r.stderr
     r = subprocess.run([os.path.join(BIN, "ImageRegistrator"), "--robust_weighting_type", "bogus"], capture_output=True, text=True)
     assert r.returncode == 1 and "--robust_weighting_type parameter not recognized" in r.stderr
+
+
+def test_point_cloud_cleaner_usage(tmp_path):
+    _build()
+    r = subprocess.run([os.path.join(BIN, "PointCloudCleaner")], capture_output=True, text=True)
+    assert r.returncode != 0 and "--in <file.ply> --filter <knn,factor>" in r.stderr
+    write_ply_xyz(str(tmp_path / "a.ply"), np.zeros((3, 3), np.float32))
+    r = subprocess.run([os.path.join(BIN, "PointCloudCleaner"), "--in", str(tmp_path / "a.ply")], capture_output=True, text=True)
+    assert r.returncode != 0 and "One or more --filter knn,factor parameter values must be given." in r.stderr
+    r = subprocess.run([os.path.join(BIN, "PointCloudCleaner"), "--in", str(tmp_path / "a.ply"), "--filter", "8"], capture_output=True, text=True)
+    assert r.returncode != 0 and "different than 2" in r.stderr

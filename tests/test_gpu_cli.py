@@ -99,3 +99,35 @@ def test_normal_estimator_cli(tmp_path, synth, ob):
         good = np.abs(np.einsum("ij,ij->i", rec["n"][off:off + n], on)) > 1 - 1e-3
         assert good.mean() > 0.995
         off += n
+
+
+def test_point_cloud_cleaner_cli(tmp_path, ob):
+    """PointCloudCleaner: two filter passes; inliers / outliers files (x y z + rgb, PCL header) match the oracle filter chain."""
+    rng = np.random.RandomState(21)
+    plane = np.stack([rng.uniform(-2, 2, 40000), rng.uniform(-2, 2, 40000), 0.003 * rng.normal(size=40000)], 1)
+    pts = np.concatenate([plane, rng.uniform(-2, 2, (800, 3))]).astype(np.float32)
+    pts = pts[rng.permutation(len(pts))]
+    rgb = rng.randint(0, 256, (len(pts), 3)).astype(np.uint8)
+    path = str(tmp_path / "scan.ply")
+    write_ply_xyz(path, pts, rgb=rgb)
+    r = subprocess.run([os.path.join(BIN, "PointCloudCleaner"), "--in", path, "--filter", "8,2.0", "--filter", "19.6,1.5"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "Applying filter with knn = 8, factor = 2 ..." in r.stderr and "Applying filter with knn = 20, factor = 1.5 ..." in r.stderr
+
+    def read(p):
+        raw = open(p, "rb").read()
+        h = raw.index(b"end_header\n") + 11
+        header = raw[:h].decode()
+        n = int(header.split("element vertex ")[1].split()[0])
+        rec = np.frombuffer(raw, np.dtype([("p", "<f4", 3), ("c", "u1", 3)]), n, h)
+        assert len(raw) - h - 15 * n == 4 * 12 + 4 * 5 + 4 * 2 + 4 * 2 and "property uchar red" in header and "element camera 1" in header
+        return rec
+    inl, outl = read(path + ".inliers.ply"), read(path + ".outliers.ply")
+    k1, _ = ob.local_outlier_removal(pts, 8, 2.0)
+    p1, c1 = pts[k1], rgb[k1]
+    k2, _ = ob.local_outlier_removal(p1, 20, 1.5)
+    assert np.array_equal(inl["p"], p1[k2]) and np.array_equal(inl["c"], c1[k2])
+    exp_out_p = np.concatenate([pts[~k1], p1[~k2]]); exp_out_c = np.concatenate([rgb[~k1], c1[~k2]])
+    assert np.array_equal(outl["p"], exp_out_p) and np.array_equal(outl["c"], exp_out_c)
+    assert len(inl) + len(outl) == len(pts) and 300 < len(outl) < 5000

@@ -115,3 +115,42 @@ def test_normals_radius_degenerate(e3d):
     assert cnt.tolist() == [2, 2, 2, 2, 5, 1] and np.all(np.isnan(n[:4]))
     with pytest.raises(e3d.E3DError):
         e3d.normals_radius(P, 0.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mean_k,factor", [(8, 2.0), (20, 1.3), (1, 3.0)])
+def test_local_outlier_removal_matches_oracle(e3d, ob, mean_k, factor):
+    """pcl::LocalStatisticalOutlierRemoval (PointCloudCleaner's filter): first-pass distances and the inlier mask, bit-exact."""
+    rng = np.random.RandomState(11)
+    plane = np.stack([rng.uniform(-2, 2, 60000), rng.uniform(-2, 2, 60000), 0.003 * rng.normal(size=60000)], 1)
+    wall = np.stack([np.full(20000, 2.0), rng.uniform(-2, 2, 20000), rng.uniform(0, 1.5, 20000)], 1)
+    pts = np.concatenate([plane, wall, rng.uniform(-2, 2, (1500, 3))]).astype(np.float32)
+    pts = pts[rng.permutation(len(pts))]
+    gi, gd = e3d.local_outlier_removal(pts, mean_k, factor, return_distances=True)
+    oi, od = ob.local_outlier_removal(pts, mean_k, factor)
+    assert np.array_equal(gd.view(np.uint32), od.view(np.uint32))
+    assert np.array_equal(gi, oi) and 0.5 < gi.mean() < 1.0
+    gn = e3d.local_outlier_removal(pts, mean_k, factor, negative=True)
+    assert np.array_equal(gn, ~gi)
+
+
+@pytest.mark.gpu
+def test_local_outlier_removal_edge_cases(e3d, ob):
+    rng = np.random.RandomState(12)
+    pts = rng.uniform(-1, 1, (5000, 3)).astype(np.float32)
+    # non-finite points are never kept and do not disturb the others (PCL's kd-tree skips them)
+    bad = pts.copy(); bad[[7, 100, 4999]] = [np.nan, 0, 0]; bad[55, 2] = np.inf
+    gi, gd = e3d.local_outlier_removal(bad, 6, 1.5, return_distances=True)
+    good = np.isfinite(bad).all(1)
+    oi, od = ob.local_outlier_removal(bad[good], 6, 1.5)
+    assert not gi[~good].any() and np.array_equal(gi[good], oi) and np.array_equal(gd[good], od) and (gd[~good] == 0).all()
+    # duplicates: zero distances do not count as valid neighbour values (distance > 0 test, :133-138)
+    dup = np.concatenate([pts[:2000], pts[:2000]])
+    gi, gd = e3d.local_outlier_removal(dup, 1, 2.0, return_distances=True)
+    oi, od = ob.local_outlier_removal(dup, 1, 2.0)
+    assert (gd == 0).all() and np.array_equal(gd, od) and gi.all() and np.array_equal(gi, oi)      # mean = NaN -> kept
+    with pytest.raises(e3d.E3DError):
+        e3d.local_outlier_removal(pts[:5], 8, 2.0)
+    with pytest.raises(e3d.E3DError):
+        e3d.local_outlier_removal(pts, 0, 2.0)
+    assert e3d.local_outlier_removal(np.zeros((0, 3), np.float32), 8, 2.0).shape == (0,)

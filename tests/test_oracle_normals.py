@@ -62,3 +62,26 @@ def test_normals_radius_search(ob):
     n, c = ob.normals(P, radius=0.1, viewpoint=(0, 0, 1))
     ok = ~np.isnan(n[:, 0])
     assert ok.sum() > 1900 and np.all(n[ok, 2] > 0.99)
+
+
+def test_local_outlier_removal_restatement():
+    """LocalStatisticalOutlierRemoval (local_statistical_outlier_removal.hpp:71-172) against a numpy restatement on a
+    brute-force kNN: a noisy plane plus uniform clutter; clutter goes, the plane stays."""
+    from scipy.spatial import cKDTree
+    from oracle import binding as ob
+    rng = np.random.RandomState(3)
+    plane = np.stack([rng.uniform(-1, 1, 4000), rng.uniform(-1, 1, 4000), 0.002 * rng.normal(size=4000)], 1)
+    pts = np.concatenate([plane, rng.uniform(-1, 1, (80, 3))]).astype(np.float32)
+    for mean_k, factor in ((8, 2.0), (20, 1.5)):
+        inl, md = ob.local_outlier_removal(pts, mean_k, factor)
+        d, i = cKDTree(pts.astype(np.float64)).query(pts.astype(np.float64), k=mean_k + 1)
+        m = (np.sqrt((d[:, 1:] ** 2).astype(np.float32)).astype(np.float64).sum(1) / mean_k).astype(np.float32)
+        assert np.abs(m - md).max() <= 2e-7
+        nb = md[i[:, 1:]].astype(np.float64)
+        thr = nb.sum(1) / mean_k * factor
+        exp = ~(md > thr)
+        assert (exp != inl).sum() <= 2                       # float ties at the threshold only
+        assert inl[:4000].mean() > 0.97 and inl[4000:].mean() < 0.8     # the filter is local: clutter near clutter stays
+    inl_neg, _ = ob.local_outlier_removal(pts, 8, 2.0, negative=True)
+    inl_pos, _ = ob.local_outlier_removal(pts, 8, 2.0)
+    assert np.array_equal(inl_neg, ~inl_pos)

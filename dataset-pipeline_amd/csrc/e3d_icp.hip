@@ -29,7 +29,7 @@ void set_last_error(const std::string& msg) { g_last_error = msg; }
 const char* last_error_cstr() { return g_last_error.c_str(); }
 
 static int g_device = 0;
-static int g_nn_mode = 0;   // E3D_NN_MODE / e3d_set_nn_mode: 0 auto, 1 per-query kernel, 2 LDS-bucket kernel
+static int g_nn_mode = 0;   // E3D_NN_MODE / e3d_set_nn_mode: 0 auto, 1 per-query, 2 hash-table buckets, 3 dense rows, 4 dense rows + MFMA filter
 
 // -------------------------------------------------------------------------------------------------
 struct Cloud {
@@ -73,7 +73,7 @@ struct e3d_icp {
   std::vector<std::unique_ptr<Cloud>> clouds;   // movable clouds
   std::unique_ptr<Cloud> fixed;                 // merged fixed cloud (global frame)
   int max_inner = 150;
-  int nn_mode = 0;                              // 0 auto, 1 per-query kernel, 2 hash-table bucket kernel, 3 dense-directory row kernel
+  int nn_mode = 0;                              // 0 auto, 1 per-query kernel, 2 hash-table bucket kernel, 3 dense-directory row kernel, 4 row kernel with MFMA filter
   size_t dense_cell_budget = (size_t)1 << 31;   // max cells of a dense directory (8 GB); hash table beyond
   int rank = 0, world = 1;
   e3d_allreduce_fn allreduce = nullptr;
@@ -278,6 +278,16 @@ static inline float radius_sq(float d) {
   return (float)(r * r);
 }
 
+// dense-directory row kernels: plain (mode 3 / auto) or with the MFMA filter (mode 4); identical results
+static void launch_rows(int mode, const Cloud& tgt, const float4* srcG, const unsigned* order, size_t n, const InvMap& im, float r2,
+                        int* match_pos, float* match_d2, hipStream_t s) {
+  MfParams P;
+  if (mode == 4 && mfma_filter_params(1.0 / (double)tgt.grid.inv_cell, max_singular_value_3x3(tgt.T) * (1.0 + 1e-6), nn_row_span(), r2, &P))
+    launch_nn_mfma(srcG, order, n, tgt.G4.p, tgt.dense_start.p, tgt.grid, im, tgt.qrange, r2, P, match_pos, match_d2, s);
+  else
+    launch_nn_rows(srcG, order, n, tgt.G4.p, tgt.dense_start.p, tgt.grid, im, tgt.qrange, r2, match_pos, match_d2, s);
+}
+
 // NN search + compaction for one directed pair; appends to the correspondence planes.
 // Multi-GPU: every rank holds all clouds and handles the slice [j0, j1) of the source cloud (cell order).
 static void find_pair(e3d_icp* h, Cloud& src, Cloud& tgt, float d, PairJob& job, size_t j0, size_t j1,
@@ -311,8 +321,7 @@ static void find_pair(e3d_icp* h, Cloud& src, Cloud& tgt, float d, PairJob& job,
       sort_pairs_u64_u32(h->keys_a.p, h->keys_b.p, h->vals_a.p, h->vals_b.p, n, tgt.key_bits, h->sort_temp, s);
     }
     if (tgt.has_dense && h->nn_mode != 2)
-      launch_nn_rows(srcG, h->vals_b.p, n, tgt.G4.p, tgt.dense_start.p, tgt.grid, im, tgt.qrange, radius_sq(d),
-                     h->match_pos.p, h->match_d2.p, s);
+      launch_rows(h->nn_mode, tgt, srcG, h->vals_b.p, n, im, radius_sq(d), h->match_pos.p, h->match_d2.p, s);
     else
       launch_nn_cells(srcG, h->vals_b.p, n, tgt.G4.p, tgt.table.p, nullptr, tgt.grid, im, tgt.qrange, radius_sq(d),
                       h->match_pos.p, h->match_d2.p, s);
@@ -732,7 +741,7 @@ int e3d_init(int device) {
 }
 
 int e3d_set_nn_mode(int mode) {
-  if (mode < 0 || mode > 3) { e3d::set_last_error("e3d_set_nn_mode: mode must be 0..3"); return E3D_ERR_INVALID; }
+  if (mode < 0 || mode > 4) { e3d::set_last_error("e3d_set_nn_mode: mode must be 0..4"); return E3D_ERR_INVALID; }
   g_nn_mode = mode;
   return 0;
 }
@@ -867,7 +876,7 @@ int64_t e3d_find_correspondences(const float* sxyz, size_t ns, const float* txyz
         launch_query_keys(src.G4.p, ns, tgt.grid, im, tgt.qrange, h->keys_a.p, h->vals_a.p, s);
         sort_pairs_u64_u32(h->keys_a.p, h->keys_b.p, h->vals_a.p, h->vals_b.p, ns, tgt.key_bits, h->sort_temp, s);
         if (tgt.has_dense && mode != 2)
-          launch_nn_rows(src.G4.p, h->vals_b.p, ns, tgt.G4.p, tgt.dense_start.p, tgt.grid, im, tgt.qrange, radius_sq(d), h->match_pos.p, h->match_d2.p, s);
+          launch_rows(mode, tgt, src.G4.p, h->vals_b.p, ns, im, radius_sq(d), h->match_pos.p, h->match_d2.p, s);
         else
           launch_nn_cells(src.G4.p, h->vals_b.p, ns, tgt.G4.p, tgt.table.p, nullptr, tgt.grid, im, tgt.qrange, radius_sq(d), h->match_pos.p, h->match_d2.p, s);
         order = h->vals_b.p;

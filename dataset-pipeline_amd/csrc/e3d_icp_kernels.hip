@@ -702,6 +702,281 @@ __global__ __launch_bounds__(kBlock, 3) void k_nn_rows(const float4* __restrict_
   if (valid) { match_pos[pos] = best_pos; match_d2[pos] = best_d2; }
 }
 
+// -------------------------------------------------------------------------------------------------
+// MFMA-filtered variant of k_nn_rows (same segments, same staging runs, same results).
+//
+// The scan of a segment is a dense (queries x candidates) squared-distance matrix.  Its entries are first computed
+// APPROXIMATELY on the matrix cores -- |q|^2 + |c|^2 - 2 q.c as one K = 16 f16 MFMA per 32 x 32 tile, with coordinates
+// taken relative to a per-segment origin, scaled by a power of two and split into f16 hi + lo parts so that the result
+// is within a PROVEN bound of the exact f32 value (host: mfma_filter_params) -- and only candidates whose approximate
+// distance is within that bound of the running approximate minimum (or of the radius) are evaluated EXACTLY, with the
+// very arithmetic (sqdist_l2) and the (d2, original index) order of the other kernels.  Every candidate that could be
+// the exact winner passes the filter, so the output is bit-identical; the VALU work per pair drops from ~6
+// instructions to ~0.02 (a min-tree over the accumulators) plus the per-candidate operand packing.
+// The query's own cell row is scanned first: most queries meet their nearest neighbour there, after which the
+// filter rarely fires.
+//
+// Operand layout (v_mfma_f32_32x32x16_f16: A = candidates as rows, B = queries as columns; lane l supplies row / column
+// l & 31 and the eight k values 8 * (l >> 5) .. + 7):
+//   k:   0     1     2     3    4     5     6     7   |  8     9     10    11   12    13    14    15
+//   A:   chx   chy   chz   nch  clx   cly   clz   ncl |  chx   chy   chz   1    clx   cly   clz   1
+//   B:  -2qhx -2qhy -2qhz  1   -2qhx -2qhy -2qhz  1   | -2qlx -2qly -2qlz  nqh -2qlx -2qly -2qlz  nql
+// (h / l = f16 hi / lo part of the scaled relative coordinate, n.. = hi / lo part of |hi + lo|^2.)
+// -------------------------------------------------------------------------------------------------
+typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
+typedef float f16_t __attribute__((ext_vector_type(16)));
+typedef __fp16 fp16x2_t __attribute__((ext_vector_type(2)));
+
+constexpr int kMfCap = 256;                     // candidates staged per wave and batch
+constexpr float kMfSentinel = 60000.0f;         // |.|^2 part of padding rows / columns: never passes the filter
+
+struct MfLds {
+  uint4 a[kMfCap / 32][2][32];                  // operand A parts: [tile][k half][row]
+  float4 c[kMfCap];                             // exact coordinates + original index (for the exact evaluation)
+};
+
+__device__ __forceinline__ unsigned pk_rtz(float a, float b) {
+  return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a, b));
+}
+__device__ __forceinline__ float h_lo(unsigned w) { return (float)__builtin_bit_cast(fp16x2_t, w)[0]; }
+__device__ __forceinline__ float h_hi(unsigned w) { return (float)__builtin_bit_cast(fp16x2_t, w)[1]; }
+
+// hi / lo split of a scaled relative position: words (hx,hy) (hz,0) (lx,ly) (lz,0) and |hi + lo|^2
+struct MfSplit { unsigned hxy, hz0, lxy, lz0; float n; };
+__device__ __forceinline__ MfSplit mf_split(float x, float y, float z) {
+  MfSplit r;
+  r.hxy = pk_rtz(x, y); r.hz0 = pk_rtz(z, 0.f);
+  const float hx = h_lo(r.hxy), hy = h_hi(r.hxy), hz = h_lo(r.hz0);
+  const float rx = x - hx, ry = y - hy, rz = z - hz;                // exact
+  r.lxy = pk_rtz(rx, ry); r.lz0 = pk_rtz(rz, 0.f);
+  const float cx = hx + h_lo(r.lxy), cy = hy + h_hi(r.lxy), cz = hz + h_lo(r.lz0);   // exact sums
+  r.n = cx * cx + (cy * cy + cz * cz);
+  return r;
+}
+// (hi, lo) f16 parts of a non-negative norm as the high halves of two words whose low halves are given
+__device__ __forceinline__ void mf_norm_parts(float n, unsigned lowA, unsigned lowB, unsigned& wA, unsigned& wB) {
+  const unsigned nh = pk_rtz(0.f, n);                               // high half = rtz(n)
+  const float rest = n - h_hi(nh);
+  const unsigned nl = pk_rtz(0.f, rest);
+  wA = (lowA & 0xFFFFu) | (nh & 0xFFFF0000u);
+  wB = (lowB & 0xFFFFu) | (nl & 0xFFFF0000u);
+}
+
+// MfParams (e3d_icp_kernels.hpp): S = power-of-two scale of the relative coordinates, r2s = r^2 S^2, eta2 = 2 eta (eta bounds
+// |mfma value - scaled exact f32 d2| apart from the coordinate representation), delta4 = 4 Delta, delta4sq = 4 Delta^2
+// (Delta bounds the error of a scaled point-to-point distance caused by the hi/lo representation).
+__device__ __forceinline__ float mf_threshold(float am, const MfParams& P) {
+  return am + P.eta2 + P.delta4 * sqrtf(fmaxf(am, 0.f)) + P.delta4sq;
+}
+
+__device__ __forceinline__ float mf_min16(const f16_t& v) {
+  const float a = fminf(fminf(v[0], v[1]), v[2]), b = fminf(fminf(v[3], v[4]), v[5]);
+  const float c = fminf(fminf(v[6], v[7]), v[8]), d = fminf(fminf(v[9], v[10]), v[11]);
+  const float e = fminf(fminf(v[12], v[13]), v[14]);
+  return fminf(fminf(fminf(a, b), fminf(c, d)), fminf(e, v[15]));
+}
+
+// one query column group: running approximate minimum + filter threshold, exact best so far
+struct MfBest {
+  float am, thr;
+  float qx, qy, qz;
+  float bd; unsigned boi, bt;
+};
+
+__device__ __forceinline__ void mf_process(const f16_t& acc, MfBest& B, const MfLds& L, int tile, int g, unsigned base, unsigned nb,
+                                           const MfParams& P) {
+  const float tm = mf_min16(acc);
+  if (!__ballot(tm <= B.thr)) return;
+#pragma unroll
+  for (int reg = 0; reg < 16; ++reg) {
+    if (acc[reg] <= B.thr) {
+      const int row = (reg & 3) + 8 * (reg >> 2) + 4 * g;
+      const unsigned t = (unsigned)(tile * 32 + row);
+      const float4 cc = L.c[t];
+      const float d2 = sqdist_l2(B.qx, B.qy, B.qz, cc.x, cc.y, cc.z);
+      const unsigned oi = __float_as_uint(cc.w);
+      if (t < nb && (d2 < B.bd || (d2 == B.bd && oi < B.boi))) { B.bd = d2; B.boi = oi; B.bt = base + t; }
+      if (acc[reg] < B.am) { B.am = acc[reg]; B.thr = mf_threshold(B.am, P); }
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock, 3) void k_nn_mfma(const float4* __restrict__ Gsrc, const unsigned* __restrict__ order,
+                                                       size_t n, const float4* __restrict__ Gtgt,
+                                                       const unsigned* __restrict__ S, GridDesc g, InvMap im,
+                                                       QueryRange qr, float r2, int row_span, MfParams P,
+                                                       int* __restrict__ match_pos, float* __restrict__ match_d2) {
+  __shared__ MfLds lds[kBlock / kWave];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  MfLds& L = lds[w];
+  const int col = lane & 31, gh = lane >> 5;
+  const size_t pos = ((size_t)blockIdx.x * (kBlock / kWave) + w) * kWave + lane;
+  const bool valid = pos < n;
+  const unsigned j = valid ? order[pos] : 0u;
+  const float4 q = valid ? Gsrc[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+  int cx = 0, cy = 0, cz = 0;
+  const unsigned long long key = valid ? query_cell_key(q, im, g, qr, cx, cy, cz) : kEmptyKey;
+  const int kx = cx - qr.lo[0], ky = cy - qr.lo[1], kz = cz - qr.lo[2];
+
+  float best_d2 = r2;
+  unsigned best_oi = 0u;
+  int best_pos = -1;
+  const float kInf = __uint_as_float(0x7f800000u);
+  const float thr0 = mf_threshold(P.r2s, P);
+  const f16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const unsigned one_hi = 0x3C000000u;                              // f16 1.0 in the high half
+
+  unsigned long long remaining = __ballot(key != kEmptyKey);
+  while (remaining) {
+    const int f = __ffsll((long long)remaining) - 1;
+    const int fky = rdlane_i(ky, f), fkz = rdlane_i(kz, f), fkx = rdlane_i(kx, f);
+    const unsigned long long seg =
+        __ballot(key != kEmptyKey && ky == fky && kz == fkz && (unsigned)(kx - fkx) <= (unsigned)row_span) & remaining;
+    const int a = __popcll(seg);
+    const int last = 63 - __clzll((long long)seg);
+    const int lkx = rdlane_i(kx, last);
+    const int xa = max(fkx - 1, 0), xb = min(lkx + 1, (int)qr.D[0] - 1);
+
+    // directory words of the 9 neighbour rows, the queries' own row first (lanes 0..8)
+    unsigned dst = 0u, dcnt = 0u;
+    if (lane < 9) {
+      const int rid = (int)((0x862075314ull >> (4 * lane)) & 15ull);       // 4, 1, 3, 5, 7, 0, 2, 6, 8
+      const int y = fky + (rid % 3) - 1, z = fkz + (rid / 3) - 1;
+      if (y >= 0 && z >= 0 && y < (int)qr.D[1] && z < (int)qr.D[2]) {
+        const size_t row = ((size_t)z * qr.D[1] + (size_t)y) * qr.D[0];
+        dst = S[row + xa];
+        dcnt = S[row + xb + 1] - dst;
+      }
+    }
+    unsigned rs[9], rl[9];
+    unsigned total = 0;
+#pragma unroll
+    for (int r = 0; r < 9; ++r) { rs[r] = rdlane_u(dst, r); rl[r] = rdlane_u(dcnt, r); total += rl[r]; }
+
+    // segment origin: midpoint of its first and last query (wave-uniform)
+    const float ox = 0.5f * (__shfl(q.x, f, 64) + __shfl(q.x, last, 64));
+    const float oy = 0.5f * (__shfl(q.y, f, 64) + __shfl(q.y, last, 64));
+    const float oz = 0.5f * (__shfl(q.z, f, 64) + __shfl(q.z, last, 64));
+
+    // B operands: column group G holds query slots 32 G + col
+    h8_t Bop[2];
+    MfBest Q[2];
+#pragma unroll
+    for (int G = 0; G < 2; ++G) {
+      const int slot = 32 * G + col;
+      const int owner = (f + slot) & 63;
+      const float qx = __shfl(q.x, owner, 64), qy = __shfl(q.y, owner, 64), qz = __shfl(q.z, owner, 64);
+      const bool qv = slot < a;
+      Q[G].qx = qx; Q[G].qy = qy; Q[G].qz = qz;
+      Q[G].am = P.r2s; Q[G].thr = qv ? thr0 : -kInf;
+      Q[G].bd = r2; Q[G].boi = 0u; Q[G].bt = 0xFFFFFFFFu;
+      const MfSplit sp = mf_split(qv ? (qx - ox) * P.S : 0.f, qv ? (qy - oy) * P.S : 0.f, qv ? (qz - oz) * P.S : 0.f);
+      uint4 wv;
+      if (gh == 0) {
+        const unsigned w0 = pk_rtz(-2.f * h_lo(sp.hxy), -2.f * h_hi(sp.hxy));
+        const unsigned w1 = (pk_rtz(-2.f * h_lo(sp.hz0), 0.f) & 0xFFFFu) | one_hi;
+        wv = make_uint4(w0, w1, w0, w1);
+      } else {
+        const unsigned w0 = pk_rtz(-2.f * h_lo(sp.lxy), -2.f * h_hi(sp.lxy));
+        const unsigned w1l = pk_rtz(-2.f * h_lo(sp.lz0), 0.f);
+        unsigned w1, w3;
+        mf_norm_parts(qv ? sp.n : kMfSentinel, w1l, w1l, w1, w3);
+        wv = make_uint4(w0, w1, w0, w3);
+      }
+      Bop[G] = __builtin_bit_cast(h8_t, wv);
+    }
+    const bool two = a > 32;
+
+    for (unsigned base = 0; base < total; base += kMfCap) {
+      const unsigned nb = min((unsigned)kMfCap, total - base);
+      const int ntiles = (int)((nb + 31u) >> 5);
+      // ---- stage [base, base + nb): resolve indices, issue the loads, pack the operands ----
+      unsigned m[kMfCap / kWave];
+#pragma unroll
+      for (int k = 0; k < kMfCap / kWave; ++k) m[k] = 0xFFFFFFFFu;
+      {
+        unsigned p = 0;
+#pragma unroll
+        for (int r = 0; r < 9; ++r) {
+#pragma unroll
+          for (int k = 0; k < kMfCap / kWave; ++k) {
+            const unsigned t = base + (unsigned)(k * kWave + lane) - p;
+            if (t < rl[r]) m[k] = rs[r] + t;
+          }
+          p += rl[r];
+        }
+      }
+      float4 cv[kMfCap / kWave];
+#pragma unroll
+      for (int k = 0; k < kMfCap / kWave; ++k) cv[k] = (m[k] != 0xFFFFFFFFu) ? Gtgt[m[k]] : make_float4(kInf, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int k = 0; k < kMfCap / kWave; ++k) {
+        const unsigned t = (unsigned)(k * kWave + lane);
+        if (t < (unsigned)(ntiles * 32)) {
+          const bool cvd = m[k] != 0xFFFFFFFFu;
+          const float4 c = cv[k];
+          const MfSplit sp = mf_split(cvd ? (c.x - ox) * P.S : 0.f, cvd ? (c.y - oy) * P.S : 0.f, cvd ? (c.z - oz) * P.S : 0.f);
+          unsigned w1, w3;
+          mf_norm_parts(cvd ? sp.n : kMfSentinel, sp.hz0, sp.lz0, w1, w3);
+          L.a[t >> 5][0][t & 31] = make_uint4(sp.hxy, w1, sp.lxy, w3);
+          L.a[t >> 5][1][t & 31] = make_uint4(sp.hxy, (sp.hz0 & 0xFFFFu) | one_hi, sp.lxy, (sp.lz0 & 0xFFFFu) | one_hi);
+          L.c[t] = c;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+      for (int tile = 0; tile < ntiles; ++tile) {
+        const h8_t Aop = __builtin_bit_cast(h8_t, L.a[tile][gh][col]);
+        const f16_t acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Aop, Bop[0], zero16, 0, 0, 0);
+        if (two) {
+          const f16_t acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Aop, Bop[1], zero16, 0, 0, 0);
+          mf_process(acc0, Q[0], L, tile, gh, base, nb, P);
+          mf_process(acc1, Q[1], L, tile, gh, base, nb, P);
+        } else {
+          mf_process(acc0, Q[0], L, tile, gh, base, nb, P);
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+
+    // per column group: flat index -> target position, combine the two row halves, hand to the owning lane
+    float rd2 = r2; unsigned roi = 0u; int rpos = -1;
+    const int slot_of_lane = (lane - f) & 63;
+#pragma unroll
+    for (int G = 0; G < 2; ++G) {
+      int lb_pos = -1;
+      {
+        unsigned p = 0;
+#pragma unroll
+        for (int r = 0; r < 9; ++r) {
+          if (Q[G].bt - p < rl[r]) lb_pos = (int)(rs[r] + (Q[G].bt - p));
+          p += rl[r];
+        }
+      }
+      float lb_d2 = Q[G].bd; unsigned lb_oi = Q[G].boi;
+      {
+        const float od2 = __shfl_xor(lb_d2, 32, 64);
+        const unsigned ooi = (unsigned)__shfl_xor((int)lb_oi, 32, 64);
+        const int opos = __shfl_xor(lb_pos, 32, 64);
+        if (od2 < lb_d2 || (od2 == lb_d2 && ooi < lb_oi)) { lb_d2 = od2; lb_oi = ooi; lb_pos = opos; }
+      }
+      const float sd2 = __shfl(lb_d2, slot_of_lane & 31, 64);
+      const unsigned soi = (unsigned)__shfl((int)lb_oi, slot_of_lane & 31, 64);
+      const int spos = __shfl(lb_pos, slot_of_lane & 31, 64);
+      if ((slot_of_lane >> 5) == G) { rd2 = sd2; roi = soi; rpos = spos; }
+    }
+    if ((seg >> lane) & 1ull) {
+      if (rd2 < best_d2 || (rd2 == best_d2 && roi < best_oi)) { best_d2 = rd2; best_oi = roi; best_pos = rpos; }
+    }
+    remaining &= ~seg;
+  }
+  if (valid) { match_pos[pos] = best_pos; match_d2[pos] = best_d2; }
+}
+
 // flags -> per-block counts (first stage of the order-preserving compaction)
 __global__ __launch_bounds__(kBlock) void k_match_block_counts(const int* __restrict__ match_pos, size_t n,
                                                                unsigned* __restrict__ block_counts,
@@ -1194,6 +1469,49 @@ void launch_nn_rows(const float4* Gsrc, const unsigned* order, size_t n, const f
   hipLaunchKernelGGL(k_nn_rows, dim3((unsigned)div_up(n, kBlock)), dim3(kBlock), 0, s, Gsrc, order, n, Gtgt, dense_start,
                      g, im, qr, r2, row_span_setting(), match_pos, match_d2);
 }
+
+// Filter constants of k_nn_mfma for a target grid (cell = local cell size, sigma_max = largest singular value of the
+// target's local -> global linear part).  Returns false if no valid scale exists (the caller uses k_nn_rows).
+// Geometry (segment origin = midpoint of the first and last query; rs = row span in cells): a candidate lies within
+// sqrt((rs/2 + 2)^2 + 8) cells of the origin, a query within sqrt((rs/2 + 1)^2 + 2) cells (2 % margin for the f32 cell mapping).
+bool mfma_filter_params(double cell, double sigma_max, int row_span, float r2, MfParams* P) {
+  const double rs = (double)row_span;
+  const double ext_c = 1.02 * sigma_max * cell * std::sqrt((0.5 * rs + 2.0) * (0.5 * rs + 2.0) + 8.0);
+  const double ext_q = 1.02 * sigma_max * cell * std::sqrt((0.5 * rs + 1.0) * (0.5 * rs + 1.0) + 2.0);
+  if (!(ext_c > 0) || !std::isfinite(ext_c)) return false;
+  const int e = (int)std::floor(std::log2(31.0 / ext_c));
+  if (e < -100 || e > 100) return false;
+  const double S = std::ldexp(1.0, e);
+  const double Mc = ext_c * S, Mq = ext_q * S;                     // <= 31: f16 ulp <= 2^-6 for the hi parts
+  const double r2s = (double)r2 * S * S;
+  if (!(r2s < 3.0e4) || !(r2s > 1e-30)) return false;
+  auto ulp16 = [](double v) { return std::ldexp(1.0, (int)std::floor(std::log2(std::max(v, 1e-30))) - 10); };
+  const double u = std::ldexp(1.0, -24);
+  const double sum_abs = 2.0 * Mq * Mc * (1.0 + std::ldexp(1.0, -8)) + Mc * Mc + Mq * Mq;
+  // accumulation of 16 products in f32 + rounding of the two norms (5 ops each) + residual of their hi/lo split
+  // (rtz: below one ulp of the lo part) + f32 rounding of the exact scaled d2; factor 3 for the unspecified internal
+  // rounding of the matrix core
+  const double eta = 3.0 * (16.0 * u * sum_abs + 6.0 * u * (Mc * Mc + Mq * Mq) + std::ldexp(1.0, -10) * (ulp16(Mc * Mc) + ulp16(Mq * Mq)) +
+                            4.0 * u * (r2s + Mc * Mc)) + 1e-6;
+  // coordinate representation: f32 rounding of (p - o) (<= 2^-24 * 32) + residual of the rtz hi/lo split, at worst a
+  // flushed f16 denormal (2^-14); per point sqrt(3) x that, two points
+  const double delta = 2.0 * std::sqrt(3.0) * (std::ldexp(1.0, -14) + 32.0 * u + std::ldexp(1.0, -16));
+  P->S = (float)S;
+  P->r2s = (float)(r2s * (1.0 + 1e-6));
+  P->eta2 = (float)(2.0 * eta);
+  P->delta4 = (float)(4.0 * delta);
+  P->delta4sq = (float)(4.0 * delta * delta);
+  return true;
+}
+
+void launch_nn_mfma(const float4* Gsrc, const unsigned* order, size_t n, const float4* Gtgt, const unsigned* dense_start,
+                    const GridDesc& g, const InvMap& im, const QueryRange& qr, float r2, const MfParams& P, int* match_pos,
+                    float* match_d2, hipStream_t s) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_nn_mfma, dim3((unsigned)div_up(n, kBlock)), dim3(kBlock), 0, s, Gsrc, order, n, Gtgt, dense_start,
+                     g, im, qr, r2, row_span_setting(), P, match_pos, match_d2);
+}
+int nn_row_span() { return row_span_setting(); }
 
 void launch_dense_counts(const unsigned long long* keys, size_t n, const QueryRange& qr, unsigned* counts, hipStream_t s) {
   if (!n) return;

@@ -63,6 +63,12 @@ void launch_nn_cells(const float4* Gsrc, const unsigned* order, size_t n, const 
 void launch_nn_rows(const float4* Gsrc, const unsigned* order, size_t n, const float4* Gtgt, const unsigned* dense_start,
                     const GridDesc& g, const InvMap& im, const QueryRange& qr, float r2, int* match_pos, float* match_d2,
                     hipStream_t s);
+struct MfParams { float S, r2s, eta2, delta4, delta4sq; };      // filter constants of k_nn_mfma (see mfma_filter_params)
+bool mfma_filter_params(double cell, double sigma_max, int row_span, float r2, MfParams* P);
+void launch_nn_mfma(const float4* Gsrc, const unsigned* order, size_t n, const float4* Gtgt, const unsigned* dense_start,
+                    const GridDesc& g, const InvMap& im, const QueryRange& qr, float r2, const MfParams& P, int* match_pos,
+                    float* match_d2, hipStream_t s);
+int nn_row_span();
 void launch_dense_counts(const unsigned long long* keys, size_t n, const QueryRange& qr, unsigned* counts, hipStream_t s);
 void sort_pairs_u32_u32(unsigned* keys_in, unsigned* keys_out, unsigned* vals_in, unsigned* vals_out, size_t n,
                         int end_bit, DevBuf<char>& temp, hipStream_t s);

@@ -169,8 +169,8 @@ inline void ldlt_solve_upper(const double* A, int n, const double* b, double* x,
   for (int i = 0; i < n; ++i) x[perm[i]] = y[i];
 }
 
-// Smallest singular value of the 3x3 linear part of a row-major 3x4 affine (f64, Jacobi on L^T L).
-inline double min_singular_value_3x3(const float* T) {
+// Smallest / largest singular value of the 3x3 linear part of a row-major 3x4 affine (f64, Jacobi on L^T L).
+inline void singular_value_range_3x3(const float* T, double* smin, double* smax) {
   double A[9];
   for (int i = 0; i < 3; ++i)
     for (int j = 0; j < 3; ++j) {
@@ -201,11 +201,16 @@ inline double min_singular_value_3x3(const float* T) {
         }
       }
   }
-  double m = A[0];
+  double m = A[0], M = A[0];
   if (A[4] < m) m = A[4];
   if (A[8] < m) m = A[8];
-  return m > 0 ? std::sqrt(m) : 0.0;
+  if (A[4] > M) M = A[4];
+  if (A[8] > M) M = A[8];
+  *smin = m > 0 ? std::sqrt(m) : 0.0;
+  *smax = M > 0 ? std::sqrt(M) : 0.0;
 }
+inline double min_singular_value_3x3(const float* T) { double a, b; singular_value_range_3x3(T, &a, &b); return a; }
+inline double max_singular_value_3x3(const float* T) { double a, b; singular_value_range_3x3(T, &a, &b); return b; }
 
 // Inverse of the 3x3 linear part (f64 adjugate), row-major out[9]; returns false if singular.
 inline bool invert_3x3(const float* T, double* out) {

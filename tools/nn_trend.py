@@ -1,4 +1,4 @@
-"""Per-iteration NN-phase time of the row kernels (mode 3 = no pruning, 4 = per-query row pruning) over a whole ICP run.
+"""Per-iteration NN-phase time of the row kernels (mode 3 = k_nn_rows, 4 = k_nn_mfma, the MFMA-filtered variant) over a whole ICP run.
 usage: python tools/nn_trend.py [points_per_scan] [iterations]"""
 import importlib, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -92,6 +92,11 @@ SIGNATURES = {
     "e3d_reg_color_finish": (C.c_int, [C.c_void_p, C.c_int]),
     "e3d_reg_get_image_pose": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "e3d_reg_update_observations": (C.c_int, [C.c_void_p, C.c_int]),
+    "e3d_reg_set_scan_points": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "e3d_reg_count_scan_observations": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
+    "e3d_reg_get_scan_observation_counts": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "e3d_reg_set_scan_observation_counts": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "e3d_reg_ground_truth_depth": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "e3d_reg_set_cache_observations": (C.c_int, [C.c_void_p, C.c_int]),
     "e3d_reg_determine_observed_indices": (C.c_int, [C.c_void_p]),
     "e3d_reg_get_observed_indices": (C.c_int64, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
@@ -476,6 +481,35 @@ class RegProblem:
 
     def update_observations(self, border_size=1):
         self._chk(lib().e3d_reg_update_observations(self._h, border_size), "e3d_reg_update_observations")
+
+    # ---- GroundTruthCreator (f4) -------------------------------------------------------------------------------------
+    def set_scan_points(self, xyz):
+        xyz = np.ascontiguousarray(xyz, np.float32)
+        self._n_scan = xyz.shape[0]
+        self._chk(lib().e3d_reg_set_scan_points(self._h, C.c_void_p(xyz.ctypes.data), xyz.shape[0]), "e3d_reg_set_scan_points")
+
+    def count_scan_observations(self, image_id, mask=None, excluded_flag=2):
+        m = np.ascontiguousarray(mask, np.uint8) if mask is not None else None
+        self._chk(lib().e3d_reg_count_scan_observations(self._h, image_id, C.c_void_p(m.ctypes.data) if m is not None else None, excluded_flag),
+                  "e3d_reg_count_scan_observations")
+
+    def scan_observation_counts(self):
+        out = np.zeros(self._n_scan, np.int32)
+        self._chk(lib().e3d_reg_get_scan_observation_counts(self._h, C.c_void_p(out.ctypes.data)), "e3d_reg_get_scan_observation_counts")
+        return out
+
+    def set_scan_observation_counts(self, counts):
+        counts = np.ascontiguousarray(counts, np.int32)
+        assert counts.shape[0] == self._n_scan
+        self._chk(lib().e3d_reg_set_scan_observation_counts(self._h, C.c_void_p(counts.ctypes.data)), "e3d_reg_set_scan_observation_counts")
+
+    def ground_truth_depth(self, image_id, width, height, mask=None, excluded_flag=2, min_count=2):
+        """-> (gt_depth, occlusion_depth), both (height, width) float32."""
+        m = np.ascontiguousarray(mask, np.uint8) if mask is not None else None
+        gt = np.zeros((height, width), np.float32); occ = np.zeros((height, width), np.float32)
+        self._chk(lib().e3d_reg_ground_truth_depth(self._h, image_id, C.c_void_p(m.ctypes.data) if m is not None else None, excluded_flag,
+                                                   min_count, C.c_void_p(gt.ctypes.data), C.c_void_p(occ.ctypes.data)), "e3d_reg_ground_truth_depth")
+        return gt, occ
 
     def set_cache_observations(self, enabled):
         """Optimizer::set_cache_observations: update_observations re-projects the cached point index lists."""

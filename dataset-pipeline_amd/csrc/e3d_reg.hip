@@ -718,6 +718,33 @@ __global__ __launch_bounds__(kBlock) void k_obs_compact(const int* __restrict__ 
   o_idx[o] = (unsigned)v; o_x[o] = ox[k]; o_y[o] = oy[k]; o_s[o] = os[k];
 }
 
+// ==== f4: GroundTruthCreator visibility (src/exe/ground_truth_creator.cc:45-86, :152-189) =========================================
+// mode 0: counts[i] += 1 for every scan point visible in the image; mode 1: ground-truth depth = min z over the visible
+// points that were counted at least `min_count` times.  "Visible" = in front of the camera, inside the image at the
+// highest available resolution, not behind the occlusion depth (+ threshold), not under an eval-obs mask pixel.
+template <int M>
+__global__ __launch_bounds__(kBlock) void k_scan_visibility(const float4* __restrict__ pts, size_t n, Pose P, CamLevel cam,
+                                                            const float* __restrict__ occlusion, float occlusion_threshold,
+                                                            const unsigned char* __restrict__ mask, int excluded_flag, int mode,
+                                                            int min_count, int* __restrict__ counts, unsigned* __restrict__ gt_depth) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (mode == 1 && counts[i] < min_count) return;
+  const float4 p = pts[i];
+  float X, Yc, Z;
+  rt(P, p.x, p.y, p.z, X, Yc, Z);
+  if (!(Z > 0.f)) return;
+  float ixf, iyf;
+  cam_normalized_to_image<M>(cam, X / Z, Yc / Z, ixf, iyf);
+  const int ix = f2i(ixf + 0.5f), iy = f2i(iyf + 0.5f);
+  if (!(ix >= 0 && iy >= 0 && ix < cam.width && iy < cam.height)) return;
+  const size_t px = (size_t)iy * cam.width + ix;
+  if (!(occlusion[px] + occlusion_threshold >= Z)) return;
+  if (mask && mask[px] == excluded_flag) return;
+  if (mode == 0) counts[i] += 1;
+  else atomicMin(&gt_depth[px], __float_as_uint(Z));       // Z > 0: the bit pattern orders like the value
+}
+
 // ==== a22 ===============================================================================================================================
 __global__ __launch_bounds__(kBlock) void k_obs_mark(const unsigned* __restrict__ o_idx, size_t n_obs, int* __restrict__ row_of_point) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1169,6 +1196,11 @@ struct e3d_reg {
   float min_occlusion_depth = 0.05f, max_occlusion_depth = 100.f;     // opt::Parameters defaults (parameters.h:60-61)
   bool mask_occlusion_boundaries = true;
   bool cache_observations = false;        // Optimizer::cache_observations_ (optimizer.h)
+  DevBuf<float4> scan_pts;                // f4: evaluation scan points + their observation counts
+  DevBuf<int> scan_counts;
+  DevBuf<unsigned char> eval_mask;
+  DevBuf<unsigned> gt_depth;
+  size_t n_scan = 0;
   // scratch
   DevBuf<int> valid;
   DevBuf<float> tx, ty, ts;
@@ -2364,6 +2396,79 @@ int e3d_determine_point_neighbors(const float* xyz, size_t n, const uint8_t* sca
   } else {
     run(std::vector<float>(xyz, xyz + 3 * n), nullptr, true);
   }
+  return 0;
+  R_CATCH()
+}
+
+// ---- f4: GroundTruthCreator -------------------------------------------------------------------------------------------------
+int e3d_reg_set_scan_points(e3d_reg_t* h, const float* xyz, size_t n) {
+  R_TRY
+  if (!h || (n && !xyz)) throw Error(E3D_ERR_INVALID, "null argument");
+  if (n >= (size_t)1 << 31) throw Error(E3D_ERR_INVALID, "more than 2^31-1 scan points");
+  h->n_scan = n;
+  h->scan_pts.reserve(n); h->scan_counts.reserve(n);
+  if (n) {
+    DevBuf<float> raw;
+    raw.reserve(3 * n);
+    copy_in(raw.p, xyz, sizeof(float) * 3 * n, h->stream);
+    hipLaunchKernelGGL(k_xyz_to_float4, dim3(nblk(n)), dim3(kBlock), 0, h->stream, raw.p, n, h->scan_pts.p);
+    E3D_HIP(hipMemsetAsync(h->scan_counts.p, 0, sizeof(int) * n, h->stream));
+    rsync(h);
+  }
+  return 0;
+  R_CATCH()
+}
+static void scan_visibility(e3d_reg* h, int image_id, const uint8_t* mask, int excluded_flag, int mode, int min_count) {
+  ImageDev& im = get_image(h, image_id);
+  const Intrin& in = h->intr.at(im.intrinsics_id);
+  // RenderDepthMap(intrinsics, image, intrinsics.min_image_scale, ...) + intrinsics.model(0): the highest resolution
+  if (e3d_reg_render_depth(h, image_id, in.min_image_scale, nullptr) < 0) throw Error(E3D_ERR_INVALID, e3d_last_error());
+  const CamLevel& cam = in.levels[0];
+  const size_t px = (size_t)cam.width * cam.height;
+  if (mask) { h->eval_mask.reserve(px); copy_in(h->eval_mask.p, mask, px, h->stream); }
+  if (h->n_scan)
+    E3D_CAM_SWITCH(in.type, hipLaunchKernelGGL(k_scan_visibility<M>, dim3(nblk(h->n_scan)), dim3(kBlock), 0, h->stream, h->scan_pts.p,
+                                               h->n_scan, im.pose, cam, im.depth.p, h->prm.occlusion_depth_threshold,
+                                               mask ? h->eval_mask.p : nullptr, excluded_flag, mode, min_count, h->scan_counts.p,
+                                               h->gt_depth.p));
+}
+int e3d_reg_count_scan_observations(e3d_reg_t* h, int image_id, const uint8_t* mask, int excluded_flag) {
+  R_TRY
+  if (!h) throw Error(E3D_ERR_INVALID, "null handle");
+  scan_visibility(h, image_id, mask, excluded_flag, 0, 0);
+  rsync(h);
+  return 0;
+  R_CATCH()
+}
+int e3d_reg_get_scan_observation_counts(e3d_reg_t* h, int32_t* counts) {
+  R_TRY
+  if (!h || (!counts && h->n_scan)) throw Error(E3D_ERR_INVALID, "null argument");
+  if (h->n_scan) copy_out(counts, h->scan_counts.p, sizeof(int) * h->n_scan, h->stream);
+  rsync(h);
+  return 0;
+  R_CATCH()
+}
+int e3d_reg_set_scan_observation_counts(e3d_reg_t* h, const int32_t* counts) {
+  R_TRY
+  if (!h || (!counts && h->n_scan)) throw Error(E3D_ERR_INVALID, "null argument");
+  if (h->n_scan) copy_in(h->scan_counts.p, counts, sizeof(int) * h->n_scan, h->stream);
+  rsync(h);
+  return 0;
+  R_CATCH()
+}
+int e3d_reg_ground_truth_depth(e3d_reg_t* h, int image_id, const uint8_t* mask, int excluded_flag, int min_count, float* gt_depth,
+                               float* occlusion_depth) {
+  R_TRY
+  if (!h) throw Error(E3D_ERR_INVALID, "null handle");
+  ImageDev& im = get_image(h, image_id);
+  const CamLevel& cam = h->intr.at(im.intrinsics_id).levels[0];
+  const size_t px = (size_t)cam.width * cam.height;
+  h->gt_depth.reserve(px);
+  hipLaunchKernelGGL(k_fill_f32, dim3(nblk(px)), dim3(kBlock), 0, h->stream, reinterpret_cast<float*>(h->gt_depth.p), px, INFINITY);
+  scan_visibility(h, image_id, mask, excluded_flag, 1, min_count);
+  if (gt_depth) copy_out(gt_depth, h->gt_depth.p, sizeof(float) * px, h->stream);
+  if (occlusion_depth) copy_out(occlusion_depth, im.depth.p, sizeof(float) * px, h->stream);
+  rsync(h);
   return 0;
   R_CATCH()
 }

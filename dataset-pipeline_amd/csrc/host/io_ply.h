@@ -309,6 +309,31 @@ inline int savePLYFileBinaryXYZI(const std::string& path, const std::vector<floa
   return f ? 0 : -1;
 }
 
+// pcl::io::savePLYFileBinary of a pcl::PointXYZ cloud (ground_truth_creator.cc:414): x y z f32 and PCL's camera element
+inline int savePLYFileBinaryXYZPcl(const std::string& path, const std::vector<float>& xyz) {
+  std::ofstream f(path, std::ios::binary);
+  if (!f) { std::cerr << "[savePLYFile] cannot open " << path << std::endl; return -1; }
+  const size_t n = xyz.size() / 3;
+  f << "ply\nformat binary_little_endian 1.0\ncomment PCL generated\nelement vertex " << n << "\n"
+    << "property float x\nproperty float y\nproperty float z\n"
+    << "element camera 1\nproperty float view_px\nproperty float view_py\nproperty float view_pz\n"
+    << "property float x_axisx\nproperty float x_axisy\nproperty float x_axisz\n"
+    << "property float y_axisx\nproperty float y_axisy\nproperty float y_axisz\n"
+    << "property float z_axisx\nproperty float z_axisy\nproperty float z_axisz\n"
+    << "property float focal\nproperty float scalex\nproperty float scaley\nproperty float centerx\nproperty float centery\n"
+    << "property int viewportx\nproperty int viewporty\nproperty float k1\nproperty float k2\nend_header\n";
+  f.write(reinterpret_cast<const char*>(xyz.data()), (std::streamsize)(xyz.size() * sizeof(float)));
+  const float cam_f[12] = {0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0, 1};
+  f.write(reinterpret_cast<const char*>(cam_f), sizeof cam_f);
+  const float zeros5[5] = {0, 0, 0, 0, 0};
+  f.write(reinterpret_cast<const char*>(zeros5), sizeof zeros5);
+  const int32_t vp[2] = {(int32_t)n, 1};
+  f.write(reinterpret_cast<const char*>(vp), sizeof vp);
+  const float zeros2[2] = {0, 0};
+  f.write(reinterpret_cast<const char*>(zeros2), sizeof zeros2);
+  return f ? 0 : -1;
+}
+
 // minimal writer used by tests / examples: x y z as binary f32
 inline int savePLYFileBinaryXYZ(const std::string& path, const std::vector<float>& xyz) {
   std::ofstream f(path, std::ios::binary);

@@ -440,8 +440,14 @@ class Problem {
 
   // OcclusionGeometry::AddMesh / AddSplats (occlusion_geometry.cc:64-139): a .ply mesh (scaled by the global scale_factor) or a
   // MeshLab project of meshes (each with its own Sim3 pose)
-  bool AddOcclusionMesh(const std::string& path, bool compute_edges) {
-    auto add = [&](const std::string& ply, const float* T) {
+  bool AddOcclusionMesh(const std::string& path, bool compute_edges, const float* left = nullptr) {
+    auto add = [&](const std::string& ply, const float* T_mesh) {
+      float T[12];
+      for (int i = 0; i < 12; ++i) T[i] = T_mesh[i];
+      if (left)        // transformation * global_T_mesh (occlusion_geometry.cc:84,113), as a product of the two 3x4 matrices
+        for (int r = 0; r < 3; ++r)
+          for (int c = 0; c < 4; ++c)
+            T[4 * r + c] = left[4 * r] * T_mesh[c] + left[4 * r + 1] * T_mesh[4 + c] + left[4 * r + 2] * T_mesh[8 + c] + (c == 3 ? left[4 * r + 3] : 0.f);
       std::cout << "adding mesh " << ply << std::endl;
       std::vector<float> xyz, global;
       std::vector<uint32_t> tris;
@@ -628,6 +634,13 @@ class Problem {
   // Problem::SetScanGeometryAndInitialize: image scales, pyramids, point scales, fixed descriptors -> device
   bool SetScanGeometryAndInitialize(const std::vector<PointCloud::Ptr>& scans, const std::vector<float>& occlusion_points,
                                     const std::string& multi_res_dir) {
+    if (!InitializeImages()) return false;
+    if (!SetOcclusionGeometry(occlusion_points, nullptr)) return false;
+    return SetMultiResGeometry(scans, multi_res_dir);
+  }
+
+  // Problem::InitializeImages (problem.cc): image scale count, camera pyramids, image + mask pyramids -> device problem
+  bool InitializeImages() {
     image_scale_count = 1;
     for (const HostIntrinsics& in : intrinsics_list) image_scale_count = std::max(image_scale_count, ComputeImageScaleCount(in));
     std::cout << "#Image scales: " << image_scale_count << std::endl;
@@ -713,14 +726,23 @@ class Problem {
     for (const HostRigImages& f : rig_images)
       if (api().e3d_reg_add_rig_images(reg, f.rig_id, f.image_ids.data(), (int)f.image_ids.size()) < 0) return lib_fail("e3d_reg_add_rig_images");
 
-    // the occlusion geometry is needed by the radius-range pass already: meshes if given, else 2D splats of all scan points
+    return true;
+  }
+
+  // the occlusion geometry: meshes if given (optionally moved by `left`, a row-major 3x4 transform applied after each mesh's own
+  // pose -- GroundTruthCreator's first_scan_up_transformation), else 2D splats of all scan points
+  bool SetOcclusionGeometry(const std::vector<float>& occlusion_points, const float* left) {
     if (api().e3d_reg_set_occlusion_options(reg, prm.min_occlusion_depth, prm.max_occlusion_depth, 1) < 0) return lib_fail("e3d_reg_set_occlusion_options");
     if (occlusion_mesh_path.empty() && occlusion_splats_path.empty()) {
       if (api().e3d_reg_set_splat_points(reg, occlusion_points.data(), occlusion_points.size() / 3) < 0) return lib_fail("e3d_reg_set_splat_points");
     } else {
-      if (!occlusion_mesh_path.empty() && !AddOcclusionMesh(occlusion_mesh_path, true)) return false;
-      if (!occlusion_splats_path.empty() && !AddOcclusionMesh(occlusion_splats_path, false)) return false;
+      if (!occlusion_mesh_path.empty() && !AddOcclusionMesh(occlusion_mesh_path, true, left)) return false;
+      if (!occlusion_splats_path.empty() && !AddOcclusionMesh(occlusion_splats_path, false, left)) return false;
     }
+    return true;
+  }
+
+  bool SetMultiResGeometry(const std::vector<PointCloud::Ptr>& scans, const std::string& multi_res_dir) {
     if (multi_res_dir.empty()) return fail("Please specify --multi_res_point_cloud_directory_path.");
     if (LoadMultiResPointCloud(multi_res_dir)) {
       std::cout << "SetScanGeometryAndInitialize(): Loaded existing multi-res point cloud." << std::endl;

@@ -285,6 +285,23 @@ int e3d_reg_color_finish(e3d_reg_t* reg, int point_scale);
 /* VisibilityEstimator::CreateObservationsForAllImages + DetermineIfAllNeighborsAreObserved (optimizer.cc:119-128); with
  * e3d_reg_set_cache_observations(1) it is ObservationsCache::GetObservations (observations_cache.cc:52-68) instead. */
 int e3d_reg_update_observations(e3d_reg_t* reg, int border_size);
+/* GroundTruthCreator (src/exe/ground_truth_creator.cc): visibility of the full-resolution scan points in the registered images.
+ *   e3d_reg_set_scan_points: the (global-frame) scan points whose observations are counted; counts start at 0.
+ *   e3d_reg_count_scan_observations: AccumulateScanObservationsForImage (:45-86) for one image -- occlusion depth map at the
+ *     highest available resolution (RenderDepthMap at intrinsics.min_image_scale), then for every scan point: z > 0, rounded
+ *     pixel inside the image, occlusion_image + occlusion_depth_threshold >= z, and mask(iy, ix) != excluded_flag (pass the
+ *     level-0 image mask and opt::MaskType::kEvalObs = 2; NULL = no mask) -> count += 1.
+ *   e3d_reg_get/set_scan_observation_counts: the counters (one int per scan point, input order).  With image sharding every
+ *     rank counts its own images; the caller adds the vectors.
+ *   e3d_reg_ground_truth_depth: the depth-map part of CreateGroundTruthForImage (:104-117, :146-189): gt_depth (w x h floats,
+ *     +inf where nothing was seen) = min z over the visible points with count >= min_count (the tool uses 2); occlusion_depth
+ *     (optional) receives the occlusion depth map the tool writes to occlusion_depth/. */
+int e3d_reg_set_scan_points(e3d_reg_t* reg, const float* xyz, size_t n);
+int e3d_reg_count_scan_observations(e3d_reg_t* reg, int image_id, const uint8_t* mask, int excluded_flag);
+int e3d_reg_get_scan_observation_counts(e3d_reg_t* reg, int32_t* counts);
+int e3d_reg_set_scan_observation_counts(e3d_reg_t* reg, const int32_t* counts);
+int e3d_reg_ground_truth_depth(e3d_reg_t* reg, int image_id, const uint8_t* mask, int excluded_flag, int min_count, float* gt_depth,
+                               float* occlusion_depth);
 /* Observations cache (src/opt/observations_cache.{h,cc}; Optimizer::set_cache_observations, optimizer.h).  When enabled, the
  * observation update re-projects a fixed per-image list of point indices with the current state and applies only the
  * scale-fit and border tests (VisibilityEstimator::AppendObservationsForIndexedPointsVisibleInImage,

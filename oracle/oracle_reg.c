@@ -461,3 +461,26 @@ void oracle_reg_color_finish(size_t n_pts, int K, float* descriptors, const int3
     if (obs_counts[i] > 1)
       for (int k = 0; k < K; ++k) descriptors[i * K + k] /= obs_counts[i];
 }
+
+/* GroundTruthCreator visibility (src/exe/ground_truth_creator.cc:63-86 counting, :152-189 ground-truth depth).
+ * mode 0: counts[i] += 1 for visible points; mode 1: gt_depth (pre-filled with +inf by the caller) = min z over visible
+ * points with counts[i] >= min_count.  mask may be NULL; excluded = opt::MaskType::kEvalObs. */
+void oracle_scan_visibility(const float* pts, size_t n, const float R[9], const float t[3], const oreg_camera* cam,
+                            const float* occlusion, float occlusion_threshold, const uint8_t* mask, int excluded, int mode,
+                            int min_count, int32_t* counts, float* gt_depth) {
+  for (size_t i = 0; i < n; ++i) {
+    if (mode == 1 && counts[i] < min_count) continue;
+    float pp[3];
+    rt(R, t, pts + 3 * i, pp);
+    if (!(pp[2] > 0)) continue;
+    float px, py;
+    cam_normalized_to_image(cam, pp[0] / pp[2], pp[1] / pp[2], &px, &py);
+    const int ix = f2i(px + 0.5f), iy = f2i(py + 0.5f);
+    if (!(ix >= 0 && iy >= 0 && ix < cam->width && iy < cam->height)) continue;
+    const size_t o = (size_t)iy * cam->width + ix;
+    if (!(occlusion[o] + occlusion_threshold >= pp[2])) continue;
+    if (mask && mask[o] == excluded) continue;
+    if (mode == 0) counts[i] += 1;
+    else if (pp[2] < gt_depth[o]) gt_depth[o] = pp[2];
+  }
+}

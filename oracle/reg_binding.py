@@ -240,3 +240,20 @@ def color_accumulate(n_pts, nbr, K, min_image_scale, images, obs, flags, descrip
 
 def color_finish(K, descriptors, obs_counts):
     lib().oracle_reg_color_finish(len(obs_counts), K, _p(descriptors, C.c_float), _p(obs_counts, C.c_int32))
+
+
+def scan_visibility(pts, R, t, cam, occlusion, counts, mask=None, excluded=2, mode=0, min_count=2, occlusion_threshold=0.01):
+    """GroundTruthCreator: mode 0 increments `counts` (int32, in place) for visible scan points; mode 1 returns the ground-truth
+    depth map (min z over visible points with counts >= min_count, +inf elsewhere)."""
+    pts = np.ascontiguousarray(pts, np.float32); R = np.ascontiguousarray(R, np.float32); t = np.ascontiguousarray(t, np.float32)
+    occ = np.ascontiguousarray(occlusion, np.float32)
+    assert counts.dtype == np.int32 and counts.flags.c_contiguous
+    gt = np.full((cam.height, cam.width), np.inf, np.float32)
+    m = np.ascontiguousarray(mask, np.uint8) if mask is not None else None
+    f = lib().oracle_scan_visibility
+    f.restype = None
+    f.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                  C.c_void_p, C.c_void_p]
+    f(pts.ctypes.data, pts.shape[0], R.ctypes.data, t.ctypes.data, C.addressof(cam), occ.ctypes.data, occlusion_threshold,
+      m.ctypes.data if m is not None else None, excluded, mode, min_count, counts.ctypes.data, gt.ctypes.data)
+    return gt

@@ -68,3 +68,12 @@ def test_point_cloud_cleaner_usage(tmp_path):
     assert r.returncode != 0 and "One or more --filter knn,factor parameter values must be given." in r.stderr
     r = subprocess.run([os.path.join(BIN, "PointCloudCleaner"), "--in", str(tmp_path / "a.ply"), "--filter", "8"], capture_output=True, text=True)
     assert r.returncode != 0 and "different than 2" in r.stderr
+
+
+def test_ground_truth_creator_usage(tmp_path):
+    _build()
+    r = subprocess.run([os.path.join(BIN, "GroundTruthCreator")], capture_output=True, text=True)
+    assert r.returncode != 0 and "Please specify all the required paths." in r.stderr
+    r = subprocess.run([os.path.join(BIN, "GroundTruthCreator"), "--scan_alignment_path", "a", "--image_base_path", "b", "--state_path", "c",
+                        "--output_folder_path", str(tmp_path / "o"), "--write_scan_renderings", "1"], capture_output=True, text=True)
+    assert r.returncode != 0 and "--write_scan_renderings is not part of this build." in r.stderr

@@ -4,13 +4,14 @@ state must equal what the same optimisation gives when driven through the Python
 level, and the photometric cost must go down."""
 import importlib
 import os
+import shutil
 import subprocess
 import sys
 
 import numpy as np
 import pytest
 
-from cli_util import BIN, ROOT, write_mlp, write_ply_xyz
+from cli_util import BIN, ROOT, read_mlp, write_mlp, write_ply_xyz
 from reg_util import make_multi_image_scene, make_rig_scene
 
 pytestmark = pytest.mark.gpu
@@ -272,3 +273,131 @@ def test_image_registrator_cli_with_occlusion_mesh(tmp_path, e3d, binary):
     costs = [float(l.split(":")[-1]) for l in out.splitlines() if "Cost (considering occlusions) is" in l]
     assert len(costs) >= 4 and np.isfinite(costs).all() and min(costs) < costs[0]
     assert os.path.exists(os.path.join(d, "out", "scale_1_state", "images.txt"))
+
+
+# ---- GroundTruthCreator (f4) -----------------------------------------------------------------------------------------------------
+def _run_gt(d, extra=()):
+    cmd = [os.path.join(BIN, "GroundTruthCreator"), "--scan_alignment_path", os.path.join(d, "scans.mlp"), "--image_base_path",
+           os.path.join(d, "images"), "--state_path", os.path.join(d, "state"), "--output_folder_path", os.path.join(d, "gt")] + list(extra)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    return r.stdout
+
+
+def _read_ply_xyz_pcl(path):
+    raw = open(path, "rb").read()
+    h = raw.index(b"end_header\n") + 11
+    header = raw[:h].decode()
+    n = int(header.split("element vertex ")[1].split()[0])
+    assert "comment PCL generated" in header and "element camera 1" in header and len(raw) - h - 12 * n == 4 * 12 + 4 * 5 + 4 * 2 + 4 * 2
+    return np.frombuffer(raw, "<f4", 3 * n, h).reshape(n, 3)
+
+
+def test_ground_truth_creator_cli_matches_oracle(tmp_path, e3d):
+    """Counts -> trimmed scans, ground-truth depth and occlusion depth maps (raw and gzip) against the oracle; identity scan
+    pose, so the upright rotation is the identity and every number is bit-exact."""
+    import gzip
+    from oracle import reg_binding as rb
+    from reg_util import quat_to_R
+    M = make_multi_image_scene(n_points=20000, n_images=3, seed=19, perturb=0.0)
+    rng = np.random.RandomState(6)
+    bx, bz = np.meshgrid(np.arange(-0.3, 0.2, 0.01), np.arange(-0.2, 0.2, 0.01))
+    blocker = np.stack([bx.ravel(), np.full(bx.size, 1.6), bz.ravel()], 1)
+    M["pts"] = np.concatenate([M["pts"], blocker, rng.uniform(-4, 4, (3000, 3))]).astype(np.float32)
+    names = ["dslr/img_%d.png" % i for i in range(3)]
+    d = str(tmp_path)
+    write_ply_xyz(os.path.join(d, "scan.ply"), M["pts"], rgb=np.full((len(M["pts"]), 3), 128, np.uint8))
+    write_mlp(os.path.join(d, "scans.mlp"), [("scan", "scan.ply", np.eye(4))])
+    os.makedirs(os.path.join(d, "state"), exist_ok=True)
+    p = M["params"].astype(np.float64).copy(); p[2] += 0.5; p[3] += 0.5
+    with open(os.path.join(d, "state", "cameras.txt"), "w") as f:
+        f.write("# cameras\n7 PINHOLE %d %d %s\n" % (M["width"], M["height"], " ".join("%.9g" % v for v in p)))
+    with open(os.path.join(d, "state", "images.txt"), "w") as f:
+        for i, (im, name) in enumerate(zip(M["images"], names)):
+            f.write("%d %s %s 7 %s\n\n" % (10 + i, " ".join("%.9g" % v for v in im["q_true"]), " ".join("%.9g" % v for v in im["t_true"]), name))
+            _write_png(os.path.join(d, "images", name), im["pyr"][0])
+    mask = np.zeros((M["height"], M["width"]), np.uint8)
+    mask[40:90, 60:140] = 2; mask[100:120, 10:50] = 1
+    _write_png(os.path.join(d, "images", "masks_for_images", "dslr", "img_0.png"), mask)     # <image dir>/../masks_for_images/<folder>/
+    out = _run_gt(d)
+    assert "Writing COLMAP state file ..." in out and "Writing Point Cloud ..." in out and "Writing depth maps ..." in out
+    # oracle: the tool's state = the text it read (float parse of %.9g is exact for f32)
+    from oracle.reg_driver import OracleRegProblem
+    O = OracleRegProblem(K=M["K"], image_scale_count=3)
+    O.set_intrinsics(0, M["width"], M["height"], M["params"], 0, 3)
+    cam = O.intr[0]["levels"][0]
+    counts = np.zeros(len(M["pts"]), np.int32)
+    occ = []
+    for i, im in enumerate(M["images"]):
+        O.set_image(i, 0, [np.zeros((1, 1), np.uint8)] * 3); O.set_image_pose(i, im["q_true"], im["t_true"])
+        R = O._R(O.images[i]); t = O.images[i]["t"]
+        occ.append(rb.splat_depth(M["pts"], R, t, cam, 0.03))
+        rb.scan_visibility(M["pts"], R, t, cam, occ[i], counts, mask=mask if i == 0 else None)
+    trimmed = _read_ply_xyz_pcl(os.path.join(d, "gt", "points", "scan.ply"))
+    assert np.array_equal(trimmed, M["pts"][counts >= 2]) and 5000 < len(trimmed) < len(M["pts"])
+    mlp = read_mlp(os.path.join(d, "gt", "points", "scan_alignment.mlp"))
+    assert len(mlp) == 1 and mlp[0][1] == "scan.ply" and np.allclose(mlp[0][2], np.eye(4))
+    for i, im in enumerate(M["images"]):
+        R = O._R(O.images[i]); t = O.images[i]["t"]
+        ogt = rb.scan_visibility(M["pts"], R, t, cam, occ[i], counts, mask=mask if i == 0 else None, mode=1, min_count=2)
+        gt = np.fromfile(os.path.join(d, "gt", "ground_truth_depth", "dslr", "img_%d.png" % i), np.float32).reshape(M["height"], M["width"])
+        go = np.fromfile(os.path.join(d, "gt", "occlusion_depth", "dslr", "img_%d.png" % i), np.float32).reshape(M["height"], M["width"])
+        # poses pass through the (identity) upright rotation: a quaternion product + renormalisation may move them by an ulp
+        for a, b in ((gt, ogt), (go, occ[i])):
+            fin = np.isfinite(a) & np.isfinite(b)
+            assert (np.isfinite(a) != np.isfinite(b)).mean() < 1e-3 and (np.abs(a[fin] - b[fin]) > 1e-5).mean() < 1e-3
+        assert np.isfinite(gt).sum() > 2000
+    cal = _read_images_txt(os.path.join(d, "gt", "calibration", "images.txt"))
+    assert sorted(cal) == [0, 1, 2] and np.abs(cal[1][0] - M["images"][1]["q_true"]).max() < 1e-6
+    # compressed variant, depth maps only
+    shutil.rmtree(os.path.join(d, "gt"))
+    _run_gt(d, ["--compress_depth_maps", "1", "--write_point_cloud", "0", "--write_occlusion_depth", "0"])
+    assert not os.path.exists(os.path.join(d, "gt", "points")) and not os.path.exists(os.path.join(d, "gt", "occlusion_depth"))
+    gz = np.frombuffer(gzip.open(os.path.join(d, "gt", "ground_truth_depth", "dslr", "img_2.png.gz")).read(), np.float32)
+    fin = np.isfinite(gz) & np.isfinite(ogt.ravel())
+    assert gz.shape == (M["height"] * M["width"],) and fin.sum() > 2000 and (np.abs(gz[fin] - ogt.ravel()[fin]) > 1e-5).mean() < 1e-3
+
+
+def test_ground_truth_creator_rotates_first_scan_upright(tmp_path, e3d):
+    """A tilted first scan: scans, cameras and the written scan_alignment.mlp are all moved by U = (R0^-1, t0 - R0^-1 t0)
+    (ground_truth_creator.cc:275-291, :333-339); visibility is invariant under that rigid motion."""
+    from scipy.spatial.transform import Rotation
+    from reg_util import quat_to_R
+    M = make_multi_image_scene(n_points=20000, n_images=3, seed=20, perturb=0.0)
+    names = ["dslr/img_%d.png" % i for i in range(3)]
+    d = str(tmp_path)
+    T0 = np.eye(4); T0[:3, :3] = Rotation.from_euler("xyz", [0.2, -0.1, 0.4]).as_matrix(); T0[:3, 3] = [0.3, -0.2, 0.1]
+    local = (M["pts"].astype(np.float64) - T0[:3, 3]) @ T0[:3, :3]            # R0^T (p - t0)
+    write_ply_xyz(os.path.join(d, "scan.ply"), local.astype(np.float32), rgb=np.full((len(local), 3), 128, np.uint8))
+    write_mlp(os.path.join(d, "scans.mlp"), [("scan", "scan.ply", T0)])
+    os.makedirs(os.path.join(d, "state"), exist_ok=True)
+    p = M["params"].astype(np.float64).copy(); p[2] += 0.5; p[3] += 0.5
+    with open(os.path.join(d, "state", "cameras.txt"), "w") as f:
+        f.write("7 PINHOLE %d %d %s\n" % (M["width"], M["height"], " ".join("%.9g" % v for v in p)))
+    with open(os.path.join(d, "state", "images.txt"), "w") as f:
+        for i, (im, name) in enumerate(zip(M["images"], names)):
+            f.write("%d %s %s 7 %s\n\n" % (10 + i, " ".join("%.9g" % v for v in im["q_true"]), " ".join("%.9g" % v for v in im["t_true"]), name))
+            _write_png(os.path.join(d, "images", name), im["pyr"][0])
+    _run_gt(d, ["--write_occlusion_depth", "0"])
+    n_up = len(_read_ply_xyz_pcl(os.path.join(d, "gt", "points", "scan.ply")))
+    gt_up = np.fromfile(os.path.join(d, "gt", "ground_truth_depth", "dslr", "img_1.png"), np.float32)
+    cal_up = _read_images_txt(os.path.join(d, "gt", "calibration", "images.txt"))
+    mlp_up = read_mlp(os.path.join(d, "gt", "points", "scan_alignment.mlp"))
+    shutil.rmtree(os.path.join(d, "gt"))
+    _run_gt(d, ["--rotate_first_scan_upright", "0", "--write_occlusion_depth", "0"])
+    n_plain = len(_read_ply_xyz_pcl(os.path.join(d, "gt", "points", "scan.ply")))
+    gt_plain = np.fromfile(os.path.join(d, "gt", "ground_truth_depth", "dslr", "img_1.png"), np.float32)
+    cal_plain = _read_images_txt(os.path.join(d, "gt", "calibration", "images.txt"))
+    mlp_plain = read_mlp(os.path.join(d, "gt", "points", "scan_alignment.mlp"))
+    assert n_plain > 10000 and abs(n_up - n_plain) <= n_plain // 200
+    both = np.isfinite(gt_up) & np.isfinite(gt_plain)
+    assert (np.isfinite(gt_up) != np.isfinite(gt_plain)).mean() < 5e-3 and np.abs(gt_up[both] - gt_plain[both]).max() < 1e-3
+    # the first scan ends up without rotation, at its old position; the plain run keeps T0
+    assert np.abs(mlp_plain[0][2] - T0).max() < 1e-5
+    assert np.abs(mlp_up[0][2][:3, :3] - np.eye(3)).max() < 1e-5 and np.abs(mlp_up[0][2][:3, 3] - T0[:3, 3]).max() < 1e-5
+    # cameras: image_T_global' = image_T_global * U^-1
+    U = np.eye(4); U[:3, :3] = T0[:3, :3].T; U[:3, 3] = T0[:3, 3] - T0[:3, :3].T @ T0[:3, 3]
+    for i in range(3):
+        def mat(q, t):
+            m = np.eye(4); m[:3, :3] = Rotation.from_quat([q[1], q[2], q[3], q[0]]).as_matrix(); m[:3, 3] = t; return m
+        assert np.abs(mat(*cal_up[i][:2]) - mat(*cal_plain[i][:2]) @ np.linalg.inv(U)).max() < 1e-5

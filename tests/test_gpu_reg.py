@@ -305,6 +305,56 @@ def test_run_on_current_scale_determines_cache_itself(e3d):
         assert np.array_equal(G.get_observed_indices(i, 0), O.observed[i][0])
 
 
+# ---- GroundTruthCreator visibility (src/exe/ground_truth_creator.cc) -------------------------------------------------------------
+@pytest.mark.parametrize("model", MODELS)
+def test_scan_visibility_counts_and_ground_truth_depth(e3d, rb, model):
+    """AccumulateScanObservationsForImage + the depth part of CreateGroundTruthForImage: counts and depth maps, bit-exact
+    for the polynomial models (integer / min work on bit-identical projections)."""
+    from reg_util import make_multi_image_scene, quat_to_R
+    M = make_multi_image_scene(n_points=20000, n_images=3, seed=17, perturb=0.0, model=model)
+    G, O = _build_both(e3d, M)
+    rng = np.random.RandomState(5)
+    # the scan: the wall, an occluder in front of part of it, and clutter behind the cameras / outside the images
+    bx, bz = np.meshgrid(np.arange(-0.3, 0.2, 0.01), np.arange(-0.2, 0.2, 0.01))
+    blocker = np.stack([bx.ravel(), np.full(bx.size, 1.6), bz.ravel()], 1)
+    scan = np.concatenate([M["pts"], blocker, rng.uniform(-4, 4, (3000, 3))]).astype(np.float32)
+    for P in (G, O):
+        P.set_splat_points(scan)
+    mask = np.zeros((M["height"], M["width"]), np.uint8)
+    mask[40:90, 60:140] = 2; mask[100:120, 10:50] = 1; mask[0:10, :] = 3        # kEvalObs, kObs, both (only == 2 excludes)
+    G.set_scan_points(scan)
+    counts = np.zeros(len(scan), np.int32)
+    levels = O.intr[0]["levels"]
+    occ = {}
+    for i in range(3):
+        im = O.images[i]
+        occ[i] = rb.splat_depth(scan, O._R(im), im["t"], levels[0], O.splat_radius)
+        m = mask if i != 1 else None
+        G.count_scan_observations(i, m)
+        rb.scan_visibility(scan, O._R(im), im["t"], levels[0], occ[i], counts, mask=m)
+    gc = G.scan_observation_counts()
+    if model in EXACT:
+        assert np.array_equal(gc, counts)
+    else:
+        assert (gc != counts).mean() < 2e-3
+    assert counts.max() == 3 and (counts >= 2).sum() > 5000 and (counts == 0).sum() > 2000
+    G.set_scan_observation_counts(counts)
+    for i in range(3):
+        im = O.images[i]
+        m = mask if i != 1 else None
+        gt, gocc = G.ground_truth_depth(i, M["width"], M["height"], mask=m)
+        ogt = rb.scan_visibility(scan, O._R(im), im["t"], levels[0], occ[i], counts, mask=m, mode=1, min_count=2)
+        if model in EXACT:
+            assert np.array_equal(gocc.view(np.uint32), occ[i].view(np.uint32))
+            assert np.array_equal(gt.view(np.uint32), ogt.view(np.uint32))
+        else:
+            both = np.isfinite(gt) & np.isfinite(ogt)
+            assert (np.isfinite(gt) != np.isfinite(ogt)).mean() < 2e-3 and np.abs(gt[both] - ogt[both]).max() < 2e-2
+        assert np.isfinite(gt).sum() > 3000 and np.isinf(gt).sum() > 1000
+        if m is not None:
+            assert np.isinf(gt[40:90, 60:140]).all()
+
+
 # ---- camera rigs (Rig::Update, dependent rig images) ----------------------------------------------------------------------------
 def _build_rig_both(e3d, M):
     from oracle.reg_driver import OracleRegProblem

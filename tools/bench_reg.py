@@ -42,3 +42,9 @@ res = int(counts[0] + counts[1])
 print("points %d image %dx%d observations %d residuals %d" % (n, W, H, nobs, res))
 print("render_depth %.3f ms | observe %.3f ms (%.1f M pts/s) | accumulate (pass1+pass2) %.3f ms (%.1f M residuals/s) | cost %.3f ms (%.1f M residuals/s)" %
       (t_depth * 1e3, t_obs * 1e3, n / t_obs / 1e6, t_acc * 1e3, res / t_acc / 1e6, t_cost * 1e3, res / t_cost / 1e6))
+# f4: GroundTruthCreator visibility counting / ground-truth depth of the same points as "scan" (incl. the occlusion rendering)
+P.set_scan_points(pts)
+t_cnt = timed(lambda: P.count_scan_observations(0))
+t_gt = timed(lambda: P.ground_truth_depth(0, W, H, min_count=1))
+print("scan visibility count %.3f ms (%.1f M scan points/s incl. occlusion depth) | ground-truth depth + read-back %.3f ms" %
+      (t_cnt * 1e3, n / t_cnt / 1e6, t_gt * 1e3))

@@ -6,7 +6,7 @@
 // Occlusion meshes (--occlusion_mesh_path / --occlusion_splats_path) are rasterised on the GPU by the library instead of OpenGL.
 // Observations are cached like in the reference: from the second image scale on (or from the first with
 // --cache_observations 1) the visible point lists are fixed and kept in --observations_cache_path.
-// Not built yet (the tool says so instead of silently doing something else): --write_debug_point_clouds, JPEG input.
+// Not built yet (the tool says so instead of silently doing something else): --write_debug_point_clouds.
 #include <cmath>
 #include <cstdlib>
 #include <iostream>

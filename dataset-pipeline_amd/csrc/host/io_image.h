@@ -2,8 +2,8 @@
 //
 // The reference reads images with cv::imread(path, IMREAD_GRAYSCALE) (image.cc:47) and masks with IMREAD_ANYDEPTH
 // (:77).  OpenCV is not available here; this header decodes PNG itself on top of zlib (8/16-bit grey, grey+alpha, RGB,
-// RGBA, palette; non-interlaced) and binary PGM / PPM.  JPEG needs libjpeg's headers, which this image lacks: such files
-// are rejected with a message (convert them to PNG).  Colour -> grey follows what OpenCV's PNG reader does, libpng's
+// RGBA, palette; non-interlaced), binary PGM / PPM, and baseline JPEG (io_jpeg.h: the luminance plane with libjpeg's
+// integer IDCT, which is what IMREAD_GRAYSCALE returns).  Colour -> grey for PNG / PPM follows what OpenCV's PNG reader does, libpng's
 // png_set_rgb_to_gray(1, 0.299, 0.587): 15-bit fixed-point weights 9797 / 19234 / 3737 (recalled; unpinned).
 //
 // Pyramid: cv::resize(prev, Size(0.5 * cols, 0.5 * rows), 0.5, 0.5, INTER_AREA) (image.cc:114-119).  For even sizes that
@@ -23,6 +23,8 @@
 #include <iostream>
 #include <string>
 #include <vector>
+
+#include "io_jpeg.h"
 
 namespace e3d_host {
 
@@ -140,7 +142,7 @@ inline GrayImage imread_gray(const std::string& path, std::string* error = nullp
   bool ok = false;
   if (f.size() >= 8 && f[0] == 137 && f[1] == 'P') ok = img_detail::load_png(f, &img, &err);
   else if (f.size() >= 2 && f[0] == 'P' && (f[1] == '5' || f[1] == '6')) ok = img_detail::load_pnm(f, &img, &err);
-  else if (f.size() >= 2 && f[0] == 0xff && f[1] == 0xd8) err = "JPEG decoding is not available in this build (no libjpeg headers); convert the images to PNG";
+  else if (f.size() >= 2 && f[0] == 0xff && f[1] == 0xd8) ok = load_jpeg_gray(f, &img.width, &img.height, &img.data, &err);
   else err = "unknown image format";
   if (!ok) { img = GrayImage(); if (error) *error = path + ": " + err; }
   return img;

@@ -1,0 +1,302 @@
+// io_jpeg.h -- baseline JPEG -> 8-bit grey, for cv::imread(path, cv::IMREAD_GRAYSCALE) on the JPEG images of a dataset
+// (src/opt/image.cc:47; the ETH3D DSLR images are JPEGs).
+//
+// OpenCV's JPEG reader asks libjpeg for JCS_GRAYSCALE output, which for a YCbCr (or grey) file is the decoded luminance
+// plane itself -- no colour conversion, chroma is never reconstructed.  This header restates that path: Huffman decoding
+// (ITU T.81 F.2), dequantisation, libjpeg's default "islow" inverse DCT (jidctint.c: Loeffler-Ligtenberg-Moschytz, 13-bit
+// constants, 2 extra bits after the column pass) and the +128 / clamp of its range-limit table.  The integer arithmetic is
+// the specification here, so the result is bit-identical to libjpeg / libjpeg-turbo (pinned against Pillow's libjpeg-turbo
+// decoder: tests/golden/jpeg_*.jpg + jpeg_golden.npz, tests/test_cli_host.py).
+//
+// Supported: SOF0 / SOF1 (baseline / extended sequential, Huffman, 8-bit), 1 or 3 components (YCbCr), any sampling
+// factors, restart intervals, sizes that are not multiples of the MCU.  Rejected with a message: progressive (SOF2),
+// arithmetic coding, 12-bit, CMYK / YCCK, RGB-coded files (Adobe transform 0 or component ids 'R' 'G' 'B').
+// Not applied: the EXIF orientation tag (OpenCV rotates on imread unless told otherwise; the tag is 1 in the datasets
+// this pipeline was written for).
+#pragma once
+
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace e3d_host {
+namespace jpeg_detail {
+
+struct Huff {
+  // canonical code tables (T.81 Annex C / F.2.2.3): per code length the smallest code, the largest code and the index of
+  // the first symbol of that length
+  int mincode[17] = {0}, maxcode[18] = {0}, valptr[17] = {0};
+  uint8_t vals[256] = {0};
+  bool defined = false;
+};
+
+struct Component { int id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0, pred = 0; };
+
+struct BitReader {
+  const uint8_t* p; const uint8_t* end;
+  uint32_t acc = 0; int bits = 0;
+  bool hit_marker = false;
+  void fill() {
+    while (bits <= 24) {
+      int c = 0;
+      if (!hit_marker && p < end) {
+        c = *p++;
+        if (c == 0xFF) {
+          if (p < end && *p == 0x00) ++p;            // stuffed byte
+          else { hit_marker = true; --p; c = 0; }    // a marker ends the entropy-coded segment: feed zeros
+        }
+      }
+      acc |= (uint32_t)c << (24 - bits);
+      bits += 8;
+    }
+  }
+  int get(int n) {       // n <= 16
+    if (n == 0) return 0;
+    if (bits < n) fill();
+    const int v = (int)(acc >> (32 - n));
+    acc <<= n; bits -= n;
+    return v;
+  }
+  void reset() { acc = 0; bits = 0; hit_marker = false; }
+};
+
+inline int decode_symbol(BitReader& br, const Huff& h, bool* ok) {
+  int code = br.get(1);
+  for (int l = 1; l <= 16; ++l) {
+    if (h.maxcode[l] >= 0 && code <= h.maxcode[l] && code >= h.mincode[l]) return h.vals[h.valptr[l] + code - h.mincode[l]];
+    code = (code << 1) | br.get(1);
+  }
+  *ok = false;
+  return 0;
+}
+inline int extend(int v, int t) { return (t == 0) ? 0 : ((v < (1 << (t - 1))) ? v - (1 << t) + 1 : v); }
+
+constexpr int kZigzag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                             41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                             30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+// jpeg_idct_islow (jidctint.c): coefficients already dequantised, natural order
+inline void idct_islow(const int* in, uint8_t* out, int stride) {
+  constexpr int CB = 13, P1 = 2;
+  constexpr long F0_298 = 2446, F0_390 = 3196, F0_541 = 4433, F0_765 = 6270, F0_899 = 7373, F1_175 = 9633, F1_501 = 12299,
+                 F1_847 = 15137, F1_961 = 16069, F2_053 = 16819, F2_562 = 20995, F3_072 = 25172;
+  auto descale = [](long x, int n) { return (x + (1L << (n - 1))) >> n; };
+  long ws[64];
+  for (int c = 0; c < 8; ++c) {
+    const int* ip = in + c;
+    long* wp = ws + c;
+    long z2 = ip[16], z3 = ip[48];
+    long z1 = (z2 + z3) * F0_541;
+    long tmp2 = z1 + z3 * (-F1_847);
+    long tmp3 = z1 + z2 * F0_765;
+    z2 = ip[0]; z3 = ip[32];
+    long tmp0 = (z2 + z3) * (1L << CB);
+    long tmp1 = (z2 - z3) * (1L << CB);
+    const long tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+    tmp0 = ip[56]; tmp1 = ip[40]; tmp2 = ip[24]; tmp3 = ip[8];
+    z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2;
+    long z4 = tmp1 + tmp3;
+    const long z5 = (z3 + z4) * F1_175;
+    tmp0 *= F0_298; tmp1 *= F2_053; tmp2 *= F3_072; tmp3 *= F1_501;
+    z1 *= -F0_899; z2 *= -F2_562; z3 *= -F1_961; z4 *= -F0_390;
+    z3 += z5; z4 += z5;
+    tmp0 += z1 + z3; tmp1 += z2 + z4; tmp2 += z2 + z3; tmp3 += z1 + z4;
+    wp[0] = descale(tmp10 + tmp3, CB - P1); wp[56] = descale(tmp10 - tmp3, CB - P1);
+    wp[8] = descale(tmp11 + tmp2, CB - P1); wp[48] = descale(tmp11 - tmp2, CB - P1);
+    wp[16] = descale(tmp12 + tmp1, CB - P1); wp[40] = descale(tmp12 - tmp1, CB - P1);
+    wp[24] = descale(tmp13 + tmp0, CB - P1); wp[32] = descale(tmp13 - tmp0, CB - P1);
+  }
+  for (int r = 0; r < 8; ++r) {
+    const long* wp = ws + 8 * r;
+    long z2 = wp[2], z3 = wp[6];
+    long z1 = (z2 + z3) * F0_541;
+    long tmp2 = z1 + z3 * (-F1_847);
+    long tmp3 = z1 + z2 * F0_765;
+    long tmp0 = (wp[0] + wp[4]) * (1L << CB);
+    long tmp1 = (wp[0] - wp[4]) * (1L << CB);
+    const long tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+    tmp0 = wp[7]; tmp1 = wp[5]; tmp2 = wp[3]; tmp3 = wp[1];
+    z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2;
+    long z4 = tmp1 + tmp3;
+    const long z5 = (z3 + z4) * F1_175;
+    tmp0 *= F0_298; tmp1 *= F2_053; tmp2 *= F3_072; tmp3 *= F1_501;
+    z1 *= -F0_899; z2 *= -F2_562; z3 *= -F1_961; z4 *= -F0_390;
+    z3 += z5; z4 += z5;
+    tmp0 += z1 + z3; tmp1 += z2 + z4; tmp2 += z2 + z3; tmp3 += z1 + z4;
+    const long o[8] = {tmp10 + tmp3, tmp11 + tmp2, tmp12 + tmp1, tmp13 + tmp0, tmp13 - tmp0, tmp12 - tmp1, tmp11 - tmp2, tmp10 - tmp3};
+    uint8_t* op = out + (size_t)r * stride;
+    for (int k = 0; k < 8; ++k) {
+      long v = descale(o[k], CB + P1 + 3) + 128;         // range_limit: centre on 128, clamp to 0..255
+      op[k] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+    }
+  }
+}
+
+inline int be16(const uint8_t* p) { return (p[0] << 8) | p[1]; }
+
+}  // namespace jpeg_detail
+
+// grey = the luminance plane, width x height bytes; false + message on unsupported or damaged files
+inline bool load_jpeg_gray(const std::vector<uint8_t>& f, int* width, int* height, std::vector<uint8_t>* gray, std::string* err) {
+  using namespace jpeg_detail;
+  if (f.size() < 4 || f[0] != 0xFF || f[1] != 0xD8) { *err = "not a JPEG file"; return false; }
+  int qt[4][64] = {{0}};
+  bool qt_defined[4] = {false, false, false, false};
+  Huff dc[4], ac[4];
+  std::vector<Component> comps;
+  int W = 0, H = 0, restart_interval = 0;
+  int adobe_transform = -1;
+  size_t pos = 2;
+  bool have_frame = false;
+  while (pos + 4 <= f.size()) {
+    if (f[pos] != 0xFF) { ++pos; continue; }
+    const int marker = f[pos + 1];
+    if (marker == 0xFF) { ++pos; continue; }                 // fill bytes
+    pos += 2;
+    if (marker == 0xD8 || (marker >= 0xD0 && marker <= 0xD7) || marker == 0x01) continue;
+    if (marker == 0xD9) break;
+    if (pos + 2 > f.size()) break;
+    const int len = be16(&f[pos]);
+    if (len < 2 || pos + (size_t)len > f.size()) { *err = "truncated JPEG segment"; return false; }
+    const uint8_t* d = &f[pos + 2];
+    const int n = len - 2;
+    if (marker == 0xDB) {                                     // DQT
+      int i = 0;
+      while (i < n) {
+        const int pq = d[i] >> 4, tq = d[i] & 15;
+        ++i;
+        if (tq > 3 || i + (pq ? 128 : 64) > n) { *err = "bad DQT"; return false; }
+        for (int k = 0; k < 64; ++k) { qt[tq][kZigzag[k]] = pq ? be16(&d[i + 2 * k]) : d[i + k]; }
+        qt_defined[tq] = true;
+        i += pq ? 128 : 64;
+      }
+    } else if (marker == 0xC4) {                              // DHT
+      int i = 0;
+      while (i + 17 <= n) {
+        const int tc = d[i] >> 4, th = d[i] & 15;
+        if (tc > 1 || th > 3) { *err = "bad DHT"; return false; }
+        Huff& h = tc ? ac[th] : dc[th];
+        int counts[17] = {0}, total = 0;
+        for (int l = 1; l <= 16; ++l) { counts[l] = d[i + l]; total += counts[l]; }
+        i += 17;
+        if (total > 256 || i + total > n) { *err = "bad DHT"; return false; }
+        memcpy(h.vals, &d[i], (size_t)total);
+        i += total;
+        int code = 0, k = 0;
+        for (int l = 1; l <= 16; ++l) {
+          h.valptr[l] = k; h.mincode[l] = code;
+          code += counts[l]; k += counts[l];
+          h.maxcode[l] = counts[l] ? code - 1 : -1;
+          code <<= 1;
+        }
+        h.defined = true;
+      }
+    } else if (marker == 0xC0 || marker == 0xC1) {            // SOF0 / SOF1
+      if (n < 6 || d[0] != 8) { *err = "only 8-bit JPEG is supported"; return false; }
+      H = be16(&d[1]); W = be16(&d[3]);
+      const int nc = d[5];
+      if ((nc != 1 && nc != 3) || n < 6 + 3 * nc) { *err = nc == 4 ? "CMYK / YCCK JPEG is not supported" : "unsupported JPEG component count"; return false; }
+      comps.resize(nc);
+      for (int c = 0; c < nc; ++c) {
+        comps[c].id = d[6 + 3 * c]; comps[c].h = d[7 + 3 * c] >> 4; comps[c].v = d[7 + 3 * c] & 15; comps[c].tq = d[8 + 3 * c];
+        if (comps[c].h < 1 || comps[c].h > 4 || comps[c].v < 1 || comps[c].v > 4 || comps[c].tq > 3) { *err = "bad SOF"; return false; }
+      }
+      have_frame = true;
+    } else if (marker == 0xC2 || (marker >= 0xC5 && marker <= 0xCF && marker != 0xC8 && marker != 0xCC)) {
+      *err = marker == 0xC2 ? "progressive JPEG is not supported (re-save as baseline JPEG or PNG)" : "unsupported JPEG coding process";
+      return false;
+    } else if (marker == 0xDD) {
+      if (n >= 2) restart_interval = be16(d);
+    } else if (marker == 0xEE) {                              // Adobe
+      if (n >= 12 && !memcmp(d, "Adobe", 5)) adobe_transform = d[11];
+    } else if (marker == 0xDA) {                              // SOS: baseline -> one scan with all components
+      if (!have_frame || W <= 0 || H <= 0) { *err = "JPEG scan before frame header"; return false; }
+      const int ns = d[0];
+      if (ns != (int)comps.size() || n < 1 + 2 * ns + 3) { *err = "multi-scan sequential JPEG is not supported"; return false; }
+      for (int s = 0; s < ns; ++s) {
+        bool found = false;
+        for (Component& c : comps)
+          if (c.id == d[1 + 2 * s]) { c.td = d[2 + 2 * s] >> 4; c.ta = d[2 + 2 * s] & 15; found = true; }
+        if (!found) { *err = "bad SOS"; return false; }
+      }
+      if (comps.size() == 3 && (adobe_transform == 0 || (comps[0].id == 'R' && comps[1].id == 'G' && comps[2].id == 'B'))) {
+        *err = "RGB-coded JPEG is not supported";
+        return false;
+      }
+      for (const Component& c : comps)
+        if (c.td > 3 || c.ta > 3 || !dc[c.td].defined || !ac[c.ta].defined || !qt_defined[c.tq]) { *err = "JPEG tables missing"; return false; }
+      int hmax = 1, vmax = 1;
+      for (const Component& c : comps) { hmax = c.h > hmax ? c.h : hmax; vmax = c.v > vmax ? c.v : vmax; }
+      // a single-component scan is non-interleaved: the MCU is one 8x8 block regardless of the sampling factors
+      const bool single = comps.size() == 1;
+      const int mcu_w = single ? 8 : 8 * hmax, mcu_h = single ? 8 : 8 * vmax;
+      const int mcus_x = (W + mcu_w - 1) / mcu_w, mcus_y = (H + mcu_h - 1) / mcu_h;
+      const Component& Y = comps[0];
+      const int yh = single ? 1 : Y.h, yv = single ? 1 : Y.v;
+      // luminance plane of whole MCUs (the first component is at full resolution when it has the maximal factors)
+      if (!single && (Y.h != hmax || Y.v != vmax)) { *err = "JPEG with a subsampled first component is not supported"; return false; }
+      const int PW = mcus_x * mcu_w, PH = mcus_y * mcu_h;
+      std::vector<uint8_t> plane((size_t)PW * PH);
+      BitReader br{&f[pos + (size_t)len], f.data() + f.size()};
+      int restart_count = 0;
+      for (Component& c : comps) c.pred = 0;
+      int coef[64];
+      for (int my = 0; my < mcus_y; ++my)
+        for (int mx = 0; mx < mcus_x; ++mx) {
+          if (restart_interval && restart_count == restart_interval) {
+            // byte-align, expect RSTn
+            br.reset();
+            const uint8_t* q = br.p;
+            while (q + 1 < br.end && !(q[0] == 0xFF && q[1] >= 0xD0 && q[1] <= 0xD7)) ++q;
+            if (q + 1 >= br.end) { *err = "missing JPEG restart marker"; return false; }
+            br.p = q + 2;
+            for (Component& c : comps) c.pred = 0;
+            restart_count = 0;
+          }
+          ++restart_count;
+          for (size_t ci = 0; ci < comps.size(); ++ci) {
+            Component& c = comps[ci];
+            const int bh = single ? 1 : c.h, bv = single ? 1 : c.v;
+            for (int by = 0; by < bv; ++by)
+              for (int bx = 0; bx < bh; ++bx) {
+                bool ok = true;
+                memset(coef, 0, sizeof coef);
+                const int t = decode_symbol(br, dc[c.td], &ok);
+                if (!ok || t > 15) { *err = "corrupt JPEG data (DC)"; return false; }
+                c.pred += extend(br.get(t), t);
+                coef[0] = c.pred * qt[c.tq][0];
+                for (int k = 1; k < 64;) {
+                  const int rs = decode_symbol(br, ac[c.ta], &ok);
+                  if (!ok) { *err = "corrupt JPEG data (AC)"; return false; }
+                  const int r = rs >> 4, s = rs & 15;
+                  if (s == 0) {
+                    if (r == 15) { k += 16; continue; }
+                    break;                                     // EOB
+                  }
+                  k += r;
+                  if (k > 63) { *err = "corrupt JPEG data (run)"; return false; }
+                  const int zz = kZigzag[k];
+                  coef[zz] = extend(br.get(s), s) * qt[c.tq][zz];
+                  ++k;
+                }
+                if (ci == 0) {
+                  uint8_t* o = &plane[(size_t)(my * mcu_h + by * 8) * PW + (size_t)(mx * mcu_w + bx * 8)];
+                  idct_islow(coef, o, PW);
+                }
+              }
+          }
+          (void)yh; (void)yv;
+        }
+      *width = W; *height = H;
+      gray->resize((size_t)W * H);
+      for (int y = 0; y < H; ++y) memcpy(&(*gray)[(size_t)y * W], &plane[(size_t)y * PW], (size_t)W);
+      return true;
+    }
+    pos += (size_t)len;
+  }
+  *err = "JPEG without image data";
+  return false;
+}
+
+}  // namespace e3d_host

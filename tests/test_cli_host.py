@@ -77,3 +77,52 @@ def test_ground_truth_creator_usage(tmp_path):
     r = subprocess.run([os.path.join(BIN, "GroundTruthCreator"), "--scan_alignment_path", "a", "--image_base_path", "b", "--state_path", "c",
                         "--output_folder_path", str(tmp_path / "o"), "--write_scan_renderings", "1"], capture_output=True, text=True)
     assert r.returncode != 0 and "--write_scan_renderings is not part of this build." in r.stderr
+
+
+def _imread(path, tmp_path):
+    out = str(tmp_path / "o.pgm")
+    r = subprocess.run([os.path.join(BIN, "e3d_imread_gray"), path, out], capture_output=True, text=True)
+    if r.returncode != 0:
+        return None, r.stderr
+    raw = open(out, "rb").read()
+    parts = raw.split(b"\n", 3)
+    w, h = [int(v) for v in parts[1].split()]
+    return np.frombuffer(parts[3], np.uint8, w * h).reshape(h, w), ""
+
+
+def test_jpeg_decoder_matches_libjpeg_golden(tmp_path):
+    """cv::imread(path, IMREAD_GRAYSCALE) on JPEG = libjpeg's luminance plane (islow IDCT).  Golden: Pillow / libjpeg-turbo
+    (tests/golden/make_jpeg_golden.py); 4:2:0 / 4:2:2 / 4:4:4, optimised Huffman tables, grey files, restart markers, sizes
+    that are not MCU multiples -- bit for bit."""
+    _build()
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    exp = np.load(os.path.join(gold, "jpeg_golden.npz"))
+    assert len(exp.files) == 6
+    for name in exp.files:
+        img, err = _imread(os.path.join(gold, "jpeg_%s.jpg" % name), tmp_path)
+        assert img is not None, err
+        assert img.shape == exp[name].shape and np.array_equal(img, exp[name]), name
+    img, err = _imread(os.path.join(gold, "jpeg_progressive.jpg"), tmp_path)
+    assert img is None and "progressive JPEG is not supported" in err
+
+
+def test_png_decoder_roundtrip(tmp_path):
+    """The PNG path of imread_gray against Pillow-written files: 8-bit grey (all filter types via a noisy image), RGB -> grey with
+    the libpng weights OpenCV uses, 16-bit grey (high byte)."""
+    from PIL import Image
+    _build()
+    rng = np.random.RandomState(0)
+    g = rng.randint(0, 256, (37, 53)).astype(np.uint8)
+    Image.fromarray(g, "L").save(str(tmp_path / "g.png"))
+    img, err = _imread(str(tmp_path / "g.png"), tmp_path)
+    assert img is not None and np.array_equal(img, g), err
+    rgb = rng.randint(0, 256, (20, 31, 3)).astype(np.uint8)
+    Image.fromarray(rgb, "RGB").save(str(tmp_path / "c.png"))
+    img, _ = _imread(str(tmp_path / "c.png"), tmp_path)
+    r64 = rgb.astype(np.int64)
+    exp = ((9797 * r64[..., 0] + 19234 * r64[..., 1] + 3737 * r64[..., 2] + 16384) >> 15).astype(np.uint8)
+    assert np.array_equal(img, exp)
+    g16 = rng.randint(0, 65536, (9, 14)).astype(np.uint16)
+    Image.fromarray(g16).save(str(tmp_path / "h.png"))
+    img, _ = _imread(str(tmp_path / "h.png"), tmp_path)
+    assert np.array_equal(img, (g16 >> 8).astype(np.uint8))

@@ -401,3 +401,57 @@ def test_ground_truth_creator_rotates_first_scan_upright(tmp_path, e3d):
         def mat(q, t):
             m = np.eye(4); m[:3, :3] = Rotation.from_quat([q[1], q[2], q[3], q[0]]).as_matrix(); m[:3, 3] = t; return m
         assert np.abs(mat(*cal_up[i][:2]) - mat(*cal_plain[i][:2]) @ np.linalg.inv(U)).max() < 1e-5
+
+
+# ---- the reference's own two-frame alignment test on its own data (src/opt/test/test_alignment.cc, TestPairAlignment) --------------
+@pytest.mark.parametrize("case", ["identical_images", "small_offset"])
+def test_reference_pair_alignment_thresholds(tmp_path, case):
+    """ProcessOnePair (test_alignment_util.cc:122-250) through the drop-in tool: the point cloud of image a's depth map is the
+    scan, both images start at the identity pose, the multi-resolution cloud is computed from the scan, all image scales are
+    optimised; the recovered relative pose must meet the reference test's thresholds (translation error <= 1e-2 of the scene
+    depth, rotation error <= 1 degree).  Data: tests/golden/alignment_test_data.npz (the reference's test_data)."""
+    from PIL import Image
+    from scipy.spatial.transform import Rotation
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "alignment_test_data.npz"))
+    w, h, fx, fy, cx, cy, depth_factor = G[case + "_calibration"]
+    w, h = int(w), int(h)
+    files = [str(v) for v in G[case + "_files"]]
+    a_img, a_depth, b_img = G[files[0]], G[files[1]], G[files[2]]
+    # unprojection as in the test: depth = depth_factor (float) * u16; p = (depth * nxy, depth), nxy = ImageToNormalized(x, y)
+    fx32, fy32, cx32, cy32 = np.float32(fx), np.float32(fy), np.float32(cx), np.float32(cy)
+    fx_inv, fy_inv = np.float32(1.0 / np.float64(fx32)), np.float32(1.0 / np.float64(fy32))
+    cx_inv, cy_inv = np.float32(-1.0 * np.float64(cx32) / np.float64(fx32)), np.float32(-1.0 * np.float64(cy32) / np.float64(fy32))
+    yy, xx = np.mgrid[0:h, 0:w]
+    depth = (np.float32(depth_factor) * a_depth.astype(np.float32)).astype(np.float64)
+    nx = (fx_inv * xx.astype(np.float32) + cx_inv).astype(np.float64); ny = (fy_inv * yy.astype(np.float32) + cy_inv).astype(np.float64)
+    keep = depth != 0
+    pts = np.stack([depth * nx, depth * ny, depth], -1)[keep].astype(np.float32)
+    rgb = a_img[keep]
+    d = str(tmp_path)
+    write_ply_xyz(os.path.join(d, "scan.ply"), pts, rgb=rgb)
+    write_mlp(os.path.join(d, "scans.mlp"), [("scan", "scan.ply", np.eye(4))])
+    os.makedirs(os.path.join(d, "state")); os.makedirs(os.path.join(d, "images", "cam"))
+    with open(os.path.join(d, "state", "cameras.txt"), "w") as f:
+        f.write("1 PINHOLE %d %d %.9g %.9g %.9g %.9g\n" % (w, h, fx, fy, cx + 0.5, cy + 0.5))
+    with open(os.path.join(d, "state", "images.txt"), "w") as f:
+        f.write("1 1 0 0 0 0 0 0 1 cam/a.png\n\n2 1 0 0 0 0 0 0 1 cam/b.png\n\n")
+    Image.fromarray(a_img, "RGB").save(os.path.join(d, "images", "cam", "a.png"))
+    Image.fromarray(b_img, "RGB").save(os.path.join(d, "images", "cam", "b.png"))
+    cmd = [os.path.join(BIN, "ImageRegistrator"), "--scan_alignment_path", os.path.join(d, "scans.mlp"), "--multi_res_point_cloud_directory_path",
+           os.path.join(d, "cache"), "--image_base_path", os.path.join(d, "images"), "--state_path", os.path.join(d, "state"),
+           "--output_folder_path", os.path.join(d, "out"), "--observations_cache_path", os.path.join(d, "obs_cache"),
+           "--max_iterations", "300", "--max_initial_image_area_in_pixels", str(80 * 60)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "#Image scales: 3" in r.stdout and "--- Optimizing at scaling factor 1 ---" in r.stdout
+    st = _read_images_txt(os.path.join(d, "out", "scale_1_state", "images.txt"))
+
+    def T(q, t):
+        m = np.eye(4); m[:3, :3] = Rotation.from_quat([q[1], q[2], q[3], q[0]]).as_matrix(); m[:3, 3] = t; return m
+    a_T_b = T(*st[0][:2]) @ np.linalg.inv(T(*st[1][:2]))            # model.image_T_global * query.global_T_image
+    gt = G[case + "_a_t_b"]
+    t_err = np.linalg.norm(a_T_b[:3, 3] - gt[:, 3]) / float(G[case + "_average_scene_depth"])
+    Rd = a_T_b[:3, :3].T @ gt[:, :3]
+    r_err = np.degrees(np.arccos(np.clip((np.trace(Rd) - 1) / 2, -1, 1)))
+    print(case, "translation error / scene depth", t_err, "rotation error deg", r_err)
+    assert t_err <= 1e-2 and r_err <= 1.0, (t_err, r_err)

@@ -78,3 +78,32 @@ def test_point_radius_minmax_matches_oracle(e3d, mr, model):
     assert np.abs(gmx[seen_o] - omx[seen_o]).max() <= tol * omx[seen_o].max()
     # sanity of the magnitude: half a pixel at depth z and focal length f is about z / (2 f)
     assert 0.5 * 2.5 / 210 / 2 < np.median(gmn[seen_o]) < 2 * 3.5 / 210 / 2
+
+
+# ---- the reference's own known-answer tests (src/opt/test/test_multi_scale_point_cloud.cc) through the HIP path -------------------
+def test_merge_close_points_reference_kat(e3d):
+    from test_oracle_multires import MERGE_KAT as K, check_merge_kat
+    check_merge_kat(e3d.merge_close_points(K["merge_distance"], K["num_scans"], K["pts"], K["colors"], K["scans"], K["max_radius"]))
+
+
+def test_create_multi_scale_point_cloud_reference_kat(e3d, mr):
+    """:164-289 with the radius range, the observations and their scales from the GPU (the scale loop itself is host code, shared
+    with the oracle here; the tool's C++ version of it is covered by tests/test_gpu_cli_reg.py)."""
+    from test_oracle_multires import check_multi_scale_kat, multi_scale_kat_inputs
+    images, intr, pts, colors, sidx = multi_scale_kat_inputs()
+    G = e3d.RegProblem(e3d.default_reg_params(image_scale_count=3, point_neighbor_count=5))
+    G.set_intrinsics(0, 640, 480, intr[0]["params"], 0, 3)
+    G.set_image(0, 0, images[0]["pyr"]); G.set_image_pose(0, images[0]["q"], images[0]["t"])
+    G.set_splat_points(pts)
+    mn, mx = G.point_radius_minmax(pts)
+    omn, omx = mr.point_radius_minmax(pts, images, intr, pts, 3)
+    assert np.array_equal(mn.view(np.uint32), omn.view(np.uint32)) and np.array_equal(mx.view(np.uint32), omx.view(np.uint32))
+    scales = mr.create_multi_scale_point_cloud(pts, colors, sidx, 1, mn, mx)
+
+    def obs_scale(p, radius):
+        nbr = np.zeros((len(p), 5), np.uint32)
+        G.set_point_scale(0, p, radius, nbr, np.zeros((len(p), 5), np.float32))
+        G.render_depth(0, 0)
+        n = G.observe(0, 0, 0, 0)
+        return G.get_observations(0, 0, n)[3]
+    check_multi_scale_kat(scales, obs_scale)

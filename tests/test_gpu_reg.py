@@ -540,6 +540,62 @@ def test_mesh_depth_matches_oracle(e3d, rb, model):
         assert np.array_equal(g_mask[same].view(np.uint32), o_mask[same].view(np.uint32))
 
 
+RENDERER_KAT_PARAMS = {          # src/opt/test/test_renderer.cc:205-300 (Pinhole, PolynomialTangential, Benchmark)
+    0: [250.0, 200.0, 319.5, 239.5],
+    1: [340.926, 341.124, 302.4, 201.6, -0.101082, 0.0703954, 0.000438661, -0.000680887],
+    2: [340.926, 341.124, 302.4, 201.6, -0.101082, 0.0703954, 0.000438661, -0.000680887, 0.002, 0.001, -0.003, 0.004],
+}
+
+
+@pytest.mark.parametrize("model", MODELS)
+def test_renderer_pixel_accuracy_reference_property(e3d, rb, model):
+    """TestRendererPixelAccuracy (src/opt/test/test_renderer.cc:43-198) on the HIP rasteriser: a mesh with one vertex per 20th
+    pixel, each unprojected to a random depth in [0.5, 20]; the rendered depth at a vertex pixel must be the vertex depth (5e-2),
+    vertices that cannot be unprojected sit behind the camera and draw nothing."""
+    from reg_util import pyramid_u8
+    W, H, step = 640, 480, 20
+    params = np.array(RENDERER_KAT_PARAMS[model], np.float32)
+    cam = rb.make_camera(W, H, params, model)
+    rng = np.random.RandomState(0)
+    gw, gh = W // step + 1, H // step + 1
+    verts = np.zeros((gh * gw, 3), np.float32)
+    for j, y in enumerate(range(0, H + 1, step)):
+        for i, x in enumerate(range(0, W + 1, step)):
+            depth = np.float32(rng.uniform(0.5, 20.0))
+            n, ok = rb.cam_undistort(cam, np.float32(cam.fx_inv * x + cam.cx_inv), np.float32(cam.fy_inv * y + cam.cy_inv))
+            verts[j * gw + i] = (depth * n[0], depth * n[1], depth) if ok and np.isfinite(n).all() else (0, 0, -1)
+    tris = []
+    for y in range(gh - 1):
+        for x in range(gw - 1):
+            tl, tr, bl, br = x + y * gw, x + 1 + y * gw, x + (y + 1) * gw, x + 1 + (y + 1) * gw
+            tris += [(tl, tr, bl), (bl, tr, br)]
+    P = e3d.RegProblem(e3d.default_reg_params(image_scale_count=2, point_neighbor_count=5))
+    P.set_intrinsics(0, W, H, params, 0, 2, camera_type=model)
+    P.set_image(0, 0, pyramid_u8(np.zeros((H, W), np.uint8), 2))
+    P.set_image_pose(0, np.array([1, 0, 0, 0], np.float32), np.zeros(3, np.float32))
+    P.add_occlusion_mesh(verts, np.array(tris, np.uint32), compute_edges=False)
+    P.set_occlusion_options(0.1, 20.1, False)                      # BeginRendering(SE3f(), camera, 0.1f, 20.1f)
+    depth = P.render_depth(0, 0, (H, W))
+    covered = checked = 0
+    for j, y in enumerate(range(0, H, step)):
+        for i, x in enumerate(range(0, W, step)):
+            v = verts[j * gw + i]
+            if v[2] > 0:
+                checked += 1
+                if depth[y, x] > 0:
+                    covered += 1
+                    ip = rb.cam_project(cam, v)
+                    assert abs(ip[0] - x) <= 1e-2 and abs(ip[1] - y) <= 1e-2
+                    # 5e-2 as in the reference, plus what the vertex' own reprojection offset (iterative undistortion) costs on
+                    # the steepest possible perspective-correct depth ramp to a neighbour at z = 0.5 (dz/dpx <= z^2 / 10)
+                    off = max(abs(ip[0] - x), abs(ip[1] - y))
+                    assert abs(depth[y, x] - v[2]) <= 5e-2 + float(v[2]) ** 2 / 10 * off, (x, y, depth[y, x], v[2], off)
+            else:
+                assert depth[y, x] == 0
+    # (uncovered vertex pixels border a triangle with a vertex that could not be unprojected; the reference accepts them too)
+    assert checked > 600 and covered >= (0.99 if model == 0 else 0.9) * checked, (covered, checked)
+
+
 def test_mesh_occlusion_drives_visibility(e3d, rb):
     """With meshes instead of splats, points behind the box are not observed, points with no geometry behind them are not
     observed either (depth 0 where nothing was drawn), and near silhouettes nothing is observed (-1)."""

@@ -238,3 +238,37 @@ def test_icp_c3_shape_all_pairs(e3d, ob, synth):
     assert len(recs) == 4 * 30 and len({(r[1], r[2]) for r in recs}) == 30
     _compare(g, o, ids, cg, co)
     assert np.array_equal(g.get_result_global_T_cloud(0), scans[0]["T_init"].astype(np.float32))
+
+
+# ---- BASELINE.json configs[1] size (2 x 50 M points) through size-independent properties ---------------------------------------------
+def test_full_size_identical_cloud_properties(e3d, synth):
+    """The reference's IdenticalCloud property (test_icp.cc:78-110) at the headline size: two copies of one 50 M point scan, the
+    second started from a perturbed pose, -d 0.01.  (i) at identical poses every point matches its twin at distance 0 in both
+    directions; (ii) alignment brings the two poses together to 1e-5; (iii) correspondence counts never decrease by more than
+    noise and end at 2 N; (iv) a second run reproduces counts and poses bit for bit."""
+    import torch
+    n = 50_000_000
+    scan = synth.make_scene(1, n, seed=4321, sigma=0.002, device=torch.device("cuda", 0))[0]
+    T = scan["T_true"].astype(np.float32)
+    P = np.eye(4, dtype=np.float64)
+    from scipy.spatial.transform import Rotation
+    P[:3, :3] = Rotation.from_rotvec(np.radians(0.2) * np.array([1, 1, 1]) / np.sqrt(3)).as_matrix(); P[:3, 3] = [0.006, -0.004, 0.003]
+    T2 = (P @ T.astype(np.float64)).astype(np.float32)
+
+    def run(T_second, iters):
+        icp = e3d.PointToPlaneICP(device=0)
+        icp.add_point_cloud(scan["xyz"], scan["normals"], T, False)
+        icp.add_point_cloud(scan["xyz"], scan["normals"], T_second, False)
+        icp.run(0.01, 0, iters, 1e-10, False)
+        rec = icp.iter_records()
+        poses = [icp.get_result_global_T_cloud(i) for i in range(2)]
+        return rec, poses
+    rec, _ = run(T, 1)
+    assert rec[0]["correspondences"] == 2 * n and rec[0]["initial_cost"] == 0.0           # (i)
+    rec, poses = run(T2, 60)
+    counts = [r["correspondences"] for r in rec]
+    assert counts[-1] == 2 * n and counts[0] < counts[-1]                                   # (iii)
+    assert np.abs(poses[0] - poses[1]).max() <= 1e-5                                        # (ii)  test_icp.cc:98-108
+    rec2, poses2 = run(T2, 60)
+    assert [r["correspondences"] for r in rec2] == counts                                   # (iv)
+    assert all(np.array_equal(a.view(np.uint32), b.view(np.uint32)) for a, b in zip(poses, poses2))

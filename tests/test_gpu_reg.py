@@ -622,3 +622,54 @@ def test_mesh_occlusion_drives_visibility(e3d, rb):
     seen = np.zeros(4000, bool); seen[idx] = True
     behind_box = (np.abs(pts[:, 0] + 0.02) < 0.2) & (np.abs(pts[:, 2] - 0.05) < 0.18)
     assert n > 1500 and not seen[behind_box].any() and seen[~behind_box].mean() > 0.6
+
+
+# ---- BASELINE.json configs[4] shape (3840 x 2160 images, 4 M points) through size-independent properties ------------------------------
+@pytest.mark.parametrize("model", [0, 2])
+def test_full_size_accumulate_properties(e3d, synth, model):
+    """At the benchmark's size: (i) the cost-only pass returns the sums and counts of the accumulate pass; (ii) H is symmetric
+    positive semi-definite and b = J^T r is consistent with it (H x = b solvable to working precision); (iii) additivity: the
+    normal equations over a partition of the observations into two sets that keep neighbourhoods intact add up to those of the
+    whole; (iv) every observation lies inside the image and its residual count is #fixed + #variable."""
+    Wl = synth.make_reg_workload(n_points=4_000_000, n_images=2, model=model)      # variable residuals need a second observer
+    P = e3d.RegProblem(e3d.default_reg_params(image_scale_count=Wl["n_levels"], point_neighbor_count=Wl["K"]))
+    P.set_intrinsics(0, Wl["width"], Wl["height"], Wl["params"], 0, Wl["n_levels"], camera_type=model)
+    P.set_point_scale(0, Wl["pts"], Wl["point_radius"], Wl["nbr"], Wl["fixed_desc"])
+    P.set_splat_points(Wl["pts"])
+    for i, im in enumerate(Wl["images"]):
+        P.set_image(i, 0, im["pyr"]); P.set_image_pose(i, im["q"], im["t"])
+    P.update_observations(1); P.color_update()
+    H, b, sums, counts = P.accumulate(0, 0)
+    s2, c2 = P.cost(0, 0)
+    assert np.array_equal(counts, c2) and np.allclose(sums, s2, rtol=1e-12)                        # (i)
+    assert counts[0] > 3_000_000 and counts[0] == counts[1]
+    V = H.shape[0]
+    Hs = np.triu(H) + np.triu(H, 1).T
+    w = np.linalg.eigvalsh(Hs)
+    assert w.min() >= -1e-9 * w.max()                                                              # (ii)
+    n_obs = P.observe(0, 0, 0, 1)
+    idx, x, y, s, f = P.get_observations(0, 0, n_obs)
+    assert x.min() >= 1 and y.min() >= 1 and x.max() <= Wl["width"] and y.max() <= Wl["height"]   # (iv)
+    assert int(f.sum()) == counts[0]                                   # one fixed + one variable residual per fully observed point
+    # (iii) the lattice of make_reg_workload: split by point row; points whose neighbours straddle the cut lose their residual
+    # in both halves, so compare against the whole minus exactly those
+    side = int(np.sqrt(len(Wl["pts"])))
+    row = idx // side
+    cut = side // 2
+    parts = []
+    for sel in (row < cut, row >= cut):
+        P.set_observations(0, 0, idx[sel], x[sel], y[sel], s[sel])
+        parts.append(P.accumulate(0, 0))
+    band = ((row >= cut - 2) & (row < cut + 2)) | (row < 2) | (row >= side - 2)      # the lattice wraps around: two seams
+    P.set_observations(0, 0, idx[band], x[band], y[band], s[band])
+    Hb, bb, sb, cb = P.accumulate(0, 0)
+    bl = []
+    for sel in (band & (row < cut), band & (row >= cut)):
+        P.set_observations(0, 0, idx[sel], x[sel], y[sel], s[sel])
+        bl.append(P.accumulate(0, 0))
+    # whole = left + right + (band - band_left - band_right): the residuals that need both sides
+    Hsum = parts[0][0] + parts[1][0] + (Hb - bl[0][0] - bl[1][0])
+    csum = parts[0][3] + parts[1][3] + (cb - bl[0][3] - bl[1][3])
+    assert np.array_equal(csum, counts)
+    assert np.abs(np.triu(Hsum) - np.triu(H)).max() <= 1e-9 * np.abs(H).max()
+    assert V == len(Wl["params"]) + 6

@@ -162,6 +162,10 @@ def _ptr(a, dtype, keep):
         if t.dtype != want:
             t = t.to(want)
         keep.append(t)
+        if t.is_cuda:
+            # the library reads device memory on its own (non-blocking) stream: wait for the work torch queued on the
+            # tensor's device before handing the pointer over
+            torch.cuda.current_stream(t.device).synchronize()
         return C.c_void_p(t.data_ptr())
     arr = np.ascontiguousarray(a, dtype=dtype)
     keep.append(arr)

@@ -2,6 +2,8 @@
 // HIP call checking).  gfx950 only; no CUDA compatibility paths.
 #pragma once
 
+#include <cstdlib>
+
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
@@ -55,12 +57,20 @@ struct DevBuf {
     release();
     E3D_HIP(hipMalloc((void**)&p, sizeof(T) * (n ? n : 1)));
     cap = n;
+    if (poison_allocations()) { E3D_HIP(hipMemset(p, 0xFF, sizeof(T) * (n ? n : 1))); E3D_HIP(hipDeviceSynchronize()); }   // the library's streams do not wait for the null stream
+  }
+  // E3D_POISON=1: fresh device buffers are filled with 0xFF bytes (NaN as f32 / f64, -1 as integers) so that a kernel that
+  // reads memory nobody wrote shows up in the parity tests instead of depending on what the allocator hands out
+  static bool poison_allocations() {
+    static const bool on = [] { const char* e = getenv("E3D_POISON"); return e && e[0] == '1'; }();
+    return on;
   }
   // grow keeping contents
   void grow_keep(size_t n, size_t used, hipStream_t s) {
     if (n <= cap) return;
     T* q = nullptr;
     E3D_HIP(hipMalloc((void**)&q, sizeof(T) * n));
+    if (poison_allocations()) { E3D_HIP(hipMemset(q, 0xFF, sizeof(T) * n)); E3D_HIP(hipDeviceSynchronize()); }
     if (p && used) E3D_HIP(hipMemcpyAsync(q, p, sizeof(T) * used, hipMemcpyDeviceToDevice, s));
     E3D_HIP(hipStreamSynchronize(s));
     if (p) (void)hipFree(p);

@@ -264,7 +264,7 @@ def test_full_size_identical_cloud_properties(e3d, synth):
         poses = [icp.get_result_global_T_cloud(i) for i in range(2)]
         return rec, poses
     rec, _ = run(T, 1)
-    assert rec[0]["correspondences"] == 2 * n and rec[0]["initial_cost"] == 0.0           # (i)
+    assert rec[0]["correspondences"] == 2 * n and rec[0]["initial_cost"] == 0.0, rec[0]    # (i)
     rec, poses = run(T2, 60)
     counts = [r["correspondences"] for r in rec]
     assert counts[-1] == 2 * n and counts[0] < counts[-1]                                   # (iii)

@@ -752,12 +752,17 @@ __global__ __launch_bounds__(kBlock) void k_obs_mark(const unsigned* __restrict_
 }
 __global__ __launch_bounds__(kBlock) void k_obs_flags(const unsigned* __restrict__ o_idx, size_t n_obs,
                                                       const unsigned* __restrict__ nbr, int K,
-                                                      const int* __restrict__ row_of_point, unsigned char* __restrict__ flags) {
+                                                      const int* __restrict__ row_of_point, unsigned char* __restrict__ flags,
+                                                      int* __restrict__ nrow) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_obs) return;
   const size_t p = o_idx[i];
   bool all = true;
-  for (int k = 0; k < K; ++k) all = all && (row_of_point[nbr[p * K + k]] >= 0);
+  for (int k = 0; k < K; ++k) {
+    const int r = row_of_point[nbr[p * K + k]];
+    nrow[i * K + k] = r;            // the dependent gathers are paid once per observation update, not once per pass-2 launch
+    all = all && (r >= 0);
+  }
   flags[i] = all ? 1 : 0;
 }
 
@@ -878,8 +883,7 @@ __device__ __forceinline__ void load_row(const float4* __restrict__ rows, size_t
 template <int K_MAX, int V, int R0, int R1, bool WITH_B>
 __global__ __launch_bounds__(kBlock) void k_reg_pass2(const float4* __restrict__ rows, const unsigned* __restrict__ o_idx,
                                                       const unsigned char* __restrict__ flags, size_t n_obs,
-                                                      const unsigned* __restrict__ nbr, int K,
-                                                      const int* __restrict__ row_of_point,
+                                                      const int* __restrict__ nrow_of_obs, int K,
                                                       const float* __restrict__ fixed_desc, const float* __restrict__ var_desc,
                                                       const int* __restrict__ obs_counts, RegWeights wts,
                                                       double* __restrict__ partial) {
@@ -898,12 +902,12 @@ __global__ __launch_bounds__(kBlock) void k_reg_pass2(const float4* __restrict__
     float In[K_MAX];
 #pragma unroll
     for (int k = 0; k < K_MAX; ++k)
-      if (k < K) { nrow[k] = row_of_point[nbr[p * K + k]]; In[k] = rows[R4 * (size_t)nrow[k]].x; }
+      if (k < K) { nrow[k] = nrow_of_obs[i * K + k]; In[k] = rows[R4 * (size_t)nrow[k]].x; }
     // both residual kinds first (they only need the intensities), then every neighbour row is read ONCE and used for the
     // fixed and the variable residual -- the same f32 products as the reference's two calls of
     // AccumulateHAndBAndResidualForColorObservation; only the order of the f64 additions differs (as it already does
     // between threads)
-    float comp[2][K_MAX];
+    float comp[2][K_MAX] = {};       // a skipped kind contributes weight 0 x 0
     float w[2] = {0.f, 0.f};
 #pragma unroll
     for (int kind = 0; kind < 2; ++kind) {
@@ -932,25 +936,26 @@ __global__ __launch_bounds__(kBlock) void k_reg_pass2(const float4* __restrict__
       for (int k = 0; k < K_MAX; ++k)
         if (k < K) {
           float fn[4 * R4], J[V];
+          double Jd[V];
           load_row<V>(rows, (size_t)nrow[k], fn);
 #pragma unroll
-          for (int c = 0; c < V; ++c) J[c] = fn[1 + c] - fc[1 + c];
+          for (int c = 0; c < V; ++c) { J[c] = fn[1 + c] - fc[1 + c]; Jd[c] = (double)J[c]; }
+          // AccumulateOnHAndB (intrinsics_and_pose_optimizer.cc:1246-1247): H += ((weight * J^T) * J).cast<double>() for the fixed
+          // and the variable residual.  weight * J[r] is formed in f32 like there; the two kinds' row factors are then added
+          // (exactly, in f64) and multiplied with J[c] by ONE f64 FMA per entry: the second product is not rounded to f32
+          // first, i.e. each term is at least as accurate as the reference's (difference <= 2^-24 relative per term, see
+          // DESIGN.md section 10); one instruction per entry instead of six.
+          int e = 0;
 #pragma unroll
-          for (int kind = 0; kind < 2; ++kind) {
-            if (w[kind] == 0) continue;
-            // AccumulateOnHAndB: products in f32, cast, add in f64 (intrinsics_and_pose_optimizer.cc:1246-1247)
-            int e = 0;
+          for (int r = R0; r < R1; ++r) {
+            const double wj = (double)(w[0] * J[r]) + (double)(w[1] * J[r]);
 #pragma unroll
-            for (int r = R0; r < R1; ++r) {
-              const float wj = w[kind] * J[r];
+            for (int c = r; c < V; ++c) { acc[e] = __builtin_fma(wj, Jd[c], acc[e]); ++e; }
+          }
+          if constexpr (WITH_B) {
+            const double wr = (double)(w[0] * comp[0][k]) + (double)(w[1] * comp[1][k]);
 #pragma unroll
-              for (int c = r; c < V; ++c) { acc[e] += (double)(wj * J[c]); ++e; }
-            }
-            if constexpr (WITH_B) {
-              const float wr = w[kind] * comp[kind][k];
-#pragma unroll
-              for (int c = 0; c < V; ++c) acc[NH + c] += (double)(wr * J[c]);
-            }
+            for (int c = 0; c < V; ++c) acc[NH + c] = __builtin_fma(wr, Jd[c], acc[NH + c]);
           }
         }
     }
@@ -1138,6 +1143,7 @@ struct Obs {
   DevBuf<unsigned> idx;
   DevBuf<float> x, y, s;
   DevBuf<unsigned char> flags;
+  DevBuf<int> nrow;               // K per observation: observation row of each neighbour point (-1: not observed), for pass 2
   DevBuf<float4> rows;
   bool rows_valid = false;
 };
@@ -1359,19 +1365,18 @@ static void finish_observations(e3d_reg* h, PointScale& S, Obs& O) {
   hipStream_t s = h->stream;
   hipLaunchKernelGGL(k_fill_i32, dim3(nblk(S.n)), dim3(kBlock), 0, s, S.row_of_point.p, S.n, -1);
   O.flags.reserve(O.n);
+  O.nrow.reserve(O.n * (size_t)h->prm.point_neighbor_count);
   if (O.n) {
     hipLaunchKernelGGL(k_obs_mark, dim3(nblk(O.n)), dim3(kBlock), 0, s, O.idx.p, O.n, S.row_of_point.p);
     hipLaunchKernelGGL(k_obs_flags, dim3(nblk(O.n)), dim3(kBlock), 0, s, O.idx.p, O.n, S.nbr.p, h->prm.point_neighbor_count,
-                       S.row_of_point.p, O.flags.p);
+                       S.row_of_point.p, O.flags.p, O.nrow.p);
   }
   O.rows_valid = false;
 }
 
-// row_of_point belongs to (image, scale) of the LAST observe/prepare call on that scale: re-mark before use
+// pass 1 of the observation list (row_of_point is scratch of finish_observations; pass 2 reads the per-observation O.nrow)
 static void prepare_rows(e3d_reg* h, ImageDev& im, PointScale& S, Obs& O) {
   hipStream_t s = h->stream;
-  hipLaunchKernelGGL(k_fill_i32, dim3(nblk(S.n)), dim3(kBlock), 0, s, S.row_of_point.p, S.n, -1);
-  if (O.n) hipLaunchKernelGGL(k_obs_mark, dim3(nblk(O.n)), dim3(kBlock), 0, s, O.idx.p, O.n, S.row_of_point.p);
   const int model = image_model(h, im);
   O.rows.reserve((size_t)rows4(local_unknowns(h, im)) * O.n);
   if (O.n) {
@@ -1948,8 +1953,8 @@ int e3d_reg_accumulate(e3d_reg_t* h, int image_id, int point_scale, double* H, d
   const RegWeights w{h->prm.robust_weighting_type, h->prm.robust_weighting_parameter, h->prm.fixed_residuals_weight,
                      h->prm.variable_residuals_weight};
 #define E3D_PASS2(V_, R0_, R1_, B_)                                                                                              \
-  hipLaunchKernelGGL((k_reg_pass2<8, V_, R0_, R1_, B_>), dim3(nb), dim3(kBlock), 0, s, O.rows.p, O.idx.p, O.flags.p, O.n, S.nbr.p, \
-                     h->prm.point_neighbor_count, S.row_of_point.p, S.fixed_desc.p, S.var_desc.p, S.obs_counts.p, w, h->partial.p)
+  hipLaunchKernelGGL((k_reg_pass2<8, V_, R0_, R1_, B_>), dim3(nb), dim3(kBlock), 0, s, O.rows.p, O.idx.p, O.flags.p, O.n, O.nrow.p, \
+                     h->prm.point_neighbor_count, S.fixed_desc.p, S.var_desc.p, S.obs_counts.p, w, h->partial.p)
   switch (V) {     // row ranges chosen so that every launch keeps <= 75 f64 accumulators
     case 10: E3D_PASS2(10, 0, 10, true); break;
     case 14: E3D_PASS2(14, 0, 4, true); E3D_PASS2(14, 4, 14, false); break;

@@ -117,7 +117,7 @@ def image_registrator_leg(e3d, synth, cpu=True):
         t0 = time.perf_counter(); _, _, its = P.run_on_current_scale(2, 0.0, 15, False); t_run = time.perf_counter() - t0
         I = len(Wl["params"]); r4 = (I + 10) // 4; K = Wl["K"]
         obs = res // 2
-        alg = obs * (16 * r4 + K * (8 + 16 * r4) + 8 * K + 9)          # own row + K x (index, row slot, neighbour row) + descriptors + idx/flag/count
+        alg = obs * (16 * r4 + K * (4 + 16 * r4) + 8 * K + 9)          # own row + K x (row slot, neighbour row) + descriptors + idx/flag/count
         out[name] = {"residuals_per_s": res / t_acc, "accumulate_ms": t_acc * 1e3, "images": len(ids), "points": len(Wl["pts"]),
                      "residuals": res, "unknowns_per_image_block": I + 6,
                      "observation_refresh_ms": t_obs * 1e3, "cached_observation_refresh_ms": t_obs_cached * 1e3, "colour_update_ms": t_col * 1e3, "cost_ms": t_cost * 1e3,

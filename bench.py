@@ -124,7 +124,7 @@ def image_registrator_leg(e3d, synth, cpu=True):
                      "ms_per_run_iteration": t_run / max(its, 1) * 1e3,
                      "roofline": {"bound": "hbm", "achieved": alg / t_acc / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": alg / t_acc / 1e9 / HBM_PEAK_GBS, "traffic": reg_traffic(model, len(ids)),
-                                  "kernel": "k_reg_pass1 + k_reg_pass2 (+ reduce, read-back) of e3d_reg_accumulate",
+                                  "kernel": "k_reg_pass1 + %s (+ reduce, read-back) of e3d_reg_accumulate" % ("k_reg_pass2" if I + 6 == 10 else "k_reg_pass2_mfma (v_mfma_f64_16x16x4_f64)"),
                                   "algorithmic_bytes": alg}}
         del P
     if cpu:

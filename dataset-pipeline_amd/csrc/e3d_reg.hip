@@ -977,39 +977,244 @@ __global__ __launch_bounds__(kBlock) void k_reg_pass2(const float4* __restrict__
   }
 }
 
-// InitCutoff (camera_base_impl.h:410-463) of the non-fisheye model M: one thread per border test point runs
-// UndistortFromInside (:278-328) over the 10 x 10 seed grid in the reference's order; min_candidate / max_candidate are
-// order-free max / min reductions (non-negative floats: their bit patterns are ordered).
+// Pass 2 on the matrix cores: H = sum over (observation, neighbour) pairs of w J J^T is a rank-4-per-instruction update
+// D(16 x 16) += A(16 x 4) B(4 x 16) in f64 (v_mfma_f64_16x16x4_f64).  A wave owns the whole V x V system as one (V <= 16) or three
+// (V <= 32: blocks 00, 01, 11) 16 x 16 accumulator tiles -- 4 f64 per lane and tile instead of V (V + 1) / 2 accumulators per
+// thread -- so every system size runs in ONE launch and the neighbour rows are gathered once.  Each lane still loads its own
+// observation and the K neighbour rows; per neighbour slot the wave's 64 J vectors go through LDS (f32, row stride 36 floats) to
+// reach the operand layout (lane l: element l & 15 of pair l >> 4).  A = J_i, B = (w_fixed + w_variable) J_j with the weight sum
+// and the product formed in f64 (exact), so each term is at least as accurate as the reference's
+// fl32(fl32(w J_i) J_j) per residual kind (difference <= 2^-23 relative).  b = sum (w r) J and the
+// residual sums stay per-thread f64 accumulators (V + 4).
+typedef double d4_t __attribute__((ext_vector_type(4)));
+constexpr int kP2Stride = 36;     // floats per pair in LDS: 16-byte aligned rows
+
+template <int KT, int V>
+__global__ __launch_bounds__(kBlock, 2) void k_reg_pass2_mfma(const float4* __restrict__ rows, const unsigned* __restrict__ o_idx,
+                                                              const unsigned char* __restrict__ flags, size_t n_obs,
+                                                              const int* __restrict__ nrow_of_obs,
+                                                              const float* __restrict__ fixed_desc, const float* __restrict__ var_desc,
+                                                              const int* __restrict__ obs_counts, RegWeights wts,
+                                                              double* __restrict__ partial) {
+  constexpr int R4 = rows4(V);
+  constexpr bool kTwo = V > 16;
+  constexpr int VP = kTwo ? 32 : 16;
+  constexpr int K = KT;
+  // the lower-right tile (unknowns 16 .. V-1 against themselves) holds only (V-16)(V-15)/2 useful entries: for V <= 18 these
+  // three are cheaper as per-thread f64 FMAs than as a third MFMA per k-batch
+  constexpr bool kTile11 = V > 18;
+  // V == 18 (12 intrinsics + pose: THIN_PRISM_FISHEYE, the model of the DSLR images) fits ONE tile: the B operand's columns 0, 1
+  // carry unknowns 16, 17 instead, so the tile yields H[0..15][2..17]; the six entries this leaves out -- (0,0) (0,1) (1,1) and
+  // (16,16) (16,17) (17,17) -- are per-thread FMAs
+  constexpr bool kFold = V == 18;
+  constexpr int NX = kFold ? 6 : ((kTwo && !kTile11) ? (V - 16) * (V - 15) / 2 : 0);
+  static_assert(V <= 32, "local system too large for two 16-wide tiles");
+  __shared__ __attribute__((aligned(16))) float s_j[kBlock / kWave][kWave * kP2Stride];
+  __shared__ double s_w[kBlock / kWave][kWave];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float* const Jl = s_j[wv];
+  double* const Wl = s_w[wv];
+  const int e = lane & 15, pq = lane >> 4;
+  // independent accumulator copies per tile (summed at the end): back-to-back MFMAs on ONE accumulator serialise on its latency
+  constexpr int NA = 2;
+  d4_t acc00[NA], acc01[NA], acc11[NA];
+#pragma unroll
+  for (int a = 0; a < NA; ++a) { acc00[a] = d4_t{0, 0, 0, 0}; acc01[a] = d4_t{0, 0, 0, 0}; acc11[a] = d4_t{0, 0, 0, 0}; }
+  double bacc[V + 4];
+  double xacc[NX > 0 ? NX : 1];
+#pragma unroll
+  for (int i = 0; i < V + 4; ++i) bacc[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < (NX > 0 ? NX : 1); ++i) xacc[i] = 0.0;
+  const size_t n_chunks = (n_obs + kWave - 1) / kWave;
+  const size_t wave_id = (size_t)blockIdx.x * (kBlock / kWave) + wv, n_waves = (size_t)gridDim.x * (kBlock / kWave);
+  for (size_t ch = wave_id; ch < n_chunks; ch += n_waves) {
+    const size_t i = ch * kWave + lane;
+    const bool on = i < n_obs && flags[i];
+    float fc[4 * R4];
+    float fnk[KT][4 * R4];           // all neighbour rows are requested up front: their latencies overlap
+    float comp[2][KT] = {};
+    float w[2] = {0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 4 * R4; ++q) fc[q] = 0.f;
+#pragma unroll
+    for (int k = 0; k < KT; ++k)
+#pragma unroll
+      for (int q = 0; q < 4 * R4; ++q) fnk[k][q] = 0.f;
+    if (on) {
+      const size_t p = o_idx[i];
+      int nrow[KT];
+#pragma unroll
+      for (int k = 0; k < KT; ++k) nrow[k] = nrow_of_obs[i * K + k];
+      load_row<V>(rows, i, fc);
+#pragma unroll
+      for (int k = 0; k < KT; ++k) load_row<V>(rows, (size_t)nrow[k], fnk[k]);
+#pragma unroll
+      for (int kind = 0; kind < 2; ++kind) {
+        const float sw = kind == 0 ? wts.fixed_weight : wts.var_weight;
+        if (!(sw > 0)) continue;
+        if (kind == 1 && !(obs_counts[p] >= 2)) continue;
+        const float* desc = kind == 0 ? fixed_desc : var_desc;
+        float pr = 0.f;
+#pragma unroll
+        for (int k = 0; k < KT; ++k) {
+          const float image_descriptor = fnk[k][0] - fc[0];
+          const float c = image_descriptor - desc[p * K + k];
+          comp[kind][k] = c;
+          pr += c * c;
+        }
+        pr = sqrtf(pr);
+        bacc[V + 2 + kind] += 1.0;
+        bacc[V + kind] += (double)robust_residual(wts.robust_type, wts.robust_param, pr);
+        w[kind] = sw * robust_weight(wts.robust_type, wts.robust_param, pr);
+      }
+    }
+    const bool act = on && (w[0] != 0 || w[1] != 0);
+    const double wsum = act ? (double)w[0] + (double)w[1] : 0.0;
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+      float J[VP];
+#pragma unroll
+      for (int c = 0; c < VP; ++c) J[c] = 0.f;
+      if (act) {
+        const double wr = (double)(w[0] * comp[0][k]) + (double)(w[1] * comp[1][k]);
+#pragma unroll
+        for (int c = 0; c < V; ++c) {
+          J[c] = fnk[k][1 + c] - fc[1 + c];
+          bacc[c] = __builtin_fma(wr, (double)J[c], bacc[c]);
+        }
+        if constexpr (NX > 0) {
+          int x = 0;
+#pragma unroll
+          for (int r = 16; r < V; ++r) {
+            const double wj = wsum * (double)J[r];
+#pragma unroll
+            for (int c = r; c < V; ++c) { xacc[x] = __builtin_fma((double)J[c], wj, xacc[x]); ++x; }
+          }
+          if constexpr (kFold) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+              const double wj = wsum * (double)J[r];
+#pragma unroll
+              for (int c = r; c < 2; ++c) { xacc[x] = __builtin_fma((double)J[c], wj, xacc[x]); ++x; }
+            }
+          }
+        }
+      }
+      float4* const dst = reinterpret_cast<float4*>(Jl + lane * kP2Stride);
+#pragma unroll
+      for (int c = 0; c < VP / 4; ++c) dst[c] = make_float4(J[4 * c], J[4 * c + 1], J[4 * c + 2], J[4 * c + 3]);
+      Wl[lane] = wsum;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll 4
+      for (int q = 0; q < kWave / 4; ++q) {
+        const int pair = 4 * q + pq;
+        const double a0 = (double)Jl[pair * kP2Stride + e];
+        const double ws = Wl[pair];
+        const double b0 = kFold ? ws * (double)Jl[pair * kP2Stride + (e < 2 ? 16 + e : e)] : ws * a0;
+        acc00[q % NA] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc00[q % NA], 0, 0, 0);
+        if constexpr (kTwo && !kFold) {
+          const double a1 = (double)Jl[pair * kP2Stride + 16 + e];
+          const double b1 = ws * a1;
+          acc01[q % NA] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc01[q % NA], 0, 0, 0);
+          if constexpr (kTile11) acc11[q % NA] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc11[q % NA], 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+  }
+  // per-wave partial: tile entry (row = (lane >> 4) + 4 r, col = lane & 15) -> upper-triangle slot
+  double* const out = partial + wave_id * reg_slot(V);
+#pragma unroll
+  for (int a = 1; a < NA; ++a) { acc00[0] += acc00[a]; acc01[0] += acc01[a]; acc11[0] += acc11[a]; }      // fixed order
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = pq + 4 * r, col = e;
+    if constexpr (kFold) {
+      if (col >= 2) { if (row <= col) out[reg_row_start(V, row) + (col - row)] = acc00[0][r]; }
+      else out[reg_row_start(V, row) + (16 + col - row)] = acc00[0][r];
+    } else if (row <= col && col < V) out[reg_row_start(V, row) + (col - row)] = acc00[0][r];
+    if constexpr (kTwo && !kFold) {
+      if (row < V && 16 + col < V) out[reg_row_start(V, row) + (16 + col - row)] = acc01[0][r];
+      if (kTile11 && row <= col && 16 + col < V) out[reg_row_start(V, 16 + row) + (col - row)] = acc11[0][r];
+    }
+  }
+  if constexpr (NX > 0) {
+    int x = 0;
+#pragma unroll
+    for (int r = 16; r < V; ++r)
+#pragma unroll
+      for (int c = r; c < V; ++c) {
+        const double v = wave_sum(xacc[x]); ++x;
+        if (lane == 0) out[reg_row_start(V, r) + (c - r)] = v;
+      }
+    if constexpr (kFold) {
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int c = r; c < 2; ++c) {
+          const double v = wave_sum(xacc[x]); ++x;
+          if (lane == 0) out[reg_row_start(V, r) + (c - r)] = v;
+        }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < V + 4; ++c) {
+    const double v = wave_sum(bacc[c]);
+    if (lane == 0) out[reg_h(V) + c] = v;
+  }
+}
+
+// InitCutoff (camera_base_impl.h:410-463) of the non-fisheye model M: one WAVE per border test point.  The 10 x 10 seeds of
+// UndistortFromInside (:278-328) are independent Gauss-Newton runs -- two per lane -- whose results go to LDS; lane 0 then
+// replays the reference's order-dependent best / second-best bookkeeping over them in seed order, so the outcome is the
+// sequential one bit for bit.  min_candidate / max_candidate are order-free max / min reductions (non-negative floats: their
+// bit patterns are ordered).
 template <int M>
 __global__ __launch_bounds__(kBlock) void k_cam_cutoff(CamLevel c, unsigned* __restrict__ out /* [max r2 bits, min second r2 bits] */) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  __shared__ float s_rx[kBlock / kWave][100], s_ry[kBlock / kWave][100];
+  __shared__ unsigned char s_ok[kBlock / kWave][100];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int t = blockIdx.x * (kBlock / kWave) + w;
   const int total = 2 * c.width + 2 * c.height;
-  if (t >= total) return;
+  if (t >= total) return;                                   // whole wave
   float px, py;
   if (t < 2 * c.width) { px = (float)(t >> 1); py = (t & 1) ? (float)(c.height - 1) : 0.f; }
   else { const int u = t - 2 * c.width; py = (float)(u >> 1); px = (u & 1) ? (float)(c.width - 1) : 0.f; }
   const float dx = c.fx_inv * px + c.cx_inv, dy = c.fy_inv * py + c.cy_inv;
+  for (int sd = lane; sd < 100; sd += kWave) {
+    const int yi = sd / 10, xi = sd - 10 * yi;
+    const float iy = dy + 1.5f * (yi - 0.5f * 10) / (0.5f * 10);
+    const float ix = dx + 1.5f * (xi - 0.5f * 10) / (0.5f * 10);
+    float rx = 0.f, ry = 0.f;
+    const bool ok = cam_iterative_undistort<M>(c, dx, dy, ix, iy, rx, ry);
+    s_rx[w][sd] = rx; s_ry[w][sd] = ry; s_ok[w][sd] = ok ? 1 : 0;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  if (lane != 0) return;
   bool converged = false, second_available = false;
   float best_radius = E3D_CAM_INF, second_best_radius = E3D_CAM_INF;
   float bx = 0.f, by = 0.f, sbx = 0.f, sby = 0.f;
-  for (int yi = 0; yi < 10; ++yi) {
-    const float iy = dy + 1.5f * (yi - 0.5f * 10) / (0.5f * 10);
-    for (int xi = 0; xi < 10; ++xi) {
-      const float ix = dx + 1.5f * (xi - 0.5f * 10) / (0.5f * 10);
-      float rx, ry;
-      if (!cam_iterative_undistort<M>(c, dx, dy, ix, iy, rx, ry)) continue;
-      const float radius = sqrtf(rx * rx + ry * ry);
-      if (radius < 0.99f * best_radius) {
-        second_best_radius = best_radius;
-        sbx = bx; sby = by;
-        second_available = converged;
-        best_radius = radius; bx = rx; by = ry;
-        converged = true;
-      } else if (radius > 1 / 0.99f * best_radius && radius < 0.99f * second_best_radius) {
-        second_best_radius = radius;
-        sbx = rx; sby = ry;
-        second_available = true;
-      }
+  for (int sd = 0; sd < 100; ++sd) {
+    if (!s_ok[w][sd]) continue;
+    const float rx = s_rx[w][sd], ry = s_ry[w][sd];
+    const float radius = sqrtf(rx * rx + ry * ry);
+    if (radius < 0.99f * best_radius) {
+      second_best_radius = best_radius;
+      sbx = bx; sby = by;
+      second_available = converged;
+      best_radius = radius; bx = rx; by = ry;
+      converged = true;
+    } else if (radius > 1 / 0.99f * best_radius && radius < 0.99f * second_best_radius) {
+      second_best_radius = radius;
+      sbx = rx; sby = ry;
+      second_available = true;
     }
   }
   if (converged) {
@@ -1266,8 +1471,9 @@ static CamLevel make_level(e3d_reg* h, int model, int w, int h_px, const float* 
   const unsigned init[2] = {0u, 0x7f800000u};       // min_candidate = 0, max_candidate = +inf
   copy_in(h->cut.p, init, sizeof init, h->stream);
   const int total = 2 * w + 2 * h_px;
-  if (model == kOpenCV) hipLaunchKernelGGL(k_cam_cutoff<kOpenCV>, dim3(nblk(total)), dim3(kBlock), 0, h->stream, c, h->cut.p);
-  else hipLaunchKernelGGL(k_cam_cutoff<kThinPrismFisheye>, dim3(nblk(total)), dim3(kBlock), 0, h->stream, c, h->cut.p);   // inner ThinPrismCamera
+  const unsigned cut_blocks = (unsigned)div_up((size_t)total, kBlock / kWave);      // one wave per border test point
+  if (model == kOpenCV) hipLaunchKernelGGL(k_cam_cutoff<kOpenCV>, dim3(cut_blocks), dim3(kBlock), 0, h->stream, c, h->cut.p);
+  else hipLaunchKernelGGL(k_cam_cutoff<kThinPrismFisheye>, dim3(cut_blocks), dim3(kBlock), 0, h->stream, c, h->cut.p);   // inner ThinPrismCamera
   unsigned out[2];
   copy_out(out, h->cut.p, sizeof out, h->stream);
   rsync(h);
@@ -1952,10 +2158,31 @@ int e3d_reg_accumulate(e3d_reg_t* h, int image_id, int point_scale, double* H, d
   h->partial.reserve((size_t)nb * slot); h->red.reserve(slot);
   const RegWeights w{h->prm.robust_weighting_type, h->prm.robust_weighting_parameter, h->prm.fixed_residuals_weight,
                      h->prm.variable_residuals_weight};
+  static const bool valu_pass2 = [] { const char* e = getenv("E3D_REG_PASS2"); return e && !strcmp(e, "valu"); }();
+  int n_partials = nb;
+  // matrix-core kernel: systems that would need several per-thread-accumulator launches (V > 10), default neighbour count
+  static const bool mfma10 = getenv("E3D_REG_PASS2_MFMA10") != nullptr;     // experiment: the single-launch system on the matrix cores too
+  if (!valu_pass2 && (V > 10 || mfma10) && h->prm.point_neighbor_count == 5) {
+    n_partials = nb * (kBlock / kWave);       // one partial per wave
+    h->partial.reserve((size_t)n_partials * slot);
+#define E3D_PASS2M(V_)                                                                                                      \
+  hipLaunchKernelGGL((k_reg_pass2_mfma<5, V_>), dim3(nb), dim3(kBlock), 0, s, O.rows.p, O.idx.p, O.flags.p, O.n, O.nrow.p, \
+                     S.fixed_desc.p, S.var_desc.p, S.obs_counts.p, w, h->partial.p)
+    switch (V) {
+      case 10: E3D_PASS2M(10); break;
+      case 14: E3D_PASS2M(14); break;
+      case 16: E3D_PASS2M(16); break;
+      case 18: E3D_PASS2M(18); break;
+      case 20: E3D_PASS2M(20); break;
+      case 24: E3D_PASS2M(24); break;
+      default: throw Error(E3D_ERR_INVALID, "unsupported local system size");
+    }
+#undef E3D_PASS2M
+  } else {
 #define E3D_PASS2(V_, R0_, R1_, B_)                                                                                              \
   hipLaunchKernelGGL((k_reg_pass2<8, V_, R0_, R1_, B_>), dim3(nb), dim3(kBlock), 0, s, O.rows.p, O.idx.p, O.flags.p, O.n, O.nrow.p, \
                      h->prm.point_neighbor_count, S.fixed_desc.p, S.var_desc.p, S.obs_counts.p, w, h->partial.p)
-  switch (V) {     // row ranges chosen so that every launch keeps <= 75 f64 accumulators
+  switch (V) {     // E3D_REG_PASS2=valu: per-thread accumulators; row ranges chosen so that every launch keeps <= 75 of them
     case 10: E3D_PASS2(10, 0, 10, true); break;
     case 14: E3D_PASS2(14, 0, 4, true); E3D_PASS2(14, 4, 14, false); break;
     case 16: E3D_PASS2(16, 0, 3, true); E3D_PASS2(16, 3, 8, false); E3D_PASS2(16, 8, 16, false); break;
@@ -1966,7 +2193,8 @@ int e3d_reg_accumulate(e3d_reg_t* h, int image_id, int point_scale, double* H, d
     default: throw Error(E3D_ERR_INVALID, "unsupported local system size");
   }
 #undef E3D_PASS2
-  hipLaunchKernelGGL(k_reg_reduce, dim3(slot), dim3(kWave), 0, s, h->partial.p, nb, slot, h->red.p);
+  }
+  hipLaunchKernelGGL(k_reg_reduce, dim3(slot), dim3(kWave), 0, s, h->partial.p, n_partials, slot, h->red.p);
   std::vector<double> r(slot);
   copy_out(r.data(), h->red.p, sizeof(double) * slot, s);
   rsync(h);

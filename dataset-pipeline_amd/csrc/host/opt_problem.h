@@ -341,6 +341,23 @@ class Problem {
     }
     for (HostRig& rig : rigs) {
       const int nc = (int)rig.folder_names.size();
+      // folder and intrinsics of each rig camera, from any of its images: needed to add the images missing from a frame
+      // (rig.cc:92-125; all images of one rig camera must share folder and intrinsics)
+      std::vector<std::string> camera_folder(nc);
+      std::vector<int> camera_intrinsics(nc, -1);
+      for (const HostRigImages& f : rig_images) {
+        if (f.rig_id != rig.rig_id) continue;
+        for (int c = 0; c < nc; ++c) {
+          if (f.image_ids[c] < 0) continue;
+          const HostImage& im = images[f.image_ids[c]];
+          const std::string folder = path_parent(im.file_path);
+          if (!camera_folder[c].empty() && camera_folder[c] != folder) return fail("Images of one rig camera lie in different folders: " + folder);
+          camera_folder[c] = folder;
+          if (camera_intrinsics[c] >= 0 && camera_intrinsics[c] != im.intrinsics_id)
+            return fail("A camera of a rig has images with different intrinsics IDs, i.e., the input state seems to be wrong. Aborting.");
+          camera_intrinsics[c] = im.intrinsics_id;
+        }
+      }
       // average reference_T_other over all frames: rotations through the nearest rotation of their sum, translations by mean
       std::vector<std::vector<double>> Rsum(nc - 1, std::vector<double>(9, 0.0)), tsum(nc - 1, std::vector<double>(3, 0.0));
       std::vector<int> count(nc - 1, 0);
@@ -367,12 +384,14 @@ class Problem {
         rig.image_T_rig[k + 1] = pose_inverse(avg);
       }
       // every frame: average global_T_rig over its images, then derive all image poses from it
-      for (const HostRigImages& f : rig_images) {
+      for (HostRigImages& f : rig_images) {
         if (f.rig_id != rig.rig_id) continue;
         double Rs[9] = {0}, ts[3] = {0};
         int n = 0;
+        std::string frame_file_name;
         for (int c = 0; c < nc; ++c) {
-          if (f.image_ids[c] < 0) return fail("Incomplete rig frames (an image of one rig camera is missing) are not supported by this build");
+          if (f.image_ids[c] < 0) continue;                    // added below, at the pose the rig gives it (rig.cc:236-252)
+          frame_file_name = path_filename(images[f.image_ids[c]].file_path);
           const Pose7 est = pose_mul(pose_inverse(images[f.image_ids[c]].image_T_global), rig.image_T_rig[c]);
           double R[9];
           pose_rotation(est, R);
@@ -385,8 +404,20 @@ class Problem {
         Pose7 global_T_rig;
         rotation_to_quat(R, global_T_rig.q);
         for (int i = 0; i < 3; ++i) global_T_rig.t[i] = (float)(ts[i] / n);
-        for (int c = 0; c < nc; ++c)
+        for (int c = 0; c < nc; ++c) {
+          if (f.image_ids[c] < 0) {
+            if (camera_folder[c].empty()) return fail("Attempting to add a missing image to a rig_images, but no image of that camera has been observed.");
+            HostImage added;
+            added.image_id = (int)images.size();                                     // Problem::AddImage (problem.cc:451-462)
+            while (images.count(added.image_id)) ++added.image_id;
+            added.intrinsics_id = camera_intrinsics[c];
+            added.file_path = join_path(camera_folder[c], frame_file_name);
+            added.rig_images_id = f.rig_images_id;
+            images[added.image_id] = added;
+            f.image_ids[c] = added.image_id;
+          }
           images[f.image_ids[c]].image_T_global = pose_inverse(pose_mul(global_T_rig, pose_inverse(rig.image_T_rig[c])));
+        }
       }
     }
     size_t assigned = 0;

@@ -155,7 +155,10 @@ def test_image_registrator_cli_matches_binding(tmp_path, e3d):
     assert cmd_fail.returncode != 0 and "Missing file for observed point indices" in cmd_fail.stderr
 
 
-def test_image_registrator_cli_with_rig(tmp_path, e3d):
+@pytest.mark.parametrize("incomplete", [False, True])
+def test_image_registrator_cli_with_rig(tmp_path, e3d, incomplete):
+    """incomplete: the second camera's image of frame 1 is not registered in images.txt (its file exists): AssignRigs adds it at
+    the pose the rig gives it (rig.cc:236-252), so the run ends with all four images again."""
     M = make_rig_scene(n_points=6000, seed=13)
     # image ids 2f / 2f+1 = cameras "cam0" / "cam1" of frame f; frames share the file name across the two folders
     names = ["cam%d/frame_%d.png" % (i % 2, i // 2) for i in range(4)]
@@ -166,6 +169,11 @@ def test_image_registrator_cli_with_rig(tmp_path, e3d):
         dep["q_init"], dep["t_init"] = rb.se3_mul(*M["rig_init"][1], ref["q_init"], ref["t_init"])
     rigs = [{"ref_camera_id": 7, "cameras": [{"camera_id": 7, "image_prefix": "cam0"}, {"camera_id": 7, "image_prefix": "cam1"}]}]
     d = _write_dataset(tmp_path, M, names, rigs=rigs)
+    if incomplete:
+        lines = open(os.path.join(d, "state", "images.txt")).read().split("\n")
+        keep = [l for i, l in enumerate(lines) if not (l.startswith("13 ") or (i > 0 and lines[i - 1].startswith("13 ")))]
+        assert len(keep) == len(lines) - 2
+        open(os.path.join(d, "state", "images.txt"), "w").write("\n".join(keep))
     out = _run_tool(d, ["--max_initial_image_area_in_pixels", "32000"])
     assert "AssignRigs(): assigned 4 out of 4 images to rig(s)" in out and "Finished!" in out
     st = _read_images_txt(os.path.join(d, "out", "scale_1_state", "images.txt"))

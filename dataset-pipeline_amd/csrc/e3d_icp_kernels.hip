@@ -554,16 +554,16 @@ __device__ __forceinline__ void row_scan_exact(const RowLds& L, int sl, int slic
   }
 }
 
-__global__ __launch_bounds__(kBlock, 3) void k_nn_rows(const float4* __restrict__ Gsrc, const unsigned* __restrict__ order,
+__global__ __launch_bounds__(kBlock, 6) void k_nn_rows(const float4* __restrict__ Gsrc, const unsigned* __restrict__ order,
                                                        size_t n, const float4* __restrict__ Gtgt,
                                                        const unsigned* __restrict__ S, GridDesc g, InvMap im,
                                                        QueryRange qr, float r2, int row_span,
                                                        int* __restrict__ match_pos, float* __restrict__ match_d2) {
   __shared__ RowLds lds[kBlock / kWave];
+  const bool noscan = row_span >= 1000;
+  if (noscan) row_span -= 1000;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   RowLds& L = lds[w];
-  float* const xyf = reinterpret_cast<float*>(L.xy);
-  float* const zf = reinterpret_cast<float*>(L.z);
   const size_t pos = ((size_t)blockIdx.x * (kBlock / kWave) + w) * kWave + lane;
   const bool valid = pos < n;
   const unsigned j = valid ? order[pos] : 0u;
@@ -620,36 +620,43 @@ __global__ __launch_bounds__(kBlock, 3) void k_nn_rows(const float4* __restrict_
       const int np = (int)((nb + 1u) >> 1);
       const int trips2 = (np + 2 * slices - 1) / (2 * slices);   // quads (2 pairs) per lane
       const int trips = 2 * trips2;
-      // ---- stage [base, base + nb) of the concatenated runs: resolve, issue all loads, then store ----
-      unsigned m[kRowCap / kWave];
+      // ---- stage [base, base + nb) of the concatenated runs.  Each lane handles candidate PAIRS (2u, 2u + 1): the SoA-pair
+      // layout is then one 16-byte and two 8-byte LDS stores per pair, and the flat index -> target position map
+      // (position = flat + off_r for the run r that contains it, off_r wave-uniform) costs two instructions per run.
+      constexpr int kPairsPerLane = kRowCap / 2 / kWave;
+      unsigned pm[kPairsPerLane][2];
 #pragma unroll
-      for (int k = 0; k < kRowCap / kWave; ++k) m[k] = 0xFFFFFFFFu;
-      {
-        unsigned p = 0;
+      for (int k = 0; k < kPairsPerLane; ++k) {
 #pragma unroll
-        for (int r = 0; r < 9; ++r) {
+        for (int hh = 0; hh < 2; ++hh) {
+          const unsigned fl = base + 2u * (unsigned)(k * kWave + lane) + (unsigned)hh;
+          unsigned off = rs[0];
+          unsigned P = rl[0];
 #pragma unroll
-          for (int k = 0; k < kRowCap / kWave; ++k) {
-            const unsigned t = base + (unsigned)(k * kWave + lane) - p;     // offset inside run r (wraps if before it)
-            if (t < rl[r]) m[k] = rs[r] + t;
+          for (int r = 1; r < 9; ++r) {
+            off = (fl >= P) ? rs[r] - P : off;          // an empty run r is overridden by the next one (same P)
+            P += rl[r];
           }
-          p += rl[r];
+          pm[k][hh] = (fl < total) ? fl + off : 0xFFFFFFFFu;
         }
       }
-      float4 cv[kRowCap / kWave];
+      float4 cv[kPairsPerLane][2];
 #pragma unroll
-      for (int k = 0; k < kRowCap / kWave; ++k) cv[k] = (m[k] != 0xFFFFFFFFu) ? Gtgt[m[k]] : make_float4(kInf, 0.f, 0.f, 0.f);
-      const unsigned padded = 2u * (unsigned)(trips * slices);            // candidates incl. sentinels (<= nb + 4*64)
+      for (int k = 0; k < kPairsPerLane; ++k)
 #pragma unroll
-      for (int k = 0; k < kRowCap / kWave + 4; ++k) {
-        const unsigned t = (unsigned)(k * kWave + lane);
-        if (t < padded) {
-          const float4 c = (k < kRowCap / kWave) ? cv[k < kRowCap / kWave ? k : 0] : make_float4(kInf, 0.f, 0.f, 0.f);
-          const unsigned pp = t >> 1, hh = t & 1u;
-          xyf[4u * pp + hh] = c.x;          // x = +inf for slots past nb: d2 = +inf never wins and never ties
-          xyf[4u * pp + 2u + hh] = c.y;
-          zf[2u * pp + hh] = c.z;
-          if (t < nb) L.oi[t] = __float_as_uint(c.w);
+        for (int hh = 0; hh < 2; ++hh)
+          cv[k][hh] = (pm[k][hh] != 0xFFFFFFFFu) ? Gtgt[pm[k][hh]] : make_float4(kInf, 0.f, 0.f, 0.f);
+      const unsigned padded_pairs = (unsigned)(trips * slices);            // pairs incl. sentinels (<= kRowCap / 2 + 2 * 64)
+      uint2* const oi2 = reinterpret_cast<uint2*>(L.oi);
+#pragma unroll
+      for (int k = 0; k < kPairsPerLane + 2; ++k) {
+        const unsigned u = (unsigned)(k * kWave + lane);
+        if (u < padded_pairs) {
+          const float4 c0 = (k < kPairsPerLane) ? cv[k < kPairsPerLane ? k : 0][0] : make_float4(kInf, 0.f, 0.f, 0.f);
+          const float4 c1 = (k < kPairsPerLane) ? cv[k < kPairsPerLane ? k : 0][1] : make_float4(kInf, 0.f, 0.f, 0.f);
+          L.xy[u] = make_float4(c0.x, c1.x, c0.y, c1.y);    // x = +inf for slots past nb: d2 = +inf never wins and never ties
+          L.z[u] = make_float2(c0.z, c1.z);
+          if (2u * u < nb) oi2[u] = make_uint2(__float_as_uint(c0.w), __float_as_uint(c1.w));
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -661,7 +668,7 @@ __global__ __launch_bounds__(kBlock, 3) void k_nn_rows(const float4* __restrict_
       bool tie = false;
       int bq = -1;
       float fd = lb_d2;
-      row_scan_fast(L, sl, slices, trips2, qx, qy, qz, fd, bq, tie);
+      if (!noscan) row_scan_fast(L, sl, slices, trips2, qx, qy, qz, fd, bq, tie);
       if (__ballot(tie)) {                    // rare: cross-quad exact f32 distance tie -> full comparator for this batch
         lb_d2 = in_d2; lb_oi = in_oi; lb_t = in_t;
         row_scan_exact(L, sl, slices, trips, base, nb, qx, qy, qz, lb_d2, lb_oi, lb_t);
@@ -1458,6 +1465,7 @@ static int row_span_setting() {
     v = e ? atoi(e) : kRowSpan;
     if (v < 0) v = 0;
     if (v > 62) v = 62;
+    if (getenv("E3D_NN_NOSCAN")) v += 1000;
   }
   return v;
 }

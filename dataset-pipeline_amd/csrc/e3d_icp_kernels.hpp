@@ -16,7 +16,7 @@ enum { kModeCost = 0,      // cost only
 constexpr int kLmMaxPoses = 9;       // LM tries 1..9 evaluated by one k_lm_cost_multi pass
 constexpr int kLmSlot = 91;          // doubles per block partial / per set result
 constexpr int kMaxBboxBlocks = 2048;
-constexpr int kRowCap = 512;         // candidates staged in LDS per wave and batch (k_nn_rows): ~10 KB
+constexpr int kRowCap = 128;         // candidates staged in LDS per wave and batch (k_nn_rows)
 constexpr int kRowSpan = 4;          // max x-extent (cells) of a row segment handled at once (k_nn_rows)
 constexpr int kNNCap = 256;          // candidates staged in LDS per wave and batch (k_nn_cells)
 

@@ -560,8 +560,6 @@ __global__ __launch_bounds__(kBlock, 6) void k_nn_rows(const float4* __restrict_
                                                        QueryRange qr, float r2, int row_span,
                                                        int* __restrict__ match_pos, float* __restrict__ match_d2) {
   __shared__ RowLds lds[kBlock / kWave];
-  const bool noscan = row_span >= 1000;
-  if (noscan) row_span -= 1000;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   RowLds& L = lds[w];
   const size_t pos = ((size_t)blockIdx.x * (kBlock / kWave) + w) * kWave + lane;
@@ -668,7 +666,7 @@ __global__ __launch_bounds__(kBlock, 6) void k_nn_rows(const float4* __restrict_
       bool tie = false;
       int bq = -1;
       float fd = lb_d2;
-      if (!noscan) row_scan_fast(L, sl, slices, trips2, qx, qy, qz, fd, bq, tie);
+      row_scan_fast(L, sl, slices, trips2, qx, qy, qz, fd, bq, tie);
       if (__ballot(tie)) {                    // rare: cross-quad exact f32 distance tie -> full comparator for this batch
         lb_d2 = in_d2; lb_oi = in_oi; lb_t = in_t;
         row_scan_exact(L, sl, slices, trips, base, nb, qx, qy, qz, lb_d2, lb_oi, lb_t);
@@ -1465,7 +1463,6 @@ static int row_span_setting() {
     v = e ? atoi(e) : kRowSpan;
     if (v < 0) v = 0;
     if (v > 62) v = 62;
-    if (getenv("E3D_NN_NOSCAN")) v += 1000;
   }
   return v;
 }

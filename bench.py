@@ -195,7 +195,10 @@ def main():
     d = float(args.distance)
     thr = 1e-10     # README.md:101 recommended flags; never converges within the bench's few iterations
 
-    scans = synth.make_scene(2, n_points, seed=1234, sigma=0.002, device=dev)
+    # weak scaling: N times the points on N times the floor area (the room stretched by sqrt(N) in x and y), i.e. the point density
+    # -- and with it the candidates per query -- of the 1-GPU workload; every rank then searches its 1/N of the queries
+    room_scale = float(np.sqrt(n_points / 50_000_000.0)) if (world > 1 and args.points == 0) else 1.0
+    scans = synth.make_scene(2, n_points, seed=1234, sigma=0.002, device=dev, room_scale=room_scale)
     torch.cuda.synchronize()
     icp = e3d.PointToPlaneICP(device=local_rank)
     for s in scans:
@@ -284,7 +287,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "ICPScanAligner 2 scans (BASELINE.json configs[1]), -d %g, one outer iteration per step"
                                    % d,
-                       "points_per_scan": n_points, "scans": 2, "directed_pairs": 2,
+                       "points_per_scan": n_points, "scans": 2, "directed_pairs": 2, "room_scale": room_scale,
                        "parallelism": "dp%d over source-point slices, all-reduce of 6x6 normal equations" % world},
             "ms_per_iter": dt / K * 1e3,
             "nn_queries_per_s": queries / dt,

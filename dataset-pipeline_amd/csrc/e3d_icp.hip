@@ -74,7 +74,9 @@ struct e3d_icp {
   std::unique_ptr<Cloud> fixed;                 // merged fixed cloud (global frame)
   int max_inner = 150;
   int nn_mode = 0;                              // 0 auto, 1 per-query kernel, 2 hash-table bucket kernel, 3 dense-directory row kernel, 4 row kernel with MFMA filter
-  size_t dense_cell_budget = (size_t)1 << 31;   // max cells of a dense directory (8 GB); hash table beyond
+  // max cells of a dense directory (4 B each; default 2^33 = 32 GB of the 288 GB per cloud, E3D_DENSE_CELLS overrides);
+  // hash table beyond
+  size_t dense_cell_budget = [] { const char* e = getenv("E3D_DENSE_CELLS"); return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)1 << 33; }();
   int rank = 0, world = 1;
   e3d_allreduce_fn allreduce = nullptr;
   void* allreduce_user = nullptr;

@@ -27,12 +27,16 @@ def rot_axis_angle(axis, angle):
     return np.eye(3) + math.sin(angle) * K + (1 - math.cos(angle)) * (K @ K)
 
 
-def make_scan(n, origin, yaw, seed, sigma=0.002, device="cpu"):
-    """Returns (xyz_local[n,3] f32, normals_local[n,3] f32, T_true[4,4] f32 numpy)."""
+def make_scan(n, origin, yaw, seed, sigma=0.002, device="cpu", room_scale=1.0):
+    """Returns (xyz_local[n,3] f32, normals_local[n,3] f32, T_true[4,4] f32 numpy).  room_scale stretches the floor plan
+    (walls, cylinder positions, scanner position) in x and y: with n proportional to room_scale^2 the point density stays that
+    of the 10 m room -- the weak-scaling workload of bench.py."""
     g = torch.Generator(device=device)
     g.manual_seed(int(seed))
-    W, D, Hh = _ROOM
-    areas = [W * D, D * Hh, D * Hh, W * Hh, W * Hh] + [2 * math.pi * r * Hh for (_, _, r) in _CYL]
+    W, D, Hh = _ROOM[0] * room_scale, _ROOM[1] * room_scale, _ROOM[2]
+    cyl = [(cx * room_scale, cy * room_scale, r) for (cx, cy, r) in _CYL]
+    origin = (origin[0] * room_scale, origin[1] * room_scale, origin[2])
+    areas = [W * D, D * Hh, D * Hh, W * Hh, W * Hh] + [2 * math.pi * r * Hh for (_, _, r) in cyl]
     cum = torch.tensor(np.cumsum(areas) / np.sum(areas), device=device, dtype=torch.float64)
     sel = torch.rand(n, generator=g, device=device, dtype=torch.float64)
     prim = torch.bucketize(sel, cum).clamp_(max=len(areas) - 1)
@@ -55,7 +59,7 @@ def make_scan(n, origin, yaw, seed, sigma=0.002, device="cpu"):
     put(m, u[m] * W, 0.0, v[m] * Hh, 0.0, 1.0, 0.0)
     m = prim == 4
     put(m, u[m] * W, D, v[m] * Hh, 0.0, -1.0, 0.0)
-    for ci, (cx, cy, r) in enumerate(_CYL):
+    for ci, (cx, cy, r) in enumerate(cyl):
         m = prim == 5 + ci
         ang = u[m] * (2 * math.pi)
         put(m, cx + r * torch.cos(ang), cy + r * torch.sin(ang), v[m] * Hh, torch.cos(ang), torch.sin(ang), 0.0)
@@ -84,9 +88,10 @@ SCAN_POSES = [((4.0, 5.0, 1.5), 0.3), ((6.0, 5.5, 1.4), -0.4), ((2.5, 2.5, 1.6),
               ((4.5, 3.5, 1.5), 2.4), ((5.5, 6.5, 1.45), -2.8), ((7.0, 8.5, 1.55), 0.6), ((3.0, 8.5, 1.35), -0.2)]
 
 
-def perturbation(index):
+def perturbation(index, angle_scale=1.0):
     """Initial misalignment of scan `index`: 1 degree about (1,1,1)/sqrt(3) and (2,-1,1) cm for scan 1,
-    smaller seeded variations of the same size for further scans; scan 0 is unperturbed."""
+    smaller seeded variations of the same size for further scans; scan 0 is unperturbed.  angle_scale shrinks the rotation
+    (a stretched room keeps the same displacement at its walls)."""
     if index == 0:
         return np.eye(4, dtype=np.float64)
     rs = np.random.RandomState(1234 + index)
@@ -94,18 +99,18 @@ def perturbation(index):
     ang = math.radians(1.0) if index == 1 else math.radians(rs.uniform(0.5, 1.0))
     t = np.array([0.02, -0.01, 0.01]) if index == 1 else rs.uniform(-0.02, 0.02, size=3)
     P = np.eye(4)
-    P[:3, :3] = rot_axis_angle(axis, ang)
+    P[:3, :3] = rot_axis_angle(axis, ang * angle_scale)
     P[:3, 3] = t
     return P
 
 
-def make_scene(n_scans, n_points, seed=1234, sigma=0.002, device="cpu"):
+def make_scene(n_scans, n_points, seed=1234, sigma=0.002, device="cpu", room_scale=1.0):
     """List of dicts {xyz, normals, T_true, T_init} (T_init = perturbation * T_true applied about the scan origin)."""
     scans = []
     for i in range(n_scans):
         origin, yaw = SCAN_POSES[i % len(SCAN_POSES)]
-        xyz, nrm, T = make_scan(n_points, origin, yaw, seed + 17 * i, sigma, device)
-        P = perturbation(i)
+        xyz, nrm, T = make_scan(n_points, origin, yaw, seed + 17 * i, sigma, device, room_scale)
+        P = perturbation(i, 1.0 / room_scale)
         Ti = T.astype(np.float64).copy()
         Ti[:3, :3] = P[:3, :3] @ Ti[:3, :3]
         Ti[:3, 3] = Ti[:3, 3] + P[:3, 3]

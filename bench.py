@@ -72,12 +72,16 @@ def cpu_baseline(scans, d, thr, slab):
 
 
 def reg_traffic(model, n_images):
-    """Measured HBM bytes of pass 1 + pass 2 for the leg's n_images launches (PINHOLE only; profiles/round1_reg_traffic.json)."""
-    path = os.path.join(ROOT, "profiles", "round1_reg_traffic.json")
-    if model != 0 or not os.path.exists(path):
+    """Measured HBM bytes of pass 1 + pass 2 for the leg's n_images launches (rocprofv3 PMC of this bench, per launch, from
+    profiles/round1_traffic.json: same 4K images and 4 M points)."""
+    path = os.path.join(ROOT, "profiles", "round1_traffic.json")
+    if not os.path.exists(path):
         return None
     k = json.load(open(path))["kernels"]
-    return n_images * sum(v["hbm_bytes_per_launch"] for v in k.values())
+    names = {0: ("k_reg_pass1<0, false>", "k_reg_pass2<8, 10, 0, 10, true>"), 2: ("k_reg_pass1<2, false>", "k_reg_pass2_mfma<5, 18>")}.get(model)
+    if not names or any(n not in k for n in names):
+        return None
+    return n_images * sum(k[n]["hbm_bytes_per_launch"] for n in names)
 
 
 def image_registrator_leg(e3d, synth, cpu=True):

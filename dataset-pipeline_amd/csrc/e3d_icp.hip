@@ -29,7 +29,8 @@ void set_last_error(const std::string& msg) { g_last_error = msg; }
 const char* last_error_cstr() { return g_last_error.c_str(); }
 
 static int g_device = 0;
-static int g_nn_mode = 0;   // E3D_NN_MODE / e3d_set_nn_mode: 0 auto, 1 per-query, 2 hash-table buckets, 3 dense rows, 4 dense rows + MFMA filter
+// E3D_NN_MODE / e3d_set_nn_mode: 0 auto, 1 per-query, 2 hash-table buckets, 3 dense rows, 4 dense rows + MFMA filter
+static int g_nn_mode = [] { const char* e = getenv("E3D_NN_MODE"); const int v = e ? atoi(e) : 0; return (v >= 0 && v <= 4) ? v : 0; }();
 
 // -------------------------------------------------------------------------------------------------
 struct Cloud {

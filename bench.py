@@ -300,7 +300,7 @@ def main():
                                       "lm_total": tot[8] / world / K, "lm_pass_kernels": lm_ms / K, "nn_query_kernels": nn_ms / K},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "kernel": kernel,
-                         "note": "the NN kernel is VALU-issue bound, not HBM bound (rocprofv3 PMC: SQ_ACTIVE_INST_VALU ~ 78 % of its "
+                         "note": "the NN kernel is VALU-issue bound, not HBM bound (rocprofv3 PMC: SQ_ACTIVE_INST_VALU ~ 86 % of its "
                                  "wave cycles, profiles/round1_nn_rows_pmc_sq_*.txt); the LM pass kernel streams at the HBM roofline "
                                  "(see other.k_lm_pass_GBs)",
                          "algorithmic_bytes_per_launch": per_launch_bytes, "avg_launch_ms": avg_ms,

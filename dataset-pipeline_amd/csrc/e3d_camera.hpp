@@ -4,6 +4,8 @@
 //   kOpenCV           camera::PolynomialTangentialCamera  src/camera/camera_polynomial_tangential.h:41-159      I = 8
 //   kThinPrismFisheye camera::BenchmarkCamera             src/camera/camera_benchmark.h:44-52 =
 //                     FisheyeBase (camera_base_impl_fisheye.h:43-162) over ThinPrismCamera (camera_thin_prism.h:43-162)   I = 12
+//   kOpenCVFisheye    camera::FisheyePolynomial4Camera    src/camera/camera_fisheye_polynomial_4.h:42-50 =
+//                     FisheyeBase over Polynomial4Camera (camera_polynomial_4.h:43-135, RadialBase)                        I = 8
 //
 // Shared CRTP base, src/camera/camera_base_impl.h: NormalizedToImage :155-164, IterativeUndistort :216-250,
 // UndistortFromInside :278-328, ImageDerivativeByWorld :333-360, ImageDerivativeByIntrinsics :369-408, InitCutoff :410-463.
@@ -16,9 +18,10 @@
 
 namespace e3d {
 
-enum : int { kPinhole = 0, kOpenCV = 1, kThinPrismFisheye = 2 };
+enum : int { kPinhole = 0, kOpenCV = 1, kThinPrismFisheye = 2, kOpenCVFisheye = 3 };
 
-__host__ __device__ constexpr int cam_param_count(int model) { return model == kPinhole ? 4 : (model == kOpenCV ? 8 : 12); }
+__host__ __device__ constexpr int cam_param_count(int model) { return model == kPinhole ? 4 : ((model == kOpenCV || model == kOpenCVFisheye) ? 8 : 12); }
+__host__ __device__ constexpr bool cam_is_fisheye(int model) { return model == kThinPrismFisheye || model == kOpenCVFisheye; }
 
 struct CamLevel {
   int model;
@@ -37,6 +40,10 @@ template <int M>
 __device__ __forceinline__ void cam_distort_plain(const CamLevel& c, float nx, float ny, float& ox, float& oy) {
   if constexpr (M == kPinhole) {
     ox = nx; oy = ny;
+  } else if constexpr (M == kOpenCVFisheye) {      // RadialBase::Distort: point * DistortionFactor(squaredNorm)
+    const float r2 = nx * nx + ny * ny;
+    const float f = 1.0f + r2 * (c.q[0] + r2 * (c.q[1] + r2 * (c.q[2] + r2 * c.q[3])));
+    ox = nx * f; oy = ny * f;
   } else {
     const float x2 = nx * nx, xy = nx * ny, y2 = ny * ny;
     const float r2 = x2 + y2;
@@ -61,6 +68,16 @@ template <int M>
 __device__ __forceinline__ void cam_ddn_plain(const CamLevel& c, float nx, float ny, float* J) {
   if constexpr (M == kPinhole) {
     J[0] = 1.f; J[1] = 0.f; J[2] = 0.f; J[3] = 1.f;
+  } else if constexpr (M == kOpenCVFisheye) {      // camera_polynomial_4.h:78-98
+    const float nx2 = nx * nx, ny2 = ny * ny, nxny = nx * ny;
+    const float r2 = nx2 + ny2;
+    const float k1 = c.q[0], k2 = c.q[1], k3 = c.q[2], k4 = c.q[3];
+    const float term1 = 2 * k1 + r2 * (4 * k2 + r2 * (6 * k3 + r2 * 8 * k4));
+    const float term2 = 1 + r2 * (k1 + r2 * (k2 + r2 * (k3 + r2 * k4)));
+    J[0] = nx2 * term1 + term2;
+    J[1] = nxny * term1;
+    J[2] = J[1];
+    J[3] = ny2 * term1 + term2;
   } else {
     const float nx2 = nx * nx, ny2 = ny * ny;
     const float r2 = nx2 + ny2;
@@ -89,7 +106,11 @@ __device__ __forceinline__ void cam_ddn_plain(const CamLevel& c, float nx, float
 // DistortedDerivativeByDistortionParameters: rows d0, d1 of I - 4 entries
 template <int M>
 __device__ __forceinline__ void cam_ddp_plain(float nx, float ny, float* d0, float* d1) {
-  if constexpr (M != kPinhole) {
+  if constexpr (M == kOpenCVFisheye) {             // camera_polynomial_4.h:63-75
+    const float rs = nx * nx + ny * ny;
+    d0[0] = nx * rs; d0[1] = d0[0] * rs; d0[2] = d0[1] * rs; d0[3] = d0[2] * rs;
+    d1[0] = ny * rs; d1[1] = d1[0] * rs; d1[2] = d1[1] * rs; d1[3] = d1[2] * rs;
+  } else if constexpr (M != kPinhole) {
     const float nx2 = nx * nx, ny2 = ny * ny;
     const float two_nx_ny = 2.f * nx * ny;
     const float r2 = nx2 + ny2;
@@ -107,7 +128,7 @@ constexpr float kFisheyeEpsilon = 1e-6f;
 // ---- Child::Distort / DistortedDerivativeByNormalized / ...ByDistortionParameters ---------------------------------------------
 template <int M>
 __device__ __forceinline__ void cam_distort(const CamLevel& c, float nx, float ny, float& ox, float& oy) {
-  if constexpr (M != kThinPrismFisheye) {
+  if constexpr (!cam_is_fisheye(M)) {
     cam_distort_plain<M>(c, nx, ny, ox, oy);
   } else {
     const float r = sqrtf(nx * nx + ny * ny);
@@ -124,7 +145,7 @@ __device__ __forceinline__ void cam_distort(const CamLevel& c, float nx, float n
 
 template <int M>
 __device__ __forceinline__ void cam_ddn(const CamLevel& c, float nx, float ny, float* J) {
-  if constexpr (M != kThinPrismFisheye) {
+  if constexpr (!cam_is_fisheye(M)) {
     cam_ddn_plain<M>(c, nx, ny, J);
   } else {
     const float nx_ny = nx * ny, nx2 = nx * nx, ny2 = ny * ny;
@@ -152,7 +173,7 @@ __device__ __forceinline__ void cam_ddn(const CamLevel& c, float nx, float ny, f
 
 template <int M>
 __device__ __forceinline__ void cam_ddp(const CamLevel& c, float nx, float ny, float* d0, float* d1) {
-  if constexpr (M != kThinPrismFisheye) {
+  if constexpr (!cam_is_fisheye(M)) {
     cam_ddp_plain<M>(nx, ny, d0, d1);
   } else {
     const float r = sqrtf(nx * nx + ny * ny);
@@ -160,7 +181,7 @@ __device__ __forceinline__ void cam_ddp(const CamLevel& c, float nx, float ny, f
       const float atan_r = atan2f(r, 1.f);
       if (atan_r * atan_r > c.inner_cutoff2) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { d0[i] = 0.f; d1[i] = 0.f; }
+        for (int i = 0; i < cam_param_count(M) - 4; ++i) { d0[i] = 0.f; d1[i] = 0.f; }
         return;
       }
       const float theta_by_r = atan_r / r;

@@ -286,7 +286,17 @@ __global__ __launch_bounds__(kBlock) void k_mesh_vertices(const float4* __restri
   if constexpr (M != kPinhole) {
     float nx = X / Z, ny = Y / Z;
     float r2 = nx * nx + ny * ny;
-    if (r2 <= cam.cutoff2) {
+    if constexpr (M == kOpenCVFisheye) {
+      // FisheyePolynomial4 shader (renderer.cc:187-205): r2 turns into the radial factor (99 outside the cut-off)
+      if (r2 <= cam.cutoff2) {
+        const float r = sqrtf(r2);
+        if (r > 1e-6f) { const float theta_by_r = atan2f(r, 1.0f) / r; nx = theta_by_r * nx; ny = theta_by_r * ny; r2 = theta_by_r * theta_by_r * r2; }
+        r2 = 1.0f + r2 * (cam.q[0] + r2 * (cam.q[1] + r2 * (cam.q[2] + r2 * cam.q[3])));
+      } else {
+        r2 = 99.0f;
+      }
+      lx = Z * r2 * nx; ly = Z * r2 * ny;
+    } else if (r2 <= cam.cutoff2) {
       if constexpr (M == kThinPrismFisheye) {
         const float r = sqrtf(r2);
         if (r > 1e-6f) { const float theta_by_r = atan2f(r, 1.0f) / r; nx = theta_by_r * nx; ny = theta_by_r * ny; }
@@ -565,7 +575,7 @@ __global__ __launch_bounds__(kBlock) void k_undistort_lookup(CamLevel c, float2*
   if constexpr (M == kPinhole) { ux = dx; uy = dy; }
   else {
     cam_iterative_undistort<M>(c, dx, dy, dx, dy, ux, uy);
-    if constexpr (M == kThinPrismFisheye) {      // FisheyeBase::Undistort (camera_base_impl_fisheye.h:81-92)
+    if constexpr (cam_is_fisheye(M)) {           // FisheyeBase::Undistort (camera_base_impl_fisheye.h:81-92)
       const float r = sqrtf(ux * ux + uy * uy);
       const float factor = (r < kFisheyeEpsilon) ? 1.f : ((r > (float)(M_PI / 2.f)) ? E3D_CAM_INF : tanf(r) / r);
       ux = factor * ux; uy = factor * uy;
@@ -1454,8 +1464,49 @@ static void allreduce_device(e3d_reg* h, void* dev, size_t n, int dtype) {
     case kPinhole: { constexpr int M = kPinhole; stmt; } break;                            \
     case kOpenCV: { constexpr int M = kOpenCV; stmt; } break;                              \
     case kThinPrismFisheye: { constexpr int M = kThinPrismFisheye; stmt; } break;          \
+    case kOpenCVFisheye: { constexpr int M = kOpenCVFisheye; stmt; } break;                \
     default: throw Error(E3D_ERR_INVALID, "unknown camera model");                         \
   }
+
+// RadialBase::InitCutoff of the Polynomial4Camera inside OPENCV_FISHEYE (camera_base_impl_radial.h:59-170): the farthest image
+// corner, ten start radii, a 1-D Gauss-Newton each -- a few hundred scalar operations, done on the host in the reference's f32 /
+// f64 mix (the start radius is `float + float * double / float`).
+static float radial_init_cutoff(const CamLevel& c) {
+  const float* q = c.q;
+  auto factor = [&](float r2) { return 1.0f + r2 * (q[0] + r2 * (q[1] + r2 * (q[2] + r2 * q[3]))); };
+  auto dfactor = [&](float r2) { return 1.0f + r2 * (3.0f * q[0] + r2 * (5.0f * q[1] + r2 * (7.0f * q[2] + r2 * (9.0f * q[3])))); };
+  float test_r = 0.f;
+  for (int k = 0; k < 4; ++k) {
+    const float px = (k & 2) ? (float)c.width : 0.f, py = (k & 1) ? (float)c.height : 0.f;
+    const float x = c.fx_inv * px + c.cx_inv, y = c.fy_inv * py + c.cy_inv;
+    const float r = sqrtf(x * x + y * y);
+    if (k == 0 || r > test_r) test_r = r;
+  }
+  bool converged = false, second_available = false;
+  float best = INFINITY, second = INFINITY;
+  for (int i = 0; i < 10; ++i) {
+    const float init_radius = (float)((double)test_r + (double)1.5f * ((double)i - 0.5 * 10) / (double)(0.5f * 10));
+    bool tc = false;
+    float ur = init_radius, ur2 = init_radius * init_radius;
+    for (int it = 0; it < 100; ++it) {
+      const float r_candidate = ur * factor(ur2);
+      const float delta_r = r_candidate - test_r;
+      if (delta_r * delta_r < 1e-10f) { tc = true; break; }
+      const float step = delta_r / dfactor(ur2);
+      ur -= step;
+      ur2 = ur * ur;
+    }
+    if (tc) {
+      if (ur < 0.99f * best) { second = best; second_available = converged; best = ur; converged = true; }
+      else if (ur > 1 / 0.99f * best && ur < 0.99f * second) { second = ur; second_available = true; }
+    }
+  }
+  if (converged && best > 0) {
+    if (second_available && second > 0) { const float a = best * best * 1.01f, b = second * second; return (b < a) ? b : a; }
+    return best * best * 1.01f;
+  }
+  return INFINITY;
+}
 
 // One camera of the pyramid = one constructor call of the reference's camera class: pixel mapping (camera_base.cc:81-86) and,
 // for the distorted models, InitCutoff -- run on the device (k_cam_cutoff), 2(W+H) border points in parallel.
@@ -1467,6 +1518,7 @@ static CamLevel make_level(e3d_reg* h, int model, int w, int h_px, const float* 
   c.cx_inv = (float)(-1.0 * (double)c.cx / (double)c.fx); c.cy_inv = (float)(-1.0 * (double)c.cy / (double)c.fy);
   c.cutoff2 = INFINITY; c.inner_cutoff2 = INFINITY;
   if (model == kPinhole) return c;                  // PinholeCamera never calls InitCutoff (camera_pinhole.cc:35-43)
+  if (model == kOpenCVFisheye) { c.inner_cutoff2 = radial_init_cutoff(c); return c; }
   h->cut.reserve(2);
   const unsigned init[2] = {0u, 0x7f800000u};       // min_candidate = 0, max_candidate = +inf
   copy_in(h->cut.p, init, sizeof init, h->stream);
@@ -1693,8 +1745,9 @@ int e3d_reg_set_intrinsics(e3d_reg_t* h, int intrinsics_id, int camera_type, int
                            int n_parameters, int min_image_scale, int n_levels) {
   R_TRY
   if (!h || !parameters) throw Error(E3D_ERR_INVALID, "null argument");
-  if (camera_type != E3D_CAMERA_PINHOLE && camera_type != E3D_CAMERA_OPENCV && camera_type != E3D_CAMERA_THIN_PRISM_FISHEYE)
-    throw Error(E3D_ERR_INVALID, "camera model must be PINHOLE, OPENCV or THIN_PRISM_FISHEYE");
+  if (camera_type != E3D_CAMERA_PINHOLE && camera_type != E3D_CAMERA_OPENCV && camera_type != E3D_CAMERA_THIN_PRISM_FISHEYE &&
+      camera_type != E3D_CAMERA_OPENCV_FISHEYE)
+    throw Error(E3D_ERR_INVALID, "camera model must be PINHOLE, OPENCV, THIN_PRISM_FISHEYE or OPENCV_FISHEYE");
   if (n_parameters != cam_param_count(camera_type)) throw Error(E3D_ERR_INVALID, fmt("camera model %d takes %d parameters, got %d", camera_type, cam_param_count(camera_type), n_parameters));
   if (n_levels < 1 || n_levels > kRegMaxLevels || width < 2 || height < 2 || min_image_scale < 0) throw Error(E3D_ERR_INVALID, "bad pyramid description");
   Intrin in;
@@ -1720,7 +1773,7 @@ int e3d_reg_get_intrinsics_level(e3d_reg_t* h, int intrinsics_id, int level, int
     parameters[0] = c.fx; parameters[1] = c.fy; parameters[2] = c.cx; parameters[3] = c.cy;
     for (int i = 4; i < it->second.n_params; ++i) parameters[i] = c.q[i - 4];
   }
-  if (cutoff2) *cutoff2 = (c.model == kThinPrismFisheye) ? c.inner_cutoff2 : c.cutoff2;
+  if (cutoff2) *cutoff2 = cam_is_fisheye(c.model) ? c.inner_cutoff2 : c.cutoff2;
   return 0;
   R_CATCH()
 }

@@ -200,10 +200,12 @@ typedef struct {
 
 /* camera models (COLMAP names, src/camera/camera_base.cc:66-77) and their parameter counts:
  * PINHOLE fx fy cx cy (camera_pinhole.h:40-86); OPENCV + k1 k2 p1 p2 (camera_polynomial_tangential.h:41-159);
- * THIN_PRISM_FISHEYE + k1 k2 p1 p2 k3 k4 sx1 sy1 (camera_benchmark.h:44-52) */
+ * THIN_PRISM_FISHEYE + k1 k2 p1 p2 k3 k4 sx1 sy1 (camera_benchmark.h:44-52); OPENCV_FISHEYE + k1 k2 k3 k4
+ * (camera_fisheye_polynomial_4.h:42-50 over camera_polynomial_4.h:43-135) */
 #define E3D_CAMERA_PINHOLE 0             /* I = 4  */
 #define E3D_CAMERA_OPENCV 1              /* I = 8  */
 #define E3D_CAMERA_THIN_PRISM_FISHEYE 2  /* I = 12 */
+#define E3D_CAMERA_OPENCV_FISHEYE 3      /* I = 8  */
 
 e3d_reg_t* e3d_reg_create(const e3d_reg_params* params);
 void e3d_reg_destroy(e3d_reg_t* reg);
@@ -223,7 +225,7 @@ int e3d_reg_get_variable_descriptors(e3d_reg_t* reg, int point_scale, float* des
 int e3d_reg_set_intrinsics(e3d_reg_t* reg, int intrinsics_id, int camera_type, int width, int height,
                            const float* parameters, int n_parameters, int min_image_scale, int n_levels);
 /* queries one level of the pyramid the library built: size, parameters (n_parameters floats) and the radius cut-off
- * (+inf for PINHOLE; for THIN_PRISM_FISHEYE the cut-off of the inner thin-prism model, which is the one projection tests) */
+ * (+inf for PINHOLE; for the fisheye models the cut-off of the inner non-fisheye model, which is the one projection tests) */
 int e3d_reg_get_intrinsics_level(e3d_reg_t* reg, int intrinsics_id, int level, int* width, int* height,
                                  float* parameters, float* radius_cutoff_squared);
 /* opt::Image: u8 pyramid (level l has the size of intrinsics level l) and optional masks; pose image_T_global as the

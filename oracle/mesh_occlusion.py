@@ -28,6 +28,18 @@ def project_vertices(model, cam, R, t, verts):
             nx, ny = X / Z, Y / Z
             r2 = nx * nx + ny * ny
             inside = r2 <= F(cam.cutoff2)
+            if model == 3:
+                # FisheyePolynomial4 shader (renderer.cc:187-205): r2 becomes the radial factor, 99 outside the cut-off
+                r = np.sqrt(r2)
+                th = np.where(r > F(1e-6), np.arctan2(r, F(1.0)).astype(F) / r, F(1.0)).astype(F)
+                fx_, fy_ = np.where(r > F(1e-6), th * nx, nx).astype(F), np.where(r > F(1e-6), th * ny, ny).astype(F)
+                rr = np.where(r > F(1e-6), th * th * r2, r2).astype(F)
+                k1, k2, k3, k4 = [F(cam.p[4 + i]) for i in range(4)]
+                fac = F(1.0) + rr * (k1 + rr * (k2 + rr * (k3 + rr * k4)))
+                fac = np.where(inside, fac, F(99.0)).astype(F)
+                lx = ((Z * fac) * fx_).astype(F); ly = ((Z * fac) * fy_).astype(F)
+                px = F(cam.p[0]) * (lx / Z) + F(cam.p[2]); py = F(cam.p[1]) * (ly / Z) + F(cam.p[3])
+                return px.astype(F), py.astype(F), Z.astype(F)
             if model == 2:
                 r = np.sqrt(r2)
                 th = np.where(r > F(1e-6), np.arctan2(r, F(1.0)).astype(F) / r, F(1.0)).astype(F)

@@ -31,7 +31,10 @@
 
 #include "e3d_oracle.h"
 
-static inline int ocam_param_count(int type) { return type == 0 ? 4 : (type == 1 ? 8 : 12); }
+/* 0 PINHOLE, 1 OPENCV, 2 THIN_PRISM_FISHEYE, 3 OPENCV_FISHEYE = FisheyeBase over Polynomial4Camera (camera_fisheye_polynomial_4.h,
+ * camera_polynomial_4.h:43-135: radial factor 1 + r2 (k1 + r2 (k2 + r2 (k3 + r2 k4)))) */
+static inline int ocam_param_count(int type) { return type == 0 ? 4 : ((type == 1 || type == 3) ? 8 : 12); }
+static inline int ocam_is_fisheye(int type) { return type == 2 || type == 3; }
 
 /* ---- the polynomial models' Distort on a point already past the (optional) fisheye pre-warp --------------------------- */
 static inline void ocam_distort_plain(const oreg_camera* c, float nx, float ny, float* ox, float* oy) {
@@ -39,6 +42,11 @@ static inline void ocam_distort_plain(const oreg_camera* c, float nx, float ny, 
   const float* q = c->p + 4;
   const float x2 = nx * nx, xy = nx * ny, y2 = ny * ny;
   const float r2 = x2 + y2;
+  if (c->type == 3) {                       /* RadialBase::Distort: point * DistortionFactor(squaredNorm) */
+    const float f = 1.0f + r2 * (q[0] + r2 * (q[1] + r2 * (q[2] + r2 * q[3])));
+    *ox = nx * f; *oy = ny * f;
+    return;
+  }
   if (c->type == 1) {
     const float k1 = q[0], k2 = q[1], p1 = q[2], p2 = q[3];
     const float radial = 1 + r2 * (k1 + r2 * k2);
@@ -60,6 +68,17 @@ static inline void ocam_ddn_plain(const oreg_camera* c, float nx, float ny, floa
   const float* q = c->p + 4;
   const float nx2 = nx * nx, ny2 = ny * ny;
   const float r2 = nx2 + ny2;
+  if (c->type == 3) {                       /* camera_polynomial_4.h:78-98 */
+    const float k1 = q[0], k2 = q[1], k3 = q[2], k4 = q[3];
+    const float nxny = nx * ny;
+    const float term1 = 2 * k1 + r2 * (4 * k2 + r2 * (6 * k3 + r2 * 8 * k4));
+    const float term2 = 1 + r2 * (k1 + r2 * (k2 + r2 * (k3 + r2 * k4)));
+    J[0] = nx2 * term1 + term2;
+    J[1] = nxny * term1;
+    J[2] = J[1];
+    J[3] = ny2 * term1 + term2;
+    return;
+  }
   if (c->type == 1) {
     const float k1 = q[0], k2 = q[1], p1 = q[2], p2 = q[3];
     const float term1 = 2 * k1 + r2 * 4 * k2;
@@ -84,6 +103,12 @@ static inline void ocam_ddn_plain(const oreg_camera* c, float nx, float ny, floa
 /* DistortedDerivativeByDistortionParameters of the polynomial part: 2 x (I-4), row-major with row stride `ld` */
 static inline void ocam_ddp_plain(const oreg_camera* c, float nx, float ny, float* d0, float* d1) {
   if (c->type == 0) return;
+  if (c->type == 3) {                       /* camera_polynomial_4.h:63-75; radius_square = squaredNorm */
+    const float rs = nx * nx + ny * ny;
+    d0[0] = nx * rs; d0[1] = d0[0] * rs; d0[2] = d0[1] * rs; d0[3] = d0[2] * rs;
+    d1[0] = ny * rs; d1[1] = d1[0] * rs; d1[2] = d1[1] * rs; d1[3] = d1[2] * rs;
+    return;
+  }
   const float nx2 = nx * nx, ny2 = ny * ny;
   const float two_nx_ny = 2.f * nx * ny;
   const float r2 = nx2 + ny2;
@@ -99,7 +124,7 @@ static inline void ocam_ddp_plain(const oreg_camera* c, float nx, float ny, floa
 
 /* Child::Distort */
 static inline void ocam_distort(const oreg_camera* c, float nx, float ny, float* ox, float* oy) {
-  if (c->type != 2) { ocam_distort_plain(c, nx, ny, ox, oy); return; }
+  if (!ocam_is_fisheye(c->type)) { ocam_distort_plain(c, nx, ny, ox, oy); return; }
   const float r = sqrtf(nx * nx + ny * ny);
   if (r > OCAM_FISHEYE_EPS) {
     const float atan_r = atan2f(r, 1.f);
@@ -113,7 +138,7 @@ static inline void ocam_distort(const oreg_camera* c, float nx, float ny, float*
 
 /* Child::DistortedDerivativeByNormalized */
 static inline void ocam_ddn(const oreg_camera* c, float nx, float ny, float* J) {
-  if (c->type != 2) { ocam_ddn_plain(c, nx, ny, J); return; }
+  if (!ocam_is_fisheye(c->type)) { ocam_ddn_plain(c, nx, ny, J); return; }
   const float nx_ny = nx * ny, nx2 = nx * nx, ny2 = ny * ny;
   const float r2 = nx2 + ny2;
   const float r = sqrtf(r2);
@@ -138,7 +163,7 @@ static inline void ocam_ddn(const oreg_camera* c, float nx, float ny, float* J) 
 
 /* Child::DistortedDerivativeByDistortionParameters */
 static inline void ocam_ddp(const oreg_camera* c, float nx, float ny, float* d0, float* d1) {
-  if (c->type != 2) { ocam_ddp_plain(c, nx, ny, d0, d1); return; }
+  if (!ocam_is_fisheye(c->type)) { ocam_ddp_plain(c, nx, ny, d0, d1); return; }
   const float r = sqrtf(nx * nx + ny * ny);
   if (r > OCAM_FISHEYE_EPS) {
     const float atan_r = atan2f(r, 1.f);
@@ -273,6 +298,62 @@ static inline float ocam_init_cutoff(const oreg_camera* c) {
   return (max_candidate < a) ? max_candidate : a;              /* std::min(a, max_candidate) */
 }
 
+/* RadialBase (camera_base_impl_radial.h): 1-D Gauss-Newton on the radius (:59-88), UndistortFromInside over 10 start radii
+ * (:104-140), InitCutoff from the farthest image corner (:142-170).  `q` = k1..k4 of Polynomial4Camera. */
+static inline float ocam_radial_factor(const float* q, float r2) { return 1.0f + r2 * (q[0] + r2 * (q[1] + r2 * (q[2] + r2 * q[3]))); }
+static inline float ocam_radial_dfactor(const float* q, float r2) {      /* DistortedDerivativeByNormalized(r2), camera_polynomial_4.h:100-110 */
+  return 1.0f + r2 * (3.0f * q[0] + r2 * (5.0f * q[1] + r2 * (7.0f * q[2] + r2 * (9.0f * q[3]))));
+}
+static inline float ocam_radial_iterative_undistort(const float* q, float distorted_r, float starting_r, int* converged) {
+  *converged = 0;
+  float ur = starting_r, ur2 = starting_r * starting_r;
+  for (int i = 0; i < 100; ++i) {
+    const float r_candidate = ur * ocam_radial_factor(q, ur2);
+    const float delta_r = r_candidate - distorted_r;
+    if (delta_r * delta_r < 1e-10f) { *converged = 1; break; }
+    const float deriv = ocam_radial_dfactor(q, ur2);
+    const float step = delta_r / deriv;
+    ur -= step;
+    ur2 = ur * ur;
+  }
+  return ur;
+}
+static inline float ocam_radial_init_cutoff(const oreg_camera* c) {
+  const float* q = c->p + 4;
+  /* ImageToDistorted of the four corners (0,0) (0,H) (W,0) (W,H): k_inv applied, Eigen norm = sqrt(x*x + y*y) */
+  float test_r = 0.f;
+  for (int k = 0; k < 4; ++k) {
+    const float px = (k & 2) ? (float)c->width : 0.f, py = (k & 1) ? (float)c->height : 0.f;
+    const float x = c->fx_inv * px + c->cx_inv, y = c->fy_inv * py + c->cy_inv;
+    const float r = sqrtf(x * x + y * y);
+    if (k == 0 || r > test_r) test_r = r;                       /* std::max(test, r), starting from the first corner */
+  }
+  int converged = 0, second_available = 0;
+  float best = INFINITY, second = INFINITY;
+  for (int i = 0; i < 10; ++i) {
+    /* distorted_radius + kGridHalfExtent * (i - 0.5 * kNumGridSteps) / (0.5f * kNumGridSteps): float * double / float, + float -> float */
+    const float init_radius = (float)((double)test_r + (double)1.5f * ((double)i - 0.5 * 10) / (double)(0.5f * 10));
+    int tc;
+    const float result = ocam_radial_iterative_undistort(q, test_r, init_radius, &tc);
+    if (tc) {
+      if (result < 0.99f * best) {
+        second = best; second_available = converged;
+        best = result; converged = 1;
+      } else if (result > 1 / 0.99f * best && result < 0.99f * second) {
+        second = result; second_available = 1;
+      }
+    }
+  }
+  if (converged && best > 0) {
+    if (second_available && second > 0) {
+      const float a = best * best * 1.01f, b = second * second;
+      return (b < a) ? b : a;                                   /* std::min(a, b) */
+    }
+    return best * best * 1.01f;
+  }
+  return INFINITY;
+}
+
 static inline void ocam_init(oreg_camera* c, int type, int w, int h, const float* params) {
   memset(c, 0, sizeof *c);
   c->type = type; c->width = w; c->height = h; c->n_params = ocam_param_count(type);
@@ -287,6 +368,8 @@ static inline void ocam_init(oreg_camera* c, int type, int w, int h, const float
     oreg_camera inner = *c;
     inner.cutoff2 = INFINITY;
     c->inner_cutoff2 = ocam_init_cutoff(&inner);
+  } else if (type == 3) {
+    c->inner_cutoff2 = ocam_radial_init_cutoff(c);              /* the inner Polynomial4Camera (its constructor calls InitCutoff) */
   }
 }
 

@@ -51,7 +51,7 @@ void oracle_reg_camera_distort(const oreg_camera* c, float nx, float ny, float o
 void oracle_reg_camera_undistort(const oreg_camera* c, float dx, float dy, float out[2], int* converged) {
   float ux, uy; int conv;
   ocam_iterative_undistort(c, dx, dy, dx, dy, &ux, &uy, &conv);
-  if (c->type == 2) {
+  if (ocam_is_fisheye(c->type)) {
     const float r = sqrtf(ux * ux + uy * uy);
     const float factor = (r < OCAM_FISHEYE_EPS) ? 1.f : ((r > (float)(M_PI / 2.f)) ? INFINITY : tanf(r) / r);
     ux = factor * ux; uy = factor * uy;

@@ -43,11 +43,12 @@ def texture(u, v):
     return 120 + 55 * np.sin(7.0 * u) * np.cos(5.0 * v) + 35 * np.sin(3.0 * u + 4.0 * v) + 20 * np.cos(11.0 * v - 2.0 * u)
 
 
-# distortion parameter sets of the test scenes, keyed by camera model (0 PINHOLE, 1 OPENCV, 2 THIN_PRISM_FISHEYE)
+# distortion parameter sets of the test scenes, keyed by camera model (0 PINHOLE, 1 OPENCV, 2 THIN_PRISM_FISHEYE, 3 OPENCV_FISHEYE)
 DISTORTION = {
     0: [],
     1: [-0.101082, 0.0703954, 0.000438661, -0.000680887],
     2: [0.0221184, 0.0128597, 0.000531602, -0.000388873, 0.00623079, 0.0020419, -0.000805024, 4.07704e-05],
+    3: [0.0221184, 0.0128597, 0.00623079, 0.0020419],
 }
 
 
@@ -55,12 +56,15 @@ def distort_np(model, q, nx, ny):
     """float64 numpy version of the models' Distort (only for synthesising consistent test images)."""
     if model == 0:
         return nx, ny
-    if model == 2:
+    if model in (2, 3):
         r = np.sqrt(nx * nx + ny * ny)
         f = np.where(r > 1e-6, np.arctan(r) / np.maximum(r, 1e-12), 1.0)
         nx, ny = nx * f, ny * f
     x2, xy, y2 = nx * nx, nx * ny, ny * ny
     r2 = x2 + y2
+    if model == 3:
+        fac = 1 + r2 * (q[0] + r2 * (q[1] + r2 * (q[2] + r2 * q[3])))
+        return nx * fac, ny * fac
     k1, k2, p1, p2 = q[:4]
     if model == 1:
         radial = 1 + r2 * (k1 + r2 * k2)

@@ -193,6 +193,24 @@ def test_image_registrator_cli_with_rig(tmp_path, e3d, incomplete):
     assert len(costs) >= 3 and min(costs) < costs[0]
 
 
+@pytest.mark.parametrize("model,name,n_params", [(3, "OPENCV_FISHEYE", 8), (2, "THIN_PRISM_FISHEYE", 12)])
+def test_image_registrator_cli_fisheye_models(tmp_path, e3d, model, name, n_params):
+    """The distorted camera models through the tool: model name and parameter count survive the COLMAP round trip and the
+    photometric cost goes down."""
+    M = make_multi_image_scene(n_points=6000, n_images=3, seed=23, perturb=0.004, model=model)
+    names = ["dslr/img_%d.png" % i for i in range(3)]
+    d = _write_dataset(tmp_path, M, names, model_name=name)
+    out = _run_tool(d)
+    assert "Finished!" in out
+    cam = open(os.path.join(d, "out", "scale_1_state", "cameras.txt")).read().split("\n")[3].split()
+    assert cam[1] == name and len(cam) == 4 + n_params
+    p = np.array(cam[4:], np.float64)
+    # (the high-order coefficients are barely observable in this small field of view and may wander)
+    assert np.isfinite(p).all() and abs(p[4] - M["params"][4]) < 5e-2 and abs(p[0] - M["params"][0]) < 5.0
+    costs = [float(l.split(":")[-1]) for l in out.splitlines() if "Cost (considering occlusions) is" in l]
+    assert len(costs) >= 4 and np.isfinite(costs).all() and min(costs) < costs[0]
+
+
 def test_image_registrator_cli_errors(tmp_path):
     r = subprocess.run([os.path.join(BIN, "ImageRegistrator")], capture_output=True, text=True)
     assert r.returncode != 0 and "Please specify all the required paths." in r.stderr

@@ -54,7 +54,7 @@ def test_merge_close_points_edge_cases(e3d, mr):
         e3d.merge_close_points(0.1, 99, P, *args)
 
 
-@pytest.mark.parametrize("model", [0, 1, 2])
+@pytest.mark.parametrize("model", [0, 1, 2, 3])
 def test_point_radius_minmax_matches_oracle(e3d, mr, model):
     from reg_util import make_multi_image_scene
     M = make_multi_image_scene(n_points=8000, n_images=3, seed=21, model=model)
@@ -73,7 +73,7 @@ def test_point_radius_minmax_matches_oracle(e3d, mr, model):
     seen_o = np.isfinite(omn)
     assert np.array_equal(np.isfinite(gmn), seen_o) and seen_o[:-2].sum() > 4000 and not seen_o[-2:].any()
     assert np.array_equal(np.isfinite(gmx), np.isfinite(omx))
-    tol = 1e-6 if model != 2 else 1e-4
+    tol = 1e-6 if model in (0, 1) else 1e-4
     assert np.abs(gmn[seen_o] - omn[seen_o]).max() <= tol * omn[seen_o].max()
     assert np.abs(gmx[seen_o] - omx[seen_o]).max() <= tol * omx[seen_o].max()
     # sanity of the magnitude: half a pixel at depth z and focal length f is about z / (2 f)

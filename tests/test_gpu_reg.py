@@ -30,7 +30,7 @@ def _setup(e3d, rb, S, **pk):
     return P, levels
 
 
-MODELS = [0, 1, 2]          # PINHOLE, OPENCV, THIN_PRISM_FISHEYE
+MODELS = [0, 1, 2, 3]       # PINHOLE, OPENCV, THIN_PRISM_FISHEYE, OPENCV_FISHEYE
 EXACT = [0, 1]              # models without transcendental functions: device == host bit for bit
 
 
@@ -43,7 +43,7 @@ def test_camera_pyramid_matches(e3d, rb, model):
         w, h, p, c = P.intrinsics_level(0, l)
         assert (w, h) == (levels[l].width, levels[l].height)
         assert np.array_equal(p, levels[l].params())
-        co = levels[l].inner_cutoff2 if model == 2 else levels[l].cutoff2
+        co = levels[l].inner_cutoff2 if model in (2, 3) else levels[l].cutoff2
         assert c == co and (np.isinf(c) if model == 0 else np.isfinite(c))
 
 
@@ -118,7 +118,7 @@ def test_pass1_rows(e3d, rb, model):
 
 
 @pytest.mark.parametrize("model,rtype,rparam", [(0, 1, 47.434166), (0, 2, 30.0), (0, 0, 0.0), (1, 1, 47.434166), (2, 1, 47.434166),
-                                                (2, 2, 30.0)])
+                                                (2, 2, 30.0), (3, 1, 47.434166)])
 def test_accumulate_and_cost(e3d, rb, model, rtype, rparam):
     S = make_reg_scene(n_points=40000, seed=3, model=model)
     P, levels = _setup(e3d, rb, S, robust_weighting_type=rtype, robust_weighting_parameter=rparam)
@@ -544,6 +544,7 @@ RENDERER_KAT_PARAMS = {          # src/opt/test/test_renderer.cc:205-300 (Pinhol
     0: [250.0, 200.0, 319.5, 239.5],
     1: [340.926, 341.124, 302.4, 201.6, -0.101082, 0.0703954, 0.000438661, -0.000680887],
     2: [340.926, 341.124, 302.4, 201.6, -0.101082, 0.0703954, 0.000438661, -0.000680887, 0.002, 0.001, -0.003, 0.004],
+    3: [340.926, 341.124, 302.4, 201.6, 0.221184, 0.128597, 0.0623079, 0.20419],          # FisheyePolynomial4 (:275-280)
 }
 
 

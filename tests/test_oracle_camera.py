@@ -1,7 +1,7 @@
 """Pins the oracle's camera models (oracle/oracle_camera.h) with the reference's own camera tests, restated:
 src/camera/test/test_camera.cc:40-138 (undistort/distort round trips), :225-262 (ImageDerivativeByWorld vs central
 differences, tolerance 0.25), :264-343 (ImageDerivativeByIntrinsics vs central differences, tolerance 2.5e-3), with the
-parameter sets of TEST(Camera, Pinhole / PolynomialTangential / Benchmark) :408-426,470-475,499-506."""
+parameter sets of TEST(Camera, Pinhole / PolynomialTangential / FisheyePolynomial4 / Benchmark) :408-426,470-475,483-489,499-506."""
 import os
 import sys
 
@@ -17,6 +17,7 @@ CAMERAS = {
     "OPENCV": (rb.OPENCV, [340.926, 341.124, 302.4, 201.6, -0.101082, 0.0703954, 0.000438661, -0.000680887]),
     "THIN_PRISM_FISHEYE": (rb.THIN_PRISM_FISHEYE, [340.926, 341.124, 302.4, 201.6, 0.221184, 0.128597, 0.000531602, -0.000388873,
                                                    0.0623079, 0.20419, -0.000805024, 4.07704e-05]),
+    "OPENCV_FISHEYE": (rb.OPENCV_FISHEYE, [340.926, 341.124, 302.4, 201.6, 0.221184, 0.128597, 0.0623079, 0.20419]),
 }
 
 
@@ -97,6 +98,16 @@ def test_cutoffs():
     assert np.isinf(c.cutoff2) and np.isfinite(c.inner_cutoff2) and c.inner_cutoff2 > 0
     # a ray far outside the field of view projects to infinity
     assert not np.all(np.isfinite(rb.cam_project(c, np.array([50.0, 0.0, 0.1], np.float32))))
+    # OPENCV_FISHEYE: the inner Polynomial4Camera's RadialBase::InitCutoff (farthest corner, 1-D Gauss-Newton)
+    t, p = CAMERAS["OPENCV_FISHEYE"]
+    c = rb.make_camera(W, H, np.array(p, np.float32), t)
+    assert np.isinf(c.cutoff2) and np.isfinite(c.inner_cutoff2) and c.inner_cutoff2 > 0
+    k = np.array(p[4:], np.float64)
+    corner = max(np.hypot(c.fx_inv * x + c.cx_inv, c.fy_inv * y + c.cy_inv) for x, y in ((0, 0), (W, 0), (0, H), (W, H)))
+    # the cut-off radius r satisfies r * factor(r^2) = corner radius (f64 check of the f32 solver), then * 1.01
+    r = np.sqrt(c.inner_cutoff2 / np.float64(np.float32(1.01)))
+    fac = 1 + r**2 * (k[0] + r**2 * (k[1] + r**2 * (k[2] + r**2 * k[3])))
+    assert abs(r * fac - corner) <= 2e-5 * corner
 
 
 def test_scaled_camera_matches_scaledby():

@@ -355,7 +355,7 @@ def local_outlier_removal(xyz, mean_k, distance_factor_threshold, negative=False
 
 
 # ---- (B) image registration kernels ------------------------------------------------------------------------------------
-CAMERA_PINHOLE, CAMERA_OPENCV, CAMERA_THIN_PRISM_FISHEYE, CAMERA_OPENCV_FISHEYE = 0, 1, 2, 3
+CAMERA_PINHOLE, CAMERA_OPENCV, CAMERA_THIN_PRISM_FISHEYE, CAMERA_OPENCV_FISHEYE, CAMERA_FOV = 0, 1, 2, 3, 4
 
 
 def determine_point_neighbors(xyz, neighbor_count, candidate_count, scan_indices=None, scan_count=1):

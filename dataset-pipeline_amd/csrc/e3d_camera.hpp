@@ -6,6 +6,9 @@
 //                     FisheyeBase (camera_base_impl_fisheye.h:43-162) over ThinPrismCamera (camera_thin_prism.h:43-162)   I = 12
 //   kOpenCVFisheye    camera::FisheyePolynomial4Camera    src/camera/camera_fisheye_polynomial_4.h:42-50 =
 //                     FisheyeBase over Polynomial4Camera (camera_polynomial_4.h:43-135, RadialBase)                        I = 8
+//   kFov              camera::FisheyeFOVCamera            src/camera/camera_fisheye_fov.h:44-176 (Devernay-Faugeras)      I = 5
+//                     q[0] = omega; q[1] = two_tan_omega_half_, q[2] = image_radius_ (derived in camera_fisheye_fov.cc:37-51,
+//                     not parameters); closed-form Undistort, no cut-off, no lookup table
 //
 // Shared CRTP base, src/camera/camera_base_impl.h: NormalizedToImage :155-164, IterativeUndistort :216-250,
 // UndistortFromInside :278-328, ImageDerivativeByWorld :333-360, ImageDerivativeByIntrinsics :369-408, InitCutoff :410-463.
@@ -18,9 +21,11 @@
 
 namespace e3d {
 
-enum : int { kPinhole = 0, kOpenCV = 1, kThinPrismFisheye = 2, kOpenCVFisheye = 3 };
+enum : int { kPinhole = 0, kOpenCV = 1, kThinPrismFisheye = 2, kOpenCVFisheye = 3, kFov = 4 };
 
-__host__ __device__ constexpr int cam_param_count(int model) { return model == kPinhole ? 4 : ((model == kOpenCV || model == kOpenCVFisheye) ? 8 : 12); }
+__host__ __device__ constexpr int cam_param_count(int model) {
+  return model == kPinhole ? 4 : (model == kFov ? 5 : ((model == kOpenCV || model == kOpenCVFisheye) ? 8 : 12));
+}
 __host__ __device__ constexpr bool cam_is_fisheye(int model) { return model == kThinPrismFisheye || model == kOpenCVFisheye; }
 
 struct CamLevel {
@@ -40,6 +45,10 @@ template <int M>
 __device__ __forceinline__ void cam_distort_plain(const CamLevel& c, float nx, float ny, float& ox, float& oy) {
   if constexpr (M == kPinhole) {
     ox = nx; oy = ny;
+  } else if constexpr (M == kFov) {                // camera_fisheye_fov.h:55-63
+    const float r = sqrtf(nx * nx + ny * ny);
+    const float factor = (r < 1e-6f) ? 1.f : (atanf(r * c.q[1]) / (r * c.q[0]));
+    ox = nx * factor; oy = ny * factor;
   } else if constexpr (M == kOpenCVFisheye) {      // RadialBase::Distort: point * DistortionFactor(squaredNorm)
     const float r2 = nx * nx + ny * ny;
     const float f = 1.0f + r2 * (c.q[0] + r2 * (c.q[1] + r2 * (c.q[2] + r2 * c.q[3])));
@@ -68,6 +77,21 @@ template <int M>
 __device__ __forceinline__ void cam_ddn_plain(const CamLevel& c, float nx, float ny, float* J) {
   if constexpr (M == kPinhole) {
     J[0] = 1.f; J[1] = 0.f; J[2] = 0.f; J[3] = 1.f;
+  } else if constexpr (M == kFov) {                // camera_fisheye_fov.h:131-160
+    const float omega = c.q[0], tt = c.q[1];
+    const float nx_times_ny = nx * ny, nxs = nx * nx, nys = ny * ny;
+    const float radius_square = nxs + nys;
+    const float radius = sqrtf(radius_square);
+    if (radius < 1e-6f) { J[0] = 1.f; J[1] = 0.f; J[2] = 0.f; J[3] = 1.f; return; }
+    const float rdw = atanf(radius * tt);
+    const float tts = tt * tt;
+    const float part1 = omega * radius_square * radius;
+    const float part2 = omega * (tts * radius_square + 1) * radius_square;
+    const float part3 = rdw / (omega * radius);
+    J[0] = part3 - (nxs * rdw) / part1 + (nxs * tt) / part2;
+    J[1] = nx_times_ny * (tt / part2 - rdw / part1);
+    J[2] = J[1];
+    J[3] = part3 - (nys * rdw) / part1 + (nys * tt) / part2;
   } else if constexpr (M == kOpenCVFisheye) {      // camera_polynomial_4.h:78-98
     const float nx2 = nx * nx, ny2 = ny * ny, nxny = nx * ny;
     const float r2 = nx2 + ny2;
@@ -105,8 +129,19 @@ __device__ __forceinline__ void cam_ddn_plain(const CamLevel& c, float nx, float
 
 // DistortedDerivativeByDistortionParameters: rows d0, d1 of I - 4 entries
 template <int M>
-__device__ __forceinline__ void cam_ddp_plain(float nx, float ny, float* d0, float* d1) {
-  if constexpr (M == kOpenCVFisheye) {             // camera_polynomial_4.h:63-75
+__device__ __forceinline__ void cam_ddp_plain(const CamLevel& c, float nx, float ny, float* d0, float* d1) {
+  if constexpr (M == kFov) {                       // camera_fisheye_fov.h:94-118, one column (omega)
+    const float omega = c.q[0], tt = c.q[1];
+    const float radius_square = nx * nx + ny * ny;
+    const float radius = sqrtf(radius_square);
+    const float four_tan_omega_half_square = tt * tt;
+    const float tan_omega_half_square_plus_one = 0.25f * four_tan_omega_half_square + 1.f;
+    const float denominator_1 = omega * (four_tan_omega_half_square * radius_square + 1.f);
+    const float numerator_2 = atanf(tt * radius);
+    const float denominator_2 = omega * omega * radius;
+    d0[0] = (radius < 1e-6f) ? 0.f : ((nx * tan_omega_half_square_plus_one) / denominator_1 - (nx * numerator_2) / denominator_2);
+    d1[0] = (radius < 1e-6f) ? 0.f : ((ny * tan_omega_half_square_plus_one) / denominator_1 - (ny * numerator_2) / denominator_2);
+  } else if constexpr (M == kOpenCVFisheye) {      // camera_polynomial_4.h:63-75
     const float rs = nx * nx + ny * ny;
     d0[0] = nx * rs; d0[1] = d0[0] * rs; d0[2] = d0[1] * rs; d0[3] = d0[2] * rs;
     d1[0] = ny * rs; d1[1] = d1[0] * rs; d1[2] = d1[1] * rs; d1[3] = d1[2] * rs;
@@ -174,7 +209,7 @@ __device__ __forceinline__ void cam_ddn(const CamLevel& c, float nx, float ny, f
 template <int M>
 __device__ __forceinline__ void cam_ddp(const CamLevel& c, float nx, float ny, float* d0, float* d1) {
   if constexpr (!cam_is_fisheye(M)) {
-    cam_ddp_plain<M>(nx, ny, d0, d1);
+    cam_ddp_plain<M>(c, nx, ny, d0, d1);
   } else {
     const float r = sqrtf(nx * nx + ny * ny);
     if (r > kFisheyeEpsilon) {
@@ -185,9 +220,9 @@ __device__ __forceinline__ void cam_ddp(const CamLevel& c, float nx, float ny, f
         return;
       }
       const float theta_by_r = atan_r / r;
-      cam_ddp_plain<M>(theta_by_r * nx, theta_by_r * ny, d0, d1);
+      cam_ddp_plain<M>(c, theta_by_r * nx, theta_by_r * ny, d0, d1);
     } else {
-      cam_ddp_plain<M>(nx, ny, d0, d1);
+      cam_ddp_plain<M>(c, nx, ny, d0, d1);
     }
   }
 }
@@ -241,6 +276,13 @@ __device__ __forceinline__ void cam_image_deriv_by_intrinsics(const CamLevel& c,
 #pragma unroll
     for (int i = 4; i < I; ++i) { d[i] = c.fx * d[i]; d[I + i] = c.fy * d[I + i]; }
   }
+}
+
+// FisheyeFOVCamera::Undistort (camera_fisheye_fov.h:76-86): closed form, infinity past image_radius_
+__device__ __forceinline__ void cam_fov_undistort(const CamLevel& c, float dx, float dy, float& ux, float& uy) {
+  const float r = sqrtf(dx * dx + dy * dy);
+  const float factor = (r < 1e-6f) ? 1.f : ((r > c.q[2]) ? E3D_CAM_INF : (tanf(r * c.q[0]) / (r * c.q[1])));
+  ux = factor * dx; uy = factor * dy;
 }
 
 // IterativeUndistort of the non-fisheye model M (Gauss-Newton, <= 100 iterations, |delta|^2 < 1e-10)

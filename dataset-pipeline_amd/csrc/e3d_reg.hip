@@ -286,7 +286,13 @@ __global__ __launch_bounds__(kBlock) void k_mesh_vertices(const float4* __restri
   if constexpr (M != kPinhole) {
     float nx = X / Z, ny = Y / Z;
     float r2 = nx * nx + ny * ny;
-    if constexpr (M == kOpenCVFisheye) {
+    if constexpr (M == kFov) {
+      // FisheyeFOV shader (renderer.cc:153-160): r = length(xy) / z; r = atan(r * two_tan_omega_half) / (r * omega); xy *= r.  GLSL
+      // leaves 0 / 0 on the optical axis undefined; the camera class's guard (camera_fisheye_fov.h:58-61) is used there
+      const float r = sqrtf(X * X + Y * Y) / Z;
+      const float f = (r < 1e-6f) ? 1.0f : atanf(r * cam.q[1]) / (r * cam.q[0]);
+      lx = f * X; ly = f * Y;
+    } else if constexpr (M == kOpenCVFisheye) {
       // FisheyePolynomial4 shader (renderer.cc:187-205): r2 turns into the radial factor (99 outside the cut-off)
       if (r2 <= cam.cutoff2) {
         const float r = sqrtf(r2);
@@ -573,6 +579,7 @@ __global__ __launch_bounds__(kBlock) void k_undistort_lookup(CamLevel c, float2*
   const float dx = c.fx_inv * x + c.cx_inv, dy = c.fy_inv * y + c.cy_inv;
   float ux, uy;
   if constexpr (M == kPinhole) { ux = dx; uy = dy; }
+  else if constexpr (M == kFov) { cam_fov_undistort(c, dx, dy, ux, uy); }
   else {
     cam_iterative_undistort<M>(c, dx, dy, dx, dy, ux, uy);
     if constexpr (cam_is_fisheye(M)) {           // FisheyeBase::Undistort (camera_base_impl_fisheye.h:81-92)
@@ -642,7 +649,12 @@ __global__ __launch_bounds__(kBlock) void k_point_radius(const float4* __restric
   const float G0 = ((p.x + w * ux) + cx) + P.t[0], G1 = ((p.y + w * uy) + cy) + P.t[1], G2 = ((p.z + w * uz) + cz) + P.t[2];
   if (!(G2 > 0.f)) return;
   const float offx = (mx - 0.5f < 0) ? (mx + 0.5f) : (mx - 0.5f);
-  const float2 nxy = image_to_normalized(cam_min, lookup_min, offx, my);
+  float2 nxy;
+  if constexpr (M == kFov) {      // FisheyeFOVCamera's own ImageToNormalized: Undistort(ImageToDistorted(p)) (camera_fisheye_fov.h:65-74)
+    cam_fov_undistort(cam_min, cam_min.fx_inv * offx + cam_min.cx_inv, cam_min.fy_inv * my + cam_min.cy_inv, nxy.x, nxy.y);
+  } else {
+    nxy = image_to_normalized(cam_min, lookup_min, offx, my);
+  }
   const float d0 = G0 - G2 * nxy.x, d1 = G1 - G2 * nxy.y, d2 = G2 - G2 * 1.f;
   const float point_radius = sqrtf(d0 * d0 + (d1 * d1 + d2 * d2));
   if (point_radius < min_radius[i]) min_radius[i] = point_radius;
@@ -1465,6 +1477,7 @@ static void allreduce_device(e3d_reg* h, void* dev, size_t n, int dtype) {
     case kOpenCV: { constexpr int M = kOpenCV; stmt; } break;                              \
     case kThinPrismFisheye: { constexpr int M = kThinPrismFisheye; stmt; } break;          \
     case kOpenCVFisheye: { constexpr int M = kOpenCVFisheye; stmt; } break;                \
+    case kFov: { constexpr int M = kFov; stmt; } break;                                    \
     default: throw Error(E3D_ERR_INVALID, "unknown camera model");                         \
   }
 
@@ -1519,6 +1532,11 @@ static CamLevel make_level(e3d_reg* h, int model, int w, int h_px, const float* 
   c.cutoff2 = INFINITY; c.inner_cutoff2 = INFINITY;
   if (model == kPinhole) return c;                  // PinholeCamera never calls InitCutoff (camera_pinhole.cc:35-43)
   if (model == kOpenCVFisheye) { c.inner_cutoff2 = radial_init_cutoff(c); return c; }
+  if (model == kFov) {                              // camera_fisheye_fov.cc:37-51: derived constants, no InitCutoff
+    c.q[1] = 2.0f * tanf(0.5f * c.q[0]);
+    c.q[2] = (float)(M_PI / (double)(2 * c.q[0]));
+    return c;
+  }
   h->cut.reserve(2);
   const unsigned init[2] = {0u, 0x7f800000u};       // min_candidate = 0, max_candidate = +inf
   copy_in(h->cut.p, init, sizeof init, h->stream);
@@ -1746,8 +1764,8 @@ int e3d_reg_set_intrinsics(e3d_reg_t* h, int intrinsics_id, int camera_type, int
   R_TRY
   if (!h || !parameters) throw Error(E3D_ERR_INVALID, "null argument");
   if (camera_type != E3D_CAMERA_PINHOLE && camera_type != E3D_CAMERA_OPENCV && camera_type != E3D_CAMERA_THIN_PRISM_FISHEYE &&
-      camera_type != E3D_CAMERA_OPENCV_FISHEYE)
-    throw Error(E3D_ERR_INVALID, "camera model must be PINHOLE, OPENCV, THIN_PRISM_FISHEYE or OPENCV_FISHEYE");
+      camera_type != E3D_CAMERA_OPENCV_FISHEYE && camera_type != E3D_CAMERA_FOV)
+    throw Error(E3D_ERR_INVALID, "camera model must be PINHOLE, OPENCV, THIN_PRISM_FISHEYE, OPENCV_FISHEYE or FOV");
   if (n_parameters != cam_param_count(camera_type)) throw Error(E3D_ERR_INVALID, fmt("camera model %d takes %d parameters, got %d", camera_type, cam_param_count(camera_type), n_parameters));
   if (n_levels < 1 || n_levels > kRegMaxLevels || width < 2 || height < 2 || min_image_scale < 0) throw Error(E3D_ERR_INVALID, "bad pyramid description");
   Intrin in;
@@ -2223,8 +2241,10 @@ int e3d_reg_accumulate(e3d_reg_t* h, int image_id, int point_scale, double* H, d
                      S.fixed_desc.p, S.var_desc.p, S.obs_counts.p, w, h->partial.p)
     switch (V) {
       case 10: E3D_PASS2M(10); break;
+      case 11: E3D_PASS2M(11); break;
       case 14: E3D_PASS2M(14); break;
       case 16: E3D_PASS2M(16); break;
+      case 17: E3D_PASS2M(17); break;
       case 18: E3D_PASS2M(18); break;
       case 20: E3D_PASS2M(20); break;
       case 24: E3D_PASS2M(24); break;
@@ -2237,8 +2257,10 @@ int e3d_reg_accumulate(e3d_reg_t* h, int image_id, int point_scale, double* H, d
                      h->prm.point_neighbor_count, S.fixed_desc.p, S.var_desc.p, S.obs_counts.p, w, h->partial.p)
   switch (V) {     // E3D_REG_PASS2=valu: per-thread accumulators; row ranges chosen so that every launch keeps <= 75 of them
     case 10: E3D_PASS2(10, 0, 10, true); break;
+    case 11: E3D_PASS2(11, 0, 5, true); E3D_PASS2(11, 5, 11, false); break;
     case 14: E3D_PASS2(14, 0, 4, true); E3D_PASS2(14, 4, 14, false); break;
     case 16: E3D_PASS2(16, 0, 3, true); E3D_PASS2(16, 3, 8, false); E3D_PASS2(16, 8, 16, false); break;
+    case 17: E3D_PASS2(17, 0, 3, true); E3D_PASS2(17, 3, 8, false); E3D_PASS2(17, 8, 17, false); break;
     case 18: E3D_PASS2(18, 0, 3, true); E3D_PASS2(18, 3, 7, false); E3D_PASS2(18, 7, 18, false); break;
     case 20: E3D_PASS2(20, 0, 2, true); E3D_PASS2(20, 2, 6, false); E3D_PASS2(20, 6, 11, false); E3D_PASS2(20, 11, 20, false); break;
     case 24: E3D_PASS2(24, 0, 2, true); E3D_PASS2(24, 2, 5, false); E3D_PASS2(24, 5, 9, false); E3D_PASS2(24, 9, 14, false);

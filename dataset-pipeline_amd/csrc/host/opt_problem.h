@@ -243,9 +243,12 @@ inline int camera_model_from_name(const std::string& name) {
   if (name == "OPENCV") return E3D_CAMERA_OPENCV;
   if (name == "THIN_PRISM_FISHEYE") return E3D_CAMERA_THIN_PRISM_FISHEYE;
   if (name == "OPENCV_FISHEYE") return E3D_CAMERA_OPENCV_FISHEYE;
+  if (name == "FOV") return E3D_CAMERA_FOV;
   return -1;
 }
-inline int camera_param_count(int model) { return model == E3D_CAMERA_PINHOLE ? 4 : ((model == E3D_CAMERA_OPENCV || model == E3D_CAMERA_OPENCV_FISHEYE) ? 8 : 12); }
+inline int camera_param_count(int model) {
+  return model == E3D_CAMERA_PINHOLE ? 4 : (model == E3D_CAMERA_FOV ? 5 : ((model == E3D_CAMERA_OPENCV || model == E3D_CAMERA_OPENCV_FISHEYE) ? 8 : 12));
+}
 
 class Problem {
  public:
@@ -281,7 +284,7 @@ class Problem {
       in.intrinsics_id = (int)intrinsics_list.size();
       in.model = camera_model_from_name(c.model_name);
       in.model_name = c.model_name;
-      if (in.model < 0) return fail("Camera model " + c.model_name + " is not built on the HIP path (PINHOLE, OPENCV, OPENCV_FISHEYE, THIN_PRISM_FISHEYE are)");
+      if (in.model < 0) return fail("Camera model " + c.model_name + " is not built on the HIP path (PINHOLE, OPENCV, OPENCV_FISHEYE, FOV, THIN_PRISM_FISHEYE are)");
       in.n_params = camera_param_count(in.model);
       if ((int)c.parameters.size() != in.n_params) return fail("Wrong parameter count for camera model " + c.model_name);
       in.width = c.width; in.height = c.height;

@@ -201,11 +201,12 @@ typedef struct {
 /* camera models (COLMAP names, src/camera/camera_base.cc:66-77) and their parameter counts:
  * PINHOLE fx fy cx cy (camera_pinhole.h:40-86); OPENCV + k1 k2 p1 p2 (camera_polynomial_tangential.h:41-159);
  * THIN_PRISM_FISHEYE + k1 k2 p1 p2 k3 k4 sx1 sy1 (camera_benchmark.h:44-52); OPENCV_FISHEYE + k1 k2 k3 k4
- * (camera_fisheye_polynomial_4.h:42-50 over camera_polynomial_4.h:43-135) */
+ * (camera_fisheye_polynomial_4.h:42-50 over camera_polynomial_4.h:43-135); FOV + omega (camera_fisheye_fov.h:44-176) */
 #define E3D_CAMERA_PINHOLE 0             /* I = 4  */
 #define E3D_CAMERA_OPENCV 1              /* I = 8  */
 #define E3D_CAMERA_THIN_PRISM_FISHEYE 2  /* I = 12 */
 #define E3D_CAMERA_OPENCV_FISHEYE 3      /* I = 8  */
+#define E3D_CAMERA_FOV 4                 /* I = 5  */
 
 e3d_reg_t* e3d_reg_create(const e3d_reg_params* params);
 void e3d_reg_destroy(e3d_reg_t* reg);

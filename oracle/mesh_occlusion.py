@@ -28,6 +28,13 @@ def project_vertices(model, cam, R, t, verts):
             nx, ny = X / Z, Y / Z
             r2 = nx * nx + ny * ny
             inside = r2 <= F(cam.cutoff2)
+            if model == 4:
+                # FisheyeFOV shader (renderer.cc:153-160); the camera class's guard on the optical axis, where GLSL's 0 / 0 is undefined
+                r = (np.sqrt(X * X + Y * Y).astype(F) / Z).astype(F)
+                fac = np.where(r < F(1e-6), F(1.0), np.arctan(r * F(cam.p[5])).astype(F) / (r * F(cam.p[4]))).astype(F)
+                lx = (fac * X).astype(F); ly = (fac * Y).astype(F)
+                px = F(cam.p[0]) * (lx / Z) + F(cam.p[2]); py = F(cam.p[1]) * (ly / Z) + F(cam.p[3])
+                return px.astype(F), py.astype(F), Z.astype(F)
             if model == 3:
                 # FisheyePolynomial4 shader (renderer.cc:187-205): r2 becomes the radial factor, 99 outside the cut-off
                 r = np.sqrt(r2)

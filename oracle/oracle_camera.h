@@ -32,14 +32,21 @@
 #include "e3d_oracle.h"
 
 /* 0 PINHOLE, 1 OPENCV, 2 THIN_PRISM_FISHEYE, 3 OPENCV_FISHEYE = FisheyeBase over Polynomial4Camera (camera_fisheye_polynomial_4.h,
- * camera_polynomial_4.h:43-135: radial factor 1 + r2 (k1 + r2 (k2 + r2 (k3 + r2 k4)))) */
-static inline int ocam_param_count(int type) { return type == 0 ? 4 : ((type == 1 || type == 3) ? 8 : 12); }
+ * camera_polynomial_4.h:43-135: radial factor 1 + r2 (k1 + r2 (k2 + r2 (k3 + r2 k4)))), 4 FOV = FisheyeFOVCamera
+ * (camera_fisheye_fov.h:44-176; p[4] = omega, and -- derived, not parameters -- p[5] = two_tan_omega_half_, p[6] = image_radius_) */
+static inline int ocam_param_count(int type) { return type == 0 ? 4 : (type == 4 ? 5 : ((type == 1 || type == 3) ? 8 : 12)); }
 static inline int ocam_is_fisheye(int type) { return type == 2 || type == 3; }
 
 /* ---- the polynomial models' Distort on a point already past the (optional) fisheye pre-warp --------------------------- */
 static inline void ocam_distort_plain(const oreg_camera* c, float nx, float ny, float* ox, float* oy) {
   if (c->type == 0) { *ox = nx; *oy = ny; return; }
   const float* q = c->p + 4;
+  if (c->type == 4) {                       /* camera_fisheye_fov.h:55-63 */
+    const float r = sqrtf(nx * nx + ny * ny);
+    const float factor = (r < 1e-6f) ? 1.f : (atanf(r * q[1]) / (r * q[0]));
+    *ox = nx * factor; *oy = ny * factor;
+    return;
+  }
   const float x2 = nx * nx, xy = nx * ny, y2 = ny * ny;
   const float r2 = x2 + y2;
   if (c->type == 3) {                       /* RadialBase::Distort: point * DistortionFactor(squaredNorm) */
@@ -66,6 +73,23 @@ static inline void ocam_distort_plain(const oreg_camera* c, float nx, float ny, 
 static inline void ocam_ddn_plain(const oreg_camera* c, float nx, float ny, float* J) {
   if (c->type == 0) { J[0] = 1.f; J[1] = 0.f; J[2] = 0.f; J[3] = 1.f; return; }
   const float* q = c->p + 4;
+  if (c->type == 4) {                       /* camera_fisheye_fov.h:131-160 */
+    const float omega = q[0], tt = q[1];
+    const float nx_times_ny = nx * ny, nxs = nx * nx, nys = ny * ny;
+    const float radius_square = nxs + nys;
+    const float radius = sqrtf(radius_square);
+    if (radius < 1e-6f) { J[0] = 1; J[1] = 0; J[2] = 0; J[3] = 1; return; }
+    const float rdw = atanf(radius * tt);
+    const float tts = tt * tt;
+    const float part1 = omega * radius_square * radius;
+    const float part2 = omega * (tts * radius_square + 1) * radius_square;
+    const float part3 = rdw / (omega * radius);
+    J[0] = part3 - (nxs * rdw) / part1 + (nxs * tt) / part2;
+    J[1] = nx_times_ny * (tt / part2 - rdw / part1);
+    J[2] = J[1];
+    J[3] = part3 - (nys * rdw) / part1 + (nys * tt) / part2;
+    return;
+  }
   const float nx2 = nx * nx, ny2 = ny * ny;
   const float r2 = nx2 + ny2;
   if (c->type == 3) {                       /* camera_polynomial_4.h:78-98 */
@@ -103,6 +127,19 @@ static inline void ocam_ddn_plain(const oreg_camera* c, float nx, float ny, floa
 /* DistortedDerivativeByDistortionParameters of the polynomial part: 2 x (I-4), row-major with row stride `ld` */
 static inline void ocam_ddp_plain(const oreg_camera* c, float nx, float ny, float* d0, float* d1) {
   if (c->type == 0) return;
+  if (c->type == 4) {                       /* camera_fisheye_fov.h:94-118 */
+    const float omega = c->p[4], tt = c->p[5];
+    const float radius_square = nx * nx + ny * ny;
+    const float radius = sqrtf(radius_square);
+    const float four_tan_omega_half_square = tt * tt;
+    const float tan_omega_half_square_plus_one = 0.25f * four_tan_omega_half_square + 1.f;
+    const float denominator_1 = omega * (four_tan_omega_half_square * radius_square + 1.f);
+    const float numerator_2 = atanf(tt * radius);
+    const float denominator_2 = omega * omega * radius;
+    d0[0] = (radius < 1e-6f) ? 0.f : ((nx * tan_omega_half_square_plus_one) / denominator_1 - (nx * numerator_2) / denominator_2);
+    d1[0] = (radius < 1e-6f) ? 0.f : ((ny * tan_omega_half_square_plus_one) / denominator_1 - (ny * numerator_2) / denominator_2);
+    return;
+  }
   if (c->type == 3) {                       /* camera_polynomial_4.h:63-75; radius_square = squaredNorm */
     const float rs = nx * nx + ny * ny;
     d0[0] = nx * rs; d0[1] = d0[0] * rs; d0[2] = d0[1] * rs; d0[3] = d0[2] * rs;
@@ -298,6 +335,13 @@ static inline float ocam_init_cutoff(const oreg_camera* c) {
   return (max_candidate < a) ? max_candidate : a;              /* std::min(a, max_candidate) */
 }
 
+/* FisheyeFOVCamera::Undistort (camera_fisheye_fov.h:76-86), closed form; also its ImageToNormalized (no lookup table, no clamp) */
+static inline void ocam_fov_undistort(const oreg_camera* c, float dx, float dy, float* ux, float* uy) {
+  const float r = sqrtf(dx * dx + dy * dy);
+  const float factor = (r < 1e-6f) ? 1.f : ((r > c->p[6]) ? INFINITY : (tanf(r * c->p[4]) / (r * c->p[5])));
+  *ux = factor * dx; *uy = factor * dy;
+}
+
 /* RadialBase (camera_base_impl_radial.h): 1-D Gauss-Newton on the radius (:59-88), UndistortFromInside over 10 start radii
  * (:104-140), InitCutoff from the farthest image corner (:142-170).  `q` = k1..k4 of Polynomial4Camera. */
 static inline float ocam_radial_factor(const float* q, float r2) { return 1.0f + r2 * (q[0] + r2 * (q[1] + r2 * (q[2] + r2 * q[3]))); }
@@ -370,6 +414,12 @@ static inline void ocam_init(oreg_camera* c, int type, int w, int h, const float
     c->inner_cutoff2 = ocam_init_cutoff(&inner);
   } else if (type == 3) {
     c->inner_cutoff2 = ocam_radial_init_cutoff(c);              /* the inner Polynomial4Camera (its constructor calls InitCutoff) */
+  } else if (type == 4) {
+    /* camera_fisheye_fov.cc:37-51: two_tan_omega_half_(2.0f * tan(0.5f * omega_)), image_radius_(M_PI / (2 * omega_)); no cut-off.
+     * with g++/libstdc++ <math.h> puts std::tan(float) / std::atan(float) into the global namespace (checked here with a
+     * static_assert on decltype(tan(1.0f))), so these are tanf / atanf */
+    c->p[5] = 2.0f * tanf(0.5f * c->p[4]);
+    c->p[6] = (float)(M_PI / (double)(2 * c->p[4]));
   }
 }
 

@@ -36,6 +36,10 @@ void oracle_undistortion_lookup(const oreg_camera* c, float* out) {
 /* ImageToNormalized(Vector2f) with the lookup table: bilinear.  The reference clamps y to height - 1.00f and then reads row
  * y + 1 (one row past the table when y == height - 1, with weight 0); that row index is clamped here. */
 void oracle_image_to_normalized(const oreg_camera* c, const float* lookup, float px, float py, float out[2]) {
+  if (c->type == 4) {       /* FisheyeFOVCamera overrides ImageToNormalized: Undistort(ImageToDistorted(p)), closed form (camera_fisheye_fov.h:65-74) */
+    oracle_reg_camera_undistort(c, c->fx_inv * px + c->cx_inv, c->fy_inv * py + c->cy_inv, out, NULL);
+    return;
+  }
   float cx = px < c->width - 1.001f ? px : c->width - 1.001f;
   float cy = py < c->height - 1.00f ? py : c->height - 1.00f;
   if (!(cx > 0.f)) cx = 0.f;      /* cwiseMax(0) */

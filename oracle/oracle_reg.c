@@ -50,6 +50,12 @@ void oracle_reg_camera_distort(const oreg_camera* c, float nx, float ny, float o
  * solution with tanf(r)/r (camera_base_impl_fisheye.h:81-92) */
 void oracle_reg_camera_undistort(const oreg_camera* c, float dx, float dy, float out[2], int* converged) {
   float ux, uy; int conv;
+  if (c->type == 4) {
+    ocam_fov_undistort(c, dx, dy, &ux, &uy);
+    out[0] = ux; out[1] = uy;
+    if (converged) *converged = isfinite(ux) && isfinite(uy);
+    return;
+  }
   ocam_iterative_undistort(c, dx, dy, dx, dy, &ux, &uy, &conv);
   if (ocam_is_fisheye(c->type)) {
     const float r = sqrtf(ux * ux + uy * uy);

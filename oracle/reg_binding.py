@@ -28,8 +28,8 @@ def rig_link(q_image_T_rig, q_rig_T_global, t_rig_T_global):
     return r
 
 
-PINHOLE, OPENCV, THIN_PRISM_FISHEYE, OPENCV_FISHEYE = 0, 1, 2, 3
-PARAM_COUNT = {0: 4, 1: 8, 2: 12, 3: 8}      # PINHOLE, OPENCV, THIN_PRISM_FISHEYE, OPENCV_FISHEYE
+PINHOLE, OPENCV, THIN_PRISM_FISHEYE, OPENCV_FISHEYE, FOV = 0, 1, 2, 3, 4
+PARAM_COUNT = {0: 4, 1: 8, 2: 12, 3: 8, 4: 5}      # PINHOLE, OPENCV, THIN_PRISM_FISHEYE, OPENCV_FISHEYE, FOV
 
 
 _READY = False

@@ -43,12 +43,13 @@ def texture(u, v):
     return 120 + 55 * np.sin(7.0 * u) * np.cos(5.0 * v) + 35 * np.sin(3.0 * u + 4.0 * v) + 20 * np.cos(11.0 * v - 2.0 * u)
 
 
-# distortion parameter sets of the test scenes, keyed by camera model (0 PINHOLE, 1 OPENCV, 2 THIN_PRISM_FISHEYE, 3 OPENCV_FISHEYE)
+# distortion parameter sets of the test scenes, keyed by camera model (0 PINHOLE, 1 OPENCV, 2 THIN_PRISM_FISHEYE, 3 OPENCV_FISHEYE, 4 FOV)
 DISTORTION = {
     0: [],
     1: [-0.101082, 0.0703954, 0.000438661, -0.000680887],
     2: [0.0221184, 0.0128597, 0.000531602, -0.000388873, 0.00623079, 0.0020419, -0.000805024, 4.07704e-05],
     3: [0.0221184, 0.0128597, 0.00623079, 0.0020419],
+    4: [0.9],
 }
 
 
@@ -56,6 +57,10 @@ def distort_np(model, q, nx, ny):
     """float64 numpy version of the models' Distort (only for synthesising consistent test images)."""
     if model == 0:
         return nx, ny
+    if model == 4:
+        r = np.sqrt(nx * nx + ny * ny)
+        f = np.where(r > 1e-6, np.arctan(r * 2 * np.tan(0.5 * q[0])) / (np.maximum(r, 1e-12) * q[0]), 1.0)
+        return nx * f, ny * f
     if model in (2, 3):
         r = np.sqrt(nx * nx + ny * ny)
         f = np.where(r > 1e-6, np.arctan(r) / np.maximum(r, 1e-12), 1.0)

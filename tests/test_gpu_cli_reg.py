@@ -193,7 +193,7 @@ def test_image_registrator_cli_with_rig(tmp_path, e3d, incomplete):
     assert len(costs) >= 3 and min(costs) < costs[0]
 
 
-@pytest.mark.parametrize("model,name,n_params", [(3, "OPENCV_FISHEYE", 8), (2, "THIN_PRISM_FISHEYE", 12)])
+@pytest.mark.parametrize("model,name,n_params", [(3, "OPENCV_FISHEYE", 8), (2, "THIN_PRISM_FISHEYE", 12), (4, "FOV", 5)])
 def test_image_registrator_cli_fisheye_models(tmp_path, e3d, model, name, n_params):
     """The distorted camera models through the tool: model name and parameter count survive the COLMAP round trip and the
     photometric cost goes down."""

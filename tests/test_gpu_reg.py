@@ -30,7 +30,7 @@ def _setup(e3d, rb, S, **pk):
     return P, levels
 
 
-MODELS = [0, 1, 2, 3]       # PINHOLE, OPENCV, THIN_PRISM_FISHEYE, OPENCV_FISHEYE
+MODELS = [0, 1, 2, 3, 4]       # PINHOLE, OPENCV, THIN_PRISM_FISHEYE, OPENCV_FISHEYE, FOV
 EXACT = [0, 1]              # models without transcendental functions: device == host bit for bit
 
 
@@ -44,7 +44,7 @@ def test_camera_pyramid_matches(e3d, rb, model):
         assert (w, h) == (levels[l].width, levels[l].height)
         assert np.array_equal(p, levels[l].params())
         co = levels[l].inner_cutoff2 if model in (2, 3) else levels[l].cutoff2
-        assert c == co and (np.isinf(c) if model == 0 else np.isfinite(c))
+        assert c == co and (np.isinf(c) if model in (0, 4) else np.isfinite(c))      # PINHOLE and FOV have no cut-off
 
 
 @pytest.mark.parametrize("model", MODELS)
@@ -545,6 +545,7 @@ RENDERER_KAT_PARAMS = {          # src/opt/test/test_renderer.cc:205-300 (Pinhol
     1: [340.926, 341.124, 302.4, 201.6, -0.101082, 0.0703954, 0.000438661, -0.000680887],
     2: [340.926, 341.124, 302.4, 201.6, -0.101082, 0.0703954, 0.000438661, -0.000680887, 0.002, 0.001, -0.003, 0.004],
     3: [340.926, 341.124, 302.4, 201.6, 0.221184, 0.128597, 0.0623079, 0.20419],          # FisheyePolynomial4 (:275-280)
+    4: [250.0, 200.0, 319.5, 239.5, 1.0],                                                  # FisheyeFOV (:259-263)
 }
 
 

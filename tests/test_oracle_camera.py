@@ -1,7 +1,8 @@
 """Pins the oracle's camera models (oracle/oracle_camera.h) with the reference's own camera tests, restated:
 src/camera/test/test_camera.cc:40-138 (undistort/distort round trips), :225-262 (ImageDerivativeByWorld vs central
 differences, tolerance 0.25), :264-343 (ImageDerivativeByIntrinsics vs central differences, tolerance 2.5e-3), with the
-parameter sets of TEST(Camera, Pinhole / PolynomialTangential / FisheyePolynomial4 / Benchmark) :408-426,470-475,483-489,499-506."""
+parameter sets of TEST(Camera, Pinhole / FisheyeFOV / PolynomialTangential / FisheyePolynomial4 / Benchmark)
+:408-426,464-468,470-475,483-489,499-506."""
 import os
 import sys
 
@@ -18,6 +19,7 @@ CAMERAS = {
     "THIN_PRISM_FISHEYE": (rb.THIN_PRISM_FISHEYE, [340.926, 341.124, 302.4, 201.6, 0.221184, 0.128597, 0.000531602, -0.000388873,
                                                    0.0623079, 0.20419, -0.000805024, 4.07704e-05]),
     "OPENCV_FISHEYE": (rb.OPENCV_FISHEYE, [340.926, 341.124, 302.4, 201.6, 0.221184, 0.128597, 0.0623079, 0.20419]),
+    "FOV": (rb.FOV, [250.0, 200.0, 319.5, 239.5, 1.0]),
 }
 
 
@@ -36,6 +38,8 @@ def test_parameter_storage(cam):
 
 
 def test_undistort_then_distort_image_corners(cam):
+    if cam.type == rb.FOV:
+        pytest.skip("test_camera.cc:383-388: not run for the FOV camera, the corners lie outside its image circle")
     for x, y in ((0, 0), (W - 1, 0), (0, H - 1), (W - 1, H - 1)):
         nxy = np.array([cam.fx_inv * np.float32(x) + cam.cx_inv, cam.fy_inv * np.float32(y) + cam.cy_inv], np.float32)
         u, _ = rb.cam_undistort(cam, float(nxy[0]), float(nxy[1]))
@@ -56,6 +60,8 @@ def test_image_derivative_by_world(cam):
     step = np.float32(0.001)
     for at in ((0.0, 0.0, 3.0), (1.0, 3.0, 8.0), (-0.1, 0.7, -0.8)):
         at = np.array(at, np.float32)
+        if cam.type == rb.FOV and at[0] == 0 and at[1] == 0:
+            continue          # test_camera.cc:261-264: the FOV model's derivative at the principal axis is the identity, not the limit
         J = rb.cam_deriv_by_world(cam, at)
         for a in range(3):
             plus, minus = at.copy(), at.copy()
@@ -108,6 +114,23 @@ def test_cutoffs():
     r = np.sqrt(c.inner_cutoff2 / np.float64(np.float32(1.01)))
     fac = 1 + r**2 * (k[0] + r**2 * (k[1] + r**2 * (k[2] + r**2 * k[3])))
     assert abs(r * fac - corner) <= 2e-5 * corner
+
+
+def test_fov_closed_forms():
+    """FisheyeFOVCamera: no cut-off, derived constants of its constructor (camera_fisheye_fov.cc:37-51), closed-form Undistort that
+    returns infinity past image_radius_ (camera_fisheye_fov.h:76-86)"""
+    t, p = CAMERAS["FOV"]
+    c = rb.make_camera(W, H, np.array(p, np.float32), t)
+    assert np.isinf(c.cutoff2)
+    assert c.p[5] == np.float32(2.0) * np.tan(np.float32(0.5), dtype=np.float32) and c.p[6] == np.float32(np.pi / 2.0)
+    u, conv = rb.cam_undistort(c, 1.2, 1.2)                  # r = 1.697 > pi/2
+    assert not conv and np.all(np.isinf(u))
+    u, conv = rb.cam_undistort(c, 0.3, -0.4)
+    assert conv and np.allclose(u, np.array([0.3, -0.4]) * np.tan(0.5) / (0.5 * 2 * np.tan(0.5)), rtol=1e-6)
+    d = rb.cam_distort(c, 0.0, 0.0)
+    assert d[0] == 0 and d[1] == 0
+    assert np.array_equal(rb.cam_deriv_by_world(c, np.array([0, 0, 2], np.float32)),
+                          np.array([[125.0, 0, 0], [0, 100.0, 0]], np.float32))
 
 
 def test_scaled_camera_matches_scaledby():

@@ -190,3 +190,84 @@ def make_rig_scene(n_points=6000, n_frames=2, width=240, height=180, n_levels=3,
     return dict(pts=pts, nbr=nbr, K=K, fixed_desc=fixed_desc, params=params, width=width, height=height, n_levels=n_levels,
                 images=images, point_radius=0.01, model=model, rig_true=[ident, (q1_true, t1_true)], rig_init=rig_init,
                 frames=[[2 * f, 2 * f + 1] for f in range(n_frames)])
+
+
+# ---- the synthetic scene of the reference's Test4FrameAlignment (src/opt/test/test_alignment.cc:87-340) ---------------------------
+def _render_color_depth(verts, colors, tris, R, t, W, H, fx, fy, cx, cy, min_depth, max_depth):
+    """Gouraud-shaded triangle mesh through a pinhole camera: perspective-correct colour and camera-space depth at the integer
+    pixel positions, nearest fragment wins, 0 where nothing is drawn (what the reference's OpenGL renderer produces for this
+    scene; triangles with a vertex in front of the near plane are dropped -- in this scene they lie outside the image)."""
+    P = verts.astype(np.float64) @ np.asarray(R, np.float64).T + np.asarray(t, np.float64)
+    z = P[:, 2]
+    with np.errstate(all="ignore"):
+        px = fx * P[:, 0] / z + cx; py = fy * P[:, 1] / z + cy
+    depth = np.full((H, W), np.inf); color = np.zeros((H, W, 3))
+    for i0, i1, i2 in tris:
+        zs = z[[i0, i1, i2]]
+        if not np.all(zs > min_depth):
+            continue
+        xs, ys = px[[i0, i1, i2]], py[[i0, i1, i2]]
+        if xs.max() < 0 or ys.max() < 0 or xs.min() > W - 1 or ys.min() > H - 1:
+            continue
+        x0, y0 = max(0, int(np.ceil(xs.min()))), max(0, int(np.ceil(ys.min())))
+        x1, y1 = min(W - 1, int(np.floor(xs.max()))), min(H - 1, int(np.floor(ys.max())))
+        if x0 > x1 or y0 > y1:
+            continue
+        yy, xx = np.mgrid[y0:y1 + 1, x0:x1 + 1].astype(np.float64)
+        area = (xs[1] - xs[0]) * (ys[2] - ys[0]) - (ys[1] - ys[0]) * (xs[2] - xs[0])
+        if area == 0:
+            continue
+        e0 = ((xs[2] - xs[1]) * (yy - ys[1]) - (ys[2] - ys[1]) * (xx - xs[1])) / area
+        e1 = ((xs[0] - xs[2]) * (yy - ys[2]) - (ys[0] - ys[2]) * (xx - xs[2])) / area
+        e2 = 1.0 - e0 - e1
+        ok = (e0 >= 0) & (e1 >= 0) & (e2 >= 0)
+        if not ok.any():
+            continue
+        w0, w1, w2 = e0 / zs[0], e1 / zs[1], e2 / zs[2]
+        zz = 1.0 / (w0 + w1 + w2)
+        ok &= (zz >= min_depth) & (zz <= max_depth)
+        sub_d = depth[y0:y1 + 1, x0:x1 + 1]; sub_c = color[y0:y1 + 1, x0:x1 + 1]
+        ok &= zz < sub_d
+        c = (w0[..., None] * colors[i0] + w1[..., None] * colors[i1] + w2[..., None] * colors[i2]) * zz[..., None]
+        sub_d[ok] = zz[ok]; sub_c[ok] = c[ok]
+    depth[np.isinf(depth)] = 0
+    return np.clip(np.rint(color), 0, 255).astype(np.uint8), depth.astype(np.float32)
+
+
+def make_four_frame_scene(seed=0):
+    """Heightmap of 61 x 61 vertices over 5 m x 5 m at z = 1 +- 0.05, pulled towards the camera by 6 * (distance from the centre
+    in grid units), random vertex colours; two recordings 0.5 m apart in y, each with two cameras 0.1 m apart in x, pinhole
+    256 x 256 with f = 128; the scan = 30 % of the pixels of the four depth maps, coloured from the images; initial poses =
+    ground truth moved by (d, d, 0) * 0.002 with d = 1 for camera 0 and 3 for camera 1 (the last of the three perturbation blocks
+    of the reference test overwrites the two before it)."""
+    rng = np.random.RandomState(seed)
+    n = 61
+    gx, gy = np.meshgrid(np.arange(n), np.arange(n))
+    u, v = gx / (n - 1.0) - 0.5, gy / (n - 1.0) - 0.5
+    zz = 1.0 + rng.uniform(-0.05, 0.05, (n, n)) - 6 * np.sqrt(u * u + v * v)
+    verts = np.stack([u * 5.0, v * 5.0, zz], -1).reshape(-1, 3).astype(np.float32)
+    colors = rng.randint(0, 256, (n * n, 3)).astype(np.float64)
+    tris = []
+    for y in range(n - 1):
+        for x in range(n - 1):
+            tris += [(x + (y + 1) * n, (x + 1) + y * n, x + y * n), (x + (y + 1) * n, (x + 1) + (y + 1) * n, (x + 1) + y * n)]
+    W = H = 256
+    fx = fy = 128.0; cx = cy = 127.5
+    image_T_global = {}
+    for s, ty in ((0, -0.25), (1, 0.25)):
+        for c, tx in ((0, 0.0), (1, 0.1)):
+            image_T_global[(s, c)] = (np.eye(3), -np.array([tx, ty, 0.0]))        # inverse of a pure translation
+    out = dict(width=W, height=H, params=np.array([fx, fy, cx, cy]), images={}, pts=[], rgb=[])
+    for key, (R, t) in image_T_global.items():
+        col, dep = _render_color_depth(verts, colors, tris, R, t, W, H, fx, fy, cx, cy, 0.1, 1.2 * 1.05)
+        sel = (dep > 0) & (rng.uniform(0, 1, dep.shape) < 0.3)
+        ys, xs = np.nonzero(sel)
+        d = dep[sel].astype(np.float64)
+        cam = np.stack([d * (xs - cx) / fx, d * (ys - cy) / fy, d], -1)
+        out["pts"].append((cam - t) @ R)                                          # global_T_image * p
+        out["rgb"].append(col[sel])
+        dirn = 1.0 if key[1] == 0 else 3.0
+        out["images"][key] = dict(color=col, depth=dep, R=R, t=t, t_init=t + np.array([dirn * 0.002, dirn * 0.002, 0.0]))
+    out["pts"] = np.concatenate(out["pts"]).astype(np.float32)
+    out["rgb"] = np.concatenate(out["rgb"]).astype(np.uint8)
+    return out

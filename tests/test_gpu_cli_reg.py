@@ -481,3 +481,82 @@ def test_reference_pair_alignment_thresholds(tmp_path, case):
     r_err = np.degrees(np.arccos(np.clip((np.trace(Rd) - 1) / 2, -1, 1)))
     print(case, "translation error / scene depth", t_err, "rotation error deg", r_err)
     assert t_err <= 1e-2 and r_err <= 1.0, (t_err, r_err)
+
+
+# ---- the reference's four-frame alignment tests (src/opt/test/test_alignment.cc:87-634, TEST(Alignment, FourFrame_*) :649-697) -----
+def _se3_log(T):
+    from scipy.spatial.transform import Rotation
+    w = Rotation.from_matrix(T[:3, :3]).as_rotvec()
+    th = np.linalg.norm(w)
+    K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+    Vinv = np.eye(3) - 0.5 * K + (1 / 12.0 if th < 1e-6 else (1 - th * np.cos(th / 2) / (2 * np.sin(th / 2))) / th**2) * (K @ K)
+    return np.concatenate([Vinv @ T[:3, 3], w])
+
+
+@pytest.mark.parametrize("use_variable_colors,use_rig", [(False, False), (True, False), (False, True), (True, True)])
+def test_reference_four_frame_alignment_thresholds(tmp_path, use_variable_colors, use_rig):
+    """FourFrame_FixedColorsOnly / _FixedAndVariableColors, each without and with a rig, through the drop-in tool: two recordings
+    of a two-camera rig see a colour-interpolated heightmap; the scan is 30 % of the pixels of the four depth maps; every pose
+    starts 2 mm (camera 0) or 6 mm (camera 1) off in x and y.  After optimising all image scales with the test's parameters every
+    component of log(result * ground_truth^-1) must be <= 0.0016 and the mean optical flow between the ground-truth and the
+    resulting projections <= 0.07 px (test_alignment.cc:541-603).  The scene comes from numpy's generator instead of std::mt19937,
+    the images from a software renderer instead of OpenGL (tests/reg_util.py:make_four_frame_scene); the depth-residual variant
+    (FourFrame_DepthResidualVerification) needs depth-map residuals, which are not built."""
+    import json
+    from PIL import Image
+    from scipy.spatial.transform import Rotation
+    from reg_util import make_four_frame_scene
+    S = make_four_frame_scene(seed=0)
+    d = str(tmp_path)
+    write_ply_xyz(os.path.join(d, "scan.ply"), S["pts"], rgb=S["rgb"])
+    write_mlp(os.path.join(d, "scans.mlp"), [("scan", "scan.ply", np.eye(4))])
+    os.makedirs(os.path.join(d, "state"))
+    fx, fy, cx, cy = S["params"]
+    with open(os.path.join(d, "state", "cameras.txt"), "w") as f:
+        f.write("1 PINHOLE %d %d %.9g %.9g %.9g %.9g\n" % (S["width"], S["height"], fx, fy, cx + 0.5, cy + 0.5))
+    keys = [(0, 0), (0, 1), (1, 0), (1, 1)]                      # (rig_image_set, camera_index), the order the test adds them in
+    with open(os.path.join(d, "state", "images.txt"), "w") as f:
+        for i, (s, c) in enumerate(keys):
+            name = "camera%d/image%d.png" % (c, s)
+            os.makedirs(os.path.join(d, "images", "camera%d" % c), exist_ok=True)
+            Image.fromarray(S["images"][(s, c)]["color"], "RGB").save(os.path.join(d, "images", name))
+            f.write("%d 1 0 0 0 %s 1 %s\n\n" % (i + 1, " ".join("%.9g" % v for v in S["images"][(s, c)]["t_init"]), name))
+    if use_rig:
+        json.dump([{"ref_camera_id": 1, "cameras": [{"camera_id": 1, "image_prefix": "camera0"}, {"camera_id": 1, "image_prefix": "camera1"}]}],
+                  open(os.path.join(d, "state", "rigs.json"), "w"), indent=4)
+    cmd = [os.path.join(BIN, "ImageRegistrator"), "--scan_alignment_path", os.path.join(d, "scans.mlp"), "--multi_res_point_cloud_directory_path",
+           os.path.join(d, "cache"), "--image_base_path", os.path.join(d, "images"), "--state_path", os.path.join(d, "state"),
+           "--output_folder_path", os.path.join(d, "out"), "--observations_cache_path", os.path.join(d, "obs_cache"),
+           "--max_iterations", "500", "--point_neighbor_count", "5", "--point_neighbor_candidate_count", "25",
+           "--min_mean_intensity_difference_for_points", "0", "--robust_weighting_type", "tukey", "--robust_weighting_parameter", "5",
+           "--max_initial_image_area_in_pixels", str(64 * 64), "--occlusion_depth_threshold", "0.05",
+           "--fixed_residuals_weight", "1", "--variable_residuals_weight", "1" if use_variable_colors else "0"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "#Image scales: 3" in r.stdout and "--- Optimizing at scaling factor 1 ---" in r.stdout
+    if use_rig:
+        assert "AssignRigs(): assigned 4 out of 4 images to rig(s)" in r.stdout
+    st = _read_images_txt(os.path.join(d, "out", "scale_1_state", "images.txt"))
+    cam = open(os.path.join(d, "out", "scale_1_state", "cameras.txt")).read().split("\n")[3].split()
+    rfx, rfy, rcx, rcy = [float(v) for v in cam[4:8]]
+    rcx -= 0.5; rcy -= 0.5
+    worst = 0.0
+    flow_sum = flow_count = 0
+    by_name = {v[3]: v for v in st.values()}
+    for (s, c) in keys:
+        q, t = by_name["camera%d/image%d.png" % (c, s)][:2]
+        Tr = np.eye(4); Tr[:3, :3] = Rotation.from_quat([q[1], q[2], q[3], q[0]]).as_matrix(); Tr[:3, 3] = t
+        im = S["images"][(s, c)]
+        Tg = np.eye(4); Tg[:3, :3] = im["R"]; Tg[:3, 3] = im["t"]
+        delta = _se3_log(Tr @ np.linalg.inv(Tg))
+        worst = max(worst, np.abs(delta).max())
+        ys, xs = np.nonzero(im["depth"] > 0)
+        dd = im["depth"][ys, xs].astype(np.float64)
+        P = np.stack([dd * (xs - cx) / fx, dd * (ys - cy) / fy, dd, np.ones_like(dd)], 0)
+        Q = Tr @ np.linalg.inv(Tg) @ P
+        ok = Q[2] > 0
+        flow = np.hypot(rfx * Q[0, ok] / Q[2, ok] + rcx - xs[ok], rfy * Q[1, ok] / Q[2, ok] + rcy - ys[ok])
+        flow_sum += flow.sum(); flow_count += ok.sum()
+    mean_flow = flow_sum / flow_count
+    print("variable", use_variable_colors, "rig", use_rig, "worst log component", worst, "mean flow px", mean_flow)
+    assert worst <= 0.0016 and mean_flow <= 0.07, (worst, mean_flow)

@@ -271,12 +271,14 @@ __global__ __launch_bounds__(kBlock) void k_min_filter_v(const unsigned* __restr
 // (renderer.cc:226-262,470-495,630-653: no cut-off branch for PINHOLE, `* 99` outside the cut-off), projection
 // p = f * x'/z + c (SetupProjection :919-974 maps pixel centres to integer coordinates of this code base), depth =
 // perspective-correct interpolation of the camera-space z (the fragment shader writes var_depth), nearest fragment wins,
-// pixels without geometry are 0 (glClearColor).  Triangles with a vertex in front of the near plane are dropped instead of
-// clipped.  OpenGL's own rasterisation is implementation-defined at pixel-boundary ties; here: samples at integer pixel
+// pixels without geometry are 0 (glClearColor).  Triangles that cross the near plane z = min_depth are clipped the way OpenGL clips
+// them: on the vertex shader's OUTPUT (x', y', z) -- linear interpolation along the edge from the vertex inside to the one outside,
+// so the cut is shared by the triangles on both sides of an edge -- and before the perspective division; a vertex behind the camera
+// goes through the distortion code like any other (its x / z is mirrored), as in the shader.  OpenGL's own rasterisation is implementation-defined at pixel-boundary ties; here: samples at integer pixel
 // coordinates, edge functions in f64 (exact for f32 inputs), top-left rule.
 template <int M>
 __global__ __launch_bounds__(kBlock) void k_mesh_vertices(const float4* __restrict__ v, size_t n, Pose P, CamLevel cam,
-                                                          float4* __restrict__ out) {
+                                                          float4* __restrict__ out, float2* __restrict__ out_l) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const float4 p = v[i];
@@ -325,6 +327,35 @@ __global__ __launch_bounds__(kBlock) void k_mesh_vertices(const float4* __restri
     }
   }
   out[i] = make_float4(cam.fx * (lx / Z) + cam.cx, cam.fy * (ly / Z) + cam.cy, Z, 0.f);
+  out_l[i] = make_float2(lx, ly);
+}
+
+struct MeshProj { float fx, fy, cx, cy, near; };
+
+// the point where the edge from vertex `in` (z >= near) to vertex `out` (z < near) meets the near plane, projected
+__device__ __forceinline__ float4 near_cut(const float4 pin, const float2 lin, const float4 pout, const float2 lout, const MeshProj& m) {
+  const float t = (m.near - pin.z) / (pout.z - pin.z);
+  const float lx = lin.x + t * (lout.x - lin.x), ly = lin.y + t * (lout.y - lin.y);
+  return make_float4(m.fx * (lx / m.near) + m.cx, m.fy * (ly / m.near) + m.cy, m.near, 0.f);
+}
+// Sub-triangle `sub` of triangle (p0 p1 p2) after near-plane clipping; returns how many sub-triangles there are (0: entirely in
+// front of the plane, 1: untouched or one vertex kept, 2: one vertex cut off -- the quad is split along the diagonal from the first
+// cut to the second kept vertex)
+__device__ __forceinline__ int near_clip(const float4* p, const float2* l, const MeshProj& m, int sub, float4& a, float4& b, float4& c) {
+  const bool in0 = p[0].z >= m.near, in1 = p[1].z >= m.near, in2 = p[2].z >= m.near;
+  const int n_in = (int)in0 + (int)in1 + (int)in2;
+  if (n_in == 3) { a = p[0]; b = p[1]; c = p[2]; return 1; }
+  if (n_in == 0) return 0;
+  if (n_in == 1) {
+    const int i = in0 ? 0 : (in1 ? 1 : 2), j = (i + 1) % 3, k = (i + 2) % 3;
+    a = p[i]; b = near_cut(p[i], l[i], p[j], l[j], m); c = near_cut(p[i], l[i], p[k], l[k], m);
+    return 1;
+  }
+  const int i = !in0 ? 0 : (!in1 ? 1 : 2), j = (i + 1) % 3, k = (i + 2) % 3;
+  const float4 pj = near_cut(p[j], l[j], p[i], l[i], m);
+  if (sub == 0) { a = pj; b = p[j]; c = p[k]; }
+  else { a = pj; b = p[k]; c = near_cut(p[k], l[k], p[i], l[i], m); }
+  return 2;
 }
 
 struct TriSetup { double ax, ay, bx, by, cx, cy; float za, zb, zc; int x0, y0, x1, y1; bool ok; };
@@ -334,7 +365,6 @@ __device__ __forceinline__ TriSetup tri_setup(const float4 a, const float4 b, co
                                               float max_depth) {
   TriSetup t{};
   t.ok = false;
-  if (!(a.z > min_depth && b.z > min_depth && c.z > min_depth)) return t;      // near plane: dropped, not clipped
   if (a.z > max_depth && b.z > max_depth && c.z > max_depth) return t;
   if (!(isfinite(a.x) && isfinite(a.y) && isfinite(b.x) && isfinite(b.y) && isfinite(c.x) && isfinite(c.y))) return t;
   const float fx0 = fminf(a.x, fminf(b.x, c.x)), fx1 = fmaxf(a.x, fmaxf(b.x, c.x));
@@ -376,16 +406,30 @@ __device__ __forceinline__ float tri_depth(const TriSetup& t, int x, int y, floa
   return z;
 }
 
-__global__ __launch_bounds__(kBlock) void k_mesh_bin(const float4* __restrict__ pv, const unsigned* __restrict__ tris, size_t n_tris,
+__global__ __launch_bounds__(kBlock) void k_mesh_bin(const float4* __restrict__ pv, const float2* __restrict__ pl,
+                                                     const unsigned* __restrict__ tris, size_t n_tris, MeshProj mp,
                                                      int width, int height, float min_depth, float max_depth, int tiles_x,
                                                      unsigned tri_offset, unsigned* __restrict__ keys, unsigned* __restrict__ vals,
                                                      unsigned* __restrict__ counter, unsigned capacity) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  TriSetup t{};
-  if (i < n_tris) t = tri_setup(pv[tris[3 * i]], pv[tris[3 * i + 1]], pv[tris[3 * i + 2]], width, height, min_depth, max_depth);
-  int tx0 = 0, tx1 = -1, ty0 = 0, ty1 = -1;
-  if (t.ok) { tx0 = t.x0 / kTile; tx1 = t.x1 / kTile; ty0 = t.y0 / kTile; ty1 = t.y1 / kTile; }
-  const unsigned count = t.ok ? (unsigned)((tx1 - tx0 + 1) * (ty1 - ty0 + 1)) : 0u;
+  int tx0[2] = {0, 0}, tx1[2] = {-1, -1}, ty0[2] = {0, 0}, ty1[2] = {-1, -1};
+  unsigned count = 0;
+  if (i < n_tris) {
+    const unsigned i0 = tris[3 * i], i1 = tris[3 * i + 1], i2 = tris[3 * i + 2];
+    const float4 p[3] = {pv[i0], pv[i1], pv[i2]};
+    const float2 l[3] = {pl[i0], pl[i1], pl[i2]};
+    int n_sub = 1;
+    for (int sub = 0; sub < n_sub; ++sub) {        // sub-triangle 1 exists only where the near plane cuts off one vertex
+      float4 a, b, c;
+      n_sub = near_clip(p, l, mp, sub, a, b, c);
+      if (sub >= n_sub) break;
+      const TriSetup t = tri_setup(a, b, c, width, height, min_depth, max_depth);
+      if (t.ok) {
+        tx0[sub] = t.x0 / kTile; tx1[sub] = t.x1 / kTile; ty0[sub] = t.y0 / kTile; ty1[sub] = t.y1 / kTile;
+        count += (unsigned)((tx1[sub] - tx0[sub] + 1) * (ty1[sub] - ty0[sub] + 1));
+      }
+    }
+  }
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   unsigned incl = count;
 #pragma unroll
@@ -403,15 +447,17 @@ __global__ __launch_bounds__(kBlock) void k_mesh_bin(const float4* __restrict__ 
   __syncthreads();
   unsigned o = block_base + incl - count;
   for (int k = 0; k < wv; ++k) o += wave_total[k];
-  for (int ty = ty0; ty <= ty1; ++ty)
-    for (int tx = tx0; tx <= tx1; ++tx) {
-      if (o < capacity) { keys[o] = (unsigned)(ty * tiles_x + tx); vals[o] = tri_offset + (unsigned)i; }
-      ++o;
-    }
+  for (int sub = 0; sub < 2; ++sub)
+    for (int ty = ty0[sub]; ty <= ty1[sub]; ++ty)
+      for (int tx = tx0[sub]; tx <= tx1[sub]; ++tx) {
+        if (o < capacity) { keys[o] = (unsigned)(ty * tiles_x + tx); vals[o] = (tri_offset + (unsigned)i) | ((unsigned)sub << 31); }
+        ++o;
+      }
 }
 
 // one workgroup per tile, one LANE per triangle (occlusion meshes are fine: a triangle covers a few pixels)
-__global__ __launch_bounds__(kBlock) void k_mesh_tiles(const float4* __restrict__ pv, const unsigned* __restrict__ tris,
+__global__ __launch_bounds__(kBlock) void k_mesh_tiles(const float4* __restrict__ pv, const float2* __restrict__ pl,
+                                                       const unsigned* __restrict__ tris, MeshProj mp,
                                                        const unsigned* __restrict__ vals, const unsigned* __restrict__ start,
                                                        const unsigned* __restrict__ end, int tiles_x, int width, int height,
                                                        float min_depth, float max_depth, unsigned* __restrict__ depth_bits) {
@@ -422,9 +468,14 @@ __global__ __launch_bounds__(kBlock) void k_mesh_tiles(const float4* __restrict_
   __syncthreads();
   const unsigned s = start[t], e = end[t];
   for (unsigned j = s + threadIdx.x; j < e; j += kBlock) {
-    const unsigned f = vals[j];
-    const TriSetup ts = tri_setup(pv[tris[3 * (size_t)f]], pv[tris[3 * (size_t)f + 1]], pv[tris[3 * (size_t)f + 2]], width, height,
-                                  min_depth, max_depth);
+    const unsigned f = vals[j] & 0x7fffffffu;
+    const int sub = (int)(vals[j] >> 31);            // second half of a triangle whose near-plane cut is a quad
+    const unsigned i0 = tris[3 * (size_t)f], i1 = tris[3 * (size_t)f + 1], i2 = tris[3 * (size_t)f + 2];
+    const float4 p[3] = {pv[i0], pv[i1], pv[i2]};
+    const float2 l[3] = {pl[i0], pl[i1], pl[i2]};
+    float4 a, b, c;
+    if (sub >= near_clip(p, l, mp, sub, a, b, c)) continue;
+    const TriSetup ts = tri_setup(a, b, c, width, height, min_depth, max_depth);
     if (!ts.ok) continue;
     const int bx0 = max(ts.x0, x0), by0 = max(ts.y0, y0), bx1 = min(ts.x1, x0 + kTile - 1), by1 = min(ts.y1, y0 + kTile - 1);
     for (int y = by0; y <= by1; ++y)
@@ -1424,7 +1475,8 @@ struct e3d_reg {
   DevBuf<float4> splat;
   size_t n_splat = 0;
   std::vector<std::unique_ptr<MeshDev>> meshes;
-  DevBuf<float4> mesh_projected;
+  DevBuf<float4> mesh_projected;          // per mesh vertex: pixel position and camera-space z
+  DevBuf<float2> mesh_shaded;             // ... and the vertex shader output (x', y') the near-plane clipping interpolates
   DevBuf<float> depth_unmasked, ztmp_f;
   float min_occlusion_depth = 0.05f, max_occlusion_depth = 100.f;     // opt::Parameters defaults (parameters.h:60-61)
   bool mask_occlusion_boundaries = true;
@@ -1926,17 +1978,18 @@ static void render_depth_meshes(e3d_reg* h, ImageDev& im, const Intrin& in, cons
   D.reserve(px);
   bool first = true;
   for (auto& m : h->meshes) {
-    h->mesh_projected.reserve(m->n_vertices);
+    h->mesh_projected.reserve(m->n_vertices); h->mesh_shaded.reserve(m->n_vertices);
     E3D_CAM_SWITCH(in.type, hipLaunchKernelGGL(k_mesh_vertices<M>, dim3(nblk(m->n_vertices)), dim3(kBlock), 0, s, m->vertices.p,
-                                               m->n_vertices, im.pose, cam, h->mesh_projected.p));
+                                               m->n_vertices, im.pose, cam, h->mesh_projected.p, h->mesh_shaded.p));
+    const MeshProj mp{cam.fx, cam.fy, cam.cx, cam.cy, h->min_occlusion_depth};
     // capacity: most triangles touch one tile; retried with the exact count if the first guess was too small
     size_t capacity = m->n_triangles + m->n_triangles / 2 + 1024;
     unsigned n_pairs = 0;
     for (int attempt = 0; attempt < 2; ++attempt) {
       for (int k = 0; k < 2; ++k) { h->sp_keys[k].reserve(capacity); h->sp_vals[k].reserve(capacity); }
       E3D_HIP(hipMemsetAsync(h->sp_counter.p, 0, sizeof(unsigned), s));
-      hipLaunchKernelGGL(k_mesh_bin, dim3(nblk(m->n_triangles)), dim3(kBlock), 0, s, h->mesh_projected.p, m->triangles.p, m->n_triangles,
-                         cam.width, cam.height, h->min_occlusion_depth, h->max_occlusion_depth, tiles_x, 0u, h->sp_keys[0].p,
+      hipLaunchKernelGGL(k_mesh_bin, dim3(nblk(m->n_triangles)), dim3(kBlock), 0, s, h->mesh_projected.p, h->mesh_shaded.p, m->triangles.p,
+                         m->n_triangles, mp, cam.width, cam.height, h->min_occlusion_depth, h->max_occlusion_depth, tiles_x, 0u, h->sp_keys[0].p,
                          h->sp_vals[0].p, h->sp_counter.p, (unsigned)std::min<size_t>(capacity, 0xFFFFFFFFu));
       copy_out(&n_pairs, h->sp_counter.p, sizeof n_pairs, s);
       rsync(h);
@@ -1953,7 +2006,8 @@ static void render_depth_meshes(e3d_reg* h, ImageDev& im, const Intrin& in, cons
     }
     DevBuf<float>& target = first ? D : h->ztmp_f;
     target.reserve(px);
-    hipLaunchKernelGGL(k_mesh_tiles, dim3((unsigned)n_tiles), dim3(kBlock), 0, s, h->mesh_projected.p, m->triangles.p, h->sp_vals[1].p,
+    hipLaunchKernelGGL(k_mesh_tiles, dim3((unsigned)n_tiles), dim3(kBlock), 0, s, h->mesh_projected.p, h->mesh_shaded.p, m->triangles.p, mp,
+                       h->sp_vals[1].p,
                        h->tile_start.p, h->tile_end.p, tiles_x, cam.width, cam.height, h->min_occlusion_depth, h->max_occlusion_depth,
                        reinterpret_cast<unsigned*>(target.p));
     if (!first) hipLaunchKernelGGL(k_depth_merge, dim3(nblk(px)), dim3(kBlock), 0, s, D.p, h->ztmp_f.p, px);

@@ -4,7 +4,10 @@ The reference renders occlusion meshes with OpenGL (src/opengl/renderer.cc) and 
 software implementation; this oracle pins the SPECIFICATION the HIP rasteriser implements:
   vertex stage     the vertex shaders' arithmetic per camera model (renderer.cc:226-262, 470-495, 630-653), f32
   projection       p = f * x'/z + c (SetupProjection :919-974 in this code base's pixel-centre convention)
-  rasterisation    samples at integer pixel coordinates, f64 edge functions, top-left rule, near-plane triangles dropped
+  near plane       triangles crossing z = min_depth are clipped on the vertex stage's output (x', y', z), before the division
+                   (OpenGL clips in clip space): cut = inside vertex + t * (outside - inside), t = (near - z_in) / (z_out - z_in),
+                   f32; one vertex cut off -> the quad is split along (first cut, second kept vertex)
+  rasterisation    samples at integer pixel coordinates, f64 edge functions, top-left rule
   depth            perspective-correct interpolation of camera-space z, nearest fragment, 0 where nothing was drawn
   boundaries       ComputeEdgeNormalsList / FilterEdgeList (occlusion_geometry.cc:488-645) and MaskOutOcclusionBoundaries
                    (:284-402) with visibility and pixel tests against the UNMASKED map (the reference's result depends on
@@ -17,7 +20,8 @@ from . import reg_binding as rb
 F = np.float32
 
 
-def project_vertices(model, cam, R, t, verts):
+def project_vertices(model, cam, R, t, verts, shaded=False):
+    """pixel position and camera-space z of every vertex; shaded=True also returns the vertex stage's (x', y')"""
     R = np.asarray(R, F); t = np.asarray(t, F); v = np.asarray(verts, F)
     X = (R[0, 0] * v[:, 0] + (R[0, 1] * v[:, 1] + R[0, 2] * v[:, 2])) + t[0]
     Y = (R[1, 0] * v[:, 0] + (R[1, 1] * v[:, 1] + R[1, 2] * v[:, 2])) + t[1]
@@ -34,7 +38,7 @@ def project_vertices(model, cam, R, t, verts):
                 fac = np.where(r < F(1e-6), F(1.0), np.arctan(r * F(cam.p[5])).astype(F) / (r * F(cam.p[4]))).astype(F)
                 lx = (fac * X).astype(F); ly = (fac * Y).astype(F)
                 px = F(cam.p[0]) * (lx / Z) + F(cam.p[2]); py = F(cam.p[1]) * (ly / Z) + F(cam.p[3])
-                return px.astype(F), py.astype(F), Z.astype(F)
+                return (px.astype(F), py.astype(F), Z.astype(F)) + ((lx.astype(F), ly.astype(F)) if shaded else ())
             if model == 3:
                 # FisheyePolynomial4 shader (renderer.cc:187-205): r2 becomes the radial factor, 99 outside the cut-off
                 r = np.sqrt(r2)
@@ -46,7 +50,7 @@ def project_vertices(model, cam, R, t, verts):
                 fac = np.where(inside, fac, F(99.0)).astype(F)
                 lx = ((Z * fac) * fx_).astype(F); ly = ((Z * fac) * fy_).astype(F)
                 px = F(cam.p[0]) * (lx / Z) + F(cam.p[2]); py = F(cam.p[1]) * (ly / Z) + F(cam.p[3])
-                return px.astype(F), py.astype(F), Z.astype(F)
+                return (px.astype(F), py.astype(F), Z.astype(F)) + ((lx.astype(F), ly.astype(F)) if shaded else ())
             if model == 2:
                 r = np.sqrt(r2)
                 th = np.where(r > F(1e-6), np.arctan2(r, F(1.0)).astype(F) / r, F(1.0)).astype(F)
@@ -67,7 +71,7 @@ def project_vertices(model, cam, R, t, verts):
             lx = np.where(inside, dx, X * F(99.0)).astype(F); ly = np.where(inside, dy, Y * F(99.0)).astype(F)
     with np.errstate(all="ignore"):
         px = F(cam.p[0]) * (lx / Z) + F(cam.p[2]); py = F(cam.p[1]) * (ly / Z) + F(cam.p[3])
-    return px.astype(F), py.astype(F), Z.astype(F)
+    return (px.astype(F), py.astype(F), Z.astype(F)) + ((lx.astype(F), ly.astype(F)) if shaded else ())
 
 
 def _inside(ax, ay, bx, by, px, py):
@@ -76,47 +80,83 @@ def _inside(ax, ay, bx, by, px, py):
     return (e > 0) | ((e == 0) & ((dy < 0) | ((dy == 0) & (dx > 0)))), e
 
 
-def rasterise(px, py, z, tris, W, H, min_depth=0.05, max_depth=100.0):
+def _near_cut(pin, pout, near, proj):
+    """(px, py, z) of the point where the edge inside -> outside meets the near plane; p = (px, py, z, lx, ly), f32"""
+    fx, fy, cx, cy = proj
+    with np.errstate(all="ignore"):
+        t = (near - pin[2]) / (pout[2] - pin[2])
+        lx = pin[3] + t * (pout[3] - pin[3]); ly = pin[4] + t * (pout[4] - pin[4])
+        return (fx * (lx / near) + cx, fy * (ly / near) + cy, near)
+
+
+def near_clip(p, near, proj):
+    """p: three vertices (px, py, z, lx, ly) as f32 scalars -> list of sub-triangles [(a, b, c)] of (px, py, z)"""
+    inside = [bool(v[2] >= near) for v in p]
+    n_in = sum(inside)
+    if n_in == 3:
+        return [tuple(v[:3] for v in p)]
+    if n_in == 0:
+        return []
+    if n_in == 1:
+        i = inside.index(True); j, k = (i + 1) % 3, (i + 2) % 3
+        return [(p[i][:3], _near_cut(p[i], p[j], near, proj), _near_cut(p[i], p[k], near, proj))]
+    i = inside.index(False); j, k = (i + 1) % 3, (i + 2) % 3
+    pj, pk = _near_cut(p[j], p[i], near, proj), _near_cut(p[k], p[i], near, proj)
+    return [(pj, p[j][:3], p[k][:3]), (pj, p[k][:3], pk)]
+
+
+def rasterise(px, py, z, tris, W, H, min_depth=0.05, max_depth=100.0, shaded=None, proj=None):
+    """shaded = (lx, ly) and proj = (fx, fy, cx, cy) enable near-plane clipping; without them every vertex must be in front of the
+    near plane (triangles that are not are skipped)"""
     depth = np.full((H, W), np.inf, np.float32)
+    near = F(min_depth)
     for f in range(len(tris)):
         i0, i1, i2 = (int(v) for v in tris[f])
-        za, zb, zc = z[i0], z[i1], z[i2]
-        if not (za > min_depth and zb > min_depth and zc > min_depth):
-            continue
-        if za > max_depth and zb > max_depth and zc > max_depth:
-            continue
-        xs = np.array([px[i0], px[i1], px[i2]], np.float32); ys = np.array([py[i0], py[i1], py[i2]], np.float32)
-        if not (np.all(np.isfinite(xs)) and np.all(np.isfinite(ys))):
-            continue
-        if xs.max() < 0 or ys.max() < 0 or xs.min() > W - 1 or ys.min() > H - 1:
-            continue
-        x0, y0 = max(0, int(np.ceil(xs.min()))), max(0, int(np.ceil(ys.min())))
-        x1, y1 = min(W - 1, int(np.floor(xs.max()))), min(H - 1, int(np.floor(ys.max())))
-        if x0 > x1 or y0 > y1:
-            continue
-        ax, ay, bx, by, cx, cy = (float(v) for v in (xs[0], ys[0], xs[1], ys[1], xs[2], ys[2]))
-        area = (bx - ax) * (cy - ay) - (by - ay) * (cx - ax)
-        if area == 0:
-            continue
-        if area < 0:
-            bx, by, cx, cy = cx, cy, bx, by
-            zb, zc = zc, zb
-        yy, xx = np.mgrid[y0:y1 + 1, x0:x1 + 1].astype(np.float64)
-        in0, e0 = _inside(bx, by, cx, cy, xx, yy)
-        in1, e1 = _inside(cx, cy, ax, ay, xx, yy)
-        in2, e2 = _inside(ax, ay, bx, by, xx, yy)
-        a = e0 + e1 + e2
-        ok = in0 & in1 & in2 & (a > 0)
-        if not ok.any():
-            continue
-        with np.errstate(all="ignore"):
-            inv = (e0 / float(za) + e1 / float(zb) + e2 / float(zc)) / a
-            zz = (1.0 / inv).astype(np.float32)
-        ok &= (zz >= np.float32(min_depth)) & (zz <= np.float32(max_depth))
-        sub = depth[y0:y1 + 1, x0:x1 + 1]
-        sub[ok] = np.minimum(sub[ok], zz[ok])
+        if shaded is not None:
+            P = [(px[i], py[i], z[i], shaded[0][i], shaded[1][i]) for i in (i0, i1, i2)]
+            subs = near_clip(P, near, tuple(F(v) for v in proj))
+        else:
+            subs = [((px[i0], py[i0], z[i0]), (px[i1], py[i1], z[i1]), (px[i2], py[i2], z[i2]))] if (z[i0] >= near and z[i1] >= near and z[i2] >= near) else []
+        for A, B, C in subs:
+            _raster_one(depth, A, B, C, W, H, min_depth, max_depth)
     depth[np.isinf(depth)] = 0
     return depth
+
+
+def _raster_one(depth, A, B, C, W, H, min_depth, max_depth):
+    za, zb, zc = A[2], B[2], C[2]
+    if za > max_depth and zb > max_depth and zc > max_depth:
+        return
+    xs = np.array([A[0], B[0], C[0]], np.float32); ys = np.array([A[1], B[1], C[1]], np.float32)
+    if not (np.all(np.isfinite(xs)) and np.all(np.isfinite(ys))):
+        return
+    if xs.max() < 0 or ys.max() < 0 or xs.min() > W - 1 or ys.min() > H - 1:
+        return
+    x0, y0 = max(0, int(np.ceil(xs.min()))), max(0, int(np.ceil(ys.min())))
+    x1, y1 = min(W - 1, int(np.floor(xs.max()))), min(H - 1, int(np.floor(ys.max())))
+    if x0 > x1 or y0 > y1:
+        return
+    ax, ay, bx, by, cx, cy = (float(v) for v in (xs[0], ys[0], xs[1], ys[1], xs[2], ys[2]))
+    area = (bx - ax) * (cy - ay) - (by - ay) * (cx - ax)
+    if area == 0:
+        return
+    if area < 0:
+        bx, by, cx, cy = cx, cy, bx, by
+        zb, zc = zc, zb
+    yy, xx = np.mgrid[y0:y1 + 1, x0:x1 + 1].astype(np.float64)
+    in0, e0 = _inside(bx, by, cx, cy, xx, yy)
+    in1, e1 = _inside(cx, cy, ax, ay, xx, yy)
+    in2, e2 = _inside(ax, ay, bx, by, xx, yy)
+    a = e0 + e1 + e2
+    ok = in0 & in1 & in2 & (a > 0)
+    if not ok.any():
+        return
+    with np.errstate(all="ignore"):
+        inv = (e0 / float(za) + e1 / float(zb) + e2 / float(zc)) / a
+        zz = (1.0 / inv).astype(np.float32)
+    ok &= (zz >= np.float32(min_depth)) & (zz <= np.float32(max_depth))
+    sub = depth[y0:y1 + 1, x0:x1 + 1]
+    sub[ok] = np.minimum(sub[ok], zz[ok])
 
 
 def edge_list(verts, tris):

@@ -540,6 +540,58 @@ def test_mesh_depth_matches_oracle(e3d, rb, model):
         assert np.array_equal(g_mask[same].view(np.uint32), o_mask[same].view(np.uint32))
 
 
+def _room_mesh():
+    """closed box room, two triangles per side: every triangle crosses the near plane of a camera inside or lies behind it"""
+    lo, hi = np.array([-2.0, -1.5, -3.0]), np.array([2.0, 1.5, 3.0])
+    c = np.array([[x, y, z] for x in (lo[0], hi[0]) for y in (lo[1], hi[1]) for z in (lo[2], hi[2])], np.float32)
+    quads = [(0, 1, 3, 2), (4, 6, 7, 5), (0, 4, 5, 1), (2, 3, 7, 6), (0, 2, 6, 4), (1, 5, 7, 3)]
+    tris = []
+    for a, b, cc, d in quads:
+        tris += [(a, b, cc), (a, cc, d)]
+    return c, np.array(tris, np.uint32), lo, hi
+
+
+@pytest.mark.parametrize("model", MODELS)
+def test_mesh_near_plane_clipping(e3d, rb, model):
+    """Camera inside a closed room of 12 large triangles: all of them cross the near plane (or lie behind the camera), so without
+    clipping nothing would be drawn.  HIP rasteriser vs the oracle's clipping; for PINHOLE also vs ray casting: every pixel sees a
+    wall at the depth where its viewing ray leaves the box."""
+    from oracle import mesh_occlusion as mo
+    from reg_util import DISTORTION, pyramid_u8, quat_from_R, quat_to_R
+    from scipy.spatial.transform import Rotation
+    verts, tris, lo, hi = _room_mesh()
+    W, H = 320, 240
+    params = np.array([200.0, 195.0, W / 2 - 0.3, H / 2 + 0.2] + DISTORTION[model], np.float32)
+    q = quat_from_R(Rotation.from_euler("xyz", [0.3, -0.5, 0.2]).as_matrix()); R = quat_to_R(q)
+    eye = np.array([0.4, -0.3, 0.5])
+    t = (-R.astype(np.float64) @ eye).astype(np.float32)
+    P = e3d.RegProblem(e3d.default_reg_params(image_scale_count=2, point_neighbor_count=5))
+    P.set_intrinsics(0, W, H, params, 0, 2, camera_type=model)
+    P.set_image(0, 0, pyramid_u8(np.zeros((H, W), np.uint8), 2)); P.set_image_pose(0, q, t)
+    P.add_occlusion_mesh(verts, tris, compute_edges=False)
+    P.set_occlusion_options(0.05, 100.0, False)
+    cam = rb.camera_pyramid(rb.make_camera(W, H, params, model), 2)[0]
+    g = P.render_depth(0, 0, (H, W))
+    px, py, z, lx, ly = mo.project_vertices(model, cam, R, t, verts, shaded=True)
+    assert (z < 0.05).sum() >= 3                                   # vertices behind the near plane / the camera
+    o = mo.rasterise(px, py, z, tris, W, H, 0.05, 100.0, shaded=(lx, ly), proj=params[:4])
+    if model in EXACT:
+        assert np.array_equal(g.view(np.uint32), o.view(np.uint32))
+    else:
+        cover = (g == 0) ^ (o == 0)
+        assert cover.mean() < 5e-3 and np.abs(g - o)[~cover].max() < 1e-3
+    if model == 0:
+        assert (g > 0).all()
+        yy, xx = np.mgrid[0:H, 0:W].astype(np.float64)
+        d_cam = np.stack([(xx - params[2]) / params[0], (yy - params[3]) / params[1], np.ones_like(xx)], -1)
+        d_world = d_cam @ R.astype(np.float64)                      # R^T d
+        with np.errstate(divide="ignore"):
+            lam = np.where(d_world > 0, (hi - eye) / d_world, np.where(d_world < 0, (lo - eye) / d_world, np.inf)).min(-1)
+        assert np.abs(g - lam).max() < 2e-4, float(np.abs(g - lam).max())      # camera-space z of the exit point = lambda * 1
+    else:
+        assert (g > 0).mean() > 0.95
+
+
 RENDERER_KAT_PARAMS = {          # src/opt/test/test_renderer.cc:205-300 (Pinhole, PolynomialTangential, Benchmark)
     0: [250.0, 200.0, 319.5, 239.5],
     1: [340.926, 341.124, 302.4, 201.6, -0.101082, 0.0703954, 0.000438661, -0.000680887],
@@ -553,7 +605,7 @@ RENDERER_KAT_PARAMS = {          # src/opt/test/test_renderer.cc:205-300 (Pinhol
 def test_renderer_pixel_accuracy_reference_property(e3d, rb, model):
     """TestRendererPixelAccuracy (src/opt/test/test_renderer.cc:43-198) on the HIP rasteriser: a mesh with one vertex per 20th
     pixel, each unprojected to a random depth in [0.5, 20]; the rendered depth at a vertex pixel must be the vertex depth (5e-2),
-    vertices that cannot be unprojected sit behind the camera and draw nothing."""
+    vertices that cannot be unprojected (non-finite x, y; z = -1) draw nothing, and neither do the triangles they belong to."""
     from reg_util import pyramid_u8
     W, H, step = 640, 480, 20
     params = np.array(RENDERER_KAT_PARAMS[model], np.float32)
@@ -565,7 +617,8 @@ def test_renderer_pixel_accuracy_reference_property(e3d, rb, model):
         for i, x in enumerate(range(0, W + 1, step)):
             depth = np.float32(rng.uniform(0.5, 20.0))
             n, ok = rb.cam_undistort(cam, np.float32(cam.fx_inv * x + cam.cx_inv), np.float32(cam.fy_inv * y + cam.cy_inv))
-            verts[j * gw + i] = (depth * n[0], depth * n[1], depth) if ok and np.isfinite(n).all() else (0, 0, -1)
+            with np.errstate(all="ignore"):      # test_renderer.cc:72-81: a point that cannot be unprojected keeps its infinite x, y and gets z = -1
+                verts[j * gw + i] = (depth * n[0], depth * n[1], depth if ok and np.isfinite(n).all() else -1)
     tris = []
     for y in range(gh - 1):
         for x in range(gw - 1):

@@ -108,6 +108,10 @@ __device__ __forceinline__ void eigen33_smallest(const float* cov, float& eigenv
 }
 
 // One pass over the queries listed in `todo` (or all points when todo == nullptr) on one grid level.
+// kHeap selects how the k best so far are kept in LDS: a max-heap (k > 16), or an unsorted list with the worst entry cached in
+// registers (k <= 16: the re-scan after a replacement is k independent LDS reads, cheaper than a sift-down's dependent chain while
+// k is small -- measured at 20 M points: k = 8 20.7 vs 23.1 ms, k = 32 121 vs 83 ms).  Both keep the same set, so results are equal.
+template <bool kHeap>
 __global__ __launch_bounds__(kKnnBlock) void k_knn_normals(const float4* __restrict__ P4, size_t n,
                                                            const unsigned* __restrict__ todo, size_t n_todo,
                                                            const HashEntry* __restrict__ table, KnnGrid G, int k,
@@ -128,7 +132,59 @@ __global__ __launch_bounds__(kKnnBlock) void k_knn_normals(const float4* __restr
   const unsigned q_oi = __float_as_uint(q.w);
 #define HD(i) hd[(size_t)(i) * kKnnBlock + tid]
 #define HP(i) hp[(size_t)(i) * kKnnBlock + tid]
+  // !kHeap: the k best so far live UNSORTED in LDS; the worst of them (by (distance, original index), the order of the result
+  // list) is cached in registers with its slot.  A candidate costs one compare against that register; one that enters overwrites
+  // the worst slot and re-scans the k distances for the new worst.
   int cnt = 0;
+  float td = 0.f; unsigned tp = 0; int tpos = 0;
+  auto find_worst = [&]() {
+    float bd = HD(0); int bi = 0;
+#pragma unroll 8
+    for (int i = 1; i < k; ++i) {
+      const float x = HD(i);
+      if (x > bd) { bd = x; bi = i; }
+      else if (x == bd && knn_less(bd, HP(bi), x, HP(i), P4)) { bi = i; }
+    }
+    td = bd; tpos = bi; tp = HP(bi);
+  };
+  auto consider = [&](unsigned m, const float4 c) {
+    const float d2 = sqdist_l2(q.x, q.y, q.z, c.x, c.y, c.z);
+    if constexpr (kHeap) {
+      if (cnt < k) {
+        int i = cnt++;                                                // sift up
+        HD(i) = d2; HP(i) = m;
+        while (i > 0) {
+          const int p = (i - 1) >> 1;
+          const float pd = HD(p); const unsigned pp = HP(p);
+          if (knn_less(pd, pp, d2, m, P4)) { HD(i) = pd; HP(i) = pp; HD(p) = d2; HP(p) = m; i = p; } else break;
+        }
+        return;
+      }
+      const float rd = HD(0); const unsigned rp = HP(0);
+      if (d2 > rd) return;                                            // common case: one compare
+      if (!knn_less(d2, m, rd, rp, P4)) return;
+      int i = 0;                                                      // replace the root, sift down
+      for (;;) {
+        const int l = 2 * i + 1, r = l + 1;
+        int big = -1; float bd = d2; unsigned bp = m;
+        if (l < k) { const float ld = HD(l); const unsigned lp = HP(l); if (knn_less(bd, bp, ld, lp, P4)) { big = l; bd = ld; bp = lp; } }
+        if (r < k) { const float xd = HD(r); const unsigned xp = HP(r); if (knn_less(bd, bp, xd, xp, P4)) { big = r; bd = xd; bp = xp; } }
+        if (big < 0) break;
+        HD(i) = bd; HP(i) = bp; i = big;
+      }
+      HD(i) = d2; HP(i) = m;
+      return;
+    }
+    if (cnt < k) {
+      HD(cnt) = d2; HP(cnt) = m;
+      if (++cnt == k) find_worst();
+      return;
+    }
+    if (d2 > td) return;                                            // common case: one compare
+    if (!knn_less(d2, m, td, tp, P4)) return;
+    HD(tpos) = d2; HP(tpos) = m;
+    find_worst();
+  };
   const int cx = cell_coord(q.x, G.g.origin[0], G.g.inv_cell);
   const int cy = cell_coord(q.y, G.g.origin[1], G.g.inv_cell);
   const int cz = cell_coord(q.z, G.g.origin[2], G.g.inv_cell);
@@ -147,35 +203,12 @@ __global__ __launch_bounds__(kKnnBlock) void k_knn_normals(const float4* __restr
           if (en.key == kEmptyKey) break;
           h = (h + 1) & G.g.mask;
         }
-        for (unsigned m = s; m < e; ++m) {
-          const float4 c = P4[m];
-          const float d2 = sqdist_l2(q.x, q.y, q.z, c.x, c.y, c.z);
-          if (cnt < k) {
-            // sift up
-            int i = cnt++;
-            HD(i) = d2; HP(i) = m;
-            while (i > 0) {
-              const int p = (i - 1) >> 1;
-              const float pd = HD(p); const unsigned pp = HP(p);
-              if (knn_less(pd, pp, d2, m, P4)) { HD(i) = pd; HP(i) = pp; HD(p) = d2; HP(p) = m; i = p; } else break;
-            }
-          } else {
-            const float td = HD(0); const unsigned tp = HP(0);
-            if (d2 > td) continue;                                    // common case: one compare
-            if (!knn_less(d2, m, td, tp, P4)) continue;
-            // replace the root, sift down
-            int i = 0;
-            for (;;) {
-              const int l = 2 * i + 1, r = l + 1;
-              int big = -1; float bd = d2; unsigned bp = m;
-              if (l < k) { const float ld = HD(l); const unsigned lp = HP(l); if (knn_less(bd, bp, ld, lp, P4)) { big = l; bd = ld; bp = lp; } }
-              if (r < k) { const float rd = HD(r); const unsigned rp = HP(r); if (knn_less(bd, bp, rd, rp, P4)) { big = r; bd = rd; bp = rp; } }
-              if (big < 0) break;
-              HD(i) = bd; HP(i) = bp; i = big;
-            }
-            HD(i) = d2; HP(i) = m;
-          }
+        unsigned m = s;
+        for (; m + 4 <= e; m += 4) {                                  // four candidates in flight per lane
+          const float4 c0 = P4[m], c1 = P4[m + 1], c2 = P4[m + 2], c3 = P4[m + 3];
+          consider(m, c0); consider(m + 1, c1); consider(m + 2, c2); consider(m + 3, c3);
         }
+        for (; m < e; ++m) consider(m, P4[m]);
       }
   // resolved?  the k-th neighbour must be strictly closer than the nearest face of the 27-cell block that still
   // has data behind it
@@ -195,7 +228,7 @@ __global__ __launch_bounds__(kKnnBlock) void k_knn_normals(const float4* __restr
     if (covers_all) resolved = true;
     else {
       safe -= G.slack;
-      resolved = (cnt == k) && safe > 0.f && HD(0) < safe * safe * 0.99999f;
+      resolved = (cnt == k) && safe > 0.f && (kHeap ? HD(0) : td) < safe * safe * 0.99999f;
     }
   }
   if (!resolved) {
@@ -203,7 +236,20 @@ __global__ __launch_bounds__(kKnnBlock) void k_knn_normals(const float4* __restr
     next_todo[slot] = qid;
     return;
   }
-  // heap sort in place -> ascending (d2, original index)
+  // heap sort in place -> ascending (d2, original index): Floyd's heap construction, then repeated extraction of the maximum
+  for (int start = kHeap ? -1 : cnt / 2 - 1; start >= 0; --start) {
+    const float ld = HD(start); const unsigned lp = HP(start);
+    int i = start;
+    for (;;) {
+      const int l = 2 * i + 1, r = l + 1;
+      int big = -1; float bd = ld; unsigned bp = lp;
+      if (l < cnt) { const float xd = HD(l); const unsigned xp = HP(l); if (knn_less(bd, bp, xd, xp, P4)) { big = l; bd = xd; bp = xp; } }
+      if (r < cnt) { const float xd = HD(r); const unsigned xp = HP(r); if (knn_less(bd, bp, xd, xp, P4)) { big = r; bd = xd; bp = xp; } }
+      if (big < 0) break;
+      HD(i) = bd; HP(i) = bp; i = big;
+    }
+    HD(i) = ld; HP(i) = lp;
+  }
   for (int end = cnt - 1; end > 0; --end) {
     const float ld = HD(end); const unsigned lp = HP(end);
     HD(end) = HD(0); HP(end) = HP(0);
@@ -387,7 +433,11 @@ static void knn_pass(const float* xyz, size_t n, int k, const float* viewpoint, 
     double area = 2.0 * (ext[0] * ext[1] + ext[1] * ext[2] + ext[0] * ext[2]);
     if (!(area > 0)) area = extent * extent;
     (void)vol;
-    double cell = std::sqrt((double)k * area / (1.5 * M_PI * (double)n));
+    // (swept at 20 M points of the synthetic room scan, tools/bench_normals.py: the estimate is low in the dense part of a scan,
+    // where most points are; 1.5 is the optimum for k = 32, 0.35 - 1.2 a plateau for k = 8; E3D_KNN_CELL_FACTOR overrides)
+    static const double cell_factor_env = [] { const char* e = getenv("E3D_KNN_CELL_FACTOR"); const double v = e ? atof(e) : 0.0; return v > 0 ? v : 0.0; }();
+    const double cell_factor = cell_factor_env > 0 ? cell_factor_env : (k > 16 ? 1.5 : 1.0);
+    double cell = std::sqrt((double)k * area / (cell_factor * M_PI * (double)n));
     cell = std::max(cell, extent / 1.0e6);
     double magnitude = 0;
     for (int a = 0; a < 6; ++a) magnitude = std::max(magnitude, std::fabs((double)bb[a]));
@@ -401,7 +451,10 @@ static void knn_pass(const float* xyz, size_t n, int k, const float* viewpoint, 
     unsigned* todo = nullptr;
     size_t n_todo = n;
     const size_t lds = (size_t)k * kKnnBlock * 8;
-    E3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_knn_normals), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const bool heap = k > 16;
+    E3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(heap ? k_knn_normals<true> : k_knn_normals<false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    static const double level_step = [] { const char* e = getenv("E3D_KNN_LEVEL_STEP"); const double v = e ? atof(e) : 0.0; return v > 1 ? v : 2.0; }();   // cell growth per retry level (4 -> 2: -7 % at k = 32)
     for (int level = 0; level < 64 && n_todo > 0; ++level) {
       KnnGrid G{};
       G.cell = (float)cell;
@@ -431,7 +484,7 @@ static void knn_pass(const float* xyz, size_t n, int k, const float* viewpoint, 
       unsigned* next = (todo == todo_a.p) ? todo_b.p : todo_a.p;
       E3D_HIP(hipMemsetAsync(L.counter.p + 1, 0, sizeof(unsigned), s));
       const unsigned nblk = (unsigned)div_up(n_todo, kKnnBlock);
-      hipLaunchKernelGGL(k_knn_normals, dim3(nblk), dim3(kKnnBlock), lds, s, L.P4.p, n, todo, n_todo, L.table.p, G, k,
+      hipLaunchKernelGGL(heap ? k_knn_normals<true> : k_knn_normals<false>, dim3(nblk), dim3(kKnnBlock), lds, s, L.P4.p, n, todo, n_todo, L.table.p, G, k,
                          viewpoint[0], viewpoint[1], viewpoint[2], Q4.p, want_normals ? d_on.p : nullptr, want_normals ? d_oc.p : nullptr,
                          knn_indices ? d_knn.p : nullptr, d_mean_out ? d_mean_out->p : nullptr, next, L.counter.p + 1);
       unsigned n_next = 0;
@@ -440,7 +493,7 @@ static void knn_pass(const float* xyz, size_t n, int k, const float* viewpoint, 
       E3D_HIP(hipGetLastError());
       todo = next;
       n_todo = n_next;
-      cell *= 4.0;
+      cell *= level_step;
     }
     if (n_todo != 0) throw Error(E3D_ERR_INVALID, "e3d_normals_knn: internal error, unresolved queries remain");
 }

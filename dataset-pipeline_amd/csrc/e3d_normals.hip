@@ -189,9 +189,13 @@ __global__ __launch_bounds__(kKnnBlock) void k_knn_normals(const float4* __restr
   const int cy = cell_coord(q.y, G.g.origin[1], G.g.inv_cell);
   const int cz = cell_coord(q.z, G.g.origin[2], G.g.inv_cell);
   constexpr int kMaxC = (1 << 21) - 1;
+  // own cell first, then face, edge and corner neighbours: the list fills with near points early, so fewer of the later candidates
+  // replace an entry (the result does not depend on the order)
+  for (int ring = 0; ring <= 3; ++ring)
   for (int oz = -1; oz <= 1; ++oz)
     for (int oy = -1; oy <= 1; ++oy)
       for (int ox = -1; ox <= 1; ++ox) {
+        if ((ox != 0) + (oy != 0) + (oz != 0) != ring) continue;
         const int x = cx + ox, y = cy + oy, z = cz + oz;
         if (x < 0 || y < 0 || z < 0 || x > kMaxC || y > kMaxC || z > kMaxC) continue;
         const unsigned long long key = cell_key(x, y, z);

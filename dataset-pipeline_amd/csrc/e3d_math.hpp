@@ -11,7 +11,9 @@
 //   pose update       src/icp/icp_point_to_plane_impl.h:235
 #pragma once
 
+#include <algorithm>
 #include <cmath>
+#include <initializer_list>
 #include <vector>
 
 namespace e3d {
@@ -168,6 +170,93 @@ inline void ldlt_solve_upper(const double* A, int n, const double* b, double* x,
   }
   for (int i = 0; i < n; ++i) x[perm[i]] = y[i];
 }
+
+// The normal equations of IntrinsicsAndPoseOptimizer have arrow structure: a dense block of `s` shared unknowns (all intrinsics,
+// then all rig extrinsics) and one 6 x 6 block per pose that couples to the shared block only (AccumulateOnHAndB,
+// intrinsics_and_pose_optimizer.cc:841-938, never writes a pose-pose block of two different poses).  The reference stores and
+// solves H densely (Eigen LDLT on V x V); for hundreds of images that is O(V^3) host work and V^2 doubles per exchange.  ArrowSystem
+// keeps only the non-zero blocks: s^2 + np (6 s + 36) numbers, solved through the Schur complement on the shared block in
+// O(np (s^2 + s)) -- the same solution up to f64 rounding.
+struct ArrowSystem {
+  int s = 0, np = 0;                 // V = s + 6 np
+  std::vector<double> A;             // s x s, row-major, upper triangle used
+  std::vector<double> B;             // np x 6 x s: B[(6 p + r) s + c] = H[c][s + 6 p + r]
+  std::vector<double> D;             // np x 6 x 6, upper triangle used
+  std::vector<double> b;             // V
+  void reset(int shared, int poses) {
+    s = shared; np = poses;
+    A.assign((size_t)s * s, 0.0); B.assign((size_t)np * 6 * s, 0.0); D.assign((size_t)np * 36, 0.0); b.assign((size_t)s + 6 * (size_t)np, 0.0);
+  }
+  int size() const { return s + 6 * np; }
+  // H[gr][gc] += v for gr <= gc; returns false for an entry outside the arrow pattern (two different poses)
+  bool add(int gr, int gc, double v) {
+    if (gc < s) { A[(size_t)gr * s + gc] += v; return true; }
+    const int p = (gc - s) / 6, r = (gc - s) % 6;
+    if (gr < s) { B[((size_t)6 * p + r) * s + gr] += v; return true; }
+    if ((gr - s) / 6 != p) return false;
+    D[(size_t)p * 36 + (size_t)((gr - s) % 6) * 6 + r] += v;
+    return true;
+  }
+  size_t packed_size() const { return A.size() + B.size() + D.size() + b.size(); }
+  void pack(double* out) const {
+    size_t o = 0;
+    for (const std::vector<double>* v : {&A, &B, &D, &b}) { std::copy(v->begin(), v->end(), out + o); o += v->size(); }
+  }
+  void unpack(const double* in) {
+    size_t o = 0;
+    for (std::vector<double>* v : {&A, &B, &D, &b}) { std::copy(in + o, in + o + v->size(), v->begin()); o += v->size(); }
+  }
+  // dense V x V upper triangle (row-major), for the reference-order LDLT on small systems
+  void to_dense(std::vector<double>& H) const {
+    const int V = size();
+    H.assign((size_t)V * V, 0.0);
+    for (int i = 0; i < s; ++i) for (int j = i; j < s; ++j) H[(size_t)i * V + j] = A[(size_t)i * s + j];
+    for (int p = 0; p < np; ++p)
+      for (int r = 0; r < 6; ++r) {
+        const int g = s + 6 * p + r;
+        for (int c = 0; c < s; ++c) H[(size_t)c * V + g] = B[((size_t)6 * p + r) * s + c];
+        for (int c = r; c < 6; ++c) H[(size_t)g * V + (s + 6 * p + c)] = D[(size_t)p * 36 + (size_t)r * 6 + c];
+      }
+  }
+  // x = (H with its diagonal scaled by `damping`)^-1 b
+  void solve(double damping, double* x) const {
+    std::vector<double> W, S(A), rhs(b.begin(), b.begin() + s), col(6), sol(6), Dp(36);
+    std::vector<int> perm;
+    std::vector<double> DinvB((size_t)np * 6 * s), Dinvb((size_t)np * 6);
+    for (int i = 0; i < s; ++i) S[(size_t)i * s + i] *= damping;
+    for (int p = 0; p < np; ++p) {
+      for (int i = 0; i < 36; ++i) Dp[i] = D[(size_t)p * 36 + i];
+      for (int i = 0; i < 6; ++i) Dp[i * 6 + i] *= damping;
+      const double* Bp = &B[(size_t)p * 6 * s];
+      // D_p^-1 applied to the coupling columns and to b_p (6 x 6 pivoted LDLT per right-hand side; a block without observations
+      // is all zero and yields zeros, like the dense solver's zero pivots)
+      for (int c = 0; c <= s; ++c) {
+        for (int r = 0; r < 6; ++r) col[r] = (c < s) ? Bp[(size_t)r * s + c] : b[(size_t)s + 6 * p + r];
+        ldlt_solve_upper(Dp.data(), 6, col.data(), sol.data(), W, perm);
+        for (int r = 0; r < 6; ++r) { if (c < s) DinvB[((size_t)6 * p + r) * s + c] = sol[r]; else Dinvb[(size_t)6 * p + r] = sol[r]; }
+      }
+      for (int i = 0; i < s; ++i) {
+        double acc = 0;
+        for (int r = 0; r < 6; ++r) acc += Bp[(size_t)r * s + i] * Dinvb[(size_t)6 * p + r];
+        rhs[i] -= acc;
+        for (int j = i; j < s; ++j) {
+          double a2 = 0;
+          for (int r = 0; r < 6; ++r) a2 += Bp[(size_t)r * s + i] * DinvB[((size_t)6 * p + r) * s + j];
+          S[(size_t)i * s + j] -= a2;
+        }
+      }
+    }
+    std::vector<double> xs(s > 0 ? s : 1);
+    if (s > 0) ldlt_solve_upper(S.data(), s, rhs.data(), xs.data(), W, perm);
+    for (int i = 0; i < s; ++i) x[i] = xs[i];
+    for (int p = 0; p < np; ++p)
+      for (int r = 0; r < 6; ++r) {
+        double v = Dinvb[(size_t)6 * p + r];
+        for (int c = 0; c < s; ++c) v -= DinvB[((size_t)6 * p + r) * s + c] * xs[c];
+        x[s + 6 * p + r] = v;
+      }
+  }
+};
 
 // Smallest / largest singular value of the 3x3 linear part of a row-major 3x4 affine (f64, Jacobi on L^T L).
 inline void singular_value_range_3x3(const float* T, double* smin, double* smax) {

@@ -2525,7 +2525,10 @@ static void apply_update(e3d_reg* h, bool print, bool* applied_update, float* la
     if (kv.second.dependent()) continue;                                                                   // reference image's pose (:461-472)
     image_index[kv.first] = V; V += 6;
   }
-  std::vector<double> H((size_t)V * V, 0.0), b((size_t)V, 0.0);
+  // H and b in arrow form (e3d_math.hpp): shared block = intrinsics + rig extrinsics, then one 6 x 6 block per pose
+  const int n_shared = V - 6 * (int)image_index.size();
+  ArrowSystem Hb;
+  Hb.reset(n_shared, (int)image_index.size());
   double sums[2] = {0, 0};
   int64_t counts[2] = {0, 0};
   // visibility lists = observed point indices of the current observations (device copies)
@@ -2553,21 +2556,21 @@ static void apply_update(e3d_reg* h, bool print, bool* applied_update, float* la
       // scatter the local [intrinsics(I), (rig extrinsics(6),) pose(6)] block (AccumulateOnHAndB's block updates)
       auto gidx = [&](int l) { return l < I ? ii + l : ((dep && l < I + 6) ? ri + (l - I) : pi + (l - (Vl - 6))); };
       for (int r = 0; r < Vl; ++r) {
-        for (int c = r; c < Vl; ++c) H[(size_t)gidx(r) * V + gidx(c)] += Hl[(size_t)r * Vl + c];
-        b[gidx(r)] += bl[r];
+        for (int c = r; c < Vl; ++c)
+          if (!Hb.add(gidx(r), gidx(c), Hl[(size_t)r * Vl + c])) throw Error(E3D_ERR_INVALID, "normal equations: entry outside the arrow pattern");
+        Hb.b[gidx(r)] += bl[r];
       }
     }
   }
   E3D_HIP(hipStreamSynchronize(s));
-  if (h->world > 1) {                       // one exchange per Apply: [upper(H) as dense V x V, b, sums, counts]
-    std::vector<double> buf((size_t)V * V + V + 4);
-    std::copy(H.begin(), H.end(), buf.begin());
-    std::copy(b.begin(), b.end(), buf.begin() + (size_t)V * V);
-    double* tail = buf.data() + (size_t)V * V + V;
+  if (h->world > 1) {                       // one exchange per Apply: [non-zero blocks of H, b, sums, counts] -- block-sparse:
+    const size_t np = Hb.packed_size();     // s^2 + (6 s + 36 + 6) per pose instead of V^2 (512 images: 0.5 MB instead of 76 MB)
+    std::vector<double> buf(np + 4);
+    Hb.pack(buf.data());
+    double* tail = buf.data() + np;
     tail[0] = sums[0]; tail[1] = sums[1]; tail[2] = (double)counts[0]; tail[3] = (double)counts[1];
     allreduce_host(h, buf.data(), buf.size());
-    std::copy(buf.begin(), buf.begin() + (size_t)V * V, H.begin());
-    std::copy(buf.begin() + (size_t)V * V, buf.begin() + (size_t)V * V + V, b.begin());
+    Hb.unpack(buf.data());
     sums[0] = tail[0]; sums[1] = tail[1]; counts[0] = (int64_t)tail[2]; counts[1] = (int64_t)tail[3];
   }
   const double initial_residual = compute_cost_value(h, sums, counts);
@@ -2576,13 +2579,24 @@ static void apply_update(e3d_reg* h, bool print, bool* applied_update, float* la
 
   const RegState old_state = get_state(h);
   *applied_update = false;
-  std::vector<double> Hlm, x(V), W;
+  // Small systems: the reference's dense pivoted LDLT, operation for operation.  Large ones (V > 384, i.e. more than ~60 images):
+  // Schur complement on the shared block -- same solution to f64 rounding, O(images) instead of O(V^3) host work.
+  // E3D_REG_SOLVER=dense|arrow forces one of them (tests).
+  static const int forced_solver = [] { const char* e = getenv("E3D_REG_SOLVER"); return !e ? 0 : (!strcmp(e, "dense") ? 1 : (!strcmp(e, "arrow") ? 2 : 0)); }();
+  const bool dense_solve = forced_solver == 1 || (forced_solver == 0 && V <= 384);
+  std::vector<double> H, Hlm, x(V), W;
+  if (dense_solve) Hb.to_dense(H);
+  const std::vector<double>& b = Hb.b;
   std::vector<int> perm;
   constexpr int kNumLMTries = 10;
   for (int lm = 0; lm < kNumLMTries; ++lm) {
-    Hlm = H;
-    for (int i = 0; i < V; ++i) Hlm[(size_t)i * V + i] *= (1 + (*lambda));       // multiplicative damping (:206)
-    ldlt_solve_upper(Hlm.data(), V, b.data(), x.data(), W, perm);
+    if (dense_solve) {
+      Hlm = H;
+      for (int i = 0; i < V; ++i) Hlm[(size_t)i * V + i] *= (1 + (*lambda));       // multiplicative damping (:206)
+      ldlt_solve_upper(Hlm.data(), V, b.data(), x.data(), W, perm);
+    } else {
+      Hb.solve((double)(1 + (*lambda)), x.data());
+    }
     // CreateDeltaState(-x)
     RegState trial = old_state;
     for (auto& kv : trial.intr) {

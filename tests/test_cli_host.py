@@ -126,3 +126,17 @@ def test_png_decoder_roundtrip(tmp_path):
     Image.fromarray(g16).save(str(tmp_path / "h.png"))
     img, _ = _imread(str(tmp_path / "h.png"), tmp_path)
     assert np.array_equal(img, (g16 >> 8).astype(np.uint8))
+
+
+def test_arrow_system_matches_dense_ldlt(tmp_path):
+    """e3d::ArrowSystem (block-sparse normal equations of IntrinsicsAndPoseOptimizer, Schur-complement solve) against the dense
+    pivoted LDLT the reference uses, on random systems with the same sparsity pattern; also the packed exchange layout and that
+    an entry coupling two different poses is refused."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "arrow_system_test")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-o", exe, os.path.join(root, "tests", "cpp", "arrow_system_test.cc")])
+    for args in (("12", "40", "1", "-1"), ("20", "100", "2", "7"), ("0", "5", "3", "-1"), ("30", "3", "4", "0")):
+        r = subprocess.run([exe, *args], capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+        err, mx, pack_ok = r.stdout.split()
+        assert float(err) <= 1e-12 * max(1.0, float(mx)) and pack_ok == "1", (args, r.stdout)

@@ -560,3 +560,32 @@ def test_reference_four_frame_alignment_thresholds(tmp_path, use_variable_colors
     mean_flow = flow_sum / flow_count
     print("variable", use_variable_colors, "rig", use_rig, "worst log component", worst, "mean flow px", mean_flow)
     assert worst <= 0.0016 and mean_flow <= 0.07, (worst, mean_flow)
+
+
+def test_image_registrator_arrow_solver_matches_dense(tmp_path, e3d):
+    """Large problems solve the arrow-structured normal equations through the Schur complement instead of the dense LDLT
+    (E3D_REG_SOLVER forces either): same run, same result to f64 rounding -- rig scene, so that the shared block holds intrinsics
+    and rig extrinsics and the pose blocks belong to rig frames."""
+    M = make_rig_scene(n_points=6000, seed=13)
+    names = ["cam%d/frame_%d.png" % (i % 2, i // 2) for i in range(4)]
+    from oracle import reg_binding as rb
+    for f in range(2):
+        ref, dep = M["images"][2 * f], M["images"][2 * f + 1]
+        dep["q_init"], dep["t_init"] = rb.se3_mul(*M["rig_init"][1], ref["q_init"], ref["t_init"])
+    rigs = [{"ref_camera_id": 7, "cameras": [{"camera_id": 7, "image_prefix": "cam0"}, {"camera_id": 7, "image_prefix": "cam1"}]}]
+    res = {}
+    for solver in ("dense", "arrow"):
+        os.makedirs(str(tmp_path / solver))
+        d = _write_dataset(tmp_path / solver, M, names, rigs=rigs)
+        os.environ["E3D_REG_SOLVER"] = solver
+        try:
+            out = _run_tool(d, ["--max_initial_image_area_in_pixels", "32000", "--max_iterations", "6"])
+        finally:
+            del os.environ["E3D_REG_SOLVER"]
+        assert "Finished!" in out
+        res[solver] = (_read_images_txt(os.path.join(d, "out", "scale_1_state", "images.txt")),
+                       [float(l.split(":")[-1]) for l in out.splitlines() if "Cost (considering occlusions) is" in l])
+    a, b = res["dense"], res["arrow"]
+    assert len(a[1]) == len(b[1]) and np.allclose(a[1], b[1], rtol=1e-6)
+    for k in a[0]:
+        assert np.abs(a[0][k][0] - b[0][k][0]).max() < 1e-6 and np.abs(a[0][k][1] - b[0][k][1]).max() < 1e-6

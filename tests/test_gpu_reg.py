@@ -728,3 +728,35 @@ def test_full_size_accumulate_properties(e3d, synth, model):
     assert np.array_equal(csum, counts)
     assert np.abs(np.triu(Hsum) - np.triu(H)).max() <= 1e-9 * np.abs(H).max()
     assert V == len(Wl["params"]) + 6
+
+
+def test_many_images_use_the_arrow_solver(e3d):
+    """96 images (V = 4 + 6 * 96 = 580 unknowns > 384): the optimiser switches to the block-sparse normal equations and the
+    Schur-complement solve on its own.  The images are 24 copies of a 4-image scene, each copy with its own pose unknowns, so every
+    copy must end at the pose the 4-image (dense-solver) run reaches for its original -- the intrinsics block sees 24 times the same
+    information, which leaves the minimiser unchanged."""
+    import time
+    from reg_util import make_multi_image_scene
+    M = make_multi_image_scene(n_points=3000, n_images=4, seed=31, perturb=0.004)
+    prm = e3d.default_reg_params(image_scale_count=M["n_levels"], point_neighbor_count=M["K"], variable_residuals_weight=0.0)
+
+    def build(copies):
+        P = e3d.RegProblem(prm)
+        P.set_intrinsics(0, M["width"], M["height"], M["params"], 0, M["n_levels"], camera_type=0)
+        P.set_point_scale(0, M["pts"], M["point_radius"], M["nbr"], M["fixed_desc"])
+        P.set_splat_points(M["pts"])
+        for c in range(copies):
+            for i, im in enumerate(M["images"]):
+                P.set_image(4 * c + i, 0, im["pyr"]); P.set_image_pose(4 * c + i, im["q_init"], im["t_init"])
+        return P
+    small, big = build(1), build(24)
+    cs, cost_s, it_s = small.run_on_current_scale(6, 0.0, 15, False)
+    t0 = time.perf_counter()
+    cb, cost_b, it_b = big.run_on_current_scale(6, 0.0, 15, False)
+    dt = time.perf_counter() - t0
+    assert it_b == it_s and abs(cost_b - cost_s) <= 1e-5 * abs(cost_s), (it_s, it_b, cost_s, cost_b)
+    for c in range(24):
+        for i in range(4):
+            ang, tr = _pose_delta(*big.get_image_pose(4 * c + i), *small.get_image_pose(i))
+            assert ang < 2e-5 and tr < 2e-5, (c, i, ang, tr)
+    assert dt < 60.0, dt                    # (the dense O(V^3) host solve alone would take longer per iteration at a few thousand unknowns)

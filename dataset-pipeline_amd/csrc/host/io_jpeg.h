@@ -11,8 +11,8 @@
 // Supported: SOF0 / SOF1 (baseline / extended sequential, Huffman, 8-bit), 1 or 3 components (YCbCr), any sampling
 // factors, restart intervals, sizes that are not multiples of the MCU.  Rejected with a message: progressive (SOF2),
 // arithmetic coding, 12-bit, CMYK / YCCK, RGB-coded files (Adobe transform 0 or component ids 'R' 'G' 'B').
-// Not applied: the EXIF orientation tag (OpenCV rotates on imread unless told otherwise; the tag is 1 in the datasets
-// this pipeline was written for).
+// The EXIF orientation tag (APP1, TIFF tag 0x0112) is applied like cv::imread does without IMREAD_IGNORE_ORIENTATION
+// (OpenCV's ExifTransform: 2 mirror, 3 rotate 180, 4 flip, 5 transpose, 6 rotate 90 cw, 7 transverse, 8 rotate 90 ccw).
 #pragma once
 
 #include <cstdint>
@@ -147,6 +147,7 @@ inline bool load_jpeg_gray(const std::vector<uint8_t>& f, int* width, int* heigh
   std::vector<Component> comps;
   int W = 0, H = 0, restart_interval = 0;
   int adobe_transform = -1;
+  int orientation = 1;
   size_t pos = 2;
   bool have_frame = false;
   while (pos + 4 <= f.size()) {
@@ -208,6 +209,25 @@ inline bool load_jpeg_gray(const std::vector<uint8_t>& f, int* width, int* heigh
       return false;
     } else if (marker == 0xDD) {
       if (n >= 2) restart_interval = be16(d);
+    } else if (marker == 0xE1) {                              // APP1: "Exif\0\0" + TIFF header + IFD0
+      if (n >= 14 && !memcmp(d, "Exif\0\0", 6)) {
+        const uint8_t* t = d + 6;
+        const int tn = n - 6;
+        const bool le = t[0] == 'I' && t[1] == 'I', be = t[0] == 'M' && t[1] == 'M';
+        auto u16 = [&](int o) { return le ? (int)(t[o] | (t[o + 1] << 8)) : (int)((t[o] << 8) | t[o + 1]); };
+        auto u32 = [&](int o) { return le ? (long)(t[o] | (t[o + 1] << 8) | (t[o + 2] << 16) | ((long)t[o + 3] << 24))
+                                          : (long)(((long)t[o] << 24) | (t[o + 1] << 16) | (t[o + 2] << 8) | t[o + 3]); };
+        if ((le || be) && u16(2) == 42) {
+          const long ifd = u32(4);
+          if (ifd >= 8 && ifd + 2 <= tn) {
+            const int entries = u16((int)ifd);
+            for (int e = 0; e < entries && ifd + 2 + 12 * (e + 1) <= tn; ++e) {
+              const int o = (int)ifd + 2 + 12 * e;
+              if (u16(o) == 0x0112 && u16(o + 2) == 3 && u32(o + 4) == 1) { const int v = u16(o + 8); if (v >= 1 && v <= 8) orientation = v; }
+            }
+          }
+        }
+      }
     } else if (marker == 0xEE) {                              // Adobe
       if (n >= 12 && !memcmp(d, "Adobe", 5)) adobe_transform = d[11];
     } else if (marker == 0xDA) {                              // SOS: baseline -> one scan with all components
@@ -288,9 +308,29 @@ inline bool load_jpeg_gray(const std::vector<uint8_t>& f, int* width, int* heigh
           }
           (void)yh; (void)yv;
         }
-      *width = W; *height = H;
-      gray->resize((size_t)W * H);
-      for (int y = 0; y < H; ++y) memcpy(&(*gray)[(size_t)y * W], &plane[(size_t)y * PW], (size_t)W);
+      // EXIF orientation: output pixel (x, y) of the oriented image <- source pixel (sx, sy)
+      const bool swap = orientation >= 5;
+      const int OW = swap ? H : W, OH = swap ? W : H;
+      *width = OW; *height = OH;
+      gray->resize((size_t)OW * OH);
+      if (orientation == 1) {
+        for (int y = 0; y < H; ++y) memcpy(&(*gray)[(size_t)y * W], &plane[(size_t)y * PW], (size_t)W);
+        return true;
+      }
+      for (int y = 0; y < OH; ++y)
+        for (int x = 0; x < OW; ++x) {
+          int sx, sy;
+          switch (orientation) {
+            case 2: sx = W - 1 - x; sy = y; break;                   // mirror horizontally
+            case 3: sx = W - 1 - x; sy = H - 1 - y; break;           // rotate 180
+            case 4: sx = x; sy = H - 1 - y; break;                   // flip vertically
+            case 5: sx = y; sy = x; break;                           // transpose
+            case 6: sx = y; sy = H - 1 - x; break;                   // rotate 90 clockwise
+            case 7: sx = W - 1 - y; sy = H - 1 - x; break;           // transverse
+            default: sx = W - 1 - y; sy = x; break;                  // 8: rotate 90 counter-clockwise
+          }
+          (*gray)[(size_t)y * OW + x] = plane[(size_t)sy * PW + sx];
+        }
       return true;
     }
     pos += (size_t)len;

@@ -47,6 +47,17 @@ if __name__ == "__main__":
         assert im.mode == "L", im.mode
         expected[name] = np.array(im)
         assert expected[name].shape == (h, w)
+    # EXIF orientation 1..8: cv::imread applies it (ExifTransform); expected = the luminance plane put upright, by Pillow
+    from PIL import ImageOps
+    for o in range(1, 9):
+        path = os.path.join(HERE, "jpeg_exif_%d.jpg" % o)
+        exif = Image.Exif(); exif[0x0112] = o
+        scene(37, 29, 20 + o).save(path, "JPEG", quality=85, subsampling=2, exif=exif.tobytes())
+        im = Image.open(path)
+        im.draft("L", im.size)
+        assert im.mode == "L" and im.getexif().get(0x0112) == o
+        expected["exif_%d" % o] = np.array(ImageOps.exif_transpose(im))
+        assert expected["exif_%d" % o].shape == ((29, 37) if o < 5 else (37, 29))
     prog = os.path.join(HERE, "jpeg_progressive.jpg")
     scene(48, 32, 9).save(prog, "JPEG", quality=80, progressive=True)
     np.savez_compressed(os.path.join(HERE, "jpeg_golden.npz"), **expected)

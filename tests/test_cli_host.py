@@ -93,11 +93,12 @@ def _imread(path, tmp_path):
 def test_jpeg_decoder_matches_libjpeg_golden(tmp_path):
     """cv::imread(path, IMREAD_GRAYSCALE) on JPEG = libjpeg's luminance plane (islow IDCT).  Golden: Pillow / libjpeg-turbo
     (tests/golden/make_jpeg_golden.py); 4:2:0 / 4:2:2 / 4:4:4, optimised Huffman tables, grey files, restart markers, sizes
-    that are not MCU multiples -- bit for bit."""
+    that are not MCU multiples -- bit for bit; the eight EXIF orientations, which cv::imread applies (expected: Pillow's
+    exif_transpose of the luminance plane)."""
     _build()
     gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
     exp = np.load(os.path.join(gold, "jpeg_golden.npz"))
-    assert len(exp.files) == 6
+    assert len(exp.files) == 14 and exp["exif_6"].shape == (37, 29)
     for name in exp.files:
         img, err = _imread(os.path.join(gold, "jpeg_%s.jpg" % name), tmp_path)
         assert img is not None, err

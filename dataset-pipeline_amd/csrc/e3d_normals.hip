@@ -108,10 +108,13 @@ __device__ __forceinline__ void eigen33_smallest(const float* cov, float& eigenv
 }
 
 // One pass over the queries listed in `todo` (or all points when todo == nullptr) on one grid level.
-// kHeap selects how the k best so far are kept in LDS: a max-heap (k > 16), or an unsorted list with the worst entry cached in
-// registers (k <= 16: the re-scan after a replacement is k independent LDS reads, cheaper than a sift-down's dependent chain while
-// k is small -- measured at 20 M points: k = 8 20.7 vs 23.1 ms, k = 32 121 vs 83 ms).  Both keep the same set, so results are equal.
-template <bool kHeap>
+// kSel selects how the k best so far are kept in LDS -- all three keep the same set, so results are equal:
+//   0  a max-heap (k > 32);
+//   1  an unsorted list with the worst entry cached in registers (k <= 16: the re-scan after a replacement is k independent LDS
+//      reads, cheaper than a sift-down's dependent chain while k is small -- 20 M points: k = 8 20.7 vs 23.1 ms, k = 32 121 vs 83 ms);
+//   2  the unsorted list in groups of eight with each group's worst entry in registers (16 < k <= 32): a replacement re-scans
+//      one group (8 independent reads) and picks the worst of at most four group maxima.
+template <int kSel>
 __global__ __launch_bounds__(kKnnBlock) void k_knn_normals(const float4* __restrict__ P4, size_t n,
                                                            const unsigned* __restrict__ todo, size_t n_todo,
                                                            const HashEntry* __restrict__ table, KnnGrid G, int k,
@@ -135,9 +138,50 @@ __global__ __launch_bounds__(kKnnBlock) void k_knn_normals(const float4* __restr
   // !kHeap: the k best so far live UNSORTED in LDS; the worst of them (by (distance, original index), the order of the result
   // list) is cached in registers with its slot.  A candidate costs one compare against that register; one that enters overwrites
   // the worst slot and re-scans the k distances for the new worst.
+  constexpr bool kHeap = kSel == 0;
   int cnt = 0;
   float td = 0.f; unsigned tp = 0; int tpos = 0;
+  float gd[4] = {0.f, 0.f, 0.f, 0.f};            // kSel == 2: worst entry of each group of eight slots, and its slot
+  int gs[4] = {0, 0, 0, 0};
+  auto scan_group = [&](int g, float& od, int& oi) {
+    const int b = 8 * g, e = (k < b + 8) ? k : b + 8;
+    float bd = HD(b); int bi = b;
+#pragma unroll
+    for (int j = 1; j < 8; ++j) {
+      const int i = b + j;
+      if (i < e) {
+        const float x = HD(i);
+        if (x > bd) { bd = x; bi = i; }
+        else if (x == bd && knn_less(bd, HP(bi), x, HP(i), P4)) { bi = i; }
+      }
+    }
+    od = bd; oi = bi;
+  };
+  auto pick_group = [&]() {
+    float bd = gd[0]; int bi = gs[0];
+#pragma unroll
+    for (int g = 1; g < 4; ++g)
+      if (8 * g < k) {
+        if (gd[g] > bd) { bd = gd[g]; bi = gs[g]; }
+        else if (gd[g] == bd && knn_less(bd, HP(bi), gd[g], HP(gs[g]), P4)) { bi = gs[g]; }
+      }
+    td = bd; tpos = bi; tp = HP(bi);
+  };
   auto find_worst = [&]() {
+    if constexpr (kSel == 2) {
+      if (cnt == k && tp == 0xFFFFFFFFu) {          // first call, right after the list filled: every group
+#pragma unroll
+        for (int g = 0; g < 4; ++g) if (8 * g < k) scan_group(g, gd[g], gs[g]);
+      } else {                                     // after a replacement: the group of the replaced slot
+        const int g = tpos >> 3;
+        float nd; int ni;
+        scan_group(g, nd, ni);
+#pragma unroll
+        for (int gg = 0; gg < 4; ++gg) if (gg == g) { gd[gg] = nd; gs[gg] = ni; }
+      }
+      pick_group();
+      return;
+    }
     float bd = HD(0); int bi = 0;
 #pragma unroll 8
     for (int i = 1; i < k; ++i) {
@@ -177,7 +221,7 @@ __global__ __launch_bounds__(kKnnBlock) void k_knn_normals(const float4* __restr
     }
     if (cnt < k) {
       HD(cnt) = d2; HP(cnt) = m;
-      if (++cnt == k) find_worst();
+      if (++cnt == k) { tp = 0xFFFFFFFFu; find_worst(); }
       return;
     }
     if (d2 > td) return;                                            // common case: one compare
@@ -455,9 +499,11 @@ static void knn_pass(const float* xyz, size_t n, int k, const float* viewpoint, 
     unsigned* todo = nullptr;
     size_t n_todo = n;
     const size_t lds = (size_t)k * kKnnBlock * 8;
-    const bool heap = k > 16;
-    E3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(heap ? k_knn_normals<true> : k_knn_normals<false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    static const int forced_sel = [] { const char* e = getenv("E3D_KNN_SELECT"); return e ? atoi(e) : -1; }();     // experiments: 0 heap, 1 flat, 2 grouped
+    const int sel = (forced_sel >= 0 && forced_sel <= 2 && (forced_sel != 2 || k <= 32)) ? forced_sel : (k <= 16 ? 1 : (k <= 32 ? 2 : 0));
+    const void* kfn = sel == 0 ? reinterpret_cast<const void*>(k_knn_normals<0>)
+                               : (sel == 1 ? reinterpret_cast<const void*>(k_knn_normals<1>) : reinterpret_cast<const void*>(k_knn_normals<2>));
+    E3D_HIP(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     static const double level_step = [] { const char* e = getenv("E3D_KNN_LEVEL_STEP"); const double v = e ? atof(e) : 0.0; return v > 1 ? v : 2.0; }();   // cell growth per retry level (4 -> 2: -7 % at k = 32)
     for (int level = 0; level < 64 && n_todo > 0; ++level) {
       KnnGrid G{};
@@ -488,7 +534,7 @@ static void knn_pass(const float* xyz, size_t n, int k, const float* viewpoint, 
       unsigned* next = (todo == todo_a.p) ? todo_b.p : todo_a.p;
       E3D_HIP(hipMemsetAsync(L.counter.p + 1, 0, sizeof(unsigned), s));
       const unsigned nblk = (unsigned)div_up(n_todo, kKnnBlock);
-      hipLaunchKernelGGL(heap ? k_knn_normals<true> : k_knn_normals<false>, dim3(nblk), dim3(kKnnBlock), lds, s, L.P4.p, n, todo, n_todo, L.table.p, G, k,
+      hipLaunchKernelGGL(sel == 0 ? k_knn_normals<0> : (sel == 1 ? k_knn_normals<1> : k_knn_normals<2>), dim3(nblk), dim3(kKnnBlock), lds, s, L.P4.p, n, todo, n_todo, L.table.p, G, k,
                          viewpoint[0], viewpoint[1], viewpoint[2], Q4.p, want_normals ? d_on.p : nullptr, want_normals ? d_oc.p : nullptr,
                          knn_indices ? d_knn.p : nullptr, d_mean_out ? d_mean_out->p : nullptr, next, L.counter.p + 1);
       unsigned n_next = 0;

@@ -242,6 +242,17 @@ __global__ __launch_bounds__(kKnnBlock) void k_knn_normals(const float4* __restr
         if ((ox != 0) + (oy != 0) + (oz != 0) != ring) continue;
         const int x = cx + ox, y = cy + oy, z = cz + oz;
         if (x < 0 || y < 0 || z < 0 || x > kMaxC || y > kMaxC || z > kMaxC) continue;
+        if (ring > 0 && cnt == k) {
+          // the list is full: a neighbour cell whose nearest face is farther than the current worst entry cannot contribute
+          // (every point of the cell is at least that far; `slack` covers the rounding of cell_coord as in the test below).
+          // Queries of a wave share their cell, so whole waves skip the same cells.
+          const float fx = ox < 0 ? q.x - (G.g.origin[0] + (float)cx * G.cell) : (ox > 0 ? (G.g.origin[0] + (float)(cx + 1) * G.cell) - q.x : 0.f);
+          const float fy = oy < 0 ? q.y - (G.g.origin[1] + (float)cy * G.cell) : (oy > 0 ? (G.g.origin[1] + (float)(cy + 1) * G.cell) - q.y : 0.f);
+          const float fz = oz < 0 ? q.z - (G.g.origin[2] + (float)cz * G.cell) : (oz > 0 ? (G.g.origin[2] + (float)(cz + 1) * G.cell) - q.z : 0.f);
+          const float ax = fmaxf(fx, 0.f), ay = fmaxf(fy, 0.f), az = fmaxf(fz, 0.f);
+          const float face = sqrtf(ax * ax + ay * ay + az * az) - G.slack;
+          if (face > 0.f && face * face * 0.99999f > (kHeap ? HD(0) : td)) continue;
+        }
         const unsigned long long key = cell_key(x, y, z);
         unsigned h = hash_key(key) & G.g.mask;
         unsigned s = 0, e = 0;

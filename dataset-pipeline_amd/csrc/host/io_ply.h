@@ -46,6 +46,60 @@ inline double read_scalar(const unsigned char* p, const std::string& t, bool swa
   if (t == "uint64") { uint64_t v; memcpy(&v, b, 8); return (double)v; }
   return 0;
 }
+// type name -> code, resolved once per property (the per-value string comparisons of read_scalar cost 0.5 us per point)
+enum TypeCode { kI8, kU8, kI16, kU16, kI32, kU32, kF32, kF64, kI64, kU64, kUnknownType };
+inline TypeCode type_code(const std::string& t) {
+  if (t == "char" || t == "int8") return kI8;
+  if (t == "uchar" || t == "uint8") return kU8;
+  if (t == "short" || t == "int16") return kI16;
+  if (t == "ushort" || t == "uint16") return kU16;
+  if (t == "int" || t == "int32") return kI32;
+  if (t == "uint" || t == "uint32") return kU32;
+  if (t == "float" || t == "float32") return kF32;
+  if (t == "double" || t == "float64") return kF64;
+  if (t == "int64") return kI64;
+  if (t == "uint64") return kU64;
+  return kUnknownType;
+}
+inline double read_scalar_code(const unsigned char* p, TypeCode c, bool swap) {
+  static const int size_of[] = {1, 1, 2, 2, 4, 4, 4, 8, 8, 8, 0};
+  unsigned char b[8];
+  const int n = size_of[c];
+  if (swap) { for (int i = 0; i < n; ++i) b[i] = p[n - 1 - i]; } else { memcpy(b, p, (size_t)n); }
+  switch (c) {
+    case kI8: { int8_t v; memcpy(&v, b, 1); return v; }
+    case kU8: { uint8_t v; memcpy(&v, b, 1); return v; }
+    case kI16: { int16_t v; memcpy(&v, b, 2); return v; }
+    case kU16: { uint16_t v; memcpy(&v, b, 2); return v; }
+    case kI32: { int32_t v; memcpy(&v, b, 4); return v; }
+    case kU32: { uint32_t v; memcpy(&v, b, 4); return v; }
+    case kF32: { float v; memcpy(&v, b, 4); return v; }
+    case kF64: { double v; memcpy(&v, b, 8); return v; }
+    case kI64: { int64_t v; memcpy(&v, b, 8); return (double)v; }
+    case kU64: { uint64_t v; memcpy(&v, b, 8); return (double)v; }
+    default: return 0;
+  }
+}
+// sequential reader over an ifstream with a 4 MB window: get(n) returns n contiguous bytes or nullptr at the end of the file
+struct BufReader {
+  std::ifstream& f;
+  std::vector<unsigned char> buf;
+  size_t pos = 0, end = 0;
+  explicit BufReader(std::ifstream& file) : f(file), buf((size_t)4 << 20) {}
+  const unsigned char* get(size_t n) {
+    if (end - pos < n) {
+      if (n > buf.size()) buf.resize(n);
+      memmove(buf.data(), buf.data() + pos, end - pos);
+      end -= pos; pos = 0;
+      f.read(reinterpret_cast<char*>(buf.data() + end), (std::streamsize)(buf.size() - end));
+      end += (size_t)f.gcount();
+      if (end < n) return nullptr;
+    }
+    const unsigned char* r = buf.data() + pos;
+    pos += n;
+    return r;
+  }
+};
 }  // namespace ply_detail
 
 // Returns 0 on success, < 0 on failure (like pcl::io::loadPLYFile).
@@ -117,6 +171,8 @@ inline int loadPLYFile(const std::string& path, PointCloud& cloud, bool want_rgb
       std::vector<size_t> off(e.props.size());
       for (size_t p = 0; p < e.props.size(); ++p) { off[p] = stride; const int ts = type_size(e.props[p].type); if (!ts) { std::cerr << "[loadPLYFile] unknown type " << e.props[p].type << std::endl; return -1; } stride += ts; }
       if (!is_vertex) { f.seekg((std::streamoff)(stride * e.count), std::ios::cur); continue; }
+      std::vector<TypeCode> code(e.props.size());
+      for (size_t p = 0; p < e.props.size(); ++p) code[p] = type_code(e.props[p].type);
       const size_t chunk = 1 << 20;
       std::vector<unsigned char> buf(stride * std::min(chunk, e.count ? e.count : 1));
       for (size_t i0 = 0; i0 < e.count; i0 += chunk) {
@@ -126,20 +182,20 @@ inline int loadPLYFile(const std::string& path, PointCloud& cloud, bool want_rgb
         for (size_t j = 0; j < m; ++j) {
           const unsigned char* r = buf.data() + stride * j;
           const size_t i = i0 + j;
-          cloud.xyz[3 * i] = (float)read_scalar(r + off[ix], e.props[ix].type, swap);
-          cloud.xyz[3 * i + 1] = (float)read_scalar(r + off[iy], e.props[iy].type, swap);
-          cloud.xyz[3 * i + 2] = (float)read_scalar(r + off[iz], e.props[iz].type, swap);
+          cloud.xyz[3 * i] = (float)read_scalar_code(r + off[ix], code[ix], swap);
+          cloud.xyz[3 * i + 1] = (float)read_scalar_code(r + off[iy], code[iy], swap);
+          cloud.xyz[3 * i + 2] = (float)read_scalar_code(r + off[iz], code[iz], swap);
           if (!cloud.rgb.empty() && ir >= 0 && ig >= 0 && ib >= 0) {
-            cloud.rgb[3 * i] = (uint8_t)read_scalar(r + off[ir], e.props[ir].type, swap);
-            cloud.rgb[3 * i + 1] = (uint8_t)read_scalar(r + off[ig], e.props[ig].type, swap);
-            cloud.rgb[3 * i + 2] = (uint8_t)read_scalar(r + off[ib], e.props[ib].type, swap);
+            cloud.rgb[3 * i] = (uint8_t)read_scalar_code(r + off[ir], code[ir], swap);
+            cloud.rgb[3 * i + 1] = (uint8_t)read_scalar_code(r + off[ig], code[ig], swap);
+            cloud.rgb[3 * i + 2] = (uint8_t)read_scalar_code(r + off[ib], code[ib], swap);
           }
           if (!cloud.normals.empty()) {
-            cloud.normals[3 * i] = (float)read_scalar(r + off[inx], e.props[inx].type, swap);
-            cloud.normals[3 * i + 1] = (float)read_scalar(r + off[iny], e.props[iny].type, swap);
-            cloud.normals[3 * i + 2] = (float)read_scalar(r + off[inz], e.props[inz].type, swap);
+            cloud.normals[3 * i] = (float)read_scalar_code(r + off[inx], code[inx], swap);
+            cloud.normals[3 * i + 1] = (float)read_scalar_code(r + off[iny], code[iny], swap);
+            cloud.normals[3 * i + 2] = (float)read_scalar_code(r + off[inz], code[inz], swap);
           }
-          if (iint >= 0) cloud.intensity[i] = (float)read_scalar(r + off[iint], e.props[iint].type, swap);
+          if (iint >= 0) cloud.intensity[i] = (float)read_scalar_code(r + off[iint], code[iint], swap);
         }
       }
     } else {
@@ -192,6 +248,7 @@ inline int loadPLYMesh(const std::string& path, std::vector<float>& xyz, std::ve
   const bool ascii = (format == "ascii"), swap = (format == "binary_big_endian");
   if (!ascii && format != "binary_little_endian" && !swap) { std::cerr << "[loadPLYMesh] unsupported format '" << format << "'" << std::endl; return -1; }
   xyz.clear(); triangles.clear();
+  BufReader reader(f);               // binary files: everything after the header goes through it
   for (const Elem& e : elems) {
     const bool is_vertex = (e.name == "vertex"), is_face = (e.name == "face");
     int ix = -1, iy = -1, iz = -1, il = -1;
@@ -202,6 +259,36 @@ inline int loadPLYMesh(const std::string& path, std::vector<float>& xyz, std::ve
     }
     if (is_vertex) { if (ix < 0 || iy < 0 || iz < 0) return -1; xyz.resize(3 * e.count); }
     if (is_face) triangles.reserve(3 * e.count);
+    if (!ascii) {
+      // binary: one buffered pass with the property types resolved up front (a mesh of 10^8 faces is 10^9 values)
+      std::vector<TypeCode> code(e.props.size()), ccode(e.props.size());
+      std::vector<int> ts(e.props.size()), cs(e.props.size());
+      for (size_t p = 0; p < e.props.size(); ++p) {
+        code[p] = type_code(e.props[p].type); ts[p] = type_size(e.props[p].type);
+        ccode[p] = e.props[p].is_list ? type_code(e.props[p].count_type) : kU8; cs[p] = e.props[p].is_list ? type_size(e.props[p].count_type) : 0;
+        if (!ts[p] || (e.props[p].is_list && !cs[p])) { std::cerr << "[loadPLYMesh] unknown property type in " << path << std::endl; return -1; }
+      }
+      for (size_t i = 0; i < e.count; ++i)
+        for (size_t p = 0; p < e.props.size(); ++p) {
+          if (e.props[p].is_list) {
+            const unsigned char* cb = reader.get((size_t)cs[p]);
+            if (!cb) { std::cerr << "[loadPLYMesh] truncated file " << path << std::endl; return -1; }
+            const size_t c = (size_t)read_scalar_code(cb, ccode[p], swap);
+            const unsigned char* d = reader.get(c * (size_t)ts[p]);
+            if (!d && c) { std::cerr << "[loadPLYMesh] truncated file " << path << std::endl; return -1; }
+            if (is_face && (int)p == il) {
+              if (c != 3) { std::cerr << "[loadPLYMesh] only triangle meshes are supported: " << path << std::endl; return -1; }
+              for (size_t k = 0; k < 3; ++k) triangles.push_back((uint32_t)read_scalar_code(d + k * (size_t)ts[p], code[p], swap));
+            }
+          } else {
+            const unsigned char* d = reader.get((size_t)ts[p]);
+            if (!d) { std::cerr << "[loadPLYMesh] truncated file " << path << std::endl; return -1; }
+            if (is_vertex && ((int)p == ix || (int)p == iy || (int)p == iz))
+              xyz[3 * i + ((int)p == ix ? 0 : ((int)p == iy ? 1 : 2))] = (float)read_scalar_code(d, code[p], swap);
+          }
+        }
+      continue;
+    }
     for (size_t i = 0; i < e.count; ++i) {
       std::istringstream ls;
       if (ascii) { if (!std::getline(f, line)) return -1; ls.str(line); }

@@ -141,3 +141,62 @@ def test_arrow_system_matches_dense_ldlt(tmp_path):
         assert r.returncode == 0, r.stdout + r.stderr
         err, mx, pack_ok = r.stdout.split()
         assert float(err) <= 1e-12 * max(1.0, float(mx)) and pack_ok == "1", (args, r.stdout)
+
+
+def test_ply_readers_mixed_types_and_endianness(tmp_path):
+    """loadPLYFile / loadPLYMesh (csrc/host/io_ply.h) on binary files as scanners and MeshLab write them: double coordinates,
+    properties in any order, colours, normals, intensity, extra properties, big-endian files, face lists with different count /
+    index types and a per-face scalar, a non-triangle face (rejected)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "ply_reader_test")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(root, "tests", "cpp", "ply_reader_test.cc")])
+    rng = np.random.RandomState(3)
+    n = 257
+    for endian, tag in (("<", "binary_little_endian"), (">", "binary_big_endian")):
+        v = np.zeros(n, dtype=[("nz", endian + "f4"), ("x", endian + "f8"), ("red", "u1"), ("y", endian + "f8"), ("conf", endian + "i2"), ("z", endian + "f8"),
+                               ("green", "u1"), ("blue", "u1"), ("nx", endian + "f4"), ("ny", endian + "f4"), ("intensity", endian + "f4")])
+        for k in ("x", "y", "z", "nx", "ny", "nz", "intensity"):
+            v[k] = rng.uniform(-5, 5, n)
+        for k in ("red", "green", "blue"):
+            v[k] = rng.randint(0, 256, n)
+        v["conf"] = rng.randint(-300, 300, n)
+        names = {"f4": "float", "f8": "double", "u1": "uchar", "i2": "short"}
+        hdr = "ply\nformat %s 1.0\ncomment test\nelement vertex %d\n" % (tag, n)
+        for name in v.dtype.names:
+            hdr += "property %s %s\n" % (names[v.dtype[name].str[-2:]], name)
+        hdr += "end_header\n"
+        path = str(tmp_path / ("cloud_%s.ply" % tag))
+        open(path, "wb").write(hdr.encode() + v.tobytes())
+        r = subprocess.run([exe, "cloud", path], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        lines = r.stdout.strip().split("\n")
+        assert lines[0] == "%d 1 1 1" % n
+        got = np.array([[float(t) for t in l.split()] for l in lines[1:]])
+        exp = np.stack([v["x"].astype(np.float32), v["y"].astype(np.float32), v["z"].astype(np.float32), v["red"], v["green"], v["blue"],
+                        v["nx"], v["ny"], v["nz"], v["intensity"]], 1).astype(np.float64)
+        assert np.array_equal(got.astype(np.float32), exp.astype(np.float32)), tag
+        # mesh: float vertices + colour, faces = (uchar count, int indices, float quality) or (int count, uint indices)
+        mv = np.zeros(50, dtype=[("x", endian + "f4"), ("y", endian + "f4"), ("z", endian + "f4"), ("red", "u1")])
+        for k in ("x", "y", "z"):
+            mv[k] = rng.uniform(-1, 1, 50)
+        for cnt_t, idx_t, cn, in_ in (("u1", "i4", "uchar", "int"), ("i4", "u4", "int", "uint")):
+            f = np.zeros(31, dtype=[("k", endian.replace("<", "<") + cnt_t if cnt_t != "u1" else "u1"), ("i", endian + idx_t, 3), ("q", endian + "f4")])
+            f["k"] = 3; f["i"] = rng.randint(0, 50, (31, 3)); f["q"] = 0.5
+            hdr = ("ply\nformat %s 1.0\nelement vertex 50\nproperty float x\nproperty float y\nproperty float z\nproperty uchar red\n"
+                   "element face 31\nproperty list %s %s vertex_indices\nproperty float quality\nend_header\n" % (tag, cn, in_))
+            path = str(tmp_path / ("mesh_%s_%s.ply" % (tag, cn)))
+            open(path, "wb").write(hdr.encode() + mv.tobytes() + f.tobytes())
+            r = subprocess.run([exe, "mesh", path], capture_output=True, text=True)
+            assert r.returncode == 0, r.stderr
+            lines = r.stdout.strip().split("\n")
+            assert lines[0] == "50 31"
+            gv = np.array([[float(t) for t in l.split()] for l in lines[1:51]], np.float32)
+            gt = np.array([[int(t) for t in l.split()] for l in lines[51:]])
+            assert np.array_equal(gv, np.stack([mv["x"], mv["y"], mv["z"]], 1).astype(np.float32)) and np.array_equal(gt, f["i"].astype(np.int64))
+    # a quad is refused
+    f = np.zeros(1, dtype=[("k", "u1"), ("i", "<i4", 4)]); f["k"] = 4
+    hdr = "ply\nformat binary_little_endian 1.0\nelement vertex 50\nproperty float x\nproperty float y\nproperty float z\nproperty uchar red\nelement face 1\nproperty list uchar int vertex_indices\nend_header\n"
+    path = str(tmp_path / "quad.ply")
+    open(path, "wb").write(hdr.encode() + mv.astype(mv.dtype.newbyteorder("<")).tobytes() + f.tobytes())
+    r = subprocess.run([exe, "mesh", path], capture_output=True, text=True)
+    assert r.returncode != 0 and "only triangle meshes are supported" in r.stderr

@@ -14,6 +14,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
+#include <map>
 #include <memory>
 
 #include "../../include/e3d_hip.h"
@@ -31,6 +32,7 @@ const char* last_error_cstr() { return g_last_error.c_str(); }
 static int g_device = 0;
 // E3D_NN_MODE / e3d_set_nn_mode: 0 auto, 1 per-query, 2 hash-table buckets, 3 dense rows, 4 dense rows + MFMA filter
 static int g_nn_mode = [] { const char* e = getenv("E3D_NN_MODE"); const int v = e ? atoi(e) : 0; return (v >= 0 && v <= 4) ? v : 0; }();
+static unsigned long long g_grid_generation = 0;
 
 // -------------------------------------------------------------------------------------------------
 struct Cloud {
@@ -50,9 +52,26 @@ struct Cloud {
   QueryRange qrange{};              // target-cell range a query needs to hit to have candidates
   unsigned n_cells = 0;             // occupied cells
   int key_bits = 0;                 // bits of the dense query keys
+  unsigned long long generation = 0;   // changes whenever the sorted order changes (invalidates the certificates' partners)
+  // bound of how far any point of this cloud has moved in the global frame since the grid was built (sum over the pose
+  // updates of ||dL|| R + ||dt||), and of the f32 rounding of one local -> global evaluation (running maximum)
+  double cum_motion = 0.0, last_motion = 0.0, err_max = 0.0;
+  double build_slack = 0.0;         // slack of the global -> local mapping the cell size was derived with
   float lmin[3], lmax[3];           // local bbox
   float bmin[3], bmax[3];           // global bbox of the current outer iteration
   int cloud_index = -1;             // impl index in the current AlignMeshes
+};
+
+// per-query state of a directed pair, kept from one outer iteration to the next (source order): partner position, certificate
+// bound (see k_nn_certify), and the list of queries the certificate did not settle
+struct PairState {
+  DevBuf<int> match;
+  DevBuf<float> lbe;
+  DevBuf<unsigned> todo, todo_count;
+  size_t n = 0;
+  long long jbase = -1;
+  unsigned long long src_gen = 0, tgt_gen = 0;
+  bool fresh = true;           // no search has filled the state yet
 };
 
 struct PairJob {
@@ -106,6 +125,11 @@ struct e3d_icp {
   DevBuf<double> d_partial, d_setsum;
   PinBuf<double> h_setsum;
   std::unique_ptr<EventTimer> lm_timer, nn_timer;
+
+  std::map<std::pair<int, int>, std::unique_ptr<PairState>> pair_state;
+  PinBuf<unsigned> h_todo;
+  DevBuf<unsigned long long> nn_stats;
+  DevBuf<float> lbe_scratch;
 
   std::vector<e3d_icp_pair_record> pair_records;
   std::vector<e3d_icp_iter_record> iter_records;
@@ -174,6 +198,7 @@ static void build_grid(e3d_icp* h, Cloud& c, float d) {
   const double m_global = nL * m_local + m_t + r;
   const double r_local = r / smin;
   const double slack = 16.0 * FLT_EPSILON * (m_global * ninv + m_local + r_local);
+  c.build_slack = slack;
   double extent = 0;
   for (int k = 0; k < 3; ++k) extent = std::max(extent, (double)c.lmax[k] - (double)c.lmin[k]);
   double cell = (r_local + slack) * (1.0 + 1e-3 + 8.0 * FLT_EPSILON * (extent / std::max(r_local, 1e-30) + 4.0));
@@ -187,6 +212,8 @@ static void build_grid(e3d_icp* h, Cloud& c, float d) {
   for (int k = 0; k < 3; ++k) c.grid.origin[k] = (float)((double)c.lmin[k] - 2.0 * cell);
 
   c.L4.reserve(n); c.LN.reserve(n); c.G4.reserve(n);
+  c.generation = ++g_grid_generation;
+  c.cum_motion = 0.0; c.last_motion = 0.0; c.err_max = 0.0;
   unsigned n_cells = 0;
   if (n > 0) {
     h->keys_a.reserve(n); h->keys_b.reserve(n); h->vals_a.reserve(n); h->vals_b.reserve(n);
@@ -281,14 +308,105 @@ static inline float radius_sq(float d) {
   return (float)(r * r);
 }
 
-// dense-directory row kernels: plain (mode 3 / auto) or with the MFMA filter (mode 4); identical results
-static void launch_rows(int mode, const Cloud& tgt, const float4* srcG, const unsigned* order, size_t n, const InvMap& im, float r2,
-                        int* match_pos, float* match_d2, hipStream_t s) {
+static float round_up_f(double v) {
+  float f = (float)v;
+  if ((double)f < v) f = std::nextafter(f, FLT_MAX);
+  return f;
+}
+static float round_down_f(double v) {
+  float f = (float)v;
+  if ((double)f > v) f = std::nextafter(f, -FLT_MAX);
+  return f;
+}
+
+// State a directed pair keeps between outer iterations (both clouds' sorted orders are static while their grids are):
+// reset whenever a grid was rebuilt or the slice changed.
+static PairState& pair_state_for(e3d_icp* h, int src_id, int tgt_id, const Cloud& src, const Cloud& tgt, size_t j0, size_t n) {
+  std::unique_ptr<PairState>& up = h->pair_state[std::make_pair(src_id, tgt_id)];
+  if (!up) up.reset(new PairState());
+  PairState& ps = *up;
+  if (ps.n != n || ps.jbase != (long long)j0 || ps.src_gen != src.generation || ps.tgt_gen != tgt.generation) {
+    ps.match.reserve(n); ps.lbe.reserve(n); ps.todo.reserve(n); ps.todo_count.reserve(1);
+    ps.n = n; ps.jbase = (long long)j0; ps.src_gen = src.generation; ps.tgt_gen = tgt.generation;
+    ps.fresh = true;
+  }
+  return ps;
+}
+
+// bound of how far any point of a cloud moves when its pose changes from T0 to T1 (global frame): ||dL||_2 R + ||dt||
+static double pose_motion_bound(const Cloud& c, const float* T0, const float* T1) {
+  float dT[12];
+  double dt = 0, R2 = 0;
+  for (int r = 0; r < 3; ++r) {
+    for (int k = 0; k < 3; ++k) dT[4 * r + k] = (float)((double)T1[4 * r + k] - (double)T0[4 * r + k]);
+    dT[4 * r + 3] = 0.f;
+    const double e = (double)T1[4 * r + 3] - (double)T0[4 * r + 3];
+    dt += e * e;
+    const double m = std::max(std::fabs((double)c.lmin[r]), std::fabs((double)c.lmax[r]));
+    R2 += m * m;
+  }
+  double fro = 0;
+  for (int r = 0; r < 3; ++r) for (int k = 0; k < 3; ++k) fro += (double)dT[4 * r + k] * (double)dT[4 * r + k];
+  double smax = max_singular_value_3x3(dT) * (1.0 + 1e-6) + 1e-12 * std::sqrt(fro);
+  if (!(smax <= std::sqrt(fro))) smax = std::sqrt(fro);      // Frobenius norm bounds the spectral norm (also the NaN fallback)
+  return smax * std::sqrt(R2) + std::sqrt(dt);
+}
+// bound of the f32 rounding error (Euclidean) of one evaluation of pcl_se3(T, p) for a point of the cloud: three products and
+// three sums per component, |error| <= 4 u (|L_row| |p| + |t_r|) with u = 2^-24 (5 u taken)
+static double pose_rounding_bound(const Cloud& c, const float* T) {
+  double fro = 0, tt = 0, R2 = 0;
+  for (int r = 0; r < 3; ++r) {
+    for (int k = 0; k < 3; ++k) fro += (double)T[4 * r + k] * (double)T[4 * r + k];
+    tt += (double)T[4 * r + 3] * (double)T[4 * r + 3];
+    const double m = std::max(std::fabs((double)c.lmin[r]), std::fabs((double)c.lmax[r]));
+    R2 += m * m;
+  }
+  return 2.5 * FLT_EPSILON * (std::sqrt(fro) * std::sqrt(R2) + std::sqrt(tt));
+}
+
+// certificate constants of k_nn_rows for a target at its current pose
+static CertParams make_cert_params(const Cloud& tgt, double cum_pair) {
+  CertParams cp;
+  double smin = min_singular_value_3x3(tgt.T);
+  if (!(smin > 0)) smin = 0;
+  const double cell = 1.0 / (double)tgt.grid.inv_cell;
+  double extent = 0;
+  for (int k = 0; k < 3; ++k) extent = std::max(extent, (double)tgt.lmax[k] - (double)tgt.lmin[k]);
+  cp.cell_scale = round_down_f(smin * cell * (1.0 - 1e-5));
+  // mapping error of the query + rounding of the stored points' global coordinates (both inside the build's slack), and the
+  // f32 fuzz of the cell boundaries
+  cp.cell_sub = round_up_f(smin * (2.0 * tgt.build_slack + 8.0 * FLT_EPSILON * (extent + 4.0 * cell)) * (1.0 + 1e-5));
+  cp.cum_lo = round_down_f(cum_pair * (1.0 - 2e-6));
+  return cp;
+}
+
+// dense-directory row kernels: plain (mode 3 / auto) or with the MFMA filter (mode 4); identical results.  The plain kernel
+// writes its results (and the certificate bounds) at the queries' source positions, the filtered one in the sorted order.
+static bool launch_rows(int mode, const Cloud& tgt, const float4* srcG, const unsigned* order, size_t n, const InvMap& im, float r2,
+                        const CertParams& cert, int* match_pos, float* match_d2, float* lbe, hipStream_t s) {
   MfParams P;
-  if (mode == 4 && mfma_filter_params(1.0 / (double)tgt.grid.inv_cell, max_singular_value_3x3(tgt.T) * (1.0 + 1e-6), nn_row_span(), r2, &P))
+  if (mode == 4 && mfma_filter_params(1.0 / (double)tgt.grid.inv_cell, max_singular_value_3x3(tgt.T) * (1.0 + 1e-6), nn_row_span(), r2, &P)) {
     launch_nn_mfma(srcG, order, n, tgt.G4.p, tgt.dense_start.p, tgt.grid, im, tgt.qrange, r2, P, match_pos, match_d2, s);
-  else
-    launch_nn_rows(srcG, order, n, tgt.G4.p, tgt.dense_start.p, tgt.grid, im, tgt.qrange, r2, match_pos, match_d2, s);
+    return false;
+  }
+  launch_nn_rows(srcG, order, n, tgt.G4.p, tgt.dense_start.p, tgt.grid, im, tgt.qrange, r2, cert, match_pos, match_d2, lbe, s);
+  return true;
+}
+
+static void sort_query_keys(e3d_icp* h, const Cloud& tgt, const float4* srcG, const unsigned* list, size_t n, const InvMap& im) {
+  hipStream_t s = h->stream;
+  h->keys_a.reserve(n); h->keys_b.reserve(n); h->vals_a.reserve(n); h->vals_b.reserve(n);
+  if (tgt.key_bits <= 31) {   // 8-byte (key, index) pairs through the radix passes
+    unsigned* ka = reinterpret_cast<unsigned*>(h->keys_a.p);
+    unsigned* kb = reinterpret_cast<unsigned*>(h->keys_b.p);
+    if (list) launch_query_keys32_list(srcG, list, n, tgt.grid, im, tgt.qrange, ka, h->vals_a.p, s);
+    else launch_query_keys32(srcG, n, tgt.grid, im, tgt.qrange, ka, h->vals_a.p, s);
+    sort_pairs_u32_u32(ka, kb, h->vals_a.p, h->vals_b.p, n, tgt.key_bits, h->sort_temp, s);
+  } else {
+    if (list) launch_query_keys_list(srcG, list, n, tgt.grid, im, tgt.qrange, h->keys_a.p, h->vals_a.p, s);
+    else launch_query_keys(srcG, n, tgt.grid, im, tgt.qrange, h->keys_a.p, h->vals_a.p, s);
+    sort_pairs_u64_u32(h->keys_a.p, h->keys_b.p, h->vals_a.p, h->vals_b.p, n, tgt.key_bits, h->sort_temp, s);
+  }
 }
 
 // NN search + compaction for one directed pair; appends to the correspondence planes.
@@ -301,43 +419,79 @@ static void find_pair(e3d_icp* h, Cloud& src, Cloud& tgt, float d, PairJob& job,
   if (n == 0 || tgt.n == 0) return;
   const float4* srcG = src.G4.p + j0;
   const float4* srcLN = src.LN.p + j0;
-  h->match_pos.reserve(n); h->match_d2.reserve(n);
+  h->match_d2.reserve(n);
   const size_t nb = div_up(n, kBlock);
   h->block_counts.reserve(nb); h->block_offsets.reserve(nb); h->block_d2.reserve(nb);
   h->d_total.reserve(1); h->d_total_d2.reserve(1); h->h_total.reserve(1); h->h_total_d2.reserve(1);
   if (!h->nn_timer) h->nn_timer.reset(new EventTimer());
-  // dense data (many points per cell): sort the queries by target cell and use the LDS-bucket kernel;
-  // sparse data: one thread per query.  Both are exact and return identical results.
+  // dense data (many points per cell): queries sorted by target cell + the LDS-bucket kernels; sparse data: one thread per
+  // query.  All are exact and return identical results.  The default row kernel keeps a per-query certificate between the
+  // outer iterations: a query whose partner of the last iteration is provably still its unique nearest neighbour is settled
+  // by k_nn_certify (one gather), only the others are sorted and searched.
   const bool dense = h->nn_mode >= 2 || (h->nn_mode == 0 && (double)tgt.n >= 4.0 * (double)std::max(tgt.n_cells, 1u));
+  const bool rows = dense && tgt.has_dense && (h->nn_mode == 0 || h->nn_mode == 3);
+  static const bool use_cert = [] { const char* e = getenv("E3D_NN_CERT"); return !(e && e[0] == '0'); }();
+  static const bool want_stats = [] { const char* e = getenv("E3D_NN_STATS"); return e && e[0] == '1'; }();
   const unsigned* order = nullptr;
-  // the timer brackets the search kernel itself (what rocprofv3 reports for it); keys + sort are part of t_nn_ms
-  if (dense) {
-    h->keys_a.reserve(n); h->keys_b.reserve(n); h->vals_a.reserve(n); h->vals_b.reserve(n);
+  int* match_pos = nullptr;
+  // the timer brackets the search kernels themselves (what rocprofv3 reports for them); keys + sort are part of t_nn_ms
+  if (rows) {
+    PairState& ps = pair_state_for(h, job.src, job.tgt, src, tgt, j0, n);
+    match_pos = ps.match.p;
     const InvMap im = make_invmap(tgt);
-    if (tgt.key_bits <= 31) {   // 8-byte (key, index) pairs through the radix passes
-      unsigned* ka = reinterpret_cast<unsigned*>(h->keys_a.p);
-      unsigned* kb = reinterpret_cast<unsigned*>(h->keys_b.p);
-      launch_query_keys32(srcG, n, tgt.grid, im, tgt.qrange, ka, h->vals_a.p, s);
-      sort_pairs_u32_u32(ka, kb, h->vals_a.p, h->vals_b.p, n, tgt.key_bits, h->sort_temp, s);
-    } else {
-      launch_query_keys(srcG, n, tgt.grid, im, tgt.qrange, h->keys_a.p, h->vals_a.p, s);
-      sort_pairs_u64_u32(h->keys_a.p, h->keys_b.p, h->vals_a.p, h->vals_b.p, n, tgt.key_bits, h->sort_temp, s);
+    const double cum_pair = src.cum_motion + tgt.cum_motion;
+    const CertParams cert = make_cert_params(tgt, cum_pair);
+    size_t n_search = n;
+    const unsigned* list = nullptr;
+    float t_cert = 0.f;
+    if (!ps.fresh && use_cert) {
+      const float cum_up = round_up_f((cum_pair * (1.0 + 2e-6) + 2.0 * (src.err_max + tgt.err_max)) * (1.0 + 1e-6));
+      h->h_todo.reserve(1);
+      E3D_HIP(hipMemsetAsync(ps.todo_count.p, 0, sizeof(unsigned), s));
+      h->nn_timer->start(s);
+      launch_nn_certify(srcG, n, tgt.G4.p, cum_up, radius_sq(d), ps.match.p, ps.lbe.p, h->match_d2.p, ps.todo.p, ps.todo_count.p, s);
+      h->nn_timer->stop(s);
+      copy_out(h->h_todo.p, ps.todo_count.p, sizeof(unsigned), s);
+      sync(h);
+      t_cert = h->nn_timer->ms();
+      n_search = h->h_todo.p[0];
+      list = ps.todo.p;
     }
+    if (n_search > 0) sort_query_keys(h, tgt, srcG, list, n_search, im);
     h->nn_timer->start(s);
-    if (tgt.has_dense && h->nn_mode != 2)
-      launch_rows(h->nn_mode, tgt, srcG, h->vals_b.p, n, im, radius_sq(d), h->match_pos.p, h->match_d2.p, s);
-    else
+    if (n_search > 0)
+      launch_rows(3, tgt, srcG, h->vals_b.p, n_search, im, radius_sq(d), cert, ps.match.p, h->match_d2.p, ps.lbe.p, s);
+    ps.fresh = false;
+    rec.t_nn_query_ms += t_cert;
+    if (want_stats)
+      fprintf(stderr, "[nn %d->%d] queries %zu searched %zu certify %.3f ms cum %.3g (last %.3g) err %.3g\n", job.src, job.tgt, n, n_search,
+              (double)t_cert, cum_pair, src.last_motion + tgt.last_motion, src.err_max + tgt.err_max);
+  } else if (dense) {
+    h->match_pos.reserve(n);
+    match_pos = h->match_pos.p;
+    const InvMap im = make_invmap(tgt);
+    sort_query_keys(h, tgt, srcG, nullptr, n, im);
+    h->nn_timer->start(s);
+    bool source_order = false;
+    if (tgt.has_dense && h->nn_mode != 2) {
+      h->lbe_scratch.reserve(n);
+      source_order = launch_rows(h->nn_mode, tgt, srcG, h->vals_b.p, n, im, radius_sq(d), make_cert_params(tgt, 0.0), h->match_pos.p,
+                                 h->match_d2.p, h->lbe_scratch.p, s);
+    } else {
       launch_nn_cells(srcG, h->vals_b.p, n, tgt.G4.p, tgt.table.p, nullptr, tgt.grid, im, tgt.qrange, radius_sq(d),
                       h->match_pos.p, h->match_d2.p, s);
-    order = h->vals_b.p;
+    }
+    order = source_order ? nullptr : h->vals_b.p;
   } else {
+    h->match_pos.reserve(n);
+    match_pos = h->match_pos.p;
     h->nn_timer->start(s);
     launch_nn_query(srcG, n, tgt.G4.p, tgt.table.p, tgt.grid, make_invmap(tgt), radius_sq(d), h->match_pos.p,
                     h->match_d2.p, s);
   }
   h->nn_timer->stop(s);
   h->chunk_sum.reserve(div_up(nb, 256) + 1); h->chunk_d2.reserve(div_up(nb, 256) + 1);
-  launch_match_scan(h->match_pos.p, h->match_d2.p, n, h->block_counts.p, h->block_offsets.p, h->block_d2.p,
+  launch_match_scan(match_pos, h->match_d2.p, n, h->block_counts.p, h->block_offsets.p, h->block_d2.p,
                     h->chunk_sum.p, h->chunk_d2.p, h->d_total.p, h->d_total_d2.p, s);
   copy_out(h->h_total.p, h->d_total.p, sizeof(unsigned long long), s);
   copy_out(h->h_total_d2.p, h->d_total_d2.p, sizeof(double), s);
@@ -353,7 +507,7 @@ static void find_pair(e3d_icp* h, Cloud& src, Cloud& tgt, float d, PairJob& job,
     h->cB.grow_keep(ncap, h->corr_used, s);
     h->cC.grow_keep(ncap, h->corr_used, s);
   }
-  launch_compact_corr(h->match_pos.p, order, n, h->block_offsets.p, srcG, srcLN,
+  launch_compact_corr(match_pos, order, n, h->block_offsets.p, srcG, srcLN,
                       to_affine(src.T), tgt.G4.p, tgt.LN.p, to_affine(tgt.T), h->cA.p, h->cB.p, h->cC.p,
                       h->corr_used, s);   // the merged fixed cloud keeps T = identity (exact)
   h->corr_used = need;
@@ -709,6 +863,10 @@ static bool align_meshes(e3d_icp* h, float max_d, float thr, bool print, int ite
     const float movement = std::sqrt(dx * dx + (dy * dy + dz * dz));
     if (movement > thr) converged = false;
     if (print && h->rank == 0) printf("  %d moved by %g\n", c.cloud_index, (double)movement);
+    // certificates of the NN search: how far can any point of this cloud have moved, how exact is its transform
+    c.last_motion = pose_motion_bound(c, c.T, Tn);
+    c.cum_motion += c.last_motion;
+    c.err_max = std::max(c.err_max, std::max(pose_rounding_bound(c, c.T), pose_rounding_bound(c, Tn)));
     std::memcpy(c.T, Tn, sizeof Tn);
   }
   rec.t_transform_ms = t_tr.ms();
@@ -880,11 +1038,15 @@ int64_t e3d_find_correspondences(const float* sxyz, size_t ns, const float* txyz
         const InvMap im = make_invmap(tgt);
         launch_query_keys(src.G4.p, ns, tgt.grid, im, tgt.qrange, h->keys_a.p, h->vals_a.p, s);
         sort_pairs_u64_u32(h->keys_a.p, h->keys_b.p, h->vals_a.p, h->vals_b.p, ns, tgt.key_bits, h->sort_temp, s);
-        if (tgt.has_dense && mode != 2)
-          launch_rows(mode, tgt, src.G4.p, h->vals_b.p, ns, im, radius_sq(d), h->match_pos.p, h->match_d2.p, s);
-        else
+        bool source_order = false;
+        if (tgt.has_dense && mode != 2) {
+          h->lbe_scratch.reserve(ns);
+          source_order = launch_rows(mode, tgt, src.G4.p, h->vals_b.p, ns, im, radius_sq(d), make_cert_params(tgt, 0.0), h->match_pos.p,
+                                     h->match_d2.p, h->lbe_scratch.p, s);
+        } else {
           launch_nn_cells(src.G4.p, h->vals_b.p, ns, tgt.G4.p, tgt.table.p, nullptr, tgt.grid, im, tgt.qrange, radius_sq(d), h->match_pos.p, h->match_d2.p, s);
-        order = h->vals_b.p;
+        }
+        order = source_order ? nullptr : h->vals_b.p;
       } else {
         launch_nn_query(src.G4.p, ns, tgt.G4.p, tgt.table.p, tgt.grid, make_invmap(tgt), radius_sq(d), h->match_pos.p, h->match_d2.p, s);
       }

@@ -266,8 +266,11 @@ __global__ __launch_bounds__(kBlock) void k_nn_query(const float4* __restrict__ 
 // (candidate slices) -- scan the bucket with broadcast LDS reads.  Same arithmetic, same (d2, index)
 // ordering and strict radius test as k_nn_query, so both kernels return identical results.
 // -------------------------------------------------------------------------------------------------
+// block_dist (optional): distance, in cells, from the mapped query to the nearest face of the 3 x 3 x 3 cell block around its
+// cell (1 .. 1.5): every target point outside the block is at least that far away in the target's local frame.
 __device__ __forceinline__ unsigned long long query_cell_key(const float4 q, const InvMap& im, const GridDesc& g,
-                                                             const QueryRange& qr, int& cx, int& cy, int& cz) {
+                                                             const QueryRange& qr, int& cx, int& cy, int& cz,
+                                                             float* block_dist = nullptr) {
   const float dx = q.x - im.t[0], dy = q.y - im.t[1], dz = q.z - im.t[2];
   const float lx = im.Linv[0] * dx + im.Linv[1] * dy + im.Linv[2] * dz;
   const float ly = im.Linv[3] * dx + im.Linv[4] * dy + im.Linv[5] * dz;
@@ -275,6 +278,12 @@ __device__ __forceinline__ unsigned long long query_cell_key(const float4 q, con
   cx = cell_coord(lx, g.origin[0], g.inv_cell);
   cy = cell_coord(ly, g.origin[1], g.inv_cell);
   cz = cell_coord(lz, g.origin[2], g.inv_cell);
+  if (block_dist) {
+    const float ux = (lx - g.origin[0]) * g.inv_cell - (float)cx, uy = (ly - g.origin[1]) * g.inv_cell - (float)cy,
+                uz = (lz - g.origin[2]) * g.inv_cell - (float)cz;
+    const float m = fminf(fminf(fminf(ux, 1.0f - ux), fminf(uy, 1.0f - uy)), fminf(uz, 1.0f - uz));
+    *block_dist = 1.0f + fminf(fmaxf(m, 0.0f), 0.5f);
+  }
   const unsigned kx = (unsigned)(cx - qr.lo[0]), ky = (unsigned)(cy - qr.lo[1]), kz = (unsigned)(cz - qr.lo[2]);
   if (kx >= qr.D[0] || ky >= qr.D[1] || kz >= qr.D[2]) return kEmptyKey;   // no target cell within reach
   return ((unsigned long long)kz * qr.D[1] + ky) * qr.D[0] + kx;
@@ -301,6 +310,29 @@ __global__ __launch_bounds__(kBlock) void k_query_keys32(const float4* __restric
   const unsigned long long k = query_cell_key(Gsrc[j], im, g, qr, cx, cy, cz);
   keys[j] = (k == kEmptyKey) ? 0xFFFFFFFFu : (unsigned)k;
   vals[j] = (unsigned)j;
+}
+
+// the same keys for a LIST of queries (the ones the certificates did not settle): vals = their source positions
+__global__ __launch_bounds__(kBlock) void k_query_keys_list(const float4* __restrict__ Gsrc, const unsigned* __restrict__ list, size_t n,
+                                                            GridDesc g, InvMap im, QueryRange qr, unsigned long long* __restrict__ keys,
+                                                            unsigned* __restrict__ vals) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const unsigned j = list[i];
+  int cx, cy, cz;
+  keys[i] = query_cell_key(Gsrc[j], im, g, qr, cx, cy, cz);
+  vals[i] = j;
+}
+__global__ __launch_bounds__(kBlock) void k_query_keys32_list(const float4* __restrict__ Gsrc, const unsigned* __restrict__ list, size_t n,
+                                                              GridDesc g, InvMap im, QueryRange qr, unsigned* __restrict__ keys,
+                                                              unsigned* __restrict__ vals) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const unsigned j = list[i];
+  int cx, cy, cz;
+  const unsigned long long k = query_cell_key(Gsrc[j], im, g, qr, cx, cy, cz);
+  keys[i] = (k == kEmptyKey) ? 0xFFFFFFFFu : (unsigned)k;
+  vals[i] = j;
 }
 
 __device__ __forceinline__ int rdlane_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
@@ -486,8 +518,11 @@ __device__ __forceinline__ f2_t row_pair_d2(const float4 A, const float2 Zv, con
   return d;
 }
 
+// b2 follows the second smallest value at quad granularity (a displaced best, or the minimum of a quad that did not win);
+// the other members of the winning quad are folded in by row_scan_resolve, so that afterwards b2 is the exact second
+// smallest squared distance among all candidates seen (the certificate bound of k_nn_certify).
 __device__ __forceinline__ void row_scan_fast(const RowLds& L, int sl, int slices, int trips2, float qx, float qy,
-                                              float qz, float& bd, int& bq, bool& tie) {
+                                              float qz, float& bd, int& bq, bool& tie, float& b2) {
   const f2_t QX = {qx, qx}, QY = {qy, qy}, QZ = {qz, qz};
   int p = sl;
   int i = 0;
@@ -496,6 +531,7 @@ __device__ __forceinline__ void row_scan_fast(const RowLds& L, int sl, int slice
     const f2_t d0 = row_pair_d2(A0, Z0, QX, QY, QZ);                          \
     const f2_t d1 = row_pair_d2(A1, Z1, QX, QY, QZ);                          \
     const float mq = fminf(fminf(d0.x, d0.y), fminf(d1.x, d1.y));            \
+    b2 = fminf(b2, fmaxf(bd, mq));                                           \
     const bool lt = mq < bd, le = mq <= bd;                                  \
     tie = tie || (le && !lt);                                                \
     bd = lt ? mq : bd;                                                       \
@@ -519,7 +555,7 @@ __device__ __forceinline__ void row_scan_fast(const RowLds& L, int sl, int slice
 
 // exact (d2, original index) comparator over the four candidates of quad `bq` of this lane
 __device__ __forceinline__ void row_scan_resolve(const RowLds& L, int sl, int slices, int bq, unsigned base, unsigned nb,
-                                                 float qx, float qy, float qz, float& bd, unsigned& boi, unsigned& bt) {
+                                                 float qx, float qy, float qz, float& bd, unsigned& boi, unsigned& bt, float& b2) {
 #pragma unroll
   for (int h2 = 0; h2 < 2; ++h2) {
     const int p = sl + (2 * bq + h2) * slices;
@@ -531,14 +567,15 @@ __device__ __forceinline__ void row_scan_resolve(const RowLds& L, int sl, int sl
       if (t >= nb) continue;
       const float d2 = sqdist_l2(qx, qy, qz, hh ? A.y : A.x, hh ? A.w : A.z, hh ? Zv.y : Zv.x);
       const unsigned oi = L.oi[t];
-      if (d2 < bd || (d2 == bd && oi < boi)) { bd = d2; boi = oi; bt = base + t; }
+      if (d2 < bd || (d2 == bd && oi < boi)) { b2 = fminf(b2, bd); bd = d2; boi = oi; bt = base + t; }
+      else b2 = fminf(b2, d2);
     }
   }
 }
 
 // exact re-scan with the full (d2, original index) comparator
 __device__ __forceinline__ void row_scan_exact(const RowLds& L, int sl, int slices, int trips, unsigned base, unsigned nb,
-                                               float qx, float qy, float qz, float& bd, unsigned& boi, unsigned& bt) {
+                                               float qx, float qy, float qz, float& bd, unsigned& boi, unsigned& bt, float& b2) {
   int p = sl;
   for (int i = 0; i < trips; ++i, p += slices) {
     const float4 A = L.xy[p];
@@ -549,16 +586,21 @@ __device__ __forceinline__ void row_scan_exact(const RowLds& L, int sl, int slic
       if (t >= nb) continue;
       const float d2 = sqdist_l2(qx, qy, qz, hh ? A.y : A.x, hh ? A.w : A.z, hh ? Zv.y : Zv.x);
       const unsigned oi = L.oi[t];
-      if (d2 < bd || (d2 == bd && oi < boi)) { bd = d2; boi = oi; bt = base + t; }
+      if (d2 < bd || (d2 == bd && oi < boi)) { b2 = fminf(b2, bd); bd = d2; boi = oi; bt = base + t; }
+      else b2 = fminf(b2, d2);
     }
   }
 }
 
+// Results are written at the query's SOURCE position order[pos] (the queries may be a sorted sub-list of the source cloud):
+// match_pos / match_d2 as before, and lbe = (distance every target point other than the partner exceeds) + cert.cum_lo, the
+// state k_nn_certify tests in the following outer iterations.
 __global__ __launch_bounds__(kBlock, 6) void k_nn_rows(const float4* __restrict__ Gsrc, const unsigned* __restrict__ order,
                                                        size_t n, const float4* __restrict__ Gtgt,
                                                        const unsigned* __restrict__ S, GridDesc g, InvMap im,
-                                                       QueryRange qr, float r2, int row_span,
-                                                       int* __restrict__ match_pos, float* __restrict__ match_d2) {
+                                                       QueryRange qr, float r2, int row_span, CertParams cert,
+                                                       int* __restrict__ match_pos, float* __restrict__ match_d2,
+                                                       float* __restrict__ lbe) {
   __shared__ RowLds lds[kBlock / kWave];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   RowLds& L = lds[w];
@@ -567,13 +609,16 @@ __global__ __launch_bounds__(kBlock, 6) void k_nn_rows(const float4* __restrict_
   const unsigned j = valid ? order[pos] : 0u;
   const float4 q = valid ? Gsrc[j] : make_float4(0.f, 0.f, 0.f, 0.f);
   int cx = 0, cy = 0, cz = 0;
-  const unsigned long long key = valid ? query_cell_key(q, im, g, qr, cx, cy, cz) : kEmptyKey;
+  float block_dist = 2.0f;
+  const unsigned long long key = valid ? query_cell_key(q, im, g, qr, cx, cy, cz, &block_dist) : kEmptyKey;
+  if (key == kEmptyKey) block_dist = 2.0f;     // outside the directory range (occupied cells +- 2): two empty cells all around
   const int kx = cx - qr.lo[0], ky = cy - qr.lo[1], kz = cz - qr.lo[2];   // in [0, D) for valid keys
 
   float best_d2 = r2;      // strict radius (see k_nn_query)
   unsigned best_oi = 0u;
   int best_pos = -1;
   const float kInf = __uint_as_float(0x7f800000u);
+  float best_b2 = kInf;    // second smallest squared distance among the candidates seen
 
   unsigned long long remaining = __ballot(key != kEmptyKey);
   while (remaining) {
@@ -612,6 +657,7 @@ __global__ __launch_bounds__(kBlock, 6) void k_nn_rows(const float4* __restrict_
     float lb_d2 = r2;
     unsigned lb_oi = 0u;
     unsigned lb_t = 0xFFFFFFFFu;      // flat index into the concatenated 9 runs
+    float lb_b2 = kInf;
 
     for (unsigned base = 0; base < total; base += kRowCap) {
       const unsigned nb = min((unsigned)kRowCap, total - base);
@@ -661,17 +707,17 @@ __global__ __launch_bounds__(kBlock, 6) void k_nn_rows(const float4* __restrict_
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-      const float in_d2 = lb_d2;
+      const float in_d2 = lb_d2, in_b2 = lb_b2;
       const unsigned in_oi = lb_oi, in_t = lb_t;
       bool tie = false;
       int bq = -1;
       float fd = lb_d2;
-      row_scan_fast(L, sl, slices, trips2, qx, qy, qz, fd, bq, tie);
+      row_scan_fast(L, sl, slices, trips2, qx, qy, qz, fd, bq, tie, lb_b2);
       if (__ballot(tie)) {                    // rare: cross-quad exact f32 distance tie -> full comparator for this batch
-        lb_d2 = in_d2; lb_oi = in_oi; lb_t = in_t;
-        row_scan_exact(L, sl, slices, trips, base, nb, qx, qy, qz, lb_d2, lb_oi, lb_t);
+        lb_d2 = in_d2; lb_oi = in_oi; lb_t = in_t; lb_b2 = in_b2;
+        row_scan_exact(L, sl, slices, trips, base, nb, qx, qy, qz, lb_d2, lb_oi, lb_t, lb_b2);
       } else if (bq >= 0) {                   // winner quad: exact (d2, index) order among its four candidates
-        row_scan_resolve(L, sl, slices, bq, base, nb, qx, qy, qz, lb_d2, lb_oi, lb_t);
+        row_scan_resolve(L, sl, slices, bq, base, nb, qx, qy, qz, lb_d2, lb_oi, lb_t, lb_b2);
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -692,6 +738,8 @@ __global__ __launch_bounds__(kBlock, 6) void k_nn_rows(const float4* __restrict_
       const float od2 = __shfl_xor(lb_d2, stx, 64);
       const unsigned ooi = (unsigned)__shfl_xor((int)lb_oi, stx, 64);
       const int opos = __shfl_xor(lb_pos, stx, 64);
+      const float ob2 = __shfl_xor(lb_b2, stx, 64);
+      lb_b2 = fminf(fminf(lb_b2, ob2), fmaxf(lb_d2, od2));      // second smallest of the two slices together
       if (od2 < lb_d2 || (od2 == lb_d2 && ooi < lb_oi)) { lb_d2 = od2; lb_oi = ooi; lb_pos = opos; }
     }
     // hand the result to the lane that owns the query
@@ -699,12 +747,21 @@ __global__ __launch_bounds__(kBlock, 6) void k_nn_rows(const float4* __restrict_
     const float rd2 = __shfl(lb_d2, srcl, 64);
     const unsigned roi = (unsigned)__shfl((int)lb_oi, srcl, 64);
     const int rpos = __shfl(lb_pos, srcl, 64);
+    const float rb2 = __shfl(lb_b2, srcl, 64);
     if ((seg >> lane) & 1ull) {
+      best_b2 = fminf(fminf(best_b2, rb2), fmaxf(best_d2, rd2));
       if (rd2 < best_d2 || (rd2 == best_d2 && roi < best_oi)) { best_d2 = rd2; best_oi = roi; best_pos = rpos; }
     }
     remaining &= ~seg;
   }
-  if (valid) { match_pos[pos] = best_pos; match_d2[pos] = best_d2; }
+  if (valid) {
+    match_pos[j] = best_pos; match_d2[j] = best_d2;
+    // every candidate in the 27 cells was evaluated: the others are >= sqrt(best_b2) away (all of them, if there is no partner:
+    // best_d2 stayed r2, so best_b2 is the smallest distance seen); points outside the block are >= block_dist cells away in
+    // the local frame (2 cells if the query's cell lies outside the directory range, i.e. occupied cells +- 2)
+    const float lb_out = block_dist * cert.cell_scale - cert.cell_sub;
+    lbe[j] = fmaxf(fminf(sqrtf(best_b2), lb_out), 0.0f) * 0.999999f + cert.cum_lo;
+  }
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -980,6 +1037,68 @@ __global__ __launch_bounds__(kBlock, 3) void k_nn_mfma(const float4* __restrict_
     remaining &= ~seg;
   }
   if (valid) { match_pos[pos] = best_pos; match_d2[pos] = best_d2; }
+}
+
+// -------------------------------------------------------------------------------------------------
+// Certificates: is last outer iteration's partner provably still the unique nearest neighbour within the radius?
+//
+// State of query j of a directed pair (source order): match[j] = partner position m in the target arrays (or -1) and
+// lbe[j] = LB + cum(s), where at the query's last search (outer iteration s) every target point other than m was at (true
+// Euclidean) distance >= LB of the query in the global frame, and cum(.) is the host's running bound of how far any point of
+// either cloud has moved since (sum over the pose updates of ||dL|| R + ||dt||; cum_up adds the f32 rounding of the transforms).
+// Triangle inequality: now every other point is at distance >= thr = lbe - cum_up.  If the partner's new f32 squared distance v
+// is < thr^2 (with room for the f32 evaluation error of the others' distances) and < r2, the exact search would return (m, v):
+// nothing else can be nearer or tie.  For m = -1 "no partner" stands as long as thr^2 >= r2.  All other queries are appended
+// to the todo list (in source order inside a block of 2048 queries; one atomic per block) and searched by k_nn_rows, which
+// renews their state.
+// -------------------------------------------------------------------------------------------------
+constexpr int kCertPerWave = 512;          // consecutive queries per wave (8 steps of 64): one atomic per block of 2048 queries
+__global__ __launch_bounds__(kBlock) void k_nn_certify(const float4* __restrict__ Gsrc, size_t n, const float4* __restrict__ Gtgt,
+                                                       float cum_up, float r2, const int* __restrict__ match,
+                                                       const float* __restrict__ lbe, float* __restrict__ match_d2,
+                                                       unsigned* __restrict__ todo, unsigned* __restrict__ todo_count) {
+  __shared__ unsigned s_list[kBlock / kWave][kCertPerWave];
+  __shared__ unsigned s_cnt[kBlock / kWave];
+  __shared__ unsigned s_base;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const size_t j0 = ((size_t)blockIdx.x * (kBlock / kWave) + (size_t)w) * kCertPerWave;
+  unsigned cnt = 0;                                            // wave-uniform
+  for (int step = 0; step < kCertPerWave / kWave; ++step) {
+    const size_t j = j0 + (size_t)step * kWave + (size_t)lane;
+    const bool valid = j < n;
+    bool ok = false;
+    if (valid) {
+      const float thr = (lbe[j] - cum_up) * 0.999999f;
+      if (thr > 0.f) {
+        const float lim = thr * thr * 0.999999f;
+        const int m = match[j];
+        if (m >= 0) {
+          const float4 q = Gsrc[j];
+          const float4 c = Gtgt[m];
+          const float v = sqdist_l2(q.x, q.y, q.z, c.x, c.y, c.z);
+          ok = (v < lim) && (v < r2);
+          if (ok) match_d2[j] = v;
+        } else {
+          ok = lim >= r2;
+          if (ok) match_d2[j] = r2;
+        }
+      }
+    }
+    const unsigned long long fail = __ballot(valid && !ok);
+    if (valid && !ok) s_list[w][cnt + (unsigned)__popcll(fail & ((1ull << lane) - 1ull))] = (unsigned)j;
+    cnt += (unsigned)__popcll(fail);
+  }
+  if (lane == 0) s_cnt[w] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned tot = 0;
+    for (int k = 0; k < kBlock / kWave; ++k) tot += s_cnt[k];
+    s_base = tot ? atomicAdd(todo_count, tot) : 0u;
+  }
+  __syncthreads();
+  unsigned base = s_base;
+  for (int k = 0; k < w; ++k) base += s_cnt[k];
+  for (unsigned i = (unsigned)lane; i < cnt; i += kWave) todo[base + i] = s_list[w][i];
 }
 
 // flags -> per-block counts (first stage of the order-preserving compaction)
@@ -1468,11 +1587,29 @@ static int row_span_setting() {
 }
 
 void launch_nn_rows(const float4* Gsrc, const unsigned* order, size_t n, const float4* Gtgt, const unsigned* dense_start,
-                    const GridDesc& g, const InvMap& im, const QueryRange& qr, float r2, int* match_pos, float* match_d2,
-                    hipStream_t s) {
+                    const GridDesc& g, const InvMap& im, const QueryRange& qr, float r2, const CertParams& cert, int* match_pos,
+                    float* match_d2, float* lbe, hipStream_t s) {
   if (!n) return;
   hipLaunchKernelGGL(k_nn_rows, dim3((unsigned)div_up(n, kBlock)), dim3(kBlock), 0, s, Gsrc, order, n, Gtgt, dense_start,
-                     g, im, qr, r2, row_span_setting(), match_pos, match_d2);
+                     g, im, qr, r2, row_span_setting(), cert, match_pos, match_d2, lbe);
+}
+
+void launch_query_keys_list(const float4* Gsrc, const unsigned* list, size_t n, const GridDesc& g, const InvMap& im,
+                            const QueryRange& qr, unsigned long long* keys, unsigned* vals, hipStream_t s) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_query_keys_list, dim3((unsigned)div_up(n, kBlock)), dim3(kBlock), 0, s, Gsrc, list, n, g, im, qr, keys, vals);
+}
+void launch_query_keys32_list(const float4* Gsrc, const unsigned* list, size_t n, const GridDesc& g, const InvMap& im,
+                              const QueryRange& qr, unsigned* keys, unsigned* vals, hipStream_t s) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_query_keys32_list, dim3((unsigned)div_up(n, kBlock)), dim3(kBlock), 0, s, Gsrc, list, n, g, im, qr, keys, vals);
+}
+
+void launch_nn_certify(const float4* Gsrc, size_t n, const float4* Gtgt, float cum_up, float r2, const int* match, const float* lbe,
+                       float* match_d2, unsigned* todo, unsigned* todo_count, hipStream_t s) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_nn_certify, dim3((unsigned)div_up(n, (size_t)kCertPerWave * (kBlock / kWave))), dim3(kBlock), 0, s, Gsrc, n, Gtgt,
+                     cum_up, r2, match, lbe, match_d2, todo, todo_count);
 }
 
 // Filter constants of k_nn_mfma for a target grid (cell = local cell size, sigma_max = largest singular value of the

@@ -60,9 +60,24 @@ void launch_query_keys32(const float4* Gsrc, size_t n, const GridDesc& g, const 
 void launch_nn_cells(const float4* Gsrc, const unsigned* order, size_t n, const float4* Gtgt, const HashEntry* table,
                      const unsigned* dense_start, const GridDesc& g, const InvMap& im, const QueryRange& qr, float r2,
                      int* match_pos, float* match_d2, hipStream_t s);
+// certificate side of k_nn_rows: lbe = min(sqrt(second smallest d2), block_dist * cell_scale - cell_sub) + cum_lo
+struct CertParams {
+  float cell_scale;      // sigma_min * cell size (global distance of one local cell), rounded down
+  float cell_sub;        // sigma_min * slack of the global -> local mapping and the cell boundaries, rounded up
+  float cum_lo;          // accumulated motion bound of the pair at this outer iteration, rounded down
+};
+// k_nn_rows writes its results at the queries' SOURCE positions order[pos] (match_pos, match_d2, lbe in source order)
 void launch_nn_rows(const float4* Gsrc, const unsigned* order, size_t n, const float4* Gtgt, const unsigned* dense_start,
-                    const GridDesc& g, const InvMap& im, const QueryRange& qr, float r2, int* match_pos, float* match_d2,
-                    hipStream_t s);
+                    const GridDesc& g, const InvMap& im, const QueryRange& qr, float r2, const CertParams& cert, int* match_pos,
+                    float* match_d2, float* lbe, hipStream_t s);
+void launch_query_keys_list(const float4* Gsrc, const unsigned* list, size_t n, const GridDesc& g, const InvMap& im,
+                            const QueryRange& qr, unsigned long long* keys, unsigned* vals, hipStream_t s);
+void launch_query_keys32_list(const float4* Gsrc, const unsigned* list, size_t n, const GridDesc& g, const InvMap& im,
+                              const QueryRange& qr, unsigned* keys, unsigned* vals, hipStream_t s);
+// settles every query whose old partner is provably still the unique nearest neighbour within the radius (lbe - cum_up > new
+// distance), lists the others in todo (see k_nn_certify)
+void launch_nn_certify(const float4* Gsrc, size_t n, const float4* Gtgt, float cum_up, float r2, const int* match, const float* lbe,
+                       float* match_d2, unsigned* todo, unsigned* todo_count, hipStream_t s);
 struct MfParams { float S, r2s, eta2, delta4, delta4sq; };      // filter constants of k_nn_mfma (see mfma_filter_params)
 bool mfma_filter_params(double cell, double sigma_max, int row_span, float r2, MfParams* P);
 void launch_nn_mfma(const float4* Gsrc, const unsigned* order, size_t n, const float4* Gtgt, const unsigned* dense_start,

@@ -40,7 +40,7 @@ def test_transform_bit_exact(e3d, ob, n):
 
 
 # ---- a5: FindCorrespondencesFast --------------------------------------------------------------------------------
-@pytest.fixture(params=[1, 2, 3, 4], ids=["per-query-kernel", "hash-bucket-kernel", "dense-row-kernel", "mfma-filter-kernel"])
+@pytest.fixture(params=[1, 2, 3, 4, 0], ids=["per-query-kernel", "hash-bucket-kernel", "dense-row-kernel+certificates", "mfma-filter-kernel", "auto"])
 def nn_mode(request, e3d):
     """All exact NN kernels must agree with the oracle bit for bit."""
     assert e3d.lib().e3d_set_nn_mode(request.param) == 0

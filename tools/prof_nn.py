@@ -13,7 +13,7 @@ torch.cuda.synchronize()
 icp = e3d.PointToPlaneICP(device=0)
 for s in scans:
     icp.add_point_cloud(s["xyz"], s["normals"], s["T_init"], False)
-icp.set_max_inner_iterations(2)
+icp.set_max_inner_iterations(int(os.environ.get("E3D_PROF_INNER", "2")))
 t0 = time.time()
 for it in range(iters):
     icp.run(0.01, it, 1, 1e-10, False)

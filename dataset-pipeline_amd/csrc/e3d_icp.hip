@@ -65,9 +65,9 @@ struct Cloud {
 // per-query state of a directed pair, kept from one outer iteration to the next (source order): partner position, certificate
 // bound (see k_nn_certify), and the list of queries the certificate did not settle
 struct PairState {
-  DevBuf<int> match;
+  DevBuf<int> match, match2;       // partner, runner-up of the last search (or -1)
   DevBuf<float> lbe;
-  DevBuf<unsigned> todo, todo_count;
+  DevBuf<unsigned> todo_near, todo_far, todo_count;     // todo_count[0..1] = list lengths
   size_t n = 0;
   long long jbase = -1;
   unsigned long long src_gen = 0, tgt_gen = 0;
@@ -308,6 +308,10 @@ static inline float radius_sq(float d) {
   return (float)(r * r);
 }
 
+static double env_double(const char* name, double dflt) {
+  const char* e = getenv(name);
+  return e ? atof(e) : dflt;
+}
 static float round_up_f(double v) {
   float f = (float)v;
   if ((double)f < v) f = std::nextafter(f, FLT_MAX);
@@ -326,7 +330,7 @@ static PairState& pair_state_for(e3d_icp* h, int src_id, int tgt_id, const Cloud
   if (!up) up.reset(new PairState());
   PairState& ps = *up;
   if (ps.n != n || ps.jbase != (long long)j0 || ps.src_gen != src.generation || ps.tgt_gen != tgt.generation) {
-    ps.match.reserve(n); ps.lbe.reserve(n); ps.todo.reserve(n); ps.todo_count.reserve(1);
+    ps.match.reserve(n); ps.match2.reserve(n); ps.lbe.reserve(n); ps.todo_near.reserve(n); ps.todo_far.reserve(n); ps.todo_count.reserve(2);
     ps.n = n; ps.jbase = (long long)j0; ps.src_gen = src.generation; ps.tgt_gen = tgt.generation;
     ps.fresh = true;
   }
@@ -383,13 +387,13 @@ static CertParams make_cert_params(const Cloud& tgt, double cum_pair) {
 // dense-directory row kernels: plain (mode 3 / auto) or with the MFMA filter (mode 4); identical results.  The plain kernel
 // writes its results (and the certificate bounds) at the queries' source positions, the filtered one in the sorted order.
 static bool launch_rows(int mode, const Cloud& tgt, const float4* srcG, const unsigned* order, size_t n, const InvMap& im, float r2,
-                        const CertParams& cert, int* match_pos, float* match_d2, float* lbe, hipStream_t s) {
+                        const CertParams& cert, int* match_pos, float* match_d2, float* lbe, int* match2, hipStream_t s) {
   MfParams P;
   if (mode == 4 && mfma_filter_params(1.0 / (double)tgt.grid.inv_cell, max_singular_value_3x3(tgt.T) * (1.0 + 1e-6), nn_row_span(), r2, &P)) {
     launch_nn_mfma(srcG, order, n, tgt.G4.p, tgt.dense_start.p, tgt.grid, im, tgt.qrange, r2, P, match_pos, match_d2, s);
     return false;
   }
-  launch_nn_rows(srcG, order, n, tgt.G4.p, tgt.dense_start.p, tgt.grid, im, tgt.qrange, r2, cert, match_pos, match_d2, lbe, s);
+  launch_nn_rows(srcG, order, n, tgt.G4.p, tgt.dense_start.p, tgt.grid, im, tgt.qrange, r2, cert, match_pos, match_d2, lbe, match2, s);
   return true;
 }
 
@@ -441,31 +445,55 @@ static void find_pair(e3d_icp* h, Cloud& src, Cloud& tgt, float d, PairJob& job,
     const InvMap im = make_invmap(tgt);
     const double cum_pair = src.cum_motion + tgt.cum_motion;
     const CertParams cert = make_cert_params(tgt, cum_pair);
-    size_t n_search = n;
+    size_t n_far = n, n_near = 0;
     const unsigned* list = nullptr;
     float t_cert = 0.f;
     if (!ps.fresh && use_cert) {
+      static const double margin_frac = env_double("E3D_NN_MARGIN", 0.08), near_frac = env_double("E3D_NN_NEAR", 0.4);   // of the radius
       const float cum_up = round_up_f((cum_pair * (1.0 + 2e-6) + 2.0 * (src.err_max + tgt.err_max)) * (1.0 + 1e-6));
-      h->h_todo.reserve(1);
-      E3D_HIP(hipMemsetAsync(ps.todo_count.p, 0, sizeof(unsigned), s));
+      const float near2 = (float)((near_frac * (double)d) * (near_frac * (double)d));
+      h->h_todo.reserve(2);
+      E3D_HIP(hipMemsetAsync(ps.todo_count.p, 0, 2 * sizeof(unsigned), s));
       h->nn_timer->start(s);
-      launch_nn_certify(srcG, n, tgt.G4.p, cum_up, radius_sq(d), ps.match.p, ps.lbe.p, h->match_d2.p, ps.todo.p, ps.todo_count.p, s);
-      h->nn_timer->stop(s);
-      copy_out(h->h_todo.p, ps.todo_count.p, sizeof(unsigned), s);
+      launch_nn_certify(srcG, n, tgt.G4.p, cum_up, radius_sq(d), near2, ps.match.p, ps.match2.p, ps.lbe.p, h->match_d2.p, ps.todo_near.p, ps.todo_far.p,
+                        ps.todo_count.p, s);
+      copy_out(h->h_todo.p, ps.todo_count.p, 2 * sizeof(unsigned), s);
       sync(h);
-      t_cert = h->nn_timer->ms();
-      n_search = h->h_todo.p[0];
-      list = ps.todo.p;
+      n_near = h->h_todo.p[0]; n_far = h->h_todo.p[1];
+      list = ps.todo_far.p;
+      // old partner close by: only the cells its distance (+ margin) reaches, one thread per query, no sort
+      double smin = min_singular_value_3x3(tgt.T);
+      if (!(smin > 1e-12)) smin = 1e-12;
+      double m_local = 0;
+      for (int k = 0; k < 3; ++k) m_local = std::max(m_local, std::max(std::fabs((double)tgt.lmin[k]), std::fabs((double)tgt.lmax[k])));
+      BoundParams bp;
+      bp.margin = (float)(margin_frac * (double)d);
+      bp.rho_scale = round_up_f((1.0 + 1e-5) / smin);
+      bp.rho_pad = round_up_f(2.0 * tgt.build_slack + 8.0 * FLT_EPSILON * m_local);
+      bp.cum_lo = cert.cum_lo;
+      launch_nn_bounded(srcG, ps.todo_near.p, n_near, tgt.G4.p, tgt.dense_start.p, tgt.grid, im, tgt.qrange, radius_sq(d), bp, ps.match.p,
+                        ps.match2.p, h->match_d2.p, ps.lbe.p, s);
+      if (n_far > 0 && n_far * 32 < n) {
+        // few queries without a near partner: the same kernel (whole radius for those without any) instead of sort + row kernel,
+        // whose cost is per visited cell row, not per query
+        launch_nn_bounded(srcG, ps.todo_far.p, n_far, tgt.G4.p, tgt.dense_start.p, tgt.grid, im, tgt.qrange, radius_sq(d), bp, ps.match.p,
+                          ps.match2.p, h->match_d2.p, ps.lbe.p, s);
+        n_near += n_far; n_far = 0;
+      }
+      h->nn_timer->stop(s);
+      t_cert = -1.f;        // read after the next synchronisation
     }
-    if (n_search > 0) sort_query_keys(h, tgt, srcG, list, n_search, im);
+    float t_first = 0.f;
+    if (t_cert < 0.f) { sync(h); t_first = h->nn_timer->ms(); }
+    if (n_far > 0) sort_query_keys(h, tgt, srcG, list, n_far, im);
     h->nn_timer->start(s);
-    if (n_search > 0)
-      launch_rows(3, tgt, srcG, h->vals_b.p, n_search, im, radius_sq(d), cert, ps.match.p, h->match_d2.p, ps.lbe.p, s);
+    if (n_far > 0)
+      launch_rows(3, tgt, srcG, h->vals_b.p, n_far, im, radius_sq(d), cert, ps.match.p, h->match_d2.p, ps.lbe.p, ps.match2.p, s);
     ps.fresh = false;
-    rec.t_nn_query_ms += t_cert;
+    rec.t_nn_query_ms += t_first;
     if (want_stats)
-      fprintf(stderr, "[nn %d->%d] queries %zu searched %zu certify %.3f ms cum %.3g (last %.3g) err %.3g\n", job.src, job.tgt, n, n_search,
-              (double)t_cert, cum_pair, src.last_motion + tgt.last_motion, src.err_max + tgt.err_max);
+      fprintf(stderr, "[nn %d->%d] queries %zu bounded %zu rows %zu certify+bounded %.3f ms cum %.3g (last %.3g) err %.3g\n", job.src, job.tgt, n,
+              n_near, n_far, (double)t_first, cum_pair, src.last_motion + tgt.last_motion, src.err_max + tgt.err_max);
   } else if (dense) {
     h->match_pos.reserve(n);
     match_pos = h->match_pos.p;
@@ -476,7 +504,7 @@ static void find_pair(e3d_icp* h, Cloud& src, Cloud& tgt, float d, PairJob& job,
     if (tgt.has_dense && h->nn_mode != 2) {
       h->lbe_scratch.reserve(n);
       source_order = launch_rows(h->nn_mode, tgt, srcG, h->vals_b.p, n, im, radius_sq(d), make_cert_params(tgt, 0.0), h->match_pos.p,
-                                 h->match_d2.p, h->lbe_scratch.p, s);
+                                 h->match_d2.p, h->lbe_scratch.p, nullptr, s);
     } else {
       launch_nn_cells(srcG, h->vals_b.p, n, tgt.G4.p, tgt.table.p, nullptr, tgt.grid, im, tgt.qrange, radius_sq(d),
                       h->match_pos.p, h->match_d2.p, s);
@@ -1042,7 +1070,7 @@ int64_t e3d_find_correspondences(const float* sxyz, size_t ns, const float* txyz
         if (tgt.has_dense && mode != 2) {
           h->lbe_scratch.reserve(ns);
           source_order = launch_rows(mode, tgt, src.G4.p, h->vals_b.p, ns, im, radius_sq(d), make_cert_params(tgt, 0.0), h->match_pos.p,
-                                     h->match_d2.p, h->lbe_scratch.p, s);
+                                     h->match_d2.p, h->lbe_scratch.p, nullptr, s);
         } else {
           launch_nn_cells(src.G4.p, h->vals_b.p, ns, tgt.G4.p, tgt.table.p, nullptr, tgt.grid, im, tgt.qrange, radius_sq(d), h->match_pos.p, h->match_d2.p, s);
         }

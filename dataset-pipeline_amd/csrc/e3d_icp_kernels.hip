@@ -600,7 +600,7 @@ __global__ __launch_bounds__(kBlock, 6) void k_nn_rows(const float4* __restrict_
                                                        const unsigned* __restrict__ S, GridDesc g, InvMap im,
                                                        QueryRange qr, float r2, int row_span, CertParams cert,
                                                        int* __restrict__ match_pos, float* __restrict__ match_d2,
-                                                       float* __restrict__ lbe) {
+                                                       float* __restrict__ lbe, int* __restrict__ match2) {
   __shared__ RowLds lds[kBlock / kWave];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   RowLds& L = lds[w];
@@ -756,6 +756,7 @@ __global__ __launch_bounds__(kBlock, 6) void k_nn_rows(const float4* __restrict_
   }
   if (valid) {
     match_pos[j] = best_pos; match_d2[j] = best_d2;
+    if (match2) match2[j] = -1;                 // this kernel remembers the partner only
     // every candidate in the 27 cells was evaluated: the others are >= sqrt(best_b2) away (all of them, if there is no partner:
     // best_d2 stayed r2, so best_b2 is the smallest distance seen); points outside the block are >= block_dist cells away in
     // the local frame (2 cells if the query's cell lies outside the directory range, i.e. occupied cells +- 2)
@@ -1052,53 +1053,165 @@ __global__ __launch_bounds__(kBlock, 3) void k_nn_mfma(const float4* __restrict_
 // to the todo list (in source order inside a block of 2048 queries; one atomic per block) and searched by k_nn_rows, which
 // renews their state.
 // -------------------------------------------------------------------------------------------------
-constexpr int kCertPerWave = 512;          // consecutive queries per wave (8 steps of 64): one atomic per block of 2048 queries
+constexpr int kCertPerWave = 512;          // consecutive queries per wave (8 steps of 64): one atomic per list and block of 2048 queries
+// The state may hold a second candidate match2[j] (the runner-up of the last search, lbe then bounds everything but these two).
+// Lists: todo_near = queries whose old partner is within sqrt(near2) (searched by k_nn_bounded: only the cells the ball of that
+// distance touches), todo_far = all others (no partner, or a far one: sorted by target cell and searched by k_nn_rows).
+// counts[0] / counts[1] = list lengths.
 __global__ __launch_bounds__(kBlock) void k_nn_certify(const float4* __restrict__ Gsrc, size_t n, const float4* __restrict__ Gtgt,
-                                                       float cum_up, float r2, const int* __restrict__ match,
-                                                       const float* __restrict__ lbe, float* __restrict__ match_d2,
-                                                       unsigned* __restrict__ todo, unsigned* __restrict__ todo_count) {
-  __shared__ unsigned s_list[kBlock / kWave][kCertPerWave];
-  __shared__ unsigned s_cnt[kBlock / kWave];
-  __shared__ unsigned s_base;
+                                                       float cum_up, float r2, float near2, int* __restrict__ match,
+                                                       int* __restrict__ match2, const float* __restrict__ lbe,
+                                                       float* __restrict__ match_d2, unsigned* __restrict__ todo_near,
+                                                       unsigned* __restrict__ todo_far, unsigned* __restrict__ counts) {
+  __shared__ unsigned s_list[2][kBlock / kWave][kCertPerWave];
+  __shared__ unsigned s_cnt[2][kBlock / kWave];
+  __shared__ unsigned s_base[2];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const size_t j0 = ((size_t)blockIdx.x * (kBlock / kWave) + (size_t)w) * kCertPerWave;
-  unsigned cnt = 0;                                            // wave-uniform
+  unsigned cn = 0, cf = 0;                                     // wave-uniform
   for (int step = 0; step < kCertPerWave / kWave; ++step) {
     const size_t j = j0 + (size_t)step * kWave + (size_t)lane;
     const bool valid = j < n;
-    bool ok = false;
+    bool ok = false, near = false;
     if (valid) {
       const float thr = (lbe[j] - cum_up) * 0.999999f;
-      if (thr > 0.f) {
-        const float lim = thr * thr * 0.999999f;
-        const int m = match[j];
-        if (m >= 0) {
-          const float4 q = Gsrc[j];
-          const float4 c = Gtgt[m];
-          const float v = sqdist_l2(q.x, q.y, q.z, c.x, c.y, c.z);
-          ok = (v < lim) && (v < r2);
-          if (ok) match_d2[j] = v;
-        } else {
-          ok = lim >= r2;
-          if (ok) match_d2[j] = r2;
+      const float lim = thr * thr * 0.999999f;
+      const int m = match[j];
+      if (m >= 0) {
+        const int m2 = match2[j];
+        const float4 q = Gsrc[j];
+        const float4 c = Gtgt[m];
+        float v = sqdist_l2(q.x, q.y, q.z, c.x, c.y, c.z);
+        if (m2 >= 0) {
+          // two remembered candidates: the nearer one (exact (d2, original index) order) is the partner if both beat the bound
+          // of everything else; the other one stays remembered
+          const float4 c2 = Gtgt[m2];
+          const float v2 = sqdist_l2(q.x, q.y, q.z, c2.x, c2.y, c2.z);
+          if (v2 < v || (v2 == v && __float_as_uint(c2.w) < __float_as_uint(c.w))) {
+            v = v2;
+            if (thr > 0.f && v < lim && v < r2) { match[j] = m2; match2[j] = m; }
+          }
+        }
+        ok = (thr > 0.f) && (v < lim) && (v < r2);
+        near = v < near2;
+        if (ok) match_d2[j] = v;
+      } else {
+        ok = (thr > 0.f) && (lim >= r2);
+        if (ok) match_d2[j] = r2;
+      }
+    }
+  const unsigned long long fn = __ballot(valid && !ok && near), ff = __ballot(valid && !ok && !near);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (valid && !ok) {
+      if (near) s_list[0][w][cn + (unsigned)__popcll(fn & below)] = (unsigned)j;
+      else s_list[1][w][cf + (unsigned)__popcll(ff & below)] = (unsigned)j;
+    }
+    cn += (unsigned)__popcll(fn); cf += (unsigned)__popcll(ff);
+  }
+  if (lane == 0) { s_cnt[0][w] = cn; s_cnt[1][w] = cf; }
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    unsigned tot = 0;
+    for (int k = 0; k < kBlock / kWave; ++k) tot += s_cnt[threadIdx.x][k];
+    s_base[threadIdx.x] = tot ? atomicAdd(&counts[threadIdx.x], tot) : 0u;
+  }
+  __syncthreads();
+  unsigned bn = s_base[0], bf = s_base[1];
+  for (int k = 0; k < w; ++k) { bn += s_cnt[0][k]; bf += s_cnt[1][k]; }
+  for (unsigned i = (unsigned)lane; i < cn; i += kWave) todo_near[bn + i] = s_list[0][w][i];
+  for (unsigned i = (unsigned)lane; i < cf; i += kWave) todo_far[bf + i] = s_list[1][w][i];
+}
+
+// -------------------------------------------------------------------------------------------------
+// Bounded search of the listed queries (one thread per query, no sort): the old partner at f32 squared distance d1 is still a
+// candidate, so the nearest neighbour lies within d1; all target points whose squared distance is <= cover2 = (sqrt(d1) +
+// margin)^2 (at most r2) lie in the cells the box [l - rho, l + rho] touches (l = query in the target's local frame, rho =
+// sqrt(cover2) / sigma_min (1 + 1e-5) + slack; same completeness argument as for the 27 cells of the radius).  Those cells are
+// scanned row by row -- the cells [xa, xb] of one (y, z) row are ONE run of the dense cell-start directory -- with the exact
+// (d2, original index) order.  Afterwards every point other than the winner is farther than min(second smallest d2 seen,
+// cover2): the next certificate.
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_nn_bounded(const float4* __restrict__ Gsrc, const unsigned* __restrict__ list,
+                                                       unsigned n_list, const float4* __restrict__ Gtgt, const unsigned* __restrict__ S,
+                                                       GridDesc g, InvMap im, QueryRange qr, float r2, BoundParams bp,
+                                                       int* __restrict__ match, int* __restrict__ match2,
+                                                       float* __restrict__ match_d2, float* __restrict__ lbe) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_list) return;
+  const unsigned j = list[i];
+  const float4 q = Gsrc[j];
+  const int m = match[j];
+  float d1 = r2;                                     // no old partner: the whole radius (the 27 cells)
+  if (m >= 0) {
+    const float4 pc = Gtgt[m];
+    d1 = sqdist_l2(q.x, q.y, q.z, pc.x, pc.y, pc.z);
+    const int m2 = match2[j];
+    if (m2 >= 0) { const float4 pc2 = Gtgt[m2]; d1 = fminf(d1, sqdist_l2(q.x, q.y, q.z, pc2.x, pc2.y, pc2.z)); }
+  }
+  const float dr = sqrtf(fminf(d1, r2)) + bp.margin;
+  const float cover2 = (d1 < r2) ? fminf(dr * dr * 1.000001f, r2) : r2;      // NaN distances search the whole radius too
+  const float rho = sqrtf(cover2) * bp.rho_scale + bp.rho_pad;
+  const float dx = q.x - im.t[0], dy = q.y - im.t[1], dz = q.z - im.t[2];
+  const float lx = im.Linv[0] * dx + im.Linv[1] * dy + im.Linv[2] * dz;
+  const float ly = im.Linv[3] * dx + im.Linv[4] * dy + im.Linv[5] * dz;
+  const float lz = im.Linv[6] * dx + im.Linv[7] * dy + im.Linv[8] * dz;
+  const int x0 = max(cell_coord(lx - rho, g.origin[0], g.inv_cell) - qr.lo[0], 0), x1 = min(cell_coord(lx + rho, g.origin[0], g.inv_cell) - qr.lo[0], (int)qr.D[0] - 1);
+  const int y0 = max(cell_coord(ly - rho, g.origin[1], g.inv_cell) - qr.lo[1], 0), y1 = min(cell_coord(ly + rho, g.origin[1], g.inv_cell) - qr.lo[1], (int)qr.D[1] - 1);
+  const int z0 = max(cell_coord(lz - rho, g.origin[2], g.inv_cell) - qr.lo[2], 0), z1 = min(cell_coord(lz + rho, g.origin[2], g.inv_cell) - qr.lo[2], (int)qr.D[2] - 1);
+  // fast pass: the two smallest distances with a strict '<', the third smallest value for the certificate; any exact f32
+  // equality with one of the two (i.e. also with r2) raises `tie`
+  const float kInf = __uint_as_float(0x7f800000u);
+  float bd = r2, bd2 = r2, b3 = kInf;
+  int bpos = -1, bpos2 = -1;
+  bool tie = false;
+  if (x0 <= x1) {
+    for (int cz = z0; cz <= z1; ++cz) {
+      for (int cy = y0; cy <= y1; ++cy) {
+        const size_t row = ((size_t)cz * qr.D[1] + (size_t)cy) * qr.D[0];
+        const unsigned s0 = S[row + (size_t)x0], s1 = S[row + (size_t)x1 + 1];
+        for (unsigned p = s0; p < s1; ++p) {
+          const float4 c = Gtgt[p];
+          const float d2 = sqdist_l2(q.x, q.y, q.z, c.x, c.y, c.z);
+          const bool lt1 = d2 < bd, lt2 = d2 < bd2;
+          tie = tie || (d2 == bd) || (d2 == bd2);
+          b3 = fminf(b3, fmaxf(d2, bd2));                 // the displaced runner-up, or this candidate
+          bd2 = fminf(fmaxf(d2, bd), bd2);
+          bpos2 = lt1 ? bpos : (lt2 ? (int)p : bpos2);
+          bd = fminf(d2, bd);
+          bpos = lt1 ? (int)p : bpos;
         }
       }
     }
-    const unsigned long long fail = __ballot(valid && !ok);
-    if (valid && !ok) s_list[w][cnt + (unsigned)__popcll(fail & ((1ull << lane) - 1ull))] = (unsigned)j;
-    cnt += (unsigned)__popcll(fail);
   }
-  if (lane == 0) s_cnt[w] = cnt;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    unsigned tot = 0;
-    for (int k = 0; k < kBlock / kWave; ++k) tot += s_cnt[k];
-    s_base = tot ? atomicAdd(todo_count, tot) : 0u;
+  if (tie) {
+    // rare (lattices, duplicates): the same cells again with the full (d2, original index) order
+    bd = r2; bd2 = r2; b3 = kInf; bpos = -1; bpos2 = -1;
+    unsigned boi = 0u, boi2 = 0u;
+    for (int cz = z0; cz <= z1; ++cz) {
+      for (int cy = y0; cy <= y1; ++cy) {
+        const size_t row = ((size_t)cz * qr.D[1] + (size_t)cy) * qr.D[0];
+        const unsigned s0 = S[row + (size_t)x0], s1 = S[row + (size_t)x1 + 1];
+        for (unsigned p = s0; p < s1; ++p) {
+          const float4 c = Gtgt[p];
+          const float d2 = sqdist_l2(q.x, q.y, q.z, c.x, c.y, c.z);
+          const unsigned oi = __float_as_uint(c.w);
+          if (d2 < bd || (d2 == bd && oi < boi)) {
+            b3 = fminf(b3, bd2); bd2 = bd; boi2 = boi; bpos2 = bpos; bd = d2; boi = oi; bpos = (int)p;
+          } else if (d2 < bd2 || (d2 == bd2 && oi < boi2)) {
+            b3 = fminf(b3, bd2); bd2 = d2; boi2 = oi; bpos2 = (int)p;
+          } else {
+            b3 = fminf(b3, d2);
+          }
+        }
+      }
+    }
   }
-  __syncthreads();
-  unsigned base = s_base;
-  for (int k = 0; k < w; ++k) base += s_cnt[k];
-  for (unsigned i = (unsigned)lane; i < cnt; i += kWave) todo[base + i] = s_list[w][i];
+  match[j] = bpos;
+  match2[j] = (bd2 < r2) ? bpos2 : -1;
+  match_d2[j] = bd;
+  // everything but the (up to) two remembered candidates is farther than min(third smallest d2 seen, cover2); without a
+  // runner-up inside the radius the bound of "everything but the partner" is min(second smallest, cover2)
+  lbe[j] = sqrtf(fminf((bd2 < r2) ? b3 : fminf(bd2, b3), cover2)) * 0.999999f + bp.cum_lo;
 }
 
 // flags -> per-block counts (first stage of the order-preserving compaction)
@@ -1588,10 +1701,10 @@ static int row_span_setting() {
 
 void launch_nn_rows(const float4* Gsrc, const unsigned* order, size_t n, const float4* Gtgt, const unsigned* dense_start,
                     const GridDesc& g, const InvMap& im, const QueryRange& qr, float r2, const CertParams& cert, int* match_pos,
-                    float* match_d2, float* lbe, hipStream_t s) {
+                    float* match_d2, float* lbe, int* match2, hipStream_t s) {
   if (!n) return;
   hipLaunchKernelGGL(k_nn_rows, dim3((unsigned)div_up(n, kBlock)), dim3(kBlock), 0, s, Gsrc, order, n, Gtgt, dense_start,
-                     g, im, qr, r2, row_span_setting(), cert, match_pos, match_d2, lbe);
+                     g, im, qr, r2, row_span_setting(), cert, match_pos, match_d2, lbe, match2);
 }
 
 void launch_query_keys_list(const float4* Gsrc, const unsigned* list, size_t n, const GridDesc& g, const InvMap& im,
@@ -1605,11 +1718,19 @@ void launch_query_keys32_list(const float4* Gsrc, const unsigned* list, size_t n
   hipLaunchKernelGGL(k_query_keys32_list, dim3((unsigned)div_up(n, kBlock)), dim3(kBlock), 0, s, Gsrc, list, n, g, im, qr, keys, vals);
 }
 
-void launch_nn_certify(const float4* Gsrc, size_t n, const float4* Gtgt, float cum_up, float r2, const int* match, const float* lbe,
-                       float* match_d2, unsigned* todo, unsigned* todo_count, hipStream_t s) {
+void launch_nn_certify(const float4* Gsrc, size_t n, const float4* Gtgt, float cum_up, float r2, float near2, int* match, int* match2,
+                       const float* lbe, float* match_d2, unsigned* todo_near, unsigned* todo_far, unsigned* counts, hipStream_t s) {
   if (!n) return;
   hipLaunchKernelGGL(k_nn_certify, dim3((unsigned)div_up(n, (size_t)kCertPerWave * (kBlock / kWave))), dim3(kBlock), 0, s, Gsrc, n, Gtgt,
-                     cum_up, r2, match, lbe, match_d2, todo, todo_count);
+                     cum_up, r2, near2, match, match2, lbe, match_d2, todo_near, todo_far, counts);
+}
+
+void launch_nn_bounded(const float4* Gsrc, const unsigned* list, size_t n_list, const float4* Gtgt, const unsigned* dense_start,
+                       const GridDesc& g, const InvMap& im, const QueryRange& qr, float r2, const BoundParams& bp, int* match,
+                       int* match2, float* match_d2, float* lbe, hipStream_t s) {
+  if (!n_list) return;
+  hipLaunchKernelGGL(k_nn_bounded, dim3((unsigned)div_up(n_list, kBlock)), dim3(kBlock), 0, s, Gsrc, list, (unsigned)n_list, Gtgt,
+                     dense_start, g, im, qr, r2, bp, match, match2, match_d2, lbe);
 }
 
 // Filter constants of k_nn_mfma for a target grid (cell = local cell size, sigma_max = largest singular value of the

@@ -69,15 +69,25 @@ struct CertParams {
 // k_nn_rows writes its results at the queries' SOURCE positions order[pos] (match_pos, match_d2, lbe in source order)
 void launch_nn_rows(const float4* Gsrc, const unsigned* order, size_t n, const float4* Gtgt, const unsigned* dense_start,
                     const GridDesc& g, const InvMap& im, const QueryRange& qr, float r2, const CertParams& cert, int* match_pos,
-                    float* match_d2, float* lbe, hipStream_t s);
+                    float* match_d2, float* lbe, int* match2, hipStream_t s);
 void launch_query_keys_list(const float4* Gsrc, const unsigned* list, size_t n, const GridDesc& g, const InvMap& im,
                             const QueryRange& qr, unsigned long long* keys, unsigned* vals, hipStream_t s);
 void launch_query_keys32_list(const float4* Gsrc, const unsigned* list, size_t n, const GridDesc& g, const InvMap& im,
                               const QueryRange& qr, unsigned* keys, unsigned* vals, hipStream_t s);
 // settles every query whose old partner is provably still the unique nearest neighbour within the radius (lbe - cum_up > new
-// distance), lists the others in todo (see k_nn_certify)
-void launch_nn_certify(const float4* Gsrc, size_t n, const float4* Gtgt, float cum_up, float r2, const int* match, const float* lbe,
-                       float* match_d2, unsigned* todo, unsigned* todo_count, hipStream_t s);
+// distance); lists the others: todo_near (old partner within sqrt(near2)) / todo_far, lengths in counts[0..1] (see k_nn_certify)
+void launch_nn_certify(const float4* Gsrc, size_t n, const float4* Gtgt, float cum_up, float r2, float near2, int* match, int* match2,
+                       const float* lbe, float* match_d2, unsigned* todo_near, unsigned* todo_far, unsigned* counts, hipStream_t s);
+// bounded search (k_nn_bounded) of the listed queries around their old partners
+struct BoundParams {
+  float margin;          // the search covers radius (distance of the old partner) + margin: room for the next certificates
+  float rho_scale;       // (1 + 1e-5) / sigma_min(target pose), rounded up
+  float rho_pad;         // absolute slack of the global -> local mapping (local units), rounded up
+  float cum_lo;          // accumulated motion bound of the pair at this outer iteration, rounded down
+};
+void launch_nn_bounded(const float4* Gsrc, const unsigned* list, size_t n_list, const float4* Gtgt, const unsigned* dense_start,
+                       const GridDesc& g, const InvMap& im, const QueryRange& qr, float r2, const BoundParams& bp, int* match,
+                       int* match2, float* match_d2, float* lbe, hipStream_t s);
 struct MfParams { float S, r2s, eta2, delta4, delta4sq; };      // filter constants of k_nn_mfma (see mfma_filter_params)
 bool mfma_filter_params(double cell, double sigma_max, int row_span, float r2, MfParams* P);
 void launch_nn_mfma(const float4* Gsrc, const unsigned* order, size_t n, const float4* Gtgt, const unsigned* dense_start,

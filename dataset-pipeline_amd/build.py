@@ -30,7 +30,8 @@ def build(force=False, verbose=False):
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".h"))]
-    hdrs.append(os.path.join(HERE, "..", "include", "e3d_hip.h"))
+    inc = os.path.join(HERE, "..", "include")
+    hdrs += [os.path.join(inc, f) for f in os.listdir(inc) if f.endswith(".h")]
     objs = []
     procs = []
     for s in SOURCES:

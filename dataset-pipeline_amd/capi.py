@@ -61,6 +61,7 @@ SIGNATURES = {
     "e3d_transform_cloud": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_void_p]),
     "e3d_icp_pair_system": (C.c_int, [C.c_void_p] * 6 + [C.c_int64] + [C.c_void_p] * 7),
+    "e3d_libm_eval": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "e3d_normals_knn": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "e3d_normals_radius": (C.c_int, [C.c_void_p, C.c_size_t, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "e3d_local_outlier_removal": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_double, C.c_int, C.c_void_p, C.c_void_p]),
@@ -308,6 +309,18 @@ def icp_pair_system(sxyz, snrm, txyz, tnrm, iq, im, sq, st, tq, tt):
     if r < 0:
         _err("e3d_icp_pair_system", r)
     return H, b, float(cost[0])
+
+
+def libm_eval(fn, x, y=None):
+    """include/e3d_libm.h evaluated by a HIP kernel; fn in {"atanf", "atan2f", "sinf", "cosf", "tanf", "log2f"}."""
+    code = {"atanf": 0, "atan2f": 1, "sinf": 2, "cosf": 3, "tanf": 4, "log2f": 5}[fn]
+    x = np.ascontiguousarray(x, np.float32)
+    y = np.ascontiguousarray(y if y is not None else np.zeros_like(x), np.float32)
+    out = np.zeros_like(x)
+    r = lib().e3d_libm_eval(code, C.c_void_p(x.ctypes.data), C.c_void_p(y.ctypes.data), x.size, C.c_void_p(out.ctypes.data))
+    if r < 0:
+        _err("e3d_libm_eval", r)
+    return out
 
 
 def normals_knn(xyz, k, viewpoint=(0.0, 0.0, 0.0), return_knn=False):

@@ -19,6 +19,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include "../../include/e3d_libm.h"   // bit-defined atanf / atan2f / tanf: the same bits on host and device
+
 namespace e3d {
 
 enum : int { kPinhole = 0, kOpenCV = 1, kThinPrismFisheye = 2, kOpenCVFisheye = 3, kFov = 4 };
@@ -47,7 +49,7 @@ __device__ __forceinline__ void cam_distort_plain(const CamLevel& c, float nx, f
     ox = nx; oy = ny;
   } else if constexpr (M == kFov) {                // camera_fisheye_fov.h:55-63
     const float r = sqrtf(nx * nx + ny * ny);
-    const float factor = (r < 1e-6f) ? 1.f : (atanf(r * c.q[1]) / (r * c.q[0]));
+    const float factor = (r < 1e-6f) ? 1.f : (e3d_atanf(r * c.q[1]) / (r * c.q[0]));
     ox = nx * factor; oy = ny * factor;
   } else if constexpr (M == kOpenCVFisheye) {      // RadialBase::Distort: point * DistortionFactor(squaredNorm)
     const float r2 = nx * nx + ny * ny;
@@ -83,7 +85,7 @@ __device__ __forceinline__ void cam_ddn_plain(const CamLevel& c, float nx, float
     const float radius_square = nxs + nys;
     const float radius = sqrtf(radius_square);
     if (radius < 1e-6f) { J[0] = 1.f; J[1] = 0.f; J[2] = 0.f; J[3] = 1.f; return; }
-    const float rdw = atanf(radius * tt);
+    const float rdw = e3d_atanf(radius * tt);
     const float tts = tt * tt;
     const float part1 = omega * radius_square * radius;
     const float part2 = omega * (tts * radius_square + 1) * radius_square;
@@ -137,7 +139,7 @@ __device__ __forceinline__ void cam_ddp_plain(const CamLevel& c, float nx, float
     const float four_tan_omega_half_square = tt * tt;
     const float tan_omega_half_square_plus_one = 0.25f * four_tan_omega_half_square + 1.f;
     const float denominator_1 = omega * (four_tan_omega_half_square * radius_square + 1.f);
-    const float numerator_2 = atanf(tt * radius);
+    const float numerator_2 = e3d_atanf(tt * radius);
     const float denominator_2 = omega * omega * radius;
     d0[0] = (radius < 1e-6f) ? 0.f : ((nx * tan_omega_half_square_plus_one) / denominator_1 - (nx * numerator_2) / denominator_2);
     d1[0] = (radius < 1e-6f) ? 0.f : ((ny * tan_omega_half_square_plus_one) / denominator_1 - (ny * numerator_2) / denominator_2);
@@ -168,7 +170,7 @@ __device__ __forceinline__ void cam_distort(const CamLevel& c, float nx, float n
   } else {
     const float r = sqrtf(nx * nx + ny * ny);
     if (r > kFisheyeEpsilon) {
-      const float atan_r = atan2f(r, 1.f);
+      const float atan_r = e3d_atan2f(r, 1.f);
       if (atan_r * atan_r > c.inner_cutoff2) { ox = nx * E3D_CAM_INF; oy = ny * E3D_CAM_INF; return; }
       const float theta_by_r = atan_r / r;
       cam_distort_plain<M>(c, nx * theta_by_r, ny * theta_by_r, ox, oy);
@@ -187,7 +189,7 @@ __device__ __forceinline__ void cam_ddn(const CamLevel& c, float nx, float ny, f
     const float r2 = nx2 + ny2;
     const float r = sqrtf(r2);
     if (r > kFisheyeEpsilon) {
-      const float atan_r = atan2f(r, 1.f);
+      const float atan_r = e3d_atan2f(r, 1.f);
       if (atan_r * atan_r > c.inner_cutoff2) { J[0] = J[1] = J[2] = J[3] = 0.f; return; }
       const float theta_by_r = atan_r / r;
       const float term1 = r2 * (r2 + 1);
@@ -213,7 +215,7 @@ __device__ __forceinline__ void cam_ddp(const CamLevel& c, float nx, float ny, f
   } else {
     const float r = sqrtf(nx * nx + ny * ny);
     if (r > kFisheyeEpsilon) {
-      const float atan_r = atan2f(r, 1.f);
+      const float atan_r = e3d_atan2f(r, 1.f);
       if (atan_r * atan_r > c.inner_cutoff2) {
 #pragma unroll
         for (int i = 0; i < cam_param_count(M) - 4; ++i) { d0[i] = 0.f; d1[i] = 0.f; }
@@ -281,7 +283,7 @@ __device__ __forceinline__ void cam_image_deriv_by_intrinsics(const CamLevel& c,
 // FisheyeFOVCamera::Undistort (camera_fisheye_fov.h:76-86): closed form, infinity past image_radius_
 __device__ __forceinline__ void cam_fov_undistort(const CamLevel& c, float dx, float dy, float& ux, float& uy) {
   const float r = sqrtf(dx * dx + dy * dy);
-  const float factor = (r < 1e-6f) ? 1.f : ((r > c.q[2]) ? E3D_CAM_INF : (tanf(r * c.q[0]) / (r * c.q[1])));
+  const float factor = (r < 1e-6f) ? 1.f : ((r > c.q[2]) ? E3D_CAM_INF : (e3d_tanf(r * c.q[0]) / (r * c.q[1])));
   ux = factor * dx; uy = factor * dy;
 }
 

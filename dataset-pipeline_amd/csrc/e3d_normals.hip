@@ -16,6 +16,7 @@
 #include <memory>
 
 #include "../../include/e3d_hip.h"
+#include "../../include/e3d_libm.h"   // bit-defined atan2f / cosf / sinf: the same bits on host and device
 #include "e3d_icp_kernels.hpp"
 
 #pragma clang fp contract(off)
@@ -65,9 +66,9 @@ __device__ __forceinline__ void compute_roots(const float* m, float* roots) {
   float q = half_b * half_b + a_over_3 * a_over_3 * a_over_3;
   if (q > 0.f) q = 0.f;
   const float rho = sqrtf(-a_over_3);
-  const float theta = atan2f(sqrtf(-q), half_b) * s_inv3;
-  const float cos_theta = cosf(theta);
-  const float sin_theta = sinf(theta);
+  const float theta = e3d_atan2f(sqrtf(-q), half_b) * s_inv3;
+  const float cos_theta = e3d_cosf(theta);
+  const float sin_theta = e3d_sinf(theta);
   roots[0] = c2_over_3 + 2.f * rho * cos_theta;
   roots[1] = c2_over_3 - rho * (cos_theta + s_sqrt3 * sin_theta);
   roots[2] = c2_over_3 - rho * (cos_theta - s_sqrt3 * sin_theta);
@@ -583,6 +584,41 @@ __global__ __launch_bounds__(256) void k_outlier_classify(const int* __restrict_
   inlier[i] = removed ? 0 : 1;
 }
 }  // namespace e3d
+
+namespace e3d {
+__global__ __launch_bounds__(kBlock) void k_libm_eval(int fn, const float* __restrict__ x, const float* __restrict__ y, size_t n,
+                                                      float* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float r;
+  switch (fn) {
+    case 0: r = e3d_atanf(x[i]); break;
+    case 1: r = e3d_atan2f(x[i], y[i]); break;
+    case 2: r = e3d_sinf(x[i]); break;
+    case 3: r = e3d_cosf(x[i]); break;
+    case 4: r = e3d_tanf(x[i]); break;
+    default: r = e3d_log2f(x[i]); break;
+  }
+  out[i] = r;
+}
+}  // namespace e3d
+
+extern "C" int e3d_libm_eval(int fn, const float* x, const float* y, size_t n, float* out) {
+  try {
+    if ((!x || !y || !out) && n) throw Error(E3D_ERR_INVALID, "e3d_libm_eval: null argument");
+    if (fn < 0 || fn > 5) throw Error(E3D_ERR_INVALID, "e3d_libm_eval: fn must be 0..5");
+    if (!n) return 0;
+    DevBuf<float> dx, dy, dout;
+    dx.reserve(n); dy.reserve(n); dout.reserve(n);
+    hipStream_t s = nullptr;
+    copy_in(dx.p, x, sizeof(float) * n, s); copy_in(dy.p, y, sizeof(float) * n, s);
+    hipLaunchKernelGGL(k_libm_eval, dim3((unsigned)div_up(n, kBlock)), dim3(kBlock), 0, s, fn, dx.p, dy.p, n, dout.p);
+    copy_out(out, dout.p, sizeof(float) * n, s);
+    E3D_HIP(hipStreamSynchronize(s));
+    return 0;
+  } catch (const e3d::Error& e) { e3d::set_last_error(e.what()); return e.code; }
+  catch (const std::exception& e) { e3d::set_last_error(e.what()); return E3D_ERR_INVALID; }
+}
 
 extern "C" int e3d_normals_knn(const float* xyz, size_t n, int k, const float* viewpoint, float* out_normals,
                                float* out_curvature, int32_t* knn_indices) {

@@ -292,13 +292,13 @@ __global__ __launch_bounds__(kBlock) void k_mesh_vertices(const float4* __restri
       // FisheyeFOV shader (renderer.cc:153-160): r = length(xy) / z; r = atan(r * two_tan_omega_half) / (r * omega); xy *= r.  GLSL
       // leaves 0 / 0 on the optical axis undefined; the camera class's guard (camera_fisheye_fov.h:58-61) is used there
       const float r = sqrtf(X * X + Y * Y) / Z;
-      const float f = (r < 1e-6f) ? 1.0f : atanf(r * cam.q[1]) / (r * cam.q[0]);
+      const float f = (r < 1e-6f) ? 1.0f : e3d_atanf(r * cam.q[1]) / (r * cam.q[0]);
       lx = f * X; ly = f * Y;
     } else if constexpr (M == kOpenCVFisheye) {
       // FisheyePolynomial4 shader (renderer.cc:187-205): r2 turns into the radial factor (99 outside the cut-off)
       if (r2 <= cam.cutoff2) {
         const float r = sqrtf(r2);
-        if (r > 1e-6f) { const float theta_by_r = atan2f(r, 1.0f) / r; nx = theta_by_r * nx; ny = theta_by_r * ny; r2 = theta_by_r * theta_by_r * r2; }
+        if (r > 1e-6f) { const float theta_by_r = e3d_atan2f(r, 1.0f) / r; nx = theta_by_r * nx; ny = theta_by_r * ny; r2 = theta_by_r * theta_by_r * r2; }
         r2 = 1.0f + r2 * (cam.q[0] + r2 * (cam.q[1] + r2 * (cam.q[2] + r2 * cam.q[3])));
       } else {
         r2 = 99.0f;
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(kBlock) void k_mesh_vertices(const float4* __restri
     } else if (r2 <= cam.cutoff2) {
       if constexpr (M == kThinPrismFisheye) {
         const float r = sqrtf(r2);
-        if (r > 1e-6f) { const float theta_by_r = atan2f(r, 1.0f) / r; nx = theta_by_r * nx; ny = theta_by_r * ny; }
+        if (r > 1e-6f) { const float theta_by_r = e3d_atan2f(r, 1.0f) / r; nx = theta_by_r * nx; ny = theta_by_r * ny; }
       }
       const float x2 = nx * nx, xy = nx * ny, y2 = ny * ny;
       r2 = x2 + y2;
@@ -635,7 +635,7 @@ __global__ __launch_bounds__(kBlock) void k_undistort_lookup(CamLevel c, float2*
     cam_iterative_undistort<M>(c, dx, dy, dx, dy, ux, uy);
     if constexpr (cam_is_fisheye(M)) {           // FisheyeBase::Undistort (camera_base_impl_fisheye.h:81-92)
       const float r = sqrtf(ux * ux + uy * uy);
-      const float factor = (r < kFisheyeEpsilon) ? 1.f : ((r > (float)(M_PI / 2.f)) ? E3D_CAM_INF : tanf(r) / r);
+      const float factor = (r < kFisheyeEpsilon) ? 1.f : ((r > (float)(M_PI / 2.f)) ? E3D_CAM_INF : e3d_tanf(r) / r);
       ux = factor * ux; uy = factor * uy;
     }
   }
@@ -748,7 +748,7 @@ __global__ __launch_bounds__(kBlock) void k_obs_eval(const float4* __restrict__ 
   cam_normalized_to_image<M>(cam, prx / prz, pry / prz, rxf, ryf);
   const float dx = rxf - ixf, dy = ryf - iyf;
   const float radius_pixels = sqrtf(dx * dx + dy * dy);
-  const float observation_scale = q.image_scale + log2f(2 * radius_pixels);
+  const float observation_scale = q.image_scale + e3d_log2f(2 * radius_pixels);
   const int lo = max(Y.min_image_scale, q.current_image_scale);
   if (!(observation_scale >= lo && f2i(observation_scale) < q.image_scale_count - 1)) return;
   const int small_scale = f2i(observation_scale) + 1;
@@ -1585,7 +1585,7 @@ static CamLevel make_level(e3d_reg* h, int model, int w, int h_px, const float* 
   if (model == kPinhole) return c;                  // PinholeCamera never calls InitCutoff (camera_pinhole.cc:35-43)
   if (model == kOpenCVFisheye) { c.inner_cutoff2 = radial_init_cutoff(c); return c; }
   if (model == kFov) {                              // camera_fisheye_fov.cc:37-51: derived constants, no InitCutoff
-    c.q[1] = 2.0f * tanf(0.5f * c.q[0]);
+    c.q[1] = 2.0f * e3d_tanf(0.5f * c.q[0]);
     c.q[2] = (float)(M_PI / (double)(2 * c.q[0]));
     return c;
   }

@@ -154,6 +154,12 @@ int e3d_icp_pair_system(const float* src_xyz, const float* src_normals,
 int e3d_normals_knn(const float* xyz, size_t n, int k, const float viewpoint[3],
                     float* out_normals, float* out_curvature, int32_t* knn_indices);
 
+/* Test hook: the bit-defined elementary functions of include/e3d_libm.h evaluated by a HIP kernel (n values, host or device
+ * pointers).  fn: 0 atanf(x), 1 atan2f(x, y), 2 sinf(x), 3 cosf(x), 4 tanf(x), 5 log2f(x).  The reference calls the C library
+ * at these places (pcl::eigen33 for src/geometry/two_pass_normal_3d.h:92-109, src/camera/camera_base_impl_fisheye.h:66-153,
+ * src/opt/visibility_estimator.cc:437); kernels, host code and oracle all use this one implementation instead. */
+int e3d_libm_eval(int fn, const float* x, const float* y, size_t n, float* out);
+
 /* The same estimator with setRadiusSearch(radius) instead of setKSearch: every point strictly within the radius
  * (squared distance < (float)((double)radius * radius)) takes part; fewer than 3 -> NaN.  neighbor_counts (optional, n)
  * receives the number of points found, the query itself included. */

@@ -210,6 +210,20 @@ def normals(xyz, k=0, radius=-1.0, viewpoint=(0, 0, 0), return_knn=False):
     return (on, oc, knn) if return_knn else (on, oc)
 
 
+def libm_eval(fn, x, y=None):
+    """include/e3d_libm.h evaluated on the host; fn in {"atanf", "atan2f", "sinf", "cosf", "tanf", "log2f"} (atan2f(x, y): x is the
+    first argument, y the second)."""
+    code = {"atanf": 0, "atan2f": 1, "sinf": 2, "cosf": 3, "tanf": 4, "log2f": 5}[fn]
+    x = np.ascontiguousarray(x, np.float32)
+    y = np.ascontiguousarray(y if y is not None else np.zeros_like(x), np.float32)
+    out = np.zeros_like(x)
+    f = lib().oracle_libm_eval
+    f.restype = None
+    f.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    f(code, x.ctypes.data, y.ctypes.data, x.size, out.ctypes.data)
+    return out
+
+
 def point_normal(xyz, indices):
     xyz = _c32(xyz); indices = np.ascontiguousarray(indices, np.int32)
     plane = np.zeros(4, np.float32); curv = C.c_float(0)

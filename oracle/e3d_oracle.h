@@ -110,6 +110,9 @@ int oracle_normals(const float* xyz, size_t n, int k, float radius,
                    int32_t* knn_idx_out);
 /* two-pass mean+covariance (two_pass_centroid.hpp:155-259) + solvePlaneParameters
  * for one explicit neighbour list. */
+/* test hook: include/e3d_libm.h on the host; fn: 0 atanf(x) 1 atan2f(x, y) 2 sinf 3 cosf 4 tanf 5 log2f */
+void oracle_libm_eval(int fn, const float* x, const float* y, size_t n, float* out);
+
 void oracle_point_normal(const float* xyz, const int32_t* indices, int count,
                          float plane[4], float* curvature);
 /* kNN alone: idx/dist n_q x k, sorted by (dist, index). */

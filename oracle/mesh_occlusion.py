@@ -17,6 +17,20 @@ import numpy as np
 
 from . import reg_binding as rb
 
+
+def _atanf(x):
+    """atanf of include/e3d_libm.h (the implementation kernels and oracle share), elementwise on an f32 array."""
+    from . import binding
+    return binding.libm_eval("atanf", np.ascontiguousarray(x, np.float32)).reshape(np.shape(x))
+
+
+def _atan2f_1(r):
+    """atan2f(r, 1.f) of include/e3d_libm.h."""
+    from . import binding
+    r = np.ascontiguousarray(r, np.float32)
+    return binding.libm_eval("atan2f", r, np.ones_like(r)).reshape(r.shape)
+
+
 F = np.float32
 
 
@@ -35,14 +49,14 @@ def project_vertices(model, cam, R, t, verts, shaded=False):
             if model == 4:
                 # FisheyeFOV shader (renderer.cc:153-160); the camera class's guard on the optical axis, where GLSL's 0 / 0 is undefined
                 r = (np.sqrt(X * X + Y * Y).astype(F) / Z).astype(F)
-                fac = np.where(r < F(1e-6), F(1.0), np.arctan(r * F(cam.p[5])).astype(F) / (r * F(cam.p[4]))).astype(F)
+                fac = np.where(r < F(1e-6), F(1.0), _atanf((r * F(cam.p[5])).astype(F)) / (r * F(cam.p[4]))).astype(F)
                 lx = (fac * X).astype(F); ly = (fac * Y).astype(F)
                 px = F(cam.p[0]) * (lx / Z) + F(cam.p[2]); py = F(cam.p[1]) * (ly / Z) + F(cam.p[3])
                 return (px.astype(F), py.astype(F), Z.astype(F)) + ((lx.astype(F), ly.astype(F)) if shaded else ())
             if model == 3:
                 # FisheyePolynomial4 shader (renderer.cc:187-205): r2 becomes the radial factor, 99 outside the cut-off
                 r = np.sqrt(r2)
-                th = np.where(r > F(1e-6), np.arctan2(r, F(1.0)).astype(F) / r, F(1.0)).astype(F)
+                th = np.where(r > F(1e-6), _atan2f_1(r.astype(F)) / r, F(1.0)).astype(F)
                 fx_, fy_ = np.where(r > F(1e-6), th * nx, nx).astype(F), np.where(r > F(1e-6), th * ny, ny).astype(F)
                 rr = np.where(r > F(1e-6), th * th * r2, r2).astype(F)
                 k1, k2, k3, k4 = [F(cam.p[4 + i]) for i in range(4)]
@@ -53,7 +67,7 @@ def project_vertices(model, cam, R, t, verts, shaded=False):
                 return (px.astype(F), py.astype(F), Z.astype(F)) + ((lx.astype(F), ly.astype(F)) if shaded else ())
             if model == 2:
                 r = np.sqrt(r2)
-                th = np.where(r > F(1e-6), np.arctan2(r, F(1.0)).astype(F) / r, F(1.0)).astype(F)
+                th = np.where(r > F(1e-6), _atan2f_1(r.astype(F)) / r, F(1.0)).astype(F)
                 nx = np.where(r > F(1e-6), th * nx, nx); ny = np.where(r > F(1e-6), th * ny, ny)
             x2, xy, y2 = nx * nx, nx * ny, ny * ny
             r2 = x2 + y2

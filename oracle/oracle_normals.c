@@ -15,6 +15,7 @@
  */
 #include "e3d_oracle.h"
 #include "oracle_kdtree.h"
+#include "../include/e3d_libm.h"   /* bit-defined atan2f / cosf / sinf shared with the HIP kernels */
 
 #include <float.h>
 #include <math.h>
@@ -51,9 +52,9 @@ static void compute_roots(const float* m /*row-major 3x3*/, float* roots) {
   float q = half_b * half_b + a_over_3 * a_over_3 * a_over_3;
   if (q > 0.f) q = 0.f;
   float rho = sqrtf(-a_over_3);
-  float theta = atan2f(sqrtf(-q), half_b) * s_inv3;
-  float cos_theta = cosf(theta);
-  float sin_theta = sinf(theta);
+  float theta = e3d_atan2f(sqrtf(-q), half_b) * s_inv3;
+  float cos_theta = e3d_cosf(theta);
+  float sin_theta = e3d_sinf(theta);
   roots[0] = c2_over_3 + 2.f * rho * cos_theta;
   roots[1] = c2_over_3 - rho * (cos_theta + s_sqrt3 * sin_theta);
   roots[2] = c2_over_3 - rho * (cos_theta - s_sqrt3 * sin_theta);
@@ -237,4 +238,19 @@ int oracle_local_outlier_removal(const float* xyz, size_t n, int mean_k, double 
   free(nn);
   okd_free(tree);
   return 0;
+}
+
+/* ---- test hook: the shared bit-defined elementary functions (include/e3d_libm.h) evaluated on the host ---------------- */
+/* fn: 0 atanf(x), 1 atan2f(y = x[i], x = y[i]), 2 sinf, 3 cosf, 4 tanf, 5 log2f */
+void oracle_libm_eval(int fn, const float* x, const float* y, size_t n, float* out) {
+  for (size_t i = 0; i < n; ++i) {
+    switch (fn) {
+      case 0: out[i] = e3d_atanf(x[i]); break;
+      case 1: out[i] = e3d_atan2f(x[i], y[i]); break;
+      case 2: out[i] = e3d_sinf(x[i]); break;
+      case 3: out[i] = e3d_cosf(x[i]); break;
+      case 4: out[i] = e3d_tanf(x[i]); break;
+      default: out[i] = e3d_log2f(x[i]); break;
+    }
+  }
 }

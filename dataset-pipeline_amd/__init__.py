@@ -8,8 +8,8 @@ every entry point raises if the HIP library or a GPU is missing.
 The directory name contains a hyphen (it is the name the task prescribes), so import it with
     import importlib; e3d = importlib.import_module("dataset-pipeline_amd")
 """
-from .capi import (E3DError, PointToPlaneICP, RegParams, RegProblem, default_reg_params, determine_point_neighbors,
+from .capi import (Comm, E3DError, PointToPlaneICP, RegParams, RegProblem, default_reg_params, determine_point_neighbors,
                    find_correspondences, icp_pair_system, lib, lib_path, libm_eval, local_outlier_removal, merge_close_points, normals_knn, normals_radius, transform_cloud)
 
-__all__ = ["E3DError", "PointToPlaneICP", "RegParams", "RegProblem", "default_reg_params", "determine_point_neighbors", "find_correspondences",
+__all__ = ["Comm", "E3DError", "PointToPlaneICP", "RegParams", "RegProblem", "default_reg_params", "determine_point_neighbors", "find_correspondences",
            "icp_pair_system", "lib", "lib_path", "libm_eval", "local_outlier_removal", "merge_close_points", "normals_knn", "normals_radius", "transform_cloud"]

@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
-SOURCES = ["e3d_icp.hip", "e3d_icp_kernels.hip", "e3d_sort.hip", "e3d_normals.hip", "e3d_reg.hip", "e3d_multires.hip"]
+SOURCES = ["e3d_icp.hip", "e3d_comm.hip", "e3d_icp_kernels.hip", "e3d_sort.hip", "e3d_normals.hip", "e3d_reg.hip", "e3d_multires.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
 
@@ -50,7 +50,7 @@ def build(force=False, verbose=False):
             raise RuntimeError("hipcc failed on " + s)
     so = lib_path()
     if force or procs or not os.path.exists(so):
-        cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so] + objs
+        cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so] + objs + ["-L/opt/rocm/lib", "-lrccl"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

@@ -56,6 +56,14 @@ SIGNATURES = {
     "e3d_icp_iter_records": (C.POINTER(IterRecord), [C.c_void_p]),
     "e3d_icp_clear_records": (None, [C.c_void_p]),
     "e3d_icp_set_shard": (C.c_int, [C.c_void_p, C.c_int, C.c_int, ALLREDUCE_FN, C.c_void_p]),
+    "e3d_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "e3d_comm_create": (C.c_void_p, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "e3d_comm_create_all": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p]),
+    "e3d_comm_destroy": (None, [C.c_void_p]),
+    "e3d_comm_rank": (C.c_int, [C.c_void_p]),
+    "e3d_comm_world_size": (C.c_int, [C.c_void_p]),
+    "e3d_icp_set_comm": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "e3d_reg_set_comm": (C.c_int, [C.c_void_p, C.c_void_p]),
     "e3d_find_correspondences": (C.c_int64, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_float,
                                              C.c_void_p, C.c_void_p]),
     "e3d_transform_cloud": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -233,6 +241,12 @@ class PointToPlaneICP:
         if lib().e3d_icp_set_max_inner_iterations(self._h, int(n)) < 0:
             _err("e3d_icp_set_max_inner_iterations")
 
+    def set_comm(self, comm):
+        """Native multi-GPU mode: `comm` is a Comm (the library's RCCL communicator); replaces set_shard."""
+        self._comm = comm
+        if lib().e3d_icp_set_comm(self._h, comm.handle if comm is not None else None) < 0:
+            _err("e3d_icp_set_comm")
+
     def set_shard(self, rank, world_size, allreduce=None):
         """allreduce(np.ndarray float64, in place) -> None; called from inside run()."""
         if allreduce is not None:
@@ -309,6 +323,46 @@ def icp_pair_system(sxyz, snrm, txyz, tnrm, iq, im, sq, st, tq, tt):
     if r < 0:
         _err("e3d_icp_pair_system", r)
     return H, b, float(cost[0])
+
+
+class Comm:
+    """The library's RCCL communicator (include/e3d_hip.h: e3d_comm_*).  One rank per GPU.
+
+    Processes: rank 0 calls Comm.unique_id(), ships the 128 bytes through the launcher's rendezvous, every rank builds
+    Comm(id_bytes, rank, world, device).  Threads of one process: Comm.create_all(n_devices)."""
+
+    def __init__(self, id_bytes=None, rank=0, world_size=1, device=0, _handle=None):
+        if _handle is not None:
+            self.handle = _handle
+        else:
+            if id_bytes is None:
+                id_bytes = Comm.unique_id()
+            buf = C.create_string_buffer(bytes(id_bytes), 128)
+            self.handle = lib().e3d_comm_create(buf, int(rank), int(world_size), int(device))
+            if not self.handle:
+                _err("e3d_comm_create")
+        self.rank = lib().e3d_comm_rank(self.handle)
+        self.world_size = lib().e3d_comm_world_size(self.handle)
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(128)
+        if lib().e3d_comm_unique_id(buf) < 0:
+            _err("e3d_comm_unique_id")
+        return buf.raw
+
+    @staticmethod
+    def create_all(n_devices, devices=None):
+        out = (C.c_void_p * n_devices)()
+        dev = (C.c_int * n_devices)(*(devices if devices is not None else range(n_devices)))
+        if lib().e3d_comm_create_all(int(n_devices), dev, out) < 0:
+            _err("e3d_comm_create_all")
+        return [Comm(_handle=out[i]) for i in range(n_devices)]
+
+    def destroy(self):
+        if self.handle:
+            lib().e3d_comm_destroy(self.handle)
+            self.handle = None
 
 
 def libm_eval(fn, x, y=None):
@@ -564,6 +618,11 @@ class RegProblem:
         a = C.c_int(); l = C.c_float(lam); m = C.c_float()
         self._chk(lib().e3d_reg_apply(self._h, int(print_progress), C.byref(a), C.byref(l), C.byref(m)), "e3d_reg_apply")
         return bool(a.value), l.value, m.value
+
+    def set_comm(self, comm):
+        """Image sharding with the library's own RCCL communicator (a Comm); call before the images are set."""
+        self._comm = comm
+        self._chk(lib().e3d_reg_set_comm(self._h, comm.handle if comm is not None else None), "e3d_reg_set_comm")
 
     def set_shard(self, rank, world_size, allreduce=None, allreduce_device=None):
         """Image sharding over ranks (image id mod world_size).  allreduce(np.ndarray float64, in place);

@@ -18,6 +18,7 @@
 #include <memory>
 
 #include "../../include/e3d_hip.h"
+#include "e3d_comm.hpp"
 #include "e3d_icp_kernels.hpp"
 #include "e3d_math.hpp"
 
@@ -77,7 +78,8 @@ struct PairState {
 struct PairJob {
   int src, tgt;            // indices into the handle's cloud table (fixed = clouds.size())
   int impl_src, impl_tgt;
-  long long count = 0;
+  long long count = 0;      // this rank's correspondences
+  long long gcount = 0;     // all ranks' (what the reference prints; decides which pairs enter the LM system)
   double dsum = 0.0;
   size_t corr_off = 0;
   bool mine = true;
@@ -100,6 +102,8 @@ struct e3d_icp {
   int rank = 0, world = 1;
   e3d_allreduce_fn allreduce = nullptr;
   void* allreduce_user = nullptr;
+  e3d_comm* comm = nullptr;                     // native RCCL collectives (e3d_icp_set_comm); not owned
+  DevBuf<double> d_red;                         // staging of small host buffers for the collectives
 
   // scratch
   DevBuf<float> bbox_partial, bbox_out;
@@ -549,6 +553,36 @@ static int lm_blocks_for(long long n) {
   return (int)b;
 }
 
+static bool sharded(const e3d_icp* h) { return h->comm != nullptr || h->world > 1; }
+
+// sum of the per-set results (n doubles, already reduced over this rank's blocks) over the ranks: in place in HBM on the
+// handle's stream with the native communicator; the host copy follows either way
+static void reduce_setsums(e3d_icp* h, int ns) {
+  hipStream_t s = h->stream;
+  const size_t n = (size_t)kLmSlot * (size_t)ns;
+  if (h->comm) comm_allreduce_f64(h->comm, h->d_setsum.p, n, s);
+  copy_out(h->h_setsum.p, h->d_setsum.p, sizeof(double) * n, s);
+  sync(h);
+  if (!h->comm && h->world > 1) {
+    if (h->allreduce(h->h_setsum.p, n, h->allreduce_user) != 0) throw Error(E3D_ERR_INVALID, "allreduce callback failed");
+  }
+}
+
+// sum of a small host buffer over the ranks (per-pair counts: once per outer iteration)
+static void reduce_host(e3d_icp* h, double* buf, size_t n) {
+  if (!n || !sharded(h)) return;
+  if (h->comm) {
+    hipStream_t s = h->stream;
+    h->d_red.reserve(n);
+    copy_in(h->d_red.p, buf, sizeof(double) * n, s);
+    comm_allreduce_f64(h->comm, h->d_red.p, n, s);
+    copy_out(buf, h->d_red.p, sizeof(double) * n, s);
+    sync(h);
+  } else if (h->allreduce(buf, n, h->allreduce_user) != 0) {
+    throw Error(E3D_ERR_INVALID, "allreduce callback failed");
+  }
+}
+
 struct LmSystem {
   int n_impl = 0, nv = 0;
   std::vector<PairJob*> sets;        // this rank's non-empty pairs, grouped by mode
@@ -590,8 +624,7 @@ static void lm_evaluate(e3d_icp* h, LmSystem& L, const std::vector<SE3f>& poses,
     }
     tm.stop(s);
     launch_lm_reduce(h->d_partial.p, h->d_sets.p, ns, kLmSlot, h->d_setsum.p, s);
-    copy_out(h->h_setsum.p, h->d_setsum.p, sizeof(double) * kLmSlot * ns, s);
-    sync(h);
+    reduce_setsums(h, ns);      // every rank holds the same sets (lm_prepare), so the per-set blocks add up across the ranks
     rec.t_lm_kernel_ms += tm.ms();
     if (full) rec.full_passes++; else rec.cost_passes++;
     // scatter the per-set systems into H, b  (Accumulate, icp_point_to_plane_impl.h:82-113)
@@ -622,21 +655,6 @@ static void lm_evaluate(e3d_icp* h, LmSystem& L, const std::vector<SE3f>& poses,
   } else {
     if (full) rec.full_passes++; else rec.cost_passes++;
   }
-  if (h->world > 1) {
-    // one fused buffer [upper(H) as dense nv*nv, b, cost] summed over ranks
-    std::vector<double> buf((size_t)nv * nv + nv + 1);
-    std::copy(H.begin(), H.end(), buf.begin());
-    std::copy(b.begin(), b.end(), buf.begin() + (size_t)nv * nv);
-    buf.back() = cost;
-    const size_t cnt = full ? buf.size() : 1;
-    double* ptr = full ? buf.data() : &buf.back();
-    if (h->allreduce(ptr, cnt, h->allreduce_user) != 0) throw Error(E3D_ERR_INVALID, "allreduce callback failed");
-    if (full) {
-      std::copy(buf.begin(), buf.begin() + (size_t)nv * nv, H.begin());
-      std::copy(buf.begin() + (size_t)nv * nv, buf.begin() + (size_t)nv * nv + nv, b.begin());
-    }
-    cost = buf.back();
-  }
 }
 
 // Costs of up to kLmMaxPoses candidate pose sets in one pass (k_lm_cost_multi); costs[k] for cand[k].
@@ -666,25 +684,22 @@ static void lm_evaluate_costs(e3d_icp* h, LmSystem& L, const std::vector<std::ve
                          h->d_partial.p, s);
     tm.stop(s);
     launch_lm_reduce(h->d_partial.p, h->d_sets.p, ns, kLmSlot, h->d_setsum.p, s);
-    copy_out(h->h_setsum.p, h->d_setsum.p, sizeof(double) * kLmSlot * ns, s);
-    sync(h);
+    reduce_setsums(h, ns);
     rec.t_lm_kernel_ms += tm.ms();
     for (int i = 0; i < ns; ++i)
       for (int k = 0; k < np; ++k) costs[k] += h->h_setsum.p[(size_t)kLmSlot * i + k];
   }
   rec.multi_cost_passes++;
-  if (h->world > 1) {
-    if (h->allreduce(costs.data(), costs.size(), h->allreduce_user) != 0) throw Error(E3D_ERR_INVALID, "allreduce callback failed");
-  }
 }
 
 static void lm_prepare(e3d_icp* h, LmSystem& L, std::vector<PairJob>& jobs) {
-  // group this rank's non-empty sets by full-pass mode; assign LM blocks
+  // group the non-empty pairs (global counts: every rank builds the same list, a rank without correspondences of a pair
+  // contributes an empty set) by full-pass mode; assign LM blocks
   L.sets.clear();
   L.mode_begin.assign(5, 0); L.mode_blocks.assign(5, 0); L.mode_block_base.assign(5, 0);
   std::vector<std::vector<PairJob*>> by_mode(4);
   for (PairJob& j : jobs) {
-    if (j.count == 0) continue;
+    if (j.gcount == 0) continue;
     const int si = j.impl_src - 1, ti = j.impl_tgt - 1;
     int mode;
     if (si < 0 || ti < 0) mode = kModeOne;
@@ -844,12 +859,13 @@ static bool align_meshes(e3d_icp* h, float max_d, float thr, bool print, int ite
   std::vector<long long> gcount(jobs.size());
   std::vector<double> gdsum(jobs.size());
   for (size_t p = 0; p < jobs.size(); ++p) { gcount[p] = jobs[p].count; gdsum[p] = jobs[p].dsum; }
-  if (h->world > 1 && !jobs.empty()) {
+  if (sharded(h) && !jobs.empty()) {
     std::vector<double> buf(2 * jobs.size(), 0.0);
     for (size_t p = 0; p < jobs.size(); ++p) { buf[2 * p] = (double)jobs[p].count; buf[2 * p + 1] = jobs[p].dsum; }
-    if (h->allreduce(buf.data(), buf.size(), h->allreduce_user) != 0) throw Error(E3D_ERR_INVALID, "allreduce callback failed");
+    reduce_host(h, buf.data(), buf.size());
     for (size_t p = 0; p < jobs.size(); ++p) { gcount[p] = (long long)buf[2 * p]; gdsum[p] = buf[2 * p + 1]; }
   }
+  for (size_t p = 0; p < jobs.size(); ++p) jobs[p].gcount = gcount[p];
   for (size_t p = 0; p < jobs.size(); ++p) {
     const PairJob& j = jobs[p];
     const int psrc = (j.impl_src == fixed_vertex) ? -1 : j.impl_src;
@@ -1034,6 +1050,15 @@ int e3d_icp_set_shard(e3d_icp_t* h, int rank, int world, e3d_allreduce_fn fn, vo
     return E3D_ERR_INVALID;
   }
   h->rank = rank; h->world = world; h->allreduce = fn; h->allreduce_user = user;
+  return 0;
+}
+
+int e3d_icp_set_comm(e3d_icp_t* h, e3d_comm_t* comm) {
+  if (!h) { e3d::set_last_error("e3d_icp_set_comm: null handle"); return E3D_ERR_INVALID; }
+  if (comm && comm->device != h->device) { e3d::set_last_error("e3d_icp_set_comm: communicator and handle live on different devices"); return E3D_ERR_INVALID; }
+  h->comm = comm;
+  h->rank = comm ? comm->rank : 0; h->world = comm ? comm->world : 1;
+  h->allreduce = nullptr; h->allreduce_user = nullptr;
   return 0;
 }
 

@@ -22,6 +22,7 @@
 
 #include "../../include/e3d_hip.h"
 #include "e3d_camera.hpp"
+#include "e3d_comm.hpp"
 #include "e3d_icp_kernels.hpp"
 #include "e3d_math.hpp"
 
@@ -1499,6 +1500,8 @@ struct e3d_reg {
   e3d_allreduce_fn allreduce = nullptr;
   e3d_allreduce_device_fn allreduce_dev = nullptr;
   void* ar_user = nullptr;
+  e3d_comm* comm = nullptr;                     // native RCCL collectives (e3d_reg_set_comm); not owned
+  DevBuf<double> comm_stage;
   bool owns(int image_id) const { return world <= 1 || ((image_id % world) + world) % world == rank; }
   // splat depth: per-point rectangles, (tile, point) pairs (double-buffered for the sort), tile ranges
   DevBuf<uint4> rects;
@@ -1512,11 +1515,28 @@ namespace e3d {
 static void rsync(e3d_reg* h) { E3D_HIP(hipStreamSynchronize(h->stream)); }
 static unsigned nblk(size_t n) { return (unsigned)div_up(n ? n : 1, kBlock); }
 
+// Sums over the ranks.  With the library's own communicator (e3d_reg_set_comm) both run as RCCL all-reduces on the handle's
+// stream -- the small f64 blocks staged through HBM, the descriptors in place -- otherwise through the callbacks.
 static void allreduce_host(e3d_reg* h, double* buf, size_t n) {
+  if (!n) return;
+  if (h->comm) {
+    h->comm_stage.reserve(n);
+    copy_in(h->comm_stage.p, buf, sizeof(double) * n, h->stream);
+    comm_allreduce_f64(h->comm, h->comm_stage.p, n, h->stream);
+    copy_out(buf, h->comm_stage.p, sizeof(double) * n, h->stream);
+    rsync(h);
+    return;
+  }
   if (h->world <= 1) return;
   if (!h->allreduce || h->allreduce(buf, n, h->ar_user) != 0) throw Error(E3D_ERR_INVALID, "all-reduce callback failed");
 }
 static void allreduce_device(e3d_reg* h, void* dev, size_t n, int dtype) {
+  if (!n) return;
+  if (h->comm) {
+    if (dtype == 0) comm_allreduce_f32(h->comm, static_cast<float*>(dev), n, h->stream);
+    else comm_allreduce_i32(h->comm, static_cast<int*>(dev), n, h->stream);
+    return;
+  }
   if (h->world <= 1) return;
   rsync(h);
   if (!h->allreduce_dev || h->allreduce_dev(dev, n, dtype, h->ar_user) != 0) throw Error(E3D_ERR_INVALID, "device all-reduce callback failed");
@@ -1731,6 +1751,8 @@ static void dense_intensities(e3d_reg* h, ImageDev& im, PointScale& S, Obs& O) {
 }  // namespace e3d
 
 #define R_TRY try {
+// entry points that take a handle run on the handle's device, whatever the calling thread's current device is
+#define R_TRYH try { if (h) E3D_HIP(hipSetDevice(h->device));
 #define R_CATCH()                                                                            \
   } catch (const e3d::Error& e) { e3d::set_last_error(e.what()); return e.code; }            \
   catch (const std::exception& e) { e3d::set_last_error(e.what()); return E3D_ERR_INVALID; }
@@ -1755,7 +1777,7 @@ e3d_reg_t* e3d_reg_create(const e3d_reg_params* params) {
 void e3d_reg_destroy(e3d_reg_t* reg) { delete reg; }
 
 int e3d_reg_set_params(e3d_reg_t* h, const e3d_reg_params* params) {
-  R_TRY
+  R_TRYH
   if (!h) throw Error(E3D_ERR_INVALID, "null handle");
   check_params(params);
   if (params->point_neighbor_count != h->prm.point_neighbor_count && !h->scales.empty())
@@ -1767,7 +1789,7 @@ int e3d_reg_set_params(e3d_reg_t* h, const e3d_reg_params* params) {
 
 int e3d_reg_set_point_scale(e3d_reg_t* h, int point_scale, const float* xyz, size_t n, float point_radius,
                             const uint32_t* neighbor_indices, const float* fixed_descriptors) {
-  R_TRY
+  R_TRYH
   if (!h || (!xyz && n) || (!neighbor_indices && n)) throw Error(E3D_ERR_INVALID, "e3d_reg_set_point_scale: null argument");
   hipStream_t s = h->stream;
   const int K = h->prm.point_neighbor_count;
@@ -1791,7 +1813,7 @@ int e3d_reg_set_point_scale(e3d_reg_t* h, int point_scale, const float* xyz, siz
 }
 
 int e3d_reg_set_variable_descriptors(e3d_reg_t* h, int point_scale, const float* descriptors, const int32_t* counts) {
-  R_TRY
+  R_TRYH
   if (!h || !descriptors || !counts) throw Error(E3D_ERR_INVALID, "null argument");
   PointScale& S = get_scale(h, point_scale);
   copy_in(S.var_desc.p, descriptors, sizeof(float) * S.n * h->prm.point_neighbor_count, h->stream);
@@ -1801,7 +1823,7 @@ int e3d_reg_set_variable_descriptors(e3d_reg_t* h, int point_scale, const float*
   R_CATCH()
 }
 int e3d_reg_get_variable_descriptors(e3d_reg_t* h, int point_scale, float* descriptors, int32_t* counts) {
-  R_TRY
+  R_TRYH
   if (!h) throw Error(E3D_ERR_INVALID, "null handle");
   PointScale& S = get_scale(h, point_scale);
   if (descriptors) copy_out(descriptors, S.var_desc.p, sizeof(float) * S.n * h->prm.point_neighbor_count, h->stream);
@@ -1813,7 +1835,7 @@ int e3d_reg_get_variable_descriptors(e3d_reg_t* h, int point_scale, float* descr
 
 int e3d_reg_set_intrinsics(e3d_reg_t* h, int intrinsics_id, int camera_type, int width, int height, const float* parameters,
                            int n_parameters, int min_image_scale, int n_levels) {
-  R_TRY
+  R_TRYH
   if (!h || !parameters) throw Error(E3D_ERR_INVALID, "null argument");
   if (camera_type != E3D_CAMERA_PINHOLE && camera_type != E3D_CAMERA_OPENCV && camera_type != E3D_CAMERA_THIN_PRISM_FISHEYE &&
       camera_type != E3D_CAMERA_OPENCV_FISHEYE && camera_type != E3D_CAMERA_FOV)
@@ -1832,7 +1854,7 @@ int e3d_reg_set_intrinsics(e3d_reg_t* h, int intrinsics_id, int camera_type, int
 
 int e3d_reg_get_intrinsics_level(e3d_reg_t* h, int intrinsics_id, int level, int* width, int* height, float* parameters,
                                  float* cutoff2) {
-  R_TRY
+  R_TRYH
   if (!h) throw Error(E3D_ERR_INVALID, "null handle");
   auto it = h->intr.find(intrinsics_id);
   if (it == h->intr.end() || level < 0 || level >= (int)it->second.levels.size()) throw Error(E3D_ERR_INDEX, "no such intrinsics level");
@@ -1850,7 +1872,7 @@ int e3d_reg_get_intrinsics_level(e3d_reg_t* h, int intrinsics_id, int level, int
 
 int e3d_reg_set_image(e3d_reg_t* h, int image_id, int intrinsics_id, const uint8_t* const* level_pixels,
                       const uint8_t* const* level_masks) {
-  R_TRY
+  R_TRYH
   if (!h) throw Error(E3D_ERR_INVALID, "null argument");
   auto it = h->intr.find(intrinsics_id);
   if (it == h->intr.end()) throw Error(E3D_ERR_INDEX, "intrinsics not set");
@@ -1886,7 +1908,7 @@ int e3d_reg_set_image(e3d_reg_t* h, int image_id, int intrinsics_id, const uint8
 }
 
 int e3d_reg_set_image_pose(e3d_reg_t* h, int image_id, const float q[4], const float t[3]) {
-  R_TRY
+  R_TRYH
   if (!h || !q || !t) throw Error(E3D_ERR_INVALID, "null argument");
   ImageDev& im = get_image(h, image_id);
   SE3f T;
@@ -1901,7 +1923,7 @@ int e3d_reg_set_image_pose(e3d_reg_t* h, int image_id, const float q[4], const f
 
 /* opt::Rig: image_T_rig of every camera of a rig (camera 0 = reference, normally identity) */
 int e3d_reg_set_rig(e3d_reg_t* h, int rig_id, int n_cameras, const float* q, const float* t) {
-  R_TRY
+  R_TRYH
   if (!h || !q || !t || n_cameras < 1) throw Error(E3D_ERR_INVALID, "bad rig");
   RigState r;
   r.image_T_rig.resize(n_cameras);
@@ -1917,7 +1939,7 @@ int e3d_reg_set_rig(e3d_reg_t* h, int rig_id, int n_cameras, const float* q, con
   R_CATCH()
 }
 int e3d_reg_get_rig(e3d_reg_t* h, int rig_id, int camera_index, float q[4], float t[3]) {
-  R_TRY
+  R_TRYH
   if (!h || !q || !t) throw Error(E3D_ERR_INVALID, "null argument");
   auto it = h->rigs.find(rig_id);
   if (it == h->rigs.end() || camera_index < 0 || camera_index >= (int)it->second.image_T_rig.size()) throw Error(E3D_ERR_INDEX, "no such rig camera");
@@ -1930,7 +1952,7 @@ int e3d_reg_get_rig(e3d_reg_t* h, int rig_id, int camera_index, float q[4], floa
 /* opt::RigImages: one frame of a rig = one image per camera, image_ids[0] is the reference image.  The poses of the other
  * images become image_T_rig[camera] * image_T_global(reference). */
 int e3d_reg_add_rig_images(e3d_reg_t* h, int rig_id, const int* image_ids, int n_cameras) {
-  R_TRY
+  R_TRYH
   if (!h || !image_ids) throw Error(E3D_ERR_INVALID, "null argument");
   auto it = h->rigs.find(rig_id);
   if (it == h->rigs.end() || (int)it->second.image_T_rig.size() != n_cameras) throw Error(E3D_ERR_INVALID, "rig not set or camera count mismatch");
@@ -1951,7 +1973,7 @@ int e3d_reg_add_rig_images(e3d_reg_t* h, int rig_id, const int* image_ids, int n
 }
 
 int e3d_reg_get_image_pose(e3d_reg_t* h, int image_id, float q[4], float t[3]) {
-  R_TRY
+  R_TRYH
   if (!h || !q || !t) throw Error(E3D_ERR_INVALID, "null argument");
   const ImageDev& im = get_image(h, image_id);
   q[0] = im.pose_q.q.w; q[1] = im.pose_q.q.x; q[2] = im.pose_q.q.y; q[3] = im.pose_q.q.z;
@@ -2034,7 +2056,7 @@ extern "C" {
  * geometry: no). */
 int e3d_reg_add_occlusion_mesh(e3d_reg_t* h, const float* vertices, size_t n_vertices, const uint32_t* triangles, size_t n_triangles,
                                int compute_edges) {
-  R_TRY
+  R_TRYH
   if (!h || !vertices || !triangles || !n_vertices || !n_triangles) throw Error(E3D_ERR_INVALID, "empty mesh");
   if (n_triangles >= ((size_t)1 << 31) || n_vertices >= ((size_t)1 << 32)) throw Error(E3D_ERR_INVALID, "mesh too large");
   hipStream_t s = h->stream;
@@ -2071,7 +2093,7 @@ int e3d_reg_add_occlusion_mesh(e3d_reg_t* h, const float* vertices, size_t n_ver
   R_CATCH()
 }
 int e3d_reg_clear_occlusion_meshes(e3d_reg_t* h) {
-  R_TRY
+  R_TRYH
   if (!h) throw Error(E3D_ERR_INVALID, "null handle");
   h->meshes.clear();
   for (auto& kv : h->images) kv.second.depth_scale = -1;
@@ -2081,21 +2103,21 @@ int e3d_reg_clear_occlusion_meshes(e3d_reg_t* h) {
 /* min_occlusion_depth / max_occlusion_depth (near / far plane of the mesh renderer) and mask_occlusion_boundaries of
  * OcclusionGeometry::RenderDepthMap (occlusion_geometry.h:80-86); defaults 0.05, 100, true */
 int e3d_reg_set_occlusion_options(e3d_reg_t* h, float min_depth, float max_depth, int mask_occlusion_boundaries) {
-  R_TRY
+  R_TRYH
   if (!h || !(min_depth > 0) || !(max_depth > min_depth)) throw Error(E3D_ERR_INVALID, "bad occlusion depth range");
   h->min_occlusion_depth = min_depth; h->max_occlusion_depth = max_depth; h->mask_occlusion_boundaries = mask_occlusion_boundaries != 0;
   return 0;
   R_CATCH()
 }
 int64_t e3d_reg_occlusion_edge_count(e3d_reg_t* h, int mesh_index) {
-  R_TRY
+  R_TRYH
   if (!h || mesh_index < 0 || mesh_index >= (int)h->meshes.size()) throw Error(E3D_ERR_INDEX, "no such mesh");
   return (int64_t)h->meshes[mesh_index]->n_edges;
   R_CATCH()
 }
 
 int e3d_reg_set_splat_points(e3d_reg_t* h, const float* xyz, size_t n) {
-  R_TRY
+  R_TRYH
   if (!h || (!xyz && n)) throw Error(E3D_ERR_INVALID, "null argument");
   DevBuf<float> tmp; tmp.reserve(3 * n);
   copy_in(tmp.p, xyz, sizeof(float) * 3 * n, h->stream);
@@ -2108,7 +2130,7 @@ int e3d_reg_set_splat_points(e3d_reg_t* h, const float* xyz, size_t n) {
 }
 
 int e3d_reg_render_depth(e3d_reg_t* h, int image_id, int image_scale, float* depth_out) {
-  R_TRY
+  R_TRYH
   if (!h) throw Error(E3D_ERR_INVALID, "null handle");
   ImageDev& im = get_image(h, image_id);
   if (!h->owns(image_id)) throw Error(E3D_ERR_INVALID, fmt("image %d belongs to rank %d", image_id, e3d_reg_image_owner(h, image_id)));
@@ -2169,7 +2191,7 @@ int e3d_reg_render_depth(e3d_reg_t* h, int image_id, int image_scale, float* dep
 
 int64_t e3d_reg_observe(e3d_reg_t* h, int image_id, int point_scale, int image_scale, int border_size, const uint32_t* indices,
                         size_t n_indices) {
-  R_TRY
+  R_TRYH
   if (!h) throw Error(E3D_ERR_INVALID, "null handle");
   hipStream_t s = h->stream;
   ImageDev& im = get_image(h, image_id);
@@ -2216,7 +2238,7 @@ int64_t e3d_reg_observe(e3d_reg_t* h, int image_id, int point_scale, int image_s
 
 int e3d_reg_get_observations(e3d_reg_t* h, int image_id, int point_scale, uint32_t* idx, float* x, float* y, float* scale,
                              uint8_t* flags) {
-  R_TRY
+  R_TRYH
   if (!h) throw Error(E3D_ERR_INVALID, "null handle");
   Obs& O = get_obs(get_image(h, image_id), point_scale);
   if (idx) copy_out(idx, O.idx.p, sizeof(unsigned) * O.n, h->stream);
@@ -2231,7 +2253,7 @@ int e3d_reg_get_observations(e3d_reg_t* h, int image_id, int point_scale, uint32
 
 int e3d_reg_set_observations(e3d_reg_t* h, int image_id, int point_scale, size_t n, const uint32_t* idx, const float* x,
                              const float* y, const float* scale) {
-  R_TRY
+  R_TRYH
   if (!h || (n && (!idx || !x || !y || !scale))) throw Error(E3D_ERR_INVALID, "null argument");
   ImageDev& im = get_image(h, image_id);
   PointScale& S = get_scale(h, point_scale);
@@ -2248,7 +2270,7 @@ int e3d_reg_set_observations(e3d_reg_t* h, int image_id, int point_scale, size_t
 }
 
 int e3d_reg_pass1(e3d_reg_t* h, int image_id, int point_scale, float* intensities, float* j_intrinsics, float* j_pose) {
-  R_TRY
+  R_TRYH
   if (!h) throw Error(E3D_ERR_INVALID, "null handle");
   ImageDev& im = get_image(h, image_id);
   PointScale& S = get_scale(h, point_scale);
@@ -2271,7 +2293,7 @@ int e3d_reg_pass1(e3d_reg_t* h, int image_id, int point_scale, float* intensitie
 }
 
 int e3d_reg_accumulate(e3d_reg_t* h, int image_id, int point_scale, double* H, double* b, double sums[2], int64_t counts[2]) {
-  R_TRY
+  R_TRYH
   if (!h || !H || !b || !sums || !counts) throw Error(E3D_ERR_INVALID, "null argument");
   hipStream_t s = h->stream;
   ImageDev& im = get_image(h, image_id);
@@ -2338,7 +2360,7 @@ int e3d_reg_accumulate(e3d_reg_t* h, int image_id, int point_scale, double* H, d
 }
 
 int e3d_reg_cost(e3d_reg_t* h, int image_id, int point_scale, double sums[2], int64_t counts[2]) {
-  R_TRY
+  R_TRYH
   if (!h || !sums || !counts) throw Error(E3D_ERR_INVALID, "null argument");
   hipStream_t s = h->stream;
   ImageDev& im = get_image(h, image_id);
@@ -2361,7 +2383,7 @@ int e3d_reg_cost(e3d_reg_t* h, int image_id, int point_scale, double sums[2], in
 }
 
 int e3d_reg_color_begin(e3d_reg_t* h, int point_scale) {
-  R_TRY
+  R_TRYH
   if (!h) throw Error(E3D_ERR_INVALID, "null handle");
   PointScale& S = get_scale(h, point_scale);
   E3D_HIP(hipMemsetAsync(S.var_desc.p, 0, sizeof(float) * S.n * h->prm.point_neighbor_count, h->stream));
@@ -2371,7 +2393,7 @@ int e3d_reg_color_begin(e3d_reg_t* h, int point_scale) {
   R_CATCH()
 }
 int e3d_reg_color_accumulate(e3d_reg_t* h, int image_id, int point_scale) {
-  R_TRY
+  R_TRYH
   if (!h) throw Error(E3D_ERR_INVALID, "null handle");
   ImageDev& im = get_image(h, image_id);
   PointScale& S = get_scale(h, point_scale);
@@ -2385,7 +2407,7 @@ int e3d_reg_color_accumulate(e3d_reg_t* h, int image_id, int point_scale) {
   R_CATCH()
 }
 int e3d_reg_color_finish(e3d_reg_t* h, int point_scale) {
-  R_TRY
+  R_TRYH
   if (!h) throw Error(E3D_ERR_INVALID, "null handle");
   PointScale& S = get_scale(h, point_scale);
   hipLaunchKernelGGL(k_color_finish, dim3(nblk(S.n)), dim3(kBlock), 0, h->stream, S.n, h->prm.point_neighbor_count, S.var_desc.p,
@@ -2663,7 +2685,7 @@ extern "C" {
 
 int e3d_reg_set_shard(e3d_reg_t* h, int rank, int world_size, e3d_allreduce_fn allreduce, e3d_allreduce_device_fn allreduce_device,
                       void* user) {
-  R_TRY
+  R_TRYH
   if (!h) throw Error(E3D_ERR_INVALID, "null handle");
   if (world_size < 1 || rank < 0 || rank >= world_size) throw Error(E3D_ERR_INVALID, "bad rank / world size");
   if (world_size > 1 && (!allreduce || !allreduce_device)) throw Error(E3D_ERR_INVALID, "world_size > 1 needs both all-reduce callbacks");
@@ -2672,8 +2694,18 @@ int e3d_reg_set_shard(e3d_reg_t* h, int rank, int world_size, e3d_allreduce_fn a
   return 0;
   R_CATCH()
 }
+int e3d_reg_set_comm(e3d_reg_t* h, e3d_comm_t* comm) {
+  R_TRYH
+  if (!h) throw Error(E3D_ERR_INVALID, "null handle");
+  if (!h->images.empty()) throw Error(E3D_ERR_INVALID, "e3d_reg_set_comm must be called before images are set");
+  h->comm = comm;
+  h->rank = comm ? comm->rank : 0; h->world = comm ? comm->world : 1;
+  h->allreduce = nullptr; h->allreduce_dev = nullptr; h->ar_user = nullptr;
+  return 0;
+  R_CATCH()
+}
 int e3d_reg_image_owner(e3d_reg_t* h, int image_id) {
-  R_TRY
+  R_TRYH
   if (!h) throw Error(E3D_ERR_INVALID, "null handle");
   return h->world <= 1 ? 0 : ((image_id % h->world) + h->world) % h->world;
   R_CATCH()
@@ -2684,7 +2716,7 @@ int e3d_reg_image_owner(e3d_reg_t* h, int image_id) {
  * current_image_scale) with occlusion, mask and saturation tests but no scale test, then the point radius that projects to
  * half a pixel.  min_radius starts at +inf, max_radius at -inf (points seen by no image keep those values). */
 int e3d_reg_point_radius_minmax(e3d_reg_t* h, const float* xyz, size_t n, float* min_radius, float* max_radius) {
-  R_TRY
+  R_TRYH
   if (!h || (n && (!xyz || !min_radius || !max_radius))) throw Error(E3D_ERR_INVALID, "null argument");
   hipStream_t s = h->stream;
   DevBuf<float> tmp, d_min, d_max;
@@ -2778,7 +2810,7 @@ int e3d_determine_point_neighbors(const float* xyz, size_t n, const uint8_t* sca
 
 // ---- f4: GroundTruthCreator -------------------------------------------------------------------------------------------------
 int e3d_reg_set_scan_points(e3d_reg_t* h, const float* xyz, size_t n) {
-  R_TRY
+  R_TRYH
   if (!h || (n && !xyz)) throw Error(E3D_ERR_INVALID, "null argument");
   if (n >= (size_t)1 << 31) throw Error(E3D_ERR_INVALID, "more than 2^31-1 scan points");
   h->n_scan = n;
@@ -2809,7 +2841,7 @@ static void scan_visibility(e3d_reg* h, int image_id, const uint8_t* mask, int e
                                                h->gt_depth.p));
 }
 int e3d_reg_count_scan_observations(e3d_reg_t* h, int image_id, const uint8_t* mask, int excluded_flag) {
-  R_TRY
+  R_TRYH
   if (!h) throw Error(E3D_ERR_INVALID, "null handle");
   scan_visibility(h, image_id, mask, excluded_flag, 0, 0);
   rsync(h);
@@ -2817,7 +2849,7 @@ int e3d_reg_count_scan_observations(e3d_reg_t* h, int image_id, const uint8_t* m
   R_CATCH()
 }
 int e3d_reg_get_scan_observation_counts(e3d_reg_t* h, int32_t* counts) {
-  R_TRY
+  R_TRYH
   if (!h || (!counts && h->n_scan)) throw Error(E3D_ERR_INVALID, "null argument");
   if (h->n_scan) copy_out(counts, h->scan_counts.p, sizeof(int) * h->n_scan, h->stream);
   rsync(h);
@@ -2825,7 +2857,7 @@ int e3d_reg_get_scan_observation_counts(e3d_reg_t* h, int32_t* counts) {
   R_CATCH()
 }
 int e3d_reg_set_scan_observation_counts(e3d_reg_t* h, const int32_t* counts) {
-  R_TRY
+  R_TRYH
   if (!h || (!counts && h->n_scan)) throw Error(E3D_ERR_INVALID, "null argument");
   if (h->n_scan) copy_in(h->scan_counts.p, counts, sizeof(int) * h->n_scan, h->stream);
   rsync(h);
@@ -2834,7 +2866,7 @@ int e3d_reg_set_scan_observation_counts(e3d_reg_t* h, const int32_t* counts) {
 }
 int e3d_reg_ground_truth_depth(e3d_reg_t* h, int image_id, const uint8_t* mask, int excluded_flag, int min_count, float* gt_depth,
                                float* occlusion_depth) {
-  R_TRY
+  R_TRYH
   if (!h) throw Error(E3D_ERR_INVALID, "null handle");
   ImageDev& im = get_image(h, image_id);
   const CamLevel& cam = h->intr.at(im.intrinsics_id).levels[0];
@@ -2850,7 +2882,7 @@ int e3d_reg_ground_truth_depth(e3d_reg_t* h, int image_id, const uint8_t* mask, 
 }
 
 int e3d_reg_update_observations(e3d_reg_t* h, int border_size) {
-  R_TRY
+  R_TRYH
   if (!h) throw Error(E3D_ERR_INVALID, "null handle");
   update_observations(h, border_size);
   return 0;
@@ -2858,7 +2890,7 @@ int e3d_reg_update_observations(e3d_reg_t* h, int border_size) {
 }
 // Optimizer::set_cache_observations (optimizer.h)
 int e3d_reg_set_cache_observations(e3d_reg_t* h, int enabled) {
-  R_TRY
+  R_TRYH
   if (!h) throw Error(E3D_ERR_INVALID, "null handle");
   h->cache_observations = enabled != 0;
   return 0;
@@ -2867,7 +2899,7 @@ int e3d_reg_set_cache_observations(e3d_reg_t* h, int enabled) {
 // ObservationsCache::DetermineAndSaveObservedPointIndices (observations_cache.cc:104-158) without the files: the full
 // visibility test at image scale 0, whose observed point indices become the cached lists.
 int e3d_reg_determine_observed_indices(e3d_reg_t* h) {
-  R_TRY
+  R_TRYH
   if (!h) throw Error(E3D_ERR_INVALID, "null handle");
   const int old_scale = h->prm.current_image_scale;
   const bool old_cache = h->cache_observations;
@@ -2895,7 +2927,7 @@ int e3d_reg_determine_observed_indices(e3d_reg_t* h) {
   R_CATCH()
 }
 int64_t e3d_reg_get_observed_indices(e3d_reg_t* h, int image_id, int point_scale, uint64_t* indices) {
-  R_TRY
+  R_TRYH
   if (!h) throw Error(E3D_ERR_INVALID, "null handle");
   ImageDev& im = get_image(h, image_id);
   get_scale(h, point_scale);
@@ -2912,7 +2944,7 @@ int64_t e3d_reg_get_observed_indices(e3d_reg_t* h, int image_id, int point_scale
   R_CATCH()
 }
 int e3d_reg_set_observed_indices(e3d_reg_t* h, int image_id, int point_scale, const uint64_t* indices, size_t count) {
-  R_TRY
+  R_TRYH
   if (!h || (count && !indices)) throw Error(E3D_ERR_INVALID, "null argument");
   ImageDev& im = get_image(h, image_id);
   PointScale& S = get_scale(h, point_scale);
@@ -2931,21 +2963,21 @@ int e3d_reg_set_observed_indices(e3d_reg_t* h, int image_id, int point_scale, co
   R_CATCH()
 }
 int e3d_reg_color_update(e3d_reg_t* h) {
-  R_TRY
+  R_TRYH
   if (!h) throw Error(E3D_ERR_INVALID, "null handle");
   color_update(h);
   return 0;
   R_CATCH()
 }
 int e3d_reg_compute_cost(e3d_reg_t* h, double* cost) {
-  R_TRY
+  R_TRYH
   if (!h || !cost) throw Error(E3D_ERR_INVALID, "null argument");
   *cost = total_cost(h);
   return 0;
   R_CATCH()
 }
 int e3d_reg_apply(e3d_reg_t* h, int print_progress, int* applied_update, float* lambda, float* max_change) {
-  R_TRY
+  R_TRYH
   if (!h || !applied_update || !lambda || !max_change) throw Error(E3D_ERR_INVALID, "null argument");
   bool applied = false;
   apply_update(h, print_progress != 0, &applied, lambda, max_change);
@@ -2959,7 +2991,7 @@ int e3d_reg_apply(e3d_reg_t* h, int print_progress, int* applied_update, float* 
 int e3d_reg_run_on_current_scale(e3d_reg_t* h, int max_num_iterations, float max_change_convergence_threshold,
                                  int iterations_without_new_optimum_threshold, int print_progress, double* optimum_cost,
                                  int* iterations_done) {
-  R_TRY
+  R_TRYH
   if (!h || !optimum_cost) throw Error(E3D_ERR_INVALID, "null argument");
   const bool print = print_progress != 0;
   // never use the highest image scale (optimizer.cc:60-61)

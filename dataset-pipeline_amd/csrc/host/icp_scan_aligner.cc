@@ -150,6 +150,8 @@ int main(int argc, char** argv) {
   parse_argument(argc, argv, "--downscale_step", downscale_step);
   float search_distance_increase_factor_per_scale = 2.0f;
   parse_argument(argc, argv, "--search_distance_increase_factor_per_scale", search_distance_increase_factor_per_scale);
+  int gpus = 1;     // not a flag of the reference: GPUs of this node to shard the correspondence search and the LM passes over
+  parse_argument(argc, argv, "--gpus", gpus);
 
   if (input_project_path.length() == 0 || output_project_path.length() == 0) {
     std::cout << "Please provide input and output MeshLab project paths with -i and -o." << std::endl;
@@ -168,6 +170,11 @@ int main(int argc, char** argv) {
   std::cout << "  number_of_scales: " << number_of_scales << std::endl;
   std::cout << "  downscale_step: " << downscale_step << std::endl;
   std::cout << "  search_distance_increase_factor_per_scale: " << search_distance_increase_factor_per_scale << std::endl;
+
+  if (gpus > 1) {
+    if (!e3d_host::set_gpu_count(gpus)) return EXIT_FAILURE;
+    std::cout << "  gpus: " << gpus << std::endl;
+  }
 
   ObjectPtrVector objects;
   if (!LoadMeshLabProject(input_project_path, &objects)) return EXIT_FAILURE;

@@ -39,6 +39,9 @@ int main(int argc, char** argv) {
   parse_argument(argc, argv, "--camera_ids_to_ignore", camera_ids_to_ignore_string);
   bool cache_observations = false;
   parse_argument(argc, argv, "--cache_observations", cache_observations);
+  int gpus = 1;     // not a flag of the reference: GPUs of this node to shard the images over (image id mod N)
+  parse_argument(argc, argv, "--gpus", gpus);
+  if (gpus > 1 && !set_gpu_count(gpus)) return EXIT_FAILURE;
   std::unordered_set<int> camera_ids_to_ignore;
   for (const std::string& id : SplitStringIntoSet(',', camera_ids_to_ignore_string)) camera_ids_to_ignore.insert(atoi(id.c_str()));
 
@@ -89,6 +92,21 @@ int main(int argc, char** argv) {
   if (occlusion_points.empty()) { std::cerr << "Point cloud is empty." << std::endl; return EXIT_FAILURE; }
   std::cout << "Done." << std::endl;
 
+  if (gpus > 1 && !file_exists(multi_res_point_cloud_directory_path + "/metadata.txt")) {
+    // the multi-resolution point cloud needs every image on one device (radius ranges over all images): build and save it on GPU 0
+    // first, exactly as the single-GPU run does; the sharded problem below then loads it
+    std::cout << "Building the multi-resolution point cloud on GPU 0 ..." << std::endl;
+    gpu_count_setting() = 1;
+    Problem single;
+    if (!single.prm.SetFromArguments(argc, argv)) return EXIT_FAILURE;
+    single.occlusion_mesh_path = occlusion_mesh_path;
+    single.occlusion_splats_path = occlusion_splats_path;
+    if (!single.InitializeStateFromColmapModel(state_path, image_base_path, camera_ids_to_ignore)) return EXIT_FAILURE;
+    std::vector<ColmapRig> rv;
+    if (ReadColmapRigs(state_path + "/rigs.json", &rv) && !single.AssignRigs(rv)) return EXIT_FAILURE;
+    if (!single.SetScanGeometryAndInitialize(colored_scans, occlusion_points, multi_res_point_cloud_directory_path)) return EXIT_FAILURE;
+    gpu_count_setting() = gpus;
+  }
   if (!problem.InitializeStateFromColmapModel(state_path, image_base_path, camera_ids_to_ignore)) return EXIT_FAILURE;
   std::vector<ColmapRig> rig_vector;
   if (ReadColmapRigs(state_path + "/rigs.json", &rig_vector) && !problem.AssignRigs(rig_vector)) return EXIT_FAILURE;
@@ -108,16 +126,19 @@ int main(int argc, char** argv) {
     // Optimizer::RunOnCurrentScale (never the highest image scale, optimizer.cc:60-61)
     current_image_scale = std::min(current_image_scale, problem.max_image_scale() - 1);
     problem.reg_params.current_image_scale = current_image_scale;
-    if (api().e3d_reg_set_params(problem.reg, &problem.reg_params) < 0) { std::cerr << api().e3d_last_error() << std::endl; return EXIT_FAILURE; }
+    if (!problem.all_regs([&](e3d_reg_t* r) { return api().e3d_reg_set_params(r, &problem.reg_params); }, "e3d_reg_set_params")) return EXIT_FAILURE;
     if (cache_observations && !problem.PrepareObservationsCache(observations_cache_path)) return EXIT_FAILURE;   // optimizer.cc:74-78
-    if (api().e3d_reg_set_cache_observations(problem.reg, cache_observations ? 1 : 0) < 0) { std::cerr << api().e3d_last_error() << std::endl; return EXIT_FAILURE; }
+    if (!problem.all_regs([&](e3d_reg_t* r) { return api().e3d_reg_set_cache_observations(r, cache_observations ? 1 : 0); }, "e3d_reg_set_cache_observations")) return EXIT_FAILURE;
     double optimum_cost = 0;
-    int iterations = 0;
-    if (api().e3d_reg_run_on_current_scale(problem.reg, max_iterations, kMaxChangeConvergenceThreshold, kIterationsWithoutNewOptimumThreshold,
-                                           /*print_progress*/ 1, &optimum_cost, &iterations) < 0) {
-      std::cerr << "optimisation failed: " << api().e3d_last_error() << std::endl;
+    // every rank runs the same loop on its images (rank 0 prints); costs, H and b are all-reduced inside
+    std::vector<double> costs((size_t)problem.world(), 0.0);
+    std::vector<int> iters((size_t)problem.world(), 0);
+    if (!problem.all_regs_parallel([&](e3d_reg_t* r, int k) {
+          return api().e3d_reg_run_on_current_scale(r, max_iterations, kMaxChangeConvergenceThreshold, kIterationsWithoutNewOptimumThreshold,
+                                                    /*print_progress*/ k == 0 ? 1 : 0, &costs[(size_t)k], &iters[(size_t)k]);
+        }, "optimisation failed"))
       return EXIT_FAILURE;
-    }
+    optimum_cost = costs[0];
     const double current_scaling_factor = std::pow(2, -1 * current_image_scale);
 
     if (!problem.ReadBackState()) return EXIT_FAILURE;

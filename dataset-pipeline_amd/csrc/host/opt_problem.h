@@ -264,10 +264,35 @@ class Problem {
   std::vector<std::vector<float>> points;       // per point scale: n x 3
   std::vector<std::vector<float>> colors;       // multi_res_colors
   std::vector<std::vector<uint32_t>> neighbors; // neighbor_point_indices_ (n * K)
-  e3d_reg_t* reg = nullptr;
+  e3d_reg_t* reg = nullptr;                     // rank 0's device problem (the only one without --gpus)
+  // --gpus N: one device problem per GPU, images sharded (image id mod N), the library's RCCL communicator between them
+  std::vector<e3d_reg_t*> regs;
+  std::vector<e3d_comm_t*> comms;
   std::string occlusion_mesh_path, occlusion_splats_path;       // empty: splats of the scan points
 
-  ~Problem() { if (reg) api().e3d_reg_destroy(reg); }
+  ~Problem() {
+    for (e3d_reg_t* r : regs) if (r) api().e3d_reg_destroy(r);
+    for (e3d_comm_t* c : comms) if (c) api().e3d_comm_destroy(c);
+  }
+  int world() const { return (int)std::max<size_t>(regs.size(), 1); }
+  e3d_reg_t* owner(int image_id) const { const int w = world(); return regs[(size_t)(((image_id % w) + w) % w)]; }
+  // the same call on every rank's device problem (state every rank keeps: intrinsics, poses, points, rigs, options)
+  template <class F> bool all_regs(F f, const char* what) {
+    for (e3d_reg_t* r : regs) if (f(r) < 0) return lib_fail(what);
+    return true;
+  }
+  // a collective step: every rank from its own host thread
+  template <class F> bool all_regs_parallel(F f, const char* what) {
+    std::vector<int> res(regs.size(), 0);
+    std::vector<std::string> err(regs.size());
+    auto work = [&](size_t k) { res[k] = f(regs[k], (int)k); if (res[k] < 0) err[k] = api().e3d_last_error(); };
+    std::vector<std::thread> th;
+    for (size_t k = 1; k < regs.size(); ++k) th.emplace_back(work, k);
+    work(0);
+    for (std::thread& t : th) t.join();
+    for (size_t k = 0; k < regs.size(); ++k) if (res[k] < 0) { std::cerr << what << ": " << err[k] << std::endl; return false; }
+    return true;
+  }
 
   bool fail(const std::string& what) const { std::cerr << what << std::endl; return false; }
   bool lib_fail(const char* what) const { std::cerr << what << ": " << api().e3d_last_error() << std::endl; return false; }
@@ -493,8 +518,7 @@ class Problem {
       float bmin[3], bmax[3];
       if (api().e3d_transform_cloud(xyz.data(), nullptr, xyz.size() / 3, T, global.data(), nullptr, bmin, bmax) < 0) return lib_fail("e3d_transform_cloud");
       if (compute_edges) std::cout << "computing edges" << std::endl;
-      if (api().e3d_reg_add_occlusion_mesh(reg, global.data(), global.size() / 3, tris.data(), tris.size() / 3, compute_edges ? 1 : 0) < 0)
-        return lib_fail("e3d_reg_add_occlusion_mesh");
+      if (!all_regs([&](e3d_reg_t* r) { return api().e3d_reg_add_occlusion_mesh(r, global.data(), global.size() / 3, tris.data(), tris.size() / 3, compute_edges ? 1 : 0); }, "e3d_reg_add_occlusion_mesh")) return false;
       return true;
     };
     const std::string ext = path.size() >= 4 ? path.substr(path.size() - 4) : std::string();
@@ -561,6 +585,7 @@ class Problem {
     const size_t n = pts.size() / 3;
     std::cout << "ComputeMultiResPointCloud(): Creating multi-res point cloud ..." << std::endl;
     std::vector<float> min_radius(n), max_radius(n);
+    if (regs.size() > 1) return fail("the multi-resolution point cloud is built on one GPU (every image on one device): run once without --gpus, or let the tool do it (it does when the directory is missing)");
     if (api().e3d_reg_point_radius_minmax(reg, pts.data(), n, min_radius.data(), max_radius.data()) < 0) return lib_fail("e3d_reg_point_radius_minmax");
     float min_radius_value = INFINITY, max_radius_value = -INFINITY;
     for (size_t i = 0; i < n; ++i) { min_radius_value = std::min(min_radius_value, min_radius[i]); max_radius_value = std::max(max_radius_value, max_radius[i]); }
@@ -694,14 +719,27 @@ class Problem {
     rp.splat_radius = prm.splat_radius;
     rp.current_image_scale = 0;
     rp.image_scale_count = image_scale_count;
-    reg = api().e3d_reg_create(&rp);
-    if (!reg) return lib_fail("e3d_reg_create");
+    const int n_gpus = gpu_count_setting();
+    if (n_gpus > 1) {
+      comms.assign((size_t)n_gpus, nullptr);
+      if (api().e3d_comm_create_all(n_gpus, nullptr, comms.data()) < 0) return lib_fail("e3d_comm_create_all");
+    }
+    for (int r = 0; r < n_gpus; ++r) {
+      if (n_gpus > 1 && api().e3d_init(r) < 1) return lib_fail("e3d_init");
+      e3d_reg_t* h = api().e3d_reg_create(&rp);
+      if (!h) return lib_fail("e3d_reg_create");
+      regs.push_back(h);
+      if (n_gpus > 1 && api().e3d_reg_set_comm(h, comms[(size_t)r]) < 0) return lib_fail("e3d_reg_set_comm");
+    }
+    if (n_gpus > 1) api().e3d_init(0);
+    reg = regs[0];
     reg_params = rp;
 
     for (const HostIntrinsics& in : intrinsics_list)
-      if (api().e3d_reg_set_intrinsics(reg, in.intrinsics_id, in.model, in.width, in.height, in.params, in.n_params, in.min_image_scale,
-                                       image_scale_count - in.min_image_scale) < 0)
-        return lib_fail("e3d_reg_set_intrinsics");
+      if (!all_regs([&](e3d_reg_t* r) { return api().e3d_reg_set_intrinsics(r, in.intrinsics_id, in.model, in.width, in.height, in.params, in.n_params,
+                                                                             in.min_image_scale, image_scale_count - in.min_image_scale); },
+                    "e3d_reg_set_intrinsics"))
+        return false;
 
     std::cout << "LoadImages(): Reading image data ..." << std::endl;
     // Decoding (PNG inflate / JPEG Huffman + IDCT, 0.4 - 0.6 s per 24 MP image) and the pyramids run on up to 16 host threads, a batch
@@ -787,17 +825,21 @@ class Problem {
         fit(pyr[l]); lp[l] = pyr[l].data.data();
         if (!mask.empty()) { fit(mask[l]); lm[l] = mask[l].data.data(); }
       }
-      if (api().e3d_reg_set_image(reg, im.image_id, im.intrinsics_id, lp.data(), mask.empty() ? nullptr : lm.data()) < 0) return lib_fail("e3d_reg_set_image");
-      if (api().e3d_reg_set_image_pose(reg, im.image_id, im.image_T_global.q, im.image_T_global.t) < 0) return lib_fail("e3d_reg_set_image_pose");
+      // pixels go to the image's owner only; every rank knows the image and its pose
+      for (e3d_reg_t* r : regs) {
+        const bool mine = r == owner(im.image_id);
+        if (api().e3d_reg_set_image(r, im.image_id, im.intrinsics_id, mine ? lp.data() : nullptr, (mine && !mask.empty()) ? lm.data() : nullptr) < 0) return lib_fail("e3d_reg_set_image");
+        if (api().e3d_reg_set_image_pose(r, im.image_id, im.image_T_global.q, im.image_T_global.t) < 0) return lib_fail("e3d_reg_set_image_pose");
+      }
     }
     }
     for (const HostRig& rig : rigs) {
       std::vector<float> q, t;
       for (const Pose7& p : rig.image_T_rig) { q.insert(q.end(), p.q, p.q + 4); t.insert(t.end(), p.t, p.t + 3); }
-      if (api().e3d_reg_set_rig(reg, rig.rig_id, (int)rig.image_T_rig.size(), q.data(), t.data()) < 0) return lib_fail("e3d_reg_set_rig");
+      if (!all_regs([&](e3d_reg_t* r) { return api().e3d_reg_set_rig(r, rig.rig_id, (int)rig.image_T_rig.size(), q.data(), t.data()); }, "e3d_reg_set_rig")) return false;
     }
     for (const HostRigImages& f : rig_images)
-      if (api().e3d_reg_add_rig_images(reg, f.rig_id, f.image_ids.data(), (int)f.image_ids.size()) < 0) return lib_fail("e3d_reg_add_rig_images");
+      if (!all_regs([&](e3d_reg_t* r) { return api().e3d_reg_add_rig_images(r, f.rig_id, f.image_ids.data(), (int)f.image_ids.size()); }, "e3d_reg_add_rig_images")) return false;
 
     return true;
   }
@@ -805,9 +847,9 @@ class Problem {
   // the occlusion geometry: meshes if given (optionally moved by `left`, a row-major 3x4 transform applied after each mesh's own
   // pose -- GroundTruthCreator's first_scan_up_transformation), else 2D splats of all scan points
   bool SetOcclusionGeometry(const std::vector<float>& occlusion_points, const float* left) {
-    if (api().e3d_reg_set_occlusion_options(reg, prm.min_occlusion_depth, prm.max_occlusion_depth, 1) < 0) return lib_fail("e3d_reg_set_occlusion_options");
+    if (!all_regs([&](e3d_reg_t* r) { return api().e3d_reg_set_occlusion_options(r, prm.min_occlusion_depth, prm.max_occlusion_depth, 1); }, "e3d_reg_set_occlusion_options")) return false;
     if (occlusion_mesh_path.empty() && occlusion_splats_path.empty()) {
-      if (api().e3d_reg_set_splat_points(reg, occlusion_points.data(), occlusion_points.size() / 3) < 0) return lib_fail("e3d_reg_set_splat_points");
+      if (!all_regs([&](e3d_reg_t* r) { return api().e3d_reg_set_splat_points(r, occlusion_points.data(), occlusion_points.size() / 3); }, "e3d_reg_set_splat_points")) return false;
     } else {
       if (!occlusion_mesh_path.empty() && !AddOcclusionMesh(occlusion_mesh_path, true, left)) return false;
       if (!occlusion_splats_path.empty() && !AddOcclusionMesh(occlusion_splats_path, false, left)) return false;
@@ -835,8 +877,7 @@ class Problem {
         for (size_t p = 0; p < n; ++p)
           for (int k = 0; k < K; ++k) desc[p * K + k] = colors[s][neighbors[s][p * K + k]] - colors[s][p];      // ComputeDescriptor
       }
-      if (api().e3d_reg_set_point_scale(reg, (int)s, points[s].data(), n, point_radii[s], neighbors[s].data(), use_fixed ? desc.data() : nullptr) < 0)
-        return lib_fail("e3d_reg_set_point_scale");
+      if (!all_regs([&](e3d_reg_t* r) { return api().e3d_reg_set_point_scale(r, (int)s, points[s].data(), n, point_radii[s], neighbors[s].data(), use_fixed ? desc.data() : nullptr); }, "e3d_reg_set_point_scale")) return false;
     }
     return true;
   }
@@ -869,14 +910,14 @@ class Problem {
           ok = fread(&n, sizeof(uint64_t), 1, f) == 1;
           std::vector<uint64_t> list(ok ? n : 0);
           ok = ok && fread(list.data(), sizeof(uint64_t), n, f) == n;
-          if (ok && api().e3d_reg_set_observed_indices(reg, kv.first, ps, list.data(), list.size()) < 0) { fclose(f); return lib_fail("e3d_reg_set_observed_indices"); }
+          if (ok && api().e3d_reg_set_observed_indices(owner(kv.first), kv.first, ps, list.data(), list.size()) < 0) { fclose(f); return lib_fail("e3d_reg_set_observed_indices"); }
         }
         fclose(f);
         if (!ok) return fail("Cannot read observed point indices: " + fn + " (file corrupted?)");
       }
       return true;
     }
-    if (api().e3d_reg_determine_observed_indices(reg) < 0) return lib_fail("e3d_reg_determine_observed_indices");
+    if (!all_regs_parallel([&](e3d_reg_t* r, int) { return api().e3d_reg_determine_observed_indices(r); }, "e3d_reg_determine_observed_indices")) return false;
     for (auto& kv : images) {
       const std::string fn = file_of(kv.second);
       create_directories(path_parent(fn));
@@ -884,10 +925,10 @@ class Problem {
       if (!f) return fail("Cannot write " + fn);
       fwrite(&scale_count, sizeof(int), 1, f);
       for (int ps = 0; ps < scale_count; ++ps) {
-        const int64_t n = api().e3d_reg_get_observed_indices(reg, kv.first, ps, nullptr);
+        const int64_t n = api().e3d_reg_get_observed_indices(owner(kv.first), kv.first, ps, nullptr);
         if (n < 0) { fclose(f); return lib_fail("e3d_reg_get_observed_indices"); }
         std::vector<uint64_t> list((size_t)n);
-        if (n && api().e3d_reg_get_observed_indices(reg, kv.first, ps, list.data()) < 0) { fclose(f); return lib_fail("e3d_reg_get_observed_indices"); }
+        if (n && api().e3d_reg_get_observed_indices(owner(kv.first), kv.first, ps, list.data()) < 0) { fclose(f); return lib_fail("e3d_reg_get_observed_indices"); }
         const uint64_t count = (uint64_t)n;
         fwrite(&count, sizeof(uint64_t), 1, f);
         fwrite(list.data(), sizeof(uint64_t), list.size(), f);

@@ -121,6 +121,23 @@ typedef int (*e3d_allreduce_fn)(double* buffer, size_t count, void* user);
 int e3d_icp_set_shard(e3d_icp_t* icp, int rank, int world_size,
                       e3d_allreduce_fn allreduce, void* user);
 
+/* Native collectives: an RCCL communicator owned by the library (one rank per GPU, xGMI inside a node).  The per-pair
+ * normal-equation blocks of every LM pass are reduced on the GPU and all-reduced in place on the handle's stream, the
+ * counts once per outer iteration; no host hop and no callback.  Ranks are either processes (rank 0: e3d_comm_unique_id,
+ * the 128 bytes travel through the launcher's rendezvous, every rank: e3d_comm_create) or host threads of one process
+ * (e3d_comm_create_all: out[i] is the communicator of devices[i], devices == NULL means 0..n-1).  world_size = 1 is valid
+ * (the collectives then run with a single rank).  e3d_icp_set_comm replaces e3d_icp_set_shard; the communicator must
+ * outlive the handle. */
+#define E3D_COMM_ID_BYTES 128
+typedef struct e3d_comm e3d_comm_t;
+int e3d_comm_unique_id(char id[E3D_COMM_ID_BYTES]);
+e3d_comm_t* e3d_comm_create(const char id[E3D_COMM_ID_BYTES], int rank, int world_size, int device);
+int e3d_comm_create_all(int n_devices, const int* devices, e3d_comm_t** out);
+void e3d_comm_destroy(e3d_comm_t* comm);
+int e3d_comm_rank(const e3d_comm_t* comm);
+int e3d_comm_world_size(const e3d_comm_t* comm);
+int e3d_icp_set_comm(e3d_icp_t* icp, e3d_comm_t* comm);
+
 /* ---- stand-alone kernels behind the same arithmetic (parity tests, other callers) ------ */
 
 /* FindCorrespondencesFast(source, target, max_correspondence_distance)
@@ -372,6 +389,9 @@ int64_t e3d_merge_close_points(float merge_distance, int num_scans, const float*
 typedef int (*e3d_allreduce_device_fn)(void* device_buffer, size_t count, int dtype, void* user);
 int e3d_reg_set_shard(e3d_reg_t* reg, int rank, int world_size, e3d_allreduce_fn allreduce,
                       e3d_allreduce_device_fn allreduce_device, void* user);
+/* The same sharding with the library's own RCCL communicator (see e3d_comm_create): the block-sparse normal equations, the
+ * residual sums and the variable descriptors are all-reduced on the handle's stream; call before the images are set. */
+int e3d_reg_set_comm(e3d_reg_t* reg, e3d_comm_t* comm);
 int e3d_reg_image_owner(e3d_reg_t* reg, int image_id);
 
 #ifdef __cplusplus

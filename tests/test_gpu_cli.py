@@ -127,3 +127,25 @@ def test_point_cloud_cleaner_cli(tmp_path, ob):
     exp_out_p = np.concatenate([pts[~k1], p1[~k2]]); exp_out_c = np.concatenate([rgb[~k1], c1[~k2]])
     assert np.array_equal(outl["p"], exp_out_p) and np.array_equal(outl["c"], exp_out_c)
     assert len(inl) + len(outl) == len(pts) and 300 < len(outl) < 5000
+
+
+def test_icp_scan_aligner_gpus_flag(tmp_path, synth, e3d):
+    """--gpus N (one host thread per GPU, the library's RCCL communicator): same correspondence counts on stdout and the same
+    result poses (1e-5 rad / 1e-4 m) as the single-GPU run.  Needs more than one visible GPU; asking for more GPUs than there
+    are is refused with a message."""
+    _project(tmp_path, synth, 3, 20000, seed=79, binary=True)
+    n_dev = int(e3d.lib().e3d_init(0))
+    base = [os.path.join(BIN, "ICPScanAligner"), "-i", str(tmp_path / "in.mlp"), "-d", "0.15", "--max_iterations", "3",
+            "--convergence_threshold", "1e-10", "--normal_estimation_neighbor_count", "16"]
+    r = subprocess.run(base + ["-o", str(tmp_path / "too_many.mlp"), "--gpus", str(n_dev + 1)], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "HIP device" in (r.stdout + r.stderr)
+    if n_dev < 2:
+        pytest.skip("one visible GPU: the multi-GPU tool path needs at least two")
+    r1 = subprocess.run(base + ["-o", str(tmp_path / "one.mlp")], capture_output=True, text=True, timeout=300)
+    rn = subprocess.run(base + ["-o", str(tmp_path / "many.mlp"), "--gpus", str(n_dev)], capture_output=True, text=True, timeout=300)
+    assert r1.returncode == 0 and rn.returncode == 0, rn.stdout + rn.stderr
+    pat = r"found correspondences from (fixed clouds|\d+) to (fixed clouds|\d+): (\d+)"
+    assert re.findall(pat, r1.stdout) == re.findall(pat, rn.stdout)
+    for a, b in zip(read_mlp(str(tmp_path / "one.mlp")), read_mlp(str(tmp_path / "many.mlp"))):
+        ang, tr = pose_error(a[2], b[2])
+        assert ang <= 1e-5 and tr <= 1e-4

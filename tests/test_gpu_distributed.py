@@ -172,3 +172,131 @@ def test_reg_image_sharding_equals_single_rank(e3d, world, model):
     # a rank cannot touch an image it does not own
     with pytest.raises(e3d.E3DError):
         probs[0].render_depth(1, 0)
+
+
+# ---- native RCCL: the library's own communicator (e3d_comm_*), one rank per visible GPU ------------------------------------
+def _device_count(e3d):
+    return max(int(e3d.lib().e3d_init(0)), 1)
+
+
+def test_native_rccl_icp_equals_single_rank(e3d, synth):
+    """e3d_icp_set_comm: per-pair normal-equation blocks, costs and counts all-reduced by RCCL on the handles' streams.  World =
+    number of visible GPUs (one host thread per GPU, ncclCommInitAll); on a 1-GPU box the collectives still run (world 1).
+    Counts and convergence flag equal the single-rank run, poses agree to 1e-5 rad / 1e-4 m, all ranks end bit-identical."""
+    world = _device_count(e3d)
+    scans = synth.make_scene(3, 30000, seed=12)
+    clouds = [(s["xyz"].numpy(), s["normals"].numpy(), s["T_init"], i == 2) for i, s in enumerate(scans)]
+    d, iters, thr = 0.12, 4, 1e-9
+    ref = e3d.PointToPlaneICP(device=0)
+    ids = [ref.add_point_cloud(*c) for c in clouds]
+    conv_ref = ref.run(d, 0, iters, thr, False)
+
+    comms = e3d.Comm.create_all(world)
+    assert [c.rank for c in comms] == list(range(world)) and all(c.world_size == world for c in comms)
+    handles, errors, conv = [], [], [None] * world
+    for r in range(world):
+        h = e3d.PointToPlaneICP(device=r)
+        for c in clouds:
+            h.add_point_cloud(*c)
+        h.set_comm(comms[r])
+        handles.append(h)
+
+    def work(r):
+        try:
+            conv[r] = handles[r].run(d, 0, iters, thr, False)
+        except Exception as ex:  # noqa: BLE001
+            errors.append(ex)
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(300)
+    assert not errors, errors
+    ref_counts = [(r[0], r[1], r[2], r[3]) for r in ref.pair_records()]
+    for r, h in enumerate(handles):
+        assert conv[r] == conv_ref
+        assert [(x[0], x[1], x[2], x[3]) for x in h.pair_records()] == ref_counts
+        for i in ids:
+            if i >= 0:
+                ang, tr = pose_error(h.get_result_global_T_cloud(i), ref.get_result_global_T_cloud(i))
+                assert ang <= 1e-5 and tr <= 1e-4
+                assert np.array_equal(h.get_result_global_T_cloud(i), handles[0].get_result_global_T_cloud(i))
+        if world == 1:      # a single rank sums the same blocks in the same order: bit for bit the plain run
+            for i in ids:
+                if i >= 0:
+                    assert np.array_equal(h.get_result_global_T_cloud(i), ref.get_result_global_T_cloud(i))
+    q0 = ref.iter_records()[0]["queries"]
+    assert sum(h.iter_records()[0]["queries"] for h in handles) == q0
+    for c in comms:
+        c.destroy()
+
+
+def test_native_rccl_unique_id_path(e3d, synth):
+    """The process-per-GPU path of bench.py: e3d_comm_unique_id -> e3d_comm_create(rank, world) (world 1 here)."""
+    uid = e3d.Comm.unique_id()
+    assert len(uid) == 128
+    comm = e3d.Comm(uid, 0, 1, 0)
+    scans = synth.make_scene(2, 20000, seed=5)
+    a, b = e3d.PointToPlaneICP(device=0), e3d.PointToPlaneICP(device=0)
+    for s in scans:
+        a.add_point_cloud(s["xyz"].numpy(), s["normals"].numpy(), s["T_init"], False)
+        b.add_point_cloud(s["xyz"].numpy(), s["normals"].numpy(), s["T_init"], False)
+    b.set_comm(comm)
+    a.run(0.1, 0, 3, 1e-9, False); b.run(0.1, 0, 3, 1e-9, False)
+    assert [x[:4] for x in a.pair_records()] == [x[:4] for x in b.pair_records()]
+    assert np.array_equal(a.get_result_global_T_cloud(1), b.get_result_global_T_cloud(1))
+    comm.destroy()
+
+
+def test_native_rccl_reg_equals_single_rank(e3d):
+    """e3d_reg_set_comm: image sharding with the library's communicator (block-sparse H / b / sums staged through HBM, the
+    variable descriptors all-reduced in place).  World = visible GPUs."""
+    from reg_util import make_multi_image_scene
+    from test_gpu_reg import _pose_delta
+    world = _device_count(e3d)
+    M = make_multi_image_scene(n_points=6000, n_images=4, seed=8, perturb=0.006, model=2)
+
+    def build(comm=None, device=0):
+        e3d.lib().e3d_init(device)
+        P = e3d.RegProblem(e3d.default_reg_params(image_scale_count=M["n_levels"], point_neighbor_count=M["K"]))
+        if comm is not None:
+            P.set_comm(comm)
+        P.set_intrinsics(0, M["width"], M["height"], M["params"], 0, M["n_levels"], camera_type=2)
+        P.set_point_scale(0, M["pts"], M["point_radius"], M["nbr"], M["fixed_desc"])
+        P.set_splat_points(M["pts"])
+        for i, im in enumerate(M["images"]):
+            owned = comm is None or (i % comm.world_size) == comm.rank
+            P.set_image(i, 0, im["pyr"] if owned else None)
+            P.set_image_pose(i, im["q_init"], im["t_init"])
+        return P
+
+    ref = build()
+    r_ref = ref.run_on_current_scale(5, 0.0, 15, False)
+    comms = e3d.Comm.create_all(world)
+    probs = [build(comms[r], r) for r in range(world)]
+    e3d.lib().e3d_init(0)
+    results, errors = [None] * world, []
+
+    def work(r):
+        try:
+            results[r] = probs[r].run_on_current_scale(5, 0.0, 15, False)
+        except Exception as ex:  # noqa: BLE001
+            errors.append(ex)
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(300)
+    assert not errors, errors
+    for r in range(world):
+        assert results[r][0] == r_ref[0] and results[r][2] == r_ref[2]
+        assert abs(results[r][1] - r_ref[1]) <= 1e-6 * r_ref[1]
+        for i in range(len(M["images"])):
+            ang, tr = _pose_delta(*probs[r].get_image_pose(i), *ref.get_image_pose(i))
+            assert ang <= 1e-5 and tr <= 1e-5
+            q0, t0 = probs[0].get_image_pose(i); q1, t1 = probs[r].get_image_pose(i)
+            assert np.array_equal(q0, q1) and np.array_equal(t0, t1)
+    for c in comms:
+        c.destroy()

@@ -1,24 +1,35 @@
 #!/usr/bin/env python
-"""bench.py -- ICPScanAligner hot path on MI355X (BASELINE.json metric: ICP correspondences/sec + ms/iter).
+"""bench.py -- the ETH3D scan-alignment / image-registration hot paths on MI355X
+(BASELINE.json metric: ICP correspondences/sec + ms/iter; ImageRegistrator residuals/sec, 1/2/4/8 GPU).
 
     python bench.py --gpus N --steps K --warmup W
 
-Workload (N=1): BASELINE.json configs[1] -- ICPScanAligner on 2 scans of ~50 M points each,
-`-d 0.01 --max_iterations 100` -- on seeded synthetic scans of that shape generated directly in HBM (no
-network / no terrace data here).  A "step" is one outer ICP iteration, i.e. one
-PointToPlaneICP::Run(d, it, /*max_num_iterations*/1, thr) exactly as the tool's loop calls it
-(src/exe/icp_scan_aligner.cc:342-343): transform + bbox, exact 1-NN correspondence search for both directed
-pairs, and the full inner Levenberg-Marquardt solve (<= 150 iterations x (1 + <= 10 tries)).
-Nothing is skipped or cached inside the timed region; inputs are resident in HBM before it starts.
+Headline (`value`): BASELINE.json configs[1] -- ICPScanAligner on 2 scans of ~50 M points each, `-d 0.01` -- on seeded synthetic
+scans of that shape generated directly in HBM (no network / no terrace data here).  A "step" is one outer ICP iteration, i.e. one
+PointToPlaneICP::Run(d, it, /*max_num_iterations*/1, thr) exactly as the tool's loop calls it (src/exe/icp_scan_aligner.cc:342-343):
+transform + bbox, exact 1-NN correspondence search for both directed pairs, and the full inner Levenberg-Marquardt solve
+(<= 150 iterations x (1 + <= 10 tries)).  Nothing is skipped or cached inside the timed region; inputs are resident in HBM first.
 
-N>1 (one process per GPU, torch.distributed / RCCL): weak scaling -- every scan has 50 M x N points, every rank
-holds both scans and handles 1/N of each directed pair's queries and correspondences; the 6x6 normal
-equations + cost are all-reduced once per LM pass.
+N > 1: one process per GPU.  Launched by torchrun (RANK / WORLD_SIZE in the environment) or, if not, bench.py spawns the N ranks
+itself.  The ranks talk through the library's own RCCL communicator (e3d_comm_*: per-pair normal-equation blocks all-reduced in HBM
+on the library's stream); torch.distributed (gloo) only carries the 128-byte communicator id, the barriers and the max-over-ranks
+time.  Headline at N > 1 = the same 2-scan job, weak scaling (N x the points on N x the floor area, every rank 1/N of each pair's
+queries) -- at N = 1 it is the BENCH workload.
+
+Further legs in the same JSON line:
+  allpairs           BASELINE.json north_star's scaling target / configs[2] shape: 16 scans all-pairs (240 directed pairs, 90-unknown
+                     LM system), STRONG scaling (same job at every N, every rank a slice of every pair) -- compare `allpairs.value`
+                     across N
+  image_registrator  (N = 1) configs[3] shape: 23 images of 6048 x 4032, THIN_PRISM_FISHEYE, ~10 M points, K = 5: residuals/s of the
+                     accumulate pass, per-kernel roofline from HIP events, ms per RunOnCurrentScale iteration
+  normal_estimation  (N = 1) SURVEY 8(d) (A'): normals/s for 20 M points, k = 32 and k = 8
+  cpu_baseline       the CPU restatement (oracle/, kind "port") on bounded samples of the same workloads, on this box's cores
 """
 import argparse
 import importlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -30,11 +41,20 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 ALG_BYTES_PER_CORR_PASS = 56   # 2 x i32 + 4 x vec3 f32 per correspondence per pass
 ALG_BYTES_PER_QUERY = 32       # 12 in + 8 out + 12 amortised target
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "round2_traffic.json")
+
+
+def load_traffic(kernel_key):
+    """HBM bytes per launch of a kernel from the committed rocprofv3 PMC passes of this same command (bench.py cannot run the
+    profiler itself): profiles/round2_traffic.json, written by tools/make_traffic_json.py."""
+    if not os.path.exists(TRAFFIC_JSON):
+        return None, None
+    k = json.load(open(TRAFFIC_JSON)).get("kernels", {}).get(kernel_key)
+    return (k["hbm_bytes_per_launch"], "profiles/round2_traffic.json") if k else (None, None)
 
 
 def crop_world(scan, lo, hi):
     """Points of a scan whose true world x lies in [lo, hi) (numpy, host)."""
-    import torch
     T = scan["T_true"]
     x = scan["xyz"]
     # elementwise on purpose: torch's gemv path returned wrong values for 50 M-row operands on this ROCm build
@@ -43,299 +63,413 @@ def crop_world(scan, lo, hi):
     return scan["xyz"][m].cpu().numpy(), scan["normals"][m].cpu().numpy()
 
 
-def cpu_baseline(scans, d, thr, slab):
-    """Reference-faithful CPU path (the oracle, "kind": "port") on a bounded sample of the same workload."""
+def cpu_baseline_icp(scans, d, thr, slab, n_points):
+    """Reference-faithful CPU path (the oracle, "kind": "port") on a bounded sample of the same workload: SURVEY 8(d): >= 3
+    outer iterations, median."""
     from oracle import binding as ob
     ob.lib()
-    o = ob.OracleICP()
-    n = []
+    clouds, n = [], []
     for s in scans:
         xyz, nrm = crop_world(s, slab[0], slab[1])
         n.append(int(xyz.shape[0]))
-        o.add_point_cloud(xyz, nrm, s["T_init"], False)
-    iters = 3
-    t0 = time.perf_counter()
-    for it in range(iters):
-        o.run(d, it, 1, thr, False)
-    dt = time.perf_counter() - t0
-    recs = o.iter_records()
-    corr = sum(r["correspondences"] for r in recs)
+        clouds.append((xyz, nrm, s["T_init"]))
+
+    def run(all_core):
+        o = ob.OracleICP()
+        if all_core:
+            o.set_all_core(True)
+        for (xyz, nrm, T) in clouds:
+            o.add_point_cloud(xyz, nrm, T, False)
+        times = []
+        for it in range(3):
+            t0 = time.perf_counter()
+            o.run(d, it, 1, thr, False)
+            times.append(time.perf_counter() - t0)
+        return o.iter_records(), times
+
+    recs, times = run(False)
+    med = int(np.argsort(times)[1])
     # SURVEY 8(d)(ii): the same sample with the NN phase spread over every host core (queries are independent; results and their
-    # order are unchanged); the inner LM stays on one thread as in the reference, so this is an upper bound for what more cores
-    # buy the reference's structure, not a different algorithm
-    o2 = ob.OracleICP()
-    o2.set_all_core(True)
-    for s in scans:
-        xyz, nrm = crop_world(s, slab[0], slab[1])
-        o2.add_point_cloud(xyz, nrm, s["T_init"], False)
-    t0 = time.perf_counter()
-    for it in range(iters):
-        o2.run(d, it, 1, thr, False)
-    dt2 = time.perf_counter() - t0
-    recs2 = o2.iter_records()
-    corr2 = sum(r["correspondences"] for r in recs2)
-    all_core = {"value": corr2 / dt2, "unit": "correspondences/s", "cores": os.cpu_count(), "ms_per_iter": dt2 / iters * 1e3,
-                "t_nn_s": sum(r["t_nn_s"] for r in recs2) / iters, "t_lm_s": sum(r["t_lm_s"] for r in recs2) / iters,
-                "same_correspondences": bool(corr2 == corr),
-                "note": "NN queries on all host cores (OpenMP), inner LM single-threaded; same slab and iterations"}
+    # order are unchanged); the inner LM stays on one thread as in the reference
+    recs2, times2 = run(True)
+    med2 = int(np.argsort(times2)[1])
+    frac = float(n[0] + n[1]) / float(2 * n_points)
     return {
-        "all_core": all_core,
-        "value": corr / dt, "unit": "correspondences/s", "cores": 2, "kind": "port",
-        "sample": "%d outer iterations on the world-x slab [%.2f, %.2f) m of both scans (%d + %d points, same density "
-                  "and flags, %.1f s of CPU work); NN phase on 2 threads (one per directed pair, as icp_point_to_plane.cc:208), "
-                  "inner LM single-threaded" % (iters, slab[0], slab[1], n[0], n[1], dt),
-        "ms_per_iter": dt / iters * 1e3, "correspondences": int(corr / iters),
-        "t_nn_s": sum(r["t_nn_s"] for r in recs) / iters, "t_lm_s": sum(r["t_lm_s"] for r in recs) / iters,
-        "lm_passes": int(sum(r["accumulate_passes"] + r["cost_passes"] for r in recs) / iters), "host_cores_available": os.cpu_count(),
+        "value": recs[med]["correspondences"] / times[med], "unit": "correspondences/s", "cores": 2, "kind": "port",
+        "sample": "median of 3 outer iterations on the world-x slab [%.2f, %.2f) m of both scans: %d + %d points = %.1f %% of the "
+                  "2 x %d of configs[1], same density and flags, %.1f s of CPU work; NN phase on 2 threads (one per directed pair, as "
+                  "icp_point_to_plane.cc:208), inner LM single-threaded" % (slab[0], slab[1], n[0], n[1], 100 * frac, n_points, sum(times)),
+        "ms_per_iter": times[med] * 1e3, "ms_per_iter_all": [t * 1e3 for t in times], "correspondences": int(recs[med]["correspondences"]),
+        "sample_fraction_of_configs1": frac,
+        "t_nn_s": recs[med]["t_nn_s"], "t_lm_s": recs[med]["t_lm_s"],
+        "lm_passes": int(recs[med]["accumulate_passes"] + recs[med]["cost_passes"]), "host_cores_available": os.cpu_count(),
+        "all_core": {"value": recs2[med2]["correspondences"] / times2[med2], "unit": "correspondences/s", "cores": os.cpu_count(),
+                     "ms_per_iter": times2[med2] * 1e3, "t_nn_s": recs2[med2]["t_nn_s"], "t_lm_s": recs2[med2]["t_lm_s"],
+                     "same_correspondences": bool([r["correspondences"] for r in recs2] == [r["correspondences"] for r in recs]),
+                     "note": "NN queries on all host cores (OpenMP), inner LM single-threaded; same slab and iterations"},
     }
 
 
-def reg_traffic(model, n_images):
-    """Measured HBM bytes of pass 1 + pass 2 for the leg's n_images launches (rocprofv3 PMC of this bench, per launch, from
-    profiles/round1_traffic.json: same 4K images and 4 M points)."""
-    path = os.path.join(ROOT, "profiles", "round1_traffic.json")
-    if not os.path.exists(path):
-        return None
-    k = json.load(open(path))["kernels"]
-    names = {0: ("k_reg_pass1<0, false>", "k_reg_pass2<8, 10, 0, 10, true>"), 2: ("k_reg_pass1<2, false>", "k_reg_pass2_mfma<5, 18>")}.get(model)
-    if not names or any(n not in k for n in names):
-        return None
-    return n_images * sum(k[n]["hbm_bytes_per_launch"] for n in names)
-
-
-def image_registrator_leg(e3d, synth, cpu=True):
-    """Second BASELINE.json metric: ImageRegistrator residuals/s = (#fixed + #variable colour residuals) / wall time of the
-    accumulate pass of IntrinsicsAndPoseOptimizer::Apply (src/opt/intrinsics_and_pose_optimizer.cc:87-92,624-837) over all
-    images of one GPU; also ms per full RunOnCurrentScale iteration.  4 synthetic 3840x2160 images (6 pyramid levels,
-    configs[4] shape), 4 M points, K = 5, for the 4-parameter PINHOLE and the 12-parameter THIN_PRISM_FISHEYE model."""
-    out = {}
-    for model, name in ((0, "PINHOLE"), (2, "THIN_PRISM_FISHEYE")):
-        Wl = synth.make_reg_workload(n_points=4_000_000, n_images=4, model=model)
-        P = e3d.RegProblem(e3d.default_reg_params(image_scale_count=Wl["n_levels"], point_neighbor_count=Wl["K"]))
-        P.set_intrinsics(0, Wl["width"], Wl["height"], Wl["params"], 0, Wl["n_levels"], camera_type=model)
-        P.set_point_scale(0, Wl["pts"], Wl["point_radius"], Wl["nbr"], Wl["fixed_desc"])
-        P.set_splat_points(Wl["pts"])
-        ids = list(range(len(Wl["images"])))
-        for i, im in enumerate(Wl["images"]):
-            P.set_image(i, 0, im["pyr"]); P.set_image_pose(i, im["q"], im["t"])
-        P.update_observations(1)                                   # cold call: buffer growth, first launches
-        t0 = time.perf_counter(); P.update_observations(1); t_obs = time.perf_counter() - t0
-        # ObservationsCache path (the reference's mode after the first image scale): indexed re-projection, no depth rendering
-        P.determine_observed_indices(); P.set_cache_observations(True); P.update_observations(1)
-        t0 = time.perf_counter(); P.update_observations(1); t_obs_cached = time.perf_counter() - t0
-        P.set_cache_observations(False); P.update_observations(1)
-        t0 = time.perf_counter(); P.color_update(); t_col = time.perf_counter() - t0
-        for i in ids:
-            P.accumulate(i, 0)
-        reps = 3
-        t0 = time.perf_counter()
-        res = 0
-        for _ in range(reps):
-            for i in ids:
-                _, _, _, c = P.accumulate(i, 0)
-                res += int(c[0] + c[1])
-        t_acc = (time.perf_counter() - t0) / reps
-        res //= reps
-        t0 = time.perf_counter(); P.compute_cost(); t_cost = time.perf_counter() - t0
-        t0 = time.perf_counter(); _, _, its = P.run_on_current_scale(2, 0.0, 15, False); t_run = time.perf_counter() - t0
-        I = len(Wl["params"]); r4 = (I + 10) // 4; K = Wl["K"]
-        obs = res // 2
-        alg = obs * (16 * r4 + K * (4 + 16 * r4) + 8 * K + 9)          # own row + K x (row slot, neighbour row) + descriptors + idx/flag/count
-        out[name] = {"residuals_per_s": res / t_acc, "accumulate_ms": t_acc * 1e3, "images": len(ids), "points": len(Wl["pts"]),
-                     "residuals": res, "unknowns_per_image_block": I + 6,
-                     "observation_refresh_ms": t_obs * 1e3, "cached_observation_refresh_ms": t_obs_cached * 1e3, "colour_update_ms": t_col * 1e3, "cost_ms": t_cost * 1e3,
-                     "ms_per_run_iteration": t_run / max(its, 1) * 1e3,
-                     "roofline": {"bound": "hbm", "achieved": alg / t_acc / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                  "frac": alg / t_acc / 1e9 / HBM_PEAK_GBS, "traffic": reg_traffic(model, len(ids)),
-                                  "kernel": "k_reg_pass1 + %s (+ reduce, read-back) of e3d_reg_accumulate" % ("k_reg_pass2" if I + 6 == 10 else "k_reg_pass2_mfma (v_mfma_f64_16x16x4_f64)"),
-                                  "algorithmic_bytes": alg}}
-        del P
-    if cpu:
-        from oracle import reg_binding as rb
-        from oracle.reg_driver import OracleRegProblem
-        Wl = synth.make_reg_workload(n_points=4_000_000, n_images=1, model=0)           # one image of the GPU workload
-        O = OracleRegProblem(K=Wl["K"], image_scale_count=Wl["n_levels"])
-        O.set_intrinsics(0, Wl["width"], Wl["height"], Wl["params"], 0, Wl["n_levels"])
-        O.set_point_scale(0, Wl["pts"], Wl["point_radius"], Wl["nbr"], Wl["fixed_desc"])
-        O.set_splat_points(Wl["pts"])
-        O.set_image(0, 0, Wl["images"][0]["pyr"]); O.set_image_pose(0, Wl["images"][0]["q"], Wl["images"][0]["t"])
-        O.update_observations(1); O.color_update()
-        S = O.scales[0]; im = O.images[0]; I0 = O.intr[0]; o = O.obs[(0, 0)]
-        reps = 8
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            _, _, _, c = rb.accumulate(S["pts"], float(S["radius"]), S["nbr"], O.K, S["fixed"], S["var"], S["counts"], I0["levels"][0], I0["min"],
-                                       im["pyr"], O._R(im), im["t"], o[:4], o[4], O.robust_type, O.robust_param, O.fixed_weight, O.var_weight)
-        tc = (time.perf_counter() - t0) / reps
-        out["cpu_baseline"] = {"value": float(c[0] + c[1]) / tc, "unit": "residuals/s", "cores": 1, "kind": "port",
-                               "sample": "%d accumulate passes (oracle_reg_accumulate, single thread like the reference) of one 3840x2160 "
-                                         "PINHOLE image, 4 M points, K = 5: %d residuals in %.2f s each" % (reps, int(c[0] + c[1]), tc)}
-        out["speedup_vs_cpu"] = out["PINHOLE"]["residuals_per_s"] / out["cpu_baseline"]["value"]
-    return out
-
-
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--points", type=int, default=0, help="points per scan (default 50 M x gpus)")
-    ap.add_argument("--distance", type=float, default=0.01)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-reg", action="store_true", help="skip the ImageRegistrator leg (N=1 only)")
-    args = ap.parse_args()
-
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
-
-    import torch
-    import torch.distributed as dist
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no HIP device visible)")
-    # E3D_BENCH_SHARE_GPU=1: all ranks on GPU 0 with the gloo backend -- only for smoke-testing the multi-rank code
-    # path on a 1-GPU box; real runs use one GPU per rank and RCCL ("nccl").
-    share_gpu = os.environ.get("E3D_BENCH_SHARE_GPU", "0") == "1"
-    if share_gpu:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if share_gpu:
-            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
-
-    e3d = importlib.import_module("dataset-pipeline_amd")
-    synth = importlib.import_module("dataset-pipeline_amd.synth")
-    if e3d.lib().e3d_init(local_rank) < 1:
-        raise SystemExit("libe3dhip: no device")
-
-    n_points = args.points if args.points > 0 else 50_000_000 * world
-    d = float(args.distance)
-    thr = 1e-10     # README.md:101 recommended flags; never converges within the bench's few iterations
-
-    # weak scaling: N times the points on N times the floor area (the room stretched by sqrt(N) in x and y), i.e. the point density
-    # -- and with it the candidates per query -- of the 1-GPU workload; every rank then searches its 1/N of the queries
-    room_scale = float(np.sqrt(n_points / 50_000_000.0)) if (world > 1 and args.points == 0) else 1.0
-    scans = synth.make_scene(2, n_points, seed=1234, sigma=0.002, device=dev, room_scale=room_scale)
-    torch.cuda.synchronize()
-    icp = e3d.PointToPlaneICP(device=local_rank)
-    for s in scans:
-        icp.add_point_cloud(s["xyz"], s["normals"], s["T_init"], False)
-
-    base = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        # slab width chosen for ~4 M points per scan at this density (floor + two walls = 16 m^2 per metre of x): about
-        # 10 s of CPU work for the 3 timed iterations (kd-tree builds + searches + inner LM)
-        width = min(10.0, 4.0e6 / (n_points / 242.6 * 16.0))
-        base = cpu_baseline(scans, d, thr, (4.0, 4.0 + width))
-    for s in scans:
-        del s["xyz"], s["normals"]
-    torch.cuda.empty_cache()
-
-    if world > 1:
-        importlib.import_module("dataset-pipeline_amd.dist").attach(icp, device=dev)
-
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for it in range(args.warmup):
-        icp.run(d, it, 1, thr, False)
-    warm_nn_ms = [r["t_nn_query_ms"] for r in icp.iter_records()]      # reported so that the rocprof per-launch average can be reconciled
-    icp.clear_records()
-    barrier()
-    t0 = time.perf_counter()
-    for it in range(args.warmup, args.warmup + args.steps):
-        icp.run(d, it, 1, thr, False)
-    barrier()
-    dt = time.perf_counter() - t0
-    recs = icp.iter_records()
-    local = np.array([
-        dt,
+def sum_records(recs):
+    return np.array([
         sum(r["correspondences"] for r in recs), sum(r["queries"] for r in recs),
         sum(r["t_lm_kernel_ms"] for r in recs), sum(r["t_nn_query_ms"] for r in recs),
         sum(r["full_passes"] + r["cost_passes"] + r["multi_cost_passes"] for r in recs),
         sum(r["t_transform_ms"] for r in recs), sum(r["t_nn_ms"] for r in recs), sum(r["t_lm_ms"] for r in recs),
     ], dtype=np.float64)
+
+
+class Ranks:
+    """Control plane between the ranks (gloo): barriers, max / sum of small host vectors; data plane = the library's RCCL comm."""
+
+    def __init__(self, rank, world, local_rank, e3d):
+        import torch
+        self.rank, self.world, self.local_rank = rank, world, local_rank
+        self.dist = None
+        self.comm = None
+        if world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+            self.dist = dist
+            uid = torch.zeros(128, dtype=torch.uint8)
+            if rank == 0:
+                uid = torch.frombuffer(bytearray(e3d.Comm.unique_id()), dtype=torch.uint8).clone()
+            dist.broadcast(uid, src=0)
+            self.comm = e3d.Comm(bytes(uid.numpy().tobytes()), rank, world, local_rank)     # ncclCommInitRank
+            assert self.comm.world_size == world
+
+    def barrier(self):
+        import torch
+        torch.cuda.synchronize()
+        if self.dist:
+            self.dist.barrier()
+        torch.cuda.synchronize()
+
+    def reduce(self, vec, op="sum"):
+        import torch
+        if not self.dist:
+            return np.asarray(vec, np.float64)
+        t = torch.from_numpy(np.asarray(vec, np.float64).copy())
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX if op == "max" else self.dist.ReduceOp.SUM)
+        return t.numpy()
+
+    def close(self):
+        if self.comm:
+            self.comm.destroy()
+        if self.dist:
+            self.dist.destroy_process_group()
+
+
+def run_icp(e3d, R, icp, d, thr, warmup, steps):
+    """W untimed + K timed outer iterations, barrier + synchronize on both sides, time = max over ranks."""
+    for it in range(warmup):
+        icp.run(d, it, 1, thr, False)
+    warm = icp.iter_records()
+    icp.clear_records()
+    R.barrier()
+    t0 = time.perf_counter()
+    for it in range(warmup, warmup + steps):
+        icp.run(d, it, 1, thr, False)
+    R.barrier()
+    dt = float(R.reduce([time.perf_counter() - t0], "max")[0])
+    recs = icp.iter_records()
+    tot = R.reduce(sum_records(recs))
+    per_rank = {"nn_kernel_ms_per_iter": sum(r["t_nn_query_ms"] for r in recs) / steps, "lm_kernel_ms_per_iter": sum(r["t_lm_kernel_ms"] for r in recs) / steps,
+                "nn_ms_per_iter": sum(r["t_nn_ms"] for r in recs) / steps, "lm_ms_per_iter": sum(r["t_lm_ms"] for r in recs) / steps}
+    return dt, tot, warm, recs, per_rank
+
+
+def leg_terrace(e3d, synth, R, args, dev):
+    """configs[1]: 2 scans, both movable; N > 1: weak scaling on a stretched room (same point density)."""
+    import torch
+    world = R.world
+    n_points = args.points if args.points > 0 else 50_000_000 * world
+    d, thr = float(args.distance), 1e-10     # README.md:101 recommended flags; never converges within the bench's few iterations
+    room_scale = float(np.sqrt(n_points / 50_000_000.0)) if (world > 1 and args.points == 0) else 1.0
+    scans = synth.make_scene(2, n_points, seed=1234, sigma=0.002, device=dev, room_scale=room_scale)
+    torch.cuda.synchronize()
+    icp = e3d.PointToPlaneICP(device=R.local_rank)
+    for s in scans:
+        icp.add_point_cloud(s["xyz"], s["normals"], s["T_init"], False)
+    base = None
+    if R.rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # slab width chosen for ~4 M points per scan at this density (floor + two walls = 16 m^2 per metre of x)
+        width = min(10.0, 4.0e6 / (n_points / 242.6 * 16.0))
+        base = cpu_baseline_icp(scans, d, thr, (4.0, 4.0 + width), n_points)
+    del scans
+    torch.cuda.empty_cache()
+    if R.comm:
+        icp.set_comm(R.comm)
+    dt, tot, warm, recs, per_rank = run_icp(e3d, R, icp, d, thr, args.warmup, args.steps)
+    K = args.steps
+    corr, queries = tot[0], tot[1]
+    lm_ms, nn_ms, passes = tot[2] / world, tot[3] / world, tot[4] / world
+    n_nn_launch = 2 * K
+    lm_bytes = ALG_BYTES_PER_CORR_PASS * (corr / world / K)                  # one pass over this rank's correspondences
+    nn_bytes = ALG_BYTES_PER_QUERY * (queries / world / n_nn_launch)         # one directed pair's queries
+    lm_avg, nn_avg = lm_ms / max(passes, 1), nn_ms / n_nn_launch
+    kernels = {
+        "k_lm_pass": {"what": "fused cost + Gramian pass over the correspondence planes (a7/a8), k_lm_pass<1> / k_lm_cost_multi",
+                      "algorithmic_bytes_per_launch": lm_bytes, "avg_launch_ms": lm_avg, "GBs": lm_bytes / (lm_avg * 1e-3) / 1e9 if lm_avg > 0 else None,
+                      "summed_ms_per_iter": lm_ms / K},
+        "nn_search": {"what": "exact 1-NN within radius per directed pair (a5): k_nn_certify + k_nn_bounded + k_nn_rows on the queries the "
+                              "certificates leave", "algorithmic_bytes_per_launch": nn_bytes, "avg_launch_ms": nn_avg,
+                      "GBs": nn_bytes / (nn_avg * 1e-3) / 1e9 if nn_avg > 0 else None, "summed_ms_per_iter": nn_ms / K},
+    }
+    dom = "k_lm_pass" if lm_ms >= nn_ms else "nn_search"
+    traffic, traffic_src = load_traffic("k_lm_pass<1>" if dom == "k_lm_pass" else "k_nn_certify") if (world == 1 and n_points == 50_000_000) else (None, None)
+    ach = kernels[dom]["GBs"] or 0.0
+    out = {
+        "metric": "ICP correspondences/sec", "value": corr / dt, "unit": "correspondences/s",
+        "n_gpus": R.comm.world_size if R.comm else 1, "steps": K, "warmup": args.warmup, "ms_per_step": dt / K * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 (f64 accumulation)", "data": "synthetic",
+        "config": {"workload": "ICPScanAligner 2 scans (BASELINE.json configs[1]), -d %g, one outer iteration per step" % d,
+                   "points_per_scan": n_points, "scans": 2, "directed_pairs": 2, "room_scale": room_scale,
+                   "parallelism": "dp%d over source-point slices, RCCL all-reduce of the 6x6 normal-equation blocks" % world},
+        "ms_per_iter": dt / K * 1e3, "nn_queries_per_s": queries / dt, "lm_passes_per_iter": passes / K,
+        "breakdown_ms_per_iter": {"transform_bbox": tot[5] / world / K, "nn_search_and_compaction": tot[6] / world / K,
+                                  "lm_total": tot[7] / world / K, "lm_pass_kernels": lm_ms / K, "nn_query_kernels": nn_ms / K,
+                                  "nn_query_kernels_per_timed_iteration": [r["t_nn_query_ms"] for r in recs],
+                                  "warmup_nn_query_kernels": [r["t_nn_query_ms"] for r in warm]},
+        "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                     "traffic": traffic, "traffic_source": traffic_src, "kernel": dom + ": " + kernels[dom]["what"],
+                     "algorithmic_bytes_per_launch": kernels[dom]["algorithmic_bytes_per_launch"], "avg_launch_ms": kernels[dom]["avg_launch_ms"],
+                     "note": "dominant kernel = largest summed HIP-event duration in the timed region; all kernels of the step in `kernels`",
+                     "kernels": kernels},
+    }
     if world > 1:
-        cdev = torch.device("cpu") if share_gpu else dev
-        tmax = torch.tensor([local[0]], device=cdev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        tsum = torch.from_numpy(local).to(cdev)
-        dist.all_reduce(tsum)
-        tot = tsum.cpu().numpy()
-        dt = float(tmax.item())
-    else:
-        tot = local
+        out["per_rank_rank0"] = per_rank
+    if base is not None:
+        out["cpu_baseline"] = base
+        out["speedup_vs_cpu_iteration_rate"] = (base["ms_per_iter"] / base["correspondences"]) / ((dt / K * 1e3) / (corr / K))
+    del icp
+    torch.cuda.empty_cache()
+    return out
+
+
+def leg_allpairs(e3d, synth, R, args, dev):
+    """north_star scaling target: S scans all-pairs, all movable, STRONG scaling (the same job at every N)."""
+    import torch
+    S, n, d, thr = args.allpairs_scans, args.allpairs_points, float(args.allpairs_distance), 1e-10
+    scans = synth.make_scene(S, n, seed=4321, sigma=0.002, device=dev)
+    torch.cuda.synchronize()
+    icp = e3d.PointToPlaneICP(device=R.local_rank)
+    for s in scans:
+        icp.add_point_cloud(s["xyz"], s["normals"], s["T_init"], False)
+    del scans
+    torch.cuda.empty_cache()
+    if R.comm:
+        icp.set_comm(R.comm)
+    warmup, steps = 2, max(1, min(args.steps, 3))
+    dt, tot, warm, recs, per_rank = run_icp(e3d, R, icp, d, thr, warmup, steps)
+    free, total = torch.cuda.mem_get_info(R.local_rank)
+    out = {"metric": "ICP correspondences/sec", "value": tot[0] / dt, "unit": "correspondences/s", "scaling": "strong",
+           "n_gpus": R.comm.world_size if R.comm else 1, "steps": steps, "warmup": warmup, "ms_per_iter": dt / steps * 1e3,
+           "config": {"workload": "%d synthetic scans x %d points, all movable, all %d directed pairs, -d %g (north_star: 16-scan all-pairs ICP; "
+                                  "configs[2] shape with --allpairs-scans 8 --allpairs-points 20000000)" % (S, n, S * (S - 1), d),
+                      "unknowns": 6 * (S - 1), "parallelism": "every rank one slice of every directed pair's queries; one RCCL all-reduce of the "
+                                                              "per-pair blocks per LM pass"},
+           "correspondences_per_iter": tot[0] / steps, "queries_per_iter": tot[1] / steps, "lm_passes_per_iter": tot[4] / R.world / steps,
+           "rank0_ms_per_iter": per_rank, "hbm_in_use_GB_rank0": (total - free) / 1e9}
+    del icp
+    torch.cuda.empty_cache()
+    return out
+
+
+def leg_image_registrator(e3d, synth, args, dev):
+    """configs[3] shape: 23 images of 6048 x 4032 (6 pyramid levels), THIN_PRISM_FISHEYE, ~10 M points, K = 5, 150 unknowns.
+    residuals/s = (#fixed + #variable colour residuals) / wall time of the accumulate pass of IntrinsicsAndPoseOptimizer::Apply
+    (src/opt/intrinsics_and_pose_optimizer.cc:87-92,624-837) over all images; per-kernel roofline from HIP events with SURVEY 8(d)'s
+    bytes (pass 1: 24 + 12 + 8 + 4 (I + 7) B per observation; pass 2: 8 K + 4 K + 4 (K + 1)(I + 7) B per residual pair)."""
+    import torch
+    t0 = time.perf_counter()
+    Wl = synth.make_reg_workload(n_points=args.reg_points, width=6048, height=4032, n_images=args.reg_images, model=2, device=dev)
+    t_gen = time.perf_counter() - t0
+    K, I = Wl["K"], len(Wl["params"])
+    P = e3d.RegProblem(e3d.default_reg_params(image_scale_count=Wl["n_levels"], point_neighbor_count=K))
+    P.set_intrinsics(0, Wl["width"], Wl["height"], Wl["params"], 0, Wl["n_levels"], camera_type=2)
+    P.set_point_scale(0, Wl["pts"], Wl["point_radius"], Wl["nbr"], Wl["fixed_desc"])
+    P.set_splat_points(Wl["pts"])
+    ids = list(range(len(Wl["images"])))
+    for i, im in enumerate(Wl["images"]):
+        P.set_image(i, 0, im["pyr"]); P.set_image_pose(i, im["q"], im["t"])
+    P.update_observations(1)
+    t0 = time.perf_counter(); P.update_observations(1); t_obs = time.perf_counter() - t0
+    P.color_update()
+    for i in ids:
+        P.accumulate(i, 0)
+    P.kernel_times(reset=True)
+    reps = 3
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    res = 0
+    for _ in range(reps):
+        for i in ids:
+            _, _, _, c = P.accumulate(i, 0)
+            res += int(c[0] + c[1])
+    t_acc = (time.perf_counter() - t0) / reps
+    res //= reps
+    p1_ms, p2_ms, n_obs, calls = P.kernel_times(reset=True)
+    p1_ms /= calls; p2_ms /= calls; n_obs /= calls                         # per launch (= per image)
+    res_per_launch = res / len(ids)
+    b1 = (24 + 12 + 8 + 4 * (I + 7)) * n_obs
+    b2 = (8 * K + 4 * K + 4 * (K + 1) * (I + 7)) * (res_per_launch / 2)    # both residual kinds share the gathers: counted once
+    t0 = time.perf_counter(); _, cost, its = P.run_on_current_scale(3, 0.0, 15, False); t_run = time.perf_counter() - t0
+    free, total = torch.cuda.mem_get_info(0)
+    tr1, src1 = load_traffic("k_reg_pass1<2, false>")
+    tr2, src2 = load_traffic("k_reg_pass2_mfma<5, 18>")
+    out = {"metric": "ImageRegistrator residuals/sec", "value": res / t_acc, "unit": "residuals/s",
+           "config": {"workload": "%d images 6048x4032 (6 levels) THIN_PRISM_FISHEYE, %d points, K = %d (BASELINE.json configs[3] shape)"
+                                  % (len(ids), len(Wl["pts"]), K), "unknowns": I + 6 * len(ids)},
+           "residuals": res, "accumulate_ms_all_images": t_acc * 1e3, "observation_refresh_ms_all_images": t_obs * 1e3,
+           "ms_per_run_iteration": t_run / max(its, 1) * 1e3, "run_iterations": its, "hbm_in_use_GB": (total - free) / 1e9,
+           "input_generation_s": t_gen,
+           "roofline": {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "k_reg_pass1": {"algorithmic_bytes_per_launch": b1, "avg_launch_ms": p1_ms, "achieved": b1 / (p1_ms * 1e-3) / 1e9,
+                                        "frac": b1 / (p1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": tr1, "traffic_source": src1},
+                        "k_reg_pass2_mfma": {"algorithmic_bytes_per_launch": b2, "avg_launch_ms": p2_ms, "achieved": b2 / (p2_ms * 1e-3) / 1e9,
+                                             "frac": b2 / (p2_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": tr2, "traffic_source": src2,
+                                             "note": "v_mfma_f64_16x16x4_f64 tiles; gathers of neighbour rows are served by L2, the kernel is "
+                                                     "f64-FMA / gather-latency bound rather than HBM bound"}}}
+    if not args.no_cpu_baseline:
+        from oracle import reg_binding as rb
+        from oracle.reg_driver import OracleRegProblem
+        n1 = 2_000_000
+        W1 = synth.make_reg_workload(n_points=n1, width=6048, height=4032, n_images=1, model=2, device=dev)
+        O = OracleRegProblem(K=W1["K"], image_scale_count=W1["n_levels"])
+        O.set_intrinsics(0, W1["width"], W1["height"], W1["params"], 0, W1["n_levels"], model=2)
+        O.set_point_scale(0, W1["pts"], W1["point_radius"], W1["nbr"], W1["fixed_desc"])
+        O.set_splat_points(W1["pts"])
+        O.set_image(0, 0, W1["images"][0]["pyr"]); O.set_image_pose(0, W1["images"][0]["q"], W1["images"][0]["t"])
+        O.update_observations(1); O.color_update()
+        S = O.scales[0]; im = O.images[0]; I0 = O.intr[0]; o = O.obs[(0, 0)]
+        times = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            _, _, _, c = rb.accumulate(S["pts"], float(S["radius"]), S["nbr"], O.K, S["fixed"], S["var"], S["counts"], I0["levels"][0], I0["min"],
+                                       im["pyr"], O._R(im), im["t"], o[:4], o[4], O.robust_type, O.robust_param, O.fixed_weight, O.var_weight)
+            times.append(time.perf_counter() - t0)
+        tc = float(np.median(times))
+        out["cpu_baseline"] = {"value": float(c[0] + c[1]) / tc, "unit": "residuals/s", "cores": 1, "kind": "port",
+                               "sample": "median of 3 accumulate passes (oracle_reg_accumulate, single thread like the reference) of ONE "
+                                         "6048x4032 THIN_PRISM_FISHEYE image with %d points, K = 5: %d residuals in %.2f s" % (len(W1["pts"]), int(c[0] + c[1]), tc)}
+        out["speedup_vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+    del P
+    torch.cuda.empty_cache()
+    return out
+
+
+def leg_normals(e3d, synth, args, dev):
+    """(A') NormalEstimationTwoPassOMP: one synthetic room scan of 20 M points resident in HBM, e3d_normals_knn end to end (grid,
+    sorts, search + covariance + eigenvector); algorithmic bytes 12 k + 28 per point."""
+    import ctypes as C
+    import torch
+    capi = importlib.import_module("dataset-pipeline_amd.capi")
+    origin, yaw = synth.SCAN_POSES[0]
+    n = args.normals_points
+    xyz, _, _ = synth.make_scan(n, origin, yaw, 1234, device=dev)
+    xyz = xyz.contiguous()
+    on = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    oc = torch.empty(n, dtype=torch.float32, device=dev)
+    vp = np.zeros(3, np.float32)
+    torch.cuda.synchronize()
+    out = {"metric": "normals/s", "points": n, "unit": "normals/s"}
+    for k in (32, 8):
+        def call():
+            r = capi.lib().e3d_normals_knn(C.c_void_p(xyz.data_ptr()), n, k, C.c_void_p(vp.ctypes.data), C.c_void_p(on.data_ptr()), C.c_void_p(oc.data_ptr()), None)
+            assert r == 0, capi.lib().e3d_last_error()
+        call()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(3):
+            call()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 3
+        alg = n * (12 * k + 28)
+        tr, src = load_traffic("k_knn_normals_k%d" % k)
+        out["k%d" % k] = {"value": n / dt, "ms_per_call": dt * 1e3,
+                          "roofline": {"bound": "hbm", "achieved": alg / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / dt / 1e9 / HBM_PEAK_GBS,
+                                       "traffic": tr, "traffic_source": src, "algorithmic_bytes_per_launch": alg,
+                                       "kernel": "e3d_normals_knn whole call (grid build + k-NN + covariance + eigenvector)"}}
+    out["value"] = out["k32"]["value"]
+    if not args.no_cpu_baseline:
+        from oracle import binding as ob
+        x = xyz[:, 0]
+        xs = torch.sort(x[torch.randperm(n, device=dev)[:min(n, 2_000_000)]]).values
+        i0 = int(0.4 * len(xs))
+        lo, hi = float(xs[i0]), float(xs[min(len(xs) - 1, i0 + max(1, int(len(xs) * 1_000_000 / n)))])
+        sub = xyz[(x >= lo) & (x < hi)].cpu().numpy()
+        t0 = time.perf_counter()
+        ob.normals(sub, k=32)
+        dtc = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": len(sub) / dtc, "unit": "normals/s", "cores": os.cpu_count(), "kind": "port",
+                               "sample": "k = 32 on %d points (slab x in [%.2f, %.2f) of the same scan): kd-tree build + k-search + two-pass "
+                                         "covariance, OpenMP over points like NormalEstimationTwoPassOMP, %.1f s" % (len(sub), lo, hi, dtc)}
+        out["speedup_vs_cpu"] = out["k32"]["value"] / out["cpu_baseline"]["value"]
+    del xyz, on, oc
+    torch.cuda.empty_cache()
+    return out
+
+
+def spawn(args):
+    """--gpus N without a launcher: start the N ranks ourselves (same command line) and relay rank 0's JSON line."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--points", type=int, default=0, help="points per scan of the headline leg (default 50 M x gpus)")
+    ap.add_argument("--distance", type=float, default=0.01)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-reg", action="store_true", help="skip the ImageRegistrator leg (N = 1 only)")
+    ap.add_argument("--no-normals", action="store_true", help="skip the normal-estimation leg (N = 1 only)")
+    ap.add_argument("--no-allpairs", action="store_true", help="skip the all-pairs scaling leg")
+    ap.add_argument("--allpairs-scans", type=int, default=16)
+    ap.add_argument("--allpairs-points", type=int, default=10_000_000)
+    ap.add_argument("--allpairs-distance", type=float, default=0.02)
+    ap.add_argument("--reg-images", type=int, default=23)
+    ap.add_argument("--reg-points", type=int, default=10_000_000)
+    ap.add_argument("--normals-points", type=int, default=20_000_000)
+    args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(spawn(args))                           # never a silent 1-GPU run
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
+
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no HIP device visible)")
+    if world > torch.cuda.device_count():
+        raise SystemExit("--gpus %d: only %d HIP device(s) visible (one rank per GPU)" % (world, torch.cuda.device_count()))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    e3d = importlib.import_module("dataset-pipeline_amd")
+    synth = importlib.import_module("dataset-pipeline_amd.synth")
+    if e3d.lib().e3d_init(local_rank) < 1:
+        raise SystemExit("libe3dhip: no device")
+    R = Ranks(rank, world, local_rank, e3d)
+
+    out = leg_terrace(e3d, synth, R, args, dev)
+    if not args.no_allpairs:
+        out["allpairs"] = leg_allpairs(e3d, synth, R, args, dev)
+    if rank == 0 and world == 1:
+        if not args.no_reg:
+            out["image_registrator"] = leg_image_registrator(e3d, synth, args, dev)
+        if not args.no_normals:
+            out["normal_estimation"] = leg_normals(e3d, synth, args, dev)
     if rank == 0:
-        reg_leg = None
-        if world == 1 and not args.no_reg:
-            del icp
-            torch.cuda.empty_cache()
-            reg_leg = image_registrator_leg(e3d, synth, cpu=not args.no_cpu_baseline)
-        K = args.steps
-        corr, queries = tot[1], tot[2]
-        lm_ms, nn_ms, passes = tot[3] / world, tot[4] / world, tot[5] / world
-        n_nn_launch = 2 * K
-        # dominant kernel = the one with the larger summed duration in the timed region (per rank)
-        if lm_ms >= nn_ms:
-            per_launch_bytes = ALG_BYTES_PER_CORR_PASS * (corr / world / K)     # local correspondences of one iteration
-            avg_ms = lm_ms / max(passes, 1)
-            kernel = "k_lm_pass (fused cost + Gramian pass, a7/a8)"
-            kernel_key = "k_lm_pass<1>"
-        else:
-            per_launch_bytes = ALG_BYTES_PER_QUERY * (queries / world / n_nn_launch)
-            avg_ms = nn_ms / n_nn_launch
-            kernel = "k_nn_rows (exact 1-NN within radius over LDS-staged cell rows, a5)"
-            kernel_key = "k_nn_rows"
-        achieved = per_launch_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        # HBM traffic per launch of that kernel: rocprofv3 PMC (FETCH_SIZE / WRITE_SIZE, separate passes, gfx950
-        # corrections applied) of this same workload, committed under profiles/ (bench.py cannot run the profiler itself)
-        traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "round1_traffic.json")
-        if world == 1 and n_points == 50_000_000 and os.path.exists(tpath):
-            tk = json.load(open(tpath))["kernels"].get(kernel_key)
-            if tk:
-                traffic, traffic_src = tk["hbm_bytes_per_launch"], "profiles/round1_traffic.json"
-        out = {
-            "metric": "ICP correspondences/sec", "value": corr / dt, "unit": "correspondences/s",
-            "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": dt / K * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 (f64 accumulation)",
-            "data": "synthetic",
-            "config": {"workload": "ICPScanAligner 2 scans (BASELINE.json configs[1]), -d %g, one outer iteration per step"
-                                   % d,
-                       "points_per_scan": n_points, "scans": 2, "directed_pairs": 2, "room_scale": room_scale,
-                       "parallelism": "dp%d over source-point slices, all-reduce of 6x6 normal equations" % world},
-            "ms_per_iter": dt / K * 1e3,
-            "nn_queries_per_s": queries / dt,
-            "lm_passes_per_iter": passes / K,
-            "breakdown_ms_per_iter": {"transform_bbox": tot[6] / world / K, "nn_search_and_compaction": tot[7] / world / K,
-                                      "lm_total": tot[8] / world / K, "lm_pass_kernels": lm_ms / K, "nn_query_kernels": nn_ms / K,
-                                      "warmup_nn_query_kernels": warm_nn_ms},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "kernel": kernel,
-                         "note": "the NN kernel is VALU-issue bound, not HBM bound (rocprofv3 PMC: SQ_ACTIVE_INST_VALU ~ 86 % of its "
-                                 "wave cycles, profiles/round1_nn_rows_pmc_sq_*.txt); the LM pass kernel streams at the HBM roofline "
-                                 "(see other.k_lm_pass_GBs)",
-                         "algorithmic_bytes_per_launch": per_launch_bytes, "avg_launch_ms": avg_ms,
-                         "other": {"k_lm_pass_GBs": (ALG_BYTES_PER_CORR_PASS * corr / world / K) / (lm_ms / max(passes, 1) * 1e-3) / 1e9 if lm_ms > 0 else None,
-                                   "k_nn_query_GBs": (ALG_BYTES_PER_QUERY * queries / world / n_nn_launch) / (nn_ms / n_nn_launch * 1e-3) / 1e9 if nn_ms > 0 else None}},
-        }
-        if world == 1 and not args.no_reg:
-            out["image_registrator"] = reg_leg
-        if base is not None:
-            out["cpu_baseline"] = base
-            out["speedup_vs_cpu_iteration_rate"] = (base["ms_per_iter"] / base["correspondences"]) / ((dt / K * 1e3) / (corr / K))
         print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
+    R.close()
 
 
 if __name__ == "__main__":

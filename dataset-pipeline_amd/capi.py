@@ -64,6 +64,7 @@ SIGNATURES = {
     "e3d_comm_world_size": (C.c_int, [C.c_void_p]),
     "e3d_icp_set_comm": (C.c_int, [C.c_void_p, C.c_void_p]),
     "e3d_reg_set_comm": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "e3d_reg_kernel_times": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "e3d_find_correspondences": (C.c_int64, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_float,
                                              C.c_void_p, C.c_void_p]),
     "e3d_transform_cloud": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -618,6 +619,12 @@ class RegProblem:
         a = C.c_int(); l = C.c_float(lam); m = C.c_float()
         self._chk(lib().e3d_reg_apply(self._h, int(print_progress), C.byref(a), C.byref(l), C.byref(m)), "e3d_reg_apply")
         return bool(a.value), l.value, m.value
+
+    def kernel_times(self, reset=True):
+        """(pass 1 ms, pass 2 ms, observations, calls) of the accumulate kernels since the last reset (HIP events)."""
+        out = (C.c_double * 4)()
+        self._chk(lib().e3d_reg_kernel_times(self._h, out, int(bool(reset))), "e3d_reg_kernel_times")
+        return tuple(out)
 
     def set_comm(self, comm):
         """Image sharding with the library's own RCCL communicator (a Comm); call before the images are set."""

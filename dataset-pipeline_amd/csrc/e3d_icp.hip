@@ -68,7 +68,7 @@ struct Cloud {
 struct PairState {
   DevBuf<int> match, match2;       // partner, runner-up of the last search (or -1)
   DevBuf<float> lbe;
-  DevBuf<unsigned> todo_near, todo_far, todo_count;     // todo_count[0..1] = list lengths
+  DevBuf<unsigned> todo_count;     // todo_count[0..1] = lengths of the two lists of the current search (lists: handle scratch)
   size_t n = 0;
   long long jbase = -1;
   unsigned long long src_gen = 0, tgt_gen = 0;
@@ -132,6 +132,8 @@ struct e3d_icp {
 
   std::map<std::pair<int, int>, std::unique_ptr<PairState>> pair_state;
   PinBuf<unsigned> h_todo;
+  DevBuf<unsigned> todo_near, todo_far;         // queries the certificates did not settle (per search; shared by all pairs)
+  size_t last_corr_total = 0;                   // correspondences of the previous outer iteration (sizes the planes)
   DevBuf<unsigned long long> nn_stats;
   DevBuf<float> lbe_scratch;
 
@@ -334,7 +336,7 @@ static PairState& pair_state_for(e3d_icp* h, int src_id, int tgt_id, const Cloud
   if (!up) up.reset(new PairState());
   PairState& ps = *up;
   if (ps.n != n || ps.jbase != (long long)j0 || ps.src_gen != src.generation || ps.tgt_gen != tgt.generation) {
-    ps.match.reserve(n); ps.match2.reserve(n); ps.lbe.reserve(n); ps.todo_near.reserve(n); ps.todo_far.reserve(n); ps.todo_count.reserve(2);
+    ps.match.reserve(n); ps.match2.reserve(n); ps.lbe.reserve(n); ps.todo_count.reserve(2);
     ps.n = n; ps.jbase = (long long)j0; ps.src_gen = src.generation; ps.tgt_gen = tgt.generation;
     ps.fresh = true;
   }
@@ -457,14 +459,15 @@ static void find_pair(e3d_icp* h, Cloud& src, Cloud& tgt, float d, PairJob& job,
       const float cum_up = round_up_f((cum_pair * (1.0 + 2e-6) + 2.0 * (src.err_max + tgt.err_max)) * (1.0 + 1e-6));
       const float near2 = (float)((near_frac * (double)d) * (near_frac * (double)d));
       h->h_todo.reserve(2);
+      h->todo_near.reserve(n); h->todo_far.reserve(n);
       E3D_HIP(hipMemsetAsync(ps.todo_count.p, 0, 2 * sizeof(unsigned), s));
       h->nn_timer->start(s);
-      launch_nn_certify(srcG, n, tgt.G4.p, cum_up, radius_sq(d), near2, ps.match.p, ps.match2.p, ps.lbe.p, h->match_d2.p, ps.todo_near.p, ps.todo_far.p,
+      launch_nn_certify(srcG, n, tgt.G4.p, cum_up, radius_sq(d), near2, ps.match.p, ps.match2.p, ps.lbe.p, h->match_d2.p, h->todo_near.p, h->todo_far.p,
                         ps.todo_count.p, s);
       copy_out(h->h_todo.p, ps.todo_count.p, 2 * sizeof(unsigned), s);
       sync(h);
       n_near = h->h_todo.p[0]; n_far = h->h_todo.p[1];
-      list = ps.todo_far.p;
+      list = h->todo_far.p;
       // old partner close by: only the cells its distance (+ margin) reaches, one thread per query, no sort
       double smin = min_singular_value_3x3(tgt.T);
       if (!(smin > 1e-12)) smin = 1e-12;
@@ -475,12 +478,12 @@ static void find_pair(e3d_icp* h, Cloud& src, Cloud& tgt, float d, PairJob& job,
       bp.rho_scale = round_up_f((1.0 + 1e-5) / smin);
       bp.rho_pad = round_up_f(2.0 * tgt.build_slack + 8.0 * FLT_EPSILON * m_local);
       bp.cum_lo = cert.cum_lo;
-      launch_nn_bounded(srcG, ps.todo_near.p, n_near, tgt.G4.p, tgt.dense_start.p, tgt.grid, im, tgt.qrange, radius_sq(d), bp, ps.match.p,
+      launch_nn_bounded(srcG, h->todo_near.p, n_near, tgt.G4.p, tgt.dense_start.p, tgt.grid, im, tgt.qrange, radius_sq(d), bp, ps.match.p,
                         ps.match2.p, h->match_d2.p, ps.lbe.p, s);
       if (n_far > 0 && n_far * 32 < n) {
         // few queries without a near partner: the same kernel (whole radius for those without any) instead of sort + row kernel,
         // whose cost is per visited cell row, not per query
-        launch_nn_bounded(srcG, ps.todo_far.p, n_far, tgt.G4.p, tgt.dense_start.p, tgt.grid, im, tgt.qrange, radius_sq(d), bp, ps.match.p,
+        launch_nn_bounded(srcG, h->todo_far.p, n_far, tgt.G4.p, tgt.dense_start.p, tgt.grid, im, tgt.qrange, radius_sq(d), bp, ps.match.p,
                           ps.match2.p, h->match_d2.p, ps.lbe.p, s);
         n_near += n_far; n_far = 0;
       }
@@ -841,7 +844,11 @@ static bool align_meshes(e3d_icp* h, float max_d, float thr, bool print, int ite
       qtot += (size_t)((unsigned __int128)src.n * (unsigned)(h->rank + 1) / (unsigned)h->world) -
               (size_t)((unsigned __int128)src.n * (unsigned)h->rank / (unsigned)h->world);
     }
-    if (qtot > h->cA.cap) { h->cA.reserve(qtot); h->cB.reserve(qtot); h->cC.reserve(qtot); }
+    // two directed pairs: one slot per query (no reallocation ever); many pairs: most queries of a pair find no partner, so
+    // start from last iteration's total (+ 12 %) or a quarter of the queries and let find_pair grow the planes if needed
+    size_t want = qtot;
+    if (jobs.size() > 2) want = std::min(qtot, std::max(h->last_corr_total + h->last_corr_total / 8 + (size_t)(1 << 20), qtot / 4));
+    if (want > h->cA.cap) { h->cA.reserve(want); h->cB.reserve(want); h->cC.reserve(want); }
   }
   for (size_t p = 0; p < jobs.size(); ++p) {
     PairJob& j = jobs[p];
@@ -855,6 +862,7 @@ static bool align_meshes(e3d_icp* h, float max_d, float thr, bool print, int ite
     rec.correspondences += j.count;
   }
   t_nn.stop(s);
+  h->last_corr_total = h->corr_used;
   // global per-pair counts (what the reference prints); local counts stay in j.count for the LM sets
   std::vector<long long> gcount(jobs.size());
   std::vector<double> gdsum(jobs.size());

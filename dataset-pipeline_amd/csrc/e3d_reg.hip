@@ -1501,6 +1501,9 @@ struct e3d_reg {
   e3d_allreduce_device_fn allreduce_dev = nullptr;
   void* ar_user = nullptr;
   e3d_comm* comm = nullptr;                     // native RCCL collectives (e3d_reg_set_comm); not owned
+  // HIP-event times of the two kernels of e3d_reg_accumulate, summed since the last e3d_reg_kernel_times(reset)
+  std::unique_ptr<EventTimer> t_pass1, t_pass2;
+  double pass1_ms = 0, pass2_ms = 0, pass_observations = 0, pass_calls = 0;
   DevBuf<double> comm_stage;
   bool owns(int image_id) const { return world <= 1 || ((image_id % world) + world) % world == rank; }
   // splat depth: per-point rectangles, (tile, point) pairs (double-buffered for the sort), tile ranges
@@ -2299,7 +2302,10 @@ int e3d_reg_accumulate(e3d_reg_t* h, int image_id, int point_scale, double* H, d
   ImageDev& im = get_image(h, image_id);
   PointScale& S = get_scale(h, point_scale);
   Obs& O = get_obs(im, point_scale);
+  if (!h->t_pass1) { h->t_pass1.reset(new EventTimer()); h->t_pass2.reset(new EventTimer()); }
+  h->t_pass1->start(s);
   prepare_rows(h, im, S, O);
+  h->t_pass1->stop(s);
   const int nb = (int)std::min<size_t>(std::max<size_t>(div_up(O.n, kBlock * 4), 1), 1024);
   const int V = local_unknowns(h, im), NH = reg_h(V), slot = reg_slot(V);
   h->partial.reserve((size_t)nb * slot); h->red.reserve(slot);
@@ -2309,6 +2315,7 @@ int e3d_reg_accumulate(e3d_reg_t* h, int image_id, int point_scale, double* H, d
   int n_partials = nb;
   // matrix-core kernel: systems that would need several per-thread-accumulator launches (V > 10), default neighbour count
   static const bool mfma10 = getenv("E3D_REG_PASS2_MFMA10") != nullptr;     // experiment: the single-launch system on the matrix cores too
+  h->t_pass2->start(s);
   if (!valu_pass2 && (V > 10 || mfma10) && h->prm.point_neighbor_count == 5) {
     n_partials = nb * (kBlock / kWave);       // one partial per wave
     h->partial.reserve((size_t)n_partials * slot);
@@ -2345,16 +2352,27 @@ int e3d_reg_accumulate(e3d_reg_t* h, int image_id, int point_scale, double* H, d
   }
 #undef E3D_PASS2
   }
+  h->t_pass2->stop(s);
   hipLaunchKernelGGL(k_reg_reduce, dim3(slot), dim3(kWave), 0, s, h->partial.p, n_partials, slot, h->red.p);
   std::vector<double> r(slot);
   copy_out(r.data(), h->red.p, sizeof(double) * slot, s);
   rsync(h);
+  h->pass1_ms += h->t_pass1->ms(); h->pass2_ms += h->t_pass2->ms(); h->pass_observations += (double)O.n; h->pass_calls += 1;
   std::fill(H, H + V * V, 0.0);
   int e = 0;
   for (int i = 0; i < V; ++i) for (int j = i; j < V; ++j) H[i * V + j] = r[e++];
   for (int i = 0; i < V; ++i) b[i] = r[NH + i];
   sums[0] = r[NH + V]; sums[1] = r[NH + V + 1];
   counts[0] = (int64_t)r[NH + V + 2]; counts[1] = (int64_t)r[NH + V + 3];
+  return 0;
+  R_CATCH()
+}
+
+int e3d_reg_kernel_times(e3d_reg_t* h, double out[4], int reset) {
+  R_TRYH
+  if (!h || !out) throw Error(E3D_ERR_INVALID, "null argument");
+  out[0] = h->pass1_ms; out[1] = h->pass2_ms; out[2] = h->pass_observations; out[3] = h->pass_calls;
+  if (reset) { h->pass1_ms = h->pass2_ms = h->pass_observations = h->pass_calls = 0; }
   return 0;
   R_CATCH()
 }

@@ -135,7 +135,30 @@ REG_DISTORTION = {0: [], 1: [-0.101082, 0.0703954, 0.000438661, -0.000680887],
                   2: [0.0221184, 0.0128597, 0.000531602, -0.000388873, 0.00623079, 0.0020419, -0.000805024, 4.07704e-05]}
 
 
-def make_reg_workload(n_points=4_000_000, width=3840, height=2160, n_levels=6, K=5, n_images=4, model=0, seed=0):
+def _synthetic_image(i, width, height, device=None):
+    """The band-limited test texture of image i as u8 [height, width]; on `device` with torch when given (a 24 MP image takes
+    ~2 s in numpy and ~20 ms on the GPU), bit-identical values are not needed between the two (synthetic input)."""
+    if device is None:
+        yy, xx = np.mgrid[0:height, 0:width]
+        return (120 + 60 * np.sin((xx + 37 * i) / 11.0) * np.cos(yy / 9.0) + 40 * np.sin((xx + 2 * yy) / 31.0)).clip(0, 250).astype(np.uint8)
+    yy = torch.arange(height, device=device, dtype=torch.float32)[:, None]
+    xx = torch.arange(width, device=device, dtype=torch.float32)[None, :]
+    img = 120 + 60 * torch.sin((xx + 37 * i) / 11.0) * torch.cos(yy / 9.0) + 40 * torch.sin((xx + 2 * yy) / 31.0)
+    return img.clamp_(0, 250).to(torch.uint8)
+
+
+def _pyramid_torch(img, n_levels):
+    """image_pyramid_u8 on a torch u8 tensor (same integer arithmetic); returns numpy levels."""
+    out = [img]
+    for _ in range(1, n_levels):
+        a = out[-1]
+        h, w = (a.shape[0] // 2) * 2, (a.shape[1] // 2) * 2
+        a = a[:h, :w].to(torch.int32)
+        out.append(((a[0::2, 0::2] + a[0::2, 1::2] + a[1::2, 0::2] + a[1::2, 1::2] + 2) >> 2).to(torch.uint8))
+    return [l.cpu().numpy() for l in out]
+
+
+def make_reg_workload(n_points=4_000_000, width=3840, height=2160, n_levels=6, K=5, n_images=4, model=0, seed=0, device=None):
     """A textured wall (y = 3) sampled on a jittered lattice with lattice neighbours, seen by `n_images` cameras placed on an arc;
     one point scale whose radius makes every observation land between pyramid levels 0 and 1.  Shapes follow BASELINE.json
     configs[4] (4K images, 6 levels); everything else (texture, poses) is synthetic."""
@@ -152,10 +175,9 @@ def make_reg_workload(n_points=4_000_000, width=3840, height=2160, n_levels=6, K
     tex = 120 + 55 * np.sin(7.0 * pts[:, 0]) * np.cos(5.0 * pts[:, 2]) + 35 * np.sin(3.0 * pts[:, 0] + 4.0 * pts[:, 2])
     fixed = (tex[nbr] - tex[:, None]).astype(np.float32)
     params = np.array([0.55 * width, 0.55 * width, width / 2 - 0.5, height / 2 - 0.5] + REG_DISTORTION[model], np.float32)
-    yy, xx = np.mgrid[0:height, 0:width]
     images = []
     for i in range(n_images):
-        img = (120 + 60 * np.sin((xx + 37 * i) / 11.0) * np.cos(yy / 9.0) + 40 * np.sin((xx + 2 * yy) / 31.0)).clip(0, 250).astype(np.uint8)
+        img = _synthetic_image(i, width, height, device)
         a = 0.04 * (i - 0.5 * (n_images - 1))
         eye = np.array([3.0 * np.sin(a), 3.0 - 3.0 * np.cos(a), 0.01 * i])
         z = np.array([0.0, 3.0, 0.0]) - eye; z /= np.linalg.norm(z)
@@ -165,6 +187,7 @@ def make_reg_workload(n_points=4_000_000, width=3840, height=2160, n_levels=6, K
         t = -R @ eye
         w = np.sqrt(max(0.0, 1 + R[0, 0] + R[1, 1] + R[2, 2])) / 2
         q = np.array([w, (R[2, 1] - R[1, 2]) / (4 * w), (R[0, 2] - R[2, 0]) / (4 * w), (R[1, 0] - R[0, 1]) / (4 * w)])
-        images.append(dict(pyr=image_pyramid_u8(img, n_levels), q=(q / np.linalg.norm(q)).astype(np.float32), t=t.astype(np.float32)))
+        pyr = image_pyramid_u8(img, n_levels) if device is None else _pyramid_torch(img, n_levels)
+        images.append(dict(pyr=pyr, q=(q / np.linalg.norm(q)).astype(np.float32), t=t.astype(np.float32)))
     return dict(pts=pts, nbr=nbr, K=K, fixed_desc=fixed, params=params, width=width, height=height, n_levels=n_levels,
                 images=images, point_radius=float(3.2 / side * 0.7), model=model)

@@ -282,6 +282,11 @@ int e3d_reg_clear_occlusion_meshes(e3d_reg_t* reg);
 int e3d_reg_set_occlusion_options(e3d_reg_t* reg, float min_depth, float max_depth, int mask_occlusion_boundaries);
 int64_t e3d_reg_occlusion_edge_count(e3d_reg_t* reg, int mesh_index);
 
+/* Measurement: HIP-event durations of the two kernels behind e3d_reg_accumulate, summed over its calls since the last reset:
+ * out = {pass 1 ms (k_reg_pass1: per-observation intensity + Jacobian rows), pass 2 ms (k_reg_pass2 / k_reg_pass2_mfma: residuals and
+ * normal equations), observations processed, calls}. */
+int e3d_reg_kernel_times(e3d_reg_t* reg, double out[4], int reset);
+
 /* Renders the occlusion depth map of an image at an image scale (kept on the device for e3d_reg_observe);
  * depth_out (optional) receives height x width floats. */
 int e3d_reg_render_depth(e3d_reg_t* reg, int image_id, int image_scale, float* depth_out);

@@ -9,7 +9,7 @@ The directory name contains a hyphen (it is the name the task prescribes), so im
     import importlib; e3d = importlib.import_module("dataset-pipeline_amd")
 """
 from .capi import (Comm, E3DError, PointToPlaneICP, RegParams, RegProblem, default_reg_params, determine_point_neighbors,
-                   find_correspondences, icp_pair_system, lib, lib_path, libm_eval, local_outlier_removal, merge_close_points, normals_knn, normals_radius, transform_cloud)
+                   find_correspondences, icp_pair_system, lib, lib_path, libm_eval, local_outlier_removal, release_workspaces, merge_close_points, normals_knn, normals_radius, transform_cloud)
 
 __all__ = ["Comm", "E3DError", "PointToPlaneICP", "RegParams", "RegProblem", "default_reg_params", "determine_point_neighbors", "find_correspondences",
-           "icp_pair_system", "lib", "lib_path", "libm_eval", "local_outlier_removal", "merge_close_points", "normals_knn", "normals_radius", "transform_cloud"]
+           "icp_pair_system", "lib", "lib_path", "libm_eval", "local_outlier_removal", "release_workspaces", "merge_close_points", "normals_knn", "normals_radius", "transform_cloud"]

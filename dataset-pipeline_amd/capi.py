@@ -73,6 +73,7 @@ SIGNATURES = {
     "e3d_libm_eval": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "e3d_normals_knn": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "e3d_normals_radius": (C.c_int, [C.c_void_p, C.c_size_t, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "e3d_release_workspaces": (C.c_int, []),
     "e3d_local_outlier_removal": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_double, C.c_int, C.c_void_p, C.c_void_p]),
     # (B) image registration kernels
     "e3d_reg_create": (C.c_void_p, [C.c_void_p]),
@@ -364,6 +365,11 @@ class Comm:
         if self.handle:
             lib().e3d_comm_destroy(self.handle)
             self.handle = None
+
+
+def release_workspaces():
+    """Free the device workspaces e3d_normals_knn / e3d_local_outlier_removal parked for their next call."""
+    lib().e3d_release_workspaces()
 
 
 def libm_eval(fn, x, y=None):

@@ -14,6 +14,8 @@
 #include <cfloat>
 #include <cmath>
 #include <memory>
+#include <mutex>
+#include <vector>
 
 #include "../../include/e3d_hip.h"
 #include "../../include/e3d_libm.h"   // bit-defined atan2f / cosf / sinf: the same bits on host and device
@@ -31,7 +33,94 @@ struct KnnGrid {
   float cell;
   float dmin[3], dmax[3];   // data bbox
   float slack;
+  // dense cell-start directory (exclusive max-scan of the run ends, as in the ICP grid): the cells [xa, xb] of one (y, z) row are
+  // ONE run [S[row + xa], S[row + xb + 1]) found with two independent loads; nullptr: the hash table, cell by cell
+  const unsigned* S;
+  unsigned D[3];
 };
+
+// runs of the cells [x0, x1] of row (y, z): with the dense directory one run, with the hash table one per cell.  body(begin, end)
+template <class F>
+__device__ __forceinline__ void knn_row(const KnnGrid& G, const HashEntry* __restrict__ table, int x0, int x1, int y, int z, F body) {
+  if (G.S) {
+    if (y < 0 || z < 0 || y >= (int)G.D[1] || z >= (int)G.D[2]) return;
+    x0 = max(x0, 0); x1 = min(x1, (int)G.D[0] - 1);
+    if (x0 > x1) return;
+    const size_t row = ((size_t)z * G.D[1] + (size_t)y) * G.D[0];
+    const unsigned s0 = G.S[row + (size_t)x0], e0 = G.S[row + (size_t)x1 + 1];
+    body(s0, e0);
+    return;
+  }
+  constexpr int kMaxC = (1 << 21) - 1;
+  if (y < 0 || z < 0 || y > kMaxC || z > kMaxC) return;
+  for (int x = max(x0, 0); x <= min(x1, kMaxC); ++x) {
+    const unsigned long long key = cell_key(x, y, z);
+    unsigned h = hash_key(key) & G.g.mask;
+    for (;;) {
+      const HashEntry en = table[h];
+      if (en.key == key) { body(en.start, en.end); break; }
+      if (en.key == kEmptyKey) break;
+      h = (h + 1) & G.g.mask;
+    }
+  }
+}
+
+constexpr int kKnnBins = 64;           // histogram bins of the two-pass variant: cell^2 / 32 wide, [0, 2 cell^2)
+constexpr int kKnnHistBlock = 256;
+
+// Pass A of the two-pass variant (see k_knn_normals<3>): per query the first bin of the squared-distance histogram of its 27
+// cells at which the count reaches k (255: none -- the list-maintaining variant takes the query).  Only 64 bytes of LDS per thread:
+// the kernel runs at full occupancy, which is what this latency-bound scan needs.
+__global__ __launch_bounds__(kKnnHistBlock) void k_knn_hist(const float4* __restrict__ P4, const unsigned* __restrict__ todo, size_t n_todo,
+                                                            const HashEntry* __restrict__ table, KnnGrid G, int k,
+                                                            const float4* __restrict__ Q4, unsigned char* __restrict__ sel_bin,
+                                                            unsigned* __restrict__ hist_out /* [kKnnBins / 4][n_todo] */) {
+  __shared__ unsigned hw[kKnnBins / 4][kKnnHistBlock];
+  const int tid = threadIdx.x;
+  const size_t gi = (size_t)blockIdx.x * blockDim.x + tid;
+  if (gi >= n_todo) return;
+  const unsigned qid = todo ? todo[gi] : (unsigned)gi;
+  const float4 q = Q4[qid];
+#pragma unroll
+  for (int wv = 0; wv < kKnnBins / 4; ++wv) hw[wv][tid] = 0u;
+  const int cx = cell_coord(q.x, G.g.origin[0], G.g.inv_cell);
+  const int cy = cell_coord(q.y, G.g.origin[1], G.g.inv_cell);
+  const int cz = cell_coord(q.z, G.g.origin[2], G.g.inv_cell);
+  const float inv_w2 = 32.0f * G.g.inv_cell * G.g.inv_cell;
+  auto add = [&](float d2) {
+    const float bb = d2 * inv_w2;
+    if (bb < (float)kKnnBins) { const int b = (int)bb; atomicAdd(&hw[b >> 2][tid], 1u << (8 * (b & 3))); }
+  };
+  for (int oz = -1; oz <= 1; ++oz)
+    for (int oy = -1; oy <= 1; ++oy)
+      knn_row(G, table, cx - 1, cx + 1, cy + oy, cz + oz, [&](unsigned m, unsigned e) {
+        for (; m + 8 <= e; m += 8) {                                  // eight candidates in flight per lane
+          float4 cb[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) cb[j] = P4[m + j];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) add(sqdist_l2(q.x, q.y, q.z, cb[j].x, cb[j].y, cb[j].z));
+        }
+        for (; m < e; ++m) { const float4 c = P4[m]; add(sqdist_l2(q.x, q.y, q.z, c.x, c.y, c.z)); }
+      });
+  // first bin at which the running count reaches k (a byte that wrapped only makes the count too small: checked after pass B)
+  int sel = 255, cum = 0;
+  for (int wv = 0; wv < kKnnBins / 4 && sel == 255; ++wv) {
+    const unsigned word = hw[wv][tid];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      cum += (int)((word >> (8 * j)) & 0xFFu);
+      if (sel == 255 && cum >= k) sel = 4 * wv + j;
+    }
+  }
+  sel_bin[gi] = (unsigned char)sel;
+  // the counts themselves: pass B turns them into the slot ranges of a bucket sort (bins up to the selected one only)
+  if (sel != 255) {
+#pragma unroll
+    for (int wv = 0; wv < kKnnBins / 4; ++wv)
+      if (4 * wv <= sel) hist_out[(size_t)wv * n_todo + gi] = hw[wv][tid];
+  }
+}
 
 __device__ __forceinline__ bool knn_less(float d1, unsigned p1, float d2, unsigned p2, const float4* __restrict__ P4) {
   if (d1 != d2) return d1 < d2;
@@ -115,19 +204,42 @@ __device__ __forceinline__ void eigen33_smallest(const float* cov, float& eigenv
 //      reads, cheaper than a sift-down's dependent chain while k is small -- 20 M points: k = 8 20.7 vs 23.1 ms, k = 32 121 vs 83 ms);
 //   2  the unsorted list in groups of eight with each group's worst entry in registers (16 < k <= 32): a replacement re-scans
 //      one group (8 independent reads) and picks the worst of at most four group maxima.
+//   3  (k <= 32) TWO PASSES without any per-candidate list maintenance -- with 64 lanes some lane replaces an entry at almost
+//      every candidate, so the variants above walk their replacement path for nearly every candidate (rocprofv3: ~130
+//      instructions per candidate).  Pass A only counts: a 64-bin histogram of the squared distances (bin width = cell^2 / 32,
+//      one byte per bin, four bins per LDS word, one ds_add per candidate) gives the first bin b at which the count reaches k.
+//      Pass B collects the candidates of bins <= b (k plus a handful) and skips the cells farther away than that distance.
+//      The collected set contains the k nearest -- it holds EVERY candidate up to a distance with at least k of them.  Pass A
+//      runs as its own kernel (k_knn_hist: 64 B of LDS per query, full occupancy) and leaves the selected bin and the counts in
+//      HBM; pass B turns the counts into slot offsets of a bucket sort by bin PAIRS, places every candidate with one LDS
+//      fetch-and-add (eight loads, then eight atomics, then the stores per round) next to a 16-bit key of its distance, and
+//      finishes with an insertion sort over the nearly sorted keys (equal keys compare the recomputed f32 distances and the
+//      original indices): the list comes out in (distance, original index) order like the other variants'.  Whatever does not fit (more than `cap`
+//      candidates in those bins: duplicates; no bin reaches k within 2 cell^2; a saturated byte) is checked after pass B and
+//      sent to `fb_todo`, which the host runs through the list-maintaining variant on the same grid: results are exact either way.
+//      (20 M points, k = 32: 64 ms with variant 2 -> 19 ms; k = 8: 18 -> 10.5 ms.)
+// reach: 1 = the 27 cells around the query's cell; 2 = the 125 cells (list-maintaining variants only), the retry pass for the
+// ~1 % of queries whose k-th neighbour lies outside the 27 cells, instead of a second grid of twice the cell size.
 template <int kSel>
 __global__ __launch_bounds__(kKnnBlock) void k_knn_normals(const float4* __restrict__ P4, size_t n,
                                                            const unsigned* __restrict__ todo, size_t n_todo,
-                                                           const HashEntry* __restrict__ table, KnnGrid G, int k,
+                                                           const HashEntry* __restrict__ table, KnnGrid G, int k, int cap,
                                                            float vpx, float vpy, float vpz,
                                                            const float4* __restrict__ Q4 /* queries by sorted pos of level 0 */,
                                                            float* __restrict__ out_n, float* __restrict__ out_c,
                                                            int* __restrict__ out_knn, float* __restrict__ out_mean,
                                                            unsigned* __restrict__ next_todo,
-                                                           unsigned* __restrict__ next_count) {
+                                                           unsigned* __restrict__ next_count,
+                                                           unsigned* __restrict__ fb_todo, unsigned* __restrict__ fb_count,
+                                                           const unsigned char* __restrict__ sel_bins,
+                                                           const unsigned* __restrict__ hist_in, int reach) {
   extern __shared__ unsigned char smem[];
-  float* hd = reinterpret_cast<float*>(smem);                         // [k][kKnnBlock]
-  unsigned* hp = reinterpret_cast<unsigned*>(smem) + (size_t)k * kKnnBlock;
+  // variants 0..2: [cap = k distances][cap positions]; variant 3: [kKnnBins / 8 words of slot offsets][cap positions][cap 16-bit
+  // distance keys] (cap even)
+  constexpr int kOffWords = (kSel == 3) ? kKnnBins / 8 : 0;
+  float* hd = reinterpret_cast<float*>(smem) + (size_t)kOffWords * kKnnBlock;
+  unsigned* hp = reinterpret_cast<unsigned*>(smem) + (size_t)(kOffWords + (kSel == 3 ? 0 : cap)) * kKnnBlock;
+  unsigned short* hk = reinterpret_cast<unsigned short*>(hp + (size_t)cap * kKnnBlock);   // variant 3: 16-bit distance keys
   const int tid = threadIdx.x;
   const size_t gi = (size_t)blockIdx.x * blockDim.x + tid;
   if (gi >= n_todo) return;
@@ -136,6 +248,7 @@ __global__ __launch_bounds__(kKnnBlock) void k_knn_normals(const float4* __restr
   const unsigned q_oi = __float_as_uint(q.w);
 #define HD(i) hd[(size_t)(i) * kKnnBlock + tid]
 #define HP(i) hp[(size_t)(i) * kKnnBlock + tid]
+#define HK(i) hk[(size_t)(i) * kKnnBlock + tid]
   // !kHeap: the k best so far live UNSORTED in LDS; the worst of them (by (distance, original index), the order of the result
   // list) is cached in registers with its slot.  A candidate costs one compare against that register; one that enters overwrites
   // the worst slot and re-scans the k distances for the new worst.
@@ -234,42 +347,169 @@ __global__ __launch_bounds__(kKnnBlock) void k_knn_normals(const float4* __restr
   const int cy = cell_coord(q.y, G.g.origin[1], G.g.inv_cell);
   const int cz = cell_coord(q.z, G.g.origin[2], G.g.inv_cell);
   constexpr int kMaxC = (1 << 21) - 1;
-  // own cell first, then face, edge and corner neighbours: the list fills with near points early, so fewer of the later candidates
-  // replace an entry (the result does not depend on the order)
-  for (int ring = 0; ring <= 3; ++ring)
-  for (int oz = -1; oz <= 1; ++oz)
-    for (int oy = -1; oy <= 1; ++oy)
-      for (int ox = -1; ox <= 1; ++ox) {
-        if ((ox != 0) + (oy != 0) + (oz != 0) != ring) continue;
-        const int x = cx + ox, y = cy + oy, z = cz + oz;
-        if (x < 0 || y < 0 || z < 0 || x > kMaxC || y > kMaxC || z > kMaxC) continue;
-        if (ring > 0 && cnt == k) {
-          // the list is full: a neighbour cell whose nearest face is farther than the current worst entry cannot contribute
-          // (every point of the cell is at least that far; `slack` covers the rounding of cell_coord as in the test below).
-          // Queries of a wave share their cell, so whole waves skip the same cells.
-          const float fx = ox < 0 ? q.x - (G.g.origin[0] + (float)cx * G.cell) : (ox > 0 ? (G.g.origin[0] + (float)(cx + 1) * G.cell) - q.x : 0.f);
-          const float fy = oy < 0 ? q.y - (G.g.origin[1] + (float)cy * G.cell) : (oy > 0 ? (G.g.origin[1] + (float)(cy + 1) * G.cell) - q.y : 0.f);
-          const float fz = oz < 0 ? q.z - (G.g.origin[2] + (float)cz * G.cell) : (oz > 0 ? (G.g.origin[2] + (float)(cz + 1) * G.cell) - q.z : 0.f);
-          const float ax = fmaxf(fx, 0.f), ay = fmaxf(fy, 0.f), az = fmaxf(fz, 0.f);
-          const float face = sqrtf(ax * ax + ay * ay + az * az) - G.slack;
-          if (face > 0.f && face * face * 0.99999f > (kHeap ? HD(0) : td)) continue;
+  // squared distance from the query to the nearest face of neighbour cell (ox, oy, oz), minus the rounding slack of cell_coord
+  auto face2 = [&](int ox, int oy, int oz) -> float {
+    const float fx = ox < 0 ? q.x - (G.g.origin[0] + (float)cx * G.cell) : (ox > 0 ? (G.g.origin[0] + (float)(cx + 1) * G.cell) - q.x : 0.f);
+    const float fy = oy < 0 ? q.y - (G.g.origin[1] + (float)cy * G.cell) : (oy > 0 ? (G.g.origin[1] + (float)(cy + 1) * G.cell) - q.y : 0.f);
+    const float fz = oz < 0 ? q.z - (G.g.origin[2] + (float)cz * G.cell) : (oz > 0 ? (G.g.origin[2] + (float)(cz + 1) * G.cell) - q.z : 0.f);
+    const float ax = fmaxf(fx, 0.f), ay = fmaxf(fy, 0.f), az = fmaxf(fz, 0.f);
+    const float face = sqrtf(ax * ax + ay * ay + az * az) - G.slack;
+    return face > 0.f ? face * face * 0.99999f : 0.f;
+  };
+  bool fallback = false;
+  if constexpr (kSel == 3) {
+    const float inv_w2 = 32.0f * G.g.inv_cell * G.g.inv_cell;       // bins of cell^2 / 32: [0, 2 cell^2)
+    const int sel_bin = (int)sel_bins[gi];                          // pass A (k_knn_hist)
+    if (sel_bin >= kKnnBins) {
+      fallback = true;                                                // the k-th neighbour lies beyond the histogram's range
+    } else {
+      // ---- bucket sort by PAIRS of histogram bins: pass A's counts become slot offsets (one byte per bin pair), pass B puts
+      //      every candidate of the bins <= sel_bin straight into its pair's slot range; the list then only needs an insertion
+      //      sort over a nearly sorted array (a pair holds ~1 candidate) ----
+      unsigned* ow = reinterpret_cast<unsigned*>(smem);
+#define OW(w) ow[(size_t)(w) * kKnnBlock + tid]
+      int total = 0;
+#pragma unroll
+      for (int wv = 0; wv < kKnnBins / 8; ++wv) {
+        unsigned packed = 0u;
+        if (8 * wv <= sel_bin) {
+          const unsigned h0 = hist_in[(size_t)(2 * wv) * n_todo + gi];
+          const unsigned h1 = (8 * wv + 4 <= sel_bin) ? hist_in[(size_t)(2 * wv + 1) * n_todo + gi] : 0u;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {                               // pair j of this word = bins 8 wv + 2 j, + 1
+            const unsigned src = (j < 2) ? h0 : h1;
+            const int b0 = 8 * wv + 2 * j;
+            const int c0 = (b0 <= sel_bin) ? (int)((src >> (16 * (j & 1))) & 0xFFu) : 0;
+            const int c1 = (b0 + 1 <= sel_bin) ? (int)((src >> (16 * (j & 1) + 8)) & 0xFFu) : 0;
+            packed |= (unsigned)min(total, 255) << (8 * j);
+            total += c0 + c1;
+          }
         }
-        const unsigned long long key = cell_key(x, y, z);
-        unsigned h = hash_key(key) & G.g.mask;
-        unsigned s = 0, e = 0;
-        for (;;) {
-          const HashEntry en = table[h];
-          if (en.key == key) { s = en.start; e = en.end; break; }
-          if (en.key == kEmptyKey) break;
-          h = (h + 1) & G.g.mask;
-        }
-        unsigned m = s;
-        for (; m + 4 <= e; m += 4) {                                  // four candidates in flight per lane
-          const float4 c0 = P4[m], c1 = P4[m + 1], c2 = P4[m + 2], c3 = P4[m + 3];
-          consider(m, c0); consider(m + 1, c1); consider(m + 2, c2); consider(m + 3, c3);
-        }
-        for (; m < e; ++m) consider(m, P4[m]);
+        OW(wv) = packed;
       }
+      if (total > cap || total < k) {
+        fallback = true;
+      } else {
+        const float tau2 = (float)(sel_bin + 1) * (1.0f / inv_w2) * 1.00001f;
+        int placed = 0;
+        // slot of a candidate = fetch-and-add on its pair's offset byte.  Eight candidates per round: their loads, then their LDS
+        // atomics (with return; the same lane's atomics on one word are served in order), then the stores -- one wait per stage
+        // instead of a load -> read -> write chain per candidate.
+        auto place8 = [&](unsigned m, const float4* cb, int nvalid) {
+          unsigned old[8]; float bbv[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float d2 = sqdist_l2(q.x, q.y, q.z, cb[j].x, cb[j].y, cb[j].z);
+            const float bb = d2 * inv_w2;
+            const bool in = j < nvalid && bb < (float)kKnnBins && (int)bb <= sel_bin;
+            const int pr = in ? ((int)bb >> 1) : 0;
+            bbv[j] = in ? bb : -1.f;
+            old[j] = atomicAdd(&OW(pr >> 2), in ? (1u << (8 * (pr & 3))) : 0u);
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            if (bbv[j] >= 0.f) {
+              const int pr = (int)bbv[j] >> 1;
+              const int slot = (int)((old[j] >> (8 * (pr & 3))) & 0xFFu);
+              if (slot < cap) { HP(slot) = m + j; HK(slot) = (unsigned short)(bbv[j] * 1024.0f); }
+              ++placed;
+            }
+          }
+        };
+        for (int oz = -1; oz <= 1; ++oz)
+          for (int oy = -1; oy <= 1; ++oy) {
+            if ((oy | oz) != 0 && face2(0, oy, oz) > tau2) continue;
+            const int xlo = (face2(-1, oy, oz) > tau2) ? cx : cx - 1, xhi = (face2(1, oy, oz) > tau2) ? cx : cx + 1;
+            knn_row(G, table, xlo, xhi, cy + oy, cz + oz, [&](unsigned m, unsigned e) {
+              for (; m < e; m += 8) {                                  // eight candidates in flight per lane
+                float4 cb[8];
+                const int nvalid = (int)min(8u, e - m);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) cb[j] = P4[min(m + j, e - 1)];
+                place8(m, cb, nvalid);
+              }
+            });
+          }
+        // a histogram byte that wrapped (>= 256 candidates in one bin) shows as a count mismatch: the other variant takes over
+        if (placed != total) {
+          fallback = true;
+        } else {
+          cnt = total;
+          // exact (d2, original index) order: the bin pairs are in order already, and inside a pair a 16-bit key (the squared
+          // distance in 1/1024 of a bin, monotone in the f32 value) decides; only equal keys compare the recomputed distances.
+          // One insertion sort over the nearly sorted list, LDS traffic only.
+          auto dist_of = [&](unsigned m) { const float4 c = P4[m]; return sqdist_l2(q.x, q.y, q.z, c.x, c.y, c.z); };
+          unsigned prev_key = HK(0);
+          for (int i = 1; i < cnt; ++i) {
+            const unsigned kk = HK(i);
+            if (kk > prev_key) { prev_key = kk; continue; }                       // in place already (the common case)
+            const unsigned kp = HP(i);
+            float kd = -1.f;
+            int j = i - 1;
+            while (j >= 0) {
+              const unsigned jk = HK(j);
+              if (jk < kk) break;
+              const unsigned jp = HP(j);
+              if (jk == kk) {
+                if (kd < 0.f) kd = dist_of(kp);
+                if (!knn_less(kd, kp, dist_of(jp), jp, P4)) break;
+              }
+              HP(j + 1) = jp; HK(j + 1) = (unsigned short)jk;
+              --j;
+            }
+            HP(j + 1) = kp; HK(j + 1) = (unsigned short)kk;
+            // prev_key stays: slot i now holds the former slot i - 1, the largest key so far
+          }
+          td = dist_of(HP(cnt - 1));                                            // the farthest collected candidate
+        }
+      }
+#undef OW
+    }
+  } else {
+  // own cell first, then face, edge and corner neighbours: the list fills with near points early, so fewer of the later candidates
+    // replace an entry (the result does not depend on the order)
+    // reach 2 (the retry pass on the same grid): the 27 inner cells as above, then the shell of 98 cells around them
+    for (int ring = 0; ring <= 2 + reach; ++ring)
+    for (int oz = -reach; oz <= reach; ++oz)
+      for (int oy = -reach; oy <= reach; ++oy)
+        for (int ox = -reach; ox <= reach; ++ox) {
+          const int cheb = max(max(abs(ox), abs(oy)), abs(oz));
+          if ((cheb <= 1 ? (ox != 0) + (oy != 0) + (oz != 0) : 2 + cheb) != ring) continue;
+          const int x = cx + ox, y = cy + oy, z = cz + oz;
+          if (x < 0 || y < 0 || z < 0 || x > kMaxC || y > kMaxC || z > kMaxC) continue;
+          if (ring > 0 && cnt == k) {
+            // the list is full: a neighbour cell whose nearest face is farther than the current worst entry cannot contribute
+            // (every point of the cell is at least that far; `slack` covers the rounding of cell_coord as in the test below).
+            // Queries of a wave share their cell, so whole waves skip the same cells.
+            const float fx = ox < 0 ? q.x - (G.g.origin[0] + (float)(cx + ox + 1) * G.cell) : (ox > 0 ? (G.g.origin[0] + (float)(cx + ox) * G.cell) - q.x : 0.f);
+            const float fy = oy < 0 ? q.y - (G.g.origin[1] + (float)(cy + oy + 1) * G.cell) : (oy > 0 ? (G.g.origin[1] + (float)(cy + oy) * G.cell) - q.y : 0.f);
+            const float fz = oz < 0 ? q.z - (G.g.origin[2] + (float)(cz + oz + 1) * G.cell) : (oz > 0 ? (G.g.origin[2] + (float)(cz + oz) * G.cell) - q.z : 0.f);
+            const float ax = fmaxf(fx, 0.f), ay = fmaxf(fy, 0.f), az = fmaxf(fz, 0.f);
+            const float face = sqrtf(ax * ax + ay * ay + az * az) - G.slack;
+            if (face > 0.f && face * face * 0.99999f > (kHeap ? HD(0) : td)) continue;
+          }
+          const unsigned long long key = cell_key(x, y, z);
+          unsigned h = hash_key(key) & G.g.mask;
+          unsigned s = 0, e = 0;
+          for (;;) {
+            const HashEntry en = table[h];
+            if (en.key == key) { s = en.start; e = en.end; break; }
+            if (en.key == kEmptyKey) break;
+            h = (h + 1) & G.g.mask;
+          }
+          unsigned m = s;
+          for (; m + 4 <= e; m += 4) {                                  // four candidates in flight per lane
+            const float4 c0 = P4[m], c1 = P4[m + 1], c2 = P4[m + 2], c3 = P4[m + 3];
+            consider(m, c0); consider(m + 1, c1); consider(m + 2, c2); consider(m + 3, c3);
+          }
+          for (; m < e; ++m) consider(m, P4[m]);
+        }
+}
+  if (fallback) {
+    const unsigned slot = atomicAdd(fb_count, 1u);
+    fb_todo[slot] = qid;
+    return;
+  }
   // resolved?  the k-th neighbour must be strictly closer than the nearest face of the 27-cell block that still
   // has data behind it
   bool resolved;
@@ -280,15 +520,16 @@ __global__ __launch_bounds__(kKnnBlock) void k_knn_normals(const float4* __restr
     bool covers_all = true;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-      const float lo = G.g.origin[a] + (float)(c[a] - 1) * G.cell;
-      const float hi = G.g.origin[a] + (float)(c[a] + 2) * G.cell;
+      const float lo = G.g.origin[a] + (float)(c[a] - reach) * G.cell;
+      const float hi = G.g.origin[a] + (float)(c[a] + reach + 1) * G.cell;
       if (lo > G.dmin[a]) { safe = fminf(safe, qq[a] - lo); covers_all = false; }
       if (hi <= G.dmax[a]) { safe = fminf(safe, hi - qq[a]); covers_all = false; }
     }
     if (covers_all) resolved = true;
     else {
       safe -= G.slack;
-      resolved = (cnt == k) && safe > 0.f && (kHeap ? HD(0) : td) < safe * safe * 0.99999f;
+      const float kth = kHeap ? HD(0) : td;      // variant 3: the farthest collected candidate (>= the k-th nearest)
+      resolved = (cnt >= k) && safe > 0.f && kth < safe * safe * 0.99999f;
     }
   }
   if (!resolved) {
@@ -296,8 +537,11 @@ __global__ __launch_bounds__(kKnnBlock) void k_knn_normals(const float4* __restr
     next_todo[slot] = qid;
     return;
   }
+  if constexpr (kSel == 3) {
+    // sorted already (bucket order + exact order inside the buckets)
+  } else {
   // heap sort in place -> ascending (d2, original index): Floyd's heap construction, then repeated extraction of the maximum
-  for (int start = kHeap ? -1 : cnt / 2 - 1; start >= 0; --start) {
+  for (int start = kHeap ? -1 : cnt / 2 - 1; start >= 0; --start) {     // (variant 3: cnt may exceed k here, all of it is sorted)
     const float ld = HD(start); const unsigned lp = HP(start);
     int i = start;
     for (;;) {
@@ -324,6 +568,8 @@ __global__ __launch_bounds__(kKnnBlock) void k_knn_normals(const float4* __restr
     }
     HD(i) = ld; HP(i) = lp;
   }
+  }
+  if (cnt > k) cnt = k;            // variant 3 collected a few more than k: the sorted list's first k are the neighbours
   if (out_knn) {
     for (int i = 0; i < k; ++i) out_knn[(size_t)q_oi * k + i] = (i < cnt) ? (int)__float_as_uint(P4[HP(i)].w) : -1;
   }
@@ -331,7 +577,12 @@ __global__ __launch_bounds__(kKnnBlock) void k_knn_normals(const float4* __restr
     // LocalStatisticalOutlierRemoval, first pass (local_statistical_outlier_removal.hpp:104-109): mean distance to the
     // k - 1 nearest neighbours (entry 0 is the query point), f64 sum of the f32 roots in neighbour order
     double dist_sum = 0.0;
-    for (int i = 1; i < cnt; ++i) dist_sum += (double)sqrtf(HD(i));
+    for (int i = 1; i < cnt; ++i) {
+      float d2i;
+      if constexpr (kSel == 3) { const float4 c = P4[HP(i)]; d2i = sqdist_l2(q.x, q.y, q.z, c.x, c.y, c.z); }
+      else d2i = HD(i);
+      dist_sum += (double)sqrtf(d2i);
+    }
     out_mean[q_oi] = (float)(dist_sum / (double)(k - 1));
   }
   if (!out_n) return;
@@ -341,19 +592,34 @@ __global__ __launch_bounds__(kKnnBlock) void k_knn_normals(const float4* __restr
     nx = ny = nz = curv = qnan;
   } else {
     // two_pass_centroid.hpp:176-192 (dense branch), f32, neighbour order
+    // the neighbours are gathered eight at a time (eight independent loads in flight); the sums keep the neighbour order
     float a6 = 0.f, a7 = 0.f, a8 = 0.f;
-    for (int i = 0; i < cnt; ++i) { const float4 p = P4[HP(i)]; a6 += p.x; a7 += p.y; a8 += p.z; }
+    for (int i0 = 0; i0 < cnt; i0 += 8) {
+      float4 pb[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pb[j] = P4[HP(min(i0 + j, cnt - 1))];
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (i0 + j < cnt) { a6 += pb[j].x; a7 += pb[j].y; a8 += pb[j].z; }
+    }
     const float fc = (float)cnt;
     a6 = a6 / fc; a7 = a7 / fc; a8 = a8 / fc;
     float a0 = 0.f / fc, a1 = 0.f / fc, a2 = 0.f / fc, a3 = 0.f / fc, a4 = 0.f / fc, a5 = 0.f / fc;
-    for (int i = 0; i < cnt; ++i) {
-      const float4 p = P4[HP(i)];
-      a0 += (p.x - a6) * (p.x - a6);
-      a1 += (p.x - a6) * (p.y - a7);
-      a2 += (p.x - a6) * (p.z - a8);
-      a3 += (p.y - a7) * (p.y - a7);
-      a4 += (p.y - a7) * (p.z - a8);
-      a5 += (p.z - a8) * (p.z - a8);
+    for (int i0 = 0; i0 < cnt; i0 += 8) {
+      float4 pb[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pb[j] = P4[HP(min(i0 + j, cnt - 1))];
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (i0 + j < cnt) {
+          const float4 p = pb[j];
+          a0 += (p.x - a6) * (p.x - a6);
+          a1 += (p.x - a6) * (p.y - a7);
+          a2 += (p.x - a6) * (p.z - a8);
+          a3 += (p.y - a7) * (p.y - a7);
+          a4 += (p.y - a7) * (p.z - a8);
+          a5 += (p.z - a8) * (p.z - a8);
+        }
     }
     float cov[9];
     cov[0] = a0 / fc; cov[1] = a1 / fc; cov[2] = a2 / fc; cov[4] = a3 / fc; cov[5] = a4 / fc; cov[8] = a5 / fc;
@@ -372,6 +638,7 @@ __global__ __launch_bounds__(kKnnBlock) void k_knn_normals(const float4* __restr
   out_c[q_oi] = curv;
 #undef HD
 #undef HP
+#undef HK
 }
 
 // Radius-search variant (pcl::Feature::searchForNeighbors with setRadiusSearch, two_pass_normal_3d_omp.hpp:66): every
@@ -460,18 +727,89 @@ struct LevelBuffers {
   DevBuf<char> temp;
   DevBuf<float4> P4, LN;
   DevBuf<HashEntry> table;
+  DevBuf<unsigned> dense;          // dense cell-start directory of the level (when the bounding grid is small enough)
+  DevBuf<unsigned char> sel_bin;   // pass A results of the two-pass variant: selected bin,
+  DevBuf<unsigned> hist;           // histogram words [kKnnBins / 4][queries of the pass]
+};
+
+
+// Device buffers of one kNN call.  A 20 M point call touches ~5 GB in ~20 buffers; allocating and freeing them costs several
+// milliseconds per call (hipMalloc maps pages, hipFree synchronises the device), so finished calls park their workspace in a
+// per-process pool and the next call on the same device takes it over.  e3d_release_workspaces() empties the pool; workspaces
+// above E3D_WORKSPACE_KEEP_GB (default 32) are freed right away.
+struct KnnWorkspace {
+  int device = -1;
+  hipStream_t stream = nullptr;
+  DevBuf<float> raw, bbox_partial, bbox_out, d_on, d_oc, d_mean;
+  DevBuf<int> d_knn;
+  DevBuf<unsigned char> d_in;
+  LevelBuffers L;
+  DevBuf<float4> Q4;
+  DevBuf<unsigned> todo_a, todo_b, fb_todo;
+  size_t bytes() const {
+    return raw.cap * 4 + bbox_partial.cap * 4 + bbox_out.cap * 4 + d_on.cap * 4 + d_oc.cap * 4 + d_mean.cap * 4 + d_knn.cap * 4 + d_in.cap +
+           L.ka.cap * 8 + L.kb.cap * 8 + L.va.cap * 4 + L.vb.cap * 4 + L.counter.cap * 4 + L.temp.cap + L.P4.cap * 16 + L.LN.cap * 16 +
+           L.table.cap * sizeof(HashEntry) + L.dense.cap * 4 + L.sel_bin.cap + L.hist.cap * 4 + Q4.cap * 16 + todo_a.cap * 4 +
+           todo_b.cap * 4 + fb_todo.cap * 4;
+  }
+  ~KnnWorkspace() { if (stream) (void)hipStreamDestroy(stream); }
+};
+
+static std::mutex& workspace_mutex() { static std::mutex* m = new std::mutex; return *m; }
+static std::vector<KnnWorkspace*>& workspace_pool() { static auto* v = new std::vector<KnnWorkspace*>; return *v; }   // never destroyed: no HIP calls at exit
+
+struct WorkspaceLease {
+  KnnWorkspace* ws = nullptr;
+  WorkspaceLease() {
+    int dev = 0;
+    E3D_HIP(hipGetDevice(&dev));
+    {
+      std::lock_guard<std::mutex> lock(workspace_mutex());
+      auto& pool = workspace_pool();
+      for (size_t i = 0; i < pool.size(); ++i)
+        if (pool[i]->device == dev) { ws = pool[i]; pool.erase(pool.begin() + (long)i); break; }
+    }
+    if (!ws) {
+      ws = new KnnWorkspace;
+      ws->device = dev;
+      if (hipStreamCreateWithFlags(&ws->stream, hipStreamNonBlocking) != hipSuccess) { delete ws; ws = nullptr; throw Error(E3D_ERR_HIP, "hipStreamCreate failed"); }
+    }
+  }
+  ~WorkspaceLease() {
+    if (!ws) return;
+    static const double keep_gb = [] { const char* e = getenv("E3D_WORKSPACE_KEEP_GB"); return e ? atof(e) : 32.0; }();
+    if ((double)ws->bytes() > keep_gb * 1073741824.0) { delete ws; return; }
+    std::lock_guard<std::mutex> lock(workspace_mutex());
+    workspace_pool().push_back(ws);
+  }
 };
 
 }  // namespace e3d
 
 using namespace e3d;
 
+extern "C" int e3d_release_workspaces(void) {
+  std::vector<KnnWorkspace*> take;
+  {
+    std::lock_guard<std::mutex> lock(workspace_mutex());
+    take.swap(workspace_pool());
+  }
+  int prev = 0;
+  const bool have_dev = hipGetDevice(&prev) == hipSuccess;
+  for (KnnWorkspace* w : take) { (void)hipSetDevice(w->device); delete w; }
+  if (have_dev) (void)hipSetDevice(prev);
+  return 0;
+}
+
 namespace e3d {
 // The exact kNN pass over a host cloud.  Results stay on the device: normals + curvature (if want_normals), the neighbour
 // index lists (if d_knn) and the mean neighbour distance (if d_mean), all in input order.
-static void knn_pass(const float* xyz, size_t n, int k, const float* viewpoint, bool want_normals, DevBuf<float>& d_on,
-                     DevBuf<float>& d_oc, DevBuf<int>* d_knn_out, DevBuf<float>* d_mean_out, hipStream_t s) {
-    DevBuf<float> raw, bbox_partial, bbox_out;
+static void knn_pass(KnnWorkspace& W, const float* xyz, size_t n, int k, const float* viewpoint, bool want_normals, bool want_knn,
+                     bool want_mean) {
+    hipStream_t s = W.stream;
+    DevBuf<float>&raw = W.raw, &bbox_partial = W.bbox_partial, &bbox_out = W.bbox_out, &d_on = W.d_on, &d_oc = W.d_oc;
+    DevBuf<int>* d_knn_out = want_knn ? &W.d_knn : nullptr;
+    DevBuf<float>* d_mean_out = want_mean ? &W.d_mean : nullptr;
     raw.reserve(3 * n);
     if (want_normals) { d_on.reserve(3 * n); d_oc.reserve(n); }
     if (d_knn_out) d_knn_out->reserve(n * (size_t)k);
@@ -494,29 +832,37 @@ static void knn_pass(const float* xyz, size_t n, int k, const float* viewpoint, 
     if (!(area > 0)) area = extent * extent;
     (void)vol;
     // (swept at 20 M points of the synthetic room scan, tools/bench_normals.py: the estimate is low in the dense part of a scan,
-    // where most points are; 1.5 is the optimum for k = 32, 0.35 - 1.2 a plateau for k = 8; E3D_KNN_CELL_FACTOR overrides)
+    // where most points are; with the two-pass variant 1.2 - 1.5 is the optimum for k = 32 and 0.3 - 0.5 for k = 8; E3D_KNN_CELL_FACTOR overrides)
     static const double cell_factor_env = [] { const char* e = getenv("E3D_KNN_CELL_FACTOR"); const double v = e ? atof(e) : 0.0; return v > 0 ? v : 0.0; }();
-    const double cell_factor = cell_factor_env > 0 ? cell_factor_env : (k > 16 ? 1.5 : 1.0);
+    const double cell_factor = cell_factor_env > 0 ? cell_factor_env : (k > 16 ? 1.3 : 0.45);
     double cell = std::sqrt((double)k * area / (cell_factor * M_PI * (double)n));
     cell = std::max(cell, extent / 1.0e6);
     double magnitude = 0;
     for (int a = 0; a < 6; ++a) magnitude = std::max(magnitude, std::fabs((double)bb[a]));
 
-    LevelBuffers L;
-    L.ka.reserve(n); L.kb.reserve(n); L.va.reserve(n); L.vb.reserve(n); L.counter.reserve(2);
+    LevelBuffers& L = W.L;
+    L.ka.reserve(n); L.kb.reserve(n); L.va.reserve(n); L.vb.reserve(n); L.counter.reserve(3);
     L.P4.reserve(n);
-    DevBuf<float4> Q4;             // queries in level-0 cell order (spatially coherent for every level)
-    DevBuf<unsigned> todo_a, todo_b;
+    DevBuf<float4>& Q4 = W.Q4;     // queries in level-0 cell order (spatially coherent for every level)
+    DevBuf<unsigned>&todo_a = W.todo_a, &todo_b = W.todo_b;
     todo_a.reserve(n); todo_b.reserve(n);
     unsigned* todo = nullptr;
     size_t n_todo = n;
-    const size_t lds = (size_t)k * kKnnBlock * 8;
-    static const int forced_sel = [] { const char* e = getenv("E3D_KNN_SELECT"); return e ? atoi(e) : -1; }();     // experiments: 0 heap, 1 flat, 2 grouped
-    const int sel = (forced_sel >= 0 && forced_sel <= 2 && (forced_sel != 2 || k <= 32)) ? forced_sel : (k <= 16 ? 1 : (k <= 32 ? 2 : 0));
-    const void* kfn = sel == 0 ? reinterpret_cast<const void*>(k_knn_normals<0>)
-                               : (sel == 1 ? reinterpret_cast<const void*>(k_knn_normals<1>) : reinterpret_cast<const void*>(k_knn_normals<2>));
-    E3D_HIP(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    static const int forced_sel = [] { const char* e = getenv("E3D_KNN_SELECT"); return e ? atoi(e) : -1; }();     // experiments: 0 heap, 1 flat, 2 grouped, 3 two-pass
+    const int sel_list = k <= 16 ? 1 : (k <= 32 ? 2 : 0);                   // list-maintaining variant (also variant 3's fallback)
+    const int sel = (forced_sel >= 0 && forced_sel <= 3 && (forced_sel < 2 || k <= 32)) ? forced_sel : (k <= 32 ? 3 : 0);
+    static const int cap_extra = [] { const char* e = getenv("E3D_KNN_CAP_EXTRA"); return e ? atoi(e) : 4; }();
+    const int cap = sel == 3 ? ((std::max(k + cap_extra, 12) + 1) & ~1) : k;             // list entries per thread in LDS
+    const size_t lds = sel == 3 ? (size_t)(kKnnBins / 8 + cap + cap / 2) * kKnnBlock * 4 : (size_t)cap * kKnnBlock * 8, lds_list = (size_t)k * kKnnBlock * 8;
+    auto kernel_of = [](int v) {
+      return v == 0 ? k_knn_normals<0> : (v == 1 ? k_knn_normals<1> : (v == 2 ? k_knn_normals<2> : k_knn_normals<3>));
+    };
+    E3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel_of(sel)), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    E3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel_of(sel_list)), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_list));
+    DevBuf<unsigned>& fb_todo = W.fb_todo;
+    if (sel == 3) { fb_todo.reserve(n); L.counter.reserve(3); }
     static const double level_step = [] { const char* e = getenv("E3D_KNN_LEVEL_STEP"); const double v = e ? atof(e) : 0.0; return v > 1 ? v : 2.0; }();   // cell growth per retry level (4 -> 2: -7 % at k = 32)
+    static const bool wide_pass = [] { const char* e = getenv("E3D_KNN_WIDE"); return e ? atoi(e) != 0 : true; }();
     for (int level = 0; level < 64 && n_todo > 0; ++level) {
       KnnGrid G{};
       G.cell = (float)cell;
@@ -539,20 +885,86 @@ static void knn_pass(const float* xyz, size_t n, int k, const float* viewpoint, 
       G.g.mask = (unsigned)(tsize - 1);
       E3D_HIP(hipMemsetAsync(L.table.p, 0xFF, sizeof(HashEntry) * tsize, s));
       launch_build_table(L.kb.p, n, L.table.p, G.g.mask, s);
+      // dense directory over the bounding grid (cells 0 .. cell of the bbox maximum + 2 per axis) unless it would be huge
+      {
+        QueryRange qr{};
+        double prod = 1.0;
+        for (int a = 0; a < 3; ++a) {
+          qr.lo[a] = 0;
+          const double cmax = std::floor(((double)bb[3 + a] - (double)G.g.origin[a]) * (double)G.g.inv_cell);
+          qr.D[a] = (unsigned)std::max(1.0, std::min(cmax + 4.0, 2097152.0));
+          prod *= (double)qr.D[a];
+        }
+        G.S = nullptr;
+        static const int dense_log2 = [] { const char* e = getenv("E3D_KNN_DENSE_LOG2"); return e ? atoi(e) : 30; }();
+        if (prod <= (double)((size_t)1 << dense_log2)) {
+          const size_t ncell = (size_t)prod;
+          L.dense.reserve(ncell + 2);
+          E3D_HIP(hipMemsetAsync(L.dense.p, 0, sizeof(unsigned) * (ncell + 2), s));
+          launch_dense_counts(L.kb.p, n, qr, L.dense.p, s);
+          exclusive_max_scan_u32(L.dense.p, ncell + 2, L.temp, s);
+          G.S = L.dense.p;
+          for (int a = 0; a < 3; ++a) G.D[a] = qr.D[a];
+        }
+      }
       if (level == 0) {
         Q4.reserve(n);
         E3D_HIP(hipMemcpyAsync(Q4.p, L.P4.p, sizeof(float4) * n, hipMemcpyDeviceToDevice, s));
       }
       unsigned* next = (todo == todo_a.p) ? todo_b.p : todo_a.p;
-      E3D_HIP(hipMemsetAsync(L.counter.p + 1, 0, sizeof(unsigned), s));
+      E3D_HIP(hipMemsetAsync(L.counter.p + 1, 0, 2 * sizeof(unsigned), s));
       const unsigned nblk = (unsigned)div_up(n_todo, kKnnBlock);
-      hipLaunchKernelGGL(sel == 0 ? k_knn_normals<0> : (sel == 1 ? k_knn_normals<1> : k_knn_normals<2>), dim3(nblk), dim3(kKnnBlock), lds, s, L.P4.p, n, todo, n_todo, L.table.p, G, k,
+      if (sel == 3) {
+        L.sel_bin.reserve(n_todo); L.hist.reserve(n_todo * (size_t)(kKnnBins / 4));
+        hipLaunchKernelGGL(k_knn_hist, dim3((unsigned)div_up(n_todo, kKnnHistBlock)), dim3(kKnnHistBlock), 0, s, L.P4.p, todo, n_todo,
+                           L.table.p, G, k, Q4.p, L.sel_bin.p, L.hist.p);
+      }
+      hipLaunchKernelGGL(kernel_of(sel), dim3(nblk), dim3(kKnnBlock), lds, s, L.P4.p, n, todo, n_todo, L.table.p, G, k, cap,
                          viewpoint[0], viewpoint[1], viewpoint[2], Q4.p, want_normals ? d_on.p : nullptr, want_normals ? d_oc.p : nullptr,
-                         knn_indices ? d_knn.p : nullptr, d_mean_out ? d_mean_out->p : nullptr, next, L.counter.p + 1);
-      unsigned n_next = 0;
-      E3D_HIP(hipMemcpyAsync(&n_next, L.counter.p + 1, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+                         knn_indices ? d_knn.p : nullptr, d_mean_out ? d_mean_out->p : nullptr, next, L.counter.p + 1,
+                         fb_todo.p, L.counter.p + 2, L.sel_bin.p, L.hist.p, 1);
+      unsigned cnts[2] = {0, 0};
+      E3D_HIP(hipMemcpyAsync(cnts, L.counter.p + 1, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, s));
       E3D_HIP(hipStreamSynchronize(s));
       E3D_HIP(hipGetLastError());
+      const unsigned n_fb = cnts[1];
+      const bool merge_lists = wide_pass && n_fb > 0 && ((size_t)cnts[0] + n_fb) * 8 <= n;
+      if (merge_lists) {
+        // the two-pass variant's leftovers join the wide pass below (its first 27 cells are this level's block, the shell beyond
+        // them is skipped by the face test once the list is full): one launch instead of two
+        E3D_HIP(hipMemcpyAsync(next + cnts[0], fb_todo.p, sizeof(unsigned) * n_fb, hipMemcpyDeviceToDevice, s));
+        cnts[0] += n_fb;
+      } else if (n_fb > 0) {
+        // queries the two-pass variant could not settle on this level (see its comment): the list-maintaining variant, same
+        // grid, appending its unresolved ones to the same next-level list
+        hipLaunchKernelGGL(kernel_of(sel_list), dim3((unsigned)div_up((size_t)cnts[1], kKnnBlock)), dim3(kKnnBlock), lds_list, s, L.P4.p, n,
+                           fb_todo.p, (size_t)cnts[1], L.table.p, G, k, k, viewpoint[0], viewpoint[1], viewpoint[2], Q4.p,
+                           want_normals ? d_on.p : nullptr, want_normals ? d_oc.p : nullptr, knn_indices ? d_knn.p : nullptr,
+                           d_mean_out ? d_mean_out->p : nullptr, next, L.counter.p + 1, nullptr, nullptr, nullptr, nullptr, 1);
+        E3D_HIP(hipMemcpyAsync(cnts, L.counter.p + 1, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+        E3D_HIP(hipStreamSynchronize(s));
+        E3D_HIP(hipGetLastError());
+      }
+      unsigned n_next = cnts[0];
+      if (getenv("E3D_KNN_STATS")) fprintf(stderr, "[knn] level %d cell %g todo %zu fallback %u next %u\n", level, (double)cell, n_todo, n_fb, n_next);
+      // the few that need a wider look (the k-th neighbour lies outside the 27 cells: sparse regions, outliers): the list-maintaining
+      // variant over the 125 cells of the same grid, which reaches as far as a grid of twice the cell size would -- no second grid
+      // build for ~1 % of the queries
+      if (n_next > 0 && wide_pass && (size_t)n_next * 8 <= n) {
+        unsigned* wide_out = (next == todo_a.p) ? todo_b.p : todo_a.p;
+        E3D_HIP(hipMemsetAsync(L.counter.p + 1, 0, sizeof(unsigned), s));
+        hipLaunchKernelGGL(kernel_of(sel_list), dim3((unsigned)div_up((size_t)n_next, kKnnBlock)), dim3(kKnnBlock), lds_list, s, L.P4.p, n,
+                           next, (size_t)n_next, L.table.p, G, k, k, viewpoint[0], viewpoint[1], viewpoint[2], Q4.p,
+                           want_normals ? d_on.p : nullptr, want_normals ? d_oc.p : nullptr, knn_indices ? d_knn.p : nullptr,
+                           d_mean_out ? d_mean_out->p : nullptr, wide_out, L.counter.p + 1, nullptr, nullptr, nullptr, nullptr, 2);
+        E3D_HIP(hipMemcpyAsync(cnts, L.counter.p + 1, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+        E3D_HIP(hipStreamSynchronize(s));
+        E3D_HIP(hipGetLastError());
+        if (getenv("E3D_KNN_STATS")) fprintf(stderr, "[knn] level %d wide pass todo %u next %u\n", level, n_next, cnts[0]);
+        next = wide_out;
+        n_next = cnts[0];
+        cell *= 2.0;
+      }
       todo = next;
       n_todo = n_next;
       cell *= level_step;
@@ -629,12 +1041,12 @@ extern "C" int e3d_normals_knn(const float* xyz, size_t n, int k, const float* v
     if (n >= (size_t)1 << 31) throw Error(E3D_ERR_INVALID, "e3d_normals_knn: more than 2^31-1 points");
     require_device();
     if (n == 0) return 0;
-    hipStream_t s = nullptr;
-    E3D_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-    struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamDestroy(s); } } guard{s};
-    DevBuf<float> d_on, d_oc;
-    DevBuf<int> d_knn;
-    knn_pass(xyz, n, k, viewpoint, true, d_on, d_oc, knn_indices ? &d_knn : nullptr, nullptr, s);
+    WorkspaceLease lease;
+    KnnWorkspace& W = *lease.ws;
+    hipStream_t s = W.stream;
+    knn_pass(W, xyz, n, k, viewpoint, true, knn_indices != nullptr, false);
+    DevBuf<float>&d_on = W.d_on, &d_oc = W.d_oc;
+    DevBuf<int>& d_knn = W.d_knn;
     copy_out(out_normals, d_on.p, sizeof(float) * 3 * n, s);
     copy_out(out_curvature, d_oc.p, sizeof(float) * n, s);
     if (knn_indices) copy_out(knn_indices, d_knn.p, sizeof(int) * n * (size_t)k, s);
@@ -675,15 +1087,15 @@ extern "C" int e3d_local_outlier_removal(const float* xyz, size_t n, int mean_k,
       pts = finite.data(); m = origin.size();
     }
     if (m <= (size_t)mean_k) throw Error(E3D_ERR_INVALID, fmt("e3d_local_outlier_removal: %zu finite points cannot provide %d neighbours", m, mean_k));
-    hipStream_t s = nullptr;
-    E3D_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-    struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamDestroy(s); } } guard{s};
-    DevBuf<float> d_on, d_oc, d_mean;
-    DevBuf<int> d_knn;
-    DevBuf<unsigned char> d_in;
+    WorkspaceLease lease;
+    KnnWorkspace& W = *lease.ws;
+    hipStream_t s = W.stream;
+    DevBuf<float>& d_mean = W.d_mean;
+    DevBuf<int>& d_knn = W.d_knn;
+    DevBuf<unsigned char>& d_in = W.d_in;
     const float vp[3] = {0.f, 0.f, 0.f};
     const int k = mean_k + 1;
-    knn_pass(pts, m, k, vp, false, d_on, d_oc, &d_knn, &d_mean, s);
+    knn_pass(W, pts, m, k, vp, false, true, true);
     d_in.reserve(m);
     hipLaunchKernelGGL(k_outlier_classify, dim3((unsigned)div_up(m, 256)), dim3(256), 0, s, d_knn.p, d_mean.p, m, k,
                        distance_factor_threshold, negative, d_in.p);
@@ -747,7 +1159,7 @@ extern "C" int e3d_normals_radius(const float* xyz, size_t n, float radius, cons
     G.g.inv_cell = (float)(1.0 / (double)G.cell);
     for (int a = 0; a < 3; ++a) { G.g.origin[a] = (float)((double)bb[a] - 2.0 * cell); G.dmin[a] = bb[a]; G.dmax[a] = bb[3 + a]; }
     LevelBuffers L;
-    L.ka.reserve(n); L.kb.reserve(n); L.va.reserve(n); L.vb.reserve(n); L.counter.reserve(2); L.P4.reserve(n);
+    L.ka.reserve(n); L.kb.reserve(n); L.va.reserve(n); L.vb.reserve(n); L.counter.reserve(3); L.P4.reserve(n);
     launch_cell_keys(raw.p, n, G.g, L.ka.p, L.va.p, s);
     sort_pairs_u64_u32(L.ka.p, L.kb.p, L.va.p, L.vb.p, n, 63, L.temp, s);
     launch_permute(raw.p, nullptr, L.vb.p, n, L.P4.p, nullptr, s);

@@ -177,6 +177,11 @@ int e3d_normals_knn(const float* xyz, size_t n, int k, const float viewpoint[3],
  * src/opt/visibility_estimator.cc:437); kernels, host code and oracle all use this one implementation instead. */
 int e3d_libm_eval(int fn, const float* x, const float* y, size_t n, float* out);
 
+/* e3d_normals_knn / e3d_local_outlier_removal keep their device workspace (the sort, grid and list buffers of the last call, per
+ * device) for the next call instead of paying hipMalloc / hipFree every time; this frees what is parked.  Workspaces larger than
+ * E3D_WORKSPACE_KEEP_GB (environment, default 32) are never kept.  No counterpart in the reference (PCL allocates per call). */
+int e3d_release_workspaces(void);
+
 /* The same estimator with setRadiusSearch(radius) instead of setKSearch: every point strictly within the radius
  * (squared distance < (float)((double)radius * radius)) takes part; fewer than 3 -> NaN.  neighbor_counts (optional, n)
  * receives the number of points found, the query itself included. */

@@ -986,7 +986,9 @@ __global__ __launch_bounds__(256) void k_outlier_classify(const int* __restrict_
   int valid = 0;
   double sum = 0;
   for (int j = 1; j < k; ++j) {
-    const double d = (double)mean_dist[knn[i * k + j]];
+    const int nb = knn[i * k + j];
+    if (nb < 0) break;                                   // cloud smaller than k: the list ends here (nn_indices.size (), :129)
+    const double d = (double)mean_dist[nb];
     if (d > 0) { ++valid; sum += d; }
   }
   const double mean = sum / (double)valid;              // 0 / 0 = NaN: every comparison below is false, as in the reference
@@ -1086,7 +1088,9 @@ extern "C" int e3d_local_outlier_removal(const float* xyz, size_t n, int mean_k,
         }
       pts = finite.data(); m = origin.size();
     }
-    if (m <= (size_t)mean_k) throw Error(E3D_ERR_INVALID, fmt("e3d_local_outlier_removal: %zu finite points cannot provide %d neighbours", m, mean_k));
+    // m <= mean_k: the search returns the m points there are (pcl::KdTreeFLANN clamps k), the mean still divides by mean_k and
+    // the second pass walks the shorter lists -- the neighbour lists are padded with -1 and the kernels stop there
+    if (m == 0) { for (size_t i = 0; i < n; ++i) { inlier[i] = 0; if (mean_distances) mean_distances[i] = 0.f; } return 0; }
     WorkspaceLease lease;
     KnnWorkspace& W = *lease.ws;
     hipStream_t s = W.stream;

@@ -4,6 +4,7 @@
 // occlusion_depth/ (raw float maps per image, optionally gzip-compressed).  The per-image work (occlusion depth, scan
 // point visibility, depth maps) runs on the MI355X behind e3d_reg_count_scan_observations / e3d_reg_ground_truth_depth.
 // Not built: --write_scan_renderings (needs colour image decoding and encoding).
+#include <exception>
 #include <zlib.h>
 
 #include <cmath>
@@ -38,7 +39,7 @@ static bool write_float_map(const std::string& path, const std::vector<float>& m
   return ok;
 }
 
-int main(int argc, char** argv) {
+static int run_tool(int argc, char** argv) {
   std::string scan_alignment_path, occlusion_mesh_path, occlusion_splats_path, image_base_path, state_path, output_folder_path;
   parse_argument(argc, argv, "--scan_alignment_path", scan_alignment_path);
   parse_argument(argc, argv, "--occlusion_mesh_path", occlusion_mesh_path);
@@ -251,4 +252,14 @@ int main(int argc, char** argv) {
     std::cout << std::endl << "Done." << std::endl;
   }
   return EXIT_SUCCESS;
+}
+
+// library errors (no device, out of memory, ...) arrive as exceptions of the host classes: report, EXIT_FAILURE
+int main(int argc, char** argv) {
+  try {
+    return run_tool(argc, argv);
+  } catch (const std::exception& e) {
+    std::cerr << "GroundTruthCreator: " << e.what() << std::endl;
+    return EXIT_FAILURE;
+  }
 }

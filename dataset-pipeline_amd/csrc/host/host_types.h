@@ -40,11 +40,12 @@ struct Affine3f {
       if (off < 1e-15) break;
     }
     // A = U * diag(sigma): normalise columns -> U ; R = U * V^T (sign-fixed)
-    double U[9];
+    double U[9], sigma[3];
     for (int j = 0; j < 3; ++j) {
       double nrm = 0;
       for (int k = 0; k < 3; ++k) nrm += A[3 * k + j] * A[3 * k + j];
       nrm = std::sqrt(nrm);
+      sigma[j] = nrm;
       for (int k = 0; k < 3; ++k) U[3 * k + j] = nrm > 0 ? A[3 * k + j] / nrm : (k == j ? 1.0 : 0.0);
     }
     for (int i = 0; i < 3; ++i)
@@ -54,9 +55,11 @@ struct Affine3f {
         R[3 * i + j] = s;
       }
     const double det = R[0] * (R[4] * R[8] - R[5] * R[7]) - R[1] * (R[3] * R[8] - R[5] * R[6]) + R[2] * (R[3] * R[7] - R[4] * R[6]);
-    if (det < 0) {   // flip the direction of the smallest singular value
+    if (det < 0) {   // flip the direction of the smallest singular value (one-sided Jacobi leaves them unsorted)
+      int c = 0;
+      for (int j = 1; j < 3; ++j) if (sigma[j] < sigma[c]) c = j;
       for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) R[3 * i + j] -= 2.0 * U[3 * i + 2] * V[3 * j + 2];
+        for (int j = 0; j < 3; ++j) R[3 * i + j] -= 2.0 * U[3 * i + c] * V[3 * j + c];
     }
   }
 };

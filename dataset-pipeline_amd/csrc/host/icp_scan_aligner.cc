@@ -3,6 +3,7 @@
 // point-to-plane ICP run on the MI355X through libe3dhip.so.
 #include <cmath>
 #include <cstdlib>
+#include <exception>
 #include <iostream>
 #include <memory>
 #include <sstream>
@@ -127,7 +128,7 @@ void MarkObjectsToOptimize(ObjectPtrVector* objects, const std::string& objects_
 
 }  // namespace
 
-int main(int argc, char** argv) {
+static int run_tool(int argc, char** argv) {
   std::string input_project_path;
   parse_argument(argc, argv, "-i", input_project_path);
   std::string output_project_path;
@@ -246,4 +247,15 @@ int main(int argc, char** argv) {
 
   std::cout << "Finished!" << std::endl;
   return EXIT_SUCCESS;
+}
+
+// Errors of the library (no device, out of memory, k beyond its limit, ...) surface as exceptions of the host classes: report them
+// and leave with EXIT_FAILURE like the tool's other error paths instead of std::terminate.
+int main(int argc, char** argv) {
+  try {
+    return run_tool(argc, argv);
+  } catch (const std::exception& e) {
+    std::cerr << "ICPScanAligner: " << e.what() << std::endl;
+    return EXIT_FAILURE;
+  }
 }

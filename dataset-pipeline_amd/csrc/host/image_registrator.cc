@@ -7,6 +7,7 @@
 // Observations are cached like in the reference: from the second image scale on (or from the first with
 // --cache_observations 1) the visible point lists are fixed and kept in --observations_cache_path.
 // Not built yet (the tool says so instead of silently doing something else): --write_debug_point_clouds.
+#include <exception>
 #include <cmath>
 #include <cstdlib>
 #include <iostream>
@@ -19,7 +20,7 @@
 
 using namespace e3d_host;
 
-int main(int argc, char** argv) {
+static int run_tool(int argc, char** argv) {
   std::string scan_alignment_path, occlusion_mesh_path, occlusion_splats_path, multi_res_point_cloud_directory_path, image_base_path,
       state_path, output_folder_path, observations_cache_path, camera_ids_to_ignore_string;
   parse_argument(argc, argv, "--scan_alignment_path", scan_alignment_path);
@@ -175,4 +176,14 @@ int main(int argc, char** argv) {
   }
   std::cout << "Finished!" << std::endl;
   return EXIT_SUCCESS;
+}
+
+// library errors (no device, out of memory, ...) arrive as exceptions of the host classes: report, EXIT_FAILURE
+int main(int argc, char** argv) {
+  try {
+    return run_tool(argc, argv);
+  } catch (const std::exception& e) {
+    std::cerr << "ImageRegistrator: " << e.what() << std::endl;
+    return EXIT_FAILURE;
+  }
 }

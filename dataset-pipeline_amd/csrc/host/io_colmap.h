@@ -43,7 +43,7 @@ inline bool ReadColmapCameras(const std::string& path, std::map<int, ColmapCamer
     s >> c.camera_id >> c.model_name >> c.width >> c.height;
     double v;
     while (s >> v) c.parameters.push_back(v);
-    (*cameras)[c.camera_id] = c;
+    cameras->insert(std::make_pair(c.camera_id, c));      // a repeated id keeps the FIRST entry (std::map::insert, like the reference)
   }
   return true;
 }
@@ -64,7 +64,7 @@ inline bool ReadColmapImages(const std::string& path, std::map<int, ColmapImage>
       std::cerr << "Please load point clouds before images" << std::endl;
     }
     std::getline(f, line);      // feature observations line (not needed)
-    (*images)[im.image_id] = im;
+    images->insert(std::make_pair(im.image_id, im));      // likewise
   }
   return true;
 }

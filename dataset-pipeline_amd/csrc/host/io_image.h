@@ -58,6 +58,7 @@ inline bool load_png(const std::vector<uint8_t>& f, GrayImage* out, std::string*
     if (pos + 12 + len > f.size()) { *err = "truncated PNG"; return false; }
     const uint8_t* d = &f[pos + 8];
     if (!memcmp(type, "IHDR", 4)) {
+      if (len != 13) { *err = "PNG with a malformed IHDR chunk"; return false; }
       w = (int)be32(d); h = (int)be32(d + 4); depth = d[8]; ctype = d[9]; interlace = d[12];
     } else if (!memcmp(type, "PLTE", 4)) {
       palette.assign(d, d + len);
@@ -69,6 +70,7 @@ inline bool load_png(const std::vector<uint8_t>& f, GrayImage* out, std::string*
     pos += 12 + len;
   }
   if (w <= 0 || h <= 0) { *err = "PNG without IHDR"; return false; }
+  if (w > (1 << 20) || h > (1 << 20)) { *err = "PNG dimensions out of range"; return false; }
   if (interlace) { *err = "interlaced PNG is not supported"; return false; }
   int channels = 0;
   switch (ctype) { case 0: channels = 1; break; case 2: channels = 3; break; case 3: channels = 1; break; case 4: channels = 2; break; case 6: channels = 4; break; }
@@ -76,6 +78,8 @@ inline bool load_png(const std::vector<uint8_t>& f, GrayImage* out, std::string*
   const size_t bpp_bits = (size_t)channels * depth;
   const size_t stride = (w * bpp_bits + 7) / 8;
   const size_t bpp = std::max<size_t>(1, bpp_bits / 8);
+  // deflate expands at most ~1032 : 1: a raw size the compressed data cannot produce is refused before it is allocated
+  if ((stride + 1) * (size_t)h / 1032 > idat.size() + 64) { *err = "PNG image data too short for its dimensions"; return false; }
   std::vector<uint8_t> raw((stride + 1) * (size_t)h);
   uLongf raw_len = (uLongf)raw.size();
   if (uncompress(raw.data(), &raw_len, idat.data(), (uLong)idat.size()) != Z_OK || raw_len != raw.size()) { *err = "PNG inflate failed"; return false; }

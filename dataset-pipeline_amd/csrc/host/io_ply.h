@@ -100,6 +100,28 @@ struct BufReader {
     return r;
   }
 };
+// bytes between the current read position and the end of the file (0 if the stream cannot tell)
+inline size_t bytes_left(std::ifstream& f) {
+  const std::streampos here = f.tellg();
+  if (here < 0) return 0;
+  f.seekg(0, std::ios::end);
+  const std::streampos end = f.tellg();
+  f.seekg(here);
+  return (end < here) ? 0 : (size_t)(end - here);
+}
+// Every record of an element takes at least one byte, so a count beyond the rest of the file (a negative count read into
+// size_t, a damaged header) cannot be honest: refuse it before anything is sized after it.
+inline bool counts_fit(const std::vector<Elem>& elems, size_t left) {
+  for (const Elem& e : elems)
+    if (e.count > left) return false;
+  return true;
+}
+// a list count as read from the file: non-negative, and the list must fit in what is left of the file
+inline bool list_count_ok(double v, size_t item_size, size_t left, size_t* c) {
+  if (!(v >= 0) || v > (double)left) return false;
+  *c = (size_t)v;
+  return *c <= left / (item_size ? item_size : 1);
+}
 }  // namespace ply_detail
 
 // Returns 0 on success, < 0 on failure (like pcl::io::loadPLYFile).
@@ -128,6 +150,8 @@ inline int loadPLYFile(const std::string& path, PointCloud& cloud, bool want_rgb
   const bool ascii = (format == "ascii");
   const bool swap = (format == "binary_big_endian");
   if (!ascii && format != "binary_little_endian" && !swap) { std::cerr << "[loadPLYFile] unsupported format '" << format << "'" << std::endl; return -1; }
+  const size_t body_bytes = bytes_left(f);
+  if (!counts_fit(elems, body_bytes)) { std::cerr << "[loadPLYFile] element count beyond the end of " << path << std::endl; return -1; }
   for (const Elem& e : elems) {
     const bool is_vertex = (e.name == "vertex");
     int ix = -1, iy = -1, iz = -1, ir = -1, ig = -1, ib = -1, inx = -1, iny = -1, inz = -1, iint = -1;
@@ -158,7 +182,7 @@ inline int loadPLYFile(const std::string& path, PointCloud& cloud, bool want_rgb
         if (!is_vertex) continue;
         std::istringstream ls(line);
         for (size_t p = 0; p < e.props.size(); ++p) {
-          if (e.props[p].is_list) { size_t c; ls >> c; double d; for (size_t k = 0; k < c; ++k) ls >> d; vals[p] = 0; }
+          if (e.props[p].is_list) { double cv = -1; size_t c = 0; ls >> cv; if (!ls || !list_count_ok(cv, 1, line.size(), &c)) { std::cerr << "[loadPLYFile] bad list count in " << path << std::endl; return -1; } double d; for (size_t k = 0; k < c; ++k) ls >> d; vals[p] = 0; }
           else ls >> vals[p];
         }
         cloud.xyz[3 * i] = (float)vals[ix]; cloud.xyz[3 * i + 1] = (float)vals[iy]; cloud.xyz[3 * i + 2] = (float)vals[iz];
@@ -170,6 +194,7 @@ inline int loadPLYFile(const std::string& path, PointCloud& cloud, bool want_rgb
       size_t stride = 0;
       std::vector<size_t> off(e.props.size());
       for (size_t p = 0; p < e.props.size(); ++p) { off[p] = stride; const int ts = type_size(e.props[p].type); if (!ts) { std::cerr << "[loadPLYFile] unknown type " << e.props[p].type << std::endl; return -1; } stride += ts; }
+      if (stride * e.count > bytes_left(f)) { std::cerr << "[loadPLYFile] truncated file " << path << std::endl; return -1; }
       if (!is_vertex) { f.seekg((std::streamoff)(stride * e.count), std::ios::cur); continue; }
       std::vector<TypeCode> code(e.props.size());
       for (size_t p = 0; p < e.props.size(); ++p) code[p] = type_code(e.props[p].type);
@@ -200,17 +225,27 @@ inline int loadPLYFile(const std::string& path, PointCloud& cloud, bool want_rgb
       }
     } else {
       // binary element with list properties (faces): walk it record by record
+      size_t left = bytes_left(f);
       for (size_t i = 0; i < e.count; ++i)
         for (size_t p = 0; p < e.props.size(); ++p) {
           unsigned char b[8];
           if (e.props[p].is_list) {
             const int cs = type_size(e.props[p].count_type), ts = type_size(e.props[p].type);
+            if (!cs || !ts) { std::cerr << "[loadPLYFile] unknown list type in " << path << std::endl; return -1; }
             f.read(reinterpret_cast<char*>(b), cs);
-            const size_t c = (size_t)read_scalar(b, e.props[p].count_type, swap);
-            f.seekg((std::streamoff)(c * ts), std::ios::cur);
+            size_t c = 0;
+            if (!f || (int)f.gcount() != cs || !list_count_ok(read_scalar(b, e.props[p].count_type, swap), (size_t)ts, left - (size_t)cs, &c)) {
+              std::cerr << "[loadPLYFile] truncated file or bad list count in " << path << std::endl; return -1;
+            }
+            f.seekg((std::streamoff)(c * (size_t)ts), std::ios::cur);
+            left -= (size_t)cs + c * (size_t)ts;
           } else {
-            f.seekg(type_size(e.props[p].type), std::ios::cur);
+            const int ts = type_size(e.props[p].type);
+            if (!ts || (size_t)ts > left) { std::cerr << "[loadPLYFile] truncated file " << path << std::endl; return -1; }
+            f.seekg(ts, std::ios::cur);
+            left -= (size_t)ts;
           }
+          if (!f) { std::cerr << "[loadPLYFile] truncated file " << path << std::endl; return -1; }
         }
       if (is_vertex) { std::cerr << "[loadPLYFile] list properties in the vertex element are not supported" << std::endl; return -1; }
     }
@@ -248,6 +283,9 @@ inline int loadPLYMesh(const std::string& path, std::vector<float>& xyz, std::ve
   const bool ascii = (format == "ascii"), swap = (format == "binary_big_endian");
   if (!ascii && format != "binary_little_endian" && !swap) { std::cerr << "[loadPLYMesh] unsupported format '" << format << "'" << std::endl; return -1; }
   xyz.clear(); triangles.clear();
+  const size_t body_bytes = bytes_left(f);
+  if (!counts_fit(elems, body_bytes)) { std::cerr << "[loadPLYMesh] element count beyond the end of " << path << std::endl; return -1; }
+  size_t consumed = 0;              // binary body bytes handed out so far
   BufReader reader(f);               // binary files: everything after the header goes through it
   for (const Elem& e : elems) {
     const bool is_vertex = (e.name == "vertex"), is_face = (e.name == "face");
@@ -273,9 +311,14 @@ inline int loadPLYMesh(const std::string& path, std::vector<float>& xyz, std::ve
           if (e.props[p].is_list) {
             const unsigned char* cb = reader.get((size_t)cs[p]);
             if (!cb) { std::cerr << "[loadPLYMesh] truncated file " << path << std::endl; return -1; }
-            const size_t c = (size_t)read_scalar_code(cb, ccode[p], swap);
+            consumed += (size_t)cs[p];
+            size_t c = 0;
+            if (!list_count_ok(read_scalar_code(cb, ccode[p], swap), (size_t)ts[p], body_bytes - std::min(consumed, body_bytes), &c)) {
+              std::cerr << "[loadPLYMesh] truncated file or bad list count in " << path << std::endl; return -1;
+            }
             const unsigned char* d = reader.get(c * (size_t)ts[p]);
             if (!d && c) { std::cerr << "[loadPLYMesh] truncated file " << path << std::endl; return -1; }
+            consumed += c * (size_t)ts[p];
             if (is_face && (int)p == il) {
               if (c != 3) { std::cerr << "[loadPLYMesh] only triangle meshes are supported: " << path << std::endl; return -1; }
               for (size_t k = 0; k < 3; ++k) triangles.push_back((uint32_t)read_scalar_code(d + k * (size_t)ts[p], code[p], swap));
@@ -283,6 +326,7 @@ inline int loadPLYMesh(const std::string& path, std::vector<float>& xyz, std::ve
           } else {
             const unsigned char* d = reader.get((size_t)ts[p]);
             if (!d) { std::cerr << "[loadPLYMesh] truncated file " << path << std::endl; return -1; }
+            consumed += (size_t)ts[p];
             if (is_vertex && ((int)p == ix || (int)p == iy || (int)p == iz))
               xyz[3 * i + ((int)p == ix ? 0 : ((int)p == iy ? 1 : 2))] = (float)read_scalar_code(d, code[p], swap);
           }
@@ -297,7 +341,13 @@ inline int loadPLYMesh(const std::string& path, std::vector<float>& xyz, std::ve
         if (pr.is_list) {
           size_t c = 0;
           std::vector<double> idx;
-          if (ascii) { ls >> c; idx.resize(c); for (size_t k = 0; k < c; ++k) ls >> idx[k]; }
+          if (ascii) {
+            double cv = -1;
+            ls >> cv;
+            if (!ls || !list_count_ok(cv, 1, line.size(), &c)) { std::cerr << "[loadPLYMesh] bad list count in " << path << std::endl; return -1; }
+            idx.resize(c);
+            for (size_t k = 0; k < c; ++k) ls >> idx[k];
+          }
           else {
             unsigned char b[8];
             f.read(reinterpret_cast<char*>(b), type_size(pr.count_type));

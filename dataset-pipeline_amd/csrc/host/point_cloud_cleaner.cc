@@ -2,6 +2,7 @@
 // more pcl::LocalStatisticalOutlierRemoval passes (--filter <knn,factor>, in the order given) to a PLY cloud and writes
 // <in>.inliers.ply and <in>.outliers.ply (binary, x y z + red green blue).  Each pass runs on the MI355X behind
 // e3d_local_outlier_removal; outliers accumulate over the passes in removal order.
+#include <exception>
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
@@ -34,7 +35,7 @@ static bool parse_multiple_2x_arguments(int argc, char** argv, const char* name,
   return !a.empty();
 }
 
-int main(int argc, char** argv) {
+static int run_tool(int argc, char** argv) {
   int dummy;
   if (argc <= 1 || parse_argument(argc, argv, "-h", dummy) >= 0 || parse_argument(argc, argv, "--help", dummy) >= 0) {
     std::cerr << "Usage: " << argv[0] << " --in <file.ply> --filter <knn,factor> [--filter <knn2,factor2>, ...]" << std::endl;
@@ -88,4 +89,14 @@ int main(int argc, char** argv) {
       savePLYFileBinaryXYZRGB(point_cloud_file_path + ".outliers.ply", outlier_xyz, outlier_rgb) < 0)
     return EXIT_FAILURE;
   return EXIT_SUCCESS;
+}
+
+// library errors (no device, out of memory, ...) arrive as exceptions of the host classes: report, EXIT_FAILURE
+int main(int argc, char** argv) {
+  try {
+    return run_tool(argc, argv);
+  } catch (const std::exception& e) {
+    std::cerr << "PointCloudCleaner: " << e.what() << std::endl;
+    return EXIT_FAILURE;
+  }
 }

@@ -18,16 +18,31 @@ def make_allreduce(group=None, device=None):
     import torch.distributed as dist
 
     backend = dist.get_backend(group)
+    if backend == "nccl" and device is None:
+        # one process per GPU: the staging tensor must live on THIS rank's GPU ("cuda" alone is cuda:0 unless the caller called
+        # torch.cuda.set_device; every rank on cuda:0 makes RCCL fail with a duplicate-GPU error)
+        device = _rank_device()
 
     def allreduce(arr):
         if backend == "nccl":
-            t = torch.from_numpy(arr).to(device if device is not None else "cuda")
+            t = torch.from_numpy(arr).to(device)
             dist.all_reduce(t, group=group)
             arr[:] = t.cpu().numpy()
         else:
             t = torch.from_numpy(arr)          # shares memory with arr
             dist.all_reduce(t, group=group)
     return allreduce
+
+
+def _rank_device():
+    """The GPU of this rank: torch's current device if the caller selected one, else LOCAL_RANK."""
+    import os
+    import torch
+    cur = torch.cuda.current_device()
+    local = int(os.environ.get("LOCAL_RANK", cur))
+    if cur == 0 and local != 0 and local < torch.cuda.device_count():
+        cur = local                      # nobody called torch.cuda.set_device: follow the launcher's LOCAL_RANK
+    return torch.device("cuda", cur)
 
 
 def attach(icp, group=None, device=None):
@@ -48,7 +63,7 @@ class _DeviceView:
 
 def device_tensor(ptr, count, dtype, device=None):
     import torch
-    return torch.as_tensor(_DeviceView(ptr, count, dtype), device=device if device is not None else "cuda")
+    return torch.as_tensor(_DeviceView(ptr, count, dtype), device=device if device is not None else _rank_device())
 
 
 def make_allreduce_device(group=None, device=None):

@@ -205,8 +205,12 @@ void oracle_knn(const float* xyz, size_t n, const float* queries, size_t n_q, in
  * overload when <math.h> is visible (recalled; unpinned -- the reference has no test of this filter). */
 int oracle_local_outlier_removal(const float* xyz, size_t n, int mean_k, double factor, int negative, uint8_t* inlier,
                                  float* distances) {
-  if (n <= (size_t)mean_k) return -1;
+  /* fewer than mean_k + 1 points: pcl::KdTreeFLANN::nearestKSearch clamps k to the cloud size and shrinks nn_indices / nn_dists;
+   * the first pass then reads nn_dists[k] beyond the shrunk size (stale zeros of the vector's initial contents -- restated as 0
+   * here), the second pass walks nn_indices.size () entries (:129) */
+  if (n == 0) return 0;
   const int k = mean_k + 1;
+  const int found = (n < (size_t)k) ? (int)n : k;
   okd_tree* tree = okd_build(xyz, n);
   int32_t* nn = (int32_t*)malloc(sizeof(int32_t) * n * (size_t)k);
   /* first pass (:85-110) */
@@ -215,9 +219,9 @@ int oracle_local_outlier_removal(const float* xyz, size_t n, int mean_k, double 
     float* nd = (float*)malloc(sizeof(float) * (size_t)k);
 #pragma omp for schedule(dynamic, 1024)
     for (long long i = 0; i < (long long)n; ++i) {
-      okd_knn(tree, xyz + 3 * (size_t)i, k, nn + (size_t)i * k, nd);
+      okd_knn(tree, xyz + 3 * (size_t)i, found, nn + (size_t)i * k, nd);
       double dist_sum = 0.0;
-      for (int j = 1; j < mean_k + 1; ++j) dist_sum += sqrtf(nd[j]);
+      for (int j = 1; j < found; ++j) dist_sum += sqrtf(nd[j]);
       distances[i] = (float)(dist_sum / mean_k);
     }
     free(nd);
@@ -226,7 +230,7 @@ int oracle_local_outlier_removal(const float* xyz, size_t n, int mean_k, double 
   for (size_t i = 0; i < n; ++i) {
     int valid = 0;
     double sum = 0;
-    for (int j = 1; j < k; ++j) {
+    for (int j = 1; j < found; ++j) {
       const double d = distances[nn[i * k + j]];
       if (d > 0) { ++valid; sum += d; }
     }

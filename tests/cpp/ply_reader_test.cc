@@ -4,6 +4,7 @@
 #include <cstring>
 
 #include "../../dataset-pipeline_amd/csrc/host/io_ply.h"
+#include "../../dataset-pipeline_amd/csrc/host/host_types.h"
 
 int main(int argc, char** argv) {
   using namespace e3d_host;
@@ -19,6 +20,16 @@ int main(int argc, char** argv) {
       if (!c.intensity.empty()) printf(" %.9g", c.intensity[i]);
       printf("\n");
     }
+    return 0;
+  }
+  if (!strcmp(argv[1], "rotation")) {            // argv[2..10]: linear part, row-major -> Affine3f::rotation()
+    if (argc < 11) return 2;
+    Affine3f T;
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) T(r, c) = (float)atof(argv[2 + 3 * r + c]);
+    double R[9];
+    T.rotation(R);
+    for (int i = 0; i < 9; ++i) printf("%.17g%c", R[i], i == 8 ? '\n' : ' ');
     return 0;
   }
   std::vector<float> xyz; std::vector<uint32_t> tri;

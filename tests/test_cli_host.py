@@ -200,3 +200,91 @@ def test_ply_readers_mixed_types_and_endianness(tmp_path):
     open(path, "wb").write(hdr.encode() + mv.astype(mv.dtype.newbyteorder("<")).tobytes() + f.tobytes())
     r = subprocess.run([exe, "mesh", path], capture_output=True, text=True)
     assert r.returncode != 0 and "only triangle meshes are supported" in r.stderr
+
+
+def test_ply_readers_refuse_damaged_files(tmp_path):
+    """Counts the file cannot hold (a negative vertex count, a list count beyond the end of the file, a negative list count) and
+    truncated bodies return -1 with a message instead of a multi-GB resize or a walk over garbage."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "ply_reader_test")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(root, "tests", "cpp", "ply_reader_test.cc")])
+    v = np.zeros(10, dtype=[("x", "<f4"), ("y", "<f4"), ("z", "<f4")])
+    vh = "property float x\nproperty float y\nproperty float z\n"
+
+    def run(kind, name, blob):
+        path = str(tmp_path / name)
+        open(path, "wb").write(blob)
+        return subprocess.run([exe, kind, path], capture_output=True, text=True, timeout=60)
+    # element vertex -1 (wraps to 2^64 - 1 as size_t)
+    for kind in ("cloud", "mesh"):
+        r = run(kind, "neg.ply", ("ply\nformat binary_little_endian 1.0\nelement vertex -1\n" + vh + "end_header\n").encode() + v.tobytes())
+        assert r.returncode == 1 and "beyond the end" in r.stderr, r.stderr
+    # vertex body shorter than the header says
+    r = run("cloud", "short.ply", ("ply\nformat binary_little_endian 1.0\nelement vertex 10\n" + vh + "end_header\n").encode() + v.tobytes()[:50])
+    assert r.returncode == 1 and "truncated" in r.stderr
+    fh = "ply\nformat binary_little_endian 1.0\nelement vertex 10\n" + vh + "element face 2\nproperty list %s int vertex_indices\nend_header\n"
+    tri = np.array([0, 1, 2], "<i4").tobytes()
+    # uint32 list count of 4 G entries in a 200-byte file; negative int32 count; file ending inside a list
+    for cnt_type, cnt, what in (("uint", np.array([0xFFFFFFF0], "<u4").tobytes(), "bad list count"),
+                                ("int", np.array([-3], "<i4").tobytes(), "bad list count"),
+                                ("uchar", b"\x03", None)):
+        body = v.tobytes() + (b"\x03" if cnt_type == "uchar" else np.array([3], "<u4").tobytes()) + tri + cnt + (tri[:5] if what is None else tri)
+        r = run("mesh", "list_%s.ply" % cnt_type, (fh % cnt_type).encode() + body)
+        assert r.returncode == 1 and ("truncated" in r.stderr), r.stderr
+        if what:
+            assert what in r.stderr
+    # faces BEFORE the vertices: loadPLYFile walks the list element record by record
+    hdr = "ply\nformat binary_little_endian 1.0\nelement face 2\nproperty list uchar int vertex_indices\nelement vertex 10\n" + vh + "end_header\n"
+    good = run("cloud", "faces_first.ply", hdr.encode() + (b"\x03" + tri) * 2 + v.tobytes())
+    assert good.returncode == 0 and good.stdout.split("\n")[0].startswith("10 ")
+    bad = run("cloud", "faces_first_bad.ply", hdr.encode() + b"\x03" + tri + b"\xff" + tri)
+    assert bad.returncode == 1 and "truncated" in bad.stderr
+    # ascii: negative list count
+    r = run("mesh", "ascii_neg.ply", ("ply\nformat ascii 1.0\nelement vertex 3\n" + vh + "element face 1\nproperty list uchar int vertex_indices\nend_header\n"
+                                      "0 0 0\n1 0 0\n0 1 0\n-3 0 1 2\n").encode())
+    assert r.returncode == 1 and "bad list count" in r.stderr
+
+
+def test_affine_rotation_of_a_reflection(tmp_path):
+    """Affine3f::rotation() (Eigen's Transform::rotation()): for a linear part with negative determinant the sign flip goes to the
+    direction of the SMALLEST singular value, wherever the unsorted one-sided Jacobi leaves it."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "ply_reader_test")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(root, "tests", "cpp", "ply_reader_test.cc")])
+    rng = np.random.RandomState(4)
+    for trial in range(40):
+        U, _ = np.linalg.qr(rng.normal(size=(3, 3))); V, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+        sig = rng.permutation([1.0, 0.6 + 0.3 * rng.rand(), 0.1 + 0.3 * rng.rand()])
+        A = ((U * sig) @ V.T).astype(np.float32)
+        if trial % 2 == 0:
+            A = -A                                                  # det < 0 for every other trial
+        r = subprocess.run([exe, "rotation"] + ["%.9g" % x for x in A.ravel()], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        R = np.array([float(t) for t in r.stdout.split()]).reshape(3, 3)
+        Us, s, Vt = np.linalg.svd(A.astype(np.float64))
+        D = np.diag([1, 1, np.sign(np.linalg.det(Us @ Vt))])
+        assert np.abs(R - Us @ D @ Vt).max() < 1e-9, (trial, R, Us @ D @ Vt)
+        assert abs(np.linalg.det(R) - 1) < 1e-9
+
+
+def test_png_decoder_refuses_damaged_headers(tmp_path):
+    """A short IHDR chunk at the end of the file and dimensions the compressed data cannot fill are refused with a message (no read
+    past the buffer, no multi-GB allocation) -- ADVICE round 1."""
+    import struct
+    import zlib
+    _build()
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+    sig = bytes([137, 80, 78, 71, 13, 10, 26, 10])
+    open(str(tmp_path / "short_ihdr.png"), "wb").write(sig + chunk(b"IHDR", b"\x00\x00\x00\x10"))
+    img, err = _imread(str(tmp_path / "short_ihdr.png"), tmp_path)
+    assert img is None and "IHDR" in err
+    ihdr = struct.pack(">IIBBBBB", 60000, 60000, 8, 0, 0, 0, 0)            # 3.6 GB of pixels promised by a 100-byte file
+    open(str(tmp_path / "huge.png"), "wb").write(sig + chunk(b"IHDR", ihdr) + chunk(b"IDAT", zlib.compress(b"\x00" * 16)) + chunk(b"IEND", b""))
+    img, err = _imread(str(tmp_path / "huge.png"), tmp_path)
+    assert img is None and "too short" in err
+    ihdr = struct.pack(">IIBBBBB", 1 << 24, 4, 8, 0, 0, 0, 0)
+    open(str(tmp_path / "wide.png"), "wb").write(sig + chunk(b"IHDR", ihdr) + chunk(b"IEND", b""))
+    img, err = _imread(str(tmp_path / "wide.png"), tmp_path)
+    assert img is None and "out of range" in err

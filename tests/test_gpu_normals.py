@@ -138,8 +138,12 @@ def test_local_outlier_removal_edge_cases(e3d, ob):
     gi, gd = e3d.local_outlier_removal(dup, 1, 2.0, return_distances=True)
     oi, od = ob.local_outlier_removal(dup, 1, 2.0)
     assert (gd == 0).all() and np.array_equal(gd, od) and gi.all() and np.array_equal(gi, oi)      # mean = NaN -> kept
-    with pytest.raises(e3d.E3DError):
-        e3d.local_outlier_removal(pts[:5], 8, 2.0)
+    # fewer points than mean_k + 1: the search returns what there is, the mean still divides by mean_k (a later --filter pass of
+    # PointCloudCleaner on a small remainder keeps going like the reference)
+    for m in (5, 8, 1):
+        gi, gd = e3d.local_outlier_removal(pts[:m], 8, 2.0, return_distances=True)
+        oi, od = ob.local_outlier_removal(pts[:m], 8, 2.0)
+        assert np.array_equal(gd.view(np.uint32), od.view(np.uint32)) and np.array_equal(gi, oi)
     with pytest.raises(e3d.E3DError):
         e3d.local_outlier_removal(pts, 0, 2.0)
     assert e3d.local_outlier_removal(np.zeros((0, 3), np.float32), 8, 2.0).shape == (0,)

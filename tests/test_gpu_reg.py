@@ -679,14 +679,15 @@ def test_mesh_occlusion_drives_visibility(e3d, rb):
     assert n > 1500 and not seen[behind_box].any() and seen[~behind_box].mean() > 0.6
 
 
-# ---- BASELINE.json configs[4] shape (3840 x 2160 images, 4 M points) through size-independent properties ------------------------------
-@pytest.mark.parametrize("model", [0, 2])
-def test_full_size_accumulate_properties(e3d, synth, model):
+# ---- BASELINE.json configs[4] shape (3840 x 2160 images, 4 M points) and configs[3] shape (24 MP DSLR images: 6048 x 4032,
+#      THIN_PRISM_FISHEYE, 10 M points) through size-independent properties ------------------------------------------------------------
+@pytest.mark.parametrize("model,width,height,n_points", [(0, 3840, 2160, 4_000_000), (2, 3840, 2160, 4_000_000), (2, 6048, 4032, 10_000_000)])
+def test_full_size_accumulate_properties(e3d, synth, model, width, height, n_points):
     """At the benchmark's size: (i) the cost-only pass returns the sums and counts of the accumulate pass; (ii) H is symmetric
     positive semi-definite and b = J^T r is consistent with it (H x = b solvable to working precision); (iii) additivity: the
     normal equations over a partition of the observations into two sets that keep neighbourhoods intact add up to those of the
     whole; (iv) every observation lies inside the image and its residual count is #fixed + #variable."""
-    Wl = synth.make_reg_workload(n_points=4_000_000, n_images=2, model=model)      # variable residuals need a second observer
+    Wl = synth.make_reg_workload(n_points=n_points, width=width, height=height, n_images=2, model=model, device="cuda")      # variable residuals need a second observer
     P = e3d.RegProblem(e3d.default_reg_params(image_scale_count=Wl["n_levels"], point_neighbor_count=Wl["K"]))
     P.set_intrinsics(0, Wl["width"], Wl["height"], Wl["params"], 0, Wl["n_levels"], camera_type=model)
     P.set_point_scale(0, Wl["pts"], Wl["point_radius"], Wl["nbr"], Wl["fixed_desc"])
@@ -697,7 +698,7 @@ def test_full_size_accumulate_properties(e3d, synth, model):
     H, b, sums, counts = P.accumulate(0, 0)
     s2, c2 = P.cost(0, 0)
     assert np.array_equal(counts, c2) and np.allclose(sums, s2, rtol=1e-12)                        # (i)
-    assert counts[0] > 3_000_000 and counts[0] == counts[1]
+    assert counts[0] > 0.75 * n_points and counts[0] == counts[1]
     V = H.shape[0]
     Hs = np.triu(H) + np.triu(H, 1).T
     w = np.linalg.eigvalsh(Hs)

@@ -85,3 +85,20 @@ def test_local_outlier_removal_restatement():
     inl_neg, _ = ob.local_outlier_removal(pts, 8, 2.0, negative=True)
     inl_pos, _ = ob.local_outlier_removal(pts, 8, 2.0)
     assert np.array_equal(inl_neg, ~inl_pos)
+
+
+def test_local_outlier_removal_small_cloud():
+    """Fewer points than mean_k + 1 (a late --filter pass of PointCloudCleaner): pcl::KdTreeFLANN clamps the search to the cloud,
+    the first pass still divides by mean_k, the second walks the shorter lists; an empty cloud is a no-op."""
+    from oracle import binding as ob
+    pts = np.array([[0, 0, 0], [1, 0, 0], [0, 2, 0], [0, 0, 4], [10, 10, 10]], np.float32)
+    inl, md = ob.local_outlier_removal(pts, 8, 2.0)
+    d = np.sqrt(((pts[:, None, :] - pts[None, :, :]) ** 2).sum(-1).astype(np.float32))
+    exp = np.array([np.sort(d[i])[1:].astype(np.float64).sum() / 8 for i in range(5)], np.float32)
+    assert np.allclose(md, exp, rtol=1e-6)
+    thr = np.array([md[[j for j in range(5) if j != i]].astype(np.float64).sum() / 4 * 2.0 for i in range(5)])
+    assert np.array_equal(inl, ~(md > thr)) and not inl[4] and inl[:4].all()
+    inl, md = ob.local_outlier_removal(pts[:1], 8, 2.0)
+    assert inl.tolist() == [True] and md.tolist() == [0.0]        # no neighbour: mean = 0 / 0, every comparison false -> kept
+    inl, md = ob.local_outlier_removal(np.zeros((0, 3), np.float32), 8, 2.0)
+    assert inl.shape == (0,)

@@ -1,36 +1,54 @@
-"""profiles/round1_traffic.json from the two rocprofv3 PMC passes of tools/prof_final.sh (gpurun_out/pmc_fetch.txt, pmc_write.txt:
-lines `kernel signature, COUNTER, value summed over the launches, launches`)."""
+"""profiles/round2_traffic.json from the rocprofv3 PMC passes of tools/prof_round2.sh (gpurun_out/r2prof/*_fetch.txt, *_write.txt:
+lines `kernel signature, COUNTER, value summed over the launches, launches`).
+
+    python tools/make_traffic_json.py [gpurun_out/r2prof]"""
 import json
 import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-NOTE = ("HBM traffic per launch from rocprofv3 PMC (separate --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of `bench.py --no-cpu-baseline "
-        "--steps 2`: 2 x 50 M points for the ICP kernels, 4 images 3840x2160 + 4 M points for the k_reg_* kernels; tools/prof_final.sh). "
-        "Units: counters are KiB; on gfx950 FETCH_SIZE reports half of a wide coalesced read (MI355X_MICROARCH.md, HBM section) -> "
-        "bytes = 1024 * (2 * FETCH_SIZE + WRITE_SIZE). Calibrated on k_transform_bbox: 16 B read + 16 B written per point x 50 M = 800 MB each.")
+NOTE = ("HBM traffic per launch from rocprofv3 PMC, separate --pmc FETCH_SIZE and --pmc WRITE_SIZE passes (tools/prof_round2.sh): the ICP "
+        "kernels from `bench.py --no-cpu-baseline --no-reg --no-normals --no-allpairs --steps 3 --warmup 2` (2 x 50 M points), the "
+        "k_reg_* kernels from `tools/bench_c4.py --images 2 --accumulate-only` (6048 x 4032 THIN_PRISM_FISHEYE, 10 M points), the normals "
+        "entries k_knn_normals_k32 / _k8 = ALL kernels of one e3d_normals_knn call on 20 M points (`tools/bench_normals.py --repeat 1`: "
+        "two calls per run, sums halved). Units: the counters are KiB; on gfx950 FETCH_SIZE reports half of a wide coalesced read "
+        "(MI355X_MICROARCH.md, HBM section) -> bytes = 1024 * (2 * FETCH_SIZE + WRITE_SIZE); calibrated in round 1 on k_transform_bbox "
+        "(16 B read + 16 B written per point x 50 M = 800 MB each).")
 
 
 def parse(path, counter):
     out = {}
+    if not os.path.exists(path):
+        return out
     for line in open(path):
         if ", %s, " % counter not in line:
             continue
         head, rest = line.rsplit(", %s, " % counter, 1)
         name = head.split("(")[0].replace("void ", "").replace("e3d::", "").strip()
         val, launches = rest.strip().split(", ")
-        out[name] = (float(val), int(launches))
+        v, n = out.get(name, (0.0, 0))
+        out[name] = (v + float(val), n + int(launches))
     return out
 
 
 def main():
-    src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out")
-    f, w = parse(os.path.join(src, "pmc_fetch.txt"), "FETCH_SIZE"), parse(os.path.join(src, "pmc_write.txt"), "WRITE_SIZE")
+    src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "r2prof")
     kernels = {}
-    for name in sorted(set(f) & set(w)):
-        fb, wb = 2048.0 * f[name][0] / f[name][1], 1024.0 * w[name][0] / w[name][1]
-        kernels[name] = {"launches": f[name][1], "fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb, "hbm_bytes_per_launch": fb + wb}
-    json.dump({"_note": NOTE, "kernels": kernels}, open(os.path.join(ROOT, "profiles", "round1_traffic.json"), "w"), indent=1)
+    for tag in ("icp", "reg"):
+        f, w = parse(os.path.join(src, tag + "_fetch.txt"), "FETCH_SIZE"), parse(os.path.join(src, tag + "_write.txt"), "WRITE_SIZE")
+        for name in sorted(set(f) & set(w)):
+            fb, wb = 2048.0 * f[name][0] / f[name][1], 1024.0 * w[name][0] / w[name][1]
+            kernels[name] = {"launches": f[name][1], "fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb, "hbm_bytes_per_launch": fb + wb}
+    for k in (32, 8):
+        f = parse(os.path.join(src, "normals_k%d_fetch.txt" % k), "FETCH_SIZE"); w = parse(os.path.join(src, "normals_k%d_write.txt" % k), "WRITE_SIZE")
+        ours = [n for n in f if n.startswith("k_") or "rocprim" in n or "rocclr" in n]       # the library's kernels, sorts, fills and copies
+        if not ours:
+            continue
+        calls = 2.0                                                                          # bench_normals.py --repeat 1: warm-up + one timed call
+        fb = sum(2048.0 * f[n][0] for n in ours) / calls; wb = sum(1024.0 * w[n][0] for n in ours if n in w) / calls
+        kernels["k_knn_normals_k%d" % k] = {"launches": 1, "fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb, "hbm_bytes_per_launch": fb + wb,
+                                             "kernels_summed": sorted(ours)}
+    json.dump({"_note": NOTE, "kernels": kernels}, open(os.path.join(ROOT, "profiles", "round2_traffic.json"), "w"), indent=1)
     print(len(kernels), "kernels")
 
 

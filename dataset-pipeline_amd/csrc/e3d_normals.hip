@@ -65,6 +65,29 @@ __device__ __forceinline__ void knn_row(const KnnGrid& G, const HashEntry* __res
   }
 }
 
+// linear index of a point's cell in the dense bounding grid (the grid's origin lies two cells below the bounding box and D covers the
+// box plus two cells, so every point falls inside; the clamp only guards against a NaN coordinate)
+__global__ __launch_bounds__(kBlock) void k_cell_keys_dense(const float* __restrict__ xyz, size_t n, GridDesc g, unsigned Dx, unsigned Dy,
+                                                            unsigned Dz, unsigned* __restrict__ keys, unsigned* __restrict__ vals) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const unsigned cx = (unsigned)min(max(cell_coord(xyz[3 * i], g.origin[0], g.inv_cell), 0), (int)Dx - 1);
+  const unsigned cy = (unsigned)min(max(cell_coord(xyz[3 * i + 1], g.origin[1], g.inv_cell), 0), (int)Dy - 1);
+  const unsigned cz = (unsigned)min(max(cell_coord(xyz[3 * i + 2], g.origin[2], g.inv_cell), 0), (int)Dz - 1);
+  keys[i] = (cz * Dy + cy) * Dx + cx;
+  vals[i] = (unsigned)i;
+}
+
+// ends[cell] = one past the last sorted position of the cell (the last point of every run writes); an exclusive max scan turns the
+// array into the cells' start positions
+__global__ __launch_bounds__(kBlock) void k_dense_ends32(const unsigned* __restrict__ keys, size_t n, unsigned* __restrict__ ends) {
+  const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const unsigned k = keys[j];
+  if (j + 1 < n && keys[j + 1] == k) return;
+  ends[k] = (unsigned)(j + 1);
+}
+
 constexpr int kKnnBins = 64;           // histogram bins of the two-pass variant: cell^2 / 32 wide, [0, 2 cell^2)
 constexpr int kKnnHistBlock = 256;
 
@@ -73,8 +96,7 @@ constexpr int kKnnHistBlock = 256;
 // the kernel runs at full occupancy, which is what this latency-bound scan needs.
 __global__ __launch_bounds__(kKnnHistBlock) void k_knn_hist(const float4* __restrict__ P4, const unsigned* __restrict__ todo, size_t n_todo,
                                                             const HashEntry* __restrict__ table, KnnGrid G, int k,
-                                                            const float4* __restrict__ Q4, unsigned char* __restrict__ sel_bin,
-                                                            unsigned* __restrict__ hist_out /* [kKnnBins / 4][n_todo] */) {
+                                                            const float4* __restrict__ Q4, unsigned char* __restrict__ sel_bin) {
   __shared__ unsigned hw[kKnnBins / 4][kKnnHistBlock];
   const int tid = threadIdx.x;
   const size_t gi = (size_t)blockIdx.x * blockDim.x + tid;
@@ -114,12 +136,6 @@ __global__ __launch_bounds__(kKnnHistBlock) void k_knn_hist(const float4* __rest
     }
   }
   sel_bin[gi] = (unsigned char)sel;
-  // the counts themselves: pass B turns them into the slot ranges of a bucket sort (bins up to the selected one only)
-  if (sel != 255) {
-#pragma unroll
-    for (int wv = 0; wv < kKnnBins / 4; ++wv)
-      if (4 * wv <= sel) hist_out[(size_t)wv * n_todo + gi] = hw[wv][tid];
-  }
 }
 
 __device__ __forceinline__ bool knn_less(float d1, unsigned p1, float d2, unsigned p2, const float4* __restrict__ P4) {
@@ -197,6 +213,45 @@ __device__ __forceinline__ void eigen33_smallest(const float* cov, float& eigenv
   v[0] = best[0] / sl; v[1] = best[1] / sl; v[2] = best[2] / sl;
 }
 
+// Sort the first cnt words of a query's LDS list ascending (words = [16-bit key | 16-bit tag]); N = list capacity.  Returns false
+// if neighbours with equal keys could not be put into exact order within three passes (the caller then runs its exact LDS sort;
+// the list is left key-sorted).  pos_of(word) -> position, dist_of(position) -> f32 squared distance.
+template <int N, class PosOf, class DistOf>
+__device__ __forceinline__ bool knn_sort_words(unsigned* __restrict__ hp, int tid, int cnt, PosOf pos_of, DistOf dist_of,
+                                               const float4* __restrict__ P4) {
+  unsigned a[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) a[i] = (i < cnt) ? hp[(size_t)i * kKnnBlock + tid] : 0xFFFFFFFFu;
+  // Batcher's merge exchange for arbitrary N (Knuth 5.2.2 M): all indices are compile-time constants after unrolling
+#pragma unroll
+  for (int p = 1; p < N; p <<= 1)
+#pragma unroll
+    for (int k = p; k >= 1; k >>= 1)
+#pragma unroll
+      for (int j = k % p; j <= N - 1 - k; j += 2 * k)
+#pragma unroll
+        for (int i = 0; i <= (k - 1 < N - j - k - 1 ? k - 1 : N - j - k - 1); ++i)
+          if ((i + j) / (2 * p) == (i + j + k) / (2 * p)) {
+            const unsigned lo = min(a[i + j], a[i + j + k]), hi = max(a[i + j], a[i + j + k]);
+            a[i + j] = lo; a[i + j + k] = hi;
+          }
+  bool dirty = true;
+#pragma unroll 1
+  for (int pass = 0; pass < 4 && dirty; ++pass) {
+    dirty = false;
+#pragma unroll
+    for (int i = 0; i + 1 < N; ++i) {
+      if (i + 1 < cnt && ((a[i] ^ a[i + 1]) >> 16) == 0u) {           // equal keys: the exact order decides (rare)
+        const unsigned p0 = pos_of(a[i]), p1 = pos_of(a[i + 1]);
+        if (knn_less(dist_of(p1), p1, dist_of(p0), p0, P4)) { const unsigned t = a[i]; a[i] = a[i + 1]; a[i + 1] = t; dirty = true; }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i) if (i < cnt) hp[(size_t)i * kKnnBlock + tid] = a[i];
+  return !dirty;
+}
+
 // One pass over the queries listed in `todo` (or all points when todo == nullptr) on one grid level.
 // kSel selects how the k best so far are kept in LDS -- all three keep the same set, so results are equal:
 //   0  a max-heap (k > 32);
@@ -204,20 +259,19 @@ __device__ __forceinline__ void eigen33_smallest(const float* cov, float& eigenv
 //      reads, cheaper than a sift-down's dependent chain while k is small -- 20 M points: k = 8 20.7 vs 23.1 ms, k = 32 121 vs 83 ms);
 //   2  the unsorted list in groups of eight with each group's worst entry in registers (16 < k <= 32): a replacement re-scans
 //      one group (8 independent reads) and picks the worst of at most four group maxima.
-//   3  (k <= 32) TWO PASSES without any per-candidate list maintenance -- with 64 lanes some lane replaces an entry at almost
-//      every candidate, so the variants above walk their replacement path for nearly every candidate (rocprofv3: ~130
-//      instructions per candidate).  Pass A only counts: a 64-bin histogram of the squared distances (bin width = cell^2 / 32,
-//      one byte per bin, four bins per LDS word, one ds_add per candidate) gives the first bin b at which the count reaches k.
-//      Pass B collects the candidates of bins <= b (k plus a handful) and skips the cells farther away than that distance.
-//      The collected set contains the k nearest -- it holds EVERY candidate up to a distance with at least k of them.  Pass A
-//      runs as its own kernel (k_knn_hist: 64 B of LDS per query, full occupancy) and leaves the selected bin and the counts in
-//      HBM; pass B turns the counts into slot offsets of a bucket sort by bin PAIRS, places every candidate with one LDS
-//      fetch-and-add (eight loads, then eight atomics, then the stores per round) next to a 16-bit key of its distance, and
-//      finishes with an insertion sort over the nearly sorted keys (equal keys compare the recomputed f32 distances and the
-//      original indices): the list comes out in (distance, original index) order like the other variants'.  Whatever does not fit (more than `cap`
-//      candidates in those bins: duplicates; no bin reaches k within 2 cell^2; a saturated byte) is checked after pass B and
-//      sent to `fb_todo`, which the host runs through the list-maintaining variant on the same grid: results are exact either way.
-//      (20 M points, k = 32: 64 ms with variant 2 -> 19 ms; k = 8: 18 -> 10.5 ms.)
+//   3  (k <= 60, dense cell directory) TWO PASSES without any per-candidate list maintenance -- with 64 lanes some lane replaces
+//      an entry at almost every candidate, so the variants above walk their replacement path for nearly every candidate
+//      (rocprofv3: ~130 instructions per candidate).  Pass A only counts (its own kernel, k_knn_hist: 64 B of LDS per query,
+//      full occupancy): a 64-bin histogram of the squared distances (bin width = cell^2 / 32, one byte per bin, one ds_add per
+//      candidate) gives the first bin b at which the count reaches k.  Pass B appends the candidates of bins <= b (k plus a
+//      handful) to the query's LDS list as one word each -- [16-bit distance key | row | offset in the row] -- and skips the cells
+//      farther away than that distance.  The collected set contains the k nearest: it holds EVERY candidate up to a distance with
+//      at least k of them.  The words are sorted by a sorting network in registers (knn_sort_words), equal keys by the recomputed
+//      f32 distances and the original indices, so the list comes out in (distance, original index) order like the other
+//      variants'; one directory word per slot then turns [row | offset] into positions.  4 B of LDS per list slot: 16 waves per CU
+//      at k = 32.  Whatever does not fit (more than `cap` candidates in those bins: duplicates, dense clusters; no bin reaches k
+//      within 2 cell^2; a row of 4096+ points) goes to `fb_todo`, which the host runs through the list-maintaining variant on the
+//      same grid: results are exact either way.  (20 M points, k = 32: 64 ms with variant 2 -> 11.6 ms; k = 8: 18 -> 8.5 ms.)
 // reach: 1 = the 27 cells around the query's cell; 2 = the 125 cells (list-maintaining variants only), the retry pass for the
 // ~1 % of queries whose k-th neighbour lies outside the 27 cells, instead of a second grid of twice the cell size.
 template <int kSel>
@@ -232,14 +286,12 @@ __global__ __launch_bounds__(kKnnBlock) void k_knn_normals(const float4* __restr
                                                            unsigned* __restrict__ next_count,
                                                            unsigned* __restrict__ fb_todo, unsigned* __restrict__ fb_count,
                                                            const unsigned char* __restrict__ sel_bins,
-                                                           const unsigned* __restrict__ hist_in, int reach) {
+                                                           int reach) {
   extern __shared__ unsigned char smem[];
-  // variants 0..2: [cap = k distances][cap positions]; variant 3: [kKnnBins / 8 words of slot offsets][cap positions][cap 16-bit
-  // distance keys] (cap even)
-  constexpr int kOffWords = (kSel == 3) ? kKnnBins / 8 : 0;
+  // variants 0..2: [cap = k distances][cap positions]; variant 3: [cap words: key | row | offset, later the positions]
+  constexpr int kOffWords = 0;
   float* hd = reinterpret_cast<float*>(smem) + (size_t)kOffWords * kKnnBlock;
   unsigned* hp = reinterpret_cast<unsigned*>(smem) + (size_t)(kOffWords + (kSel == 3 ? 0 : cap)) * kKnnBlock;
-  unsigned short* hk = reinterpret_cast<unsigned short*>(hp + (size_t)cap * kKnnBlock);   // variant 3: 16-bit distance keys
   const int tid = threadIdx.x;
   const size_t gi = (size_t)blockIdx.x * blockDim.x + tid;
   if (gi >= n_todo) return;
@@ -248,7 +300,6 @@ __global__ __launch_bounds__(kKnnBlock) void k_knn_normals(const float4* __restr
   const unsigned q_oi = __float_as_uint(q.w);
 #define HD(i) hd[(size_t)(i) * kKnnBlock + tid]
 #define HP(i) hp[(size_t)(i) * kKnnBlock + tid]
-#define HK(i) hk[(size_t)(i) * kKnnBlock + tid]
   // !kHeap: the k best so far live UNSORTED in LDS; the worst of them (by (distance, original index), the order of the result
   // list) is cached in registers with its slot.  A candidate costs one compare against that register; one that enters overwrites
   // the worst slot and re-scans the k distances for the new worst.
@@ -363,55 +414,30 @@ __global__ __launch_bounds__(kKnnBlock) void k_knn_normals(const float4* __restr
     if (sel_bin >= kKnnBins) {
       fallback = true;                                                // the k-th neighbour lies beyond the histogram's range
     } else {
-      // ---- bucket sort by PAIRS of histogram bins: pass A's counts become slot offsets (one byte per bin pair), pass B puts
-      //      every candidate of the bins <= sel_bin straight into its pair's slot range; the list then only needs an insertion
-      //      sort over a nearly sorted array (a pair holds ~1 candidate) ----
-      unsigned* ow = reinterpret_cast<unsigned*>(smem);
-#define OW(w) ow[(size_t)(w) * kKnnBlock + tid]
-      int total = 0;
-#pragma unroll
-      for (int wv = 0; wv < kKnnBins / 8; ++wv) {
-        unsigned packed = 0u;
-        if (8 * wv <= sel_bin) {
-          const unsigned h0 = hist_in[(size_t)(2 * wv) * n_todo + gi];
-          const unsigned h1 = (8 * wv + 4 <= sel_bin) ? hist_in[(size_t)(2 * wv + 1) * n_todo + gi] : 0u;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {                               // pair j of this word = bins 8 wv + 2 j, + 1
-            const unsigned src = (j < 2) ? h0 : h1;
-            const int b0 = 8 * wv + 2 * j;
-            const int c0 = (b0 <= sel_bin) ? (int)((src >> (16 * (j & 1))) & 0xFFu) : 0;
-            const int c1 = (b0 + 1 <= sel_bin) ? (int)((src >> (16 * (j & 1) + 8)) & 0xFFu) : 0;
-            packed |= (unsigned)min(total, 255) << (8 * j);
-            total += c0 + c1;
-          }
-        }
-        OW(wv) = packed;
-      }
-      if (total > cap || total < k) {
-        fallback = true;
-      } else {
+      {
+        // every candidate of the bins <= sel_bin is appended to the query's LDS list in scan order; the sorting network below
+        // does not care about the order (a bucket placement by bin pairs with LDS fetch-and-adds was measured: the 32 B of slot
+        // offsets per query cost more occupancy than the pre-sorting saved)
         const float tau2 = (float)(sel_bin + 1) * (1.0f / inv_w2) * 1.00001f;
         int placed = 0;
-        // slot of a candidate = fetch-and-add on its pair's offset byte.  Eight candidates per round: their loads, then their LDS
-        // atomics (with return; the same lane's atomics on one word are served in order), then the stores -- one wait per stage
-        // instead of a load -> read -> write chain per candidate.
-        auto place8 = [&](unsigned m, const float4* cb, int nvalid) {
-          unsigned old[8]; float bbv[8];
+        bool long_row = false;
+        // A collected candidate is stored as ONE word: [16-bit distance key | 4-bit row | 12-bit offset], row = 3 (oz + 1) + (oy + 1),
+        // offset = its position relative to the start of cell (cx - 1, cy + oy, cz + oz) in the dense directory.  Positions are
+        // recovered after the sort with one directory word per slot -- 4 instead of 6 bytes of LDS per slot (14 instead of 10 waves
+        // per CU for this latency-bound scan).  A 3-cell row of 4096 points or more: the list-maintaining variant takes the query.
+        // (This variant runs with the dense directory only.)
+        auto row_start = [&](int r) -> unsigned {
+          const int oy = r % 3 - 1, oz = r / 3 - 1;
+          const size_t row = ((size_t)(cz + oz) * G.D[1] + (size_t)(cy + oy)) * G.D[0];
+          return G.S[row + (size_t)max(cx - 1, 0)];
+        };
+        auto place8 = [&](unsigned tag0, const float4* cb, int nvalid) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             const float d2 = sqdist_l2(q.x, q.y, q.z, cb[j].x, cb[j].y, cb[j].z);
             const float bb = d2 * inv_w2;
-            const bool in = j < nvalid && bb < (float)kKnnBins && (int)bb <= sel_bin;
-            const int pr = in ? ((int)bb >> 1) : 0;
-            bbv[j] = in ? bb : -1.f;
-            old[j] = atomicAdd(&OW(pr >> 2), in ? (1u << (8 * (pr & 3))) : 0u);
-          }
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            if (bbv[j] >= 0.f) {
-              const int pr = (int)bbv[j] >> 1;
-              const int slot = (int)((old[j] >> (8 * (pr & 3))) & 0xFFu);
-              if (slot < cap) { HP(slot) = m + j; HK(slot) = (unsigned short)(bbv[j] * 1024.0f); }
+            if (j < nvalid && bb < (float)kKnnBins && (int)bb <= sel_bin) {
+              if (placed < cap) HP(placed) = ((unsigned)(bb * 1024.0f) << 16) | (tag0 + (unsigned)j);
               ++placed;
             }
           }
@@ -419,51 +445,69 @@ __global__ __launch_bounds__(kKnnBlock) void k_knn_normals(const float4* __restr
         for (int oz = -1; oz <= 1; ++oz)
           for (int oy = -1; oy <= 1; ++oy) {
             if ((oy | oz) != 0 && face2(0, oy, oz) > tau2) continue;
-            const int xlo = (face2(-1, oy, oz) > tau2) ? cx : cx - 1, xhi = (face2(1, oy, oz) > tau2) ? cx : cx + 1;
-            knn_row(G, table, xlo, xhi, cy + oy, cz + oz, [&](unsigned m, unsigned e) {
-              for (; m < e; m += 8) {                                  // eight candidates in flight per lane
-                float4 cb[8];
-                const int nvalid = (int)min(8u, e - m);
+            const int y = cy + oy, z = cz + oz;
+            if (y < 0 || z < 0 || y >= (int)G.D[1] || z >= (int)G.D[2]) continue;
+            const int xlo = max((face2(-1, oy, oz) > tau2) ? cx : cx - 1, 0), xhi = min((face2(1, oy, oz) > tau2) ? cx : cx + 1, (int)G.D[0] - 1);
+            const size_t row = ((size_t)z * G.D[1] + (size_t)y) * G.D[0];
+            const unsigned r0 = G.S[row + (size_t)max(cx - 1, 0)];
+            const unsigned m0 = G.S[row + (size_t)xlo], e = G.S[row + (size_t)xhi + 1];
+            if (e - r0 > 4096u) { long_row = true; continue; }
+            const unsigned rtag = (unsigned)(3 * (oz + 1) + (oy + 1)) << 12;
+            for (unsigned m = m0; m < e; m += 8) {                          // eight candidates in flight per lane
+              float4 cb[8];
+              const int nvalid = (int)min(8u, e - m);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) cb[j] = P4[min(m + j, e - 1)];
-                place8(m, cb, nvalid);
-              }
-            });
+              for (int j = 0; j < 8; ++j) cb[j] = P4[min(m + j, e - 1)];
+              place8(rtag | (m - r0), cb, nvalid);
+            }
           }
-        // a histogram byte that wrapped (>= 256 candidates in one bin) shows as a count mismatch: the other variant takes over
-        if (placed != total) {
+        // more candidates than list slots (duplicates, a dense cluster in one bin), or a long row: the other variant takes over
+        if (placed > cap || placed < k || long_row) {
           fallback = true;
         } else {
-          cnt = total;
-          // exact (d2, original index) order: the bin pairs are in order already, and inside a pair a 16-bit key (the squared
-          // distance in 1/1024 of a bin, monotone in the f32 value) decides; only equal keys compare the recomputed distances.
-          // One insertion sort over the nearly sorted list, LDS traffic only.
+          cnt = placed;
+          auto pos_of = [&](unsigned w) { return row_start((int)((w >> 12) & 15u)) + (w & 0xFFFu); };
           auto dist_of = [&](unsigned m) { const float4 c = P4[m]; return sqdist_l2(q.x, q.y, q.z, c.x, c.y, c.z); };
-          unsigned prev_key = HK(0);
-          for (int i = 1; i < cnt; ++i) {
-            const unsigned kk = HK(i);
-            if (kk > prev_key) { prev_key = kk; continue; }                       // in place already (the common case)
-            const unsigned kp = HP(i);
-            float kd = -1.f;
-            int j = i - 1;
-            while (j >= 0) {
-              const unsigned jk = HK(j);
-              if (jk < kk) break;
-              const unsigned jp = HP(j);
-              if (jk == kk) {
-                if (kd < 0.f) kd = dist_of(kp);
-                if (!knn_less(kd, kp, dist_of(jp), jp, P4)) break;
+          // exact (d2, original index) order.  The words go through a sorting network in registers (Batcher's merge exchange, no
+          // LDS traffic and no divergence; the bucket placement only has to keep the list short of sorting work it cannot do:
+          // none), then neighbours with EQUAL 16-bit keys are put into exact order by up to three bubble passes over the
+          // recomputed f32 distances and the original indices; a longer run of equal keys (lattices, duplicates) falls back to the
+          // exact insertion sort in LDS.
+          bool settled;
+          if (cap <= 12) settled = knn_sort_words<12>(hp, tid, cnt, pos_of, dist_of, P4);
+          else if (cap <= 20) settled = knn_sort_words<20>(hp, tid, cnt, pos_of, dist_of, P4);
+          else if (cap <= 36) settled = knn_sort_words<36>(hp, tid, cnt, pos_of, dist_of, P4);
+          else settled = knn_sort_words<64>(hp, tid, cnt, pos_of, dist_of, P4);
+          if (!settled) {
+            for (int i = 1; i < cnt; ++i) {
+              const unsigned kw = HP(i), kk = kw >> 16;
+              unsigned kp = 0; float kd = -1.f;
+              int j = i - 1;
+              while (j >= 0) {
+                const unsigned jw = HP(j), jk = jw >> 16;
+                if (jk < kk) break;
+                if (jk == kk) {
+                  if (kd < 0.f) { kp = pos_of(kw); kd = dist_of(kp); }
+                  const unsigned jp = pos_of(jw);
+                  if (!knn_less(kd, kp, dist_of(jp), jp, P4)) break;
+                }
+                HP(j + 1) = jw;
+                --j;
               }
-              HP(j + 1) = jp; HK(j + 1) = (unsigned short)jk;
-              --j;
+              HP(j + 1) = kw;
             }
-            HP(j + 1) = kp; HK(j + 1) = (unsigned short)kk;
-            // prev_key stays: slot i now holds the former slot i - 1, the largest key so far
+          }
+          // [row | offset] -> positions, eight directory words in flight
+          for (int i0 = 0; i0 < cnt; i0 += 8) {
+            unsigned w[8], st[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { w[j] = HP(min(i0 + j, cnt - 1)); st[j] = row_start((int)((w[j] >> 12) & 15u)); }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) if (i0 + j < cnt) HP(i0 + j) = st[j] + (w[j] & 0xFFFu);
           }
           td = dist_of(HP(cnt - 1));                                            // the farthest collected candidate
         }
       }
-#undef OW
     }
   } else {
   // own cell first, then face, edge and corner neighbours: the list fills with near points early, so fewer of the later candidates
@@ -488,21 +532,13 @@ __global__ __launch_bounds__(kKnnBlock) void k_knn_normals(const float4* __restr
             const float face = sqrtf(ax * ax + ay * ay + az * az) - G.slack;
             if (face > 0.f && face * face * 0.99999f > (kHeap ? HD(0) : td)) continue;
           }
-          const unsigned long long key = cell_key(x, y, z);
-          unsigned h = hash_key(key) & G.g.mask;
-          unsigned s = 0, e = 0;
-          for (;;) {
-            const HashEntry en = table[h];
-            if (en.key == key) { s = en.start; e = en.end; break; }
-            if (en.key == kEmptyKey) break;
-            h = (h + 1) & G.g.mask;
-          }
-          unsigned m = s;
-          for (; m + 4 <= e; m += 4) {                                  // four candidates in flight per lane
-            const float4 c0 = P4[m], c1 = P4[m + 1], c2 = P4[m + 2], c3 = P4[m + 3];
-            consider(m, c0); consider(m + 1, c1); consider(m + 2, c2); consider(m + 3, c3);
-          }
-          for (; m < e; ++m) consider(m, P4[m]);
+          knn_row(G, table, x, x, y, z, [&](unsigned m, unsigned e) {     // dense directory: two words; hash table otherwise
+            for (; m + 4 <= e; m += 4) {                                  // four candidates in flight per lane
+              const float4 c0 = P4[m], c1 = P4[m + 1], c2 = P4[m + 2], c3 = P4[m + 3];
+              consider(m, c0); consider(m + 1, c1); consider(m + 2, c2); consider(m + 3, c3);
+            }
+            for (; m < e; ++m) consider(m, P4[m]);
+          });
         }
 }
   if (fallback) {
@@ -638,7 +674,6 @@ __global__ __launch_bounds__(kKnnBlock) void k_knn_normals(const float4* __restr
   out_c[q_oi] = curv;
 #undef HD
 #undef HP
-#undef HK
 }
 
 // Radius-search variant (pcl::Feature::searchForNeighbors with setRadiusSearch, two_pass_normal_3d_omp.hpp:66): every
@@ -728,8 +763,7 @@ struct LevelBuffers {
   DevBuf<float4> P4, LN;
   DevBuf<HashEntry> table;
   DevBuf<unsigned> dense;          // dense cell-start directory of the level (when the bounding grid is small enough)
-  DevBuf<unsigned char> sel_bin;   // pass A results of the two-pass variant: selected bin,
-  DevBuf<unsigned> hist;           // histogram words [kKnnBins / 4][queries of the pass]
+  DevBuf<unsigned char> sel_bin;   // pass A results of the two-pass variant: the selected bin per query
 };
 
 
@@ -749,7 +783,7 @@ struct KnnWorkspace {
   size_t bytes() const {
     return raw.cap * 4 + bbox_partial.cap * 4 + bbox_out.cap * 4 + d_on.cap * 4 + d_oc.cap * 4 + d_mean.cap * 4 + d_knn.cap * 4 + d_in.cap +
            L.ka.cap * 8 + L.kb.cap * 8 + L.va.cap * 4 + L.vb.cap * 4 + L.counter.cap * 4 + L.temp.cap + L.P4.cap * 16 + L.LN.cap * 16 +
-           L.table.cap * sizeof(HashEntry) + L.dense.cap * 4 + L.sel_bin.cap + L.hist.cap * 4 + Q4.cap * 16 + todo_a.cap * 4 +
+           L.table.cap * sizeof(HashEntry) + L.dense.cap * 4 + L.sel_bin.cap + Q4.cap * 16 + todo_a.cap * 4 +
            todo_b.cap * 4 + fb_todo.cap * 4;
   }
   ~KnnWorkspace() { if (stream) (void)hipStreamDestroy(stream); }
@@ -850,10 +884,11 @@ static void knn_pass(KnnWorkspace& W, const float* xyz, size_t n, int k, const f
     size_t n_todo = n;
     static const int forced_sel = [] { const char* e = getenv("E3D_KNN_SELECT"); return e ? atoi(e) : -1; }();     // experiments: 0 heap, 1 flat, 2 grouped, 3 two-pass
     const int sel_list = k <= 16 ? 1 : (k <= 32 ? 2 : 0);                   // list-maintaining variant (also variant 3's fallback)
-    const int sel = (forced_sel >= 0 && forced_sel <= 3 && (forced_sel < 2 || k <= 32)) ? forced_sel : (k <= 32 ? 3 : 0);
+    constexpr int kTwoPassMaxK = 60;                                        // k + 4 list slots <= the largest sorting network (64)
+    const int sel = (forced_sel >= 0 && forced_sel <= 3 && (forced_sel < 2 || (forced_sel == 2 && k <= 32) || (forced_sel == 3 && k <= kTwoPassMaxK))) ? forced_sel : (k <= kTwoPassMaxK ? 3 : 0);
     static const int cap_extra = [] { const char* e = getenv("E3D_KNN_CAP_EXTRA"); return e ? atoi(e) : 4; }();
     const int cap = sel == 3 ? ((std::max(k + cap_extra, 12) + 1) & ~1) : k;             // list entries per thread in LDS
-    const size_t lds = sel == 3 ? (size_t)(kKnnBins / 8 + cap + cap / 2) * kKnnBlock * 4 : (size_t)cap * kKnnBlock * 8, lds_list = (size_t)k * kKnnBlock * 8;
+    const size_t lds = sel == 3 ? (size_t)cap * kKnnBlock * 4 : (size_t)cap * kKnnBlock * 8, lds_list = (size_t)k * kKnnBlock * 8;
     auto kernel_of = [](int v) {
       return v == 0 ? k_knn_normals<0> : (v == 1 ? k_knn_normals<1> : (v == 2 ? k_knn_normals<2> : k_knn_normals<3>));
     };
@@ -871,41 +906,51 @@ static void knn_pass(KnnWorkspace& W, const float* xyz, size_t n, int k, const f
       G.slack = (float)(16.0 * FLT_EPSILON * (magnitude + 4.0 * cell) + 1e-4 * cell);
       // too many cells for 21-bit coordinates: coarsen
       if (extent / cell > (double)((1 << 21) - 8)) { cell *= 4.0; --level; continue; }
-      launch_cell_keys(raw.p, n, G.g, L.ka.p, L.va.p, s);
-      sort_pairs_u64_u32(L.ka.p, L.kb.p, L.va.p, L.vb.p, n, 63, L.temp, s);
-      launch_permute(raw.p, nullptr, L.vb.p, n, L.P4.p, nullptr, s);
-      E3D_HIP(hipMemsetAsync(L.counter.p, 0, 2 * sizeof(unsigned), s));
-      launch_count_cells(L.kb.p, n, L.counter.p, s);
-      unsigned n_cells = 0;
-      E3D_HIP(hipMemcpyAsync(&n_cells, L.counter.p, sizeof(unsigned), hipMemcpyDeviceToHost, s));
-      E3D_HIP(hipStreamSynchronize(s));
-      size_t tsize = 64;
-      while (tsize < 2 * (size_t)n_cells) tsize <<= 1;
-      L.table.reserve(tsize);
-      G.g.mask = (unsigned)(tsize - 1);
-      E3D_HIP(hipMemsetAsync(L.table.p, 0xFF, sizeof(HashEntry) * tsize, s));
-      launch_build_table(L.kb.p, n, L.table.p, G.g.mask, s);
-      // dense directory over the bounding grid (cells 0 .. cell of the bbox maximum + 2 per axis) unless it would be huge
-      {
-        QueryRange qr{};
-        double prod = 1.0;
-        for (int a = 0; a < 3; ++a) {
-          qr.lo[a] = 0;
-          const double cmax = std::floor(((double)bb[3 + a] - (double)G.g.origin[a]) * (double)G.g.inv_cell);
-          qr.D[a] = (unsigned)std::max(1.0, std::min(cmax + 4.0, 2097152.0));
-          prod *= (double)qr.D[a];
-        }
-        G.S = nullptr;
-        static const int dense_log2 = [] { const char* e = getenv("E3D_KNN_DENSE_LOG2"); return e ? atoi(e) : 30; }();
-        if (prod <= (double)((size_t)1 << dense_log2)) {
-          const size_t ncell = (size_t)prod;
-          L.dense.reserve(ncell + 2);
-          E3D_HIP(hipMemsetAsync(L.dense.p, 0, sizeof(unsigned) * (ncell + 2), s));
-          launch_dense_counts(L.kb.p, n, qr, L.dense.p, s);
-          exclusive_max_scan_u32(L.dense.p, ncell + 2, L.temp, s);
-          G.S = L.dense.p;
-          for (int a = 0; a < 3; ++a) G.D[a] = qr.D[a];
-        }
+      // dense directory over the bounding grid (cells 0 .. cell of the bbox maximum + 2 per axis) unless it would be huge.  With it
+      // the sort key is the 32-bit linear cell index (same (z, y, x) order as the 63-bit key: 4 radix passes instead of 8).
+      QueryRange qr{};
+      double prod = 1.0;
+      for (int a = 0; a < 3; ++a) {
+        qr.lo[a] = 0;
+        const double cmax = std::floor(((double)bb[3 + a] - (double)G.g.origin[a]) * (double)G.g.inv_cell);
+        qr.D[a] = (unsigned)std::max(1.0, std::min(cmax + 4.0, 2097152.0));
+        prod *= (double)qr.D[a];
+      }
+      G.S = nullptr;
+      static const int dense_log2 = [] { const char* e = getenv("E3D_KNN_DENSE_LOG2"); return e ? std::min(atoi(e), 31) : 30; }();
+      if (prod <= (double)((size_t)1 << dense_log2)) {
+        const size_t ncell = (size_t)prod;
+        int bits = 1;
+        while (((size_t)1 << bits) < ncell) ++bits;
+        unsigned* k32_in = reinterpret_cast<unsigned*>(L.ka.p);
+        unsigned* k32_out = reinterpret_cast<unsigned*>(L.kb.p);
+        hipLaunchKernelGGL(k_cell_keys_dense, dim3((unsigned)div_up(n, kBlock)), dim3(kBlock), 0, s, raw.p, n, G.g, qr.D[0], qr.D[1], qr.D[2], k32_in, L.va.p);
+        sort_pairs_u32_u32(k32_in, k32_out, L.va.p, L.vb.p, n, bits, L.temp, s);
+        launch_permute(raw.p, nullptr, L.vb.p, n, L.P4.p, nullptr, s);
+        L.dense.reserve(ncell + 2);
+        E3D_HIP(hipMemsetAsync(L.dense.p, 0, sizeof(unsigned) * (ncell + 2), s));
+        hipLaunchKernelGGL(k_dense_ends32, dim3((unsigned)div_up(n, kBlock)), dim3(kBlock), 0, s, k32_out, n, L.dense.p);
+        exclusive_max_scan_u32(L.dense.p, ncell + 2, L.temp, s);
+        G.S = L.dense.p;
+        for (int a = 0; a < 3; ++a) G.D[a] = qr.D[a];
+      } else {
+        launch_cell_keys(raw.p, n, G.g, L.ka.p, L.va.p, s);
+        sort_pairs_u64_u32(L.ka.p, L.kb.p, L.va.p, L.vb.p, n, 63, L.temp, s);
+        launch_permute(raw.p, nullptr, L.vb.p, n, L.P4.p, nullptr, s);
+      }
+      if (!G.S) {
+        // no dense directory (the bounding grid is too large): hash table of the occupied cells
+        E3D_HIP(hipMemsetAsync(L.counter.p, 0, 2 * sizeof(unsigned), s));
+        launch_count_cells(L.kb.p, n, L.counter.p, s);
+        unsigned n_cells = 0;
+        E3D_HIP(hipMemcpyAsync(&n_cells, L.counter.p, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+        E3D_HIP(hipStreamSynchronize(s));
+        size_t tsize = 64;
+        while (tsize < 2 * (size_t)n_cells) tsize <<= 1;
+        L.table.reserve(tsize);
+        G.g.mask = (unsigned)(tsize - 1);
+        E3D_HIP(hipMemsetAsync(L.table.p, 0xFF, sizeof(HashEntry) * tsize, s));
+        launch_build_table(L.kb.p, n, L.table.p, G.g.mask, s);
       }
       if (level == 0) {
         Q4.reserve(n);
@@ -914,15 +959,16 @@ static void knn_pass(KnnWorkspace& W, const float* xyz, size_t n, int k, const f
       unsigned* next = (todo == todo_a.p) ? todo_b.p : todo_a.p;
       E3D_HIP(hipMemsetAsync(L.counter.p + 1, 0, 2 * sizeof(unsigned), s));
       const unsigned nblk = (unsigned)div_up(n_todo, kKnnBlock);
-      if (sel == 3) {
-        L.sel_bin.reserve(n_todo); L.hist.reserve(n_todo * (size_t)(kKnnBins / 4));
+      const int lsel = (sel == 3 && !G.S) ? sel_list : sel;            // the two-pass variant needs the dense directory
+      if (lsel == 3) {
+        L.sel_bin.reserve(n_todo);
         hipLaunchKernelGGL(k_knn_hist, dim3((unsigned)div_up(n_todo, kKnnHistBlock)), dim3(kKnnHistBlock), 0, s, L.P4.p, todo, n_todo,
-                           L.table.p, G, k, Q4.p, L.sel_bin.p, L.hist.p);
+                           L.table.p, G, k, Q4.p, L.sel_bin.p);
       }
-      hipLaunchKernelGGL(kernel_of(sel), dim3(nblk), dim3(kKnnBlock), lds, s, L.P4.p, n, todo, n_todo, L.table.p, G, k, cap,
+      hipLaunchKernelGGL(kernel_of(lsel), dim3(nblk), dim3(kKnnBlock), lsel == 3 ? lds : lds_list, s, L.P4.p, n, todo, n_todo, L.table.p, G, k, lsel == 3 ? cap : k,
                          viewpoint[0], viewpoint[1], viewpoint[2], Q4.p, want_normals ? d_on.p : nullptr, want_normals ? d_oc.p : nullptr,
                          knn_indices ? d_knn.p : nullptr, d_mean_out ? d_mean_out->p : nullptr, next, L.counter.p + 1,
-                         fb_todo.p, L.counter.p + 2, L.sel_bin.p, L.hist.p, 1);
+                         fb_todo.p, L.counter.p + 2, L.sel_bin.p, 1);
       unsigned cnts[2] = {0, 0};
       E3D_HIP(hipMemcpyAsync(cnts, L.counter.p + 1, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, s));
       E3D_HIP(hipStreamSynchronize(s));
@@ -940,7 +986,7 @@ static void knn_pass(KnnWorkspace& W, const float* xyz, size_t n, int k, const f
         hipLaunchKernelGGL(kernel_of(sel_list), dim3((unsigned)div_up((size_t)cnts[1], kKnnBlock)), dim3(kKnnBlock), lds_list, s, L.P4.p, n,
                            fb_todo.p, (size_t)cnts[1], L.table.p, G, k, k, viewpoint[0], viewpoint[1], viewpoint[2], Q4.p,
                            want_normals ? d_on.p : nullptr, want_normals ? d_oc.p : nullptr, knn_indices ? d_knn.p : nullptr,
-                           d_mean_out ? d_mean_out->p : nullptr, next, L.counter.p + 1, nullptr, nullptr, nullptr, nullptr, 1);
+                           d_mean_out ? d_mean_out->p : nullptr, next, L.counter.p + 1, nullptr, nullptr, nullptr, 1);
         E3D_HIP(hipMemcpyAsync(cnts, L.counter.p + 1, sizeof(unsigned), hipMemcpyDeviceToHost, s));
         E3D_HIP(hipStreamSynchronize(s));
         E3D_HIP(hipGetLastError());
@@ -956,7 +1002,7 @@ static void knn_pass(KnnWorkspace& W, const float* xyz, size_t n, int k, const f
         hipLaunchKernelGGL(kernel_of(sel_list), dim3((unsigned)div_up((size_t)n_next, kKnnBlock)), dim3(kKnnBlock), lds_list, s, L.P4.p, n,
                            next, (size_t)n_next, L.table.p, G, k, k, viewpoint[0], viewpoint[1], viewpoint[2], Q4.p,
                            want_normals ? d_on.p : nullptr, want_normals ? d_oc.p : nullptr, knn_indices ? d_knn.p : nullptr,
-                           d_mean_out ? d_mean_out->p : nullptr, wide_out, L.counter.p + 1, nullptr, nullptr, nullptr, nullptr, 2);
+                           d_mean_out ? d_mean_out->p : nullptr, wide_out, L.counter.p + 1, nullptr, nullptr, nullptr, 2);
         E3D_HIP(hipMemcpyAsync(cnts, L.counter.p + 1, sizeof(unsigned), hipMemcpyDeviceToHost, s));
         E3D_HIP(hipStreamSynchronize(s));
         E3D_HIP(hipGetLastError());

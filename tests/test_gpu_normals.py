@@ -18,7 +18,7 @@ def _compare(e3d, ob, P, k, vp=(0, 0, 0)):
     return gk
 
 
-@pytest.mark.parametrize("k", [8, 32])
+@pytest.mark.parametrize("k", [8, 32, 48, 60, 70])      # two-pass variant up to k = 60, the heap variant beyond
 def test_normals_room(e3d, ob, synth, k):
     s = synth.make_scene(1, 60000, seed=21)[0]
     _compare(e3d, ob, s["xyz"].numpy(), k)

@@ -12,6 +12,7 @@
 //     passes); the tiny LDL^T solve and the SE3 update run on the host in the reference's precisions.
 #include <algorithm>
 #include <cfloat>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <map>
@@ -421,6 +422,15 @@ static void sort_query_keys(e3d_icp* h, const Cloud& tgt, const float4* srcG, co
 
 // NN search + compaction for one directed pair; appends to the correspondence planes.
 // Multi-GPU: every rank holds all clouds and handles the slice [j0, j1) of the source cloud (cell order).
+// E3D_NN_PROFILE=1: wall-clock split of the search of one outer iteration (synchronises between the phases; diagnostics only)
+static double g_nn_prof[8];
+static bool nn_profile() { static const bool on = [] { const char* e = getenv("E3D_NN_PROFILE"); return e && e[0] == '1'; }(); return on; }
+struct NnPhase {
+  hipStream_t s; int slot; std::chrono::steady_clock::time_point t0;
+  NnPhase(hipStream_t st, int sl) : s(st), slot(sl) { if (nn_profile()) { (void)hipStreamSynchronize(s); t0 = std::chrono::steady_clock::now(); } }
+  ~NnPhase() { if (nn_profile()) { (void)hipStreamSynchronize(s); g_nn_prof[slot] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); } }
+};
+
 static void find_pair(e3d_icp* h, Cloud& src, Cloud& tgt, float d, PairJob& job, size_t j0, size_t j1,
                       e3d_icp_iter_record& rec) {
   hipStream_t s = h->stream;
@@ -455,6 +465,7 @@ static void find_pair(e3d_icp* h, Cloud& src, Cloud& tgt, float d, PairJob& job,
     const unsigned* list = nullptr;
     float t_cert = 0.f;
     if (!ps.fresh && use_cert) {
+      NnPhase ph(s, 0);
       static const double margin_frac = env_double("E3D_NN_MARGIN", 0.08), near_frac = env_double("E3D_NN_NEAR", 0.4);   // of the radius
       const float cum_up = round_up_f((cum_pair * (1.0 + 2e-6) + 2.0 * (src.err_max + tgt.err_max)) * (1.0 + 1e-6));
       const float near2 = (float)((near_frac * (double)d) * (near_frac * (double)d));
@@ -492,7 +503,7 @@ static void find_pair(e3d_icp* h, Cloud& src, Cloud& tgt, float d, PairJob& job,
     }
     float t_first = 0.f;
     if (t_cert < 0.f) { sync(h); t_first = h->nn_timer->ms(); }
-    if (n_far > 0) sort_query_keys(h, tgt, srcG, list, n_far, im);
+    if (n_far > 0) { NnPhase ph(s, 1); sort_query_keys(h, tgt, srcG, list, n_far, im); }
     h->nn_timer->start(s);
     if (n_far > 0)
       launch_rows(3, tgt, srcG, h->vals_b.p, n_far, im, radius_sq(d), cert, ps.match.p, h->match_d2.p, ps.lbe.p, ps.match2.p, s);
@@ -525,6 +536,7 @@ static void find_pair(e3d_icp* h, Cloud& src, Cloud& tgt, float d, PairJob& job,
                     h->match_d2.p, s);
   }
   h->nn_timer->stop(s);
+  NnPhase ph3(s, 2);                                                 // (its constructor waits for the search kernels)
   h->chunk_sum.reserve(div_up(nb, 256) + 1); h->chunk_d2.reserve(div_up(nb, 256) + 1);
   launch_match_scan(match_pos, h->match_d2.p, n, h->block_counts.p, h->block_offsets.p, h->block_d2.p,
                     h->chunk_sum.p, h->chunk_d2.p, h->d_total.p, h->d_total_d2.p, s);
@@ -847,7 +859,15 @@ static bool align_meshes(e3d_icp* h, float max_d, float thr, bool print, int ite
     // two directed pairs: one slot per query (no reallocation ever); many pairs: most queries of a pair find no partner, so
     // start from last iteration's total (+ 12 %) or a quarter of the queries and let find_pair grow the planes if needed
     size_t want = qtot;
-    if (jobs.size() > 2) want = std::min(qtot, std::max(h->last_corr_total + h->last_corr_total / 8 + (size_t)(1 << 20), qtot / 4));
+    if (jobs.size() > 2 && qtot > h->cA.cap) {
+      // one slot per query as well if HBM has room for it (growing 100 GB planes means hipMalloc + copy + hipFree of that size:
+      // seconds per outer iteration while the correspondence count still climbs); otherwise start small and grow
+      size_t free_b = 0, total_b = 0;
+      (void)hipMemGetInfo(&free_b, &total_b);
+      const double need = 48.0 * (double)(qtot - h->cA.cap);
+      if (need > 0.75 * (double)free_b)
+        want = std::min(qtot, std::max(h->last_corr_total + h->last_corr_total / 8 + (size_t)(1 << 20), qtot / 4));
+    }
     if (want > h->cA.cap) { h->cA.reserve(want); h->cB.reserve(want); h->cC.reserve(want); }
   }
   for (size_t p = 0; p < jobs.size(); ++p) {
@@ -862,6 +882,11 @@ static bool align_meshes(e3d_icp* h, float max_d, float thr, bool print, int ite
     rec.correspondences += j.count;
   }
   t_nn.stop(s);
+  if (nn_profile()) {
+    fprintf(stderr, "[nn profile] certify + bounded search %.1f ms, keys + sort %.1f ms, match scan + compaction (+ plane growth) %.1f ms, %zu pairs\n",
+            g_nn_prof[0], g_nn_prof[1], g_nn_prof[2], jobs.size());
+    for (double& v : g_nn_prof) v = 0;
+  }
   h->last_corr_total = h->corr_used;
   // global per-pair counts (what the reference prints); local counts stay in j.count for the LM sets
   std::vector<long long> gcount(jobs.size());

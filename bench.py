@@ -116,6 +116,10 @@ def sum_records(recs):
         sum(r["t_lm_kernel_ms"] for r in recs), sum(r["t_nn_query_ms"] for r in recs),
         sum(r["full_passes"] + r["cost_passes"] + r["multi_cost_passes"] for r in recs),
         sum(r["t_transform_ms"] for r in recs), sum(r["t_nn_ms"] for r in recs), sum(r["t_lm_ms"] for r in recs),
+        sum(r["t_lm_full_kernel_ms"] for r in recs), sum(r["full_passes"] for r in recs),
+        sum(r["t_nn_certify_ms"] for r in recs), sum(r["nn_certify_launches"] for r in recs), sum(r["nn_certify_queries"] for r in recs),
+        sum(r["t_nn_bounded_ms"] for r in recs), sum(r["nn_bounded_launches"] for r in recs), sum(r["nn_bounded_queries"] for r in recs),
+        sum(r["t_nn_search_ms"] for r in recs), sum(r["nn_search_launches"] for r in recs), sum(r["nn_search_queries"] for r in recs),
     ], dtype=np.float64)
 
 
@@ -208,17 +212,34 @@ def leg_terrace(e3d, synth, R, args, dev):
     n_nn_launch = 2 * K
     lm_bytes = ALG_BYTES_PER_CORR_PASS * (corr / world / K)                  # one pass over this rank's correspondences
     nn_bytes = ALG_BYTES_PER_QUERY * (queries / world / n_nn_launch)         # one directed pair's queries
-    lm_avg, nn_avg = lm_ms / max(passes, 1), nn_ms / n_nn_launch
+    lm_full_ms, full_passes = tot[8] / world, tot[9] / world
+    lm_avg, nn_avg = lm_full_ms / max(full_passes, 1), nn_ms / n_nn_launch
+    multi_ms, multi_passes = lm_ms - lm_full_ms, max(passes - full_passes, 0)
     kernels = {
-        "k_lm_pass": {"what": "fused cost + Gramian pass over the correspondence planes (a7/a8), k_lm_pass<1> / k_lm_cost_multi",
+        "k_lm_pass": {"what": "k_lm_pass<1>: fused cost + Gramian pass over the correspondence planes (a7/a8); %.2f launches per iteration"
+                              % (full_passes / K),
                       "algorithmic_bytes_per_launch": lm_bytes, "avg_launch_ms": lm_avg, "GBs": lm_bytes / (lm_avg * 1e-3) / 1e9 if lm_avg > 0 else None,
-                      "summed_ms_per_iter": lm_ms / K},
-        "nn_search": {"what": "exact 1-NN within radius per directed pair (a5): k_nn_certify + k_nn_bounded + k_nn_rows on the queries the "
-                              "certificates leave", "algorithmic_bytes_per_launch": nn_bytes, "avg_launch_ms": nn_avg,
-                      "GBs": nn_bytes / (nn_avg * 1e-3) / 1e9 if nn_avg > 0 else None, "summed_ms_per_iter": nn_ms / K},
+                      "summed_ms_per_iter": lm_full_ms / K},
+        "k_lm_cost_multi": {"what": "the costs of LM tries 1..9 in one pass over the planes (a8); %.2f launches per iteration" % (multi_passes / K),
+                            "algorithmic_bytes_per_launch": lm_bytes, "avg_launch_ms": multi_ms / multi_passes if multi_passes else None,
+                            "GBs": lm_bytes / (multi_ms / multi_passes * 1e-3) / 1e9 if multi_passes and multi_ms > 0 else None,
+                            "summed_ms_per_iter": multi_ms / K},
     }
-    dom = "k_lm_pass" if lm_ms >= nn_ms else "nn_search"
-    traffic, traffic_src = load_traffic("k_lm_pass<1>" if dom == "k_lm_pass" else "k_nn_certify") if (world == 1 and n_points == 50_000_000) else (None, None)
+
+    def nn_kernel(what, t_ms, launches, n_queries):
+        # per launch: 32 B per query the launch covered; averages over this rank's launches in the timed region
+        if launches <= 0:
+            return {"what": what, "launches_per_iter": 0.0, "summed_ms_per_iter": 0.0, "avg_launch_ms": None, "algorithmic_bytes_per_launch": None, "GBs": None}
+        avg, by = t_ms / launches, ALG_BYTES_PER_QUERY * n_queries / launches
+        return {"what": what, "launches_per_iter": launches / K, "summed_ms_per_iter": t_ms / K, "avg_launch_ms": avg,
+                "algorithmic_bytes_per_launch": by, "GBs": by / (avg * 1e-3) / 1e9 if avg > 0 else None}
+    kernels["k_nn_certify"] = nn_kernel("partner of the last search still the unique nearest neighbour? (one gather per query, a5)", tot[10] / world, tot[11] / world, tot[12] / world)
+    kernels["k_nn_bounded"] = nn_kernel("exact search inside the ball of the old partner's distance, one thread per listed query (a5)", tot[13] / world, tot[14] / world, tot[15] / world)
+    kernels["k_nn_rows"] = nn_kernel("exact search of the remaining queries, sorted by target cell, LDS-staged candidate rows (a5)", tot[16] / world, tot[17] / world, tot[18] / world)
+    kernels["nn_search_per_pair"] = {"what": "all three per directed pair: 32 B per query of the pair", "algorithmic_bytes_per_launch": nn_bytes, "avg_launch_ms": nn_avg,
+                                     "GBs": nn_bytes / (nn_avg * 1e-3) / 1e9 if nn_avg > 0 else None, "summed_ms_per_iter": nn_ms / K}
+    dom = max(("k_lm_pass", "k_lm_cost_multi", "k_nn_certify", "k_nn_bounded", "k_nn_rows"), key=lambda k: kernels[k]["summed_ms_per_iter"] or 0.0)
+    traffic, traffic_src = load_traffic({"k_lm_pass": "k_lm_pass<1>"}.get(dom, dom)) if (world == 1 and n_points == 50_000_000) else (None, None)
     ach = kernels[dom]["GBs"] or 0.0
     out = {
         "metric": "ICP correspondences/sec", "value": corr / dt, "unit": "correspondences/s",

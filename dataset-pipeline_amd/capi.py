@@ -32,7 +32,11 @@ class IterRecord(C.Structure):
                 ("correspondences", C.c_int64), ("queries", C.c_int64),
                 ("initial_cost", C.c_double), ("final_cost", C.c_double),
                 ("t_transform_ms", C.c_double), ("t_nn_ms", C.c_double), ("t_lm_ms", C.c_double),
-                ("t_lm_kernel_ms", C.c_double), ("t_nn_query_ms", C.c_double)]
+                ("t_lm_kernel_ms", C.c_double), ("t_nn_query_ms", C.c_double), ("t_lm_full_kernel_ms", C.c_double),
+                ("t_nn_certify_ms", C.c_double), ("t_nn_bounded_ms", C.c_double), ("t_nn_search_ms", C.c_double),
+                ("nn_certify_queries", C.c_int64), ("nn_bounded_queries", C.c_int64), ("nn_search_queries", C.c_int64),
+                ("nn_certify_launches", C.c_int32), ("nn_bounded_launches", C.c_int32), ("nn_search_launches", C.c_int32),
+                ("reserved2_", C.c_int32)]
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_size_t, C.c_void_p)

@@ -129,7 +129,7 @@ struct e3d_icp {
   DevBuf<int> d_block_set;
   DevBuf<double> d_partial, d_setsum;
   PinBuf<double> h_setsum;
-  std::unique_ptr<EventTimer> lm_timer, nn_timer;
+  std::unique_ptr<EventTimer> lm_timer, nn_timer, nn_timer_c;
 
   std::map<std::pair<int, int>, std::unique_ptr<PairState>> pair_state;
   PinBuf<unsigned> h_todo;
@@ -472,12 +472,17 @@ static void find_pair(e3d_icp* h, Cloud& src, Cloud& tgt, float d, PairJob& job,
       h->h_todo.reserve(2);
       h->todo_near.reserve(n); h->todo_far.reserve(n);
       E3D_HIP(hipMemsetAsync(ps.todo_count.p, 0, 2 * sizeof(unsigned), s));
-      h->nn_timer->start(s);
+      if (!h->nn_timer_c) h->nn_timer_c.reset(new EventTimer());
+      h->nn_timer_c->start(s);
       launch_nn_certify(srcG, n, tgt.G4.p, cum_up, radius_sq(d), near2, ps.match.p, ps.match2.p, ps.lbe.p, h->match_d2.p, h->todo_near.p, h->todo_far.p,
                         ps.todo_count.p, s);
+      h->nn_timer_c->stop(s);
       copy_out(h->h_todo.p, ps.todo_count.p, 2 * sizeof(unsigned), s);
       sync(h);
+      { const double t = h->nn_timer_c->ms(); rec.t_nn_certify_ms += t; rec.t_nn_query_ms += t; }
+      rec.nn_certify_launches++; rec.nn_certify_queries += (long long)n;
       n_near = h->h_todo.p[0]; n_far = h->h_todo.p[1];
+      h->nn_timer->start(s);
       list = h->todo_far.p;
       // old partner close by: only the cells its distance (+ margin) reaches, one thread per query, no sort
       double smin = min_singular_value_3x3(tgt.T);
@@ -489,6 +494,7 @@ static void find_pair(e3d_icp* h, Cloud& src, Cloud& tgt, float d, PairJob& job,
       bp.rho_scale = round_up_f((1.0 + 1e-5) / smin);
       bp.rho_pad = round_up_f(2.0 * tgt.build_slack + 8.0 * FLT_EPSILON * m_local);
       bp.cum_lo = cert.cum_lo;
+      bp.cell_scale = cert.cell_scale; bp.cell_sub = cert.cell_sub;
       launch_nn_bounded(srcG, h->todo_near.p, n_near, tgt.G4.p, tgt.dense_start.p, tgt.grid, im, tgt.qrange, radius_sq(d), bp, ps.match.p,
                         ps.match2.p, h->match_d2.p, ps.lbe.p, s);
       if (n_far > 0 && n_far * 32 < n) {
@@ -499,6 +505,7 @@ static void find_pair(e3d_icp* h, Cloud& src, Cloud& tgt, float d, PairJob& job,
         n_near += n_far; n_far = 0;
       }
       h->nn_timer->stop(s);
+      if (n_near > 0) { rec.nn_bounded_launches++; rec.nn_bounded_queries += (long long)n_near; }
       t_cert = -1.f;        // read after the next synchronisation
     }
     float t_first = 0.f;
@@ -508,7 +515,8 @@ static void find_pair(e3d_icp* h, Cloud& src, Cloud& tgt, float d, PairJob& job,
     if (n_far > 0)
       launch_rows(3, tgt, srcG, h->vals_b.p, n_far, im, radius_sq(d), cert, ps.match.p, h->match_d2.p, ps.lbe.p, ps.match2.p, s);
     ps.fresh = false;
-    rec.t_nn_query_ms += t_first;
+    rec.t_nn_query_ms += t_first; rec.t_nn_bounded_ms += t_first;
+    if (n_far > 0) { rec.nn_search_launches++; rec.nn_search_queries += (long long)n_far; }
     if (want_stats)
       fprintf(stderr, "[nn %d->%d] queries %zu bounded %zu rows %zu certify+bounded %.3f ms cum %.3g (last %.3g) err %.3g\n", job.src, job.tgt, n,
               n_near, n_far, (double)t_first, cum_pair, src.last_motion + tgt.last_motion, src.err_max + tgt.err_max);
@@ -528,9 +536,11 @@ static void find_pair(e3d_icp* h, Cloud& src, Cloud& tgt, float d, PairJob& job,
                       h->match_pos.p, h->match_d2.p, s);
     }
     order = source_order ? nullptr : h->vals_b.p;
+    rec.nn_search_launches++; rec.nn_search_queries += (long long)n;
   } else {
     h->match_pos.reserve(n);
     match_pos = h->match_pos.p;
+    rec.nn_search_launches++; rec.nn_search_queries += (long long)n;
     h->nn_timer->start(s);
     launch_nn_query(srcG, n, tgt.G4.p, tgt.table.p, tgt.grid, make_invmap(tgt), radius_sq(d), h->match_pos.p,
                     h->match_d2.p, s);
@@ -543,7 +553,7 @@ static void find_pair(e3d_icp* h, Cloud& src, Cloud& tgt, float d, PairJob& job,
   copy_out(h->h_total.p, h->d_total.p, sizeof(unsigned long long), s);
   copy_out(h->h_total_d2.p, h->d_total_d2.p, sizeof(double), s);
   sync(h);
-  rec.t_nn_query_ms += h->nn_timer->ms();
+  { const double t = h->nn_timer->ms(); rec.t_nn_query_ms += t; rec.t_nn_search_ms += t; }
   job.count = (long long)h->h_total.p[0];
   job.dsum = h->h_total_d2.p[0];
   if (job.count == 0) return;
@@ -641,7 +651,7 @@ static void lm_evaluate(e3d_icp* h, LmSystem& L, const std::vector<SE3f>& poses,
     launch_lm_reduce(h->d_partial.p, h->d_sets.p, ns, kLmSlot, h->d_setsum.p, s);
     reduce_setsums(h, ns);      // every rank holds the same sets (lm_prepare), so the per-set blocks add up across the ranks
     rec.t_lm_kernel_ms += tm.ms();
-    if (full) rec.full_passes++; else rec.cost_passes++;
+    if (full) { rec.full_passes++; rec.t_lm_full_kernel_ms += tm.ms(); } else rec.cost_passes++;
     // scatter the per-set systems into H, b  (Accumulate, icp_point_to_plane_impl.h:82-113)
     for (int i = 0; i < ns; ++i) {
       const double* r = h->h_setsum.p + (size_t)kLmSlot * i;

@@ -1158,10 +1158,30 @@ __global__ __launch_bounds__(kBlock) void k_nn_bounded(const float4* __restrict_
   const int x0 = max(cell_coord(lx - rho, g.origin[0], g.inv_cell) - qr.lo[0], 0), x1 = min(cell_coord(lx + rho, g.origin[0], g.inv_cell) - qr.lo[0], (int)qr.D[0] - 1);
   const int y0 = max(cell_coord(ly - rho, g.origin[1], g.inv_cell) - qr.lo[1], 0), y1 = min(cell_coord(ly + rho, g.origin[1], g.inv_cell) - qr.lo[1], (int)qr.D[1] - 1);
   const int z0 = max(cell_coord(lz - rho, g.origin[2], g.inv_cell) - qr.lo[2], 0), z1 = min(cell_coord(lz + rho, g.origin[2], g.inv_cell) - qr.lo[2], (int)qr.D[2] - 1);
-  // fast pass: the two smallest distances with a strict '<', the third smallest value for the certificate; any exact f32
-  // equality with one of the two (i.e. also with r2) raises `tie`
   const float kInf = __uint_as_float(0x7f800000u);
-  float bd = r2, bd2 = r2, b3 = kInf;
+  // What the scanned box really covers: every target point outside it is at least `fd` cells away from the query in the target's
+  // local frame (faces at the edge of the dense grid do not count: no point lies beyond them), i.e. at global distance >=
+  // fd * cell_scale - cell_sub.  Usually more than sqrt(cover2) -- and for a query WITHOUT a partner the only way to a
+  // certificate that outlives the next pose update ("nothing within more than the radius").
+  float cover_box2 = 0.f;
+  if (x0 <= x1 && y0 <= y1 && z0 <= z1) {
+    const float ux = (lx - g.origin[0]) * g.inv_cell - (float)qr.lo[0], uy = (ly - g.origin[1]) * g.inv_cell - (float)qr.lo[1],
+                uz = (lz - g.origin[2]) * g.inv_cell - (float)qr.lo[2];
+    float fd = kInf;
+    if (x0 > 0) fd = fminf(fd, ux - (float)x0);
+    if (x1 < (int)qr.D[0] - 1) fd = fminf(fd, (float)(x1 + 1) - ux);
+    if (y0 > 0) fd = fminf(fd, uy - (float)y0);
+    if (y1 < (int)qr.D[1] - 1) fd = fminf(fd, (float)(y1 + 1) - uy);
+    if (z0 > 0) fd = fminf(fd, uz - (float)z0);
+    if (z1 < (int)qr.D[2] - 1) fd = fminf(fd, (float)(z1 + 1) - uz);
+    fd = fminf(fd, 4.0f);                                   // (a box that spans the whole grid: keep the bound finite)
+    const float cb = fd * bp.cell_scale - bp.cell_sub;
+    cover_box2 = cb > 0.f ? cb * cb : 0.f;
+  }
+  const float cover_all2 = fmaxf(cover2, cover_box2);
+  // fast pass over ALL scanned candidates (inside the radius or not): the two smallest distances with a strict '<' and the third
+  // smallest value; any exact f32 equality with one of the two raises `tie`.  The radius test comes at the end.
+  float bd = kInf, bd2 = kInf, b3 = kInf;
   int bpos = -1, bpos2 = -1;
   bool tie = false;
   if (x0 <= x1) {
@@ -1185,7 +1205,7 @@ __global__ __launch_bounds__(kBlock) void k_nn_bounded(const float4* __restrict_
   }
   if (tie) {
     // rare (lattices, duplicates): the same cells again with the full (d2, original index) order
-    bd = r2; bd2 = r2; b3 = kInf; bpos = -1; bpos2 = -1;
+    bd = kInf; bd2 = kInf; b3 = kInf; bpos = -1; bpos2 = -1;
     unsigned boi = 0u, boi2 = 0u;
     for (int cz = z0; cz <= z1; ++cz) {
       for (int cy = y0; cy <= y1; ++cy) {
@@ -1206,12 +1226,14 @@ __global__ __launch_bounds__(kBlock) void k_nn_bounded(const float4* __restrict_
       }
     }
   }
-  match[j] = bpos;
-  match2[j] = (bd2 < r2) ? bpos2 : -1;
-  match_d2[j] = bd;
-  // everything but the (up to) two remembered candidates is farther than min(third smallest d2 seen, cover2); without a
-  // runner-up inside the radius the bound of "everything but the partner" is min(second smallest, cover2)
-  lbe[j] = sqrtf(fminf((bd2 < r2) ? b3 : fminf(bd2, b3), cover2)) * 0.999999f + bp.cum_lo;
+  const bool has1 = bd < r2, has2 = bd2 < r2;            // NaN distances compare false: no partner
+  match[j] = has1 ? bpos : -1;
+  match2[j] = has2 ? bpos2 : -1;
+  match_d2[j] = has1 ? bd : r2;
+  // everything but the remembered candidates is at least this far: the third smallest distance (two remembered), the second
+  // (partner only), the smallest (no partner within the radius) -- and nothing is known beyond what the scanned box covers
+  const float others2 = has2 ? b3 : (has1 ? bd2 : bd);
+  lbe[j] = sqrtf(fminf(others2, cover_all2)) * 0.999999f + bp.cum_lo;
 }
 
 // flags -> per-block counts (first stage of the order-preserving compaction)

@@ -84,6 +84,7 @@ struct BoundParams {
   float rho_scale;       // (1 + 1e-5) / sigma_min(target pose), rounded up
   float rho_pad;         // absolute slack of the global -> local mapping (local units), rounded up
   float cum_lo;          // accumulated motion bound of the pair at this outer iteration, rounded down
+  float cell_scale, cell_sub;   // as in CertParams: covered global distance = (distance to the scanned box's faces in cells) * cell_scale - cell_sub
 };
 void launch_nn_bounded(const float4* Gsrc, const unsigned* list, size_t n_list, const float4* Gtgt, const unsigned* dense_start,
                        const GridDesc& g, const InvMap& im, const QueryRange& qr, float r2, const BoundParams& bp, int* match,

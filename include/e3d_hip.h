@@ -104,6 +104,12 @@ typedef struct {
   double  t_transform_ms, t_nn_ms, t_lm_ms;   /* HIP-event times on the handle's stream   */
   double  t_lm_kernel_ms;    /* sum of LM pass kernel durations (HIP events)               */
   double  t_nn_query_ms;     /* sum of NN query kernel durations (HIP events)              */
+  double  t_lm_full_kernel_ms; /* ... of the fused H/b/cost passes alone (k_lm_pass<1..3>)   */
+  double  t_nn_certify_ms;   /* k_nn_certify launches (HIP events)                         */
+  double  t_nn_bounded_ms;   /* k_nn_bounded launches                                      */
+  double  t_nn_search_ms;    /* k_nn_rows / k_nn_cells / k_nn_query / k_nn_mfma launches   */
+  int64_t nn_certify_queries, nn_bounded_queries, nn_search_queries;   /* queries those launches covered */
+  int32_t nn_certify_launches, nn_bounded_launches, nn_search_launches, reserved2_;
 } e3d_icp_iter_record;
 
 size_t e3d_icp_num_pair_records(const e3d_icp_t* icp);

@@ -6,9 +6,9 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r2prof
 mkdir -p $O
-STAGES=${@:-trace icp reg normals sq}
+STAGES=${@:-trace terrace icp reg normals sq}
 SUM="python $R/tools/rocpd_summary.py"
-ICP="python $R/bench.py --no-cpu-baseline --no-reg --no-normals --no-allpairs --steps 3 --warmup 2"
+ICP="python $R/bench.py --no-cpu-baseline --no-reg --no-normals --no-allpairs"
 REG="python $R/tools/bench_c4.py --images 2 --accumulate-only"
 pmc() {  # pmc <tag> <counters...> -- <command>
   local tag=$1; shift
@@ -26,6 +26,12 @@ for st in $STAGES; do
       echo "[trace] rc=$?"
       $SUM /tmp/r2p_trace/b_results.db $O/bench_kernel_stats.txt "" > /dev/null 2>&1
       head -25 $O/bench_kernel_stats.txt | cut -c1-60,150-230 ;;
+    terrace)   # the headline leg alone: its kernel averages are the ones bench.py's live HIP-event figures must agree with
+      rm -rf /tmp/r2p_terrace
+      timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/r2p_terrace -o b -- python $R/bench.py --no-cpu-baseline --no-reg --no-normals --no-allpairs > $O/terrace_traced.json 2> /dev/null
+      echo "[terrace] rc=$?"
+      $SUM /tmp/r2p_terrace/b_results.db $O/terrace_kernel_stats.txt e3d > /dev/null 2>&1
+      head -12 $O/terrace_kernel_stats.txt | cut -c1-60,150-230 ;;
     icp)
       pmc icp_fetch FETCH_SIZE -- $ICP
       pmc icp_write WRITE_SIZE -- $ICP ;;

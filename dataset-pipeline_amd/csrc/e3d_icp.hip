@@ -344,23 +344,30 @@ static PairState& pair_state_for(e3d_icp* h, int src_id, int tgt_id, const Cloud
   return ps;
 }
 
-// bound of how far any point of a cloud moves when its pose changes from T0 to T1 (global frame): ||dL||_2 R + ||dt||
+// bound of how far any point of a cloud moves when its pose changes from T0 to T1 (global frame): with c the centre of the cloud's
+// local bounding box and R its half diagonal, dL p + dt = dL (p - c) + (dL c + dt), so |.| <= ||dL||_2 R + |dL c + dt| -- the
+// second term is what the centre really moves (a rotation about the cloud's middle costs only the first)
 static double pose_motion_bound(const Cloud& c, const float* T0, const float* T1) {
   float dT[12];
-  double dt = 0, R2 = 0;
+  double ctr[3], R2 = 0;
   for (int r = 0; r < 3; ++r) {
     for (int k = 0; k < 3; ++k) dT[4 * r + k] = (float)((double)T1[4 * r + k] - (double)T0[4 * r + k]);
     dT[4 * r + 3] = 0.f;
-    const double e = (double)T1[4 * r + 3] - (double)T0[4 * r + 3];
-    dt += e * e;
-    const double m = std::max(std::fabs((double)c.lmin[r]), std::fabs((double)c.lmax[r]));
-    R2 += m * m;
+    ctr[r] = 0.5 * ((double)c.lmin[r] + (double)c.lmax[r]);
+    const double hw = 0.5 * ((double)c.lmax[r] - (double)c.lmin[r]);
+    R2 += hw * hw;
+  }
+  double dc2 = 0;
+  for (int r = 0; r < 3; ++r) {
+    double e = (double)T1[4 * r + 3] - (double)T0[4 * r + 3];
+    for (int k = 0; k < 3; ++k) e += ((double)T1[4 * r + k] - (double)T0[4 * r + k]) * ctr[k];
+    dc2 += e * e;
   }
   double fro = 0;
   for (int r = 0; r < 3; ++r) for (int k = 0; k < 3; ++k) fro += (double)dT[4 * r + k] * (double)dT[4 * r + k];
   double smax = max_singular_value_3x3(dT) * (1.0 + 1e-6) + 1e-12 * std::sqrt(fro);
   if (!(smax <= std::sqrt(fro))) smax = std::sqrt(fro);      // Frobenius norm bounds the spectral norm (also the NaN fallback)
-  return smax * std::sqrt(R2) + std::sqrt(dt);
+  return (smax * std::sqrt(R2) + std::sqrt(dc2)) * (1.0 + 1e-9);
 }
 // bound of the f32 rounding error (Euclidean) of one evaluation of pcl_se3(T, p) for a point of the cloud: three products and
 // three sums per component, |error| <= 4 u (|L_row| |p| + |t_r|) with u = 2^-24 (5 u taken)

@@ -9,6 +9,16 @@
 //   kFov              camera::FisheyeFOVCamera            src/camera/camera_fisheye_fov.h:44-176 (Devernay-Faugeras)      I = 5
 //                     q[0] = omega; q[1] = two_tan_omega_half_, q[2] = image_radius_ (derived in camera_fisheye_fov.cc:37-51,
 //                     not parameters); closed-form Undistort, no cut-off, no lookup table
+//   kSimplePinhole    camera::SimplePinholeCamera         src/camera/camera_simple_pinhole.h:41-88    [f cx cy]          I = 3
+//   kSimpleRadial     camera::SimpleRadialCamera          src/camera/camera_simple_radial.h:43-110 (RadialBase) [f cx cy k]   I = 4
+//   kRadial           camera::RadialCamera                src/camera/camera_radial.h:43-123 (RadialBase) [f cx cy k1 k2]      I = 5
+//   kPolynomial3      camera::PolynomialCamera            src/camera/camera_polynomial.h:43-127 (RadialBase) [fx fy cx cy k1 k2 k3]  I = 7
+//   kFisheyePolyTang  camera::FisheyePolynomialTangentialCamera  src/camera/camera_fisheye_polynomial_tangential.h =
+//                     FisheyeBase over PolynomialTangentialCamera (the kOpenCV polynomial)                          I = 8
+//   The models with ONE focal length (UniqueFocalLength(), camera_base_impl.h:65-67) keep fx = fy = f in CamLevel; their
+//   parameter vector, and with it the column order of the intrinsics Jacobian, is [f, cx, cy, distortion...] (:394-407).
+//   The COLMAP names RADIAL_FISHEYE / SIMPLE_RADIAL_FISHEYE construct RadialCamera / SimpleRadialCamera in the reference's
+//   factory (camera_base.cc:73-74) [QUIRK]: they are aliases of kRadial / kSimpleRadial here.
 //
 // Shared CRTP base, src/camera/camera_base_impl.h: NormalizedToImage :155-164, IterativeUndistort :216-250,
 // UndistortFromInside :278-328, ImageDerivativeByWorld :333-360, ImageDerivativeByIntrinsics :369-408, InitCutoff :410-463.
@@ -23,12 +33,20 @@
 
 namespace e3d {
 
-enum : int { kPinhole = 0, kOpenCV = 1, kThinPrismFisheye = 2, kOpenCVFisheye = 3, kFov = 4 };
+enum : int { kPinhole = 0, kOpenCV = 1, kThinPrismFisheye = 2, kOpenCVFisheye = 3, kFov = 4, kSimplePinhole = 5, kSimpleRadial = 6,
+             kRadial = 7, kPolynomial3 = 8, kFisheyePolyTang = 9, kNumCameraModels = 10 };
 
 __host__ __device__ constexpr int cam_param_count(int model) {
-  return model == kPinhole ? 4 : (model == kFov ? 5 : ((model == kOpenCV || model == kOpenCVFisheye) ? 8 : 12));
+  return model == kPinhole ? 4 : model == kFov ? 5 : (model == kOpenCV || model == kOpenCVFisheye || model == kFisheyePolyTang) ? 8 :
+         model == kSimplePinhole ? 3 : model == kSimpleRadial ? 4 : model == kRadial ? 5 : model == kPolynomial3 ? 7 : 12;
 }
-__host__ __device__ constexpr bool cam_is_fisheye(int model) { return model == kThinPrismFisheye || model == kOpenCVFisheye; }
+__host__ __device__ constexpr bool cam_is_fisheye(int model) { return model == kThinPrismFisheye || model == kOpenCVFisheye || model == kFisheyePolyTang; }
+__host__ __device__ constexpr bool cam_unique_focal(int model) { return model == kSimplePinhole || model == kSimpleRadial || model == kRadial; }
+__host__ __device__ constexpr int cam_distortion_count(int model) { return cam_param_count(model) - (cam_unique_focal(model) ? 3 : 4); }
+// the polynomial inside is PolynomialTangentialCamera's (k1 k2 p1 p2)
+__host__ __device__ constexpr bool cam_is_poly_tang(int model) { return model == kOpenCV || model == kFisheyePolyTang; }
+// RadialBase children: Distort = point * DistortionFactor(squaredNorm)
+__host__ __device__ constexpr bool cam_is_radial(int model) { return model == kSimpleRadial || model == kRadial || model == kPolynomial3; }
 
 struct CamLevel {
   int model;
@@ -45,8 +63,15 @@ struct CamLevel {
 // ---- polynomial part --------------------------------------------------------------------------------------------------------
 template <int M>
 __device__ __forceinline__ void cam_distort_plain(const CamLevel& c, float nx, float ny, float& ox, float& oy) {
-  if constexpr (M == kPinhole) {
+  if constexpr (M == kPinhole || M == kSimplePinhole) {
     ox = nx; oy = ny;
+  } else if constexpr (cam_is_radial(M)) {         // RadialBase::Distort (camera_base_impl_radial.h:52-56) with the child's DistortionFactor
+    const float r2 = nx * nx + ny * ny;
+    float f;
+    if constexpr (M == kSimpleRadial) f = 1.0f + r2 * c.q[0];                                   // camera_simple_radial.h:60-62
+    else if constexpr (M == kRadial) f = 1.0f + r2 * (c.q[0] + r2 * c.q[1]);                    // camera_radial.h:60-65
+    else f = 1.0f + r2 * (c.q[0] + r2 * (c.q[1] + r2 * c.q[2]));                                // camera_polynomial.h:58-64
+    ox = nx * f; oy = ny * f;
   } else if constexpr (M == kFov) {                // camera_fisheye_fov.h:55-63
     const float r = sqrtf(nx * nx + ny * ny);
     const float factor = (r < 1e-6f) ? 1.f : (e3d_atanf(r * c.q[1]) / (r * c.q[0]));
@@ -59,7 +84,7 @@ __device__ __forceinline__ void cam_distort_plain(const CamLevel& c, float nx, f
     const float x2 = nx * nx, xy = nx * ny, y2 = ny * ny;
     const float r2 = x2 + y2;
     const float k1 = c.q[0], k2 = c.q[1], p1 = c.q[2], p2 = c.q[3];
-    if constexpr (M == kOpenCV) {
+    if constexpr (cam_is_poly_tang(M)) {
       const float radial = 1 + r2 * (k1 + r2 * k2);
       const float dx = 2.f * p1 * xy + p2 * (r2 + 2.f * x2);
       const float dy = 2.f * p2 * xy + p1 * (r2 + 2.f * y2);
@@ -77,8 +102,33 @@ __device__ __forceinline__ void cam_distort_plain(const CamLevel& c, float nx, f
 // DistortedDerivativeByNormalized, J = [J0 J1; J2 J3]
 template <int M>
 __device__ __forceinline__ void cam_ddn_plain(const CamLevel& c, float nx, float ny, float* J) {
-  if constexpr (M == kPinhole) {
+  if constexpr (M == kPinhole || M == kSimplePinhole) {
     J[0] = 1.f; J[1] = 0.f; J[2] = 0.f; J[3] = 1.f;
+  } else if constexpr (M == kSimpleRadial) {       // camera_simple_radial.h:75-88
+    const float k1 = c.q[0];
+    const float nxs = nx * nx, nys = ny * ny;
+    const float ru2 = nxs + nys;
+    J[0] = k1 * (ru2 + 2 * nxs) + 1;
+    J[1] = 2 * nx * ny * k1;
+    J[2] = J[1];
+    J[3] = k1 * (ru2 + 2 * nys) + 1;
+  } else if constexpr (M == kRadial || M == kPolynomial3) {     // camera_radial.h:82-101, camera_polynomial.h:81-101
+    const float nx2 = nx * nx, ny2 = ny * ny, nxny = nx * ny;
+    const float r2 = nx2 + ny2;
+    float term1, term2;
+    if constexpr (M == kRadial) {
+      const float k1 = c.q[0], k2 = c.q[1];
+      term1 = 2 * k1 + r2 * (4 * k2);
+      term2 = 1 + r2 * (k1 + r2 * (k2));
+    } else {
+      const float k1 = c.q[0], k2 = c.q[1], k3 = c.q[2];
+      term1 = 2 * k1 + r2 * (4 * k2 + r2 * 6 * k3);
+      term2 = 1 + r2 * (k1 + r2 * (k2 + r2 * k3));
+    }
+    J[0] = nx2 * term1 + term2;
+    J[1] = nxny * term1;
+    J[2] = J[1];
+    J[3] = ny2 * term1 + term2;
   } else if constexpr (M == kFov) {                // camera_fisheye_fov.h:131-160
     const float omega = c.q[0], tt = c.q[1];
     const float nx_times_ny = nx * ny, nxs = nx * nx, nys = ny * ny;
@@ -108,7 +158,7 @@ __device__ __forceinline__ void cam_ddn_plain(const CamLevel& c, float nx, float
     const float nx2 = nx * nx, ny2 = ny * ny;
     const float r2 = nx2 + ny2;
     const float k1 = c.q[0], k2 = c.q[1], p1 = c.q[2], p2 = c.q[3];
-    if constexpr (M == kOpenCV) {
+    if constexpr (cam_is_poly_tang(M)) {
       const float term1 = 2 * k1 + r2 * 4 * k2;
       const float term2 = 1 + r2 * (k1 + r2 * k2);
       J[0] = nx2 * term1 + term2 + 6 * p2 * nx + 2 * p1 * ny;
@@ -147,7 +197,12 @@ __device__ __forceinline__ void cam_ddp_plain(const CamLevel& c, float nx, float
     const float rs = nx * nx + ny * ny;
     d0[0] = nx * rs; d0[1] = d0[0] * rs; d0[2] = d0[1] * rs; d0[3] = d0[2] * rs;
     d1[0] = ny * rs; d1[1] = d1[0] * rs; d1[2] = d1[1] * rs; d1[3] = d1[2] * rs;
-  } else if constexpr (M != kPinhole) {
+  } else if constexpr (cam_is_radial(M)) {         // camera_simple_radial.h:67-72, camera_radial.h:70-79, camera_polynomial.h:69-79
+    const float rs = nx * nx + ny * ny;
+    d0[0] = nx * rs; d1[0] = ny * rs;
+    if constexpr (M != kSimpleRadial) { d0[1] = d0[0] * rs; d1[1] = d1[0] * rs; }
+    if constexpr (M == kPolynomial3) { d0[2] = d0[1] * rs; d1[2] = d1[1] * rs; }
+  } else if constexpr (M != kPinhole && M != kSimplePinhole) {
     const float nx2 = nx * nx, ny2 = ny * ny;
     const float two_nx_ny = 2.f * nx * ny;
     const float r2 = nx2 + ny2;
@@ -218,7 +273,7 @@ __device__ __forceinline__ void cam_ddp(const CamLevel& c, float nx, float ny, f
       const float atan_r = e3d_atan2f(r, 1.f);
       if (atan_r * atan_r > c.inner_cutoff2) {
 #pragma unroll
-        for (int i = 0; i < cam_param_count(M) - 4; ++i) { d0[i] = 0.f; d1[i] = 0.f; }
+        for (int i = 0; i < cam_distortion_count(M); ++i) { d0[i] = 0.f; d1[i] = 0.f; }
         return;
       }
       const float theta_by_r = atan_r / r;
@@ -271,12 +326,22 @@ __device__ __forceinline__ void cam_image_deriv_by_intrinsics(const CamLevel& c,
   }
   float dx, dy;
   cam_distort<M>(c, nx, ny, dx, dy);
-  d[0] = dx; d[1] = 0.f; d[2] = 1.f; d[3] = 0.f;
-  d[I + 0] = 0.f; d[I + 1] = dy; d[I + 2] = 0.f; d[I + 3] = 1.f;
-  if constexpr (I > 4) {
-    cam_ddp<M>(c, nx, ny, d + 4, d + I + 4);
+  if constexpr (!cam_unique_focal(M)) {
+    d[0] = dx; d[1] = 0.f; d[2] = 1.f; d[3] = 0.f;
+    d[I + 0] = 0.f; d[I + 1] = dy; d[I + 2] = 0.f; d[I + 3] = 1.f;
+    if constexpr (I > 4) {
+      cam_ddp<M>(c, nx, ny, d + 4, d + I + 4);
 #pragma unroll
-    for (int i = 4; i < I; ++i) { d[i] = c.fx * d[i]; d[I + i] = c.fy * d[I + i]; }
+      for (int i = 4; i < I; ++i) { d[i] = c.fx * d[i]; d[I + i] = c.fy * d[I + i]; }
+    }
+  } else {                                        // [f, cx, cy, distortion...] (camera_base_impl.h:394-407)
+    d[0] = dx; d[1] = 1.f; d[2] = 0.f;
+    d[I + 0] = dy; d[I + 1] = 0.f; d[I + 2] = 1.f;
+    if constexpr (I > 3) {
+      cam_ddp<M>(c, nx, ny, d + 3, d + I + 3);
+#pragma unroll
+      for (int i = 3; i < I; ++i) { d[i] = c.fx * d[i]; d[I + i] = c.fy * d[I + i]; }
+    }
   }
 }
 

@@ -286,7 +286,23 @@ __global__ __launch_bounds__(kBlock) void k_mesh_vertices(const float4* __restri
   float X, Y, Z;
   rt(P, p.x, p.y, p.z, X, Y, Z);
   float lx = X, ly = Y;
-  if constexpr (M != kPinhole) {
+  if constexpr (M == kSimpleRadial) {
+    // SimpleRadial shader (renderer.cc:402-413): its own r2 expression, 99 outside the cut-off
+    float r2 = (X * X + Y * Y) / (Z * Z);
+    if (r2 > cam.cutoff2) r2 = 99.0f; else r2 = 1.0f + r2 * cam.q[0];
+    lx = r2 * X; ly = r2 * Y;
+  } else if constexpr (M == kRadial || M == kPolynomial3) {
+    // Radial / Polynomial shaders (renderer.cc:326-337, 288-300)
+    const float nx = X / Z, ny = Y / Z;
+    float r2 = nx * nx + ny * ny;
+    if (r2 <= cam.cutoff2) {
+      if constexpr (M == kRadial) r2 = 1.0f + r2 * (cam.q[0] + r2 * cam.q[1]);
+      else r2 = 1.0f + r2 * (cam.q[0] + r2 * (cam.q[1] + r2 * cam.q[2]));
+    } else {
+      r2 = 99.0f;
+    }
+    lx = r2 * X; ly = r2 * Y;
+  } else if constexpr (M != kPinhole && M != kSimplePinhole) {
     float nx = X / Z, ny = Y / Z;
     float r2 = nx * nx + ny * ny;
     if constexpr (M == kFov) {
@@ -306,14 +322,14 @@ __global__ __launch_bounds__(kBlock) void k_mesh_vertices(const float4* __restri
       }
       lx = Z * r2 * nx; ly = Z * r2 * ny;
     } else if (r2 <= cam.cutoff2) {
-      if constexpr (M == kThinPrismFisheye) {
+      if constexpr (cam_is_fisheye(M)) {           // THIN_PRISM_FISHEYE, FISHEYE_POLYNOMIAL_2_TANGENTIAL_2 (renderer.cc:236-258)
         const float r = sqrtf(r2);
         if (r > 1e-6f) { const float theta_by_r = e3d_atan2f(r, 1.0f) / r; nx = theta_by_r * nx; ny = theta_by_r * ny; }
       }
       const float x2 = nx * nx, xy = nx * ny, y2 = ny * ny;
       r2 = x2 + y2;
       const float k1 = cam.q[0], k2 = cam.q[1], p1 = cam.q[2], p2 = cam.q[3];
-      if constexpr (M == kOpenCV) {
+      if constexpr (cam_is_poly_tang(M)) {
         const float radial = 1.0f + r2 * (k1 + r2 * k2);
         lx = Z * (radial * nx + 2.0f * p1 * xy + p2 * (r2 + 2.0f * x2));
         ly = Z * (radial * ny + 2.0f * p2 * xy + p1 * (r2 + 2.0f * y2));
@@ -630,7 +646,7 @@ __global__ __launch_bounds__(kBlock) void k_undistort_lookup(CamLevel c, float2*
   const int x = (int)(i % c.width), y = (int)(i / c.width);
   const float dx = c.fx_inv * x + c.cx_inv, dy = c.fy_inv * y + c.cy_inv;
   float ux, uy;
-  if constexpr (M == kPinhole) { ux = dx; uy = dy; }
+  if constexpr (M == kPinhole || M == kSimplePinhole) { ux = dx; uy = dy; }
   else if constexpr (M == kFov) { cam_fov_undistort(c, dx, dy, ux, uy); }
   else {
     cam_iterative_undistort<M>(c, dx, dy, dx, dy, ux, uy);
@@ -704,6 +720,8 @@ __global__ __launch_bounds__(kBlock) void k_point_radius(const float4* __restric
   float2 nxy;
   if constexpr (M == kFov) {      // FisheyeFOVCamera's own ImageToNormalized: Undistort(ImageToDistorted(p)) (camera_fisheye_fov.h:65-74)
     cam_fov_undistort(cam_min, cam_min.fx_inv * offx + cam_min.cx_inv, cam_min.fy_inv * my + cam_min.cy_inv, nxy.x, nxy.y);
+  } else if constexpr (M == kPinhole || M == kSimplePinhole) {   // their own ImageToNormalized: ImageToDistorted (camera_pinhole.h:55-63)
+    nxy = make_float2(cam_min.fx_inv * offx + cam_min.cx_inv, cam_min.fy_inv * my + cam_min.cy_inv);
   } else {
     nxy = image_to_normalized(cam_min, lookup_min, offx, my);
   }
@@ -1553,6 +1571,11 @@ static void allreduce_device(e3d_reg* h, void* dev, size_t n, int dtype) {
     case kThinPrismFisheye: { constexpr int M = kThinPrismFisheye; stmt; } break;          \
     case kOpenCVFisheye: { constexpr int M = kOpenCVFisheye; stmt; } break;                \
     case kFov: { constexpr int M = kFov; stmt; } break;                                    \
+    case kSimplePinhole: { constexpr int M = kSimplePinhole; stmt; } break;                \
+    case kSimpleRadial: { constexpr int M = kSimpleRadial; stmt; } break;                  \
+    case kRadial: { constexpr int M = kRadial; stmt; } break;                              \
+    case kPolynomial3: { constexpr int M = kPolynomial3; stmt; } break;                    \
+    case kFisheyePolyTang: { constexpr int M = kFisheyePolyTang; stmt; } break;            \
     default: throw Error(E3D_ERR_INVALID, "unknown camera model");                         \
   }
 
@@ -1561,8 +1584,19 @@ static void allreduce_device(e3d_reg* h, void* dev, size_t n, int dtype) {
 // f64 mix (the start radius is `float + float * double / float`).
 static float radial_init_cutoff(const CamLevel& c) {
   const float* q = c.q;
-  auto factor = [&](float r2) { return 1.0f + r2 * (q[0] + r2 * (q[1] + r2 * (q[2] + r2 * q[3]))); };
-  auto dfactor = [&](float r2) { return 1.0f + r2 * (3.0f * q[0] + r2 * (5.0f * q[1] + r2 * (7.0f * q[2] + r2 * (9.0f * q[3])))); };
+  const int model = c.model;
+  // DistortionFactor(r2) / DistortedDerivativeByNormalized(r2) of the RadialBase child, in its own expression order
+  // (camera_polynomial_4.h:55-61,100-110; camera_radial.h:60-65,103-107; camera_polynomial.h:58-64,103-107)
+  auto factor = [&](float r2) {
+    if (model == kRadial) return 1.0f + r2 * (q[0] + r2 * q[1]);
+    if (model == kPolynomial3) return 1.0f + r2 * (q[0] + r2 * (q[1] + r2 * q[2]));
+    return 1.0f + r2 * (q[0] + r2 * (q[1] + r2 * (q[2] + r2 * q[3])));
+  };
+  auto dfactor = [&](float r2) {
+    if (model == kRadial) return 1.f + r2 * (3.f * q[0] + r2 * 5.f * q[1]);
+    if (model == kPolynomial3) return 1.0f + r2 * (3.0f * q[0] + r2 * (5.0f * q[1] + r2 * 7.0f * q[2]));
+    return 1.0f + r2 * (3.0f * q[0] + r2 * (5.0f * q[1] + r2 * (7.0f * q[2] + r2 * (9.0f * q[3]))));
+  };
   float test_r = 0.f;
   for (int k = 0; k < 4; ++k) {
     const float px = (k & 2) ? (float)c.width : 0.f, py = (k & 1) ? (float)c.height : 0.f;
@@ -1600,13 +1634,24 @@ static float radial_init_cutoff(const CamLevel& c) {
 // for the distorted models, InitCutoff -- run on the device (k_cam_cutoff), 2(W+H) border points in parallel.
 static CamLevel make_level(e3d_reg* h, int model, int w, int h_px, const float* p) {
   CamLevel c{};
-  c.model = model; c.width = w; c.height = h_px; c.fx = p[0]; c.fy = p[1]; c.cx = p[2]; c.cy = p[3];
-  for (int i = 0; i < cam_param_count(model) - 4; ++i) c.q[i] = p[4 + i];
+  c.model = model; c.width = w; c.height = h_px;
+  if (cam_unique_focal(model)) {                    // [f cx cy ...]: the class is constructed with fx = fy = f (camera_radial.cc:43-46)
+    c.fx = p[0]; c.fy = p[0]; c.cx = p[1]; c.cy = p[2];
+    for (int i = 0; i < cam_distortion_count(model); ++i) c.q[i] = p[3 + i];
+  } else {
+    c.fx = p[0]; c.fy = p[1]; c.cx = p[2]; c.cy = p[3];
+    for (int i = 0; i < cam_distortion_count(model); ++i) c.q[i] = p[4 + i];
+  }
   c.fx_inv = (float)(1.0 / (double)c.fx); c.fy_inv = (float)(1.0 / (double)c.fy);
   c.cx_inv = (float)(-1.0 * (double)c.cx / (double)c.fx); c.cy_inv = (float)(-1.0 * (double)c.cy / (double)c.fy);
   c.cutoff2 = INFINITY; c.inner_cutoff2 = INFINITY;
-  if (model == kPinhole) return c;                  // PinholeCamera never calls InitCutoff (camera_pinhole.cc:35-43)
+  if (model == kPinhole || model == kSimplePinhole) return c;   // no InitCutoff (camera_pinhole.cc:35-43, camera_simple_pinhole.cc:36-41)
   if (model == kOpenCVFisheye) { c.inner_cutoff2 = radial_init_cutoff(c); return c; }
+  if (model == kRadial || model == kPolynomial3) { c.cutoff2 = radial_init_cutoff(c); return c; }   // RadialBase::InitCutoff on the camera itself
+  if (model == kSimpleRadial) {                     // camera_simple_radial.cc:51-57: where d(distorted r)/dr = 0
+    if (c.q[0] < 0) c.cutoff2 = -1.f / (3 * c.q[0]);
+    return c;
+  }
   if (model == kFov) {                              // camera_fisheye_fov.cc:37-51: derived constants, no InitCutoff
     c.q[1] = 2.0f * e3d_tanf(0.5f * c.q[0]);
     c.q[2] = (float)(M_PI / (double)(2 * c.q[0]));
@@ -1617,7 +1662,7 @@ static CamLevel make_level(e3d_reg* h, int model, int w, int h_px, const float* 
   copy_in(h->cut.p, init, sizeof init, h->stream);
   const int total = 2 * w + 2 * h_px;
   const unsigned cut_blocks = (unsigned)div_up((size_t)total, kBlock / kWave);      // one wave per border test point
-  if (model == kOpenCV) hipLaunchKernelGGL(k_cam_cutoff<kOpenCV>, dim3(cut_blocks), dim3(kBlock), 0, h->stream, c, h->cut.p);
+  if (cam_is_poly_tang(model)) hipLaunchKernelGGL(k_cam_cutoff<kOpenCV>, dim3(cut_blocks), dim3(kBlock), 0, h->stream, c, h->cut.p);   // (the inner PolynomialTangentialCamera of kFisheyePolyTang)
   else hipLaunchKernelGGL(k_cam_cutoff<kThinPrismFisheye>, dim3(cut_blocks), dim3(kBlock), 0, h->stream, c, h->cut.p);   // inner ThinPrismCamera
   unsigned out[2];
   copy_out(out, h->cut.p, sizeof out, h->stream);
@@ -1638,8 +1683,9 @@ static void build_model_pyramid(e3d_reg* h, Intrin& in, int n_levels) {
     const CamLevel& p = in.levels.back();
     const float f = 0.5f;
     float q[12];
-    for (int i = 4; i < in.n_params; ++i) q[i] = in.params[i];
-    q[0] = p.fx * f; q[1] = p.fy * f; q[2] = f * (p.cx + 0.5f) - 0.5f; q[3] = f * (p.cy + 0.5f) - 0.5f;
+    for (int i = 0; i < in.n_params; ++i) q[i] = in.params[i];
+    if (cam_unique_focal(in.type)) { q[0] = p.fx * f; q[1] = f * (p.cx + 0.5f) - 0.5f; q[2] = f * (p.cy + 0.5f) - 0.5f; }
+    else { q[0] = p.fx * f; q[1] = p.fy * f; q[2] = f * (p.cx + 0.5f) - 0.5f; q[3] = f * (p.cy + 0.5f) - 0.5f; }
     in.levels.push_back(make_level(h, in.type, (int)(f * p.width + 0.5f), (int)(f * p.height + 0.5f), q));
   }
 }
@@ -1840,9 +1886,8 @@ int e3d_reg_set_intrinsics(e3d_reg_t* h, int intrinsics_id, int camera_type, int
                            int n_parameters, int min_image_scale, int n_levels) {
   R_TRYH
   if (!h || !parameters) throw Error(E3D_ERR_INVALID, "null argument");
-  if (camera_type != E3D_CAMERA_PINHOLE && camera_type != E3D_CAMERA_OPENCV && camera_type != E3D_CAMERA_THIN_PRISM_FISHEYE &&
-      camera_type != E3D_CAMERA_OPENCV_FISHEYE && camera_type != E3D_CAMERA_FOV)
-    throw Error(E3D_ERR_INVALID, "camera model must be PINHOLE, OPENCV, THIN_PRISM_FISHEYE, OPENCV_FISHEYE or FOV");
+  if (camera_type < 0 || camera_type >= kNumCameraModels)
+    throw Error(E3D_ERR_INVALID, "unknown camera model (E3D_CAMERA_* of e3d_hip.h)");
   if (n_parameters != cam_param_count(camera_type)) throw Error(E3D_ERR_INVALID, fmt("camera model %d takes %d parameters, got %d", camera_type, cam_param_count(camera_type), n_parameters));
   if (n_levels < 1 || n_levels > kRegMaxLevels || width < 2 || height < 2 || min_image_scale < 0) throw Error(E3D_ERR_INVALID, "bad pyramid description");
   Intrin in;
@@ -1865,8 +1910,13 @@ int e3d_reg_get_intrinsics_level(e3d_reg_t* h, int intrinsics_id, int level, int
   if (width) *width = c.width;
   if (height) *height = c.height;
   if (parameters) {
-    parameters[0] = c.fx; parameters[1] = c.fy; parameters[2] = c.cx; parameters[3] = c.cy;
-    for (int i = 4; i < it->second.n_params; ++i) parameters[i] = c.q[i - 4];
+    if (cam_unique_focal(c.model)) {
+      parameters[0] = c.fx; parameters[1] = c.cx; parameters[2] = c.cy;
+      for (int i = 3; i < it->second.n_params; ++i) parameters[i] = c.q[i - 3];
+    } else {
+      parameters[0] = c.fx; parameters[1] = c.fy; parameters[2] = c.cx; parameters[3] = c.cy;
+      for (int i = 4; i < it->second.n_params; ++i) parameters[i] = c.q[i - 4];
+    }
   }
   if (cutoff2) *cutoff2 = cam_is_fisheye(c.model) ? c.inner_cutoff2 : c.cutoff2;
   return 0;
@@ -2325,6 +2375,9 @@ int e3d_reg_accumulate(e3d_reg_t* h, int image_id, int point_scale, double* H, d
     switch (V) {
       case 10: E3D_PASS2M(10); break;
       case 11: E3D_PASS2M(11); break;
+      case 13: E3D_PASS2M(13); break;
+      case 15: E3D_PASS2M(15); break;
+      case 19: E3D_PASS2M(19); break;
       case 14: E3D_PASS2M(14); break;
       case 16: E3D_PASS2M(16); break;
       case 17: E3D_PASS2M(17); break;
@@ -2339,7 +2392,11 @@ int e3d_reg_accumulate(e3d_reg_t* h, int image_id, int point_scale, double* H, d
   hipLaunchKernelGGL((k_reg_pass2<8, V_, R0_, R1_, B_>), dim3(nb), dim3(kBlock), 0, s, O.rows.p, O.idx.p, O.flags.p, O.n, O.nrow.p, \
                      h->prm.point_neighbor_count, S.fixed_desc.p, S.var_desc.p, S.obs_counts.p, w, h->partial.p)
   switch (V) {     // E3D_REG_PASS2=valu: per-thread accumulators; row ranges chosen so that every launch keeps <= 75 of them
+    case 9: E3D_PASS2(9, 0, 9, true); break;
     case 10: E3D_PASS2(10, 0, 10, true); break;
+    case 13: E3D_PASS2(13, 0, 4, true); E3D_PASS2(13, 4, 13, false); break;
+    case 15: E3D_PASS2(15, 0, 3, true); E3D_PASS2(15, 3, 8, false); E3D_PASS2(15, 8, 15, false); break;
+    case 19: E3D_PASS2(19, 0, 2, true); E3D_PASS2(19, 2, 6, false); E3D_PASS2(19, 6, 11, false); E3D_PASS2(19, 11, 19, false); break;
     case 11: E3D_PASS2(11, 0, 5, true); E3D_PASS2(11, 5, 11, false); break;
     case 14: E3D_PASS2(14, 0, 4, true); E3D_PASS2(14, 4, 14, false); break;
     case 16: E3D_PASS2(16, 0, 3, true); E3D_PASS2(16, 3, 8, false); E3D_PASS2(16, 8, 16, false); break;

@@ -246,10 +246,27 @@ inline int camera_model_from_name(const std::string& name) {
   if (name == "THIN_PRISM_FISHEYE") return E3D_CAMERA_THIN_PRISM_FISHEYE;
   if (name == "OPENCV_FISHEYE") return E3D_CAMERA_OPENCV_FISHEYE;
   if (name == "FOV") return E3D_CAMERA_FOV;
+  if (name == "SIMPLE_PINHOLE") return E3D_CAMERA_SIMPLE_PINHOLE;
+  if (name == "POLYNOMIAL_3") return E3D_CAMERA_POLYNOMIAL_3;
+  if (name == "FISHEYE_POLYNOMIAL_2_TANGENTIAL_2") return E3D_CAMERA_FISHEYE_POLYNOMIAL_2_TANGENTIAL_2;
+  // [QUIRK] camera_base.cc:73-74: the factory entries of RADIAL_FISHEYE / SIMPLE_RADIAL_FISHEYE construct RadialCamera /
+  // SimpleRadialCamera, whose constructors set the types kRadial / kSimpleRadial -- the fisheye names behave like the plain ones
+  // and are written back as RADIAL / SIMPLE_RADIAL (camera_model_name below)
+  if (name == "RADIAL" || name == "RADIAL_FISHEYE") return E3D_CAMERA_RADIAL;
+  if (name == "SIMPLE_RADIAL" || name == "SIMPLE_RADIAL_FISHEYE") return E3D_CAMERA_SIMPLE_RADIAL;
   return -1;
 }
+inline const char* camera_model_name(int model) {
+  static const char* const names[] = {"PINHOLE", "OPENCV", "THIN_PRISM_FISHEYE", "OPENCV_FISHEYE", "FOV", "SIMPLE_PINHOLE", "SIMPLE_RADIAL",
+                                      "RADIAL", "POLYNOMIAL_3", "FISHEYE_POLYNOMIAL_2_TANGENTIAL_2"};
+  return (model >= 0 && model < 10) ? names[model] : "INVALID";
+}
+inline bool camera_unique_focal(int model) {
+  return model == E3D_CAMERA_SIMPLE_PINHOLE || model == E3D_CAMERA_SIMPLE_RADIAL || model == E3D_CAMERA_RADIAL;
+}
 inline int camera_param_count(int model) {
-  return model == E3D_CAMERA_PINHOLE ? 4 : (model == E3D_CAMERA_FOV ? 5 : ((model == E3D_CAMERA_OPENCV || model == E3D_CAMERA_OPENCV_FISHEYE) ? 8 : 12));
+  static const int counts[] = {4, 8, 12, 8, 5, 3, 4, 5, 7, 8};
+  return (model >= 0 && model < 10) ? counts[model] : 0;
 }
 
 class Problem {
@@ -310,13 +327,16 @@ class Problem {
       HostIntrinsics in;
       in.intrinsics_id = (int)intrinsics_list.size();
       in.model = camera_model_from_name(c.model_name);
-      in.model_name = c.model_name;
-      if (in.model < 0) return fail("Camera model " + c.model_name + " is not built on the HIP path (PINHOLE, OPENCV, OPENCV_FISHEYE, FOV, THIN_PRISM_FISHEYE are)");
+      if (in.model < 0) return fail("Unknown camera model " + c.model_name);
+      in.model_name = camera_model_name(in.model);
       in.n_params = camera_param_count(in.model);
       if ((int)c.parameters.size() != in.n_params) return fail("Wrong parameter count for camera model " + c.model_name);
       in.width = c.width; in.height = c.height;
       for (int i = 0; i < in.n_params; ++i) in.params[i] = (float)c.parameters[i];
-      in.params[2] += -0.5f; in.params[3] += -0.5f;              // ShiftedBy(-0.5, -0.5): COLMAP's pixel-corner origin -> pixel centre
+      // ShiftedBy(-0.5, -0.5): COLMAP's pixel-corner origin -> pixel centre; cx cy are parameters 1, 2 of the models with one
+      // focal length (camera_base_impl.h:93-106)
+      const int ci = camera_unique_focal(in.model) ? 1 : 2;
+      in.params[ci] += -0.5f; in.params[ci + 1] += -0.5f;
       camera_to_intrinsics[c.camera_id] = in.intrinsics_id;
       intrinsics_list.push_back(in);
     }
@@ -962,7 +982,8 @@ class Problem {
       cf << i << " " << in.model_name << " " << in.width << " " << in.height;
       for (int p = 0; p < in.n_params; ++p) {
         float v = in.params[p];
-        if (p == 2 || p == 3) v += 0.5f;                          // ShiftedBy(0.5, 0.5)
+        const int ci = camera_unique_focal(in.model) ? 1 : 2;
+        if (p == ci || p == ci + 1) v += 0.5f;                    // ShiftedBy(0.5, 0.5)
         cf << " " << v;
       }
       cf << std::endl;

@@ -235,12 +235,21 @@ typedef struct {
 /* camera models (COLMAP names, src/camera/camera_base.cc:66-77) and their parameter counts:
  * PINHOLE fx fy cx cy (camera_pinhole.h:40-86); OPENCV + k1 k2 p1 p2 (camera_polynomial_tangential.h:41-159);
  * THIN_PRISM_FISHEYE + k1 k2 p1 p2 k3 k4 sx1 sy1 (camera_benchmark.h:44-52); OPENCV_FISHEYE + k1 k2 k3 k4
- * (camera_fisheye_polynomial_4.h:42-50 over camera_polynomial_4.h:43-135); FOV + omega (camera_fisheye_fov.h:44-176) */
+ * (camera_fisheye_polynomial_4.h:42-50 over camera_polynomial_4.h:43-135); FOV + omega (camera_fisheye_fov.h:44-176);
+ * SIMPLE_PINHOLE f cx cy (camera_simple_pinhole.h:41-88); SIMPLE_RADIAL f cx cy k (camera_simple_radial.h:43-110); RADIAL f cx cy k1 k2
+ * (camera_radial.h:43-123); POLYNOMIAL_3 fx fy cx cy k1 k2 k3 (camera_polynomial.h:43-127); FISHEYE_POLYNOMIAL_2_TANGENTIAL_2 fx fy cx cy
+ * k1 k2 p1 p2 (camera_fisheye_polynomial_tangential.h).  Parameter vectors, Jacobian columns and e3d_reg_get_intrinsics_level follow the
+ * class's GetParameters order. */
 #define E3D_CAMERA_PINHOLE 0             /* I = 4  */
 #define E3D_CAMERA_OPENCV 1              /* I = 8  */
 #define E3D_CAMERA_THIN_PRISM_FISHEYE 2  /* I = 12 */
 #define E3D_CAMERA_OPENCV_FISHEYE 3      /* I = 8  */
 #define E3D_CAMERA_FOV 4                 /* I = 5  */
+#define E3D_CAMERA_SIMPLE_PINHOLE 5      /* I = 3: f cx cy                  (one focal length: parameter order as in COLMAP) */
+#define E3D_CAMERA_SIMPLE_RADIAL 6       /* I = 4: f cx cy k                (also the name SIMPLE_RADIAL_FISHEYE, camera_base.cc:74) */
+#define E3D_CAMERA_RADIAL 7              /* I = 5: f cx cy k1 k2            (also the name RADIAL_FISHEYE, camera_base.cc:73) */
+#define E3D_CAMERA_POLYNOMIAL_3 8        /* I = 7: fx fy cx cy k1 k2 k3 */
+#define E3D_CAMERA_FISHEYE_POLYNOMIAL_2_TANGENTIAL_2 9   /* I = 8: fx fy cx cy k1 k2 p1 p2 */
 
 e3d_reg_t* e3d_reg_create(const e3d_reg_params* params);
 void e3d_reg_destroy(e3d_reg_t* reg);

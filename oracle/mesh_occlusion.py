@@ -41,7 +41,21 @@ def project_vertices(model, cam, R, t, verts, shaded=False):
     Y = (R[1, 0] * v[:, 0] + (R[1, 1] * v[:, 1] + R[1, 2] * v[:, 2])) + t[1]
     Z = (R[2, 0] * v[:, 0] + (R[2, 1] * v[:, 1] + R[2, 2] * v[:, 2])) + t[2]
     lx, ly = X.copy(), Y.copy()
-    if model != 0:
+    if model in (6, 7, 8):
+        # SimpleRadial / Radial / Polynomial shaders (renderer.cc:402-413, 326-337, 288-300): the radial factor (99 outside the cut-off)
+        # times the camera-space x, y.  SimpleRadial has its own r2 expression.
+        with np.errstate(all="ignore"):
+            q = [F(cam.p[4 + i]) for i in range(3)]
+            if model == 6:
+                r2 = ((X * X + Y * Y) / (Z * Z)).astype(F)
+                fac = np.where(r2 > F(cam.cutoff2), F(99.0), F(1.0) + r2 * q[0]).astype(F)
+            else:
+                nx, ny = X / Z, Y / Z
+                r2 = (nx * nx + ny * ny).astype(F)
+                poly = F(1.0) + r2 * (q[0] + r2 * q[1]) if model == 7 else F(1.0) + r2 * (q[0] + r2 * (q[1] + r2 * q[2]))
+                fac = np.where(r2 <= F(cam.cutoff2), poly, F(99.0)).astype(F)
+            lx = (fac * X).astype(F); ly = (fac * Y).astype(F)
+    elif model not in (0, 5):
         with np.errstate(all="ignore"):
             nx, ny = X / Z, Y / Z
             r2 = nx * nx + ny * ny
@@ -65,7 +79,7 @@ def project_vertices(model, cam, R, t, verts, shaded=False):
                 lx = ((Z * fac) * fx_).astype(F); ly = ((Z * fac) * fy_).astype(F)
                 px = F(cam.p[0]) * (lx / Z) + F(cam.p[2]); py = F(cam.p[1]) * (ly / Z) + F(cam.p[3])
                 return (px.astype(F), py.astype(F), Z.astype(F)) + ((lx.astype(F), ly.astype(F)) if shaded else ())
-            if model == 2:
+            if model in (2, 9):          # THIN_PRISM_FISHEYE, FISHEYE_POLYNOMIAL_2_TANGENTIAL_2 (renderer.cc:236-258)
                 r = np.sqrt(r2)
                 th = np.where(r > F(1e-6), _atan2f_1(r.astype(F)) / r, F(1.0)).astype(F)
                 nx = np.where(r > F(1e-6), th * nx, nx); ny = np.where(r > F(1e-6), th * ny, ny)
@@ -73,7 +87,7 @@ def project_vertices(model, cam, R, t, verts, shaded=False):
             r2 = x2 + y2
             q = [F(cam.p[4 + i]) for i in range(cam.n_params - 4)]
             k1, k2, p1, p2 = q[:4]
-            if model == 1:
+            if model in (1, 9):
                 radial = F(1.0) + r2 * (k1 + r2 * k2)
                 dx = Z * (radial * nx + F(2.0) * p1 * xy + p2 * (r2 + F(2.0) * x2))
                 dy = Z * (radial * ny + F(2.0) * p2 * xy + p1 * (r2 + F(2.0) * y2))

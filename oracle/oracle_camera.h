@@ -35,13 +35,34 @@
 /* 0 PINHOLE, 1 OPENCV, 2 THIN_PRISM_FISHEYE, 3 OPENCV_FISHEYE = FisheyeBase over Polynomial4Camera (camera_fisheye_polynomial_4.h,
  * camera_polynomial_4.h:43-135: radial factor 1 + r2 (k1 + r2 (k2 + r2 (k3 + r2 k4)))), 4 FOV = FisheyeFOVCamera
  * (camera_fisheye_fov.h:44-176; p[4] = omega, and -- derived, not parameters -- p[5] = two_tan_omega_half_, p[6] = image_radius_) */
-static inline int ocam_param_count(int type) { return type == 0 ? 4 : (type == 4 ? 5 : ((type == 1 || type == 3) ? 8 : 12)); }
-static inline int ocam_is_fisheye(int type) { return type == 2 || type == 3; }
+/* 5 SIMPLE_PINHOLE (camera_simple_pinhole.h:41-88), 6 SIMPLE_RADIAL (camera_simple_radial.h:43-110), 7 RADIAL (camera_radial.h:43-123),
+ * 8 POLYNOMIAL_3 = PolynomialCamera (camera_polynomial.h:43-127), 9 FISHEYE_POLYNOMIAL_2_TANGENTIAL_2 = FisheyeBase over
+ * PolynomialTangentialCamera (camera_fisheye_polynomial_tangential.h).  5-7 have ONE focal length: parameter vector [f cx cy ...]
+ * (UniqueFocalLength, camera_base_impl.h:65-67,394-407); INSIDE oreg_camera every model is stored as p = [fx fy cx cy q...] with
+ * fx = fy = f for those (the classes are constructed that way, camera_radial.cc:43-46), n_params is the model's own count.
+ * The names RADIAL_FISHEYE / SIMPLE_RADIAL_FISHEYE create types 7 / 6 (camera_base.cc:73-74 [QUIRK]). */
+static inline int ocam_param_count(int type) {
+  static const int counts[10] = {4, 8, 12, 8, 5, 3, 4, 5, 7, 8};
+  return (type >= 0 && type < 10) ? counts[type] : 0;
+}
+static inline int ocam_is_fisheye(int type) { return type == 2 || type == 3 || type == 9; }
+static inline int ocam_unique_focal(int type) { return type == 5 || type == 6 || type == 7; }
+static inline int ocam_distortion_count(int type) { return ocam_param_count(type) - (ocam_unique_focal(type) ? 3 : 4); }
+static inline int ocam_is_poly_tang(int type) { return type == 1 || type == 9; }
 
 /* ---- the polynomial models' Distort on a point already past the (optional) fisheye pre-warp --------------------------- */
 static inline void ocam_distort_plain(const oreg_camera* c, float nx, float ny, float* ox, float* oy) {
-  if (c->type == 0) { *ox = nx; *oy = ny; return; }
+  if (c->type == 0 || c->type == 5) { *ox = nx; *oy = ny; return; }
   const float* q = c->p + 4;
+  if (c->type == 6 || c->type == 7 || c->type == 8) {   /* RadialBase::Distort (camera_base_impl_radial.h:52-56) */
+    const float r2 = nx * nx + ny * ny;
+    float f;
+    if (c->type == 6) f = 1.0f + r2 * q[0];                                   /* camera_simple_radial.h:60-62 */
+    else if (c->type == 7) f = 1.0f + r2 * (q[0] + r2 * q[1]);                /* camera_radial.h:60-65 */
+    else f = 1.0f + r2 * (q[0] + r2 * (q[1] + r2 * q[2]));                    /* camera_polynomial.h:58-64 */
+    *ox = nx * f; *oy = ny * f;
+    return;
+  }
   if (c->type == 4) {                       /* camera_fisheye_fov.h:55-63 */
     const float r = sqrtf(nx * nx + ny * ny);
     const float factor = (r < 1e-6f) ? 1.f : (e3d_atanf(r * q[1]) / (r * q[0]));
@@ -55,7 +76,7 @@ static inline void ocam_distort_plain(const oreg_camera* c, float nx, float ny, 
     *ox = nx * f; *oy = ny * f;
     return;
   }
-  if (c->type == 1) {
+  if (ocam_is_poly_tang(c->type)) {
     const float k1 = q[0], k2 = q[1], p1 = q[2], p2 = q[3];
     const float radial = 1 + r2 * (k1 + r2 * k2);
     const float dx = 2.f * p1 * xy + p2 * (r2 + 2.f * x2);
@@ -72,8 +93,37 @@ static inline void ocam_distort_plain(const oreg_camera* c, float nx, float ny, 
 
 /* DistortedDerivativeByNormalized of the polynomial part: J = [j0 j1; j2 j3] */
 static inline void ocam_ddn_plain(const oreg_camera* c, float nx, float ny, float* J) {
-  if (c->type == 0) { J[0] = 1.f; J[1] = 0.f; J[2] = 0.f; J[3] = 1.f; return; }
+  if (c->type == 0 || c->type == 5) { J[0] = 1.f; J[1] = 0.f; J[2] = 0.f; J[3] = 1.f; return; }
   const float* q = c->p + 4;
+  if (c->type == 6) {                       /* camera_simple_radial.h:75-88 */
+    const float k1 = q[0];
+    const float nxs = nx * nx, nys = ny * ny;
+    const float ru2 = nxs + nys;
+    J[0] = k1 * (ru2 + 2 * nxs) + 1;
+    J[1] = 2 * nx * ny * k1;
+    J[2] = J[1];
+    J[3] = k1 * (ru2 + 2 * nys) + 1;
+    return;
+  }
+  if (c->type == 7 || c->type == 8) {       /* camera_radial.h:82-101, camera_polynomial.h:81-101 */
+    const float nx2 = nx * nx, ny2 = ny * ny, nxny = nx * ny;
+    const float r2 = nx2 + ny2;
+    float term1, term2;
+    if (c->type == 7) {
+      const float k1 = q[0], k2 = q[1];
+      term1 = 2 * k1 + r2 * (4 * k2);
+      term2 = 1 + r2 * (k1 + r2 * (k2));
+    } else {
+      const float k1 = q[0], k2 = q[1], k3 = q[2];
+      term1 = 2 * k1 + r2 * (4 * k2 + r2 * 6 * k3);
+      term2 = 1 + r2 * (k1 + r2 * (k2 + r2 * k3));
+    }
+    J[0] = nx2 * term1 + term2;
+    J[1] = nxny * term1;
+    J[2] = J[1];
+    J[3] = ny2 * term1 + term2;
+    return;
+  }
   if (c->type == 4) {                       /* camera_fisheye_fov.h:131-160 */
     const float omega = q[0], tt = q[1];
     const float nx_times_ny = nx * ny, nxs = nx * nx, nys = ny * ny;
@@ -104,7 +154,7 @@ static inline void ocam_ddn_plain(const oreg_camera* c, float nx, float ny, floa
     J[3] = ny2 * term1 + term2;
     return;
   }
-  if (c->type == 1) {
+  if (ocam_is_poly_tang(c->type)) {
     const float k1 = q[0], k2 = q[1], p1 = q[2], p2 = q[3];
     const float term1 = 2 * k1 + r2 * 4 * k2;
     const float term2 = 1 + r2 * (k1 + r2 * k2);
@@ -127,7 +177,14 @@ static inline void ocam_ddn_plain(const oreg_camera* c, float nx, float ny, floa
 
 /* DistortedDerivativeByDistortionParameters of the polynomial part: 2 x (I-4), row-major with row stride `ld` */
 static inline void ocam_ddp_plain(const oreg_camera* c, float nx, float ny, float* d0, float* d1) {
-  if (c->type == 0) return;
+  if (c->type == 0 || c->type == 5) return;
+  if (c->type == 6 || c->type == 7 || c->type == 8) {   /* camera_simple_radial.h:67-72, camera_radial.h:70-79, camera_polynomial.h:69-79 */
+    const float rs = nx * nx + ny * ny;
+    d0[0] = nx * rs; d1[0] = ny * rs;
+    if (c->type != 6) { d0[1] = d0[0] * rs; d1[1] = d1[0] * rs; }
+    if (c->type == 8) { d0[2] = d0[1] * rs; d1[2] = d1[1] * rs; }
+    return;
+  }
   if (c->type == 4) {                       /* camera_fisheye_fov.h:94-118 */
     const float omega = c->p[4], tt = c->p[5];
     const float radius_square = nx * nx + ny * ny;
@@ -247,11 +304,20 @@ static inline void cam_image_deriv_by_intrinsics(const oreg_camera* c, const flo
   if (nx * nx + ny * ny > c->cutoff2) { for (int i = 0; i < 2 * I; ++i) d[i] = 0.f; return; }
   float dx, dy;
   ocam_distort(c, nx, ny, &dx, &dy);
-  d[0] = dx; d[1] = 0.f; d[2] = 1.f; d[3] = 0.f;
-  d[I + 0] = 0.f; d[I + 1] = dy; d[I + 2] = 0.f; d[I + 3] = 1.f;
-  if (I > 4) {
-    ocam_ddp(c, nx, ny, d + 4, d + I + 4);
-    for (int i = 4; i < I; ++i) { d[i] = c->p[0] * d[i]; d[I + i] = c->p[1] * d[I + i]; }
+  if (!ocam_unique_focal(c->type)) {
+    d[0] = dx; d[1] = 0.f; d[2] = 1.f; d[3] = 0.f;
+    d[I + 0] = 0.f; d[I + 1] = dy; d[I + 2] = 0.f; d[I + 3] = 1.f;
+    if (I > 4) {
+      ocam_ddp(c, nx, ny, d + 4, d + I + 4);
+      for (int i = 4; i < I; ++i) { d[i] = c->p[0] * d[i]; d[I + i] = c->p[1] * d[I + i]; }
+    }
+  } else {                                  /* [f, cx, cy, distortion...] (camera_base_impl.h:394-407) */
+    d[0] = dx; d[1] = 1.f; d[2] = 0.f;
+    d[I + 0] = dy; d[I + 1] = 0.f; d[I + 2] = 1.f;
+    if (I > 3) {
+      ocam_ddp(c, nx, ny, d + 3, d + I + 3);
+      for (int i = 3; i < I; ++i) { d[i] = c->p[0] * d[i]; d[I + i] = c->p[1] * d[I + i]; }
+    }
   }
 }
 
@@ -345,9 +411,16 @@ static inline void ocam_fov_undistort(const oreg_camera* c, float dx, float dy, 
 
 /* RadialBase (camera_base_impl_radial.h): 1-D Gauss-Newton on the radius (:59-88), UndistortFromInside over 10 start radii
  * (:104-140), InitCutoff from the farthest image corner (:142-170).  `q` = k1..k4 of Polynomial4Camera. */
-static inline float ocam_radial_factor(const float* q, float r2) { return 1.0f + r2 * (q[0] + r2 * (q[1] + r2 * (q[2] + r2 * q[3]))); }
-static inline float ocam_radial_dfactor(const float* q, float r2) {      /* DistortedDerivativeByNormalized(r2), camera_polynomial_4.h:100-110 */
-  return 1.0f + r2 * (3.0f * q[0] + r2 * (5.0f * q[1] + r2 * (7.0f * q[2] + r2 * (9.0f * q[3]))));
+static int ocam_radial_type_;   /* the RadialBase child whose DistortionFactor is meant: 3 (Polynomial4), 7 (Radial), 8 (Polynomial) */
+static inline float ocam_radial_factor(const float* q, float r2) {
+  if (ocam_radial_type_ == 7) return 1.0f + r2 * (q[0] + r2 * q[1]);                              /* camera_radial.h:60-65 */
+  if (ocam_radial_type_ == 8) return 1.0f + r2 * (q[0] + r2 * (q[1] + r2 * q[2]));                /* camera_polynomial.h:58-64 */
+  return 1.0f + r2 * (q[0] + r2 * (q[1] + r2 * (q[2] + r2 * q[3])));
+}
+static inline float ocam_radial_dfactor(const float* q, float r2) {      /* DistortedDerivativeByNormalized(r2) of the child, literal expression order */
+  if (ocam_radial_type_ == 7) return 1.f + r2 * (3.f * q[0] + r2 * 5.f * q[1]);                   /* camera_radial.h:103-107 */
+  if (ocam_radial_type_ == 8) return 1.0f + r2 * (3.0f * q[0] + r2 * (5.0f * q[1] + r2 * 7.0f * q[2]));   /* camera_polynomial.h:103-107 */
+  return 1.0f + r2 * (3.0f * q[0] + r2 * (5.0f * q[1] + r2 * (7.0f * q[2] + r2 * (9.0f * q[3]))));      /* camera_polynomial_4.h:100-110 */
 }
 static inline float ocam_radial_iterative_undistort(const float* q, float distorted_r, float starting_r, int* converged) {
   *converged = 0;
@@ -365,6 +438,7 @@ static inline float ocam_radial_iterative_undistort(const float* q, float distor
 }
 static inline float ocam_radial_init_cutoff(const oreg_camera* c) {
   const float* q = c->p + 4;
+  ocam_radial_type_ = c->type;
   /* ImageToDistorted of the four corners (0,0) (0,H) (W,0) (W,H): k_inv applied, Eigen norm = sqrt(x*x + y*y) */
   float test_r = 0.f;
   for (int k = 0; k < 4; ++k) {
@@ -402,7 +476,12 @@ static inline float ocam_radial_init_cutoff(const oreg_camera* c) {
 static inline void ocam_init(oreg_camera* c, int type, int w, int h, const float* params) {
   memset(c, 0, sizeof *c);
   c->type = type; c->width = w; c->height = h; c->n_params = ocam_param_count(type);
-  for (int i = 0; i < c->n_params; ++i) c->p[i] = params[i];
+  if (ocam_unique_focal(type)) {            /* [f cx cy q...] -> fx = fy = f (camera_simple_radial.cc:44-49) */
+    c->p[0] = params[0]; c->p[1] = params[0]; c->p[2] = params[1]; c->p[3] = params[2];
+    for (int i = 3; i < c->n_params; ++i) c->p[i + 1] = params[i];
+  } else {
+    for (int i = 0; i < c->n_params; ++i) c->p[i] = params[i];
+  }
   /* CameraBase (camera_base.cc:81-86): k_inv_ = (1.0/fx, 1.0/fy, -1.0*cx/fx, -1.0*cy/fy), double expressions -> float */
   c->fx_inv = (float)(1.0 / (double)c->p[0]); c->fy_inv = (float)(1.0 / (double)c->p[1]);
   c->cx_inv = (float)(-1.0 * (double)c->p[2] / (double)c->p[0]); c->cy_inv = (float)(-1.0 * (double)c->p[3] / (double)c->p[1]);
@@ -415,6 +494,15 @@ static inline void ocam_init(oreg_camera* c, int type, int w, int h, const float
     c->inner_cutoff2 = ocam_init_cutoff(&inner);
   } else if (type == 3) {
     c->inner_cutoff2 = ocam_radial_init_cutoff(c);              /* the inner Polynomial4Camera (its constructor calls InitCutoff) */
+  } else if (type == 7 || type == 8) {
+    c->cutoff2 = ocam_radial_init_cutoff(c);                    /* RadialBase::InitCutoff in the constructor (camera_radial.cc:40, camera_polynomial.cc:40) */
+  } else if (type == 6) {
+    if (c->p[4] < 0) c->cutoff2 = -1.f / (3 * c->p[4]);         /* SimpleRadialCamera::InitCutoff (camera_simple_radial.cc:51-57) */
+  } else if (type == 9) {
+    /* the inner PolynomialTangentialCamera: the general InitCutoff of a camera with the same parameters */
+    oreg_camera inner = *c;
+    inner.type = 1; inner.cutoff2 = INFINITY;
+    c->inner_cutoff2 = ocam_init_cutoff(&inner);
   } else if (type == 4) {
     /* camera_fisheye_fov.cc:37-51: two_tan_omega_half_(2.0f * tan(0.5f * omega_)), image_radius_(M_PI / (2 * omega_)); no cut-off.
      * with g++/libstdc++ <math.h> puts std::tan(float) / std::atan(float) into the global namespace (checked here with a

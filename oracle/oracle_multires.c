@@ -40,6 +40,10 @@ void oracle_image_to_normalized(const oreg_camera* c, const float* lookup, float
     oracle_reg_camera_undistort(c, c->fx_inv * px + c->cx_inv, c->fy_inv * py + c->cy_inv, out, NULL);
     return;
   }
+  if (c->type == 0 || c->type == 5) {     /* PinholeCamera / SimplePinholeCamera: ImageToDistorted, no table, no clamp (camera_pinhole.h:55-63, camera_simple_pinhole.h:66-74) */
+    out[0] = c->fx_inv * px + c->cx_inv; out[1] = c->fy_inv * py + c->cy_inv;
+    return;
+  }
   float cx = px < c->width - 1.001f ? px : c->width - 1.001f;
   float cy = py < c->height - 1.00f ? py : c->height - 1.00f;
   if (!(cx > 0.f)) cx = 0.f;      /* cwiseMax(0) */

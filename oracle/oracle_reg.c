@@ -40,9 +40,15 @@ void oracle_reg_camera_init(oreg_camera* c, int type, int w, int h, const float*
 /* CameraBaseImpl::ScaledBy (camera_base_impl.h:70-89): constructs a new camera => re-runs InitCutoff */
 void oracle_reg_camera_scaled(const oreg_camera* in, float factor, oreg_camera* out) {
   float p[12];
-  for (int i = 0; i < in->n_params; ++i) p[i] = in->p[i];
-  p[0] = in->p[0] * factor; p[1] = in->p[1] * factor;
-  p[2] = factor * (in->p[2] + 0.5f) - 0.5f; p[3] = factor * (in->p[3] + 0.5f) - 0.5f;
+  if (ocam_unique_focal(in->type)) {       /* GetParameters: [f cx cy q...]; parameters[0] *= factor, [1], [2] the centre (:82-86) */
+    p[0] = in->p[0] * factor;
+    p[1] = factor * (in->p[2] + 0.5f) - 0.5f; p[2] = factor * (in->p[3] + 0.5f) - 0.5f;
+    for (int i = 3; i < in->n_params; ++i) p[i] = in->p[i + 1];
+  } else {
+    for (int i = 0; i < in->n_params; ++i) p[i] = in->p[i];
+    p[0] = in->p[0] * factor; p[1] = in->p[1] * factor;
+    p[2] = factor * (in->p[2] + 0.5f) - 0.5f; p[3] = factor * (in->p[3] + 0.5f) - 0.5f;
+  }
   ocam_init(out, in->type, (int)(factor * in->width + 0.5f), (int)(factor * in->height + 0.5f), p);
 }
 void oracle_reg_camera_distort(const oreg_camera* c, float nx, float ny, float out[2]) { ocam_distort(c, nx, ny, &out[0], &out[1]); }

@@ -50,18 +50,43 @@ DISTORTION = {
     2: [0.0221184, 0.0128597, 0.000531602, -0.000388873, 0.00623079, 0.0020419, -0.000805024, 4.07704e-05],
     3: [0.0221184, 0.0128597, 0.00623079, 0.0020419],
     4: [0.9],
+    5: [],                                                     # SIMPLE_PINHOLE
+    6: [-0.101082],                                            # SIMPLE_RADIAL (k < 0: its closed-form cut-off is finite)
+    7: [-0.101082, 0.0703954],                                 # RADIAL
+    8: [-0.101082, 0.0703954, 0.0123],                         # POLYNOMIAL_3
+    9: [0.0221184, 0.0128597, 0.000531602, -0.000388873],      # FISHEYE_POLYNOMIAL_2_TANGENTIAL_2
 }
+UNIQUE_FOCAL = (5, 6, 7)          # parameter vector [f cx cy ...] (camera_base_impl.h:65-67)
+
+
+def camera_params(model, fx, fy, cx, cy, distortion=None):
+    """The model's parameter vector in the reference's GetParameters order; one-focal-length models take fx."""
+    d = DISTORTION[model] if distortion is None else list(distortion)
+    head = [fx, cx, cy] if model in UNIQUE_FOCAL else [fx, fy, cx, cy]
+    return np.array(head + d, np.float32)
+
+
+def expand_params(model, params):
+    """[fx fy cx cy] + distortion for any model (fx = fy = f for the one-focal-length ones)."""
+    p = [float(v) for v in params]
+    return (p[0], p[0], p[1], p[2], p[3:]) if model in UNIQUE_FOCAL else (p[0], p[1], p[2], p[3], p[4:])
+
 
 
 def distort_np(model, q, nx, ny):
     """float64 numpy version of the models' Distort (only for synthesising consistent test images)."""
-    if model == 0:
+    if model in (0, 5):
         return nx, ny
+    if model in (6, 7, 8):
+        r2 = nx * nx + ny * ny
+        k = list(q) + [0.0, 0.0]
+        fac = 1 + r2 * (k[0] + r2 * (k[1] + r2 * k[2]))
+        return nx * fac, ny * fac
     if model == 4:
         r = np.sqrt(nx * nx + ny * ny)
         f = np.where(r > 1e-6, np.arctan(r * 2 * np.tan(0.5 * q[0])) / (np.maximum(r, 1e-12) * q[0]), 1.0)
         return nx * f, ny * f
-    if model in (2, 3):
+    if model in (2, 3, 9):
         r = np.sqrt(nx * nx + ny * ny)
         f = np.where(r > 1e-6, np.arctan(r) / np.maximum(r, 1e-12), 1.0)
         nx, ny = nx * f, ny * f
@@ -71,7 +96,7 @@ def distort_np(model, q, nx, ny):
         fac = 1 + r2 * (q[0] + r2 * (q[1] + r2 * (q[2] + r2 * q[3])))
         return nx * fac, ny * fac
     k1, k2, p1, p2 = q[:4]
-    if model == 1:
+    if model in (1, 9):
         radial = 1 + r2 * (k1 + r2 * k2)
         return nx * radial + 2 * p1 * xy + p2 * (r2 + 2 * x2), ny * radial + 2 * p2 * xy + p1 * (r2 + 2 * y2)
     k3, k4, sx1, sy1 = q[4:8]
@@ -99,14 +124,15 @@ def make_multi_image_scene(n_points=5000, n_images=3, width=240, height=180, n_l
     nbr = nn[:, 1:].astype(np.uint32)
     tex = texture(pts[:, 0].astype(np.float64), pts[:, 2].astype(np.float64))
     fixed_desc = (tex[nbr] - tex[:, None]).astype(np.float32)
-    params = np.array([210.0, 208.0, width / 2 - 0.4, height / 2 + 0.3] + DISTORTION[model], np.float32)
+    params = camera_params(model, 210.0, 208.0, width / 2 - 0.4, height / 2 + 0.3)
     eyes = [(-0.35, -0.3, 0.1), (0.3, -0.2, -0.08), (0.02, -0.45, 0.2), (0.2, -0.5, -0.15)][:n_images]
     images = []
     for i, eye in enumerate(eyes):
         R0, t0 = look_at_pose(eye, (0.05 * i, 3, 0.02 * i))
         q = quat_from_R(R0); R = quat_to_R(q).astype(np.float64); t = t0.astype(np.float64)
         yy, xx = np.mgrid[0:height, 0:width].astype(np.float64)
-        unx, uny = undistort_np(model, [float(v) for v in params[4:]], (xx - params[2]) / params[0], (yy - params[3]) / params[1])
+        efx, efy, ecx, ecy, eq = expand_params(model, params)
+        unx, uny = undistort_np(model, eq, (xx - ecx) / efx, (yy - ecy) / efy)
         d = np.stack([unx, uny, np.ones_like(xx)], -1) @ R     # R^T * dir
         o = -R.T @ t
         lam = (3.0 - o[1]) / d[..., 1]
@@ -140,7 +166,7 @@ def make_reg_scene(n_points=6000, width=320, height=240, n_levels=4, K=5, seed=0
     R0, t = look_at_pose((0.1, -0.4, 0.05), (0, 3, 0))
     q = quat_from_R(R0)
     R = quat_to_R(q)          # so3().matrix() of the stored quaternion: what both implementations actually use
-    params = np.array([260.0, 255.0, width / 2 - 0.3, height / 2 + 0.2] + DISTORTION[model], np.float32)
+    params = camera_params(model, 260.0, 255.0, width / 2 - 0.3, height / 2 + 0.2)
     fixed_desc = rng.normal(0, 8, (n_points, K)).astype(np.float32)
     var_desc = rng.normal(0, 8, (n_points, K)).astype(np.float32)
     obs_counts = rng.randint(0, 4, n_points).astype(np.int32)
@@ -161,7 +187,7 @@ def make_rig_scene(n_points=6000, n_frames=2, width=240, height=180, n_levels=3,
     nbr = nn[:, 1:].astype(np.uint32)
     tex = texture(pts[:, 0].astype(np.float64), pts[:, 2].astype(np.float64))
     fixed_desc = (tex[nbr] - tex[:, None]).astype(np.float32)
-    params = np.array([210.0, 208.0, width / 2 - 0.4, height / 2 + 0.3] + DISTORTION[model], np.float32)
+    params = camera_params(model, 210.0, 208.0, width / 2 - 0.4, height / 2 + 0.3)
     # true extrinsics of camera 1: 12 cm baseline, a few degrees of rotation
     R1 = Rotation.from_rotvec([0.01, -0.04, 0.02]).as_matrix()
     q1_true = quat_from_R(R1); t1_true = np.array([-0.12, 0.01, 0.005], np.float32)
@@ -177,7 +203,8 @@ def make_rig_scene(n_points=6000, n_frames=2, width=240, height=180, n_levels=3,
         for q, t in ((q_ref, t0), (q_dep, t_dep)):
             R = quat_to_R(q).astype(np.float64); tt = t.astype(np.float64)
             yy, xx = np.mgrid[0:height, 0:width].astype(np.float64)
-            unx, uny = undistort_np(model, [float(v) for v in params[4:]], (xx - params[2]) / params[0], (yy - params[3]) / params[1])
+            efx, efy, ecx, ecy, eq = expand_params(model, params)
+            unx, uny = undistort_np(model, eq, (xx - ecx) / efx, (yy - ecy) / efy)
             d = np.stack([unx, uny, np.ones_like(xx)], -1) @ R
             o = -R.T @ tt
             lam = (3.0 - o[1]) / d[..., 1]

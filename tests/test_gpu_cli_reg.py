@@ -30,7 +30,9 @@ def _write_dataset(tmp, M, names, rigs=None, model_name="PINHOLE"):
     write_ply_xyz(os.path.join(d, "scan.ply"), M["pts"], rgb=np.full((len(M["pts"]), 3), 128, np.uint8))
     write_mlp(os.path.join(d, "scans.mlp"), [("scan", "scan.ply", np.eye(4))])
     os.makedirs(os.path.join(d, "state"), exist_ok=True)
-    p = M["params"].astype(np.float64).copy(); p[2] += 0.5; p[3] += 0.5         # COLMAP's pixel-corner convention
+    from reg_util import UNIQUE_FOCAL
+    ci = 1 if M.get("model", 0) in UNIQUE_FOCAL else 2                          # cx, cy follow ONE focal length in those models
+    p = M["params"].astype(np.float64).copy(); p[ci] += 0.5; p[ci + 1] += 0.5   # COLMAP's pixel-corner convention
     with open(os.path.join(d, "state", "cameras.txt"), "w") as f:
         f.write("# cameras\n7 %s %d %d %s\n" % (model_name, M["width"], M["height"], " ".join("%.9g" % v for v in p)))
     with open(os.path.join(d, "state", "images.txt"), "w") as f:
@@ -211,6 +213,48 @@ def test_image_registrator_cli_fisheye_models(tmp_path, e3d, model, name, n_para
     assert len(costs) >= 4 and np.isfinite(costs).all() and min(costs) < costs[0]
 
 
+@pytest.mark.parametrize("model,name,out_name,n_params", [(5, "SIMPLE_PINHOLE", "SIMPLE_PINHOLE", 3), (6, "SIMPLE_RADIAL_FISHEYE", "SIMPLE_RADIAL", 4),
+                                                         (7, "RADIAL", "RADIAL", 5), (7, "RADIAL_FISHEYE", "RADIAL", 5),
+                                                         (8, "POLYNOMIAL_3", "POLYNOMIAL_3", 7),
+                                                         (9, "FISHEYE_POLYNOMIAL_2_TANGENTIAL_2", "FISHEYE_POLYNOMIAL_2_TANGENTIAL_2", 8)])
+def test_image_registrator_cli_remaining_colmap_models(tmp_path, e3d, model, name, out_name, n_params):
+    """The rest of camera_base.cc:66-77 through the tool.  The one-focal-length models keep their [f cx cy ...] parameter order; the
+    names RADIAL_FISHEYE / SIMPLE_RADIAL_FISHEYE construct the plain RADIAL / SIMPLE_RADIAL classes in the reference's factory
+    ([QUIRK] camera_base.cc:73-74) and are written back under those names."""
+    M = make_multi_image_scene(n_points=6000, n_images=3, seed=29, perturb=0.004, model=model)
+    names = ["dslr/img_%d.png" % i for i in range(3)]
+    d = _write_dataset(tmp_path, M, names, model_name=name)
+    out = _run_tool(d)
+    assert "Finished!" in out
+    cam = open(os.path.join(d, "out", "scale_1_state", "cameras.txt")).read().split("\n")[3].split()
+    assert cam[1] == out_name and len(cam) == 4 + n_params
+    p = np.array(cam[4:], np.float64)
+    assert np.isfinite(p).all() and abs(p[0] - M["params"][0]) < 5.0
+    ci = 1 if model in (5, 6, 7) else 2
+    assert abs(p[ci] - (M["params"][ci] + 0.5)) < 3.0 and abs(p[ci + 1] - (M["params"][ci + 1] + 0.5)) < 3.0
+    costs = [float(l.split(":")[-1]) for l in out.splitlines() if "Cost (considering occlusions) is" in l]
+    assert len(costs) >= 4 and np.isfinite(costs).all() and min(costs) < costs[0]
+    # the same optimisation through the binding ends at the same intrinsics and poses
+    G = e3d.RegProblem(e3d.default_reg_params(image_scale_count=3, point_neighbor_count=M["K"]))
+    G.set_intrinsics(0, M["width"], M["height"], M["params"], 0, 3, camera_type=model)
+    for s_i, sc in enumerate(_point_scales(M)):
+        G.set_point_scale(s_i, sc["pts"], sc["radius"], sc["nbr"], sc["fixed"])
+    G.set_splat_points(M["pts"])
+    from reg_util import pyramid_u8
+    for i, im in enumerate(M["images"]):
+        G.set_image(i, 0, pyramid_u8(im["pyr"][0], 3)); G.set_image_pose(i, im["q_init"], im["t_init"])
+    for scale in (1, 0):
+        prm = G.params; prm.current_image_scale = scale; G.set_params(prm)
+        G.set_cache_observations(scale != 1)
+        G.run_on_current_scale(4, 0.0, 15, False)
+    pg = G.intrinsics_level(0, 0)[2].astype(np.float64); pg[ci] += 0.5; pg[ci + 1] += 0.5
+    assert np.abs(p - pg).max() <= 2e-3 * max(1.0, np.abs(pg).max())
+    st = _read_images_txt(os.path.join(d, "out", "scale_1_state", "images.txt"))
+    for i in range(3):
+        q, t = G.get_image_pose(i)
+        assert np.abs(st[i][0] - q).max() <= 2e-5 and np.abs(st[i][1] - t).max() <= 2e-5
+
+
 def test_image_registrator_cli_errors(tmp_path):
     r = subprocess.run([os.path.join(BIN, "ImageRegistrator")], capture_output=True, text=True)
     assert r.returncode != 0 and "Please specify all the required paths." in r.stderr
@@ -264,7 +308,7 @@ def test_image_registrator_computes_multires_cloud(tmp_path, e3d):
     exp = mr.compute_multi_res_point_cloud(scans, images, intr, image_scale_count=3)
     assert len(got) == len(exp) >= 1
     for g, o in zip(got, exp):
-        assert abs(g["radius"] - float(o["radius"])) <= 1e-6 * float(o["radius"])
+        assert abs(g["radius"] - float(o["radius"])) <= 5.1e-6 * float(o["radius"])      # metadata.txt carries 6 significant digits (ostream default)
         assert abs(len(g["pts"]) - len(o["pts"])) <= max(2, len(o["pts"]) // 200)      # merged means differ in the last bits
         assert g["nbr"].max() < len(g["pts"]) and np.all(g["nbr"] != np.arange(len(g["pts"]))[:, None])
         if len(g["pts"]) == len(o["pts"]):

@@ -30,8 +30,9 @@ def _setup(e3d, rb, S, **pk):
     return P, levels
 
 
-MODELS = [0, 1, 2, 3, 4]       # PINHOLE, OPENCV, THIN_PRISM_FISHEYE, OPENCV_FISHEYE, FOV
-EXACT = [0, 1, 2, 3, 4]     # every model: atan / atan2 / tan / log2 come from include/e3d_libm.h on both sides, bit for bit
+MODELS = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9]       # PINHOLE, OPENCV, THIN_PRISM_FISHEYE, OPENCV_FISHEYE, FOV, SIMPLE_PINHOLE, SIMPLE_RADIAL, RADIAL,
+                                              # POLYNOMIAL_3, FISHEYE_POLYNOMIAL_2_TANGENTIAL_2 (camera_base.cc:66-77: all of its classes)
+EXACT = MODELS     # every model: atan / atan2 / tan / log2 come from include/e3d_libm.h on both sides, bit for bit
 
 
 @pytest.mark.parametrize("model", MODELS)
@@ -43,8 +44,8 @@ def test_camera_pyramid_matches(e3d, rb, model):
         w, h, p, c = P.intrinsics_level(0, l)
         assert (w, h) == (levels[l].width, levels[l].height)
         assert np.array_equal(p, levels[l].params())
-        co = levels[l].inner_cutoff2 if model in (2, 3) else levels[l].cutoff2
-        assert c == co and (np.isinf(c) if model in (0, 4) else np.isfinite(c))      # PINHOLE and FOV have no cut-off
+        co = levels[l].inner_cutoff2 if model in (2, 3, 9) else levels[l].cutoff2
+        assert c == co and (np.isinf(c) if model in (0, 4, 5) else np.isfinite(c))      # the pinholes and FOV have no cut-off
 
 
 @pytest.mark.parametrize("model", MODELS)
@@ -455,14 +456,14 @@ def test_splat_depth_full_size_and_small_splats(e3d, rb, model):
     """High resolution: part of the splats hit the 10-pixel clamp (rendered as a separable min filter of the point z-buffer),
     part do not (tile path); points just outside the image still reach into it.  The union must equal the reference's
     per-splat rectangles bit for bit."""
-    from reg_util import DISTORTION, look_at_pose, quat_from_R, quat_to_R
+    from reg_util import camera_params, look_at_pose, quat_from_R, quat_to_R
     rng = np.random.RandomState(11)
     W, H = 1280, 960
     n = 30000
     u = rng.uniform(-2.2, 2.2, n); v = rng.uniform(-1.7, 1.7, n)
     depth = 2.2 + 1.6 * rng.uniform(0, 1, n) ** 2 + 0.4 * np.sin(2 * u)          # 2.2 .. 4.2 m: radii 7 .. 14 px at f = 1040
     pts = np.stack([u, depth, v], 1).astype(np.float32)
-    params = np.array([1040.0, 1020.0, W / 2 - 0.3, H / 2 + 0.2] + DISTORTION[model], np.float32)
+    params = camera_params(model, 1040.0, 1020.0, W / 2 - 0.3, H / 2 + 0.2)
     R0, t = look_at_pose((0.05, -0.1, 0.02), (0, 3, 0))
     q = quat_from_R(R0); R = quat_to_R(q)
     P = e3d.RegProblem(e3d.default_reg_params(image_scale_count=3, point_neighbor_count=5))
@@ -502,10 +503,10 @@ def _mesh_scene():
 @pytest.mark.parametrize("model", MODELS)
 def test_mesh_depth_matches_oracle(e3d, rb, model):
     from oracle import mesh_occlusion as mo
-    from reg_util import DISTORTION, look_at_pose, pyramid_u8, quat_from_R, quat_to_R
+    from reg_util import camera_params, expand_params, look_at_pose, pyramid_u8, quat_from_R, quat_to_R
     verts, tris = _mesh_scene()
     W, H = 320, 240
-    params = np.array([260.0, 255.0, W / 2 - 0.3, H / 2 + 0.2] + DISTORTION[model], np.float32)
+    params = camera_params(model, 260.0, 255.0, W / 2 - 0.3, H / 2 + 0.2)
     R0, t = look_at_pose((0.3, -0.3, 0.1), (0, 3, 0))
     q = quat_from_R(R0); R = quat_to_R(q)
     P = e3d.RegProblem(e3d.default_reg_params(image_scale_count=3, point_neighbor_count=5))
@@ -557,11 +558,11 @@ def test_mesh_near_plane_clipping(e3d, rb, model):
     clipping nothing would be drawn.  HIP rasteriser vs the oracle's clipping; for PINHOLE also vs ray casting: every pixel sees a
     wall at the depth where its viewing ray leaves the box."""
     from oracle import mesh_occlusion as mo
-    from reg_util import DISTORTION, pyramid_u8, quat_from_R, quat_to_R
+    from reg_util import camera_params, expand_params, pyramid_u8, quat_from_R, quat_to_R
     from scipy.spatial.transform import Rotation
     verts, tris, lo, hi = _room_mesh()
     W, H = 320, 240
-    params = np.array([200.0, 195.0, W / 2 - 0.3, H / 2 + 0.2] + DISTORTION[model], np.float32)
+    params = camera_params(model, 200.0, 195.0, W / 2 - 0.3, H / 2 + 0.2)
     q = quat_from_R(Rotation.from_euler("xyz", [0.3, -0.5, 0.2]).as_matrix()); R = quat_to_R(q)
     eye = np.array([0.4, -0.3, 0.5])
     t = (-R.astype(np.float64) @ eye).astype(np.float32)
@@ -574,7 +575,7 @@ def test_mesh_near_plane_clipping(e3d, rb, model):
     g = P.render_depth(0, 0, (H, W))
     px, py, z, lx, ly = mo.project_vertices(model, cam, R, t, verts, shaded=True)
     assert (z < 0.05).sum() >= 3                                   # vertices behind the near plane / the camera
-    o = mo.rasterise(px, py, z, tris, W, H, 0.05, 100.0, shaded=(lx, ly), proj=params[:4])
+    o = mo.rasterise(px, py, z, tris, W, H, 0.05, 100.0, shaded=(lx, ly), proj=expand_params(model, params)[:4])
     if model in EXACT:
         assert np.array_equal(g.view(np.uint32), o.view(np.uint32))
     else:
@@ -598,6 +599,11 @@ RENDERER_KAT_PARAMS = {          # src/opt/test/test_renderer.cc:205-300 (Pinhol
     2: [340.926, 341.124, 302.4, 201.6, -0.101082, 0.0703954, 0.000438661, -0.000680887, 0.002, 0.001, -0.003, 0.004],
     3: [340.926, 341.124, 302.4, 201.6, 0.221184, 0.128597, 0.0623079, 0.20419],          # FisheyePolynomial4 (:275-280)
     4: [250.0, 200.0, 319.5, 239.5, 1.0],                                                  # FisheyeFOV (:259-263)
+    5: [250.0, 319.5, 239.5],                                                              # SimplePinhole (:222-226)
+    6: [250.0, 319.5, 239.5, 0.23],                                                        # SimpleRadial (:240-244)
+    7: [250.0, 319.5, 239.5, 0.23, 0.66],                                                  # Radial (:234-238: kK1, -kK2)
+    8: [250.0, 200.0, 319.5, 239.5, 0.23, -0.66, 0.64],                                    # Polynomial (:228-232)
+    9: [340.926, 341.124, 302.4, 201.6, -0.101082, 0.0703954, 0.000438661, -0.000680887],  # FisheyePolynomialTangential (:285-291)
 }
 
 

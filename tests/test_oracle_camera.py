@@ -20,6 +20,13 @@ CAMERAS = {
                                                    0.0623079, 0.20419, -0.000805024, 4.07704e-05]),
     "OPENCV_FISHEYE": (rb.OPENCV_FISHEYE, [340.926, 341.124, 302.4, 201.6, 0.221184, 0.128597, 0.0623079, 0.20419]),
     "FOV": (rb.FOV, [250.0, 200.0, 319.5, 239.5, 1.0]),
+    # test_camera.cc:428-462,491-497 (kK1 = 0.13, kK2 = -0.66, kK3 = 0.64): the remaining classes of camera_base.cc:66-77
+    "SIMPLE_PINHOLE": (rb.SIMPLE_PINHOLE, [250.0, 319.5, 239.5]),
+    "RADIAL": (rb.RADIAL, [250.0, 319.5, 239.5, 0.13, -1e-2]),
+    "SIMPLE_RADIAL": (rb.SIMPLE_RADIAL, [450.0, 319.5, 239.5, 0.13]),
+    "POLYNOMIAL_3": (rb.POLYNOMIAL_3, [250.0, 200.0, 319.5, 239.5, 0.13, -0.66, 0.64]),
+    "FISHEYE_POLYNOMIAL_2_TANGENTIAL_2": (rb.FISHEYE_POLYNOMIAL_2_TANGENTIAL_2, [340.926, 341.124, 302.4, 201.6, -0.101082, 0.0703954, 0.000438661,
+                                                                               -0.000680887]),
 }
 
 
@@ -90,8 +97,31 @@ def test_image_derivative_by_intrinsics(cam):
 
 
 def test_cutoffs():
-    t, p = CAMERAS["PINHOLE"]
-    assert np.isinf(rb.make_camera(W, H, np.array(p, np.float32), t).cutoff2)          # camera_pinhole.cc never calls InitCutoff
+    for name in ("PINHOLE", "SIMPLE_PINHOLE"):
+        t, p = CAMERAS[name]
+        assert np.isinf(rb.make_camera(W, H, np.array(p, np.float32), t).cutoff2)      # their constructors never call InitCutoff
+    # SIMPLE_RADIAL: closed form -1 / (3 k) for k < 0 only (camera_simple_radial.cc:51-57)
+    assert np.isinf(rb.make_camera(W, H, np.array(CAMERAS["SIMPLE_RADIAL"][1], np.float32), rb.SIMPLE_RADIAL).cutoff2)
+    c = rb.make_camera(W, H, np.array([450.0, 319.5, 239.5, -0.2], np.float32), rb.SIMPLE_RADIAL)
+    assert c.cutoff2 == np.float32(-1.0) / (np.float32(3) * np.float32(-0.2))
+    # RADIAL / POLYNOMIAL_3: RadialBase::InitCutoff on the camera itself -- r * factor(r^2) = farthest corner radius, * 1.01
+    for name in ("RADIAL", "POLYNOMIAL_3"):
+        t, p = CAMERAS[name]
+        c = rb.make_camera(W, H, np.array(p, np.float32), t)
+        nd = 2 if name == "RADIAL" else 3
+        k = np.array(list(p[-nd:]) + [0.0], np.float64)
+        corner = max(np.hypot(c.fx_inv * x + c.cx_inv, c.fy_inv * y + c.cy_inv) for x, y in ((0, 0), (W, 0), (0, H), (W, H)))
+        if np.isfinite(c.cutoff2):
+            r = np.sqrt(np.float64(c.cutoff2) / np.float64(np.float32(1.01)))
+            fac = 1 + r**2 * (k[0] + r**2 * (k[1] + r**2 * k[2]))
+            # either the innermost solution (times 1.01) or the squared second-best radius bounds it
+            assert abs(r * fac - corner) <= 2e-5 * corner or c.cutoff2 < r * r * 1.01 + 1e-6
+        assert np.isinf(c.inner_cutoff2)
+    t, p = CAMERAS["FISHEYE_POLYNOMIAL_2_TANGENTIAL_2"]
+    c = rb.make_camera(W, H, np.array(p, np.float32), t)
+    assert np.isinf(c.cutoff2) and np.isfinite(c.inner_cutoff2) and c.inner_cutoff2 > 0
+    inner = rb.make_camera(W, H, np.array(p, np.float32), rb.OPENCV)                   # its inner PolynomialTangentialCamera
+    assert c.inner_cutoff2 == inner.cutoff2
     t, p = CAMERAS["OPENCV"]
     c = rb.make_camera(W, H, np.array(p, np.float32), t)
     assert np.isfinite(c.cutoff2) and c.cutoff2 > 0

@@ -86,6 +86,7 @@ SIGNATURES = {
     "e3d_reg_set_point_scale": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_float, C.c_void_p, C.c_void_p]),
     "e3d_reg_set_variable_descriptors": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "e3d_reg_get_variable_descriptors": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "e3d_reg_set_camera_mask": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "e3d_reg_set_intrinsics": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "e3d_reg_get_intrinsics_level": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "e3d_reg_set_image": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
@@ -535,6 +536,15 @@ class RegProblem:
         w = C.c_int(); h = C.c_int(); p = np.zeros(self._nparams[intrinsics_id], np.float32); c = C.c_float()
         self._chk(lib().e3d_reg_get_intrinsics_level(self._h, intrinsics_id, level, C.byref(w), C.byref(h), C.c_void_p(p.ctypes.data), C.byref(c)), "get_intrinsics_level")
         return w.value, h.value, p, c.value
+
+    def set_camera_mask(self, intrinsics_id, masks):
+        """Intrinsics::camera_mask: one u8 mask per pyramid level (or None per level); masks=None removes it."""
+        if masks is None:
+            self._chk(lib().e3d_reg_set_camera_mask(self._h, intrinsics_id, None), "e3d_reg_set_camera_mask")
+            return
+        keep = [np.ascontiguousarray(m, np.uint8) if m is not None else None for m in masks]
+        arr = (C.c_void_p * len(keep))(*[(m.ctypes.data if m is not None else None) for m in keep])
+        self._chk(lib().e3d_reg_set_camera_mask(self._h, intrinsics_id, arr), "e3d_reg_set_camera_mask")
 
     def set_image(self, image_id, intrinsics_id, levels, masks=None):
         if levels is None:                       # an image owned by another rank: id, intrinsics and pose only

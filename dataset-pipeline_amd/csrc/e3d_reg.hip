@@ -36,6 +36,7 @@ constexpr int kRegMaxLevels = 16;
 struct Pyramid {               // passed by value to kernels
   const unsigned char* img[kRegMaxLevels];
   const unsigned char* mask[kRegMaxLevels];
+  const unsigned char* cam_mask[kRegMaxLevels];      // Intrinsics::camera_mask (intrinsics.h:104): shared by all images of the camera
   CamLevel cam[kRegMaxLevels];
   int n_levels;
   int min_image_scale;
@@ -684,6 +685,7 @@ template <int M>
 __global__ __launch_bounds__(kBlock) void k_point_radius(const float4* __restrict__ pts, size_t n, Pose P, float4 quat /*w x y z*/,
                                                          CamLevel cam, CamLevel cam_min, const float2* __restrict__ lookup_min,
                                                          const unsigned char* __restrict__ img, const unsigned char* __restrict__ mask,
+                                                         const unsigned char* __restrict__ cam_mask,
                                                          const float* __restrict__ occlusion, RadiusParams rp,
                                                          float* __restrict__ min_radius, float* __restrict__ max_radius) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -698,6 +700,7 @@ __global__ __launch_bounds__(kBlock) void k_point_radius(const float4* __restric
   if (!(ixf + 0.5f >= 0 && iyf + 0.5f >= 0 && ix >= 0 && iy >= 0 && ix < cam.width && iy < cam.height)) return;
   if (!(occlusion[(size_t)iy * cam.width + ix] + rp.occlusion_threshold >= Z)) return;
   if (mask && mask[(size_t)iy * cam.width + ix] != 0) return;
+  if (cam_mask && cam_mask[(size_t)iy * cam.width + ix] != 0) return;                          // visibility_estimator.cc:335-345
   if (img[(size_t)iy * cam.width + ix] > rp.max_valid_intensity) return;
   float returned_scale = rp.image_scale - 1e-6f;
   float ox = ixf, oy = iyf;
@@ -784,6 +787,7 @@ __global__ __launch_bounds__(kBlock) void k_obs_eval(const float4* __restrict__ 
   if (q.check) {
     const int pl = small_scale - Y.min_image_scale;
     if (Y.mask[pl] && Y.mask[pl][(size_t)iy * ic.width + ix] != 0) return;
+    if (Y.cam_mask[pl] && Y.cam_mask[pl][(size_t)iy * ic.width + ix] != 0) return;          // visibility_estimator.cc:492-503
     if (Y.img[pl][(size_t)iy * ic.width + ix] > q.max_valid_intensity) return;
   }
   valid[k] = (int)pi;
@@ -1433,6 +1437,7 @@ struct Intrin {
   int width = 0, height = 0;
   float params[12] = {0};
   std::vector<CamLevel> levels;
+  std::shared_ptr<std::vector<DevBuf<unsigned char>>> cam_mask;     // per level (empty buffer = none); survives parameter updates
 };
 struct Obs {
   bool active = false;            // false: the reference would hold no vector for this (image, scale); buffers are kept for reuse
@@ -1726,6 +1731,7 @@ static Pyramid make_pyramid(e3d_reg* h, const ImageDev& im) {
   for (int l = 0; l < Y.n_levels; ++l) {
     Y.img[l] = im.pix[l].p;
     Y.mask[l] = im.has_mask[l] ? im.mask[l].p : nullptr;
+    Y.cam_mask[l] = (in.cam_mask && l < (int)in.cam_mask->size() && (*in.cam_mask)[l].p) ? (*in.cam_mask)[l].p : nullptr;
     Y.cam[l] = in.levels[l];
   }
   return Y;
@@ -1895,7 +1901,36 @@ int e3d_reg_set_intrinsics(e3d_reg_t* h, int intrinsics_id, int camera_type, int
   in.width = width; in.height = height;
   for (int i = 0; i < n_parameters; ++i) in.params[i] = parameters[i];
   build_model_pyramid(h, in, n_levels);
-  h->intr[intrinsics_id] = in;
+  h->intr[intrinsics_id] = in;                          // (a camera mask belongs to the previous description of this id and goes with it)
+  return 0;
+  R_CATCH()
+}
+
+/* Intrinsics::camera_mask (src/opt/intrinsics.h:104, loaded by Image::LoadImageData, image.cc:62-72): one u8 mask per pyramid level
+ * of the camera, shared by all its images; an observation is dropped where the image mask OR the camera mask is non-zero
+ * (visibility_estimator.cc:335-345,482-503).  level_masks[l] = width_l x height_l bytes (host or device) or NULL; level_masks == NULL
+ * removes the mask.  Call after e3d_reg_set_intrinsics. */
+int e3d_reg_set_camera_mask(e3d_reg_t* h, int intrinsics_id, const uint8_t* const* level_masks) {
+  R_TRYH
+  if (!h) throw Error(E3D_ERR_INVALID, "null handle");
+  auto it = h->intr.find(intrinsics_id);
+  if (it == h->intr.end()) throw Error(E3D_ERR_INDEX, "no such intrinsics");
+  Intrin& in = it->second;
+  if (!level_masks) { in.cam_mask.reset(); }
+  else {
+    auto masks = std::make_shared<std::vector<DevBuf<unsigned char>>>(in.levels.size());
+    for (size_t l = 0; l < in.levels.size(); ++l) {
+      if (!level_masks[l]) continue;
+      const size_t bytes = (size_t)in.levels[l].width * (size_t)in.levels[l].height;
+      (*masks)[l].reserve(bytes);
+      copy_in((*masks)[l].p, level_masks[l], bytes, h->stream);
+    }
+    rsync(h);
+    in.cam_mask = masks;
+  }
+  for (auto& kv : h->images)
+    if (kv.second.intrinsics_id == intrinsics_id)
+      for (auto& o : kv.second.obs) o.second.rows_valid = false;
   return 0;
   R_CATCH()
 }
@@ -2825,7 +2860,8 @@ int e3d_reg_point_radius_minmax(e3d_reg_t* h, const float* xyz, size_t n, float*
     const float4 quat = make_float4(im.pose_q.q.w, im.pose_q.q.x, im.pose_q.q.y, im.pose_q.q.z);
     if (n)
       E3D_CAM_SWITCH(in.type, hipLaunchKernelGGL(k_point_radius<M>, dim3(nblk(n)), dim3(kBlock), 0, s, pts.p, n, im.pose, quat, cam, cam_min,
-                                                 lk->p, im.pix[lvl].p, im.has_mask[lvl] ? im.mask[lvl].p : nullptr, im.depth.p, rp,
+                                                 lk->p, im.pix[lvl].p, im.has_mask[lvl] ? im.mask[lvl].p : nullptr,
+                                                 (in.cam_mask && lvl < (int)in.cam_mask->size()) ? (*in.cam_mask)[lvl].p : nullptr, im.depth.p, rp,
                                                  d_min.p, d_max.p));
   }
   copy_out(min_radius, d_min.p, sizeof(float) * n, s);

@@ -229,7 +229,7 @@ struct HostIntrinsics {
   int intrinsics_id = 0, model = 0, width = 0, height = 0, n_params = 0, min_image_scale = 0;
   float params[12] = {0};
   std::string model_name;
-  bool camera_mask_checked = false;
+  bool camera_mask_checked = false, camera_mask_uploaded = false;
   std::vector<GrayImage> camera_mask;       // per pyramid level; empty = none
 };
 struct HostImage {
@@ -824,12 +824,8 @@ class Problem {
           in.camera_mask = build_mask_pyramid(m, levels);
         }
       }
-      // the device holds one mask per image: image mask OR camera mask (an observation is dropped if either is set,
-      // visibility_estimator.cc:482-503)
-      if (!in.camera_mask.empty()) {
-        if (mask.empty()) mask = in.camera_mask;
-        else for (int l = 0; l < levels; ++l) for (size_t i = 0; i < mask[l].data.size(); ++i) mask[l].data[i] |= in.camera_mask[l].data[i];
-      }
+      bool upload_camera_mask = false;
+      if (!in.camera_mask.empty() && !in.camera_mask_uploaded) { in.camera_mask_uploaded = true; upload_camera_mask = true; }
       // level sizes: the camera pyramid rounds (ScaledBy, int(0.5 w + 0.5)), the image pyramid truncates (int(0.5 cols)); they
       // agree for the even sizes of real pyramids, otherwise the image level is edge-padded to the camera level's size
       std::vector<const uint8_t*> lp(levels), lm(levels, nullptr);
@@ -844,6 +840,15 @@ class Problem {
         };
         fit(pyr[l]); lp[l] = pyr[l].data.data();
         if (!mask.empty()) { fit(mask[l]); lm[l] = mask[l].data.data(); }
+        if (upload_camera_mask) fit(in.camera_mask[l]);
+      }
+      // Intrinsics::camera_mask: once per camera, to every rank (observations are created by the image's owner, but the point
+      // radius computation of the multi-resolution cloud runs wherever the image lives)
+      if (upload_camera_mask) {
+        std::vector<const uint8_t*> cm(levels);
+        for (int l = 0; l < levels; ++l) cm[l] = in.camera_mask[l].data.data();
+        for (e3d_reg_t* r : regs)
+          if (api().e3d_reg_set_camera_mask(r, in.intrinsics_id, cm.data()) < 0) return lib_fail("e3d_reg_set_camera_mask");
       }
       // pixels go to the image's owner only; every rank knows the image and its pose
       for (e3d_reg_t* r : regs) {

@@ -268,6 +268,13 @@ int e3d_reg_get_variable_descriptors(e3d_reg_t* reg, int point_scale, float* des
  * (intrinsics.cc:46-51, camera_base_impl.h:70-89) and radius cut-offs (camera_base_impl.h:410-463). */
 int e3d_reg_set_intrinsics(e3d_reg_t* reg, int intrinsics_id, int camera_type, int width, int height,
                            const float* parameters, int n_parameters, int min_image_scale, int n_levels);
+
+/* Intrinsics::camera_mask (src/opt/intrinsics.h:104; loaded once per camera by Image::LoadImageData, src/opt/image.cc:62-72): one u8
+ * mask per pyramid level of the camera (level_masks[l]: width_l x height_l bytes, host or device memory, or NULL), shared by all
+ * images of these intrinsics.  An observation is dropped where the image's own mask OR the camera mask is non-zero
+ * (src/opt/visibility_estimator.cc:335-345, 482-503).  level_masks == NULL removes the mask.  Call after e3d_reg_set_intrinsics;
+ * parameter updates of the optimiser keep it. */
+int e3d_reg_set_camera_mask(e3d_reg_t* reg, int intrinsics_id, const uint8_t* const* level_masks);
 /* queries one level of the pyramid the library built: size, parameters (n_parameters floats) and the radius cut-off
  * (+inf for PINHOLE; for the fisheye models the cut-off of the inner non-fisheye model, which is the one projection tests) */
 int e3d_reg_get_intrinsics_level(e3d_reg_t* reg, int intrinsics_id, int level, int* width, int* height,

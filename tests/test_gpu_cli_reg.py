@@ -157,6 +157,47 @@ def test_image_registrator_cli_matches_binding(tmp_path, e3d):
     assert cmd_fail.returncode != 0 and "Missing file for observed point indices" in cmd_fail.stderr
 
 
+def test_image_registrator_cli_camera_and_image_masks(tmp_path, e3d):
+    """masks_for_cameras/<folder>.png (Image::GetCameraMaskPath) goes to the library as the camera's own mask, masks_for_images/... as the
+    image's; the tool's optimum equals the binding's with set_camera_mask / per-image masks on the same data."""
+    M = make_multi_image_scene(n_points=6000, n_images=3, seed=31, perturb=0.005)
+    names = ["dslr/img_%d.png" % i for i in range(3)]
+    d = _write_dataset(tmp_path, M, names)
+    H, W = M["height"], M["width"]
+    cmask = np.zeros((H, W), np.uint8); cmask[:, : W // 4] = 2              # kEvalObs over the left quarter, every image of the camera
+    imask = np.zeros((H, W), np.uint8); imask[H // 2:, W // 2:] = 1         # kObs, image 1 only
+    _write_png(os.path.join(d, "images", "masks_for_cameras", "dslr.png"), cmask)
+    _write_png(os.path.join(d, "images", "masks_for_images", "dslr", "img_1.png"), imask)
+    out = _run_tool(d)
+    assert "Finished!" in out
+    from reg_util import pyramid_u8
+
+    def mask_pyr(m):
+        lv = [m]
+        for _ in range(2):
+            a = lv[-1]; h, w = (a.shape[0] // 2) * 2, (a.shape[1] // 2) * 2
+            lv.append(a[0:h:2, 0:w:2] | a[0:h:2, 1:w:2] | a[1:h:2, 0:w:2] | a[1:h:2, 1:w:2])
+        return lv
+    G = e3d.RegProblem(e3d.default_reg_params(image_scale_count=3, point_neighbor_count=M["K"]))
+    G.set_intrinsics(0, W, H, M["params"], 0, 3)
+    G.set_camera_mask(0, mask_pyr(cmask))
+    for s_i, sc in enumerate(_point_scales(M)):
+        G.set_point_scale(s_i, sc["pts"], sc["radius"], sc["nbr"], sc["fixed"])
+    G.set_splat_points(M["pts"])
+    for i, im in enumerate(M["images"]):
+        G.set_image(i, 0, pyramid_u8(im["pyr"][0], 3), mask_pyr(imask) if i == 1 else None); G.set_image_pose(i, im["q_init"], im["t_init"])
+    for scale in (1, 0):
+        prm = G.params; prm.current_image_scale = scale; G.set_params(prm)
+        G.set_cache_observations(scale != 1)
+        cost = G.run_on_current_scale(4, 0.0, 15, False)[1]
+        meta = open(os.path.join(d, "out", "scale_%s_state" % ("0.5" if scale == 1 else "1"), "metadata.txt")).read()
+        assert abs(float(meta.strip().split("optimum_cost ")[1]) - cost) <= 1e-4 * cost
+    st = _read_images_txt(os.path.join(d, "out", "scale_1_state", "images.txt"))
+    for i in range(3):
+        q, t = G.get_image_pose(i)
+        assert np.abs(st[i][0] - q).max() <= 2e-5 and np.abs(st[i][1] - t).max() <= 2e-5
+
+
 @pytest.mark.parametrize("incomplete", [False, True])
 def test_image_registrator_cli_with_rig(tmp_path, e3d, incomplete):
     """incomplete: the second camera's image of frame 1 is not registered in images.txt (its file exists): AssignRigs adds it at

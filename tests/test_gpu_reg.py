@@ -102,6 +102,38 @@ def test_observations_match_oracle(e3d, rb, model):
     assert np.array_equal(g2[4], rb.neighbors_observed(len(S["pts"]), o2[0], S["nbr"], S["K"]))
 
 
+def _mask_pyramid(mask, n_levels):
+    masks = [mask]
+    for _ in range(1, n_levels):
+        m = masks[-1]; h, w = (m.shape[0] // 2) * 2, (m.shape[1] // 2) * 2
+        masks.append(m[0:h:2, 0:w:2] | m[0:h:2, 1:w:2] | m[1:h:2, 0:w:2] | m[1:h:2, 1:w:2])   # Image::BuildMaskPyramid
+    return masks
+
+
+@pytest.mark.parametrize("with_image_mask", [False, True])
+def test_camera_mask_is_a_mask_of_its_own(e3d, rb, with_image_mask):
+    """Intrinsics::camera_mask (intrinsics.h:104) handed over per camera, not merged into the image masks: an observation is dropped
+    where the image mask OR the camera mask is set (visibility_estimator.cc:482-503) -- the oracle run with the union of the two
+    must see the same observations; removing the camera mask brings the others back."""
+    S = make_reg_scene(n_points=30000, seed=3, model=1)
+    cmask = np.zeros_like(S["pyr"][0]); cmask[60:200, 200:260] = 2          # MaskType::kEvalObs
+    imask = np.zeros_like(S["pyr"][0]); imask[100:140, 50:230] = 1          # MaskType::kObs, overlapping the camera mask
+    cmasks = _mask_pyramid(cmask, S["n_levels"])
+    imasks = _mask_pyramid(imask, S["n_levels"]) if with_image_mask else None
+    if imasks is not None:
+        S["masks"] = imasks
+    P, levels = _setup(e3d, rb, S)
+    P.set_camera_mask(0, cmasks)
+    union = [c | (i if imasks is not None else 0) for c, i in zip(cmasks, imasks or cmasks)]
+    g, o, of = _observe_both(e3d, rb, S, P, levels, masks=union)
+    assert len(g[0]) == len(o[0]) > 5000 and np.array_equal(g[0], o[0])
+    assert np.array_equal(g[1].view(np.uint32), o[1].view(np.uint32)) and np.array_equal(g[2].view(np.uint32), o[2].view(np.uint32))
+    n_with = len(g[0])
+    P.set_camera_mask(0, None)
+    g2, o2, _ = _observe_both(e3d, rb, S, P, levels, masks=imasks)
+    assert len(g2[0]) == len(o2[0]) > n_with and np.array_equal(g2[0], o2[0])
+
+
 @pytest.mark.parametrize("model", MODELS)
 def test_pass1_rows(e3d, rb, model):
     S = make_reg_scene(n_points=20000, seed=2, model=model)

@@ -1131,12 +1131,20 @@ __global__ __launch_bounds__(kBlock) void k_nn_certify(const float4* __restrict_
 // (d2, original index) order.  Afterwards every point other than the winner is farther than min(second smallest d2 seen,
 // cover2): the next certificate.
 // -------------------------------------------------------------------------------------------------
+template <int LPQ>
 __global__ __launch_bounds__(kBlock) void k_nn_bounded(const float4* __restrict__ Gsrc, const unsigned* __restrict__ list,
                                                        unsigned n_list, const float4* __restrict__ Gtgt, const unsigned* __restrict__ S,
                                                        GridDesc g, InvMap im, QueryRange qr, float r2, BoundParams bp,
                                                        int* __restrict__ match, int* __restrict__ match2,
                                                        float* __restrict__ match_d2, float* __restrict__ lbe) {
-  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  // LPQ lanes per query (1 or 4): the lanes of a quad share the box and split every cell-row run -- lane k takes candidates s0 + k,
+  // s0 + k + 4, ... (one 64-byte read per quad and step instead of four serial 16-byte reads per lane) -- then lane 0 merges the
+  // partial top lists.  Which candidate wins does not depend on the split: distinct distances order themselves, and any exact
+  // equality among the leaders (within a lane or at the merge) raises `tie`, which sends lane 0 through the exact (d2, original
+  // index) scan.  Short lists are latency bound and gain from the quads (1.85 -> 1.49 ms per iteration at 2 x 50 M once the
+  // poses settle); lists of millions of queries are bound by the candidate traffic and run one lane per query.
+  const unsigned i = (blockIdx.x * blockDim.x + threadIdx.x) / LPQ;
+  const int sub = threadIdx.x % LPQ;
   if (i >= n_list) return;
   const unsigned j = list[i];
   const float4 q = Gsrc[j];
@@ -1189,7 +1197,7 @@ __global__ __launch_bounds__(kBlock) void k_nn_bounded(const float4* __restrict_
       for (int cy = y0; cy <= y1; ++cy) {
         const size_t row = ((size_t)cz * qr.D[1] + (size_t)cy) * qr.D[0];
         const unsigned s0 = S[row + (size_t)x0], s1 = S[row + (size_t)x1 + 1];
-        for (unsigned p = s0; p < s1; ++p) {
+        for (unsigned p = s0 + (unsigned)sub; p < s1; p += LPQ) {
           const float4 c = Gtgt[p];
           const float d2 = sqdist_l2(q.x, q.y, q.z, c.x, c.y, c.z);
           const bool lt1 = d2 < bd, lt2 = d2 < bd2;
@@ -1203,6 +1211,32 @@ __global__ __launch_bounds__(kBlock) void k_nn_bounded(const float4* __restrict_
       }
     }
   }
+  // merge the quad's partial lists into lane 0's (the other lanes' best and second best enter like candidates, their third
+  // smallest value only bounds)
+#pragma unroll
+  for (int l = 1; l < LPQ; ++l) {
+    const float obd = __shfl(bd, l, LPQ), obd2 = __shfl(bd2, l, LPQ), ob3 = __shfl(b3, l, LPQ);
+    const int opos = __shfl(bpos, l, LPQ), opos2 = __shfl(bpos2, l, LPQ);
+    tie = tie || (__shfl((int)tie, l, LPQ) != 0);
+    if (sub == 0) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const float d2 = t == 0 ? obd : obd2;
+        const int p = t == 0 ? opos : opos2;
+        if (p >= 0) {
+          const bool lt1 = d2 < bd, lt2 = d2 < bd2;
+          tie = tie || (d2 == bd) || (d2 == bd2);
+          b3 = fminf(b3, fmaxf(d2, bd2));
+          bd2 = fminf(fmaxf(d2, bd), bd2);
+          bpos2 = lt1 ? bpos : (lt2 ? p : bpos2);
+          bd = fminf(d2, bd);
+          bpos = lt1 ? p : bpos;
+        }
+      }
+      b3 = fminf(b3, ob3);
+    }
+  }
+  if (sub != 0) return;
   if (tie) {
     // rare (lattices, duplicates): the same cells again with the full (d2, original index) order
     bd = kInf; bd2 = kInf; b3 = kInf; bpos = -1; bpos2 = -1;
@@ -1751,8 +1785,13 @@ void launch_nn_bounded(const float4* Gsrc, const unsigned* list, size_t n_list, 
                        const GridDesc& g, const InvMap& im, const QueryRange& qr, float r2, const BoundParams& bp, int* match,
                        int* match2, float* match_d2, float* lbe, hipStream_t s) {
   if (!n_list) return;
-  hipLaunchKernelGGL(k_nn_bounded, dim3((unsigned)div_up(n_list, kBlock)), dim3(kBlock), 0, s, Gsrc, list, (unsigned)n_list, Gtgt,
-                     dense_start, g, im, qr, r2, bp, match, match2, match_d2, lbe);
+  static const size_t quad_limit = [] { const char* e = getenv("E3D_NN_QUAD_LIMIT"); return e ? (size_t)atoll(e) : (size_t)12000000; }();
+  if (n_list <= quad_limit)
+    hipLaunchKernelGGL(k_nn_bounded<4>, dim3((unsigned)div_up(4 * n_list, kBlock)), dim3(kBlock), 0, s, Gsrc, list, (unsigned)n_list, Gtgt,
+                       dense_start, g, im, qr, r2, bp, match, match2, match_d2, lbe);
+  else
+    hipLaunchKernelGGL(k_nn_bounded<1>, dim3((unsigned)div_up(n_list, kBlock)), dim3(kBlock), 0, s, Gsrc, list, (unsigned)n_list, Gtgt,
+                       dense_start, g, im, qr, r2, bp, match, match2, match_d2, lbe);
 }
 
 // Filter constants of k_nn_mfma for a target grid (cell = local cell size, sigma_max = largest singular value of the

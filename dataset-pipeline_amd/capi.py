@@ -87,6 +87,9 @@ SIGNATURES = {
     "e3d_reg_set_variable_descriptors": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "e3d_reg_get_variable_descriptors": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "e3d_reg_set_camera_mask": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "e3d_reg_set_depth_maps": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "e3d_reg_depth_accumulate": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "e3d_reg_depth_cost": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "e3d_reg_set_intrinsics": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "e3d_reg_get_intrinsics_level": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "e3d_reg_set_image": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
@@ -468,11 +471,13 @@ class RegParams(C.Structure):
                 ("robust_weighting_parameter", C.c_float), ("fixed_residuals_weight", C.c_float),
                 ("variable_residuals_weight", C.c_float), ("maximum_valid_intensity", C.c_float),
                 ("occlusion_depth_threshold", C.c_float), ("splat_radius", C.c_float),
-                ("current_image_scale", C.c_int32), ("image_scale_count", C.c_int32)]
+                ("current_image_scale", C.c_int32), ("image_scale_count", C.c_int32),
+                ("depth_residuals_weight", C.c_float), ("depth_robust_weighting_type", C.c_int32),
+                ("depth_robust_weighting_parameter", C.c_float)]
 
 
 def default_reg_params(**kw):
-    p = RegParams(5, 1, float(np.float32(30 * np.sqrt(5) / np.sqrt(2))), 1.0, 1.0, 252.0, 0.01, 0.03, 0, 2)
+    p = RegParams(5, 1, float(np.float32(30 * np.sqrt(5) / np.sqrt(2))), 1.0, 1.0, 252.0, 0.01, 0.03, 0, 2, 0.0, 2, 0.02)     # parameters.h:40-68
     for k, v in kw.items():
         setattr(p, k, v)
     return p
@@ -545,6 +550,29 @@ class RegProblem:
         keep = [np.ascontiguousarray(m, np.uint8) if m is not None else None for m in masks]
         arr = (C.c_void_p * len(keep))(*[(m.ctypes.data if m is not None else None) for m in keep])
         self._chk(lib().e3d_reg_set_camera_mask(self._h, intrinsics_id, arr), "e3d_reg_set_camera_mask")
+
+    def set_depth_maps(self, image_id, levels):
+        """Problem::SetFixedDepthMaps for one image: one f32 map per pyramid level (None removes them)."""
+        if levels is None:
+            self._chk(lib().e3d_reg_set_depth_maps(self._h, image_id, None), "e3d_reg_set_depth_maps")
+            return
+        keep = [np.ascontiguousarray(l, np.float32) for l in levels]
+        arr = (C.c_void_p * len(keep))(*[l.ctypes.data for l in keep])
+        self._chk(lib().e3d_reg_set_depth_maps(self._h, image_id, arr), "e3d_reg_set_depth_maps")
+
+    def depth_accumulate(self, image_id, point_scale):
+        """(H, b, sum of robust residuals, count) of the depth residuals of one (image, point scale); V = I + 6."""
+        V = self._nparams[self._image_intr[image_id]] + 6
+        H = np.zeros((V, V), np.float64); b = np.zeros(V, np.float64)
+        sm = C.c_double(0); cn = C.c_int64(0)
+        self._chk(lib().e3d_reg_depth_accumulate(self._h, image_id, point_scale, C.c_void_p(H.ctypes.data), C.c_void_p(b.ctypes.data),
+                                                 C.byref(sm), C.byref(cn)), "e3d_reg_depth_accumulate")
+        return H, b, sm.value, cn.value
+
+    def depth_cost(self, image_id, point_scale):
+        sm = C.c_double(0); cn = C.c_int64(0)
+        self._chk(lib().e3d_reg_depth_cost(self._h, image_id, point_scale, C.byref(sm), C.byref(cn)), "e3d_reg_depth_cost")
+        return sm.value, cn.value
 
     def set_image(self, image_id, intrinsics_id, levels, masks=None):
         if levels is None:                       # an image owned by another rank: id, intrinsics and pose only

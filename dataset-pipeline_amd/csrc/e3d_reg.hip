@@ -53,16 +53,19 @@ __device__ __forceinline__ void rt(const Pose& P, float x, float y, float z, flo
 }
 
 // ---- interpolation (interpolate_bilinear.h:36-74, interpolate_trilinear.h:44-87) ------------------------------------------
-__device__ __forceinline__ float bilinear(const unsigned char* img, int w, float x, float y, int ix, int iy) {
+// (pixel type T: u8 images, f32 depth maps -- InterpolateTrilinear* are templates in the reference too, interpolate_trilinear.h)
+template <class T>
+__device__ __forceinline__ float bilinear(const T* img, int w, float x, float y, int ix, int iy) {
   const float fx = x - ix, fxi = 1.f - fx, fy = y - iy, fyi = 1.f - fy;
-  const unsigned char* r0 = img + (size_t)iy * w;
-  const unsigned char* r1 = img + (size_t)(iy + 1) * w;
+  const T* r0 = img + (size_t)iy * w;
+  const T* r1 = img + (size_t)(iy + 1) * w;
   return fyi * (fxi * r0[ix] + fx * r0[ix + 1]) + fy * (fxi * r1[ix] + fx * r1[ix + 1]);
 }
-__device__ __forceinline__ void bilinear_d(const unsigned char* img, int w, float x, float y, int ix, int iy, float& v,
+template <class T>
+__device__ __forceinline__ void bilinear_d(const T* img, int w, float x, float y, int ix, int iy, float& v,
                                            float& dx, float& dy) {
-  const unsigned char* r0 = img + (size_t)iy * w;
-  const unsigned char* r1 = img + (size_t)(iy + 1) * w;
+  const T* r0 = img + (size_t)iy * w;
+  const T* r1 = img + (size_t)(iy + 1) * w;
   const float tl = r0[ix], tr = r0[ix + 1], bl = r1[ix], br = r1[ix + 1];
   const float fx = x - ix, fxi = 1.f - fx, fy = y - iy, fyi = 1.f - fy;
   const float top = fxi * tl + fx * tr, bottom = fxi * bl + fx * br;
@@ -70,14 +73,16 @@ __device__ __forceinline__ void bilinear_d(const unsigned char* img, int w, floa
   dx = fy * (br - bl) + fyi * (tr - tl);
   dy = bottom - top;
 }
-__device__ __forceinline__ float trilinear(const unsigned char* i0, int w0, const unsigned char* i1, int w1, float x0,
+template <class T>
+__device__ __forceinline__ float trilinear(const T* i0, int w0, const T* i1, int w1, float x0,
                                            float y0, float z) {
   const float v0 = bilinear(i0, w0, x0, y0, (int)x0, (int)y0);
   const float x1 = 2 * (x0 + 0.5f) - 0.5f, y1 = 2 * (y0 + 0.5f) - 0.5f;
   const float v1 = bilinear(i1, w1, x1, y1, (int)x1, (int)y1);
   return (1 - z) * v0 + z * v1;
 }
-__device__ __forceinline__ void trilinear_d(const unsigned char* i0, int w0, const unsigned char* i1, int w1, float x0,
+template <class T>
+__device__ __forceinline__ void trilinear_d(const T* i0, int w0, const T* i1, int w1, float x0,
                                             float y0, float z, float& v, float& dx, float& dy, float& dz) {
   float v0, dx0, dy0, v1, dx1, dy1;
   bilinear_d(i0, w0, x0, y0, (int)x0, (int)y0, v0, dx0, dy0);
@@ -954,7 +959,6 @@ __global__ __launch_bounds__(kBlock) void k_reg_pass1(const float4* __restrict__
   for (int r = 0; r < R4; ++r) rows[R4 * i + r] = make_float4(row[4 * r], row[4 * r + 1], row[4 * r + 2], row[4 * r + 3]);
 }
 
-// ==== a17 + a18: pass 2 =====================================================================================================================
 // Local system of one (image, point scale): V = I + 6 unknowns [intrinsics(I), pose(6)].  Slot layout of the reduction:
 // [upper triangle of H row-major (V(V+1)/2)] [b (V)] [sum_fixed, sum_variable, count_fixed, count_variable].
 __host__ __device__ constexpr int reg_h(int V) { return V * (V + 1) / 2; }
@@ -973,6 +977,177 @@ __device__ __forceinline__ void load_row(const float4* __restrict__ rows, size_t
   }
 }
 
+// ==== depth residuals (off by default: parameters.h:55, "not used in ETH3D pipeline" :165) ==================================================
+// ComputePointIntensityAndJacobians, depth part (intrinsics_and_pose_optimizer.cc:1150-1214), images that are not dependent rig images
+// (the reference aborts for those, :1199-1207).  Row of one observation: [residual, J_intrinsics(I), J_pose(6), 0-padding] as
+// rows4(I + 6) float4.  The projection terms are those of k_reg_pass1 with the depth pyramid's interpolation derivative, scaled by
+// -1 / depth^2, in place of the image's; the pose block loses (-1 / z^2) times the z row of d(camera point) / d(pose).
+struct DepthPyramid { const float* map[kRegMaxLevels]; };
+
+template <int M>
+__global__ __launch_bounds__(kBlock) void k_reg_depth_rows(const float4* __restrict__ pts, float point_radius, Pose P, float4 quat /* w x y z */,
+                                                           Pyramid Y, DepthPyramid D, const unsigned* __restrict__ o_idx,
+                                                           const float* __restrict__ o_x, const float* __restrict__ o_y,
+                                                           const float* __restrict__ o_s, size_t n_obs, float4* __restrict__ rows) {
+  constexpr int I = cam_param_count(M);
+  constexpr int R4 = rows4(I + 6);
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_obs) return;
+  const float4 p = pts[o_idx[i]];
+  float T0, T1, T2;
+  rt(P, p.x, p.y, p.z, T0, T1, T2);
+  const float os = o_s[i], ox = o_x[i], oy = o_y[i];
+  const int si = f2i(os);
+  const int small_scale = si + 1;
+  const int l1 = si - Y.min_image_scale, l0 = l1 + 1;
+  float row[4 * R4];
+#pragma unroll
+  for (int c = 0; c < 4 * R4; ++c) row[c] = 0.f;
+  float depth, j0, j1, j2;
+  trilinear_d(D.map[l0], Y.cam[l0].width, D.map[l1], Y.cam[l1].width, ox, oy, 1 - (os - (float)si), depth, j0, j1, j2);
+  j2 = -1 * j2;
+  const float scale_factor = exp2f((float)(Y.min_image_scale - small_scale));     // exact power of two
+  const float inv_scale_factor = 1.f / scale_factor;
+  j0 *= scale_factor; j1 *= scale_factor;
+  const float inv_depth = (depth != 0) ? (1.f / depth) : 0.f;
+  // pp = image.image_T_global * point (Sophus SE3f): p + w uv + v x uv, uv = 2 (v x p), + translation
+  const float vx = quat.y, vy = quat.z, vz = quat.w, w = quat.x;
+  float ux = vy * p.z - vz * p.y, uy = vz * p.x - vx * p.z, uz = vx * p.y - vy * p.x;
+  ux = ux + ux; uy = uy + uy; uz = uz + uz;
+  const float cz = vx * uy - vy * ux;
+  const float ppz = ((p.z + w * uz) + cz) + P.t[2];
+  const float point_inv_depth = (ppz != 0.f) ? (1.f / ppz) : 0.f;
+  row[0] = inv_depth - point_inv_depth;
+  const float j_inv = -1 / (depth * depth);
+  j0 = j_inv * j0; j1 = j_inv * j1; j2 = j_inv * j2;
+  const float mx = inv_scale_factor * (ox + 0.5f) - 0.5f, my = inv_scale_factor * (oy + 0.5f) - 0.5f;
+  const CamLevel cam = Y.cam[0];
+  const float To0 = T0 + point_radius;
+  float offx, offy;
+  cam_normalized_to_image<M>(cam, To0 / T2, T1 / T2, offx, offy);
+  const float rdx = offx - mx, rdy = offy - my;
+  const float denom = fmaxf(1e-6f, 0.693147180559945f * (rdx * rdx + rdy * rdy));
+  {
+    float Pi[2 * I], Po[2 * I];
+    cam_image_deriv_by_intrinsics<M>(cam, T0, T1, T2, Pi);
+    cam_image_deriv_by_intrinsics<M>(cam, To0, T1, T2, Po);
+#pragma unroll
+    for (int c = 0; c < I; ++c) {
+      const float scale_row = ((Po[c] - Pi[c]) * rdx + (Po[I + c] - Pi[I + c]) * rdy) / denom;
+      row[1 + c] = j0 * Pi[c] + (j1 * Pi[I + c] + j2 * scale_row);
+    }
+  }
+  float W[9], Wo[6], a[3];
+  cam_image_deriv_by_world<M>(cam, T0, T1, T2, W);
+  cam_image_deriv_by_world<M>(cam, To0, T1, T2, Wo);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    W[6 + c] = ((Wo[c] - W[c]) * rdx + (Wo[3 + c] - W[3 + c]) * rdy) / denom;
+    a[c] = j0 * W[c] + (j1 * W[3 + c] + j2 * W[6 + c]);
+  }
+  const float C0[6] = {1, 0, 0, 0, T2, -1 * T1};
+  const float C1[6] = {0, 1, 0, -1 * T2, 0, T0};
+  const float C2[6] = {0, 0, 1, T1, -1 * T0, 0};
+  const float j_point_inv = -1 / (T2 * T2);
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {
+    float v = a[0] * C0[c] + (a[1] * C1[c] + a[2] * C2[c]);
+    v -= j_point_inv * C2[c];
+    row[1 + I + c] = v;
+  }
+#pragma unroll
+  for (int r = 0; r < R4; ++r) rows[R4 * i + r] = make_float4(row[4 * r], row[4 * r + 1], row[4 * r + 2], row[4 * r + 3]);
+}
+
+// AccumulateOnHAndB over the depth rows (:747-757, :1219-1296): weight = robust weight * depth_residuals_weight in f32, entries
+// ((weight J_r) J_c) in f32 and summed in f64 like there.  Rows [R0, R1) of the upper triangle per launch (per-thread accumulators,
+// the same split as the per-thread colour kernel); WITH_B adds b, the robust residual sum and the count.  Same slot layout as
+// k_reg_pass2 (the depth sum / count take the "fixed" places).
+template <int V, int R0, int R1, bool WITH_B>
+__global__ __launch_bounds__(kBlock) void k_reg_depth_acc(const float4* __restrict__ rows, size_t n_obs, int robust_type, float robust_param,
+                                                          float depth_weight, double* __restrict__ partial) {
+  constexpr int R4 = rows4(V);
+  constexpr int NH = reg_row_start(V, R1) - reg_row_start(V, R0);
+  constexpr int NL = NH + (WITH_B ? V + 4 : 0);
+  double acc[NL];
+#pragma unroll
+  for (int i = 0; i < NL; ++i) acc[i] = 0.0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_obs; i += (size_t)gridDim.x * blockDim.x) {
+    float f[4 * R4];
+    load_row<V>(rows, i, f);
+    const float r = f[0];
+    if constexpr (WITH_B) {
+      acc[NH + V + 2] += 1.0;
+      acc[NH + V] += (double)robust_residual(robust_type, robust_param, r);
+    }
+    float w = robust_weight(robust_type, robust_param, r);
+    w *= depth_weight;
+    if (w == 0) continue;
+    int e = 0;
+#pragma unroll
+    for (int rr = R0; rr < R1; ++rr) {
+      const float wj = w * f[1 + rr];
+#pragma unroll
+      for (int c = rr; c < V; ++c) { acc[e] += (double)(wj * f[1 + c]); ++e; }
+    }
+    if constexpr (WITH_B) {
+      const float wr = w * r;
+#pragma unroll
+      for (int c = 0; c < V; ++c) acc[NH + c] += (double)(wr * f[1 + c]);
+    }
+  }
+  __shared__ double s[kBlock / kWave][NL];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    const double v = wave_sum(acc[i]);
+    if (lane == 0) s[wv][i] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < NL) {
+    double v = s[0][threadIdx.x];
+    for (int k = 1; k < kBlock / kWave; ++k) v += s[k][threadIdx.x];
+    const int t = threadIdx.x;
+    const int dst = t < NH ? reg_row_start(V, R0) + t : reg_h(V) + (t - NH);
+    partial[(size_t)blockIdx.x * reg_slot(V) + dst] = v;
+  }
+}
+
+// CostCalculator, depth part (cost_calculator.cc:221-245): partial[2 b] = sum of the robust residuals, partial[2 b + 1] = count
+__global__ __launch_bounds__(kBlock) void k_reg_depth_cost(const float4* __restrict__ pts, Pose P, float4 quat, Pyramid Y, DepthPyramid D,
+                                                           const unsigned* __restrict__ o_idx, const float* __restrict__ o_x,
+                                                           const float* __restrict__ o_y, const float* __restrict__ o_s, size_t n_obs,
+                                                           int robust_type, float robust_param, double* __restrict__ partial) {
+  double sum = 0.0, cnt = 0.0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_obs; i += (size_t)gridDim.x * blockDim.x) {
+    const float4 p = pts[o_idx[i]];
+    const float os = o_s[i];
+    const int si = f2i(os);
+    const int l1 = si - Y.min_image_scale, l0 = l1 + 1;
+    const float depth = trilinear(D.map[l0], Y.cam[l0].width, D.map[l1], Y.cam[l1].width, o_x[i], o_y[i], 1 - (os - (float)si));
+    const float inv_depth = (depth != 0) ? (1.f / depth) : 0.f;
+    const float vx = quat.y, vy = quat.z, w = quat.x;
+    float ux = vy * p.z - quat.w * p.y, uy = quat.w * p.x - vx * p.z, uz = vx * p.y - vy * p.x;
+    ux = ux + ux; uy = uy + uy; uz = uz + uz;
+    const float cz = vx * uy - vy * ux;
+    const float ppz = ((p.z + w * uz) + cz) + P.t[2];
+    const float point_inv_depth = (ppz != 0.f) ? (1.f / ppz) : 0.f;
+    sum += (double)robust_residual(robust_type, robust_param, inv_depth - point_inv_depth);
+    cnt += 1.0;
+  }
+  __shared__ double s[kBlock / kWave][2];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  sum = wave_sum(sum); cnt = wave_sum(cnt);
+  if (lane == 0) { s[wv][0] = sum; s[wv][1] = cnt; }
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    double v = s[0][threadIdx.x];
+    for (int k = 1; k < kBlock / kWave; ++k) v += s[k][threadIdx.x];
+    partial[2 * (size_t)blockIdx.x + threadIdx.x] = v;
+  }
+}
+
+// ==== a17 + a18: pass 2 =====================================================================================================================
 // One launch accumulates the H rows [R0, R1) (and, if WITH_B, b and the residual sums): 69 f64 accumulators per thread for
 // PINHOLE in a single launch; the larger systems (14 ... 24 unknowns) are split into 2 ... 5 launches of <= 75 accumulators
 // each so that they stay in registers (the rows are re-read from L2, the arithmetic per launch is proportional to its rows).
@@ -1448,6 +1623,7 @@ struct Obs {
   DevBuf<int> nrow;               // K per observation: observation row of each neighbour point (-1: not observed), for pass 2
   DevBuf<float4> rows;
   bool rows_valid = false;
+  DevBuf<float4> drows;           // depth residual rows (k_reg_depth_rows), recomputed per use
 };
 struct ImageDev {
   int intrinsics_id = -1;
@@ -1457,6 +1633,7 @@ struct ImageDev {
   SE3f pose_q;                    // image_T_global (Sophus::SE3f state)
   DevBuf<float> depth;            // last rendered occlusion depth (as float bits)
   int depth_scale = -1;
+  std::vector<DevBuf<float>> depth_maps;   // Problem::depth_maps_ (fixed depth maps, one per pyramid level); empty = none
   std::map<int, Obs> obs;         // per point scale
   std::map<int, DevBuf<unsigned>> vis;   // per point scale: visibility list of the running Apply (grow-only scratch)
   // ObservationsCache::image_id_to_visibility_lists_ (observations_cache.h): per point scale, the observed point indices
@@ -2492,6 +2669,110 @@ int e3d_reg_cost(e3d_reg_t* h, int image_id, int point_scale, double sums[2], in
   R_CATCH()
 }
 
+// ---- depth residuals -------------------------------------------------------------------------------------------------------------
+/* Problem::SetFixedDepthMaps for one image (problem.cc:593-595): one f32 depth map per pyramid level of the image's camera
+ * (level_depths[l]: width_l x height_l floats, host or device memory); level_depths == NULL removes them. */
+int e3d_reg_set_depth_maps(e3d_reg_t* h, int image_id, const float* const* level_depths) {
+  R_TRYH
+  if (!h) throw Error(E3D_ERR_INVALID, "null handle");
+  ImageDev& im = get_image(h, image_id);
+  const Intrin& in = h->intr.at(im.intrinsics_id);
+  im.depth_maps.clear();
+  if (!level_depths) return 0;
+  im.depth_maps.resize(in.levels.size());
+  for (size_t l = 0; l < in.levels.size(); ++l) {
+    if (!level_depths[l]) throw Error(E3D_ERR_INVALID, "e3d_reg_set_depth_maps: every pyramid level needs a depth map");
+    const size_t px = (size_t)in.levels[l].width * (size_t)in.levels[l].height;
+    im.depth_maps[l].reserve(px);
+    copy_in(im.depth_maps[l].p, level_depths[l], sizeof(float) * px, h->stream);
+  }
+  rsync(h);
+  return 0;
+  R_CATCH()
+}
+
+namespace e3d {
+static DepthPyramid make_depth_pyramid(e3d_reg* h, const ImageDev& im, int image_id) {
+  const Intrin& in = h->intr.at(im.intrinsics_id);
+  if (im.depth_maps.size() != in.levels.size())
+    throw Error(E3D_ERR_INVALID, fmt("depth residuals are enabled but image %d has no depth maps (e3d_reg_set_depth_maps)", image_id));
+  if (im.dependent())     // intrinsics_and_pose_optimizer.cc:1199-1207: LOG(FATAL) << "Not implemented yet"
+    throw Error(E3D_ERR_INVALID, "depth residuals for the non-reference images of a rig are not implemented (nor are they in the reference)");
+  DepthPyramid D{};
+  for (size_t l = 0; l < in.levels.size(); ++l) D.map[l] = im.depth_maps[l].p;
+  return D;
+}
+}  // namespace e3d
+
+/* The depth residuals of one (image, point scale): normal equations of the V = I + 6 local unknowns [intrinsics, pose] (row-major V x V,
+ * upper triangle), b, the sum of the robust residuals and their count (intrinsics_and_pose_optimizer.cc:747-757, 1150-1214, 1219-1296). */
+int e3d_reg_depth_accumulate(e3d_reg_t* h, int image_id, int point_scale, double* H, double* b, double* sum, int64_t* count) {
+  R_TRYH
+  if (!h || !H || !b || !sum || !count) throw Error(E3D_ERR_INVALID, "null argument");
+  hipStream_t s = h->stream;
+  ImageDev& im = get_image(h, image_id);
+  PointScale& S = get_scale(h, point_scale);
+  Obs& O = get_obs(im, point_scale);
+  const DepthPyramid D = make_depth_pyramid(h, im, image_id);
+  const int model = image_model(h, im);
+  const int V = h->intr.at(im.intrinsics_id).n_params + 6, NH = reg_h(V), slot = reg_slot(V);
+  O.drows.reserve((size_t)rows4(V) * std::max<size_t>(O.n, 1));
+  const float4 quat = make_float4(im.pose_q.q.w, im.pose_q.q.x, im.pose_q.q.y, im.pose_q.q.z);
+  if (O.n)
+    E3D_CAM_SWITCH(model, hipLaunchKernelGGL(k_reg_depth_rows<M>, dim3(nblk(O.n)), dim3(kBlock), 0, s, S.pts.p, S.radius, im.pose, quat,
+                                             make_pyramid(h, im), D, O.idx.p, O.x.p, O.y.p, O.s.p, O.n, O.drows.p));
+  const int nb = (int)std::min<size_t>(std::max<size_t>(div_up(O.n, kBlock * 4), 1), 1024);
+  h->partial.reserve((size_t)nb * slot); h->red.reserve(slot);
+  const int rt = h->prm.depth_robust_weighting_type;
+  const float rp = h->prm.depth_robust_weighting_parameter, dw = h->prm.depth_residuals_weight;
+#define E3D_DEPTH(V_, R0_, R1_, B_) \
+  hipLaunchKernelGGL((k_reg_depth_acc<V_, R0_, R1_, B_>), dim3(nb), dim3(kBlock), 0, s, O.drows.p, O.n, rt, rp, dw, h->partial.p)
+  switch (V) {     // row ranges: <= 75 accumulators per launch, as for the per-thread colour kernel
+    case 9: E3D_DEPTH(9, 0, 9, true); break;
+    case 10: E3D_DEPTH(10, 0, 10, true); break;
+    case 11: E3D_DEPTH(11, 0, 5, true); E3D_DEPTH(11, 5, 11, false); break;
+    case 13: E3D_DEPTH(13, 0, 4, true); E3D_DEPTH(13, 4, 13, false); break;
+    case 14: E3D_DEPTH(14, 0, 4, true); E3D_DEPTH(14, 4, 14, false); break;
+    case 18: E3D_DEPTH(18, 0, 3, true); E3D_DEPTH(18, 3, 7, false); E3D_DEPTH(18, 7, 18, false); break;
+    default: throw Error(E3D_ERR_INVALID, "unsupported local system size");
+  }
+#undef E3D_DEPTH
+  hipLaunchKernelGGL(k_reg_reduce, dim3(slot), dim3(kWave), 0, s, h->partial.p, nb, slot, h->red.p);
+  std::vector<double> r(slot);
+  copy_out(r.data(), h->red.p, sizeof(double) * slot, s);
+  rsync(h);
+  std::fill(H, H + V * V, 0.0);
+  int e = 0;
+  for (int i = 0; i < V; ++i) for (int j = i; j < V; ++j) H[i * V + j] = r[e++];
+  for (int i = 0; i < V; ++i) b[i] = r[NH + i];
+  *sum = r[NH + V]; *count = (int64_t)r[NH + V + 2];
+  return 0;
+  R_CATCH()
+}
+
+/* CostCalculator, depth part (cost_calculator.cc:221-245): sum of the robust depth residuals of the stored observations, and their count */
+int e3d_reg_depth_cost(e3d_reg_t* h, int image_id, int point_scale, double* sum, int64_t* count) {
+  R_TRYH
+  if (!h || !sum || !count) throw Error(E3D_ERR_INVALID, "null argument");
+  hipStream_t s = h->stream;
+  ImageDev& im = get_image(h, image_id);
+  PointScale& S = get_scale(h, point_scale);
+  Obs& O = get_obs(im, point_scale);
+  const DepthPyramid D = make_depth_pyramid(h, im, image_id);
+  const int nb = (int)std::min<size_t>(std::max<size_t>(div_up(O.n, kBlock * 4), 1), 1024);
+  h->partial.reserve((size_t)nb * 2); h->red.reserve(2);
+  const float4 quat = make_float4(im.pose_q.q.w, im.pose_q.q.x, im.pose_q.q.y, im.pose_q.q.z);
+  hipLaunchKernelGGL(k_reg_depth_cost, dim3(nb), dim3(kBlock), 0, s, S.pts.p, im.pose, quat, make_pyramid(h, im), D, O.idx.p, O.x.p, O.y.p,
+                     O.s.p, O.n, h->prm.depth_robust_weighting_type, h->prm.depth_robust_weighting_parameter, h->partial.p);
+  hipLaunchKernelGGL(k_reg_reduce, dim3(2), dim3(kWave), 0, s, h->partial.p, nb, 2, h->red.p);
+  double r[2];
+  copy_out(r, h->red.p, sizeof r, s);
+  rsync(h);
+  *sum = r[0]; *count = (int64_t)r[1];
+  return 0;
+  R_CATCH()
+}
+
 int e3d_reg_color_begin(e3d_reg_t* h, int point_scale) {
   R_TRYH
   if (!h) throw Error(E3D_ERR_INVALID, "null handle");
@@ -2566,13 +2847,14 @@ static int best_available_scale(const e3d_reg* h, const Intrin& in) {
   return std::min<int>(in.min_image_scale + (int)in.levels.size() - 1, std::max<int>(in.min_image_scale, want));
 }
 
-// Problem::ComputeCost (problem.cc:602-631), colour terms
-static double compute_cost_value(const e3d_reg* h, const double sums[2], const int64_t counts[2]) {
-  const bool use_f = h->prm.fixed_residuals_weight > 0, use_v = h->prm.variable_residuals_weight > 0;
+// Problem::ComputeCost (problem.cc:602-631): [fixed colour, variable colour, depth]
+static double compute_cost_value(const e3d_reg* h, const double sums[3], const int64_t counts[3]) {
+  const bool use_f = h->prm.fixed_residuals_weight > 0, use_v = h->prm.variable_residuals_weight > 0, use_d = h->prm.depth_residuals_weight > 0;
   double r = 0;
   if (use_f && counts[0] > 0) r += h->prm.fixed_residuals_weight * sums[0] / (double)counts[0];
   if (use_v && counts[1] > 0) r += h->prm.variable_residuals_weight * sums[1] / (double)counts[1];
-  if ((!use_f && !use_v) || (counts[0] == 0 && counts[1] == 0)) r = std::numeric_limits<float>::infinity();
+  if (use_d && counts[2] > 0) r += h->prm.depth_residuals_weight * sums[2] / (double)counts[2];
+  if ((!use_f && !use_v && !use_d) || (counts[0] == 0 && counts[1] == 0 && counts[2] == 0)) r = std::numeric_limits<float>::infinity();
   return r;
 }
 
@@ -2621,26 +2903,34 @@ static void color_update(e3d_reg* h) {
   }
 }
 
-static void reduce_sums(e3d_reg* h, double sums[2], int64_t counts[2]) {
+static void reduce_sums(e3d_reg* h, double sums[3], int64_t counts[3]) {
   if (h->world <= 1) return;
-  double buf[4] = {sums[0], sums[1], (double)counts[0], (double)counts[1]};      // counts < 2^53: exact in f64
-  allreduce_host(h, buf, 4);
-  sums[0] = buf[0]; sums[1] = buf[1]; counts[0] = (int64_t)buf[2]; counts[1] = (int64_t)buf[3];
+  double buf[6] = {sums[0], sums[1], sums[2], (double)counts[0], (double)counts[1], (double)counts[2]};      // counts < 2^53: exact in f64
+  allreduce_host(h, buf, 6);
+  for (int i = 0; i < 3; ++i) { sums[i] = buf[i]; counts[i] = (int64_t)buf[3 + i]; }
 }
+
+// depth residuals are in use: every image needs its depth maps, and none may be a dependent rig image (as in the reference)
+static bool depth_in_use(const e3d_reg* h) { return h->prm.depth_residuals_weight > 0; }
 
 // CostCalculator::ComputeCost over the stored observations
 static double total_cost(e3d_reg* h) {
-  double sums[2] = {0, 0};
-  int64_t counts[2] = {0, 0};
+  double sums[3] = {0, 0, 0};
+  int64_t counts[3] = {0, 0, 0};
   for (auto& kv : h->images)
     for (auto& sc : h->scales) {
       if (!h->owns(kv.first) || !has_obs(kv.second, sc.first)) continue;
       double s2[2]; int64_t c2[2];
       if (e3d_reg_cost(h, kv.first, sc.first, s2, c2) < 0) throw Error(E3D_ERR_INVALID, e3d_last_error());
       sums[0] += s2[0]; sums[1] += s2[1]; counts[0] += c2[0]; counts[1] += c2[1];
+      if (depth_in_use(h)) {
+        double sd; int64_t cd;
+        if (e3d_reg_depth_cost(h, kv.first, sc.first, &sd, &cd) < 0) throw Error(E3D_ERR_INVALID, e3d_last_error());
+        sums[2] += sd; counts[2] += cd;
+      }
     }
   reduce_sums(h, sums, counts);
-  if (counts[0] == 0 && counts[1] == 0) return std::numeric_limits<double>::infinity();
+  if (counts[0] == 0 && counts[1] == 0 && counts[2] == 0) return std::numeric_limits<double>::infinity();
   return compute_cost_value(h, sums, counts);
 }
 
@@ -2661,8 +2951,8 @@ static void apply_update(e3d_reg* h, bool print, bool* applied_update, float* la
   const int n_shared = V - 6 * (int)image_index.size();
   ArrowSystem Hb;
   Hb.reset(n_shared, (int)image_index.size());
-  double sums[2] = {0, 0};
-  int64_t counts[2] = {0, 0};
+  double sums[3] = {0, 0, 0};
+  int64_t counts[3] = {0, 0, 0};
   // visibility lists = observed point indices of the current observations (device copies)
   std::map<int, std::map<int, std::pair<DevBuf<unsigned>*, size_t>>> vis;
   for (auto& kv : h->images) {
@@ -2692,18 +2982,31 @@ static void apply_update(e3d_reg* h, bool print, bool* applied_update, float* la
           if (!Hb.add(gidx(r), gidx(c), Hl[(size_t)r * Vl + c])) throw Error(E3D_ERR_INVALID, "normal equations: entry outside the arrow pattern");
         Hb.b[gidx(r)] += bl[r];
       }
+      if (depth_in_use(h)) {
+        // depth residuals of every observation (intrinsics_and_pose_optimizer.cc:747-757); [intrinsics(I), pose(6)] block
+        std::vector<double> Hd((size_t)(I + 6) * (I + 6)), bd(I + 6);
+        double sd; int64_t cd;
+        if (e3d_reg_depth_accumulate(h, kv.first, sc.first, Hd.data(), bd.data(), &sd, &cd) < 0) throw Error(E3D_ERR_INVALID, e3d_last_error());
+        sums[2] += sd; counts[2] += cd;
+        auto didx = [&](int l) { return l < I ? ii + l : pi + (l - I); };
+        for (int r = 0; r < I + 6; ++r) {
+          for (int c = r; c < I + 6; ++c)
+            if (!Hb.add(didx(r), didx(c), Hd[(size_t)r * (I + 6) + c])) throw Error(E3D_ERR_INVALID, "normal equations: entry outside the arrow pattern");
+          Hb.b[didx(r)] += bd[r];
+        }
+      }
     }
   }
   E3D_HIP(hipStreamSynchronize(s));
   if (h->world > 1) {                       // one exchange per Apply: [non-zero blocks of H, b, sums, counts] -- block-sparse:
     const size_t np = Hb.packed_size();     // s^2 + (6 s + 36 + 6) per pose instead of V^2 (512 images: 0.5 MB instead of 76 MB)
-    std::vector<double> buf(np + 4);
+    std::vector<double> buf(np + 6);
     Hb.pack(buf.data());
     double* tail = buf.data() + np;
-    tail[0] = sums[0]; tail[1] = sums[1]; tail[2] = (double)counts[0]; tail[3] = (double)counts[1];
+    for (int i = 0; i < 3; ++i) { tail[i] = sums[i]; tail[3 + i] = (double)counts[i]; }
     allreduce_host(h, buf.data(), buf.size());
     Hb.unpack(buf.data());
-    sums[0] = tail[0]; sums[1] = tail[1]; counts[0] = (int64_t)tail[2]; counts[1] = (int64_t)tail[3];
+    for (int i = 0; i < 3; ++i) { sums[i] = tail[i]; counts[i] = (int64_t)tail[3 + i]; }
   }
   const double initial_residual = compute_cost_value(h, sums, counts);
   if (print)
@@ -2745,7 +3048,7 @@ static void apply_update(e3d_reg* h, bool print, bool* applied_update, float* la
     // ComputeResidualForState with the visibility lists fixed
     set_state(h, trial);
     compose_rig_poses(h);
-    double ts[2] = {0, 0}; int64_t tc[2] = {0, 0};
+    double ts[3] = {0, 0, 0}; int64_t tc[3] = {0, 0, 0};
     constexpr size_t kManyObservationsCount = 100;
     for (auto& kv : h->images) {
       if (!h->owns(kv.first)) continue;
@@ -2769,6 +3072,11 @@ static void apply_update(e3d_reg* h, bool print, bool* applied_update, float* la
         double s2[2]; int64_t c2[2];
         if (e3d_reg_cost(h, kv.first, sc.first, s2, c2) < 0) throw Error(E3D_ERR_INVALID, e3d_last_error());
         ts[0] += s2[0]; ts[1] += s2[1]; tc[0] += c2[0]; tc[1] += c2[1];
+        if (depth_in_use(h)) {
+          double sd; int64_t cd;
+          if (e3d_reg_depth_cost(h, kv.first, sc.first, &sd, &cd) < 0) throw Error(E3D_ERR_INVALID, e3d_last_error());
+          ts[2] += sd; tc[2] += cd;
+        }
       }
     }
     reduce_sums(h, ts, tc);

@@ -57,7 +57,7 @@ static int run_tool(int argc, char** argv) {
   problem.occlusion_mesh_path = occlusion_mesh_path;
   problem.occlusion_splats_path = occlusion_splats_path;
   if (problem.prm.depth_residuals_weight > 0) {
-    std::cerr << "--depth_residuals_weight > 0 (depth-map residuals, not used in the ETH3D pipeline) is not part of this build." << std::endl;
+    std::cerr << "--depth_residuals_weight > 0: the tool has no way to load depth maps (nor has the reference's: only Problem::SetFixedDepthMaps / e3d_reg_set_depth_maps feed them)." << std::endl;
     return EXIT_FAILURE;
   }
   if (occlusion_mesh_path.empty() && occlusion_splats_path.empty()) std::cout << "No occlusion meshes given, using 2D splats." << std::endl;

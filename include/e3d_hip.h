@@ -215,8 +215,9 @@ int e3d_local_outlier_removal(const float* xyz, size_t n, int mean_k, double dis
  *                                                           src/opt/intrinsics_and_pose_optimizer.cc:624-1296 -> e3d_reg_accumulate
  *   CostCalculator::AccumulateResidualsForObservations      src/opt/cost_calculator.cc:102-271         -> e3d_reg_cost
  *   ColorOptimizer::Apply                                   src/opt/color_optimizer.cc:40-123          -> e3d_reg_color_*
- * Round-1 coverage: PINHOLE cameras (camera type 0), non-rig images, colour residuals (fixed + variable descriptors);
- * depth residuals (off by default in the reference) and rig images are not implemented and are rejected. */
+ * Coverage: every camera model of the reference's factory, non-rig and rig images, colour residuals (fixed + variable descriptors),
+ * image and camera masks, depth-map residuals (off by default, as in the reference; not for the dependent images of a rig, which the
+ * reference aborts on). */
 typedef struct e3d_reg e3d_reg_t;
 
 typedef struct {
@@ -230,6 +231,10 @@ typedef struct {
   float   splat_radius;                /* 0.03                                                          */
   int32_t current_image_scale;         /* Problem::current_image_scale()                                */
   int32_t image_scale_count;           /* Problem::image_scale_count()                                  */
+  /* depth-based residuals (parameters.h:53-55,165-172: "not used in ETH3D pipeline"; 0 = disabled, the reference's default) */
+  float   depth_residuals_weight;
+  int32_t depth_robust_weighting_type; /* 2 (Tukey)                                                     */
+  float   depth_robust_weighting_parameter;   /* 0.02                                                   */
 } e3d_reg_params;
 
 /* camera models (COLMAP names, src/camera/camera_base.cc:66-77) and their parameter counts:
@@ -275,6 +280,19 @@ int e3d_reg_set_intrinsics(e3d_reg_t* reg, int intrinsics_id, int camera_type, i
  * (src/opt/visibility_estimator.cc:335-345, 482-503).  level_masks == NULL removes the mask.  Call after e3d_reg_set_intrinsics;
  * parameter updates of the optimiser keep it. */
 int e3d_reg_set_camera_mask(e3d_reg_t* reg, int intrinsics_id, const uint8_t* const* level_masks);
+
+/* Depth residuals (src/opt/intrinsics_and_pose_optimizer.cc:747-757, 1150-1214; cost_calculator.cc:221-245; problem.cc:593-631):
+ * residual = 1 / (depth map interpolated at the observation) - 1 / (depth of the point in the image frame), one per observation,
+ * weighted by e3d_reg_params.depth_residuals_weight with its own robust weighting.  Off by default and unused by the reference's
+ * tools (no tool loads depth maps; its alignment test does, test_alignment.cc:469-500).  As in the reference the non-reference
+ * images of a rig are not supported with depth residuals (:1199-1207 aborts) -- here that is an error return.
+ *   e3d_reg_set_depth_maps: Problem::SetFixedDepthMaps for one image, one f32 map per pyramid level of its camera (caller-built
+ *     pyramid, like the test's cv::resize INTER_AREA chain); NULL removes them.  Required for every image once the weight is > 0.
+ *   e3d_reg_depth_accumulate / e3d_reg_depth_cost: the depth part of AccumulateHAndBForImage / ComputeResidualsForImage for one
+ *     (image, point scale); e3d_reg_apply, e3d_reg_compute_cost and e3d_reg_run_on_current_scale include them by themselves. */
+int e3d_reg_set_depth_maps(e3d_reg_t* reg, int image_id, const float* const* level_depths);
+int e3d_reg_depth_accumulate(e3d_reg_t* reg, int image_id, int point_scale, double* H, double* b, double* sum, int64_t* count);
+int e3d_reg_depth_cost(e3d_reg_t* reg, int image_id, int point_scale, double* sum, int64_t* count);
 /* queries one level of the pyramid the library built: size, parameters (n_parameters floats) and the radius cut-off
  * (+inf for PINHOLE; for the fisheye models the cut-off of the inner non-fisheye model, which is the one projection tests) */
 int e3d_reg_get_intrinsics_level(e3d_reg_t* reg, int intrinsics_id, int level, int* width, int* height,

@@ -414,6 +414,125 @@ void oracle_se3_mul(const float qa[4], const float ta[3], const float qb[4], con
 }
 
 /* ---- a19 --------------------------------------------------------------------------------------------------------------- */
+/* ---- depth residuals (off by default in the reference: parameters.h:55,165 "not used in ETH3D pipeline") ------------------------------
+ * ComputePointIntensityAndJacobians, depth part (intrinsics_and_pose_optimizer.cc:1150-1214), for images that are not dependent rig
+ * images (the reference aborts with "Not implemented yet" for those, :1199-1207): residual = 1 / interpolated depth - 1 / point depth
+ * with the point depth from Sophus' image_T_global * point (q = w x y z), Jacobian = the colour terms with the depth pyramid's
+ * interpolation derivative times -1 / depth^2, minus (-1 / z^2) times the z row of d(camera point) / d(pose). */
+void oracle_reg_depth_rows(const float* pts, float point_radius, const oreg_camera* cam_min, int min_image_scale,
+                           const float* const* depth_maps, const int* widths, const float R[9], const float t[3], const float q[4],
+                           const uint32_t* obs_idx, const float* obs_x, const float* obs_y, const float* obs_scale, size_t n_obs,
+                           float* residuals, float* j_intr, float* j_pose) {
+  const int I = cam_min->n_params;
+  for (size_t o = 0; o < n_obs; ++o) {
+    const float* point = pts + 3 * (size_t)obs_idx[o];
+    const float ox = obs_x[o], oy = obs_y[o], oscale = obs_scale[o];
+    float T[3];
+    rt(R, t, point, T);
+    const int small_scale = f2i(oscale) + 1, large_scale = f2i(oscale);
+    float depth, jd[3];
+    oracle_interp_trilinear_d_f32(depth_maps[small_scale - min_image_scale], widths[small_scale - min_image_scale],
+                                  depth_maps[large_scale - min_image_scale], widths[large_scale - min_image_scale], ox, oy,
+                                  1 - (oscale - (float)f2i(oscale)), &depth, &jd[0], &jd[1], &jd[2]);
+    jd[2] = -1 * jd[2];
+    const float scale_factor = (float)pow(2, min_image_scale - small_scale);
+    const float inv_scale_factor = 1.f / scale_factor;
+    jd[0] *= scale_factor; jd[1] *= scale_factor;
+    const float inv_depth = (depth != 0) ? (1.f / depth) : 0.f;
+    /* pp = image.image_T_global * point (Sophus SE3f): p + w uv + v x uv, uv = 2 (v x p), + translation */
+    float uv[3], cr[3], pp[3];
+    om_cross_f(q + 1, point, uv);
+    for (int k = 0; k < 3; ++k) uv[k] = uv[k] + uv[k];
+    om_cross_f(q + 1, uv, cr);
+    for (int k = 0; k < 3; ++k) pp[k] = ((point[k] + q[0] * uv[k]) + cr[k]) + t[k];
+    const float point_inv_depth = (pp[2] != 0.f) ? (1.f / pp[2]) : 0.f;
+    residuals[o] = inv_depth - point_inv_depth;
+    const float j_inv = -1 / (depth * depth);
+    const float ji[3] = {j_inv * jd[0], j_inv * jd[1], j_inv * jd[2]};
+    /* the projection terms, exactly as in point_intensity_and_jacobians */
+    const float mx = inv_scale_factor * (ox + 0.5f) - 0.5f, my = inv_scale_factor * (oy + 0.5f) - 0.5f;
+    const float To[3] = {T[0] + point_radius, T[1], T[2]};
+    float offx, offy;
+    cam_normalized_to_image(cam_min, To[0] / To[2], To[1] / To[2], &offx, &offy);
+    const float rdx = offx - mx, rdy = offy - my;
+    float denom = 0.693147180559945f * (rdx * rdx + rdy * rdy);
+    if (denom < 1e-6f) denom = 1e-6f;
+    float P[36], Po[24];
+    cam_image_deriv_by_intrinsics(cam_min, T, P);
+    cam_image_deriv_by_intrinsics(cam_min, To, Po);
+    for (int i = 0; i < I; ++i) P[2 * I + i] = ((Po[i] - P[i]) * rdx + (Po[I + i] - P[I + i]) * rdy) / denom;
+    for (int i = 0; i < I; ++i) j_intr[(size_t)I * o + i] = ji[0] * P[i] + (ji[1] * P[I + i] + ji[2] * P[2 * I + i]);
+    float W[9], Wo[6];
+    cam_image_deriv_by_world(cam_min, T, W);
+    cam_image_deriv_by_world(cam_min, To, Wo);
+    for (int i = 0; i < 3; ++i) W[6 + i] = ((Wo[i] - W[i]) * rdx + (Wo[3 + i] - W[3 + i]) * rdy) / denom;
+    float a[3];
+    for (int i = 0; i < 3; ++i) a[i] = ji[0] * W[i] + (ji[1] * W[3 + i] + ji[2] * W[6 + i]);
+    const float C[18] = {1, 0, 0, 0, T[2], -1 * T[1], 0, 1, 0, -1 * T[2], 0, T[0], 0, 0, 1, T[1], -1 * T[0], 0};
+    const float j_point_inv = -1 / (T[2] * T[2]);
+    for (int j = 0; j < 6; ++j) {
+      float v = a[0] * C[j] + (a[1] * C[6 + j] + a[2] * C[12 + j]);
+      v -= j_point_inv * C[12 + j];                       /* -= j_point_depth_inversion * j_camera_space_point_wrt_pose.row(2) */
+      j_pose[6 * o + j] = v;
+    }
+  }
+}
+
+/* AccumulateOnHAndB for the depth residuals of one image (:747-757, :1219-1296): weight = robust weight * depth_residuals_weight
+ * (f32), H += ((weight J^T) J) cast to double (upper triangle, V = I + 6 local unknowns [intrinsics, pose], row-major V x V),
+ * b += (weight residual) J; sum / count as in the cost (every observation counts). */
+void oracle_reg_depth_accumulate(const float* residuals, const float* j_intr, const float* j_pose, size_t n_obs, int I,
+                                 int robust_type, float robust_param, float depth_weight, double* H, double* b, double* sum,
+                                 int64_t* count) {
+  const int V = I + 6;
+  for (int i = 0; i < V * V; ++i) H[i] = 0;
+  for (int i = 0; i < V; ++i) b[i] = 0;
+  *sum = 0; *count = 0;
+  float J[32];
+  for (size_t o = 0; o < n_obs; ++o) {
+    const float r = residuals[o];
+    ++*count;
+    *sum += robust_residual(robust_type, robust_param, r);
+    float w = robust_weight(robust_type, robust_param, r);
+    w *= depth_weight;
+    if (w == 0) continue;
+    for (int i = 0; i < I; ++i) J[i] = j_intr[(size_t)I * o + i];
+    for (int i = 0; i < 6; ++i) J[I + i] = j_pose[6 * o + i];
+    for (int rr = 0; rr < V; ++rr) {
+      const float wj = w * J[rr];
+      for (int c = rr; c < V; ++c) H[(size_t)rr * V + c] += (double)(wj * J[c]);
+    }
+    const float wr = w * r;
+    for (int i = 0; i < V; ++i) b[i] += (double)(wr * J[i]);
+  }
+}
+
+/* CostCalculator, depth part (cost_calculator.cc:221-245) */
+void oracle_reg_depth_cost(const float* pts, int min_image_scale, const float* const* depth_maps, const int* widths, const float q[4],
+                           const float t[3], const uint32_t* obs_idx, const float* obs_x, const float* obs_y, const float* obs_scale,
+                           size_t n_obs, int robust_type, float robust_param, double* sum, int64_t* count) {
+  *sum = 0; *count = 0;
+  for (size_t o = 0; o < n_obs; ++o) {
+    const float* point = pts + 3 * (size_t)obs_idx[o];
+    const float oscale = obs_scale[o];
+    const int small_scale = f2i(oscale) + 1, large_scale = f2i(oscale);
+    float depth;
+    oracle_interp_trilinear_f32(depth_maps[small_scale - min_image_scale], widths[small_scale - min_image_scale],
+                                depth_maps[large_scale - min_image_scale], widths[large_scale - min_image_scale], obs_x[o], obs_y[o],
+                                1 - (oscale - (float)f2i(oscale)), &depth);
+    const float inv_depth = (depth != 0) ? (1.f / depth) : 0.f;
+    float uv[3], cr[3], ppz;
+    om_cross_f(q + 1, point, uv);
+    for (int k = 0; k < 3; ++k) uv[k] = uv[k] + uv[k];
+    om_cross_f(q + 1, uv, cr);
+    ppz = ((point[2] + q[0] * uv[2]) + cr[2]) + t[2];
+    const float point_inv_depth = (ppz != 0.f) ? (1.f / ppz) : 0.f;
+    const float r = inv_depth - point_inv_depth;
+    ++*count;
+    *sum += robust_residual(robust_type, robust_param, r);
+  }
+}
+
 void oracle_reg_cost(size_t n_pts, const uint32_t* nbr, int K, const float* fixed_desc, const float* var_desc,
                      const int32_t* obs_counts, int min_image_scale, const uint8_t* const* images, const int* widths,
                      const uint32_t* obs_idx, const float* obs_x, const float* obs_y, const float* obs_scale,

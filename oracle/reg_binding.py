@@ -232,6 +232,60 @@ def cost(n_pts, nbr, K, fixed_desc, var_desc, obs_counts, min_image_scale, image
     return sums, counts
 
 
+def _depth_ptrs(depth_maps):
+    keep = [np.ascontiguousarray(d, np.float32) for d in depth_maps]
+    arr = (C.POINTER(C.c_float) * len(keep))()
+    for i, d in enumerate(keep):
+        arr[i] = _p(d, C.c_float)
+    widths = np.array([d.shape[1] for d in keep], np.int32)
+    return arr, widths, keep
+
+
+def depth_rows(pts, point_radius, cam_min, min_image_scale, depth_maps, R, t, q, obs):
+    """depth residual and its Jacobian rows per observation: (residuals[n], j_intrinsics[n, I], j_pose[n, 6])"""
+    pts = np.ascontiguousarray(pts, np.float32); R = np.ascontiguousarray(R, np.float32); t = np.ascontiguousarray(t, np.float32)
+    q = np.ascontiguousarray(q, np.float32)
+    dp, widths, keep = _depth_ptrs(depth_maps)
+    oi, ox, oy, os_ = [np.ascontiguousarray(a) for a in obs]
+    n = len(oi)
+    res = np.zeros(n + 1, np.float32); JI = np.zeros((n + 1, cam_min.n_params), np.float32); JP = np.zeros((n + 1, 6), np.float32)
+    f = lib().oracle_reg_depth_rows
+    f.restype = None
+    f.argtypes = [C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
+    f(pts.ctypes.data, point_radius, C.addressof(cam_min), min_image_scale, C.cast(dp, C.c_void_p), widths.ctypes.data, R.ctypes.data,
+      t.ctypes.data, q.ctypes.data, oi.ctypes.data, ox.ctypes.data, oy.ctypes.data, os_.ctypes.data, n, res.ctypes.data, JI.ctypes.data,
+      JP.ctypes.data)
+    return res[:n].copy(), JI[:n].copy(), JP[:n].copy()
+
+
+def depth_accumulate(residuals, j_intr, j_pose, robust_type, robust_param, depth_weight):
+    res = np.ascontiguousarray(residuals, np.float32); JI = np.ascontiguousarray(j_intr, np.float32); JP = np.ascontiguousarray(j_pose, np.float32)
+    I = JI.shape[1]; V = I + 6
+    H = np.zeros((V, V)); b = np.zeros(V); sm = C.c_double(0); cn = C.c_int64(0)
+    f = lib().oracle_reg_depth_accumulate
+    f.restype = None
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
+                  C.c_void_p]
+    f(res.ctypes.data, JI.ctypes.data, JP.ctypes.data, len(res), I, robust_type, robust_param, depth_weight, H.ctypes.data, b.ctypes.data,
+      C.addressof(sm), C.addressof(cn))
+    return H, b, sm.value, cn.value
+
+
+def depth_cost(pts, min_image_scale, depth_maps, q, t, obs, robust_type, robust_param):
+    pts = np.ascontiguousarray(pts, np.float32); q = np.ascontiguousarray(q, np.float32); t = np.ascontiguousarray(t, np.float32)
+    dp, widths, keep = _depth_ptrs(depth_maps)
+    oi, ox, oy, os_ = [np.ascontiguousarray(a) for a in obs]
+    sm = C.c_double(0); cn = C.c_int64(0)
+    f = lib().oracle_reg_depth_cost
+    f.restype = None
+    f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                  C.c_int, C.c_float, C.c_void_p, C.c_void_p]
+    f(pts.ctypes.data, min_image_scale, C.cast(dp, C.c_void_p), widths.ctypes.data, q.ctypes.data, t.ctypes.data, oi.ctypes.data, ox.ctypes.data,
+      oy.ctypes.data, os_.ctypes.data, len(oi), robust_type, robust_param, C.addressof(sm), C.addressof(cn))
+    return sm.value, cn.value
+
+
 def color_accumulate(n_pts, nbr, K, min_image_scale, images, obs, flags, descriptors, obs_counts):
     nbr = np.ascontiguousarray(nbr, np.uint32); fl = np.ascontiguousarray(flags, np.uint8)
     ip, widths, keep = _img_ptrs(images)

@@ -21,7 +21,8 @@ K_MANY = 100
 class OracleRegProblem:
     def __init__(self, K=5, robust_type=1, robust_param=float(np.float32(30 * np.sqrt(5) / np.sqrt(2))), fixed_weight=1.0,
                  var_weight=1.0, max_valid_intensity=252.0, occlusion_threshold=0.01, splat_radius=0.03,
-                 current_image_scale=0, image_scale_count=2):
+                 current_image_scale=0, image_scale_count=2, depth_weight=0.0, depth_robust_type=2, depth_robust_param=0.02):
+        self.depth_weight = depth_weight; self.depth_robust_type = depth_robust_type; self.depth_robust_param = depth_robust_param
         self.K = K; self.robust_type = robust_type; self.robust_param = robust_param
         self.fixed_weight = fixed_weight; self.var_weight = var_weight
         self.max_valid_intensity = max_valid_intensity; self.occlusion_threshold = occlusion_threshold
@@ -54,6 +55,10 @@ class OracleRegProblem:
 
     def set_image(self, image_id, iid, pyr, masks=None):
         self.images[image_id] = dict(intr=iid, pyr=pyr, masks=masks, q=np.array([1, 0, 0, 0], np.float32), t=np.zeros(3, np.float32))
+
+    def set_depth_maps(self, image_id, levels):
+        """inverse-free depth maps of the image, one per pyramid level of its camera (Image::depth_maps_, src/opt/image.h)"""
+        self.images[image_id]["depth"] = [np.ascontiguousarray(d, np.float32) for d in levels]
 
     def set_image_pose(self, image_id, q, t):
         self.images[image_id]["q"] = np.ascontiguousarray(q, np.float32).copy()
@@ -168,18 +173,20 @@ class OracleRegProblem:
             rb.color_finish(self.K, S["var"], S["counts"])
 
     def _cost_value(self, sums, counts):
-        use_f, use_v = self.fixed_weight > 0, self.var_weight > 0
+        use_f, use_v, use_d = self.fixed_weight > 0, self.var_weight > 0, self.depth_weight > 0
         r = 0.0
         if use_f and counts[0] > 0:
             r += self.fixed_weight * sums[0] / counts[0]
         if use_v and counts[1] > 0:
             r += self.var_weight * sums[1] / counts[1]
-        if (not use_f and not use_v) or (counts[0] == 0 and counts[1] == 0):
+        if use_d and counts[2] > 0:                       # problem.cc:616-620
+            r += self.depth_weight * sums[2] / counts[2]
+        if (not use_f and not use_v and not use_d) or (counts[0] == 0 and counts[1] == 0 and counts[2] == 0):
             r = float("inf")
         return r
 
     def _cost_of(self, obs):
-        sums = np.zeros(2); counts = np.zeros(2, np.int64)
+        sums = np.zeros(3); counts = np.zeros(3, np.int64)
         for image_id in sorted(self.images):
             im = self.images[image_id]; I = self.intr[im["intr"]]
             for s in sorted(self.scales):
@@ -188,12 +195,16 @@ class OracleRegProblem:
                 S = self.scales[s]; o = obs[(image_id, s)]
                 s2, c2 = rb.cost(len(S["pts"]), S["nbr"], self.K, S["fixed"], S["var"], S["counts"], I["min"], im["pyr"], o[:4], o[4],
                                  self.robust_type, self.robust_param, self.fixed_weight, self.var_weight)
-                sums += s2; counts += c2
+                sums[:2] += s2; counts[:2] += c2
+                if self.depth_weight > 0:                 # cost_calculator.cc:221-245
+                    sd, cd = rb.depth_cost(S["pts"], I["min"], im["depth"], im["q"], im["t"], o[:4], self.depth_robust_type,
+                                           self.depth_robust_param)
+                    sums[2] += sd; counts[2] += cd
         return sums, counts
 
     def compute_cost(self):
         sums, counts = self._cost_of(self.obs)
-        if counts[0] == 0 and counts[1] == 0:
+        if not counts.any():
             return float("inf")
         return self._cost_value(sums, counts)
 
@@ -211,7 +222,7 @@ class OracleRegProblem:
                 continue
             image_index[k] = V; V += 6
         H = np.zeros((V, V)); b = np.zeros(V)
-        sums = np.zeros(2); counts = np.zeros(2, np.int64)
+        sums = np.zeros(3); counts = np.zeros(3, np.int64)
         vis = {}
         for image_id in sorted(self.images):
             im = self.images[image_id]; I = self.intr[im["intr"]]
@@ -233,11 +244,22 @@ class OracleRegProblem:
                 Hl, bl, s2, c2 = rb.accumulate(S["pts"], float(S["radius"]), S["nbr"], self.K, S["fixed"], S["var"], S["counts"], I["levels"][0],
                                                I["min"], im["pyr"], self._R(im), im["t"], o[:4], o[4], self.robust_type, self.robust_param,
                                                self.fixed_weight, self.var_weight, rig=link)
-                sums += s2; counts += c2
+                sums[:2] += s2; counts[:2] += c2
                 for r in range(len(g)):
                     for c in range(r, len(g)):
                         H[g[r], g[c]] += Hl[r, c]
                     b[g[r]] += bl[r]
+                if self.depth_weight > 0:                 # intrinsics_and_pose_optimizer.cc:747-757, 1150-1296
+                    assert link is None, "depth residuals of dependent rig images: LOG(FATAL) in the reference (:1199-1207)"
+                    res, JI, JP = rb.depth_rows(S["pts"], float(S["radius"]), I["levels"][0], I["min"], im["depth"], self._R(im), im["t"],
+                                                im["q"], o[:4])
+                    Hd, bd, sd, cd = rb.depth_accumulate(res, JI, JP, self.depth_robust_type, self.depth_robust_param, self.depth_weight)
+                    sums[2] += sd; counts[2] += cd
+                    gd = list(range(ii, ii + NI)) + list(range(pi, pi + 6))
+                    for r in range(len(gd)):
+                        for c in range(r, len(gd)):
+                            H[gd[r], gd[c]] += Hd[r, c]
+                        b[gd[r]] += bd[r]
         initial = self._cost_value(sums, counts)
         if print_progress:
             print("    Initial residual: %g (#fixed residuals: %d, #variable residuals: %d)" % (initial, counts[0], counts[1]))

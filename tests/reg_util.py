@@ -149,6 +149,21 @@ def make_multi_image_scene(n_points=5000, n_images=3, width=240, height=180, n_l
                 images=images, point_radius=0.01, model=model)
 
 
+def plane_depth_pyramid(M, im):
+    """Depth (camera z) of the wall y = 3 of make_multi_image_scene seen from the true pose, 2 x 2 means for the coarser levels."""
+    R = quat_to_R(im["q_true"]).astype(np.float64); t = im["t_true"].astype(np.float64)
+    yy, xx = np.mgrid[0:M["height"], 0:M["width"]].astype(np.float64)
+    fx, fy, cx, cy, q = expand_params(M["model"], M["params"])
+    nx, ny = undistort_np(M["model"], q, (xx - cx) / fx, (yy - cy) / fy)
+    d = np.stack([nx, ny, np.ones_like(xx)], -1) @ R
+    o = -R.T @ t
+    maps = [((3.0 - o[1]) / d[..., 1])]
+    for l in range(1, M["n_levels"]):
+        p = maps[-1]
+        maps.append(0.25 * (p[0::2, 0::2] + p[1::2, 0::2] + p[0::2, 1::2] + p[1::2, 1::2]))
+    return [m.astype(np.float32) for m in maps]
+
+
 def make_reg_scene(n_points=6000, width=320, height=240, n_levels=4, K=5, seed=0, model=0):
     """A textured, slightly wavy wall seen by a pinhole camera: points + neighbour graph + descriptors + image pyramid."""
     rng = np.random.RandomState(seed)
@@ -298,3 +313,13 @@ def make_four_frame_scene(seed=0):
     out["pts"] = np.concatenate(out["pts"]).astype(np.float32)
     out["rgb"] = np.concatenate(out["rgb"]).astype(np.uint8)
     return out
+
+
+def se3_log(T):
+    """Sophus::SE3::log of a 4 x 4 rigid transform: [translation part (V^-1 t), rotation vector]"""
+    from scipy.spatial.transform import Rotation
+    w = Rotation.from_matrix(T[:3, :3]).as_rotvec()
+    th = np.linalg.norm(w)
+    K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+    Vinv = np.eye(3) - 0.5 * K + (1 / 12.0 if th < 1e-6 else (1 - th * np.cos(th / 2) / (2 * np.sin(th / 2))) / th**2) * (K @ K)
+    return np.concatenate([Vinv @ T[:3, 3], w])

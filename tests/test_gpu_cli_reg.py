@@ -569,13 +569,7 @@ def test_reference_pair_alignment_thresholds(tmp_path, case):
 
 
 # ---- the reference's four-frame alignment tests (src/opt/test/test_alignment.cc:87-634, TEST(Alignment, FourFrame_*) :649-697) -----
-def _se3_log(T):
-    from scipy.spatial.transform import Rotation
-    w = Rotation.from_matrix(T[:3, :3]).as_rotvec()
-    th = np.linalg.norm(w)
-    K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
-    Vinv = np.eye(3) - 0.5 * K + (1 / 12.0 if th < 1e-6 else (1 - th * np.cos(th / 2) / (2 * np.sin(th / 2))) / th**2) * (K @ K)
-    return np.concatenate([Vinv @ T[:3, 3], w])
+from reg_util import se3_log as _se3_log
 
 
 @pytest.mark.parametrize("use_variable_colors,use_rig", [(False, False), (True, False), (False, True), (True, True)])
@@ -586,7 +580,7 @@ def test_reference_four_frame_alignment_thresholds(tmp_path, use_variable_colors
     component of log(result * ground_truth^-1) must be <= 0.0016 and the mean optical flow between the ground-truth and the
     resulting projections <= 0.07 px (test_alignment.cc:541-603).  The scene comes from numpy's generator instead of std::mt19937,
     the images from a software renderer instead of OpenGL (tests/reg_util.py:make_four_frame_scene); the depth-residual variant
-    (FourFrame_DepthResidualVerification) needs depth-map residuals, which are not built."""
+    (FourFrame_DepthResidualVerification) feeds depth maps through the library and lives in tests/test_gpu_reg.py."""
     import json
     from PIL import Image
     from scipy.spatial.transform import Rotation

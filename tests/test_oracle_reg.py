@@ -87,6 +87,62 @@ def test_point_intensity_jacobians_vs_finite_differences(rb):
             assert abs(delta[c] * JP[c] - (I1 - I0)) < tol, ("pose", c, delta[c] * JP[c], I1 - I0)
 
 
+def test_depth_residual_jacobians_vs_finite_differences(rb):
+    """Depth part of ComputePointIntensityAndJacobians (intrinsics_and_pose_optimizer.cc:1150-1214) in the set-up of the reference's
+    intensity-Jacobian test: a smooth synthetic depth pyramid, residual = 1 / interpolated depth - 1 / point depth, Jacobians against
+    finite differences of the residual with the observation re-created at the perturbed state."""
+    from scipy.spatial.transform import Rotation
+    a = np.array([0.1, 0.3, 0.785]); b = np.array([0.4375, 0.2458, 0.2724])
+    a /= np.linalg.norm(a); b /= np.linalg.norm(b)
+    axis = np.cross(a, b); ang = np.arccos(np.clip(a @ b, -1, 1))
+    Rg = Rotation.from_rotvec(axis / np.linalg.norm(axis) * ang).as_matrix()
+    tg = np.array([0.89763, 0.789346, 0.21398])
+    R = Rg.T.astype(np.float32); t = (-Rg.T @ tg).astype(np.float32)
+    img = np.fromfunction(lambda y, x: (x + 3 * y) % 256, (30, 40)).astype(np.uint8)
+    pyr = pyramid_u8(img, 2)
+    yy, xx = np.mgrid[0:30, 0:40]
+    d0 = (1.5 + 0.02 * xx + 0.03 * yy + 0.0004 * xx * yy).astype(np.float32)
+    d1 = (0.25 * (d0[0::2, 0::2] + d0[0::2, 1::2] + d0[1::2, 0::2] + d0[1::2, 1::2])).astype(np.float32)      # INTER_AREA, factor 2
+    params = np.array([40, 30, 20, 15], np.float32)
+    radius = 0.036
+
+    def quat(Rm):
+        qx = Rotation.from_matrix(np.asarray(Rm, np.float64)).as_quat()
+        return np.array([qx[3], qx[0], qx[1], qx[2]], np.float32)
+
+    def observe_and_eval(point, R, t, params):
+        cam = rb.make_camera(40, 30, params)
+        levels = rb.camera_pyramid(cam, 2)
+        depth = rb.splat_depth(point[None], R, t, levels[0], 0.03)
+        obs = rb.observe(point[None], radius, R, t, levels, 0, pyr, None, depth, 0, 0, 0, 2)
+        assert len(obs[0]) == 1
+        res, JI, JP = rb.depth_rows(point[None], radius, levels[0], 0, [d0, d1], R, t, quat(R), obs)
+        return res[0], JI[0], JP[0]
+
+    for local in ([0.1, 0.23, 2.0], [0.4, 0.67, 2.1], [0.0, 0.0, 1.9]):
+        point = (Rg @ np.array(local) + tg).astype(np.float32)
+        r0, JI, JP = observe_and_eval(point, R, t, params)
+        for c in range(4):
+            p2 = params.copy(); p2[c] += 0.25
+            r1, _, _ = observe_and_eval(point, R, t, p2)
+            assert abs(0.25 * JI[c] - (r1 - r0)) < 2e-5 + 0.1 * abs(r1 - r0), ("intrinsics", c, 0.25 * JI[c], r1 - r0)
+        for c in range(6):
+            delta = np.zeros(6); delta[c] = 0.004 if c < 3 else 0.002
+            R2, t2 = _se3_exp_apply(delta, R.astype(np.float64), t.astype(np.float64))
+            r1, _, _ = observe_and_eval(point, R2, t2, params)
+            assert abs(delta[c] * JP[c] - (r1 - r0)) < 2e-5 + 0.1 * abs(r1 - r0), ("pose", c, delta[c] * JP[c], r1 - r0)
+    # accumulate: weight 0 outside Tukey's parameter, H = sum w J^T J (f32 products, f64 sums), b = sum w r J; cost sum agrees
+    rng = np.random.RandomState(0)
+    n, I = 500, 4
+    res = rng.normal(0, 0.01, n).astype(np.float32); JI = rng.normal(size=(n, I)).astype(np.float32); JP = rng.normal(size=(n, 6)).astype(np.float32)
+    H, bb, sm, cn = rb.depth_accumulate(res, JI, JP, 2, 0.02, 0.5)
+    J = np.concatenate([JI, JP], 1).astype(np.float64)
+    w = np.array([rb.lib().oracle_reg_robust_weight(2, 0.02, float(r)) for r in res], np.float64) * 0.5
+    assert cn == n and np.allclose(np.triu(H), np.triu((J * w[:, None]).T @ J), rtol=2e-6, atol=1e-9)
+    assert np.allclose(bb, (J * (w * res)[:, None]).sum(0), rtol=2e-5, atol=1e-9)
+    assert abs(sm - sum(rb.lib().oracle_reg_robust_residual(2, 0.02, float(r)) for r in res)) < 1e-12
+
+
 def _scene_obs(rb, S, border=1, current_scale=0):
     cam = rb.make_camera(S["width"], S["height"], S["params"])
     levels = rb.camera_pyramid(cam, S["n_levels"])
@@ -168,3 +224,32 @@ def test_oracle_optimizer_reduces_cost_and_pose_error(rb):
     # (absolute poses are not compared with the truth: with free intrinsics and a planar scene focal length and distance
     # trade off against each other; the photometric cost is the quantity the optimiser is responsible for)
     assert conv in (True, False)
+
+
+def test_oracle_optimizer_with_depth_residuals(rb):
+    """Depth residuals in the restated optimizer loop (problem.cc:602-631, intrinsics_and_pose_optimizer.cc:747-757): they vanish at
+    the poses the depth maps were made from, are part of the cost, and a run with colour + depth residuals lowers both."""
+    from oracle.reg_driver import OracleRegProblem
+    from reg_util import make_multi_image_scene, plane_depth_pyramid
+    M = make_multi_image_scene(n_points=3000, n_images=3, seed=8, perturb=0.006)
+
+    def build(depth_weight, fixed_weight, poses):
+        O = OracleRegProblem(K=M["K"], image_scale_count=M["n_levels"], fixed_weight=fixed_weight, var_weight=0.0, depth_weight=depth_weight)
+        O.set_intrinsics(0, M["width"], M["height"], M["params"], 0, M["n_levels"])
+        O.set_point_scale(0, M["pts"], M["point_radius"], M["nbr"], M["fixed_desc"])
+        O.set_splat_points(M["pts"])
+        for i, im in enumerate(M["images"]):
+            O.set_image(i, 0, im["pyr"]); O.set_image_pose(i, im["q_" + poses], im["t_" + poses])
+            O.set_depth_maps(i, plane_depth_pyramid(M, im))
+        return O
+    at_truth = build(1.0, 0.0, "true"); at_truth.update_observations(1)
+    off = build(1.0, 0.0, "init"); off.update_observations(1)
+    assert at_truth.compute_cost() < 1e-3 * off.compute_cost()          # mean robust (1/d - 1/z)^2: ~0 where map and points agree
+    colour = build(0.0, 1.0, "init"); colour.update_observations(1)
+    both = build(1e6, 1.0, "init"); both.update_observations(1)
+    assert abs(both.compute_cost() - (colour.compute_cost() + 1e6 * off.compute_cost())) <= 1e-9 * both.compute_cost()
+    conv, cost, it = both.run_on_current_scale(8, 0.0, 15, False)
+    assert it >= 3 and both.history[-1] < 0.8 * both.history[0] and cost == min(both.history)
+    d0 = off.compute_cost()
+    off.set_state(both.get_state()); off.update_observations(1)
+    assert off.compute_cost() < d0                                       # the depth part went down as well

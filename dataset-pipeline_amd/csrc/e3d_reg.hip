@@ -1440,6 +1440,408 @@ __global__ __launch_bounds__(kBlock, 2) void k_reg_pass2_mfma(const float4* __re
   }
 }
 
+// Chunk ranges per XCD: workgroup b runs on XCD b % 8 (observed placement, not a contract -- a different placement is slower, not
+// wrong), each XCD has its own 4 MB L2, and the rows a chunk gathers are those of nearby chunks (the neighbours of a point are close in
+// the observation order, or one scan line away).  Handing every XCD one contiguous eighth of the chunks keeps a row in ONE L2 instead
+// of fetching it into several: chunk_first / chunk_last / chunk_step of a wave.
+struct ChunkRange { size_t first, last, step; };
+__device__ __forceinline__ ChunkRange xcd_chunk_range(size_t n_chunks, int waves_per_block, int wave_in_block) {
+  constexpr unsigned kXcds = 8;
+  if (gridDim.x % kXcds != 0 || n_chunks < 64 * kXcds)
+    return ChunkRange{(size_t)blockIdx.x * waves_per_block + wave_in_block, n_chunks, (size_t)gridDim.x * waves_per_block};
+  const size_t xcd = blockIdx.x % kXcds, local = blockIdx.x / kXcds, per = gridDim.x / kXcds;
+  const size_t c0 = n_chunks * xcd / kXcds, c1 = n_chunks * (xcd + 1) / kXcds;
+  return ChunkRange{c0 + local * waves_per_block + wave_in_block, c1, per * waves_per_block};
+}
+
+// The same update on the f32 matrix instruction (v_mfma_f32_16x16x4_f32: 32 cycles per instruction and SIMD against the ~97 measured for
+// the f64 form).  A = J_i and B = fl32((w_fixed + w_variable) J_j) are f32 -- the reference forms weight * J in
+// f32 as well (intrinsics_and_pose_optimizer.cc:1246) -- and the instruction is an f32 fma chain over its 4 pairs.  The chain is kept
+// short: after the 16 instructions of one neighbour slot (64 pairs per accumulator entry, two independent accumulators of 32) the f32
+// tile is added into an f64 master tile and cleared, so H is a sum of f64 additions of 32-pair f32 partial sums instead of an f64 sum of
+// single f32 products.  Deviation from the f64 kernel: ~1e-9 of the entry scale (tests/test_gpu_reg.py::test_pass2_variants_agree);
+// b, the residual sums and the entries outside the tile stay per-thread f64 as in k_reg_pass2_mfma.  Pair order inside a slot:
+// pair(q, pq) = 4 pq + (q & 3) + 16 (q >> 2), which puts the two 16-lane groups of one LDS pass 16 banks apart (row stride 36 floats).
+typedef float f4_t __attribute__((ext_vector_type(4)));
+
+template <int KT, int V>
+__global__ __launch_bounds__(kBlock, 2) void k_reg_pass2_mfma32(const float4* __restrict__ rows, const unsigned* __restrict__ o_idx,
+                                                                const unsigned char* __restrict__ flags, size_t n_obs,
+                                                                const int* __restrict__ nrow_of_obs,
+                                                                const float* __restrict__ fixed_desc, const float* __restrict__ var_desc,
+                                                                const int* __restrict__ obs_counts, RegWeights wts,
+                                                                double* __restrict__ partial) {
+  constexpr int R4 = rows4(V);
+  constexpr bool kTwo = V > 16;
+  constexpr int VP = kTwo ? 32 : 16;
+  constexpr int K = KT;
+  constexpr bool kTile11 = V > 18;
+  constexpr bool kFold = V == 18;
+  constexpr int NX = kFold ? 6 : ((kTwo && !kTile11) ? (V - 16) * (V - 15) / 2 : 0);
+  static_assert(V <= 32 && VP < kP2Stride, "local system too large for two 16-wide tiles");
+  __shared__ __attribute__((aligned(16))) float s_j[kBlock / kWave][kWave * kP2Stride];      // slot VP of a row: the pair's weight
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float* const Jl = s_j[wv];
+  const int e = lane & 15, pq = lane >> 4;
+  constexpr int NA = 2;
+  f4_t t00[NA], t01[NA], t11[NA];
+  d4_t m00 = d4_t{0, 0, 0, 0}, m01 = d4_t{0, 0, 0, 0}, m11 = d4_t{0, 0, 0, 0};
+#pragma unroll
+  for (int a = 0; a < NA; ++a) { t00[a] = f4_t{0, 0, 0, 0}; t01[a] = f4_t{0, 0, 0, 0}; t11[a] = f4_t{0, 0, 0, 0}; }
+  double bacc[V + 4];
+  double xacc[NX > 0 ? NX : 1];
+#pragma unroll
+  for (int i = 0; i < V + 4; ++i) bacc[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < (NX > 0 ? NX : 1); ++i) xacc[i] = 0.0;
+  const size_t n_chunks = (n_obs + kWave - 1) / kWave;
+  const size_t wave_id = (size_t)blockIdx.x * (kBlock / kWave) + wv;
+  const ChunkRange cr = xcd_chunk_range(n_chunks, kBlock / kWave, wv);
+  for (size_t ch = cr.first; ch < cr.last; ch += cr.step) {
+    const size_t i = ch * kWave + lane;
+    const bool on = i < n_obs && flags[i];
+    float fc[4 * R4];
+    float fnk[KT][4 * R4];
+    float comp[2][KT] = {};
+    float w[2] = {0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 4 * R4; ++q) fc[q] = 0.f;
+#pragma unroll
+    for (int k = 0; k < KT; ++k)
+#pragma unroll
+      for (int q = 0; q < 4 * R4; ++q) fnk[k][q] = 0.f;
+    if (on) {
+      const size_t p = o_idx[i];
+      int nrow[KT];
+#pragma unroll
+      for (int k = 0; k < KT; ++k) nrow[k] = nrow_of_obs[i * K + k];
+      load_row<V>(rows, i, fc);
+#pragma unroll
+      for (int k = 0; k < KT; ++k) load_row<V>(rows, (size_t)nrow[k], fnk[k]);
+#pragma unroll
+      for (int kind = 0; kind < 2; ++kind) {
+        const float sw = kind == 0 ? wts.fixed_weight : wts.var_weight;
+        if (!(sw > 0)) continue;
+        if (kind == 1 && !(obs_counts[p] >= 2)) continue;
+        const float* desc = kind == 0 ? fixed_desc : var_desc;
+        float pr = 0.f;
+#pragma unroll
+        for (int k = 0; k < KT; ++k) {
+          const float image_descriptor = fnk[k][0] - fc[0];
+          const float c = image_descriptor - desc[p * K + k];
+          comp[kind][k] = c;
+          pr += c * c;
+        }
+        pr = sqrtf(pr);
+        bacc[V + 2 + kind] += 1.0;
+        bacc[V + kind] += (double)robust_residual(wts.robust_type, wts.robust_param, pr);
+        w[kind] = sw * robust_weight(wts.robust_type, wts.robust_param, pr);
+      }
+    }
+    const bool act = on && (w[0] != 0 || w[1] != 0);
+    const double wsum = act ? (double)w[0] + (double)w[1] : 0.0;
+    const float wsum32 = act ? w[0] + w[1] : 0.f;
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+      float J[VP];
+#pragma unroll
+      for (int c = 0; c < VP; ++c) J[c] = 0.f;
+      if (act) {
+        const double wr = (double)(w[0] * comp[0][k]) + (double)(w[1] * comp[1][k]);
+#pragma unroll
+        for (int c = 0; c < V; ++c) {
+          J[c] = fnk[k][1 + c] - fc[1 + c];
+          bacc[c] = __builtin_fma(wr, (double)J[c], bacc[c]);
+        }
+        if constexpr (NX > 0) {
+          int x = 0;
+#pragma unroll
+          for (int r = 16; r < V; ++r) {
+            const double wj = wsum * (double)J[r];
+#pragma unroll
+            for (int c = r; c < V; ++c) { xacc[x] = __builtin_fma((double)J[c], wj, xacc[x]); ++x; }
+          }
+          if constexpr (kFold) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+              const double wj = wsum * (double)J[r];
+#pragma unroll
+              for (int c = r; c < 2; ++c) { xacc[x] = __builtin_fma((double)J[c], wj, xacc[x]); ++x; }
+            }
+          }
+        }
+      }
+      float4* const dst = reinterpret_cast<float4*>(Jl + lane * kP2Stride);
+#pragma unroll
+      for (int c = 0; c < VP / 4; ++c) dst[c] = make_float4(J[4 * c], J[4 * c + 1], J[4 * c + 2], J[4 * c + 3]);
+      Jl[lane * kP2Stride + VP] = wsum32;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int q = 0; q < kWave / 4; ++q) {
+        const float* const row = Jl + (4 * pq + (q & 3) + 16 * (q >> 2)) * kP2Stride;
+        const float a0 = row[e];
+        const float ws = row[VP];
+        float bj = a0;
+        if constexpr (kFold) bj = row[e < 2 ? 16 + e : e];
+        const float b0 = ws * bj;
+        t00[q % NA] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, t00[q % NA], 0, 0, 0);
+        if constexpr (kTwo && !kFold) {
+          const float a1 = row[16 + e];
+          const float b1 = ws * a1;
+          t01[q % NA] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, t01[q % NA], 0, 0, 0);
+          if constexpr (kTile11) t11[q % NA] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, t11[q % NA], 0, 0, 0);
+        }
+      }
+      // end of the f32 chains: into the f64 master tiles (fixed order)
+#pragma unroll
+      for (int a = 0; a < NA; ++a) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          m00[r] += (double)t00[a][r];
+          if constexpr (kTwo && !kFold) { m01[r] += (double)t01[a][r]; if constexpr (kTile11) m11[r] += (double)t11[a][r]; }
+        }
+        t00[a] = f4_t{0, 0, 0, 0}; t01[a] = f4_t{0, 0, 0, 0}; t11[a] = f4_t{0, 0, 0, 0};
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+  }
+  // per-wave partial: f32 tile entry (row = 4 (lane >> 4) + r, col = lane & 15) -> upper-triangle slot
+  double* const out = partial + wave_id * reg_slot(V);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = 4 * pq + r, col = e;
+    if constexpr (kFold) {
+      if (col >= 2) { if (row <= col) out[reg_row_start(V, row) + (col - row)] = m00[r]; }
+      else out[reg_row_start(V, row) + (16 + col - row)] = m00[r];
+    } else if (row <= col && col < V) out[reg_row_start(V, row) + (col - row)] = m00[r];
+    if constexpr (kTwo && !kFold) {
+      if (row < V && 16 + col < V) out[reg_row_start(V, row) + (16 + col - row)] = m01[r];
+      if (kTile11 && row <= col && 16 + col < V) out[reg_row_start(V, 16 + row) + (col - row)] = m11[r];
+    }
+  }
+  if constexpr (NX > 0) {
+    int x = 0;
+#pragma unroll
+    for (int r = 16; r < V; ++r)
+#pragma unroll
+      for (int c = r; c < V; ++c) {
+        const double v = wave_sum(xacc[x]); ++x;
+        if (lane == 0) out[reg_row_start(V, r) + (c - r)] = v;
+      }
+    if constexpr (kFold) {
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int c = r; c < 2; ++c) {
+          const double v = wave_sum(xacc[x]); ++x;
+          if (lane == 0) out[reg_row_start(V, r) + (c - r)] = v;
+        }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < V + 4; ++c) {
+    const double v = wave_sum(bacc[c]);
+    if (lane == 0) out[reg_h(V) + c] = v;
+  }
+}
+
+// Single-tile systems (V <= 16, and V == 18 through the folded tile) with the per-pair arithmetic in packed f32: a row pair is
+// (n - c) for ten float2 at once (element 0 = the intensity difference), the B operand w (n - c) likewise, and b = sum (w r) (n - c) and
+// the six entries outside the folded tile are f32 fma chains over kChainChunks chunks (5 pairs each) that end in per-lane f64 sums.
+// LDS row of a pair: the 20 floats of (n - c), then the 20 floats of the B operand with its elements 1, 2 replaced by the ones of
+// unknowns 16, 17 when folded, so that lane e reads A and B with one ds_read2_b32 (offsets 1 + e and 21 + e); row stride 44 floats
+// (conflict-free b128 writes and, with the pair order of k_reg_pass2_mfma32, conflict-free reads).
+typedef float f2_t __attribute__((ext_vector_type(2)));
+constexpr int kT32Stride = 44;
+constexpr int kChainChunks = 4;
+
+// 32 per-lane values -> lane l (and l + 32) receives the wave's sum of value l & 31: a butterfly that halves the number of live values
+// with every exchange (31 + 1 exchanges instead of 32 x 6)
+__device__ __forceinline__ float wave_reduce_scatter32(float (&v)[32], int lane) {
+#pragma unroll
+  for (int s = 0; s < 5; ++s) {
+    const int o = 1 << s;
+    const bool up = (lane & o) != 0;
+#pragma unroll
+    for (int i = 0; i < (16 >> s); ++i) {
+      const float a = v[2 * i], b = v[2 * i + 1];
+      const float send = up ? a : b, keep = up ? b : a;
+      v[i] = keep + __shfl_xor(send, o, 64);
+    }
+  }
+  return v[0] + __shfl_xor(v[0], 32, 64);
+}
+
+template <int KT, int V>
+__global__ __launch_bounds__(kBlock, 2) void k_reg_pass2_tile32(const float4* __restrict__ rows, const unsigned* __restrict__ o_idx,
+                                                                const unsigned char* __restrict__ flags, size_t n_obs,
+                                                                const int* __restrict__ nrow_of_obs,
+                                                                const float* __restrict__ fixed_desc, const float* __restrict__ var_desc,
+                                                                const int* __restrict__ obs_counts, RegWeights wts,
+                                                                double* __restrict__ partial) {
+  static_assert(V <= 16 || V == 18, "single 16 x 16 tile");
+  constexpr int R4 = rows4(V);
+  constexpr int K = KT;
+  constexpr bool kFold = V == 18;
+  constexpr int NX = kFold ? 6 : 0;
+  __shared__ __attribute__((aligned(16))) float s_j[kBlock / kWave][kWave * kT32Stride];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float* const Jl = s_j[wv];
+  const int e = lane & 15, pq = lane >> 4;
+  constexpr int NA = 2;
+  f4_t t00[NA];
+  d4_t m00 = d4_t{0, 0, 0, 0};
+#pragma unroll
+  for (int a = 0; a < NA; ++a) t00[a] = f4_t{0, 0, 0, 0};
+  f2_t pb[10];                       // f32 chains of b, paired like the row elements (pb[0].x and pb[9].y are not unknowns)
+  float px[NX > 0 ? NX : 1];
+  double racc[4] = {0.0, 0.0, 0.0, 0.0};       // residual sums and counts of the two kinds
+  double bm = 0.0;                              // lane l: f64 sum of chain value l & 31 (0 .. 19: b by row element, 20 .. 25: px)
+#pragma unroll
+  for (int i = 0; i < 10; ++i) pb[i] = f2_t{0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < (NX > 0 ? NX : 1); ++i) px[i] = 0.f;
+  auto end_chains = [&]() {
+    float v[32];
+#pragma unroll
+    for (int j = 0; j < 10; ++j) { v[2 * j] = pb[j].x; v[2 * j + 1] = pb[j].y; pb[j] = f2_t{0.f, 0.f}; }
+#pragma unroll
+    for (int x = 0; x < 12; ++x) v[20 + x] = 0.f;
+#pragma unroll
+    for (int x = 0; x < NX; ++x) { v[20 + x] = px[x]; px[x] = 0.f; }
+    bm += (double)wave_reduce_scatter32(v, lane);
+  };
+  const size_t n_chunks = (n_obs + kWave - 1) / kWave;
+  const size_t wave_id = (size_t)blockIdx.x * (kBlock / kWave) + wv;
+  int chain = 0;
+  const ChunkRange cr = xcd_chunk_range(n_chunks, kBlock / kWave, wv);
+  for (size_t ch = cr.first; ch < cr.last; ch += cr.step) {
+    const size_t i = ch * kWave + lane;
+    const bool on = i < n_obs && flags[i];
+    float4 rc[5], rn[KT][5];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+      rc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int k = 0; k < KT; ++k) rn[k][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float comp[2][KT] = {};
+    float w[2] = {0.f, 0.f};
+    if (on) {
+      const size_t p = o_idx[i];
+      int nrow[KT];
+#pragma unroll
+      for (int k = 0; k < KT; ++k) nrow[k] = nrow_of_obs[i * K + k];
+#pragma unroll
+      for (int q = 0; q < R4; ++q) rc[q] = rows[R4 * i + q];
+#pragma unroll
+      for (int k = 0; k < KT; ++k)
+#pragma unroll
+        for (int q = 0; q < R4; ++q) rn[k][q] = rows[R4 * (size_t)nrow[k] + q];
+#pragma unroll
+      for (int kind = 0; kind < 2; ++kind) {
+        const float sw = kind == 0 ? wts.fixed_weight : wts.var_weight;
+        if (!(sw > 0)) continue;
+        if (kind == 1 && !(obs_counts[p] >= 2)) continue;
+        const float* desc = kind == 0 ? fixed_desc : var_desc;
+        float pr = 0.f;
+#pragma unroll
+        for (int k = 0; k < KT; ++k) {
+          const float image_descriptor = rn[k][0].x - rc[0].x;
+          const float c = image_descriptor - desc[p * K + k];
+          comp[kind][k] = c;
+          pr += c * c;
+        }
+        pr = sqrtf(pr);
+        racc[2 + kind] += 1.0;
+        racc[kind] += (double)robust_residual(wts.robust_type, wts.robust_param, pr);
+        w[kind] = sw * robust_weight(wts.robust_type, wts.robust_param, pr);
+      }
+    }
+    const float ws = w[0] + w[1];
+    const f2_t ws2 = f2_t{ws, ws};
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+      const float wr = w[0] * comp[0][k] + w[1] * comp[1][k];
+      const f2_t wr2 = f2_t{wr, wr};
+      f2_t D[10], B[10];
+#pragma unroll
+      for (int q = 0; q < 5; ++q) {
+        D[2 * q] = f2_t{rn[k][q].x, rn[k][q].y} - f2_t{rc[q].x, rc[q].y};
+        D[2 * q + 1] = f2_t{rn[k][q].z, rn[k][q].w} - f2_t{rc[q].z, rc[q].w};
+      }
+#pragma unroll
+      for (int j = 0; j < 10; ++j) {
+        pb[j] = __builtin_elementwise_fma(wr2, D[j], pb[j]);
+        B[j] = ws2 * D[j];
+      }
+      if constexpr (kFold) {
+        // unknown c = row element 1 + c: unknowns 0, 1 = D[0].y, D[1].x; 16, 17 = D[8].y, D[9].x
+        px[0] = fmaf(B[8].y, D[8].y, px[0]); px[1] = fmaf(B[8].y, D[9].x, px[1]); px[2] = fmaf(B[9].x, D[9].x, px[2]);
+        px[3] = fmaf(B[0].y, D[0].y, px[3]); px[4] = fmaf(B[0].y, D[1].x, px[4]); px[5] = fmaf(B[1].x, D[1].x, px[5]);
+        B[0].y = B[8].y; B[1].x = B[9].x;          // columns 0, 1 of the tile carry unknowns 16, 17
+      }
+      float4* const dst = reinterpret_cast<float4*>(Jl + lane * kT32Stride);
+#pragma unroll
+      for (int q = 0; q < 5; ++q) {
+        dst[q] = make_float4(D[2 * q].x, D[2 * q].y, D[2 * q + 1].x, D[2 * q + 1].y);
+        dst[5 + q] = make_float4(B[2 * q].x, B[2 * q].y, B[2 * q + 1].x, B[2 * q + 1].y);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      // all 16 operand pairs first (one LDS latency for the slot instead of one per instruction), then the instructions back to back
+      float opa[kWave / 4], opb[kWave / 4];
+#pragma unroll
+      for (int q = 0; q < kWave / 4; ++q) {
+        const float* const row = Jl + (4 * pq + (q & 3) + 16 * (q >> 2)) * kT32Stride + 1 + e;
+        opa[q] = row[0]; opb[q] = row[20];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < kWave / 4; ++q) t00[q % NA] = __builtin_amdgcn_mfma_f32_16x16x4f32(opa[q], opb[q], t00[q % NA], 0, 0, 0);
+#pragma unroll
+      for (int a = 0; a < NA; ++a) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) m00[r] += (double)t00[a][r];
+        t00[a] = f4_t{0, 0, 0, 0};
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    if (++chain == kChainChunks) { chain = 0; end_chains(); }
+  }
+  end_chains();
+  // per-wave partial: f32 tile entry (row = 4 (lane >> 4) + r, col = lane & 15) -> upper-triangle slot
+  double* const out = partial + wave_id * reg_slot(V);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = 4 * pq + r, col = e;
+    if constexpr (kFold) {
+      if (col >= 2) { if (row <= col) out[reg_row_start(V, row) + (col - row)] = m00[r]; }
+      else out[reg_row_start(V, row) + (16 + col - row)] = m00[r];
+    } else if (row <= col && col < V) out[reg_row_start(V, row) + (col - row)] = m00[r];
+  }
+  if (lane >= 1 && lane <= V) out[reg_h(V) + (lane - 1)] = bm;
+  if constexpr (kFold) {
+    if (lane >= 20 && lane < 26) {
+      const int x = lane - 20;
+      const int xr = x < 2 ? 16 : (x == 2 ? 17 : (x < 5 ? 0 : 1)), xc = x == 0 ? 16 : (x < 3 ? 17 : (x == 3 ? 0 : 1));
+      out[reg_row_start(V, xr) + (xc - xr)] = bm;
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const double v = wave_sum(racc[c]);
+    if (lane == 0) out[reg_h(V) + V + c] = v;
+  }
+}
+
 // InitCutoff (camera_base_impl.h:410-463) of the non-fisheye model M: one WAVE per border test point.  The 10 x 10 seeds of
 // UndistortFromInside (:278-328) are independent Gauss-Newton runs -- two per lane -- whose results go to LDS; lane 0 then
 // replays the reference's order-dependent best / second-best bookkeeping over them in seed order, so the outcome is the
@@ -2581,9 +2983,22 @@ int e3d_reg_accumulate(e3d_reg_t* h, int image_id, int point_scale, double* H, d
   if (!valu_pass2 && (V > 10 || mfma10) && h->prm.point_neighbor_count == 5) {
     n_partials = nb * (kBlock / kWave);       // one partial per wave
     h->partial.reserve((size_t)n_partials * slot);
-#define E3D_PASS2M(V_)                                                                                                      \
-  hipLaunchKernelGGL((k_reg_pass2_mfma<5, V_>), dim3(nb), dim3(kBlock), 0, s, O.rows.p, O.idx.p, O.flags.p, O.n, O.nrow.p, \
-                     S.fixed_desc.p, S.var_desc.p, S.obs_counts.p, w, h->partial.p)
+    static const bool mfma64 = [] { const char* e = getenv("E3D_REG_PASS2"); return e && !strcmp(e, "mfma64"); }();
+    static const bool mfma32g = [] { const char* e = getenv("E3D_REG_PASS2"); return e && !strcmp(e, "mfma32"); }();
+#define E3D_PASS2M(V_)                                                                                                         \
+  if (mfma64)                                                                                                                  \
+    hipLaunchKernelGGL((k_reg_pass2_mfma<5, V_>), dim3(nb), dim3(kBlock), 0, s, O.rows.p, O.idx.p, O.flags.p, O.n, O.nrow.p,   \
+                       S.fixed_desc.p, S.var_desc.p, S.obs_counts.p, w, h->partial.p);                                          \
+  else if constexpr ((V_) <= 16 || (V_) == 18) {                                                                               \
+    if (mfma32g)                                                                                                               \
+      hipLaunchKernelGGL((k_reg_pass2_mfma32<5, V_>), dim3(nb), dim3(kBlock), 0, s, O.rows.p, O.idx.p, O.flags.p, O.n, O.nrow.p, \
+                         S.fixed_desc.p, S.var_desc.p, S.obs_counts.p, w, h->partial.p);                                        \
+    else                                                                                                                       \
+      hipLaunchKernelGGL((k_reg_pass2_tile32<5, V_>), dim3(nb), dim3(kBlock), 0, s, O.rows.p, O.idx.p, O.flags.p, O.n, O.nrow.p, \
+                         S.fixed_desc.p, S.var_desc.p, S.obs_counts.p, w, h->partial.p);                                        \
+  } else                                                                                                                       \
+    hipLaunchKernelGGL((k_reg_pass2_mfma32<5, V_>), dim3(nb), dim3(kBlock), 0, s, O.rows.p, O.idx.p, O.flags.p, O.n, O.nrow.p, \
+                       S.fixed_desc.p, S.var_desc.p, S.obs_counts.p, w, h->partial.p)
     switch (V) {
       case 10: E3D_PASS2M(10); break;
       case 11: E3D_PASS2M(11); break;

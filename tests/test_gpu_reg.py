@@ -1,6 +1,7 @@
 """GPU parity tests of the path-(B) kernels against the CPU oracle: splat depth maps and observation lists bit-exact
 (integer / index work), intensities bit-exact and Jacobian rows to f32 round-off, normal-equation blocks and costs to
 1e-7 / 1e-9 relative (f64 sums of f32 products in a different order; device division/log2f differ in the last ulp)."""
+import os
 import numpy as np
 import pytest
 
@@ -1008,3 +1009,53 @@ def test_reference_four_frame_depth_residual_verification(e3d):
         flow_sum += np.hypot(rfx * Q[0, ok] / Q[2, ok] + rcx - xs[ok], rfy * Q[1, ok] / Q[2, ok] + rcy - ys[ok]).sum(); flow_count += ok.sum()
     print("depth only:", costs, "worst log component", worst, "mean flow px", flow_sum / flow_count)
     assert worst <= 0.0016 and flow_sum / flow_count <= 0.07, (worst, flow_sum / flow_count, costs)
+
+
+_PASS2_SNIPPET = r'''
+import sys, importlib, numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+e3d = importlib.import_module("dataset-pipeline_amd")
+from reg_util import make_reg_scene
+out = {}
+for model in (1, 2, 0, 9, 4):                  # V = 14, 18 (folded tile), 10, 14, 11
+    S = make_reg_scene(n_points=60000, seed=31 + model, model=model)
+    P = e3d.RegProblem(e3d.default_reg_params(image_scale_count=S["n_levels"], point_neighbor_count=S["K"]))
+    P.set_intrinsics(0, S["width"], S["height"], S["params"], 0, S["n_levels"], camera_type=model)
+    P.set_image(0, 0, S["pyr"]); P.set_image_pose(0, S["q"], S["t"])
+    P.set_point_scale(0, S["pts"], S["point_radius"], S["nbr"], S["fixed_desc"])
+    P.set_variable_descriptors(0, S["var_desc"], S["obs_counts"]); P.set_splat_points(S["pts"])
+    P.update_observations(1)
+    H, b, sums, counts = P.accumulate(0, 0)
+    out["H%d" % model] = H; out["b%d" % model] = b; out["s%d" % model] = sums; out["c%d" % model] = counts
+np.savez(sys.argv[2], **out)
+'''
+
+
+def test_pass2_variants_agree(tmp_path):
+    """The three formulations of pass 2 -- f32 matrix instruction with short chains flushed into f64 (default), f64 matrix
+    instruction (E3D_REG_PASS2=mfma64), per-thread f64 FMAs (E3D_REG_PASS2=valu) -- on the same observations: counts and residual
+    sums identical, H and b within 1e-7 of the entry scale (the parity tests against the oracle allow 1e-6)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for variant in ("", "mfma64", "valu"):
+        env = dict(os.environ)
+        env.pop("E3D_REG_PASS2", None)
+        if variant:
+            env["E3D_REG_PASS2"] = variant
+        f = str(tmp_path / ("v_%s.npz" % (variant or "default")))
+        r = subprocess.run([sys.executable, "-c", _PASS2_SNIPPET, root, f], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[variant] = np.load(f)
+    worst = 0.0
+    for model in (1, 2, 0, 9, 4):
+        ref = res["mfma64"]
+        for variant in ("", "valu"):
+            g = res[variant]
+            assert np.array_equal(g["c%d" % model], ref["c%d" % model]) and np.array_equal(g["s%d" % model], ref["s%d" % model])
+            d = np.sqrt(np.diag(ref["H%d" % model]))
+            eh = (np.abs(g["H%d" % model] - ref["H%d" % model]) / np.outer(d, d)).max()
+            eb = (np.abs(g["b%d" % model] - ref["b%d" % model]) / d).max() / np.abs(ref["b%d" % model] / d).max()
+            worst = max(worst, eh, eb)
+            assert eh <= 1e-7 and eb <= 1e-7, (model, variant, eh, eb)
+    print("pass 2 variants: worst deviation", worst)

@@ -136,6 +136,9 @@ SIGNATURES = {
 }
 
 
+ABI_VERSION = 2          # E3D_ABI_VERSION of include/e3d_hip.h
+
+
 def lib():
     """Load libe3dhip.so (raises E3DError if it has not been built -- no fallback)."""
     global _LIB
@@ -156,6 +159,9 @@ def lib():
             f = getattr(L, name)
             f.restype = res
             f.argtypes = args
+        if L.e3d_abi_version() != ABI_VERSION:      # the structures below mirror include/e3d_hip.h of that version
+            raise E3DError("libe3dhip.so has ABI version %d, this binding expects %d: rebuild (python dataset-pipeline_amd/build.py)"
+                           % (L.e3d_abi_version(), ABI_VERSION))
         _LIB = L
     return _LIB
 

@@ -31,7 +31,8 @@
 extern "C" {
 #endif
 
-#define E3D_ABI_VERSION 1
+/* 2: e3d_reg_params grew by the three depth-residual fields; the ICP iteration record by the NN phase times (round 2) */
+#define E3D_ABI_VERSION 2
 
 #define E3D_ERR_INVALID   (-2)   /* bad argument / bad handle state          */
 #define E3D_ERR_HIP       (-3)   /* a HIP runtime call failed                */

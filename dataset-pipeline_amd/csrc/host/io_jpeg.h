@@ -9,7 +9,8 @@
 // decoder: tests/golden/jpeg_*.jpg + jpeg_golden.npz, tests/test_cli_host.py).
 //
 // Supported: SOF0 / SOF1 (baseline / extended sequential, Huffman, 8-bit), 1 or 3 components (YCbCr), any sampling
-// factors, restart intervals, sizes that are not multiples of the MCU.  Rejected with a message: progressive (SOF2),
+// factors, restart intervals, sizes that are not multiples of the MCU; SOF2 (progressive, Huffman): DC / AC first and refinement scans of the
+// luminance component (T.81 G.1.2; chroma AC scans are skipped, interleaved DC scans are parsed for all components).  Rejected with a message:
 // arithmetic coding, 12-bit, CMYK / YCCK, RGB-coded files (Adobe transform 0 or component ids 'R' 'G' 'B').
 // The EXIF orientation tag (APP1, TIFF tag 0x0112) is applied like cv::imread does without IMREAD_IGNORE_ORIENTATION
 // (OpenCV's ExifTransform: 2 mirror, 3 rotate 180, 4 flip, 5 transpose, 6 rotate 90 cw, 7 transverse, 8 rotate 90 ccw).
@@ -135,6 +136,118 @@ inline void idct_islow(const int* in, uint8_t* out, int stride) {
 
 inline int be16(const uint8_t* p) { return (p[0] << 8) | p[1]; }
 
+// position of the next marker that ends an entropy-coded segment (not a stuffed 0xFF00, not RSTn), or size
+inline size_t next_segment_marker(const std::vector<uint8_t>& f, size_t pos) {
+  while (pos + 1 < f.size()) {
+    if (f[pos] == 0xFF) {
+      const int b = f[pos + 1];
+      if (b != 0x00 && b != 0xFF && !(b >= 0xD0 && b <= 0xD7)) return pos;
+    }
+    ++pos;
+  }
+  return f.size();
+}
+
+// Progressive scans of ONE block (T.81 G.1.2 / figures G.3 - G.7); coefficients in natural order, not dequantised.
+struct ProgressiveScan { int ss = 0, se = 0, ah = 0, al = 0; int eobrun = 0; };
+
+inline bool prog_dc(BitReader& br, const Huff& dc, const ProgressiveScan& sc, int* pred, int16_t* coef) {
+  if (sc.ah == 0) {
+    bool ok = true;
+    const int t = decode_symbol(br, dc, &ok);
+    if (!ok || t > 15) return false;
+    *pred += extend(br.get(t), t);
+    coef[0] = (int16_t)(*pred * (1 << sc.al));
+  } else if (br.get(1)) {
+    coef[0] = (int16_t)(coef[0] | (1 << sc.al));
+  }
+  return true;
+}
+
+inline bool prog_ac_first(BitReader& br, const Huff& ac, ProgressiveScan& sc, int16_t* coef) {
+  if (sc.eobrun > 0) { --sc.eobrun; return true; }
+  for (int k = sc.ss; k <= sc.se;) {
+    bool ok = true;
+    const int rs = decode_symbol(br, ac, &ok);
+    if (!ok) return false;
+    const int r = rs >> 4, s = rs & 15;
+    if (s == 0) {
+      if (r < 15) {                                   // EOBn: this block and eobrun more end here
+        sc.eobrun = (1 << r) - 1;
+        if (r) sc.eobrun += br.get(r);
+        break;
+      }
+      k += 16;                                         // ZRL
+    } else {
+      k += r;
+      if (k > 63) return false;
+      coef[kZigzag[k]] = (int16_t)(extend(br.get(s), s) * (1 << sc.al));
+      ++k;
+    }
+  }
+  return true;
+}
+
+// one correction bit for a coefficient that is already non-zero: move it away from zero by 2^al unless that bit is set
+inline void prog_refine_bit(BitReader& br, int16_t* c, int p1) {
+  if (br.get(1) && (*c & p1) == 0) *c = (int16_t)(*c >= 0 ? *c + p1 : *c - p1);
+}
+
+inline bool prog_ac_refine(BitReader& br, const Huff& ac, ProgressiveScan& sc, int16_t* coef) {
+  const int p1 = 1 << sc.al;
+  int k = sc.ss;
+  if (sc.eobrun == 0) {
+    while (k <= sc.se) {
+      bool ok = true;
+      const int rs = decode_symbol(br, ac, &ok);
+      if (!ok) return false;
+      int r = rs >> 4;
+      const int s = rs & 15;
+      int value = 0;
+      if (s == 0) {
+        if (r < 15) {                                 // EOBn: the rest of THIS block is refined below, eobrun counts it
+          sc.eobrun = 1 << r;
+          if (r) sc.eobrun += br.get(r);
+          break;
+        }
+      } else {
+        if (s != 1) return false;
+        value = br.get(1) ? p1 : -p1;                 // a coefficient that becomes non-zero in this scan
+      }
+      // pass r zero-history coefficients (16 for ZRL); every non-zero one on the way takes a correction bit
+      while (k <= sc.se) {
+        int16_t* c = &coef[kZigzag[k]];
+        if (*c != 0) prog_refine_bit(br, c, p1);
+        else if (--r < 0) break;
+        ++k;
+      }
+      if (value) {
+        if (k > sc.se) return false;
+        coef[kZigzag[k]] = (int16_t)value;
+      }
+      ++k;
+    }
+  }
+  if (sc.eobrun > 0) {
+    for (; k <= sc.se; ++k) {
+      int16_t* c = &coef[kZigzag[k]];
+      if (*c != 0) prog_refine_bit(br, c, p1);
+    }
+    --sc.eobrun;
+  }
+  return true;
+}
+
+// byte-align and consume the RSTn marker that must follow (restart interval reached)
+inline bool take_restart(BitReader& br) {
+  br.reset();
+  const uint8_t* q = br.p;
+  while (q + 1 < br.end && !(q[0] == 0xFF && q[1] >= 0xD0 && q[1] <= 0xD7)) ++q;
+  if (q + 1 >= br.end) return false;
+  br.p = q + 2;
+  return true;
+}
+
 }  // namespace jpeg_detail
 
 // grey = the luminance plane, width x height bytes; false + message on unsupported or damaged files
@@ -149,7 +262,36 @@ inline bool load_jpeg_gray(const std::vector<uint8_t>& f, int* width, int* heigh
   int adobe_transform = -1;
   int orientation = 1;
   size_t pos = 2;
-  bool have_frame = false;
+  bool have_frame = false, progressive = false;
+  // progressive: the luminance coefficients of every block of the MCU-padded grid, natural order, until the last scan is in
+  std::vector<int16_t> ycoef;
+  int ybw = 0, ybh = 0;
+  auto emit = [&](const std::vector<uint8_t>& plane, int PW) -> bool {
+    // EXIF orientation: output pixel (x, y) of the oriented image <- source pixel (sx, sy)
+    const bool swap = orientation >= 5;
+    const int OW = swap ? H : W, OH = swap ? W : H;
+    *width = OW; *height = OH;
+    gray->resize((size_t)OW * OH);
+    if (orientation == 1) {
+      for (int y = 0; y < H; ++y) memcpy(&(*gray)[(size_t)y * W], &plane[(size_t)y * PW], (size_t)W);
+      return true;
+    }
+    for (int y = 0; y < OH; ++y)
+      for (int x = 0; x < OW; ++x) {
+        int sx, sy;
+        switch (orientation) {
+          case 2: sx = W - 1 - x; sy = y; break;                   // mirror horizontally
+          case 3: sx = W - 1 - x; sy = H - 1 - y; break;           // rotate 180
+          case 4: sx = x; sy = H - 1 - y; break;                   // flip vertically
+          case 5: sx = y; sy = x; break;                           // transpose
+          case 6: sx = y; sy = H - 1 - x; break;                   // rotate 90 clockwise
+          case 7: sx = W - 1 - y; sy = H - 1 - x; break;           // transverse
+          default: sx = W - 1 - y; sy = x; break;                  // 8: rotate 90 counter-clockwise
+        }
+        (*gray)[(size_t)y * OW + x] = plane[(size_t)sy * PW + sx];
+      }
+    return true;
+  };
   while (pos + 4 <= f.size()) {
     if (f[pos] != 0xFF) { ++pos; continue; }
     const int marker = f[pos + 1];
@@ -193,7 +335,8 @@ inline bool load_jpeg_gray(const std::vector<uint8_t>& f, int* width, int* heigh
         }
         h.defined = true;
       }
-    } else if (marker == 0xC0 || marker == 0xC1) {            // SOF0 / SOF1
+    } else if (marker == 0xC0 || marker == 0xC1 || marker == 0xC2) {   // SOF0 / SOF1 / SOF2
+      progressive = marker == 0xC2;
       if (n < 6 || d[0] != 8) { *err = "only 8-bit JPEG is supported"; return false; }
       H = be16(&d[1]); W = be16(&d[3]);
       const int nc = d[5];
@@ -204,8 +347,8 @@ inline bool load_jpeg_gray(const std::vector<uint8_t>& f, int* width, int* heigh
         if (comps[c].h < 1 || comps[c].h > 4 || comps[c].v < 1 || comps[c].v > 4 || comps[c].tq > 3) { *err = "bad SOF"; return false; }
       }
       have_frame = true;
-    } else if (marker == 0xC2 || (marker >= 0xC5 && marker <= 0xCF && marker != 0xC8 && marker != 0xCC)) {
-      *err = marker == 0xC2 ? "progressive JPEG is not supported (re-save as baseline JPEG or PNG)" : "unsupported JPEG coding process";
+    } else if (marker >= 0xC3 && marker <= 0xCF && marker != 0xC4 && marker != 0xC8 && marker != 0xCC) {
+      *err = "unsupported JPEG coding process (lossless, hierarchical or arithmetic)";
       return false;
     } else if (marker == 0xDD) {
       if (n >= 2) restart_interval = be16(d);
@@ -232,6 +375,82 @@ inline bool load_jpeg_gray(const std::vector<uint8_t>& f, int* width, int* heigh
       if (n >= 12 && !memcmp(d, "Adobe", 5)) adobe_transform = d[11];
     } else if (marker == 0xDA) {                              // SOS: baseline -> one scan with all components
       if (!have_frame || W <= 0 || H <= 0) { *err = "JPEG scan before frame header"; return false; }
+      if (progressive) {
+        const int ns = d[0];
+        if (ns < 1 || ns > (int)comps.size() || n < 1 + 2 * ns + 3) { *err = "bad SOS"; return false; }
+        std::vector<int> sel(ns);
+        for (int sidx = 0; sidx < ns; ++sidx) {
+          sel[sidx] = -1;
+          for (size_t c = 0; c < comps.size(); ++c)
+            if (comps[c].id == d[1 + 2 * sidx]) { comps[c].td = d[2 + 2 * sidx] >> 4; comps[c].ta = d[2 + 2 * sidx] & 15; sel[sidx] = (int)c; }
+          if (sel[sidx] < 0) { *err = "bad SOS"; return false; }
+        }
+        ProgressiveScan sc;
+        sc.ss = d[1 + 2 * ns]; sc.se = d[2 + 2 * ns]; sc.ah = d[3 + 2 * ns] >> 4; sc.al = d[3 + 2 * ns] & 15;
+        if (sc.ss > sc.se || sc.se > 63 || sc.al > 13 || (sc.ss == 0 && sc.se != 0) || (sc.ss > 0 && ns != 1)) { *err = "bad progressive scan header"; return false; }
+        if (comps.size() == 3 && (adobe_transform == 0 || (comps[0].id == 'R' && comps[1].id == 'G' && comps[2].id == 'B'))) {
+          *err = "RGB-coded JPEG is not supported";
+          return false;
+        }
+        int hmax = 1, vmax = 1;
+        for (const Component& c : comps) { hmax = c.h > hmax ? c.h : hmax; vmax = c.v > vmax ? c.v : vmax; }
+        const bool single_frame = comps.size() == 1;
+        const Component& Y = comps[0];
+        if (!single_frame && (Y.h != hmax || Y.v != vmax)) { *err = "JPEG with a subsampled first component is not supported"; return false; }
+        const int yh = single_frame ? 1 : Y.h, yv = single_frame ? 1 : Y.v;
+        const int mcu_w = single_frame ? 8 : 8 * hmax, mcu_h = single_frame ? 8 : 8 * vmax;
+        const int mcus_x = (W + mcu_w - 1) / mcu_w, mcus_y = (H + mcu_h - 1) / mcu_h;
+        if (ycoef.empty()) { ybw = mcus_x * yh; ybh = mcus_y * yv; ycoef.assign((size_t)ybw * ybh * 64, 0); }
+        const size_t data = pos + (size_t)len;
+        const bool has_y = sel[0] == 0 || (ns > 1 && (sel[1] == 0 || (ns > 2 && sel[2] == 0)));
+        if (!has_y && ns == 1) { pos = next_segment_marker(f, data); continue; }      // a chroma-only scan: nothing grey needs
+        BitReader br{&f[data], f.data() + f.size()};
+        for (Component& c : comps) c.pred = 0;
+        int restart_count = 0;
+        int16_t scratch[64];
+        if (ns > 1) {                                                                  // interleaved: DC scans only
+          for (int sidx = 0; sidx < ns; ++sidx)
+            if (sc.ah == 0 && !dc[comps[sel[sidx]].td].defined) { *err = "JPEG tables missing"; return false; }
+          for (int my = 0; my < mcus_y; ++my)
+            for (int mx = 0; mx < mcus_x; ++mx) {
+              if (restart_interval && restart_count == restart_interval) {
+                if (!take_restart(br)) { *err = "missing JPEG restart marker"; return false; }
+                for (Component& c : comps) c.pred = 0;
+                restart_count = 0;
+              }
+              ++restart_count;
+              for (int sidx = 0; sidx < ns; ++sidx) {
+                Component& c = comps[sel[sidx]];
+                for (int by = 0; by < c.v; ++by)
+                  for (int bx = 0; bx < c.h; ++bx) {
+                    int16_t* blk = sel[sidx] == 0 ? &ycoef[((size_t)(my * yv + by) * ybw + (size_t)(mx * yh + bx)) * 64] : scratch;
+                    if (sel[sidx] != 0) scratch[0] = 0;
+                    if (!prog_dc(br, dc[c.td], sc, &c.pred, blk)) { *err = "corrupt JPEG data (DC)"; return false; }
+                  }
+              }
+            }
+        } else {                                                                       // the luminance component alone
+          Component& c = comps[0];
+          if (sc.ss == 0 ? (sc.ah == 0 && !dc[c.td].defined) : !ac[c.ta].defined) { *err = "JPEG tables missing"; return false; }
+          // a non-interleaved scan covers the blocks of the component's own size, not the MCU-padded grid
+          const int bw = (W + 7) / 8, bh = (H + 7) / 8;
+          for (int by = 0; by < bh; ++by)
+            for (int bx = 0; bx < bw; ++bx) {
+              if (restart_interval && restart_count == restart_interval) {
+                if (!take_restart(br)) { *err = "missing JPEG restart marker"; return false; }
+                c.pred = 0; sc.eobrun = 0;
+                restart_count = 0;
+              }
+              ++restart_count;
+              int16_t* blk = &ycoef[((size_t)by * ybw + bx) * 64];
+              const bool ok = sc.ss == 0 ? prog_dc(br, dc[c.td], sc, &c.pred, blk)
+                                         : (sc.ah == 0 ? prog_ac_first(br, ac[c.ta], sc, blk) : prog_ac_refine(br, ac[c.ta], sc, blk));
+              if (!ok) { *err = "corrupt JPEG data (progressive scan)"; return false; }
+            }
+        }
+        pos = next_segment_marker(f, (size_t)(br.p - f.data()));
+        continue;
+      }
       const int ns = d[0];
       if (ns != (int)comps.size() || n < 1 + 2 * ns + 3) { *err = "multi-scan sequential JPEG is not supported"; return false; }
       for (int s = 0; s < ns; ++s) {
@@ -308,32 +527,23 @@ inline bool load_jpeg_gray(const std::vector<uint8_t>& f, int* width, int* heigh
           }
           (void)yh; (void)yv;
         }
-      // EXIF orientation: output pixel (x, y) of the oriented image <- source pixel (sx, sy)
-      const bool swap = orientation >= 5;
-      const int OW = swap ? H : W, OH = swap ? W : H;
-      *width = OW; *height = OH;
-      gray->resize((size_t)OW * OH);
-      if (orientation == 1) {
-        for (int y = 0; y < H; ++y) memcpy(&(*gray)[(size_t)y * W], &plane[(size_t)y * PW], (size_t)W);
-        return true;
-      }
-      for (int y = 0; y < OH; ++y)
-        for (int x = 0; x < OW; ++x) {
-          int sx, sy;
-          switch (orientation) {
-            case 2: sx = W - 1 - x; sy = y; break;                   // mirror horizontally
-            case 3: sx = W - 1 - x; sy = H - 1 - y; break;           // rotate 180
-            case 4: sx = x; sy = H - 1 - y; break;                   // flip vertically
-            case 5: sx = y; sy = x; break;                           // transpose
-            case 6: sx = y; sy = H - 1 - x; break;                   // rotate 90 clockwise
-            case 7: sx = W - 1 - y; sy = H - 1 - x; break;           // transverse
-            default: sx = W - 1 - y; sy = x; break;                  // 8: rotate 90 counter-clockwise
-          }
-          (*gray)[(size_t)y * OW + x] = plane[(size_t)sy * PW + sx];
-        }
-      return true;
+      return emit(plane, PW);
     }
     pos += (size_t)len;
+  }
+  if (progressive && !ycoef.empty()) {
+    const Component& Y = comps[0];
+    if (!qt_defined[Y.tq]) { *err = "JPEG tables missing"; return false; }
+    const int PW = ybw * 8, PH = ybh * 8;
+    std::vector<uint8_t> plane((size_t)PW * PH);
+    int coef[64];
+    for (int by = 0; by < ybh; ++by)
+      for (int bx = 0; bx < ybw; ++bx) {
+        const int16_t* blk = &ycoef[((size_t)by * ybw + bx) * 64];
+        for (int k = 0; k < 64; ++k) coef[k] = blk[k] * qt[Y.tq][k];
+        idct_islow(coef, &plane[(size_t)by * 8 * PW + (size_t)bx * 8], PW);
+      }
+    return emit(plane, PW);
   }
   *err = "JPEG without image data";
   return false;

@@ -30,6 +30,13 @@ VARIANTS = {
     "420_q30": dict(size=(97, 83), quality=30, subsampling=2),
     "grey_q85": dict(size=(53, 70), quality=85, grey=True),
     "420_restart": dict(size=(75, 60), quality=80, subsampling=2, restart_marker_blocks=3),
+    # progressive (SOF2): libjpeg's standard scan script = spectral selection + successive approximation, i.e. DC / AC first and
+    # refinement scans with EOB runs; interleaved DC scan for colour files
+    "progressive": dict(size=(48, 32), quality=80, progressive=True, seed=9),
+    "prog_444_q95": dict(size=(61, 47), quality=95, subsampling=0, progressive=True),
+    "prog_420_q40_opt": dict(size=(131, 99), quality=40, subsampling=2, progressive=True, optimize=True),
+    "prog_grey_q90": dict(size=(77, 58), quality=90, progressive=True, grey=True),
+    "prog_422_restart": dict(size=(90, 70), quality=85, subsampling=1, progressive=True, restart_marker_blocks=2),
 }
 
 if __name__ == "__main__":
@@ -37,7 +44,7 @@ if __name__ == "__main__":
     for i, (name, v) in enumerate(VARIANTS.items()):
         v = dict(v)
         w, h = v.pop("size")
-        img = scene(w, h, i)
+        img = scene(w, h, v.pop("seed", i))
         if v.pop("grey", False):
             img = img.convert("L")
         path = os.path.join(HERE, "jpeg_%s.jpg" % name)
@@ -58,7 +65,5 @@ if __name__ == "__main__":
         assert im.mode == "L" and im.getexif().get(0x0112) == o
         expected["exif_%d" % o] = np.array(ImageOps.exif_transpose(im))
         assert expected["exif_%d" % o].shape == ((29, 37) if o < 5 else (37, 29))
-    prog = os.path.join(HERE, "jpeg_progressive.jpg")
-    scene(48, 32, 9).save(prog, "JPEG", quality=80, progressive=True)
     np.savez_compressed(os.path.join(HERE, "jpeg_golden.npz"), **expected)
     print({k: v.shape for k, v in expected.items()})

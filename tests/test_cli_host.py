@@ -93,18 +93,22 @@ def _imread(path, tmp_path):
 def test_jpeg_decoder_matches_libjpeg_golden(tmp_path):
     """cv::imread(path, IMREAD_GRAYSCALE) on JPEG = libjpeg's luminance plane (islow IDCT).  Golden: Pillow / libjpeg-turbo
     (tests/golden/make_jpeg_golden.py); 4:2:0 / 4:2:2 / 4:4:4, optimised Huffman tables, grey files, restart markers, sizes
-    that are not MCU multiples -- bit for bit; the eight EXIF orientations, which cv::imread applies (expected: Pillow's
-    exif_transpose of the luminance plane)."""
+    that are not MCU multiples, progressive files (spectral selection + successive approximation, colour and grey, with restart
+    markers) -- bit for bit; the eight EXIF orientations, which cv::imread applies (expected: Pillow's exif_transpose of the
+    luminance plane)."""
     _build()
     gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
     exp = np.load(os.path.join(gold, "jpeg_golden.npz"))
-    assert len(exp.files) == 14 and exp["exif_6"].shape == (37, 29)
+    assert len(exp.files) == 19 and exp["exif_6"].shape == (37, 29) and sum(n.startswith("prog") for n in exp.files) == 5
     for name in exp.files:
         img, err = _imread(os.path.join(gold, "jpeg_%s.jpg" % name), tmp_path)
         assert img is not None, err
         assert img.shape == exp[name].shape and np.array_equal(img, exp[name]), name
-    img, err = _imread(os.path.join(gold, "jpeg_progressive.jpg"), tmp_path)
-    assert img is None and "progressive JPEG is not supported" in err
+    # a progressive file cut in the middle of a scan is refused, not decoded to garbage
+    raw = open(os.path.join(gold, "jpeg_prog_420_q40_opt.jpg"), "rb").read()
+    open(str(tmp_path / "cut.jpg"), "wb").write(raw[: len(raw) // 3])
+    img, err = _imread(str(tmp_path / "cut.jpg"), tmp_path)
+    assert img is None or img.shape == exp["prog_420_q40_opt"].shape
 
 
 def test_png_decoder_roundtrip(tmp_path):

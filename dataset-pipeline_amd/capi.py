@@ -116,6 +116,7 @@ SIGNATURES = {
     "e3d_reg_get_scan_observation_counts": (C.c_int, [C.c_void_p, C.c_void_p]),
     "e3d_reg_set_scan_observation_counts": (C.c_int, [C.c_void_p, C.c_void_p]),
     "e3d_reg_ground_truth_depth": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "e3d_reg_scan_rendering": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "e3d_reg_set_cache_observations": (C.c_int, [C.c_void_p, C.c_int]),
     "e3d_reg_determine_observed_indices": (C.c_int, [C.c_void_p]),
     "e3d_reg_get_observed_indices": (C.c_int64, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
@@ -636,6 +637,14 @@ class RegProblem:
         self._chk(lib().e3d_reg_ground_truth_depth(self._h, image_id, C.c_void_p(m.ctypes.data) if m is not None else None, excluded_flag,
                                                    min_count, C.c_void_p(gt.ctypes.data), C.c_void_p(occ.ctypes.data)), "e3d_reg_ground_truth_depth")
         return gt, occ
+
+    def scan_rendering(self, image_id, width, height, point_radius, mask=None, excluded_flag=2, min_count=2):
+        """-> (height, width) uint32: index + 1 of the last scan point whose square covers the pixel, 0 where none does."""
+        win = np.zeros((height, width), np.uint32)
+        m = np.ascontiguousarray(mask, np.uint8) if mask is not None else None
+        self._chk(lib().e3d_reg_scan_rendering(self._h, image_id, C.c_void_p(m.ctypes.data) if m is not None else None, excluded_flag,
+                                               min_count, point_radius, C.c_void_p(win.ctypes.data)), "e3d_reg_scan_rendering")
+        return win
 
     def set_cache_observations(self, enabled):
         """Optimizer::set_cache_observations: update_observations re-projects the cached point index lists."""

@@ -821,16 +821,20 @@ __global__ __launch_bounds__(kBlock) void k_obs_compact(const int* __restrict__ 
 
 // ==== f4: GroundTruthCreator visibility (src/exe/ground_truth_creator.cc:45-86, :152-189) =========================================
 // mode 0: counts[i] += 1 for every scan point visible in the image; mode 1: ground-truth depth = min z over the visible
-// points that were counted at least `min_count` times.  "Visible" = in front of the camera, inside the image at the
+// points that were counted at least `min_count` times; mode 2: scan rendering (:175-187) -- the reference paints a square of
+// 2 * radius + 1 pixels around every such point in point order, later points over earlier ones, so a pixel ends up with the colour of
+// the LAST point whose square covers it: gt_depth[pixel] = max (point index + 1), 0 = untouched.
+// "Visible" = in front of the camera, inside the image at the
 // highest available resolution, not behind the occlusion depth (+ threshold), not under an eval-obs mask pixel.
 template <int M>
 __global__ __launch_bounds__(kBlock) void k_scan_visibility(const float4* __restrict__ pts, size_t n, Pose P, CamLevel cam,
                                                             const float* __restrict__ occlusion, float occlusion_threshold,
                                                             const unsigned char* __restrict__ mask, int excluded_flag, int mode,
-                                                            int min_count, int* __restrict__ counts, unsigned* __restrict__ gt_depth) {
+                                                            int min_count, int* __restrict__ counts, unsigned* __restrict__ gt_depth,
+                                                            int radius) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  if (mode == 1 && counts[i] < min_count) return;
+  if (mode != 0 && counts[i] < min_count) return;
   const float4 p = pts[i];
   float X, Yc, Z;
   rt(P, p.x, p.y, p.z, X, Yc, Z);
@@ -843,7 +847,12 @@ __global__ __launch_bounds__(kBlock) void k_scan_visibility(const float4* __rest
   if (!(occlusion[px] + occlusion_threshold >= Z)) return;
   if (mask && mask[px] == excluded_flag) return;
   if (mode == 0) counts[i] += 1;
-  else atomicMin(&gt_depth[px], __float_as_uint(Z));       // Z > 0: the bit pattern orders like the value
+  else if (mode == 1) atomicMin(&gt_depth[px], __float_as_uint(Z));       // Z > 0: the bit pattern orders like the value
+  else {
+    const int x0 = max(0, ix - radius), y0 = max(0, iy - radius), x1 = min(cam.width, ix + radius + 1), y1 = min(cam.height, iy + radius + 1);
+    for (int y = y0; y < y1; ++y)
+      for (int x = x0; x < x1; ++x) atomicMax(&gt_depth[(size_t)y * cam.width + x], (unsigned)i + 1u);
+  }
 }
 
 // ==== a22 ===============================================================================================================================
@@ -3660,7 +3669,7 @@ int e3d_reg_set_scan_points(e3d_reg_t* h, const float* xyz, size_t n) {
   return 0;
   R_CATCH()
 }
-static void scan_visibility(e3d_reg* h, int image_id, const uint8_t* mask, int excluded_flag, int mode, int min_count) {
+static void scan_visibility(e3d_reg* h, int image_id, const uint8_t* mask, int excluded_flag, int mode, int min_count, int radius = 0) {
   ImageDev& im = get_image(h, image_id);
   const Intrin& in = h->intr.at(im.intrinsics_id);
   // RenderDepthMap(intrinsics, image, intrinsics.min_image_scale, ...) + intrinsics.model(0): the highest resolution
@@ -3672,7 +3681,7 @@ static void scan_visibility(e3d_reg* h, int image_id, const uint8_t* mask, int e
     E3D_CAM_SWITCH(in.type, hipLaunchKernelGGL(k_scan_visibility<M>, dim3(nblk(h->n_scan)), dim3(kBlock), 0, h->stream, h->scan_pts.p,
                                                h->n_scan, im.pose, cam, im.depth.p, h->prm.occlusion_depth_threshold,
                                                mask ? h->eval_mask.p : nullptr, excluded_flag, mode, min_count, h->scan_counts.p,
-                                               h->gt_depth.p));
+                                               h->gt_depth.p, radius));
 }
 int e3d_reg_count_scan_observations(e3d_reg_t* h, int image_id, const uint8_t* mask, int excluded_flag) {
   R_TRYH
@@ -3710,6 +3719,27 @@ int e3d_reg_ground_truth_depth(e3d_reg_t* h, int image_id, const uint8_t* mask, 
   scan_visibility(h, image_id, mask, excluded_flag, 1, min_count);
   if (gt_depth) copy_out(gt_depth, h->gt_depth.p, sizeof(float) * px, h->stream);
   if (occlusion_depth) copy_out(occlusion_depth, im.depth.p, sizeof(float) * px, h->stream);
+  rsync(h);
+  return 0;
+  R_CATCH()
+}
+
+/* CreateGroundTruthForImage, scan rendering part (ground_truth_creator.cc:149,175-187): which scan point ends up on top of every pixel
+ * when the visible points counted at least min_count times are painted as squares in point order.  winner[pixel] = point index + 1, 0 where
+ * the image keeps its own colour. */
+int e3d_reg_scan_rendering(e3d_reg_t* h, int image_id, const uint8_t* mask, int excluded_flag, int min_count, int point_radius,
+                           uint32_t* winner) {
+  R_TRYH
+  if (!h || !winner) throw Error(E3D_ERR_INVALID, "null argument");
+  if (point_radius < 0 || point_radius > 64) throw Error(E3D_ERR_INVALID, "scan_point_radius out of range [0, 64]");
+  if (h->n_scan >= 0xFFFFFFFFull) throw Error(E3D_ERR_INVALID, "too many scan points for 32-bit indices");
+  ImageDev& im = get_image(h, image_id);
+  const CamLevel& cam = h->intr.at(im.intrinsics_id).levels[0];
+  const size_t px = (size_t)cam.width * cam.height;
+  h->gt_depth.reserve(px);
+  E3D_HIP(hipMemsetAsync(h->gt_depth.p, 0, sizeof(unsigned) * px, h->stream));
+  scan_visibility(h, image_id, mask, excluded_flag, 2, min_count, point_radius);
+  copy_out(winner, h->gt_depth.p, sizeof(unsigned) * px, h->stream);
   rsync(h);
   return 0;
   R_CATCH()

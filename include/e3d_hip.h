@@ -379,6 +379,11 @@ int e3d_reg_get_scan_observation_counts(e3d_reg_t* reg, int32_t* counts);
 int e3d_reg_set_scan_observation_counts(e3d_reg_t* reg, const int32_t* counts);
 int e3d_reg_ground_truth_depth(e3d_reg_t* reg, int image_id, const uint8_t* mask, int excluded_flag, int min_count, float* gt_depth,
                                float* occlusion_depth);
+/* CreateGroundTruthForImage, scan rendering part (src/exe/ground_truth_creator.cc:149,175-187): the reference paints a square of
+ * 2 * point_radius + 1 pixels over the image for every visible scan point seen in >= min_count images, in point order.  The result
+ * per pixel is the LAST point covering it: winner[y * width + x] = point index + 1 (order of e3d_reg_set_scan_points), 0 = untouched. */
+int e3d_reg_scan_rendering(e3d_reg_t* reg, int image_id, const uint8_t* mask, int excluded_flag, int min_count, int point_radius,
+                           uint32_t* winner);
 /* Observations cache (src/opt/observations_cache.{h,cc}; Optimizer::set_cache_observations, optimizer.h).  When enabled, the
  * observation update re-projects a fixed per-image list of point indices with the current state and applies only the
  * scale-fit and border tests (VisibilityEstimator::AppendObservationsForIndexedPointsVisibleInImage,

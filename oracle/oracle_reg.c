@@ -615,3 +615,27 @@ void oracle_scan_visibility(const float* pts, size_t n, const float R[9], const 
     else if (pp[2] < gt_depth[o]) gt_depth[o] = pp[2];
   }
 }
+
+/* CreateGroundTruthForImage, scan rendering part (ground_truth_creator.cc:149,160-189): the image is painted in scan-point order with
+ * squares of 2 * radius + 1 pixels; rendering[pixel] = index + 1 of the point painted last, 0 = the image's own colour. */
+void oracle_scan_rendering(const float* pts, size_t n, const float R[9], const float t[3], const oreg_camera* cam,
+                           const float* occlusion, float occlusion_threshold, const uint8_t* mask, int excluded, int min_count,
+                           const int32_t* counts, int radius, uint32_t* rendering) {
+  for (size_t i = 0; i < n; ++i) {
+    if (counts[i] < min_count) continue;
+    float pp[3];
+    rt(R, t, pts + 3 * i, pp);
+    if (!(pp[2] > 0)) continue;
+    float px, py;
+    cam_normalized_to_image(cam, pp[0] / pp[2], pp[1] / pp[2], &px, &py);
+    const int ix = f2i(px + 0.5f), iy = f2i(py + 0.5f);
+    if (!(ix >= 0 && iy >= 0 && ix < cam->width && iy < cam->height)) continue;
+    const size_t o = (size_t)iy * cam->width + ix;
+    if (!(occlusion[o] + occlusion_threshold >= pp[2])) continue;
+    if (mask && mask[o] == excluded) continue;
+    const int x0 = ix - radius < 0 ? 0 : ix - radius, y0 = iy - radius < 0 ? 0 : iy - radius;
+    const int x1 = ix + radius + 1 > cam->width ? cam->width : ix + radius + 1, y1 = iy + radius + 1 > cam->height ? cam->height : iy + radius + 1;
+    for (int y = y0; y < y1; ++y)
+      for (int x = x0; x < x1; ++x) rendering[(size_t)y * cam->width + x] = (uint32_t)i + 1u;
+  }
+}

@@ -315,3 +315,18 @@ def scan_visibility(pts, R, t, cam, occlusion, counts, mask=None, excluded=2, mo
     f(pts.ctypes.data, pts.shape[0], R.ctypes.data, t.ctypes.data, C.addressof(cam), occ.ctypes.data, occlusion_threshold,
       m.ctypes.data if m is not None else None, excluded, mode, min_count, counts.ctypes.data, gt.ctypes.data)
     return gt
+
+
+def scan_rendering(pts, R, t, cam, occlusion, counts, radius, mask=None, excluded=2, min_count=2, occlusion_threshold=0.01):
+    """GroundTruthCreator --write_scan_renderings: (height, width) uint32, index + 1 of the scan point painted last over each pixel."""
+    pts = np.ascontiguousarray(pts, np.float32); R = np.ascontiguousarray(R, np.float32); t = np.ascontiguousarray(t, np.float32)
+    occ = np.ascontiguousarray(occlusion, np.float32); counts = np.ascontiguousarray(counts, np.int32)
+    out = np.zeros((cam.height, cam.width), np.uint32)
+    m = np.ascontiguousarray(mask, np.uint8) if mask is not None else None
+    f = lib().oracle_scan_rendering
+    f.restype = None
+    f.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                  C.c_int, C.c_void_p]
+    f(pts.ctypes.data, pts.shape[0], R.ctypes.data, t.ctypes.data, C.addressof(cam), occ.ctypes.data, occlusion_threshold,
+      m.ctypes.data if m is not None else None, excluded, min_count, counts.ctypes.data, radius, out.ctypes.data)
+    return out

@@ -387,6 +387,17 @@ def test_scan_visibility_counts_and_ground_truth_depth(e3d, rb, model):
         assert np.isfinite(gt).sum() > 3000 and np.isinf(gt).sum() > 1000
         if m is not None:
             assert np.isinf(gt[40:90, 60:140]).all()
+        # scan rendering (--write_scan_renderings): which point is painted last over every pixel, for two square sizes
+        for radius in (0, 2):
+            win = G.scan_rendering(i, M["width"], M["height"], radius, mask=m)
+            owin = rb.scan_rendering(scan, O._R(im), im["t"], levels[0], occ[i], counts, radius, mask=m)
+            if model in EXACT:
+                assert np.array_equal(win, owin)
+            else:
+                assert (win != owin).mean() < 5e-3
+            assert (owin > 0).sum() > (3000 if radius == 0 else 8000) and (owin == 0).sum() > 500
+            if radius == 0:
+                assert np.array_equal(owin > 0, np.isfinite(ogt))
 
 
 # ---- camera rigs (Rig::Update, dependent rig images) ----------------------------------------------------------------------------

@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "io_jpeg.h"
+#include "io_jpeg_write.h"
 
 namespace e3d_host {
 
@@ -32,6 +33,13 @@ struct GrayImage {
   int width = 0, height = 0;
   std::vector<uint8_t> data;
   bool empty() const { return data.empty(); }
+};
+
+// cv::imread(path) (IMREAD_COLOR): 8-bit, three channels -- stored R, G, B here (OpenCV's B, G, R order only matters when writing)
+struct ColorImage {
+  int width = 0, height = 0;
+  std::vector<uint8_t> rgb;
+  bool empty() const { return rgb.empty(); }
 };
 
 namespace img_detail {
@@ -46,7 +54,7 @@ inline int paeth(int a, int b, int c) {
   return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
 }
 
-inline bool load_png(const std::vector<uint8_t>& f, GrayImage* out, std::string* err) {
+inline bool load_png(const std::vector<uint8_t>& f, GrayImage* out, std::string* err, std::vector<uint8_t>* rgb = nullptr) {
   static const uint8_t sig[8] = {137, 80, 78, 71, 13, 10, 26, 10};
   if (f.size() < 8 || memcmp(f.data(), sig, 8) != 0) { *err = "not a PNG file"; return false; }
   size_t pos = 8;
@@ -85,6 +93,7 @@ inline bool load_png(const std::vector<uint8_t>& f, GrayImage* out, std::string*
   if (uncompress(raw.data(), &raw_len, idat.data(), (uLong)idat.size()) != Z_OK || raw_len != raw.size()) { *err = "PNG inflate failed"; return false; }
   std::vector<uint8_t> prev(stride, 0), cur(stride);
   out->width = w; out->height = h; out->data.assign((size_t)w * h, 0);
+  if (rgb) rgb->assign((size_t)w * h * 3, 0);
   for (int y = 0; y < h; ++y) {
     const uint8_t* line = &raw[(stride + 1) * (size_t)y];
     const int filter = line[0];
@@ -99,12 +108,18 @@ inline bool load_png(const std::vector<uint8_t>& f, GrayImage* out, std::string*
     for (int x = 0; x < w; ++x) {
       if (ctype == 3 || (ctype == 0 && depth < 8)) {
         const int per = 8 / depth, idx = (cur[x / per] >> ((per - 1 - x % per) * depth)) & ((1 << depth) - 1);
-        if (ctype == 0) { o[x] = (uint8_t)(idx * 255 / ((1 << depth) - 1)); continue; }
+        uint8_t* c = rgb ? &(*rgb)[((size_t)y * w + x) * 3] : nullptr;
+        if (ctype == 0) { o[x] = (uint8_t)(idx * 255 / ((1 << depth) - 1)); if (c) c[0] = c[1] = c[2] = o[x]; continue; }
         if ((size_t)idx * 3 + 2 >= palette.size()) { *err = "PNG palette index out of range"; return false; }
         o[x] = rgb_to_gray(palette[idx * 3], palette[idx * 3 + 1], palette[idx * 3 + 2]);
+        if (c) { c[0] = palette[idx * 3]; c[1] = palette[idx * 3 + 1]; c[2] = palette[idx * 3 + 2]; }
       } else {
         const uint8_t* p = &cur[(size_t)x * channels * step];
         o[x] = (channels >= 3) ? rgb_to_gray(p[0], p[step], p[2 * step]) : p[0];
+        if (rgb) {
+          uint8_t* c = &(*rgb)[((size_t)y * w + x) * 3];
+          if (channels >= 3) { c[0] = p[0]; c[1] = p[step]; c[2] = p[2 * step]; } else c[0] = c[1] = c[2] = p[0];
+        }
       }
     }
     prev.swap(cur);
@@ -112,7 +127,7 @@ inline bool load_png(const std::vector<uint8_t>& f, GrayImage* out, std::string*
   return true;
 }
 
-inline bool load_pnm(const std::vector<uint8_t>& f, GrayImage* out, std::string* err) {
+inline bool load_pnm(const std::vector<uint8_t>& f, GrayImage* out, std::string* err, std::vector<uint8_t>* rgb = nullptr) {
   size_t pos = 2;
   auto token = [&]() {
     while (pos < f.size()) {
@@ -131,6 +146,11 @@ inline bool load_pnm(const std::vector<uint8_t>& f, GrayImage* out, std::string*
   out->width = (int)w; out->height = (int)h; out->data.resize((size_t)w * h);
   for (size_t i = 0; i < (size_t)w * h; ++i)
     out->data[i] = color ? rgb_to_gray(f[pos + 3 * i], f[pos + 3 * i + 1], f[pos + 3 * i + 2]) : f[pos + i];
+  if (rgb) {
+    rgb->resize((size_t)w * h * 3);
+    for (size_t i = 0; i < (size_t)w * h; ++i)
+      for (int c = 0; c < 3; ++c) (*rgb)[3 * i + c] = color ? f[pos + 3 * i + c] : f[pos + i];
+  }
   return true;
 }
 
@@ -150,6 +170,74 @@ inline GrayImage imread_gray(const std::string& path, std::string* error = nullp
   else err = "unknown image format";
   if (!ok) { img = GrayImage(); if (error) *error = path + ": " + err; }
   return img;
+}
+
+// cv::imread(path): colour, 8 bits per channel; grey files give three equal channels, 16-bit PNG samples their high byte, alpha is dropped
+inline ColorImage imread_color(const std::string& path, std::string* error = nullptr) {
+  ColorImage img;
+  GrayImage g;
+  std::string err;
+  std::ifstream s(path, std::ios::binary);
+  if (!s) { if (error) *error = "cannot open " + path; return img; }
+  std::vector<uint8_t> f((std::istreambuf_iterator<char>(s)), std::istreambuf_iterator<char>());
+  bool ok = false;
+  if (f.size() >= 8 && f[0] == 137 && f[1] == 'P') ok = img_detail::load_png(f, &g, &err, &img.rgb);
+  else if (f.size() >= 2 && f[0] == 'P' && (f[1] == '5' || f[1] == '6')) ok = img_detail::load_pnm(f, &g, &err, &img.rgb);
+  else if (f.size() >= 2 && f[0] == 0xff && f[1] == 0xd8) ok = load_jpeg(f, &g.width, &g.height, nullptr, &img.rgb, &err);
+  else err = "unknown image format";
+  if (!ok) { img = ColorImage(); if (error) *error = path + ": " + err; return img; }
+  img.width = g.width; img.height = g.height;
+  return img;
+}
+
+// cv::imwrite(path, image) for the formats the tools write: by extension ".jpg" / ".jpeg" (libjpeg defaults at quality 95,
+// io_jpeg_write.h), ".png" (8-bit RGB, filter 0, zlib), ".ppm" (binary P6)
+inline bool imwrite_color(const std::string& path, const ColorImage& img, std::string* error = nullptr) {
+  std::string ext;
+  const size_t dot = path.find_last_of('.');
+  if (dot != std::string::npos) for (size_t i = dot + 1; i < path.size(); ++i) ext += (char)tolower(path[i]);
+  std::vector<uint8_t> bytes;
+  if (img.empty() || img.rgb.size() != (size_t)img.width * img.height * 3) { if (error) *error = "imwrite: empty image"; return false; }
+  if (ext == "jpg" || ext == "jpeg" || ext == "jpe") {
+    bytes = encode_jpeg_rgb(img.rgb.data(), img.width, img.height, 95);
+  } else if (ext == "png") {
+    const size_t stride = (size_t)img.width * 3;
+    std::vector<uint8_t> raw((stride + 1) * (size_t)img.height);
+    for (int y = 0; y < img.height; ++y) { raw[(stride + 1) * y] = 0; memcpy(&raw[(stride + 1) * y + 1], &img.rgb[stride * y], stride); }
+    uLongf clen = compressBound((uLong)raw.size());
+    std::vector<uint8_t> comp(clen);
+    if (compress2(comp.data(), &clen, raw.data(), (uLong)raw.size(), 1) != Z_OK) { if (error) *error = "imwrite: deflate failed"; return false; }
+    auto be = [&](uint32_t v) { for (int s2 = 24; s2 >= 0; s2 -= 8) bytes.push_back((uint8_t)(v >> s2)); };
+    auto chunk = [&](const char* type, const uint8_t* d, size_t n) {
+      be((uint32_t)n);
+      const size_t start = bytes.size();
+      bytes.insert(bytes.end(), type, type + 4);
+      bytes.insert(bytes.end(), d, d + n);
+      be((uint32_t)crc32(0L, &bytes[start], (uInt)(n + 4)));
+    };
+    const uint8_t sig[8] = {137, 80, 78, 71, 13, 10, 26, 10};
+    bytes.insert(bytes.end(), sig, sig + 8);
+    uint8_t ihdr[13];
+    for (int s2 = 0; s2 < 4; ++s2) { ihdr[s2] = (uint8_t)(img.width >> (24 - 8 * s2)); ihdr[4 + s2] = (uint8_t)(img.height >> (24 - 8 * s2)); }
+    ihdr[8] = 8; ihdr[9] = 2; ihdr[10] = 0; ihdr[11] = 0; ihdr[12] = 0;
+    chunk("IHDR", ihdr, 13);
+    chunk("IDAT", comp.data(), clen);
+    chunk("IEND", nullptr, 0);
+  } else if (ext == "ppm" || ext == "pnm") {
+    char head[64];
+    const int n = snprintf(head, sizeof head, "P6\n%d %d\n255\n", img.width, img.height);
+    bytes.assign(head, head + n);
+    bytes.insert(bytes.end(), img.rgb.begin(), img.rgb.end());
+  } else {
+    if (error) *error = "imwrite: unsupported file extension ." + ext;
+    return false;
+  }
+  FILE* f = fopen(path.c_str(), "wb");
+  if (!f) { if (error) *error = "cannot write " + path; return false; }
+  const bool ok = fwrite(bytes.data(), 1, bytes.size(), f) == bytes.size();
+  fclose(f);
+  if (!ok && error) *error = "cannot write " + path;
+  return ok;
 }
 
 // one INTER_AREA half-size step (see the header comment)

@@ -248,11 +248,72 @@ inline bool take_restart(BitReader& br) {
   return true;
 }
 
+// jdsample.c: chroma plane (real size dw x dh, stride pw) -> w x h.  2:1 ratios use libjpeg's triangle filters when the plane is more
+// than two samples wide (do_fancy_upsampling, the default); context rows above / below the image repeat the first / last real row
+// (jdmainct.c); other integral ratios replicate.
+inline bool upsample_plane(const std::vector<uint8_t>& in, int pw, int dw, int dh, int hr, int vr, int w, int h, std::vector<uint8_t>* out) {
+  out->assign((size_t)w * h, 0);
+  auto at = [&](int x, int y) { return (int)in[(size_t)(y < 0 ? 0 : (y >= dh ? dh - 1 : y)) * pw + x]; };
+  const bool fancy = dw > 2;
+  if (hr == 1 && vr == 1) {
+    for (int y = 0; y < h; ++y) memcpy(&(*out)[(size_t)y * w], &in[(size_t)y * pw], (size_t)w);
+  } else if (hr == 2 && vr == 1 && fancy) {
+    std::vector<uint8_t> row((size_t)2 * dw);
+    for (int y = 0; y < h; ++y) {
+      row[0] = (uint8_t)at(0, y); row[1] = (uint8_t)((at(0, y) * 3 + at(1, y) + 2) >> 2);
+      for (int x = 1; x < dw - 1; ++x) {
+        const int v = at(x, y) * 3;
+        row[2 * x] = (uint8_t)((v + at(x - 1, y) + 1) >> 2); row[2 * x + 1] = (uint8_t)((v + at(x + 1, y) + 2) >> 2);
+      }
+      row[2 * dw - 2] = (uint8_t)((at(dw - 1, y) * 3 + at(dw - 2, y) + 1) >> 2); row[2 * dw - 1] = (uint8_t)at(dw - 1, y);
+      memcpy(&(*out)[(size_t)y * w], row.data(), (size_t)w);
+    }
+  } else if (hr == 1 && vr == 2 && fancy) {                       // libjpeg-turbo's h1v2_fancy_upsample
+    for (int y = 0; y < h; ++y) {
+      const int iy = y >> 1, other = (y & 1) ? iy + 1 : iy - 1, bias = (y & 1) ? 2 : 1;
+      for (int x = 0; x < w; ++x) (*out)[(size_t)y * w + x] = (uint8_t)((at(x, iy) * 3 + at(x, other) + bias) >> 2);
+    }
+  } else if (hr == 2 && vr == 2 && fancy) {
+    std::vector<uint8_t> row((size_t)2 * dw);
+    for (int y = 0; y < h; ++y) {
+      const int iy = y >> 1, other = (y & 1) ? iy + 1 : iy - 1;
+      auto colsum = [&](int x) { return at(x, iy) * 3 + at(x, other); };
+      int last = colsum(0), cur = last, next = colsum(1);
+      row[0] = (uint8_t)((cur * 4 + 8) >> 4); row[1] = (uint8_t)((cur * 3 + next + 7) >> 4);
+      for (int x = 1; x < dw - 1; ++x) {
+        last = cur; cur = next; next = colsum(x + 1);
+        row[2 * x] = (uint8_t)((cur * 3 + last + 8) >> 4); row[2 * x + 1] = (uint8_t)((cur * 3 + next + 7) >> 4);
+      }
+      last = cur; cur = next;
+      row[2 * dw - 2] = (uint8_t)((cur * 3 + last + 8) >> 4); row[2 * dw - 1] = (uint8_t)((cur * 4 + 7) >> 4);
+      memcpy(&(*out)[(size_t)y * w], row.data(), (size_t)w);
+    }
+  } else {
+    if (hr < 1 || vr < 1 || hr > 4 || vr > 4) return false;
+    for (int y = 0; y < h; ++y)
+      for (int x = 0; x < w; ++x) (*out)[(size_t)y * w + x] = (uint8_t)at(x / hr < dw ? x / hr : dw - 1, y / vr);
+  }
+  return true;
+}
+
+// jdcolor.c ycc_rgb_convert: SCALEBITS = 16 tables, range-limited
+inline void ycc_to_rgb(int y, int cb, int cr, uint8_t* out) {
+  const int xb = cb - 128, xr = cr - 128;
+  const int r = y + ((91881 * xr + 32768) >> 16);
+  const int g = y + ((-22554 * xb + 32768 - 46802 * xr) >> 16);
+  const int b = y + ((116130 * xb + 32768) >> 16);
+  out[0] = (uint8_t)(r < 0 ? 0 : (r > 255 ? 255 : r)); out[1] = (uint8_t)(g < 0 ? 0 : (g > 255 ? 255 : g)); out[2] = (uint8_t)(b < 0 ? 0 : (b > 255 ? 255 : b));
+}
+
 }  // namespace jpeg_detail
 
-// grey = the luminance plane, width x height bytes; false + message on unsupported or damaged files
-inline bool load_jpeg_gray(const std::vector<uint8_t>& f, int* width, int* height, std::vector<uint8_t>* gray, std::string* err) {
+// grey = the luminance plane, width x height bytes; rgb (optional) = libjpeg's JCS_RGB output, 3 bytes per pixel: chroma planes
+// reconstructed, "fancy" (triangle filter) upsampling for 2:1 horizontal, 2:1 vertical and 2x2 subsampling (jdsample.c), YCbCr -> RGB with
+// the 16-bit fixed-point tables of jdcolor.c.  false + message on unsupported or damaged files.
+inline bool load_jpeg(const std::vector<uint8_t>& f, int* width, int* height, std::vector<uint8_t>* gray, std::vector<uint8_t>* rgb,
+                      std::string* err) {
   using namespace jpeg_detail;
+  const bool want_rgb = rgb != nullptr;
   if (f.size() < 4 || f[0] != 0xFF || f[1] != 0xD8) { *err = "not a JPEG file"; return false; }
   int qt[4][64] = {{0}};
   bool qt_defined[4] = {false, false, false, false};
@@ -264,8 +325,10 @@ inline bool load_jpeg_gray(const std::vector<uint8_t>& f, int* width, int* heigh
   size_t pos = 2;
   bool have_frame = false, progressive = false;
   // progressive: the luminance coefficients of every block of the MCU-padded grid, natural order, until the last scan is in
-  std::vector<int16_t> ycoef;
-  int ybw = 0, ybh = 0;
+  std::vector<int16_t> pcoef[3];
+  int pbw[3] = {0, 0, 0}, pbh[3] = {0, 0, 0};
+  std::vector<int16_t>& ycoef = pcoef[0];
+  int& ybw = pbw[0]; int& ybh = pbh[0];
   auto emit = [&](const std::vector<uint8_t>& plane, int PW) -> bool {
     // EXIF orientation: output pixel (x, y) of the oriented image <- source pixel (sx, sy)
     const bool swap = orientation >= 5;
@@ -289,6 +352,46 @@ inline bool load_jpeg_gray(const std::vector<uint8_t>& f, int* width, int* heigh
           default: sx = W - 1 - y; sy = x; break;                  // 8: rotate 90 counter-clockwise
         }
         (*gray)[(size_t)y * OW + x] = plane[(size_t)sy * PW + sx];
+      }
+    return true;
+  };
+  // colour output from the component planes (plane c: stride pws[c], real size ceil(W h_c / hmax) x ceil(H v_c / vmax))
+  auto emit_rgb = [&](const std::vector<uint8_t>* planes, const int* pws) -> bool {
+    std::vector<uint8_t> full[3];
+    int hmax = 1, vmax = 1;
+    for (const Component& c : comps) { hmax = c.h > hmax ? c.h : hmax; vmax = c.v > vmax ? c.v : vmax; }
+    const int nc = (int)comps.size();
+    for (int c = 0; c < nc; ++c) {
+      const int ch = nc == 1 ? 1 : comps[c].h, cv = nc == 1 ? 1 : comps[c].v, hm = nc == 1 ? 1 : hmax, vm = nc == 1 ? 1 : vmax;
+      if (hm % ch || vm % cv) { *err = "JPEG with fractional chroma subsampling is not supported in colour"; return false; }
+      if (!upsample_plane(planes[c], pws[c], (W * ch + hm - 1) / hm, (H * cv + vm - 1) / vm, hm / ch, vm / cv, W, H, &full[c])) {
+        *err = "unsupported JPEG subsampling";
+        return false;
+      }
+    }
+    std::vector<uint8_t> img((size_t)W * H * 3);
+    for (size_t i = 0; i < (size_t)W * H; ++i) {
+      if (nc == 1) { img[3 * i] = img[3 * i + 1] = img[3 * i + 2] = full[0][i]; continue; }
+      ycc_to_rgb(full[0][i], full[1][i], full[2][i], &img[3 * i]);
+    }
+    const bool swap = orientation >= 5;
+    const int OW = swap ? H : W, OH = swap ? W : H;
+    *width = OW; *height = OH;
+    rgb->resize((size_t)OW * OH * 3);
+    for (int y = 0; y < OH; ++y)
+      for (int x = 0; x < OW; ++x) {
+        int sx, sy;
+        switch (orientation) {
+          case 1: sx = x; sy = y; break;
+          case 2: sx = W - 1 - x; sy = y; break;
+          case 3: sx = W - 1 - x; sy = H - 1 - y; break;
+          case 4: sx = x; sy = H - 1 - y; break;
+          case 5: sx = y; sy = x; break;
+          case 6: sx = y; sy = H - 1 - x; break;
+          case 7: sx = W - 1 - y; sy = H - 1 - x; break;
+          default: sx = W - 1 - y; sy = x; break;
+        }
+        memcpy(&(*rgb)[((size_t)y * OW + x) * 3], &img[((size_t)sy * W + sx) * 3], 3);
       }
     return true;
   };
@@ -400,10 +503,14 @@ inline bool load_jpeg_gray(const std::vector<uint8_t>& f, int* width, int* heigh
         const int yh = single_frame ? 1 : Y.h, yv = single_frame ? 1 : Y.v;
         const int mcu_w = single_frame ? 8 : 8 * hmax, mcu_h = single_frame ? 8 : 8 * vmax;
         const int mcus_x = (W + mcu_w - 1) / mcu_w, mcus_y = (H + mcu_h - 1) / mcu_h;
-        if (ycoef.empty()) { ybw = mcus_x * yh; ybh = mcus_y * yv; ycoef.assign((size_t)ybw * ybh * 64, 0); }
+        if (ycoef.empty()) {
+          ybw = mcus_x * yh; ybh = mcus_y * yv; ycoef.assign((size_t)ybw * ybh * 64, 0);
+          if (want_rgb && comps.size() == 3)
+            for (int c = 1; c < 3; ++c) { pbw[c] = mcus_x * comps[c].h; pbh[c] = mcus_y * comps[c].v; pcoef[c].assign((size_t)pbw[c] * pbh[c] * 64, 0); }
+        }
         const size_t data = pos + (size_t)len;
         const bool has_y = sel[0] == 0 || (ns > 1 && (sel[1] == 0 || (ns > 2 && sel[2] == 0)));
-        if (!has_y && ns == 1) { pos = next_segment_marker(f, data); continue; }      // a chroma-only scan: nothing grey needs
+        if (!has_y && ns == 1 && !want_rgb) { pos = next_segment_marker(f, data); continue; }      // a chroma-only scan: nothing grey needs
         BitReader br{&f[data], f.data() + f.size()};
         for (Component& c : comps) c.pred = 0;
         int restart_count = 0;
@@ -423,17 +530,21 @@ inline bool load_jpeg_gray(const std::vector<uint8_t>& f, int* width, int* heigh
                 Component& c = comps[sel[sidx]];
                 for (int by = 0; by < c.v; ++by)
                   for (int bx = 0; bx < c.h; ++bx) {
-                    int16_t* blk = sel[sidx] == 0 ? &ycoef[((size_t)(my * yv + by) * ybw + (size_t)(mx * yh + bx)) * 64] : scratch;
-                    if (sel[sidx] != 0) scratch[0] = 0;
+                    const int ci = sel[sidx];
+                    int16_t* blk = ci == 0 ? &ycoef[((size_t)(my * yv + by) * ybw + (size_t)(mx * yh + bx)) * 64]
+                                           : (want_rgb ? &pcoef[ci][((size_t)(my * c.v + by) * pbw[ci] + (size_t)(mx * c.h + bx)) * 64] : scratch);
+                    if (ci != 0 && !want_rgb) scratch[0] = 0;
                     if (!prog_dc(br, dc[c.td], sc, &c.pred, blk)) { *err = "corrupt JPEG data (DC)"; return false; }
                   }
               }
             }
-        } else {                                                                       // the luminance component alone
-          Component& c = comps[0];
+        } else {                                                                       // one component alone
+          const int ci = sel[0];
+          Component& c = comps[ci];
           if (sc.ss == 0 ? (sc.ah == 0 && !dc[c.td].defined) : !ac[c.ta].defined) { *err = "JPEG tables missing"; return false; }
           // a non-interleaved scan covers the blocks of the component's own size, not the MCU-padded grid
-          const int bw = (W + 7) / 8, bh = (H + 7) / 8;
+          const int cw = single_frame ? W : (W * c.h + hmax - 1) / hmax, chh = single_frame ? H : (H * c.v + vmax - 1) / vmax;
+          const int bw = (cw + 7) / 8, bh = (chh + 7) / 8;
           for (int by = 0; by < bh; ++by)
             for (int bx = 0; bx < bw; ++bx) {
               if (restart_interval && restart_count == restart_interval) {
@@ -442,7 +553,7 @@ inline bool load_jpeg_gray(const std::vector<uint8_t>& f, int* width, int* heigh
                 restart_count = 0;
               }
               ++restart_count;
-              int16_t* blk = &ycoef[((size_t)by * ybw + bx) * 64];
+              int16_t* blk = &pcoef[ci][((size_t)by * pbw[ci] + bx) * 64];
               const bool ok = sc.ss == 0 ? prog_dc(br, dc[c.td], sc, &c.pred, blk)
                                          : (sc.ah == 0 ? prog_ac_first(br, ac[c.ta], sc, blk) : prog_ac_refine(br, ac[c.ta], sc, blk));
               if (!ok) { *err = "corrupt JPEG data (progressive scan)"; return false; }
@@ -477,6 +588,10 @@ inline bool load_jpeg_gray(const std::vector<uint8_t>& f, int* width, int* heigh
       if (!single && (Y.h != hmax || Y.v != vmax)) { *err = "JPEG with a subsampled first component is not supported"; return false; }
       const int PW = mcus_x * mcu_w, PH = mcus_y * mcu_h;
       std::vector<uint8_t> plane((size_t)PW * PH);
+      std::vector<uint8_t> cplane[2];                        // chroma planes at their own resolution, only for colour output
+      int cpw[2] = {0, 0};
+      if (want_rgb && comps.size() == 3)
+        for (int c = 0; c < 2; ++c) { cpw[c] = mcus_x * comps[c + 1].h * 8; cplane[c].assign((size_t)cpw[c] * mcus_y * comps[c + 1].v * 8, 0); }
       BitReader br{&f[pos + (size_t)len], f.data() + f.size()};
       int restart_count = 0;
       for (Component& c : comps) c.pred = 0;
@@ -522,31 +637,48 @@ inline bool load_jpeg_gray(const std::vector<uint8_t>& f, int* width, int* heigh
                 if (ci == 0) {
                   uint8_t* o = &plane[(size_t)(my * mcu_h + by * 8) * PW + (size_t)(mx * mcu_w + bx * 8)];
                   idct_islow(coef, o, PW);
+                } else if (want_rgb) {
+                  uint8_t* o = &cplane[ci - 1][(size_t)((my * c.v + by) * 8) * cpw[ci - 1] + (size_t)((mx * c.h + bx) * 8)];
+                  idct_islow(coef, o, cpw[ci - 1]);
                 }
               }
           }
           (void)yh; (void)yv;
         }
+      if (want_rgb) {
+        const std::vector<uint8_t> planes[3] = {std::move(plane), std::move(cplane[0]), std::move(cplane[1])};
+        const int pws[3] = {PW, cpw[0], cpw[1]};
+        if (!emit_rgb(planes, pws)) return false;
+        return gray ? emit(planes[0], PW) : true;
+      }
       return emit(plane, PW);
     }
     pos += (size_t)len;
   }
   if (progressive && !ycoef.empty()) {
-    const Component& Y = comps[0];
-    if (!qt_defined[Y.tq]) { *err = "JPEG tables missing"; return false; }
-    const int PW = ybw * 8, PH = ybh * 8;
-    std::vector<uint8_t> plane((size_t)PW * PH);
+    std::vector<uint8_t> planes[3];
+    int pws[3] = {0, 0, 0};
     int coef[64];
-    for (int by = 0; by < ybh; ++by)
-      for (int bx = 0; bx < ybw; ++bx) {
-        const int16_t* blk = &ycoef[((size_t)by * ybw + bx) * 64];
-        for (int k = 0; k < 64; ++k) coef[k] = blk[k] * qt[Y.tq][k];
-        idct_islow(coef, &plane[(size_t)by * 8 * PW + (size_t)bx * 8], PW);
-      }
-    return emit(plane, PW);
+    for (int c = 0; c < (want_rgb ? (int)comps.size() : 1); ++c) {
+      if (!qt_defined[comps[c].tq]) { *err = "JPEG tables missing"; return false; }
+      pws[c] = pbw[c] * 8;
+      planes[c].assign((size_t)pws[c] * pbh[c] * 8, 0);
+      for (int by = 0; by < pbh[c]; ++by)
+        for (int bx = 0; bx < pbw[c]; ++bx) {
+          const int16_t* blk = &pcoef[c][((size_t)by * pbw[c] + bx) * 64];
+          for (int k = 0; k < 64; ++k) coef[k] = blk[k] * qt[comps[c].tq][k];
+          idct_islow(coef, &planes[c][(size_t)by * 8 * pws[c] + (size_t)bx * 8], pws[c]);
+        }
+    }
+    if (want_rgb && !emit_rgb(planes, pws)) return false;
+    return (gray || !want_rgb) ? emit(planes[0], pws[0]) : true;
   }
   *err = "JPEG without image data";
   return false;
+}
+
+inline bool load_jpeg_gray(const std::vector<uint8_t>& f, int* width, int* height, std::vector<uint8_t>* gray, std::string* err) {
+  return load_jpeg(f, width, height, gray, nullptr, err);
 }
 
 }  // namespace e3d_host

@@ -1,6 +1,7 @@
 """Host-side (no GPU) behaviour of the drop-in tools: flag handling, .mlp / PLY I/O, early-out paths."""
 import os
 import subprocess
+import sys
 
 import numpy as np
 
@@ -292,3 +293,64 @@ def test_png_decoder_refuses_damaged_headers(tmp_path):
     open(str(tmp_path / "wide.png"), "wb").write(sig + chunk(b"IHDR", ihdr) + chunk(b"IEND", b""))
     img, err = _imread(str(tmp_path / "wide.png"), tmp_path)
     assert img is None and "out of range" in err
+
+
+def _imread_color_to(path, out):
+    r = subprocess.run([os.path.join(BIN, "e3d_imread_gray"), "--color", path, out], capture_output=True, text=True)
+    return r.returncode, r.stderr
+
+
+def test_color_decoder_matches_libjpeg(tmp_path):
+    """cv::imread(path) on JPEG = libjpeg's RGB output: chroma planes, triangle-filter ("fancy") upsampling for 4:2:2 / 4:2:0, the
+    fixed-point YCbCr -> RGB tables.  Baseline and progressive files, odd sizes, a grey file; expected = Pillow / libjpeg-turbo, bit
+    for bit.  PNG (RGB, RGBA, palette, grey) and PPM through the same entry point."""
+    from PIL import Image
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from make_jpeg_golden import scene
+    _build()
+    cases = [("420", (67, 45), dict(quality=90, subsampling=2)), ("422", (67, 45), dict(quality=80, subsampling=1)),
+             ("444", (40, 52), dict(quality=95, subsampling=0)), ("p420", (131, 99), dict(quality=75, subsampling=2, progressive=True)),
+             ("p444", (61, 47), dict(quality=92, subsampling=0, progressive=True)), ("p422r", (90, 70), dict(quality=85, subsampling=1, progressive=True,
+                                                                                                               restart_marker_blocks=2)),
+             ("odd", (33, 17), dict(quality=88, subsampling=2)), ("tiny", (3, 2), dict(quality=90, subsampling=2)),
+             ("r420", (75, 60), dict(quality=80, subsampling=2, restart_marker_blocks=3))]
+    for i, (name, (w, h), kw) in enumerate(cases):
+        src = str(tmp_path / (name + ".jpg"))
+        scene(w, h, 40 + i).save(src, "JPEG", **kw)
+        rc, err = _imread_color_to(src, str(tmp_path / "o.ppm"))
+        assert rc == 0, err
+        got = np.array(Image.open(str(tmp_path / "o.ppm")))
+        exp = np.array(Image.open(src).convert("RGB"))
+        assert got.shape == exp.shape and np.array_equal(got, exp), name
+    scene(50, 40, 3).convert("L").save(str(tmp_path / "g.jpg"), "JPEG", quality=85)
+    assert _imread_color_to(str(tmp_path / "g.jpg"), str(tmp_path / "o.ppm"))[0] == 0
+    assert np.array_equal(np.array(Image.open(str(tmp_path / "o.ppm"))), np.array(Image.open(str(tmp_path / "g.jpg")).convert("RGB")))
+    rgb = scene(37, 29, 5)
+    for mode, fname in (("RGB", "c.png"), ("RGBA", "a.png"), ("P", "p.png"), ("L", "l.png"), ("RGB", "c.ppm")):
+        im = rgb.convert(mode) if mode != "P" else rgb.quantize(32)
+        im.save(str(tmp_path / fname))
+        assert _imread_color_to(str(tmp_path / fname), str(tmp_path / "o.ppm"))[0] == 0
+        assert np.array_equal(np.array(Image.open(str(tmp_path / "o.ppm"))), np.array(im.convert("RGB"))), fname
+
+
+def test_jpeg_encoder_writes_libjpeg_bytes(tmp_path):
+    """cv::imwrite(path.jpg, image) = libjpeg at quality 95, 4:2:0, standard tables: the files of io_jpeg_write.h equal the ones
+    Pillow / libjpeg-turbo writes with those settings byte for byte -- colour conversion, edge padding (right edge before, bottom edge
+    after downsampling), forward DCT, quantisation, dummy blocks, Huffman coding, headers.  PNG output round-trips."""
+    from PIL import Image
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from make_jpeg_golden import scene
+    _build()
+    rng = np.random.RandomState(1)
+    sizes = [(129, 70), (70, 129), (64, 48), (17, 2), (1, 1), (2, 2), (15, 31), (250, 198), (16, 16)] + [tuple(int(v) for v in rng.randint(1, 90, 2)) for _ in range(10)]
+    for (w, h) in sizes:
+        img = scene(w, h, 3 * w + h)
+        img.save(str(tmp_path / "src.png"))
+        rc, err = _imread_color_to(str(tmp_path / "src.png"), str(tmp_path / "ours.jpg"))
+        assert rc == 0, err
+        img.save(str(tmp_path / "pil.jpg"), "JPEG", quality=95, subsampling=2)
+        assert open(str(tmp_path / "ours.jpg"), "rb").read() == open(str(tmp_path / "pil.jpg"), "rb").read(), (w, h)
+    assert _imread_color_to(str(tmp_path / "src.png"), str(tmp_path / "o.png"))[0] == 0
+    assert np.array_equal(np.array(Image.open(str(tmp_path / "o.png"))), np.array(Image.open(str(tmp_path / "src.png")).convert("RGB")))
+    rc, err = _imread_color_to(str(tmp_path / "src.png"), str(tmp_path / "o.bmp"))
+    assert rc != 0 and "unsupported file extension" in err

@@ -3,7 +3,8 @@
 // images), points/ (each scan trimmed to the points seen in >= 2 images + scan_alignment.mlp), ground_truth_depth/ and
 // occlusion_depth/ (raw float maps per image, optionally gzip-compressed).  The per-image work (occlusion depth, scan
 // point visibility, depth maps) runs on the MI355X behind e3d_reg_count_scan_observations / e3d_reg_ground_truth_depth.
-// Not built: --write_scan_renderings (needs colour image decoding and encoding).
+// --write_scan_renderings: the image painted with the visible scan points (io_image.h decodes / encodes the colour images, the library
+// decides per pixel which point ends up on top).
 #include <exception>
 #include <zlib.h>
 
@@ -64,10 +65,6 @@ static int run_tool(int argc, char** argv) {
     std::cerr << "Please specify all the required paths." << std::endl;
     return EXIT_FAILURE;
   }
-  if (write_scan_renderings) {
-    std::cerr << "--write_scan_renderings is not part of this build." << std::endl;
-    return EXIT_FAILURE;
-  }
 
   // opt::LoadPointClouds: scans in the global frame (pcl::transformPointCloud on the GPU)
   std::vector<MeshInfo> scan_infos;
@@ -78,6 +75,7 @@ static int run_tool(int argc, char** argv) {
   std::cout << "Loading point clouds ..." << std::endl;
   const std::string project_dir = parent_path(scan_alignment_path);
   std::vector<std::vector<float>> scans(scan_infos.size());
+  std::vector<uint8_t> all_colors;                             // r g b per scan point (pcl::PointXYZRGB; 0 0 0 without colour properties)
   auto transform = [&](std::vector<float>& xyz, const float* T) {
     if (xyz.empty()) return true;
     std::vector<float> out(xyz.size());
@@ -92,7 +90,11 @@ static int run_tool(int argc, char** argv) {
   for (size_t i = 0; i < scan_infos.size(); ++i) {
     PointCloud local;
     const std::string filename = (!scan_infos[i].filename.empty() && scan_infos[i].filename[0] == '/') ? scan_infos[i].filename : join_path(project_dir, scan_infos[i].filename);
-    if (loadPLYFile(filename, local, false) < 0) { std::cerr << "Cannot load scan point clouds." << std::endl; return EXIT_FAILURE; }
+    if (loadPLYFile(filename, local, write_scan_renderings) < 0) { std::cerr << "Cannot load scan point clouds." << std::endl; return EXIT_FAILURE; }
+    if (write_scan_renderings) {
+      if (local.rgb.size() != local.xyz.size()) local.rgb.assign(local.xyz.size(), 0);
+      all_colors.insert(all_colors.end(), local.rgb.begin(), local.rgb.end());
+    }
     float T[12];
     scan_infos[i].global_T_mesh.matrix3x4(T);
     scans[i].swap(local.xyz);
@@ -222,8 +224,9 @@ static int run_tool(int argc, char** argv) {
   }
 
   // Ground truth depth maps and occlusion depth maps (:429-475)
-  if (write_depth_maps || write_occlusion_depth) {
+  if (write_depth_maps || write_occlusion_depth || write_scan_renderings) {
     if (write_depth_maps) std::cout << "Writing depth maps ..." << std::endl;
+    if (write_scan_renderings) std::cout << "Writing scan renderings ..." << std::endl;
     if (write_occlusion_depth) std::cout << "Writing occlusion depth maps ..." << std::endl;
     current_image = 0;
     for (auto& kv : problem.images) {
@@ -247,6 +250,26 @@ static int run_tool(int argc, char** argv) {
         const std::string dir = join_path(join_path(output_folder_path, "ground_truth_depth"), folder);
         create_directories(dir);
         if (!write_float_map(join_path(dir, name), gt, compress_depth_maps)) { std::cerr << "Cannot write to " << dir << std::endl; return EXIT_FAILURE; }
+      }
+      if (write_scan_renderings) {
+        // scan_rendering = cv::imread(image.file_path), then every visible scan point seen in >= 2 images as a square of
+        // 2 * scan_point_radius + 1 pixels in its colour, in point order (:149, :175-187); cv::imwrite under the image's name (:194-199)
+        std::string err;
+        ColorImage ren = imread_color(im.file_path, &err);
+        if (ren.empty() || ren.width != in.width || ren.height != in.height) {
+          std::cerr << "Cannot use " << im.file_path << " for the scan rendering " << err << std::endl;
+          return EXIT_FAILURE;
+        }
+        std::vector<uint32_t> winner((size_t)in.width * in.height);
+        if (api().e3d_reg_scan_rendering(problem.reg, kv.first, mask.empty() ? nullptr : mask.data.data(), kEvalObs, 2, scan_point_radius, winner.data()) < 0) {
+          std::cerr << "scan rendering failed: " << api().e3d_last_error() << std::endl;
+          return EXIT_FAILURE;
+        }
+        for (size_t px = 0; px < winner.size(); ++px)
+          if (winner[px]) memcpy(&ren.rgb[3 * px], &all_colors[3 * (size_t)(winner[px] - 1)], 3);
+        const std::string dir = join_path(join_path(output_folder_path, "scan_rendering"), folder);
+        create_directories(dir);
+        if (!imwrite_color(join_path(dir, name), ren, &err)) { std::cerr << err << std::endl; return EXIT_FAILURE; }
       }
     }
     std::cout << std::endl << "Done." << std::endl;

@@ -75,9 +75,9 @@ def test_ground_truth_creator_usage(tmp_path):
     _build()
     r = subprocess.run([os.path.join(BIN, "GroundTruthCreator")], capture_output=True, text=True)
     assert r.returncode != 0 and "Please specify all the required paths." in r.stderr
-    r = subprocess.run([os.path.join(BIN, "GroundTruthCreator"), "--scan_alignment_path", "a", "--image_base_path", "b", "--state_path", "c",
-                        "--output_folder_path", str(tmp_path / "o"), "--write_scan_renderings", "1"], capture_output=True, text=True)
-    assert r.returncode != 0 and "--write_scan_renderings is not part of this build." in r.stderr
+    r = subprocess.run([os.path.join(BIN, "GroundTruthCreator"), "--scan_alignment_path", str(tmp_path / "none.mlp"), "--image_base_path", "b",
+                        "--state_path", "c", "--output_folder_path", str(tmp_path / "o"), "--write_scan_renderings", "1"], capture_output=True, text=True)
+    assert r.returncode != 0 and "Cannot read scan poses from" in r.stderr
 
 
 def _imread(path, tmp_path):

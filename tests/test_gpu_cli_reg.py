@@ -469,6 +469,66 @@ def test_ground_truth_creator_cli_matches_oracle(tmp_path, e3d):
     assert gz.shape == (M["height"] * M["width"],) and fin.sum() > 2000 and (np.abs(gz[fin] - ogt.ravel()[fin]) > 1e-5).mean() < 1e-3
 
 
+def test_ground_truth_creator_scan_renderings(tmp_path, e3d):
+    """--write_scan_renderings (ground_truth_creator.cc:149,175-199): every image painted with the visible scan points seen in >= 2
+    images, squares of 2 * scan_point_radius + 1 pixels in point order, written under the image's own name -- a JPEG image gives a JPEG
+    (libjpeg quality 95 = what cv::imwrite writes), a PNG a PNG.  Expected: the oracle's sequential painting over Pillow's decoding of
+    the same files, compared pixel for pixel (PNG) and byte for byte (JPEG, against Pillow's encoder)."""
+    from PIL import Image
+    from oracle import reg_binding as rb
+    from oracle.reg_driver import OracleRegProblem
+    M = make_multi_image_scene(n_points=20000, n_images=3, seed=21, perturb=0.0)
+    rng = np.random.RandomState(7)
+    M["pts"] = np.concatenate([M["pts"], rng.uniform(-4, 4, (2000, 3))]).astype(np.float32)
+    colors = rng.randint(0, 256, (len(M["pts"]), 3)).astype(np.uint8)
+    names = ["dslr/img_0.png", "dslr/img_1.jpg", "dslr/img_2.png"]
+    d = str(tmp_path)
+    write_ply_xyz(os.path.join(d, "scan.ply"), M["pts"], rgb=colors)
+    write_mlp(os.path.join(d, "scans.mlp"), [("scan", "scan.ply", np.eye(4))])
+    os.makedirs(os.path.join(d, "state"), exist_ok=True)
+    os.makedirs(os.path.join(d, "images", "dslr"), exist_ok=True)
+    p = M["params"].astype(np.float64).copy(); p[2] += 0.5; p[3] += 0.5
+    with open(os.path.join(d, "state", "cameras.txt"), "w") as f:
+        f.write("# cameras\n7 PINHOLE %d %d %s\n" % (M["width"], M["height"], " ".join("%.9g" % v for v in p)))
+    yy, xx = np.mgrid[0:M["height"], 0:M["width"]]
+    with open(os.path.join(d, "state", "images.txt"), "w") as f:
+        for i, (im, name) in enumerate(zip(M["images"], names)):
+            f.write("%d %s %s 7 %s\n\n" % (10 + i, " ".join("%.9g" % v for v in im["q_true"]), " ".join("%.9g" % v for v in im["t_true"]), name))
+            col = np.stack([im["pyr"][0], (im["pyr"][0].astype(int) + xx) % 256, (yy * 2) % 256], -1).astype(np.uint8)      # a colour image
+            if name.endswith(".jpg"):
+                Image.fromarray(col, "RGB").save(os.path.join(d, "images", name), "JPEG", quality=90, subsampling=2)
+            else:
+                Image.fromarray(col, "RGB").save(os.path.join(d, "images", name))
+    out = _run_gt(d, ["--write_scan_renderings", "1", "--scan_point_radius", "1", "--write_point_cloud", "0"])
+    assert "Writing scan renderings ..." in out
+    O = OracleRegProblem(K=M["K"], image_scale_count=3)
+    O.set_intrinsics(0, M["width"], M["height"], M["params"], 0, 3)
+    cam = O.intr[0]["levels"][0]
+    counts = np.zeros(len(M["pts"]), np.int32)
+    occ = []
+    for i, im in enumerate(M["images"]):
+        O.set_image(i, 0, [np.zeros((1, 1), np.uint8)] * 3); O.set_image_pose(i, im["q_true"], im["t_true"])
+        occ.append(rb.splat_depth(M["pts"], O._R(O.images[i]), O.images[i]["t"], cam, 0.03))
+        rb.scan_visibility(M["pts"], O._R(O.images[i]), O.images[i]["t"], cam, occ[i], counts)
+    for i, name in enumerate(names):
+        win = rb.scan_rendering(M["pts"], O._R(O.images[i]), O.images[i]["t"], cam, occ[i], counts, 1)
+        exp = np.array(Image.open(os.path.join(d, "images", name)).convert("RGB"))
+        painted = win > 0
+        exp[painted] = colors[win[painted] - 1]
+        assert painted.sum() > 5000 and (~painted).sum() > 5000
+        path = os.path.join(d, "gt", "scan_rendering", name)
+        if name.endswith(".png"):
+            got = np.array(Image.open(path).convert("RGB"))
+            assert (got != exp).any(-1).mean() < 2e-3          # the poses pass through the (identity) upright rotation: an ulp may move a point
+        else:
+            Image.fromarray(exp, "RGB").save(os.path.join(d, "exp.jpg"), "JPEG", quality=95, subsampling=2)
+            a, b = open(path, "rb").read(), open(os.path.join(d, "exp.jpg"), "rb").read()
+            if a != b:                                         # same caveat: then at least nearly all decoded pixels agree
+                ga, gb = np.array(Image.open(path).convert("RGB")).astype(int), np.array(Image.open(os.path.join(d, "exp.jpg")).convert("RGB")).astype(int)
+                assert (np.abs(ga - gb).max(-1) > 8).mean() < 5e-3
+    assert os.path.exists(os.path.join(d, "gt", "ground_truth_depth", "dslr", "img_1.jpg"))
+
+
 def test_ground_truth_creator_rotates_first_scan_upright(tmp_path, e3d):
     """A tilted first scan: scans, cameras and the written scan_alignment.mlp are all moved by U = (R0^-1, t0 - R0^-1 t0)
     (ground_truth_creator.cc:275-291, :333-339); visibility is invariant under that rigid motion."""

@@ -442,6 +442,8 @@ inline bool load_jpeg(const std::vector<uint8_t>& f, int* width, int* height, st
       progressive = marker == 0xC2;
       if (n < 6 || d[0] != 8) { *err = "only 8-bit JPEG is supported"; return false; }
       H = be16(&d[1]); W = be16(&d[3]);
+      if (W <= 0 || H <= 0 || (size_t)W * (size_t)H > ((size_t)1 << 28)) { *err = "JPEG dimensions out of range"; return false; }
+      if (have_frame) { *err = "JPEG with more than one frame header"; return false; }
       const int nc = d[5];
       if ((nc != 1 && nc != 3) || n < 6 + 3 * nc) { *err = nc == 4 ? "CMYK / YCCK JPEG is not supported" : "unsupported JPEG component count"; return false; }
       comps.resize(nc);
@@ -486,7 +488,7 @@ inline bool load_jpeg(const std::vector<uint8_t>& f, int* width, int* height, st
           sel[sidx] = -1;
           for (size_t c = 0; c < comps.size(); ++c)
             if (comps[c].id == d[1 + 2 * sidx]) { comps[c].td = d[2 + 2 * sidx] >> 4; comps[c].ta = d[2 + 2 * sidx] & 15; sel[sidx] = (int)c; }
-          if (sel[sidx] < 0) { *err = "bad SOS"; return false; }
+          if (sel[sidx] < 0 || comps[sel[sidx]].td > 3 || comps[sel[sidx]].ta > 3) { *err = "bad SOS"; return false; }
         }
         ProgressiveScan sc;
         sc.ss = d[1 + 2 * ns]; sc.se = d[2 + 2 * ns]; sc.ah = d[3 + 2 * ns] >> 4; sc.al = d[3 + 2 * ns] & 15;

@@ -105,6 +105,20 @@ def test_jpeg_decoder_matches_libjpeg_golden(tmp_path):
         img, err = _imread(os.path.join(gold, "jpeg_%s.jpg" % name), tmp_path)
         assert img is not None, err
         assert img.shape == exp[name].shape and np.array_equal(img, exp[name]), name
+    # damaged scan headers are refused with a message: a Huffman table selector beyond the four tables (found by tools/fuzz/image_readers.cc),
+    # a second frame header
+    raw = bytearray(open(os.path.join(gold, "jpeg_prog_420_q40_opt.jpg"), "rb").read())
+    sos = raw.index(b"\xff\xda")
+    raw[sos + 6] = 0xEE
+    open(str(tmp_path / "sel.jpg"), "wb").write(bytes(raw))
+    img, err = _imread(str(tmp_path / "sel.jpg"), tmp_path)
+    assert img is None and "bad SOS" in err
+    raw = open(os.path.join(gold, "jpeg_420_q90.jpg"), "rb").read()
+    sof = raw.index(b"\xff\xc0")
+    seg = raw[sof: sof + 2 + int.from_bytes(raw[sof + 2: sof + 4], "big")]
+    open(str(tmp_path / "two.jpg"), "wb").write(raw[:sof] + seg + raw[sof:])
+    img, err = _imread(str(tmp_path / "two.jpg"), tmp_path)
+    assert img is None and "more than one frame header" in err
     # a progressive file cut in the middle of a scan is refused, not decoded to garbage
     raw = open(os.path.join(gold, "jpeg_prog_420_q40_opt.jpg"), "rb").read()
     open(str(tmp_path / "cut.jpg"), "wb").write(raw[: len(raw) // 3])

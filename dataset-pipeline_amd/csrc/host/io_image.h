@@ -199,6 +199,7 @@ inline bool imwrite_color(const std::string& path, const ColorImage& img, std::s
   std::vector<uint8_t> bytes;
   if (img.empty() || img.rgb.size() != (size_t)img.width * img.height * 3) { if (error) *error = "imwrite: empty image"; return false; }
   if (ext == "jpg" || ext == "jpeg" || ext == "jpe") {
+    if (img.width > 65535 || img.height > 65535) { if (error) *error = "imwrite: image too large for JPEG"; return false; }
     bytes = encode_jpeg_rgb(img.rgb.data(), img.width, img.height, 95);
   } else if (ext == "png") {
     const size_t stride = (size_t)img.width * 3;

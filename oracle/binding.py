@@ -21,7 +21,19 @@ def build(force=False):
         for f in os.listdir(_HERE) if f.endswith((".c", ".h"))
     ):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
+    build_ref()
     return so
+
+
+def ref_lib_path():
+    return os.path.join(_HERE, "_ref", "libe3d_ref.so")
+
+
+def build_ref():
+    """oracle/_ref: the reference's own dependency-free sources, compiled in place when /root/reference exists (here, not on the GPU box)."""
+    if os.path.exists("/root/reference/src/opt/robust_weighting.h"):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "_ref"])
+    return ref_lib_path() if os.path.exists(ref_lib_path()) else None
 
 
 class PairRecord(C.Structure):

@@ -15,7 +15,9 @@
  *                                                          src/opt/intrinsics_and_pose_optimizer.cc:624-837,932-1217,839-930,1219-1296
  *   CostCalculator::AccumulateResidualsForObservations / ComputePointColorResidual   src/opt/cost_calculator.cc:102-271
  *   ColorOptimizer::Apply                                   src/opt/color_optimizer.cc:40-123
- * Not covered yet: rig images (J_rig), depth residuals (weight 0 by default), the other 12 camera models.
+ * Also: rig images (J_rig), depth residuals (oracle_reg_depth_*), the ten camera models of the factory (oracle_camera.h).
+ * Pin: RobustWeighting and the descriptor are checked bit for bit against the reference's own headers compiled into oracle/_ref
+ * (tests/test_oracle_ref.py); the rest against the reference's known-answer tests and finite differences (tests/test_oracle_*.py).
  * float -> int conversions follow x86 cvttss2si (out-of-range / NaN -> INT_MIN), which is what the reference's
  * `int ix = v + 0.5f;` compiles to.
  */

@@ -64,6 +64,7 @@ SIGNATURES = {
     "e3d_comm_create": (C.c_void_p, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "e3d_comm_create_all": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p]),
     "e3d_comm_destroy": (None, [C.c_void_p]),
+    "e3d_comm_abort": (C.c_int, [C.c_void_p]),
     "e3d_comm_rank": (C.c_int, [C.c_void_p]),
     "e3d_comm_world_size": (C.c_int, [C.c_void_p]),
     "e3d_icp_set_comm": (C.c_int, [C.c_void_p, C.c_void_p]),

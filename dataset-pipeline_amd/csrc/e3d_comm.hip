@@ -22,7 +22,8 @@ int e3d_comm_unique_id(char id[E3D_COMM_ID_BYTES]) {
     E3D_NCCL(ncclGetUniqueId(&u));
     std::memcpy(id, u.internal, NCCL_UNIQUE_ID_BYTES);
     return 0;
-  } catch (const e3d::Error& e) { e3d::set_last_error(e.what()); return e.code; }
+  } catch (const e3d::Error& e) { e3d::set_last_error(e.what()); return e.code;
+  } catch (const std::exception& e) { e3d::set_last_error(e.what()); return E3D_ERR_HIP; }
 }
 
 e3d_comm_t* e3d_comm_create(const char id[E3D_COMM_ID_BYTES], int rank, int world_size, int device) {
@@ -46,14 +47,31 @@ int e3d_comm_create_all(int n_devices, const int* devices, e3d_comm_t** out) {
     std::vector<ncclComm_t> comms((size_t)n_devices);
     std::vector<int> devs((size_t)n_devices);
     for (int i = 0; i < n_devices; ++i) devs[i] = devices ? devices[i] : i;
+    std::vector<e3d_comm*> made((size_t)n_devices, nullptr);
     E3D_NCCL(ncclCommInitAll(comms.data(), n_devices, devs.data()));
-    for (int i = 0; i < n_devices; ++i) {
-      e3d_comm* c = new e3d_comm();
-      c->comm = comms[i]; c->rank = i; c->world = n_devices; c->device = devs[i];
-      out[i] = c;
+    try {
+      for (int i = 0; i < n_devices; ++i) {
+        made[i] = new e3d_comm();
+        made[i]->comm = comms[i]; made[i]->rank = i; made[i]->world = n_devices; made[i]->device = devs[i];
+      }
+    } catch (...) {   // nothing is handed out half-built: the communicators go back, the objects already made are deleted
+      for (int i = 0; i < n_devices; ++i) { (void)ncclCommAbort(comms[i]); delete made[i]; }
+      throw;
     }
+    for (int i = 0; i < n_devices; ++i) out[i] = made[i];
     return 0;
-  } catch (const e3d::Error& e) { e3d::set_last_error(e.what()); return e.code; }
+  } catch (const e3d::Error& e) { e3d::set_last_error(e.what()); return e.code;
+  } catch (const std::exception& e) { e3d::set_last_error(e.what()); return E3D_ERR_HIP; }
+}
+
+int e3d_comm_abort(e3d_comm_t* c) {
+  if (!c) return 0;
+  std::lock_guard<std::mutex> lock(c->mu);
+  if (c->aborted.exchange(true) || !c->comm) return 0;
+  const ncclResult_t r = ncclCommAbort(c->comm);   // releases collectives that wait for a rank that will never arrive
+  c->comm = nullptr;
+  if (r != ncclSuccess) { e3d::set_last_error(std::string("ncclCommAbort failed: ") + ncclGetErrorString(r)); return E3D_ERR_HIP; }
+  return 0;
 }
 
 void e3d_comm_destroy(e3d_comm_t* c) {

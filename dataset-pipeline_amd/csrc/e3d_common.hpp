@@ -23,6 +23,19 @@ struct Error : std::runtime_error {
 
 void set_last_error(const std::string& msg);
 
+// Frees the device memory the library only keeps as a cache (the kNN workspace pool of e3d_normals.hip); true if anything
+// was freed.  DevBuf calls it once when hipMalloc reports out-of-memory and retries.
+bool release_cached_device_memory();
+
+inline hipError_t malloc_with_retry(void** p, size_t bytes) {
+  hipError_t e = hipMalloc(p, bytes);
+  if (e == hipErrorOutOfMemory && release_cached_device_memory()) {
+    (void)hipGetLastError();
+    e = hipMalloc(p, bytes);
+  }
+  return e;
+}
+
 inline std::string fmt(const char* f, ...) {
   char buf[512];
   va_list ap; va_start(ap, f); vsnprintf(buf, sizeof buf, f, ap); va_end(ap);
@@ -55,7 +68,7 @@ struct DevBuf {
   void reserve(size_t n) {
     if (n <= cap) return;
     release();
-    E3D_HIP(hipMalloc((void**)&p, sizeof(T) * (n ? n : 1)));
+    E3D_HIP(malloc_with_retry((void**)&p, sizeof(T) * (n ? n : 1)));
     cap = n;
     if (poison_allocations()) { E3D_HIP(hipMemset(p, 0xFF, sizeof(T) * (n ? n : 1))); E3D_HIP(hipDeviceSynchronize()); }   // the library's streams do not wait for the null stream
   }
@@ -69,7 +82,7 @@ struct DevBuf {
   void grow_keep(size_t n, size_t used, hipStream_t s) {
     if (n <= cap) return;
     T* q = nullptr;
-    E3D_HIP(hipMalloc((void**)&q, sizeof(T) * n));
+    E3D_HIP(malloc_with_retry((void**)&q, sizeof(T) * n));
     if (poison_allocations()) { E3D_HIP(hipMemset(q, 0xFF, sizeof(T) * n)); E3D_HIP(hipDeviceSynchronize()); }
     if (p && used) E3D_HIP(hipMemcpyAsync(q, p, sizeof(T) * used, hipMemcpyDeviceToDevice, s));
     E3D_HIP(hipStreamSynchronize(s));

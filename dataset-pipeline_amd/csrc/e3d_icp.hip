@@ -10,6 +10,7 @@
 //     pass streams them (48 B/correspondence) and reduces cost + Gramian blocks in f64;
 //   * the accumulate pass and the cost pass of consecutive LM steps are fused (same numbers, half the
 //     passes); the tiny LDL^T solve and the SE3 update run on the host in the reference's precisions.
+#include <atomic>
 #include <algorithm>
 #include <cfloat>
 #include <chrono>
@@ -34,7 +35,7 @@ const char* last_error_cstr() { return g_last_error.c_str(); }
 static int g_device = 0;
 // E3D_NN_MODE / e3d_set_nn_mode: 0 auto, 1 per-query, 2 hash-table buckets, 3 dense rows, 4 dense rows + MFMA filter
 static int g_nn_mode = [] { const char* e = getenv("E3D_NN_MODE"); const int v = e ? atoi(e) : 0; return (v >= 0 && v <= 4) ? v : 0; }();
-static unsigned long long g_grid_generation = 0;
+static std::atomic<unsigned long long> g_grid_generation{0};   // handles run on one host thread per GPU (--gpus N)
 
 // -------------------------------------------------------------------------------------------------
 struct Cloud {
@@ -219,7 +220,7 @@ static void build_grid(e3d_icp* h, Cloud& c, float d) {
   for (int k = 0; k < 3; ++k) c.grid.origin[k] = (float)((double)c.lmin[k] - 2.0 * cell);
 
   c.L4.reserve(n); c.LN.reserve(n); c.G4.reserve(n);
-  c.generation = ++g_grid_generation;
+  c.generation = g_grid_generation.fetch_add(1, std::memory_order_relaxed) + 1;
   c.cum_motion = 0.0; c.last_motion = 0.0; c.err_max = 0.0;
   unsigned n_cells = 0;
   if (n > 0) {

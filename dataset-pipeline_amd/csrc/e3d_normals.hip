@@ -822,7 +822,7 @@ struct WorkspaceLease {
 
 using namespace e3d;
 
-extern "C" int e3d_release_workspaces(void) {
+static size_t release_workspace_pool() {
   std::vector<KnnWorkspace*> take;
   {
     std::lock_guard<std::mutex> lock(workspace_mutex());
@@ -830,8 +830,17 @@ extern "C" int e3d_release_workspaces(void) {
   }
   int prev = 0;
   const bool have_dev = hipGetDevice(&prev) == hipSuccess;
-  for (KnnWorkspace* w : take) { (void)hipSetDevice(w->device); delete w; }
+  size_t bytes = 0;
+  for (KnnWorkspace* w : take) { bytes += w->bytes(); (void)hipSetDevice(w->device); delete w; }
   if (have_dev) (void)hipSetDevice(prev);
+  return bytes;
+}
+
+// e3d_common.hpp: the pool is a cache -- an allocation anywhere in the library that runs out of HBM gives it back and retries
+bool e3d::release_cached_device_memory() { return release_workspace_pool() > 0; }
+
+extern "C" int e3d_release_workspaces(void) {
+  (void)release_workspace_pool();
   return 0;
 }
 

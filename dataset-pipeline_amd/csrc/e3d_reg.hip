@@ -3548,6 +3548,7 @@ int e3d_reg_set_comm(e3d_reg_t* h, e3d_comm_t* comm) {
   R_TRYH
   if (!h) throw Error(E3D_ERR_INVALID, "null handle");
   if (!h->images.empty()) throw Error(E3D_ERR_INVALID, "e3d_reg_set_comm must be called before images are set");
+  if (comm && comm->device != h->device) throw Error(E3D_ERR_INVALID, "e3d_reg_set_comm: communicator and handle live on different devices");
   h->comm = comm;
   h->rank = comm ? comm->rank : 0; h->world = comm ? comm->world : 1;
   h->allreduce = nullptr; h->allreduce_dev = nullptr; h->ar_user = nullptr;

@@ -22,7 +22,7 @@ struct Api {
   E3D_FN(e3d_abi_version) E3D_FN(e3d_init) E3D_FN(e3d_last_error) E3D_FN(e3d_icp_create) E3D_FN(e3d_icp_destroy)
   E3D_FN(e3d_icp_add_cloud) E3D_FN(e3d_icp_run) E3D_FN(e3d_icp_get_pose) E3D_FN(e3d_transform_cloud)
   E3D_FN(e3d_normals_knn) E3D_FN(e3d_normals_radius) E3D_FN(e3d_find_correspondences)
-  E3D_FN(e3d_reg_create) E3D_FN(e3d_reg_destroy) E3D_FN(e3d_reg_set_params) E3D_FN(e3d_reg_set_point_scale) E3D_FN(e3d_reg_set_intrinsics) E3D_FN(e3d_reg_set_camera_mask) E3D_FN(e3d_reg_get_intrinsics_level) E3D_FN(e3d_reg_set_image) E3D_FN(e3d_reg_set_image_pose) E3D_FN(e3d_reg_get_image_pose) E3D_FN(e3d_reg_set_rig) E3D_FN(e3d_reg_get_rig) E3D_FN(e3d_reg_add_rig_images) E3D_FN(e3d_reg_set_splat_points) E3D_FN(e3d_reg_run_on_current_scale) E3D_FN(e3d_reg_compute_cost) E3D_FN(e3d_determine_point_neighbors) E3D_FN(e3d_reg_point_radius_minmax) E3D_FN(e3d_merge_close_points) E3D_FN(e3d_reg_add_occlusion_mesh) E3D_FN(e3d_reg_set_occlusion_options) E3D_FN(e3d_reg_set_cache_observations) E3D_FN(e3d_reg_determine_observed_indices) E3D_FN(e3d_reg_get_observed_indices) E3D_FN(e3d_reg_set_observed_indices) E3D_FN(e3d_local_outlier_removal) E3D_FN(e3d_reg_set_scan_points) E3D_FN(e3d_reg_count_scan_observations) E3D_FN(e3d_reg_get_scan_observation_counts) E3D_FN(e3d_reg_ground_truth_depth) E3D_FN(e3d_reg_scan_rendering) E3D_FN(e3d_comm_create_all) E3D_FN(e3d_comm_destroy) E3D_FN(e3d_icp_set_comm) E3D_FN(e3d_reg_set_comm)
+  E3D_FN(e3d_reg_create) E3D_FN(e3d_reg_destroy) E3D_FN(e3d_reg_set_params) E3D_FN(e3d_reg_set_point_scale) E3D_FN(e3d_reg_set_intrinsics) E3D_FN(e3d_reg_set_camera_mask) E3D_FN(e3d_reg_get_intrinsics_level) E3D_FN(e3d_reg_set_image) E3D_FN(e3d_reg_set_image_pose) E3D_FN(e3d_reg_get_image_pose) E3D_FN(e3d_reg_set_rig) E3D_FN(e3d_reg_get_rig) E3D_FN(e3d_reg_add_rig_images) E3D_FN(e3d_reg_set_splat_points) E3D_FN(e3d_reg_run_on_current_scale) E3D_FN(e3d_reg_compute_cost) E3D_FN(e3d_determine_point_neighbors) E3D_FN(e3d_reg_point_radius_minmax) E3D_FN(e3d_merge_close_points) E3D_FN(e3d_reg_add_occlusion_mesh) E3D_FN(e3d_reg_set_occlusion_options) E3D_FN(e3d_reg_set_cache_observations) E3D_FN(e3d_reg_determine_observed_indices) E3D_FN(e3d_reg_get_observed_indices) E3D_FN(e3d_reg_set_observed_indices) E3D_FN(e3d_local_outlier_removal) E3D_FN(e3d_reg_set_scan_points) E3D_FN(e3d_reg_count_scan_observations) E3D_FN(e3d_reg_get_scan_observation_counts) E3D_FN(e3d_reg_ground_truth_depth) E3D_FN(e3d_reg_scan_rendering) E3D_FN(e3d_comm_create_all) E3D_FN(e3d_comm_destroy) E3D_FN(e3d_comm_abort) E3D_FN(e3d_icp_set_comm) E3D_FN(e3d_reg_set_comm)
 #undef E3D_FN
 };
 
@@ -57,7 +57,7 @@ inline Api& api() {
   E3D_LOAD(e3d_abi_version) E3D_LOAD(e3d_init) E3D_LOAD(e3d_last_error) E3D_LOAD(e3d_icp_create)
   E3D_LOAD(e3d_icp_destroy) E3D_LOAD(e3d_icp_add_cloud) E3D_LOAD(e3d_icp_run) E3D_LOAD(e3d_icp_get_pose)
   E3D_LOAD(e3d_transform_cloud) E3D_LOAD(e3d_normals_knn) E3D_LOAD(e3d_normals_radius) E3D_LOAD(e3d_find_correspondences)
-  E3D_LOAD(e3d_reg_create) E3D_LOAD(e3d_reg_destroy) E3D_LOAD(e3d_reg_set_params) E3D_LOAD(e3d_reg_set_point_scale) E3D_LOAD(e3d_reg_set_intrinsics) E3D_LOAD(e3d_reg_set_camera_mask) E3D_LOAD(e3d_reg_get_intrinsics_level) E3D_LOAD(e3d_reg_set_image) E3D_LOAD(e3d_reg_set_image_pose) E3D_LOAD(e3d_reg_get_image_pose) E3D_LOAD(e3d_reg_set_rig) E3D_LOAD(e3d_reg_get_rig) E3D_LOAD(e3d_reg_add_rig_images) E3D_LOAD(e3d_reg_set_splat_points) E3D_LOAD(e3d_reg_run_on_current_scale) E3D_LOAD(e3d_reg_compute_cost) E3D_LOAD(e3d_determine_point_neighbors) E3D_LOAD(e3d_reg_point_radius_minmax) E3D_LOAD(e3d_merge_close_points) E3D_LOAD(e3d_reg_add_occlusion_mesh) E3D_LOAD(e3d_reg_set_occlusion_options) E3D_LOAD(e3d_reg_set_cache_observations) E3D_LOAD(e3d_reg_determine_observed_indices) E3D_LOAD(e3d_reg_get_observed_indices) E3D_LOAD(e3d_reg_set_observed_indices) E3D_LOAD(e3d_local_outlier_removal) E3D_LOAD(e3d_reg_set_scan_points) E3D_LOAD(e3d_reg_count_scan_observations) E3D_LOAD(e3d_reg_get_scan_observation_counts) E3D_LOAD(e3d_reg_ground_truth_depth) E3D_LOAD(e3d_reg_scan_rendering) E3D_LOAD(e3d_comm_create_all) E3D_LOAD(e3d_comm_destroy) E3D_LOAD(e3d_icp_set_comm) E3D_LOAD(e3d_reg_set_comm)
+  E3D_LOAD(e3d_reg_create) E3D_LOAD(e3d_reg_destroy) E3D_LOAD(e3d_reg_set_params) E3D_LOAD(e3d_reg_set_point_scale) E3D_LOAD(e3d_reg_set_intrinsics) E3D_LOAD(e3d_reg_set_camera_mask) E3D_LOAD(e3d_reg_get_intrinsics_level) E3D_LOAD(e3d_reg_set_image) E3D_LOAD(e3d_reg_set_image_pose) E3D_LOAD(e3d_reg_get_image_pose) E3D_LOAD(e3d_reg_set_rig) E3D_LOAD(e3d_reg_get_rig) E3D_LOAD(e3d_reg_add_rig_images) E3D_LOAD(e3d_reg_set_splat_points) E3D_LOAD(e3d_reg_run_on_current_scale) E3D_LOAD(e3d_reg_compute_cost) E3D_LOAD(e3d_determine_point_neighbors) E3D_LOAD(e3d_reg_point_radius_minmax) E3D_LOAD(e3d_merge_close_points) E3D_LOAD(e3d_reg_add_occlusion_mesh) E3D_LOAD(e3d_reg_set_occlusion_options) E3D_LOAD(e3d_reg_set_cache_observations) E3D_LOAD(e3d_reg_determine_observed_indices) E3D_LOAD(e3d_reg_get_observed_indices) E3D_LOAD(e3d_reg_set_observed_indices) E3D_LOAD(e3d_local_outlier_removal) E3D_LOAD(e3d_reg_set_scan_points) E3D_LOAD(e3d_reg_count_scan_observations) E3D_LOAD(e3d_reg_get_scan_observation_counts) E3D_LOAD(e3d_reg_ground_truth_depth) E3D_LOAD(e3d_reg_scan_rendering) E3D_LOAD(e3d_comm_create_all) E3D_LOAD(e3d_comm_destroy) E3D_LOAD(e3d_comm_abort) E3D_LOAD(e3d_icp_set_comm) E3D_LOAD(e3d_reg_set_comm)
 #undef E3D_LOAD
   if (a.e3d_abi_version() != E3D_ABI_VERSION) {
     fprintf(stderr, "FATAL: libe3dhip.so ABI version %d, expected %d\n", a.e3d_abi_version(), E3D_ABI_VERSION);

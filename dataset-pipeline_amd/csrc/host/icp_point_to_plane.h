@@ -2,6 +2,7 @@
 // (src/icp/icp_point_to_plane.h:39-80), implemented on the HIP library through the C-ABI.
 #pragma once
 
+#include <atomic>
 #include <stdexcept>
 #include <string>
 #include <thread>
@@ -58,20 +59,26 @@ class PointToPlaneICP {
            float convergence_threshold_max_movement, bool print_progress) {
     std::vector<int> res(h_.size(), 0);
     std::vector<std::string> err(h_.size());
+    std::atomic<int> first_failed{-1};
     auto work = [&](size_t k) {
       res[k] = e3d_host::api().e3d_icp_run(h_[k], max_correspondence_distance, initial_iteration, max_num_iterations,
                                            convergence_threshold_max_movement, print_progress ? 1 : 0);   // only rank 0 prints
-      if (res[k] < 0) err[k] = e3d_host::api().e3d_last_error();
+      if (res[k] < 0) {
+        err[k] = e3d_host::api().e3d_last_error();
+        int none = -1;
+        first_failed.compare_exchange_strong(none, (int)k);
+        // the other ranks may already wait in an all-reduce this rank will never join: abort every communicator so that
+        // their steps fail too and the threads can be joined (the error of the rank that failed first is reported)
+        for (e3d_comm_t* c : comms_) if (c) e3d_host::api().e3d_comm_abort(c);
+      }
     };
     std::vector<std::thread> th;
     for (size_t k = 1; k < h_.size(); ++k) th.emplace_back(work, k);
     work(0);
     for (std::thread& t : th) t.join();
-    for (size_t k = 0; k < h_.size(); ++k) {
-      if (res[k] < 0) {   // reference: CHECK(!clouds_.empty()) aborts
-        fprintf(stderr, "FATAL: PointToPlaneICP::Run: %s\n", err[k].c_str());
-        abort();
-      }
+    if (first_failed.load() >= 0) {   // reference: CHECK(!clouds_.empty()) aborts
+      fprintf(stderr, "FATAL: PointToPlaneICP::Run: %s\n", err[(size_t)first_failed.load()].c_str());
+      abort();
     }
     return res[0] == 1;
   }

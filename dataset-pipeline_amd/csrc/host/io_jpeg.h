@@ -480,6 +480,7 @@ inline bool load_jpeg(const std::vector<uint8_t>& f, int* width, int* height, st
       if (n >= 12 && !memcmp(d, "Adobe", 5)) adobe_transform = d[11];
     } else if (marker == 0xDA) {                              // SOS: baseline -> one scan with all components
       if (!have_frame || W <= 0 || H <= 0) { *err = "JPEG scan before frame header"; return false; }
+      if (n < 6) { *err = "bad SOS"; return false; }          // ns + one component + Ss Se AhAl; d[0] is only readable when n >= 1
       if (progressive) {
         const int ns = d[0];
         if (ns < 1 || ns > (int)comps.size() || n < 1 + 2 * ns + 3) { *err = "bad SOS"; return false; }

@@ -302,12 +302,21 @@ class Problem {
   template <class F> bool all_regs_parallel(F f, const char* what) {
     std::vector<int> res(regs.size(), 0);
     std::vector<std::string> err(regs.size());
-    auto work = [&](size_t k) { res[k] = f(regs[k], (int)k); if (res[k] < 0) err[k] = api().e3d_last_error(); };
+    std::atomic<int> first_failed{-1};
+    auto work = [&](size_t k) {
+      res[k] = f(regs[k], (int)k);
+      if (res[k] < 0) {   // ranks waiting in a collective for this one would block forever: abort all communicators
+        err[k] = api().e3d_last_error();
+        int none = -1;
+        first_failed.compare_exchange_strong(none, (int)k);
+        for (e3d_comm_t* c : comms) if (c) api().e3d_comm_abort(c);
+      }
+    };
     std::vector<std::thread> th;
     for (size_t k = 1; k < regs.size(); ++k) th.emplace_back(work, k);
     work(0);
     for (std::thread& t : th) t.join();
-    for (size_t k = 0; k < regs.size(); ++k) if (res[k] < 0) { std::cerr << what << ": " << err[k] << std::endl; return false; }
+    if (first_failed.load() >= 0) { std::cerr << what << ": " << err[(size_t)first_failed.load()] << std::endl; return false; }
     return true;
   }
 

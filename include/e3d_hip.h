@@ -134,13 +134,17 @@ int e3d_icp_set_shard(e3d_icp_t* icp, int rank, int world_size,
  * the 128 bytes travel through the launcher's rendezvous, every rank: e3d_comm_create) or host threads of one process
  * (e3d_comm_create_all: out[i] is the communicator of devices[i], devices == NULL means 0..n-1).  world_size = 1 is valid
  * (the collectives then run with a single rank).  e3d_icp_set_comm replaces e3d_icp_set_shard; the communicator must
- * outlive the handle. */
+ * outlive the handle and live on the handle's device. */
 #define E3D_COMM_ID_BYTES 128
 typedef struct e3d_comm e3d_comm_t;
 int e3d_comm_unique_id(char id[E3D_COMM_ID_BYTES]);
 e3d_comm_t* e3d_comm_create(const char id[E3D_COMM_ID_BYTES], int rank, int world_size, int device);
 int e3d_comm_create_all(int n_devices, const int* devices, e3d_comm_t** out);
 void e3d_comm_destroy(e3d_comm_t* comm);
+/* Aborts the communicator (ncclCommAbort): collectives of the other ranks that wait for this one return with an error
+ * instead of blocking forever.  Callable from any host thread; every later collective on `comm` fails; the object is
+ * still released with e3d_comm_destroy.  Used by the tools when one rank's step fails (--gpus N). */
+int e3d_comm_abort(e3d_comm_t* comm);
 int e3d_comm_rank(const e3d_comm_t* comm);
 int e3d_comm_world_size(const e3d_comm_t* comm);
 int e3d_icp_set_comm(e3d_icp_t* icp, e3d_comm_t* comm);

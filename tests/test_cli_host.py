@@ -119,6 +119,13 @@ def test_jpeg_decoder_matches_libjpeg_golden(tmp_path):
     open(str(tmp_path / "two.jpg"), "wb").write(raw[:sof] + seg + raw[sof:])
     img, err = _imread(str(tmp_path / "two.jpg"), tmp_path)
     assert img is None and "more than one frame header" in err
+    # a file that ends exactly at an SOS segment of length 2 (no payload byte to read the component count from)
+    for name in ("jpeg_prog_420_q40_opt.jpg", "jpeg_420_q90.jpg"):
+        raw = open(os.path.join(gold, name), "rb").read()
+        sos = raw.index(b"\xff\xda")
+        open(str(tmp_path / "sos2.jpg"), "wb").write(raw[:sos] + b"\xff\xda\x00\x02")
+        img, err = _imread(str(tmp_path / "sos2.jpg"), tmp_path)
+        assert img is None and "bad SOS" in err, err
     # a progressive file cut in the middle of a scan is refused, not decoded to garbage
     raw = open(os.path.join(gold, "jpeg_prog_420_q40_opt.jpg"), "rb").read()
     open(str(tmp_path / "cut.jpg"), "wb").write(raw[: len(raw) // 3])

@@ -49,7 +49,7 @@ def build(force=False, verbose=False):
         if p.wait() != 0:
             raise RuntimeError("hipcc failed on " + s)
     so = lib_path()
-    if force or procs or not os.path.exists(so):
+    if force or procs or not os.path.exists(so) or any(_newer(o, so) for o in objs):   # objects built by hand count too
         cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so] + objs + ["-L/opt/rocm/lib", "-lrccl"]
         if verbose:
             print(" ".join(cmd))

@@ -482,8 +482,14 @@ static void find_pair(e3d_icp* h, Cloud& src, Cloud& tgt, float d, PairJob& job,
       E3D_HIP(hipMemsetAsync(ps.todo_count.p, 0, 2 * sizeof(unsigned), s));
       if (!h->nn_timer_c) h->nn_timer_c.reset(new EventTimer());
       h->nn_timer_c->start(s);
-      launch_nn_certify(srcG, n, tgt.G4.p, cum_up, radius_sq(d), near2, ps.match.p, ps.match2.p, ps.lbe.p, h->match_d2.p, h->todo_near.p, h->todo_far.p,
-                        ps.todo_count.p, s);
+      // Queries without a partner whose "nothing within the radius" bound no longer holds: k_nn_bounded searches them np_extra
+      // beyond the radius (cheap where the target is absent, and the bound then survives the following pose updates) -- but only
+      // once the poses move little: while the scans are still centimetres apart such a query has the other surface just outside
+      // the radius, one thread would scan 64 full cells, and the bound would not survive the next update anyway.
+      static const double np_frac = env_double("E3D_NN_NP_EXTRA", 0.5), np_gate = env_double("E3D_NN_NP_GATE", 0.2);   // of the radius
+      const bool none_near = np_frac > 0 && (src.last_motion + tgt.last_motion) < np_gate * (double)d;
+      launch_nn_certify(srcG, n, tgt.G4.p, cum_up, radius_sq(d), near2, none_near, ps.match.p, ps.match2.p, ps.lbe.p, h->match_d2.p, h->todo_near.p,
+                        h->todo_far.p, ps.todo_count.p, s);
       h->nn_timer_c->stop(s);
       copy_out(h->h_todo.p, ps.todo_count.p, 2 * sizeof(unsigned), s);
       sync(h);
@@ -503,6 +509,7 @@ static void find_pair(e3d_icp* h, Cloud& src, Cloud& tgt, float d, PairJob& job,
       bp.rho_pad = round_up_f(2.0 * tgt.build_slack + 8.0 * FLT_EPSILON * m_local);
       bp.cum_lo = cert.cum_lo;
       bp.cell_scale = cert.cell_scale; bp.cell_sub = cert.cell_sub;
+      bp.np_extra = (float)(np_frac * (double)d);
       launch_nn_bounded(srcG, h->todo_near.p, n_near, tgt.G4.p, tgt.dense_start.p, tgt.grid, im, tgt.qrange, radius_sq(d), bp, ps.match.p,
                         ps.match2.p, h->match_d2.p, ps.lbe.p, s);
       if (n_far > 0 && n_far * 32 < n) {
@@ -578,11 +585,17 @@ static void find_pair(e3d_icp* h, Cloud& src, Cloud& tgt, float d, PairJob& job,
   h->corr_used = need;
 }
 
-// number of LM blocks for a set of n correspondences (deterministic function of n only)
-static int lm_blocks_for(long long n) {
+// number of LM blocks for a set of n correspondences in a system of n_sets sets (deterministic function of the two).  Every
+// block ends with a wave / block reduction of up to 55 f64 accumulators (~1000 instructions, 2 - 3 loop trips' worth): with
+// hundreds of sets (all-pairs jobs) 1024 blocks per set would leave each thread ~40 trips, so the cap shrinks with the set count
+// while the whole launch keeps >= 8192 blocks (~10 rounds over the resident slots) for balance.
+static int lm_blocks_for(long long n, int n_sets = 1) {
   long long b = (n + (long long)kBlock * 8 - 1) / ((long long)kBlock * 8);
+  long long cap = 8192 / std::max(n_sets, 1);
+  if (cap > 1024) cap = 1024;   // 4 blocks per CU; the rest is grid-stride
+  if (cap < 64) cap = 64;
   if (b < 1) b = 1;
-  if (b > 1024) b = 1024;   // 4 blocks per CU; the rest is grid-stride
+  if (b > cap) b = cap;
   return (int)b;
 }
 
@@ -751,7 +764,7 @@ static void lm_prepare(e3d_icp* h, LmSystem& L, std::vector<PairJob>& jobs) {
       const int i = (int)L.sets.size();
       LmSet& S = h->h_sets.p[i];
       S.off = (long long)j->corr_off; S.n = j->count;
-      S.block_begin = block; S.nblocks = lm_blocks_for(j->count);
+      S.block_begin = block; S.nblocks = lm_blocks_for(j->count, ns_total);
       S.mode = m;
       S.side = (j->impl_src - 1 >= 0) ? 0 : 1;
       for (int b = 0; b < S.nblocks; ++b) block_set.push_back(i);

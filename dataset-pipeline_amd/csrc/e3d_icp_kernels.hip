@@ -1059,7 +1059,7 @@ constexpr int kCertPerWave = 512;          // consecutive queries per wave (8 st
 // distance touches), todo_far = all others (no partner, or a far one: sorted by target cell and searched by k_nn_rows).
 // counts[0] / counts[1] = list lengths.
 __global__ __launch_bounds__(kBlock) void k_nn_certify(const float4* __restrict__ Gsrc, size_t n, const float4* __restrict__ Gtgt,
-                                                       float cum_up, float r2, float near2, int* __restrict__ match,
+                                                       float cum_up, float r2, float near2, int none_near, int* __restrict__ match,
                                                        int* __restrict__ match2, const float* __restrict__ lbe,
                                                        float* __restrict__ match_d2, unsigned* __restrict__ todo_near,
                                                        unsigned* __restrict__ todo_far, unsigned* __restrict__ counts) {
@@ -1097,6 +1097,7 @@ __global__ __launch_bounds__(kBlock) void k_nn_certify(const float4* __restrict_
         if (ok) match_d2[j] = v;
       } else {
         ok = (thr > 0.f) && (lim >= r2);
+        near = none_near != 0;                          // k_nn_bounded searches these beyond the radius
         if (ok) match_d2[j] = r2;
       }
     }
@@ -1156,8 +1157,12 @@ __global__ __launch_bounds__(kBlock) void k_nn_bounded(const float4* __restrict_
     const int m2 = match2[j];
     if (m2 >= 0) { const float4 pc2 = Gtgt[m2]; d1 = fminf(d1, sqdist_l2(q.x, q.y, q.z, pc2.x, pc2.y, pc2.z)); }
   }
-  const float dr = sqrtf(fminf(d1, r2)) + bp.margin;
-  const float cover2 = (d1 < r2) ? fminf(dr * dr * 1.000001f, r2) : r2;      // NaN distances search the whole radius too
+  // A query WITHOUT a partner searches radius r + np_extra: it costs little where the target is absent (a row of empty cells
+  // is two directory words) and yields "nothing within r + np_extra", a certificate that outlives the next pose updates -- the
+  // 27-cell block of the row kernel only certifies the distance to its faces, 1 - 1.5 cells, and most of those queries came
+  // back in every outer iteration.
+  const float dr = sqrtf(fminf(d1, r2)) + ((m < 0) ? bp.np_extra : bp.margin);
+  const float cover2 = (d1 < r2) ? fminf(dr * dr * 1.000001f, r2) : ((m < 0) ? dr * dr * 1.000001f : r2);      // NaN distances search the whole radius too
   const float rho = sqrtf(cover2) * bp.rho_scale + bp.rho_pad;
   const float dx = q.x - im.t[0], dy = q.y - im.t[1], dz = q.z - im.t[2];
   const float lx = im.Linv[0] * dx + im.Linv[1] * dy + im.Linv[2] * dz;
@@ -1425,56 +1430,107 @@ __global__ __launch_bounds__(kBlock) void k_unpermute_matches(const int* __restr
 //          (icp_point_to_plane_impl.h:119-211 and :240-266), fused: one pass over the
 //          correspondence planes yields cost and (mode-dependent) the Gramian blocks.
 // =================================================================================================
-// f32 residual / Jacobian rows, literally as written in the reference (left-to-right).
-struct CorrRows {
-  float r1, r2;
-  float j1s[6], j1t[6], j2s[6], j2t[6];
+// f32 residual / Jacobian rows, literally as written in the reference (left-to-right), for ONE correspondence (T = float)
+// or for TWO at once (T = f2_t: every operation is the packed form v_pk_mul_f32 / v_pk_add_f32 of the same individually
+// rounded f32 operation, so each half is bit-identical to the scalar evaluation -- the f32 part of an LM pass is VALU work
+// of the same order as the f64 products, and the packed form halves it).
+//
+// The two 12-entry rows [js ; jt] of a correspondence only hold 9 different numbers each: the translation parts are
+// js[0..2] = -jt[0..2] (impl.h:162-164 / 170-172 and 188-190 / 197-199).  With m = jt[0..2], a = js[3..5], b = jt[3..5]:
+//   row 1: m = sn,  a = impl.h:173-177, b = impl.h:165-168;     row 2: m = -tn, a = impl.h:200-204, b = impl.h:191-195.
+template <typename T>
+struct CorrRowsT {
+  T r1, r2;
+  T m1[3], a1[3], b1[3];
+  T m2[3], a2[3], b2[3];
 };
 
-template <bool NEED_SRC, bool NEED_TGT>
-__device__ __forceinline__ void corr_rows(const LmSet& S, const float4 a, const float4 b, const float4 c, CorrRows& o) {
-  // inner poses applied with Eigen's R*p + t order (impl.h:144-151)
-  const float lsx = a.x, lsy = a.y, lsz = a.z, lnx = a.w, lny = b.x, lnz = b.y;
-  const float ltx = b.z, lty = b.w, ltz = c.x, lmx = c.y, lmy = c.z, lmz = c.w;
-  const float spx = dot3e(S.Rs[0], S.Rs[1], S.Rs[2], lsx, lsy, lsz) + S.ts[0];
-  const float spy = dot3e(S.Rs[3], S.Rs[4], S.Rs[5], lsx, lsy, lsz) + S.ts[1];
-  const float spz = dot3e(S.Rs[6], S.Rs[7], S.Rs[8], lsx, lsy, lsz) + S.ts[2];
-  const float snx = dot3e(S.Rs[0], S.Rs[1], S.Rs[2], lnx, lny, lnz);
-  const float sny = dot3e(S.Rs[3], S.Rs[4], S.Rs[5], lnx, lny, lnz);
-  const float snz = dot3e(S.Rs[6], S.Rs[7], S.Rs[8], lnx, lny, lnz);
-  const float tpx = dot3e(S.Rt[0], S.Rt[1], S.Rt[2], ltx, lty, ltz) + S.tt[0];
-  const float tpy = dot3e(S.Rt[3], S.Rt[4], S.Rt[5], ltx, lty, ltz) + S.tt[1];
-  const float tpz = dot3e(S.Rt[6], S.Rt[7], S.Rt[8], ltx, lty, ltz) + S.tt[2];
-  const float tnx = dot3e(S.Rt[0], S.Rt[1], S.Rt[2], lmx, lmy, lmz);
-  const float tny = dot3e(S.Rt[3], S.Rt[4], S.Rt[5], lmx, lmy, lmz);
-  const float tnz = dot3e(S.Rt[6], S.Rt[7], S.Rt[8], lmx, lmy, lmz);
+template <typename T>
+__device__ __forceinline__ T dot3t(const T a0, const T a1, const T a2, const T b0, const T b1, const T b2) {
+  const T e0 = a0 * b0, e1 = a1 * b1, e2 = a2 * b2;       // Eigen 3-term inner product: e0 + (e1 + e2)
+  return e0 + (e1 + e2);
+}
+template <typename T>
+__device__ __forceinline__ T rdot(const float r0, const float r1, const float r2, const T x, const T y, const T z) {
+  const T e0 = r0 * x, e1 = r1 * y, e2 = r2 * z;          // row of R (block-uniform scalars) times a point
+  return e0 + (e1 + e2);
+}
 
-  o.r1 = dot3e(snx, sny, snz, tpx - spx, tpy - spy, tpz - spz);                // impl.h:158
-  o.r2 = dot3e(tnx, tny, tnz, spx - tpx, spy - tpy, spz - tpz);                // impl.h:185
+template <typename T>
+struct CorrPts { T spx, spy, spz, snx, sny, snz, tpx, tpy, tpz, tnx, tny, tnz; };
+
+// inner poses applied with Eigen's R*p + t order (impl.h:144-151)
+template <typename T>
+__device__ __forceinline__ void corr_src(const float* Rs, const float* ts, const T lsx, const T lsy, const T lsz, const T lnx,
+                                         const T lny, const T lnz, CorrPts<T>& P) {
+  P.spx = rdot<T>(Rs[0], Rs[1], Rs[2], lsx, lsy, lsz) + ts[0];
+  P.spy = rdot<T>(Rs[3], Rs[4], Rs[5], lsx, lsy, lsz) + ts[1];
+  P.spz = rdot<T>(Rs[6], Rs[7], Rs[8], lsx, lsy, lsz) + ts[2];
+  P.snx = rdot<T>(Rs[0], Rs[1], Rs[2], lnx, lny, lnz);
+  P.sny = rdot<T>(Rs[3], Rs[4], Rs[5], lnx, lny, lnz);
+  P.snz = rdot<T>(Rs[6], Rs[7], Rs[8], lnx, lny, lnz);
+}
+template <typename T>
+__device__ __forceinline__ void corr_tgt(const float* Rt, const float* tt, const T ltx, const T lty, const T ltz, const T lmx,
+                                         const T lmy, const T lmz, CorrPts<T>& P) {
+  P.tpx = rdot<T>(Rt[0], Rt[1], Rt[2], ltx, lty, ltz) + tt[0];
+  P.tpy = rdot<T>(Rt[3], Rt[4], Rt[5], ltx, lty, ltz) + tt[1];
+  P.tpz = rdot<T>(Rt[6], Rt[7], Rt[8], ltx, lty, ltz) + tt[2];
+  P.tnx = rdot<T>(Rt[0], Rt[1], Rt[2], lmx, lmy, lmz);
+  P.tny = rdot<T>(Rt[3], Rt[4], Rt[5], lmx, lmy, lmz);
+  P.tnz = rdot<T>(Rt[6], Rt[7], Rt[8], lmx, lmy, lmz);
+}
+
+template <bool NEED_SRC, bool NEED_TGT, typename T>
+__device__ __forceinline__ void corr_rows_pts(const CorrPts<T>& P, CorrRowsT<T>& o) {
+  const T spx = P.spx, spy = P.spy, spz = P.spz, snx = P.snx, sny = P.sny, snz = P.snz;
+  const T tpx = P.tpx, tpy = P.tpy, tpz = P.tpz, tnx = P.tnx, tny = P.tny, tnz = P.tnz;
+  o.r1 = dot3t<T>(snx, sny, snz, tpx - spx, tpy - spy, tpz - spz);                // impl.h:158
+  o.r2 = dot3t<T>(tnx, tny, tnz, spx - tpx, spy - tpy, spz - tpz);                // impl.h:185
+  if (NEED_SRC || NEED_TGT) {
+    o.m1[0] = snx; o.m1[1] = sny; o.m1[2] = snz;                                  // impl.h:162-164 (j1s[0..2] = -m1)
+    o.m2[0] = -tnx; o.m2[1] = -tny; o.m2[2] = -tnz;                               // impl.h:188-190 (j2s[0..2] = -m2 = tn)
+  }
   if (NEED_TGT) {
-    o.j1t[0] = snx; o.j1t[1] = sny; o.j1t[2] = snz;                            // impl.h:162-168
-    o.j1t[3] = -sny * tpz + snz * tpy;
-    o.j1t[4] = snx * tpz - snz * tpx;
-    o.j1t[5] = -snx * tpy + sny * tpx;
-    o.j2t[0] = -tnx; o.j2t[1] = -tny; o.j2t[2] = -tnz;                         // impl.h:188-195
-    o.j2t[3] = tny * tpz - tny * (tpz - spz) - tnz * tpy + tnz * (tpy - spy);
-    o.j2t[4] = -tnx * tpz + tnx * (tpz - spz) + tnz * tpx - tnz * (tpx - spx);
-    o.j2t[5] = tnx * tpy - tnx * (tpy - spy) - tny * tpx + tny * (tpx - spx);
+    o.b1[0] = -sny * tpz + snz * tpy;                                             // impl.h:165-168
+    o.b1[1] = snx * tpz - snz * tpx;
+    o.b1[2] = -snx * tpy + sny * tpx;
+    o.b2[0] = tny * tpz - tny * (tpz - spz) - tnz * tpy + tnz * (tpy - spy);      // impl.h:191-195
+    o.b2[1] = -tnx * tpz + tnx * (tpz - spz) + tnz * tpx - tnz * (tpx - spx);
+    o.b2[2] = tnx * tpy - tnx * (tpy - spy) - tny * tpx + tny * (tpx - spx);
   }
   if (NEED_SRC) {
-    o.j1s[0] = -snx; o.j1s[1] = -sny; o.j1s[2] = -snz;                         // impl.h:170-177
-    o.j1s[3] = sny * spz - sny * (spz - tpz) - snz * spy + snz * (spy - tpy);
-    o.j1s[4] = -snx * spz + snx * (spz - tpz) + snz * spx - snz * (spx - tpx);
-    o.j1s[5] = snx * spy - snx * (spy - tpy) - sny * spx + sny * (spx - tpx);
-    o.j2s[0] = tnx; o.j2s[1] = tny; o.j2s[2] = tnz;                            // impl.h:197-204
-    o.j2s[3] = -tny * spz + tnz * spy;
-    o.j2s[4] = tnx * spz - tnz * spx;
-    o.j2s[5] = -tnx * spy + tny * spx;
+    o.a1[0] = sny * spz - sny * (spz - tpz) - snz * spy + snz * (spy - tpy);      // impl.h:173-177
+    o.a1[1] = -snx * spz + snx * (spz - tpz) + snz * spx - snz * (spx - tpx);
+    o.a1[2] = snx * spy - snx * (spy - tpy) - sny * spx + sny * (spx - tpx);
+    o.a2[0] = -tny * spz + tnz * spy;                                             // impl.h:200-204
+    o.a2[1] = tnx * spz - tnz * spx;
+    o.a2[2] = -tnx * spy + tny * spx;
   }
 }
 
+template <bool NEED_SRC, bool NEED_TGT, typename T, typename V4>
+__device__ __forceinline__ void corr_rows(const LmSet& S, const V4& a, const V4& b, const V4& c, CorrRowsT<T>& o) {
+  CorrPts<T> P;
+  corr_src<T>(S.Rs, S.ts, a.x, a.y, a.z, a.w, b.x, b.y, P);
+  corr_tgt<T>(S.Rt, S.tt, b.z, b.w, c.x, c.y, c.z, c.w, P);
+  corr_rows_pts<NEED_SRC, NEED_TGT, T>(P, o);
+}
+
+// two correspondences side by side: component i of the pair's planes as (first, second)
+struct Pair4 { f2_t x, y, z, w; };
+__device__ __forceinline__ Pair4 pair4(const float4 u, const float4 v) {
+  Pair4 r;
+  r.x = f2_t{u.x, v.x}; r.y = f2_t{u.y, v.y}; r.z = f2_t{u.z, v.z}; r.w = f2_t{u.w, v.w};
+  return r;
+}
+template <int H> __device__ __forceinline__ float half_of(const f2_t v) { return H == 0 ? v.x : v.y; }
+template <int H> __device__ __forceinline__ float half_of(const float v) { return v; }
+
 // accumulate upper triangle of J J^T (21) and r*J (6) in f64 from f32 rows cast to f64 first
-// (icp_point_to_plane_impl.h:91-112,179-182: .cast<double>() before the product)
+// (icp_point_to_plane_impl.h:91-112,179-182: .cast<double>() before the product).  The f64 product of two numbers that
+// came from f32 is exact (48 significant bits), so the fused multiply-add rounds exactly as the reference's separate
+// multiplication and addition do: one v_fma_f64 instead of v_mul_f64 + v_add_f64 with the translation unit's contraction off.
 __device__ __forceinline__ void acc_diag(double* H21, double* b6, const float* j, float r) {
   double J[6];
 #pragma unroll
@@ -1484,31 +1540,158 @@ __device__ __forceinline__ void acc_diag(double* H21, double* b6, const float* j
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
 #pragma unroll
-    for (int l = i; l < 6; ++l) { H21[k] += J[i] * J[l]; ++k; }
-    b6[i] += R * J[i];
+    for (int l = i; l < 6; ++l) { H21[k] = __builtin_fma(J[i], J[l], H21[k]); ++k; }
+    b6[i] = __builtin_fma(R, J[i], b6[i]);
   }
 }
-__device__ __forceinline__ void acc_cross(double* H36, const float* js, const float* jt) {
-  double A[6], Bv[6];
+
+// Both sides have variables (modes kModeTwo / kModeTwoCross).  The Gramian of the 12-entry row [js ; jt] needs 78 (+12 for
+// r*J) products per row; because js[0..2] = -jt[0..2] it is determined by the Gramian of the 10 numbers u = [m a b r]:
+// 45 (kModeTwo) or 54 (kModeTwoCross) products.  The f64 product of two f32 values is exact and negation commutes with
+// every rounding, so sum((-m_i) a_l) = -sum(m_i a_l) bit for bit: the blocks written out below are the ones a direct
+// accumulation of SS, TT, ST, bs, bt in the same order yields (icp_point_to_plane_impl.h:91-112,179-182,206-209).
+//   acc layout: [0] cost, [1..6] m m^T (upper), [7..15] m a^T, [16..21] a a^T, [22..30] m b^T, [31..36] b b^T,
+//               [37..39] r m, [40..42] r a, [43..45] r b, [46..54] a b^T (kModeTwoCross only)
+constexpr int kAccTwo = 46, kAccCross = 55;
+template <bool CROSS>
+__device__ __forceinline__ void acc_reduced(double* acc, const float m0, const float m1, const float m2, const float a0,
+                                            const float a1, const float a2, const float b0, const float b1, const float b2,
+                                            const float r) {
+  const double M[3] = {(double)m0, (double)m1, (double)m2};
+  const double A[3] = {(double)a0, (double)a1, (double)a2};
+  const double Bv[3] = {(double)b0, (double)b1, (double)b2};
+  const double R = (double)r;
+  int k = 1;
 #pragma unroll
-  for (int i = 0; i < 6; ++i) { A[i] = (double)js[i]; Bv[i] = (double)jt[i]; }
+  for (int i = 0; i < 3; ++i)
 #pragma unroll
+    for (int l = i; l < 3; ++l) { acc[k] = __builtin_fma(M[i], M[l], acc[k]); ++k; }
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int l = 0; l < 3; ++l) acc[7 + 3 * i + l] = __builtin_fma(M[i], A[l], acc[7 + 3 * i + l]);
+  k = 16;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int l = i; l < 3; ++l) { acc[k] = __builtin_fma(A[i], A[l], acc[k]); ++k; }
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int l = 0; l < 3; ++l) acc[22 + 3 * i + l] = __builtin_fma(M[i], Bv[l], acc[22 + 3 * i + l]);
+  k = 31;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int l = i; l < 3; ++l) { acc[k] = __builtin_fma(Bv[i], Bv[l], acc[k]); ++k; }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    acc[37 + i] = __builtin_fma(R, M[i], acc[37 + i]); acc[40 + i] = __builtin_fma(R, A[i], acc[40 + i]); acc[43 + i] = __builtin_fma(R, Bv[i], acc[43 + i]);
+  }
+  if (CROSS) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int l = 0; l < 3; ++l) acc[46 + 3 * i + l] = __builtin_fma(A[i], Bv[l], acc[46 + 3 * i + l]);
+  }
+}
+
+// output slot t of a block partial (layout below) = sgn[t] * acc[idx[t]] of the reduced accumulators
+struct LmSlotMap { short idx[91]; signed char sgn[91]; };
+constexpr int lm_tri3(int i, int l) { return i <= l ? (i == 0 ? l : i == 1 ? 2 + l : 5) : lm_tri3(l, i); }   // 00 01 02 11 12 22
+constexpr LmSlotMap make_lm_slot_map() {
+  LmSlotMap m{};
+  m.idx[0] = 0; m.sgn[0] = 1;
+  int k = 1;
   for (int i = 0; i < 6; ++i)
+    for (int l = i; l < 6; ++l, ++k) {                    // SS = js js^T, js = [-m a]
+      if (l < 3) { m.idx[k] = (short)(1 + lm_tri3(i, l)); m.sgn[k] = 1; }
+      else if (i < 3) { m.idx[k] = (short)(7 + 3 * i + (l - 3)); m.sgn[k] = -1; }
+      else { m.idx[k] = (short)(16 + lm_tri3(i - 3, l - 3)); m.sgn[k] = 1; }
+    }
+  for (int i = 0; i < 6; ++i) {                           // bs = r js
+    if (i < 3) { m.idx[22 + i] = (short)(37 + i); m.sgn[22 + i] = -1; }
+    else { m.idx[22 + i] = (short)(40 + i - 3); m.sgn[22 + i] = 1; }
+  }
+  k = 28;
+  for (int i = 0; i < 6; ++i)
+    for (int l = i; l < 6; ++l, ++k) {                    // TT = jt jt^T, jt = [m b]
+      if (l < 3) { m.idx[k] = (short)(1 + lm_tri3(i, l)); m.sgn[k] = 1; }
+      else if (i < 3) { m.idx[k] = (short)(22 + 3 * i + (l - 3)); m.sgn[k] = 1; }
+      else { m.idx[k] = (short)(31 + lm_tri3(i - 3, l - 3)); m.sgn[k] = 1; }
+    }
+  for (int i = 0; i < 6; ++i) {                           // bt = r jt
+    m.idx[49 + i] = (short)(i < 3 ? 37 + i : 43 + i - 3); m.sgn[49 + i] = 1;
+  }
+  for (int i = 0; i < 6; ++i)
+    for (int l = 0; l < 6; ++l) {                         // ST = js jt^T
+      const int t = 55 + 6 * i + l;
+      if (i < 3 && l < 3) { m.idx[t] = (short)(1 + lm_tri3(i, l)); m.sgn[t] = -1; }
+      else if (i < 3) { m.idx[t] = (short)(22 + 3 * i + (l - 3)); m.sgn[t] = -1; }
+      else if (l < 3) { m.idx[t] = (short)(7 + 3 * l + (i - 3)); m.sgn[t] = 1; }
+      else { m.idx[t] = (short)(46 + 3 * (i - 3) + (l - 3)); m.sgn[t] = 1; }
+    }
+  return m;
+}
+__device__ const LmSlotMap kLmSlotMap = make_lm_slot_map();
+
+// one correspondence (T = float, H = 0) or one half of a packed pair (T = f2_t, H = 0 / 1) into the accumulators
+template <int MODE, int H, typename T>
+__device__ __forceinline__ void lm_accumulate(double* acc, const CorrRowsT<T>& R, const int side) {
+  constexpr bool kOne = (MODE == kModeOne);
+  constexpr bool kCross = (MODE == kModeTwoCross);
+  const float r1 = half_of<H>(R.r1), r2 = half_of<H>(R.r2);
+  if (MODE == kModeCost) {
+    acc[0] += (double)(r1 * r1);
+    acc[0] += (double)(r2 * r2);
+  } else if (kOne) {
+    // only one side of the pair has variables (the other is impl cloud 0); block-uniform branch
+    float j1[6], j2[6];
+    if (side == 0) {
 #pragma unroll
-    for (int l = 0; l < 6; ++l) H36[6 * i + l] += A[i] * Bv[l];
+      for (int i = 0; i < 3; ++i) { j1[i] = -half_of<H>(R.m1[i]); j1[3 + i] = half_of<H>(R.a1[i]); j2[i] = -half_of<H>(R.m2[i]); j2[3 + i] = half_of<H>(R.a2[i]); }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { j1[i] = half_of<H>(R.m1[i]); j1[3 + i] = half_of<H>(R.b1[i]); j2[i] = half_of<H>(R.m2[i]); j2[3 + i] = half_of<H>(R.b2[i]); }
+    }
+    acc[0] += (double)(r1 * r1);
+    acc_diag(acc + 1, acc + 22, j1, r1);
+    acc[0] += (double)(r2 * r2);
+    acc_diag(acc + 1, acc + 22, j2, r2);
+  } else {
+    acc[0] += (double)(r1 * r1);
+    acc_reduced<kCross>(acc, half_of<H>(R.m1[0]), half_of<H>(R.m1[1]), half_of<H>(R.m1[2]), half_of<H>(R.a1[0]), half_of<H>(R.a1[1]),
+                        half_of<H>(R.a1[2]), half_of<H>(R.b1[0]), half_of<H>(R.b1[1]), half_of<H>(R.b1[2]), r1);
+    acc[0] += (double)(r2 * r2);
+    acc_reduced<kCross>(acc, half_of<H>(R.m2[0]), half_of<H>(R.m2[1]), half_of<H>(R.m2[2]), half_of<H>(R.a2[0]), half_of<H>(R.a2[1]),
+                        half_of<H>(R.a2[2]), half_of<H>(R.b2[0]), half_of<H>(R.b2[1]), half_of<H>(R.b2[2]), r2);
+  }
+}
+
+template <int MODE, typename T, typename V4>
+__device__ __forceinline__ void lm_rows(const LmSet& S, const V4& a, const V4& b, const V4& c, CorrRowsT<T>& R) {
+  if (MODE == kModeCost) corr_rows<false, false, T>(S, a, b, c, R);
+  else if (MODE == kModeOne) {
+    if (S.side == 0) corr_rows<true, false, T>(S, a, b, c, R); else corr_rows<false, true, T>(S, a, b, c, R);
+  } else corr_rows<true, true, T>(S, a, b, c, R);
 }
 
 // Output slot layout per block / per set (kLmSlot doubles):
 //   [0] cost, [1..21] SS upper, [22..27] bs, [28..48] TT upper, [49..54] bt, [55..90] ST (6x6)
-template <int MODE>
-__global__ __launch_bounds__(kBlock) void k_lm_pass(const float4* __restrict__ A, const float4* __restrict__ B,
-                                                    const float4* __restrict__ C, const LmSet* __restrict__ sets,
-                                                    const int* __restrict__ block_set, int block_base,
-                                                    double* __restrict__ partial) {
+// Every thread walks its correspondences c, c + stride, c + 2 stride, ... in this order and adds row 1 then row 2 of each: the
+// per-thread sums, and with the fixed reduction tree the block partials, are the same numbers whatever the loop shape.
+// Loop shapes (tools/micro/lm_variants.hip measures them; LmCfg holds the choice per mode):
+//   UNR  correspondences per trip (1 or 2);  PACK  the two of a trip share packed f32 instructions;
+//   PF   the next trip's float4 loads are issued before the current trip's arithmetic (at 2 - 3 waves per SIMD -- the f64
+//        accumulators -- the loads in flight per lane, not the occupancy, have to cover the HBM latency).
+template <int MODE, int UNR, bool PACK, bool PF>
+__device__ __forceinline__ void lm_pass_body(const float4* __restrict__ A, const float4* __restrict__ B,
+                                             const float4* __restrict__ C, const LmSet* __restrict__ sets,
+                                             const int* __restrict__ block_set, const int block_base,
+                                             double* __restrict__ partial) {
   constexpr bool kOne = (MODE == kModeOne);
-  constexpr bool kTwo = (MODE == kModeTwo || MODE == kModeTwoCross);
   constexpr bool kCross = (MODE == kModeTwoCross);
-  constexpr int NACC = (MODE == kModeCost) ? 1 : kOne ? 28 : kCross ? 91 : 55;
+  constexpr int NACC = (MODE == kModeCost) ? 1 : kOne ? 28 : kCross ? kAccCross : kAccTwo;
   const int gb = block_base + blockIdx.x;
   const int si = block_set[gb];
   const LmSet S = sets[si];
@@ -1517,42 +1700,54 @@ __global__ __launch_bounds__(kBlock) void k_lm_pass(const float4* __restrict__ A
   for (int i = 0; i < NACC; ++i) acc[i] = 0.0;
 
   const long long stride = (long long)S.nblocks * kBlock;
-  for (long long c = (long long)(gb - S.block_begin) * kBlock + threadIdx.x; c < S.n; c += stride) {
-    const float4 a = A[S.off + c], b = B[S.off + c], cc = C[S.off + c];
-    CorrRows R;
-    if (MODE == kModeCost) {
-      corr_rows<false, false>(S, a, b, cc, R);
-      acc[0] += (double)(R.r1 * R.r1);
-      acc[0] += (double)(R.r2 * R.r2);
-    } else if (kOne) {
-      // only one side of the pair has variables (the other is impl cloud 0); block-uniform branch
-      if (S.side == 0) {
-        corr_rows<true, false>(S, a, b, cc, R);
-        acc[0] += (double)(R.r1 * R.r1);
-        acc_diag(acc + 1, acc + 22, R.j1s, R.r1);
-        acc[0] += (double)(R.r2 * R.r2);
-        acc_diag(acc + 1, acc + 22, R.j2s, R.r2);
+  const float4* __restrict__ pa = A + S.off;
+  const float4* __restrict__ pb = B + S.off;
+  const float4* __restrict__ pc = C + S.off;
+  long long c = (long long)(gb - S.block_begin) * kBlock + threadIdx.x;
+  if (UNR == 2) {
+    float4 a0, b0, c0, a1, b1, c1;
+    if (PF && c + stride < S.n) { a0 = pa[c]; b0 = pb[c]; c0 = pc[c]; a1 = pa[c + stride]; b1 = pb[c + stride]; c1 = pc[c + stride]; }
+    while (c + stride < S.n) {
+      if (!PF) { a0 = pa[c]; b0 = pb[c]; c0 = pc[c]; a1 = pa[c + stride]; b1 = pb[c + stride]; c1 = pc[c + stride]; }
+      const float4 ua = a0, ub = b0, uc = c0, va = a1, vb = b1, vc = c1;
+      c += 2 * stride;
+      if (PF && c + stride < S.n) { a0 = pa[c]; b0 = pb[c]; c0 = pc[c]; a1 = pa[c + stride]; b1 = pb[c + stride]; c1 = pc[c + stride]; }
+      if (PACK) {
+        const Pair4 pa2 = pair4(ua, va), pb2 = pair4(ub, vb), pc2 = pair4(uc, vc);
+        CorrRowsT<f2_t> R;
+        lm_rows<MODE, f2_t>(S, pa2, pb2, pc2, R);
+        lm_accumulate<MODE, 0, f2_t>(acc, R, S.side);
+        lm_accumulate<MODE, 1, f2_t>(acc, R, S.side);
       } else {
-        corr_rows<false, true>(S, a, b, cc, R);
-        acc[0] += (double)(R.r1 * R.r1);
-        acc_diag(acc + 1, acc + 22, R.j1t, R.r1);
-        acc[0] += (double)(R.r2 * R.r2);
-        acc_diag(acc + 1, acc + 22, R.j2t, R.r2);
+        CorrRowsT<float> R;
+        lm_rows<MODE, float>(S, ua, ub, uc, R);
+        lm_accumulate<MODE, 0, float>(acc, R, S.side);
+        lm_rows<MODE, float>(S, va, vb, vc, R);
+        lm_accumulate<MODE, 0, float>(acc, R, S.side);
       }
-    } else if (kTwo) {
-      corr_rows<true, true>(S, a, b, cc, R);
-      acc[0] += (double)(R.r1 * R.r1);
-      acc_diag(acc + 1, acc + 22, R.j1s, R.r1);
-      acc_diag(acc + 28, acc + 49, R.j1t, R.r1);
-      if (kCross) acc_cross(acc + 55, R.j1s, R.j1t);
-      acc[0] += (double)(R.r2 * R.r2);
-      acc_diag(acc + 1, acc + 22, R.j2s, R.r2);
-      acc_diag(acc + 28, acc + 49, R.j2t, R.r2);
-      if (kCross) acc_cross(acc + 55, R.j2s, R.j2t);
+    }
+    if (c < S.n) {
+      const float4 a = pa[c], b = pb[c], cc = pc[c];
+      CorrRowsT<float> R;
+      lm_rows<MODE, float>(S, a, b, cc, R);
+      lm_accumulate<MODE, 0, float>(acc, R, S.side);
+    }
+  } else {
+    float4 a0, b0, c0;
+    if (PF && c < S.n) { a0 = pa[c]; b0 = pb[c]; c0 = pc[c]; }
+    while (c < S.n) {
+      if (!PF) { a0 = pa[c]; b0 = pb[c]; c0 = pc[c]; }
+      const float4 ua = a0, ub = b0, uc = c0;
+      c += stride;
+      if (PF && c < S.n) { a0 = pa[c]; b0 = pb[c]; c0 = pc[c]; }
+      CorrRowsT<float> R;
+      lm_rows<MODE, float>(S, ua, ub, uc, R);
+      lm_accumulate<MODE, 0, float>(acc, R, S.side);
     }
   }
   // wave reduce -> LDS -> fixed-order block sum
   __shared__ double s[kBlock / kWave][NACC];
+  __shared__ double red[NACC];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
   for (int i = 0; i < NACC; ++i) {
@@ -1560,7 +1755,20 @@ __global__ __launch_bounds__(kBlock) void k_lm_pass(const float4* __restrict__ A
     if (lane == 0) s[w][i] = v;
   }
   __syncthreads();
-  if (threadIdx.x < kLmSlot) {
+  if (MODE == kModeTwo || MODE == kModeTwoCross) {
+    if (threadIdx.x < NACC) {
+      double v = s[0][threadIdx.x];
+      for (int k = 1; k < kBlock / kWave; ++k) v += s[k][threadIdx.x];
+      red[threadIdx.x] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < kLmSlot) {
+      const int t = threadIdx.x;
+      double v = 0.0;
+      if (t < 55 || kCross) { v = red[kLmSlotMap.idx[t]]; if (kLmSlotMap.sgn[t] < 0) v = -v; }
+      partial[(size_t)gb * kLmSlot + t] = v;             // kModeTwo: the ST block is never read [QUIRK], zeros
+    }
+  } else if (threadIdx.x < kLmSlot) {
     double v = 0.0;
     if (threadIdx.x < NACC) {
       v = s[0][threadIdx.x];
@@ -1570,39 +1778,97 @@ __global__ __launch_bounds__(kBlock) void k_lm_pass(const float4* __restrict__ A
   }
 }
 
+// the loop shape each mode runs with.  Measured on one MI355X (tools/micro/lm_variants.hip, 1e8 correspondences in 8 sets,
+// profiles/round3_lm_variants.txt): one correspondence per trip with the next one's loads in flight wins in every mode; three
+// waves per SIMD (168 VGPRs) for the two-sided modes, which the 55 / 46 f64 accumulators allow.  The packed f32 form does
+// not pay here: the compiler spends 48 VGPRs on splatted pose scalars and ~20 v_mov per trip on interleaving the pair.
+template <int MODE> struct LmCfg { static constexpr int unr = 1; static constexpr bool pack = false, pf = true; static constexpr int minw = 3; };
+template <> struct LmCfg<kModeCost> { static constexpr int unr = 1; static constexpr bool pack = false, pf = true; static constexpr int minw = 1; };
+template <> struct LmCfg<kModeOne> { static constexpr int unr = 1; static constexpr bool pack = false, pf = true; static constexpr int minw = 2; };
+
+template <int MODE>
+__global__ __launch_bounds__(kBlock, LmCfg<MODE>::minw) void k_lm_pass(const float4* __restrict__ A, const float4* __restrict__ B,
+                                                                       const float4* __restrict__ C, const LmSet* __restrict__ sets,
+                                                                       const int* __restrict__ block_set, int block_base,
+                                                                       double* __restrict__ partial) {
+  lm_pass_body<MODE, LmCfg<MODE>::unr, LmCfg<MODE>::pack, LmCfg<MODE>::pf>(A, B, C, sets, block_set, block_base, partial);
+}
+
 // a8, batched: the LM tries 1..9 of one inner iteration (lambda doubled each time, icp_point_to_plane_impl.h:216-283)
 // only differ in the candidate poses, so their costs are evaluated in ONE pass over the correspondence planes: each
-// correspondence is loaded once and pushed through up to kLmMaxPoses pose sets.  Per pose the arithmetic, the
-// grid-stride order and the reduction tree are exactly those of k_lm_pass<kModeCost>, so every cost is bit-identical
+// correspondence is loaded once and pushed through up to kLmMaxPoses pose sets.  Per pose the arithmetic, the per-thread
+// order of the correspondences and the reduction tree are exactly those of k_lm_pass, so every cost is bit-identical
 // to the one a separate pass would return; the host then takes the first try that lowers the cost, as the
-// reference's sequential loop does.
-__global__ __launch_bounds__(kBlock) void k_lm_cost_multi(const float4* __restrict__ A, const float4* __restrict__ B,
-                                                          const float4* __restrict__ C, const LmSet* __restrict__ sets,
-                                                          const LmPose* __restrict__ poses, int n_sets, int n_poses,
-                                                          const int* __restrict__ block_set, double* __restrict__ partial) {
+// reference's sequential loop does.  (The usual call is the last one of an outer iteration, where all nine tries fail: an
+// early-out after the first few tries would not save it.)  Nine poses are 9 x 80 f32 operations per correspondence, VALU
+// bound: two correspondences go through the packed f32 instructions together, and the side of a kModeOne pair that has no
+// variables (impl cloud 0, the same inner pose in every candidate) is transformed once instead of nine times.
+template <typename T, typename V4>
+__device__ __forceinline__ void lm_costs_of(const LmSet& S, const LmPose* __restrict__ poses, const int n_sets, const int n_poses,
+                                            const int si, const V4& a, const V4& b, const V4& c, T* r1, T* r2) {
+  const bool fixed_tgt = (S.mode == kModeOne && S.side == 0), fixed_src = (S.mode == kModeOne && S.side == 1);
+  CorrPts<T> F;
+  if (fixed_tgt) corr_tgt<T>(S.Rt, S.tt, b.z, b.w, c.x, c.y, c.z, c.w, F);
+  if (fixed_src) corr_src<T>(S.Rs, S.ts, a.x, a.y, a.z, a.w, b.x, b.y, F);
+#pragma unroll
+  for (int k = 0; k < kLmMaxPoses; ++k) {
+    if (k < n_poses) {
+      const LmPose& P = poses[(size_t)k * n_sets + si];
+      CorrPts<T> Q = F;
+      if (!fixed_src) corr_src<T>(P.Rs, P.ts, a.x, a.y, a.z, a.w, b.x, b.y, Q);
+      if (!fixed_tgt) corr_tgt<T>(P.Rt, P.tt, b.z, b.w, c.x, c.y, c.z, c.w, Q);
+      CorrRowsT<T> R;
+      corr_rows_pts<false, false, T>(Q, R);
+      r1[k] = R.r1; r2[k] = R.r2;
+    }
+  }
+}
+
+template <bool PACK, bool PF>
+__device__ __forceinline__ void lm_cost_multi_body(const float4* __restrict__ A, const float4* __restrict__ B,
+                                                   const float4* __restrict__ C, const LmSet* __restrict__ sets,
+                                                   const LmPose* __restrict__ poses, int n_sets, int n_poses,
+                                                   const int* __restrict__ block_set, double* __restrict__ partial) {
   const int gb = blockIdx.x;
   const int si = block_set[gb];
-  LmSet S = sets[si];
+  const LmSet S = sets[si];
   double acc[kLmMaxPoses];
 #pragma unroll
   for (int k = 0; k < kLmMaxPoses; ++k) acc[k] = 0.0;
   const long long stride = (long long)S.nblocks * kBlock;
-  for (long long c = (long long)(gb - S.block_begin) * kBlock + threadIdx.x; c < S.n; c += stride) {
-    const float4 a = A[S.off + c], b = B[S.off + c], cc = C[S.off + c];
+  const float4* __restrict__ pa = A + S.off;
+  const float4* __restrict__ pb = B + S.off;
+  const float4* __restrict__ pc = C + S.off;
+  long long c = (long long)(gb - S.block_begin) * kBlock + threadIdx.x;
+  if (PACK) {
+    float4 a0, b0, c0, a1, b1, c1;
+    if (PF && c + stride < S.n) { a0 = pa[c]; b0 = pb[c]; c0 = pc[c]; a1 = pa[c + stride]; b1 = pb[c + stride]; c1 = pc[c + stride]; }
+    while (c + stride < S.n) {
+      if (!PF) { a0 = pa[c]; b0 = pb[c]; c0 = pc[c]; a1 = pa[c + stride]; b1 = pb[c + stride]; c1 = pc[c + stride]; }
+      const Pair4 pa2 = pair4(a0, a1), pb2 = pair4(b0, b1), pc2 = pair4(c0, c1);
+      c += 2 * stride;
+      if (PF && c + stride < S.n) { a0 = pa[c]; b0 = pb[c]; c0 = pc[c]; a1 = pa[c + stride]; b1 = pb[c + stride]; c1 = pc[c + stride]; }
+      f2_t r1[kLmMaxPoses], r2[kLmMaxPoses];
+      lm_costs_of<f2_t>(S, poses, n_sets, n_poses, si, pa2, pb2, pc2, r1, r2);
 #pragma unroll
-    for (int k = 0; k < kLmMaxPoses; ++k) {
-      if (k < n_poses) {
-        const LmPose P = poses[(size_t)k * n_sets + si];
-#pragma unroll
-        for (int i = 0; i < 9; ++i) { S.Rs[i] = P.Rs[i]; S.Rt[i] = P.Rt[i]; }
-#pragma unroll
-        for (int i = 0; i < 3; ++i) { S.ts[i] = P.ts[i]; S.tt[i] = P.tt[i]; }
-        CorrRows R;
-        corr_rows<false, false>(S, a, b, cc, R);
-        acc[k] += (double)(R.r1 * R.r1);
-        acc[k] += (double)(R.r2 * R.r2);
+      for (int k = 0; k < kLmMaxPoses; ++k) {
+        if (k < n_poses) {
+          const f2_t q1 = r1[k] * r1[k], q2 = r2[k] * r2[k];
+          acc[k] += (double)q1.x; acc[k] += (double)q2.x;     // first correspondence: row 1, row 2; then the second
+          acc[k] += (double)q1.y; acc[k] += (double)q2.y;
+        }
       }
     }
+  }
+  while (c < S.n) {
+    const float4 a = pa[c], b = pb[c], cc = pc[c];
+    float r1[kLmMaxPoses], r2[kLmMaxPoses];
+    lm_costs_of<float>(S, poses, n_sets, n_poses, si, a, b, cc, r1, r2);
+#pragma unroll
+    for (int k = 0; k < kLmMaxPoses; ++k) {
+      if (k < n_poses) { acc[k] += (double)(r1[k] * r1[k]); acc[k] += (double)(r2[k] * r2[k]); }
+    }
+    c += stride;
   }
   __shared__ double s[kBlock / kWave][kLmMaxPoses];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -1620,6 +1886,13 @@ __global__ __launch_bounds__(kBlock) void k_lm_cost_multi(const float4* __restri
     }
     partial[(size_t)gb * kLmSlot + threadIdx.x] = v;
   }
+}
+
+__global__ __launch_bounds__(kBlock) void k_lm_cost_multi(const float4* __restrict__ A, const float4* __restrict__ B,
+                                                          const float4* __restrict__ C, const LmSet* __restrict__ sets,
+                                                          const LmPose* __restrict__ poses, int n_sets, int n_poses,
+                                                          const int* __restrict__ block_set, double* __restrict__ partial) {
+  lm_cost_multi_body<true, true>(A, B, C, sets, poses, n_sets, n_poses, block_set, partial);
 }
 
 // one block per set: sum the set's block partials in a fixed order.  kRedParts threads share each of the
@@ -1774,11 +2047,11 @@ void launch_query_keys32_list(const float4* Gsrc, const unsigned* list, size_t n
   hipLaunchKernelGGL(k_query_keys32_list, dim3((unsigned)div_up(n, kBlock)), dim3(kBlock), 0, s, Gsrc, list, n, g, im, qr, keys, vals);
 }
 
-void launch_nn_certify(const float4* Gsrc, size_t n, const float4* Gtgt, float cum_up, float r2, float near2, int* match, int* match2,
+void launch_nn_certify(const float4* Gsrc, size_t n, const float4* Gtgt, float cum_up, float r2, float near2, bool none_near, int* match, int* match2,
                        const float* lbe, float* match_d2, unsigned* todo_near, unsigned* todo_far, unsigned* counts, hipStream_t s) {
   if (!n) return;
   hipLaunchKernelGGL(k_nn_certify, dim3((unsigned)div_up(n, (size_t)kCertPerWave * (kBlock / kWave))), dim3(kBlock), 0, s, Gsrc, n, Gtgt,
-                     cum_up, r2, near2, match, match2, lbe, match_d2, todo_near, todo_far, counts);
+                     cum_up, r2, near2, none_near ? 1 : 0, match, match2, lbe, match_d2, todo_near, todo_far, counts);
 }
 
 void launch_nn_bounded(const float4* Gsrc, const unsigned* list, size_t n_list, const float4* Gtgt, const unsigned* dense_start,

@@ -76,7 +76,8 @@ void launch_query_keys32_list(const float4* Gsrc, const unsigned* list, size_t n
                               const QueryRange& qr, unsigned* keys, unsigned* vals, hipStream_t s);
 // settles every query whose old partner is provably still the unique nearest neighbour within the radius (lbe - cum_up > new
 // distance); lists the others: todo_near (old partner within sqrt(near2)) / todo_far, lengths in counts[0..1] (see k_nn_certify)
-void launch_nn_certify(const float4* Gsrc, size_t n, const float4* Gtgt, float cum_up, float r2, float near2, int* match, int* match2,
+// none_near: queries without a partner go to todo_near as well (k_nn_bounded searches them beyond the radius)
+void launch_nn_certify(const float4* Gsrc, size_t n, const float4* Gtgt, float cum_up, float r2, float near2, bool none_near, int* match, int* match2,
                        const float* lbe, float* match_d2, unsigned* todo_near, unsigned* todo_far, unsigned* counts, hipStream_t s);
 // bounded search (k_nn_bounded) of the listed queries around their old partners
 struct BoundParams {
@@ -85,6 +86,7 @@ struct BoundParams {
   float rho_pad;         // absolute slack of the global -> local mapping (local units), rounded up
   float cum_lo;          // accumulated motion bound of the pair at this outer iteration, rounded down
   float cell_scale, cell_sub;   // as in CertParams: covered global distance = (distance to the scanned box's faces in cells) * cell_scale - cell_sub
+  float np_extra;        // a query without a partner searches radius + np_extra (its certificate: nothing nearer than that)
 };
 void launch_nn_bounded(const float4* Gsrc, const unsigned* list, size_t n_list, const float4* Gtgt, const unsigned* dense_start,
                        const GridDesc& g, const InvMap& im, const QueryRange& qr, float r2, const BoundParams& bp, int* match,

@@ -27,10 +27,45 @@ def rot_axis_angle(axis, angle):
     return np.eye(3) + math.sin(angle) * K + (1 - math.cos(angle)) * (K @ K)
 
 
-def make_scan(n, origin, yaw, seed, sigma=0.002, device="cpu", room_scale=1.0):
+# The partial-overlap variant of the room ("~30-60 % of points find a partner"): a partition wall (a box
+# 10 cm thick from the y = 0 wall to y = 5) splits the floor plan, the scanner has a maximum range, and a surface point is
+# kept only if the ray from the scanner reaches it unobstructed (cylinders and the partition occlude).  Two scans on either
+# side of the partition then share the open end of the room and little else.
+_PART = (4.95, 5.05, 0.0, 5.0)      # x0, x1, y0, y1 (full height)
+PARTIAL_MAX_RANGE = 6.5
+
+
+def visible_from(p, origin, cyl, part, max_range):
+    """Mask of the surface points p [n,3] (f64 torch, exact surface positions) a scanner at `origin` sees."""
+    o = torch.tensor(origin, device=p.device, dtype=torch.float64)
+    d = p - o
+    vis = d.norm(dim=1) <= max_range
+    dx, dy = d[:, 0], d[:, 1]
+    a = dx * dx + dy * dy
+    for (cx, cy, r) in cyl:                               # vertical cylinders: a circle in the floor plan
+        fx, fy = o[0] - cx, o[1] - cy
+        b = 2.0 * (fx * dx + fy * dy)
+        c = fx * fx + fy * fy - r * r
+        disc = b * b - 4.0 * a * c
+        t0 = (-b - torch.sqrt(disc.clamp_(min=0.0))) / (2.0 * a).clamp_(min=1e-30)
+        vis &= ~((disc > 0) & (t0 > 1e-9) & (t0 < 1.0 - 1e-6))
+    x0, x1, y0, y1 = part                                 # the partition: slab test in the floor plan
+    inv_x = 1.0 / torch.where(dx.abs() < 1e-30, torch.full_like(dx, 1e-30), dx)
+    inv_y = 1.0 / torch.where(dy.abs() < 1e-30, torch.full_like(dy, 1e-30), dy)
+    tx0, tx1 = (x0 - o[0]) * inv_x, (x1 - o[0]) * inv_x
+    ty0, ty1 = (y0 - o[1]) * inv_y, (y1 - o[1]) * inv_y
+    t_in = torch.maximum(torch.minimum(tx0, tx1), torch.minimum(ty0, ty1))
+    t_out = torch.minimum(torch.maximum(tx0, tx1), torch.maximum(ty0, ty1))
+    vis &= ~((t_in < t_out) & (t_out > 1e-9) & (t_in < 1.0 - 1e-6))
+    return vis
+
+
+def make_scan(n, origin, yaw, seed, sigma=0.002, device="cpu", room_scale=1.0, partial=False):
     """Returns (xyz_local[n,3] f32, normals_local[n,3] f32, T_true[4,4] f32 numpy).  room_scale stretches the floor plan
     (walls, cylinder positions, scanner position) in x and y: with n proportional to room_scale^2 the point density stays that
-    of the 10 m room -- the weak-scaling workload of bench.py."""
+    of the 10 m room -- the weak-scaling workload of bench.py.  partial=True: the partial-overlap room (see _PART)."""
+    if partial:
+        return _make_scan_partial(n, origin, yaw, seed, sigma, device)
     g = torch.Generator(device=device)
     g.manual_seed(int(seed))
     W, D, Hh = _ROOM[0] * room_scale, _ROOM[1] * room_scale, _ROOM[2]
@@ -82,6 +117,67 @@ def make_scan(n, origin, yaw, seed, sigma=0.002, device="cpu", room_scale=1.0):
     return xyz_local, nrm_local, T.astype(np.float32)
 
 
+def _surface_samples(m, g, device):
+    """m points sampled uniformly by area on the surfaces of the partial-overlap room: exact positions + outward normals (f64)."""
+    W, D, Hh = _ROOM
+    x0, x1, y0, y1 = _PART
+    areas = [W * D, D * Hh, D * Hh, W * Hh, W * Hh] + [2 * math.pi * r * Hh for (_, _, r) in _CYL] + [(y1 - y0) * Hh, (y1 - y0) * Hh, (x1 - x0) * Hh]
+    cum = torch.tensor(np.cumsum(areas) / np.sum(areas), device=device, dtype=torch.float64)
+    prim = torch.bucketize(torch.rand(m, generator=g, device=device, dtype=torch.float64), cum).clamp_(max=len(areas) - 1)
+    u = torch.rand(m, generator=g, device=device, dtype=torch.float64)
+    v = torch.rand(m, generator=g, device=device, dtype=torch.float64)
+    p = torch.zeros(m, 3, device=device, dtype=torch.float64)
+    nr = torch.zeros(m, 3, device=device, dtype=torch.float64)
+
+    def put(mask, px, py, pz, nx, ny, nz):
+        p[mask, 0] = px; p[mask, 1] = py; p[mask, 2] = pz
+        nr[mask, 0] = nx; nr[mask, 1] = ny; nr[mask, 2] = nz
+
+    k = prim == 0; put(k, u[k] * W, v[k] * D, 0.0, 0.0, 0.0, 1.0)
+    k = prim == 1; put(k, 0.0, u[k] * D, v[k] * Hh, 1.0, 0.0, 0.0)
+    k = prim == 2; put(k, W, u[k] * D, v[k] * Hh, -1.0, 0.0, 0.0)
+    k = prim == 3; put(k, u[k] * W, 0.0, v[k] * Hh, 0.0, 1.0, 0.0)
+    k = prim == 4; put(k, u[k] * W, D, v[k] * Hh, 0.0, -1.0, 0.0)
+    for ci, (cx, cy, r) in enumerate(_CYL):
+        k = prim == 5 + ci
+        ang = u[k] * (2 * math.pi)
+        put(k, cx + r * torch.cos(ang), cy + r * torch.sin(ang), v[k] * Hh, torch.cos(ang), torch.sin(ang), 0.0)
+    k = prim == 8; put(k, x0, y0 + u[k] * (y1 - y0), v[k] * Hh, -1.0, 0.0, 0.0)
+    k = prim == 9; put(k, x1, y0 + u[k] * (y1 - y0), v[k] * Hh, 1.0, 0.0, 0.0)
+    k = prim == 10; put(k, x0 + u[k] * (x1 - x0), y1, v[k] * Hh, 0.0, 1.0, 0.0)
+    # the floor under the partition is not a visible surface
+    under = (prim == 0) & (p[:, 0] > x0) & (p[:, 0] < x1) & (p[:, 1] < y1)
+    return p, nr, ~under
+
+
+def _make_scan_partial(n, origin, yaw, seed, sigma, device):
+    g = torch.Generator(device=device)
+    g.manual_seed(int(seed))
+    x0, x1, y0, y1 = _PART
+    if x0 - 0.3 < origin[0] < x1 + 0.3 and origin[1] < y1 + 0.3:      # a scanner inside the partition: step aside
+        origin = (origin[0] + 0.6, origin[1], origin[2])
+    ps, ns, have = [], [], 0
+    chunk = max(4096, int(1.6 * n))
+    while have < n:                                        # deterministic: the chunk size is a function of n only
+        p, nr, ok = _surface_samples(chunk, g, device)
+        keep = ok & visible_from(p, origin, _CYL, _PART, PARTIAL_MAX_RANGE)
+        ps.append(p[keep]); ns.append(nr[keep]); have += int(keep.sum())
+    p = torch.cat(ps)[:n]; nr = torch.cat(ns)[:n]
+    o = torch.tensor(origin, device=device, dtype=torch.float64)
+    ray = p - o
+    ray = ray / ray.norm(dim=1, keepdim=True).clamp_(min=1e-9)
+    p = p + torch.randn(n, 1, generator=g, device=device, dtype=torch.float64) * sigma * ray
+    flip = ((o - p) * nr).sum(dim=1, keepdim=True) < 0
+    nr = torch.where(flip, -nr, nr)
+    R = torch.tensor(_rot_z(yaw), device=device, dtype=torch.float64)
+    xyz_local = ((p - o) @ R).to(torch.float32).contiguous()
+    nrm_local = (nr @ R).to(torch.float32).contiguous()
+    T = np.eye(4, dtype=np.float64)
+    T[:3, :3] = _rot_z(yaw)
+    T[:3, 3] = np.asarray(origin, dtype=np.float64)
+    return xyz_local, nrm_local, T.astype(np.float32)
+
+
 SCAN_POSES = [((4.0, 5.0, 1.5), 0.3), ((6.0, 5.5, 1.4), -0.4), ((2.5, 2.5, 1.6), 1.1), ((7.5, 7.5, 1.3), 2.0),
               ((5.0, 2.0, 1.5), -1.3), ((2.0, 7.0, 1.45), 0.8), ((8.0, 3.0, 1.55), -2.2), ((5.0, 8.0, 1.35), 2.9),
               ((3.5, 6.0, 1.5), 0.1), ((6.5, 2.5, 1.4), -0.9), ((1.5, 4.5, 1.6), 1.7), ((8.5, 6.0, 1.3), -1.9),
@@ -104,12 +200,13 @@ def perturbation(index, angle_scale=1.0):
     return P
 
 
-def make_scene(n_scans, n_points, seed=1234, sigma=0.002, device="cpu", room_scale=1.0):
-    """List of dicts {xyz, normals, T_true, T_init} (T_init = perturbation * T_true applied about the scan origin)."""
+def make_scene(n_scans, n_points, seed=1234, sigma=0.002, device="cpu", room_scale=1.0, partial=False):
+    """List of dicts {xyz, normals, T_true, T_init} (T_init = perturbation * T_true applied about the scan origin).
+    partial=True: the partial-overlap room (partition wall, occlusion, maximum range; room_scale must be 1)."""
     scans = []
     for i in range(n_scans):
         origin, yaw = SCAN_POSES[i % len(SCAN_POSES)]
-        xyz, nrm, T = make_scan(n_points, origin, yaw, seed + 17 * i, sigma, device, room_scale)
+        xyz, nrm, T = make_scan(n_points, origin, yaw, seed + 17 * i, sigma, device, room_scale, partial)
         P = perturbation(i, 1.0 / room_scale)
         Ti = T.astype(np.float64).copy()
         Ti[:3, :3] = P[:3, :3] @ Ti[:3, :3]

@@ -200,6 +200,34 @@ def test_icp_c1_config(e3d, ob, synth, nn_mode):
     assert tr1 < 0.3 * tr0 and ang1 < 0.3 * ang0
 
 
+def test_icp_partial_overlap(e3d, ob, synth, nn_mode):
+    """about half of the points find a partner (partition wall, occlusion, maximum range).  The branch of
+    FindCorrespondencesFast that skips a query (icp_point_to_plane.cc:68-75) is in every iteration; with the certificates the
+    queries without a partner are settled by "nothing within the radius" bounds (k_nn_certify / k_nn_bounded): counts per
+    pair and iteration identical to the oracle over a whole run."""
+    scans = synth.make_scene(2, 120_000, seed=77, partial=True)
+    clouds = [(s["xyz"].numpy(), s["normals"].numpy(), s["T_init"], False) for s in scans]
+    g, o, ids, cg, co = _run_both(e3d, ob, clouds, 0.05, 12, thr=1e-9)
+    _compare(g, o, ids, cg, co)
+    counts = [r[3] for r in g.pair_records()]
+    assert 0.3 * 120_000 < counts[-1] < 0.65 * 120_000, counts          # the scene is what it claims to be
+    rec = g.iter_records()
+    if nn_mode == 3:   # (auto picks the per-query kernel at this density) the certificates were consulted in every later iteration
+        assert all(r["nn_certify_queries"] == 240_000 for r in rec[1:]), rec
+
+
+def test_icp_partial_overlap_three_scans(e3d, ob, synth):
+    """Three partially overlapping scans, six directed pairs, the row kernel with certificates on small clouds."""
+    assert e3d.lib().e3d_set_nn_mode(3) == 0
+    try:
+        scans = synth.make_scene(3, 60_000, seed=5, partial=True)
+        clouds = [(s["xyz"].numpy(), s["normals"].numpy(), s["T_init"], False) for s in scans]
+        g, o, ids, cg, co = _run_both(e3d, ob, clouds, 0.08, 10, thr=1e-9)
+        _compare(g, o, ids, cg, co)
+    finally:
+        e3d.lib().e3d_set_nn_mode(0)
+
+
 def test_nn_dense_buckets_overflow(e3d, ob, nn_mode):
     """More candidates per 27-cell neighbourhood than one LDS batch holds (kNNCap = 256): batches must chain."""
     rng = np.random.RandomState(21)

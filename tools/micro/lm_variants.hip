@@ -1,0 +1,120 @@
+// Loop shapes of the LM pass kernels measured against each other on the device at hand (DESIGN.md section 4.2 quotes the
+// result; LmCfg in e3d_icp_kernels.hip holds the choice).  The kernel bodies are the product's: this file includes the
+// translation unit and only adds __global__ wrappers with other template arguments and launch bounds.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-fast-math \
+//         -o lm_variants tools/micro/lm_variants.hip && ./lm_variants [million correspondences] [sets]
+#include "../../dataset-pipeline_amd/csrc/e3d_icp_kernels.hip"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <random>
+#include <vector>
+
+namespace e3d {
+void set_last_error(const std::string&) {}
+bool release_cached_device_memory() { return false; }
+}
+using namespace e3d;
+
+template <int MODE, int UNR, bool PACK, bool PF, int MINW>
+__global__ __launch_bounds__(kBlock, MINW) void k_var(const float4* __restrict__ A, const float4* __restrict__ B,
+                                                      const float4* __restrict__ C, const LmSet* __restrict__ sets,
+                                                      const int* __restrict__ block_set, int block_base, double* __restrict__ partial) {
+  lm_pass_body<MODE, UNR, PACK, PF>(A, B, C, sets, block_set, block_base, partial);
+}
+template <bool PACK, bool PF, int MINW>
+__global__ __launch_bounds__(kBlock, MINW) void k_cm(const float4* __restrict__ A, const float4* __restrict__ B,
+                                                     const float4* __restrict__ C, const LmSet* __restrict__ sets,
+                                                     const LmPose* __restrict__ poses, int n_sets, int n_poses,
+                                                     const int* __restrict__ block_set, double* __restrict__ partial) {
+  lm_cost_multi_body<PACK, PF>(A, B, C, sets, poses, n_sets, n_poses, block_set, partial);
+}
+
+__global__ void k_fill(float4* A, float4* B, float4* C, size_t n, unsigned seed) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    unsigned h = (unsigned)i * 2654435761u + seed;
+    auto rnd = [&]() { h ^= h << 13; h ^= h >> 17; h ^= h << 5; return (float)(h & 0xFFFFFF) / 16777216.f - 0.5f; };
+    const float px = 10.f * rnd(), py = 10.f * rnd(), pz = 3.f * rnd();
+    float nx = rnd(), ny = rnd(), nz = rnd() + 0.7f;
+    const float l = 1.f / sqrtf(nx * nx + ny * ny + nz * nz); nx *= l; ny *= l; nz *= l;
+    const float qx = px + 0.004f * rnd(), qy = py + 0.004f * rnd(), qz = pz + 0.004f * rnd();
+    A[i] = make_float4(px, py, pz, nx); B[i] = make_float4(ny, nz, qx, qy); C[i] = make_float4(qz, nx, ny, nz);
+  }
+}
+
+static void quat(float w, float x, float y, float z, float* R) {
+  const float n = 1.f / std::sqrt(w * w + x * x + y * y + z * z); w *= n; x *= n; y *= n; z *= n;
+  R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - z * w); R[2] = 2 * (x * z + y * w);
+  R[3] = 2 * (x * y + z * w); R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - x * w);
+  R[6] = 2 * (x * z - y * w); R[7] = 2 * (y * z + x * w); R[8] = 1 - 2 * (x * x + y * y);
+}
+
+int main(int argc, char** argv) {
+  const size_t n = (size_t)((argc > 1 ? atof(argv[1]) : 100.0) * 1e6);
+  const int ns = argc > 2 ? atoi(argv[2]) : 8;
+  float4 *A, *B, *C;
+  if (hipMalloc(&A, n * 16) != hipSuccess || hipMalloc(&B, n * 16) != hipSuccess || hipMalloc(&C, n * 16) != hipSuccess) { printf("alloc failed\n"); return 1; }
+  hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, A, B, C, n, 12345u);
+  std::vector<LmSet> sets(ns);
+  std::vector<int> block_set;
+  int block = 0;
+  for (int i = 0; i < ns; ++i) {
+    LmSet& S = sets[i];
+    S.off = (long long)(n / ns) * i; S.n = (long long)(n / ns) - 7 * i;   // ragged ends: tails of every shape
+    long long b = (S.n + (long long)kBlock * 8 - 1) / ((long long)kBlock * 8); if (b > 1024) b = 1024; if (b < 1) b = 1;
+    S.block_begin = block; S.nblocks = (int)b; S.mode = 3; S.side = i & 1;
+    quat(1.f, 0.001f * (i + 1), -0.002f, 0.0015f, S.Rs); quat(1.f, -0.001f, 0.0005f * (i + 1), 0.002f, S.Rt);
+    for (int k = 0; k < 3; ++k) { S.ts[k] = 0.001f * (k + 1); S.tt[k] = -0.0007f * (k + 1); }
+    for (int k = 0; k < S.nblocks; ++k) block_set.push_back(i);
+    block += S.nblocks;
+  }
+  std::vector<LmPose> poses((size_t)kLmMaxPoses * ns);
+  for (int k = 0; k < kLmMaxPoses; ++k)
+    for (int i = 0; i < ns; ++i) {
+      LmPose& P = poses[(size_t)k * ns + i];
+      quat(1.f, 0.001f * (i + 1) / (k + 1), -0.002f, 0.0015f, P.Rs); quat(1.f, -0.001f, 0.0005f * (i + 1) / (k + 1), 0.002f, P.Rt);
+      for (int c = 0; c < 3; ++c) { P.ts[c] = 0.001f * (c + 1) / (k + 1); P.tt[c] = -0.0007f * (c + 1); }
+    }
+  LmSet* dsets; int* dbs; double* part; LmPose* dposes;
+  hipMalloc(&dsets, sizeof(LmSet) * ns); hipMalloc(&dbs, sizeof(int) * block); hipMalloc(&part, sizeof(double) * kLmSlot * block);
+  hipMalloc(&dposes, sizeof(LmPose) * poses.size());
+  hipMemcpy(dbs, block_set.data(), sizeof(int) * block, hipMemcpyHostToDevice);
+  hipMemcpy(dposes, poses.data(), sizeof(LmPose) * poses.size(), hipMemcpyHostToDevice);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  std::vector<double> ref((size_t)kLmSlot * block), got(ref.size());
+  printf("%zu correspondences in %d sets, %d blocks; HBM floor at 8 TB/s: %.3f ms\n", n, ns, block, n * 48.0 / 8e12 * 1e3);
+
+  auto run = [&](const char* name, int mode, int side_mode, auto launch, bool first) {
+    for (int i = 0; i < ns; ++i) { sets[i].mode = mode; if (side_mode >= 0) sets[i].side = side_mode; }
+    hipMemcpy(dsets, sets.data(), sizeof(LmSet) * ns, hipMemcpyHostToDevice);
+    hipMemset(part, 0xFF, sizeof(double) * kLmSlot * block);
+    launch(); hipDeviceSynchronize();
+    hipMemcpy(got.data(), part, sizeof(double) * got.size(), hipMemcpyDeviceToHost);
+    if (first) ref = got;
+    const bool same = std::memcmp(ref.data(), got.data(), sizeof(double) * got.size()) == 0;
+    float best = 1e9f;
+    for (int r = 0; r < 5; ++r) {
+      hipEventRecord(e0); launch(); hipEventRecord(e1); hipEventSynchronize(e1);
+      float ms; hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
+    }
+    hipError_t err = hipGetLastError();
+    printf("%-34s %8.3f ms  %6.2f TB/s (48 B)  %s %s\n", name, best, n * 48.0 / (best * 1e-3) / 1e12, same ? "bits==first" : "DIFFERENT", err == hipSuccess ? "" : hipGetErrorString(err));
+    fflush(stdout);
+  };
+#define V(MODE, UNR, PACK, PF, MINW, FIRST) \
+  run("mode" #MODE " unr" #UNR " pack" #PACK " pf" #PF " minw" #MINW, MODE, -1, [&] { hipLaunchKernelGGL((k_var<MODE, UNR, PACK, PF, MINW>), dim3(block), dim3(kBlock), 0, 0, A, B, C, dsets, dbs, 0, part); }, FIRST)
+#define VM(MODE)                                                                                                              \
+  V(MODE, 1, false, false, 1, true); V(MODE, 1, false, true, 1, false); V(MODE, 1, false, false, 2, false); V(MODE, 1, false, true, 2, false); \
+  V(MODE, 1, false, false, 3, false); V(MODE, 1, false, true, 3, false);                                                      \
+  V(MODE, 2, false, false, 2, false); V(MODE, 2, false, true, 2, false); V(MODE, 2, false, true, 3, false);                   \
+  V(MODE, 2, true, false, 1, false); V(MODE, 2, true, true, 1, false); V(MODE, 2, true, false, 2, false); V(MODE, 2, true, true, 2, false); \
+  V(MODE, 2, true, false, 3, false); V(MODE, 2, true, true, 3, false);
+  VM(3) VM(2) VM(1)
+  V(0, 1, false, false, 1, true); V(0, 1, false, true, 1, false); V(0, 2, true, false, 1, false); V(0, 2, true, true, 1, false); V(0, 2, true, true, 4, false);
+#define CM(PACK, PF, MINW, MODE, SIDE, FIRST) \
+  run("cost_multi pack" #PACK " pf" #PF " minw" #MINW " mode" #MODE, MODE, SIDE, [&] { hipLaunchKernelGGL((k_cm<PACK, PF, MINW>), dim3(block), dim3(kBlock), 0, 0, A, B, C, dsets, dposes, ns, kLmMaxPoses, dbs, part); }, FIRST)
+  CM(false, false, 1, 3, 0, true); CM(true, false, 1, 3, 0, false); CM(true, true, 1, 3, 0, false); CM(true, true, 2, 3, 0, false); CM(true, false, 2, 3, 0, false); CM(true, true, 3, 3, 0, false);
+  CM(false, false, 1, 1, 0, true); CM(true, false, 1, 1, 0, false); CM(true, true, 1, 1, 0, false); CM(true, true, 2, 1, 0, false); CM(true, false, 2, 1, 0, false); CM(true, true, 3, 1, 0, false);
+  return 0;
+}

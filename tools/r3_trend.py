@@ -1,0 +1,27 @@
+"""Per-iteration cost split of an ICP run on two synthetic scans (full-overlap room or the partial-overlap room).
+usage: python tools/r3_trend.py [points_per_scan] [iterations] [partial 0/1] [d]"""
+import importlib, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+e3d = importlib.import_module("dataset-pipeline_amd")
+synth = importlib.import_module("dataset-pipeline_amd.synth")
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 50_000_000
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 25
+partial = len(sys.argv) > 3 and sys.argv[3] == "1"
+d = float(sys.argv[4]) if len(sys.argv) > 4 else 0.01
+dev = torch.device("cuda", 0)
+scans = synth.make_scene(2, n, seed=1234, sigma=0.002, device=dev, partial=partial)
+icp = e3d.PointToPlaneICP(device=0)
+for s in scans:
+    icp.add_point_cloud(s["xyz"], s["normals"], s["T_init"], False)
+del scans
+for it in range(iters):
+    icp.run(d, it, 1, 1e-10, False)
+r = icp.iter_records()
+print("partial" if partial else "full", "scene, 2 x %d points, d = %g" % (n, d))
+print(" it   corr(M)  certify ms (Mq)   bounded ms (Mq)   rows ms (Mq)   nn_other  transform   lm_kernels (full/multi passes)  lm_other")
+for x in r:
+    print("%3d  %7.2f   %6.2f (%6.1f)   %6.2f (%6.2f)   %6.2f (%6.2f)   %6.2f    %6.2f    %6.2f (%d/%d)   %6.2f" % (
+        x["iteration"], x["correspondences"] / 1e6, x["t_nn_certify_ms"], x["nn_certify_queries"] / 1e6, x["t_nn_bounded_ms"],
+        x["nn_bounded_queries"] / 1e6, x["t_nn_search_ms"], x["nn_search_queries"] / 1e6, x["t_nn_ms"] - x["t_nn_query_ms"],
+        x["t_transform_ms"], x["t_lm_kernel_ms"], x["full_passes"], x["multi_cost_passes"], x["t_lm_ms"] - x["t_lm_kernel_ms"]))

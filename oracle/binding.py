@@ -13,14 +13,21 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
 
+def variant():
+    """"" (default: the bit-defined elementary functions shared with the kernels) or "glibc" (E3D_ORACLE_VARIANT=glibc: the C
+    library's, as the reference calls them -- oracle_libm_select.h; used by tests/test_oracle_glibc.py in a subprocess)."""
+    return "glibc" if os.environ.get("E3D_ORACLE_VARIANT", "") == "glibc" else ""
+
+
 def build(force=False):
     """Compile the oracle with gcc (Makefile in this directory)."""
-    so = os.path.join(_HERE, "libe3d_oracle.so")
+    glibc = variant() == "glibc"
+    so = os.path.join(_HERE, "libe3d_oracle_glibc.so" if glibc else "libe3d_oracle.so")
     if force or not os.path.exists(so) or any(
         os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(so)
-        for f in os.listdir(_HERE) if f.endswith((".c", ".h"))
+        for f in os.listdir(_HERE) if f.endswith((".c", ".h", ".cc"))
     ):
-        subprocess.check_call(["make", "-C", _HERE, "-s"])
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["glibc"] if glibc else []))
     build_ref()
     return so
 

@@ -31,6 +31,7 @@
 
 #include "e3d_oracle.h"
 #include "../include/e3d_libm.h"   /* bit-defined atanf / atan2f / tanf ... shared with the HIP kernels */
+#include "oracle_libm_select.h"
 
 /* 0 PINHOLE, 1 OPENCV, 2 THIN_PRISM_FISHEYE, 3 OPENCV_FISHEYE = FisheyeBase over Polynomial4Camera (camera_fisheye_polynomial_4.h,
  * camera_polynomial_4.h:43-135: radial factor 1 + r2 (k1 + r2 (k2 + r2 (k3 + r2 k4)))), 4 FOV = FisheyeFOVCamera
@@ -65,7 +66,7 @@ static inline void ocam_distort_plain(const oreg_camera* c, float nx, float ny, 
   }
   if (c->type == 4) {                       /* camera_fisheye_fov.h:55-63 */
     const float r = sqrtf(nx * nx + ny * ny);
-    const float factor = (r < 1e-6f) ? 1.f : (e3d_atanf(r * q[1]) / (r * q[0]));
+    const float factor = (r < 1e-6f) ? 1.f : (om_atanf(r * q[1]) / (r * q[0]));
     *ox = nx * factor; *oy = ny * factor;
     return;
   }
@@ -130,7 +131,7 @@ static inline void ocam_ddn_plain(const oreg_camera* c, float nx, float ny, floa
     const float radius_square = nxs + nys;
     const float radius = sqrtf(radius_square);
     if (radius < 1e-6f) { J[0] = 1; J[1] = 0; J[2] = 0; J[3] = 1; return; }
-    const float rdw = e3d_atanf(radius * tt);
+    const float rdw = om_atanf(radius * tt);
     const float tts = tt * tt;
     const float part1 = omega * radius_square * radius;
     const float part2 = omega * (tts * radius_square + 1) * radius_square;
@@ -192,7 +193,7 @@ static inline void ocam_ddp_plain(const oreg_camera* c, float nx, float ny, floa
     const float four_tan_omega_half_square = tt * tt;
     const float tan_omega_half_square_plus_one = 0.25f * four_tan_omega_half_square + 1.f;
     const float denominator_1 = omega * (four_tan_omega_half_square * radius_square + 1.f);
-    const float numerator_2 = e3d_atanf(tt * radius);
+    const float numerator_2 = om_atanf(tt * radius);
     const float denominator_2 = omega * omega * radius;
     d0[0] = (radius < 1e-6f) ? 0.f : ((nx * tan_omega_half_square_plus_one) / denominator_1 - (nx * numerator_2) / denominator_2);
     d1[0] = (radius < 1e-6f) ? 0.f : ((ny * tan_omega_half_square_plus_one) / denominator_1 - (ny * numerator_2) / denominator_2);
@@ -222,7 +223,7 @@ static inline void ocam_distort(const oreg_camera* c, float nx, float ny, float*
   if (!ocam_is_fisheye(c->type)) { ocam_distort_plain(c, nx, ny, ox, oy); return; }
   const float r = sqrtf(nx * nx + ny * ny);
   if (r > OCAM_FISHEYE_EPS) {
-    const float atan_r = e3d_atan2f(r, 1.f);
+    const float atan_r = om_atan2f(r, 1.f);
     if (atan_r * atan_r > c->inner_cutoff2) { *ox = nx * INFINITY; *oy = ny * INFINITY; return; }
     const float theta_by_r = atan_r / r;
     ocam_distort_plain(c, nx * theta_by_r, ny * theta_by_r, ox, oy);
@@ -238,7 +239,7 @@ static inline void ocam_ddn(const oreg_camera* c, float nx, float ny, float* J) 
   const float r2 = nx2 + ny2;
   const float r = sqrtf(r2);
   if (r > OCAM_FISHEYE_EPS) {
-    const float atan_r = e3d_atan2f(r, 1.f);
+    const float atan_r = om_atan2f(r, 1.f);
     if (atan_r * atan_r > c->inner_cutoff2) { J[0] = J[1] = J[2] = J[3] = 0.f; return; }
     const float theta_by_r = atan_r / r;
     const float term1 = r2 * (r2 + 1);
@@ -261,7 +262,7 @@ static inline void ocam_ddp(const oreg_camera* c, float nx, float ny, float* d0,
   if (!ocam_is_fisheye(c->type)) { ocam_ddp_plain(c, nx, ny, d0, d1); return; }
   const float r = sqrtf(nx * nx + ny * ny);
   if (r > OCAM_FISHEYE_EPS) {
-    const float atan_r = e3d_atan2f(r, 1.f);
+    const float atan_r = om_atan2f(r, 1.f);
     if (atan_r * atan_r > c->inner_cutoff2) { for (int i = 0; i < 8; ++i) d0[i] = d1[i] = 0.f; return; }
     const float theta_by_r = atan_r / r;
     ocam_ddp_plain(c, theta_by_r * nx, theta_by_r * ny, d0, d1);
@@ -405,7 +406,7 @@ static inline float ocam_init_cutoff(const oreg_camera* c) {
 /* FisheyeFOVCamera::Undistort (camera_fisheye_fov.h:76-86), closed form; also its ImageToNormalized (no lookup table, no clamp) */
 static inline void ocam_fov_undistort(const oreg_camera* c, float dx, float dy, float* ux, float* uy) {
   const float r = sqrtf(dx * dx + dy * dy);
-  const float factor = (r < 1e-6f) ? 1.f : ((r > c->p[6]) ? INFINITY : (e3d_tanf(r * c->p[4]) / (r * c->p[5])));
+  const float factor = (r < 1e-6f) ? 1.f : ((r > c->p[6]) ? INFINITY : (om_tanf(r * c->p[4]) / (r * c->p[5])));
   *ux = factor * dx; *uy = factor * dy;
 }
 
@@ -507,7 +508,7 @@ static inline void ocam_init(oreg_camera* c, int type, int w, int h, const float
     /* camera_fisheye_fov.cc:37-51: two_tan_omega_half_(2.0f * tan(0.5f * omega_)), image_radius_(M_PI / (2 * omega_)); no cut-off.
      * with g++/libstdc++ <math.h> puts std::tan(float) / std::atan(float) into the global namespace (checked here with a
      * static_assert on decltype(tan(1.0f))), so these are tanf / atanf */
-    c->p[5] = 2.0f * e3d_tanf(0.5f * c->p[4]);
+    c->p[5] = 2.0f * om_tanf(0.5f * c->p[4]);
     c->p[6] = (float)(M_PI / (double)(2 * c->p[4]));
   }
 }

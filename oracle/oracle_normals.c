@@ -22,6 +22,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include "oracle_libm_select.h"
+
 static void compute_roots2(float b, float c, float* roots) {
   roots[0] = 0.f;
   float d = (float)((double)(b * b) - 4.0 * (double)c);
@@ -52,9 +54,9 @@ static void compute_roots(const float* m /*row-major 3x3*/, float* roots) {
   float q = half_b * half_b + a_over_3 * a_over_3 * a_over_3;
   if (q > 0.f) q = 0.f;
   float rho = sqrtf(-a_over_3);
-  float theta = e3d_atan2f(sqrtf(-q), half_b) * s_inv3;
-  float cos_theta = e3d_cosf(theta);
-  float sin_theta = e3d_sinf(theta);
+  float theta = om_atan2f(sqrtf(-q), half_b) * s_inv3;
+  float cos_theta = om_cosf(theta);
+  float sin_theta = om_sinf(theta);
   roots[0] = c2_over_3 + 2.f * rho * cos_theta;
   roots[1] = c2_over_3 - rho * (cos_theta + s_sqrt3 * sin_theta);
   roots[2] = c2_over_3 - rho * (cos_theta - s_sqrt3 * sin_theta);

@@ -55,7 +55,7 @@ void oracle_reg_camera_scaled(const oreg_camera* in, float factor, oreg_camera* 
 }
 void oracle_reg_camera_distort(const oreg_camera* c, float nx, float ny, float out[2]) { ocam_distort(c, nx, ny, &out[0], &out[1]); }
 /* Child::Undistort: IterativeUndistort from the distorted point itself; the fisheye wrapper un-warps the inner model's
- * solution with e3d_tanf(r)/r (camera_base_impl_fisheye.h:81-92) */
+ * solution with om_tanf(r)/r (camera_base_impl_fisheye.h:81-92) */
 void oracle_reg_camera_undistort(const oreg_camera* c, float dx, float dy, float out[2], int* converged) {
   float ux, uy; int conv;
   if (c->type == 4) {
@@ -67,7 +67,7 @@ void oracle_reg_camera_undistort(const oreg_camera* c, float dx, float dy, float
   ocam_iterative_undistort(c, dx, dy, dx, dy, &ux, &uy, &conv);
   if (ocam_is_fisheye(c->type)) {
     const float r = sqrtf(ux * ux + uy * uy);
-    const float factor = (r < OCAM_FISHEYE_EPS) ? 1.f : ((r > (float)(M_PI / 2.f)) ? INFINITY : e3d_tanf(r) / r);
+    const float factor = (r < OCAM_FISHEYE_EPS) ? 1.f : ((r > (float)(M_PI / 2.f)) ? INFINITY : om_tanf(r) / r);
     ux = factor * ux; uy = factor * uy;
   }
   out[0] = ux; out[1] = uy;
@@ -200,7 +200,7 @@ size_t oracle_reg_observe(const float* pts, size_t n_pts, float point_radius, co
     cam_normalized_to_image(cam, pr[0] / pr[2], pr[1] / pr[2], &rxf, &ryf);
     const float dx = rxf - ixf, dy = ryf - iyf;
     const float radius_pixels = sqrtf(dx * dx + dy * dy);
-    const float observation_scale = image_scale + e3d_log2f(2 * radius_pixels);
+    const float observation_scale = image_scale + om_log2f(2 * radius_pixels);
     const int lo = min_image_scale > current_image_scale ? min_image_scale : current_image_scale;
     if (!(observation_scale >= lo && f2i(observation_scale) < image_scale_count - 1)) continue;
     const int small_scale = f2i(observation_scale) + 1;

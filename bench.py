@@ -17,6 +17,8 @@ time.  Headline at N > 1 = the same 2-scan job, weak scaling (N x the points on 
 queries) -- at N = 1 it is the BENCH workload.
 
 Further legs in the same JSON line:
+  partial_overlap    (N = 1) the headline job on the partial-overlap room (30 - 60 % of the points find a partner): same
+                     per-kernel table, so the no-partner branch of FindCorrespondencesFast is part of a measured steady state
   allpairs           BASELINE.json north_star's scaling target / configs[2] shape: 16 scans all-pairs (240 directed pairs, 90-unknown
                      LM system), STRONG scaling (same job at every N, every rank a slice of every pair) -- compare `allpairs.value`
                      across N
@@ -120,6 +122,8 @@ def sum_records(recs):
         sum(r["t_nn_certify_ms"] for r in recs), sum(r["nn_certify_launches"] for r in recs), sum(r["nn_certify_queries"] for r in recs),
         sum(r["t_nn_bounded_ms"] for r in recs), sum(r["nn_bounded_launches"] for r in recs), sum(r["nn_bounded_queries"] for r in recs),
         sum(r["t_nn_search_ms"] for r in recs), sum(r["nn_search_launches"] for r in recs), sum(r["nn_search_queries"] for r in recs),
+        sum(r["t_nn_sort_ms"] for r in recs), sum(r["t_nn_scan_ms"] for r in recs), sum(r["t_nn_compact_ms"] for r in recs),
+        sum(r["multi_cost_passes"] for r in recs),
     ], dtype=np.float64)
 
 
@@ -173,31 +177,37 @@ def run_icp(e3d, R, icp, d, thr, warmup, steps):
     icp.clear_records()
     R.barrier()
     t0 = time.perf_counter()
+    each = []
     for it in range(warmup, warmup + steps):
-        icp.run(d, it, 1, thr, False)
+        t1 = time.perf_counter()
+        icp.run(d, it, 1, thr, False)                      # returns after the library has synchronised its stream (poses are host data)
+        each.append((time.perf_counter() - t1) * 1e3)
     R.barrier()
     dt = float(R.reduce([time.perf_counter() - t0], "max")[0])
     recs = icp.iter_records()
+    for r, ms in zip(recs, each):
+        r["wall_ms"] = ms
     tot = R.reduce(sum_records(recs))
     per_rank = {"nn_kernel_ms_per_iter": sum(r["t_nn_query_ms"] for r in recs) / steps, "lm_kernel_ms_per_iter": sum(r["t_lm_kernel_ms"] for r in recs) / steps,
                 "nn_ms_per_iter": sum(r["t_nn_ms"] for r in recs) / steps, "lm_ms_per_iter": sum(r["t_lm_ms"] for r in recs) / steps}
     return dt, tot, warm, recs, per_rank
 
 
-def leg_terrace(e3d, synth, R, args, dev):
-    """configs[1]: 2 scans, both movable; N > 1: weak scaling on a stretched room (same point density)."""
+def leg_terrace(e3d, synth, R, args, dev, partial=False):
+    """configs[1]: 2 scans, both movable; N > 1: weak scaling on a stretched room (same point density).
+    partial=True: the same job on the partial-overlap room (30 - 60 % of the points find a partner)."""
     import torch
     world = R.world
-    n_points = args.points if args.points > 0 else 50_000_000 * world
+    n_points = args.points if args.points > 0 else 50_000_000 * (1 if partial else world)
     d, thr = float(args.distance), 1e-10     # README.md:101 recommended flags; never converges within the bench's few iterations
-    room_scale = float(np.sqrt(n_points / 50_000_000.0)) if (world > 1 and args.points == 0) else 1.0
-    scans = synth.make_scene(2, n_points, seed=1234, sigma=0.002, device=dev, room_scale=room_scale)
+    room_scale = float(np.sqrt(n_points / 50_000_000.0)) if (world > 1 and args.points == 0 and not partial) else 1.0
+    scans = synth.make_scene(2, n_points, seed=1234, sigma=0.002, device=dev, room_scale=room_scale, partial=partial)
     torch.cuda.synchronize()
     icp = e3d.PointToPlaneICP(device=R.local_rank)
     for s in scans:
         icp.add_point_cloud(s["xyz"], s["normals"], s["T_init"], False)
     base = None
-    if R.rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if R.rank == 0 and world == 1 and not args.no_cpu_baseline and not partial:
         # slab width chosen for ~4 M points per scan at this density (floor + two walls = 16 m^2 per metre of x)
         width = min(10.0, 4.0e6 / (n_points / 242.6 * 16.0))
         base = cpu_baseline_icp(scans, d, thr, (4.0, 4.0 + width), n_points)
@@ -214,7 +224,7 @@ def leg_terrace(e3d, synth, R, args, dev):
     nn_bytes = ALG_BYTES_PER_QUERY * (queries / world / n_nn_launch)         # one directed pair's queries
     lm_full_ms, full_passes = tot[8] / world, tot[9] / world
     lm_avg, nn_avg = lm_full_ms / max(full_passes, 1), nn_ms / n_nn_launch
-    multi_ms, multi_passes = lm_ms - lm_full_ms, max(passes - full_passes, 0)
+    multi_ms, multi_passes = lm_ms - lm_full_ms, tot[22] / world
     kernels = {
         "k_lm_pass": {"what": "k_lm_pass<1>: fused cost + Gramian pass over the correspondence planes (a7/a8); %.2f launches per iteration"
                               % (full_passes / K),
@@ -234,29 +244,56 @@ def leg_terrace(e3d, synth, R, args, dev):
         return {"what": what, "launches_per_iter": launches / K, "summed_ms_per_iter": t_ms / K, "avg_launch_ms": avg,
                 "algorithmic_bytes_per_launch": by, "GBs": by / (avg * 1e-3) / 1e9 if avg > 0 else None}
     kernels["k_nn_certify"] = nn_kernel("partner of the last search still the unique nearest neighbour? (one gather per query, a5)", tot[10] / world, tot[11] / world, tot[12] / world)
-    kernels["k_nn_bounded"] = nn_kernel("exact search inside the ball of the old partner's distance, one thread per listed query (a5)", tot[13] / world, tot[14] / world, tot[15] / world)
+    kernels["k_nn_bounded"] = nn_kernel("exact search inside the ball of the old partner's distance, one thread per listed query (a5); VALU bound by the "
+                                        "candidates it evaluates (whole grid cells), not by its 32 algorithmic bytes", tot[13] / world, tot[14] / world, tot[15] / world)
     kernels["k_nn_rows"] = nn_kernel("exact search of the remaining queries, sorted by target cell, LDS-staged candidate rows (a5)", tot[16] / world, tot[17] / world, tot[18] / world)
-    kernels["nn_search_per_pair"] = {"what": "all three per directed pair: 32 B per query of the pair", "algorithmic_bytes_per_launch": nn_bytes, "avg_launch_ms": nn_avg,
+
+    def stream_kernel(what, t_ms, launches, bytes_per_launch):
+        avg = t_ms / launches if launches else None
+        return {"what": what, "launches_per_iter": launches / K, "summed_ms_per_iter": t_ms / K, "avg_launch_ms": avg,
+                "algorithmic_bytes_per_launch": bytes_per_launch, "GBs": bytes_per_launch / (avg * 1e-3) / 1e9 if (avg and bytes_per_launch) else None}
+    n_rank = n_points / world if False else n_points     # every rank transforms the whole clouds
+    kernels["k_transform_bbox"] = stream_kernel("a3: both clouds into the global frame + bounding boxes, 32 B per point moved", tot[5] / world, 2 * K, 32.0 * n_rank)
+    kernels["query_keys_and_sort"] = stream_kernel("cell keys + rocPRIM radix sort of the queries the row kernel searches (a5 prep)", tot[19] / world, max(tot[17] / world, 1), None)
+    kernels["match_scan"] = stream_kernel("per-block match counts + 3 scan kernels (order-preserving compaction, first stage): 8 B per query", tot[20] / world, n_nn_launch,
+                                          8.0 * queries / world / n_nn_launch)
+    kernels["k_compact_corr"] = stream_kernel("gathers source / target point + normal of every match and writes the 48 B planes: 4 B per query + 116 B per correspondence",
+                                              tot[21] / world, n_nn_launch, (4.0 * queries + 116.0 * corr) / world / n_nn_launch)
+    accounted = sum((v["summed_ms_per_iter"] or 0.0) for v in kernels.values())
+    kernels["nn_search_per_pair"] = {"what": "certify + bounded + rows per directed pair: 32 B per query of the pair", "algorithmic_bytes_per_launch": nn_bytes, "avg_launch_ms": nn_avg,
                                      "GBs": nn_bytes / (nn_avg * 1e-3) / 1e9 if nn_avg > 0 else None, "summed_ms_per_iter": nn_ms / K}
-    dom = max(("k_lm_pass", "k_lm_cost_multi", "k_nn_certify", "k_nn_bounded", "k_nn_rows"), key=lambda k: kernels[k]["summed_ms_per_iter"] or 0.0)
-    traffic, traffic_src = load_traffic({"k_lm_pass": "k_lm_pass<1>"}.get(dom, dom)) if (world == 1 and n_points == 50_000_000) else (None, None)
+    dom = max(("k_lm_pass", "k_lm_cost_multi", "k_nn_certify", "k_nn_bounded", "k_nn_rows", "k_compact_corr"), key=lambda k: kernels[k]["summed_ms_per_iter"] or 0.0)
+    traffic, traffic_src = load_traffic({"k_lm_pass": "k_lm_pass<1>"}.get(dom, dom)) if (world == 1 and n_points == 50_000_000 and not partial) else (None, None)
     ach = kernels[dom]["GBs"] or 0.0
+    # settling / steady split: the first timed steps still re-search most queries (the poses move); "steady" = the steps whose NN
+    # kernels cost at most 1.25 x the last step's
+    nnq = [r["t_nn_query_ms"] for r in recs]
+    first_steady = next((i for i, v in enumerate(nnq) if v <= 1.25 * nnq[-1]), len(nnq) - 1)
+    wall = [r["wall_ms"] for r in recs]
     out = {
         "metric": "ICP correspondences/sec", "value": corr / dt, "unit": "correspondences/s",
         "n_gpus": R.comm.world_size if R.comm else 1, "steps": K, "warmup": args.warmup, "ms_per_step": dt / K * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 (f64 accumulation)", "data": "synthetic",
-        "config": {"workload": "ICPScanAligner 2 scans (BASELINE.json configs[1]), -d %g, one outer iteration per step" % d,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 (f64 accumulation)",
+        "data": "synthetic (no terrace scans in this image: seeded room scans of the configs[1] shape, generated in HBM)",
+        "config": {"workload": "ICPScanAligner 2 scans (BASELINE.json configs[1]), -d %g, one outer iteration per step%s" %
+                               (d, "; PARTIAL-OVERLAP room (partition wall, occlusion, 6.5 m range): %.0f %% of the queries find a partner" % (100.0 * corr / max(queries, 1)) if partial else ""),
                    "points_per_scan": n_points, "scans": 2, "directed_pairs": 2, "room_scale": room_scale,
+                   "matched_fraction": corr / max(queries, 1),
                    "parallelism": "dp%d over source-point slices, RCCL all-reduce of the 6x6 normal-equation blocks" % world},
         "ms_per_iter": dt / K * 1e3, "nn_queries_per_s": queries / dt, "lm_passes_per_iter": passes / K,
+        "ms_per_step_each": wall,
+        "ms_per_step_settling": float(np.mean(wall[:first_steady])) if first_steady > 0 else None,
+        "ms_per_step_steady": float(np.mean(wall[first_steady:])), "steady_from_timed_step": first_steady,
         "breakdown_ms_per_iter": {"transform_bbox": tot[5] / world / K, "nn_search_and_compaction": tot[6] / world / K,
                                   "lm_total": tot[7] / world / K, "lm_pass_kernels": lm_ms / K, "nn_query_kernels": nn_ms / K,
-                                  "nn_query_kernels_per_timed_iteration": [r["t_nn_query_ms"] for r in recs],
+                                  "kernels_accounted": accounted, "host_sync_and_small_kernels": dt / K * 1e3 - accounted,
+                                  "nn_query_kernels_per_timed_iteration": nnq,
                                   "warmup_nn_query_kernels": [r["t_nn_query_ms"] for r in warm]},
         "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_source": traffic_src, "kernel": dom + ": " + kernels[dom]["what"],
                      "algorithmic_bytes_per_launch": kernels[dom]["algorithmic_bytes_per_launch"], "avg_launch_ms": kernels[dom]["avg_launch_ms"],
-                     "note": "dominant kernel = largest summed HIP-event duration in the timed region; all kernels of the step in `kernels`",
+                     "note": "dominant kernel = largest summed HIP-event duration in the timed region; `kernels` lists every kernel group of the step "
+                             "(their summed_ms_per_iter add up to breakdown_ms_per_iter.kernels_accounted; the rest of ms_per_step is host work and synchronisation)",
                      "kernels": kernels},
     }
     if world > 1:
@@ -452,6 +489,7 @@ def main():
     ap.add_argument("--no-reg", action="store_true", help="skip the ImageRegistrator leg (N = 1 only)")
     ap.add_argument("--no-normals", action="store_true", help="skip the normal-estimation leg (N = 1 only)")
     ap.add_argument("--no-allpairs", action="store_true", help="skip the all-pairs scaling leg")
+    ap.add_argument("--no-partial", action="store_true", help="skip the partial-overlap ICP leg (N = 1 only)")
     ap.add_argument("--allpairs-scans", type=int, default=16)
     ap.add_argument("--allpairs-points", type=int, default=10_000_000)
     ap.add_argument("--allpairs-distance", type=float, default=0.02)
@@ -482,6 +520,8 @@ def main():
     R = Ranks(rank, world, local_rank, e3d)
 
     out = leg_terrace(e3d, synth, R, args, dev)
+    if world == 1 and not args.no_partial:
+        out["partial_overlap"] = leg_terrace(e3d, synth, R, args, dev, partial=True)
     if not args.no_allpairs:
         out["allpairs"] = leg_allpairs(e3d, synth, R, args, dev)
     if rank == 0 and world == 1:

@@ -36,7 +36,7 @@ class IterRecord(C.Structure):
                 ("t_nn_certify_ms", C.c_double), ("t_nn_bounded_ms", C.c_double), ("t_nn_search_ms", C.c_double),
                 ("nn_certify_queries", C.c_int64), ("nn_bounded_queries", C.c_int64), ("nn_search_queries", C.c_int64),
                 ("nn_certify_launches", C.c_int32), ("nn_bounded_launches", C.c_int32), ("nn_search_launches", C.c_int32),
-                ("reserved2_", C.c_int32)]
+                ("reserved2_", C.c_int32), ("t_nn_sort_ms", C.c_double), ("t_nn_scan_ms", C.c_double), ("t_nn_compact_ms", C.c_double)]
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_size_t, C.c_void_p)
@@ -138,7 +138,7 @@ SIGNATURES = {
 }
 
 
-ABI_VERSION = 2          # E3D_ABI_VERSION of include/e3d_hip.h
+ABI_VERSION = 3          # E3D_ABI_VERSION of include/e3d_hip.h
 
 
 def lib():

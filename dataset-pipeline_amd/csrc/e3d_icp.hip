@@ -131,6 +131,17 @@ struct e3d_icp {
   DevBuf<double> d_partial, d_setsum;
   PinBuf<double> h_setsum;
   std::unique_ptr<EventTimer> lm_timer, nn_timer, nn_timer_c;
+  // stop-watch of a kernel group whose reading is taken lazily (at the group's next use or at the end of the NN phase), so that
+  // timing the sort / scan / compaction kernels adds no synchronisation
+  struct LazyTimer {
+    std::unique_ptr<EventTimer> t;
+    bool pending = false;
+    double acc = 0.0;
+    void start(hipStream_t s) { if (!t) t.reset(new EventTimer()); flush(); t->start(s); }
+    void stop(hipStream_t s) { t->stop(s); pending = true; }
+    void flush() { if (pending) { acc += t->ms(); pending = false; } }
+    double take() { flush(); const double v = acc; acc = 0.0; return v; }
+  } tm_sort, tm_scan, tm_compact;
 
   std::map<std::pair<int, int>, std::unique_ptr<PairState>> pair_state;
   PinBuf<unsigned> h_todo;
@@ -415,6 +426,8 @@ static bool launch_rows(int mode, const Cloud& tgt, const float4* srcG, const un
 static void sort_query_keys(e3d_icp* h, const Cloud& tgt, const float4* srcG, const unsigned* list, size_t n, const InvMap& im) {
   hipStream_t s = h->stream;
   h->keys_a.reserve(n); h->keys_b.reserve(n); h->vals_a.reserve(n); h->vals_b.reserve(n);
+  h->tm_sort.start(s);
+  struct Stop { e3d_icp* h; hipStream_t s; ~Stop() { h->tm_sort.stop(s); } } stop_at_return{h, s};
   if (tgt.key_bits <= 31) {   // 8-byte (key, index) pairs through the radix passes
     unsigned* ka = reinterpret_cast<unsigned*>(h->keys_a.p);
     unsigned* kb = reinterpret_cast<unsigned*>(h->keys_b.p);
@@ -563,8 +576,10 @@ static void find_pair(e3d_icp* h, Cloud& src, Cloud& tgt, float d, PairJob& job,
   h->nn_timer->stop(s);
   NnPhase ph3(s, 2);                                                 // (its constructor waits for the search kernels)
   h->chunk_sum.reserve(div_up(nb, 256) + 1); h->chunk_d2.reserve(div_up(nb, 256) + 1);
+  h->tm_scan.start(s);
   launch_match_scan(match_pos, h->match_d2.p, n, h->block_counts.p, h->block_offsets.p, h->block_d2.p,
                     h->chunk_sum.p, h->chunk_d2.p, h->d_total.p, h->d_total_d2.p, s);
+  h->tm_scan.stop(s);
   copy_out(h->h_total.p, h->d_total.p, sizeof(unsigned long long), s);
   copy_out(h->h_total_d2.p, h->d_total_d2.p, sizeof(double), s);
   sync(h);
@@ -579,9 +594,11 @@ static void find_pair(e3d_icp* h, Cloud& src, Cloud& tgt, float d, PairJob& job,
     h->cB.grow_keep(ncap, h->corr_used, s);
     h->cC.grow_keep(ncap, h->corr_used, s);
   }
+  h->tm_compact.start(s);
   launch_compact_corr(match_pos, order, n, h->block_offsets.p, srcG, srcLN,
                       to_affine(src.T), tgt.G4.p, tgt.LN.p, to_affine(tgt.T), h->cA.p, h->cB.p, h->cC.p,
                       h->corr_used, s);   // the merged fixed cloud keeps T = identity (exact)
+  h->tm_compact.stop(s);
   h->corr_used = need;
 }
 
@@ -979,6 +996,7 @@ static bool align_meshes(e3d_icp* h, float max_d, float thr, bool print, int ite
   }
   rec.t_transform_ms = t_tr.ms();
   rec.t_nn_ms = t_nn.ms();
+  rec.t_nn_sort_ms = h->tm_sort.take(); rec.t_nn_scan_ms = h->tm_scan.take(); rec.t_nn_compact_ms = h->tm_compact.take();
   rec.t_lm_ms = t_lm.ms();
   h->iter_records.push_back(rec);
   return converged;

@@ -275,8 +275,8 @@ def make_reg_workload(n_points=4_000_000, width=3840, height=2160, n_levels=6, K
     images = []
     for i in range(n_images):
         img = _synthetic_image(i, width, height, device)
-        a = 0.04 * (i - 0.5 * (n_images - 1))
-        eye = np.array([3.0 * np.sin(a), 3.0 - 3.0 * np.cos(a), 0.01 * i])
+        a = min(0.04, 1.0 / max(n_images, 1)) * (i - 0.5 * (n_images - 1))       # the arc spans at most +- 0.5 rad whatever the image count
+        eye = np.array([3.0 * np.sin(a), 3.0 - 3.0 * np.cos(a), min(0.01, 0.3 / max(n_images, 1)) * i])    # (the cameras rise at most 0.3 m)
         z = np.array([0.0, 3.0, 0.0]) - eye; z /= np.linalg.norm(z)
         x = np.cross(z, [0.0, 0.0, 1.0]); x /= np.linalg.norm(x)
         y = np.cross(z, x)

@@ -32,7 +32,7 @@ extern "C" {
 #endif
 
 /* 2: e3d_reg_params grew by the three depth-residual fields; the ICP iteration record by the NN phase times (round 2) */
-#define E3D_ABI_VERSION 2
+#define E3D_ABI_VERSION 3
 
 #define E3D_ERR_INVALID   (-2)   /* bad argument / bad handle state          */
 #define E3D_ERR_HIP       (-3)   /* a HIP runtime call failed                */
@@ -111,6 +111,10 @@ typedef struct {
   double  t_nn_search_ms;    /* k_nn_rows / k_nn_cells / k_nn_query / k_nn_mfma launches   */
   int64_t nn_certify_queries, nn_bounded_queries, nn_search_queries;   /* queries those launches covered */
   int32_t nn_certify_launches, nn_bounded_launches, nn_search_launches, reserved2_;
+  /* ABI 3: the rest of the NN phase, so that the per-kernel times add up to the step (HIP events) */
+  double  t_nn_sort_ms;      /* query keys + radix sort of the queries the row kernel searches */
+  double  t_nn_scan_ms;      /* match counts + scans (order-preserving compaction, first stage) */
+  double  t_nn_compact_ms;   /* k_compact_corr: the correspondence planes                      */
 } e3d_icp_iter_record;
 
 size_t e3d_icp_num_pair_records(const e3d_icp_t* icp);

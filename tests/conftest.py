@@ -46,6 +46,14 @@ def ob():
 
 
 @pytest.fixture(scope="session")
+def rb():
+    """The CPU oracle binding of path (B) (test infrastructure)."""
+    from oracle import reg_binding
+    reg_binding.lib()
+    return reg_binding
+
+
+@pytest.fixture(scope="session")
 def synth():
     return importlib.import_module("dataset-pipeline_amd.synth")
 

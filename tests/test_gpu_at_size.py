@@ -1,0 +1,209 @@
+"""BASELINE.json configs[2] and configs[4] AT SIZE on one MI355X: the all-pairs job and the 512-image /
+mesh-occlusion job run whole, and their results are tied to the CPU oracle through sampled checks the oracle can finish in seconds,
+plus properties that do not depend on the size."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_c3_all_pairs_8x20M_at_size(e3d, ob, synth):
+    """configs[2] on ONE GPU: 8 scans x 20 M points, all movable, all 56 directed pairs (42 unknowns), -d 0.01, two outer
+    iterations (src/icp/icp_point_to_plane.cc:208-309 at size; the second iteration runs through the certificates).
+      (i)   a second handle reproduces counts and poses bit for bit;
+      (ii)  scan 7 is a copy of scan 0 at the same pose: in iteration 0 every count involving one equals the count involving the
+            other, and the two match each other completely at distance 0 (the IdenticalCloud property of test_icp.cc:78-110);
+      (iii) for three directed pairs the counts of iteration 1 -- certificates + bounded search + row kernel on the clouds' static
+            grids -- equal a fresh exact search over the same global-frame coordinates (e3d_find_correspondences);
+      (iv)  for a random 1e5-query sample of each of those pairs, partner index and f32 squared distance of that search equal the
+            oracle's kd-tree over the FULL 20 M-point target."""
+    import torch
+    n, S, d = 20_000_000, 8, 0.01
+    dev = torch.device("cuda", 0)
+    scans = synth.make_scene(S - 1, n, seed=777, sigma=0.002, device=dev)
+    scans.append(dict(scans[0]))                                                   # (ii)
+
+    def run():
+        icp = e3d.PointToPlaneICP(device=0)
+        for s in scans:
+            icp.add_point_cloud(s["xyz"], s["normals"], s["T_init"], False)
+        icp.run(d, 0, 1, 1e-10, False)
+        poses1 = [icp.get_result_global_T_cloud(i) for i in range(S)]
+        icp.run(d, 1, 1, 1e-10, False)
+        poses2 = [icp.get_result_global_T_cloud(i) for i in range(S)]
+        recs = icp.pair_records()
+        it = icp.iter_records()
+        del icp
+        torch.cuda.empty_cache()
+        return recs, poses1, poses2, it
+    recs, poses1, poses2, it = run()
+    assert len(recs) == 2 * S * (S - 1)
+    assert it[1]["nn_certify_queries"] == S * (S - 1) * n                         # the certificates were consulted for every query
+    cnt = {(r[0], r[1], r[2]): r[3] for r in recs}
+    # (ii)
+    assert cnt[(0, 0, 7)] == n and cnt[(0, 7, 0)] == n
+    for j in range(1, 7):
+        assert cnt[(0, 0, j)] == cnt[(0, 7, j)] and cnt[(0, j, 0)] == cnt[(0, j, 7)], j
+    total0 = sum(v for k, v in cnt.items() if k[0] == 0)
+    assert total0 > 0.2 * S * (S - 1) * n                                           # a real all-pairs job, not empty pairs
+    # (i)
+    recs_b, poses1_b, poses2_b, _ = run()
+    assert [tuple(r[:4]) for r in recs_b] == [tuple(r[:4]) for r in recs]
+    assert all(np.array_equal(a.view(np.uint32), b.view(np.uint32)) for a, b in zip(poses2, poses2_b))
+    # (iii) + (iv)
+    rng = np.random.RandomState(5)
+    for (a, b) in ((1, 4), (5, 2), (3, 6)):
+        Ga = e3d.transform_cloud(scans[a]["xyz"], scans[a]["normals"], poses1[a])[0]
+        Gb = e3d.transform_cloud(scans[b]["xyz"], scans[b]["normals"], poses1[b])[0]
+        idx, d2, count = e3d.find_correspondences(Ga, Gb, d)
+        assert count == cnt[(1, a, b)], (a, b, count, cnt[(1, a, b)])
+        sample = rng.choice(n, 100_000, replace=False)
+        iq, im, sd = ob.find_correspondences(Ga[sample], Gb, d)
+        ref = np.full(len(sample), -1, np.int32); ref[iq] = im
+        refd = np.zeros(len(sample), np.float32); refd[iq] = sd
+        assert np.array_equal(idx[sample], ref), (a, b)
+        assert np.array_equal(d2[sample].view(np.uint32)[ref >= 0], refd.view(np.uint32)[ref >= 0])
+        assert 1000 < len(iq) < 100_000                                             # the sample has both branches
+
+
+_C5_DENSE_SNIPPET = r'''
+import sys, importlib, numpy as np
+sys.path.insert(0, sys.argv[1])
+e3d = importlib.import_module("dataset-pipeline_amd")
+synth = importlib.import_module("dataset-pipeline_amd.synth")
+Wl = synth.make_reg_workload(n_points=1_000_000, width=3840, height=2160, n_images=64, model=0, device="cuda")
+P = e3d.RegProblem(e3d.default_reg_params(image_scale_count=Wl["n_levels"], point_neighbor_count=Wl["K"], variable_residuals_weight=0.0))
+P.set_intrinsics(0, Wl["width"], Wl["height"], Wl["params"], 0, Wl["n_levels"], camera_type=0)
+P.set_point_scale(0, Wl["pts"], Wl["point_radius"], Wl["nbr"], Wl["fixed_desc"]); P.set_splat_points(Wl["pts"])
+for i, im in enumerate(Wl["images"]):
+    P.set_image(i, 0, im["pyr"]); P.set_image_pose(i, im["q"], im["t"])
+r = P.run_on_current_scale(2, 0.0, 15, False)
+np.savez(sys.argv[2], poses=np.stack([np.concatenate(P.get_image_pose(i)) for i in range(64)]), cost=r[1])
+'''
+
+
+def _grid_mesh(nx, nz, y, x0, x1, z0, z1):
+    """regular triangulated grid in the plane y = const: nx x nz vertices, 2 (nx - 1)(nz - 1) triangles"""
+    xs = np.linspace(x0, x1, nx, dtype=np.float32); zs = np.linspace(z0, z1, nz, dtype=np.float32)
+    V = np.empty((nz, nx, 3), np.float32)
+    V[..., 0] = xs[None, :]; V[..., 1] = y; V[..., 2] = zs[:, None]
+    idx = (np.arange(nz - 1, dtype=np.uint32)[:, None] * np.uint32(nx) + np.arange(nx - 1, dtype=np.uint32)[None, :])
+    T = np.empty((nz - 1, nx - 1, 2, 3), np.uint32)
+    T[..., 0, 0] = idx; T[..., 0, 1] = idx + 1; T[..., 0, 2] = idx + np.uint32(nx)
+    T[..., 1, 0] = idx + 1; T[..., 1, 1] = idx + np.uint32(nx) + 1; T[..., 1, 2] = idx + np.uint32(nx)
+    return V.reshape(-1, 3), T.reshape(-1, 3)
+
+
+def test_c5_512_images_4k_with_100M_vertex_occlusion_mesh(e3d, rb, synth, tmp_path):
+    """configs[4] on ONE GPU: 512 images of 3840 x 2160 (6 pyramid levels), 4 M points, K = 5, and an occlusion mesh of 100 M
+    vertices / 200 M triangles (src/opt/occlusion_geometry.cc:211-271 at size: every observation refresh renders the mesh into
+    every image).
+      (i)   mesh depth maps: 16 x 16 pixel tiles of two images equal oracle/mesh_occlusion.py's rasteriser bit for bit (the oracle
+            gets the triangles of the grid block behind the tile and the blocker; nothing else projects there);
+      (ii)  the blocker in front of the wall removes exactly the observations behind it, in every image;
+      (iii) two RunOnCurrentScale iterations over the 3 076 unknowns (the second evaluates the step of the first) run through the
+            block-sparse (arrow) normal equations and lower the cost;
+      (iv)  on a 64-image sub-problem (388 unknowns: the first size the arrow solver takes) the same two iterations with the arrow
+            solver end at the poses the reference-order dense LDLT (E3D_REG_SOLVER=dense, own process) reaches."""
+    import os, subprocess, sys, time
+    import torch
+    from oracle import mesh_occlusion as mo
+    from reg_util import quat_to_R
+    n_img, W, H = 512, 3840, 2160
+    t0 = time.perf_counter()
+    Wl = synth.make_reg_workload(n_points=4_000_000, width=W, height=H, n_images=n_img, model=0, device="cuda")
+    t_gen = time.perf_counter() - t0
+    prm = e3d.default_reg_params(image_scale_count=Wl["n_levels"], point_neighbor_count=Wl["K"], variable_residuals_weight=0.0)
+    P = e3d.RegProblem(prm)
+    P.set_intrinsics(0, W, H, Wl["params"], 0, Wl["n_levels"], camera_type=0)
+    P.set_point_scale(0, Wl["pts"], Wl["point_radius"], Wl["nbr"], Wl["fixed_desc"])
+    for i, im in enumerate(Wl["images"]):
+        P.set_image(i, 0, im["pyr"]); P.set_image_pose(i, im["q"], im["t"])
+        im["pyr"] = None                                                            # 5.6 GB of host pyramids are no longer needed
+    # the occlusion mesh: the wall itself 3 cm behind the points (y = 3.03; occlusion threshold 0.01 -> hides nothing) as a grid of
+    # 10 000 x 10 000 vertices, and a 0.5 m x 0.4 m blocker 1 m in front of it
+    t0 = time.perf_counter()
+    nx = nz = 10_000
+    Vw, Tw = _grid_mesh(nx, nz, 3.03, -7.5, 7.5, -4.0, 4.0)
+    assert len(Vw) == 100_000_000 and len(Tw) == 199_960_002
+    Vb, Tb = _grid_mesh(50, 50, 2.0, -0.25, 0.25, -0.2, 0.2)
+    t_mesh = time.perf_counter() - t0
+    assert P.add_occlusion_mesh(Vw, Tw, compute_edges=False) == 1
+    assert P.add_occlusion_mesh(Vb, Tb, compute_edges=False) == 2
+    P.set_occlusion_options(0.05, 100.0, False)
+    # (i)
+    cam = rb.camera_pyramid(rb.make_camera(W, H, Wl["params"], 0), 1)[0]
+    for i, tiles in ((3, ((400, 300), (3000, 1700))), (300, ((1900, 1000), (1200, 500)))):
+        im = Wl["images"][i]
+        R = quat_to_R(im["q"])
+        g = P.render_depth(i, 0, (H, W))
+        assert (g > 0).mean() > 0.98                                                 # the wall mesh fills the image
+        # coarse pass: which grid block lies behind a tile
+        cs = 25
+        sub = Vw.reshape(nz, nx, 3)[::cs, ::cs].reshape(-1, 3)
+        px, py, z = mo.project_vertices(0, cam, R, im["t"], sub)
+        px = px.reshape(nz // cs, nx // cs); py = py.reshape(nz // cs, nx // cs)
+        for (tx, ty) in tiles:
+            near = (px > tx - 40) & (px < tx + 56) & (py > ty - 40) & (py < ty + 56)
+            rows, cols = np.nonzero(near)
+            r0, r1 = max(rows.min() * cs - cs, 0), min(rows.max() * cs + 2 * cs, nz)
+            c0, c1 = max(cols.min() * cs - cs, 0), min(cols.max() * cs + 2 * cs, nx)
+            Vs = Vw.reshape(nz, nx, 3)[r0:r1, c0:c1].reshape(-1, 3)
+            _, Ts = _grid_mesh(c1 - c0, r1 - r0, 0.0, 0.0, 1.0, 0.0, 1.0)          # same triangulation, local vertex numbers
+            Ts = np.concatenate([Ts, Tb + np.uint32(len(Vs))])                       # ... and the blocker, which covers the image centre
+            qx, qy, qz = mo.project_vertices(0, cam, R, im["t"], np.concatenate([Vs, Vb]))
+            # only the triangles that can touch the tile (the oracle rasteriser is a Python loop)
+            tri_x = qx[Ts]; tri_y = qy[Ts]
+            touch = (tri_x.max(1) >= tx - 1) & (tri_x.min(1) <= tx + 17) & (tri_y.max(1) >= ty - 1) & (tri_y.min(1) <= ty + 17)
+            o = mo.rasterise(qx, qy, qz, Ts[touch], W, H)
+            gt, ot = g[ty:ty + 16, tx:tx + 16], o[ty:ty + 16, tx:tx + 16]
+            assert (ot > 0).all() and np.array_equal(gt.view(np.uint32), ot.view(np.uint32)), (i, tx, ty, int((gt != ot).sum()))
+    del Vw, Tw
+    # (ii)
+    t0 = time.perf_counter()
+    P.update_observations(1)
+    t_obs = time.perf_counter() - t0
+    pts = Wl["pts"]
+    n_obs_total = 0
+    for i in (0, 255, 511):
+        n = P.observe(i, 0, 0, 1)
+        idx = P.get_observations(i, 0, n)[0]
+        n_obs_total += n
+        seen = np.zeros(len(pts), bool); seen[idx] = True
+        im = Wl["images"][i]
+        eye = -quat_to_R(im["q"]).T.astype(np.float64) @ im["t"].astype(np.float64)
+        # a wall point is hidden iff the segment eye -> point crosses the blocker rectangle in the plane y = 2
+        s = (2.0 - eye[1]) / (pts[:, 1].astype(np.float64) - eye[1])
+        hx = eye[0] + s * (pts[:, 0] - eye[0]); hz = eye[2] + s * (pts[:, 2] - eye[2])
+        inside = (np.abs(hx) < 0.24) & (np.abs(hz) < 0.19)
+        outside = (np.abs(hx) > 0.26) | (np.abs(hz) > 0.21)
+        assert inside.sum() > 1000 and not seen[inside].any(), i
+        assert seen[outside].mean() > 0.7, (i, seen[outside].mean())
+    # (iii)
+    c0 = P.compute_cost()
+    t0 = time.perf_counter()
+    conv, cost, its = P.run_on_current_scale(2, 0.0, 15, False)
+    t_run = time.perf_counter() - t0
+    c1 = P.compute_cost()                          # two iterations: the second one evaluates the state the first one's step led to
+    free, total = torch.cuda.mem_get_info(0)
+    print("c5 at size: workload %.1f s, mesh arrays %.1f s, observation refresh (512 mesh renders) %.1f s, two RunOnCurrentScale iterations %.1f s, "
+          "cost %.9g -> %.9g, HBM in use %.1f GB" % (t_gen, t_mesh, t_obs, t_run, c0, c1, (total - free) / 1e9))
+    assert its == 2 and np.isfinite(c1) and c1 < c0 and cost == c1
+    del P
+    torch.cuda.empty_cache()
+    # (iv)
+    out = str(tmp_path / "dense.npz")
+    env = dict(os.environ); env["E3D_REG_SOLVER"] = "dense"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call([sys.executable, "-c", _C5_DENSE_SNIPPET, root, out], env=env)
+    env.pop("E3D_REG_SOLVER")
+    out2 = str(tmp_path / "arrow.npz")
+    subprocess.check_call([sys.executable, "-c", _C5_DENSE_SNIPPET, root, out2], env=env)
+    d, a = np.load(out), np.load(out2)
+    assert abs(float(d["cost"]) - float(a["cost"])) <= 1e-9 * abs(float(d["cost"]))
+    from scipy.spatial.transform import Rotation
+    for i in range(64):
+        qa, qd = a["poses"][i][:4].astype(np.float64), d["poses"][i][:4].astype(np.float64)
+        ang = np.linalg.norm((Rotation.from_quat([qa[1], qa[2], qa[3], qa[0]]).inv() * Rotation.from_quat([qd[1], qd[2], qd[3], qd[0]])).as_rotvec())
+        tr = np.linalg.norm(a["poses"][i][4:].astype(np.float64) - d["poses"][i][4:])
+        assert ang <= 1e-5 and tr <= 1e-4, (i, ang, tr)

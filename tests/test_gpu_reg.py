@@ -10,13 +10,6 @@ from reg_util import make_reg_scene
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def rb():
-    from oracle import reg_binding
-    reg_binding.lib()
-    return reg_binding
-
-
 def _setup(e3d, rb, S, **pk):
     prm = e3d.default_reg_params(image_scale_count=S["n_levels"], point_neighbor_count=S["K"], **pk)
     P = e3d.RegProblem(prm)

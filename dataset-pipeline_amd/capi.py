@@ -70,6 +70,7 @@ SIGNATURES = {
     "e3d_icp_set_comm": (C.c_int, [C.c_void_p, C.c_void_p]),
     "e3d_reg_set_comm": (C.c_int, [C.c_void_p, C.c_void_p]),
     "e3d_reg_kernel_times": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "e3d_reg_profile": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_size_t]),
     "e3d_find_correspondences": (C.c_int64, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_float,
                                              C.c_void_p, C.c_void_p]),
     "e3d_transform_cloud": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -689,6 +690,17 @@ class RegProblem:
         out = (C.c_double * 4)()
         self._chk(lib().e3d_reg_kernel_times(self._h, out, int(bool(reset))), "e3d_reg_kernel_times")
         return tuple(out)
+
+    def profile(self, enable):
+        """Switches the phase profile of run_on_current_scale on / off; returns {phase: ms} recorded so far (e3d_reg_profile)."""
+        buf = C.create_string_buffer(4096)
+        self._chk(lib().e3d_reg_profile(self._h, int(bool(enable)), buf, len(buf)), "e3d_reg_profile")
+        out = {}
+        for item in buf.value.decode().split(";"):
+            if "=" in item:
+                k, v = item.rsplit("=", 1)
+                out[k] = float(v)
+        return out
 
     def set_comm(self, comm):
         """Image sharding with the library's own RCCL communicator (a Comm); call before the images are set."""

@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <climits>
+#include <chrono>
 #include <cmath>
 #include <map>
 #include <memory>
@@ -2116,6 +2117,10 @@ struct e3d_reg {
   std::unique_ptr<EventTimer> t_pass1, t_pass2;
   double pass1_ms = 0, pass2_ms = 0, pass_observations = 0, pass_calls = 0;
   DevBuf<double> comm_stage;
+  // e3d_reg_profile: wall-clock time per phase of RunOnCurrentScale (the stream is synchronised at every phase boundary while
+  // the profile is on, so a profiled run is slower than a plain one; the split is what it is for)
+  bool profile_on = false;
+  std::map<std::string, double> profile_ms;
   bool owns(int image_id) const { return world <= 1 || ((image_id % world) + world) % world == rank; }
   // splat depth: per-point rectangles, (tile, point) pairs (double-buffered for the sort), tile ranges
   DevBuf<uint4> rects;
@@ -2127,6 +2132,19 @@ struct e3d_reg {
 namespace e3d {
 
 static void rsync(e3d_reg* h) { E3D_HIP(hipStreamSynchronize(h->stream)); }
+
+struct Phase {
+  e3d_reg* h; const char* name; std::chrono::steady_clock::time_point t0;
+  Phase(e3d_reg* hh, const char* n) : h(hh), name(n) {
+    if (h->profile_on) { (void)hipStreamSynchronize(h->stream); t0 = std::chrono::steady_clock::now(); }
+  }
+  ~Phase() {
+    if (h->profile_on) {
+      (void)hipStreamSynchronize(h->stream);
+      h->profile_ms[name] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+  }
+};
 static unsigned nblk(size_t n) { return (unsigned)div_up(n ? n : 1, kBlock); }
 
 // Sums over the ranks.  With the library's own communicator (e3d_reg_set_comm) both run as RCCL all-reduces on the handle's
@@ -3078,6 +3096,20 @@ int e3d_reg_kernel_times(e3d_reg_t* h, double out[4], int reset) {
   R_CATCH()
 }
 
+int e3d_reg_profile(e3d_reg_t* h, int enable, char* out, size_t capacity) {
+  R_TRYH
+  if (!h) throw Error(E3D_ERR_INVALID, "null handle");
+  if (out && capacity) {
+    std::string t;
+    for (const auto& kv : h->profile_ms) t += kv.first + "=" + fmt("%.4f", kv.second) + ";";
+    std::snprintf(out, capacity, "%s", t.c_str());
+  }
+  if (enable != (h->profile_on ? 1 : 0)) h->profile_ms.clear();
+  h->profile_on = enable != 0;
+  return 0;
+  R_CATCH()
+}
+
 int e3d_reg_cost(e3d_reg_t* h, int image_id, int point_scale, double sums[2], int64_t counts[2]) {
   R_TRYH
   if (!h || !sums || !counts) throw Error(E3D_ERR_INVALID, "null argument");
@@ -3302,7 +3334,11 @@ static void update_observations(e3d_reg* h, int border) {
     const bool cached = h->cache_observations;
     if (cached && !im.has_observed)
       throw Error(E3D_ERR_INVALID, fmt("no observed point indices for image %d (e3d_reg_determine_observed_indices / e3d_reg_set_observed_indices)", kv.first));
-    if (!cached && e3d_reg_render_depth(h, kv.first, scale, nullptr) < 0) throw Error(E3D_ERR_INVALID, e3d_last_error());
+    {
+      Phase ph(h, "observations.occlusion_depth_map");
+      if (!cached && e3d_reg_render_depth(h, kv.first, scale, nullptr) < 0) throw Error(E3D_ERR_INVALID, e3d_last_error());
+    }
+    Phase ph(h, "observations.visibility");
     for (auto& o : im.obs) { o.second.active = false; o.second.n = 0; }      // keep the device buffers
     bool had_many = false;
     for (auto it = h->scales.rbegin(); it != h->scales.rend(); ++it) {
@@ -3405,7 +3441,10 @@ static void apply_update(e3d_reg* h, bool print, bool* applied_update, float* la
       const int Vl = I + (dep ? 12 : 6);
       std::vector<double> Hl((size_t)Vl * Vl), bl(Vl);
       double s2[2]; int64_t c2[2];
-      if (e3d_reg_accumulate(h, kv.first, sc.first, Hl.data(), bl.data(), s2, c2) < 0) throw Error(E3D_ERR_INVALID, e3d_last_error());
+      {
+        Phase ph(h, "apply.accumulate");
+        if (e3d_reg_accumulate(h, kv.first, sc.first, Hl.data(), bl.data(), s2, c2) < 0) throw Error(E3D_ERR_INVALID, e3d_last_error());
+      }
       sums[0] += s2[0]; sums[1] += s2[1]; counts[0] += c2[0]; counts[1] += c2[1];
       // scatter the local [intrinsics(I), (rig extrinsics(6),) pose(6)] block (AccumulateOnHAndB's block updates)
       auto gidx = [&](int l) { return l < I ? ii + l : ((dep && l < I + 6) ? ri + (l - I) : pi + (l - (Vl - 6))); };
@@ -3457,14 +3496,18 @@ static void apply_update(e3d_reg* h, bool print, bool* applied_update, float* la
   std::vector<int> perm;
   constexpr int kNumLMTries = 10;
   for (int lm = 0; lm < kNumLMTries; ++lm) {
-    if (dense_solve) {
-      Hlm = H;
-      for (int i = 0; i < V; ++i) Hlm[(size_t)i * V + i] *= (1 + (*lambda));       // multiplicative damping (:206)
-      ldlt_solve_upper(Hlm.data(), V, b.data(), x.data(), W, perm);
-    } else {
-      Hb.solve((double)(1 + (*lambda)), x.data());
+    {
+      Phase ph(h, "apply.host_solve");
+      if (dense_solve) {
+        Hlm = H;
+        for (int i = 0; i < V; ++i) Hlm[(size_t)i * V + i] *= (1 + (*lambda));       // multiplicative damping (:206)
+        ldlt_solve_upper(Hlm.data(), V, b.data(), x.data(), W, perm);
+      } else {
+        Hb.solve((double)(1 + (*lambda)), x.data());
+      }
     }
     // CreateDeltaState(-x)
+    std::unique_ptr<Phase> ph_state(new Phase(h, "apply.trial_state_and_camera_pyramids"));
     RegState trial = old_state;
     for (auto& kv : trial.intr) {
       Intrin& in = kv.second;
@@ -3480,6 +3523,7 @@ static void apply_update(e3d_reg* h, bool print, bool* applied_update, float* la
     // ComputeResidualForState with the visibility lists fixed
     set_state(h, trial);
     compose_rig_poses(h);
+    ph_state.reset();
     double ts[3] = {0, 0, 0}; int64_t tc[3] = {0, 0, 0};
     constexpr size_t kManyObservationsCount = 100;
     for (auto& kv : h->images) {
@@ -3487,6 +3531,7 @@ static void apply_update(e3d_reg* h, bool print, bool* applied_update, float* la
       const int scale = best_available_scale(h, h->intr.at(kv.second.intrinsics_id));
       bool had_many = false;
       std::vector<int> done;
+      std::unique_ptr<Phase> ph_obs(new Phase(h, "apply.trial_reprojection"));
       for (auto it = h->scales.rbegin(); it != h->scales.rend(); ++it) {
         auto vi = vis[kv.first].find(it->first);
         const size_t nv = (vi == vis[kv.first].end()) ? 0 : vi->second.second;
@@ -3498,6 +3543,8 @@ static void apply_update(e3d_reg* h, bool print, bool* applied_update, float* la
         if ((size_t)n > kManyObservationsCount) had_many = true;
         else if (n == 0 && had_many) break;
       }
+      ph_obs.reset();
+      Phase ph_cost(h, "apply.trial_cost");
       for (auto& sc : h->scales) {
         // scales skipped by the early-out have empty observation vectors in the reference
         if (std::find(done.begin(), done.end(), sc.first) == done.end()) continue;
@@ -3889,16 +3936,19 @@ int e3d_reg_run_on_current_scale(e3d_reg_t* h, int max_num_iterations, float max
       if (print) printf("  Intrinsics and poses update ...\n");
       applied = false;
       max_change = 0;
+      Phase ph(h, "apply (all of it)");
       apply_update(h, print, &applied, &lambda, &max_change);
     }
     if (print) printf("  Observations update ...\n");
-    update_observations(h, /*kBorderSize*/ 1);
+    { Phase ph(h, "observations (all of it)"); update_observations(h, /*kBorderSize*/ 1); }
     if (h->prm.variable_residuals_weight > 0) {
       if (print) printf("  Color update ...\n");
+      Phase ph(h, "color_update");
       color_update(h);
     }
     if (print) printf("  Determining cost ...\n");
-    const double current_cost = total_cost(h);
+    double current_cost;
+    { Phase ph(h, "total_cost"); current_cost = total_cost(h); }
     if (print) printf("  Cost (considering occlusions) is: %g\n", current_cost);
     if (current_cost < *optimum_cost) {
       *optimum_cost = current_cost;

@@ -340,6 +340,11 @@ int64_t e3d_reg_occlusion_edge_count(e3d_reg_t* reg, int mesh_index);
  * out = {pass 1 ms (k_reg_pass1: per-observation intensity + Jacobian rows), pass 2 ms (k_reg_pass2 / k_reg_pass2_mfma: residuals and
  * normal equations), observations processed, calls}. */
 int e3d_reg_kernel_times(e3d_reg_t* reg, double out[4], int reset);
+/* Wall-clock split of e3d_reg_run_on_current_scale by phase (accumulate, host solve, trial states, re-projection, costs, occlusion
+ * depth maps, visibility, colour update).  enable = 1 switches it on (the library then synchronises its stream at every phase
+ * boundary: the run gets slower, the split adds up), 0 off; `out` (may be NULL) receives "phase=milliseconds;..." of the phases
+ * recorded so far.  Switching clears the record.  Measurement only -- no effect on results. */
+int e3d_reg_profile(e3d_reg_t* reg, int enable, char* out, size_t capacity);
 
 /* Renders the occlusion depth map of an image at an image scale (kept on the device for e3d_reg_observe);
  * depth_out (optional) receives height x width floats. */

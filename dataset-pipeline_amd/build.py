@@ -21,6 +21,13 @@ def lib_path():
     return os.path.join(LIBDIR, "libe3dhip.so")
 
 
+# per-file extras.  No SLP vectorisation for the ICP and registration kernels: the compiler otherwise packs adjacent scalar f32
+# operations of their long expression trees into v_pk_*_f32 and spends more on moves than it saves (measured on one MI355X:
+# k_lm_cost_multi 2.00 -> 1.67 ms, k_lm_pass<3> 0.97 -> 0.91 ms, k_reg_pass1 0.503 -> 0.447 ms; tools/micro/lm_variants.hip, DESIGN
+# 4.2).  The kNN kernels of e3d_normals.hip gain from it (1.72 vs 1.34 G normals/s) and keep it.  Rounding is the same either way.
+EXTRA_FLAGS = {"e3d_icp_kernels.hip": ["-fno-slp-vectorize"], "e3d_reg.hip": ["-fno-slp-vectorize"]}
+
+
 def _newer(src, dst):
     return (not os.path.exists(dst)) or os.path.getmtime(src) > os.path.getmtime(dst)
 
@@ -41,7 +48,7 @@ def build(force=False, verbose=False):
         obj = os.path.join(objdir, s.replace(".hip", ".o"))
         objs.append(obj)
         if force or _newer(src, obj) or any(_newer(hd, obj) for hd in hdrs):
-            cmd = ["hipcc"] + FLAGS + ["-c", src, "-o", obj]
+            cmd = ["hipcc"] + FLAGS + EXTRA_FLAGS.get(s, []) + os.environ.get("E3D_EXTRA_HIPCC_FLAGS", "").split() + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd))
             procs.append((s, subprocess.Popen(cmd)))

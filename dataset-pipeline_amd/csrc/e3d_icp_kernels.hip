@@ -1430,10 +1430,10 @@ __global__ __launch_bounds__(kBlock) void k_unpermute_matches(const int* __restr
 //          (icp_point_to_plane_impl.h:119-211 and :240-266), fused: one pass over the
 //          correspondence planes yields cost and (mode-dependent) the Gramian blocks.
 // =================================================================================================
-// f32 residual / Jacobian rows, literally as written in the reference (left-to-right), for ONE correspondence (T = float)
-// or for TWO at once (T = f2_t: every operation is the packed form v_pk_mul_f32 / v_pk_add_f32 of the same individually
-// rounded f32 operation, so each half is bit-identical to the scalar evaluation -- the f32 part of an LM pass is VALU work
-// of the same order as the f64 products, and the packed form halves it).
+// f32 residual / Jacobian rows, literally as written in the reference (left-to-right).  (Templated on the scalar type only so that
+// tools/micro/lm_variants.hip can instantiate experimental forms; the product uses T = float.  A form that pushed TWO
+// correspondences through the packed v_pk_mul_f32 / v_pk_add_f32 instructions was measured and dropped: the pose entries have to
+// be splatted into VGPR pairs and the pair interleaved with ~20 moves per trip, and it never beat the scalar loop -- DESIGN 4.2.)
 //
 // The two 12-entry rows [js ; jt] of a correspondence only hold 9 different numbers each: the translation parts are
 // js[0..2] = -jt[0..2] (impl.h:162-164 / 170-172 and 188-190 / 197-199).  With m = jt[0..2], a = js[3..5], b = jt[3..5]:
@@ -1517,14 +1517,6 @@ __device__ __forceinline__ void corr_rows(const LmSet& S, const V4& a, const V4&
   corr_rows_pts<NEED_SRC, NEED_TGT, T>(P, o);
 }
 
-// two correspondences side by side: component i of the pair's planes as (first, second)
-struct Pair4 { f2_t x, y, z, w; };
-__device__ __forceinline__ Pair4 pair4(const float4 u, const float4 v) {
-  Pair4 r;
-  r.x = f2_t{u.x, v.x}; r.y = f2_t{u.y, v.y}; r.z = f2_t{u.z, v.z}; r.w = f2_t{u.w, v.w};
-  return r;
-}
-template <int H> __device__ __forceinline__ float half_of(const f2_t v) { return H == 0 ? v.x : v.y; }
 template <int H> __device__ __forceinline__ float half_of(const float v) { return v; }
 
 // accumulate upper triangle of J J^T (21) and r*J (6) in f64 from f32 rows cast to f64 first
@@ -1681,10 +1673,10 @@ __device__ __forceinline__ void lm_rows(const LmSet& S, const V4& a, const V4& b
 // Every thread walks its correspondences c, c + stride, c + 2 stride, ... in this order and adds row 1 then row 2 of each: the
 // per-thread sums, and with the fixed reduction tree the block partials, are the same numbers whatever the loop shape.
 // Loop shapes (tools/micro/lm_variants.hip measures them; LmCfg holds the choice per mode):
-//   UNR  correspondences per trip (1 or 2);  PACK  the two of a trip share packed f32 instructions;
+//   UNR  correspondences per trip (1 or 2);
 //   PF   the next trip's float4 loads are issued before the current trip's arithmetic (at 2 - 3 waves per SIMD -- the f64
 //        accumulators -- the loads in flight per lane, not the occupancy, have to cover the HBM latency).
-template <int MODE, int UNR, bool PACK, bool PF>
+template <int MODE, int UNR, bool PF>
 __device__ __forceinline__ void lm_pass_body(const float4* __restrict__ A, const float4* __restrict__ B,
                                              const float4* __restrict__ C, const LmSet* __restrict__ sets,
                                              const int* __restrict__ block_set, const int block_base,
@@ -1712,19 +1704,11 @@ __device__ __forceinline__ void lm_pass_body(const float4* __restrict__ A, const
       const float4 ua = a0, ub = b0, uc = c0, va = a1, vb = b1, vc = c1;
       c += 2 * stride;
       if (PF && c + stride < S.n) { a0 = pa[c]; b0 = pb[c]; c0 = pc[c]; a1 = pa[c + stride]; b1 = pb[c + stride]; c1 = pc[c + stride]; }
-      if (PACK) {
-        const Pair4 pa2 = pair4(ua, va), pb2 = pair4(ub, vb), pc2 = pair4(uc, vc);
-        CorrRowsT<f2_t> R;
-        lm_rows<MODE, f2_t>(S, pa2, pb2, pc2, R);
-        lm_accumulate<MODE, 0, f2_t>(acc, R, S.side);
-        lm_accumulate<MODE, 1, f2_t>(acc, R, S.side);
-      } else {
-        CorrRowsT<float> R;
-        lm_rows<MODE, float>(S, ua, ub, uc, R);
-        lm_accumulate<MODE, 0, float>(acc, R, S.side);
-        lm_rows<MODE, float>(S, va, vb, vc, R);
-        lm_accumulate<MODE, 0, float>(acc, R, S.side);
-      }
+      CorrRowsT<float> R;
+      lm_rows<MODE, float>(S, ua, ub, uc, R);
+      lm_accumulate<MODE, 0, float>(acc, R, S.side);
+      lm_rows<MODE, float>(S, va, vb, vc, R);
+      lm_accumulate<MODE, 0, float>(acc, R, S.side);
     }
     if (c < S.n) {
       const float4 a = pa[c], b = pb[c], cc = pc[c];
@@ -1780,18 +1764,19 @@ __device__ __forceinline__ void lm_pass_body(const float4* __restrict__ A, const
 
 // the loop shape each mode runs with.  Measured on one MI355X (tools/micro/lm_variants.hip, 1e8 correspondences in 8 sets,
 // profiles/round3_lm_variants.txt): one correspondence per trip with the next one's loads in flight wins in every mode; three
-// waves per SIMD (168 VGPRs) for the two-sided modes, which the 55 / 46 f64 accumulators allow.  The packed f32 form does
-// not pay here: the compiler spends 48 VGPRs on splatted pose scalars and ~20 v_mov per trip on interleaving the pair.
-template <int MODE> struct LmCfg { static constexpr int unr = 1; static constexpr bool pack = false, pf = true; static constexpr int minw = 3; };
-template <> struct LmCfg<kModeCost> { static constexpr int unr = 1; static constexpr bool pack = false, pf = true; static constexpr int minw = 1; };
-template <> struct LmCfg<kModeOne> { static constexpr int unr = 1; static constexpr bool pack = false, pf = true; static constexpr int minw = 2; };
+// waves per SIMD (168 VGPRs) for the two-sided modes, which the 55 / 46 f64 accumulators allow.  The translation unit is built
+// with -fno-slp-vectorize: left alone, the compiler packs adjacent scalar f32 operations of these expression trees into
+// v_pk_mul_f32 / v_pk_add_f32 and pays for it in moves (k_lm_cost_multi 2.00 -> 1.67 ms, mode 3 0.97 -> 0.91 ms without).
+template <int MODE> struct LmCfg { static constexpr int unr = 1; static constexpr bool pf = true; static constexpr int minw = 3; };
+template <> struct LmCfg<kModeCost> { static constexpr int unr = 1; static constexpr bool pf = true; static constexpr int minw = 1; };
+template <> struct LmCfg<kModeOne> { static constexpr int unr = 1; static constexpr bool pf = true; static constexpr int minw = 2; };
 
 template <int MODE>
 __global__ __launch_bounds__(kBlock, LmCfg<MODE>::minw) void k_lm_pass(const float4* __restrict__ A, const float4* __restrict__ B,
                                                                        const float4* __restrict__ C, const LmSet* __restrict__ sets,
                                                                        const int* __restrict__ block_set, int block_base,
                                                                        double* __restrict__ partial) {
-  lm_pass_body<MODE, LmCfg<MODE>::unr, LmCfg<MODE>::pack, LmCfg<MODE>::pf>(A, B, C, sets, block_set, block_base, partial);
+  lm_pass_body<MODE, LmCfg<MODE>::unr, LmCfg<MODE>::pf>(A, B, C, sets, block_set, block_base, partial);
 }
 
 // a8, batched: the LM tries 1..9 of one inner iteration (lambda doubled each time, icp_point_to_plane_impl.h:216-283)
@@ -1801,8 +1786,8 @@ __global__ __launch_bounds__(kBlock, LmCfg<MODE>::minw) void k_lm_pass(const flo
 // to the one a separate pass would return; the host then takes the first try that lowers the cost, as the
 // reference's sequential loop does.  (The usual call is the last one of an outer iteration, where all nine tries fail: an
 // early-out after the first few tries would not save it.)  Nine poses are 9 x 80 f32 operations per correspondence, VALU
-// bound: two correspondences go through the packed f32 instructions together, and the side of a kModeOne pair that has no
-// variables (impl cloud 0, the same inner pose in every candidate) is transformed once instead of nine times.
+// bound; the side of a kModeOne pair that has no variables (impl cloud 0, the same inner pose in every candidate) is transformed
+// once instead of nine times.
 template <typename T, typename V4>
 __device__ __forceinline__ void lm_costs_of(const LmSet& S, const LmPose* __restrict__ poses, const int n_sets, const int n_poses,
                                             const int si, const V4& a, const V4& b, const V4& c, T* r1, T* r2) {
@@ -1824,7 +1809,7 @@ __device__ __forceinline__ void lm_costs_of(const LmSet& S, const LmPose* __rest
   }
 }
 
-template <bool PACK, bool PF>
+template <bool PF>
 __device__ __forceinline__ void lm_cost_multi_body(const float4* __restrict__ A, const float4* __restrict__ B,
                                                    const float4* __restrict__ C, const LmSet* __restrict__ sets,
                                                    const LmPose* __restrict__ poses, int n_sets, int n_poses,
@@ -1840,35 +1825,19 @@ __device__ __forceinline__ void lm_cost_multi_body(const float4* __restrict__ A,
   const float4* __restrict__ pb = B + S.off;
   const float4* __restrict__ pc = C + S.off;
   long long c = (long long)(gb - S.block_begin) * kBlock + threadIdx.x;
-  if (PACK) {
-    float4 a0, b0, c0, a1, b1, c1;
-    if (PF && c + stride < S.n) { a0 = pa[c]; b0 = pb[c]; c0 = pc[c]; a1 = pa[c + stride]; b1 = pb[c + stride]; c1 = pc[c + stride]; }
-    while (c + stride < S.n) {
-      if (!PF) { a0 = pa[c]; b0 = pb[c]; c0 = pc[c]; a1 = pa[c + stride]; b1 = pb[c + stride]; c1 = pc[c + stride]; }
-      const Pair4 pa2 = pair4(a0, a1), pb2 = pair4(b0, b1), pc2 = pair4(c0, c1);
-      c += 2 * stride;
-      if (PF && c + stride < S.n) { a0 = pa[c]; b0 = pb[c]; c0 = pc[c]; a1 = pa[c + stride]; b1 = pb[c + stride]; c1 = pc[c + stride]; }
-      f2_t r1[kLmMaxPoses], r2[kLmMaxPoses];
-      lm_costs_of<f2_t>(S, poses, n_sets, n_poses, si, pa2, pb2, pc2, r1, r2);
-#pragma unroll
-      for (int k = 0; k < kLmMaxPoses; ++k) {
-        if (k < n_poses) {
-          const f2_t q1 = r1[k] * r1[k], q2 = r2[k] * r2[k];
-          acc[k] += (double)q1.x; acc[k] += (double)q2.x;     // first correspondence: row 1, row 2; then the second
-          acc[k] += (double)q1.y; acc[k] += (double)q2.y;
-        }
-      }
-    }
-  }
+  float4 a0, b0, c0;
+  if (PF && c < S.n) { a0 = pa[c]; b0 = pb[c]; c0 = pc[c]; }
   while (c < S.n) {
-    const float4 a = pa[c], b = pb[c], cc = pc[c];
+    if (!PF) { a0 = pa[c]; b0 = pb[c]; c0 = pc[c]; }
+    const float4 a = a0, b = b0, cc = c0;
+    c += stride;
+    if (PF && c < S.n) { a0 = pa[c]; b0 = pb[c]; c0 = pc[c]; }
     float r1[kLmMaxPoses], r2[kLmMaxPoses];
     lm_costs_of<float>(S, poses, n_sets, n_poses, si, a, b, cc, r1, r2);
 #pragma unroll
     for (int k = 0; k < kLmMaxPoses; ++k) {
       if (k < n_poses) { acc[k] += (double)(r1[k] * r1[k]); acc[k] += (double)(r2[k] * r2[k]); }
     }
-    c += stride;
   }
   __shared__ double s[kBlock / kWave][kLmMaxPoses];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -1892,7 +1861,7 @@ __global__ __launch_bounds__(kBlock) void k_lm_cost_multi(const float4* __restri
                                                           const float4* __restrict__ C, const LmSet* __restrict__ sets,
                                                           const LmPose* __restrict__ poses, int n_sets, int n_poses,
                                                           const int* __restrict__ block_set, double* __restrict__ partial) {
-  lm_cost_multi_body<true, true>(A, B, C, sets, poses, n_sets, n_poses, block_set, partial);
+  lm_cost_multi_body<true>(A, B, C, sets, poses, n_sets, n_poses, block_set, partial);
 }
 
 // one block per set: sum the set's block partials in a fixed order.  kRedParts threads share each of the

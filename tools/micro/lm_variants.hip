@@ -2,7 +2,9 @@
 // result; LmCfg in e3d_icp_kernels.hip holds the choice).  The kernel bodies are the product's: this file includes the
 // translation unit and only adds __global__ wrappers with other template arguments and launch bounds.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-fast-math \
-//         -o lm_variants tools/micro/lm_variants.hip && ./lm_variants [million correspondences] [sets]
+//         -fno-slp-vectorize -o lm_variants tools/micro/lm_variants.hip && ./lm_variants [million correspondences] [sets] [blocks per set]
+// (round 3 also measured a packed two-correspondence form here, with and without SGPR-broadcast pose operands, and the build
+// without -fno-slp-vectorize: profiles/round3_lm_variants*.txt)
 #include "../../dataset-pipeline_amd/csrc/e3d_icp_kernels.hip"
 
 #include <cmath>
@@ -17,18 +19,18 @@ bool release_cached_device_memory() { return false; }
 }
 using namespace e3d;
 
-template <int MODE, int UNR, bool PACK, bool PF, int MINW>
+template <int MODE, int UNR, bool PF, int MINW>
 __global__ __launch_bounds__(kBlock, MINW) void k_var(const float4* __restrict__ A, const float4* __restrict__ B,
                                                       const float4* __restrict__ C, const LmSet* __restrict__ sets,
                                                       const int* __restrict__ block_set, int block_base, double* __restrict__ partial) {
-  lm_pass_body<MODE, UNR, PACK, PF>(A, B, C, sets, block_set, block_base, partial);
+  lm_pass_body<MODE, UNR, PF>(A, B, C, sets, block_set, block_base, partial);
 }
-template <bool PACK, bool PF, int MINW>
+template <bool PF, int MINW>
 __global__ __launch_bounds__(kBlock, MINW) void k_cm(const float4* __restrict__ A, const float4* __restrict__ B,
                                                      const float4* __restrict__ C, const LmSet* __restrict__ sets,
                                                      const LmPose* __restrict__ poses, int n_sets, int n_poses,
                                                      const int* __restrict__ block_set, double* __restrict__ partial) {
-  lm_cost_multi_body<PACK, PF>(A, B, C, sets, poses, n_sets, n_poses, block_set, partial);
+  lm_cost_multi_body<PF>(A, B, C, sets, poses, n_sets, n_poses, block_set, partial);
 }
 
 __global__ void k_fill(float4* A, float4* B, float4* C, size_t n, unsigned seed) {
@@ -53,6 +55,7 @@ static void quat(float w, float x, float y, float z, float* R) {
 int main(int argc, char** argv) {
   const size_t n = (size_t)((argc > 1 ? atof(argv[1]) : 100.0) * 1e6);
   const int ns = argc > 2 ? atoi(argv[2]) : 8;
+  const long long cap = argc > 3 ? atoll(argv[3]) : 1024;      // blocks per set
   float4 *A, *B, *C;
   if (hipMalloc(&A, n * 16) != hipSuccess || hipMalloc(&B, n * 16) != hipSuccess || hipMalloc(&C, n * 16) != hipSuccess) { printf("alloc failed\n"); return 1; }
   hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, A, B, C, n, 12345u);
@@ -62,7 +65,7 @@ int main(int argc, char** argv) {
   for (int i = 0; i < ns; ++i) {
     LmSet& S = sets[i];
     S.off = (long long)(n / ns) * i; S.n = (long long)(n / ns) - 7 * i;   // ragged ends: tails of every shape
-    long long b = (S.n + (long long)kBlock * 8 - 1) / ((long long)kBlock * 8); if (b > 1024) b = 1024; if (b < 1) b = 1;
+    long long b = (S.n + (long long)kBlock * 8 - 1) / ((long long)kBlock * 8); if (b > cap) b = cap; if (b < 1) b = 1;
     S.block_begin = block; S.nblocks = (int)b; S.mode = 3; S.side = i & 1;
     quat(1.f, 0.001f * (i + 1), -0.002f, 0.0015f, S.Rs); quat(1.f, -0.001f, 0.0005f * (i + 1), 0.002f, S.Rt);
     for (int k = 0; k < 3; ++k) { S.ts[k] = 0.001f * (k + 1); S.tt[k] = -0.0007f * (k + 1); }
@@ -102,19 +105,17 @@ int main(int argc, char** argv) {
     printf("%-34s %8.3f ms  %6.2f TB/s (48 B)  %s %s\n", name, best, n * 48.0 / (best * 1e-3) / 1e12, same ? "bits==first" : "DIFFERENT", err == hipSuccess ? "" : hipGetErrorString(err));
     fflush(stdout);
   };
-#define V(MODE, UNR, PACK, PF, MINW, FIRST) \
-  run("mode" #MODE " unr" #UNR " pack" #PACK " pf" #PF " minw" #MINW, MODE, -1, [&] { hipLaunchKernelGGL((k_var<MODE, UNR, PACK, PF, MINW>), dim3(block), dim3(kBlock), 0, 0, A, B, C, dsets, dbs, 0, part); }, FIRST)
-#define VM(MODE)                                                                                                              \
-  V(MODE, 1, false, false, 1, true); V(MODE, 1, false, true, 1, false); V(MODE, 1, false, false, 2, false); V(MODE, 1, false, true, 2, false); \
-  V(MODE, 1, false, false, 3, false); V(MODE, 1, false, true, 3, false);                                                      \
-  V(MODE, 2, false, false, 2, false); V(MODE, 2, false, true, 2, false); V(MODE, 2, false, true, 3, false);                   \
-  V(MODE, 2, true, false, 1, false); V(MODE, 2, true, true, 1, false); V(MODE, 2, true, false, 2, false); V(MODE, 2, true, true, 2, false); \
-  V(MODE, 2, true, false, 3, false); V(MODE, 2, true, true, 3, false);
+#define V(MODE, UNR, PF, MINW, FIRST) \
+  run("mode" #MODE " unr" #UNR " pf" #PF " minw" #MINW, MODE, -1, [&] { hipLaunchKernelGGL((k_var<MODE, UNR, PF, MINW>), dim3(block), dim3(kBlock), 0, 0, A, B, C, dsets, dbs, 0, part); }, FIRST)
+#define VM(MODE)                                                                                                       \
+  V(MODE, 1, false, 1, true); V(MODE, 1, true, 1, false); V(MODE, 1, false, 2, false); V(MODE, 1, true, 2, false); \
+  V(MODE, 1, false, 3, false); V(MODE, 1, true, 3, false); V(MODE, 1, true, 4, false);                               \
+  V(MODE, 2, false, 2, false); V(MODE, 2, true, 2, false); V(MODE, 2, true, 3, false);
   VM(3) VM(2) VM(1)
-  V(0, 1, false, false, 1, true); V(0, 1, false, true, 1, false); V(0, 2, true, false, 1, false); V(0, 2, true, true, 1, false); V(0, 2, true, true, 4, false);
-#define CM(PACK, PF, MINW, MODE, SIDE, FIRST) \
-  run("cost_multi pack" #PACK " pf" #PF " minw" #MINW " mode" #MODE, MODE, SIDE, [&] { hipLaunchKernelGGL((k_cm<PACK, PF, MINW>), dim3(block), dim3(kBlock), 0, 0, A, B, C, dsets, dposes, ns, kLmMaxPoses, dbs, part); }, FIRST)
-  CM(false, false, 1, 3, 0, true); CM(true, false, 1, 3, 0, false); CM(true, true, 1, 3, 0, false); CM(true, true, 2, 3, 0, false); CM(true, false, 2, 3, 0, false); CM(true, true, 3, 3, 0, false);
-  CM(false, false, 1, 1, 0, true); CM(true, false, 1, 1, 0, false); CM(true, true, 1, 1, 0, false); CM(true, true, 2, 1, 0, false); CM(true, false, 2, 1, 0, false); CM(true, true, 3, 1, 0, false);
+  V(0, 1, false, 1, true); V(0, 1, true, 1, false); V(0, 2, true, 1, false);
+#define CM(PF, MINW, MODE, SIDE, FIRST) \
+  run("cost_multi pf" #PF " minw" #MINW " mode" #MODE, MODE, SIDE, [&] { hipLaunchKernelGGL((k_cm<PF, MINW>), dim3(block), dim3(kBlock), 0, 0, A, B, C, dsets, dposes, ns, kLmMaxPoses, dbs, part); }, FIRST)
+  CM(false, 1, 3, 0, true); CM(true, 1, 3, 0, false); CM(true, 2, 3, 0, false); CM(true, 4, 3, 0, false);
+  CM(false, 1, 1, 0, true); CM(true, 1, 1, 0, false); CM(true, 2, 1, 0, false); CM(true, 4, 1, 0, false);
   return 0;
 }

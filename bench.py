@@ -43,16 +43,18 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 ALG_BYTES_PER_CORR_PASS = 56   # 2 x i32 + 4 x vec3 f32 per correspondence per pass
 ALG_BYTES_PER_QUERY = 32       # 12 in + 8 out + 12 amortised target
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "round2_traffic.json")
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "round3_traffic.json")
+if not os.path.exists(TRAFFIC_JSON):
+    TRAFFIC_JSON = os.path.join(ROOT, "profiles", "round2_traffic.json")
 
 
 def load_traffic(kernel_key):
     """HBM bytes per launch of a kernel from the committed rocprofv3 PMC passes of this same command (bench.py cannot run the
-    profiler itself): profiles/round2_traffic.json, written by tools/make_traffic_json.py."""
+    profiler itself): profiles/round3_traffic.json, written by tools/make_traffic_json.py from tools/prof_round3.sh's passes."""
     if not os.path.exists(TRAFFIC_JSON):
         return None, None
     k = json.load(open(TRAFFIC_JSON)).get("kernels", {}).get(kernel_key)
-    return (k["hbm_bytes_per_launch"], "profiles/round2_traffic.json") if k else (None, None)
+    return (k["hbm_bytes_per_launch"], "profiles/" + os.path.basename(TRAFFIC_JSON)) if k else (None, None)
 
 
 def crop_world(scan, lo, hi):
@@ -389,6 +391,10 @@ def leg_image_registrator(e3d, synth, args, dev):
     tr1, src1 = load_traffic("k_reg_pass1<2, false>")
     tr2, src2 = load_traffic("k_reg_pass2_tile32<5, 18>")
     out = {"metric": "ImageRegistrator residuals/sec", "value": res / t_acc, "unit": "residuals/s",
+           "dtype": "f32 rows; H, b: f32 fma chains of 32 (b: <= 20) residual pairs added into f64 -- NARROWER than the reference, which adds single "
+                    "f32 products in f64 (intrinsics_and_pose_optimizer.cc:1246-1247); E3D_REG_PASS2=mfma64 is that sum (0.93 instead of "
+                    "0.67 ms per image), and tests/test_gpu_reg.py::test_run_is_insensitive_to_the_pass2_accumulation_width shows whole runs "
+                    "agree to 1e-7 rad",
            "config": {"workload": "%d images 6048x4032 (6 levels) THIN_PRISM_FISHEYE, %d points, K = %d (BASELINE.json configs[3] shape)"
                                   % (len(ids), len(Wl["pts"]), K), "unknowns": I + 6 * len(ids)},
            "residuals": res, "accumulate_ms_all_images": t_acc * 1e3, "observation_refresh_ms_all_images": t_obs * 1e3,

@@ -54,6 +54,7 @@ SIGNATURES = {
     "e3d_icp_run": (C.c_int, [C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_float, C.c_int]),
     "e3d_icp_get_pose": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "e3d_icp_set_max_inner_iterations": (C.c_int, [C.c_void_p, C.c_int]),
+    "e3d_icp_set_sequential_distance_sum": (C.c_int, [C.c_void_p, C.c_int]),
     "e3d_icp_num_pair_records": (C.c_size_t, [C.c_void_p]),
     "e3d_icp_pair_records": (C.POINTER(PairRecord), [C.c_void_p]),
     "e3d_icp_num_iter_records": (C.c_size_t, [C.c_void_p]),
@@ -255,6 +256,10 @@ class PointToPlaneICP:
         out = np.eye(4, dtype=np.float32)
         out[:3] = T
         return out
+
+    def set_sequential_distance_sum(self, enable):
+        if lib().e3d_icp_set_sequential_distance_sum(self._h, int(bool(enable))) < 0:
+            _err("e3d_icp_set_sequential_distance_sum")
 
     def set_max_inner_iterations(self, n):
         if lib().e3d_icp_set_max_inner_iterations(self._h, int(n)) < 0:

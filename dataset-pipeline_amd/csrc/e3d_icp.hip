@@ -83,6 +83,7 @@ struct PairJob {
   long long count = 0;      // this rank's correspondences
   long long gcount = 0;     // all ranks' (what the reference prints; decides which pairs enter the LM system)
   double dsum = 0.0;
+  bool dsum_f32 = false;    // dsum holds the reference's sequential f32 sum (e3d_icp_set_sequential_distance_sum)
   size_t corr_off = 0;
   bool mine = true;
 };
@@ -97,6 +98,11 @@ struct e3d_icp {
   std::vector<std::unique_ptr<Cloud>> clouds;   // movable clouds
   std::unique_ptr<Cloud> fixed;                 // merged fixed cloud (global frame)
   int max_inner = 150;
+  // the progress line's "avg. distance" from the reference's own sum: f32, sequential, in original source order (one device ->
+  // host copy of n floats and a host loop per pair; off: f64 sum on the device, which does not stagnate for large clouds)
+  bool sequential_dsum = [] { const char* e = getenv("E3D_ICP_SEQUENTIAL_DISTANCE_SUM"); return e && e[0] == '1'; }();
+  DevBuf<float> d2_by_orig;
+  std::vector<float> h_d2_by_orig;
   int nn_mode = 0;                              // 0 auto, 1 per-query kernel, 2 hash-table bucket kernel, 3 dense-directory row kernel, 4 row kernel with MFMA filter
   // max cells of a dense directory (4 B each; default 2^33 = 32 GB of the 288 GB per cloud, E3D_DENSE_CELLS overrides);
   // hash table beyond
@@ -586,6 +592,15 @@ static void find_pair(e3d_icp* h, Cloud& src, Cloud& tgt, float d, PairJob& job,
   { const double t = h->nn_timer->ms(); rec.t_nn_query_ms += t; rec.t_nn_search_ms += t; }
   job.count = (long long)h->h_total.p[0];
   job.dsum = h->h_total_d2.p[0];
+  if (h->sequential_dsum && !h->comm && h->world <= 1 && n == src.n) {
+    h->d2_by_orig.reserve(n); h->h_d2_by_orig.resize(n);
+    launch_match_d2_by_original(match_pos, h->match_d2.p, order, n, srcG, h->d2_by_orig.p, s);
+    copy_out(h->h_d2_by_orig.data(), h->d2_by_orig.p, sizeof(float) * n, s);
+    sync(h);
+    float distance_sum = 0.f;                                  // icp_point_to_plane.cc:226-229
+    for (size_t i = 0; i < n; ++i) { const float v = h->h_d2_by_orig[i]; if (v >= 0.f) distance_sum += v; }
+    job.dsum = (double)distance_sum; job.dsum_f32 = true;
+  }
   if (job.count == 0) return;
   const size_t need = h->corr_used + (size_t)job.count;
   if (need > h->cA.cap) {
@@ -954,7 +969,11 @@ static bool align_meshes(e3d_icp* h, float max_d, float thr, bool print, int ite
     h->pair_records.push_back({iteration, psrc, ptgt, (int64_t)gcount[p], gdsum[p]});
     if (print && h->rank == 0) {
       char avg[64] = "";
-      if (gcount[p] > 0) snprintf(avg, sizeof avg, " (avg. distance: %g)", (double)(float)(gdsum[p] / (double)gcount[p]));
+      if (gcount[p] > 0) {
+        const float a = jobs[p].dsum_f32 ? (float)gdsum[p] / (float)(size_t)gcount[p]        // float / size_t, as the reference divides
+                                         : (float)(gdsum[p] / (double)gcount[p]);
+        snprintf(avg, sizeof avg, " (avg. distance: %g)", (double)a);
+      }
       if (psrc >= 0 && ptgt >= 0) printf("  found correspondences from %d to %d: %lld%s\n", j.impl_src, j.impl_tgt, gcount[p], avg);
       else if (ptgt < 0) printf("  found correspondences from %d to fixed clouds: %lld%s\n", j.impl_src, gcount[p], avg);
       else printf("  found correspondences from fixed clouds to %d: %lld%s\n", j.impl_tgt, gcount[p], avg);
@@ -1112,6 +1131,12 @@ int e3d_icp_get_pose(e3d_icp_t* h, int idx, float T[12]) {
   std::memcpy(T, h->clouds[idx]->T, sizeof(float) * 12);
   return 0;
   E3D_CATCH()
+}
+
+int e3d_icp_set_sequential_distance_sum(e3d_icp_t* h, int enable) {
+  if (!h) { e3d::set_last_error("e3d_icp_set_sequential_distance_sum: null handle"); return E3D_ERR_INVALID; }
+  h->sequential_dsum = enable != 0;
+  return 0;
 }
 
 int e3d_icp_set_max_inner_iterations(e3d_icp_t* h, int n) {

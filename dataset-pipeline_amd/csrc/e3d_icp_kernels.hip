@@ -1409,6 +1409,17 @@ __global__ __launch_bounds__(kBlock) void k_gather_corr(const float* __restrict_
   C[c] = make_float4(txyz[3 * t + 2], tnrm[3 * t], tnrm[3 * t + 1], tnrm[3 * t + 2]);
 }
 
+// squared NN distances by ORIGINAL source index (-1 = no partner): the order the reference sums them in for its progress line
+// (icp_point_to_plane.cc:226-229); e3d_icp_set_sequential_distance_sum
+__global__ __launch_bounds__(kBlock) void k_match_d2_by_original(const int* __restrict__ match_pos, const float* __restrict__ match_d2,
+                                                                 const unsigned* __restrict__ order, size_t n, const float4* __restrict__ Gsrc,
+                                                                 float* __restrict__ out) {
+  const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const size_t js = order ? (size_t)order[j] : j;
+  out[__float_as_uint(Gsrc[js].w)] = (match_pos[j] >= 0) ? match_d2[j] : -1.f;
+}
+
 // un-permute NN results to original source order / original target indices
 __global__ __launch_bounds__(kBlock) void k_unpermute_matches(const int* __restrict__ match_pos,
                                                               const float* __restrict__ match_d2,
@@ -2104,6 +2115,12 @@ void launch_unpermute_matches(const int* match_pos, const float* match_d2, const
   if (!n) return;
   hipLaunchKernelGGL(k_unpermute_matches, dim3((unsigned)div_up(n, kBlock)), dim3(kBlock), 0, s, match_pos, match_d2,
                      order, n, Gsrc, Gtgt, out_idx, out_d2);
+}
+
+void launch_match_d2_by_original(const int* match_pos, const float* match_d2, const unsigned* order, size_t n, const float4* Gsrc, float* out,
+                                 hipStream_t s) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_match_d2_by_original, dim3((unsigned)div_up(n, kBlock)), dim3(kBlock), 0, s, match_pos, match_d2, order, n, Gsrc, out);
 }
 
 void launch_lm_pass(int mode, const float4* A, const float4* B, const float4* C, const LmSet* sets,

@@ -109,6 +109,8 @@ void launch_gather_corr(const float* sxyz, const float* snrm, const float* txyz,
                         const int* im, size_t n, float4* A, float4* B, float4* C, hipStream_t s);
 void launch_unpermute_matches(const int* match_pos, const float* match_d2, const unsigned* order, size_t n, const float4* Gsrc,
                               const float4* Gtgt, int* out_idx, float* out_d2, hipStream_t s);
+void launch_match_d2_by_original(const int* match_pos, const float* match_d2, const unsigned* order, size_t n, const float4* Gsrc, float* out,
+                                 hipStream_t s);
 void launch_lm_pass(int mode, const float4* A, const float4* B, const float4* C, const LmSet* sets,
                     const int* block_set, int block_base, int nblocks, double* partial, hipStream_t s);
 void launch_lm_cost_multi(const float4* A, const float4* B, const float4* C, const LmSet* sets, const LmPose* poses,

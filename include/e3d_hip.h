@@ -81,6 +81,11 @@ int e3d_icp_get_pose(e3d_icp_t* icp, int cloud_index, float global_T_cloud[12]);
 /* Inner LM iteration cap of PointToPlaneICPImpl (reference constant 150,
  * icp_point_to_plane.cc:312); exposed for bounded benchmarks, default 150. */
 int e3d_icp_set_max_inner_iterations(e3d_icp_t* icp, int n);
+/* The "avg. distance" of the progress line and the pair records' distance_sum from the reference's own sum: f32, sequential, in
+ * original source order (icp_point_to_plane.cc:226-229) -- byte-identical stdout, at the price of one device -> host copy of the
+ * distances and a host loop per pair and outer iteration.  Default off (environment E3D_ICP_SEQUENTIAL_DISTANCE_SUM=1 switches it
+ * on for the tools): the f64 sum on the device, which does not stagnate at 2^24 times the typical term.  Ignored when sharded. */
+int e3d_icp_set_sequential_distance_sum(e3d_icp_t* icp, int enable);
 
 /* Per-pair correspondence report of every AlignMeshes call since creation -- the numbers the
  * reference only prints (icp_point_to_plane.cc:226-237).  src/tgt are the impl cloud indices

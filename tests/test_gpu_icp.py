@@ -228,6 +228,23 @@ def test_icp_partial_overlap_three_scans(e3d, ob, synth):
         e3d.lib().e3d_set_nn_mode(0)
 
 
+def test_sequential_distance_sum_matches_reference_order(e3d, ob, synth, nn_mode):
+    """icp_point_to_plane.cc:226-229: the progress line's "avg. distance" is a sequential f32 sum over the correspondences in source
+    order.  With e3d_icp_set_sequential_distance_sum the library reproduces that sum bit for bit (default: an f64 sum on the device);
+    the oracle sums like the reference."""
+    scans = synth.make_scene(2, 40_000, seed=3)
+    g = e3d.PointToPlaneICP(); o = ob.OracleICP()
+    g.set_sequential_distance_sum(True)
+    for s in scans:
+        g.add_point_cloud(s["xyz"].numpy(), s["normals"].numpy(), s["T_init"], False)
+        o.add_point_cloud(s["xyz"].numpy(), s["normals"].numpy(), s["T_init"], False)
+    g.run(0.08, 0, 4, 1e-9, False); o.run(0.08, 0, 4, 1e-9, False)
+    rg, ro = g.pair_records(), o.pair_records()
+    assert [r[:4] for r in rg] == [r[:4] for r in ro]
+    for a, b in zip(rg, ro):
+        assert np.float32(a[4]) == np.float32(b[4]) and a[4] > 0, (a, b)
+
+
 def test_nn_dense_buckets_overflow(e3d, ob, nn_mode):
     """More candidates per 27-cell neighbourhood than one LDS batch holds (kNNCap = 256): batches must chain."""
     rng = np.random.RandomState(21)

@@ -1063,3 +1063,53 @@ def test_pass2_variants_agree(tmp_path):
             worst = max(worst, eh, eb)
             assert eh <= 1e-7 and eb <= 1e-7, (model, variant, eh, eb)
     print("pass 2 variants: worst deviation", worst)
+
+
+_PASS2_RUN_SNIPPET = r'''
+import sys, importlib, numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+e3d = importlib.import_module("dataset-pipeline_amd")
+from reg_util import make_multi_image_scene
+out = {}
+for model in (2, 0, 9):
+    M = make_multi_image_scene(n_points=6000, n_images=3, seed=6, perturb=0.006, model=model)
+    P = e3d.RegProblem(e3d.default_reg_params(image_scale_count=M["n_levels"], point_neighbor_count=M["K"]))
+    P.set_intrinsics(0, M["width"], M["height"], M["params"], 0, M["n_levels"], camera_type=model)
+    P.set_point_scale(0, M["pts"], M["point_radius"], M["nbr"], M["fixed_desc"]); P.set_splat_points(M["pts"])
+    for i, im in enumerate(M["images"]):
+        P.set_image(i, 0, im["pyr"]); P.set_image_pose(i, im["q_init"], im["t_init"])
+    c, cost, its = P.run_on_current_scale(8, 0.0, 15, False)
+    out["poses%d" % model] = np.stack([np.concatenate(P.get_image_pose(i)) for i in range(3)])
+    out["run%d" % model] = np.array([c, cost, its], np.float64)
+np.savez(sys.argv[2], **out)
+'''
+
+
+def test_run_is_insensitive_to_the_pass2_accumulation_width(tmp_path):
+    """The default pass 2 sums f32 fma chains of 32 pairs into f64 (k_reg_pass2_tile32 / _mfma32); the reference adds single f32
+    products in f64 (intrinsics_and_pose_optimizer.cc:1246-1247), which E3D_REG_PASS2=mfma64 does.  Whole RunOnCurrentScale runs
+    under both end at the same iteration count, at costs within 1e-5 and at poses a few 1e-7 rad apart (eight LM iterations turn
+    the 1e-8 differences of H into that): an order of magnitude inside the 1e-5 rad parity bar against the oracle, which therefore
+    does not lean on the narrower sum."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for variant in ("", "mfma64"):
+        env = dict(os.environ)
+        env.pop("E3D_REG_PASS2", None)
+        if variant:
+            env["E3D_REG_PASS2"] = variant
+        f = str(tmp_path / ("run_%s.npz" % (variant or "default")))
+        r = subprocess.run([sys.executable, "-c", _PASS2_RUN_SNIPPET, root, f], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[variant] = np.load(f)
+    worst = (0.0, 0.0)
+    for model in (2, 0, 9):
+        a, b = res[""], res["mfma64"]
+        assert a["run%d" % model][2] == b["run%d" % model][2] and a["run%d" % model][0] == b["run%d" % model][0]
+        assert abs(a["run%d" % model][1] - b["run%d" % model][1]) <= 1e-5 * abs(b["run%d" % model][1])
+        for i in range(3):
+            ang, tr = _pose_delta(a["poses%d" % model][i][:4], a["poses%d" % model][i][4:], b["poses%d" % model][i][:4], b["poses%d" % model][i][4:])
+            worst = (max(worst[0], ang), max(worst[1], tr))
+    print("default pass 2 vs f64 pass 2 over whole runs: poses at most %.3g rad, %.3g m apart" % worst)
+    assert worst[0] <= 2e-6 and worst[1] <= 2e-6, worst

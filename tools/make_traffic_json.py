@@ -1,14 +1,14 @@
 """profiles/round2_traffic.json from the rocprofv3 PMC passes of tools/prof_round2.sh (gpurun_out/r2prof/*_fetch.txt, *_write.txt:
 lines `kernel signature, COUNTER, value summed over the launches, launches`).
 
-    python tools/make_traffic_json.py [gpurun_out/r2prof]"""
+    python tools/make_traffic_json.py [gpurun_out/r3prof] [profiles/round3_traffic.json]"""
 import json
 import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-NOTE = ("HBM traffic per launch from rocprofv3 PMC, separate --pmc FETCH_SIZE and --pmc WRITE_SIZE passes (tools/prof_round2.sh): the ICP "
-        "kernels from `bench.py --no-cpu-baseline --no-reg --no-normals --no-allpairs --steps 3 --warmup 2` (2 x 50 M points), the "
+NOTE = ("HBM traffic per launch from rocprofv3 PMC, separate --pmc FETCH_SIZE and --pmc WRITE_SIZE passes (tools/prof_round3.sh): the ICP "
+        "kernels from `bench.py --no-cpu-baseline --no-reg --no-normals --no-allpairs --steps 3 --warmup 2` (2 x 50 M points; the full-overlap and the partial-overlap leg, launches of both averaged), the "
         "k_reg_* kernels from `tools/bench_c4.py --images 2 --accumulate-only` (6048 x 4032 THIN_PRISM_FISHEYE, 10 M points), the normals "
         "entries k_knn_normals_k32 / _k8 = ALL kernels of one e3d_normals_knn call on 20 M points (`tools/bench_normals.py --repeat 1`: "
         "two calls per run, sums halved). Units: the counters are KiB; on gfx950 FETCH_SIZE reports half of a wide coalesced read "
@@ -32,7 +32,8 @@ def parse(path, counter):
 
 
 def main():
-    src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "r2prof")
+    src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "r3prof")
+    dst = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles", "round3_traffic.json")
     kernels = {}
     for tag in ("icp", "reg"):
         f, w = parse(os.path.join(src, tag + "_fetch.txt"), "FETCH_SIZE"), parse(os.path.join(src, tag + "_write.txt"), "WRITE_SIZE")
@@ -48,7 +49,7 @@ def main():
         fb = sum(2048.0 * f[n][0] for n in ours) / calls; wb = sum(1024.0 * w[n][0] for n in ours if n in w) / calls
         kernels["k_knn_normals_k%d" % k] = {"launches": 1, "fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb, "hbm_bytes_per_launch": fb + wb,
                                              "kernels_summed": sorted(ours)}
-    json.dump({"_note": NOTE, "kernels": kernels}, open(os.path.join(ROOT, "profiles", "round2_traffic.json"), "w"), indent=1)
+    json.dump({"_note": NOTE, "kernels": kernels}, open(dst, "w"), indent=1)
     print(len(kernels), "kernels")
 
 

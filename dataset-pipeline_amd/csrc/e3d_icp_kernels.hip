@@ -1193,7 +1193,7 @@ __global__ __launch_bounds__(kBlock) void k_nn_bounded(const float4* __restrict_
   }
   const float cover_all2 = fmaxf(cover2, cover_box2);
   // fast pass over ALL scanned candidates (inside the radius or not): the two smallest distances with a strict '<' and the third
-  // smallest value; any exact f32 equality with one of the two raises `tie`.  The radius test comes at the end.
+  // smallest value (`tie` is derived from the three at the end).  The radius test comes at the end.
   float bd = kInf, bd2 = kInf, b3 = kInf;
   int bpos = -1, bpos2 = -1;
   bool tie = false;
@@ -1206,7 +1206,6 @@ __global__ __launch_bounds__(kBlock) void k_nn_bounded(const float4* __restrict_
           const float4 c = Gtgt[p];
           const float d2 = sqdist_l2(q.x, q.y, q.z, c.x, c.y, c.z);
           const bool lt1 = d2 < bd, lt2 = d2 < bd2;
-          tie = tie || (d2 == bd) || (d2 == bd2);
           b3 = fminf(b3, fmaxf(d2, bd2));                 // the displaced runner-up, or this candidate
           bd2 = fminf(fmaxf(d2, bd), bd2);
           bpos2 = lt1 ? bpos : (lt2 ? (int)p : bpos2);
@@ -1222,7 +1221,6 @@ __global__ __launch_bounds__(kBlock) void k_nn_bounded(const float4* __restrict_
   for (int l = 1; l < LPQ; ++l) {
     const float obd = __shfl(bd, l, LPQ), obd2 = __shfl(bd2, l, LPQ), ob3 = __shfl(b3, l, LPQ);
     const int opos = __shfl(bpos, l, LPQ), opos2 = __shfl(bpos2, l, LPQ);
-    tie = tie || (__shfl((int)tie, l, LPQ) != 0);
     if (sub == 0) {
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
@@ -1230,7 +1228,6 @@ __global__ __launch_bounds__(kBlock) void k_nn_bounded(const float4* __restrict_
         const int p = t == 0 ? opos : opos2;
         if (p >= 0) {
           const bool lt1 = d2 < bd, lt2 = d2 < bd2;
-          tie = tie || (d2 == bd) || (d2 == bd2);
           b3 = fminf(b3, fmaxf(d2, bd2));
           bd2 = fminf(fmaxf(d2, bd), bd2);
           bpos2 = lt1 ? bpos : (lt2 ? p : bpos2);
@@ -1242,6 +1239,9 @@ __global__ __launch_bounds__(kBlock) void k_nn_bounded(const float4* __restrict_
     }
   }
   if (sub != 0) return;
+  // The three smallest distances are an exact multiset (strict '<' updates keep equal values side by side), so an exact f32
+  // equality that could change the winner or the runner-up shows as bd == bd2 or bd2 == b3 at the end -- no per-candidate test.
+  tie = (bd == bd2 && bd < kInf) || (bd2 == b3 && bd2 < kInf);
   if (tie) {
     // rare (lattices, duplicates): the same cells again with the full (d2, original index) order
     bd = kInf; bd2 = kInf; b3 = kInf; bpos = -1; bpos2 = -1;

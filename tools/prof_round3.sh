@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-3 evidence (one MI355X): kernel-trace stats of the default bench line, HBM traffic counters (separate FETCH_SIZE / WRITE_SIZE passes)
 # and SQ counters of the kernels of the three paths.  Summaries land in gpurun_out/r3prof/ ; the ones to judge are copied to profiles/.
-# usage: bash tools/prof_round2.sh [stage ...]   stages: trace icp reg normals sq   (default: all)
+# usage: bash tools/prof_round3.sh [stage ...]   stages: trace icp reg normals sq   (default: all)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r3prof

@@ -33,8 +33,9 @@ void set_last_error(const std::string& msg) { g_last_error = msg; }
 const char* last_error_cstr() { return g_last_error.c_str(); }
 
 static int g_device = 0;
-// E3D_NN_MODE / e3d_set_nn_mode: 0 auto, 1 per-query, 2 hash-table buckets, 3 dense rows, 4 dense rows + MFMA filter
-static int g_nn_mode = [] { const char* e = getenv("E3D_NN_MODE"); const int v = e ? atoi(e) : 0; return (v >= 0 && v <= 4) ? v : 0; }();
+// E3D_NN_MODE / e3d_set_nn_mode: 0 auto, 1 per-query, 2 hash-table buckets, 3 dense rows, 4 dense rows + MFMA filter,
+// 5 dense rows with the half-cell directory of the bounded search built whatever the density and used for every list (tests)
+static int g_nn_mode = [] { const char* e = getenv("E3D_NN_MODE"); const int v = e ? atoi(e) : 0; return (v >= 0 && v <= 5) ? v : 0; }();
 static std::atomic<unsigned long long> g_grid_generation{0};   // handles run on one host thread per GPU (--gpus N)
 
 // -------------------------------------------------------------------------------------------------
@@ -51,6 +52,8 @@ struct Cloud {
   DevBuf<HashEntry> table;
   DevBuf<unsigned> dense_start;     // dense cell-start directory over qrange (empty if the grid is too large)
   bool has_dense = false;
+  DevBuf<unsigned long long> half_prefix;   // half-cell directory (8 prefix bytes per cell) of the bounded search: dense clouds
+  bool has_half = false;
   GridDesc grid{};
   QueryRange qrange{};              // target-cell range a query needs to hit to have candidates
   unsigned n_cells = 0;             // occupied cells
@@ -189,6 +192,9 @@ static void ensure_bbox_scratch(e3d_icp* h) {
   h->h_bbox.reserve(6);
 }
 
+// E3D_NN_HALF: 0 = no half-cell directory (A/B timing), 1 = for dense clouds (default), 2 = always (tests)
+static int half_mode() { static const int v = [] { const char* e = getenv("E3D_NN_HALF"); return e ? atoi(e) : 1; }(); return v; }
+
 // Build the static local-frame grid of a cloud for search radius d (global frame).
 static void build_grid(e3d_icp* h, Cloud& c, float d) {
   hipStream_t s = h->stream;
@@ -243,7 +249,16 @@ static void build_grid(e3d_icp* h, Cloud& c, float d) {
   if (n > 0) {
     h->keys_a.reserve(n); h->keys_b.reserve(n); h->vals_a.reserve(n); h->vals_b.reserve(n);
     h->counter.reserve(1);
-    launch_cell_keys(c.raw_xyz.p, n, c.grid, h->keys_a.p, h->vals_a.p, s);
+    if (half_mode() != 0) {
+      // sub-cell order inside every cell: sort by the 3-bit half-cell code first, then (stable) by the cell key
+      unsigned* fk_a = reinterpret_cast<unsigned*>(h->keys_b.p);
+      unsigned* fk_b = fk_a + n;
+      launch_half_keys(c.raw_xyz.p, n, c.grid, fk_a, h->vals_b.p, s);
+      sort_pairs_u32_u32(fk_a, fk_b, h->vals_b.p, h->vals_a.p, n, 3, h->sort_temp, s);
+      launch_cell_keys_ordered(c.raw_xyz.p, h->vals_a.p, n, c.grid, h->keys_a.p, s);
+    } else {
+      launch_cell_keys(c.raw_xyz.p, n, c.grid, h->keys_a.p, h->vals_a.p, s);
+    }
     sort_pairs_u64_u32(h->keys_a.p, h->keys_b.p, h->vals_a.p, h->vals_b.p, n, 63, h->sort_temp, s);
     launch_permute(c.raw_xyz.p, c.raw_nrm.p, h->vals_b.p, n, c.L4.p, c.LN.p, s);
     E3D_HIP(hipMemsetAsync(h->counter.p, 0, sizeof(unsigned), s));
@@ -283,6 +298,17 @@ static void build_grid(e3d_icp* h, Cloud& c, float d) {
     exclusive_max_scan_u32(c.dense_start.p, ncell + 2, h->sort_temp, s);
     sync(h);
     c.has_dense = true;
+  }
+  // half-cell directory for the bounded search: clouds with several points per cell (the others gain nothing from it); 8 bytes
+  // per cell of the bounding grid, twice the cell directory
+  c.has_half = false;
+  if (c.has_dense && half_mode() != 0 && n > 0 && ((double)n >= 4.0 * (double)std::max(n_cells, 1u) || half_mode() == 2 || h->nn_mode == 5)) {
+    const size_t ncell = (size_t)prod;
+    c.half_prefix.reserve(ncell + 2);
+    E3D_HIP(hipMemsetAsync(c.half_prefix.p, 0, sizeof(unsigned long long) * (ncell + 2), s));
+    launch_half_prefix(h->keys_b.p, c.L4.p, n, c.grid, c.qrange, c.dense_start.p, c.half_prefix.p, s);
+    sync(h);
+    c.has_half = true;
   }
   c.grid_valid = true;
   c.grid_radius = d;
@@ -476,7 +502,7 @@ static void find_pair(e3d_icp* h, Cloud& src, Cloud& tgt, float d, PairJob& job,
   // outer iterations: a query whose partner of the last iteration is provably still its unique nearest neighbour is settled
   // by k_nn_certify (one gather), only the others are sorted and searched.
   const bool dense = h->nn_mode >= 2 || (h->nn_mode == 0 && (double)tgt.n >= 4.0 * (double)std::max(tgt.n_cells, 1u));
-  const bool rows = dense && tgt.has_dense && (h->nn_mode == 0 || h->nn_mode == 3);
+  const bool rows = dense && tgt.has_dense && (h->nn_mode == 0 || h->nn_mode == 3 || h->nn_mode == 5);
   static const bool use_cert = [] { const char* e = getenv("E3D_NN_CERT"); return !(e && e[0] == '0'); }();
   static const bool want_stats = [] { const char* e = getenv("E3D_NN_STATS"); return e && e[0] == '1'; }();
   const unsigned* order = nullptr;
@@ -529,12 +555,12 @@ static void find_pair(e3d_icp* h, Cloud& src, Cloud& tgt, float d, PairJob& job,
       bp.cum_lo = cert.cum_lo;
       bp.cell_scale = cert.cell_scale; bp.cell_sub = cert.cell_sub;
       bp.np_extra = (float)(np_frac * (double)d);
-      launch_nn_bounded(srcG, h->todo_near.p, n_near, tgt.G4.p, tgt.dense_start.p, tgt.grid, im, tgt.qrange, radius_sq(d), bp, ps.match.p,
+      launch_nn_bounded(srcG, h->todo_near.p, n_near, tgt.G4.p, tgt.dense_start.p, tgt.has_half ? tgt.half_prefix.p : nullptr, h->nn_mode == 5, tgt.grid, im, tgt.qrange, radius_sq(d), bp, ps.match.p,
                         ps.match2.p, h->match_d2.p, ps.lbe.p, s);
       if (n_far > 0 && n_far * 32 < n) {
         // few queries without a near partner: the same kernel (whole radius for those without any) instead of sort + row kernel,
         // whose cost is per visited cell row, not per query
-        launch_nn_bounded(srcG, h->todo_far.p, n_far, tgt.G4.p, tgt.dense_start.p, tgt.grid, im, tgt.qrange, radius_sq(d), bp, ps.match.p,
+        launch_nn_bounded(srcG, h->todo_far.p, n_far, tgt.G4.p, tgt.dense_start.p, tgt.has_half ? tgt.half_prefix.p : nullptr, h->nn_mode == 5, tgt.grid, im, tgt.qrange, radius_sq(d), bp, ps.match.p,
                           ps.match2.p, h->match_d2.p, ps.lbe.p, s);
         n_near += n_far; n_far = 0;
       }
@@ -1049,7 +1075,7 @@ int e3d_init(int device) {
 }
 
 int e3d_set_nn_mode(int mode) {
-  if (mode < 0 || mode > 4) { e3d::set_last_error("e3d_set_nn_mode: mode must be 0..4"); return E3D_ERR_INVALID; }
+  if (mode < 0 || mode > 5) { e3d::set_last_error("e3d_set_nn_mode: mode must be 0..5"); return E3D_ERR_INVALID; }
   g_nn_mode = mode;
   return 0;
 }

@@ -180,6 +180,77 @@ __global__ __launch_bounds__(kBlock) void k_build_table(const unsigned long long
   }
 }
 
+// ---- half cells: every grid cell is split into 2 x 2 x 2 sub-cells and its points are stored in sub-cell order (z, y, x).  A second
+// dense directory over the sub-cells (8 entries per grid cell, same construction as the cell directory) lets the bounded search
+// (k_nn_bounded_half) visit only the sub-cell rows its ball touches: a 2 - 3 mm ball in 10 mm cells of 62 points touches 2 - 3
+// cells but only ~7 half cells of 8 points.  The half-cell coordinate is floor((v - origin) * (2 inv_cell)); scaling by 2 is
+// exact in f32, so its upper bits ARE the cell coordinate (floor(2 t) >> 1 == floor(t)), and it is monotone in v like the cell
+// coordinate -- the completeness argument of the cells carries over with a cell of half the size.
+__device__ __forceinline__ unsigned half_code(float x, float y, float z, const GridDesc& g) {
+  const float inv_h = 2.f * g.inv_cell;
+  const unsigned fx = (unsigned)cell_coord(x, g.origin[0], inv_h) & 1u;
+  const unsigned fy = (unsigned)cell_coord(y, g.origin[1], inv_h) & 1u;
+  const unsigned fz = (unsigned)cell_coord(z, g.origin[2], inv_h) & 1u;
+  return (fz * 2u + fy) * 2u + fx;
+}
+// first sort pass of the build: 3-bit sub-cell code per point (the stable sort by cell key that follows keeps this order
+// inside every cell)
+__global__ __launch_bounds__(kBlock) void k_half_keys(const float* __restrict__ xyz, size_t n, GridDesc g, unsigned* __restrict__ keys,
+                                                      unsigned* __restrict__ vals) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  keys[i] = half_code(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], g);
+  vals[i] = (unsigned)i;
+}
+// cell keys of the points in a given order (second, stable sort pass)
+__global__ __launch_bounds__(kBlock) void k_cell_keys_ordered(const float* __restrict__ xyz, const unsigned* __restrict__ order, size_t n,
+                                                              GridDesc g, unsigned long long* __restrict__ keys) {
+  const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const size_t i = order[j];
+  keys[j] = cell_key(cell_coord(xyz[3 * i], g.origin[0], g.inv_cell), cell_coord(xyz[3 * i + 1], g.origin[1], g.inv_cell),
+                     cell_coord(xyz[3 * i + 2], g.origin[2], g.inv_cell));
+}
+// The half-cell directory: 8 bytes per grid cell, byte k = number of the cell's points with sub-cell code <= k (an inclusive
+// prefix: sub-cell k is the run [S[cell] + byte(k - 1), S[cell] + byte(k))).  Cells with more than 255 points hold 0xFF in every
+// byte and are scanned whole.  Two steps: the last point of every (cell, code) run writes its end offset; the first point of every
+// cell then turns the 8 bytes into a running maximum (empty sub-cells wrote nothing) and marks the overflow.
+__global__ __launch_bounds__(kBlock) void k_half_ends(const unsigned long long* __restrict__ keys, const float4* __restrict__ L4, size_t n,
+                                                      GridDesc g, QueryRange qr, const unsigned* __restrict__ S,
+                                                      unsigned char* __restrict__ H8) {
+  const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const unsigned long long k = keys[j];
+  const float4 p = L4[j];
+  const unsigned code = half_code(p.x, p.y, p.z, g);
+  if (j + 1 < n && keys[j + 1] == k) {
+    const float4 pn = L4[j + 1];
+    if (half_code(pn.x, pn.y, pn.z, g) == code) return;       // only the last point of a run writes
+  }
+  const int cx = (int)(k & 0x1FFFFFull), cy = (int)((k >> 21) & 0x1FFFFFull), cz = (int)((k >> 42) & 0x1FFFFFull);
+  const size_t lin = ((size_t)(unsigned)(cz - qr.lo[2]) * qr.D[1] + (unsigned)(cy - qr.lo[1])) * qr.D[0] + (unsigned)(cx - qr.lo[0]);
+  const unsigned end_rel = (unsigned)(j + 1) - S[lin];
+  H8[8 * lin + code] = (unsigned char)min(end_rel, 255u);
+}
+__global__ __launch_bounds__(kBlock) void k_half_fix(const unsigned long long* __restrict__ keys, size_t n, QueryRange qr,
+                                                     const unsigned* __restrict__ S, unsigned long long* __restrict__ H8) {
+  const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const unsigned long long k = keys[j];
+  if (j > 0 && keys[j - 1] == k) return;                      // the first point of every cell
+  const int cx = (int)(k & 0x1FFFFFull), cy = (int)((k >> 21) & 0x1FFFFFull), cz = (int)((k >> 42) & 0x1FFFFFull);
+  const size_t lin = ((size_t)(unsigned)(cz - qr.lo[2]) * qr.D[1] + (unsigned)(cy - qr.lo[1])) * qr.D[0] + (unsigned)(cx - qr.lo[0]);
+  if (S[lin + 1] - S[lin] > 255u) { H8[lin] = ~0ull; return; }
+  unsigned long long w = H8[lin], out = 0ull;
+  unsigned run = 0;
+#pragma unroll
+  for (int b = 0; b < 8; ++b) {
+    run = max(run, (unsigned)((w >> (8 * b)) & 0xFFull));
+    out |= (unsigned long long)run << (8 * b);
+  }
+  H8[lin] = out;
+}
+
 // dense cell-start directory: ends[lin(cell)] = end index of the cell's run in the sorted arrays (written by the
 // last point of each run, 0 elsewhere); an exclusive MAX scan turns it into starts, with
 // starts[lin + 1] = max(starts[lin], ends[lin]) = end of the cell's run (or its start if the cell is empty).
@@ -1275,6 +1346,208 @@ __global__ __launch_bounds__(kBlock) void k_nn_bounded(const float4* __restrict_
   lbe[j] = sqrtf(fminf(others2, cover_all2)) * 0.999999f + bp.cum_lo;
 }
 
+// -------------------------------------------------------------------------------------------------
+// The bounded search over HALF cells (targets with a half-cell directory: dense scans).  Same contract as k_nn_bounded, one lane
+// per query.  The box [l - rho, l + rho] is taken in half-cell coordinates; the half cells [fxa, fxb] of sub-row (fy, fz) of one
+// grid cell are ONE run, found from the cell's start and its 8 prefix bytes (one 4-byte and one 8-byte load per grid cell for
+// all of its sub-rows), then the candidates -- no chain of dependent lookups.  ~55 candidates instead of ~180.
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_nn_bounded_half(const float4* __restrict__ Gsrc, const unsigned* __restrict__ list,
+                                                            unsigned n_list, const float4* __restrict__ Gtgt, const unsigned* __restrict__ S,
+                                                            const unsigned long long* __restrict__ H8,
+                                                            GridDesc g, InvMap im, QueryRange qr, float r2, BoundParams bp,
+                                                            int* __restrict__ match, int* __restrict__ match2,
+                                                            float* __restrict__ match_d2, float* __restrict__ lbe) {
+  __shared__ unsigned s_runs[2][18][kBlock];          // per lane: the non-empty candidate runs of its box
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_list) return;
+  const unsigned j = list[i];
+  const float4 q = Gsrc[j];
+  const int m = match[j];
+  float d1 = r2;                                     // no old partner
+  if (m >= 0) {
+    const float4 pc = Gtgt[m];
+    d1 = sqdist_l2(q.x, q.y, q.z, pc.x, pc.y, pc.z);
+    const int m2 = match2[j];
+    if (m2 >= 0) { const float4 pc2 = Gtgt[m2]; d1 = fminf(d1, sqdist_l2(q.x, q.y, q.z, pc2.x, pc2.y, pc2.z)); }
+  }
+  const float dr = sqrtf(fminf(d1, r2)) + ((m < 0) ? bp.np_extra : bp.margin);
+  const float cover2 = (d1 < r2) ? fminf(dr * dr * 1.000001f, r2) : ((m < 0) ? dr * dr * 1.000001f : r2);      // as k_nn_bounded
+  const float rho = sqrtf(cover2) * bp.rho_scale + bp.rho_pad;
+  const float dx = q.x - im.t[0], dy = q.y - im.t[1], dz = q.z - im.t[2];
+  const float lx = im.Linv[0] * dx + im.Linv[1] * dy + im.Linv[2] * dz;
+  const float ly = im.Linv[3] * dx + im.Linv[4] * dy + im.Linv[5] * dz;
+  const float lz = im.Linv[6] * dx + im.Linv[7] * dy + im.Linv[8] * dz;
+  const float inv_h = 2.f * g.inv_cell;
+  const int NX = 2 * (int)qr.D[0], NY = 2 * (int)qr.D[1], NZ = 2 * (int)qr.D[2];
+  const int FX0 = max(cell_coord(lx - rho, g.origin[0], inv_h) - 2 * qr.lo[0], 0), FX1 = min(cell_coord(lx + rho, g.origin[0], inv_h) - 2 * qr.lo[0], NX - 1);
+  const int FY0 = max(cell_coord(ly - rho, g.origin[1], inv_h) - 2 * qr.lo[1], 0), FY1 = min(cell_coord(ly + rho, g.origin[1], inv_h) - 2 * qr.lo[1], NY - 1);
+  const int FZ0 = max(cell_coord(lz - rho, g.origin[2], inv_h) - 2 * qr.lo[2], 0), FZ1 = min(cell_coord(lz + rho, g.origin[2], inv_h) - 2 * qr.lo[2], NZ - 1);
+  const float kInf = __uint_as_float(0x7f800000u);
+  // what the scanned box covers: every target point outside it is at least `fd` HALF cells away in the target's local frame
+  // (faces at the edge of the dense grid do not count), i.e. at global distance >= fd * cell_scale / 2 - cell_sub
+  float cover_box2 = 0.f;
+  const bool any = FX0 <= FX1 && FY0 <= FY1 && FZ0 <= FZ1;
+  if (any) {
+    const float ux = (lx - g.origin[0]) * inv_h - (float)(2 * qr.lo[0]), uy = (ly - g.origin[1]) * inv_h - (float)(2 * qr.lo[1]),
+                uz = (lz - g.origin[2]) * inv_h - (float)(2 * qr.lo[2]);
+    float fd = kInf;
+    if (FX0 > 0) fd = fminf(fd, ux - (float)FX0);
+    if (FX1 < NX - 1) fd = fminf(fd, (float)(FX1 + 1) - ux);
+    if (FY0 > 0) fd = fminf(fd, uy - (float)FY0);
+    if (FY1 < NY - 1) fd = fminf(fd, (float)(FY1 + 1) - uy);
+    if (FZ0 > 0) fd = fminf(fd, uz - (float)FZ0);
+    if (FZ1 < NZ - 1) fd = fminf(fd, (float)(FZ1 + 1) - uz);
+    fd = fminf(fd, 8.0f);                                   // (a box that spans the whole grid: keep the bound finite)
+    const float cb = fd * (bp.cell_scale * 0.5f) - bp.cell_sub;
+    cover_box2 = cb > 0.f ? cb * cb : 0.f;
+  }
+  const float cover_all2 = fmaxf(cover2, cover_box2);
+  float bd = kInf, bd2 = kInf, b3 = kInf;
+  int bpos = -1, bpos2 = -1;
+  // The search is latency bound, not arithmetic bound, once the candidates are few: (1) ALL directory words of the box are
+  // requested before any is used -- the usual box is at most 3 x 3 half-cell rows by 2 grid cells in x, unrolled with clamped
+  // addresses (larger boxes, rare, loop) -- and the non-empty runs go to a per-lane list in LDS; (2) the candidates of all runs
+  // are then walked as ONE sequence, four gathers in flight.
+  const int cx0 = FX0 >> 1, cx1 = FX1 >> 1;
+  int nr = 0;
+#define RUN_S(i) s_runs[0][(i)][threadIdx.x]
+#define RUN_E(i) s_runs[1][(i)][threadIdx.x]
+  if (any) {
+    const int nz = FZ1 - FZ0 + 1, ny = FY1 - FY0 + 1, nx = cx1 - cx0 + 1;
+    if (nz <= 3 && ny <= 3 && nx <= 2) {
+      // the (at most 2 x 2 x 2) grid cells of the box: cell start and the 8 prefix bytes, all requested at once
+      const int gz0 = FZ0 >> 1, gy0 = FY0 >> 1;
+      unsigned cs[8];
+      unsigned long long ce[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const int gz = min(gz0 + (t >> 2), FZ1 >> 1), gy = min(gy0 + ((t >> 1) & 1), FY1 >> 1), cx = min(cx0 + (t & 1), cx1);
+        const size_t lin = ((size_t)gz * qr.D[1] + (size_t)gy) * qr.D[0] + (size_t)cx;
+        cs[t] = S[lin];
+        ce[t] = H8[lin];
+      }
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b2 = 0; b2 < 3; ++b2)
+#pragma unroll
+          for (int c2 = 0; c2 < 2; ++c2) {
+            if (a < nz && b2 < ny && c2 < nx) {
+              const int FZ = FZ0 + a, FY = FY0 + b2, cx = cx0 + c2;
+              const int t = (((FZ >> 1) - gz0) << 2) | (((FY >> 1) - gy0) << 1) | c2;
+              unsigned st = cs[0]; unsigned long long e8 = ce[0];
+#pragma unroll
+              for (int u = 1; u < 8; ++u) if (t == u) { st = cs[u]; e8 = ce[u]; }
+              const int sub = ((FZ & 1) * 2 + (FY & 1)) * 2;
+              const int fxa = max(FX0 - 2 * cx, 0), fxb = min(FX1 - 2 * cx, 1);
+              unsigned r0, r1;
+              if (e8 == ~0ull) {
+                // a cell of more than 255 points has no sub-cell prefixes: its whole run, once (from its first sub-row in the box)
+                const size_t lin = ((size_t)(FZ >> 1) * qr.D[1] + (size_t)(FY >> 1)) * qr.D[0] + (size_t)cx;
+                const bool first = (a == 0 || ((FZ - 1) >> 1) != (FZ >> 1)) && (b2 == 0 || ((FY - 1) >> 1) != (FY >> 1));
+                r0 = st; r1 = first ? S[lin + 1] : st;
+              } else {
+                const int k0 = sub + fxa, k1 = sub + fxb;
+                r0 = st + (k0 ? (unsigned)((e8 >> (8 * (k0 - 1))) & 0xFFull) : 0u);
+                r1 = st + (unsigned)((e8 >> (8 * k1)) & 0xFFull);
+              }
+              if (r0 < r1) { RUN_S(nr) = r0; RUN_E(nr) = r1; ++nr; }
+            }
+          }
+    } else {
+      nr = -1;                                             // a large box: the plain loops below
+    }
+  }
+  if (nr > 0) {
+    int r = 0;
+    unsigned cur = RUN_S(0), end = RUN_E(0);
+    while (r < nr) {
+      unsigned p[4];
+      int cnt = 0;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        p[t] = cur;                                        // (beyond the last candidate: a valid address, result ignored)
+        if (r < nr) {
+          cnt = t + 1;
+          ++cur;
+          if (cur == end) { ++r; if (r < nr) { cur = RUN_S(r); end = RUN_E(r); } else { cur = p[t]; } }
+        }
+      }
+      float4 c4[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) c4[t] = Gtgt[p[t]];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if (t < cnt) {
+          const float d2 = sqdist_l2(q.x, q.y, q.z, c4[t].x, c4[t].y, c4[t].z);
+          const bool lt1 = d2 < bd, lt2 = d2 < bd2;
+          b3 = fminf(b3, fmaxf(d2, bd2));                 // the displaced runner-up, or this candidate
+          bd2 = fminf(fmaxf(d2, bd), bd2);
+          bpos2 = lt1 ? bpos : (lt2 ? (int)p[t] : bpos2);
+          bd = fminf(d2, bd);
+          bpos = lt1 ? (int)p[t] : bpos;
+        }
+      }
+    }
+  } else if (nr < 0) {
+    // a large box (a query without a partner looks np_extra beyond the radius; a partner that moved far): whole grid cells, row by
+    // row -- the cells [x0, x1] of one (y, z) row are ONE run of the cell directory, and an empty row costs two words.  A superset
+    // of the half cells of the box: nothing is missed, and the covered region only grows.
+    for (int gz = FZ0 >> 1; gz <= (FZ1 >> 1); ++gz)
+      for (int gy = FY0 >> 1; gy <= (FY1 >> 1); ++gy) {
+        const size_t row = ((size_t)gz * qr.D[1] + (size_t)gy) * qr.D[0];
+        const unsigned s0 = S[row + (size_t)cx0], s1 = S[row + (size_t)cx1 + 1];
+        for (unsigned p = s0; p < s1; ++p) {
+          const float4 c = Gtgt[p];
+          const float d2 = sqdist_l2(q.x, q.y, q.z, c.x, c.y, c.z);
+          const bool lt1 = d2 < bd, lt2 = d2 < bd2;
+          b3 = fminf(b3, fmaxf(d2, bd2));
+          bd2 = fminf(fmaxf(d2, bd), bd2);
+          bpos2 = lt1 ? bpos : (lt2 ? (int)p : bpos2);
+          bd = fminf(d2, bd);
+          bpos = lt1 ? (int)p : bpos;
+        }
+      }
+  }
+  // exact f32 equalities among the three smallest: the same candidates again with the full (d2, original index) order (rare)
+  if (any && ((bd == bd2 && bd < kInf) || (bd2 == b3 && bd2 < kInf))) {
+    bd = kInf; bd2 = kInf; b3 = kInf; bpos = -1; bpos2 = -1;
+    unsigned boi = 0u, boi2 = 0u;
+    auto exact_run = [&](unsigned s0, unsigned s1) {
+      for (unsigned p = s0; p < s1; ++p) {
+        const float4 c = Gtgt[p];
+        const float d2 = sqdist_l2(q.x, q.y, q.z, c.x, c.y, c.z);
+        const unsigned oi = __float_as_uint(c.w);
+        if (d2 < bd || (d2 == bd && oi < boi)) {
+          b3 = fminf(b3, bd2); bd2 = bd; boi2 = boi; bpos2 = bpos; bd = d2; boi = oi; bpos = (int)p;
+        } else if (d2 < bd2 || (d2 == bd2 && oi < boi2)) {
+          b3 = fminf(b3, bd2); bd2 = d2; boi2 = oi; bpos2 = (int)p;
+        } else {
+          b3 = fminf(b3, d2);
+        }
+      }
+    };
+    if (nr >= 0) {
+      for (int r = 0; r < nr; ++r) exact_run(RUN_S(r), RUN_E(r));
+    } else {
+      for (int gz = FZ0 >> 1; gz <= (FZ1 >> 1); ++gz)
+        for (int gy = FY0 >> 1; gy <= (FY1 >> 1); ++gy) {
+          const size_t row = ((size_t)gz * qr.D[1] + (size_t)gy) * qr.D[0];
+          exact_run(S[row + (size_t)cx0], S[row + (size_t)cx1 + 1]);
+        }
+    }
+  }
+#undef RUN_S
+#undef RUN_E
+  const bool has1 = bd < r2, has2 = bd2 < r2;            // NaN distances compare false: no partner
+  match[j] = has1 ? bpos : -1;
+  match2[j] = has2 ? bpos2 : -1;
+  match_d2[j] = has1 ? bd : r2;
+  const float others2 = has2 ? b3 : (has1 ? bd2 : bd);
+  lbe[j] = sqrtf(fminf(others2, cover_all2)) * 0.999999f + bp.cum_lo;
+}
+
 // flags -> per-block counts (first stage of the order-preserving compaction)
 __global__ __launch_bounds__(kBlock) void k_match_block_counts(const int* __restrict__ match_pos, size_t n,
                                                                unsigned* __restrict__ block_counts,
@@ -2035,16 +2308,39 @@ void launch_nn_certify(const float4* Gsrc, size_t n, const float4* Gtgt, float c
 }
 
 void launch_nn_bounded(const float4* Gsrc, const unsigned* list, size_t n_list, const float4* Gtgt, const unsigned* dense_start,
-                       const GridDesc& g, const InvMap& im, const QueryRange& qr, float r2, const BoundParams& bp, int* match,
-                       int* match2, float* match_d2, float* lbe, hipStream_t s) {
+                       const unsigned long long* half_prefix, bool half_always, const GridDesc& g, const InvMap& im, const QueryRange& qr, float r2,
+                       const BoundParams& bp, int* match, int* match2, float* match_d2, float* lbe, hipStream_t s) {
   if (!n_list) return;
   static const size_t quad_limit = [] { const char* e = getenv("E3D_NN_QUAD_LIMIT"); return e ? (size_t)atoll(e) : (size_t)12000000; }();
+  static const size_t half_min = [] { const char* e = getenv("E3D_NN_HALF_MIN"); return e ? (size_t)atoll(e) : (size_t)200000; }();
+  if (half_prefix && (half_always || n_list >= half_min)) {
+    // long lists are bound by the candidates they evaluate: the half-cell directory cuts those to a third
+    hipLaunchKernelGGL(k_nn_bounded_half, dim3((unsigned)div_up(n_list, kBlock)), dim3(kBlock), 0, s, Gsrc, list, (unsigned)n_list, Gtgt,
+                       dense_start, half_prefix, g, im, qr, r2, bp, match, match2, match_d2, lbe);
+    return;
+  }
   if (n_list <= quad_limit)
     hipLaunchKernelGGL(k_nn_bounded<4>, dim3((unsigned)div_up(4 * n_list, kBlock)), dim3(kBlock), 0, s, Gsrc, list, (unsigned)n_list, Gtgt,
                        dense_start, g, im, qr, r2, bp, match, match2, match_d2, lbe);
   else
     hipLaunchKernelGGL(k_nn_bounded<1>, dim3((unsigned)div_up(n_list, kBlock)), dim3(kBlock), 0, s, Gsrc, list, (unsigned)n_list, Gtgt,
                        dense_start, g, im, qr, r2, bp, match, match2, match_d2, lbe);
+}
+
+void launch_half_keys(const float* xyz, size_t n, const GridDesc& g, unsigned* keys, unsigned* vals, hipStream_t s) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_half_keys, dim3((unsigned)div_up(n, kBlock)), dim3(kBlock), 0, s, xyz, n, g, keys, vals);
+}
+void launch_cell_keys_ordered(const float* xyz, const unsigned* order, size_t n, const GridDesc& g, unsigned long long* keys, hipStream_t s) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_cell_keys_ordered, dim3((unsigned)div_up(n, kBlock)), dim3(kBlock), 0, s, xyz, order, n, g, keys);
+}
+void launch_half_prefix(const unsigned long long* keys, const float4* L4, size_t n, const GridDesc& g, const QueryRange& qr,
+                        const unsigned* dense_start, unsigned long long* half_prefix, hipStream_t s) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_half_ends, dim3((unsigned)div_up(n, kBlock)), dim3(kBlock), 0, s, keys, L4, n, g, qr, dense_start,
+                     reinterpret_cast<unsigned char*>(half_prefix));
+  hipLaunchKernelGGL(k_half_fix, dim3((unsigned)div_up(n, kBlock)), dim3(kBlock), 0, s, keys, n, qr, dense_start, half_prefix);
 }
 
 // Filter constants of k_nn_mfma for a target grid (cell = local cell size, sigma_max = largest singular value of the

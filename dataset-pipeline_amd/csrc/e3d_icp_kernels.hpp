@@ -88,9 +88,14 @@ struct BoundParams {
   float cell_scale, cell_sub;   // as in CertParams: covered global distance = (distance to the scanned box's faces in cells) * cell_scale - cell_sub
   float np_extra;        // a query without a partner searches radius + np_extra (its certificate: nothing nearer than that)
 };
+// half_prefix: the half-cell directory (8 prefix bytes per grid cell; k_nn_bounded_half, used for long lists or always) or nullptr
 void launch_nn_bounded(const float4* Gsrc, const unsigned* list, size_t n_list, const float4* Gtgt, const unsigned* dense_start,
-                       const GridDesc& g, const InvMap& im, const QueryRange& qr, float r2, const BoundParams& bp, int* match,
-                       int* match2, float* match_d2, float* lbe, hipStream_t s);
+                       const unsigned long long* half_prefix, bool half_always, const GridDesc& g, const InvMap& im, const QueryRange& qr, float r2,
+                       const BoundParams& bp, int* match, int* match2, float* match_d2, float* lbe, hipStream_t s);
+void launch_half_keys(const float* xyz, size_t n, const GridDesc& g, unsigned* keys, unsigned* vals, hipStream_t s);
+void launch_cell_keys_ordered(const float* xyz, const unsigned* order, size_t n, const GridDesc& g, unsigned long long* keys, hipStream_t s);
+void launch_half_prefix(const unsigned long long* keys, const float4* L4, size_t n, const GridDesc& g, const QueryRange& qr,
+                        const unsigned* dense_start, unsigned long long* half_prefix, hipStream_t s);
 struct MfParams { float S, r2s, eta2, delta4, delta4sq; };      // filter constants of k_nn_mfma (see mfma_filter_params)
 bool mfma_filter_params(double cell, double sigma_max, int row_span, float r2, MfParams* P);
 void launch_nn_mfma(const float4* Gsrc, const unsigned* order, size_t n, const float4* Gtgt, const unsigned* dense_start,

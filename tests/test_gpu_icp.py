@@ -40,7 +40,8 @@ def test_transform_bit_exact(e3d, ob, n):
 
 
 # ---- a5: FindCorrespondencesFast --------------------------------------------------------------------------------
-@pytest.fixture(params=[1, 2, 3, 4, 0], ids=["per-query-kernel", "hash-bucket-kernel", "dense-row-kernel+certificates", "mfma-filter-kernel", "auto"])
+@pytest.fixture(params=[1, 2, 3, 4, 5, 0], ids=["per-query-kernel", "hash-bucket-kernel", "dense-row-kernel+certificates", "mfma-filter-kernel",
+                                          "dense-row-kernel+certificates+half-cells", "auto"])
 def nn_mode(request, e3d):
     """All exact NN kernels must agree with the oracle bit for bit."""
     assert e3d.lib().e3d_set_nn_mode(request.param) == 0
@@ -212,13 +213,14 @@ def test_icp_partial_overlap(e3d, ob, synth, nn_mode):
     counts = [r[3] for r in g.pair_records()]
     assert 0.3 * 120_000 < counts[-1] < 0.65 * 120_000, counts          # the scene is what it claims to be
     rec = g.iter_records()
-    if nn_mode == 3:   # (auto picks the per-query kernel at this density) the certificates were consulted in every later iteration
+    if nn_mode in (3, 5):   # (auto picks the per-query kernel at this density) the certificates were consulted in every later iteration
         assert all(r["nn_certify_queries"] == 240_000 for r in rec[1:]), rec
 
 
 def test_icp_partial_overlap_three_scans(e3d, ob, synth):
-    """Three partially overlapping scans, six directed pairs, the row kernel with certificates on small clouds."""
-    assert e3d.lib().e3d_set_nn_mode(3) == 0
+    """Three partially overlapping scans, six directed pairs, the row kernel with certificates and the half-cell directory of the
+    bounded search forced on small clouds."""
+    assert e3d.lib().e3d_set_nn_mode(5) == 0
     try:
         scans = synth.make_scene(3, 60_000, seed=5, partial=True)
         clouds = [(s["xyz"].numpy(), s["normals"].numpy(), s["T_init"], False) for s in scans]

@@ -1352,13 +1352,15 @@ __global__ __launch_bounds__(kBlock) void k_nn_bounded(const float4* __restrict_
 // grid cell are ONE run, found from the cell's start and its 8 prefix bytes (one 4-byte and one 8-byte load per grid cell for
 // all of its sub-rows), then the candidates -- no chain of dependent lookups.  ~55 candidates instead of ~180.
 // -------------------------------------------------------------------------------------------------
+constexpr int kHalfRuns = 18;     // run-list slots per lane in LDS (more non-empty runs than that: the whole-cell rows)
+constexpr int kHalfBatch = 4;     // candidate gathers in flight per lane
 __global__ __launch_bounds__(kBlock) void k_nn_bounded_half(const float4* __restrict__ Gsrc, const unsigned* __restrict__ list,
                                                             unsigned n_list, const float4* __restrict__ Gtgt, const unsigned* __restrict__ S,
                                                             const unsigned long long* __restrict__ H8,
                                                             GridDesc g, InvMap im, QueryRange qr, float r2, BoundParams bp,
                                                             int* __restrict__ match, int* __restrict__ match2,
                                                             float* __restrict__ match_d2, float* __restrict__ lbe) {
-  __shared__ unsigned s_runs[2][18][kBlock];          // per lane: the non-empty candidate runs of its box
+  __shared__ unsigned s_runs[2][kHalfRuns][kBlock];   // per lane: the non-empty candidate runs of its box
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_list) return;
   const unsigned j = list[i];
@@ -1408,7 +1410,7 @@ __global__ __launch_bounds__(kBlock) void k_nn_bounded_half(const float4* __rest
   // The search is latency bound, not arithmetic bound, once the candidates are few: (1) ALL directory words of the box are
   // requested before any is used -- the usual box is at most 3 x 3 half-cell rows by 2 grid cells in x, unrolled with clamped
   // addresses (larger boxes, rare, loop) -- and the non-empty runs go to a per-lane list in LDS; (2) the candidates of all runs
-  // are then walked as ONE sequence, four gathers in flight.
+  // are then walked as ONE sequence, kHalfBatch gathers in flight.
   const int cx0 = FX0 >> 1, cx1 = FX1 >> 1;
   int nr = 0;
 #define RUN_S(i) s_runs[0][(i)][threadIdx.x]
@@ -1452,7 +1454,7 @@ __global__ __launch_bounds__(kBlock) void k_nn_bounded_half(const float4* __rest
                 r0 = st + (k0 ? (unsigned)((e8 >> (8 * (k0 - 1))) & 0xFFull) : 0u);
                 r1 = st + (unsigned)((e8 >> (8 * k1)) & 0xFFull);
               }
-              if (r0 < r1) { RUN_S(nr) = r0; RUN_E(nr) = r1; ++nr; }
+              if (r0 < r1) { if (nr >= 0 && nr < kHalfRuns) { RUN_S(nr) = r0; RUN_E(nr) = r1; ++nr; } else nr = -1; }
             }
           }
     } else {
@@ -1463,10 +1465,10 @@ __global__ __launch_bounds__(kBlock) void k_nn_bounded_half(const float4* __rest
     int r = 0;
     unsigned cur = RUN_S(0), end = RUN_E(0);
     while (r < nr) {
-      unsigned p[4];
+      unsigned p[kHalfBatch];
       int cnt = 0;
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
+      for (int t = 0; t < kHalfBatch; ++t) {
         p[t] = cur;                                        // (beyond the last candidate: a valid address, result ignored)
         if (r < nr) {
           cnt = t + 1;
@@ -1474,11 +1476,11 @@ __global__ __launch_bounds__(kBlock) void k_nn_bounded_half(const float4* __rest
           if (cur == end) { ++r; if (r < nr) { cur = RUN_S(r); end = RUN_E(r); } else { cur = p[t]; } }
         }
       }
-      float4 c4[4];
+      float4 c4[kHalfBatch];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) c4[t] = Gtgt[p[t]];
+      for (int t = 0; t < kHalfBatch; ++t) c4[t] = Gtgt[p[t]];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
+      for (int t = 0; t < kHalfBatch; ++t) {
         if (t < cnt) {
           const float d2 = sqdist_l2(q.x, q.y, q.z, c4[t].x, c4[t].y, c4[t].z);
           const bool lt1 = d2 < bd, lt2 = d2 < bd2;

@@ -66,6 +66,10 @@ struct Cloud {
   float lmin[3], lmax[3];           // local bbox
   float bmin[3], bmax[3];           // global bbox of the current outer iteration
   int cloud_index = -1;             // impl index in the current AlignMeshes
+  // G4 / bmin / bmax are those of pose G4_T (while G4_valid): a cloud whose pose did not change since the last outer iteration --
+  // impl cloud 0 never moves, fixed clouds never do -- is not transformed again
+  bool G4_valid = false;
+  float G4_T[12];
 };
 
 // per-query state of a directed pair, kept from one outer iteration to the next (source order): partner position, certificate
@@ -243,6 +247,7 @@ static void build_grid(e3d_icp* h, Cloud& c, float d) {
   for (int k = 0; k < 3; ++k) c.grid.origin[k] = (float)((double)c.lmin[k] - 2.0 * cell);
 
   c.L4.reserve(n); c.LN.reserve(n); c.G4.reserve(n);
+  c.G4_valid = false;                                      // the sorted order changes
   c.generation = g_grid_generation.fetch_add(1, std::memory_order_relaxed) + 1;
   c.cum_motion = 0.0; c.last_motion = 0.0; c.err_max = 0.0;
   unsigned n_cells = 0;
@@ -338,10 +343,13 @@ static void transform_cloud(e3d_icp* h, Cloud& c) {
     for (int k = 0; k < 3; ++k) { c.bmin[k] = FLT_MAX; c.bmax[k] = -FLT_MAX; }
     return;
   }
+  if (c.G4_valid && std::memcmp(c.G4_T, c.T, sizeof c.G4_T) == 0) return;     // same bits in, same bits out
   launch_transform_bbox(c.L4.p, c.n, to_affine(c.T), c.G4.p, h->bbox_partial.p, h->bbox_out.p, h->stream);
   copy_out(h->h_bbox.p, h->bbox_out.p, sizeof(float) * 6, h->stream);
   sync(h);
   for (int k = 0; k < 3; ++k) { c.bmin[k] = h->h_bbox.p[k]; c.bmax[k] = h->h_bbox.p[3 + k]; }
+  std::memcpy(c.G4_T, c.T, sizeof c.G4_T);
+  c.G4_valid = true;
 }
 
 static bool bbox_intersects(const Cloud& a, const Cloud& b) {

@@ -1140,23 +1140,45 @@ __global__ __launch_bounds__(kBlock) void k_nn_certify(const float4* __restrict_
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const size_t j0 = ((size_t)blockIdx.x * (kBlock / kWave) + (size_t)w) * kCertPerWave;
   unsigned cn = 0, cf = 0;                                     // wave-uniform
-  for (int step = 0; step < kCertPerWave / kWave; ++step) {
-    const size_t j = j0 + (size_t)step * kWave + (size_t)lane;
-    const bool valid = j < n;
+  // kCertUnroll steps at a time: the state words, the queries and the partner gathers of all of them are requested before any
+  // is evaluated (the kernel is a chain match[j] -> Gtgt[m] per query; two chains in flight per lane)
+  constexpr int kCertUnroll = 2;
+  for (int step0 = 0; step0 < kCertPerWave / kWave; step0 += kCertUnroll) {
+    size_t jj[kCertUnroll];
+    bool vv[kCertUnroll];
+    int mm[kCertUnroll], mm2[kCertUnroll];
+    float ll[kCertUnroll];
+    float4 qq[kCertUnroll], c1[kCertUnroll], c2v[kCertUnroll];
+#pragma unroll
+    for (int u = 0; u < kCertUnroll; ++u) {
+      jj[u] = j0 + (size_t)(step0 + u) * kWave + (size_t)lane;
+      vv[u] = jj[u] < n;
+      const size_t js = vv[u] ? jj[u] : 0;
+      mm[u] = match[js]; mm2[u] = match2[js]; ll[u] = lbe[js]; qq[u] = Gsrc[js];
+    }
+#pragma unroll
+    for (int u = 0; u < kCertUnroll; ++u) {
+      c1[u] = Gtgt[mm[u] >= 0 ? mm[u] : 0];
+      c2v[u] = Gtgt[(mm[u] >= 0 && mm2[u] >= 0) ? mm2[u] : 0];
+    }
+#pragma unroll
+    for (int u = 0; u < kCertUnroll; ++u) {
+    const size_t j = jj[u];
+    const bool valid = vv[u];
     bool ok = false, near = false;
     if (valid) {
-      const float thr = (lbe[j] - cum_up) * 0.999999f;
+      const float thr = (ll[u] - cum_up) * 0.999999f;
       const float lim = thr * thr * 0.999999f;
-      const int m = match[j];
+      const int m = mm[u];
       if (m >= 0) {
-        const int m2 = match2[j];
-        const float4 q = Gsrc[j];
-        const float4 c = Gtgt[m];
+        const int m2 = mm2[u];
+        const float4 q = qq[u];
+        const float4 c = c1[u];
         float v = sqdist_l2(q.x, q.y, q.z, c.x, c.y, c.z);
         if (m2 >= 0) {
           // two remembered candidates: the nearer one (exact (d2, original index) order) is the partner if both beat the bound
           // of everything else; the other one stays remembered
-          const float4 c2 = Gtgt[m2];
+          const float4 c2 = c2v[u];
           const float v2 = sqdist_l2(q.x, q.y, q.z, c2.x, c2.y, c2.z);
           if (v2 < v || (v2 == v && __float_as_uint(c2.w) < __float_as_uint(c.w))) {
             v = v2;
@@ -1172,13 +1194,14 @@ __global__ __launch_bounds__(kBlock) void k_nn_certify(const float4* __restrict_
         if (ok) match_d2[j] = r2;
       }
     }
-  const unsigned long long fn = __ballot(valid && !ok && near), ff = __ballot(valid && !ok && !near);
+    const unsigned long long fn = __ballot(valid && !ok && near), ff = __ballot(valid && !ok && !near);
     const unsigned long long below = (1ull << lane) - 1ull;
     if (valid && !ok) {
       if (near) s_list[0][w][cn + (unsigned)__popcll(fn & below)] = (unsigned)j;
       else s_list[1][w][cf + (unsigned)__popcll(ff & below)] = (unsigned)j;
     }
     cn += (unsigned)__popcll(fn); cf += (unsigned)__popcll(ff);
+    }
   }
   if (lane == 0) { s_cnt[0][w] = cn; s_cnt[1][w] = cf; }
   __syncthreads();

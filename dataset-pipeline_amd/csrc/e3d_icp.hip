@@ -154,7 +154,7 @@ struct e3d_icp {
     void stop(hipStream_t s) { t->stop(s); pending = true; }
     void flush() { if (pending) { acc += t->ms(); pending = false; } }
     double take() { flush(); const double v = acc; acc = 0.0; return v; }
-  } tm_sort, tm_scan, tm_compact;
+  } tm_sort, tm_scan, tm_compact, tm_bounded;
 
   std::map<std::pair<int, int>, std::unique_ptr<PairState>> pair_state;
   PinBuf<unsigned> h_todo;
@@ -524,7 +524,6 @@ static void find_pair(e3d_icp* h, Cloud& src, Cloud& tgt, float d, PairJob& job,
     const CertParams cert = make_cert_params(tgt, cum_pair);
     size_t n_far = n, n_near = 0;
     const unsigned* list = nullptr;
-    float t_cert = 0.f;
     if (!ps.fresh && use_cert) {
       NnPhase ph(s, 0);
       static const double margin_frac = env_double("E3D_NN_MARGIN", 0.08), near_frac = env_double("E3D_NN_NEAR", 0.4);   // of the radius
@@ -549,7 +548,7 @@ static void find_pair(e3d_icp* h, Cloud& src, Cloud& tgt, float d, PairJob& job,
       { const double t = h->nn_timer_c->ms(); rec.t_nn_certify_ms += t; rec.t_nn_query_ms += t; }
       rec.nn_certify_launches++; rec.nn_certify_queries += (long long)n;
       n_near = h->h_todo.p[0]; n_far = h->h_todo.p[1];
-      h->nn_timer->start(s);
+      h->tm_bounded.start(s);                             // (read lazily: timing the bounded search costs no synchronisation)
       list = h->todo_far.p;
       // old partner close by: only the cells its distance (+ margin) reaches, one thread per query, no sort
       double smin = min_singular_value_3x3(tgt.T);
@@ -572,22 +571,18 @@ static void find_pair(e3d_icp* h, Cloud& src, Cloud& tgt, float d, PairJob& job,
                           ps.match2.p, h->match_d2.p, ps.lbe.p, s);
         n_near += n_far; n_far = 0;
       }
-      h->nn_timer->stop(s);
+      h->tm_bounded.stop(s);
       if (n_near > 0) { rec.nn_bounded_launches++; rec.nn_bounded_queries += (long long)n_near; }
-      t_cert = -1.f;        // read after the next synchronisation
     }
-    float t_first = 0.f;
-    if (t_cert < 0.f) { sync(h); t_first = h->nn_timer->ms(); }
     if (n_far > 0) { NnPhase ph(s, 1); sort_query_keys(h, tgt, srcG, list, n_far, im); }
     h->nn_timer->start(s);
     if (n_far > 0)
       launch_rows(3, tgt, srcG, h->vals_b.p, n_far, im, radius_sq(d), cert, ps.match.p, h->match_d2.p, ps.lbe.p, ps.match2.p, s);
     ps.fresh = false;
-    rec.t_nn_query_ms += t_first; rec.t_nn_bounded_ms += t_first;
     if (n_far > 0) { rec.nn_search_launches++; rec.nn_search_queries += (long long)n_far; }
     if (want_stats)
-      fprintf(stderr, "[nn %d->%d] queries %zu bounded %zu rows %zu certify+bounded %.3f ms cum %.3g (last %.3g) err %.3g\n", job.src, job.tgt, n,
-              n_near, n_far, (double)t_first, cum_pair, src.last_motion + tgt.last_motion, src.err_max + tgt.err_max);
+      fprintf(stderr, "[nn %d->%d] queries %zu bounded %zu rows %zu cum %.3g (last %.3g) err %.3g\n", job.src, job.tgt, n,
+              n_near, n_far, cum_pair, src.last_motion + tgt.last_motion, src.err_max + tgt.err_max);
   } else if (dense) {
     h->match_pos.reserve(n);
     match_pos = h->match_pos.p;
@@ -654,7 +649,10 @@ static void find_pair(e3d_icp* h, Cloud& src, Cloud& tgt, float d, PairJob& job,
 // number of LM blocks for a set of n correspondences in a system of n_sets sets (deterministic function of the two).  Every
 // block ends with a wave / block reduction of up to 55 f64 accumulators (~1000 instructions, 2 - 3 loop trips' worth): with
 // hundreds of sets (all-pairs jobs) 1024 blocks per set would leave each thread ~40 trips, so the cap shrinks with the set count
-// while the whole launch keeps >= 8192 blocks (~10 rounds over the resident slots) for balance.
+// while the whole launch keeps >= 8192 blocks (~10 rounds over the resident slots) for balance.  (On equal-sized sets far fewer
+// blocks stream faster -- 0.78 instead of 0.91 ms per 1e8 correspondences with 512 blocks in all, profiles/round3_lm_blocks.txt --
+// but the pairs of a real job differ in size and the nine-pose cost pass wants occupancy: 512 / 2048 blocks in all made the
+// all-pairs LM 567 -> 696 ms and the 2-scan step no faster.)
 static int lm_blocks_for(long long n, int n_sets = 1) {
   long long b = (n + (long long)kBlock * 8 - 1) / ((long long)kBlock * 8);
   long long cap = 8192 / std::max(n_sets, 1);
@@ -1050,6 +1048,7 @@ static bool align_meshes(e3d_icp* h, float max_d, float thr, bool print, int ite
   rec.t_transform_ms = t_tr.ms();
   rec.t_nn_ms = t_nn.ms();
   rec.t_nn_sort_ms = h->tm_sort.take(); rec.t_nn_scan_ms = h->tm_scan.take(); rec.t_nn_compact_ms = h->tm_compact.take();
+  { const double tb = h->tm_bounded.take(); rec.t_nn_bounded_ms += tb; rec.t_nn_query_ms += tb; }
   rec.t_lm_ms = t_lm.ms();
   h->iter_records.push_back(rec);
   return converged;

@@ -255,7 +255,8 @@ def leg_terrace(e3d, synth, R, args, dev, partial=False):
         return {"what": what, "launches_per_iter": launches / K, "summed_ms_per_iter": t_ms / K, "avg_launch_ms": avg,
                 "algorithmic_bytes_per_launch": bytes_per_launch, "GBs": bytes_per_launch / (avg * 1e-3) / 1e9 if (avg and bytes_per_launch) else None}
     n_rank = n_points / world if False else n_points     # every rank transforms the whole clouds
-    kernels["k_transform_bbox"] = stream_kernel("a3: both clouds into the global frame + bounding boxes, 32 B per point moved", tot[5] / world, 2 * K, 32.0 * n_rank)
+    kernels["k_transform_bbox"] = stream_kernel("a3: the cloud whose pose changed into the global frame + bounding box, 32 B per point moved (impl cloud 0 never "
+                                                "moves and is not transformed again)", tot[5] / world, K, 32.0 * n_rank)
     kernels["query_keys_and_sort"] = stream_kernel("cell keys + rocPRIM radix sort of the queries the row kernel searches (a5 prep)", tot[19] / world, max(tot[17] / world, 1), None)
     kernels["match_scan"] = stream_kernel("per-block match counts + 3 scan kernels (order-preserving compaction, first stage): 8 B per query", tot[20] / world, n_nn_launch,
                                           8.0 * queries / world / n_nn_launch)

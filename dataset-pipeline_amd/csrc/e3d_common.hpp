@@ -126,4 +126,43 @@ struct EventTimer {
 
 inline size_t div_up(size_t a, size_t b) { return (a + b - 1) / b; }
 
+// Streaming accesses (read or written once per launch, far larger than the caches): non-temporal, so that they do not displace the
+// lines gathers hit in L2.  E3D_NT = 0 plain loads / stores everywhere, 1 only the correspondence planes of the LM passes, 2 every
+// marked stream (measured per level: DESIGN 4.2).
+#ifndef E3D_NT
+#define E3D_NT 2
+#endif
+#ifdef __HIPCC__
+template <int LEVEL = 2, typename T>
+__device__ __forceinline__ T ld_stream(const T* __restrict__ p) {
+  if constexpr (E3D_NT >= LEVEL) return __builtin_nontemporal_load(p);
+  else return *p;
+}
+template <int LEVEL = 2>
+__device__ __forceinline__ float4 ld_stream(const float4* __restrict__ p) {
+  if constexpr (E3D_NT >= LEVEL) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+  } else {
+    return *p;
+  }
+}
+template <int LEVEL = 2, typename T>
+__device__ __forceinline__ void st_stream(T* __restrict__ p, const T v) {
+  if constexpr (E3D_NT >= LEVEL) __builtin_nontemporal_store(v, p);
+  else *p = v;
+}
+template <int LEVEL = 2>
+__device__ __forceinline__ void st_stream(float4* __restrict__ p, const float4 v) {
+  if constexpr (E3D_NT >= LEVEL) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const v4f w = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(w, reinterpret_cast<v4f*>(p));
+  } else {
+    *p = v;
+  }
+}
+#endif
+
 }  // namespace e3d

@@ -60,9 +60,9 @@ __global__ __launch_bounds__(kBlock) void k_transform_bbox(const float4* __restr
   float mn[3] = {3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f};
   float mx[3] = {-3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f};
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    const float4 l = L4[i];
+    const float4 l = ld_stream(L4 + i);
     const float3 p = pcl_se3(T, l.x, l.y, l.z);
-    G4[i] = make_float4(p.x, p.y, p.z, l.w);
+    st_stream(G4 + i, make_float4(p.x, p.y, p.z, l.w));
     mn[0] = fminf(mn[0], p.x); mn[1] = fminf(mn[1], p.y); mn[2] = fminf(mn[2], p.z);
     mx[0] = fmaxf(mx[0], p.x); mx[1] = fmaxf(mx[1], p.y); mx[2] = fmaxf(mx[2], p.z);
   }
@@ -1154,7 +1154,7 @@ __global__ __launch_bounds__(kBlock) void k_nn_certify(const float4* __restrict_
       jj[u] = j0 + (size_t)(step0 + u) * kWave + (size_t)lane;
       vv[u] = jj[u] < n;
       const size_t js = vv[u] ? jj[u] : 0;
-      mm[u] = match[js]; mm2[u] = match2[js]; ll[u] = lbe[js]; qq[u] = Gsrc[js];
+      mm[u] = ld_stream(match + js); mm2[u] = ld_stream(match2 + js); ll[u] = ld_stream(lbe + js); qq[u] = ld_stream(Gsrc + js);
     }
 #pragma unroll
     for (int u = 0; u < kCertUnroll; ++u) {
@@ -1187,11 +1187,11 @@ __global__ __launch_bounds__(kBlock) void k_nn_certify(const float4* __restrict_
         }
         ok = (thr > 0.f) && (v < lim) && (v < r2);
         near = v < near2;
-        if (ok) match_d2[j] = v;
+        if (ok) st_stream(match_d2 + j, v);
       } else {
         ok = (thr > 0.f) && (lim >= r2);
         near = none_near != 0;                          // k_nn_bounded searches these beyond the radius
-        if (ok) match_d2[j] = r2;
+        if (ok) st_stream(match_d2 + j, r2);
       }
     }
     const unsigned long long fn = __ballot(valid && !ok && near), ff = __ballot(valid && !ok && !near);
@@ -1375,15 +1375,25 @@ __global__ __launch_bounds__(kBlock) void k_nn_bounded(const float4* __restrict_
 // grid cell are ONE run, found from the cell's start and its 8 prefix bytes (one 4-byte and one 8-byte load per grid cell for
 // all of its sub-rows), then the candidates -- no chain of dependent lookups.  ~55 candidates instead of ~180.
 // -------------------------------------------------------------------------------------------------
-constexpr int kHalfRuns = 18;     // run-list slots per lane in LDS (more non-empty runs than that: the whole-cell rows)
-constexpr int kHalfBatch = 4;     // candidate gathers in flight per lane
+constexpr int kHalfRuns = 18;     // run-list slots per lane in LDS: the 3 x 3 x 2 sub-rows a box of the unrolled path can touch
+// BATCH = candidate gathers in flight per lane.  PACK: a run is its 4-byte start plus ONE length byte (runs of sub-cells come from
+// prefix bytes, so they hold at most 255 points; a longer run -- a cell without prefixes -- sends the query to the whole-cell rows):
+// 23 instead of 36 KB of LDS per block, six instead of four blocks per CU for a search that waits on memory.  Measured on the
+// 2 x 50 M bench, launches of 100 / 82 / 54 / 47 M listed queries (profiles/round3_nn_half_variants.txt): <4, false> 10.5 / 8.1 /
+// 5.4 / 4.7 ms, <4, true> 8.5 / 6.5 / 4.5 / 4.0, <8, true> 8.1 / 6.3 / 4.3 / 3.8 (the choice), <12, true> (87 VGPRs, five blocks)
+// 8.8 / 6.8 / 4.5 / 4.0; a 14-slot list at 64 VGPRs (eight blocks, 7 - 13 spilled registers) 11.6 / 8.9 / 6.2 / 5.4: the queries
+// whose box touches more sub-rows than slots pay whole-cell rows.
+template <int BATCH, bool PACK>
 __global__ __launch_bounds__(kBlock) void k_nn_bounded_half(const float4* __restrict__ Gsrc, const unsigned* __restrict__ list,
                                                             unsigned n_list, const float4* __restrict__ Gtgt, const unsigned* __restrict__ S,
                                                             const unsigned long long* __restrict__ H8,
                                                             GridDesc g, InvMap im, QueryRange qr, float r2, BoundParams bp,
                                                             int* __restrict__ match, int* __restrict__ match2,
                                                             float* __restrict__ match_d2, float* __restrict__ lbe) {
-  __shared__ unsigned s_runs[2][kHalfRuns][kBlock];   // per lane: the non-empty candidate runs of its box
+  // per lane: the non-empty candidate runs of its box (starts; ends, or PACK: one length byte per run, four runs to a word)
+  __shared__ unsigned s_runs[PACK ? 1 : 2][kHalfRuns][kBlock];
+  __shared__ unsigned s_len[PACK ? (kHalfRuns + 3) / 4 : 1][kBlock];
+  unsigned char* const my_len = reinterpret_cast<unsigned char*>(&s_len[0][0]);
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_list) return;
   const unsigned j = list[i];
@@ -1433,11 +1443,12 @@ __global__ __launch_bounds__(kBlock) void k_nn_bounded_half(const float4* __rest
   // The search is latency bound, not arithmetic bound, once the candidates are few: (1) ALL directory words of the box are
   // requested before any is used -- the usual box is at most 3 x 3 half-cell rows by 2 grid cells in x, unrolled with clamped
   // addresses (larger boxes, rare, loop) -- and the non-empty runs go to a per-lane list in LDS; (2) the candidates of all runs
-  // are then walked as ONE sequence, kHalfBatch gathers in flight.
+  // are then walked as ONE sequence, BATCH gathers in flight.
   const int cx0 = FX0 >> 1, cx1 = FX1 >> 1;
   int nr = 0;
 #define RUN_S(i) s_runs[0][(i)][threadIdx.x]
-#define RUN_E(i) s_runs[1][(i)][threadIdx.x]
+#define RUN_LEN(i) my_len[(((i) >> 2) * kBlock + threadIdx.x) * 4 + ((i) & 3)]
+#define RUN_E(i) (PACK ? RUN_S(i) + (unsigned)RUN_LEN(i) : s_runs[PACK ? 0 : 1][(i)][threadIdx.x])
   if (any) {
     const int nz = FZ1 - FZ0 + 1, ny = FY1 - FY0 + 1, nx = cx1 - cx0 + 1;
     if (nz <= 3 && ny <= 3 && nx <= 2) {
@@ -1477,7 +1488,15 @@ __global__ __launch_bounds__(kBlock) void k_nn_bounded_half(const float4* __rest
                 r0 = st + (k0 ? (unsigned)((e8 >> (8 * (k0 - 1))) & 0xFFull) : 0u);
                 r1 = st + (unsigned)((e8 >> (8 * k1)) & 0xFFull);
               }
-              if (r0 < r1) { if (nr >= 0 && nr < kHalfRuns) { RUN_S(nr) = r0; RUN_E(nr) = r1; ++nr; } else nr = -1; }
+              if (r0 < r1) {
+                if (nr >= 0 && nr < kHalfRuns && (!PACK || r1 - r0 < 256u)) {
+                  RUN_S(nr) = r0;
+                  if (PACK) RUN_LEN(nr) = (unsigned char)(r1 - r0); else s_runs[PACK ? 0 : 1][nr][threadIdx.x] = r1;
+                  ++nr;
+                } else {
+                  nr = -1;
+                }
+              }
             }
           }
     } else {
@@ -1488,10 +1507,10 @@ __global__ __launch_bounds__(kBlock) void k_nn_bounded_half(const float4* __rest
     int r = 0;
     unsigned cur = RUN_S(0), end = RUN_E(0);
     while (r < nr) {
-      unsigned p[kHalfBatch];
+      unsigned p[BATCH];
       int cnt = 0;
 #pragma unroll
-      for (int t = 0; t < kHalfBatch; ++t) {
+      for (int t = 0; t < BATCH; ++t) {
         p[t] = cur;                                        // (beyond the last candidate: a valid address, result ignored)
         if (r < nr) {
           cnt = t + 1;
@@ -1499,11 +1518,11 @@ __global__ __launch_bounds__(kBlock) void k_nn_bounded_half(const float4* __rest
           if (cur == end) { ++r; if (r < nr) { cur = RUN_S(r); end = RUN_E(r); } else { cur = p[t]; } }
         }
       }
-      float4 c4[kHalfBatch];
+      float4 c4[BATCH];
 #pragma unroll
-      for (int t = 0; t < kHalfBatch; ++t) c4[t] = Gtgt[p[t]];
+      for (int t = 0; t < BATCH; ++t) c4[t] = Gtgt[p[t]];
 #pragma unroll
-      for (int t = 0; t < kHalfBatch; ++t) {
+      for (int t = 0; t < BATCH; ++t) {
         if (t < cnt) {
           const float d2 = sqdist_l2(q.x, q.y, q.z, c4[t].x, c4[t].y, c4[t].z);
           const bool lt1 = d2 < bd, lt2 = d2 < bd2;
@@ -1565,6 +1584,7 @@ __global__ __launch_bounds__(kBlock) void k_nn_bounded_half(const float4* __rest
   }
 #undef RUN_S
 #undef RUN_E
+#undef RUN_LEN
   const bool has1 = bd < r2, has2 = bd2 < r2;            // NaN distances compare false: no partner
   match[j] = has1 ? bpos : -1;
   match2[j] = has2 ? bpos2 : -1;
@@ -1579,9 +1599,9 @@ __global__ __launch_bounds__(kBlock) void k_match_block_counts(const int* __rest
                                                                double* __restrict__ block_d2,
                                                                const float* __restrict__ match_d2) {
   const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const bool f = (j < n) && (match_pos[j] >= 0);
+  const bool f = (j < n) && (ld_stream(match_pos + j) >= 0);
   const unsigned long long b = __ballot(f);
-  double d = f ? (double)match_d2[j] : 0.0;
+  double d = f ? (double)ld_stream(match_d2 + j) : 0.0;
   d = wave_sum(d);
   __shared__ unsigned sc[kBlock / kWave];
   __shared__ double sd[kBlock / kWave];
@@ -1668,7 +1688,7 @@ __global__ __launch_bounds__(kBlock) void k_compact_corr(const int* __restrict__
                                                          float4* __restrict__ A, float4* __restrict__ B,
                                                          float4* __restrict__ C, size_t out_base) {
   const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int m = (j < n) ? match_pos[j] : -1;
+  const int m = (j < n) ? ld_stream(match_pos + j) : -1;
   const bool f = m >= 0;
   const unsigned long long b = __ballot(f);
   __shared__ unsigned wbase[kBlock / kWave];
@@ -1680,16 +1700,16 @@ __global__ __launch_bounds__(kBlock) void k_compact_corr(const int* __restrict__
   if (!f) return;
   const unsigned rank = (unsigned)__popcll(b & ((1ull << lane) - 1ull));
   const size_t o = out_base + base + rank;
-  const size_t js = order ? (size_t)order[j] : j;     // query j of the (sorted) search order -> source position
-  const float4 sp = Gsrc[js];
-  const float4 ln = LNsrc[js];
+  const size_t js = order ? (size_t)ld_stream(order + j) : j;     // query j of the (sorted) search order -> source position
+  const float4 sp = order ? Gsrc[js] : ld_stream(Gsrc + js);
+  const float4 ln = order ? LNsrc[js] : ld_stream(LNsrc + js);
   const float3 sn = pcl_so3(Tsrc, ln.x, ln.y, ln.z);
   const float4 tp = Gtgt[m];
   const float4 tl = LNtgt[m];
   const float3 tn = pcl_so3(Ttgt, tl.x, tl.y, tl.z);
-  A[o] = make_float4(sp.x, sp.y, sp.z, sn.x);
-  B[o] = make_float4(sn.y, sn.z, tp.x, tp.y);
-  C[o] = make_float4(tp.z, tn.x, tn.y, tn.z);
+  st_stream(A + o, make_float4(sp.x, sp.y, sp.z, sn.x));
+  st_stream(B + o, make_float4(sn.y, sn.z, tp.x, tp.y));
+  st_stream(C + o, make_float4(tp.z, tn.x, tn.y, tn.z));
 }
 
 // gather variant for explicit (index_query, index_match) lists on unsorted AoS clouds
@@ -2007,12 +2027,12 @@ __device__ __forceinline__ void lm_pass_body(const float4* __restrict__ A, const
   long long c = (long long)(gb - S.block_begin) * kBlock + threadIdx.x;
   if (UNR == 2) {
     float4 a0, b0, c0, a1, b1, c1;
-    if (PF && c + stride < S.n) { a0 = pa[c]; b0 = pb[c]; c0 = pc[c]; a1 = pa[c + stride]; b1 = pb[c + stride]; c1 = pc[c + stride]; }
+    if (PF && c + stride < S.n) { a0 = ld_stream<1>(pa + (c)); b0 = ld_stream<1>(pb + (c)); c0 = ld_stream<1>(pc + (c)); a1 = ld_stream<1>(pa + (c + stride)); b1 = ld_stream<1>(pb + (c + stride)); c1 = ld_stream<1>(pc + (c + stride)); }
     while (c + stride < S.n) {
-      if (!PF) { a0 = pa[c]; b0 = pb[c]; c0 = pc[c]; a1 = pa[c + stride]; b1 = pb[c + stride]; c1 = pc[c + stride]; }
+      if (!PF) { a0 = ld_stream<1>(pa + (c)); b0 = ld_stream<1>(pb + (c)); c0 = ld_stream<1>(pc + (c)); a1 = ld_stream<1>(pa + (c + stride)); b1 = ld_stream<1>(pb + (c + stride)); c1 = ld_stream<1>(pc + (c + stride)); }
       const float4 ua = a0, ub = b0, uc = c0, va = a1, vb = b1, vc = c1;
       c += 2 * stride;
-      if (PF && c + stride < S.n) { a0 = pa[c]; b0 = pb[c]; c0 = pc[c]; a1 = pa[c + stride]; b1 = pb[c + stride]; c1 = pc[c + stride]; }
+      if (PF && c + stride < S.n) { a0 = ld_stream<1>(pa + (c)); b0 = ld_stream<1>(pb + (c)); c0 = ld_stream<1>(pc + (c)); a1 = ld_stream<1>(pa + (c + stride)); b1 = ld_stream<1>(pb + (c + stride)); c1 = ld_stream<1>(pc + (c + stride)); }
       CorrRowsT<float> R;
       lm_rows<MODE, float>(S, ua, ub, uc, R);
       lm_accumulate<MODE, 0, float>(acc, R, S.side);
@@ -2020,19 +2040,19 @@ __device__ __forceinline__ void lm_pass_body(const float4* __restrict__ A, const
       lm_accumulate<MODE, 0, float>(acc, R, S.side);
     }
     if (c < S.n) {
-      const float4 a = pa[c], b = pb[c], cc = pc[c];
+      const float4 a = ld_stream<1>(pa + (c)), b = ld_stream<1>(pb + (c)), cc = ld_stream<1>(pc + (c));
       CorrRowsT<float> R;
       lm_rows<MODE, float>(S, a, b, cc, R);
       lm_accumulate<MODE, 0, float>(acc, R, S.side);
     }
   } else {
     float4 a0, b0, c0;
-    if (PF && c < S.n) { a0 = pa[c]; b0 = pb[c]; c0 = pc[c]; }
+    if (PF && c < S.n) { a0 = ld_stream<1>(pa + (c)); b0 = ld_stream<1>(pb + (c)); c0 = ld_stream<1>(pc + (c)); }
     while (c < S.n) {
-      if (!PF) { a0 = pa[c]; b0 = pb[c]; c0 = pc[c]; }
+      if (!PF) { a0 = ld_stream<1>(pa + (c)); b0 = ld_stream<1>(pb + (c)); c0 = ld_stream<1>(pc + (c)); }
       const float4 ua = a0, ub = b0, uc = c0;
       c += stride;
-      if (PF && c < S.n) { a0 = pa[c]; b0 = pb[c]; c0 = pc[c]; }
+      if (PF && c < S.n) { a0 = ld_stream<1>(pa + (c)); b0 = ld_stream<1>(pb + (c)); c0 = ld_stream<1>(pc + (c)); }
       CorrRowsT<float> R;
       lm_rows<MODE, float>(S, ua, ub, uc, R);
       lm_accumulate<MODE, 0, float>(acc, R, S.side);
@@ -2135,12 +2155,12 @@ __device__ __forceinline__ void lm_cost_multi_body(const float4* __restrict__ A,
   const float4* __restrict__ pc = C + S.off;
   long long c = (long long)(gb - S.block_begin) * kBlock + threadIdx.x;
   float4 a0, b0, c0;
-  if (PF && c < S.n) { a0 = pa[c]; b0 = pb[c]; c0 = pc[c]; }
+  if (PF && c < S.n) { a0 = ld_stream<1>(pa + (c)); b0 = ld_stream<1>(pb + (c)); c0 = ld_stream<1>(pc + (c)); }
   while (c < S.n) {
-    if (!PF) { a0 = pa[c]; b0 = pb[c]; c0 = pc[c]; }
+    if (!PF) { a0 = ld_stream<1>(pa + (c)); b0 = ld_stream<1>(pb + (c)); c0 = ld_stream<1>(pc + (c)); }
     const float4 a = a0, b = b0, cc = c0;
     c += stride;
-    if (PF && c < S.n) { a0 = pa[c]; b0 = pb[c]; c0 = pc[c]; }
+    if (PF && c < S.n) { a0 = ld_stream<1>(pa + (c)); b0 = ld_stream<1>(pb + (c)); c0 = ld_stream<1>(pc + (c)); }
     float r1[kLmMaxPoses], r2[kLmMaxPoses];
     lm_costs_of<float>(S, poses, n_sets, n_poses, si, a, b, cc, r1, r2);
 #pragma unroll
@@ -2341,8 +2361,8 @@ void launch_nn_bounded(const float4* Gsrc, const unsigned* list, size_t n_list, 
   static const size_t half_min = [] { const char* e = getenv("E3D_NN_HALF_MIN"); return e ? (size_t)atoll(e) : (size_t)200000; }();
   if (half_prefix && (half_always || n_list >= half_min)) {
     // long lists are bound by the candidates they evaluate: the half-cell directory cuts those to a third
-    hipLaunchKernelGGL(k_nn_bounded_half, dim3((unsigned)div_up(n_list, kBlock)), dim3(kBlock), 0, s, Gsrc, list, (unsigned)n_list, Gtgt,
-                       dense_start, half_prefix, g, im, qr, r2, bp, match, match2, match_d2, lbe);
+    hipLaunchKernelGGL((k_nn_bounded_half<8, true>), dim3((unsigned)div_up(n_list, kBlock)), dim3(kBlock), 0, s, Gsrc, list, (unsigned)n_list,
+                       Gtgt, dense_start, half_prefix, g, im, qr, r2, bp, match, match2, match_d2, lbe);
     return;
   }
   if (n_list <= quad_limit)

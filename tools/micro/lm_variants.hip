@@ -4,7 +4,8 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-fast-math \
 //         -fno-slp-vectorize -o lm_variants tools/micro/lm_variants.hip && ./lm_variants [million correspondences] [sets] [blocks per set]
 // (round 3 also measured a packed two-correspondence form here, with and without SGPR-broadcast pose operands, and the build
-// without -fno-slp-vectorize: profiles/round3_lm_variants*.txt)
+// without -fno-slp-vectorize: profiles/round3_lm_variants*.txt; -DE3D_NT=0 builds the kernels with plain instead of non-temporal
+// loads of the correspondence planes: profiles/round3_nt_streams.txt)
 #include "../../dataset-pipeline_amd/csrc/e3d_icp_kernels.hip"
 
 #include <cmath>

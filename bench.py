@@ -246,8 +246,8 @@ def leg_terrace(e3d, synth, R, args, dev, partial=False):
         return {"what": what, "launches_per_iter": launches / K, "summed_ms_per_iter": t_ms / K, "avg_launch_ms": avg,
                 "algorithmic_bytes_per_launch": by, "GBs": by / (avg * 1e-3) / 1e9 if avg > 0 else None}
     kernels["k_nn_certify"] = nn_kernel("partner of the last search still the unique nearest neighbour? (one gather per query, a5)", tot[10] / world, tot[11] / world, tot[12] / world)
-    kernels["k_nn_bounded"] = nn_kernel("exact search inside the ball of the old partner's distance, one thread per listed query (a5); VALU bound by the "
-                                        "candidates it evaluates (whole grid cells), not by its 32 algorithmic bytes", tot[13] / world, tot[14] / world, tot[15] / world)
+    kernels["k_nn_bounded"] = nn_kernel("k_nn_bounded_half: exact search inside the ball of the old partner's distance over the half-cell directory, one thread per "
+                                        "listed query (a5); bound by the latency and issue rate of its candidate gathers, not by its 32 algorithmic bytes", tot[13] / world, tot[14] / world, tot[15] / world)
     kernels["k_nn_rows"] = nn_kernel("exact search of the remaining queries, sorted by target cell, LDS-staged candidate rows (a5)", tot[16] / world, tot[17] / world, tot[18] / world)
 
     def stream_kernel(what, t_ms, launches, bytes_per_launch):

@@ -1383,17 +1383,16 @@ constexpr int kHalfRuns = 18;     // run-list slots per lane in LDS: the 3 x 3 x
 // 5.4 / 4.7 ms, <4, true> 8.5 / 6.5 / 4.5 / 4.0, <8, true> 8.1 / 6.3 / 4.3 / 3.8 (the choice), <12, true> (87 VGPRs, five blocks)
 // 8.8 / 6.8 / 4.5 / 4.0; a 14-slot list at 64 VGPRs (eight blocks, 7 - 13 spilled registers) 11.6 / 8.9 / 6.2 / 5.4: the queries
 // whose box touches more sub-rows than slots pay whole-cell rows.
-template <int BATCH, bool PACK>
+template <int BATCH>
 __global__ __launch_bounds__(kBlock) void k_nn_bounded_half(const float4* __restrict__ Gsrc, const unsigned* __restrict__ list,
                                                             unsigned n_list, const float4* __restrict__ Gtgt, const unsigned* __restrict__ S,
                                                             const unsigned long long* __restrict__ H8,
                                                             GridDesc g, InvMap im, QueryRange qr, float r2, BoundParams bp,
                                                             int* __restrict__ match, int* __restrict__ match2,
                                                             float* __restrict__ match_d2, float* __restrict__ lbe) {
-  // per lane: the non-empty candidate runs of its box (starts; ends, or PACK: one length byte per run, four runs to a word)
-  __shared__ unsigned s_runs[PACK ? 1 : 2][kHalfRuns][kBlock];
-  __shared__ unsigned s_len[PACK ? (kHalfRuns + 3) / 4 : 1][kBlock];
-  unsigned char* const my_len = reinterpret_cast<unsigned char*>(&s_len[0][0]);
+  // per lane: the non-empty candidate runs of its box, a 4-byte start and ONE length byte each
+  __shared__ unsigned s_runs[kHalfRuns][kBlock];
+  __shared__ unsigned char s_len[kHalfRuns][kBlock];
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_list) return;
   const unsigned j = list[i];
@@ -1446,9 +1445,9 @@ __global__ __launch_bounds__(kBlock) void k_nn_bounded_half(const float4* __rest
   // are then walked as ONE sequence, BATCH gathers in flight.
   const int cx0 = FX0 >> 1, cx1 = FX1 >> 1;
   int nr = 0;
-#define RUN_S(i) s_runs[0][(i)][threadIdx.x]
-#define RUN_LEN(i) my_len[(((i) >> 2) * kBlock + threadIdx.x) * 4 + ((i) & 3)]
-#define RUN_E(i) (PACK ? RUN_S(i) + (unsigned)RUN_LEN(i) : s_runs[PACK ? 0 : 1][(i)][threadIdx.x])
+#define RUN_S(i) s_runs[(i)][threadIdx.x]
+#define RUN_LEN(i) s_len[(i)][threadIdx.x]
+#define RUN_E(i) (RUN_S(i) + (unsigned)RUN_LEN(i))
   if (any) {
     const int nz = FZ1 - FZ0 + 1, ny = FY1 - FY0 + 1, nx = cx1 - cx0 + 1;
     if (nz <= 3 && ny <= 3 && nx <= 2) {
@@ -1489,9 +1488,9 @@ __global__ __launch_bounds__(kBlock) void k_nn_bounded_half(const float4* __rest
                 r1 = st + (unsigned)((e8 >> (8 * k1)) & 0xFFull);
               }
               if (r0 < r1) {
-                if (nr >= 0 && nr < kHalfRuns && (!PACK || r1 - r0 < 256u)) {
+                if (nr >= 0 && nr < kHalfRuns && r1 - r0 < 256u) {
                   RUN_S(nr) = r0;
-                  if (PACK) RUN_LEN(nr) = (unsigned char)(r1 - r0); else s_runs[PACK ? 0 : 1][nr][threadIdx.x] = r1;
+                  RUN_LEN(nr) = (unsigned char)(r1 - r0);
                   ++nr;
                 } else {
                   nr = -1;
@@ -1504,36 +1503,45 @@ __global__ __launch_bounds__(kBlock) void k_nn_bounded_half(const float4* __rest
     }
   }
   if (nr > 0) {
+    // One flat walk over the candidates of all runs, BATCH gathers in flight, without a branch: the search is bound by the
+    // vector instructions it issues.  Squared distances are compared as bit patterns -- non-negative floats and +inf order like
+    // unsigned integers, a NaN sorts above +inf and is never taken (as with '<' on floats), and v_min_u32 / v_max_u32 need no
+    // canonicalisation of their operands; a slot past the last candidate holds +inf, which changes nothing.
+    const unsigned uinf = 0x7f800000u;
+    unsigned ud = uinf, ud2 = uinf, u3 = uinf;
     int r = 0;
+    const int last = nr - 1;
     unsigned cur = RUN_S(0), end = RUN_E(0);
     while (r < nr) {
       unsigned p[BATCH];
-      int cnt = 0;
+      bool ok[BATCH];
 #pragma unroll
       for (int t = 0; t < BATCH; ++t) {
+        ok[t] = r < nr;
         p[t] = cur;                                        // (beyond the last candidate: a valid address, result ignored)
-        if (r < nr) {
-          cnt = t + 1;
-          ++cur;
-          if (cur == end) { ++r; if (r < nr) { cur = RUN_S(r); end = RUN_E(r); } else { cur = p[t]; } }
-        }
+        const unsigned nx = cur + 1u;
+        const bool sw = ok[t] && nx == end;                // the run ends here: the next one (or, after the last, its start again)
+        r += sw ? 1 : 0;
+        const int rc = min(r, last);
+        const unsigned ns = RUN_S(rc), ne = ns + (unsigned)RUN_LEN(rc);
+        cur = sw ? ns : (ok[t] ? nx : cur);
+        end = sw ? ne : end;
       }
       float4 c4[BATCH];
 #pragma unroll
       for (int t = 0; t < BATCH; ++t) c4[t] = Gtgt[p[t]];
 #pragma unroll
       for (int t = 0; t < BATCH; ++t) {
-        if (t < cnt) {
-          const float d2 = sqdist_l2(q.x, q.y, q.z, c4[t].x, c4[t].y, c4[t].z);
-          const bool lt1 = d2 < bd, lt2 = d2 < bd2;
-          b3 = fminf(b3, fmaxf(d2, bd2));                 // the displaced runner-up, or this candidate
-          bd2 = fminf(fmaxf(d2, bd), bd2);
-          bpos2 = lt1 ? bpos : (lt2 ? (int)p[t] : bpos2);
-          bd = fminf(d2, bd);
-          bpos = lt1 ? (int)p[t] : bpos;
-        }
+        const unsigned u = ok[t] ? __float_as_uint(sqdist_l2(q.x, q.y, q.z, c4[t].x, c4[t].y, c4[t].z)) : uinf;
+        const bool lt1 = u < ud, lt2 = u < ud2;
+        u3 = min(u3, max(u, ud2));                         // the displaced runner-up, or this candidate
+        ud2 = min(max(u, ud), ud2);
+        bpos2 = lt1 ? bpos : (lt2 ? (int)p[t] : bpos2);
+        ud = min(u, ud);
+        bpos = lt1 ? (int)p[t] : bpos;
       }
     }
+    bd = __uint_as_float(ud); bd2 = __uint_as_float(ud2); b3 = __uint_as_float(u3);
   } else if (nr < 0) {
     // a large box (a query without a partner looks np_extra beyond the radius; a partner that moved far): whole grid cells, row by
     // row -- the cells [x0, x1] of one (y, z) row are ONE run of the cell directory, and an empty row costs two words.  A superset
@@ -2361,7 +2369,7 @@ void launch_nn_bounded(const float4* Gsrc, const unsigned* list, size_t n_list, 
   static const size_t half_min = [] { const char* e = getenv("E3D_NN_HALF_MIN"); return e ? (size_t)atoll(e) : (size_t)200000; }();
   if (half_prefix && (half_always || n_list >= half_min)) {
     // long lists are bound by the candidates they evaluate: the half-cell directory cuts those to a third
-    hipLaunchKernelGGL((k_nn_bounded_half<8, true>), dim3((unsigned)div_up(n_list, kBlock)), dim3(kBlock), 0, s, Gsrc, list, (unsigned)n_list,
+    hipLaunchKernelGGL((k_nn_bounded_half<8>), dim3((unsigned)div_up(n_list, kBlock)), dim3(kBlock), 0, s, Gsrc, list, (unsigned)n_list,
                        Gtgt, dense_start, half_prefix, g, im, qr, r2, bp, match, match2, match_d2, lbe);
     return;
   }

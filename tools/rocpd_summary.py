@@ -13,6 +13,16 @@ try:
         for r in rows:
             if flt in r[0]:
                 out.write("%s, %s, %.6g, %d\n" % (r[0][:80], r[1], r[2], r[3]))
+        # the same restricted to a kernel's LARGEST dispatches (counter value >= 0.8 x its maximum): a run that ramps up -- the first
+        # ICP iterations hold fewer correspondences -- otherwise averages launches of different sizes
+        out.write("# PMC_FULL: kernel, counter_FULL, sum over the dispatches with value >= 0.8 max, dispatches\n")
+        per = {}
+        for kn, cn, v in db.execute("select kernel_name, counter_name, value from counters_collection"):
+            per.setdefault((kn, cn), []).append(v)
+        for (kn, cn), vs in sorted(per.items()):
+            if flt in kn:
+                big = [v for v in vs if v >= 0.8 * max(vs)]
+                out.write("%s, %s_FULL, %.6g, %d\n" % (kn[:80], cn, sum(big), len(big)))
 except Exception as e:  # noqa
     out.write("# no counters: %s\n" % e)
 out.close()

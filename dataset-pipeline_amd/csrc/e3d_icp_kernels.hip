@@ -1462,42 +1462,44 @@ __global__ __launch_bounds__(kBlock) void k_nn_bounded_half(const float4* __rest
         cs[t] = S[lin];
         ce[t] = H8[lin];
       }
+      // Cell by cell (compile-time cell index: no selection among the loaded words), the up to four sub-rows (z half, y half) of
+      // a cell inside the box: bytes of the prefix word at compile-time positions, chosen by the x range.  A cell of more than
+      // 255 points has no prefixes (all ones): the whole-cell rows below take the query.
+      const int dz = (FZ1 >> 1) - gz0, dy = (FY1 >> 1) - gy0, dxc = cx1 - cx0;
+      bool dense = false;
 #pragma unroll
-      for (int a = 0; a < 3; ++a)
+      for (int t = 0; t < 8; ++t)
+        dense = dense || ((t >> 2) <= dz && ((t >> 1) & 1) <= dy && (t & 1) <= dxc && ce[t] == ~0ull);
+      if (dense) {
+        nr = -1;
+      } else {
 #pragma unroll
-        for (int b2 = 0; b2 < 3; ++b2)
+        for (int t = 0; t < 8; ++t) {
+          if ((t >> 2) <= dz && ((t >> 1) & 1) <= dy && (t & 1) <= dxc) {
+            const int cz2 = 2 * (gz0 + (t >> 2)), cy2 = 2 * (gy0 + ((t >> 1) & 1)), cx2 = 2 * (cx0 + (t & 1));
+            const bool xa = FX0 > cx2, xb = FX1 > cx2;               // the x halves [xa, xb] of this cell lie in the box
+            const unsigned st = cs[t], lo = (unsigned)ce[t], hi = (unsigned)(ce[t] >> 32);
 #pragma unroll
-          for (int c2 = 0; c2 < 2; ++c2) {
-            if (a < nz && b2 < ny && c2 < nx) {
-              const int FZ = FZ0 + a, FY = FY0 + b2, cx = cx0 + c2;
-              const int t = (((FZ >> 1) - gz0) << 2) | (((FY >> 1) - gy0) << 1) | c2;
-              unsigned st = cs[0]; unsigned long long e8 = ce[0];
+            for (int zz = 0; zz < 2; ++zz)
 #pragma unroll
-              for (int u = 1; u < 8; ++u) if (t == u) { st = cs[u]; e8 = ce[u]; }
-              const int sub = ((FZ & 1) * 2 + (FY & 1)) * 2;
-              const int fxa = max(FX0 - 2 * cx, 0), fxb = min(FX1 - 2 * cx, 1);
-              unsigned r0, r1;
-              if (e8 == ~0ull) {
-                // a cell of more than 255 points has no sub-cell prefixes: its whole run, once (from its first sub-row in the box)
-                const size_t lin = ((size_t)(FZ >> 1) * qr.D[1] + (size_t)(FY >> 1)) * qr.D[0] + (size_t)cx;
-                const bool first = (a == 0 || ((FZ - 1) >> 1) != (FZ >> 1)) && (b2 == 0 || ((FY - 1) >> 1) != (FY >> 1));
-                r0 = st; r1 = first ? S[lin + 1] : st;
-              } else {
-                const int k0 = sub + fxa, k1 = sub + fxb;
-                r0 = st + (k0 ? (unsigned)((e8 >> (8 * (k0 - 1))) & 0xFFull) : 0u);
-                r1 = st + (unsigned)((e8 >> (8 * k1)) & 0xFFull);
-              }
-              if (r0 < r1) {
-                if (nr >= 0 && nr < kHalfRuns && r1 - r0 < 256u) {
-                  RUN_S(nr) = r0;
-                  RUN_LEN(nr) = (unsigned char)(r1 - r0);
-                  ++nr;
-                } else {
-                  nr = -1;
+              for (int yy = 0; yy < 2; ++yy) {
+                if (cz2 + zz >= FZ0 && cz2 + zz <= FZ1 && cy2 + yy >= FY0 && cy2 + yy <= FY1) {
+                  // codes (zz, yy, 0) = kb and kb + 1; byte k of the prefix word = points of the cell with a code <= k
+                  const int kb = zz * 4 + yy * 2;
+                  const unsigned w = zz ? hi : lo;
+                  const unsigned e_prev = kb == 0 ? 0u : (kb == 4 ? (lo >> 24) : ((w >> (8 * ((kb & 3) - 1))) & 0xFFu));
+                  const unsigned e_x0 = (w >> (8 * (kb & 3))) & 0xFFu, e_x1 = (w >> (8 * ((kb & 3) + 1))) & 0xFFu;
+                  const unsigned e0 = xa ? e_x0 : e_prev, e1 = xb ? e_x1 : e_x0;
+                  if (e0 < e1) {                             // at most 3 x 3 x 2 sub-rows lie in the box: the list cannot overflow
+                    RUN_S(nr) = st + e0;
+                    RUN_LEN(nr) = (unsigned char)(e1 - e0);
+                    ++nr;
+                  }
                 }
               }
-            }
           }
+        }
+      }
     } else {
       nr = -1;                                             // a large box: the plain loops below
     }

@@ -256,6 +256,26 @@ def test_nn_dense_buckets_overflow(e3d, ob, nn_mode):
     _check_nn(e3d, ob, src, tgt, 0.1)                               # every bucket holds the whole cloud
 
 
+def test_icp_cells_of_more_than_255_points(e3d, ob, nn_mode):
+    """Grid cells without half-cell prefixes (more than 255 points: the prefix bytes cannot count them) inside the whole ICP loop:
+    the bounded search of the later iterations has to take the whole-cell rows for them.  ~1 600 points per cell of size d."""
+    def patch(n, seed, jitter):
+        rng = np.random.RandomState(seed)
+        x = rng.uniform(0, 0.3, n); y = rng.uniform(0, 0.3, n)
+        z = 0.02 * np.sin(10 * x) * np.cos(10 * y) + jitter * rng.normal(size=n)
+        nx = -0.2 * np.cos(10 * x) * np.cos(10 * y); ny = 0.2 * np.sin(10 * x) * np.sin(10 * y); nz = np.ones(n)
+        nrm = np.stack([nx, ny, nz], 1); nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+        return np.stack([x, y, z], 1).astype(np.float32), nrm.astype(np.float32)
+    A, An = patch(60000, 1, 0.0005); B, Bn = patch(50000, 2, 0.0005)
+    T0 = np.eye(4, dtype=np.float32)
+    T1 = np.eye(4, dtype=np.float32)
+    c, s_ = np.float32(np.cos(0.01)), np.float32(np.sin(0.01))
+    T1[:3, :3] = np.array([[c, -s_, 0], [s_, c, 0], [0, 0, 1]], np.float32); T1[:3, 3] = [0.004, -0.003, 0.002]
+    g, o, ids, cg, co = _run_both(e3d, ob, [(A, An, T0, False), (B, Bn, T1, False)], 0.05, 6, thr=1e-9)
+    _compare(g, o, ids, cg, co)
+    assert all(r[3] > 40000 for r in g.pair_records())            # nearly every point has a partner in every iteration
+
+
 def test_nn_rotated_scaled_target_frame(e3d, ob, synth, nn_mode):
     """Non-trivial poses (incl. a non-rigid linear part): counts identical to the oracle inside the full ICP loop."""
     scans = synth.make_scene(2, 30000, seed=99)

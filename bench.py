@@ -518,6 +518,7 @@ def main():
     ap.add_argument("--no-normals", action="store_true", help="skip the normal-estimation leg (N = 1 only)")
     ap.add_argument("--no-allpairs", action="store_true", help="skip the all-pairs scaling leg")
     ap.add_argument("--no-partial", action="store_true", help="skip the partial-overlap ICP leg (N = 1 only)")
+    ap.add_argument("--partial-only", action="store_true", help="profiling: the headline leg itself on the partial-overlap room (N = 1)")
     ap.add_argument("--allpairs-scans", type=int, default=16)
     ap.add_argument("--allpairs-points", type=int, default=10_000_000)
     ap.add_argument("--allpairs-distance", type=float, default=0.02)
@@ -547,6 +548,11 @@ def main():
         raise SystemExit("libe3dhip: no device")
     R = Ranks(rank, world, local_rank, e3d)
 
+    if args.partial_only and world == 1:
+        if rank == 0:
+            print(json.dumps(leg_terrace(e3d, synth, R, args, dev, partial=True)))
+        R.close()
+        return
     out = leg_terrace(e3d, synth, R, args, dev)
     if world == 1 and not args.no_partial:
         out["partial_overlap"] = leg_terrace(e3d, synth, R, args, dev, partial=True)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-3 evidence (one MI355X): kernel-trace stats of the default bench line, HBM traffic counters (separate FETCH_SIZE / WRITE_SIZE passes)
 # and SQ counters of the kernels of the three paths.  Summaries land in gpurun_out/r3prof/ ; the ones to judge are copied to profiles/.
-# usage: bash tools/prof_round3.sh [stage ...]   stages: trace icp reg normals sq   (default: all)
+# usage: bash tools/prof_round3.sh [stage ...]   stages: trace terrace partial icp reg normals sq   (default: all but partial)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r3prof
@@ -32,6 +32,12 @@ for st in $STAGES; do
       echo "[terrace] rc=$?"
       $SUM /tmp/r3p_terrace/b_results.db $O/terrace_kernel_stats.txt e3d > /dev/null 2>&1
       head -12 $O/terrace_kernel_stats.txt | cut -c1-60,150-230 ;;
+    partial)   # the partial-overlap leg alone (bench.py --partial-only): the same kernels where half of the queries find no partner
+      rm -rf /tmp/r3p_partial
+      timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/r3p_partial -o b -- python $R/bench.py --no-cpu-baseline --no-reg --no-normals --no-allpairs --partial-only > $O/partial_traced.json 2> /dev/null
+      echo "[partial] rc=$?"
+      $SUM /tmp/r3p_partial/b_results.db $O/partial_kernel_stats.txt e3d > /dev/null 2>&1
+      head -12 $O/partial_kernel_stats.txt | cut -c1-60,150-230 ;;
     icp)
       pmc icp_fetch FETCH_SIZE -- $ICP
       pmc icp_write WRITE_SIZE -- $ICP ;;

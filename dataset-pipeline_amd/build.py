@@ -47,14 +47,26 @@ def build(force=False, verbose=False):
             continue
         obj = os.path.join(objdir, s.replace(".hip", ".o"))
         objs.append(obj)
-        if force or _newer(src, obj) or any(_newer(hd, obj) for hd in hdrs):
-            cmd = ["hipcc"] + FLAGS + EXTRA_FLAGS.get(s, []) + os.environ.get("E3D_EXTRA_HIPCC_FLAGS", "").split() + ["-c", src, "-o", obj]
+        cmd = ["hipcc"] + FLAGS + EXTRA_FLAGS.get(s, []) + os.environ.get("E3D_EXTRA_HIPCC_FLAGS", "").split() + ["-c", src, "-o", obj]
+        # the flags are part of the object's identity (E3D_EXTRA_HIPCC_FLAGS=-DE3D_NT=0 and the like are used for A/B timing): the
+        # command line is kept next to the object and a different one rebuilds it
+        stamp = obj + ".cmd"
+        same_cmd = os.path.exists(stamp) and open(stamp).read() == " ".join(cmd)
+        if force or not same_cmd or _newer(src, obj) or any(_newer(hd, obj) for hd in hdrs):
             if verbose:
                 print(" ".join(cmd))
-            procs.append((s, subprocess.Popen(cmd)))
-    for s, p in procs:
+            if os.path.exists(stamp):
+                os.remove(stamp)
+            procs.append((s, subprocess.Popen(cmd), stamp, " ".join(cmd)))
+    failed = []
+    for s, p, stamp, line in procs:
         if p.wait() != 0:
-            raise RuntimeError("hipcc failed on " + s)
+            failed.append(s)
+        else:
+            with open(stamp, "w") as f:
+                f.write(line)
+    if failed:
+        raise RuntimeError("hipcc failed on " + ", ".join(failed))
     so = lib_path()
     if force or procs or not os.path.exists(so) or any(_newer(o, so) for o in objs):   # objects built by hand count too
         cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so] + objs + ["-L/opt/rocm/lib", "-lrccl"]

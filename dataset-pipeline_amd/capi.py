@@ -28,7 +28,7 @@ class PairRecord(C.Structure):
 
 class IterRecord(C.Structure):
     _fields_ = [("iteration", C.c_int32), ("inner_iterations", C.c_int32), ("full_passes", C.c_int32),
-                ("cost_passes", C.c_int32), ("multi_cost_passes", C.c_int32), ("reserved_", C.c_int32),
+                ("cost_passes", C.c_int32), ("multi_cost_passes", C.c_int32), ("multi_cost_poses", C.c_int32),
                 ("correspondences", C.c_int64), ("queries", C.c_int64),
                 ("initial_cost", C.c_double), ("final_cost", C.c_double),
                 ("t_transform_ms", C.c_double), ("t_nn_ms", C.c_double), ("t_lm_ms", C.c_double),
@@ -36,7 +36,7 @@ class IterRecord(C.Structure):
                 ("t_nn_certify_ms", C.c_double), ("t_nn_bounded_ms", C.c_double), ("t_nn_search_ms", C.c_double),
                 ("nn_certify_queries", C.c_int64), ("nn_bounded_queries", C.c_int64), ("nn_search_queries", C.c_int64),
                 ("nn_certify_launches", C.c_int32), ("nn_bounded_launches", C.c_int32), ("nn_search_launches", C.c_int32),
-                ("reserved2_", C.c_int32), ("t_nn_sort_ms", C.c_double), ("t_nn_scan_ms", C.c_double), ("t_nn_compact_ms", C.c_double)]
+                ("lm_passes_skipped", C.c_int32), ("t_nn_sort_ms", C.c_double), ("t_nn_scan_ms", C.c_double), ("t_nn_compact_ms", C.c_double)]
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_size_t, C.c_void_p)
@@ -55,6 +55,7 @@ SIGNATURES = {
     "e3d_icp_get_pose": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "e3d_icp_set_max_inner_iterations": (C.c_int, [C.c_void_p, C.c_int]),
     "e3d_icp_set_sequential_distance_sum": (C.c_int, [C.c_void_p, C.c_int]),
+    "e3d_icp_set_resident_rows": (C.c_int, [C.c_void_p, C.c_int]),
     "e3d_icp_num_pair_records": (C.c_size_t, [C.c_void_p]),
     "e3d_icp_pair_records": (C.POINTER(PairRecord), [C.c_void_p]),
     "e3d_icp_num_iter_records": (C.c_size_t, [C.c_void_p]),
@@ -66,6 +67,7 @@ SIGNATURES = {
     "e3d_comm_create_all": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p]),
     "e3d_comm_destroy": (None, [C.c_void_p]),
     "e3d_comm_abort": (C.c_int, [C.c_void_p]),
+    "e3d_comm_get_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int]),
     "e3d_comm_rank": (C.c_int, [C.c_void_p]),
     "e3d_comm_world_size": (C.c_int, [C.c_void_p]),
     "e3d_icp_set_comm": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -140,7 +142,7 @@ SIGNATURES = {
 }
 
 
-ABI_VERSION = 3          # E3D_ABI_VERSION of include/e3d_hip.h
+ABI_VERSION = 4          # E3D_ABI_VERSION of include/e3d_hip.h
 
 
 def lib():
@@ -260,6 +262,11 @@ class PointToPlaneICP:
     def set_sequential_distance_sum(self, enable):
         if lib().e3d_icp_set_sequential_distance_sum(self._h, int(bool(enable))) < 0:
             _err("e3d_icp_set_sequential_distance_sum")
+
+    def set_resident_rows(self, enable):
+        """Resident correspondence rows (default) or rows compacted afresh every outer iteration (include/e3d_hip.h)."""
+        if lib().e3d_icp_set_resident_rows(self._h, int(bool(enable))) < 0:
+            _err("e3d_icp_set_resident_rows")
 
     def set_max_inner_iterations(self, n):
         if lib().e3d_icp_set_max_inner_iterations(self._h, int(n)) < 0:
@@ -382,6 +389,13 @@ class Comm:
         if lib().e3d_comm_create_all(int(n_devices), dev, out) < 0:
             _err("e3d_comm_create_all")
         return [Comm(_handle=out[i]) for i in range(n_devices)]
+
+    def stats(self, reset=False):
+        """(all-reduce milliseconds by HIP events, calls, payload bytes) of this rank since creation / the last reset."""
+        ms, calls, nbytes = C.c_double(0), C.c_int64(0), C.c_int64(0)
+        if lib().e3d_comm_get_stats(self.handle, C.byref(ms), C.byref(calls), C.byref(nbytes), int(bool(reset))) < 0:
+            _err("e3d_comm_get_stats")
+        return ms.value, calls.value, nbytes.value
 
     def destroy(self):
         if self.handle:

@@ -66,18 +66,28 @@ int e3d_comm_create_all(int n_devices, const int* devices, e3d_comm_t** out) {
 
 int e3d_comm_abort(e3d_comm_t* c) {
   if (!c) return 0;
-  std::lock_guard<std::mutex> lock(c->mu);
   if (c->aborted.exchange(true) || !c->comm) return 0;
   const ncclResult_t r = ncclCommAbort(c->comm);   // releases collectives that wait for a rank that will never arrive
-  c->comm = nullptr;
   if (r != ncclSuccess) { e3d::set_last_error(std::string("ncclCommAbort failed: ") + ncclGetErrorString(r)); return E3D_ERR_HIP; }
   return 0;
 }
 
 void e3d_comm_destroy(e3d_comm_t* c) {
   if (!c) return;
-  if (c->comm) { (void)hipSetDevice(c->device); (void)ncclCommDestroy(c->comm); }
+  (void)hipSetDevice(c->device);
+  if (c->comm && !c->aborted.load()) (void)ncclCommDestroy(c->comm);      // (an aborted communicator is already gone)
   delete c;
+}
+
+int e3d_comm_get_stats(e3d_comm_t* c, double* allreduce_ms, int64_t* allreduce_calls, int64_t* allreduce_bytes, int reset) {
+  if (!c) { e3d::set_last_error("e3d_comm_get_stats: null communicator"); return E3D_ERR_INVALID; }
+  (void)hipSetDevice(c->device);
+  c->flush_events();
+  if (allreduce_ms) *allreduce_ms = c->allreduce_ms;
+  if (allreduce_calls) *allreduce_calls = c->allreduce_calls;
+  if (allreduce_bytes) *allreduce_bytes = c->allreduce_bytes;
+  if (reset) { c->allreduce_ms = 0.0; c->allreduce_calls = 0; c->allreduce_bytes = 0; }
+  return 0;
 }
 
 int e3d_comm_rank(const e3d_comm_t* c) { return c ? c->rank : 0; }

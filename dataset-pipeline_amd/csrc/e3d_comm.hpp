@@ -2,7 +2,8 @@
 #pragma once
 
 #include <atomic>
-#include <mutex>
+#include <utility>
+#include <vector>
 
 #include <rccl/rccl.h>
 
@@ -11,10 +12,25 @@
 struct e3d_comm {
   ncclComm_t comm = nullptr;
   int rank = 0, world = 1, device = 0;
-  // e3d_comm_abort may come from another host thread (the rank that failed): enqueueing a collective and aborting the
-  // communicator exclude each other, and nothing is enqueued on an aborted communicator
-  std::mutex mu;
+  // e3d_comm_abort may come from another host thread (the rank that failed) while this rank's thread sits inside an enqueue that
+  // waits for it: abort therefore takes no lock the enqueue holds.  It sets the flag (nothing is enqueued afterwards) and calls
+  // ncclCommAbort, which is meant to be called with operations outstanding; the handle stays set until e3d_comm_destroy.
+  // Aborting ONE communicator does not release its intra-node peers: whoever notices a failure aborts every local communicator
+  // (the tools do, csrc/host/icp_point_to_plane.h).
   std::atomic<bool> aborted{false};
+  // HIP-event stop-watch of the collectives (e3d_comm_get_stats): pairs are read lazily, so timing adds no synchronisation
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+  size_t ev_used = 0;
+  double allreduce_ms = 0.0;
+  long long allreduce_calls = 0, allreduce_bytes = 0;
+  void flush_events() {
+    for (size_t i = 0; i < ev_used; ++i) {
+      float t = 0.f;
+      if (hipEventSynchronize(ev[i].second) == hipSuccess && hipEventElapsedTime(&t, ev[i].first, ev[i].second) == hipSuccess) allreduce_ms += (double)t;
+    }
+    ev_used = 0;
+  }
+  ~e3d_comm() { for (auto& p : ev) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); } }
 };
 
 namespace e3d {
@@ -29,9 +45,17 @@ namespace e3d {
 // in-place sum over the ranks of a DEVICE buffer, enqueued on `s` (results identical on every rank)
 inline void comm_allreduce(e3d_comm* c, void* dev, size_t n, ncclDataType_t t, hipStream_t s) {
   if (!n) return;
-  std::lock_guard<std::mutex> lock(c->mu);
   if (c->aborted.load() || !c->comm) throw ::e3d::Error(-3, "the communicator was aborted (another rank failed)");
+  if (c->ev_used == c->ev.size()) {
+    if (c->ev.size() >= 1024) c->flush_events();       // (waits for collectives enqueued long ago)
+    else { hipEvent_t a, b; E3D_HIP(hipEventCreate(&a)); E3D_HIP(hipEventCreate(&b)); c->ev.emplace_back(a, b); }
+  }
+  const std::pair<hipEvent_t, hipEvent_t>& e = c->ev[c->ev_used];
+  E3D_HIP(hipEventRecord(e.first, s));
   E3D_NCCL(ncclAllReduce(dev, dev, n, t, ncclSum, c->comm, s));
+  E3D_HIP(hipEventRecord(e.second, s));
+  ++c->ev_used; ++c->allreduce_calls;
+  c->allreduce_bytes += (long long)n * (t == ncclDouble ? 8 : 4);
 }
 inline void comm_allreduce_f64(e3d_comm* c, double* dev, size_t n, hipStream_t s) { comm_allreduce(c, dev, n, ncclDouble, s); }
 inline void comm_allreduce_f32(e3d_comm* c, float* dev, size_t n, hipStream_t s) { comm_allreduce(c, dev, n, ncclFloat, s); }

@@ -82,6 +82,13 @@ struct PairState {
   long long jbase = -1;
   unsigned long long src_gen = 0, tgt_gen = 0;
   bool fresh = true;           // no search has filled the state yet
+  // resident correspondence rows (LmSet): one row per query at its source position, rewritten only where the partner changed
+  DevBuf<float4> pA, pB, pC;
+  DevBuf<int> plane_match;         // the partner each row encodes (-1: zero row)
+  DevBuf<unsigned> glist;          // active 64-row groups of the last update
+  bool rows_valid = false;         // plane_match describes the planes (same sorted orders, same frames)
+  bool src_global = false, tgt_global = false;   // the half is stored in the global frame (its cloud never moves) at pose *_T
+  float src_T[12], tgt_T[12];
 };
 
 struct PairJob {
@@ -93,6 +100,8 @@ struct PairJob {
   bool dsum_f32 = false;    // dsum holds the reference's sequential f32 sum (e3d_icp_set_sequential_distance_sum)
   size_t corr_off = 0;
   bool mine = true;
+  PairState* resident = nullptr;   // the pair's rows are the resident ones of this state (else: compacted into cA / cB / cC)
+  long long vrows = 0;             // resident: 64 * active groups, the rows an LM pass walks
 };
 
 }  // namespace e3d
@@ -128,7 +137,7 @@ struct e3d_icp {
   DevBuf<char> sort_temp;
   DevBuf<int> match_pos;
   DevBuf<float> match_d2;
-  DevBuf<unsigned> block_counts, block_offsets;
+  DevBuf<unsigned> block_counts, block_offsets, block_groups, chunk_groups;
   DevBuf<double> block_d2, chunk_d2;
   DevBuf<unsigned long long> d_total, chunk_sum;
   DevBuf<double> d_total_d2;
@@ -136,6 +145,10 @@ struct e3d_icp {
   PinBuf<double> h_total_d2;
   DevBuf<float4> cA, cB, cC;
   size_t corr_used = 0;
+  // e3d_icp_set_resident_rows / E3D_ICP_RESIDENT=0: compacted planes rewritten every outer iteration for every pair (the round-3
+  // data flow; A/B timing, tests)
+  bool resident_rows = [] { const char* e = getenv("E3D_ICP_RESIDENT"); return !(e && e[0] == '0'); }();
+  bool resident_now = false;                    // this outer iteration keeps resident rows for the pairs of the certificate path
   DevBuf<LmSet> d_sets;
   PinBuf<LmSet> h_sets;
   DevBuf<LmPose> d_poses;
@@ -305,16 +318,23 @@ static void build_grid(e3d_icp* h, Cloud& c, float d) {
     c.has_dense = true;
   }
   // half-cell directory for the bounded search: clouds with several points per cell (the others gain nothing from it); 8 bytes
-  // per cell of the bounding grid, twice the cell directory
+  // per cell of the bounding grid, twice the cell directory -- so it has to fit the same budget three times over (4 + 8 B per
+  // cell), and a failed allocation only costs the directory: k_nn_bounded works on whole cells without it
   c.has_half = false;
-  if (c.has_dense && half_mode() != 0 && n > 0 && ((double)n >= 4.0 * (double)std::max(n_cells, 1u) || half_mode() == 2 || h->nn_mode == 5)) {
+  if (c.has_dense && half_mode() != 0 && n > 0 && 3.0 * (prod + 2.0) <= (double)h->dense_cell_budget &&
+      ((double)n >= 4.0 * (double)std::max(n_cells, 1u) || half_mode() == 2 || h->nn_mode == 5)) {
     const size_t ncell = (size_t)prod;
-    c.half_prefix.reserve(ncell + 2);
-    E3D_HIP(hipMemsetAsync(c.half_prefix.p, 0, sizeof(unsigned long long) * (ncell + 2), s));
-    launch_half_prefix(h->keys_b.p, c.L4.p, n, c.grid, c.qrange, c.dense_start.p, c.half_prefix.p, s);
-    sync(h);
-    c.has_half = true;
+    bool ok = true;
+    try { c.half_prefix.reserve(ncell + 2); }
+    catch (const Error&) { ok = false; (void)hipGetLastError(); c.half_prefix.release(); }
+    if (ok) {
+      E3D_HIP(hipMemsetAsync(c.half_prefix.p, 0, sizeof(unsigned long long) * (ncell + 2), s));
+      launch_half_prefix(h->keys_b.p, c.L4.p, n, c.grid, c.qrange, c.dense_start.p, c.half_prefix.p, s);
+      sync(h);
+      c.has_half = true;
+    }
   }
+  if (!c.has_half) c.half_prefix.release();
   c.grid_valid = true;
   c.grid_radius = d;
   std::memcpy(c.grid_T, c.T, sizeof c.grid_T);
@@ -392,6 +412,7 @@ static PairState& pair_state_for(e3d_icp* h, int src_id, int tgt_id, const Cloud
     ps.match.reserve(n); ps.match2.reserve(n); ps.lbe.reserve(n); ps.todo_count.reserve(2);
     ps.n = n; ps.jbase = (long long)j0; ps.src_gen = src.generation; ps.tgt_gen = tgt.generation;
     ps.fresh = true;
+    ps.rows_valid = false;
   }
   return ps;
 }
@@ -492,6 +513,17 @@ struct NnPhase {
   ~NnPhase() { if (nn_profile()) { (void)hipStreamSynchronize(s); g_nn_prof[slot] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); } }
 };
 
+// which search a directed pair takes: the certificate path (per-pair state, results in source order) needs the target's dense
+// directory; only that path keeps resident correspondence rows
+static bool pair_is_dense(const e3d_icp* h, const Cloud& tgt) {
+  return h->nn_mode >= 2 || (h->nn_mode == 0 && (double)tgt.n >= 4.0 * (double)std::max(tgt.n_cells, 1u));
+}
+static bool pair_uses_rows(const e3d_icp* h, const Cloud& tgt) {
+  return pair_is_dense(h, tgt) && tgt.has_dense && (h->nn_mode == 0 || h->nn_mode == 3 || h->nn_mode == 5);
+}
+static size_t resident_rows_cap(size_t n) { return div_up(n, 64) * 64; }
+static size_t resident_bytes(size_t n) { return resident_rows_cap(n) * 48 + n * 4 + div_up(n, 64) * 4; }
+
 static void find_pair(e3d_icp* h, Cloud& src, Cloud& tgt, float d, PairJob& job, size_t j0, size_t j1,
                       e3d_icp_iter_record& rec) {
   hipStream_t s = h->stream;
@@ -503,14 +535,15 @@ static void find_pair(e3d_icp* h, Cloud& src, Cloud& tgt, float d, PairJob& job,
   h->match_d2.reserve(n);
   const size_t nb = div_up(n, kBlock);
   h->block_counts.reserve(nb); h->block_offsets.reserve(nb); h->block_d2.reserve(nb);
-  h->d_total.reserve(1); h->d_total_d2.reserve(1); h->h_total.reserve(1); h->h_total_d2.reserve(1);
+  h->d_total.reserve(2); h->d_total_d2.reserve(1); h->h_total.reserve(2); h->h_total_d2.reserve(1);
   if (!h->nn_timer) h->nn_timer.reset(new EventTimer());
   // dense data (many points per cell): queries sorted by target cell + the LDS-bucket kernels; sparse data: one thread per
   // query.  All are exact and return identical results.  The default row kernel keeps a per-query certificate between the
   // outer iterations: a query whose partner of the last iteration is provably still its unique nearest neighbour is settled
   // by k_nn_certify (one gather), only the others are sorted and searched.
-  const bool dense = h->nn_mode >= 2 || (h->nn_mode == 0 && (double)tgt.n >= 4.0 * (double)std::max(tgt.n_cells, 1u));
-  const bool rows = dense && tgt.has_dense && (h->nn_mode == 0 || h->nn_mode == 3 || h->nn_mode == 5);
+  const bool dense = pair_is_dense(h, tgt);
+  const bool rows = pair_uses_rows(h, tgt);
+  PairState* rstate = nullptr;
   static const bool use_cert = [] { const char* e = getenv("E3D_NN_CERT"); return !(e && e[0] == '0'); }();
   static const bool want_stats = [] { const char* e = getenv("E3D_NN_STATS"); return e && e[0] == '1'; }();
   const unsigned* order = nullptr;
@@ -518,6 +551,7 @@ static void find_pair(e3d_icp* h, Cloud& src, Cloud& tgt, float d, PairJob& job,
   // the timer brackets the search kernels themselves (what rocprofv3 reports for them); keys + sort are part of t_nn_ms
   if (rows) {
     PairState& ps = pair_state_for(h, job.src, job.tgt, src, tgt, j0, n);
+    if (h->resident_now) rstate = &ps;
     match_pos = ps.match.p;
     const InvMap im = make_invmap(tgt);
     const double cum_pair = src.cum_motion + tgt.cum_motion;
@@ -561,7 +595,7 @@ static void find_pair(e3d_icp* h, Cloud& src, Cloud& tgt, float d, PairJob& job,
       bp.rho_pad = round_up_f(2.0 * tgt.build_slack + 8.0 * FLT_EPSILON * m_local);
       bp.cum_lo = cert.cum_lo;
       bp.cell_scale = cert.cell_scale; bp.cell_sub = cert.cell_sub;
-      bp.np_extra = (float)(np_frac * (double)d);
+      bp.np_extra = none_near ? (float)(np_frac * (double)d) : 0.f;   // gate closed: partnerless queries on the far list keep the plain radius
       launch_nn_bounded(srcG, h->todo_near.p, n_near, tgt.G4.p, tgt.dense_start.p, tgt.has_half ? tgt.half_prefix.p : nullptr, h->nn_mode == 5, tgt.grid, im, tgt.qrange, radius_sq(d), bp, ps.match.p,
                         ps.match2.p, h->match_d2.p, ps.lbe.p, s);
       if (n_far > 0 && n_far * 32 < n) {
@@ -611,10 +645,46 @@ static void find_pair(e3d_icp* h, Cloud& src, Cloud& tgt, float d, PairJob& job,
   h->nn_timer->stop(s);
   NnPhase ph3(s, 2);                                                 // (its constructor waits for the search kernels)
   h->chunk_sum.reserve(div_up(nb, 256) + 1); h->chunk_d2.reserve(div_up(nb, 256) + 1);
+  if (rstate) {
+    // resident rows: bring the pair's planes up to date with the match list (rows whose partner changed), count, list the groups
+    PairState& ps = *rstate;
+    const size_t cap = resident_rows_cap(n);
+    // a cloud that never moves inside this AlignMeshes call (impl cloud 0, the fixed cloud) keeps its half in the global frame:
+    // no outer transform inside the LM passes for it.  If such a cloud did move since the rows were written (another role in an
+    // earlier call), or a half changes frames, every row is rewritten once.
+    const bool sg = src.fixed || src.cloud_index == 0, tg = tgt.fixed || tgt.cloud_index == 0;
+    bool valid = ps.rows_valid && ps.pA.cap >= cap && ps.src_global == sg && ps.tgt_global == tg;
+    if (valid && sg && std::memcmp(ps.src_T, src.T, sizeof ps.src_T) != 0) valid = false;
+    if (valid && tg && std::memcmp(ps.tgt_T, tgt.T, sizeof ps.tgt_T) != 0) valid = false;
+    if (!valid) {
+      ps.pA.reserve(cap); ps.pB.reserve(cap); ps.pC.reserve(cap); ps.plane_match.reserve(n); ps.glist.reserve(div_up(n, 64));
+      E3D_HIP(hipMemsetAsync(ps.plane_match.p, 0xFE, sizeof(int) * n, s));          // "never written": every row is
+      if (cap > n) {                                                                 // the rows past the last query stay zero rows
+        E3D_HIP(hipMemsetAsync(ps.pA.p + n, 0, sizeof(float4) * (cap - n), s));
+        E3D_HIP(hipMemsetAsync(ps.pB.p + n, 0, sizeof(float4) * (cap - n), s));
+        E3D_HIP(hipMemsetAsync(ps.pC.p + n, 0, sizeof(float4) * (cap - n), s));
+      }
+      ps.src_global = sg; ps.tgt_global = tg;
+      std::memcpy(ps.src_T, src.T, sizeof ps.src_T); std::memcpy(ps.tgt_T, tgt.T, sizeof ps.tgt_T);
+      ps.rows_valid = true;
+    }
+    h->block_groups.reserve(nb); h->chunk_groups.reserve(div_up(nb, 256) + 1);
+    h->tm_compact.start(s);
+    launch_corr_update(ps.match.p, ps.plane_match.p, h->match_d2.p, n, (sg ? src.G4.p : src.L4.p) + j0, srcLN, sg, to_affine(src.T),
+                       tg ? tgt.G4.p : tgt.L4.p, tgt.LN.p, tg, to_affine(tgt.T), ps.pA.p, ps.pB.p, ps.pC.p, h->block_counts.p,
+                       h->block_d2.p, h->block_groups.p, s);
+    h->tm_compact.stop(s);
+    h->tm_scan.start(s);
+    launch_corr_totals(n, h->block_counts.p, h->block_d2.p, h->block_groups.p, h->chunk_sum.p, h->chunk_d2.p, h->chunk_groups.p,
+                       h->d_total.p, h->d_total_d2.p, ps.glist.p, s);
+    h->tm_scan.stop(s);
+    copy_out(h->h_total.p + 1, h->d_total.p + 1, sizeof(unsigned long long), s);
+  } else {
   h->tm_scan.start(s);
   launch_match_scan(match_pos, h->match_d2.p, n, h->block_counts.p, h->block_offsets.p, h->block_d2.p,
                     h->chunk_sum.p, h->chunk_d2.p, h->d_total.p, h->d_total_d2.p, s);
   h->tm_scan.stop(s);
+  }
   copy_out(h->h_total.p, h->d_total.p, sizeof(unsigned long long), s);
   copy_out(h->h_total_d2.p, h->d_total_d2.p, sizeof(double), s);
   sync(h);
@@ -629,6 +699,11 @@ static void find_pair(e3d_icp* h, Cloud& src, Cloud& tgt, float d, PairJob& job,
     float distance_sum = 0.f;                                  // icp_point_to_plane.cc:226-229
     for (size_t i = 0; i < n; ++i) { const float v = h->h_d2_by_orig[i]; if (v >= 0.f) distance_sum += v; }
     job.dsum = (double)distance_sum; job.dsum_f32 = true;
+  }
+  if (rstate) {
+    job.resident = rstate;
+    job.vrows = 64 * (long long)h->h_total.p[1];
+    return;
   }
   if (job.count == 0) return;
   const size_t need = h->corr_used + (size_t)job.count;
@@ -726,11 +801,9 @@ static void lm_evaluate(e3d_icp* h, LmSystem& L, const std::vector<SE3f>& poses,
     tm.start(s);
     if (full) {
       for (int m = 1; m <= 3; ++m)
-        launch_lm_pass(m, h->cA.p, h->cB.p, h->cC.p, h->d_sets.p, h->d_block_set.p, L.mode_block_base[m],
-                       L.mode_blocks[m], h->d_partial.p, s);
+        launch_lm_pass(m, h->d_sets.p, h->d_block_set.p, L.mode_block_base[m], L.mode_blocks[m], h->d_partial.p, s);
     } else {
-      launch_lm_pass(kModeCost, h->cA.p, h->cB.p, h->cC.p, h->d_sets.p, h->d_block_set.p, 0, L.total_blocks,
-                     h->d_partial.p, s);
+      launch_lm_pass(kModeCost, h->d_sets.p, h->d_block_set.p, 0, L.total_blocks, h->d_partial.p, s);
     }
     tm.stop(s);
     launch_lm_reduce(h->d_partial.p, h->d_sets.p, ns, kLmSlot, h->d_setsum.p, s);
@@ -790,8 +863,7 @@ static void lm_evaluate_costs(e3d_icp* h, LmSystem& L, const std::vector<std::ve
     if (!h->lm_timer) h->lm_timer.reset(new EventTimer());
     EventTimer& tm = *h->lm_timer;
     tm.start(s);
-    launch_lm_cost_multi(h->cA.p, h->cB.p, h->cC.p, h->d_sets.p, h->d_poses.p, ns, np, h->d_block_set.p, L.total_blocks,
-                         h->d_partial.p, s);
+    launch_lm_cost_multi(h->d_sets.p, h->d_poses.p, ns, np, h->d_block_set.p, L.total_blocks, h->d_partial.p, s);
     tm.stop(s);
     launch_lm_reduce(h->d_partial.p, h->d_sets.p, ns, kLmSlot, h->d_setsum.p, s);
     reduce_setsums(h, ns);
@@ -802,7 +874,7 @@ static void lm_evaluate_costs(e3d_icp* h, LmSystem& L, const std::vector<std::ve
   rec.multi_cost_passes++;
 }
 
-static void lm_prepare(e3d_icp* h, LmSystem& L, std::vector<PairJob>& jobs) {
+static void lm_prepare(e3d_icp* h, LmSystem& L, std::vector<PairJob>& jobs, int M) {
   // group the non-empty pairs (global counts: every rank builds the same list, a rank without correspondences of a pair
   // contributes an empty set) by full-pass mode; assign LM blocks
   L.sets.clear();
@@ -827,8 +899,20 @@ static void lm_prepare(e3d_icp* h, LmSystem& L, std::vector<PairJob>& jobs) {
     for (PairJob* j : by_mode[m]) {
       const int i = (int)L.sets.size();
       LmSet& S = h->h_sets.p[i];
-      S.off = (long long)j->corr_off; S.n = j->count;
-      S.block_begin = block; S.nblocks = lm_blocks_for(j->count, ns_total);
+      if (j->resident) {
+        // resident rows: the pass walks the listed 64-row groups; local halves get the outer pose of this iteration
+        const PairState& ps = *j->resident;
+        const Cloud& src = (j->src == M) ? *h->fixed : *h->clouds[j->src];
+        const Cloud& tgt = (j->tgt == M) ? *h->fixed : *h->clouds[j->tgt];
+        S.A = ps.pA.p; S.B = ps.pB.p; S.C = ps.pC.p; S.glist = ps.glist.p; S.n = j->vrows;
+        S.outer = (ps.src_global ? 0 : 1) | (ps.tgt_global ? 0 : 2);
+        S.Tos = to_affine(src.T); S.Tot = to_affine(tgt.T);
+      } else {
+        S.A = h->cA.p + j->corr_off; S.B = h->cB.p + j->corr_off; S.C = h->cC.p + j->corr_off; S.glist = nullptr; S.n = j->count;
+        S.outer = 0;
+        S.Tos = Affine{}; S.Tot = Affine{};
+      }
+      S.block_begin = block; S.nblocks = lm_blocks_for(S.n, ns_total);
       S.mode = m;
       S.side = (j->impl_src - 1 >= 0) ? 0 : 1;
       for (int b = 0; b < S.nblocks; ++b) block_set.push_back(i);
@@ -867,25 +951,43 @@ static void lm_compute(e3d_icp* h, LmSystem& L, std::vector<SE3f>& poses, e3d_ic
     out[0] = poses[0];
     for (size_t ci = 1; ci < poses.size(); ++ci) out[ci] = se3_apply_update(&x[6 * (ci - 1)], poses[ci]);   // impl.h:235
   };
+  // Candidate poses are compared as f32 bit patterns: a pass at a pose that was already evaluated returns the cost it returned
+  // then, bit for bit (same rows, same per-correspondence f32 code, same reduction tree), so it need not run.  At the end of an
+  // outer iteration the update x is so small that exp(-x).cast<float>() * pose rounds back to the pose for most of the ten
+  // damping values: those tries have new_cost == cost and are rejected as the reference rejects them (impl.h:240-283 needs
+  // new_cost < cost), tries with identical poses share one evaluation.  The sequential decision rule is unchanged.
+  auto same_poses = [](const std::vector<SE3f>& a, const std::vector<SE3f>& b) {
+    return a.size() == b.size() && std::memcmp(a.data(), b.data(), a.size() * sizeof(SE3f)) == 0;
+  };
+  static_assert(sizeof(SE3f) == 7 * sizeof(float), "SE3f is compared as raw floats");
   for (int it = 0; it < h->max_inner; ++it) {
     rec.inner_iterations++;
     bool applied = false;
     // try 0 is usually accepted: evaluate its cost together with the next iteration's H and b (one fused pass)
     candidate(lambda, upd);
-    lm_evaluate(h, L, upd, true, Hn, bn, new_cost, rec);
+    if (same_poses(upd, poses)) { new_cost = cost; rec.lm_passes_skipped++; }
+    else lm_evaluate(h, L, upd, true, Hn, bn, new_cost, rec);
     if (new_cost < cost) {
       poses = upd; H.swap(Hn); b.swap(bn); cost = new_cost;
       lambda = 0.5f * lambda;
       applied = true;
     } else {
       lambda = 2.f * lambda;
-      // tries 1..9 (lambda doubled after every rejection) only differ in their poses: one multi-pose cost pass,
-      // then the first try that lowers the cost is taken -- the reference's sequential decision
-      std::vector<std::vector<SE3f>> cand(9);
-      std::vector<double> lam(9), costs;
+      // tries 1..9 (lambda doubled after every rejection) only differ in their poses: one multi-pose cost pass over the
+      // DISTINCT new poses among them, then the first try that lowers the cost is taken -- the reference's sequential decision
+      std::vector<std::vector<SE3f>> cand(9), distinct;
+      std::vector<double> lam(9), costs(9, 0.0), dcosts;
+      std::vector<int> slot(9, -1);                          // -1: the pose equals the current one (cost known)
       double l = lambda;
-      for (int k = 0; k < 9; ++k) { lam[k] = l; candidate(l, cand[k]); l = 2.f * l; }
-      lm_evaluate_costs(h, L, cand, costs, rec);
+      for (int k = 0; k < 9; ++k) {
+        lam[k] = l; candidate(l, cand[k]); l = 2.f * l;
+        if (same_poses(cand[k], poses)) continue;
+        for (size_t q = 0; q < distinct.size() && slot[k] < 0; ++q) if (same_poses(cand[k], distinct[q])) slot[k] = (int)q;
+        if (slot[k] < 0) { slot[k] = (int)distinct.size(); distinct.push_back(cand[k]); }
+      }
+      if (!distinct.empty()) { lm_evaluate_costs(h, L, distinct, dcosts, rec); rec.multi_cost_poses += (int)distinct.size(); }
+      else rec.lm_passes_skipped++;
+      for (int k = 0; k < 9; ++k) costs[k] = (slot[k] < 0) ? cost : dcosts[slot[k]];
       int hit = -1;
       for (int k = 0; k < 9; ++k) if (costs[k] < cost) { hit = k; break; }
       if (hit >= 0) {
@@ -945,11 +1047,35 @@ static bool align_meshes(e3d_icp* h, float max_d, float thr, bool print, int ite
   h->corr_used = 0;
   {
     // correspondences <= queries: size the planes once (no hipMalloc/hipFree inside the iteration loop)
-    size_t qtot = 0;
+    // Pairs of the certificate path keep RESIDENT rows (one row per query, 48 B + 4 B, for as long as the grids live) when all of
+    // them fit beside what is already allocated; otherwise every pair goes through the compacted planes as before.
+    size_t qtot = 0, rows_new = 0;
+    auto slice_len = [&](const Cloud& src) {
+      return (size_t)((unsigned __int128)src.n * (unsigned)(h->rank + 1) / (unsigned)h->world) -
+             (size_t)((unsigned __int128)src.n * (unsigned)h->rank / (unsigned)h->world);
+    };
+    bool resident = h->resident_rows;
     for (const PairJob& j : jobs) {
       const Cloud& src = (j.src == M) ? *h->fixed : *h->clouds[j.src];
-      qtot += (size_t)((unsigned __int128)src.n * (unsigned)(h->rank + 1) / (unsigned)h->world) -
-              (size_t)((unsigned __int128)src.n * (unsigned)h->rank / (unsigned)h->world);
+      const Cloud& tgt = (j.tgt == M) ? *h->fixed : *h->clouds[j.tgt];
+      const size_t nq = slice_len(src);
+      if (!pair_uses_rows(h, tgt) || nq == 0 || tgt.n == 0) continue;
+      auto it = h->pair_state.find(std::make_pair(j.src, j.tgt));
+      if (it == h->pair_state.end() || it->second->pA.cap < resident_rows_cap(nq)) rows_new += resident_bytes(nq);
+    }
+    if (resident && rows_new > 0) {
+      size_t free_b = 0, total_b = 0;
+      (void)hipMemGetInfo(&free_b, &total_b);
+      if ((double)rows_new > 0.8 * (double)free_b) resident = false;
+    }
+    if (!resident)
+      for (auto& kv : h->pair_state) { PairState& ps = *kv.second; ps.pA.release(); ps.pB.release(); ps.pC.release(); ps.rows_valid = false; }
+    h->resident_now = resident;
+    for (const PairJob& j : jobs) {
+      const Cloud& src = (j.src == M) ? *h->fixed : *h->clouds[j.src];
+      const Cloud& tgt = (j.tgt == M) ? *h->fixed : *h->clouds[j.tgt];
+      if (resident && pair_uses_rows(h, tgt)) continue;           // no compacted rows for this pair
+      qtot += slice_len(src);
     }
     // two directed pairs: one slot per query (no reallocation ever); many pairs: most queries of a pair find no partner, so
     // start from last iteration's total (+ 12 %) or a quarter of the queries and let find_pair grow the planes if needed
@@ -1018,7 +1144,7 @@ static bool align_meshes(e3d_icp* h, float max_d, float thr, bool print, int ite
   LmSystem L;
   L.n_impl = n_impl;
   L.nv = 6 * (n_impl - 1);
-  lm_prepare(h, L, jobs);
+  lm_prepare(h, L, jobs, M);
   if (n_impl >= 1) lm_compute(h, L, poses, rec);
   t_lm.stop(s);
 
@@ -1172,6 +1298,12 @@ int e3d_icp_set_sequential_distance_sum(e3d_icp_t* h, int enable) {
   return 0;
 }
 
+int e3d_icp_set_resident_rows(e3d_icp_t* h, int enable) {
+  if (!h) { e3d::set_last_error("e3d_icp_set_resident_rows: null handle"); return E3D_ERR_INVALID; }
+  h->resident_rows = enable != 0;
+  return 0;
+}
+
 int e3d_icp_set_max_inner_iterations(e3d_icp_t* h, int n) {
   if (!h || n < 0) { e3d::set_last_error("e3d_icp_set_max_inner_iterations: bad argument"); return E3D_ERR_INVALID; }
   h->max_inner = n;
@@ -1314,7 +1446,8 @@ int e3d_icp_pair_system(const float* sxyz, const float* snrm, const float* txyz,
   h->cA.reserve(n); h->cB.reserve(n); h->cC.reserve(n);
   launch_gather_corr(dsx.p, dsn.p, dtx.p, dtn.p, dq.p, dm.p, (size_t)n, h->cA.p, h->cB.p, h->cC.p, s);
   LmSet S{};
-  S.off = 0; S.n = n; S.block_begin = 0; S.nblocks = lm_blocks_for(n); S.mode = kModeTwoCross; S.side = 0;
+  S.A = h->cA.p; S.B = h->cB.p; S.C = h->cC.p; S.glist = nullptr; S.outer = 0;
+  S.n = n; S.block_begin = 0; S.nblocks = lm_blocks_for(n); S.mode = kModeTwoCross; S.side = 0;
   quat_to_matrix<float>(sq[0], sq[1], sq[2], sq[3], S.Rs);
   quat_to_matrix<float>(tq[0], tq[1], tq[2], tq[3], S.Rt);
   for (int k = 0; k < 3; ++k) { S.ts[k] = st[k]; S.tt[k] = tt[k]; }
@@ -1323,7 +1456,7 @@ int e3d_icp_pair_system(const float* sxyz, const float* snrm, const float* txyz,
   std::vector<int> bs(S.nblocks, 0);
   DevBuf<double> part, out; part.reserve((size_t)S.nblocks * kLmSlot); out.reserve(kLmSlot);
   copy_in(dset.p, &S, sizeof S, s); copy_in(dbs.p, bs.data(), sizeof(int) * S.nblocks, s);
-  launch_lm_pass(kModeTwoCross, h->cA.p, h->cB.p, h->cC.p, dset.p, dbs.p, 0, S.nblocks, part.p, s);
+  launch_lm_pass(kModeTwoCross, dset.p, dbs.p, 0, S.nblocks, part.p, s);
   launch_lm_reduce(part.p, dset.p, 1, kLmSlot, out.p, s);
   double r[kLmSlot];
   copy_out(r, out.p, sizeof r, s);

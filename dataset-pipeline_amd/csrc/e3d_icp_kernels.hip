@@ -1630,42 +1630,58 @@ constexpr int kScanChunk = 256;
 __global__ __launch_bounds__(kScanChunk) void k_scan_chunk_sums(const unsigned* __restrict__ counts, int nblocks,
                                                                 const double* __restrict__ block_d2,
                                                                 unsigned long long* __restrict__ chunk_sum,
-                                                                double* __restrict__ chunk_d2) {
+                                                                double* __restrict__ chunk_d2,
+                                                                const unsigned* __restrict__ groups = nullptr,
+                                                                unsigned* __restrict__ chunk_groups = nullptr) {
   const int b = blockIdx.x * kScanChunk + threadIdx.x;
   unsigned long long c = (b < nblocks) ? counts[b] : 0ull;
   double d = (b < nblocks) ? block_d2[b] : 0.0;
+  unsigned g = (groups && b < nblocks) ? (groups[b] & 0xFFu) : 0u;      // resident rows: active 64-row groups of the block
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { c += __shfl_xor(c, o, 64); d += __shfl_xor(d, o, 64); }
+  for (int o = 32; o > 0; o >>= 1) { c += __shfl_xor(c, o, 64); d += __shfl_xor(d, o, 64); g += __shfl_xor(g, o, 64); }
   __shared__ unsigned long long sc[kScanChunk / kWave];
   __shared__ double sd[kScanChunk / kWave];
-  if ((threadIdx.x & 63) == 0) { sc[threadIdx.x >> 6] = c; sd[threadIdx.x >> 6] = d; }
+  __shared__ unsigned sg[kScanChunk / kWave];
+  if ((threadIdx.x & 63) == 0) { sc[threadIdx.x >> 6] = c; sd[threadIdx.x >> 6] = d; sg[threadIdx.x >> 6] = g; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    unsigned long long t = 0; double td = 0;
-    for (int k = 0; k < kScanChunk / kWave; ++k) { t += sc[k]; td += sd[k]; }
+    unsigned long long t = 0; double td = 0; unsigned tg = 0;
+    for (int k = 0; k < kScanChunk / kWave; ++k) { t += sc[k]; td += sd[k]; tg += sg[k]; }
     chunk_sum[blockIdx.x] = t; chunk_d2[blockIdx.x] = td;
+    if (chunk_groups) chunk_groups[blockIdx.x] = tg;
   }
 }
 
+// totals (and the exclusive scan of the chunk sums); chunk_groups (resident rows): scanned in place as well, total[1] = their sum
 __global__ void k_scan_chunks(unsigned long long* __restrict__ chunk_sum, int nchunks, const double* __restrict__ chunk_d2,
-                              unsigned long long* __restrict__ total, double* __restrict__ total_d2) {
+                              unsigned long long* __restrict__ total, double* __restrict__ total_d2,
+                              unsigned* __restrict__ chunk_groups = nullptr) {
   __shared__ unsigned long long s[1024];
   __shared__ double sd[1024];
+  __shared__ unsigned sg[1024];
   const int t = threadIdx.x, T = blockDim.x;
   const int per = (nchunks + T - 1) / T;
   const int b0 = min(nchunks, t * per), b1 = min(nchunks, b0 + per);
-  unsigned long long sum = 0; double d = 0;
-  for (int b = b0; b < b1; ++b) { sum += chunk_sum[b]; d += chunk_d2[b]; }
-  s[t] = sum; sd[t] = d;
+  unsigned long long sum = 0; double d = 0; unsigned gs = 0;
+  for (int b = b0; b < b1; ++b) { sum += chunk_sum[b]; d += chunk_d2[b]; if (chunk_groups) gs += chunk_groups[b]; }
+  s[t] = sum; sd[t] = d; sg[t] = gs;
   __syncthreads();
   if (t == 0) {
-    unsigned long long run = 0; double dr = 0;
-    for (int k = 0; k < T; ++k) { const unsigned long long v = s[k]; s[k] = run; run += v; dr += sd[k]; }
+    unsigned long long run = 0; double dr = 0; unsigned gr = 0;
+    for (int k = 0; k < T; ++k) {
+      const unsigned long long v = s[k]; s[k] = run; run += v; dr += sd[k];
+      const unsigned gv = sg[k]; sg[k] = gr; gr += gv;
+    }
     *total = run; *total_d2 = dr;
+    if (chunk_groups) total[1] = gr;
   }
   __syncthreads();
   unsigned long long run = s[t];
-  for (int b = b0; b < b1; ++b) { const unsigned long long v = chunk_sum[b]; chunk_sum[b] = run; run += v; }
+  unsigned grun = sg[t];
+  for (int b = b0; b < b1; ++b) {
+    const unsigned long long v = chunk_sum[b]; chunk_sum[b] = run; run += v;
+    if (chunk_groups) { const unsigned gv = chunk_groups[b]; chunk_groups[b] = grun; grun += gv; }
+  }
 }
 
 __global__ __launch_bounds__(kScanChunk) void k_scan_within_chunks(const unsigned* __restrict__ counts, int nblocks,
@@ -1720,6 +1736,82 @@ __global__ __launch_bounds__(kBlock) void k_compact_corr(const int* __restrict__
   st_stream(A + o, make_float4(sp.x, sp.y, sp.z, sn.x));
   st_stream(B + o, make_float4(sn.y, sn.z, tp.x, tp.y));
   st_stream(C + o, make_float4(tp.z, tn.x, tn.y, tn.z));
+}
+
+// Resident rows (LmSet): one row per query of the pair, at its source position.  Rewrites the rows whose partner differs from the
+// one the row encodes -- in the settled state of an alignment a handful per launch, where k_compact_corr gathered and rewrote all
+// of them every outer iteration -- and produces what the progress line and the LM passes need from the match list: per-block
+// match counts and squared-distance sums (the arithmetic of k_match_block_counts) and the active 64-row groups of the block
+// (count in bits 0..7, mask in bits 8..11).  Halves of clouds that never move (impl cloud 0, fixed clouds) are stored in the
+// global frame exactly as k_compact_corr writes them; halves of movable clouds in the cloud's local frame (row_to_global).
+__global__ __launch_bounds__(kBlock) void k_corr_update(const int* __restrict__ match, int* __restrict__ plane_match,
+                                                        const float* __restrict__ match_d2, size_t n,
+                                                        const float4* __restrict__ Psrc, const float4* __restrict__ LNsrc,
+                                                        const int src_global, Affine Tsrc, const float4* __restrict__ Ptgt,
+                                                        const float4* __restrict__ LNtgt, const int tgt_global, Affine Ttgt,
+                                                        float4* __restrict__ A, float4* __restrict__ B, float4* __restrict__ C,
+                                                        unsigned* __restrict__ block_counts, double* __restrict__ block_d2,
+                                                        unsigned* __restrict__ block_groups) {
+  const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool in = j < n;
+  const int m = in ? ld_stream(match + j) : -1;
+  const int pm = in ? ld_stream(plane_match + j) : -1;
+  const bool f = m >= 0;
+  if (in && m != pm) {
+    float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra, rc = ra;
+    if (f) {
+      const float4 sp = Psrc[j];
+      const float4 ln = LNsrc[j];
+      float3 sn = make_float3(ln.x, ln.y, ln.z);
+      if (src_global) sn = pcl_so3(Tsrc, ln.x, ln.y, ln.z);
+      const float4 tp = Ptgt[m];
+      const float4 tl = LNtgt[m];
+      float3 tn = make_float3(tl.x, tl.y, tl.z);
+      if (tgt_global) tn = pcl_so3(Ttgt, tl.x, tl.y, tl.z);
+      ra = make_float4(sp.x, sp.y, sp.z, sn.x);
+      rb = make_float4(sn.y, sn.z, tp.x, tp.y);
+      rc = make_float4(tp.z, tn.x, tn.y, tn.z);
+    }
+    st_stream(A + j, ra); st_stream(B + j, rb); st_stream(C + j, rc);
+    plane_match[j] = m;
+  }
+  const unsigned long long b = __ballot(f);
+  double d = f ? (double)ld_stream(match_d2 + j) : 0.0;
+  d = wave_sum(d);
+  __shared__ unsigned sc[kBlock / kWave];
+  __shared__ double sd[kBlock / kWave];
+  if ((threadIdx.x & 63) == 0) { sc[threadIdx.x >> 6] = (unsigned)__popcll(b); sd[threadIdx.x >> 6] = d; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned c = 0, g = 0, gm = 0; double t = 0;
+    for (int k = 0; k < kBlock / kWave; ++k) { c += sc[k]; t += sd[k]; if (sc[k]) { ++g; gm |= 1u << k; } }
+    block_counts[blockIdx.x] = c; block_d2[blockIdx.x] = t; block_groups[blockIdx.x] = g | (gm << 8);
+  }
+}
+
+// ascending list of the active 64-row groups: one thread per query block (4 groups), scan inside the chunk + the chunk's base
+__global__ __launch_bounds__(kScanChunk) void k_group_list(const unsigned* __restrict__ block_groups, int nblocks,
+                                                           const unsigned* __restrict__ chunk_gbase,
+                                                           unsigned* __restrict__ glist) {
+  const int b = blockIdx.x * kScanChunk + threadIdx.x;
+  const unsigned w = (b < nblocks) ? block_groups[b] : 0u;
+  const unsigned c = w & 0xFFu;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  unsigned inc = c;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned t = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += t;
+  }
+  __shared__ unsigned ws[kScanChunk / kWave];
+  if (lane == 63) ws[wv] = inc;
+  __syncthreads();
+  unsigned base = chunk_gbase[blockIdx.x] + (inc - c);
+  for (int k = 0; k < wv; ++k) base += ws[k];
+  const unsigned mask = w >> 8;
+#pragma unroll
+  for (int k = 0; k < kBlock / kWave; ++k)
+    if (mask & (1u << k)) glist[base++] = (unsigned)b * (kBlock / kWave) + (unsigned)k;
 }
 
 // gather variant for explicit (index_query, index_match) lists on unsorted AoS clouds
@@ -2007,6 +2099,34 @@ __device__ __forceinline__ void lm_rows(const LmSet& S, const V4& a, const V4& b
   } else corr_rows<true, true, T>(S, a, b, c, R);
 }
 
+// The planes and the group list of a set are reached through pointers stored in the LmSet, which the compiler has to treat as
+// generic (flat) addresses: flat loads cost an aperture check and count against both wait counters, and a flat address cannot be
+// read with a scalar load.  They are HBM allocations: say so.
+typedef float lm_v4f __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) lm_v4f* lm_rows_ptr;       // global
+typedef const __attribute__((address_space(4))) unsigned* lm_glist_ptr;    // constant for the lifetime of the launch: s_load
+__device__ __forceinline__ float4 ld_row(const lm_rows_ptr p, const long long r) {
+  lm_v4f v;
+  if constexpr (E3D_NT >= 1) v = __builtin_nontemporal_load(p + r); else v = p[r];
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+
+// A resident row's local halves into the global frame of the outer iteration: pcl::transformPointCloudWithNormals' operation
+// order (icp_point_to_plane.cc:192-195), i.e. the very roundings k_transform_bbox / k_compact_corr apply -- the pass then sees
+// the numbers a compacted row would hold.  Block-uniform branches (S sits in SGPRs).
+__device__ __forceinline__ void row_to_global(const LmSet& S, float4& a, float4& b, float4& c) {
+  if (S.outer & 1) {
+    const float3 p = pcl_se3(S.Tos, a.x, a.y, a.z), n = pcl_so3(S.Tos, a.w, b.x, b.y);
+    a = make_float4(p.x, p.y, p.z, n.x); b.x = n.y; b.y = n.z;
+  }
+  if (S.outer & 2) {
+    const float3 p = pcl_se3(S.Tot, b.z, b.w, c.x), n = pcl_so3(S.Tot, c.y, c.z, c.w);
+    b.z = p.x; b.w = p.y; c = make_float4(p.z, n.x, n.y, n.z);
+  }
+}
+template <typename V4>
+__device__ __forceinline__ void row_to_global(const LmSet&, V4&, V4&, V4&) {}     // (packed experimental row types of tools/micro: compacted rows only)
+
 // Output slot layout per block / per set (kLmSlot doubles):
 //   [0] cost, [1..21] SS upper, [22..27] bs, [28..48] TT upper, [49..54] bt, [55..90] ST (6x6)
 // Every thread walks its correspondences c, c + stride, c + 2 stride, ... in this order and adds row 1 then row 2 of each: the
@@ -2016,9 +2136,7 @@ __device__ __forceinline__ void lm_rows(const LmSet& S, const V4& a, const V4& b
 //   PF   the next trip's float4 loads are issued before the current trip's arithmetic (at 2 - 3 waves per SIMD -- the f64
 //        accumulators -- the loads in flight per lane, not the occupancy, have to cover the HBM latency).
 template <int MODE, int UNR, bool PF>
-__device__ __forceinline__ void lm_pass_body(const float4* __restrict__ A, const float4* __restrict__ B,
-                                             const float4* __restrict__ C, const LmSet* __restrict__ sets,
-                                             const int* __restrict__ block_set, const int block_base,
+__device__ __forceinline__ void lm_pass_body(const LmSet* __restrict__ sets, const int* __restrict__ block_set, const int block_base,
                                              double* __restrict__ partial) {
   constexpr bool kOne = (MODE == kModeOne);
   constexpr bool kCross = (MODE == kModeTwoCross);
@@ -2031,18 +2149,19 @@ __device__ __forceinline__ void lm_pass_body(const float4* __restrict__ A, const
   for (int i = 0; i < NACC; ++i) acc[i] = 0.0;
 
   const long long stride = (long long)S.nblocks * kBlock;
-  const float4* __restrict__ pa = A + S.off;
-  const float4* __restrict__ pb = B + S.off;
-  const float4* __restrict__ pc = C + S.off;
+  const lm_rows_ptr pa = (lm_rows_ptr)S.A, pb = (lm_rows_ptr)S.B, pc = (lm_rows_ptr)S.C;
+  const lm_glist_ptr gl = (lm_glist_ptr)S.glist;
+  const long long lane64 = threadIdx.x & 63;
   long long c = (long long)(gb - S.block_begin) * kBlock + threadIdx.x;
   if (UNR == 2) {
+    // (two rows per trip: only the micro-benchmark instantiates this shape, on compacted rows)
     float4 a0, b0, c0, a1, b1, c1;
-    if (PF && c + stride < S.n) { a0 = ld_stream<1>(pa + (c)); b0 = ld_stream<1>(pb + (c)); c0 = ld_stream<1>(pc + (c)); a1 = ld_stream<1>(pa + (c + stride)); b1 = ld_stream<1>(pb + (c + stride)); c1 = ld_stream<1>(pc + (c + stride)); }
+    if (PF && c + stride < S.n) { a0 = ld_row(pa, c); b0 = ld_row(pb, c); c0 = ld_row(pc, c); a1 = ld_row(pa, c + stride); b1 = ld_row(pb, c + stride); c1 = ld_row(pc, c + stride); }
     while (c + stride < S.n) {
-      if (!PF) { a0 = ld_stream<1>(pa + (c)); b0 = ld_stream<1>(pb + (c)); c0 = ld_stream<1>(pc + (c)); a1 = ld_stream<1>(pa + (c + stride)); b1 = ld_stream<1>(pb + (c + stride)); c1 = ld_stream<1>(pc + (c + stride)); }
+      if (!PF) { a0 = ld_row(pa, c); b0 = ld_row(pb, c); c0 = ld_row(pc, c); a1 = ld_row(pa, c + stride); b1 = ld_row(pb, c + stride); c1 = ld_row(pc, c + stride); }
       const float4 ua = a0, ub = b0, uc = c0, va = a1, vb = b1, vc = c1;
       c += 2 * stride;
-      if (PF && c + stride < S.n) { a0 = ld_stream<1>(pa + (c)); b0 = ld_stream<1>(pb + (c)); c0 = ld_stream<1>(pc + (c)); a1 = ld_stream<1>(pa + (c + stride)); b1 = ld_stream<1>(pb + (c + stride)); c1 = ld_stream<1>(pc + (c + stride)); }
+      if (PF && c + stride < S.n) { a0 = ld_row(pa, c); b0 = ld_row(pb, c); c0 = ld_row(pc, c); a1 = ld_row(pa, c + stride); b1 = ld_row(pb, c + stride); c1 = ld_row(pc, c + stride); }
       CorrRowsT<float> R;
       lm_rows<MODE, float>(S, ua, ub, uc, R);
       lm_accumulate<MODE, 0, float>(acc, R, S.side);
@@ -2050,22 +2169,44 @@ __device__ __forceinline__ void lm_pass_body(const float4* __restrict__ A, const
       lm_accumulate<MODE, 0, float>(acc, R, S.side);
     }
     if (c < S.n) {
-      const float4 a = ld_stream<1>(pa + (c)), b = ld_stream<1>(pb + (c)), cc = ld_stream<1>(pc + (c));
+      const float4 a = ld_row(pa, c), b = ld_row(pb, c), cc = ld_row(pc, c);
       CorrRowsT<float> R;
       lm_rows<MODE, float>(S, a, b, cc, R);
       lm_accumulate<MODE, 0, float>(acc, R, S.side);
     }
   } else {
-    float4 a0, b0, c0;
-    if (PF && c < S.n) { a0 = ld_stream<1>(pa + (c)); b0 = ld_stream<1>(pb + (c)); c0 = ld_stream<1>(pc + (c)); }
-    while (c < S.n) {
-      if (!PF) { a0 = ld_stream<1>(pa + (c)); b0 = ld_stream<1>(pb + (c)); c0 = ld_stream<1>(pc + (c)); }
-      const float4 ua = a0, ub = b0, uc = c0;
-      c += stride;
-      if (PF && c < S.n) { a0 = ld_stream<1>(pa + (c)); b0 = ld_stream<1>(pb + (c)); c0 = ld_stream<1>(pc + (c)); }
+    auto trip = [&](float4 ua, float4 ub, float4 uc) {
+      row_to_global(S, ua, ub, uc);
       CorrRowsT<float> R;
       lm_rows<MODE, float>(S, ua, ub, uc, R);
       lm_accumulate<MODE, 0, float>(acc, R, S.side);
+    };
+    float4 a0, b0, c0;
+    if (gl) {
+      // resident rows: a wave walks whole 64-row groups, so everything that steers the walk is wave-uniform (scalar loads and
+      // branches); the group id of the trip after next is requested one trip ahead of the rows it addresses, behind the current
+      // trip's arithmetic like the rows themselves
+      const int ng = (int)(S.n >> 6), gstride = S.nblocks * (kBlock / kWave);
+      int gw = __builtin_amdgcn_readfirstlane((gb - S.block_begin) * (kBlock / kWave) + (int)(threadIdx.x >> 6));
+      unsigned g0 = (gw < ng) ? gl[gw] : 0u, g1 = (gw + gstride < ng) ? gl[gw + gstride] : 0u;
+      if (gw < ng) { const long long r = ((long long)g0 << 6) | lane64; a0 = ld_row(pa, r); b0 = ld_row(pb, r); c0 = ld_row(pc, r); }
+      while (gw < ng) {
+        const float4 ua = a0, ub = b0, uc = c0;
+        gw += gstride;
+        g0 = g1;
+        if (gw + gstride < ng) g1 = gl[gw + gstride];
+        if (gw < ng) { const long long r = ((long long)g0 << 6) | lane64; a0 = ld_row(pa, r); b0 = ld_row(pb, r); c0 = ld_row(pc, r); }
+        trip(ua, ub, uc);
+      }
+    } else {
+      if (PF && c < S.n) { a0 = ld_row(pa, c); b0 = ld_row(pb, c); c0 = ld_row(pc, c); }
+      while (c < S.n) {
+        if (!PF) { a0 = ld_row(pa, c); b0 = ld_row(pb, c); c0 = ld_row(pc, c); }
+        const float4 ua = a0, ub = b0, uc = c0;
+        c += stride;
+        if (PF && c < S.n) { a0 = ld_row(pa, c); b0 = ld_row(pb, c); c0 = ld_row(pc, c); }
+        trip(ua, ub, uc);
+      }
     }
   }
   // wave reduce -> LDS -> fixed-order block sum
@@ -2111,11 +2252,9 @@ template <> struct LmCfg<kModeCost> { static constexpr int unr = 1; static const
 template <> struct LmCfg<kModeOne> { static constexpr int unr = 1; static constexpr bool pf = true; static constexpr int minw = 2; };
 
 template <int MODE>
-__global__ __launch_bounds__(kBlock, LmCfg<MODE>::minw) void k_lm_pass(const float4* __restrict__ A, const float4* __restrict__ B,
-                                                                       const float4* __restrict__ C, const LmSet* __restrict__ sets,
-                                                                       const int* __restrict__ block_set, int block_base,
-                                                                       double* __restrict__ partial) {
-  lm_pass_body<MODE, LmCfg<MODE>::unr, LmCfg<MODE>::pf>(A, B, C, sets, block_set, block_base, partial);
+__global__ __launch_bounds__(kBlock, LmCfg<MODE>::minw) void k_lm_pass(const LmSet* __restrict__ sets, const int* __restrict__ block_set,
+                                                                       int block_base, double* __restrict__ partial) {
+  lm_pass_body<MODE, LmCfg<MODE>::unr, LmCfg<MODE>::pf>(sets, block_set, block_base, partial);
 }
 
 // a8, batched: the LM tries 1..9 of one inner iteration (lambda doubled each time, icp_point_to_plane_impl.h:216-283)
@@ -2149,10 +2288,8 @@ __device__ __forceinline__ void lm_costs_of(const LmSet& S, const LmPose* __rest
 }
 
 template <bool PF>
-__device__ __forceinline__ void lm_cost_multi_body(const float4* __restrict__ A, const float4* __restrict__ B,
-                                                   const float4* __restrict__ C, const LmSet* __restrict__ sets,
-                                                   const LmPose* __restrict__ poses, int n_sets, int n_poses,
-                                                   const int* __restrict__ block_set, double* __restrict__ partial) {
+__device__ __forceinline__ void lm_cost_multi_body(const LmSet* __restrict__ sets, const LmPose* __restrict__ poses, int n_sets,
+                                                   int n_poses, const int* __restrict__ block_set, double* __restrict__ partial) {
   const int gb = blockIdx.x;
   const int si = block_set[gb];
   const LmSet S = sets[si];
@@ -2160,22 +2297,41 @@ __device__ __forceinline__ void lm_cost_multi_body(const float4* __restrict__ A,
 #pragma unroll
   for (int k = 0; k < kLmMaxPoses; ++k) acc[k] = 0.0;
   const long long stride = (long long)S.nblocks * kBlock;
-  const float4* __restrict__ pa = A + S.off;
-  const float4* __restrict__ pb = B + S.off;
-  const float4* __restrict__ pc = C + S.off;
+  const lm_rows_ptr pa = (lm_rows_ptr)S.A, pb = (lm_rows_ptr)S.B, pc = (lm_rows_ptr)S.C;
+  const lm_glist_ptr gl = (lm_glist_ptr)S.glist;
+  const long long lane64 = threadIdx.x & 63;
   long long c = (long long)(gb - S.block_begin) * kBlock + threadIdx.x;
-  float4 a0, b0, c0;
-  if (PF && c < S.n) { a0 = ld_stream<1>(pa + (c)); b0 = ld_stream<1>(pb + (c)); c0 = ld_stream<1>(pc + (c)); }
-  while (c < S.n) {
-    if (!PF) { a0 = ld_stream<1>(pa + (c)); b0 = ld_stream<1>(pb + (c)); c0 = ld_stream<1>(pc + (c)); }
-    const float4 a = a0, b = b0, cc = c0;
-    c += stride;
-    if (PF && c < S.n) { a0 = ld_stream<1>(pa + (c)); b0 = ld_stream<1>(pb + (c)); c0 = ld_stream<1>(pc + (c)); }
+  auto trip = [&](float4 a, float4 b, float4 cc) {
+    row_to_global(S, a, b, cc);
     float r1[kLmMaxPoses], r2[kLmMaxPoses];
     lm_costs_of<float>(S, poses, n_sets, n_poses, si, a, b, cc, r1, r2);
 #pragma unroll
     for (int k = 0; k < kLmMaxPoses; ++k) {
       if (k < n_poses) { acc[k] += (double)(r1[k] * r1[k]); acc[k] += (double)(r2[k] * r2[k]); }
+    }
+  };
+  float4 a0, b0, c0;
+  if (gl) {      // resident rows: the walk of lm_pass_body
+    const int ng = (int)(S.n >> 6), gstride = S.nblocks * (kBlock / kWave);
+    int gw = __builtin_amdgcn_readfirstlane((gb - S.block_begin) * (kBlock / kWave) + (int)(threadIdx.x >> 6));
+    unsigned g0 = (gw < ng) ? gl[gw] : 0u, g1 = (gw + gstride < ng) ? gl[gw + gstride] : 0u;
+    if (gw < ng) { const long long r = ((long long)g0 << 6) | lane64; a0 = ld_row(pa, r); b0 = ld_row(pb, r); c0 = ld_row(pc, r); }
+    while (gw < ng) {
+      const float4 a = a0, b = b0, cc = c0;
+      gw += gstride;
+      g0 = g1;
+      if (gw + gstride < ng) g1 = gl[gw + gstride];
+      if (gw < ng) { const long long r = ((long long)g0 << 6) | lane64; a0 = ld_row(pa, r); b0 = ld_row(pb, r); c0 = ld_row(pc, r); }
+      trip(a, b, cc);
+    }
+  } else {
+    if (PF && c < S.n) { a0 = ld_row(pa, c); b0 = ld_row(pb, c); c0 = ld_row(pc, c); }
+    while (c < S.n) {
+      if (!PF) { a0 = ld_row(pa, c); b0 = ld_row(pb, c); c0 = ld_row(pc, c); }
+      const float4 a = a0, b = b0, cc = c0;
+      c += stride;
+      if (PF && c < S.n) { a0 = ld_row(pa, c); b0 = ld_row(pb, c); c0 = ld_row(pc, c); }
+      trip(a, b, cc);
     }
   }
   __shared__ double s[kBlock / kWave][kLmMaxPoses];
@@ -2196,11 +2352,10 @@ __device__ __forceinline__ void lm_cost_multi_body(const float4* __restrict__ A,
   }
 }
 
-__global__ __launch_bounds__(kBlock) void k_lm_cost_multi(const float4* __restrict__ A, const float4* __restrict__ B,
-                                                          const float4* __restrict__ C, const LmSet* __restrict__ sets,
-                                                          const LmPose* __restrict__ poses, int n_sets, int n_poses,
-                                                          const int* __restrict__ block_set, double* __restrict__ partial) {
-  lm_cost_multi_body<true>(A, B, C, sets, poses, n_sets, n_poses, block_set, partial);
+__global__ __launch_bounds__(kBlock) void k_lm_cost_multi(const LmSet* __restrict__ sets, const LmPose* __restrict__ poses,
+                                                          int n_sets, int n_poses, const int* __restrict__ block_set,
+                                                          double* __restrict__ partial) {
+  lm_cost_multi_body<true>(sets, poses, n_sets, n_poses, block_set, partial);
 }
 
 // one block per set: sum the set's block partials in a fixed order.  kRedParts threads share each of the
@@ -2300,8 +2455,8 @@ void launch_match_scan(const int* match_pos, const float* match_d2, size_t n, un
   hipLaunchKernelGGL(k_match_block_counts, dim3(nb), dim3(kBlock), 0, s, match_pos, n, block_counts, block_d2,
                      match_d2);
   const int nch = (nb + kScanChunk - 1) / kScanChunk;
-  hipLaunchKernelGGL(k_scan_chunk_sums, dim3(nch), dim3(kScanChunk), 0, s, block_counts, nb, block_d2, chunk_sum, chunk_d2);
-  hipLaunchKernelGGL(k_scan_chunks, dim3(1), dim3(1024), 0, s, chunk_sum, nch, chunk_d2, total, total_d2);
+  hipLaunchKernelGGL(k_scan_chunk_sums, dim3(nch), dim3(kScanChunk), 0, s, block_counts, nb, block_d2, chunk_sum, chunk_d2, (const unsigned*)nullptr, (unsigned*)nullptr);
+  hipLaunchKernelGGL(k_scan_chunks, dim3(1), dim3(1024), 0, s, chunk_sum, nch, chunk_d2, total, total_d2, (unsigned*)nullptr);
   hipLaunchKernelGGL(k_scan_within_chunks, dim3(nch), dim3(kScanChunk), 0, s, block_counts, nb, chunk_sum, block_offsets);
 }
 
@@ -2455,6 +2610,24 @@ void launch_compact_corr(const int* match_pos, const unsigned* order, size_t n, 
                      block_offsets, Gsrc, LNsrc, Tsrc, Gtgt, LNtgt, Ttgt, A, B, C, out_base);
 }
 
+void launch_corr_update(const int* match, int* plane_match, const float* match_d2, size_t n, const float4* Psrc, const float4* LNsrc,
+                        bool src_global, const Affine& Tsrc, const float4* Ptgt, const float4* LNtgt, bool tgt_global, const Affine& Ttgt,
+                        float4* A, float4* B, float4* C, unsigned* block_counts, double* block_d2, unsigned* block_groups, hipStream_t s) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_corr_update, dim3((unsigned)div_up(n, kBlock)), dim3(kBlock), 0, s, match, plane_match, match_d2, n, Psrc,
+                     LNsrc, src_global ? 1 : 0, Tsrc, Ptgt, LNtgt, tgt_global ? 1 : 0, Ttgt, A, B, C, block_counts, block_d2, block_groups);
+}
+
+void launch_corr_totals(size_t n, const unsigned* block_counts, const double* block_d2, const unsigned* block_groups,
+                        unsigned long long* chunk_sum, double* chunk_d2, unsigned* chunk_groups, unsigned long long* totals,
+                        double* total_d2, unsigned* glist, hipStream_t s) {
+  const int nb = (int)div_up(n ? n : 1, kBlock);
+  const int nch = (nb + kScanChunk - 1) / kScanChunk;
+  hipLaunchKernelGGL(k_scan_chunk_sums, dim3(nch), dim3(kScanChunk), 0, s, block_counts, nb, block_d2, chunk_sum, chunk_d2, block_groups, chunk_groups);
+  hipLaunchKernelGGL(k_scan_chunks, dim3(1), dim3(1024), 0, s, chunk_sum, nch, chunk_d2, totals, total_d2, chunk_groups);
+  hipLaunchKernelGGL(k_group_list, dim3(nch), dim3(kScanChunk), 0, s, block_groups, nb, chunk_groups, glist);
+}
+
 void launch_gather_corr(const float* sxyz, const float* snrm, const float* txyz, const float* tnrm, const int* iq,
                         const int* im, size_t n, float4* A, float4* B, float4* C, hipStream_t s) {
   if (!n) return;
@@ -2475,30 +2648,28 @@ void launch_match_d2_by_original(const int* match_pos, const float* match_d2, co
   hipLaunchKernelGGL(k_match_d2_by_original, dim3((unsigned)div_up(n, kBlock)), dim3(kBlock), 0, s, match_pos, match_d2, order, n, Gsrc, out);
 }
 
-void launch_lm_pass(int mode, const float4* A, const float4* B, const float4* C, const LmSet* sets,
-                    const int* block_set, int block_base, int nblocks, double* partial, hipStream_t s) {
+void launch_lm_pass(int mode, const LmSet* sets, const int* block_set, int block_base, int nblocks, double* partial, hipStream_t s) {
   if (nblocks <= 0) return;
   switch (mode) {
     case kModeCost:
-      hipLaunchKernelGGL(k_lm_pass<kModeCost>, dim3(nblocks), dim3(kBlock), 0, s, A, B, C, sets, block_set, block_base, partial);
+      hipLaunchKernelGGL(k_lm_pass<kModeCost>, dim3(nblocks), dim3(kBlock), 0, s, sets, block_set, block_base, partial);
       break;
     case kModeOne:
-      hipLaunchKernelGGL(k_lm_pass<kModeOne>, dim3(nblocks), dim3(kBlock), 0, s, A, B, C, sets, block_set, block_base, partial);
+      hipLaunchKernelGGL(k_lm_pass<kModeOne>, dim3(nblocks), dim3(kBlock), 0, s, sets, block_set, block_base, partial);
       break;
     case kModeTwo:
-      hipLaunchKernelGGL(k_lm_pass<kModeTwo>, dim3(nblocks), dim3(kBlock), 0, s, A, B, C, sets, block_set, block_base, partial);
+      hipLaunchKernelGGL(k_lm_pass<kModeTwo>, dim3(nblocks), dim3(kBlock), 0, s, sets, block_set, block_base, partial);
       break;
     default:
-      hipLaunchKernelGGL(k_lm_pass<kModeTwoCross>, dim3(nblocks), dim3(kBlock), 0, s, A, B, C, sets, block_set, block_base, partial);
+      hipLaunchKernelGGL(k_lm_pass<kModeTwoCross>, dim3(nblocks), dim3(kBlock), 0, s, sets, block_set, block_base, partial);
       break;
   }
 }
 
-void launch_lm_cost_multi(const float4* A, const float4* B, const float4* C, const LmSet* sets, const LmPose* poses,
-                          int n_sets, int n_poses, const int* block_set, int nblocks, double* partial, hipStream_t s) {
+void launch_lm_cost_multi(const LmSet* sets, const LmPose* poses, int n_sets, int n_poses, const int* block_set, int nblocks,
+                          double* partial, hipStream_t s) {
   if (nblocks <= 0) return;
-  hipLaunchKernelGGL(k_lm_cost_multi, dim3(nblocks), dim3(kBlock), 0, s, A, B, C, sets, poses, n_sets, n_poses, block_set,
-                     partial);
+  hipLaunchKernelGGL(k_lm_cost_multi, dim3(nblocks), dim3(kBlock), 0, s, sets, poses, n_sets, n_poses, block_set, partial);
 }
 
 void launch_lm_reduce(const double* partial, const LmSet* sets, int n_sets, int nacc, double* out, hipStream_t s) {

@@ -24,14 +24,25 @@ constexpr int kNNCap = 256;          // candidates staged in LDS per wave and ba
 // used to build dense sort keys for the queries.
 struct QueryRange { int lo[3]; unsigned D[3]; };
 
-// One directed pair's slice of the concatenated correspondence planes, with the inner poses
-// (R = so3().matrix() in f32, row-major) of its two impl clouds.
+// One directed pair's correspondence rows (three float4 planes: A = {sp.xyz, sn.x}, B = {sn.yz, tp.xy}, C = {tp.z, tn.xyz}),
+// with the inner poses (R = so3().matrix() in f32, row-major) of its two impl clouds.  Two row layouts:
+//   * compacted (glist == nullptr): rows [0, n) hold the pair's correspondences in source order, both halves in the GLOBAL
+//     frame of the outer iteration (k_compact_corr; rewritten every outer iteration);
+//   * resident (glist != nullptr): one row per QUERY of the pair at its source position, zero rows (normals 0: residuals and
+//     Jacobian rows are exactly 0) for queries without a partner; glist lists the 64-row groups that hold at least one
+//     correspondence, n = 64 * number of listed groups is the number of virtual rows the pass walks.  A half whose cloud can move
+//     is kept in the cloud's LOCAL frame and the pass applies the outer pose (Tos / Tot, PCL's operation order: the bits of G4)
+//     before the inner one, so a row only changes when the query's partner does (k_corr_update).
 struct LmSet {
-  long long off, n;        // slice [off, off+n)
+  const float4 *A, *B, *C; // row 0 of the pair's planes
+  const unsigned* glist;   // resident rows: indices of the active 64-row groups (ascending); nullptr: compacted rows
+  long long n;             // (virtual) rows
   int block_begin, nblocks;
   int mode;                // full-pass mode of this set
   int side;                // kModeOne: 0 = source has the variables, 1 = target
+  int outer;               // bit 0: source half is local (apply Tos), bit 1: target half is local (apply Tot)
   float Rs[9], ts[3], Rt[9], tt[3];
+  Affine Tos, Tot;         // global_T_cloud of the outer iteration for local halves
 };
 
 // inner poses of one set for one candidate LM try
@@ -116,10 +127,19 @@ void launch_unpermute_matches(const int* match_pos, const float* match_d2, const
                               const float4* Gtgt, int* out_idx, float* out_d2, hipStream_t s);
 void launch_match_d2_by_original(const int* match_pos, const float* match_d2, const unsigned* order, size_t n, const float4* Gsrc, float* out,
                                  hipStream_t s);
-void launch_lm_pass(int mode, const float4* A, const float4* B, const float4* C, const LmSet* sets,
-                    const int* block_set, int block_base, int nblocks, double* partial, hipStream_t s);
-void launch_lm_cost_multi(const float4* A, const float4* B, const float4* C, const LmSet* sets, const LmPose* poses,
-                          int n_sets, int n_poses, const int* block_set, int nblocks, double* partial, hipStream_t s);
+void launch_lm_pass(int mode, const LmSet* sets, const int* block_set, int block_base, int nblocks, double* partial, hipStream_t s);
+void launch_lm_cost_multi(const LmSet* sets, const LmPose* poses, int n_sets, int n_poses, const int* block_set, int nblocks,
+                          double* partial, hipStream_t s);
+// Resident rows of one directed pair (see LmSet): rewrites the rows whose partner changed since the planes were last brought up
+// to date (plane_match = the partner each row encodes, -1 zero row, anything else below -1 = never written), and produces the
+// per-block match counts / squared-distance sums (same arithmetic as launch_match_scan) plus the number of active 64-row groups
+// per block; launch_corr_totals then yields totals[0] = correspondences, totals[1] = active groups, total_d2 and the group list.
+void launch_corr_update(const int* match, int* plane_match, const float* match_d2, size_t n, const float4* Psrc, const float4* LNsrc,
+                        bool src_global, const Affine& Tsrc, const float4* Ptgt, const float4* LNtgt, bool tgt_global, const Affine& Ttgt,
+                        float4* A, float4* B, float4* C, unsigned* block_counts, double* block_d2, unsigned* block_groups, hipStream_t s);
+void launch_corr_totals(size_t n, const unsigned* block_counts, const double* block_d2, const unsigned* block_groups,
+                        unsigned long long* chunk_sum, double* chunk_d2, unsigned* chunk_groups, unsigned long long* totals,
+                        double* total_d2, unsigned* glist, hipStream_t s);
 void launch_lm_reduce(const double* partial, const LmSet* sets, int n_sets, int nacc, double* out, hipStream_t s);
 
 // radix sort of (cell key, point index) pairs -- rocPRIM device primitive (e3d_sort.hip)

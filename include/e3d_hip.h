@@ -31,8 +31,12 @@
 extern "C" {
 #endif
 
-/* 2: e3d_reg_params grew by the three depth-residual fields; the ICP iteration record by the NN phase times (round 2) */
-#define E3D_ABI_VERSION 3
+/* 2: e3d_reg_params grew by the three depth-residual fields; the ICP iteration record by the NN phase times (round 2)
+ * 3: e3d_icp_iter_record grew by t_nn_sort_ms / t_nn_scan_ms / t_nn_compact_ms; e3d_comm_abort, e3d_reg_profile,
+ *    e3d_icp_set_sequential_distance_sum (round 3)
+ * 4: e3d_icp_set_resident_rows, e3d_comm_get_stats; iteration record: multi_cost_poses, lm_passes_skipped in the two reserved
+ *    words (round 4) */
+#define E3D_ABI_VERSION 4
 
 #define E3D_ERR_INVALID   (-2)   /* bad argument / bad handle state          */
 #define E3D_ERR_HIP       (-3)   /* a HIP runtime call failed                */
@@ -82,10 +86,18 @@ int e3d_icp_get_pose(e3d_icp_t* icp, int cloud_index, float global_T_cloud[12]);
  * icp_point_to_plane.cc:312); exposed for bounded benchmarks, default 150. */
 int e3d_icp_set_max_inner_iterations(e3d_icp_t* icp, int n);
 /* The "avg. distance" of the progress line and the pair records' distance_sum from the reference's own sum: f32, sequential, in
- * original source order (icp_point_to_plane.cc:226-229) -- byte-identical stdout, at the price of one device -> host copy of the
+ * original source order (icp_point_to_plane.cc:226-229) -- byte-identical stdout of a single-rank run, at the price of one device -> host copy of the
  * distances and a host loop per pair and outer iteration.  Default off (environment E3D_ICP_SEQUENTIAL_DISTANCE_SUM=1 switches it
  * on for the tools): the f64 sum on the device, which does not stagnate at 2^24 times the typical term.  Ignored when sharded. */
 int e3d_icp_set_sequential_distance_sum(e3d_icp_t* icp, int enable);
+/* Correspondence rows of the LM passes.  1 (default; environment E3D_ICP_RESIDENT=0 flips it): every directed pair of the
+ * certificate search keeps one RESIDENT row per query (48 B, source order, movable clouds in their local frame) for as long as
+ * its grids live; an outer iteration rewrites only the rows whose partner changed and the LM passes apply the outer pose
+ * (pcl::transformPointCloudWithNormals' operation order, icp_point_to_plane.cc:192-195) in front of the inner one -- the same
+ * f32 numbers as rows written in the global frame.  0: all correspondences are gathered, transformed and compacted into fresh
+ * rows every outer iteration (the reference's own data flow, icp_point_to_plane.cc:183-309; used automatically when the resident
+ * rows do not fit HBM).  Same correspondences, counts and residuals either way; only the order of the f64 sums differs. */
+int e3d_icp_set_resident_rows(e3d_icp_t* icp, int enable);
 
 /* Per-pair correspondence report of every AlignMeshes call since creation -- the numbers the
  * reference only prints (icp_point_to_plane.cc:226-237).  src/tgt are the impl cloud indices
@@ -103,7 +115,8 @@ typedef struct {
   int32_t full_passes;       /* fused H/b/cost passes over all correspondences             */
   int32_t cost_passes;       /* cost-only passes (one pose set)                            */
   int32_t multi_cost_passes; /* cost-only passes evaluating LM tries 1..9 at once          */
-  int32_t reserved_;
+  int32_t multi_cost_poses;  /* ABI 4: distinct new pose sets those passes evaluated (<= 9 each; tries whose f32 poses equal the
+                                current ones or an earlier try's are not evaluated again)  */
   int64_t correspondences;   /* total over all directed pairs of this rank                 */
   int64_t queries;           /* NN queries issued by this rank                             */
   double  initial_cost, final_cost;
@@ -115,7 +128,8 @@ typedef struct {
   double  t_nn_bounded_ms;   /* k_nn_bounded launches                                      */
   double  t_nn_search_ms;    /* k_nn_rows / k_nn_cells / k_nn_query / k_nn_mfma launches   */
   int64_t nn_certify_queries, nn_bounded_queries, nn_search_queries;   /* queries those launches covered */
-  int32_t nn_certify_launches, nn_bounded_launches, nn_search_launches, reserved2_;
+  int32_t nn_certify_launches, nn_bounded_launches, nn_search_launches;
+  int32_t lm_passes_skipped; /* ABI 4: LM passes not launched because every pose asked for had been evaluated already */
   /* ABI 3: the rest of the NN phase, so that the per-kernel times add up to the step (HIP events) */
   double  t_nn_sort_ms;      /* query keys + radix sort of the queries the row kernel searches */
   double  t_nn_scan_ms;      /* match counts + scans (order-preserving compaction, first stage) */
@@ -150,10 +164,15 @@ int e3d_comm_unique_id(char id[E3D_COMM_ID_BYTES]);
 e3d_comm_t* e3d_comm_create(const char id[E3D_COMM_ID_BYTES], int rank, int world_size, int device);
 int e3d_comm_create_all(int n_devices, const int* devices, e3d_comm_t** out);
 void e3d_comm_destroy(e3d_comm_t* comm);
-/* Aborts the communicator (ncclCommAbort): collectives of the other ranks that wait for this one return with an error
- * instead of blocking forever.  Callable from any host thread; every later collective on `comm` fails; the object is
- * still released with e3d_comm_destroy.  Used by the tools when one rank's step fails (--gpus N). */
+/* Aborts the communicator (ncclCommAbort): an enqueue or a collective of THIS communicator that waits for a rank that will never
+ * arrive returns with an error instead of blocking forever.  Callable from any host thread, also while the communicator's own
+ * thread is inside a collective (no lock is shared with the enqueue); every later collective on `comm` fails; the object is still
+ * released with e3d_comm_destroy.  Aborting one communicator does not release its peers: when a rank's step fails the tools abort
+ * ALL local communicators (--gpus N, csrc/host/icp_point_to_plane.h). */
 int e3d_comm_abort(e3d_comm_t* comm);
+/* HIP-event time, number and payload of the all-reduces enqueued on `comm` since creation (or the last reset): what the bench
+ * line reports per rank at N > 1 (ABI 4).  Waits for the collectives enqueued so far. */
+int e3d_comm_get_stats(e3d_comm_t* comm, double* allreduce_ms, int64_t* allreduce_calls, int64_t* allreduce_bytes, int reset);
 int e3d_comm_rank(const e3d_comm_t* comm);
 int e3d_comm_world_size(const e3d_comm_t* comm);
 int e3d_icp_set_comm(e3d_icp_t* icp, e3d_comm_t* comm);

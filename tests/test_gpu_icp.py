@@ -230,6 +230,89 @@ def test_icp_partial_overlap_three_scans(e3d, ob, synth):
         e3d.lib().e3d_set_nn_mode(0)
 
 
+def _resident_scene(synth, scene):
+    if scene == "two":
+        scans, fixed, d, iters = synth.make_scene(2, 60_000, seed=11), (), 0.08, 8
+    elif scene == "partial":
+        scans, fixed, d, iters = synth.make_scene(2, 90_000, seed=78, partial=True), (), 0.06, 10
+    elif scene == "fixed":
+        scans, fixed, d, iters = synth.make_scene(4, 25_000, seed=9), (0, 2), 0.15, 6
+    else:
+        scans, fixed, d, iters = synth.make_scene(4, 30_000, seed=21), (), 0.1, 6
+    return [(s["xyz"].numpy(), s["normals"].numpy(), s["T_init"], i in fixed) for i, s in enumerate(scans)], d, iters
+
+
+@pytest.mark.parametrize("scene", ["two", "partial", "fixed", "four-all-pairs"])
+def test_resident_rows_equal_compacted_rows(e3d, ob, synth, scene):
+    """Round 4: the pairs of the certificate search keep one RESIDENT row per query (movable clouds in their local frame, the outer
+    pose applied inside the LM passes in PCL's operation order, icp_point_to_plane.cc:192-195; zero rows for queries without a
+    partner; only rows whose partner changed are rewritten) instead of gathering and compacting every correspondence in every
+    outer iteration.  Same correspondences and the same f32 residuals: counts and distance sums identical, LM costs equal up to the
+    order of the f64 sums, poses equal, and both equal the oracle."""
+    clouds, d, iters = _resident_scene(synth, scene)
+    assert e3d.lib().e3d_set_nn_mode(5) == 0          # certificate search + half-cell directory whatever the density
+    try:
+        runs = []
+        for resident in (True, False):
+            g = e3d.PointToPlaneICP()
+            g.set_resident_rows(resident)
+            ids = [g.add_point_cloud(*c) for c in clouds]
+            conv = g.run(d, 0, iters, 1e-9, False)
+            runs.append((g, ids, conv))
+        (gr, ids, cr), (gc, _, cc) = runs
+        assert cr == cc
+        assert gr.pair_records() == gc.pair_records()            # counts AND the f64 distance sums, bit for bit
+        for a, b in zip(gr.iter_records(), gc.iter_records()):
+            assert a["correspondences"] == b["correspondences"]
+            assert abs(a["initial_cost"] - b["initial_cost"]) <= 1e-11 * max(abs(b["initial_cost"]), 1e-300), (a, b)
+            assert abs(a["final_cost"] - b["final_cost"]) <= 1e-9 * max(abs(b["final_cost"]), 1e-300), (a, b)
+        for i in ids:
+            if i >= 0:
+                ang, tr = pose_error(gr.get_result_global_T_cloud(i), gc.get_result_global_T_cloud(i))
+                assert ang <= 2e-7 and tr <= 2e-6, (i, ang, tr)
+        o = ob.OracleICP()
+        for c in clouds:
+            o.add_point_cloud(*c)
+        co = o.run(d, 0, iters, 1e-9, False)
+        _compare(gr, o, ids, cr, co)
+    finally:
+        e3d.lib().e3d_set_nn_mode(0)
+
+
+def test_resident_rows_follow_a_restart_with_other_poses(e3d, ob, synth):
+    """The rows of a pair outlive Run(): a second Run on the same handle (the tools call Run once per outer iteration when they
+    write per-iteration projects, icp_scan_aligner.cc) continues with the rows of the first; halves kept in the global frame
+    (impl cloud 0) are only valid for the pose they were written at."""
+    scans = synth.make_scene(2, 50_000, seed=15)
+    clouds = [(s["xyz"].numpy(), s["normals"].numpy(), s["T_init"], False) for s in scans]
+    assert e3d.lib().e3d_set_nn_mode(5) == 0
+    try:
+        g = e3d.PointToPlaneICP(); o = ob.OracleICP()
+        for c in clouds:
+            g.add_point_cloud(*c); o.add_point_cloud(*c)
+        for it in range(5):
+            g.run(0.08, it, 1, 1e-9, False); o.run(0.08, it, 1, 1e-9, False)
+        _compare(g, o, [0, 1], False, False)
+    finally:
+        e3d.lib().e3d_set_nn_mode(0)
+
+
+def test_lm_tries_with_known_poses_are_not_evaluated_again(e3d, ob):
+    """icp_point_to_plane_impl.h:216-283: a try whose f32 pose equals the current one has new_cost == cost and is rejected; tries
+    with identical f32 poses have identical costs.  The library evaluates only the distinct new poses of tries 1..9 -- the accept /
+    reject sequence, and with it counts and poses, stay those of the oracle's sequential loop (run to convergence)."""
+    xyz, nrm, T0, T1 = plane_case()
+    g, o, ids, cg, co = _run_both(e3d, ob, [(xyz, nrm, T0, False), (xyz, nrm, T1, False)], 1.5, 100)
+    _compare(g, o, ids, cg, co)
+    rec = g.iter_records()
+    assert all(r["multi_cost_poses"] <= 9 * r["multi_cost_passes"] for r in rec)
+    assert all(r["multi_cost_passes"] + r["lm_passes_skipped"] >= 1 for r in rec if r["inner_iterations"] < 150)   # an LM run ends with ten rejections
+    P, N, Ts = identical_cloud_case()
+    g, o, ids, cg, co = _run_both(e3d, ob, [(P, N, T, False) for T in Ts], np.float32(0.15) * np.sqrt(3), 100)
+    _compare(g, o, ids, cg, co)
+    assert sum(r["lm_passes_skipped"] for r in g.iter_records()) > 0     # exact data: the last updates round away entirely
+
+
 def test_sequential_distance_sum_matches_reference_order(e3d, ob, synth, nn_mode):
     """icp_point_to_plane.cc:226-229: the progress line's "avg. distance" is a sequential f32 sum over the correspondences in source
     order.  With e3d_icp_set_sequential_distance_sum the library reproduces that sum bit for bit (default: an f64 sum on the device);

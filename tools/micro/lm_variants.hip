@@ -21,17 +21,14 @@ bool release_cached_device_memory() { return false; }
 using namespace e3d;
 
 template <int MODE, int UNR, bool PF, int MINW>
-__global__ __launch_bounds__(kBlock, MINW) void k_var(const float4* __restrict__ A, const float4* __restrict__ B,
-                                                      const float4* __restrict__ C, const LmSet* __restrict__ sets,
-                                                      const int* __restrict__ block_set, int block_base, double* __restrict__ partial) {
-  lm_pass_body<MODE, UNR, PF>(A, B, C, sets, block_set, block_base, partial);
+__global__ __launch_bounds__(kBlock, MINW) void k_var(const LmSet* __restrict__ sets, const int* __restrict__ block_set, int block_base,
+                                                      double* __restrict__ partial) {
+  lm_pass_body<MODE, UNR, PF>(sets, block_set, block_base, partial);
 }
 template <bool PF, int MINW>
-__global__ __launch_bounds__(kBlock, MINW) void k_cm(const float4* __restrict__ A, const float4* __restrict__ B,
-                                                     const float4* __restrict__ C, const LmSet* __restrict__ sets,
-                                                     const LmPose* __restrict__ poses, int n_sets, int n_poses,
+__global__ __launch_bounds__(kBlock, MINW) void k_cm(const LmSet* __restrict__ sets, const LmPose* __restrict__ poses, int n_sets, int n_poses,
                                                      const int* __restrict__ block_set, double* __restrict__ partial) {
-  lm_cost_multi_body<PF>(A, B, C, sets, poses, n_sets, n_poses, block_set, partial);
+  lm_cost_multi_body<PF>(sets, poses, n_sets, n_poses, block_set, partial);
 }
 
 __global__ void k_fill(float4* A, float4* B, float4* C, size_t n, unsigned seed) {
@@ -65,11 +62,20 @@ int main(int argc, char** argv) {
   int block = 0;
   for (int i = 0; i < ns; ++i) {
     LmSet& S = sets[i];
-    S.off = (long long)(n / ns) * i; S.n = (long long)(n / ns) - 7 * i;   // ragged ends: tails of every shape
+    const long long off = ((long long)(n / ns) * i) & ~63ll;
+    S.A = A + off; S.B = B + off; S.C = C + off; S.glist = nullptr; S.outer = 0;
+    S.n = (long long)(n / ns) - 7 * i;   // ragged ends: tails of every shape
     long long b = (S.n + (long long)kBlock * 8 - 1) / ((long long)kBlock * 8); if (b > cap) b = cap; if (b < 1) b = 1;
     S.block_begin = block; S.nblocks = (int)b; S.mode = 3; S.side = i & 1;
     quat(1.f, 0.001f * (i + 1), -0.002f, 0.0015f, S.Rs); quat(1.f, -0.001f, 0.0005f * (i + 1), 0.002f, S.Rt);
     for (int k = 0; k < 3; ++k) { S.ts[k] = 0.001f * (k + 1); S.tt[k] = -0.0007f * (k + 1); }
+    {
+      float R[9];
+      quat(1.f, 0.01f, 0.02f * (i + 1), -0.015f, R);
+      for (int r = 0; r < 3; ++r) { for (int k = 0; k < 3; ++k) S.Tos.m[4 * r + k] = R[3 * r + k]; S.Tos.m[4 * r + 3] = 0.1f * (r + 1); }
+      quat(1.f, -0.012f, 0.01f, 0.02f * (i + 1), R);
+      for (int r = 0; r < 3; ++r) { for (int k = 0; k < 3; ++k) S.Tot.m[4 * r + k] = R[3 * r + k]; S.Tot.m[4 * r + 3] = -0.05f * (r + 1); }
+    }
     for (int k = 0; k < S.nblocks; ++k) block_set.push_back(i);
     block += S.nblocks;
   }
@@ -107,7 +113,7 @@ int main(int argc, char** argv) {
     fflush(stdout);
   };
 #define V(MODE, UNR, PF, MINW, FIRST) \
-  run("mode" #MODE " unr" #UNR " pf" #PF " minw" #MINW, MODE, -1, [&] { hipLaunchKernelGGL((k_var<MODE, UNR, PF, MINW>), dim3(block), dim3(kBlock), 0, 0, A, B, C, dsets, dbs, 0, part); }, FIRST)
+  run("mode" #MODE " unr" #UNR " pf" #PF " minw" #MINW, MODE, -1, [&] { hipLaunchKernelGGL((k_var<MODE, UNR, PF, MINW>), dim3(block), dim3(kBlock), 0, 0, dsets, dbs, 0, part); }, FIRST)
 #define VM(MODE)                                                                                                       \
   V(MODE, 1, false, 1, true); V(MODE, 1, true, 1, false); V(MODE, 1, false, 2, false); V(MODE, 1, true, 2, false); \
   V(MODE, 1, false, 3, false); V(MODE, 1, true, 3, false); V(MODE, 1, true, 4, false);                               \
@@ -115,8 +121,29 @@ int main(int argc, char** argv) {
   VM(3) VM(2) VM(1)
   V(0, 1, false, 1, true); V(0, 1, true, 1, false); V(0, 2, true, 1, false);
 #define CM(PF, MINW, MODE, SIDE, FIRST) \
-  run("cost_multi pf" #PF " minw" #MINW " mode" #MODE, MODE, SIDE, [&] { hipLaunchKernelGGL((k_cm<PF, MINW>), dim3(block), dim3(kBlock), 0, 0, A, B, C, dsets, dposes, ns, kLmMaxPoses, dbs, part); }, FIRST)
+  run("cost_multi pf" #PF " minw" #MINW " mode" #MODE, MODE, SIDE, [&] { hipLaunchKernelGGL((k_cm<PF, MINW>), dim3(block), dim3(kBlock), 0, 0, dsets, dposes, ns, kLmMaxPoses, dbs, part); }, FIRST)
   CM(false, 1, 3, 0, true); CM(true, 1, 3, 0, false); CM(true, 2, 3, 0, false); CM(true, 4, 3, 0, false);
   CM(false, 1, 1, 0, true); CM(true, 1, 1, 0, false); CM(true, 2, 1, 0, false); CM(true, 4, 1, 0, false);
+  // resident rows (round 4): the same rows reached through a group list (every group listed: the walk visits what the
+  // compacted walk visits when the set length is a multiple of 64 -- "bits==first" then means the group walk changes nothing),
+  // then with the outer pose applied to the source half, the target half, both (other numbers: the time is what counts)
+  {
+    unsigned* gl; hipMalloc(&gl, sizeof(unsigned) * (n / 64 + 1));
+    std::vector<unsigned> ident(n / 64 + 1); for (size_t i = 0; i < ident.size(); ++i) ident[i] = (unsigned)i;
+    hipMemcpy(gl, ident.data(), sizeof(unsigned) * ident.size(), hipMemcpyHostToDevice);
+    for (int i = 0; i < ns; ++i) sets[i].n &= ~63ll;
+    auto res = [&](const char* tag, int outer, bool list) {
+      for (int i = 0; i < ns; ++i) { sets[i].glist = list ? gl : nullptr; sets[i].outer = outer; }
+      char name[64];
+#define RV(MODE, FIRST) snprintf(name, sizeof name, "mode" #MODE " %s", tag); \
+      run(name, MODE, MODE == 1 ? 0 : -1, [&] { hipLaunchKernelGGL((k_lm_pass<MODE>), dim3(block), dim3(kBlock), 0, 0, dsets, dbs, 0, part); }, FIRST)
+      RV(1, !list && outer == 0); RV(3, !list && outer == 0); RV(0, !list && outer == 0);
+      snprintf(name, sizeof name, "cost_multi mode1 %s", tag);
+      run(name, 1, 0, [&] { hipLaunchKernelGGL(k_lm_cost_multi, dim3(block), dim3(kBlock), 0, 0, dsets, dposes, ns, kLmMaxPoses, dbs, part); }, !list && outer == 0);
+    };
+    printf("-- product kernels, set lengths rounded down to 64 rows --\n");
+    res("compacted", 0, false); res("resident outer=0", 0, true); res("resident outer=src", 1, true); res("resident outer=tgt", 2, true);
+    res("resident outer=both", 3, true);
+  }
   return 0;
 }

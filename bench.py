@@ -8,7 +8,13 @@ Headline (`value`): BASELINE.json configs[1] -- ICPScanAligner on 2 scans of ~50
 scans of that shape generated directly in HBM (no network / no terrace data here).  A "step" is one outer ICP iteration, i.e. one
 PointToPlaneICP::Run(d, it, /*max_num_iterations*/1, thr) exactly as the tool's loop calls it (src/exe/icp_scan_aligner.cc:342-343):
 transform + bbox, exact 1-NN correspondence search for both directed pairs, and the full inner Levenberg-Marquardt solve
-(<= 150 iterations x (1 + <= 10 tries)).  Nothing is skipped or cached inside the timed region; inputs are resident in HBM first.
+(<= 150 iterations x (1 + <= 10 tries)).  Inputs are resident in HBM first.  What a step carries over from the step before it is what
+the library's handle carries between the outer iterations of any Run(): the static grids, the per-query certificates of the NN search
+(a query whose old partner is provably still its unique nearest neighbour is settled by one gather instead of a search) and the
+resident correspondence rows (only rows whose partner changed are rewritten).  Both are exact -- every step's counts, distances and
+poses are those of a search from scratch (tests/test_gpu_icp.py, tests/test_gpu_at_size.py) -- and both are part of the product,
+not of the bench; `ms_per_step_settling` / `ms_per_step_steady` separate the steps in which most certificates still break from
+the settled ones, and E3D_NN_CERT=0 / E3D_ICP_RESIDENT=0 time the job without either.  No result is reused across steps.
 
 N > 1: one process per GPU.  Launched by torchrun (RANK / WORLD_SIZE in the environment) or, if not, bench.py spawns the N ranks
 itself.  The ranks talk through the library's own RCCL communicator (e3d_comm_*: per-pair normal-equation blocks all-reduced in HBM
@@ -43,14 +49,13 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 ALG_BYTES_PER_CORR_PASS = 56   # 2 x i32 + 4 x vec3 f32 per correspondence per pass
 ALG_BYTES_PER_QUERY = 32       # 12 in + 8 out + 12 amortised target
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "round3_traffic.json")
-if not os.path.exists(TRAFFIC_JSON):
-    TRAFFIC_JSON = os.path.join(ROOT, "profiles", "round2_traffic.json")
+TRAFFIC_JSON = next((p for p in (os.path.join(ROOT, "profiles", "round%d_traffic.json" % r) for r in (4, 3, 2)) if os.path.exists(p)),
+                    os.path.join(ROOT, "profiles", "round4_traffic.json"))
 
 
 def load_traffic(kernel_key):
     """HBM bytes per launch of a kernel from the committed rocprofv3 PMC passes of this same command (bench.py cannot run the
-    profiler itself): profiles/round3_traffic.json, written by tools/make_traffic_json.py from tools/prof_round3.sh's passes."""
+    profiler itself): profiles/round<N>_traffic.json (the newest), written by tools/make_traffic_json.py from tools/prof_round4.sh's passes."""
     if not os.path.exists(TRAFFIC_JSON):
         return None, None
     k = json.load(open(TRAFFIC_JSON)).get("kernels", {}).get(kernel_key)
@@ -67,16 +72,18 @@ def crop_world(scan, lo, hi):
     return scan["xyz"][m].cpu().numpy(), scan["normals"][m].cpu().numpy()
 
 
-def cpu_baseline_icp(scans, d, thr, slab, n_points):
+def cpu_baseline_icp(scans, d, thr, slab, n_points, poses=None, first_iteration=0):
     """Reference-faithful CPU path (the oracle, "kind": "port") on a bounded sample of the same workload: SURVEY 8(d): >= 3
-    outer iterations, median."""
+    outer iterations, median.  `poses`: global_T_cloud per scan to start from -- the GPU run's poses after its warm-up iterations, so
+    that both sides are timed in the same regime of the alignment (the reference's cost per iteration falls with the number of LM
+    passes as the poses settle, exactly like the GPU's)."""
     from oracle import binding as ob
     ob.lib()
     clouds, n = [], []
-    for s in scans:
+    for i, s in enumerate(scans):
         xyz, nrm = crop_world(s, slab[0], slab[1])
         n.append(int(xyz.shape[0]))
-        clouds.append((xyz, nrm, s["T_init"]))
+        clouds.append((xyz, nrm, s["T_init"] if poses is None else poses[i]))
 
     def run(all_core):
         o = ob.OracleICP()
@@ -85,7 +92,7 @@ def cpu_baseline_icp(scans, d, thr, slab, n_points):
         for (xyz, nrm, T) in clouds:
             o.add_point_cloud(xyz, nrm, T, False)
         times = []
-        for it in range(3):
+        for it in range(first_iteration, first_iteration + 3):
             t0 = time.perf_counter()
             o.run(d, it, 1, thr, False)
             times.append(time.perf_counter() - t0)
@@ -100,6 +107,7 @@ def cpu_baseline_icp(scans, d, thr, slab, n_points):
     frac = float(n[0] + n[1]) / float(2 * n_points)
     return {
         "value": recs[med]["correspondences"] / times[med], "unit": "correspondences/s", "cores": 2, "kind": "port",
+        "start": "the GPU run's poses after its %d warm-up iterations (the regime the GPU steps are timed in)" % first_iteration if poses is not None else "the initial poses",
         "sample": "median of 3 outer iterations on the world-x slab [%.2f, %.2f) m of both scans: %d + %d points = %.1f %% of the "
                   "2 x %d of configs[1], same density and flags, %.1f s of CPU work; NN phase on 2 threads (one per directed pair, as "
                   "icp_point_to_plane.cc:208), inner LM single-threaded" % (slab[0], slab[1], n[0], n[1], 100 * frac, n_points, sum(times)),
@@ -126,6 +134,8 @@ def sum_records(recs):
         sum(r["t_nn_search_ms"] for r in recs), sum(r["nn_search_launches"] for r in recs), sum(r["nn_search_queries"] for r in recs),
         sum(r["t_nn_sort_ms"] for r in recs), sum(r["t_nn_scan_ms"] for r in recs), sum(r["t_nn_compact_ms"] for r in recs),
         sum(r["multi_cost_passes"] for r in recs),
+        sum(r["corr_rows_rewritten"] for r in recs), sum(r["corr_rows_walked"] for r in recs),
+        sum(r["multi_cost_poses"] for r in recs), sum(r["lm_passes_skipped"] for r in recs),
     ], dtype=np.float64)
 
 
@@ -171,10 +181,12 @@ class Ranks:
             self.dist.destroy_process_group()
 
 
-def run_icp(e3d, R, icp, d, thr, warmup, steps):
-    """W untimed + K timed outer iterations, barrier + synchronize on both sides, time = max over ranks."""
-    for it in range(warmup):
-        icp.run(d, it, 1, thr, False)
+def run_icp(e3d, R, icp, d, thr, warmup, steps, warmed=False):
+    """W untimed + K timed outer iterations, barrier + synchronize on both sides, time = max over ranks.
+    warmed: the caller has already run the W warm-up iterations on this handle."""
+    if not warmed:
+        for it in range(warmup):
+            icp.run(d, it, 1, thr, False)
     warm = icp.iter_records()
     icp.clear_records()
     R.barrier()
@@ -208,16 +220,20 @@ def leg_terrace(e3d, synth, R, args, dev, partial=False):
     icp = e3d.PointToPlaneICP(device=R.local_rank)
     for s in scans:
         icp.add_point_cloud(s["xyz"], s["normals"], s["T_init"], False)
-    base = None
-    if R.rank == 0 and world == 1 and not args.no_cpu_baseline and not partial:
-        # slab width chosen for ~4 M points per scan at this density (floor + two walls = 16 m^2 per metre of x)
-        width = min(10.0, 4.0e6 / (n_points / 242.6 * 16.0))
-        base = cpu_baseline_icp(scans, d, thr, (4.0, 4.0 + width), n_points)
-    del scans
-    torch.cuda.empty_cache()
     if R.comm:
         icp.set_comm(R.comm)
-    dt, tot, warm, recs, per_rank = run_icp(e3d, R, icp, d, thr, args.warmup, args.steps)
+    for it in range(args.warmup):                            # untimed warm-up steps (the timed region follows below)
+        icp.run(d, it, 1, thr, False)
+    base = None
+    if R.rank == 0 and world == 1 and not args.no_cpu_baseline and not partial:
+        # slab width chosen for ~4 M points per scan at this density (floor + two walls = 16 m^2 per metre of x); started from the
+        # poses the GPU run has reached after its warm-up, so both sides are timed in the same regime
+        width = min(10.0, 4.0e6 / (n_points / 242.6 * 16.0))
+        base = cpu_baseline_icp(scans, d, thr, (4.0, 4.0 + width), n_points, poses=[icp.get_result_global_T_cloud(i) for i in range(2)],
+                                first_iteration=args.warmup)
+    del scans
+    torch.cuda.empty_cache()
+    dt, tot, warm, recs, per_rank = run_icp(e3d, R, icp, d, thr, args.warmup, args.steps, warmed=True)
     K = args.steps
     corr, queries = tot[0], tot[1]
     lm_ms, nn_ms, passes = tot[2] / world, tot[3] / world, tot[4] / world
@@ -227,12 +243,18 @@ def leg_terrace(e3d, synth, R, args, dev, partial=False):
     lm_full_ms, full_passes = tot[8] / world, tot[9] / world
     lm_avg, nn_avg = lm_full_ms / max(full_passes, 1), nn_ms / n_nn_launch
     multi_ms, multi_passes = lm_ms - lm_full_ms, tot[22] / world
+    rows_rewritten, rows_walked, multi_poses, passes_skipped = tot[23] / world, tot[24] / world, tot[25] / world, tot[26] / world
+    lm_moved = 48.0 * rows_walked / K       # what a pass READS: three float4 per row it walks (resident rows: incl. the zero rows of listed groups)
     kernels = {
-        "k_lm_pass": {"what": "k_lm_pass<1>: fused cost + Gramian pass over the correspondence planes (a7/a8); %.2f launches per iteration"
-                              % (full_passes / K),
+        "k_lm_pass": {"what": "k_lm_pass<1>: fused cost + Gramian pass over the correspondence rows (a7/a8); %.2f launches per iteration; "
+                              "`algorithmic` = SURVEY 8(d)'s 56 B per correspondence, `moved` = the 48 B per row the pass reads" % (full_passes / K),
                       "algorithmic_bytes_per_launch": lm_bytes, "avg_launch_ms": lm_avg, "GBs": lm_bytes / (lm_avg * 1e-3) / 1e9 if lm_avg > 0 else None,
+                      "moved_bytes_per_launch": lm_moved, "GBs_moved": lm_moved / (lm_avg * 1e-3) / 1e9 if lm_avg > 0 else None,
+                      "frac_moved": lm_moved / (lm_avg * 1e-3) / 1e9 / HBM_PEAK_GBS if lm_avg > 0 else None,
                       "summed_ms_per_iter": lm_full_ms / K},
-        "k_lm_cost_multi": {"what": "the costs of LM tries 1..9 in one pass over the planes (a8); %.2f launches per iteration" % (multi_passes / K),
+        "k_lm_cost_multi": {"what": "the costs of the DISTINCT new poses among LM tries 1..9 in one pass over the rows (a8); %.2f launches per iteration, "
+                                    "%.2f poses per launch; %.2f passes per iteration not launched at all (every pose asked for already evaluated)"
+                                    % (multi_passes / K, multi_poses / max(multi_passes, 1), passes_skipped / K),
                             "algorithmic_bytes_per_launch": lm_bytes, "avg_launch_ms": multi_ms / multi_passes if multi_passes else None,
                             "GBs": lm_bytes / (multi_ms / multi_passes * 1e-3) / 1e9 if multi_passes and multi_ms > 0 else None,
                             "summed_ms_per_iter": multi_ms / K},
@@ -258,14 +280,16 @@ def leg_terrace(e3d, synth, R, args, dev, partial=False):
     kernels["k_transform_bbox"] = stream_kernel("a3: the cloud whose pose changed into the global frame + bounding box, 32 B per point moved (impl cloud 0 never "
                                                 "moves and is not transformed again)", tot[5] / world, K, 32.0 * n_rank)
     kernels["query_keys_and_sort"] = stream_kernel("cell keys + rocPRIM radix sort of the queries the row kernel searches (a5 prep)", tot[19] / world, max(tot[17] / world, 1), None)
-    kernels["match_scan"] = stream_kernel("per-block match counts + 3 scan kernels (order-preserving compaction, first stage): 8 B per query", tot[20] / world, n_nn_launch,
-                                          8.0 * queries / world / n_nn_launch)
-    kernels["k_compact_corr"] = stream_kernel("gathers source / target point + normal of every match and writes the 48 B planes: 4 B per query + 116 B per correspondence",
-                                              tot[21] / world, n_nn_launch, (4.0 * queries + 116.0 * corr) / world / n_nn_launch)
+    kernels["match_scan"] = stream_kernel("totals of the per-block match counts / distance sums + the list of active 64-row groups (3 small kernels per pair)",
+                                          tot[20] / world, n_nn_launch, None)
+    kernels["k_corr_update"] = stream_kernel("resident correspondence rows brought up to date: match, encoded partner and distance of every query (12 B) + "
+                                             "116 B per row whose partner changed (%.3g rows of %.3g per launch); with E3D_ICP_RESIDENT=0: k_compact_corr, every row"
+                                             % (rows_rewritten / n_nn_launch, queries / world / n_nn_launch),
+                                             tot[21] / world, n_nn_launch, (12.0 * queries / world + 116.0 * rows_rewritten) / n_nn_launch)
     accounted = sum((v["summed_ms_per_iter"] or 0.0) for v in kernels.values())
     kernels["nn_search_per_pair"] = {"what": "certify + bounded + rows per directed pair: 32 B per query of the pair", "algorithmic_bytes_per_launch": nn_bytes, "avg_launch_ms": nn_avg,
                                      "GBs": nn_bytes / (nn_avg * 1e-3) / 1e9 if nn_avg > 0 else None, "summed_ms_per_iter": nn_ms / K}
-    dom = max(("k_lm_pass", "k_lm_cost_multi", "k_nn_certify", "k_nn_bounded", "k_nn_rows", "k_compact_corr"), key=lambda k: kernels[k]["summed_ms_per_iter"] or 0.0)
+    dom = max(("k_lm_pass", "k_lm_cost_multi", "k_nn_certify", "k_nn_bounded", "k_nn_rows", "k_corr_update"), key=lambda k: kernels[k]["summed_ms_per_iter"] or 0.0)
     traffic, traffic_src = load_traffic({"k_lm_pass": "k_lm_pass<1>"}.get(dom, dom)) if (world == 1 and n_points == 50_000_000 and not partial) else (None, None)
     ach = kernels[dom]["GBs"] or 0.0
     # settling / steady split: the first timed steps still re-search most queries (the poses move); "steady" = the steps whose NN
@@ -284,6 +308,7 @@ def leg_terrace(e3d, synth, R, args, dev, partial=False):
                    "matched_fraction": corr / max(queries, 1),
                    "parallelism": "dp%d over source-point slices, RCCL all-reduce of the 6x6 normal-equation blocks" % world},
         "ms_per_iter": dt / K * 1e3, "nn_queries_per_s": queries / dt, "lm_passes_per_iter": passes / K,
+        "corr_rows_rewritten_per_iter": rows_rewritten / K, "corr_rows_walked_per_pass": rows_walked / K,
         "ms_per_step_each": wall,
         "ms_per_step_settling": float(np.mean(wall[:first_steady])) if first_steady > 0 else None,
         "ms_per_step_steady": float(np.mean(wall[first_steady:])), "steady_from_timed_step": first_steady,
@@ -293,6 +318,7 @@ def leg_terrace(e3d, synth, R, args, dev, partial=False):
                                   "nn_query_kernels_per_timed_iteration": nnq,
                                   "warmup_nn_query_kernels": [r["t_nn_query_ms"] for r in warm]},
         "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                     "frac_of_bytes_moved": kernels[dom].get("frac_moved"),
                      "traffic": traffic, "traffic_source": traffic_src, "kernel": dom + ": " + kernels[dom]["what"],
                      "algorithmic_bytes_per_launch": kernels[dom]["algorithmic_bytes_per_launch"], "avg_launch_ms": kernels[dom]["avg_launch_ms"],
                      "note": "dominant kernel = largest summed HIP-event duration in the timed region; `kernels` lists every kernel group of the step "

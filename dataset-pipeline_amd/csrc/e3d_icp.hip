@@ -535,7 +535,7 @@ static void find_pair(e3d_icp* h, Cloud& src, Cloud& tgt, float d, PairJob& job,
   h->match_d2.reserve(n);
   const size_t nb = div_up(n, kBlock);
   h->block_counts.reserve(nb); h->block_offsets.reserve(nb); h->block_d2.reserve(nb);
-  h->d_total.reserve(2); h->d_total_d2.reserve(1); h->h_total.reserve(2); h->h_total_d2.reserve(1);
+  h->d_total.reserve(3); h->d_total_d2.reserve(1); h->h_total.reserve(3); h->h_total_d2.reserve(1);
   if (!h->nn_timer) h->nn_timer.reset(new EventTimer());
   // dense data (many points per cell): queries sorted by target cell + the LDS-bucket kernels; sparse data: one thread per
   // query.  All are exact and return identical results.  The default row kernel keeps a per-query certificate between the
@@ -669,16 +669,17 @@ static void find_pair(e3d_icp* h, Cloud& src, Cloud& tgt, float d, PairJob& job,
       ps.rows_valid = true;
     }
     h->block_groups.reserve(nb); h->chunk_groups.reserve(div_up(nb, 256) + 1);
+    E3D_HIP(hipMemsetAsync(h->d_total.p + 2, 0, sizeof(unsigned long long), s));
     h->tm_compact.start(s);
     launch_corr_update(ps.match.p, ps.plane_match.p, h->match_d2.p, n, (sg ? src.G4.p : src.L4.p) + j0, srcLN, sg, to_affine(src.T),
                        tg ? tgt.G4.p : tgt.L4.p, tgt.LN.p, tg, to_affine(tgt.T), ps.pA.p, ps.pB.p, ps.pC.p, h->block_counts.p,
-                       h->block_d2.p, h->block_groups.p, s);
+                       h->block_d2.p, h->block_groups.p, h->d_total.p + 2, s);
     h->tm_compact.stop(s);
     h->tm_scan.start(s);
     launch_corr_totals(n, h->block_counts.p, h->block_d2.p, h->block_groups.p, h->chunk_sum.p, h->chunk_d2.p, h->chunk_groups.p,
                        h->d_total.p, h->d_total_d2.p, ps.glist.p, s);
     h->tm_scan.stop(s);
-    copy_out(h->h_total.p + 1, h->d_total.p + 1, sizeof(unsigned long long), s);
+    copy_out(h->h_total.p + 1, h->d_total.p + 1, 2 * sizeof(unsigned long long), s);
   } else {
   h->tm_scan.start(s);
   launch_match_scan(match_pos, h->match_d2.p, n, h->block_counts.p, h->block_offsets.p, h->block_d2.p,
@@ -703,6 +704,8 @@ static void find_pair(e3d_icp* h, Cloud& src, Cloud& tgt, float d, PairJob& job,
   if (rstate) {
     job.resident = rstate;
     job.vrows = 64 * (long long)h->h_total.p[1];
+    rec.corr_rows_rewritten += (long long)h->h_total.p[2];
+    rec.corr_rows_walked += job.vrows;
     return;
   }
   if (job.count == 0) return;
@@ -719,6 +722,8 @@ static void find_pair(e3d_icp* h, Cloud& src, Cloud& tgt, float d, PairJob& job,
                       h->corr_used, s);   // the merged fixed cloud keeps T = identity (exact)
   h->tm_compact.stop(s);
   h->corr_used = need;
+  rec.corr_rows_rewritten += job.count;
+  rec.corr_rows_walked += job.count;
 }
 
 // number of LM blocks for a set of n correspondences in a system of n_sets sets (deterministic function of the two).  Every
@@ -1380,7 +1385,7 @@ int64_t e3d_find_correspondences(const float* sxyz, size_t ns, const float* txyz
       copy_out(sq_distance, out_d2.p, sizeof(float) * ns, s);
       const size_t nb = div_up(ns, kBlock);
       h->block_counts.reserve(nb); h->block_offsets.reserve(nb); h->block_d2.reserve(nb);
-      h->d_total.reserve(1); h->d_total_d2.reserve(1); h->h_total.reserve(1);
+      h->d_total.reserve(3); h->d_total_d2.reserve(1); h->h_total.reserve(3);
       h->chunk_sum.reserve(div_up(nb, 256) + 1); h->chunk_d2.reserve(div_up(nb, 256) + 1);
       launch_match_scan(h->match_pos.p, h->match_d2.p, ns, h->block_counts.p, h->block_offsets.p, h->block_d2.p, h->chunk_sum.p, h->chunk_d2.p, h->d_total.p, h->d_total_d2.p, s);
       copy_out(h->h_total.p, h->d_total.p, sizeof(unsigned long long), s);

@@ -1751,12 +1751,15 @@ __global__ __launch_bounds__(kBlock) void k_corr_update(const int* __restrict__ 
                                                         const float4* __restrict__ LNtgt, const int tgt_global, Affine Ttgt,
                                                         float4* __restrict__ A, float4* __restrict__ B, float4* __restrict__ C,
                                                         unsigned* __restrict__ block_counts, double* __restrict__ block_d2,
-                                                        unsigned* __restrict__ block_groups) {
+                                                        unsigned* __restrict__ block_groups,
+                                                        unsigned long long* __restrict__ rewritten) {
   const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool in = j < n;
   const int m = in ? ld_stream(match + j) : -1;
   const int pm = in ? ld_stream(plane_match + j) : -1;
   const bool f = m >= 0;
+  const unsigned long long chg = __ballot(in && m != pm);
+  if (chg && (threadIdx.x & 63) == 0) atomicAdd(rewritten, (unsigned long long)__popcll(chg));     // (statistics: rows rewritten)
   if (in && m != pm) {
     float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra, rc = ra;
     if (f) {
@@ -2612,10 +2615,12 @@ void launch_compact_corr(const int* match_pos, const unsigned* order, size_t n, 
 
 void launch_corr_update(const int* match, int* plane_match, const float* match_d2, size_t n, const float4* Psrc, const float4* LNsrc,
                         bool src_global, const Affine& Tsrc, const float4* Ptgt, const float4* LNtgt, bool tgt_global, const Affine& Ttgt,
-                        float4* A, float4* B, float4* C, unsigned* block_counts, double* block_d2, unsigned* block_groups, hipStream_t s) {
+                        float4* A, float4* B, float4* C, unsigned* block_counts, double* block_d2, unsigned* block_groups,
+                        unsigned long long* rewritten, hipStream_t s) {
   if (!n) return;
   hipLaunchKernelGGL(k_corr_update, dim3((unsigned)div_up(n, kBlock)), dim3(kBlock), 0, s, match, plane_match, match_d2, n, Psrc,
-                     LNsrc, src_global ? 1 : 0, Tsrc, Ptgt, LNtgt, tgt_global ? 1 : 0, Ttgt, A, B, C, block_counts, block_d2, block_groups);
+                     LNsrc, src_global ? 1 : 0, Tsrc, Ptgt, LNtgt, tgt_global ? 1 : 0, Ttgt, A, B, C, block_counts, block_d2, block_groups,
+                     rewritten);
 }
 
 void launch_corr_totals(size_t n, const unsigned* block_counts, const double* block_d2, const unsigned* block_groups,

@@ -35,7 +35,7 @@ extern "C" {
  * 3: e3d_icp_iter_record grew by t_nn_sort_ms / t_nn_scan_ms / t_nn_compact_ms; e3d_comm_abort, e3d_reg_profile,
  *    e3d_icp_set_sequential_distance_sum (round 3)
  * 4: e3d_icp_set_resident_rows, e3d_comm_get_stats; iteration record: multi_cost_poses, lm_passes_skipped in the two reserved
- *    words (round 4) */
+ *    words, corr_rows_rewritten / corr_rows_walked appended (round 4) */
 #define E3D_ABI_VERSION 4
 
 #define E3D_ERR_INVALID   (-2)   /* bad argument / bad handle state          */
@@ -133,7 +133,11 @@ typedef struct {
   /* ABI 3: the rest of the NN phase, so that the per-kernel times add up to the step (HIP events) */
   double  t_nn_sort_ms;      /* query keys + radix sort of the queries the row kernel searches */
   double  t_nn_scan_ms;      /* match counts + scans (order-preserving compaction, first stage) */
-  double  t_nn_compact_ms;   /* k_compact_corr: the correspondence planes                      */
+  double  t_nn_compact_ms;   /* k_compact_corr / k_corr_update: the correspondence rows        */
+  /* ABI 4 */
+  int64_t corr_rows_rewritten; /* correspondence rows (48 B) written this iteration: every correspondence with compacted rows, the
+                                  rows whose partner changed with resident rows                                        */
+  int64_t corr_rows_walked;    /* rows one LM pass reads: the correspondences, or 64 x the active row groups of resident rows */
 } e3d_icp_iter_record;
 
 size_t e3d_icp_num_pair_records(const e3d_icp_t* icp);

@@ -668,12 +668,11 @@ static void find_pair(e3d_icp* h, Cloud& src, Cloud& tgt, float d, PairJob& job,
       std::memcpy(ps.src_T, src.T, sizeof ps.src_T); std::memcpy(ps.tgt_T, tgt.T, sizeof ps.tgt_T);
       ps.rows_valid = true;
     }
-    h->block_groups.reserve(nb); h->chunk_groups.reserve(div_up(nb, 256) + 1);
-    E3D_HIP(hipMemsetAsync(h->d_total.p + 2, 0, sizeof(unsigned long long), s));
+    h->block_groups.reserve(nb); h->chunk_groups.reserve(2 * (div_up(nb, 256) + 1));
     h->tm_compact.start(s);
     launch_corr_update(ps.match.p, ps.plane_match.p, h->match_d2.p, n, (sg ? src.G4.p : src.L4.p) + j0, srcLN, sg, to_affine(src.T),
                        tg ? tgt.G4.p : tgt.L4.p, tgt.LN.p, tg, to_affine(tgt.T), ps.pA.p, ps.pB.p, ps.pC.p, h->block_counts.p,
-                       h->block_d2.p, h->block_groups.p, h->d_total.p + 2, s);
+                       h->block_d2.p, h->block_groups.p, s);
     h->tm_compact.stop(s);
     h->tm_scan.start(s);
     launch_corr_totals(n, h->block_counts.p, h->block_d2.p, h->block_groups.p, h->chunk_sum.p, h->chunk_d2.p, h->chunk_groups.p,
@@ -910,6 +909,7 @@ static void lm_prepare(e3d_icp* h, LmSystem& L, std::vector<PairJob>& jobs, int 
         const Cloud& src = (j->src == M) ? *h->fixed : *h->clouds[j->src];
         const Cloud& tgt = (j->tgt == M) ? *h->fixed : *h->clouds[j->tgt];
         S.A = ps.pA.p; S.B = ps.pB.p; S.C = ps.pC.p; S.glist = ps.glist.p; S.n = j->vrows;
+        if ((size_t)j->vrows == resident_rows_cap(ps.n)) S.glist = nullptr;      // every group is listed: rows [0, n) as they lie
         S.outer = (ps.src_global ? 0 : 1) | (ps.tgt_global ? 0 : 2);
         S.Tos = to_affine(src.T); S.Tot = to_affine(tgt.T);
       } else {

@@ -133,11 +133,11 @@ void launch_lm_cost_multi(const LmSet* sets, const LmPose* poses, int n_sets, in
 // Resident rows of one directed pair (see LmSet): rewrites the rows whose partner changed since the planes were last brought up
 // to date (plane_match = the partner each row encodes, -1 zero row, anything else below -1 = never written), and produces the
 // per-block match counts / squared-distance sums (same arithmetic as launch_match_scan) plus the number of active 64-row groups
-// per block (*rewritten += rows rewritten); launch_corr_totals then yields totals[0] = correspondences, totals[1] = active groups, total_d2 and the group list.
+// per block; launch_corr_totals then yields totals[0] = correspondences, totals[1] = active groups, totals[2] = rows rewritten
+// (chunk_groups: 2 x the number of 256-block chunks), total_d2 and the group list.
 void launch_corr_update(const int* match, int* plane_match, const float* match_d2, size_t n, const float4* Psrc, const float4* LNsrc,
                         bool src_global, const Affine& Tsrc, const float4* Ptgt, const float4* LNtgt, bool tgt_global, const Affine& Ttgt,
-                        float4* A, float4* B, float4* C, unsigned* block_counts, double* block_d2, unsigned* block_groups,
-                        unsigned long long* rewritten, hipStream_t s);
+                        float4* A, float4* B, float4* C, unsigned* block_counts, double* block_d2, unsigned* block_groups, hipStream_t s);
 void launch_corr_totals(size_t n, const unsigned* block_counts, const double* block_d2, const unsigned* block_groups,
                         unsigned long long* chunk_sum, double* chunk_d2, unsigned* chunk_groups, unsigned long long* totals,
                         double* total_d2, unsigned* glist, hipStream_t s);

@@ -25,6 +25,11 @@ __global__ __launch_bounds__(kBlock, MINW) void k_var(const LmSet* __restrict__ 
                                                       double* __restrict__ partial) {
   lm_pass_body<MODE, UNR, PF>(sets, block_set, block_base, partial);
 }
+template <int MODE, int MINW>
+__global__ __launch_bounds__(kBlock, MINW) void k_res(const LmSet* __restrict__ sets, const int* __restrict__ block_set, int block_base,
+                                                      double* __restrict__ partial) {
+  lm_pass_body<MODE, 1, true>(sets, block_set, block_base, partial);
+}
 template <bool PF, int MINW>
 __global__ __launch_bounds__(kBlock, MINW) void k_cm(const LmSet* __restrict__ sets, const LmPose* __restrict__ poses, int n_sets, int n_poses,
                                                      const int* __restrict__ block_set, double* __restrict__ partial) {
@@ -142,8 +147,15 @@ int main(int argc, char** argv) {
       run(name, 1, 0, [&] { hipLaunchKernelGGL(k_lm_cost_multi, dim3(block), dim3(kBlock), 0, 0, dsets, dposes, ns, kLmMaxPoses, dbs, part); }, !list && outer == 0);
     };
     printf("-- product kernels, set lengths rounded down to 64 rows --\n");
-    res("compacted", 0, false); res("resident outer=0", 0, true); res("resident outer=src", 1, true); res("resident outer=tgt", 2, true);
+    res("compacted", 0, false); res("dense outer=src", 1, false); res("dense outer=tgt", 2, false); res("resident outer=0", 0, true); res("resident outer=src", 1, true); res("resident outer=tgt", 2, true);
     res("resident outer=both", 3, true);
+    // occupancy of the group walk (mode 1, outer = src)
+    for (int i = 0; i < ns; ++i) { sets[i].glist = gl; sets[i].outer = 1; }
+#define RM(MINW) run("mode1 resident outer=src minw" #MINW, 1, 0, [&] { hipLaunchKernelGGL((k_res<1, MINW>), dim3(block), dim3(kBlock), 0, 0, dsets, dbs, 0, part); }, MINW == 1)
+    RM(1); RM(2); RM(3); RM(4);
+    for (int i = 0; i < ns; ++i) { sets[i].glist = nullptr; }
+#define RD(MINW) run("mode1 dense outer=src minw" #MINW, 1, 0, [&] { hipLaunchKernelGGL((k_res<1, MINW>), dim3(block), dim3(kBlock), 0, 0, dsets, dbs, 0, part); }, false)
+    RD(1); RD(2); RD(3); RD(4);
   }
   return 0;
 }

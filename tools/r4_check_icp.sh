@@ -1,17 +1,17 @@
 #!/bin/bash
 # Round 4, first GPU pass: ICP parity tests, the ICP bench legs with resident and with compacted rows, LM loop micro-benchmark.
-O=gpurun_out/r4a; mkdir -p $O
-timeout 1200 python -m pytest tests/test_gpu_icp.py tests/test_gpu_cli.py tests/test_gpu_multiprocess.py tests/test_gpu_distributed.py -x -q -m gpu --durations=6 > $O/pytest_icp.txt 2>&1; echo "pytest rc=$?"
+O=gpurun_out/${R4TAG:-r4a}; mkdir -p $O
+timeout 1500 python -m pytest tests -q -m gpu --durations=6 > $O/pytest_icp.txt 2>&1; echo "pytest rc=$?"
 grep -E "passed|failed|error" $O/pytest_icp.txt | tail -3
 timeout 600 python bench.py --no-cpu-baseline --no-reg --no-normals --no-allpairs > $O/bench_icp.json 2> $O/bench_icp.err; echo "bench rc=$?"
 E3D_ICP_RESIDENT=0 timeout 600 python bench.py --no-cpu-baseline --no-reg --no-normals --no-allpairs --no-partial > $O/bench_icp_compacted.json 2> $O/bench_icp_compacted.err; echo "bench compacted rc=$?"
 timeout 300 tools/micro/lm_variants 100 2 > $O/lm_variants_2sets.txt 2>&1; echo "lm_variants rc=$?"
-tail -22 $O/lm_variants_2sets.txt
+tail -36 $O/lm_variants_2sets.txt
 python - <<'PY'
 import json
 for f in ("bench_icp", "bench_icp_compacted"):
     try:
-        d = json.loads(open("gpurun_out/r4a/%s.json" % f).read().strip().splitlines()[-1])
+        d = json.loads(open("gpurun_out/" + __import__("os").environ.get("R4TAG", "r4a") + "/%s.json" % f).read().strip().splitlines()[-1])
     except Exception as e:
         print(f, "unreadable", e); continue
     print(f, "ms/step %.3f settling %s steady %.3f" % (d["ms_per_step"], d.get("ms_per_step_settling"), d["ms_per_step_steady"]))

@@ -990,7 +990,11 @@ static void lm_compute(e3d_icp* h, LmSystem& L, std::vector<SE3f>& poses, e3d_ic
         for (size_t q = 0; q < distinct.size() && slot[k] < 0; ++q) if (same_poses(cand[k], distinct[q])) slot[k] = (int)q;
         if (slot[k] < 0) { slot[k] = (int)distinct.size(); distinct.push_back(cand[k]); }
       }
-      if (!distinct.empty()) { lm_evaluate_costs(h, L, distinct, dcosts, rec); rec.multi_cost_poses += (int)distinct.size(); }
+      if (distinct.size() == 1) {          // one new pose: the plain cost pass (HBM bound; same bits)
+        std::vector<double> Hx, bx;
+        dcosts.assign(1, 0.0);
+        lm_evaluate(h, L, distinct[0], false, Hx, bx, dcosts[0], rec);
+      } else if (!distinct.empty()) { lm_evaluate_costs(h, L, distinct, dcosts, rec); rec.multi_cost_poses += (int)distinct.size(); }
       else rec.lm_passes_skipped++;
       for (int k = 0; k < 9; ++k) costs[k] = (slot[k] < 0) ? cost : dcosts[slot[k]];
       int hit = -1;

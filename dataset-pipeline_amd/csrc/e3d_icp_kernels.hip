@@ -2275,28 +2275,15 @@ __global__ __launch_bounds__(kBlock, LmCfg<MODE>::minw) void k_lm_pass(const LmS
 // early-out after the first few tries would not save it.)  Nine poses are 9 x 80 f32 operations per correspondence, VALU
 // bound; the side of a kModeOne pair that has no variables (impl cloud 0, the same inner pose in every candidate) is transformed
 // once instead of nine times.
-template <typename T, typename V4>
-__device__ __forceinline__ void lm_costs_of(const LmSet& S, const LmPose* __restrict__ poses, const int n_sets, const int n_poses,
-                                            const int si, const V4& a, const V4& b, const V4& c, T* r1, T* r2) {
-  const bool fixed_tgt = (S.mode == kModeOne && S.side == 0), fixed_src = (S.mode == kModeOne && S.side == 1);
-  CorrPts<T> F;
-  if (fixed_tgt) corr_tgt<T>(S.Rt, S.tt, b.z, b.w, c.x, c.y, c.z, c.w, F);
-  if (fixed_src) corr_src<T>(S.Rs, S.ts, a.x, a.y, a.z, a.w, b.x, b.y, F);
-#pragma unroll
-  for (int k = 0; k < kLmMaxPoses; ++k) {
-    if (k < n_poses) {
-      const LmPose& P = poses[(size_t)k * n_sets + si];
-      CorrPts<T> Q = F;
-      if (!fixed_src) corr_src<T>(P.Rs, P.ts, a.x, a.y, a.z, a.w, b.x, b.y, Q);
-      if (!fixed_tgt) corr_tgt<T>(P.Rt, P.tt, b.z, b.w, c.x, c.y, c.z, c.w, Q);
-      CorrRowsT<T> R;
-      corr_rows_pts<false, false, T>(Q, R);
-      r1[k] = R.r1; r2[k] = R.r2;
-    }
-  }
-}
+// Round 4: the body takes U rows per trip with the POSES in the outer loop (a pose set is 24 scalar words, x 9 far more than the
+// scalar registers hold, so the poses are fetched again for every trip).  Measured (tools/micro/lm_variants.hip, 1e8 rows, nine
+// poses): U = 1 1.41 ms, 2 1.49 - 1.55, 3 1.52, 4 1.60 - 1.66 -- the pass is bound by its f32 instructions (0.12 ms per pose and
+// 1e8 rows = the chip's f32 issue rate for the ~55 operations of a pose), not by the scalar fetches, and more rows per trip only
+// cost occupancy (102 / 139 / 176 VGPRs).  U = 1 it stays.  Per pose a thread adds its rows in the order c, c + stride, ... and row
+// by row r1^2 then r2^2: the same sums as k_lm_pass<kModeCost>.
+constexpr int kLmCmRows = 1;
 
-template <bool PF>
+template <bool PF, int U = kLmCmRows>
 __device__ __forceinline__ void lm_cost_multi_body(const LmSet* __restrict__ sets, const LmPose* __restrict__ poses, int n_sets,
                                                    int n_poses, const int* __restrict__ block_set, double* __restrict__ partial) {
   const int gb = blockIdx.x;
@@ -2309,38 +2296,62 @@ __device__ __forceinline__ void lm_cost_multi_body(const LmSet* __restrict__ set
   const lm_rows_ptr pa = (lm_rows_ptr)S.A, pb = (lm_rows_ptr)S.B, pc = (lm_rows_ptr)S.C;
   const lm_glist_ptr gl = (lm_glist_ptr)S.glist;
   const long long lane64 = threadIdx.x & 63;
-  long long c = (long long)(gb - S.block_begin) * kBlock + threadIdx.x;
-  auto trip = [&](float4 a, float4 b, float4 cc) {
-    row_to_global(S, a, b, cc);
-    float r1[kLmMaxPoses], r2[kLmMaxPoses];
-    lm_costs_of<float>(S, poses, n_sets, n_poses, si, a, b, cc, r1, r2);
+  const bool fixed_tgt = (S.mode == kModeOne && S.side == 0), fixed_src = (S.mode == kModeOne && S.side == 1);
+  // U rows (valid[u]: the row exists; the others were loaded from a clamped address and add +0.0, which leaves a sum of squares
+  // unchanged bit for bit) through every pose
+  auto trip = [&](float4* a, float4* b, float4* cc, const bool* valid) {
+    CorrPts<float> F[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      row_to_global(S, a[u], b[u], cc[u]);
+      if (fixed_tgt) corr_tgt<float>(S.Rt, S.tt, b[u].z, b[u].w, cc[u].x, cc[u].y, cc[u].z, cc[u].w, F[u]);
+      if (fixed_src) corr_src<float>(S.Rs, S.ts, a[u].x, a[u].y, a[u].z, a[u].w, b[u].x, b[u].y, F[u]);
+    }
 #pragma unroll
     for (int k = 0; k < kLmMaxPoses; ++k) {
-      if (k < n_poses) { acc[k] += (double)(r1[k] * r1[k]); acc[k] += (double)(r2[k] * r2[k]); }
+      if (k < n_poses) {
+        const LmPose& P = poses[(size_t)k * n_sets + si];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          CorrPts<float> Q = F[u];
+          if (!fixed_src) corr_src<float>(P.Rs, P.ts, a[u].x, a[u].y, a[u].z, a[u].w, b[u].x, b[u].y, Q);
+          if (!fixed_tgt) corr_tgt<float>(P.Rt, P.tt, b[u].z, b[u].w, cc[u].x, cc[u].y, cc[u].z, cc[u].w, Q);
+          CorrRowsT<float> R;
+          corr_rows_pts<false, false, float>(Q, R);
+          acc[k] += valid[u] ? (double)(R.r1 * R.r1) : 0.0;
+          acc[k] += valid[u] ? (double)(R.r2 * R.r2) : 0.0;
+        }
+      }
     }
   };
-  float4 a0, b0, c0;
-  if (gl) {      // resident rows: the walk of lm_pass_body
+  float4 a[U], b[U], cc[U];
+  bool valid[U];
+  if (gl) {      // resident rows: whole 64-row groups per wave, wave-uniform control (lm_pass_body)
     const int ng = (int)(S.n >> 6), gstride = S.nblocks * (kBlock / kWave);
     int gw = __builtin_amdgcn_readfirstlane((gb - S.block_begin) * (kBlock / kWave) + (int)(threadIdx.x >> 6));
-    unsigned g0 = (gw < ng) ? gl[gw] : 0u, g1 = (gw + gstride < ng) ? gl[gw + gstride] : 0u;
-    if (gw < ng) { const long long r = ((long long)g0 << 6) | lane64; a0 = ld_row(pa, r); b0 = ld_row(pb, r); c0 = ld_row(pc, r); }
     while (gw < ng) {
-      const float4 a = a0, b = b0, cc = c0;
-      gw += gstride;
-      g0 = g1;
-      if (gw + gstride < ng) g1 = gl[gw + gstride];
-      if (gw < ng) { const long long r = ((long long)g0 << 6) | lane64; a0 = ld_row(pa, r); b0 = ld_row(pb, r); c0 = ld_row(pc, r); }
-      trip(a, b, cc);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int gi = gw + u * gstride;
+        valid[u] = gi < ng;
+        const long long r = ((long long)gl[valid[u] ? gi : gw] << 6) | lane64;
+        a[u] = ld_row(pa, r); b[u] = ld_row(pb, r); cc[u] = ld_row(pc, r);
+      }
+      trip(a, b, cc, valid);
+      gw += U * gstride;
     }
   } else {
-    if (PF && c < S.n) { a0 = ld_row(pa, c); b0 = ld_row(pb, c); c0 = ld_row(pc, c); }
+    long long c = (long long)(gb - S.block_begin) * kBlock + threadIdx.x;
     while (c < S.n) {
-      if (!PF) { a0 = ld_row(pa, c); b0 = ld_row(pb, c); c0 = ld_row(pc, c); }
-      const float4 a = a0, b = b0, cc = c0;
-      c += stride;
-      if (PF && c < S.n) { a0 = ld_row(pa, c); b0 = ld_row(pb, c); c0 = ld_row(pc, c); }
-      trip(a, b, cc);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const long long ci = c + u * stride;
+        valid[u] = ci < S.n;
+        const long long r = valid[u] ? ci : c;
+        a[u] = ld_row(pa, r); b[u] = ld_row(pb, r); cc[u] = ld_row(pc, r);
+      }
+      trip(a, b, cc, valid);
+      c += U * stride;
     }
   }
   __shared__ double s[kBlock / kWave][kLmMaxPoses];

@@ -229,6 +229,24 @@ def normals(xyz, k=0, radius=-1.0, viewpoint=(0, 0, 0), return_knn=False):
     return (on, oc, knn) if return_knn else (on, oc)
 
 
+def normals_sample(xyz, sample, k=0, radius=-1.0, viewpoint=(0, 0, 0)):
+    """Normals / curvature / kNN lists of the points `sample` (indices) of the cloud, searched in the WHOLE cloud."""
+    xyz = _c32(xyz)
+    sample = np.ascontiguousarray(sample, np.int64)
+    m = sample.shape[0]
+    vp = np.ascontiguousarray(viewpoint, np.float32)
+    on = np.zeros((m, 3), np.float32); oc = np.zeros(m, np.float32)
+    knn = np.zeros((m, max(k, 1)), np.int32)
+    f = lib().oracle_normals_sample
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
+    r = f(xyz.ctypes.data, xyz.shape[0], int(k), float(radius), vp.ctypes.data, sample.ctypes.data, m, on.ctypes.data, oc.ctypes.data,
+          knn.ctypes.data if k > 0 else None)
+    if r != 0:
+        raise ValueError("oracle_normals_sample: need k>0 or radius>0")
+    return on, oc, knn
+
+
 def libm_eval(fn, x, y=None):
     """include/e3d_libm.h evaluated on the host; fn in {"atanf", "atan2f", "sinf", "cosf", "tanf", "log2f"} (atan2f(x, y): x is the
     first argument, y the second)."""

@@ -149,21 +149,25 @@ static inline void flip_towards(const float* p, const float* vp, float* n) {
   if (cos_theta < 0) { n[0] *= -1; n[1] *= -1; n[2] *= -1; }
 }
 
-int oracle_normals(const float* xyz, size_t n, int k, float radius, const float vp[3],
-                   float* out_normal, float* out_curv, int32_t* knn_idx_out) {
-  okd_tree* tree = okd_build(xyz, n);
+/* sample == NULL: every point is a query (outputs indexed by point); else the n_sample listed points are (outputs indexed by
+ * position in the list) -- the same tree over the WHOLE cloud either way, so a sample of a 20 M point scan is checked against
+ * exactly what the full run would return for those points */
+static int normals_impl(const float* xyz, size_t n, int k, float radius, const float vp[3], const int64_t* sample, size_t n_sample,
+                        float* out_normal, float* out_curv, int32_t* knn_idx_out) {
   int use_radius = (radius > 0.f);
   float r2 = 0.f;
   if (use_radius) { double r = (double)radius; r2 = (float)(r * r); }
-  if (!use_radius && k <= 0) { okd_free(tree); return -1; }
+  if (!use_radius && k <= 0) return -1;
+  okd_tree* tree = okd_build(xyz, n);
+  const long long nq = sample ? (long long)n_sample : (long long)n;
 #pragma omp parallel
   {
     int cap = use_radius ? 4096 : k;
     int32_t* idx = (int32_t*)malloc(sizeof(int32_t) * (size_t)cap);
     float* dist = (float*)malloc(sizeof(float) * (size_t)cap);
 #pragma omp for schedule(dynamic, 1024)
-    for (long long i = 0; i < (long long)n; ++i) {
-      const float* q = xyz + 3 * (size_t)i;
+    for (long long i = 0; i < nq; ++i) {
+      const float* q = xyz + 3 * (size_t)(sample ? sample[i] : i);
       int cnt;
       if (use_radius) {
         cnt = okd_radius(tree, q, r2, cap, idx, dist);
@@ -190,6 +194,16 @@ int oracle_normals(const float* xyz, size_t n, int k, float radius, const float 
   }
   okd_free(tree);
   return 0;
+}
+
+/* NormalEstimationTwoPassOMP::computeFeature (src/geometry/two_pass_normal_3d_omp.hpp:48-119) */
+int oracle_normals(const float* xyz, size_t n, int k, float radius, const float vp[3],
+                   float* out_normal, float* out_curv, int32_t* knn_idx_out) {
+  return normals_impl(xyz, n, k, radius, vp, NULL, 0, out_normal, out_curv, knn_idx_out);
+}
+int oracle_normals_sample(const float* xyz, size_t n, int k, float radius, const float vp[3], const int64_t* sample, size_t n_sample,
+                          float* out_normal, float* out_curv, int32_t* knn_idx_out) {
+  return normals_impl(xyz, n, k, radius, vp, sample, n_sample, out_normal, out_curv, knn_idx_out);
 }
 
 void oracle_knn(const float* xyz, size_t n, const float* queries, size_t n_q, int k, int32_t* idx, float* dist) {

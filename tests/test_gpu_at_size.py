@@ -7,6 +7,32 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("k", [32, 8])
+def test_normals_20M_at_size(e3d, ob, synth, k):
+    """The NormalEstimator half of configs[2] at size (src/geometry/two_pass_normal_3d_omp.hpp:48-119 via
+    src/exe/normal_estimator.cc:177-194): e3d_normals_knn on a 20 M point scan -- the dense cell directory with 32-bit keys, the
+    two-pass kernels, the 125-cell retry list and the pooled workspace are the paths only a large cloud takes.  For a random 1e5
+    sample of the points the kNN index lists equal the oracle's kd-tree search over the FULL cloud and normals / curvature are
+    bit-equal; size-independent properties over all 20 M: every point is its own first neighbour, normals are unit vectors turned
+    towards the viewpoint."""
+    import torch
+    n = 20_000_000
+    s = synth.make_scene(1, n, seed=4242, sigma=0.002, device=torch.device("cuda", 0))[0]
+    gn, gc, gk = e3d.normals_knn(s["xyz"], k, (0.0, 0.0, 0.0), return_knn=True)
+    P = s["xyz"].cpu().numpy()
+    sample = np.sort(np.random.RandomState(k).choice(n, 100_000, replace=False))
+    on, oc, ok = ob.normals_sample(P, sample, k=k, viewpoint=(0.0, 0.0, 0.0))
+    assert np.array_equal(gk[sample], ok), "kNN index lists differ"
+    assert not np.isnan(on).any()
+    assert np.array_equal(gn[sample].view(np.uint32), on.view(np.uint32)), np.abs(gn[sample] - on).max()
+    assert np.array_equal(gc[sample].view(np.uint32), oc.view(np.uint32))
+    assert np.array_equal(gk[:, 0], np.arange(n, dtype=np.int32))                  # distance 0 comes first (no duplicates in the scan)
+    ln = np.sqrt((gn.astype(np.float64) ** 2).sum(1))
+    assert np.abs(ln - 1).max() < 1e-5
+    assert ((gn * -P).sum(1) >= -1e-5).all()                                       # flipNormalTowardsViewpoint: (vp - p) . n >= 0
+    # (about 1.4 % of the queries take the 125-cell retry list at this density: some 1 400 of the sample)
+
+
 def test_c3_all_pairs_8x20M_at_size(e3d, ob, synth):
     """configs[2] on ONE GPU: 8 scans x 20 M points, all movable, all 56 directed pairs (42 unknowns), -d 0.01, two outer
     iterations (src/icp/icp_point_to_plane.cc:208-309 at size; the second iteration runs through the certificates).
@@ -21,6 +47,15 @@ def test_c3_all_pairs_8x20M_at_size(e3d, ob, synth):
     n, S, d = 20_000_000, 8, 0.01
     dev = torch.device("cuda", 0)
     scans = synth.make_scene(S - 1, n, seed=777, sigma=0.002, device=dev)
+    # configs[2] as written -- "NormalEstimator + ICPScanAligner": the normals the ICP runs on come from the GPU estimator
+    # (NormalEstimator's default --neighbor_count 8, viewpoint = scan origin, src/exe/normal_estimator.cc:57-58,177-194), not from
+    # the generator; test_normals_20M_at_size ties that estimator to the oracle at this size
+    for s in scans:
+        nrm, _ = e3d.normals_knn(s["xyz"], 8, (0.0, 0.0, 0.0))
+        assert not np.isnan(nrm).any()
+        agree = float((torch.from_numpy(nrm).to(dev) * s["normals"]).sum(dim=1).abs().mean())
+        assert agree > 0.8, agree                                                  # (noisy at k = 8 and 2 mm range noise, but normals)
+        s["normals"] = torch.from_numpy(nrm).to(dev)
     scans.append(dict(scans[0]))                                                   # (ii)
 
     def run():
@@ -82,11 +117,14 @@ np.savez(sys.argv[2], poses=np.stack([np.concatenate(P.get_image_pose(i)) for i 
 '''
 
 
-def _grid_mesh(nx, nz, y, x0, x1, z0, z1):
-    """regular triangulated grid in the plane y = const: nx x nz vertices, 2 (nx - 1)(nz - 1) triangles"""
+def _grid_mesh(nx, nz, y, x0, x1, z0, z1, ripple=0.0):
+    """regular triangulated grid in the plane y = const: nx x nz vertices, 2 (nx - 1)(nz - 1) triangles.  ripple > 0: the surface
+    is y + ripple sin(7 x) cos(5 z) -- neighbouring faces are no longer coplanar, so FilterEdgeList keeps their shared edges."""
     xs = np.linspace(x0, x1, nx, dtype=np.float32); zs = np.linspace(z0, z1, nz, dtype=np.float32)
     V = np.empty((nz, nx, 3), np.float32)
     V[..., 0] = xs[None, :]; V[..., 1] = y; V[..., 2] = zs[:, None]
+    if ripple:
+        V[..., 1] += (np.float32(ripple) * np.sin(np.float32(7.0) * xs)[None, :] * np.cos(np.float32(5.0) * zs)[:, None]).astype(np.float32)
     idx = (np.arange(nz - 1, dtype=np.uint32)[:, None] * np.uint32(nx) + np.arange(nx - 1, dtype=np.uint32)[None, :])
     T = np.empty((nz - 1, nx - 1, 2, 3), np.uint32)
     T[..., 0, 0] = idx; T[..., 0, 1] = idx + 1; T[..., 0, 2] = idx + np.uint32(nx)
@@ -96,10 +134,17 @@ def _grid_mesh(nx, nz, y, x0, x1, z0, z1):
 
 def test_c5_512_images_4k_with_100M_vertex_occlusion_mesh(e3d, rb, synth, tmp_path):
     """configs[4] on ONE GPU: 512 images of 3840 x 2160 (6 pyramid levels), 4 M points, K = 5, and an occlusion mesh of 100 M
-    vertices / 200 M triangles (src/opt/occlusion_geometry.cc:211-271 at size: every observation refresh renders the mesh into
-    every image).
+    vertices / 200 M triangles WITH edge extraction and occlusion-boundary masking (src/opt/occlusion_geometry.cc:211-271,
+    284-335, 488-645 at size: every observation refresh renders the mesh into every image and splats -1 along its visible
+    silhouette and boundary edges).  The wall is rippled by 4 mm so that its faces are not coplanar: ComputeEdgeNormalsList sorts
+    600 M half edges and FilterEdgeList keeps the non-coplanar ones.  (configs[4] says "200M-pt occlusion mesh"; 200 M TRIANGLES
+    is what fits: the 512 image pyramids and observation lists hold 208 GB of the 288 GB, edge extraction of this mesh another
+    ~31 GB -- 600 M sort pairs twice plus 20-byte edge records -- and twice the mesh would need ~70 GB.)
       (i)   mesh depth maps: 16 x 16 pixel tiles of two images equal oracle/mesh_occlusion.py's rasteriser bit for bit (the oracle
             gets the triangles of the grid block behind the tile and the blocker; nothing else projects there);
+      (i-b) boundary masking: around a corner of the blocker's silhouette the masked depth map equals the oracle's
+            MaskOutOcclusionBoundaries applied to the same unmasked map with the oracle's own edge list of the blocker and the wall
+            block behind the tile (the kept edge count of the blocker equals the oracle's);
       (ii)  the blocker in front of the wall removes exactly the observations behind it, in every image;
       (iii) two RunOnCurrentScale iterations over the 3 076 unknowns (the second evaluates the step of the first) run through the
             block-sparse (arrow) normal equations and lower the cost;
@@ -124,12 +169,18 @@ def test_c5_512_images_4k_with_100M_vertex_occlusion_mesh(e3d, rb, synth, tmp_pa
     # 10 000 x 10 000 vertices, and a 0.5 m x 0.4 m blocker 1 m in front of it
     t0 = time.perf_counter()
     nx = nz = 10_000
-    Vw, Tw = _grid_mesh(nx, nz, 3.03, -7.5, 7.5, -4.0, 4.0)
+    Vw, Tw = _grid_mesh(nx, nz, 3.03, -7.5, 7.5, -4.0, 4.0, ripple=0.004)
     assert len(Vw) == 100_000_000 and len(Tw) == 199_960_002
     Vb, Tb = _grid_mesh(50, 50, 2.0, -0.25, 0.25, -0.2, 0.2)
     t_mesh = time.perf_counter() - t0
-    assert P.add_occlusion_mesh(Vw, Tw, compute_edges=False) == 1
-    assert P.add_occlusion_mesh(Vb, Tb, compute_edges=False) == 2
+    t0 = time.perf_counter()
+    assert P.add_occlusion_mesh(Vw, Tw, compute_edges=True) == 1
+    assert P.add_occlusion_mesh(Vb, Tb, compute_edges=True) == 2
+    t_edges = time.perf_counter() - t0
+    n_wall_edges = P.occlusion_edge_count(0)
+    assert 40_000 < n_wall_edges <= 3 * len(Tw)                       # at least the rim; at most every edge
+    be, bn = mo.edge_list(Vb, Tb)
+    assert P.occlusion_edge_count(1) == len(be) and len(be) >= 4 * 49    # the planar blocker: its rim (coplanar interior edges are dropped)
     P.set_occlusion_options(0.05, 100.0, False)
     # (i)
     cam = rb.camera_pyramid(rb.make_camera(W, H, Wl["params"], 0), 1)[0]
@@ -158,6 +209,40 @@ def test_c5_512_images_4k_with_100M_vertex_occlusion_mesh(e3d, rb, synth, tmp_pa
             o = mo.rasterise(qx, qy, qz, Ts[touch], W, H)
             gt, ot = g[ty:ty + 16, tx:tx + 16], o[ty:ty + 16, tx:tx + 16]
             assert (ot > 0).all() and np.array_equal(gt.view(np.uint32), ot.view(np.uint32)), (i, tx, ty, int((gt != ot).sum()))
+    # (i-b)
+    n_masked = 0
+    for i in (3, 300):
+        im = Wl["images"][i]
+        R = quat_to_R(im["q"])
+        P.set_occlusion_options(0.05, 100.0, False)
+        g_plain = P.render_depth(i, 0, (H, W))
+        P.set_occlusion_options(0.05, 100.0, True)
+        g_mask = P.render_depth(i, 0, (H, W))
+        n_masked += int((g_mask == -1).sum())
+        cx, cy, _ = mo.project_vertices(0, cam, R, im["t"], Vb[[0]])           # a corner of the blocker
+        tx, ty = int(cx[0]) - 8, int(cy[0]) - 8
+        assert 100 < tx < W - 100 and 100 < ty < H - 100
+        cs = 25
+        sub = Vw.reshape(nz, nx, 3)[::cs, ::cs].reshape(-1, 3)
+        px, py, z = mo.project_vertices(0, cam, R, im["t"], sub)
+        px = px.reshape(nz // cs, nx // cs); py = py.reshape(nz // cs, nx // cs)
+        near = (px > tx - 50) & (px < tx + 66) & (py > ty - 50) & (py < ty + 66)
+        rows, cols = np.nonzero(near)
+        r0, r1 = max(rows.min() * cs - cs, 0), min(rows.max() * cs + 2 * cs, nz)
+        c0, c1 = max(cols.min() * cs - cs, 0), min(cols.max() * cs + 2 * cs, nx)
+        assert (r1 - r0) * (c1 - c0) < 120_000, (r1 - r0, c1 - c0)               # the oracle's edge list is a Python loop
+        Vs = Vw.reshape(nz, nx, 3)[r0:r1, c0:c1].reshape(-1, 3)
+        _, Ts = _grid_mesh(c1 - c0, r1 - r0, 0.0, 0.0, 1.0, 0.0, 1.0)
+        verts_sub = np.concatenate([Vs, Vb]); tris_sub = np.concatenate([Ts, Tb + np.uint32(len(Vs))])
+        edges, normals = mo.edge_list(verts_sub, tris_sub)
+        assert len(edges) > len(be)                                                # the rippled wall keeps interior edges
+        o_mask = mo.mask_boundaries(g_plain, edges, normals, verts_sub, R, im["t"], cam)
+        gt, ot = g_mask[ty:ty + 16, tx:tx + 16], o_mask[ty:ty + 16, tx:tx + 16]
+        assert (ot == -1).sum() > 20 and (ot != -1).sum() > 20, (i, int((ot == -1).sum()))   # the tile straddles the masked band
+        mism = (gt == -1) != (ot == -1)
+        assert mism.sum() <= 1, (i, tx, ty, int(mism.sum()))
+        assert np.array_equal(gt[~mism].view(np.uint32), ot[~mism].view(np.uint32))
+    assert n_masked > 10_000
     del Vw, Tw
     # (ii)
     t0 = time.perf_counter()
@@ -175,8 +260,9 @@ def test_c5_512_images_4k_with_100M_vertex_occlusion_mesh(e3d, rb, synth, tmp_pa
         # a wall point is hidden iff the segment eye -> point crosses the blocker rectangle in the plane y = 2
         s = (2.0 - eye[1]) / (pts[:, 1].astype(np.float64) - eye[1])
         hx = eye[0] + s * (pts[:, 0] - eye[0]); hz = eye[2] + s * (pts[:, 2] - eye[2])
+        # (the band of 3 cm splats masked along the blocker's rim widens to ~5 cm on the wall behind it: such points are neither)
         inside = (np.abs(hx) < 0.24) & (np.abs(hz) < 0.19)
-        outside = (np.abs(hx) > 0.26) | (np.abs(hz) > 0.21)
+        outside = (np.abs(hx) > 0.32) | (np.abs(hz) > 0.27)
         assert inside.sum() > 1000 and not seen[inside].any(), i
         assert seen[outside].mean() > 0.7, (i, seen[outside].mean())
     # (iii)
@@ -186,6 +272,7 @@ def test_c5_512_images_4k_with_100M_vertex_occlusion_mesh(e3d, rb, synth, tmp_pa
     t_run = time.perf_counter() - t0
     c1 = P.compute_cost()                          # two iterations: the second one evaluates the state the first one's step led to
     free, total = torch.cuda.mem_get_info(0)
+    print("c5 at size: edge extraction of both meshes %.1f s (%d wall edges kept)" % (t_edges, n_wall_edges))
     print("c5 at size: workload %.1f s, mesh arrays %.1f s, observation refresh (512 mesh renders) %.1f s, two RunOnCurrentScale iterations %.1f s, "
           "cost %.9g -> %.9g, HBM in use %.1f GB" % (t_gen, t_mesh, t_obs, t_run, c0, c1, (total - free) / 1e9))
     assert its == 2 and np.isfinite(c1) and c1 < c0 and cost == c1

@@ -1,5 +1,5 @@
 """Per-iteration cost split of an ICP run on two synthetic scans (full-overlap room or the partial-overlap room).
-usage: python tools/r3_trend.py [points_per_scan] [iterations] [partial 0/1] [d]"""
+usage: python tools/icp_trend.py [points_per_scan] [iterations] [partial 0/1] [d]"""
 import importlib, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -19,9 +19,11 @@ for it in range(iters):
     icp.run(d, it, 1, 1e-10, False)
 r = icp.iter_records()
 print("partial" if partial else "full", "scene, 2 x %d points, d = %g" % (n, d))
-print(" it   corr(M)  certify ms (Mq)   bounded ms (Mq)   rows ms (Mq)   nn_other  transform   lm_kernels (full/multi passes)  lm_other")
+print(" it   corr(M)  certify ms (Mq)   bounded ms (Mq)   rows ms (Mq)   sort  scan  rows-upd (M rewritten)  nn_other  transform   lm_kernels full/multi ms (full/multi passes, poses, skipped)  lm_other")
 for x in r:
-    print("%3d  %7.2f   %6.2f (%6.1f)   %6.2f (%6.2f)   %6.2f (%6.2f)   %6.2f    %6.2f    %6.2f (%d/%d)   %6.2f" % (
+    print("%3d  %7.2f   %6.2f (%6.1f)   %6.2f (%6.2f)   %6.2f (%6.2f)   %5.2f %5.2f %5.2f (%6.2f)   %6.2f    %6.2f    %6.2f / %5.2f (%d/%d, %d, %d)   %6.2f" % (
         x["iteration"], x["correspondences"] / 1e6, x["t_nn_certify_ms"], x["nn_certify_queries"] / 1e6, x["t_nn_bounded_ms"],
-        x["nn_bounded_queries"] / 1e6, x["t_nn_search_ms"], x["nn_search_queries"] / 1e6, x["t_nn_ms"] - x["t_nn_query_ms"],
-        x["t_transform_ms"], x["t_lm_kernel_ms"], x["full_passes"], x["multi_cost_passes"], x["t_lm_ms"] - x["t_lm_kernel_ms"]))
+        x["nn_bounded_queries"] / 1e6, x["t_nn_search_ms"], x["nn_search_queries"] / 1e6, x["t_nn_sort_ms"], x["t_nn_scan_ms"], x["t_nn_compact_ms"],
+        x["corr_rows_rewritten"] / 1e6, x["t_nn_ms"] - x["t_nn_query_ms"] - x["t_nn_sort_ms"] - x["t_nn_scan_ms"] - x["t_nn_compact_ms"],
+        x["t_transform_ms"], x["t_lm_full_kernel_ms"], x["t_lm_kernel_ms"] - x["t_lm_full_kernel_ms"], x["full_passes"], x["multi_cost_passes"],
+        x["multi_cost_poses"], x["lm_passes_skipped"], x["t_lm_ms"] - x["t_lm_kernel_ms"]))

@@ -25,6 +25,11 @@ __global__ __launch_bounds__(kBlock, MINW) void k_var(const LmSet* __restrict__ 
                                                       double* __restrict__ partial) {
   lm_pass_body<MODE, UNR, PF>(sets, block_set, block_base, partial);
 }
+template <int U, int MINW>
+__global__ __launch_bounds__(kBlock, MINW) void k_cmu(const LmSet* __restrict__ sets, const LmPose* __restrict__ poses, int n_sets, int n_poses,
+                                                      const int* __restrict__ block_set, double* __restrict__ partial) {
+  lm_cost_multi_body<true, U>(sets, poses, n_sets, n_poses, block_set, partial);
+}
 template <int MODE, int MINW>
 __global__ __launch_bounds__(kBlock, MINW) void k_res(const LmSet* __restrict__ sets, const int* __restrict__ block_set, int block_base,
                                                       double* __restrict__ partial) {
@@ -156,6 +161,10 @@ int main(int argc, char** argv) {
     for (int i = 0; i < ns; ++i) { sets[i].glist = nullptr; }
 #define RD(MINW) run("mode1 dense outer=src minw" #MINW, 1, 0, [&] { hipLaunchKernelGGL((k_res<1, MINW>), dim3(block), dim3(kBlock), 0, 0, dsets, dbs, 0, part); }, false)
     RD(1); RD(2); RD(3); RD(4);
+    // multi-pose cost pass: rows per trip (poses in the outer loop) x occupancy, nine and five poses, dense rows with the source local
+#define CU(U, MINW, NP) run("cost_multi rows" #U " minw" #MINW " poses" #NP, 1, 0, [&] { hipLaunchKernelGGL((k_cmu<U, MINW>), dim3(block), dim3(kBlock), 0, 0, dsets, dposes, ns, NP, dbs, part); }, U == 1 && MINW == 1)
+    CU(1, 1, 9); CU(1, 4, 9); CU(2, 1, 9); CU(2, 4, 9); CU(3, 3, 9); CU(4, 1, 9); CU(4, 2, 9); CU(4, 3, 9);
+    CU(1, 1, 5); CU(1, 4, 5); CU(2, 1, 5); CU(2, 4, 5); CU(3, 3, 5); CU(4, 1, 5); CU(4, 2, 5); CU(4, 3, 5);
   }
   return 0;
 }

@@ -171,7 +171,7 @@ def test_c5_512_images_4k_with_100M_vertex_occlusion_mesh(e3d, rb, synth, tmp_pa
     nx = nz = 10_000
     Vw, Tw = _grid_mesh(nx, nz, 3.03, -7.5, 7.5, -4.0, 4.0, ripple=0.004)
     assert len(Vw) == 100_000_000 and len(Tw) == 199_960_002
-    Vb, Tb = _grid_mesh(50, 50, 2.0, -0.25, 0.25, -0.2, 0.2)
+    Vb, Tb = _grid_mesh(5, 5, 2.0, -0.25, 0.25, -0.2, 0.2)
     t_mesh = time.perf_counter() - t0
     t0 = time.perf_counter()
     assert P.add_occlusion_mesh(Vw, Tw, compute_edges=True) == 1
@@ -180,7 +180,7 @@ def test_c5_512_images_4k_with_100M_vertex_occlusion_mesh(e3d, rb, synth, tmp_pa
     n_wall_edges = P.occlusion_edge_count(0)
     assert 40_000 < n_wall_edges <= 3 * len(Tw)                       # at least the rim; at most every edge
     be, bn = mo.edge_list(Vb, Tb)
-    assert P.occlusion_edge_count(1) == len(be) and len(be) >= 4 * 49    # the planar blocker: its rim (coplanar interior edges are dropped)
+    assert P.occlusion_edge_count(1) == len(be) and len(be) >= 4 * 4     # the planar blocker: its rim (coplanar interior edges are dropped)
     P.set_occlusion_options(0.05, 100.0, False)
     # (i)
     cam = rb.camera_pyramid(rb.make_camera(W, H, Wl["params"], 0), 1)[0]
@@ -219,28 +219,34 @@ def test_c5_512_images_4k_with_100M_vertex_occlusion_mesh(e3d, rb, synth, tmp_pa
         P.set_occlusion_options(0.05, 100.0, True)
         g_mask = P.render_depth(i, 0, (H, W))
         n_masked += int((g_mask == -1).sum())
-        cx, cy, _ = mo.project_vertices(0, cam, R, im["t"], Vb[[0]])           # a corner of the blocker
-        tx, ty = int(cx[0]) - 8, int(cy[0]) - 8
-        assert 100 < tx < W - 100 and 100 < ty < H - 100
+        # a corner of the blocker.  Its rim edges are 10 - 12 cm long: MaskOutOcclusionBoundaries walks an edge in steps of the
+        # 3 cm splat radius and splats squares of that radius; [QUIRK] an edge shorter than half a step has count = 1 and its only
+        # sample sits at 0 / 0 = NaN (occlusion_geometry.cc:318-321) -- the 1.5 mm edges of the rippled wall therefore never mask
+        # anything, in the reference, the oracle and here
+        cx, cy, cz = mo.project_vertices(0, cam, R, im["t"], Vb[[0]])
+        rx = float(Wl["params"][0]) * 0.03 / float(cz[0])                        # splat radius in pixels at the blocker
+        hs = min(int(1.7 * rx) + 8, 110)
+        tx, ty = int(cx[0]) - hs, int(cy[0]) - hs
+        assert hs < tx < W - 3 * hs and hs < ty < H - 3 * hs, (tx, ty, hs)
         cs = 25
         sub = Vw.reshape(nz, nx, 3)[::cs, ::cs].reshape(-1, 3)
         px, py, z = mo.project_vertices(0, cam, R, im["t"], sub)
         px = px.reshape(nz // cs, nx // cs); py = py.reshape(nz // cs, nx // cs)
-        near = (px > tx - 50) & (px < tx + 66) & (py > ty - 50) & (py < ty + 66)
+        near = (px > cx[0] - 30) & (px < cx[0] + 30) & (py > cy[0] - 30) & (py < cy[0] + 30)
         rows, cols = np.nonzero(near)
         r0, r1 = max(rows.min() * cs - cs, 0), min(rows.max() * cs + 2 * cs, nz)
         c0, c1 = max(cols.min() * cs - cs, 0), min(cols.max() * cs + 2 * cs, nx)
-        assert (r1 - r0) * (c1 - c0) < 120_000, (r1 - r0, c1 - c0)               # the oracle's edge list is a Python loop
+        assert (r1 - r0) * (c1 - c0) < 60_000, (r1 - r0, c1 - c0)                # the oracle's edge list is a Python loop
         Vs = Vw.reshape(nz, nx, 3)[r0:r1, c0:c1].reshape(-1, 3)
         _, Ts = _grid_mesh(c1 - c0, r1 - r0, 0.0, 0.0, 1.0, 0.0, 1.0)
         verts_sub = np.concatenate([Vs, Vb]); tris_sub = np.concatenate([Ts, Tb + np.uint32(len(Vs))])
         edges, normals = mo.edge_list(verts_sub, tris_sub)
         assert len(edges) > len(be)                                                # the rippled wall keeps interior edges
         o_mask = mo.mask_boundaries(g_plain, edges, normals, verts_sub, R, im["t"], cam)
-        gt, ot = g_mask[ty:ty + 16, tx:tx + 16], o_mask[ty:ty + 16, tx:tx + 16]
-        assert (ot == -1).sum() > 20 and (ot != -1).sum() > 20, (i, int((ot == -1).sum()))   # the tile straddles the masked band
+        gt, ot = g_mask[ty:ty + 2 * hs, tx:tx + 2 * hs], o_mask[ty:ty + 2 * hs, tx:tx + 2 * hs]
+        assert (ot == -1).sum() > 200 and (ot != -1).sum() > 200, (i, hs, int((ot == -1).sum()))   # the tile straddles the masked band
         mism = (gt == -1) != (ot == -1)
-        assert mism.sum() <= 1, (i, tx, ty, int(mism.sum()))
+        assert mism.mean() < 1e-3, (i, tx, ty, int(mism.sum()))
         assert np.array_equal(gt[~mism].view(np.uint32), ot[~mism].view(np.uint32))
     assert n_masked > 10_000
     del Vw, Tw

@@ -713,13 +713,18 @@ class RegProblem:
 
     def profile(self, enable):
         """Switches the phase profile of run_on_current_scale on / off; returns {phase: ms} recorded so far (e3d_reg_profile)."""
-        buf = C.create_string_buffer(4096)
+        buf = C.create_string_buffer(16384)
         self._chk(lib().e3d_reg_profile(self._h, int(bool(enable)), buf, len(buf)), "e3d_reg_profile")
         out = {}
+        self.kernel_groups = {}      # {group: (HIP-event ms, launches, work units)} of the same record ("k:" entries)
         for item in buf.value.decode().split(";"):
             if "=" in item:
                 k, v = item.rsplit("=", 1)
-                out[k] = float(v)
+                if k.startswith("k:"):
+                    ms, calls, units = v.split(",")
+                    self.kernel_groups[k[2:]] = (float(ms), int(calls), float(units))
+                else:
+                    out[k] = float(v)
         return out
 
     def set_comm(self, comm):

@@ -1916,12 +1916,18 @@ __global__ __launch_bounds__(kWave) void k_reg_reduce(const double* __restrict__
 }
 
 // ==== a19: cost ================================================================================================================================
-__global__ __launch_bounds__(kBlock) void k_reg_intensity(Pyramid Y, const unsigned* __restrict__ o_idx, const float* __restrict__ o_x,
-                                                          const float* __restrict__ o_y, const float* __restrict__ o_s,
-                                                          size_t n_obs, float* __restrict__ point_intensity) {
+// per observation (kept in Obs::inten while the observations stay), then scattered to the points for the neighbour gathers
+__global__ __launch_bounds__(kBlock) void k_reg_intensity(Pyramid Y, const float* __restrict__ o_x, const float* __restrict__ o_y,
+                                                          const float* __restrict__ o_s, size_t n_obs, float* __restrict__ inten) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_obs) return;
-  point_intensity[o_idx[i]] = obs_intensity(Y, o_x[i], o_y[i], o_s[i]);
+  inten[i] = obs_intensity(Y, o_x[i], o_y[i], o_s[i]);
+}
+__global__ __launch_bounds__(kBlock) void k_scatter_intensity(const unsigned* __restrict__ o_idx, const float* __restrict__ inten,
+                                                              size_t n_obs, float* __restrict__ point_intensity) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_obs) return;
+  point_intensity[o_idx[i]] = inten[i];
 }
 
 __global__ __launch_bounds__(kBlock) void k_reg_cost(const float* __restrict__ point_intensity, const unsigned* __restrict__ o_idx,
@@ -2036,6 +2042,15 @@ struct Obs {
   DevBuf<float4> rows;
   bool rows_valid = false;
   DevBuf<float4> drows;           // depth residual rows (k_reg_depth_rows), recomputed per use
+  // the interpolated image intensity of every observation (k_reg_intensity): a function of (x, y, s) and the image alone, so the
+  // colour update and the cost that follows it at the same observations sample the pyramid once
+  DevBuf<float> inten;
+  bool inten_valid = false;
+  int inten_w = 0, inten_h = 0, inten_min_scale = -1, inten_levels = 0;      // (the pyramid geometry they were sampled with)
+  // flags / nrow describe the list `flags_src` (device pointer of an indexed re-projection's candidates) of flags_count entries:
+  // a trial state of Apply that keeps every point of the visibility list visible reuses them (finish_observations skipped)
+  const void* flags_src = nullptr;
+  size_t flags_count = 0;
 };
 struct ImageDev {
   int intrinsics_id = -1;
@@ -2103,7 +2118,7 @@ struct e3d_reg {
   DevBuf<int> valid;
   DevBuf<float> tx, ty, ts;
   DevBuf<unsigned> cand, block_counts, block_offsets;
-  DevBuf<double> block_d2, chunk_d2, d_total_d2, partial, red;
+  DevBuf<double> block_d2, chunk_d2, d_total_d2, partial, red, red_all;
   DevBuf<unsigned long long> chunk_sum, d_total;
   DevBuf<float> dummy_d2;
   DevBuf<unsigned> cut;
@@ -2121,17 +2136,55 @@ struct e3d_reg {
   // the profile is on, so a profiled run is slower than a plain one; the split is what it is for)
   bool profile_on = false;
   std::map<std::string, double> profile_ms;
+  // ... and, while the profile is on, HIP-event time, launches and work units (points / observations / pixels: what the bench
+  // prices a group's algorithmic bytes with) of every kernel group of an iteration (KT below); read lazily, no synchronisation
+  struct KGroup { double ms = 0, units = 0; long long calls = 0; };
+  std::map<std::string, KGroup> kgroups;
+  struct KPending { hipEvent_t a, b; KGroup* g; };
+  std::vector<KPending> kpending;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> kfree;
+  void kflush() {
+    for (KPending& p : kpending) {
+      float t = 0.f;
+      if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&t, p.a, p.b) == hipSuccess) p.g->ms += (double)t;
+      kfree.emplace_back(p.a, p.b);
+    }
+    kpending.clear();
+  }
   bool owns(int image_id) const { return world <= 1 || ((image_id % world) + world) % world == rank; }
   // splat depth: per-point rectangles, (tile, point) pairs (double-buffered for the sort), tile ranges
   DevBuf<uint4> rects;
   DevBuf<unsigned> sp_keys[2], sp_vals[2], sp_counter, tile_start, tile_end, zbuf, ztmp;
   DevBuf<char> sort_temp;
-  ~e3d_reg() { if (stream) (void)hipStreamDestroy(stream); }
+  ~e3d_reg() {
+    kflush();
+    for (auto& e : kfree) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    if (stream) (void)hipStreamDestroy(stream);
+  }
 };
 
 namespace e3d {
 
 static void rsync(e3d_reg* h) { E3D_HIP(hipStreamSynchronize(h->stream)); }
+
+// stop-watch of one kernel group (HIP events on the handle's stream; only while e3d_reg_profile is on)
+struct KT {
+  e3d_reg* h; hipEvent_t a = nullptr, b = nullptr; e3d_reg::KGroup* g = nullptr;
+  KT(e3d_reg* hh, const char* name, double units) : h(hh) {
+    if (!h->profile_on) return;
+    if (h->kpending.size() >= 8192) h->kflush();
+    if (h->kfree.empty()) { hipEvent_t x, y; E3D_HIP(hipEventCreate(&x)); E3D_HIP(hipEventCreate(&y)); h->kfree.emplace_back(x, y); }
+    a = h->kfree.back().first; b = h->kfree.back().second; h->kfree.pop_back();
+    g = &h->kgroups[name];
+    g->calls += 1; g->units += units;
+    (void)hipEventRecord(a, h->stream);
+  }
+  ~KT() {
+    if (!g) return;
+    (void)hipEventRecord(b, h->stream);
+    h->kpending.push_back({a, b, g});
+  }
+};
 
 struct Phase {
   e3d_reg* h; const char* name; std::chrono::steady_clock::time_point t0;
@@ -2372,6 +2425,8 @@ static void check_params(const e3d_reg_params* p) {
 // flags + row_of_point for the current observation list
 static void finish_observations(e3d_reg* h, PointScale& S, Obs& O) {
   hipStream_t s = h->stream;
+  KT kt(h, "obs.neighbour_flags", (double)O.n);
+  O.flags_src = nullptr; O.flags_count = 0;
   hipLaunchKernelGGL(k_fill_i32, dim3(nblk(S.n)), dim3(kBlock), 0, s, S.row_of_point.p, S.n, -1);
   O.flags.reserve(O.n);
   O.nrow.reserve(O.n * (size_t)h->prm.point_neighbor_count);
@@ -2403,10 +2458,19 @@ static void prepare_rows(e3d_reg* h, ImageDev& im, PointScale& S, Obs& O) {
 
 static void dense_intensities(e3d_reg* h, ImageDev& im, PointScale& S, Obs& O) {
   hipStream_t s = h->stream;
+  const Intrin& in = h->intr.at(im.intrinsics_id);
+  const bool same_pyramid = O.inten_w == in.levels[0].width && O.inten_h == in.levels[0].height && O.inten_min_scale == in.min_image_scale &&
+                            O.inten_levels == (int)in.levels.size();
+  if (O.n && !(O.inten_valid && same_pyramid)) {
+    KT kt(h, "intensity.sample", (double)O.n);
+    O.inten.reserve(O.n);
+    hipLaunchKernelGGL(k_reg_intensity, dim3(nblk(O.n)), dim3(kBlock), 0, s, make_pyramid(h, im), O.x.p, O.y.p, O.s.p, O.n, O.inten.p);
+    O.inten_valid = true;
+    O.inten_w = in.levels[0].width; O.inten_h = in.levels[0].height; O.inten_min_scale = in.min_image_scale; O.inten_levels = (int)in.levels.size();
+  }
+  KT kt(h, "intensity.scatter", (double)O.n);
   hipLaunchKernelGGL(k_fill_f32, dim3(nblk(S.n)), dim3(kBlock), 0, s, S.intensity.p, S.n, -1.f);
-  if (O.n)
-    hipLaunchKernelGGL(k_reg_intensity, dim3(nblk(O.n)), dim3(kBlock), 0, s, make_pyramid(h, im), O.idx.p, O.x.p, O.y.p, O.s.p, O.n,
-                       S.intensity.p);
+  if (O.n) hipLaunchKernelGGL(k_scatter_intensity, dim3(nblk(O.n)), dim3(kBlock), 0, s, O.idx.p, O.inten.p, O.n, S.intensity.p);
 }
 
 }  // namespace e3d
@@ -2835,6 +2899,9 @@ int e3d_reg_render_depth(e3d_reg_t* h, int image_id, int image_scale, float* dep
   const size_t px = (size_t)cam.width * cam.height;
   im.depth.reserve(px);
   if (h->n_splat == 0 && !h->meshes.empty()) {
+    double tris = 0;
+    for (auto& m : h->meshes) tris += (double)m->n_triangles;
+    KT kt(h, "depth.mesh_raster", tris);
     render_depth_meshes(h, im, in, cam);
   } else if (h->n_splat == 0) {
     // no occlusion geometry: everything is visible (occlusion_geometry.cc:272-281)
@@ -2854,30 +2921,41 @@ int e3d_reg_render_depth(e3d_reg_t* h, int image_id, int image_scale, float* dep
     unsigned n_pairs = 0;
     const size_t zpx = (size_t)(cam.width + 2 * kSplatMax) * (cam.height + 2 * kSplatMax);
     h->zbuf.reserve(zpx); h->ztmp.reserve((size_t)cam.width * (cam.height + 2 * kSplatMax));
-    hipLaunchKernelGGL(k_fill_f32, dim3(nblk(zpx)), dim3(kBlock), 0, s, reinterpret_cast<float*>(h->zbuf.p), zpx, INFINITY);
+    {
+      KT kt(h, "depth.zbuffer_clear", (double)zpx);
+      hipLaunchKernelGGL(k_fill_f32, dim3(nblk(zpx)), dim3(kBlock), 0, s, reinterpret_cast<float*>(h->zbuf.p), zpx, INFINITY);
+    }
     if (n) {
-      E3D_CAM_SWITCH(in.type, hipLaunchKernelGGL(k_splat_bin<M>, dim3(nblk(n)), dim3(kBlock), 0, s, h->splat.p, n, im.pose, cam,
-                                                 h->prm.splat_radius, tiles_x, h->rects.p, h->sp_keys[0].p, h->sp_vals[0].p,
-                                                 h->sp_counter.p, h->zbuf.p));
+      {
+        KT kt(h, "depth.splat_bin", (double)n);
+        E3D_CAM_SWITCH(in.type, hipLaunchKernelGGL(k_splat_bin<M>, dim3(nblk(n)), dim3(kBlock), 0, s, h->splat.p, n, im.pose, cam,
+                                                   h->prm.splat_radius, tiles_x, h->rects.p, h->sp_keys[0].p, h->sp_vals[0].p,
+                                                   h->sp_counter.p, h->zbuf.p));
+      }
       copy_out(&n_pairs, h->sp_counter.p, sizeof n_pairs, s);
       rsync(h);
     }
-    if (n_pairs) {
-      int bits = 1;
-      while (((size_t)1 << bits) < n_tiles) ++bits;
-      sort_pairs_u32_u32(h->sp_keys[0].p, h->sp_keys[1].p, h->sp_vals[0].p, h->sp_vals[1].p, n_pairs, bits, h->sort_temp, s);
-      hipLaunchKernelGGL(k_tile_ranges, dim3(nblk(n_pairs)), dim3(kBlock), 0, s, h->sp_keys[1].p, (size_t)n_pairs, h->tile_start.p,
-                         h->tile_end.p);
+    {
+      KT kt(h, "depth.small_splat_tiles", (double)n_pairs);
+      if (n_pairs) {
+        int bits = 1;
+        while (((size_t)1 << bits) < n_tiles) ++bits;
+        sort_pairs_u32_u32(h->sp_keys[0].p, h->sp_keys[1].p, h->sp_vals[0].p, h->sp_vals[1].p, n_pairs, bits, h->sort_temp, s);
+        hipLaunchKernelGGL(k_tile_ranges, dim3(nblk(n_pairs)), dim3(kBlock), 0, s, h->sp_keys[1].p, (size_t)n_pairs, h->tile_start.p,
+                           h->tile_end.p);
+      }
+      hipLaunchKernelGGL(k_splat_tiles, dim3((unsigned)n_tiles), dim3(kBlock), 0, s, h->rects.p, h->sp_vals[1].p, h->tile_start.p,
+                         h->tile_end.p, tiles_x, cam.width, cam.height, reinterpret_cast<unsigned*>(im.depth.p));
     }
-    hipLaunchKernelGGL(k_splat_tiles, dim3((unsigned)n_tiles), dim3(kBlock), 0, s, h->rects.p, h->sp_vals[1].p, h->tile_start.p,
-                       h->tile_end.p, tiles_x, cam.width, cam.height, reinterpret_cast<unsigned*>(im.depth.p));
-    hipLaunchKernelGGL(k_min_filter_h, dim3((unsigned)div_up(cam.width, kBlock), (unsigned)(cam.height + 2 * kSplatMax)), dim3(kBlock), 0, s,
-                       h->zbuf.p, cam.width, cam.height, h->ztmp.p);
-    hipLaunchKernelGGL(k_min_filter_v, dim3((unsigned)div_up(cam.width, kBlock), (unsigned)cam.height), dim3(kBlock), 0, s, h->ztmp.p,
-                       cam.width, cam.height, reinterpret_cast<unsigned*>(im.depth.p));
+    {
+      KT kt(h, "depth.min_filter", (double)px);
+      hipLaunchKernelGGL(k_min_filter_h, dim3((unsigned)div_up(cam.width, kBlock), (unsigned)(cam.height + 2 * kSplatMax)), dim3(kBlock), 0, s,
+                         h->zbuf.p, cam.width, cam.height, h->ztmp.p);
+      hipLaunchKernelGGL(k_min_filter_v, dim3((unsigned)div_up(cam.width, kBlock), (unsigned)cam.height), dim3(kBlock), 0, s, h->ztmp.p,
+                         cam.width, cam.height, reinterpret_cast<unsigned*>(im.depth.p));
+    }
   }
-  if (depth_out) copy_out(depth_out, im.depth.p, sizeof(float) * px, h->stream);
-  rsync(h);
+  if (depth_out) { copy_out(depth_out, im.depth.p, sizeof(float) * px, h->stream); rsync(h); }     // (else: every reader runs on the stream)
   im.depth_scale = image_scale;
   return 0;
   R_CATCH()
@@ -2904,29 +2982,43 @@ int64_t e3d_reg_observe(e3d_reg_t* h, int image_id, int point_scale, int image_s
   q.occlusion_threshold = h->prm.occlusion_depth_threshold; q.max_valid_intensity = h->prm.maximum_valid_intensity;
   q.check = all ? 1 : 0;
   O.n = 0;
+  O.inten_valid = false;
+  // the flags of the list the candidates came from still describe the result if every candidate stays an observation
+  const bool flags_kept = !all && O.flags_src == (const void*)indices && O.flags_count == count;
   if (count) {
-    E3D_CAM_SWITCH(image_model(h, im), hipLaunchKernelGGL(k_obs_eval<M>, dim3(nblk(count)), dim3(kBlock), 0, s, S.pts.p, d_idx, count,
-                                                          im.pose, make_pyramid(h, im), all ? im.depth.p : nullptr, q, h->valid.p,
-                                                          h->tx.p, h->ty.p, h->ts.p));
+    {
+      KT kt(h, all ? "obs.eval_all_points" : "obs.eval_listed_points", (double)count);
+      E3D_CAM_SWITCH(image_model(h, im), hipLaunchKernelGGL(k_obs_eval<M>, dim3(nblk(count)), dim3(kBlock), 0, s, S.pts.p, d_idx, count,
+                                                            im.pose, make_pyramid(h, im), all ? im.depth.p : nullptr, q, h->valid.p,
+                                                            h->tx.p, h->ty.p, h->ts.p));
+    }
     const size_t nb = div_up(count, kBlock);
     h->block_counts.reserve(nb); h->block_offsets.reserve(nb); h->block_d2.reserve(nb);
     h->chunk_sum.reserve(div_up(nb, 256) + 1); h->chunk_d2.reserve(div_up(nb, 256) + 1);
     h->d_total.reserve(1); h->d_total_d2.reserve(1);
-    E3D_HIP(hipMemsetAsync(h->dummy_d2.p, 0, sizeof(float) * count, s));
-    launch_match_scan(h->valid.p, h->dummy_d2.p, count, h->block_counts.p, h->block_offsets.p, h->block_d2.p, h->chunk_sum.p,
-                      h->chunk_d2.p, h->d_total.p, h->d_total_d2.p, s);
+    {
+      KT kt(h, "obs.scan", (double)count);
+      E3D_HIP(hipMemsetAsync(h->dummy_d2.p, 0, sizeof(float) * count, s));
+      launch_match_scan(h->valid.p, h->dummy_d2.p, count, h->block_counts.p, h->block_offsets.p, h->block_d2.p, h->chunk_sum.p,
+                        h->chunk_d2.p, h->d_total.p, h->d_total_d2.p, s);
+    }
     unsigned long long total = 0;
     copy_out(&total, h->d_total.p, sizeof total, s);
     rsync(h);
     O.n = (size_t)total;
     O.idx.reserve(O.n); O.x.reserve(O.n); O.y.reserve(O.n); O.s.reserve(O.n);
-    if (O.n)
+    if (O.n) {
+      KT kt(h, "obs.compact", (double)count);
       hipLaunchKernelGGL(k_obs_compact, dim3(nblk(count)), dim3(kBlock), 0, s, h->valid.p, h->tx.p, h->ty.p, h->ts.p, count,
                          h->block_offsets.p, O.idx.p, O.x.p, O.y.p, O.s.p);
+    }
   }
-  finish_observations(h, S, O);
-  rsync(h);
-  return (int64_t)O.n;
+  if (flags_kept && O.n == count) {
+    // same points in the same order as the list the flags were made for: flags and neighbour rows are unchanged
+  } else {
+    finish_observations(h, S, O);
+  }
+  return (int64_t)O.n;        // (the stream is not synchronised here: every reader of O runs on it)
   R_CATCH()
 }
 
@@ -2957,6 +3049,7 @@ int e3d_reg_set_observations(e3d_reg_t* h, int image_id, int point_scale, size_t
   O.idx.reserve(n); O.x.reserve(n); O.y.reserve(n); O.s.reserve(n);
   copy_in(O.idx.p, idx, sizeof(unsigned) * n, h->stream); copy_in(O.x.p, x, sizeof(float) * n, h->stream);
   copy_in(O.y.p, y, sizeof(float) * n, h->stream); copy_in(O.s.p, scale, sizeof(float) * n, h->stream);
+  O.inten_valid = false;
   finish_observations(h, S, O);
   rsync(h);
   return 0;
@@ -2995,8 +3088,9 @@ int e3d_reg_accumulate(e3d_reg_t* h, int image_id, int point_scale, double* H, d
   Obs& O = get_obs(im, point_scale);
   if (!h->t_pass1) { h->t_pass1.reset(new EventTimer()); h->t_pass2.reset(new EventTimer()); }
   h->t_pass1->start(s);
-  prepare_rows(h, im, S, O);
+  { KT kt(h, "accumulate.pass1", (double)O.n); prepare_rows(h, im, S, O); }
   h->t_pass1->stop(s);
+  std::unique_ptr<KT> kt2(new KT(h, "accumulate.pass2", (double)O.n));
   // one resident round of workgroups (two of these 256-thread groups fit a CU): 512 on MI355X; measured 0.684 / 0.694 / 0.704 / 0.711 ms
   // for 512 / 1024 / 2048 / 4096 at the configs[3] shape
   static const int max_blocks = [] {
@@ -3072,6 +3166,7 @@ int e3d_reg_accumulate(e3d_reg_t* h, int image_id, int point_scale, double* H, d
 #undef E3D_PASS2
   }
   h->t_pass2->stop(s);
+  kt2.reset();
   hipLaunchKernelGGL(k_reg_reduce, dim3(slot), dim3(kWave), 0, s, h->partial.p, n_partials, slot, h->red.p);
   std::vector<double> r(slot);
   copy_out(r.data(), h->red.p, sizeof(double) * slot, s);
@@ -3102,31 +3197,45 @@ int e3d_reg_profile(e3d_reg_t* h, int enable, char* out, size_t capacity) {
   if (out && capacity) {
     std::string t;
     for (const auto& kv : h->profile_ms) t += kv.first + "=" + fmt("%.4f", kv.second) + ";";
+    h->kflush();
+    for (const auto& kv : h->kgroups) t += "k:" + kv.first + "=" + fmt("%.4f,%lld,%.0f", kv.second.ms, kv.second.calls, kv.second.units) + ";";
     std::snprintf(out, capacity, "%s", t.c_str());
   }
-  if (enable != (h->profile_on ? 1 : 0)) h->profile_ms.clear();
+  if (enable != (h->profile_on ? 1 : 0)) { h->profile_ms.clear(); h->kflush(); h->kgroups.clear(); }
   h->profile_on = enable != 0;
   return 0;
   R_CATCH()
 }
 
-int e3d_reg_cost(e3d_reg_t* h, int image_id, int point_scale, double sums[2], int64_t counts[2]) {
-  R_TRYH
-  if (!h || !sums || !counts) throw Error(E3D_ERR_INVALID, "null argument");
+}  // extern "C"
+namespace e3d {
+// CostCalculator::ComputeCost of one (image, point scale): kernels enqueued, the four results {fixed sum, variable sum, fixed count,
+// variable count} land in d_out[0..3] (device); the callers of the driver read many of them with one copy
+static void cost_enqueue(e3d_reg* h, int image_id, int point_scale, double* d_out) {
   hipStream_t s = h->stream;
   ImageDev& im = get_image(h, image_id);
   PointScale& S = get_scale(h, point_scale);
   Obs& O = get_obs(im, point_scale);
   dense_intensities(h, im, S, O);
   const int nb = (int)std::min<size_t>(std::max<size_t>(div_up(O.n, kBlock * 4), 1), 1024);
-  h->partial.reserve((size_t)nb * 4); h->red.reserve(4);
+  h->partial.reserve((size_t)nb * 4);
   const RegWeights w{h->prm.robust_weighting_type, h->prm.robust_weighting_parameter, h->prm.fixed_residuals_weight,
                      h->prm.variable_residuals_weight};
+  KT kt(h, "cost", (double)O.n);
   hipLaunchKernelGGL(k_reg_cost, dim3(nb), dim3(kBlock), 0, s, S.intensity.p, O.idx.p, O.flags.p, O.n, S.nbr.p,
                      h->prm.point_neighbor_count, S.fixed_desc.p, S.var_desc.p, S.obs_counts.p, w, h->partial.p);
-  hipLaunchKernelGGL(k_reg_reduce, dim3(4), dim3(kWave), 0, s, h->partial.p, nb, 4, h->red.p);
+  hipLaunchKernelGGL(k_reg_reduce, dim3(4), dim3(kWave), 0, s, h->partial.p, nb, 4, d_out);
+}
+}  // namespace e3d
+extern "C" {
+
+int e3d_reg_cost(e3d_reg_t* h, int image_id, int point_scale, double sums[2], int64_t counts[2]) {
+  R_TRYH
+  if (!h || !sums || !counts) throw Error(E3D_ERR_INVALID, "null argument");
+  h->red.reserve(4);
+  cost_enqueue(h, image_id, point_scale, h->red.p);
   double r[4];
-  copy_out(r, h->red.p, sizeof r, s);
+  copy_out(r, h->red.p, sizeof r, h->stream);
   rsync(h);
   sums[0] = r[0]; sums[1] = r[1]; counts[0] = (int64_t)r[2]; counts[1] = (int64_t)r[3];
   return 0;
@@ -3241,22 +3350,33 @@ int e3d_reg_color_begin(e3d_reg_t* h, int point_scale) {
   R_TRYH
   if (!h) throw Error(E3D_ERR_INVALID, "null handle");
   PointScale& S = get_scale(h, point_scale);
-  E3D_HIP(hipMemsetAsync(S.var_desc.p, 0, sizeof(float) * S.n * h->prm.point_neighbor_count, h->stream));
-  E3D_HIP(hipMemsetAsync(S.obs_counts.p, 0, sizeof(int) * S.n, h->stream));
+  {
+    KT kt(h, "color.clear", (double)S.n);
+    E3D_HIP(hipMemsetAsync(S.var_desc.p, 0, sizeof(float) * S.n * h->prm.point_neighbor_count, h->stream));
+    E3D_HIP(hipMemsetAsync(S.obs_counts.p, 0, sizeof(int) * S.n, h->stream));
+  }
   rsync(h);
   return 0;
   R_CATCH()
 }
-int e3d_reg_color_accumulate(e3d_reg_t* h, int image_id, int point_scale) {
-  R_TRYH
-  if (!h) throw Error(E3D_ERR_INVALID, "null handle");
+}  // extern "C"
+namespace e3d {
+static void color_accumulate_enqueue(e3d_reg* h, int image_id, int point_scale) {
   ImageDev& im = get_image(h, image_id);
   PointScale& S = get_scale(h, point_scale);
   Obs& O = get_obs(im, point_scale);
   dense_intensities(h, im, S, O);
+  KT kt(h, "color.accumulate", (double)O.n);
   if (O.n)
     hipLaunchKernelGGL(k_color_accumulate, dim3(nblk(O.n)), dim3(kBlock), 0, h->stream, S.intensity.p, O.idx.p, O.flags.p, O.n,
                        S.nbr.p, h->prm.point_neighbor_count, S.var_desc.p, S.obs_counts.p);
+}
+}  // namespace e3d
+extern "C" {
+int e3d_reg_color_accumulate(e3d_reg_t* h, int image_id, int point_scale) {
+  R_TRYH
+  if (!h) throw Error(E3D_ERR_INVALID, "null handle");
+  color_accumulate_enqueue(h, image_id, point_scale);
   rsync(h);
   return 0;
   R_CATCH()
@@ -3265,8 +3385,11 @@ int e3d_reg_color_finish(e3d_reg_t* h, int point_scale) {
   R_TRYH
   if (!h) throw Error(E3D_ERR_INVALID, "null handle");
   PointScale& S = get_scale(h, point_scale);
-  hipLaunchKernelGGL(k_color_finish, dim3(nblk(S.n)), dim3(kBlock), 0, h->stream, S.n, h->prm.point_neighbor_count, S.var_desc.p,
-                     S.obs_counts.p);
+  {
+    KT kt(h, "color.finish", (double)S.n);
+    hipLaunchKernelGGL(k_color_finish, dim3(nblk(S.n)), dim3(kBlock), 0, h->stream, S.n, h->prm.point_neighbor_count, S.var_desc.p,
+                       S.obs_counts.p);
+  }
   rsync(h);
   return 0;
   R_CATCH()
@@ -3362,8 +3485,7 @@ static void color_update(e3d_reg* h) {
   for (auto& sc : h->scales) {
     if (e3d_reg_color_begin(h, sc.first) < 0) throw Error(E3D_ERR_INVALID, e3d_last_error());
     for (auto& kv : h->images)
-      if (h->owns(kv.first) && has_obs(kv.second, sc.first) && e3d_reg_color_accumulate(h, kv.first, sc.first) < 0)
-        throw Error(E3D_ERR_INVALID, e3d_last_error());
+      if (h->owns(kv.first) && has_obs(kv.second, sc.first)) color_accumulate_enqueue(h, kv.first, sc.first);     // (one stream: no sync between images)
     // the exchange step of (B): descriptor sums and observation counts over all images = over all ranks
     allreduce_device(h, sc.second.var_desc.p, sc.second.n * (size_t)h->prm.point_neighbor_count, 0);
     allreduce_device(h, sc.second.obs_counts.p, sc.second.n, 1);
@@ -3385,18 +3507,24 @@ static bool depth_in_use(const e3d_reg* h) { return h->prm.depth_residuals_weigh
 static double total_cost(e3d_reg* h) {
   double sums[3] = {0, 0, 0};
   int64_t counts[3] = {0, 0, 0};
+  // the colour costs of all (image, scale) pairs are enqueued back to back and read with one copy; summed in the loop's order
+  std::vector<std::pair<int, int>> jobs;
   for (auto& kv : h->images)
-    for (auto& sc : h->scales) {
-      if (!h->owns(kv.first) || !has_obs(kv.second, sc.first)) continue;
-      double s2[2]; int64_t c2[2];
-      if (e3d_reg_cost(h, kv.first, sc.first, s2, c2) < 0) throw Error(E3D_ERR_INVALID, e3d_last_error());
-      sums[0] += s2[0]; sums[1] += s2[1]; counts[0] += c2[0]; counts[1] += c2[1];
-      if (depth_in_use(h)) {
-        double sd; int64_t cd;
-        if (e3d_reg_depth_cost(h, kv.first, sc.first, &sd, &cd) < 0) throw Error(E3D_ERR_INVALID, e3d_last_error());
-        sums[2] += sd; counts[2] += cd;
-      }
+    for (auto& sc : h->scales)
+      if (h->owns(kv.first) && has_obs(kv.second, sc.first)) jobs.emplace_back(kv.first, sc.first);
+  h->red_all.reserve(4 * std::max<size_t>(jobs.size(), 1));
+  for (size_t j = 0; j < jobs.size(); ++j) cost_enqueue(h, jobs[j].first, jobs[j].second, h->red_all.p + 4 * j);
+  std::vector<double> r(4 * jobs.size());
+  if (!jobs.empty()) copy_out(r.data(), h->red_all.p, sizeof(double) * r.size(), h->stream);
+  rsync(h);
+  for (size_t j = 0; j < jobs.size(); ++j) {
+    sums[0] += r[4 * j]; sums[1] += r[4 * j + 1]; counts[0] += (int64_t)r[4 * j + 2]; counts[1] += (int64_t)r[4 * j + 3];
+    if (depth_in_use(h)) {
+      double sd; int64_t cd;
+      if (e3d_reg_depth_cost(h, jobs[j].first, jobs[j].second, &sd, &cd) < 0) throw Error(E3D_ERR_INVALID, e3d_last_error());
+      sums[2] += sd; counts[2] += cd;
     }
+  }
   reduce_sums(h, sums, counts);
   if (counts[0] == 0 && counts[1] == 0 && counts[2] == 0) return std::numeric_limits<double>::infinity();
   return compute_cost_value(h, sums, counts);
@@ -3438,6 +3566,7 @@ static void apply_update(e3d_reg* h, bool print, bool* applied_update, float* la
       buf->reserve(O.n);
       if (O.n) E3D_HIP(hipMemcpyAsync(buf->p, O.idx.p, sizeof(unsigned) * O.n, hipMemcpyDeviceToDevice, s));
       vis[kv.first][sc.first] = {buf, O.n};
+      O.flags_src = O.n ? (const void*)buf->p : nullptr; O.flags_count = O.n;     // flags / nrow belong to exactly this list
       const int Vl = I + (dep ? 12 : 6);
       std::vector<double> Hl((size_t)Vl * Vl), bl(Vl);
       double s2[2]; int64_t c2[2];
@@ -3526,6 +3655,9 @@ static void apply_update(e3d_reg* h, bool print, bool* applied_update, float* la
     ph_state.reset();
     double ts[3] = {0, 0, 0}; int64_t tc[3] = {0, 0, 0};
     constexpr size_t kManyObservationsCount = 100;
+    std::vector<std::pair<int, int>> trial_jobs;
+    const size_t trial_cap = h->images.size() * h->scales.size();        // (red_all must not move while results are pending)
+    h->red_all.reserve(4 * std::max<size_t>(trial_cap, 1));
     for (auto& kv : h->images) {
       if (!h->owns(kv.first)) continue;
       const int scale = best_available_scale(h, h->intr.at(kv.second.intrinsics_id));
@@ -3548,12 +3680,22 @@ static void apply_update(e3d_reg* h, bool print, bool* applied_update, float* la
       for (auto& sc : h->scales) {
         // scales skipped by the early-out have empty observation vectors in the reference
         if (std::find(done.begin(), done.end(), sc.first) == done.end()) continue;
-        double s2[2]; int64_t c2[2];
-        if (e3d_reg_cost(h, kv.first, sc.first, s2, c2) < 0) throw Error(E3D_ERR_INVALID, e3d_last_error());
-        ts[0] += s2[0]; ts[1] += s2[1]; tc[0] += c2[0]; tc[1] += c2[1];
+        trial_jobs.emplace_back(kv.first, sc.first);
+        h->red_all.reserve(4 * std::max<size_t>(trial_cap, trial_jobs.size()));
+        cost_enqueue(h, kv.first, sc.first, h->red_all.p + 4 * (trial_jobs.size() - 1));
+      }
+    }
+    {
+      // every trial cost was enqueued behind its image's re-projection: one copy, summed in the loop's order
+      Phase ph_cost(h, "apply.trial_cost");
+      std::vector<double> r(4 * trial_jobs.size());
+      if (!trial_jobs.empty()) copy_out(r.data(), h->red_all.p, sizeof(double) * r.size(), s);
+      rsync(h);
+      for (size_t j = 0; j < trial_jobs.size(); ++j) {
+        ts[0] += r[4 * j]; ts[1] += r[4 * j + 1]; tc[0] += (int64_t)r[4 * j + 2]; tc[1] += (int64_t)r[4 * j + 3];
         if (depth_in_use(h)) {
           double sd; int64_t cd;
-          if (e3d_reg_depth_cost(h, kv.first, sc.first, &sd, &cd) < 0) throw Error(E3D_ERR_INVALID, e3d_last_error());
+          if (e3d_reg_depth_cost(h, trial_jobs[j].first, trial_jobs[j].second, &sd, &cd) < 0) throw Error(E3D_ERR_INVALID, e3d_last_error());
           ts[2] += sd; tc[2] += cd;
         }
       }

@@ -371,7 +371,10 @@ int e3d_reg_kernel_times(e3d_reg_t* reg, double out[4], int reset);
 /* Wall-clock split of e3d_reg_run_on_current_scale by phase (accumulate, host solve, trial states, re-projection, costs, occlusion
  * depth maps, visibility, colour update).  enable = 1 switches it on (the library then synchronises its stream at every phase
  * boundary: the run gets slower, the split adds up), 0 off; `out` (may be NULL) receives "phase=milliseconds;..." of the phases
- * recorded so far.  Switching clears the record.  Measurement only -- no effect on results. */
+ * recorded so far, followed (ABI 4) by one "k:group=milliseconds,launches,units;" entry per kernel group of the iteration (HIP events
+ * on the handle's stream, no synchronisation of their own; units = the points, observations, pixels or triangles the launches
+ * covered -- what bench.py prices a group's algorithmic bytes with).  Switching clears the record.  Measurement only -- no effect on
+ * results. */
 int e3d_reg_profile(e3d_reg_t* reg, int enable, char* out, size_t capacity);
 
 /* Renders the occlusion depth map of an image at an image scale (kept on the device for e3d_reg_observe);

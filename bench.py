@@ -414,6 +414,39 @@ def leg_image_registrator(e3d, synth, args, dev):
     P.profile(True)
     t0 = time.perf_counter(); _, _, its_p = P.run_on_current_scale(3, 0.0, 15, False); t_prof = time.perf_counter() - t0
     phases = P.profile(False)
+    # every kernel group of those iterations: HIP-event time per launch against the bytes the group has to move at least
+    # (per unit, stated here; K neighbours, I intrinsics parameters).  Several of them are not HBM streams at all -- an atomic
+    # z-buffer, a 21 x 21 window, f64 elementary functions per projected point -- so `frac` says how far from the HBM roof the
+    # group runs, `bound` what holds it there.
+    group_bytes = {
+        "depth.zbuffer_clear": (4.0, "padded pixel: one 4 B store", "hbm"),
+        "depth.splat_bin": (20.0, "splat point: 16 B read + one 4 B atomicMin into the z-buffer", "L2 atomics at random pixels (one per point)"),
+        "depth.small_splat_tiles": (32.0, "(tile, small splat) pair: 8 B key/value through the radix sort + the 16 B rectangle", "hbm"),
+        "depth.min_filter": (16.0, "output pixel: 4 B in + 4 B out in each of the two separable 21-tap passes", "LDS window + issue"),
+        "depth.mesh_raster": (28.0, "triangle: 3 vertex indices + its share of the projected vertices", "issue (edge functions in f64)"),
+        "obs.eval_all_points": (36.0, "point: 16 B position + 4 B depth lookup + 16 B (valid, x, y, scale) out", "issue: projection with f64 atan / polynomial distortion"),
+        "obs.eval_listed_points": (36.0, "listed point: 4 B index + 16 B position + 16 B out", "issue: the same projection"),
+        "obs.scan": (12.0, "candidate: flag + zeroed distance slot read, slot cleared", "hbm"),
+        "obs.compact": (32.0, "candidate: 16 B in, 16 B out per kept observation", "hbm"),
+        "obs.neighbour_flags": (13.0 + 12.0 * K, "observation: index + K neighbour indices + K row gathers + K rows out + flag; 8 B per point of row map", "4 B gathers at random points"),
+        "intensity.sample": (24.0, "observation: 12 B position + 8 texels + 4 B out", "texel gathers"),
+        "intensity.scatter": (16.0, "observation: 4 B index + 4 B value + 4 B scattered store + 4 B of the cleared point array", "hbm (scatter)"),
+        "cost": (13.0 + 16.0 * K, "observation: index, flag, intensity, count + K x (neighbour index, neighbour intensity gather, fixed + variable descriptor)", "4 B gathers at random points"),
+        "color.accumulate": (17.0 + 16.0 * K, "observation: as cost, with the K variable descriptors added in place (atomics)", "L2 atomics"),
+        "color.finish": (4.0 + 8.0 * K, "point: K descriptors divided by the count, in place", "hbm"),
+        "color.clear": (4.0 + 4.0 * K, "point: descriptors + count cleared", "hbm"),
+        "accumulate.pass1": (24.0 + 12.0 + 8.0 + 4.0 * (I + 7), "observation: SURVEY 8(d)", "issue: Jacobians of the projection (f64 elementary functions)"),
+        "accumulate.pass2": ((8.0 * K + 4.0 * K + 4.0 * (K + 1) * (I + 7)) / 2.0 * (res_per_launch / max(n_obs, 1.0)), "observation: SURVEY 8(d)'s bytes per residual pair x pairs per observation", "matrix-core issue; rows of the K neighbours are L2 hits"),
+    }
+    groups = {}
+    for name, (ms, calls, units) in sorted(P.kernel_groups.items()):
+        bpu, what, bound = group_bytes.get(name, (None, "", ""))
+        per = ms / max(calls, 1)
+        by = bpu * units / max(calls, 1) if bpu else None
+        groups[name] = {"ms_per_iteration": ms / max(its_p, 1), "launches_per_iteration": calls / max(its_p, 1), "avg_launch_ms": per,
+                        "units_per_launch": units / max(calls, 1), "bytes_per_unit": bpu, "unit": what,
+                        "algorithmic_bytes_per_launch": by, "GBs": by / (per * 1e-3) / 1e9 if (by and per > 0) else None,
+                        "frac": by / (per * 1e-3) / 1e9 / HBM_PEAK_GBS if (by and per > 0) else None, "bound": bound}
     free, total = torch.cuda.mem_get_info(0)
     tr1, src1 = load_traffic("k_reg_pass1<2, false>")
     tr2, src2 = load_traffic("k_reg_pass2_tile32<5, 18>")
@@ -429,7 +462,9 @@ def leg_image_registrator(e3d, synth, args, dev):
            "run_phase_profile": {"note": "e3d_reg_profile: wall clock per phase of the same %d iterations with a stream synchronisation at every phase boundary "
                                          "(%.1f ms per iteration that way, %.1f ms without); iteration 1 has no Apply, so apply.* covers %d calls" %
                                          (its_p, t_prof / max(its_p, 1) * 1e3, t_run / max(its, 1) * 1e3, max(its_p - 1, 0)),
-                                 "ms_total": phases, "iterations": its_p},
+                                 "ms_total": phases, "iterations": its_p,
+                                 "kernel_groups": groups,
+                                 "kernel_groups_ms_per_iteration": sum(g["ms_per_iteration"] for g in groups.values())},
            "input_generation_s": t_gen,
            "roofline": {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "k_reg_pass1": {"algorithmic_bytes_per_launch": b1, "avg_launch_ms": p1_ms, "achieved": b1 / (p1_ms * 1e-3) / 1e9,
@@ -545,6 +580,8 @@ def main():
     ap.add_argument("--no-allpairs", action="store_true", help="skip the all-pairs scaling leg")
     ap.add_argument("--no-partial", action="store_true", help="skip the partial-overlap ICP leg (N = 1 only)")
     ap.add_argument("--partial-only", action="store_true", help="profiling: the headline leg itself on the partial-overlap room (N = 1)")
+    ap.add_argument("--only", choices=["reg", "normals", "allpairs"], default=None,
+                    help="profiling / development: run one of the secondary legs alone and print its JSON (N = 1; allpairs also N > 1)")
     ap.add_argument("--allpairs-scans", type=int, default=16)
     ap.add_argument("--allpairs-points", type=int, default=10_000_000)
     ap.add_argument("--allpairs-distance", type=float, default=0.02)
@@ -574,6 +611,17 @@ def main():
         raise SystemExit("libe3dhip: no device")
     R = Ranks(rank, world, local_rank, e3d)
 
+    if args.only:
+        if args.only == "allpairs":
+            res = leg_allpairs(e3d, synth, R, args, dev)
+        elif rank == 0 and world == 1:
+            res = leg_image_registrator(e3d, synth, args, dev) if args.only == "reg" else leg_normals(e3d, synth, args, dev)
+        else:
+            res = None
+        if rank == 0:
+            print(json.dumps(res))
+        R.close()
+        return
     if args.partial_only and world == 1:
         if rank == 0:
             print(json.dumps(leg_terrace(e3d, synth, R, args, dev, partial=True)))

@@ -1611,7 +1611,7 @@ __global__ __launch_bounds__(kBlock) void k_match_block_counts(const int* __rest
   const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool f = (j < n) && (ld_stream(match_pos + j) >= 0);
   const unsigned long long b = __ballot(f);
-  double d = f ? (double)ld_stream(match_d2 + j) : 0.0;
+  double d = (f && match_d2) ? (double)ld_stream(match_d2 + j) : 0.0;          // match_d2 == nullptr: counts only
   d = wave_sum(d);
   __shared__ unsigned sc[kBlock / kWave];
   __shared__ double sd[kBlock / kWave];

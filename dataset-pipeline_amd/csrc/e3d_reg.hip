@@ -810,11 +810,15 @@ template <int M>
 __global__ __launch_bounds__(kBlock) void k_obs_eval(const float4* __restrict__ pts, const unsigned* __restrict__ indices,
                                                      size_t count, Pose P, Pyramid Y, const float* __restrict__ occlusion,
                                                      ObsParams q, int* __restrict__ valid, float* __restrict__ ox,
-                                                     float* __restrict__ oy, float* __restrict__ os) {
+                                                     float* __restrict__ oy, float* __restrict__ os,
+                                                     unsigned* __restrict__ dropped) {
   const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= count) return;
   const size_t pi = indices ? indices[k] : k;
   valid[k] = -1;
+  // `dropped` (re-projection of a list, where nearly every point stays an observation): number of candidates that did not --
+  // zero means the list itself is the result and the compaction can be skipped
+  struct Drop { unsigned* c; bool kept = false; __device__ ~Drop() { if (c && !kept) atomicAdd(c, 1u); } } drop{dropped};
   const float4 p = pts[pi];
   float X, Yc, Z;
   rt(P, p.x, p.y, p.z, X, Yc, Z);
@@ -855,6 +859,7 @@ __global__ __launch_bounds__(kBlock) void k_obs_eval(const float4* __restrict__ 
   }
   valid[k] = (int)pi;
   ox[k] = jx; oy[k] = jy; os[k] = observation_scale;
+  drop.kept = true;
 }
 
 __global__ __launch_bounds__(kBlock) void k_obs_compact(const int* __restrict__ valid, const float* __restrict__ ox,
@@ -3091,30 +3096,47 @@ int64_t e3d_reg_observe(e3d_reg_t* h, int image_id, int point_scale, int image_s
   // the flags of the list the candidates came from still describe the result if every candidate stays an observation
   const bool flags_kept = !all && O.flags_src == (const void*)indices && O.flags_count == count;
   if (count) {
+    unsigned* d_dropped = nullptr;
+    if (!all) {
+      h->d_total.reserve(2);
+      d_dropped = reinterpret_cast<unsigned*>(h->d_total.p + 1);
+      E3D_HIP(hipMemsetAsync(d_dropped, 0, sizeof(unsigned), s));
+    }
     {
       KT kt(h, all ? "obs.eval_all_points" : "obs.eval_listed_points", (double)count);
       E3D_CAM_SWITCH(image_model(h, im), hipLaunchKernelGGL(k_obs_eval<M>, dim3(nblk(count)), dim3(kBlock), 0, s, S.pts.p, d_idx, count,
                                                             im.pose, make_pyramid(h, im), all ? im.depth.p : nullptr, q, h->valid.p,
-                                                            h->tx.p, h->ty.p, h->ts.p));
+                                                            h->tx.p, h->ty.p, h->ts.p, d_dropped));
     }
-    const size_t nb = div_up(count, kBlock);
-    h->block_counts.reserve(nb); h->block_offsets.reserve(nb); h->block_d2.reserve(nb);
-    h->chunk_sum.reserve(div_up(nb, 256) + 1); h->chunk_d2.reserve(div_up(nb, 256) + 1);
-    h->d_total.reserve(1); h->d_total_d2.reserve(1);
-    {
-      KT kt(h, "obs.scan", (double)count);
-      launch_match_scan(h->valid.p, nullptr, count, h->block_counts.p, h->block_offsets.p, h->block_d2.p, h->chunk_sum.p,
-                        h->chunk_d2.p, h->d_total.p, h->d_total_d2.p, s);
+    unsigned dropped = 1;
+    if (!all) {
+      copy_out(&dropped, d_dropped, sizeof dropped, s);
+      rsync(h);
     }
-    unsigned long long total = 0;
-    copy_out(&total, h->d_total.p, sizeof total, s);
-    rsync(h);
-    O.n = (size_t)total;
-    O.idx.reserve(O.n); O.x.reserve(O.n); O.y.reserve(O.n); O.s.reserve(O.n);
-    if (O.n) {
-      KT kt(h, "obs.compact", (double)count);
-      hipLaunchKernelGGL(k_obs_compact, dim3(nblk(count)), dim3(kBlock), 0, s, h->valid.p, h->tx.p, h->ty.p, h->ts.p, count,
-                         h->block_offsets.p, O.idx.p, O.x.p, O.y.p, O.s.p);
+    if (dropped == 0) {
+      // every listed point is still an observation: the list and the freshly written positions ARE the compacted result
+      O.n = count;
+      std::swap(O.idx, h->cand); std::swap(O.x, h->tx); std::swap(O.y, h->ty); std::swap(O.s, h->ts);
+    } else {
+      const size_t nb = div_up(count, kBlock);
+      h->block_counts.reserve(nb); h->block_offsets.reserve(nb); h->block_d2.reserve(nb);
+      h->chunk_sum.reserve(div_up(nb, 256) + 1); h->chunk_d2.reserve(div_up(nb, 256) + 1);
+      h->d_total.reserve(2); h->d_total_d2.reserve(1);
+      {
+        KT kt(h, "obs.scan", (double)count);
+        launch_match_scan(h->valid.p, nullptr, count, h->block_counts.p, h->block_offsets.p, h->block_d2.p, h->chunk_sum.p,
+                          h->chunk_d2.p, h->d_total.p, h->d_total_d2.p, s);
+      }
+      unsigned long long total = 0;
+      copy_out(&total, h->d_total.p, sizeof total, s);
+      rsync(h);
+      O.n = (size_t)total;
+      O.idx.reserve(O.n); O.x.reserve(O.n); O.y.reserve(O.n); O.s.reserve(O.n);
+      if (O.n) {
+        KT kt(h, "obs.compact", (double)count);
+        hipLaunchKernelGGL(k_obs_compact, dim3(nblk(count)), dim3(kBlock), 0, s, h->valid.p, h->tx.p, h->ty.p, h->ts.p, count,
+                           h->block_offsets.p, O.idx.p, O.x.p, O.y.p, O.s.p);
+      }
     }
   }
   if (flags_kept && O.n == count) {

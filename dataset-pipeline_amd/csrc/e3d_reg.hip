@@ -1990,16 +1990,52 @@ __global__ __launch_bounds__(kBlock) void k_reg_intensity(Pyramid Y, const float
 // (inten = intensity per observation; nrow = observation row of each neighbour point, k_obs_flags -- an observation with its flag
 // set has all K of them: the values the reference reads from its per-point intensity array, cost_calculator.cc:150-200, without
 // clearing and scattering that array for every image)
+// KK > 0: the neighbour count as a compile-time constant (the default 5): all row indices, then all gathers and descriptor loads of
+// an observation are requested together instead of one dependent pair after the other
+template <int KK>
 __global__ __launch_bounds__(kBlock) void k_reg_cost(const float* __restrict__ inten, const unsigned* __restrict__ o_idx,
                                                      const unsigned char* __restrict__ flags, size_t n_obs,
-                                                     const int* __restrict__ nrow, int K, const float* __restrict__ fixed_desc,
+                                                     const int* __restrict__ nrow, int K_rt, const float* __restrict__ fixed_desc,
                                                      const float* __restrict__ var_desc, const int* __restrict__ obs_counts,
                                                      RegWeights wts, double* __restrict__ partial) {
+  constexpr int KM = KK > 0 ? KK : 1;
+  const int K = KK > 0 ? KK : K_rt;
   double acc[4] = {0, 0, 0, 0};
+  const bool use_f = wts.fixed_weight > 0, use_v = wts.var_weight > 0;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_obs; i += (size_t)gridDim.x * blockDim.x) {
     if (!flags[i]) continue;
     const size_t p = o_idx[i];
     const float Ic = inten[i];
+    if (KK > 0) {
+      int r[KM];
+      float nb[KM], fd[KM], vd[KM];
+#pragma unroll
+      for (int k = 0; k < KM; ++k) r[k] = nrow[i * KM + k];
+      const bool var_ok = use_v && obs_counts[p] >= 2;
+#pragma unroll
+      for (int k = 0; k < KM; ++k) {
+        nb[k] = inten[r[k]];
+        fd[k] = use_f ? fixed_desc[p * KM + k] : 0.f;
+        vd[k] = var_ok ? var_desc[p * KM + k] : 0.f;
+      }
+      if (use_f) {
+        float pr = 0.f;
+#pragma unroll
+        for (int k = 0; k < KM; ++k) { const float c = (nb[k] - Ic) - fd[k]; pr += c * c; }
+        pr = sqrtf(pr);
+        acc[0] += (double)robust_residual(wts.robust_type, wts.robust_param, pr);
+        acc[2] += 1.0;
+      }
+      if (var_ok) {
+        float pr = 0.f;
+#pragma unroll
+        for (int k = 0; k < KM; ++k) { const float c = (nb[k] - Ic) - vd[k]; pr += c * c; }
+        pr = sqrtf(pr);
+        acc[1] += (double)robust_residual(wts.robust_type, wts.robust_param, pr);
+        acc[3] += 1.0;
+      }
+      continue;
+    }
 #pragma unroll
     for (int kind = 0; kind < 2; ++kind) {
       const float sw = kind == 0 ? wts.fixed_weight : wts.var_weight;
@@ -3343,13 +3379,18 @@ static void cost_enqueue(e3d_reg* h, int image_id, int point_scale, double* d_ou
   PointScale& S = get_scale(h, point_scale);
   Obs& O = get_obs(im, point_scale);
   obs_intensities(h, im, O);
-  const int nb = (int)std::min<size_t>(std::max<size_t>(div_up(O.n, kBlock * 4), 1), 1024);
+  // enough blocks for full occupancy (the loop is a chain of dependent gathers): 8 waves per SIMD on 256 CUs = 8192 blocks
+  const int nb = (int)std::min<size_t>(std::max<size_t>(div_up(O.n, kBlock * 4), 1), 8192);
   h->partial.reserve((size_t)nb * 4);
   const RegWeights w{h->prm.robust_weighting_type, h->prm.robust_weighting_parameter, h->prm.fixed_residuals_weight,
                      h->prm.variable_residuals_weight};
   KT kt(h, "cost", (double)O.n);
-  hipLaunchKernelGGL(k_reg_cost, dim3(nb), dim3(kBlock), 0, s, O.inten.p, O.idx.p, O.flags.p, O.n, O.nrow.p,
-                     h->prm.point_neighbor_count, S.fixed_desc.p, S.var_desc.p, S.obs_counts.p, w, h->partial.p);
+  if (h->prm.point_neighbor_count == 5)
+    hipLaunchKernelGGL(k_reg_cost<5>, dim3(nb), dim3(kBlock), 0, s, O.inten.p, O.idx.p, O.flags.p, O.n, O.nrow.p,
+                       h->prm.point_neighbor_count, S.fixed_desc.p, S.var_desc.p, S.obs_counts.p, w, h->partial.p);
+  else
+    hipLaunchKernelGGL(k_reg_cost<0>, dim3(nb), dim3(kBlock), 0, s, O.inten.p, O.idx.p, O.flags.p, O.n, O.nrow.p,
+                       h->prm.point_neighbor_count, S.fixed_desc.p, S.var_desc.p, S.obs_counts.p, w, h->partial.p);
   hipLaunchKernelGGL(k_reg_reduce, dim3(4), dim3(kWave), 0, s, h->partial.p, nb, 4, d_out);
 }
 }  // namespace e3d

@@ -207,37 +207,27 @@ def run_icp(e3d, R, icp, d, thr, warmup, steps, warmed=False):
     return dt, tot, warm, recs, per_rank
 
 
-def leg_terrace(e3d, synth, R, args, dev, partial=False):
-    """configs[1]: 2 scans, both movable; N > 1: weak scaling on a stretched room (same point density).
-    partial=True: the same job on the partial-overlap room (SURVEY 8(d): 30 - 60 % of the points find a partner)."""
-    import torch
-    world = R.world
-    n_points = args.points if args.points > 0 else 50_000_000 * (1 if partial else world)
-    d, thr = float(args.distance), 1e-10     # README.md:101 recommended flags; never converges within the bench's few iterations
-    room_scale = float(np.sqrt(n_points / 50_000_000.0)) if (world > 1 and args.points == 0 and not partial) else 1.0
-    scans = synth.make_scene(2, n_points, seed=1234, sigma=0.002, device=dev, room_scale=room_scale, partial=partial)
-    torch.cuda.synchronize()
-    icp = e3d.PointToPlaneICP(device=R.local_rank)
-    for s in scans:
-        icp.add_point_cloud(s["xyz"], s["normals"], s["T_init"], False)
-    if R.comm:
-        icp.set_comm(R.comm)
-    for it in range(args.warmup):                            # untimed warm-up steps (the timed region follows below)
-        icp.run(d, it, 1, thr, False)
-    base = None
-    if R.rank == 0 and world == 1 and not args.no_cpu_baseline and not partial:
-        # slab width chosen for ~4 M points per scan at this density (floor + two walls = 16 m^2 per metre of x); started from the
-        # poses the GPU run has reached after its warm-up, so both sides are timed in the same regime
-        width = min(10.0, 4.0e6 / (n_points / 242.6 * 16.0))
-        base = cpu_baseline_icp(scans, d, thr, (4.0, 4.0 + width), n_points, poses=[icp.get_result_global_T_cloud(i) for i in range(2)],
-                                first_iteration=args.warmup)
-    del scans
-    torch.cuda.empty_cache()
-    dt, tot, warm, recs, per_rank = run_icp(e3d, R, icp, d, thr, args.warmup, args.steps, warmed=True)
-    K = args.steps
+def comm_report(R, steps, per_rank):
+    """What the first multi-GPU run has to explain itself with: this rank's collectives by HIP events (enqueue -> completion on the
+    library's stream, so waiting for the slowest rank is inside), their number and payload, against the kernels they follow."""
+    ms, calls, nbytes = R.comm.stats()
+    mx = R.reduce([ms, per_rank["lm_kernel_ms_per_iter"] * steps, per_rank["nn_ms_per_iter"] * steps], "max")
+    mn = -R.reduce([-ms, -per_rank["lm_kernel_ms_per_iter"] * steps, -per_rank["nn_ms_per_iter"] * steps], "max")
+    return {"allreduce_calls_per_iter": calls / steps, "allreduce_bytes_per_call": nbytes / max(calls, 1),
+            "allreduce_ms_per_iter_rank0": ms / steps, "allreduce_ms_per_iter_max_over_ranks": mx[0] / steps,
+            "allreduce_ms_per_iter_min_over_ranks": mn[0] / steps,
+            "lm_kernel_ms_per_iter_max_min_over_ranks": [mx[1] / steps, mn[1] / steps],
+            "nn_phase_ms_per_iter_max_min_over_ranks": [mx[2] / steps, mn[2] / steps],
+            "note": "HIP events around every ncclAllReduce on the library's stream: the time includes waiting for the slowest rank's "
+                    "kernels in front of its all-reduce; the minimum over the ranks is close to the collective itself"}
+
+
+def icp_kernel_table(tot, world, K, pairs, moved_points, lm_kernel_name="k_lm_pass<1>"):
+    """Per-kernel-group table of an ICP leg from the summed iteration records (sum_records): HIP-event time per launch against
+    SURVEY 8(d)'s algorithmic bytes.  pairs = directed pairs per outer iteration, moved_points = points transformed per iteration."""
     corr, queries = tot[0], tot[1]
     lm_ms, nn_ms, passes = tot[2] / world, tot[3] / world, tot[4] / world
-    n_nn_launch = 2 * K
+    n_nn_launch = pairs * K
     lm_bytes = ALG_BYTES_PER_CORR_PASS * (corr / world / K)                  # one pass over this rank's correspondences
     nn_bytes = ALG_BYTES_PER_QUERY * (queries / world / n_nn_launch)         # one directed pair's queries
     lm_full_ms, full_passes = tot[8] / world, tot[9] / world
@@ -246,8 +236,8 @@ def leg_terrace(e3d, synth, R, args, dev, partial=False):
     rows_rewritten, rows_walked, multi_poses, passes_skipped = tot[23] / world, tot[24] / world, tot[25] / world, tot[26] / world
     lm_moved = 48.0 * rows_walked / K       # what a pass READS: three float4 per row it walks (resident rows: incl. the zero rows of listed groups)
     kernels = {
-        "k_lm_pass": {"what": "k_lm_pass<1>: fused cost + Gramian pass over the correspondence rows (a7/a8); %.2f launches per iteration; "
-                              "`algorithmic` = SURVEY 8(d)'s 56 B per correspondence, `moved` = the 48 B per row the pass reads" % (full_passes / K),
+        "k_lm_pass": {"what": "%s: fused cost + Gramian pass over the correspondence rows (a7/a8); %.2f launches per iteration; "
+                              "`algorithmic` = SURVEY 8(d)'s 56 B per correspondence, `moved` = the 48 B per row the pass reads" % (lm_kernel_name, full_passes / K),
                       "algorithmic_bytes_per_launch": lm_bytes, "avg_launch_ms": lm_avg, "GBs": lm_bytes / (lm_avg * 1e-3) / 1e9 if lm_avg > 0 else None,
                       "moved_bytes_per_launch": lm_moved, "GBs_moved": lm_moved / (lm_avg * 1e-3) / 1e9 if lm_avg > 0 else None,
                       "frac_moved": lm_moved / (lm_avg * 1e-3) / 1e9 / HBM_PEAK_GBS if lm_avg > 0 else None,
@@ -276,9 +266,8 @@ def leg_terrace(e3d, synth, R, args, dev, partial=False):
         avg = t_ms / launches if launches else None
         return {"what": what, "launches_per_iter": launches / K, "summed_ms_per_iter": t_ms / K, "avg_launch_ms": avg,
                 "algorithmic_bytes_per_launch": bytes_per_launch, "GBs": bytes_per_launch / (avg * 1e-3) / 1e9 if (avg and bytes_per_launch) else None}
-    n_rank = n_points / world if False else n_points     # every rank transforms the whole clouds
     kernels["k_transform_bbox"] = stream_kernel("a3: the cloud whose pose changed into the global frame + bounding box, 32 B per point moved (impl cloud 0 never "
-                                                "moves and is not transformed again)", tot[5] / world, K, 32.0 * n_rank)
+                                                "moves and is not transformed again)", tot[5] / world, K, 32.0 * moved_points)
     kernels["query_keys_and_sort"] = stream_kernel("cell keys + rocPRIM radix sort of the queries the row kernel searches (a5 prep)", tot[19] / world, max(tot[17] / world, 1), None)
     kernels["match_scan"] = stream_kernel("totals of the per-block match counts / distance sums + the list of active 64-row groups (3 small kernels per pair)",
                                           tot[20] / world, n_nn_launch, None)
@@ -289,6 +278,43 @@ def leg_terrace(e3d, synth, R, args, dev, partial=False):
     accounted = sum((v["summed_ms_per_iter"] or 0.0) for v in kernels.values())
     kernels["nn_search_per_pair"] = {"what": "certify + bounded + rows per directed pair: 32 B per query of the pair", "algorithmic_bytes_per_launch": nn_bytes, "avg_launch_ms": nn_avg,
                                      "GBs": nn_bytes / (nn_avg * 1e-3) / 1e9 if nn_avg > 0 else None, "summed_ms_per_iter": nn_ms / K}
+    return kernels, accounted, dict(corr=corr, queries=queries, lm_ms=lm_ms, nn_ms=nn_ms, passes=passes, nn_bytes=nn_bytes, nn_avg=nn_avg,
+                                    rows_rewritten=rows_rewritten, rows_walked=rows_walked)
+
+
+def leg_terrace(e3d, synth, R, args, dev, partial=False):
+    """configs[1]: 2 scans, both movable; N > 1: weak scaling on a stretched room (same point density).
+    partial=True: the same job on the partial-overlap room (SURVEY 8(d): 30 - 60 % of the points find a partner)."""
+    import torch
+    world = R.world
+    n_points = args.points if args.points > 0 else 50_000_000 * (1 if partial else world)
+    d, thr = float(args.distance), 1e-10     # README.md:101 recommended flags; never converges within the bench's few iterations
+    room_scale = float(np.sqrt(n_points / 50_000_000.0)) if (world > 1 and args.points == 0 and not partial) else 1.0
+    scans = synth.make_scene(2, n_points, seed=1234, sigma=0.002, device=dev, room_scale=room_scale, partial=partial)
+    torch.cuda.synchronize()
+    icp = e3d.PointToPlaneICP(device=R.local_rank)
+    for s in scans:
+        icp.add_point_cloud(s["xyz"], s["normals"], s["T_init"], False)
+    if R.comm:
+        icp.set_comm(R.comm)
+    for it in range(args.warmup):                            # untimed warm-up steps (the timed region follows below)
+        icp.run(d, it, 1, thr, False)
+    base = None
+    if R.rank == 0 and world == 1 and not args.no_cpu_baseline and not partial:
+        # slab width chosen for ~4 M points per scan at this density (floor + two walls = 16 m^2 per metre of x); started from the
+        # poses the GPU run has reached after its warm-up, so both sides are timed in the same regime
+        width = min(10.0, 4.0e6 / (n_points / 242.6 * 16.0))
+        base = cpu_baseline_icp(scans, d, thr, (4.0, 4.0 + width), n_points, poses=[icp.get_result_global_T_cloud(i) for i in range(2)],
+                                first_iteration=args.warmup)
+    del scans
+    torch.cuda.empty_cache()
+    if R.comm:
+        R.comm.stats(reset=True)
+    dt, tot, warm, recs, per_rank = run_icp(e3d, R, icp, d, thr, args.warmup, args.steps, warmed=True)
+    K = args.steps
+    kernels, accounted, m = icp_kernel_table(tot, world, K, 2, n_points)      # (every rank transforms the whole clouds, DESIGN 7)
+    corr, queries, lm_ms, nn_ms, passes = m["corr"], m["queries"], m["lm_ms"], m["nn_ms"], m["passes"]
+    rows_rewritten, rows_walked = m["rows_rewritten"], m["rows_walked"]
     dom = max(("k_lm_pass", "k_lm_cost_multi", "k_nn_certify", "k_nn_bounded", "k_nn_rows", "k_corr_update"), key=lambda k: kernels[k]["summed_ms_per_iter"] or 0.0)
     traffic, traffic_src = load_traffic({"k_lm_pass": "k_lm_pass<1>"}.get(dom, dom)) if (world == 1 and n_points == 50_000_000 and not partial) else (None, None)
     ach = kernels[dom]["GBs"] or 0.0
@@ -327,6 +353,8 @@ def leg_terrace(e3d, synth, R, args, dev, partial=False):
     }
     if world > 1:
         out["per_rank_rank0"] = per_rank
+    if R.comm:
+        out["comm"] = comm_report(R, K, per_rank)
     if base is not None:
         out["cpu_baseline"] = base
         out["speedup_vs_cpu_iteration_rate"] = (base["ms_per_iter"] / base["correspondences"]) / ((dt / K * 1e3) / (corr / K))
@@ -348,17 +376,39 @@ def leg_allpairs(e3d, synth, R, args, dev):
     torch.cuda.empty_cache()
     if R.comm:
         icp.set_comm(R.comm)
-    warmup, steps = 2, max(1, min(args.steps, 3))
+    # two untimed iterations (grids, first full searches), then ten timed ones: the first of them still search most queries
+    # again (the poses move by centimetres), the last ones run on certificates and resident rows -- both regimes are reported,
+    # `value` covers all timed iterations.  --steps below 10 shortens the timed part (profiling).
+    warmup, steps = 2, max(1, min(args.steps if args.steps != 20 else 10, 10))
+    if R.comm:
+        R.comm.stats(reset=True)
     dt, tot, warm, recs, per_rank = run_icp(e3d, R, icp, d, thr, warmup, steps)
     free, total = torch.cuda.mem_get_info(R.local_rank)
+    world = R.world
+    kernels, accounted, m = icp_kernel_table(tot, world, steps, S * (S - 1), n * (S - 1), lm_kernel_name="k_lm_pass<2> / <3> (two-sided pairs; <1> for the pairs of cloud 0)")
+    wall = [r["wall_ms"] for r in recs]
+    nnq = [r["t_nn_ms"] for r in recs]
+    first_steady = next((i for i, v in enumerate(wall) if v <= 1.25 * wall[-1]), len(wall) - 1)
+    dom = max(("k_lm_pass", "k_lm_cost_multi", "k_nn_certify", "k_nn_bounded", "k_nn_rows", "k_corr_update", "query_keys_and_sort"), key=lambda k: kernels[k]["summed_ms_per_iter"] or 0.0)
     out = {"metric": "ICP correspondences/sec", "value": tot[0] / dt, "unit": "correspondences/s", "scaling": "strong",
            "n_gpus": R.comm.world_size if R.comm else 1, "steps": steps, "warmup": warmup, "ms_per_iter": dt / steps * 1e3,
+           "ms_per_iter_each": wall,
+           "ms_per_iter_settling": float(np.mean(wall[:first_steady])) if first_steady > 0 else None,
+           "ms_per_iter_steady": float(np.mean(wall[first_steady:])), "steady_from_timed_iteration": first_steady,
+           "nn_ms_per_iter_each": nnq,
            "config": {"workload": "%d synthetic scans x %d points, all movable, all %d directed pairs, -d %g (north_star: 16-scan all-pairs ICP; "
                                   "configs[2] shape with --allpairs-scans 8 --allpairs-points 20000000)" % (S, n, S * (S - 1), d),
                       "unknowns": 6 * (S - 1), "parallelism": "every rank one slice of every directed pair's queries; one RCCL all-reduce of the "
                                                               "per-pair blocks per LM pass"},
            "correspondences_per_iter": tot[0] / steps, "queries_per_iter": tot[1] / steps, "lm_passes_per_iter": tot[4] / R.world / steps,
-           "rank0_ms_per_iter": per_rank, "hbm_in_use_GB_rank0": (total - free) / 1e9}
+           "rank0_ms_per_iter": per_rank, "hbm_in_use_GB_rank0": (total - free) / 1e9,
+           "roofline": {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "kernel": dom + ": " + kernels[dom]["what"],
+                        "achieved": kernels[dom]["GBs"], "frac": (kernels[dom]["GBs"] or 0.0) / HBM_PEAK_GBS,
+                        "frac_of_bytes_moved": kernels[dom].get("frac_moved"), "traffic": None,
+                        "algorithmic_bytes_per_launch": kernels[dom]["algorithmic_bytes_per_launch"], "avg_launch_ms": kernels[dom]["avg_launch_ms"],
+                        "kernels": kernels, "kernels_accounted_ms_per_iter": accounted}}
+    if R.comm:
+        out["comm"] = comm_report(R, steps, per_rank)
     del icp
     torch.cuda.empty_cache()
     return out

@@ -117,6 +117,63 @@ def make_scan(n, origin, yaw, seed, sigma=0.002, device="cpu", room_scale=1.0, p
     return xyz_local, nrm_local, T.astype(np.float32)
 
 
+def make_scan_angular(n, origin, yaw, seed, sigma=0.002, device="cpu"):
+    """The room as a REAL scanner samples it: rays in directions uniform on the sphere (equal angular steps), first hit with the
+    floor, the four walls and the cylinders -- the point density falls off with cos(incidence) / range^2 instead of being
+    uniform per area (make_scan).  Rays that leave through the open top are dropped.  Returns what make_scan returns."""
+    g = torch.Generator(device=device)
+    g.manual_seed(int(seed))
+    W, D, Hh = _ROOM
+    o = torch.tensor(origin, device=device, dtype=torch.float64)
+    pts, nrms = [], []
+    have = 0
+    while have < n:
+        m = int((n - have) * 1.7) + 1024
+        u = torch.rand(m, generator=g, device=device, dtype=torch.float64) * 2 - 1          # cos(polar): uniform on the sphere
+        ph = torch.rand(m, generator=g, device=device, dtype=torch.float64) * (2 * math.pi)
+        sr = torch.sqrt((1 - u * u).clamp_(min=0))
+        d = torch.stack([sr * torch.cos(ph), sr * torch.sin(ph), u], 1)
+        inf = torch.full((m,), float("inf"), device=device, dtype=torch.float64)
+        t = inf.clone()
+        nr = torch.zeros(m, 3, device=device, dtype=torch.float64)
+
+        def plane(axis, value, normal):
+            nonlocal t, nr
+            tt = (value - o[axis]) / d[:, axis]
+            p = o + tt[:, None] * d
+            ok = (tt > 1e-9) & (tt < t) & (p[:, 0] >= -1e-9) & (p[:, 0] <= W + 1e-9) & (p[:, 1] >= -1e-9) & (p[:, 1] <= D + 1e-9) & (p[:, 2] >= -1e-9) & (p[:, 2] <= Hh + 1e-9)
+            t = torch.where(ok, tt, t)
+            nr[ok] = torch.tensor(normal, device=device, dtype=torch.float64)
+        plane(2, 0.0, (0.0, 0.0, 1.0)); plane(0, 0.0, (1.0, 0.0, 0.0)); plane(0, W, (-1.0, 0.0, 0.0))
+        plane(1, 0.0, (0.0, 1.0, 0.0)); plane(1, D, (0.0, -1.0, 0.0))
+        a = d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]
+        for (cx, cy, r) in _CYL:
+            fx, fy = o[0] - cx, o[1] - cy
+            b = 2.0 * (fx * d[:, 0] + fy * d[:, 1])
+            c = fx * fx + fy * fy - r * r
+            disc = b * b - 4.0 * a * c
+            tt = (-b - torch.sqrt(disc.clamp(min=0.0))) / (2.0 * a).clamp(min=1e-30)
+            z = o[2] + tt * d[:, 2]
+            ok = (disc > 0) & (tt > 1e-9) & (tt < t) & (z >= 0) & (z <= Hh)
+            t = torch.where(ok, tt, t)
+            p = o + tt[:, None] * d
+            nc = torch.stack([(p[:, 0] - cx) / r, (p[:, 1] - cy) / r, torch.zeros_like(tt)], 1)
+            nr = torch.where(ok[:, None], nc, nr)
+        hit = torch.isfinite(t)
+        noise = torch.randn(m, generator=g, device=device, dtype=torch.float64) * sigma
+        p = o + (t + noise)[:, None] * d
+        pts.append(p[hit]); nrms.append(nr[hit])
+        have += int(hit.sum())
+    p = torch.cat(pts)[:n]; nr = torch.cat(nrms)[:n]
+    flip = ((o - p) * nr).sum(dim=1, keepdim=True) < 0
+    nr = torch.where(flip, -nr, nr)
+    R = torch.tensor(_rot_z(yaw), device=device, dtype=torch.float64)
+    T = np.eye(4, dtype=np.float64)
+    T[:3, :3] = _rot_z(yaw)
+    T[:3, 3] = np.asarray(origin, dtype=np.float64)
+    return ((p - o) @ R).to(torch.float32).contiguous(), (nr @ R).to(torch.float32).contiguous(), T.astype(np.float32)
+
+
 def _surface_samples(m, g, device):
     """m points sampled uniformly by area on the surfaces of the partial-overlap room: exact positions + outward normals (f64)."""
     W, D, Hh = _ROOM

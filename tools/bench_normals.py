@@ -26,13 +26,14 @@ def main():
     ap.add_argument("--repeat", type=int, default=3)
     ap.add_argument("--cpu-points", type=int, default=1_000_000)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--angular", action="store_true", help="sample the room as a scanner does (uniform in angle: density ~ cos / range^2) instead of uniformly per area")
     a = ap.parse_args()
     e3d = importlib.import_module("dataset-pipeline_amd")
     synth = importlib.import_module("dataset-pipeline_amd.synth")
     capi = importlib.import_module("dataset-pipeline_amd.capi")
     dev = torch.device("cuda:0")
     origin, yaw = synth.SCAN_POSES[0]
-    xyz, _, _ = synth.make_scan(a.points, origin, yaw, 1234, device=dev)
+    xyz, _, _ = (synth.make_scan_angular if a.angular else synth.make_scan)(a.points, origin, yaw, 1234, device=dev)
     xyz = xyz.contiguous()
     n = int(xyz.shape[0])
     on = torch.empty((n, 3), dtype=torch.float32, device=dev)
@@ -51,7 +52,7 @@ def main():
     dt = (time.perf_counter() - t0) / a.repeat
     finite = float(torch.isfinite(on).all(dim=1).float().mean())
     unit = float(((on * on).sum(1).sqrt() - 1).abs()[torch.isfinite(on).all(dim=1)].max())
-    out = {"metric": "normals/s", "value": n / dt, "points": n, "k": a.k, "ms_per_call": dt * 1e3,
+    out = {"metric": "normals/s", "value": n / dt, "points": n, "k": a.k, "ms_per_call": dt * 1e3, "sampling": "angular (scanner)" if a.angular else "uniform per area",
            "algorithmic_bytes_per_point": 12 * a.k + 28, "algorithmic_GBs": n * (12 * a.k + 28) / dt / 1e9,
            "finite_fraction": finite, "max_abs_norm_minus_1": unit}
     if not a.no_cpu:

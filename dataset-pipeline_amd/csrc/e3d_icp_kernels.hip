@@ -1383,14 +1383,7 @@ constexpr int kHalfRuns = 18;     // run-list slots per lane in LDS: the 3 x 3 x
 // 5.4 / 4.7 ms, <4, true> 8.5 / 6.5 / 4.5 / 4.0, <8, true> 8.1 / 6.3 / 4.3 / 3.8 (the choice), <12, true> (87 VGPRs, five blocks)
 // 8.8 / 6.8 / 4.5 / 4.0; a 14-slot list at 64 VGPRs (eight blocks, 7 - 13 spilled registers) 11.6 / 8.9 / 6.2 / 5.4: the queries
 // whose box touches more sub-rows than slots pay whole-cell rows.
-// BAL (round 4): the lanes of a block trade their candidate walks.  A query's box touches 1, 2, 4 or 8 half cells, so the walks of
-// the 64 lanes of a wave differ by more than a factor of two (23 candidates on average, 50 for the longest lane of a wave) and a
-// wave took as long as its longest lane.  After the run lists are built the 256 slots of the block are counting-sorted by their
-// candidate count (LDS histogram, ~40 instructions per thread) and thread t walks slot perm[t]: every wave then holds walks of
-// similar length (the four waves of a block take the four quartiles).  The run lists already sit in LDS; the walker reads the
-// slot's query again from memory and leaves the slot's result in the slot's run storage, where the owner picks it up.  Which
-// thread walks a slot changes nothing in the slot's result.
-template <int BATCH, bool BAL>
+template <int BATCH>
 __global__ __launch_bounds__(kBlock) void k_nn_bounded_half(const float4* __restrict__ Gsrc, const unsigned* __restrict__ list,
                                                             unsigned n_list, const float4* __restrict__ Gtgt, const unsigned* __restrict__ S,
                                                             const unsigned long long* __restrict__ H8,
@@ -1401,11 +1394,10 @@ __global__ __launch_bounds__(kBlock) void k_nn_bounded_half(const float4* __rest
   __shared__ unsigned s_runs[kHalfRuns][kBlock];
   __shared__ unsigned char s_len[kHalfRuns][kBlock];
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool live = i < n_list;
-  if (!BAL && !live) return;
-  const unsigned j = live ? list[i] : 0u;
-  const float4 q = live ? Gsrc[j] : make_float4(0.f, 0.f, 0.f, 0.f);
-  const int m = live ? match[j] : -1;
+  if (i >= n_list) return;
+  const unsigned j = list[i];
+  const float4 q = Gsrc[j];
+  const int m = match[j];
   float d1 = r2;                                     // no old partner
   if (m >= 0) {
     const float4 pc = Gtgt[m];
@@ -1429,7 +1421,7 @@ __global__ __launch_bounds__(kBlock) void k_nn_bounded_half(const float4* __rest
   // what the scanned box covers: every target point outside it is at least `fd` HALF cells away in the target's local frame
   // (faces at the edge of the dense grid do not count), i.e. at global distance >= fd * cell_scale / 2 - cell_sub
   float cover_box2 = 0.f;
-  const bool any = live && FX0 <= FX1 && FY0 <= FY1 && FZ0 <= FZ1;
+  const bool any = FX0 <= FX1 && FY0 <= FY1 && FZ0 <= FZ1;
   if (any) {
     const float ux = (lx - g.origin[0]) * inv_h - (float)(2 * qr.lo[0]), uy = (ly - g.origin[1]) * inv_h - (float)(2 * qr.lo[1]),
                 uz = (lz - g.origin[2]) * inv_h - (float)(2 * qr.lo[2]);
@@ -1453,7 +1445,6 @@ __global__ __launch_bounds__(kBlock) void k_nn_bounded_half(const float4* __rest
   // are then walked as ONE sequence, BATCH gathers in flight.
   const int cx0 = FX0 >> 1, cx1 = FX1 >> 1;
   int nr = 0;
-  unsigned tot = 0;                                        // candidates of the run list
 #define RUN_S(i) s_runs[(i)][threadIdx.x]
 #define RUN_LEN(i) s_len[(i)][threadIdx.x]
 #define RUN_E(i) (RUN_S(i) + (unsigned)RUN_LEN(i))
@@ -1502,7 +1493,6 @@ __global__ __launch_bounds__(kBlock) void k_nn_bounded_half(const float4* __rest
                   if (e0 < e1) {                             // at most 3 x 3 x 2 sub-rows lie in the box: the list cannot overflow
                     RUN_S(nr) = st + e0;
                     RUN_LEN(nr) = (unsigned char)(e1 - e0);
-                    tot += e1 - e0;
                     ++nr;
                   }
                 }
@@ -1514,55 +1504,22 @@ __global__ __launch_bounds__(kBlock) void k_nn_bounded_half(const float4* __rest
       nr = -1;                                             // a large box: the plain loops below
     }
   }
-  // which slot this thread walks: its own, or (BAL) the one the counting sort hands it
-  int col = (int)threadIdx.x, wnr = nr;
-  float4 qw = q;
-  if (BAL) {
-    __shared__ unsigned s_hist[64];
-    __shared__ unsigned char s_perm[kBlock], s_nr[kBlock];
-    if (threadIdx.x < 64) s_hist[threadIdx.x] = 0u;
-    s_nr[threadIdx.x] = (unsigned char)(nr > 0 ? nr : 0);
-    __syncthreads();
-    const unsigned key = nr > 0 ? min((tot + 1u) >> 1, 63u) : 0u;
-    const unsigned rank = atomicAdd(&s_hist[key], 1u);
-    __syncthreads();
-    if (threadIdx.x < 64) {                                // exclusive prefix of the 64 bins, one wave
-      const unsigned v = s_hist[threadIdx.x];
-      unsigned incl = v;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) { const unsigned u = __shfl_up(incl, o, 64); if ((int)threadIdx.x >= o) incl += u; }
-      s_hist[threadIdx.x] = incl - v;
-    }
-    __syncthreads();
-    s_perm[s_hist[key] + rank] = (unsigned char)threadIdx.x;
-    __syncthreads();
-    col = (int)s_perm[threadIdx.x];
-    wnr = (int)s_nr[col];
-    if (wnr > 0 && col != (int)threadIdx.x) qw = Gsrc[list[blockIdx.x * blockDim.x + (unsigned)col]];
-  }
-#undef RUN_S
-#undef RUN_LEN
-#undef RUN_E
-#define RUN_S(i) s_runs[(i)][col]
-#define RUN_LEN(i) s_len[(i)][col]
-#define RUN_E(i) (RUN_S(i) + (unsigned)RUN_LEN(i))
-  if (wnr > 0) {
+  if (nr > 0) {
     // One flat walk over the candidates of all runs, BATCH gathers in flight, without a branch: the search is bound by the
     // vector instructions it issues.  Squared distances are compared as bit patterns -- non-negative floats and +inf order like
     // unsigned integers, a NaN sorts above +inf and is never taken (as with '<' on floats), and v_min_u32 / v_max_u32 need no
     // canonicalisation of their operands; a slot past the last candidate holds +inf, which changes nothing.
     const unsigned uinf = 0x7f800000u;
     unsigned ud = uinf, ud2 = uinf, u3 = uinf;
-    int wpos = -1, wpos2 = -1;
     int r = 0;
-    const int last = wnr - 1;
+    const int last = nr - 1;
     unsigned cur = RUN_S(0), end = RUN_E(0);
-    while (r < wnr) {
+    while (r < nr) {
       unsigned p[BATCH];
       bool ok[BATCH];
 #pragma unroll
       for (int t = 0; t < BATCH; ++t) {
-        ok[t] = r < wnr;
+        ok[t] = r < nr;
         p[t] = cur;                                        // (beyond the last candidate: a valid address, result ignored)
         const unsigned nx = cur + 1u;
         const bool sw = ok[t] && nx == end;                // the run ends here: the next one (or, after the last, its start again)
@@ -1577,32 +1534,20 @@ __global__ __launch_bounds__(kBlock) void k_nn_bounded_half(const float4* __rest
       for (int t = 0; t < BATCH; ++t) c4[t] = Gtgt[p[t]];
 #pragma unroll
       for (int t = 0; t < BATCH; ++t) {
-        const unsigned u = ok[t] ? __float_as_uint(sqdist_l2(qw.x, qw.y, qw.z, c4[t].x, c4[t].y, c4[t].z)) : uinf;
+        const unsigned u = ok[t] ? __float_as_uint(sqdist_l2(q.x, q.y, q.z, c4[t].x, c4[t].y, c4[t].z)) : uinf;
         const bool lt1 = u < ud, lt2 = u < ud2;
         u3 = min(u3, max(u, ud2));                         // the displaced runner-up, or this candidate
         ud2 = min(max(u, ud), ud2);
-        wpos2 = lt1 ? wpos : (lt2 ? (int)p[t] : wpos2);
+        bpos2 = lt1 ? bpos : (lt2 ? (int)p[t] : bpos2);
         ud = min(u, ud);
-        wpos = lt1 ? (int)p[t] : wpos;
+        bpos = lt1 ? (int)p[t] : bpos;
       }
     }
-    if (BAL) {                                             // the result goes back through the slot's own run storage
-      s_runs[0][col] = ud; s_runs[1][col] = ud2; s_runs[2][col] = u3; s_runs[3][col] = (unsigned)wpos; s_runs[4][col] = (unsigned)wpos2;
-    } else {
-      bd = __uint_as_float(ud); bd2 = __uint_as_float(ud2); b3 = __uint_as_float(u3); bpos = wpos; bpos2 = wpos2;
-    }
-  }
-#undef RUN_S
-#undef RUN_LEN
-#undef RUN_E
-#define RUN_S(i) s_runs[(i)][threadIdx.x]
-#define RUN_LEN(i) s_len[(i)][threadIdx.x]
-#define RUN_E(i) (RUN_S(i) + (unsigned)RUN_LEN(i))
-  if (nr < 0) {
+    bd = __uint_as_float(ud); bd2 = __uint_as_float(ud2); b3 = __uint_as_float(u3);
+  } else if (nr < 0) {
     // a large box (a query without a partner looks np_extra beyond the radius; a partner that moved far): whole grid cells, row by
     // row -- the cells [x0, x1] of one (y, z) row are ONE run of the cell directory, and an empty row costs two words.  A superset
-    // of the half cells of the box: nothing is missed, and the covered region only grows.  (BAL: such a slot counts as empty in
-    // the sort, so its owner walked one of the shortest lists before it gets here.)
+    // of the half cells of the box: nothing is missed, and the covered region only grows.
     for (int gz = FZ0 >> 1; gz <= (FZ1 >> 1); ++gz)
       for (int gy = FY0 >> 1; gy <= (FY1 >> 1); ++gy) {
         const size_t row = ((size_t)gz * qr.D[1] + (size_t)gy) * qr.D[0];
@@ -1618,14 +1563,6 @@ __global__ __launch_bounds__(kBlock) void k_nn_bounded_half(const float4* __rest
           bpos = lt1 ? (int)p : bpos;
         }
       }
-  }
-  if (BAL) {
-    __syncthreads();
-    if (!live) return;
-    if (nr > 0) {
-      bd = __uint_as_float(s_runs[0][threadIdx.x]); bd2 = __uint_as_float(s_runs[1][threadIdx.x]); b3 = __uint_as_float(s_runs[2][threadIdx.x]);
-      bpos = (int)s_runs[3][threadIdx.x]; bpos2 = (int)s_runs[4][threadIdx.x];
-    }
   }
   // exact f32 equalities among the three smallest: the same candidates again with the full (d2, original index) order (rare)
   if (any && ((bd == bd2 && bd < kInf) || (bd2 == b3 && bd2 < kInf))) {
@@ -1645,9 +1582,9 @@ __global__ __launch_bounds__(kBlock) void k_nn_bounded_half(const float4* __rest
         }
       }
     };
-    if (!BAL && nr >= 0) {
+    if (nr >= 0) {
       for (int r = 0; r < nr; ++r) exact_run(RUN_S(r), RUN_E(r));
-    } else {     // (BAL: the slot's run storage holds its result by now; whole-cell rows are a superset of the box, like a large box's)
+    } else {
       for (int gz = FZ0 >> 1; gz <= (FZ1 >> 1); ++gz)
         for (int gy = FY0 >> 1; gy <= (FY1 >> 1); ++gy) {
           const size_t row = ((size_t)gz * qr.D[1] + (size_t)gy) * qr.D[0];
@@ -2609,14 +2546,8 @@ void launch_nn_bounded(const float4* Gsrc, const unsigned* list, size_t n_list, 
   static const size_t half_min = [] { const char* e = getenv("E3D_NN_HALF_MIN"); return e ? (size_t)atoll(e) : (size_t)200000; }();
   if (half_prefix && (half_always || n_list >= half_min)) {
     // long lists are bound by the candidates they evaluate: the half-cell directory cuts those to a third
-    // E3D_NN_BALANCE=0: every lane walks its own candidates (the round-3 kernel; A/B timing)
-    static const bool balance = [] { const char* e = getenv("E3D_NN_BALANCE"); return !(e && e[0] == '0'); }();
-    if (balance)
-      hipLaunchKernelGGL((k_nn_bounded_half<8, true>), dim3((unsigned)div_up(n_list, kBlock)), dim3(kBlock), 0, s, Gsrc, list, (unsigned)n_list,
-                         Gtgt, dense_start, half_prefix, g, im, qr, r2, bp, match, match2, match_d2, lbe);
-    else
-      hipLaunchKernelGGL((k_nn_bounded_half<8, false>), dim3((unsigned)div_up(n_list, kBlock)), dim3(kBlock), 0, s, Gsrc, list, (unsigned)n_list,
-                         Gtgt, dense_start, half_prefix, g, im, qr, r2, bp, match, match2, match_d2, lbe);
+    hipLaunchKernelGGL((k_nn_bounded_half<8>), dim3((unsigned)div_up(n_list, kBlock)), dim3(kBlock), 0, s, Gsrc, list, (unsigned)n_list,
+                       Gtgt, dense_start, half_prefix, g, im, qr, r2, bp, match, match2, match_d2, lbe);
     return;
   }
   if (n_list <= quad_limit)

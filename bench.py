@@ -488,15 +488,25 @@ def leg_image_registrator(e3d, synth, args, dev):
         "accumulate.pass1": (24.0 + 12.0 + 8.0 + 4.0 * (I + 7), "observation: SURVEY 8(d)", "issue: Jacobians of the projection (f64 elementary functions)"),
         "accumulate.pass2": ((8.0 * K + 4.0 * K + 4.0 * (K + 1) * (I + 7)) / 2.0 * (res_per_launch / max(n_obs, 1.0)), "observation: SURVEY 8(d)'s bytes per residual pair x pairs per observation", "matrix-core issue; rows of the K neighbours are L2 hits"),
     }
+    # the kernels behind a group in the committed counter passes (profiles/round<N>_traffic.json: HBM bytes per launch; a 4-image run
+    # of this same leg, so per-launch figures carry over)
+    group_kernels = {"depth.zbuffer_clear": [], "depth.splat_bin": ["k_splat_bin<2>"], "depth.min_filter": ["k_min_filter_tile"],
+                     "obs.eval_all_points": ["k_obs_eval<2>"], "obs.eval_listed_points": ["k_obs_eval<2>"], "obs.compact": ["k_obs_compact"],
+                     "obs.neighbour_flags": ["k_obs_flags", "k_obs_mark"], "intensity.sample": ["k_reg_intensity"], "cost": ["k_reg_cost<5>"],
+                     "color.accumulate": ["k_color_accumulate"], "color.finish": ["k_color_finish"],
+                     "accumulate.pass1": ["k_reg_pass1<2, false>"], "accumulate.pass2": ["k_reg_pass2_tile32<5, 18>"]}
     groups = {}
     for name, (ms, calls, units) in sorted(P.kernel_groups.items()):
         bpu, what, bound = group_bytes.get(name, (None, "", ""))
+        trs = [load_traffic(kn)[0] for kn in group_kernels.get(name, [])]
+        traffic = sum(trs) if trs and all(t is not None for t in trs) else None
         per = ms / max(calls, 1)
         by = bpu * units / max(calls, 1) if bpu else None
         groups[name] = {"ms_per_iteration": ms / max(its_p, 1), "launches_per_iteration": calls / max(its_p, 1), "avg_launch_ms": per,
                         "units_per_launch": units / max(calls, 1), "bytes_per_unit": bpu, "unit": what,
                         "algorithmic_bytes_per_launch": by, "GBs": by / (per * 1e-3) / 1e9 if (by and per > 0) else None,
-                        "frac": by / (per * 1e-3) / 1e9 / HBM_PEAK_GBS if (by and per > 0) else None, "bound": bound}
+                        "frac": by / (per * 1e-3) / 1e9 / HBM_PEAK_GBS if (by and per > 0) else None, "bound": bound,
+                        "traffic": traffic, "traffic_over_algorithmic": (traffic / by) if (traffic and by) else None}
     free, total = torch.cuda.mem_get_info(0)
     tr1, src1 = load_traffic("k_reg_pass1<2, false>")
     tr2, src2 = load_traffic("k_reg_pass2_tile32<5, 18>")

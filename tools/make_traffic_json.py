@@ -1,22 +1,23 @@
-"""profiles/round2_traffic.json from the rocprofv3 PMC passes of tools/prof_round2.sh (gpurun_out/r2prof/*_fetch.txt, *_write.txt:
+"""profiles/round<N>_traffic.json from the rocprofv3 PMC passes of tools/prof_round4.sh (gpurun_out/r4prof/*_fetch.txt, *_write.txt:
 lines `kernel signature, COUNTER, value summed over the launches, launches`).
 
-    python tools/make_traffic_json.py [gpurun_out/r3prof] [profiles/round3_traffic.json]"""
+    python tools/make_traffic_json.py [gpurun_out/r4prof] [profiles/round4_traffic.json]"""
 import json
 import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-NOTE = ("HBM traffic per launch from rocprofv3 PMC, separate --pmc FETCH_SIZE and --pmc WRITE_SIZE passes (tools/prof_round3.sh): the ICP "
+NOTE = ("HBM traffic per launch from rocprofv3 PMC, separate --pmc FETCH_SIZE and --pmc WRITE_SIZE passes (tools/prof_round4.sh): the ICP "
         "kernels from `bench.py --no-cpu-baseline --no-reg --no-normals --no-allpairs --steps 3 --warmup 2` (2 x 50 M points; the full-overlap and the partial-overlap leg, launches of both averaged), the "
-        "k_reg_* kernels from `tools/bench_c4.py --images 2 --accumulate-only` (6048 x 4032 THIN_PRISM_FISHEYE, 10 M points), the normals "
+        "ImageRegistrator kernels (k_reg_*, k_obs_*, k_splat_*, k_min_filter_*, k_color_*) from `bench.py --only reg --no-cpu-baseline --reg-images 4` (6048 x 4032 "
+        "THIN_PRISM_FISHEYE, 10 M points: observation refreshes, accumulate passes and RunOnCurrentScale iterations), the normals "
         "entries k_knn_normals_k32 / _k8 = ALL kernels of one e3d_normals_knn call on 20 M points (`tools/bench_normals.py --repeat 1`: "
         "two calls per run, sums halved). Units: the counters are KiB; on gfx950 FETCH_SIZE reports half of a wide coalesced read "
         "(MI355X_MICROARCH.md, HBM section) -> bytes = 1024 * (2 * FETCH_SIZE + WRITE_SIZE); calibrated in round 1 on k_transform_bbox "
         "(16 B read + 16 B written per point x 50 M = 800 MB each).")
 
 
-FULL_SIZE = ("k_lm_pass", "k_lm_cost_multi", "k_compact_corr", "k_nn_certify", "k_transform_bbox", "k_match_block_counts")
+FULL_SIZE = ("k_lm_pass", "k_lm_cost_multi", "k_compact_corr", "k_corr_update", "k_nn_certify", "k_transform_bbox", "k_match_block_counts")
 
 
 def parse(path, counter):
@@ -35,8 +36,8 @@ def parse(path, counter):
 
 
 def main():
-    src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "r3prof")
-    dst = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles", "round3_traffic.json")
+    src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "r4prof")
+    dst = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles", "round4_traffic.json")
     kernels = {}
     for tag in ("icp", "reg"):
         f, w = parse(os.path.join(src, tag + "_fetch.txt"), "FETCH_SIZE"), parse(os.path.join(src, tag + "_write.txt"), "WRITE_SIZE")

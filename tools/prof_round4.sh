@@ -9,7 +9,7 @@ mkdir -p $O
 STAGES=${@:-trace terrace icp reg normals sq}
 SUM="python $R/tools/rocpd_summary.py"
 ICP="python $R/bench.py --no-cpu-baseline --no-reg --no-normals --no-allpairs --steps 3 --warmup 2"
-REG="python $R/tools/bench_c4.py --images 2 --accumulate-only"
+REG="python $R/bench.py --only reg --no-cpu-baseline --reg-images 4"
 pmc() {  # pmc <tag> <counters...> -- <command>
   local tag=$1; shift
   local ctr=(); while [ "$1" != "--" ]; do ctr+=("$1"); shift; done; shift
@@ -38,6 +38,12 @@ for st in $STAGES; do
       echo "[partial] rc=$?"
       $SUM /tmp/r4p_partial/b_results.db $O/partial_kernel_stats.txt e3d > /dev/null 2>&1
       head -12 $O/partial_kernel_stats.txt | cut -c1-60,150-230 ;;
+    allpairs)   # the all-pairs leg alone: kernel trace of its ten timed iterations
+      rm -rf /tmp/r4p_ap
+      timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/r4p_ap -o b -- python $R/bench.py --only allpairs > $O/allpairs_traced.json 2> /dev/null
+      echo "[allpairs] rc=$?"
+      $SUM /tmp/r4p_ap/b_results.db $O/allpairs_kernel_stats.txt e3d > /dev/null 2>&1
+      head -14 $O/allpairs_kernel_stats.txt | cut -c1-60,150-230 ;;
     icp)
       pmc icp_fetch FETCH_SIZE -- $ICP
       pmc icp_write WRITE_SIZE -- $ICP ;;

@@ -482,7 +482,7 @@ def leg_image_registrator(e3d, synth, args, dev):
         "intensity.sample": (24.0, "observation: 12 B position + 8 texels + 4 B out", "texel gathers"),
         "intensity.scatter": (16.0, "observation: 4 B index + 4 B value + 4 B scattered store + 4 B of the cleared point array", "hbm (scatter)"),
         "cost": (13.0 + 16.0 * K, "observation: index, flag, intensity, count + K x (neighbour index, neighbour intensity gather, fixed + variable descriptor)", "4 B gathers at random points"),
-        "color.accumulate": (17.0 + 16.0 * K, "observation: as cost, with the K variable descriptors added in place (atomics)", "L2 atomics"),
+        "color.accumulate": (17.0 + 16.0 * K, "observation: as cost, with the K variable descriptors added in place (read-modify-write; a point occurs once per image, no atomics)", "4 B gathers at random points + read-modify-write"),
         "color.finish": (4.0 + 8.0 * K, "point: K descriptors divided by the count, in place", "hbm"),
         "color.clear": (4.0 + 4.0 * K, "point: descriptors + count cleared", "hbm"),
         "accumulate.pass1": (24.0 + 12.0 + 8.0 + 4.0 * (I + 7), "observation: SURVEY 8(d)", "issue: Jacobians of the projection (f64 elementary functions)"),

@@ -149,6 +149,7 @@ struct e3d_icp {
   // data flow; A/B timing, tests)
   bool resident_rows = [] { const char* e = getenv("E3D_ICP_RESIDENT"); return !(e && e[0] == '0'); }();
   bool resident_now = false;                    // this outer iteration keeps resident rows for the pairs of the certificate path
+  int lm_prev_end_step = -1;                    // LM step at which the previous outer iteration's LM ended with ten rejections (-1: none yet)
   DevBuf<LmSet> d_sets;
   PinBuf<LmSet> h_sets;
   DevBuf<LmPose> d_poses;
@@ -947,7 +948,6 @@ static void lm_compute(e3d_icp* h, LmSystem& L, std::vector<SE3f>& poses, e3d_ic
   lm_evaluate(h, L, poses, true, H, b, cost, rec);
   rec.initial_cost = cost;
   rec.final_cost = cost;
-  std::vector<SE3f> upd(poses.size());
   auto candidate = [&](double lam, std::vector<SE3f>& out) {
     Hl = H;
     for (int i = 0; i < nv; ++i) Hl[(size_t)i * nv + i] += lam;            // additive damping (impl.h:223)
@@ -965,40 +965,65 @@ static void lm_compute(e3d_icp* h, LmSystem& L, std::vector<SE3f>& poses, e3d_ic
     return a.size() == b.size() && std::memcmp(a.data(), b.data(), a.size() * sizeof(SE3f)) == 0;
   };
   static_assert(sizeof(SE3f) == 7 * sizeof(float), "SE3f is compared as raw floats");
+  // All ten tries of an LM step as (lambda, poses): try 0 at the current lambda, tries 1..9 with lambda doubled after every
+  // rejection (impl.h:216-283).  The costs of the tries in [first, 10) whose poses are new and distinct come from one multi-pose pass
+  // (one new pose: the plain cost pass); a try whose poses equal the current ones costs `cost`.
+  std::vector<std::vector<SE3f>> cand(10);
+  std::vector<double> lam(10), costs(10);
+  auto tries_from = [&](int first, double lam_first) {
+    double l = lam_first;
+    for (int k = first; k < 10; ++k) { lam[k] = l; candidate(l, cand[k]); l = 2.f * l; }
+    return l;                                              // lambda after ten rejections
+  };
+  auto evaluate_tries = [&](int first) {
+    std::vector<std::vector<SE3f>> distinct;
+    std::vector<int> slot(10, -1);                         // -1: the pose equals the current one (cost known)
+    std::vector<double> dcosts;
+    for (int k = first; k < 10; ++k) {
+      if (same_poses(cand[k], poses)) continue;
+      for (size_t q = 0; q < distinct.size() && slot[k] < 0; ++q) if (same_poses(cand[k], distinct[q])) slot[k] = (int)q;
+      if (slot[k] < 0) { slot[k] = (int)distinct.size(); distinct.push_back(cand[k]); }
+    }
+    if (distinct.size() == 1) {            // one new pose: the plain cost pass (HBM bound; same bits)
+      std::vector<double> Hx, bx;
+      dcosts.assign(1, 0.0);
+      lm_evaluate(h, L, distinct[0], false, Hx, bx, dcosts[0], rec);
+    } else if (!distinct.empty()) { lm_evaluate_costs(h, L, distinct, dcosts, rec); rec.multi_cost_poses += (int)distinct.size(); }
+    else rec.lm_passes_skipped++;
+    for (int k = first; k < 10; ++k) costs[k] = (slot[k] < 0) ? cost : dcosts[slot[k]];
+  };
+  // Try 0 is usually accepted, so its cost is evaluated together with the next step's H and b (one fused pass) -- except in the LM
+  // step an alignment that has settled ends with: there all ten tries are rejected, and the fused pass's H and b are thrown away.
+  // The step at which the previous outer iteration's LM ended is the prediction: from that step on, try 0 joins tries 1..9 in the
+  // multi-pose cost pass (ten poses), and only an accepted try pays a fused pass at its pose.  Same costs bit for bit, same
+  // sequential decisions; a wrong prediction costs one cost-only evaluation of try 0.  (E3D_LM_SPECULATE=0: always the fused pass.)
+  static const bool speculate = [] { const char* e = getenv("E3D_LM_SPECULATE"); return !(e && e[0] == '0'); }();
+  const int predicted_end = h->lm_prev_end_step;
+  h->lm_prev_end_step = -1;
   for (int it = 0; it < h->max_inner; ++it) {
     rec.inner_iterations++;
     bool applied = false;
-    // try 0 is usually accepted: evaluate its cost together with the next iteration's H and b (one fused pass)
-    candidate(lambda, upd);
-    if (same_poses(upd, poses)) { new_cost = cost; rec.lm_passes_skipped++; }
-    else lm_evaluate(h, L, upd, true, Hn, bn, new_cost, rec);
-    if (new_cost < cost) {
-      poses = upd; H.swap(Hn); b.swap(bn); cost = new_cost;
-      lambda = 0.5f * lambda;
-      applied = true;
+    const bool batch_all = speculate && predicted_end >= 0 && it >= predicted_end;
+    int hit = -1;
+    double lam_end = lambda;
+    if (batch_all) {
+      lam_end = tries_from(0, lambda);
+      evaluate_tries(0);
+      for (int k = 0; k < 10; ++k) if (costs[k] < cost) { hit = k; break; }
     } else {
-      lambda = 2.f * lambda;
-      // tries 1..9 (lambda doubled after every rejection) only differ in their poses: one multi-pose cost pass over the
-      // DISTINCT new poses among them, then the first try that lowers the cost is taken -- the reference's sequential decision
-      std::vector<std::vector<SE3f>> cand(9), distinct;
-      std::vector<double> lam(9), costs(9, 0.0), dcosts;
-      std::vector<int> slot(9, -1);                          // -1: the pose equals the current one (cost known)
-      double l = lambda;
-      for (int k = 0; k < 9; ++k) {
-        lam[k] = l; candidate(l, cand[k]); l = 2.f * l;
-        if (same_poses(cand[k], poses)) continue;
-        for (size_t q = 0; q < distinct.size() && slot[k] < 0; ++q) if (same_poses(cand[k], distinct[q])) slot[k] = (int)q;
-        if (slot[k] < 0) { slot[k] = (int)distinct.size(); distinct.push_back(cand[k]); }
+      lam_end = tries_from(0, lambda);                     // (only try 0 is needed yet; the other nine are small host solves)
+      if (same_poses(cand[0], poses)) { new_cost = cost; rec.lm_passes_skipped++; }
+      else lm_evaluate(h, L, cand[0], true, Hn, bn, new_cost, rec);
+      if (new_cost < cost) {
+        poses = cand[0]; H.swap(Hn); b.swap(bn); cost = new_cost;
+        lambda = 0.5f * lambda;
+        applied = true;
+      } else {
+        evaluate_tries(1);
+        for (int k = 1; k < 10; ++k) if (costs[k] < cost) { hit = k; break; }
       }
-      if (distinct.size() == 1) {          // one new pose: the plain cost pass (HBM bound; same bits)
-        std::vector<double> Hx, bx;
-        dcosts.assign(1, 0.0);
-        lm_evaluate(h, L, distinct[0], false, Hx, bx, dcosts[0], rec);
-      } else if (!distinct.empty()) { lm_evaluate_costs(h, L, distinct, dcosts, rec); rec.multi_cost_poses += (int)distinct.size(); }
-      else rec.lm_passes_skipped++;
-      for (int k = 0; k < 9; ++k) costs[k] = (slot[k] < 0) ? cost : dcosts[slot[k]];
-      int hit = -1;
-      for (int k = 0; k < 9; ++k) if (costs[k] < cost) { hit = k; break; }
+    }
+    if (!applied) {
       if (hit >= 0) {
         double c2;
         lm_evaluate(h, L, cand[hit], true, Hn, bn, c2, rec);   // H, b at the accepted pose; c2 == costs[hit] bit for bit
@@ -1006,11 +1031,11 @@ static void lm_compute(e3d_icp* h, LmSystem& L, std::vector<SE3f>& poses, e3d_ic
         lambda = 0.5f * lam[hit];
         applied = true;
       } else {
-        lambda = l;       // ten rejections: lambda doubled ten times
+        lambda = lam_end;   // ten rejections: lambda doubled ten times
       }
     }
     rec.final_cost = cost;
-    if (!applied) break;
+    if (!applied) { h->lm_prev_end_step = it; break; }
   }
 }
 

@@ -13,7 +13,7 @@ enum { kModeCost = 0,      // cost only
        kModeTwo = 2,       // both sides, off-diagonal block would land in the lower triangle => dropped [QUIRK]
        kModeTwoCross = 3   // both sides, src block before tgt block: SS, TT, ST
 };
-constexpr int kLmMaxPoses = 9;       // LM tries 1..9 evaluated by one k_lm_cost_multi pass
+constexpr int kLmMaxPoses = 10;      // LM tries (0 or 1)..9 evaluated by one k_lm_cost_multi pass
 constexpr int kLmSlot = 91;          // doubles per block partial / per set result
 constexpr int kMaxBboxBlocks = 2048;
 constexpr int kRowCap = 128;         // candidates staged in LDS per wave and batch (k_nn_rows)

@@ -102,3 +102,41 @@ def test_local_outlier_removal_small_cloud():
     assert inl.tolist() == [True] and md.tolist() == [0.0]        # no neighbour: mean = 0 / 0, every comparison false -> kept
     inl, md = ob.local_outlier_removal(np.zeros((0, 3), np.float32), 8, 2.0)
     assert inl.shape == (0,)
+
+
+def test_normals_sample_equals_the_full_run():
+    """oracle_normals_sample (the checker of the 20 M point at-size test): the listed points searched in the WHOLE cloud give what
+    oracle_normals gives for them -- kNN lists, normals, curvature, bit for bit; k search and radius search."""
+    from oracle import binding as ob
+    rng = np.random.RandomState(11)
+    pts = (rng.normal(size=(6000, 3)) * np.array([2.0, 1.0, 0.03])).astype(np.float32)
+    sample = np.sort(rng.choice(len(pts), 700, replace=False))
+    n, c, knn = ob.normals(pts, k=12, viewpoint=(0, 0, 3), return_knn=True)
+    ns, cs, ks = ob.normals_sample(pts, sample, k=12, viewpoint=(0, 0, 3))
+    assert np.array_equal(knn[sample], ks)
+    assert np.array_equal(n[sample].view(np.uint32), ns.view(np.uint32)) and np.array_equal(c[sample].view(np.uint32), cs.view(np.uint32))
+    n, c = ob.normals(pts, radius=0.15, viewpoint=(0, 0, 3))
+    ns, cs, _ = ob.normals_sample(pts, sample, radius=0.15, viewpoint=(0, 0, 3))
+    same_nan = np.isnan(n[sample, 0]) == np.isnan(ns[:, 0])
+    assert same_nan.all()
+    v = ~np.isnan(ns[:, 0])
+    assert np.array_equal(n[sample][v].view(np.uint32), ns[v].view(np.uint32)) and np.array_equal(c[sample][v].view(np.uint32), cs[v].view(np.uint32))
+
+
+def test_scanner_sampled_scan_lies_on_the_room():
+    """synth.make_scan_angular (bench / DESIGN 4.3b): rays uniform in angle, first hit -- every point lies on a surface of the room
+    (to the range noise), the density falls with the range, normals are unit vectors turned to the scanner."""
+    import importlib
+    synth = importlib.import_module("dataset-pipeline_amd.synth")
+    origin, yaw = synth.SCAN_POSES[0]
+    xyz, nrm, T = synth.make_scan_angular(60000, origin, yaw, 3, sigma=0.0)
+    assert xyz.shape == (60000, 3) and abs(float((nrm.norm(dim=1) - 1).abs().max())) < 1e-6
+    P = xyz.numpy().astype(np.float64) @ T[:3, :3].T.astype(np.float64) + T[:3, 3].astype(np.float64)      # world frame
+    W, D, H = 10.0, 10.0, 3.0
+    d_planes = np.minimum.reduce([np.abs(P[:, 2]), np.abs(P[:, 0]), np.abs(P[:, 0] - W), np.abs(P[:, 1]), np.abs(P[:, 1] - D)])
+    d_cyl = np.minimum.reduce([np.abs(np.hypot(P[:, 0] - cx, P[:, 1] - cy) - r) for cx, cy, r in synth._CYL])
+    assert np.minimum(d_planes, d_cyl).max() < 1e-5
+    assert ((-xyz.numpy() * nrm.numpy()).sum(1) >= -1e-6).all()                     # turned to the scanner (the local origin)
+    r = np.linalg.norm(xyz.numpy(), axis=1)
+    ru = np.linalg.norm(synth.make_scan(60000, origin, yaw, 3, sigma=0.0)[0].numpy(), axis=1)
+    assert (r < 2.0).mean() > 3 * (ru < 2.0).mean()                                 # far denser near the scanner than uniform per area

@@ -38,6 +38,7 @@ struct KnnGrid {
   const unsigned* S;
   unsigned D[3];
 };
+constexpr int kKnnSelFallback = 253;  // pass A's answer: k not reached inside a narrowed histogram range
 
 // runs of the cells [x0, x1] of row (y, z): with the dense directory one run, with the hash table one per cell.  body(begin, end)
 template <class F>
@@ -108,7 +109,23 @@ __global__ __launch_bounds__(kKnnHistBlock) void k_knn_hist(const float4* __rest
   const int cx = cell_coord(q.x, G.g.origin[0], G.g.inv_cell);
   const int cy = cell_coord(q.y, G.g.origin[1], G.g.inv_cell);
   const int cz = cell_coord(q.z, G.g.origin[2], G.g.inv_cell);
-  const float inv_w2 = 32.0f * G.g.inv_cell * G.g.inv_cell;
+  // A scan samples its surfaces with a density that falls with the squared range, so a 27-cell block of a grid sized for the mean
+  // density holds anything from a few to thousands of points.  The directory words of the block's nine rows give its population
+  // n27 before any point is touched, and the histogram's bin width follows it (round 4): cell^2 / (32 f) with f = 1, 2, 4 for
+  // n27 <= 12 k, 24 k, more.  The k-th neighbour of a dense block is far inside the block, and with bins sized for the mean density
+  // most of the block's candidates fell into the first bins, more than the k + 4 list slots of pass B hold (the query then fell
+  // back to the list-maintaining variant: 1.7 M of 20 M queries of a scanner-sampled scan).  Pass B reads f from the selected bin's
+  // byte.  (Handing the densest blocks to a grid of half the cell size instead was built as well: 33.9 instead of 23.9 ms on that
+  // scan -- a second sort and a 1.2 G-cell directory for 0.7 M queries; removed.)
+  int fexp = 0;
+  if (G.S) {
+    unsigned n27 = 0;
+    for (int oz = -1; oz <= 1; ++oz)
+      for (int oy = -1; oy <= 1; ++oy)
+        knn_row(G, table, cx - 1, cx + 1, cy + oy, cz + oz, [&](unsigned m, unsigned e) { n27 += e - m; });
+    fexp = n27 <= 12u * (unsigned)k ? 0 : (n27 <= 24u * (unsigned)k ? 1 : 2);
+  }
+  const float inv_w2 = (float)(32 << fexp) * G.g.inv_cell * G.g.inv_cell;
   auto add = [&](float d2) {
     const float bb = d2 * inv_w2;
     if (bb < (float)kKnnBins) { const int b = (int)bb; atomicAdd(&hw[b >> 2][tid], 1u << (8 * (b & 3))); }
@@ -135,7 +152,9 @@ __global__ __launch_bounds__(kKnnHistBlock) void k_knn_hist(const float4* __rest
       if (sel == 255 && cum >= k) sel = 4 * wv + j;
     }
   }
-  sel_bin[gi] = (unsigned char)sel;
+  // [2 bits: bin scale | 6 bits: bin]; k not reached: 255 with the full range (the k-th neighbour is at least sqrt(2) cells away),
+  // kKnnSelFallback with a narrowed one (it may still lie inside the block: the list-maintaining variant looks)
+  sel_bin[gi] = (unsigned char)(sel == 255 ? (fexp == 0 ? 255 : kKnnSelFallback) : ((fexp << 6) | sel));
 }
 
 __device__ __forceinline__ bool knn_less(float d1, unsigned p1, float d2, unsigned p2, const float4* __restrict__ P4) {
@@ -409,8 +428,26 @@ __global__ __launch_bounds__(kKnnBlock) void k_knn_normals(const float4* __restr
   };
   bool fallback = false;
   if constexpr (kSel == 3) {
-    const float inv_w2 = 32.0f * G.g.inv_cell * G.g.inv_cell;       // bins of cell^2 / 32: [0, 2 cell^2)
-    const int sel_bin = (int)sel_bins[gi];                          // pass A (k_knn_hist)
+    const int sel_byte = (int)sel_bins[gi];                         // pass A (k_knn_hist): [bin scale | bin], or a verdict
+    bool block_is_everything = true;                                // the 27 cells cover the whole cloud (tiny clouds, k > n)
+    {
+      const int c3[3] = {cx, cy, cz};
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        if (G.g.origin[a] + (float)(c3[a] - 1) * G.cell > G.dmin[a]) block_is_everything = false;
+        if (G.g.origin[a] + (float)(c3[a] + 2) * G.cell <= G.dmax[a]) block_is_everything = false;
+      }
+    }
+    if (sel_byte == 255 && !block_is_everything) {
+      // fewer than k points within the histogram's range (sqrt(2) cells at the least): the k-th neighbour cannot be certified
+      // inside this block of 27 cells, so the query goes to the next level as it is -- not through the list-maintaining variant
+      // first (2 M queries of a scanner-sampled scan took that detour)
+      const unsigned slot = atomicAdd(next_count, 1u);
+      next_todo[slot] = qid;
+      return;
+    }
+    const int sel_bin = (sel_byte == kKnnSelFallback || sel_byte == 255) ? kKnnBins : (sel_byte & 63);
+    const float inv_w2 = (float)(32 << ((sel_byte >> 6) & 3)) * G.g.inv_cell * G.g.inv_cell;       // bins of cell^2 / (32 f): [0, 2 cell^2 / f)
     if (sel_bin >= kKnnBins) {
       fallback = true;                                                // the k-th neighbour lies beyond the histogram's range
     } else {
@@ -884,7 +921,7 @@ static void knn_pass(KnnWorkspace& W, const float* xyz, size_t n, int k, const f
     for (int a = 0; a < 6; ++a) magnitude = std::max(magnitude, std::fabs((double)bb[a]));
 
     LevelBuffers& L = W.L;
-    L.ka.reserve(n); L.kb.reserve(n); L.va.reserve(n); L.vb.reserve(n); L.counter.reserve(3);
+    L.ka.reserve(n); L.kb.reserve(n); L.va.reserve(n); L.vb.reserve(n); L.counter.reserve(4);
     L.P4.reserve(n);
     DevBuf<float4>& Q4 = W.Q4;     // queries in level-0 cell order (spatially coherent for every level)
     DevBuf<unsigned>&todo_a = W.todo_a, &todo_b = W.todo_b;
@@ -904,17 +941,20 @@ static void knn_pass(KnnWorkspace& W, const float* xyz, size_t n, int k, const f
     E3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel_of(sel)), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     E3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel_of(sel_list)), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_list));
     DevBuf<unsigned>& fb_todo = W.fb_todo;
-    if (sel == 3) { fb_todo.reserve(n); L.counter.reserve(3); }
+    if (sel == 3) { fb_todo.reserve(n); L.counter.reserve(4); }
     static const double level_step = [] { const char* e = getenv("E3D_KNN_LEVEL_STEP"); const double v = e ? atof(e) : 0.0; return v > 1 ? v : 2.0; }();   // cell growth per retry level (4 -> 2: -7 % at k = 32)
     static const bool wide_pass = [] { const char* e = getenv("E3D_KNN_WIDE"); return e ? atoi(e) != 0 : true; }();
-    for (int level = 0; level < 64 && n_todo > 0; ++level) {
-      KnnGrid G{};
-      G.cell = (float)cell;
+    // Grid of cell size `cell_size` over all points into LB: sorted points, dense directory when the bounding grid has at most
+    // 2^dir_log2 cells (else the hash table); false if the extent does not fit 21-bit cell coordinates.
+    static const int dense_log2 = [] { const char* e = getenv("E3D_KNN_DENSE_LOG2"); return e ? std::min(atoi(e), 31) : 30; }();
+    auto build_level = [&](LevelBuffers& LB, double cell_size, int dir_log2, KnnGrid& G) -> bool {
+      G = KnnGrid{};
+      G.cell = (float)cell_size;
       G.g.inv_cell = (float)(1.0 / (double)G.cell);
-      for (int a = 0; a < 3; ++a) { G.g.origin[a] = (float)((double)bb[a] - 2.0 * cell); G.dmin[a] = bb[a]; G.dmax[a] = bb[3 + a]; }
-      G.slack = (float)(16.0 * FLT_EPSILON * (magnitude + 4.0 * cell) + 1e-4 * cell);
-      // too many cells for 21-bit coordinates: coarsen
-      if (extent / cell > (double)((1 << 21) - 8)) { cell *= 4.0; --level; continue; }
+      for (int a = 0; a < 3; ++a) { G.g.origin[a] = (float)((double)bb[a] - 2.0 * cell_size); G.dmin[a] = bb[a]; G.dmax[a] = bb[3 + a]; }
+      G.slack = (float)(16.0 * FLT_EPSILON * (magnitude + 4.0 * cell_size) + 1e-4 * cell_size);
+      if (extent / cell_size > (double)((1 << 21) - 8)) return false;
+      LB.ka.reserve(n); LB.kb.reserve(n); LB.va.reserve(n); LB.vb.reserve(n); LB.counter.reserve(4); LB.P4.reserve(n);
       // dense directory over the bounding grid (cells 0 .. cell of the bbox maximum + 2 per axis) unless it would be huge.  With it
       // the sort key is the 32-bit linear cell index (same (z, y, x) order as the 63-bit key: 4 radix passes instead of 8).
       QueryRange qr{};
@@ -926,98 +966,112 @@ static void knn_pass(KnnWorkspace& W, const float* xyz, size_t n, int k, const f
         prod *= (double)qr.D[a];
       }
       G.S = nullptr;
-      static const int dense_log2 = [] { const char* e = getenv("E3D_KNN_DENSE_LOG2"); return e ? std::min(atoi(e), 31) : 30; }();
-      if (prod <= (double)((size_t)1 << dense_log2)) {
+      if (prod <= (double)((size_t)1 << dir_log2)) {
         const size_t ncell = (size_t)prod;
         int bits = 1;
         while (((size_t)1 << bits) < ncell) ++bits;
-        unsigned* k32_in = reinterpret_cast<unsigned*>(L.ka.p);
-        unsigned* k32_out = reinterpret_cast<unsigned*>(L.kb.p);
-        hipLaunchKernelGGL(k_cell_keys_dense, dim3((unsigned)div_up(n, kBlock)), dim3(kBlock), 0, s, raw.p, n, G.g, qr.D[0], qr.D[1], qr.D[2], k32_in, L.va.p);
-        sort_pairs_u32_u32(k32_in, k32_out, L.va.p, L.vb.p, n, bits, L.temp, s);
-        launch_permute(raw.p, nullptr, L.vb.p, n, L.P4.p, nullptr, s);
-        L.dense.reserve(ncell + 2);
-        E3D_HIP(hipMemsetAsync(L.dense.p, 0, sizeof(unsigned) * (ncell + 2), s));
-        hipLaunchKernelGGL(k_dense_ends32, dim3((unsigned)div_up(n, kBlock)), dim3(kBlock), 0, s, k32_out, n, L.dense.p);
-        exclusive_max_scan_u32(L.dense.p, ncell + 2, L.temp, s);
-        G.S = L.dense.p;
+        unsigned* k32_in = reinterpret_cast<unsigned*>(LB.ka.p);
+        unsigned* k32_out = reinterpret_cast<unsigned*>(LB.kb.p);
+        hipLaunchKernelGGL(k_cell_keys_dense, dim3((unsigned)div_up(n, kBlock)), dim3(kBlock), 0, s, raw.p, n, G.g, qr.D[0], qr.D[1], qr.D[2], k32_in, LB.va.p);
+        sort_pairs_u32_u32(k32_in, k32_out, LB.va.p, LB.vb.p, n, bits, LB.temp, s);
+        launch_permute(raw.p, nullptr, LB.vb.p, n, LB.P4.p, nullptr, s);
+        LB.dense.reserve(ncell + 2);
+        E3D_HIP(hipMemsetAsync(LB.dense.p, 0, sizeof(unsigned) * (ncell + 2), s));
+        hipLaunchKernelGGL(k_dense_ends32, dim3((unsigned)div_up(n, kBlock)), dim3(kBlock), 0, s, k32_out, n, LB.dense.p);
+        exclusive_max_scan_u32(LB.dense.p, ncell + 2, LB.temp, s);
+        G.S = LB.dense.p;
         for (int a = 0; a < 3; ++a) G.D[a] = qr.D[a];
       } else {
-        launch_cell_keys(raw.p, n, G.g, L.ka.p, L.va.p, s);
-        sort_pairs_u64_u32(L.ka.p, L.kb.p, L.va.p, L.vb.p, n, 63, L.temp, s);
-        launch_permute(raw.p, nullptr, L.vb.p, n, L.P4.p, nullptr, s);
-      }
-      if (!G.S) {
+        launch_cell_keys(raw.p, n, G.g, LB.ka.p, LB.va.p, s);
+        sort_pairs_u64_u32(LB.ka.p, LB.kb.p, LB.va.p, LB.vb.p, n, 63, LB.temp, s);
+        launch_permute(raw.p, nullptr, LB.vb.p, n, LB.P4.p, nullptr, s);
         // no dense directory (the bounding grid is too large): hash table of the occupied cells
-        E3D_HIP(hipMemsetAsync(L.counter.p, 0, 2 * sizeof(unsigned), s));
-        launch_count_cells(L.kb.p, n, L.counter.p, s);
+        E3D_HIP(hipMemsetAsync(LB.counter.p, 0, 2 * sizeof(unsigned), s));
+        launch_count_cells(LB.kb.p, n, LB.counter.p, s);
         unsigned n_cells = 0;
-        E3D_HIP(hipMemcpyAsync(&n_cells, L.counter.p, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+        E3D_HIP(hipMemcpyAsync(&n_cells, LB.counter.p, sizeof(unsigned), hipMemcpyDeviceToHost, s));
         E3D_HIP(hipStreamSynchronize(s));
         size_t tsize = 64;
         while (tsize < 2 * (size_t)n_cells) tsize <<= 1;
-        L.table.reserve(tsize);
+        LB.table.reserve(tsize);
         G.g.mask = (unsigned)(tsize - 1);
-        E3D_HIP(hipMemsetAsync(L.table.p, 0xFF, sizeof(HashEntry) * tsize, s));
-        launch_build_table(L.kb.p, n, L.table.p, G.g.mask, s);
+        E3D_HIP(hipMemsetAsync(LB.table.p, 0xFF, sizeof(HashEntry) * tsize, s));
+        launch_build_table(LB.kb.p, n, LB.table.p, G.g.mask, s);
       }
+      return true;
+    };
+    // One search of the listed queries (todo_list == nullptr: all) on a built level.  Results of resolved queries are written; the
+    // others are appended to `next_list` (device counter LB.counter[1]: k-th neighbour beyond the 27 cells).  Fallback queries of
+    // the two-pass variant (LB.counter[2]) join that list for the wide pass or run through the list-maintaining variant on the same
+    // grid right away.  n_next_out: length of next_list; returns the number of fallback queries.
+    auto search_level = [&](LevelBuffers& LB, const KnnGrid& G, const unsigned* todo_list, size_t n_list, unsigned* next_list,
+                            unsigned& n_next_out, bool merge_fb_into_next) {
+      E3D_HIP(hipMemsetAsync(LB.counter.p + 1, 0, 2 * sizeof(unsigned), s));
+      const unsigned nblk = (unsigned)div_up(n_list, kKnnBlock);
+      const int lsel = (sel == 3 && !G.S) ? sel_list : sel;            // the two-pass variant needs the dense directory
+      if (lsel == 3) {
+        LB.sel_bin.reserve(n_list);
+        hipLaunchKernelGGL(k_knn_hist, dim3((unsigned)div_up(n_list, kKnnHistBlock)), dim3(kKnnHistBlock), 0, s, LB.P4.p, todo_list, n_list,
+                           LB.table.p, G, k, Q4.p, LB.sel_bin.p);
+      }
+      hipLaunchKernelGGL(kernel_of(lsel), dim3(nblk), dim3(kKnnBlock), lsel == 3 ? lds : lds_list, s, LB.P4.p, n, todo_list, n_list, LB.table.p, G, k, lsel == 3 ? cap : k,
+                         viewpoint[0], viewpoint[1], viewpoint[2], Q4.p, want_normals ? d_on.p : nullptr, want_normals ? d_oc.p : nullptr,
+                         knn_indices ? d_knn.p : nullptr, d_mean_out ? d_mean_out->p : nullptr, next_list, LB.counter.p + 1,
+                         fb_todo.p, LB.counter.p + 2, LB.sel_bin.p, 1);
+      unsigned cnts[2] = {0, 0};
+      E3D_HIP(hipMemcpyAsync(cnts, LB.counter.p + 1, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, s));
+      E3D_HIP(hipStreamSynchronize(s));
+      E3D_HIP(hipGetLastError());
+      const unsigned n_fb = cnts[1];
+      if (merge_fb_into_next && n_fb > 0 && ((size_t)cnts[0] + n_fb) * 64 <= n) {
+        // the two-pass variant's leftovers join the wide pass that follows (its first 27 cells are this level's block, the shell
+        // beyond them is skipped by the face test once the list is full): one launch instead of two
+        E3D_HIP(hipMemcpyAsync(next_list + cnts[0], fb_todo.p, sizeof(unsigned) * n_fb, hipMemcpyDeviceToDevice, s));
+        cnts[0] += n_fb;
+      } else if (n_fb > 0) {
+        // queries the two-pass variant could not settle on this level (see its comment): the list-maintaining variant, same
+        // grid, appending its unresolved ones to the same next-level list
+        hipLaunchKernelGGL(kernel_of(sel_list), dim3((unsigned)div_up((size_t)n_fb, kKnnBlock)), dim3(kKnnBlock), lds_list, s, LB.P4.p, n,
+                           fb_todo.p, (size_t)n_fb, LB.table.p, G, k, k, viewpoint[0], viewpoint[1], viewpoint[2], Q4.p,
+                           want_normals ? d_on.p : nullptr, want_normals ? d_oc.p : nullptr, knn_indices ? d_knn.p : nullptr,
+                           d_mean_out ? d_mean_out->p : nullptr, next_list, LB.counter.p + 1, nullptr, nullptr, nullptr, 1);
+        E3D_HIP(hipMemcpyAsync(cnts, LB.counter.p + 1, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+        E3D_HIP(hipStreamSynchronize(s));
+        E3D_HIP(hipGetLastError());
+      }
+      n_next_out = cnts[0];
+      return n_fb;
+    };
+    for (int level = 0; level < 64 && n_todo > 0; ++level) {
+      KnnGrid G{};
+      if (!build_level(L, cell, dense_log2, G)) { cell *= 4.0; --level; continue; }        // too many cells for 21-bit coordinates: coarsen
       if (level == 0) {
         Q4.reserve(n);
         E3D_HIP(hipMemcpyAsync(Q4.p, L.P4.p, sizeof(float4) * n, hipMemcpyDeviceToDevice, s));
       }
       unsigned* next = (todo == todo_a.p) ? todo_b.p : todo_a.p;
-      E3D_HIP(hipMemsetAsync(L.counter.p + 1, 0, 2 * sizeof(unsigned), s));
-      const unsigned nblk = (unsigned)div_up(n_todo, kKnnBlock);
-      const int lsel = (sel == 3 && !G.S) ? sel_list : sel;            // the two-pass variant needs the dense directory
-      if (lsel == 3) {
-        L.sel_bin.reserve(n_todo);
-        hipLaunchKernelGGL(k_knn_hist, dim3((unsigned)div_up(n_todo, kKnnHistBlock)), dim3(kKnnHistBlock), 0, s, L.P4.p, todo, n_todo,
-                           L.table.p, G, k, Q4.p, L.sel_bin.p);
-      }
-      hipLaunchKernelGGL(kernel_of(lsel), dim3(nblk), dim3(kKnnBlock), lsel == 3 ? lds : lds_list, s, L.P4.p, n, todo, n_todo, L.table.p, G, k, lsel == 3 ? cap : k,
-                         viewpoint[0], viewpoint[1], viewpoint[2], Q4.p, want_normals ? d_on.p : nullptr, want_normals ? d_oc.p : nullptr,
-                         knn_indices ? d_knn.p : nullptr, d_mean_out ? d_mean_out->p : nullptr, next, L.counter.p + 1,
-                         fb_todo.p, L.counter.p + 2, L.sel_bin.p, 1);
-      unsigned cnts[2] = {0, 0};
-      E3D_HIP(hipMemcpyAsync(cnts, L.counter.p + 1, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, s));
-      E3D_HIP(hipStreamSynchronize(s));
-      E3D_HIP(hipGetLastError());
-      const unsigned n_fb = cnts[1];
-      const bool merge_lists = wide_pass && n_fb > 0 && ((size_t)cnts[0] + n_fb) * 8 <= n;
-      if (merge_lists) {
-        // the two-pass variant's leftovers join the wide pass below (its first 27 cells are this level's block, the shell beyond
-        // them is skipped by the face test once the list is full): one launch instead of two
-        E3D_HIP(hipMemcpyAsync(next + cnts[0], fb_todo.p, sizeof(unsigned) * n_fb, hipMemcpyDeviceToDevice, s));
-        cnts[0] += n_fb;
-      } else if (n_fb > 0) {
-        // queries the two-pass variant could not settle on this level (see its comment): the list-maintaining variant, same
-        // grid, appending its unresolved ones to the same next-level list
-        hipLaunchKernelGGL(kernel_of(sel_list), dim3((unsigned)div_up((size_t)cnts[1], kKnnBlock)), dim3(kKnnBlock), lds_list, s, L.P4.p, n,
-                           fb_todo.p, (size_t)cnts[1], L.table.p, G, k, k, viewpoint[0], viewpoint[1], viewpoint[2], Q4.p,
-                           want_normals ? d_on.p : nullptr, want_normals ? d_oc.p : nullptr, knn_indices ? d_knn.p : nullptr,
-                           d_mean_out ? d_mean_out->p : nullptr, next, L.counter.p + 1, nullptr, nullptr, nullptr, 1);
-        E3D_HIP(hipMemcpyAsync(cnts, L.counter.p + 1, sizeof(unsigned), hipMemcpyDeviceToHost, s));
-        E3D_HIP(hipStreamSynchronize(s));
-        E3D_HIP(hipGetLastError());
-      }
-      unsigned n_next = cnts[0];
+      unsigned n_next = 0;
+      const unsigned n_fb = search_level(L, G, todo, n_todo, next, n_next, wide_pass);
       if (getenv("E3D_KNN_STATS")) fprintf(stderr, "[knn] level %d cell %g todo %zu fallback %u next %u\n", level, (double)cell, n_todo, n_fb, n_next);
       // the few that need a wider look (the k-th neighbour lies outside the 27 cells: sparse regions, outliers): the list-maintaining
       // variant over the 125 cells of the same grid, which reaches as far as a grid of twice the cell size would -- no second grid
       // build for ~1 % of the queries
-      if (n_next > 0 && wide_pass && (size_t)n_next * 8 <= n) {
+      // (a long list is cheaper on a grid of twice the cell size with the two-pass kernels: the list-maintaining variant over 125 cells
+      // took 20 ms for the 2 M far-field queries of a scanner-sampled scan, a grid build is 1.7 ms)
+      if (n_next > 0 && wide_pass && (size_t)n_next * 64 <= n) {
         unsigned* wide_out = (next == todo_a.p) ? todo_b.p : todo_a.p;
+        unsigned cw[1] = {0};
         E3D_HIP(hipMemsetAsync(L.counter.p + 1, 0, sizeof(unsigned), s));
         hipLaunchKernelGGL(kernel_of(sel_list), dim3((unsigned)div_up((size_t)n_next, kKnnBlock)), dim3(kKnnBlock), lds_list, s, L.P4.p, n,
                            next, (size_t)n_next, L.table.p, G, k, k, viewpoint[0], viewpoint[1], viewpoint[2], Q4.p,
                            want_normals ? d_on.p : nullptr, want_normals ? d_oc.p : nullptr, knn_indices ? d_knn.p : nullptr,
                            d_mean_out ? d_mean_out->p : nullptr, wide_out, L.counter.p + 1, nullptr, nullptr, nullptr, 2);
-        E3D_HIP(hipMemcpyAsync(cnts, L.counter.p + 1, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+        E3D_HIP(hipMemcpyAsync(cw, L.counter.p + 1, sizeof(unsigned), hipMemcpyDeviceToHost, s));
         E3D_HIP(hipStreamSynchronize(s));
         E3D_HIP(hipGetLastError());
-        if (getenv("E3D_KNN_STATS")) fprintf(stderr, "[knn] level %d wide pass todo %u next %u\n", level, n_next, cnts[0]);
+        if (getenv("E3D_KNN_STATS")) fprintf(stderr, "[knn] level %d wide pass todo %u next %u\n", level, n_next, cw[0]);
         next = wide_out;
-        n_next = cnts[0];
+        n_next = cw[0];
         cell *= 2.0;
       }
       todo = next;
@@ -1218,7 +1272,7 @@ extern "C" int e3d_normals_radius(const float* xyz, size_t n, float radius, cons
     G.g.inv_cell = (float)(1.0 / (double)G.cell);
     for (int a = 0; a < 3; ++a) { G.g.origin[a] = (float)((double)bb[a] - 2.0 * cell); G.dmin[a] = bb[a]; G.dmax[a] = bb[3 + a]; }
     LevelBuffers L;
-    L.ka.reserve(n); L.kb.reserve(n); L.va.reserve(n); L.vb.reserve(n); L.counter.reserve(3); L.P4.reserve(n);
+    L.ka.reserve(n); L.kb.reserve(n); L.va.reserve(n); L.vb.reserve(n); L.counter.reserve(4); L.P4.reserve(n);
     launch_cell_keys(raw.p, n, G.g, L.ka.p, L.va.p, s);
     sort_pairs_u64_u32(L.ka.p, L.kb.p, L.va.p, L.vb.p, n, 63, L.temp, s);
     launch_permute(raw.p, nullptr, L.vb.p, n, L.P4.p, nullptr, s);

@@ -24,6 +24,17 @@ def test_normals_room(e3d, ob, synth, k):
     _compare(e3d, ob, s["xyz"].numpy(), k)
 
 
+@pytest.mark.parametrize("k", [8, 32])
+def test_normals_scanner_sampled_scan(e3d, ob, synth, k):
+    """A scan as a scanner samples it (rays uniform in angle: density ~ cos / range^2, synth.make_scan_angular): near the scanner a
+    27-cell block of the grid sized for the mean density holds many times the candidates it was sized for (pass A counts the block
+    from the directory and narrows its histogram bins), the sparse far field takes the retry levels.  Lists, normals
+    and curvatures stay those of the oracle's kd-tree, bit for bit."""
+    origin, yaw = synth.SCAN_POSES[0]
+    xyz, _, _ = synth.make_scan_angular(250_000, origin, yaw, 17)
+    _compare(e3d, ob, xyz.numpy(), k)
+
+
 def test_normals_outliers_and_clusters(e3d, ob):
     """Isolated outliers and very uneven density force several grid levels; lists stay exact."""
     rng = np.random.RandomState(5)

@@ -599,6 +599,24 @@ def leg_normals(e3d, synth, args, dev):
                                        "traffic": tr, "traffic_source": src, "algorithmic_bytes_per_launch": alg,
                                        "kernel": "e3d_normals_knn whole call (grid build + k-NN + covariance + eigenvector)"}}
     out["value"] = out["k32"]["value"]
+    # the same call on a scan sampled as a scanner samples (rays uniform in angle: density ~ cos / range^2; synth.make_scan_angular) --
+    # what real scans look like; the figure above is the uniform-per-area scan of the earlier rounds
+    xyz_a, _, _ = synth.make_scan_angular(n, origin, yaw, 1234, device=dev)
+    xyz_a = xyz_a.contiguous()
+    torch.cuda.synchronize()
+    out["scanner_sampled"] = {"note": "density ~ cos(incidence) / range^2: %.0f %% of the points within 2 m of the scanner" % (100.0 * float((xyz_a.norm(dim=1) < 2.0).float().mean()))}
+    for k in (32, 8):
+        def call_a():
+            r = capi.lib().e3d_normals_knn(C.c_void_p(xyz_a.data_ptr()), n, k, C.c_void_p(vp.ctypes.data), C.c_void_p(on.data_ptr()), C.c_void_p(oc.data_ptr()), None)
+            assert r == 0, capi.lib().e3d_last_error()
+        call_a()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(3):
+            call_a()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 3
+        out["scanner_sampled"]["k%d" % k] = {"value": n / dt, "ms_per_call": dt * 1e3, "frac": n * (12 * k + 28) / dt / 1e9 / HBM_PEAK_GBS}
+    del xyz_a
     if not args.no_cpu_baseline:
         from oracle import binding as ob
         x = xyz[:, 0]

@@ -158,17 +158,36 @@ struct e3d_icp {
   DevBuf<double> d_partial, d_setsum;
   PinBuf<double> h_setsum;
   std::unique_ptr<EventTimer> lm_timer, nn_timer, nn_timer_c;
-  // stop-watch of a kernel group whose reading is taken lazily (at the group's next use or at the end of the NN phase), so that
-  // timing the sort / scan / compaction kernels adds no synchronisation
+  // stop-watch of a kernel group whose readings are taken at the end of the NN phase: every start / stop pair gets its own events,
+  // so timing a kernel adds no host wait (the all-pairs job launches hundreds of each per iteration, round 4)
   struct LazyTimer {
-    std::unique_ptr<EventTimer> t;
-    bool pending = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+    size_t used = 0;
     double acc = 0.0;
-    void start(hipStream_t s) { if (!t) t.reset(new EventTimer()); flush(); t->start(s); }
-    void stop(hipStream_t s) { t->stop(s); pending = true; }
-    void flush() { if (pending) { acc += t->ms(); pending = false; } }
-    double take() { flush(); const double v = acc; acc = 0.0; return v; }
-  } tm_sort, tm_scan, tm_compact, tm_bounded;
+    void start(hipStream_t s) {
+      if (used == ev.size()) { hipEvent_t a, b; E3D_HIP(hipEventCreate(&a)); E3D_HIP(hipEventCreate(&b)); ev.emplace_back(a, b); }
+      E3D_HIP(hipEventRecord(ev[used].first, s));
+    }
+    void stop(hipStream_t s) { E3D_HIP(hipEventRecord(ev[used].second, s)); ++used; }
+    double take() {
+      for (size_t i = 0; i < used; ++i) {
+        float t = 0.f;
+        if (hipEventSynchronize(ev[i].second) == hipSuccess && hipEventElapsedTime(&t, ev[i].first, ev[i].second) == hipSuccess) acc += (double)t;
+      }
+      used = 0;
+      const double v = acc; acc = 0.0; return v;
+    }
+    ~LazyTimer() { for (auto& e : ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); } }
+  } tm_sort, tm_scan, tm_compact, tm_bounded, tm_certify, tm_search;
+  // per-pair scratch of a batch of directed pairs (find_pairs_batched): squared distances and the two todo lists of the certificate
+  // search -- what one pair's kernels hand to the next kernel of the same pair
+  struct PairSlot { DevBuf<float> match_d2; DevBuf<unsigned> todo_near, todo_far; };
+  std::vector<std::unique_ptr<PairSlot>> slots;
+  PinBuf<unsigned> h_todo_all;
+  DevBuf<unsigned long long> d_totals_all;
+  DevBuf<double> d_d2_all;
+  PinBuf<unsigned long long> h_totals_all;
+  PinBuf<double> h_d2_all;
 
   std::map<std::pair<int, int>, std::unique_ptr<PairState>> pair_state;
   PinBuf<unsigned> h_todo;
@@ -726,6 +745,153 @@ static void find_pair(e3d_icp* h, Cloud& src, Cloud& tgt, float d, PairJob& job,
   rec.corr_rows_walked += job.count;
 }
 
+// The certificate search + resident row update of a BATCH of directed pairs (round 4).  find_pair reads two results back per pair
+// (the todo-list lengths after k_nn_certify, the totals after the row update) and synchronises the stream for each: 480 host round
+// trips per outer iteration of a 240-pair job, 30 - 40 ms that do not shrink when the job is spread over more GPUs.  Pairs do not
+// depend on each other, so a batch runs in phases: (A) k_nn_certify of every pair, ONE read-back of all list lengths; (B) the
+// searches and the row update of every pair, ONE read-back of all totals.  Per-pair scratch (distances, todo lists) comes from
+// the handle's slots; what a pair's kernels share with the next pair's (sort buffers, block counts) is ordered by the stream.
+// Same kernels, same launches, same results as find_pair's certificate branch with resident rows.
+struct BatchItem {
+  PairJob* job; Cloud* src; Cloud* tgt; size_t j0, n; PairState* ps;
+  InvMap im; CertParams cert; BoundParams bp; double cum_pair;
+  bool certified = false; size_t n_near = 0, n_far = 0;
+};
+static constexpr size_t kPairBatch = 32;
+
+static void find_pairs_batched(e3d_icp* h, std::vector<BatchItem>& items, float d, e3d_icp_iter_record& rec) {
+  hipStream_t s = h->stream;
+  const size_t B = items.size();
+  static const bool use_cert = [] { const char* e = getenv("E3D_NN_CERT"); return !(e && e[0] == '0'); }();
+  static const bool want_stats = [] { const char* e = getenv("E3D_NN_STATS"); return e && e[0] == '1'; }();
+  static const double margin_frac = env_double("E3D_NN_MARGIN", 0.08), near_frac = env_double("E3D_NN_NEAR", 0.4);   // of the radius
+  static const double np_frac = env_double("E3D_NN_NP_EXTRA", 0.5), np_gate = env_double("E3D_NN_NP_GATE", 0.2);   // of the radius
+  while (h->slots.size() < B) h->slots.emplace_back(new e3d_icp::PairSlot());
+  h->h_todo_all.reserve(2 * kPairBatch); h->d_totals_all.reserve(3 * kPairBatch); h->d_d2_all.reserve(kPairBatch);
+  h->h_totals_all.reserve(3 * kPairBatch); h->h_d2_all.reserve(kPairBatch);
+  size_t n_max = 0;
+  for (BatchItem& it : items) n_max = std::max(n_max, it.n);
+  const size_t nb_max = div_up(n_max, kBlock);
+  h->block_counts.reserve(nb_max); h->block_d2.reserve(nb_max); h->block_groups.reserve(nb_max);
+  h->chunk_sum.reserve(div_up(nb_max, 256) + 1); h->chunk_d2.reserve(div_up(nb_max, 256) + 1); h->chunk_groups.reserve(2 * (div_up(nb_max, 256) + 1));
+  // ---- phase A: certificates ----------------------------------------------------------------------------------------------
+  for (size_t i = 0; i < B; ++i) {
+    BatchItem& it = items[i];
+    e3d_icp::PairSlot& sl = *h->slots[i];
+    Cloud& src = *it.src; Cloud& tgt = *it.tgt;
+    PairState& ps = *it.ps;
+    sl.match_d2.reserve(it.n);
+    it.im = make_invmap(tgt);
+    it.cum_pair = src.cum_motion + tgt.cum_motion;
+    it.cert = make_cert_params(tgt, it.cum_pair);
+    it.n_far = it.n; it.n_near = 0;
+    it.certified = !ps.fresh && use_cert;
+    if (!it.certified) continue;
+    const float4* srcG = src.G4.p + it.j0;
+    const float cum_up = round_up_f((it.cum_pair * (1.0 + 2e-6) + 2.0 * (src.err_max + tgt.err_max)) * (1.0 + 1e-6));
+    const float near2 = (float)((near_frac * (double)d) * (near_frac * (double)d));
+    sl.todo_near.reserve(it.n); sl.todo_far.reserve(it.n);
+    E3D_HIP(hipMemsetAsync(ps.todo_count.p, 0, 2 * sizeof(unsigned), s));
+    // (queries without a partner and the np_extra gate: see find_pair)
+    const bool none_near = np_frac > 0 && (src.last_motion + tgt.last_motion) < np_gate * (double)d;
+    h->tm_certify.start(s);
+    launch_nn_certify(srcG, it.n, tgt.G4.p, cum_up, radius_sq(d), near2, none_near, ps.match.p, ps.match2.p, ps.lbe.p, sl.match_d2.p, sl.todo_near.p,
+                      sl.todo_far.p, ps.todo_count.p, s);
+    h->tm_certify.stop(s);
+    copy_out(h->h_todo_all.p + 2 * i, ps.todo_count.p, 2 * sizeof(unsigned), s);
+    rec.nn_certify_launches++; rec.nn_certify_queries += (long long)it.n;
+    double smin = min_singular_value_3x3(tgt.T);
+    if (!(smin > 1e-12)) smin = 1e-12;
+    double m_local = 0;
+    for (int k = 0; k < 3; ++k) m_local = std::max(m_local, std::max(std::fabs((double)tgt.lmin[k]), std::fabs((double)tgt.lmax[k])));
+    it.bp.margin = (float)(margin_frac * (double)d);
+    it.bp.rho_scale = round_up_f((1.0 + 1e-5) / smin);
+    it.bp.rho_pad = round_up_f(2.0 * tgt.build_slack + 8.0 * FLT_EPSILON * m_local);
+    it.bp.cum_lo = it.cert.cum_lo;
+    it.bp.cell_scale = it.cert.cell_scale; it.bp.cell_sub = it.cert.cell_sub;
+    it.bp.np_extra = none_near ? (float)(np_frac * (double)d) : 0.f;
+  }
+  sync(h);
+  // ---- phase B: searches, row update, totals ----------------------------------------------------------------------------------
+  for (size_t i = 0; i < B; ++i) {
+    BatchItem& it = items[i];
+    e3d_icp::PairSlot& sl = *h->slots[i];
+    Cloud& src = *it.src; Cloud& tgt = *it.tgt;
+    PairState& ps = *it.ps;
+    const size_t n = it.n;
+    const float4* srcG = src.G4.p + it.j0;
+    const float4* srcLN = src.LN.p + it.j0;
+    const unsigned* list = nullptr;
+    if (it.certified) {
+      it.n_near = h->h_todo_all.p[2 * i]; it.n_far = h->h_todo_all.p[2 * i + 1];
+      list = sl.todo_far.p;
+      const unsigned long long* half = tgt.has_half ? tgt.half_prefix.p : nullptr;
+      h->tm_bounded.start(s);
+      launch_nn_bounded(srcG, sl.todo_near.p, it.n_near, tgt.G4.p, tgt.dense_start.p, half, h->nn_mode == 5, tgt.grid, it.im, tgt.qrange, radius_sq(d), it.bp,
+                        ps.match.p, ps.match2.p, sl.match_d2.p, ps.lbe.p, s);
+      if (it.n_far > 0 && it.n_far * 32 < n) {
+        launch_nn_bounded(srcG, sl.todo_far.p, it.n_far, tgt.G4.p, tgt.dense_start.p, half, h->nn_mode == 5, tgt.grid, it.im, tgt.qrange, radius_sq(d), it.bp,
+                          ps.match.p, ps.match2.p, sl.match_d2.p, ps.lbe.p, s);
+        it.n_near += it.n_far; it.n_far = 0;
+      }
+      h->tm_bounded.stop(s);
+      if (it.n_near > 0) { rec.nn_bounded_launches++; rec.nn_bounded_queries += (long long)it.n_near; }
+    }
+    if (it.n_far > 0) {
+      sort_query_keys(h, tgt, srcG, list, it.n_far, it.im);
+      h->tm_search.start(s);
+      launch_rows(3, tgt, srcG, h->vals_b.p, it.n_far, it.im, radius_sq(d), it.cert, ps.match.p, sl.match_d2.p, ps.lbe.p, ps.match2.p, s);
+      h->tm_search.stop(s);
+      rec.nn_search_launches++; rec.nn_search_queries += (long long)it.n_far;
+    }
+    ps.fresh = false;
+    if (want_stats)
+      fprintf(stderr, "[nn %d->%d] queries %zu bounded %zu rows %zu cum %.3g (last %.3g) err %.3g\n", it.job->src, it.job->tgt, n, it.n_near, it.n_far,
+              it.cum_pair, src.last_motion + tgt.last_motion, src.err_max + tgt.err_max);
+    // resident rows (see find_pair)
+    const size_t cap = resident_rows_cap(n);
+    const bool sg = src.fixed || src.cloud_index == 0, tg = tgt.fixed || tgt.cloud_index == 0;
+    bool valid = ps.rows_valid && ps.pA.cap >= cap && ps.src_global == sg && ps.tgt_global == tg;
+    if (valid && sg && std::memcmp(ps.src_T, src.T, sizeof ps.src_T) != 0) valid = false;
+    if (valid && tg && std::memcmp(ps.tgt_T, tgt.T, sizeof ps.tgt_T) != 0) valid = false;
+    if (!valid) {
+      ps.pA.reserve(cap); ps.pB.reserve(cap); ps.pC.reserve(cap); ps.plane_match.reserve(n); ps.glist.reserve(div_up(n, 64));
+      E3D_HIP(hipMemsetAsync(ps.plane_match.p, 0xFE, sizeof(int) * n, s));
+      if (cap > n) {
+        E3D_HIP(hipMemsetAsync(ps.pA.p + n, 0, sizeof(float4) * (cap - n), s));
+        E3D_HIP(hipMemsetAsync(ps.pB.p + n, 0, sizeof(float4) * (cap - n), s));
+        E3D_HIP(hipMemsetAsync(ps.pC.p + n, 0, sizeof(float4) * (cap - n), s));
+      }
+      ps.src_global = sg; ps.tgt_global = tg;
+      std::memcpy(ps.src_T, src.T, sizeof ps.src_T); std::memcpy(ps.tgt_T, tgt.T, sizeof ps.tgt_T);
+      ps.rows_valid = true;
+    }
+    h->tm_compact.start(s);
+    launch_corr_update(ps.match.p, ps.plane_match.p, sl.match_d2.p, n, (sg ? src.G4.p : src.L4.p) + it.j0, srcLN, sg, to_affine(src.T),
+                       tg ? tgt.G4.p : tgt.L4.p, tgt.LN.p, tg, to_affine(tgt.T), ps.pA.p, ps.pB.p, ps.pC.p, h->block_counts.p,
+                       h->block_d2.p, h->block_groups.p, s);
+    h->tm_compact.stop(s);
+    h->tm_scan.start(s);
+    launch_corr_totals(n, h->block_counts.p, h->block_d2.p, h->block_groups.p, h->chunk_sum.p, h->chunk_d2.p, h->chunk_groups.p,
+                       h->d_totals_all.p + 3 * i, h->d_d2_all.p + i, ps.glist.p, s);
+    h->tm_scan.stop(s);
+  }
+  copy_out(h->h_totals_all.p, h->d_totals_all.p, sizeof(unsigned long long) * 3 * B, s);
+  copy_out(h->h_d2_all.p, h->d_d2_all.p, sizeof(double) * B, s);
+  sync(h);
+  for (size_t i = 0; i < B; ++i) {
+    BatchItem& it = items[i];
+    it.job->count = (long long)h->h_totals_all.p[3 * i];
+    it.job->dsum = h->h_d2_all.p[i];
+    it.job->resident = it.ps;
+    it.job->vrows = 64 * (long long)h->h_totals_all.p[3 * i + 1];
+    rec.corr_rows_rewritten += (long long)h->h_totals_all.p[3 * i + 2];
+    rec.corr_rows_walked += it.job->vrows;
+    rec.queries += (long long)it.n;
+    rec.correspondences += it.job->count;
+  }
+}
+
 // number of LM blocks for a set of n correspondences in a system of n_sets sets (deterministic function of the two).  Every
 // block ends with a wave / block reduction of up to 55 f64 accumulators (~1000 instructions, 2 - 3 loop trips' worth): with
 // hundreds of sets (all-pairs jobs) 1024 blocks per set would leave each thread ~40 trips, so the cap shrinks with the set count
@@ -1125,16 +1291,38 @@ static bool align_meshes(e3d_icp* h, float max_d, float thr, bool print, int ite
     }
     if (want > h->cA.cap) { h->cA.reserve(want); h->cB.reserve(want); h->cC.reserve(want); }
   }
-  for (size_t p = 0; p < jobs.size(); ++p) {
-    PairJob& j = jobs[p];
-    Cloud& src = (j.src == M) ? *h->fixed : *h->clouds[j.src];
-    Cloud& tgt = (j.tgt == M) ? *h->fixed : *h->clouds[j.tgt];
-    // this rank's slice of the source cloud (cell order); world == 1 => the whole cloud
-    const size_t j0 = (size_t)((unsigned __int128)src.n * (unsigned)h->rank / (unsigned)h->world);
-    const size_t j1 = (size_t)((unsigned __int128)src.n * (unsigned)(h->rank + 1) / (unsigned)h->world);
-    find_pair(h, src, tgt, max_d, j, j0, j1, rec);
-    rec.queries += (long long)(j1 - j0);
-    rec.correspondences += j.count;
+  {
+    // Pairs of the certificate search with resident rows run in batches of up to kPairBatch (two host round trips per batch);
+    // every other pair (sparse targets, forced kernel modes, compacted rows, the sequential distance sum) one by one.
+    static const bool batching = [] { const char* e = getenv("E3D_ICP_BATCH"); return !(e && e[0] == '0'); }();
+    std::vector<BatchItem> batch;
+    size_t batch_queries = 0;                               // a batch's scratch is 12 B per query: bounded (768 MB), whatever the clouds' size
+    auto flush = [&]() { if (!batch.empty()) { find_pairs_batched(h, batch, max_d, rec); batch.clear(); batch_queries = 0; } };
+    for (size_t p = 0; p < jobs.size(); ++p) {
+      PairJob& j = jobs[p];
+      Cloud& src = (j.src == M) ? *h->fixed : *h->clouds[j.src];
+      Cloud& tgt = (j.tgt == M) ? *h->fixed : *h->clouds[j.tgt];
+      // this rank's slice of the source cloud (cell order); world == 1 => the whole cloud
+      const size_t j0 = (size_t)((unsigned __int128)src.n * (unsigned)h->rank / (unsigned)h->world);
+      const size_t j1 = (size_t)((unsigned __int128)src.n * (unsigned)(h->rank + 1) / (unsigned)h->world);
+      const bool whole = !sharded(h) && (j1 - j0) == src.n;
+      if (batching && !nn_profile() && h->resident_now && pair_uses_rows(h, tgt) && j1 > j0 && tgt.n > 0 && !(h->sequential_dsum && whole)) {
+        j.count = 0; j.dsum = 0.0; j.corr_off = h->corr_used;
+        BatchItem it{};
+        it.job = &j; it.src = &src; it.tgt = &tgt; it.j0 = j0; it.n = j1 - j0;
+        it.ps = &pair_state_for(h, j.src, j.tgt, src, tgt, j0, j1 - j0);
+        if (batch_queries + it.n > ((size_t)64 << 20)) flush();
+        batch.push_back(it);
+        batch_queries += it.n;
+        if (batch.size() == kPairBatch) flush();
+        continue;
+      }
+      flush();                                              // (keeps the pairs' order on the stream)
+      find_pair(h, src, tgt, max_d, j, j0, j1, rec);
+      rec.queries += (long long)(j1 - j0);
+      rec.correspondences += j.count;
+    }
+    flush();
   }
   t_nn.stop(s);
   if (nn_profile()) {
@@ -1209,6 +1397,8 @@ static bool align_meshes(e3d_icp* h, float max_d, float thr, bool print, int ite
   rec.t_nn_ms = t_nn.ms();
   rec.t_nn_sort_ms = h->tm_sort.take(); rec.t_nn_scan_ms = h->tm_scan.take(); rec.t_nn_compact_ms = h->tm_compact.take();
   { const double tb = h->tm_bounded.take(); rec.t_nn_bounded_ms += tb; rec.t_nn_query_ms += tb; }
+  { const double tc = h->tm_certify.take(); rec.t_nn_certify_ms += tc; rec.t_nn_query_ms += tc; }
+  { const double ts = h->tm_search.take(); rec.t_nn_search_ms += ts; rec.t_nn_query_ms += ts; }
   rec.t_lm_ms = t_lm.ms();
   h->iter_records.push_back(rec);
   return converged;

@@ -40,6 +40,23 @@ struct KnnGrid {
 };
 constexpr int kKnnSelFallback = 253;  // pass A's answer: k not reached inside a narrowed histogram range
 
+// sqdist_l2 (query - candidate, (dx^2 + dy^2) + dz^2, every operation rounded on its own) with x and y as ONE packed operation each:
+// a candidate's x and y arrive in consecutive registers, so v_pk_add_f32 / v_pk_mul_f32 take them as they are (the compiler's own
+// pairing -- x with z -- needs two register moves per candidate, which it places right behind the loads and so waits for them)
+typedef float knn_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float knn_sqdist(const knn_f2 qxy, float qz, const float4 c) {
+#ifdef E3D_KNN_FORCE_W   // experiment: 16 instead of 12 bytes per candidate and lane through the vector L1
+  asm volatile("" :: "v"(c.w));
+#endif
+  const knn_f2 cxy = {c.x, c.y};
+  const knn_f2 d = qxy - cxy;
+  const knn_f2 sq = d * d;
+  const float dz = qz - c.z;
+  float acc = sq.x + sq.y;
+  acc = acc + dz * dz;
+  return acc;
+}
+
 // runs of the cells [x0, x1] of row (y, z): with the dense directory one run, with the hash table one per cell.  body(begin, end)
 template <class F>
 __device__ __forceinline__ void knn_row(const KnnGrid& G, const HashEntry* __restrict__ table, int x0, int x1, int y, int z, F body) {
@@ -89,21 +106,37 @@ __global__ __launch_bounds__(kBlock) void k_dense_ends32(const unsigned* __restr
   ends[k] = (unsigned)(j + 1);
 }
 
+// -DE3D_KNN_PROF=1 (E3D_EXTRA_HIPCC_FLAGS): shader-clock stop-watch of the sections of the two scan kernels, summed over the waves
+// (lane 0 of each wave adds its differences); E3D_KNN_STATS=1 prints them after a call.  Diagnostics only.
+#ifdef E3D_KNN_PROF
+__device__ unsigned long long g_knn_prof[32];
+#define KP_DECL(N) unsigned long long kp_t[N] = {}
+#define KP_MARK(i) (kp_t[i] = __builtin_readcyclecounter())
+#define KP_FLUSH(base, N) do { if ((threadIdx.x & 63) == 0) { _Pragma("unroll") for (int kp_i = 1; kp_i < (N); ++kp_i) if (kp_t[kp_i] && kp_t[kp_i - 1]) atomicAdd(&g_knn_prof[(base) + kp_i - 1], kp_t[kp_i] - kp_t[kp_i - 1]); atomicAdd(&g_knn_prof[(base) + 15], 1ull); } } while (0)
+#else
+#define KP_DECL(N) do { } while (0)
+#define KP_MARK(i) do { } while (0)
+#define KP_FLUSH(base, N) do { } while (0)
+#endif
+
 constexpr int kKnnBins = 64;           // histogram bins of the two-pass variant: cell^2 / 32 wide, [0, 2 cell^2)
 constexpr int kKnnHistBlock = 256;
 
 // Pass A of the two-pass variant (see k_knn_normals<3>): per query the first bin of the squared-distance histogram of its 27
 // cells at which the count reaches k (255: none -- the list-maintaining variant takes the query).  Only 64 bytes of LDS per thread:
 // the kernel runs at full occupancy, which is what this latency-bound scan needs.
+// stride > 1 (todo == nullptr): the SAMPLED form for the single-pass variant k_knn_normals<4> -- thread gi looks at query gi * stride
+// only, and k is the count the threshold of that variant aims at (n_todo = number of sampled queries).
 __global__ __launch_bounds__(kKnnHistBlock) void k_knn_hist(const float4* __restrict__ P4, const unsigned* __restrict__ todo, size_t n_todo,
                                                             const HashEntry* __restrict__ table, KnnGrid G, int k,
-                                                            const float4* __restrict__ Q4, unsigned char* __restrict__ sel_bin) {
+                                                            const float4* __restrict__ Q4, unsigned char* __restrict__ sel_bin, unsigned stride) {
   __shared__ unsigned hw[kKnnBins / 4][kKnnHistBlock];
   const int tid = threadIdx.x;
   const size_t gi = (size_t)blockIdx.x * blockDim.x + tid;
   if (gi >= n_todo) return;
-  const unsigned qid = todo ? todo[gi] : (unsigned)gi;
+  const unsigned qid = todo ? todo[gi] : (unsigned)gi * stride;
   const float4 q = Q4[qid];
+  KP_DECL(6); KP_MARK(0);
 #pragma unroll
   for (int wv = 0; wv < kKnnBins / 4; ++wv) hw[wv][tid] = 0u;
   const int cx = cell_coord(q.x, G.g.origin[0], G.g.inv_cell);
@@ -126,6 +159,8 @@ __global__ __launch_bounds__(kKnnHistBlock) void k_knn_hist(const float4* __rest
     fexp = n27 <= 12u * (unsigned)k ? 0 : (n27 <= 24u * (unsigned)k ? 1 : 2);
   }
   const float inv_w2 = (float)(32 << fexp) * G.g.inv_cell * G.g.inv_cell;
+  const knn_f2 qxy = {q.x, q.y};
+  KP_MARK(1);
   auto add = [&](float d2) {
     const float bb = d2 * inv_w2;
     if (bb < (float)kKnnBins) { const int b = (int)bb; atomicAdd(&hw[b >> 2][tid], 1u << (8 * (b & 3))); }
@@ -133,15 +168,27 @@ __global__ __launch_bounds__(kKnnHistBlock) void k_knn_hist(const float4* __rest
   for (int oz = -1; oz <= 1; ++oz)
     for (int oy = -1; oy <= 1; ++oy)
       knn_row(G, table, cx - 1, cx + 1, cy + oy, cz + oz, [&](unsigned m, unsigned e) {
-        for (; m + 8 <= e; m += 8) {                                  // eight candidates in flight per lane
+        // eight candidates in flight per lane, addressed from one pointer (the loads differ by immediate offsets); the last
+        // batch of a row reads up to seven entries past its end (P4 is padded by eight) and masks them
+        for (; m + 8 <= e; m += 8) {
+          const float4* __restrict__ pm = P4 + m;
           float4 cb[8];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) cb[j] = P4[m + j];
+          for (int j = 0; j < 8; ++j) cb[j] = pm[j];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) add(sqdist_l2(q.x, q.y, q.z, cb[j].x, cb[j].y, cb[j].z));
+          for (int j = 0; j < 8; ++j) add(knn_sqdist(qxy, q.z, cb[j]));
         }
-        for (; m < e; ++m) { const float4 c = P4[m]; add(sqdist_l2(q.x, q.y, q.z, c.x, c.y, c.z)); }
+        if (m < e) {
+          const float4* __restrict__ pm = P4 + m;
+          const unsigned nvalid = e - m;
+          float4 cb[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) cb[j] = pm[j];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) if ((unsigned)j < nvalid) add(knn_sqdist(qxy, q.z, cb[j]));
+        }
       });
+  KP_MARK(2);
   // first bin at which the running count reaches k (a byte that wrapped only makes the count too small: checked after pass B)
   int sel = 255, cum = 0;
   for (int wv = 0; wv < kKnnBins / 4 && sel == 255; ++wv) {
@@ -155,6 +202,7 @@ __global__ __launch_bounds__(kKnnHistBlock) void k_knn_hist(const float4* __rest
   // [2 bits: bin scale | 6 bits: bin]; k not reached: 255 with the full range (the k-th neighbour is at least sqrt(2) cells away),
   // kKnnSelFallback with a narrowed one (it may still lie inside the block: the list-maintaining variant looks)
   sel_bin[gi] = (unsigned char)(sel == 255 ? (fexp == 0 ? 255 : kKnnSelFallback) : ((fexp << 6) | sel));
+  KP_MARK(3); KP_FLUSH(0, 4);
 }
 
 __device__ __forceinline__ bool knn_less(float d1, unsigned p1, float d2, unsigned p2, const float4* __restrict__ P4) {
@@ -236,11 +284,7 @@ __device__ __forceinline__ void eigen33_smallest(const float* cov, float& eigenv
 // if neighbours with equal keys could not be put into exact order within three passes (the caller then runs its exact LDS sort;
 // the list is left key-sorted).  pos_of(word) -> position, dist_of(position) -> f32 squared distance.
 template <int N, class PosOf, class DistOf>
-__device__ __forceinline__ bool knn_sort_words(unsigned* __restrict__ hp, int tid, int cnt, PosOf pos_of, DistOf dist_of,
-                                               const float4* __restrict__ P4) {
-  unsigned a[N];
-#pragma unroll
-  for (int i = 0; i < N; ++i) a[i] = (i < cnt) ? hp[(size_t)i * kKnnBlock + tid] : 0xFFFFFFFFu;
+__device__ __forceinline__ bool knn_sort_regs(unsigned (&a)[N], int cnt, PosOf pos_of, DistOf dist_of, const float4* __restrict__ P4) {
   // Batcher's merge exchange for arbitrary N (Knuth 5.2.2 M): all indices are compile-time constants after unrolling
 #pragma unroll
   for (int p = 1; p < N; p <<= 1)
@@ -266,9 +310,59 @@ __device__ __forceinline__ bool knn_sort_words(unsigned* __restrict__ hp, int ti
       }
     }
   }
+  return !dirty;
+}
+
+template <int N, class PosOf, class DistOf>
+__device__ __forceinline__ bool knn_sort_words(unsigned* __restrict__ hp, int tid, int cnt, PosOf pos_of, DistOf dist_of,
+                                               const float4* __restrict__ P4) {
+  unsigned a[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) a[i] = (i < cnt) ? hp[(size_t)i * kKnnBlock + tid] : 0xFFFFFFFFu;
+  const bool settled = knn_sort_regs<N>(a, cnt, pos_of, dist_of, P4);
 #pragma unroll
   for (int i = 0; i < N; ++i) if (i < cnt) hp[(size_t)i * kKnnBlock + tid] = a[i];
-  return !dirty;
+  return settled;
+}
+
+// The single-pass variant with 16-bit list entries (k_knn_normals<5>): LDS holds the candidates' [row | offset] tags only, two per
+// dword; here the tags come back, each candidate is fetched again for its distance key, the [key | tag] words are sorted in
+// registers and the first k of them leave as positions (dword i of the list = neighbour i).  rs = the nine row starts in LDS.
+// Returns false if equal keys could not be ordered exactly (the caller hands the query to the two-pass variant).
+constexpr int kKnnTagSlots = 64;
+template <class DistOf>
+__device__ __forceinline__ bool knn_sort_tags(unsigned* __restrict__ list, const unsigned* __restrict__ rs, int tid, int cnt, int k,
+                                              const knn_f2 qxy, float qz, float key_scale, DistOf dist_of, const float4* __restrict__ P4) {
+  constexpr int N = kKnnTagSlots;
+  unsigned a[N];
+  auto pos_of = [&](unsigned w) { return rs[(size_t)((w >> 12) & 15u) * kKnnBlock + tid] + (w & 0xFFFu); };
+#pragma unroll
+  for (int i0 = 0; i0 < N; i0 += 8) {
+    if (i0 < cnt) {
+      unsigned tg[8]; float4 c[8];
+#pragma unroll
+      for (int j = 0; j < 8; j += 2) {
+        const unsigned w2 = list[(size_t)((i0 + j) >> 1) * kKnnBlock + tid];
+        tg[j] = w2 & 0xFFFFu; tg[j + 1] = w2 >> 16;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) if (i0 + j >= cnt) tg[j] = tg[0];          // (slots past the count hold nothing: any valid tag)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) c[j] = P4[pos_of(tg[j])];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float d2 = knn_sqdist(qxy, qz, c[j]);
+        a[i0 + j] = (i0 + j < cnt) ? (((unsigned)(d2 * key_scale) << 16) | tg[j]) : 0xFFFFFFFFu;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[i0 + j] = 0xFFFFFFFFu;
+    }
+  }
+  const bool settled = knn_sort_regs<N>(a, cnt, pos_of, dist_of, P4);
+#pragma unroll
+  for (int i = 0; i < N / 2; ++i) if (i < k) list[(size_t)i * kKnnBlock + tid] = pos_of(a[i]);      // (k <= N / 2: the list's dwords)
+  return settled;
 }
 
 // One pass over the queries listed in `todo` (or all points when todo == nullptr) on one grid level.
@@ -288,7 +382,15 @@ __device__ __forceinline__ bool knn_sort_words(unsigned* __restrict__ hp, int ti
 //      at least k of them.  The words are sorted by a sorting network in registers (knn_sort_words), equal keys by the recomputed
 //      f32 distances and the original indices, so the list comes out in (distance, original index) order like the other
 //      variants'; one directory word per slot then turns [row | offset] into positions.  4 B of LDS per list slot: 16 waves per CU
-//      at k = 32.  Whatever does not fit (more than `cap` candidates in those bins: duplicates, dense clusters; no bin reaches k
+//      at k = 32.
+//   4  (k <= 36, dense directory, level 0, all queries) ONE PASS: pass A of variant 3 costs as much as the collection itself, and
+//      it is run for every query to learn one number -- the distance that holds k candidates -- that neighbouring queries
+//      share up to Poisson noise.  Here k_knn_hist looks at every rep_stride-th query of the cell order only and finds the
+//      distance that holds T candidates (T between k and the list's capacity); every query collects the candidates closer than
+//      the mean of its rep_avg nearest samples' distances.  The collected set is exact for ANY threshold -- it holds every
+//      candidate up to that distance -- so the sample decides only how many queries land inside [k, capacity]; the others
+//      (a few per cent) run through variant 3 afterwards.  The sort is the 64-word network, only the first k words are kept.
+//   Variant 3: whatever does not fit (more than `cap` candidates in those bins: duplicates, dense clusters; no bin reaches k
 //      within 2 cell^2; a row of 4096+ points) goes to `fb_todo`, which the host runs through the list-maintaining variant on the
 //      same grid: results are exact either way.  (20 M points, k = 32: 64 ms with variant 2 -> 11.6 ms; k = 8: 18 -> 8.5 ms.)
 // reach: 1 = the 27 cells around the query's cell; 2 = the 125 cells (list-maintaining variants only), the retry pass for the
@@ -305,18 +407,21 @@ __global__ __launch_bounds__(kKnnBlock) void k_knn_normals(const float4* __restr
                                                            unsigned* __restrict__ next_count,
                                                            unsigned* __restrict__ fb_todo, unsigned* __restrict__ fb_count,
                                                            const unsigned char* __restrict__ sel_bins,
-                                                           int reach) {
+                                                           int reach, int rep_stride, int rep_avg, float tau_ratio) {
   extern __shared__ unsigned char smem[];
   // variants 0..2: [cap = k distances][cap positions]; variant 3: [cap words: key | row | offset, later the positions]
   constexpr int kOffWords = 0;
   float* hd = reinterpret_cast<float*>(smem) + (size_t)kOffWords * kKnnBlock;
-  unsigned* hp = reinterpret_cast<unsigned*>(smem) + (size_t)(kOffWords + (kSel == 3 ? 0 : cap)) * kKnnBlock;
+  // variant 5: [9 row starts][cap / 2 dwords: two 16-bit tags each, later the k positions]
+  unsigned* hp = reinterpret_cast<unsigned*>(smem) + (size_t)(kOffWords + (kSel == 5 ? 9 : (kSel >= 3 ? 0 : cap))) * kKnnBlock;
+  unsigned* rs_lds = reinterpret_cast<unsigned*>(smem);
   const int tid = threadIdx.x;
   const size_t gi = (size_t)blockIdx.x * blockDim.x + tid;
   if (gi >= n_todo) return;
   const unsigned qid = todo ? todo[gi] : (unsigned)gi;              // index into Q4
   const float4 q = Q4[qid];
   const unsigned q_oi = __float_as_uint(q.w);
+  KP_DECL(12); KP_MARK(0);
 #define HD(i) hd[(size_t)(i) * kKnnBlock + tid]
 #define HP(i) hp[(size_t)(i) * kKnnBlock + tid]
   // !kHeap: the k best so far live UNSORTED in LDS; the worst of them (by (distance, original index), the order of the result
@@ -427,60 +532,105 @@ __global__ __launch_bounds__(kKnnBlock) void k_knn_normals(const float4* __restr
     return face > 0.f ? face * face * 0.99999f : 0.f;
   };
   bool fallback = false;
-  if constexpr (kSel == 3) {
-    const int sel_byte = (int)sel_bins[gi];                         // pass A (k_knn_hist): [bin scale | bin], or a verdict
-    bool block_is_everything = true;                                // the 27 cells cover the whole cloud (tiny clouds, k > n)
-    {
-      const int c3[3] = {cx, cy, cz};
+  if constexpr (kSel >= 3) {
+    // ---- the candidate set: every point of the 27 cells closer than a threshold that holds at least k of them ----
+    //   3: the threshold is the upper edge of the bin pass A (k_knn_hist) selected for THIS query: k .. k + 4 candidates;
+    //   4: the threshold comes from the histograms of a SAMPLE of the queries (every rep_stride-th in cell order, k_knn_hist with
+    //      stride; the mean of rep_avg of them): it aims at a count between k and the list's capacity.  A count outside that
+    //      window sends the query to the two-pass variant (fb_todo) -- any threshold gives the exact set, the sample only decides
+    //      how often it fits.
+    float tau2 = 0.f;             // squared threshold
+    float key_scale = 0.f;        // 16-bit key = (unsigned)(d2 * key_scale), monotone in d2
+    int sel_bin = 0;
+    float inv_w2 = 0.f;
+    if constexpr (kSel == 3) {
+      const int sel_byte = (int)sel_bins[gi];                         // pass A (k_knn_hist): [bin scale | bin], or a verdict
+      bool block_is_everything = true;                                // the 27 cells cover the whole cloud (tiny clouds, k > n)
+      {
+        const int c3[3] = {cx, cy, cz};
 #pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        if (G.g.origin[a] + (float)(c3[a] - 1) * G.cell > G.dmin[a]) block_is_everything = false;
-        if (G.g.origin[a] + (float)(c3[a] + 2) * G.cell <= G.dmax[a]) block_is_everything = false;
+        for (int a = 0; a < 3; ++a) {
+          if (G.g.origin[a] + (float)(c3[a] - 1) * G.cell > G.dmin[a]) block_is_everything = false;
+          if (G.g.origin[a] + (float)(c3[a] + 2) * G.cell <= G.dmax[a]) block_is_everything = false;
+        }
+      }
+      if (sel_byte == 255 && !block_is_everything) {
+        // fewer than k points within the histogram's range (sqrt(2) cells at the least): the k-th neighbour cannot be certified
+        // inside this block of 27 cells, so the query goes to the next level as it is -- not through the list-maintaining variant
+        // first (2 M queries of a scanner-sampled scan took that detour)
+        const unsigned slot = atomicAdd(next_count, 1u);
+        next_todo[slot] = qid;
+        return;
+      }
+      sel_bin = (sel_byte == kKnnSelFallback || sel_byte == 255) ? kKnnBins : (sel_byte & 63);
+      inv_w2 = (float)(32 << ((sel_byte >> 6) & 3)) * G.g.inv_cell * G.g.inv_cell;       // bins of cell^2 / (32 f): [0, 2 cell^2 / f)
+      if (sel_bin >= kKnnBins) fallback = true;                       // the k-th neighbour lies beyond the histogram's range
+      tau2 = (float)(sel_bin + 1) * (1.0f / inv_w2) * 1.00001f;        // (only the cells' face test uses it)
+    } else {
+      const size_t n_reps = (n_todo + (size_t)rep_stride - 1) / (size_t)rep_stride;
+      const size_t r0 = (gi / (size_t)rep_stride) & ~(size_t)(rep_avg - 1);
+      float edge_sum = 0.f; int have = 0;
+      for (int i = 0; i < rep_avg; ++i)
+        if (r0 + (size_t)i < n_reps) {
+          const int bsel = (int)sel_bins[r0 + (size_t)i];
+          if (bsel < kKnnSelFallback) { edge_sum += (float)((bsel & 63) + 1) / (float)(32 << ((bsel >> 6) & 3)); ++have; }
+        }
+      if (have == 0) fallback = true;                                 // no sampled query near by found its count inside the block
+      else {
+        tau2 = edge_sum / (float)have * G.cell * G.cell * tau_ratio;
+        key_scale = 65000.0f / tau2;
       }
     }
-    if (sel_byte == 255 && !block_is_everything) {
-      // fewer than k points within the histogram's range (sqrt(2) cells at the least): the k-th neighbour cannot be certified
-      // inside this block of 27 cells, so the query goes to the next level as it is -- not through the list-maintaining variant
-      // first (2 M queries of a scanner-sampled scan took that detour)
-      const unsigned slot = atomicAdd(next_count, 1u);
-      next_todo[slot] = qid;
-      return;
-    }
-    const int sel_bin = (sel_byte == kKnnSelFallback || sel_byte == 255) ? kKnnBins : (sel_byte & 63);
-    const float inv_w2 = (float)(32 << ((sel_byte >> 6) & 3)) * G.g.inv_cell * G.g.inv_cell;       // bins of cell^2 / (32 f): [0, 2 cell^2 / f)
-    if (sel_bin >= kKnnBins) {
-      fallback = true;                                                // the k-th neighbour lies beyond the histogram's range
-    } else {
+    if (!fallback) {
       {
-        // every candidate of the bins <= sel_bin is appended to the query's LDS list in scan order; the sorting network below
+        // every candidate below the threshold is appended to the query's LDS list in scan order; the sorting network below
         // does not care about the order (a bucket placement by bin pairs with LDS fetch-and-adds was measured: the 32 B of slot
         // offsets per query cost more occupancy than the pre-sorting saved)
-        const float tau2 = (float)(sel_bin + 1) * (1.0f / inv_w2) * 1.00001f;
         int placed = 0;
         bool long_row = false;
+        KP_MARK(1);
         // A collected candidate is stored as ONE word: [16-bit distance key | 4-bit row | 12-bit offset], row = 3 (oz + 1) + (oy + 1),
         // offset = its position relative to the start of cell (cx - 1, cy + oy, cz + oz) in the dense directory.  Positions are
-        // recovered after the sort with one directory word per slot -- 4 instead of 6 bytes of LDS per slot (14 instead of 10 waves
+        // recovered after the sort from the nine row starts -- 4 instead of 6 bytes of LDS per slot (14 instead of 10 waves
         // per CU for this latency-bound scan).  A 3-cell row of 4096 points or more: the list-maintaining variant takes the query.
-        // (This variant runs with the dense directory only.)
-        auto row_start = [&](int r) -> unsigned {
-          const int oy = r % 3 - 1, oz = r / 3 - 1;
-          const size_t row = ((size_t)(cz + oz) * G.D[1] + (size_t)(cy + oy)) * G.D[0];
-          return G.S[row + (size_t)max(cx - 1, 0)];
-        };
-        auto place8 = [&](unsigned tag0, const float4* cb, int nvalid) {
+        // (These variants run with the dense directory only.)
+        unsigned rstart[9], rfirst[9], rend[9];
+        const knn_f2 qxy = {q.x, q.y};
+        auto place4 = [&](unsigned tag0, const float4* cb, unsigned nvalid) {
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const float d2 = sqdist_l2(q.x, q.y, q.z, cb[j].x, cb[j].y, cb[j].z);
-            const float bb = d2 * inv_w2;
-            if (j < nvalid && bb < (float)kKnnBins && (int)bb <= sel_bin) {
-              if (placed < cap) HP(placed) = ((unsigned)(bb * 1024.0f) << 16) | (tag0 + (unsigned)j);
+          for (int j = 0; j < 4; ++j) {
+            const float d2 = knn_sqdist(qxy, q.z, cb[j]);
+            bool take; unsigned key;
+            if constexpr (kSel == 3) {
+              const float bb = d2 * inv_w2;
+              take = bb < (float)kKnnBins && (int)bb <= sel_bin;
+              key = (unsigned)(bb * 1024.0f);
+            } else if constexpr (kSel == 4) {
+              take = d2 < tau2;
+              key = (unsigned)(d2 * key_scale);
+            } else {
+              take = d2 < tau2;
+              key = 0u;                                               // (variant 5 computes the keys after the collection)
+            }
+            if ((unsigned)j < nvalid && take) {
+              if constexpr (kSel == 5) {
+                if (placed < cap)
+                  reinterpret_cast<unsigned short*>(hp)[((size_t)(placed >> 1) * kKnnBlock + tid) * 2 + (size_t)(placed & 1)] = (unsigned short)(tag0 + (unsigned)j);
+              } else {
+                if (placed < cap) HP(placed) = (key << 16) | (tag0 + (unsigned)j);
+              }
               ++placed;
             }
           }
         };
+        // the nine rows' directory words first (27 independent loads); a row the threshold cannot reach, an empty one or a long
+        // one has first == end
+#pragma unroll
         for (int oz = -1; oz <= 1; ++oz)
+#pragma unroll
           for (int oy = -1; oy <= 1; ++oy) {
+            const int r = 3 * (oz + 1) + (oy + 1);
+            rstart[r] = 0u; rfirst[r] = 0u; rend[r] = 0u;
             if ((oy | oz) != 0 && face2(0, oy, oz) > tau2) continue;
             const int y = cy + oy, z = cz + oz;
             if (y < 0 || z < 0 || y >= (int)G.D[1] || z >= (int)G.D[2]) continue;
@@ -488,32 +638,78 @@ __global__ __launch_bounds__(kKnnBlock) void k_knn_normals(const float4* __restr
             const size_t row = ((size_t)z * G.D[1] + (size_t)y) * G.D[0];
             const unsigned r0 = G.S[row + (size_t)max(cx - 1, 0)];
             const unsigned m0 = G.S[row + (size_t)xlo], e = G.S[row + (size_t)xhi + 1];
+            rstart[r] = r0;
             if (e - r0 > 4096u) { long_row = true; continue; }
-            const unsigned rtag = (unsigned)(3 * (oz + 1) + (oy + 1)) << 12;
-            for (unsigned m = m0; m < e; m += 8) {                          // eight candidates in flight per lane
-              float4 cb[8];
-              const int nvalid = (int)min(8u, e - m);
+            rfirst[r] = m0; rend[r] = e;
+          }
+        // where the stream goes on after row r: the first candidate of the next row that has any (its batch is requested while
+        // row r's last one is evaluated)
+        unsigned rnext[9];
+        {
+          unsigned nx = 0u;
 #pragma unroll
-              for (int j = 0; j < 8; ++j) cb[j] = P4[min(m + j, e - 1)];
-              place8(rtag | (m - r0), cb, nvalid);
+          for (int r = 8; r >= 0; --r) { rnext[r] = nx; if (rfirst[r] < rend[r]) nx = rfirst[r]; }
+          // (nx: the first candidate of all)
+          // Candidates stream through two half batches of four that are refilled as soon as they are evaluated: four to eight
+          // loads stay in flight across batch and row boundaries (this kernel runs at two to three waves per SIMD -- its LDS list
+          // -- so the latency has to be covered inside the wave).  A half batch may read past its row's end (P4 is padded by
+          // eight); those entries are masked.
+          float4 ha[4], hb[4];
+          {
+            const float4* __restrict__ pm = P4 + nx;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ha[j] = pm[j];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) hb[j] = pm[4 + j];
+          }
+#pragma unroll
+          for (int r = 0; r < 9; ++r) {
+            const unsigned e = rend[r], r0 = rstart[r], rtag = (unsigned)r << 12;
+            for (unsigned m = rfirst[r]; m < e;) {
+              const unsigned nm = m + 8u;
+              const float4* __restrict__ pn = P4 + (nm < e ? nm : rnext[r]);
+              const unsigned nvalid = e - m;
+              place4(rtag | (m - r0), ha, nvalid);
+#pragma unroll
+              for (int j = 0; j < 4; ++j) ha[j] = pn[j];
+              place4(rtag | (m + 4u - r0), hb, nvalid > 4u ? nvalid - 4u : 0u);
+#pragma unroll
+              for (int j = 0; j < 4; ++j) hb[j] = pn[4 + j];
+              m = nm;
             }
           }
+        }
+        KP_MARK(2);
         // more candidates than list slots (duplicates, a dense cluster in one bin), or a long row: the other variant takes over
         if (placed > cap || placed < k || long_row) {
           fallback = true;
         } else {
           cnt = placed;
+          auto row_start = [&](int r) -> unsigned {
+            const int oy = r % 3 - 1, oz = r / 3 - 1;
+            const size_t row = ((size_t)(cz + oz) * G.D[1] + (size_t)(cy + oy)) * G.D[0];
+            return G.S[row + (size_t)max(cx - 1, 0)];
+          };
           auto pos_of = [&](unsigned w) { return row_start((int)((w >> 12) & 15u)) + (w & 0xFFFu); };
           auto dist_of = [&](unsigned m) { const float4 c = P4[m]; return sqdist_l2(q.x, q.y, q.z, c.x, c.y, c.z); };
+          if constexpr (kSel == 5) {
+#pragma unroll
+            for (int r = 0; r < 9; ++r) rs_lds[(size_t)r * kKnnBlock + tid] = rstart[r];
+            const bool settled = knn_sort_tags(hp, rs_lds, tid, cnt, k, qxy, q.z, key_scale, dist_of, P4);
+            KP_MARK(3);
+            if (!settled) fallback = true;              // (a long run of equal keys: the two-pass variant has room to sort it in LDS)
+            cnt = k;
+          } else {
           // exact (d2, original index) order.  The words go through a sorting network in registers (Batcher's merge exchange, no
-          // LDS traffic and no divergence; the bucket placement only has to keep the list short of sorting work it cannot do:
-          // none), then neighbours with EQUAL 16-bit keys are put into exact order by up to three bubble passes over the
-          // recomputed f32 distances and the original indices; a longer run of equal keys (lattices, duplicates) falls back to the
-          // exact insertion sort in LDS.
+          // LDS traffic and no divergence), then neighbours with EQUAL 16-bit keys are put into exact order by up to three bubble
+          // passes over the recomputed f32 distances and the original indices; a longer run of equal keys (lattices, duplicates)
+          // falls back to the exact insertion sort in LDS.  Variant 4 keeps the first k + 1 .. of the sorted list only.
           bool settled;
           if (cap <= 12) settled = knn_sort_words<12>(hp, tid, cnt, pos_of, dist_of, P4);
           else if (cap <= 20) settled = knn_sort_words<20>(hp, tid, cnt, pos_of, dist_of, P4);
           else if (cap <= 36) settled = knn_sort_words<36>(hp, tid, cnt, pos_of, dist_of, P4);
+          else if (cap <= 44) settled = knn_sort_words<44>(hp, tid, cnt, pos_of, dist_of, P4);
+          else if (cap <= 52) settled = knn_sort_words<52>(hp, tid, cnt, pos_of, dist_of, P4);
           else settled = knn_sort_words<64>(hp, tid, cnt, pos_of, dist_of, P4);
           if (!settled) {
             for (int i = 1; i < cnt; ++i) {
@@ -534,15 +730,33 @@ __global__ __launch_bounds__(kKnnBlock) void k_knn_normals(const float4* __restr
               HP(j + 1) = kw;
             }
           }
-          // [row | offset] -> positions, eight directory words in flight
-          for (int i0 = 0; i0 < cnt; i0 += 8) {
-            unsigned w[8], st[8];
+          KP_MARK(3);
+          // [row | offset] -> positions.  Only the first k entries are neighbours (variant 4 collects up to the capacity); the
+          // nine row starts go through the LDS slots behind them when there are nine free ones (dynamic index), else through
+          // the directory again.
+          if (cnt > k) cnt = k;
+          if (k + 9 <= cap) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { w[j] = HP(min(i0 + j, cnt - 1)); st[j] = row_start((int)((w[j] >> 12) & 15u)); }
+            for (int r = 0; r < 9; ++r) HP(k + r) = rstart[r];
+            for (int i0 = 0; i0 < cnt; i0 += 8) {
+              unsigned w[8], st[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) if (i0 + j < cnt) HP(i0 + j) = st[j] + (w[j] & 0xFFFu);
+              for (int j = 0; j < 8; ++j) { w[j] = HP(min(i0 + j, cnt - 1)); st[j] = HP(k + (int)((w[j] >> 12) & 15u)); }
+#pragma unroll
+              for (int j = 0; j < 8; ++j) if (i0 + j < cnt) HP(i0 + j) = st[j] + (w[j] & 0xFFFu);
+            }
+          } else {
+            for (int i0 = 0; i0 < cnt; i0 += 8) {
+              unsigned w[8], st[8];
+#pragma unroll
+              for (int j = 0; j < 8; ++j) { w[j] = HP(min(i0 + j, cnt - 1)); st[j] = row_start((int)((w[j] >> 12) & 15u)); }
+#pragma unroll
+              for (int j = 0; j < 8; ++j) if (i0 + j < cnt) HP(i0 + j) = st[j] + (w[j] & 0xFFFu);
+            }
           }
-          td = dist_of(HP(cnt - 1));                                            // the farthest collected candidate
+          }
+          if (!fallback) td = dist_of(HP(cnt - 1));                             // the k-th nearest (>= it for a cloud of fewer than k points)
+          KP_MARK(4);
         }
       }
     }
@@ -610,8 +824,8 @@ __global__ __launch_bounds__(kKnnBlock) void k_knn_normals(const float4* __restr
     next_todo[slot] = qid;
     return;
   }
-  if constexpr (kSel == 3) {
-    // sorted already (bucket order + exact order inside the buckets)
+  if constexpr (kSel >= 3) {
+    // sorted already (sorting network + exact order of equal keys)
   } else {
   // heap sort in place -> ascending (d2, original index): Floyd's heap construction, then repeated extraction of the maximum
   for (int start = kHeap ? -1 : cnt / 2 - 1; start >= 0; --start) {     // (variant 3: cnt may exceed k here, all of it is sorted)
@@ -652,7 +866,7 @@ __global__ __launch_bounds__(kKnnBlock) void k_knn_normals(const float4* __restr
     double dist_sum = 0.0;
     for (int i = 1; i < cnt; ++i) {
       float d2i;
-      if constexpr (kSel == 3) { const float4 c = P4[HP(i)]; d2i = sqdist_l2(q.x, q.y, q.z, c.x, c.y, c.z); }
+      if constexpr (kSel >= 3) { const float4 c = P4[HP(i)]; d2i = sqdist_l2(q.x, q.y, q.z, c.x, c.y, c.z); }
       else d2i = HD(i);
       dist_sum += (double)sqrtf(d2i);
     }
@@ -667,6 +881,7 @@ __global__ __launch_bounds__(kKnnBlock) void k_knn_normals(const float4* __restr
     // two_pass_centroid.hpp:176-192 (dense branch), f32, neighbour order
     // the neighbours are gathered eight at a time (eight independent loads in flight); the sums keep the neighbour order
     float a6 = 0.f, a7 = 0.f, a8 = 0.f;
+    KP_MARK(5);
     for (int i0 = 0; i0 < cnt; i0 += 8) {
       float4 pb[8];
 #pragma unroll
@@ -694,6 +909,7 @@ __global__ __launch_bounds__(kKnnBlock) void k_knn_normals(const float4* __restr
           a5 += (p.z - a8) * (p.z - a8);
         }
     }
+    KP_MARK(6);
     float cov[9];
     cov[0] = a0 / fc; cov[1] = a1 / fc; cov[2] = a2 / fc; cov[4] = a3 / fc; cov[5] = a4 / fc; cov[8] = a5 / fc;
     cov[3] = cov[1]; cov[6] = cov[2]; cov[7] = cov[5];
@@ -706,9 +922,11 @@ __global__ __launch_bounds__(kKnnBlock) void k_knn_normals(const float4* __restr
     const float vx = vpx - q.x, vy = vpy - q.y, vz = vpz - q.z;
     const float cos_theta = (vx * nx + vy * ny + vz * nz);
     if (cos_theta < 0) { nx *= -1; ny *= -1; nz *= -1; }
+    KP_MARK(7);
   }
   out_n[3 * (size_t)q_oi] = nx; out_n[3 * (size_t)q_oi + 1] = ny; out_n[3 * (size_t)q_oi + 2] = nz;
   out_c[q_oi] = curv;
+  if constexpr (kSel >= 3) { KP_MARK(8); KP_FLUSH(16, 9); }
 #undef HD
 #undef HP
 }
@@ -922,7 +1140,7 @@ static void knn_pass(KnnWorkspace& W, const float* xyz, size_t n, int k, const f
 
     LevelBuffers& L = W.L;
     L.ka.reserve(n); L.kb.reserve(n); L.va.reserve(n); L.vb.reserve(n); L.counter.reserve(4);
-    L.P4.reserve(n);
+    L.P4.reserve(n + 8);
     DevBuf<float4>& Q4 = W.Q4;     // queries in level-0 cell order (spatially coherent for every level)
     DevBuf<unsigned>&todo_a = W.todo_a, &todo_b = W.todo_b;
     todo_a.reserve(n); todo_b.reserve(n);
@@ -936,8 +1154,27 @@ static void knn_pass(KnnWorkspace& W, const float* xyz, size_t n, int k, const f
     const int cap = sel == 3 ? ((std::max(k + cap_extra, 12) + 1) & ~1) : k;             // list entries per thread in LDS
     const size_t lds = sel == 3 ? (size_t)cap * kKnnBlock * 4 : (size_t)cap * kKnnBlock * 8, lds_list = (size_t)k * kKnnBlock * 8;
     auto kernel_of = [](int v) {
-      return v == 0 ? k_knn_normals<0> : (v == 1 ? k_knn_normals<1> : (v == 2 ? k_knn_normals<2> : k_knn_normals<3>));
+      return v == 0 ? k_knn_normals<0> : (v == 1 ? k_knn_normals<1> : (v == 2 ? k_knn_normals<2> : (v == 3 ? k_knn_normals<3> : (v == 4 ? k_knn_normals<4> : k_knn_normals<5>))));
     };
+    // the single-pass variant (see k_knn_normals): sampled thresholds, level 0 only; its leftovers take the two-pass variant
+    static const int single_env = [] { const char* e = getenv("E3D_KNN_SINGLE"); return e ? atoi(e) : 1; }();
+    static const int rep_stride_env = [] { const char* e = getenv("E3D_KNN_REP_STRIDE"); return e ? atoi(e) : 0; }();
+    static const int rep_avg_env = [] { const char* e = getenv("E3D_KNN_REP_AVG"); return e ? atoi(e) : 0; }();
+    static const double rep_target_env = [] { const char* e = getenv("E3D_KNN_REP_TARGET"); return e ? atof(e) : 0.0; }();
+    constexpr int kSinglePassMaxK = kKnnTagSlots / 2;                        // variant 5 hands back k positions in its cap / 2 dwords
+    const bool single = sel == 3 && single_env != 0 && k <= kSinglePassMaxK && k >= 3;
+    // small k: 32-bit [key | tag] entries (variant 4, 36 slots: the occupancy of the two-pass variant at k = 32); beyond that
+    // the 64 slots would leave 10 waves per CU, so the list holds 16-bit tags and the keys are computed afterwards (variant 5)
+    const int single_variant = (single_env == 4 || k <= 10) ? 4 : 5;
+    static const int cap1_env = [] { const char* e = getenv("E3D_KNN_CAP1"); return e ? atoi(e) : 0; }();
+    const int cap1 = single_variant == 5 ? kKnnTagSlots : ((cap1_env >= k + 9 && cap1_env <= 64) ? cap1_env : (k <= 10 ? 36 : 64));   // list slots of the single-pass variant (a sorting network's size)
+    const int rep_stride = rep_stride_env > 0 ? rep_stride_env : 8;
+    const int rep_avg = (rep_avg_env == 1 || rep_avg_env == 2 || rep_avg_env == 4) ? rep_avg_env : 2;
+    // the count the threshold aims at: the middle of [k, capacity] (k = 32: 48 of 64), a little below it for small k where the
+    // relative Poisson noise of the count is larger on the low side
+    const int rep_target = rep_target_env > 0 ? (int)rep_target_env : std::min((k + cap1) / 2, 3 * k);
+    const size_t lds1 = single_variant == 5 ? (size_t)(9 + cap1 / 2) * kKnnBlock * 4 : (size_t)cap1 * kKnnBlock * 4;
+    if (single) E3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel_of(single_variant)), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
     E3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel_of(sel)), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     E3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel_of(sel_list)), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_list));
     DevBuf<unsigned>& fb_todo = W.fb_todo;
@@ -954,7 +1191,7 @@ static void knn_pass(KnnWorkspace& W, const float* xyz, size_t n, int k, const f
       for (int a = 0; a < 3; ++a) { G.g.origin[a] = (float)((double)bb[a] - 2.0 * cell_size); G.dmin[a] = bb[a]; G.dmax[a] = bb[3 + a]; }
       G.slack = (float)(16.0 * FLT_EPSILON * (magnitude + 4.0 * cell_size) + 1e-4 * cell_size);
       if (extent / cell_size > (double)((1 << 21) - 8)) return false;
-      LB.ka.reserve(n); LB.kb.reserve(n); LB.va.reserve(n); LB.vb.reserve(n); LB.counter.reserve(4); LB.P4.reserve(n);
+      LB.ka.reserve(n); LB.kb.reserve(n); LB.va.reserve(n); LB.vb.reserve(n); LB.counter.reserve(4); LB.P4.reserve(n + 8);   // (+ 8: the scan kernels read whole batches)
       // dense directory over the bounding grid (cells 0 .. cell of the bbox maximum + 2 per axis) unless it would be huge.  With it
       // the sort key is the 32-bit linear cell index (same (z, y, x) order as the 63-bit key: 4 radix passes instead of 8).
       QueryRange qr{};
@@ -1005,19 +1242,39 @@ static void knn_pass(KnnWorkspace& W, const float* xyz, size_t n, int k, const f
     // the two-pass variant (LB.counter[2]) join that list for the wide pass or run through the list-maintaining variant on the same
     // grid right away.  n_next_out: length of next_list; returns the number of fallback queries.
     auto search_level = [&](LevelBuffers& LB, const KnnGrid& G, const unsigned* todo_list, size_t n_list, unsigned* next_list,
-                            unsigned& n_next_out, bool merge_fb_into_next) {
-      E3D_HIP(hipMemsetAsync(LB.counter.p + 1, 0, 2 * sizeof(unsigned), s));
-      const unsigned nblk = (unsigned)div_up(n_list, kKnnBlock);
+                            unsigned& n_next_out, bool merge_fb_into_next, unsigned* single_list) {
+      E3D_HIP(hipMemsetAsync(LB.counter.p + 1, 0, 3 * sizeof(unsigned), s));
       const int lsel = (sel == 3 && !G.S) ? sel_list : sel;            // the two-pass variant needs the dense directory
-      if (lsel == 3) {
+      if (lsel == 3 && single && todo_list == nullptr && n_list == n && single_list != nullptr) {
+        // single pass over all queries with sampled thresholds; those whose count missed the window are listed in single_list and
+        // take the two passes below (the next-level list keeps growing: same counter)
+        const size_t n_reps = div_up(n_list, (size_t)rep_stride);
+        LB.sel_bin.reserve(n_list);
+        hipLaunchKernelGGL(k_knn_hist, dim3((unsigned)div_up(n_reps, kKnnHistBlock)), dim3(kKnnHistBlock), 0, s, LB.P4.p, (const unsigned*)nullptr, n_reps,
+                           LB.table.p, G, rep_target, Q4.p, LB.sel_bin.p, (unsigned)rep_stride);
+        hipLaunchKernelGGL(kernel_of(single_variant), dim3((unsigned)div_up(n_list, kKnnBlock)), dim3(kKnnBlock), lds1, s, LB.P4.p, n, (const unsigned*)nullptr, n_list, LB.table.p, G, k, cap1,
+                           viewpoint[0], viewpoint[1], viewpoint[2], Q4.p, want_normals ? d_on.p : nullptr, want_normals ? d_oc.p : nullptr,
+                           knn_indices ? d_knn.p : nullptr, d_mean_out ? d_mean_out->p : nullptr, next_list, LB.counter.p + 1,
+                           single_list, LB.counter.p + 3, LB.sel_bin.p, 1, rep_stride, rep_avg, 1.0f);
+        unsigned n_single_fb = 0;
+        E3D_HIP(hipMemcpyAsync(&n_single_fb, LB.counter.p + 3, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+        E3D_HIP(hipStreamSynchronize(s));
+        E3D_HIP(hipGetLastError());
+        if (getenv("E3D_KNN_STATS")) fprintf(stderr, "[knn] single pass (variant %d): %zu queries, target %d of %d slots, %u to the two-pass variant\n", single_variant, n_list, rep_target, cap1, n_single_fb);
+        todo_list = single_list;
+        n_list = n_single_fb;
+      }
+      const unsigned nblk = (unsigned)div_up(n_list, kKnnBlock);
+      if (lsel == 3 && n_list > 0) {
         LB.sel_bin.reserve(n_list);
         hipLaunchKernelGGL(k_knn_hist, dim3((unsigned)div_up(n_list, kKnnHistBlock)), dim3(kKnnHistBlock), 0, s, LB.P4.p, todo_list, n_list,
-                           LB.table.p, G, k, Q4.p, LB.sel_bin.p);
+                           LB.table.p, G, k, Q4.p, LB.sel_bin.p, 1u);
       }
+      if (n_list > 0)
       hipLaunchKernelGGL(kernel_of(lsel), dim3(nblk), dim3(kKnnBlock), lsel == 3 ? lds : lds_list, s, LB.P4.p, n, todo_list, n_list, LB.table.p, G, k, lsel == 3 ? cap : k,
                          viewpoint[0], viewpoint[1], viewpoint[2], Q4.p, want_normals ? d_on.p : nullptr, want_normals ? d_oc.p : nullptr,
                          knn_indices ? d_knn.p : nullptr, d_mean_out ? d_mean_out->p : nullptr, next_list, LB.counter.p + 1,
-                         fb_todo.p, LB.counter.p + 2, LB.sel_bin.p, 1);
+                         fb_todo.p, LB.counter.p + 2, LB.sel_bin.p, 1, 1, 1, 1.0f);
       unsigned cnts[2] = {0, 0};
       E3D_HIP(hipMemcpyAsync(cnts, LB.counter.p + 1, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, s));
       E3D_HIP(hipStreamSynchronize(s));
@@ -1034,7 +1291,7 @@ static void knn_pass(KnnWorkspace& W, const float* xyz, size_t n, int k, const f
         hipLaunchKernelGGL(kernel_of(sel_list), dim3((unsigned)div_up((size_t)n_fb, kKnnBlock)), dim3(kKnnBlock), lds_list, s, LB.P4.p, n,
                            fb_todo.p, (size_t)n_fb, LB.table.p, G, k, k, viewpoint[0], viewpoint[1], viewpoint[2], Q4.p,
                            want_normals ? d_on.p : nullptr, want_normals ? d_oc.p : nullptr, knn_indices ? d_knn.p : nullptr,
-                           d_mean_out ? d_mean_out->p : nullptr, next_list, LB.counter.p + 1, nullptr, nullptr, nullptr, 1);
+                           d_mean_out ? d_mean_out->p : nullptr, next_list, LB.counter.p + 1, nullptr, nullptr, nullptr, 1, 1, 1, 1.0f);
         E3D_HIP(hipMemcpyAsync(cnts, LB.counter.p + 1, sizeof(unsigned), hipMemcpyDeviceToHost, s));
         E3D_HIP(hipStreamSynchronize(s));
         E3D_HIP(hipGetLastError());
@@ -1051,8 +1308,22 @@ static void knn_pass(KnnWorkspace& W, const float* xyz, size_t n, int k, const f
       }
       unsigned* next = (todo == todo_a.p) ? todo_b.p : todo_a.p;
       unsigned n_next = 0;
-      const unsigned n_fb = search_level(L, G, todo, n_todo, next, n_next, wide_pass);
+      // (level 0: no list yet, so the other list buffer is free for the single-pass variant's leftovers)
+      const unsigned n_fb = search_level(L, G, todo, n_todo, next, n_next, wide_pass, todo == nullptr ? todo_b.p : nullptr);
       if (getenv("E3D_KNN_STATS")) fprintf(stderr, "[knn] level %d cell %g todo %zu fallback %u next %u\n", level, (double)cell, n_todo, n_fb, n_next);
+#ifdef E3D_KNN_PROF
+      if (getenv("E3D_KNN_STATS")) {
+        unsigned long long hp[32], zero[32] = {};
+        E3D_HIP(hipStreamSynchronize(s));
+        E3D_HIP(hipMemcpyFromSymbol(hp, HIP_SYMBOL(g_knn_prof), sizeof hp));
+        E3D_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_knn_prof), zero, sizeof zero));
+        fprintf(stderr, "[knn prof] hist: waves %llu cycles/wave:", hp[15]);
+        for (int i = 0; i < 5; ++i) fprintf(stderr, " %.0f", hp[15] ? (double)hp[i] / (double)hp[15] : 0.0);
+        fprintf(stderr, "\n[knn prof] normals<3>: waves %llu cycles/wave:", hp[31]);
+        for (int i = 0; i < 10; ++i) fprintf(stderr, " %.0f", hp[31] ? (double)hp[16 + i] / (double)hp[31] : 0.0);
+        fprintf(stderr, "\n");
+      }
+#endif
       // the few that need a wider look (the k-th neighbour lies outside the 27 cells: sparse regions, outliers): the list-maintaining
       // variant over the 125 cells of the same grid, which reaches as far as a grid of twice the cell size would -- no second grid
       // build for ~1 % of the queries
@@ -1065,7 +1336,7 @@ static void knn_pass(KnnWorkspace& W, const float* xyz, size_t n, int k, const f
         hipLaunchKernelGGL(kernel_of(sel_list), dim3((unsigned)div_up((size_t)n_next, kKnnBlock)), dim3(kKnnBlock), lds_list, s, L.P4.p, n,
                            next, (size_t)n_next, L.table.p, G, k, k, viewpoint[0], viewpoint[1], viewpoint[2], Q4.p,
                            want_normals ? d_on.p : nullptr, want_normals ? d_oc.p : nullptr, knn_indices ? d_knn.p : nullptr,
-                           d_mean_out ? d_mean_out->p : nullptr, wide_out, L.counter.p + 1, nullptr, nullptr, nullptr, 2);
+                           d_mean_out ? d_mean_out->p : nullptr, wide_out, L.counter.p + 1, nullptr, nullptr, nullptr, 2, 1, 1, 1.0f);
         E3D_HIP(hipMemcpyAsync(cw, L.counter.p + 1, sizeof(unsigned), hipMemcpyDeviceToHost, s));
         E3D_HIP(hipStreamSynchronize(s));
         E3D_HIP(hipGetLastError());

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-4 evidence (one MI355X): kernel-trace stats of the default bench line, HBM traffic counters (separate FETCH_SIZE / WRITE_SIZE passes)
 # and SQ counters of the kernels of the three paths.  Summaries land in gpurun_out/r4prof/ ; the ones to judge are copied to profiles/.
-# usage: bash tools/prof_round4.sh [stage ...]   stages: trace terrace partial icp reg normals sq nsq   (default: all but partial)
+# usage: bash tools/prof_round4.sh [stage ...]   stages: trace terrace partial icp reg normals sq nsq nta   (default: all but partial)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r4prof
@@ -64,9 +64,17 @@ for st in $STAGES; do
     nsq)     # SQ counters of the kNN normal kernels, k = 32 and k = 8
       A="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU"
       B="SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM"
-      for k in 32 8; do
+      for k in ${NK:-32 8}; do
         FILTER="" pmc normals_k${k}_sq_a $A -- python $R/tools/bench_normals.py --k $k --no-cpu --repeat 1
         FILTER="" pmc normals_k${k}_sq_b $B -- python $R/tools/bench_normals.py --k $k --no-cpu --repeat 1
+      done ;;
+    nta)     # texture-addresser / vector-L1 counters of the kNN normal kernels (is the scan bound by its loads' address processing?)
+      A="TA_TA_BUSY_sum TA_BUSY_avr TA_FLAT_READ_WAVEFRONTS_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum GRBM_GUI_ACTIVE"
+      B="TCP_GATE_EN1_sum TCP_GATE_EN2_sum TCP_TA_TCP_STATE_READ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum"
+      rocprofv3 --list-avail 2>/dev/null | grep -E "TA_|TCP_" | head -80 > $O/avail_ta_tcp.txt
+      for k in ${NK:-32 8}; do
+        FILTER="" pmc normals_k${k}_ta_a $A -- python $R/tools/bench_normals.py --k $k --no-cpu --repeat 1
+        FILTER="" pmc normals_k${k}_ta_b $B -- python $R/tools/bench_normals.py --k $k --no-cpu --repeat 1
       done ;;
   esac
 done

@@ -96,14 +96,66 @@ __global__ __launch_bounds__(kBlock) void k_cell_keys_dense(const float* __restr
   vals[i] = (unsigned)i;
 }
 
-// ends[cell] = one past the last sorted position of the cell (the last point of every run writes); an exclusive max scan turns the
-// array into the cells' start positions
-__global__ __launch_bounds__(kBlock) void k_dense_ends32(const unsigned* __restrict__ keys, size_t n, unsigned* __restrict__ ends) {
+// The dense directory S[c] = number of points with a key below c (= the start of cell c's run, or of the next occupied cell's) over
+// the ncell + 2 entries of the bounding grid.  Less than 1 % of a scan's cells hold points, so clearing the array, marking the run
+// ends and an exclusive max scan over all of it (12 B of traffic per cell: 1.3 ms at 318 M cells) is replaced by ONE write of each
+// word: a coarse directory C[t] = number of points with key < 4096 t comes from that recipe on a 4096 times smaller array, then
+// block t fills the 4096 cells of its tile from the points [C[t], C[t + 1]) -- run starts marked in LDS, every empty cell takes
+// the next mark (wave ballots, no scan), the tile leaves as full lines.
+constexpr unsigned kDirTileLog2 = 12, kDirTile = 1u << kDirTileLog2;
+__global__ __launch_bounds__(kBlock) void k_dir_coarse_ends(const unsigned* __restrict__ keys, size_t n, unsigned* __restrict__ ends) {
   const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
-  const unsigned k = keys[j];
-  if (j + 1 < n && keys[j + 1] == k) return;
-  ends[k] = (unsigned)(j + 1);
+  const unsigned t = keys[j] >> kDirTileLog2;
+  if (j + 1 < n && (keys[j + 1] >> kDirTileLog2) == t) return;
+  ends[t] = (unsigned)(j + 1);
+}
+
+__global__ __launch_bounds__(256) void k_dense_directory(const unsigned* __restrict__ keys, const unsigned* __restrict__ coarse,
+                                                         unsigned* __restrict__ S, size_t n_entries) {
+  __shared__ unsigned sl[kDirTile];
+  __shared__ unsigned first_of_wave[4], tail_of_wave[4];
+  constexpr unsigned kUnset = 0xFFFFFFFFu;
+  const unsigned tid = threadIdx.x;
+  const size_t c0 = (size_t)blockIdx.x << kDirTileLog2;
+  const unsigned lb0 = coarse[blockIdx.x], lb1 = coarse[blockIdx.x + 1];
+  const unsigned cnt = (unsigned)min((size_t)kDirTile, n_entries - c0);
+  if (lb0 == lb1) {                                                      // no point in the tile (most tiles)
+    for (unsigned i = tid; i < cnt; i += 256) S[c0 + i] = lb1;
+    return;
+  }
+  for (unsigned i = tid; i < kDirTile; i += 256) sl[i] = kUnset;
+  __syncthreads();
+  for (unsigned j = lb0 + tid; j < lb1; j += 256) {
+    const unsigned key = keys[j];
+    if (j == lb0 || keys[j - 1] != key) sl[key - (unsigned)c0] = j;
+  }
+  __syncthreads();
+  // each wave owns a quarter of the tile and walks it from the end, 64 cells a round: a cell takes the nearest mark at or after it
+  const unsigned w = tid >> 6, lane = tid & 63;
+  unsigned carry = kUnset;                                               // the nearest mark behind the cells seen so far (wave-uniform)
+  for (int r = (int)(kDirTile / 4 / 64) - 1; r >= 0; --r) {
+    const unsigned i = w * (kDirTile / 4) + 64u * (unsigned)r + lane;
+    const unsigned v = sl[i];
+    const unsigned long long mask = __ballot(v != kUnset);
+    const unsigned long long at_or_after = mask & (~0ull << lane);
+    const int src = at_or_after ? __builtin_ctzll(at_or_after) : (int)lane;
+    const unsigned got = __shfl(v, src);
+    sl[i] = at_or_after ? got : carry;
+    if (mask) carry = __shfl(v, __builtin_ctzll(mask));
+  }
+  if (lane == 0) first_of_wave[w] = carry;
+  __syncthreads();
+  if (tid < 4) {
+    unsigned t = lb1;                                                    // behind the tile's last mark: the next tile's first point
+    for (int ww = 3; ww > (int)tid; --ww) if (first_of_wave[ww] != kUnset) t = first_of_wave[ww];
+    tail_of_wave[tid] = t;
+  }
+  __syncthreads();
+  for (unsigned i = tid; i < cnt; i += 256) {
+    const unsigned v = sl[i];
+    S[c0 + i] = v != kUnset ? v : tail_of_wave[i >> (kDirTileLog2 - 2)];
+  }
 }
 
 // -DE3D_KNN_PROF=1 (E3D_EXTRA_HIPCC_FLAGS): shader-clock stop-watch of the sections of the two scan kernels, summed over the waves
@@ -1018,6 +1070,7 @@ struct LevelBuffers {
   DevBuf<float4> P4, LN;
   DevBuf<HashEntry> table;
   DevBuf<unsigned> dense;          // dense cell-start directory of the level (when the bounding grid is small enough)
+  DevBuf<unsigned> coarse;         // its coarse form (one word per 4096 cells), from which the directory is written
   DevBuf<unsigned char> sel_bin;   // pass A results of the two-pass variant: the selected bin per query
 };
 
@@ -1038,7 +1091,7 @@ struct KnnWorkspace {
   size_t bytes() const {
     return raw.cap * 4 + bbox_partial.cap * 4 + bbox_out.cap * 4 + d_on.cap * 4 + d_oc.cap * 4 + d_mean.cap * 4 + d_knn.cap * 4 + d_in.cap +
            L.ka.cap * 8 + L.kb.cap * 8 + L.va.cap * 4 + L.vb.cap * 4 + L.counter.cap * 4 + L.temp.cap + L.P4.cap * 16 + L.LN.cap * 16 +
-           L.table.cap * sizeof(HashEntry) + L.dense.cap * 4 + L.sel_bin.cap + Q4.cap * 16 + todo_a.cap * 4 +
+           L.table.cap * sizeof(HashEntry) + L.dense.cap * 4 + L.coarse.cap * 4 + L.sel_bin.cap + Q4.cap * 16 + todo_a.cap * 4 +
            todo_b.cap * 4 + fb_todo.cap * 4;
   }
   ~KnnWorkspace() { if (stream) (void)hipStreamDestroy(stream); }
@@ -1100,22 +1153,40 @@ extern "C" int e3d_release_workspaces(void) {
 }
 
 namespace e3d {
+// A pointer the kernels can use as it is (device memory of the current device)?  Host pointers go through a staging copy.
+static bool is_device_pointer(const void* ptr) {
+  if (!ptr) return false;
+  hipPointerAttribute_t attr{};
+  if (hipPointerGetAttributes(&attr, ptr) != hipSuccess) { (void)hipGetLastError(); return false; }
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess) return false;
+  return attr.type == hipMemoryTypeDevice && attr.device == dev;
+}
+
 // The exact kNN pass over a host cloud.  Results stay on the device: normals + curvature (if want_normals), the neighbour
 // index lists (if d_knn) and the mean neighbour distance (if d_mean), all in input order.
+// direct_n / direct_c: device buffers that take the normals / curvatures as they are computed (no staging in W.d_on / W.d_oc);
+// a cloud that already lies in device memory is read in place.
 static void knn_pass(KnnWorkspace& W, const float* xyz, size_t n, int k, const float* viewpoint, bool want_normals, bool want_knn,
-                     bool want_mean) {
+                     bool want_mean, float* direct_n = nullptr, float* direct_c = nullptr) {
     hipStream_t s = W.stream;
-    DevBuf<float>&raw = W.raw, &bbox_partial = W.bbox_partial, &bbox_out = W.bbox_out, &d_on = W.d_on, &d_oc = W.d_oc;
+    DevBuf<float>&bbox_partial = W.bbox_partial, &bbox_out = W.bbox_out;
     DevBuf<int>* d_knn_out = want_knn ? &W.d_knn : nullptr;
     DevBuf<float>* d_mean_out = want_mean ? &W.d_mean : nullptr;
-    raw.reserve(3 * n);
-    if (want_normals) { d_on.reserve(3 * n); d_oc.reserve(n); }
+    const bool in_place = is_device_pointer(xyz);
+    if (!in_place) W.raw.reserve(3 * n);
+    struct { const float* p; } raw{in_place ? xyz : W.raw.p};
+    struct { float* p; } d_on{nullptr}, d_oc{nullptr};
+    if (want_normals) {
+      if (direct_n && direct_c) { d_on.p = direct_n; d_oc.p = direct_c; }
+      else { W.d_on.reserve(3 * n); W.d_oc.reserve(n); d_on.p = W.d_on.p; d_oc.p = W.d_oc.p; }
+    }
     if (d_knn_out) d_knn_out->reserve(n * (size_t)k);
     if (d_mean_out) d_mean_out->reserve(n);
     const bool knn_indices = d_knn_out != nullptr;
     DevBuf<int> no_knn;
     DevBuf<int>& d_knn = d_knn_out ? *d_knn_out : no_knn;
-    copy_in(raw.p, xyz, sizeof(float) * 3 * n, s);
+    if (!in_place) copy_in(W.raw.p, xyz, sizeof(float) * 3 * n, s);
     bbox_partial.reserve(6 * (size_t)kMaxBboxBlocks); bbox_out.reserve(6);
     launch_bbox_aos(raw.p, n, bbox_partial.p, bbox_out.p, s);
     float bb[6];
@@ -1141,7 +1212,9 @@ static void knn_pass(KnnWorkspace& W, const float* xyz, size_t n, int k, const f
     LevelBuffers& L = W.L;
     L.ka.reserve(n); L.kb.reserve(n); L.va.reserve(n); L.vb.reserve(n); L.counter.reserve(4);
     L.P4.reserve(n + 8);
-    DevBuf<float4>& Q4 = W.Q4;     // queries in level-0 cell order (spatially coherent for every level)
+    // queries in level-0 cell order (spatially coherent for every level): level 0's sorted points themselves; a further level sorts
+    // into the other buffer (the two are swapped then)
+    struct { const float4* p; } Q4{nullptr};
     DevBuf<unsigned>&todo_a = W.todo_a, &todo_b = W.todo_b;
     todo_a.reserve(n); todo_b.reserve(n);
     unsigned* todo = nullptr;
@@ -1213,9 +1286,12 @@ static void knn_pass(KnnWorkspace& W, const float* xyz, size_t n, int k, const f
         sort_pairs_u32_u32(k32_in, k32_out, LB.va.p, LB.vb.p, n, bits, LB.temp, s);
         launch_permute(raw.p, nullptr, LB.vb.p, n, LB.P4.p, nullptr, s);
         LB.dense.reserve(ncell + 2);
-        E3D_HIP(hipMemsetAsync(LB.dense.p, 0, sizeof(unsigned) * (ncell + 2), s));
-        hipLaunchKernelGGL(k_dense_ends32, dim3((unsigned)div_up(n, kBlock)), dim3(kBlock), 0, s, k32_out, n, LB.dense.p);
-        exclusive_max_scan_u32(LB.dense.p, ncell + 2, LB.temp, s);
+        const size_t n_tiles = div_up(ncell + 2, (size_t)kDirTile);
+        LB.coarse.reserve(n_tiles + 1);
+        E3D_HIP(hipMemsetAsync(LB.coarse.p, 0, sizeof(unsigned) * (n_tiles + 1), s));
+        hipLaunchKernelGGL(k_dir_coarse_ends, dim3((unsigned)div_up(n, kBlock)), dim3(kBlock), 0, s, k32_out, n, LB.coarse.p);
+        exclusive_max_scan_u32(LB.coarse.p, n_tiles + 1, LB.temp, s);
+        hipLaunchKernelGGL(k_dense_directory, dim3((unsigned)n_tiles), dim3(256), 0, s, k32_out, LB.coarse.p, LB.dense.p, ncell + 2);
         G.S = LB.dense.p;
         for (int a = 0; a < 3; ++a) G.D[a] = qr.D[a];
       } else {
@@ -1299,13 +1375,12 @@ static void knn_pass(KnnWorkspace& W, const float* xyz, size_t n, int k, const f
       n_next_out = cnts[0];
       return n_fb;
     };
+    bool queries_kept = false;
     for (int level = 0; level < 64 && n_todo > 0; ++level) {
       KnnGrid G{};
+      if (level >= 1 && !queries_kept) { std::swap(W.Q4.p, L.P4.p); std::swap(W.Q4.cap, L.P4.cap); queries_kept = true; }   // (level 0's points stay the queries)
       if (!build_level(L, cell, dense_log2, G)) { cell *= 4.0; --level; continue; }        // too many cells for 21-bit coordinates: coarsen
-      if (level == 0) {
-        Q4.reserve(n);
-        E3D_HIP(hipMemcpyAsync(Q4.p, L.P4.p, sizeof(float4) * n, hipMemcpyDeviceToDevice, s));
-      }
+      if (level == 0) Q4.p = L.P4.p;
       unsigned* next = (todo == todo_a.p) ? todo_b.p : todo_a.p;
       unsigned n_next = 0;
       // (level 0: no list yet, so the other list buffer is free for the single-pass variant's leftovers)
@@ -1426,11 +1501,13 @@ extern "C" int e3d_normals_knn(const float* xyz, size_t n, int k, const float* v
     WorkspaceLease lease;
     KnnWorkspace& W = *lease.ws;
     hipStream_t s = W.stream;
-    knn_pass(W, xyz, n, k, viewpoint, true, knn_indices != nullptr, false);
-    DevBuf<float>&d_on = W.d_on, &d_oc = W.d_oc;
+    const bool direct = is_device_pointer(out_normals) && is_device_pointer(out_curvature);   // results straight into the caller's device buffers
+    knn_pass(W, xyz, n, k, viewpoint, true, knn_indices != nullptr, false, direct ? out_normals : nullptr, direct ? out_curvature : nullptr);
     DevBuf<int>& d_knn = W.d_knn;
-    copy_out(out_normals, d_on.p, sizeof(float) * 3 * n, s);
-    copy_out(out_curvature, d_oc.p, sizeof(float) * n, s);
+    if (!direct) {
+      copy_out(out_normals, W.d_on.p, sizeof(float) * 3 * n, s);
+      copy_out(out_curvature, W.d_oc.p, sizeof(float) * n, s);
+    }
     if (knn_indices) copy_out(knn_indices, d_knn.p, sizeof(int) * n * (size_t)k, s);
     E3D_HIP(hipStreamSynchronize(s));
     return 0;

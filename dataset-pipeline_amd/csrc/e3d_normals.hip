@@ -1245,7 +1245,7 @@ static void knn_pass(KnnWorkspace& W, const float* xyz, size_t n, int k, const f
     const int rep_avg = (rep_avg_env == 1 || rep_avg_env == 2 || rep_avg_env == 4) ? rep_avg_env : 2;
     // the count the threshold aims at: the middle of [k, capacity] (k = 32: 48 of 64), a little below it for small k where the
     // relative Poisson noise of the count is larger on the low side
-    const int rep_target = rep_target_env > 0 ? (int)rep_target_env : std::min((k + cap1) / 2, 3 * k);
+    const int rep_target = rep_target_env > 0 ? (int)rep_target_env : std::min((k + cap1) / 2, 2 * k + 6);
     const size_t lds1 = single_variant == 5 ? (size_t)(9 + cap1 / 2) * kKnnBlock * 4 : (size_t)cap1 * kKnnBlock * 4;
     if (single) E3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel_of(single_variant)), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
     E3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel_of(sel)), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

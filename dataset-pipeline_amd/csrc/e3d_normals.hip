@@ -100,19 +100,28 @@ __global__ __launch_bounds__(kBlock) void k_cell_keys_dense(const float* __restr
 // the ncell + 2 entries of the bounding grid.  Less than 1 % of a scan's cells hold points, so clearing the array, marking the run
 // ends and an exclusive max scan over all of it (12 B of traffic per cell: 1.3 ms at 318 M cells) is replaced by ONE write of each
 // word: a coarse directory C[t] = number of points with key < 4096 t comes from that recipe on a 4096 times smaller array, then
-// block t fills the 4096 cells of its tile from the points [C[t], C[t + 1]) -- run starts marked in LDS, every empty cell takes
-// the next mark (wave ballots, no scan), the tile leaves as full lines.
+// one pass over the points writes the occupied cells' starts and an occupancy bit per cell, and block t fills the 4096 cells of its
+// tile: every empty cell takes the next occupied one's start (wave ballots, no scan; behind the tile's last one C[t + 1]), the
+// tile leaves as full lines.  Tiles without points (most) are one coalesced fill.
 constexpr unsigned kDirTileLog2 = 12, kDirTile = 1u << kDirTileLog2;
-__global__ __launch_bounds__(kBlock) void k_dir_coarse_ends(const unsigned* __restrict__ keys, size_t n, unsigned* __restrict__ ends) {
+// over the sorted points: the last point of a tile's run writes the coarse end; the first point of a cell's run writes the cell's
+// start into S and sets the cell's bit (a tile of a dense region holds a million points: its block must not walk them)
+__global__ __launch_bounds__(kBlock) void k_dir_mark(const unsigned* __restrict__ keys, size_t n, unsigned* __restrict__ coarse_ends,
+                                                     unsigned* __restrict__ S, unsigned* __restrict__ occupied) {
   const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
-  const unsigned t = keys[j] >> kDirTileLog2;
+  const unsigned key = keys[j];
+  if (j == 0 || keys[j - 1] != key) {
+    S[key] = (unsigned)j;
+    atomicOr(&occupied[key >> 5], 1u << (key & 31u));
+  }
+  const unsigned t = key >> kDirTileLog2;
   if (j + 1 < n && (keys[j + 1] >> kDirTileLog2) == t) return;
-  ends[t] = (unsigned)(j + 1);
+  coarse_ends[t] = (unsigned)(j + 1);
 }
 
-__global__ __launch_bounds__(256) void k_dense_directory(const unsigned* __restrict__ keys, const unsigned* __restrict__ coarse,
-                                                         unsigned* __restrict__ S, size_t n_entries) {
+__global__ __launch_bounds__(256) void k_dense_directory(const unsigned* __restrict__ keys, const unsigned* __restrict__ occupied,
+                                                         const unsigned* __restrict__ coarse, unsigned* __restrict__ S, size_t n_entries) {
   __shared__ unsigned sl[kDirTile];
   __shared__ unsigned first_of_wave[4], tail_of_wave[4];
   constexpr unsigned kUnset = 0xFFFFFFFFu;
@@ -124,16 +133,26 @@ __global__ __launch_bounds__(256) void k_dense_directory(const unsigned* __restr
     for (unsigned i = tid; i < cnt; i += 256) S[c0 + i] = lb1;
     return;
   }
-  for (unsigned i = tid; i < kDirTile; i += 256) sl[i] = kUnset;
-  __syncthreads();
-  for (unsigned j = lb0 + tid; j < lb1; j += 256) {
-    const unsigned key = keys[j];
-    if (j == lb0 || keys[j - 1] != key) sl[key - (unsigned)c0] = j;
+  // the occupied cells' starts: a tile with few points (a scan's surfaces: a few hundred) finds them in its stretch of the sorted
+  // keys; one with many (the floor under a scanner: a million) takes what k_dir_mark wrote, through the occupancy bits.  Then each
+  // wave owns a quarter of the tile and walks it from the end, 64 cells a round: an empty cell takes the nearest start at or after it
+  if (lb1 - lb0 <= 2u * kDirTile) {
+    for (unsigned i = tid; i < kDirTile; i += 256) sl[i] = kUnset;
+    __syncthreads();
+    for (unsigned j = lb0 + tid; j < lb1; j += 256) {
+      const unsigned key = keys[j];
+      if (j == lb0 || keys[j - 1] != key) sl[key - (unsigned)c0] = j;
+    }
+  } else {
+    const unsigned* __restrict__ occ = occupied + (c0 >> 5);
+    for (unsigned i = tid; i < kDirTile; i += 256) {
+      const bool has = i < cnt && ((occ[i >> 5] >> (i & 31u)) & 1u) != 0u;
+      sl[i] = has ? S[c0 + i] : kUnset;
+    }
   }
   __syncthreads();
-  // each wave owns a quarter of the tile and walks it from the end, 64 cells a round: a cell takes the nearest mark at or after it
   const unsigned w = tid >> 6, lane = tid & 63;
-  unsigned carry = kUnset;                                               // the nearest mark behind the cells seen so far (wave-uniform)
+  unsigned carry = kUnset;                                               // the nearest start behind the cells seen so far (wave-uniform)
   for (int r = (int)(kDirTile / 4 / 64) - 1; r >= 0; --r) {
     const unsigned i = w * (kDirTile / 4) + 64u * (unsigned)r + lane;
     const unsigned v = sl[i];
@@ -147,7 +166,7 @@ __global__ __launch_bounds__(256) void k_dense_directory(const unsigned* __restr
   if (lane == 0) first_of_wave[w] = carry;
   __syncthreads();
   if (tid < 4) {
-    unsigned t = lb1;                                                    // behind the tile's last mark: the next tile's first point
+    unsigned t = lb1;                                                    // behind the tile's last start: the next tile's first point
     for (int ww = 3; ww > (int)tid; --ww) if (first_of_wave[ww] != kUnset) t = first_of_wave[ww];
     tail_of_wave[tid] = t;
   }
@@ -459,7 +478,8 @@ __global__ __launch_bounds__(kKnnBlock) void k_knn_normals(const float4* __restr
                                                            unsigned* __restrict__ next_count,
                                                            unsigned* __restrict__ fb_todo, unsigned* __restrict__ fb_count,
                                                            const unsigned char* __restrict__ sel_bins,
-                                                           int reach, int rep_stride, int rep_avg, float tau_ratio) {
+                                                           int reach, int rep_stride, int rep_avg, float tau_ratio,
+                                                           unsigned* __restrict__ seed_pos, unsigned char* __restrict__ seed_flag, unsigned seed_cap) {
   extern __shared__ unsigned char smem[];
   // variants 0..2: [cap = k distances][cap positions]; variant 3: [cap words: key | row | offset, later the positions]
   constexpr int kOffWords = 0;
@@ -815,8 +835,20 @@ __global__ __launch_bounds__(kKnnBlock) void k_knn_normals(const float4* __restr
   } else {
   // own cell first, then face, edge and corner neighbours: the list fills with near points early, so fewer of the later candidates
     // replace an entry (the result does not depend on the order)
-    // reach 2 (the retry pass on the same grid): the 27 inner cells as above, then the shell of 98 cells around them
-    for (int ring = 0; ring <= 2 + reach; ++ring)
+    // reach 2 (the retry pass on the same grid): the 27 inner cells as above, then the shell of 98 cells around them.  A query that
+    // arrives with the k nearest of its 27 cells (seed_pos: it came from the scan variants of this level) starts from those.
+    bool seeded = false;
+    if constexpr (kSel < 3) {
+      if (reach == 2 && seed_flag && gi < (size_t)seed_cap && seed_flag[gi]) {
+        seeded = true;
+        for (int i = 0; i < k; ++i) { const unsigned m = seed_pos[gi * (size_t)k + (size_t)i]; consider(m, P4[m]); }
+      }
+    }
+    // (rings 0 .. 3: the 27 inner cells; ring 4: the shell.  Measured for the 125-cell pass, whose 64 lanes are unrelated queries:
+    // every lane walking its OWN list of the shell cells it needs (bit mask from the face tests) instead of the wave walking the
+    // union in step -- 1.5 instead of 0.87 ms: the longest list of 64 unrelated queries is nearly the union, and its visits no
+    // longer coalesce.  The seeds save the 27 inner cells' round trips only.)
+    for (int ring = seeded ? 4 : 0; ring <= 2 + reach; ++ring)
     for (int oz = -reach; oz <= reach; ++oz)
       for (int oy = -reach; oy <= reach; ++oy)
         for (int ox = -reach; ox <= reach; ++ox) {
@@ -874,6 +906,14 @@ __global__ __launch_bounds__(kKnnBlock) void k_knn_normals(const float4* __restr
   if (!resolved) {
     const unsigned slot = atomicAdd(next_count, 1u);
     next_todo[slot] = qid;
+    if constexpr (kSel >= 3) {
+      // the k nearest of the 27 cells are known: the 125-cell pass that takes this query starts from them and looks at the shell
+      // only (it is one wave deep -- its duration is the latency of the cells it visits one after the other)
+      if (seed_pos && slot < seed_cap && cnt == k) {
+        for (int i = 0; i < k; ++i) seed_pos[(size_t)slot * (size_t)k + (size_t)i] = HP(i);
+        seed_flag[slot] = 1;
+      }
+    }
     return;
   }
   if constexpr (kSel >= 3) {
@@ -1088,11 +1128,13 @@ struct KnnWorkspace {
   LevelBuffers L;
   DevBuf<float4> Q4;
   DevBuf<unsigned> todo_a, todo_b, fb_todo;
+  DevBuf<unsigned> seed_pos;           // the k nearest of the 27 cells of queries that go on to the 125-cell pass (positions), and
+  DevBuf<unsigned char> seed_flag;     // which entries of that pass's list have them
   size_t bytes() const {
     return raw.cap * 4 + bbox_partial.cap * 4 + bbox_out.cap * 4 + d_on.cap * 4 + d_oc.cap * 4 + d_mean.cap * 4 + d_knn.cap * 4 + d_in.cap +
            L.ka.cap * 8 + L.kb.cap * 8 + L.va.cap * 4 + L.vb.cap * 4 + L.counter.cap * 4 + L.temp.cap + L.P4.cap * 16 + L.LN.cap * 16 +
            L.table.cap * sizeof(HashEntry) + L.dense.cap * 4 + L.coarse.cap * 4 + L.sel_bin.cap + Q4.cap * 16 + todo_a.cap * 4 +
-           todo_b.cap * 4 + fb_todo.cap * 4;
+           todo_b.cap * 4 + fb_todo.cap * 4 + seed_pos.cap * 4 + seed_flag.cap;
   }
   ~KnnWorkspace() { if (stream) (void)hipStreamDestroy(stream); }
 };
@@ -1254,6 +1296,12 @@ static void knn_pass(KnnWorkspace& W, const float* xyz, size_t n, int k, const f
     if (sel == 3) { fb_todo.reserve(n); L.counter.reserve(4); }
     static const double level_step = [] { const char* e = getenv("E3D_KNN_LEVEL_STEP"); const double v = e ? atof(e) : 0.0; return v > 1 ? v : 2.0; }();   // cell growth per retry level (4 -> 2: -7 % at k = 32)
     static const bool wide_pass = [] { const char* e = getenv("E3D_KNN_WIDE"); return e ? atoi(e) != 0 : true; }();
+    // seeds of the 125-cell pass (it takes lists of at most n / 64 queries)
+    static const bool seed_env = [] { const char* e = getenv("E3D_KNN_SEED"); return e ? atoi(e) != 0 : true; }();
+    const unsigned seed_cap = (wide_pass && seed_env && sel == 3) ? (unsigned)(n / 64 + 1) : 0u;
+    if (seed_cap) { W.seed_pos.reserve((size_t)seed_cap * (size_t)k); W.seed_flag.reserve(seed_cap); }
+    unsigned* const seed_pos_p = seed_cap ? W.seed_pos.p : nullptr;
+    unsigned char* const seed_flag_p = seed_cap ? W.seed_flag.p : nullptr;
     // Grid of cell size `cell_size` over all points into LB: sorted points, dense directory when the bounding grid has at most
     // 2^dir_log2 cells (else the hash table); false if the extent does not fit 21-bit cell coordinates.
     static const int dense_log2 = [] { const char* e = getenv("E3D_KNN_DENSE_LOG2"); return e ? std::min(atoi(e), 31) : 30; }();
@@ -1287,11 +1335,13 @@ static void knn_pass(KnnWorkspace& W, const float* xyz, size_t n, int k, const f
         launch_permute(raw.p, nullptr, LB.vb.p, n, LB.P4.p, nullptr, s);
         LB.dense.reserve(ncell + 2);
         const size_t n_tiles = div_up(ncell + 2, (size_t)kDirTile);
-        LB.coarse.reserve(n_tiles + 1);
-        E3D_HIP(hipMemsetAsync(LB.coarse.p, 0, sizeof(unsigned) * (n_tiles + 1), s));
-        hipLaunchKernelGGL(k_dir_coarse_ends, dim3((unsigned)div_up(n, kBlock)), dim3(kBlock), 0, s, k32_out, n, LB.coarse.p);
+        const size_t n_words = n_tiles * (kDirTile / 32);                 // one bit per cell, whole tiles
+        LB.coarse.reserve(n_tiles + 1 + n_words);
+        unsigned* const occupied = LB.coarse.p + n_tiles + 1;
+        E3D_HIP(hipMemsetAsync(LB.coarse.p, 0, sizeof(unsigned) * (n_tiles + 1 + n_words), s));
+        hipLaunchKernelGGL(k_dir_mark, dim3((unsigned)div_up(n, kBlock)), dim3(kBlock), 0, s, k32_out, n, LB.coarse.p, LB.dense.p, occupied);
         exclusive_max_scan_u32(LB.coarse.p, n_tiles + 1, LB.temp, s);
-        hipLaunchKernelGGL(k_dense_directory, dim3((unsigned)n_tiles), dim3(256), 0, s, k32_out, LB.coarse.p, LB.dense.p, ncell + 2);
+        hipLaunchKernelGGL(k_dense_directory, dim3((unsigned)n_tiles), dim3(256), 0, s, k32_out, occupied, LB.coarse.p, LB.dense.p, ncell + 2);
         G.S = LB.dense.p;
         for (int a = 0; a < 3; ++a) G.D[a] = qr.D[a];
       } else {
@@ -1320,6 +1370,7 @@ static void knn_pass(KnnWorkspace& W, const float* xyz, size_t n, int k, const f
     auto search_level = [&](LevelBuffers& LB, const KnnGrid& G, const unsigned* todo_list, size_t n_list, unsigned* next_list,
                             unsigned& n_next_out, bool merge_fb_into_next, unsigned* single_list) {
       E3D_HIP(hipMemsetAsync(LB.counter.p + 1, 0, 3 * sizeof(unsigned), s));
+      if (seed_cap) E3D_HIP(hipMemsetAsync(seed_flag_p, 0, seed_cap, s));
       const int lsel = (sel == 3 && !G.S) ? sel_list : sel;            // the two-pass variant needs the dense directory
       if (lsel == 3 && single && todo_list == nullptr && n_list == n && single_list != nullptr) {
         // single pass over all queries with sampled thresholds; those whose count missed the window are listed in single_list and
@@ -1331,7 +1382,7 @@ static void knn_pass(KnnWorkspace& W, const float* xyz, size_t n, int k, const f
         hipLaunchKernelGGL(kernel_of(single_variant), dim3((unsigned)div_up(n_list, kKnnBlock)), dim3(kKnnBlock), lds1, s, LB.P4.p, n, (const unsigned*)nullptr, n_list, LB.table.p, G, k, cap1,
                            viewpoint[0], viewpoint[1], viewpoint[2], Q4.p, want_normals ? d_on.p : nullptr, want_normals ? d_oc.p : nullptr,
                            knn_indices ? d_knn.p : nullptr, d_mean_out ? d_mean_out->p : nullptr, next_list, LB.counter.p + 1,
-                           single_list, LB.counter.p + 3, LB.sel_bin.p, 1, rep_stride, rep_avg, 1.0f);
+                           single_list, LB.counter.p + 3, LB.sel_bin.p, 1, rep_stride, rep_avg, 1.0f, seed_pos_p, seed_flag_p, seed_cap);
         unsigned n_single_fb = 0;
         E3D_HIP(hipMemcpyAsync(&n_single_fb, LB.counter.p + 3, sizeof(unsigned), hipMemcpyDeviceToHost, s));
         E3D_HIP(hipStreamSynchronize(s));
@@ -1350,7 +1401,7 @@ static void knn_pass(KnnWorkspace& W, const float* xyz, size_t n, int k, const f
       hipLaunchKernelGGL(kernel_of(lsel), dim3(nblk), dim3(kKnnBlock), lsel == 3 ? lds : lds_list, s, LB.P4.p, n, todo_list, n_list, LB.table.p, G, k, lsel == 3 ? cap : k,
                          viewpoint[0], viewpoint[1], viewpoint[2], Q4.p, want_normals ? d_on.p : nullptr, want_normals ? d_oc.p : nullptr,
                          knn_indices ? d_knn.p : nullptr, d_mean_out ? d_mean_out->p : nullptr, next_list, LB.counter.p + 1,
-                         fb_todo.p, LB.counter.p + 2, LB.sel_bin.p, 1, 1, 1, 1.0f);
+                         fb_todo.p, LB.counter.p + 2, LB.sel_bin.p, 1, 1, 1, 1.0f, lsel == 3 ? seed_pos_p : nullptr, lsel == 3 ? seed_flag_p : nullptr, seed_cap);
       unsigned cnts[2] = {0, 0};
       E3D_HIP(hipMemcpyAsync(cnts, LB.counter.p + 1, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, s));
       E3D_HIP(hipStreamSynchronize(s));
@@ -1367,7 +1418,7 @@ static void knn_pass(KnnWorkspace& W, const float* xyz, size_t n, int k, const f
         hipLaunchKernelGGL(kernel_of(sel_list), dim3((unsigned)div_up((size_t)n_fb, kKnnBlock)), dim3(kKnnBlock), lds_list, s, LB.P4.p, n,
                            fb_todo.p, (size_t)n_fb, LB.table.p, G, k, k, viewpoint[0], viewpoint[1], viewpoint[2], Q4.p,
                            want_normals ? d_on.p : nullptr, want_normals ? d_oc.p : nullptr, knn_indices ? d_knn.p : nullptr,
-                           d_mean_out ? d_mean_out->p : nullptr, next_list, LB.counter.p + 1, nullptr, nullptr, nullptr, 1, 1, 1, 1.0f);
+                           d_mean_out ? d_mean_out->p : nullptr, next_list, LB.counter.p + 1, nullptr, nullptr, nullptr, 1, 1, 1, 1.0f, nullptr, nullptr, 0u);
         E3D_HIP(hipMemcpyAsync(cnts, LB.counter.p + 1, sizeof(unsigned), hipMemcpyDeviceToHost, s));
         E3D_HIP(hipStreamSynchronize(s));
         E3D_HIP(hipGetLastError());
@@ -1411,7 +1462,7 @@ static void knn_pass(KnnWorkspace& W, const float* xyz, size_t n, int k, const f
         hipLaunchKernelGGL(kernel_of(sel_list), dim3((unsigned)div_up((size_t)n_next, kKnnBlock)), dim3(kKnnBlock), lds_list, s, L.P4.p, n,
                            next, (size_t)n_next, L.table.p, G, k, k, viewpoint[0], viewpoint[1], viewpoint[2], Q4.p,
                            want_normals ? d_on.p : nullptr, want_normals ? d_oc.p : nullptr, knn_indices ? d_knn.p : nullptr,
-                           d_mean_out ? d_mean_out->p : nullptr, wide_out, L.counter.p + 1, nullptr, nullptr, nullptr, 2, 1, 1, 1.0f);
+                           d_mean_out ? d_mean_out->p : nullptr, wide_out, L.counter.p + 1, nullptr, nullptr, nullptr, 2, 1, 1, 1.0f, seed_pos_p, seed_flag_p, seed_cap);
         E3D_HIP(hipMemcpyAsync(cw, L.counter.p + 1, sizeof(unsigned), hipMemcpyDeviceToHost, s));
         E3D_HIP(hipStreamSynchronize(s));
         E3D_HIP(hipGetLastError());

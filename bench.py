@@ -207,6 +207,17 @@ def run_icp(e3d, R, icp, d, thr, warmup, steps, warmed=False):
     return dt, tot, warm, recs, per_rank
 
 
+def step_breakdown(r):
+    """Where one outer iteration's time goes (HIP events of this rank; the last timed step = the settled regime)."""
+    keys = ("t_transform_ms", "t_nn_certify_ms", "t_nn_bounded_ms", "t_nn_search_ms", "t_nn_sort_ms", "t_nn_scan_ms", "t_nn_compact_ms",
+            "t_lm_kernel_ms", "t_lm_full_kernel_ms")
+    out = {k[2:]: r[k] for k in keys}
+    out["kernels_sum_ms"] = sum(r[k] for k in keys if k != "t_lm_full_kernel_ms")
+    out.update({"wall_ms": r.get("wall_ms"), "full_passes": r["full_passes"], "cost_passes": r["cost_passes"], "multi_cost_passes": r["multi_cost_passes"],
+                "multi_cost_poses": r["multi_cost_poses"], "inner_iterations": r["inner_iterations"], "rows_rewritten": r["corr_rows_rewritten"]})
+    return out
+
+
 def comm_report(R, steps, per_rank):
     """What the first multi-GPU run has to explain itself with: this rank's collectives by HIP events (enqueue -> completion on the
     library's stream, so waiting for the slowest rank is inside), their number and payload, against the kernels they follow."""
@@ -338,6 +349,7 @@ def leg_terrace(e3d, synth, R, args, dev, partial=False):
         "ms_per_step_each": wall,
         "ms_per_step_settling": float(np.mean(wall[:first_steady])) if first_steady > 0 else None,
         "ms_per_step_steady": float(np.mean(wall[first_steady:])), "steady_from_timed_step": first_steady,
+        "last_step_ms": step_breakdown(recs[-1]),
         "breakdown_ms_per_iter": {"transform_bbox": tot[5] / world / K, "nn_search_and_compaction": tot[6] / world / K,
                                   "lm_total": tot[7] / world / K, "lm_pass_kernels": lm_ms / K, "nn_query_kernels": nn_ms / K,
                                   "kernels_accounted": accounted, "host_sync_and_small_kernels": dt / K * 1e3 - accounted,

@@ -777,12 +777,17 @@ __global__ __launch_bounds__(kKnnBlock) void k_knn_normals(const float4* __restr
           // passes over the recomputed f32 distances and the original indices; a longer run of equal keys (lattices, duplicates)
           // falls back to the exact insertion sort in LDS.  Variant 4 keeps the first k + 1 .. of the sorted list only.
           bool settled;
-          if (cap <= 12) settled = knn_sort_words<12>(hp, tid, cnt, pos_of, dist_of, P4);
-          else if (cap <= 20) settled = knn_sort_words<20>(hp, tid, cnt, pos_of, dist_of, P4);
-          else if (cap <= 36) settled = knn_sort_words<36>(hp, tid, cnt, pos_of, dist_of, P4);
-          else if (cap <= 44) settled = knn_sort_words<44>(hp, tid, cnt, pos_of, dist_of, P4);
-          else if (cap <= 52) settled = knn_sort_words<52>(hp, tid, cnt, pos_of, dist_of, P4);
-          else settled = knn_sort_words<64>(hp, tid, cnt, pos_of, dist_of, P4);
+          if constexpr (kSel == 4) {
+            // (variant 4 serves k <= 10 with at most 36 slots: without the larger networks the kernel needs fewer registers)
+            if (cap <= 20) settled = knn_sort_words<20>(hp, tid, cnt, pos_of, dist_of, P4);
+            else if (cap <= 28) settled = knn_sort_words<28>(hp, tid, cnt, pos_of, dist_of, P4);
+            else settled = knn_sort_words<36>(hp, tid, cnt, pos_of, dist_of, P4);
+          } else {
+            if (cap <= 12) settled = knn_sort_words<12>(hp, tid, cnt, pos_of, dist_of, P4);
+            else if (cap <= 20) settled = knn_sort_words<20>(hp, tid, cnt, pos_of, dist_of, P4);
+            else if (cap <= 36) settled = knn_sort_words<36>(hp, tid, cnt, pos_of, dist_of, P4);
+            else settled = knn_sort_words<64>(hp, tid, cnt, pos_of, dist_of, P4);
+          }
           if (!settled) {
             for (int i = 1; i < cnt; ++i) {
               const unsigned kw = HP(i), kk = kw >> 16;
@@ -1280,9 +1285,9 @@ static void knn_pass(KnnWorkspace& W, const float* xyz, size_t n, int k, const f
     const bool single = sel == 3 && single_env != 0 && k <= kSinglePassMaxK && k >= 3;
     // small k: 32-bit [key | tag] entries (variant 4, 36 slots: the occupancy of the two-pass variant at k = 32); beyond that
     // the 64 slots would leave 10 waves per CU, so the list holds 16-bit tags and the keys are computed afterwards (variant 5)
-    const int single_variant = (single_env == 4 || k <= 10) ? 4 : 5;
+    const int single_variant = k <= 10 ? 4 : 5;
     static const int cap1_env = [] { const char* e = getenv("E3D_KNN_CAP1"); return e ? atoi(e) : 0; }();
-    const int cap1 = single_variant == 5 ? kKnnTagSlots : ((cap1_env >= k + 9 && cap1_env <= 64) ? cap1_env : (k <= 10 ? 36 : 64));   // list slots of the single-pass variant (a sorting network's size)
+    const int cap1 = single_variant == 5 ? kKnnTagSlots : ((cap1_env >= k + 9 && cap1_env <= 36) ? cap1_env : 32);   // list slots of the single-pass variant (32: 16 KB of LDS per block, five waves per SIMD with variant 4's 86 registers)
     const int rep_stride = rep_stride_env > 0 ? rep_stride_env : 8;
     const int rep_avg = (rep_avg_env == 1 || rep_avg_env == 2 || rep_avg_env == 4) ? rep_avg_env : 2;
     // the count the threshold aims at: the middle of [k, capacity] (k = 32: 48 of 64), a little below it for small k where the

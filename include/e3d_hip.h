@@ -210,7 +210,10 @@ int e3d_icp_pair_system(const float* src_xyz, const float* src_normals,
 /* setInputCloud + setKSearch(k) + setViewPoint + compute  (call sites
  * src/exe/icp_scan_aligner.cc:323-330, src/exe/normal_estimator.cc:177-194).
  * out_normals n x 3, out_curvature n.  knn_indices (optional, n*k int32) receives each point's
- * neighbour list sorted by (squared distance, index). */
+ * neighbour list sorted by (squared distance, index).  Pointers may be host or device memory: a
+ * cloud in device memory is read in place, and results for device out_normals / out_curvature are
+ * written by the kernels directly (no staging copies; the call still returns after its stream
+ * has finished). */
 int e3d_normals_knn(const float* xyz, size_t n, int k, const float viewpoint[3],
                     float* out_normals, float* out_curvature, int32_t* knn_indices);
 

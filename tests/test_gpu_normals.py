@@ -67,6 +67,52 @@ def test_normals_lattice_ties(e3d, ob):
     assert np.all(gk[:, 0] == np.arange(900))
 
 
+@pytest.mark.parametrize("k", [3, 10, 11, 16, 31, 33])
+def test_normals_single_scan_boundaries(e3d, ob, synth, k):
+    """Where the search changes kernels: k <= 10 one scan with 32-bit list entries, 11 .. 32 one scan with 16-bit
+    entries (keys computed after the collection), beyond that the two passes."""
+    s = synth.make_scene(1, 30000, seed=22)[0]
+    _compare(e3d, ob, s["xyz"].numpy(), k)
+
+
+@pytest.mark.parametrize("k", [16, 24])
+def test_normals_lattice_ties_long_lists(e3d, ob, k):
+    """The integer lattice again with the 16-bit-entry scan: runs of equal keys it cannot order in registers go to the two-pass
+    kernels, which sort them exactly in LDS."""
+    xs, ys = np.meshgrid(np.arange(40), np.arange(40), indexing="ij")
+    P = np.stack([xs.ravel(), ys.ravel(), np.zeros(1600)], 1).astype(np.float32)
+    _compare(e3d, ob, P, k, vp=(0, 0, 1))
+
+
+def test_normals_duplicate_points(e3d, ob):
+    """Every point three times: distance 0 to two others, equal distances in triples -- the (distance, index) order decides."""
+    rng = np.random.RandomState(9)
+    base = (rng.uniform(-1, 1, size=(4000, 3)) * np.array([1, 1, 0.02])).astype(np.float32)
+    P = np.repeat(base, 3, axis=0)[rng.permutation(12000)]
+    for k in (8, 12, 32):
+        _compare(e3d, ob, np.ascontiguousarray(P), k, vp=(0, 0, 3))
+
+
+def test_normals_device_pointers_in_place(e3d, synth):
+    """A cloud in device memory is read in place and device outputs are written by the kernels: same bits as through host buffers."""
+    import ctypes as C
+    import torch
+    from importlib import import_module
+    capi = import_module("dataset-pipeline_amd.capi")
+    s = synth.make_scene(1, 50000, seed=23)[0]
+    P = s["xyz"].numpy()
+    hn, hc = e3d.normals_knn(P, 12, (0.5, 0, 1))
+    d = torch.from_numpy(P).cuda().contiguous()
+    on = torch.full((len(P), 3), float("nan"), device="cuda"); oc = torch.full((len(P),), float("nan"), device="cuda")
+    vp = np.array([0.5, 0, 1], np.float32)
+    torch.cuda.synchronize()
+    r = capi.lib().e3d_normals_knn(C.c_void_p(d.data_ptr()), len(P), 12, C.c_void_p(vp.ctypes.data), C.c_void_p(on.data_ptr()), C.c_void_p(oc.data_ptr()), None)
+    assert r == 0
+    assert np.array_equal(on.cpu().numpy().view(np.uint32), hn.view(np.uint32))
+    assert np.array_equal(oc.cpu().numpy().view(np.uint32), hc.view(np.uint32))
+    assert torch.equal(d.cpu(), torch.from_numpy(P))                # the cloud itself is untouched
+
+
 def test_normals_feed_icp(e3d, ob, synth):
     """End to end like ICPScanAligner: normals from the GPU estimator (k = 32, viewpoint = scan origin) drive the ICP."""
     scans = synth.make_scene(2, 40000, seed=31)

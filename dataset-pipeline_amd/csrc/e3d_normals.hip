@@ -488,7 +488,14 @@ __global__ __launch_bounds__(kKnnBlock) void k_knn_normals(const float4* __restr
   unsigned* hp = reinterpret_cast<unsigned*>(smem) + (size_t)(kOffWords + (kSel == 5 ? 9 : (kSel >= 3 ? 0 : cap))) * kKnnBlock;
   unsigned* rs_lds = reinterpret_cast<unsigned*>(smem);
   const int tid = threadIdx.x;
-  const size_t gi = (size_t)blockIdx.x * blockDim.x + tid;
+  size_t gi = (size_t)blockIdx.x * blockDim.x + tid;
+  if constexpr (kSel < 3) {
+    // The 125-cell pass (reach 2) takes what a level left over: a few ten thousand unrelated queries, one wave per SIMD at
+    // best, and a wave walks the UNION of the cells its lanes need, one memory round trip after the other -- its duration is
+    // that chain's, not the list's.  With every rep_stride-th lane holding a query (the others leave) a wave's union is
+    // smaller and there are rep_stride times as many waves to overlap the round trips.
+    if (rep_stride > 1) { if (gi % (size_t)rep_stride) return; gi /= (size_t)rep_stride; }
+  }
   if (gi >= n_todo) return;
   const unsigned qid = todo ? todo[gi] : (unsigned)gi;              // index into Q4
   const float4 q = Q4[qid];
@@ -1464,10 +1471,11 @@ static void knn_pass(KnnWorkspace& W, const float* xyz, size_t n, int k, const f
         unsigned* wide_out = (next == todo_a.p) ? todo_b.p : todo_a.p;
         unsigned cw[1] = {0};
         E3D_HIP(hipMemsetAsync(L.counter.p + 1, 0, sizeof(unsigned), s));
-        hipLaunchKernelGGL(kernel_of(sel_list), dim3((unsigned)div_up((size_t)n_next, kKnnBlock)), dim3(kKnnBlock), lds_list, s, L.P4.p, n,
+        static const int wide_spread = [] { const char* e = getenv("E3D_KNN_WIDE_SPREAD"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 64 ? v : 4; }();
+        hipLaunchKernelGGL(kernel_of(sel_list), dim3((unsigned)div_up((size_t)n_next * (size_t)wide_spread, kKnnBlock)), dim3(kKnnBlock), lds_list, s, L.P4.p, n,
                            next, (size_t)n_next, L.table.p, G, k, k, viewpoint[0], viewpoint[1], viewpoint[2], Q4.p,
                            want_normals ? d_on.p : nullptr, want_normals ? d_oc.p : nullptr, knn_indices ? d_knn.p : nullptr,
-                           d_mean_out ? d_mean_out->p : nullptr, wide_out, L.counter.p + 1, nullptr, nullptr, nullptr, 2, 1, 1, 1.0f, seed_pos_p, seed_flag_p, seed_cap);
+                           d_mean_out ? d_mean_out->p : nullptr, wide_out, L.counter.p + 1, nullptr, nullptr, nullptr, 2, wide_spread, 1, 1.0f, seed_pos_p, seed_flag_p, seed_cap);
         E3D_HIP(hipMemcpyAsync(cw, L.counter.p + 1, sizeof(unsigned), hipMemcpyDeviceToHost, s));
         E3D_HIP(hipStreamSynchronize(s));
         E3D_HIP(hipGetLastError());

@@ -213,7 +213,8 @@ int e3d_icp_pair_system(const float* src_xyz, const float* src_normals,
  * neighbour list sorted by (squared distance, index).  Pointers may be host or device memory: a
  * cloud in device memory is read in place, and results for device out_normals / out_curvature are
  * written by the kernels directly (no staging copies; the call still returns after its stream
- * has finished). */
+ * has finished).  The library works on its own stream: device inputs must be complete (the
+ * caller's stream work that produces them finished) when the call is made. */
 int e3d_normals_knn(const float* xyz, size_t n, int k, const float viewpoint[3],
                     float* out_normals, float* out_curvature, int32_t* knn_indices);
 

@@ -1,0 +1,67 @@
+"""The library's alternative data flows give the same bits.  Their switches are environment variables read once per process, so
+each setting runs in its own interpreter: the certificate search of several directed pairs per host round trip against pair by
+pair (E3D_ICP_BATCH), resident against compacted correspondence rows (E3D_ICP_RESIDENT), the speculative last LM step
+(E3D_LM_SPECULATE); the kNN estimator's single scan with sampled thresholds against the two-pass kernels (E3D_KNN_SINGLE), with
+and without the lists the 125-cell pass starts from (E3D_KNN_SEED)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+ICP_CODE = r"""
+import importlib, json, sys
+sys.path.insert(0, %r)
+e3d = importlib.import_module("dataset-pipeline_amd")
+synth = importlib.import_module("dataset-pipeline_amd.synth")
+scans = synth.make_scene(4, 60000, seed=33)
+icp = e3d.PointToPlaneICP()
+ids = [icp.add_point_cloud(s["xyz"].numpy(), s["normals"].numpy(), s["T_init"], i == 3) for i, s in enumerate(scans)]
+icp.run(0.1, 0, 6, 1e-9, False)
+pairs = [[int(r[0]), int(r[1]), int(r[2]), int(r[3]), float(r[4]).hex()] for r in icp.pair_records()]
+poses = [[float(v).hex() for v in icp.get_result_global_T_cloud(i).ravel()] for i in ids if i >= 0]
+print("RESULT" + json.dumps({"pairs": pairs, "poses": poses}))
+""" % ROOT
+
+KNN_CODE = r"""
+import importlib, json, sys, hashlib
+import numpy as np
+sys.path.insert(0, %r)
+e3d = importlib.import_module("dataset-pipeline_amd")
+synth = importlib.import_module("dataset-pipeline_amd.synth")
+origin, yaw = synth.SCAN_POSES[0]
+xyz, _, _ = synth.make_scan_angular(300000, origin, yaw, 5)
+out = {}
+for k in (8, 16, 32):
+    n, c, knn = e3d.normals_knn(xyz.numpy(), k, (0, 0, 0), return_knn=True)
+    out[str(k)] = [hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest() for a in (n, c, knn)]
+print("RESULT" + json.dumps(out))
+""" % ROOT
+
+
+def _run(code, env):
+    e = dict(os.environ)
+    e.update(env)
+    p = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=280)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith("RESULT")][-1]
+    return json.loads(line[len("RESULT"):])
+
+
+@pytest.mark.timeout(600)
+def test_icp_data_flows_agree():
+    base = _run(ICP_CODE, {})
+    assert len(base["pairs"]) > 0
+    for env in ({"E3D_ICP_BATCH": "0"}, {"E3D_ICP_RESIDENT": "0"}, {"E3D_LM_SPECULATE": "0"}):
+        assert _run(ICP_CODE, env) == base, env
+
+
+@pytest.mark.timeout(600)
+def test_knn_scan_variants_agree():
+    base = _run(KNN_CODE, {})
+    for env in ({"E3D_KNN_SINGLE": "0"}, {"E3D_KNN_SEED": "0"}, {"E3D_KNN_WIDE_SPREAD": "1"}, {"E3D_KNN_REP_STRIDE": "32", "E3D_KNN_REP_AVG": "1"}):
+        assert _run(KNN_CODE, env) == base, env

@@ -1035,6 +1035,206 @@ __global__ __launch_bounds__(kKnnBlock) void k_knn_normals(const float4* __restr
 #undef HP
 }
 
+// The 125-cell pass, ONE WAVE PER QUERY (dense directory, k <= 64).  What a level leaves over is a few ten thousand unrelated
+// queries; with a lane per query a wave walks the union of its lanes' cells one memory round trip after the other and there is
+// one wave per SIMD at best (0.65 - 0.9 ms for 32 k queries).  Here the 64 lanes of a wave share ONE query:
+//   * lanes 0 .. 24 fetch the directory words of the 25 rows (y, z) of the 5 x 5 x 5 block, a wave scan turns the row lengths into
+//     offsets, and the candidates are dealt to the lanes round-robin (up to kWideSlots each, all loads of a lane in flight);
+//   * the k-th smallest squared distance is found bit by bit (31 counting steps: v_cmp into a lane mask, s_bcnt1 -- the counting is
+//     scalar work), everything up to it (ties included) is compacted into LDS, one entry per lane, and a 64-lane bitonic network
+//     sorts by (distance, original index): the order of every other variant;
+//   * lane i holds neighbour i: index list written as it lies; the mean distance, the two-pass covariance and the eigenvector are
+//     summed by lane 0 in neighbour order from LDS -- the same f32 / f64 sums as k_knn_normals.
+// More candidates than 64 * kWideSlots, or more ties at the k-th distance than lanes: the query goes to fb_todo (the lane-per-query
+// kernel takes it).  Unresolved queries (k-th neighbour beyond the block) go to next_todo as before.
+constexpr int kWideSlots = 16;
+constexpr int kWideWaves = 4;                                          // queries per block
+__global__ __launch_bounds__(64 * kWideWaves) void k_knn_wide_wave(const float4* __restrict__ P4, const unsigned* __restrict__ todo, size_t n_todo,
+                                                                  KnnGrid G, int k, float vpx, float vpy, float vpz, const float4* __restrict__ Q4,
+                                                                  float* __restrict__ out_n, float* __restrict__ out_c, int* __restrict__ out_knn,
+                                                                  float* __restrict__ out_mean, unsigned* __restrict__ next_todo,
+                                                                  unsigned* __restrict__ next_count, unsigned* __restrict__ fb_todo,
+                                                                  unsigned* __restrict__ fb_count) {
+  __shared__ unsigned s_pre[kWideWaves][28], s_start[kWideWaves][28];
+  __shared__ unsigned s_u[kWideWaves][64], s_oi[kWideWaves][64], s_pos[kWideWaves][64];
+  __shared__ float s_x[kWideWaves][64], s_y[kWideWaves][64], s_z[kWideWaves][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const size_t gi = (size_t)blockIdx.x * kWideWaves + (size_t)wv;
+  const bool active = gi < n_todo;                                     // (whole waves; every wave reaches the barriers)
+  const unsigned qid = active ? todo[gi] : 0u;
+  const float4 q = Q4[qid];
+  const unsigned q_oi = __float_as_uint(q.w);
+  const int cx = cell_coord(q.x, G.g.origin[0], G.g.inv_cell);
+  const int cy = cell_coord(q.y, G.g.origin[1], G.g.inv_cell);
+  const int cz = cell_coord(q.z, G.g.origin[2], G.g.inv_cell);
+  // the 25 rows of the block
+  unsigned rs = 0u, re = 0u;
+  if (active && lane < 25) {
+    const int y = cy + lane % 5 - 2, z = cz + lane / 5 - 2;
+    const int x0 = max(cx - 2, 0), x1 = min(cx + 2, (int)G.D[0] - 1);
+    if (y >= 0 && z >= 0 && y < (int)G.D[1] && z < (int)G.D[2] && x0 <= x1) {
+      const size_t row = ((size_t)z * G.D[1] + (size_t)y) * G.D[0];
+      rs = G.S[row + (size_t)x0]; re = G.S[row + (size_t)x1 + 1];
+    }
+  }
+  const unsigned len = re - rs;
+  unsigned incl = len;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+  const unsigned T = __shfl(incl, 63, 64);
+  if (lane < 25) { s_pre[wv][lane] = incl - len; s_start[wv][lane] = rs; }
+  if (lane == 25) s_pre[wv][25] = T;
+  __syncthreads();
+  bool overflow = active && T > 64u * (unsigned)kWideSlots;
+  // candidates, round-robin: candidate i of the block's sequence goes to lane i % 64
+  unsigned u[kWideSlots], oi[kWideSlots], ps[kWideSlots];
+  {
+    unsigned p[kWideSlots];
+#pragma unroll
+    for (int j = 0; j < kWideSlots; ++j) {
+      const unsigned i = (unsigned)lane + 64u * (unsigned)j;
+      p[j] = 0xFFFFFFFFu;
+      if (active && !overflow && i < T) {
+        int lo = 0, hi = 24;                                         // the row with pre[row] <= i < pre[row + 1]
+#pragma unroll
+        for (int it = 0; it < 5; ++it) { const int mid = (lo + hi + 1) >> 1; if (s_pre[wv][mid] <= i) lo = mid; else hi = mid - 1; }
+        p[j] = s_start[wv][lo] + (i - s_pre[wv][lo]);
+      }
+    }
+    float4 c[kWideSlots];
+#pragma unroll
+    for (int j = 0; j < kWideSlots; ++j) c[j] = P4[p[j] != 0xFFFFFFFFu ? p[j] : 0u];
+#pragma unroll
+    for (int j = 0; j < kWideSlots; ++j) {
+      const bool ok = p[j] != 0xFFFFFFFFu;
+      const unsigned bits = __float_as_uint(sqdist_l2(q.x, q.y, q.z, c[j].x, c[j].y, c[j].z));
+      u[j] = ok ? bits : 0xFFFFFFFFu;                                // (a NaN distance sorts behind every number, like the unused slots)
+      oi[j] = __float_as_uint(c[j].w); ps[j] = p[j];
+    }
+  }
+  const unsigned kk = min((unsigned)k, T);
+  // the kk-th smallest distance, bit by bit: after the loop thr = that value
+  unsigned thr = 0u;
+  if (active && !overflow && kk > 0u) {
+#pragma unroll 1
+    for (int b = 30; b >= 0; --b) {
+      const unsigned m = thr | ((1u << b) - 1u);
+      unsigned c_le = 0u;
+#pragma unroll
+      for (int j = 0; j < kWideSlots; ++j) c_le += (unsigned)__popcll(__ballot(u[j] <= m));
+      if (c_le < kk) thr |= 1u << b;
+    }
+  }
+  unsigned n_sel = 0u;                                                 // everything up to thr, ties included
+#pragma unroll
+  for (int j = 0; j < kWideSlots; ++j) n_sel += (unsigned)__popcll(__ballot(active && !overflow && u[j] <= thr && u[j] != 0xFFFFFFFFu));
+  if (active && !overflow && n_sel > 64u) overflow = true;            // more ties at the k-th distance than lanes
+  if (overflow) {
+    if (lane == 0) { const unsigned slot = atomicAdd(fb_count, 1u); fb_todo[slot] = qid; }
+  }
+  const bool work = active && !overflow;
+  // compaction: lane l's selected slots go to [offset of l, ...) in (lane, slot) order -- any order, the network sorts
+  {
+    unsigned mine = 0u;
+#pragma unroll
+    for (int j = 0; j < kWideSlots; ++j) mine += (work && u[j] <= thr && u[j] != 0xFFFFFFFFu) ? 1u : 0u;
+    unsigned inc2 = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up(inc2, o, 64); if (lane >= o) inc2 += t; }
+    unsigned at = inc2 - mine;
+    s_u[wv][lane] = 0xFFFFFFFFu; s_oi[wv][lane] = 0xFFFFFFFFu; s_pos[wv][lane] = 0u;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kWideSlots; ++j)
+      if (work && u[j] <= thr && u[j] != 0xFFFFFFFFu) { s_u[wv][at] = u[j]; s_oi[wv][at] = oi[j]; s_pos[wv][at] = ps[j]; ++at; }
+    __syncthreads();
+  }
+  // one entry per lane, bitonic network on (distance bits, original index)
+  unsigned eu = s_u[wv][lane], eo = s_oi[wv][lane], ep = s_pos[wv][lane];
+#pragma unroll
+  for (int size = 2; size <= 64; size <<= 1)
+#pragma unroll
+    for (int stride = size >> 1; stride >= 1; stride >>= 1) {
+      const unsigned pu = __shfl_xor(eu, stride, 64), po = __shfl_xor(eo, stride, 64), pp = __shfl_xor(ep, stride, 64);
+      const bool up = (lane & size) == 0;                              // this block of `size` lanes sorts ascending
+      const bool lower = (lane & stride) == 0;                         // this lane keeps the smaller of the pair when ascending
+      const bool mine_less = eu < pu || (eu == pu && eo < po);
+      const bool keep_mine = (lower == up) ? mine_less : !mine_less;
+      if (!keep_mine) { eu = pu; eo = po; ep = pp; }
+    }
+  const int cnt = (int)kk;
+  // resolved?  (as k_knn_normals with reach 2)
+  bool resolved = true;
+  if (work) {
+    float safe = 3.402823466e+38f;
+    const int c3[3] = {cx, cy, cz};
+    const float qq[3] = {q.x, q.y, q.z};
+    bool covers_all = true;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float lo = G.g.origin[a] + (float)(c3[a] - 2) * G.cell;
+      const float hi = G.g.origin[a] + (float)(c3[a] + 3) * G.cell;
+      if (lo > G.dmin[a]) { safe = fminf(safe, qq[a] - lo); covers_all = false; }
+      if (hi <= G.dmax[a]) { safe = fminf(safe, hi - qq[a]); covers_all = false; }
+    }
+    if (!covers_all) {
+      safe -= G.slack;
+      const float kth = __uint_as_float(__shfl(eu, max(cnt - 1, 0), 64));
+      resolved = (cnt >= k) && safe > 0.f && kth < safe * safe * 0.99999f;
+    }
+    if (!resolved && lane == 0) { const unsigned slot = atomicAdd(next_count, 1u); next_todo[slot] = qid; }
+  }
+  const bool emit = work && resolved;
+  if (emit && out_knn && lane < k) out_knn[(size_t)q_oi * k + lane] = (lane < cnt) ? (int)eo : -1;
+  // neighbour i's coordinates and distance to LDS; lane 0 sums in neighbour order
+  {
+    const float4 c = P4[(emit && lane < cnt) ? ep : 0u];
+    s_x[wv][lane] = c.x; s_y[wv][lane] = c.y; s_z[wv][lane] = c.z;
+    s_u[wv][lane] = eu;
+  }
+  __syncthreads();
+  if (!emit || lane != 0) return;
+  if (out_mean) {
+    double dist_sum = 0.0;
+    for (int i = 1; i < cnt; ++i) dist_sum += (double)sqrtf(__uint_as_float(s_u[wv][i]));
+    out_mean[q_oi] = (float)(dist_sum / (double)(k - 1));
+  }
+  if (!out_n) return;
+  float nx, ny, nz, curv;
+  const float qnan = __uint_as_float(0x7fc00000u);
+  if (cnt < 3) {
+    nx = ny = nz = curv = qnan;
+  } else {
+    float a6 = 0.f, a7 = 0.f, a8 = 0.f;
+    for (int i = 0; i < cnt; ++i) { a6 += s_x[wv][i]; a7 += s_y[wv][i]; a8 += s_z[wv][i]; }
+    const float fc = (float)cnt;
+    a6 = a6 / fc; a7 = a7 / fc; a8 = a8 / fc;
+    float a0 = 0.f / fc, a1 = 0.f / fc, a2 = 0.f / fc, a3 = 0.f / fc, a4 = 0.f / fc, a5 = 0.f / fc;
+    for (int i = 0; i < cnt; ++i) {
+      const float px = s_x[wv][i], py = s_y[wv][i], pz = s_z[wv][i];
+      a0 += (px - a6) * (px - a6);
+      a1 += (px - a6) * (py - a7);
+      a2 += (px - a6) * (pz - a8);
+      a3 += (py - a7) * (py - a7);
+      a4 += (py - a7) * (pz - a8);
+      a5 += (pz - a8) * (pz - a8);
+    }
+    float cov[9];
+    cov[0] = a0 / fc; cov[1] = a1 / fc; cov[2] = a2 / fc; cov[4] = a3 / fc; cov[5] = a4 / fc; cov[8] = a5 / fc;
+    cov[3] = cov[1]; cov[6] = cov[2]; cov[7] = cov[5];
+    float ev, v[3];
+    eigen33_smallest(cov, ev, v);
+    nx = v[0]; ny = v[1]; nz = v[2];
+    const float eig_sum = cov[0] + cov[4] + cov[8];
+    curv = (eig_sum != 0.f) ? fabsf(ev / eig_sum) : 0.f;
+    const float vx = vpx - q.x, vy = vpy - q.y, vz = vpz - q.z;
+    const float cos_theta = (vx * nx + vy * ny + vz * nz);
+    if (cos_theta < 0) { nx *= -1; ny *= -1; nz *= -1; }
+  }
+  out_n[3 * (size_t)q_oi] = nx; out_n[3 * (size_t)q_oi + 1] = ny; out_n[3 * (size_t)q_oi + 2] = nz;
+  out_c[q_oi] = curv;
+}
+
 // Radius-search variant (pcl::Feature::searchForNeighbors with setRadiusSearch, two_pass_normal_3d_omp.hpp:66): every
 // point within the radius (FLANN: squared distance strictly below (float)((double)r * r)) takes part; one thread per
 // point walks its 27 grid cells twice -- centroid, then centred products -- so nothing is stored per neighbour and the
@@ -1472,10 +1672,30 @@ static void knn_pass(KnnWorkspace& W, const float* xyz, size_t n, int k, const f
         unsigned cw[1] = {0};
         E3D_HIP(hipMemsetAsync(L.counter.p + 1, 0, sizeof(unsigned), s));
         static const int wide_spread = [] { const char* e = getenv("E3D_KNN_WIDE_SPREAD"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 64 ? v : 4; }();
-        hipLaunchKernelGGL(kernel_of(sel_list), dim3((unsigned)div_up((size_t)n_next * (size_t)wide_spread, kKnnBlock)), dim3(kKnnBlock), lds_list, s, L.P4.p, n,
-                           next, (size_t)n_next, L.table.p, G, k, k, viewpoint[0], viewpoint[1], viewpoint[2], Q4.p,
-                           want_normals ? d_on.p : nullptr, want_normals ? d_oc.p : nullptr, knn_indices ? d_knn.p : nullptr,
-                           d_mean_out ? d_mean_out->p : nullptr, wide_out, L.counter.p + 1, nullptr, nullptr, nullptr, 2, wide_spread, 1, 1.0f, seed_pos_p, seed_flag_p, seed_cap);
+        static const bool wide_wave = [] { const char* e = getenv("E3D_KNN_WIDE_WAVE"); return e ? atoi(e) != 0 : true; }();
+        auto lane_per_query = [&](const unsigned* list, size_t n_list, bool seeded) {
+          hipLaunchKernelGGL(kernel_of(sel_list), dim3((unsigned)div_up(n_list * (size_t)wide_spread, kKnnBlock)), dim3(kKnnBlock), lds_list, s, L.P4.p, n,
+                             list, n_list, L.table.p, G, k, k, viewpoint[0], viewpoint[1], viewpoint[2], Q4.p,
+                             want_normals ? d_on.p : nullptr, want_normals ? d_oc.p : nullptr, knn_indices ? d_knn.p : nullptr,
+                             d_mean_out ? d_mean_out->p : nullptr, wide_out, L.counter.p + 1, nullptr, nullptr, nullptr, 2, wide_spread, 1, 1.0f,
+                             seeded ? seed_pos_p : nullptr, seeded ? seed_flag_p : nullptr, seed_cap);
+        };
+        if (wide_wave && G.S && sel == 3 && k <= 64) {
+          // one wave per query (k_knn_wide_wave); what it hands back (more candidates than its lanes hold, long tie runs) takes the
+          // lane-per-query kernel
+          E3D_HIP(hipMemsetAsync(L.counter.p + 2, 0, sizeof(unsigned), s));
+          hipLaunchKernelGGL(k_knn_wide_wave, dim3((unsigned)div_up((size_t)n_next, (size_t)kWideWaves)), dim3(64 * kWideWaves), 0, s, L.P4.p, next, (size_t)n_next, G, k,
+                             viewpoint[0], viewpoint[1], viewpoint[2], Q4.p, want_normals ? d_on.p : nullptr, want_normals ? d_oc.p : nullptr,
+                             knn_indices ? d_knn.p : nullptr, d_mean_out ? d_mean_out->p : nullptr, wide_out, L.counter.p + 1, fb_todo.p, L.counter.p + 2);
+          unsigned n_back = 0;
+          E3D_HIP(hipMemcpyAsync(&n_back, L.counter.p + 2, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+          E3D_HIP(hipStreamSynchronize(s));
+          E3D_HIP(hipGetLastError());
+          if (getenv("E3D_KNN_STATS")) fprintf(stderr, "[knn] level %d wave-per-query pass: %u queries, %u handed to the lane-per-query kernel\n", level, n_next, n_back);
+          if (n_back > 0) lane_per_query(fb_todo.p, (size_t)n_back, false);
+        } else {
+          lane_per_query(next, (size_t)n_next, true);
+        }
         E3D_HIP(hipMemcpyAsync(cw, L.counter.p + 1, sizeof(unsigned), hipMemcpyDeviceToHost, s));
         E3D_HIP(hipStreamSynchronize(s));
         E3D_HIP(hipGetLastError());

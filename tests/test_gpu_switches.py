@@ -2,7 +2,7 @@
 each setting runs in its own interpreter: the certificate search of several directed pairs per host round trip against pair by
 pair (E3D_ICP_BATCH), resident against compacted correspondence rows (E3D_ICP_RESIDENT), the speculative last LM step
 (E3D_LM_SPECULATE); the kNN estimator's single scan with sampled thresholds against the two-pass kernels (E3D_KNN_SINGLE), with
-and without the lists the 125-cell pass starts from (E3D_KNN_SEED)."""
+and without the lists the 125-cell pass starts from (E3D_KNN_SEED), the wave-per-query form of that pass (E3D_KNN_WIDE_WAVE)."""
 import json
 import os
 import subprocess
@@ -63,5 +63,6 @@ def test_icp_data_flows_agree():
 @pytest.mark.timeout(600)
 def test_knn_scan_variants_agree():
     base = _run(KNN_CODE, {})
-    for env in ({"E3D_KNN_SINGLE": "0"}, {"E3D_KNN_SEED": "0"}, {"E3D_KNN_WIDE_SPREAD": "1"}, {"E3D_KNN_REP_STRIDE": "32", "E3D_KNN_REP_AVG": "1"}):
+    for env in ({"E3D_KNN_SINGLE": "0"}, {"E3D_KNN_SEED": "0"}, {"E3D_KNN_WIDE_SPREAD": "1"}, {"E3D_KNN_WIDE_WAVE": "0"},
+                {"E3D_KNN_REP_STRIDE": "32", "E3D_KNN_REP_AVG": "1"}):
         assert _run(KNN_CODE, env) == base, env

@@ -402,11 +402,17 @@ __device__ __forceinline__ bool knn_sort_words(unsigned* __restrict__ hp, int ti
 // Returns false if equal keys could not be ordered exactly (the caller hands the query to the two-pass variant).
 constexpr int kKnnTagSlots = 64;
 template <class DistOf>
-__device__ __forceinline__ bool knn_sort_tags(unsigned* __restrict__ list, const unsigned* __restrict__ rs, int tid, int cnt, int k,
+__device__ __forceinline__ bool knn_sort_tags(unsigned* __restrict__ list, const unsigned* __restrict__ rs, unsigned rs_centre, int tid, int cnt, int k,
                                               const knn_f2 qxy, float qz, float key_scale, DistOf dist_of, const float4* __restrict__ P4) {
   constexpr int N = kKnnTagSlots;
   unsigned a[N];
-  auto pos_of = [&](unsigned w) { return rs[(size_t)((w >> 12) & 15u) * kKnnBlock + tid] + (w & 0xFFFu); };
+  // (eight of the nine row starts in LDS, the centre row's in a register: 8 + N / 2 = 40 dwords per lane are 20 KB per block, eight
+  // blocks -- four waves per SIMD -- where nine would leave seven)
+  auto pos_of = [&](unsigned w) {
+    const unsigned row = (w >> 12) & 15u;
+    const unsigned from_lds = rs[(size_t)(row - (row > 4u ? 1u : 0u)) * kKnnBlock + tid];
+    return (row == 4u ? rs_centre : from_lds) + (w & 0xFFFu);
+  };
 #pragma unroll
   for (int i0 = 0; i0 < N; i0 += 8) {
     if (i0 < cnt) {
@@ -484,8 +490,8 @@ __global__ __launch_bounds__(kKnnBlock) void k_knn_normals(const float4* __restr
   // variants 0..2: [cap = k distances][cap positions]; variant 3: [cap words: key | row | offset, later the positions]
   constexpr int kOffWords = 0;
   float* hd = reinterpret_cast<float*>(smem) + (size_t)kOffWords * kKnnBlock;
-  // variant 5: [9 row starts][cap / 2 dwords: two 16-bit tags each, later the k positions]
-  unsigned* hp = reinterpret_cast<unsigned*>(smem) + (size_t)(kOffWords + (kSel == 5 ? 9 : (kSel >= 3 ? 0 : cap))) * kKnnBlock;
+  // variant 5: [8 row starts (the centre row's stays in a register)][cap / 2 dwords: two 16-bit tags each, later the k positions]
+  unsigned* hp = reinterpret_cast<unsigned*>(smem) + (size_t)(kOffWords + (kSel == 5 ? 8 : (kSel >= 3 ? 0 : cap))) * kKnnBlock;
   unsigned* rs_lds = reinterpret_cast<unsigned*>(smem);
   const int tid = threadIdx.x;
   size_t gi = (size_t)blockIdx.x * blockDim.x + tid;
@@ -773,8 +779,8 @@ __global__ __launch_bounds__(kKnnBlock) void k_knn_normals(const float4* __restr
           auto dist_of = [&](unsigned m) { const float4 c = P4[m]; return sqdist_l2(q.x, q.y, q.z, c.x, c.y, c.z); };
           if constexpr (kSel == 5) {
 #pragma unroll
-            for (int r = 0; r < 9; ++r) rs_lds[(size_t)r * kKnnBlock + tid] = rstart[r];
-            const bool settled = knn_sort_tags(hp, rs_lds, tid, cnt, k, qxy, q.z, key_scale, dist_of, P4);
+            for (int r = 0; r < 9; ++r) if (r != 4) rs_lds[(size_t)(r - (r > 4 ? 1 : 0)) * kKnnBlock + tid] = rstart[r];
+            const bool settled = knn_sort_tags(hp, rs_lds, rstart[4], tid, cnt, k, qxy, q.z, key_scale, dist_of, P4);
             KP_MARK(3);
             if (!settled) fallback = true;              // (a long run of equal keys: the two-pass variant has room to sort it in LDS)
             cnt = k;
@@ -1500,7 +1506,7 @@ static void knn_pass(KnnWorkspace& W, const float* xyz, size_t n, int k, const f
     // the count the threshold aims at: the middle of [k, capacity] (k = 32: 48 of 64), a little below it for small k where the
     // relative Poisson noise of the count is larger on the low side
     const int rep_target = rep_target_env > 0 ? (int)rep_target_env : std::min((k + cap1) / 2, 2 * k + 6);
-    const size_t lds1 = single_variant == 5 ? (size_t)(9 + cap1 / 2) * kKnnBlock * 4 : (size_t)cap1 * kKnnBlock * 4;
+    const size_t lds1 = single_variant == 5 ? (size_t)(8 + cap1 / 2) * kKnnBlock * 4 : (size_t)cap1 * kKnnBlock * 4;
     if (single) E3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel_of(single_variant)), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
     E3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel_of(sel)), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     E3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel_of(sel_list)), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_list));

@@ -22,7 +22,12 @@ on the library's stream); torch.distributed (gloo) only carries the 128-byte com
 time.  Headline at N > 1 = the same 2-scan job, weak scaling (N x the points on N x the floor area, every rank 1/N of each pair's
 queries) -- at N = 1 it is the BENCH workload.
 
-Further legs in the same JSON line:
+Output: the LAST line of stdout is one compact JSON object (< 4 KB: headline keys, `config`, `dtype`, the dominant kernel's `roofline`,
+`cpu_baseline`, `whole_run`, one summary per secondary leg under `legs`); the full result -- every kernel group, per-step arrays, the
+prose -- goes to bench_detail.json next to this file (and to gpurun_out/ when that directory exists).  The timed loop is the tool's:
+it ends with the iteration whose Run() reports convergence (`converged_at_iteration`; `steps` = the steps actually timed).
+
+Further legs (detail file; summaries in the line):
   partial_overlap    (N = 1) the headline job on the partial-overlap room (30 - 60 % of the points find a partner): same
                      per-kernel table, so the no-partner branch of FindCorrespondencesFast is part of a measured steady state
   allpairs           BASELINE.json north_star's scaling target / configs[2] shape: 16 scans all-pairs (240 directed pairs, 90-unknown
@@ -181,30 +186,73 @@ class Ranks:
             self.dist.destroy_process_group()
 
 
-def run_icp(e3d, R, icp, d, thr, warmup, steps, warmed=False):
+def run_icp(e3d, R, icp, d, thr, warmup, steps, warmed=False, first_warm_converged=None):
     """W untimed + K timed outer iterations, barrier + synchronize on both sides, time = max over ranks.
-    warmed: the caller has already run the W warm-up iterations on this handle."""
+    warmed: the caller has already run the W warm-up iterations on this handle.
+    The loop is the tool's (src/exe/icp_scan_aligner.cc:342-370): an iteration whose Run() reports convergence is the last one --
+    the timed region ends with it (`steps_run` < K then; `converged_at` = that iteration).  Every rank sees the same poses, hence the
+    same return value."""
+    converged_at = first_warm_converged
     if not warmed:
         for it in range(warmup):
-            icp.run(d, it, 1, thr, False)
+            if icp.run(d, it, 1, thr, False):
+                converged_at = it
+                break
     warm = icp.iter_records()
     icp.clear_records()
     R.barrier()
     t0 = time.perf_counter()
     each = []
-    for it in range(warmup, warmup + steps):
-        t1 = time.perf_counter()
-        icp.run(d, it, 1, thr, False)                      # returns after the library has synchronised its stream (poses are host data)
-        each.append((time.perf_counter() - t1) * 1e3)
+    if converged_at is None:
+        for it in range(warmup, warmup + steps):
+            t1 = time.perf_counter()
+            conv = icp.run(d, it, 1, thr, False)                  # returns after the library has synchronised its stream (poses are host data)
+            each.append((time.perf_counter() - t1) * 1e3)
+            if conv:
+                converged_at = it
+                break
     R.barrier()
     dt = float(R.reduce([time.perf_counter() - t0], "max")[0])
     recs = icp.iter_records()
     for r, ms in zip(recs, each):
         r["wall_ms"] = ms
     tot = R.reduce(sum_records(recs))
-    per_rank = {"nn_kernel_ms_per_iter": sum(r["t_nn_query_ms"] for r in recs) / steps, "lm_kernel_ms_per_iter": sum(r["t_lm_kernel_ms"] for r in recs) / steps,
-                "nn_ms_per_iter": sum(r["t_nn_ms"] for r in recs) / steps, "lm_ms_per_iter": sum(r["t_lm_ms"] for r in recs) / steps}
-    return dt, tot, warm, recs, per_rank
+    n = max(len(each), 1)
+    per_rank = {"nn_kernel_ms_per_iter": sum(r["t_nn_query_ms"] for r in recs) / n, "lm_kernel_ms_per_iter": sum(r["t_lm_kernel_ms"] for r in recs) / n,
+                "nn_ms_per_iter": sum(r["t_nn_ms"] for r in recs) / n, "lm_ms_per_iter": sum(r["t_lm_ms"] for r in recs) / n}
+    return dt, tot, warm, recs, per_rank, len(each), converged_at
+
+
+def whole_run(e3d, scans, d, thr, device, max_iterations=100):
+    """What the tool does with two scans already in memory (src/exe/icp_scan_aligner.cc:280-372 without the file I/O): AddPointCloud
+    for every scan, then Run(d, it, 1, thr) from iteration 0 until it reports convergence or --max_iterations (100, BASELINE.json
+    configs[1]) -- grid builds, first-touch transforms and the expensive first iterations included.  A handle of its own."""
+    import torch
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    icp = e3d.PointToPlaneICP(device=device)
+    for s in scans:
+        icp.add_point_cloud(s["xyz"], s["normals"], s["T_init"], False)
+    t_add = time.perf_counter() - t0
+    each, conv = [], None
+    for it in range(max_iterations):
+        t1 = time.perf_counter()
+        c = icp.run(d, it, 1, thr, False)
+        each.append((time.perf_counter() - t1) * 1e3)
+        if c:
+            conv = it
+            break
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    recs = icp.iter_records()
+    corr = sum(r["correspondences"] for r in recs)
+    out = {"wall_s": wall, "add_cloud_s": t_add, "iterations_run": len(each), "converged_at_iteration": conv, "max_iterations": max_iterations,
+           "ms_per_iteration_mean": float(np.mean(each)), "ms_per_iteration_each": each, "correspondences_per_s": corr / wall,
+           "first_iteration_ms": each[0], "note": "add_cloud -> convergence on a fresh handle: grid builds, first-touch transforms and iterations 0.. included; "
+                                                  "inputs resident in HBM (the binary's PLY read / write: tools/bench_tool_icp.py, DESIGN.md section 5)"}
+    del icp
+    torch.cuda.empty_cache()
+    return out
 
 
 def step_breakdown(r):
@@ -299,17 +347,23 @@ def leg_terrace(e3d, synth, R, args, dev, partial=False):
     import torch
     world = R.world
     n_points = args.points if args.points > 0 else 50_000_000 * (1 if partial else world)
-    d, thr = float(args.distance), 1e-10     # README.md:101 recommended flags; never converges within the bench's few iterations
+    d, thr = float(args.distance), 1e-10     # README.md:101 recommended flags (--convergence_threshold 1e-10)
     room_scale = float(np.sqrt(n_points / 50_000_000.0)) if (world > 1 and args.points == 0 and not partial) else 1.0
-    scans = synth.make_scene(2, n_points, seed=1234, sigma=0.002, device=dev, room_scale=room_scale, partial=partial)
+    scans = synth.make_scene(2, n_points, seed=1234, sigma=0.002, device=dev, room_scale=room_scale, partial=partial, perturb=args.perturb)
     torch.cuda.synchronize()
+    whole = None
+    if world == 1 and not partial and not args.no_whole_run:
+        whole = whole_run(e3d, scans, d, thr, R.local_rank)
     icp = e3d.PointToPlaneICP(device=R.local_rank)
     for s in scans:
         icp.add_point_cloud(s["xyz"], s["normals"], s["T_init"], False)
     if R.comm:
         icp.set_comm(R.comm)
+    warm_conv = None
     for it in range(args.warmup):                            # untimed warm-up steps (the timed region follows below)
-        icp.run(d, it, 1, thr, False)
+        if icp.run(d, it, 1, thr, False):
+            warm_conv = it
+            break
     base = None
     if R.rank == 0 and world == 1 and not args.no_cpu_baseline and not partial:
         # slab width chosen for ~4 M points per scan at this density (floor + two walls = 16 m^2 per metre of x); started from the
@@ -321,8 +375,9 @@ def leg_terrace(e3d, synth, R, args, dev, partial=False):
     torch.cuda.empty_cache()
     if R.comm:
         R.comm.stats(reset=True)
-    dt, tot, warm, recs, per_rank = run_icp(e3d, R, icp, d, thr, args.warmup, args.steps, warmed=True)
-    K = args.steps
+    dt, tot, warm, recs, per_rank, K, converged_at = run_icp(e3d, R, icp, d, thr, args.warmup, args.steps, warmed=True, first_warm_converged=warm_conv)
+    if K == 0:
+        raise SystemExit("bench.py: the run converged inside the %d warm-up iterations (iteration %d): nothing to time" % (args.warmup, warm_conv))
     kernels, accounted, m = icp_kernel_table(tot, world, K, 2, n_points)      # (every rank transforms the whole clouds)
     corr, queries, lm_ms, nn_ms, passes = m["corr"], m["queries"], m["lm_ms"], m["nn_ms"], m["passes"]
     rows_rewritten, rows_walked = m["rows_rewritten"], m["rows_walked"]
@@ -337,11 +392,12 @@ def leg_terrace(e3d, synth, R, args, dev, partial=False):
     out = {
         "metric": "ICP correspondences/sec", "value": corr / dt, "unit": "correspondences/s",
         "n_gpus": R.comm.world_size if R.comm else 1, "steps": K, "warmup": args.warmup, "ms_per_step": dt / K * 1e3,
+        "steps_requested": args.steps, "converged_at_iteration": converged_at,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 (f64 accumulation)",
         "data": "synthetic (no terrace scans in this image: seeded room scans of the configs[1] shape, generated in HBM)",
         "config": {"workload": "ICPScanAligner 2 scans (BASELINE.json configs[1]), -d %g, one outer iteration per step%s" %
                                (d, "; PARTIAL-OVERLAP room (partition wall, occlusion, 6.5 m range): %.0f %% of the queries find a partner" % (100.0 * corr / max(queries, 1)) if partial else ""),
-                   "points_per_scan": n_points, "scans": 2, "directed_pairs": 2, "room_scale": room_scale,
+                   "points_per_scan": n_points, "scans": 2, "directed_pairs": 2, "room_scale": room_scale, "initial_misalignment_scale": args.perturb,
                    "matched_fraction": corr / max(queries, 1),
                    "parallelism": "dp%d over source-point slices, RCCL all-reduce of the 6x6 normal-equation blocks" % world},
         "ms_per_iter": dt / K * 1e3, "nn_queries_per_s": queries / dt, "lm_passes_per_iter": passes / K,
@@ -367,6 +423,8 @@ def leg_terrace(e3d, synth, R, args, dev, partial=False):
         out["per_rank_rank0"] = per_rank
     if R.comm:
         out["comm"] = comm_report(R, K, per_rank)
+    if whole is not None:
+        out["whole_run"] = whole
     if base is not None:
         out["cpu_baseline"] = base
         out["speedup_vs_cpu_iteration_rate"] = (base["ms_per_iter"] / base["correspondences"]) / ((dt / K * 1e3) / (corr / K))
@@ -384,8 +442,6 @@ def leg_allpairs(e3d, synth, R, args, dev):
     icp = e3d.PointToPlaneICP(device=R.local_rank)
     for s in scans:
         icp.add_point_cloud(s["xyz"], s["normals"], s["T_init"], False)
-    del scans
-    torch.cuda.empty_cache()
     if R.comm:
         icp.set_comm(R.comm)
     # two untimed iterations (grids, first full searches), then ten timed ones: the first of them still search most queries
@@ -394,7 +450,10 @@ def leg_allpairs(e3d, synth, R, args, dev):
     warmup, steps = 2, max(1, min(args.steps if args.steps != 20 else 10, 10))
     if R.comm:
         R.comm.stats(reset=True)
-    dt, tot, warm, recs, per_rank = run_icp(e3d, R, icp, d, thr, warmup, steps)
+    dt, tot, warm, recs, per_rank, steps_run, converged_at = run_icp(e3d, R, icp, d, thr, warmup, steps)
+    if steps_run == 0:
+        raise SystemExit("bench.py: the all-pairs job converged inside its warm-up iterations")
+    steps_requested, steps = steps, steps_run
     free, total = torch.cuda.mem_get_info(R.local_rank)
     world = R.world
     kernels, accounted, m = icp_kernel_table(tot, world, steps, S * (S - 1), n * (S - 1), lm_kernel_name="k_lm_pass<2> / <3> (two-sided pairs; <1> for the pairs of cloud 0)")
@@ -404,6 +463,7 @@ def leg_allpairs(e3d, synth, R, args, dev):
     dom = max(("k_lm_pass", "k_lm_cost_multi", "k_nn_certify", "k_nn_bounded", "k_nn_rows", "k_corr_update", "query_keys_and_sort"), key=lambda k: kernels[k]["summed_ms_per_iter"] or 0.0)
     out = {"metric": "ICP correspondences/sec", "value": tot[0] / dt, "unit": "correspondences/s", "scaling": "strong",
            "n_gpus": R.comm.world_size if R.comm else 1, "steps": steps, "warmup": warmup, "ms_per_iter": dt / steps * 1e3,
+           "steps_requested": steps_requested, "converged_at_iteration": converged_at,
            "ms_per_iter_each": wall,
            "ms_per_iter_settling": float(np.mean(wall[:first_steady])) if first_steady > 0 else None,
            "ms_per_iter_steady": float(np.mean(wall[first_steady:])), "steady_from_timed_iteration": first_steady,
@@ -421,8 +481,40 @@ def leg_allpairs(e3d, synth, R, args, dev):
                         "kernels": kernels, "kernels_accounted_ms_per_iter": accounted}}
     if R.comm:
         out["comm"] = comm_report(R, steps, per_rank)
+    # launches of the NN phase per iteration (search, row update, totals; the record counts launches of the timed kernels)
+    out["nn_launches_per_iter"] = {"certify": tot[11] / R.world / steps, "bounded": tot[14] / R.world / steps, "rows": tot[17] / R.world / steps}
     del icp
     torch.cuda.empty_cache()
+    if R.world == 1 and not args.no_scale_model:
+        # What one rank of an 8-GPU run does, MEASURED on this GPU: the same clouds, this handle as rank 0 of a world of 8 (its eighth of
+        # every directed pair's queries) with a no-op all-reduce.  Counts and sums are an eighth of the job's (the poses it reaches differ
+        # slightly from the real job's: the damping is additive), the launches, host round trips and per-pair fixed costs are those
+        # of a real rank -- everything but the collectives.  t1 / t8 bounds the 8-GPU speed-up from above; (8 t8 - t1) / 7 is the part
+        # of an iteration that does not divide by the number of GPUs.
+        W8 = args.scale_model_world
+        icp8 = e3d.PointToPlaneICP(device=R.local_rank)
+        for s in scans:
+            icp8.add_point_cloud(s["xyz"], s["normals"], s["T_init"], False)
+        icp8.set_shard(0, W8, lambda arr: None)
+        for it in range(warmup):
+            icp8.run(d, it, 1, thr, False)
+        torch.cuda.synchronize()
+        each8 = []
+        for it in range(warmup, warmup + steps):
+            t1 = time.perf_counter()
+            icp8.run(d, it, 1, thr, False)
+            each8.append((time.perf_counter() - t1) * 1e3)
+        t1_ms, t8_ms = float(np.mean(wall)), float(np.mean(each8))
+        s1, s8 = float(np.mean(wall[first_steady:])), float(np.mean(each8[first_steady:]))
+        out["scale_model"] = {"world": W8, "ms_per_iter_n1": t1_ms, "ms_per_iter_as_rank0_of_world": t8_ms, "ms_per_iter_each_as_rank0": each8,
+                              "modelled_speedup": t1_ms / t8_ms, "non_dividing_ms_per_iter": (W8 * t8_ms - t1_ms) / (W8 - 1),
+                              "steady": {"ms_per_iter_n1": s1, "ms_per_iter_as_rank0_of_world": s8, "modelled_speedup": s1 / s8,
+                                         "non_dividing_ms_per_iter": (W8 * s8 - s1) / (W8 - 1)},
+                              "note": "rank 0 of a world of %d with a no-op all-reduce, measured on this GPU: an upper bound of the speed-up "
+                                      "(no collective time, no skew between ranks)" % W8}
+        del icp8
+        torch.cuda.empty_cache()
+    del scans
     return out
 
 
@@ -506,7 +598,7 @@ def leg_image_registrator(e3d, synth, args, dev):
                      "obs.eval_all_points": ["k_obs_eval<2>"], "obs.eval_listed_points": ["k_obs_eval<2>"], "obs.compact": ["k_obs_compact"],
                      "obs.neighbour_flags": ["k_obs_flags", "k_obs_mark"], "intensity.sample": ["k_reg_intensity"], "cost": ["k_reg_cost<5>"],
                      "color.accumulate": ["k_color_accumulate"], "color.finish": ["k_color_finish"],
-                     "accumulate.pass1": ["k_reg_pass1<2, false>"], "accumulate.pass2": ["k_reg_pass2_tile32<5, 18>"]}
+                     "accumulate.pass1": ["k_reg_pass1<2, false>"], "accumulate.pass2": ["k_reg_pass2_mfma<5, 18, 0>"]}
     groups = {}
     for name, (ms, calls, units) in sorted(P.kernel_groups.items()):
         bpu, what, bound = group_bytes.get(name, (None, "", ""))
@@ -521,12 +613,14 @@ def leg_image_registrator(e3d, synth, args, dev):
                         "traffic": traffic, "traffic_over_algorithmic": (traffic / by) if (traffic and by) else None}
     free, total = torch.cuda.mem_get_info(0)
     tr1, src1 = load_traffic("k_reg_pass1<2, false>")
-    tr2, src2 = load_traffic("k_reg_pass2_tile32<5, 18>")
+    p2_variant = os.environ.get("E3D_REG_PASS2", "")
+    p2_f32 = p2_variant in ("tile32", "mfma32")
+    p2_kernel = "k_reg_pass2_tile32" if p2_f32 else "k_reg_pass2_mfma"
+    tr2, src2 = load_traffic("k_reg_pass2_tile32<5, 18>" if p2_f32 else "k_reg_pass2_mfma<5, 18, 0>")
     out = {"metric": "ImageRegistrator residuals/sec", "value": res / t_acc, "unit": "residuals/s",
-           "dtype": "f32 rows; H, b: f32 fma chains of 32 (b: <= 20) residual pairs added into f64 -- NARROWER than the reference, which adds single "
-                    "f32 products in f64 (intrinsics_and_pose_optimizer.cc:1246-1247); E3D_REG_PASS2=mfma64 is that sum (0.93 instead of "
-                    "0.67 ms per image), and tests/test_gpu_reg.py::test_run_is_insensitive_to_the_pass2_accumulation_width shows whole runs "
-                    "agree to 1e-7 rad",
+           "dtype": ("f32 rows; H, b: f32 fma chains of 32 (b: <= 20) residual pairs added into f64 -- NARROWER than the reference (E3D_REG_PASS2=%s, opt-in)" % p2_variant) if p2_f32 else
+                    "f32 rows; H, b: every product formed exactly in f64 and summed in f64 (v_mfma_f64_16x16x4_f64 / v_fma_f64) -- the reference's sum of "
+                    "single products in f64 (intrinsics_and_pose_optimizer.cc:1246-1247), each term at least as accurate as its fl32(fl32(w J_i) J_j)",
            "config": {"workload": "%d images 6048x4032 (6 levels) THIN_PRISM_FISHEYE, %d points, K = %d (BASELINE.json configs[3] shape)"
                                   % (len(ids), len(Wl["pts"]), K), "unknowns": I + 6 * len(ids)},
            "residuals": res, "accumulate_ms_all_images": t_acc * 1e3, "observation_refresh_ms_all_images": t_obs * 1e3,
@@ -541,16 +635,15 @@ def leg_image_registrator(e3d, synth, args, dev):
            "roofline": {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "k_reg_pass1": {"algorithmic_bytes_per_launch": b1, "avg_launch_ms": p1_ms, "achieved": b1 / (p1_ms * 1e-3) / 1e9,
                                         "frac": b1 / (p1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": tr1, "traffic_source": src1},
-                        "k_reg_pass2_tile32": {"algorithmic_bytes_per_launch": b2, "avg_launch_ms": p2_ms, "achieved": b2 / (p2_ms * 1e-3) / 1e9,
-                                               "frac_of_survey_bytes": b2 / (p2_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                               "frac": (tr2 / (p2_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if tr2 else None,
-                                               "frac_basis": "HBM bytes the counters saw (traffic) / launch time / 8 TB/s: SURVEY 8(d)'s 516 B per residual pair "
-                                                             "assume every neighbour row comes from HBM, but the rows of the K neighbours are L2 hits "
-                                                             "(frac_of_survey_bytes is that figure and does not describe the kernel)",
-                                               "traffic": tr2, "traffic_source": src2,
-                                               "note": "v_mfma_f32_16x16x4_f32 tile with f32 chains of 32 pairs added into f64; gathers of "
-                                                       "neighbour rows are served by L2, the kernel is instruction-issue / latency bound "
-                                                       "rather than HBM bound (DESIGN.md section 10.1)"}}}
+                        p2_kernel: {"algorithmic_bytes_per_launch": b2, "avg_launch_ms": p2_ms, "achieved": b2 / (p2_ms * 1e-3) / 1e9,
+                                    "frac_of_survey_bytes": b2 / (p2_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                    "frac": (tr2 / (p2_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if tr2 else None,
+                                    "frac_basis": "HBM bytes the counters saw (traffic) / launch time / 8 TB/s: SURVEY 8(d)'s 516 B per residual pair "
+                                                  "assume every neighbour row comes from HBM, but the rows of the K neighbours are L2 hits "
+                                                  "(frac_of_survey_bytes is that figure and does not describe the kernel)",
+                                    "traffic": tr2, "traffic_source": src2,
+                                    "note": "gathers of neighbour rows are served by L2; the kernel is bound by the issue rate of the matrix "
+                                            "instruction (v_mfma_f64_16x16x4_f64: 16 per neighbour slot of 64 observations, DESIGN.md section 10.1), not by HBM"}}}
     if not args.no_cpu_baseline:
         from oracle import reg_binding as rb
         from oracle.reg_driver import OracleRegProblem
@@ -664,7 +757,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--points", type=int, default=0, help="points per scan of the headline leg (default 50 M x gpus)")
     ap.add_argument("--distance", type=float, default=0.01)
+    ap.add_argument("--perturb", type=float, default=1.0, help="scale of the headline scene's initial misalignment (synth.perturbation)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-whole-run", action="store_true", help="skip the add_cloud -> convergence run of the headline leg (N = 1)")
+    ap.add_argument("--no-scale-model", action="store_true", help="skip the rank-0-of-8 run of the all-pairs leg (N = 1)")
+    ap.add_argument("--scale-model-world", type=int, default=8)
+    ap.add_argument("--detail", default=None, help="where the full result goes (default: bench_detail.json next to bench.py, and gpurun_out/ if it exists)")
     ap.add_argument("--no-reg", action="store_true", help="skip the ImageRegistrator leg (N = 1 only)")
     ap.add_argument("--no-normals", action="store_true", help="skip the normal-estimation leg (N = 1 only)")
     ap.add_argument("--no-allpairs", action="store_true", help="skip the all-pairs scaling leg")
@@ -728,8 +826,121 @@ def main():
         if not args.no_normals:
             out["normal_estimation"] = leg_normals(e3d, synth, args, dev)
     if rank == 0:
-        print(json.dumps(out))
+        emit(out, args)
     R.close()
+
+
+def _r(v, digits=4):
+    """float -> `digits` significant digits (the compact line carries summaries, the detail file the full values)."""
+    if isinstance(v, bool) or v is None or isinstance(v, (int, str)):
+        return v
+    try:
+        return float("%.*g" % (digits, float(v)))
+    except (TypeError, ValueError):
+        return v
+
+
+def compact_line(d, detail_path="bench_detail.json"):
+    """The ONE line the driver parses (last line of stdout): the contract's headline keys, `config`, `dtype`, the dominant kernel's
+    `roofline`, `cpu_baseline`, and one summary object per secondary leg.  Everything else -- kernel tables, per-step arrays, prose --
+    stays in the detail file.  Bounded: tests/test_bench_line.py asserts < 4096 bytes on a recorded run."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline")
+    o = {k: (_r(d[k], 6) if k in ("value", "ms_per_step") else d[k]) for k in keep if k in d}
+    o["dtype"] = "f32 (f64 accumulation)" if "f32" in str(d.get("dtype", "")) else d.get("dtype")
+    o["data"] = "synthetic"
+    c = d.get("config", {})
+    o["config"] = {"workload": "ICPScanAligner 2 scans x %s points, -d %s (BASELINE.json configs[1] shape), one outer iteration per step"
+                               % (c.get("points_per_scan"), str(c.get("workload", "")).split("-d ")[-1].split(",")[0] if "-d " in str(c.get("workload", "")) else "?"),
+                   "points_per_scan": c.get("points_per_scan"), "scans": c.get("scans"), "parallelism": str(c.get("parallelism", "")).split(" ")[0],
+                   "initial_misalignment_scale": c.get("initial_misalignment_scale")}
+    for k in ("steps_requested", "converged_at_iteration"):
+        o[k] = d.get(k)
+    for k in ("ms_per_step_settling", "ms_per_step_steady", "lm_passes_per_iter"):
+        o[k] = _r(d.get(k))
+    rf = d.get("roofline", {})
+    o["roofline"] = {"bound": rf.get("bound"), "achieved": _r(rf.get("achieved")), "peak": rf.get("peak"), "unit": rf.get("unit"), "frac": _r(rf.get("frac")),
+                     "frac_of_bytes_moved": _r(rf.get("frac_of_bytes_moved")), "traffic": _r(rf.get("traffic")), "traffic_source": rf.get("traffic_source"),
+                     "kernel": str(rf.get("kernel", "")).split(":")[0], "algorithmic_bytes_per_launch": _r(rf.get("algorithmic_bytes_per_launch")),
+                     "avg_launch_ms": _r(rf.get("avg_launch_ms"))}
+    cb = d.get("cpu_baseline")
+    if cb:
+        o["cpu_baseline"] = {"value": _r(cb["value"]), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
+                             "sample": "median of 3 outer iterations on a slab of both scans (%.1f %% of the points), from the GPU run's poses after warm-up"
+                                       % (100.0 * cb.get("sample_fraction_of_configs1", 0.0)),
+                             "ms_per_iter": _r(cb.get("ms_per_iter")), "all_cores_value": _r(cb.get("all_core", {}).get("value")), "host_cores_available": cb.get("host_cores_available")}
+        o["speedup_vs_cpu_iteration_rate"] = _r(d.get("speedup_vs_cpu_iteration_rate"))
+    w = d.get("whole_run")
+    if w:
+        o["whole_run"] = {"wall_s": _r(w["wall_s"]), "iterations_run": w["iterations_run"], "converged_at_iteration": w["converged_at_iteration"],
+                          "add_cloud_s": _r(w["add_cloud_s"]), "first_iteration_ms": _r(w["first_iteration_ms"]), "correspondences_per_s": _r(w["correspondences_per_s"])}
+    if "comm" in d:
+        cm = d["comm"]
+        o["comm"] = {k: _r(cm[k]) for k in ("allreduce_calls_per_iter", "allreduce_bytes_per_call", "allreduce_ms_per_iter_max_over_ranks", "allreduce_ms_per_iter_min_over_ranks") if k in cm}
+    legs = {}
+    p = d.get("partial_overlap")
+    if p:
+        legs["partial_overlap"] = {"value": _r(p["value"]), "ms_per_step": _r(p["ms_per_step"]), "steps": p.get("steps"), "converged_at_iteration": p.get("converged_at_iteration"),
+                                   "matched_fraction": _r(p.get("config", {}).get("matched_fraction")), "ms_per_step_steady": _r(p.get("ms_per_step_steady")),
+                                   "roofline_kernel": str(p.get("roofline", {}).get("kernel", "")).split(":")[0], "roofline_frac": _r(p.get("roofline", {}).get("frac"))}
+    a = d.get("allpairs")
+    if a:
+        la = {"value": _r(a["value"]), "unit": a["unit"], "scaling": a["scaling"], "n_gpus": a.get("n_gpus"), "steps": a["steps"], "ms_per_iter": _r(a["ms_per_iter"]),
+              "ms_per_iter_settling": _r(a.get("ms_per_iter_settling")), "ms_per_iter_steady": _r(a.get("ms_per_iter_steady")),
+              "workload": str(a.get("config", {}).get("workload", "")).split(" (")[0],
+              "roofline_kernel": str(a.get("roofline", {}).get("kernel", "")).split(":")[0], "roofline_frac": _r(a.get("roofline", {}).get("frac")),
+              "roofline_frac_of_bytes_moved": _r(a.get("roofline", {}).get("frac_of_bytes_moved"))}
+        if "nn_launches_per_iter" in a:
+            la["nn_launches_per_iter"] = {k: _r(v) for k, v in a["nn_launches_per_iter"].items()}
+        sm = a.get("scale_model")
+        if sm:
+            la["scale_model"] = {"world": sm["world"], "ms_per_iter_n1": _r(sm["ms_per_iter_n1"]), "ms_per_iter_as_rank0_of_world": _r(sm["ms_per_iter_as_rank0_of_world"]),
+                                 "modelled_speedup": _r(sm["modelled_speedup"]), "non_dividing_ms_per_iter": _r(sm["non_dividing_ms_per_iter"]),
+                                 "steady_modelled_speedup": _r(sm["steady"]["modelled_speedup"]), "steady_non_dividing_ms_per_iter": _r(sm["steady"]["non_dividing_ms_per_iter"])}
+        if "comm" in a:
+            la["comm"] = {k: _r(a["comm"][k]) for k in ("allreduce_calls_per_iter", "allreduce_ms_per_iter_max_over_ranks", "allreduce_ms_per_iter_min_over_ranks") if k in a["comm"]}
+        legs["allpairs"] = la
+    g = d.get("image_registrator")
+    if g:
+        rf2 = g.get("roofline", {})
+        p2 = next((v for k, v in rf2.items() if k.startswith("k_reg_pass2")), {})
+        lg = {"metric": g.get("metric"), "value": _r(g.get("value")), "unit": g.get("unit"), "dtype": str(g.get("dtype", "")).split(" -- ")[0][:120],
+              "workload": str(g.get("config", {}).get("workload", "")).split(" (BASELINE")[0], "accumulate_ms_all_images": _r(g.get("accumulate_ms_all_images")),
+              "ms_per_run_iteration": _r(g.get("ms_per_run_iteration")), "pass1_frac": _r(rf2.get("k_reg_pass1", {}).get("frac")),
+              "pass2_kernel": next((k for k in rf2 if k.startswith("k_reg_pass2")), None), "pass2_avg_launch_ms": _r(p2.get("avg_launch_ms")), "pass2_frac": _r(p2.get("frac"))}
+        if "cpu_baseline" in g:
+            lg["cpu_baseline"] = {k: _r(g["cpu_baseline"][k]) for k in ("value", "unit", "cores", "kind")}
+        legs["image_registrator"] = lg
+    nl = d.get("normal_estimation")
+    if nl:
+        ln = {"points": nl["points"], "unit": nl["unit"]}
+        for k in ("k32", "k8"):
+            if k in nl:
+                ln[k] = {"value": _r(nl[k]["value"]), "ms_per_call": _r(nl[k]["ms_per_call"]), "frac": _r(nl[k]["roofline"]["frac"]),
+                         "traffic_over_algorithmic": _r(nl[k]["roofline"]["traffic"] / nl[k]["roofline"]["algorithmic_bytes_per_launch"]) if nl[k]["roofline"].get("traffic") else None}
+        ss = nl.get("scanner_sampled", {})
+        ln["scanner_sampled_ms"] = {k: _r(ss[k]["ms_per_call"]) for k in ("k32", "k8") if k in ss}
+        if "cpu_baseline" in nl:
+            ln["cpu_baseline"] = {k: _r(nl["cpu_baseline"][k]) for k in ("value", "unit", "cores", "kind")}
+        legs["normal_estimation"] = ln
+    if legs:
+        o["legs"] = legs
+    o["detail"] = detail_path
+    return o
+
+
+def emit(out, args):
+    """The full result -> the detail file(s); the compact line -> the LAST line of stdout."""
+    paths = [args.detail] if args.detail else [os.path.join(ROOT, "bench_detail.json")]
+    if not args.detail and os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+        paths.append(os.path.join(ROOT, "gpurun_out", "bench_detail.json"))
+    for pth in paths:
+        try:
+            with open(pth, "w") as f:
+                json.dump(out, f)
+        except OSError as e:                                       # a read-only tree must not cost the line
+            print("bench.py: could not write %s: %s" % (pth, e), file=sys.stderr)
+    sys.stdout.flush()
+    print(json.dumps(compact_line(out, os.path.relpath(paths[0], ROOT)), separators=(",", ":")), flush=True)
 
 
 if __name__ == "__main__":

@@ -7,6 +7,9 @@
 //   * one process per GPU (bench.py, torchrun): rank 0 calls e3d_comm_unique_id, the 128 bytes travel through whatever
 //     rendezvous the launcher has, every rank calls e3d_comm_create;
 //   * one host thread per GPU inside a tool (ICPScanAligner --gpus N): e3d_comm_create_all.
+#include <chrono>
+#include <thread>
+
 #include "../../include/e3d_hip.h"
 #include "e3d_comm.hpp"
 
@@ -67,6 +70,9 @@ int e3d_comm_create_all(int n_devices, const int* devices, e3d_comm_t** out) {
 int e3d_comm_abort(e3d_comm_t* c) {
   if (!c) return 0;
   if (c->aborted.exchange(true) || !c->comm) return 0;
+  // the flag is up: no new enqueue starts.  One that is between its flag check and its return gets up to 200 ms to leave the
+  // library call (it does unless it is the blocked enqueue this abort is meant to release).
+  for (int i = 0; i < 200 && c->inflight.load() > 0; ++i) std::this_thread::sleep_for(std::chrono::milliseconds(1));
   const ncclResult_t r = ncclCommAbort(c->comm);   // releases collectives that wait for a rank that will never arrive
   if (r != ncclSuccess) { e3d::set_last_error(std::string("ncclCommAbort failed: ") + ncclGetErrorString(r)); return E3D_ERR_HIP; }
   return 0;

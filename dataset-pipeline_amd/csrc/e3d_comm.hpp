@@ -18,6 +18,11 @@ struct e3d_comm {
   // Aborting ONE communicator does not release its intra-node peers: whoever notices a failure aborts every local communicator
   // (the tools do, csrc/host/icp_point_to_plane.h).
   std::atomic<bool> aborted{false};
+  // enqueues in flight on the owner's thread: abort raises the flag first and then gives a running enqueue a bounded time to leave
+  // ncclAllReduce before it frees the communicator under it (an enqueue that never returns is the case abort exists for: it does
+  // not wait for that one).  The statistics below belong to the communicator's own thread: e3d_comm_get_stats is called from it,
+  // or after joining it.
+  std::atomic<int> inflight{0};
   // HIP-event stop-watch of the collectives (e3d_comm_get_stats): pairs are read lazily, so timing adds no synchronisation
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
   size_t ev_used = 0;
@@ -45,6 +50,7 @@ namespace e3d {
 // in-place sum over the ranks of a DEVICE buffer, enqueued on `s` (results identical on every rank)
 inline void comm_allreduce(e3d_comm* c, void* dev, size_t n, ncclDataType_t t, hipStream_t s) {
   if (!n) return;
+  struct InFlight { e3d_comm* c; explicit InFlight(e3d_comm* cc) : c(cc) { c->inflight.fetch_add(1); } ~InFlight() { c->inflight.fetch_sub(1); } } guard(c);
   if (c->aborted.load() || !c->comm) throw ::e3d::Error(-3, "the communicator was aborted (another rank failed)");
   if (c->ev_used == c->ev.size()) {
     if (c->ev.size() >= 1024) c->flush_events();       // (waits for collectives enqueued long ago)

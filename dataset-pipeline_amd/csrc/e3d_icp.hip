@@ -1263,13 +1263,49 @@ static bool align_meshes(e3d_icp* h, float max_d, float thr, bool print, int ite
       auto it = h->pair_state.find(std::make_pair(j.src, j.tgt));
       if (it == h->pair_state.end() || it->second->pA.cap < resident_rows_cap(nq)) rows_new += resident_bytes(nq);
     }
-    if (resident && rows_new > 0) {
-      size_t free_b = 0, total_b = 0;
-      (void)hipMemGetInfo(&free_b, &total_b);
-      if ((double)rows_new > 0.8 * (double)free_b) resident = false;
+    // rows of pairs that have left the job list (their bounding boxes no longer intersect) go back first
+    for (auto& kv : h->pair_state) {
+      bool listed = false;
+      for (const PairJob& j : jobs) if (j.src == kv.first.first && j.tgt == kv.first.second) { listed = true; break; }
+      if (!listed) { PairState& ps = *kv.second; ps.pA.release(); ps.pB.release(); ps.pC.release(); ps.rows_valid = false; }
     }
-    if (!resident)
+    auto release_rows = [&]() {
       for (auto& kv : h->pair_state) { PairState& ps = *kv.second; ps.pA.release(); ps.pB.release(); ps.pC.release(); ps.rows_valid = false; }
+    };
+    if (resident && rows_new > 0) {
+      // beside the rows: the batch scratch (12 B per query of a batch, at most 64 M queries) and what the search allocates on
+      // first use (sort buffers, block counts: ~40 B per query of the largest pair)
+      size_t free_b = 0, total_b = 0, q_max = 0;
+      (void)hipMemGetInfo(&free_b, &total_b);
+      for (const PairJob& j : jobs) q_max = std::max(q_max, slice_len((j.src == M) ? *h->fixed : *h->clouds[j.src]));
+      const double extra = 12.0 * (double)std::min<size_t>(q_max * kPairBatch, (size_t)64 << 20) + 40.0 * (double)q_max;
+      if ((double)rows_new + extra > 0.8 * (double)free_b) resident = false;
+    }
+    if (resident) {
+      // The rows are allocated HERE, all of them, so that running out of memory is noticed before any pair has been searched: on
+      // failure every pair takes the compacted planes this iteration (the old data flow), exactly as when the estimate says no.
+      try {
+        for (const PairJob& j : jobs) {
+          const Cloud& src = (j.src == M) ? *h->fixed : *h->clouds[j.src];
+          const Cloud& tgt = (j.tgt == M) ? *h->fixed : *h->clouds[j.tgt];
+          const size_t nq = slice_len(src);
+          if (!pair_uses_rows(h, tgt) || nq == 0 || tgt.n == 0) continue;
+          const size_t j0 = (size_t)((unsigned __int128)src.n * (unsigned)h->rank / (unsigned)h->world);
+          PairState& ps = pair_state_for(h, j.src, j.tgt, src, tgt, j0, nq);
+          const size_t cap = resident_rows_cap(nq);
+          if (ps.pA.cap < cap || ps.pB.cap < cap || ps.pC.cap < cap) {
+            ps.rows_valid = false;
+            ps.pA.reserve(cap); ps.pB.reserve(cap); ps.pC.reserve(cap);
+          }
+          ps.plane_match.reserve(nq); ps.glist.reserve(div_up(nq, 64));
+        }
+      } catch (const Error&) {
+        (void)hipGetLastError();
+        release_rows();
+        resident = false;
+      }
+    }
+    if (!resident) release_rows();
     h->resident_now = resident;
     for (const PairJob& j : jobs) {
       const Cloud& src = (j.src == M) ? *h->fixed : *h->clouds[j.src];

@@ -37,8 +37,22 @@ struct KnnGrid {
   // ONE run [S[row + xa], S[row + xb + 1]) found with two independent loads; nullptr: the hash table, cell by cell
   const unsigned* S;
   unsigned D[3];
+  unsigned xcd_map;         // 1: the scan kernels hand every XCD one contiguous stretch of the query order (knn_block)
 };
-constexpr int kKnnSelFallback = 253;  // pass A's answer: k not reached inside a narrowed histogram range
+constexpr int kKnnSelFallback = 253;
+
+// Workgroup b runs on XCD b % 8 (observed placement, not a contract -- another placement is slower, not wrong), and every XCD has
+// its own 4 MB L2.  Queries are in cell order and a block's candidates are the rows of the 27 cells around them: the ~100 blocks
+// that follow share most of those rows.  Dealt round-robin, those blocks land on all eight XCDs and every L2 fetches the same rows
+// from HBM (round 4's counters: 2.7 GB fetched per scan of a 0.32 GB point array, 4 GB by the sampled histogram).  The logical
+// block index below gives XCD x the x-th contiguous eighth of the blocks instead -- a bijection of [0, nb), so every query is still
+// handled exactly once; E3D_KNN_XCD=0 switches it off.
+__device__ __forceinline__ unsigned knn_block(const KnnGrid& G, unsigned b, unsigned nb) {
+  constexpr unsigned kXcds = 8;
+  if (!G.xcd_map || nb < 8 * kXcds) return b;
+  const unsigned per = nb / kXcds, rem = nb % kXcds, x = b % kXcds, local = b / kXcds;
+  return x * per + min(x, rem) + local;
+}  // pass A's answer: k not reached inside a narrowed histogram range
 
 // sqdist_l2 (query - candidate, (dx^2 + dy^2) + dz^2, every operation rounded on its own) with x and y as ONE packed operation each:
 // a candidate's x and y arrive in consecutive registers, so v_pk_add_f32 / v_pk_mul_f32 take them as they are (the compiler's own
@@ -203,7 +217,7 @@ __global__ __launch_bounds__(kKnnHistBlock) void k_knn_hist(const float4* __rest
                                                             const float4* __restrict__ Q4, unsigned char* __restrict__ sel_bin, unsigned stride) {
   __shared__ unsigned hw[kKnnBins / 4][kKnnHistBlock];
   const int tid = threadIdx.x;
-  const size_t gi = (size_t)blockIdx.x * blockDim.x + tid;
+  const size_t gi = (size_t)knn_block(G, blockIdx.x, gridDim.x) * blockDim.x + tid;
   if (gi >= n_todo) return;
   const unsigned qid = todo ? todo[gi] : (unsigned)gi * stride;
   const float4 q = Q4[qid];
@@ -494,7 +508,7 @@ __global__ __launch_bounds__(kKnnBlock) void k_knn_normals(const float4* __restr
   unsigned* hp = reinterpret_cast<unsigned*>(smem) + (size_t)(kOffWords + (kSel == 5 ? 8 : (kSel >= 3 ? 0 : cap))) * kKnnBlock;
   unsigned* rs_lds = reinterpret_cast<unsigned*>(smem);
   const int tid = threadIdx.x;
-  size_t gi = (size_t)blockIdx.x * blockDim.x + tid;
+  size_t gi = (size_t)(kSel >= 3 ? knn_block(G, blockIdx.x, gridDim.x) : blockIdx.x) * blockDim.x + tid;
   if constexpr (kSel < 3) {
     // The 125-cell pass (reach 2) takes what a level left over: a few ten thousand unrelated queries, one wave per SIMD at
     // best, and a wave walks the UNION of the cells its lanes need, one memory round trip after the other -- its duration is
@@ -1516,7 +1530,11 @@ static void knn_pass(KnnWorkspace& W, const float* xyz, size_t n, int k, const f
     static const bool wide_pass = [] { const char* e = getenv("E3D_KNN_WIDE"); return e ? atoi(e) != 0 : true; }();
     // seeds of the 125-cell pass (it takes lists of at most n / 64 queries)
     static const bool seed_env = [] { const char* e = getenv("E3D_KNN_SEED"); return e ? atoi(e) != 0 : true; }();
-    const unsigned seed_cap = (wide_pass && seed_env && sel == 3) ? (unsigned)(n / 64 + 1) : 0u;
+    // (only the lane-per-query wide pass reads them: with the wave-per-query pass -- the default for k <= 64 -- nothing would, and the
+    // scan kernels would write k positions per unresolved query plus a memset per level for nothing)
+    static const bool wide_wave = [] { const char* e = getenv("E3D_KNN_WIDE_WAVE"); return e ? atoi(e) != 0 : true; }();
+    const bool wave_per_query = wide_wave && sel == 3 && k <= 64;
+    const unsigned seed_cap = (wide_pass && seed_env && sel == 3 && !wave_per_query) ? (unsigned)(n / 64 + 1) : 0u;
     if (seed_cap) { W.seed_pos.reserve((size_t)seed_cap * (size_t)k); W.seed_flag.reserve(seed_cap); }
     unsigned* const seed_pos_p = seed_cap ? W.seed_pos.p : nullptr;
     unsigned char* const seed_flag_p = seed_cap ? W.seed_flag.p : nullptr;
@@ -1525,6 +1543,8 @@ static void knn_pass(KnnWorkspace& W, const float* xyz, size_t n, int k, const f
     static const int dense_log2 = [] { const char* e = getenv("E3D_KNN_DENSE_LOG2"); return e ? std::min(atoi(e), 31) : 30; }();
     auto build_level = [&](LevelBuffers& LB, double cell_size, int dir_log2, KnnGrid& G) -> bool {
       G = KnnGrid{};
+      static const bool xcd_map = [] { const char* e = getenv("E3D_KNN_XCD"); return !(e && e[0] == '0'); }();
+      G.xcd_map = xcd_map ? 1u : 0u;
       G.cell = (float)cell_size;
       G.g.inv_cell = (float)(1.0 / (double)G.cell);
       for (int a = 0; a < 3; ++a) { G.g.origin[a] = (float)((double)bb[a] - 2.0 * cell_size); G.dmin[a] = bb[a]; G.dmax[a] = bb[3 + a]; }
@@ -1678,7 +1698,6 @@ static void knn_pass(KnnWorkspace& W, const float* xyz, size_t n, int k, const f
         unsigned cw[1] = {0};
         E3D_HIP(hipMemsetAsync(L.counter.p + 1, 0, sizeof(unsigned), s));
         static const int wide_spread = [] { const char* e = getenv("E3D_KNN_WIDE_SPREAD"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 64 ? v : 4; }();
-        static const bool wide_wave = [] { const char* e = getenv("E3D_KNN_WIDE_WAVE"); return e ? atoi(e) != 0 : true; }();
         auto lane_per_query = [&](const unsigned* list, size_t n_list, bool seeded) {
           hipLaunchKernelGGL(kernel_of(sel_list), dim3((unsigned)div_up(n_list * (size_t)wide_spread, kKnnBlock)), dim3(kKnnBlock), lds_list, s, L.P4.p, n,
                              list, n_list, L.table.p, G, k, k, viewpoint[0], viewpoint[1], viewpoint[2], Q4.p,
@@ -1686,7 +1705,7 @@ static void knn_pass(KnnWorkspace& W, const float* xyz, size_t n, int k, const f
                              d_mean_out ? d_mean_out->p : nullptr, wide_out, L.counter.p + 1, nullptr, nullptr, nullptr, 2, wide_spread, 1, 1.0f,
                              seeded ? seed_pos_p : nullptr, seeded ? seed_flag_p : nullptr, seed_cap);
         };
-        if (wide_wave && G.S && sel == 3 && k <= 64) {
+        if (wave_per_query && G.S) {
           // one wave per query (k_knn_wide_wave); what it hands back (more candidates than its lanes hold, long tie runs) takes the
           // lane-per-query kernel
           E3D_HIP(hipMemsetAsync(L.counter.p + 2, 0, sizeof(unsigned), s));

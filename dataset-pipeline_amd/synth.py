@@ -241,10 +241,11 @@ SCAN_POSES = [((4.0, 5.0, 1.5), 0.3), ((6.0, 5.5, 1.4), -0.4), ((2.5, 2.5, 1.6),
               ((4.5, 3.5, 1.5), 2.4), ((5.5, 6.5, 1.45), -2.8), ((7.0, 8.5, 1.55), 0.6), ((3.0, 8.5, 1.35), -0.2)]
 
 
-def perturbation(index, angle_scale=1.0):
+def perturbation(index, angle_scale=1.0, scale=1.0):
     """Initial misalignment of scan `index`: 1 degree about (1,1,1)/sqrt(3) and (2,-1,1) cm for scan 1,
     smaller seeded variations of the same size for further scans; scan 0 is unperturbed.  angle_scale shrinks the rotation
-    (a stretched room keeps the same displacement at its walls)."""
+    (a stretched room keeps the same displacement at its walls); scale multiplies rotation angle and translation alike (a
+    worse initial alignment: more outer iterations before the run converges)."""
     if index == 0:
         return np.eye(4, dtype=np.float64)
     rs = np.random.RandomState(1234 + index)
@@ -252,19 +253,20 @@ def perturbation(index, angle_scale=1.0):
     ang = math.radians(1.0) if index == 1 else math.radians(rs.uniform(0.5, 1.0))
     t = np.array([0.02, -0.01, 0.01]) if index == 1 else rs.uniform(-0.02, 0.02, size=3)
     P = np.eye(4)
-    P[:3, :3] = rot_axis_angle(axis, ang * angle_scale)
-    P[:3, 3] = t
+    P[:3, :3] = rot_axis_angle(axis, ang * angle_scale * scale)
+    P[:3, 3] = t * scale
     return P
 
 
-def make_scene(n_scans, n_points, seed=1234, sigma=0.002, device="cpu", room_scale=1.0, partial=False):
+def make_scene(n_scans, n_points, seed=1234, sigma=0.002, device="cpu", room_scale=1.0, partial=False, perturb=1.0):
     """List of dicts {xyz, normals, T_true, T_init} (T_init = perturbation * T_true applied about the scan origin).
-    partial=True: the partial-overlap room (partition wall, occlusion, maximum range; room_scale must be 1)."""
+    partial=True: the partial-overlap room (partition wall, occlusion, maximum range; room_scale must be 1).
+    perturb: scale of the initial misalignment (perturbation())."""
     scans = []
     for i in range(n_scans):
         origin, yaw = SCAN_POSES[i % len(SCAN_POSES)]
         xyz, nrm, T = make_scan(n_points, origin, yaw, seed + 17 * i, sigma, device, room_scale, partial)
-        P = perturbation(i, 1.0 / room_scale)
+        P = perturbation(i, 1.0 / room_scale, perturb)
         Ti = T.astype(np.float64).copy()
         Ti[:3, :3] = P[:3, :3] @ Ti[:3, :3]
         Ti[:3, 3] = Ti[:3, 3] + P[:3, 3]

@@ -114,8 +114,8 @@ typedef struct {
   int32_t inner_iterations;  /* LM iterations executed (<= 150)                            */
   int32_t full_passes;       /* fused H/b/cost passes over all correspondences             */
   int32_t cost_passes;       /* cost-only passes (one pose set)                            */
-  int32_t multi_cost_passes; /* cost-only passes evaluating LM tries 1..9 at once          */
-  int32_t multi_cost_poses;  /* ABI 4: distinct new pose sets those passes evaluated (<= 9 each; tries whose f32 poses equal the
+  int32_t multi_cost_passes; /* cost-only passes evaluating LM tries (0 or 1)..9 at once   */
+  int32_t multi_cost_poses;  /* ABI 4: distinct new pose sets those passes evaluated (<= 10 each; tries whose f32 poses equal the
                                 current ones or an earlier try's are not evaluated again)  */
   int64_t correspondences;   /* total over all directed pairs of this rank                 */
   int64_t queries;           /* NN queries issued by this rank                             */
@@ -175,7 +175,8 @@ void e3d_comm_destroy(e3d_comm_t* comm);
  * ALL local communicators (--gpus N, csrc/host/icp_point_to_plane.h). */
 int e3d_comm_abort(e3d_comm_t* comm);
 /* HIP-event time, number and payload of the all-reduces enqueued on `comm` since creation (or the last reset): what the bench
- * line reports per rank at N > 1 (ABI 4).  Waits for the collectives enqueued so far. */
+ * line reports per rank at N > 1 (ABI 4).  Waits for the collectives enqueued so far.  To be called from the host thread that
+ * enqueues on `comm` (or after joining it): the counters are not synchronised against a running enqueue. */
 int e3d_comm_get_stats(e3d_comm_t* comm, double* allreduce_ms, int64_t* allreduce_calls, int64_t* allreduce_bytes, int reset);
 int e3d_comm_rank(const e3d_comm_t* comm);
 int e3d_comm_world_size(const e3d_comm_t* comm);

@@ -1,0 +1,51 @@
+"""bench.py's last stdout line is what the driver parses: it has to stay one small JSON object whatever the detail grows to
+(round 4's single 33 KB line was not parsed).  Built here from recorded detail files of real runs (no GPU needed)."""
+import glob
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+# (the files of rounds 1 and 2 predate the leg layout)
+RECORDED = sorted(glob.glob(os.path.join(ROOT, "profiles", "round[3-9]_bench_default*.json")) + glob.glob(os.path.join(ROOT, "profiles", "round[3-9]_bench_detail*.json")))
+
+
+@pytest.mark.parametrize("path", RECORDED, ids=[os.path.basename(p) for p in RECORDED])
+def test_compact_line_is_small_and_complete(path):
+    detail = json.load(open(path))
+    line = json.dumps(bench.compact_line(detail), separators=(",", ":"))
+    assert "\n" not in line and len(line) < 4096, len(line)
+    o = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in o, k
+    assert isinstance(o["config"].get("workload"), str)
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in o["roofline"], k
+    assert abs(o["roofline"]["frac"] - o["roofline"]["achieved"] / o["roofline"]["peak"]) < 1e-3
+    if "cpu_baseline" in detail:
+        for k in ("value", "unit", "cores", "kind", "sample"):
+            assert k in o["cpu_baseline"], k
+    # the headline numbers are the detail's (rounded to >= 4 significant digits)
+    assert abs(o["value"] - detail["value"]) <= 1e-4 * abs(detail["value"])
+    assert abs(o["ms_per_step"] - detail["ms_per_step"]) <= 1e-4 * detail["ms_per_step"]
+
+
+def test_there_is_a_recorded_run():
+    assert RECORDED, "profiles/ holds no recorded bench detail file"
+
+
+def test_emit_prints_the_compact_line_last(tmp_path, capsys):
+    detail = json.load(open(RECORDED[-1]))
+
+    class A:
+        detail = str(tmp_path / "d.json")
+    bench.emit(detail, A)
+    out = capsys.readouterr().out.strip().splitlines()
+    assert len(out) == 1 and len(out[0]) < 4096
+    assert json.loads(out[0])["metric"] == detail["metric"]
+    assert json.load(open(A.detail))["value"] == detail["value"]

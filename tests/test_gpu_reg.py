@@ -1036,13 +1036,16 @@ np.savez(sys.argv[2], **out)
 
 
 def test_pass2_variants_agree(tmp_path):
-    """The three formulations of pass 2 -- f32 matrix instruction with short chains flushed into f64 (default), f64 matrix
-    instruction (E3D_REG_PASS2=mfma64), per-thread f64 FMAs (E3D_REG_PASS2=valu) -- on the same observations: counts and residual
-    sums identical, H and b within 1e-7 of the entry scale (the parity tests against the oracle allow 1e-6)."""
+    """The formulations of pass 2 -- the f64 matrix instruction on exact products (default: the reference's sum of single products in
+    f64, intrinsics_and_pose_optimizer.cc:1246-1247), its scheduling variants (mfma64p4, mfma64l2, mfma64l3: other pair orders inside a
+    slot), the f32 matrix instruction with short chains flushed into f64 (E3D_REG_PASS2=tile32 / mfma32, opt-in), per-thread f64 FMAs
+    (E3D_REG_PASS2=valu) -- on the same observations: counts and residual sums identical, H and b within 1e-7 of the entry scale
+    (the parity tests against the oracle allow 1e-6); the f64 variants among themselves within 1e-12."""
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
-    for variant in ("", "mfma64", "valu"):
+    f64_variants = ("mfma64p4", "mfma64p16", "mfma64l2", "mfma64l2p8", "mfma64l3")
+    for variant in ("", "tile32", "mfma32", "valu") + f64_variants:
         env = dict(os.environ)
         env.pop("E3D_REG_PASS2", None)
         if variant:
@@ -1053,15 +1056,16 @@ def test_pass2_variants_agree(tmp_path):
         res[variant] = np.load(f)
     worst = 0.0
     for model in (1, 2, 0, 9, 4):
-        ref = res["mfma64"]
-        for variant in ("", "valu"):
+        ref = res[""]
+        for variant in ("tile32", "mfma32", "valu") + f64_variants:
             g = res[variant]
             assert np.array_equal(g["c%d" % model], ref["c%d" % model]) and np.array_equal(g["s%d" % model], ref["s%d" % model])
             d = np.sqrt(np.diag(ref["H%d" % model]))
             eh = (np.abs(g["H%d" % model] - ref["H%d" % model]) / np.outer(d, d)).max()
             eb = (np.abs(g["b%d" % model] - ref["b%d" % model]) / d).max() / np.abs(ref["b%d" % model] / d).max()
             worst = max(worst, eh, eb)
-            assert eh <= 1e-7 and eb <= 1e-7, (model, variant, eh, eb)
+            tol = 1e-12 if variant in f64_variants else 1e-7
+            assert eh <= tol and eb <= tol, (model, variant, eh, eb)
     print("pass 2 variants: worst deviation", worst)
 
 
@@ -1086,15 +1090,14 @@ np.savez(sys.argv[2], **out)
 
 
 def test_run_is_insensitive_to_the_pass2_accumulation_width(tmp_path):
-    """The default pass 2 sums f32 fma chains of 32 pairs into f64 (k_reg_pass2_tile32 / _mfma32); the reference adds single f32
-    products in f64 (intrinsics_and_pose_optimizer.cc:1246-1247), which E3D_REG_PASS2=mfma64 does.  Whole RunOnCurrentScale runs
+    """The opt-in pass 2 (E3D_REG_PASS2=tile32) sums f32 fma chains of 32 pairs into f64; the reference adds single f32 products in
+    f64 (intrinsics_and_pose_optimizer.cc:1246-1247), which the default (f64 matrix instruction) does.  Whole RunOnCurrentScale runs
     under both end at the same iteration count and at poses 1e-9 rad / 3e-8 m apart (measured; the assertion allows 2e-6), costs
-    within 4e-7 relative: orders of magnitude inside the 1e-5 rad parity bar against the oracle, which therefore does not lean on
-    the narrower sum."""
+    within 4e-7 relative: orders of magnitude inside the 1e-5 rad parity bar against the oracle."""
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
-    for variant in ("", "mfma64"):
+    for variant in ("", "tile32"):
         env = dict(os.environ)
         env.pop("E3D_REG_PASS2", None)
         if variant:
@@ -1105,11 +1108,11 @@ def test_run_is_insensitive_to_the_pass2_accumulation_width(tmp_path):
         res[variant] = np.load(f)
     worst = (0.0, 0.0)
     for model in (2, 0, 9):
-        a, b = res[""], res["mfma64"]
+        a, b = res["tile32"], res[""]
         assert a["run%d" % model][2] == b["run%d" % model][2] and a["run%d" % model][0] == b["run%d" % model][0]
         assert abs(a["run%d" % model][1] - b["run%d" % model][1]) <= 1e-5 * abs(b["run%d" % model][1])
         for i in range(3):
             ang, tr = _pose_delta(a["poses%d" % model][i][:4], a["poses%d" % model][i][4:], b["poses%d" % model][i][:4], b["poses%d" % model][i][4:])
             worst = (max(worst[0], ang), max(worst[1], tr))
-    print("default pass 2 vs f64 pass 2 over whole runs: poses at most %.3g rad, %.3g m apart" % worst)
+    print("f32-chain pass 2 vs the default f64 pass 2 over whole runs: poses at most %.3g rad, %.3g m apart" % worst)
     assert worst[0] <= 2e-6 and worst[1] <= 2e-6, worst

@@ -56,8 +56,18 @@ def _run(code, env):
 def test_icp_data_flows_agree():
     base = _run(ICP_CODE, {})
     assert len(base["pairs"]) > 0
-    for env in ({"E3D_ICP_BATCH": "0"}, {"E3D_ICP_RESIDENT": "0"}, {"E3D_LM_SPECULATE": "0"}):
-        assert _run(ICP_CODE, env) == base, env
+    for env in ({"E3D_ICP_BATCH": "0"}, {"E3D_LM_SPECULATE": "0"}):
+        assert _run(ICP_CODE, env) == base, env                      # same kernels, same sums: bit for bit
+    # resident vs compacted rows: the pair records (counts, distance sums) are those of the same searches; the LM passes add the
+    # same f32 terms in a different order of f64 sums (include/e3d_hip.h), so the poses agree to the tolerances of
+    # test_gpu_icp.py::test_resident_rows_equal_compacted_rows, not necessarily bit for bit
+    other = _run(ICP_CODE, {"E3D_ICP_RESIDENT": "0"})
+    assert [p[:4] for p in other["pairs"]] == [p[:4] for p in base["pairs"]]
+    for a, b in zip(other["pairs"], base["pairs"]):
+        assert abs(float.fromhex(a[4]) - float.fromhex(b[4])) <= 1e-9 * max(1.0, abs(float.fromhex(b[4])))
+    for pa, pb in zip(other["poses"], base["poses"]):
+        for a, b in zip(pa, pb):
+            assert abs(float.fromhex(a) - float.fromhex(b)) <= 2e-6
 
 
 @pytest.mark.timeout(600)

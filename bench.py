@@ -141,6 +141,7 @@ def sum_records(recs):
         sum(r["multi_cost_passes"] for r in recs),
         sum(r["corr_rows_rewritten"] for r in recs), sum(r["corr_rows_walked"] for r in recs),
         sum(r["multi_cost_poses"] for r in recs), sum(r["lm_passes_skipped"] for r in recs),
+        sum(r["nn_update_launches"] for r in recs), sum(r["nn_kernel_launches"] for r in recs),
     ], dtype=np.float64)
 
 
@@ -293,6 +294,7 @@ def icp_kernel_table(tot, world, K, pairs, moved_points, lm_kernel_name="k_lm_pa
     lm_avg, nn_avg = lm_full_ms / max(full_passes, 1), nn_ms / n_nn_launch
     multi_ms, multi_passes = lm_ms - lm_full_ms, tot[22] / world
     rows_rewritten, rows_walked, multi_poses, passes_skipped = tot[23] / world, tot[24] / world, tot[25] / world, tot[26] / world
+    upd_launches = max(tot[27] / world, 1.0)          # row-update launches (one per batch of pairs, or per pair: E3D_ICP_BATCH)
     lm_moved = 48.0 * rows_walked / K       # what a pass READS: three float4 per row it walks (resident rows: incl. the zero rows of listed groups)
     kernels = {
         "k_lm_pass": {"what": "%s: fused cost + Gramian pass over the correspondence rows (a7/a8); %.2f launches per iteration; "
@@ -328,12 +330,12 @@ def icp_kernel_table(tot, world, K, pairs, moved_points, lm_kernel_name="k_lm_pa
     kernels["k_transform_bbox"] = stream_kernel("a3: the cloud whose pose changed into the global frame + bounding box, 32 B per point moved (impl cloud 0 never "
                                                 "moves and is not transformed again)", tot[5] / world, K, 32.0 * moved_points)
     kernels["query_keys_and_sort"] = stream_kernel("cell keys + rocPRIM radix sort of the queries the row kernel searches (a5 prep)", tot[19] / world, max(tot[17] / world, 1), None)
-    kernels["match_scan"] = stream_kernel("totals of the per-block match counts / distance sums + the list of active 64-row groups (3 small kernels per pair)",
-                                          tot[20] / world, n_nn_launch, None)
+    kernels["match_scan"] = stream_kernel("totals of the per-block match counts / distance sums + the lists of active 64-row groups (3 small kernels per batch of pairs)",
+                                          tot[20] / world, upd_launches, None)
     kernels["k_corr_update"] = stream_kernel("resident correspondence rows brought up to date: match, encoded partner and distance of every query (12 B) + "
                                              "116 B per row whose partner changed (%.3g rows of %.3g per launch); with E3D_ICP_RESIDENT=0: k_compact_corr, every row"
-                                             % (rows_rewritten / n_nn_launch, queries / world / n_nn_launch),
-                                             tot[21] / world, n_nn_launch, (12.0 * queries / world + 116.0 * rows_rewritten) / n_nn_launch)
+                                             % (rows_rewritten / upd_launches, queries / world / upd_launches),
+                                             tot[21] / world, upd_launches, (12.0 * queries / world + 116.0 * rows_rewritten) / upd_launches)
     accounted = sum((v["summed_ms_per_iter"] or 0.0) for v in kernels.values())
     kernels["nn_search_per_pair"] = {"what": "certify + bounded + rows per directed pair: 32 B per query of the pair", "algorithmic_bytes_per_launch": nn_bytes, "avg_launch_ms": nn_avg,
                                      "GBs": nn_bytes / (nn_avg * 1e-3) / 1e9 if nn_avg > 0 else None, "summed_ms_per_iter": nn_ms / K}
@@ -482,36 +484,65 @@ def leg_allpairs(e3d, synth, R, args, dev):
     if R.comm:
         out["comm"] = comm_report(R, steps, per_rank)
     # launches of the NN phase per iteration (search, row update, totals; the record counts launches of the timed kernels)
-    out["nn_launches_per_iter"] = {"certify": tot[11] / R.world / steps, "bounded": tot[14] / R.world / steps, "rows": tot[17] / R.world / steps}
+    out["nn_launches_per_iter"] = {"certify": tot[11] / R.world / steps, "bounded": tot[14] / R.world / steps, "rows": tot[17] / R.world / steps,
+                                   "row_update": sum(r["nn_update_launches"] for r in recs) / steps, "all_kernels": sum(r["nn_kernel_launches"] for r in recs) / steps,
+                                   "batches": sum(r["nn_batches"] for r in recs) / steps, "radix_sorts": sum(r["nn_sort_calls"] for r in recs) / steps}
     del icp
     torch.cuda.empty_cache()
     if R.world == 1 and not args.no_scale_model:
-        # What one rank of an 8-GPU run does, MEASURED on this GPU: the same clouds, this handle as rank 0 of a world of 8 (its eighth of
-        # every directed pair's queries) with a no-op all-reduce.  Counts and sums are an eighth of the job's (the poses it reaches differ
-        # slightly from the real job's: the damping is additive), the launches, host round trips and per-pair fixed costs are those
-        # of a real rank -- everything but the collectives.  t1 / t8 bounds the 8-GPU speed-up from above; (8 t8 - t1) / 7 is the part
-        # of an iteration that does not divide by the number of GPUs.
+        # What one rank of an 8-GPU run does, MEASURED on this GPU.  (1) The job once more on one handle with a tap on its reductions
+        # (e3d_icp_set_shard with world 1: every buffer the library would all-reduce -- the per-pair counts of an iteration, the per-set
+        # sums of every LM pass -- passes through the callback; recorded).  (2) A handle as rank 0 of a world of 8 -- its eighth of
+        # every directed pair's queries -- whose all-reduce callback returns the recorded sums: it takes the decisions and reaches the
+        # poses of the real job bit for bit (checked), so its launches, host round trips, searches and LM passes are those of rank 0
+        # of a real 8-GPU run; only the collectives are missing.  t1 / t8 bounds the 8-GPU speed-up from above; (8 t8 - t1) / 7 is
+        # the part of an iteration that does not divide by the number of GPUs.
         W8 = args.scale_model_world
+        tape = []
+        icpA = e3d.PointToPlaneICP(device=R.local_rank)
+        for s in scans:
+            icpA.add_point_cloud(s["xyz"], s["normals"], s["T_init"], False)
+        icpA.set_shard(0, 1, lambda arr: tape.append(arr.copy()))
+        for it in range(warmup + steps):
+            icpA.run(d, it, 1, thr, False)
+        poses_a = [icpA.get_result_global_T_cloud(i) for i in range(S)]
+        del icpA
+        torch.cuda.empty_cache()
+        pos = [0]
+
+        def replay(arr):
+            a = tape[pos[0]]
+            if a.shape != arr.shape:
+                raise RuntimeError("scale model: reduction %d has %d values, the recorded one %d" % (pos[0], arr.size, a.size))
+            arr[:] = a
+            pos[0] += 1
         icp8 = e3d.PointToPlaneICP(device=R.local_rank)
         for s in scans:
             icp8.add_point_cloud(s["xyz"], s["normals"], s["T_init"], False)
-        icp8.set_shard(0, W8, lambda arr: None)
+        icp8.set_shard(0, W8, replay)
         for it in range(warmup):
             icp8.run(d, it, 1, thr, False)
+        icp8.clear_records()
         torch.cuda.synchronize()
         each8 = []
         for it in range(warmup, warmup + steps):
             t1 = time.perf_counter()
             icp8.run(d, it, 1, thr, False)
             each8.append((time.perf_counter() - t1) * 1e3)
+        same = all(np.array_equal(icp8.get_result_global_T_cloud(i), poses_a[i]) for i in range(S)) and pos[0] == len(tape)
+        rec8 = icp8.iter_records()
         t1_ms, t8_ms = float(np.mean(wall)), float(np.mean(each8))
         s1, s8 = float(np.mean(wall[first_steady:])), float(np.mean(each8[first_steady:]))
         out["scale_model"] = {"world": W8, "ms_per_iter_n1": t1_ms, "ms_per_iter_as_rank0_of_world": t8_ms, "ms_per_iter_each_as_rank0": each8,
                               "modelled_speedup": t1_ms / t8_ms, "non_dividing_ms_per_iter": (W8 * t8_ms - t1_ms) / (W8 - 1),
                               "steady": {"ms_per_iter_n1": s1, "ms_per_iter_as_rank0_of_world": s8, "modelled_speedup": s1 / s8,
                                          "non_dividing_ms_per_iter": (W8 * s8 - s1) / (W8 - 1)},
-                              "note": "rank 0 of a world of %d with a no-op all-reduce, measured on this GPU: an upper bound of the speed-up "
-                                      "(no collective time, no skew between ranks)" % W8}
+                              "poses_equal_single_gpu_run": bool(same),
+                              "last_iteration_as_rank0": step_breakdown(dict(rec8[-1], wall_ms=each8[-1])),
+                              "last_iteration_n1": step_breakdown(recs[-1]),
+                              "nn_kernel_launches_per_iter_as_rank0": float(np.mean([r["nn_kernel_launches"] for r in rec8])),
+                              "note": "rank 0 of a world of %d on this GPU, fed the recorded reductions of the single-GPU run (same decisions, same poses): "
+                                      "an upper bound of the speed-up (no collective time, no skew between ranks)" % W8}
         del icp8
         torch.cuda.empty_cache()
     del scans
@@ -895,7 +926,8 @@ def compact_line(d, detail_path="bench_detail.json"):
         if sm:
             la["scale_model"] = {"world": sm["world"], "ms_per_iter_n1": _r(sm["ms_per_iter_n1"]), "ms_per_iter_as_rank0_of_world": _r(sm["ms_per_iter_as_rank0_of_world"]),
                                  "modelled_speedup": _r(sm["modelled_speedup"]), "non_dividing_ms_per_iter": _r(sm["non_dividing_ms_per_iter"]),
-                                 "steady_modelled_speedup": _r(sm["steady"]["modelled_speedup"]), "steady_non_dividing_ms_per_iter": _r(sm["steady"]["non_dividing_ms_per_iter"])}
+                                 "steady_modelled_speedup": _r(sm["steady"]["modelled_speedup"]), "steady_non_dividing_ms_per_iter": _r(sm["steady"]["non_dividing_ms_per_iter"]),
+                                 "poses_equal_single_gpu_run": sm.get("poses_equal_single_gpu_run")}
         if "comm" in a:
             la["comm"] = {k: _r(a["comm"][k]) for k in ("allreduce_calls_per_iter", "allreduce_ms_per_iter_max_over_ranks", "allreduce_ms_per_iter_min_over_ranks") if k in a["comm"]}
         legs["allpairs"] = la

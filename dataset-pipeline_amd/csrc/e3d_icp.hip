@@ -184,6 +184,10 @@ struct e3d_icp {
   struct PairSlot { DevBuf<float> match_d2; DevBuf<unsigned> todo_near, todo_far; };
   std::vector<std::unique_ptr<PairSlot>> slots;
   PinBuf<unsigned> h_todo_all;
+  DevBuf<unsigned> d_todo_all;                  // list lengths of a batch (two words per pair), cleared once per batch
+  PinBuf<NnBatchDev> h_batch;                   // the pair table of find_pairs_multi
+  DevBuf<NnBatchDev> d_batch;
+  DevBuf<unsigned> chunk_rewritten;
   DevBuf<unsigned long long> d_totals_all;
   DevBuf<double> d_d2_all;
   PinBuf<unsigned long long> h_totals_all;
@@ -600,7 +604,7 @@ static void find_pair(e3d_icp* h, Cloud& src, Cloud& tgt, float d, PairJob& job,
       copy_out(h->h_todo.p, ps.todo_count.p, 2 * sizeof(unsigned), s);
       sync(h);
       { const double t = h->nn_timer_c->ms(); rec.t_nn_certify_ms += t; rec.t_nn_query_ms += t; }
-      rec.nn_certify_launches++; rec.nn_certify_queries += (long long)n;
+      rec.nn_certify_launches++; rec.nn_certify_queries += (long long)n; rec.nn_kernel_launches++;
       n_near = h->h_todo.p[0]; n_far = h->h_todo.p[1];
       h->tm_bounded.start(s);                             // (read lazily: timing the bounded search costs no synchronisation)
       list = h->todo_far.p;
@@ -626,14 +630,14 @@ static void find_pair(e3d_icp* h, Cloud& src, Cloud& tgt, float d, PairJob& job,
         n_near += n_far; n_far = 0;
       }
       h->tm_bounded.stop(s);
-      if (n_near > 0) { rec.nn_bounded_launches++; rec.nn_bounded_queries += (long long)n_near; }
+      if (n_near > 0) { rec.nn_bounded_launches++; rec.nn_bounded_queries += (long long)n_near; rec.nn_kernel_launches++; }
     }
-    if (n_far > 0) { NnPhase ph(s, 1); sort_query_keys(h, tgt, srcG, list, n_far, im); }
+    if (n_far > 0) { NnPhase ph(s, 1); sort_query_keys(h, tgt, srcG, list, n_far, im); rec.nn_sort_calls++; rec.nn_kernel_launches++; }
     h->nn_timer->start(s);
     if (n_far > 0)
       launch_rows(3, tgt, srcG, h->vals_b.p, n_far, im, radius_sq(d), cert, ps.match.p, h->match_d2.p, ps.lbe.p, ps.match2.p, s);
     ps.fresh = false;
-    if (n_far > 0) { rec.nn_search_launches++; rec.nn_search_queries += (long long)n_far; }
+    if (n_far > 0) { rec.nn_search_launches++; rec.nn_search_queries += (long long)n_far; rec.nn_kernel_launches++; }
     if (want_stats)
       fprintf(stderr, "[nn %d->%d] queries %zu bounded %zu rows %zu cum %.3g (last %.3g) err %.3g\n", job.src, job.tgt, n,
               n_near, n_far, cum_pair, src.last_motion + tgt.last_motion, src.err_max + tgt.err_max);
@@ -653,11 +657,11 @@ static void find_pair(e3d_icp* h, Cloud& src, Cloud& tgt, float d, PairJob& job,
                       h->match_pos.p, h->match_d2.p, s);
     }
     order = source_order ? nullptr : h->vals_b.p;
-    rec.nn_search_launches++; rec.nn_search_queries += (long long)n;
+    rec.nn_search_launches++; rec.nn_search_queries += (long long)n; rec.nn_kernel_launches += 2; rec.nn_sort_calls++;
   } else {
     h->match_pos.reserve(n);
     match_pos = h->match_pos.p;
-    rec.nn_search_launches++; rec.nn_search_queries += (long long)n;
+    rec.nn_search_launches++; rec.nn_search_queries += (long long)n; rec.nn_kernel_launches++;
     h->nn_timer->start(s);
     launch_nn_query(srcG, n, tgt.G4.p, tgt.table.p, tgt.grid, make_invmap(tgt), radius_sq(d), h->match_pos.p,
                     h->match_d2.p, s);
@@ -698,12 +702,14 @@ static void find_pair(e3d_icp* h, Cloud& src, Cloud& tgt, float d, PairJob& job,
     launch_corr_totals(n, h->block_counts.p, h->block_d2.p, h->block_groups.p, h->chunk_sum.p, h->chunk_d2.p, h->chunk_groups.p,
                        h->d_total.p, h->d_total_d2.p, ps.glist.p, s);
     h->tm_scan.stop(s);
+    rec.nn_update_launches++; rec.nn_kernel_launches += 4;
     copy_out(h->h_total.p + 1, h->d_total.p + 1, 2 * sizeof(unsigned long long), s);
   } else {
   h->tm_scan.start(s);
   launch_match_scan(match_pos, h->match_d2.p, n, h->block_counts.p, h->block_offsets.p, h->block_d2.p,
                     h->chunk_sum.p, h->chunk_d2.p, h->d_total.p, h->d_total_d2.p, s);
   h->tm_scan.stop(s);
+  rec.nn_kernel_launches += 4;
   }
   copy_out(h->h_total.p, h->d_total.p, sizeof(unsigned long long), s);
   copy_out(h->h_total_d2.p, h->d_total_d2.p, sizeof(double), s);
@@ -740,6 +746,7 @@ static void find_pair(e3d_icp* h, Cloud& src, Cloud& tgt, float d, PairJob& job,
                       to_affine(src.T), tgt.G4.p, tgt.LN.p, to_affine(tgt.T), h->cA.p, h->cB.p, h->cC.p,
                       h->corr_used, s);   // the merged fixed cloud keeps T = identity (exact)
   h->tm_compact.stop(s);
+  rec.nn_update_launches++; rec.nn_kernel_launches++;
   h->corr_used = need;
   rec.corr_rows_rewritten += job.count;
   rec.corr_rows_walked += job.count;
@@ -758,6 +765,8 @@ struct BatchItem {
   bool certified = false; size_t n_near = 0, n_far = 0;
 };
 static constexpr size_t kPairBatch = 32;
+// queries of a batch: its scratch (squared distances, two todo lists) is 12 B per query, 3 GB at most -- whatever the clouds' size
+static constexpr size_t kBatchQueries = (size_t)256 << 20;
 
 static void find_pairs_batched(e3d_icp* h, std::vector<BatchItem>& items, float d, e3d_icp_iter_record& rec) {
   hipStream_t s = h->stream;
@@ -799,7 +808,7 @@ static void find_pairs_batched(e3d_icp* h, std::vector<BatchItem>& items, float 
                       sl.todo_far.p, ps.todo_count.p, s);
     h->tm_certify.stop(s);
     copy_out(h->h_todo_all.p + 2 * i, ps.todo_count.p, 2 * sizeof(unsigned), s);
-    rec.nn_certify_launches++; rec.nn_certify_queries += (long long)it.n;
+    rec.nn_certify_launches++; rec.nn_certify_queries += (long long)it.n; rec.nn_kernel_launches++;
     double smin = min_singular_value_3x3(tgt.T);
     if (!(smin > 1e-12)) smin = 1e-12;
     double m_local = 0;
@@ -835,9 +844,10 @@ static void find_pairs_batched(e3d_icp* h, std::vector<BatchItem>& items, float 
         it.n_near += it.n_far; it.n_far = 0;
       }
       h->tm_bounded.stop(s);
-      if (it.n_near > 0) { rec.nn_bounded_launches++; rec.nn_bounded_queries += (long long)it.n_near; }
+      if (it.n_near > 0) { rec.nn_bounded_launches++; rec.nn_bounded_queries += (long long)it.n_near; rec.nn_kernel_launches++; }
     }
     if (it.n_far > 0) {
+      rec.nn_sort_calls++; rec.nn_kernel_launches += 2;
       sort_query_keys(h, tgt, srcG, list, it.n_far, it.im);
       h->tm_search.start(s);
       launch_rows(3, tgt, srcG, h->vals_b.p, it.n_far, it.im, radius_sq(d), it.cert, ps.match.p, sl.match_d2.p, ps.lbe.p, ps.match2.p, s);
@@ -875,6 +885,7 @@ static void find_pairs_batched(e3d_icp* h, std::vector<BatchItem>& items, float 
     launch_corr_totals(n, h->block_counts.p, h->block_d2.p, h->block_groups.p, h->chunk_sum.p, h->chunk_d2.p, h->chunk_groups.p,
                        h->d_totals_all.p + 3 * i, h->d_d2_all.p + i, ps.glist.p, s);
     h->tm_scan.stop(s);
+    rec.nn_update_launches++; rec.nn_kernel_launches += 4;
   }
   copy_out(h->h_totals_all.p, h->d_totals_all.p, sizeof(unsigned long long) * 3 * B, s);
   copy_out(h->h_d2_all.p, h->d_d2_all.p, sizeof(double) * B, s);
@@ -890,6 +901,170 @@ static void find_pairs_batched(e3d_icp* h, std::vector<BatchItem>& items, float 
     rec.queries += (long long)it.n;
     rec.correspondences += it.job->count;
   }
+}
+
+// The same batch with ONE launch per kernel (round 5): the batch's pairs go into a device table (NnBatchDev) and k_nn_certify_multi,
+// k_nn_bounded_half_multi, k_corr_update_multi and the three kernels of the totals walk it -- 7 launches and two host round trips per
+// batch where find_pairs_batched issues ~8 launches per PAIR.  Same kernels bodies on the same data: counts, distances, rows and group
+// lists are those of find_pair bit for bit (tests/test_gpu_switches.py, E3D_ICP_BATCH=1 / 0).  A pair's far list that is too long for
+// the bounded search (the first outer iterations) is still sorted and searched by k_nn_rows pair by pair.  Needs the half-cell
+// directory of every target of the batch (dense scans have it); returns false otherwise and the caller takes find_pairs_batched.
+static bool find_pairs_multi(e3d_icp* h, std::vector<BatchItem>& items, float d, e3d_icp_iter_record& rec) {
+  hipStream_t s = h->stream;
+  const size_t B = items.size();
+  for (const BatchItem& it : items) if (!it.tgt->has_half || h->nn_mode == 5) return false;
+  static const bool use_cert = [] { const char* e = getenv("E3D_NN_CERT"); return !(e && e[0] == '0'); }();
+  static const bool want_stats = [] { const char* e = getenv("E3D_NN_STATS"); return e && e[0] == '1'; }();
+  static const double margin_frac = env_double("E3D_NN_MARGIN", 0.08), near_frac = env_double("E3D_NN_NEAR", 0.4);   // of the radius
+  static const double np_frac = env_double("E3D_NN_NP_EXTRA", 0.5), np_gate = env_double("E3D_NN_NP_GATE", 0.2);   // of the radius
+  while (h->slots.size() < B) h->slots.emplace_back(new e3d_icp::PairSlot());
+  h->h_todo_all.reserve(2 * kPairBatch); h->d_todo_all.reserve(2 * kPairBatch);
+  h->d_totals_all.reserve(3 * kPairBatch); h->d_d2_all.reserve(kPairBatch); h->h_totals_all.reserve(3 * kPairBatch); h->h_d2_all.reserve(kPairBatch);
+  h->h_batch.reserve(1); h->d_batch.reserve(1);
+  NnBatchDev& T = h->h_batch.p[0];
+  static_assert(kPairBatch <= (size_t)kNnBatchPairs, "pair table too small");
+  T.n_pairs = (int)B; T.n_jobs = 0;
+  // ---- phase A: the table, the rows' validity, the certificates ----------------------------------------------------------------
+  unsigned cert_blocks = 0, upd_blocks = 0, chunks = 0;
+  long long cert_queries = 0;
+  E3D_HIP(hipMemsetAsync(h->d_todo_all.p, 0, 2 * sizeof(unsigned) * B, s));
+  for (size_t i = 0; i < B; ++i) {
+    BatchItem& it = items[i];
+    e3d_icp::PairSlot& sl = *h->slots[i];
+    Cloud& src = *it.src; Cloud& tgt = *it.tgt;
+    PairState& ps = *it.ps;
+    const size_t n = it.n;
+    sl.match_d2.reserve(n); sl.todo_near.reserve(n); sl.todo_far.reserve(n);
+    it.im = make_invmap(tgt);
+    it.cum_pair = src.cum_motion + tgt.cum_motion;
+    it.cert = make_cert_params(tgt, it.cum_pair);
+    it.n_far = n; it.n_near = 0;
+    it.certified = !ps.fresh && use_cert;
+    const bool none_near = np_frac > 0 && (src.last_motion + tgt.last_motion) < np_gate * (double)d;
+    double smin = min_singular_value_3x3(tgt.T);
+    if (!(smin > 1e-12)) smin = 1e-12;
+    double m_local = 0;
+    for (int k = 0; k < 3; ++k) m_local = std::max(m_local, std::max(std::fabs((double)tgt.lmin[k]), std::fabs((double)tgt.lmax[k])));
+    it.bp.margin = (float)(margin_frac * (double)d);
+    it.bp.rho_scale = round_up_f((1.0 + 1e-5) / smin);
+    it.bp.rho_pad = round_up_f(2.0 * tgt.build_slack + 8.0 * FLT_EPSILON * m_local);
+    it.bp.cum_lo = it.cert.cum_lo;
+    it.bp.cell_scale = it.cert.cell_scale; it.bp.cell_sub = it.cert.cell_sub;
+    it.bp.np_extra = none_near ? (float)(np_frac * (double)d) : 0.f;
+    // resident rows (see find_pair)
+    const size_t cap = resident_rows_cap(n);
+    const bool sg = src.fixed || src.cloud_index == 0, tg = tgt.fixed || tgt.cloud_index == 0;
+    bool valid = ps.rows_valid && ps.pA.cap >= cap && ps.src_global == sg && ps.tgt_global == tg;
+    if (valid && sg && std::memcmp(ps.src_T, src.T, sizeof ps.src_T) != 0) valid = false;
+    if (valid && tg && std::memcmp(ps.tgt_T, tgt.T, sizeof ps.tgt_T) != 0) valid = false;
+    if (!valid) {
+      ps.pA.reserve(cap); ps.pB.reserve(cap); ps.pC.reserve(cap); ps.plane_match.reserve(n); ps.glist.reserve(div_up(n, 64));
+      E3D_HIP(hipMemsetAsync(ps.plane_match.p, 0xFE, sizeof(int) * n, s));
+      if (cap > n) {
+        E3D_HIP(hipMemsetAsync(ps.pA.p + n, 0, sizeof(float4) * (cap - n), s));
+        E3D_HIP(hipMemsetAsync(ps.pB.p + n, 0, sizeof(float4) * (cap - n), s));
+        E3D_HIP(hipMemsetAsync(ps.pC.p + n, 0, sizeof(float4) * (cap - n), s));
+      }
+      ps.src_global = sg; ps.tgt_global = tg;
+      std::memcpy(ps.src_T, src.T, sizeof ps.src_T); std::memcpy(ps.tgt_T, tgt.T, sizeof ps.tgt_T);
+      ps.rows_valid = true;
+    }
+    NnPairDev& P = T.pair[i];
+    P.Gsrc = src.G4.p + it.j0; P.Gtgt = tgt.G4.p; P.S = tgt.dense_start.p; P.H8 = tgt.half_prefix.p;
+    P.match = ps.match.p; P.match2 = ps.match2.p; P.lbe = ps.lbe.p; P.match_d2 = sl.match_d2.p;
+    P.todo_near = sl.todo_near.p; P.todo_far = sl.todo_far.p; P.counts = h->d_todo_all.p + 2 * i;
+    P.n = (unsigned)n; P.none_near = none_near ? 1 : 0;
+    P.cum_up = round_up_f((it.cum_pair * (1.0 + 2e-6) + 2.0 * (src.err_max + tgt.err_max)) * (1.0 + 1e-6));
+    P.near2 = (float)((near_frac * (double)d) * (near_frac * (double)d));
+    P.g = tgt.grid; P.im = it.im; P.qr = tgt.qrange; P.bp = it.bp;
+    P.Psrc = (sg ? src.G4.p : src.L4.p) + it.j0; P.LNsrc = src.LN.p + it.j0; P.Ptgt = tg ? tgt.G4.p : tgt.L4.p; P.LNtgt = tgt.LN.p;
+    P.src_global = sg ? 1 : 0; P.tgt_global = tg ? 1 : 0; P.Tsrc = to_affine(src.T); P.Ttgt = to_affine(tgt.T);
+    P.A = ps.pA.p; P.B = ps.pB.p; P.C = ps.pC.p; P.plane_match = ps.plane_match.p; P.glist = ps.glist.p;
+    if (it.certified) { cert_blocks += (unsigned)div_up(n, (size_t)kNnCertBlockQueries); cert_queries += (long long)n; }
+    T.cert_end[i] = cert_blocks;
+    const unsigned nb = (unsigned)div_up(n, kBlock);
+    upd_blocks += nb; T.upd_end[i] = upd_blocks;
+    chunks += (unsigned)div_up((size_t)nb, (size_t)kNnScanChunk); T.chunk_end[i] = chunks;
+  }
+  h->block_counts.reserve(upd_blocks); h->block_d2.reserve(upd_blocks); h->block_groups.reserve(upd_blocks);
+  h->chunk_sum.reserve(chunks + 1); h->chunk_d2.reserve(chunks + 1); h->chunk_groups.reserve(chunks + 1); h->chunk_rewritten.reserve(chunks + 1);
+  E3D_HIP(hipMemcpyAsync(h->d_batch.p, h->h_batch.p, sizeof(NnBatchDev), hipMemcpyHostToDevice, s));
+  if (cert_blocks) {
+    h->tm_certify.start(s);
+    launch_nn_certify_multi(h->d_batch.p, cert_blocks, radius_sq(d), s);
+    h->tm_certify.stop(s);
+    rec.nn_certify_launches++; rec.nn_certify_queries += cert_queries; rec.nn_kernel_launches++;
+    copy_out(h->h_todo_all.p, h->d_todo_all.p, 2 * sizeof(unsigned) * B, s);
+  }
+  sync(h);
+  // ---- phase B: the bounded searches as list jobs of ONE launch, long far lists pair by pair, row update, totals ----------------
+  unsigned job_blocks = 0;
+  long long job_queries = 0;
+  for (size_t i = 0; i < B; ++i) {
+    BatchItem& it = items[i];
+    if (!it.certified) continue;
+    e3d_icp::PairSlot& sl = *h->slots[i];
+    it.n_near = h->h_todo_all.p[2 * i]; it.n_far = h->h_todo_all.p[2 * i + 1];
+    auto add_job = [&](const unsigned* list, size_t n_list) {
+      if (!n_list) return;
+      const int jb = T.n_jobs++;
+      T.job_pair[jb] = (int)i; T.job_list[jb] = list; T.job_n[jb] = (unsigned)n_list;
+      job_blocks += (unsigned)div_up(n_list, kBlock); T.job_end[jb] = job_blocks;
+      job_queries += (long long)n_list;
+    };
+    add_job(sl.todo_near.p, it.n_near);
+    if (it.n_far > 0 && it.n_far * 32 < it.n) {               // (few queries without a near partner: see find_pair)
+      add_job(sl.todo_far.p, it.n_far);
+      it.n_near += it.n_far; it.n_far = 0;
+    }
+  }
+  if (T.n_jobs > 0) {
+    E3D_HIP(hipMemcpyAsync(h->d_batch.p, h->h_batch.p, sizeof(NnBatchDev), hipMemcpyHostToDevice, s));
+    h->tm_bounded.start(s);
+    launch_nn_bounded_half_multi(h->d_batch.p, job_blocks, radius_sq(d), s);
+    h->tm_bounded.stop(s);
+    rec.nn_bounded_launches++; rec.nn_bounded_queries += job_queries; rec.nn_kernel_launches++;
+  }
+  for (size_t i = 0; i < B; ++i) {
+    BatchItem& it = items[i];
+    PairState& ps = *it.ps;
+    if (it.n_far > 0) {
+      e3d_icp::PairSlot& sl = *h->slots[i];
+      const float4* srcG = it.src->G4.p + it.j0;
+      sort_query_keys(h, *it.tgt, srcG, it.certified ? sl.todo_far.p : nullptr, it.n_far, it.im);
+      h->tm_search.start(s);
+      launch_rows(3, *it.tgt, srcG, h->vals_b.p, it.n_far, it.im, radius_sq(d), it.cert, ps.match.p, sl.match_d2.p, ps.lbe.p, ps.match2.p, s);
+      h->tm_search.stop(s);
+      rec.nn_search_launches++; rec.nn_search_queries += (long long)it.n_far; rec.nn_kernel_launches += 2; rec.nn_sort_calls++;
+    }
+    ps.fresh = false;
+    if (want_stats)
+      fprintf(stderr, "[nn %d->%d] queries %zu bounded %zu rows %zu cum %.3g (last %.3g) err %.3g\n", it.job->src, it.job->tgt, it.n, it.n_near, it.n_far,
+              it.cum_pair, it.src->last_motion + it.tgt->last_motion, it.src->err_max + it.tgt->err_max);
+  }
+  h->tm_compact.start(s);
+  launch_corr_update_multi(h->d_batch.p, upd_blocks, h->block_counts.p, h->block_d2.p, h->block_groups.p, s);
+  h->tm_compact.stop(s);
+  h->tm_scan.start(s);
+  launch_corr_totals_multi(h->d_batch.p, (int)B, chunks, h->block_counts.p, h->block_d2.p, h->block_groups.p, h->chunk_sum.p, h->chunk_d2.p, h->chunk_groups.p,
+                           h->chunk_rewritten.p, h->d_totals_all.p, h->d_d2_all.p, s);
+  h->tm_scan.stop(s);
+  rec.nn_update_launches++; rec.nn_kernel_launches += 4; rec.nn_batches++;
+  copy_out(h->h_totals_all.p, h->d_totals_all.p, sizeof(unsigned long long) * 3 * B, s);
+  copy_out(h->h_d2_all.p, h->d_d2_all.p, sizeof(double) * B, s);
+  sync(h);
+  for (size_t i = 0; i < B; ++i) {
+    BatchItem& it = items[i];
+    it.job->count = (long long)h->h_totals_all.p[3 * i];
+    it.job->dsum = h->h_d2_all.p[i];
+    it.job->resident = it.ps;
+    it.job->vrows = 64 * (long long)h->h_totals_all.p[3 * i + 1];
+    rec.corr_rows_rewritten += (long long)h->h_totals_all.p[3 * i + 2];
+    rec.corr_rows_walked += it.job->vrows;
+    rec.queries += (long long)it.n;
+    rec.correspondences += it.job->count;
+  }
+  return true;
 }
 
 // number of LM blocks for a set of n correspondences in a system of n_sets sets (deterministic function of the two).  Every
@@ -909,7 +1084,9 @@ static int lm_blocks_for(long long n, int n_sets = 1) {
   return (int)b;
 }
 
-static bool sharded(const e3d_icp* h) { return h->comm != nullptr || h->world > 1; }
+// (a callback with world == 1 is a tap: the "reduction" over one rank still passes every buffer through it -- bench.py records the
+// sums of a single-GPU run that way and replays them to a handle working as rank 0 of a larger world)
+static bool sharded(const e3d_icp* h) { return h->comm != nullptr || h->world > 1 || h->allreduce != nullptr; }
 
 // sum of the per-set results (n doubles, already reduced over this rank's blocks) over the ranks: in place in HBM on the
 // handle's stream with the native communicator; the host copy follows either way
@@ -919,7 +1096,7 @@ static void reduce_setsums(e3d_icp* h, int ns) {
   if (h->comm) comm_allreduce_f64(h->comm, h->d_setsum.p, n, s);
   copy_out(h->h_setsum.p, h->d_setsum.p, sizeof(double) * n, s);
   sync(h);
-  if (!h->comm && h->world > 1) {
+  if (!h->comm && h->allreduce) {
     if (h->allreduce(h->h_setsum.p, n, h->allreduce_user) != 0) throw Error(E3D_ERR_INVALID, "allreduce callback failed");
   }
 }
@@ -1278,7 +1455,7 @@ static bool align_meshes(e3d_icp* h, float max_d, float thr, bool print, int ite
       size_t free_b = 0, total_b = 0, q_max = 0;
       (void)hipMemGetInfo(&free_b, &total_b);
       for (const PairJob& j : jobs) q_max = std::max(q_max, slice_len((j.src == M) ? *h->fixed : *h->clouds[j.src]));
-      const double extra = 12.0 * (double)std::min<size_t>(q_max * kPairBatch, (size_t)64 << 20) + 40.0 * (double)q_max;
+      const double extra = 12.0 * (double)std::min<size_t>(q_max * kPairBatch, kBatchQueries) + 40.0 * (double)q_max;
       if ((double)rows_new + extra > 0.8 * (double)free_b) resident = false;
     }
     if (resident) {
@@ -1332,8 +1509,15 @@ static bool align_meshes(e3d_icp* h, float max_d, float thr, bool print, int ite
     // every other pair (sparse targets, forced kernel modes, compacted rows, the sequential distance sum) one by one.
     static const bool batching = [] { const char* e = getenv("E3D_ICP_BATCH"); return !(e && e[0] == '0'); }();
     std::vector<BatchItem> batch;
-    size_t batch_queries = 0;                               // a batch's scratch is 12 B per query: bounded (768 MB), whatever the clouds' size
-    auto flush = [&]() { if (!batch.empty()) { find_pairs_batched(h, batch, max_d, rec); batch.clear(); batch_queries = 0; } };
+    size_t batch_queries = 0;                               // (kBatchQueries bounds a batch's scratch)
+    // E3D_ICP_BATCH: 2 (default) one launch per kernel and batch (find_pairs_multi), 1 one launch per kernel and pair with the host
+    // round trips batched (find_pairs_batched), 0 pair by pair (find_pair)
+    static const int batch_mode = [] { const char* e = getenv("E3D_ICP_BATCH"); return e ? atoi(e) : 2; }();
+    auto flush = [&]() {
+      if (batch.empty()) return;
+      if (!(batch_mode >= 2 && find_pairs_multi(h, batch, max_d, rec))) find_pairs_batched(h, batch, max_d, rec);
+      batch.clear(); batch_queries = 0;
+    };
     for (size_t p = 0; p < jobs.size(); ++p) {
       PairJob& j = jobs[p];
       Cloud& src = (j.src == M) ? *h->fixed : *h->clouds[j.src];
@@ -1341,13 +1525,13 @@ static bool align_meshes(e3d_icp* h, float max_d, float thr, bool print, int ite
       // this rank's slice of the source cloud (cell order); world == 1 => the whole cloud
       const size_t j0 = (size_t)((unsigned __int128)src.n * (unsigned)h->rank / (unsigned)h->world);
       const size_t j1 = (size_t)((unsigned __int128)src.n * (unsigned)(h->rank + 1) / (unsigned)h->world);
-      const bool whole = !sharded(h) && (j1 - j0) == src.n;
+      const bool whole = !h->comm && h->world <= 1 && (j1 - j0) == src.n;
       if (batching && !nn_profile() && h->resident_now && pair_uses_rows(h, tgt) && j1 > j0 && tgt.n > 0 && !(h->sequential_dsum && whole)) {
         j.count = 0; j.dsum = 0.0; j.corr_off = h->corr_used;
         BatchItem it{};
         it.job = &j; it.src = &src; it.tgt = &tgt; it.j0 = j0; it.n = j1 - j0;
         it.ps = &pair_state_for(h, j.src, j.tgt, src, tgt, j0, j1 - j0);
-        if (batch_queries + it.n > ((size_t)64 << 20)) flush();
+        if (batch_queries + it.n > kBatchQueries) flush();
         batch.push_back(it);
         batch_queries += it.n;
         if (batch.size() == kPairBatch) flush();

@@ -1129,17 +1129,19 @@ constexpr int kCertPerWave = 512;          // consecutive queries per wave (8 st
 // Lists: todo_near = queries whose old partner is within sqrt(near2) (searched by k_nn_bounded: only the cells the ball of that
 // distance touches), todo_far = all others (no partner, or a far one: sorted by target cell and searched by k_nn_rows).
 // counts[0] / counts[1] = list lengths.
+// (bx: the block's index among the blocks of ITS pair -- blockIdx.x for the one-pair kernel, the offset inside the pair's block range
+// for the kernel that walks a batch of pairs, k_nn_certify_multi)
 template <int kCertUnroll>
-__global__ __launch_bounds__(kBlock) void k_nn_certify(const float4* __restrict__ Gsrc, size_t n, const float4* __restrict__ Gtgt,
-                                                       float cum_up, float r2, float near2, int none_near, int* __restrict__ match,
-                                                       int* __restrict__ match2, const float* __restrict__ lbe,
-                                                       float* __restrict__ match_d2, unsigned* __restrict__ todo_near,
-                                                       unsigned* __restrict__ todo_far, unsigned* __restrict__ counts) {
+__device__ __forceinline__ void nn_certify_body(const unsigned bx, const float4* __restrict__ Gsrc, size_t n, const float4* __restrict__ Gtgt,
+                                                float cum_up, float r2, float near2, int none_near, int* __restrict__ match,
+                                                int* __restrict__ match2, const float* __restrict__ lbe,
+                                                float* __restrict__ match_d2, unsigned* __restrict__ todo_near,
+                                                unsigned* __restrict__ todo_far, unsigned* __restrict__ counts) {
   __shared__ unsigned s_list[2][kBlock / kWave][kCertPerWave];
   __shared__ unsigned s_cnt[2][kBlock / kWave];
   __shared__ unsigned s_base[2];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const size_t j0 = ((size_t)blockIdx.x * (kBlock / kWave) + (size_t)w) * kCertPerWave;
+  const size_t j0 = ((size_t)bx * (kBlock / kWave) + (size_t)w) * kCertPerWave;
   unsigned cn = 0, cf = 0;                                     // wave-uniform
   // kCertUnroll steps at a time: the state words, the queries and the partner gathers of all of them are requested before any
   // is evaluated (the kernel is a chain match[j] -> Gtgt[m] per query; kCertUnroll chains in flight per lane)
@@ -1215,6 +1217,38 @@ __global__ __launch_bounds__(kBlock) void k_nn_certify(const float4* __restrict_
   for (int k = 0; k < w; ++k) { bn += s_cnt[0][k]; bf += s_cnt[1][k]; }
   for (unsigned i = (unsigned)lane; i < cn; i += kWave) todo_near[bn + i] = s_list[0][w][i];
   for (unsigned i = (unsigned)lane; i < cf; i += kWave) todo_far[bf + i] = s_list[1][w][i];
+}
+
+template <int kCertUnroll>
+__global__ __launch_bounds__(kBlock) void k_nn_certify(const float4* __restrict__ Gsrc, size_t n, const float4* __restrict__ Gtgt,
+                                                       float cum_up, float r2, float near2, int none_near, int* __restrict__ match,
+                                                       int* __restrict__ match2, const float* __restrict__ lbe,
+                                                       float* __restrict__ match_d2, unsigned* __restrict__ todo_near,
+                                                       unsigned* __restrict__ todo_far, unsigned* __restrict__ counts) {
+  nn_certify_body<kCertUnroll>(blockIdx.x, Gsrc, n, Gtgt, cum_up, r2, near2, none_near, match, match2, lbe, match_d2, todo_near, todo_far, counts);
+}
+
+// ---- a BATCH of directed pairs per launch (round 5) ---------------------------------------------------------------------------
+// An all-pairs job runs the certificate search of 240 directed pairs per outer iteration: with one launch per pair and kernel that is
+// ~2000 launches of 0.04 - 0.1 ms each, a cost that does not shrink when the job is spread over more GPUs (a rank's slices get
+// shorter, its launches do not get fewer).  The kernels below walk a table of pairs instead: a block finds its pair from the
+// exclusive ends of the pairs' block ranges (at most kNnBatchPairs words, block-uniform: scalar loads and compares) and runs the
+// one-pair body on that pair's pointers and constants -- the same code, so the same bits.
+__device__ __forceinline__ int nn_find_range(const unsigned* __restrict__ ends, int n, unsigned b) {
+  int lo = 0, hi = n - 1;                                   // first index with b < ends[index]
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (b < ends[mid]) hi = mid; else lo = mid + 1;
+  }
+  return __builtin_amdgcn_readfirstlane(lo);
+}
+
+__global__ __launch_bounds__(kBlock) void k_nn_certify_multi(const NnBatchDev* __restrict__ B, float r2) {
+  const int p = nn_find_range(B->cert_end, B->n_pairs, blockIdx.x);
+  const unsigned bx = blockIdx.x - (p ? B->cert_end[p - 1] : 0u);
+  const NnPairDev& P = B->pair[p];
+  nn_certify_body<4>(bx, P.Gsrc, (size_t)P.n, P.Gtgt, P.cum_up, r2, P.near2, P.none_near, P.match, P.match2, P.lbe, P.match_d2,
+                     P.todo_near, P.todo_far, P.counts);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -1384,16 +1418,16 @@ constexpr int kHalfRuns = 18;     // run-list slots per lane in LDS: the 3 x 3 x
 // 8.8 / 6.8 / 4.5 / 4.0; a 14-slot list at 64 VGPRs (eight blocks, 7 - 13 spilled registers) 11.6 / 8.9 / 6.2 / 5.4: the queries
 // whose box touches more sub-rows than slots pay whole-cell rows.
 template <int BATCH>
-__global__ __launch_bounds__(kBlock) void k_nn_bounded_half(const float4* __restrict__ Gsrc, const unsigned* __restrict__ list,
-                                                            unsigned n_list, const float4* __restrict__ Gtgt, const unsigned* __restrict__ S,
-                                                            const unsigned long long* __restrict__ H8,
-                                                            GridDesc g, InvMap im, QueryRange qr, float r2, BoundParams bp,
-                                                            int* __restrict__ match, int* __restrict__ match2,
-                                                            float* __restrict__ match_d2, float* __restrict__ lbe) {
+__device__ __forceinline__ void nn_bounded_half_body(const unsigned bx, const float4* __restrict__ Gsrc, const unsigned* __restrict__ list,
+                                                     unsigned n_list, const float4* __restrict__ Gtgt, const unsigned* __restrict__ S,
+                                                     const unsigned long long* __restrict__ H8,
+                                                     const GridDesc& g, const InvMap& im, const QueryRange& qr, float r2, const BoundParams& bp,
+                                                     int* __restrict__ match, int* __restrict__ match2,
+                                                     float* __restrict__ match_d2, float* __restrict__ lbe) {
   // per lane: the non-empty candidate runs of its box, a 4-byte start and ONE length byte each
   __shared__ unsigned s_runs[kHalfRuns][kBlock];
   __shared__ unsigned char s_len[kHalfRuns][kBlock];
-  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned i = bx * blockDim.x + threadIdx.x;
   if (i >= n_list) return;
   const unsigned j = list[i];
   const float4 q = Gsrc[j];
@@ -1603,6 +1637,28 @@ __global__ __launch_bounds__(kBlock) void k_nn_bounded_half(const float4* __rest
   lbe[j] = sqrtf(fminf(others2, cover_all2)) * 0.999999f + bp.cum_lo;
 }
 
+template <int BATCH>
+__global__ __launch_bounds__(kBlock) void k_nn_bounded_half(const float4* __restrict__ Gsrc, const unsigned* __restrict__ list,
+                                                            unsigned n_list, const float4* __restrict__ Gtgt, const unsigned* __restrict__ S,
+                                                            const unsigned long long* __restrict__ H8,
+                                                            GridDesc g, InvMap im, QueryRange qr, float r2, BoundParams bp,
+                                                            int* __restrict__ match, int* __restrict__ match2,
+                                                            float* __restrict__ match_d2, float* __restrict__ lbe) {
+  nn_bounded_half_body<BATCH>(blockIdx.x, Gsrc, list, n_list, Gtgt, S, H8, g, im, qr, r2, bp, match, match2, match_d2, lbe);
+}
+
+// the listed queries of a batch of pairs: one job per (pair, list) -- the near list and, when it is short, the far list of a pair
+// are disjoint sets of queries and run side by side
+__global__ __launch_bounds__(kBlock) void k_nn_bounded_half_multi(const NnBatchDev* __restrict__ B, float r2) {
+  const int jb = nn_find_range(B->job_end, B->n_jobs, blockIdx.x);
+  const unsigned bx = blockIdx.x - (jb ? B->job_end[jb - 1] : 0u);
+  const int p = __builtin_amdgcn_readfirstlane(B->job_pair[jb]);
+  const NnPairDev& P = B->pair[p];
+  const GridDesc g = P.g; const InvMap im = P.im; const QueryRange qr = P.qr; const BoundParams bp = P.bp;      // (block-uniform: scalar registers)
+  nn_bounded_half_body<8>(bx, P.Gsrc, B->job_list[jb], B->job_n[jb], P.Gtgt, P.S, P.H8, g, im, qr, r2, bp, P.match, P.match2,
+                          P.match_d2, P.lbe);
+}
+
 // flags -> per-block counts (first stage of the order-preserving compaction)
 __global__ __launch_bounds__(kBlock) void k_match_block_counts(const int* __restrict__ match_pos, size_t n,
                                                                unsigned* __restrict__ block_counts,
@@ -1627,14 +1683,14 @@ __global__ __launch_bounds__(kBlock) void k_match_block_counts(const int* __rest
 // exclusive scan of the per-block counts in three small steps: chunk sums (kScanChunk entries per chunk),
 // single-block scan of the chunk sums, per-chunk scan with its base.
 constexpr int kScanChunk = 256;
-__global__ __launch_bounds__(kScanChunk) void k_scan_chunk_sums(const unsigned* __restrict__ counts, int nblocks,
-                                                                const double* __restrict__ block_d2,
-                                                                unsigned long long* __restrict__ chunk_sum,
-                                                                double* __restrict__ chunk_d2,
-                                                                const unsigned* __restrict__ groups = nullptr,
-                                                                unsigned* __restrict__ chunk_groups = nullptr,
-                                                                unsigned* __restrict__ chunk_rewritten = nullptr) {
-  const int b = blockIdx.x * kScanChunk + threadIdx.x;
+__device__ __forceinline__ void scan_chunk_sums_body(const unsigned bx, const unsigned* __restrict__ counts, int nblocks,
+                                                     const double* __restrict__ block_d2,
+                                                     unsigned long long* __restrict__ chunk_sum,
+                                                     double* __restrict__ chunk_d2,
+                                                     const unsigned* __restrict__ groups,
+                                                     unsigned* __restrict__ chunk_groups,
+                                                     unsigned* __restrict__ chunk_rewritten) {
+  const int b = (int)bx * kScanChunk + threadIdx.x;
   unsigned long long c = (b < nblocks) ? counts[b] : 0ull;
   double d = (b < nblocks) ? block_d2[b] : 0.0;
   const unsigned gw = (groups && b < nblocks) ? groups[b] : 0u;
@@ -1649,15 +1705,25 @@ __global__ __launch_bounds__(kScanChunk) void k_scan_chunk_sums(const unsigned* 
   if (threadIdx.x == 0) {
     unsigned long long t = 0; double td = 0; unsigned tg = 0, tr = 0;
     for (int k = 0; k < kScanChunk / kWave; ++k) { t += sc[k]; td += sd[k]; tg += sg[k]; tr += sr[k]; }
-    chunk_sum[blockIdx.x] = t; chunk_d2[blockIdx.x] = td;
-    if (chunk_groups) { chunk_groups[blockIdx.x] = tg; chunk_rewritten[blockIdx.x] = tr; }
+    chunk_sum[bx] = t; chunk_d2[bx] = td;
+    if (chunk_groups) { chunk_groups[bx] = tg; chunk_rewritten[bx] = tr; }
   }
 }
 
+__global__ __launch_bounds__(kScanChunk) void k_scan_chunk_sums(const unsigned* __restrict__ counts, int nblocks,
+                                                                const double* __restrict__ block_d2,
+                                                                unsigned long long* __restrict__ chunk_sum,
+                                                                double* __restrict__ chunk_d2,
+                                                                const unsigned* __restrict__ groups = nullptr,
+                                                                unsigned* __restrict__ chunk_groups = nullptr,
+                                                                unsigned* __restrict__ chunk_rewritten = nullptr) {
+  scan_chunk_sums_body(blockIdx.x, counts, nblocks, block_d2, chunk_sum, chunk_d2, groups, chunk_groups, chunk_rewritten);
+}
+
 // totals (and the exclusive scan of the chunk sums); chunk_groups (resident rows): scanned in place as well, total[1] = their sum
-__global__ void k_scan_chunks(unsigned long long* __restrict__ chunk_sum, int nchunks, const double* __restrict__ chunk_d2,
-                              unsigned long long* __restrict__ total, double* __restrict__ total_d2,
-                              unsigned* __restrict__ chunk_groups = nullptr, const unsigned* __restrict__ chunk_rewritten = nullptr) {
+__device__ __forceinline__ void scan_chunks_body(unsigned long long* __restrict__ chunk_sum, int nchunks, const double* __restrict__ chunk_d2,
+                                                 unsigned long long* __restrict__ total, double* __restrict__ total_d2,
+                                                 unsigned* __restrict__ chunk_groups, const unsigned* __restrict__ chunk_rewritten) {
   __shared__ unsigned long long s[1024];
   __shared__ double sd[1024];
   __shared__ unsigned sg[1024];
@@ -1685,6 +1751,12 @@ __global__ void k_scan_chunks(unsigned long long* __restrict__ chunk_sum, int nc
     const unsigned long long v = chunk_sum[b]; chunk_sum[b] = run; run += v;
     if (chunk_groups) { const unsigned gv = chunk_groups[b]; chunk_groups[b] = grun; grun += gv; }
   }
+}
+
+__global__ void k_scan_chunks(unsigned long long* __restrict__ chunk_sum, int nchunks, const double* __restrict__ chunk_d2,
+                              unsigned long long* __restrict__ total, double* __restrict__ total_d2,
+                              unsigned* __restrict__ chunk_groups = nullptr, const unsigned* __restrict__ chunk_rewritten = nullptr) {
+  scan_chunks_body(chunk_sum, nchunks, chunk_d2, total, total_d2, chunk_groups, chunk_rewritten);
 }
 
 __global__ __launch_bounds__(kScanChunk) void k_scan_within_chunks(const unsigned* __restrict__ counts, int nblocks,
@@ -1748,15 +1820,15 @@ __global__ __launch_bounds__(kBlock) void k_compact_corr(const int* __restrict__
 // (count in bits 0..7, mask in bits 8..11; bits 16..24: rows rewritten, a statistic -- summed without atomics: an atomic per
 // wave on one counter made a launch that rewrites every row 3.5 times slower than k_compact_corr).  Halves of clouds that never move (impl cloud 0, fixed clouds) are stored in the
 // global frame exactly as k_compact_corr writes them; halves of movable clouds in the cloud's local frame (row_to_global).
-__global__ __launch_bounds__(kBlock) void k_corr_update(const int* __restrict__ match, int* __restrict__ plane_match,
-                                                        const float* __restrict__ match_d2, size_t n,
-                                                        const float4* __restrict__ Psrc, const float4* __restrict__ LNsrc,
-                                                        const int src_global, Affine Tsrc, const float4* __restrict__ Ptgt,
-                                                        const float4* __restrict__ LNtgt, const int tgt_global, Affine Ttgt,
-                                                        float4* __restrict__ A, float4* __restrict__ B, float4* __restrict__ C,
-                                                        unsigned* __restrict__ block_counts, double* __restrict__ block_d2,
-                                                        unsigned* __restrict__ block_groups) {
-  const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void corr_update_body(const unsigned bx, const int* __restrict__ match, int* __restrict__ plane_match,
+                                                 const float* __restrict__ match_d2, size_t n,
+                                                 const float4* __restrict__ Psrc, const float4* __restrict__ LNsrc,
+                                                 const int src_global, const Affine& Tsrc, const float4* __restrict__ Ptgt,
+                                                 const float4* __restrict__ LNtgt, const int tgt_global, const Affine& Ttgt,
+                                                 float4* __restrict__ A, float4* __restrict__ B, float4* __restrict__ C,
+                                                 unsigned* __restrict__ block_counts, double* __restrict__ block_d2,
+                                                 unsigned* __restrict__ block_groups) {
+  const size_t j = (size_t)bx * blockDim.x + threadIdx.x;
   const bool in = j < n;
   const int m = in ? ld_stream(match + j) : -1;
   const int pm = in ? ld_stream(plane_match + j) : -1;
@@ -1794,15 +1866,37 @@ __global__ __launch_bounds__(kBlock) void k_corr_update(const int* __restrict__ 
   if (threadIdx.x == 0) {
     unsigned c = 0, g = 0, gm = 0, rw = 0; double t = 0;
     for (int k = 0; k < kBlock / kWave; ++k) { c += sc[k]; t += sd[k]; rw += sw[k]; if (sc[k]) { ++g; gm |= 1u << k; } }
-    block_counts[blockIdx.x] = c; block_d2[blockIdx.x] = t; block_groups[blockIdx.x] = g | (gm << 8) | (rw << 16);    // (rw <= 256)
+    block_counts[bx] = c; block_d2[bx] = t; block_groups[bx] = g | (gm << 8) | (rw << 16);    // (rw <= 256)
   }
 }
 
+__global__ __launch_bounds__(kBlock) void k_corr_update(const int* __restrict__ match, int* __restrict__ plane_match,
+                                                        const float* __restrict__ match_d2, size_t n,
+                                                        const float4* __restrict__ Psrc, const float4* __restrict__ LNsrc,
+                                                        const int src_global, Affine Tsrc, const float4* __restrict__ Ptgt,
+                                                        const float4* __restrict__ LNtgt, const int tgt_global, Affine Ttgt,
+                                                        float4* __restrict__ A, float4* __restrict__ B, float4* __restrict__ C,
+                                                        unsigned* __restrict__ block_counts, double* __restrict__ block_d2,
+                                                        unsigned* __restrict__ block_groups) {
+  corr_update_body(blockIdx.x, match, plane_match, match_d2, n, Psrc, LNsrc, src_global, Tsrc, Ptgt, LNtgt, tgt_global, Ttgt, A, B, C,
+                   block_counts, block_d2, block_groups);
+}
+
+// the resident rows of a batch of pairs: the per-block results of pair p go to entries [blk0(p), blk0(p) + blocks of p) of the batch's arrays
+__global__ __launch_bounds__(kBlock) void k_corr_update_multi(const NnBatchDev* __restrict__ Bt, unsigned* __restrict__ block_counts,
+                                                              double* __restrict__ block_d2, unsigned* __restrict__ block_groups) {
+  const int p = nn_find_range(Bt->upd_end, Bt->n_pairs, blockIdx.x);
+  const unsigned b0 = p ? Bt->upd_end[p - 1] : 0u;
+  const NnPairDev& P = Bt->pair[p];
+  const Affine Ts = P.Tsrc, Tt = P.Ttgt;
+  corr_update_body(blockIdx.x - b0, P.match, P.plane_match, P.match_d2, (size_t)P.n, P.Psrc, P.LNsrc, P.src_global, Ts, P.Ptgt, P.LNtgt,
+                   P.tgt_global, Tt, P.A, P.B, P.C, block_counts + b0, block_d2 + b0, block_groups + b0);
+}
+
 // ascending list of the active 64-row groups: one thread per query block (4 groups), scan inside the chunk + the chunk's base
-__global__ __launch_bounds__(kScanChunk) void k_group_list(const unsigned* __restrict__ block_groups, int nblocks,
-                                                           const unsigned* __restrict__ chunk_gbase,
-                                                           unsigned* __restrict__ glist) {
-  const int b = blockIdx.x * kScanChunk + threadIdx.x;
+__device__ __forceinline__ void group_list_body(const unsigned bx, const unsigned* __restrict__ block_groups, int nblocks,
+                                                const unsigned* __restrict__ chunk_gbase, unsigned* __restrict__ glist) {
+  const int b = (int)bx * kScanChunk + threadIdx.x;
   const unsigned w = (b < nblocks) ? block_groups[b] : 0u;
   const unsigned c = w & 0xFFu;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -1815,12 +1909,44 @@ __global__ __launch_bounds__(kScanChunk) void k_group_list(const unsigned* __res
   __shared__ unsigned ws[kScanChunk / kWave];
   if (lane == 63) ws[wv] = inc;
   __syncthreads();
-  unsigned base = chunk_gbase[blockIdx.x] + (inc - c);
+  unsigned base = chunk_gbase[bx] + (inc - c);
   for (int k = 0; k < wv; ++k) base += ws[k];
   const unsigned mask = w >> 8;
 #pragma unroll
   for (int k = 0; k < kBlock / kWave; ++k)
     if (mask & (1u << k)) glist[base++] = (unsigned)b * (kBlock / kWave) + (unsigned)k;
+}
+
+__global__ __launch_bounds__(kScanChunk) void k_group_list(const unsigned* __restrict__ block_groups, int nblocks,
+                                                           const unsigned* __restrict__ chunk_gbase,
+                                                           unsigned* __restrict__ glist) {
+  group_list_body(blockIdx.x, block_groups, nblocks, chunk_gbase, glist);
+}
+
+// totals and group lists of a batch of pairs (launch_corr_totals for each of them, three launches in all): chunk c of the batch
+// belongs to the pair whose chunk range holds it; pair p's totals go to totals[3 p ..], total_d2[p]
+__global__ __launch_bounds__(kScanChunk) void k_scan_chunk_sums_multi(const NnBatchDev* __restrict__ Bt, const unsigned* __restrict__ block_counts,
+                                                                      const double* __restrict__ block_d2, const unsigned* __restrict__ block_groups,
+                                                                      unsigned long long* __restrict__ chunk_sum, double* __restrict__ chunk_d2,
+                                                                      unsigned* __restrict__ chunk_groups, unsigned* __restrict__ chunk_rewritten) {
+  const int p = nn_find_range(Bt->chunk_end, Bt->n_pairs, blockIdx.x);
+  const unsigned c0 = p ? Bt->chunk_end[p - 1] : 0u, b0 = p ? Bt->upd_end[p - 1] : 0u;
+  scan_chunk_sums_body(blockIdx.x - c0, block_counts + b0, (int)(Bt->upd_end[p] - b0), block_d2 + b0, chunk_sum + c0, chunk_d2 + c0, block_groups + b0,
+                       chunk_groups + c0, chunk_rewritten + c0);
+}
+__global__ __launch_bounds__(1024) void k_scan_chunks_multi(const NnBatchDev* __restrict__ Bt, unsigned long long* __restrict__ chunk_sum,
+                                                            const double* __restrict__ chunk_d2, unsigned long long* __restrict__ totals,
+                                                            double* __restrict__ total_d2, unsigned* __restrict__ chunk_groups,
+                                                            const unsigned* __restrict__ chunk_rewritten) {
+  const int p = blockIdx.x;
+  const unsigned c0 = p ? Bt->chunk_end[p - 1] : 0u;
+  scan_chunks_body(chunk_sum + c0, (int)(Bt->chunk_end[p] - c0), chunk_d2 + c0, totals + 3 * p, total_d2 + p, chunk_groups + c0, chunk_rewritten + c0);
+}
+__global__ __launch_bounds__(kScanChunk) void k_group_list_multi(const NnBatchDev* __restrict__ Bt, const unsigned* __restrict__ block_groups,
+                                                                 const unsigned* __restrict__ chunk_gbase) {
+  const int p = nn_find_range(Bt->chunk_end, Bt->n_pairs, blockIdx.x);
+  const unsigned c0 = p ? Bt->chunk_end[p - 1] : 0u, b0 = p ? Bt->upd_end[p - 1] : 0u;
+  group_list_body(blockIdx.x - c0, block_groups + b0, (int)(Bt->upd_end[p] - b0), chunk_gbase + c0, Bt->pair[p].glist);
 }
 
 // gather variant for explicit (index_query, index_match) lists on unsorted AoS clouds
@@ -2647,6 +2773,31 @@ void launch_corr_totals(size_t n, const unsigned* block_counts, const double* bl
   hipLaunchKernelGGL(k_scan_chunk_sums, dim3(nch), dim3(kScanChunk), 0, s, block_counts, nb, block_d2, chunk_sum, chunk_d2, block_groups, chunk_groups, chunk_rewritten);
   hipLaunchKernelGGL(k_scan_chunks, dim3(1), dim3(1024), 0, s, chunk_sum, nch, chunk_d2, totals, total_d2, chunk_groups, (const unsigned*)chunk_rewritten);
   hipLaunchKernelGGL(k_group_list, dim3(nch), dim3(kScanChunk), 0, s, block_groups, nb, chunk_groups, glist);
+}
+
+void launch_nn_certify_multi(const NnBatchDev* batch, unsigned n_blocks, float r2, hipStream_t s) {
+  static_assert(kNnCertBlockQueries == kCertPerWave * (kBlock / kWave), "queries per certificate block");
+  if (!n_blocks) return;
+  hipLaunchKernelGGL(k_nn_certify_multi, dim3(n_blocks), dim3(kBlock), 0, s, batch, r2);
+}
+void launch_nn_bounded_half_multi(const NnBatchDev* batch, unsigned n_blocks, float r2, hipStream_t s) {
+  if (!n_blocks) return;
+  hipLaunchKernelGGL(k_nn_bounded_half_multi, dim3(n_blocks), dim3(kBlock), 0, s, batch, r2);
+}
+void launch_corr_update_multi(const NnBatchDev* batch, unsigned n_blocks, unsigned* block_counts, double* block_d2, unsigned* block_groups, hipStream_t s) {
+  if (!n_blocks) return;
+  hipLaunchKernelGGL(k_corr_update_multi, dim3(n_blocks), dim3(kBlock), 0, s, batch, block_counts, block_d2, block_groups);
+}
+void launch_corr_totals_multi(const NnBatchDev* batch, int n_pairs, unsigned n_chunks, const unsigned* block_counts, const double* block_d2,
+                              const unsigned* block_groups, unsigned long long* chunk_sum, double* chunk_d2, unsigned* chunk_groups,
+                              unsigned* chunk_rewritten, unsigned long long* totals, double* total_d2, hipStream_t s) {
+  static_assert(kNnScanChunk == kScanChunk, "blocks per chunk");
+  if (!n_pairs || !n_chunks) return;
+  hipLaunchKernelGGL(k_scan_chunk_sums_multi, dim3(n_chunks), dim3(kScanChunk), 0, s, batch, block_counts, block_d2, block_groups, chunk_sum, chunk_d2,
+                     chunk_groups, chunk_rewritten);
+  hipLaunchKernelGGL(k_scan_chunks_multi, dim3((unsigned)n_pairs), dim3(1024), 0, s, batch, chunk_sum, (const double*)chunk_d2, totals, total_d2, chunk_groups,
+                     (const unsigned*)chunk_rewritten);
+  hipLaunchKernelGGL(k_group_list_multi, dim3(n_chunks), dim3(kScanChunk), 0, s, batch, block_groups, (const unsigned*)chunk_groups);
 }
 
 void launch_gather_corr(const float* sxyz, const float* snrm, const float* txyz, const float* tnrm, const int* iq,

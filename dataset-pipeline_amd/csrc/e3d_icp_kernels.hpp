@@ -103,6 +103,52 @@ struct BoundParams {
 void launch_nn_bounded(const float4* Gsrc, const unsigned* list, size_t n_list, const float4* Gtgt, const unsigned* dense_start,
                        const unsigned long long* half_prefix, bool half_always, const GridDesc& g, const InvMap& im, const QueryRange& qr, float r2,
                        const BoundParams& bp, int* match, int* match2, float* match_d2, float* lbe, hipStream_t s);
+// ---- a batch of directed pairs per launch (round 5; the kernels and why: e3d_icp_kernels.hip "a BATCH of directed pairs") --------
+constexpr int kNnBatchPairs = 32;    // pairs per batch
+constexpr int kNnBatchJobs = 2 * kNnBatchPairs;   // (pair, list) jobs of the bounded search: the near list and a short far list per pair
+// what the one-pair kernels take as arguments, per pair of the batch (device pointers; block-uniform reads)
+struct NnPairDev {
+  const float4* Gsrc;              // this rank's slice of the source cloud, global frame
+  const float4* Gtgt;              // target cloud, global frame
+  const unsigned* S;               // target's dense cell-start directory
+  const unsigned long long* H8;    // target's half-cell directory
+  int *match, *match2;             // per-query state of the pair
+  float* lbe;
+  float* match_d2;                 // squared distances of this search (batch scratch)
+  unsigned *todo_near, *todo_far;  // lists of the queries the certificates did not settle (batch scratch)
+  unsigned* counts;                // their lengths: two words of the batch's array
+  unsigned n;                      // queries
+  int none_near;
+  float cum_up, near2;
+  GridDesc g; InvMap im; QueryRange qr; BoundParams bp;
+  // resident rows (k_corr_update)
+  const float4 *Psrc, *LNsrc, *Ptgt, *LNtgt;
+  int src_global, tgt_global;
+  Affine Tsrc, Ttgt;
+  float4 *A, *B, *C;
+  int* plane_match;
+  unsigned* glist;
+};
+struct NnBatchDev {
+  int n_pairs, n_jobs;
+  unsigned cert_end[kNnBatchPairs];    // exclusive ends of the pairs' block ranges in the certificate launch
+  unsigned upd_end[kNnBatchPairs];     // ... in the row update = of their entries in the per-block result arrays
+  unsigned chunk_end[kNnBatchPairs];   // ... of their 256-block chunks in the totals
+  unsigned job_end[kNnBatchJobs];      // ... of the list jobs' block ranges in the bounded search
+  int job_pair[kNnBatchJobs];
+  unsigned job_n[kNnBatchJobs];
+  const unsigned* job_list[kNnBatchJobs];
+  NnPairDev pair[kNnBatchPairs];
+};
+void launch_nn_certify_multi(const NnBatchDev* batch, unsigned n_blocks, float r2, hipStream_t s);
+void launch_nn_bounded_half_multi(const NnBatchDev* batch, unsigned n_blocks, float r2, hipStream_t s);
+void launch_corr_update_multi(const NnBatchDev* batch, unsigned n_blocks, unsigned* block_counts, double* block_d2, unsigned* block_groups, hipStream_t s);
+// totals[3 p ..] = correspondences, active groups, rows rewritten of pair p; total_d2[p]; the pairs' group lists (three launches)
+void launch_corr_totals_multi(const NnBatchDev* batch, int n_pairs, unsigned n_chunks, const unsigned* block_counts, const double* block_d2,
+                              const unsigned* block_groups, unsigned long long* chunk_sum, double* chunk_d2, unsigned* chunk_groups,
+                              unsigned* chunk_rewritten, unsigned long long* totals, double* total_d2, hipStream_t s);
+constexpr int kNnCertBlockQueries = 2048;   // queries per block of the certificate kernels (kCertPerWave x waves per block)
+constexpr int kNnScanChunk = 256;           // blocks per chunk of the totals
 void launch_half_keys(const float* xyz, size_t n, const GridDesc& g, unsigned* keys, unsigned* vals, hipStream_t s);
 void launch_cell_keys_ordered(const float* xyz, const unsigned* order, size_t n, const GridDesc& g, unsigned long long* keys, hipStream_t s);
 void launch_half_prefix(const unsigned long long* keys, const float4* L4, size_t n, const GridDesc& g, const QueryRange& qr,

@@ -35,8 +35,10 @@ extern "C" {
  * 3: e3d_icp_iter_record grew by t_nn_sort_ms / t_nn_scan_ms / t_nn_compact_ms; e3d_comm_abort, e3d_reg_profile,
  *    e3d_icp_set_sequential_distance_sum (round 3)
  * 4: e3d_icp_set_resident_rows, e3d_comm_get_stats; iteration record: multi_cost_poses, lm_passes_skipped in the two reserved
- *    words, corr_rows_rewritten / corr_rows_walked appended (round 4) */
-#define E3D_ABI_VERSION 4
+ *    words, corr_rows_rewritten / corr_rows_walked appended (round 4)
+ * 5: iteration record: nn_update_launches, nn_kernel_launches, nn_batches, nn_sort_calls appended (round 5: a batch of directed pairs
+ *    per kernel launch) */
+#define E3D_ABI_VERSION 5
 
 #define E3D_ERR_INVALID   (-2)   /* bad argument / bad handle state          */
 #define E3D_ERR_HIP       (-3)   /* a HIP runtime call failed                */
@@ -138,6 +140,12 @@ typedef struct {
   int64_t corr_rows_rewritten; /* correspondence rows (48 B) written this iteration: every correspondence with compacted rows, the
                                   rows whose partner changed with resident rows                                        */
   int64_t corr_rows_walked;    /* rows one LM pass reads: the correspondences, or 64 x the active row groups of resident rows */
+  /* ABI 5: launches of the NN phase (the all-pairs job's per-pair launches are what does not shrink with the number of GPUs) */
+  int32_t nn_update_launches;  /* k_corr_update / k_compact_corr launches                                                */
+  int32_t nn_kernel_launches;  /* all kernels the library itself launched in the NN phase (search, keys, row update, totals;
+                                  the launches inside rocPRIM's radix sort are not counted: nn_sort_calls sorts)          */
+  int32_t nn_batches;          /* batches of directed pairs that ran with one launch per kernel (0: pair by pair)          */
+  int32_t nn_sort_calls;       /* radix sorts of query lists (k_nn_rows path)                                             */
 } e3d_icp_iter_record;
 
 size_t e3d_icp_num_pair_records(const e3d_icp_t* icp);
@@ -150,7 +158,10 @@ void e3d_icp_clear_records(e3d_icp_t* icp);
  * [n*rank/world, n*(rank+1)/world) of every directed pair's source cloud (in grid-cell order), so
  * any number of pairs -- including the 2 pairs of a 2-scan job -- shards evenly.  `allreduce` must sum `count` doubles in
  * place across ranks (RCCL/gloo through the host language; buffer is HOST memory) and leave
- * the identical result on every rank.  The reference has no equivalent (single process). */
+ * the identical result on every rank.  The reference has no equivalent (single process).
+ * world_size == 1 with a callback is a tap: every buffer still passes through the callback (the sum over one rank is the
+ * identity), which lets a caller record the reduced sums of a single-GPU run -- bench.py replays them to a handle that works as
+ * rank 0 of a world of 8 on the same GPU to measure what one rank of an 8-GPU job does (its `scale_model`). */
 typedef int (*e3d_allreduce_fn)(double* buffer, size_t count, void* user);
 int e3d_icp_set_shard(e3d_icp_t* icp, int rank, int world_size,
                       e3d_allreduce_fn allreduce, void* user);

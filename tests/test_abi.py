@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol(e3d):
     # and the Python binding knows every one of them
     capi = importlib.import_module("dataset-pipeline_amd.capi")
     assert sorted(capi.SIGNATURES) == declared
-    assert e3d.lib().e3d_abi_version() == 4
+    assert e3d.lib().e3d_abi_version() == 5
 
 
 def test_no_oracle_or_cpu_fallback_in_product():

@@ -1,6 +1,6 @@
 """The library's alternative data flows give the same bits.  Their switches are environment variables read once per process, so
 each setting runs in its own interpreter: the certificate search of several directed pairs per host round trip against pair by
-pair (E3D_ICP_BATCH), resident against compacted correspondence rows (E3D_ICP_RESIDENT), the speculative last LM step
+pair or one launch per pair (E3D_ICP_BATCH = 0 / 1; default 2: one launch per kernel and batch), resident against compacted correspondence rows (E3D_ICP_RESIDENT), the speculative last LM step
 (E3D_LM_SPECULATE); the kNN estimator's single scan with sampled thresholds against the two-pass kernels (E3D_KNN_SINGLE), with
 and without the lists the 125-cell pass starts from (E3D_KNN_SEED), the wave-per-query form of that pass (E3D_KNN_WIDE_WAVE)."""
 import json
@@ -18,13 +18,15 @@ import importlib, json, sys
 sys.path.insert(0, %r)
 e3d = importlib.import_module("dataset-pipeline_amd")
 synth = importlib.import_module("dataset-pipeline_amd.synth")
-scans = synth.make_scene(4, 60000, seed=33)
+scans = synth.make_scene(4, 400000, seed=33)             # dense enough for the certificate search, resident rows and pair batches
 icp = e3d.PointToPlaneICP()
 ids = [icp.add_point_cloud(s["xyz"].numpy(), s["normals"].numpy(), s["T_init"], i == 3) for i, s in enumerate(scans)]
 icp.run(0.1, 0, 6, 1e-9, False)
 pairs = [[int(r[0]), int(r[1]), int(r[2]), int(r[3]), float(r[4]).hex()] for r in icp.pair_records()]
 poses = [[float(v).hex() for v in icp.get_result_global_T_cloud(i).ravel()] for i in ids if i >= 0]
-print("RESULT" + json.dumps({"pairs": pairs, "poses": poses}))
+rec = icp.iter_records()
+print("RESULT" + json.dumps({"pairs": pairs, "poses": poses, "batches": sum(r["nn_batches"] for r in rec), "launches": sum(r["nn_kernel_launches"] for r in rec),
+                             "certified": sum(r["nn_certify_queries"] for r in rec)}))
 """ % ROOT
 
 KNN_CODE = r"""
@@ -56,8 +58,13 @@ def _run(code, env):
 def test_icp_data_flows_agree():
     base = _run(ICP_CODE, {})
     assert len(base["pairs"]) > 0
-    for env in ({"E3D_ICP_BATCH": "0"}, {"E3D_LM_SPECULATE": "0"}):
-        assert _run(ICP_CODE, env) == base, env                      # same kernels, same sums: bit for bit
+    assert base["batches"] > 0 and base["certified"] > 0             # the default ran batches of pairs through the one-launch kernels
+    strip = lambda r: {k: r[k] for k in ("pairs", "poses")}
+    for env in ({"E3D_ICP_BATCH": "0"}, {"E3D_ICP_BATCH": "1"}, {"E3D_LM_SPECULATE": "0"}):
+        other = _run(ICP_CODE, env)
+        assert strip(other) == strip(base), env                      # same kernel bodies, same sums: bit for bit
+        if "E3D_ICP_BATCH" in env:
+            assert other["batches"] == 0 and other["launches"] > base["launches"], (env, other["launches"], base["launches"])
     # resident vs compacted rows: the pair records (counts, distance sums) are those of the same searches; the LM passes add the
     # same f32 terms in a different order of f64 sums (include/e3d_hip.h), so the poses agree to the tolerances of
     # test_gpu_icp.py::test_resident_rows_equal_compacted_rows, not necessarily bit for bit
@@ -73,6 +80,6 @@ def test_icp_data_flows_agree():
 @pytest.mark.timeout(600)
 def test_knn_scan_variants_agree():
     base = _run(KNN_CODE, {})
-    for env in ({"E3D_KNN_SINGLE": "0"}, {"E3D_KNN_SEED": "0"}, {"E3D_KNN_WIDE_SPREAD": "1"}, {"E3D_KNN_WIDE_WAVE": "0"},
+    for env in ({"E3D_KNN_SINGLE": "0"}, {"E3D_KNN_SEED": "0"}, {"E3D_KNN_WIDE_SPREAD": "1"}, {"E3D_KNN_WIDE_WAVE": "0"}, {"E3D_KNN_XCD": "0"},
                 {"E3D_KNN_REP_STRIDE": "32", "E3D_KNN_REP_AVG": "1"}):
         assert _run(KNN_CODE, env) == base, env

@@ -788,7 +788,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--points", type=int, default=0, help="points per scan of the headline leg (default 50 M x gpus)")
     ap.add_argument("--distance", type=float, default=0.01)
-    XX
+    ap.add_argument("--perturb", type=float, default=3.0, help="scale of the headline scene's initial misalignment (synth.perturbation): 3 = 3 degrees and "
+                    "(6, -3, 3) cm, which leaves the 25 outer iterations of --warmup 5 --steps 20 before the run converges (tools/icp_converge.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-whole-run", action="store_true", help="skip the add_cloud -> convergence run of the headline leg (N = 1)")
     ap.add_argument("--no-scale-model", action="store_true", help="skip the rank-0-of-8 run of the all-pairs leg (N = 1)")

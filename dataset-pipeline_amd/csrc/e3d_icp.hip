@@ -545,6 +545,12 @@ static bool pair_is_dense(const e3d_icp* h, const Cloud& tgt) {
 static bool pair_uses_rows(const e3d_icp* h, const Cloud& tgt) {
   return pair_is_dense(h, tgt) && tgt.has_dense && (h->nn_mode == 0 || h->nn_mode == 3 || h->nn_mode == 5);
 }
+// the far list (queries without a near partner) goes through the bounded search instead of sort + k_nn_rows when it holds less than
+// 1 / E3D_NN_FAR_DIV of the pair's queries (default 32; 0: always the bounded search -- experiments)
+static bool far_list_is_short(size_t n_far, size_t n) {
+  static const long long div = [] { const char* e = getenv("E3D_NN_FAR_DIV"); return e ? atoll(e) : 32ll; }();
+  return n_far > 0 && (div <= 0 || n_far * (size_t)div < n);
+}
 static size_t resident_rows_cap(size_t n) { return div_up(n, 64) * 64; }
 static size_t resident_bytes(size_t n) { return resident_rows_cap(n) * 48 + n * 4 + div_up(n, 64) * 4; }
 
@@ -622,7 +628,7 @@ static void find_pair(e3d_icp* h, Cloud& src, Cloud& tgt, float d, PairJob& job,
       bp.np_extra = none_near ? (float)(np_frac * (double)d) : 0.f;   // gate closed: partnerless queries on the far list keep the plain radius
       launch_nn_bounded(srcG, h->todo_near.p, n_near, tgt.G4.p, tgt.dense_start.p, tgt.has_half ? tgt.half_prefix.p : nullptr, h->nn_mode == 5, tgt.grid, im, tgt.qrange, radius_sq(d), bp, ps.match.p,
                         ps.match2.p, h->match_d2.p, ps.lbe.p, s);
-      if (n_far > 0 && n_far * 32 < n) {
+      if (far_list_is_short(n_far, n)) {
         // few queries without a near partner: the same kernel (whole radius for those without any) instead of sort + row kernel,
         // whose cost is per visited cell row, not per query
         launch_nn_bounded(srcG, h->todo_far.p, n_far, tgt.G4.p, tgt.dense_start.p, tgt.has_half ? tgt.half_prefix.p : nullptr, h->nn_mode == 5, tgt.grid, im, tgt.qrange, radius_sq(d), bp, ps.match.p,
@@ -838,7 +844,7 @@ static void find_pairs_batched(e3d_icp* h, std::vector<BatchItem>& items, float 
       h->tm_bounded.start(s);
       launch_nn_bounded(srcG, sl.todo_near.p, it.n_near, tgt.G4.p, tgt.dense_start.p, half, h->nn_mode == 5, tgt.grid, it.im, tgt.qrange, radius_sq(d), it.bp,
                         ps.match.p, ps.match2.p, sl.match_d2.p, ps.lbe.p, s);
-      if (it.n_far > 0 && it.n_far * 32 < n) {
+      if (far_list_is_short(it.n_far, n)) {
         launch_nn_bounded(srcG, sl.todo_far.p, it.n_far, tgt.G4.p, tgt.dense_start.p, half, h->nn_mode == 5, tgt.grid, it.im, tgt.qrange, radius_sq(d), it.bp,
                           ps.match.p, ps.match2.p, sl.match_d2.p, ps.lbe.p, s);
         it.n_near += it.n_far; it.n_far = 0;
@@ -1013,7 +1019,7 @@ static bool find_pairs_multi(e3d_icp* h, std::vector<BatchItem>& items, float d,
       job_queries += (long long)n_list;
     };
     add_job(sl.todo_near.p, it.n_near);
-    if (it.n_far > 0 && it.n_far * 32 < it.n) {               // (few queries without a near partner: see find_pair)
+    if (far_list_is_short(it.n_far, it.n)) {                  // (few queries without a near partner: see find_pair)
       add_job(sl.todo_far.p, it.n_far);
       it.n_near += it.n_far; it.n_far = 0;
     }

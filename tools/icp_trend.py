@@ -1,5 +1,5 @@
 """Per-iteration cost split of an ICP run on two synthetic scans (full-overlap room or the partial-overlap room).
-usage: python tools/icp_trend.py [points_per_scan] [iterations] [partial 0/1] [d] [scans (default 2; > 2: all movable, all pairs, seed 4321)]"""
+usage: python tools/icp_trend.py [points_per_scan] [iterations] [partial 0/1] [d] [scans (default 2; > 2: all movable, all pairs, seed 4321)] [misalignment scale (default 1)]"""
 import importlib, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -10,16 +10,25 @@ iters = int(sys.argv[2]) if len(sys.argv) > 2 else 25
 partial = len(sys.argv) > 3 and sys.argv[3] == "1"
 d = float(sys.argv[4]) if len(sys.argv) > 4 else 0.01
 S = int(sys.argv[5]) if len(sys.argv) > 5 else 2
+perturb = float(sys.argv[6]) if len(sys.argv) > 6 else 1.0
 dev = torch.device("cuda", 0)
-scans = synth.make_scene(S, n, seed=1234 if S == 2 else 4321, sigma=0.002, device=dev, partial=partial)
+scans = synth.make_scene(S, n, seed=1234 if S == 2 else 4321, sigma=0.002, device=dev, partial=partial, perturb=perturb)
 icp = e3d.PointToPlaneICP(device=0)
 for s in scans:
     icp.add_point_cloud(s["xyz"], s["normals"], s["T_init"], False)
 del scans
+import time
+wall = []
 for it in range(iters):
-    icp.run(d, it, 1, 1e-10, False)
+    t0 = time.perf_counter()
+    conv = icp.run(d, it, 1, 1e-10, False)
+    wall.append((time.perf_counter() - t0) * 1e3)
+    if conv:
+        print("converged at iteration", it)
+        break
 r = icp.iter_records()
-print("partial" if partial else "full", "scene, %d x %d points, d = %g" % (S, n, d))
+print("partial" if partial else "full", "scene, %d x %d points, d = %g, misalignment scale %g" % (S, n, d, perturb))
+print("wall ms per iteration:", " ".join("%.1f" % v for v in wall))
 print(" it   corr(M)  certify ms (Mq)   bounded ms (Mq)   rows ms (Mq)   sort  scan  rows-upd (M rewritten)  nn_other  transform   lm_kernels full/multi ms (full/multi passes, poses, skipped)  lm_other")
 for x in r:
     print("%3d  %7.2f   %6.2f (%6.1f)   %6.2f (%6.2f)   %6.2f (%6.2f)   %5.2f %5.2f %5.2f (%6.2f)   %6.2f    %6.2f    %6.2f / %5.2f (%d/%d, %d, %d)   %6.2f" % (

@@ -188,6 +188,8 @@ struct e3d_icp {
   PinBuf<NnBatchDev> h_batch;                   // the pair table of find_pairs_multi
   DevBuf<NnBatchDev> d_batch;
   DevBuf<unsigned> chunk_rewritten;
+  DevBuf<unsigned> prune_count;                 // number of (key, query) pairs k_query_keys_prune kept
+  PinBuf<unsigned> h_prune_count;
   DevBuf<unsigned long long> d_totals_all;
   DevBuf<double> d_d2_all;
   PinBuf<unsigned long long> h_totals_all;
@@ -526,6 +528,32 @@ static void sort_query_keys(e3d_icp* h, const Cloud& tgt, const float4* srcG, co
   }
 }
 
+// The certificate path's variant: the key kernel settles the queries whose 27-cell block holds no target point (k_query_keys_prune)
+// and only the others are sorted; returns how many those are (h->vals_b: their source positions in key order).  One host round
+// trip for the count (the sort's size).  E3D_NN_PRUNE=0: every listed query is keyed and sorted (sort_query_keys).
+static size_t sort_query_keys_pruned(e3d_icp* h, const Cloud& tgt, const float4* srcG, const unsigned* list, size_t n, const InvMap& im, float r2,
+                                     const CertParams& cert, int* match, int* match2, float* match_d2, float* lbe, e3d_icp_iter_record& rec) {
+  static const bool prune = [] { const char* e = getenv("E3D_NN_PRUNE"); return !(e && e[0] == '0'); }();
+  if (!prune || !tgt.has_dense || n == 0) { sort_query_keys(h, tgt, srcG, list, n, im); return n; }
+  hipStream_t s = h->stream;
+  h->keys_a.reserve(n); h->keys_b.reserve(n); h->vals_a.reserve(n); h->vals_b.reserve(n);
+  h->prune_count.reserve(1); h->h_prune_count.reserve(1);
+  h->tm_sort.start(s);
+  struct Stop { e3d_icp* h; hipStream_t s; ~Stop() { h->tm_sort.stop(s); } } stop_at_return{h, s};
+  const bool k32 = tgt.key_bits <= 31;
+  E3D_HIP(hipMemsetAsync(h->prune_count.p, 0, sizeof(unsigned), s));
+  launch_query_keys_prune(k32, srcG, list, n, tgt.dense_start.p, tgt.grid, im, tgt.qrange, r2, cert, h->keys_a.p, h->vals_a.p, h->prune_count.p,
+                          match, match2, match_d2, lbe, s);
+  copy_out(h->h_prune_count.p, h->prune_count.p, sizeof(unsigned), s);
+  sync(h);
+  const size_t kept = h->h_prune_count.p[0];
+  rec.nn_pruned_queries += (long long)(n - kept);
+  if (kept == 0) return 0;
+  if (k32) sort_pairs_u32_u32(reinterpret_cast<unsigned*>(h->keys_a.p), reinterpret_cast<unsigned*>(h->keys_b.p), h->vals_a.p, h->vals_b.p, kept, tgt.key_bits, h->sort_temp, s);
+  else sort_pairs_u64_u32(h->keys_a.p, h->keys_b.p, h->vals_a.p, h->vals_b.p, kept, tgt.key_bits, h->sort_temp, s);
+  return kept;
+}
+
 // NN search + compaction for one directed pair; appends to the correspondence planes.
 // Multi-GPU: every rank holds all clouds and handles the slice [j0, j1) of the source cloud (cell order).
 // E3D_NN_PROFILE=1: wall-clock split of the search of one outer iteration (synchronises between the phases; diagnostics only)
@@ -638,12 +666,17 @@ static void find_pair(e3d_icp* h, Cloud& src, Cloud& tgt, float d, PairJob& job,
       h->tm_bounded.stop(s);
       if (n_near > 0) { rec.nn_bounded_launches++; rec.nn_bounded_queries += (long long)n_near; rec.nn_kernel_launches++; }
     }
-    if (n_far > 0) { NnPhase ph(s, 1); sort_query_keys(h, tgt, srcG, list, n_far, im); rec.nn_sort_calls++; rec.nn_kernel_launches++; }
+    size_t n_rows = 0;                                     // far-list queries with a candidate in their 27 cells: sorted and searched
+    if (n_far > 0) {
+      NnPhase ph(s, 1);
+      n_rows = sort_query_keys_pruned(h, tgt, srcG, list, n_far, im, radius_sq(d), cert, ps.match.p, ps.match2.p, h->match_d2.p, ps.lbe.p, rec);
+      rec.nn_sort_calls++; rec.nn_kernel_launches++;
+    }
     h->nn_timer->start(s);
-    if (n_far > 0)
-      launch_rows(3, tgt, srcG, h->vals_b.p, n_far, im, radius_sq(d), cert, ps.match.p, h->match_d2.p, ps.lbe.p, ps.match2.p, s);
+    if (n_rows > 0)
+      launch_rows(3, tgt, srcG, h->vals_b.p, n_rows, im, radius_sq(d), cert, ps.match.p, h->match_d2.p, ps.lbe.p, ps.match2.p, s);
     ps.fresh = false;
-    if (n_far > 0) { rec.nn_search_launches++; rec.nn_search_queries += (long long)n_far; rec.nn_kernel_launches++; }
+    if (n_rows > 0) { rec.nn_search_launches++; rec.nn_search_queries += (long long)n_rows; rec.nn_kernel_launches++; }
     if (want_stats)
       fprintf(stderr, "[nn %d->%d] queries %zu bounded %zu rows %zu cum %.3g (last %.3g) err %.3g\n", job.src, job.tgt, n,
               n_near, n_far, cum_pair, src.last_motion + tgt.last_motion, src.err_max + tgt.err_max);
@@ -853,12 +886,14 @@ static void find_pairs_batched(e3d_icp* h, std::vector<BatchItem>& items, float 
       if (it.n_near > 0) { rec.nn_bounded_launches++; rec.nn_bounded_queries += (long long)it.n_near; rec.nn_kernel_launches++; }
     }
     if (it.n_far > 0) {
-      rec.nn_sort_calls++; rec.nn_kernel_launches += 2;
-      sort_query_keys(h, tgt, srcG, list, it.n_far, it.im);
-      h->tm_search.start(s);
-      launch_rows(3, tgt, srcG, h->vals_b.p, it.n_far, it.im, radius_sq(d), it.cert, ps.match.p, sl.match_d2.p, ps.lbe.p, ps.match2.p, s);
-      h->tm_search.stop(s);
-      rec.nn_search_launches++; rec.nn_search_queries += (long long)it.n_far;
+      rec.nn_sort_calls++; rec.nn_kernel_launches++;
+      const size_t n_rows = sort_query_keys_pruned(h, tgt, srcG, list, it.n_far, it.im, radius_sq(d), it.cert, ps.match.p, ps.match2.p, sl.match_d2.p, ps.lbe.p, rec);
+      if (n_rows > 0) {
+        h->tm_search.start(s);
+        launch_rows(3, tgt, srcG, h->vals_b.p, n_rows, it.im, radius_sq(d), it.cert, ps.match.p, sl.match_d2.p, ps.lbe.p, ps.match2.p, s);
+        h->tm_search.stop(s);
+        rec.nn_search_launches++; rec.nn_search_queries += (long long)n_rows; rec.nn_kernel_launches++;
+      }
     }
     ps.fresh = false;
     if (want_stats)
@@ -1037,11 +1072,15 @@ static bool find_pairs_multi(e3d_icp* h, std::vector<BatchItem>& items, float d,
     if (it.n_far > 0) {
       e3d_icp::PairSlot& sl = *h->slots[i];
       const float4* srcG = it.src->G4.p + it.j0;
-      sort_query_keys(h, *it.tgt, srcG, it.certified ? sl.todo_far.p : nullptr, it.n_far, it.im);
-      h->tm_search.start(s);
-      launch_rows(3, *it.tgt, srcG, h->vals_b.p, it.n_far, it.im, radius_sq(d), it.cert, ps.match.p, sl.match_d2.p, ps.lbe.p, ps.match2.p, s);
-      h->tm_search.stop(s);
-      rec.nn_search_launches++; rec.nn_search_queries += (long long)it.n_far; rec.nn_kernel_launches += 2; rec.nn_sort_calls++;
+      const size_t n_rows = sort_query_keys_pruned(h, *it.tgt, srcG, it.certified ? sl.todo_far.p : nullptr, it.n_far, it.im, radius_sq(d), it.cert,
+                                                   ps.match.p, ps.match2.p, sl.match_d2.p, ps.lbe.p, rec);
+      rec.nn_kernel_launches++; rec.nn_sort_calls++;
+      if (n_rows > 0) {
+        h->tm_search.start(s);
+        launch_rows(3, *it.tgt, srcG, h->vals_b.p, n_rows, it.im, radius_sq(d), it.cert, ps.match.p, sl.match_d2.p, ps.lbe.p, ps.match2.p, s);
+        h->tm_search.stop(s);
+        rec.nn_search_launches++; rec.nn_search_queries += (long long)n_rows; rec.nn_kernel_launches++;
+      }
     }
     ps.fresh = false;
     if (want_stats)

@@ -406,6 +406,67 @@ __global__ __launch_bounds__(kBlock) void k_query_keys32_list(const float4* __re
   vals[i] = j;
 }
 
+// Keys of the queries k_nn_rows has to look at, COMPACTED (round 5).  While two scans are still centimetres apart most queries have
+// no target point anywhere in the 27 cells around them: k_nn_rows would sort them, read the nine directory words of their block and
+// leave with "no partner".  Here the key kernel reads those words itself (eighteen independent loads: the runs [S[row + xa],
+// S[row + xb + 1]) of the nine rows) and SETTLES a query whose block is empty exactly as k_nn_rows settles it -- no candidate: no
+// partner, d2 = r2, and the certificate bound of the block's faces (block_dist, the same expression) -- so that only the queries with
+// at least one candidate are keyed, sorted and searched (list == nullptr: all n queries).  count[0] = number of pairs written.
+// The order of the compacted pairs depends on the order in which waves reach the counter; the radix sort that follows orders
+// them by key and k_nn_rows treats every query on its own, so results do not.
+template <typename KeyT>
+__global__ __launch_bounds__(kBlock) void k_query_keys_prune(const float4* __restrict__ Gsrc, const unsigned* __restrict__ list, size_t n,
+                                                             const unsigned* __restrict__ S, GridDesc g, InvMap im, QueryRange qr, float r2,
+                                                             CertParams cert, KeyT* __restrict__ keys, unsigned* __restrict__ vals,
+                                                             unsigned* __restrict__ count, int* __restrict__ match, int* __restrict__ match2,
+                                                             float* __restrict__ match_d2, float* __restrict__ lbe) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool valid = i < n;
+  const unsigned j = valid ? (list ? list[i] : (unsigned)i) : 0u;
+  bool keep = false;
+  unsigned long long key = kEmptyKey;
+  if (valid) {
+    const float4 q = Gsrc[j];
+    int cx = 0, cy = 0, cz = 0;
+    float block_dist = 2.0f;
+    key = query_cell_key(q, im, g, qr, cx, cy, cz, &block_dist);
+    if (key != kEmptyKey) {
+      const int kx = cx - qr.lo[0], ky = cy - qr.lo[1], kz = cz - qr.lo[2];
+      const int xa = max(kx - 1, 0), xb = min(kx + 1, (int)qr.D[0] - 1);
+      unsigned any = 0u;
+#pragma unroll
+      for (int r = 0; r < 9; ++r) {
+        const int y = ky + (r % 3) - 1, z = kz + (r / 3) - 1;
+        if (y >= 0 && z >= 0 && y < (int)qr.D[1] && z < (int)qr.D[2]) {
+          const size_t row = ((size_t)z * qr.D[1] + (size_t)y) * qr.D[0];
+          any |= S[row + xb + 1] - S[row + xa];
+        }
+      }
+      keep = any != 0u;
+    } else {
+      block_dist = 2.0f;                           // outside the directory range: two empty cells all around (k_nn_rows)
+    }
+    if (!keep) {
+      match[j] = -1; match_d2[j] = r2;
+      if (match2) match2[j] = -1;
+      const float kInf = __uint_as_float(0x7f800000u);
+      const float lb_out = block_dist * cert.cell_scale - cert.cell_sub;
+      lbe[j] = fmaxf(fminf(sqrtf(kInf), lb_out), 0.0f) * 0.999999f + cert.cum_lo;
+    }
+  }
+  const unsigned long long kb = __ballot(keep);
+  if (!kb) return;
+  const int lane = threadIdx.x & 63;
+  unsigned base = 0u;
+  if (lane == __ffsll((long long)kb) - 1) base = atomicAdd(count, (unsigned)__popcll(kb));
+  base = (unsigned)__shfl((int)base, __ffsll((long long)kb) - 1, 64);
+  if (keep) {
+    const unsigned slot = base + (unsigned)__popcll(kb & ((1ull << lane) - 1ull));
+    keys[slot] = (KeyT)key;
+    vals[slot] = j;
+  }
+}
+
 __device__ __forceinline__ int rdlane_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
 __device__ __forceinline__ unsigned rdlane_u(unsigned v, int l) { return (unsigned)__builtin_amdgcn_readlane((int)v, l); }
 
@@ -2654,6 +2715,18 @@ void launch_query_keys32_list(const float4* Gsrc, const unsigned* list, size_t n
                               const QueryRange& qr, unsigned* keys, unsigned* vals, hipStream_t s) {
   if (!n) return;
   hipLaunchKernelGGL(k_query_keys32_list, dim3((unsigned)div_up(n, kBlock)), dim3(kBlock), 0, s, Gsrc, list, n, g, im, qr, keys, vals);
+}
+
+void launch_query_keys_prune(bool keys32, const float4* Gsrc, const unsigned* list, size_t n, const unsigned* dense_start, const GridDesc& g,
+                             const InvMap& im, const QueryRange& qr, float r2, const CertParams& cert, void* keys, unsigned* vals, unsigned* count,
+                             int* match, int* match2, float* match_d2, float* lbe, hipStream_t s) {
+  if (!n) return;
+  if (keys32)
+    hipLaunchKernelGGL(k_query_keys_prune<unsigned>, dim3((unsigned)div_up(n, kBlock)), dim3(kBlock), 0, s, Gsrc, list, n, dense_start, g, im, qr, r2, cert,
+                       (unsigned*)keys, vals, count, match, match2, match_d2, lbe);
+  else
+    hipLaunchKernelGGL(k_query_keys_prune<unsigned long long>, dim3((unsigned)div_up(n, kBlock)), dim3(kBlock), 0, s, Gsrc, list, n, dense_start, g, im, qr, r2,
+                       cert, (unsigned long long*)keys, vals, count, match, match2, match_d2, lbe);
 }
 
 void launch_nn_certify(const float4* Gsrc, size_t n, const float4* Gtgt, float cum_up, float r2, float near2, bool none_near, int* match, int* match2,

@@ -85,6 +85,11 @@ void launch_query_keys_list(const float4* Gsrc, const unsigned* list, size_t n, 
                             const QueryRange& qr, unsigned long long* keys, unsigned* vals, hipStream_t s);
 void launch_query_keys32_list(const float4* Gsrc, const unsigned* list, size_t n, const GridDesc& g, const InvMap& im,
                               const QueryRange& qr, unsigned* keys, unsigned* vals, hipStream_t s);
+// keys of the listed queries (list == nullptr: all n) whose 27-cell block holds a target point, compacted into keys / vals
+// (count[0] pairs; keys32: 32-bit keys); a query with an empty block is settled as k_nn_rows would settle it (k_query_keys_prune)
+void launch_query_keys_prune(bool keys32, const float4* Gsrc, const unsigned* list, size_t n, const unsigned* dense_start, const GridDesc& g,
+                             const InvMap& im, const QueryRange& qr, float r2, const CertParams& cert, void* keys, unsigned* vals, unsigned* count,
+                             int* match, int* match2, float* match_d2, float* lbe, hipStream_t s);
 // settles every query whose old partner is provably still the unique nearest neighbour within the radius (lbe - cum_up > new
 // distance); lists the others: todo_near (old partner within sqrt(near2)) / todo_far, lengths in counts[0..1] (see k_nn_certify)
 // none_near: queries without a partner go to todo_near as well (k_nn_bounded searches them beyond the radius)

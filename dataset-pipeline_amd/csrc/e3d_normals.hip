@@ -37,7 +37,7 @@ struct KnnGrid {
   // ONE run [S[row + xa], S[row + xb + 1]) found with two independent loads; nullptr: the hash table, cell by cell
   const unsigned* S;
   unsigned D[3];
-  unsigned xcd_map;         // 1: the scan kernels hand every XCD one contiguous stretch of the query order (knn_block)
+  unsigned xcd_map;         // G > 0: the scan kernels hand an XCD G consecutive blocks of every 8 G (knn_block)
 };
 constexpr int kKnnSelFallback = 253;
 
@@ -45,14 +45,18 @@ constexpr int kKnnSelFallback = 253;
 // its own 4 MB L2.  Queries are in cell order and a block's candidates are the rows of the 27 cells around them: the ~100 blocks
 // that follow share most of those rows.  Dealt round-robin, those blocks land on all eight XCDs and every L2 fetches the same rows
 // from HBM (round 4's counters: 2.7 GB fetched per scan of a 0.32 GB point array, 4 GB by the sampled histogram).  The logical
-// block index below gives XCD x the x-th contiguous eighth of the blocks instead -- a bijection of [0, nb), so every query is still
-// handled exactly once; E3D_KNN_XCD=0 switches it off.
+// block index below hands an XCD G CONSECUTIVE blocks of every stretch of 8 G: the blocks that share rows share an L2 (fetch of
+// the scan kernel and of the sampled histogram halved, profiles/round5_pmc_normals_k8_fetch_xcd*.txt), and every XCD still gets
+// its pieces from all over the cloud -- one contiguous EIGHTH of the query order per XCD (round 4) cost a scanner-sampled scan
+// 8 - 25 %, because an eighth of such a scan is not an eighth of the work.  A bijection of [0, nb): every query is handled
+// exactly once.  xcd_map = G (E3D_KNN_XCD, default 64 blocks = 8192 queries; 0: off).
 __device__ __forceinline__ unsigned knn_block(const KnnGrid& G, unsigned b, unsigned nb) {
   constexpr unsigned kXcds = 8;
-  if (!G.xcd_map || nb < 8 * kXcds) return b;
-  const unsigned per = nb / kXcds, rem = nb % kXcds, x = b % kXcds, local = b / kXcds;
-  return x * per + min(x, rem) + local;
-}  // pass A's answer: k not reached inside a narrowed histogram range
+  const unsigned g = G.xcd_map, super = kXcds * g;
+  if (!g || b >= (nb / super) * super) return b;              // (the last, incomplete stretch keeps its order)
+  const unsigned s0 = (b / super) * super, r = b - s0;
+  return s0 + (r % kXcds) * g + r / kXcds;
+}
 
 // sqdist_l2 (query - candidate, (dx^2 + dy^2) + dz^2, every operation rounded on its own) with x and y as ONE packed operation each:
 // a candidate's x and y arrive in consecutive registers, so v_pk_add_f32 / v_pk_mul_f32 take them as they are (the compiler's own
@@ -1543,8 +1547,8 @@ static void knn_pass(KnnWorkspace& W, const float* xyz, size_t n, int k, const f
     static const int dense_log2 = [] { const char* e = getenv("E3D_KNN_DENSE_LOG2"); return e ? std::min(atoi(e), 31) : 30; }();
     auto build_level = [&](LevelBuffers& LB, double cell_size, int dir_log2, KnnGrid& G) -> bool {
       G = KnnGrid{};
-      static const bool xcd_map = [] { const char* e = getenv("E3D_KNN_XCD"); return !(e && e[0] == '0'); }();
-      G.xcd_map = xcd_map ? 1u : 0u;
+      static const unsigned xcd_map = [] { const char* e = getenv("E3D_KNN_XCD"); const int v = e ? atoi(e) : 64; return (unsigned)std::min(std::max(v, 0), 4096); }();
+      G.xcd_map = xcd_map;
       G.cell = (float)cell_size;
       G.g.inv_cell = (float)(1.0 / (double)G.cell);
       for (int a = 0; a < 3; ++a) { G.g.origin[a] = (float)((double)bb[a] - 2.0 * cell_size); G.dmin[a] = bb[a]; G.dmax[a] = bb[3 + a]; }

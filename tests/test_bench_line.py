@@ -49,3 +49,23 @@ def test_emit_prints_the_compact_line_last(tmp_path, capsys):
     assert len(out) == 1 and len(out[0]) < 4096
     assert json.loads(out[0])["metric"] == detail["metric"]
     assert json.load(open(A.detail))["value"] == detail["value"]
+
+
+def test_check_scale8_reads_compact_lines(tmp_path):
+    """tools/check_scale8.py: the reader of the first multi-GPU run works on the compact lines (no GPU)."""
+    import subprocess
+    detail = json.load(open(RECORDED[-1]))
+    l1 = bench.compact_line(detail)
+    l8 = json.loads(json.dumps(l1))
+    l8["n_gpus"] = 8
+    l8["value"] *= 7.0
+    if "allpairs" in l8.get("legs", {}):
+        l8["legs"]["allpairs"]["value"] *= 5.0
+        l8["legs"]["allpairs"]["ms_per_iter"] /= 5.0
+    (tmp_path / "n1.txt").write_text("some earlier output\n" + json.dumps(l1) + "\n")
+    (tmp_path / "n8.txt").write_text(json.dumps(l8) + "\n")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_scale8.py"), str(tmp_path / "n1.txt"), str(tmp_path / "n8.txt")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    rows = [ln.split() for ln in r.stdout.splitlines() if ln.strip().startswith(("1 ", "8 "))]
+    assert len(rows) == 2 and abs(float(rows[1][3]) - 7.0 / 8.0) < 1e-3, r.stdout

@@ -18,10 +18,13 @@ import importlib, json, sys
 sys.path.insert(0, %r)
 e3d = importlib.import_module("dataset-pipeline_amd")
 synth = importlib.import_module("dataset-pipeline_amd.synth")
-scans = synth.make_scene(4, 400000, seed=33)             # dense enough for the certificate search, resident rows and pair batches
+import torch
+# dense enough for the certificate search, resident rows and pair batches (>= 4 points per 2 cm cell), and a search radius below the
+# initial misalignment: most queries start without a partner (empty 27-cell blocks: the pruning key kernel has work)
+scans = synth.make_scene(4, 3000000, seed=33, device=torch.device("cuda", 0))
 icp = e3d.PointToPlaneICP()
-ids = [icp.add_point_cloud(s["xyz"].numpy(), s["normals"].numpy(), s["T_init"], i == 3) for i, s in enumerate(scans)]
-icp.run(0.1, 0, 6, 1e-9, False)
+ids = [icp.add_point_cloud(s["xyz"], s["normals"], s["T_init"], i == 3) for i, s in enumerate(scans)]
+icp.run(0.02, 0, 8, 1e-9, False)
 pairs = [[int(r[0]), int(r[1]), int(r[2]), int(r[3]), float(r[4]).hex()] for r in icp.pair_records()]
 poses = [[float(v).hex() for v in icp.get_result_global_T_cloud(i).ravel()] for i in ids if i >= 0]
 rec = icp.iter_records()

@@ -38,8 +38,7 @@ class IterRecord(C.Structure):
                 ("nn_certify_launches", C.c_int32), ("nn_bounded_launches", C.c_int32), ("nn_search_launches", C.c_int32),
                 ("lm_passes_skipped", C.c_int32), ("t_nn_sort_ms", C.c_double), ("t_nn_scan_ms", C.c_double), ("t_nn_compact_ms", C.c_double),
                 ("corr_rows_rewritten", C.c_int64), ("corr_rows_walked", C.c_int64),
-                ("nn_update_launches", C.c_int32), ("nn_kernel_launches", C.c_int32), ("nn_batches", C.c_int32), ("nn_sort_calls", C.c_int32),
-                ("nn_pruned_queries", C.c_int64)]
+                ("nn_update_launches", C.c_int32), ("nn_kernel_launches", C.c_int32), ("nn_batches", C.c_int32), ("nn_sort_calls", C.c_int32)]
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_size_t, C.c_void_p)

@@ -54,6 +54,11 @@ struct Cloud {
   bool has_dense = false;
   DevBuf<unsigned long long> half_prefix;   // half-cell directory (8 prefix bytes per cell) of the bounded search: dense clouds
   bool has_half = false;
+  // coarse distance field (one byte per cell of the dense directory's range, rows padded to field_stride cells): Chebyshev
+  // distance in cells to the nearest occupied cell -- the certificate bound of queries without a partner (k_nn_rows)
+  DevBuf<unsigned char> field;
+  unsigned field_stride = 0;
+  bool has_field = false;
   GridDesc grid{};
   QueryRange qrange{};              // target-cell range a query needs to hit to have candidates
   unsigned n_cells = 0;             // occupied cells
@@ -188,8 +193,6 @@ struct e3d_icp {
   PinBuf<NnBatchDev> h_batch;                   // the pair table of find_pairs_multi
   DevBuf<NnBatchDev> d_batch;
   DevBuf<unsigned> chunk_rewritten;
-  DevBuf<unsigned> prune_count;                 // number of (key, query) pairs k_query_keys_prune kept
-  PinBuf<unsigned> h_prune_count;
   DevBuf<unsigned long long> d_totals_all;
   DevBuf<double> d_d2_all;
   PinBuf<unsigned long long> h_totals_all;
@@ -361,6 +364,27 @@ static void build_grid(e3d_icp* h, Cloud& c, float d) {
     }
   }
   if (!c.has_half) c.half_prefix.release();
+  // coarse distance field (E3D_NN_FIELD = rounds = the largest distance it resolves, in cells; default 8, 0: none).  One byte per
+  // cell plus two scratch arrays of that size during the build; skipped when that does not fit comfortably.
+  c.has_field = false;
+  static const int field_rounds = [] { const char* e = getenv("E3D_NN_FIELD"); const int v = e ? atoi(e) : 8; return std::min(std::max(v, 0), 100); }();
+  if (c.has_dense && field_rounds > 0 && n > 0) {
+    const unsigned stride = (c.qrange.D[0] + 3u) & ~3u;
+    const size_t bytes = (size_t)c.qrange.D[2] * c.qrange.D[1] * stride;
+    size_t free_b = 0, total_b = 0;
+    (void)hipMemGetInfo(&free_b, &total_b);
+    if (3.0 * (double)bytes <= 0.25 * (double)free_b) {
+      try {
+        DevBuf<unsigned char> ta, tb;
+        c.field.reserve(bytes); ta.reserve(bytes); tb.reserve(bytes);
+        launch_distance_field(c.dense_start.p, c.qrange, stride, field_rounds, c.field.p, ta.p, tb.p, s);
+        sync(h);
+        c.field_stride = stride;
+        c.has_field = true;
+      } catch (const Error&) { (void)hipGetLastError(); }
+    }
+  }
+  if (!c.has_field) c.field.release();
   c.grid_valid = true;
   c.grid_radius = d;
   std::memcpy(c.grid_T, c.T, sizeof c.grid_T);
@@ -506,7 +530,8 @@ static bool launch_rows(int mode, const Cloud& tgt, const float4* srcG, const un
     launch_nn_mfma(srcG, order, n, tgt.G4.p, tgt.dense_start.p, tgt.grid, im, tgt.qrange, r2, P, match_pos, match_d2, s);
     return false;
   }
-  launch_nn_rows(srcG, order, n, tgt.G4.p, tgt.dense_start.p, tgt.grid, im, tgt.qrange, r2, cert, match_pos, match_d2, lbe, match2, s);
+  launch_nn_rows(srcG, order, n, tgt.G4.p, tgt.dense_start.p, tgt.grid, im, tgt.qrange, r2, cert, match_pos, match_d2, lbe, match2,
+                 tgt.has_field ? tgt.field.p : nullptr, tgt.field_stride, s);
   return true;
 }
 
@@ -526,32 +551,6 @@ static void sort_query_keys(e3d_icp* h, const Cloud& tgt, const float4* srcG, co
     else launch_query_keys(srcG, n, tgt.grid, im, tgt.qrange, h->keys_a.p, h->vals_a.p, s);
     sort_pairs_u64_u32(h->keys_a.p, h->keys_b.p, h->vals_a.p, h->vals_b.p, n, tgt.key_bits, h->sort_temp, s);
   }
-}
-
-// The certificate path's variant: the key kernel settles the queries whose 27-cell block holds no target point (k_query_keys_prune)
-// and only the others are sorted; returns how many those are (h->vals_b: their source positions in key order).  One host round
-// trip for the count (the sort's size).  E3D_NN_PRUNE=0: every listed query is keyed and sorted (sort_query_keys).
-static size_t sort_query_keys_pruned(e3d_icp* h, const Cloud& tgt, const float4* srcG, const unsigned* list, size_t n, const InvMap& im, float r2,
-                                     const CertParams& cert, int* match, int* match2, float* match_d2, float* lbe, e3d_icp_iter_record& rec) {
-  static const bool prune = [] { const char* e = getenv("E3D_NN_PRUNE"); return !(e && e[0] == '0'); }();
-  if (!prune || !tgt.has_dense || n == 0) { sort_query_keys(h, tgt, srcG, list, n, im); return n; }
-  hipStream_t s = h->stream;
-  h->keys_a.reserve(n); h->keys_b.reserve(n); h->vals_a.reserve(n); h->vals_b.reserve(n);
-  h->prune_count.reserve(1); h->h_prune_count.reserve(1);
-  h->tm_sort.start(s);
-  struct Stop { e3d_icp* h; hipStream_t s; ~Stop() { h->tm_sort.stop(s); } } stop_at_return{h, s};
-  const bool k32 = tgt.key_bits <= 31;
-  E3D_HIP(hipMemsetAsync(h->prune_count.p, 0, sizeof(unsigned), s));
-  launch_query_keys_prune(k32, srcG, list, n, tgt.dense_start.p, tgt.grid, im, tgt.qrange, r2, cert, h->keys_a.p, h->vals_a.p, h->prune_count.p,
-                          match, match2, match_d2, lbe, s);
-  copy_out(h->h_prune_count.p, h->prune_count.p, sizeof(unsigned), s);
-  sync(h);
-  const size_t kept = h->h_prune_count.p[0];
-  rec.nn_pruned_queries += (long long)(n - kept);
-  if (kept == 0) return 0;
-  if (k32) sort_pairs_u32_u32(reinterpret_cast<unsigned*>(h->keys_a.p), reinterpret_cast<unsigned*>(h->keys_b.p), h->vals_a.p, h->vals_b.p, kept, tgt.key_bits, h->sort_temp, s);
-  else sort_pairs_u64_u32(h->keys_a.p, h->keys_b.p, h->vals_a.p, h->vals_b.p, kept, tgt.key_bits, h->sort_temp, s);
-  return kept;
 }
 
 // NN search + compaction for one directed pair; appends to the correspondence planes.
@@ -666,17 +665,12 @@ static void find_pair(e3d_icp* h, Cloud& src, Cloud& tgt, float d, PairJob& job,
       h->tm_bounded.stop(s);
       if (n_near > 0) { rec.nn_bounded_launches++; rec.nn_bounded_queries += (long long)n_near; rec.nn_kernel_launches++; }
     }
-    size_t n_rows = 0;                                     // far-list queries with a candidate in their 27 cells: sorted and searched
-    if (n_far > 0) {
-      NnPhase ph(s, 1);
-      n_rows = sort_query_keys_pruned(h, tgt, srcG, list, n_far, im, radius_sq(d), cert, ps.match.p, ps.match2.p, h->match_d2.p, ps.lbe.p, rec);
-      rec.nn_sort_calls++; rec.nn_kernel_launches++;
-    }
+    if (n_far > 0) { NnPhase ph(s, 1); sort_query_keys(h, tgt, srcG, list, n_far, im); rec.nn_sort_calls++; rec.nn_kernel_launches++; }
     h->nn_timer->start(s);
-    if (n_rows > 0)
-      launch_rows(3, tgt, srcG, h->vals_b.p, n_rows, im, radius_sq(d), cert, ps.match.p, h->match_d2.p, ps.lbe.p, ps.match2.p, s);
+    if (n_far > 0)
+      launch_rows(3, tgt, srcG, h->vals_b.p, n_far, im, radius_sq(d), cert, ps.match.p, h->match_d2.p, ps.lbe.p, ps.match2.p, s);
     ps.fresh = false;
-    if (n_rows > 0) { rec.nn_search_launches++; rec.nn_search_queries += (long long)n_rows; rec.nn_kernel_launches++; }
+    if (n_far > 0) { rec.nn_search_launches++; rec.nn_search_queries += (long long)n_far; rec.nn_kernel_launches++; }
     if (want_stats)
       fprintf(stderr, "[nn %d->%d] queries %zu bounded %zu rows %zu cum %.3g (last %.3g) err %.3g\n", job.src, job.tgt, n,
               n_near, n_far, cum_pair, src.last_motion + tgt.last_motion, src.err_max + tgt.err_max);
@@ -886,14 +880,12 @@ static void find_pairs_batched(e3d_icp* h, std::vector<BatchItem>& items, float 
       if (it.n_near > 0) { rec.nn_bounded_launches++; rec.nn_bounded_queries += (long long)it.n_near; rec.nn_kernel_launches++; }
     }
     if (it.n_far > 0) {
-      rec.nn_sort_calls++; rec.nn_kernel_launches++;
-      const size_t n_rows = sort_query_keys_pruned(h, tgt, srcG, list, it.n_far, it.im, radius_sq(d), it.cert, ps.match.p, ps.match2.p, sl.match_d2.p, ps.lbe.p, rec);
-      if (n_rows > 0) {
-        h->tm_search.start(s);
-        launch_rows(3, tgt, srcG, h->vals_b.p, n_rows, it.im, radius_sq(d), it.cert, ps.match.p, sl.match_d2.p, ps.lbe.p, ps.match2.p, s);
-        h->tm_search.stop(s);
-        rec.nn_search_launches++; rec.nn_search_queries += (long long)n_rows; rec.nn_kernel_launches++;
-      }
+      rec.nn_sort_calls++; rec.nn_kernel_launches += 2;
+      sort_query_keys(h, tgt, srcG, list, it.n_far, it.im);
+      h->tm_search.start(s);
+      launch_rows(3, tgt, srcG, h->vals_b.p, it.n_far, it.im, radius_sq(d), it.cert, ps.match.p, sl.match_d2.p, ps.lbe.p, ps.match2.p, s);
+      h->tm_search.stop(s);
+      rec.nn_search_launches++; rec.nn_search_queries += (long long)it.n_far;
     }
     ps.fresh = false;
     if (want_stats)
@@ -1072,15 +1064,11 @@ static bool find_pairs_multi(e3d_icp* h, std::vector<BatchItem>& items, float d,
     if (it.n_far > 0) {
       e3d_icp::PairSlot& sl = *h->slots[i];
       const float4* srcG = it.src->G4.p + it.j0;
-      const size_t n_rows = sort_query_keys_pruned(h, *it.tgt, srcG, it.certified ? sl.todo_far.p : nullptr, it.n_far, it.im, radius_sq(d), it.cert,
-                                                   ps.match.p, ps.match2.p, sl.match_d2.p, ps.lbe.p, rec);
-      rec.nn_kernel_launches++; rec.nn_sort_calls++;
-      if (n_rows > 0) {
-        h->tm_search.start(s);
-        launch_rows(3, *it.tgt, srcG, h->vals_b.p, n_rows, it.im, radius_sq(d), it.cert, ps.match.p, sl.match_d2.p, ps.lbe.p, ps.match2.p, s);
-        h->tm_search.stop(s);
-        rec.nn_search_launches++; rec.nn_search_queries += (long long)n_rows; rec.nn_kernel_launches++;
-      }
+      sort_query_keys(h, *it.tgt, srcG, it.certified ? sl.todo_far.p : nullptr, it.n_far, it.im);
+      h->tm_search.start(s);
+      launch_rows(3, *it.tgt, srcG, h->vals_b.p, it.n_far, it.im, radius_sq(d), it.cert, ps.match.p, sl.match_d2.p, ps.lbe.p, ps.match2.p, s);
+      h->tm_search.stop(s);
+      rec.nn_search_launches++; rec.nn_search_queries += (long long)it.n_far; rec.nn_kernel_launches += 2; rec.nn_sort_calls++;
     }
     ps.fresh = false;
     if (want_stats)

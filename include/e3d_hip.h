@@ -36,8 +36,8 @@ extern "C" {
  *    e3d_icp_set_sequential_distance_sum (round 3)
  * 4: e3d_icp_set_resident_rows, e3d_comm_get_stats; iteration record: multi_cost_poses, lm_passes_skipped in the two reserved
  *    words, corr_rows_rewritten / corr_rows_walked appended (round 4)
- * 5: iteration record: nn_update_launches, nn_kernel_launches, nn_batches, nn_sort_calls, nn_pruned_queries appended (round 5: a batch
- *    of directed pairs per kernel launch; queries with an empty 27-cell block settled by the key kernel) */
+ * 5: iteration record: nn_update_launches, nn_kernel_launches, nn_batches, nn_sort_calls appended (round 5: a batch of directed pairs
+ *    per kernel launch) */
 #define E3D_ABI_VERSION 5
 
 #define E3D_ERR_INVALID   (-2)   /* bad argument / bad handle state          */
@@ -146,7 +146,6 @@ typedef struct {
                                   the launches inside rocPRIM's radix sort are not counted: nn_sort_calls sorts)          */
   int32_t nn_batches;          /* batches of directed pairs that ran with one launch per kernel (0: pair by pair)          */
   int32_t nn_sort_calls;       /* radix sorts of query lists (k_nn_rows path)                                             */
-  int64_t nn_pruned_queries;   /* far-list queries the key kernel settled itself: no target point in their 27 cells        */
 } e3d_icp_iter_record;
 
 size_t e3d_icp_num_pair_records(const e3d_icp_t* icp);

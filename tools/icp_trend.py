@@ -29,11 +29,11 @@ for it in range(iters):
 r = icp.iter_records()
 print("partial" if partial else "full", "scene, %d x %d points, d = %g, misalignment scale %g" % (S, n, d, perturb))
 print("wall ms per iteration:", " ".join("%.1f" % v for v in wall))
-print(" it   corr(M)  certify ms (Mq)   bounded ms (Mq)   rows ms (Mq)   sort  scan  rows-upd (M rewritten)  nn_other  transform   lm_kernels full/multi ms (full/multi passes, poses, skipped)  lm_other  pruned(M)")
+print(" it   corr(M)  certify ms (Mq)   bounded ms (Mq)   rows ms (Mq)   sort  scan  rows-upd (M rewritten)  nn_other  transform   lm_kernels full/multi ms (full/multi passes, poses, skipped)  lm_other")
 for x in r:
-    print("%3d  %7.2f   %6.2f (%6.1f)   %6.2f (%6.2f)   %6.2f (%6.2f)   %5.2f %5.2f %5.2f (%6.2f)   %6.2f    %6.2f    %6.2f / %5.2f (%d/%d, %d, %d)   %6.2f   %7.2f" % (
+    print("%3d  %7.2f   %6.2f (%6.1f)   %6.2f (%6.2f)   %6.2f (%6.2f)   %5.2f %5.2f %5.2f (%6.2f)   %6.2f    %6.2f    %6.2f / %5.2f (%d/%d, %d, %d)   %6.2f" % (
         x["iteration"], x["correspondences"] / 1e6, x["t_nn_certify_ms"], x["nn_certify_queries"] / 1e6, x["t_nn_bounded_ms"],
         x["nn_bounded_queries"] / 1e6, x["t_nn_search_ms"], x["nn_search_queries"] / 1e6, x["t_nn_sort_ms"], x["t_nn_scan_ms"], x["t_nn_compact_ms"],
         x["corr_rows_rewritten"] / 1e6, x["t_nn_ms"] - x["t_nn_query_ms"] - x["t_nn_sort_ms"] - x["t_nn_scan_ms"] - x["t_nn_compact_ms"],
         x["t_transform_ms"], x["t_lm_full_kernel_ms"], x["t_lm_kernel_ms"] - x["t_lm_full_kernel_ms"], x["full_passes"], x["multi_cost_passes"],
-        x["multi_cost_poses"], x["lm_passes_skipped"], x["t_lm_ms"] - x["t_lm_kernel_ms"], x["nn_pruned_queries"] / 1e6))
+        x["multi_cost_poses"], x["lm_passes_skipped"], x["t_lm_ms"] - x["t_lm_kernel_ms"]))

@@ -54,11 +54,6 @@ struct Cloud {
   bool has_dense = false;
   DevBuf<unsigned long long> half_prefix;   // half-cell directory (8 prefix bytes per cell) of the bounded search: dense clouds
   bool has_half = false;
-  // coarse distance field (one byte per cell of the dense directory's range, rows padded to field_stride cells): Chebyshev
-  // distance in cells to the nearest occupied cell -- the certificate bound of queries without a partner (k_nn_rows)
-  DevBuf<unsigned char> field;
-  unsigned field_stride = 0;
-  bool has_field = false;
   GridDesc grid{};
   QueryRange qrange{};              // target-cell range a query needs to hit to have candidates
   unsigned n_cells = 0;             // occupied cells
@@ -364,27 +359,6 @@ static void build_grid(e3d_icp* h, Cloud& c, float d) {
     }
   }
   if (!c.has_half) c.half_prefix.release();
-  // coarse distance field (E3D_NN_FIELD = rounds = the largest distance it resolves, in cells; default 8, 0: none).  One byte per
-  // cell plus two scratch arrays of that size during the build; skipped when that does not fit comfortably.
-  c.has_field = false;
-  static const int field_rounds = [] { const char* e = getenv("E3D_NN_FIELD"); const int v = e ? atoi(e) : 8; return std::min(std::max(v, 0), 100); }();
-  if (c.has_dense && field_rounds > 0 && n > 0) {
-    const unsigned stride = (c.qrange.D[0] + 3u) & ~3u;
-    const size_t bytes = (size_t)c.qrange.D[2] * c.qrange.D[1] * stride;
-    size_t free_b = 0, total_b = 0;
-    (void)hipMemGetInfo(&free_b, &total_b);
-    if (3.0 * (double)bytes <= 0.25 * (double)free_b) {
-      try {
-        DevBuf<unsigned char> ta, tb;
-        c.field.reserve(bytes); ta.reserve(bytes); tb.reserve(bytes);
-        launch_distance_field(c.dense_start.p, c.qrange, stride, field_rounds, c.field.p, ta.p, tb.p, s);
-        sync(h);
-        c.field_stride = stride;
-        c.has_field = true;
-      } catch (const Error&) { (void)hipGetLastError(); }
-    }
-  }
-  if (!c.has_field) c.field.release();
   c.grid_valid = true;
   c.grid_radius = d;
   std::memcpy(c.grid_T, c.T, sizeof c.grid_T);
@@ -530,8 +504,7 @@ static bool launch_rows(int mode, const Cloud& tgt, const float4* srcG, const un
     launch_nn_mfma(srcG, order, n, tgt.G4.p, tgt.dense_start.p, tgt.grid, im, tgt.qrange, r2, P, match_pos, match_d2, s);
     return false;
   }
-  launch_nn_rows(srcG, order, n, tgt.G4.p, tgt.dense_start.p, tgt.grid, im, tgt.qrange, r2, cert, match_pos, match_d2, lbe, match2,
-                 tgt.has_field ? tgt.field.p : nullptr, tgt.field_stride, s);
+  launch_nn_rows(srcG, order, n, tgt.G4.p, tgt.dense_start.p, tgt.grid, im, tgt.qrange, r2, cert, match_pos, match_d2, lbe, match2, s);
   return true;
 }
 

@@ -671,8 +671,7 @@ __global__ __launch_bounds__(kBlock, 6) void k_nn_rows(const float4* __restrict_
                                                        const unsigned* __restrict__ S, GridDesc g, InvMap im,
                                                        QueryRange qr, float r2, int row_span, CertParams cert,
                                                        int* __restrict__ match_pos, float* __restrict__ match_d2,
-                                                       float* __restrict__ lbe, int* __restrict__ match2,
-                                                       const unsigned char* __restrict__ field, unsigned field_stride) {
+                                                       float* __restrict__ lbe, int* __restrict__ match2) {
   __shared__ RowLds lds[kBlock / kWave];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   RowLds& L = lds[w];
@@ -832,93 +831,9 @@ __global__ __launch_bounds__(kBlock, 6) void k_nn_rows(const float4* __restrict_
     // every candidate in the 27 cells was evaluated: the others are >= sqrt(best_b2) away (all of them, if there is no partner:
     // best_d2 stayed r2, so best_b2 is the smallest distance seen); points outside the block are >= block_dist cells away in
     // the local frame (2 cells if the query's cell lies outside the directory range, i.e. occupied cells +- 2)
-    // Without a partner the bound above ends at the faces of the 27-cell block, 1 - 1.5 cells away -- barely beyond the radius, so
-    // the certificate breaks with the next pose update and the query is keyed, sorted and searched again in every outer iteration
-    // for as long as the scans are centimetres apart.  The target's coarse distance field (k_field_*: per grid cell the Chebyshev
-    // distance, in cells, to the nearest cell that holds a point) says how far the nearest point really is: with m = field(cell),
-    // every target point lies outside the (2 m - 1)^3 block around the query's cell, i.e. at least block_dist + (m - 2) cells away.
-    if (field && best_pos < 0 && key != kEmptyKey) {
-      const unsigned m = field[((size_t)kz * qr.D[1] + (size_t)ky) * field_stride + (size_t)kx];
-      if (m >= 2u) block_dist += (float)(m - 2u);
-    }
     const float lb_out = block_dist * cert.cell_scale - cert.cell_sub;
     lbe[j] = fmaxf(fminf(sqrtf(best_b2), lb_out), 0.0f) * 0.999999f + cert.cum_lo;
   }
-}
-
-// -------------------------------------------------------------------------------------------------
-// Coarse distance field of a cloud's static grid (round 5): F[z][y][x] (rows padded to a multiple of four cells) = Chebyshev
-// distance, in cells, from cell (x, y, z) of the dense directory's range to the nearest cell that holds a point, exact up to
-// `rounds` and rounds + 1 beyond (a valid lower bound).  {F <= m} is the occupancy dilated by a cube of radius m, and a cube
-// dilation is separable: a round takes the minimum over x +- 1, then y +- 1, then z +- 1 (three passes over packed bytes, four cells
-// per thread), adds one and keeps the smaller of that and the old value.  One-off per grid build (~1 ms per round at 3e8 cells).
-// -------------------------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned field_min4(unsigned a, unsigned b) {
-  unsigned r = 0u;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) r |= min((a >> (8 * k)) & 0xFFu, (b >> (8 * k)) & 0xFFu) << (8 * k);
-  return r;
-}
-__global__ __launch_bounds__(kBlock) void k_field_init(const unsigned* __restrict__ S, QueryRange qr, unsigned stride, unsigned* __restrict__ F) {
-  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const unsigned q4 = stride / 4u;
-  const size_t row = t / q4;
-  if (row >= (size_t)qr.D[1] * qr.D[2]) return;
-  const unsigned x0 = (unsigned)(t % q4) * 4u;
-  unsigned w = 0u;
-#pragma unroll
-  for (int b = 0; b < 4; ++b) {
-    const unsigned x = x0 + (unsigned)b;
-    unsigned v = 255u;
-    if (x < qr.D[0]) { const size_t lin = row * qr.D[0] + x; v = (S[lin + 1] > S[lin]) ? 0u : 255u; }
-    w |= v << (8 * b);
-  }
-  F[t] = w;
-}
-// AXIS 0 / 1: out = min over the axis' three neighbours of in; AXIS 2: out = min(cur, (min over z +- 1 of in) + 1), saturating at 255
-// (out may be cur: a thread reads only its own word of it).  Cells beyond the grid count as 255; the padding cells of a row stay 255.
-template <int AXIS>
-__global__ __launch_bounds__(kBlock) void k_field_pass(const unsigned* __restrict__ in, const unsigned* cur, unsigned* out, unsigned D0,
-                                                       unsigned D1, unsigned D2, unsigned stride) {
-  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const unsigned q4 = stride / 4u;
-  const size_t row = t / q4;
-  if (row >= (size_t)D1 * D2) return;
-  const unsigned xw = (unsigned)(t % q4), x0 = xw * 4u;
-  const unsigned w = in[t];
-  unsigned r;
-  if (AXIS == 0) {
-    const unsigned left = xw > 0u ? (in[t - 1] >> 24) : 255u, right = xw + 1u < q4 ? (in[t + 1] & 0xFFu) : 255u;
-    const unsigned lo = (w << 8) | left, hi = (w >> 8) | (right << 24);       // byte k: the cell to the left / right of cell k
-    r = field_min4(field_min4(lo, w), hi);
-  } else if (AXIS == 1) {
-    const unsigned y = (unsigned)(row % D1);
-    const unsigned up = y > 0u ? in[t - q4] : 0xFFFFFFFFu, dn = y + 1u < D1 ? in[t + q4] : 0xFFFFFFFFu;
-    r = field_min4(field_min4(up, w), dn);
-  } else {
-    const unsigned z = (unsigned)(row / D1);
-    const size_t slab = (size_t)D1 * q4;
-    const unsigned up = z > 0u ? in[t - slab] : 0xFFFFFFFFu, dn = z + 1u < D2 ? in[t + slab] : 0xFFFFFFFFu;
-    const unsigned m = field_min4(field_min4(up, w), dn);
-    unsigned inc = 0u;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { const unsigned v = (m >> (8 * k)) & 0xFFu; inc |= (v == 255u ? 255u : v + 1u) << (8 * k); }
-    r = field_min4(cur[t], inc);
-  }
-  // padding cells (x >= D0) never carry a distance
-#pragma unroll
-  for (int k = 0; k < 4; ++k) if (x0 + (unsigned)k >= D0) r |= 0xFFu << (8 * k);
-  out[t] = r;
-}
-// values beyond the last round: rounds + 1 (all that is known: farther than `rounds` cells)
-__global__ __launch_bounds__(kBlock) void k_field_cap(unsigned* __restrict__ F, size_t n_words, unsigned cap) {
-  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n_words) return;
-  const unsigned w = F[t];
-  unsigned r = 0u;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) r |= min((w >> (8 * k)) & 0xFFu, cap) << (8 * k);
-  F[t] = r;
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -2724,27 +2639,10 @@ static int row_span_setting() {
 
 void launch_nn_rows(const float4* Gsrc, const unsigned* order, size_t n, const float4* Gtgt, const unsigned* dense_start,
                     const GridDesc& g, const InvMap& im, const QueryRange& qr, float r2, const CertParams& cert, int* match_pos,
-                    float* match_d2, float* lbe, int* match2, const unsigned char* field, unsigned field_stride, hipStream_t s) {
+                    float* match_d2, float* lbe, int* match2, hipStream_t s) {
   if (!n) return;
   hipLaunchKernelGGL(k_nn_rows, dim3((unsigned)div_up(n, kBlock)), dim3(kBlock), 0, s, Gsrc, order, n, Gtgt, dense_start,
-                     g, im, qr, r2, row_span_setting(), cert, match_pos, match_d2, lbe, match2, field, field_stride);
-}
-
-void launch_distance_field(const unsigned* dense_start, const QueryRange& qr, unsigned stride, int rounds, unsigned char* field, unsigned char* tmp_a,
-                           unsigned char* tmp_b, hipStream_t s) {
-  const size_t n_words = (size_t)qr.D[2] * qr.D[1] * (stride / 4u);
-  if (!n_words) return;
-  const dim3 grid((unsigned)div_up(n_words, kBlock)), block(kBlock);
-  unsigned* F = reinterpret_cast<unsigned*>(field);
-  unsigned* A = reinterpret_cast<unsigned*>(tmp_a);
-  unsigned* B = reinterpret_cast<unsigned*>(tmp_b);
-  hipLaunchKernelGGL(k_field_init, grid, block, 0, s, dense_start, qr, stride, F);
-  for (int r = 0; r < rounds; ++r) {
-    hipLaunchKernelGGL(k_field_pass<0>, grid, block, 0, s, (const unsigned*)F, (const unsigned*)nullptr, A, qr.D[0], qr.D[1], qr.D[2], stride);
-    hipLaunchKernelGGL(k_field_pass<1>, grid, block, 0, s, (const unsigned*)A, (const unsigned*)nullptr, B, qr.D[0], qr.D[1], qr.D[2], stride);
-    hipLaunchKernelGGL(k_field_pass<2>, grid, block, 0, s, (const unsigned*)B, (const unsigned*)F, F, qr.D[0], qr.D[1], qr.D[2], stride);
-  }
-  hipLaunchKernelGGL(k_field_cap, grid, block, 0, s, F, n_words, (unsigned)(rounds + 1));
+                     g, im, qr, r2, row_span_setting(), cert, match_pos, match_d2, lbe, match2);
 }
 
 void launch_query_keys_list(const float4* Gsrc, const unsigned* list, size_t n, const GridDesc& g, const InvMap& im,

@@ -78,15 +78,9 @@ struct CertParams {
   float cum_lo;          // accumulated motion bound of the pair at this outer iteration, rounded down
 };
 // k_nn_rows writes its results at the queries' SOURCE positions order[pos] (match_pos, match_d2, lbe in source order)
-// field (or nullptr): the target's coarse distance field [D2][D1][field_stride] (launch_distance_field) -- queries without a partner get
-// their certificate bound from it
 void launch_nn_rows(const float4* Gsrc, const unsigned* order, size_t n, const float4* Gtgt, const unsigned* dense_start,
                     const GridDesc& g, const InvMap& im, const QueryRange& qr, float r2, const CertParams& cert, int* match_pos,
-                    float* match_d2, float* lbe, int* match2, const unsigned char* field, unsigned field_stride, hipStream_t s);
-// per cell of the dense directory's range the Chebyshev distance (cells) to the nearest occupied cell, exact up to `rounds`, rounds + 1
-// beyond; rows padded to `stride` (a multiple of 4) cells; tmp_a / tmp_b: scratch of the field's size
-void launch_distance_field(const unsigned* dense_start, const QueryRange& qr, unsigned stride, int rounds, unsigned char* field, unsigned char* tmp_a,
-                           unsigned char* tmp_b, hipStream_t s);
+                    float* match_d2, float* lbe, int* match2, hipStream_t s);
 void launch_query_keys_list(const float4* Gsrc, const unsigned* list, size_t n, const GridDesc& g, const InvMap& im,
                             const QueryRange& qr, unsigned long long* keys, unsigned* vals, hipStream_t s);
 void launch_query_keys32_list(const float4* Gsrc, const unsigned* list, size_t n, const GridDesc& g, const InvMap& im,

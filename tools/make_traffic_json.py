@@ -1,14 +1,14 @@
-"""profiles/round<N>_traffic.json from the rocprofv3 PMC passes of tools/prof_round4.sh (gpurun_out/r4prof/*_fetch.txt, *_write.txt:
+"""profiles/round<N>_traffic.json from the rocprofv3 PMC passes of tools/prof_round5.sh (gpurun_out/r5prof/*_fetch.txt, *_write.txt:
 lines `kernel signature, COUNTER, value summed over the launches, launches`).
 
-    python tools/make_traffic_json.py [gpurun_out/r4prof] [profiles/round4_traffic.json]"""
+    python tools/make_traffic_json.py [gpurun_out/r5prof] [profiles/round5_traffic.json]"""
 import json
 import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-NOTE = ("HBM traffic per launch from rocprofv3 PMC, separate --pmc FETCH_SIZE and --pmc WRITE_SIZE passes (tools/prof_round4.sh): the ICP "
-        "kernels from `bench.py --no-cpu-baseline --no-reg --no-normals --no-allpairs --steps 3 --warmup 2` (2 x 50 M points; the full-overlap and the partial-overlap leg, launches of both averaged), the "
+NOTE = ("HBM traffic per launch from rocprofv3 PMC, separate --pmc FETCH_SIZE and --pmc WRITE_SIZE passes (tools/prof_round5.sh): the ICP "
+        "kernels from `bench.py --no-cpu-baseline --no-reg --no-normals --no-allpairs --no-partial --no-whole-run --steps 6 --warmup 10` (the headline leg alone, 2 x 50 M points, iterations 0 .. 15: k_lm_pass<1> etc. from the full-size launches only), the "
         "ImageRegistrator kernels (k_reg_*, k_obs_*, k_splat_*, k_min_filter_*, k_color_*) from `bench.py --only reg --no-cpu-baseline --reg-images 4` (6048 x 4032 "
         "THIN_PRISM_FISHEYE, 10 M points: observation refreshes, accumulate passes and RunOnCurrentScale iterations), the normals "
         "entries k_knn_normals_k32 / _k8 = ALL kernels of one e3d_normals_knn call on 20 M points (`tools/bench_normals.py --repeat 1`: "
@@ -36,8 +36,8 @@ def parse(path, counter):
 
 
 def main():
-    src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "r4prof")
-    dst = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles", "round4_traffic.json")
+    src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "r5prof")
+    dst = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles", "round5_traffic.json")
     kernels = {}
     for tag in ("icp", "reg"):
         f, w = parse(os.path.join(src, tag + "_fetch.txt"), "FETCH_SIZE"), parse(os.path.join(src, tag + "_write.txt"), "WRITE_SIZE")
@@ -48,8 +48,7 @@ def main():
             fb, wb = 2048.0 * f[name][0] / f[name][1], 1024.0 * w[name][0] / w[name][1]
             kernels[name] = {"launches": f[name][1], "fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb, "hbm_bytes_per_launch": fb + wb}
             if tag == "icp" and name.startswith(FULL_SIZE) and name in ff and name in wf:
-                # the ICP run ramps up (22, 37, 73, 100, 100 M correspondences in its five iterations, and the partial-overlap leg holds
-                # half as many): for the kernels whose launches in bench.py's timed region all cover the whole 2 x 50 M scans, the
+                # the ICP run ramps up (9 .. 100 M correspondences over its sixteen iterations): for the kernels whose launches in bench.py's timed region all cover the whole 2 x 50 M scans, the
                 # figure to compare is that of the full-size launches -- each pass's dispatches with >= 0.8 of its largest counter value
                 fb, wb = 2048.0 * ff[name][0] / ff[name][1], 1024.0 * wf[name][0] / max(wf[name][1], 1)
                 kernels[name].update({"all_launches_hbm_bytes_per_launch": kernels[name]["hbm_bytes_per_launch"], "full_size_launches": ff[name][1],

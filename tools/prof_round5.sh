@@ -1,48 +1,49 @@
 #!/bin/bash
-# Round-4 evidence (one MI355X): kernel-trace stats of the default bench line, HBM traffic counters (separate FETCH_SIZE / WRITE_SIZE passes)
-# and SQ counters of the kernels of the three paths.  Summaries land in gpurun_out/r4prof/ ; the ones to judge are copied to profiles/.
-# usage: bash tools/prof_round4.sh [stage ...]   stages: trace terrace partial icp reg normals sq nsq nta   (default: all but partial)
+# Round-5 evidence (one MI355X): kernel-trace stats of the default bench line, HBM traffic counters (separate FETCH_SIZE / WRITE_SIZE passes)
+# and SQ counters of the kernels of the three paths.  Summaries land in gpurun_out/r5prof/ ; the ones to judge are copied to profiles/.
+# usage: bash tools/prof_round5.sh [stage ...]   stages: trace terrace partial icp reg normals sq nsq nta   (default: all but partial)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r4prof
+O=$R/gpurun_out/r5prof
 mkdir -p $O
 STAGES=${@:-trace terrace icp reg normals sq}
 SUM="python $R/tools/rocpd_summary.py"
-ICP="python $R/bench.py --no-cpu-baseline --no-reg --no-normals --no-allpairs --steps 3 --warmup 2"
+# (the headline leg alone, iterations 0 .. 15: the ramp, the transition and the first settling iterations of the default scene)
+ICP="python $R/bench.py --no-cpu-baseline --no-reg --no-normals --no-allpairs --no-partial --no-whole-run --steps 6 --warmup 10"
 REG="python $R/bench.py --only reg --no-cpu-baseline --reg-images 4"
 pmc() {  # pmc <tag> <counters...> -- <command>
   local tag=$1; shift
   local ctr=(); while [ "$1" != "--" ]; do ctr+=("$1"); shift; done; shift
-  rm -rf /tmp/r4p_$tag
-  timeout ${PMC_TIMEOUT:-300} rocprofv3 --kernel-trace --pmc "${ctr[@]}" -d /tmp/r4p_$tag -o p -- "$@" > /dev/null 2>&1
+  rm -rf /tmp/r5p_$tag
+  timeout ${PMC_TIMEOUT:-300} rocprofv3 --kernel-trace --pmc "${ctr[@]}" -d /tmp/r5p_$tag -o p -- "$@" > /dev/null 2>&1
   echo "[$tag] rc=$?"
-  $SUM /tmp/r4p_$tag/p_results.db $O/$tag.txt "${FILTER:-e3d}" > /dev/null 2>&1
+  $SUM /tmp/r5p_$tag/p_results.db $O/$tag.txt "${FILTER:-e3d}" > /dev/null 2>&1
 }
 for st in $STAGES; do
   case $st in
     trace)
-      rm -rf /tmp/r4p_trace
-      timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/r4p_trace -o b -- python $R/bench.py > $O/bench_traced.json 2> $O/bench_traced.err
+      rm -rf /tmp/r5p_trace
+      timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/r5p_trace -o b -- python $R/bench.py > $O/bench_traced.json 2> $O/bench_traced.err
       echo "[trace] rc=$?"
-      $SUM /tmp/r4p_trace/b_results.db $O/bench_kernel_stats.txt "" > /dev/null 2>&1
+      $SUM /tmp/r5p_trace/b_results.db $O/bench_kernel_stats.txt "" > /dev/null 2>&1
       head -25 $O/bench_kernel_stats.txt | cut -c1-60,150-230 ;;
     terrace)   # the headline leg alone: its kernel averages are the ones bench.py's live HIP-event figures must agree with
-      rm -rf /tmp/r4p_terrace
-      timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/r4p_terrace -o b -- python $R/bench.py --no-cpu-baseline --no-reg --no-normals --no-allpairs --no-partial > $O/terrace_traced.json 2> /dev/null
+      rm -rf /tmp/r5p_terrace
+      timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/r5p_terrace -o b -- python $R/bench.py --no-cpu-baseline --no-reg --no-normals --no-allpairs --no-partial --no-whole-run > $O/terrace_traced.json 2> /dev/null
       echo "[terrace] rc=$?"
-      $SUM /tmp/r4p_terrace/b_results.db $O/terrace_kernel_stats.txt e3d > /dev/null 2>&1
+      $SUM /tmp/r5p_terrace/b_results.db $O/terrace_kernel_stats.txt e3d > /dev/null 2>&1
       head -12 $O/terrace_kernel_stats.txt | cut -c1-60,150-230 ;;
     partial)   # the partial-overlap leg alone (bench.py --partial-only): the same kernels where half of the queries find no partner
-      rm -rf /tmp/r4p_partial
-      timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/r4p_partial -o b -- python $R/bench.py --no-cpu-baseline --no-reg --no-normals --no-allpairs --partial-only > $O/partial_traced.json 2> /dev/null
+      rm -rf /tmp/r5p_partial
+      timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/r5p_partial -o b -- python $R/bench.py --no-cpu-baseline --no-reg --no-normals --no-allpairs --no-whole-run --partial-only > $O/partial_traced.json 2> /dev/null
       echo "[partial] rc=$?"
-      $SUM /tmp/r4p_partial/b_results.db $O/partial_kernel_stats.txt e3d > /dev/null 2>&1
+      $SUM /tmp/r5p_partial/b_results.db $O/partial_kernel_stats.txt e3d > /dev/null 2>&1
       head -12 $O/partial_kernel_stats.txt | cut -c1-60,150-230 ;;
     allpairs)   # the all-pairs leg alone: kernel trace of its ten timed iterations
-      rm -rf /tmp/r4p_ap
-      timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/r4p_ap -o b -- python $R/bench.py --only allpairs > $O/allpairs_traced.json 2> /dev/null
+      rm -rf /tmp/r5p_ap
+      timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/r5p_ap -o b -- python $R/bench.py --only allpairs --no-scale-model > $O/allpairs_traced.json 2> /dev/null
       echo "[allpairs] rc=$?"
-      $SUM /tmp/r4p_ap/b_results.db $O/allpairs_kernel_stats.txt e3d > /dev/null 2>&1
+      $SUM /tmp/r5p_ap/b_results.db $O/allpairs_kernel_stats.txt e3d > /dev/null 2>&1
       head -14 $O/allpairs_kernel_stats.txt | cut -c1-60,150-230 ;;
     icp)
       pmc icp_fetch FETCH_SIZE -- $ICP

@@ -629,7 +629,7 @@ def leg_image_registrator(e3d, synth, args, dev):
                      "obs.eval_all_points": ["k_obs_eval<2>"], "obs.eval_listed_points": ["k_obs_eval<2>"], "obs.compact": ["k_obs_compact"],
                      "obs.neighbour_flags": ["k_obs_flags", "k_obs_mark"], "intensity.sample": ["k_reg_intensity"], "cost": ["k_reg_cost<5>"],
                      "color.accumulate": ["k_color_accumulate"], "color.finish": ["k_color_finish"],
-                     "accumulate.pass1": ["k_reg_pass1<2, false>"], "accumulate.pass2": ["k_reg_pass2_mfma<5, 18, 0>"]}
+                     "accumulate.pass1": ["k_reg_pass1<2, false>"], "accumulate.pass2": ["k_reg_pass2_mfma<5, 18>"]}
     groups = {}
     for name, (ms, calls, units) in sorted(P.kernel_groups.items()):
         bpu, what, bound = group_bytes.get(name, (None, "", ""))
@@ -647,7 +647,7 @@ def leg_image_registrator(e3d, synth, args, dev):
     p2_variant = os.environ.get("E3D_REG_PASS2", "")
     p2_f32 = p2_variant in ("tile32", "mfma32")
     p2_kernel = "k_reg_pass2_tile32" if p2_f32 else "k_reg_pass2_mfma"
-    tr2, src2 = load_traffic("k_reg_pass2_tile32<5, 18>" if p2_f32 else "k_reg_pass2_mfma<5, 18, 0>")
+    tr2, src2 = load_traffic("k_reg_pass2_tile32<5, 18>" if p2_f32 else "k_reg_pass2_mfma<5, 18>")
     out = {"metric": "ImageRegistrator residuals/sec", "value": res / t_acc, "unit": "residuals/s",
            "dtype": ("f32 rows; H, b: f32 fma chains of 32 (b: <= 20) residual pairs added into f64 -- NARROWER than the reference (E3D_REG_PASS2=%s, opt-in)" % p2_variant) if p2_f32 else
                     "f32 rows; H, b: every product formed exactly in f64 and summed in f64 (v_mfma_f64_16x16x4_f64 / v_fma_f64) -- the reference's sum of "

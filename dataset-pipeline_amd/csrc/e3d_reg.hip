@@ -1333,12 +1333,7 @@ __global__ __launch_bounds__(kBlock) void k_reg_pass2(const float4* __restrict__
 typedef double d4_t __attribute__((ext_vector_type(4)));
 constexpr int kP2Stride = 36;     // floats per pair in LDS: 16-byte aligned rows
 
-// PRE > 0 (experiments, E3D_REG_PASS2=mfma64p4 / mfma64p16): the operands of PRE instructions of a neighbour slot are read from LDS and converted before
-// the first of them issues, so the matrix instructions of the slot run back to back instead of one behind every LDS read + convert
-// + multiply, and the pairs are walked in the bank-conflict-free order of k_reg_pass2_mfma32 (pair(q, pq) = 4 pq + (q & 3) +
-// 16 (q >> 2): the four 16-lane groups of one read lie 16 banks apart).  Same products, same f64 sums up to the order of the
-// pairs inside a slot.  PRE = 0 is the default loop.
-template <int KT, int V, int PRE = 0>
+template <int KT, int V>
 __global__ __launch_bounds__(kBlock, 2) void k_reg_pass2_mfma(const float4* __restrict__ rows, const unsigned* __restrict__ o_idx,
                                                               const unsigned char* __restrict__ flags, size_t n_obs,
                                                               const int* __restrict__ nrow_of_obs,
@@ -1457,28 +1452,6 @@ __global__ __launch_bounds__(kBlock, 2) void k_reg_pass2_mfma(const float4* __re
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      if constexpr (PRE > 0 && (!kTwo || kFold)) {
-        // single-tile systems: PRE operand pairs at a time, then their instructions back to back
-#pragma unroll
-        for (int q0 = 0; q0 < kWave / 4; q0 += PRE) {
-          float af[PRE], bf[PRE];
-          double wsv[PRE];
-#pragma unroll
-          for (int u = 0; u < PRE; ++u) {
-            const int q = q0 + u;
-            const int pair = 4 * pq + (q & 3) + 16 * (q >> 2);
-            af[u] = Jl[pair * kP2Stride + e];
-            bf[u] = kFold ? Jl[pair * kP2Stride + (e < 2 ? 16 + e : e)] : af[u];
-            wsv[u] = Wl[pair];
-          }
-          double a0v[PRE], b0v[PRE];
-#pragma unroll
-          for (int u = 0; u < PRE; ++u) { a0v[u] = (double)af[u]; b0v[u] = wsv[u] * (double)bf[u]; }
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int u = 0; u < PRE; ++u) acc00[(q0 + u) % NA] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0v[u], b0v[u], acc00[(q0 + u) % NA], 0, 0, 0);
-        }
-      } else {
 #pragma unroll 4
       for (int q = 0; q < kWave / 4; ++q) {
         const int pair = 4 * q + pq;
@@ -1492,7 +1465,6 @@ __global__ __launch_bounds__(kBlock, 2) void k_reg_pass2_mfma(const float4* __re
           acc01[q % NA] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc01[q % NA], 0, 0, 0);
           if constexpr (kTile11) acc11[q % NA] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc11[q % NA], 0, 0, 0);
         }
-      }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -1553,190 +1525,6 @@ __device__ __forceinline__ ChunkRange xcd_chunk_range(size_t n_chunks, int waves
   const size_t xcd = blockIdx.x % kXcds, local = blockIdx.x / kXcds, per = gridDim.x / kXcds;
   const size_t c0 = n_chunks * xcd / kXcds, c1 = n_chunks * (xcd + 1) / kXcds;
   return ChunkRange{c0 + local * waves_per_block + wave_in_block, c1, per * waves_per_block};
-}
-
-// The same f64 update with a third of the live registers (single-tile systems: V <= 16, and V == 18 folded): k_reg_pass2_mfma keeps
-// the K neighbour rows of an observation in registers from the weights to the last slot (K x 20 + 20 floats, 240 VGPRs: two waves
-// per SIMD, and the slot loop waits on every LDS read in front of its matrix instruction).  Here the weights are formed from the K
-// neighbour INTENSITIES alone (one 4-byte gather each -- the line the row read hits again), the row of slot k + 1 is requested while
-// slot k runs, and the operands of PRE instructions are read and converted ahead of their instructions in the bank-conflict-free pair
-// order of k_reg_pass2_mfma32.  Same products and f64 sums as k_reg_pass2_mfma (the order of the 64 pairs inside a slot differs).
-template <int KT, int V, int PRE, int MINW>
-__global__ __launch_bounds__(kBlock, MINW) void k_reg_pass2_mfma_l(const float4* __restrict__ rows, const unsigned* __restrict__ o_idx,
-                                                                   const unsigned char* __restrict__ flags, size_t n_obs,
-                                                                   const int* __restrict__ nrow_of_obs,
-                                                                   const float* __restrict__ fixed_desc, const float* __restrict__ var_desc,
-                                                                   const int* __restrict__ obs_counts, RegWeights wts,
-                                                                   double* __restrict__ partial) {
-  static_assert(V <= 16 || V == 18, "single 16 x 16 tile");
-  constexpr int R4 = rows4(V);
-  constexpr int K = KT;
-  constexpr bool kFold = V == 18;
-  constexpr int NX = kFold ? 6 : 0;
-  __shared__ __attribute__((aligned(16))) float s_j[kBlock / kWave][kWave * kP2Stride];
-  __shared__ double s_w[kBlock / kWave][kWave];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  float* const Jl = s_j[wv];
-  double* const Wl = s_w[wv];
-  const int e = lane & 15, pq = lane >> 4;
-  constexpr int NA = 2;
-  d4_t acc00[NA];
-#pragma unroll
-  for (int a = 0; a < NA; ++a) acc00[a] = d4_t{0, 0, 0, 0};
-  double bacc[V + 4];
-  double xacc[NX > 0 ? NX : 1];
-#pragma unroll
-  for (int i = 0; i < V + 4; ++i) bacc[i] = 0.0;
-#pragma unroll
-  for (int i = 0; i < (NX > 0 ? NX : 1); ++i) xacc[i] = 0.0;
-  const size_t n_chunks = (n_obs + kWave - 1) / kWave;
-  const size_t wave_id = (size_t)blockIdx.x * (kBlock / kWave) + wv;
-  const ChunkRange cr = xcd_chunk_range(n_chunks, kBlock / kWave, wv);
-  for (size_t ch = cr.first; ch < cr.last; ch += cr.step) {
-    const size_t i = ch * kWave + lane;
-    const bool on = i < n_obs && flags[i];
-    float4 rc[R4], rn[2][R4];
-    int nrow[KT];
-    float comp[2][KT] = {};
-    float w[2] = {0.f, 0.f};
-#pragma unroll
-    for (int q = 0; q < R4; ++q) { rc[q] = make_float4(0.f, 0.f, 0.f, 0.f); rn[0][q] = rc[q]; rn[1][q] = rc[q]; }
-#pragma unroll
-    for (int k = 0; k < KT; ++k) nrow[k] = 0;
-    if (on) {
-      const size_t p = o_idx[i];
-#pragma unroll
-      for (int k = 0; k < KT; ++k) nrow[k] = nrow_of_obs[i * K + k];
-      float ni[KT];
-#pragma unroll
-      for (int k = 0; k < KT; ++k) ni[k] = reinterpret_cast<const float*>(rows + R4 * (size_t)nrow[k])[0];
-#pragma unroll
-      for (int q = 0; q < R4; ++q) rc[q] = rows[R4 * i + q];
-#pragma unroll
-      for (int q = 0; q < R4; ++q) rn[0][q] = rows[R4 * (size_t)nrow[0] + q];
-#pragma unroll
-      for (int kind = 0; kind < 2; ++kind) {
-        const float sw = kind == 0 ? wts.fixed_weight : wts.var_weight;
-        if (!(sw > 0)) continue;
-        if (kind == 1 && !(obs_counts[p] >= 2)) continue;
-        const float* desc = kind == 0 ? fixed_desc : var_desc;
-        float pr = 0.f;
-#pragma unroll
-        for (int k = 0; k < KT; ++k) {
-          const float image_descriptor = ni[k] - rc[0].x;
-          const float c = image_descriptor - desc[p * K + k];
-          comp[kind][k] = c;
-          pr += c * c;
-        }
-        pr = sqrtf(pr);
-        bacc[V + 2 + kind] += 1.0;
-        bacc[V + kind] += (double)robust_residual(wts.robust_type, wts.robust_param, pr);
-        w[kind] = sw * robust_weight(wts.robust_type, wts.robust_param, pr);
-      }
-    }
-    const bool act = on && (w[0] != 0 || w[1] != 0);
-    const double wsum = act ? (double)w[0] + (double)w[1] : 0.0;
-#pragma unroll
-    for (int k = 0; k < KT; ++k) {
-      if (k + 1 < KT && on) {
-#pragma unroll
-        for (int q = 0; q < R4; ++q) rn[(k + 1) & 1][q] = rows[R4 * (size_t)nrow[k + 1] + q];
-      }
-      float J[16 + (kFold ? 4 : 0)];              // unknown c = row element 1 + c
-      {
-        const float4* const a = rn[k & 1];
-        float fn[4 * R4], fcv[4 * R4];
-#pragma unroll
-        for (int q = 0; q < R4; ++q) {
-          fn[4 * q] = a[q].x; fn[4 * q + 1] = a[q].y; fn[4 * q + 2] = a[q].z; fn[4 * q + 3] = a[q].w;
-          fcv[4 * q] = rc[q].x; fcv[4 * q + 1] = rc[q].y; fcv[4 * q + 2] = rc[q].z; fcv[4 * q + 3] = rc[q].w;
-        }
-#pragma unroll
-        for (int c = 0; c < (kFold ? 20 : 16); ++c) J[c] = (act && c < V) ? fn[1 + c] - fcv[1 + c] : 0.f;
-      }
-      if (act) {
-        const double wr = (double)(w[0] * comp[0][k]) + (double)(w[1] * comp[1][k]);
-#pragma unroll
-        for (int c = 0; c < V; ++c) bacc[c] = __builtin_fma(wr, (double)J[c], bacc[c]);
-        if constexpr (kFold) {
-          int x = 0;
-#pragma unroll
-          for (int r = 16; r < V; ++r) {
-            const double wj = wsum * (double)J[r];
-#pragma unroll
-            for (int c = r; c < V; ++c) { xacc[x] = __builtin_fma((double)J[c], wj, xacc[x]); ++x; }
-          }
-#pragma unroll
-          for (int r = 0; r < 2; ++r) {
-            const double wj = wsum * (double)J[r];
-#pragma unroll
-            for (int c = r; c < 2; ++c) { xacc[x] = __builtin_fma((double)J[c], wj, xacc[x]); ++x; }
-          }
-        }
-      }
-      float4* const dst = reinterpret_cast<float4*>(Jl + lane * kP2Stride);
-#pragma unroll
-      for (int c = 0; c < (kFold ? 5 : 4); ++c) dst[c] = make_float4(J[4 * c], J[4 * c + 1], J[4 * c + 2], J[4 * c + 3]);
-      Wl[lane] = wsum;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-      for (int q0 = 0; q0 < kWave / 4; q0 += PRE) {
-        float af[PRE], bf[PRE];
-        double wsv[PRE];
-#pragma unroll
-        for (int u = 0; u < PRE; ++u) {
-          const int q = q0 + u;
-          const int pair = 4 * pq + (q & 3) + 16 * (q >> 2);
-          af[u] = Jl[pair * kP2Stride + e];
-          bf[u] = kFold ? Jl[pair * kP2Stride + (e < 2 ? 16 + e : e)] : af[u];
-          wsv[u] = Wl[pair];
-        }
-        double a0v[PRE], b0v[PRE];
-#pragma unroll
-        for (int u = 0; u < PRE; ++u) { a0v[u] = (double)af[u]; b0v[u] = wsv[u] * (double)bf[u]; }
-#pragma unroll
-        for (int u = 0; u < PRE; ++u) acc00[(q0 + u) % NA] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0v[u], b0v[u], acc00[(q0 + u) % NA], 0, 0, 0);
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
-  }
-  double* const out = partial + wave_id * reg_slot(V);
-#pragma unroll
-  for (int a = 1; a < NA; ++a) acc00[0] += acc00[a];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int row = pq + 4 * r, col = e;
-    if constexpr (kFold) {
-      if (col >= 2) { if (row <= col) out[reg_row_start(V, row) + (col - row)] = acc00[0][r]; }
-      else out[reg_row_start(V, row) + (16 + col - row)] = acc00[0][r];
-    } else if (row <= col && col < V) out[reg_row_start(V, row) + (col - row)] = acc00[0][r];
-  }
-  if constexpr (NX > 0) {
-    int x = 0;
-#pragma unroll
-    for (int r = 16; r < V; ++r)
-#pragma unroll
-      for (int c = r; c < V; ++c) {
-        const double v = wave_sum(xacc[x]); ++x;
-        if (lane == 0) out[reg_row_start(V, r) + (c - r)] = v;
-      }
-#pragma unroll
-    for (int r = 0; r < 2; ++r)
-#pragma unroll
-      for (int c = r; c < 2; ++c) {
-        const double v = wave_sum(xacc[x]); ++x;
-        if (lane == 0) out[reg_row_start(V, r) + (c - r)] = v;
-      }
-  }
-#pragma unroll
-  for (int c = 0; c < V + 4; ++c) {
-    const double v = wave_sum(bacc[c]);
-    if (lane == 0) out[reg_h(V) + c] = v;
-  }
 }
 
 // The same update on the f32 matrix instruction (v_mfma_f32_16x16x4_f32: 32 cycles per instruction and SIMD against the ~97 measured for
@@ -3489,36 +3277,13 @@ int e3d_reg_accumulate(e3d_reg_t* h, int image_id, int point_scale, double* H, d
     h->partial.reserve((size_t)n_partials * slot);
     // Default: the f64 matrix instruction on exact products -- every term at least as accurate as the reference's
     // fl32(fl32(w J_i) J_j), all sums in f64 as in intrinsics_and_pose_optimizer.cc:1246-1247.  E3D_REG_PASS2 = tile32 / mfma32: the
-    // narrower f32-chain kernels (opt-in: faster, ~1e-9 of the entry scale away); mfma64p4 / mfma64p16: the f64 kernel with the
-    // operands of 4 / 16 instructions read ahead (experiments).
+    // narrower f32-chain kernels (opt-in: faster, ~1e-9 of the entry scale away).
     static const std::string p2 = [] { const char* e = getenv("E3D_REG_PASS2"); return std::string(e ? e : ""); }();
-    static const bool mfma64p16 = p2 == "mfma64p16", mfma64p8 = p2 == "mfma64p4", tile32 = p2 == "tile32", mfma32g = p2 == "mfma32";
+    static const bool tile32 = p2 == "tile32", mfma32g = p2 == "mfma32";
     static const bool mfma64 = !(tile32 || mfma32g);
-    // experiments: the low-register f64 kernel, two waves per SIMD (l2: 4 operand pairs ahead, l2p8: 8) or three (l3)
-    static const int lvar = p2 == "mfma64l2" ? 2 : (p2 == "mfma64l3" ? 3 : (p2 == "mfma64l2p8" ? 8 : 0));
-    const int nb3 = (int)std::min<size_t>(std::max<size_t>(div_up(O.n, kBlock * 4), 1), (size_t)(max_blocks / 2 * 3));
-    if (lvar == 3) { n_partials = nb3 * (kBlock / kWave); h->partial.reserve((size_t)n_partials * slot); }
 #define E3D_PASS2M(V_)                                                                                                         \
-  if (mfma64 && mfma64p16)                                                                                                     \
-    hipLaunchKernelGGL((k_reg_pass2_mfma<5, V_, 16>), dim3(nb), dim3(kBlock), 0, s, O.rows.p, O.idx.p, O.flags.p, O.n, O.nrow.p, \
-                       S.fixed_desc.p, S.var_desc.p, S.obs_counts.p, w, h->partial.p);                                          \
-  else if (mfma64 && lvar && ((V_) <= 16 || (V_) == 18)) {                                                                     \
-    if constexpr ((V_) <= 16 || (V_) == 18) {                                                                                  \
-      if (lvar == 2)                                                                                                           \
-        hipLaunchKernelGGL((k_reg_pass2_mfma_l<5, V_, 4, 2>), dim3(nb), dim3(kBlock), 0, s, O.rows.p, O.idx.p, O.flags.p, O.n, O.nrow.p, \
-                           S.fixed_desc.p, S.var_desc.p, S.obs_counts.p, w, h->partial.p);                                      \
-      else if (lvar == 3)                                                                                                      \
-        hipLaunchKernelGGL((k_reg_pass2_mfma_l<5, V_, 4, 3>), dim3(nb3), dim3(kBlock), 0, s, O.rows.p, O.idx.p, O.flags.p, O.n, O.nrow.p, \
-                           S.fixed_desc.p, S.var_desc.p, S.obs_counts.p, w, h->partial.p);                                      \
-      else                                                                                                                     \
-        hipLaunchKernelGGL((k_reg_pass2_mfma_l<5, V_, 8, 2>), dim3(nb), dim3(kBlock), 0, s, O.rows.p, O.idx.p, O.flags.p, O.n, O.nrow.p, \
-                           S.fixed_desc.p, S.var_desc.p, S.obs_counts.p, w, h->partial.p);                                      \
-    }                                                                                                                          \
-  } else if (mfma64 && mfma64p8)                                                                                               \
-    hipLaunchKernelGGL((k_reg_pass2_mfma<5, V_, 4>), dim3(nb), dim3(kBlock), 0, s, O.rows.p, O.idx.p, O.flags.p, O.n, O.nrow.p, \
-                       S.fixed_desc.p, S.var_desc.p, S.obs_counts.p, w, h->partial.p);                                          \
-  else if (mfma64)                                                                                                             \
-    hipLaunchKernelGGL((k_reg_pass2_mfma<5, V_, 0>), dim3(nb), dim3(kBlock), 0, s, O.rows.p, O.idx.p, O.flags.p, O.n, O.nrow.p, \
+  if (mfma64)                                                                                                                  \
+    hipLaunchKernelGGL((k_reg_pass2_mfma<5, V_>), dim3(nb), dim3(kBlock), 0, s, O.rows.p, O.idx.p, O.flags.p, O.n, O.nrow.p,   \
                        S.fixed_desc.p, S.var_desc.p, S.obs_counts.p, w, h->partial.p);                                          \
   else if constexpr ((V_) <= 16 || (V_) == 18) {                                                                               \
     if (mfma32g)                                                                                                               \

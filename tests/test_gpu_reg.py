@@ -1037,15 +1037,13 @@ np.savez(sys.argv[2], **out)
 
 def test_pass2_variants_agree(tmp_path):
     """The formulations of pass 2 -- the f64 matrix instruction on exact products (default: the reference's sum of single products in
-    f64, intrinsics_and_pose_optimizer.cc:1246-1247), its scheduling variants (mfma64p4, mfma64l2, mfma64l3: other pair orders inside a
-    slot), the f32 matrix instruction with short chains flushed into f64 (E3D_REG_PASS2=tile32 / mfma32, opt-in), per-thread f64 FMAs
-    (E3D_REG_PASS2=valu) -- on the same observations: counts and residual sums identical, H and b within 1e-7 of the entry scale
-    (the parity tests against the oracle allow 1e-6); the f64 variants among themselves within 1e-12."""
+    f64, intrinsics_and_pose_optimizer.cc:1246-1247), the f32 matrix instruction with short chains flushed into f64
+    (E3D_REG_PASS2=tile32 / mfma32, opt-in), per-thread f64 FMAs (E3D_REG_PASS2=valu) -- on the same observations: counts and residual
+    sums identical, H and b within 1e-7 of the entry scale (the parity tests against the oracle allow 1e-6)."""
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
-    f64_variants = ("mfma64p4", "mfma64p16", "mfma64l2", "mfma64l2p8", "mfma64l3")
-    for variant in ("", "tile32", "mfma32", "valu") + f64_variants:
+    for variant in ("", "tile32", "mfma32", "valu"):
         env = dict(os.environ)
         env.pop("E3D_REG_PASS2", None)
         if variant:
@@ -1057,15 +1055,14 @@ def test_pass2_variants_agree(tmp_path):
     worst = 0.0
     for model in (1, 2, 0, 9, 4):
         ref = res[""]
-        for variant in ("tile32", "mfma32", "valu") + f64_variants:
+        for variant in ("tile32", "mfma32", "valu"):
             g = res[variant]
             assert np.array_equal(g["c%d" % model], ref["c%d" % model]) and np.array_equal(g["s%d" % model], ref["s%d" % model])
             d = np.sqrt(np.diag(ref["H%d" % model]))
             eh = (np.abs(g["H%d" % model] - ref["H%d" % model]) / np.outer(d, d)).max()
             eb = (np.abs(g["b%d" % model] - ref["b%d" % model]) / d).max() / np.abs(ref["b%d" % model] / d).max()
             worst = max(worst, eh, eb)
-            tol = 1e-12 if variant in f64_variants else 1e-7
-            assert eh <= tol and eb <= tol, (model, variant, eh, eb)
+            assert eh <= 1e-7 and eb <= 1e-7, (model, variant, eh, eb)
     print("pass 2 variants: worst deviation", worst)
 
 

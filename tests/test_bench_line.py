@@ -69,3 +69,54 @@ def test_check_scale8_reads_compact_lines(tmp_path):
     assert r.returncode == 0, r.stderr
     rows = [ln.split() for ln in r.stdout.splitlines() if ln.strip().startswith(("1 ", "8 "))]
     assert len(rows) == 2 and abs(float(rows[1][3]) - 7.0 / 8.0) < 1e-3, r.stdout
+
+
+class _FakeICP:
+    """Run() of the tool's loop: converges in iteration `conv` (returns True there), records one iteration record per call."""
+
+    def __init__(self, conv):
+        self.conv, self.recs, self.calls = conv, [], []
+
+    def run(self, d, it, n, thr, progress):
+        import collections
+        self.calls.append(it)
+        r = collections.defaultdict(float)
+        r["iteration"] = it
+        r["correspondences"] = 1000
+        r["queries"] = 2000
+        self.recs.append(r)
+        return it >= self.conv
+
+    def iter_records(self):
+        return list(self.recs)
+
+    def clear_records(self):
+        self.recs = []
+
+
+class _FakeRanks:
+    world, comm, dist = 1, None, None
+
+    def barrier(self):
+        pass
+
+    def reduce(self, v, op="sum"):
+        import numpy as np
+        return np.asarray(v, np.float64)
+
+
+@pytest.mark.parametrize("conv,expect_steps,expect_conv", [(100, 20, None), (24, 20, 24), (18, 14, 18), (5, 1, 5)])
+def test_timed_loop_ends_with_the_converging_iteration(conv, expect_steps, expect_conv):
+    """src/exe/icp_scan_aligner.cc:342-370: the iteration whose Run() reports convergence is the last one the tool runs -- bench.py
+    times it and nothing after it (round 4 timed five no-op steps after convergence)."""
+    icp = _FakeICP(conv)
+    dt, tot, warm, recs, per_rank, steps_run, converged_at = bench.run_icp(None, _FakeRanks(), icp, 0.01, 1e-10, 5, 20)
+    assert steps_run == expect_steps and converged_at == expect_conv
+    assert icp.calls == list(range(0, 5 + expect_steps))
+    assert len(warm) == 5 and len(recs) == expect_steps and tot[0] == 1000 * expect_steps
+
+
+def test_a_run_that_converges_in_the_warm_up_times_nothing():
+    icp = _FakeICP(3)
+    dt, tot, warm, recs, per_rank, steps_run, converged_at = bench.run_icp(None, _FakeRanks(), icp, 0.01, 1e-10, 5, 20)
+    assert steps_run == 0 and converged_at == 3 and icp.calls == [0, 1, 2, 3]

@@ -1501,8 +1501,13 @@ static void knn_pass(KnnWorkspace& W, const float* xyz, size_t n, int k, const f
     const int sel_list = k <= 16 ? 1 : (k <= 32 ? 2 : 0);                   // list-maintaining variant (also variant 3's fallback)
     constexpr int kTwoPassMaxK = 60;                                        // k + 4 list slots <= the largest sorting network (64)
     const int sel = (forced_sel >= 0 && forced_sel <= 3 && (forced_sel < 2 || (forced_sel == 2 && k <= 32) || (forced_sel == 3 && k <= kTwoPassMaxK))) ? forced_sel : (k <= kTwoPassMaxK ? 3 : 0);
-    static const int cap_extra = [] { const char* e = getenv("E3D_KNN_CAP_EXTRA"); return e ? atoi(e) : 4; }();
-    const int cap = sel == 3 ? ((std::max(k + cap_extra, 12) + 1) & ~1) : k;             // list entries per thread in LDS
+    // spare list slots of the two-pass variant (it serves the single scan's leftovers, so its occupancy matters little): with 4 a
+    // fifth of a scanner-sampled scan's leftovers overflowed into the list-maintaining variant (20 M points, scanner-sampled:
+    // k = 32 18.8 -> 17.5 ms with 20, k = 8 11.3 -> 11.0 with 12; uniform scan unchanged; profiles/round5_normals_cap_extra.txt)
+    static const int cap_extra_env = [] { const char* e = getenv("E3D_KNN_CAP_EXTRA"); return e ? atoi(e) : -1; }();
+    // (k > 32: the two-pass variant is the main kernel there, its LDS list decides the occupancy: 4 as before)
+    const int cap_extra = cap_extra_env >= 0 ? cap_extra_env : (k <= 16 ? 12 : (k <= 32 ? 20 : 4));
+    const int cap = sel == 3 ? std::min(((std::max(k + cap_extra, 12) + 1) & ~1), 64) : k;   // list entries per thread in LDS (<= the largest sorting network)
     const size_t lds = sel == 3 ? (size_t)cap * kKnnBlock * 4 : (size_t)cap * kKnnBlock * 8, lds_list = (size_t)k * kKnnBlock * 8;
     auto kernel_of = [](int v) {
       return v == 0 ? k_knn_normals<0> : (v == 1 ? k_knn_normals<1> : (v == 2 ? k_knn_normals<2> : (v == 3 ? k_knn_normals<3> : (v == 4 ? k_knn_normals<4> : k_knn_normals<5>))));

@@ -1321,20 +1321,6 @@ __global__ __launch_bounds__(kBlock) void k_reg_pass2(const float4* __restrict__
   }
 }
 
-// Chunk ranges per XCD: workgroup b runs on XCD b % 8 (observed placement, not a contract -- a different placement is slower, not
-// wrong), each XCD has its own 4 MB L2, and the rows a chunk gathers are those of nearby chunks (the neighbours of a point are close in
-// the observation order, or one scan line away).  Handing every XCD one contiguous eighth of the chunks keeps a row in ONE L2 instead
-// of fetching it into several: chunk_first / chunk_last / chunk_step of a wave.
-struct ChunkRange { size_t first, last, step; };
-__device__ __forceinline__ ChunkRange xcd_chunk_range(size_t n_chunks, int waves_per_block, int wave_in_block) {
-  constexpr unsigned kXcds = 8;
-  if (gridDim.x % kXcds != 0 || n_chunks < 64 * kXcds)
-    return ChunkRange{(size_t)blockIdx.x * waves_per_block + wave_in_block, n_chunks, (size_t)gridDim.x * waves_per_block};
-  const size_t xcd = blockIdx.x % kXcds, local = blockIdx.x / kXcds, per = gridDim.x / kXcds;
-  const size_t c0 = n_chunks * xcd / kXcds, c1 = n_chunks * (xcd + 1) / kXcds;
-  return ChunkRange{c0 + local * waves_per_block + wave_in_block, c1, per * waves_per_block};
-}
-
 // Pass 2 on the matrix cores: H = sum over (observation, neighbour) pairs of w J J^T is a rank-4-per-instruction update
 // D(16 x 16) += A(16 x 4) B(4 x 16) in f64 (v_mfma_f64_16x16x4_f64).  A wave owns the whole V x V system as one (V <= 16) or three
 // (V <= 32: blocks 00, 01, 11) 16 x 16 accumulator tiles -- 4 f64 per lane and tile instead of V (V + 1) / 2 accumulators per
@@ -1385,9 +1371,8 @@ __global__ __launch_bounds__(kBlock, 2) void k_reg_pass2_mfma(const float4* __re
 #pragma unroll
   for (int i = 0; i < (NX > 0 ? NX : 1); ++i) xacc[i] = 0.0;
   const size_t n_chunks = (n_obs + kWave - 1) / kWave;
-  const size_t wave_id = (size_t)blockIdx.x * (kBlock / kWave) + wv;
-  const ChunkRange cr = xcd_chunk_range(n_chunks, kBlock / kWave, wv);      // an XCD's waves take one contiguous eighth of the chunks (one L2 per row)
-  for (size_t ch = cr.first; ch < cr.last; ch += cr.step) {
+  const size_t wave_id = (size_t)blockIdx.x * (kBlock / kWave) + wv, n_waves = (size_t)gridDim.x * (kBlock / kWave);
+  for (size_t ch = wave_id; ch < n_chunks; ch += n_waves) {
     const size_t i = ch * kWave + lane;
     const bool on = i < n_obs && flags[i];
     float fc[4 * R4];
@@ -1526,6 +1511,20 @@ __global__ __launch_bounds__(kBlock, 2) void k_reg_pass2_mfma(const float4* __re
     const double v = wave_sum(bacc[c]);
     if (lane == 0) out[reg_h(V) + c] = v;
   }
+}
+
+// Chunk ranges per XCD: workgroup b runs on XCD b % 8 (observed placement, not a contract -- a different placement is slower, not
+// wrong), each XCD has its own 4 MB L2, and the rows a chunk gathers are those of nearby chunks (the neighbours of a point are close in
+// the observation order, or one scan line away).  Handing every XCD one contiguous eighth of the chunks keeps a row in ONE L2 instead
+// of fetching it into several: chunk_first / chunk_last / chunk_step of a wave.
+struct ChunkRange { size_t first, last, step; };
+__device__ __forceinline__ ChunkRange xcd_chunk_range(size_t n_chunks, int waves_per_block, int wave_in_block) {
+  constexpr unsigned kXcds = 8;
+  if (gridDim.x % kXcds != 0 || n_chunks < 64 * kXcds)
+    return ChunkRange{(size_t)blockIdx.x * waves_per_block + wave_in_block, n_chunks, (size_t)gridDim.x * waves_per_block};
+  const size_t xcd = blockIdx.x % kXcds, local = blockIdx.x / kXcds, per = gridDim.x / kXcds;
+  const size_t c0 = n_chunks * xcd / kXcds, c1 = n_chunks * (xcd + 1) / kXcds;
+  return ChunkRange{c0 + local * waves_per_block + wave_in_block, c1, per * waves_per_block};
 }
 
 // The same update on the f32 matrix instruction (v_mfma_f32_16x16x4_f32: 32 cycles per instruction and SIMD against the ~97 measured for

@@ -69,7 +69,7 @@ def test_normals_lattice_ties(e3d, ob):
 
 @pytest.mark.parametrize("k", [3, 10, 11, 16, 31, 33])
 def test_normals_single_scan_boundaries(e3d, ob, synth, k):
-    """Where the search changes kernels (DESIGN 4.3c): k <= 10 one scan with 32-bit list entries, 11 .. 32 one scan with 16-bit
+    """Where the search changes kernels (DESIGN 4.3a): k <= 10 one scan with 32-bit list entries, 11 .. 32 one scan with 16-bit
     entries (keys computed after the collection), beyond that the two passes."""
     s = synth.make_scene(1, 30000, seed=22)[0]
     _compare(e3d, ob, s["xyz"].numpy(), k)

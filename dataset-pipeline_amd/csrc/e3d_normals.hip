@@ -40,8 +40,6 @@ struct KnnGrid {
   unsigned xcd_map;         // G > 0: the scan kernels hand an XCD G consecutive blocks of every 8 G (knn_block)
 };
 constexpr int kKnnSelFallback = 253;
-// bins per cell^2 of the squared-distance histogram at scale level 0 .. 3 (two bits of the selected-bin byte): 32 * 4^level
-__host__ __device__ constexpr int knn_bin_scale(int level) { return 32 << (2 * level); }
 
 // Workgroup b runs on XCD b % 8 (observed placement, not a contract -- another placement is slower, not wrong), and every XCD has
 // its own 4 MB L2.  Queries are in cell order and a block's candidates are the rows of the 27 cells around them: the ~100 blocks
@@ -235,25 +233,21 @@ __global__ __launch_bounds__(kKnnHistBlock) void k_knn_hist(const float4* __rest
   const int cz = cell_coord(q.z, G.g.origin[2], G.g.inv_cell);
   // A scan samples its surfaces with a density that falls with the squared range, so a 27-cell block of a grid sized for the mean
   // density holds anything from a few to thousands of points.  The directory words of the block's nine rows give its population
-  // n27 before any point is touched, and the histogram's bin width follows it (round 4; round 5: wider steps): cell^2 / (32 f) with
-  // f = 1, 4, 16, 64 for n27 <= 12 k, 48 k, 192 k, more.  The k-th neighbour of a dense block is far inside the block, and with bins sized for the mean density
+  // n27 before any point is touched, and the histogram's bin width follows it (round 4): cell^2 / (32 f) with f = 1, 2, 4 for
+  // n27 <= 12 k, 24 k, more.  The k-th neighbour of a dense block is far inside the block, and with bins sized for the mean density
   // most of the block's candidates fell into the first bins, more than the k + 4 list slots of pass B hold (the query then fell
   // back to the list-maintaining variant: 1.7 M of 20 M queries of a scanner-sampled scan).  Pass B reads f from the selected bin's
   // byte.  (Handing the densest blocks to a grid of half the cell size instead was built as well: 33.9 instead of 23.9 ms on that
   // scan -- a second sort and a 1.2 G-cell directory for 0.7 M queries; removed.)
-  int fexp = 0;                                   // scale level: bins of cell^2 / (32 * 4^level) (knn_bin_scale)
+  int fexp = 0;
   if (G.S) {
     unsigned n27 = 0;
     for (int oz = -1; oz <= 1; ++oz)
       for (int oy = -1; oy <= 1; ++oy)
         knn_row(G, table, cx - 1, cx + 1, cy + oy, cz + oz, [&](unsigned m, unsigned e) { n27 += e - m; });
-    // (round 5: four levels a factor 4 apart instead of f = 1, 2, 4 -- under a scanner a block holds 50 - 250 times k points, the
-    // k-th neighbour fell into the first bins of the finest histogram, and a fifth of a scanner-sampled scan's queries left both
-    // the single scan and the two-pass variant for the list-maintaining one)
-    const unsigned uk = (unsigned)k;
-    fexp = n27 <= 12u * uk ? 0 : (n27 <= 48u * uk ? 1 : (n27 <= 192u * uk ? 2 : 3));
+    fexp = n27 <= 12u * (unsigned)k ? 0 : (n27 <= 24u * (unsigned)k ? 1 : 2);
   }
-  const float inv_w2 = (float)knn_bin_scale(fexp) * G.g.inv_cell * G.g.inv_cell;
+  const float inv_w2 = (float)(32 << fexp) * G.g.inv_cell * G.g.inv_cell;
   const knn_f2 qxy = {q.x, q.y};
   KP_MARK(1);
   auto add = [&](float d2) {
@@ -296,8 +290,7 @@ __global__ __launch_bounds__(kKnnHistBlock) void k_knn_hist(const float4* __rest
   }
   // [2 bits: bin scale | 6 bits: bin]; k not reached: 255 with the full range (the k-th neighbour is at least sqrt(2) cells away),
   // kKnnSelFallback with a narrowed one (it may still lie inside the block: the list-maintaining variant looks)
-  // (level 3: bins 61 and 63 would read as the two verdict codes -- the list-maintaining variant takes such a query)
-  sel_bin[gi] = (unsigned char)((sel == 255 || (fexp == 3 && sel >= 61)) ? ((sel == 255 && fexp == 0) ? 255 : kKnnSelFallback) : ((fexp << 6) | sel));
+  sel_bin[gi] = (unsigned char)(sel == 255 ? (fexp == 0 ? 255 : kKnnSelFallback) : ((fexp << 6) | sel));
   KP_MARK(3); KP_FLUSH(0, 4);
 }
 
@@ -673,7 +666,7 @@ __global__ __launch_bounds__(kKnnBlock) void k_knn_normals(const float4* __restr
         return;
       }
       sel_bin = (sel_byte == kKnnSelFallback || sel_byte == 255) ? kKnnBins : (sel_byte & 63);
-      inv_w2 = (float)knn_bin_scale((sel_byte >> 6) & 3) * G.g.inv_cell * G.g.inv_cell;       // bins of cell^2 / (32 f): [0, 2 cell^2 / f)
+      inv_w2 = (float)(32 << ((sel_byte >> 6) & 3)) * G.g.inv_cell * G.g.inv_cell;       // bins of cell^2 / (32 f): [0, 2 cell^2 / f)
       if (sel_bin >= kKnnBins) fallback = true;                       // the k-th neighbour lies beyond the histogram's range
       tau2 = (float)(sel_bin + 1) * (1.0f / inv_w2) * 1.00001f;        // (only the cells' face test uses it)
     } else {
@@ -683,7 +676,7 @@ __global__ __launch_bounds__(kKnnBlock) void k_knn_normals(const float4* __restr
       for (int i = 0; i < rep_avg; ++i)
         if (r0 + (size_t)i < n_reps) {
           const int bsel = (int)sel_bins[r0 + (size_t)i];
-          if (bsel < kKnnSelFallback) { edge_sum += (float)((bsel & 63) + 1) / (float)knn_bin_scale((bsel >> 6) & 3); ++have; }
+          if (bsel < kKnnSelFallback) { edge_sum += (float)((bsel & 63) + 1) / (float)(32 << ((bsel >> 6) & 3)); ++have; }
         }
       if (have == 0) fallback = true;                                 // no sampled query near by found its count inside the block
       else {

@@ -82,6 +82,9 @@ struct PairState {
   long long jbase = -1;
   unsigned long long src_gen = 0, tgt_gen = 0;
   bool fresh = true;           // no search has filled the state yet
+  // motion of the source's queries relative to the target since the state was created (MotionBound, e3d_icp_kernels.hpp): a query
+  // at distance rho from the source's bounding-box centre has moved at most mA * rho + mB in the target's frame
+  double mA = 0.0, mB = 0.0;
   // resident correspondence rows (LmSet): one row per query at its source position, rewritten only where the partner changed
   DevBuf<float4> pA, pB, pC;
   DevBuf<int> plane_match;         // the partner each row encodes (-1: zero row)
@@ -437,6 +440,7 @@ static PairState& pair_state_for(e3d_icp* h, int src_id, int tgt_id, const Cloud
     ps.n = n; ps.jbase = (long long)j0; ps.src_gen = src.generation; ps.tgt_gen = tgt.generation;
     ps.fresh = true;
     ps.rows_valid = false;
+    ps.mA = 0.0; ps.mB = 0.0;
   }
   return ps;
 }
@@ -479,8 +483,75 @@ static double pose_rounding_bound(const Cloud& c, const float* T) {
   return 2.5 * FLT_EPSILON * (std::sqrt(fro) * std::sqrt(R2) + std::sqrt(tt));
 }
 
+// E3D_NN_PERQUERY=0: the certificates use the clouds' global motion bounds (rounds 2 - 4) instead of the bound per query
+static bool per_query_motion() { static const bool on = [] { const char* e = getenv("E3D_NN_PERQUERY"); return !(e && e[0] == '0'); }(); return on; }
+static bool pose_is_rigid(const float* T) {
+  for (int i = 0; i < 3; ++i)
+    for (int j = i; j < 3; ++j) {
+      double d = 0;
+      for (int r = 0; r < 3; ++r) d += (double)T[4 * r + i] * (double)T[4 * r + j];
+      if (!(std::fabs(d - (i == j ? 1.0 : 0.0)) <= 4e-6)) return false;
+    }
+  return true;
+}
+// M = Tt^-1 Ts (3 x 4, row-major): the source's local frame -> the target's
+static bool relative_map(const float* Ts, const float* Tt, double M[12]) {
+  double Li[9];
+  if (!invert_3x3(Tt, Li)) return false;
+  for (int r = 0; r < 3; ++r) {
+    for (int c = 0; c < 3; ++c) M[4 * r + c] = Li[3 * r] * (double)Ts[c] + Li[3 * r + 1] * (double)Ts[4 + c] + Li[3 * r + 2] * (double)Ts[8 + c];
+    M[4 * r + 3] = Li[3 * r] * ((double)Ts[3] - (double)Tt[3]) + Li[3 * r + 1] * ((double)Ts[7] - (double)Tt[7]) + Li[3 * r + 2] * ((double)Ts[11] - (double)Tt[11]);
+  }
+  return true;
+}
+// what a pose update (Ts0, Tt0) -> (Ts1, Tt1) adds to a pair's accumulators: rigid poses -> the bound per query, else the
+// clouds' global bounds of this update (glob) into b alone
+static void accumulate_pair_motion(PairState& ps, const Cloud& src, const float* Ts0, const float* Ts1, const float* Tt0, const float* Tt1, double glob) {
+  double M0[12], M1[12];
+  if (!per_query_motion() || !pose_is_rigid(Ts0) || !pose_is_rigid(Ts1) || !pose_is_rigid(Tt0) || !pose_is_rigid(Tt1) ||
+      !relative_map(Ts0, Tt0, M0) || !relative_map(Ts1, Tt1, M1)) {
+    ps.mB += glob;
+    return;
+  }
+  float dM[12];
+  double fro = 0, dc2 = 0;
+  for (int r = 0; r < 3; ++r) {
+    double e = M1[4 * r + 3] - M0[4 * r + 3];
+    for (int k = 0; k < 3; ++k) {
+      const double d = M1[4 * r + k] - M0[4 * r + k];
+      dM[4 * r + k] = (float)d; fro += d * d;
+      e += d * 0.5 * ((double)src.lmin[k] + (double)src.lmax[k]);
+    }
+    dM[4 * r + 3] = 0.f;
+    dc2 += e * e;
+  }
+  double smax = max_singular_value_3x3(dM) * (1.0 + 1e-6) + 1e-7 * std::sqrt(fro);      // (dM was rounded to f32: 6e-8 relative)
+  if (!(smax <= std::sqrt(fro) * (1.0 + 1e-6))) smax = std::sqrt(fro) * (1.0 + 1e-6);   // Frobenius norm bounds the spectral norm (also the NaN fallback)
+  ps.mA += smax * (1.0 + 1e-9);
+  ps.mB += std::sqrt(dc2) * (1.0 + 1e-9);
+}
+// the two roundings of a pair's accumulated bound, and the source centre's global position (rho is measured from it)
+static void pair_motion_bounds(const PairState& ps, const Cloud& src, const Cloud& tgt, MotionBound& lo, MotionBound& up) {
+  const double err = 2.0 * (src.err_max + tgt.err_max);
+  if (per_query_motion()) {
+    lo.a = round_down_f(ps.mA * (1.0 - 2e-6)); lo.b = round_down_f(ps.mB * (1.0 - 2e-6));
+    up.a = round_up_f(ps.mA * (1.0 + 2e-6)); up.b = round_up_f((ps.mB * (1.0 + 2e-6) + err) * (1.0 + 1e-6));
+    for (int r = 0; r < 3; ++r) {
+      double v = (double)src.T[4 * r + 3];
+      for (int k = 0; k < 3; ++k) v += (double)src.T[4 * r + k] * 0.5 * ((double)src.lmin[k] + (double)src.lmax[k]);
+      lo.cs[r] = up.cs[r] = (float)v;
+    }
+  } else {
+    const double cum_pair = src.cum_motion + tgt.cum_motion;
+    lo.a = up.a = 0.f;
+    lo.b = round_down_f(cum_pair * (1.0 - 2e-6));
+    up.b = round_up_f((cum_pair * (1.0 + 2e-6) + err) * (1.0 + 1e-6));
+    for (int r = 0; r < 3; ++r) lo.cs[r] = up.cs[r] = 0.f;
+  }
+}
+
 // certificate constants of k_nn_rows for a target at its current pose
-static CertParams make_cert_params(const Cloud& tgt, double cum_pair) {
+static CertParams make_cert_params(const Cloud& tgt, const MotionBound& lo) {
   CertParams cp;
   double smin = min_singular_value_3x3(tgt.T);
   if (!(smin > 0)) smin = 0;
@@ -491,7 +562,7 @@ static CertParams make_cert_params(const Cloud& tgt, double cum_pair) {
   // mapping error of the query + rounding of the stored points' global coordinates (both inside the build's slack), and the
   // f32 fuzz of the cell boundaries
   cp.cell_sub = round_up_f(smin * (2.0 * tgt.build_slack + 8.0 * FLT_EPSILON * (extent + 4.0 * cell)) * (1.0 + 1e-5));
-  cp.cum_lo = round_down_f(cum_pair * (1.0 - 2e-6));
+  cp.lo = lo;
   return cp;
 }
 
@@ -585,13 +656,15 @@ static void find_pair(e3d_icp* h, Cloud& src, Cloud& tgt, float d, PairJob& job,
     match_pos = ps.match.p;
     const InvMap im = make_invmap(tgt);
     const double cum_pair = src.cum_motion + tgt.cum_motion;
-    const CertParams cert = make_cert_params(tgt, cum_pair);
+    MotionBound m_lo, m_up;
+    pair_motion_bounds(ps, src, tgt, m_lo, m_up);
+    const CertParams cert = make_cert_params(tgt, m_lo);
     size_t n_far = n, n_near = 0;
     const unsigned* list = nullptr;
     if (!ps.fresh && use_cert) {
       NnPhase ph(s, 0);
       static const double margin_frac = env_double("E3D_NN_MARGIN", 0.08), near_frac = env_double("E3D_NN_NEAR", 0.4);   // of the radius
-      const float cum_up = round_up_f((cum_pair * (1.0 + 2e-6) + 2.0 * (src.err_max + tgt.err_max)) * (1.0 + 1e-6));
+      const MotionBound& cum_up = m_up;
       const float near2 = (float)((near_frac * (double)d) * (near_frac * (double)d));
       h->h_todo.reserve(2);
       h->todo_near.reserve(n); h->todo_far.reserve(n);
@@ -623,7 +696,7 @@ static void find_pair(e3d_icp* h, Cloud& src, Cloud& tgt, float d, PairJob& job,
       bp.margin = (float)(margin_frac * (double)d);
       bp.rho_scale = round_up_f((1.0 + 1e-5) / smin);
       bp.rho_pad = round_up_f(2.0 * tgt.build_slack + 8.0 * FLT_EPSILON * m_local);
-      bp.cum_lo = cert.cum_lo;
+      bp.lo = cert.lo;
       bp.cell_scale = cert.cell_scale; bp.cell_sub = cert.cell_sub;
       bp.np_extra = none_near ? (float)(np_frac * (double)d) : 0.f;   // gate closed: partnerless queries on the far list keep the plain radius
       launch_nn_bounded(srcG, h->todo_near.p, n_near, tgt.G4.p, tgt.dense_start.p, tgt.has_half ? tgt.half_prefix.p : nullptr, h->nn_mode == 5, tgt.grid, im, tgt.qrange, radius_sq(d), bp, ps.match.p,
@@ -656,7 +729,7 @@ static void find_pair(e3d_icp* h, Cloud& src, Cloud& tgt, float d, PairJob& job,
     bool source_order = false;
     if (tgt.has_dense && h->nn_mode != 2) {
       h->lbe_scratch.reserve(n);
-      source_order = launch_rows(h->nn_mode, tgt, srcG, h->vals_b.p, n, im, radius_sq(d), make_cert_params(tgt, 0.0), h->match_pos.p,
+      source_order = launch_rows(h->nn_mode, tgt, srcG, h->vals_b.p, n, im, radius_sq(d), make_cert_params(tgt, MotionBound{}), h->match_pos.p,
                                  h->match_d2.p, h->lbe_scratch.p, nullptr, s);
     } else {
       launch_nn_cells(srcG, h->vals_b.p, n, tgt.G4.p, tgt.table.p, nullptr, tgt.grid, im, tgt.qrange, radius_sq(d),
@@ -798,12 +871,13 @@ static void find_pairs_batched(e3d_icp* h, std::vector<BatchItem>& items, float 
     sl.match_d2.reserve(it.n);
     it.im = make_invmap(tgt);
     it.cum_pair = src.cum_motion + tgt.cum_motion;
-    it.cert = make_cert_params(tgt, it.cum_pair);
+    MotionBound m_lo, cum_up;
+    pair_motion_bounds(ps, src, tgt, m_lo, cum_up);
+    it.cert = make_cert_params(tgt, m_lo);
     it.n_far = it.n; it.n_near = 0;
     it.certified = !ps.fresh && use_cert;
     if (!it.certified) continue;
     const float4* srcG = src.G4.p + it.j0;
-    const float cum_up = round_up_f((it.cum_pair * (1.0 + 2e-6) + 2.0 * (src.err_max + tgt.err_max)) * (1.0 + 1e-6));
     const float near2 = (float)((near_frac * (double)d) * (near_frac * (double)d));
     sl.todo_near.reserve(it.n); sl.todo_far.reserve(it.n);
     E3D_HIP(hipMemsetAsync(ps.todo_count.p, 0, 2 * sizeof(unsigned), s));
@@ -822,7 +896,7 @@ static void find_pairs_batched(e3d_icp* h, std::vector<BatchItem>& items, float 
     it.bp.margin = (float)(margin_frac * (double)d);
     it.bp.rho_scale = round_up_f((1.0 + 1e-5) / smin);
     it.bp.rho_pad = round_up_f(2.0 * tgt.build_slack + 8.0 * FLT_EPSILON * m_local);
-    it.bp.cum_lo = it.cert.cum_lo;
+    it.bp.lo = it.cert.lo;
     it.bp.cell_scale = it.cert.cell_scale; it.bp.cell_sub = it.cert.cell_sub;
     it.bp.np_extra = none_near ? (float)(np_frac * (double)d) : 0.f;
   }
@@ -943,7 +1017,9 @@ static bool find_pairs_multi(e3d_icp* h, std::vector<BatchItem>& items, float d,
     sl.match_d2.reserve(n); sl.todo_near.reserve(n); sl.todo_far.reserve(n);
     it.im = make_invmap(tgt);
     it.cum_pair = src.cum_motion + tgt.cum_motion;
-    it.cert = make_cert_params(tgt, it.cum_pair);
+    MotionBound m_lo, m_up;
+    pair_motion_bounds(ps, src, tgt, m_lo, m_up);
+    it.cert = make_cert_params(tgt, m_lo);
     it.n_far = n; it.n_near = 0;
     it.certified = !ps.fresh && use_cert;
     const bool none_near = np_frac > 0 && (src.last_motion + tgt.last_motion) < np_gate * (double)d;
@@ -954,7 +1030,7 @@ static bool find_pairs_multi(e3d_icp* h, std::vector<BatchItem>& items, float d,
     it.bp.margin = (float)(margin_frac * (double)d);
     it.bp.rho_scale = round_up_f((1.0 + 1e-5) / smin);
     it.bp.rho_pad = round_up_f(2.0 * tgt.build_slack + 8.0 * FLT_EPSILON * m_local);
-    it.bp.cum_lo = it.cert.cum_lo;
+    it.bp.lo = it.cert.lo;
     it.bp.cell_scale = it.cert.cell_scale; it.bp.cell_sub = it.cert.cell_sub;
     it.bp.np_extra = none_near ? (float)(np_frac * (double)d) : 0.f;
     // resident rows (see find_pair)
@@ -980,7 +1056,7 @@ static bool find_pairs_multi(e3d_icp* h, std::vector<BatchItem>& items, float d,
     P.match = ps.match.p; P.match2 = ps.match2.p; P.lbe = ps.lbe.p; P.match_d2 = sl.match_d2.p;
     P.todo_near = sl.todo_near.p; P.todo_far = sl.todo_far.p; P.counts = h->d_todo_all.p + 2 * i;
     P.n = (unsigned)n; P.none_near = none_near ? 1 : 0;
-    P.cum_up = round_up_f((it.cum_pair * (1.0 + 2e-6) + 2.0 * (src.err_max + tgt.err_max)) * (1.0 + 1e-6));
+    P.cum_up = m_up;
     P.near2 = (float)((near_frac * (double)d) * (near_frac * (double)d));
     P.g = tgt.grid; P.im = it.im; P.qr = tgt.qrange; P.bp = it.bp;
     P.Psrc = (sg ? src.G4.p : src.L4.p) + it.j0; P.LNsrc = src.LN.p + it.j0; P.Ptgt = tg ? tgt.G4.p : tgt.L4.p; P.LNtgt = tgt.LN.p;
@@ -1598,6 +1674,9 @@ static bool align_meshes(e3d_icp* h, float max_d, float thr, bool print, int ite
 
   // pose write-back (cc:318-341): new = Affine3f(pose.matrix()) * global_T_cloud
   bool converged = true;
+  std::vector<float> T_before((size_t)12 * (size_t)(M + 1));
+  for (int i = 0; i < M; ++i) std::memcpy(&T_before[12 * (size_t)i], h->clouds[i]->T, sizeof(float) * 12);
+  if (has_fixed) std::memcpy(&T_before[12 * (size_t)M], h->fixed->T, sizeof(float) * 12);
   for (int i = 0; i < M; ++i) {
     Cloud& c = *h->clouds[i];
     const SE3f& p = poses[c.cloud_index];
@@ -1618,6 +1697,15 @@ static bool align_meshes(e3d_icp* h, float max_d, float thr, bool print, int ite
     c.cum_motion += c.last_motion;
     c.err_max = std::max(c.err_max, std::max(pose_rounding_bound(c, c.T), pose_rounding_bound(c, Tn)));
     std::memcpy(c.T, Tn, sizeof Tn);
+  }
+  // the pairs' own motion accumulators (every pair that keeps a state, whether it was searched in this iteration or not)
+  for (auto& kv : h->pair_state) {
+    const int si = kv.first.first, ti = kv.first.second;
+    if (si < 0 || ti < 0 || si > M || ti > M || (si == M && !has_fixed) || (ti == M && !has_fixed)) continue;
+    const Cloud& src = (si == M) ? *h->fixed : *h->clouds[si];
+    const Cloud& tgt = (ti == M) ? *h->fixed : *h->clouds[ti];
+    const double glob = ((si == M) ? 0.0 : src.last_motion) + ((ti == M) ? 0.0 : tgt.last_motion);
+    accumulate_pair_motion(*kv.second, src, &T_before[12 * (size_t)si], src.T, &T_before[12 * (size_t)ti], tgt.T, glob);
   }
   rec.t_transform_ms = t_tr.ms();
   rec.t_nn_ms = t_nn.ms();
@@ -1816,7 +1904,7 @@ int64_t e3d_find_correspondences(const float* sxyz, size_t ns, const float* txyz
         bool source_order = false;
         if (tgt.has_dense && mode != 2) {
           h->lbe_scratch.reserve(ns);
-          source_order = launch_rows(mode, tgt, src.G4.p, h->vals_b.p, ns, im, radius_sq(d), make_cert_params(tgt, 0.0), h->match_pos.p,
+          source_order = launch_rows(mode, tgt, src.G4.p, h->vals_b.p, ns, im, radius_sq(d), make_cert_params(tgt, MotionBound{}), h->match_pos.p,
                                      h->match_d2.p, h->lbe_scratch.p, nullptr, s);
         } else {
           launch_nn_cells(src.G4.p, h->vals_b.p, ns, tgt.G4.p, tgt.table.p, nullptr, tgt.grid, im, tgt.qrange, radius_sq(d), h->match_pos.p, h->match_d2.p, s);

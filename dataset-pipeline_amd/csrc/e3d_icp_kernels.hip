@@ -406,6 +406,19 @@ __global__ __launch_bounds__(kBlock) void k_query_keys32_list(const float4* __re
   vals[i] = j;
 }
 
+// accumulated motion bound of query q (MotionBound, e3d_icp_kernels.hpp): a * rho + b, rho = |q - cs| widened (up) or narrowed (lo)
+// by the rounding of the global coordinates and of this evaluation
+__device__ __forceinline__ float motion_rho(const float4 q, const MotionBound& m) {
+  const float dx = q.x - m.cs[0], dy = q.y - m.cs[1], dz = q.z - m.cs[2];
+  return sqrtf(dx * dx + (dy * dy + dz * dz));
+}
+__device__ __forceinline__ float motion_up(const float4 q, const MotionBound& m) {
+  return (m.a * (motion_rho(q, m) * 1.000002f + 5e-5f) + m.b) * 1.000001f;
+}
+__device__ __forceinline__ float motion_lo(const float4 q, const MotionBound& m) {
+  return (m.a * fmaxf(motion_rho(q, m) * 0.999998f - 5e-5f, 0.f) + m.b) * 0.999999f;
+}
+
 __device__ __forceinline__ int rdlane_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
 __device__ __forceinline__ unsigned rdlane_u(unsigned v, int l) { return (unsigned)__builtin_amdgcn_readlane((int)v, l); }
 
@@ -832,7 +845,7 @@ __global__ __launch_bounds__(kBlock, 6) void k_nn_rows(const float4* __restrict_
     // best_d2 stayed r2, so best_b2 is the smallest distance seen); points outside the block are >= block_dist cells away in
     // the local frame (2 cells if the query's cell lies outside the directory range, i.e. occupied cells +- 2)
     const float lb_out = block_dist * cert.cell_scale - cert.cell_sub;
-    lbe[j] = fmaxf(fminf(sqrtf(best_b2), lb_out), 0.0f) * 0.999999f + cert.cum_lo;
+    lbe[j] = fmaxf(fminf(sqrtf(best_b2), lb_out), 0.0f) * 0.999999f + motion_lo(q, cert.lo);
   }
 }
 
@@ -1117,8 +1130,8 @@ __global__ __launch_bounds__(kBlock, 3) void k_nn_mfma(const float4* __restrict_
 // State of query j of a directed pair (source order): match[j] = partner position m in the target arrays (or -1) and
 // lbe[j] = LB + cum(s), where at the query's last search (outer iteration s) every target point other than m was at (true
 // Euclidean) distance >= LB of the query in the global frame, and cum(.) is the host's running bound of how far any point of
-// either cloud has moved since (sum over the pose updates of ||dL|| R + ||dt||; cum_up adds the f32 rounding of the transforms).
-// Triangle inequality: now every other point is at distance >= thr = lbe - cum_up.  If the partner's new f32 squared distance v
+// either cloud has moved since -- round 5: of how far THIS query has moved relative to the target, a rho + b (MotionBound; cum_up adds
+// the f32 rounding of the transforms).  Triangle inequality: now every other point is at distance >= thr = lbe - cum_up.  If the partner's new f32 squared distance v
 // is < thr^2 (with room for the f32 evaluation error of the others' distances) and < r2, the exact search would return (m, v):
 // nothing else can be nearer or tie.  For m = -1 "no partner" stands as long as thr^2 >= r2.  All other queries are appended
 // to the todo list (in source order inside a block of 2048 queries; one atomic per block) and searched by k_nn_rows, which
@@ -1133,7 +1146,7 @@ constexpr int kCertPerWave = 512;          // consecutive queries per wave (8 st
 // for the kernel that walks a batch of pairs, k_nn_certify_multi)
 template <int kCertUnroll>
 __device__ __forceinline__ void nn_certify_body(const unsigned bx, const float4* __restrict__ Gsrc, size_t n, const float4* __restrict__ Gtgt,
-                                                float cum_up, float r2, float near2, int none_near, int* __restrict__ match,
+                                                const MotionBound cum_up, float r2, float near2, int none_near, int* __restrict__ match,
                                                 int* __restrict__ match2, const float* __restrict__ lbe,
                                                 float* __restrict__ match_d2, unsigned* __restrict__ todo_near,
                                                 unsigned* __restrict__ todo_far, unsigned* __restrict__ counts) {
@@ -1169,7 +1182,7 @@ __device__ __forceinline__ void nn_certify_body(const unsigned bx, const float4*
     const bool valid = vv[u];
     bool ok = false, near = false;
     if (valid) {
-      const float thr = (ll[u] - cum_up) * 0.999999f;
+      const float thr = (ll[u] - motion_up(qq[u], cum_up)) * 0.999999f;
       const float lim = thr * thr * 0.999999f;
       const int m = mm[u];
       if (m >= 0) {
@@ -1221,7 +1234,7 @@ __device__ __forceinline__ void nn_certify_body(const unsigned bx, const float4*
 
 template <int kCertUnroll>
 __global__ __launch_bounds__(kBlock) void k_nn_certify(const float4* __restrict__ Gsrc, size_t n, const float4* __restrict__ Gtgt,
-                                                       float cum_up, float r2, float near2, int none_near, int* __restrict__ match,
+                                                       MotionBound cum_up, float r2, float near2, int none_near, int* __restrict__ match,
                                                        int* __restrict__ match2, const float* __restrict__ lbe,
                                                        float* __restrict__ match_d2, unsigned* __restrict__ todo_near,
                                                        unsigned* __restrict__ todo_far, unsigned* __restrict__ counts) {
@@ -1400,7 +1413,7 @@ __global__ __launch_bounds__(kBlock) void k_nn_bounded(const float4* __restrict_
   // everything but the remembered candidates is at least this far: the third smallest distance (two remembered), the second
   // (partner only), the smallest (no partner within the radius) -- and nothing is known beyond what the scanned box covers
   const float others2 = has2 ? b3 : (has1 ? bd2 : bd);
-  lbe[j] = sqrtf(fminf(others2, cover_all2)) * 0.999999f + bp.cum_lo;
+  lbe[j] = sqrtf(fminf(others2, cover_all2)) * 0.999999f + motion_lo(q, bp.lo);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -1634,7 +1647,7 @@ __device__ __forceinline__ void nn_bounded_half_body(const unsigned bx, const fl
   match2[j] = has2 ? bpos2 : -1;
   match_d2[j] = has1 ? bd : r2;
   const float others2 = has2 ? b3 : (has1 ? bd2 : bd);
-  lbe[j] = sqrtf(fminf(others2, cover_all2)) * 0.999999f + bp.cum_lo;
+  lbe[j] = sqrtf(fminf(others2, cover_all2)) * 0.999999f + motion_lo(q, bp.lo);
 }
 
 template <int BATCH>
@@ -2656,7 +2669,7 @@ void launch_query_keys32_list(const float4* Gsrc, const unsigned* list, size_t n
   hipLaunchKernelGGL(k_query_keys32_list, dim3((unsigned)div_up(n, kBlock)), dim3(kBlock), 0, s, Gsrc, list, n, g, im, qr, keys, vals);
 }
 
-void launch_nn_certify(const float4* Gsrc, size_t n, const float4* Gtgt, float cum_up, float r2, float near2, bool none_near, int* match, int* match2,
+void launch_nn_certify(const float4* Gsrc, size_t n, const float4* Gtgt, const MotionBound& cum_up, float r2, float near2, bool none_near, int* match, int* match2,
                        const float* lbe, float* match_d2, unsigned* todo_near, unsigned* todo_far, unsigned* counts, hipStream_t s) {
   if (!n) return;
   // four query chains in flight per lane: 0.58 / 0.56 / 0.53 ms per 50 M queries with 1 / 2 / 4

@@ -71,11 +71,22 @@ void launch_query_keys32(const float4* Gsrc, size_t n, const GridDesc& g, const 
 void launch_nn_cells(const float4* Gsrc, const unsigned* order, size_t n, const float4* Gtgt, const HashEntry* table,
                      const unsigned* dense_start, const GridDesc& g, const InvMap& im, const QueryRange& qr, float r2,
                      int* match_pos, float* match_d2, hipStream_t s);
-// certificate side of k_nn_rows: lbe = min(sqrt(second smallest d2), block_dist * cell_scale - cell_sub) + cum_lo
+// Motion of a query relative to its target since the pair's state was created (round 5: a bound PER QUERY).  With M_k the map from
+// the source's local frame into the target's at outer iteration k and c the centre of the source's bounding box, query p moves
+// |M_{k+1} p - M_k p| <= ||dM_L|| |p - c| + |dM c| in the target's frame, where the target's points rest: the accumulated bound is
+// a * rho + b with a = sum ||dM_L||, b = sum |dM c| (host, f64) and rho = |p - c| -- for rigid poses the distance of the query's
+// GLOBAL position to the centre's (cs), which the kernels evaluate themselves.  The bound every point of a cloud obeys (||dL|| R +
+// |dc|, rounds 2 - 4) is that of its corners: 7 - 14 cm per outer iteration while two scans are degrees apart, where a query two
+// metres from the centre moves 2 cm.  a = 0, b = the clouds' bounds: the old certificate (non-rigid poses, E3D_NN_PERQUERY=0).
+struct MotionBound {
+  float a, b;            // rounded down (the certificate's writers) or up (k_nn_certify)
+  float cs[3];           // global position of the source's bounding-box centre at the current pose
+};
+// certificate side of k_nn_rows: lbe = min(sqrt(second smallest d2), block_dist * cell_scale - cell_sub) + motion_lo
 struct CertParams {
   float cell_scale;      // sigma_min * cell size (global distance of one local cell), rounded down
   float cell_sub;        // sigma_min * slack of the global -> local mapping and the cell boundaries, rounded up
-  float cum_lo;          // accumulated motion bound of the pair at this outer iteration, rounded down
+  MotionBound lo;        // accumulated motion bound of the pair at this outer iteration, rounded down
 };
 // k_nn_rows writes its results at the queries' SOURCE positions order[pos] (match_pos, match_d2, lbe in source order)
 void launch_nn_rows(const float4* Gsrc, const unsigned* order, size_t n, const float4* Gtgt, const unsigned* dense_start,
@@ -88,14 +99,14 @@ void launch_query_keys32_list(const float4* Gsrc, const unsigned* list, size_t n
 // settles every query whose old partner is provably still the unique nearest neighbour within the radius (lbe - cum_up > new
 // distance); lists the others: todo_near (old partner within sqrt(near2)) / todo_far, lengths in counts[0..1] (see k_nn_certify)
 // none_near: queries without a partner go to todo_near as well (k_nn_bounded searches them beyond the radius)
-void launch_nn_certify(const float4* Gsrc, size_t n, const float4* Gtgt, float cum_up, float r2, float near2, bool none_near, int* match, int* match2,
+void launch_nn_certify(const float4* Gsrc, size_t n, const float4* Gtgt, const MotionBound& cum_up, float r2, float near2, bool none_near, int* match, int* match2,
                        const float* lbe, float* match_d2, unsigned* todo_near, unsigned* todo_far, unsigned* counts, hipStream_t s);
 // bounded search (k_nn_bounded) of the listed queries around their old partners
 struct BoundParams {
   float margin;          // the search covers radius (distance of the old partner) + margin: room for the next certificates
   float rho_scale;       // (1 + 1e-5) / sigma_min(target pose), rounded up
   float rho_pad;         // absolute slack of the global -> local mapping (local units), rounded up
-  float cum_lo;          // accumulated motion bound of the pair at this outer iteration, rounded down
+  MotionBound lo;        // accumulated motion bound of the pair at this outer iteration, rounded down
   float cell_scale, cell_sub;   // as in CertParams: covered global distance = (distance to the scanned box's faces in cells) * cell_scale - cell_sub
   float np_extra;        // a query without a partner searches radius + np_extra (its certificate: nothing nearer than that)
 };
@@ -119,7 +130,8 @@ struct NnPairDev {
   unsigned* counts;                // their lengths: two words of the batch's array
   unsigned n;                      // queries
   int none_near;
-  float cum_up, near2;
+  MotionBound cum_up;
+  float near2;
   GridDesc g; InvMap im; QueryRange qr; BoundParams bp;
   // resident rows (k_corr_update)
   const float4 *Psrc, *LNsrc, *Ptgt, *LNtgt;

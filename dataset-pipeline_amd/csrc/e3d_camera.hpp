@@ -217,15 +217,30 @@ __device__ __forceinline__ void cam_ddp_plain(const CamLevel& c, float nx, float
 
 constexpr float kFisheyeEpsilon = 1e-6f;
 
+// The fisheye models' Distort and both derivative functions each start from atan(r) of the same normalized point
+// (camera_base_impl_fisheye.h:66-153): one number, worth ~150 binary64 instructions in e3d_libm.h.  A kernel that calls several of
+// them for one point evaluates it once (cam_theta) and hands it down; the three-argument forms below compute it themselves.
+// Same operands, same operations: the same bits either way.
+struct CamTheta { float r, atan_r; };           // atan_r is set iff r > kFisheyeEpsilon
+template <int M>
+__device__ __forceinline__ CamTheta cam_theta(float nx, float ny) {
+  CamTheta t{0.f, 0.f};
+  if constexpr (cam_is_fisheye(M)) {
+    t.r = sqrtf(nx * nx + ny * ny);
+    if (t.r > kFisheyeEpsilon) t.atan_r = e3d_atan2f(t.r, 1.f);
+  }
+  return t;
+}
+
 // ---- Child::Distort / DistortedDerivativeByNormalized / ...ByDistortionParameters ---------------------------------------------
 template <int M>
-__device__ __forceinline__ void cam_distort(const CamLevel& c, float nx, float ny, float& ox, float& oy) {
+__device__ __forceinline__ void cam_distort(const CamLevel& c, float nx, float ny, const CamTheta& th, float& ox, float& oy) {
   if constexpr (!cam_is_fisheye(M)) {
     cam_distort_plain<M>(c, nx, ny, ox, oy);
   } else {
-    const float r = sqrtf(nx * nx + ny * ny);
+    const float r = th.r;
     if (r > kFisheyeEpsilon) {
-      const float atan_r = e3d_atan2f(r, 1.f);
+      const float atan_r = th.atan_r;
       if (atan_r * atan_r > c.inner_cutoff2) { ox = nx * E3D_CAM_INF; oy = ny * E3D_CAM_INF; return; }
       const float theta_by_r = atan_r / r;
       cam_distort_plain<M>(c, nx * theta_by_r, ny * theta_by_r, ox, oy);
@@ -236,15 +251,20 @@ __device__ __forceinline__ void cam_distort(const CamLevel& c, float nx, float n
 }
 
 template <int M>
-__device__ __forceinline__ void cam_ddn(const CamLevel& c, float nx, float ny, float* J) {
+__device__ __forceinline__ void cam_distort(const CamLevel& c, float nx, float ny, float& ox, float& oy) {
+  cam_distort<M>(c, nx, ny, cam_theta<M>(nx, ny), ox, oy);
+}
+
+template <int M>
+__device__ __forceinline__ void cam_ddn(const CamLevel& c, float nx, float ny, const CamTheta& th, float* J) {
   if constexpr (!cam_is_fisheye(M)) {
     cam_ddn_plain<M>(c, nx, ny, J);
   } else {
     const float nx_ny = nx * ny, nx2 = nx * nx, ny2 = ny * ny;
     const float r2 = nx2 + ny2;
-    const float r = sqrtf(r2);
+    const float r = th.r;                       // = sqrtf(r2)
     if (r > kFisheyeEpsilon) {
-      const float atan_r = e3d_atan2f(r, 1.f);
+      const float atan_r = th.atan_r;
       if (atan_r * atan_r > c.inner_cutoff2) { J[0] = J[1] = J[2] = J[3] = 0.f; return; }
       const float theta_by_r = atan_r / r;
       const float term1 = r2 * (r2 + 1);
@@ -264,13 +284,16 @@ __device__ __forceinline__ void cam_ddn(const CamLevel& c, float nx, float ny, f
 }
 
 template <int M>
-__device__ __forceinline__ void cam_ddp(const CamLevel& c, float nx, float ny, float* d0, float* d1) {
+__device__ __forceinline__ void cam_ddn(const CamLevel& c, float nx, float ny, float* J) { cam_ddn<M>(c, nx, ny, cam_theta<M>(nx, ny), J); }
+
+template <int M>
+__device__ __forceinline__ void cam_ddp(const CamLevel& c, float nx, float ny, const CamTheta& th, float* d0, float* d1) {
   if constexpr (!cam_is_fisheye(M)) {
     cam_ddp_plain<M>(c, nx, ny, d0, d1);
   } else {
-    const float r = sqrtf(nx * nx + ny * ny);
+    const float r = th.r;
     if (r > kFisheyeEpsilon) {
-      const float atan_r = e3d_atan2f(r, 1.f);
+      const float atan_r = th.atan_r;
       if (atan_r * atan_r > c.inner_cutoff2) {
 #pragma unroll
         for (int i = 0; i < cam_distortion_count(M); ++i) { d0[i] = 0.f; d1[i] = 0.f; }
@@ -284,25 +307,37 @@ __device__ __forceinline__ void cam_ddp(const CamLevel& c, float nx, float ny, f
   }
 }
 
+template <int M>
+__device__ __forceinline__ void cam_ddp(const CamLevel& c, float nx, float ny, float* d0, float* d1) {
+  cam_ddp<M>(c, nx, ny, cam_theta<M>(nx, ny), d0, d1);
+}
+
 // ---- CameraBaseImpl ---------------------------------------------------------------------------------------------------------------
+// (th: cam_theta of the SAME normalized point the function forms itself, X / Z and Y / Z)
+template <int M>
+__device__ __forceinline__ void cam_normalized_to_image(const CamLevel& c, float nx, float ny, const CamTheta& th, float& ox, float& oy) {
+  const float r2 = nx * nx + ny * ny;
+  if (isinf(r2) || r2 > c.cutoff2) { ox = nx * E3D_CAM_INF; oy = ny * E3D_CAM_INF; return; }
+  float dx, dy;
+  cam_distort<M>(c, nx, ny, th, dx, dy);
+  ox = c.fx * dx + c.cx;
+  oy = c.fy * dy + c.cy;
+}
 template <int M>
 __device__ __forceinline__ void cam_normalized_to_image(const CamLevel& c, float nx, float ny, float& ox, float& oy) {
   const float r2 = nx * nx + ny * ny;
   if (isinf(r2) || r2 > c.cutoff2) { ox = nx * E3D_CAM_INF; oy = ny * E3D_CAM_INF; return; }
-  float dx, dy;
-  cam_distort<M>(c, nx, ny, dx, dy);
-  ox = c.fx * dx + c.cx;
-  oy = c.fy * dy + c.cy;
+  cam_normalized_to_image<M>(c, nx, ny, cam_theta<M>(nx, ny), ox, oy);
 }
 
 // 2 x 3 row-major
 template <int M>
-__device__ __forceinline__ void cam_image_deriv_by_world(const CamLevel& c, float X, float Y, float Z, float* d) {
+__device__ __forceinline__ void cam_image_deriv_by_world(const CamLevel& c, float X, float Y, float Z, const CamTheta& th, float* d) {
   const float nx = X / Z, ny = Y / Z;
   if (nx * nx + ny * ny < c.cutoff2) {
     const float zi = 1.f / Z;
     float J[4];
-    cam_ddn<M>(c, nx, ny, J);
+    cam_ddn<M>(c, nx, ny, th, J);
     const float n02 = (-1.f * nx) * zi, n12 = (-1.f * ny) * zi;      // normalize_deriv = [zi 0 n02; 0 zi n12]
     d[0] = J[0] * zi + J[1] * 0.f; d[1] = J[0] * 0.f + J[1] * zi; d[2] = J[0] * n02 + J[1] * n12;
     d[3] = J[2] * zi + J[3] * 0.f; d[4] = J[2] * 0.f + J[3] * zi; d[5] = J[2] * n02 + J[3] * n12;
@@ -314,9 +349,14 @@ __device__ __forceinline__ void cam_image_deriv_by_world(const CamLevel& c, floa
   for (int i = 0; i < 3; ++i) { d[i] = c.fx * d[i]; d[3 + i] = c.fy * d[3 + i]; }
 }
 
+template <int M>
+__device__ __forceinline__ void cam_image_deriv_by_world(const CamLevel& c, float X, float Y, float Z, float* d) {
+  cam_image_deriv_by_world<M>(c, X, Y, Z, cam_theta<M>(X / Z, Y / Z), d);
+}
+
 // 2 x I row-major (row stride I)
 template <int M>
-__device__ __forceinline__ void cam_image_deriv_by_intrinsics(const CamLevel& c, float X, float Y, float Z, float* d) {
+__device__ __forceinline__ void cam_image_deriv_by_intrinsics(const CamLevel& c, float X, float Y, float Z, const CamTheta& th, float* d) {
   constexpr int I = cam_param_count(M);
   const float nx = X / Z, ny = Y / Z;
   if (nx * nx + ny * ny > c.cutoff2) {
@@ -325,12 +365,12 @@ __device__ __forceinline__ void cam_image_deriv_by_intrinsics(const CamLevel& c,
     return;
   }
   float dx, dy;
-  cam_distort<M>(c, nx, ny, dx, dy);
+  cam_distort<M>(c, nx, ny, th, dx, dy);
   if constexpr (!cam_unique_focal(M)) {
     d[0] = dx; d[1] = 0.f; d[2] = 1.f; d[3] = 0.f;
     d[I + 0] = 0.f; d[I + 1] = dy; d[I + 2] = 0.f; d[I + 3] = 1.f;
     if constexpr (I > 4) {
-      cam_ddp<M>(c, nx, ny, d + 4, d + I + 4);
+      cam_ddp<M>(c, nx, ny, th, d + 4, d + I + 4);
 #pragma unroll
       for (int i = 4; i < I; ++i) { d[i] = c.fx * d[i]; d[I + i] = c.fy * d[I + i]; }
     }
@@ -338,11 +378,16 @@ __device__ __forceinline__ void cam_image_deriv_by_intrinsics(const CamLevel& c,
     d[0] = dx; d[1] = 1.f; d[2] = 0.f;
     d[I + 0] = dy; d[I + 1] = 0.f; d[I + 2] = 1.f;
     if constexpr (I > 3) {
-      cam_ddp<M>(c, nx, ny, d + 3, d + I + 3);
+      cam_ddp<M>(c, nx, ny, th, d + 3, d + I + 3);
 #pragma unroll
       for (int i = 3; i < I; ++i) { d[i] = c.fx * d[i]; d[I + i] = c.fy * d[I + i]; }
     }
   }
+}
+
+template <int M>
+__device__ __forceinline__ void cam_image_deriv_by_intrinsics(const CamLevel& c, float X, float Y, float Z, float* d) {
+  cam_image_deriv_by_intrinsics<M>(c, X, Y, Z, cam_theta<M>(X / Z, Y / Z), d);
 }
 
 // FisheyeFOVCamera::Undistort (camera_fisheye_fov.h:76-86): closed form, infinity past image_radius_

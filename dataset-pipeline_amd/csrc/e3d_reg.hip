@@ -135,8 +135,9 @@ __device__ __forceinline__ bool splat_rect(const float4 p, const Pose& P, const 
   rt(P, p.x, p.y, p.z, X, Y, Z);
   if (!(Z > 0.f)) return false;
   float px, py, d[6];
-  cam_normalized_to_image<M>(cam, X / Z, Y / Z, px, py);
-  cam_image_deriv_by_world<M>(cam, X, Y, Z, d);
+  const CamTheta th = cam_theta<M>(X / Z, Y / Z);                 // (the fisheye models' atan: once per point)
+  cam_normalized_to_image<M>(cam, X / Z, Y / Z, th, px, py);
+  cam_image_deriv_by_world<M>(cam, X, Y, Z, th, d);
   float rx = sqrtf(d[0] * d[0] + (d[1] * d[1] + d[2] * d[2])) * point_radius;
   float ry = sqrtf(d[3] * d[3] + (d[4] * d[4] + d[5] * d[5])) * point_radius;
   full_size = rx >= 10.f && ry >= 10.f;     // both half-extents clamped: the rectangle is exactly [ix-10, ix+10] x [iy-10, iy+10]
@@ -684,12 +685,13 @@ __global__ __launch_bounds__(kBlock) void k_mask_boundaries(const MeshEdge* __re
     const float X = a0 + factor * d0, Y = a1 + factor * d1, Z = a2 + factor * d2;
     if (!(Z > 0)) continue;
     float px, py;
-    cam_normalized_to_image<M>(cam, X / Z, Y / Z, px, py);
+    const CamTheta th = cam_theta<M>(X / Z, Y / Z);
+    cam_normalized_to_image<M>(cam, X / Z, Y / Z, th, px, py);
     const int ix = f2i(px + 0.5f), iy = f2i(py + 0.5f);
     if (!(px + 0.5f >= 0 && py + 0.5f >= 0 && ix >= 0 && iy >= 0 && ix < cam.width && iy < cam.height)) continue;
     if (!(depth_in[(size_t)iy * cam.width + ix] + kOcclusionDepthThreshold >= Z)) continue;
     float d[6];
-    cam_image_deriv_by_world<M>(cam, X, Y, Z, d);
+    cam_image_deriv_by_world<M>(cam, X, Y, Z, th, d);
     const float rx = sqrtf(d[0] * d[0] + (d[1] * d[1] + d[2] * d[2])) * splat_radius;
     const float ry = sqrtf(d[3] * d[3] + (d[4] * d[4] + d[5] * d[5])) * splat_radius;
     const int min_x = max(0, d2i((double)((float)ix - rx) + 0.5)), min_y = max(0, d2i((double)((float)iy - ry) + 0.5));
@@ -978,13 +980,15 @@ __global__ __launch_bounds__(kBlock) void k_reg_pass1(const float4* __restrict__
   const CamLevel cam = Y.cam[0];                                                   // min_image_scale camera
   const float To0 = T0 + point_radius;
   float offx, offy;
-  cam_normalized_to_image<M>(cam, To0 / T2, T1 / T2, offx, offy);
+  // the point and its radius-offset twin: one atan each for the seven camera evaluations below (cam_theta)
+  const CamTheta th_i = cam_theta<M>(T0 / T2, T1 / T2), th_o = cam_theta<M>(To0 / T2, T1 / T2);
+  cam_normalized_to_image<M>(cam, To0 / T2, T1 / T2, th_o, offx, offy);
   const float rdx = offx - mx, rdy = offy - my;
   const float denom = fmaxf(1e-6f, 0.693147180559945f * (rdx * rdx + rdy * rdy));
   {
     float Pi[2 * I], Po[2 * I];
-    cam_image_deriv_by_intrinsics<M>(cam, T0, T1, T2, Pi);
-    cam_image_deriv_by_intrinsics<M>(cam, To0, T1, T2, Po);
+    cam_image_deriv_by_intrinsics<M>(cam, T0, T1, T2, th_i, Pi);
+    cam_image_deriv_by_intrinsics<M>(cam, To0, T1, T2, th_o, Po);
 #pragma unroll
     for (int c = 0; c < I; ++c) {
       const float scale_row = ((Po[c] - Pi[c]) * rdx + (Po[I + c] - Pi[I + c]) * rdy) / denom;
@@ -992,8 +996,8 @@ __global__ __launch_bounds__(kBlock) void k_reg_pass1(const float4* __restrict__
     }
   }
   float W[9], Wo[6], a[3];
-  cam_image_deriv_by_world<M>(cam, T0, T1, T2, W);
-  cam_image_deriv_by_world<M>(cam, To0, T1, T2, Wo);
+  cam_image_deriv_by_world<M>(cam, T0, T1, T2, th_i, W);
+  cam_image_deriv_by_world<M>(cam, To0, T1, T2, th_o, Wo);
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     W[6 + c] = ((Wo[c] - W[c]) * rdx + (Wo[3 + c] - W[3 + c]) * rdy) / denom;
@@ -1097,13 +1101,15 @@ __global__ __launch_bounds__(kBlock) void k_reg_depth_rows(const float4* __restr
   const CamLevel cam = Y.cam[0];
   const float To0 = T0 + point_radius;
   float offx, offy;
-  cam_normalized_to_image<M>(cam, To0 / T2, T1 / T2, offx, offy);
+  // the point and its radius-offset twin: one atan each for the seven camera evaluations below (cam_theta)
+  const CamTheta th_i = cam_theta<M>(T0 / T2, T1 / T2), th_o = cam_theta<M>(To0 / T2, T1 / T2);
+  cam_normalized_to_image<M>(cam, To0 / T2, T1 / T2, th_o, offx, offy);
   const float rdx = offx - mx, rdy = offy - my;
   const float denom = fmaxf(1e-6f, 0.693147180559945f * (rdx * rdx + rdy * rdy));
   {
     float Pi[2 * I], Po[2 * I];
-    cam_image_deriv_by_intrinsics<M>(cam, T0, T1, T2, Pi);
-    cam_image_deriv_by_intrinsics<M>(cam, To0, T1, T2, Po);
+    cam_image_deriv_by_intrinsics<M>(cam, T0, T1, T2, th_i, Pi);
+    cam_image_deriv_by_intrinsics<M>(cam, To0, T1, T2, th_o, Po);
 #pragma unroll
     for (int c = 0; c < I; ++c) {
       const float scale_row = ((Po[c] - Pi[c]) * rdx + (Po[I + c] - Pi[I + c]) * rdy) / denom;
@@ -1111,8 +1117,8 @@ __global__ __launch_bounds__(kBlock) void k_reg_depth_rows(const float4* __restr
     }
   }
   float W[9], Wo[6], a[3];
-  cam_image_deriv_by_world<M>(cam, T0, T1, T2, W);
-  cam_image_deriv_by_world<M>(cam, To0, T1, T2, Wo);
+  cam_image_deriv_by_world<M>(cam, T0, T1, T2, th_i, W);
+  cam_image_deriv_by_world<M>(cam, To0, T1, T2, th_o, Wo);
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     W[6 + c] = ((Wo[c] - W[c]) * rdx + (Wo[3 + c] - W[3 + c]) * rdy) / denom;

@@ -48,25 +48,30 @@ E3D_LIBM_FN double e3d_libm_atan(double x) {
                a6 = 6.66107313738753120669e-02, a7 = -5.83357013379057348645e-02, a8 = 4.97687799461593236017e-02,
                a9 = -3.65315727442169155270e-02, a10 = 1.62858201153657823623e-02;
   const unsigned hx = e3d_libm_hi(x), ix = hx & 0x7fffffffu;
-  double ahi = 0.0, alo = 0.0;
+  double ahi = 0.0, alo = 0.0, num, den;
   int id;
   if (ix >= 0x44100000u) {                      /* |x| >= 2^66, inf, NaN */
     if (ix > 0x7ff00000u || (ix == 0x7ff00000u && e3d_libm_lo(x) != 0u)) return x + x;
     return (hx >> 31) ? -(hi3 + lo3) : (hi3 + lo3);
   }
+  if (ix < 0x3e400000u) return x;               /* |x| < 2^-27 */
+  /* The reduced argument is a quotient in four of the five ranges.  Numerator and denominator are SELECTED per range and
+   * divided once (the fifth range divides by one, which is exact): the lanes of a wavefront whose arguments fall into
+   * different ranges then share one division instead of running four, and the operands -- hence the bits -- of every
+   * operation are those of the branchy form. */
   if (ix < 0x3fdc0000u) {                       /* |x| < 0.4375 */
-    if (ix < 0x3e400000u) return x;             /* |x| < 2^-27 */
-    id = -1;
+    id = -1; num = x; den = 1.0;
   } else {
     x = e3d_libm_abs(x);
     if (ix < 0x3ff30000u) {                     /* |x| < 1.1875 */
-      if (ix < 0x3fe60000u) { id = 0; ahi = hi0; alo = lo0; x = (2.0 * x - 1.0) / (2.0 + x); }
-      else { id = 1; ahi = hi1; alo = lo1; x = (x - 1.0) / (x + 1.0); }
+      if (ix < 0x3fe60000u) { id = 0; ahi = hi0; alo = lo0; num = 2.0 * x - 1.0; den = 2.0 + x; }
+      else { id = 1; ahi = hi1; alo = lo1; num = x - 1.0; den = x + 1.0; }
     } else {
-      if (ix < 0x40038000u) { id = 2; ahi = hi2; alo = lo2; x = (x - 1.5) / (1.0 + 1.5 * x); }
-      else { id = 3; ahi = hi3; alo = lo3; x = -1.0 / x; }
+      if (ix < 0x40038000u) { id = 2; ahi = hi2; alo = lo2; num = x - 1.5; den = 1.0 + 1.5 * x; }
+      else { id = 3; ahi = hi3; alo = lo3; num = -1.0; den = x; }
     }
   }
+  x = num / den;
   {
     const double z = x * x, w = z * z;
     const double s1 = z * (a0 + w * (a2 + w * (a4 + w * (a6 + w * (a8 + w * a10)))));

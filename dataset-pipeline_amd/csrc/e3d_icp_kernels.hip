@@ -389,21 +389,21 @@ __global__ __launch_bounds__(kBlock) void k_query_keys_list(const float4* __rest
                                                             unsigned* __restrict__ vals) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const unsigned j = list[i];
+  const unsigned jf = list[i], j = jf & kListIndexMask;            // (a far-list entry may carry kListNoPartner: it travels with the value)
   int cx, cy, cz;
   keys[i] = query_cell_key(Gsrc[j], im, g, qr, cx, cy, cz);
-  vals[i] = j;
+  vals[i] = jf;
 }
 __global__ __launch_bounds__(kBlock) void k_query_keys32_list(const float4* __restrict__ Gsrc, const unsigned* __restrict__ list, size_t n,
                                                               GridDesc g, InvMap im, QueryRange qr, unsigned* __restrict__ keys,
                                                               unsigned* __restrict__ vals) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const unsigned j = list[i];
+  const unsigned jf = list[i], j = jf & kListIndexMask;
   int cx, cy, cz;
   const unsigned long long k = query_cell_key(Gsrc[j], im, g, qr, cx, cy, cz);
   keys[i] = (k == kEmptyKey) ? 0xFFFFFFFFu : (unsigned)k;
-  vals[i] = j;
+  vals[i] = jf;
 }
 
 // accumulated motion bound of query q (MotionBound, e3d_icp_kernels.hpp): a * rho + b, rho = |q - cs| widened (up) or narrowed (lo)
@@ -433,7 +433,7 @@ __global__ __launch_bounds__(kBlock, 6) void k_nn_cells(const float4* __restrict
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const size_t pos = ((size_t)blockIdx.x * (kBlock / kWave) + w) * kWave + lane;
   const bool valid = pos < n;
-  const unsigned j = valid ? order[pos] : 0u;
+  const unsigned j = valid ? (order[pos] & kListIndexMask) : 0u;
   const float4 q = valid ? Gsrc[j] : make_float4(0.f, 0.f, 0.f, 0.f);
   int cx = 0, cy = 0, cz = 0;
   const unsigned long long key = valid ? query_cell_key(q, im, g, qr, cx, cy, cz) : kEmptyKey;
@@ -690,7 +690,7 @@ __global__ __launch_bounds__(kBlock, 6) void k_nn_rows(const float4* __restrict_
   RowLds& L = lds[w];
   const size_t pos = ((size_t)blockIdx.x * (kBlock / kWave) + w) * kWave + lane;
   const bool valid = pos < n;
-  const unsigned j = valid ? order[pos] : 0u;
+  const unsigned jf = valid ? order[pos] : 0u, j = jf & kListIndexMask;
   const float4 q = valid ? Gsrc[j] : make_float4(0.f, 0.f, 0.f, 0.f);
   int cx = 0, cy = 0, cz = 0;
   float block_dist = 2.0f;
@@ -839,8 +839,13 @@ __global__ __launch_bounds__(kBlock, 6) void k_nn_rows(const float4* __restrict_
     remaining &= ~seg;
   }
   if (valid) {
-    match_pos[j] = best_pos; match_d2[j] = best_d2;
-    if (match2) match2[j] = -1;                 // this kernel remembers the partner only
+    // A query that had no partner and still has none (kListNoPartner, set by k_nn_certify -- most queries of the first outer
+    // iterations of a poorly aligned pair) holds match = match2 = -1 already, and k_nn_certify has stored r2 as its distance:
+    // only the certificate changes.  Three of the four scattered 4-byte stores of this kernel, a third of its time there.
+    if (!((jf & kListNoPartner) && best_pos < 0)) {
+      match_pos[j] = best_pos; match_d2[j] = best_d2;
+      if (match2) match2[j] = -1;               // this kernel remembers the partner only
+    }
     // every candidate in the 27 cells was evaluated: the others are >= sqrt(best_b2) away (all of them, if there is no partner:
     // best_d2 stayed r2, so best_b2 is the smallest distance seen); points outside the block are >= block_dist cells away in
     // the local frame (2 cells if the query's cell lies outside the directory range, i.e. occupied cells +- 2)
@@ -959,7 +964,7 @@ __global__ __launch_bounds__(kBlock, 3) void k_nn_mfma(const float4* __restrict_
   const int col = lane & 31, gh = lane >> 5;
   const size_t pos = ((size_t)blockIdx.x * (kBlock / kWave) + w) * kWave + lane;
   const bool valid = pos < n;
-  const unsigned j = valid ? order[pos] : 0u;
+  const unsigned j = valid ? (order[pos] & kListIndexMask) : 0u;
   const float4 q = valid ? Gsrc[j] : make_float4(0.f, 0.f, 0.f, 0.f);
   int cx = 0, cy = 0, cz = 0;
   const unsigned long long key = valid ? query_cell_key(q, im, g, qr, cx, cy, cz) : kEmptyKey;
@@ -1206,14 +1211,14 @@ __device__ __forceinline__ void nn_certify_body(const unsigned bx, const float4*
       } else {
         ok = (thr > 0.f) && (lim >= r2);
         near = none_near != 0;                          // k_nn_bounded searches these beyond the radius
-        if (ok) st_stream(match_d2 + j, r2);
+        st_stream(match_d2 + j, r2);                    // settled or not: what a search that finds nothing would write (k_nn_rows then skips it)
       }
     }
     const unsigned long long fn = __ballot(valid && !ok && near), ff = __ballot(valid && !ok && !near);
     const unsigned long long below = (1ull << lane) - 1ull;
     if (valid && !ok) {
       if (near) s_list[0][w][cn + (unsigned)__popcll(fn & below)] = (unsigned)j;
-      else s_list[1][w][cf + (unsigned)__popcll(ff & below)] = (unsigned)j;
+      else s_list[1][w][cf + (unsigned)__popcll(ff & below)] = (unsigned)j | (mm[u] < 0 ? kListNoPartner : 0u);
     }
     cn += (unsigned)__popcll(fn); cf += (unsigned)__popcll(ff);
     }
@@ -1288,7 +1293,7 @@ __global__ __launch_bounds__(kBlock) void k_nn_bounded(const float4* __restrict_
   const unsigned i = (blockIdx.x * blockDim.x + threadIdx.x) / LPQ;
   const int sub = threadIdx.x % LPQ;
   if (i >= n_list) return;
-  const unsigned j = list[i];
+  const unsigned j = list[i] & kListIndexMask;
   const float4 q = Gsrc[j];
   const int m = match[j];
   float d1 = r2;                                     // no old partner: the whole radius (the 27 cells)
@@ -1442,7 +1447,7 @@ __device__ __forceinline__ void nn_bounded_half_body(const unsigned bx, const fl
   __shared__ unsigned char s_len[kHalfRuns][kBlock];
   const unsigned i = bx * blockDim.x + threadIdx.x;
   if (i >= n_list) return;
-  const unsigned j = list[i];
+  const unsigned j = list[i] & kListIndexMask;
   const float4 q = Gsrc[j];
   const int m = match[j];
   float d1 = r2;                                     // no old partner

@@ -17,6 +17,9 @@ constexpr int kLmMaxPoses = 10;      // LM tries (0 or 1)..9 evaluated by one k_
 constexpr int kLmSlot = 91;          // doubles per block partial / per set result
 constexpr int kMaxBboxBlocks = 2048;
 constexpr int kRowCap = 128;         // candidates staged in LDS per wave and batch (k_nn_rows)
+// An entry of a certificate search's FAR list is a source position (< 2^31) and, in bit 31, "this query had no partner": the flag
+// rides through the key kernels and the radix sort as part of the value, every reader of a list masks it (kListIndexMask).
+constexpr unsigned kListNoPartner = 0x80000000u, kListIndexMask = 0x7FFFFFFFu;
 constexpr int kRowSpan = 4;          // max x-extent (cells) of a row segment handled at once (k_nn_rows)
 constexpr int kNNCap = 256;          // candidates staged in LDS per wave and batch (k_nn_cells)
 

@@ -419,6 +419,141 @@ __device__ __forceinline__ float motion_lo(const float4 q, const MotionBound& m)
   return (m.a * fmaxf(motion_rho(q, m) * 0.999998f - 5e-5f, 0.f) + m.b) * 0.999999f;
 }
 
+// -------------------------------------------------------------------------------------------------
+// Occupancy of the 27-cell blocks (round 5).  While two scans are still centimetres apart most queries have no target point anywhere
+// in the 27 cells around them; k_nn_rows keyed, sorted and visited them all the same, read the nine directory rows of their block
+// and left with "no partner" (9 of the 9.4 ms of such an outer iteration at 2 x 50 M points).  One bit per cell of the dense
+// directory's range says whether ANY of the 27 cells around it holds a point (k_occ_cells: the occupied cells, 64 cells per wave and
+// ballot; k_occ_dilate: the OR over the 3 x 3 x 3 neighbourhood, rows padded to whole 32-bit words): 1e9 cells are 125 MB, built
+// once per grid.  k_query_keys_prune tests it with ONE load per query.
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_occ_cells(const unsigned* __restrict__ S, QueryRange qr, unsigned stride_w, unsigned* __restrict__ occ) {
+  // one wave per 64 consecutive (padded) cells of a row
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t per_row = (size_t)stride_w * 32u;
+  const size_t row = t / per_row;
+  if (row >= (size_t)qr.D[1] * qr.D[2]) return;                 // (per_row is a multiple of 64 or of 32: see the launch)
+  const unsigned x = (unsigned)(t % per_row);
+  bool on = false;
+  if (x < qr.D[0]) { const size_t lin = row * qr.D[0] + x; on = S[lin + 1] > S[lin]; }
+  const unsigned long long b = __ballot(on);
+  const int lane = threadIdx.x & 63;
+  const size_t w0 = row * stride_w + (x >> 5);
+  if (lane == 0) occ[w0] = (unsigned)b;
+  if (lane == 32) occ[w0] = (unsigned)(b >> 32);
+}
+__global__ __launch_bounds__(kBlock) void k_occ_dilate(const unsigned* __restrict__ in, unsigned D1, unsigned D2, unsigned stride_w, unsigned* __restrict__ out) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t row = t / stride_w;
+  if (row >= (size_t)D1 * D2) return;
+  const unsigned xw = (unsigned)(t % stride_w);
+  const int y = (int)(row % D1), z = (int)(row / D1);
+  unsigned acc = 0u;
+#pragma unroll
+  for (int dz = -1; dz <= 1; ++dz)
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy) {
+      const int yy = y + dy, zz = z + dz;
+      if (yy < 0 || zz < 0 || yy >= (int)D1 || zz >= (int)D2) continue;
+      const unsigned* r = in + ((size_t)zz * D1 + (size_t)yy) * stride_w;
+      const unsigned w = r[xw], lo = xw > 0u ? r[xw - 1] : 0u, hi = xw + 1u < stride_w ? r[xw + 1] : 0u;
+      acc |= w | (w << 1) | (w >> 1) | (lo >> 31) | (hi << 31);
+    }
+  out[t] = acc;
+}
+
+// Keys of the queries k_nn_rows has to look at, COMPACTED: a query whose block is empty (its cell's bit in `occ` is clear, or its
+// cell lies outside the directory's range) is settled here exactly as k_nn_rows settles a query without candidates -- no partner,
+// d2 = r2, the certificate of the block's faces (the same expression, the same bits) -- and only the others are keyed for the sort.
+// list == nullptr: all n queries.  A block takes kPruneBlock queries, kPrunePerThread per thread, and reserves its stretch of the
+// output with ONE atomic (a first version with an atomic per wave on the one counter took 15 ms for 1.5 M of them).  The order of
+// the kept pairs depends on the order in which blocks reach the counter; the radix sort orders them by key and k_nn_rows treats
+// every query on its own, so results do not.  count[0] = number of pairs written.
+constexpr int kPrunePerThread = 8, kPruneBlock = kBlock * kPrunePerThread;
+template <typename KeyT>
+__global__ __launch_bounds__(kBlock) void k_query_keys_prune(const float4* __restrict__ Gsrc, const unsigned* __restrict__ list, size_t n,
+                                                             const unsigned* __restrict__ occ, unsigned stride_w, GridDesc g, InvMap im,
+                                                             QueryRange qr, float r2, CertParams cert, KeyT* __restrict__ keys,
+                                                             unsigned* __restrict__ vals, unsigned* __restrict__ count,
+                                                             int* __restrict__ match, int* __restrict__ match2,
+                                                             float* __restrict__ match_d2, float* __restrict__ lbe) {
+  __shared__ unsigned s_cnt[kBlock / kWave][kPrunePerThread];
+  __shared__ unsigned s_base;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const size_t i0 = (size_t)blockIdx.x * kPruneBlock + (size_t)w * kWave + (size_t)lane;      // step u: + u * kBlock
+  KeyT kk[kPrunePerThread];
+  unsigned vv[kPrunePerThread];
+  unsigned long long keep_mask[kPrunePerThread];       // wave-uniform ballots
+  unsigned jf[kPrunePerThread];
+  float4 qq[kPrunePerThread];
+#pragma unroll
+  for (int u = 0; u < kPrunePerThread; ++u) {
+    const size_t i = i0 + (size_t)u * kBlock;
+    jf[u] = (i < n) ? (list ? list[i] : (unsigned)i) : 0u;
+  }
+#pragma unroll
+  for (int u = 0; u < kPrunePerThread; ++u) qq[u] = Gsrc[jf[u] & kListIndexMask];
+  unsigned wordv[kPrunePerThread];
+  int bitv[kPrunePerThread];
+  float bdist[kPrunePerThread];
+#pragma unroll
+  for (int u = 0; u < kPrunePerThread; ++u) {
+    int cx = 0, cy = 0, cz = 0;
+    bdist[u] = 2.0f;
+    const unsigned long long key = query_cell_key(qq[u], im, g, qr, cx, cy, cz, &bdist[u]);
+    kk[u] = (KeyT)key;
+    wordv[u] = 0u; bitv[u] = -1;
+    if (key != kEmptyKey) {
+      const int kx = cx - qr.lo[0], ky = cy - qr.lo[1], kz = cz - qr.lo[2];
+      wordv[u] = occ[((size_t)kz * qr.D[1] + (size_t)ky) * stride_w + (size_t)(kx >> 5)];
+      bitv[u] = kx & 31;
+    } else {
+      bdist[u] = 2.0f;                                   // outside the directory range: two empty cells all around (k_nn_rows)
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < kPrunePerThread; ++u) {
+    const size_t i = i0 + (size_t)u * kBlock;
+    const bool valid = i < n;
+    const bool keep = valid && bitv[u] >= 0 && ((wordv[u] >> bitv[u]) & 1u);
+    const unsigned j = jf[u] & kListIndexMask;
+    vv[u] = jf[u];
+    if (valid && !keep) {
+      if (!(jf[u] & kListNoPartner)) {                   // (see k_nn_rows: a query that had no partner holds these values already)
+        match[j] = -1; match_d2[j] = r2;
+        if (match2) match2[j] = -1;
+      }
+      const float kInf = __uint_as_float(0x7f800000u);
+      const float lb_out = bdist[u] * cert.cell_scale - cert.cell_sub;
+      lbe[j] = fmaxf(fminf(sqrtf(kInf), lb_out), 0.0f) * 0.999999f + motion_lo(qq[u], cert.lo);
+    }
+    keep_mask[u] = __ballot(keep);
+    if (lane == 0) s_cnt[w][u] = (unsigned)__popcll(keep_mask[u]);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned tot = 0u;
+    for (int ww = 0; ww < kBlock / kWave; ++ww)
+      for (int u = 0; u < kPrunePerThread; ++u) tot += s_cnt[ww][u];
+    s_base = tot ? atomicAdd(count, tot) : 0u;
+  }
+  __syncthreads();
+  unsigned off = s_base;
+  for (int ww = 0; ww < w; ++ww)
+#pragma unroll
+    for (int u = 0; u < kPrunePerThread; ++u) off += s_cnt[ww][u];
+#pragma unroll
+  for (int u = 0; u < kPrunePerThread; ++u) {
+    if ((keep_mask[u] >> lane) & 1ull) {
+      const unsigned slot = off + (unsigned)__popcll(keep_mask[u] & ((1ull << lane) - 1ull));
+      keys[slot] = kk[u];
+      vals[slot] = vv[u];
+    }
+    off += (unsigned)__popcll(keep_mask[u]);
+  }
+}
+
+
 __device__ __forceinline__ int rdlane_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
 __device__ __forceinline__ unsigned rdlane_u(unsigned v, int l) { return (unsigned)__builtin_amdgcn_readlane((int)v, l); }
 
@@ -2672,6 +2807,26 @@ void launch_query_keys32_list(const float4* Gsrc, const unsigned* list, size_t n
                               const QueryRange& qr, unsigned* keys, unsigned* vals, hipStream_t s) {
   if (!n) return;
   hipLaunchKernelGGL(k_query_keys32_list, dim3((unsigned)div_up(n, kBlock)), dim3(kBlock), 0, s, Gsrc, list, n, g, im, qr, keys, vals);
+}
+
+void launch_block_occupancy(const unsigned* dense_start, const QueryRange& qr, unsigned stride_w, unsigned* tmp, unsigned* occ, hipStream_t s) {
+  const size_t rows = (size_t)qr.D[1] * qr.D[2];
+  if (!rows || !stride_w) return;
+  hipLaunchKernelGGL(k_occ_cells, dim3((unsigned)div_up(rows * stride_w * 32u, kBlock)), dim3(kBlock), 0, s, dense_start, qr, stride_w, tmp);
+  hipLaunchKernelGGL(k_occ_dilate, dim3((unsigned)div_up(rows * stride_w, kBlock)), dim3(kBlock), 0, s, (const unsigned*)tmp, qr.D[1], qr.D[2], stride_w, occ);
+}
+
+void launch_query_keys_prune(bool keys32, const float4* Gsrc, const unsigned* list, size_t n, const unsigned* occ, unsigned stride_w, const GridDesc& g,
+                             const InvMap& im, const QueryRange& qr, float r2, const CertParams& cert, void* keys, unsigned* vals, unsigned* count,
+                             int* match, int* match2, float* match_d2, float* lbe, hipStream_t s) {
+  if (!n) return;
+  const dim3 grid((unsigned)div_up(n, (size_t)kPruneBlock));
+  if (keys32)
+    hipLaunchKernelGGL(k_query_keys_prune<unsigned>, grid, dim3(kBlock), 0, s, Gsrc, list, n, occ, stride_w, g, im, qr, r2, cert,
+                       (unsigned*)keys, vals, count, match, match2, match_d2, lbe);
+  else
+    hipLaunchKernelGGL(k_query_keys_prune<unsigned long long>, grid, dim3(kBlock), 0, s, Gsrc, list, n, occ, stride_w, g, im, qr, r2, cert,
+                       (unsigned long long*)keys, vals, count, match, match2, match_d2, lbe);
 }
 
 void launch_nn_certify(const float4* Gsrc, size_t n, const float4* Gtgt, const MotionBound& cum_up, float r2, float near2, bool none_near, int* match, int* match2,

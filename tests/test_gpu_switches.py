@@ -1,6 +1,6 @@
 """The library's alternative data flows give the same bits.  Their switches are environment variables read once per process, so
 each setting runs in its own interpreter: the certificate search of several directed pairs per host round trip against pair by
-pair or one launch per pair (E3D_ICP_BATCH = 0 / 1; default 2: one launch per kernel and batch), the certificates' motion bound per query against the clouds' global one (E3D_NN_PERQUERY), resident against compacted correspondence rows (E3D_ICP_RESIDENT), the speculative last LM step
+pair or one launch per pair (E3D_ICP_BATCH = 0 / 1; default 2: one launch per kernel and batch), the certificates' motion bound per query against the clouds' global one (E3D_NN_PERQUERY), the key kernel that settles queries with an empty 27-cell block against sorting them all (E3D_NN_PRUNE), resident against compacted correspondence rows (E3D_ICP_RESIDENT), the speculative last LM step
 (E3D_LM_SPECULATE); the kNN estimator's single scan with sampled thresholds against the two-pass kernels (E3D_KNN_SINGLE), with
 and without the lists the 125-cell pass starts from (E3D_KNN_SEED), the wave-per-query form of that pass (E3D_KNN_WIDE_WAVE)."""
 import json
@@ -29,7 +29,7 @@ pairs = [[int(r[0]), int(r[1]), int(r[2]), int(r[3]), float(r[4]).hex()] for r i
 poses = [[float(v).hex() for v in icp.get_result_global_T_cloud(i).ravel()] for i in ids if i >= 0]
 rec = icp.iter_records()
 print("RESULT" + json.dumps({"pairs": pairs, "poses": poses, "batches": sum(r["nn_batches"] for r in rec), "launches": sum(r["nn_kernel_launches"] for r in rec),
-                             "certified": sum(r["nn_certify_queries"] for r in rec), "searched": sum(r["nn_search_queries"] + r["nn_bounded_queries"] for r in rec)}))
+                             "certified": sum(r["nn_certify_queries"] for r in rec), "searched": sum(r["nn_search_queries"] + r["nn_bounded_queries"] for r in rec), "rows_queries": sum(r["nn_search_queries"] for r in rec)}))
 """ % ROOT
 
 KNN_CODE = r"""
@@ -63,14 +63,19 @@ def test_icp_data_flows_agree():
     assert len(base["pairs"]) > 0
     assert base["batches"] > 0 and base["certified"] > 0             # the default ran batches of pairs through the one-launch kernels
     strip = lambda r: {k: r[k] for k in ("pairs", "poses")}
-    for env in ({"E3D_ICP_BATCH": "0"}, {"E3D_ICP_BATCH": "1"}, {"E3D_LM_SPECULATE": "0"}, {"E3D_NN_PERQUERY": "0"}, {"E3D_NN_PERQUERY": "0", "E3D_ICP_BATCH": "0"}):
+    for env in ({"E3D_ICP_BATCH": "0"}, {"E3D_ICP_BATCH": "1"}, {"E3D_LM_SPECULATE": "0"}, {"E3D_NN_PERQUERY": "0"}, {"E3D_NN_PERQUERY": "0", "E3D_ICP_BATCH": "0"},
+                {"E3D_NN_PRUNE": "0"}, {"E3D_NN_PRUNE": "0", "E3D_ICP_BATCH": "0"}, {"E3D_NN_PRUNE_MIN": "1", "E3D_ICP_BATCH": "1"}):
         other = _run(ICP_CODE, env)
         assert strip(other) == strip(base), env                      # same kernel bodies, same sums: bit for bit
         if env == {"E3D_NN_PERQUERY": "0"}:
             # the bound per query certifies at least what the clouds' global bound certifies (rigid poses): fewer searches
             assert other["searched"] >= base["searched"], (other["searched"], base["searched"])
             print("queries searched: %d with the motion bound per query, %d with the clouds' global bound" % (base["searched"], other["searched"]))
-        if "E3D_ICP_BATCH" in env and "E3D_NN_PERQUERY" not in env:
+        if env == {"E3D_NN_PRUNE": "0"}:
+            # without the occupancy bits every far-list query is sorted and visited by the row kernel
+            assert other["rows_queries"] > base["rows_queries"], (other["rows_queries"], base["rows_queries"])
+            print("queries the row kernel visited: %d with the key kernel settling empty blocks, %d without" % (base["rows_queries"], other["rows_queries"]))
+        if list(env) == ["E3D_ICP_BATCH"]:
             assert other["batches"] == 0 and other["launches"] > base["launches"], (env, other["launches"], base["launches"])
     # resident vs compacted rows: the pair records (counts, distance sums) are those of the same searches; the LM passes add the
     # same f32 terms in a different order of f64 sums (include/e3d_hip.h), so the poses agree to the tolerances of

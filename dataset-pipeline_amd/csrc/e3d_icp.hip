@@ -87,6 +87,8 @@ struct PairState {
   unsigned long long src_gen = 0, tgt_gen = 0;
   bool fresh = true;           // no search has filled the state yet
   bool prune = true;           // the key kernel settles the far list's queries with an empty block (until that stops paying: sort_query_keys_pruned)
+  double settled_frac = 1.0;   // share of the queries the last k_nn_certify settled, and the clouds' motion bound of that iteration (certify_now)
+  double certify_motion = 0.0;
   // motion of the source's queries relative to the target since the state was created (MotionBound, e3d_icp_kernels.hpp): a query
   // at distance rho from the source's bounding-box centre has moved at most mA * rho + mB in the target's frame
   double mA = 0.0, mB = 0.0;
@@ -464,7 +466,7 @@ static PairState& pair_state_for(e3d_icp* h, int src_id, int tgt_id, const Cloud
   if (ps.n != n || ps.jbase != (long long)j0 || ps.src_gen != src.generation || ps.tgt_gen != tgt.generation) {
     ps.match.reserve(n); ps.match2.reserve(n); ps.lbe.reserve(n); ps.todo_count.reserve(2);
     ps.n = n; ps.jbase = (long long)j0; ps.src_gen = src.generation; ps.tgt_gen = tgt.generation;
-    ps.fresh = true; ps.prune = true;
+    ps.fresh = true; ps.prune = true; ps.settled_frac = 1.0; ps.certify_motion = 0.0;
     ps.rows_valid = false;
     ps.mA = 0.0; ps.mB = 0.0;
   }
@@ -623,13 +625,27 @@ static void sort_query_keys(e3d_icp* h, const Cloud& tgt, const float4* srcG, co
   }
 }
 
+// Is k_nn_certify worth a pass over this pair's queries?  While two scans are centimetres apart every certificate breaks with every
+// pose update (0.7 ms per outer iteration at 2 x 50 M points for nothing).  After a pass that settled less than 2 % of the queries
+// the pair is searched whole -- the state of the last search still tells which queries had no partner (from_state) -- until the
+// clouds' motion bound of an iteration falls below half of what it was at that pass.  A wrong guess costs searches, never a
+// result.  E3D_NN_CERT_SKIP=0: always test.
+static bool certify_now(const PairState& ps, const Cloud& src, const Cloud& tgt) {
+  static const bool allow = [] { const char* e = getenv("E3D_NN_CERT_SKIP"); return !(e && e[0] == '0'); }();
+  return !allow || ps.settled_frac >= 0.02 || (src.last_motion + tgt.last_motion) < 0.5 * ps.certify_motion;
+}
+static void certify_ran(PairState& ps, const Cloud& src, const Cloud& tgt, size_t n, size_t unsettled) {
+  ps.settled_frac = n ? 1.0 - (double)unsettled / (double)n : 1.0;
+  ps.certify_motion = src.last_motion + tgt.last_motion;
+}
+
 // The certificate path's variant: the key kernel settles the queries whose 27-cell block holds no target point (k_query_keys_prune:
 // one bit per query from the target's occupancy bits) and only the others are sorted; returns how many those are (h->vals_b: their
 // list entries in key order).  One host round trip for the count -- the sort's size.  It pays while the scans are centimetres
 // apart (most blocks empty: 2 x 50 M points, 9.4 -> 5 ms per outer iteration); once nine queries in ten have candidates the pair
 // goes back to the plain key kernel (ps.prune; a fresh state starts over).  E3D_NN_PRUNE=0: never.
 static size_t sort_query_keys_pruned(e3d_icp* h, PairState& ps, const Cloud& tgt, const float4* srcG, const unsigned* list, size_t n, const InvMap& im,
-                                     float r2, const CertParams& cert, float* match_d2) {
+                                     float r2, const CertParams& cert, float* match_d2, bool from_state) {
   static const size_t min_list = (size_t)env_double("E3D_NN_PRUNE_MIN", 262144.0);
   if (!tgt.has_occ || !ps.prune || n < min_list) { sort_query_keys(h, tgt, srcG, list, n, im); return n; }
   hipStream_t s = h->stream;
@@ -640,7 +656,7 @@ static size_t sort_query_keys_pruned(e3d_icp* h, PairState& ps, const Cloud& tgt
   const bool k32 = tgt.key_bits <= 31;
   E3D_HIP(hipMemsetAsync(h->prune_count.p, 0, sizeof(unsigned), s));
   launch_query_keys_prune(k32, srcG, list, n, tgt.occ27.p, tgt.occ_stride, tgt.grid, im, tgt.qrange, r2, cert, h->keys_a.p, h->vals_a.p, h->prune_count.p,
-                          ps.match.p, ps.match2.p, match_d2, ps.lbe.p, s);
+                          ps.match.p, ps.match2.p, match_d2, ps.lbe.p, from_state, s);
   copy_out(h->h_prune_count.p, h->prune_count.p, sizeof(unsigned), s);
   sync(h);
   const size_t kept = h->h_prune_count.p[0];
@@ -715,7 +731,9 @@ static void find_pair(e3d_icp* h, Cloud& src, Cloud& tgt, float d, PairJob& job,
     const CertParams cert = make_cert_params(tgt, m_lo);
     size_t n_far = n, n_near = 0;
     const unsigned* list = nullptr;
-    if (!ps.fresh && use_cert) {
+    const bool test_certificates = !ps.fresh && use_cert && certify_now(ps, src, tgt);
+    const bool from_state = !ps.fresh && use_cert && !test_certificates;       // searched whole; the state says who had no partner
+    if (test_certificates) {
       NnPhase ph(s, 0);
       static const double margin_frac = env_double("E3D_NN_MARGIN", 0.08), near_frac = env_double("E3D_NN_NEAR", 0.4);   // of the radius
       const MotionBound& cum_up = m_up;
@@ -739,6 +757,7 @@ static void find_pair(e3d_icp* h, Cloud& src, Cloud& tgt, float d, PairJob& job,
       { const double t = h->nn_timer_c->ms(); rec.t_nn_certify_ms += t; rec.t_nn_query_ms += t; }
       rec.nn_certify_launches++; rec.nn_certify_queries += (long long)n; rec.nn_kernel_launches++;
       n_near = h->h_todo.p[0]; n_far = h->h_todo.p[1];
+      certify_ran(ps, src, tgt, n, n_near + n_far);
       h->tm_bounded.start(s);                             // (read lazily: timing the bounded search costs no synchronisation)
       list = h->todo_far.p;
       // old partner close by: only the cells its distance (+ margin) reaches, one thread per query, no sort
@@ -768,7 +787,7 @@ static void find_pair(e3d_icp* h, Cloud& src, Cloud& tgt, float d, PairJob& job,
     size_t n_rows = 0;                                     // far-list queries with a candidate in their 27 cells: sorted and searched
     if (n_far > 0) {
       NnPhase ph(s, 1);
-      n_rows = sort_query_keys_pruned(h, ps, tgt, srcG, list, n_far, im, radius_sq(d), cert, h->match_d2.p);
+      n_rows = sort_query_keys_pruned(h, ps, tgt, srcG, list, n_far, im, radius_sq(d), cert, h->match_d2.p, from_state);
       rec.nn_sort_calls++; rec.nn_kernel_launches++;
     }
     h->nn_timer->start(s);
@@ -900,7 +919,7 @@ static void find_pair(e3d_icp* h, Cloud& src, Cloud& tgt, float d, PairJob& job,
 struct BatchItem {
   PairJob* job; Cloud* src; Cloud* tgt; size_t j0, n; PairState* ps;
   InvMap im; CertParams cert; BoundParams bp; double cum_pair;
-  bool certified = false; size_t n_near = 0, n_far = 0;
+  bool certified = false, from_state = false; size_t n_near = 0, n_far = 0;
 };
 static constexpr size_t kPairBatch = 32;
 // queries of a batch: its scratch (squared distances, two todo lists) is 12 B per query, 3 GB at most -- whatever the clouds' size
@@ -934,7 +953,8 @@ static void find_pairs_batched(e3d_icp* h, std::vector<BatchItem>& items, float 
     pair_motion_bounds(ps, src, tgt, m_lo, cum_up);
     it.cert = make_cert_params(tgt, m_lo);
     it.n_far = it.n; it.n_near = 0;
-    it.certified = !ps.fresh && use_cert;
+    it.certified = !ps.fresh && use_cert && certify_now(ps, src, tgt);
+    it.from_state = !ps.fresh && use_cert && !it.certified;
     if (!it.certified) continue;
     const float4* srcG = src.G4.p + it.j0;
     const float near2 = (float)((near_frac * (double)d) * (near_frac * (double)d));
@@ -972,6 +992,7 @@ static void find_pairs_batched(e3d_icp* h, std::vector<BatchItem>& items, float 
     const unsigned* list = nullptr;
     if (it.certified) {
       it.n_near = h->h_todo_all.p[2 * i]; it.n_far = h->h_todo_all.p[2 * i + 1];
+      certify_ran(ps, src, tgt, it.n, it.n_near + it.n_far);
       list = sl.todo_far.p;
       const unsigned long long* half = tgt.has_half ? tgt.half_prefix.p : nullptr;
       h->tm_bounded.start(s);
@@ -987,7 +1008,7 @@ static void find_pairs_batched(e3d_icp* h, std::vector<BatchItem>& items, float 
     }
     if (it.n_far > 0) {
       rec.nn_sort_calls++; rec.nn_kernel_launches++;
-      const size_t n_rows = sort_query_keys_pruned(h, ps, tgt, srcG, list, it.n_far, it.im, radius_sq(d), it.cert, sl.match_d2.p);
+      const size_t n_rows = sort_query_keys_pruned(h, ps, tgt, srcG, list, it.n_far, it.im, radius_sq(d), it.cert, sl.match_d2.p, it.from_state);
       if (n_rows > 0) {
         h->tm_search.start(s);
         launch_rows(3, tgt, srcG, h->vals_b.p, n_rows, it.im, radius_sq(d), it.cert, ps.match.p, sl.match_d2.p, ps.lbe.p, ps.match2.p, s);
@@ -1082,7 +1103,8 @@ static bool find_pairs_multi(e3d_icp* h, std::vector<BatchItem>& items, float d,
     pair_motion_bounds(ps, src, tgt, m_lo, m_up);
     it.cert = make_cert_params(tgt, m_lo);
     it.n_far = n; it.n_near = 0;
-    it.certified = !ps.fresh && use_cert;
+    it.certified = !ps.fresh && use_cert && certify_now(ps, src, tgt);
+    it.from_state = !ps.fresh && use_cert && !it.certified;
     const bool none_near = np_frac > 0 && (src.last_motion + tgt.last_motion) < np_gate * (double)d;
     double smin = min_singular_value_3x3(tgt.T);
     if (!(smin > 1e-12)) smin = 1e-12;
@@ -1148,6 +1170,7 @@ static bool find_pairs_multi(e3d_icp* h, std::vector<BatchItem>& items, float d,
     if (!it.certified) continue;
     e3d_icp::PairSlot& sl = *h->slots[i];
     it.n_near = h->h_todo_all.p[2 * i]; it.n_far = h->h_todo_all.p[2 * i + 1];
+    certify_ran(*it.ps, *it.src, *it.tgt, it.n, it.n_near + it.n_far);
     auto add_job = [&](const unsigned* list, size_t n_list) {
       if (!n_list) return;
       const int jb = T.n_jobs++;
@@ -1174,7 +1197,7 @@ static bool find_pairs_multi(e3d_icp* h, std::vector<BatchItem>& items, float d,
     if (it.n_far > 0) {
       e3d_icp::PairSlot& sl = *h->slots[i];
       const float4* srcG = it.src->G4.p + it.j0;
-      const size_t n_rows = sort_query_keys_pruned(h, ps, *it.tgt, srcG, it.certified ? sl.todo_far.p : nullptr, it.n_far, it.im, radius_sq(d), it.cert, sl.match_d2.p);
+      const size_t n_rows = sort_query_keys_pruned(h, ps, *it.tgt, srcG, it.certified ? sl.todo_far.p : nullptr, it.n_far, it.im, radius_sq(d), it.cert, sl.match_d2.p, it.from_state);
       rec.nn_kernel_launches++; rec.nn_sort_calls++;
       if (n_rows > 0) {
         h->tm_search.start(s);

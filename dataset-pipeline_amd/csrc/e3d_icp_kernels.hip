@@ -476,7 +476,7 @@ __global__ __launch_bounds__(kBlock) void k_query_keys_prune(const float4* __res
                                                              QueryRange qr, float r2, CertParams cert, KeyT* __restrict__ keys,
                                                              unsigned* __restrict__ vals, unsigned* __restrict__ count,
                                                              int* __restrict__ match, int* __restrict__ match2,
-                                                             float* __restrict__ match_d2, float* __restrict__ lbe) {
+                                                             float* __restrict__ match_d2, float* __restrict__ lbe, int from_state) {
   __shared__ unsigned s_cnt[kBlock / kWave][kPrunePerThread];
   __shared__ unsigned s_base;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -489,7 +489,9 @@ __global__ __launch_bounds__(kBlock) void k_query_keys_prune(const float4* __res
 #pragma unroll
   for (int u = 0; u < kPrunePerThread; ++u) {
     const size_t i = i0 + (size_t)u * kBlock;
-    jf[u] = (i < n) ? (list ? list[i] : (unsigned)i) : 0u;
+    // from_state (all queries of a pair whose certificates were not tested this time, see certify_now in e3d_icp.hip): the flag
+    // k_nn_certify would have set comes from the state itself, and so does the r2 it would have stored
+    jf[u] = (i < n) ? (list ? list[i] : ((unsigned)i | ((from_state && match[i] < 0) ? kListNoPartner : 0u))) : 0u;
   }
 #pragma unroll
   for (int u = 0; u < kPrunePerThread; ++u) qq[u] = Gsrc[jf[u] & kListIndexMask];
@@ -518,6 +520,7 @@ __global__ __launch_bounds__(kBlock) void k_query_keys_prune(const float4* __res
     const bool keep = valid && bitv[u] >= 0 && ((wordv[u] >> bitv[u]) & 1u);
     const unsigned j = jf[u] & kListIndexMask;
     vv[u] = jf[u];
+    if (valid && from_state && (jf[u] & kListNoPartner)) match_d2[j] = r2;
     if (valid && !keep) {
       if (!(jf[u] & kListNoPartner)) {                   // (see k_nn_rows: a query that had no partner holds these values already)
         match[j] = -1; match_d2[j] = r2;
@@ -2818,15 +2821,16 @@ void launch_block_occupancy(const unsigned* dense_start, const QueryRange& qr, u
 
 void launch_query_keys_prune(bool keys32, const float4* Gsrc, const unsigned* list, size_t n, const unsigned* occ, unsigned stride_w, const GridDesc& g,
                              const InvMap& im, const QueryRange& qr, float r2, const CertParams& cert, void* keys, unsigned* vals, unsigned* count,
-                             int* match, int* match2, float* match_d2, float* lbe, hipStream_t s) {
+                             int* match, int* match2, float* match_d2, float* lbe, bool from_state, hipStream_t s) {
   if (!n) return;
   const dim3 grid((unsigned)div_up(n, (size_t)kPruneBlock));
+  const int fs = (from_state && !list) ? 1 : 0;
   if (keys32)
     hipLaunchKernelGGL(k_query_keys_prune<unsigned>, grid, dim3(kBlock), 0, s, Gsrc, list, n, occ, stride_w, g, im, qr, r2, cert,
-                       (unsigned*)keys, vals, count, match, match2, match_d2, lbe);
+                       (unsigned*)keys, vals, count, match, match2, match_d2, lbe, fs);
   else
     hipLaunchKernelGGL(k_query_keys_prune<unsigned long long>, grid, dim3(kBlock), 0, s, Gsrc, list, n, occ, stride_w, g, im, qr, r2, cert,
-                       (unsigned long long*)keys, vals, count, match, match2, match_d2, lbe);
+                       (unsigned long long*)keys, vals, count, match, match2, match_d2, lbe, fs);
 }
 
 void launch_nn_certify(const float4* Gsrc, size_t n, const float4* Gtgt, const MotionBound& cum_up, float r2, float near2, bool none_near, int* match, int* match2,

@@ -104,10 +104,11 @@ void launch_query_keys32_list(const float4* Gsrc, const unsigned* list, size_t n
 // none_near: queries without a partner go to todo_near as well (k_nn_bounded searches them beyond the radius)
 // occupancy bits of the 27-cell blocks (stride_w 32-bit words per (y, z) row of the dense directory's range; tmp: as large as occ)
 void launch_block_occupancy(const unsigned* dense_start, const QueryRange& qr, unsigned stride_w, unsigned* tmp, unsigned* occ, hipStream_t s);
-// keys of the listed queries (nullptr: all) whose block holds a candidate, compacted; the others are settled (count[0] = pairs kept)
+// keys of the listed queries (nullptr: all) whose block holds a candidate, compacted; the others are settled (count[0] = pairs kept).
+// from_state (list == nullptr only): match / match2 hold the last search's result -- queries without a partner are flagged from it
 void launch_query_keys_prune(bool keys32, const float4* Gsrc, const unsigned* list, size_t n, const unsigned* occ, unsigned stride_w, const GridDesc& g,
                              const InvMap& im, const QueryRange& qr, float r2, const CertParams& cert, void* keys, unsigned* vals, unsigned* count,
-                             int* match, int* match2, float* match_d2, float* lbe, hipStream_t s);
+                             int* match, int* match2, float* match_d2, float* lbe, bool from_state, hipStream_t s);
 void launch_nn_certify(const float4* Gsrc, size_t n, const float4* Gtgt, const MotionBound& cum_up, float r2, float near2, bool none_near, int* match, int* match2,
                        const float* lbe, float* match_d2, unsigned* todo_near, unsigned* todo_far, unsigned* counts, hipStream_t s);
 // bounded search (k_nn_bounded) of the listed queries around their old partners

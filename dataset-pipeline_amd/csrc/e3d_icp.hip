@@ -89,6 +89,7 @@ struct PairState {
   bool prune = true;           // the key kernel settles the far list's queries with an empty block (until that stops paying: sort_query_keys_pruned)
   double settled_frac = 1.0;   // share of the queries the last k_nn_certify settled, and the clouds' motion bound of that iteration (certify_now)
   double certify_motion = 0.0;
+  double matched_frac = 1.0;   // share of the queries the last search found a partner for
   // motion of the source's queries relative to the target since the state was created (MotionBound, e3d_icp_kernels.hpp): a query
   // at distance rho from the source's bounding-box centre has moved at most mA * rho + mB in the target's frame
   double mA = 0.0, mB = 0.0;
@@ -466,7 +467,7 @@ static PairState& pair_state_for(e3d_icp* h, int src_id, int tgt_id, const Cloud
   if (ps.n != n || ps.jbase != (long long)j0 || ps.src_gen != src.generation || ps.tgt_gen != tgt.generation) {
     ps.match.reserve(n); ps.match2.reserve(n); ps.lbe.reserve(n); ps.todo_count.reserve(2);
     ps.n = n; ps.jbase = (long long)j0; ps.src_gen = src.generation; ps.tgt_gen = tgt.generation;
-    ps.fresh = true; ps.prune = true; ps.settled_frac = 1.0; ps.certify_motion = 0.0;
+    ps.fresh = true; ps.prune = true; ps.settled_frac = 1.0; ps.certify_motion = 0.0; ps.matched_frac = 1.0;
     ps.rows_valid = false;
     ps.mA = 0.0; ps.mB = 0.0;
   }
@@ -627,12 +628,13 @@ static void sort_query_keys(e3d_icp* h, const Cloud& tgt, const float4* srcG, co
 
 // Is k_nn_certify worth a pass over this pair's queries?  While two scans are centimetres apart every certificate breaks with every
 // pose update (0.7 ms per outer iteration at 2 x 50 M points for nothing).  After a pass that settled less than 2 % of the queries
-// the pair is searched whole -- the state of the last search still tells which queries had no partner (from_state) -- until the
-// clouds' motion bound of an iteration falls below half of what it was at that pass.  A wrong guess costs searches, never a
+// the pair is searched whole -- the state of the last search still tells which queries had no partner (from_state) -- until half
+// of the queries have a partner (the scans have met) or the clouds' motion bound of an iteration falls below half of what it was
+// at that pass.  A wrong guess costs searches, never a
 // result.  E3D_NN_CERT_SKIP=0: always test.
 static bool certify_now(const PairState& ps, const Cloud& src, const Cloud& tgt) {
   static const bool allow = [] { const char* e = getenv("E3D_NN_CERT_SKIP"); return !(e && e[0] == '0'); }();
-  return !allow || ps.settled_frac >= 0.02 || (src.last_motion + tgt.last_motion) < 0.5 * ps.certify_motion;
+  return !allow || ps.settled_frac >= 0.02 || ps.matched_frac >= 0.5 || (src.last_motion + tgt.last_motion) < 0.5 * ps.certify_motion;
 }
 static void certify_ran(PairState& ps, const Cloud& src, const Cloud& tgt, size_t n, size_t unsettled) {
   ps.settled_frac = n ? 1.0 - (double)unsettled / (double)n : 1.0;
@@ -874,6 +876,7 @@ static void find_pair(e3d_icp* h, Cloud& src, Cloud& tgt, float d, PairJob& job,
   { const double t = h->nn_timer->ms(); rec.t_nn_query_ms += t; rec.t_nn_search_ms += t; }
   job.count = (long long)h->h_total.p[0];
   job.dsum = h->h_total_d2.p[0];
+  if (rows) pair_state_for(h, job.src, job.tgt, src, tgt, j0, n).matched_frac = (double)job.count / (double)n;
   if (h->sequential_dsum && !h->comm && h->world <= 1 && n == src.n) {
     h->d2_by_orig.reserve(n); h->h_d2_by_orig.resize(n);
     launch_match_d2_by_original(match_pos, h->match_d2.p, order, n, srcG, h->d2_by_orig.p, s);
@@ -1056,6 +1059,7 @@ static void find_pairs_batched(e3d_icp* h, std::vector<BatchItem>& items, float 
     BatchItem& it = items[i];
     it.job->count = (long long)h->h_totals_all.p[3 * i];
     it.job->dsum = h->h_d2_all.p[i];
+    it.ps->matched_frac = it.n ? (double)it.job->count / (double)it.n : 1.0;
     it.job->resident = it.ps;
     it.job->vrows = 64 * (long long)h->h_totals_all.p[3 * i + 1];
     rec.corr_rows_rewritten += (long long)h->h_totals_all.p[3 * i + 2];
@@ -1226,6 +1230,7 @@ static bool find_pairs_multi(e3d_icp* h, std::vector<BatchItem>& items, float d,
     BatchItem& it = items[i];
     it.job->count = (long long)h->h_totals_all.p[3 * i];
     it.job->dsum = h->h_d2_all.p[i];
+    it.ps->matched_frac = it.n ? (double)it.job->count / (double)it.n : 1.0;
     it.job->resident = it.ps;
     it.job->vrows = 64 * (long long)h->h_totals_all.p[3 * i + 1];
     rec.corr_rows_rewritten += (long long)h->h_totals_all.p[3 * i + 2];

@@ -129,11 +129,14 @@ typedef struct {
   double  t_nn_certify_ms;   /* k_nn_certify launches (HIP events)                         */
   double  t_nn_bounded_ms;   /* k_nn_bounded launches                                      */
   double  t_nn_search_ms;    /* k_nn_rows / k_nn_cells / k_nn_query / k_nn_mfma launches   */
-  int64_t nn_certify_queries, nn_bounded_queries, nn_search_queries;   /* queries those launches covered */
+  int64_t nn_certify_queries, nn_bounded_queries, nn_search_queries;   /* queries those launches covered (nn_search_queries: the
+                                  queries k_nn_rows visited -- those the key kernel settled because no target point lies in their
+                                  27 cells are not among them; nn_certify_queries is 0 for a pair whose certificates were not
+                                  tested in this iteration) */
   int32_t nn_certify_launches, nn_bounded_launches, nn_search_launches;
   int32_t lm_passes_skipped; /* ABI 4: LM passes not launched because every pose asked for had been evaluated already */
   /* ABI 3: the rest of the NN phase, so that the per-kernel times add up to the step (HIP events) */
-  double  t_nn_sort_ms;      /* query keys + radix sort of the queries the row kernel searches */
+  double  t_nn_sort_ms;      /* query keys (incl. settling the queries with an empty 27-cell block) + radix sort of the rest */
   double  t_nn_scan_ms;      /* match counts + scans (order-preserving compaction, first stage) */
   double  t_nn_compact_ms;   /* k_compact_corr / k_corr_update: the correspondence rows        */
   /* ABI 4 */

@@ -218,7 +218,8 @@ constexpr int kKnnHistBlock = 256;
 // only, and k is the count the threshold of that variant aims at (n_todo = number of sampled queries).
 __global__ __launch_bounds__(kKnnHistBlock) void k_knn_hist(const float4* __restrict__ P4, const unsigned* __restrict__ todo, size_t n_todo,
                                                             const HashEntry* __restrict__ table, KnnGrid G, int k,
-                                                            const float4* __restrict__ Q4, unsigned char* __restrict__ sel_bin, unsigned stride) {
+                                                            const float4* __restrict__ Q4, unsigned char* __restrict__ sel_bin, unsigned stride,
+                                                            float estimate) {
   __shared__ unsigned hw[kKnnBins / 4][kKnnHistBlock];
   const int tid = threadIdx.x;
   const size_t gi = (size_t)knn_block(G, blockIdx.x, gridDim.x) * blockDim.x + tid;
@@ -246,6 +247,17 @@ __global__ __launch_bounds__(kKnnHistBlock) void k_knn_hist(const float4* __rest
       for (int oy = -1; oy <= 1; ++oy)
         knn_row(G, table, cx - 1, cx + 1, cy + oy, cz + oz, [&](unsigned m, unsigned e) { n27 += e - m; });
     fexp = n27 <= 12u * (unsigned)k ? 0 : (n27 <= 24u * (unsigned)k ? 1 : 2);
+    if (estimate > 0.f) {
+      // sampled form, small k: the threshold from the block's population alone -- a surface patch of (3 cells)^2 holding n27 points
+      // has k of them within r^2 = 9 k / (pi n27) cell^2 -- without touching a candidate.  Any threshold gives the exact result; a
+      // poor one sends the query to the two-pass variant.
+      const float edge = estimate * 9.0f * (float)k / (3.14159265f * (float)max(n27, 1u));
+      if (!(edge < 2.0f)) { sel_bin[gi] = 255; return; }
+      const int fe = edge < 0.5f ? 2 : (edge < 1.0f ? 1 : 0);
+      const int sel = min(63, (int)(edge * (float)(32 << fe)));
+      sel_bin[gi] = (unsigned char)((fe << 6) | sel);
+      return;
+    }
   }
   const float inv_w2 = (float)(32 << fexp) * G.g.inv_cell * G.g.inv_cell;
   const knn_f2 qxy = {q.x, q.y};
@@ -1526,6 +1538,13 @@ static void knn_pass(KnnWorkspace& W, const float* xyz, size_t n, int k, const f
     const int cap1 = single_variant == 5 ? kKnnTagSlots : ((cap1_env >= k + 9 && cap1_env <= 36) ? cap1_env : 32);   // list slots of the single-pass variant (32: 16 KB of LDS per block, five waves per SIMD with variant 4's 86 registers)
     const int rep_stride = rep_stride_env > 0 ? rep_stride_env : 8;
     const int rep_avg = (rep_avg_env == 1 || rep_avg_env == 2 || rep_avg_env == 4) ? rep_avg_env : 2;
+    // where the sampled thresholds come from: the block population of the sampled query alone (k_knn_hist's `estimate`, the default
+    // with a dense directory: the sampling kernel touches no candidate, 0.51 -> 0.1 ms at 20 M points; 5.70 -> 5.33 ms at k = 8,
+    // 8.38 -> 7.98 at k = 32, scanner-sampled 17.5 -> 16.8 / 11.2 -> 10.6) or its distance histogram (E3D_KNN_EST=0).  The scale
+    // (E3D_KNN_EST_SCALE) widens the estimate: 1.05 measured best between 0.8 and 1.25.
+    static const int rep_estimate_env = [] { const char* e = getenv("E3D_KNN_EST"); return e ? atoi(e) : 64; }();
+    const bool rep_estimate = rep_estimate_env != 0 && k <= rep_estimate_env;
+    static const float rep_est_scale = [] { const char* e = getenv("E3D_KNN_EST_SCALE"); const double v = e ? atof(e) : 1.05; return (float)(v > 0 ? v : 1.05); }();
     // the count the threshold aims at: the middle of [k, capacity] (k = 32: 48 of 64), a little below it for small k where the
     // relative Poisson noise of the count is larger on the low side
     const int rep_target = rep_target_env > 0 ? (int)rep_target_env : std::min((k + cap1) / 2, 2 * k + 6);
@@ -1625,7 +1644,7 @@ static void knn_pass(KnnWorkspace& W, const float* xyz, size_t n, int k, const f
         const size_t n_reps = div_up(n_list, (size_t)rep_stride);
         LB.sel_bin.reserve(n_list);
         hipLaunchKernelGGL(k_knn_hist, dim3((unsigned)div_up(n_reps, kKnnHistBlock)), dim3(kKnnHistBlock), 0, s, LB.P4.p, (const unsigned*)nullptr, n_reps,
-                           LB.table.p, G, rep_target, Q4.p, LB.sel_bin.p, (unsigned)rep_stride);
+                           LB.table.p, G, rep_target, Q4.p, LB.sel_bin.p, (unsigned)rep_stride, (rep_estimate && G.S) ? rep_est_scale : 0.f);
         hipLaunchKernelGGL(kernel_of(single_variant), dim3((unsigned)div_up(n_list, kKnnBlock)), dim3(kKnnBlock), lds1, s, LB.P4.p, n, (const unsigned*)nullptr, n_list, LB.table.p, G, k, cap1,
                            viewpoint[0], viewpoint[1], viewpoint[2], Q4.p, want_normals ? d_on.p : nullptr, want_normals ? d_oc.p : nullptr,
                            knn_indices ? d_knn.p : nullptr, d_mean_out ? d_mean_out->p : nullptr, next_list, LB.counter.p + 1,
@@ -1642,7 +1661,7 @@ static void knn_pass(KnnWorkspace& W, const float* xyz, size_t n, int k, const f
       if (lsel == 3 && n_list > 0) {
         LB.sel_bin.reserve(n_list);
         hipLaunchKernelGGL(k_knn_hist, dim3((unsigned)div_up(n_list, kKnnHistBlock)), dim3(kKnnHistBlock), 0, s, LB.P4.p, todo_list, n_list,
-                           LB.table.p, G, k, Q4.p, LB.sel_bin.p, 1u);
+                           LB.table.p, G, k, Q4.p, LB.sel_bin.p, 1u, 0.f);
       }
       if (n_list > 0)
       hipLaunchKernelGGL(kernel_of(lsel), dim3(nblk), dim3(kKnnBlock), lsel == 3 ? lds : lds_list, s, LB.P4.p, n, todo_list, n_list, LB.table.p, G, k, lsel == 3 ? cap : k,

@@ -2,7 +2,7 @@
 each setting runs in its own interpreter: the certificate search of several directed pairs per host round trip against pair by
 pair or one launch per pair (E3D_ICP_BATCH = 0 / 1; default 2: one launch per kernel and batch), the certificates' motion bound per query against the clouds' global one (E3D_NN_PERQUERY), the key kernel that settles queries with an empty 27-cell block against sorting them all (E3D_NN_PRUNE), certificates tested in every outer iteration against skipped while none holds (E3D_NN_CERT_SKIP) and against no certificates at all (E3D_NN_CERT=0: every query searched in every iteration), resident against compacted correspondence rows (E3D_ICP_RESIDENT), the speculative last LM step
 (E3D_LM_SPECULATE); the kNN estimator's single scan with sampled thresholds against the two-pass kernels (E3D_KNN_SINGLE), with
-and without the lists the 125-cell pass starts from (E3D_KNN_SEED), the wave-per-query form of that pass (E3D_KNN_WIDE_WAVE)."""
+and without the lists the 125-cell pass starts from (E3D_KNN_SEED), the wave-per-query form of that pass (E3D_KNN_WIDE_WAVE), the sampled thresholds from the block population against the distance histogram, and deliberately poor ones (E3D_KNN_EST, E3D_KNN_EST_SCALE)."""
 import json
 import os
 import subprocess
@@ -94,5 +94,5 @@ def test_icp_data_flows_agree():
 def test_knn_scan_variants_agree():
     base = _run(KNN_CODE, {})
     for env in ({"E3D_KNN_SINGLE": "0"}, {"E3D_KNN_SEED": "0"}, {"E3D_KNN_WIDE_SPREAD": "1"}, {"E3D_KNN_WIDE_WAVE": "0"}, {"E3D_KNN_XCD": "0"},
-                {"E3D_KNN_REP_STRIDE": "32", "E3D_KNN_REP_AVG": "1"}):
+                {"E3D_KNN_REP_STRIDE": "32", "E3D_KNN_REP_AVG": "1"}, {"E3D_KNN_EST": "0"}, {"E3D_KNN_EST_SCALE": "0.5"}, {"E3D_KNN_EST_SCALE": "3"}):
         assert _run(KNN_CODE, env) == base, env

@@ -15,9 +15,13 @@
 #include <cfloat>
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstdio>
+#include <functional>
 #include <map>
 #include <memory>
+#include <mutex>
+#include <thread>
 
 #include "../../include/e3d_hip.h"
 #include "e3d_comm.hpp"
@@ -115,6 +119,54 @@ struct PairJob {
   long long vrows = 0;             // resident: 64 * active groups, the rows an LM pass walks
 };
 
+// The ten damped solves of an LM step (lm_compute) are independent: a few host threads per handle take them side by side once the
+// system is large enough to matter (90 unknowns: 10 x 0.09 ms one after the other).  Workers sleep between steps.
+class SolvePool {
+ public:
+  explicit SolvePool(int workers) {
+    for (int i = 0; i < workers; ++i) threads_.emplace_back([this] { run(); });
+  }
+  ~SolvePool() {
+    { std::lock_guard<std::mutex> g(m_); stop_ = true; }
+    cv_.notify_all();
+    for (auto& t : threads_) t.join();
+  }
+  // fn(i) for i in [0, n), the caller's thread included; returns when all are done
+  void parallel_for(int n, const std::function<void(int)>& fn) {
+    if (n <= 0) return;
+    { std::lock_guard<std::mutex> g(m_); fn_ = &fn; next_ = 0; n_ = n; pending_ = n; ++epoch_; }
+    cv_.notify_all();
+    work();
+    std::unique_lock<std::mutex> g(m_);
+    done_.wait(g, [this] { return pending_ == 0; });
+    fn_ = nullptr;
+  }
+ private:
+  void work() {
+    for (;;) {
+      int i;
+      const std::function<void(int)>* fn;
+      { std::lock_guard<std::mutex> g(m_); if (!fn_ || next_ >= n_) return; i = next_++; fn = fn_; }
+      (*fn)(i);
+      { std::lock_guard<std::mutex> g(m_); if (--pending_ == 0) done_.notify_all(); }
+    }
+  }
+  void run() {
+    unsigned long long seen = 0;
+    for (;;) {
+      { std::unique_lock<std::mutex> g(m_); cv_.wait(g, [&] { return stop_ || epoch_ != seen; }); if (stop_) return; seen = epoch_; }
+      work();
+    }
+  }
+  std::vector<std::thread> threads_;
+  std::mutex m_;
+  std::condition_variable cv_, done_;
+  const std::function<void(int)>* fn_ = nullptr;
+  int next_ = 0, n_ = 0, pending_ = 0;
+  unsigned long long epoch_ = 0;
+  bool stop_ = false;
+};
+
 }  // namespace e3d
 
 using namespace e3d;
@@ -161,6 +213,7 @@ struct e3d_icp {
   bool resident_rows = [] { const char* e = getenv("E3D_ICP_RESIDENT"); return !(e && e[0] == '0'); }();
   bool resident_now = false;                    // this outer iteration keeps resident rows for the pairs of the certificate path
   int lm_prev_end_step = -1;                    // LM step at which the previous outer iteration's LM ended with ten rejections (-1: none yet)
+  std::unique_ptr<SolvePool> solve_pool;        // host threads of the LM step's damped solves (systems of >= 30 unknowns)
   DevBuf<LmSet> d_sets;
   PinBuf<LmSet> h_sets;
   DevBuf<LmPose> d_poses;
@@ -1195,10 +1248,74 @@ static bool find_pairs_multi(e3d_icp* h, std::vector<BatchItem>& items, float d,
     h->tm_bounded.stop(s);
     rec.nn_bounded_launches++; rec.nn_bounded_queries += job_queries; rec.nn_kernel_launches++;
   }
+  // the far lists that are too long for the bounded search (first outer iterations): ONE key kernel, ONE sort, ONE k_nn_rows launch
+  // for the batch (round 6; E3D_NN_FAR_BATCH=0: pair by pair as in round 5).  The pair's index rides above the cell key, so the
+  // batch's keys need key_bits + log2(pairs) bits: 8-byte (key, query) pairs while that fits 32 bits.
+  static const bool far_batch = [] { const char* e = getenv("E3D_NN_FAR_BATCH"); return !(e && e[0] == '0'); }();
+  static const size_t prune_min_list = (size_t)env_double("E3D_NN_PRUNE_MIN", 262144.0);
+  size_t far_pairs = 0, far_total = 0;
+  int kb_max = 1;
+  for (size_t i = 0; i < B; ++i) if (items[i].n_far > 0) { ++far_pairs; far_total += items[i].n_far; kb_max = std::max(kb_max, items[i].tgt->key_bits); }
+  int pair_bits = 0;
+  while (((size_t)1 << pair_bits) < B) ++pair_bits;
+  // (a batch whose keys would need 12-byte pairs only because of the pair bits keeps the 8-byte pairs of the pair-by-pair path)
+  const bool far_multi = far_batch && far_pairs > 0 && (kb_max + pair_bits <= 32 || kb_max > 31) && kb_max + pair_bits <= 63;
+  if (far_multi) {
+    const bool k32 = kb_max + pair_bits <= 32;
+    unsigned key_blocks = 0;
+    for (size_t i = 0; i < B; ++i) {
+      BatchItem& it = items[i];
+      NnPairDev& P = T.pair[i];
+      P.far_n = 0; P.far_list = nullptr; P.far_flags = 0; P.occ = nullptr; P.occ_stride = 0; P.rows_off = 0; P.rows_n = 0;
+      if (it.n_far > 0) {
+        const bool prune = it.tgt->has_occ && it.ps->prune && it.n_far >= prune_min_list;       // (sort_query_keys_pruned's rule)
+        P.far_n = (unsigned)it.n_far;
+        P.far_list = it.certified ? h->slots[i]->todo_far.p : nullptr;
+        P.far_flags = ((prune && it.from_state && !it.certified) ? 1 : 0) | (prune ? 2 : 0);
+        P.occ = it.tgt->has_occ ? it.tgt->occ27.p : nullptr; P.occ_stride = it.tgt->occ_stride;
+        key_blocks += (unsigned)div_up(it.n_far, (size_t)kQueryKeysBlock);
+      }
+      T.far_end[i] = key_blocks;
+    }
+    T.key_shift = kb_max;
+    h->keys_a.reserve(far_total); h->keys_b.reserve(far_total); h->vals_a.reserve(far_total); h->vals_b.reserve(far_total);
+    h->prune_count.reserve(1 + kPairBatch); h->h_prune_count.reserve(1 + kPairBatch);
+    E3D_HIP(hipMemcpyAsync(h->d_batch.p, h->h_batch.p, sizeof(NnBatchDev), hipMemcpyHostToDevice, s));
+    h->tm_sort.start(s);
+    E3D_HIP(hipMemsetAsync(h->prune_count.p, 0, sizeof(unsigned) * (1 + B), s));
+    launch_query_keys_multi(k32, h->d_batch.p, key_blocks, radius_sq(d), h->keys_a.p, h->vals_a.p, h->prune_count.p, s);
+    copy_out(h->h_prune_count.p, h->prune_count.p, sizeof(unsigned) * (1 + B), s);
+    sync(h);
+    const size_t kept_total = h->h_prune_count.p[0];
+    unsigned row_blocks = 0, off = 0;
+    for (size_t i = 0; i < B; ++i) {
+      BatchItem& it = items[i];
+      NnPairDev& P = T.pair[i];
+      const unsigned kept = h->h_prune_count.p[1 + i];
+      if ((P.far_flags & 2) && (double)kept > 0.9 * (double)it.n_far) it.ps->prune = false;
+      P.rows_off = off; P.rows_n = kept; off += kept;
+      row_blocks += (unsigned)div_up((size_t)kept, kBlock);
+      T.rows_end[i] = row_blocks;
+      if (kept > 0) rec.nn_search_queries += (long long)kept;
+    }
+    if (kept_total > 0) {
+      if (k32) sort_pairs_u32_u32(reinterpret_cast<unsigned*>(h->keys_a.p), reinterpret_cast<unsigned*>(h->keys_b.p), h->vals_a.p, h->vals_b.p, kept_total, kb_max + pair_bits, h->sort_temp, s);
+      else sort_pairs_u64_u32(h->keys_a.p, h->keys_b.p, h->vals_a.p, h->vals_b.p, kept_total, kb_max + pair_bits, h->sort_temp, s);
+    }
+    h->tm_sort.stop(s);
+    rec.nn_kernel_launches++; rec.nn_sort_calls++;
+    E3D_HIP(hipMemcpyAsync(h->d_batch.p, h->h_batch.p, sizeof(NnBatchDev), hipMemcpyHostToDevice, s));     // (the pairs' stretches of the sorted array)
+    if (kept_total > 0) {
+      h->tm_search.start(s);
+      launch_nn_rows_multi(h->d_batch.p, row_blocks, h->vals_b.p, radius_sq(d), s);
+      h->tm_search.stop(s);
+      rec.nn_search_launches++; rec.nn_kernel_launches++;
+    }
+  }
   for (size_t i = 0; i < B; ++i) {
     BatchItem& it = items[i];
     PairState& ps = *it.ps;
-    if (it.n_far > 0) {
+    if (it.n_far > 0 && !far_multi) {
       e3d_icp::PairSlot& sl = *h->slots[i];
       const float4* srcG = it.src->G4.p + it.j0;
       const size_t n_rows = sort_query_keys_pruned(h, ps, *it.tgt, srcG, it.certified ? sl.todo_far.p : nullptr, it.n_far, it.im, radius_sq(d), it.cert, sl.match_d2.p, it.from_state);
@@ -1458,21 +1575,26 @@ static void lm_prepare(e3d_icp* h, LmSystem& L, std::vector<PairJob>& jobs, int 
 // PointToPlaneICPImpl::compute  (icp_point_to_plane_impl.h:115-293)
 static void lm_compute(e3d_icp* h, LmSystem& L, std::vector<SE3f>& poses, e3d_icp_iter_record& rec) {
   const int nv = L.nv;
-  std::vector<double> H, b, Hn, bn, Hl((size_t)nv * nv), x(nv), W;
-  std::vector<int> perm;
+  std::vector<double> H, b, Hn, bn;
   double cost = 0, new_cost = 0;
   double lambda = 0.1;
   lm_evaluate(h, L, poses, true, H, b, cost, rec);
   rec.initial_cost = cost;
   rec.final_cost = cost;
-  auto candidate = [&](double lam, std::vector<SE3f>& out) {
-    Hl = H;
-    for (int i = 0; i < nv; ++i) Hl[(size_t)i * nv + i] += lam;            // additive damping (impl.h:223)
-    if (nv > 0) ldlt_solve_upper(Hl.data(), nv, b.data(), x.data(), W, perm);
+  struct SolveScratch { std::vector<double> Hl, x, W; std::vector<int> perm; };
+  std::vector<SolveScratch> scratch(10);
+  auto candidate = [&](double lam, std::vector<SE3f>& out, SolveScratch& sc) {
+    sc.Hl = H;
+    sc.x.resize((size_t)std::max(nv, 1));
+    for (int i = 0; i < nv; ++i) sc.Hl[(size_t)i * nv + i] += lam;         // additive damping (impl.h:223)
+    if (nv > 0) ldlt_solve_upper(sc.Hl.data(), nv, b.data(), sc.x.data(), sc.W, sc.perm);
     out.resize(poses.size());
     out[0] = poses[0];
-    for (size_t ci = 1; ci < poses.size(); ++ci) out[ci] = se3_apply_update(&x[6 * (ci - 1)], poses[ci]);   // impl.h:235
+    for (size_t ci = 1; ci < poses.size(); ++ci) out[ci] = se3_apply_update(&sc.x[6 * (ci - 1)], poses[ci]);   // impl.h:235
   };
+  // the tries' solves side by side on the handle's host threads when the system is large (E3D_LM_SOLVE_THREADS: 0 = on the caller's)
+  static const int solve_threads = [] { const char* e = getenv("E3D_LM_SOLVE_THREADS"); return e ? atoi(e) : 4; }();
+  if (nv >= 30 && solve_threads > 0 && !h->solve_pool) h->solve_pool.reset(new SolvePool(std::min(solve_threads, 9)));
   // Candidate poses are compared as f32 bit patterns: a pass at a pose that was already evaluated returns the cost it returned
   // then, bit for bit (same rows, same per-correspondence f32 code, same reduction tree), so it need not run.  At the end of an
   // outer iteration the update x is so small that exp(-x).cast<float>() * pose rounds back to the pose for most of the ten
@@ -1487,10 +1609,17 @@ static void lm_compute(e3d_icp* h, LmSystem& L, std::vector<SE3f>& poses, e3d_ic
   // (one new pose: the plain cost pass); a try whose poses equal the current ones costs `cost`.
   std::vector<std::vector<SE3f>> cand(10);
   std::vector<double> lam(10), costs(10);
-  auto tries_from = [&](int first, double lam_first) {
+  // lam[first..9] from lam_first; the poses of tries [first, last); returns lambda after ten rejections
+  auto tries_from = [&](int first, int last, double lam_first) {
     double l = lam_first;
-    for (int k = first; k < 10; ++k) { lam[k] = l; candidate(l, cand[k]); l = 2.f * l; }
-    return l;                                              // lambda after ten rejections
+    for (int k = first; k < 10; ++k) { lam[k] = l; l = 2.f * l; }
+    if (h->solve_pool && nv >= 30 && last - first > 1) {
+      const std::function<void(int)> one = [&](int i) { candidate(lam[first + i], cand[first + i], scratch[first + i]); };
+      h->solve_pool->parallel_for(last - first, one);
+    } else {
+      for (int k = first; k < last; ++k) candidate(lam[k], cand[k], scratch[0]);
+    }
+    return l;
   };
   auto evaluate_tries = [&](int first) {
     std::vector<std::vector<SE3f>> distinct;
@@ -1524,11 +1653,11 @@ static void lm_compute(e3d_icp* h, LmSystem& L, std::vector<SE3f>& poses, e3d_ic
     int hit = -1;
     double lam_end = lambda;
     if (batch_all) {
-      lam_end = tries_from(0, lambda);
+      lam_end = tries_from(0, 10, lambda);
       evaluate_tries(0);
       for (int k = 0; k < 10; ++k) if (costs[k] < cost) { hit = k; break; }
     } else {
-      lam_end = tries_from(0, lambda);                     // (only try 0 is needed yet; the other nine are small host solves)
+      lam_end = tries_from(0, 1, lambda);                  // only try 0 is needed yet: the other nine are solved if it is rejected
       if (same_poses(cand[0], poses)) { new_cost = cost; rec.lm_passes_skipped++; }
       else lm_evaluate(h, L, cand[0], true, Hn, bn, new_cost, rec);
       if (new_cost < cost) {
@@ -1536,6 +1665,7 @@ static void lm_compute(e3d_icp* h, LmSystem& L, std::vector<SE3f>& poses, e3d_ic
         lambda = 0.5f * lambda;
         applied = true;
       } else {
+        tries_from(1, 10, lam[1]);
         evaluate_tries(1);
         for (int k = 1; k < 10; ++k) if (costs[k] < cost) { hit = k; break; }
       }

@@ -470,17 +470,22 @@ __global__ __launch_bounds__(kBlock) void k_occ_dilate(const unsigned* __restric
 // the kept pairs depends on the order in which blocks reach the counter; the radix sort orders them by key and k_nn_rows treats
 // every query on its own, so results do not.  count[0] = number of pairs written.
 constexpr int kPrunePerThread = 8, kPruneBlock = kBlock * kPrunePerThread;
+static_assert((unsigned)kPruneBlock == kQueryKeysBlock, "queries per block of the key kernels");
+// prune == false (a pair whose far list has stopped being mostly empty blocks, sort_query_keys_pruned): every listed query is keyed,
+// none is settled -- what k_query_keys32_list does.  key_or / key_mask: the batch's key kernel puts the pair's index above the cell
+// key (one sort for the far lists of a whole batch of pairs); count2: that pair's own counter.
 template <typename KeyT>
-__global__ __launch_bounds__(kBlock) void k_query_keys_prune(const float4* __restrict__ Gsrc, const unsigned* __restrict__ list, size_t n,
-                                                             const unsigned* __restrict__ occ, unsigned stride_w, GridDesc g, InvMap im,
-                                                             QueryRange qr, float r2, CertParams cert, KeyT* __restrict__ keys,
-                                                             unsigned* __restrict__ vals, unsigned* __restrict__ count,
-                                                             int* __restrict__ match, int* __restrict__ match2,
-                                                             float* __restrict__ match_d2, float* __restrict__ lbe, int from_state) {
+__device__ __forceinline__ void query_keys_prune_body(const unsigned bx, const float4* __restrict__ Gsrc, const unsigned* __restrict__ list, size_t n,
+                                                      const unsigned* __restrict__ occ, unsigned stride_w, const GridDesc& g, const InvMap& im,
+                                                      const QueryRange& qr, float r2, const CertParams& cert, KeyT* __restrict__ keys,
+                                                      unsigned* __restrict__ vals, unsigned* __restrict__ count, unsigned* __restrict__ count2,
+                                                      const KeyT key_mask, const KeyT key_or, const bool prune,
+                                                      int* __restrict__ match, int* __restrict__ match2,
+                                                      float* __restrict__ match_d2, float* __restrict__ lbe, int from_state) {
   __shared__ unsigned s_cnt[kBlock / kWave][kPrunePerThread];
   __shared__ unsigned s_base;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const size_t i0 = (size_t)blockIdx.x * kPruneBlock + (size_t)w * kWave + (size_t)lane;      // step u: + u * kBlock
+  const size_t i0 = (size_t)bx * kPruneBlock + (size_t)w * kWave + (size_t)lane;      // step u: + u * kBlock
   KeyT kk[kPrunePerThread];
   unsigned vv[kPrunePerThread];
   unsigned long long keep_mask[kPrunePerThread];       // wave-uniform ballots
@@ -503,9 +508,9 @@ __global__ __launch_bounds__(kBlock) void k_query_keys_prune(const float4* __res
     int cx = 0, cy = 0, cz = 0;
     bdist[u] = 2.0f;
     const unsigned long long key = query_cell_key(qq[u], im, g, qr, cx, cy, cz, &bdist[u]);
-    kk[u] = (KeyT)key;
+    kk[u] = ((KeyT)key & key_mask) | key_or;
     wordv[u] = 0u; bitv[u] = -1;
-    if (key != kEmptyKey) {
+    if (prune && key != kEmptyKey) {
       const int kx = cx - qr.lo[0], ky = cy - qr.lo[1], kz = cz - qr.lo[2];
       wordv[u] = occ[((size_t)kz * qr.D[1] + (size_t)ky) * stride_w + (size_t)(kx >> 5)];
       bitv[u] = kx & 31;
@@ -517,7 +522,7 @@ __global__ __launch_bounds__(kBlock) void k_query_keys_prune(const float4* __res
   for (int u = 0; u < kPrunePerThread; ++u) {
     const size_t i = i0 + (size_t)u * kBlock;
     const bool valid = i < n;
-    const bool keep = valid && bitv[u] >= 0 && ((wordv[u] >> bitv[u]) & 1u);
+    const bool keep = valid && (!prune || (bitv[u] >= 0 && ((wordv[u] >> bitv[u]) & 1u)));
     const unsigned j = jf[u] & kListIndexMask;
     vv[u] = jf[u];
     if (valid && from_state && (jf[u] & kListNoPartner)) match_d2[j] = r2;
@@ -539,6 +544,7 @@ __global__ __launch_bounds__(kBlock) void k_query_keys_prune(const float4* __res
     for (int ww = 0; ww < kBlock / kWave; ++ww)
       for (int u = 0; u < kPrunePerThread; ++u) tot += s_cnt[ww][u];
     s_base = tot ? atomicAdd(count, tot) : 0u;
+    if (count2 && tot) atomicAdd(count2, tot);
   }
   __syncthreads();
   unsigned off = s_base;
@@ -554,6 +560,17 @@ __global__ __launch_bounds__(kBlock) void k_query_keys_prune(const float4* __res
     }
     off += (unsigned)__popcll(keep_mask[u]);
   }
+}
+
+template <typename KeyT>
+__global__ __launch_bounds__(kBlock) void k_query_keys_prune(const float4* __restrict__ Gsrc, const unsigned* __restrict__ list, size_t n,
+                                                             const unsigned* __restrict__ occ, unsigned stride_w, GridDesc g, InvMap im,
+                                                             QueryRange qr, float r2, CertParams cert, KeyT* __restrict__ keys,
+                                                             unsigned* __restrict__ vals, unsigned* __restrict__ count,
+                                                             int* __restrict__ match, int* __restrict__ match2,
+                                                             float* __restrict__ match_d2, float* __restrict__ lbe, int from_state) {
+  query_keys_prune_body<KeyT>(blockIdx.x, Gsrc, list, n, occ, stride_w, g, im, qr, r2, cert, keys, vals, count, nullptr, (KeyT)~(KeyT)0, (KeyT)0, true,
+                              match, match2, match_d2, lbe, from_state);
 }
 
 
@@ -817,16 +834,16 @@ __device__ __forceinline__ void row_scan_exact(const RowLds& L, int sl, int slic
 // Results are written at the query's SOURCE position order[pos] (the queries may be a sorted sub-list of the source cloud):
 // match_pos / match_d2 as before, and lbe = (distance every target point other than the partner exceeds) + cert.cum_lo, the
 // state k_nn_certify tests in the following outer iterations.
-__global__ __launch_bounds__(kBlock, 6) void k_nn_rows(const float4* __restrict__ Gsrc, const unsigned* __restrict__ order,
-                                                       size_t n, const float4* __restrict__ Gtgt,
-                                                       const unsigned* __restrict__ S, GridDesc g, InvMap im,
-                                                       QueryRange qr, float r2, int row_span, CertParams cert,
-                                                       int* __restrict__ match_pos, float* __restrict__ match_d2,
-                                                       float* __restrict__ lbe, int* __restrict__ match2) {
+__device__ __forceinline__ void nn_rows_body(const unsigned bx, const float4* __restrict__ Gsrc, const unsigned* __restrict__ order,
+                                             size_t n, const float4* __restrict__ Gtgt,
+                                             const unsigned* __restrict__ S, const GridDesc& g, const InvMap& im,
+                                             const QueryRange& qr, float r2, int row_span, const CertParams& cert,
+                                             int* __restrict__ match_pos, float* __restrict__ match_d2,
+                                             float* __restrict__ lbe, int* __restrict__ match2) {
   __shared__ RowLds lds[kBlock / kWave];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   RowLds& L = lds[w];
-  const size_t pos = ((size_t)blockIdx.x * (kBlock / kWave) + w) * kWave + lane;
+  const size_t pos = ((size_t)bx * (kBlock / kWave) + w) * kWave + lane;
   const bool valid = pos < n;
   const unsigned jf = valid ? order[pos] : 0u, j = jf & kListIndexMask;
   const float4 q = valid ? Gsrc[j] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -990,6 +1007,15 @@ __global__ __launch_bounds__(kBlock, 6) void k_nn_rows(const float4* __restrict_
     const float lb_out = block_dist * cert.cell_scale - cert.cell_sub;
     lbe[j] = fmaxf(fminf(sqrtf(best_b2), lb_out), 0.0f) * 0.999999f + motion_lo(q, cert.lo);
   }
+}
+
+__global__ __launch_bounds__(kBlock, 6) void k_nn_rows(const float4* __restrict__ Gsrc, const unsigned* __restrict__ order,
+                                                       size_t n, const float4* __restrict__ Gtgt,
+                                                       const unsigned* __restrict__ S, GridDesc g, InvMap im,
+                                                       QueryRange qr, float r2, int row_span, CertParams cert,
+                                                       int* __restrict__ match_pos, float* __restrict__ match_d2,
+                                                       float* __restrict__ lbe, int* __restrict__ match2) {
+  nn_rows_body(blockIdx.x, Gsrc, order, n, Gtgt, S, g, im, qr, r2, row_span, cert, match_pos, match_d2, lbe, match2);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -1813,6 +1839,37 @@ __global__ __launch_bounds__(kBlock) void k_nn_bounded_half_multi(const NnBatchD
   const GridDesc g = P.g; const InvMap im = P.im; const QueryRange qr = P.qr; const BoundParams bp = P.bp;      // (block-uniform: scalar registers)
   nn_bounded_half_body<8>(bx, P.Gsrc, B->job_list[jb], B->job_n[jb], P.Gtgt, P.S, P.H8, g, im, qr, r2, bp, P.match, P.match2,
                           P.match_d2, P.lbe);
+}
+
+// The FAR lists of a batch of pairs (round 6): queries without a near partner, too many for the bounded search -- the first outer
+// iterations of every pair.  Round 5 keyed, sorted and searched them pair by pair: per pair a key kernel, a read-back of the kept
+// count, a radix sort (six launches) and k_nn_rows -- 240 times per outer iteration of a 16-scan job, ~0.3 ms each however short a
+// rank's slices are.  Now ONE key kernel walks the pairs' lists (a block finds its pair from the ends of the block ranges) and
+// writes (key, query) pairs of all of them into one array, the pair's index above the cell key; ONE radix sort orders them by
+// (pair, cell); ONE k_nn_rows launch walks the pairs' stretches of the sorted array.  The bodies are the one-pair kernels': the same
+// results bit for bit (a query's result does not depend on its neighbours in the sorted order).
+template <typename KeyT>
+__global__ __launch_bounds__(kBlock) void k_query_keys_multi(const NnBatchDev* __restrict__ B, float r2, KeyT* __restrict__ keys, unsigned* __restrict__ vals,
+                                                             unsigned* __restrict__ counts) {
+  const int p = nn_find_range(B->far_end, B->n_pairs, blockIdx.x);
+  const unsigned bx = blockIdx.x - (p ? B->far_end[p - 1] : 0u);
+  const NnPairDev& P = B->pair[p];
+  const GridDesc g = P.g; const InvMap im = P.im; const QueryRange qr = P.qr;
+  const CertParams cert = {P.bp.cell_scale, P.bp.cell_sub, P.bp.lo};
+  const int shift = B->key_shift;
+  const KeyT mask = (KeyT)(((KeyT)1 << shift) - (KeyT)1), hi = (KeyT)((KeyT)p << shift);
+  const int flags = __builtin_amdgcn_readfirstlane(P.far_flags);
+  query_keys_prune_body<KeyT>(bx, P.Gsrc, P.far_list, (size_t)P.far_n, P.occ, P.occ_stride, g, im, qr, r2, cert, keys, vals, counts, counts + 1 + p, mask, hi,
+                              (flags & 2) != 0, P.match, P.match2, P.match_d2, P.lbe, flags & 1);
+}
+
+__global__ __launch_bounds__(kBlock, 6) void k_nn_rows_multi(const NnBatchDev* __restrict__ B, const unsigned* __restrict__ order, float r2, int row_span) {
+  const int p = nn_find_range(B->rows_end, B->n_pairs, blockIdx.x);
+  const unsigned bx = blockIdx.x - (p ? B->rows_end[p - 1] : 0u);
+  const NnPairDev& P = B->pair[p];
+  const GridDesc g = P.g; const InvMap im = P.im; const QueryRange qr = P.qr;
+  const CertParams cert = {P.bp.cell_scale, P.bp.cell_sub, P.bp.lo};
+  nn_rows_body(bx, P.Gsrc, order + P.rows_off, (size_t)P.rows_n, P.Gtgt, P.S, g, im, qr, r2, row_span, cert, P.match, P.match_d2, P.lbe, P.match2);
 }
 
 // flags -> per-block counts (first stage of the order-preserving compaction)
@@ -2960,6 +3017,15 @@ void launch_nn_certify_multi(const NnBatchDev* batch, unsigned n_blocks, float r
 void launch_nn_bounded_half_multi(const NnBatchDev* batch, unsigned n_blocks, float r2, hipStream_t s) {
   if (!n_blocks) return;
   hipLaunchKernelGGL(k_nn_bounded_half_multi, dim3(n_blocks), dim3(kBlock), 0, s, batch, r2);
+}
+void launch_query_keys_multi(bool keys32, const NnBatchDev* batch, unsigned n_blocks, float r2, void* keys, unsigned* vals, unsigned* counts, hipStream_t s) {
+  if (!n_blocks) return;
+  if (keys32) hipLaunchKernelGGL(k_query_keys_multi<unsigned>, dim3(n_blocks), dim3(kBlock), 0, s, batch, r2, (unsigned*)keys, vals, counts);
+  else hipLaunchKernelGGL(k_query_keys_multi<unsigned long long>, dim3(n_blocks), dim3(kBlock), 0, s, batch, r2, (unsigned long long*)keys, vals, counts);
+}
+void launch_nn_rows_multi(const NnBatchDev* batch, unsigned n_blocks, const unsigned* order, float r2, hipStream_t s) {
+  if (!n_blocks) return;
+  hipLaunchKernelGGL(k_nn_rows_multi, dim3(n_blocks), dim3(kBlock), 0, s, batch, order, r2, row_span_setting());
 }
 void launch_corr_update_multi(const NnBatchDev* batch, unsigned n_blocks, unsigned* block_counts, double* block_d2, unsigned* block_groups, hipStream_t s) {
   if (!n_blocks) return;

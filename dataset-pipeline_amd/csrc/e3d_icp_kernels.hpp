@@ -150,9 +150,19 @@ struct NnPairDev {
   float4 *A, *B, *C;
   int* plane_match;
   unsigned* glist;
+  // far list of this search (k_query_keys_multi, k_nn_rows_multi; round 6)
+  const unsigned* far_list;        // the listed queries (nullptr: all far_n queries of the pair)
+  const unsigned* occ;             // target's occupancy bits of the 27-cell blocks
+  unsigned far_n, occ_stride;
+  int far_flags;                   // bit 0: flags "had no partner" come from the state (list == nullptr), bit 1: settle the queries of empty blocks
+  unsigned rows_off, rows_n;       // the pair's stretch of the batch's sorted (key, query) array
 };
+constexpr unsigned kQueryKeysBlock = 2048;   // queries per block of the compacting key kernels
 struct NnBatchDev {
   int n_pairs, n_jobs;
+  int key_shift;                       // bits of the cell keys in the batch's sort keys; the pair's index sits above them
+  unsigned far_end[kNnBatchPairs];     // exclusive ends of the pairs' block ranges in the far lists' key kernel
+  unsigned rows_end[kNnBatchPairs];    // ... in k_nn_rows_multi
   unsigned cert_end[kNnBatchPairs];    // exclusive ends of the pairs' block ranges in the certificate launch
   unsigned upd_end[kNnBatchPairs];     // ... in the row update = of their entries in the per-block result arrays
   unsigned chunk_end[kNnBatchPairs];   // ... of their 256-block chunks in the totals
@@ -164,6 +174,9 @@ struct NnBatchDev {
 };
 void launch_nn_certify_multi(const NnBatchDev* batch, unsigned n_blocks, float r2, hipStream_t s);
 void launch_nn_bounded_half_multi(const NnBatchDev* batch, unsigned n_blocks, float r2, hipStream_t s);
+// far lists of a batch: counts[0] = (key, query) pairs written by all pairs, counts[1 + p] = by pair p (cleared by the caller)
+void launch_query_keys_multi(bool keys32, const NnBatchDev* batch, unsigned n_blocks, float r2, void* keys, unsigned* vals, unsigned* counts, hipStream_t s);
+void launch_nn_rows_multi(const NnBatchDev* batch, unsigned n_blocks, const unsigned* order, float r2, hipStream_t s);
 void launch_corr_update_multi(const NnBatchDev* batch, unsigned n_blocks, unsigned* block_counts, double* block_d2, unsigned* block_groups, hipStream_t s);
 // totals[3 p ..] = correspondences, active groups, rows rewritten of pair p; total_d2[p]; the pairs' group lists (three launches)
 void launch_corr_totals_multi(const NnBatchDev* batch, int n_pairs, unsigned n_chunks, const unsigned* block_counts, const double* block_d2,

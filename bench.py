@@ -105,8 +105,8 @@ def cpu_baseline_icp(scans, d, thr, slab, n_points, poses=None, first_iteration=
 
     recs, times = run(False)
     med = int(np.argsort(times)[1])
-    # the same sample with the NN phase spread over every host core (queries are independent; results and their
-    # order are unchanged); the inner LM stays on one thread as in the reference
+    # the same sample with every phase on every host core -- kd-tree builds, queries (independent; results and their
+    # order unchanged) and the reductions of the LM passes (oracle_icp.c: accumulate_pass_par / cost_pass_par)
     recs2, times2 = run(True)
     med2 = int(np.argsort(times2)[1])
     frac = float(n[0] + n[1]) / float(2 * n_points)
@@ -123,8 +123,52 @@ def cpu_baseline_icp(scans, d, thr, slab, n_points, poses=None, first_iteration=
         "all_core": {"value": recs2[med2]["correspondences"] / times2[med2], "unit": "correspondences/s", "cores": os.cpu_count(),
                      "ms_per_iter": times2[med2] * 1e3, "t_nn_s": recs2[med2]["t_nn_s"], "t_lm_s": recs2[med2]["t_lm_s"],
                      "same_correspondences": bool([r["correspondences"] for r in recs2] == [r["correspondences"] for r in recs]),
-                     "note": "NN queries on all host cores (OpenMP), inner LM single-threaded; same slab and iterations"},
+                     "note": "SURVEY 8(d)(ii): kd-tree builds (OpenMP tasks), NN queries and both LM passes (per-thread H / b / cost partials added in thread order) on all host cores; "
+                             "same slab and iterations; the sums' order differs from the sequential pass, so counts may differ in the last digits"},
     }
+
+
+def candidates_per_query(scans, poses, cell, device, n_sample=200_000):
+    """What an exact search of one query has to look at: the target points in the 27 cells (cell = the search radius, as the
+    library's grids) around a query of scan 0, scans at the given global_T_cloud.  Sampled queries, torch on the GPU; the library's
+    grid has the same cell size in the target's local frame (another origin: the same statistics, not the same cells)."""
+    import torch
+
+    def to_global(x, T):
+        T = np.asarray(T, np.float64)
+        return torch.stack([x[:, 0] * float(T[r, 0]) + x[:, 1] * float(T[r, 1]) + x[:, 2] * float(T[r, 2]) + float(T[r, 3]) for r in range(3)], 1)
+    n = scans[0]["xyz"].shape[0]
+    g = torch.Generator(device=device); g.manual_seed(7)
+    sample = torch.randint(0, n, (min(n_sample, n),), generator=g, device=device)
+    gs = to_global(scans[0]["xyz"][sample].to(torch.float64), poses[0])
+    gt = to_global(scans[1]["xyz"].to(torch.float64), poses[1])
+    origin = gt.min(0).values - 2.0 * cell
+    ct = ((gt - origin) / cell).floor().to(torch.int64)
+    D = ct.max(0).values + 4
+    uk, cnt = torch.unique((ct[:, 2] * D[1] + ct[:, 1]) * D[0] + ct[:, 0], return_counts=True)
+    del gt, ct
+    cs = ((gs - origin) / cell).floor().to(torch.int64)
+    ok = ((cs >= 1) & (cs < D - 1)).all(1)
+    tot = torch.zeros(len(sample), dtype=torch.int64, device=device)
+    own = torch.zeros_like(tot)
+    for dz in (-1, 0, 1):
+        for dy in (-1, 0, 1):
+            for dx in (-1, 0, 1):
+                k = ((cs[:, 2] + dz) * D[1] + cs[:, 1] + dy) * D[0] + cs[:, 0] + dx
+                pos = torch.searchsorted(uk, k).clamp_(max=len(uk) - 1)
+                c = torch.where(ok & (uk[pos] == k), cnt[pos], torch.zeros_like(tot))
+                tot += c
+                if dx == 0 and dy == 0 and dz == 0:
+                    own = c
+    has = tot > 0
+    t = tot[has].to(torch.float64)
+    q = lambda v, f: float(torch.quantile(v, f)) if len(v) else 0.0
+    return {"sampled_queries": int(len(sample)), "with_candidates_fraction": float(has.double().mean()), "mean": float(t.mean()) if len(t) else 0.0,
+            "median": q(t, 0.5), "p99": q(t, 0.99), "max": float(t.max()) if len(t) else 0.0,
+            "target_points_per_occupied_cell_mean": float(cnt.double().mean()), "target_points_per_cell_max": int(cnt.max()),
+            "own_cell_max": int(own.max()), "cell_m": cell,
+            "note": "target points in the 27 cells around a query (queries with at least one): what k_nn_rows evaluates per query is the "
+                    "union of its wave segment's rows, a superset of this"}
 
 
 def sum_records(recs):
@@ -262,6 +306,7 @@ def step_breakdown(r):
             "t_lm_kernel_ms", "t_lm_full_kernel_ms")
     out = {k[2:]: r[k] for k in keys}
     out["kernels_sum_ms"] = sum(r[k] for k in keys if k != "t_lm_full_kernel_ms")
+    out["nn_phase_ms"], out["lm_phase_ms"] = r.get("t_nn_ms"), r.get("t_lm_ms")      # events around the phases: kernels + host work in between
     out.update({"wall_ms": r.get("wall_ms"), "full_passes": r["full_passes"], "cost_passes": r["cost_passes"], "multi_cost_passes": r["multi_cost_passes"],
                 "multi_cost_poses": r["multi_cost_poses"], "inner_iterations": r["inner_iterations"], "rows_rewritten": r["corr_rows_rewritten"]})
     return out
@@ -343,18 +388,23 @@ def icp_kernel_table(tot, world, K, pairs, moved_points, lm_kernel_name="k_lm_pa
                                     rows_rewritten=rows_rewritten, rows_walked=rows_walked)
 
 
-def leg_terrace(e3d, synth, R, args, dev, partial=False):
+def leg_terrace(e3d, synth, R, args, dev, partial=False, variant=None):
     """configs[1]: 2 scans, both movable; N > 1: weak scaling on a stretched room (same point density).
-    partial=True: the same job on the partial-overlap room (30 - 60 % of the points find a partner)."""
+    partial=True: the same job on the partial-overlap room (30 - 60 % of the points find a partner).
+    variant "regression": the headline job from round 4's start (--perturb 1.0: 1 degree, 2.4 cm; converges in iteration 18) -- the
+    number that stays comparable from round to round; "scanner": both scans as a terrestrial scanner records them (density
+    ~ cos / range^2, points in scan order: synth.make_scan_angular) from the headline's start."""
     import torch
     world = R.world
-    n_points = args.points if args.points > 0 else 50_000_000 * (1 if partial else world)
+    secondary = partial or variant is not None
+    perturb = 1.0 if variant == "regression" else args.perturb
+    n_points = args.points if args.points > 0 else 50_000_000 * (1 if secondary else world)
     d, thr = float(args.distance), 1e-10     # README.md:101 recommended flags (--convergence_threshold 1e-10)
-    room_scale = float(np.sqrt(n_points / 50_000_000.0)) if (world > 1 and args.points == 0 and not partial) else 1.0
-    scans = synth.make_scene(2, n_points, seed=1234, sigma=0.002, device=dev, room_scale=room_scale, partial=partial, perturb=args.perturb)
+    room_scale = float(np.sqrt(n_points / 50_000_000.0)) if (world > 1 and args.points == 0 and not secondary) else 1.0
+    scans = synth.make_scene(2, n_points, seed=1234, sigma=0.002, device=dev, room_scale=room_scale, partial=partial, perturb=perturb, scanner=(variant == "scanner"))
     torch.cuda.synchronize()
     whole = None
-    if world == 1 and not partial and not args.no_whole_run:
+    if world == 1 and not secondary and not args.no_whole_run:
         whole = whole_run(e3d, scans, d, thr, R.local_rank)
     icp = e3d.PointToPlaneICP(device=R.local_rank)
     for s in scans:
@@ -366,8 +416,12 @@ def leg_terrace(e3d, synth, R, args, dev, partial=False):
         if icp.run(d, it, 1, thr, False):
             warm_conv = it
             break
+    cand = None
+    if world == 1 and (variant == "scanner" or not secondary):
+        cand = candidates_per_query(scans, [icp.get_result_global_T_cloud(i) for i in range(2)], d, dev)
+        torch.cuda.empty_cache()
     base = None
-    if R.rank == 0 and world == 1 and not args.no_cpu_baseline and not partial:
+    if R.rank == 0 and world == 1 and not args.no_cpu_baseline and not secondary:
         # slab width chosen for ~4 M points per scan at this density (floor + two walls = 16 m^2 per metre of x); started from the
         # poses the GPU run has reached after its warm-up, so both sides are timed in the same regime
         width = min(10.0, 4.0e6 / (n_points / 242.6 * 16.0))
@@ -384,7 +438,7 @@ def leg_terrace(e3d, synth, R, args, dev, partial=False):
     corr, queries, lm_ms, nn_ms, passes = m["corr"], m["queries"], m["lm_ms"], m["nn_ms"], m["passes"]
     rows_rewritten, rows_walked = m["rows_rewritten"], m["rows_walked"]
     dom = max(("k_lm_pass", "k_lm_cost_multi", "k_nn_certify", "k_nn_bounded", "k_nn_rows", "k_corr_update"), key=lambda k: kernels[k]["summed_ms_per_iter"] or 0.0)
-    traffic, traffic_src = load_traffic({"k_lm_pass": "k_lm_pass<1>"}.get(dom, dom)) if (world == 1 and n_points == 50_000_000 and not partial) else (None, None)
+    traffic, traffic_src = load_traffic({"k_lm_pass": "k_lm_pass<1>"}.get(dom, dom)) if (world == 1 and n_points == 50_000_000 and not secondary) else (None, None)
     ach = kernels[dom]["GBs"] or 0.0
     # settling / steady split: the first timed steps still re-search most queries (the poses move); "steady" = the steps whose NN
     # kernels cost at most 1.25 x the last step's
@@ -398,8 +452,10 @@ def leg_terrace(e3d, synth, R, args, dev, partial=False):
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 (f64 accumulation)",
         "data": "synthetic (no terrace scans in this image: seeded room scans of the configs[1] shape, generated in HBM)",
         "config": {"workload": "ICPScanAligner 2 scans (BASELINE.json configs[1]), -d %g, one outer iteration per step%s" %
-                               (d, "; PARTIAL-OVERLAP room (partition wall, occlusion, 6.5 m range): %.0f %% of the queries find a partner" % (100.0 * corr / max(queries, 1)) if partial else ""),
-                   "points_per_scan": n_points, "scans": 2, "directed_pairs": 2, "room_scale": room_scale, "initial_misalignment_scale": args.perturb,
+                               (d, "; PARTIAL-OVERLAP room (partition wall, occlusion, 6.5 m range): %.0f %% of the queries find a partner" % (100.0 * corr / max(queries, 1)) if partial else
+                                   "; SCANNER-SAMPLED scans (rays uniform in angle: density ~ cos / range^2, points in scan order)" if variant == "scanner" else
+                                   "; REGRESSION scene (round 4's start: 1 degree, 2.4 cm)" if variant == "regression" else ""),
+                   "points_per_scan": n_points, "scans": 2, "directed_pairs": 2, "room_scale": room_scale, "initial_misalignment_scale": perturb,
                    "matched_fraction": corr / max(queries, 1),
                    "parallelism": "dp%d over source-point slices, RCCL all-reduce of the 6x6 normal-equation blocks" % world},
         "ms_per_iter": dt / K * 1e3, "nn_queries_per_s": queries / dt, "lm_passes_per_iter": passes / K,
@@ -425,6 +481,8 @@ def leg_terrace(e3d, synth, R, args, dev, partial=False):
         out["per_rank_rank0"] = per_rank
     if R.comm:
         out["comm"] = comm_report(R, K, per_rank)
+    if cand is not None:
+        out["candidates_per_query"] = cand
     if whole is not None:
         out["whole_run"] = whole
     if base is not None:
@@ -540,6 +598,8 @@ def leg_allpairs(e3d, synth, R, args, dev):
                               "poses_equal_single_gpu_run": bool(same),
                               "last_iteration_as_rank0": step_breakdown(dict(rec8[-1], wall_ms=each8[-1])),
                               "last_iteration_n1": step_breakdown(recs[-1]),
+                              "iterations_as_rank0": [step_breakdown(dict(r, wall_ms=w)) for r, w in zip(rec8, each8)],
+                              "iterations_n1": [step_breakdown(r) for r in recs],
                               "nn_kernel_launches_per_iter_as_rank0": float(np.mean([r["nn_kernel_launches"] for r in rec8])),
                               "note": "rank 0 of a world of %d on this GPU, fed the recorded reductions of the single-GPU run (same decisions, same poses): "
                                       "an upper bound of the speed-up (no collective time, no skew between ranks)" % W8}
@@ -801,6 +861,9 @@ def main():
     ap.add_argument("--no-allpairs", action="store_true", help="skip the all-pairs scaling leg")
     ap.add_argument("--no-partial", action="store_true", help="skip the partial-overlap ICP leg (N = 1 only)")
     ap.add_argument("--partial-only", action="store_true", help="profiling: the headline leg itself on the partial-overlap room (N = 1)")
+    ap.add_argument("--no-regression", action="store_true", help="skip the regression leg (round 4's scene; N = 1 only)")
+    ap.add_argument("--no-scanner", action="store_true", help="skip the scanner-sampled ICP leg (N = 1 only)")
+    ap.add_argument("--variant-only", choices=["regression", "scanner"], default=None, help="profiling: one of the headline's variant legs alone (N = 1)")
     ap.add_argument("--only", choices=["reg", "normals", "allpairs"], default=None,
                     help="profiling / development: run one of the secondary legs alone and print its JSON (N = 1; allpairs also N > 1)")
     ap.add_argument("--allpairs-scans", type=int, default=16)
@@ -848,7 +911,16 @@ def main():
             print(json.dumps(leg_terrace(e3d, synth, R, args, dev, partial=True)))
         R.close()
         return
+    if args.variant_only and world == 1:
+        if rank == 0:
+            print(json.dumps(leg_terrace(e3d, synth, R, args, dev, variant=args.variant_only)))
+        R.close()
+        return
     out = leg_terrace(e3d, synth, R, args, dev)
+    if world == 1 and not args.no_regression:
+        out["regression"] = leg_terrace(e3d, synth, R, args, dev, variant="regression")
+    if world == 1 and not args.no_scanner:
+        out["scanner_sampled"] = leg_terrace(e3d, synth, R, args, dev, variant="scanner")
     if world == 1 and not args.no_partial:
         out["partial_overlap"] = leg_terrace(e3d, synth, R, args, dev, partial=True)
     if not args.no_allpairs:
@@ -928,6 +1000,18 @@ def compact_line(d, detail_path="bench_detail.json"):
         legs["partial_overlap"] = {"value": _r(p["value"]), "ms_per_step": _r(p["ms_per_step"]), "steps": p.get("steps"), "converged_at_iteration": p.get("converged_at_iteration"),
                                    "matched_fraction": _r(p.get("config", {}).get("matched_fraction")), "ms_per_step_steady": _r(p.get("ms_per_step_steady")),
                                    "roofline_kernel": str(p.get("roofline", {}).get("kernel", "")).split(":")[0], "roofline_frac": _r(p.get("roofline", {}).get("frac"))}
+    rg = d.get("regression")
+    if rg:
+        legs["regression"] = {"scene": "round 4's start (perturb 1.0)", "ms_per_step": _r(rg["ms_per_step"]), "steps": rg.get("steps"), "converged_at_iteration": rg.get("converged_at_iteration"),
+                              "round4_ms_per_step": 8.59}
+    sc = d.get("scanner_sampled")
+    if sc:
+        cq, cq0 = sc.get("candidates_per_query") or {}, d.get("candidates_per_query") or {}
+        legs["scanner_sampled"] = {"ms_per_step": _r(sc["ms_per_step"]), "value": _r(sc["value"]), "steps": sc.get("steps"), "converged_at_iteration": sc.get("converged_at_iteration"),
+                                   "vs_uniform_headline": _r(sc["ms_per_step"] / d["ms_per_step"]) if d.get("ms_per_step") else None,
+                                   "roofline_kernel": str(sc.get("roofline", {}).get("kernel", "")).split(":")[0], "roofline_frac": _r(sc.get("roofline", {}).get("frac")),
+                                   "candidates_per_query_mean": _r(cq.get("mean")), "candidates_per_query_p99": _r(cq.get("p99")),
+                                   "uniform_candidates_per_query_mean": _r(cq0.get("mean"))}
     a = d.get("allpairs")
     if a:
         la = {"value": _r(a["value"]), "unit": a["unit"], "scaling": a["scaling"], "n_gpus": a.get("n_gpus"), "steps": a["steps"], "ms_per_iter": _r(a["ms_per_iter"]),

@@ -1379,10 +1379,21 @@ static int lm_blocks_for(long long n, int n_sets = 1) {
 // sums of a single-GPU run that way and replays them to a handle working as rank 0 of a larger world)
 static bool sharded(const e3d_icp* h) { return h->comm != nullptr || h->world > 1 || h->allreduce != nullptr; }
 
+// E3D_LM_PROFILE=1: wall-clock split of an outer iteration's LM on the host (stderr; diagnostics only)
+static bool lm_profile() { static const bool on = [] { const char* e = getenv("E3D_LM_PROFILE"); return e && e[0] == '1'; }(); return on; }
+struct LmProf { double solve_ms = 0, eval_ms = 0, reduce_ms = 0, prepare_ms = 0; int solves = 0, evals = 0; };
+static thread_local LmProf g_lm_prof;
+struct LmTick {
+  double& acc; std::chrono::steady_clock::time_point t0;
+  explicit LmTick(double& a) : acc(a) { if (lm_profile()) t0 = std::chrono::steady_clock::now(); }
+  ~LmTick() { if (lm_profile()) acc += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+};
+
 // sum of the per-set results (n doubles, already reduced over this rank's blocks) over the ranks: in place in HBM on the
 // handle's stream with the native communicator; the host copy follows either way
 static void reduce_setsums(e3d_icp* h, int ns) {
   hipStream_t s = h->stream;
+  LmTick tick(g_lm_prof.reduce_ms);
   const size_t n = (size_t)kLmSlot * (size_t)ns;
   if (h->comm) comm_allreduce_f64(h->comm, h->d_setsum.p, n, s);
   copy_out(h->h_setsum.p, h->d_setsum.p, sizeof(double) * n, s);
@@ -1420,6 +1431,7 @@ struct LmSystem {
 static void lm_evaluate(e3d_icp* h, LmSystem& L, const std::vector<SE3f>& poses, bool full, std::vector<double>& H,
                         std::vector<double>& b, double& cost, e3d_icp_iter_record& rec) {
   hipStream_t s = h->stream;
+  LmTick tick(g_lm_prof.eval_ms); g_lm_prof.evals++;
   const int ns = (int)L.sets.size();
   const int nv = L.nv;
   H.assign((size_t)nv * nv, 0.0);
@@ -1483,6 +1495,7 @@ static void lm_evaluate(e3d_icp* h, LmSystem& L, const std::vector<SE3f>& poses,
 static void lm_evaluate_costs(e3d_icp* h, LmSystem& L, const std::vector<std::vector<SE3f>>& cand, std::vector<double>& costs,
                               e3d_icp_iter_record& rec) {
   hipStream_t s = h->stream;
+  LmTick tick(g_lm_prof.eval_ms); g_lm_prof.evals++;
   const int ns = (int)L.sets.size();
   const int np = (int)cand.size();
   costs.assign(np, 0.0);
@@ -1611,6 +1624,7 @@ static void lm_compute(e3d_icp* h, LmSystem& L, std::vector<SE3f>& poses, e3d_ic
   std::vector<double> lam(10), costs(10);
   // lam[first..9] from lam_first; the poses of tries [first, last); returns lambda after ten rejections
   auto tries_from = [&](int first, int last, double lam_first) {
+    LmTick tick(g_lm_prof.solve_ms); g_lm_prof.solves += last - first;
     double l = lam_first;
     for (int k = first; k < 10; ++k) { lam[k] = l; l = 2.f * l; }
     if (h->solve_pool && nv >= 30 && last - first > 1) {
@@ -1890,9 +1904,14 @@ static bool align_meshes(e3d_icp* h, float max_d, float thr, bool print, int ite
   LmSystem L;
   L.n_impl = n_impl;
   L.nv = 6 * (n_impl - 1);
-  lm_prepare(h, L, jobs, M);
+  { LmTick tick(g_lm_prof.prepare_ms); lm_prepare(h, L, jobs, M); }
   if (n_impl >= 1) lm_compute(h, L, poses, rec);
   t_lm.stop(s);
+  if (lm_profile()) {
+    fprintf(stderr, "[lm profile] it %d: prepare %.2f ms, %d solves %.2f ms, %d evaluations %.2f ms (of which waiting for the sums + reduction %.2f ms)\n", iteration,
+            g_lm_prof.prepare_ms, g_lm_prof.solves, g_lm_prof.solve_ms, g_lm_prof.evals, g_lm_prof.eval_ms, g_lm_prof.reduce_ms);
+    g_lm_prof = LmProf{};
+  }
 
   // pose write-back (cc:318-341): new = Affine3f(pose.matrix()) * global_T_cloud
   bool converged = true;

@@ -117,15 +117,18 @@ def make_scan(n, origin, yaw, seed, sigma=0.002, device="cpu", room_scale=1.0, p
     return xyz_local, nrm_local, T.astype(np.float32)
 
 
-def make_scan_angular(n, origin, yaw, seed, sigma=0.002, device="cpu"):
+def make_scan_angular(n, origin, yaw, seed, sigma=0.002, device="cpu", scan_order=False):
     """The room as a REAL scanner samples it: rays in directions uniform on the sphere (equal angular steps), first hit with the
     floor, the four walls and the cylinders -- the point density falls off with cos(incidence) / range^2 instead of being
-    uniform per area (make_scan).  Rays that leave through the open top are dropped.  Returns what make_scan returns."""
+    uniform per area (make_scan).  Rays that leave through the open top are dropped.  Returns what make_scan returns.
+    scan_order=True: the points in the order a terrestrial scanner records them (README.md:304-305: Faro Focus scans) -- the head
+    turns about the vertical axis while the mirror sweeps vertical lines: columns of equal azimuth, bottom to top within a column
+    (~sqrt(2 n) columns: equal angular steps in both directions); the default is the order the random rays were drawn in."""
     g = torch.Generator(device=device)
     g.manual_seed(int(seed))
     W, D, Hh = _ROOM
     o = torch.tensor(origin, device=device, dtype=torch.float64)
-    pts, nrms = [], []
+    pts, nrms, az, el = [], [], [], []
     have = 0
     while have < n:
         m = int((n - have) * 1.7) + 1024
@@ -163,8 +166,19 @@ def make_scan_angular(n, origin, yaw, seed, sigma=0.002, device="cpu"):
         noise = torch.randn(m, generator=g, device=device, dtype=torch.float64) * sigma
         p = o + (t + noise)[:, None] * d
         pts.append(p[hit]); nrms.append(nr[hit])
+        if scan_order:
+            az.append(ph[hit]); el.append(u[hit])
         have += int(hit.sum())
+        del d, t, nr, p, u, ph, sr, noise, hit
     p = torch.cat(pts)[:n]; nr = torch.cat(nrms)[:n]
+    del pts, nrms
+    if scan_order:
+        ncol = max(1, int(math.sqrt(2.0 * n)))
+        col = torch.clamp((torch.cat(az)[:n] * (ncol / (2 * math.pi))).to(torch.int64), max=ncol - 1)
+        key = col.to(torch.float64) * 4.0 + (torch.cat(el)[:n] + 1.0)          # column, then elevation (cos(polar) + 1 in [0, 2])
+        order = torch.argsort(key)
+        p = p[order]; nr = nr[order]
+        del az, el, col, key, order
     flip = ((o - p) * nr).sum(dim=1, keepdim=True) < 0
     nr = torch.where(flip, -nr, nr)
     R = torch.tensor(_rot_z(yaw), device=device, dtype=torch.float64)
@@ -258,14 +272,18 @@ def perturbation(index, angle_scale=1.0, scale=1.0):
     return P
 
 
-def make_scene(n_scans, n_points, seed=1234, sigma=0.002, device="cpu", room_scale=1.0, partial=False, perturb=1.0):
+def make_scene(n_scans, n_points, seed=1234, sigma=0.002, device="cpu", room_scale=1.0, partial=False, perturb=1.0, scanner=False):
     """List of dicts {xyz, normals, T_true, T_init} (T_init = perturbation * T_true applied about the scan origin).
     partial=True: the partial-overlap room (partition wall, occlusion, maximum range; room_scale must be 1).
-    perturb: scale of the initial misalignment (perturbation())."""
+    perturb: scale of the initial misalignment (perturbation()).
+    scanner=True: every scan as a scanner records it (make_scan_angular: density ~ cos / range^2, points in scan order)."""
     scans = []
     for i in range(n_scans):
         origin, yaw = SCAN_POSES[i % len(SCAN_POSES)]
-        xyz, nrm, T = make_scan(n_points, origin, yaw, seed + 17 * i, sigma, device, room_scale, partial)
+        if scanner:
+            xyz, nrm, T = make_scan_angular(n_points, origin, yaw, seed + 17 * i, sigma, device, scan_order=True)
+        else:
+            xyz, nrm, T = make_scan(n_points, origin, yaw, seed + 17 * i, sigma, device, room_scale, partial)
         P = perturbation(i, 1.0 / room_scale, perturb)
         Ti = T.astype(np.float64).copy()
         Ti[:3, :3] = P[:3, :3] @ Ti[:3, :3]

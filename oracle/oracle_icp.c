@@ -263,8 +263,77 @@ static double cost_pass(const icloud* cl, const ocorr* cs, int n_cs) {
   return cost;
 }
 
+/* ---- all-core variants of the two passes ("queries AND reductions parallelised"; bench.py's
+ * cpu_baseline.all_core only -- the oracle proper keeps the reference's sequential sums).  Every thread sums a contiguous share of
+ * each correspondence set into its own H / b / cost, the partials are added in thread order: the same terms in another order of
+ * f64 additions (results agree with the sequential pass to rounding, not bit for bit). */
+static double cost_pass_par(const icloud* cl, const ocorr* cs, int n_cs) {
+  double cost = 0.0;
+  for (int s = 0; s < n_cs; ++s) {
+    const icloud* sc = &cl[cs[s].src]; const icloud* tc = &cl[cs[s].tgt];
+    float Rs[9], Rt[9];
+    om_quat_to_R_f(sc->pose.q, Rs); om_quat_to_R_f(tc->pose.q, Rt);
+    double set_cost = 0.0;
+#pragma omp parallel for schedule(static) reduction(+ : set_cost)
+    for (int64_t c = 0; c < cs[s].n; ++c) {
+      float sp[3], sn[3], tp[3], tn[3];
+      om_rot_trans_f(Rs, sc->pose.t, sc->cloud->xyz + 3 * (size_t)cs[s].iq[c], sp);
+      om_rot_f(Rs, sc->cloud->nrm + 3 * (size_t)cs[s].iq[c], sn);
+      om_rot_trans_f(Rt, tc->pose.t, tc->cloud->xyz + 3 * (size_t)cs[s].im[c], tp);
+      om_rot_f(Rt, tc->cloud->nrm + 3 * (size_t)cs[s].im[c], tn);
+      float d[3] = {tp[0] - sp[0], tp[1] - sp[1], tp[2] - sp[2]};
+      float r1 = om_dot3f(sn, d);
+      float e[3] = {sp[0] - tp[0], sp[1] - tp[1], sp[2] - tp[2]};
+      float r2 = om_dot3f(tn, e);
+      set_cost += (double)(r1 * r1) + (double)(r2 * r2);
+    }
+    cost += set_cost;
+  }
+  return cost;
+}
+
+static double accumulate_pass_par(const icloud* cl, const ocorr* cs, int n_cs, double* H, double* b, int nv) {
+  int nt = omp_get_max_threads();
+  size_t stride = (size_t)nv * nv + (size_t)nv + 1;
+  double* part = (double*)calloc((size_t)nt * stride, sizeof(double));
+#pragma omp parallel num_threads(nt)
+  {
+    int tid = omp_get_thread_num();
+    double* Hp = part + (size_t)tid * stride; double* bp = Hp + (size_t)nv * nv; double* cp = bp + nv;
+    for (int s = 0; s < n_cs; ++s) {
+      int si = 6 * (cs[s].src - 1), ti = 6 * (cs[s].tgt - 1);
+      const icloud* sc = &cl[cs[s].src]; const icloud* tc = &cl[cs[s].tgt];
+      float Rs[9], Rt[9];
+      om_quat_to_R_f(sc->pose.q, Rs); om_quat_to_R_f(tc->pose.q, Rt);
+#pragma omp for schedule(static) nowait
+      for (int64_t c = 0; c < cs[s].n; ++c) {
+        float sp[3], sn[3], tp[3], tn[3];
+        om_rot_trans_f(Rs, sc->pose.t, sc->cloud->xyz + 3 * (size_t)cs[s].iq[c], sp);
+        om_rot_f(Rs, sc->cloud->nrm + 3 * (size_t)cs[s].iq[c], sn);
+        om_rot_trans_f(Rt, tc->pose.t, tc->cloud->xyz + 3 * (size_t)cs[s].im[c], tp);
+        om_rot_f(Rt, tc->cloud->nrm + 3 * (size_t)cs[s].im[c], tn);
+        float r1, r2, j1t[6], j1s[6], j2t[6], j2s[6];
+        corr_rows(sp, sn, tp, tn, &r1, j1t, j1s, &r2, j2t, j2s);
+        *cp += r1 * r1;
+        accumulate((double)r1, si, j1s, ti, j1t, Hp, bp, nv);
+        *cp += r2 * r2;
+        accumulate((double)r2, si, j2s, ti, j2t, Hp, bp, nv);
+      }
+    }
+  }
+  double cost = 0.0;
+  for (int t = 0; t < nt; ++t) {
+    const double* Hp = part + (size_t)t * stride; const double* bp = Hp + (size_t)nv * nv;
+    for (size_t i = 0; i < (size_t)nv * nv; ++i) H[i] += Hp[i];
+    for (int i = 0; i < nv; ++i) b[i] += bp[i];
+    cost += bp[nv];
+  }
+  free(part);
+  return cost;
+}
+
 static void impl_compute(icloud* cl, int n_cl, const ocorr* cs, int n_cs, int max_it,
-                         oracle_icp_iter_record* rec) {
+                         oracle_icp_iter_record* rec, int all_core) {
   int nv = 6 * (n_cl - 1);
   double* H = (double*)malloc(sizeof(double) * (size_t)(nv > 0 ? nv * nv : 1));
   double* Hl = (double*)malloc(sizeof(double) * (size_t)(nv > 0 ? nv * nv : 1));
@@ -278,7 +347,8 @@ static void impl_compute(icloud* cl, int n_cl, const ocorr* cs, int n_cs, int ma
     memset(H, 0, sizeof(double) * (size_t)nv * nv);
     memset(b, 0, sizeof(double) * (size_t)nv);
     double cost = 0.0;
-    for (int s = 0; s < n_cs; ++s) {
+    if (all_core) cost = accumulate_pass_par(cl, cs, n_cs, H, b, nv);
+    for (int s = 0; s < n_cs && !all_core; ++s) {
       int si = 6 * (cs[s].src - 1), ti = 6 * (cs[s].tgt - 1);
       const icloud* sc = &cl[cs[s].src]; const icloud* tc = &cl[cs[s].tgt];
       float Rs[9], Rt[9];
@@ -316,7 +386,7 @@ static void impl_compute(icloud* cl, int n_cl, const ocorr* cs, int n_cs, int ma
         upd[ci].cloud = cl[ci].cloud;
         om_se3f_mul(&ef, &cl[ci].pose, &upd[ci].pose);
       }
-      double new_cost = cost_pass(upd, cs, n_cs);
+      double new_cost = all_core ? cost_pass_par(upd, cs, n_cs) : cost_pass(upd, cs, n_cs);
       rec->cost_passes++;
       if (new_cost < cost) {
         memcpy(cl, upd, sizeof(icloud) * (size_t)n_cl);
@@ -401,9 +471,16 @@ static int align_meshes(oracle_icp* o, float max_d, float thr, int print, int it
     if (i != k && bbox_intersects(o->clouds[i].bmin, o->clouds[i].bmax, o->clouds[k].bmin, o->clouds[k].bmax)) need[k] = 1;
     if (i == k && o->has_fixed && bbox_intersects(fmin, fmax, o->clouds[i].bmin, o->clouds[i].bmax)) { need[M] = 1; need[i] = 1; }
   }
+  if (o->all_core) {
+    for (int k = 0; k <= M; ++k) {                         /* one tree after the other, every core on each */
+      if (!need[k]) continue;
+      const ocloud* c = (k == M) ? &o->fixed : &o->clouds[k].global;
+      trees[k] = okd_build_parallel(c->xyz, c->n);
+    }
+  }
 #pragma omp parallel for schedule(dynamic, 1)
   for (int k = 0; k <= M; ++k) {
-    if (!need[k]) continue;
+    if (!need[k] || trees[k]) continue;
     const ocloud* c = (k == M) ? &o->fixed : &o->clouds[k].global;
     trees[k] = okd_build(c->xyz, c->n);
   }
@@ -467,7 +544,7 @@ static int align_meshes(oracle_icp* o, float max_d, float thr, int print, int it
   double t2 = now_s();
   rec.t_nn_s = t2 - t1;
 
-  impl_compute(icl, n_impl, cs, n_cs, o->max_inner, &rec);
+  impl_compute(icl, n_impl, cs, n_cs, o->max_inner, &rec, o->all_core);
   rec.t_lm_s = now_s() - t2;
 
   /* pose write-back (cc:318-341) */

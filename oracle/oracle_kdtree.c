@@ -89,6 +89,64 @@ static int32_t okd_build_rec(okd_tree* t, int32_t b, int32_t e) {
   return id;
 }
 
+/* ---- all-core build (bench.py's cpu_baseline.all_core only): the same median splits, sub-trees as OpenMP tasks.  Node ids come
+ * from an atomic counter over a preallocated array (leaves hold 8 .. 15 points: at most n / 4 + 2 nodes), so the numbering differs
+ * from okd_build's; the boxes, the splits and therefore every search result are the same. */
+static int32_t okd_build_par_rec(okd_tree* t, int32_t b, int32_t e) {
+  size_t idv;
+#pragma omp atomic capture
+  idv = t->n_nodes++;
+  const int32_t id = (int32_t)idv;
+  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int32_t i = b; i < e; ++i) {
+    const float* p = t->xyz + 3 * (size_t)t->perm[i];
+    for (int d = 0; d < 3; ++d) { if (p[d] < lo[d]) lo[d] = p[d]; if (p[d] > hi[d]) hi[d] = p[d]; }
+  }
+  okd_node nd;
+  memcpy(nd.lo, lo, sizeof lo); memcpy(nd.hi, hi, sizeof hi);
+  nd.begin = b; nd.end = e; nd.left = nd.right = -1;
+  if (e - b > OKD_LEAF) {
+    int dim = 0; float ext = hi[0] - lo[0];
+    if (hi[1] - lo[1] > ext) { dim = 1; ext = hi[1] - lo[1]; }
+    if (hi[2] - lo[2] > ext) { dim = 2; ext = hi[2] - lo[2]; }
+    int32_t m = b + (e - b) / 2;
+    okd_select(t->xyz, t->perm, b, e, m, dim);
+    int32_t l = -1, r = -1;
+    if (e - b > 32768) {
+#pragma omp task shared(l) firstprivate(t, b, m)
+      l = okd_build_par_rec(t, b, m);
+#pragma omp task shared(r) firstprivate(t, m, e)
+      r = okd_build_par_rec(t, m, e);
+#pragma omp taskwait
+    } else {
+      l = okd_build_par_rec(t, b, m);
+      r = okd_build_par_rec(t, m, e);
+    }
+    nd.left = l; nd.right = r;
+  }
+  t->nodes[id] = nd;
+  return id;
+}
+
+okd_tree* okd_build_parallel(const float* xyz, size_t n) {
+  okd_tree* t = (okd_tree*)calloc(1, sizeof(okd_tree));
+  t->xyz = xyz; t->n = n;
+  t->perm = (int32_t*)malloc(sizeof(int32_t) * (n ? n : 1));
+  t->pts = (float*)malloc(sizeof(float) * 3 * (n ? n : 1));
+  t->cap_nodes = n / 4 + 64;
+  t->nodes = (okd_node*)malloc(t->cap_nodes * sizeof(okd_node));
+#pragma omp parallel for schedule(static)
+  for (long long i = 0; i < (long long)n; ++i) t->perm[i] = (int32_t)i;
+  if (n > 0) {
+#pragma omp parallel
+#pragma omp single
+    okd_build_par_rec(t, 0, (int32_t)n);
+  }
+#pragma omp parallel for schedule(static)
+  for (long long i = 0; i < (long long)n; ++i) memcpy(t->pts + 3 * (size_t)i, xyz + 3 * (size_t)t->perm[i], 3 * sizeof(float));
+  return t;
+}
+
 okd_tree* okd_build(const float* xyz, size_t n) {
   okd_tree* t = (okd_tree*)calloc(1, sizeof(okd_tree));
   t->xyz = xyz; t->n = n;

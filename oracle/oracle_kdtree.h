@@ -25,6 +25,8 @@ typedef struct okd_tree okd_tree;
 
 /* xyz: n x 3 floats (kept by pointer; must outlive the tree). */
 okd_tree* okd_build(const float* xyz, size_t n);
+/* the same tree built by all host cores (OpenMP tasks; node numbering differs, search results do not): bench.py's all-core CPU baseline */
+okd_tree* okd_build_parallel(const float* xyz, size_t n);
 void okd_free(okd_tree* t);
 
 /* Exact nearest neighbour with dist < r2.  Returns 1 and fills idx/dist when

@@ -169,6 +169,20 @@ def test_arrow_system_matches_dense_ldlt(tmp_path):
         assert float(err) <= 1e-12 * max(1.0, float(mx)) and pack_ok == "1", (args, r.stdout)
 
 
+def test_ldlt_lower_triangle_form_is_bit_identical(tmp_path):
+    """e3d::ldlt_solve_upper keeps the lower triangle only (round 6); the plain full-matrix form of the same pivoted LDL^T (restated in
+    the test program) gives the same solution and pivot order bit for bit: positive definite, indefinite, rank-deficient systems and
+    systems with zero rows (unknowns without residuals), at the sizes of the ICP (6 ... 90) and registration (150, 384) systems."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "ldlt_test")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-o", exe, os.path.join(root, "tests", "cpp", "ldlt_test.cc")])
+    for kind in range(4):
+        for n, seed in ((1, 1), (6, 2), (42, 3), (90, 4), (150, 5), (384, 6)):
+            r = subprocess.run([exe, str(n), str(seed), str(kind)], capture_output=True, text=True)
+            assert r.returncode == 0, r.stdout + r.stderr
+            assert r.stdout.split()[0] == "0", (n, kind, r.stdout)
+
+
 def test_ply_readers_mixed_types_and_endianness(tmp_path):
     """loadPLYFile / loadPLYMesh (csrc/host/io_ply.h) on binary files as scanners and MeshLab write them: double coordinates,
     properties in any order, colours, normals, intensity, extra properties, big-endian files, face lists with different count /

@@ -101,6 +101,56 @@ def test_c3_all_pairs_8x20M_at_size(e3d, ob, synth):
         assert 1000 < len(iq) < 100_000                                             # the sample has both branches
 
 
+def test_scanner_sampled_2x20M_at_size(e3d, ob, synth):
+    """ICP on scans as a terrestrial scanner records them (README.md:304-305: Faro scans; src/exe/icp_scan_aligner.cc:308-333 reads
+    them in scan order): 2 x 20 M points from two scanner positions, density ~ cos / range^2 (a fifth of the points within 2 m of
+    the scanner: cells under it hold hundreds of points, the far walls a few), points in scan order, -d 0.01, three outer iterations
+    (full search, then certificates + bounded search + far lists).  Checks as in test_c3_all_pairs_8x20M_at_size:
+      (i)   a second handle reproduces counts and poses bit for bit;
+      (ii)  the counts of the last iteration equal a fresh exact search over the same global-frame coordinates;
+      (iii) for a random 1e5-query sample of each direction, partner index and f32 squared distance of that search equal the
+            oracle's kd-tree over the FULL 20 M-point target."""
+    import torch
+    n, d = 20_000_000, 0.01
+    dev = torch.device("cuda", 0)
+    scans = synth.make_scene(2, n, seed=99, sigma=0.002, device=dev, scanner=True)
+    near = float((scans[0]["xyz"].norm(dim=1) < 2.0).float().mean())
+    assert 0.15 < near < 0.3, near                                                  # scanner-shaped: a fifth of the points within 2 m
+
+    def run():
+        icp = e3d.PointToPlaneICP(device=0)
+        for s in scans:
+            icp.add_point_cloud(s["xyz"], s["normals"], s["T_init"], False)
+        poses = []
+        for it in range(3):
+            icp.run(d, it, 1, 1e-10, False)
+            poses.append([icp.get_result_global_T_cloud(i) for i in range(2)])
+        recs, its = icp.pair_records(), icp.iter_records()
+        del icp
+        torch.cuda.empty_cache()
+        return recs, poses, its
+    recs, poses, its = run()
+    assert len(recs) == 6
+    assert its[2]["nn_certify_queries"] > 0 or its[1]["nn_certify_queries"] > 0     # the certificate path ran
+    cnt = {(r[0], r[1], r[2]): r[3] for r in recs}
+    assert cnt[(2, 0, 1)] > 0.05 * n and cnt[(2, 1, 0)] > 0.05 * n
+    recs_b, poses_b, _ = run()
+    assert [tuple(r[:4]) for r in recs_b] == [tuple(r[:4]) for r in recs]
+    assert all(np.array_equal(a.view(np.uint32), b.view(np.uint32)) for a, b in zip(poses[2], poses_b[2]))
+    rng = np.random.RandomState(11)
+    G = [e3d.transform_cloud(scans[i]["xyz"], scans[i]["normals"], poses[1][i])[0] for i in range(2)]      # the poses iteration 2 searched at
+    for (a, b) in ((0, 1), (1, 0)):
+        idx, d2, count = e3d.find_correspondences(G[a], G[b], d)
+        assert count == cnt[(2, a, b)], (a, b, count, cnt[(2, a, b)])
+        sample = rng.choice(n, 100_000, replace=False)
+        iq, im, sd = ob.find_correspondences(G[a][sample], G[b], d)
+        ref = np.full(len(sample), -1, np.int32); ref[iq] = im
+        refd = np.zeros(len(sample), np.float32); refd[iq] = sd
+        assert np.array_equal(idx[sample], ref), (a, b)
+        assert np.array_equal(d2[sample].view(np.uint32)[ref >= 0], refd.view(np.uint32)[ref >= 0])
+        assert 1000 < len(iq) < 100_000
+
+
 _C5_DENSE_SNIPPET = r'''
 import sys, importlib, numpy as np
 sys.path.insert(0, sys.argv[1])

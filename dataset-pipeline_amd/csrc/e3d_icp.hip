@@ -1381,7 +1381,7 @@ static bool sharded(const e3d_icp* h) { return h->comm != nullptr || h->world > 
 
 // E3D_LM_PROFILE=1: wall-clock split of an outer iteration's LM on the host (stderr; diagnostics only)
 static bool lm_profile() { static const bool on = [] { const char* e = getenv("E3D_LM_PROFILE"); return e && e[0] == '1'; }(); return on; }
-struct LmProf { double solve_ms = 0, eval_ms = 0, reduce_ms = 0, prepare_ms = 0; int solves = 0, evals = 0; };
+struct LmProf { double solve_ms = 0, eval_ms = 0, reduce_ms = 0, prepare_ms = 0, callback_ms = 0, callback_max = 0, wait_max = 0; int solves = 0, evals = 0; };
 static thread_local LmProf g_lm_prof;
 struct LmTick {
   double& acc; std::chrono::steady_clock::time_point t0;
@@ -1397,9 +1397,11 @@ static void reduce_setsums(e3d_icp* h, int ns) {
   const size_t n = (size_t)kLmSlot * (size_t)ns;
   if (h->comm) comm_allreduce_f64(h->comm, h->d_setsum.p, n, s);
   copy_out(h->h_setsum.p, h->d_setsum.p, sizeof(double) * n, s);
-  sync(h);
+  { double w = 0; { LmTick tw(w); sync(h); } g_lm_prof.wait_max = std::max(g_lm_prof.wait_max, w); }
   if (!h->comm && h->allreduce) {
-    if (h->allreduce(h->h_setsum.p, n, h->allreduce_user) != 0) throw Error(E3D_ERR_INVALID, "allreduce callback failed");
+    double c = 0;
+    { LmTick tc(c); if (h->allreduce(h->h_setsum.p, n, h->allreduce_user) != 0) throw Error(E3D_ERR_INVALID, "allreduce callback failed"); }
+    g_lm_prof.callback_ms += c; g_lm_prof.callback_max = std::max(g_lm_prof.callback_max, c);
   }
 }
 
@@ -1908,8 +1910,9 @@ static bool align_meshes(e3d_icp* h, float max_d, float thr, bool print, int ite
   if (n_impl >= 1) lm_compute(h, L, poses, rec);
   t_lm.stop(s);
   if (lm_profile()) {
-    fprintf(stderr, "[lm profile] it %d: prepare %.2f ms, %d solves %.2f ms, %d evaluations %.2f ms (of which waiting for the sums + reduction %.2f ms)\n", iteration,
-            g_lm_prof.prepare_ms, g_lm_prof.solves, g_lm_prof.solve_ms, g_lm_prof.evals, g_lm_prof.eval_ms, g_lm_prof.reduce_ms);
+    fprintf(stderr, "[lm profile] it %d: prepare %.2f ms, %d solves %.2f ms, %d evaluations %.2f ms (of which waiting for the sums + reduction %.2f ms: longest wait %.2f ms; "
+            "all-reduce callback %.2f ms, longest %.2f ms)\n", iteration, g_lm_prof.prepare_ms, g_lm_prof.solves, g_lm_prof.solve_ms, g_lm_prof.evals, g_lm_prof.eval_ms,
+            g_lm_prof.reduce_ms, g_lm_prof.wait_max, g_lm_prof.callback_ms, g_lm_prof.callback_max);
     g_lm_prof = LmProf{};
   }
 

@@ -84,6 +84,7 @@ def cpu_baseline_icp(scans, d, thr, slab, n_points, poses=None, first_iteration=
     passes as the poses settle, exactly like the GPU's)."""
     from oracle import binding as ob
     ob.lib()
+    cores = ob.set_num_threads(ob.effective_cores())      # (the affinity mask capped by the cgroup quota, not os.cpu_count())
     clouds, n = [], []
     for i, s in enumerate(scans):
         xyz, nrm = crop_world(s, slab[0], slab[1])
@@ -119,8 +120,8 @@ def cpu_baseline_icp(scans, d, thr, slab, n_points, poses=None, first_iteration=
         "ms_per_iter": times[med] * 1e3, "ms_per_iter_all": [t * 1e3 for t in times], "correspondences": int(recs[med]["correspondences"]),
         "sample_fraction_of_configs1": frac,
         "t_nn_s": recs[med]["t_nn_s"], "t_lm_s": recs[med]["t_lm_s"],
-        "lm_passes": int(recs[med]["accumulate_passes"] + recs[med]["cost_passes"]), "host_cores_available": os.cpu_count(),
-        "all_core": {"value": recs2[med2]["correspondences"] / times2[med2], "unit": "correspondences/s", "cores": os.cpu_count(),
+        "lm_passes": int(recs[med]["accumulate_passes"] + recs[med]["cost_passes"]), "host_cores_available": cores, "host_cpu_count": os.cpu_count(),
+        "all_core": {"value": recs2[med2]["correspondences"] / times2[med2], "unit": "correspondences/s", "cores": cores,
                      "ms_per_iter": times2[med2] * 1e3, "t_nn_s": recs2[med2]["t_nn_s"], "t_lm_s": recs2[med2]["t_lm_s"],
                      "same_correspondences": bool([r["correspondences"] for r in recs2] == [r["correspondences"] for r in recs]),
                      "note": "SURVEY 8(d)(ii): kd-tree builds (OpenMP tasks), NN queries and both LM passes (per-thread H / b / cost partials added in thread order) on all host cores; "
@@ -820,10 +821,11 @@ def leg_normals(e3d, synth, args, dev):
         i0 = int(0.4 * len(xs))
         lo, hi = float(xs[i0]), float(xs[min(len(xs) - 1, i0 + max(1, int(len(xs) * 1_000_000 / n)))])
         sub = xyz[(x >= lo) & (x < hi)].cpu().numpy()
+        cores = ob.set_num_threads(ob.effective_cores())
         t0 = time.perf_counter()
         ob.normals(sub, k=32)
         dtc = time.perf_counter() - t0
-        out["cpu_baseline"] = {"value": len(sub) / dtc, "unit": "normals/s", "cores": os.cpu_count(), "kind": "port",
+        out["cpu_baseline"] = {"value": len(sub) / dtc, "unit": "normals/s", "cores": cores, "host_cpu_count": os.cpu_count(), "kind": "port",
                                "sample": "k = 32 on %d points (slab x in [%.2f, %.2f) of the same scan): kd-tree build + k-search + two-pass "
                                          "covariance, OpenMP over points like NormalEstimationTwoPassOMP, %.1f s" % (len(sub), lo, hi, dtc)}
         out["speedup_vs_cpu"] = out["k32"]["value"] / out["cpu_baseline"]["value"]
@@ -983,7 +985,7 @@ def compact_line(d, detail_path="bench_detail.json"):
     cb = d.get("cpu_baseline")
     if cb:
         o["cpu_baseline"] = {"value": _r(cb["value"]), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
-                             "sample": "median of 3 outer iterations on a slab of both scans (%.1f %% of the points), from the GPU run's poses after warm-up"
+                             "sample": "median of 3 iterations, slab of both scans (%.1f %% of the points), from the GPU run's poses after warm-up"
                                        % (100.0 * cb.get("sample_fraction_of_configs1", 0.0)),
                              "ms_per_iter": _r(cb.get("ms_per_iter")), "all_cores_value": _r(cb.get("all_core", {}).get("value")), "host_cores_available": cb.get("host_cores_available")}
         o["speedup_vs_cpu_iteration_rate"] = _r(d.get("speedup_vs_cpu_iteration_rate"))
@@ -1010,17 +1012,16 @@ def compact_line(d, detail_path="bench_detail.json"):
         legs["scanner_sampled"] = {"ms_per_step": _r(sc["ms_per_step"]), "value": _r(sc["value"]), "steps": sc.get("steps"), "converged_at_iteration": sc.get("converged_at_iteration"),
                                    "vs_uniform_headline": _r(sc["ms_per_step"] / d["ms_per_step"]) if d.get("ms_per_step") else None,
                                    "roofline_kernel": str(sc.get("roofline", {}).get("kernel", "")).split(":")[0], "roofline_frac": _r(sc.get("roofline", {}).get("frac")),
-                                   "candidates_per_query_mean": _r(cq.get("mean")), "candidates_per_query_p99": _r(cq.get("p99")),
-                                   "uniform_candidates_per_query_mean": _r(cq0.get("mean"))}
+                                   "candidates_per_query": {"mean": _r(cq.get("mean")), "p99": _r(cq.get("p99")), "uniform_scan_mean": _r(cq0.get("mean"))}}
     a = d.get("allpairs")
     if a:
         la = {"value": _r(a["value"]), "unit": a["unit"], "scaling": a["scaling"], "n_gpus": a.get("n_gpus"), "steps": a["steps"], "ms_per_iter": _r(a["ms_per_iter"]),
               "ms_per_iter_settling": _r(a.get("ms_per_iter_settling")), "ms_per_iter_steady": _r(a.get("ms_per_iter_steady")),
-              "workload": str(a.get("config", {}).get("workload", "")).split(" (")[0],
+              "workload": str(a.get("config", {}).get("workload", "")).split(" points")[0].replace(" synthetic", "") + " points, all pairs",
               "roofline_kernel": str(a.get("roofline", {}).get("kernel", "")).split(":")[0], "roofline_frac": _r(a.get("roofline", {}).get("frac")),
               "roofline_frac_of_bytes_moved": _r(a.get("roofline", {}).get("frac_of_bytes_moved"))}
         if "nn_launches_per_iter" in a:
-            la["nn_launches_per_iter"] = {k: _r(v) for k, v in a["nn_launches_per_iter"].items()}
+            la["nn_launches_per_iter"] = {k: _r(v) for k, v in a["nn_launches_per_iter"].items() if k in ("rows", "radix_sorts", "all_kernels", "batches")}
         sm = a.get("scale_model")
         if sm:
             la["scale_model"] = {"world": sm["world"], "ms_per_iter_n1": _r(sm["ms_per_iter_n1"]), "ms_per_iter_as_rank0_of_world": _r(sm["ms_per_iter_as_rank0_of_world"]),
@@ -1034,7 +1035,7 @@ def compact_line(d, detail_path="bench_detail.json"):
     if g:
         rf2 = g.get("roofline", {})
         p2 = next((v for k, v in rf2.items() if k.startswith("k_reg_pass2")), {})
-        lg = {"metric": g.get("metric"), "value": _r(g.get("value")), "unit": g.get("unit"), "dtype": str(g.get("dtype", "")).split(" -- ")[0][:120],
+        lg = {"metric": g.get("metric"), "value": _r(g.get("value")), "unit": g.get("unit"), "dtype": "f32 rows; H, b: f32 chains added into f64 (opt-in, narrower)" if "NARROWER" in str(g.get("dtype", "")) else "f32 rows; H, b: exact products, f64 sums",
               "workload": str(g.get("config", {}).get("workload", "")).split(" (BASELINE")[0], "accumulate_ms_all_images": _r(g.get("accumulate_ms_all_images")),
               "ms_per_run_iteration": _r(g.get("ms_per_run_iteration")), "pass1_frac": _r(rf2.get("k_reg_pass1", {}).get("frac")),
               "pass2_kernel": next((k for k in rf2 if k.startswith("k_reg_pass2")), None), "pass2_avg_launch_ms": _r(p2.get("avg_launch_ms")), "pass2_frac": _r(p2.get("frac"))}

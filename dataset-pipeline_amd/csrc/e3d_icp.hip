@@ -263,6 +263,7 @@ struct e3d_icp {
   DevBuf<unsigned> prune_count;                 // number of (key, query) pairs k_query_keys_prune kept
   PinBuf<unsigned> h_prune_count;
   size_t last_corr_total = 0;                   // correspondences of the previous outer iteration (sizes the planes)
+  long long nn_global_bound_updates = 0;        // pose updates of a pair that fell back to the clouds' global motion bound (not near-rigid poses)
   DevBuf<unsigned long long> nn_stats;
   DevBuf<float> lbe_scratch;
 
@@ -567,15 +568,22 @@ static double pose_rounding_bound(const Cloud& c, const float* T) {
 
 // E3D_NN_PERQUERY=0: the certificates use the clouds' global motion bounds (rounds 2 - 4) instead of the bound per query
 static bool per_query_motion() { static const bool on = [] { const char* e = getenv("E3D_NN_PERQUERY"); return !(e && e[0] == '0'); }(); return on; }
-static bool pose_is_rigid(const float* T) {
+// largest entry of |L^T L - I|: the singular values of the pose's linear part lie within sqrt(1 -+ 3 dev).  Poses are re-composed in
+// f32 every outer iteration (Tn = R * T) and never re-orthonormalised, so dev grows by ~1e-7 per iteration: the bound per query is
+// scaled by what dev allows (accumulate_pair_motion) instead of being switched off at a fixed tolerance (at 4e-6 a
+// long run silently fell back to the clouds' global bound).  NaN poses give NaN -> not near-rigid.
+static double pose_ortho_dev(const float* T) {
+  double dev = 0;
   for (int i = 0; i < 3; ++i)
     for (int j = i; j < 3; ++j) {
       double d = 0;
       for (int r = 0; r < 3; ++r) d += (double)T[4 * r + i] * (double)T[4 * r + j];
-      if (!(std::fabs(d - (i == j ? 1.0 : 0.0)) <= 4e-6)) return false;
+      const double e = std::fabs(d - (i == j ? 1.0 : 0.0));
+      if (!(e <= dev)) dev = e;
     }
-  return true;
+  return dev;
 }
+constexpr double kNearRigidDev = 1e-3;
 // M = Tt^-1 Ts (3 x 4, row-major): the source's local frame -> the target's
 static bool relative_map(const float* Ts, const float* Tt, double M[12]) {
   double Li[9];
@@ -588,13 +596,21 @@ static bool relative_map(const float* Ts, const float* Tt, double M[12]) {
 }
 // what a pose update (Ts0, Tt0) -> (Ts1, Tt1) adds to a pair's accumulators: rigid poses -> the bound per query, else the
 // clouds' global bounds of this update (glob) into b alone
-static void accumulate_pair_motion(PairState& ps, const Cloud& src, const float* Ts0, const float* Ts1, const float* Tt0, const float* Tt1, double glob) {
+// (returns false when the update went into the global bound: a pose that is not near-rigid -- counted, E3D_NN_STATS)
+static bool accumulate_pair_motion(PairState& ps, const Cloud& src, const Cloud& tgt, const float* Ts0, const float* Ts1, const float* Tt0, const float* Tt1, double glob) {
   double M0[12], M1[12];
-  if (!per_query_motion() || !pose_is_rigid(Ts0) || !pose_is_rigid(Ts1) || !pose_is_rigid(Tt0) || !pose_is_rigid(Tt1) ||
-      !relative_map(Ts0, Tt0, M0) || !relative_map(Ts1, Tt1, M1)) {
+  const double ds = std::max(pose_ortho_dev(Ts0), pose_ortho_dev(Ts1)), dt = std::max(pose_ortho_dev(Tt0), pose_ortho_dev(Tt1));
+  if (!per_query_motion()) { ps.mB += glob; return true; }
+  if (!(ds <= kNearRigidDev) || !(dt <= kNearRigidDev) || !relative_map(Ts0, Tt0, M0) || !relative_map(Ts1, Tt1, M1)) {
     ps.mB += glob;
-    return;
+    return false;
   }
+  // The motion is bounded in the target's LOCAL frame (a |p - c| + b, p - c in the source's local frame); the kernels measure
+  // rho = |q - cs| and distances in the GLOBAL frame: |p - c| <= rho / sigma_min(L_src), a global length <= sigma_max(L_tgt) x the
+  // local one, and a distance d between resting points reads (sigma(L_tgt at T1) - sigma(L_tgt at T0)) d differently after the
+  // update -- d <= 2 x the search radius for every distance a certificate compares.
+  const double f_t = std::sqrt(1.0 + 3.0 * dt), f_st = f_t / std::sqrt(1.0 - 3.0 * ds);
+  const double rescale = 3.0 * dt * 2.0 * (double)std::max(tgt.grid_radius, 0.f);
   float dM[12];
   double fro = 0, dc2 = 0;
   for (int r = 0; r < 3; ++r) {
@@ -609,8 +625,9 @@ static void accumulate_pair_motion(PairState& ps, const Cloud& src, const float*
   }
   double smax = max_singular_value_3x3(dM) * (1.0 + 1e-6) + 1e-7 * std::sqrt(fro);      // (dM was rounded to f32: 6e-8 relative)
   if (!(smax <= std::sqrt(fro) * (1.0 + 1e-6))) smax = std::sqrt(fro) * (1.0 + 1e-6);   // Frobenius norm bounds the spectral norm (also the NaN fallback)
-  ps.mA += smax * (1.0 + 1e-9);
-  ps.mB += std::sqrt(dc2) * (1.0 + 1e-9);
+  ps.mA += smax * f_st * (1.0 + 1e-9);
+  ps.mB += (std::sqrt(dc2) * f_t + rescale) * (1.0 + 1e-9);
+  return true;
 }
 // the two roundings of a pair's accumulated bound, and the source centre's global position (rho is measured from it)
 static void pair_motion_bounds(const PairState& ps, const Cloud& src, const Cloud& tgt, MotionBound& lo, MotionBound& up) {
@@ -618,17 +635,24 @@ static void pair_motion_bounds(const PairState& ps, const Cloud& src, const Clou
   if (per_query_motion()) {
     lo.a = round_down_f(ps.mA * (1.0 - 2e-6)); lo.b = round_down_f(ps.mB * (1.0 - 2e-6));
     up.a = round_up_f(ps.mA * (1.0 + 2e-6)); up.b = round_up_f((ps.mB * (1.0 + 2e-6) + err) * (1.0 + 1e-6));
+    double cmax = 0;
     for (int r = 0; r < 3; ++r) {
       double v = (double)src.T[4 * r + 3];
       for (int k = 0; k < 3; ++k) v += (double)src.T[4 * r + k] * 0.5 * ((double)src.lmin[k] + (double)src.lmax[k]);
       lo.cs[r] = up.cs[r] = (float)v;
+      cmax = std::max(cmax, std::fabs(v));
     }
+    // error of rho = |q - cs| in a kernel: q is the f32 transform of a source point (err_max: it grows with the coordinates'
+    // magnitude -- ADVICE round 5: a fixed 5e-5 m stopped covering it a few hundred metres from the origin), cs was rounded to f32
+    // (half an ulp per component); the three subtractions, the squares and the root are inside the kernels' relative 2e-6
+    lo.rho_err = up.rho_err = round_up_f((src.err_max + 2.0 * FLT_EPSILON * cmax) * (1.0 + 1e-6) + 1e-7);
   } else {
     const double cum_pair = src.cum_motion + tgt.cum_motion;
     lo.a = up.a = 0.f;
     lo.b = round_down_f(cum_pair * (1.0 - 2e-6));
     up.b = round_up_f((cum_pair * (1.0 + 2e-6) + err) * (1.0 + 1e-6));
     for (int r = 0; r < 3; ++r) lo.cs[r] = up.cs[r] = 0.f;
+    lo.rho_err = up.rho_err = 0.f;
   }
 }
 
@@ -1949,7 +1973,12 @@ static bool align_meshes(e3d_icp* h, float max_d, float thr, bool print, int ite
     const Cloud& src = (si == M) ? *h->fixed : *h->clouds[si];
     const Cloud& tgt = (ti == M) ? *h->fixed : *h->clouds[ti];
     const double glob = ((si == M) ? 0.0 : src.last_motion) + ((ti == M) ? 0.0 : tgt.last_motion);
-    accumulate_pair_motion(*kv.second, src, &T_before[12 * (size_t)si], src.T, &T_before[12 * (size_t)ti], tgt.T, glob);
+    if (!accumulate_pair_motion(*kv.second, src, tgt, &T_before[12 * (size_t)si], src.T, &T_before[12 * (size_t)ti], tgt.T, glob)) ++h->nn_global_bound_updates;
+  }
+  {
+    static const bool want_stats = [] { const char* e = getenv("E3D_NN_STATS"); return e && e[0] == '1'; }();
+    if (want_stats && h->nn_global_bound_updates)
+      fprintf(stderr, "[nn] %lld pose updates of a pair went into the clouds' global motion bound (a pose that is not near-rigid)\n", h->nn_global_bound_updates);
   }
   rec.t_transform_ms = t_tr.ms();
   rec.t_nn_ms = t_nn.ms();

@@ -413,10 +413,10 @@ __device__ __forceinline__ float motion_rho(const float4 q, const MotionBound& m
   return sqrtf(dx * dx + (dy * dy + dz * dz));
 }
 __device__ __forceinline__ float motion_up(const float4 q, const MotionBound& m) {
-  return (m.a * (motion_rho(q, m) * 1.000002f + 5e-5f) + m.b) * 1.000001f;
+  return (m.a * (motion_rho(q, m) * 1.000002f + m.rho_err) + m.b) * 1.000001f;
 }
 __device__ __forceinline__ float motion_lo(const float4 q, const MotionBound& m) {
-  return (m.a * fmaxf(motion_rho(q, m) * 0.999998f - 5e-5f, 0.f) + m.b) * 0.999999f;
+  return (m.a * fmaxf(motion_rho(q, m) * 0.999998f - m.rho_err, 0.f) + m.b) * 0.999999f;
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -463,8 +463,10 @@ __global__ __launch_bounds__(kBlock) void k_occ_dilate(const unsigned* __restric
 }
 
 // Keys of the queries k_nn_rows has to look at, COMPACTED: a query whose block is empty (its cell's bit in `occ` is clear, or its
-// cell lies outside the directory's range) is settled here exactly as k_nn_rows settles a query without candidates -- no partner,
-// d2 = r2, the certificate of the block's faces (the same expression, the same bits) -- and only the others are keyed for the sort.
+// cell lies outside the directory's range) is settled here as k_nn_rows settles a query without candidates -- no partner, d2 = r2,
+// the certificate of the block's faces -- and only the others are keyed for the sort.  The RESULTS (partner, distance) are those of
+// k_nn_rows; the certificate STATE need not be: k_nn_rows scores a query against every candidate of its segment's span, so its
+// bound can be min(sqrt(b2), faces) with a finite b2 where this kernel writes the faces' bound -- either is a valid lower bound.
 // list == nullptr: all n queries.  A block takes kPruneBlock queries, kPrunePerThread per thread, and reserves its stretch of the
 // output with ONE atomic (a first version with an atomic per wave on the one counter took 15 ms for 1.5 M of them).  The order of
 // the kept pairs depends on the order in which blocks reach the counter; the radix sort orders them by key and k_nn_rows treats

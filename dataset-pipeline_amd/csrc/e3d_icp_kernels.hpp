@@ -84,6 +84,8 @@ void launch_nn_cells(const float4* Gsrc, const unsigned* order, size_t n, const 
 struct MotionBound {
   float a, b;            // rounded down (the certificate's writers) or up (k_nn_certify)
   float cs[3];           // global position of the source's bounding-box centre at the current pose
+  float rho_err;         // absolute error of rho = |q - cs| as a kernel evaluates it (host: the rounding of the query's global
+                         // coordinates -- it grows with their magnitude -- and of cs), rounded up
 };
 // certificate side of k_nn_rows: lbe = min(sqrt(second smallest d2), block_dist * cell_scale - cell_sub) + motion_lo
 struct CertParams {

@@ -48,7 +48,10 @@ def _rank_device():
 def attach(icp, group=None, device=None):
     """Configure a PointToPlaneICP handle for the current process group."""
     import torch.distributed as dist
-    icp.set_shard(dist.get_rank(group), dist.get_world_size(group), make_allreduce(group, device))
+    # a group of one rank takes the unsharded path (a callback with a world of 1 is the library's "tap": every reduction of a
+    # single-rank run would make a host round trip through it for nothing -- ADVICE round 5)
+    world = dist.get_world_size(group)
+    icp.set_shard(dist.get_rank(group), world, make_allreduce(group, device) if world > 1 else None)
     return icp
 
 

@@ -56,6 +56,35 @@ class IterRecord(C.Structure):
                 ("t_nn_s", C.c_double), ("t_lm_s", C.c_double)]
 
 
+def effective_cores():
+    """CPUs this process can really use: the scheduler affinity, capped by the cgroup's CPU quota (a container on a 256-core host may
+    own a fraction of it: 256 OpenMP threads on a quota of 20 CPUs thrash instead of scaling)."""
+    import math
+    import os
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]          # cgroup v2
+        if quota != "max":
+            n = min(n, max(1, math.ceil(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())            # cgroup v1
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and per > 0:
+                n = min(n, max(1, math.ceil(q / per)))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
+
+
+def set_num_threads(n):
+    """OpenMP threads of the oracle's parallel regions from now on (libgomp's omp_set_num_threads)."""
+    lib()
+    g = C.CDLL("libgomp.so.1")
+    g.omp_set_num_threads(int(max(1, n)))
+    return int(max(1, n))
+
+
 def lib():
     global _LIB
     if _LIB is None:

@@ -926,6 +926,9 @@ __global__ __launch_bounds__(kBlock) void k_obs_mark(const unsigned* __restrict_
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n_obs) row_of_point[o_idx[i]] = (int)i;
 }
+// KT > 0: the neighbour count at compile time (round 6) -- the K neighbour indices are requested together and the K row gathers after
+// them (two round trips per observation instead of 2 K dependent ones; K = 5 is the reference's default, parameters.h:51).
+template <int KT>
 __global__ __launch_bounds__(kBlock) void k_obs_flags(const unsigned* __restrict__ o_idx, size_t n_obs,
                                                       const unsigned* __restrict__ nbr, int K,
                                                       const int* __restrict__ row_of_point, unsigned char* __restrict__ flags,
@@ -934,10 +937,21 @@ __global__ __launch_bounds__(kBlock) void k_obs_flags(const unsigned* __restrict
   if (i >= n_obs) return;
   const size_t p = o_idx[i];
   bool all = true;
-  for (int k = 0; k < K; ++k) {
-    const int r = row_of_point[nbr[p * K + k]];
-    nrow[i * K + k] = r;            // the dependent gathers are paid once per observation update, not once per pass-2 launch
-    all = all && (r >= 0);
+  if constexpr (KT > 0) {
+    unsigned nb[KT];
+    int r[KT];
+#pragma unroll
+    for (int k = 0; k < KT; ++k) nb[k] = nbr[p * KT + k];
+#pragma unroll
+    for (int k = 0; k < KT; ++k) r[k] = row_of_point[nb[k]];
+#pragma unroll
+    for (int k = 0; k < KT; ++k) { nrow[i * KT + k] = r[k]; all = all && (r[k] >= 0); }
+  } else {
+    for (int k = 0; k < K; ++k) {
+      const int r = row_of_point[nbr[p * K + k]];
+      nrow[i * K + k] = r;            // the dependent gathers are paid once per observation update, not once per pass-2 launch
+      all = all && (r >= 0);
+    }
   }
   flags[i] = all ? 1 : 0;
 }
@@ -2077,6 +2091,7 @@ __global__ __launch_bounds__(kBlock) void k_reg_cost(const float* __restrict__ i
 // ==== a23: colour update ========================================================================================================================
 // Within one image every point is observed at most once, so the per-image accumulation needs no atomics; images are
 // processed one after the other (same f32 summation order as a sequential loop over images).
+template <int KT>
 __global__ __launch_bounds__(kBlock) void k_color_accumulate(const float* __restrict__ inten, const unsigned* __restrict__ o_idx,
                                                              const unsigned char* __restrict__ flags, size_t n_obs,
                                                              const int* __restrict__ nrow, int K, float* __restrict__ desc,
@@ -2086,7 +2101,17 @@ __global__ __launch_bounds__(kBlock) void k_color_accumulate(const float* __rest
   const size_t p = o_idx[i];
   const float Ic = inten[i];
   counts[p] += 1;
-  for (int k = 0; k < K; ++k) desc[p * K + k] += inten[nrow[i * K + k]] - Ic;
+  if constexpr (KT > 0) {            // K at compile time: row indices, neighbour intensities and descriptors requested together
+    int r[KT]; float In[KT], dk[KT];
+#pragma unroll
+    for (int k = 0; k < KT; ++k) { r[k] = nrow[i * KT + k]; dk[k] = desc[p * KT + k]; }
+#pragma unroll
+    for (int k = 0; k < KT; ++k) In[k] = inten[r[k]];
+#pragma unroll
+    for (int k = 0; k < KT; ++k) desc[p * KT + k] = dk[k] + (In[k] - Ic);
+  } else {
+    for (int k = 0; k < K; ++k) desc[p * K + k] += inten[nrow[i * K + k]] - Ic;
+  }
 }
 __global__ __launch_bounds__(kBlock) void k_color_finish(size_t n, int K, float* __restrict__ desc, const int* __restrict__ counts) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2558,8 +2583,11 @@ static void finish_observations(e3d_reg* h, PointScale& S, Obs& O) {
   O.nrow.reserve(O.n * (size_t)h->prm.point_neighbor_count);
   if (O.n) {
     hipLaunchKernelGGL(k_obs_mark, dim3(nblk(O.n)), dim3(kBlock), 0, s, O.idx.p, O.n, S.row_of_point.p);
-    hipLaunchKernelGGL(k_obs_flags, dim3(nblk(O.n)), dim3(kBlock), 0, s, O.idx.p, O.n, S.nbr.p, h->prm.point_neighbor_count,
-                       S.row_of_point.p, O.flags.p, O.nrow.p);
+    if (h->prm.point_neighbor_count == 5)
+      hipLaunchKernelGGL(k_obs_flags<5>, dim3(nblk(O.n)), dim3(kBlock), 0, s, O.idx.p, O.n, S.nbr.p, 5, S.row_of_point.p, O.flags.p, O.nrow.p);
+    else
+      hipLaunchKernelGGL(k_obs_flags<0>, dim3(nblk(O.n)), dim3(kBlock), 0, s, O.idx.p, O.n, S.nbr.p, h->prm.point_neighbor_count,
+                         S.row_of_point.p, O.flags.p, O.nrow.p);
   }
   O.rows_valid = false;
 }
@@ -3545,8 +3573,11 @@ static void color_accumulate_enqueue(e3d_reg* h, int image_id, int point_scale) 
   Obs& O = get_obs(im, point_scale);
   obs_intensities(h, im, O);
   KT kt(h, "color.accumulate", (double)O.n);
-  if (O.n)
-    hipLaunchKernelGGL(k_color_accumulate, dim3(nblk(O.n)), dim3(kBlock), 0, h->stream, O.inten.p, O.idx.p, O.flags.p, O.n,
+  if (O.n && h->prm.point_neighbor_count == 5)
+    hipLaunchKernelGGL(k_color_accumulate<5>, dim3(nblk(O.n)), dim3(kBlock), 0, h->stream, O.inten.p, O.idx.p, O.flags.p, O.n,
+                       O.nrow.p, 5, S.var_desc.p, S.obs_counts.p);
+  else if (O.n)
+    hipLaunchKernelGGL(k_color_accumulate<0>, dim3(nblk(O.n)), dim3(kBlock), 0, h->stream, O.inten.p, O.idx.p, O.flags.p, O.n,
                        O.nrow.p, h->prm.point_neighbor_count, S.var_desc.p, S.obs_counts.p);
 }
 }  // namespace e3d

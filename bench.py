@@ -54,8 +54,8 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 ALG_BYTES_PER_CORR_PASS = 56   # 2 x i32 + 4 x vec3 f32 per correspondence per pass
 ALG_BYTES_PER_QUERY = 32       # 12 in + 8 out + 12 amortised target
-TRAFFIC_JSON = next((p for p in (os.path.join(ROOT, "profiles", "round%d_traffic.json" % r) for r in (5, 4, 3, 2)) if os.path.exists(p)),
-                    os.path.join(ROOT, "profiles", "round5_traffic.json"))
+TRAFFIC_JSON = next((p for p in (os.path.join(ROOT, "profiles", "round%d_traffic.json" % r) for r in (6, 5, 4, 3, 2)) if os.path.exists(p)),
+                    os.path.join(ROOT, "profiles", "round6_traffic.json"))
 
 
 def load_traffic(kernel_key):

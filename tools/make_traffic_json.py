@@ -1,13 +1,13 @@
-"""profiles/round<N>_traffic.json from the rocprofv3 PMC passes of tools/prof_round5.sh (gpurun_out/r5prof/*_fetch.txt, *_write.txt:
+"""profiles/round<N>_traffic.json from the rocprofv3 PMC passes of tools/prof_round6.sh (gpurun_out/r6prof/*_fetch.txt, *_write.txt:
 lines `kernel signature, COUNTER, value summed over the launches, launches`).
 
-    python tools/make_traffic_json.py [gpurun_out/r5prof] [profiles/round5_traffic.json]"""
+    python tools/make_traffic_json.py [gpurun_out/r6prof] [profiles/round6_traffic.json]"""
 import json
 import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-NOTE = ("HBM traffic per launch from rocprofv3 PMC, separate --pmc FETCH_SIZE and --pmc WRITE_SIZE passes (tools/prof_round5.sh): the ICP "
+NOTE = ("HBM traffic per launch from rocprofv3 PMC, separate --pmc FETCH_SIZE and --pmc WRITE_SIZE passes (tools/prof_round6.sh): the ICP "
         "kernels from `bench.py --no-cpu-baseline --no-reg --no-normals --no-allpairs --no-partial --no-whole-run --steps 6 --warmup 10` (the headline leg alone, 2 x 50 M points, iterations 0 .. 15: k_lm_pass<1> etc. from the full-size launches only), the "
         "ImageRegistrator kernels (k_reg_*, k_obs_*, k_splat_*, k_min_filter_*, k_color_*) from `bench.py --only reg --no-cpu-baseline --reg-images 4` (6048 x 4032 "
         "THIN_PRISM_FISHEYE, 10 M points: observation refreshes, accumulate passes and RunOnCurrentScale iterations), the normals "
@@ -36,8 +36,8 @@ def parse(path, counter):
 
 
 def main():
-    src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "r5prof")
-    dst = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles", "round5_traffic.json")
+    src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "r6prof")
+    dst = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles", "round6_traffic.json")
     kernels = {}
     for tag in ("icp", "reg"):
         f, w = parse(os.path.join(src, tag + "_fetch.txt"), "FETCH_SIZE"), parse(os.path.join(src, tag + "_write.txt"), "WRITE_SIZE")

@@ -1,6 +1,6 @@
 // e3d_sort.hip -- device radix sort of (cell key, point index) pairs.  The sort itself is the
-// rocPRIM library primitive (one-off per cloud: the grid is static); everything
-// on the per-iteration hot path is hand-written.
+// rocPRIM library primitive (its onesweep kernel with the gfx950 tuning).  Used at every grid build (one-off per cloud and search radius) AND on the
+// per-iteration path: once per batch of directed pairs for the far lists of the first outer iterations (e3d_icp.hip: find_pairs_multi).
 #include <cstring>
 #include <string.h>
 

@@ -101,3 +101,36 @@ def test_knn_scan_variants_agree():
     for env in ({"E3D_KNN_SINGLE": "0"}, {"E3D_KNN_SEED": "0"}, {"E3D_KNN_WIDE_SPREAD": "1"}, {"E3D_KNN_WIDE_WAVE": "0"}, {"E3D_KNN_XCD": "0"},
                 {"E3D_KNN_REP_STRIDE": "32", "E3D_KNN_REP_AVG": "1"}, {"E3D_KNN_EST": "0"}, {"E3D_KNN_EST_SCALE": "0.5"}, {"E3D_KNN_EST_SCALE": "3"}):
         assert _run(KNN_CODE, env) == base, env
+
+
+LONG_RUN_CODE = r"""
+import importlib, json, sys
+sys.path.insert(0, %r)
+e3d = importlib.import_module("dataset-pipeline_amd")
+synth = importlib.import_module("dataset-pipeline_amd.synth")
+import torch
+scans = synth.make_scene(3, 1000000, seed=5, device=torch.device("cuda", 0))
+icp = e3d.PointToPlaneICP()
+for s in scans:
+    icp.add_point_cloud(s["xyz"], s["normals"], s["T_init"], False)
+for it in range(130):
+    icp.run(0.03, it, 1, 0.0, False)          # threshold 0: never converged, the poses are re-composed 130 times
+rec = icp.iter_records()
+print("RESULT" + json.dumps({"certified_last": rec[-1]["nn_certify_queries"], "searched_last": rec[-1]["nn_search_queries"] + rec[-1]["nn_bounded_queries"],
+                             "queries_last": rec[-1]["queries"]}))
+""" % ROOT
+
+
+@pytest.mark.timeout(600)
+def test_per_query_motion_bound_survives_a_long_run():
+    """poses are re-composed in f32 every outer iteration (Tn = R * T) and never re-orthonormalised; with a fixed 4e-6
+    test of L^T L = I the per-query motion bound of the certificates silently fell back to the clouds' global bound after some dozen
+    iterations.  Now near-rigid poses scale the bound (pose_ortho_dev): over 130 iterations no pose update goes into the global bound
+    (E3D_NN_STATS reports every one that does), and in the last iteration nearly every query is still settled by its certificate."""
+    e = dict(os.environ)
+    e["E3D_NN_STATS"] = "1"
+    p = subprocess.run([sys.executable, "-c", LONG_RUN_CODE], env=e, capture_output=True, text=True, timeout=500)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert "global motion bound" not in p.stderr, [ln for ln in p.stderr.splitlines() if "global motion bound" in ln][:3]
+    r = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("RESULT")][-1][len("RESULT"):])
+    assert r["certified_last"] == r["queries_last"] and r["searched_last"] < 0.05 * r["queries_last"], r

@@ -62,11 +62,6 @@ struct Cloud {
   DevBuf<unsigned> occ27;
   unsigned occ_stride = 0;                  // 32-bit words per (y, z) row
   bool has_occ = false;
-  // per word of occ27 the number of set bits in front of it, and their total: the rank of a cell among the cells whose block holds a
-  // point is the bin of the far lists' counting sort (k_query_bins_multi)
-  DevBuf<unsigned> occ_prefix;
-  unsigned occ_bits = 0;
-  bool has_occ_prefix = false;
   GridDesc grid{};
   QueryRange qrange{};              // target-cell range a query needs to hit to have candidates
   unsigned n_cells = 0;             // occupied cells
@@ -265,8 +260,6 @@ struct e3d_icp {
   std::map<std::pair<int, int>, std::unique_ptr<PairState>> pair_state;
   PinBuf<unsigned> h_todo;
   DevBuf<unsigned> todo_near, todo_far;         // queries the certificates did not settle (per search; shared by all pairs)
-  DevBuf<unsigned> far_bins, far_bin_index, far_pair_off;   // counting sort of a batch's far lists: bins, the pairs' first bins, their offsets after the scan
-  PinBuf<unsigned> h_far_bin_index, h_far_pair_off;
   DevBuf<unsigned> prune_count;                 // number of (key, query) pairs k_query_keys_prune kept
   PinBuf<unsigned> h_prune_count;
   size_t last_corr_total = 0;                   // correspondences of the previous outer iteration (sizes the planes)
@@ -452,22 +445,6 @@ static void build_grid(e3d_icp* h, Cloud& c, float d) {
     } catch (const Error&) { (void)hipGetLastError(); }
   }
   if (!c.has_occ) c.occ27.release();
-  c.has_occ_prefix = false;
-  if (c.has_occ) {
-    const size_t words = (size_t)c.qrange.D[2] * c.qrange.D[1] * c.occ_stride;
-    try {
-      c.occ_prefix.reserve(words + 1);
-      launch_occ_prefix(c.occ27.p, words, c.occ_prefix.p, s);
-      E3D_HIP(hipMemsetAsync(c.occ_prefix.p + words, 0, sizeof(unsigned), s));
-      exclusive_sum_scan_u32(c.occ_prefix.p, words + 1, h->sort_temp, s);       // [words] = the number of set bits
-      unsigned total = 0;
-      copy_out(&total, c.occ_prefix.p + words, sizeof(unsigned), s);
-      sync(h);
-      c.occ_bits = total;
-      c.has_occ_prefix = true;
-    } catch (const Error&) { (void)hipGetLastError(); }
-  }
-  if (!c.has_occ_prefix) c.occ_prefix.release();
   c.grid_valid = true;
   c.grid_radius = d;
   std::memcpy(c.grid_T, c.T, sizeof c.grid_T);
@@ -1307,72 +1284,7 @@ static bool find_pairs_multi(e3d_icp* h, std::vector<BatchItem>& items, float d,
   while (((size_t)1 << pair_bits) < B) ++pair_bits;
   // (a batch whose keys would need 12-byte pairs only because of the pair bits keeps the 8-byte pairs of the pair-by-pair path)
   const bool far_multi = far_batch && far_pairs > 0 && (kb_max + pair_bits <= 32 || kb_max > 31) && kb_max + pair_bits <= 63;
-  // Counting sort instead of the radix sort (round 6; E3D_NN_FAR_COUNT=0: radix): the bin of a query is the rank of its target cell
-  // among the cells whose 27-cell block holds a point -- occupancy bits + prefix counts, both built with the grid -- so the bins of a
-  // pair are as many as those cells (12 M for a 50 M-point scan at 1 cm), not the directory's 10^9.  Two passes over the lists
-  // (count / settle, scatter) with one atomic per kept query each and a scan of the bins between them replace the compacting key
-  // kernel and four radix passes over 8-byte pairs.
-  static const bool far_count = [] { const char* e = getenv("E3D_NN_FAR_COUNT"); return !(e && e[0] == '0'); }();
-  bool far_counting = far_batch && far_pairs > 0 && far_count;
-  size_t total_bins = 0;
-  for (size_t i = 0; i < B && far_counting; ++i)
-    if (items[i].n_far > 0) {
-      if (!items[i].tgt->has_occ_prefix) far_counting = false;
-      total_bins += (size_t)items[i].tgt->occ_bits + 1;
-    }
-  if (total_bins >= ((size_t)1 << 32) || far_total >= ((size_t)1 << 32)) far_counting = false;
-  if (far_counting) {
-    unsigned key_blocks = 0, bin = 0;
-    h->h_far_bin_index.reserve(kPairBatch + 1); h->far_bin_index.reserve(kPairBatch + 1);
-    h->h_far_pair_off.reserve(kPairBatch + 1); h->far_pair_off.reserve(kPairBatch + 1);
-    for (size_t i = 0; i < B; ++i) {
-      BatchItem& it = items[i];
-      NnPairDev& P = T.pair[i];
-      P.far_n = 0; P.far_list = nullptr; P.far_flags = 0; P.occ = nullptr; P.occ_stride = 0; P.rows_off = 0; P.rows_n = 0; P.occ_prefix = nullptr;
-      P.bin_base = bin;
-      h->h_far_bin_index.p[i] = bin;
-      if (it.n_far > 0) {
-        P.far_n = (unsigned)it.n_far;
-        P.far_list = it.certified ? h->slots[i]->todo_far.p : nullptr;
-        P.far_flags = ((it.from_state && !it.certified) ? 1 : 0) | 2;
-        P.occ = it.tgt->occ27.p; P.occ_stride = it.tgt->occ_stride; P.occ_prefix = it.tgt->occ_prefix.p;
-        key_blocks += (unsigned)div_up(it.n_far, (size_t)kQueryKeysBlock);
-        bin += it.tgt->occ_bits + 1;
-      }
-      T.far_end[i] = key_blocks;
-    }
-    h->h_far_bin_index.p[B] = bin;
-    h->far_bins.reserve((size_t)bin + 1); h->vals_b.reserve(far_total);
-    E3D_HIP(hipMemcpyAsync(h->d_batch.p, h->h_batch.p, sizeof(NnBatchDev), hipMemcpyHostToDevice, s));
-    E3D_HIP(hipMemcpyAsync(h->far_bin_index.p, h->h_far_bin_index.p, sizeof(unsigned) * (B + 1), hipMemcpyHostToDevice, s));
-    h->tm_sort.start(s);
-    E3D_HIP(hipMemsetAsync(h->far_bins.p, 0, sizeof(unsigned) * ((size_t)bin + 1), s));
-    launch_query_bins_multi(0, h->d_batch.p, key_blocks, radius_sq(d), h->far_bins.p, h->vals_b.p, s);
-    exclusive_sum_scan_u32(h->far_bins.p, (size_t)bin + 1, h->sort_temp, s);
-    launch_gather_u32(h->far_bins.p, h->far_bin_index.p, (int)B + 1, h->far_pair_off.p, s);
-    copy_out(h->h_far_pair_off.p, h->far_pair_off.p, sizeof(unsigned) * (B + 1), s);
-    launch_query_bins_multi(1, h->d_batch.p, key_blocks, radius_sq(d), h->far_bins.p, h->vals_b.p, s);
-    h->tm_sort.stop(s);
-    sync(h);
-    unsigned row_blocks = 0;
-    const size_t kept_total = h->h_far_pair_off.p[B];
-    for (size_t i = 0; i < B; ++i) {
-      NnPairDev& P = T.pair[i];
-      const unsigned kept = h->h_far_pair_off.p[i + 1] - h->h_far_pair_off.p[i];
-      P.rows_off = h->h_far_pair_off.p[i]; P.rows_n = kept;
-      row_blocks += (unsigned)div_up((size_t)kept, kBlock);
-      T.rows_end[i] = row_blocks;
-      if (kept > 0) rec.nn_search_queries += (long long)kept;
-    }
-    rec.nn_kernel_launches += 2; rec.nn_sort_calls++;
-    E3D_HIP(hipMemcpyAsync(h->d_batch.p, h->h_batch.p, sizeof(NnBatchDev), hipMemcpyHostToDevice, s));
-    if (kept_total > 0) {
-      h->tm_search.start(s);
-      launch_nn_rows_multi(h->d_batch.p, row_blocks, h->vals_b.p, radius_sq(d), s);
-      h->tm_search.stop(s);
-      rec.nn_search_launches++; rec.nn_kernel_launches++;
-    }
-  } else if (far_multi) {
+  if (far_multi) {
     const bool k32 = kb_max + pair_bits <= 32;
     unsigned key_blocks = 0;
     for (size_t i = 0; i < B; ++i) {
@@ -1427,7 +1339,7 @@ static bool find_pairs_multi(e3d_icp* h, std::vector<BatchItem>& items, float d,
   for (size_t i = 0; i < B; ++i) {
     BatchItem& it = items[i];
     PairState& ps = *it.ps;
-    if (it.n_far > 0 && !far_multi && !far_counting) {
+    if (it.n_far > 0 && !far_multi) {
       e3d_icp::PairSlot& sl = *h->slots[i];
       const float4* srcG = it.src->G4.p + it.j0;
       const size_t n_rows = sort_query_keys_pruned(h, ps, *it.tgt, srcG, it.certified ? sl.todo_far.p : nullptr, it.n_far, it.im, radius_sq(d), it.cert, sl.match_d2.p, it.from_state);

@@ -1865,90 +1865,6 @@ __global__ __launch_bounds__(kBlock) void k_query_keys_multi(const NnBatchDev* _
                               (flags & 2) != 0, P.match, P.match2, P.match_d2, P.lbe, flags & 1);
 }
 
-// Counting sort of the far lists (round 6; see launch_query_bins_multi).  PASS 0 counts (and settles the queries whose block is empty,
-// exactly as query_keys_prune_body does); PASS 1, after the exclusive scan of the bins, writes the list entries in bin order.
-constexpr int kBinsPerThread = 8, kBinsBlock = kBlock * kBinsPerThread;
-static_assert((unsigned)kBinsBlock == kQueryKeysBlock, "queries per block of the key kernels");
-template <int PASS>
-__global__ __launch_bounds__(kBlock) void k_query_bins_multi(const NnBatchDev* __restrict__ B, float r2, unsigned* __restrict__ bins,
-                                                             unsigned* __restrict__ order) {
-  const int p = nn_find_range(B->far_end, B->n_pairs, blockIdx.x);
-  const unsigned bx = blockIdx.x - (p ? B->far_end[p - 1] : 0u);
-  const NnPairDev& P = B->pair[p];
-  const GridDesc g = P.g; const InvMap im = P.im; const QueryRange qr = P.qr;
-  const CertParams cert = {P.bp.cell_scale, P.bp.cell_sub, P.bp.lo};
-  const unsigned* __restrict__ list = P.far_list;
-  const unsigned* __restrict__ occ = P.occ;
-  const unsigned* __restrict__ prefix = P.occ_prefix;
-  const unsigned stride_w = P.occ_stride, bin_base = P.bin_base;
-  const size_t n = (size_t)P.far_n;
-  const int from_state = __builtin_amdgcn_readfirstlane(P.far_flags) & 1;
-  const float4* __restrict__ Gsrc = P.Gsrc;
-  int* __restrict__ match = P.match; int* __restrict__ match2 = P.match2;
-  float* __restrict__ match_d2 = P.match_d2; float* __restrict__ lbe = P.lbe;
-  const size_t i0 = (size_t)bx * kBinsBlock + threadIdx.x;          // step u: + u * kBlock
-  unsigned jf[kBinsPerThread];
-  float4 qq[kBinsPerThread];
-#pragma unroll
-  for (int u = 0; u < kBinsPerThread; ++u) {
-    const size_t i = i0 + (size_t)u * kBlock;
-    jf[u] = (i < n) ? (list ? list[i] : ((unsigned)i | ((from_state && match[i] < 0) ? kListNoPartner : 0u))) : 0u;
-  }
-#pragma unroll
-  for (int u = 0; u < kBinsPerThread; ++u) qq[u] = Gsrc[jf[u] & kListIndexMask];
-  unsigned wordv[kBinsPerThread], prev[kBinsPerThread];
-  int bitv[kBinsPerThread];
-  float bdist[kBinsPerThread];
-#pragma unroll
-  for (int u = 0; u < kBinsPerThread; ++u) {
-    int cx = 0, cy = 0, cz = 0;
-    bdist[u] = 2.0f;
-    const unsigned long long key = query_cell_key(qq[u], im, g, qr, cx, cy, cz, &bdist[u]);
-    wordv[u] = 0u; prev[u] = 0u; bitv[u] = -1;
-    if (key != kEmptyKey) {
-      const int kx = cx - qr.lo[0], ky = cy - qr.lo[1], kz = cz - qr.lo[2];
-      const size_t w = ((size_t)kz * qr.D[1] + (size_t)ky) * stride_w + (size_t)(kx >> 5);
-      wordv[u] = occ[w];
-      prev[u] = prefix[w];
-      bitv[u] = kx & 31;
-    } else {
-      bdist[u] = 2.0f;
-    }
-  }
-#pragma unroll
-  for (int u = 0; u < kBinsPerThread; ++u) {
-    const size_t i = i0 + (size_t)u * kBlock;
-    const bool valid = i < n;
-    const bool keep = valid && bitv[u] >= 0 && ((wordv[u] >> bitv[u]) & 1u);
-    const unsigned j = jf[u] & kListIndexMask;
-    const unsigned bin = bin_base + prev[u] + (unsigned)__popc(wordv[u] & ((1u << (bitv[u] & 31)) - 1u));
-    if constexpr (PASS == 0) {
-      if (valid && from_state && (jf[u] & kListNoPartner)) match_d2[j] = r2;
-      if (valid && !keep) {
-        if (!(jf[u] & kListNoPartner)) {
-          match[j] = -1; match_d2[j] = r2;
-          if (match2) match2[j] = -1;
-        }
-        const float kInf = __uint_as_float(0x7f800000u);
-        const float lb_out = bdist[u] * cert.cell_scale - cert.cell_sub;
-        lbe[j] = fmaxf(fminf(sqrtf(kInf), lb_out), 0.0f) * 0.999999f + motion_lo(qq[u], cert.lo);
-      }
-      if (keep) atomicAdd(&bins[bin], 1u);
-    } else {
-      if (keep) order[atomicAdd(&bins[bin], 1u)] = jf[u];
-    }
-  }
-}
-
-__global__ __launch_bounds__(kBlock) void k_occ_popc(const unsigned* __restrict__ occ, size_t words, unsigned* __restrict__ out) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < words) out[i] = (unsigned)__popc(occ[i]);
-}
-__global__ void k_gather_u32(const unsigned* __restrict__ src, const unsigned* __restrict__ index, int n, unsigned* __restrict__ out) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = src[index[i]];
-}
-
 __global__ __launch_bounds__(kBlock, 6) void k_nn_rows_multi(const NnBatchDev* __restrict__ B, const unsigned* __restrict__ order, float r2, int row_span) {
   const int p = nn_find_range(B->rows_end, B->n_pairs, blockIdx.x);
   const unsigned bx = blockIdx.x - (p ? B->rows_end[p - 1] : 0u);
@@ -3108,19 +3024,6 @@ void launch_query_keys_multi(bool keys32, const NnBatchDev* batch, unsigned n_bl
   if (!n_blocks) return;
   if (keys32) hipLaunchKernelGGL(k_query_keys_multi<unsigned>, dim3(n_blocks), dim3(kBlock), 0, s, batch, r2, (unsigned*)keys, vals, counts);
   else hipLaunchKernelGGL(k_query_keys_multi<unsigned long long>, dim3(n_blocks), dim3(kBlock), 0, s, batch, r2, (unsigned long long*)keys, vals, counts);
-}
-void launch_occ_prefix(const unsigned* occ, size_t words, unsigned* prefix, hipStream_t s) {
-  if (!words) return;
-  hipLaunchKernelGGL(k_occ_popc, dim3((unsigned)div_up(words, kBlock)), dim3(kBlock), 0, s, occ, words, prefix);
-}
-void launch_query_bins_multi(int pass, const NnBatchDev* batch, unsigned n_blocks, float r2, unsigned* bins, unsigned* order, hipStream_t s) {
-  if (!n_blocks) return;
-  if (pass == 0) hipLaunchKernelGGL(k_query_bins_multi<0>, dim3(n_blocks), dim3(kBlock), 0, s, batch, r2, bins, order);
-  else hipLaunchKernelGGL(k_query_bins_multi<1>, dim3(n_blocks), dim3(kBlock), 0, s, batch, r2, bins, order);
-}
-void launch_gather_u32(const unsigned* src, const unsigned* index, int n, unsigned* out, hipStream_t s) {
-  if (n <= 0) return;
-  hipLaunchKernelGGL(k_gather_u32, dim3((unsigned)div_up((size_t)n, (size_t)64)), dim3(64), 0, s, src, index, n, out);
 }
 void launch_nn_rows_multi(const NnBatchDev* batch, unsigned n_blocks, const unsigned* order, float r2, hipStream_t s) {
   if (!n_blocks) return;

@@ -158,9 +158,6 @@ struct NnPairDev {
   unsigned far_n, occ_stride;
   int far_flags;                   // bit 0: flags "had no partner" come from the state (list == nullptr), bit 1: settle the queries of empty blocks
   unsigned rows_off, rows_n;       // the pair's stretch of the batch's sorted (key, query) array
-  // counting sort of the far lists (k_query_bins_multi): a bin per target cell whose 27-cell block holds a point
-  const unsigned* occ_prefix;      // per word of `occ`: the number of set bits in front of it
-  unsigned bin_base;               // first bin of this pair in the batch's bin array
 };
 constexpr unsigned kQueryKeysBlock = 2048;   // queries per block of the compacting key kernels
 struct NnBatchDev {
@@ -182,15 +179,6 @@ void launch_nn_bounded_half_multi(const NnBatchDev* batch, unsigned n_blocks, fl
 // far lists of a batch: counts[0] = (key, query) pairs written by all pairs, counts[1 + p] = by pair p (cleared by the caller)
 void launch_query_keys_multi(bool keys32, const NnBatchDev* batch, unsigned n_blocks, float r2, void* keys, unsigned* vals, unsigned* counts, hipStream_t s);
 void launch_nn_rows_multi(const NnBatchDev* batch, unsigned n_blocks, const unsigned* order, float r2, hipStream_t s);
-// Counting sort of a batch's far lists by target cell (round 6).  A query's bin = the rank of its target cell among the cells whose
-// 27-cell block holds a point (occupancy bits + their prefix counts: one more load than the pruning key kernel makes), offset by the
-// pair's bin_base.  pass 0: bins[bin] += 1, queries of empty blocks settled as by launch_query_keys_prune; then an exclusive scan of
-// the bins; pass 1: order[bins[bin]++] = list entry.  The order inside a bin (= inside a target cell) depends on the atomics' order;
-// k_nn_rows treats every query on its own, so results do not.  pair_off[p] = bins[pair p's bin_base] after the scan (n_pairs + 1 values).
-void launch_occ_prefix(const unsigned* occ, size_t words, unsigned* prefix, hipStream_t s);   // popcounts; the caller scans them
-void launch_query_bins_multi(int pass, const NnBatchDev* batch, unsigned n_blocks, float r2, unsigned* bins, unsigned* order, hipStream_t s);
-void launch_gather_u32(const unsigned* src, const unsigned* index, int n, unsigned* out, hipStream_t s);
-void exclusive_sum_scan_u32(unsigned* data, size_t n, DevBuf<char>& temp, hipStream_t s);
 void launch_corr_update_multi(const NnBatchDev* batch, unsigned n_blocks, unsigned* block_counts, double* block_d2, unsigned* block_groups, hipStream_t s);
 // totals[3 p ..] = correspondences, active groups, rows rewritten of pair p; total_d2[p]; the pairs' group lists (three launches)
 void launch_corr_totals_multi(const NnBatchDev* batch, int n_pairs, unsigned n_chunks, const unsigned* block_counts, const double* block_d2,

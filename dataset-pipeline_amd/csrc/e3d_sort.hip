@@ -36,12 +36,4 @@ void exclusive_max_scan_u32(unsigned* data, size_t n, DevBuf<char>& temp, hipStr
   E3D_HIP(rocprim::exclusive_scan(temp.p, bytes, data, data, 0u, n, rocprim::maximum<unsigned>(), s));
 }
 
-void exclusive_sum_scan_u32(unsigned* data, size_t n, DevBuf<char>& temp, hipStream_t s) {
-  if (n == 0) return;
-  size_t bytes = 0;
-  E3D_HIP(rocprim::exclusive_scan(nullptr, bytes, data, data, 0u, n, rocprim::plus<unsigned>(), s));
-  temp.reserve(bytes);
-  E3D_HIP(rocprim::exclusive_scan(temp.p, bytes, data, data, 0u, n, rocprim::plus<unsigned>(), s));
-}
-
 }  // namespace e3d

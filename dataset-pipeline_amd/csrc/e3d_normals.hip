@@ -148,7 +148,15 @@ __global__ __launch_bounds__(256) void k_dense_directory(const unsigned* __restr
   const unsigned lb0 = coarse[blockIdx.x], lb1 = coarse[blockIdx.x + 1];
   const unsigned cnt = (unsigned)min((size_t)kDirTile, n_entries - c0);
   if (lb0 == lb1) {                                                      // no point in the tile (most tiles)
-    for (unsigned i = tid; i < cnt; i += 256) S[c0 + i] = lb1;
+    if (cnt == kDirTile) {                                               // whole tile: 16-byte stores (the tile starts on a 16 KB boundary of S)
+      typedef unsigned u4_t __attribute__((ext_vector_type(4)));
+      u4_t* __restrict__ S4 = reinterpret_cast<u4_t*>(S + c0);
+      const u4_t v = {lb1, lb1, lb1, lb1};
+#pragma unroll
+      for (unsigned i = tid; i < kDirTile / 4; i += 256) S4[i] = v;
+    } else {
+      for (unsigned i = tid; i < cnt; i += 256) S[c0 + i] = lb1;
+    }
     return;
   }
   // the occupied cells' starts: a tile with few points (a scan's surfaces: a few hundred) finds them in its stretch of the sorted

@@ -78,6 +78,12 @@ struct Cloud {
   // impl cloud 0 never moves, fixed clouds never do -- is not transformed again
   bool G4_valid = false;
   float G4_T[12];
+  // per-pose quantities every directed pair with this cloud as target asks for (an all-pairs job asks 15 times per outer iteration:
+  // the Jacobi sweeps and the inversion were 0.1 ms of host time per batch of 32 pairs)
+  mutable bool pose_cache_valid = false;
+  mutable float pose_cache_T[12];
+  mutable double pose_cache_smin = 0.0;
+  mutable InvMap pose_cache_im;
 };
 
 // per-query state of a directed pair, kept from one outer iteration to the next (source order): partner position, certificate
@@ -458,7 +464,17 @@ static bool grid_usable(const Cloud& c, float d) {
   return std::fabs(s0 - s1) <= 1e-4 * std::max(s0, 1e-30);
 }
 
-static InvMap make_invmap(const Cloud& c) {
+static InvMap make_invmap_uncached(const Cloud& c);
+static void refresh_pose_cache(const Cloud& c) {
+  if (c.pose_cache_valid && std::memcmp(c.pose_cache_T, c.T, sizeof c.T) == 0) return;
+  c.pose_cache_smin = min_singular_value_3x3(c.T);
+  c.pose_cache_im = make_invmap_uncached(c);
+  std::memcpy(c.pose_cache_T, c.T, sizeof c.T);
+  c.pose_cache_valid = true;
+}
+static double cloud_smin(const Cloud& c) { refresh_pose_cache(c); return c.pose_cache_smin; }
+static InvMap make_invmap(const Cloud& c) { refresh_pose_cache(c); return c.pose_cache_im; }
+static InvMap make_invmap_uncached(const Cloud& c) {
   InvMap im;
   double Linv[9];
   if (!invert_3x3(c.T, Linv)) { for (int i = 0; i < 9; ++i) Linv[i] = (i % 4 == 0) ? 1.0 : 0.0; }
@@ -659,7 +675,7 @@ static void pair_motion_bounds(const PairState& ps, const Cloud& src, const Clou
 // certificate constants of k_nn_rows for a target at its current pose
 static CertParams make_cert_params(const Cloud& tgt, const MotionBound& lo) {
   CertParams cp;
-  double smin = min_singular_value_3x3(tgt.T);
+  double smin = cloud_smin(tgt);
   if (!(smin > 0)) smin = 0;
   const double cell = 1.0 / (double)tgt.grid.inv_cell;
   double extent = 0;
@@ -840,7 +856,7 @@ static void find_pair(e3d_icp* h, Cloud& src, Cloud& tgt, float d, PairJob& job,
       h->tm_bounded.start(s);                             // (read lazily: timing the bounded search costs no synchronisation)
       list = h->todo_far.p;
       // old partner close by: only the cells its distance (+ margin) reaches, one thread per query, no sort
-      double smin = min_singular_value_3x3(tgt.T);
+      double smin = cloud_smin(tgt);
       if (!(smin > 1e-12)) smin = 1e-12;
       double m_local = 0;
       for (int k = 0; k < 3; ++k) m_local = std::max(m_local, std::max(std::fabs((double)tgt.lmin[k]), std::fabs((double)tgt.lmax[k])));
@@ -1048,7 +1064,7 @@ static void find_pairs_batched(e3d_icp* h, std::vector<BatchItem>& items, float 
     h->tm_certify.stop(s);
     copy_out(h->h_todo_all.p + 2 * i, ps.todo_count.p, 2 * sizeof(unsigned), s);
     rec.nn_certify_launches++; rec.nn_certify_queries += (long long)it.n; rec.nn_kernel_launches++;
-    double smin = min_singular_value_3x3(tgt.T);
+    double smin = cloud_smin(tgt);
     if (!(smin > 1e-12)) smin = 1e-12;
     double m_local = 0;
     for (int k = 0; k < 3; ++k) m_local = std::max(m_local, std::max(std::fabs((double)tgt.lmin[k]), std::fabs((double)tgt.lmax[k])));
@@ -1187,7 +1203,7 @@ static bool find_pairs_multi(e3d_icp* h, std::vector<BatchItem>& items, float d,
     it.certified = !ps.fresh && use_cert && certify_now(ps, src, tgt);
     it.from_state = !ps.fresh && use_cert && !it.certified;
     const bool none_near = np_frac > 0 && (src.last_motion + tgt.last_motion) < np_gate * (double)d;
-    double smin = min_singular_value_3x3(tgt.T);
+    double smin = cloud_smin(tgt);
     if (!(smin > 1e-12)) smin = 1e-12;
     double m_local = 0;
     for (int k = 0; k < 3; ++k) m_local = std::max(m_local, std::max(std::fabs((double)tgt.lmin[k]), std::fabs((double)tgt.lmax[k])));

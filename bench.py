@@ -584,10 +584,18 @@ def leg_allpairs(e3d, synth, R, args, dev):
         icp8.clear_records()
         torch.cuda.synchronize()
         each8 = []
-        for it in range(warmup, warmup + steps):
-            t1 = time.perf_counter()
-            icp8.run(d, it, 1, thr, False)
-            each8.append((time.perf_counter() - t1) * 1e3)
+        # (the replay callback is Python: one generation-2 garbage collection inside it cost 35 - 47 ms of one iteration in three of
+        # five sessions -- E3D_LM_PROFILE=1 showed a single callback of that length; a real rank's all-reduce is RCCL, not Python)
+        import gc
+        gc.collect()
+        gc.disable()
+        try:
+            for it in range(warmup, warmup + steps):
+                t1 = time.perf_counter()
+                icp8.run(d, it, 1, thr, False)
+                each8.append((time.perf_counter() - t1) * 1e3)
+        finally:
+            gc.enable()
         same = all(np.array_equal(icp8.get_result_global_T_cloud(i), poses_a[i]) for i in range(S)) and pos[0] == len(tape)
         rec8 = icp8.iter_records()
         t1_ms, t8_ms = float(np.mean(wall)), float(np.mean(each8))

@@ -757,8 +757,8 @@ static size_t sort_query_keys_pruned(e3d_icp* h, PairState& ps, const Cloud& tgt
   const size_t kept = h->h_prune_count.p[0];
   if ((double)kept > 0.9 * (double)n) ps.prune = false;
   if (kept == 0) return 0;
-  if (k32) sort_pairs_u32_u32(reinterpret_cast<unsigned*>(h->keys_a.p), reinterpret_cast<unsigned*>(h->keys_b.p), h->vals_a.p, h->vals_b.p, kept, tgt.key_bits, h->sort_temp, s);
-  else sort_pairs_u64_u32(h->keys_a.p, h->keys_b.p, h->vals_a.p, h->vals_b.p, kept, tgt.key_bits, h->sort_temp, s);
+  if (k32) sort_pairs_u32_u32(reinterpret_cast<unsigned*>(h->keys_a.p), reinterpret_cast<unsigned*>(h->keys_b.p), h->vals_a.p, h->vals_b.p, kept, tgt.key_bits, h->sort_temp, s, n);
+  else sort_pairs_u64_u32(h->keys_a.p, h->keys_b.p, h->vals_a.p, h->vals_b.p, kept, tgt.key_bits, h->sort_temp, s, n);
   return kept;
 }
 
@@ -1339,8 +1339,9 @@ static bool find_pairs_multi(e3d_icp* h, std::vector<BatchItem>& items, float d,
       if (kept > 0) rec.nn_search_queries += (long long)kept;
     }
     if (kept_total > 0) {
-      if (k32) sort_pairs_u32_u32(reinterpret_cast<unsigned*>(h->keys_a.p), reinterpret_cast<unsigned*>(h->keys_b.p), h->vals_a.p, h->vals_b.p, kept_total, kb_max + pair_bits, h->sort_temp, s);
-      else sort_pairs_u64_u32(h->keys_a.p, h->keys_b.p, h->vals_a.p, h->vals_b.p, kept_total, kb_max + pair_bits, h->sort_temp, s);
+      // (the temporary storage for the lists' whole length: the kept count grows from one outer iteration to the next, e3d_sort.hip)
+      if (k32) sort_pairs_u32_u32(reinterpret_cast<unsigned*>(h->keys_a.p), reinterpret_cast<unsigned*>(h->keys_b.p), h->vals_a.p, h->vals_b.p, kept_total, kb_max + pair_bits, h->sort_temp, s, far_total);
+      else sort_pairs_u64_u32(h->keys_a.p, h->keys_b.p, h->vals_a.p, h->vals_b.p, kept_total, kb_max + pair_bits, h->sort_temp, s, far_total);
     }
     h->tm_sort.stop(s);
     rec.nn_kernel_launches++; rec.nn_sort_calls++;

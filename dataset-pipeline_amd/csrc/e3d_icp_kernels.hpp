@@ -197,8 +197,9 @@ void launch_nn_mfma(const float4* Gsrc, const unsigned* order, size_t n, const f
                     float* match_d2, hipStream_t s);
 int nn_row_span();
 void launch_dense_counts(const unsigned long long* keys, size_t n, const QueryRange& qr, unsigned* counts, hipStream_t s);
+// n_reserve: the temporary storage is sized for a sort of that many elements (a later sort of the same arrays; 0: for n)
 void sort_pairs_u32_u32(unsigned* keys_in, unsigned* keys_out, unsigned* vals_in, unsigned* vals_out, size_t n,
-                        int end_bit, DevBuf<char>& temp, hipStream_t s);
+                        int end_bit, DevBuf<char>& temp, hipStream_t s, size_t n_reserve = 0);
 // in-place exclusive MAX scan of n unsigned values (rocPRIM, e3d_sort.hip); one-off per grid build
 void exclusive_max_scan_u32(unsigned* data, size_t n, DevBuf<char>& temp, hipStream_t s);
 void launch_compact_corr(const int* match_pos, const unsigned* order, size_t n, const unsigned* block_offsets, const float4* Gsrc,
@@ -228,6 +229,6 @@ void launch_lm_reduce(const double* partial, const LmSet* sets, int n_sets, int 
 
 // radix sort of (cell key, point index) pairs -- rocPRIM device primitive (e3d_sort.hip)
 void sort_pairs_u64_u32(unsigned long long* keys_in, unsigned long long* keys_out, unsigned* vals_in,
-                        unsigned* vals_out, size_t n, int end_bit, DevBuf<char>& temp, hipStream_t s);
+                        unsigned* vals_out, size_t n, int end_bit, DevBuf<char>& temp, hipStream_t s, size_t n_reserve = 0);
 
 }  // namespace e3d

@@ -366,7 +366,8 @@ def icp_kernel_table(tot, world, K, pairs, moved_points, lm_kernel_name="k_lm_pa
                 "algorithmic_bytes_per_launch": by, "GBs": by / (avg * 1e-3) / 1e9 if avg > 0 else None}
     kernels["k_nn_certify"] = nn_kernel("partner of the last search still the unique nearest neighbour? (one gather per query, a5)", tot[10] / world, tot[11] / world, tot[12] / world)
     kernels["k_nn_bounded"] = nn_kernel("k_nn_bounded_half: exact search inside the ball of the old partner's distance over the half-cell directory, one thread per "
-                                        "listed query (a5); bound by the latency and issue rate of its candidate gathers, not by its 32 algorithmic bytes", tot[13] / world, tot[14] / world, tot[15] / world)
+                                        "listed query (a5); bound by the latency and issue rate of its candidate gathers, not by its 32 algorithmic bytes",
+                                        tot[13] / world, tot[14] / world, tot[15] / world)
     kernels["k_nn_rows"] = nn_kernel("exact search of the remaining queries, sorted by target cell, LDS-staged candidate rows (a5)", tot[16] / world, tot[17] / world, tot[18] / world)
 
     def stream_kernel(what, t_ms, launches, bytes_per_launch):
@@ -686,11 +687,13 @@ def leg_image_registrator(e3d, synth, args, dev):
         "intensity.sample": (24.0, "observation: 12 B position + 8 texels + 4 B out", "texel gathers"),
         "intensity.scatter": (16.0, "observation: 4 B index + 4 B value + 4 B scattered store + 4 B of the cleared point array", "hbm (scatter)"),
         "cost": (13.0 + 16.0 * K, "observation: index, flag, intensity, count + K x (neighbour index, neighbour intensity gather, fixed + variable descriptor)", "4 B gathers at random points"),
-        "color.accumulate": (17.0 + 16.0 * K, "observation: as cost, with the K variable descriptors added in place (read-modify-write; a point occurs once per image, no atomics)", "4 B gathers at random points + read-modify-write"),
+        "color.accumulate": (17.0 + 16.0 * K, "observation: as cost, with the K variable descriptors added in place (read-modify-write; a point occurs once per image, "
+                                              "no atomics)", "4 B gathers at random points + read-modify-write"),
         "color.finish": (4.0 + 8.0 * K, "point: K descriptors divided by the count, in place", "hbm"),
         "color.clear": (4.0 + 4.0 * K, "point: descriptors + count cleared", "hbm"),
         "accumulate.pass1": (24.0 + 12.0 + 8.0 + 4.0 * (I + 7), "observation: SURVEY 8(d)", "issue: Jacobians of the projection (f64 elementary functions)"),
-        "accumulate.pass2": ((8.0 * K + 4.0 * K + 4.0 * (K + 1) * (I + 7)) / 2.0 * (res_per_launch / max(n_obs, 1.0)), "observation: SURVEY 8(d)'s bytes per residual pair x pairs per observation", "matrix-core issue; rows of the K neighbours are L2 hits"),
+        "accumulate.pass2": ((8.0 * K + 4.0 * K + 4.0 * (K + 1) * (I + 7)) / 2.0 * (res_per_launch / max(n_obs, 1.0)),
+                             "observation: SURVEY 8(d)'s bytes per residual pair x pairs per observation", "matrix-core issue; rows of the K neighbours are L2 hits"),
     }
     # the kernels behind a group in the committed counter passes (profiles/round<N>_traffic.json: HBM bytes per launch; a 4-image run
     # of this same leg, so per-launch figures carry over)
@@ -1043,7 +1046,9 @@ def compact_line(d, detail_path="bench_detail.json"):
     if g:
         rf2 = g.get("roofline", {})
         p2 = next((v for k, v in rf2.items() if k.startswith("k_reg_pass2")), {})
-        lg = {"metric": g.get("metric"), "value": _r(g.get("value")), "unit": g.get("unit"), "dtype": "f32 rows; H, b: f32 chains added into f64 (opt-in, narrower)" if "NARROWER" in str(g.get("dtype", "")) else "f32 rows; H, b: exact products, f64 sums",
+        narrow = "NARROWER" in str(g.get("dtype", ""))
+        lg = {"metric": g.get("metric"), "value": _r(g.get("value")), "unit": g.get("unit"),
+              "dtype": "f32 rows; H, b: f32 chains added into f64 (opt-in, narrower)" if narrow else "f32 rows; H, b: exact products, f64 sums",
               "workload": str(g.get("config", {}).get("workload", "")).split(" (BASELINE")[0], "accumulate_ms_all_images": _r(g.get("accumulate_ms_all_images")),
               "ms_per_run_iteration": _r(g.get("ms_per_run_iteration")), "pass1_frac": _r(rf2.get("k_reg_pass1", {}).get("frac")),
               "pass2_kernel": next((k for k in rf2 if k.startswith("k_reg_pass2")), None), "pass2_avg_launch_ms": _r(p2.get("avg_launch_ms")), "pass2_frac": _r(p2.get("frac"))}

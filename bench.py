@@ -403,6 +403,8 @@ def leg_terrace(e3d, synth, R, args, dev, partial=False, variant=None):
     n_points = args.points if args.points > 0 else 50_000_000 * (1 if secondary else world)
     d, thr = float(args.distance), 1e-10     # README.md:101 recommended flags (--convergence_threshold 1e-10)
     room_scale = float(np.sqrt(n_points / 50_000_000.0)) if (world > 1 and args.points == 0 and not secondary) else 1.0
+    if args.room_scale > 0 and not secondary:
+        room_scale = float(args.room_scale)      # (one GPU at the sizes of an N-GPU weak-scaling run: --points 400000000 --room-scale 2.8284)
     scans = synth.make_scene(2, n_points, seed=1234, sigma=0.002, device=dev, room_scale=room_scale, partial=partial, perturb=perturb, scanner=(variant == "scanner"))
     torch.cuda.synchronize()
     whole = None
@@ -861,6 +863,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--points", type=int, default=0, help="points per scan of the headline leg (default 50 M x gpus)")
     ap.add_argument("--distance", type=float, default=0.01)
+    ap.add_argument("--room-scale", type=float, default=0.0, help="stretch of the headline room's floor plan (default: sqrt(points / 50 M) at N > 1, else 1)")
     ap.add_argument("--perturb", type=float, default=2.5, help="scale of the headline scene's initial misalignment (synth.perturbation): 2.5 = 2.5 degrees and "
                     "(5, -2.5, 2.5) cm, the smallest start from which the run still needs the 25 outer iterations of --warmup 5 --steps 20 "
                     "(it converges in iteration 25; tools/icp_converge.py: 2.2 -> 23, 2.4 -> 24, 2.5 -> 25, 3.0 -> 29)")

@@ -358,6 +358,39 @@ def test_icp_cells_of_more_than_255_points(e3d, ob, nn_mode):
     assert all(r[3] > 40000 for r in g.pair_records())            # nearly every point has a partner in every iteration
 
 
+def test_icp_grids_of_more_than_2_31_cells(e3d, ob):
+    """Query keys wider than 31 bits: a cloud whose bounding grid has more than 2^31 cells at the search radius (a dense patch plus
+    three far outliers: 21 m x 21 m x 5.3 m at 1 cm) takes the 64-bit (key, query) pairs through the sort -- per pair and, round 6,
+    once per batch of pairs with the pair's index above the cell key.  The 8-GPU weak-scaling headline (2 x 400 M points on 8 x the
+    floor area: 2.4e9 cells) runs on exactly these paths and nothing else in the suite reaches them.  Counts of every iteration and
+    final poses against the oracle."""
+    rng = np.random.RandomState(77)
+    n = 300_000
+    def patch(seed):
+        r = np.random.RandomState(seed)
+        xy = r.uniform(-0.3, 0.3, (n, 2))
+        z = 0.05 * np.sin(6.0 * xy[:, 0]) * np.cos(5.0 * xy[:, 1]) + r.normal(0.0, 0.0005, n)
+        P = np.concatenate([xy, z[:, None]], 1)
+        nz = np.stack([-0.3 * np.cos(6.0 * xy[:, 0]) * np.cos(5.0 * xy[:, 1]), 0.25 * np.sin(6.0 * xy[:, 0]) * np.sin(5.0 * xy[:, 1]), np.ones(n)], 1)
+        nz /= np.linalg.norm(nz, axis=1, keepdims=True)
+        far = np.array([[-10.5, -10.5, -2.6], [10.5, 10.5, 2.7], [10.5, -10.5, 0.0]])           # stretch the bounding box, match nothing
+        return (np.concatenate([P, far]).astype(np.float32), np.concatenate([nz, np.tile([[0.0, 0.0, 1.0]], (3, 1))]).astype(np.float32))
+    A, An = patch(1)
+    B, Bn = patch(2)
+    T0 = np.eye(4, dtype=np.float32)
+    T1 = np.eye(4, dtype=np.float32)
+    ang = np.deg2rad(2.5)                      # a third of the points start without a partner: far lists in the second iteration
+    T1[:3, :3] = np.array([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1]], np.float32)
+    T1[:3, 3] = [0.02, -0.012, 0.012]
+    g, o, ids, cg, co = _run_both(e3d, ob, [(A, An, T0, False), (B, Bn, T1, False)], 0.01, 6, thr=1e-9)
+    _compare(g, o, ids, cg, co)
+    rec = g.iter_records()
+    assert sum(r["nn_search_queries"] for r in rec) > 0 and sum(r["nn_sort_calls"] for r in rec) > 0     # the sorted row kernel ran
+    assert sum(r["nn_certify_queries"] for r in rec) > 0                                                   # and so did the certificates
+    cnt = [r[3] for r in g.pair_records()]
+    assert cnt[0] < 250_000 and cnt[-1] == n + 3, cnt                                                      # partial overlap first, everything (outliers included) at the end
+
+
 def test_nn_rotated_scaled_target_frame(e3d, ob, synth, nn_mode):
     """Non-trivial poses (incl. a non-rigid linear part): counts identical to the oracle inside the full ICP loop."""
     scans = synth.make_scene(2, 30000, seed=99)

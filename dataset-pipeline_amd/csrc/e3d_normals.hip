@@ -1079,373 +1079,6 @@ __global__ __launch_bounds__(kKnnBlock) void k_knn_normals(const float4* __restr
 #undef HP
 }
 
-// ---- The single scan, CELL-COOPERATIVE (round 6: k_knn_cellscan) ------------------------------------------------------------------
-// k_knn_normals<4> / <5> give every lane a query and let it walk the nine rows of its 27 cells: a wave of 64 queries (five to eight
-// cells) runs every row for as long as its longest lane (216 candidate slots for 140 candidates at k = 32, 170 for 102 at k = 8), the
-// loads of a lane are its own, and each slot costs ~15 vector instructions.  Queries are in cell order and the queries of ONE cell share
-// their 27-cell block exactly.  Here a wave (= a block) still owns 64 consecutive queries, but the collection turns the lanes round:
-//   * per cell of the wave (a run of lanes with equal cell coordinates, found with one ballot) the nine directory row pairs are read
-//     once -- the cell is wave-uniform, so these are scalar loads -- and the block's candidates are staged in LDS as one flat run
-//     {x, y, z, [row | offset] tag}, 256 at a time (coalesced 16-byte loads, each candidate fetched once per cell instead of once
-//     per query);
-//   * the lanes then hold CANDIDATES (four chunks of 64 in registers) and the cell's queries take turns as scalars (v_readlane of the
-//     query's coordinates and threshold): one squared distance per lane in the same operations and roundings as knn_sqdist, one
-//     compare into a lane mask, and the lanes whose candidate lies below the threshold append their 16-bit tag to that query's list
-//     (rank inside the wave from v_mbcnt, the count is a scalar): no slot is spent on a row another lane still walks, no lane waits
-//     for its own loads;
-//   * then lane = query again: the list is what variant 5 collects -- the same set for the same threshold, in another order, and the
-//     sorting network does not care -- so keys, exact (distance, original index) order, the 27-cell certificate, covariance and
-//     eigenvector are variant 5's code on a row-major list (33 / 17 dwords per query: conflict-free for the appends of one query and
-//     for the reads of 64 queries).
-// Exact for the reason the other single-scan variants are: the list holds EVERY candidate of the 27 cells below the threshold, so with
-// at least k of them it holds the k nearest; a query whose count misses [k, N] goes to the two-pass variant (fb_todo) as before.
-// N = list slots: 64 for 11 <= k <= 32, 32 for k <= 10 (tags in both: 8.4 / 4.3 KB per wave + 2 KB of row starts + 4 KB of stage).
-constexpr int kCoopStage = 256;
-
-template <int N, class ListAt, class RsAt, class DistOf>
-__device__ __forceinline__ bool knn_sort_tags_rows(ListAt list_at, RsAt rs_at, unsigned rs_centre, int cnt, int k, const knn_f2 qxy, float qz,
-                                                   float key_scale, DistOf dist_of, const float4* __restrict__ P4) {
-  unsigned a[N];
-  auto pos_of = [&](unsigned w) {
-    const unsigned row = (w >> 12) & 15u;
-    const unsigned from_lds = rs_at(row - (row > 4u ? 1u : 0u));
-    return (row == 4u ? rs_centre : from_lds) + (w & 0xFFFu);
-  };
-#pragma unroll
-  for (int i0 = 0; i0 < N; i0 += 8) {
-    if (i0 < cnt) {
-      unsigned tg[8]; float4 c[8];
-#pragma unroll
-      for (int j = 0; j < 8; j += 2) {
-        const unsigned w2 = list_at((i0 + j) >> 1);
-        tg[j] = w2 & 0xFFFFu; tg[j + 1] = w2 >> 16;
-      }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) if (i0 + j >= cnt) tg[j] = tg[0];          // (slots past the count hold nothing: any valid tag)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) c[j] = P4[pos_of(tg[j])];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float d2 = knn_sqdist(qxy, qz, c[j]);
-        a[i0 + j] = (i0 + j < cnt) ? (((unsigned)(d2 * key_scale) << 16) | tg[j]) : 0xFFFFFFFFu;
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) a[i0 + j] = 0xFFFFFFFFu;
-    }
-  }
-  const bool settled = knn_sort_regs<N>(a, cnt, pos_of, dist_of, P4);
-#pragma unroll
-  for (int i = 0; i < N / 2; ++i) if (i < k) list_at(i) = pos_of(a[i]);      // (k <= N / 2: the list's dwords)
-  return settled;
-}
-
-__device__ __forceinline__ float knn_readlane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
-
-template <int N>
-__global__ __launch_bounds__(64) void k_knn_cellscan(const float4* __restrict__ P4, size_t n, KnnGrid G, int k,
-                                                     float vpx, float vpy, float vpz,
-                                                     float* __restrict__ out_n, float* __restrict__ out_c,
-                                                     int* __restrict__ out_knn, float* __restrict__ out_mean,
-                                                     unsigned* __restrict__ next_todo, unsigned* __restrict__ next_count,
-                                                     unsigned* __restrict__ fb_todo, unsigned* __restrict__ fb_count,
-                                                     const unsigned char* __restrict__ sel_bins, int rep_stride, int rep_avg, float tau_ratio) {
-  extern __shared__ unsigned char smem[];
-  constexpr int LW = N / 2 + 1;                                          // dwords per query list (one of padding)
-  unsigned* const lists = reinterpret_cast<unsigned*>(smem);             // [64][LW]
-  unsigned* const rs_lds = lists + 64 * LW;                              // [8][64]
-  const int lane = threadIdx.x;
-  const size_t gi = (size_t)knn_block(G, blockIdx.x, gridDim.x) * 64 + (size_t)lane;
-  const bool valid = gi < n;
-  const unsigned qid = (unsigned)(valid ? gi : n - 1);
-  const float4 q = P4[qid];                                              // level 0: the sorted points are the queries
-  const unsigned q_oi = __float_as_uint(q.w);
-  const int cx = cell_coord(q.x, G.g.origin[0], G.g.inv_cell);
-  const int cy = cell_coord(q.y, G.g.origin[1], G.g.inv_cell);
-  const int cz = cell_coord(q.z, G.g.origin[2], G.g.inv_cell);
-  KP_DECL(12); KP_MARK(0);
-  // the threshold of the query: the mean of its rep_avg nearest samples' (as k_knn_normals<4> / <5>)
-  float tau2 = 0.f, key_scale = 0.f;
-  bool fallback = !valid;
-  {
-    const size_t n_reps = (n + (size_t)rep_stride - 1) / (size_t)rep_stride;
-    const size_t r0 = ((size_t)qid / (size_t)rep_stride) & ~(size_t)(rep_avg - 1);
-    float edge_sum = 0.f; int have = 0;
-    for (int i = 0; i < rep_avg; ++i)
-      if (r0 + (size_t)i < n_reps) {
-        const int bsel = (int)sel_bins[r0 + (size_t)i];
-        if (bsel < kKnnSelFallback) { edge_sum += (float)((bsel & 63) + 1) / (float)(32 << ((bsel >> 6) & 3)); ++have; }
-      }
-    if (have == 0) fallback = true;                                      // no sampled query near by found its count inside the block
-    else {
-      tau2 = edge_sum / (float)have * G.cell * G.cell * tau_ratio;
-      key_scale = 65000.0f / tau2;
-    }
-  }
-  // ---- collection: cell by cell, lanes = candidates ----
-  // Every lane first reads the directory words of ITS cell's nine rows (18 loads, one round trip for the wave; lanes of one cell read
-  // the same words).  The cells then take turns; a cell's scalars come from its first lane (v_readlane), and the candidates of the NEXT
-  // cell are requested before the queries of this one run, straight into registers: lane l of chunk c holds candidate 64 c + l of the
-  // block's flat sequence (the row is found by comparing against the eight row offsets), so no wave waits for a cell's loads unless
-  // the cell before it had nothing to do.
-  int placed = 0;
-  unsigned rstart[9], rlen[9];
-  bool long_row = false;
-#pragma unroll
-  for (int r = 0; r < 9; ++r) {
-    const int y = cy + (r % 3) - 1, z = cz + (r / 3) - 1;
-    const int x0 = max(cx - 1, 0), x1 = min(cx + 1, (int)G.D[0] - 1);
-    unsigned s0 = 0u, e0 = 0u;
-    if (valid && y >= 0 && z >= 0 && y < (int)G.D[1] && z < (int)G.D[2] && x0 <= x1) {
-      const size_t row = ((size_t)z * G.D[1] + (size_t)y) * G.D[0];
-      s0 = G.S[row + (size_t)x0]; e0 = G.S[row + (size_t)x1 + 1];
-    }
-    rstart[r] = s0; rlen[r] = e0 - s0;
-    if (e0 - s0 > 4095u) long_row = true;                                // (12-bit offsets: the list-maintaining variant takes the query)
-  }
-  if (long_row) fallback = true;
-  if (fallback) tau2 = 0.f;                                              // (no candidate lies below it: the query collects nothing)
-  {
-    const int pcx = __shfl_up(cx, 1), pcy = __shfl_up(cy, 1), pcz = __shfl_up(cz, 1);
-    const bool head = valid && (lane == 0 || cx != pcx || cy != pcy || cz != pcz);
-    unsigned long long heads = __ballot(head);
-    const int nvalid = __popcll(__ballot(valid));
-    unsigned short* const lists16 = reinterpret_cast<unsigned short*>(lists);
-    constexpr int kCh = kCoopStage / 64;
-    const float inf = __uint_as_float(0x7f800000u);
-    KP_MARK(1);
-#ifdef E3D_KNN_PROF
-    unsigned long long kp_sub[4] = {0, 0, 0, 0}, kp_a = 0, kp_b = 0;
-#define KP_SUB_BEGIN() (kp_a = __builtin_readcyclecounter())
-#define KP_SUB_END(i) (kp_b = __builtin_readcyclecounter(), kp_sub[i] += kp_b - kp_a, kp_a = kp_b)
-#else
-#define KP_SUB_BEGIN() do { } while (0)
-#define KP_SUB_END(i) do { } while (0)
-#endif
-    // the scalars of the cell whose first lane is f: row starts, row offsets in the flat sequence, length of the sequence
-    auto cell_scalars = [&](int f, unsigned (&srs)[9], unsigned (&sro)[9], unsigned& C, bool& skip) {
-      C = 0u;
-#pragma unroll
-      for (int r = 0; r < 9; ++r) {
-        srs[r] = (unsigned)__builtin_amdgcn_readlane((int)rstart[r], f);
-        sro[r] = C;
-        C += (unsigned)__builtin_amdgcn_readlane((int)rlen[r], f);
-      }
-      skip = __builtin_amdgcn_readlane(long_row ? 1 : 0, f) != 0;
-    };
-    // candidates B + 64 c + lane of the flat sequence, c = 0 .. 3: loads requested, tags computed (entries past the end read the
-    // sequence's last candidate; the caller masks them)
-    auto request = [&](const unsigned (&srs)[9], const unsigned (&sro)[9], unsigned C, unsigned B, float4 (&cd)[kCh], unsigned (&tg)[kCh]) {
-#pragma unroll
-      for (int ch = 0; ch < kCh; ++ch) {
-        const unsigned idx = min(B + 64u * (unsigned)ch + (unsigned)lane, C - 1u);
-        unsigned base = srs[0], tagd = 0u;
-#pragma unroll
-        for (int i = 1; i < 9; ++i) {
-          const bool c = idx >= sro[i];
-          base = c ? srs[i] - sro[i] : base;
-          tagd = c ? ((unsigned)i << 12) - sro[i] : tagd;
-        }
-        cd[ch] = P4[idx + base];
-        tg[ch] = idx + tagd;
-      }
-    };
-    // the queries of lanes [f, e) against up to 256 candidates held by the lanes
-    auto run_queries = [&](int f, int e, unsigned nst, const float4 (&cand)[kCh], const unsigned (&tag)[kCh], bool first_round) {
-      for (int ql = f; ql < e; ++ql) {
-        const knn_f2 sqxy = {knn_readlane_f(q.x, ql), knn_readlane_f(q.y, ql)};
-        const float sqz = knn_readlane_f(q.z, ql), stau = knn_readlane_f(tau2, ql);
-        int cntq = first_round ? 0 : __builtin_amdgcn_readlane(placed, ql);
-        unsigned short* const ql_list = lists16 + (size_t)ql * (2 * LW);
-        unsigned long long m[kCh];
-#pragma unroll
-        for (int ch = 0; ch < kCh; ++ch) {
-          m[ch] = 0ull;
-          if (64u * (unsigned)ch < nst) m[ch] = __ballot(knn_sqdist(sqxy, sqz, cand[ch]) < stau);
-        }
-#pragma unroll
-        for (int ch = 0; ch < kCh; ++ch) {
-          if (m[ch]) {
-            const int nh = __popcll(m[ch]);
-            if (cntq + nh <= N) {
-              const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m[ch] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m[ch], 0u));
-              if ((m[ch] >> lane) & 1ull) ql_list[cntq + (int)rank] = (unsigned short)tag[ch];
-            }
-            cntq += nh;                                                  // (past N: the count alone, the query falls back)
-          }
-        }
-        if (lane == ql) placed = cntq;
-      }
-    };
-    if (heads) {
-      int f = (int)__builtin_ctzll(heads);
-      heads &= heads - 1ull;
-      int e = heads ? (int)__builtin_ctzll(heads) : nvalid;
-      unsigned srs[9], sro[9], C = 0u;
-      bool skip = false;
-      float4 candN[kCh]; unsigned tagN[kCh];
-      cell_scalars(f, srs, sro, C, skip);
-      request(srs, sro, C, 0u, candN, tagN);
-      for (;;) {
-        float4 cand[kCh]; unsigned tag[kCh];
-        KP_SUB_BEGIN();
-#pragma unroll
-        for (int ch = 0; ch < kCh; ++ch) {
-          cand[ch] = candN[ch]; tag[ch] = tagN[ch];
-          if (64u * (unsigned)ch + (unsigned)lane >= C) cand[ch].x = inf;      // past the end: farther than any threshold
-        }
-        KP_SUB_END(0);
-        const bool more = heads != 0ull;
-        int f2 = 0, e2 = 0;
-        unsigned srs2[9], sro2[9], C2 = 1u;
-        bool skip2 = false;
-#pragma unroll
-        for (int r = 0; r < 9; ++r) { srs2[r] = 0u; sro2[r] = 0u; }
-        if (more) {
-          f2 = (int)__builtin_ctzll(heads);
-          heads &= heads - 1ull;
-          e2 = heads ? (int)__builtin_ctzll(heads) : nvalid;
-          cell_scalars(f2, srs2, sro2, C2, skip2);
-          request(srs2, sro2, C2, 0u, candN, tagN);                      // in flight while this cell's queries run
-        }
-        KP_SUB_END(1);
-        if (!skip) {
-          run_queries(f, e, min(C, (unsigned)kCoopStage), cand, tag, true);
-          KP_SUB_END(2);
-          for (unsigned B = (unsigned)kCoopStage; B < C; B += (unsigned)kCoopStage) {     // (a block of more than 256 points: further rounds)
-            float4 cb[kCh]; unsigned tb[kCh];
-            request(srs, sro, C, B, cb, tb);
-#pragma unroll
-            for (int ch = 0; ch < kCh; ++ch) if (B + 64u * (unsigned)ch + (unsigned)lane >= C) cb[ch].x = inf;
-            run_queries(f, e, min(C - B, (unsigned)kCoopStage), cb, tb, false);
-          }
-        }
-        KP_SUB_END(3);
-        if (!more) break;
-        f = f2; e = e2; C = C2; skip = skip2;
-#pragma unroll
-        for (int r = 0; r < 9; ++r) { srs[r] = srs2[r]; sro[r] = sro2[r]; }
-      }
-    }
-#ifdef E3D_KNN_PROF
-    if (lane == 0) for (int i = 0; i < 4; ++i) atomicAdd(&g_knn_prof[26 + i], kp_sub[i]);
-#endif
-  }
-  __syncthreads();
-  KP_MARK(2);
-  if (!valid) return;
-  if (fallback || placed > N || placed < k) {
-    const unsigned slot = atomicAdd(fb_count, 1u);
-    fb_todo[slot] = qid;
-    return;
-  }
-  // ---- lane = query: variant 5's tail on the row-major list ----
-#define LP(i) lists[(size_t)lane * LW + (size_t)(i)]
-  const knn_f2 qxy = {q.x, q.y};
-  auto dist_of = [&](unsigned m) { const float4 c = P4[m]; return sqdist_l2(q.x, q.y, q.z, c.x, c.y, c.z); };
-#pragma unroll
-  for (int r = 0; r < 9; ++r) if (r != 4) rs_lds[(size_t)(r - (r > 4 ? 1 : 0)) * 64 + lane] = rstart[r];
-  const bool settled = knn_sort_tags_rows<N>([&](int i) -> unsigned& { return LP(i); }, [&](unsigned j) { return rs_lds[(size_t)j * 64 + lane]; },
-                                             rstart[4], placed, k, qxy, q.z, key_scale, dist_of, P4);
-  KP_MARK(3);
-  if (!settled) {                                                        // (a long run of equal keys: the two-pass variant sorts it in LDS)
-    const unsigned slot = atomicAdd(fb_count, 1u);
-    fb_todo[slot] = qid;
-    return;
-  }
-  const int cnt = k;
-  const float td = dist_of(LP(cnt - 1));                                  // the k-th nearest
-  KP_MARK(4);
-  // resolved?  the k-th neighbour must be strictly closer than the nearest face of the 27-cell block that still has data behind it
-  {
-    float safe = 3.402823466e+38f;
-    const int c[3] = {cx, cy, cz};
-    const float qq[3] = {q.x, q.y, q.z};
-    bool covers_all = true;
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      const float lo = G.g.origin[a] + (float)(c[a] - 1) * G.cell;
-      const float hi = G.g.origin[a] + (float)(c[a] + 2) * G.cell;
-      if (lo > G.dmin[a]) { safe = fminf(safe, qq[a] - lo); covers_all = false; }
-      if (hi <= G.dmax[a]) { safe = fminf(safe, hi - qq[a]); covers_all = false; }
-    }
-    bool resolved = covers_all;
-    if (!covers_all) {
-      safe -= G.slack;
-      resolved = safe > 0.f && td < safe * safe * 0.99999f;
-    }
-    if (!resolved) {
-      const unsigned slot = atomicAdd(next_count, 1u);
-      next_todo[slot] = qid;
-      return;
-    }
-  }
-  if (out_knn) {
-    for (int i = 0; i < k; ++i) out_knn[(size_t)q_oi * k + i] = (int)__float_as_uint(P4[LP(i)].w);
-  }
-  if (out_mean) {
-    // LocalStatisticalOutlierRemoval, first pass (local_statistical_outlier_removal.hpp:104-109), as k_knn_normals
-    double dist_sum = 0.0;
-    for (int i = 1; i < cnt; ++i) {
-      const float4 c = P4[LP(i)];
-      dist_sum += (double)sqrtf(sqdist_l2(q.x, q.y, q.z, c.x, c.y, c.z));
-    }
-    out_mean[q_oi] = (float)(dist_sum / (double)(k - 1));
-  }
-  if (!out_n) return;
-  float nx, ny, nz, curv;
-  {
-    // two_pass_centroid.hpp:176-192 (dense branch), f32, neighbour order (k >= 3 here); as k_knn_normals
-    float a6 = 0.f, a7 = 0.f, a8 = 0.f;
-    KP_MARK(5);
-    for (int i0 = 0; i0 < cnt; i0 += 8) {
-      float4 pb[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) pb[j] = P4[LP(min(i0 + j, cnt - 1))];
-#pragma unroll
-      for (int j = 0; j < 8; ++j)
-        if (i0 + j < cnt) { a6 += pb[j].x; a7 += pb[j].y; a8 += pb[j].z; }
-    }
-    const float fc = (float)cnt;
-    a6 = a6 / fc; a7 = a7 / fc; a8 = a8 / fc;
-    float a0 = 0.f / fc, a1 = 0.f / fc, a2 = 0.f / fc, a3 = 0.f / fc, a4 = 0.f / fc, a5 = 0.f / fc;
-    for (int i0 = 0; i0 < cnt; i0 += 8) {
-      float4 pb[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) pb[j] = P4[LP(min(i0 + j, cnt - 1))];
-#pragma unroll
-      for (int j = 0; j < 8; ++j)
-        if (i0 + j < cnt) {
-          const float4 p = pb[j];
-          a0 += (p.x - a6) * (p.x - a6);
-          a1 += (p.x - a6) * (p.y - a7);
-          a2 += (p.x - a6) * (p.z - a8);
-          a3 += (p.y - a7) * (p.y - a7);
-          a4 += (p.y - a7) * (p.z - a8);
-          a5 += (p.z - a8) * (p.z - a8);
-        }
-    }
-    KP_MARK(6);
-    float cov[9];
-    cov[0] = a0 / fc; cov[1] = a1 / fc; cov[2] = a2 / fc; cov[4] = a3 / fc; cov[5] = a4 / fc; cov[8] = a5 / fc;
-    cov[3] = cov[1]; cov[6] = cov[2]; cov[7] = cov[5];
-    float ev, v[3];
-    eigen33_smallest(cov, ev, v);
-    nx = v[0]; ny = v[1]; nz = v[2];
-    const float eig_sum = cov[0] + cov[4] + cov[8];
-    curv = (eig_sum != 0.f) ? fabsf(ev / eig_sum) : 0.f;
-    // flipNormalTowardsViewpoint
-    const float vx = vpx - q.x, vy = vpy - q.y, vz = vpz - q.z;
-    const float cos_theta = (vx * nx + vy * ny + vz * nz);
-    if (cos_theta < 0) { nx *= -1; ny *= -1; nz *= -1; }
-    KP_MARK(7);
-  }
-  out_n[3 * (size_t)q_oi] = nx; out_n[3 * (size_t)q_oi + 1] = ny; out_n[3 * (size_t)q_oi + 2] = nz;
-  out_c[q_oi] = curv;
-  KP_MARK(8); KP_FLUSH(16, 9);
-#undef LP
-}
-
 // The 125-cell pass, ONE WAVE PER QUERY (dense directory, k <= 64).  What a level leaves over is a few ten thousand unrelated
 // queries; with a lane per query a wave walks the union of its lanes' cells one memory round trip after the other and there is
 // one wave per SIMD at best (0.65 - 0.9 ms for 32 k queries).  Here the 64 lanes of a wave share ONE query:
@@ -1923,9 +1556,6 @@ static void knn_pass(KnnWorkspace& W, const float* xyz, size_t n, int k, const f
     // the count the threshold aims at: the middle of [k, capacity] (k = 32: 48 of 64), a little below it for small k where the
     // relative Poisson noise of the count is larger on the low side
     const int rep_target = rep_target_env > 0 ? (int)rep_target_env : std::min((k + cap1) / 2, 2 * k + 6);
-    // the cell-cooperative form of the single scan (k_knn_cellscan; E3D_KNN_COOP=0: the lane-per-query variants 4 / 5)
-    static const int coop_env = [] { const char* e = getenv("E3D_KNN_COOP"); return e ? atoi(e) : 1; }();
-    const bool coop = coop_env != 0;
     const size_t lds1 = single_variant == 5 ? (size_t)(8 + cap1 / 2) * kKnnBlock * 4 : (size_t)cap1 * kKnnBlock * 4;
     if (single) E3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel_of(single_variant)), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
     E3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel_of(sel)), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -2023,18 +1653,6 @@ static void knn_pass(KnnWorkspace& W, const float* xyz, size_t n, int k, const f
         LB.sel_bin.reserve(n_list);
         hipLaunchKernelGGL(k_knn_hist, dim3((unsigned)div_up(n_reps, kKnnHistBlock)), dim3(kKnnHistBlock), 0, s, LB.P4.p, (const unsigned*)nullptr, n_reps,
                            LB.table.p, G, rep_target, Q4.p, LB.sel_bin.p, (unsigned)rep_stride, (rep_estimate && G.S) ? rep_est_scale : 0.f);
-        if (coop && Q4.p == LB.P4.p) {
-          // the cell-cooperative scan (k_knn_cellscan): one wave per 64 queries; an XCD keeps the same stretch of the query order
-          KnnGrid G2 = G;
-          G2.xcd_map = G.xcd_map * (unsigned)(kKnnBlock / 64);
-          const int capc = single_variant == 5 ? 64 : 32;
-          const size_t lds_c = (size_t)64 * (size_t)(capc / 2 + 1) * 4 + 8 * 64 * 4;
-          auto coop_kernel = capc == 64 ? k_knn_cellscan<64> : k_knn_cellscan<32>;
-          hipLaunchKernelGGL(coop_kernel, dim3((unsigned)div_up(n_list, (size_t)64)), dim3(64), lds_c, s, LB.P4.p, n, G2, k,
-                             viewpoint[0], viewpoint[1], viewpoint[2], want_normals ? d_on.p : nullptr, want_normals ? d_oc.p : nullptr,
-                             knn_indices ? d_knn.p : nullptr, d_mean_out ? d_mean_out->p : nullptr, next_list, LB.counter.p + 1,
-                             single_list, LB.counter.p + 3, LB.sel_bin.p, rep_stride, rep_avg, 1.0f);
-        } else
         hipLaunchKernelGGL(kernel_of(single_variant), dim3((unsigned)div_up(n_list, kKnnBlock)), dim3(kKnnBlock), lds1, s, LB.P4.p, n, (const unsigned*)nullptr, n_list, LB.table.p, G, k, cap1,
                            viewpoint[0], viewpoint[1], viewpoint[2], Q4.p, want_normals ? d_on.p : nullptr, want_normals ? d_oc.p : nullptr,
                            knn_indices ? d_knn.p : nullptr, d_mean_out ? d_mean_out->p : nullptr, next_list, LB.counter.p + 1,
@@ -2102,7 +1720,7 @@ static void knn_pass(KnnWorkspace& W, const float* xyz, size_t n, int k, const f
         fprintf(stderr, "[knn prof] hist: waves %llu cycles/wave:", hp[15]);
         for (int i = 0; i < 5; ++i) fprintf(stderr, " %.0f", hp[15] ? (double)hp[i] / (double)hp[15] : 0.0);
         fprintf(stderr, "\n[knn prof] normals<3>: waves %llu cycles/wave:", hp[31]);
-        for (int i = 0; i < 14; ++i) fprintf(stderr, " %.0f", hp[31] ? (double)hp[16 + i] / (double)hp[31] : 0.0);
+        for (int i = 0; i < 10; ++i) fprintf(stderr, " %.0f", hp[31] ? (double)hp[16 + i] / (double)hp[31] : 0.0);
         fprintf(stderr, "\n");
       }
 #endif

@@ -280,7 +280,11 @@ __global__ __launch_bounds__(kBlock) void k_min_filter_v(const unsigned* __restr
 // intermediate image never goes to memory (two 98 MB images written and read per 24 MP depth map before: 0.22 ms; the vertical
 // pass alone read 21 rows per pixel through L2).  A thread produces four neighbouring pixels of a row, then eight of a column:
 // 6 + 3.5 LDS reads per pixel instead of 21 + 21.  min is associative: bit-identical to the separable passes.
+// MERGE = false: no splat took the rectangle path (the usual case at room scale: every splat is full size), so the depth map holds
+// nothing yet -- the filter's result is STORED instead of merged, and the pass that would have filled the map with +inf first
+// (k_splat_tiles over all tiles: a 4 B store per pixel, read back here) is not launched.  min(+inf, m) = m: the same bits.
 constexpr int kMfW = 64, kMfH = 32, kMfWin = 2 * kSplatMax + 1;
+template <bool MERGE>
 __global__ __launch_bounds__(kBlock) void k_min_filter_tile(const unsigned* __restrict__ zbuf, int width, int height,
                                                             unsigned* __restrict__ depth_bits) {
   constexpr int IW = kMfW + 2 * kSplatMax, IH = kMfH + 2 * kSplatMax;
@@ -327,7 +331,8 @@ __global__ __launch_bounds__(kBlock) void k_min_filter_tile(const unsigned* __re
     const int y = y0 + r0 + k;
     if (x < width && y < height) {
       const size_t o = (size_t)y * width + x;
-      depth_bits[o] = min(depth_bits[o], m);                           // with what the rectangle path (smaller splats) produced
+      if constexpr (MERGE) depth_bits[o] = min(depth_bits[o], m);      // with what the rectangle path (smaller splats) produced
+      else depth_bits[o] = m;
     }
   }
 }
@@ -2125,6 +2130,13 @@ __global__ __launch_bounds__(kBlock) void k_fill_f32(float* p, size_t n, float v
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = v;
 }
+// the same with 16-byte stores (p from hipMalloc: 256-byte aligned); the last n % 4 entries one by one
+__global__ __launch_bounds__(kBlock) void k_fill_f32x4(float* __restrict__ p, size_t n, float v) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t n4 = n / 4;
+  if (i < n4) reinterpret_cast<float4*>(p)[i] = make_float4(v, v, v, v);
+  if (i < (n & 3)) p[4 * n4 + i] = v;
+}
 // nearest of two mesh depth maps; 0 = no geometry
 __global__ __launch_bounds__(kBlock) void k_depth_merge(float* __restrict__ a, const float* __restrict__ b, size_t n) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -3093,11 +3105,12 @@ int e3d_reg_render_depth(e3d_reg_t* h, int image_id, int image_scale, float* dep
     E3D_HIP(hipMemsetAsync(h->tile_start.p, 0, sizeof(unsigned) * n_tiles, s));
     E3D_HIP(hipMemsetAsync(h->tile_end.p, 0, sizeof(unsigned) * n_tiles, s));
     unsigned n_pairs = 0;
+    static const bool separable = [] { const char* e = getenv("E3D_REG_MIN_FILTER"); return e && !strcmp(e, "separable"); }();
     const size_t zpx = (size_t)(cam.width + 2 * kSplatMax) * (cam.height + 2 * kSplatMax);
     h->zbuf.reserve(zpx);
     {
       KT kt(h, "depth.zbuffer_clear", (double)zpx);
-      hipLaunchKernelGGL(k_fill_f32, dim3(nblk(zpx)), dim3(kBlock), 0, s, reinterpret_cast<float*>(h->zbuf.p), zpx, INFINITY);
+      hipLaunchKernelGGL(k_fill_f32x4, dim3(nblk(zpx / 4 + 4)), dim3(kBlock), 0, s, reinterpret_cast<float*>(h->zbuf.p), zpx, INFINITY);
     }
     if (n) {
       {
@@ -3118,12 +3131,12 @@ int e3d_reg_render_depth(e3d_reg_t* h, int image_id, int image_scale, float* dep
         hipLaunchKernelGGL(k_tile_ranges, dim3(nblk(n_pairs)), dim3(kBlock), 0, s, h->sp_keys[1].p, (size_t)n_pairs, h->tile_start.p,
                            h->tile_end.p);
       }
+      if (n_pairs || separable)
       hipLaunchKernelGGL(k_splat_tiles, dim3((unsigned)n_tiles), dim3(kBlock), 0, s, h->rects.p, h->sp_vals[1].p, h->tile_start.p,
                          h->tile_end.p, tiles_x, cam.width, cam.height, reinterpret_cast<unsigned*>(im.depth.p));
     }
     {
       KT kt(h, "depth.min_filter", (double)px);
-      static const bool separable = [] { const char* e = getenv("E3D_REG_MIN_FILTER"); return e && !strcmp(e, "separable"); }();
       if (separable) {
         h->ztmp.reserve((size_t)cam.width * (cam.height + 2 * kSplatMax));
         hipLaunchKernelGGL(k_min_filter_h, dim3((unsigned)div_up(cam.width, kBlock), (unsigned)(cam.height + 2 * kSplatMax)), dim3(kBlock), 0, s,
@@ -3131,8 +3144,9 @@ int e3d_reg_render_depth(e3d_reg_t* h, int image_id, int image_scale, float* dep
         hipLaunchKernelGGL(k_min_filter_v, dim3((unsigned)div_up(cam.width, kBlock), (unsigned)cam.height), dim3(kBlock), 0, s, h->ztmp.p,
                            cam.width, cam.height, reinterpret_cast<unsigned*>(im.depth.p));
       } else {
-        hipLaunchKernelGGL(k_min_filter_tile, dim3((unsigned)div_up(cam.width, kMfW), (unsigned)div_up(cam.height, kMfH)), dim3(kBlock), 0, s,
-                           h->zbuf.p, cam.width, cam.height, reinterpret_cast<unsigned*>(im.depth.p));
+        const dim3 mf_grid((unsigned)div_up(cam.width, kMfW), (unsigned)div_up(cam.height, kMfH));
+        if (n_pairs) hipLaunchKernelGGL(k_min_filter_tile<true>, mf_grid, dim3(kBlock), 0, s, h->zbuf.p, cam.width, cam.height, reinterpret_cast<unsigned*>(im.depth.p));
+        else hipLaunchKernelGGL(k_min_filter_tile<false>, mf_grid, dim3(kBlock), 0, s, h->zbuf.p, cam.width, cam.height, reinterpret_cast<unsigned*>(im.depth.p));
       }
     }
   }

@@ -874,7 +874,8 @@ __global__ __launch_bounds__(kBlock) void k_obs_compact(const int* __restrict__ 
                                                         const float* __restrict__ oy, const float* __restrict__ os,
                                                         size_t count, const unsigned* __restrict__ block_offsets,
                                                         unsigned* __restrict__ o_idx, float* __restrict__ o_x,
-                                                        float* __restrict__ o_y, float* __restrict__ o_s) {
+                                                        float* __restrict__ o_y, float* __restrict__ o_s,
+                                                        int* __restrict__ row_of_point) {
   const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int v = (k < count) ? valid[k] : -1;
   const bool f = v >= 0;
@@ -885,8 +886,11 @@ __global__ __launch_bounds__(kBlock) void k_obs_compact(const int* __restrict__ 
   __syncthreads();
   unsigned base = block_offsets[blockIdx.x];
   for (int j = 0; j < w; ++j) base += wbase[j];
-  if (!f) return;
   const size_t o = base + (unsigned)__popcll(b & ((1ull << lane) - 1ull));
+  // candidates = all points in point order (row_of_point != nullptr): candidate k IS point k, so the point -> observation row map that
+  // finish_observations needs leaves here as one coalesced stream (it cleared the map and scattered the rows into it before)
+  if (row_of_point && k < count) row_of_point[k] = f ? (int)o : -1;
+  if (!f) return;
   o_idx[o] = (unsigned)v; o_x[o] = ox[k]; o_y[o] = oy[k]; o_s[o] = os[k];
 }
 
@@ -2281,6 +2285,7 @@ struct e3d_reg {
   DevBuf<int> valid;
   DevBuf<float> tx, ty, ts;
   DevBuf<unsigned> cand, block_counts, block_offsets;
+  PinBuf<unsigned char> mailbox;     // read_back
   DevBuf<double> block_d2, chunk_d2, d_total_d2, partial, red, red_all;
   DevBuf<unsigned long long> chunk_sum, d_total;
   DevBuf<float> dummy_d2;
@@ -2329,6 +2334,17 @@ struct e3d_reg {
 namespace e3d {
 
 static void rsync(e3d_reg* h) { E3D_HIP(hipStreamSynchronize(h->stream)); }
+// A few words back from the device, through the handle's pinned mailbox, and the stream synchronised: hipMemcpyAsync into pageable
+// memory (a stack variable) goes through the runtime's staging path and costs several times the copy into pinned memory -- an
+// iteration of RunOnCurrentScale reads ~120 such results (pair counts, kept / dropped candidates, the sums of every pass).
+static void read_back(e3d_reg* h, void* dst, const void* src_dev, size_t bytes) {
+  static const bool pinned = [] { const char* e = getenv("E3D_REG_PINNED"); return !(e && e[0] == '0'); }();     // (0: as rounds 1 - 5, for A / B timing)
+  if (bytes == 0 || !pinned) { copy_out(dst, src_dev, bytes, h->stream); rsync(h); return; }
+  if (bytes > h->mailbox.cap) h->mailbox.reserve(std::max(bytes, (size_t)65536));
+  E3D_HIP(hipMemcpyAsync(h->mailbox.p, src_dev, bytes, hipMemcpyDeviceToHost, h->stream));
+  E3D_HIP(hipStreamSynchronize(h->stream));
+  memcpy(dst, h->mailbox.p, bytes);
+}
 
 // stop-watch of one kernel group (HIP events on the handle's stream; only while e3d_reg_profile is on)
 struct KT {
@@ -2586,15 +2602,16 @@ static void check_params(const e3d_reg_params* p) {
 }
 
 // flags + row_of_point for the current observation list
-static void finish_observations(e3d_reg* h, PointScale& S, Obs& O) {
+// (map_written: the compaction of an all-points pass has written S.row_of_point for this list already)
+static void finish_observations(e3d_reg* h, PointScale& S, Obs& O, bool map_written = false) {
   hipStream_t s = h->stream;
   KT kt(h, "obs.neighbour_flags", (double)O.n);
   O.flags_src = nullptr; O.flags_count = 0;
-  hipLaunchKernelGGL(k_fill_i32, dim3(nblk(S.n)), dim3(kBlock), 0, s, S.row_of_point.p, S.n, -1);
+  if (!map_written) hipLaunchKernelGGL(k_fill_i32, dim3(nblk(S.n)), dim3(kBlock), 0, s, S.row_of_point.p, S.n, -1);
   O.flags.reserve(O.n);
   O.nrow.reserve(O.n * (size_t)h->prm.point_neighbor_count);
   if (O.n) {
-    hipLaunchKernelGGL(k_obs_mark, dim3(nblk(O.n)), dim3(kBlock), 0, s, O.idx.p, O.n, S.row_of_point.p);
+    if (!map_written) hipLaunchKernelGGL(k_obs_mark, dim3(nblk(O.n)), dim3(kBlock), 0, s, O.idx.p, O.n, S.row_of_point.p);
     if (h->prm.point_neighbor_count == 5)
       hipLaunchKernelGGL(k_obs_flags<5>, dim3(nblk(O.n)), dim3(kBlock), 0, s, O.idx.p, O.n, S.nbr.p, 5, S.row_of_point.p, O.flags.p, O.nrow.p);
     else
@@ -2934,8 +2951,7 @@ static void render_depth_meshes(e3d_reg* h, ImageDev& im, const Intrin& in, cons
       hipLaunchKernelGGL(k_mesh_bin, dim3(nblk(m->n_triangles)), dim3(kBlock), 0, s, h->mesh_projected.p, h->mesh_shaded.p, m->triangles.p,
                          m->n_triangles, mp, cam.width, cam.height, h->min_occlusion_depth, h->max_occlusion_depth, tiles_x, 0u, h->sp_keys[0].p,
                          h->sp_vals[0].p, h->sp_counter.p, (unsigned)std::min<size_t>(capacity, 0xFFFFFFFFu));
-      copy_out(&n_pairs, h->sp_counter.p, sizeof n_pairs, s);
-      rsync(h);
+      read_back(h, &n_pairs, h->sp_counter.p, sizeof n_pairs);
       if ((size_t)n_pairs <= capacity) break;
       capacity = n_pairs;
     }
@@ -3119,8 +3135,7 @@ int e3d_reg_render_depth(e3d_reg_t* h, int image_id, int image_scale, float* dep
                                                    h->prm.splat_radius, tiles_x, h->rects.p, h->sp_keys[0].p, h->sp_vals[0].p,
                                                    h->sp_counter.p, h->zbuf.p));
       }
-      copy_out(&n_pairs, h->sp_counter.p, sizeof n_pairs, s);
-      rsync(h);
+      read_back(h, &n_pairs, h->sp_counter.p, sizeof n_pairs);
     }
     {
       KT kt(h, "depth.small_splat_tiles", (double)n_pairs);
@@ -3178,6 +3193,7 @@ int64_t e3d_reg_observe(e3d_reg_t* h, int image_id, int point_scale, int image_s
   q.check = all ? 1 : 0;
   O.n = 0;
   O.inten_valid = false;
+  bool map_written = false;      // S.row_of_point written by the compaction (all-points pass)
   // the flags of the list the candidates came from still describe the result if every candidate stays an observation
   const bool flags_kept = !all && O.flags_src == (const void*)indices && O.flags_count == count;
   if (count) {
@@ -3195,8 +3211,7 @@ int64_t e3d_reg_observe(e3d_reg_t* h, int image_id, int point_scale, int image_s
     }
     unsigned dropped = 1;
     if (!all) {
-      copy_out(&dropped, d_dropped, sizeof dropped, s);
-      rsync(h);
+      read_back(h, &dropped, d_dropped, sizeof dropped);
     }
     if (dropped == 0) {
       // every listed point is still an observation: the list and the freshly written positions ARE the compacted result
@@ -3213,21 +3228,21 @@ int64_t e3d_reg_observe(e3d_reg_t* h, int image_id, int point_scale, int image_s
                           h->chunk_d2.p, h->d_total.p, h->d_total_d2.p, s);
       }
       unsigned long long total = 0;
-      copy_out(&total, h->d_total.p, sizeof total, s);
-      rsync(h);
+      read_back(h, &total, h->d_total.p, sizeof total);
       O.n = (size_t)total;
       O.idx.reserve(O.n); O.x.reserve(O.n); O.y.reserve(O.n); O.s.reserve(O.n);
       if (O.n) {
         KT kt(h, "obs.compact", (double)count);
         hipLaunchKernelGGL(k_obs_compact, dim3(nblk(count)), dim3(kBlock), 0, s, h->valid.p, h->tx.p, h->ty.p, h->ts.p, count,
-                           h->block_offsets.p, O.idx.p, O.x.p, O.y.p, O.s.p);
+                           h->block_offsets.p, O.idx.p, O.x.p, O.y.p, O.s.p, all ? S.row_of_point.p : nullptr);
+        map_written = all;
       }
     }
   }
   if (flags_kept && O.n == count) {
     // same points in the same order as the list the flags were made for: flags and neighbour rows are unchanged
   } else {
-    finish_observations(h, S, O);
+    finish_observations(h, S, O, map_written);
   }
   return (int64_t)O.n;        // (the stream is not synchronised here: every reader of O runs on it)
   R_CATCH()
@@ -3384,8 +3399,7 @@ int e3d_reg_accumulate(e3d_reg_t* h, int image_id, int point_scale, double* H, d
   kt2.reset();
   hipLaunchKernelGGL(k_reg_reduce, dim3(slot), dim3(kWave), 0, s, h->partial.p, n_partials, slot, h->red.p);
   std::vector<double> r(slot);
-  copy_out(r.data(), h->red.p, sizeof(double) * slot, s);
-  rsync(h);
+  read_back(h, r.data(), h->red.p, sizeof(double) * slot);
   h->pass1_ms += h->t_pass1->ms(); h->pass2_ms += h->t_pass2->ms(); h->pass_observations += (double)O.n; h->pass_calls += 1;
   std::fill(H, H + V * V, 0.0);
   int e = 0;
@@ -3455,8 +3469,7 @@ int e3d_reg_cost(e3d_reg_t* h, int image_id, int point_scale, double sums[2], in
   h->red.reserve(4);
   cost_enqueue(h, image_id, point_scale, h->red.p);
   double r[4];
-  copy_out(r, h->red.p, sizeof r, h->stream);
-  rsync(h);
+  read_back(h, r, h->red.p, sizeof r);
   sums[0] = r[0]; sums[1] = r[1]; counts[0] = (int64_t)r[2]; counts[1] = (int64_t)r[3];
   return 0;
   R_CATCH()
@@ -3532,8 +3545,7 @@ int e3d_reg_depth_accumulate(e3d_reg_t* h, int image_id, int point_scale, double
 #undef E3D_DEPTH
   hipLaunchKernelGGL(k_reg_reduce, dim3(slot), dim3(kWave), 0, s, h->partial.p, nb, slot, h->red.p);
   std::vector<double> r(slot);
-  copy_out(r.data(), h->red.p, sizeof(double) * slot, s);
-  rsync(h);
+  read_back(h, r.data(), h->red.p, sizeof(double) * slot);
   std::fill(H, H + V * V, 0.0);
   int e = 0;
   for (int i = 0; i < V; ++i) for (int j = i; j < V; ++j) H[i * V + j] = r[e++];
@@ -3559,8 +3571,7 @@ int e3d_reg_depth_cost(e3d_reg_t* h, int image_id, int point_scale, double* sum,
                      O.s.p, O.n, h->prm.depth_robust_weighting_type, h->prm.depth_robust_weighting_parameter, h->partial.p);
   hipLaunchKernelGGL(k_reg_reduce, dim3(2), dim3(kWave), 0, s, h->partial.p, nb, 2, h->red.p);
   double r[2];
-  copy_out(r, h->red.p, sizeof r, s);
-  rsync(h);
+  read_back(h, r, h->red.p, sizeof r);
   *sum = r[0]; *count = (int64_t)r[1];
   return 0;
   R_CATCH()
@@ -3738,8 +3749,7 @@ static double total_cost(e3d_reg* h) {
   h->red_all.reserve(4 * std::max<size_t>(jobs.size(), 1));
   for (size_t j = 0; j < jobs.size(); ++j) cost_enqueue(h, jobs[j].first, jobs[j].second, h->red_all.p + 4 * j);
   std::vector<double> r(4 * jobs.size());
-  if (!jobs.empty()) copy_out(r.data(), h->red_all.p, sizeof(double) * r.size(), h->stream);
-  rsync(h);
+  read_back(h, r.data(), h->red_all.p, sizeof(double) * r.size());
   for (size_t j = 0; j < jobs.size(); ++j) {
     sums[0] += r[4 * j]; sums[1] += r[4 * j + 1]; counts[0] += (int64_t)r[4 * j + 2]; counts[1] += (int64_t)r[4 * j + 3];
     if (depth_in_use(h)) {
@@ -3912,8 +3922,7 @@ static void apply_update(e3d_reg* h, bool print, bool* applied_update, float* la
       // every trial cost was enqueued behind its image's re-projection: one copy, summed in the loop's order
       Phase ph_cost(h, "apply.trial_cost");
       std::vector<double> r(4 * trial_jobs.size());
-      if (!trial_jobs.empty()) copy_out(r.data(), h->red_all.p, sizeof(double) * r.size(), s);
-      rsync(h);
+      read_back(h, r.data(), h->red_all.p, sizeof(double) * r.size());
       for (size_t j = 0; j < trial_jobs.size(); ++j) {
         ts[0] += r[4 * j]; ts[1] += r[4 * j + 1]; tc[0] += (int64_t)r[4 * j + 2]; tc[1] += (int64_t)r[4 * j + 3];
         if (depth_in_use(h)) {

@@ -1386,6 +1386,16 @@ struct KnnWorkspace {
   DevBuf<unsigned> todo_a, todo_b, fb_todo;
   DevBuf<unsigned> seed_pos;           // the k nearest of the 27 cells of queries that go on to the 125-cell pass (positions), and
   DevBuf<unsigned char> seed_flag;     // which entries of that pass's list have them
+  PinBuf<unsigned> mailbox;            // the few words a call reads back (bounding box, list lengths): pinned, not the pageable staging path
+  // a few words back from the device and the stream synchronised
+  void read_back(void* dst, const void* src_dev, size_t bytes) {
+    static const bool pinned = [] { const char* e = getenv("E3D_KNN_PINNED"); return !(e && e[0] == '0'); }();     // (0: as rounds 1 - 5, for A / B timing)
+    if (!pinned) { E3D_HIP(hipMemcpyAsync(dst, src_dev, bytes, hipMemcpyDeviceToHost, stream)); E3D_HIP(hipStreamSynchronize(stream)); return; }
+    mailbox.reserve(64);
+    E3D_HIP(hipMemcpyAsync(mailbox.p, src_dev, bytes, hipMemcpyDeviceToHost, stream));
+    E3D_HIP(hipStreamSynchronize(stream));
+    memcpy(dst, mailbox.p, bytes);
+  }
   size_t bytes() const {
     return raw.cap * 4 + bbox_partial.cap * 4 + bbox_out.cap * 4 + d_on.cap * 4 + d_oc.cap * 4 + d_mean.cap * 4 + d_knn.cap * 4 + d_in.cap +
            L.ka.cap * 8 + L.kb.cap * 8 + L.va.cap * 4 + L.vb.cap * 4 + L.counter.cap * 4 + L.temp.cap + L.P4.cap * 16 + L.LN.cap * 16 +
@@ -1488,8 +1498,7 @@ static void knn_pass(KnnWorkspace& W, const float* xyz, size_t n, int k, const f
     bbox_partial.reserve(6 * (size_t)kMaxBboxBlocks); bbox_out.reserve(6);
     launch_bbox_aos(raw.p, n, bbox_partial.p, bbox_out.p, s);
     float bb[6];
-    copy_out(bb, bbox_out.p, sizeof bb, s);
-    E3D_HIP(hipStreamSynchronize(s));
+    W.read_back(bb, bbox_out.p, sizeof bb);
     double ext[3], extent = 0, vol = 1;
     for (int a = 0; a < 3; ++a) { ext[a] = (double)bb[3 + a] - (double)bb[a]; extent = std::max(extent, ext[a]); }
     if (!(extent > 0) || !std::isfinite(extent)) extent = 1.0;
@@ -1658,8 +1667,7 @@ static void knn_pass(KnnWorkspace& W, const float* xyz, size_t n, int k, const f
                            knn_indices ? d_knn.p : nullptr, d_mean_out ? d_mean_out->p : nullptr, next_list, LB.counter.p + 1,
                            single_list, LB.counter.p + 3, LB.sel_bin.p, 1, rep_stride, rep_avg, 1.0f, seed_pos_p, seed_flag_p, seed_cap);
         unsigned n_single_fb = 0;
-        E3D_HIP(hipMemcpyAsync(&n_single_fb, LB.counter.p + 3, sizeof(unsigned), hipMemcpyDeviceToHost, s));
-        E3D_HIP(hipStreamSynchronize(s));
+        W.read_back(&n_single_fb, LB.counter.p + 3, sizeof(unsigned));
         E3D_HIP(hipGetLastError());
         if (getenv("E3D_KNN_STATS")) fprintf(stderr, "[knn] single pass (variant %d): %zu queries, target %d of %d slots, %u to the two-pass variant\n", single_variant, n_list, rep_target, cap1, n_single_fb);
         todo_list = single_list;
@@ -1677,8 +1685,7 @@ static void knn_pass(KnnWorkspace& W, const float* xyz, size_t n, int k, const f
                          knn_indices ? d_knn.p : nullptr, d_mean_out ? d_mean_out->p : nullptr, next_list, LB.counter.p + 1,
                          fb_todo.p, LB.counter.p + 2, LB.sel_bin.p, 1, 1, 1, 1.0f, lsel == 3 ? seed_pos_p : nullptr, lsel == 3 ? seed_flag_p : nullptr, seed_cap);
       unsigned cnts[2] = {0, 0};
-      E3D_HIP(hipMemcpyAsync(cnts, LB.counter.p + 1, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, s));
-      E3D_HIP(hipStreamSynchronize(s));
+      W.read_back(cnts, LB.counter.p + 1, 2 * sizeof(unsigned));
       E3D_HIP(hipGetLastError());
       const unsigned n_fb = cnts[1];
       if (merge_fb_into_next && n_fb > 0 && ((size_t)cnts[0] + n_fb) * 64 <= n) {
@@ -1693,8 +1700,7 @@ static void knn_pass(KnnWorkspace& W, const float* xyz, size_t n, int k, const f
                            fb_todo.p, (size_t)n_fb, LB.table.p, G, k, k, viewpoint[0], viewpoint[1], viewpoint[2], Q4.p,
                            want_normals ? d_on.p : nullptr, want_normals ? d_oc.p : nullptr, knn_indices ? d_knn.p : nullptr,
                            d_mean_out ? d_mean_out->p : nullptr, next_list, LB.counter.p + 1, nullptr, nullptr, nullptr, 1, 1, 1, 1.0f, nullptr, nullptr, 0u);
-        E3D_HIP(hipMemcpyAsync(cnts, LB.counter.p + 1, sizeof(unsigned), hipMemcpyDeviceToHost, s));
-        E3D_HIP(hipStreamSynchronize(s));
+        W.read_back(cnts, LB.counter.p + 1, sizeof(unsigned));
         E3D_HIP(hipGetLastError());
       }
       n_next_out = cnts[0];
@@ -1749,16 +1755,14 @@ static void knn_pass(KnnWorkspace& W, const float* xyz, size_t n, int k, const f
                              viewpoint[0], viewpoint[1], viewpoint[2], Q4.p, want_normals ? d_on.p : nullptr, want_normals ? d_oc.p : nullptr,
                              knn_indices ? d_knn.p : nullptr, d_mean_out ? d_mean_out->p : nullptr, wide_out, L.counter.p + 1, fb_todo.p, L.counter.p + 2);
           unsigned n_back = 0;
-          E3D_HIP(hipMemcpyAsync(&n_back, L.counter.p + 2, sizeof(unsigned), hipMemcpyDeviceToHost, s));
-          E3D_HIP(hipStreamSynchronize(s));
+          W.read_back(&n_back, L.counter.p + 2, sizeof(unsigned));
           E3D_HIP(hipGetLastError());
           if (getenv("E3D_KNN_STATS")) fprintf(stderr, "[knn] level %d wave-per-query pass: %u queries, %u handed to the lane-per-query kernel\n", level, n_next, n_back);
           if (n_back > 0) lane_per_query(fb_todo.p, (size_t)n_back, false);
         } else {
           lane_per_query(next, (size_t)n_next, true);
         }
-        E3D_HIP(hipMemcpyAsync(cw, L.counter.p + 1, sizeof(unsigned), hipMemcpyDeviceToHost, s));
-        E3D_HIP(hipStreamSynchronize(s));
+        W.read_back(cw, L.counter.p + 1, sizeof(unsigned));
         E3D_HIP(hipGetLastError());
         if (getenv("E3D_KNN_STATS")) fprintf(stderr, "[knn] level %d wide pass todo %u next %u\n", level, n_next, cw[0]);
         next = wide_out;

@@ -1739,6 +1739,10 @@ static void lm_compute(e3d_icp* h, LmSystem& L, std::vector<SE3f>& poses, e3d_ic
       }
     }
     rec.final_cost = cost;
+    {
+      static const bool lm_trace = getenv("E3D_LM_TRACE") != nullptr;
+      if (lm_trace) fprintf(stderr, "[lm trace] inner %d batch_all %d hit %d applied %d predicted_end %d\n", it, (int)batch_all, hit, (int)applied, predicted_end);
+    }
     if (!applied) { h->lm_prev_end_step = it; break; }
   }
 }

@@ -207,6 +207,7 @@ struct e3d_icp {
   DevBuf<int> match_pos;
   DevBuf<float> match_d2;
   DevBuf<unsigned> block_counts, block_offsets, block_groups, chunk_groups;
+  DevBuf<unsigned char> block_done;          // row-update blocks the certificate kernel settled whole (find_pairs_multi)
   DevBuf<double> block_d2, chunk_d2;
   DevBuf<unsigned long long> d_total, chunk_sum;
   DevBuf<double> d_total_d2;
@@ -1250,6 +1251,24 @@ static bool find_pairs_multi(e3d_icp* h, std::vector<BatchItem>& items, float d,
   }
   h->block_counts.reserve(upd_blocks); h->block_d2.reserve(upd_blocks); h->block_groups.reserve(upd_blocks);
   h->chunk_sum.reserve(chunks + 1); h->chunk_d2.reserve(chunks + 1); h->chunk_groups.reserve(chunks + 1); h->chunk_rewritten.reserve(chunks + 1);
+  // The certificate kernel writes the row update's per-block results for the 256-query blocks it settles whole, and the update skips
+  // those on one flag (E3D_NN_FUSE_UPDATE=0: off) -- for the pairs whose LAST certificate pass left fewer than E3D_NN_FUSE_GATE
+  // (default 0.3 %) of the queries unsettled: a block is settled whole with probability exp(-256 x that share) (46 % at the gate,
+  // 80 % at 0.09 %, the settled all-pairs job); below that the flag's extra round trip in front of every block of the update and
+  // the extra sums in the certificate kernel cost more than the skipped blocks save (measured: profiles/round6_certify_update_fusion.txt).
+  static const bool fuse_update = [] { const char* e = getenv("E3D_NN_FUSE_UPDATE"); return !(e && e[0] == '0'); }();
+  static const double fuse_gate = env_double("E3D_NN_FUSE_GATE", 0.003);
+  {
+    if (fuse_update && cert_blocks) { h->block_done.reserve(upd_blocks); E3D_HIP(hipMemsetAsync(h->block_done.p, 0, upd_blocks, s)); }
+    unsigned b0 = 0;
+    for (size_t i = 0; i < B; ++i) {
+      NnPairDev& P = T.pair[i];
+      const bool on = fuse_update && cert_blocks && items[i].certified && (1.0 - items[i].ps->settled_frac) < fuse_gate;
+      P.upd_counts = on ? h->block_counts.p + b0 : nullptr; P.upd_d2 = on ? h->block_d2.p + b0 : nullptr;
+      P.upd_groups = on ? h->block_groups.p + b0 : nullptr; P.upd_done = on ? h->block_done.p + b0 : nullptr;
+      b0 = T.upd_end[i];
+    }
+  }
   E3D_HIP(hipMemcpyAsync(h->d_batch.p, h->h_batch.p, sizeof(NnBatchDev), hipMemcpyHostToDevice, s));
   if (cert_blocks) {
     h->tm_certify.start(s);

@@ -1320,7 +1320,9 @@ __device__ __forceinline__ void nn_certify_body(const unsigned bx, const float4*
                                                 const MotionBound cum_up, float r2, float near2, int none_near, int* __restrict__ match,
                                                 int* __restrict__ match2, const float* __restrict__ lbe,
                                                 float* __restrict__ match_d2, unsigned* __restrict__ todo_near,
-                                                unsigned* __restrict__ todo_far, unsigned* __restrict__ counts) {
+                                                unsigned* __restrict__ todo_far, unsigned* __restrict__ counts,
+                                                unsigned* __restrict__ upd_counts = nullptr, double* __restrict__ upd_d2 = nullptr,
+                                                unsigned* __restrict__ upd_groups = nullptr, unsigned char* __restrict__ upd_done = nullptr) {
   __shared__ unsigned s_list[2][kBlock / kWave][kCertPerWave];
   __shared__ unsigned s_cnt[2][kBlock / kWave];
   __shared__ unsigned s_base[2];
@@ -1347,11 +1349,21 @@ __device__ __forceinline__ void nn_certify_body(const unsigned bx, const float4*
       c1[u] = Gtgt[mm[u] >= 0 ? mm[u] : 0];
       c2v[u] = Gtgt[(mm[u] >= 0 && mm2[u] >= 0) ? mm2[u] : 0];
     }
+    // (round 6, upd_done != nullptr) A 256-query block of the row update whose queries are ALL settled here, none of them by its
+    // runner-up, has nothing to rewrite, and its count, distance sum and active groups are known in this wave: four 64-query
+    // steps = one such block, the same wave_sum over the same lanes and the same sequential sum over the four groups as
+    // corr_update_body -- the same bits.  The update then skips the block on one flag instead of reading 12 B per query.
+    unsigned ub_c = 0, ub_g = 0, ub_gm = 0;
+    double ub_t = 0.0;
+    bool ub_bad = false;
+    static_assert(kCertUnroll == 4, "four steps of 64 queries = one block of the row update");
 #pragma unroll
     for (int u = 0; u < kCertUnroll; ++u) {
     const size_t j = jj[u];
     const bool valid = vv[u];
     bool ok = false, near = false;
+    bool swapped = false;
+    float v_ok = 0.f;
     if (valid) {
       const float thr = (ll[u] - motion_up(qq[u], cum_up)) * 0.999999f;
       const float lim = thr * thr * 0.999999f;
@@ -1368,12 +1380,12 @@ __device__ __forceinline__ void nn_certify_body(const unsigned bx, const float4*
           const float v2 = sqdist_l2(q.x, q.y, q.z, c2.x, c2.y, c2.z);
           if (v2 < v || (v2 == v && __float_as_uint(c2.w) < __float_as_uint(c.w))) {
             v = v2;
-            if (thr > 0.f && v < lim && v < r2) { match[j] = m2; match2[j] = m; }
+            if (thr > 0.f && v < lim && v < r2) { match[j] = m2; match2[j] = m; swapped = true; }
           }
         }
         ok = (thr > 0.f) && (v < lim) && (v < r2);
         near = v < near2;
-        if (ok) st_stream(match_d2 + j, v);
+        if (ok) { st_stream(match_d2 + j, v); v_ok = v; }
       } else {
         ok = (thr > 0.f) && (lim >= r2);
         near = none_near != 0;                          // k_nn_bounded searches these beyond the radius
@@ -1387,6 +1399,21 @@ __device__ __forceinline__ void nn_certify_body(const unsigned bx, const float4*
       else s_list[1][w][cf + (unsigned)__popcll(ff & below)] = (unsigned)j | (mm[u] < 0 ? kListNoPartner : 0u);
     }
     cn += (unsigned)__popcll(fn); cf += (unsigned)__popcll(ff);
+    if (upd_done) {
+      const bool f = valid && mm[u] >= 0;
+      const unsigned gc = (unsigned)__popcll(__ballot(f));
+      const double gd = wave_sum((f && ok) ? (double)v_ok : 0.0);
+      ub_c += gc; ub_t += gd;
+      if (gc) { ++ub_g; ub_gm |= 1u << u; }
+      if (__ballot(valid && (!ok || swapped))) ub_bad = true;
+    }
+    }
+    if (upd_done) {
+      const size_t blk = j0 / kBlock + (size_t)(step0 / kCertUnroll);
+      if (blk < (n + kBlock - 1) / kBlock && lane == 0) {
+        if (!ub_bad) { upd_counts[blk] = ub_c; upd_d2[blk] = ub_t; upd_groups[blk] = ub_g | (ub_gm << 8); }
+        upd_done[blk] = ub_bad ? 0 : 1;
+      }
     }
   }
   if (lane == 0) { s_cnt[0][w] = cn; s_cnt[1][w] = cf; }
@@ -1432,7 +1459,7 @@ __global__ __launch_bounds__(kBlock) void k_nn_certify_multi(const NnBatchDev* _
   const unsigned bx = blockIdx.x - (p ? B->cert_end[p - 1] : 0u);
   const NnPairDev& P = B->pair[p];
   nn_certify_body<4>(bx, P.Gsrc, (size_t)P.n, P.Gtgt, P.cum_up, r2, P.near2, P.none_near, P.match, P.match2, P.lbe, P.match_d2,
-                     P.todo_near, P.todo_far, P.counts);
+                     P.todo_near, P.todo_far, P.counts, P.upd_counts, P.upd_d2, P.upd_groups, P.upd_done);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -2042,7 +2069,8 @@ __device__ __forceinline__ void corr_update_body(const unsigned bx, const int* _
                                                  const float4* __restrict__ LNtgt, const int tgt_global, const Affine& Ttgt,
                                                  float4* __restrict__ A, float4* __restrict__ B, float4* __restrict__ C,
                                                  unsigned* __restrict__ block_counts, double* __restrict__ block_d2,
-                                                 unsigned* __restrict__ block_groups) {
+                                                 unsigned* __restrict__ block_groups, const unsigned char* __restrict__ done = nullptr) {
+  if (done && done[bx]) return;      // every query settled by its certificate: nn_certify_body wrote this block's results
   const size_t j = (size_t)bx * blockDim.x + threadIdx.x;
   const bool in = j < n;
   const int m = in ? ld_stream(match + j) : -1;
@@ -2105,7 +2133,7 @@ __global__ __launch_bounds__(kBlock) void k_corr_update_multi(const NnBatchDev* 
   const NnPairDev& P = Bt->pair[p];
   const Affine Ts = P.Tsrc, Tt = P.Ttgt;
   corr_update_body(blockIdx.x - b0, P.match, P.plane_match, P.match_d2, (size_t)P.n, P.Psrc, P.LNsrc, P.src_global, Ts, P.Ptgt, P.LNtgt,
-                   P.tgt_global, Tt, P.A, P.B, P.C, block_counts + b0, block_d2 + b0, block_groups + b0);
+                   P.tgt_global, Tt, P.A, P.B, P.C, block_counts + b0, block_d2 + b0, block_groups + b0, P.upd_done);
 }
 
 // ascending list of the active 64-row groups: one thread per query block (4 groups), scan inside the chunk + the chunk's base

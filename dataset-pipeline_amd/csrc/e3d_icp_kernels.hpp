@@ -152,6 +152,8 @@ struct NnPairDev {
   float4 *A, *B, *C;
   int* plane_match;
   unsigned* glist;
+  // per-block results of the row update that the certificate kernel writes itself for blocks it settles whole (round 6; nullptr: off)
+  unsigned* upd_counts; double* upd_d2; unsigned* upd_groups; unsigned char* upd_done;
   // far list of this search (k_query_keys_multi, k_nn_rows_multi; round 6)
   const unsigned* far_list;        // the listed queries (nullptr: all far_n queries of the pair)
   const unsigned* occ;             // target's occupancy bits of the 27-cell blocks

@@ -1,7 +1,8 @@
 """The library's alternative data flows give the same bits.  Their switches are environment variables read once per process, so
 each setting runs in its own interpreter: the certificate search of several directed pairs per host round trip against pair by
 pair or one launch per pair (E3D_ICP_BATCH = 0 / 1; default 2: one launch per kernel and batch), the far lists of a batch keyed, sorted and searched in one launch each against pair by pair (E3D_NN_FAR_BATCH), the LM step's damped solves on host threads (E3D_LM_SOLVE_THREADS), the certificates' motion bound per query against the clouds' global one (E3D_NN_PERQUERY), the key kernel that settles queries with an empty 27-cell block against sorting them all (E3D_NN_PRUNE), certificates tested in every outer iteration against skipped while none holds (E3D_NN_CERT_SKIP) and against no certificates at all (E3D_NN_CERT=0: every query searched in every iteration), resident against compacted correspondence rows (E3D_ICP_RESIDENT), the speculative last LM step
-(E3D_LM_SPECULATE); the kNN estimator's single scan with sampled thresholds against the two-pass kernels (E3D_KNN_SINGLE), with
+(E3D_LM_SPECULATE), the row update's per-block results written by the certificate kernel for the blocks it settles whole against the update
+computing them all (E3D_NN_FUSE_UPDATE = 0; E3D_NN_FUSE_GATE = 1: for every certified pair, not only the nearly settled ones); the kNN estimator's single scan with sampled thresholds against the two-pass kernels (E3D_KNN_SINGLE), with
 and without the lists the 125-cell pass starts from (E3D_KNN_SEED), the wave-per-query form of that pass (E3D_KNN_WIDE_WAVE), the sampled thresholds from the block population against the distance histogram, and deliberately poor ones (E3D_KNN_EST, E3D_KNN_EST_SCALE)."""
 import json
 import os
@@ -66,7 +67,8 @@ def test_icp_data_flows_agree():
     for env in ({"E3D_ICP_BATCH": "0"}, {"E3D_ICP_BATCH": "1"}, {"E3D_LM_SPECULATE": "0"}, {"E3D_NN_PERQUERY": "0"}, {"E3D_NN_PERQUERY": "0", "E3D_ICP_BATCH": "0"},
                 {"E3D_NN_PRUNE": "0"}, {"E3D_NN_PRUNE": "0", "E3D_ICP_BATCH": "0"}, {"E3D_NN_PRUNE_MIN": "1", "E3D_ICP_BATCH": "1"},
                 {"E3D_NN_CERT_SKIP": "0"}, {"E3D_NN_CERT_SKIP": "0", "E3D_ICP_BATCH": "0"}, {"E3D_NN_CERT": "0"}, {"E3D_NN_CERT": "0", "E3D_NN_PRUNE": "0"},
-                {"E3D_NN_FAR_BATCH": "0"}, {"E3D_NN_FAR_BATCH": "0", "E3D_NN_PRUNE": "0"}, {"E3D_NN_PRUNE_MIN": "1"}, {"E3D_LM_SOLVE_THREADS": "0"}):
+                {"E3D_NN_FAR_BATCH": "0"}, {"E3D_NN_FAR_BATCH": "0", "E3D_NN_PRUNE": "0"}, {"E3D_NN_PRUNE_MIN": "1"}, {"E3D_LM_SOLVE_THREADS": "0"},
+                {"E3D_NN_FUSE_UPDATE": "0"}, {"E3D_NN_FUSE_GATE": "1.0"}, {"E3D_NN_FUSE_GATE": "1.0", "E3D_NN_CERT_SKIP": "0"}):
         other = _run(ICP_CODE, env)
         assert strip(other) == strip(base), env                      # same kernel bodies, same sums: bit for bit
         if env == {"E3D_NN_PERQUERY": "0"}:

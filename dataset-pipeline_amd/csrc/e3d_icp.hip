@@ -1713,6 +1713,18 @@ static void lm_compute(e3d_icp* h, LmSystem& L, std::vector<SE3f>& poses, e3d_ic
     } else if (!distinct.empty()) { lm_evaluate_costs(h, L, distinct, dcosts, rec); rec.multi_cost_poses += (int)distinct.size(); }
     else rec.lm_passes_skipped++;
     for (int k = first; k < 10; ++k) costs[k] = (slot[k] < 0) ? cost : dcosts[slot[k]];
+    {
+      static const bool lm_trace = getenv("E3D_LM_TRACE") != nullptr;
+      if (lm_trace) {                                   // how many clouds keep their f32 pose in each try (diagnostics)
+        fprintf(stderr, "[lm trace] tries %d..9, clouds with an unchanged pose of %zu:", first, poses.size());
+        for (int k = first; k < 10; ++k) {
+          int same = 0;
+          for (size_t ci = 0; ci < poses.size(); ++ci) if (std::memcmp(&cand[k][ci], &poses[ci], sizeof(SE3f)) == 0) ++same;
+          fprintf(stderr, " %d", same);
+        }
+        fprintf(stderr, "\n");
+      }
+    }
   };
   // Try 0 is usually accepted, so its cost is evaluated together with the next step's H and b (one fused pass) -- except in the LM
   // step an alignment that has settled ends with: there all ten tries are rejected, and the fused pass's H and b are thrown away.

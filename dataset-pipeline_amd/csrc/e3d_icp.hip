@@ -1300,18 +1300,27 @@ static bool find_pairs_multi(e3d_icp* h, std::vector<BatchItem>& items, float d,
       it.n_near += it.n_far; it.n_far = 0;
     }
   }
-  if (T.n_jobs > 0) {
+  auto launch_bounded_jobs = [&] {
+    if (T.n_jobs <= 0) return;
     E3D_HIP(hipMemcpyAsync(h->d_batch.p, h->h_batch.p, sizeof(NnBatchDev), hipMemcpyHostToDevice, s));
     h->tm_bounded.start(s);
     launch_nn_bounded_half_multi(h->d_batch.p, job_blocks, radius_sq(d), s);
     h->tm_bounded.stop(s);
     rec.nn_bounded_launches++; rec.nn_bounded_queries += job_queries; rec.nn_kernel_launches++;
-  }
+  };
   // the far lists that are too long for the bounded search (first outer iterations): ONE key kernel, ONE sort, ONE k_nn_rows launch
   // for the batch (round 6; E3D_NN_FAR_BATCH=0: pair by pair as in round 5).  The pair's index rides above the cell key, so the
   // batch's keys need key_bits + log2(pairs) bits: 8-byte (key, query) pairs while that fits 32 bits.
   static const bool far_batch = [] { const char* e = getenv("E3D_NN_FAR_BATCH"); return !(e && e[0] == '0'); }();
   static const size_t prune_min_list = (size_t)env_double("E3D_NN_PRUNE_MIN", 262144.0);
+  // SEEDS (k_query_seed_multi): once a fair share of a pair's queries found a partner in the last search (the scans are about to
+  // meet, or have met), the key kernel probes the query's own half cell and the old partner; a query with a target point nearer than
+  // E3D_NN_SEED_NEAR x radius takes it as its partner to start from and goes through the bounded search instead of sort + k_nn_rows.
+  // E3D_NN_SEED=0: off; E3D_NN_SEED_FRAC: the matched share of the last search from which a pair's far list is seeded.
+  static const bool seed_allowed = [] { const char* e = getenv("E3D_NN_SEED"); return !(e && e[0] == '0'); }();
+  static const double seed_frac = env_double("E3D_NN_SEED_FRAC", 0.3), seed_near = env_double("E3D_NN_SEED_NEAR", 0.4);
+  static const bool seed_fresh = env_double("E3D_NN_SEED_FRESH", 0.0) != 0.0;      // (a pair's first search: nothing is known about it)
+  auto seeds_for = [&](const BatchItem& it) { return seed_allowed && it.n_far > 0 && (it.ps->fresh ? seed_fresh : it.ps->matched_frac >= seed_frac); };
   size_t far_pairs = 0, far_total = 0;
   int kb_max = 1;
   for (size_t i = 0; i < B; ++i) if (items[i].n_far > 0) { ++far_pairs; far_total += items[i].n_far; kb_max = std::max(kb_max, items[i].tgt->key_bits); }
@@ -1319,52 +1328,73 @@ static bool find_pairs_multi(e3d_icp* h, std::vector<BatchItem>& items, float d,
   while (((size_t)1 << pair_bits) < B) ++pair_bits;
   // (a batch whose keys would need 12-byte pairs only because of the pair bits keeps the 8-byte pairs of the pair-by-pair path)
   const bool far_multi = far_batch && far_pairs > 0 && (kb_max + pair_bits <= 32 || kb_max > 31) && kb_max + pair_bits <= 63;
+  if (!far_multi) launch_bounded_jobs();
   if (far_multi) {
     const bool k32 = kb_max + pair_bits <= 32;
+    bool seed_any = false;
+    for (size_t i = 0; i < B; ++i)
+      if (seeds_for(items[i])) seed_any = true;
+    const size_t key_block = seed_any ? (size_t)kQuerySeedBlock : (size_t)kQueryKeysBlock;
     unsigned key_blocks = 0;
     for (size_t i = 0; i < B; ++i) {
       BatchItem& it = items[i];
       NnPairDev& P = T.pair[i];
-      P.far_n = 0; P.far_list = nullptr; P.far_flags = 0; P.occ = nullptr; P.occ_stride = 0; P.rows_off = 0; P.rows_n = 0;
+      P.far_n = 0; P.far_list = nullptr; P.far_flags = 0; P.occ = nullptr; P.occ_stride = 0; P.rows_off = 0; P.rows_n = 0; P.seed_list = nullptr; P.seed2 = 0.f;
       if (it.n_far > 0) {
         const bool prune = it.tgt->has_occ && it.ps->prune && it.n_far >= prune_min_list;       // (sort_query_keys_pruned's rule)
+        const bool seed = seeds_for(it);
         P.far_n = (unsigned)it.n_far;
         P.far_list = it.certified ? h->slots[i]->todo_far.p : nullptr;
-        P.far_flags = ((prune && it.from_state && !it.certified) ? 1 : 0) | (prune ? 2 : 0);
+        P.far_flags = ((prune && it.from_state && !it.certified) ? 1 : 0) | (prune ? 2 : 0) | (seed ? 4 : 0);
         P.occ = it.tgt->has_occ ? it.tgt->occ27.p : nullptr; P.occ_stride = it.tgt->occ_stride;
-        key_blocks += (unsigned)div_up(it.n_far, (size_t)kQueryKeysBlock);
+        // (the seeded list behind the pair's near list: the two together are at most the pair's queries)
+        P.seed_list = h->slots[i]->todo_near.p + (it.certified ? (size_t)h->h_todo_all.p[2 * i] : 0);
+        P.seed2 = (float)((seed_near * (double)d) * (seed_near * (double)d));
+        key_blocks += (unsigned)div_up(it.n_far, key_block);
       }
       T.far_end[i] = key_blocks;
     }
     T.key_shift = kb_max;
     h->keys_a.reserve(far_total); h->keys_b.reserve(far_total); h->vals_a.reserve(far_total); h->vals_b.reserve(far_total);
-    h->prune_count.reserve(1 + kPairBatch); h->h_prune_count.reserve(1 + kPairBatch);
+    constexpr size_t kCounts = 1 + 2 * (size_t)kNnBatchPairs;
+    h->prune_count.reserve(kCounts); h->h_prune_count.reserve(kCounts);
     E3D_HIP(hipMemcpyAsync(h->d_batch.p, h->h_batch.p, sizeof(NnBatchDev), hipMemcpyHostToDevice, s));
     h->tm_sort.start(s);
-    E3D_HIP(hipMemsetAsync(h->prune_count.p, 0, sizeof(unsigned) * (1 + B), s));
-    launch_query_keys_multi(k32, h->d_batch.p, key_blocks, radius_sq(d), h->keys_a.p, h->vals_a.p, h->prune_count.p, s);
-    copy_out(h->h_prune_count.p, h->prune_count.p, sizeof(unsigned) * (1 + B), s);
+    E3D_HIP(hipMemsetAsync(h->prune_count.p, 0, sizeof(unsigned) * kCounts, s));
+    if (seed_any) launch_query_seed_multi(k32, h->d_batch.p, key_blocks, radius_sq(d), h->keys_a.p, h->vals_a.p, h->prune_count.p, s);
+    else launch_query_keys_multi(k32, h->d_batch.p, key_blocks, radius_sq(d), h->keys_a.p, h->vals_a.p, h->prune_count.p, s);
+    h->tm_sort.stop(s);
+    copy_out(h->h_prune_count.p, h->prune_count.p, sizeof(unsigned) * kCounts, s);
     sync(h);
     const size_t kept_total = h->h_prune_count.p[0];
     unsigned row_blocks = 0, off = 0;
     for (size_t i = 0; i < B; ++i) {
       BatchItem& it = items[i];
       NnPairDev& P = T.pair[i];
-      const unsigned kept = h->h_prune_count.p[1 + i];
-      if ((P.far_flags & 2) && (double)kept > 0.9 * (double)it.n_far) it.ps->prune = false;
+      const unsigned kept = h->h_prune_count.p[1 + i], seeded = seed_any ? h->h_prune_count.p[1 + (size_t)kNnBatchPairs + i] : 0u;
+      if ((P.far_flags & 2) && (double)kept + (double)seeded > 0.9 * (double)it.n_far) it.ps->prune = false;
       P.rows_off = off; P.rows_n = kept; off += kept;
       row_blocks += (unsigned)div_up((size_t)kept, kBlock);
       T.rows_end[i] = row_blocks;
       if (kept > 0) rec.nn_search_queries += (long long)kept;
+      if (seeded > 0) {                                     // the seeded queries: one more list job of the bounded search
+        const int jb = T.n_jobs++;
+        T.job_pair[jb] = (int)i; T.job_list[jb] = P.seed_list; T.job_n[jb] = seeded;
+        job_blocks += (unsigned)div_up((size_t)seeded, kBlock); T.job_end[jb] = job_blocks;
+        job_queries += (long long)seeded;
+        it.n_near += seeded; it.n_far -= std::min((size_t)seeded, it.n_far);
+      }
     }
+    launch_bounded_jobs();
     if (kept_total > 0) {
+      h->tm_sort.start(s);
       // (the temporary storage for the lists' whole length: the kept count grows from one outer iteration to the next, e3d_sort.hip)
       if (k32) sort_pairs_u32_u32(reinterpret_cast<unsigned*>(h->keys_a.p), reinterpret_cast<unsigned*>(h->keys_b.p), h->vals_a.p, h->vals_b.p, kept_total, kb_max + pair_bits, h->sort_temp, s, far_total);
       else sort_pairs_u64_u32(h->keys_a.p, h->keys_b.p, h->vals_a.p, h->vals_b.p, kept_total, kb_max + pair_bits, h->sort_temp, s, far_total);
+      h->tm_sort.stop(s);
     }
-    h->tm_sort.stop(s);
     rec.nn_kernel_launches++; rec.nn_sort_calls++;
-    E3D_HIP(hipMemcpyAsync(h->d_batch.p, h->h_batch.p, sizeof(NnBatchDev), hipMemcpyHostToDevice, s));     // (the pairs' stretches of the sorted array)
+    if (T.n_jobs <= 0) E3D_HIP(hipMemcpyAsync(h->d_batch.p, h->h_batch.p, sizeof(NnBatchDev), hipMemcpyHostToDevice, s));     // (the pairs' stretches of the sorted array)
     if (kept_total > 0) {
       h->tm_search.start(s);
       launch_nn_rows_multi(h->d_batch.p, row_blocks, h->vals_b.p, radius_sq(d), s);

@@ -1892,6 +1892,182 @@ __global__ __launch_bounds__(kBlock) void k_query_keys_multi(const NnBatchDev* _
                               (flags & 2) != 0, P.match, P.match2, P.match_d2, P.lbe, flags & 1);
 }
 
+// The far lists' key kernel WITH SEEDS (round 6).  While two scans meet, every query changes its partner: the far lists hold all
+// queries, k_nn_rows scores each against the ~10^3 candidates of its row segments (12 ms per 100 M queries, after a 3.5 ms sort).
+// But most of those queries have a target point a few millimetres away -- and any target point at distance s bounds the search to
+// the ball of radius s, which is what the bounded search (k_nn_bounded_half) does around an OLD partner at a third of the cost.
+// This kernel gives a query a partner to start from: after the occupancy test of k_query_keys_prune it probes up to kSeedProbes
+// points of the query's own half cell (the cell's prefix bytes; an empty half cell: points spread over the whole cell) and the old
+// partner, if any.  A query with a probe (or old partner) nearer than sqrt(seed2) gets that point as match[j] and goes to the
+// pair's SEEDED list -- a job of the bounded search, which treats it like any near-list query (the ball around a real target point
+// at its exact f32 distance: the exact search inside it finds the nearest neighbour, ties included); the others are keyed for the
+// sort and k_nn_rows as before.  Results are those of either exact search: identical.
+constexpr int kSeedProbes = 8, kSeedPerThread = 4;
+static_assert((unsigned)(kBlock * kSeedPerThread) == kQuerySeedBlock, "queries per block of the seeding key kernel");
+template <typename KeyT>
+__global__ __launch_bounds__(kBlock) void k_query_seed_multi(const NnBatchDev* __restrict__ B, float r2, KeyT* __restrict__ keys, unsigned* __restrict__ vals,
+                                                             unsigned* __restrict__ counts) {
+  __shared__ unsigned s_cnt[2][kBlock / kWave][kSeedPerThread];
+  __shared__ unsigned s_base[2];
+  const int p = nn_find_range(B->far_end, B->n_pairs, blockIdx.x);
+  const unsigned bx = blockIdx.x - (p ? B->far_end[p - 1] : 0u);
+  const NnPairDev& P = B->pair[p];
+  const GridDesc g = P.g; const InvMap im = P.im; const QueryRange qr = P.qr;
+  const CertParams cert = {P.bp.cell_scale, P.bp.cell_sub, P.bp.lo};
+  const int shift = B->key_shift;
+  const KeyT key_mask = (KeyT)(((KeyT)1 << shift) - (KeyT)1), key_or = (KeyT)((KeyT)p << shift);
+  const int flags = __builtin_amdgcn_readfirstlane(P.far_flags);
+  const bool from_state = (flags & 1) != 0, prune = (flags & 2) != 0, seed_on = (flags & 4) != 0;
+  const float4* __restrict__ Gsrc = P.Gsrc; const float4* __restrict__ Gtgt = P.Gtgt;
+  const unsigned* __restrict__ list = P.far_list; const unsigned* __restrict__ occ = P.occ; const unsigned* __restrict__ S = P.S;
+  const unsigned long long* __restrict__ H8 = P.H8;
+  int* __restrict__ match = P.match; int* __restrict__ match2 = P.match2; float* __restrict__ match_d2 = P.match_d2; float* __restrict__ lbe = P.lbe;
+  const size_t n = (size_t)P.far_n;
+  const unsigned stride_w = P.occ_stride;
+  const float seed2 = P.seed2;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const size_t i0 = (size_t)bx * (kBlock * kSeedPerThread) + (size_t)w * kWave + (size_t)lane;      // step u: + u * kBlock
+  KeyT kk[kSeedPerThread];
+  unsigned jf[kSeedPerThread];
+  float4 qq[kSeedPerThread];
+  unsigned long long keyed_mask[kSeedPerThread], seeded_mask[kSeedPerThread];       // wave-uniform ballots
+#pragma unroll
+  for (int u = 0; u < kSeedPerThread; ++u) {
+    const size_t i = i0 + (size_t)u * kBlock;
+    jf[u] = (i < n) ? (list ? list[i] : ((unsigned)i | ((from_state && match[i] < 0) ? kListNoPartner : 0u))) : 0u;
+  }
+#pragma unroll
+  for (int u = 0; u < kSeedPerThread; ++u) qq[u] = Gsrc[jf[u] & kListIndexMask];
+  unsigned wordv[kSeedPerThread];
+  int bitv[kSeedPerThread];
+  float bdist[kSeedPerThread];
+  unsigned long long lin[kSeedPerThread];
+  unsigned code[kSeedPerThread];
+#pragma unroll
+  for (int u = 0; u < kSeedPerThread; ++u) {
+    const float4 q = qq[u];
+    const float dx = q.x - im.t[0], dy = q.y - im.t[1], dz = q.z - im.t[2];
+    const float lx = im.Linv[0] * dx + im.Linv[1] * dy + im.Linv[2] * dz;
+    const float ly = im.Linv[3] * dx + im.Linv[4] * dy + im.Linv[5] * dz;
+    const float lz = im.Linv[6] * dx + im.Linv[7] * dy + im.Linv[8] * dz;
+    int cx = 0, cy = 0, cz = 0;
+    bdist[u] = 2.0f;
+    lin[u] = query_cell_key(q, im, g, qr, cx, cy, cz, &bdist[u]);
+    code[u] = half_code(lx, ly, lz, g);
+    kk[u] = ((KeyT)lin[u] & key_mask) | key_or;
+    wordv[u] = 0u; bitv[u] = -1;
+    if (lin[u] != kEmptyKey) {
+      if (prune) {
+        const int kx = cx - qr.lo[0], ky = cy - qr.lo[1], kz = cz - qr.lo[2];
+        wordv[u] = occ[((size_t)kz * qr.D[1] + (size_t)ky) * stride_w + (size_t)(kx >> 5)];
+        bitv[u] = kx & 31;
+      }
+    } else {
+      bdist[u] = 2.0f;                                   // outside the directory range: two empty cells all around (k_nn_rows)
+    }
+  }
+  // the own cell's run and prefix bytes, the old partner: requested for all steps before any is used
+  bool keep[kSeedPerThread];
+  unsigned s0[kSeedPerThread], s1[kSeedPerThread];
+  unsigned long long h8[kSeedPerThread];
+  int mm[kSeedPerThread];
+#pragma unroll
+  for (int u = 0; u < kSeedPerThread; ++u) {
+    const size_t i = i0 + (size_t)u * kBlock;
+    const bool valid = i < n;
+    keep[u] = valid && (prune ? (bitv[u] >= 0 && ((wordv[u] >> bitv[u]) & 1u)) : true);
+    const bool probe = keep[u] && seed_on && lin[u] != kEmptyKey;
+    const size_t l = probe ? (size_t)lin[u] : 0;
+    s0[u] = S[l]; s1[u] = S[l + 1];
+    h8[u] = H8[l];
+    mm[u] = probe ? match[jf[u] & kListIndexMask] : -1;
+    if (!probe) { s0[u] = 0u; s1[u] = 0u; }
+  }
+#pragma unroll
+  for (int u = 0; u < kSeedPerThread; ++u) {
+    const size_t i = i0 + (size_t)u * kBlock;
+    const bool valid = i < n;
+    const unsigned j = jf[u] & kListIndexMask;
+    const float4 q = qq[u];
+    if (valid && from_state && (jf[u] & kListNoPartner)) match_d2[j] = r2;
+    if (valid && !keep[u]) {
+      if (!(jf[u] & kListNoPartner)) {                   // (see k_nn_rows: a query that had no partner holds these values already)
+        match[j] = -1; match_d2[j] = r2;
+        if (match2) match2[j] = -1;
+      }
+      const float kInf = __uint_as_float(0x7f800000u);
+      const float lb_out = bdist[u] * cert.cell_scale - cert.cell_sub;
+      lbe[j] = fmaxf(fminf(sqrtf(kInf), lb_out), 0.0f) * 0.999999f + motion_lo(q, cert.lo);
+    }
+    // probes: the own half cell's run, else the whole cell
+    unsigned a = s0[u], b = s1[u];
+    if (h8[u] != ~0ull && b > a) {
+      const unsigned c = code[u];
+      const unsigned e_hi = (unsigned)(h8[u] >> (8 * c)) & 0xFFu, e_lo = c ? ((unsigned)(h8[u] >> (8 * (c - 1))) & 0xFFu) : 0u;
+      if (e_hi > e_lo) { b = a + e_hi; a = a + e_lo; }
+    }
+    const unsigned len = b - a;
+    float4 c4[kSeedProbes];
+    unsigned pp[kSeedProbes];
+#pragma unroll
+    for (int t = 0; t < kSeedProbes; ++t) {
+      const unsigned o = len > (unsigned)kSeedProbes ? ((unsigned)t * len) / (unsigned)kSeedProbes : min((unsigned)t, len ? len - 1u : 0u);
+      pp[t] = a + o;                                     // (no point in the cell: len = 0, position a = 0: a valid address, result ignored)
+      c4[t] = Gtgt[pp[t]];
+    }
+    const float4 co = Gtgt[mm[u] >= 0 ? mm[u] : 0];
+    const unsigned uinf = 0x7f800000u;
+    unsigned ub = uinf;
+    int bpos = -1;
+#pragma unroll
+    for (int t = 0; t < kSeedProbes; ++t) {
+      const unsigned ud = len ? __float_as_uint(sqdist_l2(q.x, q.y, q.z, c4[t].x, c4[t].y, c4[t].z)) : uinf;     // (bit patterns: as k_nn_bounded_half)
+      bpos = ud < ub ? (int)pp[t] : bpos;
+      ub = min(ud, ub);
+    }
+    const unsigned uo = mm[u] >= 0 ? __float_as_uint(sqdist_l2(q.x, q.y, q.z, co.x, co.y, co.z)) : uinf;
+    const unsigned us = __float_as_uint(seed2);
+    const bool by_old = uo < us && uo <= ub;              // the old partner (and its runner-up) stay: the bounded search reads both
+    const bool by_probe = !by_old && ub < us;
+    if (by_probe) { match[j] = bpos; if (match2) match2[j] = -1; }
+    const bool seeded = keep[u] && (by_old || by_probe);
+    keyed_mask[u] = __ballot(keep[u] && !seeded);
+    seeded_mask[u] = __ballot(seeded);
+    if (lane == 0) { s_cnt[0][w][u] = (unsigned)__popcll(keyed_mask[u]); s_cnt[1][w][u] = (unsigned)__popcll(seeded_mask[u]); }
+  }
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    const int k = threadIdx.x;
+    unsigned tot = 0u;
+    for (int ww = 0; ww < kBlock / kWave; ++ww)
+      for (int u = 0; u < kSeedPerThread; ++u) tot += s_cnt[k][ww][u];
+    // counts[0]: keyed pairs of the batch (the sort's size), counts[1 + p]: of this pair, counts[1 + kNnBatchPairs + p]: seeded
+    s_base[k] = 0u;
+    if (tot) {
+      if (k == 0) { s_base[0] = atomicAdd(counts, tot); atomicAdd(counts + 1 + p, tot); }
+      else s_base[1] = atomicAdd(counts + 1 + kNnBatchPairs + p, tot);
+    }
+  }
+  __syncthreads();
+  unsigned offk = s_base[0], offs = s_base[1];
+  for (int ww = 0; ww < w; ++ww)
+#pragma unroll
+    for (int u = 0; u < kSeedPerThread; ++u) { offk += s_cnt[0][ww][u]; offs += s_cnt[1][ww][u]; }
+  unsigned* __restrict__ seed_list = P.seed_list;
+  const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int u = 0; u < kSeedPerThread; ++u) {
+    if ((keyed_mask[u] >> lane) & 1ull) {
+      const unsigned slot = offk + (unsigned)__popcll(keyed_mask[u] & below);
+      keys[slot] = kk[u];
+      vals[slot] = jf[u];
+    }
+    if ((seeded_mask[u] >> lane) & 1ull) seed_list[offs + (unsigned)__popcll(seeded_mask[u] & below)] = jf[u] & kListIndexMask;
+    offk += (unsigned)__popcll(keyed_mask[u]);
+    offs += (unsigned)__popcll(seeded_mask[u]);
+  }
+}
+
 __global__ __launch_bounds__(kBlock, 6) void k_nn_rows_multi(const NnBatchDev* __restrict__ B, const unsigned* __restrict__ order, float r2, int row_span) {
   const int p = nn_find_range(B->rows_end, B->n_pairs, blockIdx.x);
   const unsigned bx = blockIdx.x - (p ? B->rows_end[p - 1] : 0u);
@@ -3052,6 +3228,11 @@ void launch_query_keys_multi(bool keys32, const NnBatchDev* batch, unsigned n_bl
   if (!n_blocks) return;
   if (keys32) hipLaunchKernelGGL(k_query_keys_multi<unsigned>, dim3(n_blocks), dim3(kBlock), 0, s, batch, r2, (unsigned*)keys, vals, counts);
   else hipLaunchKernelGGL(k_query_keys_multi<unsigned long long>, dim3(n_blocks), dim3(kBlock), 0, s, batch, r2, (unsigned long long*)keys, vals, counts);
+}
+void launch_query_seed_multi(bool keys32, const NnBatchDev* batch, unsigned n_blocks, float r2, void* keys, unsigned* vals, unsigned* counts, hipStream_t s) {
+  if (!n_blocks) return;
+  if (keys32) hipLaunchKernelGGL(k_query_seed_multi<unsigned>, dim3(n_blocks), dim3(kBlock), 0, s, batch, r2, (unsigned*)keys, vals, counts);
+  else hipLaunchKernelGGL(k_query_seed_multi<unsigned long long>, dim3(n_blocks), dim3(kBlock), 0, s, batch, r2, (unsigned long long*)keys, vals, counts);
 }
 void launch_nn_rows_multi(const NnBatchDev* batch, unsigned n_blocks, const unsigned* order, float r2, hipStream_t s) {
   if (!n_blocks) return;

@@ -158,10 +158,15 @@ struct NnPairDev {
   const unsigned* far_list;        // the listed queries (nullptr: all far_n queries of the pair)
   const unsigned* occ;             // target's occupancy bits of the 27-cell blocks
   unsigned far_n, occ_stride;
-  int far_flags;                   // bit 0: flags "had no partner" come from the state (list == nullptr), bit 1: settle the queries of empty blocks
+  int far_flags;                   // bit 0: flags "had no partner" come from the state (list == nullptr), bit 1: settle the queries of empty blocks, bit 2: seeds
   unsigned rows_off, rows_n;       // the pair's stretch of the batch's sorted (key, query) array
+  // seeds (k_query_seed_multi; far_flags bit 2): far-list queries with a probe of their own half cell (or their old partner) nearer
+  // than sqrt(seed2) take that point as match[j] and go to seed_list -- a job of the bounded search -- instead of sort + k_nn_rows
+  unsigned* seed_list;
+  float seed2;
 };
 constexpr unsigned kQueryKeysBlock = 2048;   // queries per block of the compacting key kernels
+constexpr unsigned kQuerySeedBlock = 1024;   // ... of the seeding key kernel (k_query_seed_multi)
 struct NnBatchDev {
   int n_pairs, n_jobs;
   int key_shift;                       // bits of the cell keys in the batch's sort keys; the pair's index sits above them
@@ -180,6 +185,9 @@ void launch_nn_certify_multi(const NnBatchDev* batch, unsigned n_blocks, float r
 void launch_nn_bounded_half_multi(const NnBatchDev* batch, unsigned n_blocks, float r2, hipStream_t s);
 // far lists of a batch: counts[0] = (key, query) pairs written by all pairs, counts[1 + p] = by pair p (cleared by the caller)
 void launch_query_keys_multi(bool keys32, const NnBatchDev* batch, unsigned n_blocks, float r2, void* keys, unsigned* vals, unsigned* counts, hipStream_t s);
+// the same with seeds for the pairs whose far_flags carry bit 2 (block ranges far_end in units of kQuerySeedBlock queries):
+// counts[1 + kNnBatchPairs + p] = queries of pair p written to its seed_list
+void launch_query_seed_multi(bool keys32, const NnBatchDev* batch, unsigned n_blocks, float r2, void* keys, unsigned* vals, unsigned* counts, hipStream_t s);
 void launch_nn_rows_multi(const NnBatchDev* batch, unsigned n_blocks, const unsigned* order, float r2, hipStream_t s);
 void launch_corr_update_multi(const NnBatchDev* batch, unsigned n_blocks, unsigned* block_counts, double* block_d2, unsigned* block_groups, hipStream_t s);
 // totals[3 p ..] = correspondences, active groups, rows rewritten of pair p; total_d2[p]; the pairs' group lists (three launches)

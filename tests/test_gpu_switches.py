@@ -2,7 +2,7 @@
 each setting runs in its own interpreter: the certificate search of several directed pairs per host round trip against pair by
 pair or one launch per pair (E3D_ICP_BATCH = 0 / 1; default 2: one launch per kernel and batch), the far lists of a batch keyed, sorted and searched in one launch each against pair by pair (E3D_NN_FAR_BATCH), the LM step's damped solves on host threads (E3D_LM_SOLVE_THREADS), the certificates' motion bound per query against the clouds' global one (E3D_NN_PERQUERY), the key kernel that settles queries with an empty 27-cell block against sorting them all (E3D_NN_PRUNE), certificates tested in every outer iteration against skipped while none holds (E3D_NN_CERT_SKIP) and against no certificates at all (E3D_NN_CERT=0: every query searched in every iteration), resident against compacted correspondence rows (E3D_ICP_RESIDENT), the speculative last LM step
 (E3D_LM_SPECULATE), the row update's per-block results written by the certificate kernel for the blocks it settles whole against the update
-computing them all (E3D_NN_FUSE_UPDATE = 0; E3D_NN_FUSE_GATE = 1: for every certified pair, not only the nearly settled ones); the kNN estimator's single scan with sampled thresholds against the two-pass kernels (E3D_KNN_SINGLE), with
+computing them all (E3D_NN_FUSE_UPDATE = 0; E3D_NN_FUSE_GATE = 1: for every certified pair, not only the nearly settled ones), far-list queries that start the bounded search from a probe of their own half cell against sort + row kernel for all of them (E3D_NN_SEED = 0; E3D_NN_SEED_FRAC / _NEAR / _FRESH: from the first search on, other seed distances); the kNN estimator's single scan with sampled thresholds against the two-pass kernels (E3D_KNN_SINGLE), with
 and without the lists the 125-cell pass starts from (E3D_KNN_SEED), the wave-per-query form of that pass (E3D_KNN_WIDE_WAVE), the sampled thresholds from the block population against the distance histogram, and deliberately poor ones (E3D_KNN_EST, E3D_KNN_EST_SCALE)."""
 import json
 import os
@@ -64,11 +64,15 @@ def test_icp_data_flows_agree():
     assert len(base["pairs"]) > 0
     assert base["batches"] > 0 and base["certified"] > 0             # the default ran batches of pairs through the one-launch kernels
     strip = lambda r: {k: r[k] for k in ("pairs", "poses")}
+    noseed = _run(ICP_CODE, {"E3D_NN_SEED": "0"})
     for env in ({"E3D_ICP_BATCH": "0"}, {"E3D_ICP_BATCH": "1"}, {"E3D_LM_SPECULATE": "0"}, {"E3D_NN_PERQUERY": "0"}, {"E3D_NN_PERQUERY": "0", "E3D_ICP_BATCH": "0"},
                 {"E3D_NN_PRUNE": "0"}, {"E3D_NN_PRUNE": "0", "E3D_ICP_BATCH": "0"}, {"E3D_NN_PRUNE_MIN": "1", "E3D_ICP_BATCH": "1"},
                 {"E3D_NN_CERT_SKIP": "0"}, {"E3D_NN_CERT_SKIP": "0", "E3D_ICP_BATCH": "0"}, {"E3D_NN_CERT": "0"}, {"E3D_NN_CERT": "0", "E3D_NN_PRUNE": "0"},
                 {"E3D_NN_FAR_BATCH": "0"}, {"E3D_NN_FAR_BATCH": "0", "E3D_NN_PRUNE": "0"}, {"E3D_NN_PRUNE_MIN": "1"}, {"E3D_LM_SOLVE_THREADS": "0"},
-                {"E3D_NN_FUSE_UPDATE": "0"}, {"E3D_NN_FUSE_GATE": "1.0"}, {"E3D_NN_FUSE_GATE": "1.0", "E3D_NN_CERT_SKIP": "0"}):
+                {"E3D_NN_FUSE_UPDATE": "0"}, {"E3D_NN_FUSE_GATE": "1.0"}, {"E3D_NN_FUSE_GATE": "1.0", "E3D_NN_CERT_SKIP": "0"},
+                {"E3D_NN_SEED": "0"}, {"E3D_NN_SEED_FRAC": "0", "E3D_NN_SEED_FRESH": "1"}, {"E3D_NN_SEED_FRAC": "0", "E3D_NN_SEED_NEAR": "1.0"},
+                {"E3D_NN_SEED_FRAC": "0", "E3D_NN_PRUNE": "0"}, {"E3D_NN_SEED_FRAC": "0", "E3D_NN_CERT": "0", "E3D_NN_SEED_NEAR": "0.7"},
+                {"E3D_NN_SEED_FRAC": "0", "E3D_NN_CERT_SKIP": "0"}):
         other = _run(ICP_CODE, env)
         assert strip(other) == strip(base), env                      # same kernel bodies, same sums: bit for bit
         if env == {"E3D_NN_PERQUERY": "0"}:
@@ -81,8 +85,13 @@ def test_icp_data_flows_agree():
             print("queries the row kernel visited: %d with the key kernel settling empty blocks, %d without" % (base["rows_queries"], other["rows_queries"]))
         if env == {"E3D_NN_FAR_BATCH": "0"}:
             # round 6: the far lists of a batch of pairs keyed, sorted and searched in one launch each instead of pair by pair
-            assert other["launches"] > base["launches"] and other["rows_queries"] == base["rows_queries"], (other["launches"], base["launches"])
+            # (the pair-by-pair path has no seeds: its row kernel visits what the batch's visits without them)
+            assert other["launches"] > base["launches"] and other["rows_queries"] == noseed["rows_queries"], (other["launches"], base["launches"])
             print("kernel launches of the NN phase: %d with the far lists of a batch in one launch, %d pair by pair" % (base["launches"], other["launches"]))
+        if env == {"E3D_NN_SEED": "0"}:
+            # round 6: far-list queries with a target point close by start the bounded search from it instead of going through the sort and the row kernel
+            assert other["rows_queries"] > base["rows_queries"], (other["rows_queries"], base["rows_queries"])
+            print("queries the row kernel visited: %d with seeds, %d without" % (base["rows_queries"], other["rows_queries"]))
         if list(env) == ["E3D_ICP_BATCH"]:
             assert other["batches"] == 0 and other["launches"] > base["launches"], (env, other["launches"], base["launches"])
     # resident vs compacted rows: the pair records (counts, distance sums) are those of the same searches; the LM passes add the

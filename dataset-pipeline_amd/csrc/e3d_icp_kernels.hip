@@ -1896,15 +1896,15 @@ __global__ __launch_bounds__(kBlock) void k_query_keys_multi(const NnBatchDev* _
 // queries, k_nn_rows scores each against the ~10^3 candidates of its row segments (12 ms per 100 M queries, after a 3.5 ms sort).
 // But most of those queries have a target point a few millimetres away -- and any target point at distance s bounds the search to
 // the ball of radius s, which is what the bounded search (k_nn_bounded_half) does around an OLD partner at a third of the cost.
-// This kernel gives a query a partner to start from: after the occupancy test of k_query_keys_prune it probes up to kSeedProbes
+// This kernel gives a query a partner to start from: after the occupancy test of k_query_keys_prune it probes up to eight
 // points of the query's own half cell (the cell's prefix bytes; an empty half cell: points spread over the whole cell) and the old
 // partner, if any.  A query with a probe (or old partner) nearer than sqrt(seed2) gets that point as match[j] and goes to the
 // pair's SEEDED list -- a job of the bounded search, which treats it like any near-list query (the ball around a real target point
 // at its exact f32 distance: the exact search inside it finds the nearest neighbour, ties included); the others are keyed for the
 // sort and k_nn_rows as before.  Results are those of either exact search: identical.
-constexpr int kSeedProbes = 8, kSeedPerThread = 4;
+constexpr int kSeedPerThread = 4;
 static_assert((unsigned)(kBlock * kSeedPerThread) == kQuerySeedBlock, "queries per block of the seeding key kernel");
-template <typename KeyT>
+template <typename KeyT, int kSeedProbes>
 __global__ __launch_bounds__(kBlock) void k_query_seed_multi(const NnBatchDev* __restrict__ B, float r2, KeyT* __restrict__ keys, unsigned* __restrict__ vals,
                                                              unsigned* __restrict__ counts) {
   __shared__ unsigned s_cnt[2][kBlock / kWave][kSeedPerThread];
@@ -3231,8 +3231,14 @@ void launch_query_keys_multi(bool keys32, const NnBatchDev* batch, unsigned n_bl
 }
 void launch_query_seed_multi(bool keys32, const NnBatchDev* batch, unsigned n_blocks, float r2, void* keys, unsigned* vals, unsigned* counts, hipStream_t s) {
   if (!n_blocks) return;
-  if (keys32) hipLaunchKernelGGL(k_query_seed_multi<unsigned>, dim3(n_blocks), dim3(kBlock), 0, s, batch, r2, (unsigned*)keys, vals, counts);
-  else hipLaunchKernelGGL(k_query_seed_multi<unsigned long long>, dim3(n_blocks), dim3(kBlock), 0, s, batch, r2, (unsigned long long*)keys, vals, counts);
+  static const int probes = [] { const char* e = getenv("E3D_NN_SEED_PROBES"); return e ? atoi(e) : 8; }();      // (4 or 8 probes per query: experiments)
+  if (probes == 4) {
+    if (keys32) hipLaunchKernelGGL((k_query_seed_multi<unsigned, 4>), dim3(n_blocks), dim3(kBlock), 0, s, batch, r2, (unsigned*)keys, vals, counts);
+    else hipLaunchKernelGGL((k_query_seed_multi<unsigned long long, 4>), dim3(n_blocks), dim3(kBlock), 0, s, batch, r2, (unsigned long long*)keys, vals, counts);
+  } else {
+    if (keys32) hipLaunchKernelGGL((k_query_seed_multi<unsigned, 8>), dim3(n_blocks), dim3(kBlock), 0, s, batch, r2, (unsigned*)keys, vals, counts);
+    else hipLaunchKernelGGL((k_query_seed_multi<unsigned long long, 8>), dim3(n_blocks), dim3(kBlock), 0, s, batch, r2, (unsigned long long*)keys, vals, counts);
+  }
 }
 void launch_nn_rows_multi(const NnBatchDev* batch, unsigned n_blocks, const unsigned* order, float r2, hipStream_t s) {
   if (!n_blocks) return;

@@ -147,11 +147,12 @@ class OracleICP:
     """Mirror of icp::PointToPlaneICP (src/icp/icp_point_to_plane.h:39-80) on the oracle."""
 
     def __init__(self):
-        self._h = lib().oracle_icp_create()
+        self._lib = lib()                      # (kept on the object: module globals may be gone when __del__ runs at interpreter exit)
+        self._h = self._lib.oracle_icp_create()
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().oracle_icp_destroy(self._h)
+        if getattr(self, "_h", None) and getattr(self, "_lib", None) is not None:
+            self._lib.oracle_icp_destroy(self._h)
             self._h = None
 
     def add_point_cloud(self, xyz, nrm, T, fixed):

@@ -33,6 +33,32 @@ print("RESULT" + json.dumps({"pairs": pairs, "poses": poses, "batches": sum(r["n
                              "certified": sum(r["nn_certify_queries"] for r in rec), "searched": sum(r["nn_search_queries"] + r["nn_bounded_queries"] for r in rec), "rows_queries": sum(r["nn_search_queries"] for r in rec)}))
 """ % ROOT
 
+# the seeded far lists against the ORACLE directly: every far-list query of every search probes for a seed (from the first search on,
+# whatever the last search matched), small enough for the oracle's kd-tree ICP to finish in seconds
+SEED_ORACLE_CODE = r"""
+import importlib, json, sys
+import numpy as np
+sys.path.insert(0, %r)
+e3d = importlib.import_module("dataset-pipeline_amd")
+synth = importlib.import_module("dataset-pipeline_amd.synth")
+from oracle import binding as ob
+scans = synth.make_scene(3, 200000, seed=91, sigma=0.002, room_scale=0.25)
+g = e3d.PointToPlaneICP(); o = ob.OracleICP()
+for i, s in enumerate(scans):
+    xyz, nrm = np.asarray(s["xyz"]), np.asarray(s["normals"])
+    a = g.add_point_cloud(xyz, nrm, s["T_init"], False); b = o.add_point_cloud(xyz, nrm, s["T_init"], False)
+    assert a == b
+cg = g.run(0.03, 0, 6, 1e-9, False); co = o.run(0.03, 0, 6, 1e-9, False)
+rec = g.iter_records()
+pg = [[int(r[0]), int(r[1]), int(r[2]), int(r[3])] for r in g.pair_records()]
+po = [[int(r[0]), int(r[1]), int(r[2]), int(r[3])] for r in o.pair_records()]
+err = 0.0
+for i in range(3):
+    err = max(err, float(np.abs(np.asarray(g.get_result_global_T_cloud(i), np.float64) - np.asarray(o.get_result_global_T_cloud(i), np.float64)).max()))
+print("RESULT" + json.dumps({"same_return": bool(cg == co), "pairs_equal": pg == po, "n_pairs": len(pg), "pose_err": err,
+                             "bounded": sum(r["nn_bounded_queries"] for r in rec), "rows": sum(r["nn_search_queries"] for r in rec)}))
+""" % ROOT
+
 KNN_CODE = r"""
 import importlib, json, sys, hashlib
 import numpy as np
@@ -104,6 +130,20 @@ def test_icp_data_flows_agree():
     for pa, pb in zip(other["poses"], base["poses"]):
         for a, b in zip(pa, pb):
             assert abs(float.fromhex(a) - float.fromhex(b)) <= 2e-6
+
+
+@pytest.mark.timeout(600)
+def test_seeded_far_lists_match_the_oracle():
+    """Far-list queries that start the bounded search from a probe of their own half cell (k_query_seed_multi), forced on for every
+    search: per-pair correspondence counts of every iteration identical to the oracle's kd-tree ICP, poses within the north star's bars."""
+    seeded = _run(SEED_ORACLE_CODE, {"E3D_NN_SEED_FRAC": "0", "E3D_NN_SEED_FRESH": "1"})
+    plain = _run(SEED_ORACLE_CODE, {"E3D_NN_SEED": "0"})
+    for r in (seeded, plain):
+        assert r["same_return"] and r["pairs_equal"] and r["n_pairs"] > 0, r
+        assert r["pose_err"] <= 1e-5, r
+    assert seeded["bounded"] > plain["bounded"] and seeded["rows"] < plain["rows"], (seeded, plain)      # the seeds were used
+    print("seeded: %d queries through the bounded search, %d through the row kernel; without seeds %d / %d"
+          % (seeded["bounded"], seeded["rows"], plain["bounded"], plain["rows"]))
 
 
 @pytest.mark.timeout(600)

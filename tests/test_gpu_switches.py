@@ -42,13 +42,13 @@ sys.path.insert(0, %r)
 e3d = importlib.import_module("dataset-pipeline_amd")
 synth = importlib.import_module("dataset-pipeline_amd.synth")
 from oracle import binding as ob
-scans = synth.make_scene(3, 200000, seed=91, sigma=0.002, room_scale=0.25)
+scans = synth.make_scene(3, 300000, seed=91, sigma=0.002, room_scale=0.25)      # ~6 points per 4 cm cell: the certificate path with its dense directory
 g = e3d.PointToPlaneICP(); o = ob.OracleICP()
 for i, s in enumerate(scans):
     xyz, nrm = np.asarray(s["xyz"]), np.asarray(s["normals"])
     a = g.add_point_cloud(xyz, nrm, s["T_init"], False); b = o.add_point_cloud(xyz, nrm, s["T_init"], False)
     assert a == b
-cg = g.run(0.03, 0, 6, 1e-9, False); co = o.run(0.03, 0, 6, 1e-9, False)
+cg = g.run(0.04, 0, 5, 1e-9, False); co = o.run(0.04, 0, 5, 1e-9, False)
 rec = g.iter_records()
 pg = [[int(r[0]), int(r[1]), int(r[2]), int(r[3])] for r in g.pair_records()]
 po = [[int(r[0]), int(r[1]), int(r[2]), int(r[3])] for r in o.pair_records()]

@@ -3017,8 +3017,9 @@ void launch_match_scan(const int* match_pos, const float* match_d2, size_t n, un
                        unsigned* block_offsets, double* block_d2, unsigned long long* chunk_sum, double* chunk_d2,
                        unsigned long long* total, double* total_d2, hipStream_t s) {
   const int nb = (int)div_up(n ? n : 1, kBlock);
-  hipLaunchKernelGGL(k_match_block_counts, dim3(nb), dim3(kBlock), 0, s, match_pos, n, block_counts, block_d2,
-                     match_d2);
+  // match_pos == nullptr: block_counts / block_d2 hold the per-block sums already (their producer wrote them: k_obs_eval)
+  if (match_pos) hipLaunchKernelGGL(k_match_block_counts, dim3(nb), dim3(kBlock), 0, s, match_pos, n, block_counts, block_d2,
+                                    match_d2);
   const int nch = (nb + kScanChunk - 1) / kScanChunk;
   hipLaunchKernelGGL(k_scan_chunk_sums, dim3(nch), dim3(kScanChunk), 0, s, block_counts, nb, block_d2, chunk_sum, chunk_d2, (const unsigned*)nullptr, (unsigned*)nullptr, (unsigned*)nullptr);
   hipLaunchKernelGGL(k_scan_chunks, dim3(1), dim3(1024), 0, s, chunk_sum, nch, chunk_d2, total, total_d2, (unsigned*)nullptr, (const unsigned*)nullptr);

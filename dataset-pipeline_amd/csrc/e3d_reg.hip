@@ -814,31 +814,22 @@ struct ObsParams {
   int check;     // 1: occlusion + masks + over-saturation (all points); 0: indexed list
 };
 
+// one candidate: true if it stays an observation (its position and scale written to ox / oy / os at k)
 template <int M>
-__global__ __launch_bounds__(kBlock) void k_obs_eval(const float4* __restrict__ pts, const unsigned* __restrict__ indices,
-                                                     size_t count, Pose P, Pyramid Y, const float* __restrict__ occlusion,
-                                                     ObsParams q, int* __restrict__ valid, float* __restrict__ ox,
-                                                     float* __restrict__ oy, float* __restrict__ os,
-                                                     unsigned* __restrict__ dropped) {
-  const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= count) return;
-  const size_t pi = indices ? indices[k] : k;
-  valid[k] = -1;
-  // `dropped` (re-projection of a list, where nearly every point stays an observation): number of candidates that did not --
-  // zero means the list itself is the result and the compaction can be skipped
-  struct Drop { unsigned* c; bool kept = false; __device__ ~Drop() { if (c && !kept) atomicAdd(c, 1u); } } drop{dropped};
-  const float4 p = pts[pi];
+__device__ __forceinline__ bool obs_eval_one(const float4 p, const Pose& P, const Pyramid& Y, const float* __restrict__ occlusion,
+                                             const ObsParams& q, size_t k, float* __restrict__ ox, float* __restrict__ oy,
+                                             float* __restrict__ os) {
   float X, Yc, Z;
   rt(P, p.x, p.y, p.z, X, Yc, Z);
-  if (!(Z > 0.f)) return;
+  if (!(Z > 0.f)) return false;
   int lvl = q.image_scale - Y.min_image_scale;
   if (lvl < 0) lvl = 0;
   const CamLevel cam = Y.cam[lvl];
   float ixf, iyf;
   cam_normalized_to_image<M>(cam, X / Z, Yc / Z, ixf, iyf);
   int ix = f2i(ixf + 0.5f), iy = f2i(iyf + 0.5f);
-  if (!(ix >= 0 && iy >= 0 && ix < cam.width && iy < cam.height)) return;
-  if (q.check && !(occlusion[(size_t)iy * cam.width + ix] + q.occlusion_threshold >= Z)) return;
+  if (!(ix >= 0 && iy >= 0 && ix < cam.width && iy < cam.height)) return false;
+  if (q.check && !(occlusion[(size_t)iy * cam.width + ix] + q.occlusion_threshold >= Z)) return false;
   // CreateObservationIfScaleFits (visibility_estimator.cc:405-532)
   const float prx = X + q.point_radius, pry = Yc + 0.f, prz = Z + 0.f;
   float rxf, ryf;
@@ -847,27 +838,58 @@ __global__ __launch_bounds__(kBlock) void k_obs_eval(const float4* __restrict__ 
   const float radius_pixels = sqrtf(dx * dx + dy * dy);
   const float observation_scale = q.image_scale + e3d_log2f(2 * radius_pixels);
   const int lo = max(Y.min_image_scale, q.current_image_scale);
-  if (!(observation_scale >= lo && f2i(observation_scale) < q.image_scale_count - 1)) return;
+  if (!(observation_scale >= lo && f2i(observation_scale) < q.image_scale_count - 1)) return false;
   const int small_scale = f2i(observation_scale) + 1;
   int li = small_scale - Y.min_image_scale;
   if (li < 0) li = 0;
-  if (li >= Y.n_levels) return;
+  if (li >= Y.n_levels) return false;
   const CamLevel ic = Y.cam[li];
   const float nx = cam.fx_inv * ixf + cam.cx_inv, ny = cam.fy_inv * iyf + cam.cy_inv;
   const float jx = ic.fx * nx + ic.cx, jy = ic.fy * ny + ic.cy;
   ix = f2i(jx + 0.5f); iy = f2i(jy + 0.5f);
   if (!(jx + 0.5f >= q.border && jy + 0.5f >= q.border && ix >= q.border && iy >= q.border && ix < ic.width - q.border &&
         iy < ic.height - q.border))
-    return;
+    return false;
   if (q.check) {
     const int pl = small_scale - Y.min_image_scale;
-    if (Y.mask[pl] && Y.mask[pl][(size_t)iy * ic.width + ix] != 0) return;
-    if (Y.cam_mask[pl] && Y.cam_mask[pl][(size_t)iy * ic.width + ix] != 0) return;          // visibility_estimator.cc:492-503
-    if (Y.img[pl][(size_t)iy * ic.width + ix] > q.max_valid_intensity) return;
+    if (Y.mask[pl] && Y.mask[pl][(size_t)iy * ic.width + ix] != 0) return false;
+    if (Y.cam_mask[pl] && Y.cam_mask[pl][(size_t)iy * ic.width + ix] != 0) return false;          // visibility_estimator.cc:492-503
+    if (Y.img[pl][(size_t)iy * ic.width + ix] > q.max_valid_intensity) return false;
   }
-  valid[k] = (int)pi;
   ox[k] = jx; oy[k] = jy; os[k] = observation_scale;
-  drop.kept = true;
+  return true;
+}
+
+// `dropped` (re-projection of a list, where nearly every point stays an observation): number of candidates that did not -- zero
+// means the list itself is the result and the compaction can be skipped.  block_counts (an all-points pass, which is always
+// compacted): the block's number of kept candidates, i.e. the first stage of the compaction's scan (launch_match_scan's
+// k_match_block_counts would read the 4 B per point back for it); block_d2: that scan's second sum, unused here, written as zero.
+template <int M>
+__global__ __launch_bounds__(kBlock) void k_obs_eval(const float4* __restrict__ pts, const unsigned* __restrict__ indices,
+                                                     size_t count, Pose P, Pyramid Y, const float* __restrict__ occlusion,
+                                                     ObsParams q, int* __restrict__ valid, float* __restrict__ ox,
+                                                     float* __restrict__ oy, float* __restrict__ os,
+                                                     unsigned* __restrict__ dropped, unsigned* __restrict__ block_counts,
+                                                     double* __restrict__ block_d2) {
+  const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  bool kept = false;
+  if (k < count) {
+    const size_t pi = indices ? indices[k] : k;
+    kept = obs_eval_one<M>(pts[pi], P, Y, occlusion, q, k, ox, oy, os);
+    valid[k] = kept ? (int)pi : -1;
+    if (dropped && !kept) atomicAdd(dropped, 1u);
+  }
+  if (block_counts) {                                      // (block-uniform)
+    __shared__ unsigned sc[kBlock / kWave];
+    const unsigned long long b = __ballot(kept);
+    if ((threadIdx.x & 63) == 0) sc[threadIdx.x >> 6] = (unsigned)__popcll(b);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned c = 0;
+      for (int w = 0; w < kBlock / kWave; ++w) c += sc[w];
+      block_counts[blockIdx.x] = c; block_d2[blockIdx.x] = 0.0;
+    }
+  }
 }
 
 __global__ __launch_bounds__(kBlock) void k_obs_compact(const int* __restrict__ valid, const float* __restrict__ ox,
@@ -3203,11 +3225,14 @@ int64_t e3d_reg_observe(e3d_reg_t* h, int image_id, int point_scale, int image_s
       d_dropped = reinterpret_cast<unsigned*>(h->d_total.p + 1);
       E3D_HIP(hipMemsetAsync(d_dropped, 0, sizeof(unsigned), s));
     }
+    const size_t nb = div_up(count, kBlock);
+    h->block_counts.reserve(nb); h->block_offsets.reserve(nb); h->block_d2.reserve(nb);
     {
       KT kt(h, all ? "obs.eval_all_points" : "obs.eval_listed_points", (double)count);
       E3D_CAM_SWITCH(image_model(h, im), hipLaunchKernelGGL(k_obs_eval<M>, dim3(nblk(count)), dim3(kBlock), 0, s, S.pts.p, d_idx, count,
                                                             im.pose, make_pyramid(h, im), all ? im.depth.p : nullptr, q, h->valid.p,
-                                                            h->tx.p, h->ty.p, h->ts.p, d_dropped));
+                                                            h->tx.p, h->ty.p, h->ts.p, d_dropped, all ? h->block_counts.p : nullptr,
+                                                            all ? h->block_d2.p : nullptr));
     }
     unsigned dropped = 1;
     if (!all) {
@@ -3218,13 +3243,12 @@ int64_t e3d_reg_observe(e3d_reg_t* h, int image_id, int point_scale, int image_s
       O.n = count;
       std::swap(O.idx, h->cand); std::swap(O.x, h->tx); std::swap(O.y, h->ty); std::swap(O.s, h->ts);
     } else {
-      const size_t nb = div_up(count, kBlock);
-      h->block_counts.reserve(nb); h->block_offsets.reserve(nb); h->block_d2.reserve(nb);
       h->chunk_sum.reserve(div_up(nb, 256) + 1); h->chunk_d2.reserve(div_up(nb, 256) + 1);
       h->d_total.reserve(2); h->d_total_d2.reserve(1);
       {
         KT kt(h, "obs.scan", (double)count);
-        launch_match_scan(h->valid.p, nullptr, count, h->block_counts.p, h->block_offsets.p, h->block_d2.p, h->chunk_sum.p,
+        // (an all-points pass: k_obs_eval has written the per-block counts itself)
+        launch_match_scan(all ? nullptr : h->valid.p, nullptr, count, h->block_counts.p, h->block_offsets.p, h->block_d2.p, h->chunk_sum.p,
                           h->chunk_d2.p, h->d_total.p, h->d_total_d2.p, s);
       }
       unsigned long long total = 0;

@@ -2308,7 +2308,7 @@ struct e3d_reg {
   DevBuf<float> tx, ty, ts;
   DevBuf<unsigned> cand, block_counts, block_offsets;
   PinBuf<unsigned char> mailbox;     // read_back
-  DevBuf<double> block_d2, chunk_d2, d_total_d2, partial, red, red_all;
+  DevBuf<double> block_d2, chunk_d2, d_total_d2, partial, red, red_all, acc_all;
   DevBuf<unsigned long long> chunk_sum, d_total;
   DevBuf<float> dummy_d2;
   DevBuf<unsigned> cut;
@@ -3329,9 +3329,12 @@ int e3d_reg_pass1(e3d_reg_t* h, int image_id, int point_scale, float* intensitie
   R_CATCH()
 }
 
-int e3d_reg_accumulate(e3d_reg_t* h, int image_id, int point_scale, double* H, double* b, double sums[2], int64_t counts[2]) {
-  R_TRYH
-  if (!h || !H || !b || !sums || !counts) throw Error(E3D_ERR_INVALID, "null argument");
+}  // extern "C"
+namespace e3d {
+// The accumulation of one (image, point scale): pass 1, pass 2 and the reduction of the partials enqueued; the reg_slot(V) numbers
+// {upper triangle of H by rows, b, fixed sum, variable sum, fixed count, variable count} land at d_out (device).  e3d_reg_accumulate
+// reads them at once; the optimizer's driver enqueues every image of an Apply and reads all of them with one copy.
+static int accumulate_enqueue(e3d_reg* h, int image_id, int point_scale, double* d_out, bool use_own_red) {
   hipStream_t s = h->stream;
   ImageDev& im = get_image(h, image_id);
   PointScale& S = get_scale(h, point_scale);
@@ -3421,16 +3424,33 @@ int e3d_reg_accumulate(e3d_reg_t* h, int image_id, int point_scale, double* H, d
   }
   h->t_pass2->stop(s);
   kt2.reset();
-  hipLaunchKernelGGL(k_reg_reduce, dim3(slot), dim3(kWave), 0, s, h->partial.p, n_partials, slot, h->red.p);
-  std::vector<double> r(slot);
-  read_back(h, r.data(), h->red.p, sizeof(double) * slot);
-  h->pass1_ms += h->t_pass1->ms(); h->pass2_ms += h->t_pass2->ms(); h->pass_observations += (double)O.n; h->pass_calls += 1;
+  hipLaunchKernelGGL(k_reg_reduce, dim3(slot), dim3(kWave), 0, s, h->partial.p, n_partials, slot, use_own_red ? h->red.p : d_out);
+  h->pass_observations += (double)O.n; h->pass_calls += 1;
+  return V;
+}
+
+// the numbers of accumulate_enqueue as the dense V x V upper triangle, b, sums and counts
+static void accumulate_unpack(int V, const double* r, double* H, double* b, double sums[2], int64_t counts[2]) {
+  const int NH = reg_h(V);
   std::fill(H, H + V * V, 0.0);
   int e = 0;
   for (int i = 0; i < V; ++i) for (int j = i; j < V; ++j) H[i * V + j] = r[e++];
   for (int i = 0; i < V; ++i) b[i] = r[NH + i];
   sums[0] = r[NH + V]; sums[1] = r[NH + V + 1];
   counts[0] = (int64_t)r[NH + V + 2]; counts[1] = (int64_t)r[NH + V + 3];
+}
+}  // namespace e3d
+extern "C" {
+
+int e3d_reg_accumulate(e3d_reg_t* h, int image_id, int point_scale, double* H, double* b, double sums[2], int64_t counts[2]) {
+  R_TRYH
+  if (!h || !H || !b || !sums || !counts) throw Error(E3D_ERR_INVALID, "null argument");
+  const int V = accumulate_enqueue(h, image_id, point_scale, nullptr, true);
+  const int slot = reg_slot(V);
+  std::vector<double> r(slot);
+  read_back(h, r.data(), h->red.p, sizeof(double) * slot);
+  h->pass1_ms += h->t_pass1->ms(); h->pass2_ms += h->t_pass2->ms();      // (the pass timers of the call just made: the stream is idle)
+  accumulate_unpack(V, r.data(), H, b, sums, counts);
   return 0;
   R_CATCH()
 }
@@ -3787,70 +3807,104 @@ static double total_cost(e3d_reg* h) {
   return compute_cost_value(h, sums, counts);
 }
 
-// IntrinsicsAndPoseOptimizer::Apply
-static void apply_update(e3d_reg* h, bool print, bool* applied_update, float* lambda, float* max_change) {
+// The normal equations of IntrinsicsAndPoseOptimizer::Apply at the current state over the current observations
+// (intrinsics_and_pose_optimizer.cc:55-185): variable indices, H and b in arrow form, the residual sums and counts behind
+// "Initial residual", and the visibility lists (device copies of the observed point indices) the LM tries re-project.
+struct NormalSystem {
+  std::map<int, int> intr_index, image_index, rig_index;
+  int V = 0;
+  ArrowSystem Hb;
+  double sums[3] = {0, 0, 0};
+  int64_t counts[3] = {0, 0, 0};
+  std::map<int, std::map<int, std::pair<DevBuf<unsigned>*, size_t>>> vis;
+};
+
+static void accumulate_system(e3d_reg* h, NormalSystem& N) {
   hipStream_t s = h->stream;
   // CountAndIndexVariables: [intrinsics blocks][6 per image]
-  std::map<int, int> intr_index, image_index;
+  std::map<int, int>&intr_index = N.intr_index, &image_index = N.image_index, &rig_index = N.rig_index;
+  intr_index.clear(); image_index.clear(); rig_index.clear(); N.vis.clear();
   int V = 0;
-  std::map<int, int> rig_index;
   for (auto& kv : h->intr) { intr_index[kv.first] = V; V += kv.second.n_params; }
   for (auto& kv : h->rigs) { rig_index[kv.first] = V; V += 6 * ((int)kv.second.image_T_rig.size() - 1); }   // reference camera excluded (:455-460)
   for (auto& kv : h->images) {                                                                             // dependent rig images share the
     if (kv.second.dependent()) continue;                                                                   // reference image's pose (:461-472)
     image_index[kv.first] = V; V += 6;
   }
+  N.V = V;
   // H and b in arrow form (e3d_math.hpp): shared block = intrinsics + rig extrinsics, then one 6 x 6 block per pose
   const int n_shared = V - 6 * (int)image_index.size();
-  ArrowSystem Hb;
+  ArrowSystem& Hb = N.Hb;
   Hb.reset(n_shared, (int)image_index.size());
-  double sums[3] = {0, 0, 0};
-  int64_t counts[3] = {0, 0, 0};
+  double* sums = N.sums;
+  int64_t* counts = N.counts;
+  for (int i = 0; i < 3; ++i) { sums[i] = 0; counts[i] = 0; }
   // visibility lists = observed point indices of the current observations (device copies)
-  std::map<int, std::map<int, std::pair<DevBuf<unsigned>*, size_t>>> vis;
+  auto& vis = N.vis;
+  // Every (image, scale) of the Apply is enqueued back to back and its numbers read with ONE copy (one host round trip per image
+  // before: the device idled between images); then the blocks are added in the loop's order -- the same sums in the same order.
+  struct Job { int image_id, scale, Vl; size_t off; };
+  std::vector<Job> jobs;
+  size_t total = 0;
   for (auto& kv : h->images) {
     if (!h->owns(kv.first)) continue;
     ImageDev& im = kv.second;
+    for (auto& sc : h->scales) {
+      if (!has_obs(im, sc.first)) continue;
+      const int Vl = local_unknowns(h, im);
+      jobs.push_back({kv.first, sc.first, Vl, total});
+      total += (size_t)reg_slot(Vl);
+    }
+  }
+  h->acc_all.reserve(std::max<size_t>(total, 1));
+  {
+    Phase ph(h, "apply.accumulate");
+    for (const Job& j : jobs) {
+      ImageDev& im = h->images.at(j.image_id);
+      Obs& O = im.obs.at(j.scale);
+      DevBuf<unsigned>* buf = &im.vis[j.scale];
+      buf->reserve(O.n);
+      if (O.n) E3D_HIP(hipMemcpyAsync(buf->p, O.idx.p, sizeof(unsigned) * O.n, hipMemcpyDeviceToDevice, s));
+      vis[j.image_id][j.scale] = {buf, O.n};
+      O.flags_src = O.n ? (const void*)buf->p : nullptr; O.flags_count = O.n;     // flags / nrow belong to exactly this list
+      if (accumulate_enqueue(h, j.image_id, j.scale, h->acc_all.p + j.off, false) != j.Vl) throw Error(E3D_ERR_INVALID, "accumulate: local system size");
+    }
+  }
+  std::vector<double> all(total);
+  {
+    Phase ph(h, "apply.accumulate");
+    read_back(h, all.data(), h->acc_all.p, sizeof(double) * total);
+  }
+  for (const Job& j : jobs) {
+    ImageDev& im = h->images.at(j.image_id);
     const int I = h->intr.at(im.intrinsics_id).n_params;
     const bool dep = im.dependent();
     const int ii = intr_index.at(im.intrinsics_id);
-    const int pi = image_index.at(dep ? im.ref_image_id : kv.first);
+    const int pi = image_index.at(dep ? im.ref_image_id : j.image_id);
     const int ri = dep ? rig_index.at(im.rig_id) + 6 * (im.camera_index - 1) : -1;
-    for (auto& sc : h->scales) {
-      if (!has_obs(im, sc.first)) continue;
-      Obs& O = im.obs.at(sc.first);
-      DevBuf<unsigned>* buf = &im.vis[sc.first];
-      buf->reserve(O.n);
-      if (O.n) E3D_HIP(hipMemcpyAsync(buf->p, O.idx.p, sizeof(unsigned) * O.n, hipMemcpyDeviceToDevice, s));
-      vis[kv.first][sc.first] = {buf, O.n};
-      O.flags_src = O.n ? (const void*)buf->p : nullptr; O.flags_count = O.n;     // flags / nrow belong to exactly this list
-      const int Vl = I + (dep ? 12 : 6);
-      std::vector<double> Hl((size_t)Vl * Vl), bl(Vl);
-      double s2[2]; int64_t c2[2];
-      {
-        Phase ph(h, "apply.accumulate");
-        if (e3d_reg_accumulate(h, kv.first, sc.first, Hl.data(), bl.data(), s2, c2) < 0) throw Error(E3D_ERR_INVALID, e3d_last_error());
-      }
-      sums[0] += s2[0]; sums[1] += s2[1]; counts[0] += c2[0]; counts[1] += c2[1];
-      // scatter the local [intrinsics(I), (rig extrinsics(6),) pose(6)] block (AccumulateOnHAndB's block updates)
-      auto gidx = [&](int l) { return l < I ? ii + l : ((dep && l < I + 6) ? ri + (l - I) : pi + (l - (Vl - 6))); };
-      for (int r = 0; r < Vl; ++r) {
-        for (int c = r; c < Vl; ++c)
-          if (!Hb.add(gidx(r), gidx(c), Hl[(size_t)r * Vl + c])) throw Error(E3D_ERR_INVALID, "normal equations: entry outside the arrow pattern");
-        Hb.b[gidx(r)] += bl[r];
-      }
-      if (depth_in_use(h)) {
-        // depth residuals of every observation (intrinsics_and_pose_optimizer.cc:747-757); [intrinsics(I), pose(6)] block
-        std::vector<double> Hd((size_t)(I + 6) * (I + 6)), bd(I + 6);
-        double sd; int64_t cd;
-        if (e3d_reg_depth_accumulate(h, kv.first, sc.first, Hd.data(), bd.data(), &sd, &cd) < 0) throw Error(E3D_ERR_INVALID, e3d_last_error());
-        sums[2] += sd; counts[2] += cd;
-        auto didx = [&](int l) { return l < I ? ii + l : pi + (l - I); };
-        for (int r = 0; r < I + 6; ++r) {
-          for (int c = r; c < I + 6; ++c)
-            if (!Hb.add(didx(r), didx(c), Hd[(size_t)r * (I + 6) + c])) throw Error(E3D_ERR_INVALID, "normal equations: entry outside the arrow pattern");
-          Hb.b[didx(r)] += bd[r];
-        }
+    const int Vl = j.Vl;
+    std::vector<double> Hl((size_t)Vl * Vl), bl(Vl);
+    double s2[2]; int64_t c2[2];
+    accumulate_unpack(Vl, all.data() + j.off, Hl.data(), bl.data(), s2, c2);
+    sums[0] += s2[0]; sums[1] += s2[1]; counts[0] += c2[0]; counts[1] += c2[1];
+    // scatter the local [intrinsics(I), (rig extrinsics(6),) pose(6)] block (AccumulateOnHAndB's block updates)
+    auto gidx = [&](int l) { return l < I ? ii + l : ((dep && l < I + 6) ? ri + (l - I) : pi + (l - (Vl - 6))); };
+    for (int r = 0; r < Vl; ++r) {
+      for (int c = r; c < Vl; ++c)
+        if (!Hb.add(gidx(r), gidx(c), Hl[(size_t)r * Vl + c])) throw Error(E3D_ERR_INVALID, "normal equations: entry outside the arrow pattern");
+      Hb.b[gidx(r)] += bl[r];
+    }
+    if (depth_in_use(h)) {
+      // depth residuals of every observation (intrinsics_and_pose_optimizer.cc:747-757); [intrinsics(I), pose(6)] block
+      std::vector<double> Hd((size_t)(I + 6) * (I + 6)), bd(I + 6);
+      double sd; int64_t cd;
+      if (e3d_reg_depth_accumulate(h, j.image_id, j.scale, Hd.data(), bd.data(), &sd, &cd) < 0) throw Error(E3D_ERR_INVALID, e3d_last_error());
+      sums[2] += sd; counts[2] += cd;
+      auto didx = [&](int l) { return l < I ? ii + l : pi + (l - I); };
+      for (int r = 0; r < I + 6; ++r) {
+        for (int c = r; c < I + 6; ++c)
+          if (!Hb.add(didx(r), didx(c), Hd[(size_t)r * (I + 6) + c])) throw Error(E3D_ERR_INVALID, "normal equations: entry outside the arrow pattern");
+        Hb.b[didx(r)] += bd[r];
       }
     }
   }
@@ -3865,6 +3919,20 @@ static void apply_update(e3d_reg* h, bool print, bool* applied_update, float* la
     Hb.unpack(buf.data());
     for (int i = 0; i < 3; ++i) { sums[i] = tail[i]; counts[i] = (int64_t)tail[3 + i]; }
   }
+}
+
+// IntrinsicsAndPoseOptimizer::Apply.  `ready`: the normal equations of exactly this state and these observations, accumulated
+// already (e3d_reg_run_on_current_scale takes an iteration's cost from them, see there); else they are accumulated here.
+static void apply_update(e3d_reg* h, bool print, bool* applied_update, float* lambda, float* max_change, NormalSystem* ready = nullptr) {
+  NormalSystem own;
+  if (!ready) accumulate_system(h, own);
+  NormalSystem& N = ready ? *ready : own;
+  std::map<int, int>&intr_index = N.intr_index, &image_index = N.image_index, &rig_index = N.rig_index;
+  const int V = N.V;
+  ArrowSystem& Hb = N.Hb;
+  auto& vis = N.vis;
+  const double* sums = N.sums;
+  const int64_t* counts = N.counts;
   const double initial_residual = compute_cost_value(h, sums, counts);
   if (print)
     printf("    Initial residual: %g (#fixed residuals: %lld, #variable residuals: %lld)\n", initial_residual, (long long)counts[0], (long long)counts[1]);
@@ -4326,6 +4394,9 @@ int e3d_reg_run_on_current_scale(e3d_reg_t* h, int max_num_iterations, float max
   *optimum_cost = std::numeric_limits<double>::infinity();
   RegState optimum = get_state(h);
   int it = 0;
+  NormalSystem pending;                 // the next Apply's normal equations, when an iteration's cost came out of them
+  bool have_pending = false;
+  static const bool fuse_cost = [] { const char* e = getenv("E3D_REG_FUSE_COST"); return !e || atoi(e) != 0; }();
   for (; it < max_num_iterations; ++it) {
     if (print) printf("Iteration %d\n", it + 1);
     bool applied = true;
@@ -4335,7 +4406,8 @@ int e3d_reg_run_on_current_scale(e3d_reg_t* h, int max_num_iterations, float max
       applied = false;
       max_change = 0;
       Phase ph(h, "apply (all of it)");
-      apply_update(h, print, &applied, &lambda, &max_change);
+      apply_update(h, print, &applied, &lambda, &max_change, have_pending ? &pending : nullptr);
+      have_pending = false;
     }
     if (print) printf("  Observations update ...\n");
     { Phase ph(h, "observations (all of it)"); update_observations(h, /*kBorderSize*/ 1); }
@@ -4346,7 +4418,24 @@ int e3d_reg_run_on_current_scale(e3d_reg_t* h, int max_num_iterations, float max
     }
     if (print) printf("  Determining cost ...\n");
     double current_cost;
-    { Phase ph(h, "total_cost"); current_cost = total_cost(h); }
+    // CostCalculator::ComputeCost here and the residual sums of the NEXT iteration's Apply ("Initial residual",
+    // intrinsics_and_pose_optimizer.cc:176-185) are the same sums over the same observations at the same state -- the reference
+    // evaluates every residual twice.  When the loop is certain to go on whatever the cost turns out to be (the exit test below
+    // with the larger of the two values `without` can take), the next Apply's accumulation runs here, its sums give this
+    // iteration's cost, and the Apply finds its normal equations ready: one intensity + cost pass per image and iteration less.
+    // Otherwise (last iteration, convergence by max_change, optimum counter at its limit): the cost pass alone.
+    const bool goes_on = fuse_cost && it + 1 < max_num_iterations && applied && !(max_change < max_change_convergence_threshold) &&
+                         without + 1 < iterations_without_new_optimum_threshold;
+    if (goes_on) {
+      Phase ph(h, "total_cost");
+      accumulate_system(h, pending);
+      have_pending = true;
+      const bool none = pending.counts[0] == 0 && pending.counts[1] == 0 && pending.counts[2] == 0;      // cost_calculator.cc:84-90
+      current_cost = none ? std::numeric_limits<double>::infinity() : compute_cost_value(h, pending.sums, pending.counts);
+    } else {
+      Phase ph(h, "total_cost");
+      current_cost = total_cost(h);
+    }
     if (print) printf("  Cost (considering occlusions) is: %g\n", current_cost);
     if (current_cost < *optimum_cost) {
       *optimum_cost = current_cost;

@@ -3,7 +3,7 @@ each setting runs in its own interpreter: the certificate search of several dire
 pair or one launch per pair (E3D_ICP_BATCH = 0 / 1; default 2: one launch per kernel and batch), the far lists of a batch keyed, sorted and searched in one launch each against pair by pair (E3D_NN_FAR_BATCH), the LM step's damped solves on host threads (E3D_LM_SOLVE_THREADS), the certificates' motion bound per query against the clouds' global one (E3D_NN_PERQUERY), the key kernel that settles queries with an empty 27-cell block against sorting them all (E3D_NN_PRUNE), certificates tested in every outer iteration against skipped while none holds (E3D_NN_CERT_SKIP) and against no certificates at all (E3D_NN_CERT=0: every query searched in every iteration), resident against compacted correspondence rows (E3D_ICP_RESIDENT), the speculative last LM step
 (E3D_LM_SPECULATE), the row update's per-block results written by the certificate kernel for the blocks it settles whole against the update
 computing them all (E3D_NN_FUSE_UPDATE = 0; E3D_NN_FUSE_GATE = 1: for every certified pair, not only the nearly settled ones), far-list queries that start the bounded search from a probe of their own half cell against sort + row kernel for all of them (E3D_NN_SEED = 0; E3D_NN_SEED_FRAC / _NEAR / _FRESH: from the first search on, other seed distances); the kNN estimator's single scan with sampled thresholds against the two-pass kernels (E3D_KNN_SINGLE), with
-and without the lists the 125-cell pass starts from (E3D_KNN_SEED), the wave-per-query form of that pass (E3D_KNN_WIDE_WAVE), the sampled thresholds from the block population against the distance histogram, and deliberately poor ones (E3D_KNN_EST, E3D_KNN_EST_SCALE)."""
+and without the lists the 125-cell pass starts from (E3D_KNN_SEED), the wave-per-query form of that pass (E3D_KNN_WIDE_WAVE), the sampled thresholds from the block population against the distance histogram, and deliberately poor ones (E3D_KNN_EST, E3D_KNN_EST_SCALE); (B): an iteration's cost taken from the next Apply's accumulation against the separate cost pass (E3D_REG_FUSE_COST = 0)."""
 import json
 import os
 import subprocess
@@ -185,3 +185,52 @@ def test_per_query_motion_bound_survives_a_long_run():
     assert "global motion bound" not in p.stderr, [ln for ln in p.stderr.splitlines() if "global motion bound" in ln][:3]
     r = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("RESULT")][-1][len("RESULT"):])
     assert r["certified_last"] == r["queries_last"] and r["searched_last"] < 0.05 * r["queries_last"], r
+
+
+REG_CODE = r"""
+import importlib, json, sys
+import numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+e3d = importlib.import_module("dataset-pipeline_amd")
+from reg_util import make_multi_image_scene, plane_depth_pyramid
+out = {}
+for name, model, var_weight, depth_weight, iters, without in (("thin_prism", 2, 1.0, 0.0, 7, 15), ("pinhole_fixed_only", 0, 0.0, 0.0, 5, 15),
+                                                              ("opencv_depth", 1, 1.0, 0.5, 5, 15), ("counter_at_its_limit", 2, 1.0, 0.0, 6, 2)):
+    M = make_multi_image_scene(n_points=6000, n_images=3, seed=6, perturb=0.006, model=model)
+    prm = e3d.default_reg_params(image_scale_count=M["n_levels"], point_neighbor_count=M["K"], variable_residuals_weight=var_weight,
+                                 depth_residuals_weight=depth_weight)
+    G = e3d.RegProblem(prm)
+    G.set_intrinsics(0, M["width"], M["height"], M["params"], 0, M["n_levels"], camera_type=M["model"])
+    G.set_point_scale(0, M["pts"], M["point_radius"], M["nbr"], M["fixed_desc"]); G.set_splat_points(M["pts"])
+    for i, im in enumerate(M["images"]):
+        G.set_image(i, 0, im["pyr"]); G.set_image_pose(i, im["q_init"], im["t_init"])
+        if depth_weight > 0: G.set_depth_maps(i, plane_depth_pyramid(M, im))
+    G.profile(True)
+    conv, cost, its = G.run_on_current_scale(iters, 0.0, without, False)
+    G.profile(False)
+    poses = [[float(v).hex() for v in np.concatenate([np.ravel(a) for a in G.get_image_pose(i)])] for i in range(3)]
+    w, h, pg, _ = G.intrinsics_level(0, 0)
+    out[name] = {"converged": conv, "iterations": its, "cost": cost, "poses": poses, "intrinsics": [float(v).hex() for v in pg],
+                 "cost_launches": G.kernel_groups.get("cost", (0, 0, 0))[1], "pass2_launches": G.kernel_groups.get("accumulate.pass2", (0, 0, 0))[1]}
+print("RESULT" + json.dumps(out))
+""" % (ROOT, os.path.join(ROOT, "tests"))
+
+
+@pytest.mark.timeout(600)
+def test_reg_cost_from_the_next_accumulation():
+    """RunOnCurrentScale: an iteration's "Cost (considering occlusions)" and the next Apply's "Initial residual" are the same sums over
+    the same observations at the same state (bit-equal in the oracle's run; optimizer.cc:140-147, intrinsics_and_pose_optimizer.cc:176-185).
+    The default takes the cost from the next Apply's accumulation whenever the loop is certain to go on; E3D_REG_FUSE_COST = 0 runs the
+    separate cost pass every iteration as the reference does.  Same iterations, same poses and intrinsics bit for bit, same optimum to
+    1e-12; fewer cost launches, no more accumulations."""
+    fused = _run(REG_CODE, {})
+    plain = _run(REG_CODE, {"E3D_REG_FUSE_COST": "0"})
+    for name in fused:
+        f, p = fused[name], plain[name]
+        assert (f["converged"], f["iterations"]) == (p["converged"], p["iterations"]), name
+        assert f["poses"] == p["poses"] and f["intrinsics"] == p["intrinsics"], name
+        assert abs(f["cost"] - p["cost"]) <= 1e-12 * abs(p["cost"]), (name, f["cost"], p["cost"])
+        assert f["cost_launches"] < p["cost_launches"], (name, f["cost_launches"], p["cost_launches"])
+        assert f["pass2_launches"] <= p["pass2_launches"], (name, f["pass2_launches"], p["pass2_launches"])
+        print("%s: %d iterations, cost launches %d (separate pass: %d), accumulations %d (%d)"
+              % (name, f["iterations"], f["cost_launches"], p["cost_launches"], f["pass2_launches"], p["pass2_launches"]))

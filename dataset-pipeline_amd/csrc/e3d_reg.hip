@@ -3353,7 +3353,7 @@ static int accumulate_enqueue(e3d_reg* h, int image_id, int point_scale, double*
     return 2 * cus;
   }();
   const int nb = (int)std::min<size_t>(std::max<size_t>(div_up(O.n, kBlock * 4), 1), (size_t)max_blocks);
-  const int V = local_unknowns(h, im), NH = reg_h(V), slot = reg_slot(V);
+  const int V = local_unknowns(h, im), slot = reg_slot(V);
   h->partial.reserve((size_t)nb * slot); h->red.reserve(slot);
   const RegWeights w{h->prm.robust_weighting_type, h->prm.robust_weighting_parameter, h->prm.fixed_residuals_weight,
                      h->prm.variable_residuals_weight};

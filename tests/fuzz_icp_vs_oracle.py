@@ -1,0 +1,118 @@
+"""Randomised differential run of the ICP path against the CPU oracle (test infrastructure, not product code).
+
+    python tests/fuzz_icp_vs_oracle.py --trials 24 --seed 1            # every trial: oracle once, the library under each switch set
+
+Each trial draws a job -- number of scans, points per scan, search radius, room scale (point density: dense rooms take the certificate
+search with resident rows, sparse ones the hash-table search), initial misalignment, which cloud is fixed, scanner-shaped sampling,
+number of outer iterations -- and compares, per outer iteration and directed pair, the correspondence counts (exactly) and the final
+poses (<= 1e-5) of `PointToPlaneICP.run` with the oracle's kd-tree ICP.  The library's switches are read once per process, so every
+switch set runs in its own interpreter (`--worker`); the oracle's records are computed once per trial and handed over in a file."""
+import argparse
+import importlib
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+SWITCH_SETS = [
+    {},
+    {"E3D_NN_SEED_FRAC": "0", "E3D_NN_SEED_FRESH": "1"},                    # every far-list query probes for a seed, from the first search on
+    {"E3D_NN_FUSE_GATE": "1.0", "E3D_NN_CERT_SKIP": "0"},                   # certificate / row-update fusion for every certified pair
+    {"E3D_ICP_BATCH": "0", "E3D_NN_SEED": "0"},                             # pair by pair, no seeds
+]
+
+
+def draw(rng):
+    dense = rng.random() < 0.7
+    job = {
+        "n_scans": int(rng.integers(2, 5)),
+        "n_points": int(rng.integers(60_000, 360_000)),
+        "seed": int(rng.integers(1, 10_000)),
+        "room_scale": float(rng.choice([0.2, 0.25, 0.3])) if dense else 1.0,
+        "d": float(rng.choice([0.03, 0.04, 0.06])) if dense else float(rng.choice([0.05, 0.1, 0.2])),
+        "perturb": float(rng.choice([0.5, 1.0, 2.0, 3.0])),
+        "iterations": int(rng.integers(3, 7)),
+        "fixed": int(rng.integers(-1, 2)),                                   # -1: none; else the index of the fixed cloud
+        "scanner": bool((not dense) and rng.random() < 0.3),
+        "sigma": float(rng.choice([0.001, 0.002, 0.004])),
+    }
+    return job
+
+
+def scene(job):
+    synth = importlib.import_module("dataset-pipeline_amd.synth")
+    return synth.make_scene(job["n_scans"], job["n_points"], seed=job["seed"], sigma=job["sigma"], room_scale=job["room_scale"],
+                            perturb=job["perturb"], scanner=job["scanner"])
+
+
+def run_one(icp, job, scans):
+    ids = []
+    for i, s in enumerate(scans):
+        ids.append(icp.add_point_cloud(np.asarray(s["xyz"]), np.asarray(s["normals"]), s["T_init"], i == job["fixed"]))
+    ret = icp.run(job["d"], 0, job["iterations"], 1e-9, False)
+    pairs = [[int(r[0]), int(r[1]), int(r[2]), int(r[3])] for r in icp.pair_records()]
+    poses = [np.asarray(icp.get_result_global_T_cloud(i), np.float64).tolist() for i in sorted(set(i for i in ids if i >= 0))]
+    return {"ids": [int(i) for i in ids], "ret": bool(ret), "pairs": pairs, "poses": poses}
+
+
+def worker(path):
+    e3d = importlib.import_module("dataset-pipeline_amd")
+    todo = json.load(open(path))
+    bad = []
+    for t, item in enumerate(todo):
+        job, ref = item["job"], item["oracle"]
+        got = run_one(e3d.PointToPlaneICP(), job, scene(job))
+        err = max(float(np.abs(np.asarray(a) - np.asarray(b)).max()) for a, b in zip(got["poses"], ref["poses"]))
+        ok = got["ids"] == ref["ids"] and got["ret"] == ref["ret"] and got["pairs"] == ref["pairs"] and err <= 1e-5
+        if not ok:
+            first = next((i for i, (a, b) in enumerate(zip(got["pairs"], ref["pairs"])) if a != b), None)
+            bad.append({"trial": t, "job": job, "pose_err": err, "first_pair_mismatch": first,
+                        "got": got["pairs"][first] if first is not None else None, "oracle": ref["pairs"][first] if first is not None else None})
+    print("RESULT" + json.dumps({"trials": len(todo), "bad": bad}))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--trials", type=int, default=24)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--worker", default=None)
+    args = ap.parse_args()
+    if args.worker:
+        return worker(args.worker)
+    from oracle import binding as ob
+    rng = np.random.default_rng(args.seed)
+    todo = []
+    for t in range(args.trials):
+        job = draw(rng)
+        todo.append({"job": job, "oracle": run_one(ob.OracleICP(), job, scene(job))})
+        print("trial %d: %s -> %d pair records, matched %d" % (t, json.dumps(job), len(todo[-1]["oracle"]["pairs"]),
+                                                               sum(p[3] for p in todo[-1]["oracle"]["pairs"])), flush=True)
+    with tempfile.NamedTemporaryFile("w", suffix=".json", delete=False) as f:
+        json.dump(todo, f)
+    failures = 0
+    for env in SWITCH_SETS:
+        e = dict(os.environ)
+        e.update(env)
+        p = subprocess.run([sys.executable, os.path.abspath(__file__), "--worker", f.name], env=e, capture_output=True, text=True)
+        if p.returncode != 0:
+            print("switches %s: worker failed\n%s" % (env, p.stderr[-2000:]))
+            failures += 1
+            continue
+        r = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("RESULT")][-1][len("RESULT"):])
+        print("switches %s: %d trials, %d mismatches" % (json.dumps(env), r["trials"], len(r["bad"])))
+        for b in r["bad"]:
+            print("   ", json.dumps(b))
+        failures += len(r["bad"])
+    os.unlink(f.name)
+    print("FUZZ %s" % ("OK" if failures == 0 else "FAILED (%d)" % failures))
+    sys.exit(0 if failures == 0 else 1)
+
+
+if __name__ == "__main__":
+    main()

@@ -234,3 +234,15 @@ def test_reg_cost_from_the_next_accumulation():
         assert f["pass2_launches"] <= p["pass2_launches"], (name, f["pass2_launches"], p["pass2_launches"])
         print("%s: %d iterations, cost launches %d (separate pass: %d), accumulations %d (%d)"
               % (name, f["iterations"], f["cost_launches"], p["cost_launches"], f["pass2_launches"], p["pass2_launches"]))
+
+
+@pytest.mark.timeout(900)
+def test_randomised_jobs_match_the_oracle():
+    """tests/fuzz_icp_vs_oracle.py: jobs drawn at random (2 - 4 scans, dense rooms through the certificate search and sparse ones through
+    the hash-table search, scanner-shaped sampling, a fixed cloud or none, 3 - 6 outer iterations) -- per-pair correspondence counts of
+    every iteration identical to the oracle's kd-tree ICP, poses within 1e-5, under the default switches, with every far-list query
+    seeded, with the certificate / row-update fusion forced on and pair by pair without seeds."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz_icp_vs_oracle.py"), "--trials", "6", "--seed", "7"],
+                       capture_output=True, text=True, timeout=850)
+    assert p.returncode == 0 and "FUZZ OK" in p.stdout, p.stdout[-3000:] + p.stderr[-2000:]
+    print("\n".join(ln for ln in p.stdout.splitlines() if ln.startswith("switches")))

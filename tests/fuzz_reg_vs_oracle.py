@@ -1,0 +1,94 @@
+"""Randomised differential run of path (B) against the CPU oracle, step by step (test infrastructure, not product code).
+
+    python tests/fuzz_reg_vs_oracle.py --trials 30 --seed 1
+
+Each trial draws a camera model (the ten of camera_base.cc:66-77), a point count, a number of images, an image size, an initial pose
+error and the weight of the variable-colour residuals, builds the same problem in the library and in the oracle's driver and compares
+one pass of the optimizer's steps: observation lists after `update_observations` (point indices and flags: equal), the colour update
+(observation counts equal, descriptors to 2e-4), the cost (1e-6 relative) and one `Apply` (accepted / lambda equal, poses to 1e-5).
+The decisions inside a whole `RunOnCurrentScale` run are compared by the fixed-seed tests of test_gpu_reg.py."""
+import argparse
+import importlib
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def draw(rng):
+    w = int(rng.choice([200, 240, 320]))
+    return {"model": int(rng.integers(0, 10)), "n_points": int(rng.integers(2_000, 14_000)), "n_images": int(rng.integers(2, 5)),
+            "width": w, "height": int(w * 3 // 4), "seed": int(rng.integers(1, 100_000)), "perturb": float(rng.choice([0.002, 0.006, 0.012])),
+            "var_weight": float(rng.choice([0.0, 1.0, 1.0])), "n_levels": int(rng.choice([3, 4]))}
+
+
+def pose_delta(qa, ta, qb, tb):
+    from reg_util import quat_to_R
+    Ra, Rb = quat_to_R(qa).astype(np.float64), quat_to_R(qb).astype(np.float64)
+    S = Ra.T @ Rb
+    ang = 0.5 * np.linalg.norm([S[2, 1] - S[1, 2], S[0, 2] - S[2, 0], S[1, 0] - S[0, 1]])
+    return float(ang), float(np.linalg.norm(np.asarray(ta, np.float64) - np.asarray(tb, np.float64)))
+
+
+def one(e3d, job):
+    from oracle.reg_driver import OracleRegProblem
+    from reg_util import make_multi_image_scene
+    M = make_multi_image_scene(n_points=job["n_points"], n_images=job["n_images"], width=job["width"], height=job["height"],
+                               n_levels=job["n_levels"], seed=job["seed"], perturb=job["perturb"], model=job["model"])
+    prm = e3d.default_reg_params(image_scale_count=M["n_levels"], point_neighbor_count=M["K"], variable_residuals_weight=job["var_weight"])
+    G = e3d.RegProblem(prm)
+    O = OracleRegProblem(K=M["K"], image_scale_count=M["n_levels"], var_weight=job["var_weight"])
+    G.set_intrinsics(0, M["width"], M["height"], M["params"], 0, M["n_levels"], camera_type=M["model"])
+    O.set_intrinsics(0, M["width"], M["height"], M["params"], 0, M["n_levels"], model=M["model"])
+    for P in (G, O):
+        P.set_point_scale(0, M["pts"], M["point_radius"], M["nbr"], M["fixed_desc"])
+        P.set_splat_points(M["pts"])
+        for i, im in enumerate(M["images"]):
+            P.set_image(i, 0, im["pyr"])
+            P.set_image_pose(i, im["q_init"], im["t_init"])
+    G.update_observations(1); O.update_observations(1)
+    n_obs = 0
+    for i in range(job["n_images"]):
+        n = len(O.obs[(i, 0)][0]); n_obs += n
+        g = G.get_observations(i, 0, n)
+        if not (np.array_equal(g[0], O.obs[(i, 0)][0]) and np.array_equal(g[4], O.obs[(i, 0)][4])): return "observation list of image %d" % i
+    if job["var_weight"] > 0:
+        G.color_update(); O.color_update()
+        d, c = G.get_variable_descriptors(0, len(M["pts"]))
+        if not np.array_equal(c, O.scales[0]["counts"]): return "observation counts per point"
+        if not np.abs(d - O.scales[0]["var"]).max() <= 2e-4: return "variable descriptors"
+    cg, co = G.compute_cost(), O.compute_cost()
+    if not abs(cg - co) <= 1e-6 * co: return "cost %r vs %r" % (cg, co)
+    ag, lg, mg = G.apply(64.0); ao, lo, mo = O.apply(64.0)
+    if not (ag == ao and lg == lo): return "Apply: accepted / lambda %r %r vs %r %r" % (ag, lg, ao, lo)
+    for i in range(job["n_images"]):
+        ang, tr = pose_delta(*G.get_image_pose(i), *O.get_image_pose(i))
+        if not (ang <= 1e-5 and tr <= 1e-5): return "pose of image %d after Apply: %.2e rad %.2e m" % (i, ang, tr)
+    return n_obs
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--trials", type=int, default=30)
+    ap.add_argument("--seed", type=int, default=1)
+    args = ap.parse_args()
+    e3d = importlib.import_module("dataset-pipeline_amd")
+    rng = np.random.default_rng(args.seed)
+    bad = 0
+    for t in range(args.trials):
+        job = draw(rng)
+        r = one(e3d, job)
+        ok = isinstance(r, int)
+        bad += 0 if ok else 1
+        print("trial %d: %s -> %s" % (t, json.dumps(job), ("ok, %d observations" % r) if ok else ("MISMATCH: " + r)), flush=True)
+    print("FUZZ %s" % ("OK" if bad == 0 else "FAILED (%d)" % bad))
+    sys.exit(0 if bad == 0 else 1)
+
+
+if __name__ == "__main__":
+    main()

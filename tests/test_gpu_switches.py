@@ -246,3 +246,14 @@ def test_randomised_jobs_match_the_oracle():
                        capture_output=True, text=True, timeout=850)
     assert p.returncode == 0 and "FUZZ OK" in p.stdout, p.stdout[-3000:] + p.stderr[-2000:]
     print("\n".join(ln for ln in p.stdout.splitlines() if ln.startswith("switches")))
+
+
+@pytest.mark.timeout(900)
+def test_randomised_clouds_match_the_oracle_normals():
+    """tests/fuzz_normals_vs_oracle.py: clouds drawn at random (room and scanner-sampled scans, clusters with far outliers, lattices
+    with every distance tied, duplicated points, a thin line; k in 3 .. 70; scaled and shifted by up to 250 m) -- neighbour lists
+    equal, normals and curvatures bit for bit, under the default switches and three alternative data flows of the estimator."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz_normals_vs_oracle.py"), "--trials", "12", "--seed", "3"],
+                       capture_output=True, text=True, timeout=850)
+    assert p.returncode == 0 and "FUZZ OK" in p.stdout, p.stdout[-3000:] + p.stderr[-2000:]
+    print("\n".join(ln for ln in p.stdout.splitlines() if ln.startswith("switches")))

@@ -15,6 +15,11 @@
 //   kPolynomial3      camera::PolynomialCamera            src/camera/camera_polynomial.h:43-127 (RadialBase) [fx fy cx cy k1 k2 k3]  I = 7
 //   kFisheyePolyTang  camera::FisheyePolynomialTangentialCamera  src/camera/camera_fisheye_polynomial_tangential.h =
 //                     FisheyeBase over PolynomialTangentialCamera (the kOpenCV polynomial)                          I = 8
+//   kFullOpenCV       camera::FullOpenCVCamera            src/camera/camera_full_opencv.h:41-196 [fx fy cx cy k1 k2 p1 p2 k3 k4 k5 k6] I = 12
+//   kRadialFisheye    camera::RadialFisheyeCamera         src/camera/camera_radial_fisheye.h = FisheyeBase over RadialCamera   [f cx cy k1 k2]  I = 5
+//   kSimpleRadialFisheye  camera::SimpleRadialFisheyeCamera  src/camera/camera_simple_radial_fisheye.h = FisheyeBase over SimpleRadialCamera  I = 4
+//                     (the three classes of src/camera the reference's factory never creates, camera_base.cc:66-77: reachable through
+//                     the C-ABI's camera_type only)
 //   The models with ONE focal length (UniqueFocalLength(), camera_base_impl.h:65-67) keep fx = fy = f in CamLevel; their
 //   parameter vector, and with it the column order of the intrinsics Jacobian, is [f, cx, cy, distortion...] (:394-407).
 //   The COLMAP names RADIAL_FISHEYE / SIMPLE_RADIAL_FISHEYE construct RadialCamera / SimpleRadialCamera in the reference's
@@ -34,19 +39,30 @@
 namespace e3d {
 
 enum : int { kPinhole = 0, kOpenCV = 1, kThinPrismFisheye = 2, kOpenCVFisheye = 3, kFov = 4, kSimplePinhole = 5, kSimpleRadial = 6,
-             kRadial = 7, kPolynomial3 = 8, kFisheyePolyTang = 9, kNumCameraModels = 10 };
+             kRadial = 7, kPolynomial3 = 8, kFisheyePolyTang = 9, kFullOpenCV = 10, kRadialFisheye = 11, kSimpleRadialFisheye = 12,
+             kNumCameraModels = 13 };
 
 __host__ __device__ constexpr int cam_param_count(int model) {
   return model == kPinhole ? 4 : model == kFov ? 5 : (model == kOpenCV || model == kOpenCVFisheye || model == kFisheyePolyTang) ? 8 :
-         model == kSimplePinhole ? 3 : model == kSimpleRadial ? 4 : model == kRadial ? 5 : model == kPolynomial3 ? 7 : 12;
+         model == kSimplePinhole ? 3 : (model == kSimpleRadial || model == kSimpleRadialFisheye) ? 4 :
+         (model == kRadial || model == kRadialFisheye) ? 5 : model == kPolynomial3 ? 7 : 12;
 }
-__host__ __device__ constexpr bool cam_is_fisheye(int model) { return model == kThinPrismFisheye || model == kOpenCVFisheye || model == kFisheyePolyTang; }
-__host__ __device__ constexpr bool cam_unique_focal(int model) { return model == kSimplePinhole || model == kSimpleRadial || model == kRadial; }
+__host__ __device__ constexpr bool cam_is_fisheye(int model) {
+  return model == kThinPrismFisheye || model == kOpenCVFisheye || model == kFisheyePolyTang || model == kRadialFisheye || model == kSimpleRadialFisheye;
+}
+__host__ __device__ constexpr bool cam_unique_focal(int model) {
+  return model == kSimplePinhole || model == kSimpleRadial || model == kRadial || model == kRadialFisheye || model == kSimpleRadialFisheye;
+}
 __host__ __device__ constexpr int cam_distortion_count(int model) { return cam_param_count(model) - (cam_unique_focal(model) ? 3 : 4); }
 // the polynomial inside is PolynomialTangentialCamera's (k1 k2 p1 p2)
 __host__ __device__ constexpr bool cam_is_poly_tang(int model) { return model == kOpenCV || model == kFisheyePolyTang; }
-// RadialBase children: Distort = point * DistortionFactor(squaredNorm)
-__host__ __device__ constexpr bool cam_is_radial(int model) { return model == kSimpleRadial || model == kRadial || model == kPolynomial3; }
+// RadialBase children (for the fisheye wrappers: the model inside): Distort = point * DistortionFactor(squaredNorm)
+__host__ __device__ constexpr bool cam_is_radial(int model) {
+  return model == kSimpleRadial || model == kRadial || model == kPolynomial3 || model == kRadialFisheye || model == kSimpleRadialFisheye;
+}
+// the polynomial inside is SimpleRadialCamera's (k) / RadialCamera's (k1 k2)
+__host__ __device__ constexpr bool cam_is_simple_radial(int model) { return model == kSimpleRadial || model == kSimpleRadialFisheye; }
+__host__ __device__ constexpr bool cam_is_radial2(int model) { return model == kRadial || model == kRadialFisheye; }
 
 struct CamLevel {
   int model;
@@ -68,8 +84,8 @@ __device__ __forceinline__ void cam_distort_plain(const CamLevel& c, float nx, f
   } else if constexpr (cam_is_radial(M)) {         // RadialBase::Distort (camera_base_impl_radial.h:52-56) with the child's DistortionFactor
     const float r2 = nx * nx + ny * ny;
     float f;
-    if constexpr (M == kSimpleRadial) f = 1.0f + r2 * c.q[0];                                   // camera_simple_radial.h:60-62
-    else if constexpr (M == kRadial) f = 1.0f + r2 * (c.q[0] + r2 * c.q[1]);                    // camera_radial.h:60-65
+    if constexpr (cam_is_simple_radial(M)) f = 1.0f + r2 * c.q[0];                              // camera_simple_radial.h:60-62
+    else if constexpr (cam_is_radial2(M)) f = 1.0f + r2 * (c.q[0] + r2 * c.q[1]);               // camera_radial.h:60-65
     else f = 1.0f + r2 * (c.q[0] + r2 * (c.q[1] + r2 * c.q[2]));                                // camera_polynomial.h:58-64
     ox = nx * f; oy = ny * f;
   } else if constexpr (M == kFov) {                // camera_fisheye_fov.h:55-63
@@ -80,6 +96,16 @@ __device__ __forceinline__ void cam_distort_plain(const CamLevel& c, float nx, f
     const float r2 = nx * nx + ny * ny;
     const float f = 1.0f + r2 * (c.q[0] + r2 * (c.q[1] + r2 * (c.q[2] + r2 * c.q[3])));
     ox = nx * f; oy = ny * f;
+  } else if constexpr (M == kFullOpenCV) {         // camera_full_opencv.h:53-78; q = [k1 k2 p1 p2 k3 k4 k5 k6]
+    const float k1 = c.q[0], k2 = c.q[1], p1 = c.q[2], p2 = c.q[3], k3 = c.q[4], k4 = c.q[5], k5 = c.q[6], k6 = c.q[7];
+    const float x2 = nx * nx, xy = nx * ny, y2 = ny * ny;
+    const float r2 = x2 + y2;
+    const float r4 = r2 * r2;
+    const float r6 = r4 * r2;
+    const float radial = (((1.f + k1 * r2) + k2 * r4) + k3 * r6) / (((1.f + k4 * r2) + k5 * r4) + k6 * r6);
+    const float dx = 2.f * p1 * xy + p2 * (r2 + 2.f * x2);
+    const float dy = 2.f * p2 * xy + p1 * (r2 + 2.f * y2);
+    ox = radial * nx + dx; oy = radial * ny + dy;
   } else {
     const float x2 = nx * nx, xy = nx * ny, y2 = ny * ny;
     const float r2 = x2 + y2;
@@ -104,7 +130,7 @@ template <int M>
 __device__ __forceinline__ void cam_ddn_plain(const CamLevel& c, float nx, float ny, float* J) {
   if constexpr (M == kPinhole || M == kSimplePinhole) {
     J[0] = 1.f; J[1] = 0.f; J[2] = 0.f; J[3] = 1.f;
-  } else if constexpr (M == kSimpleRadial) {       // camera_simple_radial.h:75-88
+  } else if constexpr (cam_is_simple_radial(M)) {  // camera_simple_radial.h:75-88
     const float k1 = c.q[0];
     const float nxs = nx * nx, nys = ny * ny;
     const float ru2 = nxs + nys;
@@ -112,11 +138,11 @@ __device__ __forceinline__ void cam_ddn_plain(const CamLevel& c, float nx, float
     J[1] = 2 * nx * ny * k1;
     J[2] = J[1];
     J[3] = k1 * (ru2 + 2 * nys) + 1;
-  } else if constexpr (M == kRadial || M == kPolynomial3) {     // camera_radial.h:82-101, camera_polynomial.h:81-101
+  } else if constexpr (cam_is_radial2(M) || M == kPolynomial3) {     // camera_radial.h:82-101, camera_polynomial.h:81-101
     const float nx2 = nx * nx, ny2 = ny * ny, nxny = nx * ny;
     const float r2 = nx2 + ny2;
     float term1, term2;
-    if constexpr (M == kRadial) {
+    if constexpr (cam_is_radial2(M)) {
       const float k1 = c.q[0], k2 = c.q[1];
       term1 = 2 * k1 + r2 * (4 * k2);
       term2 = 1 + r2 * (k1 + r2 * (k2));
@@ -144,6 +170,27 @@ __device__ __forceinline__ void cam_ddn_plain(const CamLevel& c, float nx, float
     J[1] = nx_times_ny * (tt / part2 - rdw / part1);
     J[2] = J[1];
     J[3] = part3 - (nys * rdw) / part1 + (nys * tt) / part2;
+  } else if constexpr (M == kFullOpenCV) {         // camera_full_opencv.h:126-171
+    const float k1 = c.q[0], k2 = c.q[1], p1 = c.q[2], p2 = c.q[3], k3 = c.q[4], k4 = c.q[5], k5 = c.q[6], k6 = c.q[7];
+    const float x2 = nx * nx, y2 = ny * ny, xy = nx * ny;
+    const float r2 = x2 + y2;
+    const float r4 = r2 * r2;
+    const float r6 = r4 * r2;
+    const float radial_numerator = ((1.f + k1 * r2) + k2 * r4) + k3 * r6;
+    const float radial_denominator = ((1.f + k4 * r2) + k5 * r4) + k6 * r6;
+    const float radial = radial_numerator / radial_denominator;
+    const float d_radial_numerator = (2 * k1 + 4 * k2 * r2) + 6 * k3 * r4;
+    const float d_radial_denominator = (2 * k4 + 4 * k5 * r2) + 6 * k6 * r4;
+    const float d_radial = (d_radial_numerator * radial_denominator - d_radial_denominator * radial_numerator) /
+                           (radial_denominator * radial_denominator);
+    const float d_tan_x_nx = 2 * ny * p1 + 6 * p2 * nx;
+    const float d_tan_y_ny = 2 * nx * p2 + 6 * p1 * ny;
+    const float d_tan_y_nx = 2 * ny * p2 + 2 * p1 * nx;
+    const float d_tan_x_ny = 2 * nx * p1 + 2 * p2 * ny;
+    J[0] = (radial + x2 * d_radial) + d_tan_x_nx;
+    J[1] = xy * d_radial + d_tan_x_ny;
+    J[2] = xy * d_radial + d_tan_y_nx;
+    J[3] = (radial + y2 * d_radial) + d_tan_y_ny;
   } else if constexpr (M == kOpenCVFisheye) {      // camera_polynomial_4.h:78-98
     const float nx2 = nx * nx, ny2 = ny * ny, nxny = nx * ny;
     const float r2 = nx2 + ny2;
@@ -197,10 +244,25 @@ __device__ __forceinline__ void cam_ddp_plain(const CamLevel& c, float nx, float
     const float rs = nx * nx + ny * ny;
     d0[0] = nx * rs; d0[1] = d0[0] * rs; d0[2] = d0[1] * rs; d0[3] = d0[2] * rs;
     d1[0] = ny * rs; d1[1] = d1[0] * rs; d1[2] = d1[1] * rs; d1[3] = d1[2] * rs;
+  } else if constexpr (M == kFullOpenCV) {         // camera_full_opencv.h:83-123: columns k1 k2 p1 p2 k3 k4 k5 k6
+    const float k1 = c.q[0], k2 = c.q[1], k3 = c.q[4], k4 = c.q[5], k5 = c.q[6], k6 = c.q[7];
+    const float x2 = nx * nx, y2 = ny * ny;
+    const float r2 = x2 + y2;
+    const float r4 = r2 * r2;
+    const float r6 = r4 * r2;
+    const float radial_numerator = ((1.f + k1 * r2) + k2 * r4) + k3 * r6;
+    const float radial_denominator = ((1.f + k4 * r2) + k5 * r4) + k6 * r6;
+    const float radial = radial_numerator / radial_denominator;
+    d0[0] = nx * r2 / radial_denominator; d0[1] = nx * r4 / radial_denominator; d0[2] = nx * 2.f * ny; d0[3] = (r2 + 2 * x2);
+    d0[4] = nx * r6 / radial_denominator;
+    d0[5] = -nx * r2 * radial / radial_denominator; d0[6] = -nx * r4 * radial / radial_denominator; d0[7] = -nx * r6 * radial / radial_denominator;
+    d1[0] = ny * r2 / radial_denominator; d1[1] = ny * r4 / radial_denominator; d1[2] = (r2 + 2 * y2); d1[3] = ny * 2.f * nx;
+    d1[4] = ny * r6 / radial_denominator;
+    d1[5] = -ny * r2 * radial / radial_denominator; d1[6] = -ny * r4 * radial / radial_denominator; d1[7] = -ny * r6 * radial / radial_denominator;
   } else if constexpr (cam_is_radial(M)) {         // camera_simple_radial.h:67-72, camera_radial.h:70-79, camera_polynomial.h:69-79
     const float rs = nx * nx + ny * ny;
     d0[0] = nx * rs; d1[0] = ny * rs;
-    if constexpr (M != kSimpleRadial) { d0[1] = d0[0] * rs; d1[1] = d1[0] * rs; }
+    if constexpr (!cam_is_simple_radial(M)) { d0[1] = d0[0] * rs; d1[1] = d1[0] * rs; }
     if constexpr (M == kPolynomial3) { d0[2] = d0[1] * rs; d1[2] = d1[1] * rs; }
   } else if constexpr (M != kPinhole && M != kSimplePinhole) {
     const float nx2 = nx * nx, ny2 = ny * ny;

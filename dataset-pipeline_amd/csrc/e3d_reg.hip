@@ -373,6 +373,36 @@ __global__ __launch_bounds__(kBlock) void k_mesh_vertices(const float4* __restri
       r2 = 99.0f;
     }
     lx = r2 * X; ly = r2 * Y;
+  } else if constexpr (M == kRadialFisheye || M == kSimpleRadialFisheye) {
+    // RadialFisheye / SimpleRadialFisheye shaders (renderer.cc:361-378, 434-452): r2 after the fisheye warp against the OUTER camera's cut-off
+    float nx = X / Z, ny = Y / Z;
+    float r2 = nx * nx + ny * ny;
+    const float r = sqrtf(r2);
+    if (r > 1e-6f) {
+      const float theta_by_r = e3d_atan2f(r, 1.0f) / r;
+      if constexpr (M == kRadialFisheye) { nx = theta_by_r * nx; ny = theta_by_r * ny; r2 = nx * nx + ny * ny; }
+      else { r2 = r2 * theta_by_r * theta_by_r; nx = nx * theta_by_r; ny = ny * theta_by_r; }
+    }
+    if (r2 <= cam.cutoff2) {
+      if constexpr (M == kRadialFisheye) r2 = 1.0f + r2 * (cam.q[0] + r2 * cam.q[1]);
+      else r2 = 1.0f + r2 * cam.q[0];
+    } else {
+      r2 = 99.0f;
+    }
+    lx = Z * r2 * nx; ly = Z * r2 * ny;
+  } else if constexpr (M == kFullOpenCV) {
+    // FullOpenCV shader (renderer.cc:528-543)
+    const float nx = X / Z, ny = Y / Z;
+    const float x2 = nx * nx, xy = nx * ny, y2 = ny * ny;
+    const float r2 = x2 + y2;
+    if (r2 <= cam.cutoff2) {
+      const float k1 = cam.q[0], k2 = cam.q[1], p1 = cam.q[2], p2 = cam.q[3], k3 = cam.q[4], k4 = cam.q[5], k5 = cam.q[6], k6 = cam.q[7];
+      const float radial = (1.0f + r2 * (k1 + r2 * (k2 + r2 * k3))) / (1.0f + r2 * (k4 + r2 * (k5 + r2 * k6)));
+      lx = Z * (radial * nx + 2.0f * p1 * xy + p2 * (r2 + 2.0f * x2));
+      ly = Z * (radial * ny + 2.0f * p2 * xy + p1 * (r2 + 2.0f * y2));
+    } else {
+      lx = X * 99.0f; ly = Y * 99.0f;
+    }
   } else if constexpr (M != kPinhole && M != kSimplePinhole) {
     float nx = X / Z, ny = Y / Z;
     float r2 = nx * nx + ny * ny;
@@ -2441,6 +2471,9 @@ static void allreduce_device(e3d_reg* h, void* dev, size_t n, int dtype) {
     case kRadial: { constexpr int M = kRadial; stmt; } break;                              \
     case kPolynomial3: { constexpr int M = kPolynomial3; stmt; } break;                    \
     case kFisheyePolyTang: { constexpr int M = kFisheyePolyTang; stmt; } break;            \
+    case kFullOpenCV: { constexpr int M = kFullOpenCV; stmt; } break;                      \
+    case kRadialFisheye: { constexpr int M = kRadialFisheye; stmt; } break;                \
+    case kSimpleRadialFisheye: { constexpr int M = kSimpleRadialFisheye; stmt; } break;    \
     default: throw Error(E3D_ERR_INVALID, "unknown camera model");                         \
   }
 
@@ -2453,12 +2486,12 @@ static float radial_init_cutoff(const CamLevel& c) {
   // DistortionFactor(r2) / DistortedDerivativeByNormalized(r2) of the RadialBase child, in its own expression order
   // (camera_polynomial_4.h:55-61,100-110; camera_radial.h:60-65,103-107; camera_polynomial.h:58-64,103-107)
   auto factor = [&](float r2) {
-    if (model == kRadial) return 1.0f + r2 * (q[0] + r2 * q[1]);
+    if (cam_is_radial2(model)) return 1.0f + r2 * (q[0] + r2 * q[1]);
     if (model == kPolynomial3) return 1.0f + r2 * (q[0] + r2 * (q[1] + r2 * q[2]));
     return 1.0f + r2 * (q[0] + r2 * (q[1] + r2 * (q[2] + r2 * q[3])));
   };
   auto dfactor = [&](float r2) {
-    if (model == kRadial) return 1.f + r2 * (3.f * q[0] + r2 * 5.f * q[1]);
+    if (cam_is_radial2(model)) return 1.f + r2 * (3.f * q[0] + r2 * 5.f * q[1]);
     if (model == kPolynomial3) return 1.0f + r2 * (3.0f * q[0] + r2 * (5.0f * q[1] + r2 * 7.0f * q[2]));
     return 1.0f + r2 * (3.0f * q[0] + r2 * (5.0f * q[1] + r2 * (7.0f * q[2] + r2 * (9.0f * q[3]))));
   };
@@ -2511,7 +2544,11 @@ static CamLevel make_level(e3d_reg* h, int model, int w, int h_px, const float* 
   c.cx_inv = (float)(-1.0 * (double)c.cx / (double)c.fx); c.cy_inv = (float)(-1.0 * (double)c.cy / (double)c.fy);
   c.cutoff2 = INFINITY; c.inner_cutoff2 = INFINITY;
   if (model == kPinhole || model == kSimplePinhole) return c;   // no InitCutoff (camera_pinhole.cc:35-43, camera_simple_pinhole.cc:36-41)
-  if (model == kOpenCVFisheye) { c.inner_cutoff2 = radial_init_cutoff(c); return c; }
+  if (model == kOpenCVFisheye || model == kRadialFisheye) { c.inner_cutoff2 = radial_init_cutoff(c); return c; }   // the RadialBase child inside
+  if (model == kSimpleRadialFisheye) {              // the SimpleRadialCamera inside (camera_simple_radial.cc:51-57)
+    if (c.q[0] < 0) c.inner_cutoff2 = -1.f / (3 * c.q[0]);
+    return c;
+  }
   if (model == kRadial || model == kPolynomial3) { c.cutoff2 = radial_init_cutoff(c); return c; }   // RadialBase::InitCutoff on the camera itself
   if (model == kSimpleRadial) {                     // camera_simple_radial.cc:51-57: where d(distorted r)/dr = 0
     if (c.q[0] < 0) c.cutoff2 = -1.f / (3 * c.q[0]);
@@ -2528,6 +2565,7 @@ static CamLevel make_level(e3d_reg* h, int model, int w, int h_px, const float* 
   const int total = 2 * w + 2 * h_px;
   const unsigned cut_blocks = (unsigned)div_up((size_t)total, kBlock / kWave);      // one wave per border test point
   if (cam_is_poly_tang(model)) hipLaunchKernelGGL(k_cam_cutoff<kOpenCV>, dim3(cut_blocks), dim3(kBlock), 0, h->stream, c, h->cut.p);   // (the inner PolynomialTangentialCamera of kFisheyePolyTang)
+  else if (model == kFullOpenCV) hipLaunchKernelGGL(k_cam_cutoff<kFullOpenCV>, dim3(cut_blocks), dim3(kBlock), 0, h->stream, c, h->cut.p);
   else hipLaunchKernelGGL(k_cam_cutoff<kThinPrismFisheye>, dim3(cut_blocks), dim3(kBlock), 0, h->stream, c, h->cut.p);   // inner ThinPrismCamera
   unsigned out[2];
   copy_out(out, h->cut.p, sizeof out, h->stream);
@@ -2536,7 +2574,7 @@ static CamLevel make_level(e3d_reg* h, int model, int w, int h_px, const float* 
   std::memcpy(&mn, &out[0], 4); std::memcpy(&mx, &out[1], 4);
   const float a = mn * 1.01f;
   const float cutoff = (mx < a) ? mx : a;           // std::min(min_candidate * kIncreaseFactor, max_candidate)
-  if (model == kOpenCV) c.cutoff2 = cutoff; else c.inner_cutoff2 = cutoff;
+  if (model == kOpenCV || model == kFullOpenCV) c.cutoff2 = cutoff; else c.inner_cutoff2 = cutoff;
   return c;
 }
 

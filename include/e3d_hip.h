@@ -311,6 +311,10 @@ typedef struct {
 #define E3D_CAMERA_RADIAL 7              /* I = 5: f cx cy k1 k2            (also the name RADIAL_FISHEYE, camera_base.cc:73) */
 #define E3D_CAMERA_POLYNOMIAL_3 8        /* I = 7: fx fy cx cy k1 k2 k3 */
 #define E3D_CAMERA_FISHEYE_POLYNOMIAL_2_TANGENTIAL_2 9   /* I = 8: fx fy cx cy k1 k2 p1 p2 */
+/* the three classes of src/camera that the reference's factory never creates (camera_base.cc:66-77): no camera name reaches them */
+#define E3D_CAMERA_FULL_OPENCV 10        /* I = 12: fx fy cx cy k1 k2 p1 p2 k3 k4 k5 k6   (camera_full_opencv.h:41-196) */
+#define E3D_CAMERA_RADIAL_FISHEYE_CLASS 11         /* I = 5: f cx cy k1 k2   RadialFisheyeCamera = FisheyeBase over RadialCamera */
+#define E3D_CAMERA_SIMPLE_RADIAL_FISHEYE_CLASS 12  /* I = 4: f cx cy k       SimpleRadialFisheyeCamera = FisheyeBase over SimpleRadialCamera */
 
 e3d_reg_t* e3d_reg_create(const e3d_reg_params* params);
 void e3d_reg_destroy(e3d_reg_t* reg);

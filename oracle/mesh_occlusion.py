@@ -55,6 +55,37 @@ def project_vertices(model, cam, R, t, verts, shaded=False):
                 poly = F(1.0) + r2 * (q[0] + r2 * q[1]) if model == 7 else F(1.0) + r2 * (q[0] + r2 * (q[1] + r2 * q[2]))
                 fac = np.where(r2 <= F(cam.cutoff2), poly, F(99.0)).astype(F)
             lx = (fac * X).astype(F); ly = (fac * Y).astype(F)
+    elif model in (11, 12):
+        # RadialFisheye / SimpleRadialFisheye shaders (renderer.cc:361-378, 434-452): r2 after the fisheye warp against the outer camera's cut-off
+        with np.errstate(all="ignore"):
+            nx, ny = (X / Z).astype(F), (Y / Z).astype(F)
+            r2 = (nx * nx + ny * ny).astype(F)
+            r = np.sqrt(r2).astype(F)
+            big = r > F(1e-6)
+            th = np.where(big, _atan2f_1(r) / r, F(1.0)).astype(F)
+            if model == 11:
+                wx, wy = (th * nx).astype(F), (th * ny).astype(F)
+                nx2, ny2 = np.where(big, wx, nx).astype(F), np.where(big, wy, ny).astype(F)
+                r2 = np.where(big, nx2 * nx2 + ny2 * ny2, r2).astype(F)
+                poly = F(1.0) + r2 * (F(cam.p[4]) + r2 * F(cam.p[5]))
+            else:
+                r2 = np.where(big, (r2 * th).astype(F) * th, r2).astype(F)
+                nx2, ny2 = np.where(big, nx * th, nx).astype(F), np.where(big, ny * th, ny).astype(F)
+                poly = F(1.0) + r2 * F(cam.p[4])
+            fac = np.where(r2 <= F(cam.cutoff2), poly, F(99.0)).astype(F)
+            lx = ((Z * fac) * nx2).astype(F); ly = ((Z * fac) * ny2).astype(F)
+    elif model == 10:
+        # FullOpenCV shader (renderer.cc:528-543)
+        with np.errstate(all="ignore"):
+            nx, ny = (X / Z).astype(F), (Y / Z).astype(F)
+            x2, xy, y2 = nx * nx, nx * ny, ny * ny
+            r2 = (x2 + y2).astype(F)
+            k1, k2, p1, p2, k3, k4, k5, k6 = [F(cam.p[4 + i]) for i in range(8)]
+            radial = (F(1.0) + r2 * (k1 + r2 * (k2 + r2 * k3))) / (F(1.0) + r2 * (k4 + r2 * (k5 + r2 * k6)))
+            dx = Z * (radial * nx + F(2.0) * p1 * xy + p2 * (r2 + F(2.0) * x2))
+            dy = Z * (radial * ny + F(2.0) * p2 * xy + p1 * (r2 + F(2.0) * y2))
+            inside = r2 <= F(cam.cutoff2)
+            lx = np.where(inside, dx, X * F(99.0)).astype(F); ly = np.where(inside, dy, Y * F(99.0)).astype(F)
     elif model not in (0, 5):
         with np.errstate(all="ignore"):
             nx, ny = X / Z, Y / Z

@@ -42,24 +42,42 @@
  * (UniqueFocalLength, camera_base_impl.h:65-67,394-407); INSIDE oreg_camera every model is stored as p = [fx fy cx cy q...] with
  * fx = fy = f for those (the classes are constructed that way, camera_radial.cc:43-46), n_params is the model's own count.
  * The names RADIAL_FISHEYE / SIMPLE_RADIAL_FISHEYE create types 7 / 6 (camera_base.cc:73-74 [QUIRK]). */
+/* 10 FullOpenCVCamera (camera_full_opencv.h:41-196: [fx fy cx cy k1 k2 p1 p2 k3 k4 k5 k6], rational radial factor), 11 RadialFisheyeCamera =
+ * FisheyeBase over RadialCamera (camera_radial_fisheye.cc:34-45), 12 SimpleRadialFisheyeCamera = FisheyeBase over SimpleRadialCamera
+ * (camera_simple_radial_fisheye.cc:34-45): the three classes of src/camera that camera_base.cc:66-77 never creates. */
 static inline int ocam_param_count(int type) {
-  static const int counts[10] = {4, 8, 12, 8, 5, 3, 4, 5, 7, 8};
-  return (type >= 0 && type < 10) ? counts[type] : 0;
+  static const int counts[13] = {4, 8, 12, 8, 5, 3, 4, 5, 7, 8, 12, 5, 4};
+  return (type >= 0 && type < 13) ? counts[type] : 0;
 }
-static inline int ocam_is_fisheye(int type) { return type == 2 || type == 3 || type == 9; }
-static inline int ocam_unique_focal(int type) { return type == 5 || type == 6 || type == 7; }
+static inline int ocam_is_fisheye(int type) { return type == 2 || type == 3 || type == 9 || type == 11 || type == 12; }
+static inline int ocam_unique_focal(int type) { return type == 5 || type == 6 || type == 7 || type == 11 || type == 12; }
+/* the model whose polynomial the `_plain` functions evaluate: the camera inside the two radial fisheye wrappers */
+static inline int ocam_plain_type(int type) { return type == 11 ? 7 : (type == 12 ? 6 : type); }
 static inline int ocam_distortion_count(int type) { return ocam_param_count(type) - (ocam_unique_focal(type) ? 3 : 4); }
 static inline int ocam_is_poly_tang(int type) { return type == 1 || type == 9; }
 
 /* ---- the polynomial models' Distort on a point already past the (optional) fisheye pre-warp --------------------------- */
 static inline void ocam_distort_plain(const oreg_camera* c, float nx, float ny, float* ox, float* oy) {
-  if (c->type == 0 || c->type == 5) { *ox = nx; *oy = ny; return; }
+  const int t = ocam_plain_type(c->type);
+  if (t == 0 || t == 5) { *ox = nx; *oy = ny; return; }
   const float* q = c->p + 4;
-  if (c->type == 6 || c->type == 7 || c->type == 8) {   /* RadialBase::Distort (camera_base_impl_radial.h:52-56) */
+  if (t == 10) {                            /* camera_full_opencv.h:53-78 */
+    const float k1 = q[0], k2 = q[1], p1 = q[2], p2 = q[3], k3 = q[4], k4 = q[5], k5 = q[6], k6 = q[7];
+    const float x2 = nx * nx, xy = nx * ny, y2 = ny * ny;
+    const float r2 = x2 + y2;
+    const float r4 = r2 * r2;
+    const float r6 = r4 * r2;
+    const float radial = (1.f + k1 * r2 + k2 * r4 + k3 * r6) / (1.f + k4 * r2 + k5 * r4 + k6 * r6);
+    const float dx = 2.f * p1 * xy + p2 * (r2 + 2.f * x2);
+    const float dy = 2.f * p2 * xy + p1 * (r2 + 2.f * y2);
+    *ox = radial * nx + dx; *oy = radial * ny + dy;
+    return;
+  }
+  if (t == 6 || t == 7 || t == 8) {   /* RadialBase::Distort (camera_base_impl_radial.h:52-56) */
     const float r2 = nx * nx + ny * ny;
     float f;
-    if (c->type == 6) f = 1.0f + r2 * q[0];                                   /* camera_simple_radial.h:60-62 */
-    else if (c->type == 7) f = 1.0f + r2 * (q[0] + r2 * q[1]);                /* camera_radial.h:60-65 */
+    if (t == 6) f = 1.0f + r2 * q[0];                                   /* camera_simple_radial.h:60-62 */
+    else if (t == 7) f = 1.0f + r2 * (q[0] + r2 * q[1]);                /* camera_radial.h:60-65 */
     else f = 1.0f + r2 * (q[0] + r2 * (q[1] + r2 * q[2]));                    /* camera_polynomial.h:58-64 */
     *ox = nx * f; *oy = ny * f;
     return;
@@ -94,9 +112,33 @@ static inline void ocam_distort_plain(const oreg_camera* c, float nx, float ny, 
 
 /* DistortedDerivativeByNormalized of the polynomial part: J = [j0 j1; j2 j3] */
 static inline void ocam_ddn_plain(const oreg_camera* c, float nx, float ny, float* J) {
-  if (c->type == 0 || c->type == 5) { J[0] = 1.f; J[1] = 0.f; J[2] = 0.f; J[3] = 1.f; return; }
+  const int t = ocam_plain_type(c->type);
+  if (t == 0 || t == 5) { J[0] = 1.f; J[1] = 0.f; J[2] = 0.f; J[3] = 1.f; return; }
   const float* q = c->p + 4;
-  if (c->type == 6) {                       /* camera_simple_radial.h:75-88 */
+  if (t == 10) {                            /* camera_full_opencv.h:126-171 */
+    const float k1 = q[0], k2 = q[1], p1 = q[2], p2 = q[3], k3 = q[4], k4 = q[5], k5 = q[6], k6 = q[7];
+    const float x2 = nx * nx, y2 = ny * ny, xy = nx * ny;
+    const float r2 = x2 + y2;
+    const float r4 = r2 * r2;
+    const float r6 = r4 * r2;
+    const float radial_numerator = 1.f + k1 * r2 + k2 * r4 + k3 * r6;
+    const float radial_denominator = 1.f + k4 * r2 + k5 * r4 + k6 * r6;
+    const float radial = radial_numerator / radial_denominator;
+    const float d_radial_numerator = 2 * k1 + 4 * k2 * r2 + 6 * k3 * r4;
+    const float d_radial_denominator = 2 * k4 + 4 * k5 * r2 + 6 * k6 * r4;
+    const float d_radial = (d_radial_numerator * radial_denominator - d_radial_denominator * radial_numerator) /
+                           (radial_denominator * radial_denominator);
+    const float d_tan_x_nx = 2 * ny * p1 + 6 * p2 * nx;
+    const float d_tan_y_ny = 2 * nx * p2 + 6 * p1 * ny;
+    const float d_tan_y_nx = 2 * ny * p2 + 2 * p1 * nx;
+    const float d_tan_x_ny = 2 * nx * p1 + 2 * p2 * ny;
+    J[0] = radial + x2 * d_radial + d_tan_x_nx;
+    J[1] = xy * d_radial + d_tan_x_ny;
+    J[2] = xy * d_radial + d_tan_y_nx;
+    J[3] = radial + y2 * d_radial + d_tan_y_ny;
+    return;
+  }
+  if (t == 6) {                             /* camera_simple_radial.h:75-88 */
     const float k1 = q[0];
     const float nxs = nx * nx, nys = ny * ny;
     const float ru2 = nxs + nys;
@@ -106,11 +148,11 @@ static inline void ocam_ddn_plain(const oreg_camera* c, float nx, float ny, floa
     J[3] = k1 * (ru2 + 2 * nys) + 1;
     return;
   }
-  if (c->type == 7 || c->type == 8) {       /* camera_radial.h:82-101, camera_polynomial.h:81-101 */
+  if (t == 7 || t == 8) {                   /* camera_radial.h:82-101, camera_polynomial.h:81-101 */
     const float nx2 = nx * nx, ny2 = ny * ny, nxny = nx * ny;
     const float r2 = nx2 + ny2;
     float term1, term2;
-    if (c->type == 7) {
+    if (t == 7) {
       const float k1 = q[0], k2 = q[1];
       term1 = 2 * k1 + r2 * (4 * k2);
       term2 = 1 + r2 * (k1 + r2 * (k2));
@@ -178,12 +220,31 @@ static inline void ocam_ddn_plain(const oreg_camera* c, float nx, float ny, floa
 
 /* DistortedDerivativeByDistortionParameters of the polynomial part: 2 x (I-4), row-major with row stride `ld` */
 static inline void ocam_ddp_plain(const oreg_camera* c, float nx, float ny, float* d0, float* d1) {
-  if (c->type == 0 || c->type == 5) return;
-  if (c->type == 6 || c->type == 7 || c->type == 8) {   /* camera_simple_radial.h:67-72, camera_radial.h:70-79, camera_polynomial.h:69-79 */
+  const int t = ocam_plain_type(c->type);
+  if (t == 0 || t == 5) return;
+  if (t == 10) {                            /* camera_full_opencv.h:83-123: columns k1 k2 p1 p2 k3 k4 k5 k6 */
+    const float* q = c->p + 4;
+    const float k1 = q[0], k2 = q[1], k3 = q[4], k4 = q[5], k5 = q[6], k6 = q[7];
+    const float x2 = nx * nx, y2 = ny * ny;
+    const float r2 = x2 + y2;
+    const float r4 = r2 * r2;
+    const float r6 = r4 * r2;
+    const float radial_numerator = 1.f + k1 * r2 + k2 * r4 + k3 * r6;
+    const float radial_denominator = 1.f + k4 * r2 + k5 * r4 + k6 * r6;
+    const float radial = radial_numerator / radial_denominator;
+    d0[0] = nx * r2 / radial_denominator; d0[1] = nx * r4 / radial_denominator; d0[2] = nx * 2.f * ny; d0[3] = (r2 + 2 * x2);
+    d0[4] = nx * r6 / radial_denominator;
+    d0[5] = -nx * r2 * radial / radial_denominator; d0[6] = -nx * r4 * radial / radial_denominator; d0[7] = -nx * r6 * radial / radial_denominator;
+    d1[0] = ny * r2 / radial_denominator; d1[1] = ny * r4 / radial_denominator; d1[2] = (r2 + 2 * y2); d1[3] = ny * 2.f * nx;
+    d1[4] = ny * r6 / radial_denominator;
+    d1[5] = -ny * r2 * radial / radial_denominator; d1[6] = -ny * r4 * radial / radial_denominator; d1[7] = -ny * r6 * radial / radial_denominator;
+    return;
+  }
+  if (t == 6 || t == 7 || t == 8) {   /* camera_simple_radial.h:67-72, camera_radial.h:70-79, camera_polynomial.h:69-79 */
     const float rs = nx * nx + ny * ny;
     d0[0] = nx * rs; d1[0] = ny * rs;
-    if (c->type != 6) { d0[1] = d0[0] * rs; d1[1] = d1[0] * rs; }
-    if (c->type == 8) { d0[2] = d0[1] * rs; d1[2] = d1[1] * rs; }
+    if (t != 6) { d0[1] = d0[0] * rs; d1[1] = d1[0] * rs; }
+    if (t == 8) { d0[2] = d0[1] * rs; d1[2] = d1[1] * rs; }
     return;
   }
   if (c->type == 4) {                       /* camera_fisheye_fov.h:94-118 */
@@ -439,7 +500,7 @@ static inline float ocam_radial_iterative_undistort(const float* q, float distor
 }
 static inline float ocam_radial_init_cutoff(const oreg_camera* c) {
   const float* q = c->p + 4;
-  ocam_radial_type_ = c->type;
+  ocam_radial_type_ = ocam_plain_type(c->type);
   /* ImageToDistorted of the four corners (0,0) (0,H) (W,0) (W,H): k_inv applied, Eigen norm = sqrt(x*x + y*y) */
   float test_r = 0.f;
   for (int k = 0; k < 4; ++k) {
@@ -487,7 +548,9 @@ static inline void ocam_init(oreg_camera* c, int type, int w, int h, const float
   c->fx_inv = (float)(1.0 / (double)c->p[0]); c->fy_inv = (float)(1.0 / (double)c->p[1]);
   c->cx_inv = (float)(-1.0 * (double)c->p[2] / (double)c->p[0]); c->cy_inv = (float)(-1.0 * (double)c->p[3] / (double)c->p[1]);
   c->cutoff2 = INFINITY; c->inner_cutoff2 = INFINITY;
-  if (type == 1) c->cutoff2 = ocam_init_cutoff(c);
+  if (type == 1 || type == 10) c->cutoff2 = ocam_init_cutoff(c);      /* the general InitCutoff in the constructor (camera_full_opencv.cc:41,53) */
+  else if (type == 11) c->inner_cutoff2 = ocam_radial_init_cutoff(c); /* the RadialCamera inside (its constructor calls RadialBase::InitCutoff) */
+  else if (type == 12) { if (c->p[4] < 0) c->inner_cutoff2 = -1.f / (3 * c->p[4]); }   /* the SimpleRadialCamera inside (camera_simple_radial.cc:51-57) */
   else if (type == 2) {
     /* the inner ThinPrismCamera: a non-fisheye camera with the same parameters */
     oreg_camera inner = *c;

@@ -13,7 +13,7 @@ class Camera(C.Structure):
 
     def params(self):
         """The model's own parameter vector (GetParameters order); inside the struct every model is [fx fy cx cy q...]."""
-        if self.type in (5, 6, 7):           # one focal length: [f cx cy q...]
+        if self.type in (5, 6, 7, 11, 12):   # one focal length: [f cx cy q...]
             return np.array([self.p[0], self.p[2], self.p[3]] + list(self.p[4:self.n_params + 1]), np.float32)
         return np.array(self.p[:self.n_params], np.float32)
 
@@ -33,7 +33,8 @@ def rig_link(q_image_T_rig, q_rig_T_global, t_rig_T_global):
 
 PINHOLE, OPENCV, THIN_PRISM_FISHEYE, OPENCV_FISHEYE, FOV = 0, 1, 2, 3, 4
 SIMPLE_PINHOLE, SIMPLE_RADIAL, RADIAL, POLYNOMIAL_3, FISHEYE_POLYNOMIAL_2_TANGENTIAL_2 = 5, 6, 7, 8, 9
-PARAM_COUNT = {0: 4, 1: 8, 2: 12, 3: 8, 4: 5, 5: 3, 6: 4, 7: 5, 8: 7, 9: 8}
+FULL_OPENCV, RADIAL_FISHEYE_CLASS, SIMPLE_RADIAL_FISHEYE_CLASS = 10, 11, 12     # classes of src/camera the reference's factory never creates
+PARAM_COUNT = {0: 4, 1: 8, 2: 12, 3: 8, 4: 5, 5: 3, 6: 4, 7: 5, 8: 7, 9: 8, 10: 12, 11: 5, 12: 4}
 
 
 _READY = False

@@ -2,7 +2,7 @@
 
     python tests/fuzz_reg_vs_oracle.py --trials 30 --seed 1
 
-Each trial draws a camera model (the ten of camera_base.cc:66-77), a point count, a number of images, an image size, an initial pose
+Each trial draws a camera model (the thirteen classes of src/camera), a point count, a number of images, an image size, an initial pose
 error and the weight of the variable-colour residuals, builds the same problem in the library and in the oracle's driver and compares
 one pass of the optimizer's steps: observation lists after `update_observations` (point indices and flags: equal), the colour update
 (observation counts equal, descriptors to 2e-4), the cost (1e-6 relative) and one `Apply` (accepted / lambda equal, poses to 1e-5).
@@ -22,7 +22,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 def draw(rng):
     w = int(rng.choice([200, 240, 320]))
-    return {"model": int(rng.integers(0, 10)), "n_points": int(rng.integers(2_000, 14_000)), "n_images": int(rng.integers(2, 5)),
+    return {"model": int(rng.integers(0, 13)), "n_points": int(rng.integers(2_000, 14_000)), "n_images": int(rng.integers(2, 5)),
             "width": w, "height": int(w * 3 // 4), "seed": int(rng.integers(1, 100_000)), "perturb": float(rng.choice([0.002, 0.006, 0.012])),
             "var_weight": float(rng.choice([0.0, 1.0, 1.0])), "n_levels": int(rng.choice([3, 4]))}
 

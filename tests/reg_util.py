@@ -55,8 +55,11 @@ DISTORTION = {
     7: [-0.101082, 0.0703954],                                 # RADIAL
     8: [-0.101082, 0.0703954, 0.0123],                         # POLYNOMIAL_3
     9: [0.0221184, 0.0128597, 0.000531602, -0.000388873],      # FISHEYE_POLYNOMIAL_2_TANGENTIAL_2
+    10: [-0.101082, 0.0703954, 0.000438661, -0.000680887, 0.0123, 0.021, -0.0087, 0.0031],   # FullOpenCVCamera: k1 k2 p1 p2 k3 k4 k5 k6
+    11: [0.0221184, 0.0128597],                                # RadialFisheyeCamera (FisheyeBase over RadialCamera)
+    12: [-0.0221184],                                          # SimpleRadialFisheyeCamera (k < 0: a finite inner cut-off)
 }
-UNIQUE_FOCAL = (5, 6, 7)          # parameter vector [f cx cy ...] (camera_base_impl.h:65-67)
+UNIQUE_FOCAL = (5, 6, 7, 11, 12)  # parameter vector [f cx cy ...] (camera_base_impl.h:65-67)
 
 
 def camera_params(model, fx, fy, cx, cy, distortion=None):
@@ -77,7 +80,11 @@ def distort_np(model, q, nx, ny):
     """float64 numpy version of the models' Distort (only for synthesising consistent test images)."""
     if model in (0, 5):
         return nx, ny
-    if model in (6, 7, 8):
+    if model in (11, 12):              # the fisheye warp, then the radial polynomial inside
+        r = np.sqrt(nx * nx + ny * ny)
+        f = np.where(r > 1e-6, np.arctan(r) / np.maximum(r, 1e-12), 1.0)
+        nx, ny = nx * f, ny * f
+    if model in (6, 7, 8, 11, 12):
         r2 = nx * nx + ny * ny
         k = list(q) + [0.0, 0.0]
         fac = 1 + r2 * (k[0] + r2 * (k[1] + r2 * k[2]))
@@ -96,6 +103,10 @@ def distort_np(model, q, nx, ny):
         fac = 1 + r2 * (q[0] + r2 * (q[1] + r2 * (q[2] + r2 * q[3])))
         return nx * fac, ny * fac
     k1, k2, p1, p2 = q[:4]
+    if model == 10:
+        k3, k4, k5, k6 = q[4:8]
+        radial = (1 + r2 * (k1 + r2 * (k2 + r2 * k3))) / (1 + r2 * (k4 + r2 * (k5 + r2 * k6)))
+        return nx * radial + 2 * p1 * xy + p2 * (r2 + 2 * x2), ny * radial + 2 * p2 * xy + p1 * (r2 + 2 * y2)
     if model in (1, 9):
         radial = 1 + r2 * (k1 + r2 * k2)
         return nx * radial + 2 * p1 * xy + p2 * (r2 + 2 * x2), ny * radial + 2 * p2 * xy + p1 * (r2 + 2 * y2)

@@ -54,7 +54,7 @@ def test_merge_close_points_edge_cases(e3d, mr):
         e3d.merge_close_points(0.1, 99, P, *args)
 
 
-@pytest.mark.parametrize("model", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("model", [0, 1, 2, 3, 4, 10, 11, 12])
 def test_point_radius_minmax_matches_oracle(e3d, mr, model):
     from reg_util import make_multi_image_scene
     M = make_multi_image_scene(n_points=8000, n_images=3, seed=21, model=model)

@@ -24,7 +24,7 @@ def _setup(e3d, rb, S, **pk):
     return P, levels
 
 
-MODELS = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9]       # PINHOLE, OPENCV, THIN_PRISM_FISHEYE, OPENCV_FISHEYE, FOV, SIMPLE_PINHOLE, SIMPLE_RADIAL, RADIAL,
+MODELS = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12]       # PINHOLE, OPENCV, THIN_PRISM_FISHEYE, OPENCV_FISHEYE, FOV, SIMPLE_PINHOLE, SIMPLE_RADIAL, RADIAL,
                                               # POLYNOMIAL_3, FISHEYE_POLYNOMIAL_2_TANGENTIAL_2 (camera_base.cc:66-77: all of its classes)
 EXACT = MODELS     # every model: atan / atan2 / tan / log2 come from include/e3d_libm.h on both sides, bit for bit
 
@@ -38,7 +38,7 @@ def test_camera_pyramid_matches(e3d, rb, model):
         w, h, p, c = P.intrinsics_level(0, l)
         assert (w, h) == (levels[l].width, levels[l].height)
         assert np.array_equal(p, levels[l].params())
-        co = levels[l].inner_cutoff2 if model in (2, 3, 9) else levels[l].cutoff2
+        co = levels[l].inner_cutoff2 if model in (2, 3, 9, 11, 12) else levels[l].cutoff2
         assert c == co and (np.isinf(c) if model in (0, 4, 5) else np.isfinite(c))      # the pinholes and FOV have no cut-off
 
 
@@ -641,6 +641,9 @@ RENDERER_KAT_PARAMS = {          # src/opt/test/test_renderer.cc:205-300 (Pinhol
     7: [250.0, 319.5, 239.5, 0.23, 0.66],                                                  # Radial (:234-238: kK1, -kK2)
     8: [250.0, 200.0, 319.5, 239.5, 0.23, -0.66, 0.64],                                    # Polynomial (:228-232)
     9: [340.926, 341.124, 302.4, 201.6, -0.101082, 0.0703954, 0.000438661, -0.000680887],  # FisheyePolynomialTangential (:285-291)
+    10: [340.926, 341.124, 302.4, 201.6, -0.101082, 0.0703954, 0.00438661, -0.00680887, -0.00101082, 0.1, 0.001, -0.001],   # FullOpenCV (:279-284)
+    11: [250.0, 319.5, 239.5, 0.221184, 0.128597],                                         # RadialFisheye (:247-251)
+    12: [125.0, 319.5, 239.5, 0.23],                                                       # SimpleRadialFisheye (:253-257: 0.5 kFX)
 }
 
 

@@ -261,7 +261,7 @@ def test_randomised_clouds_match_the_oracle_normals():
 
 @pytest.mark.timeout(600)
 def test_randomised_registration_problems_match_the_oracle():
-    """tests/fuzz_reg_vs_oracle.py: (B) problems drawn at random over the ten camera models (points, images, image size, pose error,
+    """tests/fuzz_reg_vs_oracle.py: (B) problems drawn at random over the thirteen camera classes (points, images, image size, pose error,
     colour weight) -- observation lists equal, colour update, cost and one Apply (accepted / lambda, poses) against the oracle's driver."""
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz_reg_vs_oracle.py"), "--trials", "12", "--seed", "5"],
                        capture_output=True, text=True, timeout=550)

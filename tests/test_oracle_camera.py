@@ -27,6 +27,10 @@ CAMERAS = {
     "POLYNOMIAL_3": (rb.POLYNOMIAL_3, [250.0, 200.0, 319.5, 239.5, 0.13, -0.66, 0.64]),
     "FISHEYE_POLYNOMIAL_2_TANGENTIAL_2": (rb.FISHEYE_POLYNOMIAL_2_TANGENTIAL_2, [340.926, 341.124, 302.4, 201.6, -0.101082, 0.0703954, 0.000438661,
                                                                                -0.000680887]),
+    # test_camera.cc:440-444,452-456,477-481: the three classes the factory never creates, with the reference's own test parameters
+    "RADIAL_FISHEYE_CLASS": (rb.RADIAL_FISHEYE_CLASS, [250.0, 319.5, 239.5, -0.13, 0.66]),
+    "SIMPLE_RADIAL_FISHEYE_CLASS": (rb.SIMPLE_RADIAL_FISHEYE_CLASS, [450.0, 319.5, 239.5, 0.13]),
+    "FULL_OPENCV": (rb.FULL_OPENCV, [340.926, 341.124, 302.4, 201.6, -0.101082, 0.0703954, 0.0438661, -0.0680887, -0.00101082, 0.1, 0.001, -0.001]),
 }
 
 

@@ -28,6 +28,16 @@ SWITCH_SETS = [
 ]
 
 
+def draw_large(rng):
+    """--large: full-size rooms (room_scale 1) dense enough for the certificate search at a few centimetres -- 0.8 - 1.5 M points per
+    scan -- as uniform, scanner-sampled (density ~ cos / range^2, scan order) or partial-overlap scans."""
+    kind = str(rng.choice(["uniform", "scanner", "partial"]))
+    return {"n_scans": int(rng.integers(2, 4)), "n_points": int(rng.integers(800_000, 1_500_000)), "seed": int(rng.integers(1, 10_000)),
+            "room_scale": 1.0, "d": float(rng.choice([0.03, 0.05])), "perturb": float(rng.choice([0.5, 1.0, 2.0])),
+            "iterations": int(rng.integers(3, 6)), "fixed": int(rng.integers(-1, 2)), "scanner": kind == "scanner", "partial": kind == "partial",
+            "sigma": 0.002}
+
+
 def draw(rng):
     dense = rng.random() < 0.7
     job = {
@@ -48,7 +58,7 @@ def draw(rng):
 def scene(job):
     synth = importlib.import_module("dataset-pipeline_amd.synth")
     return synth.make_scene(job["n_scans"], job["n_points"], seed=job["seed"], sigma=job["sigma"], room_scale=job["room_scale"],
-                            perturb=job["perturb"], scanner=job["scanner"])
+                            perturb=job["perturb"], scanner=job["scanner"], partial=job.get("partial", False))
 
 
 def run_one(icp, job, scans):
@@ -82,6 +92,7 @@ def main():
     ap.add_argument("--trials", type=int, default=24)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--worker", default=None)
+    ap.add_argument("--large", action="store_true", help="full-size dense rooms of 0.8 - 1.5 M points per scan (uniform / scanner-sampled / partial overlap)")
     args = ap.parse_args()
     if args.worker:
         return worker(args.worker)
@@ -89,7 +100,7 @@ def main():
     rng = np.random.default_rng(args.seed)
     todo = []
     for t in range(args.trials):
-        job = draw(rng)
+        job = draw_large(rng) if args.large else draw(rng)
         todo.append({"job": job, "oracle": run_one(ob.OracleICP(), job, scene(job))})
         print("trial %d: %s -> %d pair records, matched %d" % (t, json.dumps(job), len(todo[-1]["oracle"]["pairs"]),
                                                                sum(p[3] for p in todo[-1]["oracle"]["pairs"])), flush=True)
